@@ -1,0 +1,358 @@
+"""CPU oracle for the self-paced contrastive pre-train hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``oracle/`` is shipped or measured as the
+product: only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import it, and only as the checker / the CPU baseline.  The product path
+(``self-paced-contrastive-learning_amd``) never routes through this file.
+
+It is a plain PyTorch-CPU restatement (own code, written from the arithmetic, not
+copied) of the reference functions on the hot path:
+
+* ``supcon_loss``      <- contrastyou/losses/contrast_loss3.py:25-31 (exp_sim_temperature),
+                          :41-110 (SupConLoss1), :126-214 (SelfPacedSupConLoss)
+* ``supcon_grad``      <- the closed-form gradient autograd produces for the above
+* ``projector_forward``<- contrastyou/projectors/heads.py:9-25,78-92, nn.py:29-36
+* ``encoder_forward``  <- semi_seg/arch/unet.py:67-82 (_ConvBlock), :156-190 (forward until Conv5)
+* ``unet_forward``     <- semi_seg/arch/unet.py:156-230 (full network, "next" row N1)
+* ``PScheduler``       <- semi_seg/hooks/infonce.py:34-53
+* label generators     <- semi_seg/epochers/helper.py:48-65, semi_seg/hooks/utils.py:45-65
+* ``random_flip``      <- deepclustering2 TensorRandomFlip(axis=[1,2], threshold=0.8) *by contract*
+                          (un-vendored third party; restated from its call sites
+                          semi_seg/epochers/new_epocher.py:112, new_pretrain.py:57-58)
+
+Pinning: the reference's own tests hold no numeric fixtures for this path, so the
+oracle is pinned against outputs of the reference itself, imported in the build container by
+``tools/gen_golden.py`` -> ``tests/golden/*.npz`` (``tests/test_oracle_golden.py``).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+ENCODER_NAMES = ("Conv1", "Conv2", "Conv3", "Conv4", "Conv5")
+DECODER_BLOCKS = ("Up_conv5", "Up_conv4", "Up_conv3", "Up_conv2")
+LAYER_DIMENSION = {"Conv1": 1, "Conv2": 2, "Conv3": 4, "Conv4": 8, "Conv5": 16, "Up_conv5": 8,
+                   "Up_conv4": 4, "Up_conv3": 2, "Up_conv2": 1}
+
+
+# --------------------------------------------------------------------------------------
+# contrastive loss
+# --------------------------------------------------------------------------------------
+def build_masks(n: int, labels=None, mask: Optional[Tensor] = None, dtype=torch.float32):
+    """pos/neg masks of shape [2n,2n] (contrast_loss3.py:128-145,158-167)."""
+    if mask is not None:
+        assert tuple(mask.shape) == (n, n)
+        pos = (mask == 1)
+        neg = (mask == 0)
+    elif labels is not None:
+        y = torch.as_tensor(labels, dtype=torch.float32)
+        eq = y[:, None] == y[None, :]
+        pos, neg = eq, ~eq
+    else:  # SimCLR
+        pos = torch.eye(n, dtype=torch.bool)
+        neg = ~pos
+    offdiag = 1 - torch.eye(2 * n, dtype=dtype)
+    pos = pos.to(dtype).repeat(2, 2) * offdiag
+    neg = neg.to(dtype).repeat(2, 2) * offdiag
+    return pos, neg
+
+
+def supcon_loss(z1: Tensor, z2: Tensor, labels=None, mask: Optional[Tensor] = None, *, t: float = 0.07,
+                gamma: Optional[float] = None, mode: str = "hard", correct_grad: bool = False) -> Dict[str, Tensor]:
+    """Self-paced supervised contrastive loss.  ``gamma=None`` -> plain SupConLoss1 (w == 1).
+
+    Differentiable w.r.t. z1/z2 through torch autograd; dtype follows the inputs (fp32 or fp64).
+    """
+    n = z1.shape[0]
+    dt = z1.dtype
+    pos, neg = build_masks(n, labels, mask, dtype=dt)
+    P = torch.cat([z1, z2], 0)
+    S = (P @ P.t()) / t
+    m = S.max().detach()
+    L = S - m
+    E = torch.exp(L)
+    c = pos.sum(1)
+    D = (E * pos).sum(1, keepdim=True) + (E * neg).sum(1, keepdim=True)
+    ll = L - torch.log(D + 1e-16)
+    out = {"sim_logits": L, "sim_exp": E, "pos_mask": pos, "neg_mask": neg}
+    if gamma is None:
+        w = torch.ones_like(ll)
+        rho = torch.tensor(1.0, dtype=dt)
+    else:
+        with torch.no_grad():
+            l_ij = -ll
+            if mode == "hard":
+                w = (l_ij <= gamma).to(dt)
+            else:
+                w = torch.clamp(1 - l_ij / gamma, min=0)
+            w = torch.maximum(w, 1 - pos)
+            rho = w[pos.bool()].mean()
+        out["sp_mask"] = w
+    per_row = (ll * w * pos).sum(1) / c
+    loss = -per_row.mean()
+    if gamma is not None and correct_grad and float(rho) > 0:
+        loss = loss / float(rho)
+    out["loss"] = loss
+    out["rho"] = rho
+    return out
+
+
+def supcon_grad(z1: Tensor, z2: Tensor, labels=None, mask=None, *, t=0.07, gamma=None, mode="hard",
+                correct_grad=False):
+    """Closed-form dLoss/dz1, dLoss/dz2, independent of autograd (KAT-4)."""
+    n = z1.shape[0]
+    with torch.no_grad():
+        r = supcon_loss(z1, z2, labels, mask, t=t, gamma=gamma, mode=mode, correct_grad=correct_grad)
+        pos, neg, E, L = r["pos_mask"], r["neg_mask"], r["sim_exp"], r["sim_logits"]
+        w = r.get("sp_mask", torch.ones_like(E))
+        c = pos.sum(1, keepdim=True)
+        valid = ((pos + neg) > 0).to(E.dtype)
+        D = (E * valid).sum(1, keepdim=True)
+        W = (pos * w).sum(1, keepdim=True)
+        kappa = 1.0 / (2 * n)
+        if gamma is not None and correct_grad and float(r["rho"]) > 0:
+            kappa = kappa / float(r["rho"])
+        G = -kappa / c * (pos * w - W * E * valid / (D + 1e-16))
+        P = torch.cat([z1, z2], 0)
+        dP = (G + G.t()) @ P / t
+    return dP[:n], dP[n:]
+
+
+# --------------------------------------------------------------------------------------
+# projector
+# --------------------------------------------------------------------------------------
+def projector_forward(feat: Tensor, params: Dict[str, Tensor], *, head_type="mlp", normalize=True) -> Tensor:
+    """AdaptiveAvgPool2d((1,1)) -> Flatten -> Linear -> LeakyReLU(0.01) -> Linear -> L2 normalise.
+
+    ``params`` uses the reference's state_dict keys: ``_header.2.{weight,bias}``, ``_header.4.{weight,bias}``.
+    """
+    x = feat.mean(dim=(2, 3))
+    if head_type == "mlp":
+        x = F.linear(x, params["_header.2.weight"], params["_header.2.bias"])
+        x = F.leaky_relu(x, 0.01)
+        x = F.linear(x, params["_header.4.weight"], params["_header.4.bias"])
+    else:
+        x = F.linear(x, params["_header.2.weight"], params["_header.2.bias"])
+    if normalize:
+        x = x / x.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    return x
+
+
+# --------------------------------------------------------------------------------------
+# UNet
+# --------------------------------------------------------------------------------------
+def channel_dim(name: str, max_channel: int = 256) -> int:
+    return int(LAYER_DIMENSION[name] / 16 * max_channel)
+
+
+def _conv_block(x, sd, prefix, train, momentum, eps=1e-5):
+    """conv3x3(no bias) -> BN -> ReLU, twice (unet.py:67-82).  Updates running stats in ``sd`` in train mode."""
+    for ci, bi in ((0, 1), (3, 4)):
+        x = F.conv2d(x, sd[f"{prefix}.conv.{ci}.weight"], None, 1, 1)
+        x = F.batch_norm(x, sd[f"{prefix}.conv.{bi}.running_mean"], sd[f"{prefix}.conv.{bi}.running_var"],
+                         sd[f"{prefix}.conv.{bi}.weight"], sd[f"{prefix}.conv.{bi}.bias"], train, momentum, eps)
+        if train:
+            sd[f"{prefix}.conv.{bi}.num_batches_tracked"] += 1
+        x = F.relu(x)
+    return x
+
+
+def _up_conv(x, sd, prefix, train, momentum, eps=1e-5):
+    """nearest x2 upsample -> conv3x3 -> BN -> ReLU (unet.py:85-97)."""
+    x = F.interpolate(x, scale_factor=2, mode="nearest")
+    x = F.conv2d(x, sd[f"{prefix}.up.1.weight"], None, 1, 1)
+    x = F.batch_norm(x, sd[f"{prefix}.up.2.running_mean"], sd[f"{prefix}.up.2.running_var"],
+                     sd[f"{prefix}.up.2.weight"], sd[f"{prefix}.up.2.bias"], train, momentum, eps)
+    if train:
+        sd[f"{prefix}.up.2.num_batches_tracked"] += 1
+    return F.relu(x)
+
+
+def unet_forward(x: Tensor, sd: Dict[str, Tensor], until: Optional[str] = None, *, train=True, momentum=0.1):
+    """Full UNet forward with early exit (unet.py:156-230).  ``sd`` = state_dict-style dict (mutated: BN stats)."""
+    if until is not None and until not in LAYER_DIMENSION and until != "Deconv_1x1":
+        raise KeyError(until)
+    feats = {}
+    e = x
+    for k, name in enumerate(ENCODER_NAMES):
+        if k > 0:
+            e = F.max_pool2d(e, 2, 2)
+        e = _conv_block(e, sd, f"_{name}", train, momentum)
+        feats[name] = e
+        if until == name:
+            return e
+    d = e
+    for lvl, skip in ((5, "Conv4"), (4, "Conv3"), (3, "Conv2"), (2, "Conv1")):
+        d = _up_conv(d, sd, f"_Up{lvl}", train, momentum)
+        d = torch.cat((feats[skip], d), 1)
+        d = _conv_block(d, sd, f"_Up_conv{lvl}", train, momentum)
+        if until == f"Up_conv{lvl}":
+            return d
+    return F.conv2d(d, sd["_Deconv_1x1.weight"], sd["_Deconv_1x1.bias"])
+
+
+def encoder_forward(x, sd, until="Conv5", *, train=True, momentum=0.1):
+    assert until in ENCODER_NAMES
+    return unet_forward(x, sd, until, train=train, momentum=momentum)
+
+
+def init_unet_state(input_dim=1, num_classes=4, max_channel=256, seed=0, encoder_only=False, dtype=torch.float32):
+    """Deterministic state_dict with the reference's key names (kaiming-uniform-like; NOT torch's default
+    init stream -- used only where weights are generated, never compared with a reference init)."""
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, Tensor] = {}
+
+    def conv_w(co, ci, k=3):
+        bound = 1.0 / math.sqrt(ci * k * k)
+        return ((torch.rand(co, ci, k, k, generator=g, dtype=torch.float64) * 2 - 1) * bound).to(dtype)
+
+    def bn(prefix, c):
+        sd[f"{prefix}.weight"] = (1 + 0.2 * (torch.rand(c, generator=g, dtype=torch.float64) - 0.5)).to(dtype)
+        sd[f"{prefix}.bias"] = (0.2 * (torch.rand(c, generator=g, dtype=torch.float64) - 0.5)).to(dtype)
+        sd[f"{prefix}.running_mean"] = torch.zeros(c, dtype=dtype)
+        sd[f"{prefix}.running_var"] = torch.ones(c, dtype=dtype)
+        sd[f"{prefix}.num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+
+    def block(prefix, ci, co):
+        sd[f"{prefix}.conv.0.weight"] = conv_w(co, ci)
+        bn(f"{prefix}.conv.1", co)
+        sd[f"{prefix}.conv.3.weight"] = conv_w(co, co)
+        bn(f"{prefix}.conv.4", co)
+
+    cin = input_dim
+    for name in ENCODER_NAMES:
+        co = channel_dim(name, max_channel)
+        block(f"_{name}", cin, co)
+        cin = co
+    if not encoder_only:
+        for lvl, name in ((5, "Up_conv5"), (4, "Up_conv4"), (3, "Up_conv3"), (2, "Up_conv2")):
+            co = channel_dim(name, max_channel)
+            sd[f"_Up{lvl}.up.1.weight"] = conv_w(co, cin)
+            bn(f"_Up{lvl}.up.2", co)
+            block(f"_Up_conv{lvl}", 2 * co, co)
+            cin = co
+        sd["_Deconv_1x1.weight"] = conv_w(num_classes, cin, 1)
+        sd["_Deconv_1x1.bias"] = torch.zeros(num_classes, dtype=dtype)
+    return sd
+
+
+def init_projector_state(input_dim=256, hidden_dim=256, output_dim=256, seed=0, head_type="mlp", dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+
+    def lin(o, i):
+        b = 1.0 / math.sqrt(i)
+        w = ((torch.rand(o, i, generator=g, dtype=torch.float64) * 2 - 1) * b).to(dtype)
+        bias = ((torch.rand(o, generator=g, dtype=torch.float64) * 2 - 1) * b).to(dtype)
+        return w, bias
+
+    sd = {}
+    if head_type == "mlp":
+        sd["_header.2.weight"], sd["_header.2.bias"] = lin(hidden_dim, input_dim)
+        sd["_header.4.weight"], sd["_header.4.bias"] = lin(output_dim, hidden_dim)
+    else:
+        sd["_header.2.weight"], sd["_header.2.bias"] = lin(output_dim, input_dim)
+    return sd
+
+
+# --------------------------------------------------------------------------------------
+# host-side pieces
+# --------------------------------------------------------------------------------------
+class PScheduler:
+    """gamma_e = begin + (end-begin) * (e/max_epoch)^p  (semi_seg/hooks/infonce.py:34-53)."""
+
+    def __init__(self, max_epoch, begin_value=0.0, end_value=1.0, p=0.5):
+        self.max_epoch, self.begin_value, self.end_value, self.p = max_epoch, float(begin_value), float(end_value), p
+        self.epoch = 0
+
+    def step(self):
+        self.epoch += 1
+
+    @property
+    def value(self):
+        return self.begin_value + (self.end_value - self.begin_value) * (self.epoch / self.max_epoch) ** self.p
+
+
+def label_encode(items: Sequence) -> List[int]:
+    """sklearn LabelEncoder().fit(x).transform(x): rank among sorted unique values."""
+    uniq = sorted(set(items))
+    index = {v: i for i, v in enumerate(uniq)}
+    return [index[v] for v in items]
+
+
+def get_label(contrast_on: str, data_name: str, partition_group: Sequence, label_group: Sequence[str]) -> List[int]:
+    """semi_seg/hooks/utils.py:45-65 + semi_seg/epochers/helper.py:48-65."""
+    if data_name == "acdc":
+        patients = [p.split("_")[0] for p in label_group]
+        experiments = [p.split("_")[1] for p in label_group]
+    elif data_name in ("prostate", "prostate_md"):
+        patients = [p.split("_")[0] for p in label_group]
+        experiments = None
+    elif data_name in ("mmwhsct", "mmwhsmr"):
+        patients, experiments = list(label_group), None
+    else:
+        raise NotImplementedError(data_name)
+    if contrast_on == "partition":
+        return label_encode(list(partition_group))
+    if contrast_on == "patient":
+        return label_encode(patients)
+    if contrast_on == "cycle":
+        if data_name != "acdc":
+            raise NotImplementedError(contrast_on)
+        return [0 if e == "00" else 1 for e in experiments]
+    if contrast_on == "self":
+        return list(range(len(partition_group)))
+    raise NotImplementedError(contrast_on)
+
+
+def random_flip_decisions(seed: int, n: int, threshold: float = 0.8, axes=(1, 2)):
+    """Per-sample flip decisions, restated BY CONTRACT (deepclustering2 is un-vendored):
+    under a fixed seed, for each sample and each axis draw u~U[0,1) from python's ``random`` and flip when
+    u < threshold.  Returned as a bool tensor [n, len(axes)]."""
+    import random as _r
+    st = _r.getstate()
+    _r.seed(seed)
+    out = torch.zeros(n, len(axes), dtype=torch.bool)
+    for i in range(n):
+        for a in range(len(axes)):
+            out[i, a] = _r.random() < threshold
+    _r.setstate(st)
+    return out
+
+
+def apply_flips(x: Tensor, decisions: Tensor) -> Tensor:
+    """x: [N,C,H,W]; decisions[:,0] -> flip H (axis 1 of a [C,H,W] sample), [:,1] -> flip W."""
+    out = x.clone()
+    for i in range(x.shape[0]):
+        s = x[i]
+        if decisions[i, 0]:
+            s = s.flip(1)
+        if decisions[i, 1]:
+            s = s.flip(2)
+        out[i] = s
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# one full pre-train step (forward + backward), the unit bench.py's cpu_baseline times
+# --------------------------------------------------------------------------------------
+def pretrain_step(images: Tensor, images_tf: Tensor, sd: Dict[str, Tensor], proj_sd: Dict[str, Tensor],
+                  labels: Sequence[int], *, gamma: Optional[float], mode="soft", correct_grad=True, t=0.07,
+                  momentum=0.1, flip: Optional[Tensor] = None):
+    """semi_seg/epochers/new_pretrain.py:52-96 + semi_seg/hooks/infonce.py:171-195 for one batch.
+
+    Returns dict(loss, rho, grads{name: Tensor}, feature).  ``sd``/``proj_sd`` leaves must require grad."""
+    n = images.shape[0]
+    feat = encoder_forward(torch.cat([images, images_tf], 0), sd, "Conv5", train=True, momentum=momentum)
+    f, f_tf2 = feat[:n], feat[n:]
+    if flip is not None:
+        f = apply_flips(f, flip)
+    z = projector_forward(torch.cat([f, f_tf2], 0), proj_sd)
+    r = supcon_loss(z[:n], z[n:], labels, t=t, gamma=gamma, mode=mode, correct_grad=correct_grad)
+    leaves = {k: v for k, v in list(sd.items()) + list(proj_sd.items()) if v.is_floating_point() and v.requires_grad}
+    grads = torch.autograd.grad(r["loss"], list(leaves.values()), allow_unused=True)
+    return {"loss": r["loss"].detach(), "rho": r["rho"], "feature": feat.detach(),
+            "grads": {k: g for k, g in zip(leaves.keys(), grads)}}

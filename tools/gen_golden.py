@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REFERENCE implementation (runs only in the build container).
+
+The reference's arithmetic modules are imported from a scratch copy of /root/reference (the import has
+side effects on the tree -- SURVEY 8c pitfall) with three in-process stubs (loguru, torch._six,
+deepclustering2.configparser._utils).  Only data (inputs + the reference's outputs) is written; no
+reference source travels.  Inputs that would be large are regenerated from seeds by
+oracle/spcl_oracle.py's init_* helpers and pinned by a checksum.
+
+    python tools/gen_golden.py            # writes tests/golden/
+"""
+import collections.abc
+import os
+import shutil
+import sys
+import types
+
+sys.dont_write_bytecode = True
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+REF_SRC = "/root/reference"
+REF_TMP = "/tmp/ref"
+OUT = os.path.join(REPO, "tests", "golden")
+
+
+def _import_reference():
+    if not os.path.isdir(REF_TMP):
+        shutil.copytree(REF_SRC, REF_TMP)
+    sys.path.insert(0, REF_TMP)
+
+    def _mod(name, **a):
+        m = types.ModuleType(name)
+        m.__dict__.update(a)
+        sys.modules[name] = m
+        return m
+
+    class _L:
+        def __getattr__(s, k):
+            return lambda *a, **kw: s if k in ("opt", "bind") else None
+
+        def catch(s, *a, **kw):
+            return lambda f: f
+
+    _mod("loguru", logger=_L())
+    _mod("torch._six", container_abcs=collections.abc, int_classes=int, string_classes=str)
+    _mod("deepclustering2")
+    _mod("deepclustering2.configparser")
+    _mod("deepclustering2.configparser._utils", get_config=lambda scope="base": {})
+    from contrastyou.losses.contrast_loss3 import SupConLoss1, SelfPacedSupConLoss
+    from contrastyou.projectors.heads import ProjectionHead
+    from semi_seg.arch.unet import UNet
+    from semi_seg.arch.hook import SingleFeatureExtractor
+    return SupConLoss1, SelfPacedSupConLoss, ProjectionHead, UNet, SingleFeatureExtractor
+
+
+def unit_rows(n, d, seed):
+    g = torch.Generator().manual_seed(seed)
+    z = torch.randn(n, d, generator=g)
+    return torch.nn.functional.normalize(z, dim=1)
+
+
+def label_sets(n):
+    acdc = [(i % 3) for i in range(n)]  # ContrastBatchSampler: scans x 3 partitions
+    return {"mod3": [i % 3 for i in range(n)], "distinct": list(range(n)),
+            "acdc": sorted(acdc), "none": None}
+
+
+LOSS_MODES = [  # (name, mode, gamma, correct_grad)   gamma None -> SupConLoss1
+    ("supcon1", None, None, False),
+    ("hard_1e6", "hard", 1e6, False),
+    ("hard_7", "hard", 7.0, False),
+    ("soft_12", "soft", 12.0, False),
+    ("soft_12_cg", "soft", 12.0, True),
+    ("soft_3_cg", "soft", 3.0, True),
+]
+
+
+def gen_loss(SupConLoss1, SelfPacedSupConLoss):
+    out = {}
+    cases = []
+    for (n, d) in [(4, 16), (8, 256), (30, 256), (96, 128)]:
+        z1, z2 = unit_rows(n, d, 100 + n), unit_rows(n, d, 200 + n)
+        for lname, labels in label_sets(n).items():
+            for (mname, mode, gamma, cg) in LOSS_MODES:
+                if n >= 96 and (lname != "mod3" or mname not in ("supcon1", "hard_7", "soft_12_cg")):
+                    continue  # keep the fixture small
+                key = f"n{n}_d{d}_{lname}_{mname}"
+                a = z1.clone().requires_grad_(True)
+                b = z2.clone().requires_grad_(True)
+                if mode is None:
+                    crit = SupConLoss1(temperature=0.07)
+                else:
+                    crit = SelfPacedSupConLoss(temperature=0.07, weight_update=mode, correct_grad=cg)
+                    crit.set_gamma(gamma)
+                loss = crit(a, b, target=labels)
+                loss.backward()
+                out[f"{key}/loss"] = loss.detach().numpy()
+                out[f"{key}/dz1"] = a.grad.numpy()
+                out[f"{key}/dz2"] = b.grad.numpy()
+                if mode is not None:
+                    out[f"{key}/rho"] = np.float64(crit.downgrade_ratio)
+                if n <= 8:
+                    out[f"{key}/sim_logits"] = crit.sim_logits.detach().numpy()
+                    out[f"{key}/sim_exp"] = crit.sim_exp.detach().numpy()
+                    out[f"{key}/pos_mask"] = crit.pos_mask.numpy()
+                    if mode is not None:
+                        out[f"{key}/sp_mask"] = crit.sp_mask.numpy()
+                cases.append(key)
+        out[f"n{n}_d{d}/z1"] = z1.numpy()
+        out[f"n{n}_d{d}/z2"] = z2.numpy()
+    # explicit (asymmetric-free) mask case: mask given instead of target
+    n, d = 6, 32
+    z1, z2 = unit_rows(n, d, 7), unit_rows(n, d, 8)
+    mask = (torch.arange(n)[:, None] % 2 == torch.arange(n)[None, :] % 2).float()
+    a = z1.clone().requires_grad_(True)
+    b = z2.clone().requires_grad_(True)
+    crit = SelfPacedSupConLoss(weight_update="soft", correct_grad=True)
+    crit.set_gamma(9.0)
+    loss = crit(a, b, mask=mask)
+    loss.backward()
+    out["mask_n6_d32/z1"], out["mask_n6_d32/z2"], out["mask_n6_d32/mask"] = z1.numpy(), z2.numpy(), mask.numpy()
+    out["mask_n6_d32/loss"], out["mask_n6_d32/rho"] = loss.detach().numpy(), np.float64(crit.downgrade_ratio)
+    out["mask_n6_d32/dz1"], out["mask_n6_d32/dz2"] = a.grad.numpy(), b.grad.numpy()
+    out["cases"] = np.array(cases)
+    np.savez_compressed(os.path.join(OUT, "g1_loss.npz"), **out)
+    print("g1_loss:", len(cases), "cases")
+
+
+def gen_projector(ProjectionHead):
+    from oracle.spcl_oracle import init_projector_state
+    out = {}
+    for tag, (ci, ch, co, seed) in {"small": (16, 32, 16, 3), "base": (256, 256, 256, 4)}.items():
+        head = ProjectionHead(input_dim=ci, hidden_dim=ch, output_dim=co, head_type="mlp", normalize=True)
+        sd = init_projector_state(ci, ch, co, seed=seed)
+        head.load_state_dict(sd, strict=True)
+        g = torch.Generator().manual_seed(50 + ci)
+        nb = 4 if tag == "small" else 2
+        x = torch.randn(nb, ci, 14, 14, generator=g).relu_().requires_grad_(True)
+        r = torch.randn(nb, co, generator=g)
+        y = head(x)
+        (y * r).sum().backward()
+        out[f"{tag}/x"], out[f"{tag}/r"], out[f"{tag}/y"] = x.detach().numpy(), r.numpy(), y.detach().numpy()
+        out[f"{tag}/dx"] = x.grad.numpy()
+        for k, p in head.named_parameters():
+            out[f"{tag}/grad/{k}"] = p.grad.numpy()
+        if tag == "small":
+            for k, v in sd.items():
+                out[f"{tag}/param/{k}"] = v.numpy()
+        out[f"{tag}/param_checksum"] = np.float64(sum(float(v.double().sum()) for v in sd.values()))
+        out[f"{tag}/dims"] = np.array([ci, ch, co, seed])
+    np.savez_compressed(os.path.join(OUT, "g2_projector.npz"), **out)
+    print("g2_projector done")
+
+
+def gen_encoder(UNet):
+    from oracle.spcl_oracle import init_unet_state
+    out = {}
+    # small: max_channel=128 (8/16/32/64/128), [4,1,32,32]
+    net = UNet(input_dim=1, num_classes=4, max_channel=128)
+    sd = init_unet_state(1, 4, 128, seed=11)
+    net.load_state_dict(sd, strict=True)
+    net.train()
+    g = torch.Generator().manual_seed(12)
+    x = torch.rand(4, 1, 32, 32, generator=g)
+    out["small/x"] = x.numpy()
+    out["small/param_checksum"] = np.float64(sum(float(v.double().sum()) for v in sd.values()))
+    for until in ("Conv1", "Conv2", "Conv3", "Conv4"):
+        ref = UNet(input_dim=1, num_classes=4, max_channel=128)
+        ref.load_state_dict(sd, strict=True)
+        ref.train()
+        out[f"small/out/{until}"] = ref(x, until=until).detach().numpy()
+    y = net(x, until="Conv5")
+    out["small/out/Conv5"] = y.detach().numpy()
+    r = torch.randn(y.shape, generator=g)
+    out["small/r"] = r.numpy()
+    (y * r).sum().backward()
+    for k, p in net.named_parameters():
+        if p.grad is not None:
+            out[f"small/grad/{k}"] = p.grad.numpy()
+    for k, b in net.named_buffers():
+        if k.startswith(("_Conv",)):
+            out[f"small/buf/{k}"] = b.numpy()
+    # eval-mode forward with the updated running stats
+    net.eval()
+    out["small/eval_out/Conv5"] = net(x, until="Conv5").detach().numpy()
+    # full UNet (decoder, "next" row N1) small output
+    net.train()
+    full = UNet(input_dim=1, num_classes=4, max_channel=128)
+    full.load_state_dict(sd, strict=True)
+    full.train()
+    out["small/out/full"] = full(x).detach().numpy()
+
+    # base: max_channel=256, [2,1,224,224], Conv5 checksum only
+    sd2 = init_unet_state(1, 4, 256, seed=21)
+    net2 = UNet(input_dim=1, num_classes=4, max_channel=256)
+    net2.load_state_dict(sd2, strict=True)
+    net2.train()
+    x2 = torch.rand(2, 1, 224, 224, generator=torch.Generator().manual_seed(22))
+    y2 = net2(x2, until="Conv5").detach()
+    out["base/out_mean_c"] = y2.mean(dim=(0, 2, 3)).numpy()
+    out["base/out_absmax_c"] = y2.abs().amax(dim=(0, 2, 3)).numpy()
+    out["base/out_n0"] = y2[0, :, :, :].numpy()
+    out["base/param_checksum"] = np.float64(sum(float(v.double().sum()) for v in sd2.values()))
+    np.savez_compressed(os.path.join(OUT, "g3_encoder.npz"), **out)
+    print("g3_encoder done")
+
+
+def gen_step(UNet, ProjectionHead, SelfPacedSupConLoss, SingleFeatureExtractor):
+    """G4: one pre-train step through the reference modules incl. the forward-hook tap (arch/hook.py)."""
+    from oracle.spcl_oracle import init_unet_state, init_projector_state
+    out = {}
+    sd = init_unet_state(1, 4, 128, seed=31)
+    psd = init_projector_state(128, 64, 32, seed=32)
+    net = UNet(input_dim=1, num_classes=4, max_channel=128)
+    net.load_state_dict(sd, strict=True)
+    net.train()
+    head = ProjectionHead(input_dim=128, hidden_dim=64, output_dim=32, head_type="mlp", normalize=True)
+    head.load_state_dict(psd, strict=True)
+    crit = SelfPacedSupConLoss(weight_update="soft", correct_grad=True)
+    crit.set_gamma(10.0)
+    g = torch.Generator().manual_seed(33)
+    n = 6
+    img, img_tf = torch.rand(n, 1, 32, 32, generator=g), torch.rand(n, 1, 32, 32, generator=g)
+    labels = [i % 3 for i in range(n)]
+    ext = SingleFeatureExtractor(net, "Conv5")
+    ext.bind()
+    ext.clear()
+    ext.set_enable(True)
+    net(torch.cat([img, img_tf], 0), until="Conv5")
+    ext.set_enable(False)
+    feat = ext.feature()[-2 * n:]
+    z = head(feat)
+    a, b = torch.chunk(z, 2)
+    loss = crit(a, b, target=labels)
+    loss.backward()
+    ext.remove()
+    out["img"], out["img_tf"], out["labels"] = img.numpy(), img_tf.numpy(), np.array(labels)
+    out["loss"], out["rho"] = loss.detach().numpy(), np.float64(crit.downgrade_ratio)
+    out["z"] = z.detach().numpy()
+    for k, p in list(net.named_parameters()) + [("proj." + k, p) for k, p in head.named_parameters()]:
+        if p.grad is not None:
+            out[f"grad/{k}"] = p.grad.numpy()
+    out["dims"] = np.array([128, 64, 32, 31, 32])
+    np.savez_compressed(os.path.join(OUT, "g4_step.npz"), **out)
+    print("g4_step done: loss", float(loss.detach()), "rho", crit.downgrade_ratio)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    SupConLoss1, SelfPacedSupConLoss, ProjectionHead, UNet, SFE = _import_reference()
+    gen_loss(SupConLoss1, SelfPacedSupConLoss)
+    gen_projector(ProjectionHead)
+    gen_encoder(UNet)
+    gen_step(UNet, ProjectionHead, SelfPacedSupConLoss, SFE)
+
+
+if __name__ == "__main__":
+    main()
