@@ -1,0 +1,154 @@
+"""HIP-backed mirror of the reference module ``contrastyou/losses/contrast_loss3.py``.
+
+Same public names and call contract (reference line numbers cited per symbol); the arithmetic runs in the fused
+gfx950 kernels of csrc/supcon.hip through the C ABI -- the [2n,2n] similarity matrix is never materialised unless
+one of the hook taps (``sim_exp``, ``sim_logits``, ``pos_mask``, ``neg_mask``, ``sp_mask``) is read.
+
+Host synchronisation: the reference synchronises 4x per call (two ``allclose``, ``.item()``, ``isnan``).  Here a
+call enqueues kernels only.  With ``sync_checks=True`` (default, reference-identical error behaviour) ONE readback
+of the 8-float result block performs the unit-norm assertion and the NaN check; with ``sync_checks=False`` nothing
+synchronises and ``check()`` / ``downgrade_ratio`` read the block when asked.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from ... import functional as F_hip
+
+__all__ = ["SupConLoss1", "SelfPacedSupConLoss", "is_normalized", "exp_sim_temperature"]
+
+
+def is_normalized(feature: Tensor, dim=1) -> bool:
+    """contrast_loss3.py:20-22 (host-side helper; the fused kernel evaluates the same test on device)."""
+    norms = feature.norm(dim=dim)
+    return bool(torch.allclose(norms, torch.ones_like(norms)))
+
+
+def exp_sim_temperature(proj_feat1: Tensor, proj_feat2: Tensor, t: float) -> Tuple[Tensor, Tensor]:
+    """contrast_loss3.py:25-31: (exp(S-max S), S-max S) for S = cat(z1,z2) cat(z1,z2)^T / t, materialised."""
+    st = F_hip.SupConState()
+    F_hip.supcon_loss(proj_feat1, proj_feat2, None, None, t=t, state=st)
+    taps = F_hip.supcon_materialize(st, want=("sim_logits", "sim_exp"))
+    return taps["sim_exp"], taps["sim_logits"]
+
+
+class _SupConBase(nn.Module):
+    _TAPS = ("sim_exp", "sim_logits", "pos_mask", "neg_mask", "sp_mask")
+
+    def __init__(self, temperature: float, sync_checks: bool = True):
+        super().__init__()
+        self._t = temperature
+        self.sync_checks = sync_checks
+        self._state: Optional[F_hip.SupConState] = None
+        self._taps_cache = None
+        self._host_out = None
+
+    # ---- inputs -------------------------------------------------------------------------------------------
+    @staticmethod
+    def _prepare_targets(proj_feat1: Tensor, proj_feat2: Tensor, target, mask):
+        batch_size = proj_feat1.size(0)
+        dev = proj_feat2.device
+        labels_t = mask_t = None
+        if mask is not None:  # contrast_loss3.py:43-46 / :128-131
+            assert mask.shape == torch.Size([batch_size, batch_size])
+            mask_t = mask.to(device=dev, dtype=torch.float32).contiguous()
+        elif target is not None:  # :48-54 / :133-139  (labels are compared as floats, like torch.Tensor(list))
+            if isinstance(target, Tensor):
+                labels_t = target.to(device=dev, dtype=torch.float32).contiguous()
+            else:
+                labels_t = torch.tensor(list(target), dtype=torch.float32, device=dev)
+            assert labels_t.numel() == batch_size, (labels_t.shape, batch_size)
+        return labels_t, mask_t
+
+    def _run(self, proj_feat1, proj_feat2, labels_t, mask_t, sp_mode, gamma, correct_grad):
+        assert proj_feat1.shape == proj_feat2.shape, (proj_feat1.shape, proj_feat2.shape)  # :63 / :155
+        self._state = F_hip.SupConState()
+        self._taps_cache = None
+        self._host_out = None
+        loss = F_hip.supcon_loss(proj_feat1, proj_feat2, labels_t, mask_t, t=self._t, sp_mode=sp_mode, gamma=gamma,
+                                 correct_grad=correct_grad, state=self._state)
+        if self.sync_checks:
+            self.check()
+        return loss
+
+    # ---- deferred contract checks -------------------------------------------------------------------------
+    def _out(self):
+        if self._host_out is None:
+            self._host_out = self._state.out.tolist()  # the single device->host readback
+        return self._host_out
+
+    def check(self):
+        """Unit-norm assertion (contrast_loss3.py:62,154) and NaN guard (:107-108,203-204) of the last call."""
+        out = self._out()
+        assert out[3] <= 1e-8 + 1e-5, "features need to be normalized first"
+        if math.isnan(out[0]):
+            raise RuntimeError(torch.tensor(out[0]))
+
+    # ---- hook taps (contrast_loss3.py:83-88,175-178,188) --------------------------------------------------
+    def _tap(self, name):
+        if self._state is None:
+            raise AttributeError(name)
+        if self._taps_cache is None:
+            self._taps_cache = F_hip.supcon_materialize(self._state)
+        return self._taps_cache[name]
+
+    sim_exp = property(lambda self: self._tap("sim_exp"))
+    sim_logits = property(lambda self: self._tap("sim_logits"))
+    pos_mask = property(lambda self: self._tap("pos_mask"))
+    neg_mask = property(lambda self: self._tap("neg_mask"))
+
+
+class SupConLoss1(_SupConBase):
+    """contrast_loss3.py:34-110."""
+
+    def __init__(self, temperature=0.07, exclude_other_pos=False, sync_checks=True):
+        super().__init__(temperature, sync_checks)
+        if exclude_other_pos:
+            raise NotImplementedError("exclude_other_pos=True (contrast_loss3.py:97-100) is not on the pre-train hot "
+                                      "path (INFONCEHook.init_criterion uses the default) and is not built")
+        self._exclude_pos = exclude_other_pos
+
+    def forward(self, proj_feat1, proj_feat2, target=None, mask: Tensor = None, **kwargs):
+        labels_t, mask_t = self._prepare_targets(proj_feat1, proj_feat2, target, mask)
+        return self._run(proj_feat1, proj_feat2, labels_t, mask_t, F_hip.SP_NONE, 1e6, False)
+
+
+class SelfPacedSupConLoss(_SupConBase):
+    """contrast_loss3.py:113-222."""
+
+    def __repr__(self):
+        return f"{self.__class__.__name__} with T: {self._t}, method: {self._weight_update} gamma: {self.__gamma}"
+
+    def __init__(self, temperature=0.07, weight_update="hard", correct_grad=False, sync_checks=True, **kwargs):
+        super().__init__(temperature, sync_checks)
+        self._weight_update = weight_update
+        self.__gamma = 1e6
+        self._correct_grad = correct_grad
+
+    def forward(self, proj_feat1, proj_feat2, target=None, mask: Tensor = None, **kwargs):
+        labels_t, mask_t = self._prepare_targets(proj_feat1, proj_feat2, target, mask)
+        mode = F_hip.SP_HARD if self._weight_update == "hard" else F_hip.SP_SOFT  # :209-213
+        return self._run(proj_feat1, proj_feat2, labels_t, mask_t, mode, self.__gamma, self._correct_grad)
+
+    sp_mask = property(lambda self: self._tap("sp_mask"))
+
+    @property
+    def downgrade_ratio(self) -> float:
+        """rho: mean self-paced weight over the positive pairs (:189-191), as a python float (reads the device)."""
+        return float(self._out()[1])
+
+    @property
+    def downgrade_ratio_tensor(self) -> Tensor:
+        """rho as a 0-dim device tensor (no synchronisation)."""
+        return self._state.out[1]
+
+    def set_gamma(self, gamma):  # :216-218
+        self.__gamma = float(gamma)
+
+    @property
+    def age_param(self):  # :220-222
+        return self.__gamma

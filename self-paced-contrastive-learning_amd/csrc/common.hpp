@@ -1,0 +1,70 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels of libspcl_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/spcl_hip.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) short bf16x8;  // 8 bf16 = 4 VGPRs (MFMA 16x16x32 operand)
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef uint16_t bf16_t;
+
+namespace spcl {
+
+void set_error(const char* fmt, ...);
+
+#define SPCL_CHECK_ARG(cond, ...)        \
+  do {                                   \
+    if (!(cond)) {                       \
+      spcl::set_error(__VA_ARGS__);      \
+      return SPCL_EINVAL;                \
+    }                                    \
+  } while (0)
+
+#define SPCL_LAUNCH_CHECK(name)                                                 \
+  do {                                                                          \
+    hipError_t e_ = hipGetLastError();                                          \
+    if (e_ != hipSuccess) {                                                     \
+      spcl::set_error("%s: launch failed: %s", name, hipGetErrorString(e_));    \
+      return SPCL_ELAUNCH;                                                      \
+    }                                                                           \
+  } while (0)
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even via the hardware convert (keeps NaN a NaN, MI355X_MICROARCH "Correctness boundaries")
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, b);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int kDtype = SPCL_F32;
+  __device__ static __forceinline__ float load(const float* p) { return *p; }
+  __device__ static __forceinline__ void store(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int kDtype = SPCL_BF16;
+  __device__ static __forceinline__ float load(const bf16_t* p) { return bf16_to_f32(*p); }
+  __device__ static __forceinline__ void store(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// butterfly sum over the 64 lanes of a wave (every lane gets the total; fixed order -> deterministic)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline int round_up(int a, int b) { return cdiv(a, b) * b; }
+
+}  // namespace spcl

@@ -1,0 +1,222 @@
+// Projector head for gfx950: global average pool -> Linear -> LeakyReLU(0.01) -> Linear -> L2 normalise, fwd + bwd.
+// Replaces contrastyou/projectors/heads.py:9-25,78-92 and nn.py:8-15,29-36,56-58 (K8-K10 + their backward).
+// Sizes are tiny (N=64 rows, 256x256 weights): every kernel is launch/latency-bound, so they are plain
+// coalesced FMA kernels with fixed (deterministic) reduction order; fp32 throughout.
+#include "common.hpp"
+
+namespace spcl {
+
+constexpr float kLeaky = 0.01f;
+
+// pooled[n][c] = mean_hw feat[n][hw][c]          (thread per channel: coalesced across c)
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_kernel(const T* __restrict__ feat, int HW, int C, int Cs,
+                                                      float* __restrict__ pooled) {
+  const int n = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const T* p = feat + (size_t)n * HW * Cs + c;
+  float s = 0.f;
+  for (int i = 0; i < HW; ++i) s += Elem<T>::load(p + (size_t)i * Cs);
+  pooled[(size_t)n * C + c] = s / (float)HW;
+}
+
+// y[n][o] = sum_k act(x[n][k]) * W[o][k] + b[o];  one wave per output column o, loops over rows n.
+// act = leaky (x is a saved pre-activation) when LEAKY_IN.
+template <bool LEAKY_IN>
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                         const float* __restrict__ b, int N, int K, int O,
+                                                         float* __restrict__ y) {
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (o >= O) return;
+  const float bias = b[o];
+  for (int n = blockIdx.y; n < N; n += gridDim.y) {
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) {
+      float xv = x[(size_t)n * K + k];
+      if (LEAKY_IN) xv = xv > 0.f ? xv : kLeaky * xv;
+      s = fmaf(xv, W[(size_t)o * K + k], s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) y[(size_t)n * O + o] = s + bias;
+  }
+}
+
+// z = o / max(||o||, 1e-12)   (F.normalize p=2 dim=1)
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ o, int N, int O,
+                                                         float* __restrict__ z) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int k = lane; k < O; k += 64) {
+    float v = o[(size_t)n * O + k];
+    s = fmaf(v, v, s);
+  }
+  s = wave_sum(s);
+  const float inv = 1.f / fmaxf(sqrtf(s), 1e-12f);
+  for (int k = lane; k < O; k += 64) z[(size_t)n * O + k] = o[(size_t)n * O + k] * inv;
+}
+
+// do = (dz - z (z.dz)) / max(||o||,eps)
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ o, const float* __restrict__ dz,
+                                                         int N, int O, float* __restrict__ d_o) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (n >= N) return;
+  float s = 0.f, dot = 0.f;
+  for (int k = lane; k < O; k += 64) {
+    float v = o[(size_t)n * O + k];
+    s = fmaf(v, v, s);
+    dot = fmaf(v, dz[(size_t)n * O + k], dot);
+  }
+  s = wave_sum(s);
+  dot = wave_sum(dot);
+  const float nrm = sqrtf(s);
+  if (nrm > 1e-12f) {
+    const float inv = 1.f / nrm;
+    const float zd = dot * inv;  // z . dz
+    for (int k = lane; k < O; k += 64) {
+      float zk = o[(size_t)n * O + k] * inv;
+      d_o[(size_t)n * O + k] = (dz[(size_t)n * O + k] - zk * zd) * inv;
+    }
+  } else {  // clamp branch of F.normalize: denominator is the constant eps
+    for (int k = lane; k < O; k += 64) d_o[(size_t)n * O + k] = dz[(size_t)n * O + k] * 1e12f;
+  }
+}
+
+// dW[o][k] = sum_n g[n][o] * act(x[n][k]);  db[o] = sum_n g[n][o]      (thread per (o,k), n sequential)
+template <bool LEAKY_IN>
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                           int N, int K, int O, float* __restrict__ dW,
+                                                           float* __restrict__ db) {
+  const int o = blockIdx.y;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  float s = 0.f, sb = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const float gv = g[(size_t)n * O + o];
+    float xv = x[(size_t)n * K + k];
+    if (LEAKY_IN) xv = xv > 0.f ? xv : kLeaky * xv;
+    s = fmaf(gv, xv, s);
+    sb += gv;
+  }
+  dW[(size_t)o * K + k] = s;
+  if (k == 0) db[o] = sb;
+}
+
+// dx[n][k] = (sum_o g[n][o] W[o][k]) * (LEAKY_OUT ? leaky'(pre[n][k]) : 1)
+template <bool LEAKY_OUT>
+__global__ __launch_bounds__(256) void linear_dgrad_kernel(const float* __restrict__ g, const float* __restrict__ W,
+                                                           const float* __restrict__ pre, int N, int K, int O,
+                                                           float* __restrict__ dx) {
+  const int n = blockIdx.y;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  float s = 0.f;
+  for (int o = 0; o < O; ++o) s = fmaf(g[(size_t)n * O + o], W[(size_t)o * K + k], s);
+  if (LEAKY_OUT) s *= pre[(size_t)n * K + k] > 0.f ? 1.f : kLeaky;
+  dx[(size_t)n * K + k] = s;
+}
+
+// dfeat[n][hw][c] = dpooled[n][c] / HW  (0 in the channel padding)
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dpooled, int HW, int C, int Cs,
+                                                          T* __restrict__ dfeat, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % Cs);
+  const size_t n = idx / ((size_t)HW * Cs);
+  const float v = c < C ? dpooled[n * C + c] / (float)HW : 0.f;
+  Elem<T>::store(dfeat + idx, v);
+}
+
+}  // namespace spcl
+
+using namespace spcl;
+
+extern "C" int spcl_proj_forward(const void* feat, int dtype, int N, int HW, int C, int Cs, const float* w1,
+                                 const float* b1, const float* w2, const float* b2, int hid, int out_dim,
+                                 int normalize, float* pooled, float* pre, float* o, float* z, void* stream) {
+  SPCL_CHECK_ARG(feat && w1 && b1 && pooled && o && z, "proj_forward: null pointer");
+  SPCL_CHECK_ARG(N > 0 && HW > 0 && C > 0 && Cs >= C && out_dim > 0 && hid >= 0, "proj_forward: bad shape");
+  SPCL_CHECK_ARG(hid == 0 || (w2 && b2 && pre), "proj_forward: mlp head needs w2/b2/pre");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 pg(cdiv(C, 256), N);
+  if (dtype == SPCL_F32)
+    hipLaunchKernelGGL(avgpool_kernel<float>, pg, dim3(256), 0, st, (const float*)feat, HW, C, Cs, pooled);
+  else if (dtype == SPCL_BF16)
+    hipLaunchKernelGGL(avgpool_kernel<bf16_t>, pg, dim3(256), 0, st, (const bf16_t*)feat, HW, C, Cs, pooled);
+  else {
+    set_error("proj_forward: dtype %d", dtype);
+    return SPCL_EINVAL;
+  }
+  const int ny = N < 8 ? N : 8;
+  if (hid > 0) {
+    hipLaunchKernelGGL(linear_fwd_kernel<false>, dim3(cdiv(hid, 4), ny), dim3(256), 0, st, (const float*)pooled, w1,
+                       b1, N, C, hid, pre);
+    hipLaunchKernelGGL(linear_fwd_kernel<true>, dim3(cdiv(out_dim, 4), ny), dim3(256), 0, st, (const float*)pre, w2,
+                       b2, N, hid, out_dim, o);
+  } else {
+    hipLaunchKernelGGL(linear_fwd_kernel<false>, dim3(cdiv(out_dim, 4), ny), dim3(256), 0, st, (const float*)pooled,
+                       w1, b1, N, C, out_dim, o);
+  }
+  if (normalize)
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, (const float*)o, N, out_dim, z);
+  else
+    (void)hipMemcpyAsync(z, o, (size_t)N * out_dim * sizeof(float), hipMemcpyDeviceToDevice, st);
+  SPCL_LAUNCH_CHECK("proj_forward");
+  return SPCL_OK;
+}
+
+extern "C" int spcl_proj_backward(const float* dz, int dtype, int N, int HW, int C, int Cs, const float* w1,
+                                  const float* w2, int hid, int out_dim, int normalize, const float* pooled,
+                                  const float* pre, const float* o, float* dw1, float* db1, float* dw2, float* db2,
+                                  float* scratch, void* dfeat, void* stream) {
+  SPCL_CHECK_ARG(dz && w1 && pooled && o && dw1 && db1 && scratch, "proj_backward: null pointer");
+  SPCL_CHECK_ARG(N > 0 && HW > 0 && C > 0 && Cs >= C && out_dim > 0 && hid >= 0, "proj_backward: bad shape");
+  SPCL_CHECK_ARG(hid == 0 || (w2 && pre && dw2 && db2), "proj_backward: mlp head needs w2/pre/dw2/db2");
+  hipStream_t st = (hipStream_t)stream;
+  float* d_o = scratch;                                 // [N,out]
+  float* dpre = scratch + (size_t)N * out_dim;          // [N,hid]
+  float* dpool = dpre + (size_t)N * (hid > 0 ? hid : 0);  // [N,C]
+  const float* go = dz;
+  if (normalize) {
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, o, dz, N, out_dim, d_o);
+    go = d_o;
+  }
+  if (hid > 0) {
+    hipLaunchKernelGGL(linear_wgrad_kernel<true>, dim3(cdiv(hid, 256), out_dim), dim3(256), 0, st, go, pre, N, hid,
+                       out_dim, dw2, db2);
+    hipLaunchKernelGGL(linear_dgrad_kernel<true>, dim3(cdiv(hid, 256), N), dim3(256), 0, st, go, w2, pre, N, hid,
+                       out_dim, dpre);
+    hipLaunchKernelGGL(linear_wgrad_kernel<false>, dim3(cdiv(C, 256), hid), dim3(256), 0, st, (const float*)dpre,
+                       pooled, N, C, hid, dw1, db1);
+    if (dfeat)
+      hipLaunchKernelGGL(linear_dgrad_kernel<false>, dim3(cdiv(C, 256), N), dim3(256), 0, st, (const float*)dpre, w1,
+                         (const float*)nullptr, N, C, hid, dpool);
+  } else {
+    hipLaunchKernelGGL(linear_wgrad_kernel<false>, dim3(cdiv(C, 256), out_dim), dim3(256), 0, st, go, pooled, N, C,
+                       out_dim, dw1, db1);
+    if (dfeat)
+      hipLaunchKernelGGL(linear_dgrad_kernel<false>, dim3(cdiv(C, 256), N), dim3(256), 0, st, go, w1,
+                         (const float*)nullptr, N, C, out_dim, dpool);
+  }
+  if (dfeat) {
+    const size_t total = (size_t)N * HW * Cs;
+    dim3 g((unsigned)((total + 255) / 256));
+    if (dtype == SPCL_F32)
+      hipLaunchKernelGGL(avgpool_bwd_kernel<float>, g, dim3(256), 0, st, (const float*)dpool, HW, C, Cs,
+                         (float*)dfeat, total);
+    else if (dtype == SPCL_BF16)
+      hipLaunchKernelGGL(avgpool_bwd_kernel<bf16_t>, g, dim3(256), 0, st, (const float*)dpool, HW, C, Cs,
+                         (bf16_t*)dfeat, total);
+    else {
+      set_error("proj_backward: dtype %d", dtype);
+      return SPCL_EINVAL;
+    }
+  }
+  SPCL_LAUNCH_CHECK("proj_backward");
+  return SPCL_OK;
+}

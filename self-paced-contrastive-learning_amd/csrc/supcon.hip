@@ -1,0 +1,517 @@
+// Self-paced supervised-contrastive loss for gfx950: flash-style tiled similarity, never materialising the
+// [2n,2n] matrix.  Replaces contrastyou/losses/contrast_loss3.py:25-31,41-110,126-214 (+ autograd backward).
+//
+// Math:  P = cat(z1,z2) [N2,d];  S = P P^T / t;  L = S - m;  E = exp(L)
+//   D_i = sum_{j valid} E_ij;  ell_ij = L_ij - log(D_i + 1e-16);  w_ij = selfpaced(-ell_ij)
+//   loss = -kappa * sum_i (sum_j pos_ij w_ij ell_ij) / c_i,   kappa = 1/N2 (/rho if correct_grad)
+//   G_ij = -kappa/c_i (pos_ij w_ij - W_i valid_ij exp(ell_ij));   dP = (G + G^T) P / t
+//
+// Kernel plan: prep (pad + row norms) -> sweep<0> (D_i, c_i) -> fin<0> -> sweep<1> (row loss, W_i) -> fin<1>;
+// backward: bwd sweep (S tile -> H = G + G^T in registers -> second MFMA H*P) -> reduce over column splits.
+// S tiles use the exact-f32 MFMA v_mfma_f32_16x16x4_f32 (bitwise an fmaf chain), so results agree with the
+// reference's fp32 torch.mm to rounding.  One wave owns 16 rows of S; a workgroup of 4 waves shares the
+// 64-row P_J tile staged in LDS (16-byte chunks XOR-swizzled by row -> conflict-free ds_read_b128).
+#include "common.hpp"
+
+namespace spcl {
+
+struct SupconLayout {
+  int n, d, N2, N2p, DP, CS;
+  size_t off_P, off_rn2, off_logD, off_c, off_W, off_rowloss, off_partA, off_partB, total;
+};
+
+static SupconLayout supcon_layout(int n, int d) {
+  SupconLayout L;
+  L.n = n;
+  L.d = d;
+  L.N2 = 2 * n;
+  L.N2p = round_up(L.N2, 64);
+  L.DP = d <= 64 ? 64 : (d <= 128 ? 128 : 256);
+  int rb = L.N2p / 64;
+  int cs = 1;
+  while (rb * cs < 512 && cs * 2 <= rb) cs *= 2;
+  L.CS = cs;
+  size_t o = 0;
+  L.off_P = o;        o += (size_t)L.N2p * L.DP;
+  L.off_rn2 = o;      o += L.N2p;
+  L.off_logD = o;     o += L.N2p;
+  L.off_c = o;        o += L.N2p;
+  L.off_W = o;        o += L.N2p;
+  L.off_rowloss = o;  o += L.N2p;
+  L.off_partA = o;    o += (size_t)L.CS * L.N2p;
+  L.off_partB = o;    o += (size_t)L.CS * L.N2p;
+  L.total = o;
+  return L;
+}
+
+struct SupconArgs {
+  const float* P;        // [N2p][DP]
+  const float* rn2;      // [N2p] squared row norms
+  const float* labels;   // [n] or null
+  const float* mask;     // [n][n] or null
+  const float* logD;     // [N2p]
+  const float* cnt;      // [N2p]
+  const float* W;        // [N2p]
+  float* partA;          // [CS][N2p]
+  float* partB;
+  int n, N2, N2p;
+  float t, gamma, inv_gamma;
+  int sp_mode;
+};
+
+// ------------------------------------------------------------------------------------------------ prep
+__global__ __launch_bounds__(256) void supcon_prep_kernel(const float* __restrict__ z1, const float* __restrict__ z2,
+                                                          int n, int d, int N2p, int DP, float* __restrict__ P,
+                                                          float* __restrict__ rn2) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= N2p) return;
+  const float* src = row < n ? z1 + (size_t)row * d : (row < 2 * n ? z2 + (size_t)(row - n) * d : nullptr);
+  float s = 0.f;
+  for (int k = lane; k < DP; k += 64) {
+    float v = (src != nullptr && k < d) ? src[k] : 0.f;
+    P[(size_t)row * DP + k] = v;
+    s += v * v;
+  }
+  s = wave_sum(s);
+  if (lane == 0) rn2[row] = s;
+}
+
+__device__ __forceinline__ float block_max_logit(const float* rn2, int N2, float t, float* red /*[4]*/) {
+  float v = 0.f;
+  for (int i = threadIdx.x; i < N2; i += blockDim.x) v = fmaxf(v, rn2[i] / t);
+  v = wave_max(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float m = red[0];
+  for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmaxf(m, red[w]);
+  __syncthreads();
+  return m;
+}
+
+// stage 64 rows x DP floats of P (rows J0..J0+63) into LDS, 16-B chunk index XOR (row & 15)
+template <int DP>
+__device__ __forceinline__ void stage_tile(const float* __restrict__ P, int J0, float* lds) {
+  constexpr int CPR = DP / 4;  // chunks per row
+  for (int c = threadIdx.x; c < 64 * CPR; c += 256) {
+    int row = c / CPR, ch = c % CPR;
+    f32x4 v = *(const f32x4*)(P + (size_t)(J0 + row) * DP + ch * 4);
+    *(f32x4*)(lds + row * DP + ((ch ^ (row & 15)) << 2)) = v;
+  }
+}
+
+// S^T tile: returns c[r] = dot(P_J[16*nt + 4g + r], P_I[i]) with i = this lane's row (lane&15), g = lane>>4
+template <int DP>
+__device__ __forceinline__ f32x4 sim_tile(const float* lds, int nt, const f32x4* bi, int r16, int g) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int row = nt * 16 + r16;
+  const float* base = lds + row * DP;
+#pragma unroll
+  for (int s = 0; s < DP / 16; ++s) {
+    f32x4 a4 = *(const f32x4*)(base + (((4 * s + g) ^ r16) << 2));
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[0], bi[s][0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[1], bi[s][1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[2], bi[s][2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[3], bi[s][3], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+struct PairMask {
+  bool pos, valid;
+};
+__device__ __forceinline__ PairMask pair_mask(const SupconArgs& a, int i, int j, float lab_i) {
+  PairMask p;
+  if (i >= a.N2 || j >= a.N2 || i == j) {
+    p.pos = false;
+    p.valid = false;
+    return p;
+  }
+  const int in = i >= a.n ? i - a.n : i, jn = j >= a.n ? j - a.n : j;
+  if (a.mask != nullptr) {
+    float mv = a.mask[(size_t)in * a.n + jn];
+    p.pos = (mv == 1.f);
+    p.valid = p.pos || (mv == 0.f);
+  } else if (a.labels != nullptr) {
+    p.pos = (a.labels[jn] == lab_i);
+    p.valid = true;
+  } else {
+    p.pos = (in == jn);
+    p.valid = true;
+  }
+  return p;
+}
+
+__device__ __forceinline__ float sp_weight(int sp_mode, float ell, float gamma, float inv_gamma) {
+  if (sp_mode == 0) return 1.f;
+  float l = -ell;
+  if (sp_mode == 1) return l <= gamma ? 1.f : 0.f;
+  return fmaxf(1.f - inv_gamma * l, 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------ sweeps
+template <int DP, int MODE>
+__global__ __launch_bounds__(256) void supcon_sweep_kernel(SupconArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ float red[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int i = blockIdx.x * 64 + wave * 16 + r16;
+  const float m = block_max_logit(a.rn2, a.N2, a.t, red);
+
+  f32x4 bi[DP / 16];
+#pragma unroll
+  for (int s = 0; s < DP / 16; ++s) bi[s] = *(const f32x4*)(a.P + (size_t)i * DP + 16 * s + 4 * g);
+  const int in = i >= a.n ? i - a.n : i;
+  const float lab_i = (a.labels != nullptr && i < a.N2) ? a.labels[in] : 0.f;
+  float logD_i = 0.f;
+  if (MODE == 1) logD_i = a.logD[i];
+
+  float acc0 = 0.f, acc1 = 0.f;
+  const int ntiles = a.N2p / 64;
+  for (int jt = blockIdx.y; jt < ntiles; jt += gridDim.y) {
+    __syncthreads();
+    stage_tile<DP>(a.P, jt * 64, lds);
+    __syncthreads();
+#pragma unroll 1
+    for (int nt = 0; nt < 4; ++nt) {
+      f32x4 c = sim_tile<DP>(lds, nt, bi, r16, g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = jt * 64 + nt * 16 + 4 * g + r;
+        PairMask pm = pair_mask(a, i, j, lab_i);
+        const float logit = c[r] / a.t - m;
+        if (MODE == 0) {
+          acc0 += pm.valid ? expf(logit) : 0.f;
+          acc1 += pm.pos ? 1.f : 0.f;
+        } else {
+          const float ell = logit - logD_i;
+          const float w = sp_weight(a.sp_mode, ell, a.gamma, a.inv_gamma);
+          acc0 += pm.pos ? w * ell : 0.f;
+          acc1 += pm.pos ? w : 0.f;
+        }
+      }
+    }
+  }
+  acc0 += __shfl_xor(acc0, 16, 64);
+  acc0 += __shfl_xor(acc0, 32, 64);
+  acc1 += __shfl_xor(acc1, 16, 64);
+  acc1 += __shfl_xor(acc1, 32, 64);
+  if (g == 0) {
+    a.partA[(size_t)blockIdx.y * a.N2p + i] = acc0;
+    a.partB[(size_t)blockIdx.y * a.N2p + i] = acc1;
+  }
+}
+
+// STAGE 0: logD_i = log(sum_cs partA + 1e-16), c_i = sum_cs partB.
+// STAGE 1: rowloss_i, W_i; then loss / rho / kappa (single workgroup, fixed reduction order).
+template <int STAGE>
+__global__ __launch_bounds__(1024) void supcon_fin_kernel(const float* __restrict__ partA,
+                                                          const float* __restrict__ partB, int CS, int N2, int N2p,
+                                                          float* __restrict__ outA, float* __restrict__ outB,
+                                                          const float* __restrict__ cnt, const float* __restrict__ rn2,
+                                                          int correct_grad, float* __restrict__ out) {
+  __shared__ double red[3][16];
+  __shared__ float redm[16];
+  double s_loss = 0.0, s_w = 0.0, s_c = 0.0;
+  float dev = 0.f;
+  for (int i = threadIdx.x; i < N2p; i += blockDim.x) {
+    float a = 0.f, b = 0.f;
+    for (int c = 0; c < CS; ++c) {
+      a += partA[(size_t)c * N2p + i];
+      b += partB[(size_t)c * N2p + i];
+    }
+    if (STAGE == 0) {
+      outA[i] = logf(a + 1e-16f);
+      outB[i] = b;
+    } else {
+      outA[i] = a;  // row loss numerator  sum_j pos w ell
+      outB[i] = b;  // W_i
+      if (i < N2) {
+        s_loss += (double)(a / cnt[i]);
+        s_w += (double)b;
+        s_c += (double)cnt[i];
+        dev = fmaxf(dev, fabsf(sqrtf(rn2[i]) - 1.f));
+      }
+    }
+  }
+  if (STAGE == 1) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int o = 32; o > 0; o >>= 1) {
+      s_loss += __shfl_xor(s_loss, o, 64);
+      s_w += __shfl_xor(s_w, o, 64);
+      s_c += __shfl_xor(s_c, o, 64);
+      dev = fmaxf(dev, __shfl_xor(dev, o, 64));
+    }
+    if (lane == 0) {
+      red[0][wave] = s_loss;
+      red[1][wave] = s_w;
+      red[2][wave] = s_c;
+      redm[wave] = dev;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double L = 0, Wt = 0, Ct = 0;
+      float dm = 0.f;
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
+        L += red[0][w];
+        Wt += red[1][w];
+        Ct += red[2][w];
+        dm = fmaxf(dm, redm[w]);
+      }
+      float loss = (float)(-(L / (double)N2));
+      float rho = (float)(Wt / Ct);
+      float kappa = 1.f / (float)N2;
+      if (correct_grad && rho > 0.f) {
+        loss = loss / rho;
+        kappa = kappa / rho;
+      }
+      out[0] = loss;
+      out[1] = rho;
+      out[2] = kappa;
+      out[3] = dm;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+template <int DP>
+__global__ __launch_bounds__(256) void supcon_bwd_kernel(SupconArgs a, const float* __restrict__ out_fwd,
+                                                         float* __restrict__ dPpart /* [CS][N2p][DP] */) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ float red[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int I0 = blockIdx.x * 64 + wave * 16;
+  const int i = I0 + r16;
+  const float m = block_max_logit(a.rn2, a.N2, a.t, red);
+  const float kappa = out_fwd[2];
+
+  f32x4 bi[DP / 16];
+#pragma unroll
+  for (int s = 0; s < DP / 16; ++s) bi[s] = *(const f32x4*)(a.P + (size_t)i * DP + 16 * s + 4 * g);
+  const int in = i >= a.n ? i - a.n : i;
+  const float lab_i = (a.labels != nullptr && i < a.N2) ? a.labels[in] : 0.f;
+  const float logD_i = a.logD[i], W_i = a.W[i];
+  const float kc_i = -kappa / a.cnt[i];
+
+  f32x4 acc2[DP / 64][4];
+#pragma unroll
+  for (int kt = 0; kt < DP / 64; ++kt)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc2[kt][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int ntiles = a.N2p / 64;
+  for (int jt = blockIdx.y; jt < ntiles; jt += gridDim.y) {
+    __syncthreads();
+    stage_tile<DP>(a.P, jt * 64, lds);
+    __syncthreads();
+#pragma unroll 1
+    for (int nt = 0; nt < 4; ++nt) {
+      f32x4 c = sim_tile<DP>(lds, nt, bi, r16, g);
+      float h[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = jt * 64 + nt * 16 + 4 * g + r;
+        float hv = 0.f;
+        if (i < a.N2 && j < a.N2 && i != j) {
+          const int jn = j >= a.n ? j - a.n : j;
+          const float lab_j = a.labels != nullptr ? a.labels[jn] : 0.f;
+          PairMask pij = pair_mask(a, i, j, lab_i);
+          PairMask pji = pair_mask(a, j, i, lab_j);
+          const float logit = c[r] / a.t - m;
+          const float ell_ij = logit - logD_i;
+          const float ell_ji = logit - a.logD[j];
+          const float w_ij = sp_weight(a.sp_mode, ell_ij, a.gamma, a.inv_gamma);
+          const float w_ji = sp_weight(a.sp_mode, ell_ji, a.gamma, a.inv_gamma);
+          const float g_ij = kc_i * ((pij.pos ? w_ij : 0.f) - (pij.valid ? W_i * expf(ell_ij) : 0.f));
+          const float g_ji = (-kappa / a.cnt[j]) * ((pji.pos ? w_ji : 0.f) - (pji.valid ? a.W[j] * expf(ell_ji) : 0.f));
+          hv = g_ij + g_ji;
+        }
+        h[r] = hv;
+      }
+      // dP[i][64kt + 4*r16 + u] += sum_j H[i][j] P_J[j][...]: H (D layout) is already the A operand
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = nt * 16 + 4 * g + r;
+        const float* base = lds + row * DP;
+#pragma unroll
+        for (int kt = 0; kt < DP / 64; ++kt) {
+          f32x4 b4 = *(const f32x4*)(base + (((16 * kt + r16) ^ (row & 15)) << 2));
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            acc2[kt][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(h[r], b4[u], acc2[kt][u], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // acc2[kt][u][r'] = dP[I0 + 4g + r'][64kt + 4*r16 + u]
+  float* dst = dPpart + (size_t)blockIdx.y * a.N2p * DP;
+#pragma unroll
+  for (int kt = 0; kt < DP / 64; ++kt)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      f32x4 v = {acc2[kt][0][rr], acc2[kt][1][rr], acc2[kt][2][rr], acc2[kt][3][rr]};
+      *(f32x4*)(dst + (size_t)(I0 + 4 * g + rr) * DP + 64 * kt + 4 * r16) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void supcon_bwd_fin_kernel(const float* __restrict__ dPpart, int CS, int n, int d,
+                                                             int N2p, int DP, float t,
+                                                             const float* __restrict__ grad_out,
+                                                             float* __restrict__ dz1, float* __restrict__ dz2) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)2 * n * d;
+  if (idx >= total) return;
+  const int row = (int)(idx / d), k = (int)(idx % d);
+  float s = 0.f;
+  for (int c = 0; c < CS; ++c) s += dPpart[((size_t)c * N2p + row) * DP + k];
+  const float v = s * grad_out[0] / t;
+  if (row < n) dz1[(size_t)row * d + k] = v;
+  else dz2[(size_t)(row - n) * d + k] = v;
+}
+
+// ------------------------------------------------------------------------------------------------ taps
+// Lazily materialised hook taps; same k order as the MFMA chain (k = 16s + 4g + u) -> bitwise the same logits.
+__global__ __launch_bounds__(256) void supcon_materialize_kernel(SupconArgs a, int DP, float* sim_logits, float* sim_exp,
+                                                                 float* pos_mask, float* neg_mask, float* sp_mask) {
+  __shared__ float red[4];
+  const float m = block_max_logit(a.rn2, a.N2, a.t, red);
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)a.N2 * a.N2) return;
+  const int i = (int)(idx / a.N2), j = (int)(idx % a.N2);
+  const float* pi = a.P + (size_t)i * DP;
+  const float* pj = a.P + (size_t)j * DP;
+  float acc = 0.f;
+  for (int s = 0; s < DP / 16; ++s)
+    for (int u = 0; u < 4; ++u)
+      for (int g = 0; g < 4; ++g) {
+        int k = 16 * s + 4 * g + u;
+        acc = __fmaf_rn(pj[k], pi[k], acc);
+      }
+  const float logit = acc / a.t - m;
+  const int in = i >= a.n ? i - a.n : i;
+  const float lab_i = a.labels != nullptr ? a.labels[in] : 0.f;
+  PairMask pm = pair_mask(a, i, j, lab_i);
+  if (sim_logits) sim_logits[idx] = logit;
+  if (sim_exp) sim_exp[idx] = expf(logit);
+  if (pos_mask) pos_mask[idx] = pm.pos ? 1.f : 0.f;
+  if (neg_mask) neg_mask[idx] = (pm.valid && !pm.pos) ? 1.f : 0.f;
+  if (sp_mask) {
+    const float ell = logit - a.logD[i];
+    const float w = sp_weight(a.sp_mode, ell, a.gamma, a.inv_gamma);
+    sp_mask[idx] = fmaxf(w, pm.pos ? 0.f : 1.f);
+  }
+}
+
+static SupconArgs make_args(const SupconLayout& L, const float* ws, const float* labels, const float* mask, float t,
+                            int sp_mode, float gamma) {
+  SupconArgs a;
+  a.P = ws + L.off_P;
+  a.rn2 = ws + L.off_rn2;
+  a.labels = labels;
+  a.mask = mask;
+  a.logD = ws + L.off_logD;
+  a.cnt = ws + L.off_c;
+  a.W = ws + L.off_W;
+  a.partA = const_cast<float*>(ws) + L.off_partA;
+  a.partB = const_cast<float*>(ws) + L.off_partB;
+  a.n = L.n;
+  a.N2 = L.N2;
+  a.N2p = L.N2p;
+  a.t = t;
+  a.gamma = gamma;
+  a.inv_gamma = (float)(1.0 / (double)gamma);
+  a.sp_mode = sp_mode;
+  return a;
+}
+
+template <int DP>
+static int launch_forward(const SupconLayout& L, SupconArgs a, float* ws, int correct_grad, float* out,
+                          hipStream_t st) {
+  dim3 grid(L.N2p / 64, L.CS);
+  size_t lds = (size_t)64 * DP * sizeof(float);
+  hipLaunchKernelGGL((supcon_sweep_kernel<DP, 0>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((supcon_fin_kernel<0>), dim3(1), dim3(1024), 0, st, a.partA, a.partB, L.CS, L.N2, L.N2p,
+                     ws + L.off_logD, ws + L.off_c, (const float*)nullptr, (const float*)nullptr, 0, out);
+  hipLaunchKernelGGL((supcon_sweep_kernel<DP, 1>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((supcon_fin_kernel<1>), dim3(1), dim3(1024), 0, st, a.partA, a.partB, L.CS, L.N2, L.N2p,
+                     ws + L.off_rowloss, ws + L.off_W, (const float*)(ws + L.off_c), (const float*)(ws + L.off_rn2),
+                     correct_grad, out);
+  return 0;
+}
+
+}  // namespace spcl
+
+using namespace spcl;
+
+extern "C" size_t spcl_supcon_workspace_bytes(int n, int d) {
+  if (n <= 0 || d <= 0 || d > 256) return 0;
+  return supcon_layout(n, d).total * sizeof(float);
+}
+
+extern "C" size_t spcl_supcon_bwd_workspace_bytes(int n, int d) {
+  if (n <= 0 || d <= 0 || d > 256) return 0;
+  SupconLayout L = supcon_layout(n, d);
+  return (size_t)L.CS * L.N2p * L.DP * sizeof(float);
+}
+
+extern "C" int spcl_supcon_forward(const float* z1, const float* z2, const float* labels, const float* mask, int n,
+                                   int d, float temperature, int sp_mode, float gamma, int correct_grad, float* ws,
+                                   float* out, void* stream) {
+  SPCL_CHECK_ARG(z1 && z2 && ws && out, "supcon_forward: null pointer");
+  SPCL_CHECK_ARG(n > 0 && d > 0, "supcon_forward: bad shape n=%d d=%d", n, d);
+  if (d > 256) {
+    set_error("supcon_forward: proj dim %d > 256 unsupported", d);
+    return SPCL_EUNSUPPORTED;
+  }
+  SPCL_CHECK_ARG(sp_mode >= 0 && sp_mode <= 2, "supcon_forward: sp_mode %d", sp_mode);
+  SPCL_CHECK_ARG(temperature > 0.f, "supcon_forward: temperature must be > 0");
+  hipStream_t st = (hipStream_t)stream;
+  SupconLayout L = supcon_layout(n, d);
+  hipLaunchKernelGGL(supcon_prep_kernel, dim3(L.N2p / 4), dim3(256), 0, st, z1, z2, n, d, L.N2p, L.DP,
+                     ws + L.off_P, ws + L.off_rn2);
+  SupconArgs a = make_args(L, ws, labels, mask, temperature, sp_mode, gamma);
+  if (L.DP == 64) launch_forward<64>(L, a, ws, correct_grad, out, st);
+  else if (L.DP == 128) launch_forward<128>(L, a, ws, correct_grad, out, st);
+  else launch_forward<256>(L, a, ws, correct_grad, out, st);
+  SPCL_LAUNCH_CHECK("supcon_forward");
+  return SPCL_OK;
+}
+
+extern "C" int spcl_supcon_backward(const float* labels, const float* mask, int n, int d, float temperature,
+                                    int sp_mode, float gamma, const float* ws_fwd, float* ws_bwd,
+                                    const float* out_fwd, const float* grad_out, float* dz1, float* dz2,
+                                    void* stream) {
+  SPCL_CHECK_ARG(ws_fwd && ws_bwd && out_fwd && grad_out && dz1 && dz2, "supcon_backward: null pointer");
+  SPCL_CHECK_ARG(n > 0 && d > 0 && d <= 256, "supcon_backward: bad shape n=%d d=%d", n, d);
+  hipStream_t st = (hipStream_t)stream;
+  SupconLayout L = supcon_layout(n, d);
+  SupconArgs a = make_args(L, ws_fwd, labels, mask, temperature, sp_mode, gamma);
+  dim3 grid(L.N2p / 64, L.CS);
+  size_t lds = (size_t)64 * L.DP * sizeof(float);
+  if (L.DP == 64) hipLaunchKernelGGL((supcon_bwd_kernel<64>), grid, dim3(256), lds, st, a, out_fwd, ws_bwd);
+  else if (L.DP == 128) hipLaunchKernelGGL((supcon_bwd_kernel<128>), grid, dim3(256), lds, st, a, out_fwd, ws_bwd);
+  else hipLaunchKernelGGL((supcon_bwd_kernel<256>), grid, dim3(256), lds, st, a, out_fwd, ws_bwd);
+  size_t total = (size_t)2 * n * d;
+  hipLaunchKernelGGL(supcon_bwd_fin_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                     (const float*)ws_bwd, L.CS, n, d, L.N2p, L.DP, temperature, grad_out, dz1, dz2);
+  SPCL_LAUNCH_CHECK("supcon_backward");
+  return SPCL_OK;
+}
+
+extern "C" int spcl_supcon_materialize(const float* labels, const float* mask, int n, int d, float temperature,
+                                       int sp_mode, float gamma, const float* ws_fwd, float* sim_logits,
+                                       float* sim_exp, float* pos_mask, float* neg_mask, float* sp_mask,
+                                       void* stream) {
+  SPCL_CHECK_ARG(ws_fwd, "supcon_materialize: null workspace");
+  SPCL_CHECK_ARG(n > 0 && d > 0 && d <= 256, "supcon_materialize: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  SupconLayout L = supcon_layout(n, d);
+  SupconArgs a = make_args(L, ws_fwd, labels, mask, temperature, sp_mode, gamma);
+  size_t total = (size_t)L.N2 * L.N2;
+  hipLaunchKernelGGL(supcon_materialize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, L.DP,
+                     sim_logits, sim_exp, pos_mask, neg_mask, sp_mask);
+  SPCL_LAUNCH_CHECK("supcon_materialize");
+  return SPCL_OK;
+}

@@ -1,0 +1,108 @@
+"""ctypes binding of libspcl_hip.so (the C ABI declared in include/spcl_hip.h).
+
+PyTorch is used only for device memory and streams: every call passes raw device pointers and the current
+HIP stream.  There is NO CPU or eager-PyTorch fallback: a missing library or a non-GPU tensor raises."""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_size_t, c_void_p
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libspcl_hip.so")
+SPCL_F32, SPCL_BF16 = 0, 1
+
+_lib = None
+
+# name -> (restype, argtypes); kept in the order of include/spcl_hip.h
+_P = c_void_p
+_SIGNATURES = {
+    "spcl_abi_version": (c_int, []),
+    "spcl_last_error": (c_char_p, []),
+    "spcl_supcon_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "spcl_supcon_forward": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_int, c_float, c_int, _P, _P, _P]),
+    "spcl_supcon_backward": (c_int, [_P, _P, c_int, c_int, c_float, c_int, c_float, _P, _P, _P, _P, _P, _P, _P]),
+    "spcl_supcon_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "spcl_supcon_materialize": (c_int, [_P, _P, c_int, c_int, c_float, c_int, c_float, _P, _P, _P, _P, _P, _P, _P]),
+    "spcl_proj_forward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int,
+                                  _P, _P, _P, _P, _P]),
+    "spcl_proj_backward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, _P, _P, _P,
+                                   _P, _P, _P, _P, _P, _P, _P]),
+    "spcl_conv_packed_elems": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "spcl_conv_pack_weights": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
+    "spcl_conv_num_tiles": (c_int, [c_int, c_int, c_int]),
+    "spcl_conv3x3_forward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P, _P]),
+    "spcl_conv3x3_first_forward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P]),
+    "spcl_conv3x3_first_wgrad": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P]),
+    "spcl_conv_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "spcl_conv3x3_wgrad": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P,
+                                   _P, _P, _P]),
+    "spcl_bn_finalize": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P]),
+    "spcl_bn_eval_affine": (c_int, [c_int, c_int, _P, _P, _P, _P, c_float, _P, _P, _P]),
+    "spcl_bnrelu_pool_forward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    "spcl_bnrelu_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "spcl_bnrelu_pool_backward": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P,
+                                          _P, _P, _P, _P, _P]),
+    "spcl_nchw_to_nhwc": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "spcl_nhwc_to_nchw": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+}
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libspcl_hip.so (once).  Raises loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryError(
+                f"{LIB_PATH} is missing: build it with `python self-paced-contrastive-learning_amd/build.py` "
+                "(there is no CPU / eager fallback for the hot path)")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name, None)
+            if fn is None:
+                continue  # reported by tests/test_abi.py; calling it raises below
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def call(name: str, *args):
+    L = lib()
+    fn = getattr(L, name, None)
+    if fn is None:
+        raise NativeLibraryError(f"libspcl_hip.so does not export {name}")
+    rc = fn(*args)
+    if fn.restype is c_int and name != "spcl_abi_version" and name != "spcl_conv_num_tiles" and rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {L.spcl_last_error().decode()}")
+    return rc
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("self-paced-contrastive-learning_amd runs on MI355X only: got a CPU tensor "
+                               "(the HIP path has no CPU fallback)")
+
+
+def ptr(t):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return SPCL_F32
+    if dt == torch.bfloat16:
+        return SPCL_BF16
+    raise TypeError(f"unsupported activation dtype {dt}")

@@ -1,0 +1,70 @@
+"""GPU parity of the HIP projector (avg-pool -> MLP -> L2 normalise, fwd+bwd) vs golden vectors and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import spcl_oracle as O
+
+
+def _head(ci, ch, co, seed, head_type="mlp", normalize=True):
+    import spcl_amd  # noqa
+    from spcl_amd.contrastyou.projectors.heads import ProjectionHead
+    h = ProjectionHead(input_dim=ci, hidden_dim=ch, output_dim=co, head_type=head_type, normalize=normalize)
+    sd = O.init_projector_state(ci, ch, co, seed=seed, head_type=head_type)
+    h.load_state_dict(sd, strict=True)
+    return h.cuda(), sd
+
+
+@pytest.mark.parametrize("tag", ["small", "base"])
+@pytest.mark.parametrize("layout", ["nchw", "channels_last", "bf16_cl"])
+def test_projector_golden(golden, tag, layout):
+    g = golden("g2_projector.npz")
+    ci, ch, co, seed = [int(v) for v in g[f"{tag}/dims"]]
+    head, _ = _head(ci, ch, co, seed)
+    x = torch.tensor(g[f"{tag}/x"]).cuda()
+    if layout == "channels_last":
+        x = x.contiguous(memory_format=torch.channels_last)
+    if layout == "bf16_cl":
+        x = x.contiguous(memory_format=torch.channels_last).bfloat16()
+    x.requires_grad_(True)
+    y = head(x)
+    (y * torch.tensor(g[f"{tag}/r"]).cuda()).sum().backward()
+    tol = dict(rtol=1e-4, atol=1e-5) if layout != "bf16_cl" else dict(rtol=3e-2, atol=3e-3)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g[f"{tag}/y"], **tol)
+    gtol = dict(rtol=1e-3, atol=1e-6) if layout != "bf16_cl" else dict(rtol=5e-2, atol=2e-4)
+    assert x.grad.shape == x.shape
+    np.testing.assert_allclose(x.grad.float().cpu().numpy(), g[f"{tag}/dx"], **gtol)
+    for k, p in head.named_parameters():
+        ref = g[f"{tag}/grad/{k}"]
+        a = 1e-4 * float(np.abs(ref).max()) if layout != "bf16_cl" else 3e-2 * float(np.abs(ref).max())
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=1e-3 if layout != "bf16_cl" else 5e-2, atol=a,
+                                   err_msg=k)
+
+
+@pytest.mark.parametrize("head_type,normalize", [("linear", True), ("mlp", False)])
+def test_projector_variants_vs_oracle(head_type, normalize):
+    head, sd = _head(24, 40, 12, 9, head_type, normalize)
+    x = torch.randn(5, 24, 7, 7, generator=torch.Generator().manual_seed(4)).relu()
+    r = torch.randn(5, 12, generator=torch.Generator().manual_seed(5))
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    yr = O.projector_forward(xr, sdg, head_type=head_type, normalize=normalize)
+    (yr * r).sum().backward()
+    xg = x.cuda().requires_grad_(True)
+    y = head(xg)
+    (y * r.cuda()).sum().backward()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), yr.detach().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-3, atol=1e-6)
+    for k, p in head.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), sdg[k].grad.numpy(), rtol=1e-3, atol=1e-5, err_msg=k)
+
+
+def test_projector_scope_errors():
+    import spcl_amd  # noqa
+    from spcl_amd.contrastyou.projectors.heads import ProjectionHead
+    with pytest.raises(NotImplementedError):
+        ProjectionHead(input_dim=8, output_dim=8, head_type="mlp", normalize=True, pool_name="adaptive_max")
+    with pytest.raises(AssertionError):
+        ProjectionHead(input_dim=8, output_dim=8, head_type="conv", normalize=True)
