@@ -81,60 +81,60 @@ int spcl_proj_backward(const float* dz, int dtype, int N, int HW, int C, int Cs,
  * :118-121 (MaxPool2d 2x2), :156-190 (forward until Conv5) and their autograd backward (K1-K4, K17).
  */
 
-/* weights: OIHW f32 master (state_dict layout) <-> MFMA fragment-packed kernel layout.
- * kind 0: forward  (K = tap*CinP + ci, N = co)      kind 1: dgrad (K = tap'*CoutP + co, N = ci, taps flipped)
- * packed size in elements: spcl_conv_packed_elems(Cin,Cout,kind) of `dtype` */
+/* weights: OIHW f32 master (state_dict layout) -> MFMA fragment-packed kernel layout (zero padded to 16-channel
+ * multiples).  kind 0: forward  (K = (tap, ci), N = co);  kind 1: dgrad (K = (tap', co), N = ci, taps flipped
+ * 180 degrees) -- the data gradient of a 3x3 same-conv is the same conv on these weights.
+ * size in elements of `dtype`: spcl_conv_packed_elems(Cin, Cout, kind, dtype). */
 size_t spcl_conv_packed_elems(int Cin, int Cout, int kind, int dtype);
 int spcl_conv_pack_weights(const float* w_oihw, int Cin, int Cout, int kind, int dtype, void* packed, void* stream);
 
-/* y = conv3x3(act(x)) for Cin>=1 via implicit GEMM on MFMA; NHWC.
- * x [N,H,W,CinS]; in_mode 0: act = identity, 1: act = relu(scale[c]*x+shift[c]) (fused BN-apply+ReLU of the
- * producer layer, unet.py:73-74 applied on load).  y [N,H,W,CoutS] raw conv output.
- * stats != NULL: per-workgroup Chan partials (count, mean, M2) per output channel written to
- * stats[spcl_conv_num_tiles(...)][CoutS][3] f32 for the train-mode BatchNorm that follows (unet.py:73,76). */
+/* y = conv3x3(act(x)), NHWC, implicit GEMM on MFMA.                    (unet.py:72,75; dgrad: with kind-1 weights)
+ * x [N,H,W,CinS] of dtype; CinK = GEMM-K channels (multiple of 16, == CinS for in_mode 0/1).
+ * in_mode 0: act = identity;  1: act = relu(in_scale[c]*x+in_shift[c])  (the producer's BatchNorm-apply + ReLU,
+ * unet.py:73-74, fused into the load);  2: x is the f32 input image [N,H,W,CinS] with CinS<=16 real channels
+ * (== NCHW when CinS==1), zero-padded to CinK=16 on load.
+ * y [N,H,W,CoutS] raw conv output (dtype).  stats != NULL: per-tile Chan partials (count, mean, M2) per output
+ * channel, stats[spcl_conv_num_tiles(N,H,W)][CoutS][3] f32, for the train-mode BatchNorm that follows. */
 int spcl_conv_num_tiles(int N, int H, int W);
-int spcl_conv3x3_forward(const void* x, int dtype, int N, int H, int W, int CinS, int CoutS, const void* w_packed,
-                         int in_mode, const float* in_scale, const float* in_shift, void* y, float* stats,
-                         void* stream);
-/* first layer (tiny Cin, e.g. 1): direct conv, x [N,H,W,Cin] f32 (== NCHW for Cin==1), w OIHW f32 */
-int spcl_conv3x3_first_forward(const float* x, int N, int H, int W, int Cin, int Cout, int CoutS, const float* w_oihw,
-                               int dtype, void* y, float* stats, void* stream);
-int spcl_conv3x3_first_wgrad(const float* x, const void* dy, int dtype, int N, int H, int W, int Cin, int Cout,
-                             int CoutS, float* partial /* [nblk][Cout*Cin*9] */, int nblk, float* dw_oihw,
-                             void* stream);
-/* dW (OIHW f32, overwritten) = sum_pixels act(x)[p+tap] (x) dy[p];  x/in_mode as in forward.
- * partial: workspace of spcl_conv_wgrad_workspace_bytes() */
-size_t spcl_conv_wgrad_workspace_bytes(int N, int H, int W, int CinS, int CoutS);
-int spcl_conv3x3_wgrad(const void* x, const void* dy, int dtype, int N, int H, int W, int Cin, int CinS, int Cout,
-                       int CoutS, int in_mode, const float* in_scale, const float* in_shift, float* partial,
+int spcl_conv3x3_forward(const void* x, int dtype, int N, int H, int W, int CinS, int CinK, int CoutS,
+                         const void* w_packed, int in_mode, const float* in_scale, const float* in_shift, void* y,
+                         float* stats, void* stream);
+
+/* dW[co][ci][ky][kx] (OIHW f32, overwritten) = sum_pixels act(x)[p+tap][ci] * dy[p][co]   (weight gradient of
+ * unet.py:72,75).  x / in_mode / CinK as in forward; Cin, Cout = real channel counts of dW.
+ * partial: workspace of spcl_conv_wgrad_workspace_bytes() (deterministic two-stage reduction, no atomics). */
+size_t spcl_conv_wgrad_workspace_bytes(int N, int H, int W, int CinK, int CoutS);
+int spcl_conv3x3_wgrad(const void* x, const void* dy, int dtype, int N, int H, int W, int Cin, int CinS, int CinK,
+                       int Cout, int CoutS, int in_mode, const float* in_scale, const float* in_shift, float* partial,
                        float* dw_oihw, void* stream);
 
-/* train-mode BatchNorm statistics (unet.py:73,76; torch.nn.BatchNorm2d momentum/eps semantics):
- * combines the conv epilogue partials -> mean, invstd, scale=gamma*invstd, shift=beta-mean*scale and updates
- * running_mean/var (unbiased var, momentum).  eval mode: spcl_bn_eval_affine builds scale/shift from running stats */
+/* train-mode BatchNorm statistics (unet.py:73,76; torch.nn.BatchNorm2d semantics): combines the conv epilogue
+ * partials (Chan, fixed order) -> mean, invstd = 1/sqrt(var_biased+eps), scale = gamma*invstd,
+ * shift = beta-mean*scale (all [CS] f32, zero in the channel padding) and updates running_mean / running_var
+ * (unbiased variance, momentum) and num_batches_tracked (+1) when those pointers are non-NULL. */
 int spcl_bn_finalize(const float* stats, int ntiles, int C, int CS, const float* gamma, const float* beta,
-                     float momentum, float eps, float* running_mean, float* running_var, float* mean, float* invstd,
-                     float* scale, float* shift, void* stream);
+                     float momentum, float eps, float* running_mean, float* running_var,
+                     int64_t* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift,
+                     void* stream);
+/* eval mode: mean/invstd/scale/shift from the running statistics */
 int spcl_bn_eval_affine(int C, int CS, const float* gamma, const float* beta, const float* running_mean,
-                        const float* running_var, float eps, float* scale, float* shift, void* stream);
+                        const float* running_var, float eps, float* mean, float* invstd, float* scale, float* shift,
+                        void* stream);
 
-/* a = relu(scale*y+shift) [N,H,W,CS] (act_out, may be NULL) and/or 2x2/2 max-pooled p [N,H/2,W/2,CS]
- * (pool_out, may be NULL)  -- unet.py:74,77 + :118-121 */
+/* a = relu(scale*y+shift) [N,H,W,CS] (act_out, may be NULL) and/or its 2x2/2 max-pool p [N,H/2,W/2,CS]
+ * (pool_out, may be NULL)                                                       -- unet.py:74,77 + :118-121 */
 int spcl_bnrelu_pool_forward(const void* y, int dtype, int N, int H, int W, int CS, const float* scale,
                              const float* shift, void* act_out, void* pool_out, void* stream);
-/* backward of the above + BatchNorm backward:
- *   g = d(act) (+ scatter of d(pool) to the window arg-max, first max in scan order as torch.max_pool2d)
- *   dz = g*[scale*y+shift>0];  dbeta=sum dz;  dgamma=sum dz*yhat;  dy = scale*(dz - dbeta/M - yhat*dgamma/M)
- * two launches inside: reduce (deterministic two-stage) then apply.  dact/dpool may be NULL (not both). */
+/* backward of the above through ReLU, (optional) max-pool and BatchNorm:
+ *   g  = dact (+ dpool routed to the window arg-max: first maximum in scan order, as torch.max_pool2d)
+ *   dz = g * [scale*y+shift > 0];  dbeta = sum dz;  dgamma = sum dz*yhat,  yhat = (y-mean)*invstd
+ *   training: dy = scale*(dz - dbeta/M - yhat*dgamma/M);   eval: dy = scale*dz
+ * dact / dpool may be NULL (not both).  Deterministic: per-workgroup partials + fixed-order second stage. */
 size_t spcl_bnrelu_bwd_workspace_bytes(int N, int H, int W, int CS);
 int spcl_bnrelu_pool_backward(const void* y, const void* dact, const void* dpool, int dtype, int N, int H, int W,
-                              int C, int CS, const float* gamma, const float* mean, const float* invstd,
-                              const float* scale, const float* shift, float* ws, float* dgamma, float* dbeta,
-                              void* dy, void* stream);
-
-/* layout helpers: NCHW f32 <-> NHWC(dtype, channel-padded) */
-int spcl_nchw_to_nhwc(const float* src, int N, int C, int H, int W, int CS, int dtype, void* dst, void* stream);
-int spcl_nhwc_to_nchw(const void* src, int dtype, int N, int C, int H, int W, int CS, float* dst, void* stream);
+                              int C, int CS, const float* mean, const float* invstd, const float* scale,
+                              const float* shift, int training, float* ws, float* dgamma, float* dbeta, void* dy,
+                              void* stream);
 
 #ifdef __cplusplus
 }

@@ -149,15 +149,51 @@ def channel_dim(name: str, max_channel: int = 256) -> int:
     return int(LAYER_DIMENSION[name] / 16 * max_channel)
 
 
-def _conv_block(x, sd, prefix, train, momentum, eps=1e-5):
+class _QuantBF16(torch.autograd.Function):
+    """Storage-point emulation of the bf16 mode: round to bf16 in forward AND round the gradient in backward
+    (every tensor the HIP path materialises in HBM -- raw conv outputs, staged activations, their gradients --
+    is stored as bf16 there; all arithmetic stays fp32)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+class BF16Emulation:
+    """q.act: activation/gradient storage point; q.weight: bf16 weights with an fp32 (unrounded) gradient;
+    q.input: forward-only rounding of the input image."""
+
+    @staticmethod
+    def act(x):
+        return _QuantBF16.apply(x)
+
+    @staticmethod
+    def weight(w):
+        return w + (w.detach().to(torch.bfloat16).to(w.dtype) - w.detach())
+
+    @staticmethod
+    def input(x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+
+def _conv_block(x, sd, prefix, train, momentum, eps=1e-5, q=None):
     """conv3x3(no bias) -> BN -> ReLU, twice (unet.py:67-82).  Updates running stats in ``sd`` in train mode."""
     for ci, bi in ((0, 1), (3, 4)):
-        x = F.conv2d(x, sd[f"{prefix}.conv.{ci}.weight"], None, 1, 1)
+        w = sd[f"{prefix}.conv.{ci}.weight"]
+        x = F.conv2d(x, q.weight(w) if q else w, None, 1, 1)
+        if q:
+            x = q.act(x)
         x = F.batch_norm(x, sd[f"{prefix}.conv.{bi}.running_mean"], sd[f"{prefix}.conv.{bi}.running_var"],
                          sd[f"{prefix}.conv.{bi}.weight"], sd[f"{prefix}.conv.{bi}.bias"], train, momentum, eps)
         if train:
             sd[f"{prefix}.conv.{bi}.num_batches_tracked"] += 1
         x = F.relu(x)
+        if q:
+            x = q.act(x)
     return x
 
 
@@ -172,16 +208,18 @@ def _up_conv(x, sd, prefix, train, momentum, eps=1e-5):
     return F.relu(x)
 
 
-def unet_forward(x: Tensor, sd: Dict[str, Tensor], until: Optional[str] = None, *, train=True, momentum=0.1):
-    """Full UNet forward with early exit (unet.py:156-230).  ``sd`` = state_dict-style dict (mutated: BN stats)."""
+def unet_forward(x: Tensor, sd: Dict[str, Tensor], until: Optional[str] = None, *, train=True, momentum=0.1,
+                 q=None):
+    """Full UNet forward with early exit (unet.py:156-230).  ``sd`` = state_dict-style dict (mutated: BN stats).
+    ``q`` = BF16Emulation to mimic the bf16 mode's storage roundings in the encoder (None = reference fp32)."""
     if until is not None and until not in LAYER_DIMENSION and until != "Deconv_1x1":
         raise KeyError(until)
     feats = {}
-    e = x
+    e = q.input(x) if q else x
     for k, name in enumerate(ENCODER_NAMES):
         if k > 0:
             e = F.max_pool2d(e, 2, 2)
-        e = _conv_block(e, sd, f"_{name}", train, momentum)
+        e = _conv_block(e, sd, f"_{name}", train, momentum, q=q)
         feats[name] = e
         if until == name:
             return e
@@ -195,9 +233,9 @@ def unet_forward(x: Tensor, sd: Dict[str, Tensor], until: Optional[str] = None, 
     return F.conv2d(d, sd["_Deconv_1x1.weight"], sd["_Deconv_1x1.bias"])
 
 
-def encoder_forward(x, sd, until="Conv5", *, train=True, momentum=0.1):
+def encoder_forward(x, sd, until="Conv5", *, train=True, momentum=0.1, q=None):
     assert until in ENCODER_NAMES
-    return unet_forward(x, sd, until, train=train, momentum=momentum)
+    return unet_forward(x, sd, until, train=train, momentum=momentum, q=q)
 
 
 def init_unet_state(input_dim=1, num_classes=4, max_channel=256, seed=0, encoder_only=False, dtype=torch.float32):
@@ -341,12 +379,12 @@ def apply_flips(x: Tensor, decisions: Tensor) -> Tensor:
 # --------------------------------------------------------------------------------------
 def pretrain_step(images: Tensor, images_tf: Tensor, sd: Dict[str, Tensor], proj_sd: Dict[str, Tensor],
                   labels: Sequence[int], *, gamma: Optional[float], mode="soft", correct_grad=True, t=0.07,
-                  momentum=0.1, flip: Optional[Tensor] = None):
+                  momentum=0.1, flip: Optional[Tensor] = None, q=None):
     """semi_seg/epochers/new_pretrain.py:52-96 + semi_seg/hooks/infonce.py:171-195 for one batch.
 
     Returns dict(loss, rho, grads{name: Tensor}, feature).  ``sd``/``proj_sd`` leaves must require grad."""
     n = images.shape[0]
-    feat = encoder_forward(torch.cat([images, images_tf], 0), sd, "Conv5", train=True, momentum=momentum)
+    feat = encoder_forward(torch.cat([images, images_tf], 0), sd, "Conv5", train=True, momentum=momentum, q=q)
     f, f_tf2 = feat[:n], feat[n:]
     if flip is not None:
         f = apply_flips(f, flip)

@@ -1,0 +1,468 @@
+// BatchNorm2d (train/eval) + ReLU + 2x2 max-pool glue kernels for the NHWC encoder on gfx950.
+// Replaces nn.BatchNorm2d(momentum) / nn.ReLU / nn.MaxPool2d(2,2) of semi_seg/arch/unet.py:73-77,118-121 and their
+// autograd backward.  All of these are HBM-bound streaming kernels: 16-byte vector loads/stores per lane, per-channel
+// reductions as per-workgroup partials + a fixed-order second stage (deterministic, no float atomics).
+#include "common.hpp"
+
+namespace spcl {
+
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+template <typename T> struct Chunk;
+template <> struct Chunk<float> { static constexpr int EPC = 4; };
+template <> struct Chunk<bf16_t> { static constexpr int EPC = 8; };
+
+template <typename T> __device__ __forceinline__ void unpack(u32x4 raw, float* v);
+template <> __device__ __forceinline__ void unpack<float>(u32x4 raw, float* v) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = __uint_as_float(raw[e]);
+}
+template <> __device__ __forceinline__ void unpack<bf16_t>(u32x4 raw, float* v) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    v[2 * e] = __uint_as_float(raw[e] << 16);
+    v[2 * e + 1] = __uint_as_float(raw[e] & 0xffff0000u);
+  }
+}
+template <typename T> __device__ __forceinline__ u32x4 pack(const float* v);
+template <> __device__ __forceinline__ u32x4 pack<float>(const float* v) {
+  return (u32x4){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+}
+template <> __device__ __forceinline__ u32x4 pack<bf16_t>(const float* v) {
+  u32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = (uint32_t)f32_to_bf16(v[2 * e]) | ((uint32_t)f32_to_bf16(v[2 * e + 1]) << 16);
+  return o;
+}
+
+// ------------------------------------------------------------------------------------------------ statistics
+// One wave per channel: Chan-combine the per-tile (count, mean, M2) partials in double, fixed order.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int ntiles, int C, int CS,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float momentum, float eps,
+                                                          float* running_mean, float* running_var, int64_t* nbt,
+                                                          float* __restrict__ mean, float* __restrict__ invstd,
+                                                          float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (c >= CS) return;
+  if (c >= C) {
+    if (lane == 0) { mean[c] = 0.f; invstd[c] = 0.f; scale[c] = 0.f; shift[c] = 0.f; }
+    return;
+  }
+  double n = 0.0, mu = 0.0, m2 = 0.0;
+  for (int t = lane; t < ntiles; t += 64) {
+    const float* s = stats + ((size_t)t * CS + c) * 3;
+    const double nb = s[0], mb = s[1], qb = s[2];
+    if (nb > 0.0) {
+      const double nn = n + nb, d = mb - mu;
+      mu += d * nb / nn;
+      m2 += qb + d * d * n * nb / nn;
+      n = nn;
+    }
+  }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const double nb = __shfl_xor(n, o, 64), mb = __shfl_xor(mu, o, 64), qb = __shfl_xor(m2, o, 64);
+    const double nn = n + nb;
+    if (nn > 0.0) {
+      // symmetric form so both partners compute the identical result
+      const double d = mb - mu;
+      const double mu_new = (n * mu + nb * mb) / nn;
+      m2 = m2 + qb + d * d * n * nb / nn;
+      mu = mu_new;
+      n = nn;
+    }
+  }
+  if (lane == 0) {
+    const double var = m2 / n;
+    const float is = 1.0f / sqrtf((float)var + eps);
+    const float sc = gamma[c] * is;
+    mean[c] = (float)mu;
+    invstd[c] = is;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mu * sc;
+    if (running_mean != nullptr) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
+    if (running_var != nullptr) {
+      const double unbiased = n > 1.0 ? m2 / (n - 1.0) : var;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+    if (nbt != nullptr && c == 0) nbt[0] += 1;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_eval_affine_kernel(int C, int CS, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             const float* __restrict__ rm, const float* __restrict__ rv,
+                                                             float eps, float* mean, float* invstd, float* scale,
+                                                             float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= CS) return;
+  if (c >= C) { mean[c] = 0.f; invstd[c] = 0.f; scale[c] = 0.f; shift[c] = 0.f; return; }
+  const float is = 1.0f / sqrtf(rv[c] + eps);
+  const float sc = gamma[c] * is;
+  mean[c] = rm[c];
+  invstd[c] = is;
+  scale[c] = sc;
+  shift[c] = beta[c] - rm[c] * sc;
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+// thread = (output position, 16-byte channel chunk).  POOL: position = 2x2 window, else a single pixel.
+template <typename T, bool POOL>
+__global__ __launch_bounds__(256) void bnrelu_fwd_kernel(const T* __restrict__ y, int N, int H, int W, int CS,
+                                                         const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, T* __restrict__ act,
+                                                         T* __restrict__ pool) {
+  constexpr int EPC = Chunk<T>::EPC;
+  const int CPC = CS / EPC;
+  // POOL: positions are 2x2 windows on the CEIL grid; torch.max_pool2d floors, so a window cut by an odd edge
+  // produces no pooled value but its pixels still get their activation
+  const int PH = POOL ? (H + 1) / 2 : H, PW = POOL ? (W + 1) / 2 : W;
+  const int OH = H / 2, OW = W / 2;
+  const size_t total = (size_t)N * PH * PW * CPC;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int cc = (int)(idx % CPC);
+    const size_t pos = idx / CPC;
+    const int ox = (int)(pos % PW), oy = (int)((pos / PW) % PH), n = (int)(pos / ((size_t)PW * PH));
+    float sc[EPC], sh[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; e += 4) {
+      *(f32x4*)&sc[e] = *(const f32x4*)(scale + cc * EPC + e);
+      *(f32x4*)&sh[e] = *(const f32x4*)(shift + cc * EPC + e);
+    }
+    if (POOL) {
+      float mx[EPC];
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) mx[e] = 0.f;  // activations are >= 0
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int yy = 2 * oy + (k >> 1), xx = 2 * ox + (k & 1);
+        if (yy < H && xx < W) {
+          const size_t off = (((size_t)n * H + yy) * W + xx) * CS + cc * EPC;
+          float v[EPC];
+          unpack<T>(*(const u32x4*)(y + off), v);
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) {
+            v[e] = fmaxf(fmaf(sc[e], v[e], sh[e]), 0.f);
+            mx[e] = fmaxf(mx[e], v[e]);
+          }
+          if (act != nullptr) *(u32x4*)(act + off) = pack<T>(v);
+        }
+      }
+      if (pool != nullptr && oy < OH && ox < OW)
+        *(u32x4*)(pool + (((size_t)n * OH + oy) * OW + ox) * CS + cc * EPC) = pack<T>(mx);
+    } else {
+      const size_t off = (((size_t)n * H + oy) * W + ox) * CS + cc * EPC;
+      float v[EPC];
+      unpack<T>(*(const u32x4*)(y + off), v);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) v[e] = fmaxf(fmaf(sc[e], v[e], sh[e]), 0.f);
+      *(u32x4*)(act + off) = pack<T>(v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+// dz for the EPC channels of one position (window or pixel); shared by the reduce and apply passes so both see
+// bit-identical masks.  g = dact (+ dpool at the arg-max, first max in scan order like torch.max_pool2d).
+template <typename T, bool POOL, int K /* pixels per position: 4 or 1 */>
+struct BwdPos {
+  static constexpr int EPC = Chunk<T>::EPC;
+  float yv[K][EPC];
+  float dz[K][EPC];
+  size_t off[K];
+  bool valid[K];
+  __device__ __forceinline__ void load(const T* y, const T* dact, const T* dpool, int n, int oy, int ox, int H, int W,
+                                       int CS, int cc, const float* sc, const float* sh) {
+    float a[K][EPC], g[K][EPC];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int yy = POOL ? 2 * oy + (k >> 1) : oy, xx = POOL ? 2 * ox + (k & 1) : ox;
+      valid[k] = yy < H && xx < W;
+      off[k] = (((size_t)n * H + yy) * W + xx) * CS + cc * EPC;
+      if (valid[k]) unpack<T>(*(const u32x4*)(y + off[k]), yv[k]);
+      else {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) yv[k][e] = 0.f;
+      }
+      if (valid[k] && dact != nullptr) unpack<T>(*(const u32x4*)(dact + off[k]), g[k]);
+      else {
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) g[k][e] = 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) a[k][e] = valid[k] ? fmaf(sc[e], yv[k][e], sh[e]) : -1.f;  // z (pre-ReLU)
+    }
+    if (POOL && dpool != nullptr && oy < H / 2 && ox < W / 2) {  // complete window (floor semantics)
+      float dp[EPC];
+      unpack<T>(*(const u32x4*)(dpool + (((size_t)n * (H / 2) + oy) * (W / 2) + ox) * CS + cc * EPC), dp);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        int best = 0;
+        float m = fmaxf(a[0][e], 0.f);
+#pragma unroll
+        for (int k = 1; k < K; ++k) {
+          const float v = fmaxf(a[k][e], 0.f);
+          if (v > m) { m = v; best = k; }
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) g[k][e] += (k == best) ? dp[e] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) dz[k][e] = a[k][e] > 0.f ? g[k][e] : 0.f;
+  }
+};
+
+constexpr int BWD_MAX_WG = 1024;
+
+template <typename T, bool POOL>
+__global__ __launch_bounds__(256) void bnrelu_bwd_reduce_kernel(const T* __restrict__ y, const T* __restrict__ dact,
+                                                                const T* __restrict__ dpool, int N, int H, int W,
+                                                                int CS, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ shift,
+                                                                float* __restrict__ partial /* [grid][2][CS] */) {
+  constexpr int EPC = Chunk<T>::EPC;
+  constexpr int K = POOL ? 4 : 1;
+  __shared__ float red[256][2 * EPC + 1];
+  const int CPC = CS / EPC;          // chunks per pixel (power of two, <= 256... CS<=1024)
+  const int PL = 256 / CPC;          // position lanes per workgroup
+  const int cc = threadIdx.x % CPC, pl = threadIdx.x / CPC;
+  const int OH = POOL ? (H + 1) / 2 : H, OW = POOL ? (W + 1) / 2 : W;  // ceil grid: every pixel is visited once
+  const size_t npos = (size_t)N * OH * OW;
+  float sc[EPC], sh[EPC], mu[EPC], is[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; e += 4) {
+    *(f32x4*)&sc[e] = *(const f32x4*)(scale + cc * EPC + e);
+    *(f32x4*)&sh[e] = *(const f32x4*)(shift + cc * EPC + e);
+    *(f32x4*)&mu[e] = *(const f32x4*)(mean + cc * EPC + e);
+    *(f32x4*)&is[e] = *(const f32x4*)(invstd + cc * EPC + e);
+  }
+  float s1[EPC], s2[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = 0.f;
+  if (pl < PL) {
+    for (size_t pos = (size_t)blockIdx.x * PL + pl; pos < npos; pos += (size_t)gridDim.x * PL) {
+      const int ox = (int)(pos % OW), oy = (int)((pos / OW) % OH), n = (int)(pos / ((size_t)OW * OH));
+      BwdPos<T, POOL, K> b;
+      b.load(y, dact, dpool, n, oy, ox, H, W, CS, cc, sc, sh);
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {  // invalid pixels carry dz == 0
+          s1[e] += b.dz[k][e];
+          s2[e] = fmaf(b.dz[k][e], (b.yv[k][e] - mu[e]) * is[e], s2[e]);
+        }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    red[threadIdx.x][e] = s1[e];
+    red[threadIdx.x][EPC + e] = s2[e];
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < 2 * CS; o += 256) {
+    const int which = o / CS, c = o - which * CS;
+    const int ccc = c / EPC, e = c - ccc * EPC;
+    float s = 0.f;
+    for (int p = 0; p < PL; ++p) s += red[p * CPC + ccc][which * EPC + e];
+    partial[((size_t)blockIdx.x * 2 + which) * CS + c] = s;
+  }
+}
+
+// dbeta = sum dz, dgamma = sum dz*yhat (fixed order over workgroups); k1 = dbeta/M, k2 = dgamma/M for the apply pass
+__global__ __launch_bounds__(256) void bnrelu_bwd_fin_kernel(const float* __restrict__ partial, int nwg, int C, int CS,
+                                                             float M, int training, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, float* __restrict__ k12) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= CS) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int w = 0; w < nwg; ++w) {
+    s1 += partial[((size_t)w * 2 + 0) * CS + c];
+    s2 += partial[((size_t)w * 2 + 1) * CS + c];
+  }
+  if (c < C) {
+    dbeta[c] = s1;
+    dgamma[c] = s2;
+  }
+  k12[c] = training ? s1 / M : 0.f;
+  k12[CS + c] = training ? s2 / M : 0.f;
+}
+
+template <typename T, bool POOL>
+__global__ __launch_bounds__(256) void bnrelu_bwd_apply_kernel(const T* __restrict__ y, const T* __restrict__ dact,
+                                                               const T* __restrict__ dpool, int N, int H, int W,
+                                                               int CS, const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd,
+                                                               const float* __restrict__ scale,
+                                                               const float* __restrict__ shift,
+                                                               const float* __restrict__ k12, T* __restrict__ dy) {
+  constexpr int EPC = Chunk<T>::EPC;
+  constexpr int K = POOL ? 4 : 1;
+  const int CPC = CS / EPC;
+  const int OH = POOL ? (H + 1) / 2 : H, OW = POOL ? (W + 1) / 2 : W;
+  const size_t total = (size_t)N * OH * OW * CPC;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int cc = (int)(idx % CPC);
+    const size_t pos = idx / CPC;
+    const int ox = (int)(pos % OW), oy = (int)((pos / OW) % OH), n = (int)(pos / ((size_t)OW * OH));
+    float sc[EPC], sh[EPC], mu[EPC], is[EPC], k1[EPC], k2[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; e += 4) {
+      *(f32x4*)&sc[e] = *(const f32x4*)(scale + cc * EPC + e);
+      *(f32x4*)&sh[e] = *(const f32x4*)(shift + cc * EPC + e);
+      *(f32x4*)&mu[e] = *(const f32x4*)(mean + cc * EPC + e);
+      *(f32x4*)&is[e] = *(const f32x4*)(invstd + cc * EPC + e);
+      *(f32x4*)&k1[e] = *(const f32x4*)(k12 + cc * EPC + e);
+      *(f32x4*)&k2[e] = *(const f32x4*)(k12 + CS + cc * EPC + e);
+    }
+    BwdPos<T, POOL, K> b;
+    b.load(y, dact, dpool, n, oy, ox, H, W, CS, cc, sc, sh);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      if (!b.valid[k]) continue;
+      float o[EPC];
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        const float yh = (b.yv[k][e] - mu[e]) * is[e];
+        o[e] = sc[e] * (b.dz[k][e] - k1[e] - yh * k2[e]);
+      }
+      *(u32x4*)(dy + b.off[k]) = pack<T>(o);
+    }
+  }
+}
+
+static int stream_grid(size_t total_threads) {
+  size_t g = (total_threads + 255) / 256;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+template <typename T>
+static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool, int N, int H, int W, int C, int CS,
+                             const float* mean, const float* invstd, const float* scale, const float* shift,
+                             int training, float* ws, float* dgamma, float* dbeta, void* dy, hipStream_t st) {
+  constexpr int EPC = Chunk<T>::EPC;
+  const bool pool = dpool != nullptr;
+  const int OH = pool ? (H + 1) / 2 : H, OW = pool ? (W + 1) / 2 : W;
+  const size_t npos = (size_t)N * OH * OW;
+  const int CPC = CS / EPC;
+  const int PL = 256 / CPC;
+  int nwg = (int)((npos + PL - 1) / PL);
+  if (nwg > BWD_MAX_WG) nwg = BWD_MAX_WG;
+  float* partial = ws;                          // [nwg][2][CS]
+  float* k12 = ws + (size_t)BWD_MAX_WG * 2 * CS;  // [2][CS]
+  const float M = (float)((size_t)N * H * W);
+  if (pool) {
+    hipLaunchKernelGGL((bnrelu_bwd_reduce_kernel<T, true>), dim3(nwg), dim3(256), 0, st, (const T*)y, (const T*)dact,
+                       (const T*)dpool, N, H, W, CS, mean, invstd, scale, shift, partial);
+  } else {
+    hipLaunchKernelGGL((bnrelu_bwd_reduce_kernel<T, false>), dim3(nwg), dim3(256), 0, st, (const T*)y, (const T*)dact,
+                       (const T*)dpool, N, H, W, CS, mean, invstd, scale, shift, partial);
+  }
+  hipLaunchKernelGGL(bnrelu_bwd_fin_kernel, dim3(cdiv(CS, 256)), dim3(256), 0, st, (const float*)partial, nwg, C, CS,
+                     M, training, dgamma, dbeta, k12);
+  const int grid = stream_grid(npos * CPC);
+  if (pool) {
+    hipLaunchKernelGGL((bnrelu_bwd_apply_kernel<T, true>), dim3(grid), dim3(256), 0, st, (const T*)y, (const T*)dact,
+                       (const T*)dpool, N, H, W, CS, mean, invstd, scale, shift, (const float*)k12, (T*)dy);
+  } else {
+    hipLaunchKernelGGL((bnrelu_bwd_apply_kernel<T, false>), dim3(grid), dim3(256), 0, st, (const T*)y, (const T*)dact,
+                       (const T*)dpool, N, H, W, CS, mean, invstd, scale, shift, (const float*)k12, (T*)dy);
+  }
+  return 0;
+}
+
+}  // namespace spcl
+
+using namespace spcl;
+
+extern "C" int spcl_bn_finalize(const float* stats, int ntiles, int C, int CS, const float* gamma, const float* beta,
+                                float momentum, float eps, float* running_mean, float* running_var,
+                                int64_t* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift,
+                                void* stream) {
+  SPCL_CHECK_ARG(stats && gamma && beta && mean && invstd && scale && shift, "bn_finalize: null pointer");
+  SPCL_CHECK_ARG(ntiles > 0 && C > 0 && CS >= C, "bn_finalize: bad shape");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(CS, 4)), dim3(256), 0, (hipStream_t)stream, stats, ntiles, C, CS,
+                     gamma, beta, momentum, eps, running_mean, running_var, num_batches_tracked, mean, invstd, scale,
+                     shift);
+  SPCL_LAUNCH_CHECK("bn_finalize");
+  return SPCL_OK;
+}
+
+extern "C" int spcl_bn_eval_affine(int C, int CS, const float* gamma, const float* beta, const float* running_mean,
+                                   const float* running_var, float eps, float* mean, float* invstd, float* scale,
+                                   float* shift, void* stream) {
+  SPCL_CHECK_ARG(gamma && beta && running_mean && running_var && mean && invstd && scale && shift,
+                 "bn_eval_affine: null pointer");
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(cdiv(CS, 256)), dim3(256), 0, (hipStream_t)stream, C, CS, gamma, beta,
+                     running_mean, running_var, eps, mean, invstd, scale, shift);
+  SPCL_LAUNCH_CHECK("bn_eval_affine");
+  return SPCL_OK;
+}
+
+extern "C" int spcl_bnrelu_pool_forward(const void* y, int dtype, int N, int H, int W, int CS, const float* scale,
+                                        const float* shift, void* act_out, void* pool_out, void* stream) {
+  SPCL_CHECK_ARG(y && scale && shift && (act_out || pool_out), "bnrelu_pool_forward: null pointer");
+  SPCL_CHECK_ARG(N > 0 && H > 0 && W > 0 && CS > 0 && CS % 16 == 0, "bnrelu_pool_forward: bad shape");
+  SPCL_CHECK_ARG(!pool_out || (H >= 2 && W >= 2), "bnrelu_pool_forward: 2x2 pooling needs H,W >= 2");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype != SPCL_F32 && dtype != SPCL_BF16) {
+    set_error("bnrelu_pool_forward: dtype %d", dtype);
+    return SPCL_EINVAL;
+  }
+  const int epc = dtype == SPCL_F32 ? 4 : 8;
+  const size_t npos = pool_out ? (size_t)N * ((H + 1) / 2) * ((W + 1) / 2) : (size_t)N * H * W;
+  const int grid = stream_grid(npos * (CS / epc));
+  if (dtype == SPCL_F32) {
+    if (pool_out)
+      hipLaunchKernelGGL((bnrelu_fwd_kernel<float, true>), dim3(grid), dim3(256), 0, st, (const float*)y, N, H, W, CS,
+                         scale, shift, (float*)act_out, (float*)pool_out);
+    else
+      hipLaunchKernelGGL((bnrelu_fwd_kernel<float, false>), dim3(grid), dim3(256), 0, st, (const float*)y, N, H, W, CS,
+                         scale, shift, (float*)act_out, (float*)pool_out);
+  } else {
+    if (pool_out)
+      hipLaunchKernelGGL((bnrelu_fwd_kernel<bf16_t, true>), dim3(grid), dim3(256), 0, st, (const bf16_t*)y, N, H, W, CS,
+                         scale, shift, (bf16_t*)act_out, (bf16_t*)pool_out);
+    else
+      hipLaunchKernelGGL((bnrelu_fwd_kernel<bf16_t, false>), dim3(grid), dim3(256), 0, st, (const bf16_t*)y, N, H, W,
+                         CS, scale, shift, (bf16_t*)act_out, (bf16_t*)pool_out);
+  }
+  SPCL_LAUNCH_CHECK("bnrelu_pool_forward");
+  return SPCL_OK;
+}
+
+extern "C" size_t spcl_bnrelu_bwd_workspace_bytes(int N, int H, int W, int CS) {
+  (void)N; (void)H; (void)W;
+  return ((size_t)BWD_MAX_WG * 2 * CS + 2 * (size_t)CS) * sizeof(float);
+}
+
+extern "C" int spcl_bnrelu_pool_backward(const void* y, const void* dact, const void* dpool, int dtype, int N, int H,
+                                         int W, int C, int CS, const float* mean, const float* invstd,
+                                         const float* scale, const float* shift, int training, float* ws,
+                                         float* dgamma, float* dbeta, void* dy, void* stream) {
+  SPCL_CHECK_ARG(y && (dact || dpool) && mean && invstd && scale && shift && ws && dgamma && dbeta && dy,
+                 "bnrelu_pool_backward: null pointer");
+  SPCL_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && CS >= C && CS % 16 == 0 && CS <= 1024,
+                 "bnrelu_pool_backward: bad shape");
+  SPCL_CHECK_ARG(!dpool || (H >= 2 && W >= 2), "bnrelu_pool_backward: 2x2 pooling needs H,W >= 2");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SPCL_F32)
+    bnrelu_bwd_launch<float>(y, dact, dpool, N, H, W, C, CS, mean, invstd, scale, shift, training, ws, dgamma, dbeta,
+                             dy, st);
+  else if (dtype == SPCL_BF16)
+    bnrelu_bwd_launch<bf16_t>(y, dact, dpool, N, H, W, C, CS, mean, invstd, scale, shift, training, ws, dgamma, dbeta,
+                              dy, st);
+  else {
+    set_error("bnrelu_pool_backward: dtype %d", dtype);
+    return SPCL_EINVAL;
+  }
+  SPCL_LAUNCH_CHECK("bnrelu_pool_backward");
+  return SPCL_OK;
+}

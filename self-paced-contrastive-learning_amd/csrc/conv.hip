@@ -1,0 +1,421 @@
+// 3x3 same-convolution (stride 1, pad 1, no bias) on NHWC activations as an im2col-free implicit GEMM on the
+// gfx950 matrix cores.  Replaces nn.Conv2d(in,out,3,1,1,bias=False) of semi_seg/arch/unet.py:72,75 (forward) and
+// the data-gradient half of its autograd backward (dgrad == the same kernel on 180-degree-flipped, transposed
+// weights).  The producer's BatchNorm-apply + ReLU (unet.py:73-74) is fused into the input staging, and the
+// statistics the following train-mode BatchNorm needs are produced in the epilogue (Chan partials per tile).
+//
+// Mapping (one workgroup = one TH x TW tile of output pixels of one image x a block of output channels):
+//   GEMM  D[cout][pixel] += W[cout][k] * X[k][pixel],  k = (tap, cin)  -- weights are the MFMA "A" operand so a lane
+//   ends up with 4 CONSECUTIVE output channels of one pixel (8/16-byte NHWC stores, per-channel sums on 16 lanes).
+//   * input halo tile (TH+2)x(TW+2) x KC channels staged once in LDS, [pixel][channel] with a padded pixel stride
+//     (conflict-free ds_read_b128); the 9 taps are address offsets into it -- no im2col buffer anywhere.
+//   * weight fragments are pre-packed in MFMA lane order (spcl_conv_pack_weights): one coalesced 1 KiB
+//     global_load_dwordx4 per (k-step, 16-cout tile), L2-resident, no LDS.
+//   * bf16: v_mfma_f32_16x16x32_bf16 (8 bf16 / lane / operand);  f32: 4x v_mfma_f32_16x16x4_f32 per 16-byte chunk
+//     (exact-f32, the parity path).
+#include "common.hpp"
+
+namespace spcl {
+
+template <typename T> struct Chunk;
+template <> struct Chunk<float> { static constexpr int EPC = 4; };
+template <> struct Chunk<bf16_t> { static constexpr int EPC = 8; };
+
+struct uint4_ { uint32_t x, y, z, w; };
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+__host__ __device__ inline int conv_kc(int CinK) { return CinK < 64 ? CinK : 64; }
+template <typename T> __host__ __device__ inline int conv_pstride(int KC) {
+  int b = KC * (int)sizeof(T);
+  return b == 32 ? 32 : b + 32;  // bytes per halo pixel in LDS (see tools/ bank analysis in DESIGN.md)
+}
+template <typename T> __host__ __device__ inline int conv_nsteps(int KC) {
+  int cp = KC / Chunk<T>::EPC;
+  return (9 * cp + 3) / 4;
+}
+
+struct ConvArgs {
+  const void* x;
+  void* y;
+  const void* wp;
+  float* stats;
+  const float* in_scale;
+  const float* in_shift;
+  int N, H, W;
+  int CinS;     // storage stride of x in elements (mode 2: real channel count of the f32 image)
+  int CinK;     // GEMM-K channels, multiple of 16
+  int CoutS;    // storage stride of y == padded output channels (multiple of 16)
+  int in_mode;  // 0 raw, 1 relu(scale*x+shift), 2 f32 image with CinS (<16) channels zero-padded to 16
+  int tilesX, tilesY;
+};
+
+template <typename T> __device__ __forceinline__ f32x4 mfma_chunk(u32x4 w, u32x4 x, f32x4 acc);
+template <> __device__ __forceinline__ f32x4 mfma_chunk<bf16_t>(u32x4 w, u32x4 x, f32x4 acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0,
+                                                 0, 0);
+}
+template <> __device__ __forceinline__ f32x4 mfma_chunk<float>(u32x4 w, u32x4 x, f32x4 acc) {
+  f32x4 wf = __builtin_bit_cast(f32x4, w), xf = __builtin_bit_cast(f32x4, x);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0], xf[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[1], xf[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[2], xf[2], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[3], xf[3], acc, 0, 0, 0);
+  return acc;
+}
+
+// one 16-byte chunk of EPC consecutive channels: apply relu(scale*v+shift)
+template <typename T> __device__ __forceinline__ u32x4 bnrelu_chunk(u32x4 raw, const float* sc, const float* sh);
+template <> __device__ __forceinline__ u32x4 bnrelu_chunk<float>(u32x4 raw, const float* sc, const float* sh) {
+  f32x4 v = __builtin_bit_cast(f32x4, raw);
+  f32x4 s = *(const f32x4*)sc, b = *(const f32x4*)sh;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(s[e], v[e], b[e]), 0.f);
+  return __builtin_bit_cast(u32x4, v);
+}
+template <> __device__ __forceinline__ u32x4 bnrelu_chunk<bf16_t>(u32x4 raw, const float* sc, const float* sh) {
+  float s[8], b[8];
+  *(f32x4*)&s[0] = *(const f32x4*)sc;
+  *(f32x4*)&s[4] = *(const f32x4*)(sc + 4);
+  *(f32x4*)&b[0] = *(const f32x4*)sh;
+  *(f32x4*)&b[4] = *(const f32x4*)(sh + 4);
+  u32x4 out;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float lo = __uint_as_float(raw[e] << 16), hi = __uint_as_float(raw[e] & 0xffff0000u);
+    lo = fmaxf(fmaf(s[2 * e], lo, b[2 * e]), 0.f);
+    hi = fmaxf(fmaf(s[2 * e + 1], hi, b[2 * e + 1]), 0.f);
+    out[e] = (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  }
+  return out;
+}
+
+template <typename T> __device__ __forceinline__ void store4(T* p, f32x4 v);
+template <> __device__ __forceinline__ void store4<float>(float* p, f32x4 v) { *(f32x4*)p = v; }
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, f32x4 v) {
+  uint2 o;
+  o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+  o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+  *(uint2*)p = o;
+}
+
+template <typename T, int TH, int TW, int NT>
+__global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
+  constexpr int EPC = Chunk<T>::EPC;
+  constexpr int NPIX = TH * TW;
+  constexpr int MT = (NPIX + 15) / 16;
+  constexpr int HW_ = TW + 2;
+  constexpr int NHALO = (TH + 2) * HW_;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int KC = conv_kc(a.CinK);
+  const int CP = KC / EPC;
+  const int log2cp = __builtin_ctz(CP);
+  const int PSTRIDE = conv_pstride<T>(KC);
+  const int nsteps = conv_nsteps<T>(KC);
+  const int nslab = a.CinK / KC;
+  const int ntiles_n = a.CoutS >> 4;
+
+  int tile = blockIdx.x;
+  const int tpi = a.tilesX * a.tilesY;
+  const int n = tile / tpi;
+  const int trem = tile - n * tpi;
+  const int ty = trem / a.tilesX, tx = trem - ty * a.tilesX;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const int nt0 = (blockIdx.y * nwaves + wave) * NT;
+  const bool wave_active = nt0 < ntiles_n;  // uniform per wave
+  const int nvalid = min(NT, ntiles_n - nt0);  // n-tiles of this wave that exist (CoutS/16 may be odd)
+
+  // per-lane halo base address of each m-tile's pixel (p = 16 i + r16), + the lane's k-group chunk
+  int abase[MT];
+  unsigned validmask = 0;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    int p = 16 * i + r16;
+    bool ok = p < NPIX;
+    if (!ok) p = 0;
+    const int py = p / TW, px = p - py * TW;
+    abase[i] = (py * HW_ + px) * PSTRIDE;
+    if (ok && (y0 + py) < a.H && (x0 + px) < a.W) validmask |= 1u << i;
+  }
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const u32x4* wp = (const u32x4*)a.wp;
+
+  for (int slab = 0; slab < nslab; ++slab) {
+    __syncthreads();
+    // ---------------- stage the halo tile of this channel slab (fused BN-apply + ReLU of the producer)
+    for (int idx = threadIdx.x; idx < NHALO * CP; idx += blockDim.x) {
+      const int q = idx >> log2cp, ch = idx & (CP - 1);
+      const int hy = q / HW_, hx = q - hy * HW_;
+      const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+        const size_t pix = ((size_t)n * a.H + gy) * a.W + gx;
+        if (a.in_mode == 2) {
+          const float* src = (const float*)a.x + pix * a.CinS;
+          float e[EPC];
+#pragma unroll
+          for (int k = 0; k < EPC; ++k) {
+            const int c = ch * EPC + k;
+            e[k] = c < a.CinS ? src[c] : 0.f;
+          }
+          if (sizeof(T) == 4) {
+            v = (u32x4){__float_as_uint(e[0]), __float_as_uint(e[1]), __float_as_uint(e[2]), __float_as_uint(e[3])};
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              v[k] = (uint32_t)f32_to_bf16(e[(2 * k) % EPC]) | ((uint32_t)f32_to_bf16(e[(2 * k + 1) % EPC]) << 16);
+          }
+        } else {
+          const int c0 = slab * KC + ch * EPC;
+          v = *(const u32x4*)((const T*)a.x + pix * a.CinS + c0);
+          if (a.in_mode == 1) v = bnrelu_chunk<T>(v, a.in_scale + c0, a.in_shift + c0);
+        }
+      }
+      *(u32x4*)(lds + q * PSTRIDE + ch * 16) = v;
+    }
+    __syncthreads();
+    if (!wave_active) continue;
+
+    // ---------------- K loop over (tap, channel-chunk) steps; 4 chunks (k-groups g) per step
+    const u32x4* wslab = wp + ((size_t)slab * nsteps * ntiles_n + nt0) * 64 + lane;
+    u32x4 wf[NT], wnext[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) wf[j] = wslab[(size_t)(j < nvalid ? j : 0) * 64];
+#pragma unroll 1
+    for (int s = 0; s < nsteps; ++s) {
+      if (s + 1 < nsteps) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wnext[j] = wslab[((size_t)(s + 1) * ntiles_n + (j < nvalid ? j : 0)) * 64];
+      }
+      int fc = 4 * s + g;
+      if (fc >= 9 * CP) fc = 0;  // K padding: weights there are zero, any finite x will do
+      const int tap = fc >> log2cp, ch = fc & (CP - 1);
+      const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+      const int off = (ky * HW_ + kx) * PSTRIDE + ch * 16;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const u32x4 xf = *(const u32x4*)(lds + abase[i] + off);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = mfma_chunk<T>(wf[j], xf, acc[i][j]);
+      }
+      if (s + 1 < nsteps) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wf[j] = wnext[j];
+      }
+    }
+  }
+  if (!wave_active) return;
+
+  // ---------------- epilogue: lane holds couts 16(nt0+j)+4g..+3 of pixel 16i+r16
+  T* y = (T*)a.y;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    if (validmask & (1u << i)) {
+      const int p = 16 * i + r16;
+      const int py = p / TW, px = p - py * TW;
+      const size_t pix = ((size_t)n * a.H + y0 + py) * a.W + x0 + px;
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        if (j < nvalid) store4<T>(y + pix * a.CoutS + (nt0 + j) * 16 + 4 * g, acc[i][j]);
+    }
+  }
+  if (a.stats != nullptr) {
+    const int vh = min(TH, a.H - y0), vw = min(TW, a.W - x0);
+    const float cnt = (float)(vh * vw);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      if (j >= nvalid) break;
+      f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+        if (validmask & (1u << i)) s += acc[i][j];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = s[r];
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 8, 64);
+        s[r] = v / cnt;  // tile mean
+      }
+      f32x4 m2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+        if (validmask & (1u << i)) {
+          f32x4 d = acc[i][j] - s;
+          m2 += d * d;
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = m2[r];
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 8, 64);
+        m2[r] = v;
+      }
+      if (r16 == 0) {
+        float* dst = a.stats + ((size_t)tile * a.CoutS + (nt0 + j) * 16 + 4 * g) * 3;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dst[3 * r + 0] = cnt;
+          dst[3 * r + 1] = s[r];
+          dst[3 * r + 2] = m2[r];
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- weight packing
+// packed[slab][step][ntile][lane][EPC]: lane (r16 = cout within tile, g = k-group) holds the EPC channels of
+// flattened chunk fc = 4*step + g  (tap = fc / CP, channel chunk = fc % CP) of slab `slab`.
+// kind 0 (forward):  A[cout=o][k=(tap,ci)]      = W[o][ci][tap]
+// kind 1 (dgrad):    A[cout=ci][k=(tap,co)]     = W[co][ci][8-tap]        (roles of Cin/Cout swapped by the caller)
+template <typename T>
+__global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict__ w, int Cin, int Cout, int kind,
+                                                        int KinK, int NoutS, T* __restrict__ packed, size_t total) {
+  constexpr int EPC = Chunk<T>::EPC;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int KC = conv_kc(KinK);
+  const int CP = KC / EPC;
+  const int nsteps = conv_nsteps<T>(KC);
+  const int ntn = NoutS >> 4;
+  size_t r = idx;
+  const int e = (int)(r % EPC); r /= EPC;
+  const int lane = (int)(r % 64); r /= 64;
+  const int nt = (int)(r % ntn); r /= ntn;
+  const int step = (int)(r % nsteps); r /= nsteps;
+  const int slab = (int)r;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int fc = 4 * step + g;
+  float v = 0.f;
+  if (fc < 9 * CP) {
+    const int tap = fc / CP, ch = fc % CP;
+    const int kch = slab * KC + ch * EPC + e;  // GEMM-K channel
+    const int nch = nt * 16 + r16;             // GEMM-N (output) channel
+    if (kind == 0) {
+      if (kch < Cin && nch < Cout) v = w[((size_t)nch * Cin + kch) * 9 + tap];
+    } else {
+      if (kch < Cout && nch < Cin) v = w[((size_t)kch * Cin + nch) * 9 + (8 - tap)];
+    }
+  }
+  Elem<T>::store(packed + idx, v);
+}
+
+template <typename T> static size_t packed_elems(int KinK, int NoutS) {
+  const int KC = conv_kc(KinK);
+  return (size_t)(KinK / KC) * conv_nsteps<T>(KC) * (NoutS / 16) * 64 * Chunk<T>::EPC;
+}
+
+struct TileCfg { int th, tw; };
+static TileCfg pick_tile(int H, int W) {
+  if (H % 14 == 0 && W % 14 == 0) return {14, 14};
+  return {16, 16};
+}
+
+template <typename T, int TH, int TW>
+static int launch_conv(const ConvArgs& a0, hipStream_t st) {
+  ConvArgs a = a0;
+  a.tilesX = cdiv(a.W, TW);
+  a.tilesY = cdiv(a.H, TH);
+  const int ntn = a.CoutS / 16;
+  const int KC = conv_kc(a.CinK);
+  const size_t lds = (size_t)(TH + 2) * (TW + 2) * conv_pstride<T>(KC);
+  const int tiles = a.N * a.tilesX * a.tilesY;
+  // waves per workgroup x n-tiles per wave
+  int NT = ntn >= 2 ? 2 : 1;
+  int wn = cdiv(ntn, NT);
+  if (wn > 4) wn = 4;
+  const int gy = cdiv(ntn, NT * wn);
+  dim3 grid(tiles, gy), block(64 * wn);
+  if (NT == 1) {
+    if (lds > 65536) (void)hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<T, TH, TW, 1>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<T, TH, TW, 1>), grid, block, lds, st, a);
+  } else {
+    if (lds > 65536) (void)hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<T, TH, TW, 2>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<T, TH, TW, 2>), grid, block, lds, st, a);
+  }
+  return 0;
+}
+
+template <typename T>
+static int launch_conv_t(const ConvArgs& a, hipStream_t st) {
+  TileCfg t = pick_tile(a.H, a.W);
+  if (t.th == 14) return launch_conv<T, 14, 14>(a, st);
+  return launch_conv<T, 16, 16>(a, st);
+}
+
+}  // namespace spcl
+
+using namespace spcl;
+
+extern "C" int spcl_conv_num_tiles(int N, int H, int W) {
+  TileCfg t = pick_tile(H, W);
+  return N * cdiv(H, t.th) * cdiv(W, t.tw);
+}
+
+extern "C" size_t spcl_conv_packed_elems(int Cin, int Cout, int kind, int dtype) {
+  const int KinK = round_up(kind == 0 ? Cin : Cout, 16), NoutS = round_up(kind == 0 ? Cout : Cin, 16);
+  return dtype == SPCL_F32 ? packed_elems<float>(KinK, NoutS) : packed_elems<bf16_t>(KinK, NoutS);
+}
+
+extern "C" int spcl_conv_pack_weights(const float* w_oihw, int Cin, int Cout, int kind, int dtype, void* packed,
+                                      void* stream) {
+  SPCL_CHECK_ARG(w_oihw && packed, "conv_pack_weights: null pointer");
+  SPCL_CHECK_ARG(Cin > 0 && Cout > 0 && (kind == 0 || kind == 1), "conv_pack_weights: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  const int KinK = round_up(kind == 0 ? Cin : Cout, 16), NoutS = round_up(kind == 0 ? Cout : Cin, 16);
+  if (dtype == SPCL_F32) {
+    size_t total = packed_elems<float>(KinK, NoutS);
+    hipLaunchKernelGGL(conv_pack_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w_oihw, Cin,
+                       Cout, kind, KinK, NoutS, (float*)packed, total);
+  } else if (dtype == SPCL_BF16) {
+    size_t total = packed_elems<bf16_t>(KinK, NoutS);
+    hipLaunchKernelGGL(conv_pack_kernel<bf16_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w_oihw, Cin,
+                       Cout, kind, KinK, NoutS, (bf16_t*)packed, total);
+  } else {
+    set_error("conv_pack_weights: dtype %d", dtype);
+    return SPCL_EINVAL;
+  }
+  SPCL_LAUNCH_CHECK("conv_pack_weights");
+  return SPCL_OK;
+}
+
+extern "C" int spcl_conv3x3_forward(const void* x, int dtype, int N, int H, int W, int CinS, int CinK, int CoutS,
+                                    const void* w_packed, int in_mode, const float* in_scale, const float* in_shift,
+                                    void* y, float* stats, void* stream) {
+  SPCL_CHECK_ARG(x && y && w_packed, "conv3x3_forward: null pointer");
+  SPCL_CHECK_ARG(N > 0 && H > 0 && W > 0, "conv3x3_forward: bad shape");
+  SPCL_CHECK_ARG(CinK % 16 == 0 && CoutS % 16 == 0 && CinK > 0 && CoutS > 0, "conv3x3_forward: CinK=%d CoutS=%d must "
+                 "be multiples of 16", CinK, CoutS);
+  SPCL_CHECK_ARG(in_mode >= 0 && in_mode <= 2, "conv3x3_forward: in_mode %d", in_mode);
+  SPCL_CHECK_ARG(in_mode != 1 || (in_scale && in_shift), "conv3x3_forward: in_mode 1 needs scale/shift");
+  if (in_mode == 2) SPCL_CHECK_ARG(CinK == 16 && CinS >= 1 && CinS <= 16, "conv3x3_forward: image mode needs Cin<=16");
+  else SPCL_CHECK_ARG(CinS == CinK, "conv3x3_forward: CinS (%d) must equal CinK (%d)", CinS, CinK);
+  SPCL_CHECK_ARG(CinK <= 64 || CinK % 64 == 0, "conv3x3_forward: CinK=%d must be <=64 or a multiple of 64", CinK);
+  ConvArgs a;
+  a.x = x; a.y = y; a.wp = w_packed; a.stats = stats; a.in_scale = in_scale; a.in_shift = in_shift;
+  a.N = N; a.H = H; a.W = W; a.CinS = CinS; a.CinK = CinK; a.CoutS = CoutS; a.in_mode = in_mode;
+  a.tilesX = a.tilesY = 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SPCL_F32) launch_conv_t<float>(a, st);
+  else if (dtype == SPCL_BF16) launch_conv_t<bf16_t>(a, st);
+  else {
+    set_error("conv3x3_forward: dtype %d", dtype);
+    return SPCL_EINVAL;
+  }
+  SPCL_LAUNCH_CHECK("conv3x3_forward");
+  return SPCL_OK;
+}

@@ -1,0 +1,317 @@
+// Weight gradient of the 3x3 same-convolution (semi_seg/arch/unet.py:72,75, autograd backward) on gfx950 MFMA.
+//   dW[tap][ci][co] = sum_pixels act(x)[p + tap][ci] * dy[p][co]
+// GEMM per tap: D[m=ci][n=co] += A[m][k=pixel] * B[k=pixel][n]; both operands are pixel-major NHWC tiles in LDS, so
+// the MFMA operands (K = pixels) are read TRANSPOSED: bf16 uses ds_read_b64_tr_b16 (hardware transpose, 4 pixels x
+// 16 channels per 16-lane group), f32 reads one dword per lane.  The 9 taps are address offsets into the shared
+// input halo tile.  Work split: workgroup = (pixel split, 32x32 / 16x16 channel block); its 4 waves take different
+// pixel k-steps of every tile and are reduced through LDS at the end; workgroup partials go to a workspace and a
+// second kernel sums them in fixed order (deterministic, no float atomics) into the OIHW f32 gradient.
+#include "common.hpp"
+
+namespace spcl {
+
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+template <typename T> struct Chunk;
+template <> struct Chunk<float> { static constexpr int EPC = 4; };
+template <> struct Chunk<bf16_t> { static constexpr int EPC = 8; };
+
+constexpr int WG_TH = 16, WG_TW = 16, WG_HW = WG_TW + 2, WG_NHALO = (WG_TH + 2) * WG_HW, WG_NPIX = WG_TH * WG_TW;
+
+struct WgradArgs {
+  const void* x;
+  const void* dy;
+  const float* in_scale;
+  const float* in_shift;
+  float* partial;
+  int N, H, W, CinS, CinK, CoutS, in_mode;
+  int tilesX, tilesY, ntiles, nblk_ci, nblk_co;
+};
+
+// relu(scale*v+shift) on one 16-byte chunk (same arithmetic as conv.hip's staging so masks agree bit-for-bit)
+template <typename T> __device__ __forceinline__ u32x4 wg_bnrelu_chunk(u32x4 raw, const float* sc, const float* sh);
+template <> __device__ __forceinline__ u32x4 wg_bnrelu_chunk<float>(u32x4 raw, const float* sc, const float* sh) {
+  f32x4 v = __builtin_bit_cast(f32x4, raw);
+  f32x4 s = *(const f32x4*)sc, b = *(const f32x4*)sh;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(s[e], v[e], b[e]), 0.f);
+  return __builtin_bit_cast(u32x4, v);
+}
+template <> __device__ __forceinline__ u32x4 wg_bnrelu_chunk<bf16_t>(u32x4 raw, const float* sc, const float* sh) {
+  float s[8], b[8];
+  *(f32x4*)&s[0] = *(const f32x4*)sc;
+  *(f32x4*)&s[4] = *(const f32x4*)(sc + 4);
+  *(f32x4*)&b[0] = *(const f32x4*)sh;
+  *(f32x4*)&b[4] = *(const f32x4*)(sh + 4);
+  u32x4 out;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float lo = __uint_as_float(raw[e] << 16), hi = __uint_as_float(raw[e] & 0xffff0000u);
+    lo = fmaxf(fmaf(s[2 * e], lo, b[2 * e]), 0.f);
+    hi = fmaxf(fmaf(s[2 * e + 1], hi, b[2 * e + 1]), 0.f);
+    out[e] = (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  }
+  return out;
+}
+
+// Operand fragment of one k-step for a 16-channel tile, read transposed from a [pixel][channel] LDS image.
+//   bf16: k-step = 32 pixels; lane (g = lane>>4) gets pixels 8g..8g+7 of its channel (lane&15)
+//   f32 : k-step = 4 pixels;  lane gets pixel g of its channel
+// `lane_pixel(ks, lane)` = tile pixel whose address this lane supplies; the caller turns it into a byte address
+// once per k-step, every tap / channel tile is then a compile-time offset folded into the DS instruction.
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> {
+  typedef bf16x8 type;
+  static constexpr int KPIX = 32;
+  static constexpr int SECOND = 4;  // second read: 4 pixels further
+  static __device__ __forceinline__ int lane_pixel(int ks, int lane) {
+    return ks * 32 + 8 * (lane >> 4) + ((lane & 15) >> 2);
+  }
+  static __device__ __forceinline__ int lane_chan_bytes(int lane) { return (lane & 3) * 8; }
+  // a0: address of (lane pixel, lane channel group); pix_bytes: LDS bytes per pixel
+  static __device__ __forceinline__ type load(unsigned a0, int off, int pix_bytes) {
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(uintptr_t)(a0 + off));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (s16x4 __attribute__((address_space(3)))*)(uintptr_t)(a0 + off + 4 * pix_bytes));
+    type r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+  }
+  static __device__ __forceinline__ f32x4 mfma(type a, type b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Frag<float> {
+  typedef float type;
+  static constexpr int KPIX = 4;
+  static __device__ __forceinline__ int lane_pixel(int ks, int lane) { return ks * 4 + (lane >> 4); }
+  static __device__ __forceinline__ int lane_chan_bytes(int lane) { return (lane & 15) * 4; }
+  static __device__ __forceinline__ type load(unsigned a0, int off, int pix_bytes) {
+    return *(const float __attribute__((address_space(3)))*)(uintptr_t)(a0 + off);
+  }
+  static __device__ __forceinline__ f32x4 mfma(type a, type b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+};
+
+template <typename T, int MI, int NJ>
+__global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(WgradArgs a) {
+  constexpr int EPC = Chunk<T>::EPC;
+  constexpr int CIB = 16 * MI, COB = 16 * NJ;
+  constexpr int XS = CIB * (int)sizeof(T), DS = COB * (int)sizeof(T);  // LDS bytes per pixel
+  constexpr int XCP = CIB / EPC, DCP = COB / EPC;                       // 16-byte chunks per pixel
+  constexpr int X_BYTES = WG_NHALO * XS;
+  constexpr int KSTEPS = WG_NPIX / Frag<T>::KPIX;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char* ldx = lds;
+  unsigned char* ldd = lds + X_BYTES;
+  const unsigned ldx_base = (unsigned)(uintptr_t)(unsigned char __attribute__((address_space(3)))*)ldx;
+  const unsigned ldd_base = (unsigned)(uintptr_t)(unsigned char __attribute__((address_space(3)))*)ldd;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int blk = blockIdx.y;
+  const int bci = blk / a.nblk_co, bco = blk - bci * a.nblk_co;
+  const int ci0 = bci * CIB, co0 = bco * COB;
+
+  f32x4 acc[9][MI][NJ];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int m = 0; m < MI; ++m)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[t][m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int tpi = a.tilesX * a.tilesY;
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const int n = tile / tpi;
+    const int trem = tile - n * tpi;
+    const int ty = trem / a.tilesX, tx = trem - ty * a.tilesX;
+    const int y0 = ty * WG_TH, x0 = tx * WG_TW;
+    __syncthreads();
+    // ---- stage x halo [18*18][CIB] (with the producer's BN-apply+ReLU fused) and dy [256][COB]; OOB -> 0
+    for (int idx = threadIdx.x; idx < WG_NHALO * XCP; idx += 256) {
+      const int q = idx / XCP, ch = idx - q * XCP;
+      const int hy = q / WG_HW, hx = q - hy * WG_HW;
+      const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+        const size_t pix = ((size_t)n * a.H + gy) * a.W + gx;
+        if (a.in_mode == 2) {
+          const float* src = (const float*)a.x + pix * a.CinS;
+          float e[EPC];
+#pragma unroll
+          for (int k = 0; k < EPC; ++k) {
+            const int c = ch * EPC + k;
+            e[k] = c < a.CinS ? src[c] : 0.f;
+          }
+          if (sizeof(T) == 4) {
+            v = (u32x4){__float_as_uint(e[0]), __float_as_uint(e[1]), __float_as_uint(e[2]), __float_as_uint(e[3])};
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              v[k] = (uint32_t)f32_to_bf16(e[(2 * k) % EPC]) | ((uint32_t)f32_to_bf16(e[(2 * k + 1) % EPC]) << 16);
+          }
+        } else {
+          const int c0 = ci0 + ch * EPC;
+          v = *(const u32x4*)((const T*)a.x + pix * a.CinS + c0);
+          if (a.in_mode == 1) v = wg_bnrelu_chunk<T>(v, a.in_scale + c0, a.in_shift + c0);
+        }
+      }
+      *(u32x4*)(ldx + q * XS + ch * 16) = v;
+    }
+    for (int idx = threadIdx.x; idx < WG_NPIX * DCP; idx += 256) {
+      const int p = idx / DCP, ch = idx - p * DCP;
+      const int gy = y0 + (p >> 4), gx = x0 + (p & 15);
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (gy < a.H && gx < a.W) {
+        const size_t pix = ((size_t)n * a.H + gy) * a.W + gx;
+        v = *(const u32x4*)((const T*)a.dy + pix * a.CoutS + co0 + ch * EPC);
+      }
+      *(u32x4*)(ldd + p * DS + ch * 16) = v;
+    }
+    __syncthreads();
+
+    // ---- each wave takes k-steps ks = wave, wave+4, ...
+#pragma unroll 1
+    for (int ks = wave; ks < KSTEPS; ks += 4) {
+      const int p = Frag<T>::lane_pixel(ks, lane);  // a k-step's pixels never straddle a tile row (TW = 16)
+      const unsigned xa = ldx_base + (unsigned)(((p >> 4) * WG_HW + (p & 15)) * XS + Frag<T>::lane_chan_bytes(lane));
+      const unsigned da = ldd_base + (unsigned)(p * DS + Frag<T>::lane_chan_bytes(lane));
+      typename Frag<T>::type bf[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bf[j] = Frag<T>::load(da, j * 16 * (int)sizeof(T), DS);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int ky = t / 3, kx = t - 3 * ky;
+#pragma unroll
+        for (int m = 0; m < MI; ++m) {
+          typename Frag<T>::type af = Frag<T>::load(xa, (ky * WG_HW + kx) * XS + m * 16 * (int)sizeof(T), XS);
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[t][m][j] = Frag<T>::mfma(af, bf[j], acc[t][m][j]);
+        }
+      }
+    }
+  }
+
+  // ---- reduce the 4 waves through LDS (wave 0 stores, 1..2 add, 3 adds and writes the workgroup partial)
+  // D layout: lane holds n = co (lane&15), m = ci 4g+r.  slab layout [9][CIB][COB] f32
+  float* red = (float*)lds;
+  const int r16 = lane & 15, g = lane >> 4;
+  float* out = a.partial + ((size_t)blockIdx.x * gridDim.y + blk) * (9 * CIB * COB);
+#pragma unroll 1
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int m = 0; m < MI; ++m)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int off = (t * CIB + m * 16 + 4 * g + r) * COB + j * 16 + r16;
+              float v = acc[t][m][j][r];
+              if (w > 0) v += red[off];
+              if (w < 3) red[off] = v;
+              else out[off] = v;
+            }
+    }
+  }
+}
+
+// dW_oihw[co][ci][tap] = sum over pixel-split partials (fixed order)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, int nblk_ci,
+                                                           int nblk_co, int CIB, int COB, int Cin, int Cout,
+                                                           float* __restrict__ dw) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Cout * Cin * 9) return;
+  const int tap = idx % 9, ci = (idx / 9) % Cin, co = idx / (9 * Cin);
+  const int bci = ci / CIB, bco = co / COB;
+  const size_t slab = (size_t)9 * CIB * COB;
+  const size_t inner = ((size_t)tap * CIB + (ci - bci * CIB)) * COB + (co - bco * COB);
+  const size_t blk = (size_t)bci * nblk_co + bco;
+  const size_t nblk = (size_t)nblk_ci * nblk_co;
+  float s = 0.f;
+  for (int p = 0; p < nsplit; ++p) s += partial[((size_t)p * nblk + blk) * slab + inner];
+  dw[idx] = s;
+}
+
+struct WgradPlan {
+  int MI, NJ, nblk_ci, nblk_co, nsplit, ntiles, tilesX, tilesY;
+  size_t partial_floats;
+};
+static WgradPlan wgrad_plan(int N, int H, int W, int CinK, int CoutS) {
+  WgradPlan p;
+  p.NJ = CoutS >= 32 ? 2 : 1;
+  p.MI = (p.NJ == 1 && CinK >= 32) ? 2 : 1;  // <2,2> (144 accumulator regs + fragments) spills: not built
+  p.nblk_ci = CinK / (16 * p.MI);
+  p.nblk_co = CoutS / (16 * p.NJ);
+  p.tilesX = cdiv(W, WG_TW);
+  p.tilesY = cdiv(H, WG_TH);
+  p.ntiles = N * p.tilesX * p.tilesY;
+  const int nblk = p.nblk_ci * p.nblk_co;
+  int ns = cdiv(1024, nblk);
+  if (ns > p.ntiles) ns = p.ntiles;
+  if (ns < 1) ns = 1;
+  p.nsplit = ns;
+  p.partial_floats = (size_t)ns * nblk * 9 * (16 * p.MI) * (16 * p.NJ);
+  return p;
+}
+
+template <typename T, int MI, int NJ>
+static void launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t st) {
+  constexpr int CIB = 16 * MI, COB = 16 * NJ;
+  size_t lds = (size_t)WG_NHALO * CIB * sizeof(T) + (size_t)WG_NPIX * COB * sizeof(T);
+  const size_t red = (size_t)9 * CIB * COB * sizeof(float);
+  if (red > lds) lds = red;
+  if (lds > 65536)
+    (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_kernel<T, MI, NJ>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+  hipLaunchKernelGGL((conv3x3_wgrad_kernel<T, MI, NJ>), dim3(p.nsplit, p.nblk_ci * p.nblk_co), dim3(256), lds, st, a);
+}
+
+template <typename T>
+static void launch_wgrad_t(const WgradArgs& a, const WgradPlan& p, hipStream_t st) {
+  if (p.MI == 1 && p.NJ == 1) launch_wgrad<T, 1, 1>(a, p, st);
+  else if (p.MI == 1 && p.NJ == 2) launch_wgrad<T, 1, 2>(a, p, st);
+  else launch_wgrad<T, 2, 1>(a, p, st);
+}
+
+}  // namespace spcl
+
+using namespace spcl;
+
+extern "C" size_t spcl_conv_wgrad_workspace_bytes(int N, int H, int W, int CinK, int CoutS) {
+  if (N <= 0 || H <= 0 || W <= 0 || CinK <= 0 || CoutS <= 0 || CinK % 16 || CoutS % 16) return 0;
+  return wgrad_plan(N, H, W, CinK, CoutS).partial_floats * sizeof(float);
+}
+
+extern "C" int spcl_conv3x3_wgrad(const void* x, const void* dy, int dtype, int N, int H, int W, int Cin, int CinS,
+                                  int CinK, int Cout, int CoutS, int in_mode, const float* in_scale,
+                                  const float* in_shift, float* partial, float* dw_oihw, void* stream) {
+  SPCL_CHECK_ARG(x && dy && partial && dw_oihw, "conv3x3_wgrad: null pointer");
+  SPCL_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3_wgrad: bad shape");
+  SPCL_CHECK_ARG(CinK % 16 == 0 && CoutS % 16 == 0 && Cin <= CinK && Cout <= CoutS, "conv3x3_wgrad: channel padding");
+  SPCL_CHECK_ARG(in_mode >= 0 && in_mode <= 2, "conv3x3_wgrad: in_mode %d", in_mode);
+  SPCL_CHECK_ARG(in_mode != 1 || (in_scale && in_shift), "conv3x3_wgrad: in_mode 1 needs scale/shift");
+  if (in_mode == 2) SPCL_CHECK_ARG(CinK == 16 && CinS >= 1 && CinS <= 16, "conv3x3_wgrad: image mode needs Cin<=16");
+  else SPCL_CHECK_ARG(CinS == CinK, "conv3x3_wgrad: CinS must equal CinK");
+  hipStream_t st = (hipStream_t)stream;
+  WgradPlan p = wgrad_plan(N, H, W, CinK, CoutS);
+  WgradArgs a;
+  a.x = x; a.dy = dy; a.in_scale = in_scale; a.in_shift = in_shift; a.partial = partial;
+  a.N = N; a.H = H; a.W = W; a.CinS = CinS; a.CinK = CinK; a.CoutS = CoutS; a.in_mode = in_mode;
+  a.tilesX = p.tilesX; a.tilesY = p.tilesY; a.ntiles = p.ntiles; a.nblk_ci = p.nblk_ci; a.nblk_co = p.nblk_co;
+  if (dtype == SPCL_F32) launch_wgrad_t<float>(a, p, st);
+  else if (dtype == SPCL_BF16) launch_wgrad_t<bf16_t>(a, p, st);
+  else {
+    set_error("conv3x3_wgrad: dtype %d", dtype);
+    return SPCL_EINVAL;
+  }
+  const int total = Cout * Cin * 9;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, (const float*)partial, p.nsplit,
+                     p.nblk_ci, p.nblk_co, 16 * p.MI, 16 * p.NJ, Cin, Cout, dw_oihw);
+  SPCL_LAUNCH_CHECK("conv3x3_wgrad");
+  return SPCL_OK;
+}

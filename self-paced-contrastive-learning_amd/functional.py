@@ -149,3 +149,175 @@ class _ProjectorFn(torch.autograd.Function):
 
 def projector(feat, w1, b1, w2=None, b2=None, normalize=True):
     return _ProjectorFn.apply(feat, w1, b1, w2, b2, normalize)
+
+
+# --------------------------------------------------------------------------------------------- encoder blocks
+def _ru16(c: int) -> int:
+    return (c + 15) // 16 * 16
+
+
+def to_nhwc_padded(x: torch.Tensor, dtype: torch.dtype):
+    """logical NCHW -> contiguous [N,H,W,CS] storage of `dtype`, CS = C rounded up to 16 (pad channels = 0).
+    Zero-copy when x already is such a view (what the fused blocks hand to each other)."""
+    N, C, H, W = x.shape
+    cs = _ru16(C)
+    if x.dtype == dtype:
+        sN, sC, sH, sW = x.stride()
+        if sC == 1 and sW == cs and sH == W * cs and sN == H * W * cs:
+            if cs == C:
+                return x.permute(0, 2, 3, 1)
+            return torch.as_strided(x, (N, H, W, cs), (sN, sH, sW, 1))
+    if cs == C:
+        return x.to(dtype).contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
+    out = torch.zeros(N, H, W, cs, dtype=dtype, device=x.device)
+    out[..., :C] = x.permute(0, 2, 3, 1)
+    return out
+
+
+class BlockCfg:
+    """Static configuration of one fused Conv-BN-ReLU(-Conv-BN-ReLU)(-MaxPool) block call."""
+    __slots__ = ("dtype", "training", "momentum", "eps", "track", "need_act", "need_pool", "image_input", "buffers")
+
+    def __init__(self, dtype, training, momentum, eps, track, need_act, need_pool, image_input, buffers):
+        self.dtype, self.training, self.momentum, self.eps, self.track = dtype, training, momentum, eps, track
+        self.need_act, self.need_pool, self.image_input, self.buffers = need_act, need_pool, image_input, buffers
+
+
+def _pack(w, kind, dt_code, dtype):
+    co, ci = w.shape[0], w.shape[1]
+    n = _n.call("spcl_conv_packed_elems", ci, co, kind, dt_code)
+    buf = torch.empty(n, dtype=dtype, device=w.device)
+    wc = w.detach().contiguous().float()
+    _n.call("spcl_conv_pack_weights", _n.ptr(wc), ci, co, kind, dt_code, _n.ptr(buf), _n.stream())
+    return buf
+
+
+def _conv(x_store, dt_code, dtype, N, H, W, cin_s, cin_k, cout_s, wp, in_mode, scale, shift, want_stats):
+    dev = x_store.device
+    y = torch.empty(N, H, W, cout_s, dtype=dtype, device=dev)
+    stats = None
+    if want_stats:
+        nt = _n.call("spcl_conv_num_tiles", N, H, W)
+        stats = torch.empty(nt, cout_s, 3, dtype=torch.float32, device=dev)
+    _n.call("spcl_conv3x3_forward", _n.ptr(x_store), dt_code, N, H, W, cin_s, cin_k, cout_s, _n.ptr(wp), in_mode,
+            _n.ptr(scale), _n.ptr(shift), _n.ptr(y), _n.ptr(stats), _n.stream())
+    return y, stats
+
+
+def _bn_stats(stats, cfg: BlockCfg, C, cs, gamma, beta, which, dev):
+    """-> tensor [4, cs]: mean, invstd, scale, shift."""
+    st = torch.empty(4, cs, dtype=torch.float32, device=dev)
+    g, b = gamma.detach().contiguous().float(), beta.detach().contiguous().float()
+    rm, rv, nbt = cfg.buffers[which]
+    if cfg.training:
+        upd = cfg.track[which]
+        _n.call("spcl_bn_finalize", _n.ptr(stats), stats.shape[0], C, cs, _n.ptr(g), _n.ptr(b), c_float(cfg.momentum),
+                c_float(cfg.eps), _n.ptr(rm if upd else None), _n.ptr(rv if upd else None),
+                _n.ptr(nbt if upd else None), _n.ptr(st[0]), _n.ptr(st[1]), _n.ptr(st[2]), _n.ptr(st[3]), _n.stream())
+    else:
+        _n.call("spcl_bn_eval_affine", C, cs, _n.ptr(g), _n.ptr(b), _n.ptr(rm), _n.ptr(rv), c_float(cfg.eps),
+                _n.ptr(st[0]), _n.ptr(st[1]), _n.ptr(st[2]), _n.ptr(st[3]), _n.stream())
+    return st
+
+
+def _wgrad(x_store, dy, dt_code, N, H, W, cin, cin_s, cin_k, cout, cout_s, in_mode, scale, shift):
+    dev = dy.device
+    nbytes = _n.call("spcl_conv_wgrad_workspace_bytes", N, H, W, cin_k, cout_s)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    dw = torch.empty(cout, cin, 3, 3, dtype=torch.float32, device=dev)
+    _n.call("spcl_conv3x3_wgrad", _n.ptr(x_store), _n.ptr(dy), dt_code, N, H, W, cin, cin_s, cin_k, cout, cout_s,
+            in_mode, _n.ptr(scale), _n.ptr(shift), _n.ptr(ws), _n.ptr(dw), _n.stream())
+    return dw
+
+
+def _bnrelu_bwd(y, dact, dpool, dt_code, dtype, N, H, W, C, cs, st, training):
+    dev = y.device
+    ws = torch.empty(_n.call("spcl_bnrelu_bwd_workspace_bytes", N, H, W, cs) // 4, dtype=torch.float32, device=dev)
+    dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+    dy = torch.empty(N, H, W, cs, dtype=dtype, device=dev)
+    _n.call("spcl_bnrelu_pool_backward", _n.ptr(y), _n.ptr(dact), _n.ptr(dpool), dt_code, N, H, W, C, cs,
+            _n.ptr(st[0]), _n.ptr(st[1]), _n.ptr(st[2]), _n.ptr(st[3]), int(training), _n.ptr(ws), _n.ptr(dgamma),
+            _n.ptr(dbeta), _n.ptr(dy), _n.stream())
+    return dy, dgamma, dbeta
+
+
+class _ConvBlockFn(torch.autograd.Function):
+    """[conv3x3 -> BN -> ReLU] x2 (+ 2x2 max-pool), semi_seg/arch/unet.py:67-82 + :118-121, as HIP kernels.
+
+    Only the raw conv outputs are kept for backward; BN-apply+ReLU of the first conv is fused into the second conv's
+    loader, the second's into the (optional) activation / pooled writers."""
+
+    @staticmethod
+    def forward(ctx, x, wa, ga, ba, wb, gb, bb, cfg: BlockCfg):
+        _n.require_gpu(x, wa, wb)
+        dtype, dev = cfg.dtype, x.device
+        dtc = _n.dtype_code(dtype)
+        N, cin, H, W = x.shape
+        cout = wa.shape[0]
+        cout_s = _ru16(cout)
+        if cfg.image_input:
+            if cin > 16:
+                raise NotImplementedError("image-input block supports input_dim <= 16")
+            xs = x.detach().float().permute(0, 2, 3, 1).contiguous()  # [N,H,W,cin] f32 (a view when cin == 1)
+            cin_s, cin_k, mode_a = cin, 16, 2
+        else:
+            xs = to_nhwc_padded(x.detach(), dtype)
+            cin_s = cin_k = xs.shape[3]
+            mode_a = 0
+        wpa = _pack(wa, 0, dtc, dtype)
+        ya, sa = _conv(xs, dtc, dtype, N, H, W, cin_s, cin_k, cout_s, wpa, mode_a, None, None, cfg.training)
+        sta = _bn_stats(sa, cfg, cout, cout_s, ga, ba, 0, dev)
+        wpb = _pack(wb, 0, dtc, dtype)
+        yb, sb = _conv(ya, dtc, dtype, N, H, W, cout_s, cout_s, cout_s, wpb, 1, sta[2], sta[3], cfg.training)
+        stb = _bn_stats(sb, cfg, cout, cout_s, gb, bb, 1, dev)
+        act = torch.empty(N, H, W, cout_s, dtype=dtype, device=dev) if cfg.need_act else None
+        pool = torch.empty(N, H // 2, W // 2, cout_s, dtype=dtype, device=dev) if cfg.need_pool else None
+        _n.call("spcl_bnrelu_pool_forward", _n.ptr(yb), dtc, N, H, W, cout_s, _n.ptr(stb[2]), _n.ptr(stb[3]),
+                _n.ptr(act), _n.ptr(pool), _n.stream())
+        ctx.save_for_backward(xs, ya, yb, sta, stb, wa, wb)
+        ctx.cfg = cfg
+        ctx.meta = (N, cin, H, W, cout, cout_s, cin_s, cin_k, mode_a, x.dtype)
+        outs = []
+        outs.append(nhwc_to_logical(act, cout) if act is not None else None)
+        outs.append(nhwc_to_logical(pool, cout) if pool is not None else None)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, d_act, d_pool):
+        xs, ya, yb, sta, stb, wa, wb = ctx.saved_tensors
+        cfg = ctx.cfg
+        N, cin, H, W, cout, cout_s, cin_s, cin_k, mode_a, xdt = ctx.meta
+        dtype = cfg.dtype
+        dtc = _n.dtype_code(dtype)
+        da_s = to_nhwc_padded(d_act, dtype) if d_act is not None else None
+        dp_s = to_nhwc_padded(d_pool, dtype) if d_pool is not None else None
+        if da_s is None and dp_s is None:
+            return (None,) * 8
+        # ---- second conv
+        dyb, dgb, dbb = _bnrelu_bwd(yb, da_s, dp_s, dtc, dtype, N, H, W, cout, cout_s, stb, cfg.training)
+        dwb = _wgrad(ya, dyb, dtc, N, H, W, cout, cout_s, cout_s, cout, cout_s, 1, sta[2], sta[3]) \
+            if ctx.needs_input_grad[4] else None
+        wpb_t = _pack(wb, 1, dtc, dtype)
+        daa, _ = _conv(dyb, dtc, dtype, N, H, W, cout_s, cout_s, cout_s, wpb_t, 0, None, None, False)
+        # ---- first conv
+        dya, dga, dba = _bnrelu_bwd(ya, daa, None, dtc, dtype, N, H, W, cout, cout_s, sta, cfg.training)
+        dwa = _wgrad(xs, dya, dtc, N, H, W, cin, cin_s, cin_k, cout, cout_s, mode_a, None, None) \
+            if ctx.needs_input_grad[1] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if cfg.image_input:
+                raise NotImplementedError("gradient w.r.t. the input image is not on the hot path")
+            wpa_t = _pack(wa, 1, dtc, dtype)
+            dxs, _ = _conv(dya, dtc, dtype, N, H, W, cout_s, cout_s, cin_s, wpa_t, 0, None, None, False)
+            dx = nhwc_to_logical(dxs, cin)
+            if dx.dtype != xdt:
+                dx = dx.to(xdt)
+        ng = ctx.needs_input_grad
+        return (dx, dwa, dga if ng[2] else None, dba if ng[3] else None, dwb, dgb if ng[5] else None,
+                dbb if ng[6] else None, None)
+
+
+def conv_block(x, wa, ga, ba, wb, gb, bb, cfg: BlockCfg):
+    """-> (act or None, pooled or None), logical NCHW views over NHWC storage."""
+    return _ConvBlockFn.apply(x, wa, ga, ba, wb, gb, bb, cfg)

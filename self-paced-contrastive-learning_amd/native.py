@@ -33,20 +33,17 @@ _SIGNATURES = {
     "spcl_conv_packed_elems": (c_size_t, [c_int, c_int, c_int, c_int]),
     "spcl_conv_pack_weights": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
     "spcl_conv_num_tiles": (c_int, [c_int, c_int, c_int]),
-    "spcl_conv3x3_forward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P, _P]),
-    "spcl_conv3x3_first_forward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P]),
-    "spcl_conv3x3_first_wgrad": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P]),
+    "spcl_conv3x3_forward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P,
+                                     _P]),
     "spcl_conv_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
-    "spcl_conv3x3_wgrad": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P,
-                                   _P, _P, _P]),
-    "spcl_bn_finalize": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P]),
-    "spcl_bn_eval_affine": (c_int, [c_int, c_int, _P, _P, _P, _P, c_float, _P, _P, _P]),
+    "spcl_conv3x3_wgrad": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P,
+                                   _P, _P, _P, _P]),
+    "spcl_bn_finalize": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "spcl_bn_eval_affine": (c_int, [c_int, c_int, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P]),
     "spcl_bnrelu_pool_forward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "spcl_bnrelu_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
-    "spcl_bnrelu_pool_backward": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P,
-                                          _P, _P, _P, _P, _P]),
-    "spcl_nchw_to_nhwc": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
-    "spcl_nhwc_to_nchw": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "spcl_bnrelu_pool_backward": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P,
+                                          c_int, _P, _P, _P, _P, _P]),
 }
 
 

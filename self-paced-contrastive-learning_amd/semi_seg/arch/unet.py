@@ -1,0 +1,228 @@
+"""HIP-backed mirror of ``semi_seg/arch/unet.py``: same class surface (``UNet(input_dim, num_classes, max_channel,
+momentum)``, ``forward(x, until)``, name tables, ``get_channel_dim``, ``set_grad``/``set_bn_track``), same submodule
+names (``_Conv1.._Conv5, _Up5, _Up_conv5, ... _Deconv_1x1``) firing forward hooks, same ``state_dict`` keys
+(``_ConvK.conv.{0,3}.weight``, ``_ConvK.conv.{1,4}.*``, ``_UpK.up.{1,2}.*``, ``_Deconv_1x1.*``).
+
+The encoder blocks run as fused gfx950 kernels (functional.conv_block): NHWC storage, implicit-GEMM MFMA convolutions,
+BatchNorm statistics in the conv epilogue, BN-apply + ReLU (+ 2x2 max-pool) fused into the neighbouring kernels.  The
+tensors handed out (block outputs, ``until`` results, hook taps) are ordinary logical-NCHW tensors with channels-last
+strides.  The decoder half (reference ``unet.py:193-230``, SURVEY row N1, not on the pre-train hot path) keeps the
+parameters/keys and is not built as HIP kernels yet: running it raises NotImplementedError.
+"""
+from collections import OrderedDict
+from contextlib import contextmanager
+from functools import lru_cache, partial
+from typing import List
+
+import torch
+from torch import nn
+
+from ... import config as _config
+from ... import functional as F_hip
+
+__all__ = ["UNet", "arch_order", "get_channel_dim", "sort_arch"]
+
+_ENCODER = ("Conv1", "Conv2", "Conv3", "Conv4", "Conv5")
+_DECODER = ("Up5", "Up_conv5", "Up4", "Up_conv4", "Up3", "Up_conv3", "Up2", "Up_conv2", "Deconv_1x1")
+
+
+def arch_order(name: str) -> int:
+    return UNet.arch_elements.index(name)
+
+
+def sort_arch(name_list: List[str], reverse=False) -> List[str]:
+    return sorted(name_list, key=arch_order, reverse=reverse)
+
+
+def _span(start, end, include_start, include_end):
+    """names between start and end in architecture order (unet.py:34-64), with the reference's argument checks."""
+    if start is None and include_start is False:
+        raise ValueError("include_start should be True given start=None")
+    if end is None and include_end is False:
+        raise ValueError("include_end should be True given end=None")
+    for v in (start, end):
+        if isinstance(v, str) and v not in UNet.layer_dimension:
+            raise ValueError(v)
+    start, end = start or "Conv1", end or "Deconv_1x1"
+    i0, i1 = arch_order(start), arch_order(end)
+    if i0 > i1:
+        raise ValueError((start, end))
+    lo = i0 if include_start else i0 + 1
+    hi = i1 + 1 if include_end else i1
+    return [UNet.arch_elements[i] for i in range(lo, hi)]
+
+
+class _ConvBlock(nn.Module):
+    """Conv3x3(no bias) -> BatchNorm2d -> ReLU, twice (unet.py:67-82).  ``self.conv`` holds the parameters under the
+    reference's Sequential indices; ``forward`` runs the fused HIP block, not the Sequential."""
+
+    def __init__(self, in_ch, out_ch, momentum: float = 0.1, image_input: bool = False):
+        super().__init__()
+        self.conv = nn.Sequential(
+            nn.Conv2d(in_ch, out_ch, kernel_size=(3, 3), stride=(1, 1), padding=(1, 1), bias=False),
+            nn.BatchNorm2d(out_ch, momentum=momentum),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(out_ch, out_ch, kernel_size=(3, 3), stride=(1, 1), padding=(1, 1), bias=False),
+            nn.BatchNorm2d(out_ch, momentum=momentum),
+            nn.ReLU(inplace=True),
+        )
+        self._image_input = image_input
+        self._compute_dtype = None  # None -> config default at call time
+        self._plan = None           # (need_act, need_pool) set by UNet.forward for one call
+        self._pooled = None
+
+    def _cfg(self, need_act, need_pool):
+        bn_a, bn_b = self.conv[1], self.conv[4]
+        dtype = self._compute_dtype or _config.get_compute_dtype()
+
+        def use_batch_stats(bn):  # torch.nn.BatchNorm2d: batch statistics in train mode or without running stats
+            return self.training or not bn.track_running_stats
+
+        if use_batch_stats(bn_a) != use_batch_stats(bn_b):
+            raise NotImplementedError("the two BatchNorm layers of a block must be in the same mode")
+        track = tuple(self.training and bn.track_running_stats for bn in (bn_a, bn_b))
+        bufs = tuple((bn.running_mean, bn.running_var, bn.num_batches_tracked) for bn in (bn_a, bn_b))
+        assert bn_a.momentum is not None and bn_a.eps == bn_b.eps
+        return F_hip.BlockCfg(dtype, use_batch_stats(bn_a), float(bn_a.momentum), float(bn_a.eps), track, need_act,
+                              need_pool, self._image_input, bufs)
+
+    def forward(self, x):
+        need_act, need_pool = self._plan if self._plan is not None else (True, False)
+        self._plan = None
+        if len(self._forward_hooks) > 0:
+            need_act = True  # a forward hook (arch/hook.py feature tap) wants the block output
+        c = self.conv
+        act, pooled = F_hip.conv_block(x, c[0].weight, c[1].weight, c[1].bias, c[3].weight, c[4].weight, c[4].bias,
+                                       self._cfg(need_act, need_pool))
+        self._pooled = pooled
+        return act
+
+    def take_pooled(self):
+        p, self._pooled = self._pooled, None
+        return p
+
+
+class _UpConv(nn.Module):
+    """Upsample(x2, nearest) -> Conv3x3 -> BN -> ReLU (unet.py:85-97); decoder, parameters only for now."""
+
+    def __init__(self, in_ch, out_ch, momentum=0.1):
+        super().__init__()
+        self.up = nn.Sequential(
+            nn.Upsample(scale_factor=2),
+            nn.Conv2d(in_ch, out_ch, kernel_size=(3, 3), stride=(1, 1), padding=(1, 1), bias=False),
+            nn.BatchNorm2d(out_ch, momentum=momentum),
+            nn.ReLU(inplace=True),
+        )
+
+    def forward(self, x):
+        raise NotImplementedError("decoder path (_UpConv, unet.py:85-97) is SURVEY row N1: not built as HIP kernels "
+                                  "yet; the pre-train hot path stops at Conv5")
+
+
+class UNet(nn.Module):
+    layer_dimension = {"Conv1": 1, "Conv2": 2, "Conv3": 4, "Conv4": 8, "Conv5": 16, "Up_conv5": 8, "Up_conv4": 4,
+                       "Up_conv3": 2, "Up_conv2": 1, "Deconv_1x1": None}
+    encoder_names = _ENCODER
+    decoder_names = _DECODER
+    arch_elements = tuple(list(_ENCODER) + list(_DECODER))
+
+    def __init__(self, input_dim=3, num_classes=1, max_channel=256, momentum=0.1):
+        super().__init__()
+        self._input_dim = input_dim
+        self._num_classes = num_classes
+        assert max_channel % 16 == 0 and max_channel >= 128, max_channel
+        self._max_channel = max_channel
+        for i in range(1, 5):
+            setattr(self, f"_max_pool{i}", nn.MaxPool2d(kernel_size=2, stride=2))  # fused into the blocks
+        ch = self.get_channel_dim
+        prev = input_dim
+        for k, name in enumerate(_ENCODER):
+            setattr(self, "_" + name, _ConvBlock(prev, ch(name), momentum=momentum, image_input=(k == 0)))
+            prev = ch(name)
+        for lvl in (5, 4, 3, 2):
+            co = ch(f"Up_conv{lvl}")
+            setattr(self, f"_Up{lvl}", _UpConv(prev, co, momentum=momentum))
+            setattr(self, f"_Up_conv{lvl}", _ConvBlock(prev, co, momentum=momentum))
+            prev = co
+        self._Deconv_1x1 = nn.Conv2d(prev, num_classes, kernel_size=(1, 1), stride=(1, 1), padding=(0, 0))
+
+    # ------------------------------------------------------------------------------------------ forward
+    def forward(self, x, until: str = None):
+        if until:
+            if until not in self.layer_dimension:
+                raise KeyError(f"`return_until` should be in {', '.join(self.layer_dimension.keys())},"
+                               f" given {until}  ")
+        encoder_only = until in _ENCODER
+        e = x
+        for k, name in enumerate(_ENCODER):
+            blk = getattr(self, "_" + name)
+            is_last = (until == name) or k == len(_ENCODER) - 1
+            blk._plan = (is_last or not encoder_only, not is_last)
+            out = blk(e)
+            if until == name:
+                return out
+            e = blk.take_pooled()
+        raise NotImplementedError("decoder path (unet.py:193-230: Up5..Deconv_1x1) is SURVEY row N1 and is not built as "
+                                  "HIP kernels yet; call forward(x, until=<encoder layer>)")
+
+    def set_compute_dtype(self, dtype):
+        """torch.float32 (parity mode) or torch.bfloat16 for all fused blocks of this network."""
+        for m in self.modules():
+            if isinstance(m, _ConvBlock):
+                m._compute_dtype = dtype
+        return self
+
+    # ------------------------------------------------------------------------------------------ reference API
+    @lru_cache()
+    def get_channel_dim(self, name: str):
+        if name == "Deconv_1x1":
+            return self._num_classes
+        elif name in self.layer_dimension:
+            return int(self.layer_dimension[name] / 16 * self._max_channel)
+        else:
+            raise KeyError(name)
+
+    @contextmanager
+    def set_grad(self, enable=True, *, start: str = None, end: str = None, include_start=True, include_end=True):
+        comps = _span(start, end, include_start, include_end)
+        prev = OrderedDict()
+        for c in comps:
+            m = getattr(self, "_" + c)
+            states = {p.requires_grad for p in m.parameters()}
+            if len(states) != 1:
+                raise RuntimeError(f"mixed requires_grad state in {c}")
+            prev[c] = states.pop()
+            m.requires_grad_(enable)
+        yield self
+        for c in comps:
+            getattr(self, "_" + c).requires_grad_(prev[c])
+
+    @contextmanager
+    def set_bn_track(self, enable=True, *, start: str = None, end: str = None, include_start=True, include_end=True):
+        comps = _span(start, end, include_start, include_end)
+
+        def switch(m, enable=True):
+            if hasattr(m, "track_running_stats"):
+                m.track_running_stats = enable
+
+        prev = OrderedDict()
+        for c in comps:
+            m = getattr(self, "_" + c)
+            states = {s.track_running_stats for s in m.modules() if hasattr(s, "track_running_stats")}
+            if len(states) != 1:
+                continue
+            prev[c] = states.pop()
+            m.apply(partial(switch, enable=enable))
+        yield self
+        for c, st in prev.items():
+            getattr(self, "_" + c).apply(partial(switch, enable=st))
+
+    @property
+    def num_classes(self):
+        return self._num_classes
+
+
+def get_channel_dim(layer_name: str, *, max_channel=None):
+    max_channel = max_channel or 256
+    assert layer_name in {k: v for k, v in UNet.layer_dimension.items() if v is not None}
+    return int(UNet.layer_dimension[layer_name] / 16 * max_channel)

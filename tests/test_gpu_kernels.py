@@ -1,0 +1,252 @@
+"""Kernel-level GPU parity through the C ABI (ctypes), one encoder kernel at a time, on identical inputs:
+for bf16 the inputs/weights are rounded to bf16 FIRST and the fp32/fp64 CPU reference (torch ops = the oracle's
+building blocks) consumes the rounded values, so the only difference left is accumulation order and the final bf16
+store."""
+from ctypes import c_float
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DT = {"f32": torch.float32, "bf16": torch.bfloat16}
+TOL = {"f32": 2e-5, "bf16": 6e-3}  # relative to max|ref|
+
+
+def _n():
+    import spcl_amd  # noqa
+    from spcl_amd import native
+    return native
+
+
+def ru16(c):
+    return (c + 15) // 16 * 16
+
+
+def nhwc(x_nchw, dtype, cs=None):
+    N, C, H, W = x_nchw.shape
+    cs = cs or ru16(C)
+    out = torch.zeros(N, H, W, cs, dtype=dtype, device="cuda")
+    out[..., :C] = x_nchw.permute(0, 2, 3, 1).to(dtype)
+    return out
+
+
+def relerr(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def rnd(t, dtype):
+    return t.to(dtype).float()
+
+
+def pack(n, w, kind, dtype):
+    co, ci = w.shape[:2]
+    dtc = n.dtype_code(dtype)
+    buf = torch.empty(n.call("spcl_conv_packed_elems", ci, co, kind, dtc), dtype=dtype, device="cuda")
+    wc = w.cuda().contiguous()
+    n.call("spcl_conv_pack_weights", n.ptr(wc), ci, co, kind, dtc, n.ptr(buf), n.stream())
+    return buf
+
+
+def conv(n, xs, dtype, N, H, W, cin_s, cin_k, cout_s, wp, mode, scale=None, shift=None, stats=False):
+    y = torch.empty(N, H, W, cout_s, dtype=dtype, device="cuda")
+    st = None
+    if stats:
+        st = torch.empty(n.call("spcl_conv_num_tiles", N, H, W), cout_s, 3, dtype=torch.float32, device="cuda")
+    n.call("spcl_conv3x3_forward", n.ptr(xs), n.dtype_code(dtype), N, H, W, cin_s, cin_k, cout_s, n.ptr(wp), mode,
+           n.ptr(scale), n.ptr(shift), n.ptr(y), n.ptr(st), n.stream())
+    return y, st
+
+
+SHAPES = [(2, 16, 16, 28, 28), (1, 32, 64, 20, 18), (2, 128, 64, 14, 14), (1, 64, 256, 7, 9), (3, 8, 24, 33, 16),
+          (1, 256, 256, 14, 14)]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("N,ci,co,H,W", SHAPES)
+def test_conv_forward_raw_and_stats(dt, N, ci, co, H, W):
+    n = _n()
+    dtype = DT[dt]
+    g = torch.Generator().manual_seed(ci * 1000 + co + H)
+    x = rnd(torch.randn(N, ci, H, W, generator=g), dtype)
+    w = rnd(torch.randn(co, ci, 3, 3, generator=g) / (3 * ci ** 0.5), dtype)
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1).float()
+    cs_i, cs_o = ru16(ci), ru16(co)
+    xs, wp = nhwc(x, dtype), pack(n, w, 0, dtype)
+    y, st = conv(n, xs, dtype, N, H, W, cs_i, cs_i, cs_o, wp, 0, stats=True)
+    got = y[..., :co].permute(0, 3, 1, 2).float().cpu()
+    assert relerr(got, ref) < TOL[dt]
+    if cs_o > co:
+        assert float(y[..., co:].float().abs().max()) == 0.0
+    # Chan partials combine to the batch statistics
+    st = st.double().cpu()
+    cnt, mean, m2 = st[:, :co, 0], st[:, :co, 1], st[:, :co, 2]
+    tot = cnt.sum(0)
+    assert int(tot[0]) == N * H * W
+    gmean = (cnt * mean).sum(0) / tot
+    gm2 = (m2 + cnt * (mean - gmean) ** 2).sum(0)
+    np.testing.assert_allclose(gmean.numpy(), ref.double().mean(dim=(0, 2, 3)).numpy(), rtol=1e-3, atol=2e-5)
+    np.testing.assert_allclose((gm2 / tot).numpy(), ref.double().var(dim=(0, 2, 3), unbiased=False).numpy(), rtol=2e-3)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_conv_forward_fused_bnrelu_input(dt):
+    n = _n()
+    dtype = DT[dt]
+    N, ci, co, H, W = 2, 32, 48, 28, 28
+    g = torch.Generator().manual_seed(3)
+    x = rnd(torch.randn(N, ci, H, W, generator=g), dtype)
+    w = rnd(torch.randn(co, ci, 3, 3, generator=g) / 17, dtype)
+    sc, sh = torch.randn(ci, generator=g), torch.randn(ci, generator=g) * 0.3
+    act = rnd(torch.relu(x * sc[None, :, None, None] + sh[None, :, None, None]), dtype)  # staged value is rounded
+    ref = F.conv2d(act.double(), w.double(), None, 1, 1).float()
+    xs, wp, scd, shd = nhwc(x, dtype), pack(n, w, 0, dtype), sc.cuda(), sh.cuda()
+    y, _ = conv(n, xs, dtype, N, H, W, 32, 32, 48, wp, 1, scd, shd)
+    assert relerr(y.permute(0, 3, 1, 2).float().cpu(), ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("ci", [1, 2, 3])
+def test_conv_forward_image_mode(dt, ci):
+    n = _n()
+    dtype = DT[dt]
+    N, co, H, W = 2, 16, 28, 42
+    g = torch.Generator().manual_seed(4 + ci)
+    x = torch.rand(N, ci, H, W, generator=g)
+    w = rnd(torch.randn(co, ci, 3, 3, generator=g) / 3, dtype)
+    ref = F.conv2d(rnd(x, dtype).double(), w.double(), None, 1, 1).float()
+    xs = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wp = pack(n, w, 0, dtype)
+    y, _ = conv(n, xs, dtype, N, H, W, ci, 16, 16, wp, 2)
+    assert relerr(y.permute(0, 3, 1, 2).float().cpu(), ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("N,ci,co,H,W", SHAPES)
+def test_conv_dgrad(dt, N, ci, co, H, W):
+    n = _n()
+    dtype = DT[dt]
+    g = torch.Generator().manual_seed(ci + co + W)
+    dy = rnd(torch.randn(N, co, H, W, generator=g), dtype)
+    w = rnd(torch.randn(co, ci, 3, 3, generator=g) / (3 * co ** 0.5), dtype)
+    ref = F.conv_transpose2d(dy.double(), w.double(), None, 1, 1).float()  # == autograd's grad_input
+    cs_i, cs_o = ru16(ci), ru16(co)
+    dys, wp = nhwc(dy, dtype), pack(n, w, 1, dtype)
+    dx, _ = conv(n, dys, dtype, N, H, W, cs_o, cs_o, cs_i, wp, 0)
+    assert relerr(dx[..., :ci].permute(0, 3, 1, 2).float().cpu(), ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("N,ci,co,H,W", SHAPES + [(4, 16, 16, 56, 56)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_conv_wgrad(dt, N, ci, co, H, W, mode):
+    n = _n()
+    dtype = DT[dt]
+    g = torch.Generator().manual_seed(ci * 7 + co + H)
+    x = rnd(torch.randn(N, ci, H, W, generator=g), dtype)
+    dy = rnd(torch.randn(N, co, H, W, generator=g), dtype)
+    sc, sh = torch.randn(ci, generator=g), torch.randn(ci, generator=g) * 0.3
+    xin = rnd(torch.relu(x * sc[None, :, None, None] + sh[None, :, None, None]), dtype) if mode == 1 else x
+    ref = torch.nn.grad.conv2d_weight(xin.double(), (co, ci, 3, 3), dy.double(), 1, 1).float()
+    cs_i, cs_o = ru16(ci), ru16(co)
+    scp = torch.zeros(cs_i)
+    shp = torch.zeros(cs_i)
+    scp[:ci], shp[:ci] = sc, sh
+    ws = torch.empty(n.call("spcl_conv_wgrad_workspace_bytes", N, H, W, cs_i, cs_o) // 4, device="cuda")
+    dw = torch.empty(co, ci, 3, 3, device="cuda")
+    xs, dys, scd, shd = nhwc(x, dtype), nhwc(dy, dtype), scp.cuda(), shp.cuda()  # keep alive: ptr() borrows
+    n.call("spcl_conv3x3_wgrad", n.ptr(xs), n.ptr(dys), n.dtype_code(dtype), N, H, W, ci, cs_i,
+           cs_i, co, cs_o, mode, n.ptr(scd), n.ptr(shd), n.ptr(ws), n.ptr(dw), n.stream())
+    assert relerr(dw.cpu(), ref) < (2e-5 if dt == "f32" else 2e-3)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_conv_wgrad_image_mode(dt):
+    n = _n()
+    dtype = DT[dt]
+    N, ci, co, H, W = 3, 1, 16, 30, 44
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(N, ci, H, W, generator=g)
+    dy = rnd(torch.randn(N, co, H, W, generator=g), dtype)
+    ref = torch.nn.grad.conv2d_weight(rnd(x, dtype).double(), (co, ci, 3, 3), dy.double(), 1, 1).float()
+    ws = torch.empty(n.call("spcl_conv_wgrad_workspace_bytes", N, H, W, 16, 16) // 4, device="cuda")
+    dw = torch.empty(co, ci, 3, 3, device="cuda")
+    xs, dys = x.permute(0, 2, 3, 1).contiguous().cuda(), nhwc(dy, dtype)
+    n.call("spcl_conv3x3_wgrad", n.ptr(xs), n.ptr(dys),
+           n.dtype_code(dtype), N, H, W, ci, ci, 16, co, 16, 2, None, None, n.ptr(ws), n.ptr(dw), n.stream())
+    assert relerr(dw.cpu(), ref) < (2e-5 if dt == "f32" else 2e-3)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("N,C,H,W,pool,with_act", [(2, 16, 28, 28, True, False), (2, 48, 14, 10, True, True),
+                                                   (3, 32, 7, 5, True, True), (2, 64, 14, 14, False, True),
+                                                   (1, 24, 9, 9, True, False)])
+def test_bn_relu_pool_forward_backward(dt, N, C, H, W, pool, with_act):
+    """BatchNorm(train) -> ReLU -> (MaxPool 2x2, floor) forward and backward against torch autograd on the same y."""
+    n = _n()
+    dtype = DT[dt]
+    dtc = n.dtype_code(dtype)
+    cs = ru16(C)
+    g = torch.Generator().manual_seed(C + H)
+    y = rnd(torch.randn(N, C, H, W, generator=g) * 1.5 + 0.3, dtype)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    # reference
+    yr = y.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    a = F.relu(F.batch_norm(yr, None, None, gr, br, True, 0.1, 1e-5))
+    outs = []
+    if with_act or not pool:
+        outs.append(a)
+    if pool:
+        outs.append(F.max_pool2d(a, 2, 2))
+    douts = [rnd(torch.randn(o.shape, generator=g), dtype).double() for o in outs]
+    torch.autograd.backward(outs, douts)
+    # HIP statistics through bn_finalize from a single exact partial
+    mean = y.double().mean(dim=(0, 2, 3))
+    var = y.double().var(dim=(0, 2, 3), unbiased=False)
+    stats = torch.zeros(1, cs, 3)
+    stats[0, :C, 0] = N * H * W
+    stats[0, :C, 1] = mean.float()
+    stats[0, :C, 2] = (var * N * H * W).float()
+    rm, rv = torch.zeros(C).cuda(), torch.ones(C).cuda()
+    nbt = torch.zeros((), dtype=torch.long).cuda()
+    st = torch.empty(4, cs, device="cuda")
+    stats_d, gamma_d, beta_d = stats.cuda(), gamma.cuda(), beta.cuda()
+    n.call("spcl_bn_finalize", n.ptr(stats_d), 1, C, cs, n.ptr(gamma_d), n.ptr(beta_d), c_float(0.1),
+           c_float(1e-5), n.ptr(rm), n.ptr(rv), n.ptr(nbt), n.ptr(st[0]), n.ptr(st[1]), n.ptr(st[2]), n.ptr(st[3]),
+           n.stream())
+    assert int(nbt) == 1
+    np.testing.assert_allclose(rm.cpu().numpy(), 0.1 * mean.float().numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(rv.cpu().numpy(),
+                               (0.9 + 0.1 * y.double().var(dim=(0, 2, 3), unbiased=True)).float().numpy(), rtol=1e-5)
+    ys = nhwc(y, dtype)
+    act = torch.empty(N, H, W, cs, dtype=dtype, device="cuda") if (with_act or not pool) else None
+    pl = torch.empty(N, H // 2, W // 2, cs, dtype=dtype, device="cuda") if pool else None
+    n.call("spcl_bnrelu_pool_forward", n.ptr(ys), dtc, N, H, W, cs, n.ptr(st[2]), n.ptr(st[3]), n.ptr(act), n.ptr(pl),
+           n.stream())
+    k = 0
+    if act is not None:
+        assert relerr(act[..., :C].permute(0, 3, 1, 2).float().cpu(), outs[k].detach().float()) < TOL[dt]
+        k += 1
+    if pl is not None:
+        assert relerr(pl[..., :C].permute(0, 3, 1, 2).float().cpu(), outs[k].detach().float()) < TOL[dt]
+    # backward
+    k = 0
+    dact = dpool = None
+    if act is not None:
+        dact = nhwc(douts[k].float(), dtype)
+        k += 1
+    if pl is not None:
+        dpool = nhwc(douts[k].float(), dtype)
+    ws = torch.empty(n.call("spcl_bnrelu_bwd_workspace_bytes", N, H, W, cs) // 4, device="cuda")
+    dgm, dbt = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    dy = torch.empty(N, H, W, cs, dtype=dtype, device="cuda")
+    n.call("spcl_bnrelu_pool_backward", n.ptr(ys), n.ptr(dact), n.ptr(dpool), dtc, N, H, W, C, cs, n.ptr(st[0]),
+           n.ptr(st[1]), n.ptr(st[2]), n.ptr(st[3]), 1, n.ptr(ws), n.ptr(dgm), n.ptr(dbt), n.ptr(dy), n.stream())
+    tol = 5e-5 if dt == "f32" else 8e-3
+    assert relerr(dgm.cpu(), gr.grad.float()) < tol
+    assert relerr(dbt.cpu(), br.grad.float()) < tol
+    assert relerr(dy[..., :C].permute(0, 3, 1, 2).float().cpu(), yr.grad.float()) < tol
