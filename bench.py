@@ -1,0 +1,381 @@
+#!/usr/bin/env python3
+"""Benchmark of the pre-train hot path on MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W]            # N>1: launched by torch.distributed.run, one rank/GPU
+
+A "step" = one pass of the hot path over one synthetic batch, exactly the reference's pre-train iteration
+(semi_seg/epochers/new_pretrain.py:53-89): two views of bs=32 slices (64 images of 1x224x224) -> UNet encoder to Conv5
+-> forward-hook tap -> ProjectionHead(256,256,256) -> SelfPacedSupConLoss(soft, gamma 3->70, correct_grad) ->
+backward -> (flat RCCL gradient all-reduce when N>1) -> RAdam step.  bf16 storage, fp32 accumulation/statistics/loss
+(BASELINE.json configs[1]).  Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+
+Extra objects in the line:
+  roofline      the dominant kernel call of the step, timed live with HIP events on its own stream in an instrumented
+                pass right after the timed region; algorithmic bytes/FLOPs per launch as defined in DESIGN.md
+  cpu_baseline  the CPU oracle's restatement of the same step ("port"), timed on this box's host cores (rank 0, N=1)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--bs", type=int, default=32, help="slices per GPU (two views each)")
+    ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-bs", type=int, default=8, help="batch of the CPU-oracle sample (bounded work)")
+    ap.add_argument("--workload", default="pretrain", choices=["pretrain", "contrastive"])
+    return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------------ step construction
+def build_step(args, device, rank, world):
+    import spcl_amd
+    from spcl_amd import ddp
+    from spcl_amd.semi_seg.arch import UNet
+    from spcl_amd.semi_seg.hooks import create_sp_infonce_hooks
+    from spcl_amd.semi_seg.epochers import PretrainEncoderEpocher
+    from spcl_amd.synthetic import SyntheticPretrainLoader
+
+    torch.manual_seed(10)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model = UNet(input_dim=1, num_classes=4, max_channel=256, momentum=0.1).to(device)
+    model.set_compute_dtype(dtype)
+    hook = create_sp_infonce_hooks(model=model, feature_names="Conv5", weights=1.0, contrast_ons="partition",
+                                   begin_values=3.0, end_values=70.0, mode="soft", max_epoch=80, p=0.5,
+                                   correct_grad=True, data_name="acdc", sync_checks=False).to(device)
+    for sub in hook._hooks:  # mid-schedule age parameter (epoch 40 of 80: gamma = 3 + 67*sqrt(0.5) = 50.4): at epoch 0
+        sub._scheduler.epoch = 40  # gamma=3 < log(63) zeroes every weight at random init, i.e. a degenerate loss
+    ddp.broadcast_state(model, hook)
+    # freeze the decoder exactly as main_pretrain_encoder.py:69 does (set_grad(False, start="Conv5", include_start=False))
+    for name in model.decoder_names:
+        getattr(model, "_" + name).requires_grad_(False)
+    params = [p for p in model.parameters() if p.requires_grad]
+    hparams = list(hook.parameters())
+    opt = torch.optim.RAdam([{"params": params}, {"params": hparams}], lr=5e-7 * 400, weight_decay=1e-5,
+                            capturable=True, foreach=True)
+    bucket = ddp.GradBucket(params + hparams) if world > 1 else None
+    loader = SyntheticPretrainLoader(bs=args.bs, size=args.size, device=device, seed=1234 + rank, resident=True)
+    epocher = PretrainEncoderEpocher(model=model, optimizer=opt, chain_dataloader=loader, num_batches=10 ** 9,
+                                     device=device, inference_until="Conv5", grad_bucket=bucket)
+    epocher.add_hooks([hook()])
+    model.train()
+    batch = next(loader)
+    nparams = sum(p.numel() for p in params + hparams)
+
+    def step():
+        with epocher.meters.focus_on(epocher.meter_focus):
+            return epocher.step(batch, seed=7)
+
+    return step, epocher, nparams
+
+
+def graph_capture(step, device):
+    """Capture one whole step (fwd + bwd + all-reduce + optimizer) in a hipGraph: removes ~200 launches of host time."""
+    s = torch.cuda.Stream(device=device)
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        step()
+    return g.replay
+
+
+# ------------------------------------------------------------------------------------------------ roofline (live)
+def conv_cost(kind, N, H, W, cin, cout, esize):
+    """Algorithmic bytes / FLOPs of one conv-family launch (DESIGN.md 'roofline accounting')."""
+    px = N * H * W
+    flops = 2.0 * px * 9 * cin * cout
+    if kind == "wgrad":
+        byts = px * (cin + cout) * esize + 9 * cin * cout * 4
+    else:
+        byts = px * (cin + cout) * esize + 9 * cin * cout * esize
+    return byts, flops
+
+
+def measure_roofline(step, args):
+    """Instrumented pass: HIP events (torch.cuda.Event on the launch stream = torch's current stream, which is the
+    stream handed to every C-ABI call) around each C-ABI call; returns the dominant one with its roofline."""
+    from spcl_amd import native
+    esize = 2 if args.dtype == "bf16" else 4
+    records = {}
+    orig_call = native.call
+    reps = 5
+
+    def timed_call(name, *a):
+        if not name.startswith(("spcl_conv3x3", "spcl_bnrelu", "spcl_supcon_f", "spcl_supcon_b", "spcl_proj")):
+            return orig_call(name, *a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = orig_call(name, *a)
+        e1.record()
+        key = name
+        meta = None
+        if name == "spcl_conv3x3_forward":
+            N, H, W, cin_s, cin_k, cout_s, mode = a[2], a[3], a[4], a[5], a[6], a[7], a[9]
+            cin = cin_s
+            key = f"{name}[N{N} {H}x{W} {cin}->{cout_s} mode{mode}]"
+            meta = ("conv",) + conv_cost("conv", N, H, W, cin, cout_s, esize if mode != 2 else esize)
+            if mode == 2:  # f32 image in, dtype out
+                meta = ("conv", N * H * W * (cin * 4 + cout_s * esize) + 9 * 16 * cout_s * esize,
+                        2.0 * N * H * W * 9 * cin * cout_s)
+        elif name == "spcl_conv3x3_wgrad":
+            N, H, W, cin, cin_s, cin_k, cout, cout_s, mode = a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11]
+            key = f"{name}[N{N} {H}x{W} {cin}x{cout} mode{mode}]"
+            meta = ("wgrad",) + conv_cost("wgrad", N, H, W, cin if mode != 2 else cin, cout, esize)
+        elif name == "spcl_bnrelu_pool_forward":
+            N, H, W, cs = a[2], a[3], a[4], a[5]
+            act, pool = a[8], a[9]
+            outb = (N * H * W * cs if act is not None and act.value else 0) + \
+                   (N * (H // 2) * (W // 2) * cs if pool is not None and pool.value else 0)
+            key = f"{name}[N{N} {H}x{W} C{cs}]"
+            meta = ("stream", (N * H * W * cs + outb) * esize, 0.0)
+        elif name == "spcl_bnrelu_pool_backward":
+            N, H, W, cs = a[4], a[5], a[6], a[8]
+            key = f"{name}[N{N} {H}x{W} C{cs}]"
+            # reduce pass reads y + g; apply pass reads y + g and writes dy (g at pooled resolution when pooled)
+            gsz = N * H * W * cs if (a[1] is not None and a[1].value) else N * (H // 2) * (W // 2) * cs
+            meta = ("stream", (2 * (N * H * W * cs + gsz) + N * H * W * cs) * esize, 0.0)
+        records.setdefault(key, {"ev": [], "meta": meta})["ev"].append((e0, e1))
+        return r
+
+    native.call = timed_call
+    import spcl_amd.functional as F_hip
+    F_hip._n.call = timed_call
+    try:
+        for _ in range(reps):
+            step()
+        torch.cuda.synchronize()
+    finally:
+        native.call = orig_call
+        F_hip._n.call = orig_call
+    table = []
+    for key, rec in records.items():
+        ts = [e0.elapsed_time(e1) * 1e-3 for e0, e1 in rec["ev"]]
+        per_step = sum(ts) / reps
+        calls_per_step = len(ts) / reps
+        table.append((per_step, key, per_step / calls_per_step, calls_per_step, rec["meta"]))
+    table.sort(reverse=True)
+    total = sum(t[0] for t in table)
+    top = None
+    for per_step, key, avg, calls, meta in table:
+        if meta is not None:
+            top = (per_step, key, avg, calls, meta)
+            break
+    out = None
+    if top is not None:
+        per_step, key, avg, calls, (kind, byts, flops) = top
+        t_hbm = byts / (HBM_PEAK_GBS * 1e9)
+        peak_tf = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+        t_mfma = flops / (peak_tf * 1e12)
+        if t_hbm >= t_mfma:
+            ach = byts / avg / 1e9
+            out = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
+        else:
+            ach = flops / avg / 1e12
+            out = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak_tf, "unit": "TFLOP/s",
+                   "frac": round(ach / peak_tf, 4), "traffic": None}
+        out.update({"kernel": key, "avg_us": round(avg * 1e6, 2), "launches_per_step": calls,
+                    "algorithmic_bytes": int(byts), "algorithmic_flops": float(flops),
+                    "share_of_instrumented_step": round(per_step / total, 4)})
+    breakdown = [{"call": k, "us_per_step": round(p * 1e6, 1), "launches": c} for p, k, a, c, m in table[:14]]
+    return out, breakdown, total
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline(args):
+    """The oracle's restatement of the same step on the host cores: bounded sample (a few steps at --cpu-bs)."""
+    from oracle import spcl_oracle as O
+    threads = min(os.cpu_count() or 1, 32)  # torch's CPU conv stops scaling (and collapses) far below 256 threads
+    torch.set_num_threads(threads)
+    bs = args.cpu_bs
+    g = torch.Generator().manual_seed(1234)
+    sd = O.init_unet_state(1, 4, 256, seed=10, encoder_only=True)
+    sd = {k: (v.requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in sd.items()}
+    psd = {k: v.requires_grad_(True) for k, v in O.init_projector_state(256, 256, 256, seed=11).items()}
+    leaves = [v for v in list(sd.values()) + list(psd.values()) if v.is_floating_point() and v.requires_grad]
+    opt = torch.optim.RAdam(leaves, lr=2e-4, weight_decay=1e-5)
+    img = torch.rand(bs, 1, args.size, args.size, generator=g)
+    img_tf = torch.rand(bs, 1, args.size, args.size, generator=g)
+    labels = [i % 3 for i in range(bs)]
+
+    def one():
+        r = O.pretrain_step(img, img_tf, sd, psd, labels, gamma=3.0, mode="soft", correct_grad=True)
+        for k, p in list(sd.items()) + list(psd.items()):
+            if k in r["grads"] and r["grads"][k] is not None:
+                p.grad = r["grads"][k]
+        opt.step()
+        opt.zero_grad()
+
+    one()  # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while n < 2 or (time.perf_counter() - t0 < 10.0 and n < 40):
+        one()
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(bs * n / dt, 2), "unit": "slices/s", "cores": threads, "kind": "port",
+            "sample": f"{n} steps of the oracle's pre-train step (fwd+bwd+RAdam) at bs={bs} ({2 * bs} images "
+                      f"{args.size}x{args.size}), fp32, torch CPU {threads} threads, {dt:.1f}s"}
+
+
+# ------------------------------------------------------------------------------------------------ main
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    device = torch.device("cuda", local if world > 1 else 0)
+    assert args.gpus == world or world == 1, (args.gpus, world)
+
+    if args.workload == "contrastive":
+        return bench_contrastive(args, device)
+
+    step, epocher, nparams = build_step(args, device, rank, world)
+    run = step
+    used_graph = False
+    if not args.no_graph:
+        try:
+            run = graph_capture(step, device)
+            used_graph = True
+        except Exception as e:  # noqa: BLE001  -- report and fall back to eager launches (same kernels)
+            if rank == 0:
+                print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            run = step
+    for _ in range(args.warmup):
+        run()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ms = elapsed / args.steps * 1e3
+    value = args.bs * world * args.steps / elapsed
+    line = {
+        "metric": "pretrain slices/sec/node (UNet+InfoNCE, 224^2, bs=32/GPU)", "value": round(value, 1),
+        "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[1]: self-paced pretrain step, UNet base (max_channel=256) encoder "
+                               "to Conv5 + ProjectionHead(256,256,256) + SelfPacedSupConLoss(soft, partition labels, "
+                               "correct_grad) fwd+bwd + RAdam" + (" + flat RCCL grad all-reduce" if world > 1 else ""),
+                   "slices_per_gpu": args.bs, "images_per_gpu_step": 2 * args.bs, "image": f"1x{args.size}x{args.size}",
+                   "global_batch": args.bs * world, "parallelism": f"dp{world}", "params": nparams,
+                   "hipgraph": used_graph},
+    }
+    if rank == 0:
+        loss = epocher.meters.statistics()
+        line["final_meters"] = {k: round(v["mean"], 5) for g in loss.values() for k, v in g.items()
+                                if k in ("loss", "sp_weight", "reg_loss")}
+    if rank == 0 and not args.no_roofline:
+        try:
+            roof, breakdown, tot = measure_roofline(step, args)
+            line["roofline"] = roof
+            line["kernel_breakdown"] = breakdown
+            line["instrumented_step_ms"] = round(tot * 1e3, 3)
+        except Exception as e:  # noqa: BLE001
+            line["roofline"] = None
+            print(f"[bench] roofline pass failed: {type(e).__name__}: {e}", file=sys.stderr)
+    if world > 1:
+        dist.barrier()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(args)
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_contrastive(args, device):
+    """BASELINE.json configs[4] microbench: loss only, 2n=4096 samples, proj_dim=128 (fp32 exact-MFMA path)."""
+    import spcl_amd  # noqa
+    from spcl_amd.contrastyou.losses.contrast_loss3 import SelfPacedSupConLoss
+    n, d = 2048, 128
+    g = torch.Generator().manual_seed(1)
+    z1 = torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=1).to(device).requires_grad_(True)
+    z2 = torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=1).to(device).requires_grad_(True)
+    labels = torch.arange(n, device=device) % 3
+    crit = SelfPacedSupConLoss(weight_update="soft", correct_grad=True, sync_checks=False)
+    crit.set_gamma(12.0)
+
+    def fwd():
+        return crit(z1, z2, target=labels)
+
+    def fwdbwd():
+        loss = fwd()
+        loss.backward()
+
+    res = {}
+    for name, fn in (("fwd", fwd), ("fwd_bwd", fwdbwd)):
+        for _ in range(args.warmup):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(args.steps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        res[name] = e0.elapsed_time(e1) / args.steps * 1e3  # us
+    mat_bytes = 3 * 4096 * 4096 * 4 + 2 * 4096 * 128 * 4
+    ach = mat_bytes / (res["fwd"] * 1e-6) / 1e9
+    line = {"metric": "contrastive similarity+softmax 4096x128 (microbench)", "value": round(1e6 / res["fwd_bwd"], 1),
+            "unit": "loss fwd+bwd /s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(res["fwd_bwd"] * 1e-3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[4]: SelfPacedSupConLoss 2n=4096 d=128", "fwd_us": round(res["fwd"], 1),
+                       "fwd_bwd_us": round(res["fwd_bwd"], 1)},
+            "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                         "note": "materialised-fp32 schedule bytes (205.5 MB) / fused-kernel time; the fused kernel "
+                                 "itself is MFMA-bound (2 sweeps x 4.295 GFLOP exact-f32)",
+                         "mfma_f32_frac": round(2 * 4.295e9 / (res["fwd"] * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}}
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

@@ -274,23 +274,29 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_reduce_kernel(const T* __restr
   }
 }
 
-// dbeta = sum dz, dgamma = sum dz*yhat (fixed order over workgroups); k1 = dbeta/M, k2 = dgamma/M for the apply pass
+// dbeta = sum dz, dgamma = sum dz*yhat; k1 = dbeta/M, k2 = dgamma/M for the apply pass.  One wave per channel: lanes
+// stride over the workgroup partials (independent loads in flight), then a fixed-order butterfly -> deterministic.
 __global__ __launch_bounds__(256) void bnrelu_bwd_fin_kernel(const float* __restrict__ partial, int nwg, int C, int CS,
                                                              float M, int training, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta, float* __restrict__ k12) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (c >= CS) return;
   float s1 = 0.f, s2 = 0.f;
-  for (int w = 0; w < nwg; ++w) {
+  for (int w = lane; w < nwg; w += 64) {
     s1 += partial[((size_t)w * 2 + 0) * CS + c];
     s2 += partial[((size_t)w * 2 + 1) * CS + c];
   }
-  if (c < C) {
-    dbeta[c] = s1;
-    dgamma[c] = s2;
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if (lane == 0) {
+    if (c < C) {
+      dbeta[c] = s1;
+      dgamma[c] = s2;
+    }
+    k12[c] = training ? s1 / M : 0.f;
+    k12[CS + c] = training ? s2 / M : 0.f;
   }
-  k12[c] = training ? s1 / M : 0.f;
-  k12[CS + c] = training ? s2 / M : 0.f;
 }
 
 template <typename T, bool POOL>
@@ -365,7 +371,7 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
     hipLaunchKernelGGL((bnrelu_bwd_reduce_kernel<T, false>), dim3(nwg), dim3(256), 0, st, (const T*)y, (const T*)dact,
                        (const T*)dpool, N, H, W, CS, mean, invstd, scale, shift, partial);
   }
-  hipLaunchKernelGGL(bnrelu_bwd_fin_kernel, dim3(cdiv(CS, 256)), dim3(256), 0, st, (const float*)partial, nwg, C, CS,
+  hipLaunchKernelGGL(bnrelu_bwd_fin_kernel, dim3(cdiv(CS, 4)), dim3(256), 0, st, (const float*)partial, nwg, C, CS,
                      M, training, dgamma, dbeta, k12);
   const int grid = stream_grid(npos * CPC);
   if (pool) {

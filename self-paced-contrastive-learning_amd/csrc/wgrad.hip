@@ -220,21 +220,34 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(WgradArgs a) {
   }
 }
 
-// dW_oihw[co][ci][tap] = sum over pixel-split partials (fixed order)
+// dW_oihw[co][ci][tap] = sum over pixel-split partials.  Threads follow the PARTIAL layout ([tap][ci][co], co fastest:
+// coalesced 256-byte wave reads); the 4 waves of a block take splits p = w, w+4, ... (8 independent loads in flight
+// each) and are combined through LDS in fixed order -> deterministic.  One scattered 4-byte store per output.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, int nblk_ci,
                                                            int nblk_co, int CIB, int COB, int Cin, int Cout,
                                                            float* __restrict__ dw) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= Cout * Cin * 9) return;
-  const int tap = idx % 9, ci = (idx / 9) % Cin, co = idx / (9 * Cin);
-  const int bci = ci / CIB, bco = co / COB;
-  const size_t slab = (size_t)9 * CIB * COB;
-  const size_t inner = ((size_t)tap * CIB + (ci - bci * CIB)) * COB + (co - bco * COB);
-  const size_t blk = (size_t)bci * nblk_co + bco;
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slab = 9 * CIB * COB;
+  const int inner = blockIdx.x * 64 + lane;
+  const int blk = blockIdx.y;
   const size_t nblk = (size_t)nblk_ci * nblk_co;
   float s = 0.f;
-  for (int p = 0; p < nsplit; ++p) s += partial[((size_t)p * nblk + blk) * slab + inner];
-  dw[idx] = s;
+  if (inner < slab) {
+    const float* src = partial + (size_t)blk * slab + inner;
+    const size_t stride = nblk * slab;
+#pragma unroll 8
+    for (int p = wave; p < nsplit; p += 4) s += src[(size_t)p * stride];
+  }
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && inner < slab) {
+    const float v = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    const int co_l = inner % COB, ci_l = (inner / COB) % CIB, tap = inner / (COB * CIB);
+    const int bci = blk / nblk_co, bco = blk - bci * nblk_co;
+    const int ci = bci * CIB + ci_l, co = bco * COB + co_l;
+    if (ci < Cin && co < Cout) dw[((size_t)co * Cin + ci) * 9 + tap] = v;
+  }
 }
 
 struct WgradPlan {
@@ -251,7 +264,7 @@ static WgradPlan wgrad_plan(int N, int H, int W, int CinK, int CoutS) {
   p.tilesY = cdiv(H, WG_TH);
   p.ntiles = N * p.tilesX * p.tilesY;
   const int nblk = p.nblk_ci * p.nblk_co;
-  int ns = cdiv(1024, nblk);
+  int ns = cdiv(768, nblk);
   if (ns > p.ntiles) ns = p.ntiles;
   if (ns < 1) ns = 1;
   p.nsplit = ns;
@@ -309,9 +322,9 @@ extern "C" int spcl_conv3x3_wgrad(const void* x, const void* dy, int dtype, int 
     set_error("conv3x3_wgrad: dtype %d", dtype);
     return SPCL_EINVAL;
   }
-  const int total = Cout * Cin * 9;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, (const float*)partial, p.nsplit,
-                     p.nblk_ci, p.nblk_co, 16 * p.MI, 16 * p.NJ, Cin, Cout, dw_oihw);
+  const int slab = 9 * 16 * p.MI * 16 * p.NJ;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(slab, 64), p.nblk_ci * p.nblk_co), dim3(256), 0, st,
+                     (const float*)partial, p.nsplit, p.nblk_ci, p.nblk_co, 16 * p.MI, 16 * p.NJ, Cin, Cout, dw_oihw);
   SPCL_LAUNCH_CHECK("conv3x3_wgrad");
   return SPCL_OK;
 }

@@ -1,0 +1,1 @@
+from .pretrain import PretrainEncoderEpocher, unzip_twice_transformed  # noqa: F401

@@ -1,0 +1,84 @@
+"""Label generators of ``semi_seg/epochers/helper.py:48-65`` (sklearn LabelEncoder == rank among sorted uniques) and
+the seeded per-sample flip the epocher and the hook share (deepclustering2 ``TensorRandomFlip(axis=[1,2],
+threshold=0.8)`` under ``FixRandomSeed(seed)``; un-vendored third party, restated by contract -- SURVEY 8c)."""
+import random
+from typing import List
+
+import torch
+
+
+def _label_encode(items):
+    index = {v: i for i, v in enumerate(sorted(set(items)))}
+    return [index[v] for v in items]
+
+
+class PartitionLabelGenerator:
+    def __call__(self, partition_list: List[str], **kwargs):
+        return _label_encode(list(partition_list))
+
+
+class PatientLabelGenerator:
+    def __call__(self, patient_list: List[str], **kwargs):
+        return _label_encode(list(patient_list))
+
+
+class ACDCCycleGenerator:
+    def __call__(self, experiment_list: List[str], **kwargs):
+        return [0 if e == "00" else 1 for e in experiment_list]
+
+
+class SIMCLRGenerator:
+    def __call__(self, partition_list: List[str], **kwargs):
+        return list(range(len(partition_list)))
+
+
+class FixRandomSeed:
+    """Context manager: seed python's RNG, restore its state on exit (contract of deepclustering2.FixRandomSeed as
+    used at semi_seg/epochers/new_pretrain.py:57,64 and semi_seg/hooks/infonce.py:177)."""
+
+    def __init__(self, seed):
+        self._seed = seed
+
+    def __enter__(self):
+        self._state = random.getstate()
+        random.seed(self._seed)
+        return self
+
+    def __exit__(self, *a):
+        random.setstate(self._state)
+
+
+class TensorRandomFlip:
+    """Flip a [C,H,W] sample along each of ``axis`` independently when u < threshold (u ~ python ``random``)."""
+
+    def __init__(self, axis=(1, 2), threshold=0.8):
+        self._axis = tuple(axis)
+        self._threshold = threshold
+        self._plans = {}
+
+    def decisions(self, n):
+        return [[random.random() < self._threshold for _ in self._axis] for _ in range(n)]
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        dims = [a for a in self._axis if random.random() < self._threshold]
+        return x.flip(dims) if dims else x
+
+    def apply_batch(self, x: torch.Tensor) -> torch.Tensor:
+        """Batched equivalent of ``stack([self(s) for s in x])`` drawing the same random stream: one gather per flip
+        pattern instead of one kernel per sample.  Index tensors are cached per decision pattern, so a repeated
+        pattern costs no host->device copy (and the call can be captured in a hipGraph)."""
+        dec = tuple(tuple(d) for d in self.decisions(x.shape[0]))
+        key = (dec, x.device)
+        plan = self._plans.get(key)
+        if plan is None:
+            groups = {}
+            for i, d in enumerate(dec):
+                groups.setdefault(d, []).append(i)
+            plan = [([a + 1 for a, f in zip(self._axis, pat) if f],
+                     torch.tensor(idx, dtype=torch.long, device=x.device)) for pat, idx in groups.items() if any(pat)]
+            if len(self._plans) < 256:
+                self._plans[key] = plan
+        out = x.clone()
+        for dims, idx in plan:
+            out.index_copy_(0, idx, x.index_select(0, idx).flip(dims))
+        return out

@@ -1,0 +1,137 @@
+"""Mirror of the pre-train epocher: ``EpocherBase`` (contrastyou/epochers/base.py:16-114), the hook-calling
+``forward_pass``/``regularization`` wrappers (semi_seg/epochers/new_epocher.py:33-50) and the hot loop
+``_PretrainEpocherMixin._run_pretrain/_forward_pass`` (semi_seg/epochers/new_pretrain.py:52-96).
+
+Same control flow and hook wire format; what changes is WHERE work happens: no per-step ``.item()`` (meters take
+device scalars), flips are batched gathers, the encoder/projector/loss are the HIP kernels, and with
+``torch.distributed`` initialised the gradients go through one flat RCCL all-reduce (ddp.GradBucket) before the
+optimizer step."""
+import random
+from typing import Iterable, Optional
+
+import torch
+from torch import nn
+
+from ...contrastyou.meters import AverageValueMeter, MeterInterface
+from ... import ddp as _ddp
+from .helper import FixRandomSeed, TensorRandomFlip
+
+
+def unzip_twice_transformed(data, device):
+    """``preprocess_input_with_twice_transformation`` (semi_seg/epochers/helper.py:27-36) + ``_unzip_data``
+    (new_pretrain.py:98-102): ((image, image_tf, target, target_tf), filename, (partition, group))."""
+    (image, image_tf, *_), filename, (partition_list, group_list) = data
+    image = image.to(device, non_blocking=True)
+    image_tf = image_tf.to(device, non_blocking=True)
+    return (image, image_tf), None, filename, partition_list, group_list
+
+
+class PretrainEncoderEpocher:
+    meter_focus = "semi"
+
+    def __init__(self, *, model: nn.Module, optimizer, chain_dataloader: Iterable, num_batches: int, cur_epoch=0,
+                 device="cuda", inference_until: str = "Conv5", grad_bucket: Optional[_ddp.GradBucket] = None,
+                 scaler=None, **kwargs) -> None:
+        self._model = model
+        self._optimizer = optimizer
+        self._chain_dataloader = chain_dataloader
+        self._num_batches = num_batches
+        self._cur_epoch = cur_epoch
+        self._device = torch.device(device)
+        self._inference_until = inference_until
+        self._affine_transformer = TensorRandomFlip(axis=[1, 2], threshold=0.8)
+        self._grad_bucket = grad_bucket
+        self._hooks = []
+        self.meters = MeterInterface(default_focus=self.meter_focus)
+        with self.meters.focus_on(self.meter_focus):
+            self.meters.register_meter("lr", AverageValueMeter())
+            self.meters.register_meter("reg_loss", AverageValueMeter())
+        self.cur_batch_num = 0
+
+    # ---- contrastyou/epochers/base.py:47-60
+    def add_hook(self, hook):
+        self._hooks.append(hook)
+        hook.set_epocher(self)
+
+    def add_hooks(self, hooks):
+        for h in hooks:
+            self.add_hook(h)
+
+    def close_hooks(self):
+        for h in self._hooks:
+            h.close()
+
+    @staticmethod
+    def on_master():
+        return _ddp.on_master()
+
+    def init(self):
+        pass
+
+    # ---- new_epocher.py:33-50
+    def forward_pass(self, **kwargs):
+        for h in self._hooks:
+            h.before_forward_pass(**kwargs)
+        result = self._forward_pass(**kwargs)
+        for h in self._hooks:
+            h.after_forward_pass(**kwargs, result_dict=result)
+        return result
+
+    def regularization(self, **kwargs):
+        for h in self._hooks:
+            h.before_regularization(**kwargs)
+        result = self._regularization(**kwargs)
+        for h in self._hooks:
+            h.after_regularization(**kwargs, result_dict=result)
+        return result
+
+    def _regularization(self, **kwargs):  # new_epocher.py:234-238
+        if len(self._hooks) > 0:
+            return sum([h(**kwargs) for h in self._hooks])
+        return torch.tensor(0, dtype=torch.float, device=self._device)
+
+    # ---- new_pretrain.py:91-96
+    def _forward_pass(self, unlabeled_image, unlabeled_image_tf):
+        n_unl = len(unlabeled_image)
+        predict_logits = self._model(torch.cat([unlabeled_image, unlabeled_image_tf], dim=0),
+                                     until=self._inference_until)
+        unlabeled_logits, unlabeled_tf_logits = torch.split(predict_logits, [n_unl, n_unl], dim=0)
+        return unlabeled_logits, unlabeled_tf_logits
+
+    def run(self):
+        with self.meters.focus_on(self.meter_focus):
+            self.meters["lr"].add([g["lr"] for g in self._optimizer.param_groups])
+            self._model.train()
+            self._run_pretrain()
+        self.close_hooks()
+        return self.meters.statistics()
+
+    def step(self, data, seed=None):
+        """One iteration of new_pretrain.py:53-89; returns the (device) regularisation loss."""
+        seed = random.randint(0, int(1e7)) if seed is None else seed
+        (unlabeled_image, unlabeled_image_tf), _, unlabeled_filename, unl_partition, unl_group = \
+            unzip_twice_transformed(data, self._device)
+        with FixRandomSeed(seed):
+            unlabeled_image_tf = self._affine_transformer.apply_batch(unlabeled_image_tf)
+        unlabeled_logits, unlabeled_tf_logits = self.forward_pass(unlabeled_image=unlabeled_image,
+                                                                  unlabeled_image_tf=unlabeled_image_tf)
+        # new_pretrain.py:64-65 flips the Conv5 "logits" as well; the InfoNCE hook only takes len() of them
+        unlabeled_logits_tf = unlabeled_logits
+        reg_loss = self.regularization(
+            unlabeled_tf_logits=unlabeled_tf_logits, unlabeled_logits_tf=unlabeled_logits_tf, seed=seed,
+            unlabeled_image=unlabeled_image, unlabeled_image_tf=unlabeled_image_tf, label_group=unl_group,
+            partition_group=unl_partition, unlabeled_filename=unlabeled_filename,
+            affine_transformer=self._affine_transformer)
+        total_loss = reg_loss
+        self._optimizer.zero_grad(set_to_none=True)
+        total_loss.backward()
+        if self._grad_bucket is not None:
+            self._grad_bucket.allreduce()
+        self._optimizer.step()
+        if self.on_master():
+            self.meters["reg_loss"].add(reg_loss.detach())
+        return reg_loss
+
+    def _run_pretrain(self):
+        for self.cur_batch_num, data in zip(range(self._num_batches), self._chain_dataloader):
+            self.step(data)

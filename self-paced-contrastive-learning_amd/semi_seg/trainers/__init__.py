@@ -1,0 +1,1 @@
+from .pretrain import PretrainEncoderTrainer, WarmupCosine  # noqa: F401

@@ -1,0 +1,36 @@
+"""Synthetic on-device pre-train batches of the shape BASELINE.json names: ``torch.rand`` slices in
+[0,1) like ToTensor output, ACDC-like meta-labels (partition = i % 3, scan = i // 3), in the reference's loader
+tuple format ((image, image_tf, target, target_tf), filenames, (partitions, groups))."""
+import torch
+
+
+def acdc_like_meta(bs: int):
+    partitions = [str(i % 3) for i in range(bs)]
+    groups = [f"patient{i // 3:03d}_00" for i in range(bs)]
+    filenames = [f"patient{i // 3:03d}_00_{i % 3:02d}" for i in range(bs)]
+    return filenames, partitions, groups
+
+
+class SyntheticPretrainLoader:
+    """Infinite iterator; ``resident=True`` re-yields ONE pre-generated device batch (inputs already in HBM when the
+    timed region starts), otherwise draws a fresh batch on device every step."""
+
+    def __init__(self, bs=32, size=224, channels=1, device="cuda", seed=1234, resident=True):
+        self.bs, self.size, self.channels, self.device, self.resident = bs, size, channels, device, resident
+        self.gen = torch.Generator(device=device).manual_seed(seed)
+        self.meta = acdc_like_meta(bs)
+        self._batch = self._draw() if resident else None
+
+    def _draw(self):
+        shape = (self.bs, self.channels, self.size, self.size)
+        img = torch.rand(shape, device=self.device, generator=self.gen)
+        img_tf = torch.rand(shape, device=self.device, generator=self.gen)
+        tgt = torch.zeros((self.bs, 1, 1, 1), dtype=torch.long, device=self.device)
+        filenames, partitions, groups = self.meta
+        return (img, img_tf, tgt, tgt), filenames, (partitions, groups)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        return self._batch if self.resident else self._draw()
