@@ -72,12 +72,11 @@ def build_step(args, device, rank, world):
         getattr(model, "_" + name).requires_grad_(False)
     params = [p for p in model.parameters() if p.requires_grad]
     hparams = list(hook.parameters())
-    opt = torch.optim.RAdam([{"params": params}, {"params": hparams}], lr=5e-7 * 400, weight_decay=1e-5,
-                            capturable=True, foreach=True)
-    bucket = ddp.GradBucket(params + hparams) if world > 1 else None
+    flat = ddp.FlatParams(params + hparams)  # one flat parameter + one flat gradient bucket (all-reduced when N>1)
+    opt = torch.optim.RAdam([flat.param], lr=5e-7 * 400, weight_decay=1e-5, capturable=True, foreach=True)
     loader = SyntheticPretrainLoader(bs=args.bs, size=args.size, device=device, seed=1234 + rank, resident=True)
     epocher = PretrainEncoderEpocher(model=model, optimizer=opt, chain_dataloader=loader, num_batches=10 ** 9,
-                                     device=device, inference_until="Conv5", grad_bucket=bucket)
+                                     device=device, inference_until="Conv5", flat_params=flat)
     epocher.add_hooks([hook()])
     model.train()
     batch = next(loader)

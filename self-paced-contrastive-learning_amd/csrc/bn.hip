@@ -35,45 +35,45 @@ template <> __device__ __forceinline__ u32x4 pack<bf16_t>(const float* v) {
 }
 
 // ------------------------------------------------------------------------------------------------ statistics
-// One wave per channel: Chan-combine the per-tile (count, mean, M2) partials in double, fixed order.
+// One workgroup per channel: Chan-combine the per-tile (count, mean, M2) partials in double; threads stride the
+// tiles, then a butterfly inside each wave and a fixed-order combine of the 4 waves -> deterministic.
+__device__ __forceinline__ void chan_combine(double& n, double& mu, double& m2, double nb, double mb, double qb) {
+  const double nn = n + nb;
+  if (nn > 0.0) {  // symmetric form: both butterfly partners compute the identical result
+    const double d = mb - mu;
+    const double mu_new = (n * mu + nb * mb) / nn;
+    m2 = m2 + qb + d * d * n * nb / nn;
+    mu = mu_new;
+    n = nn;
+  }
+}
+
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int ntiles, int C, int CS,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float momentum, float eps,
                                                           float* running_mean, float* running_var, int64_t* nbt,
                                                           float* __restrict__ mean, float* __restrict__ invstd,
                                                           float* __restrict__ scale, float* __restrict__ shift) {
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (c >= CS) return;
-  if (c >= C) {
-    if (lane == 0) { mean[c] = 0.f; invstd[c] = 0.f; scale[c] = 0.f; shift[c] = 0.f; }
+  __shared__ double red[3][4];
+  const int c = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (c >= C) {  // channel padding
+    if (threadIdx.x == 0) { mean[c] = 0.f; invstd[c] = 0.f; scale[c] = 0.f; shift[c] = 0.f; }
     return;
   }
   double n = 0.0, mu = 0.0, m2 = 0.0;
-  for (int t = lane; t < ntiles; t += 64) {
+  for (int t = threadIdx.x; t < ntiles; t += 256) {
     const float* s = stats + ((size_t)t * CS + c) * 3;
-    const double nb = s[0], mb = s[1], qb = s[2];
-    if (nb > 0.0) {
-      const double nn = n + nb, d = mb - mu;
-      mu += d * nb / nn;
-      m2 += qb + d * d * n * nb / nn;
-      n = nn;
-    }
+    chan_combine(n, mu, m2, (double)s[0], (double)s[1], (double)s[2]);
   }
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const double nb = __shfl_xor(n, o, 64), mb = __shfl_xor(mu, o, 64), qb = __shfl_xor(m2, o, 64);
-    const double nn = n + nb;
-    if (nn > 0.0) {
-      // symmetric form so both partners compute the identical result
-      const double d = mb - mu;
-      const double mu_new = (n * mu + nb * mb) / nn;
-      m2 = m2 + qb + d * d * n * nb / nn;
-      mu = mu_new;
-      n = nn;
-    }
-  }
-  if (lane == 0) {
+  for (int o = 1; o < 64; o <<= 1)
+    chan_combine(n, mu, m2, __shfl_xor(n, o, 64), __shfl_xor(mu, o, 64), __shfl_xor(m2, o, 64));
+  if (lane == 0) { red[0][wave] = n; red[1][wave] = mu; red[2][wave] = m2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    n = red[0][0]; mu = red[1][0]; m2 = red[2][0];
+    for (int w = 1; w < 4; ++w) chan_combine(n, mu, m2, red[0][w], red[1][w], red[2][w]);
     const double var = m2 / n;
     const float is = 1.0f / sqrtf((float)var + eps);
     const float sc = gamma[c] * is;
@@ -163,73 +163,88 @@ __global__ __launch_bounds__(256) void bnrelu_fwd_kernel(const T* __restrict__ y
 }
 
 // ------------------------------------------------------------------------------------------------ backward
-// dz for the EPC channels of one position (window or pixel); shared by the reduce and apply passes so both see
-// bit-identical masks.  g = dact (+ dpool at the arg-max, first max in scan order like torch.max_pool2d).
-template <typename T, bool POOL, int K /* pixels per position: 4 or 1 */>
-struct BwdPos {
-  static constexpr int EPC = Chunk<T>::EPC;
-  float yv[K][EPC];
-  float dz[K][EPC];
+// One position = one 2x2 window (POOL) or one pixel, one 16-byte channel chunk.  The raw packed loads stay in
+// registers and the math runs channel by channel (element-outer), which keeps the live state small (occupancy):
+//   z = scale*y+shift;  g = dact (+ dpool at the window arg-max: first max in scan order like torch.max_pool2d)
+//   dz = g * [z > 0]
+template <typename T> struct Word;  // one 32-bit word of a packed chunk
+template <> struct Word<float> {
+  static constexpr int EPW = 1;
+  static __device__ __forceinline__ float get(uint32_t w, int) { return __uint_as_float(w); }
+  static __device__ __forceinline__ uint32_t make(const float* v) { return __float_as_uint(v[0]); }
+};
+template <> struct Word<bf16_t> {
+  static constexpr int EPW = 2;
+  static __device__ __forceinline__ float get(uint32_t w, int h) {
+    return __uint_as_float(h ? (w & 0xffff0000u) : (w << 16));
+  }
+  static __device__ __forceinline__ uint32_t make(const float* v) {
+    return (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+  }
+};
+
+template <typename T, bool POOL, int K>
+struct BwdRaw {
+  u32x4 ry[K], rg[K], rdp;
   size_t off[K];
-  bool valid[K];
+  bool valid[K], has_g, complete;
   __device__ __forceinline__ void load(const T* y, const T* dact, const T* dpool, int n, int oy, int ox, int H, int W,
-                                       int CS, int cc, const float* sc, const float* sh) {
-    float a[K][EPC], g[K][EPC];
+                                       int CS, int cc) {
+    constexpr int EPC = Chunk<T>::EPC;
+    has_g = dact != nullptr;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const int yy = POOL ? 2 * oy + (k >> 1) : oy, xx = POOL ? 2 * ox + (k & 1) : ox;
       valid[k] = yy < H && xx < W;
       off[k] = (((size_t)n * H + yy) * W + xx) * CS + cc * EPC;
-      if (valid[k]) unpack<T>(*(const u32x4*)(y + off[k]), yv[k]);
-      else {
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) yv[k][e] = 0.f;
-      }
-      if (valid[k] && dact != nullptr) unpack<T>(*(const u32x4*)(dact + off[k]), g[k]);
-      else {
-#pragma unroll
-        for (int e = 0; e < EPC; ++e) g[k][e] = 0.f;
-      }
-#pragma unroll
-      for (int e = 0; e < EPC; ++e) a[k][e] = valid[k] ? fmaf(sc[e], yv[k][e], sh[e]) : -1.f;  // z (pre-ReLU)
-    }
-    if (POOL && dpool != nullptr && oy < H / 2 && ox < W / 2) {  // complete window (floor semantics)
-      float dp[EPC];
-      unpack<T>(*(const u32x4*)(dpool + (((size_t)n * (H / 2) + oy) * (W / 2) + ox) * CS + cc * EPC), dp);
-#pragma unroll
-      for (int e = 0; e < EPC; ++e) {
-        int best = 0;
-        float m = fmaxf(a[0][e], 0.f);
-#pragma unroll
-        for (int k = 1; k < K; ++k) {
-          const float v = fmaxf(a[k][e], 0.f);
-          if (v > m) { m = v; best = k; }
-        }
-#pragma unroll
-        for (int k = 0; k < K; ++k) g[k][e] += (k == best) ? dp[e] : 0.f;
+      ry[k] = (u32x4){0u, 0u, 0u, 0u};
+      rg[k] = (u32x4){0u, 0u, 0u, 0u};
+      if (valid[k]) {
+        ry[k] = *(const u32x4*)(y + off[k]);
+        if (has_g) rg[k] = *(const u32x4*)(dact + off[k]);
       }
     }
+    complete = POOL && dpool != nullptr && oy < H / 2 && ox < W / 2;  // floor semantics of max_pool2d
+    rdp = (u32x4){0u, 0u, 0u, 0u};
+    if (complete) rdp = *(const u32x4*)(dpool + (((size_t)n * (H / 2) + oy) * (W / 2) + ox) * CS + cc * EPC);
+  }
+  // dz of channel element (wi, h) for the K pixels; yk = the raw y values
+  __device__ __forceinline__ void elem(int wi, int h, float sc, float sh, float* yk, float* dz) const {
+    float z[K];
+    int best = 0;
+    float m = 0.f;
 #pragma unroll
-    for (int k = 0; k < K; ++k)
+    for (int k = 0; k < K; ++k) {
+      yk[k] = Word<T>::get(ry[k][wi], h);
+      z[k] = valid[k] ? fmaf(sc, yk[k], sh) : -1.f;
+      const float a = fmaxf(z[k], 0.f);
+      if (k == 0) m = a;
+      else if (a > m) { m = a; best = k; }
+    }
+    const float dp = complete ? Word<T>::get(rdp[wi], h) : 0.f;
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) dz[k][e] = a[k][e] > 0.f ? g[k][e] : 0.f;
+    for (int k = 0; k < K; ++k) {
+      float g = Word<T>::get(rg[k][wi], h);
+      if (POOL) g += (k == best) ? dp : 0.f;
+      dz[k] = z[k] > 0.f ? g : 0.f;
+    }
   }
 };
 
 constexpr int BWD_MAX_WG = 1024;
 
 template <typename T, bool POOL>
-__global__ __launch_bounds__(256) void bnrelu_bwd_reduce_kernel(const T* __restrict__ y, const T* __restrict__ dact,
+__global__ __launch_bounds__(256, 4) void bnrelu_bwd_reduce_kernel(const T* __restrict__ y, const T* __restrict__ dact,
                                                                 const T* __restrict__ dpool, int N, int H, int W,
                                                                 int CS, const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd,
                                                                 const float* __restrict__ scale,
                                                                 const float* __restrict__ shift,
                                                                 float* __restrict__ partial /* [grid][2][CS] */) {
-  constexpr int EPC = Chunk<T>::EPC;
+  constexpr int EPC = Chunk<T>::EPC, EPW = Word<T>::EPW;
   constexpr int K = POOL ? 4 : 1;
   __shared__ float red[256][2 * EPC + 1];
-  const int CPC = CS / EPC;          // chunks per pixel (power of two, <= 256... CS<=1024)
+  const int CPC = CS / EPC;          // chunks per pixel
   const int PL = 256 / CPC;          // position lanes per workgroup
   const int cc = threadIdx.x % CPC, pl = threadIdx.x / CPC;
   const int OH = POOL ? (H + 1) / 2 : H, OW = POOL ? (W + 1) / 2 : W;  // ceil grid: every pixel is visited once
@@ -248,14 +263,20 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_reduce_kernel(const T* __restr
   if (pl < PL) {
     for (size_t pos = (size_t)blockIdx.x * PL + pl; pos < npos; pos += (size_t)gridDim.x * PL) {
       const int ox = (int)(pos % OW), oy = (int)((pos / OW) % OH), n = (int)(pos / ((size_t)OW * OH));
-      BwdPos<T, POOL, K> b;
-      b.load(y, dact, dpool, n, oy, ox, H, W, CS, cc, sc, sh);
+      BwdRaw<T, POOL, K> b;
+      b.load(y, dact, dpool, n, oy, ox, H, W, CS, cc);
 #pragma unroll
-      for (int k = 0; k < K; ++k)
+      for (int wi = 0; wi < 4; ++wi)
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) {  // invalid pixels carry dz == 0
-          s1[e] += b.dz[k][e];
-          s2[e] = fmaf(b.dz[k][e], (b.yv[k][e] - mu[e]) * is[e], s2[e]);
+        for (int h = 0; h < EPW; ++h) {
+          const int e = wi * EPW + h;
+          float yk[K], dz[K];
+          b.elem(wi, h, sc[e], sh[e], yk, dz);
+#pragma unroll
+          for (int k = 0; k < K; ++k) {  // invalid pixels carry dz == 0
+            s1[e] += dz[k];
+            s2[e] = fmaf(dz[k], (yk[k] - mu[e]) * is[e], s2[e]);
+          }
         }
     }
   }
@@ -274,11 +295,15 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_reduce_kernel(const T* __restr
   }
 }
 
-// dbeta = sum dz, dgamma = sum dz*yhat; k1 = dbeta/M, k2 = dgamma/M for the apply pass.  One wave per channel: lanes
-// stride over the workgroup partials (independent loads in flight), then a fixed-order butterfly -> deterministic.
+// dbeta = sum dz, dgamma = sum dz*yhat.  One wave per channel: lanes stride over the workgroup partials, then a
+// fixed-order butterfly -> deterministic.  For the apply pass the BN-backward is folded to  dy = scale*dz + A*y + B:
+//   training: A = -scale*invstd*dgamma/M,  B = -scale*dbeta/M - A*mean;   eval: A = B = 0
 __global__ __launch_bounds__(256) void bnrelu_bwd_fin_kernel(const float* __restrict__ partial, int nwg, int C, int CS,
-                                                             float M, int training, float* __restrict__ dgamma,
-                                                             float* __restrict__ dbeta, float* __restrict__ k12) {
+                                                             float M, int training, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd,
+                                                             const float* __restrict__ scale,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             float* __restrict__ ab) {
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (c >= CS) return;
@@ -294,20 +319,23 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_fin_kernel(const float* __rest
       dbeta[c] = s1;
       dgamma[c] = s2;
     }
-    k12[c] = training ? s1 / M : 0.f;
-    k12[CS + c] = training ? s2 / M : 0.f;
+    float A = 0.f, B = 0.f;
+    if (training) {
+      A = -scale[c] * invstd[c] * (s2 / M);
+      B = -scale[c] * (s1 / M) - A * mean[c];
+    }
+    ab[c] = A;
+    ab[CS + c] = B;
   }
 }
 
 template <typename T, bool POOL>
-__global__ __launch_bounds__(256) void bnrelu_bwd_apply_kernel(const T* __restrict__ y, const T* __restrict__ dact,
+__global__ __launch_bounds__(256, 3) void bnrelu_bwd_apply_kernel(const T* __restrict__ y, const T* __restrict__ dact,
                                                                const T* __restrict__ dpool, int N, int H, int W,
-                                                               int CS, const float* __restrict__ mean,
-                                                               const float* __restrict__ invstd,
-                                                               const float* __restrict__ scale,
+                                                               int CS, const float* __restrict__ scale,
                                                                const float* __restrict__ shift,
-                                                               const float* __restrict__ k12, T* __restrict__ dy) {
-  constexpr int EPC = Chunk<T>::EPC;
+                                                               const float* __restrict__ ab, T* __restrict__ dy) {
+  constexpr int EPC = Chunk<T>::EPC, EPW = Word<T>::EPW;
   constexpr int K = POOL ? 4 : 1;
   const int CPC = CS / EPC;
   const int OH = POOL ? (H + 1) / 2 : H, OW = POOL ? (W + 1) / 2 : W;
@@ -316,29 +344,34 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_apply_kernel(const T* __restri
     const int cc = (int)(idx % CPC);
     const size_t pos = idx / CPC;
     const int ox = (int)(pos % OW), oy = (int)((pos / OW) % OH), n = (int)(pos / ((size_t)OW * OH));
-    float sc[EPC], sh[EPC], mu[EPC], is[EPC], k1[EPC], k2[EPC];
+    float sc[EPC], sh[EPC], A[EPC], B[EPC];
 #pragma unroll
     for (int e = 0; e < EPC; e += 4) {
       *(f32x4*)&sc[e] = *(const f32x4*)(scale + cc * EPC + e);
       *(f32x4*)&sh[e] = *(const f32x4*)(shift + cc * EPC + e);
-      *(f32x4*)&mu[e] = *(const f32x4*)(mean + cc * EPC + e);
-      *(f32x4*)&is[e] = *(const f32x4*)(invstd + cc * EPC + e);
-      *(f32x4*)&k1[e] = *(const f32x4*)(k12 + cc * EPC + e);
-      *(f32x4*)&k2[e] = *(const f32x4*)(k12 + CS + cc * EPC + e);
+      *(f32x4*)&A[e] = *(const f32x4*)(ab + cc * EPC + e);
+      *(f32x4*)&B[e] = *(const f32x4*)(ab + CS + cc * EPC + e);
     }
-    BwdPos<T, POOL, K> b;
-    b.load(y, dact, dpool, n, oy, ox, H, W, CS, cc, sc, sh);
+    BwdRaw<T, POOL, K> b;
+    b.load(y, dact, dpool, n, oy, ox, H, W, CS, cc);
+    u32x4 out[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      if (!b.valid[k]) continue;
-      float o[EPC];
+    for (int wi = 0; wi < 4; ++wi) {
+      float o[K][EPW];
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) {
-        const float yh = (b.yv[k][e] - mu[e]) * is[e];
-        o[e] = sc[e] * (b.dz[k][e] - k1[e] - yh * k2[e]);
+      for (int h = 0; h < EPW; ++h) {
+        const int e = wi * EPW + h;
+        float yk[K], dz[K];
+        b.elem(wi, h, sc[e], sh[e], yk, dz);
+#pragma unroll
+        for (int k = 0; k < K; ++k) o[k][h] = fmaf(sc[e], dz[k], fmaf(A[e], yk[k], B[e]));
       }
-      *(u32x4*)(dy + b.off[k]) = pack<T>(o);
+#pragma unroll
+      for (int k = 0; k < K; ++k) out[k][wi] = Word<T>::make(o[k]);
     }
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      if (b.valid[k]) *(u32x4*)(dy + b.off[k]) = out[k];
   }
 }
 
@@ -362,7 +395,7 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
   int nwg = (int)((npos + PL - 1) / PL);
   if (nwg > BWD_MAX_WG) nwg = BWD_MAX_WG;
   float* partial = ws;                          // [nwg][2][CS]
-  float* k12 = ws + (size_t)BWD_MAX_WG * 2 * CS;  // [2][CS]
+  float* ab = ws + (size_t)BWD_MAX_WG * 2 * CS;  // [2][CS]: folded BN-backward coefficients
   const float M = (float)((size_t)N * H * W);
   if (pool) {
     hipLaunchKernelGGL((bnrelu_bwd_reduce_kernel<T, true>), dim3(nwg), dim3(256), 0, st, (const T*)y, (const T*)dact,
@@ -372,14 +405,14 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
                        (const T*)dpool, N, H, W, CS, mean, invstd, scale, shift, partial);
   }
   hipLaunchKernelGGL(bnrelu_bwd_fin_kernel, dim3(cdiv(CS, 4)), dim3(256), 0, st, (const float*)partial, nwg, C, CS,
-                     M, training, dgamma, dbeta, k12);
+                     M, training, mean, invstd, scale, dgamma, dbeta, ab);
   const int grid = stream_grid(npos * CPC);
   if (pool) {
     hipLaunchKernelGGL((bnrelu_bwd_apply_kernel<T, true>), dim3(grid), dim3(256), 0, st, (const T*)y, (const T*)dact,
-                       (const T*)dpool, N, H, W, CS, mean, invstd, scale, shift, (const float*)k12, (T*)dy);
+                       (const T*)dpool, N, H, W, CS, scale, shift, (const float*)ab, (T*)dy);
   } else {
     hipLaunchKernelGGL((bnrelu_bwd_apply_kernel<T, false>), dim3(grid), dim3(256), 0, st, (const T*)y, (const T*)dact,
-                       (const T*)dpool, N, H, W, CS, mean, invstd, scale, shift, (const float*)k12, (T*)dy);
+                       (const T*)dpool, N, H, W, CS, scale, shift, (const float*)ab, (T*)dy);
   }
   return 0;
 }
@@ -394,7 +427,7 @@ extern "C" int spcl_bn_finalize(const float* stats, int ntiles, int C, int CS, c
                                 void* stream) {
   SPCL_CHECK_ARG(stats && gamma && beta && mean && invstd && scale && shift, "bn_finalize: null pointer");
   SPCL_CHECK_ARG(ntiles > 0 && C > 0 && CS >= C, "bn_finalize: bad shape");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(CS, 4)), dim3(256), 0, (hipStream_t)stream, stats, ntiles, C, CS,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(CS), dim3(256), 0, (hipStream_t)stream, stats, ntiles, C, CS,
                      gamma, beta, momentum, eps, running_mean, running_var, num_batches_tracked, mean, invstd, scale,
                      shift);
   SPCL_LAUNCH_CHECK("bn_finalize");

@@ -8,17 +8,25 @@ namespace spcl {
 
 constexpr float kLeaky = 0.01f;
 
-// pooled[n][c] = mean_hw feat[n][hw][c]          (thread per channel: coalesced across c)
+// pooled[n][c] = mean_hw feat[n][hw][c].  Workgroup = (image, 64 channels): lanes = channels (coalesced), the 4 waves
+// take interleaved pixels and are combined through LDS in fixed order.
 template <typename T>
 __global__ __launch_bounds__(256) void avgpool_kernel(const T* __restrict__ feat, int HW, int C, int Cs,
                                                       float* __restrict__ pooled) {
+  __shared__ float red[4][64];
   const int n = blockIdx.y;
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const T* p = feat + (size_t)n * HW * Cs + c;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
   float s = 0.f;
-  for (int i = 0; i < HW; ++i) s += Elem<T>::load(p + (size_t)i * Cs);
-  pooled[(size_t)n * C + c] = s / (float)HW;
+  if (c < C) {
+    const T* p = feat + (size_t)n * HW * Cs + c;
+#pragma unroll 8
+    for (int i = wave; i < HW; i += 4) s += Elem<T>::load(p + (size_t)i * Cs);
+  }
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && c < C)
+    pooled[(size_t)n * C + c] = (((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane]) / (float)HW;
 }
 
 // y[n][o] = sum_k act(x[n][k]) * W[o][k] + b[o];  one wave per output column o, loops over rows n.
@@ -95,6 +103,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= K) return;
   float s = 0.f, sb = 0.f;
+#pragma unroll 8
   for (int n = 0; n < N; ++n) {
     const float gv = g[(size_t)n * O + o];
     float xv = x[(size_t)n * K + k];
@@ -106,18 +115,28 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
   if (k == 0) db[o] = sb;
 }
 
-// dx[n][k] = (sum_o g[n][o] W[o][k]) * (LEAKY_OUT ? leaky'(pre[n][k]) : 1)
+// dx[n][k] = (sum_o g[n][o] W[o][k]) * (LEAKY_OUT ? leaky'(pre[n][k]) : 1).  Workgroup = (row n, 64 columns k): the
+// 4 waves take interleaved o and are combined through LDS in fixed order.
 template <bool LEAKY_OUT>
 __global__ __launch_bounds__(256) void linear_dgrad_kernel(const float* __restrict__ g, const float* __restrict__ W,
                                                            const float* __restrict__ pre, int N, int K, int O,
                                                            float* __restrict__ dx) {
+  __shared__ float red[4][64];
   const int n = blockIdx.y;
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= K) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + lane;
   float s = 0.f;
-  for (int o = 0; o < O; ++o) s = fmaf(g[(size_t)n * O + o], W[(size_t)o * K + k], s);
-  if (LEAKY_OUT) s *= pre[(size_t)n * K + k] > 0.f ? 1.f : kLeaky;
-  dx[(size_t)n * K + k] = s;
+  if (k < K) {
+#pragma unroll 8
+    for (int o = wave; o < O; o += 4) s = fmaf(g[(size_t)n * O + o], W[(size_t)o * K + k], s);
+  }
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && k < K) {
+    float v = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    if (LEAKY_OUT) v *= pre[(size_t)n * K + k] > 0.f ? 1.f : kLeaky;
+    dx[(size_t)n * K + k] = v;
+  }
 }
 
 // dfeat[n][hw][c] = dpooled[n][c] / HW  (0 in the channel padding)
@@ -143,7 +162,7 @@ extern "C" int spcl_proj_forward(const void* feat, int dtype, int N, int HW, int
   SPCL_CHECK_ARG(N > 0 && HW > 0 && C > 0 && Cs >= C && out_dim > 0 && hid >= 0, "proj_forward: bad shape");
   SPCL_CHECK_ARG(hid == 0 || (w2 && b2 && pre), "proj_forward: mlp head needs w2/b2/pre");
   hipStream_t st = (hipStream_t)stream;
-  dim3 pg(cdiv(C, 256), N);
+  dim3 pg(cdiv(C, 64), N);
   if (dtype == SPCL_F32)
     hipLaunchKernelGGL(avgpool_kernel<float>, pg, dim3(256), 0, st, (const float*)feat, HW, C, Cs, pooled);
   else if (dtype == SPCL_BF16)
@@ -189,18 +208,18 @@ extern "C" int spcl_proj_backward(const float* dz, int dtype, int N, int HW, int
   if (hid > 0) {
     hipLaunchKernelGGL(linear_wgrad_kernel<true>, dim3(cdiv(hid, 256), out_dim), dim3(256), 0, st, go, pre, N, hid,
                        out_dim, dw2, db2);
-    hipLaunchKernelGGL(linear_dgrad_kernel<true>, dim3(cdiv(hid, 256), N), dim3(256), 0, st, go, w2, pre, N, hid,
+    hipLaunchKernelGGL(linear_dgrad_kernel<true>, dim3(cdiv(hid, 64), N), dim3(256), 0, st, go, w2, pre, N, hid,
                        out_dim, dpre);
     hipLaunchKernelGGL(linear_wgrad_kernel<false>, dim3(cdiv(C, 256), hid), dim3(256), 0, st, (const float*)dpre,
                        pooled, N, C, hid, dw1, db1);
     if (dfeat)
-      hipLaunchKernelGGL(linear_dgrad_kernel<false>, dim3(cdiv(C, 256), N), dim3(256), 0, st, (const float*)dpre, w1,
+      hipLaunchKernelGGL(linear_dgrad_kernel<false>, dim3(cdiv(C, 64), N), dim3(256), 0, st, (const float*)dpre, w1,
                          (const float*)nullptr, N, C, hid, dpool);
   } else {
     hipLaunchKernelGGL(linear_wgrad_kernel<false>, dim3(cdiv(C, 256), out_dim), dim3(256), 0, st, go, pooled, N, C,
                        out_dim, dw1, db1);
     if (dfeat)
-      hipLaunchKernelGGL(linear_dgrad_kernel<false>, dim3(cdiv(C, 256), N), dim3(256), 0, st, go, w1,
+      hipLaunchKernelGGL(linear_dgrad_kernel<false>, dim3(cdiv(C, 64), N), dim3(256), 0, st, go, w1,
                          (const float*)nullptr, N, C, out_dim, dpool);
   }
   if (dfeat) {

@@ -3,9 +3,10 @@
 // GEMM per tap: D[m=ci][n=co] += A[m][k=pixel] * B[k=pixel][n]; both operands are pixel-major NHWC tiles in LDS, so
 // the MFMA operands (K = pixels) are read TRANSPOSED: bf16 uses ds_read_b64_tr_b16 (hardware transpose, 4 pixels x
 // 16 channels per 16-lane group), f32 reads one dword per lane.  The 9 taps are address offsets into the shared
-// input halo tile.  Work split: workgroup = (pixel split, 32x32 / 16x16 channel block); its 4 waves take different
-// pixel k-steps of every tile and are reduced through LDS at the end; workgroup partials go to a workspace and a
-// second kernel sums them in fixed order (deterministic, no float atomics) into the OIHW f32 gradient.
+// input halo tile.  Work split: workgroup = (pixel split, 32x32 / 16x16 channel block); its 4 waves own different
+// (tap, ci-tile) output units (no cross-wave reduction), tiles are double-buffered in LDS with the next tile's global
+// loads issued before the MFMAs of the current one; workgroup partials go to a workspace and a second kernel sums
+// them in fixed order (deterministic, no float atomics) into the OIHW f32 gradient.
 #include "common.hpp"
 
 namespace spcl {
@@ -29,19 +30,13 @@ struct WgradArgs {
 
 // relu(scale*v+shift) on one 16-byte chunk (same arithmetic as conv.hip's staging so masks agree bit-for-bit)
 template <typename T> __device__ __forceinline__ u32x4 wg_bnrelu_chunk(u32x4 raw, const float* sc, const float* sh);
-template <> __device__ __forceinline__ u32x4 wg_bnrelu_chunk<float>(u32x4 raw, const float* sc, const float* sh) {
+template <> __device__ __forceinline__ u32x4 wg_bnrelu_chunk<float>(u32x4 raw, const float* s, const float* b) {
   f32x4 v = __builtin_bit_cast(f32x4, raw);
-  f32x4 s = *(const f32x4*)sc, b = *(const f32x4*)sh;
 #pragma unroll
   for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(s[e], v[e], b[e]), 0.f);
   return __builtin_bit_cast(u32x4, v);
 }
-template <> __device__ __forceinline__ u32x4 wg_bnrelu_chunk<bf16_t>(u32x4 raw, const float* sc, const float* sh) {
-  float s[8], b[8];
-  *(f32x4*)&s[0] = *(const f32x4*)sc;
-  *(f32x4*)&s[4] = *(const f32x4*)(sc + 4);
-  *(f32x4*)&b[0] = *(const f32x4*)sh;
-  *(f32x4*)&b[4] = *(const f32x4*)(sh + 4);
+template <> __device__ __forceinline__ u32x4 wg_bnrelu_chunk<bf16_t>(u32x4 raw, const float* s, const float* b) {
   u32x4 out;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -95,53 +90,76 @@ template <> struct Frag<float> {
 };
 
 template <typename T, int MI, int NJ>
-__global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(WgradArgs a) {
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
   constexpr int EPC = Chunk<T>::EPC;
   constexpr int CIB = 16 * MI, COB = 16 * NJ;
   constexpr int XS = CIB * (int)sizeof(T), DS = COB * (int)sizeof(T);  // LDS bytes per pixel
   constexpr int XCP = CIB / EPC, DCP = COB / EPC;                       // 16-byte chunks per pixel
-  constexpr int X_BYTES = WG_NHALO * XS;
+  constexpr int X_BYTES = WG_NHALO * XS, D_BYTES = WG_NPIX * DS, BUF_BYTES = X_BYTES + D_BYTES;
   constexpr int KSTEPS = WG_NPIX / Frag<T>::KPIX;
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  unsigned char* ldx = lds;
-  unsigned char* ldd = lds + X_BYTES;
-  const unsigned ldx_base = (unsigned)(uintptr_t)(unsigned char __attribute__((address_space(3)))*)ldx;
-  const unsigned ldd_base = (unsigned)(uintptr_t)(unsigned char __attribute__((address_space(3)))*)ldd;
+  constexpr int NX = (WG_NHALO * XCP + 255) / 256;  // staged 16-byte chunks per thread
+  constexpr int ND = (WG_NPIX * DCP + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 x [x halo | dy] (double buffer)
+  const unsigned lds_base = (unsigned)(uintptr_t)(unsigned char __attribute__((address_space(3)))*)lds;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int blk = blockIdx.y;
   const int bci = blk / a.nblk_co, bco = blk - bci * a.nblk_co;
   const int ci0 = bci * CIB, co0 = bco * COB;
+  // this thread always stages the same channel chunk (256 % XCP == 0): its BN scale/shift live in registers
+  const int xch = threadIdx.x % XCP, dch = threadIdx.x % DCP;
+  float sc[EPC], sh[EPC];
+  if (a.in_mode == 1) {
+#pragma unroll
+    for (int e = 0; e < EPC; e += 4) {
+      *(f32x4*)&sc[e] = *(const f32x4*)(a.in_scale + ci0 + xch * EPC + e);
+      *(f32x4*)&sh[e] = *(const f32x4*)(a.in_shift + ci0 + xch * EPC + e);
+    }
+  }
 
-  f32x4 acc[9][MI][NJ];
+  // wave w owns the output units u = w, w+4, ... (u = tap*MI + ci-tile): no cross-wave reduction, every wave walks
+  // all pixel k-steps of the tile for its own units
+  constexpr int NUNITS = 9 * MI, UPW = (NUNITS + 3) / 4;
+  f32x4 acc[UPW][NJ];
+  int uoff[UPW];  // LDS byte offset of the unit's tap shift + channel tile inside the x halo image
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int uu = 0; uu < UPW; ++uu) {
+    int u = wave + 4 * uu;
+    if (u >= NUNITS) u = NUNITS - 1;  // clamped duplicate: computed, never written
+    const int tap = u / MI, m = u - tap * MI;
+    const int ky = tap / 3, kx = tap - 3 * ky;
+    uoff[uu] = (ky * WG_HW + kx) * XS + m * 16 * (int)sizeof(T);
 #pragma unroll
-    for (int m = 0; m < MI; ++m)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) acc[t][m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[uu][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
 
+  u32x4 rx[NX], rd[ND];
+  unsigned xmask = 0;  // staged x chunks that are inside the image (zero padding must stay zero after BN+ReLU)
   const int tpi = a.tilesX * a.tilesY;
-  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+
+  // ---- global -> registers (issued one tile ahead of the MFMAs: T14 issue-early / write-late)
+  auto load_tile = [&](int tile) {
     const int n = tile / tpi;
     const int trem = tile - n * tpi;
     const int ty = trem / a.tilesX, tx = trem - ty * a.tilesX;
     const int y0 = ty * WG_TH, x0 = tx * WG_TW;
-    __syncthreads();
-    // ---- stage x halo [18*18][CIB] (with the producer's BN-apply+ReLU fused) and dy [256][COB]; OOB -> 0
-    for (int idx = threadIdx.x; idx < WG_NHALO * XCP; idx += 256) {
-      const int q = idx / XCP, ch = idx - q * XCP;
+    xmask = 0;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      const int q = idx / XCP;
       const int hy = q / WG_HW, hx = q - hy * WG_HW;
       const int gy = y0 + hy - 1, gx = x0 + hx - 1;
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+      if (idx < WG_NHALO * XCP && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
         const size_t pix = ((size_t)n * a.H + gy) * a.W + gx;
+        xmask |= 1u << i;
         if (a.in_mode == 2) {
           const float* src = (const float*)a.x + pix * a.CinS;
           float e[EPC];
 #pragma unroll
           for (int k = 0; k < EPC; ++k) {
-            const int c = ch * EPC + k;
+            const int c = xch * EPC + k;
             e[k] = c < a.CinS ? src[c] : 0.f;
           }
           if (sizeof(T) == 4) {
@@ -152,28 +170,56 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(WgradArgs a) {
               v[k] = (uint32_t)f32_to_bf16(e[(2 * k) % EPC]) | ((uint32_t)f32_to_bf16(e[(2 * k + 1) % EPC]) << 16);
           }
         } else {
-          const int c0 = ci0 + ch * EPC;
-          v = *(const u32x4*)((const T*)a.x + pix * a.CinS + c0);
-          if (a.in_mode == 1) v = wg_bnrelu_chunk<T>(v, a.in_scale + c0, a.in_shift + c0);
+          v = *(const u32x4*)((const T*)a.x + pix * a.CinS + ci0 + xch * EPC);
         }
       }
-      *(u32x4*)(ldx + q * XS + ch * 16) = v;
+      rx[i] = v;
     }
-    for (int idx = threadIdx.x; idx < WG_NPIX * DCP; idx += 256) {
-      const int p = idx / DCP, ch = idx - p * DCP;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      const int p = idx / DCP;
       const int gy = y0 + (p >> 4), gx = x0 + (p & 15);
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (gy < a.H && gx < a.W) {
+      if (idx < WG_NPIX * DCP && gy < a.H && gx < a.W) {
         const size_t pix = ((size_t)n * a.H + gy) * a.W + gx;
-        v = *(const u32x4*)((const T*)a.dy + pix * a.CoutS + co0 + ch * EPC);
+        v = *(const u32x4*)((const T*)a.dy + pix * a.CoutS + co0 + dch * EPC);
       }
-      *(u32x4*)(ldd + p * DS + ch * 16) = v;
+      rd[i] = v;
     }
-    __syncthreads();
+  };
+  // ---- registers -> LDS buffer (fused BN-apply + ReLU of the producer layer on the in-image chunks)
+  auto store_tile = [&](int buf) {
+    unsigned char* bx = lds + buf * BUF_BYTES;
+    unsigned char* bd = bx + X_BYTES;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      if (idx < WG_NHALO * XCP) {
+        u32x4 v = rx[i];
+        if (a.in_mode == 1 && (xmask & (1u << i))) v = wg_bnrelu_chunk<T>(v, sc, sh);
+        *(u32x4*)(bx + (idx / XCP) * XS + xch * 16) = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int idx = threadIdx.x + 256 * i;
+      if (idx < WG_NPIX * DCP) *(u32x4*)(bd + (idx / DCP) * DS + dch * 16) = rd[i];
+    }
+  };
 
-    // ---- each wave takes k-steps ks = wave, wave+4, ...
-#pragma unroll 1
-    for (int ks = wave; ks < KSTEPS; ks += 4) {
+  int tile = blockIdx.x;
+  int buf = 0;
+  if (tile < a.ntiles) load_tile(tile);
+  while (tile < a.ntiles) {
+    store_tile(buf);
+    __syncthreads();  // also orders this buffer's previous readers (two iterations back) before the next overwrite
+    const int next = tile + gridDim.x;
+    if (next < a.ntiles) load_tile(next);
+
+    const unsigned ldx_base = lds_base + buf * BUF_BYTES, ldd_base = ldx_base + X_BYTES;
+#pragma unroll 2
+    for (int ks = 0; ks < KSTEPS; ++ks) {
       const int p = Frag<T>::lane_pixel(ks, lane);  // a k-step's pixels never straddle a tile row (TW = 16)
       const unsigned xa = ldx_base + (unsigned)(((p >> 4) * WG_HW + (p & 15)) * XS + Frag<T>::lane_chan_bytes(lane));
       const unsigned da = ldd_base + (unsigned)(p * DS + Frag<T>::lane_chan_bytes(lane));
@@ -181,41 +227,30 @@ __global__ __launch_bounds__(256, 1) void conv3x3_wgrad_kernel(WgradArgs a) {
 #pragma unroll
       for (int j = 0; j < NJ; ++j) bf[j] = Frag<T>::load(da, j * 16 * (int)sizeof(T), DS);
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int ky = t / 3, kx = t - 3 * ky;
+      for (int uu = 0; uu < UPW; ++uu) {
+        typename Frag<T>::type af = Frag<T>::load(xa + uoff[uu], 0, XS);
 #pragma unroll
-        for (int m = 0; m < MI; ++m) {
-          typename Frag<T>::type af = Frag<T>::load(xa, (ky * WG_HW + kx) * XS + m * 16 * (int)sizeof(T), XS);
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) acc[t][m][j] = Frag<T>::mfma(af, bf[j], acc[t][m][j]);
-        }
+        for (int j = 0; j < NJ; ++j) acc[uu][j] = Frag<T>::mfma(af, bf[j], acc[uu][j]);
       }
     }
+    buf ^= 1;
+    tile = next;
   }
 
-  // ---- reduce the 4 waves through LDS (wave 0 stores, 1..2 add, 3 adds and writes the workgroup partial)
-  // D layout: lane holds n = co (lane&15), m = ci 4g+r.  slab layout [9][CIB][COB] f32
-  float* red = (float*)lds;
+  // ---- every wave writes its own units of the workgroup partial.  D layout: lane holds n = co (lane&15),
+  // m = ci 4g+r.  slab layout [9][CIB][COB] f32
   const int r16 = lane & 15, g = lane >> 4;
   float* out = a.partial + ((size_t)blockIdx.x * gridDim.y + blk) * (9 * CIB * COB);
-#pragma unroll 1
-  for (int w = 0; w < 4; ++w) {
-    __syncthreads();
-    if (wave == w) {
 #pragma unroll
-      for (int t = 0; t < 9; ++t)
+  for (int uu = 0; uu < UPW; ++uu) {
+    const int u = wave + 4 * uu;
+    if (u < NUNITS) {
+      const int tap = u / MI, m = u - tap * MI;
 #pragma unroll
-        for (int m = 0; m < MI; ++m)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
-          for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int off = (t * CIB + m * 16 + 4 * g + r) * COB + j * 16 + r16;
-              float v = acc[t][m][j][r];
-              if (w > 0) v += red[off];
-              if (w < 3) red[off] = v;
-              else out[off] = v;
-            }
+        for (int r = 0; r < 4; ++r)
+          out[(tap * CIB + m * 16 + 4 * g + r) * COB + j * 16 + r16] = acc[uu][j][r];
     }
   }
 }
@@ -257,7 +292,7 @@ struct WgradPlan {
 static WgradPlan wgrad_plan(int N, int H, int W, int CinK, int CoutS) {
   WgradPlan p;
   p.NJ = CoutS >= 32 ? 2 : 1;
-  p.MI = (p.NJ == 1 && CinK >= 32) ? 2 : 1;  // <2,2> (144 accumulator regs + fragments) spills: not built
+  p.MI = CinK >= 32 ? 2 : 1;
   p.nblk_ci = CinK / (16 * p.MI);
   p.nblk_co = CoutS / (16 * p.NJ);
   p.tilesX = cdiv(W, WG_TW);
@@ -275,9 +310,7 @@ static WgradPlan wgrad_plan(int N, int H, int W, int CinK, int CoutS) {
 template <typename T, int MI, int NJ>
 static void launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t st) {
   constexpr int CIB = 16 * MI, COB = 16 * NJ;
-  size_t lds = (size_t)WG_NHALO * CIB * sizeof(T) + (size_t)WG_NPIX * COB * sizeof(T);
-  const size_t red = (size_t)9 * CIB * COB * sizeof(float);
-  if (red > lds) lds = red;
+  size_t lds = 2 * ((size_t)WG_NHALO * CIB * sizeof(T) + (size_t)WG_NPIX * COB * sizeof(T));
   if (lds > 65536)
     (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_kernel<T, MI, NJ>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
@@ -288,7 +321,8 @@ template <typename T>
 static void launch_wgrad_t(const WgradArgs& a, const WgradPlan& p, hipStream_t st) {
   if (p.MI == 1 && p.NJ == 1) launch_wgrad<T, 1, 1>(a, p, st);
   else if (p.MI == 1 && p.NJ == 2) launch_wgrad<T, 1, 2>(a, p, st);
-  else launch_wgrad<T, 2, 1>(a, p, st);
+  else if (p.MI == 2 && p.NJ == 1) launch_wgrad<T, 2, 1>(a, p, st);
+  else launch_wgrad<T, 2, 2>(a, p, st);
 }
 
 }  // namespace spcl

@@ -63,6 +63,40 @@ class GradBucket:
         return self.flat
 
 
+class FlatParams(GradBucket):
+    """All trainable parameters as views of ONE flat fp32 tensor, optimised as a single ``nn.Parameter``.
+
+    The optimizer (torch RAdam, host code per the north star) then runs ~10 fused kernels per step instead of
+    ~10 per parameter tensor, and the flat gradient bucket it consumes is exactly the buffer the RCCL all-reduce
+    works on.  Module ``state_dict``s are unaffected (the parameters keep their identity, only their storage moves)."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None):
+        super().__init__(params, process_group)
+        self.data = torch.empty(self.numel, dtype=torch.float32, device=self.flat.device)
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                v = self.data[off:off + p.numel()].view_as(p)
+                v.copy_(p.data)
+                p.data = v
+                off += p.numel()
+        self.param = torch.nn.Parameter(self.data)
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+        self.param.grad = None
+
+    def reduce(self):
+        """module grads -> flat bucket -> (all-reduce mean across ranks) -> ``self.param.grad``."""
+        self.gather()
+        if is_distributed():
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            self.flat.div_(dist.get_world_size(self.group))
+        self.param.grad = self.flat
+        return self.flat
+
+
 @torch.no_grad()
 def broadcast_state(*modules: torch.nn.Module, src: int = 0):
     """Rank ``src``'s parameters and buffers (BN running statistics) to every rank, once, before training."""

@@ -31,7 +31,7 @@ class PretrainEncoderEpocher:
 
     def __init__(self, *, model: nn.Module, optimizer, chain_dataloader: Iterable, num_batches: int, cur_epoch=0,
                  device="cuda", inference_until: str = "Conv5", grad_bucket: Optional[_ddp.GradBucket] = None,
-                 scaler=None, **kwargs) -> None:
+                 flat_params: Optional[_ddp.FlatParams] = None, **kwargs) -> None:
         self._model = model
         self._optimizer = optimizer
         self._chain_dataloader = chain_dataloader
@@ -41,6 +41,7 @@ class PretrainEncoderEpocher:
         self._inference_until = inference_until
         self._affine_transformer = TensorRandomFlip(axis=[1, 2], threshold=0.8)
         self._grad_bucket = grad_bucket
+        self._flat_params = flat_params  # optimizer steps ONE flat parameter (ddp.FlatParams) when given
         self._hooks = []
         self.meters = MeterInterface(default_focus=self.meter_focus)
         with self.meters.focus_on(self.meter_focus):
@@ -123,10 +124,15 @@ class PretrainEncoderEpocher:
             partition_group=unl_partition, unlabeled_filename=unlabeled_filename,
             affine_transformer=self._affine_transformer)
         total_loss = reg_loss
-        self._optimizer.zero_grad(set_to_none=True)
-        total_loss.backward()
-        if self._grad_bucket is not None:
-            self._grad_bucket.allreduce()
+        if self._flat_params is not None:
+            self._flat_params.zero_grad()
+            total_loss.backward()
+            self._flat_params.reduce()
+        else:
+            self._optimizer.zero_grad(set_to_none=True)
+            total_loss.backward()
+            if self._grad_bucket is not None:
+                self._grad_bucket.allreduce()
         self._optimizer.step()
         if self.on_master():
             self.meters["reg_loss"].add(reg_loss.detach())

@@ -62,7 +62,7 @@ class PretrainEncoderTrainer:
         self.__hooks__ = nn.ModuleList()
         self.forward_until = None
         self._cur_epoch, self._start_epoch = 0, 0
-        self._optimizer = self._scheduler = self._bucket = None
+        self._optimizer = self._scheduler = self._flat = None
         self.history = []
 
     # trainer/base.py:49-58
@@ -79,18 +79,17 @@ class PretrainEncoderTrainer:
         _ddp.broadcast_state(self._model, self.__hooks__)
         params = [p for p in self._model.parameters() if p.requires_grad]
         hook_params = [p for h in self.__hooks__ for p in h.parameters()]
-        self._optimizer = torch.optim.RAdam(params, **self._optim_cfg)
-        if hook_params:
-            self._optimizer.add_param_group({"params": hook_params, **self._optim_cfg})
+        # the reference gives model and hook parameters two groups with identical lr / weight decay
+        # (trainer/base.py:62-68): one flat parameter is the same optimisation problem
+        self._flat = _ddp.FlatParams(params + hook_params)
+        self._optimizer = torch.optim.RAdam([self._flat.param], **self._optim_cfg)
         self._scheduler = WarmupCosine(self._optimizer, max_epoch=self._max_epoch, **self._sched_cfg)
-        if _ddp.is_distributed():
-            self._bucket = _ddp.GradBucket(params + hook_params)
 
     def _create_tra_epoch(self):
         epocher = PretrainEncoderEpocher(model=self._model, optimizer=self._optimizer,
                                          chain_dataloader=self._chain_dataloader, num_batches=self._num_batches,
                                          cur_epoch=self._cur_epoch, device=self._device,
-                                         inference_until=self.forward_until or "Conv5", grad_bucket=self._bucket)
+                                         inference_until=self.forward_until or "Conv5", flat_params=self._flat)
         epocher.add_hooks([h() for h in self.__hooks__])
         epocher.init()
         return epocher
