@@ -1,0 +1,89 @@
+"""CPU-only: the C-ABI shared library loads (no GPU needed) and exports every symbol include/spcl_hip.h declares;
+the ctypes signature table in native.py covers exactly those symbols; host-only entry points behave."""
+import ctypes
+import os
+import re
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(REPO, "include", "spcl_hip.h")
+LIB = os.path.join(REPO, "self-paced-contrastive-learning_amd", "lib", "libspcl_hip.so")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(spcl_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(LIB):
+        import __graft_entry__
+        __graft_entry__.build()
+    return ctypes.CDLL(LIB)
+
+
+def test_header_declares_the_expected_families():
+    syms = declared_symbols()
+    for fam in ("spcl_supcon_forward", "spcl_supcon_backward", "spcl_supcon_materialize", "spcl_proj_forward",
+                "spcl_proj_backward", "spcl_conv3x3_forward", "spcl_conv3x3_wgrad", "spcl_conv_pack_weights",
+                "spcl_bn_finalize", "spcl_bnrelu_pool_forward", "spcl_bnrelu_pool_backward"):
+        assert fam in syms
+
+
+def test_library_exports_every_declared_symbol(lib):
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    assert not missing, missing
+
+
+def test_native_signature_table_matches_header():
+    import spcl_amd  # noqa: F401
+    from spcl_amd import native
+    assert sorted(native._SIGNATURES) == declared_symbols()
+    L = native.lib()
+    assert native.call("spcl_abi_version") >= 1
+    assert L.spcl_last_error() is not None
+
+
+def test_host_only_entry_points(lib):
+    lib.spcl_supcon_workspace_bytes.restype = ctypes.c_size_t
+    lib.spcl_conv_packed_elems.restype = ctypes.c_size_t
+    lib.spcl_conv_wgrad_workspace_bytes.restype = ctypes.c_size_t
+    assert lib.spcl_supcon_workspace_bytes(32, 256) > 64 * 256 * 4
+    assert lib.spcl_supcon_workspace_bytes(32, 1000) == 0  # proj dim > 256 unsupported
+    # 16->16 bf16 forward pack: 1 slab x 5 k-steps x 1 n-tile x 64 lanes x 8 elements
+    assert lib.spcl_conv_packed_elems(16, 16, 0, 1) == 5 * 64 * 8
+    assert lib.spcl_conv_packed_elems(1, 16, 0, 1) == 5 * 64 * 8   # image layer padded to 16 input channels
+    assert lib.spcl_conv_num_tiles(64, 224, 224) == 64 * 16 * 16  # 14x14 tiles
+    assert lib.spcl_conv_num_tiles(2, 30, 30) == 2 * 2 * 2        # 16x16 tiles
+    assert lib.spcl_conv_wgrad_workspace_bytes(64, 224, 224, 16, 16) > 0
+    assert lib.spcl_conv_wgrad_workspace_bytes(64, 224, 224, 10, 16) == 0
+
+
+def test_argument_validation_reports_errors(lib):
+    lib.spcl_last_error.restype = ctypes.c_char_p
+    rc = lib.spcl_supcon_forward(None, None, None, None, 4, 16, ctypes.c_float(0.07), 0, ctypes.c_float(1.0), 0, None,
+                                 None, None)
+    assert rc == -1 and b"null" in lib.spcl_last_error()
+
+
+def test_product_path_has_no_cpu_fallback():
+    import torch
+    import spcl_amd  # noqa: F401
+    from spcl_amd.contrastyou.losses.contrast_loss3 import SupConLoss1
+    from spcl_amd.semi_seg.arch import UNet
+    z = torch.nn.functional.normalize(torch.randn(4, 16), dim=1)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        SupConLoss1()(z, z, target=[0, 1, 0, 1])
+    with pytest.raises(RuntimeError, match="MI355X"):
+        UNet(input_dim=1, num_classes=4)(torch.zeros(1, 1, 16, 16), until="Conv1")
+    # and nothing of the product imports the oracle
+    pkg = os.path.join(REPO, "self-paced-contrastive-learning_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert "oracle" not in src.replace("oracle.", "").replace("oracle", "oracle") or \
+                    "import oracle" not in src and "from oracle" not in src, os.path.join(root, f)

@@ -1,0 +1,95 @@
+"""CPU-only, world_size 2 over gloo: the N>1 exchange step (flat gradient bucket all-reduce, parameter/buffer
+broadcast, flat-parameter optimizer) behaves like single-process training on the concatenated batch."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import spcl_amd  # noqa: F401
+    from spcl_amd import ddp
+    torch.manual_seed(100 + rank)  # different init per rank -> broadcast must equalise
+    model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.BatchNorm1d(5), torch.nn.Linear(5, 2))
+    ddp.broadcast_state(model)
+    w0 = torch.cat([p.detach().flatten() for p in model.parameters()])
+    flat = ddp.FlatParams(model.parameters())
+    assert flat.nbytes == 4 * sum(p.numel() for p in model.parameters())
+    # parameters are now views of one tensor; values unchanged
+    assert torch.equal(torch.cat([p.detach().flatten() for p in model.parameters()]), w0)
+    assert flat.param.data_ptr() == next(model.parameters()).data_ptr()
+    opt = torch.optim.SGD([flat.param], lr=0.1)
+    g = torch.Generator().manual_seed(7)
+    X, Y = torch.randn(8, 6, generator=g), torch.randn(8, 2, generator=g)
+    xs, ys = X[rank * 4:(rank + 1) * 4], Y[rank * 4:(rank + 1) * 4]
+    model.eval()  # BN in eval so that per-rank statistics do not enter the comparison
+    flat.zero_grad()
+    loss = ((model(xs) - ys) ** 2).mean()
+    loss.backward()
+    red = flat.reduce().clone()
+    opt.step()
+    # plain GradBucket gives the same averaged gradients
+    m2 = torch.nn.Linear(3, 2)
+    ddp.broadcast_state(m2)
+    b = ddp.GradBucket(m2.parameters())
+    (m2(torch.full((1, 3), float(rank + 1))).sum()).backward()
+    b.allreduce()
+    q.put((rank, w0.tolist(), red.tolist(), torch.cat([p.detach().flatten() for p in model.parameters()]).tolist(),
+           m2.weight.grad.tolist(), ddp.on_master()))  # plain lists: no shared-memory handles to outlive the worker
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_flat_bucket_allreduce_matches_single_process():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=90) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    res = [(r, torch.tensor(a), torch.tensor(b), torch.tensor(c), torch.tensor(d), m) for r, a, b, c, d, m in res]
+    (r0, w0a, g0, p0, mg0, master0), (r1, w0b, g1, p1, mg1, master1) = res
+    assert torch.equal(w0a, w0b)            # broadcast equalised the initial weights
+    assert torch.allclose(g0, g1)           # every rank holds the same averaged gradient
+    assert torch.allclose(p0, p1)           # and the same updated parameters
+    assert master0 and not master1
+    assert torch.allclose(mg0, torch.full((2, 3), 1.5)) and torch.allclose(mg0, mg1)  # mean of 1 and 2
+    # single-process reference on the concatenated batch: mean over 8 samples == mean of the two rank means
+    torch.manual_seed(100)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.BatchNorm1d(5), torch.nn.Linear(5, 2)).eval()
+    g = torch.Generator().manual_seed(7)
+    X, Y = torch.randn(8, 6, generator=g), torch.randn(8, 2, generator=g)
+    ((model(X) - Y) ** 2).mean().backward()
+    ref = torch.cat([p.grad.flatten() for p in model.parameters()])
+    assert torch.allclose(g0, ref, atol=1e-6)
+
+
+def test_single_process_paths_are_noops():
+    import spcl_amd  # noqa: F401
+    from spcl_amd import ddp
+    assert not ddp.is_distributed() and ddp.on_master()
+    m = torch.nn.Linear(4, 3)
+    ddp.broadcast_state(m)
+    b = ddp.GradBucket(m.parameters())
+    m(torch.ones(2, 4)).sum().backward()
+    g = m.weight.grad.clone()
+    flat = b.allreduce()
+    assert flat.numel() == 15 and torch.equal(m.weight.grad, g) and m.weight.grad.data_ptr() == b.views[0].data_ptr()

@@ -1,0 +1,166 @@
+"""CPU-only tests of the host-side mirror: schedule, label generators, flips, meters, hook plumbing, state_dict
+keys, trainer schedule.  (Compute classes raise on CPU tensors by design; only their host logic is exercised.)"""
+import math
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import spcl_amd  # noqa: F401
+from oracle import spcl_oracle as O
+from spcl_amd.contrastyou.hooks.base import CombineEpochHook, EpocherHook, TrainerHook
+from spcl_amd.contrastyou.meters import AverageValueMeter, MeterInterface
+from spcl_amd.semi_seg.arch import SingleFeatureExtractor, UNet
+from spcl_amd.semi_seg.epochers.helper import FixRandomSeed, TensorRandomFlip
+from spcl_amd.semi_seg.hooks import PScheduler, create_infonce_hooks, create_sp_infonce_hooks, feature_until_from_hooks
+from spcl_amd.semi_seg.hooks.utils import get_label
+from spcl_amd.semi_seg.trainers import WarmupCosine
+
+
+def test_pscheduler_matches_oracle_and_closed_form():
+    s, o = PScheduler(80, 3, 70, 0.5), O.PScheduler(80, 3, 70, 0.5)
+    for e in range(80):
+        assert s.value == pytest.approx(o.value, rel=1e-12)
+        assert s.value == pytest.approx(3 + 67 * math.sqrt(e / 80), rel=1e-12)
+        s.step()
+        o.step()
+
+
+def test_label_generators_match_oracle():
+    groups = ["patient004_00", "patient004_01", "patient001_00", "patient010_01", "patient001_01"]
+    parts = ["2", "0", "1", "0", "2"]
+    for on in ("partition", "patient", "cycle", "self"):
+        assert get_label(on, "acdc", parts, groups) == O.get_label(on, "acdc", parts, groups)
+    for on in ("partition", "patient", "self"):
+        assert get_label(on, "prostate", parts, ["Case00_1", "Case03_0", "Case00_2", "Case01_1", "Case03_3"]) == \
+            O.get_label(on, "prostate", parts, ["Case00_1", "Case03_0", "Case00_2", "Case01_1", "Case03_3"])
+    with pytest.raises(NotImplementedError):
+        get_label("cycle", "prostate", parts, groups)
+    with pytest.raises(NotImplementedError):
+        get_label("partition", "spleen", parts, groups)
+
+
+def test_flip_batched_equals_per_sample_and_restores_rng_state():
+    f = TensorRandomFlip(axis=[1, 2], threshold=0.8)
+    x = torch.arange(6 * 2 * 4 * 5.).reshape(6, 2, 4, 5)
+    random.seed(99)
+    before = random.random()
+    random.seed(99)
+    with FixRandomSeed(1234):
+        a = torch.stack([f(s) for s in x])
+    assert random.random() == before  # state restored on exit
+    with FixRandomSeed(1234):
+        b = f.apply_batch(x)
+    assert torch.equal(a, b)
+    with FixRandomSeed(1234):
+        c = f.apply_batch(x)  # cached plan, same result
+    assert torch.equal(b, c)
+    assert not torch.equal(a, x)
+
+
+def test_meters_accumulate_tensors_and_floats():
+    m = MeterInterface(default_focus="semi")
+    with m.focus_on("hook"):
+        m.register_meter("loss", AverageValueMeter())
+        m["loss"].add(torch.tensor(2.0))
+        m["loss"].add(torch.tensor(4.0))
+        m["loss"].add(3.0)
+        assert "loss" in m
+    assert m.statistics()["hook"]["loss"]["mean"] == pytest.approx(3.0)
+    m.reset()
+    assert math.isnan(m.statistics()["hook"]["loss"]["mean"])
+
+
+def test_hook_api_surface_and_combine():
+    class H(EpocherHook):
+        def __init__(self, v):
+            super().__init__("h")
+            self.v, self.calls = v, []
+
+        def before_forward_pass(self, **kw):
+            self.calls.append("bf")
+
+        def __call__(self, **kw):
+            return torch.tensor(self.v)
+
+        def close(self):
+            self.calls.append("close")
+
+    a, b = H(1.0), H(2.5)
+    c = CombineEpochHook(a, b)
+    c.before_forward_pass()
+    assert float(c()) == 3.5
+    c.close()
+    assert a.calls == ["bf", "close"]
+    t = TrainerHook(hook_name="unique-name-for-test")
+    assert list(t.parameters()) == []
+    with pytest.raises(ValueError):
+        TrainerHook(hook_name="unique-name-for-test")
+
+
+def test_hook_factories_and_feature_until():
+    model = UNet(input_dim=1, num_classes=4, max_channel=256)
+    h1 = create_sp_infonce_hooks(model=model, feature_names=["Conv5", "Conv5"], weights=[1.0, 0.5],
+                                 contrast_ons=["partition", "patient"], begin_values=3, end_values=70, mode="soft",
+                                 max_epoch=80, correct_grad=True)
+    assert feature_until_from_hooks(h1) == "Conv5"
+    assert sum(p.numel() for p in h1.parameters()) == 2 * 131584
+    keys = list(h1.state_dict().keys())
+    assert "_hooks.0._projector._header.2.weight" in keys and "_hooks.1._projector._header.4.bias" in keys
+    e1 = h1()  # epoch 0: gamma = begin value
+    assert h1._hooks[0]._criterion.age_param == 3.0
+    e1.close()
+    h1()
+    assert h1._hooks[0]._criterion.age_param == pytest.approx(3 + 67 * math.sqrt(1 / 80))
+    h2 = create_infonce_hooks(model=model, feature_names="Conv4", weights=1.0, contrast_ons="self")
+    assert feature_until_from_hooks(h2) == "Conv4"
+    assert h2._hooks[0]._projector._header[2].in_features == 128
+    with pytest.raises(NotImplementedError):
+        create_infonce_hooks(model=model, feature_names="Up_conv3", weights=1.0, contrast_ons="self")
+
+
+def test_unet_state_dict_keys_are_the_reference_keys():
+    m = UNet(input_dim=1, num_classes=4, max_channel=256)
+    keys = set(m.state_dict().keys())
+    assert keys == set(O.init_unet_state(1, 4, 256).keys())
+    n_enc = sum(p.numel() for n, p in m.named_parameters() if n.startswith("_Conv"))
+    assert n_enc == 1179472  # encoder parameter count
+    assert sum(p.numel() for p in m.parameters()) == 2160180  # full UNet (fine-tune DDP message 8.64 MB)
+
+
+def test_feature_extractor_tap_semantics():
+    m = UNet(input_dim=1, num_classes=4)
+    ext = SingleFeatureExtractor(m, "Conv5")
+    ext.bind()
+    assert len(m._Conv5._forward_hooks) == 1
+    with pytest.raises(RuntimeError):
+        ext.feature()
+    ext.set_enable(True)
+    fake = torch.zeros(2, 3)
+    for _ in range(4):
+        ext._feature_extractor(None, None, fake)
+    assert ext.feature().shape == (8, 3)
+    with pytest.raises(RuntimeError):  # 5th un-cleared pass (arch/hook.py:25-27)
+        ext._feature_extractor(None, None, fake)
+    ext.clear()
+    ext.remove()
+    assert len(m._Conv5._forward_hooks) == 0
+
+
+def test_warmup_cosine_schedule():
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=5e-7)
+    s = WarmupCosine(opt, max_epoch=80, warmup_max=10, multiplier=400)
+    lrs = []
+    for _ in range(80):
+        lrs.append(opt.param_groups[0]["lr"])
+        s.step()
+    assert lrs[0] == pytest.approx(5e-7)
+    assert lrs[10] == pytest.approx(5e-7 * 400)
+    assert lrs[45] == pytest.approx(1e-7 + (2e-4 - 1e-7) * 0.5, rel=1e-6)
+    assert all(a >= b for a, b in zip(lrs[10:], lrs[11:]))
+    sd = s.state_dict()
+    s2 = WarmupCosine(torch.optim.SGD([p], lr=5e-7), max_epoch=80, warmup_max=10, multiplier=400)
+    s2.load_state_dict(sd)
+    assert s2.epoch == 80
