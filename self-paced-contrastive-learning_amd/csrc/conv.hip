@@ -13,6 +13,7 @@
 //     global_load_dwordx4 per (k-step, 16-cout tile), L2-resident, no LDS.
 //   * bf16: v_mfma_f32_16x16x32_bf16 (8 bf16 / lane / operand);  f32: 4x v_mfma_f32_16x16x4_f32 per 16-byte chunk
 //     (exact-f32, the parity path).
+#include <stdlib.h>
 #include "common.hpp"
 
 namespace spcl {
@@ -47,6 +48,7 @@ struct ConvArgs {
   int CoutS;    // storage stride of y == padded output channels (multiple of 16)
   int in_mode;  // 0 raw, 1 relu(scale*x+shift), 2 f32 image with CinS (<16) channels zero-padded to 16
   int tilesX, tilesY;
+  int tpw;  // tiles per workgroup (processed sequentially)
 };
 
 template <typename T> __device__ __forceinline__ f32x4 mfma_chunk(u32x4 w, u32x4 x, f32x4 acc);
@@ -117,27 +119,44 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
   const int nslab = a.CinK / KC;
   const int ntiles_n = a.CoutS >> 4;
 
-  int tile = blockIdx.x;
   const int tpi = a.tilesX * a.tilesY;
-  const int n = tile / tpi;
-  const int trem = tile - n * tpi;
-  const int ty = trem / a.tilesX, tx = trem - ty * a.tilesX;
-  const int y0 = ty * TH, x0 = tx * TW;
+  const int ntiles = a.N * tpi;
   const int nt0 = (blockIdx.y * nwaves + wave) * NT;
   const bool wave_active = nt0 < ntiles_n;  // uniform per wave
   const int nvalid = min(NT, ntiles_n - nt0);  // n-tiles of this wave that exist (CoutS/16 may be odd)
 
   // per-lane halo base address of each m-tile's pixel (p = 16 i + r16), + the lane's k-group chunk
   int abase[MT];
-  unsigned validmask = 0;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     int p = 16 * i + r16;
-    bool ok = p < NPIX;
-    if (!ok) p = 0;
+    if (p >= NPIX) p = 0;
     const int py = p / TW, px = p - py * TW;
     abase[i] = (py * HW_ + px) * PSTRIDE;
-    if (ok && (y0 + py) < a.H && (x0 + px) < a.W) validmask |= 1u << i;
+  }
+
+  // a workgroup processes a.tpw consecutive tiles one after the other (fewer, longer-lived workgroups: the 16k
+  // one-wave workgroups of the 224^2 layers were dispatch-bound)
+#pragma unroll 1
+  for (int rep = 0; rep < a.tpw; ++rep) {
+  const int tile = blockIdx.x * a.tpw + rep;
+  if (tile >= ntiles) break;
+  // opaque copy of the thread index: keeps the compiler from hoisting the (tile-invariant) staging index math of
+  // every staging iteration out of this loop into ~50 extra live registers
+  int tidx = threadIdx.x;
+  asm volatile("" : "+v"(tidx));
+  const int n = tile / tpi;
+  const int trem = tile - n * tpi;
+  const int ty = trem / a.tilesX, tx = trem - ty * a.tilesX;
+  const int y0 = ty * TH, x0 = tx * TW;
+  int r16e = r16;  // opaque per iteration (see tidx): the per-pixel (py, px) of the epilogue must not be hoisted
+  asm volatile("" : "+v"(r16e));
+  unsigned validmask = 0;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int p = 16 * i + r16e;
+    const int py = p / TW, px = p - py * TW;
+    if (p < NPIX && (y0 + py) < a.H && (x0 + px) < a.W) validmask |= 1u << i;
   }
 
   f32x4 acc[MT][NT];
@@ -151,7 +170,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
   for (int slab = 0; slab < nslab; ++slab) {
     __syncthreads();
     // ---------------- stage the halo tile of this channel slab (fused BN-apply + ReLU of the producer)
-    for (int idx = threadIdx.x; idx < NHALO * CP; idx += blockDim.x) {
+    for (int idx = tidx; idx < NHALO * CP; idx += blockDim.x) {
       const int q = idx >> log2cp, ch = idx & (CP - 1);
       const int hy = q / HW_, hx = q - hy * HW_;
       const int gy = y0 + hy - 1, gx = x0 + hx - 1;
@@ -212,14 +231,16 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
       }
     }
   }
-  if (!wave_active) return;
+  if (!wave_active) continue;
 
   // ---------------- epilogue: lane holds couts 16(nt0+j)+4g..+3 of pixel 16i+r16
   T* y = (T*)a.y;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     if (validmask & (1u << i)) {
-      const int p = 16 * i + r16;
+      int r16s = r16;
+      asm volatile("" : "+v"(r16s));
+      const int p = 16 * i + r16s;
       const int py = p / TW, px = p - py * TW;
       const size_t pix = ((size_t)n * a.H + y0 + py) * a.W + x0 + px;
 #pragma unroll
@@ -273,6 +294,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
       }
     }
   }
+  }  // tiles of this workgroup
 }
 
 // ---------------------------------------------------------------------------------------------- weight packing
@@ -319,6 +341,10 @@ template <typename T> static size_t packed_elems(int KinK, int NoutS) {
 
 struct TileCfg { int th, tw; };
 static TileCfg pick_tile(int H, int W) {
+  // measured (tools/bench_kernels.py, same box A/B): below 224^2 the half-height tile (twice the waves, half the
+  // accumulators per wave) is 10-35 % faster on every layer; at 224^2 the 14x14 tile wins by ~8 %
+  static const int th7_max_h = getenv("SPCL_CONV_TH7_MAXH") ? atoi(getenv("SPCL_CONV_TH7_MAXH")) : 112;
+  if (H % 14 == 0 && W % 14 == 0 && H <= th7_max_h) return {7, 14};
   if (H % 14 == 0 && W % 14 == 0) return {14, 14};
   return {16, 16};
 }
@@ -332,12 +358,14 @@ static int launch_conv(const ConvArgs& a0, hipStream_t st) {
   const int KC = conv_kc(a.CinK);
   const size_t lds = (size_t)(TH + 2) * (TW + 2) * conv_pstride<T>(KC);
   const int tiles = a.N * a.tilesX * a.tilesY;
+  static const int env_tpw = getenv("SPCL_CONV_TPW") ? atoi(getenv("SPCL_CONV_TPW")) : 0;
+  a.tpw = env_tpw > 0 ? env_tpw : 1;
   // waves per workgroup x n-tiles per wave
   int NT = ntn >= 2 ? 2 : 1;
   int wn = cdiv(ntn, NT);
   if (wn > 4) wn = 4;
   const int gy = cdiv(ntn, NT * wn);
-  dim3 grid(tiles, gy), block(64 * wn);
+  dim3 grid(cdiv(tiles, a.tpw), gy), block(64 * wn);
   if (NT == 1) {
     if (lds > 65536) (void)hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<T, TH, TW, 1>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -353,6 +381,7 @@ static int launch_conv(const ConvArgs& a0, hipStream_t st) {
 template <typename T>
 static int launch_conv_t(const ConvArgs& a, hipStream_t st) {
   TileCfg t = pick_tile(a.H, a.W);
+  if (t.th == 7) return launch_conv<T, 7, 14>(a, st);
   if (t.th == 14) return launch_conv<T, 14, 14>(a, st);
   return launch_conv<T, 16, 16>(a, st);
 }
@@ -409,6 +438,7 @@ extern "C" int spcl_conv3x3_forward(const void* x, int dtype, int N, int H, int 
   a.x = x; a.y = y; a.wp = w_packed; a.stats = stats; a.in_scale = in_scale; a.in_shift = in_shift;
   a.N = N; a.H = H; a.W = W; a.CinS = CinS; a.CinK = CinK; a.CoutS = CoutS; a.in_mode = in_mode;
   a.tilesX = a.tilesY = 0;
+  a.tpw = 1;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == SPCL_F32) launch_conv_t<float>(a, st);
   else if (dtype == SPCL_BF16) launch_conv_t<bf16_t>(a, st);

@@ -7,6 +7,7 @@
 // (tap, ci-tile) output units (no cross-wave reduction), tiles are double-buffered in LDS with the next tile's global
 // loads issued before the MFMAs of the current one; workgroup partials go to a workspace and a second kernel sums
 // them in fixed order (deterministic, no float atomics) into the OIHW f32 gradient.
+#include <stdlib.h>
 #include "common.hpp"
 
 namespace spcl {
@@ -26,6 +27,7 @@ struct WgradArgs {
   float* partial;
   int N, H, W, CinS, CinK, CoutS, in_mode;
   int tilesX, tilesY, ntiles, nblk_ci, nblk_co;
+  int dbuf;  // 1: LDS tile image double buffered (one barrier per tile); 0: single buffer, twice the residency
 };
 
 // relu(scale*v+shift) on one 16-byte chunk (same arithmetic as conv.hip's staging so masks agree bit-for-bit)
@@ -233,7 +235,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
         for (int j = 0; j < NJ; ++j) acc[uu][j] = Frag<T>::mfma(af, bf[j], acc[uu][j]);
       }
     }
-    buf ^= 1;
+    if (a.dbuf) buf ^= 1;
+    else __syncthreads();  // single buffer: all reads of this tile are done before the next one is written
     tile = next;
   }
 
@@ -289,7 +292,7 @@ struct WgradPlan {
   int MI, NJ, nblk_ci, nblk_co, nsplit, ntiles, tilesX, tilesY;
   size_t partial_floats;
 };
-static WgradPlan wgrad_plan(int N, int H, int W, int CinK, int CoutS) {
+static WgradPlan wgrad_plan(int N, int H, int W, int CinK, int CoutS, int esize) {
   WgradPlan p;
   p.NJ = CoutS >= 32 ? 2 : 1;
   p.MI = CinK >= 32 ? 2 : 1;
@@ -299,7 +302,14 @@ static WgradPlan wgrad_plan(int N, int H, int W, int CinK, int CoutS) {
   p.tilesY = cdiv(H, WG_TH);
   p.ntiles = N * p.tilesX * p.tilesY;
   const int nblk = p.nblk_ci * p.nblk_co;
-  int ns = cdiv(768, nblk);
+  // exactly one resident "wave" of workgroups (LDS-limited residency x 256 CUs): measured optimum -- more workgroups
+  // only add partial slabs and a tail, fewer leave CUs idle (tools/bench_kernels.py wgrad sweeps)
+  const size_t lds = 2 * ((size_t)WG_NHALO * 16 * p.MI + (size_t)WG_NPIX * 16 * p.NJ) * esize;
+  int per_cu = (int)((160 * 1024) / lds);
+  if (per_cu > 4) per_cu = 4;
+  if (per_cu < 1) per_cu = 1;
+  static const int env_wgs = getenv("SPCL_WGRAD_WGS") ? atoi(getenv("SPCL_WGRAD_WGS")) : 0;
+  int ns = cdiv(env_wgs > 0 ? env_wgs : 256 * per_cu, nblk);
   if (ns > p.ntiles) ns = p.ntiles;
   if (ns < 1) ns = 1;
   p.nsplit = ns;
@@ -310,7 +320,7 @@ static WgradPlan wgrad_plan(int N, int H, int W, int CinK, int CoutS) {
 template <typename T, int MI, int NJ>
 static void launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t st) {
   constexpr int CIB = 16 * MI, COB = 16 * NJ;
-  size_t lds = 2 * ((size_t)WG_NHALO * CIB * sizeof(T) + (size_t)WG_NPIX * COB * sizeof(T));
+  size_t lds = (a.dbuf ? 2 : 1) * ((size_t)WG_NHALO * CIB * sizeof(T) + (size_t)WG_NPIX * COB * sizeof(T));
   if (lds > 65536)
     (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_kernel<T, MI, NJ>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
@@ -331,7 +341,9 @@ using namespace spcl;
 
 extern "C" size_t spcl_conv_wgrad_workspace_bytes(int N, int H, int W, int CinK, int CoutS) {
   if (N <= 0 || H <= 0 || W <= 0 || CinK <= 0 || CoutS <= 0 || CinK % 16 || CoutS % 16) return 0;
-  return wgrad_plan(N, H, W, CinK, CoutS).partial_floats * sizeof(float);
+  // sized for the f32 plan (its split count is >= the bf16 one)
+  const size_t a = wgrad_plan(N, H, W, CinK, CoutS, 4).partial_floats, b = wgrad_plan(N, H, W, CinK, CoutS, 2).partial_floats;
+  return (a > b ? a : b) * sizeof(float);
 }
 
 extern "C" int spcl_conv3x3_wgrad(const void* x, const void* dy, int dtype, int N, int H, int W, int Cin, int CinS,
@@ -345,11 +357,13 @@ extern "C" int spcl_conv3x3_wgrad(const void* x, const void* dy, int dtype, int 
   if (in_mode == 2) SPCL_CHECK_ARG(CinK == 16 && CinS >= 1 && CinS <= 16, "conv3x3_wgrad: image mode needs Cin<=16");
   else SPCL_CHECK_ARG(CinS == CinK, "conv3x3_wgrad: CinS must equal CinK");
   hipStream_t st = (hipStream_t)stream;
-  WgradPlan p = wgrad_plan(N, H, W, CinK, CoutS);
+  WgradPlan p = wgrad_plan(N, H, W, CinK, CoutS, dtype == SPCL_F32 ? 4 : 2);
   WgradArgs a;
   a.x = x; a.dy = dy; a.in_scale = in_scale; a.in_shift = in_shift; a.partial = partial;
   a.N = N; a.H = H; a.W = W; a.CinS = CinS; a.CinK = CinK; a.CoutS = CoutS; a.in_mode = in_mode;
   a.tilesX = p.tilesX; a.tilesY = p.tilesY; a.ntiles = p.ntiles; a.nblk_ci = p.nblk_ci; a.nblk_co = p.nblk_co;
+  static const int env_dbuf = getenv("SPCL_WGRAD_DBUF") ? atoi(getenv("SPCL_WGRAD_DBUF")) : 1;
+  a.dbuf = env_dbuf;
   if (dtype == SPCL_F32) launch_wgrad_t<float>(a, p, st);
   else if (dtype == SPCL_BF16) launch_wgrad_t<bf16_t>(a, p, st);
   else {
