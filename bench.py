@@ -189,7 +189,7 @@ def measure_roofline(step, args):
             continue
         cout = int(key.split("->")[1].split()[0])
         hw = int(key.split()[1].split("x")[0])
-        tile = ("7, 14" if hw <= 112 else "14, 14") if hw % 14 == 0 else "16, 16"
+        tile = ("7, 7" if hw <= 14 else ("7, 14" if hw <= 112 else "14, 14")) if hw % 14 == 0 else "16, 16"
         sym = f"spcl::conv3x3_mfma_kernel<{tname}, {tile}, {2 if cout >= 32 else 1}>"
         g = groups.setdefault(sym, {"t": 0.0, "n": 0.0, "bytes": 0.0, "flops": 0.0, "roof": 0.0})
         kind, byts, flops = meta

@@ -87,6 +87,9 @@ int spcl_proj_backward(const float* dz, int dtype, int N, int HW, int C, int Cs,
  * size in elements of `dtype`: spcl_conv_packed_elems(Cin, Cout, kind, dtype). */
 size_t spcl_conv_packed_elems(int Cin, int Cout, int kind, int dtype);
 int spcl_conv_pack_weights(const float* w_oihw, int Cin, int Cout, int kind, int dtype, void* packed, void* stream);
+/* both layouts of one layer in one launch (forward keeps the dgrad copy for its backward) */
+int spcl_conv_pack_weights_both(const float* w_oihw, int Cin, int Cout, int dtype, void* packed_fwd,
+                                void* packed_dgrad, void* stream);
 
 /* y = conv3x3(act(x)), NHWC, implicit GEMM on MFMA.                    (unet.py:72,75; dgrad: with kind-1 weights)
  * x [N,H,W,CinS] of dtype; CinK = GEMM-K channels (multiple of 16, == CinS for in_mode 0/1).
@@ -94,7 +97,7 @@ int spcl_conv_pack_weights(const float* w_oihw, int Cin, int Cout, int kind, int
  * unet.py:73-74, fused into the load);  2: x is the f32 input image [N,H,W,CinS] with CinS<=16 real channels
  * (== NCHW when CinS==1), zero-padded to CinK=16 on load.
  * y [N,H,W,CoutS] raw conv output (dtype).  stats != NULL: per-tile Chan partials (count, mean, M2) per output
- * channel, stats[spcl_conv_num_tiles(N,H,W)][CoutS][3] f32, for the train-mode BatchNorm that follows. */
+ * channel, component-major stats[3][CoutS][spcl_conv_num_tiles(N,H,W)] f32, for the train-mode BatchNorm that follows. */
 int spcl_conv_num_tiles(int N, int H, int W);
 int spcl_conv3x3_forward(const void* x, int dtype, int N, int H, int W, int CinS, int CinK, int CoutS,
                          const void* w_packed, int in_mode, const float* in_scale, const float* in_shift, void* y,

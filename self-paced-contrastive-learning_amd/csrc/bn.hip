@@ -48,13 +48,13 @@ __device__ __forceinline__ void chan_combine(double& n, double& mu, double& m2, 
   }
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int ntiles, int C, int CS,
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ stats, int ntiles, int C, int CS,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float momentum, float eps,
                                                           float* running_mean, float* running_var, int64_t* nbt,
                                                           float* __restrict__ mean, float* __restrict__ invstd,
                                                           float* __restrict__ scale, float* __restrict__ shift) {
-  __shared__ double red[3][4];
+  __shared__ double red[3][16];
   const int c = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (c >= C) {  // channel padding
@@ -62,10 +62,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     return;
   }
   double n = 0.0, mu = 0.0, m2 = 0.0;
-  for (int t = threadIdx.x; t < ntiles; t += 256) {
-    const float* s = stats + ((size_t)t * CS + c) * 3;
-    chan_combine(n, mu, m2, (double)s[0], (double)s[1], (double)s[2]);
-  }
+  // stats[3][CS][ntiles] (component-major): consecutive threads read consecutive partials
+  const float* s0 = stats + (size_t)c * ntiles;
+  const size_t kstride = (size_t)CS * ntiles;
+  for (int t = threadIdx.x; t < ntiles; t += blockDim.x)
+    chan_combine(n, mu, m2, (double)s0[t], (double)s0[kstride + t], (double)s0[2 * kstride + t]);
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1)
     chan_combine(n, mu, m2, __shfl_xor(n, o, 64), __shfl_xor(mu, o, 64), __shfl_xor(m2, o, 64));
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   __syncthreads();
   if (threadIdx.x == 0) {
     n = red[0][0]; mu = red[1][0]; m2 = red[2][0];
-    for (int w = 1; w < 4; ++w) chan_combine(n, mu, m2, red[0][w], red[1][w], red[2][w]);
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) chan_combine(n, mu, m2, red[0][w], red[1][w], red[2][w]);
     const double var = m2 / n;
     const float is = 1.0f / sqrtf((float)var + eps);
     const float sc = gamma[c] * is;
@@ -231,7 +232,7 @@ struct BwdRaw {
   }
 };
 
-constexpr int BWD_MAX_WG = 1024;
+constexpr int BWD_MAX_WG = 512;
 
 template <typename T, bool POOL>
 __global__ __launch_bounds__(256, 4) void bnrelu_bwd_reduce_kernel(const T* __restrict__ y, const T* __restrict__ dact,
@@ -427,7 +428,7 @@ extern "C" int spcl_bn_finalize(const float* stats, int ntiles, int C, int CS, c
                                 void* stream) {
   SPCL_CHECK_ARG(stats && gamma && beta && mean && invstd && scale && shift, "bn_finalize: null pointer");
   SPCL_CHECK_ARG(ntiles > 0 && C > 0 && CS >= C, "bn_finalize: bad shape");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(CS), dim3(256), 0, (hipStream_t)stream, stats, ntiles, C, CS,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(CS), dim3(ntiles >= 2048 ? 1024 : 256), 0, (hipStream_t)stream, stats, ntiles, C, CS,
                      gamma, beta, momentum, eps, running_mean, running_var, num_batches_tracked, mean, invstd, scale,
                      shift);
   SPCL_LAUNCH_CHECK("bn_finalize");

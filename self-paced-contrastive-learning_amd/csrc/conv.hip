@@ -284,12 +284,14 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
         m2[r] = v;
       }
       if (r16 == 0) {
-        float* dst = a.stats + ((size_t)tile * a.CoutS + (nt0 + j) * 16 + 4 * g) * 3;
+        // component-major layout stats[3][CoutS][ntiles]: the finalize kernel reads consecutive tiles coalesced
+        const size_t cstride = (size_t)ntiles, kstride = (size_t)a.CoutS * ntiles;
+        float* dst = a.stats + (size_t)((nt0 + j) * 16 + 4 * g) * cstride + tile;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          dst[3 * r + 0] = cnt;
-          dst[3 * r + 1] = s[r];
-          dst[3 * r + 2] = m2[r];
+          dst[r * cstride] = cnt;
+          dst[r * cstride + kstride] = s[r];
+          dst[r * cstride + 2 * kstride] = m2[r];
         }
       }
     }
@@ -303,11 +305,9 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
 // kind 0 (forward):  A[cout=o][k=(tap,ci)]      = W[o][ci][tap]
 // kind 1 (dgrad):    A[cout=ci][k=(tap,co)]     = W[co][ci][8-tap]        (roles of Cin/Cout swapped by the caller)
 template <typename T>
-__global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict__ w, int Cin, int Cout, int kind,
-                                                        int KinK, int NoutS, T* __restrict__ packed, size_t total) {
+__device__ __forceinline__ float pack_value(const float* __restrict__ w, int Cin, int Cout, int kind, int KinK, int NoutS,
+                                            size_t idx) {
   constexpr int EPC = Chunk<T>::EPC;
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
   const int KC = conv_kc(KinK);
   const int CP = KC / EPC;
   const int nsteps = conv_nsteps<T>(KC);
@@ -331,7 +331,25 @@ __global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict_
       if (kch < Cout && nch < Cin) v = w[((size_t)kch * Cin + nch) * 9 + (8 - tap)];
     }
   }
-  Elem<T>::store(packed + idx, v);
+  return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict__ w, int Cin, int Cout, int kind,
+                                                        int KinK, int NoutS, T* __restrict__ packed, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  Elem<T>::store(packed + idx, pack_value<T>(w, Cin, Cout, kind, KinK, NoutS, idx));
+}
+
+// forward (kind 0) and dgrad (kind 1) layouts of one layer in one launch
+template <typename T>
+__global__ __launch_bounds__(256) void conv_pack_both_kernel(const float* __restrict__ w, int Cin, int Cout, int CinK,
+                                                             int CoutS, T* __restrict__ p0, size_t t0,
+                                                             T* __restrict__ p1, size_t t1) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < t0) Elem<T>::store(p0 + idx, pack_value<T>(w, Cin, Cout, 0, CinK, CoutS, idx));
+  else if (idx < t0 + t1) Elem<T>::store(p1 + idx - t0, pack_value<T>(w, Cin, Cout, 1, CoutS, CinK, idx - t0));
 }
 
 template <typename T> static size_t packed_elems(int KinK, int NoutS) {
@@ -344,6 +362,8 @@ static TileCfg pick_tile(int H, int W) {
   // measured (tools/bench_kernels.py, same box A/B): below 224^2 the half-height tile (twice the waves, half the
   // accumulators per wave) is 10-35 % faster on every layer; at 224^2 the 14x14 tile wins by ~8 %
   static const int th7_max_h = getenv("SPCL_CONV_TH7_MAXH") ? atoi(getenv("SPCL_CONV_TH7_MAXH")) : 112;
+  static const int t77_max_h = getenv("SPCL_CONV_T77_MAXH") ? atoi(getenv("SPCL_CONV_T77_MAXH")) : 14;
+  if (H % 14 == 0 && W % 14 == 0 && H <= t77_max_h) return {7, 7};
   if (H % 14 == 0 && W % 14 == 0 && H <= th7_max_h) return {7, 14};
   if (H % 14 == 0 && W % 14 == 0) return {14, 14};
   return {16, 16};
@@ -381,6 +401,7 @@ static int launch_conv(const ConvArgs& a0, hipStream_t st) {
 template <typename T>
 static int launch_conv_t(const ConvArgs& a, hipStream_t st) {
   TileCfg t = pick_tile(a.H, a.W);
+  if (t.th == 7 && t.tw == 7) return launch_conv<T, 7, 7>(a, st);
   if (t.th == 7) return launch_conv<T, 7, 14>(a, st);
   if (t.th == 14) return launch_conv<T, 14, 14>(a, st);
   return launch_conv<T, 16, 16>(a, st);
@@ -419,6 +440,28 @@ extern "C" int spcl_conv_pack_weights(const float* w_oihw, int Cin, int Cout, in
     return SPCL_EINVAL;
   }
   SPCL_LAUNCH_CHECK("conv_pack_weights");
+  return SPCL_OK;
+}
+
+extern "C" int spcl_conv_pack_weights_both(const float* w_oihw, int Cin, int Cout, int dtype, void* packed_fwd,
+                                           void* packed_dgrad, void* stream) {
+  SPCL_CHECK_ARG(w_oihw && packed_fwd && packed_dgrad, "conv_pack_weights_both: null pointer");
+  SPCL_CHECK_ARG(Cin > 0 && Cout > 0, "conv_pack_weights_both: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  const int CinK = round_up(Cin, 16), CoutS = round_up(Cout, 16);
+  if (dtype == SPCL_F32) {
+    const size_t t0 = packed_elems<float>(CinK, CoutS), t1 = packed_elems<float>(CoutS, CinK);
+    hipLaunchKernelGGL(conv_pack_both_kernel<float>, dim3((unsigned)((t0 + t1 + 255) / 256)), dim3(256), 0, st, w_oihw,
+                       Cin, Cout, CinK, CoutS, (float*)packed_fwd, t0, (float*)packed_dgrad, t1);
+  } else if (dtype == SPCL_BF16) {
+    const size_t t0 = packed_elems<bf16_t>(CinK, CoutS), t1 = packed_elems<bf16_t>(CoutS, CinK);
+    hipLaunchKernelGGL(conv_pack_both_kernel<bf16_t>, dim3((unsigned)((t0 + t1 + 255) / 256)), dim3(256), 0, st,
+                       w_oihw, Cin, Cout, CinK, CoutS, (bf16_t*)packed_fwd, t0, (bf16_t*)packed_dgrad, t1);
+  } else {
+    set_error("conv_pack_weights_both: dtype %d", dtype);
+    return SPCL_EINVAL;
+  }
+  SPCL_LAUNCH_CHECK("conv_pack_weights_both");
   return SPCL_OK;
 }
 

@@ -261,10 +261,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
 // dW_oihw[co][ci][tap] = sum over pixel-split partials.  Threads follow the PARTIAL layout ([tap][ci][co], co fastest:
 // coalesced 256-byte wave reads); the 4 waves of a block take splits p = w, w+4, ... (8 independent loads in flight
 // each) and are combined through LDS in fixed order -> deterministic.  One scattered 4-byte store per output.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, int nblk_ci,
-                                                           int nblk_co, int CIB, int COB, int Cin, int Cout,
-                                                           float* __restrict__ dw) {
-  __shared__ float red[4][64];
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, int nblk_ci,
+                                                            int nblk_co, int CIB, int COB, int Cin, int Cout,
+                                                            float* __restrict__ dw) {
+  __shared__ float red[16][64];
+  const int nwaves = blockDim.x >> 6;  // 4 or 16 split lanes
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int slab = 9 * CIB * COB;
   const int inner = blockIdx.x * 64 + lane;
@@ -275,12 +276,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const float* src = partial + (size_t)blk * slab + inner;
     const size_t stride = nblk * slab;
 #pragma unroll 8
-    for (int p = wave; p < nsplit; p += 4) s += src[(size_t)p * stride];
+    for (int p = wave; p < nsplit; p += nwaves) s += src[(size_t)p * stride];
   }
   red[wave][lane] = s;
   __syncthreads();
   if (wave == 0 && inner < slab) {
-    const float v = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+    float v = red[0][lane];
+    for (int w = 1; w < nwaves; ++w) v += red[w][lane];  // fixed order
     const int co_l = inner % COB, ci_l = (inner / COB) % CIB, tap = inner / (COB * CIB);
     const int bci = blk / nblk_co, bco = blk - bci * nblk_co;
     const int ci = bci * CIB + ci_l, co = bco * COB + co_l;
@@ -371,7 +373,7 @@ extern "C" int spcl_conv3x3_wgrad(const void* x, const void* dy, int dtype, int 
     return SPCL_EINVAL;
   }
   const int slab = 9 * 16 * p.MI * 16 * p.NJ;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(slab, 64), p.nblk_ci * p.nblk_co), dim3(256), 0, st,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(slab, 64), p.nblk_ci * p.nblk_co), dim3(p.nsplit >= 64 ? 1024 : 256), 0, st,
                      (const float*)partial, p.nsplit, p.nblk_ci, p.nblk_co, 16 * p.MI, 16 * p.NJ, Cin, Cout, dw_oihw);
   SPCL_LAUNCH_CHECK("conv3x3_wgrad");
   return SPCL_OK;

@@ -192,13 +192,25 @@ def _pack(w, kind, dt_code, dtype):
     return buf
 
 
+def _pack_both(w, dt_code, dtype):
+    """forward and dgrad fragment layouts in one launch -> (packed_fwd, packed_dgrad)."""
+    co, ci = w.shape[0], w.shape[1]
+    n0 = _n.call("spcl_conv_packed_elems", ci, co, 0, dt_code)
+    n1 = _n.call("spcl_conv_packed_elems", ci, co, 1, dt_code)
+    buf = torch.empty(n0 + n1, dtype=dtype, device=w.device)
+    wc = w.detach().contiguous().float()
+    p0, p1 = buf[:n0], buf[n0:]
+    _n.call("spcl_conv_pack_weights_both", _n.ptr(wc), ci, co, dt_code, _n.ptr(p0), _n.ptr(p1), _n.stream())
+    return p0, p1
+
+
 def _conv(x_store, dt_code, dtype, N, H, W, cin_s, cin_k, cout_s, wp, in_mode, scale, shift, want_stats):
     dev = x_store.device
     y = torch.empty(N, H, W, cout_s, dtype=dtype, device=dev)
     stats = None
     if want_stats:
         nt = _n.call("spcl_conv_num_tiles", N, H, W)
-        stats = torch.empty(nt, cout_s, 3, dtype=torch.float32, device=dev)
+        stats = torch.empty(3, cout_s, nt, dtype=torch.float32, device=dev)
     _n.call("spcl_conv3x3_forward", _n.ptr(x_store), dt_code, N, H, W, cin_s, cin_k, cout_s, _n.ptr(wp), in_mode,
             _n.ptr(scale), _n.ptr(shift), _n.ptr(y), _n.ptr(stats), _n.stream())
     return y, stats
@@ -211,7 +223,7 @@ def _bn_stats(stats, cfg: BlockCfg, C, cs, gamma, beta, which, dev):
     rm, rv, nbt = cfg.buffers[which]
     if cfg.training:
         upd = cfg.track[which]
-        _n.call("spcl_bn_finalize", _n.ptr(stats), stats.shape[0], C, cs, _n.ptr(g), _n.ptr(b), c_float(cfg.momentum),
+        _n.call("spcl_bn_finalize", _n.ptr(stats), stats.shape[2], C, cs, _n.ptr(g), _n.ptr(b), c_float(cfg.momentum),
                 c_float(cfg.eps), _n.ptr(rm if upd else None), _n.ptr(rv if upd else None),
                 _n.ptr(nbt if upd else None), _n.ptr(st[0]), _n.ptr(st[1]), _n.ptr(st[2]), _n.ptr(st[3]), _n.stream())
     else:
@@ -265,10 +277,14 @@ class _ConvBlockFn(torch.autograd.Function):
             xs = to_nhwc_padded(x.detach(), dtype)
             cin_s = cin_k = xs.shape[3]
             mode_a = 0
-        wpa = _pack(wa, 0, dtc, dtype)
+        need_bwd = any(ctx.needs_input_grad)
+        if need_bwd:  # the dgrad layouts are packed alongside (same launch) and kept for backward
+            wpa, wpa_t = _pack_both(wa, dtc, dtype)
+            wpb, wpb_t = _pack_both(wb, dtc, dtype)
+        else:
+            wpa, wpb, wpa_t, wpb_t = _pack(wa, 0, dtc, dtype), _pack(wb, 0, dtc, dtype), None, None
         ya, sa = _conv(xs, dtc, dtype, N, H, W, cin_s, cin_k, cout_s, wpa, mode_a, None, None, cfg.training)
         sta = _bn_stats(sa, cfg, cout, cout_s, ga, ba, 0, dev)
-        wpb = _pack(wb, 0, dtc, dtype)
         yb, sb = _conv(ya, dtc, dtype, N, H, W, cout_s, cout_s, cout_s, wpb, 1, sta[2], sta[3], cfg.training)
         stb = _bn_stats(sb, cfg, cout, cout_s, gb, bb, 1, dev)
         act = torch.empty(N, H, W, cout_s, dtype=dtype, device=dev) if cfg.need_act else None
@@ -276,6 +292,7 @@ class _ConvBlockFn(torch.autograd.Function):
         _n.call("spcl_bnrelu_pool_forward", _n.ptr(yb), dtc, N, H, W, cout_s, _n.ptr(stb[2]), _n.ptr(stb[3]),
                 _n.ptr(act), _n.ptr(pool), _n.stream())
         ctx.save_for_backward(xs, ya, yb, sta, stb, wa, wb)
+        ctx.packed_t = (wpa_t, wpb_t)
         ctx.cfg = cfg
         ctx.meta = (N, cin, H, W, cout, cout_s, cin_s, cin_k, mode_a, x.dtype)
         outs = []
@@ -298,7 +315,9 @@ class _ConvBlockFn(torch.autograd.Function):
         dyb, dgb, dbb = _bnrelu_bwd(yb, da_s, dp_s, dtc, dtype, N, H, W, cout, cout_s, stb, cfg.training)
         dwb = _wgrad(ya, dyb, dtc, N, H, W, cout, cout_s, cout_s, cout, cout_s, 1, sta[2], sta[3]) \
             if ctx.needs_input_grad[4] else None
-        wpb_t = _pack(wb, 1, dtc, dtype)
+        wpa_t, wpb_t = ctx.packed_t
+        if wpb_t is None:
+            wpb_t = _pack(wb, 1, dtc, dtype)
         daa, _ = _conv(dyb, dtc, dtype, N, H, W, cout_s, cout_s, cout_s, wpb_t, 0, None, None, False)
         # ---- first conv
         dya, dga, dba = _bnrelu_bwd(ya, daa, None, dtc, dtype, N, H, W, cout, cout_s, sta, cfg.training)
@@ -308,7 +327,8 @@ class _ConvBlockFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if cfg.image_input:
                 raise NotImplementedError("gradient w.r.t. the input image is not on the hot path")
-            wpa_t = _pack(wa, 1, dtc, dtype)
+            if wpa_t is None:
+                wpa_t = _pack(wa, 1, dtc, dtype)
             dxs, _ = _conv(dya, dtc, dtype, N, H, W, cout_s, cout_s, cin_s, wpa_t, 0, None, None, False)
             dx = nhwc_to_logical(dxs, cin)
             if dx.dtype != xdt:

@@ -47,7 +47,7 @@ def main():
             wp = torch.empty(n.call("spcl_conv_packed_elems", ci, co, 0, dtc), dtype=dtype, device="cuda")
             n.call("spcl_conv_pack_weights", n.ptr(w), ci, co, 0, dtc, n.ptr(wp), n.stream())
             y = torch.empty(N, H, W, cs_o, dtype=dtype, device="cuda")
-            st = torch.empty(n.call("spcl_conv_num_tiles", N, H, W), cs_o, 3, device="cuda")
+            st = torch.empty(3, cs_o, n.call("spcl_conv_num_tiles", N, H, W), device="cuda")
             mode = 2 if img else 1
             t = timeit(lambda: n.call("spcl_conv3x3_forward", n.ptr(x), dtc, N, H, W, ci if img else cs_i, 16 if img else cs_i,
                                       cs_o, n.ptr(wp), mode, n.ptr(sc), n.ptr(sh), n.ptr(y), n.ptr(st), n.stream()))
