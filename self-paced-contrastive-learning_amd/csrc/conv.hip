@@ -49,6 +49,8 @@ struct ConvArgs {
   int in_mode;  // 0 raw, 1 relu(scale*x+shift), 2 f32 image with CinS (<16) channels zero-padded to 16
   int tilesX, tilesY;
   int tpw;  // tiles per workgroup (processed sequentially)
+  int dbg;  // ablation bits (experiments only, 0 in production): 1 no BN transform, 2 no k-loop, 4 no stats,
+            // 8 no output stores, 16 no staging loads
 };
 
 template <typename T> __device__ __forceinline__ f32x4 mfma_chunk(u32x4 w, u32x4 x, f32x4 acc);
@@ -65,41 +67,55 @@ template <> __device__ __forceinline__ f32x4 mfma_chunk<float>(u32x4 w, u32x4 x,
   return acc;
 }
 
-// one 16-byte chunk of EPC consecutive channels: apply relu(scale*v+shift)
-template <typename T> __device__ __forceinline__ u32x4 bnrelu_chunk(u32x4 raw, const float* sc, const float* sh);
-template <> __device__ __forceinline__ u32x4 bnrelu_chunk<float>(u32x4 raw, const float* sc, const float* sh) {
+// sum over the 16 lanes that share lane>>4 (one pixel column group), DPP only (no LDS traffic): xor 1, xor 2,
+// mirror within 8, mirror within 16
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+  return v;
+}
+
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2v;
+
+// relu(scale*v+shift) on one 16-byte chunk with the coefficients already in registers (packed-f32 FMA and one
+// v_cvt_pk_bf16_f32 per channel pair on the bf16 path)
+template <typename T> __device__ __forceinline__ u32x4 bnrelu_regs(u32x4 raw, const float* s, const float* b);
+template <> __device__ __forceinline__ u32x4 bnrelu_regs<float>(u32x4 raw, const float* s, const float* b) {
   f32x4 v = __builtin_bit_cast(f32x4, raw);
-  f32x4 s = *(const f32x4*)sc, b = *(const f32x4*)sh;
 #pragma unroll
   for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(s[e], v[e], b[e]), 0.f);
   return __builtin_bit_cast(u32x4, v);
 }
-template <> __device__ __forceinline__ u32x4 bnrelu_chunk<bf16_t>(u32x4 raw, const float* sc, const float* sh) {
-  float s[8], b[8];
-  *(f32x4*)&s[0] = *(const f32x4*)sc;
-  *(f32x4*)&s[4] = *(const f32x4*)(sc + 4);
-  *(f32x4*)&b[0] = *(const f32x4*)sh;
-  *(f32x4*)&b[4] = *(const f32x4*)(sh + 4);
+template <> __device__ __forceinline__ u32x4 bnrelu_regs<bf16_t>(u32x4 raw, const float* s, const float* b) {
   u32x4 out;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     float lo = __uint_as_float(raw[e] << 16), hi = __uint_as_float(raw[e] & 0xffff0000u);
-    lo = fmaxf(fmaf(s[2 * e], lo, b[2 * e]), 0.f);
+    lo = fmaxf(fmaf(s[2 * e], lo, b[2 * e]), 0.f);  // same arithmetic as wgrad's staging: identical activations
     hi = fmaxf(fmaf(s[2 * e + 1], hi, b[2 * e + 1]), 0.f);
-    out[e] = (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    const f32x2 v = {lo, hi};
+    out[e] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2v));
   }
   return out;
 }
 
-template <typename T> __device__ __forceinline__ void store4(T* p, f32x4 v);
-template <> __device__ __forceinline__ void store4<float>(float* p, f32x4 v) { *(f32x4*)p = v; }
-template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, f32x4 v) {
+template <typename T> __device__ __forceinline__ void store4_fast(unsigned char* p, f32x4 v);
+template <> __device__ __forceinline__ void store4_fast<float>(unsigned char* p, f32x4 v) { *(f32x4*)p = v; }
+template <> __device__ __forceinline__ void store4_fast<bf16_t>(unsigned char* p, f32x4 v) {
+  const f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
   uint2 o;
-  o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-  o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+  o.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf16x2v));
+  o.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, bf16x2v));
   *(uint2*)p = o;
 }
 
+// One workgroup = one TH x TW pixel tile (x a block of output channels); see the file header.  Instruction budget
+// (ISA audit): staging walks the halo with incremental coordinates (no divisions in the loop, no bounds
+// tests on interior tiles, BN coefficients of the thread's fixed channel chunk in registers); the epilogue walks the
+// pixels incrementally and accumulates the BatchNorm sums in one pass, reduced across lanes with DPP.
 template <typename T, int TH, int TW, int NT>
 __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
   constexpr int EPC = Chunk<T>::EPC;
@@ -107,6 +123,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
   constexpr int MT = (NPIX + 15) / 16;
   constexpr int HW_ = TW + 2;
   constexpr int NHALO = (TH + 2) * HW_;
+  constexpr int ESZ = (int)sizeof(T);
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
@@ -122,10 +139,10 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
   const int tpi = a.tilesX * a.tilesY;
   const int ntiles = a.N * tpi;
   const int nt0 = (blockIdx.y * nwaves + wave) * NT;
-  const bool wave_active = nt0 < ntiles_n;  // uniform per wave
+  const bool wave_active = nt0 < ntiles_n;     // uniform per wave
   const int nvalid = min(NT, ntiles_n - nt0);  // n-tiles of this wave that exist (CoutS/16 may be odd)
 
-  // per-lane halo base address of each m-tile's pixel (p = 16 i + r16), + the lane's k-group chunk
+  // per-lane halo base address of each m-tile's pixel (p = 16 i + r16)
   int abase[MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
@@ -134,30 +151,21 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
     const int py = p / TW, px = p - py * TW;
     abase[i] = (py * HW_ + px) * PSTRIDE;
   }
+  // staging: the thread's channel chunk is fixed (blockDim % CP == 0); its halo pixel advances by QS per iteration
+  const int sch = threadIdx.x & (CP - 1);
+  const int sq0 = threadIdx.x >> log2cp;
+  const int QS = (int)blockDim.x >> log2cp;
+  const int dhy = QS / HW_, dhx = QS - dhy * HW_;
 
-  // a workgroup processes a.tpw consecutive tiles one after the other (fewer, longer-lived workgroups: the 16k
-  // one-wave workgroups of the 224^2 layers were dispatch-bound)
 #pragma unroll 1
   for (int rep = 0; rep < a.tpw; ++rep) {
   const int tile = blockIdx.x * a.tpw + rep;
   if (tile >= ntiles) break;
-  // opaque copy of the thread index: keeps the compiler from hoisting the (tile-invariant) staging index math of
-  // every staging iteration out of this loop into ~50 extra live registers
-  int tidx = threadIdx.x;
-  asm volatile("" : "+v"(tidx));
   const int n = tile / tpi;
   const int trem = tile - n * tpi;
   const int ty = trem / a.tilesX, tx = trem - ty * a.tilesX;
   const int y0 = ty * TH, x0 = tx * TW;
-  int r16e = r16;  // opaque per iteration (see tidx): the per-pixel (py, px) of the epilogue must not be hoisted
-  asm volatile("" : "+v"(r16e));
-  unsigned validmask = 0;
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int p = 16 * i + r16e;
-    const int py = p / TW, px = p - py * TW;
-    if (p < NPIX && (y0 + py) < a.H && (x0 + px) < a.W) validmask |= 1u << i;
-  }
+  const bool interior = y0 > 0 && x0 > 0 && y0 + TH < a.H && x0 + TW < a.W;  // whole halo inside the image
 
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -170,15 +178,52 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
   for (int slab = 0; slab < nslab; ++slab) {
     __syncthreads();
     // ---------------- stage the halo tile of this channel slab (fused BN-apply + ReLU of the producer)
-    for (int idx = tidx; idx < NHALO * CP; idx += blockDim.x) {
-      const int q = idx >> log2cp, ch = idx & (CP - 1);
-      const int hy = q / HW_, hx = q - hy * HW_;
-      const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-        const size_t pix = ((size_t)n * a.H + gy) * a.W + gx;
-        if (a.in_mode == 2) {
-          const float* src = (const float*)a.x + pix * a.CinS;
+    if (a.in_mode != 2) {
+      float ssc[EPC], ssh[EPC];
+      if (a.in_mode == 1) {
+#pragma unroll
+        for (int e = 0; e < EPC; e += 4) {
+          *(f32x4*)&ssc[e] = *(const f32x4*)(a.in_scale + slab * KC + sch * EPC + e);
+          *(f32x4*)&ssh[e] = *(const f32x4*)(a.in_shift + slab * KC + sch * EPC + e);
+        }
+      }
+      // element offsets relative to the halo origin (y0-1, x0-1); dereferenced only when inside the image
+      const T* xb = (const T*)a.x + (((long)n * a.H + (y0 - 1)) * a.W + (x0 - 1)) * a.CinS + slab * KC + sch * EPC;
+      int hy = sq0 / HW_, hx = sq0 - hy * HW_;
+      int goff = (hy * a.W + hx) * a.CinS;
+      const int dgoff = (dhy * a.W + dhx) * a.CinS, wrapg = (a.W - HW_) * a.CinS;
+      unsigned char* lp = lds + sq0 * PSTRIDE + sch * 16;
+      const int dlp = QS * PSTRIDE;
+      for (int q = sq0; q < NHALO; q += QS) {
+        bool inb = true;
+        if (!interior) {
+          const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+          inb = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        }
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (inb && !(a.dbg & 16)) {
+          v = *(const u32x4*)(xb + goff);
+          if (a.in_mode == 1 && !(a.dbg & 1)) v = bnrelu_regs<T>(v, ssc, ssh);
+        }
+        *(u32x4*)lp = v;
+        lp += dlp;
+        hx += dhx;
+        hy += dhy;
+        goff += dgoff;
+        if (hx >= HW_) {
+          hx -= HW_;
+          hy += 1;
+          goff += wrapg;
+        }
+      }
+    } else {
+      for (int idx = threadIdx.x; idx < NHALO * CP; idx += blockDim.x) {
+        const int q = idx >> log2cp, ch = idx & (CP - 1);
+        const int hy = q / HW_, hx = q - hy * HW_;
+        const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+          const float* src = (const float*)a.x + (((size_t)n * a.H + gy) * a.W + gx) * a.CinS;
           float e[EPC];
 #pragma unroll
           for (int k = 0; k < EPC; ++k) {
@@ -192,13 +237,9 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
             for (int k = 0; k < 4; ++k)
               v[k] = (uint32_t)f32_to_bf16(e[(2 * k) % EPC]) | ((uint32_t)f32_to_bf16(e[(2 * k + 1) % EPC]) << 16);
           }
-        } else {
-          const int c0 = slab * KC + ch * EPC;
-          v = *(const u32x4*)((const T*)a.x + pix * a.CinS + c0);
-          if (a.in_mode == 1) v = bnrelu_chunk<T>(v, a.in_scale + c0, a.in_shift + c0);
         }
+        *(u32x4*)(lds + q * PSTRIDE + ch * 16) = v;
       }
-      *(u32x4*)(lds + q * PSTRIDE + ch * 16) = v;
     }
     __syncthreads();
     if (!wave_active) continue;
@@ -209,16 +250,25 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) wf[j] = wslab[(size_t)(j < nvalid ? j : 0) * 64];
 #pragma unroll 1
-    for (int s = 0; s < nsteps; ++s) {
+    for (int s = 0; s < ((a.dbg & 2) ? 0 : nsteps); ++s) {
       if (s + 1 < nsteps) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) wnext[j] = wslab[((size_t)(s + 1) * ntiles_n + (j < nvalid ? j : 0)) * 64];
       }
-      int fc = 4 * s + g;
-      if (fc >= 9 * CP) fc = 0;  // K padding: weights there are zero, any finite x will do
-      const int tap = fc >> log2cp, ch = fc & (CP - 1);
-      const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
-      const int off = (ky * HW_ + kx) * PSTRIDE + ch * 16;
+      int off;
+      if (CP >= 4) {
+        // the step's 4 k-groups lie in ONE tap: the tap part is wave-uniform (scalar ALU), the lane adds its chunk
+        const int fc0 = 4 * s;
+        const int tap = fc0 >> log2cp, ch0 = fc0 & (CP - 1);
+        const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+        off = (ky * HW_ + kx) * PSTRIDE + (ch0 + g) * 16;
+      } else {
+        int fc = 4 * s + g;
+        if (fc >= 9 * CP) fc = 0;  // K padding: weights there are zero, any finite x will do
+        const int tap = fc >> log2cp, ch = fc & (CP - 1);
+        const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+        off = (ky * HW_ + kx) * PSTRIDE + ch * 16;
+      }
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         const u32x4 xf = *(const u32x4*)(lds + abase[i] + off);
@@ -233,65 +283,65 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
   }
   if (!wave_active) continue;
 
-  // ---------------- epilogue: lane holds couts 16(nt0+j)+4g..+3 of pixel 16i+r16
-  T* y = (T*)a.y;
+  // ---------------- epilogue: lane holds couts 16(nt0+j)+4g..+3 of pixel p = 16 i + r16, walked incrementally
+  constexpr int DPY = 16 / TW, DPX = 16 % TW;
+  const bool full_tile = y0 + TH <= a.H && x0 + TW <= a.W;
+  int r16e = r16;  // opaque per tile: keeps (py, px, ob) out of the registers live across the k-loop
+  asm volatile("" : "+v"(r16e));
+  int py = r16e / TW, px = r16e - py * TW;
+  const int rowb = a.CoutS * ESZ;
+  int ob = (py * a.W + px) * rowb + (nt0 * 16 + 4 * g) * ESZ;
+  const int dob = (DPY * a.W + DPX) * rowb, wrapo = (a.W - TW) * rowb;
+  unsigned char* yb = (unsigned char*)a.y + (((size_t)n * a.H + y0) * a.W + x0) * rowb;
+  f32x4 ssum[NT], ssq[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    ssum[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    ssq[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    if (validmask & (1u << i)) {
-      int r16s = r16;
-      asm volatile("" : "+v"(r16s));
-      const int p = 16 * i + r16s;
-      const int py = p / TW, px = p - py * TW;
-      const size_t pix = ((size_t)n * a.H + y0 + py) * a.W + x0 + px;
+    bool ok = (16 * i + 15 < NPIX) || (16 * i + r16e < NPIX);  // compile-time true except in the last m-tile
+    if (!full_tile) ok = ok && (y0 + py) < a.H && (x0 + px) < a.W;
+    if (ok) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
-        if (j < nvalid) store4<T>(y + pix * a.CoutS + (nt0 + j) * 16 + 4 * g, acc[i][j]);
+      for (int j = 0; j < NT; ++j) {
+        if (j < nvalid && !(a.dbg & 8)) store4_fast<T>(yb + ob + j * 16 * ESZ, acc[i][j]);
+        ssum[j] += acc[i][j];
+        ssq[j] += acc[i][j] * acc[i][j];
+      }
+    }
+    px += DPX;
+    py += DPY;
+    ob += dob;
+    if (px >= TW) {
+      px -= TW;
+      py += 1;
+      ob += wrapo;
     }
   }
-  if (a.stats != nullptr) {
+  if (a.stats != nullptr && !(a.dbg & 4)) {
     const int vh = min(TH, a.H - y0), vw = min(TW, a.W - x0);
     const float cnt = (float)(vh * vw);
+    const float inv = 1.f / cnt;
+    // component-major layout stats[3][CoutS][ntiles]: the finalize kernel reads consecutive tiles coalesced
+    const size_t cstride = (size_t)ntiles, kstride = (size_t)a.CoutS * ntiles;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       if (j >= nvalid) break;
-      f32x4 s = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-        if (validmask & (1u << i)) s += acc[i][j];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float v = s[r];
-        v += __shfl_xor(v, 1, 64);
-        v += __shfl_xor(v, 2, 64);
-        v += __shfl_xor(v, 4, 64);
-        v += __shfl_xor(v, 8, 64);
-        s[r] = v / cnt;  // tile mean
-      }
-      f32x4 m2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-        if (validmask & (1u << i)) {
-          f32x4 d = acc[i][j] - s;
-          m2 += d * d;
-        }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = m2[r];
-        v += __shfl_xor(v, 1, 64);
-        v += __shfl_xor(v, 2, 64);
-        v += __shfl_xor(v, 4, 64);
-        v += __shfl_xor(v, 8, 64);
-        m2[r] = v;
+        ssum[j][r] = row16_sum(ssum[j][r]);
+        ssq[j][r] = row16_sum(ssq[j][r]);
       }
       if (r16 == 0) {
-        // component-major layout stats[3][CoutS][ntiles]: the finalize kernel reads consecutive tiles coalesced
-        const size_t cstride = (size_t)ntiles, kstride = (size_t)a.CoutS * ntiles;
         float* dst = a.stats + (size_t)((nt0 + j) * 16 + 4 * g) * cstride + tile;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
+          const float mean = ssum[j][r] * inv;
           dst[r * cstride] = cnt;
-          dst[r * cstride + kstride] = s[r];
-          dst[r * cstride + 2 * kstride] = m2[r];
+          dst[r * cstride + kstride] = mean;
+          dst[r * cstride + 2 * kstride] = fmaxf(ssq[j][r] - ssum[j][r] * mean, 0.f);  // M2 = sum x^2 - n mean^2
         }
       }
     }
@@ -376,10 +426,13 @@ static int launch_conv(const ConvArgs& a0, hipStream_t st) {
   a.tilesY = cdiv(a.H, TH);
   const int ntn = a.CoutS / 16;
   const int KC = conv_kc(a.CinK);
-  const size_t lds = (size_t)(TH + 2) * (TW + 2) * conv_pstride<T>(KC);
+  static const int env_lds_extra = getenv("SPCL_CONV_LDS_EXTRA") ? atoi(getenv("SPCL_CONV_LDS_EXTRA")) : 0;
+  const size_t lds = (size_t)(TH + 2) * (TW + 2) * conv_pstride<T>(KC) + env_lds_extra;
   const int tiles = a.N * a.tilesX * a.tilesY;
   static const int env_tpw = getenv("SPCL_CONV_TPW") ? atoi(getenv("SPCL_CONV_TPW")) : 0;
   a.tpw = env_tpw > 0 ? env_tpw : 1;
+  static const int env_dbg = getenv("SPCL_CONV_DBG") ? atoi(getenv("SPCL_CONV_DBG")) : 0;
+  a.dbg = env_dbg;
   // waves per workgroup x n-tiles per wave
   int NT = ntn >= 2 ? 2 : 1;
   int wn = cdiv(ntn, NT);
@@ -482,6 +535,7 @@ extern "C" int spcl_conv3x3_forward(const void* x, int dtype, int N, int H, int 
   a.N = N; a.H = H; a.W = W; a.CinS = CinS; a.CinK = CinK; a.CoutS = CoutS; a.in_mode = in_mode;
   a.tilesX = a.tilesY = 0;
   a.tpw = 1;
+  a.dbg = 0;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == SPCL_F32) launch_conv_t<float>(a, st);
   else if (dtype == SPCL_BF16) launch_conv_t<bf16_t>(a, st);
