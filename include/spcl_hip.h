@@ -97,8 +97,11 @@ int spcl_conv_pack_weights_both(const float* w_oihw, int Cin, int Cout, int dtyp
  * unet.py:73-74, fused into the load);  2: x is the f32 input image [N,H,W,CinS] with CinS<=16 real channels
  * (== NCHW when CinS==1), zero-padded to CinK=16 on load.
  * y [N,H,W,CoutS] raw conv output (dtype).  stats != NULL: per-tile Chan partials (count, mean, M2) per output
- * channel, component-major stats[3][CoutS][spcl_conv_num_tiles(N,H,W)] f32, for the train-mode BatchNorm that follows. */
+ * channel, one row stats[tile][3][CoutS] f32 per pixel tile (tile < spcl_conv_num_tiles(N,H,W)), for the train-mode
+ * BatchNorm that follows; the buffer holds spcl_bn_stats_elems(ntiles, CoutS) floats (tile rows + the finalize
+ * kernel's partial rows). */
 int spcl_conv_num_tiles(int N, int H, int W);
+size_t spcl_bn_stats_elems(int ntiles, int CS);
 int spcl_conv3x3_forward(const void* x, int dtype, int N, int H, int W, int CinS, int CinK, int CoutS,
                          const void* w_packed, int in_mode, const float* in_scale, const float* in_shift, void* y,
                          float* stats, void* stream);
@@ -112,10 +115,10 @@ int spcl_conv3x3_wgrad(const void* x, const void* dy, int dtype, int N, int H, i
                        float* dw_oihw, void* stream);
 
 /* train-mode BatchNorm statistics (unet.py:73,76; torch.nn.BatchNorm2d semantics): combines the conv epilogue
- * partials (Chan, fixed order) -> mean, invstd = 1/sqrt(var_biased+eps), scale = gamma*invstd,
+ * partials stats[ntiles][3][CS] (Chan, fixed order, in double; the tail of the buffer is scratch) -> mean, invstd = 1/sqrt(var_biased+eps), scale = gamma*invstd,
  * shift = beta-mean*scale (all [CS] f32, zero in the channel padding) and updates running_mean / running_var
  * (unbiased variance, momentum) and num_batches_tracked (+1) when those pointers are non-NULL. */
-int spcl_bn_finalize(const float* stats, int ntiles, int C, int CS, const float* gamma, const float* beta,
+int spcl_bn_finalize(float* stats, int ntiles, int C, int CS, const float* gamma, const float* beta,
                      float momentum, float eps, float* running_mean, float* running_var,
                      int64_t* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift,
                      void* stream);

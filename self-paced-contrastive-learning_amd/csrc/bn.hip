@@ -35,60 +35,93 @@ template <> __device__ __forceinline__ u32x4 pack<bf16_t>(const float* v) {
 }
 
 // ------------------------------------------------------------------------------------------------ statistics
-// One workgroup per channel: Chan-combine the per-tile (count, mean, M2) partials in double; threads stride the
-// tiles, then a butterfly inside each wave and a fixed-order combine of the 4 waves -> deterministic.
-__device__ __forceinline__ void chan_combine(double& n, double& mu, double& m2, double nb, double mb, double qb) {
-  const double nn = n + nb;
-  if (nn > 0.0) {  // symmetric form: both butterfly partners compute the identical result
-    const double d = mb - mu;
-    const double mu_new = (n * mu + nb * mb) / nn;
-    m2 = m2 + qb + d * d * n * nb / nn;
-    mu = mu_new;
-    n = nn;
-  }
+// The conv epilogue leaves one row [3][CS] = (count, mean, M2) per pixel tile (f32, exact within the tile).  They are
+// combined in DOUBLE as raw moments (n, sum x = n mean, sum x^2 = M2 + n mean^2) -- at 53 bits the final
+// var = E[x^2] - mean^2 loses nothing that matters (relative error ~1e-16 (1 + mean^2/var)) and the inner loop is
+// three FMAs with no division -- in a fixed order (deterministic): a workgroup = 16 channels x TL tile lanes; a lane
+// walks its rows serially, the TL lanes of a channel are folded by a tree in LDS.  Up to BN_DIRECT_TILES rows one
+// launch does everything; beyond that a first launch reduces groups of BN_GROUP_TILES rows to double-precision
+// partial rows (n, sum x, sum x^2; kept behind the tile rows of the same buffer, see spcl_bn_stats_elems) and a
+// second launch finishes from those.
+constexpr int BN_GROUP_TILES = 256;
+constexpr int BN_DIRECT_TILES = 2048;
+__host__ __device__ inline int bn_groups(int ntiles) {
+  return ntiles <= BN_DIRECT_TILES ? 0 : (ntiles + BN_GROUP_TILES - 1) / BN_GROUP_TILES;
 }
 
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ stats, int ntiles, int C, int CS,
-                                                          const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float momentum, float eps,
-                                                          float* running_mean, float* running_var, int64_t* nbt,
-                                                          float* __restrict__ mean, float* __restrict__ invstd,
-                                                          float* __restrict__ scale, float* __restrict__ shift) {
-  __shared__ double red[3][16];
-  const int c = blockIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (c >= C) {  // channel padding
-    if (threadIdx.x == 0) { mean[c] = 0.f; invstd[c] = 0.f; scale[c] = 0.f; shift[c] = 0.f; }
+struct BnFinalArgs {
+  const float* gamma;
+  const float* beta;
+  float momentum, eps;
+  float* running_mean;
+  float* running_var;
+  int64_t* nbt;
+  float* mean;
+  float* invstd;
+  float* scale;
+  float* shift;
+};
+
+// SRC = float: tile rows (count, mean, M2);  double: partial rows (n, sum x, sum x^2).
+// FINAL: write the BatchNorm coefficients, else one partial row per blockIdx.y.
+template <typename SRC, bool FINAL>
+__global__ __launch_bounds__(1024) void bn_reduce_kernel(const SRC* __restrict__ rows, int nrows, int rows_per_group,
+                                                         int C, int CS, double* __restrict__ partial, BnFinalArgs f) {
+  __shared__ double red[3][64][16];
+  const int TL = blockDim.x >> 4;
+  const int c16 = threadIdx.x & 15, tl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + c16;
+  const int r0 = blockIdx.y * rows_per_group, r1 = min(nrows, r0 + rows_per_group);
+  double n = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll 4
+  for (int r = r0 + tl; r < r1; r += TL) {
+    const SRC* p = rows + (size_t)r * 3 * CS + c;
+    const double a = (double)p[0], b = (double)p[CS], q = (double)p[2 * CS];
+    if (sizeof(SRC) == 4) {
+      const double ab = a * b;
+      n += a;
+      s1 += ab;
+      s2 += fma(ab, b, q);
+    } else {
+      n += a;
+      s1 += b;
+      s2 += q;
+    }
+  }
+  red[0][tl][c16] = n; red[1][tl][c16] = s1; red[2][tl][c16] = s2;
+  __syncthreads();
+  for (int o = TL >> 1; o > 0; o >>= 1) {
+    if (tl < o) {
+      n += red[0][tl + o][c16]; s1 += red[1][tl + o][c16]; s2 += red[2][tl + o][c16];
+      red[0][tl][c16] = n; red[1][tl][c16] = s1; red[2][tl][c16] = s2;
+    }
+    __syncthreads();
+  }
+  if (tl != 0) return;
+  if (!FINAL) {
+    double* q = partial + (size_t)blockIdx.y * 3 * CS + c;
+    q[0] = n; q[CS] = s1; q[2 * CS] = s2;
     return;
   }
-  double n = 0.0, mu = 0.0, m2 = 0.0;
-  // stats[3][CS][ntiles] (component-major): consecutive threads read consecutive partials
-  const float* s0 = stats + (size_t)c * ntiles;
-  const size_t kstride = (size_t)CS * ntiles;
-  for (int t = threadIdx.x; t < ntiles; t += blockDim.x)
-    chan_combine(n, mu, m2, (double)s0[t], (double)s0[kstride + t], (double)s0[2 * kstride + t]);
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1)
-    chan_combine(n, mu, m2, __shfl_xor(n, o, 64), __shfl_xor(mu, o, 64), __shfl_xor(m2, o, 64));
-  if (lane == 0) { red[0][wave] = n; red[1][wave] = mu; red[2][wave] = m2; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    n = red[0][0]; mu = red[1][0]; m2 = red[2][0];
-    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) chan_combine(n, mu, m2, red[0][w], red[1][w], red[2][w]);
-    const double var = m2 / n;
-    const float is = 1.0f / sqrtf((float)var + eps);
-    const float sc = gamma[c] * is;
-    mean[c] = (float)mu;
-    invstd[c] = is;
-    scale[c] = sc;
-    shift[c] = beta[c] - (float)mu * sc;
-    if (running_mean != nullptr) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mu;
-    if (running_var != nullptr) {
-      const double unbiased = n > 1.0 ? m2 / (n - 1.0) : var;
-      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-    }
-    if (nbt != nullptr && c == 0) nbt[0] += 1;
+  if (c >= C) {  // channel padding
+    f.mean[c] = 0.f; f.invstd[c] = 0.f; f.scale[c] = 0.f; f.shift[c] = 0.f;
+    return;
   }
+  const double mu = s1 / n;
+  const double m2 = fmax(s2 - s1 * mu, 0.0);
+  const double var = m2 / n;
+  const float is = 1.0f / sqrtf((float)var + f.eps);
+  const float sc = f.gamma[c] * is;
+  f.mean[c] = (float)mu;
+  f.invstd[c] = is;
+  f.scale[c] = sc;
+  f.shift[c] = f.beta[c] - (float)mu * sc;
+  if (f.running_mean != nullptr) f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * (float)mu;
+  if (f.running_var != nullptr) {
+    const double unbiased = n > 1.0 ? m2 / (n - 1.0) : var;
+    f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unbiased;
+  }
+  if (f.nbt != nullptr && c == 0) f.nbt[0] += 1;
 }
 
 __global__ __launch_bounds__(256) void bn_eval_affine_kernel(int C, int CS, const float* __restrict__ gamma,
@@ -422,15 +455,29 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
 
 using namespace spcl;
 
-extern "C" int spcl_bn_finalize(const float* stats, int ntiles, int C, int CS, const float* gamma, const float* beta,
+extern "C" size_t spcl_bn_stats_elems(int ntiles, int CS) {
+  return ((size_t)ntiles + 2 * (size_t)bn_groups(ntiles)) * 3 * CS;  // tile rows + double-precision partial rows
+}
+
+extern "C" int spcl_bn_finalize(float* stats, int ntiles, int C, int CS, const float* gamma, const float* beta,
                                 float momentum, float eps, float* running_mean, float* running_var,
                                 int64_t* num_batches_tracked, float* mean, float* invstd, float* scale, float* shift,
                                 void* stream) {
   SPCL_CHECK_ARG(stats && gamma && beta && mean && invstd && scale && shift, "bn_finalize: null pointer");
-  SPCL_CHECK_ARG(ntiles > 0 && C > 0 && CS >= C, "bn_finalize: bad shape");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(CS), dim3(ntiles >= 2048 ? 1024 : 256), 0, (hipStream_t)stream, stats, ntiles, C, CS,
-                     gamma, beta, momentum, eps, running_mean, running_var, num_batches_tracked, mean, invstd, scale,
-                     shift);
+  SPCL_CHECK_ARG(ntiles > 0 && C > 0 && CS >= C && CS % 16 == 0, "bn_finalize: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  BnFinalArgs f{gamma, beta, momentum, eps, running_mean, running_var, num_batches_tracked, mean, invstd, scale, shift};
+  const int groups = bn_groups(ntiles);
+  if (groups == 0) {
+    hipLaunchKernelGGL((bn_reduce_kernel<float, true>), dim3(CS / 16, 1), dim3(ntiles > 256 ? 1024 : 256), 0, st, stats,
+                       ntiles, ntiles, C, CS, (double*)nullptr, f);
+  } else {
+    double* partial = (double*)(stats + (size_t)ntiles * 3 * CS);  // spcl_bn_stats_elems reserves it
+    hipLaunchKernelGGL((bn_reduce_kernel<float, false>), dim3(CS / 16, groups), dim3(256), 0, st, stats, ntiles,
+                       BN_GROUP_TILES, C, CS, partial, f);
+    hipLaunchKernelGGL((bn_reduce_kernel<double, true>), dim3(CS / 16, 1), dim3(groups > 64 ? 1024 : 256), 0, st,
+                       (const double*)partial, groups, groups, C, CS, (double*)nullptr, f);
+  }
   SPCL_LAUNCH_CHECK("bn_finalize");
   return SPCL_OK;
 }

@@ -14,103 +14,9 @@
 //   * bf16: v_mfma_f32_16x16x32_bf16 (8 bf16 / lane / operand);  f32: 4x v_mfma_f32_16x16x4_f32 per 16-byte chunk
 //     (exact-f32, the parity path).
 #include <stdlib.h>
-#include "common.hpp"
+#include "conv_common.hpp"
 
 namespace spcl {
-
-template <typename T> struct Chunk;
-template <> struct Chunk<float> { static constexpr int EPC = 4; };
-template <> struct Chunk<bf16_t> { static constexpr int EPC = 8; };
-
-struct uint4_ { uint32_t x, y, z, w; };
-typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
-
-__host__ __device__ inline int conv_kc(int CinK) { return CinK < 64 ? CinK : 64; }
-template <typename T> __host__ __device__ inline int conv_pstride(int KC) {
-  int b = KC * (int)sizeof(T);
-  return b == 32 ? 32 : b + 32;  // bytes per halo pixel in LDS (see tools/ bank analysis in DESIGN.md)
-}
-template <typename T> __host__ __device__ inline int conv_nsteps(int KC) {
-  int cp = KC / Chunk<T>::EPC;
-  return (9 * cp + 3) / 4;
-}
-
-struct ConvArgs {
-  const void* x;
-  void* y;
-  const void* wp;
-  float* stats;
-  const float* in_scale;
-  const float* in_shift;
-  int N, H, W;
-  int CinS;     // storage stride of x in elements (mode 2: real channel count of the f32 image)
-  int CinK;     // GEMM-K channels, multiple of 16
-  int CoutS;    // storage stride of y == padded output channels (multiple of 16)
-  int in_mode;  // 0 raw, 1 relu(scale*x+shift), 2 f32 image with CinS (<16) channels zero-padded to 16
-  int tilesX, tilesY;
-  int tpw;  // tiles per workgroup (processed sequentially)
-  int dbg;  // ablation bits (experiments only, 0 in production): 1 no BN transform, 2 no k-loop, 4 no stats,
-            // 8 no output stores, 16 no staging loads
-};
-
-template <typename T> __device__ __forceinline__ f32x4 mfma_chunk(u32x4 w, u32x4 x, f32x4 acc);
-template <> __device__ __forceinline__ f32x4 mfma_chunk<bf16_t>(u32x4 w, u32x4 x, f32x4 acc) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0,
-                                                 0, 0);
-}
-template <> __device__ __forceinline__ f32x4 mfma_chunk<float>(u32x4 w, u32x4 x, f32x4 acc) {
-  f32x4 wf = __builtin_bit_cast(f32x4, w), xf = __builtin_bit_cast(f32x4, x);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0], xf[0], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[1], xf[1], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[2], xf[2], acc, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[3], xf[3], acc, 0, 0, 0);
-  return acc;
-}
-
-// sum over the 16 lanes that share lane>>4 (one pixel column group), DPP only (no LDS traffic): xor 1, xor 2,
-// mirror within 8, mirror within 16
-__device__ __forceinline__ float row16_sum(float v) {
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
-  return v;
-}
-
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2v;
-
-// relu(scale*v+shift) on one 16-byte chunk with the coefficients already in registers (packed-f32 FMA and one
-// v_cvt_pk_bf16_f32 per channel pair on the bf16 path)
-template <typename T> __device__ __forceinline__ u32x4 bnrelu_regs(u32x4 raw, const float* s, const float* b);
-template <> __device__ __forceinline__ u32x4 bnrelu_regs<float>(u32x4 raw, const float* s, const float* b) {
-  f32x4 v = __builtin_bit_cast(f32x4, raw);
-#pragma unroll
-  for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaf(s[e], v[e], b[e]), 0.f);
-  return __builtin_bit_cast(u32x4, v);
-}
-template <> __device__ __forceinline__ u32x4 bnrelu_regs<bf16_t>(u32x4 raw, const float* s, const float* b) {
-  u32x4 out;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    float lo = __uint_as_float(raw[e] << 16), hi = __uint_as_float(raw[e] & 0xffff0000u);
-    lo = fmaxf(fmaf(s[2 * e], lo, b[2 * e]), 0.f);  // same arithmetic as wgrad's staging: identical activations
-    hi = fmaxf(fmaf(s[2 * e + 1], hi, b[2 * e + 1]), 0.f);
-    const f32x2 v = {lo, hi};
-    out[e] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2v));
-  }
-  return out;
-}
-
-template <typename T> __device__ __forceinline__ void store4_fast(unsigned char* p, f32x4 v);
-template <> __device__ __forceinline__ void store4_fast<float>(unsigned char* p, f32x4 v) { *(f32x4*)p = v; }
-template <> __device__ __forceinline__ void store4_fast<bf16_t>(unsigned char* p, f32x4 v) {
-  const f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
-  uint2 o;
-  o.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf16x2v));
-  o.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, bf16x2v));
-  *(uint2*)p = o;
-}
 
 // One workgroup = one TH x TW pixel tile (x a block of output channels); see the file header.  Instruction budget
 // (ISA audit): staging walks the halo with incremental coordinates (no divisions in the loop, no bounds
@@ -323,27 +229,10 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
   if (a.stats != nullptr && !(a.dbg & 4)) {
     const int vh = min(TH, a.H - y0), vw = min(TW, a.W - x0);
     const float cnt = (float)(vh * vw);
-    const float inv = 1.f / cnt;
-    // component-major layout stats[3][CoutS][ntiles]: the finalize kernel reads consecutive tiles coalesced
-    const size_t cstride = (size_t)ntiles, kstride = (size_t)a.CoutS * ntiles;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       if (j >= nvalid) break;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        ssum[j][r] = row16_sum(ssum[j][r]);
-        ssq[j][r] = row16_sum(ssq[j][r]);
-      }
-      if (r16 == 0) {
-        float* dst = a.stats + (size_t)((nt0 + j) * 16 + 4 * g) * cstride + tile;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float mean = ssum[j][r] * inv;
-          dst[r * cstride] = cnt;
-          dst[r * cstride + kstride] = mean;
-          dst[r * cstride + 2 * kstride] = fmaxf(ssq[j][r] - ssum[j][r] * mean, 0.f);  // M2 = sum x^2 - n mean^2
-        }
-      }
+      write_tile_stats(a.stats, tile, a.CoutS, (nt0 + j) * 16 + 4 * g, r16, cnt, ssum[j], ssq[j]);
     }
   }
   }  // tiles of this workgroup
@@ -454,6 +343,8 @@ static int launch_conv(const ConvArgs& a0, hipStream_t st) {
 template <typename T>
 static int launch_conv_t(const ConvArgs& a, hipStream_t st) {
   TileCfg t = pick_tile(a.H, a.W);
+  static const int no_fast = getenv("SPCL_CONV_NO_FAST") ? atoi(getenv("SPCL_CONV_NO_FAST")) : 0;
+  if (sizeof(T) == 2 && t.tw == 14 && !no_fast && launch_conv_fast(a, t.th, st)) return 0;
   if (t.th == 7 && t.tw == 7) return launch_conv<T, 7, 7>(a, st);
   if (t.th == 7) return launch_conv<T, 7, 14>(a, st);
   if (t.th == 14) return launch_conv<T, 14, 14>(a, st);

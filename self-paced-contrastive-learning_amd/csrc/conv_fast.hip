@@ -1,0 +1,335 @@
+// Compile-time-specialised 3x3 convolution kernels (bf16, NHWC, 14-pixel-wide tiles) for the layer shapes of the UNet
+// encoder (semi_seg/arch/unet.py:67-82,123-131): same mapping, packed-weight layout and numerics as the generic kernel
+// of conv.hip, but the K-chunking, tile shape, n-tiles per wave, input mode and workgroup width are template
+// parameters.  What that buys (measured with tools/experiments/convlab.hip):
+//   * the tile comes from a 3-D grid (no integer divisions), the halo walk has compile-time pixel steps on top of one
+//     per-lane offset, all global loads of a slab are issued back to back before the first use;
+//   * the k-loop is fully unrolled: tap offsets fold into the ds_read_b128 offset field, weight fragments of the
+//     16-channel layers are all fetched before staging so their L2 latency hides under the activation loads;
+//   * BatchNorm partials leave as three 16-byte stores per 16-lane row.
+// On the 16->16 layer at 224^2 this is 47 us against 80 us for the generic kernel (pure copy of the same tiles: 42).
+#include <stdlib.h>
+#include "conv_common.hpp"
+
+namespace spcl {
+
+struct FastArgs {
+  const unsigned char* x;
+  unsigned char* y;
+  const u32x4* wp;
+  float* stats;
+  const float* in_scale;
+  const float* in_shift;
+  int N, H, W, CinK, CoutS, tilesX, tilesY, gy;
+};
+
+// waves per SIMD the register allocator must leave room for: what the tile's LDS footprint allows anyway, at most 4
+// (fewer waves than that would not be resident regardless, so the extra registers are free)
+constexpr int fast_lds_bytes(int KC, int TH) { return (TH + 2) * 16 * (KC == 16 ? 32 : KC * 2 + 32); }
+constexpr int fast_wpe(int KC, int TH, int NW) {
+  const int wgs = 160 * 1024 / fast_lds_bytes(KC, TH);
+  const int w = (wgs * NW + 3) / 4;
+  return w > 4 ? 4 : (w < 1 ? 1 : w);
+}
+
+template <int KC, int TH, int NT, int MODE, int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(fast_wpe(KC, TH, NW)))) void
+conv3x3_fast_kernel(FastArgs a) {
+  constexpr int TW = 14, HW_ = 16, CP = KC / 8, NHALO = (TH + 2) * HW_, PS = (KC == 16 ? 32 : KC * 2 + 32);
+  constexpr int NTHR = 64 * NW, NCH = NHALO * CP, ITER = (NCH + NTHR - 1) / NTHR, QS = NTHR / CP;
+  constexpr int NPIX = TH * TW, MT = (NPIX + 15) / 16, NSTEPS = (9 * CP + 3) / 4;
+  constexpr bool PRELOAD_W = KC == 16;  // 5 k-steps: every weight fragment of the wave lives in registers
+  static_assert(QS >= HW_ ? QS % HW_ == 0 : HW_ % QS == 0, "staging walk needs whole/even halo rows per iteration");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r16 = lane & 15, g = lane >> 4;
+  const int tx = blockIdx.x, ty = blockIdx.y;
+  int n = blockIdx.z, by = 0;
+  if (a.gy > 1) {
+    by = n % a.gy;
+    n /= a.gy;
+  }
+  const int y0 = ty * TH, x0 = tx * TW;
+  const int tile = (n * a.tilesY + ty) * a.tilesX + tx;
+  const int ntn = a.CoutS >> 4;
+  const int nt0 = (by * NW + wave) * NT;
+  const bool interior = y0 > 0 && x0 > 0 && y0 + TH < a.H && x0 + TW < a.W;  // whole halo inside the image
+  const int nslab = KC < 64 ? 1 : a.CinK / KC;
+  const int gps = (KC < 64 ? KC : a.CinK) * 2;  // bytes per pixel of x
+
+  u32x4 wall[PRELOAD_W ? NSTEPS : 1][NT];
+  if (PRELOAD_W) {
+#pragma unroll
+    for (int s = 0; s < NSTEPS; ++s)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) wall[s][j] = a.wp[(size_t)(s * ntn + nt0 + j) * 64 + lane];
+  }
+
+  // staging map: thread -> (halo pixel q0 + k QS, 16-byte channel chunk ch); QS and the halo width are powers of two,
+  // so iteration k moves by a compile-time (dky, dkx)
+  const int ch = t & (CP - 1), q0 = t / CP;
+  const int hy0 = q0 / HW_, hx0 = q0 % HW_;
+  const unsigned char* xb = a.x + (((long)n * a.H + (y0 - 1)) * a.W + (x0 - 1)) * gps;  // halo origin (may be outside)
+  const unsigned voff = (unsigned)((hy0 * a.W + hx0) * gps + ch * 16);
+  unsigned char* const lp = lds + (hy0 * HW_ + hx0) * PS + ch * 16;
+
+  // per-lane LDS base of each m-tile's pixel p = 16 i + r16 (+ the lane's k-group when a step stays inside one tap)
+  int abase[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    int p = 16 * i + r16;
+    if (p >= NPIX) p = 0;
+    const int py = p / TW, px = p - py * TW;
+    abase[i] = (py * HW_ + px) * PS + (CP >= 4 ? g * 16 : 0);
+  }
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+  for (int slab = 0; slab < nslab; ++slab) {
+    if (slab > 0) __syncthreads();  // every wave is done reading the previous slab
+    float ssc[8], ssh[8];
+    if (MODE == 1) {
+#pragma unroll
+      for (int e = 0; e < 8; e += 4) {
+        *(f32x4*)&ssc[e] = *(const f32x4*)(a.in_scale + slab * KC + ch * 8 + e);
+        *(f32x4*)&ssh[e] = *(const f32x4*)(a.in_shift + slab * KC + ch * 8 + e);
+      }
+    }
+    const unsigned char* xs = xb + slab * (KC * 2);
+    u32x4 v[ITER];
+#pragma unroll
+    for (int k = 0; k < ITER; ++k) {
+      const int dky = QS >= HW_ ? k * (QS / HW_) : k / (HW_ / QS);
+      const int dkx = QS >= HW_ ? 0 : (k % (HW_ / QS)) * QS;
+      const long soff = ((long)dky * a.W + dkx) * gps;  // wave-uniform
+      bool inb = (NCH % NTHR == 0) || (k * NTHR + t < NCH);
+      if (!interior) {
+        const int gy = y0 - 1 + hy0 + dky, gx = x0 - 1 + hx0 + dkx;
+        inb = inb && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      }
+      v[k] = (u32x4){0u, 0u, 0u, 0u};
+      if (inb) v[k] = *(const u32x4*)(xs + soff + voff);
+    }
+#pragma unroll
+    for (int k = 0; k < ITER; ++k) {
+      const int dky = QS >= HW_ ? k * (QS / HW_) : k / (HW_ / QS);
+      const int dkx = QS >= HW_ ? 0 : (k % (HW_ / QS)) * QS;
+      const bool in_range = (NCH % NTHR == 0) || (k * NTHR + t < NCH);
+      u32x4 tv = v[k];
+      if (MODE == 1) {
+        bool inb = true;  // zero padding applies to the ACTIVATION: outside pixels stay 0, not relu(shift)
+        if (!interior) {
+          const int gy = y0 - 1 + hy0 + dky, gx = x0 - 1 + hx0 + dkx;
+          inb = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        }
+        if (inb) tv = bnrelu_regs<bf16_t>(tv, ssc, ssh);
+      }
+      if (in_range) *(u32x4*)(lp + (dky * HW_ + dkx) * PS) = tv;
+    }
+    __syncthreads();
+
+    // ------------ k-loop: NSTEPS x (one 16-byte x fragment per m-tile, NT MFMAs on it)
+    const u32x4* wslab = a.wp + ((size_t)slab * NSTEPS * ntn + nt0) * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < NSTEPS; ++s) {
+      u32x4 wf[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) wf[j] = PRELOAD_W ? wall[s][j] : wslab[(size_t)(s * ntn + j) * 64];
+      int off;
+      if (CP >= 4) {
+        const int fc0 = 4 * s, tap = fc0 / CP, c0 = fc0 % CP, ky = tap / 3, kx = tap % 3;
+        off = (ky * HW_ + kx) * PS + c0 * 16;  // compile-time: the ds_read offset field
+      } else {
+        int fc = 4 * s + g;
+        if (fc >= 9 * CP) fc = 0;  // K padding: the weights there are zero, any finite x will do
+        const int tap = fc / CP, c = fc % CP, ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+        off = (ky * HW_ + kx) * PS + c * 16;
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const u32x4 xf = *(const u32x4*)(lds + abase[i] + off);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = mfma_chunk<bf16_t>(wf[j], xf, acc[i][j]);
+      }
+    }
+  }
+
+  // ------------ epilogue: lane holds couts 16 (nt0 + j) + 4 g .. +3 of pixel p = 16 i + r16 (tiles are always full)
+  constexpr int DPY = 16 / TW, DPX = 16 % TW;
+  const int rowb = a.CoutS * 2;
+  unsigned char* yb = a.y + (((size_t)n * a.H + y0) * a.W + x0) * rowb + (nt0 * 16 + 4 * g) * 2;
+  int py = r16 / TW, px = r16 - py * TW;
+  int ob = (py * a.W + px) * rowb;
+  const int dob = (DPY * a.W + DPX) * rowb, wrapo = (a.W - TW) * rowb;
+  f32x4 ssum[NT], ssq[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    ssum[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    ssq[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const bool ok = (16 * i + 15 < NPIX) || (16 * i + r16 < NPIX);  // compile-time true except in the last m-tile
+    if (ok) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        store4_fast<bf16_t>(yb + ob + j * 32, acc[i][j]);
+        ssum[j] += acc[i][j];
+        ssq[j] += acc[i][j] * acc[i][j];
+      }
+    }
+    px += DPX;
+    ob += dob;
+    if (px >= TW) {
+      px -= TW;
+      ob += wrapo;
+    }
+  }
+  if (a.stats != nullptr) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+      write_tile_stats(a.stats, tile, a.CoutS, (nt0 + j) * 16 + 4 * g, r16, (float)NPIX, ssum[j], ssq[j]);
+  }
+}
+
+// First layer (unet.py:123: input_dim == 1 -> 16): the f32 single-channel image convolved with 16 filters, K = 9.
+// One v_mfma_f32_16x16x16_bf16 per 16 pixels with k = (ky, kx | pad): k-group g = ky holds (kx = 0, 1, 2, pad).  The
+// halo tile sits in LDS as bf16 PAIRS (x[q], x[q+1]) per pixel q, so that a lane's whole B fragment
+// (x[q], x[q+1], x[q+2], x[q+3]: three taps and a finite pad against a zero weight) is one ds_read2_b32.
+// Weights come from the ordinary packed forward layout (kind 0, CinK = 16): three 2-byte loads per lane.
+// The kernel is a pure output stream (32 bytes per pixel out, 4 in).
+template <int TH>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void conv3x3_image_kernel(FastArgs a) {
+  constexpr int TW = 14, HW_ = 16, LW = HW_ + 2;  // LDS row: 16 halo pixels + 2 so that pair q+2 of the last tap exists
+  constexpr int NPIX = TH * TW, MT = (NPIX + 15) / 16, NHALO = (TH + 2) * HW_;
+  __shared__ uint32_t pairs[(TH + 2) * LW];
+  const int lane = threadIdx.x, r16 = lane & 15, g = lane >> 4;
+  const int tx = blockIdx.x, ty = blockIdx.y, n = blockIdx.z;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const int tile = (n * a.tilesY + ty) * a.tilesX + tx;
+
+  // A fragment: row = cout r16, k-group g = ky: W[cout][0][ky][0..2], 0.  Packed index of (cout, ci = 0, tap):
+  // chunk fc = 2 tap -> step tap >> 1, k-group 2 (tap & 1), element 0
+  s16x4 wfrag = {0, 0, 0, 0};
+  if (g < 3) {
+    const bf16_t* wp = (const bf16_t*)a.wp;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int tap = 3 * g + kx;
+      wfrag[kx] = (short)wp[(size_t)(((tap >> 1) * 64) + (2 * (tap & 1)) * 16 + r16) * 8];
+    }
+  }
+
+  // stage: lane -> halo pixels q = lane + 64 k; pair = (x[q], x[q+1]) with zero outside the image
+  const float* img = (const float*)a.x + (size_t)n * a.H * a.W;
+#pragma unroll
+  for (int k = 0; k < (NHALO + 63) / 64; ++k) {
+    const int q = lane + 64 * k;
+    const int hy = q / HW_, hx = q % HW_;
+    const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+    float v0 = 0.f, v1 = 0.f;
+    if (q < NHALO && gy >= 0 && gy < a.H) {
+      if (gx >= 0 && gx < a.W) v0 = img[(size_t)gy * a.W + gx];
+      if (gx + 1 >= 0 && gx + 1 < a.W && hx + 1 < HW_) v1 = img[(size_t)gy * a.W + gx + 1];
+    }
+    const f32x2 pv = {v0, v1};
+    if (q < NHALO) pairs[hy * LW + hx] = __builtin_bit_cast(uint32_t, __builtin_convertvector(pv, bf16x2v));
+  }
+  if (lane < 2 * (TH + 2)) pairs[(lane >> 1) * LW + HW_ + (lane & 1)] = 0u;  // the two pad pairs of each row
+  __syncthreads();
+
+  f32x4 acc[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    int p = 16 * i + r16;
+    if (p >= NPIX) p = 0;
+    const int py = p / TW, px = p - py * TW;
+    const int gg = g < 3 ? g : 0;  // k-group 3 is all padding (zero weights): read something valid
+    const uint32_t* src = pairs + (py + gg) * LW + px;
+    const uint32_t lo = src[0], hi = src[2];
+    const uint2 xv = {lo, hi};
+    acc[i] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wfrag, __builtin_bit_cast(s16x4, xv),
+                                                       (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+  }
+
+  constexpr int DPY = 16 / TW, DPX = 16 % TW;
+  const int rowb = a.CoutS * 2;
+  unsigned char* yb = a.y + (((size_t)n * a.H + y0) * a.W + x0) * rowb + 4 * g * 2;
+  int py = r16 / TW, px = r16 - py * TW;
+  int ob = (py * a.W + px) * rowb;
+  const int dob = (DPY * a.W + DPX) * rowb, wrapo = (a.W - TW) * rowb;
+  f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const bool ok = (16 * i + 15 < NPIX) || (16 * i + r16 < NPIX);
+    if (ok) {
+      store4_fast<bf16_t>(yb + ob, acc[i]);
+      ssum += acc[i];
+      ssq += acc[i] * acc[i];
+    }
+    px += DPX;
+    ob += dob;
+    if (px >= TW) {
+      px -= TW;
+      ob += wrapo;
+    }
+  }
+  if (a.stats != nullptr) write_tile_stats(a.stats, tile, a.CoutS, 4 * g, r16, (float)NPIX, ssum, ssq);
+}
+
+template <int KC, int TH, int NT, int NW>
+static void launch_fast(const FastArgs& a, int mode, hipStream_t st) {
+  const size_t lds = fast_lds_bytes(KC, TH);
+  dim3 grid(a.tilesX, a.tilesY, a.N * a.gy), block(64 * NW);
+  if (mode == 1) hipLaunchKernelGGL((conv3x3_fast_kernel<KC, TH, NT, 1, NW>), grid, block, lds, st, a);
+  else hipLaunchKernelGGL((conv3x3_fast_kernel<KC, TH, NT, 0, NW>), grid, block, lds, st, a);
+}
+
+bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st) {
+  if (c.H % th != 0 || c.W % 14 != 0) return false;
+  if (c.in_mode == 2) {
+    if (c.CinS != 1 || c.CoutS != 16 || th != 14) return false;
+    FastArgs a;
+    a.x = (const unsigned char*)c.x; a.y = (unsigned char*)c.y; a.wp = (const u32x4*)c.wp; a.stats = c.stats;
+    a.in_scale = a.in_shift = nullptr;
+    a.N = c.N; a.H = c.H; a.W = c.W; a.CinK = 16; a.CoutS = 16;
+    a.tilesX = c.W / 14; a.tilesY = c.H / 14; a.gy = 1;
+    hipLaunchKernelGGL((conv3x3_image_kernel<14>), dim3(a.tilesX, a.tilesY, a.N), dim3(64), 0, st, a);
+    return true;
+  }
+  if (c.CinS != c.CinK) return false;
+  const int ntn = c.CoutS / 16, KC = conv_kc(c.CinK);
+  static const int env_nt1 = getenv("SPCL_CONV_FAST_NT1") ? atoi(getenv("SPCL_CONV_FAST_NT1")) : 0;
+  int NT = ntn >= 2 ? 2 : 1;
+  if (env_nt1 && KC == 64 && ntn == 2) NT = 1;
+  int nw = ntn / NT;
+  if (nw > 4) nw = 4;
+  if (ntn % (NT * nw) != 0) return false;
+  FastArgs a;
+  a.x = (const unsigned char*)c.x; a.y = (unsigned char*)c.y; a.wp = (const u32x4*)c.wp; a.stats = c.stats;
+  a.in_scale = c.in_scale; a.in_shift = c.in_shift;
+  a.N = c.N; a.H = c.H; a.W = c.W; a.CinK = c.CinK; a.CoutS = c.CoutS;
+  a.tilesX = c.W / 14; a.tilesY = c.H / th; a.gy = ntn / (NT * nw);
+#define SPCL_FAST_CASE(KC_, TH_, NT_, NW_)                               \
+  if (KC == KC_ && th == TH_ && NT == NT_ && nw == NW_) {                \
+    launch_fast<KC_, TH_, NT_, NW_>(a, c.in_mode, st);                   \
+    return true;                                                         \
+  }
+  SPCL_FAST_CASE(16, 14, 1, 1)  // Conv1.b forward / dgrad (16 -> 16 @ 224^2)
+  SPCL_FAST_CASE(16, 7, 2, 1)   // Conv2.a forward (16 -> 32 @ 112^2)
+  SPCL_FAST_CASE(32, 7, 1, 1)   // Conv2.a dgrad (32 -> 16)
+  SPCL_FAST_CASE(32, 7, 2, 1)   // Conv2.b forward / dgrad
+  SPCL_FAST_CASE(32, 7, 2, 2)   // Conv3.a forward (32 -> 64 @ 56^2)
+  SPCL_FAST_CASE(64, 7, 2, 1)   // Conv3.a dgrad (64 -> 32)
+  SPCL_FAST_CASE(64, 7, 1, 2)   //   "   as two one-n-tile waves
+  SPCL_FAST_CASE(64, 7, 2, 2)   // Conv3.b, Conv4.a dgrad
+  SPCL_FAST_CASE(64, 7, 2, 4)   // Conv4.a forward, Conv4.b, (Conv5 when tiled 7x14)
+#undef SPCL_FAST_CASE
+  return false;
+}
+
+}  // namespace spcl

@@ -209,8 +209,10 @@ def _conv(x_store, dt_code, dtype, N, H, W, cin_s, cin_k, cout_s, wp, in_mode, s
     y = torch.empty(N, H, W, cout_s, dtype=dtype, device=dev)
     stats = None
     if want_stats:
+        # rows [tile][3][cout_s] of Chan partials (+ the finalize kernel's scratch rows), see include/spcl_hip.h
         nt = _n.call("spcl_conv_num_tiles", N, H, W)
-        stats = torch.empty(3, cout_s, nt, dtype=torch.float32, device=dev)
+        stats = torch.empty(_n.call("spcl_bn_stats_elems", nt, cout_s), dtype=torch.float32, device=dev)
+        stats.ntiles = nt
     _n.call("spcl_conv3x3_forward", _n.ptr(x_store), dt_code, N, H, W, cin_s, cin_k, cout_s, _n.ptr(wp), in_mode,
             _n.ptr(scale), _n.ptr(shift), _n.ptr(y), _n.ptr(stats), _n.stream())
     return y, stats
@@ -223,7 +225,7 @@ def _bn_stats(stats, cfg: BlockCfg, C, cs, gamma, beta, which, dev):
     rm, rv, nbt = cfg.buffers[which]
     if cfg.training:
         upd = cfg.track[which]
-        _n.call("spcl_bn_finalize", _n.ptr(stats), stats.shape[2], C, cs, _n.ptr(g), _n.ptr(b), c_float(cfg.momentum),
+        _n.call("spcl_bn_finalize", _n.ptr(stats), stats.ntiles, C, cs, _n.ptr(g), _n.ptr(b), c_float(cfg.momentum),
                 c_float(cfg.eps), _n.ptr(rm if upd else None), _n.ptr(rv if upd else None),
                 _n.ptr(nbt if upd else None), _n.ptr(st[0]), _n.ptr(st[1]), _n.ptr(st[2]), _n.ptr(st[3]), _n.stream())
     else:

@@ -55,7 +55,9 @@ def conv(n, xs, dtype, N, H, W, cin_s, cin_k, cout_s, wp, mode, scale=None, shif
     y = torch.empty(N, H, W, cout_s, dtype=dtype, device="cuda")
     st = None
     if stats:
-        st = torch.empty(3, cout_s, n.call("spcl_conv_num_tiles", N, H, W), dtype=torch.float32, device="cuda")
+        nt = n.call("spcl_conv_num_tiles", N, H, W)
+        st = torch.empty(n.call("spcl_bn_stats_elems", nt, cout_s), dtype=torch.float32, device="cuda")
+        st.ntiles = nt
     n.call("spcl_conv3x3_forward", n.ptr(xs), n.dtype_code(dtype), N, H, W, cin_s, cin_k, cout_s, n.ptr(wp), mode,
            n.ptr(scale), n.ptr(shift), n.ptr(y), n.ptr(st), n.stream())
     return y, st
@@ -82,8 +84,8 @@ def test_conv_forward_raw_and_stats(dt, N, ci, co, H, W):
     if cs_o > co:
         assert float(y[..., co:].float().abs().max()) == 0.0
     # Chan partials combine to the batch statistics
-    st = st.double().cpu()
-    cnt, mean, m2 = st[0, :co].t(), st[1, :co].t(), st[2, :co].t()
+    st = st[:st.ntiles * 3 * cs_o].view(st.ntiles, 3, cs_o).double().cpu()  # rows [tile][3][CoutS]
+    cnt, mean, m2 = st[:, 0, :co], st[:, 1, :co], st[:, 2, :co]
     tot = cnt.sum(0)
     assert int(tot[0]) == N * H * W
     gmean = (cnt * mean).sum(0) / tot
@@ -207,10 +209,10 @@ def test_bn_relu_pool_forward_backward(dt, N, C, H, W, pool, with_act):
     # HIP statistics through bn_finalize from a single exact partial
     mean = y.double().mean(dim=(0, 2, 3))
     var = y.double().var(dim=(0, 2, 3), unbiased=False)
-    stats = torch.zeros(3, cs, 1)
-    stats[0, :C, 0] = N * H * W
-    stats[1, :C, 0] = mean.float()
-    stats[2, :C, 0] = (var * N * H * W).float()
+    stats = torch.zeros(1, 3, cs)
+    stats[0, 0, :C] = N * H * W
+    stats[0, 1, :C] = mean.float()
+    stats[0, 2, :C] = (var * N * H * W).float()
     rm, rv = torch.zeros(C).cuda(), torch.ones(C).cuda()
     nbt = torch.zeros((), dtype=torch.long).cuda()
     st = torch.empty(4, cs, device="cuda")

@@ -1,4 +1,5 @@
 """Micro-benchmark of individual C-ABI kernels at the BASELINE layer shapes (HIP-event timed, isolated launches)."""
+from ctypes import c_float
 import os
 import sys
 
@@ -47,13 +48,20 @@ def main():
             wp = torch.empty(n.call("spcl_conv_packed_elems", ci, co, 0, dtc), dtype=dtype, device="cuda")
             n.call("spcl_conv_pack_weights", n.ptr(w), ci, co, 0, dtc, n.ptr(wp), n.stream())
             y = torch.empty(N, H, W, cs_o, dtype=dtype, device="cuda")
-            st = torch.empty(3, cs_o, n.call("spcl_conv_num_tiles", N, H, W), device="cuda")
+            nt_ = n.call("spcl_conv_num_tiles", N, H, W)
+            st = torch.empty(n.call("spcl_bn_stats_elems", nt_, cs_o), device="cuda")
             mode = 2 if img else 1
             t = timeit(lambda: n.call("spcl_conv3x3_forward", n.ptr(x), dtc, N, H, W, ci if img else cs_i, 16 if img else cs_i,
                                       cs_o, n.ptr(wp), mode, n.ptr(sc), n.ptr(sh), n.ptr(y), n.ptr(st), n.stream()))
             byts = px * ((ci * 4 if img else cs_i * es) + cs_o * es)
             fl = 2.0 * px * 9 * ci * co
             line += f"fwd {t:7.1f}us ({byts / t / 1e3:6.0f} GB/s, {fl / t / 1e6:6.1f} TF) | "
+            gam, bet = torch.ones(co, device="cuda"), torch.zeros(co, device="cuda")
+            o4 = torch.empty(4, cs_o, device="cuda")
+            t = timeit(lambda: n.call("spcl_bn_finalize", n.ptr(st), nt_, co, cs_o, n.ptr(gam), n.ptr(bet), c_float(0.1),
+                                      c_float(1e-5), None, None, None, n.ptr(o4[0]), n.ptr(o4[1]), n.ptr(o4[2]),
+                                      n.ptr(o4[3]), n.stream()))
+            line += f"bnfin {t:5.1f}us | "
         if "dgrad" in which and not img:
             wp = torch.empty(n.call("spcl_conv_packed_elems", ci, co, 1, dtc), dtype=dtype, device="cuda")
             n.call("spcl_conv_pack_weights", n.ptr(w), ci, co, 1, dtc, n.ptr(wp), n.stream())
