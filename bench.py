@@ -73,7 +73,8 @@ def build_step(args, device, rank, world):
     params = [p for p in model.parameters() if p.requires_grad]
     hparams = list(hook.parameters())
     flat = ddp.FlatParams(params + hparams)  # one flat parameter + one flat gradient bucket (all-reduced when N>1)
-    opt = torch.optim.RAdam([flat.param], lr=5e-7 * 400, weight_decay=1e-5, capturable=True, foreach=True)
+    from spcl_amd.optim import FusedRAdam
+    opt = FusedRAdam([flat.param], lr=5e-7 * 400, weight_decay=1e-5)  # torch.optim.RAdam semantics, HIP kernel
     loader = SyntheticPretrainLoader(bs=args.bs, size=args.size, device=device, seed=1234 + rank, resident=True)
     epocher = PretrainEncoderEpocher(model=model, optimizer=opt, chain_dataloader=loader, num_batches=10 ** 9,
                                      device=device, inference_until="Conv5", flat_params=flat)

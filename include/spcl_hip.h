@@ -142,6 +142,17 @@ int spcl_bnrelu_pool_backward(const void* y, const void* dact, const void* dpool
                               const float* shift, int training, float* ws, float* dgamma, float* dbeta, void* dy,
                               void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Optimizer step of the pre-train iteration (contrastyou/trainer/base.py:62 builds RAdam from the un-vendored
+ * deepclustering2; the build follows torch.optim.RAdam(decoupled_weight_decay=False)) on ONE
+ * flat fp32 parameter:  g' = g + wd p;  m = lerp(m, g', 1-b1);  v = b2 v + (1-b2) g'^2;  t = ++step;
+ *   rho_t = rho_inf - 2 t b2^t/(1-b2^t);  p -= lr m/(1-b1^t) * (rho_t > 5 ? rect(rho_t) sqrt(1-b2^t)/(sqrt(v)+eps) : 1).
+ * step (int64) and lr (float) live in device memory so that a captured hipGraph replays with an advancing step
+ * count and a host-updated learning rate; coef: 4 floats of device scratch.  All buffers 16-byte aligned. */
+int spcl_radam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, int64_t* step,
+                    const float* lr, double beta1, double beta2, double eps, double weight_decay, float* coef,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,83 @@
+// Fused RAdam step on ONE flat fp32 parameter (the optimizer step of the pre-train iteration,
+// contrastyou/trainer/base.py:62 -> RAdam; the build follows torch.optim.RAdam).
+// torch's foreach implementation is ~40 elementwise launches over the 1.3 M-element flat parameter (~270 us per
+// step); this is one 1-thread "tick" (step counter + the scalar coefficients, in double) and one streaming kernel
+// (p, g, m, v read once, p, m, v written once: 28 bytes per element).
+#include "common.hpp"
+
+namespace spcl {
+
+// coef[0] = lr / (1 - beta1^t);  coef[1] = rect * sqrt(1 - beta2^t) when rho_t > 5 else 0;  coef[2] = rho_t > 5
+__global__ void radam_tick_kernel(int64_t* step, const float* lr, double beta1, double beta2, float* coef) {
+  const int64_t t = step[0] + 1;
+  step[0] = t;
+  const double b1t = pow(beta1, (double)t), b2t = pow(beta2, (double)t);
+  const double bc1 = 1.0 - b1t, bc2 = 1.0 - b2t;
+  const double rho_inf = 2.0 / (1.0 - beta2) - 1.0;
+  const double rho_t = rho_inf - 2.0 * (double)t * b2t / bc2;
+  coef[0] = (float)((double)lr[0] / bc1);
+  if (rho_t > 5.0) {
+    const double rect = sqrt((rho_t - 4.0) * (rho_t - 2.0) * rho_inf / ((rho_inf - 4.0) * (rho_inf - 2.0) * rho_t));
+    coef[1] = (float)(rect * sqrt(bc2));
+    coef[2] = 1.f;
+  } else {
+    coef[1] = 0.f;
+    coef[2] = 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void radam_apply_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                          float* __restrict__ m, float* __restrict__ v, size_t n4,
+                                                          size_t n, const float* __restrict__ coef, float omb1,
+                                                          float beta2, float omb2, float eps, float wd) {
+  const float c_m = coef[0], c_u = coef[1];
+  const bool rect = coef[2] != 0.f;
+  auto upd = [&](float& pp, float gg, float& mm, float& vv) {
+    gg = fmaf(wd, pp, gg);
+    mm = fmaf(omb1, gg - mm, mm);              // lerp_(grad, 1 - beta1)
+    vv = fmaf(vv, beta2, omb2 * gg * gg);      // mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+    const float u = rect ? c_u / (sqrtf(vv) + eps) : 1.f;
+    pp = fmaf(-c_m * mm, u, pp);
+  };
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    f32x4 pp = ((f32x4*)p)[i], gg = ((const f32x4*)g)[i], mm = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float pe = pp[e], me = mm[e], ve = vv[e];
+      upd(pe, gg[e], me, ve);
+      pp[e] = pe; mm[e] = me; vv[e] = ve;
+    }
+    ((f32x4*)p)[i] = pp;
+    ((f32x4*)m)[i] = mm;
+    ((f32x4*)v)[i] = vv;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * n4)) {  // tail of n % 4 elements
+    const size_t i = 4 * n4 + threadIdx.x;
+    upd(p[i], g[i], m[i], v[i]);
+  }
+}
+
+}  // namespace spcl
+
+using namespace spcl;
+
+extern "C" int spcl_radam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                               int64_t* step, const float* lr, double beta1, double beta2, double eps,
+                               double weight_decay, float* coef, void* stream) {
+  SPCL_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && step && lr && coef, "radam_step: null pointer");
+  SPCL_CHECK_ARG(n > 0, "radam_step: empty parameter");
+  SPCL_CHECK_ARG(((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16 == 0,
+                 "radam_step: buffers must be 16-byte aligned");
+  SPCL_CHECK_ARG(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0, "radam_step: betas");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(radam_tick_kernel, dim3(1), dim3(1), 0, st, step, lr, beta1, beta2, coef);
+  const size_t n4 = n / 4;
+  size_t blocks = (n4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(radam_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, n4,
+                     n, (const float*)coef, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
+                     (float)weight_decay);
+  SPCL_LAUNCH_CHECK("radam_step");
+  return SPCL_OK;
+}

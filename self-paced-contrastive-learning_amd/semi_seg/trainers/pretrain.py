@@ -4,7 +4,7 @@ and the checkpoint layout of ``contrastyou/trainer/_io.py:49-71`` (``_model``/``
 ``__hooks__`` sub-dicts, so ``extract_model_state_dict`` style reuse of ``["_model"]`` interchanges).
 
 The reference's RAdam / GradualWarmupScheduler come from the un-vendored ``deepclustering2``; restated by contract with
-``torch.optim.RAdam`` and a linear warm-up to ``multiplier`` x lr over ``warmup_max`` epochs followed by
+``torch.optim.RAdam`` (as the fused HIP kernel ``optim.FusedRAdam``) and a linear warm-up to ``multiplier`` x lr over ``warmup_max`` epochs followed by
 CosineAnnealingLR(T_max=max_epoch-warmup_max, eta_min=1e-7)."""
 import math
 import os
@@ -14,6 +14,7 @@ import torch
 from torch import nn
 
 from ... import ddp as _ddp
+from ...optim import FusedRAdam
 from ..epochers.pretrain import PretrainEncoderEpocher
 from ..hooks.creator import feature_until_from_hooks
 
@@ -82,7 +83,7 @@ class PretrainEncoderTrainer:
         # the reference gives model and hook parameters two groups with identical lr / weight decay
         # (trainer/base.py:62-68): one flat parameter is the same optimisation problem
         self._flat = _ddp.FlatParams(params + hook_params)
-        self._optimizer = torch.optim.RAdam([self._flat.param], **self._optim_cfg)
+        self._optimizer = FusedRAdam([self._flat.param], **self._optim_cfg)  # torch.optim.RAdam semantics, one launch
         self._scheduler = WarmupCosine(self._optimizer, max_epoch=self._max_epoch, **self._sched_cfg)
 
     def _create_tra_epoch(self):

@@ -252,3 +252,33 @@ def test_bn_relu_pool_forward_backward(dt, N, C, H, W, pool, with_act):
     assert relerr(dgm.cpu(), gr.grad.float()) < tol
     assert relerr(dbt.cpu(), br.grad.float()) < tol
     assert relerr(dy[..., :C].permute(0, 3, 1, 2).float().cpu(), yr.grad.float()) < tol
+
+
+def test_fused_radam_matches_torch_radam():
+    """spcl_radam_step == torch.optim.RAdam (CPU, single tensor) over the un-rectified (rho_t <= 5) and rectified
+    steps, with weight decay and a learning-rate change in between."""
+    from spcl_amd.optim import FusedRAdam
+    g = torch.Generator().manual_seed(5)
+    n = 10007  # not a multiple of 4: exercises the tail
+    p0 = torch.randn(n, generator=g)
+    ref_p = torch.nn.Parameter(p0.clone())
+    hip_p = torch.nn.Parameter(p0.clone().cuda())
+    ref = torch.optim.RAdam([ref_p], lr=2e-3, weight_decay=1e-2, foreach=False)
+    hip = FusedRAdam([hip_p], lr=2e-3, weight_decay=1e-2)
+    for it in range(9):
+        grad = torch.randn(n, generator=g) * (1.0 + it)
+        if it == 6:
+            for o in (ref, hip):
+                o.param_groups[0]["lr"] = 5e-4
+        ref_p.grad = grad.clone()
+        hip_p.grad = grad.clone().cuda()
+        ref.step()
+        hip.step()
+        np.testing.assert_allclose(hip_p.detach().cpu().numpy(), ref_p.detach().numpy(), rtol=2e-6, atol=2e-7)
+    st = hip.state[hip_p]
+    assert int(st["step"]) == 9
+    np.testing.assert_allclose(st["exp_avg_sq"].cpu().numpy(), ref.state[ref_p]["exp_avg_sq"].numpy(), rtol=1e-5)
+    sd = hip.state_dict()
+    hip2 = FusedRAdam([hip_p], lr=2e-3, weight_decay=1e-2)
+    hip2.load_state_dict(sd)
+    assert hip2.state[hip_p]["step"].dtype == torch.int64 and int(hip2.state[hip_p]["step"]) == 9
