@@ -153,6 +153,13 @@ int spcl_radam_step(float* param, const float* grad, float* exp_avg, float* exp_
                     const float* lr, double beta1, double beta2, double eps, double weight_decay, float* coef,
                     void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Per-sample random flips of an NCHW batch (TensorRandomFlip(axis=[1,2], threshold=0.8), new_epocher.py:112, applied
+ * per sample in new_pretrain.py:57-58): out[n] = x[n] flipped along H when flags[n] & 1 and along W when flags[n] & 2.
+ * flags: device uint8[N] (the host draws the decisions from python `random`, as the reference does).  x != out. */
+int spcl_flip_batch(const void* x, void* out, int elem_size, int N, int C, int H, int W, const uint8_t* flags,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

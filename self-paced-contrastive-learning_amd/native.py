@@ -46,6 +46,7 @@ _SIGNATURES = {
     "spcl_bnrelu_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "spcl_bnrelu_pool_backward": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P,
                                           c_int, _P, _P, _P, _P, _P]),
+    "spcl_flip_batch": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "spcl_radam_step": (c_int, [_P, _P, _P, _P, c_size_t, _P, _P, c_double, c_double, c_double, c_double, _P, _P]),
 }
 

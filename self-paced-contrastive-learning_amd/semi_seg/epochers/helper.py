@@ -63,11 +63,33 @@ class TensorRandomFlip:
         dims = [a for a in self._axis if random.random() < self._threshold]
         return x.flip(dims) if dims else x
 
-    def apply_batch(self, x: torch.Tensor) -> torch.Tensor:
-        """Batched equivalent of ``stack([self(s) for s in x])`` drawing the same random stream: one gather per flip
-        pattern instead of one kernel per sample.  Index tensors are cached per decision pattern, so a repeated
-        pattern costs no host->device copy (and the call can be captured in a hipGraph)."""
+    def apply_batch(self, x: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+        """Batched equivalent of ``stack([self(s) for s in x])`` drawing the same random stream.
+
+        GPU tensors: ONE HIP launch (``spcl_flip_batch``) driven by a per-sample flag byte (bit 0: flip H, bit 1:
+        flip W); the flag tensor is cached per decision pattern, so a repeated pattern costs no host->device copy and
+        the call can be captured in a hipGraph.  ``out`` (same shape, contiguous) receives the result when given.
+        CPU tensors (host-side tests of the random stream only): one gather per flip pattern with torch ops."""
         dec = tuple(tuple(d) for d in self.decisions(x.shape[0]))
+        if x.is_cuda:
+            if x.dim() != 4 or tuple(self._axis) != (1, 2):
+                raise NotImplementedError("the HIP flip handles [N,C,H,W] batches flipped along H and/or W")
+            from ... import native as _n
+            key = (dec, x.device, "flags")
+            flags = self._plans.get(key)
+            if flags is None:
+                flags = torch.tensor([int(d[0]) | (int(d[1]) << 1) for d in dec], dtype=torch.uint8, device=x.device)
+                if len(self._plans) < 256:
+                    self._plans[key] = flags
+            xc = x.contiguous()
+            if out is None:
+                out = torch.empty_like(xc)
+            elif out.shape != xc.shape or not out.is_contiguous() or out.dtype != xc.dtype:
+                raise ValueError("apply_batch: `out` must be a contiguous tensor of x's shape and dtype")
+            N, C, H, W = xc.shape
+            _n.call("spcl_flip_batch", _n.ptr(xc), _n.ptr(out), xc.element_size(), N, C, H, W, _n.ptr(flags),
+                    _n.stream())
+            return out
         key = (dec, x.device)
         plan = self._plans.get(key)
         if plan is None:
@@ -78,7 +100,7 @@ class TensorRandomFlip:
                      torch.tensor(idx, dtype=torch.long, device=x.device)) for pat, idx in groups.items() if any(pat)]
             if len(self._plans) < 256:
                 self._plans[key] = plan
-        out = x.clone()
+        res = x.clone() if out is None else out.copy_(x)
         for dims, idx in plan:
-            out.index_copy_(0, idx, x.index_select(0, idx).flip(dims))
-        return out
+            res.index_copy_(0, idx, x.index_select(0, idx).flip(dims))
+        return res

@@ -26,6 +26,15 @@ def unzip_twice_transformed(data, device):
     return (image, image_tf), None, filename, partition_list, group_list
 
 
+def _cat_views(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """``torch.cat([a, b])`` (new_pretrain.py:93) -- as a view when a and b already are the two halves of one buffer."""
+    if (a.shape == b.shape and a.dtype == b.dtype and a.is_contiguous() and b.is_contiguous() and a.device == b.device
+            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+            and b.storage_offset() == a.storage_offset() + a.numel()):
+        return torch.as_strided(a, (2 * a.shape[0],) + tuple(a.shape[1:]), a.stride(), a.storage_offset())
+    return torch.cat([a, b], dim=0)
+
+
 class PretrainEncoderEpocher:
     meter_focus = "semi"
 
@@ -94,8 +103,7 @@ class PretrainEncoderEpocher:
     # ---- new_pretrain.py:91-96
     def _forward_pass(self, unlabeled_image, unlabeled_image_tf):
         n_unl = len(unlabeled_image)
-        predict_logits = self._model(torch.cat([unlabeled_image, unlabeled_image_tf], dim=0),
-                                     until=self._inference_until)
+        predict_logits = self._model(_cat_views(unlabeled_image, unlabeled_image_tf), until=self._inference_until)
         unlabeled_logits, unlabeled_tf_logits = torch.split(predict_logits, [n_unl, n_unl], dim=0)
         return unlabeled_logits, unlabeled_tf_logits
 
@@ -112,8 +120,19 @@ class PretrainEncoderEpocher:
         seed = random.randint(0, int(1e7)) if seed is None else seed
         (unlabeled_image, unlabeled_image_tf), _, unlabeled_filename, unl_partition, unl_group = \
             unzip_twice_transformed(data, self._device)
-        with FixRandomSeed(seed):
-            unlabeled_image_tf = self._affine_transformer.apply_batch(unlabeled_image_tf)
+        if unlabeled_image.is_cuda and unlabeled_image.shape == unlabeled_image_tf.shape:
+            # both views land in ONE [2n,C,H,W] buffer (view 1 copied, view 2 flipped straight into its half), so the
+            # torch.cat of new_pretrain.py:93 is a zero-copy view in `_forward_pass`
+            pair = torch.empty((2 * len(unlabeled_image),) + tuple(unlabeled_image.shape[1:]),
+                               dtype=unlabeled_image.dtype, device=unlabeled_image.device)
+            n_unl = len(unlabeled_image)
+            pair[:n_unl].copy_(unlabeled_image)
+            with FixRandomSeed(seed):
+                self._affine_transformer.apply_batch(unlabeled_image_tf.to(pair.dtype), out=pair[n_unl:])
+            unlabeled_image, unlabeled_image_tf = pair[:n_unl], pair[n_unl:]
+        else:
+            with FixRandomSeed(seed):
+                unlabeled_image_tf = self._affine_transformer.apply_batch(unlabeled_image_tf)
         unlabeled_logits, unlabeled_tf_logits = self.forward_pass(unlabeled_image=unlabeled_image,
                                                                   unlabeled_image_tf=unlabeled_image_tf)
         # new_pretrain.py:64-65 flips the Conv5 "logits" as well; the InfoNCE hook only takes len() of them

@@ -169,7 +169,9 @@ class _INFONCEEpochHook(EpocherHook):
     def __call__(self, *, affine_transformer, seed, unlabeled_tf_logits, unlabeled_logits_tf, partition_group,
                  label_group, **kwargs):
         n_unl = len(unlabeled_logits_tf)
-        feature_ = self._extractor.feature()[-n_unl * 2:]
+        feature_ = self._extractor.feature()
+        if feature_.shape[0] != n_unl * 2:  # a slice costs a zero-fill + strided copy in backward: only when needed
+            feature_ = feature_[-n_unl * 2:]
         unlabeled_features, unlabeled_tf_features = torch.chunk(feature_, 2, dim=0)
         pooled_global = tuple(getattr(self._projector, "_spatial_size", (1, 1))) == (1, 1)
         if not pooled_global:

@@ -282,3 +282,21 @@ def test_fused_radam_matches_torch_radam():
     hip2 = FusedRAdam([hip_p], lr=2e-3, weight_decay=1e-2)
     hip2.load_state_dict(sd)
     assert hip2.state[hip_p]["step"].dtype == torch.int64 and int(hip2.state[hip_p]["step"]) == 9
+
+
+@pytest.mark.parametrize("shape,dtype", [((32, 1, 224, 224), torch.float32), ((6, 3, 14, 10), torch.bfloat16),
+                                         ((5, 2, 7, 9), torch.float32)])
+def test_flip_batch_matches_per_sample_flips(shape, dtype):
+    """spcl_flip_batch == stack([flip(sample) ...]) with the reference's per-sample random stream (same seed)."""
+    from spcl_amd.semi_seg.epochers.helper import FixRandomSeed, TensorRandomFlip
+    f = TensorRandomFlip(axis=[1, 2], threshold=0.8)
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(1)).to(dtype)
+    with FixRandomSeed(11):
+        ref = torch.stack([f(s) for s in x], dim=0)
+    with FixRandomSeed(11):
+        got = f.apply_batch(x.cuda())
+    assert torch.equal(got.cpu(), ref)
+    out = torch.empty(2 * shape[0], *shape[1:], dtype=dtype, device="cuda")
+    with FixRandomSeed(11):
+        f.apply_batch(x.cuda(), out=out[shape[0]:])
+    assert torch.equal(out[shape[0]:].cpu(), ref)
