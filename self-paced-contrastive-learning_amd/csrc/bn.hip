@@ -140,67 +140,14 @@ __global__ __launch_bounds__(256) void bn_eval_affine_kernel(int C, int CS, cons
   shift[c] = beta[c] - rm[c] * sc;
 }
 
-// ------------------------------------------------------------------------------------------------ forward
-// thread = (output position, 16-byte channel chunk).  POOL: position = 2x2 window, else a single pixel.
-template <typename T, bool POOL>
-__global__ __launch_bounds__(256) void bnrelu_fwd_kernel(const T* __restrict__ y, int N, int H, int W, int CS,
-                                                         const float* __restrict__ scale,
-                                                         const float* __restrict__ shift, T* __restrict__ act,
-                                                         T* __restrict__ pool) {
-  constexpr int EPC = Chunk<T>::EPC;
-  const int CPC = CS / EPC;
-  // POOL: positions are 2x2 windows on the CEIL grid; torch.max_pool2d floors, so a window cut by an odd edge
-  // produces no pooled value but its pixels still get their activation
-  const int PH = POOL ? (H + 1) / 2 : H, PW = POOL ? (W + 1) / 2 : W;
-  const int OH = H / 2, OW = W / 2;
-  const size_t total = (size_t)N * PH * PW * CPC;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    const int cc = (int)(idx % CPC);
-    const size_t pos = idx / CPC;
-    const int ox = (int)(pos % PW), oy = (int)((pos / PW) % PH), n = (int)(pos / ((size_t)PW * PH));
-    float sc[EPC], sh[EPC];
-#pragma unroll
-    for (int e = 0; e < EPC; e += 4) {
-      *(f32x4*)&sc[e] = *(const f32x4*)(scale + cc * EPC + e);
-      *(f32x4*)&sh[e] = *(const f32x4*)(shift + cc * EPC + e);
-    }
-    if (POOL) {
-      float mx[EPC];
-#pragma unroll
-      for (int e = 0; e < EPC; ++e) mx[e] = 0.f;  // activations are >= 0
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int yy = 2 * oy + (k >> 1), xx = 2 * ox + (k & 1);
-        if (yy < H && xx < W) {
-          const size_t off = (((size_t)n * H + yy) * W + xx) * CS + cc * EPC;
-          float v[EPC];
-          unpack<T>(*(const u32x4*)(y + off), v);
-#pragma unroll
-          for (int e = 0; e < EPC; ++e) {
-            v[e] = fmaxf(fmaf(sc[e], v[e], sh[e]), 0.f);
-            mx[e] = fmaxf(mx[e], v[e]);
-          }
-          if (act != nullptr) *(u32x4*)(act + off) = pack<T>(v);
-        }
-      }
-      if (pool != nullptr && oy < OH && ox < OW)
-        *(u32x4*)(pool + (((size_t)n * OH + oy) * OW + ox) * CS + cc * EPC) = pack<T>(mx);
-    } else {
-      const size_t off = (((size_t)n * H + oy) * W + ox) * CS + cc * EPC;
-      float v[EPC];
-      unpack<T>(*(const u32x4*)(y + off), v);
-#pragma unroll
-      for (int e = 0; e < EPC; ++e) v[e] = fmaxf(fmaf(sc[e], v[e], sh[e]), 0.f);
-      *(u32x4*)(act + off) = pack<T>(v);
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------ backward
-// One position = one 2x2 window (POOL) or one pixel, one 16-byte channel chunk.  The raw packed loads stay in
-// registers and the math runs channel by channel (element-outer), which keeps the live state small (occupancy):
-//   z = scale*y+shift;  g = dact (+ dpool at the window arg-max: first max in scan order like torch.max_pool2d)
-//   dz = g * [z > 0]
+// ------------------------------------------------------------------------------------------------ streaming kernels
+// BN-apply + ReLU (+ 2x2 max-pool) forward and backward are HBM streams.  Common thread geometry: a thread owns ONE
+// 16-byte channel chunk `cc` for the whole launch -- its per-channel coefficients stay in registers -- and walks the
+// positions pl, pl + PL, ... (PL = position lanes per workgroup).  No integer division in any loop (the image / row
+// split is wave-uniform scalar work per ROW), several independent 16-byte loads in flight per thread.
+//   non-pool: positions are pixels, the tensors are walked linearly;
+//   pool:     positions are 2x2 windows on the CEIL grid, walked row by row (torch.max_pool2d floors: a window cut by
+//             an odd edge produces no pooled value, but its pixels still get their activation / gradient).
 template <typename T> struct Word;  // one 32-bit word of a packed chunk
 template <> struct Word<float> {
   static constexpr int EPW = 1;
@@ -217,103 +164,132 @@ template <> struct Word<bf16_t> {
   }
 };
 
-template <typename T, bool POOL, int K>
-struct BwdRaw {
-  u32x4 ry[K], rg[K], rdp;
-  size_t off[K];
-  bool valid[K], has_g, complete;
-  __device__ __forceinline__ void load(const T* y, const T* dact, const T* dpool, int n, int oy, int ox, int H, int W,
-                                       int CS, int cc) {
-    constexpr int EPC = Chunk<T>::EPC;
-    has_g = dact != nullptr;
+template <int EPC> __device__ __forceinline__ void load_coef(float* dst, const float* src, int cc) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const int yy = POOL ? 2 * oy + (k >> 1) : oy, xx = POOL ? 2 * ox + (k & 1) : ox;
-      valid[k] = yy < H && xx < W;
-      off[k] = (((size_t)n * H + yy) * W + xx) * CS + cc * EPC;
-      ry[k] = (u32x4){0u, 0u, 0u, 0u};
-      rg[k] = (u32x4){0u, 0u, 0u, 0u};
-      if (valid[k]) {
-        ry[k] = *(const u32x4*)(y + off[k]);
-        if (has_g) rg[k] = *(const u32x4*)(dact + off[k]);
-      }
+  for (int e = 0; e < EPC; e += 4) *(f32x4*)&dst[e] = *(const f32x4*)(src + cc * EPC + e);
+}
+
+constexpr int STREAM_UNROLL = 2;
+
+// ---- forward, no pooling: act = relu(scale*y + shift)
+template <typename T>
+__global__ __launch_bounds__(256, 6) void bnrelu_fwd_lin_kernel(const T* __restrict__ y, size_t npix, int CS,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, T* __restrict__ act) {
+  constexpr int EPC = Chunk<T>::EPC, U = STREAM_UNROLL;
+  const int CPC = CS / EPC, PL = 256 / CPC;
+  const int cc = threadIdx.x % CPC, pl = threadIdx.x / CPC;
+  if (pl >= PL) return;
+  float sc[EPC], sh[EPC];
+  load_coef<EPC>(sc, scale, cc);
+  load_coef<EPC>(sh, shift, cc);
+  const size_t stride = (size_t)gridDim.x * PL;
+  for (size_t p = (size_t)blockIdx.x * PL + pl; p < npix; p += U * stride) {
+    u32x4 r[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (p + u * stride < npix) r[u] = *(const u32x4*)(y + (p + u * stride) * CS + cc * EPC);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (p + u * stride >= npix) break;
+      float v[EPC];
+      unpack<T>(r[u], v);
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) v[e] = fmaxf(fmaf(sc[e], v[e], sh[e]), 0.f);
+      *(u32x4*)(act + (p + u * stride) * CS + cc * EPC) = pack<T>(v);
     }
-    complete = POOL && dpool != nullptr && oy < H / 2 && ox < W / 2;  // floor semantics of max_pool2d
-    rdp = (u32x4){0u, 0u, 0u, 0u};
-    if (complete) rdp = *(const u32x4*)(dpool + (((size_t)n * (H / 2) + oy) * (W / 2) + ox) * CS + cc * EPC);
   }
-  // dz of channel element (wi, h) for the K pixels; yk = the raw y values
-  __device__ __forceinline__ void elem(int wi, int h, float sc, float sh, float* yk, float* dz) const {
-    float z[K];
-    int best = 0;
-    float m = 0.f;
+}
+
+// one 2x2 window of one channel chunk: raw loads (issued together), then the math
+template <typename T>
+struct Window {
+  u32x4 ry[4];
+  bool valid[4];
+  size_t off[4];
+  // (n, oy) wave-uniform; ox per thread
+  __device__ __forceinline__ void load(const T* y, size_t row0, int oy, int ox, int H, int W, int CS, int cc) {
+    constexpr int EPC = Chunk<T>::EPC;
+    const bool y1 = 2 * oy + 1 < H, x1 = 2 * ox + 1 < W;
+    const size_t o00 = (row0 * W + 2 * ox) * CS + cc * EPC;  // row0 = n*H + 2*oy
+    off[0] = o00; off[1] = o00 + CS; off[2] = o00 + (size_t)W * CS; off[3] = off[2] + CS;
+    valid[0] = true; valid[1] = x1; valid[2] = y1; valid[3] = x1 && y1;
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      yk[k] = Word<T>::get(ry[k][wi], h);
-      z[k] = valid[k] ? fmaf(sc, yk[k], sh) : -1.f;
-      const float a = fmaxf(z[k], 0.f);
-      if (k == 0) m = a;
-      else if (a > m) { m = a; best = k; }
-    }
-    const float dp = complete ? Word<T>::get(rdp[wi], h) : 0.f;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      float g = Word<T>::get(rg[k][wi], h);
-      if (POOL) g += (k == best) ? dp : 0.f;
-      dz[k] = z[k] > 0.f ? g : 0.f;
+    for (int k = 0; k < 4; ++k) {
+      ry[k] = (u32x4){0u, 0u, 0u, 0u};
+      if (valid[k]) ry[k] = *(const u32x4*)(y + off[k]);
     }
   }
 };
 
-constexpr int BWD_MAX_WG = 512;
-
-template <typename T, bool POOL>
-__global__ __launch_bounds__(256, 4) void bnrelu_bwd_reduce_kernel(const T* __restrict__ y, const T* __restrict__ dact,
-                                                                const T* __restrict__ dpool, int N, int H, int W,
-                                                                int CS, const float* __restrict__ mean,
-                                                                const float* __restrict__ invstd,
-                                                                const float* __restrict__ scale,
-                                                                const float* __restrict__ shift,
-                                                                float* __restrict__ partial /* [grid][2][CS] */) {
+// ---- forward with 2x2 max-pool (act optional)
+template <typename T>
+__global__ __launch_bounds__(256, 4) void bnrelu_fwd_pool_kernel(const T* __restrict__ y, int N, int H, int W, int CS,
+                                                              const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, T* __restrict__ act,
+                                                              T* __restrict__ pool) {
   constexpr int EPC = Chunk<T>::EPC, EPW = Word<T>::EPW;
-  constexpr int K = POOL ? 4 : 1;
-  __shared__ float red[256][2 * EPC + 1];
-  const int CPC = CS / EPC;          // chunks per pixel
-  const int PL = 256 / CPC;          // position lanes per workgroup
+  const int CPC = CS / EPC, PL = 256 / CPC;
   const int cc = threadIdx.x % CPC, pl = threadIdx.x / CPC;
-  const int OH = POOL ? (H + 1) / 2 : H, OW = POOL ? (W + 1) / 2 : W;  // ceil grid: every pixel is visited once
-  const size_t npos = (size_t)N * OH * OW;
-  float sc[EPC], sh[EPC], mu[EPC], is[EPC];
+  if (pl >= PL) return;
+  const int PH = (H + 1) / 2, PW = (W + 1) / 2, OH = H / 2, OW = W / 2;
+  float sc[EPC], sh[EPC];
+  load_coef<EPC>(sc, scale, cc);
+  load_coef<EPC>(sh, shift, cc);
+  const int rows = N * PH;
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const int n = r / PH, oy = r - n * PH;  // wave-uniform
+    const size_t row0 = (size_t)n * H + 2 * oy;
+    for (int ox = pl; ox < PW; ox += 2 * PL) {
+      Window<T> w[2];
+      const bool second = ox + PL < PW;
+      w[0].load(y, row0, oy, ox, H, W, CS, cc);
+      if (second) w[1].load(y, row0, oy, ox + PL, H, W, CS, cc);
 #pragma unroll
-  for (int e = 0; e < EPC; e += 4) {
-    *(f32x4*)&sc[e] = *(const f32x4*)(scale + cc * EPC + e);
-    *(f32x4*)&sh[e] = *(const f32x4*)(shift + cc * EPC + e);
-    *(f32x4*)&mu[e] = *(const f32x4*)(mean + cc * EPC + e);
-    *(f32x4*)&is[e] = *(const f32x4*)(invstd + cc * EPC + e);
-  }
-  float s1[EPC], s2[EPC];
+      for (int u = 0; u < 2; ++u) {
+        if (u == 1 && !second) break;
+        u32x4 mxw, aw[4];
 #pragma unroll
-  for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = 0.f;
-  if (pl < PL) {
-    for (size_t pos = (size_t)blockIdx.x * PL + pl; pos < npos; pos += (size_t)gridDim.x * PL) {
-      const int ox = (int)(pos % OW), oy = (int)((pos / OW) % OH), n = (int)(pos / ((size_t)OW * OH));
-      BwdRaw<T, POOL, K> b;
-      b.load(y, dact, dpool, n, oy, ox, H, W, CS, cc);
+        for (int wi = 0; wi < 4; ++wi) {
+          float mx[EPW], a[4][EPW];
 #pragma unroll
-      for (int wi = 0; wi < 4; ++wi)
+          for (int h = 0; h < EPW; ++h) {
+            const int e = wi * EPW + h;
+            mx[h] = 0.f;  // activations are >= 0
 #pragma unroll
-        for (int h = 0; h < EPW; ++h) {
-          const int e = wi * EPW + h;
-          float yk[K], dz[K];
-          b.elem(wi, h, sc[e], sh[e], yk, dz);
-#pragma unroll
-          for (int k = 0; k < K; ++k) {  // invalid pixels carry dz == 0
-            s1[e] += dz[k];
-            s2[e] = fmaf(dz[k], (yk[k] - mu[e]) * is[e], s2[e]);
+            for (int k = 0; k < 4; ++k) {
+              a[k][h] = fmaxf(fmaf(sc[e], Word<T>::get(w[u].ry[k][wi], h), sh[e]), 0.f);
+              if (w[u].valid[k]) mx[h] = fmaxf(mx[h], a[k][h]);
+            }
           }
+          mxw[wi] = Word<T>::make(mx);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) aw[k][wi] = Word<T>::make(a[k]);
         }
+        const int oxu = ox + u * PL;
+        if (act != nullptr) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (w[u].valid[k]) *(u32x4*)(act + w[u].off[k]) = aw[k];
+        }
+        if (pool != nullptr && oy < OH && oxu < OW)
+          *(u32x4*)(pool + (((size_t)n * OH + oy) * OW + oxu) * CS + cc * EPC) = mxw;
+      }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+//   z = scale*y + shift;  g = dact (+ dpool at the window arg-max: first max in scan order like torch.max_pool2d);
+//   dz = g * [z > 0];  dbeta = sum dz, dgamma = sum dz*yhat;
+//   training: dy = scale*(dz - dbeta/M - yhat*dgamma/M), folded to dy = scale*dz + A*y + B;  eval: dy = scale*dz.
+// Pass 1 (reduce) leaves per-workgroup partials, `fin` sums them in fixed order (deterministic), pass 2 applies.
+constexpr int BWD_MAX_WG = 2048;
+constexpr int STREAM_MAX_WG = 2048;  // long-lived workgroups: launching a wave costs more than an iteration
+
+template <typename T, int EPC>
+__device__ __forceinline__ void wg_reduce_partials(const float* s1, const float* s2, int CS, int CPC, int PL,
+                                                   float* __restrict__ partial, float (*red)[2 * EPC + 1]) {
 #pragma unroll
   for (int e = 0; e < EPC; ++e) {
     red[threadIdx.x][e] = s1[e];
@@ -329,8 +305,178 @@ __global__ __launch_bounds__(256, 4) void bnrelu_bwd_reduce_kernel(const T* __re
   }
 }
 
-// dbeta = sum dz, dgamma = sum dz*yhat.  One wave per channel: lanes stride over the workgroup partials, then a
-// fixed-order butterfly -> deterministic.  For the apply pass the BN-backward is folded to  dy = scale*dz + A*y + B:
+// ---- pass 1, no pooling (linear)
+template <typename T>
+__global__ __launch_bounds__(256, 5) void bnrelu_bwd_reduce_lin_kernel(const T* __restrict__ y, const T* __restrict__ g,
+                                                                    size_t npix, int CS,
+                                                                    const float* __restrict__ mean,
+                                                                    const float* __restrict__ invstd,
+                                                                    const float* __restrict__ scale,
+                                                                    const float* __restrict__ shift,
+                                                                    float* __restrict__ partial /* [grid][2][CS] */) {
+  constexpr int EPC = Chunk<T>::EPC, EPW = Word<T>::EPW, U = STREAM_UNROLL;
+  __shared__ float red[256][2 * EPC + 1];
+  const int CPC = CS / EPC, PL = 256 / CPC;
+  const int cc = threadIdx.x % CPC, pl = threadIdx.x / CPC;
+  float s1[EPC], s2[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = 0.f;
+  if (pl < PL) {
+    float sc[EPC], sh[EPC], mu[EPC], is[EPC];
+    load_coef<EPC>(sc, scale, cc);
+    load_coef<EPC>(sh, shift, cc);
+    load_coef<EPC>(mu, mean, cc);
+    load_coef<EPC>(is, invstd, cc);
+    const size_t stride = (size_t)gridDim.x * PL;
+    for (size_t p = (size_t)blockIdx.x * PL + pl; p < npix; p += U * stride) {
+      u32x4 ry[U], rg[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        ry[u] = rg[u] = (u32x4){0u, 0u, 0u, 0u};  // a zero gradient contributes nothing
+        if (p + u * stride < npix) {
+          ry[u] = *(const u32x4*)(y + (p + u * stride) * CS + cc * EPC);
+          rg[u] = *(const u32x4*)(g + (p + u * stride) * CS + cc * EPC);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int wi = 0; wi < 4; ++wi)
+#pragma unroll
+          for (int h = 0; h < EPW; ++h) {
+            const int e = wi * EPW + h;
+            const float yv = Word<T>::get(ry[u][wi], h);
+            const float dz = fmaf(sc[e], yv, sh[e]) > 0.f ? Word<T>::get(rg[u][wi], h) : 0.f;
+            s1[e] += dz;
+            s2[e] = fmaf(dz, yv - mu[e], s2[e]);
+          }
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) s2[e] *= is[e];  // sum dz*yhat = invstd * sum dz*(y - mean)
+  }
+  wg_reduce_partials<T, EPC>(s1, s2, CS, CPC, PL, partial, red);
+}
+
+// the window's dz for channel element (wi, h): pooled gradient routed to the first maximum, ReLU gate
+template <typename T>
+__device__ __forceinline__ void window_dz(const Window<T>& w, const u32x4* rg, bool has_g, u32x4 rdp, bool complete,
+                                          int wi, int h, float sc, float sh, float* yk, float* dz) {
+  float z[4];
+  int best = 0;
+  float m = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    yk[k] = Word<T>::get(w.ry[k][wi], h);
+    z[k] = w.valid[k] ? fmaf(sc, yk[k], sh) : -1.f;
+    const float a = fmaxf(z[k], 0.f);
+    if (k == 0) m = a;
+    else if (a > m) { m = a; best = k; }
+  }
+  const float dp = complete ? Word<T>::get(rdp[wi], h) : 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float g = has_g ? Word<T>::get(rg[k][wi], h) : 0.f;
+    g += (k == best) ? dp : 0.f;
+    dz[k] = z[k] > 0.f ? g : 0.f;
+  }
+}
+
+// ---- pass 1 / pass 2 with pooling.  APPLY == false: partial sums;  true: dy
+template <typename T, bool APPLY>
+__global__ __launch_bounds__(256, 3) void bnrelu_bwd_pool_kernel(const T* __restrict__ y, const T* __restrict__ dact,
+                                                              const T* __restrict__ dpool, int N, int H, int W, int CS,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd,
+                                                              const float* __restrict__ scale,
+                                                              const float* __restrict__ shift,
+                                                              const float* __restrict__ ab, float* __restrict__ partial,
+                                                              T* __restrict__ dy) {
+  constexpr int EPC = Chunk<T>::EPC, EPW = Word<T>::EPW;
+  __shared__ float red[APPLY ? 1 : 256][2 * EPC + 1];
+  const int CPC = CS / EPC, PL = 256 / CPC;
+  const int cc = threadIdx.x % CPC, pl = threadIdx.x / CPC;
+  const int PH = (H + 1) / 2, PW = (W + 1) / 2, OH = H / 2, OW = W / 2;
+  const bool has_g = dact != nullptr;
+  float s1[EPC], s2[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = 0.f;
+  if (pl < PL) {
+    float sc[EPC], sh[EPC], c0[EPC], c1[EPC];  // reduce: c0 = mean, c1 = invstd;  apply: c0 = A, c1 = B
+    load_coef<EPC>(sc, scale, cc);
+    load_coef<EPC>(sh, shift, cc);
+    load_coef<EPC>(c0, APPLY ? ab : mean, cc);
+    load_coef<EPC>(c1, APPLY ? ab + CS : invstd, cc);
+    const int rows = N * PH;
+    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+      const int n = r / PH, oy = r - n * PH;  // wave-uniform
+      const size_t row0 = (size_t)n * H + 2 * oy;
+      for (int ox = pl; ox < PW; ox += PL) {
+        Window<T> w;
+        w.load(y, row0, oy, ox, H, W, CS, cc);
+        u32x4 rg[4], rdp = {0u, 0u, 0u, 0u};
+        if (has_g) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            rg[k] = (u32x4){0u, 0u, 0u, 0u};
+            if (w.valid[k]) rg[k] = *(const u32x4*)(dact + w.off[k]);
+          }
+        }
+        const bool complete = dpool != nullptr && oy < OH && ox < OW;  // floor semantics of max_pool2d
+        if (complete) rdp = *(const u32x4*)(dpool + (((size_t)n * OH + oy) * OW + ox) * CS + cc * EPC);
+        u32x4 out[4];
+#pragma unroll
+        for (int wi = 0; wi < 4; ++wi) {
+          float o[4][EPW];
+#pragma unroll
+          for (int h = 0; h < EPW; ++h) {
+            const int e = wi * EPW + h;
+            if (!APPLY && !has_g) {
+              // pooled gradient only: dz is non-zero at the window's first maximum alone -> track (z, y) of it
+              float zb = -1.f, yb = 0.f;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const float yv = Word<T>::get(w.ry[k][wi], h);
+                const float z = w.valid[k] ? fmaf(sc[e], yv, sh[e]) : -1.f;
+                if (k == 0 || z > zb) { zb = z; yb = yv; }
+              }
+              const float dzb = (complete && zb > 0.f) ? Word<T>::get(rdp[wi], h) : 0.f;
+              s1[e] += dzb;
+              s2[e] = fmaf(dzb, yb - c0[e], s2[e]);
+              continue;
+            }
+            float yk[4], dz[4];
+            window_dz<T>(w, rg, has_g, rdp, complete, wi, h, sc[e], sh[e], yk, dz);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {  // invalid pixels carry dz == 0
+              if (APPLY) o[k][h] = fmaf(sc[e], dz[k], fmaf(c0[e], yk[k], c1[e]));
+              else {
+                s1[e] += dz[k];
+                s2[e] = fmaf(dz[k], yk[k] - c0[e], s2[e]);
+              }
+            }
+          }
+          if (APPLY) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) out[k][wi] = Word<T>::make(o[k]);
+          }
+        }
+        if (APPLY) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (w.valid[k]) *(u32x4*)(dy + w.off[k]) = out[k];
+        }
+      }
+    }
+    if (!APPLY) {
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) s2[e] *= c1[e];
+    }
+  }
+  if (!APPLY) wg_reduce_partials<T, EPC>(s1, s2, CS, CPC, PL, partial, red);
+}
+
+// dbeta = sum dz, dgamma = sum dz*yhat.  One workgroup per channel: threads stride over the workgroup partials, then
+// a fixed-order butterfly and a fixed-order sum of the 4 waves -> deterministic.  Folded coefficients for pass 2:
 //   training: A = -scale*invstd*dgamma/M,  B = -scale*dbeta/M - A*mean;   eval: A = B = 0
 __global__ __launch_bounds__(256) void bnrelu_bwd_fin_kernel(const float* __restrict__ partial, int nwg, int C, int CS,
                                                              float M, int training, const float* __restrict__ mean,
@@ -338,17 +484,22 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_fin_kernel(const float* __rest
                                                              const float* __restrict__ scale,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                              float* __restrict__ ab) {
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (c >= CS) return;
+  __shared__ float red[2][4];
+  const int c = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float s1 = 0.f, s2 = 0.f;
-  for (int w = lane; w < nwg; w += 64) {
+#pragma unroll 4
+  for (int w = threadIdx.x; w < nwg; w += 256) {
     s1 += partial[((size_t)w * 2 + 0) * CS + c];
     s2 += partial[((size_t)w * 2 + 1) * CS + c];
   }
   s1 = wave_sum(s1);
   s2 = wave_sum(s2);
-  if (lane == 0) {
+  if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s1 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    s2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     if (c < C) {
       dbeta[c] = s1;
       dgamma[c] = s2;
@@ -363,57 +514,75 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_fin_kernel(const float* __rest
   }
 }
 
-template <typename T, bool POOL>
-__global__ __launch_bounds__(256, 3) void bnrelu_bwd_apply_kernel(const T* __restrict__ y, const T* __restrict__ dact,
-                                                               const T* __restrict__ dpool, int N, int H, int W,
-                                                               int CS, const float* __restrict__ scale,
-                                                               const float* __restrict__ shift,
-                                                               const float* __restrict__ ab, T* __restrict__ dy) {
-  constexpr int EPC = Chunk<T>::EPC, EPW = Word<T>::EPW;
-  constexpr int K = POOL ? 4 : 1;
-  const int CPC = CS / EPC;
-  const int OH = POOL ? (H + 1) / 2 : H, OW = POOL ? (W + 1) / 2 : W;
-  const size_t total = (size_t)N * OH * OW * CPC;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    const int cc = (int)(idx % CPC);
-    const size_t pos = idx / CPC;
-    const int ox = (int)(pos % OW), oy = (int)((pos / OW) % OH), n = (int)(pos / ((size_t)OW * OH));
-    float sc[EPC], sh[EPC], A[EPC], B[EPC];
+// ---- pass 2, no pooling (linear): dy = scale*dz + A*y + B
+template <typename T>
+__global__ __launch_bounds__(256, 6) void bnrelu_bwd_apply_lin_kernel(const T* __restrict__ y, const T* __restrict__ g,
+                                                                   size_t npix, int CS,
+                                                                   const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift,
+                                                                   const float* __restrict__ ab, T* __restrict__ dy) {
+  constexpr int EPC = Chunk<T>::EPC, EPW = Word<T>::EPW, U = STREAM_UNROLL;
+  const int CPC = CS / EPC, PL = 256 / CPC;
+  const int cc = threadIdx.x % CPC, pl = threadIdx.x / CPC;
+  if (pl >= PL) return;
+  float sc[EPC], sh[EPC], A[EPC], B[EPC];
+  load_coef<EPC>(sc, scale, cc);
+  load_coef<EPC>(sh, shift, cc);
+  load_coef<EPC>(A, ab, cc);
+  load_coef<EPC>(B, ab + CS, cc);
+  const size_t stride = (size_t)gridDim.x * PL;
+  for (size_t p = (size_t)blockIdx.x * PL + pl; p < npix; p += U * stride) {
+    u32x4 ry[U], rg[U];
 #pragma unroll
-    for (int e = 0; e < EPC; e += 4) {
-      *(f32x4*)&sc[e] = *(const f32x4*)(scale + cc * EPC + e);
-      *(f32x4*)&sh[e] = *(const f32x4*)(shift + cc * EPC + e);
-      *(f32x4*)&A[e] = *(const f32x4*)(ab + cc * EPC + e);
-      *(f32x4*)&B[e] = *(const f32x4*)(ab + CS + cc * EPC + e);
-    }
-    BwdRaw<T, POOL, K> b;
-    b.load(y, dact, dpool, n, oy, ox, H, W, CS, cc);
-    u32x4 out[K];
-#pragma unroll
-    for (int wi = 0; wi < 4; ++wi) {
-      float o[K][EPW];
-#pragma unroll
-      for (int h = 0; h < EPW; ++h) {
-        const int e = wi * EPW + h;
-        float yk[K], dz[K];
-        b.elem(wi, h, sc[e], sh[e], yk, dz);
-#pragma unroll
-        for (int k = 0; k < K; ++k) o[k][h] = fmaf(sc[e], dz[k], fmaf(A[e], yk[k], B[e]));
+    for (int u = 0; u < U; ++u)
+      if (p + u * stride < npix) {
+        ry[u] = *(const u32x4*)(y + (p + u * stride) * CS + cc * EPC);
+        rg[u] = *(const u32x4*)(g + (p + u * stride) * CS + cc * EPC);
       }
 #pragma unroll
-      for (int k = 0; k < K; ++k) out[k][wi] = Word<T>::make(o[k]);
-    }
+    for (int u = 0; u < U; ++u) {
+      if (p + u * stride >= npix) break;
+      u32x4 out;
 #pragma unroll
-    for (int k = 0; k < K; ++k)
-      if (b.valid[k]) *(u32x4*)(dy + b.off[k]) = out[k];
+      for (int wi = 0; wi < 4; ++wi) {
+        float o[EPW];
+#pragma unroll
+        for (int h = 0; h < EPW; ++h) {
+          const int e = wi * EPW + h;
+          const float yv = Word<T>::get(ry[u][wi], h);
+          const float dz = fmaf(sc[e], yv, sh[e]) > 0.f ? Word<T>::get(rg[u][wi], h) : 0.f;
+          o[h] = fmaf(sc[e], dz, fmaf(A[e], yv, B[e]));
+        }
+        out[wi] = Word<T>::make(o);
+      }
+      *(u32x4*)(dy + (p + u * stride) * CS + cc * EPC) = out;
+    }
   }
 }
 
-static int stream_grid(size_t total_threads) {
-  size_t g = (total_threads + 255) / 256;
-  if (g > 4096) g = 4096;
+// enough workgroups to fill the chip several times over, never more than the positions need
+static int stream_grid(size_t positions, int PL, int unroll, int cap) {
+  size_t g = (positions + (size_t)PL * unroll - 1) / ((size_t)PL * unroll);
+  if (g > (size_t)cap) g = cap;
   if (g < 1) g = 1;
   return (int)g;
+}
+
+template <typename T>
+static int bnrelu_fwd_launch(const void* y, int N, int H, int W, int CS, const float* scale, const float* shift,
+                             void* act, void* pool, hipStream_t st) {
+  constexpr int EPC = Chunk<T>::EPC;
+  const int PL = 256 / (CS / EPC);
+  if (pool != nullptr) {
+    const int rows = N * ((H + 1) / 2);
+    hipLaunchKernelGGL((bnrelu_fwd_pool_kernel<T>), dim3(rows < STREAM_MAX_WG ? rows : STREAM_MAX_WG), dim3(256), 0, st, (const T*)y, N, H,
+                       W, CS, scale, shift, (T*)act, (T*)pool);
+  } else {
+    const size_t npix = (size_t)N * H * W;
+    hipLaunchKernelGGL((bnrelu_fwd_lin_kernel<T>), dim3(stream_grid(npix, PL, STREAM_UNROLL, STREAM_MAX_WG)), dim3(256), 0, st,
+                       (const T*)y, npix, CS, scale, shift, (T*)act);
+  }
+  return 0;
 }
 
 template <typename T>
@@ -422,31 +591,32 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
                              int training, float* ws, float* dgamma, float* dbeta, void* dy, hipStream_t st) {
   constexpr int EPC = Chunk<T>::EPC;
   const bool pool = dpool != nullptr;
-  const int OH = pool ? (H + 1) / 2 : H, OW = pool ? (W + 1) / 2 : W;
-  const size_t npos = (size_t)N * OH * OW;
-  const int CPC = CS / EPC;
-  const int PL = 256 / CPC;
-  int nwg = (int)((npos + PL - 1) / PL);
-  if (nwg > BWD_MAX_WG) nwg = BWD_MAX_WG;
-  float* partial = ws;                          // [nwg][2][CS]
+  const int PL = 256 / (CS / EPC);
+  const size_t npix = (size_t)N * H * W;
+  const int rows = N * ((H + 1) / 2);
+  float* partial = ws;                           // [nwg][2][CS]
   float* ab = ws + (size_t)BWD_MAX_WG * 2 * CS;  // [2][CS]: folded BN-backward coefficients
-  const float M = (float)((size_t)N * H * W);
+  const float M = (float)npix;
+  int nwg;
   if (pool) {
-    hipLaunchKernelGGL((bnrelu_bwd_reduce_kernel<T, true>), dim3(nwg), dim3(256), 0, st, (const T*)y, (const T*)dact,
-                       (const T*)dpool, N, H, W, CS, mean, invstd, scale, shift, partial);
+    nwg = rows < BWD_MAX_WG ? rows : BWD_MAX_WG;
+    hipLaunchKernelGGL((bnrelu_bwd_pool_kernel<T, false>), dim3(nwg), dim3(256), 0, st, (const T*)y, (const T*)dact,
+                       (const T*)dpool, N, H, W, CS, mean, invstd, scale, shift, (const float*)nullptr, partial,
+                       (T*)nullptr);
   } else {
-    hipLaunchKernelGGL((bnrelu_bwd_reduce_kernel<T, false>), dim3(nwg), dim3(256), 0, st, (const T*)y, (const T*)dact,
-                       (const T*)dpool, N, H, W, CS, mean, invstd, scale, shift, partial);
+    nwg = stream_grid(npix, PL, STREAM_UNROLL, BWD_MAX_WG);
+    hipLaunchKernelGGL((bnrelu_bwd_reduce_lin_kernel<T>), dim3(nwg), dim3(256), 0, st, (const T*)y, (const T*)dact, npix,
+                       CS, mean, invstd, scale, shift, partial);
   }
-  hipLaunchKernelGGL(bnrelu_bwd_fin_kernel, dim3(cdiv(CS, 4)), dim3(256), 0, st, (const float*)partial, nwg, C, CS,
+  hipLaunchKernelGGL(bnrelu_bwd_fin_kernel, dim3(CS), dim3(256), 0, st, (const float*)partial, nwg, C, CS,
                      M, training, mean, invstd, scale, dgamma, dbeta, ab);
-  const int grid = stream_grid(npos * CPC);
   if (pool) {
-    hipLaunchKernelGGL((bnrelu_bwd_apply_kernel<T, true>), dim3(grid), dim3(256), 0, st, (const T*)y, (const T*)dact,
-                       (const T*)dpool, N, H, W, CS, scale, shift, (const float*)ab, (T*)dy);
+    hipLaunchKernelGGL((bnrelu_bwd_pool_kernel<T, true>), dim3(rows < STREAM_MAX_WG ? rows : STREAM_MAX_WG), dim3(256), 0, st, (const T*)y,
+                       (const T*)dact, (const T*)dpool, N, H, W, CS, mean, invstd, scale, shift, (const float*)ab,
+                       (float*)nullptr, (T*)dy);
   } else {
-    hipLaunchKernelGGL((bnrelu_bwd_apply_kernel<T, false>), dim3(grid), dim3(256), 0, st, (const T*)y, (const T*)dact,
-                       (const T*)dpool, N, H, W, CS, scale, shift, (const float*)ab, (T*)dy);
+    hipLaunchKernelGGL((bnrelu_bwd_apply_lin_kernel<T>), dim3(stream_grid(npix, PL, STREAM_UNROLL, STREAM_MAX_WG)), dim3(256), 0,
+                       st, (const T*)y, (const T*)dact, npix, CS, scale, shift, (const float*)ab, (T*)dy);
   }
   return 0;
 }
@@ -496,31 +666,15 @@ extern "C" int spcl_bn_eval_affine(int C, int CS, const float* gamma, const floa
 extern "C" int spcl_bnrelu_pool_forward(const void* y, int dtype, int N, int H, int W, int CS, const float* scale,
                                         const float* shift, void* act_out, void* pool_out, void* stream) {
   SPCL_CHECK_ARG(y && scale && shift && (act_out || pool_out), "bnrelu_pool_forward: null pointer");
-  SPCL_CHECK_ARG(N > 0 && H > 0 && W > 0 && CS > 0 && CS % 16 == 0, "bnrelu_pool_forward: bad shape");
+  SPCL_CHECK_ARG(N > 0 && H > 0 && W > 0 && CS > 0 && CS % 16 == 0 && CS <= 1024, "bnrelu_pool_forward: bad shape");
   SPCL_CHECK_ARG(!pool_out || (H >= 2 && W >= 2), "bnrelu_pool_forward: 2x2 pooling needs H,W >= 2");
   hipStream_t st = (hipStream_t)stream;
   if (dtype != SPCL_F32 && dtype != SPCL_BF16) {
     set_error("bnrelu_pool_forward: dtype %d", dtype);
     return SPCL_EINVAL;
   }
-  const int epc = dtype == SPCL_F32 ? 4 : 8;
-  const size_t npos = pool_out ? (size_t)N * ((H + 1) / 2) * ((W + 1) / 2) : (size_t)N * H * W;
-  const int grid = stream_grid(npos * (CS / epc));
-  if (dtype == SPCL_F32) {
-    if (pool_out)
-      hipLaunchKernelGGL((bnrelu_fwd_kernel<float, true>), dim3(grid), dim3(256), 0, st, (const float*)y, N, H, W, CS,
-                         scale, shift, (float*)act_out, (float*)pool_out);
-    else
-      hipLaunchKernelGGL((bnrelu_fwd_kernel<float, false>), dim3(grid), dim3(256), 0, st, (const float*)y, N, H, W, CS,
-                         scale, shift, (float*)act_out, (float*)pool_out);
-  } else {
-    if (pool_out)
-      hipLaunchKernelGGL((bnrelu_fwd_kernel<bf16_t, true>), dim3(grid), dim3(256), 0, st, (const bf16_t*)y, N, H, W, CS,
-                         scale, shift, (bf16_t*)act_out, (bf16_t*)pool_out);
-    else
-      hipLaunchKernelGGL((bnrelu_fwd_kernel<bf16_t, false>), dim3(grid), dim3(256), 0, st, (const bf16_t*)y, N, H, W,
-                         CS, scale, shift, (bf16_t*)act_out, (bf16_t*)pool_out);
-  }
+  if (dtype == SPCL_F32) bnrelu_fwd_launch<float>(y, N, H, W, CS, scale, shift, act_out, pool_out, st);
+  else bnrelu_fwd_launch<bf16_t>(y, N, H, W, CS, scale, shift, act_out, pool_out, st);
   SPCL_LAUNCH_CHECK("bnrelu_pool_forward");
   return SPCL_OK;
 }

@@ -100,7 +100,12 @@ def main():
                                       n.ptr(mean), n.ptr(istd), n.ptr(scale), n.ptr(shift), 1, n.ptr(ws), n.ptr(dg),
                                       n.ptr(db), n.ptr(dyo), n.stream()))
             byts = px * cs_o * es * (2 * 1.25 + 1)
-            line += f"bnbwd(pool) {t:6.1f}us ({byts / t / 1e3:6.0f} GB/s)"
+            line += f"bnbwd(pool) {t:6.1f}us ({byts / t / 1e3:6.0f} GB/s) | "
+            t = timeit(lambda: n.call("spcl_bnrelu_pool_backward", n.ptr(dy), n.ptr(x if not img else dy), None, dtc, N, H, W,
+                                      co, cs_o, n.ptr(mean), n.ptr(istd), n.ptr(scale), n.ptr(shift), 1, n.ptr(ws),
+                                      n.ptr(dg), n.ptr(db), n.ptr(dyo), n.stream())) if cs_i == cs_o or img else float("nan")
+            byts = px * cs_o * es * 5
+            line += f"bnbwd(lin) {t:6.1f}us ({byts / t / 1e3:6.0f} GB/s)"
         print(line)
 
 
