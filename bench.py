@@ -106,105 +106,46 @@ def graph_capture(step, device):
 
 
 # ------------------------------------------------------------------------------------------------ roofline (live)
-def conv_cost(kind, N, H, W, cin, cout, esize):
-    """Algorithmic bytes / FLOPs of one conv-family launch (DESIGN.md 'roofline accounting')."""
-    px = N * H * W
-    flops = 2.0 * px * 9 * cin * cout
-    if kind == "wgrad":
-        byts = px * (cin + cout) * esize + 9 * cin * cout * 4
-    else:
-        byts = px * (cin + cout) * esize + 9 * cin * cout * esize
-    return byts, flops
-
-
 def measure_roofline(step, args):
-    """Instrumented pass: HIP events (torch.cuda.Event on the launch stream = torch's current stream, which is the
-    stream handed to every C-ABI call) around each C-ABI call; returns the dominant one with its roofline."""
+    """Instrumented pass with the library's built-in kernel timer: every kernel launch of libspcl_hip.so is bracketed
+    by HIP events ON ITS LAUNCH STREAM (spcl_profile_* of the C ABI; eager launches, not the graph) and reported with
+    its kernel symbol -- the names rocprofv3 prints -- and the algorithmic bytes / FLOPs its entry point declares
+    (DESIGN.md section 3).  Returns the roofline of the kernel symbol with the largest total time and a breakdown."""
+    import ctypes
     from spcl_amd import native
-    esize = 2 if args.dtype == "bf16" else 4
-    records = {}
-    orig_call = native.call
     reps = 5
-
-    def timed_call(name, *a):
-        if not name.startswith(("spcl_conv3x3", "spcl_bnrelu", "spcl_supcon_f", "spcl_supcon_b", "spcl_proj")):
-            return orig_call(name, *a)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        r = orig_call(name, *a)
-        e1.record()
-        key = name
-        meta = None
-        if name == "spcl_conv3x3_forward":
-            N, H, W, cin_s, cin_k, cout_s, mode = a[2], a[3], a[4], a[5], a[6], a[7], a[9]
-            cin = cin_s
-            key = f"{name}[N{N} {H}x{W} {cin}->{cout_s} mode{mode}]"
-            meta = ("conv",) + conv_cost("conv", N, H, W, cin, cout_s, esize if mode != 2 else esize)
-            if mode == 2:  # f32 image in, dtype out
-                meta = ("conv", N * H * W * (cin * 4 + cout_s * esize) + 9 * 16 * cout_s * esize,
-                        2.0 * N * H * W * 9 * cin * cout_s)
-        elif name == "spcl_conv3x3_wgrad":
-            N, H, W, cin, cin_s, cin_k, cout, cout_s, mode = a[3], a[4], a[5], a[6], a[7], a[8], a[9], a[10], a[11]
-            key = f"{name}[N{N} {H}x{W} {cin}x{cout} mode{mode}]"
-            meta = ("wgrad",) + conv_cost("wgrad", N, H, W, cin if mode != 2 else cin, cout, esize)
-        elif name == "spcl_bnrelu_pool_forward":
-            N, H, W, cs = a[2], a[3], a[4], a[5]
-            act, pool = a[8], a[9]
-            outb = (N * H * W * cs if act is not None and act.value else 0) + \
-                   (N * (H // 2) * (W // 2) * cs if pool is not None and pool.value else 0)
-            key = f"{name}[N{N} {H}x{W} C{cs}]"
-            meta = ("stream", (N * H * W * cs + outb) * esize, 0.0)
-        elif name == "spcl_bnrelu_pool_backward":
-            N, H, W, cs = a[4], a[5], a[6], a[8]
-            key = f"{name}[N{N} {H}x{W} C{cs}]"
-            # reduce pass reads y + g; apply pass reads y + g and writes dy (g at pooled resolution when pooled)
-            gsz = N * H * W * cs if (a[1] is not None and a[1].value) else N * (H // 2) * (W // 2) * cs
-            meta = ("stream", (2 * (N * H * W * cs + gsz) + N * H * W * cs) * esize, 0.0)
-        records.setdefault(key, {"ev": [], "meta": meta})["ev"].append((e0, e1))
-        return r
-
-    native.call = timed_call
-    import spcl_amd.functional as F_hip
-    F_hip._n.call = timed_call
+    step()
+    torch.cuda.synchronize()
+    native.call("spcl_profile_enable", 1)
     try:
         for _ in range(reps):
             step()
         torch.cuda.synchronize()
+        n = native.call("spcl_profile_count")
+        name = ctypes.create_string_buffer(256)
+        us, by, fl = ctypes.c_float(), ctypes.c_double(), ctypes.c_double()
+        groups = {}
+        for i in range(n):
+            native.call("spcl_profile_get", i, name, 256, ctypes.byref(us), ctypes.byref(by), ctypes.byref(fl))
+            g = groups.setdefault(name.value.decode(), {"t": 0.0, "n": 0, "bytes": 0.0, "flops": 0.0, "roof": 0.0,
+                                                        "hbm_t": 0.0, "mfma_t": 0.0})
+            g["t"] += us.value * 1e-6
+            g["n"] += 1
+            g["bytes"] += by.value
+            g["flops"] += fl.value
+            peak_tf = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+            hbm_t, mfma_t = by.value / (HBM_PEAK_GBS * 1e9), fl.value / (peak_tf * 1e12)
+            g["roof"] += max(hbm_t, mfma_t)
+            g["hbm_t"] += hbm_t
+            g["mfma_t"] += mfma_t
     finally:
-        native.call = orig_call
-        F_hip._n.call = orig_call
-    table = []
-    for key, rec in records.items():
-        ts = [e0.elapsed_time(e1) * 1e-3 for e0, e1 in rec["ev"]]
-        per_step = sum(ts) / reps
-        calls_per_step = len(ts) / reps
-        table.append((per_step, key, per_step / calls_per_step, calls_per_step, rec["meta"]))
-    table.sort(reverse=True)
-    total = sum(t[0] for t in table)
-    # ---- dominant KERNEL: spcl_conv3x3_forward is exactly one launch of conv3x3_mfma_kernel<T,14,14,NT>
-    # (NT = 2 when CoutS >= 32): group its calls by kernel symbol, as rocprofv3 --stats does
-    tname = "unsigned short" if args.dtype == "bf16" else "float"
-    groups = {}
-    for per_step, key, avg, calls, meta in table:
-        if not key.startswith("spcl_conv3x3_forward"):
-            continue
-        cout = int(key.split("->")[1].split()[0])
-        hw = int(key.split()[1].split("x")[0])
-        tile = ("7, 7" if hw <= 14 else ("7, 14" if hw <= 112 else "14, 14")) if hw % 14 == 0 else "16, 16"
-        sym = f"spcl::conv3x3_mfma_kernel<{tname}, {tile}, {2 if cout >= 32 else 1}>"
-        g = groups.setdefault(sym, {"t": 0.0, "n": 0.0, "bytes": 0.0, "flops": 0.0, "roof": 0.0})
-        kind, byts, flops = meta
-        peak_tf = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
-        g["t"] += per_step
-        g["n"] += calls
-        g["bytes"] += byts * calls
-        g["flops"] += flops * calls
-        g["roof"] += calls * max(byts / (HBM_PEAK_GBS * 1e9), flops / (peak_tf * 1e12))
-        g["hbm_t"] = g.get("hbm_t", 0.0) + calls * byts / (HBM_PEAK_GBS * 1e9)
-        g["mfma_t"] = g.get("mfma_t", 0.0) + calls * flops / (peak_tf * 1e12)
+        native.call("spcl_profile_enable", 0)
+    total = sum(g["t"] for g in groups.values()) / reps
+    ranked = sorted(groups.items(), key=lambda kv: -kv[1]["t"])
     out = None
-    if groups:
-        sym, g = max(groups.items(), key=lambda kv: kv[1]["t"])
+    for sym, g in ranked:
+        if g["bytes"] <= 0:
+            continue  # kernels without a declared cost (latency-bound glue) cannot carry a roofline
         avg = g["t"] / g["n"]
         peak_tf = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
         traffic = None
@@ -221,16 +162,19 @@ def measure_roofline(step, args):
             ach = g["flops"] / g["t"] / 1e12
             out = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak_tf, "unit": "TFLOP/s",
                    "frac": round(ach / peak_tf, 4), "traffic": traffic}
-        out.update({"kernel": sym, "avg_us": round(avg * 1e6, 2), "launches_per_step": g["n"],
+        out.update({"kernel": sym, "avg_us": round(avg * 1e6, 2), "launches_per_step": g["n"] / reps,
                     "algorithmic_bytes_per_launch": int(g["bytes"] / g["n"]),
                     "algorithmic_flops_per_launch": float(g["flops"] / g["n"]),
                     "mfma_tflops": round(g["flops"] / g["t"] / 1e12, 1),
                     "mixed_roofline_frac": round(g["roof"] / g["t"], 4),
-                    "share_of_instrumented_step": round(g["t"] / total, 4),
-                    "note": "aggregate over the launches of this kernel symbol in one step (forward convs of layers "
-                            "with >=32 output channels and the dgrad convs), HIP-event timed; mixed_roofline_frac = "
-                            "sum_l max(bytes_l/8TB/s, flops_l/2.5PF) / sum_l t_l"})
-    breakdown = [{"call": k, "us_per_step": round(p * 1e6, 1), "launches": c} for p, k, a, c, m in table[:14]]
+                    "share_of_instrumented_step": round(g["t"] / reps / total, 4),
+                    "note": "kernel symbol with the largest total time among the library's launches in one step "
+                            "(eager pass, HIP events on the launch stream via spcl_profile_*); bytes/FLOPs are the "
+                            "algorithmic figures of DESIGN.md section 3 summed over its launches"})
+        break
+    breakdown = [{"kernel": k, "us_per_step": round(g["t"] / reps * 1e6, 1), "launches": g["n"] / reps,
+                  "GBps": round(g["bytes"] / g["t"] / 1e9, 0) if g["bytes"] > 0 else None,
+                  "TFLOPs": round(g["flops"] / g["t"] / 1e12, 1) if g["flops"] > 0 else None} for k, g in ranked[:16]]
     return out, breakdown, total
 
 

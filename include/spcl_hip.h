@@ -160,6 +160,15 @@ int spcl_radam_step(float* param, const float* grad, float* exp_avg, float* exp_
 int spcl_flip_batch(const void* x, void* out, int elem_size, int N, int C, int H, int W, const uint8_t* flags,
                     void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Built-in kernel timer (bench.py's live roofline measurement): spcl_profile_enable(1) clears the log and makes every
+ * kernel launch of the library record HIP events on its launch stream; spcl_profile_get returns launch i's kernel
+ * symbol (as rocprofv3 prints it), its duration and the algorithmic bytes / FLOPs its entry point declared (0 when
+ * none).  Not usable inside a hipGraph capture.  spcl_profile_enable(0) clears the log and switches it off. */
+int spcl_profile_enable(int on);
+int spcl_profile_count(void);
+int spcl_profile_get(int i, char* name, int name_cap, float* usec, double* bytes, double* flops);
+
 #ifdef __cplusplus
 }
 #endif

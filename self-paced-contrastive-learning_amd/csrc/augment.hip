@@ -42,9 +42,9 @@ static void launch_flip(const void* x, void* out, int N, int C, int H, int W, co
   const size_t total = (size_t)N * C * H * (vec ? W / V : W);
   size_t blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
-  if (vec) hipLaunchKernelGGL((flip_batch_kernel<T, V>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)x, (T*)out, N,
+  if (vec) SPCL_LAUNCH((flip_batch_kernel<T, V>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)x, (T*)out, N,
                               C, H, W, flags);
-  else hipLaunchKernelGGL((flip_batch_kernel<T, 1>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)x, (T*)out, N, C,
+  else SPCL_LAUNCH((flip_batch_kernel<T, 1>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)x, (T*)out, N, C,
                           H, W, flags);
 }
 

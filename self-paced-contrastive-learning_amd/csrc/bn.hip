@@ -573,13 +573,15 @@ static int bnrelu_fwd_launch(const void* y, int N, int H, int W, int CS, const f
                              void* act, void* pool, hipStream_t st) {
   constexpr int EPC = Chunk<T>::EPC;
   const int PL = 256 / (CS / EPC);
+  const double tb = (double)N * H * W * CS * sizeof(T);  // bytes of one full-resolution tensor
+  prof_cost(tb * (1.0 + (act != nullptr ? 1.0 : 0.0) + (pool != nullptr ? 0.25 : 0.0)), 0.0);
   if (pool != nullptr) {
     const int rows = N * ((H + 1) / 2);
-    hipLaunchKernelGGL((bnrelu_fwd_pool_kernel<T>), dim3(rows < STREAM_MAX_WG ? rows : STREAM_MAX_WG), dim3(256), 0, st, (const T*)y, N, H,
+    SPCL_LAUNCH((bnrelu_fwd_pool_kernel<T>), dim3(rows < STREAM_MAX_WG ? rows : STREAM_MAX_WG), dim3(256), 0, st, (const T*)y, N, H,
                        W, CS, scale, shift, (T*)act, (T*)pool);
   } else {
     const size_t npix = (size_t)N * H * W;
-    hipLaunchKernelGGL((bnrelu_fwd_lin_kernel<T>), dim3(stream_grid(npix, PL, STREAM_UNROLL, STREAM_MAX_WG)), dim3(256), 0, st,
+    SPCL_LAUNCH((bnrelu_fwd_lin_kernel<T>), dim3(stream_grid(npix, PL, STREAM_UNROLL, STREAM_MAX_WG)), dim3(256), 0, st,
                        (const T*)y, npix, CS, scale, shift, (T*)act);
   }
   return 0;
@@ -598,24 +600,28 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
   float* ab = ws + (size_t)BWD_MAX_WG * 2 * CS;  // [2][CS]: folded BN-backward coefficients
   const float M = (float)npix;
   int nwg;
+  const double tb = (double)npix * CS * sizeof(T);  // bytes of one full-resolution tensor
+  const double gb = (dact != nullptr ? tb : 0.0) + (pool ? 0.25 * tb : 0.0);
+  prof_cost(tb + gb, 0.0);
   if (pool) {
     nwg = rows < BWD_MAX_WG ? rows : BWD_MAX_WG;
-    hipLaunchKernelGGL((bnrelu_bwd_pool_kernel<T, false>), dim3(nwg), dim3(256), 0, st, (const T*)y, (const T*)dact,
+    SPCL_LAUNCH((bnrelu_bwd_pool_kernel<T, false>), dim3(nwg), dim3(256), 0, st, (const T*)y, (const T*)dact,
                        (const T*)dpool, N, H, W, CS, mean, invstd, scale, shift, (const float*)nullptr, partial,
                        (T*)nullptr);
   } else {
     nwg = stream_grid(npix, PL, STREAM_UNROLL, BWD_MAX_WG);
-    hipLaunchKernelGGL((bnrelu_bwd_reduce_lin_kernel<T>), dim3(nwg), dim3(256), 0, st, (const T*)y, (const T*)dact, npix,
+    SPCL_LAUNCH((bnrelu_bwd_reduce_lin_kernel<T>), dim3(nwg), dim3(256), 0, st, (const T*)y, (const T*)dact, npix,
                        CS, mean, invstd, scale, shift, partial);
   }
-  hipLaunchKernelGGL(bnrelu_bwd_fin_kernel, dim3(CS), dim3(256), 0, st, (const float*)partial, nwg, C, CS,
+  SPCL_LAUNCH(bnrelu_bwd_fin_kernel, dim3(CS), dim3(256), 0, st, (const float*)partial, nwg, C, CS,
                      M, training, mean, invstd, scale, dgamma, dbeta, ab);
+  prof_cost(2.0 * tb + gb, 0.0);
   if (pool) {
-    hipLaunchKernelGGL((bnrelu_bwd_pool_kernel<T, true>), dim3(rows < STREAM_MAX_WG ? rows : STREAM_MAX_WG), dim3(256), 0, st, (const T*)y,
+    SPCL_LAUNCH((bnrelu_bwd_pool_kernel<T, true>), dim3(rows < STREAM_MAX_WG ? rows : STREAM_MAX_WG), dim3(256), 0, st, (const T*)y,
                        (const T*)dact, (const T*)dpool, N, H, W, CS, mean, invstd, scale, shift, (const float*)ab,
                        (float*)nullptr, (T*)dy);
   } else {
-    hipLaunchKernelGGL((bnrelu_bwd_apply_lin_kernel<T>), dim3(stream_grid(npix, PL, STREAM_UNROLL, STREAM_MAX_WG)), dim3(256), 0,
+    SPCL_LAUNCH((bnrelu_bwd_apply_lin_kernel<T>), dim3(stream_grid(npix, PL, STREAM_UNROLL, STREAM_MAX_WG)), dim3(256), 0,
                        st, (const T*)y, (const T*)dact, npix, CS, scale, shift, (const float*)ab, (T*)dy);
   }
   return 0;
@@ -639,13 +645,13 @@ extern "C" int spcl_bn_finalize(float* stats, int ntiles, int C, int CS, const f
   BnFinalArgs f{gamma, beta, momentum, eps, running_mean, running_var, num_batches_tracked, mean, invstd, scale, shift};
   const int groups = bn_groups(ntiles);
   if (groups == 0) {
-    hipLaunchKernelGGL((bn_reduce_kernel<float, true>), dim3(CS / 16, 1), dim3(ntiles > 256 ? 1024 : 256), 0, st, stats,
+    SPCL_LAUNCH((bn_reduce_kernel<float, true>), dim3(CS / 16, 1), dim3(ntiles > 256 ? 1024 : 256), 0, st, stats,
                        ntiles, ntiles, C, CS, (double*)nullptr, f);
   } else {
     double* partial = (double*)(stats + (size_t)ntiles * 3 * CS);  // spcl_bn_stats_elems reserves it
-    hipLaunchKernelGGL((bn_reduce_kernel<float, false>), dim3(CS / 16, groups), dim3(256), 0, st, stats, ntiles,
+    SPCL_LAUNCH((bn_reduce_kernel<float, false>), dim3(CS / 16, groups), dim3(256), 0, st, stats, ntiles,
                        BN_GROUP_TILES, C, CS, partial, f);
-    hipLaunchKernelGGL((bn_reduce_kernel<double, true>), dim3(CS / 16, 1), dim3(groups > 64 ? 1024 : 256), 0, st,
+    SPCL_LAUNCH((bn_reduce_kernel<double, true>), dim3(CS / 16, 1), dim3(groups > 64 ? 1024 : 256), 0, st,
                        (const double*)partial, groups, groups, C, CS, (double*)nullptr, f);
   }
   SPCL_LAUNCH_CHECK("bn_finalize");
@@ -657,7 +663,7 @@ extern "C" int spcl_bn_eval_affine(int C, int CS, const float* gamma, const floa
                                    float* shift, void* stream) {
   SPCL_CHECK_ARG(gamma && beta && running_mean && running_var && mean && invstd && scale && shift,
                  "bn_eval_affine: null pointer");
-  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(cdiv(CS, 256)), dim3(256), 0, (hipStream_t)stream, C, CS, gamma, beta,
+  SPCL_LAUNCH(bn_eval_affine_kernel, dim3(cdiv(CS, 256)), dim3(256), 0, (hipStream_t)stream, C, CS, gamma, beta,
                      running_mean, running_var, eps, mean, invstd, scale, shift);
   SPCL_LAUNCH_CHECK("bn_eval_affine");
   return SPCL_OK;

@@ -1,6 +1,12 @@
-// Error reporting + ABI version for libspcl_hip.so (host only).
+// Error reporting, ABI version and the built-in kernel timer of libspcl_hip.so (host only).
+#include <cxxabi.h>
+#include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
 #include "../../include/spcl_hip.h"
 
 namespace spcl {
@@ -11,7 +17,84 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+
+// ---- kernel timer
+struct ProfRecord {
+  const void* fn;
+  hipStream_t st;
+  hipEvent_t e0, e1;
+  double bytes, flops;
+};
+bool g_prof_on = false;
+static std::vector<ProfRecord> g_records;
+static double g_next_bytes = 0.0, g_next_flops = 0.0;
+
+void prof_cost(double bytes, double flops) {
+  if (!g_prof_on) return;
+  g_next_bytes = bytes;
+  g_next_flops = flops;
+}
+void prof_begin(const void* fn, hipStream_t st) {
+  ProfRecord r;
+  r.fn = fn;
+  r.st = st;
+  r.bytes = g_next_bytes;
+  r.flops = g_next_flops;
+  g_next_bytes = g_next_flops = 0.0;
+  (void)hipEventCreate(&r.e0);
+  (void)hipEventCreate(&r.e1);
+  (void)hipEventRecord(r.e0, st);
+  g_records.push_back(r);
+}
+void prof_end(hipStream_t st) {
+  if (!g_records.empty()) (void)hipEventRecord(g_records.back().e1, st);
+}
+static void prof_clear() {
+  for (auto& r : g_records) {
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  g_records.clear();
+}
 }  // namespace spcl
 
-extern "C" int spcl_abi_version(void) { return 1; }
+extern "C" int spcl_abi_version(void) { return 2; }
 extern "C" const char* spcl_last_error(void) { return spcl::g_err; }
+
+extern "C" int spcl_profile_enable(int on) {
+  spcl::prof_clear();
+  spcl::g_prof_on = on != 0;
+  return SPCL_OK;
+}
+extern "C" int spcl_profile_count(void) { return (int)spcl::g_records.size(); }
+extern "C" int spcl_profile_get(int i, char* name, int name_cap, float* usec, double* bytes, double* flops) {
+  if (i < 0 || i >= (int)spcl::g_records.size() || !name || name_cap < 2 || !usec || !bytes || !flops) {
+    spcl::set_error("profile_get: bad index / null pointer");
+    return SPCL_EINVAL;
+  }
+  const spcl::ProfRecord& r = spcl::g_records[i];
+  if (hipEventSynchronize(r.e1) != hipSuccess) {
+    spcl::set_error("profile_get: event not recorded (profiling inside a graph capture?)");
+    return SPCL_ELAUNCH;
+  }
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+  *usec = ms * 1e3f;
+  *bytes = r.bytes;
+  *flops = r.flops;
+  const char* mangled = hipKernelNameRefByPtr(r.fn, r.st);
+  std::string nm = mangled ? mangled : "?";
+  if (mangled) {
+    int status = 0;
+    char* dem = abi::__cxa_demangle(mangled, nullptr, nullptr, &status);
+    if (status == 0 && dem) {
+      nm = dem;
+      const size_t paren = nm.rfind('(');  // drop the argument list and the leading "void "
+      if (paren != std::string::npos) nm.resize(paren);
+      if (nm.rfind("void ", 0) == 0) nm.erase(0, 5);
+    }
+    free(dem);
+  }
+  snprintf(name, (size_t)name_cap, "%s", nm.c_str());
+  return SPCL_OK;
+}

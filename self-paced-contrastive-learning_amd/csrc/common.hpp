@@ -31,6 +31,25 @@ void set_error(const char* fmt, ...);
     }                                                                           \
   } while (0)
 
+// ---- built-in kernel timer (spcl_profile_* of the C ABI): when enabled, every launch of the library is bracketed by
+// HIP events on the launch stream and remembered with its kernel symbol and (where the caller states them) its
+// algorithmic bytes / FLOPs.  Disabled (the default) it costs one predictable branch per launch.
+extern bool g_prof_on;
+void prof_begin(const void* kernel_fn, hipStream_t st);
+void prof_end(hipStream_t st);
+void prof_cost(double bytes, double flops);  // cost of the NEXT launch (ignored when profiling is off)
+struct ProfScope {
+  hipStream_t st;
+  bool on;
+  ProfScope(const void* fn, hipStream_t s) : st(s), on(g_prof_on) { if (on) prof_begin(fn, s); }
+  ~ProfScope() { if (on) prof_end(st); }
+};
+#define SPCL_LAUNCH(kernel, grid, block, lds, st, ...)                   \
+  do {                                                                   \
+    spcl::ProfScope prof_scope_((const void*)(kernel), (st));            \
+    hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);       \
+  } while (0)
+
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 // round-to-nearest-even via the hardware convert (keeps NaN a NaN, MI355X_MICROARCH "Correctness boundaries")
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {

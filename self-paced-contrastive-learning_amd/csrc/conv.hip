@@ -331,11 +331,11 @@ static int launch_conv(const ConvArgs& a0, hipStream_t st) {
   if (NT == 1) {
     if (lds > 65536) (void)hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<T, TH, TW, 1>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<T, TH, TW, 1>), grid, block, lds, st, a);
+    SPCL_LAUNCH((conv3x3_mfma_kernel<T, TH, TW, 1>), grid, block, lds, st, a);
   } else {
     if (lds > 65536) (void)hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<T, TH, TW, 2>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<T, TH, TW, 2>), grid, block, lds, st, a);
+    SPCL_LAUNCH((conv3x3_mfma_kernel<T, TH, TW, 2>), grid, block, lds, st, a);
   }
   return 0;
 }
@@ -373,11 +373,11 @@ extern "C" int spcl_conv_pack_weights(const float* w_oihw, int Cin, int Cout, in
   const int KinK = round_up(kind == 0 ? Cin : Cout, 16), NoutS = round_up(kind == 0 ? Cout : Cin, 16);
   if (dtype == SPCL_F32) {
     size_t total = packed_elems<float>(KinK, NoutS);
-    hipLaunchKernelGGL(conv_pack_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w_oihw, Cin,
+    SPCL_LAUNCH(conv_pack_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w_oihw, Cin,
                        Cout, kind, KinK, NoutS, (float*)packed, total);
   } else if (dtype == SPCL_BF16) {
     size_t total = packed_elems<bf16_t>(KinK, NoutS);
-    hipLaunchKernelGGL(conv_pack_kernel<bf16_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w_oihw, Cin,
+    SPCL_LAUNCH(conv_pack_kernel<bf16_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w_oihw, Cin,
                        Cout, kind, KinK, NoutS, (bf16_t*)packed, total);
   } else {
     set_error("conv_pack_weights: dtype %d", dtype);
@@ -395,11 +395,11 @@ extern "C" int spcl_conv_pack_weights_both(const float* w_oihw, int Cin, int Cou
   const int CinK = round_up(Cin, 16), CoutS = round_up(Cout, 16);
   if (dtype == SPCL_F32) {
     const size_t t0 = packed_elems<float>(CinK, CoutS), t1 = packed_elems<float>(CoutS, CinK);
-    hipLaunchKernelGGL(conv_pack_both_kernel<float>, dim3((unsigned)((t0 + t1 + 255) / 256)), dim3(256), 0, st, w_oihw,
+    SPCL_LAUNCH(conv_pack_both_kernel<float>, dim3((unsigned)((t0 + t1 + 255) / 256)), dim3(256), 0, st, w_oihw,
                        Cin, Cout, CinK, CoutS, (float*)packed_fwd, t0, (float*)packed_dgrad, t1);
   } else if (dtype == SPCL_BF16) {
     const size_t t0 = packed_elems<bf16_t>(CinK, CoutS), t1 = packed_elems<bf16_t>(CoutS, CinK);
-    hipLaunchKernelGGL(conv_pack_both_kernel<bf16_t>, dim3((unsigned)((t0 + t1 + 255) / 256)), dim3(256), 0, st,
+    SPCL_LAUNCH(conv_pack_both_kernel<bf16_t>, dim3((unsigned)((t0 + t1 + 255) / 256)), dim3(256), 0, st,
                        w_oihw, Cin, Cout, CinK, CoutS, (bf16_t*)packed_fwd, t0, (bf16_t*)packed_dgrad, t1);
   } else {
     set_error("conv_pack_weights_both: dtype %d", dtype);
@@ -428,6 +428,12 @@ extern "C" int spcl_conv3x3_forward(const void* x, int dtype, int N, int H, int 
   a.tpw = 1;
   a.dbg = 0;
   hipStream_t st = (hipStream_t)stream;
+  {  // algorithmic cost of the launch: x once, y once, the packed weights once
+    const double px = (double)N * H * W, es = dtype == SPCL_F32 ? 4.0 : 2.0;
+    const double cin = in_mode == 2 ? CinS : CinK;
+    prof_cost(px * ((in_mode == 2 ? CinS * 4.0 : CinK * es) + CoutS * es) + 9.0 * CinK * CoutS * es,
+              2.0 * px * 9.0 * cin * CoutS);
+  }
   if (dtype == SPCL_F32) launch_conv_t<float>(a, st);
   else if (dtype == SPCL_BF16) launch_conv_t<bf16_t>(a, st);
   else {

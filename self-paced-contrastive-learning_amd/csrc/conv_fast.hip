@@ -285,8 +285,8 @@ template <int KC, int TH, int NT, int NW>
 static void launch_fast(const FastArgs& a, int mode, hipStream_t st) {
   const size_t lds = fast_lds_bytes(KC, TH);
   dim3 grid(a.tilesX, a.tilesY, a.N * a.gy), block(64 * NW);
-  if (mode == 1) hipLaunchKernelGGL((conv3x3_fast_kernel<KC, TH, NT, 1, NW>), grid, block, lds, st, a);
-  else hipLaunchKernelGGL((conv3x3_fast_kernel<KC, TH, NT, 0, NW>), grid, block, lds, st, a);
+  if (mode == 1) SPCL_LAUNCH((conv3x3_fast_kernel<KC, TH, NT, 1, NW>), grid, block, lds, st, a);
+  else SPCL_LAUNCH((conv3x3_fast_kernel<KC, TH, NT, 0, NW>), grid, block, lds, st, a);
 }
 
 bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st) {
@@ -298,7 +298,7 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st) {
     a.in_scale = a.in_shift = nullptr;
     a.N = c.N; a.H = c.H; a.W = c.W; a.CinK = 16; a.CoutS = 16;
     a.tilesX = c.W / 14; a.tilesY = c.H / 14; a.gy = 1;
-    hipLaunchKernelGGL((conv3x3_image_kernel<14>), dim3(a.tilesX, a.tilesY, a.N), dim3(64), 0, st, a);
+    SPCL_LAUNCH((conv3x3_image_kernel<14>), dim3(a.tilesX, a.tilesY, a.N), dim3(64), 0, st, a);
     return true;
   }
   if (c.CinS != c.CinK) return false;

@@ -70,12 +70,12 @@ extern "C" int spcl_radam_step(float* param, const float* grad, float* exp_avg, 
                  "radam_step: buffers must be 16-byte aligned");
   SPCL_CHECK_ARG(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0, "radam_step: betas");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(radam_tick_kernel, dim3(1), dim3(1), 0, st, step, lr, beta1, beta2, coef);
+  SPCL_LAUNCH(radam_tick_kernel, dim3(1), dim3(1), 0, st, step, lr, beta1, beta2, coef);
   const size_t n4 = n / 4;
   size_t blocks = (n4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(radam_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, n4,
+  SPCL_LAUNCH(radam_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, n4,
                      n, (const float*)coef, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
                      (float)weight_decay);
   SPCL_LAUNCH_CHECK("radam_step");

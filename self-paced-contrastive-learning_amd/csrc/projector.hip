@@ -164,25 +164,25 @@ extern "C" int spcl_proj_forward(const void* feat, int dtype, int N, int HW, int
   hipStream_t st = (hipStream_t)stream;
   dim3 pg(cdiv(C, 64), N);
   if (dtype == SPCL_F32)
-    hipLaunchKernelGGL(avgpool_kernel<float>, pg, dim3(256), 0, st, (const float*)feat, HW, C, Cs, pooled);
+    SPCL_LAUNCH(avgpool_kernel<float>, pg, dim3(256), 0, st, (const float*)feat, HW, C, Cs, pooled);
   else if (dtype == SPCL_BF16)
-    hipLaunchKernelGGL(avgpool_kernel<bf16_t>, pg, dim3(256), 0, st, (const bf16_t*)feat, HW, C, Cs, pooled);
+    SPCL_LAUNCH(avgpool_kernel<bf16_t>, pg, dim3(256), 0, st, (const bf16_t*)feat, HW, C, Cs, pooled);
   else {
     set_error("proj_forward: dtype %d", dtype);
     return SPCL_EINVAL;
   }
   const int ny = N < 8 ? N : 8;
   if (hid > 0) {
-    hipLaunchKernelGGL(linear_fwd_kernel<false>, dim3(cdiv(hid, 4), ny), dim3(256), 0, st, (const float*)pooled, w1,
+    SPCL_LAUNCH(linear_fwd_kernel<false>, dim3(cdiv(hid, 4), ny), dim3(256), 0, st, (const float*)pooled, w1,
                        b1, N, C, hid, pre);
-    hipLaunchKernelGGL(linear_fwd_kernel<true>, dim3(cdiv(out_dim, 4), ny), dim3(256), 0, st, (const float*)pre, w2,
+    SPCL_LAUNCH(linear_fwd_kernel<true>, dim3(cdiv(out_dim, 4), ny), dim3(256), 0, st, (const float*)pre, w2,
                        b2, N, hid, out_dim, o);
   } else {
-    hipLaunchKernelGGL(linear_fwd_kernel<false>, dim3(cdiv(out_dim, 4), ny), dim3(256), 0, st, (const float*)pooled,
+    SPCL_LAUNCH(linear_fwd_kernel<false>, dim3(cdiv(out_dim, 4), ny), dim3(256), 0, st, (const float*)pooled,
                        w1, b1, N, C, out_dim, o);
   }
   if (normalize)
-    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, (const float*)o, N, out_dim, z);
+    SPCL_LAUNCH(l2norm_fwd_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, (const float*)o, N, out_dim, z);
   else
     (void)hipMemcpyAsync(z, o, (size_t)N * out_dim * sizeof(float), hipMemcpyDeviceToDevice, st);
   SPCL_LAUNCH_CHECK("proj_forward");
@@ -202,34 +202,34 @@ extern "C" int spcl_proj_backward(const float* dz, int dtype, int N, int HW, int
   float* dpool = dpre + (size_t)N * (hid > 0 ? hid : 0);  // [N,C]
   const float* go = dz;
   if (normalize) {
-    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, o, dz, N, out_dim, d_o);
+    SPCL_LAUNCH(l2norm_bwd_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, o, dz, N, out_dim, d_o);
     go = d_o;
   }
   if (hid > 0) {
-    hipLaunchKernelGGL(linear_wgrad_kernel<true>, dim3(cdiv(hid, 256), out_dim), dim3(256), 0, st, go, pre, N, hid,
+    SPCL_LAUNCH(linear_wgrad_kernel<true>, dim3(cdiv(hid, 256), out_dim), dim3(256), 0, st, go, pre, N, hid,
                        out_dim, dw2, db2);
-    hipLaunchKernelGGL(linear_dgrad_kernel<true>, dim3(cdiv(hid, 64), N), dim3(256), 0, st, go, w2, pre, N, hid,
+    SPCL_LAUNCH(linear_dgrad_kernel<true>, dim3(cdiv(hid, 64), N), dim3(256), 0, st, go, w2, pre, N, hid,
                        out_dim, dpre);
-    hipLaunchKernelGGL(linear_wgrad_kernel<false>, dim3(cdiv(C, 256), hid), dim3(256), 0, st, (const float*)dpre,
+    SPCL_LAUNCH(linear_wgrad_kernel<false>, dim3(cdiv(C, 256), hid), dim3(256), 0, st, (const float*)dpre,
                        pooled, N, C, hid, dw1, db1);
     if (dfeat)
-      hipLaunchKernelGGL(linear_dgrad_kernel<false>, dim3(cdiv(C, 64), N), dim3(256), 0, st, (const float*)dpre, w1,
+      SPCL_LAUNCH(linear_dgrad_kernel<false>, dim3(cdiv(C, 64), N), dim3(256), 0, st, (const float*)dpre, w1,
                          (const float*)nullptr, N, C, hid, dpool);
   } else {
-    hipLaunchKernelGGL(linear_wgrad_kernel<false>, dim3(cdiv(C, 256), out_dim), dim3(256), 0, st, go, pooled, N, C,
+    SPCL_LAUNCH(linear_wgrad_kernel<false>, dim3(cdiv(C, 256), out_dim), dim3(256), 0, st, go, pooled, N, C,
                        out_dim, dw1, db1);
     if (dfeat)
-      hipLaunchKernelGGL(linear_dgrad_kernel<false>, dim3(cdiv(C, 64), N), dim3(256), 0, st, go, w1,
+      SPCL_LAUNCH(linear_dgrad_kernel<false>, dim3(cdiv(C, 64), N), dim3(256), 0, st, go, w1,
                          (const float*)nullptr, N, C, out_dim, dpool);
   }
   if (dfeat) {
     const size_t total = (size_t)N * HW * Cs;
     dim3 g((unsigned)((total + 255) / 256));
     if (dtype == SPCL_F32)
-      hipLaunchKernelGGL(avgpool_bwd_kernel<float>, g, dim3(256), 0, st, (const float*)dpool, HW, C, Cs,
+      SPCL_LAUNCH(avgpool_bwd_kernel<float>, g, dim3(256), 0, st, (const float*)dpool, HW, C, Cs,
                          (float*)dfeat, total);
     else if (dtype == SPCL_BF16)
-      hipLaunchKernelGGL(avgpool_bwd_kernel<bf16_t>, g, dim3(256), 0, st, (const float*)dpool, HW, C, Cs,
+      SPCL_LAUNCH(avgpool_bwd_kernel<bf16_t>, g, dim3(256), 0, st, (const float*)dpool, HW, C, Cs,
                          (bf16_t*)dfeat, total);
     else {
       set_error("proj_backward: dtype %d", dtype);

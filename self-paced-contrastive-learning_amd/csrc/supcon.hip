@@ -431,11 +431,11 @@ static int launch_forward(const SupconLayout& L, SupconArgs a, float* ws, int co
                           hipStream_t st) {
   dim3 grid(L.N2p / 64, L.CS);
   size_t lds = (size_t)64 * DP * sizeof(float);
-  hipLaunchKernelGGL((supcon_sweep_kernel<DP, 0>), grid, dim3(256), lds, st, a);
-  hipLaunchKernelGGL((supcon_fin_kernel<0>), dim3(1), dim3(1024), 0, st, a.partA, a.partB, L.CS, L.N2, L.N2p,
+  SPCL_LAUNCH((supcon_sweep_kernel<DP, 0>), grid, dim3(256), lds, st, a);
+  SPCL_LAUNCH((supcon_fin_kernel<0>), dim3(1), dim3(1024), 0, st, a.partA, a.partB, L.CS, L.N2, L.N2p,
                      ws + L.off_logD, ws + L.off_c, (const float*)nullptr, (const float*)nullptr, 0, out);
-  hipLaunchKernelGGL((supcon_sweep_kernel<DP, 1>), grid, dim3(256), lds, st, a);
-  hipLaunchKernelGGL((supcon_fin_kernel<1>), dim3(1), dim3(1024), 0, st, a.partA, a.partB, L.CS, L.N2, L.N2p,
+  SPCL_LAUNCH((supcon_sweep_kernel<DP, 1>), grid, dim3(256), lds, st, a);
+  SPCL_LAUNCH((supcon_fin_kernel<1>), dim3(1), dim3(1024), 0, st, a.partA, a.partB, L.CS, L.N2, L.N2p,
                      ws + L.off_rowloss, ws + L.off_W, (const float*)(ws + L.off_c), (const float*)(ws + L.off_rn2),
                      correct_grad, out);
   return 0;
@@ -469,7 +469,7 @@ extern "C" int spcl_supcon_forward(const float* z1, const float* z2, const float
   SPCL_CHECK_ARG(temperature > 0.f, "supcon_forward: temperature must be > 0");
   hipStream_t st = (hipStream_t)stream;
   SupconLayout L = supcon_layout(n, d);
-  hipLaunchKernelGGL(supcon_prep_kernel, dim3(L.N2p / 4), dim3(256), 0, st, z1, z2, n, d, L.N2p, L.DP,
+  SPCL_LAUNCH(supcon_prep_kernel, dim3(L.N2p / 4), dim3(256), 0, st, z1, z2, n, d, L.N2p, L.DP,
                      ws + L.off_P, ws + L.off_rn2);
   SupconArgs a = make_args(L, ws, labels, mask, temperature, sp_mode, gamma);
   if (L.DP == 64) launch_forward<64>(L, a, ws, correct_grad, out, st);
@@ -490,11 +490,11 @@ extern "C" int spcl_supcon_backward(const float* labels, const float* mask, int 
   SupconArgs a = make_args(L, ws_fwd, labels, mask, temperature, sp_mode, gamma);
   dim3 grid(L.N2p / 64, L.CS);
   size_t lds = (size_t)64 * L.DP * sizeof(float);
-  if (L.DP == 64) hipLaunchKernelGGL((supcon_bwd_kernel<64>), grid, dim3(256), lds, st, a, out_fwd, ws_bwd);
-  else if (L.DP == 128) hipLaunchKernelGGL((supcon_bwd_kernel<128>), grid, dim3(256), lds, st, a, out_fwd, ws_bwd);
-  else hipLaunchKernelGGL((supcon_bwd_kernel<256>), grid, dim3(256), lds, st, a, out_fwd, ws_bwd);
+  if (L.DP == 64) SPCL_LAUNCH((supcon_bwd_kernel<64>), grid, dim3(256), lds, st, a, out_fwd, ws_bwd);
+  else if (L.DP == 128) SPCL_LAUNCH((supcon_bwd_kernel<128>), grid, dim3(256), lds, st, a, out_fwd, ws_bwd);
+  else SPCL_LAUNCH((supcon_bwd_kernel<256>), grid, dim3(256), lds, st, a, out_fwd, ws_bwd);
   size_t total = (size_t)2 * n * d;
-  hipLaunchKernelGGL(supcon_bwd_fin_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+  SPCL_LAUNCH(supcon_bwd_fin_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
                      (const float*)ws_bwd, L.CS, n, d, L.N2p, L.DP, temperature, grad_out, dz1, dz2);
   SPCL_LAUNCH_CHECK("supcon_backward");
   return SPCL_OK;
@@ -510,7 +510,7 @@ extern "C" int spcl_supcon_materialize(const float* labels, const float* mask, i
   SupconLayout L = supcon_layout(n, d);
   SupconArgs a = make_args(L, ws_fwd, labels, mask, temperature, sp_mode, gamma);
   size_t total = (size_t)L.N2 * L.N2;
-  hipLaunchKernelGGL(supcon_materialize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, L.DP,
+  SPCL_LAUNCH(supcon_materialize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a, L.DP,
                      sim_logits, sim_exp, pos_mask, neg_mask, sp_mask);
   SPCL_LAUNCH_CHECK("supcon_materialize");
   return SPCL_OK;

@@ -17,7 +17,7 @@ template <typename T> struct Chunk;
 template <> struct Chunk<float> { static constexpr int EPC = 4; };
 template <> struct Chunk<bf16_t> { static constexpr int EPC = 8; };
 
-constexpr int WG_TH = 16, WG_TW = 16, WG_HW = WG_TW + 2, WG_NHALO = (WG_TH + 2) * WG_HW, WG_NPIX = WG_TH * WG_TW;
+constexpr int WG_TW = 16, WG_HW = WG_TW + 2;
 
 struct WgradArgs {
   const void* x;
@@ -50,57 +50,64 @@ template <> __device__ __forceinline__ u32x4 wg_bnrelu_chunk<bf16_t>(u32x4 raw, 
   return out;
 }
 
-// Operand fragment of one k-step for a 16-channel tile, read transposed from a [pixel][channel] LDS image.
-//   bf16: k-step = 32 pixels; lane (g = lane>>4) gets pixels 8g..8g+7 of its channel (lane&15)
-//   f32 : k-step = 4 pixels;  lane gets pixel g of its channel
-// `lane_pixel(ks, lane)` = tile pixel whose address this lane supplies; the caller turns it into a byte address
-// once per k-step, every tap / channel tile is then a compile-time offset folded into the DS instruction.
+// Operand fragment of one k-step for a 16-channel tile, read transposed from a [row][pixel][channel] LDS image.
+//   bf16: k-step = 32 pixels = 2 tile rows x 16; lane group g = lane>>4 holds 8 of them (two hardware-transposed
+//         4-pixel reads): row 2ks + (g&1), columns 8(g>>1) .. +7.  The 32 lanes a ds_read_b64_tr_b16 services together
+//         (g = 0,1 / 2,3) therefore sit in DIFFERENT rows, and the row pitch is padded so that they hit complementary
+//         banks (MI355X_MICROARCH.md LDS table; the former same-row mapping was a 2-way conflict on every read).
+//   f32 : k-step = 4 pixels of one row; lane gets pixel g of its channel (exact-f32 parity path).
 template <typename T> struct Frag;
 template <> struct Frag<bf16_t> {
   typedef bf16x8 type;
   static constexpr int KPIX = 32;
-  static constexpr int SECOND = 4;  // second read: 4 pixels further
-  static __device__ __forceinline__ int lane_pixel(int ks, int lane) {
-    return ks * 32 + 8 * (lane >> 4) + ((lane & 15) >> 2);
-  }
+  static __device__ __forceinline__ int lane_row(int lane) { return (lane >> 4) & 1; }  // + 2 ks
+  static __device__ __forceinline__ int lane_col(int lane) { return 8 * (lane >> 5) + ((lane & 15) >> 2); }
   static __device__ __forceinline__ int lane_chan_bytes(int lane) { return (lane & 3) * 8; }
-  // a0: address of (lane pixel, lane channel group); pix_bytes: LDS bytes per pixel
   static __device__ __forceinline__ type load(unsigned a0, int off, int pix_bytes) {
     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(uintptr_t)(a0 + off));
     s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
         (s16x4 __attribute__((address_space(3)))*)(uintptr_t)(a0 + off + 4 * pix_bytes));
-    type r;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-    return r;
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);  // register pair concatenation, no ALU
   }
   static __device__ __forceinline__ f32x4 mfma(type a, type b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+  // row pitch padding (bytes) for a [.. x 16*tiles channels] image whose rows hold `row_bytes`
+  static constexpr int row_pad(int pix_bytes, int row_bytes) {
+    // 4 consecutive pixels x 32 B are read at stride pix_bytes; the partner row must land on the other banks
+    return pix_bytes == 32 ? (128 - row_bytes % 256 + 256) % 256 : (32 - row_bytes % 64 + 64) % 64;
   }
 };
 template <> struct Frag<float> {
   typedef float type;
   static constexpr int KPIX = 4;
-  static __device__ __forceinline__ int lane_pixel(int ks, int lane) { return ks * 4 + (lane >> 4); }
+  static __device__ __forceinline__ int lane_row(int) { return 0; }
+  static __device__ __forceinline__ int lane_col(int lane) { return lane >> 4; }  // + 4 (ks % 4)
   static __device__ __forceinline__ int lane_chan_bytes(int lane) { return (lane & 15) * 4; }
-  static __device__ __forceinline__ type load(unsigned a0, int off, int pix_bytes) {
+  static __device__ __forceinline__ type load(unsigned a0, int off, int) {
     return *(const float __attribute__((address_space(3)))*)(uintptr_t)(a0 + off);
   }
   static __device__ __forceinline__ f32x4 mfma(type a, type b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
   }
+  static constexpr int row_pad(int, int) { return 0; }
 };
 
-template <typename T, int MI, int NJ>
-__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
-  constexpr int EPC = Chunk<T>::EPC;
+template <typename T, int MI, int NJ, int TH>
+__global__ __launch_bounds__(256, (MI * NJ >= 16 ? 1 : 2)) void conv3x3_wgrad_kernel(WgradArgs a) {
+  constexpr int EPC = Chunk<T>::EPC, ESZ = (int)sizeof(T);
   constexpr int CIB = 16 * MI, COB = 16 * NJ;
-  constexpr int XS = CIB * (int)sizeof(T), DS = COB * (int)sizeof(T);  // LDS bytes per pixel
-  constexpr int XCP = CIB / EPC, DCP = COB / EPC;                       // 16-byte chunks per pixel
-  constexpr int X_BYTES = WG_NHALO * XS, D_BYTES = WG_NPIX * DS, BUF_BYTES = X_BYTES + D_BYTES;
-  constexpr int KSTEPS = WG_NPIX / Frag<T>::KPIX;
-  constexpr int NX = (WG_NHALO * XCP + 255) / 256;  // staged 16-byte chunks per thread
-  constexpr int ND = (WG_NPIX * DCP + 255) / 256;
+  constexpr int XS = CIB * ESZ, DS = COB * ESZ;          // LDS bytes per pixel
+  constexpr int XCP = CIB / EPC, DCP = COB / EPC;        // 16-byte chunks per pixel
+  constexpr int XRP = WG_HW * XS + Frag<T>::row_pad(XS, WG_HW * XS);  // LDS bytes per halo row / dy row
+  constexpr int DRP = WG_TW * DS + Frag<T>::row_pad(DS, WG_TW * DS);
+  constexpr int NHROWS = TH + 2;
+  constexpr int X_BYTES = NHROWS * XRP, D_BYTES = TH * DRP, BUF_BYTES = X_BYTES + D_BYTES;
+  constexpr int KSTEPS = TH * WG_TW / Frag<T>::KPIX;
+  // staging maps: a thread owns one 16-byte channel chunk and one column; it walks the rows in compile-time steps
+  constexpr int XPL = 256 / XCP, XRPI = XPL / WG_HW, NX = (NHROWS + XRPI - 1) / XRPI;   // rows per iteration
+  constexpr int DPL = 256 / DCP, DRPI = DPL / WG_TW, ND = (TH + DRPI - 1) / DRPI;
+  static_assert(XRPI >= 1 && DRPI >= 1, "channel block too wide for the 256-thread staging map");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 x [x halo | dy] (double buffer)
   const unsigned lds_base = (unsigned)(uintptr_t)(unsigned char __attribute__((address_space(3)))*)lds;
 
@@ -108,8 +115,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
   const int blk = blockIdx.y;
   const int bci = blk / a.nblk_co, bco = blk - bci * a.nblk_co;
   const int ci0 = bci * CIB, co0 = bco * COB;
-  // this thread always stages the same channel chunk (256 % XCP == 0): its BN scale/shift live in registers
-  const int xch = threadIdx.x % XCP, dch = threadIdx.x % DCP;
+  const int xch = threadIdx.x % XCP, xpl = threadIdx.x / XCP;
+  const int xhy0 = xpl / WG_HW, xhx = xpl - xhy0 * WG_HW;
+  const bool xact = xpl < XRPI * WG_HW;
+  const int dch = threadIdx.x % DCP, dpl = threadIdx.x / DCP;
+  const int dry0 = dpl / WG_TW, dcol = dpl - dry0 * WG_TW;
   float sc[EPC], sh[EPC];
   if (a.in_mode == 1) {
 #pragma unroll
@@ -130,34 +140,44 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
     if (u >= NUNITS) u = NUNITS - 1;  // clamped duplicate: computed, never written
     const int tap = u / MI, m = u - tap * MI;
     const int ky = tap / 3, kx = tap - 3 * ky;
-    uoff[uu] = (ky * WG_HW + kx) * XS + m * 16 * (int)sizeof(T);
+    uoff[uu] = ky * XRP + kx * XS + m * 16 * ESZ;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[uu][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
+  // per-lane operand addresses of k-step 0 (later k-steps add compile-time row / column offsets)
+  const unsigned xlane = (unsigned)(Frag<T>::lane_row(lane) * XRP + Frag<T>::lane_col(lane) * XS +
+                                    Frag<T>::lane_chan_bytes(lane));
+  const unsigned dlane = (unsigned)(Frag<T>::lane_row(lane) * DRP + Frag<T>::lane_col(lane) * DS +
+                                    Frag<T>::lane_chan_bytes(lane));
 
   u32x4 rx[NX], rd[ND];
   unsigned xmask = 0;  // staged x chunks that are inside the image (zero padding must stay zero after BN+ReLU)
   const int tpi = a.tilesX * a.tilesY;
 
-  // ---- global -> registers (issued one tile ahead of the MFMAs: T14 issue-early / write-late)
+  // ---- global -> registers (issued one tile ahead of the MFMAs).  Addresses = one wave-uniform 64-bit tile base + a
+  // 32-bit per-thread offset fixed for the whole launch + a wave-uniform row step per iteration.
+  const int xvoff = (xhy0 * a.W + xhx) * a.CinS + (a.in_mode == 2 ? 0 : ci0 + xch * EPC);
+  const int dvoff = (dry0 * a.W + dcol) * a.CoutS + co0 + dch * EPC;
   auto load_tile = [&](int tile) {
     const int n = tile / tpi;
     const int trem = tile - n * tpi;
     const int ty = trem / a.tilesX, tx = trem - ty * a.tilesX;
-    const int y0 = ty * WG_TH, x0 = tx * WG_TW;
+    const int y0 = ty * TH, x0 = tx * WG_TW;
+    const bool interior = y0 > 0 && x0 > 0 && y0 + TH < a.H && x0 + WG_TW < a.W;
     xmask = 0;
+    const int gx = x0 - 1 + xhx;
+    const bool colok = interior || (gx >= 0 && gx < a.W);
+    const long xorigin = (((long)n * a.H + (y0 - 1)) * a.W + (x0 - 1)) * a.CinS;  // halo origin, may be outside
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      const int idx = threadIdx.x + 256 * i;
-      const int q = idx / XCP;
-      const int hy = q / WG_HW, hx = q - hy * WG_HW;
-      const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+      const int hy = xhy0 + i * XRPI;
+      const int gy = y0 - 1 + hy;
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (idx < WG_NHALO * XCP && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
-        const size_t pix = ((size_t)n * a.H + gy) * a.W + gx;
+      if (xact && hy < NHROWS && colok && (interior || (gy >= 0 && gy < a.H))) {
+        const long rowoff = xorigin + (long)(i * XRPI) * a.W * a.CinS;  // wave-uniform
         xmask |= 1u << i;
         if (a.in_mode == 2) {
-          const float* src = (const float*)a.x + pix * a.CinS;
+          const float* src = (const float*)a.x + rowoff + xvoff;
           float e[EPC];
 #pragma unroll
           for (int k = 0; k < EPC; ++k) {
@@ -172,21 +192,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
               v[k] = (uint32_t)f32_to_bf16(e[(2 * k) % EPC]) | ((uint32_t)f32_to_bf16(e[(2 * k + 1) % EPC]) << 16);
           }
         } else {
-          v = *(const u32x4*)((const T*)a.x + pix * a.CinS + ci0 + xch * EPC);
+          v = *(const u32x4*)((const T*)a.x + rowoff + xvoff);
         }
       }
       rx[i] = v;
     }
+    const int dgx = x0 + dcol;
+    const long dorigin = (((long)n * a.H + y0) * a.W + x0) * a.CoutS;
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
-      const int idx = threadIdx.x + 256 * i;
-      const int p = idx / DCP;
-      const int gy = y0 + (p >> 4), gx = x0 + (p & 15);
+      const int r = dry0 + i * DRPI;
+      const int gy = y0 + r;
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (idx < WG_NPIX * DCP && gy < a.H && gx < a.W) {
-        const size_t pix = ((size_t)n * a.H + gy) * a.W + gx;
-        v = *(const u32x4*)((const T*)a.dy + pix * a.CoutS + co0 + dch * EPC);
-      }
+      if (r < TH && gy < a.H && dgx < a.W)
+        v = *(const u32x4*)((const T*)a.dy + dorigin + (long)(i * DRPI) * a.W * a.CoutS + dvoff);
       rd[i] = v;
     }
   };
@@ -196,17 +215,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
     unsigned char* bd = bx + X_BYTES;
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      const int idx = threadIdx.x + 256 * i;
-      if (idx < WG_NHALO * XCP) {
+      const int hy = xhy0 + i * XRPI;
+      if (xact && hy < NHROWS) {
         u32x4 v = rx[i];
         if (a.in_mode == 1 && (xmask & (1u << i))) v = wg_bnrelu_chunk<T>(v, sc, sh);
-        *(u32x4*)(bx + (idx / XCP) * XS + xch * 16) = v;
+        *(u32x4*)(bx + hy * XRP + xhx * XS + xch * 16) = v;
       }
     }
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
-      const int idx = threadIdx.x + 256 * i;
-      if (idx < WG_NPIX * DCP) *(u32x4*)(bd + (idx / DCP) * DS + dch * 16) = rd[i];
+      const int r = dry0 + i * DRPI;
+      if (r < TH) *(u32x4*)(bd + r * DRP + dcol * DS + dch * 16) = rd[i];
     }
   };
 
@@ -219,21 +238,31 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
     const int next = tile + gridDim.x;
     if (next < a.ntiles) load_tile(next);
 
-    const unsigned ldx_base = lds_base + buf * BUF_BYTES, ldd_base = ldx_base + X_BYTES;
-#pragma unroll 2
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-      const int p = Frag<T>::lane_pixel(ks, lane);  // a k-step's pixels never straddle a tile row (TW = 16)
-      const unsigned xa = ldx_base + (unsigned)(((p >> 4) * WG_HW + (p & 15)) * XS + Frag<T>::lane_chan_bytes(lane));
-      const unsigned da = ldd_base + (unsigned)(p * DS + Frag<T>::lane_chan_bytes(lane));
-      typename Frag<T>::type bf[NJ];
+    const unsigned xa0 = lds_base + buf * BUF_BYTES + xlane, da0 = lds_base + buf * BUF_BYTES + X_BYTES + dlane;
+    // operand fragments are fetched one (k-step, unit) ahead of the MFMAs that consume them, so an LDS read's
+    // latency hides under the previous unit's matrix work instead of stalling every pair of MFMAs
+    auto kpos_x = [&](int ks) { return (sizeof(T) == 2 ? 2 * ks : ks / 4) * XRP + (sizeof(T) == 2 ? 0 : 4 * (ks % 4)) * XS; };
+    auto kpos_d = [&](int ks) { return (sizeof(T) == 2 ? 2 * ks : ks / 4) * DRP + (sizeof(T) == 2 ? 0 : 4 * (ks % 4)) * DS; };
+    typename Frag<T>::type bf[NJ], bf_next[NJ], af, af_next;
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) bf[j] = Frag<T>::load(da, j * 16 * (int)sizeof(T), DS);
+    for (int j = 0; j < NJ; ++j) bf[j] = Frag<T>::load(da0, kpos_d(0) + j * 16 * ESZ, DS);
+    af = Frag<T>::load(xa0 + uoff[0], kpos_x(0), XS);
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
 #pragma unroll
       for (int uu = 0; uu < UPW; ++uu) {
-        typename Frag<T>::type af = Frag<T>::load(xa + uoff[uu], 0, XS);
+        if (uu + 1 < UPW) af_next = Frag<T>::load(xa0 + uoff[uu + 1], kpos_x(ks), XS);
+        else if (ks + 1 < KSTEPS) {
+          af_next = Frag<T>::load(xa0 + uoff[0], kpos_x(ks + 1), XS);
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) bf_next[j] = Frag<T>::load(da0, kpos_d(ks + 1) + j * 16 * ESZ, DS);
+        }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[uu][j] = Frag<T>::mfma(af, bf[j], acc[uu][j]);
+        af = af_next;
       }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bf[j] = bf_next[j];
     }
     if (a.dbuf) buf ^= 1;
     else __syncthreads();  // single buffer: all reads of this tile are done before the next one is written
@@ -290,8 +319,16 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
   }
 }
 
+// LDS bytes of ONE tile image (x halo + dy), row pitches padded as in the kernel
+static size_t wgrad_lds_bytes(int MI, int NJ, int TH, int esize) {
+  const int XS = 16 * MI * esize, DS = 16 * NJ * esize;
+  const int xrp = WG_HW * XS + (esize == 2 ? Frag<bf16_t>::row_pad(XS, WG_HW * XS) : 0);
+  const int drp = WG_TW * DS + (esize == 2 ? Frag<bf16_t>::row_pad(DS, WG_TW * DS) : 0);
+  return (size_t)(TH + 2) * xrp + (size_t)TH * drp;
+}
+
 struct WgradPlan {
-  int MI, NJ, nblk_ci, nblk_co, nsplit, ntiles, tilesX, tilesY;
+  int TH, MI, NJ, nblk_ci, nblk_co, nsplit, ntiles, tilesX, tilesY;
   size_t partial_floats;
 };
 static WgradPlan wgrad_plan(int N, int H, int W, int CinK, int CoutS, int esize) {
@@ -300,13 +337,16 @@ static WgradPlan wgrad_plan(int N, int H, int W, int CinK, int CoutS, int esize)
   p.MI = CinK >= 32 ? 2 : 1;
   p.nblk_ci = CinK / (16 * p.MI);
   p.nblk_co = CoutS / (16 * p.NJ);
+  // 14-row tiles when the height divides by 14 but not by 16 (56 / 28 / 14: 12.5 % padded pixels instead of 23 %)
+  static const int env_th = getenv("SPCL_WGRAD_TH") ? atoi(getenv("SPCL_WGRAD_TH")) : 0;
+  p.TH = env_th ? env_th : ((H % 16 != 0 && H % 14 == 0) ? 14 : 16);
   p.tilesX = cdiv(W, WG_TW);
-  p.tilesY = cdiv(H, WG_TH);
+  p.tilesY = cdiv(H, p.TH);
   p.ntiles = N * p.tilesX * p.tilesY;
   const int nblk = p.nblk_ci * p.nblk_co;
   // exactly one resident "wave" of workgroups (LDS-limited residency x 256 CUs): measured optimum -- more workgroups
   // only add partial slabs and a tail, fewer leave CUs idle (tools/bench_kernels.py wgrad sweeps)
-  const size_t lds = 2 * ((size_t)WG_NHALO * 16 * p.MI + (size_t)WG_NPIX * 16 * p.NJ) * esize;
+  const size_t lds = 2 * wgrad_lds_bytes(p.MI, p.NJ, p.TH, esize);
   int per_cu = (int)((160 * 1024) / lds);
   if (per_cu > 4) per_cu = 4;
   if (per_cu < 1) per_cu = 1;
@@ -319,22 +359,27 @@ static WgradPlan wgrad_plan(int N, int H, int W, int CinK, int CoutS, int esize)
   return p;
 }
 
-template <typename T, int MI, int NJ>
+template <typename T, int MI, int NJ, int TH>
 static void launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t st) {
-  constexpr int CIB = 16 * MI, COB = 16 * NJ;
-  size_t lds = (a.dbuf ? 2 : 1) * ((size_t)WG_NHALO * CIB * sizeof(T) + (size_t)WG_NPIX * COB * sizeof(T));
+  const size_t lds = (a.dbuf ? 2 : 1) * wgrad_lds_bytes(MI, NJ, TH, (int)sizeof(T));
   if (lds > 65536)
-    (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_kernel<T, MI, NJ>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-  hipLaunchKernelGGL((conv3x3_wgrad_kernel<T, MI, NJ>), dim3(p.nsplit, p.nblk_ci * p.nblk_co), dim3(256), lds, st, a);
+    (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_kernel<T, MI, NJ, TH>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  SPCL_LAUNCH((conv3x3_wgrad_kernel<T, MI, NJ, TH>), dim3(p.nsplit, p.nblk_ci * p.nblk_co), dim3(256), lds, st, a);
+}
+
+template <typename T, int TH>
+static void launch_wgrad_th(const WgradArgs& a, const WgradPlan& p, hipStream_t st) {
+  if (p.MI == 1 && p.NJ == 1) launch_wgrad<T, 1, 1, TH>(a, p, st);
+  else if (p.MI == 1 && p.NJ == 2) launch_wgrad<T, 1, 2, TH>(a, p, st);
+  else if (p.MI == 2 && p.NJ == 1) launch_wgrad<T, 2, 1, TH>(a, p, st);
+  else launch_wgrad<T, 2, 2, TH>(a, p, st);
 }
 
 template <typename T>
 static void launch_wgrad_t(const WgradArgs& a, const WgradPlan& p, hipStream_t st) {
-  if (p.MI == 1 && p.NJ == 1) launch_wgrad<T, 1, 1>(a, p, st);
-  else if (p.MI == 1 && p.NJ == 2) launch_wgrad<T, 1, 2>(a, p, st);
-  else if (p.MI == 2 && p.NJ == 1) launch_wgrad<T, 2, 1>(a, p, st);
-  else launch_wgrad<T, 2, 2>(a, p, st);
+  if (p.TH == 14) launch_wgrad_th<T, 14>(a, p, st);
+  else launch_wgrad_th<T, 16>(a, p, st);
 }
 
 }  // namespace spcl
@@ -366,6 +411,11 @@ extern "C" int spcl_conv3x3_wgrad(const void* x, const void* dy, int dtype, int 
   a.tilesX = p.tilesX; a.tilesY = p.tilesY; a.ntiles = p.ntiles; a.nblk_ci = p.nblk_ci; a.nblk_co = p.nblk_co;
   static const int env_dbuf = getenv("SPCL_WGRAD_DBUF") ? atoi(getenv("SPCL_WGRAD_DBUF")) : 1;
   a.dbuf = env_dbuf;
+  {
+    const double px = (double)N * H * W, es = dtype == SPCL_F32 ? 4.0 : 2.0;
+    prof_cost(px * ((in_mode == 2 ? CinS * 4.0 : CinK * es) + CoutS * es) + 9.0 * Cin * Cout * 4.0,
+              2.0 * px * 9.0 * Cin * Cout);
+  }
   if (dtype == SPCL_F32) launch_wgrad_t<float>(a, p, st);
   else if (dtype == SPCL_BF16) launch_wgrad_t<bf16_t>(a, p, st);
   else {
@@ -373,7 +423,7 @@ extern "C" int spcl_conv3x3_wgrad(const void* x, const void* dy, int dtype, int 
     return SPCL_EINVAL;
   }
   const int slab = 9 * 16 * p.MI * 16 * p.NJ;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(slab, 64), p.nblk_ci * p.nblk_co), dim3(p.nsplit >= 64 ? 1024 : 256), 0, st,
+  SPCL_LAUNCH(wgrad_reduce_kernel, dim3(cdiv(slab, 64), p.nblk_ci * p.nblk_co), dim3(p.nsplit >= 64 ? 1024 : 256), 0, st,
                      (const float*)partial, p.nsplit, p.nblk_ci, p.nblk_co, 16 * p.MI, 16 * p.NJ, Cin, Cout, dw_oihw);
   SPCL_LAUNCH_CHECK("conv3x3_wgrad");
   return SPCL_OK;

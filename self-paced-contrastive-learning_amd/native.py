@@ -47,6 +47,9 @@ _SIGNATURES = {
     "spcl_bnrelu_pool_backward": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P,
                                           c_int, _P, _P, _P, _P, _P]),
     "spcl_flip_batch": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "spcl_profile_enable": (c_int, [c_int]),
+    "spcl_profile_count": (c_int, []),
+    "spcl_profile_get": (c_int, [c_int, c_char_p, c_int, _P, _P, _P]),
     "spcl_radam_step": (c_int, [_P, _P, _P, _P, c_size_t, _P, _P, c_double, c_double, c_double, c_double, _P, _P]),
 }
 
@@ -79,7 +82,7 @@ def call(name: str, *args):
     if fn is None:
         raise NativeLibraryError(f"libspcl_hip.so does not export {name}")
     rc = fn(*args)
-    if fn.restype is c_int and name != "spcl_abi_version" and name != "spcl_conv_num_tiles" and rc != 0:
+    if fn.restype is c_int and name not in ("spcl_abi_version", "spcl_conv_num_tiles", "spcl_profile_count") and rc != 0:
         raise RuntimeError(f"{name} failed ({rc}): {L.spcl_last_error().decode()}")
     return rc
 

@@ -300,3 +300,30 @@ def test_flip_batch_matches_per_sample_flips(shape, dtype):
     with FixRandomSeed(11):
         f.apply_batch(x.cuda(), out=out[shape[0]:])
     assert torch.equal(out[shape[0]:].cpu(), ref)
+
+
+def test_builtin_kernel_timer_reports_symbols_and_costs():
+    """spcl_profile_*: one record per kernel launch with the rocprofv3-style symbol, a positive duration and the
+    algorithmic bytes / FLOPs declared by the entry point."""
+    import ctypes
+    n = _n()
+    dtype = torch.bfloat16
+    N, ci, co, H, W = 2, 16, 16, 28, 28
+    x = torch.randn(N, ci, H, W)
+    w = torch.randn(co, ci, 3, 3) / 12
+    xs, wp = nhwc(x, dtype), pack(n, w, 0, dtype)
+    n.call("spcl_profile_enable", 1)
+    try:
+        conv(n, xs, dtype, N, H, W, 16, 16, 16, wp, 0, stats=True)
+        torch.cuda.synchronize()
+        assert n.call("spcl_profile_count") == 1
+        name = ctypes.create_string_buffer(256)
+        us, by, fl = ctypes.c_float(), ctypes.c_double(), ctypes.c_double()
+        n.call("spcl_profile_get", 0, name, 256, ctypes.byref(us), ctypes.byref(by), ctypes.byref(fl))
+        assert name.value.decode().startswith("spcl::conv3x3_") and "(" not in name.value.decode()
+        assert us.value > 0
+        assert by.value == N * H * W * (16 + 16) * 2 + 9 * 16 * 16 * 2
+        assert fl.value == 2.0 * N * H * W * 9 * 16 * 16
+    finally:
+        n.call("spcl_profile_enable", 0)
+    assert n.call("spcl_profile_count") == 0
