@@ -299,9 +299,12 @@ template <typename T> static size_t packed_elems(int KinK, int NoutS) {
 struct TileCfg { int th, tw; };
 static TileCfg pick_tile(int H, int W) {
   // measured (tools/bench_kernels.py, same box A/B): below 224^2 the half-height tile (twice the waves, half the
-  // accumulators per wave) is 10-35 % faster on every layer; at 224^2 the 14x14 tile wins by ~8 %
+  // accumulators per wave) is 10-35 % faster on every layer; at 224^2 the 14x14 tile wins by ~8 %.  7x7 tiles
+  // (SPCL_CONV_T77_MAXH=14) beat 7x14 at 14^2 only in the generic kernel; the specialised one is 10-15 % faster on 7x14.
+  // (Packing all layers' weights in one launch at the start of forward was measured too: 40 us per step SLOWER than
+  // the per-layer pack right before each conv, which leaves the fragments hot in L2 for the waves that fetch them.)
   static const int th7_max_h = getenv("SPCL_CONV_TH7_MAXH") ? atoi(getenv("SPCL_CONV_TH7_MAXH")) : 112;
-  static const int t77_max_h = getenv("SPCL_CONV_T77_MAXH") ? atoi(getenv("SPCL_CONV_T77_MAXH")) : 14;
+  static const int t77_max_h = getenv("SPCL_CONV_T77_MAXH") ? atoi(getenv("SPCL_CONV_T77_MAXH")) : 0;
   if (H % 14 == 0 && W % 14 == 0 && H <= t77_max_h) return {7, 7};
   if (H % 14 == 0 && W % 14 == 0 && H <= th7_max_h) return {7, 14};
   if (H % 14 == 0 && W % 14 == 0) return {14, 14};

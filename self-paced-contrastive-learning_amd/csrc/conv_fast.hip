@@ -327,7 +327,7 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st) {
   SPCL_FAST_CASE(64, 7, 2, 1)   // Conv3.a dgrad (64 -> 32)
   SPCL_FAST_CASE(64, 7, 1, 2)   //   "   as two one-n-tile waves
   SPCL_FAST_CASE(64, 7, 2, 2)   // Conv3.b, Conv4.a dgrad
-  SPCL_FAST_CASE(64, 7, 2, 4)   // Conv4.a forward, Conv4.b, (Conv5 when tiled 7x14)
+  SPCL_FAST_CASE(64, 7, 2, 4)   // Conv4.a forward, Conv4.b, Conv5 (7x14 tiles: 2 per 14x14 image)
 #undef SPCL_FAST_CASE
   return false;
 }
