@@ -29,6 +29,7 @@ from __future__ import annotations
 import math
 from typing import Dict, List, Optional, Sequence
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 from torch import Tensor
@@ -231,6 +232,49 @@ def unet_forward(x: Tensor, sd: Dict[str, Tensor], until: Optional[str] = None, 
         if until == f"Up_conv{lvl}":
             return d
     return F.conv2d(d, sd["_Deconv_1x1.weight"], sd["_Deconv_1x1.bias"])
+
+
+# --------------------------------------------------------------------------------------
+# fine-tune / evaluation arithmetic (SURVEY row N1)
+def class2one_hot(labels: Tensor, C: int) -> Tensor:
+    """[B,H,W] integer labels -> [B,C,H,W] one-hot (deepclustering2.utils.class2one_hot as used at
+    semi_seg/epochers/new_epocher.py:84,270)."""
+    return F.one_hot(labels.long(), C).permute(0, 3, 1, 2)
+
+
+def kl_div(prob: Tensor, target: Tensor, eps: float = 1e-16) -> Tensor:
+    """deepclustering2.loss.KL_div(reduction='mean') as called at new_epocher.py:86,271 and val.py:9 (un-vendored third
+    party, restated from its published definition): mean over (batch, positions) of
+    sum_c -target * log((prob + eps) / (target + eps))."""
+    t = target.to(prob.dtype)
+    kl = (-t * torch.log((prob + eps) / (t + eps))).sum(1)
+    return kl.mean()
+
+
+def finetune_loss(logits: Tensor, labels: Tensor, eps: float = 1e-16) -> Tensor:
+    """sup_loss of FineTuneEpocher._run_only_label (new_epocher.py:268-271)."""
+    return kl_div(logits.softmax(1), class2one_hot(labels, logits.shape[1]), eps)
+
+
+def dice_counts(pred: Tensor, target: Tensor, C: int):
+    """UniversalDice._intersaction / ._union on class-coded inputs (contrastyou/meters/general_dice_meter.py:131-
+    160,162-171): per sample and class, sum(pred_c * target_c) and sum(pred_c + target_c) -> two [B,C] int64."""
+    p, t = class2one_hot(pred, C), class2one_hot(target, C)
+    dims = list(range(2, p.dim()))
+    return (p * t).sum(dims), (p + t).sum(dims)
+
+
+def universal_dice(inters: Tensor, unions: Tensor, group_names: Sequence[str]):
+    """UniversalDice.log / .value (general_dice_meter.py:96-120): rows grouped by name, dice = (2 I + 1e-6)/(U + 1e-6),
+    then mean / std over groups.  -> (mean[C], std[C])"""
+    names = sorted(set(group_names))
+    arr = np.asarray(list(group_names))
+    rows = []
+    for nm in names:
+        idx = torch.from_numpy(arr == nm)
+        rows.append((2 * inters[idx].sum(0) + 1e-6) / (unions[idx].sum(0) + 1e-6))
+    d = torch.stack(rows, 0)
+    return d.mean(0), d.std(0)
 
 
 def encoder_forward(x, sd, until="Conv5", *, train=True, momentum=0.1, q=None):

@@ -242,3 +242,45 @@ def test_pscheduler_and_labels():
     assert O.get_label("patient", "prostate", parts, ["Case00_0", "Case01_3"]) == [0, 1]
     with pytest.raises(NotImplementedError):
         O.get_label("cycle", "prostate", parts, groups)
+
+
+def test_g5_decoder_and_finetune_step():
+    """Oracle's full UNet (decoder) + fine-tune loss vs the reference's modules (tools/gen_golden.py gen_decoder)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g5_decoder.npz"))
+    sd = O.init_unet_state(1, 4, 128, seed=11)
+    assert abs(sum(float(v.double().sum()) for v in sd.values()) - float(g["param_checksum"])) < 1e-6
+    x, labels = torch.from_numpy(g["x"]), torch.from_numpy(g["labels"])
+    for until in ("Up_conv5", "Up_conv4", "Up_conv3", "Up_conv2"):
+        sdc = {k: v.clone() for k, v in sd.items()}
+        np.testing.assert_allclose(O.unet_forward(x, sdc, until, train=True).numpy(), g[f"out/{until}"], rtol=1e-4,
+                                   atol=2e-5)
+    sdc = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+           for k, v in sd.items()}
+    logits = O.unet_forward(x, sdc, None, train=True)
+    np.testing.assert_allclose(logits.detach().numpy(), g["out/logits"], rtol=1e-4, atol=2e-5)
+    loss = O.finetune_loss(logits, labels)
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    loss.backward()
+    for k in g.files:
+        if k.startswith("grad/"):
+            ref = g[k]
+            got = sdc[k[5:]].grad.numpy()
+            assert np.abs(got - ref).max() <= 2e-4 * max(1e-6, np.abs(ref).max()) + 1e-7, k
+        elif k.startswith("buf/") and "num_batches" not in k:
+            np.testing.assert_allclose(sdc[k[4:]].detach().numpy(), g[k], rtol=1e-4, atol=1e-6)
+    ev = O.unet_forward(x, {k: v.detach() for k, v in sdc.items()}, None, train=False)
+    np.testing.assert_allclose(ev.detach().numpy(), g["eval/logits"], rtol=1e-4, atol=2e-5)
+    assert (ev.max(1)[1].numpy() == g["eval/pred"]).mean() > 0.999
+
+
+def test_dice_counts_and_universal_dice_known_answers():
+    pred = torch.tensor([[[0, 1], [1, 2]], [[2, 2], [0, 0]]])
+    tgt = torch.tensor([[[0, 1], [2, 2]], [[2, 0], [0, 0]]])
+    i, u = O.dice_counts(pred, tgt, 3)
+    assert i.tolist() == [[1, 1, 1], [2, 0, 1]] and u.tolist() == [[2, 3, 3], [5, 0, 3]]
+    mean, std = O.universal_dice(i, u, ["a", "a"])  # one 3-D group: counts are summed before the ratio
+    np.testing.assert_allclose(mean.numpy(), [(2 * 3 + 1e-6) / (7 + 1e-6), (2 + 1e-6) / (3 + 1e-6), (4 + 1e-6) / (6 + 1e-6)],
+                               rtol=1e-6)
+    mean2, _ = O.universal_dice(i, u, ["a", "b"])  # slice-wise groups: an empty class scores 1 (1e-6 / 1e-6)
+    np.testing.assert_allclose(float(mean2[1]), 0.5 * ((2 + 1e-6) / (3 + 1e-6) + 1.0), rtol=1e-6)

@@ -250,6 +250,47 @@ def gen_step(UNet, ProjectionHead, SelfPacedSupConLoss, SingleFeatureExtractor):
     print("g4_step done: loss", float(loss.detach()), "rho", crit.downgrade_ratio)
 
 
+def gen_decoder(UNet):
+    """G5: the reference's full UNet (decoder: _UpConv / skip-concat blocks / _Deconv_1x1,
+    semi_seg/arch/unet.py:85-97,193-230) in train mode on the G3 'small' weights: decoder outputs at every `until`,
+    and one fine-tune step's gradients / BN buffers under the supervised loss of new_epocher.py:270-271
+    (KL_div(softmax(logits), onehot) of the un-vendored deepclustering2, restated as -mean log(p_target + 1e-16))."""
+    from oracle.spcl_oracle import init_unet_state
+    out = {}
+    sd = init_unet_state(1, 4, 128, seed=11)
+    g = torch.Generator().manual_seed(12)
+    x = torch.rand(4, 1, 32, 32, generator=g)  # == G3 small/x
+    labels = torch.randint(0, 4, (4, 32, 32), generator=torch.Generator().manual_seed(13))
+    out["x"], out["labels"] = x.numpy(), labels.numpy()
+    out["param_checksum"] = np.float64(sum(float(v.double().sum()) for v in sd.values()))
+    for until in ("Up_conv5", "Up_conv4", "Up_conv3", "Up_conv2"):
+        ref = UNet(input_dim=1, num_classes=4, max_channel=128)
+        ref.load_state_dict(sd, strict=True)
+        ref.train()
+        out[f"out/{until}"] = ref(x, until=until).detach().numpy()
+    net = UNet(input_dim=1, num_classes=4, max_channel=128)
+    net.load_state_dict(sd, strict=True)
+    net.train()
+    logits = net(x)
+    out["out/logits"] = logits.detach().numpy()
+    prob = logits.softmax(1)
+    onehot = torch.nn.functional.one_hot(labels, 4).permute(0, 3, 1, 2).float()
+    loss = -(onehot * torch.log(prob + 1e-16)).sum(1).mean()
+    out["loss"] = np.float64(loss.item())
+    loss.backward()
+    for k, p in net.named_parameters():
+        out[f"grad/{k}"] = p.grad.numpy()
+    for k, b in net.named_buffers():
+        out[f"buf/{k}"] = b.numpy()
+    net.eval()
+    with torch.no_grad():
+        ev = net(x)
+    out["eval/logits"] = ev.numpy()
+    out["eval/pred"] = ev.max(1)[1].numpy()
+    np.savez_compressed(os.path.join(OUT, "g5_decoder.npz"), **out)
+    print("g5_decoder done")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -258,6 +299,7 @@ def main():
     gen_projector(ProjectionHead)
     gen_encoder(UNet)
     gen_step(UNet, ProjectionHead, SelfPacedSupConLoss, SFE)
+    gen_decoder(UNet)
 
 
 if __name__ == "__main__":
