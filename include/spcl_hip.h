@@ -143,6 +143,36 @@ int spcl_bnrelu_pool_backward(const void* y, const void* dact, const void* dpool
                               void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * Segmentation head and fine-tune / evaluation arithmetic.  Activations [npix][CS] of dtype (NHWC,
+ * npix = N*H*W); class maps [npix][K] f32 with K <= 16; labels [npix] int64.
+ *   spcl_conv1x1_forward/backward   nn.Conv2d(C, K, 1) with bias = `_Deconv_1x1`, semi_seg/arch/unet.py:147,229 (+ autograd):
+ *                                   out = x W^T + b;  dx (dtype, padding channels zeroed), dW [K][C], db [K]
+ *   spcl_softmax_forward/backward   `logits.softmax(1)` of semi_seg/epochers/new_epocher.py:86,271 (+ autograd)
+ *   spcl_kl_div_forward/backward    deepclustering2.loss.KL_div(reduction="mean") as called there (un-vendored; restated):
+ *                                   loss = mean_p sum_k -t log((p+eps)/(t+eps));  dprob = grad_loss * (-t/(p+eps))/npix
+ *   spcl_one_hot                    class2one_hot (new_epocher.py:84,270) into [npix][K] f32
+ *   spcl_argmax_classes             `.max(1)[1]` (new_epocher.py:89,282): first maximum
+ *   spcl_dice_counts                UniversalDice._intersaction / ._union on class-coded maps
+ *                                   (contrastyou/meters/general_dice_meter.py:131-160): inter/union [B][C] int64, which
+ *                                   the caller zeroes (integer atomics: exact and order-independent) */
+int spcl_conv1x1_forward(const void* x, int dtype, size_t npix, int C, int CS, int K, const float* w, const float* b,
+                         float* out, void* stream);
+size_t spcl_conv1x1_bwd_workspace_bytes(int C, int K);
+int spcl_conv1x1_backward(const void* x, const float* dout, int dtype, size_t npix, int C, int CS, int K, const float* w,
+                          void* dx, float* dw, float* db, float* ws, void* stream);
+int spcl_softmax_forward(const float* logits, size_t npix, int K, float* prob, void* stream);
+int spcl_softmax_backward(const float* prob, const float* dprob, size_t npix, int K, float* dlogits, void* stream);
+size_t spcl_kl_workspace_bytes(void);
+int spcl_kl_div_forward(const float* prob, const float* target, size_t npix, int K, float eps, float* ws, float* loss,
+                        void* stream);
+int spcl_kl_div_backward(const float* prob, const float* target, size_t npix, int K, float eps, const float* grad_loss,
+                         float* dprob, void* stream);
+int spcl_one_hot(const int64_t* labels, size_t npix, int K, float* out, void* stream);
+int spcl_argmax_classes(const float* logits, size_t npix, int K, int64_t* out, void* stream);
+int spcl_dice_counts(const int64_t* pred, const int64_t* target, int B, int per_sample, int C, int64_t* inter_zeroed,
+                     int64_t* union_zeroed, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * Optimizer step of the pre-train iteration (contrastyou/trainer/base.py:62 builds RAdam from the un-vendored
  * deepclustering2; the build follows torch.optim.RAdam(decoupled_weight_decay=False)) on ONE
  * flat fp32 parameter:  g' = g + wd p;  m = lerp(m, g', 1-b1);  v = b2 v + (1-b2) g'^2;  t = ++step;

@@ -1,0 +1,380 @@
+// Segmentation head and fine-tune / evaluation arithmetic on gfx950:
+//   * 1x1 convolution with bias, semi_seg/arch/unet.py:147 `_Deconv_1x1` (forward :229) + its backward;
+//   * softmax over classes (`logits.softmax(1)`, semi_seg/epochers/new_epocher.py:86,271) + backward;
+//   * deepclustering2.loss.KL_div(reduction="mean") as called there (restated: mean over positions of
+//     sum_c -t log((p+eps)/(t+eps))) + backward w.r.t. the probabilities;
+//   * class2one_hot (:84,270), arg-max over classes (`.max(1)[1]`, :89,282) and the per-sample per-class intersection /
+//     union counts of contrastyou/meters/general_dice_meter.py:131-160.
+// All of them are one-pixel-per-thread HBM streams over NHWC data: activations [N,H,W,CS] (dtype), class maps
+// [N,H,W,K] f32 (K <= 16), labels [N,H,W] int64.  Reductions are per-workgroup partials + a fixed-order second stage
+// (float) or integer atomics (counts): deterministic.
+#include "common.hpp"
+
+namespace spcl {
+
+constexpr int HEAD_MAX_K = 16;
+constexpr int HEAD_MAX_C = 256;
+constexpr int HEAD_RED_WG = 1024;
+
+// ------------------------------------------------------------------------------------------------ 1x1 conv + bias
+// KB = compile-time bound of the class count (4 / 8 / 16) so that the per-class accumulators live in registers
+template <typename T, int KB>
+__global__ __launch_bounds__(256) void conv1x1_fwd_kernel(const T* __restrict__ x, size_t npix, int C, int CS, int K,
+                                                          const float* __restrict__ w, const float* __restrict__ b,
+                                                          float* __restrict__ out) {
+  __shared__ float ws[KB * HEAD_MAX_C + KB];
+  for (int i = threadIdx.x; i < KB * C; i += 256) ws[i] = i < K * C ? w[i] : 0.f;
+  if (threadIdx.x < KB) ws[KB * C + threadIdx.x] = threadIdx.x < K ? b[threadIdx.x] : 0.f;
+  __syncthreads();
+  for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (size_t)gridDim.x * 256) {
+    float acc[KB];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) acc[k] = ws[KB * C + k];
+    const T* px = x + p * CS;
+    for (int c = 0; c < C; ++c) {
+      const float xv = Elem<T>::load(px + c);
+#pragma unroll
+      for (int k = 0; k < KB; ++k) acc[k] = fmaf(xv, ws[k * C + c], acc[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < KB; ++k)
+      if (k < K) out[p * K + k] = acc[k];
+  }
+}
+
+// dX[p][c] = sum_k dO[p][k] w[k][c]; per-workgroup partials of dW[k][c] = sum_p dO[p][k] x[p][c], db[k] = sum_p dO[p][k].
+// Channels are walked in groups of CG = 64 / KB so that the KB x CG accumulators stay in registers.
+template <typename T, int KB>
+__global__ __launch_bounds__(256) void conv1x1_bwd_kernel(const T* __restrict__ x, const float* __restrict__ dout,
+                                                          size_t npix, int C, int CS, int K,
+                                                          const float* __restrict__ w, T* __restrict__ dx,
+                                                          float* __restrict__ partial /* [grid][K][C+1] */) {
+  constexpr int CG = 64 / KB;
+  __shared__ float ws[KB * HEAD_MAX_C];
+  __shared__ float red[4][KB * (CG + 1)];
+  for (int i = threadIdx.x; i < KB * C; i += 256) ws[i] = i < K * C ? w[i] : 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* mypart = partial + (size_t)blockIdx.x * K * (C + 1);
+  for (int c0 = 0; c0 < CS; c0 += CG) {
+    float aw[KB][CG], ab[KB];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      ab[k] = 0.f;
+#pragma unroll
+      for (int c = 0; c < CG; ++c) aw[k][c] = 0.f;
+    }
+    for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (size_t)gridDim.x * 256) {
+      float g[KB];
+#pragma unroll
+      for (int k = 0; k < KB; ++k) g[k] = k < K ? dout[p * K + k] : 0.f;
+#pragma unroll
+      for (int c = 0; c < CG; ++c) {
+        const int cc = c0 + c;  // < CS (CS is a multiple of 16 >= CG)
+        const float xv = cc < C ? Elem<T>::load(x + p * CS + cc) : 0.f;
+        float d = 0.f;
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+          aw[k][c] = fmaf(g[k], xv, aw[k][c]);
+          d = fmaf(g[k], cc < C ? ws[k * C + cc] : 0.f, d);
+        }
+        Elem<T>::store(dx + p * CS + cc, d);  // padding channels get exact zeros
+      }
+      if (c0 == 0) {
+#pragma unroll
+        for (int k = 0; k < KB; ++k) ab[k] += g[k];
+      }
+    }
+    // wave butterfly, then the 4 waves in fixed order
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+#pragma unroll
+      for (int c = 0; c < CG; ++c) {
+        const float s = wave_sum(aw[k][c]);
+        if (lane == 0) red[wave][k * (CG + 1) + c] = s;
+      }
+      const float sb = wave_sum(ab[k]);
+      if (lane == 0) red[wave][k * (CG + 1) + CG] = sb;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < KB * (CG + 1); i += 256) {
+      const int k = i / (CG + 1), c = i - k * (CG + 1);
+      const float s = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+      if (k < K) {
+        if (c < CG) {
+          if (c0 + c < C) mypart[k * (C + 1) + c0 + c] = s;
+        } else if (c0 == 0) {
+          mypart[k * (C + 1) + C] = s;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T>
+static void launch_conv1x1_fwd(int grid, hipStream_t st, const void* x, size_t npix, int C, int CS, int K, const float* w,
+                               const float* b, float* out) {
+  if (K <= 4) SPCL_LAUNCH((conv1x1_fwd_kernel<T, 4>), dim3(grid), dim3(256), 0, st, (const T*)x, npix, C, CS, K, w, b, out);
+  else if (K <= 8) SPCL_LAUNCH((conv1x1_fwd_kernel<T, 8>), dim3(grid), dim3(256), 0, st, (const T*)x, npix, C, CS, K, w, b, out);
+  else SPCL_LAUNCH((conv1x1_fwd_kernel<T, 16>), dim3(grid), dim3(256), 0, st, (const T*)x, npix, C, CS, K, w, b, out);
+}
+template <typename T>
+static void launch_conv1x1_bwd(int grid, hipStream_t st, const void* x, const float* dout, size_t npix, int C, int CS,
+                               int K, const float* w, void* dx, float* ws) {
+  if (K <= 4) SPCL_LAUNCH((conv1x1_bwd_kernel<T, 4>), dim3(grid), dim3(256), 0, st, (const T*)x, dout, npix, C, CS, K, w, (T*)dx, ws);
+  else if (K <= 8) SPCL_LAUNCH((conv1x1_bwd_kernel<T, 8>), dim3(grid), dim3(256), 0, st, (const T*)x, dout, npix, C, CS, K, w, (T*)dx, ws);
+  else SPCL_LAUNCH((conv1x1_bwd_kernel<T, 16>), dim3(grid), dim3(256), 0, st, (const T*)x, dout, npix, C, CS, K, w, (T*)dx, ws);
+}
+
+// out[i] = sum over workgroup partials, fixed order (one thread per output, partial rows strided)
+__global__ __launch_bounds__(256) void head_partial_sum_kernel(const float* __restrict__ partial, int nwg, int n,
+                                                               float scale, float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int w = 0; w < nwg; ++w) s += partial[(size_t)w * n + i];
+  out[i] = s * scale;
+}
+
+// dW[k][c], db[k] from the [nwg][K][C+1] partial rows, fixed order
+__global__ __launch_bounds__(256) void conv1x1_finish_kernel(const float* __restrict__ partial, int nwg, int K, int C,
+                                                             float* __restrict__ dw, float* __restrict__ db) {
+  const int i = blockIdx.x * 256 + threadIdx.x, n = K * (C + 1);
+  if (i >= n) return;
+  float s = 0.f;
+  for (int w = 0; w < nwg; ++w) s += partial[(size_t)w * n + i];
+  const int k = i / (C + 1), c = i - k * (C + 1);
+  if (c < C) dw[k * C + c] = s;
+  else db[k] = s;
+}
+
+// ------------------------------------------------------------------------------------------------ softmax over K
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ logits, size_t npix, int K,
+                                                          float* __restrict__ prob) {
+  for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (size_t)gridDim.x * 256) {
+    float v[HEAD_MAX_K];
+    float m = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < HEAD_MAX_K; ++k)
+      if (k < K) { v[k] = logits[p * K + k]; m = fmaxf(m, v[k]); }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < HEAD_MAX_K; ++k)
+      if (k < K) { v[k] = expf(v[k] - m); s += v[k]; }
+    const float inv = 1.f / s;
+#pragma unroll
+    for (int k = 0; k < HEAD_MAX_K; ++k)
+      if (k < K) prob[p * K + k] = v[k] * inv;
+  }
+}
+
+// dlogits = p * (dp - sum_k dp_k p_k)
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ prob, const float* __restrict__ dprob,
+                                                          size_t npix, int K, float* __restrict__ dlogits) {
+  for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (size_t)gridDim.x * 256) {
+    float pv[HEAD_MAX_K], dv[HEAD_MAX_K], dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < HEAD_MAX_K; ++k)
+      if (k < K) { pv[k] = prob[p * K + k]; dv[k] = dprob[p * K + k]; dot = fmaf(pv[k], dv[k], dot); }
+#pragma unroll
+    for (int k = 0; k < HEAD_MAX_K; ++k)
+      if (k < K) dlogits[p * K + k] = pv[k] * (dv[k] - dot);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ KL_div
+// partial[wg] = sum over the workgroup's positions of sum_k -t log((p+eps)/(t+eps))
+__global__ __launch_bounds__(256) void kl_fwd_kernel(const float* __restrict__ prob, const float* __restrict__ target,
+                                                     size_t npix, int K, float eps, float* __restrict__ partial) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (size_t)gridDim.x * 256) {
+#pragma unroll
+    for (int k = 0; k < HEAD_MAX_K; ++k)
+      if (k < K) {
+        const float t = target[p * K + k];
+        s -= t * logf((prob[p * K + k] + eps) / (t + eps));
+      }
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// dprob = gscale[0] * (-t / (p + eps)) / npix
+__global__ __launch_bounds__(256) void kl_bwd_kernel(const float* __restrict__ prob, const float* __restrict__ target,
+                                                     size_t n, float eps, float inv_m,
+                                                     const float* __restrict__ gscale, float* __restrict__ dprob) {
+  const float gs = gscale[0] * inv_m;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    dprob[i] = -gs * target[i] / (prob[i] + eps);
+}
+
+// ------------------------------------------------------------------------------------------------ labels
+__global__ __launch_bounds__(256) void one_hot_kernel(const int64_t* __restrict__ labels, size_t npix, int K,
+                                                      float* __restrict__ out) {
+  for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (size_t)gridDim.x * 256) {
+    const int64_t l = labels[p];
+#pragma unroll
+    for (int k = 0; k < HEAD_MAX_K; ++k)
+      if (k < K) out[p * K + k] = l == k ? 1.f : 0.f;
+  }
+}
+
+// first maximum over the K classes (torch.max(1)[1])
+__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logits, size_t npix, int K,
+                                                     int64_t* __restrict__ out) {
+  for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (size_t)gridDim.x * 256) {
+    float m = logits[p * K];
+    int best = 0;
+    for (int k = 1; k < K; ++k) {
+      const float v = logits[p * K + k];
+      if (v > m) { m = v; best = k; }
+    }
+    out[p] = best;
+  }
+}
+
+// inter[n][c] += [pred==c && tgt==c], uni[n][c] += [pred==c] + [tgt==c]; integer atomics (exact, order-free)
+__global__ __launch_bounds__(256) void dice_counts_kernel(const int64_t* __restrict__ pred,
+                                                          const int64_t* __restrict__ target, int per_sample, int C,
+                                                          unsigned long long* __restrict__ inter,
+                                                          unsigned long long* __restrict__ uni) {
+  __shared__ unsigned int si[64], su[64];
+  const int n = blockIdx.y;
+  if (threadIdx.x < 64) si[threadIdx.x] = su[threadIdx.x] = 0u;
+  __syncthreads();
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < per_sample; i += gridDim.x * 256) {
+    const int64_t pv = pred[(size_t)n * per_sample + i], tv = target[(size_t)n * per_sample + i];
+    if (pv >= 0 && pv < C) atomicAdd(&su[pv], 1u);
+    if (tv >= 0 && tv < C) atomicAdd(&su[tv], 1u);
+    if (pv == tv && pv >= 0 && pv < C) atomicAdd(&si[pv], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < C) {
+    if (si[threadIdx.x]) atomicAdd(&inter[(size_t)n * C + threadIdx.x], (unsigned long long)si[threadIdx.x]);
+    if (su[threadIdx.x]) atomicAdd(&uni[(size_t)n * C + threadIdx.x], (unsigned long long)su[threadIdx.x]);
+  }
+}
+
+static int head_grid(size_t n, int cap) {
+  size_t g = (n + 255) / 256;
+  if (g > (size_t)cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace spcl
+
+using namespace spcl;
+
+extern "C" int spcl_conv1x1_forward(const void* x, int dtype, size_t npix, int C, int CS, int K, const float* w,
+                                    const float* b, float* out, void* stream) {
+  SPCL_CHECK_ARG(x && w && b && out, "conv1x1_forward: null pointer");
+  SPCL_CHECK_ARG(npix > 0 && C > 0 && C <= CS && C <= HEAD_MAX_C && K > 0 && K <= HEAD_MAX_K, "conv1x1_forward: shape");
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = head_grid(npix, 4096);
+  prof_cost((double)npix * (CS * (dtype == SPCL_F32 ? 4.0 : 2.0) + K * 4.0), 2.0 * npix * C * K);
+  if (dtype == SPCL_F32) launch_conv1x1_fwd<float>(grid, st, x, npix, C, CS, K, w, b, out);
+  else if (dtype == SPCL_BF16) launch_conv1x1_fwd<bf16_t>(grid, st, x, npix, C, CS, K, w, b, out);
+  else {
+    set_error("conv1x1_forward: dtype %d", dtype);
+    return SPCL_EINVAL;
+  }
+  SPCL_LAUNCH_CHECK("conv1x1_forward");
+  return SPCL_OK;
+}
+
+extern "C" size_t spcl_conv1x1_bwd_workspace_bytes(int C, int K) {
+  return (size_t)HEAD_RED_WG * K * (C + 1) * sizeof(float);
+}
+
+extern "C" int spcl_conv1x1_backward(const void* x, const float* dout, int dtype, size_t npix, int C, int CS, int K,
+                                     const float* w, void* dx, float* dw, float* db, float* ws, void* stream) {
+  SPCL_CHECK_ARG(x && dout && w && dx && dw && db && ws, "conv1x1_backward: null pointer");
+  SPCL_CHECK_ARG(npix > 0 && C > 0 && C <= CS && C <= HEAD_MAX_C && K > 0 && K <= HEAD_MAX_K && CS % 16 == 0,
+                 "conv1x1_backward: shape");
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = head_grid(npix, HEAD_RED_WG);
+  prof_cost((double)npix * (2.0 * CS * (dtype == SPCL_F32 ? 4.0 : 2.0) + K * 4.0), 4.0 * npix * C * K);
+  if (dtype == SPCL_F32) launch_conv1x1_bwd<float>(grid, st, x, dout, npix, C, CS, K, w, dx, ws);
+  else if (dtype == SPCL_BF16) launch_conv1x1_bwd<bf16_t>(grid, st, x, dout, npix, C, CS, K, w, dx, ws);
+  else {
+    set_error("conv1x1_backward: dtype %d", dtype);
+    return SPCL_EINVAL;
+  }
+  SPCL_LAUNCH(conv1x1_finish_kernel, dim3(cdiv(K * (C + 1), 256)), dim3(256), 0, st, (const float*)ws, grid, K, C, dw,
+              db);
+  SPCL_LAUNCH_CHECK("conv1x1_backward");
+  return SPCL_OK;
+}
+
+extern "C" int spcl_softmax_forward(const float* logits, size_t npix, int K, float* prob, void* stream) {
+  SPCL_CHECK_ARG(logits && prob && npix > 0 && K > 0 && K <= HEAD_MAX_K, "softmax_forward: bad args");
+  prof_cost((double)npix * K * 8.0, 0.0);
+  SPCL_LAUNCH(softmax_fwd_kernel, dim3(head_grid(npix, 4096)), dim3(256), 0, (hipStream_t)stream, logits, npix, K, prob);
+  SPCL_LAUNCH_CHECK("softmax_forward");
+  return SPCL_OK;
+}
+
+extern "C" int spcl_softmax_backward(const float* prob, const float* dprob, size_t npix, int K, float* dlogits,
+                                     void* stream) {
+  SPCL_CHECK_ARG(prob && dprob && dlogits && npix > 0 && K > 0 && K <= HEAD_MAX_K, "softmax_backward: bad args");
+  prof_cost((double)npix * K * 12.0, 0.0);
+  SPCL_LAUNCH(softmax_bwd_kernel, dim3(head_grid(npix, 4096)), dim3(256), 0, (hipStream_t)stream, prob, dprob, npix, K,
+              dlogits);
+  SPCL_LAUNCH_CHECK("softmax_backward");
+  return SPCL_OK;
+}
+
+extern "C" size_t spcl_kl_workspace_bytes(void) { return (size_t)HEAD_RED_WG * sizeof(float); }
+
+extern "C" int spcl_kl_div_forward(const float* prob, const float* target, size_t npix, int K, float eps, float* ws,
+                                   float* loss, void* stream) {
+  SPCL_CHECK_ARG(prob && target && ws && loss && npix > 0 && K > 0 && K <= HEAD_MAX_K, "kl_div_forward: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = head_grid(npix, HEAD_RED_WG);
+  prof_cost((double)npix * K * 8.0, 0.0);
+  SPCL_LAUNCH(kl_fwd_kernel, dim3(grid), dim3(256), 0, st, prob, target, npix, K, eps, ws);
+  SPCL_LAUNCH(head_partial_sum_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, grid, 1, 1.f / (float)npix, loss);
+  SPCL_LAUNCH_CHECK("kl_div_forward");
+  return SPCL_OK;
+}
+
+extern "C" int spcl_kl_div_backward(const float* prob, const float* target, size_t npix, int K, float eps,
+                                    const float* grad_loss, float* dprob, void* stream) {
+  SPCL_CHECK_ARG(prob && target && grad_loss && dprob && npix > 0 && K > 0, "kl_div_backward: bad args");
+  prof_cost((double)npix * K * 12.0, 0.0);
+  SPCL_LAUNCH(kl_bwd_kernel, dim3(head_grid(npix * K, 4096)), dim3(256), 0, (hipStream_t)stream, prob, target, npix * K,
+              eps, 1.f / (float)npix, grad_loss, dprob);
+  SPCL_LAUNCH_CHECK("kl_div_backward");
+  return SPCL_OK;
+}
+
+extern "C" int spcl_one_hot(const int64_t* labels, size_t npix, int K, float* out, void* stream) {
+  SPCL_CHECK_ARG(labels && out && npix > 0 && K > 0 && K <= HEAD_MAX_K, "one_hot: bad args");
+  SPCL_LAUNCH(one_hot_kernel, dim3(head_grid(npix, 4096)), dim3(256), 0, (hipStream_t)stream, labels, npix, K, out);
+  SPCL_LAUNCH_CHECK("one_hot");
+  return SPCL_OK;
+}
+
+extern "C" int spcl_argmax_classes(const float* logits, size_t npix, int K, int64_t* out, void* stream) {
+  SPCL_CHECK_ARG(logits && out && npix > 0 && K > 0, "argmax_classes: bad args");
+  SPCL_LAUNCH(argmax_kernel, dim3(head_grid(npix, 4096)), dim3(256), 0, (hipStream_t)stream, logits, npix, K, out);
+  SPCL_LAUNCH_CHECK("argmax_classes");
+  return SPCL_OK;
+}
+
+extern "C" int spcl_dice_counts(const int64_t* pred, const int64_t* target, int B, int per_sample, int C,
+                                int64_t* inter_zeroed, int64_t* union_zeroed, void* stream) {
+  SPCL_CHECK_ARG(pred && target && inter_zeroed && union_zeroed, "dice_counts: null pointer");
+  SPCL_CHECK_ARG(B > 0 && per_sample > 0 && C > 0 && C <= 64, "dice_counts: bad shape");
+  int gx = (per_sample + 255) / 256;
+  if (gx > 64) gx = 64;
+  SPCL_LAUNCH(dice_counts_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, pred, target, per_sample, C,
+              (unsigned long long*)inter_zeroed, (unsigned long long*)union_zeroed);
+  SPCL_LAUNCH_CHECK("dice_counts");
+  return SPCL_OK;
+}

@@ -161,12 +161,12 @@ def to_nhwc_padded(x: torch.Tensor, dtype: torch.dtype):
     Zero-copy when x already is such a view (what the fused blocks hand to each other)."""
     N, C, H, W = x.shape
     cs = _ru16(C)
-    if x.dtype == dtype:
+    if x.dtype == dtype and cs == C:
         sN, sC, sH, sW = x.stride()
         if sC == 1 and sW == cs and sH == W * cs and sN == H * W * cs:
-            if cs == C:
-                return x.permute(0, 2, 3, 1)
-            return torch.as_strided(x, (N, H, W, cs), (sN, sH, sW, 1))
+            return x.permute(0, 2, 3, 1)
+    # (a channel count that is not a multiple of 16 is always re-padded: a narrow view cannot prove that the lanes
+    # behind it hold zeros -- e.g. a channel slice of a concatenation's gradient)
     if cs == C:
         return x.to(dtype).contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1)
     out = torch.zeros(N, H, W, cs, dtype=dtype, device=x.device)
@@ -343,3 +343,205 @@ class _ConvBlockFn(torch.autograd.Function):
 def conv_block(x, wa, ga, ba, wb, gb, bb, cfg: BlockCfg):
     """-> (act or None, pooled or None), logical NCHW views over NHWC storage."""
     return _ConvBlockFn.apply(x, wa, ga, ba, wb, gb, bb, cfg)
+
+
+# --------------------------------------------------------------------------------------------- decoder / head (N1)
+class _ConvBNReLUFn(torch.autograd.Function):
+    """conv3x3 -> BN -> ReLU, ONCE (the conv of ``_UpConv``, semi_seg/arch/unet.py:85-97, after its nearest upsample),
+    from the same kernels as the two-conv block: conv with statistics epilogue, finalize, BN-apply+ReLU writer;
+    backward = BN-ReLU backward (2 passes), wgrad, dgrad."""
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, cfg: BlockCfg):
+        _n.require_gpu(x, w)
+        dtype, dev = cfg.dtype, x.device
+        dtc = _n.dtype_code(dtype)
+        N, cin, H, W = x.shape
+        cout = w.shape[0]
+        cout_s = _ru16(cout)
+        xs = to_nhwc_padded(x.detach(), dtype)
+        cin_s = xs.shape[3]
+        need_bwd = any(ctx.needs_input_grad)
+        if need_bwd:
+            wp, wp_t = _pack_both(w, dtc, dtype)
+        else:
+            wp, wp_t = _pack(w, 0, dtc, dtype), None
+        y, s = _conv(xs, dtc, dtype, N, H, W, cin_s, cin_s, cout_s, wp, 0, None, None, cfg.training)
+        st = _bn_stats(s, cfg, cout, cout_s, gamma, beta, 0, dev)
+        act = torch.empty(N, H, W, cout_s, dtype=dtype, device=dev)
+        _n.call("spcl_bnrelu_pool_forward", _n.ptr(y), dtc, N, H, W, cout_s, _n.ptr(st[2]), _n.ptr(st[3]), _n.ptr(act),
+                None, _n.stream())
+        ctx.save_for_backward(xs, y, st, w)
+        ctx.packed_t = wp_t
+        ctx.cfg = cfg
+        ctx.meta = (N, cin, H, W, cout, cout_s, cin_s, x.dtype)
+        return nhwc_to_logical(act, cout)
+
+    @staticmethod
+    def backward(ctx, d_act):
+        xs, y, st, w = ctx.saved_tensors
+        cfg = ctx.cfg
+        N, cin, H, W, cout, cout_s, cin_s, xdt = ctx.meta
+        dtype = cfg.dtype
+        dtc = _n.dtype_code(dtype)
+        da_s = to_nhwc_padded(d_act, dtype)
+        dy, dg, db = _bnrelu_bwd(y, da_s, None, dtc, dtype, N, H, W, cout, cout_s, st, cfg.training)
+        dw = _wgrad(xs, dy, dtc, N, H, W, cin, cin_s, cin_s, cout, cout_s, 0, None, None) \
+            if ctx.needs_input_grad[1] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wp_t = ctx.packed_t if ctx.packed_t is not None else _pack(w, 1, dtc, dtype)
+            dxs, _ = _conv(dy, dtc, dtype, N, H, W, cout_s, cout_s, cin_s, wp_t, 0, None, None, False)
+            dx = nhwc_to_logical(dxs, cin)
+            if dx.dtype != xdt:
+                dx = dx.to(xdt)
+        ng = ctx.needs_input_grad
+        return dx, dw, dg if ng[2] else None, db if ng[3] else None, None
+
+
+def conv_bn_relu(x, w, gamma, beta, cfg: BlockCfg):
+    return _ConvBNReLUFn.apply(x, w, gamma, beta, cfg)
+
+
+def _class_map_storage(t: torch.Tensor):
+    """logical [N,K,H,W] f32 -> contiguous [N,H,W,K] storage (zero-copy for the channels-last views these ops return)."""
+    assert t.dim() == 4
+    if t.dtype != torch.float32:
+        t = t.float()
+    s = t.permute(0, 2, 3, 1)
+    return s if s.is_contiguous() else s.contiguous()
+
+
+class _Conv1x1Fn(torch.autograd.Function):
+    """nn.Conv2d(C, K, 1) with bias (``_Deconv_1x1``, unet.py:147,229) -> f32 class map, logical [N,K,H,W]."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, dtype):
+        _n.require_gpu(x, w, b)
+        N, C, H, W = x.shape
+        K = w.shape[0]
+        if K > 16 or C > 256:
+            raise NotImplementedError("conv1x1 head: at most 16 classes / 256 input channels")
+        xs = to_nhwc_padded(x.detach(), dtype)
+        cs = xs.shape[3]
+        wc, bc = w.detach().reshape(K, C).contiguous().float(), b.detach().contiguous().float()
+        out = torch.empty(N, H, W, K, dtype=torch.float32, device=x.device)
+        _n.call("spcl_conv1x1_forward", _n.ptr(xs), _n.dtype_code(dtype), N * H * W, C, cs, K, _n.ptr(wc), _n.ptr(bc),
+                _n.ptr(out), _n.stream())
+        ctx.save_for_backward(xs, wc)
+        ctx.meta = (N, C, H, W, K, cs, dtype, x.dtype, tuple(w.shape))
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dout):
+        xs, wc = ctx.saved_tensors
+        N, C, H, W, K, cs, dtype, xdt, wshape = ctx.meta
+        do = _class_map_storage(dout)
+        dev = do.device
+        dxs = torch.empty(N, H, W, cs, dtype=dtype, device=dev)
+        dw = torch.empty(K, C, dtype=torch.float32, device=dev)
+        db = torch.empty(K, dtype=torch.float32, device=dev)
+        ws = torch.empty(_n.call("spcl_conv1x1_bwd_workspace_bytes", C, K) // 4, dtype=torch.float32, device=dev)
+        _n.call("spcl_conv1x1_backward", _n.ptr(xs), _n.ptr(do), _n.dtype_code(dtype), N * H * W, C, cs, K, _n.ptr(wc),
+                _n.ptr(dxs), _n.ptr(dw), _n.ptr(db), _n.ptr(ws), _n.stream())
+        dx = nhwc_to_logical(dxs, C)
+        if dx.dtype != xdt:
+            dx = dx.to(xdt)
+        return dx, dw.reshape(wshape), db, None
+
+
+def conv1x1(x, w, b, dtype):
+    return _Conv1x1Fn.apply(x, w, b, dtype)
+
+
+class _SoftmaxFn(torch.autograd.Function):
+    """``logits.softmax(1)`` on a logical [N,K,H,W] class map (new_epocher.py:86,271)."""
+
+    @staticmethod
+    def forward(ctx, logits):
+        _n.require_gpu(logits)
+        ls = _class_map_storage(logits.detach())
+        N, H, W, K = ls.shape
+        prob = torch.empty_like(ls)
+        _n.call("spcl_softmax_forward", _n.ptr(ls), N * H * W, K, _n.ptr(prob), _n.stream())
+        ctx.save_for_backward(prob)
+        return prob.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dprob):
+        (prob,) = ctx.saved_tensors
+        N, H, W, K = prob.shape
+        dp = _class_map_storage(dprob)
+        dl = torch.empty_like(prob)
+        _n.call("spcl_softmax_backward", _n.ptr(prob), _n.ptr(dp), N * H * W, K, _n.ptr(dl), _n.stream())
+        return dl.permute(0, 3, 1, 2)
+
+
+def softmax_classes(logits):
+    return _SoftmaxFn.apply(logits)
+
+
+class _KLDivFn(torch.autograd.Function):
+    """deepclustering2.loss.KL_div(reduction='mean')(prob, target): mean over positions of
+    sum_c -target log((prob+eps)/(target+eps)); gradient w.r.t. ``prob`` only (as the reference uses it)."""
+
+    @staticmethod
+    def forward(ctx, prob, target, eps):
+        _n.require_gpu(prob, target)
+        ps, ts = _class_map_storage(prob.detach()), _class_map_storage(target.detach())
+        N, H, W, K = ps.shape
+        dev = ps.device
+        ws = torch.empty(_n.call("spcl_kl_workspace_bytes") // 4, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        _n.call("spcl_kl_div_forward", _n.ptr(ps), _n.ptr(ts), N * H * W, K, c_float(eps), _n.ptr(ws), _n.ptr(loss),
+                _n.stream())
+        ctx.save_for_backward(ps, ts)
+        ctx.eps = eps
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        ps, ts = ctx.saved_tensors
+        N, H, W, K = ps.shape
+        gs = g.detach().reshape(1).float().contiguous()
+        dp = torch.empty_like(ps)
+        _n.call("spcl_kl_div_backward", _n.ptr(ps), _n.ptr(ts), N * H * W, K, c_float(ctx.eps), _n.ptr(gs), _n.ptr(dp),
+                _n.stream())
+        return dp.permute(0, 3, 1, 2), None, None
+
+
+def kl_div(prob, target, eps=1e-16):
+    return _KLDivFn.apply(prob, target, eps)
+
+
+def one_hot_classes(labels: torch.Tensor, K: int) -> torch.Tensor:
+    """class2one_hot: [N,H,W] integer labels -> logical [N,K,H,W] f32 one-hot (NHWC storage)."""
+    _n.require_gpu(labels)
+    lab = labels.detach().long().contiguous()
+    N, H, W = lab.shape
+    out = torch.empty(N, H, W, K, dtype=torch.float32, device=lab.device)
+    _n.call("spcl_one_hot", _n.ptr(lab), N * H * W, K, _n.ptr(out), _n.stream())
+    return out.permute(0, 3, 1, 2)
+
+
+def argmax_classes(logits: torch.Tensor) -> torch.Tensor:
+    """``logits.max(1)[1]`` -> [N,H,W] int64 (first maximum)."""
+    _n.require_gpu(logits)
+    ls = _class_map_storage(logits.detach())
+    N, H, W, K = ls.shape
+    out = torch.empty(N, H, W, dtype=torch.int64, device=ls.device)
+    _n.call("spcl_argmax_classes", _n.ptr(ls), N * H * W, K, _n.ptr(out), _n.stream())
+    return out
+
+
+def dice_counts(pred: torch.Tensor, target: torch.Tensor, C: int):
+    """per sample and class: intersection and union counts of two class-coded maps -> two [B,C] int64 tensors."""
+    _n.require_gpu(pred, target)
+    if pred.shape != target.shape:
+        raise AssertionError(f"incompatible shape of `pred` and `target`, given {pred.shape} and {target.shape}.")
+    p, t = pred.detach().long().contiguous(), target.detach().long().contiguous()
+    B = p.shape[0]
+    inter = torch.zeros(B, C, dtype=torch.int64, device=p.device)
+    union = torch.zeros(B, C, dtype=torch.int64, device=p.device)
+    _n.call("spcl_dice_counts", _n.ptr(p), _n.ptr(t), B, p[0].numel(), C, _n.ptr(inter), _n.ptr(union), _n.stream())
+    return inter, union

@@ -46,6 +46,17 @@ _SIGNATURES = {
     "spcl_bnrelu_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "spcl_bnrelu_pool_backward": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P,
                                           c_int, _P, _P, _P, _P, _P]),
+    "spcl_conv1x1_forward": (c_int, [_P, c_int, c_size_t, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "spcl_conv1x1_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "spcl_conv1x1_backward": (c_int, [_P, _P, c_int, c_size_t, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    "spcl_softmax_forward": (c_int, [_P, c_size_t, c_int, _P, _P]),
+    "spcl_softmax_backward": (c_int, [_P, _P, c_size_t, c_int, _P, _P]),
+    "spcl_kl_workspace_bytes": (c_size_t, []),
+    "spcl_kl_div_forward": (c_int, [_P, _P, c_size_t, c_int, c_float, _P, _P, _P]),
+    "spcl_kl_div_backward": (c_int, [_P, _P, c_size_t, c_int, c_float, _P, _P, _P]),
+    "spcl_one_hot": (c_int, [_P, c_size_t, c_int, _P, _P]),
+    "spcl_argmax_classes": (c_int, [_P, c_size_t, c_int, _P, _P]),
+    "spcl_dice_counts": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),
     "spcl_flip_batch": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "spcl_profile_enable": (c_int, [c_int]),
     "spcl_profile_count": (c_int, []),

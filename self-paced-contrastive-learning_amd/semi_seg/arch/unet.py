@@ -6,8 +6,11 @@ names (``_Conv1.._Conv5, _Up5, _Up_conv5, ... _Deconv_1x1``) firing forward hook
 The encoder blocks run as fused gfx950 kernels (functional.conv_block): NHWC storage, implicit-GEMM MFMA convolutions,
 BatchNorm statistics in the conv epilogue, BN-apply + ReLU (+ 2x2 max-pool) fused into the neighbouring kernels.  The
 tensors handed out (block outputs, ``until`` results, hook taps) are ordinary logical-NCHW tensors with channels-last
-strides.  The decoder half (reference ``unet.py:193-230``, SURVEY row N1, not on the pre-train hot path) keeps the
-parameters/keys and is not built as HIP kernels yet: running it raises NotImplementedError.
+strides.  The decoder half (reference ``unet.py:193-230``, SURVEY row N1: fine-tune / evaluation path) runs from the
+same kernels: ``_UpConv`` = nearest x2 upsample (a PyTorch copy for now; fusing it into the conv loader is listed in
+DESIGN.md) + one fused conv-BN-ReLU (functional.conv_bn_relu), the skip concatenation is ``torch.cat`` on channels-last
+tensors feeding the ordinary two-conv block, ``_Deconv_1x1`` is the HIP 1x1 convolution (functional.conv1x1) and
+returns an fp32 class map.
 """
 from collections import OrderedDict
 from contextlib import contextmanager
@@ -103,7 +106,7 @@ class _ConvBlock(nn.Module):
 
 
 class _UpConv(nn.Module):
-    """Upsample(x2, nearest) -> Conv3x3 -> BN -> ReLU (unet.py:85-97); decoder, parameters only for now."""
+    """Upsample(x2, nearest) -> Conv3x3 -> BN -> ReLU (unet.py:85-97)."""
 
     def __init__(self, in_ch, out_ch, momentum=0.1):
         super().__init__()
@@ -114,9 +117,29 @@ class _UpConv(nn.Module):
             nn.ReLU(inplace=True),
         )
 
+        self._compute_dtype = None
+
     def forward(self, x):
-        raise NotImplementedError("decoder path (_UpConv, unet.py:85-97) is SURVEY row N1: not built as HIP kernels "
-                                  "yet; the pre-train hot path stops at Conv5")
+        bn = self.up[2]
+        dtype = self._compute_dtype or _config.get_compute_dtype()
+        training = self.training or not bn.track_running_stats
+        cfg = F_hip.BlockCfg(dtype, training, float(bn.momentum), float(bn.eps),
+                             (self.training and bn.track_running_stats,), True, False, False,
+                             ((bn.running_mean, bn.running_var, bn.num_batches_tracked),))
+        x = torch.nn.functional.interpolate(x, scale_factor=2, mode="nearest")  # nn.Upsample(scale_factor=2)
+        return F_hip.conv_bn_relu(x, self.up[1].weight, bn.weight, bn.bias, cfg)
+
+
+class _Conv1x1(nn.Conv2d):
+    """``_Deconv_1x1`` (unet.py:147): an nn.Conv2d(prev, num_classes, 1) whose forward is the HIP head kernel; the fp32
+    class map comes back as a logical [N,K,H,W] view over [N,H,W,K] storage."""
+    _compute_dtype = None
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("self-paced-contrastive-learning_amd runs on MI355X only: got a CPU tensor "
+                               "(the HIP path has no CPU fallback)")
+        return F_hip.conv1x1(x, self.weight, self.bias, self._compute_dtype or _config.get_compute_dtype())
 
 
 class UNet(nn.Module):
@@ -144,7 +167,7 @@ class UNet(nn.Module):
             setattr(self, f"_Up{lvl}", _UpConv(prev, co, momentum=momentum))
             setattr(self, f"_Up_conv{lvl}", _ConvBlock(prev, co, momentum=momentum))
             prev = co
-        self._Deconv_1x1 = nn.Conv2d(prev, num_classes, kernel_size=(1, 1), stride=(1, 1), padding=(0, 0))
+        self._Deconv_1x1 = _Conv1x1(prev, num_classes, kernel_size=(1, 1), stride=(1, 1), padding=(0, 0))
 
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, x, until: str = None):
@@ -154,21 +177,30 @@ class UNet(nn.Module):
                                f" given {until}  ")
         encoder_only = until in _ENCODER
         e = x
+        skips = {}
         for k, name in enumerate(_ENCODER):
             blk = getattr(self, "_" + name)
             is_last = (until == name) or k == len(_ENCODER) - 1
-            blk._plan = (is_last or not encoder_only, not is_last)
+            blk._plan = (is_last or not encoder_only, not is_last)  # the decoder needs every block output (skips)
             out = blk(e)
             if until == name:
                 return out
+            skips[name] = out
             e = blk.take_pooled()
-        raise NotImplementedError("decoder path (unet.py:193-230: Up5..Deconv_1x1) is SURVEY row N1 and is not built as "
-                                  "HIP kernels yet; call forward(x, until=<encoder layer>)")
+        # decoding + concat path (unet.py:193-230)
+        d = skips["Conv5"]
+        for lvl, skip in ((5, "Conv4"), (4, "Conv3"), (3, "Conv2"), (2, "Conv1")):
+            d = getattr(self, f"_Up{lvl}")(d)
+            d = torch.cat((skips[skip], d), dim=1)
+            d = getattr(self, f"_Up_conv{lvl}")(d)
+            if until == f"Up_conv{lvl}":
+                return d
+        return self._Deconv_1x1(d)
 
     def set_compute_dtype(self, dtype):
         """torch.float32 (parity mode) or torch.bfloat16 for all fused blocks of this network."""
         for m in self.modules():
-            if isinstance(m, _ConvBlock):
+            if isinstance(m, (_ConvBlock, _UpConv, _Conv1x1)):
                 m._compute_dtype = dtype
         return self
 

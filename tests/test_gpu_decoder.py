@@ -1,0 +1,122 @@
+"""GPU parity of the decoder / fine-tune / evaluation path: full UNet forward + one fine-tune step
+against the golden vectors written from the reference UNet (tests/golden/g5_decoder.npz, tools/gen_golden.py
+gen_decoder), and the head kernels (1x1 conv, softmax, KL_div, one-hot, arg-max, Dice counts) against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import spcl_oracle as O
+
+
+def _unet(dtype=torch.float32):
+    import spcl_amd  # noqa
+    from spcl_amd.semi_seg.arch import UNet
+    m = UNet(input_dim=1, num_classes=4, max_channel=128)
+    m.load_state_dict(O.init_unet_state(1, 4, 128, seed=11), strict=True)
+    m.cuda().train()
+    m.set_compute_dtype(dtype)
+    return m
+
+
+def _relerr(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(1e-12, np.abs(b).max())
+
+
+def test_decoder_outputs_match_reference_fp32(golden):
+    g = golden("g5_decoder.npz")
+    x = torch.tensor(g["x"]).cuda()
+    for until in ("Up_conv5", "Up_conv4", "Up_conv3", "Up_conv2"):
+        y = _unet()(x, until=until)
+        assert tuple(y.shape) == g[f"out/{until}"].shape
+        assert _relerr(y.detach().float().cpu().numpy(), g[f"out/{until}"]) < 1e-3, until
+
+
+def test_finetune_step_matches_reference_fp32(golden):
+    """logits, supervised loss (softmax + KL_div on one-hot labels), every parameter gradient and BN buffer of one
+    fine-tune step (new_epocher.py:268-277) vs the reference's modules; then eval-mode logits and arg-max."""
+    from spcl_amd import functional as F
+    g = golden("g5_decoder.npz")
+    x, labels = torch.tensor(g["x"]).cuda(), torch.tensor(g["labels"]).cuda()
+    m = _unet()
+    logits = m(x)
+    assert tuple(logits.shape) == (4, 4, 32, 32) and logits.dtype == torch.float32
+    assert _relerr(logits.detach().cpu().numpy(), g["out/logits"]) < 1e-3
+    loss = F.kl_div(F.softmax_classes(logits), F.one_hot_classes(labels, 4))
+    assert abs(float(loss.detach()) - float(g["loss"])) < 2e-4 * abs(float(g["loss"]))
+    loss.backward()
+    params, bufs = dict(m.named_parameters()), dict(m.named_buffers())
+    for k in g.files:
+        if k.startswith("grad/"):
+            assert params[k[5:]].grad is not None, k
+            assert _relerr(params[k[5:]].grad.cpu().numpy(), g[k]) < 3e-3, (k, _relerr(params[k[5:]].grad.cpu().numpy(), g[k]))
+        elif k.startswith("buf/"):
+            np.testing.assert_allclose(bufs[k[4:]].cpu().numpy(), g[k], rtol=1e-4, atol=1e-6, err_msg=k)
+    m.eval()
+    with torch.no_grad():
+        ev = m(x)
+    assert _relerr(ev.cpu().numpy(), g["eval/logits"]) < 1e-3
+    pred = F.argmax_classes(ev)
+    assert (pred.cpu().numpy() == g["eval/pred"]).mean() > 0.999
+
+
+def test_finetune_step_bf16_tracks_the_emulating_oracle(golden):
+    """bf16 storage: loss within 2 % of the fp32 reference (SURVEY 8c bf16 tolerance)."""
+    from spcl_amd import functional as F
+    g = golden("g5_decoder.npz")
+    x, labels = torch.tensor(g["x"]).cuda(), torch.tensor(g["labels"]).cuda()
+    m = _unet(torch.bfloat16)
+    loss = F.kl_div(F.softmax_classes(m(x)), F.one_hot_classes(labels, 4))
+    assert abs(float(loss.detach()) - float(g["loss"])) < 2e-2 * abs(float(g["loss"]))
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("N,C,K,H,W", [(2, 16, 4, 9, 7), (1, 24, 3, 5, 5), (2, 40, 11, 4, 6)])
+def test_conv1x1_forward_backward(dt, N, C, K, H, W):
+    from spcl_amd import functional as F
+    dtype = torch.float32 if dt == "f32" else torch.bfloat16
+    g = torch.Generator().manual_seed(C * 7 + K)
+    x = torch.randn(N, C, H, W, generator=g).to(dtype).float()
+    w = torch.randn(K, C, 1, 1, generator=g) / C ** 0.5
+    b = torch.randn(K, generator=g)
+    r = torch.randn(N, K, H, W, generator=g)
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = torch.nn.functional.conv2d(xr, wr, br)
+    (ref * r.double()).sum().backward()
+    xd, wd, bd = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    out = F.conv1x1(xd, wd, bd, dtype)
+    (out * r.cuda()).sum().backward()
+    tol = 1e-5 if dt == "f32" else 6e-3
+    assert _relerr(out.detach().cpu().numpy(), ref.detach().numpy()) < tol
+    assert _relerr(xd.grad.cpu().numpy(), xr.grad.numpy()) < tol
+    assert _relerr(wd.grad.cpu().numpy(), wr.grad.numpy()) < 1e-4
+    assert _relerr(bd.grad.cpu().numpy(), br.grad.numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("K", [2, 4, 7])
+def test_softmax_kl_onehot_argmax_dice_vs_oracle(K):
+    from spcl_amd import functional as F
+    g = torch.Generator().manual_seed(K)
+    logits = torch.randn(3, K, 13, 10, generator=g) * 3
+    labels = torch.randint(0, K, (3, 13, 10), generator=g)
+    lr = logits.clone().requires_grad_(True)
+    ref = O.finetune_loss(lr, labels)
+    ref.backward()
+    ld = logits.cuda().requires_grad_(True)
+    prob = F.softmax_classes(ld)
+    np.testing.assert_allclose(prob.detach().cpu().numpy(), logits.softmax(1).numpy(), rtol=1e-5, atol=1e-7)
+    onehot = F.one_hot_classes(labels.cuda(), K)
+    assert torch.equal(onehot.cpu().long(), O.class2one_hot(labels, K))
+    loss = F.kl_div(prob, onehot)
+    assert abs(float(loss.detach()) - float(ref.detach())) < 1e-5 * max(1.0, abs(float(ref.detach())))
+    (loss * 1.7).backward()
+    np.testing.assert_allclose(ld.grad.cpu().numpy(), 1.7 * lr.grad.numpy(), rtol=1e-4, atol=1e-8)
+    pred = F.argmax_classes(ld.detach())
+    assert torch.equal(pred.cpu(), logits.max(1)[1])
+    inter, union = F.dice_counts(pred, labels.cuda(), K)
+    ri, ru = O.dice_counts(logits.max(1)[1], labels, K)
+    assert torch.equal(inter.cpu(), ri) and torch.equal(union.cpu(), ru)
