@@ -14,6 +14,7 @@ __version__ = "0.1.0"
 
 _MIRRORED = (
     "contrastyou.losses.contrast_loss3",
+    "contrastyou.meters",
     "contrastyou.projectors.heads",
     "contrastyou.projectors.nn",
     "contrastyou.hooks.base",

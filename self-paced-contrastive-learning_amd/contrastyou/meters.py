@@ -76,3 +76,82 @@ class MeterInterface:
         for ms in self._groups.values():
             for m in ms.values():
                 m.reset()
+
+
+class UniversalDice:
+    """Mirror of ``contrastyou/meters/general_dice_meter.py:19-175``: per-group Dice from accumulated per-sample
+    intersection / union counts, ``DSC = (2 I + 1e-6) / (U + 1e-6)``, mean / std over groups, ``summary()`` with
+    ``DSC{i}`` for the reported axes and ``DSC_mean``.
+
+    ``add(pred, target, group_name)`` takes class-coded maps of equal shape (``logits.max(1)[1]`` and the label map, as
+    the epochers call it, new_epocher.py:89,282).  The counts come from one HIP launch (``spcl_dice_counts``) and stay
+    on the device; nothing is read back before ``value()`` / ``summary()``."""
+
+    def __init__(self, C=4, report_axises=None) -> None:
+        assert report_axises is None or isinstance(report_axises, (list, tuple)), \
+            f"`report_axises` should be either None or an iterator, given {type(report_axises)}"
+        if report_axises is not None:
+            assert max(report_axises) <= C, "Incompatible parameter of `C`={} and `report_axises`={}".format(
+                C, report_axises)
+        self._C = C
+        self._report_axis = list(range(self._C)) if report_axises is None else report_axises
+        self.reset()
+
+    def reset(self):
+        self._intersections, self._unions, self._group_names = [], [], []
+        self._n = 0
+
+    def add(self, pred, target, group_name=None):
+        from .. import functional as F_hip
+        assert pred.shape == target.shape, \
+            f"incompatible shape of `pred` and `target`, given {pred.shape} and {target.shape}."
+        assert not pred.requires_grad and not target.requires_grad
+        B = pred.shape[0]
+        if group_name is not None and not isinstance(group_name, str):
+            if isinstance(group_name, (list, tuple)):
+                assert len(group_name) == B and isinstance(group_name[0], str)
+            else:
+                raise TypeError(f"type of `group_name` wrong {type(group_name)}")
+        if pred.is_floating_point():
+            raise NotImplementedError("UniversalDice mirror takes class-coded (integer) maps, as the epochers pass them")
+        names = [str(self._n) + f"_{i:03d}" for i in range(B)]  # slice-based dice
+        if group_name is not None:
+            names = [group_name] * B if isinstance(group_name, str) else list(group_name)
+        inter, union = F_hip.dice_counts(pred, target, self._C)
+        self._intersections.append(inter)
+        self._unions.append(union)
+        self._group_names.extend(names)
+        self._n += 1
+
+    @property
+    def group_names(self):
+        return sorted(set(self._group_names))
+
+    @property
+    def log(self):
+        if self._n == 0:
+            return None
+        import numpy as np
+        inter = torch.cat(self._intersections, 0).cpu().double()  # the one device->host readback
+        union = torch.cat(self._unions, 0).cpu().double()
+        arr = np.asarray(self._group_names)
+        rows = []
+        for name in self.group_names:
+            idx = torch.from_numpy(arr == name)
+            rows.append((2 * inter[idx].sum(0) + 1e-6) / (union[idx].sum(0) + 1e-6))
+        return torch.stack(rows, 0).float()
+
+    def value(self, **kwargs):
+        if self._n == 0:
+            return [float("nan")] * self._C, [float("nan")] * self._C
+        d = self.log
+        return d.mean(0), d.std(0) if d.shape[0] > 1 else torch.full((self._C,), float("nan"))
+
+    def summary(self) -> dict:
+        means, _ = self.value()
+        report = {f"DSC{i}": float(means[i]) for i in self._report_axis}
+        report["DSC_mean"] = sum(report.values()) / len(report) if report else float("nan")
+        return report
+
+    def __repr__(self):
+        return f"C={self._C}, report_axis={self._report_axis}\n\t{self.summary()}"

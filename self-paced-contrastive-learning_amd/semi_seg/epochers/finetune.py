@@ -1,0 +1,145 @@
+"""Mirror of the fine-tune / evaluation epochers: ``EvalEpocher`` (semi_seg/epochers/new_epocher.py:56-97) and
+``FineTuneEpocher`` (:241-289; the labelled-only branch of ``SemiSupervisedEpocher``).  Same control flow and meters
+(``sup_loss``, ``sup_dice`` / ``loss``, ``dice``); the network, softmax, KL_div, arg-max and Dice counts are HIP
+kernels and the meters take device values (no per-step ``.item()``)."""
+from typing import Iterable, Optional
+
+import torch
+from torch import nn
+
+from ... import ddp as _ddp
+from ... import functional as F_hip
+from ...contrastyou.losses.kl import class2one_hot
+from ...contrastyou.meters import AverageValueMeter, MeterInterface, UniversalDice
+
+
+def unzip_single_transformed(data, device):
+    """``preprocess_input_with_single_transformation`` (semi_seg/epochers/helper.py:39-45): ((image, target), filename,
+    (partition, group)) -> image, target, filename, partition, group."""
+    (image, target), filename, (partition_list, group_list) = data
+    return (image.to(device, non_blocking=True), target.to(device, non_blocking=True), filename, partition_list,
+            group_list)
+
+
+def unzip_twice_transformed_labeled(data, device):
+    """``preprocess_input_with_twice_transformation`` for a labelled batch: ((image, image_tf, target, target_tf), ...)."""
+    (image, image_tf, target, target_tf), filename, (partition_list, group_list) = data
+    return ((image.to(device, non_blocking=True), image_tf.to(device, non_blocking=True)),
+            target.to(device, non_blocking=True), filename, partition_list, group_list)
+
+
+class _EpocherBase:
+    meter_focus = "tra"
+
+    def __init__(self, *, model: nn.Module, num_batches: int, cur_epoch=0, device="cuda"):
+        self._model, self._num_batches, self._cur_epoch = model, num_batches, cur_epoch
+        self._device = torch.device(device)
+        self.meters = MeterInterface(default_focus=self.meter_focus)
+        with self.meters.focus_on(self.meter_focus):
+            self.configure_meters(self.meters)
+        self.cur_batch_num = 0
+
+    @property
+    def num_classes(self):
+        return self._model.num_classes
+
+    def configure_meters(self, meters):
+        return meters
+
+    def init(self):
+        pass
+
+    @staticmethod
+    def on_master():
+        return _ddp.on_master()
+
+    def run(self):
+        with self.meters.focus_on(self.meter_focus):
+            self._run()
+        return self.meters.statistics()
+
+
+class EvalEpocher(_EpocherBase):
+    meter_focus = "eval"
+
+    def __init__(self, *, model: nn.Module, loader: Iterable, sup_criterion, cur_epoch=0, device="cuda"):
+        self._loader = loader
+        self._sup_criterion = sup_criterion
+        super().__init__(model=model, num_batches=len(loader), cur_epoch=cur_epoch, device=device)
+
+    def configure_meters(self, meters):
+        C = self.num_classes
+        meters.register_meter("loss", AverageValueMeter())
+        meters.register_meter("dice", UniversalDice(C, report_axises=list(range(1, C))))
+        return meters
+
+    def get_score(self):
+        with self.meters.focus_on(self.meter_focus):
+            return self.meters["dice"].summary()["DSC_mean"]
+
+    def _run(self):
+        self._model.eval()
+        return self._run_eval()
+
+    @torch.no_grad()
+    def _run_eval(self):
+        for self.cur_batch_num, eval_data in zip(range(self._num_batches), self._loader):
+            eval_img, eval_target, file_path, _, group = unzip_single_transformed(eval_data, self._device)
+            eval_logits = self._model(eval_img)
+            onehot_target = class2one_hot(eval_target.squeeze(1), self.num_classes)
+            eval_loss = self._sup_criterion(F_hip.softmax_classes(eval_logits), onehot_target, disable_assert=True)
+            self.meters["loss"].add(eval_loss)
+            self.meters["dice"].add(F_hip.argmax_classes(eval_logits), eval_target.squeeze(1), group_name=list(group))
+
+
+class FineTuneEpocher(_EpocherBase):
+    meter_focus = "semi"
+
+    def __init__(self, *, model: nn.Module, optimizer, labeled_loader: Iterable, sup_criterion, num_batches: int,
+                 cur_epoch=0, device="cuda", flat_params: Optional[_ddp.FlatParams] = None, **kwargs):
+        self._optimizer = optimizer
+        self._labeled_loader = labeled_loader
+        self._sup_criterion = sup_criterion
+        self._flat_params = flat_params
+        super().__init__(model=model, num_batches=num_batches, cur_epoch=cur_epoch, device=device)
+
+    def configure_meters(self, meters):
+        C = self.num_classes
+        meters.register_meter("lr", AverageValueMeter())
+        meters.register_meter("sup_loss", AverageValueMeter())
+        meters.register_meter("sup_dice", UniversalDice(C, report_axises=list(range(1, C))))
+        return meters
+
+    def _run(self):
+        self.meters["lr"].add([g["lr"] for g in self._optimizer.param_groups])
+        self._model.train()
+        return self._run_only_label()
+
+    def _forward_pass(self, labeled_image):
+        return self._model(labeled_image)
+
+    def step(self, labeled_data):
+        """one iteration of ``_run_only_label`` (new_epocher.py:260-283); returns the (device) supervised loss."""
+        (labeled_image, _), labeled_target, labeled_filename, _, label_group = \
+            unzip_twice_transformed_labeled(labeled_data, self._device)
+        label_logits = self._forward_pass(labeled_image)
+        onehot_target = class2one_hot(labeled_target.squeeze(1), self.num_classes)
+        sup_loss = self._sup_criterion(F_hip.softmax_classes(label_logits), onehot_target, disable_assert=True)
+        if self._flat_params is not None:
+            self._flat_params.zero_grad()
+            sup_loss.backward()
+            self._flat_params.reduce()
+        else:
+            self._optimizer.zero_grad(set_to_none=True)
+            sup_loss.backward()
+        self._optimizer.step()
+        if self.on_master():
+            with torch.no_grad():
+                self.meters["sup_loss"].add(sup_loss.detach())
+                self.meters["sup_dice"].add(F_hip.argmax_classes(label_logits.detach()), labeled_target.squeeze(1),
+                                            group_name=list(label_group))
+        return sup_loss
+
+    def _run_only_label(self):
+        for self.cur_batch_num, labeled_data in zip(range(self._num_batches), self._labeled_loader):
+            self.step(labeled_data)

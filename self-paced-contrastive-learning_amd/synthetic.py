@@ -34,3 +34,40 @@ class SyntheticPretrainLoader:
 
     def __next__(self):
         return self._batch if self.resident else self._draw()
+
+
+class SyntheticLabeledLoader:
+    """Labelled batches for the fine-tune / evaluation epochers: images in [0,1), integer label maps [B,1,H,W] drawn as
+    a few random blobs per class; ``twice=True`` yields the labelled-loader format ((image, image_tf, target,
+    target_tf), filenames, (partitions, groups)), else the single-transform format ((image, target), ...) of the
+    validation loaders.  ``length`` makes it a finite, re-iterable loader (``len()`` is what EvalEpocher reads)."""
+
+    def __init__(self, bs=8, size=224, channels=1, num_classes=4, device="cuda", seed=99, twice=True, length=None):
+        self.bs, self.size, self.channels, self.K, self.device = bs, size, channels, num_classes, device
+        self.twice, self.length = twice, length
+        self.gen = torch.Generator(device=device).manual_seed(seed)
+        self.meta = acdc_like_meta(bs)
+        self._batch = self._draw()
+
+    def _draw(self):
+        img = torch.rand((self.bs, self.channels, self.size, self.size), device=self.device, generator=self.gen)
+        coarse = torch.randint(0, self.K, (self.bs, 1, max(1, self.size // 16), max(1, self.size // 16)),
+                               device=self.device, generator=self.gen)
+        tgt = torch.nn.functional.interpolate(coarse.float(), size=(self.size, self.size), mode="nearest").long()
+        filenames, partitions, groups = self.meta
+        if self.twice:
+            return (img, img, tgt, tgt), filenames, (partitions, groups)
+        return (img, tgt), filenames, (partitions, groups)
+
+    def __len__(self):
+        if self.length is None:
+            raise TypeError("infinite loader")
+        return self.length
+
+    def __iter__(self):
+        if self.length is None:
+            return self
+        return iter([self._batch] * self.length)
+
+    def __next__(self):
+        return self._batch
