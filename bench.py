@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-bs", type=int, default=8, help="batch of the CPU-oracle sample (bounded work)")
-    ap.add_argument("--workload", default="pretrain", choices=["pretrain", "contrastive"])
+    ap.add_argument("--workload", default="pretrain", choices=["pretrain", "contrastive", "finetune"])
     return ap.parse_args()
 
 
@@ -233,6 +233,8 @@ def main():
 
     if args.workload == "contrastive":
         return bench_contrastive(args, device)
+    if args.workload == "finetune":
+        return bench_finetune(args, device)
 
     step, epocher, nparams = build_step(args, device, rank, world)
     run = step
@@ -299,6 +301,62 @@ def main():
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def bench_finetune(args, device):
+    """SURVEY row N1 (BASELINE.json configs[2], the fine-tune half): full UNet fwd+bwd + softmax/KL_div + RAdam on
+    synthetic labelled 224^2 slices, single GPU, hipGraph.  One slice = one image here (no second view)."""
+    import spcl_amd  # noqa
+    from spcl_amd import ddp
+    from spcl_amd.contrastyou.losses.kl import KL_div
+    from spcl_amd.optim import FusedRAdam
+    from spcl_amd.semi_seg.arch import UNet
+    from spcl_amd.semi_seg.epochers import FineTuneEpocher
+    from spcl_amd.synthetic import SyntheticLabeledLoader
+    torch.manual_seed(10)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model = UNet(input_dim=1, num_classes=4, max_channel=256).to(device)
+    model.set_compute_dtype(dtype)
+    flat = ddp.FlatParams([p for p in model.parameters() if p.requires_grad])
+    opt = FusedRAdam([flat.param], lr=1e-4, weight_decay=1e-5)
+    loader = SyntheticLabeledLoader(bs=args.bs, size=args.size, device=device, seed=77)
+    ep = FineTuneEpocher(model=model, optimizer=opt, labeled_loader=loader, sup_criterion=KL_div(), num_batches=10 ** 9,
+                         device=device, flat_params=flat)
+    model.train()
+    batch = next(loader)
+
+    def step():
+        with ep.meters.focus_on(ep.meter_focus):
+            return ep.step(batch)
+
+    run = step if args.no_graph else graph_capture(step, device)
+    for _ in range(args.warmup):
+        run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    stats = ep.meters.statistics()["semi"]
+    line = {"metric": "fine-tune slices/sec (full UNet + KL_div, 224^2)", "value": round(args.bs / dt, 1),
+            "unit": "slices/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "SURVEY N1 / BASELINE.json configs[2] fine-tune half: UNet base (max_channel=256) full "
+                                   "forward+backward, softmax + KL_div on one-hot labels, RAdam",
+                       "slices_per_gpu": args.bs, "image": f"1x{args.size}x{args.size}", "hipgraph": not args.no_graph},
+            "final_meters": {"sup_loss": round(stats["sup_loss"]["mean"], 5),
+                             "sup_dice": {k: round(v, 4) for k, v in stats["sup_dice"].items()}}}
+    if not args.no_roofline:
+        try:
+            roof, breakdown, tot = measure_roofline(step, args)
+            line["roofline"], line["kernel_breakdown"] = roof, breakdown
+            line["instrumented_step_ms"] = round(tot * 1e3, 3)
+        except Exception as e:  # noqa: BLE001
+            line["roofline"] = None
+            print(f"[bench] roofline pass failed: {type(e).__name__}: {e}", file=sys.stderr)
+    print(json.dumps(line))
 
 
 def bench_contrastive(args, device):

@@ -26,14 +26,16 @@ struct FastArgs {
 // waves per SIMD the register allocator must leave room for: what the tile's LDS footprint allows anyway, at most 4
 // (fewer waves than that would not be resident regardless, so the extra registers are free)
 constexpr int fast_lds_bytes(int KC, int TH) { return (TH + 2) * 16 * (KC == 16 ? 32 : KC * 2 + 32); }
-constexpr int fast_wpe(int KC, int TH, int NW) {
+constexpr int fast_wpe(int KC, int TH, int NW, int NT) {
   const int wgs = 160 * 1024 / fast_lds_bytes(KC, TH);
-  const int w = (wgs * NW + 3) / 4;
-  return w > 4 ? 4 : (w < 1 ? 1 : w);
+  int w = (wgs * NW + 3) / 4;
+  w = w > 4 ? 4 : (w < 1 ? 1 : w);
+  const int acc = (TH * 14 + 15) / 16 * NT * 4;  // accumulator registers of a wave
+  return acc > 80 && w > 2 ? 2 : w;              // 13 m-tiles x 2 n-tiles: give the allocator 256 registers
 }
 
 template <int KC, int TH, int NT, int MODE, int NW>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(fast_wpe(KC, TH, NW)))) void
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(fast_wpe(KC, TH, NW, NT)))) void
 conv3x3_fast_kernel(FastArgs a) {
   constexpr int TW = 14, HW_ = 16, CP = KC / 8, NHALO = (TH + 2) * HW_, PS = (KC == 16 ? 32 : KC * 2 + 32);
   constexpr int NTHR = 64 * NW, NCH = NHALO * CP, ITER = (NCH + NTHR - 1) / NTHR, QS = NTHR / CP;
@@ -320,6 +322,8 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st) {
     return true;                                                         \
   }
   SPCL_FAST_CASE(16, 14, 1, 1)  // Conv1.b forward / dgrad (16 -> 16 @ 224^2)
+  SPCL_FAST_CASE(16, 14, 2, 1)  // Up_conv2.a dgrad (16 -> 32 @ 224^2)
+  SPCL_FAST_CASE(32, 14, 1, 1)  // Up_conv2.a forward (cat(16, 16) -> 16 @ 224^2)
   SPCL_FAST_CASE(16, 7, 2, 1)   // Conv2.a forward (16 -> 32 @ 112^2)
   SPCL_FAST_CASE(32, 7, 1, 1)   // Conv2.a dgrad (32 -> 16)
   SPCL_FAST_CASE(32, 7, 2, 1)   // Conv2.b forward / dgrad

@@ -127,26 +127,33 @@ static void launch_conv1x1_bwd(int grid, hipStream_t st, const void* x, const fl
   else SPCL_LAUNCH((conv1x1_bwd_kernel<T, 16>), dim3(grid), dim3(256), 0, st, (const T*)x, dout, npix, C, CS, K, w, (T*)dx, ws);
 }
 
-// out[i] = sum over workgroup partials, fixed order (one thread per output, partial rows strided)
+// out[i] = scale * sum over workgroup partials: one wave per output, fixed-order butterfly
 __global__ __launch_bounds__(256) void head_partial_sum_kernel(const float* __restrict__ partial, int nwg, int n,
                                                                float scale, float* __restrict__ out) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (i >= n) return;
   float s = 0.f;
-  for (int w = 0; w < nwg; ++w) s += partial[(size_t)w * n + i];
-  out[i] = s * scale;
+#pragma unroll 4
+  for (int w = lane; w < nwg; w += 64) s += partial[(size_t)w * n + i];
+  s = wave_sum(s);
+  if (lane == 0) out[i] = s * scale;
 }
 
-// dW[k][c], db[k] from the [nwg][K][C+1] partial rows, fixed order
+// dW[k][c], db[k] from the [nwg][K][C+1] partial rows: one wave per output, lanes stride the rows, fixed-order butterfly
 __global__ __launch_bounds__(256) void conv1x1_finish_kernel(const float* __restrict__ partial, int nwg, int K, int C,
                                                              float* __restrict__ dw, float* __restrict__ db) {
-  const int i = blockIdx.x * 256 + threadIdx.x, n = K * (C + 1);
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), n = K * (C + 1);
+  const int lane = threadIdx.x & 63;
   if (i >= n) return;
   float s = 0.f;
-  for (int w = 0; w < nwg; ++w) s += partial[(size_t)w * n + i];
-  const int k = i / (C + 1), c = i - k * (C + 1);
-  if (c < C) dw[k * C + c] = s;
-  else db[k] = s;
+#pragma unroll 4
+  for (int w = lane; w < nwg; w += 64) s += partial[(size_t)w * n + i];
+  s = wave_sum(s);
+  if (lane == 0) {
+    const int k = i / (C + 1), c = i - k * (C + 1);
+    if (c < C) dw[k * C + c] = s;
+    else db[k] = s;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ softmax over K
@@ -305,7 +312,7 @@ extern "C" int spcl_conv1x1_backward(const void* x, const float* dout, int dtype
     set_error("conv1x1_backward: dtype %d", dtype);
     return SPCL_EINVAL;
   }
-  SPCL_LAUNCH(conv1x1_finish_kernel, dim3(cdiv(K * (C + 1), 256)), dim3(256), 0, st, (const float*)ws, grid, K, C, dw,
+  SPCL_LAUNCH(conv1x1_finish_kernel, dim3(cdiv(K * (C + 1), 4)), dim3(256), 0, st, (const float*)ws, grid, K, C, dw,
               db);
   SPCL_LAUNCH_CHECK("conv1x1_backward");
   return SPCL_OK;
