@@ -172,6 +172,15 @@ int spcl_argmax_classes(const float* logits, size_t npix, int K, int64_t* out, v
 int spcl_dice_counts(const int64_t* pred, const int64_t* target, int B, int per_sample, int C, int64_t* inter_zeroed,
                      int64_t* union_zeroed, void* stream);
 
+/* Decoder data movement (NHWC, CS a multiple of 16): nn.Upsample(scale_factor=2) of `_UpConv` (unet.py:89) and its
+ * backward (H, W = the low-resolution size in both calls), torch.cat((skip, up), dim=1) (unet.py:194-224) and its
+ * backward (split).  Channel runs must be multiples of 16 bytes. */
+int spcl_upsample2x_forward(const void* x, void* y, int dtype, int N, int H, int W, int CS, void* stream);
+int spcl_upsample2x_backward(const void* dy, void* dx, int dtype, int N, int H, int W, int CS, void* stream);
+int spcl_concat2_channels(const void* a, const void* b, void* out, int elem_size, size_t npix, int CA, int CB,
+                          void* stream);
+int spcl_split2_channels(const void* in, void* a, void* b, int elem_size, size_t npix, int CA, int CB, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * Optimizer step of the pre-train iteration (contrastyou/trainer/base.py:62 builds RAdam from the un-vendored
  * deepclustering2; the build follows torch.optim.RAdam(decoupled_weight_decay=False)) on ONE

@@ -545,3 +545,66 @@ def dice_counts(pred: torch.Tensor, target: torch.Tensor, C: int):
     union = torch.zeros(B, C, dtype=torch.int64, device=p.device)
     _n.call("spcl_dice_counts", _n.ptr(p), _n.ptr(t), B, p[0].numel(), C, _n.ptr(inter), _n.ptr(union), _n.stream())
     return inter, union
+
+
+class _Upsample2xFn(torch.autograd.Function):
+    """nn.Upsample(scale_factor=2) (nearest) of ``_UpConv`` on NHWC storage; backward = 2x2 sum."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        _n.require_gpu(x)
+        N, C, H, W = x.shape
+        xs = to_nhwc_padded(x.detach(), dtype)
+        cs = xs.shape[3]
+        y = torch.empty(N, 2 * H, 2 * W, cs, dtype=dtype, device=x.device)
+        _n.call("spcl_upsample2x_forward", _n.ptr(xs), _n.ptr(y), _n.dtype_code(dtype), N, H, W, cs, _n.stream())
+        ctx.meta = (N, C, H, W, cs, dtype, x.dtype)
+        return nhwc_to_logical(y, C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, C, H, W, cs, dtype, xdt = ctx.meta
+        dys = to_nhwc_padded(dy, dtype)
+        dx = torch.empty(N, H, W, cs, dtype=dtype, device=dy.device)
+        _n.call("spcl_upsample2x_backward", _n.ptr(dys), _n.ptr(dx), _n.dtype_code(dtype), N, H, W, cs, _n.stream())
+        out = nhwc_to_logical(dx, C)
+        return (out if out.dtype == xdt else out.to(xdt)), None
+
+
+def upsample2x(x, dtype):
+    return _Upsample2xFn.apply(x, dtype)
+
+
+class _Concat2Fn(torch.autograd.Function):
+    """torch.cat((a, b), dim=1) of two logical-NCHW tensors with NHWC storage (channel counts multiples of 16);
+    backward = one split launch into two contiguous gradients."""
+
+    @staticmethod
+    def forward(ctx, a, b, dtype):
+        _n.require_gpu(a, b)
+        N, CA, H, W = a.shape
+        CB = b.shape[1]
+        sa, sb = to_nhwc_padded(a.detach(), dtype), to_nhwc_padded(b.detach(), dtype)
+        out = torch.empty(N, H, W, CA + CB, dtype=dtype, device=a.device)
+        _n.call("spcl_concat2_channels", _n.ptr(sa), _n.ptr(sb), _n.ptr(out), out.element_size(), N * H * W, CA, CB,
+                _n.stream())
+        ctx.meta = (N, CA, CB, H, W, dtype, a.dtype, b.dtype)
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        N, CA, CB, H, W, dtype, adt, bdt = ctx.meta
+        gs = to_nhwc_padded(g, dtype)
+        ga = torch.empty(N, H, W, CA, dtype=dtype, device=g.device)
+        gb = torch.empty(N, H, W, CB, dtype=dtype, device=g.device)
+        _n.call("spcl_split2_channels", _n.ptr(gs), _n.ptr(ga), _n.ptr(gb), gs.element_size(), N * H * W, CA, CB,
+                _n.stream())
+        ga, gb = ga.permute(0, 3, 1, 2), gb.permute(0, 3, 1, 2)
+        return (ga if ga.dtype == adt else ga.to(adt)), (gb if gb.dtype == bdt else gb.to(bdt)), None
+
+
+def concat_channels(a, b, dtype):
+    """cat((a, b), 1); channel counts that are not multiples of 16 (tiny test networks) go through torch.cat."""
+    if a.shape[1] % 16 or b.shape[1] % 16:
+        return torch.cat((a, b), dim=1)
+    return _Concat2Fn.apply(a, b, dtype)

@@ -7,9 +7,9 @@ The encoder blocks run as fused gfx950 kernels (functional.conv_block): NHWC sto
 BatchNorm statistics in the conv epilogue, BN-apply + ReLU (+ 2x2 max-pool) fused into the neighbouring kernels.  The
 tensors handed out (block outputs, ``until`` results, hook taps) are ordinary logical-NCHW tensors with channels-last
 strides.  The decoder half (reference ``unet.py:193-230``, SURVEY row N1: fine-tune / evaluation path) runs from the
-same kernels: ``_UpConv`` = nearest x2 upsample (a PyTorch copy for now; fusing it into the conv loader is listed in
-DESIGN.md) + one fused conv-BN-ReLU (functional.conv_bn_relu), the skip concatenation is ``torch.cat`` on channels-last
-tensors feeding the ordinary two-conv block, ``_Deconv_1x1`` is the HIP 1x1 convolution (functional.conv1x1) and
+same kernels: ``_UpConv`` = nearest x2 upsample (a HIP streaming kernel; fusing it into the conv loader is listed in
+DESIGN.md) + one fused conv-BN-ReLU (functional.conv_bn_relu), the skip concatenation is a HIP channel-interleave
+kernel feeding the ordinary two-conv block, ``_Deconv_1x1`` is the HIP 1x1 convolution (functional.conv1x1) and
 returns an fp32 class map.
 """
 from collections import OrderedDict
@@ -126,7 +126,7 @@ class _UpConv(nn.Module):
         cfg = F_hip.BlockCfg(dtype, training, float(bn.momentum), float(bn.eps),
                              (self.training and bn.track_running_stats,), True, False, False,
                              ((bn.running_mean, bn.running_var, bn.num_batches_tracked),))
-        x = torch.nn.functional.interpolate(x, scale_factor=2, mode="nearest")  # nn.Upsample(scale_factor=2)
+        x = F_hip.upsample2x(x, dtype)  # nn.Upsample(scale_factor=2), nearest
         return F_hip.conv_bn_relu(x, self.up[1].weight, bn.weight, bn.bias, cfg)
 
 
@@ -191,8 +191,9 @@ class UNet(nn.Module):
         d = skips["Conv5"]
         for lvl, skip in ((5, "Conv4"), (4, "Conv3"), (3, "Conv2"), (2, "Conv1")):
             d = getattr(self, f"_Up{lvl}")(d)
-            d = torch.cat((skips[skip], d), dim=1)
-            d = getattr(self, f"_Up_conv{lvl}")(d)
+            blk = getattr(self, f"_Up_conv{lvl}")
+            d = F_hip.concat_channels(skips[skip], d, blk._compute_dtype or _config.get_compute_dtype())
+            d = blk(d)
             if until == f"Up_conv{lvl}":
                 return d
         return self._Deconv_1x1(d)

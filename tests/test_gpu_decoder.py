@@ -172,3 +172,61 @@ def test_finetune_trainer_runs_and_learns(tmp_path):
     rm = model._Conv1.conv[1].running_mean.clone()
     tr.run_eval_epoch(model=model, loader=val)
     assert torch.equal(rm, model._Conv1.conv[1].running_mean)
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("N,C,H,W", [(2, 16, 5, 7), (1, 48, 3, 4), (2, 8, 4, 4)])
+def test_upsample2x_and_concat_match_torch(dt, N, C, H, W):
+    from spcl_amd import functional as F
+    dtype = torch.float32 if dt == "f32" else torch.bfloat16
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(N, C, H, W, generator=g).to(dtype)
+    r = torch.randn(N, C, 2 * H, 2 * W, generator=g).to(dtype)
+    xr = x.double().requires_grad_(True)
+    ref = torch.nn.functional.interpolate(xr, scale_factor=2, mode="nearest")
+    (ref * r.double()).sum().backward()
+    xd = x.cuda().requires_grad_(True)
+    y = F.upsample2x(xd, dtype)
+    assert torch.equal(y.detach().cpu().double(), ref.detach())
+    (y.float() * r.cuda().float()).sum().backward()
+    assert _relerr(xd.grad.float().cpu().numpy(), xr.grad.numpy()) < (1e-6 if dt == "f32" else 6e-3)
+    if C % 16 == 0:
+        b = torch.randn(N, 2 * C, H, W, generator=g).to(dtype)
+        r2 = torch.randn(N, 3 * C, H, W, generator=g).to(dtype)
+        a_d, b_d = x.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+        out = F.concat_channels(a_d, b_d, dtype)
+        assert torch.equal(out.detach().cpu(), torch.cat((x, b), 1))
+        (out.float() * r2.cuda().float()).sum().backward()
+        assert torch.equal(a_d.grad.cpu(), r2[:, :C]) and torch.equal(b_d.grad.cpu(), r2[:, C:])
+
+
+def test_full_unet_base_width_vs_oracle_fp32():
+    """max_channel=256 (all channel counts multiples of 16: HIP concatenation / upsample path) on a small image: logits
+    and a sample of gradients against the CPU oracle's full UNet."""
+    import spcl_amd  # noqa
+    from spcl_amd import functional as F
+    from spcl_amd.semi_seg.arch import UNet
+    sd = O.init_unet_state(1, 4, 256, seed=5)
+    m = UNet(input_dim=1, num_classes=4, max_channel=256)
+    m.load_state_dict(sd, strict=True)
+    m.cuda().train()
+    m.set_compute_dtype(torch.float32)
+    g = torch.Generator().manual_seed(6)
+    x = torch.rand(2, 1, 64, 64, generator=g)  # 4x4 at Conv5: batch statistics over 32 values per channel
+    labels = torch.randint(0, 4, (2, 64, 64), generator=g)
+    sdo = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+           for k, v in sd.items()}
+    ref_logits = O.unet_forward(x, sdo, None, train=True)
+    ref_loss = O.finetune_loss(ref_logits, labels)
+    ref_loss.backward()
+    logits = m(x.cuda())
+    assert _relerr(logits.detach().cpu().numpy(), ref_logits.detach().numpy()) < 2e-3
+    loss = F.kl_div(F.softmax_classes(logits), F.one_hot_classes(labels.cuda(), 4))
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) < 1e-3 * abs(float(ref_loss.detach()))
+    loss.backward()
+    params = dict(m.named_parameters())
+    for k in ("_Deconv_1x1.weight", "_Up_conv2.conv.0.weight", "_Up2.up.1.weight", "_Up_conv5.conv.3.weight",
+              "_Up5.up.2.weight", "_Conv5.conv.0.weight", "_Conv1.conv.0.weight", "_Conv3.conv.4.bias"):
+        # tiny batch statistics in the deepest layers amplify fp32 summation-order differences: 3e-2 of max
+        assert _relerr(params[k].grad.cpu().numpy(), sdo[k].grad.numpy()) < 3e-2, (k, _relerr(
+            params[k].grad.cpu().numpy(), sdo[k].grad.numpy()))

@@ -10,13 +10,40 @@ from torch.profiler import ProfilerActivity, profile
 import bench
 
 
+def build_finetune_step(dev, bs=32, size=224):
+    import spcl_amd  # noqa
+    from spcl_amd import ddp
+    from spcl_amd.contrastyou.losses.kl import KL_div
+    from spcl_amd.optim import FusedRAdam
+    from spcl_amd.semi_seg.arch import UNet
+    from spcl_amd.semi_seg.epochers import FineTuneEpocher
+    from spcl_amd.synthetic import SyntheticLabeledLoader
+    model = UNet(input_dim=1, num_classes=4, max_channel=256).to(dev)
+    model.set_compute_dtype(torch.bfloat16)
+    flat = ddp.FlatParams([p for p in model.parameters() if p.requires_grad])
+    opt = FusedRAdam([flat.param], lr=1e-4, weight_decay=1e-5)
+    loader = SyntheticLabeledLoader(bs=bs, size=size, device=dev, seed=77)
+    ep = FineTuneEpocher(model=model, optimizer=opt, labeled_loader=loader, sup_criterion=KL_div(), num_batches=10 ** 9,
+                         device=dev, flat_params=flat)
+    model.train()
+    batch = next(loader)
+
+    def step():
+        with ep.meters.focus_on(ep.meter_focus):
+            return ep.step(batch)
+    return step
+
+
 def main():
     args = bench.parse_args([]) if hasattr(bench, "parse_args") else None
     if args is None:
         import argparse
         args = argparse.Namespace(bs=32, size=224, dtype="bf16")
     dev = torch.device("cuda:0")
-    step, epocher, _ = bench.build_step(args, dev, 0, 1)
+    if len(sys.argv) > 1 and sys.argv[1] == "finetune":
+        step = build_finetune_step(dev)
+    else:
+        step, epocher, _ = bench.build_step(args, dev, 0, 1)
     for _ in range(3):
         step()
     torch.cuda.synchronize()
