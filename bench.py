@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
+    ap.add_argument("--split-graph", action="store_true", help="force the compute / collective / update split capture")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-bs", type=int, default=8, help="batch of the CPU-oracle sample (bounded work)")
@@ -87,6 +88,7 @@ def build_step(args, device, rank, world):
         with epocher.meters.focus_on(epocher.meter_focus):
             return epocher.step(batch, seed=7)
 
+    step.epocher, step.batch = epocher, batch
     return step, epocher, nparams
 
 
@@ -103,6 +105,44 @@ def graph_capture(step, device):
     with torch.cuda.graph(g):
         step()
     return g.replay
+
+
+def graph_capture_split(step, device):
+    """Fallback when the whole-step capture is refused (e.g. the RCCL collective cannot be captured on a given
+    stack): graph A = forward + loss + backward + gradient gather, the flat all-reduce launched eagerly, graph B =
+    optimizer step + meters.  Two replays and one collective per step instead of ~150 launches."""
+    epocher, batch = step.epocher, step.batch
+    state = {}
+
+    def compute():
+        with epocher.meters.focus_on(epocher.meter_focus):
+            state["loss"] = epocher.step_compute(batch, seed=7)
+
+    def update():
+        with epocher.meters.focus_on(epocher.meter_focus):
+            epocher.step_update(state["loss"])
+
+    s = torch.cuda.Stream(device=device)
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            compute()
+            epocher.step_exchange()
+            update()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    ga = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(ga):
+        compute()
+    gb = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gb, pool=ga.pool()):
+        update()
+
+    def run():
+        ga.replay()
+        epocher.step_exchange()
+        gb.replay()
+    return run
 
 
 # ------------------------------------------------------------------------------------------------ roofline (live)
@@ -241,12 +281,22 @@ def main():
     used_graph = False
     if not args.no_graph:
         try:
+            if args.split_graph:
+                raise RuntimeError("--split-graph")
             run = graph_capture(step, device)
             used_graph = True
-        except Exception as e:  # noqa: BLE001  -- report and fall back to eager launches (same kernels)
+        except Exception as e:  # noqa: BLE001  -- report; keep the collective outside the graphs, else eager
             if rank == 0:
-                print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-            run = step
+                print(f"[bench] whole-step hipGraph capture failed ({type(e).__name__}: {e})", file=sys.stderr)
+            try:
+                torch.cuda.synchronize()
+                run = graph_capture_split(step, device)
+                used_graph = "split"
+            except Exception as e2:  # noqa: BLE001
+                if rank == 0:
+                    print(f"[bench] split capture failed too ({type(e2).__name__}: {e2}); running eagerly",
+                          file=sys.stderr)
+                run = step
     for _ in range(args.warmup):
         run()
     torch.cuda.synchronize()

@@ -87,14 +87,23 @@ class FlatParams(GradBucket):
             p.grad = None
         self.param.grad = None
 
-    def reduce(self):
-        """module grads -> flat bucket -> (all-reduce mean across ranks) -> ``self.param.grad``."""
+    def gather_grads(self):
+        """module grads -> flat bucket, which becomes ``self.param.grad`` (no communication)."""
         self.gather()
+        self.param.grad = self.flat
+        return self.flat
+
+    def allreduce_(self):
+        """mean of the flat bucket across ranks, in place (the step's ONE collective; no-op for a single process)."""
         if is_distributed():
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
             self.flat.div_(dist.get_world_size(self.group))
-        self.param.grad = self.flat
         return self.flat
+
+    def reduce(self):
+        """module grads -> flat bucket -> (all-reduce mean across ranks) -> ``self.param.grad``."""
+        self.gather_grads()
+        return self.allreduce_()
 
 
 @torch.no_grad()

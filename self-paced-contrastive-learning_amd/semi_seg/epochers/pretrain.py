@@ -117,6 +117,15 @@ class PretrainEncoderEpocher:
 
     def step(self, data, seed=None):
         """One iteration of new_pretrain.py:53-89; returns the (device) regularisation loss."""
+        reg_loss = self.step_compute(data, seed)
+        self.step_exchange()
+        self.step_update(reg_loss)
+        return reg_loss
+
+    # the three phases of a step, separately callable so that a driver can capture the compute and the update in
+    # hipGraphs and keep the collective outside when a whole-step capture is not possible
+    def step_compute(self, data, seed=None):
+        """forward + loss + backward + gradients gathered into the flat bucket (no communication, no update)."""
         seed = random.randint(0, int(1e7)) if seed is None else seed
         (unlabeled_image, unlabeled_image_tf), _, unlabeled_filename, unl_partition, unl_group = \
             unzip_twice_transformed(data, self._device)
@@ -146,17 +155,20 @@ class PretrainEncoderEpocher:
         if self._flat_params is not None:
             self._flat_params.zero_grad()
             total_loss.backward()
-            self._flat_params.reduce()
+            self._flat_params.gather_grads()
         else:
             self._optimizer.zero_grad(set_to_none=True)
             total_loss.backward()
-            if self._grad_bucket is not None:
-                self._grad_bucket.allreduce()
+        return reg_loss
+
+    def step_exchange(self):
+        """the step's one collective: mean of the flat gradient bucket over the ranks."""
+        if self._flat_params is not None:
+            self._flat_params.allreduce_()
+        elif self._grad_bucket is not None:
+            self._grad_bucket.allreduce()
+
+    def step_update(self, reg_loss):
         self._optimizer.step()
         if self.on_master():
             self.meters["reg_loss"].add(reg_loss.detach())
-        return reg_loss
-
-    def _run_pretrain(self):
-        for self.cur_batch_num, data in zip(range(self._num_batches), self._chain_dataloader):
-            self.step(data)
