@@ -26,12 +26,18 @@ struct FastArgs {
 // waves per SIMD the register allocator must leave room for: what the tile's LDS footprint allows anyway, at most 4
 // (fewer waves than that would not be resident regardless, so the extra registers are free)
 constexpr int fast_lds_bytes(int KC, int TH) { return (TH + 2) * 16 * (KC == 16 ? 32 : KC * 2 + 32); }
+// all weight fragments of a channel slab are requested BEFORE the slab's staging (their L2 latency, ~1 us each with
+// only a handful in flight otherwise, hides under the activation loads): 9 x NT (KC = 32) or 18 x NT (KC = 64)
+// fragments of 4 registers; a one-wave KC = 64 workgroup also holds 18 staging chunks and would spill
+constexpr bool fast_preload_slab(int KC, int NW, int NT) { return KC == 32 || (KC == 64 && NW >= 2 && NT >= 1); }
 constexpr int fast_wpe(int KC, int TH, int NW, int NT) {
   const int wgs = 160 * 1024 / fast_lds_bytes(KC, TH);
   int w = (wgs * NW + 3) / 4;
   w = w > 4 ? 4 : (w < 1 ? 1 : w);
   const int acc = (TH * 14 + 15) / 16 * NT * 4;  // accumulator registers of a wave
-  return acc > 80 && w > 2 ? 2 : w;              // 13 m-tiles x 2 n-tiles: give the allocator 256 registers
+  if (acc > 80 && w > 2) return 2;               // 13 m-tiles x 2 n-tiles: give the allocator 256 registers
+  if (fast_preload_slab(KC, NW, NT) && w > 2) return 2;  // a slab's weight fragments live in registers (PRELOAD_SLAB)
+  return w;
 }
 
 template <int KC, int TH, int NT, int MODE, int NW>
@@ -41,6 +47,7 @@ conv3x3_fast_kernel(FastArgs a) {
   constexpr int NTHR = 64 * NW, NCH = NHALO * CP, ITER = (NCH + NTHR - 1) / NTHR, QS = NTHR / CP;
   constexpr int NPIX = TH * TW, MT = (NPIX + 15) / 16, NSTEPS = (9 * CP + 3) / 4;
   constexpr bool PRELOAD_W = KC == 16;  // 5 k-steps: every weight fragment of the wave lives in registers
+  constexpr bool PRELOAD_SLAB = fast_preload_slab(KC, NW, NT);
   static_assert(QS >= HW_ ? QS % HW_ == 0 : HW_ % QS == 0, "staging walk needs whole/even halo rows per iteration");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
@@ -101,6 +108,14 @@ conv3x3_fast_kernel(FastArgs a) {
         *(f32x4*)&ssh[e] = *(const f32x4*)(a.in_shift + slab * KC + ch * 8 + e);
       }
     }
+    const u32x4* wslab = a.wp + ((size_t)slab * NSTEPS * ntn + nt0) * 64 + lane;
+    u32x4 wsl[PRELOAD_SLAB ? NSTEPS : 1][NT];
+    if (PRELOAD_SLAB) {
+#pragma unroll
+      for (int s = 0; s < NSTEPS; ++s)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wsl[s][j] = wslab[(size_t)(s * ntn + j) * 64];
+    }
     const unsigned char* xs = xb + slab * (KC * 2);
     u32x4 v[ITER];
 #pragma unroll
@@ -135,12 +150,12 @@ conv3x3_fast_kernel(FastArgs a) {
     __syncthreads();
 
     // ------------ k-loop: NSTEPS x (one 16-byte x fragment per m-tile, NT MFMAs on it)
-    const u32x4* wslab = a.wp + ((size_t)slab * NSTEPS * ntn + nt0) * 64 + lane;
 #pragma unroll
     for (int s = 0; s < NSTEPS; ++s) {
       u32x4 wf[NT];
 #pragma unroll
-      for (int j = 0; j < NT; ++j) wf[j] = PRELOAD_W ? wall[s][j] : wslab[(size_t)(s * ntn + j) * 64];
+      for (int j = 0; j < NT; ++j)
+        wf[j] = PRELOAD_W ? wall[s][j] : (PRELOAD_SLAB ? wsl[s][j] : wslab[(size_t)(s * ntn + j) * 64]);
       int off;
       if (CP >= 4) {
         const int fc0 = 4 * s, tap = fc0 / CP, c0 = fc0 % CP, ky = tap / 3, kx = tap % 3;
