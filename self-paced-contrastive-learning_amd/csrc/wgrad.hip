@@ -8,6 +8,7 @@
 // loads issued before the MFMAs of the current one; workgroup partials go to a workspace and a second kernel sums
 // them in fixed order (deterministic, no float atomics) into the OIHW f32 gradient.
 #include <stdlib.h>
+#include <vector>
 #include "common.hpp"
 
 namespace spcl {
@@ -28,6 +29,7 @@ struct WgradArgs {
   int N, H, W, CinS, CinK, CoutS, in_mode;
   int tilesX, tilesY, ntiles, nblk_ci, nblk_co;
   int dbuf;  // 1: LDS tile image double buffered (one barrier per tile); 0: single buffer, twice the residency
+  unsigned long long* stamps;  // debug (SPCL_WGRAD_STAMPS=1): per-workgroup cycle counts of the loop phases, else null
 };
 
 // relu(scale*v+shift) on one 16-byte chunk (same arithmetic as conv.hip's staging so masks agree bit-for-bit)
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(256, (MI * NJ >= 16 ? 1 : 2)) void conv3x3_wgrad_ke
                                     Frag<T>::lane_chan_bytes(lane));
 
   u32x4 rx[NX], rd[ND];
-  unsigned xmask = 0;  // staged x chunks that are inside the image (zero padding must stay zero after BN+ReLU)
+  unsigned xmask = 0, dmask = 0;  // staged chunks that are inside the image (the others are written as zeros)
   const int tpi = a.tilesX * a.tilesY;
 
   // ---- global -> registers (issued one tile ahead of the MFMAs).  Addresses = one wave-uniform 64-bit tile base + a
@@ -168,15 +170,19 @@ __global__ __launch_bounds__(256, (MI * NJ >= 16 ? 1 : 2)) void conv3x3_wgrad_ke
     const int gx = x0 - 1 + xhx;
     const bool colok = interior || (gx >= 0 && gx < a.W);
     const long xorigin = (((long)n * a.H + (y0 - 1)) * a.W + (x0 - 1)) * a.CinS;  // halo origin, may be outside
+    // Loads are UNCONDITIONAL (out-of-image lanes read a valid dummy address and are zeroed when the tile is written
+    // to LDS): a load inside a divergent branch made the compiler wait for it at the join -- ten serialised L2 round
+    // trips (~2 200 cycles) per tile, measured with in-kernel stamps.
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       const int hy = xhy0 + i * XRPI;
       const int gy = y0 - 1 + hy;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (xact && hy < NHROWS && colok && (interior || (gy >= 0 && gy < a.H))) {
-        const long rowoff = xorigin + (long)(i * XRPI) * a.W * a.CinS;  // wave-uniform
-        xmask |= 1u << i;
-        if (a.in_mode == 2) {
+      const bool ok = xact && hy < NHROWS && colok && (interior || (gy >= 0 && gy < a.H));
+      xmask |= (ok ? 1u : 0u) << i;
+      const long rowoff = xorigin + (long)(i * XRPI) * a.W * a.CinS;  // wave-uniform
+      if (a.in_mode == 2) {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (ok) {
           const float* src = (const float*)a.x + rowoff + xvoff;
           float e[EPC];
 #pragma unroll
@@ -191,22 +197,25 @@ __global__ __launch_bounds__(256, (MI * NJ >= 16 ? 1 : 2)) void conv3x3_wgrad_ke
             for (int k = 0; k < 4; ++k)
               v[k] = (uint32_t)f32_to_bf16(e[(2 * k) % EPC]) | ((uint32_t)f32_to_bf16(e[(2 * k + 1) % EPC]) << 16);
           }
-        } else {
-          v = *(const u32x4*)((const T*)a.x + rowoff + xvoff);
         }
+        rx[i] = v;
+      } else {
+        const T* src = ok ? (const T*)a.x + rowoff + xvoff : (const T*)a.x + ci0 + xch * EPC;
+        rx[i] = *(const u32x4*)src;
       }
-      rx[i] = v;
     }
     const int dgx = x0 + dcol;
     const long dorigin = (((long)n * a.H + y0) * a.W + x0) * a.CoutS;
+    dmask = 0;
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
       const int r = dry0 + i * DRPI;
       const int gy = y0 + r;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (r < TH && gy < a.H && dgx < a.W)
-        v = *(const u32x4*)((const T*)a.dy + dorigin + (long)(i * DRPI) * a.W * a.CoutS + dvoff);
-      rd[i] = v;
+      const bool ok = r < TH && gy < a.H && dgx < a.W;
+      dmask |= (ok ? 1u : 0u) << i;
+      const T* src = ok ? (const T*)a.dy + dorigin + (long)(i * DRPI) * a.W * a.CoutS + dvoff
+                        : (const T*)a.dy + co0 + dch * EPC;
+      rd[i] = *(const u32x4*)src;
     }
   };
   // ---- registers -> LDS buffer (fused BN-apply + ReLU of the producer layer on the in-image chunks)
@@ -218,26 +227,19 @@ __global__ __launch_bounds__(256, (MI * NJ >= 16 ? 1 : 2)) void conv3x3_wgrad_ke
       const int hy = xhy0 + i * XRPI;
       if (xact && hy < NHROWS) {
         u32x4 v = rx[i];
-        if (a.in_mode == 1 && (xmask & (1u << i))) v = wg_bnrelu_chunk<T>(v, sc, sh);
+        if (!(xmask & (1u << i))) v = (u32x4){0u, 0u, 0u, 0u};  // zero padding stays zero (also after BN + ReLU)
+        else if (a.in_mode == 1) v = wg_bnrelu_chunk<T>(v, sc, sh);
         *(u32x4*)(bx + hy * XRP + xhx * XS + xch * 16) = v;
       }
     }
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
       const int r = dry0 + i * DRPI;
-      if (r < TH) *(u32x4*)(bd + r * DRP + dcol * DS + dch * 16) = rd[i];
+      if (r < TH) *(u32x4*)(bd + r * DRP + dcol * DS + dch * 16) = (dmask & (1u << i)) ? rd[i] : (u32x4){0u, 0u, 0u, 0u};
     }
   };
 
-  int tile = blockIdx.x;
-  int buf = 0;
-  if (tile < a.ntiles) load_tile(tile);
-  while (tile < a.ntiles) {
-    store_tile(buf);
-    __syncthreads();  // also orders this buffer's previous readers (two iterations back) before the next overwrite
-    const int next = tile + gridDim.x;
-    if (next < a.ntiles) load_tile(next);
-
+  auto compute_tile = [&](int buf) {
     const unsigned xa0 = lds_base + buf * BUF_BYTES + xlane, da0 = lds_base + buf * BUF_BYTES + X_BYTES + dlane;
     // operand fragments are fetched one (k-step, unit) ahead of the MFMAs that consume them, so an LDS read's
     // latency hides under the previous unit's matrix work instead of stalling every pair of MFMAs
@@ -264,10 +266,35 @@ __global__ __launch_bounds__(256, (MI * NJ >= 16 ? 1 : 2)) void conv3x3_wgrad_ke
 #pragma unroll
       for (int j = 0; j < NJ; ++j) bf[j] = bf_next[j];
     }
+  };
+
+  // debug stamps (SPCL_WGRAD_STAMPS=1): s_memtime ticks of wave 0 per loop phase, summed over the workgroup's tiles
+  unsigned long long t_store = 0, t_bar = 0, t_issue = 0, t_comp = 0, t_first = 0, t_all = 0, ntl = 0;
+  const bool stamp = a.stamps != nullptr;
+  const unsigned long long c_begin = stamp ? __builtin_amdgcn_s_memtime() : 0;
+  int tile = blockIdx.x;
+  int buf = 0;
+  if (tile < a.ntiles) load_tile(tile);
+  if (stamp) t_first = __builtin_amdgcn_s_memtime() - c_begin;
+  while (tile < a.ntiles) {
+    const unsigned long long c0 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+    store_tile(buf);
+    const unsigned long long c1 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+    __syncthreads();  // also orders this buffer's previous readers (two iterations back) before the next overwrite
+    const unsigned long long c2 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+    const int next = tile + gridDim.x;
+    if (next < a.ntiles) load_tile(next);
+    const unsigned long long c3 = stamp ? __builtin_amdgcn_s_memtime() : 0;
+    compute_tile(buf);
+    if (stamp) {
+      t_store += c1 - c0; t_bar += c2 - c1; t_issue += c3 - c2; t_comp += __builtin_amdgcn_s_memtime() - c3;
+      ++ntl;
+    }
     if (a.dbuf) buf ^= 1;
     else __syncthreads();  // single buffer: all reads of this tile are done before the next one is written
     tile = next;
   }
+  if (stamp) t_all = __builtin_amdgcn_s_memtime() - c_begin;
 
   // ---- every wave writes its own units of the workgroup partial.  D layout: lane holds n = co (lane&15),
   // m = ci 4g+r.  slab layout [9][CIB][COB] f32
@@ -284,6 +311,11 @@ __global__ __launch_bounds__(256, (MI * NJ >= 16 ? 1 : 2)) void conv3x3_wgrad_ke
         for (int r = 0; r < 4; ++r)
           out[(tap * CIB + m * 16 + 4 * g + r) * COB + j * 16 + r16] = acc[uu][j][r];
     }
+  }
+  if (stamp && threadIdx.x == 0) {
+    unsigned long long* o = a.stamps + ((size_t)blockIdx.x * gridDim.y + blk) * 8;
+    o[0] = t_first; o[1] = t_store; o[2] = t_bar; o[3] = t_issue; o[4] = t_comp; o[5] = t_all;
+    o[6] = __builtin_amdgcn_s_memtime() - c_begin; o[7] = ntl;
   }
 }
 
@@ -411,6 +443,14 @@ extern "C" int spcl_conv3x3_wgrad(const void* x, const void* dy, int dtype, int 
   a.tilesX = p.tilesX; a.tilesY = p.tilesY; a.ntiles = p.ntiles; a.nblk_ci = p.nblk_ci; a.nblk_co = p.nblk_co;
   static const int env_dbuf = getenv("SPCL_WGRAD_DBUF") ? atoi(getenv("SPCL_WGRAD_DBUF")) : 1;
   a.dbuf = env_dbuf;
+  static const int env_stamps = getenv("SPCL_WGRAD_STAMPS") ? atoi(getenv("SPCL_WGRAD_STAMPS")) : 0;
+  static unsigned long long* stamp_buf = nullptr;
+  a.stamps = nullptr;
+  const size_t nwg = (size_t)p.nsplit * p.nblk_ci * p.nblk_co;
+  if (env_stamps) {  // debug only: per-phase cycle counters of wave 0 of every workgroup (synchronises!)
+    if (!stamp_buf) (void)hipMalloc(&stamp_buf, 8192 * 8 * sizeof(unsigned long long));
+    if (nwg <= 8192) a.stamps = stamp_buf;
+  }
   {
     const double px = (double)N * H * W, es = dtype == SPCL_F32 ? 4.0 : 2.0;
     prof_cost(px * ((in_mode == 2 ? CinS * 4.0 : CinK * es) + CoutS * es) + 9.0 * Cin * Cout * 4.0,
@@ -425,6 +465,18 @@ extern "C" int spcl_conv3x3_wgrad(const void* x, const void* dy, int dtype, int 
   const int slab = 9 * 16 * p.MI * 16 * p.NJ;
   SPCL_LAUNCH(wgrad_reduce_kernel, dim3(cdiv(slab, 64), p.nblk_ci * p.nblk_co), dim3(p.nsplit >= 64 ? 1024 : 256), 0, st,
                      (const float*)partial, p.nsplit, p.nblk_ci, p.nblk_co, 16 * p.MI, 16 * p.NJ, Cin, Cout, dw_oihw);
+  if (a.stamps) {
+    std::vector<unsigned long long> h(nwg * 8);
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(h.data(), a.stamps, h.size() * 8, hipMemcpyDeviceToHost);
+    double s[8] = {0};
+    for (size_t i = 0; i < nwg; ++i)
+      for (int k = 0; k < 8; ++k) s[k] += (double)h[i * 8 + k];
+    for (int k = 0; k < 8; ++k) s[k] /= (double)nwg;
+    fprintf(stderr, "[wgrad stamps] %dx%d Cin%d Cout%d MI%d NJ%d TH%d wgs=%zu tiles/wg=%.1f | memtime ticks per wg: first-load "
+            "issue %.0f, store %.0f, barrier %.0f, next-load issue %.0f, compute %.0f, loop total %.0f, with epilogue %.0f\n",
+            H, W, Cin, Cout, p.MI, p.NJ, p.TH, nwg, s[7], s[0], s[1], s[2], s[3], s[4], s[5], s[6]);
+  }
   SPCL_LAUNCH_CHECK("conv3x3_wgrad");
   return SPCL_OK;
 }
