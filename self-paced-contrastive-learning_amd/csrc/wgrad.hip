@@ -95,8 +95,11 @@ template <> struct Frag<float> {
   static constexpr int row_pad(int, int) { return 0; }
 };
 
-template <typename T, int MI, int NJ, int TH>
-__global__ __launch_bounds__(256, (MI * NJ >= 16 ? 1 : 2)) void conv3x3_wgrad_kernel(WgradArgs a) {
+// NWV waves per workgroup: 4 for the 16/32-channel blocks; 8 for the 64x64 block (MI = NJ = 4), whose 36 (tap, ci-tile)
+// units and 23 staging chunks per thread would not fit two waves per SIMD in a 4-wave workgroup
+template <typename T, int MI, int NJ, int TH, int NWV>
+__global__ __launch_bounds__(64 * NWV, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
+  constexpr int NTHR = 64 * NWV;
   constexpr int EPC = Chunk<T>::EPC, ESZ = (int)sizeof(T);
   constexpr int CIB = 16 * MI, COB = 16 * NJ;
   constexpr int XS = CIB * ESZ, DS = COB * ESZ;          // LDS bytes per pixel
@@ -107,9 +110,9 @@ __global__ __launch_bounds__(256, (MI * NJ >= 16 ? 1 : 2)) void conv3x3_wgrad_ke
   constexpr int X_BYTES = NHROWS * XRP, D_BYTES = TH * DRP, BUF_BYTES = X_BYTES + D_BYTES;
   constexpr int KSTEPS = TH * WG_TW / Frag<T>::KPIX;
   // staging maps: a thread owns one 16-byte channel chunk and one column; it walks the rows in compile-time steps
-  constexpr int XPL = 256 / XCP, XRPI = XPL / WG_HW, NX = (NHROWS + XRPI - 1) / XRPI;   // rows per iteration
-  constexpr int DPL = 256 / DCP, DRPI = DPL / WG_TW, ND = (TH + DRPI - 1) / DRPI;
-  static_assert(XRPI >= 1 && DRPI >= 1, "channel block too wide for the 256-thread staging map");
+  constexpr int XPL = NTHR / XCP, XRPI = XPL / WG_HW, NX = (NHROWS + XRPI - 1) / XRPI;   // rows per iteration
+  constexpr int DPL = NTHR / DCP, DRPI = DPL / WG_TW, ND = (TH + DRPI - 1) / DRPI;
+  static_assert(XRPI >= 1 && DRPI >= 1, "channel block too wide for the staging map");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 x [x halo | dy] (double buffer)
   const unsigned lds_base = (unsigned)(uintptr_t)(unsigned char __attribute__((address_space(3)))*)lds;
 
@@ -133,12 +136,12 @@ __global__ __launch_bounds__(256, (MI * NJ >= 16 ? 1 : 2)) void conv3x3_wgrad_ke
 
   // wave w owns the output units u = w, w+4, ... (u = tap*MI + ci-tile): no cross-wave reduction, every wave walks
   // all pixel k-steps of the tile for its own units
-  constexpr int NUNITS = 9 * MI, UPW = (NUNITS + 3) / 4;
+  constexpr int NUNITS = 9 * MI, UPW = (NUNITS + NWV - 1) / NWV;
   f32x4 acc[UPW][NJ];
   int uoff[UPW];  // LDS byte offset of the unit's tap shift + channel tile inside the x halo image
 #pragma unroll
   for (int uu = 0; uu < UPW; ++uu) {
-    int u = wave + 4 * uu;
+    int u = wave + NWV * uu;
     if (u >= NUNITS) u = NUNITS - 1;  // clamped duplicate: computed, never written
     const int tap = u / MI, m = u - tap * MI;
     const int ky = tap / 3, kx = tap - 3 * ky;
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(256, (MI * NJ >= 16 ? 1 : 2)) void conv3x3_wgrad_ke
   float* out = a.partial + ((size_t)blockIdx.x * gridDim.y + blk) * (9 * CIB * COB);
 #pragma unroll
   for (int uu = 0; uu < UPW; ++uu) {
-    const int u = wave + 4 * uu;
+    const int u = wave + NWV * uu;
     if (u < NUNITS) {
       const int tap = u / MI, m = u - tap * MI;
 #pragma unroll
@@ -367,6 +370,10 @@ static WgradPlan wgrad_plan(int N, int H, int W, int CinK, int CoutS, int esize)
   WgradPlan p;
   p.NJ = CoutS >= 32 ? 2 : 1;
   p.MI = CinK >= 32 ? 2 : 1;
+  // 64x64-channel blocks (8 waves) where both channel counts allow: a 32-channel slice of a wider pixel is a 64-byte
+  // half of every 128-byte line and every tile is re-read by more block pairs (profiles/r01_conv_pmc_notes.md)
+  static const int env_big = getenv("SPCL_WGRAD_BIG") ? atoi(getenv("SPCL_WGRAD_BIG")) : 1;
+  if (env_big && esize == 2 && CinK % 64 == 0 && CoutS % 64 == 0) p.MI = p.NJ = 4;
   p.nblk_ci = CinK / (16 * p.MI);
   p.nblk_co = CoutS / (16 * p.NJ);
   // 14-row tiles when the height divides by 14 but not by 16 (56 / 28 / 14: 12.5 % padded pixels instead of 23 %)
@@ -391,21 +398,24 @@ static WgradPlan wgrad_plan(int N, int H, int W, int CinK, int CoutS, int esize)
   return p;
 }
 
-template <typename T, int MI, int NJ, int TH>
+template <typename T, int MI, int NJ, int TH, int NWV>
 static void launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t st) {
   const size_t lds = (a.dbuf ? 2 : 1) * wgrad_lds_bytes(MI, NJ, TH, (int)sizeof(T));
   if (lds > 65536)
-    (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_kernel<T, MI, NJ, TH>,
+    (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_kernel<T, MI, NJ, TH, NWV>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  SPCL_LAUNCH((conv3x3_wgrad_kernel<T, MI, NJ, TH>), dim3(p.nsplit, p.nblk_ci * p.nblk_co), dim3(256), lds, st, a);
+  SPCL_LAUNCH((conv3x3_wgrad_kernel<T, MI, NJ, TH, NWV>), dim3(p.nsplit, p.nblk_ci * p.nblk_co), dim3(64 * NWV), lds, st,
+              a);
 }
 
 template <typename T, int TH>
 static void launch_wgrad_th(const WgradArgs& a, const WgradPlan& p, hipStream_t st) {
-  if (p.MI == 1 && p.NJ == 1) launch_wgrad<T, 1, 1, TH>(a, p, st);
-  else if (p.MI == 1 && p.NJ == 2) launch_wgrad<T, 1, 2, TH>(a, p, st);
-  else if (p.MI == 2 && p.NJ == 1) launch_wgrad<T, 2, 1, TH>(a, p, st);
-  else launch_wgrad<T, 2, 2, TH>(a, p, st);
+  if (p.MI == 4 && p.NJ == 4) {
+    if (sizeof(T) == 2) launch_wgrad<bf16_t, 4, 4, TH, 8>(a, p, st);  // bf16 only (wgrad_plan)
+  } else if (p.MI == 1 && p.NJ == 1) launch_wgrad<T, 1, 1, TH, 4>(a, p, st);
+  else if (p.MI == 1 && p.NJ == 2) launch_wgrad<T, 1, 2, TH, 4>(a, p, st);
+  else if (p.MI == 2 && p.NJ == 1) launch_wgrad<T, 2, 1, TH, 4>(a, p, st);
+  else launch_wgrad<T, 2, 2, TH, 4>(a, p, st);
 }
 
 template <typename T>
