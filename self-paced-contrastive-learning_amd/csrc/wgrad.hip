@@ -322,35 +322,52 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_wgrad_kernel(WgradArgs a)
   }
 }
 
-// dW_oihw[co][ci][tap] = sum over pixel-split partials.  Threads follow the PARTIAL layout ([tap][ci][co], co fastest:
-// coalesced 256-byte wave reads); the 4 waves of a block take splits p = w, w+4, ... (8 independent loads in flight
-// each) and are combined through LDS in fixed order -> deterministic.  One scattered 4-byte store per output.
+// dW_oihw[co][ci][tap] = sum over pixel-split partials.  Threads follow the PARTIAL layout ([tap][ci][co], co fastest):
+// a lane owns 4 consecutive outputs (one 16-byte load per split: 1 KiB per wave-load); the waves of a block take the
+// splits p = w, w + nwaves, ... (8 independent loads in flight each) and are combined through LDS in fixed order ->
+// deterministic.  Four scattered 4-byte stores per lane into the OIHW gradient.
+template <int VEC>  // outputs per lane: 4 (16-byte loads) for the large slabs, 1 where a slab has too few outputs
 __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ partial, int nsplit, int nblk_ci,
                                                             int nblk_co, int CIB, int COB, int Cin, int Cout,
                                                             float* __restrict__ dw) {
-  __shared__ float red[16][64];
+  __shared__ float red[16][64 * VEC];
   const int nwaves = blockDim.x >> 6;  // 4 or 16 split lanes
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int slab = 9 * CIB * COB;
-  const int inner = blockIdx.x * 64 + lane;
+  const int slab = 9 * CIB * COB;      // a multiple of 4 (COB is a multiple of 16)
+  const int inner = (blockIdx.x * 64 + lane) * VEC;
   const int blk = blockIdx.y;
   const size_t nblk = (size_t)nblk_ci * nblk_co;
-  float s = 0.f;
+  float s[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) s[e] = 0.f;
   if (inner < slab) {
     const float* src = partial + (size_t)blk * slab + inner;
     const size_t stride = nblk * slab;
 #pragma unroll 8
-    for (int p = wave; p < nsplit; p += nwaves) s += src[(size_t)p * stride];
+    for (int p = wave; p < nsplit; p += nwaves) {
+      if (VEC == 4) {
+        const f32x4 v = *(const f32x4*)(src + (size_t)p * stride);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s[e] += v[e];
+      } else {
+        s[0] += src[(size_t)p * stride];
+      }
+    }
   }
-  red[wave][lane] = s;
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) red[wave][lane * VEC + e] = s[e];
   __syncthreads();
   if (wave == 0 && inner < slab) {
-    float v = red[0][lane];
-    for (int w = 1; w < nwaves; ++w) v += red[w][lane];  // fixed order
-    const int co_l = inner % COB, ci_l = (inner / COB) % CIB, tap = inner / (COB * CIB);
     const int bci = blk / nblk_co, bco = blk - bci * nblk_co;
-    const int ci = bci * CIB + ci_l, co = bco * COB + co_l;
-    if (ci < Cin && co < Cout) dw[((size_t)co * Cin + ci) * 9 + tap] = v;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float v = red[0][lane * VEC + e];
+      for (int w = 1; w < nwaves; ++w) v += red[w][lane * VEC + e];  // fixed order
+      const int i = inner + e;
+      const int co_l = i % COB, ci_l = (i / COB) % CIB, tap = i / (COB * CIB);
+      const int ci = bci * CIB + ci_l, co = bco * COB + co_l;
+      if (ci < Cin && co < Cout) dw[((size_t)co * Cin + ci) * 9 + tap] = v;
+    }
   }
 }
 
@@ -473,8 +490,12 @@ extern "C" int spcl_conv3x3_wgrad(const void* x, const void* dy, int dtype, int 
     return SPCL_EINVAL;
   }
   const int slab = 9 * 16 * p.MI * 16 * p.NJ;
-  SPCL_LAUNCH(wgrad_reduce_kernel, dim3(cdiv(slab, 64), p.nblk_ci * p.nblk_co), dim3(p.nsplit >= 64 ? 1024 : 256), 0, st,
-                     (const float*)partial, p.nsplit, p.nblk_ci, p.nblk_co, 16 * p.MI, 16 * p.NJ, Cin, Cout, dw_oihw);
+  if (slab >= 16384)
+    SPCL_LAUNCH(wgrad_reduce_kernel<4>, dim3(cdiv(slab, 256), p.nblk_ci * p.nblk_co), dim3(p.nsplit >= 64 ? 1024 : 256), 0,
+                st, (const float*)partial, p.nsplit, p.nblk_ci, p.nblk_co, 16 * p.MI, 16 * p.NJ, Cin, Cout, dw_oihw);
+  else
+    SPCL_LAUNCH(wgrad_reduce_kernel<1>, dim3(cdiv(slab, 64), p.nblk_ci * p.nblk_co), dim3(p.nsplit >= 64 ? 1024 : 256), 0,
+                st, (const float*)partial, p.nsplit, p.nblk_ci, p.nblk_co, 16 * p.MI, 16 * p.NJ, Cin, Cout, dw_oihw);
   if (a.stamps) {
     std::vector<unsigned long long> h(nwg * 8);
     (void)hipStreamSynchronize(st);
