@@ -91,6 +91,12 @@ int spcl_conv_pack_weights(const float* w_oihw, int Cin, int Cout, int kind, int
 int spcl_conv_pack_weights_both(const float* w_oihw, int Cin, int Cout, int dtype, void* packed_fwd,
                                 void* packed_dgrad, void* stream);
 
+/* both convolutions of a Conv-BN-ReLU x2 block (forward + dgrad layouts each, sizes as spcl_conv_packed_elems) in one
+ * launch, issued right before the block so that the fragments are still in L2 when its kernels fetch them */
+int spcl_conv_pack_weights_block(const float* wa_oihw, int CinA, int CoutA, void* a_fwd, void* a_dgrad,
+                                 const float* wb_oihw, int CinB, int CoutB, void* b_fwd, void* b_dgrad, int dtype,
+                                 void* stream);
+
 /* y = conv3x3(act(x)), NHWC, implicit GEMM on MFMA.                    (unet.py:72,75; dgrad: with kind-1 weights)
  * x [N,H,W,CinS] of dtype; CinK = GEMM-K channels (multiple of 16, == CinS for in_mode 0/1).
  * in_mode 0: act = identity;  1: act = relu(in_scale[c]*x+in_shift[c])  (the producer's BatchNorm-apply + ReLU,

@@ -291,6 +291,25 @@ __global__ __launch_bounds__(256) void conv_pack_both_kernel(const float* __rest
   else if (idx < t0 + t1) Elem<T>::store(p1 + idx - t0, pack_value<T>(w, Cin, Cout, 1, CoutS, CinK, idx - t0));
 }
 
+// the two convolutions of a block (forward + dgrad layouts each) in one launch
+template <typename T>
+__global__ __launch_bounds__(256) void conv_pack_block_kernel(const float* __restrict__ wa, int CinA, int CoutA,
+                                                              T* __restrict__ a0, size_t ta0, T* __restrict__ a1,
+                                                              size_t ta1, const float* __restrict__ wb, int CinB,
+                                                              int CoutB, T* __restrict__ b0, size_t tb0,
+                                                              T* __restrict__ b1, size_t tb1) {
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int CinKA = (CinA + 15) / 16 * 16, CoutSA = (CoutA + 15) / 16 * 16;
+  const int CinKB = (CinB + 15) / 16 * 16, CoutSB = (CoutB + 15) / 16 * 16;
+  if (idx < ta0) { Elem<T>::store(a0 + idx, pack_value<T>(wa, CinA, CoutA, 0, CinKA, CoutSA, idx)); return; }
+  idx -= ta0;
+  if (idx < ta1) { Elem<T>::store(a1 + idx, pack_value<T>(wa, CinA, CoutA, 1, CoutSA, CinKA, idx)); return; }
+  idx -= ta1;
+  if (idx < tb0) { Elem<T>::store(b0 + idx, pack_value<T>(wb, CinB, CoutB, 0, CinKB, CoutSB, idx)); return; }
+  idx -= tb0;
+  if (idx < tb1) Elem<T>::store(b1 + idx, pack_value<T>(wb, CinB, CoutB, 1, CoutSB, CinKB, idx));
+}
+
 template <typename T> static size_t packed_elems(int KinK, int NoutS) {
   const int KC = conv_kc(KinK);
   return (size_t)(KinK / KC) * conv_nsteps<T>(KC) * (NoutS / 16) * 64 * Chunk<T>::EPC;
@@ -409,6 +428,33 @@ extern "C" int spcl_conv_pack_weights_both(const float* w_oihw, int Cin, int Cou
     return SPCL_EINVAL;
   }
   SPCL_LAUNCH_CHECK("conv_pack_weights_both");
+  return SPCL_OK;
+}
+
+extern "C" int spcl_conv_pack_weights_block(const float* wa_oihw, int CinA, int CoutA, void* a_fwd, void* a_dgrad,
+                                           const float* wb_oihw, int CinB, int CoutB, void* b_fwd, void* b_dgrad,
+                                           int dtype, void* stream) {
+  SPCL_CHECK_ARG(wa_oihw && wb_oihw && a_fwd && a_dgrad && b_fwd && b_dgrad, "conv_pack_weights_block: null pointer");
+  SPCL_CHECK_ARG(CinA > 0 && CoutA > 0 && CinB > 0 && CoutB > 0, "conv_pack_weights_block: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  const int ka = round_up(CinA, 16), sa = round_up(CoutA, 16), kb = round_up(CinB, 16), sb = round_up(CoutB, 16);
+  if (dtype == SPCL_F32) {
+    const size_t ta0 = packed_elems<float>(ka, sa), ta1 = packed_elems<float>(sa, ka);
+    const size_t tb0 = packed_elems<float>(kb, sb), tb1 = packed_elems<float>(sb, kb);
+    SPCL_LAUNCH(conv_pack_block_kernel<float>, dim3((unsigned)((ta0 + ta1 + tb0 + tb1 + 255) / 256)), dim3(256), 0, st,
+                wa_oihw, CinA, CoutA, (float*)a_fwd, ta0, (float*)a_dgrad, ta1, wb_oihw, CinB, CoutB, (float*)b_fwd, tb0,
+                (float*)b_dgrad, tb1);
+  } else if (dtype == SPCL_BF16) {
+    const size_t ta0 = packed_elems<bf16_t>(ka, sa), ta1 = packed_elems<bf16_t>(sa, ka);
+    const size_t tb0 = packed_elems<bf16_t>(kb, sb), tb1 = packed_elems<bf16_t>(sb, kb);
+    SPCL_LAUNCH(conv_pack_block_kernel<bf16_t>, dim3((unsigned)((ta0 + ta1 + tb0 + tb1 + 255) / 256)), dim3(256), 0, st,
+                wa_oihw, CinA, CoutA, (bf16_t*)a_fwd, ta0, (bf16_t*)a_dgrad, ta1, wb_oihw, CinB, CoutB, (bf16_t*)b_fwd,
+                tb0, (bf16_t*)b_dgrad, tb1);
+  } else {
+    set_error("conv_pack_weights_block: dtype %d", dtype);
+    return SPCL_EINVAL;
+  }
+  SPCL_LAUNCH_CHECK("conv_pack_weights_block");
   return SPCL_OK;
 }
 

@@ -204,6 +204,23 @@ def _pack_both(w, dt_code, dtype):
     return p0, p1
 
 
+def _pack_block(wa, wb, dt_code, dtype):
+    """both convolutions of a block, forward and dgrad layouts, one launch -> ((a_fwd, a_dgrad), (b_fwd, b_dgrad))."""
+    sizes = []
+    for w in (wa, wb):
+        co, ci = w.shape[0], w.shape[1]
+        sizes += [_n.call("spcl_conv_packed_elems", ci, co, 0, dt_code), _n.call("spcl_conv_packed_elems", ci, co, 1, dt_code)]
+    buf = torch.empty(sum(sizes), dtype=dtype, device=wa.device)
+    parts, off = [], 0
+    for n_ in sizes:
+        parts.append(buf[off:off + n_])
+        off += n_
+    wac, wbc = wa.detach().contiguous().float(), wb.detach().contiguous().float()
+    _n.call("spcl_conv_pack_weights_block", _n.ptr(wac), wa.shape[1], wa.shape[0], _n.ptr(parts[0]), _n.ptr(parts[1]),
+            _n.ptr(wbc), wb.shape[1], wb.shape[0], _n.ptr(parts[2]), _n.ptr(parts[3]), dt_code, _n.stream())
+    return (parts[0], parts[1]), (parts[2], parts[3])
+
+
 def _conv(x_store, dt_code, dtype, N, H, W, cin_s, cin_k, cout_s, wp, in_mode, scale, shift, want_stats):
     dev = x_store.device
     y = torch.empty(N, H, W, cout_s, dtype=dtype, device=dev)
@@ -281,8 +298,7 @@ class _ConvBlockFn(torch.autograd.Function):
             mode_a = 0
         need_bwd = any(ctx.needs_input_grad)
         if need_bwd:  # the dgrad layouts are packed alongside (same launch) and kept for backward
-            wpa, wpa_t = _pack_both(wa, dtc, dtype)
-            wpb, wpb_t = _pack_both(wb, dtc, dtype)
+            (wpa, wpa_t), (wpb, wpb_t) = _pack_block(wa, wb, dtc, dtype)
         else:
             wpa, wpb, wpa_t, wpb_t = _pack(wa, 0, dtc, dtype), _pack(wb, 0, dtc, dtype), None, None
         ya, sa = _conv(xs, dtc, dtype, N, H, W, cin_s, cin_k, cout_s, wpa, mode_a, None, None, cfg.training)

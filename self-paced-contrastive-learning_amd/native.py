@@ -33,6 +33,7 @@ _SIGNATURES = {
     "spcl_conv_packed_elems": (c_size_t, [c_int, c_int, c_int, c_int]),
     "spcl_conv_pack_weights": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
     "spcl_conv_pack_weights_both": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
+    "spcl_conv_pack_weights_block": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, c_int, _P, _P, c_int, _P]),
     "spcl_conv_num_tiles": (c_int, [c_int, c_int, c_int]),
     "spcl_bn_stats_elems": (c_size_t, [c_int, c_int]),
     "spcl_conv3x3_forward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P,
