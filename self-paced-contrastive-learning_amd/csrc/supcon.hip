@@ -16,7 +16,7 @@
 namespace spcl {
 
 struct SupconLayout {
-  int n, d, N2, N2p, DP, CS;
+  int n, d, N2, N2p, DP, CS, NS;
   size_t off_P, off_rn2, off_logD, off_c, off_W, off_rowloss, off_partA, off_partB, total;
 };
 
@@ -30,7 +30,10 @@ static SupconLayout supcon_layout(int n, int d) {
   int rb = L.N2p / 64;
   int cs = 1;
   while (rb * cs < 512 && cs * 2 <= rb) cs *= 2;
-  L.CS = cs;
+  // small batches (the training sizes, 2n = 64): a 64-column tile is further split over its four 16-column n-tiles so
+  // that a sweep is not one workgroup grinding through 256 exact-f32 MFMAs per wave
+  L.NS = rb * cs <= 16 ? 4 : (rb * cs <= 64 ? 2 : 1);
+  L.CS = cs * L.NS;  // workgroups along the column axis == partial rows
   size_t o = 0;
   L.off_P = o;        o += (size_t)L.N2p * L.DP;
   L.off_rn2 = o;      o += L.N2p;
@@ -57,6 +60,7 @@ struct SupconArgs {
   int n, N2, N2p;
   float t, gamma, inv_gamma;
   int sp_mode;
+  int ns;  // n-tile sub-splits of a 64-column tile (1, 2 or 4): blockIdx.y = column split * ns + sub-split
 };
 
 // ------------------------------------------------------------------------------------------------ prep
@@ -91,10 +95,11 @@ __device__ __forceinline__ float block_max_logit(const float* rn2, int N2, float
 
 // stage 64 rows x DP floats of P (rows J0..J0+63) into LDS, 16-B chunk index XOR (row & 15)
 template <int DP>
-__device__ __forceinline__ void stage_tile(const float* __restrict__ P, int J0, float* lds) {
+__device__ __forceinline__ void stage_tile(const float* __restrict__ P, int J0, float* lds, int sub = 0, int ns = 1) {
   constexpr int CPR = DP / 4;  // chunks per row
   for (int c = threadIdx.x; c < 64 * CPR; c += 256) {
     int row = c / CPR, ch = c % CPR;
+    if (((row >> 4) % ns) != sub) continue;  // only the 16-row n-tiles this workgroup sweeps
     f32x4 v = *(const f32x4*)(P + (size_t)(J0 + row) * DP + ch * 4);
     *(f32x4*)(lds + row * DP + ((ch ^ (row & 15)) << 2)) = v;
   }
@@ -169,12 +174,13 @@ __global__ __launch_bounds__(256) void supcon_sweep_kernel(SupconArgs a) {
 
   float acc0 = 0.f, acc1 = 0.f;
   const int ntiles = a.N2p / 64;
-  for (int jt = blockIdx.y; jt < ntiles; jt += gridDim.y) {
+  const int ysub = blockIdx.y % a.ns, ycs = blockIdx.y / a.ns, ncs = gridDim.y / a.ns;
+  for (int jt = ycs; jt < ntiles; jt += ncs) {
     __syncthreads();
-    stage_tile<DP>(a.P, jt * 64, lds);
+    stage_tile<DP>(a.P, jt * 64, lds, ysub, a.ns);
     __syncthreads();
 #pragma unroll 1
-    for (int nt = 0; nt < 4; ++nt) {
+    for (int nt = ysub; nt < 4; nt += a.ns) {
       f32x4 c = sim_tile<DP>(lds, nt, bi, r16, g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -302,12 +308,13 @@ __global__ __launch_bounds__(256) void supcon_bwd_kernel(SupconArgs a, const flo
     for (int u = 0; u < 4; ++u) acc2[kt][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int ntiles = a.N2p / 64;
-  for (int jt = blockIdx.y; jt < ntiles; jt += gridDim.y) {
+  const int ysub = blockIdx.y % a.ns, ycs = blockIdx.y / a.ns, ncs = gridDim.y / a.ns;
+  for (int jt = ycs; jt < ntiles; jt += ncs) {
     __syncthreads();
-    stage_tile<DP>(a.P, jt * 64, lds);
+    stage_tile<DP>(a.P, jt * 64, lds, ysub, a.ns);
     __syncthreads();
 #pragma unroll 1
-    for (int nt = 0; nt < 4; ++nt) {
+    for (int nt = ysub; nt < 4; nt += a.ns) {
       f32x4 c = sim_tile<DP>(lds, nt, bi, r16, g);
       float h[4];
 #pragma unroll
@@ -407,6 +414,7 @@ __global__ __launch_bounds__(256) void supcon_materialize_kernel(SupconArgs a, i
 static SupconArgs make_args(const SupconLayout& L, const float* ws, const float* labels, const float* mask, float t,
                             int sp_mode, float gamma) {
   SupconArgs a;
+  a.ns = L.NS;
   a.P = ws + L.off_P;
   a.rn2 = ws + L.off_rn2;
   a.labels = labels;
