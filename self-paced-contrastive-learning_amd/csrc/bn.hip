@@ -73,7 +73,7 @@ __global__ __launch_bounds__(1024) void bn_reduce_kernel(const SRC* __restrict__
   const int c = blockIdx.x * 16 + c16;
   const int r0 = blockIdx.y * rows_per_group, r1 = min(nrows, r0 + rows_per_group);
   double n = 0.0, s1 = 0.0, s2 = 0.0;
-#pragma unroll 4
+#pragma unroll 8
   for (int r = r0 + tl; r < r1; r += TL) {
     const SRC* p = rows + (size_t)r * 3 * CS + c;
     const double a = (double)p[0], b = (double)p[CS], q = (double)p[2 * CS];
