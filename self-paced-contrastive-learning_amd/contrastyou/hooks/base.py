@@ -1,114 +1,118 @@
-"""Mirror of the plugin API ``contrastyou/hooks/base.py``: TrainerHook (:23-35, unique-name metaclass :11-20),
-CombineTrainerHook (:38-49), EpocherHook with its six callbacks (:52-86), CombineEpochHook summing losses (:89-118)."""
+"""The plugin contract between trainers / epochers and regularisation hooks, as the reference defines it in
+``contrastyou/hooks/base.py`` (TrainerHook :23-35 with the unique-name check :11-20, CombineTrainerHook :38-49,
+EpocherHook :52-86, CombineEpochHook :89-118) -- same class names, methods and behaviour, own implementation:
+
+* a *trainer hook* is an ``nn.Module`` that owns the learnable parts of a regulariser (projector, ...) and, called
+  once per epoch, manufactures the matching *epocher hook*;
+* an *epocher hook* is a bundle of phase callbacks (``PHASES``) around the forward pass and the regularisation term,
+  plus ``__call__(**kwargs) -> loss`` and ``close()``;
+* the ``Combine*`` variants fan a call out to several hooks and add the losses up.
+"""
+import itertools
 import weakref
-from typing import Iterator, List
 
 from torch import nn
-from torch.nn import Parameter
+
+PHASES = ("before_forward_pass", "after_forward_pass", "before_regularization", "after_regularization")
 
 
-class _ClassNameMeta(type):
-    names: List[str] = []
+class _HookNameRegistry(type):
+    """A TrainerHook constructed with the literal keyword ``hook_name=...`` claims that name; claiming it twice is a
+    ``ValueError`` (positional names and other keywords are not tracked -- exactly the reference's rule)."""
+    _claimed = set()
 
     def __call__(cls, *args, **kwargs):
-        if "hook_name" in kwargs:
-            hook_name = kwargs["hook_name"]
-            if hook_name in cls.names:
-                raise ValueError(hook_name)
-            cls.names.append(hook_name)
+        if "hook_name" not in kwargs:
+            return super().__call__(*args, **kwargs)
+        name = kwargs["hook_name"]
+        if name in _HookNameRegistry._claimed:
+            raise ValueError(name)
+        _HookNameRegistry._claimed.add(name)
         return super().__call__(*args, **kwargs)
 
 
-class TrainerHook(nn.Module, metaclass=_ClassNameMeta):
+class TrainerHook(nn.Module, metaclass=_HookNameRegistry):
     def __init__(self, hook_name: str):
         super().__init__()
         self._hook_name = hook_name
 
-    def parameters(self, recurse: bool = True) -> Iterator[Parameter]:
-        for m in self.learnable_modules:
-            yield from m.parameters(recurse=recurse)
-
     @property
-    def learnable_modules(self) -> List[nn.Module]:
+    def learnable_modules(self):
+        """modules whose parameters the trainer's optimizer must see (none by default)"""
         return []
+
+    def parameters(self, recurse: bool = True):
+        return itertools.chain.from_iterable(m.parameters(recurse=recurse) for m in self.learnable_modules)
 
 
 class CombineTrainerHook(TrainerHook):
+    """several trainer hooks behind one; its epocher hook is the CombineEpochHook of theirs"""
+
     def __init__(self, *trainer_hook):
         super().__init__("")
         self._hooks = nn.ModuleList(trainer_hook)
-
-    def __call__(self):
-        return CombineEpochHook(*[h() for h in self._hooks])
 
     @property
     def learnable_modules(self):
         return self._hooks
 
+    def __call__(self):
+        return CombineEpochHook(*(hook() for hook in self._hooks))
+
 
 class EpocherHook:
+    """per-epoch side of a hook; ``set_epocher`` hands it weak proxies of the epocher and of its meter interface"""
+    meters = None
+
     def __init__(self, name: str) -> None:
         self._name = name
-        self.meters = None
 
     def set_epocher(self, epocher):
         self._epocher = weakref.proxy(epocher)
         self.meters = weakref.proxy(epocher.meters)
         self.configure_meters(self.meters)
 
-    @property
-    def epocher(self):
-        return self._epocher
+    epocher = property(lambda self: self._epocher)
 
     def configure_meters(self, meters):
         return meters
 
-    def before_forward_pass(self, **kwargs):
-        pass
-
-    def after_forward_pass(self, **kwargs):
-        pass
-
-    def before_regularization(self, **kwargs):
-        pass
-
-    def after_regularization(self, **kwargs):
-        pass
-
     def __call__(self, **kwargs):
-        pass
+        return None
 
     def close(self):
-        pass
+        return None
+
+
+def _silent_phase(self, **kwargs):
+    return None
 
 
 class CombineEpochHook(EpocherHook):
     def __init__(self, *epocher_hook: EpocherHook) -> None:
-        self._epocher_hook = epocher_hook
+        self._epocher_hook = tuple(epocher_hook)
+
+    def _broadcast(self, method, *args, **kwargs):
+        return [getattr(hook, method)(*args, **kwargs) for hook in self._epocher_hook]
 
     def set_epocher(self, epocher):
-        for h in self._epocher_hook:
-            h.set_epocher(epocher)
-
-    def before_forward_pass(self, **kwargs):
-        for h in self._epocher_hook:
-            h.before_forward_pass(**kwargs)
-
-    def after_forward_pass(self, **kwargs):
-        for h in self._epocher_hook:
-            h.after_forward_pass(**kwargs)
-
-    def before_regularization(self, **kwargs):
-        for h in self._epocher_hook:
-            h.before_regularization(**kwargs)
-
-    def after_regularization(self, **kwargs):
-        for h in self._epocher_hook:
-            h.after_regularization(**kwargs)
+        self._broadcast("set_epocher", epocher)
 
     def __call__(self, **kwargs):
-        return sum([h(**kwargs) for h in self._epocher_hook])
+        return sum(self._broadcast("__call__", **kwargs))
 
     def close(self):
-        for h in self._epocher_hook:
-            h.close()
+        self._broadcast("close")
+
+
+def _fan_out(phase):
+    def run(self, **kwargs):
+        self._broadcast(phase, **kwargs)
+    run.__name__ = phase
+    return run
+
+
+for _phase in PHASES:
+    setattr(EpocherHook, _phase, _silent_phase)
+    setattr(CombineEpochHook, _phase, _fan_out(_phase))
+del _phase

@@ -6,14 +6,13 @@ Dense/decoder hooks (``_INFONCEDenseHook`` :201-241) are SURVEY row N3 and are n
 Differences that do not change results: the TensorBoard figure taps of the first batches (:185-192,264-266) are
 delivered to an optional ``tap_callback(name, tensor, epocher)`` instead of a global writer; the feature flip before the
 projector (:177-178) is skipped when the projector pools to (1,1) -- a global average is flip-invariant."""
-from functools import partial
-from typing import List, Union
+import math
+from typing import List
 
-import numpy as np
 import torch
 from torch import nn
 
-from ...contrastyou.hooks.base import TrainerHook, EpocherHook
+from ...contrastyou.hooks.base import EpocherHook, TrainerHook
 from ...contrastyou.losses.contrast_loss3 import SelfPacedSupConLoss, SupConLoss1
 from ...contrastyou.meters import AverageValueMeter
 from ..arch.hook import SingleFeatureExtractor
@@ -26,22 +25,21 @@ decoder_names = list(UNet.decoder_names)
 
 
 class PScheduler:
+    """age-parameter schedule of the self-paced loss: ``begin + (end - begin) * (epoch / max_epoch) ** p``; ``step()``
+    once per epoch (reference :34-53, a deepclustering2 ``WeightScheduler``)."""
+
     def __init__(self, max_epoch, begin_value=0.0, end_value=1.0, p=0.5):
-        self.max_epoch = max_epoch
-        self.begin_value = float(begin_value)
-        self.end_value = float(end_value)
-        self.epoch = 0
-        self.p = p
+        self.max_epoch, self.p, self.epoch = max_epoch, p, 0
+        self.begin_value, self.end_value = float(begin_value), float(end_value)
+
+    def get_lr(self, cur_epoch):
+        progress = math.pow(cur_epoch / self.max_epoch, self.p)
+        return self.begin_value + (self.end_value - self.begin_value) * progress
+
+    value = property(lambda self: self.get_lr(self.epoch))
 
     def step(self):
         self.epoch += 1
-
-    @property
-    def value(self):
-        return self.get_lr(self.epoch)
-
-    def get_lr(self, cur_epoch):
-        return self.begin_value + (self.end_value - self.begin_value) * np.power(cur_epoch / self.max_epoch, self.p)
 
     def state_dict(self):
         return {"epoch": self.epoch}
@@ -51,9 +49,9 @@ class PScheduler:
 
 
 class INFONCEHook(TrainerHook):
-    @property
-    def learnable_modules(self) -> List[nn.Module]:
-        return [self._projector]
+    """Trainer-side InfoNCE hook on one encoder feature: owns the feature tap, the projector (learnable) and the
+    criterion; each call (one per epoch) hands out the epocher hook that computes the loss."""
+    _epoch_hook_class = None  # set below, once the epocher hooks exist
 
     def __init__(self, *, name, model: nn.Module, feature_name: str, weight: float = 1.0, spatial_size=None,
                  data_name: str, contrast_on: str, sync_checks: bool = True, tap_callback=None) -> None:
@@ -61,56 +59,65 @@ class INFONCEHook(TrainerHook):
         assert feature_name in encoder_names + decoder_names, feature_name
         if feature_name not in encoder_names:
             raise NotImplementedError("dense (decoder) contrastive hooks are SURVEY row N3: not built")
-        self._feature_name = feature_name
-        self._weight = weight
-        self._sync_checks = sync_checks
-        self._tap_callback = tap_callback
+        self._feature_name, self._weight = feature_name, weight
+        self._sync_checks, self._tap_callback = sync_checks, tap_callback
+        self._contrast_on, self._data_name = contrast_on, data_name
         self._extractor = SingleFeatureExtractor(model, feature_name=feature_name)
-        input_dim = model.get_channel_dim(feature_name)
-        spatial_size = spatial_size or (1, 1)
-        self._projector = self.init_projector(input_dim=input_dim, spatial_size=spatial_size)
+        self._projector = self.init_projector(input_dim=model.get_channel_dim(feature_name),
+                                              spatial_size=spatial_size or (1, 1))
         self._criterion = self.init_criterion()
-        self._label_generator = partial(get_label, contrast_on=contrast_on, data_name=data_name)
         self._learnable_models = (self._projector,)
 
-    def __call__(self):
-        return _INFONCEEpochHook(name=self._hook_name, weight=self._weight, extractor=self._extractor,
-                                 projector=self._projector, criterion=self._criterion,
-                                 label_generator=self._label_generator, tap_callback=self._tap_callback)
-
-    def init_criterion(self) -> SupConLoss1:
-        self._criterion = SupConLoss1(sync_checks=self._sync_checks)
-        return self._criterion
-
-    def init_projector(self, *, input_dim, spatial_size):
-        return self.projector_class(input_dim=input_dim, hidden_dim=256, output_dim=256, head_type="mlp",
-                                    normalize=True, spatial_size=spatial_size)
-
+    # -- pieces a subclass may swap
     @property
     def projector_class(self):
         from ...contrastyou.projectors.heads import ProjectionHead
         return ProjectionHead
 
+    def init_projector(self, *, input_dim, spatial_size):
+        return self.projector_class(input_dim=input_dim, hidden_dim=256, output_dim=256, head_type="mlp",
+                                    normalize=True, spatial_size=spatial_size)
+
+    def init_criterion(self):
+        self._criterion = SupConLoss1(sync_checks=self._sync_checks)
+        return self._criterion
+
+    # -- TrainerHook interface
+    @property
+    def learnable_modules(self) -> List[nn.Module]:
+        return [self._projector]
+
     @property
     def is_encoder(self):
         return self._feature_name in encoder_names
 
+    def _label_generator(self, *, partition_group, label_group):
+        return get_label(self._contrast_on, self._data_name, partition_group, label_group)
+
+    def _new_epoch_hook(self):
+        return self._epoch_hook_class(name=self._hook_name, weight=self._weight, extractor=self._extractor,
+                                      projector=self._projector, criterion=self._criterion,
+                                      label_generator=self._label_generator, tap_callback=self._tap_callback)
+
+    def __call__(self):
+        return self._new_epoch_hook()
+
 
 class SelfPacedINFONCEHook(INFONCEHook):
+    """INFONCEHook with the self-paced criterion; every epoch it moves the age parameter gamma along the PScheduler"""
+
     def __init__(self, *, name, model: nn.Module, feature_name: str, weight: float = 1.0, spatial_size=(1, 1),
                  data_name: str, contrast_on: str, mode="soft", p=0.5, begin_value=1e6, end_value=1e6,
                  correct_grad: bool = False, max_epoch: int, sync_checks: bool = True, tap_callback=None) -> None:
-        self._mode = mode
-        self._p = float(p)
-        self._begin_value = float(begin_value)
-        self._end_value = float(end_value)
-        self._max_epoch = int(max_epoch)
-        self._correct_grad = correct_grad
+        # needed by init_criterion, which the base constructor calls
+        self._mode, self._correct_grad = mode, correct_grad
+        self._p, self._max_epoch = float(p), int(max_epoch)
+        self._begin_value, self._end_value = float(begin_value), float(end_value)
         super().__init__(name=name, model=model, feature_name=feature_name, weight=weight, spatial_size=spatial_size,
                          data_name=data_name, contrast_on=contrast_on, sync_checks=sync_checks,
                          tap_callback=tap_callback)
 
-    def init_criterion(self) -> SelfPacedSupConLoss:
+    def init_criterion(self):
         self._scheduler = PScheduler(max_epoch=self._max_epoch, begin_value=self._begin_value,
                                      end_value=self._end_value, p=self._p)
         self._criterion = SelfPacedSupConLoss(weight_update=self._mode, correct_grad=self._correct_grad,
@@ -118,27 +125,24 @@ class SelfPacedINFONCEHook(INFONCEHook):
         return self._criterion
 
     def __call__(self):
-        gamma = self._scheduler.value
+        self._criterion.set_gamma(self._scheduler.value)  # this epoch's gamma, then advance the schedule
         self._scheduler.step()
-        self._criterion.set_gamma(gamma)
-        return _SPINFONCEEpochHook(name=self._hook_name, weight=self._weight, extractor=self._extractor,
-                                   projector=self._projector, criterion=self._criterion,
-                                   label_generator=self._label_generator, tap_callback=self._tap_callback)
+        return self._new_epoch_hook()
 
 
 class _INFONCEEpochHook(EpocherHook):
-    def __init__(self, *, name: str, weight: float, extractor, projector,
-                 criterion: Union[SupConLoss1, SelfPacedSupConLoss], label_generator, tap_callback=None) -> None:
+    """per-epoch InfoNCE hook: taps the feature during the forward pass, then projector -> criterion on the two views"""
+    _taps_first_batch = ("pos_mask", "sim_exp", "sim_logits")
+
+    def __init__(self, *, name: str, weight: float, extractor, projector, criterion, label_generator,
+                 tap_callback=None) -> None:
         super().__init__(name)
+        self._weight, self._projector, self._criterion = weight, projector, criterion
+        self._label_generator, self._tap_callback = label_generator, tap_callback
         self._extractor = extractor
         self._extractor.bind()
-        self._weight = weight
-        self._projector = projector
-        self._criterion = criterion
-        self._label_generator = label_generator
-        self._tap_callback = tap_callback
-        self._n = 0
-        self._label_cache = {}
+        self._n = 0             # batches seen this epoch
+        self._label_cache = {}  # batch composition -> device label tensor
 
     @meter_focus
     def configure_meters(self, meters):
@@ -165,27 +169,34 @@ class _INFONCEEpochHook(EpocherHook):
                 self._label_cache[key] = t
         return t
 
+    def _two_views(self, n_unl, affine_transformer, seed):
+        """[view 1 | view 2] features of the current batch as one tensor.  The reference flips view 1's features with the
+        sample-wise random flip before projecting (:176-180); when the projector pools to (1, 1) a global average is
+        flip-invariant, so the flip (and the stack / cat copies around it) is skipped."""
+        feature = self._extractor.feature()
+        if feature.shape[0] != 2 * n_unl:  # a slice costs a zero-fill + strided copy in backward: only when needed
+            feature = feature[-2 * n_unl:]
+        if tuple(getattr(self._projector, "_spatial_size", (1, 1))) == (1, 1):
+            return feature
+        first, second = torch.chunk(feature, 2, dim=0)
+        with FixRandomSeed(seed):
+            first = torch.stack([affine_transformer(x) for x in first], dim=0)
+        return torch.cat([first, second], dim=0)
+
+    def _record(self, loss):
+        self.meters["loss"].add(loss.detach())
+        if self._n == 0 and self._tap_callback is not None:
+            for tap in self._taps_first_batch:
+                self._tap_callback(tap, getattr(self._criterion, tap), self.epocher)
+        self._n += 1
+
     @meter_focus
     def __call__(self, *, affine_transformer, seed, unlabeled_tf_logits, unlabeled_logits_tf, partition_group,
                  label_group, **kwargs):
-        n_unl = len(unlabeled_logits_tf)
-        feature_ = self._extractor.feature()
-        if feature_.shape[0] != n_unl * 2:  # a slice costs a zero-fill + strided copy in backward: only when needed
-            feature_ = feature_[-n_unl * 2:]
-        unlabeled_features, unlabeled_tf_features = torch.chunk(feature_, 2, dim=0)
-        pooled_global = tuple(getattr(self._projector, "_spatial_size", (1, 1))) == (1, 1)
-        if not pooled_global:
-            with FixRandomSeed(seed):
-                unlabeled_features = torch.stack([affine_transformer(x) for x in unlabeled_features], dim=0)
-            feature_ = torch.cat([unlabeled_features, unlabeled_tf_features], dim=0)
-        norm_features_tf, norm_tf_features = torch.chunk(self._projector(feature_), 2)
-        labels = self._labels(partition_group, label_group, feature_.device)
-        loss = self._criterion(norm_features_tf, norm_tf_features, target=labels)
-        self.meters["loss"].add(loss.detach())
-        if self._n == 0 and self._tap_callback is not None:
-            for tap in ("pos_mask", "sim_exp", "sim_logits"):
-                self._tap_callback(tap, getattr(self._criterion, tap), self.epocher)
-        self._n += 1
+        feature = self._two_views(len(unlabeled_logits_tf), affine_transformer, seed)
+        z_first, z_second = torch.chunk(self._projector(feature), 2)
+        loss = self._criterion(z_first, z_second, target=self._labels(partition_group, label_group, feature.device))
+        self._record(loss)
         return loss * self._weight
 
     def close(self):
@@ -211,3 +222,7 @@ class _SPINFONCEEpochHook(_INFONCEEpochHook):
         if self._n == 1 and self._tap_callback is not None:
             self._tap_callback("sp_mask", self._criterion.sp_mask, self.epocher)
         return loss
+
+
+INFONCEHook._epoch_hook_class = _INFONCEEpochHook
+SelfPacedINFONCEHook._epoch_hook_class = _SPINFONCEEpochHook
