@@ -148,6 +148,18 @@ int spcl_bnrelu_pool_backward(const void* y, const void* dact, const void* dpool
                               const float* shift, int training, float* ws, float* dgamma, float* dbeta, void* dy,
                               void* stream);
 
+/* BatchNorm+ReLU backward of the FIRST conv of a one-channel image block, fused with that conv's weight gradient
+ * (`_Conv1.conv.0`/`.1`/`.2` backward, semi_seg/arch/unet.py:70-72 with input_dim = 1, + autograd).  The input image
+ * needs no gradient, so this layer's dy feeds nothing but dW: it is formed in registers and never written.
+ *   y, dact   [N][H][W][CS] of dtype (raw conv output, gradient of the activation);  image [N][H][W] f32
+ *   dw        [C][1][3][3] f32;  dgamma, dbeta [C];  ws of spcl_bnrelu_image_wgrad_workspace_bytes
+ * CS a power of two in 16..256.  Deterministic (fixed workgroup partition, fixed-order sums). */
+size_t spcl_bnrelu_image_wgrad_workspace_bytes(int N, int H, int W, int CS);
+int spcl_bnrelu_backward_image_wgrad(const void* y, const void* dact, const float* image, int dtype, int N, int H,
+                                     int W, int C, int CS, const float* mean, const float* invstd, const float* scale,
+                                     const float* shift, int training, float* ws, float* dgamma, float* dbeta,
+                                     float* dw, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * Segmentation head and fine-tune / evaluation arithmetic.  Activations [npix][CS] of dtype (NHWC,
  * npix = N*H*W); class maps [npix][K] f32 with K <= 16; labels [npix] int64.

@@ -170,6 +170,7 @@ template <int EPC> __device__ __forceinline__ void load_coef(float* dst, const f
 }
 
 constexpr int STREAM_UNROLL = 2;
+constexpr int IMG_WGRAD_WG = 2048;  // upper bound of the workgroups of the fused image-wgrad pass
 
 // ---- forward, no pooling: act = relu(scale*y + shift)
 template <typename T>
@@ -560,6 +561,137 @@ __global__ __launch_bounds__(256, 6) void bnrelu_bwd_apply_lin_kernel(const T* _
   }
 }
 
+// ---- pass 2 of the FIRST conv of a one-channel image block, fused with that conv's weight gradient.  The layer's dy
+// feeds nothing but dW (the image needs no gradient), so it is formed in registers and never stored:
+//   dW[co][0][ky][kx] = sum_p dy[p][co] * x[p + (ky-1, kx-1)]      (zero outside the image)
+// A lane owns FOUR channels of a pixel (9 x 4 f32 accumulators: small enough for 5-6 waves per SIMD, which is what
+// hides the load latency of this stream) and walks the image row by row (the image / row split is wave-uniform scalar
+// work).  The nine image values come from clamped addresses times 0/1 factors, so that no load sits in a divergent
+// branch.  Per-workgroup partial rows [9][CS] in a fixed order (deterministic), finished by image_wgrad_final_kernel.
+template <typename T> struct Quad;  // four consecutive channels of one pixel
+template <> struct Quad<float> {
+  typedef u32x4 raw_t;
+  static __device__ __forceinline__ float get(raw_t r, int e) { return __uint_as_float(r[e]); }
+};
+template <> struct Quad<bf16_t> {
+  typedef __attribute__((ext_vector_type(2))) uint32_t raw_t;
+  static __device__ __forceinline__ float get(raw_t r, int e) {
+    return __uint_as_float((e & 1) ? (r[e >> 1] & 0xffff0000u) : (r[e >> 1] << 16));
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 5) void bnrelu_bwd_image_wgrad_kernel(const T* __restrict__ y, const T* __restrict__ g,
+                                                                     const float* __restrict__ img, int N, int H,
+                                                                     int W, int CS, const float* __restrict__ scale,
+                                                                     const float* __restrict__ shift,
+                                                                     const float* __restrict__ ab,
+                                                                     const float* __restrict__ zrow /* W zeros */,
+                                                                     float* __restrict__ wpart /* [grid][9][CS] */) {
+  typedef typename Quad<T>::raw_t raw_t;
+  constexpr int U = 2;
+  extern __shared__ float redw[];  // [4 waves][9][CS]
+  const int QPP = CS / 4, PL = 256 / QPP;  // quads per pixel: a power of two <= 64 (checked by the launcher)
+  const int q = threadIdx.x % QPP, pl = threadIdx.x / QPP;
+  float acc[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[t][e] = 0.f;
+  float sc[4], sh[4], A[4], B[4];
+  load_coef<4>(sc, scale, q);
+  load_coef<4>(sh, shift, q);
+  load_coef<4>(A, ab, q);
+  load_coef<4>(B, ab + CS, q);
+  const int rows = N * H;
+  const unsigned lane_off = q * 4 * sizeof(T), pix_bytes = CS * sizeof(T);
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const int n = r / H, h = r - n * H;  // wave-uniform
+    // the three image rows of the taps; past the top / bottom edge a row of zeros (scalar select, no lane work)
+    const float* xr[3];
+    xr[1] = img + (size_t)r * W;
+    xr[0] = h > 0 ? xr[1] - W : zrow;
+    xr[2] = h + 1 < H ? xr[1] + W : zrow;
+    const char* yr = (const char*)(y + (size_t)r * W * CS);
+    const char* gr = (const char*)(g + (size_t)r * W * CS);
+    for (int ox0 = pl; ox0 < W; ox0 += U * PL) {
+      raw_t ry[U], rg[U];
+      float xv[U][9];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int ox = ox0 + u * PL;
+        ok[u] = ox < W;
+        const int c1 = min(ox, W - 1), c0 = max(c1 - 1, 0), c2 = min(c1 + 1, W - 1);
+        const unsigned off = (unsigned)c1 * pix_bytes + lane_off;
+        ry[u] = *(const raw_t*)(yr + off);
+        rg[u] = *(const raw_t*)(gr + off);
+        const bool left = ox > 0, right = ox + 1 < W;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const char* xk = (const char*)xr[k];  // uniform base + 32-bit lane offset
+          const float a0 = *(const float*)(xk + (unsigned)(c0 * 4)), a1 = *(const float*)(xk + (unsigned)(c1 * 4)),
+                      a2 = *(const float*)(xk + (unsigned)(c2 * 4));
+          xv[u][3 * k + 0] = left ? a0 : 0.f;
+          xv[u][3 * k + 1] = a1;
+          xv[u][3 * k + 2] = right ? a2 : 0.f;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float yv = Quad<T>::get(ry[u], e);
+          const float dz = fmaf(sc[e], yv, sh[e]) > 0.f ? Quad<T>::get(rg[u], e) : 0.f;
+          float dyv = fmaf(sc[e], dz, fmaf(A[e], yv, B[e]));
+          dyv = ok[u] ? dyv : 0.f;  // lanes past the row end
+#pragma unroll
+          for (int t = 0; t < 9; ++t) acc[t][e] = fmaf(dyv, xv[u][t], acc[t][e]);
+        }
+    }
+  }
+  // lanes of one quad sit QPP apart: butterfly over the wave (all 36 values per step, so that the shuffles pipeline),
+  // then a fixed-order sum of the 4 waves
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int o = 32; o >= QPP; o >>= 1) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[t][e] += __shfl_xor(acc[t][e], o, 64);
+  }
+  if (lane < QPP) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) redw[(wave * 9 + t) * CS + lane * 4 + e] = acc[t][e];
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < 9 * CS; o += 256)
+    wpart[(size_t)blockIdx.x * 9 * CS + o] =
+        (redw[o] + redw[9 * CS + o]) + (redw[2 * 9 * CS + o] + redw[3 * 9 * CS + o]);
+}
+
+// dw[co][0][t] = sum over the workgroup rows of wpart[wg][t][co]; one workgroup per tap, fixed order
+__global__ __launch_bounds__(256) void image_wgrad_final_kernel(const float* __restrict__ wpart, int nwg, int C, int CS,
+                                                                float* __restrict__ dw) {
+  __shared__ float red[256];
+  const int t = blockIdx.x;
+  const int RL = 256 / CS;  // row lanes (CS <= 256)
+  const int c = threadIdx.x % CS, rl = threadIdx.x / CS;
+  float s = 0.f;
+  if (rl < RL) {
+#pragma unroll 8
+    for (int w = rl; w < nwg; w += RL) s += wpart[((size_t)w * 9 + t) * CS + c];
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < CS && threadIdx.x < C) {
+    float tot = 0.f;
+    for (int k = 0; k < RL; ++k) tot += red[k * CS + threadIdx.x];
+    dw[threadIdx.x * 9 + t] = tot;
+  }
+}
+
 // enough workgroups to fill the chip several times over, never more than the positions need
 static int stream_grid(size_t positions, int PL, int unroll, int cap) {
   size_t g = (positions + (size_t)PL * unroll - 1) / ((size_t)PL * unroll);
@@ -590,7 +722,8 @@ static int bnrelu_fwd_launch(const void* y, int N, int H, int W, int CS, const f
 template <typename T>
 static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool, int N, int H, int W, int C, int CS,
                              const float* mean, const float* invstd, const float* scale, const float* shift,
-                             int training, float* ws, float* dgamma, float* dbeta, void* dy, hipStream_t st) {
+                             int training, float* ws, float* dgamma, float* dbeta, void* dy, hipStream_t st,
+                             const float* img = nullptr, float* dw = nullptr) {
   constexpr int EPC = Chunk<T>::EPC;
   const bool pool = dpool != nullptr;
   const int PL = 256 / (CS / EPC);
@@ -620,6 +753,17 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
     SPCL_LAUNCH((bnrelu_bwd_pool_kernel<T, true>), dim3(rows < STREAM_MAX_WG ? rows : STREAM_MAX_WG), dim3(256), 0, st, (const T*)y,
                        (const T*)dact, (const T*)dpool, N, H, W, CS, mean, invstd, scale, shift, (const float*)ab,
                        (float*)nullptr, (T*)dy);
+  } else if (img != nullptr) {  // first conv of a one-channel image block: dy is consumed in registers by its dW
+    float* wpart = ab + 2 * CS;                              // [IMG_WGRAD_WG][9][CS]
+    float* zrow = wpart + (size_t)IMG_WGRAD_WG * 9 * CS;     // [W] zeros: the image row above / below the image
+    (void)hipMemsetAsync(zrow, 0, (size_t)W * sizeof(float), st);
+    static const int want = getenv("SPCL_IMGWG_WG") ? atoi(getenv("SPCL_IMGWG_WG")) : 1280;  // 5 resident per CU
+    const int cap = want < IMG_WGRAD_WG ? (want > 0 ? want : 1) : IMG_WGRAD_WG;
+    const int g = N * H < cap ? N * H : cap;
+    prof_cost(2.0 * tb + (double)npix * 4, 2.0 * 9 * npix * C);
+    SPCL_LAUNCH((bnrelu_bwd_image_wgrad_kernel<T>), dim3(g), dim3(256), 4 * 9 * CS * sizeof(float), st, (const T*)y,
+                       (const T*)dact, img, N, H, W, CS, scale, shift, (const float*)ab, (const float*)zrow, wpart);
+    SPCL_LAUNCH(image_wgrad_final_kernel, dim3(9), dim3(256), 0, st, (const float*)wpart, g, C, CS, dw);
   } else {
     SPCL_LAUNCH((bnrelu_bwd_apply_lin_kernel<T>), dim3(stream_grid(npix, PL, STREAM_UNROLL, STREAM_MAX_WG)), dim3(256), 0,
                        st, (const T*)y, (const T*)dact, npix, CS, scale, shift, (const float*)ab, (T*)dy);
@@ -711,5 +855,32 @@ extern "C" int spcl_bnrelu_pool_backward(const void* y, const void* dact, const 
     return SPCL_EINVAL;
   }
   SPCL_LAUNCH_CHECK("bnrelu_pool_backward");
+  return SPCL_OK;
+}
+
+extern "C" size_t spcl_bnrelu_image_wgrad_workspace_bytes(int N, int H, int W, int CS) {
+  return spcl_bnrelu_bwd_workspace_bytes(N, H, W, CS) + ((size_t)IMG_WGRAD_WG * 9 * CS + (size_t)W) * sizeof(float);
+}
+
+extern "C" int spcl_bnrelu_backward_image_wgrad(const void* y, const void* dact, const float* image, int dtype, int N,
+                                                int H, int W, int C, int CS, const float* mean, const float* invstd,
+                                                const float* scale, const float* shift, int training, float* ws,
+                                                float* dgamma, float* dbeta, float* dw, void* stream) {
+  SPCL_CHECK_ARG(y && dact && image && mean && invstd && scale && shift && ws && dgamma && dbeta && dw,
+                 "bnrelu_backward_image_wgrad: null pointer");
+  SPCL_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && CS >= C && CS % 16 == 0 && CS <= 256 && (CS & (CS - 1)) == 0,
+                 "bnrelu_backward_image_wgrad: bad shape (CS must be a power of two in 16..256)");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SPCL_F32)
+    bnrelu_bwd_launch<float>(y, dact, nullptr, N, H, W, C, CS, mean, invstd, scale, shift, training, ws, dgamma, dbeta,
+                             nullptr, st, image, dw);
+  else if (dtype == SPCL_BF16)
+    bnrelu_bwd_launch<bf16_t>(y, dact, nullptr, N, H, W, C, CS, mean, invstd, scale, shift, training, ws, dgamma,
+                              dbeta, nullptr, st, image, dw);
+  else {
+    set_error("bnrelu_backward_image_wgrad: dtype %d", dtype);
+    return SPCL_EINVAL;
+  }
+  SPCL_LAUNCH_CHECK("bnrelu_backward_image_wgrad");
   return SPCL_OK;
 }

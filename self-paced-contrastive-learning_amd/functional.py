@@ -273,6 +273,24 @@ def _bnrelu_bwd(y, dact, dpool, dt_code, dtype, N, H, W, C, cs, st, training):
     return dy, dgamma, dbeta
 
 
+def _bnrelu_bwd_image_wgrad(y, dact, image, dt_code, N, H, W, C, cs, st, training):
+    """BN+ReLU backward of a one-channel image block's first conv fused with its weight gradient (no dy tensor)."""
+    dev = y.device
+    nbytes = _n.call("spcl_bnrelu_image_wgrad_workspace_bytes", N, H, W, cs)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+    dw = torch.empty(C, 1, 3, 3, dtype=torch.float32, device=dev)
+    _n.call("spcl_bnrelu_backward_image_wgrad", _n.ptr(y), _n.ptr(dact), _n.ptr(image), dt_code, N, H, W, C, cs,
+            _n.ptr(st[0]), _n.ptr(st[1]), _n.ptr(st[2]), _n.ptr(st[3]), int(training), _n.ptr(ws), _n.ptr(dgamma),
+            _n.ptr(dbeta), _n.ptr(dw), _n.stream())
+    return dw, dgamma, dbeta
+
+
+def _image_wgrad_fusable(cfg, cin, cout_s):
+    return cfg.image_input and cin == 1 and cout_s <= 256 and cout_s & (cout_s - 1) == 0
+
+
 class _ConvBlockFn(torch.autograd.Function):
     """[conv3x3 -> BN -> ReLU] x2 (+ 2x2 max-pool), semi_seg/arch/unet.py:67-82 + :118-121, as HIP kernels.
 
@@ -338,9 +356,13 @@ class _ConvBlockFn(torch.autograd.Function):
             wpb_t = _pack(wb, 1, dtc, dtype)
         daa, _ = _conv(dyb, dtc, dtype, N, H, W, cout_s, cout_s, cout_s, wpb_t, 0, None, None, False)
         # ---- first conv
-        dya, dga, dba = _bnrelu_bwd(ya, daa, None, dtc, dtype, N, H, W, cout, cout_s, sta, cfg.training)
-        dwa = _wgrad(xs, dya, dtc, N, H, W, cin, cin_s, cin_k, cout, cout_s, mode_a, None, None) \
-            if ctx.needs_input_grad[1] else None
+        if ctx.needs_input_grad[1] and not ctx.needs_input_grad[0] and _image_wgrad_fusable(cfg, cin, cout_s):
+            dya = None  # dy of this layer feeds only dW: one fused pass, nothing written
+            dwa, dga, dba = _bnrelu_bwd_image_wgrad(ya, daa, xs, dtc, N, H, W, cout, cout_s, sta, cfg.training)
+        else:
+            dya, dga, dba = _bnrelu_bwd(ya, daa, None, dtc, dtype, N, H, W, cout, cout_s, sta, cfg.training)
+            dwa = _wgrad(xs, dya, dtc, N, H, W, cin, cin_s, cin_k, cout, cout_s, mode_a, None, None) \
+                if ctx.needs_input_grad[1] else None
         dx = None
         if ctx.needs_input_grad[0]:
             if cfg.image_input:

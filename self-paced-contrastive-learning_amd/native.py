@@ -47,6 +47,9 @@ _SIGNATURES = {
     "spcl_bnrelu_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "spcl_bnrelu_pool_backward": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P,
                                           c_int, _P, _P, _P, _P, _P]),
+    "spcl_bnrelu_image_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "spcl_bnrelu_backward_image_wgrad": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P,
+                                                 c_int, _P, _P, _P, _P, _P]),
     "spcl_conv1x1_forward": (c_int, [_P, c_int, c_size_t, c_int, c_int, c_int, _P, _P, _P, _P]),
     "spcl_conv1x1_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
     "spcl_conv1x1_backward": (c_int, [_P, _P, c_int, c_size_t, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),

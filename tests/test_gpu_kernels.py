@@ -254,6 +254,62 @@ def test_bn_relu_pool_forward_backward(dt, N, C, H, W, pool, with_act):
     assert relerr(dy[..., :C].permute(0, 3, 1, 2).float().cpu(), yr.grad.float()) < tol
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+@pytest.mark.parametrize("N,C,H,W", [(2, 16, 30, 44), (3, 8, 17, 9), (1, 32, 5, 300), (2, 16, 224, 224)])
+def test_bn_relu_backward_fused_image_wgrad(dt, N, C, H, W):
+    """conv3x3(1 -> C) -> BatchNorm(train) -> ReLU backward with dy consumed in registers by dW: against torch autograd
+    (float64) on the same raw conv output y, and against the two-launch HIP path it replaces."""
+    n = _n()
+    dtype = DT[dt]
+    dtc = n.dtype_code(dtype)
+    cs = ru16(C)
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.rand(N, 1, H, W, generator=g)
+    w = torch.randn(C, 1, 3, 3, generator=g) * 0.5
+    y = rnd(F.conv2d(x, w, padding=1), dtype)  # the raw conv output as the forward pass stored it
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    dact = rnd(torch.randn(N, C, H, W, generator=g), dtype)
+    # reference: dy from BN+ReLU backward at y, dW = correlation of dy with the image
+    yr = y.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    F.relu(F.batch_norm(yr, None, None, gr, br, True, 0.1, 1e-5)).backward(dact.double())
+    dw_ref = torch.nn.grad.conv2d_weight(x.double(), (C, 1, 3, 3), yr.grad, 1, 1).float()
+    mean = y.double().mean(dim=(0, 2, 3))
+    var = y.double().var(dim=(0, 2, 3), unbiased=False)
+    st = torch.zeros(4, cs)
+    st[0, :C], st[1, :C] = mean.float(), (1.0 / torch.sqrt(var + 1e-5)).float()
+    st[2, :C] = gamma * st[1, :C]
+    st[3, :C] = beta - st[0, :C] * st[2, :C]
+    st = st.cuda()
+    ys, das, xs = nhwc(y, dtype), nhwc(dact, dtype), x.permute(0, 2, 3, 1).contiguous().cuda()
+    ws = torch.empty(n.call("spcl_bnrelu_image_wgrad_workspace_bytes", N, H, W, cs) // 4, device="cuda")
+    dgm, dbt = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    dw = torch.full((C, 1, 3, 3), float("nan"), device="cuda")
+    n.call("spcl_bnrelu_backward_image_wgrad", n.ptr(ys), n.ptr(das), n.ptr(xs), dtc, N, H, W, C, cs, n.ptr(st[0]),
+           n.ptr(st[1]), n.ptr(st[2]), n.ptr(st[3]), 1, n.ptr(ws), n.ptr(dgm), n.ptr(dbt), n.ptr(dw), n.stream())
+    tol = 5e-5 if dt == "f32" else 8e-3
+    assert relerr(dgm.cpu(), gr.grad.float()) < tol
+    assert relerr(dbt.cpu(), br.grad.float()) < tol
+    assert relerr(dw.cpu(), dw_ref) < (1e-4 if dt == "f32" else 8e-3)
+    # the unfused pair on the same inputs (its dy is rounded to dtype before the contraction; the fused one is not)
+    ws2 = torch.empty(n.call("spcl_bnrelu_bwd_workspace_bytes", N, H, W, cs) // 4, device="cuda")
+    dg2, db2 = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    dy = torch.empty(N, H, W, cs, dtype=dtype, device="cuda")
+    n.call("spcl_bnrelu_pool_backward", n.ptr(ys), n.ptr(das), None, dtc, N, H, W, C, cs, n.ptr(st[0]), n.ptr(st[1]),
+           n.ptr(st[2]), n.ptr(st[3]), 1, n.ptr(ws2), n.ptr(dg2), n.ptr(db2), n.ptr(dy), n.stream())
+    ws3 = torch.empty(n.call("spcl_conv_wgrad_workspace_bytes", N, H, W, 16, cs) // 4, device="cuda")
+    dw2 = torch.empty(C, 1, 3, 3, device="cuda")
+    n.call("spcl_conv3x3_wgrad", n.ptr(xs), n.ptr(dy), dtc, N, H, W, 1, 1, 16, C, cs, 2, None, None, n.ptr(ws3),
+           n.ptr(dw2), n.stream())
+    assert torch.equal(dgm, dg2) and torch.equal(dbt, db2)  # same reduction kernels
+    assert relerr(dw2.cpu(), dw_ref) < (1e-4 if dt == "f32" else 1e-1)
+    # deterministic
+    dw3 = torch.empty_like(dw)
+    n.call("spcl_bnrelu_backward_image_wgrad", n.ptr(ys), n.ptr(das), n.ptr(xs), dtc, N, H, W, C, cs, n.ptr(st[0]),
+           n.ptr(st[1]), n.ptr(st[2]), n.ptr(st[3]), 1, n.ptr(ws), n.ptr(dgm), n.ptr(dbt), n.ptr(dw3), n.stream())
+    assert torch.equal(dw, dw3)
+
+
 def test_fused_radam_matches_torch_radam():
     """spcl_radam_step == torch.optim.RAdam (CPU, single tensor) over the un-rectified (rho_t <= 5) and rectified
     steps, with weight decay and a learning-rate change in between."""

@@ -106,6 +106,19 @@ def main():
                                       n.ptr(dg), n.ptr(db), n.ptr(dyo), n.stream())) if cs_i == cs_o or img else float("nan")
             byts = px * cs_o * es * 5
             line += f"bnbwd(lin) {t:6.1f}us ({byts / t / 1e3:6.0f} GB/s)"
+        if "imgwg" in which and img and ci == 1:
+            scale = torch.rand(cs_o, device="cuda") + 0.5
+            shift = torch.randn(cs_o, device="cuda") * 0.1
+            mean, istd = torch.zeros(cs_o, device="cuda"), torch.ones(cs_o, device="cuda")
+            g_ = torch.randn(N, H, W, cs_o, device="cuda").to(dtype)
+            ws = torch.empty(n.call("spcl_bnrelu_image_wgrad_workspace_bytes", N, H, W, cs_o) // 4, device="cuda")
+            dg, db = torch.empty(co, device="cuda"), torch.empty(co, device="cuda")
+            dw = torch.empty(co, 1, 3, 3, device="cuda")
+            t = timeit(lambda: n.call("spcl_bnrelu_backward_image_wgrad", n.ptr(dy), n.ptr(g_), n.ptr(x), dtc, N, H, W, co,
+                                      cs_o, n.ptr(mean), n.ptr(istd), n.ptr(scale), n.ptr(shift), 1, n.ptr(ws), n.ptr(dg),
+                                      n.ptr(db), n.ptr(dw), n.stream()))
+            byts = px * cs_o * es * 4
+            line += f"bnbwd+imgwgrad {t:6.1f}us ({byts / t / 1e3:6.0f} GB/s)"
         print(line)
 
 
