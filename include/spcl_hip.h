@@ -210,6 +210,11 @@ int spcl_radam_step(float* param, const float* grad, float* exp_avg, float* exp_
                     const float* lr, double beta1, double beta2, double eps, double weight_decay, float* coef,
                     void* stream);
 
+/* Running means of the host-side meters (contrastyou/meters/averagemeter.py via MeterInterface) kept on the device:
+ * for i < k (k <= 8):  dst[i][0] += count[i] * src[i][0];  dst[i][1] += count[i].  src / dst / count are HOST arrays
+ * (of device pointers / floats) read at call time: ONE launch for all of a step's meter updates. */
+int spcl_accumulate_scalars(int k, const void* const* src, void* const* dst, const float* count, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * Per-sample random flips of an NCHW batch (TensorRandomFlip(axis=[1,2], threshold=0.8), new_epocher.py:112, applied
  * per sample in new_pretrain.py:57-58): out[n] = x[n] flipped along H when flags[n] & 1 and along W when flags[n] & 2.

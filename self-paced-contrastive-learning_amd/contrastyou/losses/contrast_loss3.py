@@ -69,6 +69,9 @@ class _SupConBase(nn.Module):
         self._state = F_hip.SupConState()
         self._taps_cache = None
         self._host_out = None
+        stacked = F_hip.stacked_halves(proj_feat1, proj_feat2)
+        if stacked is not None:  # the two views are torch.chunk halves of one projection: skip the chunk / cat copies
+            proj_feat1, proj_feat2 = stacked, None
         loss = F_hip.supcon_loss(proj_feat1, proj_feat2, labels_t, mask_t, t=self._t, sp_mode=sp_mode, gamma=gamma,
                                  correct_grad=correct_grad, state=self._state)
         if self.sync_checks:

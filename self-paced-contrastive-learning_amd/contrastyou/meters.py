@@ -8,6 +8,34 @@ from contextlib import contextmanager
 import torch
 
 
+# ---- batched device accumulation: between begin_batch() and flush_batch() the device-scalar adds of ALL meters are
+# remembered and then performed by ONE kernel launch (spcl_accumulate_scalars) instead of two tiny launches per add.
+_BATCH = None
+
+
+def begin_batch():
+    global _BATCH
+    if _BATCH is None:
+        _BATCH = []
+
+
+def flush_batch():
+    """perform the remembered adds (same arithmetic: sum += n * value, count += n) and leave batching mode"""
+    global _BATCH
+    pending, _BATCH = _BATCH, None
+    if not pending:
+        return
+    from .. import native as _n
+    from ctypes import c_float, c_void_p
+    for i in range(0, len(pending), 8):
+        part = pending[i:i + 8]
+        k = len(part)
+        src = (c_void_p * k)(*[v.data_ptr() for v, _, _ in part])
+        dst = (c_void_p * k)(*[d.data_ptr() for _, d, _ in part])
+        cnt = (c_float * k)(*[float(n) for _, _, n in part])
+        _n.call("spcl_accumulate_scalars", k, src, dst, cnt, _n.stream())
+
+
 class AverageValueMeter:
     """Running mean.  Tensor values are accumulated IN PLACE into persistent device scalars (sum and count), so the
     accumulation is a pair of tiny device ops that also replay correctly from a captured hipGraph."""
@@ -24,6 +52,10 @@ class AverageValueMeter:
         if isinstance(value, torch.Tensor):
             if self._dev is None:
                 self._dev = torch.zeros(2, dtype=torch.float32, device=value.device)
+            if (_BATCH is not None and value.is_cuda and value.dtype == torch.float32 and value.numel() == 1
+                    and self._dev.device == value.device):
+                _BATCH.append((value.detach(), self._dev, n))  # keeps the value alive until the flush
+                return
             self._dev[0].add_(value.detach().float().reshape(()), alpha=n)
             self._dev[1].add_(n)
         elif isinstance(value, (list, tuple)):
@@ -35,6 +67,9 @@ class AverageValueMeter:
 
     def summary(self):
         total, count = self._sum, self._n
+        if _BATCH:
+            flush_batch()
+            begin_batch()
         if self._dev is not None:
             s, c = self._dev.tolist()  # the one device->host readback
             total, count = total + s, count + c

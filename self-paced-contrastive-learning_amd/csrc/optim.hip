@@ -61,6 +61,38 @@ __global__ __launch_bounds__(256) void radam_apply_kernel(float* __restrict__ p,
 
 using namespace spcl;
 
+struct ScalarAdds {
+  const float* src[8];
+  float* dst[8];
+  float count[8];
+  int k;
+};
+// running means of the host-side meters: dst = [sum, count];  sum += count_i * src,  count += count_i
+__global__ void accumulate_scalars_kernel(ScalarAdds a) {
+  const int i = threadIdx.x;
+  if (i < a.k) {
+    a.dst[i][0] = fmaf(a.count[i], a.src[i][0], a.dst[i][0]);
+    a.dst[i][1] += a.count[i];
+  }
+}
+
+extern "C" int spcl_accumulate_scalars(int k, const void* const* src, void* const* dst, const float* count,
+                                       void* stream) {
+  SPCL_CHECK_ARG(k >= 1 && k <= 8 && src && dst && count, "accumulate_scalars: 1 <= k <= 8 pairs per call");
+  ScalarAdds a;
+  a.k = k;
+  for (int i = 0; i < k; ++i) {
+    SPCL_CHECK_ARG(src[i] && dst[i], "accumulate_scalars: null pointer");
+    for (int j = 0; j < i; ++j) SPCL_CHECK_ARG(dst[j] != dst[i], "accumulate_scalars: a destination appears twice");
+    a.src[i] = (const float*)src[i];
+    a.dst[i] = (float*)dst[i];
+    a.count[i] = count[i];
+  }
+  SPCL_LAUNCH(accumulate_scalars_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
+  SPCL_LAUNCH_CHECK("accumulate_scalars");
+  return SPCL_OK;
+}
+
 extern "C" int spcl_radam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
                                int64_t* step, const float* lr, double beta1, double beta2, double eps,
                                double weight_decay, float* coef, void* stream) {

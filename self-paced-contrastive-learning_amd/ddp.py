@@ -41,8 +41,17 @@ class GradBucket:
     def nbytes(self):
         return self.numel * 4
 
+    def arm_sinks(self):
+        """Offer every parameter its slice of the bucket as the place its next gradient is written to
+        (functional.take_grad_sink): the HIP backward kernels then fill the bucket directly and ``gather`` has nothing
+        left to copy.  Call after the gradients were cleared (``p.grad = None``), once per step."""
+        for p, v in zip(self.params, self.views):
+            p._grad_sink = v
+            p._grad_sink_armed = True
+
     def gather(self):
-        """grads -> bucket (one fused foreach copy); params without a grad contribute zeros."""
+        """grads -> bucket (one fused foreach copy of those not already written in place); params without a grad
+        contribute zeros."""
         srcs, dsts = [], []
         for p, v in zip(self.params, self.views):
             if p.grad is None:
@@ -86,6 +95,7 @@ class FlatParams(GradBucket):
         for p in self.params:
             p.grad = None
         self.param.grad = None
+        self.arm_sinks()
 
     def gather_grads(self):
         """module grads -> flat bucket, which becomes ``self.param.grad`` (no communication)."""

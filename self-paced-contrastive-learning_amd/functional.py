@@ -11,6 +11,28 @@ from . import native as _n
 SP_NONE, SP_HARD, SP_SOFT = 0, 1, 2
 
 
+# --------------------------------------------------------------------------------------------- gradient sinks
+def take_grad_sink(param, needed: bool = True):
+    """Where a parameter's gradient should be written: its ARMED sink (a contiguous fp32 view of a flat gradient bucket,
+    installed by ddp.FlatParams.zero_grad) or None (allocate).  A sink serves one backward per arming: the backward
+    kernels write the gradient straight into the bucket and return a fresh view of it, which autograd adopts as
+    ``param.grad`` without a copy; a second use of the same parameter in that step allocates normally and autograd adds
+    it into the bucket in place."""
+    if not needed or param is None:
+        return None
+    sink = getattr(param, "_grad_sink", None)
+    if sink is None or not getattr(param, "_grad_sink_armed", False):
+        return None
+    if sink.shape != param.shape or sink.dtype != torch.float32 or not sink.is_contiguous() or sink.device != param.device:
+        return None
+    param._grad_sink_armed = False
+    return sink
+
+
+def _grad_buffer(sink, shape, dev):
+    return sink.view(shape) if sink is not None else torch.empty(shape, dtype=torch.float32, device=dev)
+
+
 # --------------------------------------------------------------------------------------------- contrastive loss
 class SupConState:
     """Device-side results of one loss evaluation (kept for backward and for the lazily materialised taps)."""
@@ -18,36 +40,48 @@ class SupConState:
 
 
 class _SupConFn(torch.autograd.Function):
+    """``stacked``: z1 is the whole [2n, d] projection (view 1 rows, then view 2 rows) and z2 is None; the gradient
+    comes back as one [2n, d] tensor (no chunk / cat copies around the loss)."""
+
     @staticmethod
     def forward(ctx, z1, z2, labels, mask, t, sp_mode, gamma, correct_grad, state: SupConState):
-        _n.require_gpu(z1, z2, labels, mask)
+        stacked = z2 is None
+        _n.require_gpu(z1, labels, mask) if stacked else _n.require_gpu(z1, z2, labels, mask)
         z1c = z1.detach().contiguous().float()
-        z2c = z2.detach().contiguous().float()
-        n, d = z1c.shape
+        if stacked:
+            assert z1c.dim() == 2 and z1c.shape[0] % 2 == 0, z1c.shape
+            n, d = z1c.shape[0] // 2, z1c.shape[1]
+            z2c = z1c[n:]
+        else:
+            z2c = z2.detach().contiguous().float()
+            n, d = z1c.shape
         nbytes = _n.call("spcl_supcon_workspace_bytes", n, d)
         if nbytes == 0:
             raise RuntimeError(f"supcon: unsupported shape n={n} d={d} (d must be <= 256)")
         ws = torch.empty(nbytes // 4, dtype=torch.float32, device=z1.device)
-        out = torch.zeros(8, dtype=torch.float32, device=z1.device)
+        out = torch.empty(8, dtype=torch.float32, device=z1.device)  # the kernel writes loss, rho, kappa, norm defect
         _n.call("spcl_supcon_forward", _n.ptr(z1c), _n.ptr(z2c), _n.ptr(labels), _n.ptr(mask), n, d, c_float(t),
                 sp_mode, c_float(gamma), int(bool(correct_grad)), _n.ptr(ws), _n.ptr(out), _n.stream())
         state.n, state.d, state.t, state.sp_mode, state.gamma = n, d, t, sp_mode, gamma
         state.labels, state.mask, state.ws, state.out = labels, mask, ws, out
         ctx.state = state
-        ctx.in_dtypes = (z1.dtype, z2.dtype)
-        return out[0].clone()
+        ctx.stacked = stacked
+        ctx.in_dtypes = (z1.dtype, z1.dtype if stacked else z2.dtype)
+        return out[0]
 
     @staticmethod
     def backward(ctx, grad_out):
         s = ctx.state
         dev = s.ws.device
-        dz1 = torch.empty(s.n, s.d, dtype=torch.float32, device=dev)
-        dz2 = torch.empty(s.n, s.d, dtype=torch.float32, device=dev)
+        dz = torch.empty(2 * s.n, s.d, dtype=torch.float32, device=dev)
+        dz1, dz2 = dz[:s.n], dz[s.n:]
         wsb = torch.empty(_n.call("spcl_supcon_bwd_workspace_bytes", s.n, s.d) // 4, dtype=torch.float32, device=dev)
         go = grad_out.detach().reshape(1).float().contiguous()
         _n.call("spcl_supcon_backward", _n.ptr(s.labels), _n.ptr(s.mask), s.n, s.d, c_float(s.t), s.sp_mode,
                 c_float(s.gamma), _n.ptr(s.ws), _n.ptr(wsb), _n.ptr(s.out), _n.ptr(go), _n.ptr(dz1), _n.ptr(dz2),
                 _n.stream())
+        if ctx.stacked:
+            return dz.to(ctx.in_dtypes[0]), None, None, None, None, None, None, None, None
         return dz1.to(ctx.in_dtypes[0]), dz2.to(ctx.in_dtypes[1]), None, None, None, None, None, None, None
 
 
@@ -57,6 +91,17 @@ def supcon_loss(z1, z2, labels=None, mask=None, *, t=0.07, sp_mode=SP_NONE, gamm
     if state is None:
         state = SupConState()
     return _SupConFn.apply(z1, z2, labels, mask, float(t), int(sp_mode), float(gamma), bool(correct_grad), state)
+
+
+def stacked_halves(a: torch.Tensor, b: torch.Tensor):
+    """the tensor whose first / second half of rows a and b are (``torch.chunk(z, 2)`` outputs), else None"""
+    base = a._base
+    if (base is None or base is not b._base or a.dim() != 2 or a.shape != b.shape or base.dim() != 2
+            or not base.is_contiguous() or base.shape[0] != 2 * a.shape[0] or base.shape[1] != a.shape[1]
+            or a.stride() != base.stride() or b.stride() != base.stride()
+            or a.storage_offset() != base.storage_offset() or b.storage_offset() != a.storage_offset() + a.numel()):
+        return None
+    return base
 
 
 def supcon_materialize(state: SupConState, want=("sim_logits", "sim_exp", "pos_mask", "neg_mask", "sp_mask")):
@@ -120,6 +165,8 @@ class _ProjectorFn(torch.autograd.Function):
                 _n.ptr(z), _n.stream())
         ctx.save_for_backward(w1c, w2c, pooled, pre, o)
         ctx.meta = (N, H, W, C, cs, hid, out_dim, bool(normalize), x.dtype, feat.dtype)
+        ng = ctx.needs_input_grad
+        ctx.sinks = tuple(take_grad_sink(p, ng[i + 1]) for i, p in enumerate((w1, b1, w2, b2)))
         return z
 
     @staticmethod
@@ -129,10 +176,11 @@ class _ProjectorFn(torch.autograd.Function):
         dev = dz.device
         mlp = hid > 0
         dzc = dz.detach().contiguous().float()
-        dw1 = torch.empty_like(w1c)
-        db1 = torch.empty(w1c.shape[0], dtype=torch.float32, device=dev)
-        dw2 = torch.empty_like(w2c) if mlp else None
-        db2 = torch.empty(out_dim, dtype=torch.float32, device=dev) if mlp else None
+        sk = ctx.sinks
+        dw1 = _grad_buffer(sk[0], w1c.shape, dev)
+        db1 = _grad_buffer(sk[1], (w1c.shape[0],), dev)
+        dw2 = _grad_buffer(sk[2], w2c.shape, dev) if mlp else None
+        db2 = _grad_buffer(sk[3], (out_dim,), dev) if mlp else None
         scratch = torch.empty(N * (out_dim + hid + C), dtype=torch.float32, device=dev)
         need_dfeat = ctx.needs_input_grad[0]
         dfeat = torch.empty(N, H, W, cs, dtype=xdt, device=dev) if need_dfeat else None
@@ -251,21 +299,21 @@ def _bn_stats(stats, cfg: BlockCfg, C, cs, gamma, beta, which, dev):
     return st
 
 
-def _wgrad(x_store, dy, dt_code, N, H, W, cin, cin_s, cin_k, cout, cout_s, in_mode, scale, shift):
+def _wgrad(x_store, dy, dt_code, N, H, W, cin, cin_s, cin_k, cout, cout_s, in_mode, scale, shift, sink=None):
     dev = dy.device
     nbytes = _n.call("spcl_conv_wgrad_workspace_bytes", N, H, W, cin_k, cout_s)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
-    dw = torch.empty(cout, cin, 3, 3, dtype=torch.float32, device=dev)
+    dw = _grad_buffer(sink, (cout, cin, 3, 3), dev)
     _n.call("spcl_conv3x3_wgrad", _n.ptr(x_store), _n.ptr(dy), dt_code, N, H, W, cin, cin_s, cin_k, cout, cout_s,
             in_mode, _n.ptr(scale), _n.ptr(shift), _n.ptr(ws), _n.ptr(dw), _n.stream())
     return dw
 
 
-def _bnrelu_bwd(y, dact, dpool, dt_code, dtype, N, H, W, C, cs, st, training):
+def _bnrelu_bwd(y, dact, dpool, dt_code, dtype, N, H, W, C, cs, st, training, sinks=(None, None)):
     dev = y.device
     ws = torch.empty(_n.call("spcl_bnrelu_bwd_workspace_bytes", N, H, W, cs) // 4, dtype=torch.float32, device=dev)
-    dgamma = torch.empty(C, dtype=torch.float32, device=dev)
-    dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+    dgamma = _grad_buffer(sinks[0], (C,), dev)
+    dbeta = _grad_buffer(sinks[1], (C,), dev)
     dy = torch.empty(N, H, W, cs, dtype=dtype, device=dev)
     _n.call("spcl_bnrelu_pool_backward", _n.ptr(y), _n.ptr(dact), _n.ptr(dpool), dt_code, N, H, W, C, cs,
             _n.ptr(st[0]), _n.ptr(st[1]), _n.ptr(st[2]), _n.ptr(st[3]), int(training), _n.ptr(ws), _n.ptr(dgamma),
@@ -273,14 +321,14 @@ def _bnrelu_bwd(y, dact, dpool, dt_code, dtype, N, H, W, C, cs, st, training):
     return dy, dgamma, dbeta
 
 
-def _bnrelu_bwd_image_wgrad(y, dact, image, dt_code, N, H, W, C, cs, st, training):
+def _bnrelu_bwd_image_wgrad(y, dact, image, dt_code, N, H, W, C, cs, st, training, sinks=(None, None, None)):
     """BN+ReLU backward of a one-channel image block's first conv fused with its weight gradient (no dy tensor)."""
     dev = y.device
     nbytes = _n.call("spcl_bnrelu_image_wgrad_workspace_bytes", N, H, W, cs)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
-    dgamma = torch.empty(C, dtype=torch.float32, device=dev)
-    dbeta = torch.empty(C, dtype=torch.float32, device=dev)
-    dw = torch.empty(C, 1, 3, 3, dtype=torch.float32, device=dev)
+    dw = _grad_buffer(sinks[0], (C, 1, 3, 3), dev)
+    dgamma = _grad_buffer(sinks[1], (C,), dev)
+    dbeta = _grad_buffer(sinks[2], (C,), dev)
     _n.call("spcl_bnrelu_backward_image_wgrad", _n.ptr(y), _n.ptr(dact), _n.ptr(image), dt_code, N, H, W, C, cs,
             _n.ptr(st[0]), _n.ptr(st[1]), _n.ptr(st[2]), _n.ptr(st[3]), int(training), _n.ptr(ws), _n.ptr(dgamma),
             _n.ptr(dbeta), _n.ptr(dw), _n.stream())
@@ -328,6 +376,8 @@ class _ConvBlockFn(torch.autograd.Function):
         _n.call("spcl_bnrelu_pool_forward", _n.ptr(yb), dtc, N, H, W, cout_s, _n.ptr(stb[2]), _n.ptr(stb[3]),
                 _n.ptr(act), _n.ptr(pool), _n.stream())
         ctx.save_for_backward(xs, ya, yb, sta, stb, wa, wb)
+        ng = ctx.needs_input_grad
+        ctx.sinks = tuple(take_grad_sink(p, ng[i + 1]) for i, p in enumerate((wa, ga, ba, wb, gb, bb)))
         ctx.packed_t = (wpa_t, wpb_t)
         ctx.cfg = cfg
         ctx.meta = (N, cin, H, W, cout, cout_s, cin_s, cin_k, mode_a, x.dtype)
@@ -348,8 +398,9 @@ class _ConvBlockFn(torch.autograd.Function):
         if da_s is None and dp_s is None:
             return (None,) * 8
         # ---- second conv
-        dyb, dgb, dbb = _bnrelu_bwd(yb, da_s, dp_s, dtc, dtype, N, H, W, cout, cout_s, stb, cfg.training)
-        dwb = _wgrad(ya, dyb, dtc, N, H, W, cout, cout_s, cout_s, cout, cout_s, 1, sta[2], sta[3]) \
+        sk = ctx.sinks  # (wa, ga, ba, wb, gb, bb)
+        dyb, dgb, dbb = _bnrelu_bwd(yb, da_s, dp_s, dtc, dtype, N, H, W, cout, cout_s, stb, cfg.training, sk[4:6])
+        dwb = _wgrad(ya, dyb, dtc, N, H, W, cout, cout_s, cout_s, cout, cout_s, 1, sta[2], sta[3], sk[3]) \
             if ctx.needs_input_grad[4] else None
         wpa_t, wpb_t = ctx.packed_t
         if wpb_t is None:
@@ -358,10 +409,11 @@ class _ConvBlockFn(torch.autograd.Function):
         # ---- first conv
         if ctx.needs_input_grad[1] and not ctx.needs_input_grad[0] and _image_wgrad_fusable(cfg, cin, cout_s):
             dya = None  # dy of this layer feeds only dW: one fused pass, nothing written
-            dwa, dga, dba = _bnrelu_bwd_image_wgrad(ya, daa, xs, dtc, N, H, W, cout, cout_s, sta, cfg.training)
+            dwa, dga, dba = _bnrelu_bwd_image_wgrad(ya, daa, xs, dtc, N, H, W, cout, cout_s, sta, cfg.training,
+                                                    sk[0:3])
         else:
-            dya, dga, dba = _bnrelu_bwd(ya, daa, None, dtc, dtype, N, H, W, cout, cout_s, sta, cfg.training)
-            dwa = _wgrad(xs, dya, dtc, N, H, W, cin, cin_s, cin_k, cout, cout_s, mode_a, None, None) \
+            dya, dga, dba = _bnrelu_bwd(ya, daa, None, dtc, dtype, N, H, W, cout, cout_s, sta, cfg.training, sk[1:3])
+            dwa = _wgrad(xs, dya, dtc, N, H, W, cin, cin_s, cin_k, cout, cout_s, mode_a, None, None, sk[0]) \
                 if ctx.needs_input_grad[1] else None
         dx = None
         if ctx.needs_input_grad[0]:
@@ -410,6 +462,8 @@ class _ConvBNReLUFn(torch.autograd.Function):
         _n.call("spcl_bnrelu_pool_forward", _n.ptr(y), dtc, N, H, W, cout_s, _n.ptr(st[2]), _n.ptr(st[3]), _n.ptr(act),
                 None, _n.stream())
         ctx.save_for_backward(xs, y, st, w)
+        ng = ctx.needs_input_grad
+        ctx.sinks = tuple(take_grad_sink(p, ng[i + 1]) for i, p in enumerate((w, gamma, beta)))
         ctx.packed_t = wp_t
         ctx.cfg = cfg
         ctx.meta = (N, cin, H, W, cout, cout_s, cin_s, x.dtype)
@@ -423,8 +477,9 @@ class _ConvBNReLUFn(torch.autograd.Function):
         dtype = cfg.dtype
         dtc = _n.dtype_code(dtype)
         da_s = to_nhwc_padded(d_act, dtype)
-        dy, dg, db = _bnrelu_bwd(y, da_s, None, dtc, dtype, N, H, W, cout, cout_s, st, cfg.training)
-        dw = _wgrad(xs, dy, dtc, N, H, W, cin, cin_s, cin_s, cout, cout_s, 0, None, None) \
+        sk = ctx.sinks
+        dy, dg, db = _bnrelu_bwd(y, da_s, None, dtc, dtype, N, H, W, cout, cout_s, st, cfg.training, sk[1:3])
+        dw = _wgrad(xs, dy, dtc, N, H, W, cin, cin_s, cin_s, cout, cout_s, 0, None, None, sk[0]) \
             if ctx.needs_input_grad[1] else None
         dx = None
         if ctx.needs_input_grad[0]:
@@ -467,6 +522,7 @@ class _Conv1x1Fn(torch.autograd.Function):
         _n.call("spcl_conv1x1_forward", _n.ptr(xs), _n.dtype_code(dtype), N * H * W, C, cs, K, _n.ptr(wc), _n.ptr(bc),
                 _n.ptr(out), _n.stream())
         ctx.save_for_backward(xs, wc)
+        ctx.sinks = (take_grad_sink(w, ctx.needs_input_grad[1]), take_grad_sink(b, ctx.needs_input_grad[2]))
         ctx.meta = (N, C, H, W, K, cs, dtype, x.dtype, tuple(w.shape))
         return out.permute(0, 3, 1, 2)
 
@@ -477,8 +533,8 @@ class _Conv1x1Fn(torch.autograd.Function):
         do = _class_map_storage(dout)
         dev = do.device
         dxs = torch.empty(N, H, W, cs, dtype=dtype, device=dev)
-        dw = torch.empty(K, C, dtype=torch.float32, device=dev)
-        db = torch.empty(K, dtype=torch.float32, device=dev)
+        dw = _grad_buffer(ctx.sinks[0], (K, C), dev)
+        db = _grad_buffer(ctx.sinks[1], (K,), dev)
         ws = torch.empty(_n.call("spcl_conv1x1_bwd_workspace_bytes", C, K) // 4, dtype=torch.float32, device=dev)
         _n.call("spcl_conv1x1_backward", _n.ptr(xs), _n.ptr(do), _n.dtype_code(dtype), N * H * W, C, cs, K, _n.ptr(wc),
                 _n.ptr(dxs), _n.ptr(dw), _n.ptr(db), _n.ptr(ws), _n.stream())

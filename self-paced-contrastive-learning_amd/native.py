@@ -50,6 +50,7 @@ _SIGNATURES = {
     "spcl_bnrelu_image_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "spcl_bnrelu_backward_image_wgrad": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P,
                                                  c_int, _P, _P, _P, _P, _P]),
+    "spcl_accumulate_scalars": (c_int, [c_int, _P, _P, _P, _P]),
     "spcl_conv1x1_forward": (c_int, [_P, c_int, c_size_t, c_int, c_int, c_int, _P, _P, _P, _P]),
     "spcl_conv1x1_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
     "spcl_conv1x1_backward": (c_int, [_P, _P, c_int, c_size_t, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),

@@ -10,6 +10,7 @@ from torch import nn
 from ... import ddp as _ddp
 from ... import functional as F_hip
 from ...contrastyou.losses.kl import class2one_hot
+from ...contrastyou import meters as _meters
 from ...contrastyou.meters import AverageValueMeter, MeterInterface, UniversalDice
 
 
@@ -101,6 +102,7 @@ class FineTuneEpocher(_EpocherBase):
         self._labeled_loader = labeled_loader
         self._sup_criterion = sup_criterion
         self._flat_params = flat_params
+        self._unit = None
         super().__init__(model=model, num_batches=num_batches, cur_epoch=cur_epoch, device=device)
 
     def configure_meters(self, meters):
@@ -125,17 +127,21 @@ class FineTuneEpocher(_EpocherBase):
         label_logits = self._forward_pass(labeled_image)
         onehot_target = class2one_hot(labeled_target.squeeze(1), self.num_classes)
         sup_loss = self._sup_criterion(F_hip.softmax_classes(label_logits), onehot_target, disable_assert=True)
+        if self._unit is None or self._unit.device != sup_loss.device or self._unit.dtype != sup_loss.dtype:
+            self._unit = torch.ones((), dtype=sup_loss.dtype, device=sup_loss.device)
         if self._flat_params is not None:
-            self._flat_params.zero_grad()
-            sup_loss.backward()
+            self._flat_params.zero_grad()  # arms the gradient sinks: backward fills the flat bucket in place
+            sup_loss.backward(gradient=self._unit)
             self._flat_params.reduce()
         else:
             self._optimizer.zero_grad(set_to_none=True)
-            sup_loss.backward()
+            sup_loss.backward(gradient=self._unit)
         self._optimizer.step()
         if self.on_master():
             with torch.no_grad():
+                _meters.begin_batch()
                 self.meters["sup_loss"].add(sup_loss.detach())
+                _meters.flush_batch()
                 self.meters["sup_dice"].add(F_hip.argmax_classes(label_logits.detach()), labeled_target.squeeze(1),
                                             group_name=list(label_group))
         return sup_loss

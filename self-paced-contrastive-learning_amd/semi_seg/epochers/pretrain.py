@@ -12,6 +12,7 @@ from typing import Iterable, Optional
 import torch
 from torch import nn
 
+from ...contrastyou import meters as _meters
 from ...contrastyou.meters import AverageValueMeter, MeterInterface
 from ... import ddp as _ddp
 from .helper import FixRandomSeed, TensorRandomFlip
@@ -57,6 +58,7 @@ class PretrainEncoderEpocher:
             self.meters.register_meter("lr", AverageValueMeter())
             self.meters.register_meter("reg_loss", AverageValueMeter())
         self.cur_batch_num = 0
+        self._ones = {}
 
     # ---- contrastyou/epochers/base.py:47-60
     def add_hook(self, hook):
@@ -97,7 +99,11 @@ class PretrainEncoderEpocher:
 
     def _regularization(self, **kwargs):  # new_epocher.py:234-238
         if len(self._hooks) > 0:
-            return sum([h(**kwargs) for h in self._hooks])
+            losses = [h(**kwargs) for h in self._hooks]
+            total = losses[0]  # `sum` would start from 0 + loss: one more kernel for the same value
+            for extra in losses[1:]:
+                total = total + extra
+            return total
         return torch.tensor(0, dtype=torch.float, device=self._device)
 
     # ---- new_pretrain.py:91-96
@@ -127,6 +133,7 @@ class PretrainEncoderEpocher:
     def step_compute(self, data, seed=None):
         """forward + loss + backward + gradients gathered into the flat bucket (no communication, no update)."""
         seed = random.randint(0, int(1e7)) if seed is None else seed
+        _meters.begin_batch()  # the step's meter adds become one launch in step_update
         (unlabeled_image, unlabeled_image_tf), _, unlabeled_filename, unl_partition, unl_group = \
             unzip_twice_transformed(data, self._device)
         if unlabeled_image.is_cuda and unlabeled_image.shape == unlabeled_image_tf.shape:
@@ -153,13 +160,23 @@ class PretrainEncoderEpocher:
             affine_transformer=self._affine_transformer)
         total_loss = reg_loss
         if self._flat_params is not None:
-            self._flat_params.zero_grad()
-            total_loss.backward()
+            self._flat_params.zero_grad()  # also arms the gradient sinks: backward writes into the flat bucket
+            total_loss.backward(gradient=self._unit_grad(total_loss))
             self._flat_params.gather_grads()
         else:
             self._optimizer.zero_grad(set_to_none=True)
-            total_loss.backward()
+            if self._grad_bucket is not None:
+                self._grad_bucket.arm_sinks()
+            total_loss.backward(gradient=self._unit_grad(total_loss))
         return reg_loss
+
+    def _unit_grad(self, loss):
+        """d loss / d loss = 1 as a cached device scalar (``backward()`` would fill a fresh one every step)"""
+        key = (loss.device, loss.dtype)
+        one = self._ones.get(key)
+        if one is None:
+            one = self._ones[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
+        return one
 
     def step_exchange(self):
         """the step's one collective: mean of the flat gradient bucket over the ranks."""
@@ -172,3 +189,4 @@ class PretrainEncoderEpocher:
         self._optimizer.step()
         if self.on_master():
             self.meters["reg_loss"].add(reg_loss.detach())
+        _meters.flush_batch()

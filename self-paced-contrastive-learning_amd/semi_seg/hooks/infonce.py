@@ -197,7 +197,7 @@ class _INFONCEEpochHook(EpocherHook):
         z_first, z_second = torch.chunk(self._projector(feature), 2)
         loss = self._criterion(z_first, z_second, target=self._labels(partition_group, label_group, feature.device))
         self._record(loss)
-        return loss * self._weight
+        return loss if self._weight == 1 else loss * self._weight
 
     def close(self):
         self._extractor.remove()

@@ -192,6 +192,53 @@ def test_g4_full_pretrain_step_fp32(golden):
             assert err < 5e-3, (name, err)
 
 
+def test_gradient_sinks_fill_the_flat_bucket_in_place():
+    """ddp.FlatParams arms a sink per parameter; the backward kernels write the gradients straight into the flat bucket
+    (param.grad aliases its slice, gather copies nothing) and the values are bit-identical to the allocate-and-copy path,
+    and the bucket also ends up right when a parameter is used twice in one step."""
+    import spcl_amd  # noqa
+    from spcl_amd import ddp
+    from spcl_amd.contrastyou.projectors.heads import ProjectionHead
+
+    def run(sinks, twice=False):
+        net, _ = _unet(128, 3)
+        head = ProjectionHead(input_dim=128, hidden_dim=32, output_dim=16, head_type="mlp", normalize=True)
+        head.load_state_dict(O.init_projector_state(128, 32, 16, seed=5))
+        head.cuda()
+        params = [p for p in list(net.parameters()) + list(head.parameters())]
+        flat = ddp.FlatParams(params)
+        if sinks:
+            flat.zero_grad()
+        x = torch.rand(4, 1, 32, 32, generator=torch.Generator().manual_seed(1)).cuda()
+        with net.set_grad(False, start="Conv5", include_start=False):
+            z = head(net(x, until="Conv5"))
+            loss = (z * torch.arange(16, device="cuda")).sum()
+            if twice:
+                loss = loss + 0.5 * head(net(x.flip(3), until="Conv5")).sum()
+            loss.backward()
+        named = dict(net.named_parameters())
+        named.update({"proj." + k: p for k, p in head.named_parameters()})
+        aliased = {k: p.grad is not None and any(p.grad.data_ptr() == v.data_ptr() for v in flat.views)
+                   for k, p in named.items()}
+        grads = {k: p.grad.clone() for k, p in named.items() if p.grad is not None}
+        flat.gather_grads()
+        return grads, aliased, flat.flat.clone()
+
+    g0, a0, f0 = run(False)
+    g1, a1, f1 = run(True)
+    assert not any(a0.values())
+    assert len(g1) == len(g0) and len(g0) >= 34  # 30 encoder + 4 projector tensors
+    assert all(a1[k] for k in g1), [k for k in g1 if not a1[k]]
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+    assert torch.equal(f0, f1)
+    g2, _, f2 = run(False, twice=True)
+    g3, _, f3 = run(True, twice=True)  # autograd sums the two uses itself; the bucket gets the sum either way
+    for k in g2:
+        assert _relerr(g3[k].cpu().numpy(), g2[k].cpu().numpy()) < 1e-6, k
+    assert _relerr(f3.cpu().numpy(), f2.cpu().numpy()) < 1e-6
+
+
 def test_bn_kat5_statistics():
     """KAT-5: after the first block the fused BN has mean 0 / biased var 1 before the affine; running_var uses the
     unbiased variance with momentum 0.1."""

@@ -141,3 +141,51 @@ def test_loss_deferred_checks_no_sync():
     loss.backward()
     assert c.downgrade_ratio_tensor.is_cuda and 0 < c.downgrade_ratio <= 1
     c.check()
+
+
+def test_loss_on_chunk_halves_takes_the_stacked_path_with_identical_results():
+    """criterion(*torch.chunk(z, 2)) (the hook's call, semi_seg/hooks/infonce.py:180-183) runs on the stacked
+    projection directly: same loss, rho and gradient bits as two separate tensors, and no chunk/cat copies."""
+    import spcl_amd  # noqa
+    from spcl_amd import functional as F_hip
+    g = torch.Generator().manual_seed(3)
+    z = torch.nn.functional.normalize(torch.randn(24, 64, generator=g), dim=1).cuda()
+    labels = [i % 3 for i in range(12)]
+    res = []
+    for stacked in (True, False):
+        zz = z.clone().requires_grad_(True)
+        h = zz * 1.0
+        a, b = torch.chunk(h, 2)
+        if not stacked:
+            a, b = a.clone(), b.clone()
+        assert (F_hip.stacked_halves(a, b) is not None) == stacked
+        crit = _crit("soft", 5.0, True)
+        loss = crit(a, b, target=labels)
+        loss.backward()
+        res.append((loss.detach().clone(), crit.downgrade_ratio, zz.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
+    assert torch.equal(res[0][2], res[1][2])
+
+
+def test_meter_batching_is_one_launch_with_the_same_sums():
+    import spcl_amd  # noqa
+    from spcl_amd.contrastyou import meters as M
+    vals = [torch.tensor(float(v), device="cuda") for v in (1.5, -2.25, 4.0, 0.125)]
+    plain, batched = [M.AverageValueMeter() for _ in range(3)], [M.AverageValueMeter() for _ in range(3)]
+    for step in range(3):
+        for i, m in enumerate(plain):
+            m.add(vals[(i + step) % 4])
+        M.begin_batch()
+        for i, m in enumerate(batched):
+            m.add(vals[(i + step) % 4])
+        M.flush_batch()
+    for p, b in zip(plain, batched):
+        assert p.summary() == b.summary()
+    # more than 8 pending adds are split over several launches; summary() flushes what is pending
+    many = [M.AverageValueMeter() for _ in range(11)]
+    M.begin_batch()
+    for i, m in enumerate(many):
+        m.add(vals[i % 4], n=2)
+    assert many[10].summary()["mean"] == float(vals[10 % 4])
+    M.flush_batch()
+    assert many[0].summary()["mean"] == 1.5
