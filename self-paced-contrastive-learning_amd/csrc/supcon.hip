@@ -12,20 +12,29 @@
 // reference's fp32 torch.mm to rounding.  One wave owns 16 rows of S; a workgroup of 4 waves shares the
 // 64-row P_J tile staged in LDS (16-byte chunks XOR-swizzled by row -> conflict-free ds_read_b128).
 #include "common.hpp"
+#include <vector>
 
 namespace spcl {
 
 struct SupconLayout {
   int n, d, N2, N2p, DP, CS, NS;
-  size_t off_P, off_rn2, off_logD, off_c, off_W, off_rowloss, off_partA, off_partB, total;
+  int big, CSB;  // large batches: logits materialised once by split-bf16 MFMA (CSB column splits), see below
+  size_t off_P, off_rn2, off_logD, off_c, off_W, off_rowloss, off_partA, off_partB, off_Ph, off_Pm, off_L, total;
 };
+constexpr int SUPCON_BIG_N2 = 1024;  // from this many rows on the forward materialises the logits
+
+static int supcon_big_wgs() {
+  static const int v = getenv("SPCL_SUPCON_WGS") ? atoi(getenv("SPCL_SUPCON_WGS")) : 512;
+  return v;
+}
 
 static SupconLayout supcon_layout(int n, int d) {
   SupconLayout L;
   L.n = n;
   L.d = d;
   L.N2 = 2 * n;
-  L.N2p = round_up(L.N2, 64);
+  L.big = L.N2 >= SUPCON_BIG_N2;
+  L.N2p = round_up(L.N2, L.big ? 128 : 64);
   L.DP = d <= 64 ? 64 : (d <= 128 ? 128 : 256);
   int rb = L.N2p / 64;
   int cs = 1;
@@ -41,8 +50,18 @@ static SupconLayout supcon_layout(int n, int d) {
   L.off_c = o;        o += L.N2p;
   L.off_W = o;        o += L.N2p;
   L.off_rowloss = o;  o += L.N2p;
-  L.off_partA = o;    o += (size_t)L.CS * L.N2p;
-  L.off_partB = o;    o += (size_t)L.CS * L.N2p;
+  L.CSB = 1;
+  if (L.big)  // 128-row blocks x CSB column splits ~ two workgroups per CU
+    while ((L.N2p / 128) * L.CSB < supcon_big_wgs() && L.CSB * 2 * 64 <= L.N2p) L.CSB *= 2;
+  const int prow = L.CS > L.CSB ? L.CS : L.CSB;
+  L.off_partA = o;    o += (size_t)prow * L.N2p;
+  L.off_partB = o;    o += (size_t)prow * L.N2p;
+  L.off_Ph = L.off_Pm = L.off_L = o;
+  if (L.big) {  // bf16 splits of P (2 x N2p x DP halves) and the logits [N2p][N2p]
+    L.off_Ph = o;     o += (size_t)L.N2p * L.DP / 2;
+    L.off_Pm = o;     o += (size_t)L.N2p * L.DP / 2;
+    L.off_L = o;      o += (size_t)L.N2p * L.N2p;
+  }
   L.total = o;
   return L;
 }
@@ -60,13 +79,15 @@ struct SupconArgs {
   int n, N2, N2p;
   float t, gamma, inv_gamma;
   int sp_mode;
+  unsigned long long* stamps;  // debug (SPCL_SUPCON_STAMPS=1): s_memtime ticks of wave 0 per phase, else null
   int ns;  // n-tile sub-splits of a 64-column tile (1, 2 or 4): blockIdx.y = column split * ns + sub-split
 };
 
 // ------------------------------------------------------------------------------------------------ prep
 __global__ __launch_bounds__(256) void supcon_prep_kernel(const float* __restrict__ z1, const float* __restrict__ z2,
                                                           int n, int d, int N2p, int DP, float* __restrict__ P,
-                                                          float* __restrict__ rn2) {
+                                                          float* __restrict__ rn2, bf16_t* __restrict__ Ph,
+                                                          bf16_t* __restrict__ Pm) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= N2p) return;
@@ -75,15 +96,29 @@ __global__ __launch_bounds__(256) void supcon_prep_kernel(const float* __restric
   for (int k = lane; k < DP; k += 64) {
     float v = (src != nullptr && k < d) ? src[k] : 0.f;
     P[(size_t)row * DP + k] = v;
+    if (Ph != nullptr) {  // v = hi + mid + O(2^-16 v): two bf16 terms carry 16 mantissa bits
+      const bf16_t h = f32_to_bf16(v);
+      Ph[(size_t)row * DP + k] = h;
+      Pm[(size_t)row * DP + k] = f32_to_bf16(v - bf16_to_f32(h));
+    }
     s += v * v;
   }
   s = wave_sum(s);
   if (lane == 0) rn2[row] = s;
 }
 
+// max_i |p_i|^2 / t (the largest logit: the diagonal).  16-byte loads, four independent ones per trip: one memory
+// round trip instead of one per row block (division is monotonic, so it is applied once, to the maximum).
 __device__ __forceinline__ float block_max_logit(const float* rn2, int N2, float t, float* red /*[4]*/) {
   float v = 0.f;
-  for (int i = threadIdx.x; i < N2; i += blockDim.x) v = fmaxf(v, rn2[i] / t);
+  const int n4 = N2 & ~3;
+#pragma unroll 4
+  for (int i = threadIdx.x * 4; i < n4; i += blockDim.x * 4) {
+    const f32x4 r = *(const f32x4*)(rn2 + i);
+    v = fmaxf(v, fmaxf(fmaxf(r[0], r[1]), fmaxf(r[2], r[3])));
+  }
+  if ((int)threadIdx.x < N2 - n4) v = fmaxf(v, rn2[n4 + threadIdx.x]);
+  v = v / t;
   v = wave_max(v);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
@@ -206,6 +241,210 @@ __global__ __launch_bounds__(256) void supcon_sweep_kernel(SupconArgs a) {
   if (g == 0) {
     a.partA[(size_t)blockIdx.y * a.N2p + i] = acc0;
     a.partB[(size_t)blockIdx.y * a.N2p + i] = acc1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ large batches
+// From SUPCON_BIG_N2 rows on (the 4096 x 128 configuration of BASELINE.json) the two exact-f32 sweeps above are
+// MFMA-bound at the f32 matrix rate (2 x 4.3 GFLOP at 157 TFLOP/s peak).  Instead the logits are formed ONCE on the
+// bf16 matrix pipe (16x the f32 rate) from a two-term split P = Ph + Pm:  S ~ Ph Ph^T + Ph Pm^T + Pm Ph^T  (dropped
+// terms ~2^-16 |a||b|: a logit error of ~1e-5, far inside the loss tolerance), written to HBM as f32 (N2p^2 x 4 B,
+// 67 MB at 4096) together with the row sums D_i, and the self-paced pass is then a pure HBM stream over that matrix
+// (supcon_rowpass_kernel) -- the "materialised" schedule SURVEY 8(d) prices, with the row-sum pass fused into the
+// producer.  Labels / SimCLR modes only (an explicit `mask` input keeps the exact sweeps); backward is unchanged.
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8v;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <int DP> __device__ __forceinline__ int big_swz(int row) {
+  constexpr int CPR = DP / 8;               // 16-byte chunks per row
+  return CPR >= 16 ? (row & 15) : ((row >> 1) & (CPR - 1));  // rows per 256-byte bank cycle: 1 (DP >= 128) or 2 (DP = 64)
+}
+
+// S tiles on v_mfma_f32_32x32x16_bf16: a wave owns 32 rows i (A operand, in registers), the 64-row J tile is the B
+// operand from LDS (16-byte chunks XOR-swizzled by row -> conflict-free ds_read_b128).  Lane l holds column
+// j = J0 + l % 32 of the 16 rows i = I0 + 8q + 4 (l / 32) + r (q, r = 0..3): a store instruction writes two 128-byte
+// row segments (coalesced), and the row sums stay per-lane partials (one per row slot) until one butterfly at the end.
+template <int DP>
+__global__ __launch_bounds__(256) void supcon_logits_kernel(SupconArgs a, const bf16_t* __restrict__ Ph,
+                                                           const bf16_t* __restrict__ Pm, float* __restrict__ Lmat) {
+  constexpr int CPR = DP / 8, KS = DP / 16;
+  constexpr int NPRE = 2 * 64 * CPR / 256;  // 16-byte chunks of a J tile (both splits) per thread
+  extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+  u32x4* tile = (u32x4*)lds_raw;  // [2 splits][64 rows][CPR chunks]
+  __shared__ float red[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n32 = lane & 31, kh = lane >> 5;
+  const int I0 = blockIdx.x * 128 + wave * 32;
+  const float inv_t = 1.f / a.t;
+  const int ntiles = a.N2p / 64;
+
+  // the next J tile travels through registers while the current one is multiplied (one 16-byte chunk per slot)
+  u32x4 pre[NPRE];
+  auto fetch = [&](int jt) {
+#pragma unroll
+    for (int u = 0; u < NPRE; ++u) {
+      const int c = threadIdx.x + 256 * u;
+      const int sp = c / (64 * CPR), rc = c - sp * 64 * CPR;
+      const int row = rc / CPR, ch = rc - row * CPR;
+      pre[u] = *(const u32x4*)((sp ? Pm : Ph) + (size_t)(jt * 64 + row) * DP + ch * 8);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int u = 0; u < NPRE; ++u) {
+      const int c = threadIdx.x + 256 * u;
+      const int sp = c / (64 * CPR), rc = c - sp * 64 * CPR;
+      const int row = rc / CPR, ch = rc - row * CPR;
+      tile[(sp * 64 + row) * CPR + (ch ^ big_swz<DP>(row))] = pre[u];
+    }
+  };
+
+  const bool stamp = a.stamps != nullptr && threadIdx.x == 0;
+  unsigned long long tk[6] = {0, 0, 0, 0, 0, 0}, t0 = stamp ? __builtin_amdgcn_s_memtime() : 0, t1;
+#define SUPCON_STAMP(k)                                   \
+  if (stamp) {                                            \
+    t1 = __builtin_amdgcn_s_memtime();                    \
+    tk[k] += t1 - t0;                                     \
+    t0 = t1;                                              \
+  }
+  bf16x8v ah[KS], am[KS];  // this wave's rows: lane -> row I0 + n32, k = 16 ks + 8 kh ..
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    ah[ks] = *(const bf16x8v*)(Ph + (size_t)(I0 + n32) * DP + 16 * ks + 8 * kh);
+    am[ks] = *(const bf16x8v*)(Pm + (size_t)(I0 + n32) * DP + 16 * ks + 8 * kh);
+  }
+  fetch(blockIdx.y);
+  const float m = block_max_logit(a.rn2, a.N2, a.t, red);  // its loads overlap the fetches above
+  const float k2 = inv_t * 1.44269504088896340736f, m2 = m * 1.44269504088896340736f;
+  // the A operands are complete before the tile loop: otherwise the compiler's waits for them sit inside the loop
+  // and drain the next tile's prefetch on every iteration
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(ah[ks]), "v"(am[ks]));
+  float D[16];
+#pragma unroll
+  for (int v = 0; v < 16; ++v) D[v] = 0.f;
+  SUPCON_STAMP(0)  // preamble
+  for (int jt = blockIdx.y; jt < ntiles; jt += gridDim.y) {
+    __syncthreads();  // the previous tile has been read
+    SUPCON_STAMP(1)  // waiting for the workgroup
+    commit();
+    __syncthreads();
+    SUPCON_STAMP(2)  // prefetch arrival + LDS write + barrier
+    if (jt + (int)gridDim.y < ntiles) fetch(jt + gridDim.y);
+    // both 32-column n-tiles unrolled (an inner loop would make the compiler drain the prefetch at its header)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      f32x16 c;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) c[v] = 0.f;
+      const int row = nt * 32 + n32;
+      const u32x4* rh = tile + row * CPR;
+      const u32x4* rm = tile + (64 + row) * CPR;
+      const int key = big_swz<DP>(row);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8v bh = __builtin_bit_cast(bf16x8v, rh[(2 * ks + kh) ^ key]);
+        const bf16x8v bm = __builtin_bit_cast(bf16x8v, rm[(2 * ks + kh) ^ key]);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bm, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[ks], bh, c, 0, 0, 0);
+      }
+      const int J0 = jt * 64 + nt * 32, j = J0 + n32;
+      // wave-uniform: does this 32 x 32 tile touch the diagonal or the column padding?
+      const bool edge = (I0 < J0 + 32 && J0 < I0 + 32) || J0 + 32 > a.N2;
+      float* dst = Lmat + (size_t)I0 * a.N2p + j;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int ri = 8 * (v >> 2) + 4 * kh + (v & 3);  // row slot of c[v]
+        const float lg = fmaf(c[v], inv_t, -m);          // logit = c/t - m
+        float e = __builtin_amdgcn_exp2f(fmaf(c[v], k2, -m2));  // exp(logit)
+        if (edge) e = (j == I0 + ri || j >= a.N2) ? 0.f : e;
+        D[v] += e;
+        dst[(size_t)ri * a.N2p] = lg;
+      }
+    }
+    SUPCON_STAMP(3)  // MFMA + epilogue issue of both n-tiles
+  }
+  // D[v] of lane l = partial sum of row I0 + 8 (v / 4) + 4 kh + v % 4 over this lane's columns: fold the 32 lanes
+#pragma unroll
+  for (int v = 0; v < 16; ++v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) D[v] += __shfl_xor(D[v], o, 64);
+  }
+  if (n32 == 0) {
+#pragma unroll
+    for (int v = 0; v < 16; ++v)
+      a.partA[(size_t)blockIdx.y * a.N2p + I0 + 8 * (v >> 2) + 4 * kh + (v & 3)] = D[v];
+  }
+  SUPCON_STAMP(4)  // row-sum fold
+  if (stamp) {
+    unsigned long long* o = a.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 6;
+    for (int k = 0; k < 6; ++k) o[k] = tk[k];
+  }
+#undef SUPCON_STAMP
+}
+
+// One wave per row of the materialised logits: D_i from the column-split partials, then the self-paced weights, the
+// row's weighted log-likelihood, W_i and the positive count c_i in one stream over the row (16 bytes per lane, four
+// loads in flight; VEC: n % 4 == 0, so a lane's four columns map to four consecutive labels).
+template <bool VEC>
+__global__ __launch_bounds__(256) void supcon_rowpass_kernel(SupconArgs a, const float* __restrict__ Lmat, int CSB,
+                                                             float* __restrict__ logD, float* __restrict__ cnt,
+                                                             float* __restrict__ rowloss, float* __restrict__ W) {
+  constexpr int U = 4;
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= a.N2p) return;
+  float D = 0.f;
+  for (int c = lane; c < CSB; c += 64) D += a.partA[(size_t)c * a.N2p + i];
+  D = wave_sum(D);
+  const float logD_i = logf(D + 1e-16f);
+  float s_l = 0.f, s_w = 0.f, s_c = 0.f;
+  if (i < a.N2) {
+    const int in = i >= a.n ? i - a.n : i;
+    const bool have_lab = a.labels != nullptr;
+    const float lab_i = have_lab ? a.labels[in] : 0.f;
+    const float* row = Lmat + (size_t)i * a.N2p;
+    for (int jb = lane * 4; jb < a.N2; jb += 256 * U) {
+      f32x4 lg[U], lb[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int j0 = jb + 256 * u;
+        lg[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        lb[u] = lg[u];
+        if (j0 < a.N2) {
+          lg[u] = *(const f32x4*)(row + j0);  // N2p is a multiple of 128: the whole chunk is inside the row
+          if (VEC && have_lab) lb[u] = *(const f32x4*)(a.labels + (j0 >= a.n ? j0 - a.n : j0));
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int j = jb + 256 * u + r;
+          const int jn = j >= a.n ? j - a.n : j;
+          bool pos;
+          if (!have_lab) pos = jn == in;
+          else if (VEC) pos = lb[u][r] == lab_i;
+          else pos = j < a.N2 && a.labels[jn] == lab_i;
+          pos = pos && j < a.N2 && j != i;
+          const float ell = lg[u][r] - logD_i;
+          const float w = sp_weight(a.sp_mode, ell, a.gamma, a.inv_gamma);
+          s_l += pos ? w * ell : 0.f;
+          s_w += pos ? w : 0.f;
+          s_c += pos ? 1.f : 0.f;
+        }
+    }
+  }
+  s_l = wave_sum(s_l);
+  s_w = wave_sum(s_w);
+  s_c = wave_sum(s_c);
+  if (lane == 0) {
+    logD[i] = logD_i;
+    cnt[i] = s_c;
+    rowloss[i] = s_l;
+    W[i] = s_w;
   }
 }
 
@@ -415,6 +654,7 @@ static SupconArgs make_args(const SupconLayout& L, const float* ws, const float*
                             int sp_mode, float gamma) {
   SupconArgs a;
   a.ns = L.NS;
+  a.stamps = nullptr;
   a.P = ws + L.off_P;
   a.rn2 = ws + L.off_rn2;
   a.labels = labels;
@@ -449,6 +689,50 @@ static int launch_forward(const SupconLayout& L, SupconArgs a, float* ws, int co
   return 0;
 }
 
+static bool supcon_use_big(const SupconLayout& L, const float* mask) {
+  static const bool exact = getenv("SPCL_SUPCON_EXACT") != nullptr;  // A/B switch: keep the exact-f32 sweeps
+  return L.big && mask == nullptr && !exact;
+}
+
+template <int DP>
+static int launch_forward_big(const SupconLayout& L, SupconArgs a, float* ws, int correct_grad, float* out,
+                              hipStream_t st) {
+  const bf16_t* Ph = (const bf16_t*)(ws + L.off_Ph);
+  const bf16_t* Pm = (const bf16_t*)(ws + L.off_Pm);
+  float* Lmat = ws + L.off_L;
+  const double n2 = (double)L.N2p;
+  prof_cost(n2 * n2 * 4 + 2 * n2 * DP * 4, 2.0 * n2 * n2 * DP);  // logits written once; f32-equivalent FLOPs
+  static const bool env_stamps = getenv("SPCL_SUPCON_STAMPS") != nullptr;
+  const size_t nwg = (size_t)(L.N2p / 128) * L.CSB;
+  if (env_stamps) (void)hipMalloc(&a.stamps, nwg * 6 * sizeof(unsigned long long));  // debug only (synchronises)
+  SPCL_LAUNCH((supcon_logits_kernel<DP>), dim3(L.N2p / 128, L.CSB), dim3(256), (size_t)2 * 64 * DP * 2, st, a, Ph, Pm,
+                     Lmat);
+  if (a.stamps != nullptr) {
+    std::vector<unsigned long long> h(nwg * 6);
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(h.data(), a.stamps, h.size() * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(a.stamps);
+    a.stamps = nullptr;
+    double s6[6] = {0, 0, 0, 0, 0, 0};
+    for (size_t w = 0; w < nwg; ++w)
+      for (int k = 0; k < 6; ++k) s6[k] += (double)h[w * 6 + k] / nwg;
+    fprintf(stderr, "[supcon stamps] N2p=%d DP=%d wgs=%zu tiles/wg=%d | memtime ticks per wg (100 MHz): preamble %.0f, "
+                    "wait-wg %.0f, commit %.0f, compute %.0f, fold %.0f\n", L.N2p, DP, nwg, L.N2p / 64 / L.CSB, s6[0],
+            s6[1], s6[2], s6[3], s6[4]);
+  }
+  prof_cost(n2 * n2 * 4, 0.0);
+  if (L.n % 4 == 0)
+    SPCL_LAUNCH(supcon_rowpass_kernel<true>, dim3(L.N2p / 4), dim3(256), 0, st, a, (const float*)Lmat, L.CSB,
+                       ws + L.off_logD, ws + L.off_c, a.partA, a.partB);
+  else
+    SPCL_LAUNCH(supcon_rowpass_kernel<false>, dim3(L.N2p / 4), dim3(256), 0, st, a, (const float*)Lmat, L.CSB,
+                       ws + L.off_logD, ws + L.off_c, a.partA, a.partB);
+  SPCL_LAUNCH((supcon_fin_kernel<1>), dim3(1), dim3(1024), 0, st, a.partA, a.partB, 1, L.N2, L.N2p,
+                     ws + L.off_rowloss, ws + L.off_W, (const float*)(ws + L.off_c), (const float*)(ws + L.off_rn2),
+                     correct_grad, out);
+  return 0;
+}
+
 }  // namespace spcl
 
 using namespace spcl;
@@ -477,10 +761,16 @@ extern "C" int spcl_supcon_forward(const float* z1, const float* z2, const float
   SPCL_CHECK_ARG(temperature > 0.f, "supcon_forward: temperature must be > 0");
   hipStream_t st = (hipStream_t)stream;
   SupconLayout L = supcon_layout(n, d);
+  const bool big = supcon_use_big(L, mask);
   SPCL_LAUNCH(supcon_prep_kernel, dim3(L.N2p / 4), dim3(256), 0, st, z1, z2, n, d, L.N2p, L.DP,
-                     ws + L.off_P, ws + L.off_rn2);
+                     ws + L.off_P, ws + L.off_rn2, big ? (bf16_t*)(ws + L.off_Ph) : (bf16_t*)nullptr,
+                     big ? (bf16_t*)(ws + L.off_Pm) : (bf16_t*)nullptr);
   SupconArgs a = make_args(L, ws, labels, mask, temperature, sp_mode, gamma);
-  if (L.DP == 64) launch_forward<64>(L, a, ws, correct_grad, out, st);
+  if (big) {
+    if (L.DP == 64) launch_forward_big<64>(L, a, ws, correct_grad, out, st);
+    else if (L.DP == 128) launch_forward_big<128>(L, a, ws, correct_grad, out, st);
+    else launch_forward_big<256>(L, a, ws, correct_grad, out, st);
+  } else if (L.DP == 64) launch_forward<64>(L, a, ws, correct_grad, out, st);
   else if (L.DP == 128) launch_forward<128>(L, a, ws, correct_grad, out, st);
   else launch_forward<256>(L, a, ws, correct_grad, out, st);
   SPCL_LAUNCH_CHECK("supcon_forward");

@@ -70,7 +70,7 @@ def test_loss_mask_input(golden):
 
 
 @pytest.mark.parametrize("n,d,nlab", [(32, 256, 3), (30, 256, 10), (100, 128, 7), (512, 128, 3), (2048, 128, 512),
-                                      (33, 100, 4)])
+                                      (33, 100, 4), (700, 64, 5), (601, 200, 9), (2048, 128, 3)])
 @pytest.mark.parametrize("mname", ["supcon1", "soft_12_cg", "hard_1e6"])
 def test_loss_vs_oracle_seeded(n, d, nlab, mname):
     """Sizes up to BASELINE config E (2n=4096, d=128) against the fp32 oracle on the same seeded inputs."""
