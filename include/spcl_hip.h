@@ -43,6 +43,13 @@ const char* spcl_last_error(void);
  * sp_mode 0 = no self-pacing (SupConLoss1), 1 = hard, 2 = soft;  gamma = age parameter
  * ws      workspace of spcl_supcon_workspace_bytes(n,d) bytes (f32 aligned); holds the padded projections,
  *         the per-row statistics kept for backward and the column-split partials
+ * Two schedules, chosen by size (same results within the parity tolerance, same workspace contract):
+ *   2n < 1024, or an explicit `mask`: the [2n,2n] matrix is never materialised; every sweep recomputes its S tiles on the
+ *     exact-f32 MFMA (bitwise an fmaf chain) -- the training sizes are launch-latency bound either way;
+ *   2n >= 1024 (labels / SimCLR modes): the logits are formed ONCE on the bf16 matrix pipe from the two-term split
+ *     P = Ph + Pm (S ~ Ph Ph^T + Ph Pm^T + Pm Ph^T, logit error ~1e-5), written to ws as f32 [2n,2n] (rounded up to 128)
+ *     with the row sums fused in; the self-paced pass and the backward's H = G + G^T then stream that matrix
+ *     (SURVEY 8(d)'s "materialised" schedule: 67 MB at 2n = 4096).  SPCL_SUPCON_EXACT=1 forces the first schedule.
  * out     [8] f32: out[0]=loss out[1]=rho(downgrade ratio) out[2]=kappa(effective -dloss/drow scale)
  *                  out[3]=max|‖z‖-1| (is_normalized contract, contrast_loss3.py:20-22,154)
  */

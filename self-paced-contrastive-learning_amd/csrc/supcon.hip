@@ -57,7 +57,7 @@ static SupconLayout supcon_layout(int n, int d) {
   L.off_partA = o;    o += (size_t)prow * L.N2p;
   L.off_partB = o;    o += (size_t)prow * L.N2p;
   L.off_Ph = L.off_Pm = L.off_L = o;
-  if (L.big) {  // bf16 splits of P (2 x N2p x DP halves) and the logits [N2p][N2p]
+  if (L.big) {  // bf16 splits of P (N2p x DP halves each) and the logits [N2p][N2p]
     L.off_Ph = o;     o += (size_t)L.N2p * L.DP / 2;
     L.off_Pm = o;     o += (size_t)L.N2p * L.DP / 2;
     L.off_L = o;      o += (size_t)L.N2p * L.N2p;
@@ -105,6 +105,24 @@ __global__ __launch_bounds__(256) void supcon_prep_kernel(const float* __restric
   }
   s = wave_sum(s);
   if (lane == 0) rn2[row] = s;
+}
+
+// [N2p][DP] -> [DP][N2p] of one bf16 split (blockIdx.y) through an LDS tile of 64 rows: coalesced on both sides
+// (the backward's B operand wants 8 consecutive rows j of one feature column per lane)
+__global__ __launch_bounds__(256) void supcon_transpose_kernel(const bf16_t* __restrict__ Ph,
+                                                               const bf16_t* __restrict__ Pm, int N2p, int DP,
+                                                               bf16_t* __restrict__ PhT, bf16_t* __restrict__ PmT) {
+  __shared__ bf16_t t[64][256 + 2];  // +2 halves: a column walk hits 64 different banks
+  const bf16_t* src = blockIdx.y ? Pm : Ph;
+  bf16_t* dst = blockIdx.y ? PmT : PhT;
+  const int R0 = blockIdx.x * 64;
+  for (int c = threadIdx.x; c < 64 * DP; c += 256) {
+    const int r = c / DP, k = c - r * DP;
+    t[r][k] = src[(size_t)(R0 + r) * DP + k];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  for (int k = threadIdx.x >> 6; k < DP; k += 4) dst[(size_t)k * N2p + R0 + lane] = t[lane][k];
 }
 
 // max_i |p_i|^2 / t (the largest logit: the diagonal).  16-byte loads, four independent ones per trip: one memory
@@ -602,6 +620,137 @@ __global__ __launch_bounds__(256) void supcon_bwd_kernel(SupconArgs a, const flo
     }
 }
 
+// Large batches: H = G + G^T is formed elementwise from the MATERIALISED logits (symmetric, so one read serves G_ij
+// and G_ji) and the row / column statistics, split into two bf16 terms, and multiplied with the two-term split of P on
+// the bf16 matrix pipe:  dP_I += H_IJ P_J ~ Hh Ph + Hh Pm + Hl Ph.  A operand = H (lane: row i, 8 consecutive j),
+// B operand = P_J^T from the transposed splits [DP][N2p] staged in LDS (lane: feature column, 8 consecutive j).
+template <int DP>
+__global__ __launch_bounds__(256) void supcon_bwd_big_kernel(SupconArgs a, const bf16_t* __restrict__ PhT,
+                                                            const bf16_t* __restrict__ PmT,
+                                                            const float* __restrict__ Lmat,
+                                                            const float* __restrict__ out_fwd,
+                                                            float* __restrict__ dPpart /* [CSB][N2p][DP] */) {
+  constexpr int NT = DP / 32;
+  extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+  u32x4* tileT = (u32x4*)lds_raw;                   // [2 splits][DP rows d][8 chunks of 8 columns j]
+  float* colst = lds_raw + 2 * DP * 8 * 4;          // [4][64]: logD_j, A_j = kc_j W_j / D_j, kc_j = -kappa / c_j, label_j
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n32 = lane & 31, kh = lane >> 5;
+  const int I0 = blockIdx.x * 128 + wave * 32, i = I0 + n32;
+  const float kappa = out_fwd[2];
+  const int in = i >= a.n ? i - a.n : i;
+  const bool row_ok = i < a.N2;
+  const float lab_i = a.labels != nullptr ? (row_ok ? a.labels[in] : 0.f) : (float)in;
+  const float logD_i = a.logD[i], W_i = a.W[i];
+  const float kc_i = row_ok ? -kappa / a.cnt[i] : 0.f;
+  const float A_i = kc_i * W_i * __expf(-logD_i);
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[nt][v] = 0.f;
+
+  const int ntiles = a.N2p / 64;
+  // software pipeline: the next tile's P^T chunks, column statistics and this lane's 32 logits travel through
+  // registers while the current tile is multiplied
+  constexpr int NPRE = 2 * DP * 8 / 256;
+  u32x4 pre[NPRE];
+  f32x4 lpre[8];
+  float cpre[4];
+  auto fetch = [&](int jt) {
+#pragma unroll
+    for (int u = 0; u < NPRE; ++u) {
+      const int c = threadIdx.x + 256 * u;
+      const int sp = c / (DP * 8), rc = c - sp * DP * 8;
+      const int d = rc >> 3, ch = rc & 7;
+      pre[u] = *(const u32x4*)((sp ? PmT : PhT) + (size_t)d * a.N2p + jt * 64 + ch * 8);
+    }
+    const float* lrow = Lmat + (size_t)i * a.N2p + jt * 64 + 8 * kh;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      lpre[2 * ks] = *(const f32x4*)(lrow + 16 * ks);
+      lpre[2 * ks + 1] = *(const f32x4*)(lrow + 16 * ks + 4);
+    }
+    if (threadIdx.x < 64) {
+      const int j = jt * 64 + threadIdx.x;
+      const bool ok = j < a.N2;
+      const int jn = j >= a.n ? j - a.n : j;
+      const float kc = ok ? -kappa / a.cnt[j] : 0.f;
+      cpre[0] = a.logD[j];
+      cpre[1] = kc * a.W[j] * __expf(-cpre[0]);
+      cpre[2] = kc;
+      cpre[3] = a.labels != nullptr ? (ok ? a.labels[jn] : 0.f) : (float)jn;
+    }
+  };
+  fetch(blockIdx.y);
+  for (int jt = blockIdx.y; jt < ntiles; jt += gridDim.y) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NPRE; ++u) {
+      const int c = threadIdx.x + 256 * u;
+      const int sp = c / (DP * 8), rc = c - sp * DP * 8;
+      const int d = rc >> 3, ch = rc & 7;
+      tileT[(sp * DP + d) * 8 + (ch ^ ((d >> 1) & 7))] = pre[u];
+    }
+    if (threadIdx.x < 64) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) colst[64 * q + threadIdx.x] = cpre[q];
+    }
+    f32x4 lcur[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) lcur[q] = lpre[q];
+    __syncthreads();
+    if (jt + (int)gridDim.y < ntiles) fetch(jt + gridDim.y);
+    const bool edge = (I0 < jt * 64 + 64 && jt * 64 < I0 + 32) || jt * 64 + 64 > a.N2 || I0 + 32 > a.N2;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int jl = 16 * ks + 8 * kh;  // this lane's 8 columns inside the tile
+      const f32x4 l0 = lcur[2 * ks], l1 = lcur[2 * ks + 1];
+      float hv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float lg = e < 4 ? l0[e] : l1[e - 4];
+        // G_ij = kc_i (pos w_ij - W_i exp(ell_ij)) with exp(ell_ij) = exp(logit) / D_i: one exponential serves both
+        // G_ij and G_ji, the row / column factors A = kc W / D are folded once per row / column
+        const float logD_j = colst[jl + e], A_j = colst[64 + jl + e], kc_j = colst[128 + jl + e];
+        const bool pos = colst[192 + jl + e] == lab_i;
+        const float w_ij = pos ? sp_weight(a.sp_mode, lg - logD_i, a.gamma, a.inv_gamma) : 0.f;
+        const float w_ji = pos ? sp_weight(a.sp_mode, lg - logD_j, a.gamma, a.inv_gamma) : 0.f;
+        float h = fmaf(kc_i, w_ij, fmaf(kc_j, w_ji, -__expf(lg) * (A_i + A_j)));
+        if (edge) {
+          const int j = jt * 64 + jl + e;
+          if (j == i || j >= a.N2 || !row_ok) h = 0.f;
+        }
+        hv[e] = h;
+      }
+      bf16x8v hh, hl;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const __bf16 b = (__bf16)hv[e];
+        hh[e] = b;
+        hl[e] = (__bf16)(hv[e] - (float)b);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int d = 32 * nt + n32;
+        const int key = (d >> 1) & 7;
+        const bf16x8v bh = __builtin_bit_cast(bf16x8v, tileT[d * 8 + ((2 * ks + kh) ^ key)]);
+        const bf16x8v bm = __builtin_bit_cast(bf16x8v, tileT[(DP + d) * 8 + ((2 * ks + kh) ^ key)]);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hh, bh, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hh, bm, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hl, bh, acc[nt], 0, 0, 0);
+      }
+    }
+  }
+  // acc[nt][v] = dP[I0 + 8 (v / 4) + 4 kh + v % 4][32 nt + n32]
+  float* dst = dPpart + ((size_t)blockIdx.y * a.N2p + I0) * DP + n32;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) dst[(size_t)(8 * (v >> 2) + 4 * kh + (v & 3)) * DP + 32 * nt] = acc[nt][v];
+}
+
 __global__ __launch_bounds__(256) void supcon_bwd_fin_kernel(const float* __restrict__ dPpart, int CS, int n, int d,
                                                              int N2p, int DP, float t,
                                                              const float* __restrict__ grad_out,
@@ -745,7 +894,9 @@ extern "C" size_t spcl_supcon_workspace_bytes(int n, int d) {
 extern "C" size_t spcl_supcon_bwd_workspace_bytes(int n, int d) {
   if (n <= 0 || d <= 0 || d > 256) return 0;
   SupconLayout L = supcon_layout(n, d);
-  return (size_t)L.CS * L.N2p * L.DP * sizeof(float);
+  // column-split partials of dP, then (large batches) the transposed bf16 splits of P [2][DP][N2p]
+  return (size_t)(L.CS > L.CSB ? L.CS : L.CSB) * L.N2p * L.DP * sizeof(float) +
+         (L.big ? (size_t)2 * L.N2p * L.DP * sizeof(bf16_t) : 0);
 }
 
 extern "C" int spcl_supcon_forward(const float* z1, const float* z2, const float* labels, const float* mask, int n,
@@ -765,6 +916,7 @@ extern "C" int spcl_supcon_forward(const float* z1, const float* z2, const float
   SPCL_LAUNCH(supcon_prep_kernel, dim3(L.N2p / 4), dim3(256), 0, st, z1, z2, n, d, L.N2p, L.DP,
                      ws + L.off_P, ws + L.off_rn2, big ? (bf16_t*)(ws + L.off_Ph) : (bf16_t*)nullptr,
                      big ? (bf16_t*)(ws + L.off_Pm) : (bf16_t*)nullptr);
+
   SupconArgs a = make_args(L, ws, labels, mask, temperature, sp_mode, gamma);
   if (big) {
     if (L.DP == 64) launch_forward_big<64>(L, a, ws, correct_grad, out, st);
@@ -786,14 +938,33 @@ extern "C" int spcl_supcon_backward(const float* labels, const float* mask, int 
   hipStream_t st = (hipStream_t)stream;
   SupconLayout L = supcon_layout(n, d);
   SupconArgs a = make_args(L, ws_fwd, labels, mask, temperature, sp_mode, gamma);
-  dim3 grid(L.N2p / 64, L.CS);
-  size_t lds = (size_t)64 * L.DP * sizeof(float);
-  if (L.DP == 64) SPCL_LAUNCH((supcon_bwd_kernel<64>), grid, dim3(256), lds, st, a, out_fwd, ws_bwd);
-  else if (L.DP == 128) SPCL_LAUNCH((supcon_bwd_kernel<128>), grid, dim3(256), lds, st, a, out_fwd, ws_bwd);
-  else SPCL_LAUNCH((supcon_bwd_kernel<256>), grid, dim3(256), lds, st, a, out_fwd, ws_bwd);
+  int nsplit = L.CS;
+  if (supcon_use_big(L, mask)) {  // the forward of this call materialised the logits (same decision, same workspace)
+    bf16_t* PhT = (bf16_t*)(ws_bwd + (size_t)(L.CS > L.CSB ? L.CS : L.CSB) * L.N2p * L.DP);
+    bf16_t* PmT = PhT + (size_t)L.N2p * L.DP;
+    const float* Lmat = ws_fwd + L.off_L;
+    SPCL_LAUNCH(supcon_transpose_kernel, dim3(L.N2p / 64, 2), dim3(256), 0, st,
+                       (const bf16_t*)(ws_fwd + L.off_Ph), (const bf16_t*)(ws_fwd + L.off_Pm), L.N2p, L.DP, PhT, PmT);
+    dim3 grid(L.N2p / 128, L.CSB);
+    const size_t lds = (size_t)2 * L.DP * 8 * 16 + 4 * 64 * sizeof(float);
+    const double n2 = (double)L.N2p;
+    prof_cost(n2 * n2 * 4 + 2 * n2 * L.DP * 4, 2.0 * n2 * n2 * L.DP);
+    if (L.DP == 64) SPCL_LAUNCH((supcon_bwd_big_kernel<64>), grid, dim3(256), lds, st, a, (const bf16_t*)PhT, (const bf16_t*)PmT, Lmat, out_fwd, ws_bwd);
+    else if (L.DP == 128)
+      SPCL_LAUNCH((supcon_bwd_big_kernel<128>), grid, dim3(256), lds, st, a, (const bf16_t*)PhT, (const bf16_t*)PmT, Lmat, out_fwd,
+                         ws_bwd);
+    else SPCL_LAUNCH((supcon_bwd_big_kernel<256>), grid, dim3(256), lds, st, a, (const bf16_t*)PhT, (const bf16_t*)PmT, Lmat, out_fwd, ws_bwd);
+    nsplit = L.CSB;
+  } else {
+    dim3 grid(L.N2p / 64, L.CS);
+    size_t lds = (size_t)64 * L.DP * sizeof(float);
+    if (L.DP == 64) SPCL_LAUNCH((supcon_bwd_kernel<64>), grid, dim3(256), lds, st, a, out_fwd, ws_bwd);
+    else if (L.DP == 128) SPCL_LAUNCH((supcon_bwd_kernel<128>), grid, dim3(256), lds, st, a, out_fwd, ws_bwd);
+    else SPCL_LAUNCH((supcon_bwd_kernel<256>), grid, dim3(256), lds, st, a, out_fwd, ws_bwd);
+  }
   size_t total = (size_t)2 * n * d;
   SPCL_LAUNCH(supcon_bwd_fin_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                     (const float*)ws_bwd, L.CS, n, d, L.N2p, L.DP, temperature, grad_out, dz1, dz2);
+                     (const float*)ws_bwd, nsplit, n, d, L.N2p, L.DP, temperature, grad_out, dz1, dz2);
   SPCL_LAUNCH_CHECK("supcon_backward");
   return SPCL_OK;
 }
