@@ -45,7 +45,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-bs", type=int, default=8, help="batch of the CPU-oracle sample (bounded work)")
-    ap.add_argument("--workload", default="pretrain", choices=["pretrain", "contrastive", "finetune"])
+    ap.add_argument("--workload", default="pretrain", choices=["pretrain", "contrastive", "finetune", "prostate"],
+                    help="pretrain = BASELINE configs[1] (the metric); prostate = configs[3] shape: 256x256, bs=64/GPU, "
+                         "three self-paced hooks (partition, patient, self) sharing one encoder pass")
     return ap.parse_args()
 
 
@@ -62,9 +64,16 @@ def build_step(args, device, rank, world):
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model = UNet(input_dim=1, num_classes=4, max_channel=256, momentum=0.1).to(device)
     model.set_compute_dtype(dtype)
-    hook = create_sp_infonce_hooks(model=model, feature_names="Conv5", weights=1.0, contrast_ons="partition",
-                                   begin_values=3.0, end_values=70.0, mode="soft", max_epoch=80, p=0.5,
-                                   correct_grad=True, data_name="acdc", sync_checks=False).to(device)
+    prostate = args.workload == "prostate"
+    if prostate:  # three meta-labels combined on the same feature (run_self_paced_acdc:61-70 shape, hooks/creator.py:102-124)
+        hook = create_sp_infonce_hooks(model=model, feature_names=["Conv5"] * 3, weights=[1.0, 1.0, 1.0],
+                                       contrast_ons=["partition", "patient", "self"], begin_values=3.0, end_values=70.0,
+                                       mode="soft", max_epoch=80, p=0.5, correct_grad=True, data_name="prostate",
+                                       sync_checks=False).to(device)
+    else:
+        hook = create_sp_infonce_hooks(model=model, feature_names="Conv5", weights=1.0, contrast_ons="partition",
+                                       begin_values=3.0, end_values=70.0, mode="soft", max_epoch=80, p=0.5,
+                                       correct_grad=True, data_name="acdc", sync_checks=False).to(device)
     for sub in hook._hooks:  # mid-schedule age parameter (epoch 40 of 80: gamma = 3 + 67*sqrt(0.5) = 50.4): at epoch 0
         sub._scheduler.epoch = 40  # gamma=3 < log(63) zeroes every weight at random init, i.e. a degenerate loss
     ddp.broadcast_state(model, hook)
@@ -76,7 +85,8 @@ def build_step(args, device, rank, world):
     flat = ddp.FlatParams(params + hparams)  # one flat parameter + one flat gradient bucket (all-reduced when N>1)
     from spcl_amd.optim import FusedRAdam
     opt = FusedRAdam([flat.param], lr=5e-7 * 400, weight_decay=1e-5)  # torch.optim.RAdam semantics, HIP kernel
-    loader = SyntheticPretrainLoader(bs=args.bs, size=args.size, device=device, seed=1234 + rank, resident=True)
+    loader = SyntheticPretrainLoader(bs=args.bs, size=args.size, device=device, seed=1234 + rank, resident=True,
+                                     meta="prostate" if prostate else "acdc")
     epocher = PretrainEncoderEpocher(model=model, optimizer=opt, chain_dataloader=loader, num_batches=10 ** 9,
                                      device=device, inference_until="Conv5", flat_params=flat)
     epocher.add_hooks([hook()])
@@ -276,6 +286,11 @@ def main():
     if args.workload == "finetune":
         return bench_finetune(args, device)
 
+    if args.workload == "prostate":  # BASELINE.json configs[3] shape unless overridden on the command line
+        if "--bs" not in sys.argv:
+            args.bs = 64
+        if "--size" not in sys.argv:
+            args.size = 256
     step, epocher, nparams = build_step(args, device, rank, world)
     run = step
     used_graph = False
@@ -318,14 +333,19 @@ def main():
 
     ms = elapsed / args.steps * 1e3
     value = args.bs * world * args.steps / elapsed
+    prostate = args.workload == "prostate"
     line = {
-        "metric": "pretrain slices/sec/node (UNet+InfoNCE, 224^2, bs=32/GPU)", "value": round(value, 1),
+        "metric": ("pretrain slices/sec/node (UNet + 3 combined InfoNCE hooks, 256^2, bs=64/GPU)" if prostate else
+                   "pretrain slices/sec/node (UNet+InfoNCE, 224^2, bs=32/GPU)"), "value": round(value, 1),
         "unit": "slices/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "BASELINE.json configs[1]: self-paced pretrain step, UNet base (max_channel=256) encoder "
-                               "to Conv5 + ProjectionHead(256,256,256) + SelfPacedSupConLoss(soft, partition labels, "
-                               "correct_grad) fwd+bwd + RAdam" + (" + flat RCCL grad all-reduce" if world > 1 else ""),
+        "config": {"workload": ("BASELINE.json configs[3] shape (SURVEY row N4): one encoder pass to Conv5, three "
+                                "self-paced hooks (partition / patient / self meta-labels, own projector each) summed, "
+                                "fwd+bwd + RAdam" if prostate else
+                                "BASELINE.json configs[1]: self-paced pretrain step, UNet base (max_channel=256) encoder "
+                                "to Conv5 + ProjectionHead(256,256,256) + SelfPacedSupConLoss(soft, partition labels, "
+                                "correct_grad) fwd+bwd + RAdam") + (" + flat RCCL grad all-reduce" if world > 1 else ""),
                    "slices_per_gpu": args.bs, "images_per_gpu_step": 2 * args.bs, "image": f"1x{args.size}x{args.size}",
                    "global_batch": args.bs * world, "parallelism": f"dp{world}", "params": nparams,
                    "hipgraph": used_graph},

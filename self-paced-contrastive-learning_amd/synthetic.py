@@ -11,14 +11,23 @@ def acdc_like_meta(bs: int):
     return filenames, partitions, groups
 
 
+def prostate_like_meta(bs: int, partition_num: int = 8):
+    """Prostate-like batch composition (BASELINE.json configs[3]): scans "CaseNN" cut into ``partition_num`` slice
+    partitions; group strings "CaseNN_k" (patient id before the underscore, semi_seg/hooks/utils.py:53-56)."""
+    partitions = [str(i % partition_num) for i in range(bs)]
+    groups = [f"Case{i // partition_num:02d}_{i % partition_num}" for i in range(bs)]
+    filenames = [f"Case{i // partition_num:02d}_{i % partition_num:03d}" for i in range(bs)]
+    return filenames, partitions, groups
+
+
 class SyntheticPretrainLoader:
     """Infinite iterator; ``resident=True`` re-yields ONE pre-generated device batch (inputs already in HBM when the
     timed region starts), otherwise draws a fresh batch on device every step."""
 
-    def __init__(self, bs=32, size=224, channels=1, device="cuda", seed=1234, resident=True):
+    def __init__(self, bs=32, size=224, channels=1, device="cuda", seed=1234, resident=True, meta="acdc"):
         self.bs, self.size, self.channels, self.device, self.resident = bs, size, channels, device, resident
         self.gen = torch.Generator(device=device).manual_seed(seed)
-        self.meta = acdc_like_meta(bs)
+        self.meta = prostate_like_meta(bs) if meta == "prostate" else acdc_like_meta(bs)
         self._batch = self._draw() if resident else None
 
     def _draw(self):

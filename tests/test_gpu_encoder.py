@@ -239,6 +239,63 @@ def test_gradient_sinks_fill_the_flat_bucket_in_place():
     assert _relerr(f3.cpu().numpy(), f2.cpu().numpy()) < 1e-6
 
 
+def test_three_combined_hooks_share_one_encoder_pass_fp32():
+    """SURVEY row N4 / BASELINE configs[3] shape: three self-paced hooks on Conv5 (partition, patient, self meta-labels,
+    weights 1 / 0.5 / 0.25, each with its own projector) through the pre-train epocher's step_compute, against the oracle:
+    ONE encoder forward, three projector + loss evaluations, weighted sum, one backward."""
+    import spcl_amd  # noqa
+    from spcl_amd import ddp
+    from spcl_amd.semi_seg.epochers import PretrainEncoderEpocher
+    from spcl_amd.semi_seg.hooks import create_sp_infonce_hooks
+    from spcl_amd.synthetic import prostate_like_meta
+    net, sd = _unet(128, 11)
+    ons, weights, bs = ["partition", "patient", "self"], [1.0, 0.5, 0.25], 16
+    hook = create_sp_infonce_hooks(model=net, feature_names=["Conv5"] * 3, weights=weights, contrast_ons=ons,
+                                   begin_values=8.0, end_values=8.0, mode="soft", max_epoch=10, p=0.5, correct_grad=True,
+                                   data_name="prostate", sync_checks=True).cuda()
+    for name in net.decoder_names:
+        getattr(net, "_" + name).requires_grad_(False)
+    params = [p for p in net.parameters() if p.requires_grad] + list(hook.parameters())
+    flat = ddp.FlatParams(params)
+    g = torch.Generator().manual_seed(5)
+    img, img_tf = torch.rand(bs, 1, 32, 32, generator=g), torch.rand(bs, 1, 32, 32, generator=g)
+    filenames, partitions, groups = prostate_like_meta(bs, partition_num=4)
+    tgt = torch.zeros(bs, 1, 1, 1, dtype=torch.long)
+    batch = ((img.cuda(), img_tf.cuda(), tgt.cuda(), tgt.cuda()), filenames, (partitions, groups))
+    opt = torch.optim.SGD([flat.param], lr=0.0)
+    ep = PretrainEncoderEpocher(model=net, optimizer=opt, chain_dataloader=iter([batch]), num_batches=1, device="cuda",
+                                inference_until="Conv5", flat_params=flat)
+    # projector weights BEFORE the step, for the oracle
+    heads = [{k: v.detach().cpu().clone() for k, v in h._projector.state_dict().items()} for h in hook._hooks]
+    ep.add_hooks([hook()])
+    net.train()
+    with ep.meters.focus_on(ep.meter_focus):
+        loss = ep.step_compute(batch, seed=3)
+    # ---- oracle: view 2 is flipped by the epocher with the seeded per-sample flips
+    flips = O.random_flip_decisions(3, bs)
+    x2 = O.apply_flips(img_tf, flips)
+    osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+           for k, v in sd.items()}
+    feat = O.encoder_forward(torch.cat([img, x2], 0), osd, "Conv5", train=True, momentum=0.1)
+    total, leaves = 0.0, {}
+    for hi, (on, w, psd) in enumerate(zip(ons, weights, heads)):
+        psd = {k: v.clone().requires_grad_(True) for k, v in psd.items()}
+        z = O.projector_forward(feat, psd)
+        labels = O.get_label(on, "prostate", partitions, groups)
+        r = O.supcon_loss(z[:bs], z[bs:], labels, gamma=8.0, mode="soft", correct_grad=True)
+        total = total + w * r["loss"]
+        leaves.update({f"h{hi}.{k}": v for k, v in psd.items()})
+    total.backward()
+    np.testing.assert_allclose(loss.item(), float(total.detach()), rtol=2e-4)
+    named = dict(net.named_parameters())
+    for k, p in named.items():
+        if p.requires_grad and osd[k].grad is not None:
+            assert _relerr(p.grad.cpu().numpy(), osd[k].grad.numpy()) < 5e-3, k
+    for hi, h in enumerate(hook._hooks):
+        for k, p in h._projector.named_parameters():
+            assert _relerr(p.grad.cpu().numpy(), leaves[f"h{hi}.{k}"].grad.numpy()) < 5e-3, (hi, k)
+
+
 def test_bn_kat5_statistics():
     """KAT-5: after the first block the fused BN has mean 0 / biased var 1 before the affine; running_var uses the
     unbiased variance with momentum 0.1."""
