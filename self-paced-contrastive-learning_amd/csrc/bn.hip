@@ -484,9 +484,12 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_fin_kernel(const float* __rest
                                                              const float* __restrict__ invstd,
                                                              const float* __restrict__ scale,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                             float* __restrict__ ab) {
+                                                             float* __restrict__ ab, float* __restrict__ zero_fill,
+                                                             int nzero) {
   __shared__ float red[2][4];
   const int c = blockIdx.x;
+  if (c == 0)  // scratch the next launch wants zeroed (the image-wgrad pass's zero row): saves a memset launch
+    for (int z = threadIdx.x; z < nzero; z += 256) zero_fill[z] = 0.f;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll 4
@@ -746,17 +749,17 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
     SPCL_LAUNCH((bnrelu_bwd_reduce_lin_kernel<T>), dim3(nwg), dim3(256), 0, st, (const T*)y, (const T*)dact, npix,
                        CS, mean, invstd, scale, shift, partial);
   }
+  float* zrow = ab + 2 * CS + (size_t)IMG_WGRAD_WG * 9 * CS;  // [W] zeros (image-wgrad pass only, see below)
   SPCL_LAUNCH(bnrelu_bwd_fin_kernel, dim3(CS), dim3(256), 0, st, (const float*)partial, nwg, C, CS,
-                     M, training, mean, invstd, scale, dgamma, dbeta, ab);
+                     M, training, mean, invstd, scale, dgamma, dbeta, ab, img != nullptr ? zrow : (float*)nullptr,
+                     img != nullptr ? W : 0);
   prof_cost(2.0 * tb + gb, 0.0);
   if (pool) {
     SPCL_LAUNCH((bnrelu_bwd_pool_kernel<T, true>), dim3(rows < STREAM_MAX_WG ? rows : STREAM_MAX_WG), dim3(256), 0, st, (const T*)y,
                        (const T*)dact, (const T*)dpool, N, H, W, CS, mean, invstd, scale, shift, (const float*)ab,
                        (float*)nullptr, (T*)dy);
   } else if (img != nullptr) {  // first conv of a one-channel image block: dy is consumed in registers by its dW
-    float* wpart = ab + 2 * CS;                              // [IMG_WGRAD_WG][9][CS]
-    float* zrow = wpart + (size_t)IMG_WGRAD_WG * 9 * CS;     // [W] zeros: the image row above / below the image
-    (void)hipMemsetAsync(zrow, 0, (size_t)W * sizeof(float), st);
+    float* wpart = ab + 2 * CS;  // [IMG_WGRAD_WG][9][CS];  zrow = the image row above / below the image
     static const int want = getenv("SPCL_IMGWG_WG") ? atoi(getenv("SPCL_IMGWG_WG")) : 1280;  // 5 resident per CU
     const int cap = want < IMG_WGRAD_WG ? (want > 0 ? want : 1) : IMG_WGRAD_WG;
     const int g = N * H < cap ? N * H : cap;
