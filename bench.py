@@ -64,7 +64,7 @@ def build_step(args, device, rank, world):
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model = UNet(input_dim=1, num_classes=4, max_channel=256, momentum=0.1).to(device)
     model.set_compute_dtype(dtype)
-    prostate = args.workload == "prostate"
+    prostate = getattr(args, "workload", "pretrain") == "prostate"
     if prostate:  # three meta-labels combined on the same feature (run_self_paced_acdc:61-70 shape, hooks/creator.py:102-124)
         hook = create_sp_infonce_hooks(model=model, feature_names=["Conv5"] * 3, weights=[1.0, 1.0, 1.0],
                                        contrast_ons=["partition", "patient", "self"], begin_values=3.0, end_values=70.0,
@@ -200,8 +200,9 @@ def measure_roofline(step, args):
         peak_tf = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
         traffic = None
         try:  # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, KiB -> bytes)
-            pm = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_hbm_traffic.json")))
-            traffic = pm[sym]["hbm_bytes_per_launch_corrected"]
+            import glob
+            latest = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_hbm_traffic.json")))[-1]  # newest round
+            traffic = json.load(open(latest))[sym]["hbm_bytes_per_launch_corrected"]
         except Exception:  # noqa: BLE001
             pass
         if g["hbm_t"] >= g["mfma_t"]:

@@ -1,6 +1,6 @@
 """HBM bytes per launch of every libspcl kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; KiB).
 
-    python tools/pmc_traffic.py <dir of FETCH_SIZE pass> <dir of WRITE_SIZE pass> profiles/r01_pmc_hbm_traffic.json
+    python tools/pmc_traffic.py <dir of FETCH_SIZE pass> <dir of WRITE_SIZE pass> profiles/r01_k_pmc_hbm_traffic.json
 
 gfx950 correction (MI355X_MICROARCH.md, HBM / rocprofv3 section): FETCH_SIZE reports half of the bytes of wide
 coalesced streaming reads -> doubled."""
