@@ -322,7 +322,10 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st) {
   const int ntn = c.CoutS / 16, KC = conv_kc(c.CinK);
   static const int env_nt1 = getenv("SPCL_CONV_FAST_NT1") ? atoi(getenv("SPCL_CONV_FAST_NT1")) : 0;
   int NT = ntn >= 2 ? 2 : 1;
-  if (env_nt1 && KC == 64 && ntn == 2) NT = 1;
+  if (env_nt1 == 1 && KC == 64 && ntn == 2) NT = 1;
+  // 64 -> 64 channels: four one-n-tile waves when the loader also applies BN+ReLU (more lanes for the transform:
+  // Conv3.b forward 38 -> 30 us) and on the small images; two two-n-tile waves for the plain 56^2 dgrad
+  if (KC == 64 && ntn == 4 && env_nt1 != 3 && (c.in_mode == 1 || c.H <= 28)) NT = 1;
   int nw = ntn / NT;
   if (nw > 4) nw = 4;
   if (ntn % (NT * nw) != 0) return false;
@@ -346,6 +349,7 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st) {
   SPCL_FAST_CASE(64, 7, 2, 1)   // Conv3.a dgrad (64 -> 32)
   SPCL_FAST_CASE(64, 7, 1, 2)   //   "   as two one-n-tile waves
   SPCL_FAST_CASE(64, 7, 2, 2)   // Conv3.b, Conv4.a dgrad
+  SPCL_FAST_CASE(64, 7, 1, 4)   //   "   as four one-n-tile waves
   SPCL_FAST_CASE(64, 7, 2, 4)   // Conv4.a forward, Conv4.b, Conv5 (7x14 tiles: 2 per 14x14 image)
 #undef SPCL_FAST_CASE
   return false;

@@ -296,6 +296,67 @@ def test_three_combined_hooks_share_one_encoder_pass_fp32():
             assert _relerr(p.grad.cpu().numpy(), leaves[f"h{hi}.{k}"].grad.numpy()) < 5e-3, (hi, k)
 
 
+def test_pretrain_loss_curve_matches_oracle_over_steps_fp32():
+    """Six consecutive pre-train steps (encoder -> tap -> projector -> self-paced loss -> backward -> RAdam on the flat
+    parameter, fresh batch and flip seed every step) against the oracle driven by torch.optim.RAdam on CPU: the loss curve
+    and the parameters after the last step agree within fp32 tolerance (the north star's "contrastive loss curve")."""
+    import spcl_amd  # noqa
+    from spcl_amd import ddp
+    from spcl_amd.optim import FusedRAdam
+    from spcl_amd.semi_seg.epochers import PretrainEncoderEpocher
+    from spcl_amd.semi_seg.hooks import create_sp_infonce_hooks
+    from spcl_amd.synthetic import acdc_like_meta
+    net, sd = _unet(128, 21)
+    bs, steps, lr, wd, gamma = 12, 6, 2e-3, 1e-5, 10.0
+    hook = create_sp_infonce_hooks(model=net, feature_names="Conv5", weights=1.0, contrast_ons="partition",
+                                   begin_values=gamma, end_values=gamma, mode="soft", max_epoch=10, p=0.5,
+                                   correct_grad=True, data_name="acdc", sync_checks=True).cuda()
+    for name in net.decoder_names:
+        getattr(net, "_" + name).requires_grad_(False)
+    enc_names = [k for k, p in net.named_parameters() if p.requires_grad]
+    head = hook._hooks[0]._projector
+    psd0 = {k: v.detach().cpu().clone() for k, v in head.state_dict().items()}
+    flat = ddp.FlatParams([p for p in net.parameters() if p.requires_grad] + list(hook.parameters()))
+    opt = FusedRAdam([flat.param], lr=lr, weight_decay=wd)
+    filenames, partitions, groups = acdc_like_meta(bs)
+    g = torch.Generator().manual_seed(17)
+    batches = [(torch.rand(bs, 1, 32, 32, generator=g), torch.rand(bs, 1, 32, 32, generator=g)) for _ in range(steps)]
+    tgt = torch.zeros(bs, 1, 1, 1, dtype=torch.long).cuda()
+    ep = PretrainEncoderEpocher(model=net, optimizer=opt, chain_dataloader=iter([]), num_batches=steps, device="cuda",
+                                inference_until="Conv5", flat_params=flat)
+    ep.add_hooks([hook()])
+    net.train()
+    curve = []
+    with ep.meters.focus_on(ep.meter_focus):
+        for k, (a, b) in enumerate(batches):
+            batch = ((a.cuda(), b.cuda(), tgt, tgt), filenames, (partitions, groups))
+            curve.append(float(ep.step(batch, seed=100 + k).detach()))
+    # ---- oracle
+    osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+           for k, v in sd.items()}
+    opsd = {k: v.clone().requires_grad_(True) for k, v in psd0.items()}
+    leaves = [osd[k] for k in enc_names] + [opsd[k] for k, _ in head.named_parameters()]
+    oopt = torch.optim.RAdam(leaves, lr=lr, weight_decay=wd)
+    labels = O.get_label("partition", "acdc", partitions, groups)
+    ocurve = []
+    for k, (a, b) in enumerate(batches):
+        x2 = O.apply_flips(b, O.random_flip_decisions(100 + k, bs))
+        feat = O.encoder_forward(torch.cat([a, x2], 0), osd, "Conv5", train=True, momentum=0.1)
+        z = O.projector_forward(feat, opsd)
+        r = O.supcon_loss(z[:bs], z[bs:], labels, gamma=gamma, mode="soft", correct_grad=True)
+        oopt.zero_grad()
+        r["loss"].backward()
+        oopt.step()
+        ocurve.append(float(r["loss"].detach()))
+    np.testing.assert_allclose(curve, ocurve, rtol=2e-3)
+    assert abs(curve[-1] - curve[0]) > 1e-3  # the parameters really moved
+    named = dict(net.named_parameters())
+    for k in enc_names:
+        delta = (osd[k].detach() - sd[k]).abs().max().item()
+        err = (named[k].detach().cpu() - osd[k].detach()).abs().max().item()
+        assert err < 0.05 * delta + 1e-6, (k, err, delta)
+
+
 def test_bn_kat5_statistics():
     """KAT-5: after the first block the fused BN has mean 0 / biased var 1 before the affine; running_var uses the
     unbiased variance with momentum 0.1."""
