@@ -19,7 +19,7 @@ namespace spcl {
 struct SupconLayout {
   int n, d, N2, N2p, DP, CS, NS;
   int big, CSB;  // large batches: logits materialised once by split-bf16 MFMA (CSB column splits), see below
-  size_t off_P, off_rn2, off_logD, off_c, off_W, off_rowloss, off_partA, off_partB, off_Ph, off_Pm, off_L, total;
+  size_t off_P, off_rn2, off_logD, off_c, off_W, off_rowloss, off_partA, off_partB, off_Ph, off_Pm, off_L, off_dz, total;
 };
 constexpr int SUPCON_BIG_N2 = 1024;  // from this many rows on the forward materialises the logits
 
@@ -62,6 +62,8 @@ static SupconLayout supcon_layout(int n, int d) {
     L.off_Pm = o;     o += (size_t)L.N2p * L.DP / 2;
     L.off_L = o;      o += (size_t)L.N2p * L.N2p;
   }
+  L.off_dz = o;  // training sizes (one 64-row block): dLoss/dP for a unit upstream gradient, left by the forward
+  if (!L.big && L.N2p == 64) o += (size_t)L.N2p * L.DP;
   L.total = o;
   return L;
 }
@@ -260,6 +262,238 @@ __global__ __launch_bounds__(256) void supcon_sweep_kernel(SupconArgs a) {
     a.partA[(size_t)blockIdx.y * a.N2p + i] = acc0;
     a.partB[(size_t)blockIdx.y * a.N2p + i] = acc1;
   }
+}
+
+// ------------------------------------------------------------------------------------------------ training sizes
+// 2n <= 64 (bs <= 32 per GPU): the whole loss is ONE workgroup and ONE launch -- padding + row norms, the S tiles on the
+// exact-f32 MFMA (kept in registers: 16 rows x 64 columns per wave), row sums, self-paced weights, the final scalars,
+// and dLoss/dP for a unit upstream gradient (backward then is one scaling launch).  Same arithmetic per element as the
+// sweep kernels; the seven launches they take at this size are latency, not work.
+template <int DP>
+__global__ __launch_bounds__(256) void supcon_small_kernel(const float* __restrict__ z1, const float* __restrict__ z2,
+                                                          int d, SupconArgs a, float* __restrict__ P_out,
+                                                          float* __restrict__ rn2_out, float* __restrict__ logD_out,
+                                                          float* __restrict__ cnt_out, float* __restrict__ W_out,
+                                                          float* __restrict__ rowloss_out, int correct_grad,
+                                                          float* __restrict__ out, float* __restrict__ dz_unit) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [64][DP] swizzled P, then 4 x [64] statistics
+  float* st_rn2 = lds + 64 * DP;
+  float* st_logD = st_rn2 + 64;
+  float* st_W = st_logD + 64;
+  float* st_kc = st_W + 64;
+  double* red = (double*)(st_kc + 64);  // [4 waves][4]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int I0 = wave * 16, i = I0 + r16;
+
+  // ---- padded P into LDS (and to the workspace for the lazily materialised taps), squared row norms
+  {
+    constexpr int KPL = DP / 64;
+    float v[16][KPL];
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      const int row = I0 + rr;
+      const float* src = row < a.n ? z1 + (size_t)row * d : (row < a.N2 ? z2 + (size_t)(row - a.n) * d : nullptr);
+#pragma unroll
+      for (int q = 0; q < KPL; ++q) {
+        const int k = lane + 64 * q;
+        v[rr][q] = (src != nullptr && k < d) ? src[k] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      const int row = I0 + rr;
+      float s2 = 0.f;
+#pragma unroll
+      for (int q = 0; q < KPL; ++q) {
+        const int k = lane + 64 * q;
+        lds[row * DP + ((((k >> 2) ^ (row & 15)) << 2) | (k & 3))] = v[rr][q];
+        P_out[(size_t)row * DP + k] = v[rr][q];
+        s2 += v[rr][q] * v[rr][q];
+      }
+      s2 = wave_sum(s2);
+      if (lane == 0) {
+        st_rn2[row] = s2;
+        rn2_out[row] = s2;
+      }
+    }
+  }
+  __syncthreads();
+  const float m = wave_max(st_rn2[lane]) / a.t;
+
+  // ---- S tiles of this wave's 16 rows against all 64 columns
+  f32x4 bi[DP / 16];
+#pragma unroll
+  for (int s = 0; s < DP / 16; ++s) bi[s] = *(const f32x4*)(lds + i * DP + (((4 * s + g) ^ r16) << 2));
+  f32x4 c[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) c[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // the four column tiles advance together: four independent MFMA chains per k-step instead of one 64-deep chain
+  // (same k order per tile as sim_tile, so the logits are bitwise those of the sweep kernels)
+#pragma unroll
+  for (int s = 0; s < DP / 16; ++s) {
+    f32x4 a4[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) a4[nt] = *(const f32x4*)(lds + (nt * 16 + r16) * DP + (((4 * s + g) ^ r16) << 2));
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) c[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[nt][u], bi[s][u], c[nt], 0, 0, 0);
+  }
+
+  const int in = i >= a.n ? i - a.n : i;
+  const float lab_i = (a.labels != nullptr && i < a.N2) ? a.labels[in] : 0.f;
+  float accD = 0.f, accC = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const PairMask pm = pair_mask(a, i, 16 * nt + 4 * g + r, lab_i);
+      c[nt][r] = c[nt][r] / a.t - m;  // from here on c holds the logits
+      accD += pm.valid ? expf(c[nt][r]) : 0.f;
+      accC += pm.pos ? 1.f : 0.f;
+    }
+  accD += __shfl_xor(accD, 16, 64);
+  accD += __shfl_xor(accD, 32, 64);
+  accC += __shfl_xor(accC, 16, 64);
+  accC += __shfl_xor(accC, 32, 64);
+  const float logD_i = logf(accD + 1e-16f), cnt_i = accC;
+  float accL = 0.f, accW = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const PairMask pm = pair_mask(a, i, 16 * nt + 4 * g + r, lab_i);
+      const float ell = c[nt][r] - logD_i;
+      const float w = sp_weight(a.sp_mode, ell, a.gamma, a.inv_gamma);
+      accL += pm.pos ? w * ell : 0.f;
+      accW += pm.pos ? w : 0.f;
+    }
+  accL += __shfl_xor(accL, 16, 64);
+  accL += __shfl_xor(accL, 32, 64);
+  accW += __shfl_xor(accW, 16, 64);
+  accW += __shfl_xor(accW, 32, 64);
+
+  // ---- the scalars: loss, rho, kappa, norm defect (fixed order: 16 rows of a wave by butterfly, then the 4 waves)
+  double s_loss = 0.0, s_w = 0.0, s_c = 0.0;
+  float dev = 0.f;
+  if (g == 0 && i < a.N2) {
+    s_loss = (double)(accL / cnt_i);
+    s_w = (double)accW;
+    s_c = (double)cnt_i;
+    dev = fabsf(sqrtf(st_rn2[i]) - 1.f);
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) {
+    s_loss += __shfl_xor(s_loss, o, 64);
+    s_w += __shfl_xor(s_w, o, 64);
+    s_c += __shfl_xor(s_c, o, 64);
+    dev = fmaxf(dev, __shfl_xor(dev, o, 64));
+  }
+  if (lane == 0) {
+    red[wave * 4 + 0] = s_loss;
+    red[wave * 4 + 1] = s_w;
+    red[wave * 4 + 2] = s_c;
+    red[wave * 4 + 3] = (double)dev;
+  }
+  if (g == 0) {
+    st_logD[i] = logD_i;
+    st_W[i] = accW;
+    logD_out[i] = logD_i;
+    cnt_out[i] = cnt_i;
+    W_out[i] = accW;
+    rowloss_out[i] = accL;
+  }
+  __syncthreads();
+  double Lt = 0, Wt = 0, Ct = 0;
+  float dm = 0.f;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    Lt += red[w * 4 + 0];
+    Wt += red[w * 4 + 1];
+    Ct += red[w * 4 + 2];
+    dm = fmaxf(dm, (float)red[w * 4 + 3]);
+  }
+  float loss = (float)(-(Lt / (double)a.N2));
+  const float rho = (float)(Wt / Ct);
+  float kappa = 1.f / (float)a.N2;
+  if (correct_grad && rho > 0.f) {
+    loss = loss / rho;
+    kappa = kappa / rho;
+  }
+  if (threadIdx.x == 0) {
+    out[0] = loss;
+    out[1] = rho;
+    out[2] = kappa;
+    out[3] = dm;
+  }
+  if (dz_unit == nullptr) return;
+
+  // ---- dLoss/dP for a unit upstream gradient: H = G + G^T from the logits in registers, then H P on the same MFMA
+  if (g == 0) st_kc[i] = i < a.N2 ? -kappa / cnt_i : 0.f;
+  __syncthreads();
+  const float W_i = accW, kc_i = i < a.N2 ? -kappa / cnt_i : 0.f;
+  f32x4 acc2[DP / 64][4];
+#pragma unroll
+  for (int kt = 0; kt < DP / 64; ++kt)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc2[kt][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    float h[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = 16 * nt + 4 * g + r;
+      float hv = 0.f;
+      if (i < a.N2 && j < a.N2 && i != j) {
+        const int jn = j >= a.n ? j - a.n : j;
+        const float lab_j = a.labels != nullptr ? a.labels[jn] : 0.f;
+        const PairMask pij = pair_mask(a, i, j, lab_i);
+        const PairMask pji = pair_mask(a, j, i, lab_j);
+        const float logit = c[nt][r];
+        const float ell_ij = logit - logD_i, ell_ji = logit - st_logD[j];
+        const float w_ij = sp_weight(a.sp_mode, ell_ij, a.gamma, a.inv_gamma);
+        const float w_ji = sp_weight(a.sp_mode, ell_ji, a.gamma, a.inv_gamma);
+        const float g_ij = kc_i * ((pij.pos ? w_ij : 0.f) - (pij.valid ? W_i * expf(ell_ij) : 0.f));
+        const float g_ji = st_kc[j] * ((pji.pos ? w_ji : 0.f) - (pji.valid ? st_W[j] * expf(ell_ji) : 0.f));
+        hv = g_ij + g_ji;
+      }
+      h[r] = hv;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = nt * 16 + 4 * g + r;
+      const float* base = lds + row * DP;
+#pragma unroll
+      for (int kt = 0; kt < DP / 64; ++kt) {
+        const f32x4 b4 = *(const f32x4*)(base + (((16 * kt + r16) ^ (row & 15)) << 2));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc2[kt][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(h[r], b4[u], acc2[kt][u], 0, 0, 0);
+      }
+    }
+  }
+  // acc2[kt][u][rr] = dP[I0 + 4g + rr][64kt + 4*r16 + u]  (times 1/t here, times grad_out in the backward call)
+  const float inv_t = 1.f / a.t;
+#pragma unroll
+  for (int kt = 0; kt < DP / 64; ++kt)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const f32x4 v = {acc2[kt][0][rr] * inv_t, acc2[kt][1][rr] * inv_t, acc2[kt][2][rr] * inv_t,
+                       acc2[kt][3][rr] * inv_t};
+      *(f32x4*)(dz_unit + (size_t)(I0 + 4 * g + rr) * DP + 64 * kt + 4 * r16) = v;
+    }
+}
+
+// dz = grad_out * (dLoss/dP for a unit gradient) of the training-size path
+__global__ __launch_bounds__(256) void supcon_scale_kernel(const float* __restrict__ dz_unit, int n, int d, int DP,
+                                                          const float* __restrict__ grad_out, float* __restrict__ dz1,
+                                                          float* __restrict__ dz2) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= 2 * n * d) return;
+  const int row = idx / d, k = idx - row * d;
+  const float v = dz_unit[(size_t)row * DP + k] * grad_out[0];
+  if (row < n) dz1[(size_t)row * d + k] = v;
+  else dz2[(size_t)(row - n) * d + k] = v;
 }
 
 // ------------------------------------------------------------------------------------------------ large batches
@@ -838,6 +1072,11 @@ static int launch_forward(const SupconLayout& L, SupconArgs a, float* ws, int co
   return 0;
 }
 
+static bool supcon_use_small(const SupconLayout& L) {
+  static const bool sweeps = getenv("SPCL_SUPCON_SWEEPS") != nullptr;  // A/B switch: the multi-launch sweeps at any size
+  return !L.big && L.N2p == 64 && !sweeps;
+}
+
 static bool supcon_use_big(const SupconLayout& L, const float* mask) {
   static const bool exact = getenv("SPCL_SUPCON_EXACT") != nullptr;  // A/B switch: keep the exact-f32 sweeps
   return L.big && mask == nullptr && !exact;
@@ -912,12 +1151,23 @@ extern "C" int spcl_supcon_forward(const float* z1, const float* z2, const float
   SPCL_CHECK_ARG(temperature > 0.f, "supcon_forward: temperature must be > 0");
   hipStream_t st = (hipStream_t)stream;
   SupconLayout L = supcon_layout(n, d);
+  SupconArgs a = make_args(L, ws, labels, mask, temperature, sp_mode, gamma);
+  if (supcon_use_small(L)) {
+    const size_t lds = ((size_t)64 * L.DP + 4 * 64) * sizeof(float) + 16 * sizeof(double);
+#define SPCL_SMALL(DP_)                                                                                            \
+  SPCL_LAUNCH((supcon_small_kernel<DP_>), dim3(1), dim3(256), lds, st, z1, z2, d, a, ws + L.off_P, ws + L.off_rn2,  \
+              ws + L.off_logD, ws + L.off_c, ws + L.off_W, ws + L.off_rowloss, correct_grad, out, ws + L.off_dz)
+    if (L.DP == 64) SPCL_SMALL(64);
+    else if (L.DP == 128) SPCL_SMALL(128);
+    else SPCL_SMALL(256);
+#undef SPCL_SMALL
+    SPCL_LAUNCH_CHECK("supcon_forward");
+    return SPCL_OK;
+  }
   const bool big = supcon_use_big(L, mask);
   SPCL_LAUNCH(supcon_prep_kernel, dim3(L.N2p / 4), dim3(256), 0, st, z1, z2, n, d, L.N2p, L.DP,
                      ws + L.off_P, ws + L.off_rn2, big ? (bf16_t*)(ws + L.off_Ph) : (bf16_t*)nullptr,
                      big ? (bf16_t*)(ws + L.off_Pm) : (bf16_t*)nullptr);
-
-  SupconArgs a = make_args(L, ws, labels, mask, temperature, sp_mode, gamma);
   if (big) {
     if (L.DP == 64) launch_forward_big<64>(L, a, ws, correct_grad, out, st);
     else if (L.DP == 128) launch_forward_big<128>(L, a, ws, correct_grad, out, st);
@@ -938,6 +1188,13 @@ extern "C" int spcl_supcon_backward(const float* labels, const float* mask, int 
   hipStream_t st = (hipStream_t)stream;
   SupconLayout L = supcon_layout(n, d);
   SupconArgs a = make_args(L, ws_fwd, labels, mask, temperature, sp_mode, gamma);
+  if (supcon_use_small(L)) {  // the forward left dLoss/dP for a unit gradient in its workspace
+    const int total = 2 * n * d;
+    SPCL_LAUNCH(supcon_scale_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, ws_fwd + L.off_dz, n, d, L.DP, grad_out,
+                       dz1, dz2);
+    SPCL_LAUNCH_CHECK("supcon_backward");
+    return SPCL_OK;
+  }
   int nsplit = L.CS;
   if (supcon_use_big(L, mask)) {  // the forward of this call materialised the logits (same decision, same workspace)
     bf16_t* PhT = (bf16_t*)(ws_bwd + (size_t)(L.CS > L.CSB ? L.CS : L.CSB) * L.N2p * L.DP);
