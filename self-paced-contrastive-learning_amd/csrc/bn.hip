@@ -44,7 +44,7 @@ template <> __device__ __forceinline__ u32x4 pack<bf16_t>(const float* v) {
 // partial rows (n, sum x, sum x^2; kept behind the tile rows of the same buffer, see spcl_bn_stats_elems) and a
 // second launch finishes from those.
 constexpr int BN_GROUP_TILES = 256;
-constexpr int BN_DIRECT_TILES = 2048;
+constexpr int BN_DIRECT_TILES = 1024;
 __host__ __device__ inline int bn_groups(int ntiles) {
   return ntiles <= BN_DIRECT_TILES ? 0 : (ntiles + BN_GROUP_TILES - 1) / BN_GROUP_TILES;
 }
@@ -64,13 +64,15 @@ struct BnFinalArgs {
 
 // SRC = float: tile rows (count, mean, M2);  double: partial rows (n, sum x, sum x^2).
 // FINAL: write the BatchNorm coefficients, else one partial row per blockIdx.y.
-template <typename SRC, bool FINAL>
+// CW channels per workgroup (16: 64-byte row segments; 4 workgroups of 4 channels were tried for the 64-channel /
+// 2048-tile layers and were no faster: the single launch is a latency chain, which is why 1024 tiles already go two-level)
+template <typename SRC, bool FINAL, int CW>
 __global__ __launch_bounds__(1024) void bn_reduce_kernel(const SRC* __restrict__ rows, int nrows, int rows_per_group,
                                                          int C, int CS, double* __restrict__ partial, BnFinalArgs f) {
-  __shared__ double red[3][64][16];
-  const int TL = blockDim.x >> 4;
-  const int c16 = threadIdx.x & 15, tl = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + c16;
+  __shared__ double red[3][1024 / CW][CW];
+  const int TL = blockDim.x / CW;
+  const int c16 = threadIdx.x % CW, tl = threadIdx.x / CW;
+  const int c = blockIdx.x * CW + c16;
   const int r0 = blockIdx.y * rows_per_group, r1 = min(nrows, r0 + rows_per_group);
   double n = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll 8
@@ -792,13 +794,13 @@ extern "C" int spcl_bn_finalize(float* stats, int ntiles, int C, int CS, const f
   BnFinalArgs f{gamma, beta, momentum, eps, running_mean, running_var, num_batches_tracked, mean, invstd, scale, shift};
   const int groups = bn_groups(ntiles);
   if (groups == 0) {
-    SPCL_LAUNCH((bn_reduce_kernel<float, true>), dim3(CS / 16, 1), dim3(ntiles > 256 ? 1024 : 256), 0, st, stats,
+    SPCL_LAUNCH((bn_reduce_kernel<float, true, 16>), dim3(CS / 16, 1), dim3(ntiles > 256 ? 1024 : 256), 0, st, stats,
                        ntiles, ntiles, C, CS, (double*)nullptr, f);
   } else {
     double* partial = (double*)(stats + (size_t)ntiles * 3 * CS);  // spcl_bn_stats_elems reserves it
-    SPCL_LAUNCH((bn_reduce_kernel<float, false>), dim3(CS / 16, groups), dim3(256), 0, st, stats, ntiles,
+    SPCL_LAUNCH((bn_reduce_kernel<float, false, 16>), dim3(CS / 16, groups), dim3(256), 0, st, stats, ntiles,
                        BN_GROUP_TILES, C, CS, partial, f);
-    SPCL_LAUNCH((bn_reduce_kernel<double, true>), dim3(CS / 16, 1), dim3(groups > 64 ? 1024 : 256), 0, st,
+    SPCL_LAUNCH((bn_reduce_kernel<double, true, 16>), dim3(CS / 16, 1), dim3(groups > 64 ? 1024 : 256), 0, st,
                        (const double*)partial, groups, groups, C, CS, (double*)nullptr, f);
   }
   SPCL_LAUNCH_CHECK("bn_finalize");

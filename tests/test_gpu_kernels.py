@@ -310,6 +310,33 @@ def test_bn_relu_backward_fused_image_wgrad(dt, N, C, H, W):
     assert torch.equal(dw, dw3)
 
 
+@pytest.mark.parametrize("ntiles,C", [(3000, 64), (1500, 32), (700, 64), (5000, 48), (2048, 128)])
+def test_bn_finalize_many_tiles_all_launch_shapes(ntiles, C):
+    """spcl_bn_finalize from many per-tile (count, mean, M2) rows: the one-launch (16- and 4-channel workgroups) and the
+    two-level paths against float64 pooling of the same rows."""
+    n = _n()
+    cs = ru16(C)
+    g = torch.Generator().manual_seed(ntiles + C)
+    cnt = torch.randint(90, 197, (ntiles, 1), generator=g).double().expand(ntiles, cs).clone()
+    mean = torch.randn(ntiles, cs, generator=g).double() * 0.5 + 0.2
+    m2 = (torch.rand(ntiles, cs, generator=g).double() + 0.1) * cnt
+    rows = torch.stack([cnt, mean, m2], dim=1).float()  # [ntiles][3][cs]
+    stats = torch.zeros(n.call("spcl_bn_stats_elems", ntiles, cs))
+    stats[:rows.numel()] = rows.flatten()
+    r64 = rows.double()
+    N = r64[:, 0].sum(0)
+    mu = (r64[:, 0] * r64[:, 1]).sum(0) / N
+    var = (r64[:, 2] + r64[:, 0] * r64[:, 1] ** 2).sum(0) / N - mu ** 2
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    st = torch.empty(4, cs, device="cuda")
+    stats_d, gamma_d, beta_d = stats.cuda(), gamma.cuda(), beta.cuda()
+    n.call("spcl_bn_finalize", n.ptr(stats_d), ntiles, C, cs, n.ptr(gamma_d), n.ptr(beta_d), c_float(0.1),
+           c_float(1e-5), None, None, None, n.ptr(st[0]), n.ptr(st[1]), n.ptr(st[2]), n.ptr(st[3]), n.stream())
+    np.testing.assert_allclose(st[0, :C].cpu().numpy(), mu[:C].float().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(st[1, :C].cpu().numpy(), (1 / torch.sqrt(var[:C] + 1e-5)).float().numpy(), rtol=1e-5)
+    assert float(st[:, C:].abs().max()) == 0.0 if cs > C else True
+
+
 def test_fused_radam_matches_torch_radam():
     """spcl_radam_step == torch.optim.RAdam (CPU, single tensor) over the un-rectified (rho_t <= 5) and rectified
     steps, with weight decay and a learning-rate change in between."""
