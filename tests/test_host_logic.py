@@ -164,3 +164,46 @@ def test_warmup_cosine_schedule():
     s2 = WarmupCosine(torch.optim.SGD([p], lr=5e-7), max_epoch=80, warmup_max=10, multiplier=400)
     s2.load_state_dict(sd)
     assert s2.epoch == 80
+
+
+def test_gradient_sinks_are_armed_once_per_step_on_cpu():
+    """ddp.FlatParams.zero_grad arms one sink per parameter (its slice of the flat bucket); functional.take_grad_sink hands it
+    out once, and a gradient written there and returned as a fresh view is adopted by autograd without a copy."""
+    from spcl_amd import ddp
+    from spcl_amd.functional import take_grad_sink
+    lin = torch.nn.Linear(4, 3)
+    flat = ddp.FlatParams(lin.parameters())
+    assert take_grad_sink(lin.weight) is None  # nothing armed yet
+    flat.zero_grad()
+    s = take_grad_sink(lin.weight)
+    assert s is not None and s.data_ptr() == flat.views[0].data_ptr() and s.shape == lin.weight.shape
+    assert take_grad_sink(lin.weight) is None  # one backward per arming
+    assert take_grad_sink(lin.bias, needed=False) is None and take_grad_sink(lin.bias) is not None
+    assert take_grad_sink(None) is None
+
+    class WriteIntoSink(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, w):
+            ctx.sink = take_grad_sink(w)
+            return w.sum()
+
+        @staticmethod
+        def backward(ctx, g):
+            ctx.sink.fill_(3.0)
+            return ctx.sink.view(ctx.sink.shape)
+
+    flat.zero_grad()
+    WriteIntoSink.apply(lin.weight).backward()
+    assert lin.weight.grad.data_ptr() == flat.views[0].data_ptr()
+    g = flat.gather_grads()
+    assert torch.equal(g[:12], torch.full((12,), 3.0)) and torch.equal(g[12:], torch.zeros(3))  # bias had no gradient
+
+
+def test_meter_batching_falls_back_to_immediate_adds_off_gpu():
+    from spcl_amd.contrastyou import meters as M
+    m = M.AverageValueMeter()
+    M.begin_batch()
+    m.add(torch.tensor(2.0))  # a CPU tensor is not batched (the one-launch kernel is a GPU path)
+    m.add(4.0)
+    M.flush_batch()
+    assert m.summary()["mean"] == 3.0
