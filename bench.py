@@ -438,7 +438,7 @@ def bench_contrastive(args, device):
     g = torch.Generator().manual_seed(1)
     z1 = torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=1).to(device).requires_grad_(True)
     z2 = torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=1).to(device).requires_grad_(True)
-    labels = torch.arange(n, device=device) % 3
+    labels = (torch.arange(n, device=device) % 3).float()  # device float labels, as the InfoNCE hook hands them over
     crit = SelfPacedSupConLoss(weight_update="soft", correct_grad=True, sync_checks=False)
     crit.set_gamma(12.0)
 

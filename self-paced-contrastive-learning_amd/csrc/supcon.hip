@@ -270,29 +270,37 @@ __global__ __launch_bounds__(256) void supcon_sweep_kernel(SupconArgs a) {
 // and dLoss/dP for a unit upstream gradient (backward then is one scaling launch).  Same arithmetic per element as the
 // sweep kernels; the seven launches they take at this size are latency, not work.
 template <int DP>
-__global__ __launch_bounds__(256) void supcon_small_kernel(const float* __restrict__ z1, const float* __restrict__ z2,
-                                                          int d, SupconArgs a, float* __restrict__ P_out,
-                                                          float* __restrict__ rn2_out, float* __restrict__ logD_out,
-                                                          float* __restrict__ cnt_out, float* __restrict__ W_out,
-                                                          float* __restrict__ rowloss_out, int correct_grad,
-                                                          float* __restrict__ out, float* __restrict__ dz_unit) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];  // [64][DP] swizzled P, then 4 x [64] statistics
-  float* st_rn2 = lds + 64 * DP;
-  float* st_logD = st_rn2 + 64;
-  float* st_W = st_logD + 64;
-  float* st_kc = st_W + 64;
-  double* red = (double*)(st_kc + 64);  // [4 waves][4]
+__global__ __launch_bounds__(1024) void supcon_small_kernel(const float* __restrict__ z1, const float* __restrict__ z2,
+                                                           int d, SupconArgs a, float* __restrict__ P_out,
+                                                           float* __restrict__ rn2_out, float* __restrict__ logD_out,
+                                                           float* __restrict__ cnt_out, float* __restrict__ W_out,
+                                                           float* __restrict__ rowloss_out, int correct_grad,
+                                                           float* __restrict__ out, float* __restrict__ dz_unit) {
+  // 16 waves on one CU (four per SIMD, so that the dependent exact-f32 MFMA chains of one wave hide behind the others):
+  // wave = (row block rb of 16 rows, column quarter cq).  Forward: the wave owns the 16 x 16 tile S[rb][cq]; row sums
+  // are exchanged through LDS in fixed order.  Backward: the wave owns dP[rb][64-feature slice cq] and needs the
+  // logits of all four column tiles of its rows -- they sit in the same lane / register positions of the waves
+  // (rb, 0..3), so the exchange is a lane-contiguous LDS copy.
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [64][DP] swizzled P, then the exchange areas
+  float* st_rn2 = lds + 64 * DP;      // [64]
+  float* st_logD = st_rn2 + 64;       // [64]
+  float* st_W = st_logD + 64;         // [64]
+  float* st_kc = st_W + 64;           // [64]
+  float* part = st_kc + 64;           // [2][4 cq][64 rows]: partial row sums of a column quarter
+  float* sx = part + 2 * 4 * 64;      // [4 rb][4 cq][4 r][64 lanes]: the logits, for the backward
+  double* red = (double*)(sx + 4 * 4 * 4 * 64);  // [4][4]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, g = lane >> 4;
-  const int I0 = wave * 16, i = I0 + r16;
+  const int rb = wave & 3, cq = wave >> 2;
+  const int I0 = rb * 16, i = I0 + r16;
 
-  // ---- padded P into LDS (and to the workspace for the lazily materialised taps), squared row norms
+  // ---- padded P into LDS (and to the workspace for the lazily materialised taps), squared row norms: 4 rows per wave
   {
     constexpr int KPL = DP / 64;
-    float v[16][KPL];
+    float v[4][KPL];
 #pragma unroll
-    for (int rr = 0; rr < 16; ++rr) {
-      const int row = I0 + rr;
+    for (int rr = 0; rr < 4; ++rr) {
+      const int row = 4 * wave + rr;
       const float* src = row < a.n ? z1 + (size_t)row * d : (row < a.N2 ? z2 + (size_t)(row - a.n) * d : nullptr);
 #pragma unroll
       for (int q = 0; q < KPL; ++q) {
@@ -301,8 +309,8 @@ __global__ __launch_bounds__(256) void supcon_small_kernel(const float* __restri
       }
     }
 #pragma unroll
-    for (int rr = 0; rr < 16; ++rr) {
-      const int row = I0 + rr;
+    for (int rr = 0; rr < 4; ++rr) {
+      const int row = 4 * wave + rr;
       float s2 = 0.f;
 #pragma unroll
       for (int q = 0; q < KPL; ++q) {
@@ -321,88 +329,95 @@ __global__ __launch_bounds__(256) void supcon_small_kernel(const float* __restri
   __syncthreads();
   const float m = wave_max(st_rn2[lane]) / a.t;
 
-  // ---- S tiles of this wave's 16 rows against all 64 columns
-  f32x4 bi[DP / 16];
+  // ---- the 16 x 16 tile S[rb][cq] (same k order as sim_tile: the logits are bitwise those of the sweep kernels)
+  f32x4 c = {0.f, 0.f, 0.f, 0.f};
+  {
+    const float* arow = lds + (cq * 16 + r16) * DP;
+    const float* brow = lds + i * DP;
 #pragma unroll
-  for (int s = 0; s < DP / 16; ++s) bi[s] = *(const f32x4*)(lds + i * DP + (((4 * s + g) ^ r16) << 2));
-  f32x4 c[4];
+    for (int s = 0; s < DP / 16; ++s) {
+      const f32x4 a4 = *(const f32x4*)(arow + (((4 * s + g) ^ r16) << 2));
+      const f32x4 b4 = *(const f32x4*)(brow + (((4 * s + g) ^ r16) << 2));
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) c[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  // the four column tiles advance together: four independent MFMA chains per k-step instead of one 64-deep chain
-  // (same k order per tile as sim_tile, so the logits are bitwise those of the sweep kernels)
-#pragma unroll
-  for (int s = 0; s < DP / 16; ++s) {
-    f32x4 a4[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) a4[nt] = *(const f32x4*)(lds + (nt * 16 + r16) * DP + (((4 * s + g) ^ r16) << 2));
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) c[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[nt][u], bi[s][u], c[nt], 0, 0, 0);
+      for (int u = 0; u < 4; ++u) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u], b4[u], c, 0, 0, 0);
+    }
   }
-
   const int in = i >= a.n ? i - a.n : i;
   const float lab_i = (a.labels != nullptr && i < a.N2) ? a.labels[in] : 0.f;
+  PairMask pm[4];
   float accD = 0.f, accC = 0.f;
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const PairMask pm = pair_mask(a, i, 16 * nt + 4 * g + r, lab_i);
-      c[nt][r] = c[nt][r] / a.t - m;  // from here on c holds the logits
-      accD += pm.valid ? expf(c[nt][r]) : 0.f;
-      accC += pm.pos ? 1.f : 0.f;
-    }
+  for (int r = 0; r < 4; ++r) {
+    pm[r] = pair_mask(a, i, 16 * cq + 4 * g + r, lab_i);
+    c[r] = c[r] / a.t - m;  // from here on c holds the logits
+    accD += pm[r].valid ? expf(c[r]) : 0.f;
+    accC += pm[r].pos ? 1.f : 0.f;
+    sx[((rb * 4 + cq) * 4 + r) * 64 + lane] = c[r];
+  }
   accD += __shfl_xor(accD, 16, 64);
   accD += __shfl_xor(accD, 32, 64);
   accC += __shfl_xor(accC, 16, 64);
   accC += __shfl_xor(accC, 32, 64);
-  const float logD_i = logf(accD + 1e-16f), cnt_i = accC;
+  if (g == 0) {
+    part[cq * 64 + i] = accD;
+    part[(4 + cq) * 64 + i] = accC;
+  }
+  __syncthreads();
+  const float D_i = (part[i] + part[64 + i]) + (part[128 + i] + part[192 + i]);
+  const float cnt_i = (part[256 + i] + part[320 + i]) + (part[384 + i] + part[448 + i]);
+  const float logD_i = logf(D_i + 1e-16f);
   float accL = 0.f, accW = 0.f;
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const PairMask pm = pair_mask(a, i, 16 * nt + 4 * g + r, lab_i);
-      const float ell = c[nt][r] - logD_i;
-      const float w = sp_weight(a.sp_mode, ell, a.gamma, a.inv_gamma);
-      accL += pm.pos ? w * ell : 0.f;
-      accW += pm.pos ? w : 0.f;
-    }
+  for (int r = 0; r < 4; ++r) {
+    const float ell = c[r] - logD_i;
+    const float w = sp_weight(a.sp_mode, ell, a.gamma, a.inv_gamma);
+    accL += pm[r].pos ? w * ell : 0.f;
+    accW += pm[r].pos ? w : 0.f;
+  }
   accL += __shfl_xor(accL, 16, 64);
   accL += __shfl_xor(accL, 32, 64);
   accW += __shfl_xor(accW, 16, 64);
   accW += __shfl_xor(accW, 32, 64);
-
-  // ---- the scalars: loss, rho, kappa, norm defect (fixed order: 16 rows of a wave by butterfly, then the 4 waves)
-  double s_loss = 0.0, s_w = 0.0, s_c = 0.0;
-  float dev = 0.f;
-  if (g == 0 && i < a.N2) {
-    s_loss = (double)(accL / cnt_i);
-    s_w = (double)accW;
-    s_c = (double)cnt_i;
-    dev = fabsf(sqrtf(st_rn2[i]) - 1.f);
-  }
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) {
-    s_loss += __shfl_xor(s_loss, o, 64);
-    s_w += __shfl_xor(s_w, o, 64);
-    s_c += __shfl_xor(s_c, o, 64);
-    dev = fmaxf(dev, __shfl_xor(dev, o, 64));
-  }
-  if (lane == 0) {
-    red[wave * 4 + 0] = s_loss;
-    red[wave * 4 + 1] = s_w;
-    red[wave * 4 + 2] = s_c;
-    red[wave * 4 + 3] = (double)dev;
-  }
+  __syncthreads();  // everybody has read D / count partials
   if (g == 0) {
-    st_logD[i] = logD_i;
-    st_W[i] = accW;
-    logD_out[i] = logD_i;
-    cnt_out[i] = cnt_i;
-    W_out[i] = accW;
-    rowloss_out[i] = accL;
+    part[cq * 64 + i] = accL;
+    part[(4 + cq) * 64 + i] = accW;
+  }
+  __syncthreads();
+  const float L_i = (part[i] + part[64 + i]) + (part[128 + i] + part[192 + i]);
+  const float W_i = (part[256 + i] + part[320 + i]) + (part[384 + i] + part[448 + i]);
+
+  // ---- the scalars: loss, rho, kappa, norm defect (fixed order: 16 rows by butterfly in the cq == 0 waves, then 4 blocks)
+  if (cq == 0) {
+    double s_loss = 0.0, s_w = 0.0, s_c = 0.0;
+    float dev = 0.f;
+    if (g == 0 && i < a.N2) {
+      s_loss = (double)(L_i / cnt_i);
+      s_w = (double)W_i;
+      s_c = (double)cnt_i;
+      dev = fabsf(sqrtf(st_rn2[i]) - 1.f);
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      s_loss += __shfl_xor(s_loss, o, 64);
+      s_w += __shfl_xor(s_w, o, 64);
+      s_c += __shfl_xor(s_c, o, 64);
+      dev = fmaxf(dev, __shfl_xor(dev, o, 64));
+    }
+    if (lane == 0) {
+      red[rb * 4 + 0] = s_loss;
+      red[rb * 4 + 1] = s_w;
+      red[rb * 4 + 2] = s_c;
+      red[rb * 4 + 3] = (double)dev;
+    }
+    if (g == 0) {
+      st_logD[i] = logD_i;
+      st_W[i] = W_i;
+      logD_out[i] = logD_i;
+      cnt_out[i] = cnt_i;
+      W_out[i] = W_i;
+      rowloss_out[i] = L_i;
+    }
   }
   __syncthreads();
   double Lt = 0, Wt = 0, Ct = 0;
@@ -429,15 +444,15 @@ __global__ __launch_bounds__(256) void supcon_small_kernel(const float* __restri
   }
   if (dz_unit == nullptr) return;
 
-  // ---- dLoss/dP for a unit upstream gradient: H = G + G^T from the logits in registers, then H P on the same MFMA
-  if (g == 0) st_kc[i] = i < a.N2 ? -kappa / cnt_i : 0.f;
+  // ---- dLoss/dP for a unit upstream gradient: H = G + G^T for this wave's 16 rows x all 64 columns, then
+  // dP[rows][64 cq .. 64 cq + 63] += H P_J on the same MFMA
+  const float kc_i = i < a.N2 ? -kappa / cnt_i : 0.f;
+  if (cq == 0 && g == 0) st_kc[i] = kc_i;
   __syncthreads();
-  const float W_i = accW, kc_i = i < a.N2 ? -kappa / cnt_i : 0.f;
-  f32x4 acc2[DP / 64][4];
+  if (64 * cq >= DP) return;  // feature slices beyond the padded width (DP = 64 or 128)
+  f32x4 acc2[4];
 #pragma unroll
-  for (int kt = 0; kt < DP / 64; ++kt)
-#pragma unroll
-    for (int u = 0; u < 4; ++u) acc2[kt][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int u = 0; u < 4; ++u) acc2[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
     float h[4];
@@ -450,7 +465,7 @@ __global__ __launch_bounds__(256) void supcon_small_kernel(const float* __restri
         const float lab_j = a.labels != nullptr ? a.labels[jn] : 0.f;
         const PairMask pij = pair_mask(a, i, j, lab_i);
         const PairMask pji = pair_mask(a, j, i, lab_j);
-        const float logit = c[nt][r];
+        const float logit = sx[((rb * 4 + nt) * 4 + r) * 64 + lane];
         const float ell_ij = logit - logD_i, ell_ji = logit - st_logD[j];
         const float w_ij = sp_weight(a.sp_mode, ell_ij, a.gamma, a.inv_gamma);
         const float w_ji = sp_weight(a.sp_mode, ell_ji, a.gamma, a.inv_gamma);
@@ -463,25 +478,18 @@ __global__ __launch_bounds__(256) void supcon_small_kernel(const float* __restri
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = nt * 16 + 4 * g + r;
-      const float* base = lds + row * DP;
+      const f32x4 b4 = *(const f32x4*)(lds + row * DP + (((16 * cq + r16) ^ (row & 15)) << 2));
 #pragma unroll
-      for (int kt = 0; kt < DP / 64; ++kt) {
-        const f32x4 b4 = *(const f32x4*)(base + (((16 * kt + r16) ^ (row & 15)) << 2));
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc2[kt][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(h[r], b4[u], acc2[kt][u], 0, 0, 0);
-      }
+      for (int u = 0; u < 4; ++u) acc2[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(h[r], b4[u], acc2[u], 0, 0, 0);
     }
   }
-  // acc2[kt][u][rr] = dP[I0 + 4g + rr][64kt + 4*r16 + u]  (times 1/t here, times grad_out in the backward call)
+  // acc2[u][rr] = dP[I0 + 4g + rr][64 cq + 4*r16 + u]  (times 1/t here, times grad_out in the backward call)
   const float inv_t = 1.f / a.t;
 #pragma unroll
-  for (int kt = 0; kt < DP / 64; ++kt)
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const f32x4 v = {acc2[kt][0][rr] * inv_t, acc2[kt][1][rr] * inv_t, acc2[kt][2][rr] * inv_t,
-                       acc2[kt][3][rr] * inv_t};
-      *(f32x4*)(dz_unit + (size_t)(I0 + 4 * g + rr) * DP + 64 * kt + 4 * r16) = v;
-    }
+  for (int rr = 0; rr < 4; ++rr) {
+    const f32x4 v = {acc2[0][rr] * inv_t, acc2[1][rr] * inv_t, acc2[2][rr] * inv_t, acc2[3][rr] * inv_t};
+    *(f32x4*)(dz_unit + (size_t)(I0 + 4 * g + rr) * DP + 64 * cq + 4 * r16) = v;
+  }
 }
 
 // dz = grad_out * (dLoss/dP for a unit gradient) of the training-size path
@@ -1153,9 +1161,9 @@ extern "C" int spcl_supcon_forward(const float* z1, const float* z2, const float
   SupconLayout L = supcon_layout(n, d);
   SupconArgs a = make_args(L, ws, labels, mask, temperature, sp_mode, gamma);
   if (supcon_use_small(L)) {
-    const size_t lds = ((size_t)64 * L.DP + 4 * 64) * sizeof(float) + 16 * sizeof(double);
+    const size_t lds = ((size_t)64 * L.DP + 4 * 64 + 2 * 4 * 64 + 4 * 4 * 4 * 64) * sizeof(float) + 16 * sizeof(double);
 #define SPCL_SMALL(DP_)                                                                                            \
-  SPCL_LAUNCH((supcon_small_kernel<DP_>), dim3(1), dim3(256), lds, st, z1, z2, d, a, ws + L.off_P, ws + L.off_rn2,  \
+  SPCL_LAUNCH((supcon_small_kernel<DP_>), dim3(1), dim3(1024), lds, st, z1, z2, d, a, ws + L.off_P, ws + L.off_rn2,  \
               ws + L.off_logD, ws + L.off_c, ws + L.off_W, ws + L.off_rowloss, correct_grad, out, ws + L.off_dz)
     if (L.DP == 64) SPCL_SMALL(64);
     else if (L.DP == 128) SPCL_SMALL(128);
