@@ -43,8 +43,11 @@ const char* spcl_last_error(void);
  * sp_mode 0 = no self-pacing (SupConLoss1), 1 = hard, 2 = soft;  gamma = age parameter
  * ws      workspace of spcl_supcon_workspace_bytes(n,d) bytes (f32 aligned); holds the padded projections,
  *         the per-row statistics kept for backward and the column-split partials
- * Two schedules, chosen by size (same results within the parity tolerance, same workspace contract):
- *   2n < 1024, or an explicit `mask`: the [2n,2n] matrix is never materialised; every sweep recomputes its S tiles on the
+ * Three schedules, chosen by size (same results within the parity tolerance, same workspace contract):
+ *   2n <= 64 (the training sizes): one workgroup, one launch -- forward scalars, row statistics and dLoss/dP for a unit
+ *     upstream gradient (kept in ws; spcl_supcon_backward then is one scaling launch); exact-f32 MFMA, same k order as the
+ *     sweeps.  SPCL_SUPCON_SWEEPS=1 forces the sweeps at any size;
+ *   64 < 2n < 1024, or an explicit `mask`: the [2n,2n] matrix is never materialised; every sweep recomputes its S tiles on the
  *     exact-f32 MFMA (bitwise an fmaf chain) -- the training sizes are launch-latency bound either way;
  *   2n >= 1024 (labels / SimCLR modes): the logits are formed ONCE on the bf16 matrix pipe from the two-term split
  *     P = Ph + Pm (S ~ Ph Ph^T + Ph Pm^T + Pm Ph^T, logit error ~1e-5), written to ws as f32 [2n,2n] (rounded up to 128)
