@@ -17,42 +17,90 @@ constexpr int HEAD_MAX_C = 256;
 constexpr int HEAD_RED_WG = 1024;
 
 // ------------------------------------------------------------------------------------------------ 1x1 conv + bias
-// KB = compile-time bound of the class count (4 / 8 / 16) so that the per-class accumulators live in registers
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+// 16-byte groups of a pixel's channels (CS is a multiple of 16, so a pixel is a whole number of groups)
+template <typename T> struct VecIO;
+template <> struct VecIO<bf16_t> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void load(const bf16_t* p, float* v) {
+    const u32x4 r = *(const u32x4*)p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[2 * i] = __uint_as_float(r[i] << 16);
+      v[2 * i + 1] = __uint_as_float(r[i] & 0xffff0000u);
+    }
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float* v) {
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = (uint32_t)f32_to_bf16(v[2 * i]) | ((uint32_t)f32_to_bf16(v[2 * i + 1]) << 16);
+    *(u32x4*)p = r;
+  }
+};
+template <> struct VecIO<float> {
+  static constexpr int N = 4;
+  static __device__ __forceinline__ void load(const float* p, float* v) {
+    const f32x4 r = *(const f32x4*)p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = r[i];
+  }
+  static __device__ __forceinline__ void store(float* p, const float* v) { *(f32x4*)p = (f32x4){v[0], v[1], v[2], v[3]}; }
+};
+
+// KB = compile-time bound of the class count (4 / 8 / 16) so that the per-class accumulators live in registers.
+// The weights sit in LDS as [KB][CS] with zeros in the channel padding and the unused classes: no bounds tests inside.
 template <typename T, int KB>
 __global__ __launch_bounds__(256) void conv1x1_fwd_kernel(const T* __restrict__ x, size_t npix, int C, int CS, int K,
                                                           const float* __restrict__ w, const float* __restrict__ b,
                                                           float* __restrict__ out) {
+  constexpr int VN = VecIO<T>::N;
   __shared__ float ws[KB * HEAD_MAX_C + KB];
-  for (int i = threadIdx.x; i < KB * C; i += 256) ws[i] = i < K * C ? w[i] : 0.f;
-  if (threadIdx.x < KB) ws[KB * C + threadIdx.x] = threadIdx.x < K ? b[threadIdx.x] : 0.f;
+  for (int i = threadIdx.x; i < KB * CS; i += 256) {
+    const int k = i / CS, c = i - k * CS;
+    ws[i] = (k < K && c < C) ? w[k * C + c] : 0.f;
+  }
+  if (threadIdx.x < KB) ws[KB * CS + threadIdx.x] = threadIdx.x < K ? b[threadIdx.x] : 0.f;
   __syncthreads();
   for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (size_t)gridDim.x * 256) {
     float acc[KB];
 #pragma unroll
-    for (int k = 0; k < KB; ++k) acc[k] = ws[KB * C + k];
+    for (int k = 0; k < KB; ++k) acc[k] = ws[KB * CS + k];
     const T* px = x + p * CS;
-    for (int c = 0; c < C; ++c) {
-      const float xv = Elem<T>::load(px + c);
+    for (int c0 = 0; c0 < CS; c0 += VN) {
+      float xv[VN];
+      VecIO<T>::load(px + c0, xv);
 #pragma unroll
-      for (int k = 0; k < KB; ++k) acc[k] = fmaf(xv, ws[k * C + c], acc[k]);
+      for (int e = 0; e < VN; ++e)
+#pragma unroll
+        for (int k = 0; k < KB; ++k) acc[k] = fmaf(xv[e], ws[k * CS + c0 + e], acc[k]);
     }
+    if (K == KB && KB % 4 == 0) {
 #pragma unroll
-    for (int k = 0; k < KB; ++k)
-      if (k < K) out[p * K + k] = acc[k];
+      for (int k = 0; k < KB; k += 4) *(f32x4*)(out + p * K + k) = (f32x4){acc[k], acc[k + 1], acc[k + 2], acc[k + 3]};
+    } else {
+#pragma unroll
+      for (int k = 0; k < KB; ++k)
+        if (k < K) out[p * K + k] = acc[k];
+    }
   }
 }
 
 // dX[p][c] = sum_k dO[p][k] w[k][c]; per-workgroup partials of dW[k][c] = sum_p dO[p][k] x[p][c], db[k] = sum_p dO[p][k].
-// Channels are walked in groups of CG = 64 / KB so that the KB x CG accumulators stay in registers.
+// Channels are walked in groups of CG = 64 / KB so that the KB x CG accumulators stay in registers; a pixel's group is
+// read and written as 16-byte vectors.
 template <typename T, int KB>
 __global__ __launch_bounds__(256) void conv1x1_bwd_kernel(const T* __restrict__ x, const float* __restrict__ dout,
                                                           size_t npix, int C, int CS, int K,
                                                           const float* __restrict__ w, T* __restrict__ dx,
                                                           float* __restrict__ partial /* [grid][K][C+1] */) {
-  constexpr int CG = 64 / KB;
+  constexpr int CG = 64 / KB, VN = VecIO<T>::N;
+  static_assert(CG % 4 == 0, "channel group");
   __shared__ float ws[KB * HEAD_MAX_C];
   __shared__ float red[4][KB * (CG + 1)];
-  for (int i = threadIdx.x; i < KB * C; i += 256) ws[i] = i < K * C ? w[i] : 0.f;
+  for (int i = threadIdx.x; i < KB * CS; i += 256) {
+    const int k = i / CS, c = i - k * CS;
+    ws[i] = (k < K && c < C) ? w[k * C + c] : 0.f;
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* mypart = partial + (size_t)blockIdx.x * K * (C + 1);
@@ -66,19 +114,40 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_kernel(const T* __restrict__ 
     }
     for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (size_t)gridDim.x * 256) {
       float g[KB];
+      if (K == KB && KB % 4 == 0) {
 #pragma unroll
-      for (int k = 0; k < KB; ++k) g[k] = k < K ? dout[p * K + k] : 0.f;
+        for (int k = 0; k < KB; k += 4) {
+          const f32x4 r = *(const f32x4*)(dout + p * K + k);
+          g[k] = r[0]; g[k + 1] = r[1]; g[k + 2] = r[2]; g[k + 3] = r[3];
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < KB; ++k) g[k] = k < K ? dout[p * K + k] : 0.f;
+      }
+      float xv[CG], d[CG];
+      if (CG >= VN) {
+#pragma unroll
+        for (int c = 0; c < CG; c += VN) VecIO<T>::load(x + p * CS + c0 + c, xv + c);
+      } else {  // bf16 with 16 classes: 4 channels = half a vector
+#pragma unroll
+        for (int c = 0; c < CG; ++c) xv[c] = Elem<T>::load(x + p * CS + c0 + c);
+      }
 #pragma unroll
       for (int c = 0; c < CG; ++c) {
-        const int cc = c0 + c;  // < CS (CS is a multiple of 16 >= CG)
-        const float xv = cc < C ? Elem<T>::load(x + p * CS + cc) : 0.f;
-        float d = 0.f;
+        float dd = 0.f;
 #pragma unroll
         for (int k = 0; k < KB; ++k) {
-          aw[k][c] = fmaf(g[k], xv, aw[k][c]);
-          d = fmaf(g[k], cc < C ? ws[k * C + cc] : 0.f, d);
+          aw[k][c] = fmaf(g[k], xv[c], aw[k][c]);
+          dd = fmaf(g[k], ws[k * CS + c0 + c], dd);  // zero weights in the channel padding: exact zeros there
         }
-        Elem<T>::store(dx + p * CS + cc, d);  // padding channels get exact zeros
+        d[c] = dd;
+      }
+      if (CG >= VN) {
+#pragma unroll
+        for (int c = 0; c < CG; c += VN) VecIO<T>::store(dx + p * CS + c0 + c, d + c);
+      } else {
+#pragma unroll
+        for (int c = 0; c < CG; ++c) Elem<T>::store(dx + p * CS + c0 + c, d[c]);
       }
       if (c0 == 0) {
 #pragma unroll
