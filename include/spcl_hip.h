@@ -170,6 +170,25 @@ int spcl_bnrelu_backward_image_wgrad(const void* y, const void* dact, const floa
                                      const float* shift, int training, float* ws, float* dgamma, float* dbeta,
                                      float* dw, void* stream);
 
+/* dgrad of a block's SECOND conv fused with the per-tile partial sums of the FIRST conv's BatchNorm backward
+ * (`_ConvBlock.conv.3` input gradient -> `.conv.1/.2` backward, semi_seg/arch/unet.py:70-77 + autograd): the dgrad's
+ * output g is d loss / d relu(bn(y2)), so its epilogue already holds what the reduction pass over (y2, g) would read.
+ *   dy [N][H][W][CinK], g [N][H][W][CoutS], y2 [N][H][W][CoutS] (raw output of the first conv), all bf16;
+ *   rows2 [spcl_conv_num_tiles(N,H,W)][2][CoutS] f32: sum dz and sum dz (y2 - mean) per conv tile, dz = g [bn(y2) > 0].
+ * Exists only where a specialised conv kernel does: ask spcl_conv_dgrad_bnstats_supported (1 / 0) first, else run
+ * spcl_conv3x3_forward + spcl_bnrelu_pool_backward.  spcl_bnrelu_backward_rows finishes from the rows: dgamma, dbeta and
+ * either dy (image == dw == NULL) or, for a one-channel image block, that layer's dW (dy == NULL), as the two entry
+ * points above do after their own reduction pass.  Same workspace sizes as those. */
+int spcl_conv_dgrad_bnstats_supported(int dtype, int N, int H, int W, int CinK, int CoutS);
+int spcl_conv3x3_dgrad_bnstats(const void* dy, int dtype, int N, int H, int W, int CinK, int CoutS, const void* w_packed,
+                               void* g, const void* y2, const float* scale2, const float* shift2, const float* mean2,
+                               float* rows2, void* stream);
+int spcl_bnrelu_backward_rows(const void* y, const void* dact, const float* image, const float* rows, int nrows, int dtype,
+                              int N, int H, int W, int C, int CS, const float* mean, const float* invstd,
+                              const float* scale, const float* shift, int training, float* ws, float* dgamma,
+                              float* dbeta, void* dy, float* dw, void* stream);
+
+
 /* ---------------------------------------------------------------------------------------------------------------
  * Segmentation head and fine-tune / evaluation arithmetic.  Activations [npix][CS] of dtype (NHWC,
  * npix = N*H*W); class maps [npix][K] f32 with K <= 16; labels [npix] int64.

@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_fin_kernel(const float* __rest
                                                              const float* __restrict__ scale,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                              float* __restrict__ ab, float* __restrict__ zero_fill,
-                                                             int nzero) {
+                                                             int nzero, int s2_centered) {
   __shared__ float red[2][4];
   const int c = blockIdx.x;
   if (c == 0)  // scratch the next launch wants zeroed (the image-wgrad pass's zero row): saves a memset launch
@@ -506,6 +506,7 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_fin_kernel(const float* __rest
   if (threadIdx.x == 0) {
     s1 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
     s2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    if (s2_centered) s2 *= invstd[c];  // rows held sum dz (y - mean): dgamma = invstd * that
     if (c < C) {
       dbeta[c] = s1;
       dgamma[c] = s2;
@@ -517,6 +518,21 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_fin_kernel(const float* __rest
     }
     ab[c] = A;
     ab[CS + c] = B;
+  }
+}
+
+// rows [nrows][2][CS] of per-tile partial sums (the dgrad epilogue of conv_fast.hip, MODE 2) folded G at a time, so that
+// the per-channel final sum never walks more than BWD_MAX_WG rows
+__global__ __launch_bounds__(256) void bwd_rows_group_kernel(const float* __restrict__ rows, int nrows, int G, int CS,
+                                                             float* __restrict__ out) {
+  const int w = blockIdx.x;
+  for (int o = threadIdx.x; o < 2 * CS; o += 256) {
+    float s = 0.f;
+    for (int k = 0; k < G; ++k) {
+      const int r = w * G + k;
+      if (r < nrows) s += rows[(size_t)r * 2 * CS + o];
+    }
+    out[(size_t)w * 2 * CS + o] = s;
   }
 }
 
@@ -728,12 +744,13 @@ template <typename T>
 static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool, int N, int H, int W, int C, int CS,
                              const float* mean, const float* invstd, const float* scale, const float* shift,
                              int training, float* ws, float* dgamma, float* dbeta, void* dy, hipStream_t st,
-                             const float* img = nullptr, float* dw = nullptr) {
+                             const float* img = nullptr, float* dw = nullptr, const float* rows = nullptr,
+                             int nrows = 0) {
   constexpr int EPC = Chunk<T>::EPC;
   const bool pool = dpool != nullptr;
   const int PL = 256 / (CS / EPC);
   const size_t npix = (size_t)N * H * W;
-  const int rows = N * ((H + 1) / 2);
+  const int prows = N * ((H + 1) / 2);
   float* partial = ws;                           // [nwg][2][CS]
   float* ab = ws + (size_t)BWD_MAX_WG * 2 * CS;  // [2][CS]: folded BN-backward coefficients
   const float M = (float)npix;
@@ -741,8 +758,18 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
   const double tb = (double)npix * CS * sizeof(T);  // bytes of one full-resolution tensor
   const double gb = (dact != nullptr ? tb : 0.0) + (pool ? 0.25 * tb : 0.0);
   prof_cost(tb + gb, 0.0);
-  if (pool) {
-    nwg = rows < BWD_MAX_WG ? rows : BWD_MAX_WG;
+  const float* fin_src = partial;
+  if (rows != nullptr) {  // the partial sums came with the dgrad that produced dact (per conv tile, centred s2)
+    if (nrows <= BWD_MAX_WG) {
+      fin_src = rows;
+      nwg = nrows;
+    } else {
+      const int G = (nrows + BWD_MAX_WG - 1) / BWD_MAX_WG;
+      nwg = (nrows + G - 1) / G;
+      SPCL_LAUNCH(bwd_rows_group_kernel, dim3(nwg), dim3(256), 0, st, rows, nrows, G, CS, partial);
+    }
+  } else if (pool) {
+    nwg = prows < BWD_MAX_WG ? prows : BWD_MAX_WG;
     SPCL_LAUNCH((bnrelu_bwd_pool_kernel<T, false>), dim3(nwg), dim3(256), 0, st, (const T*)y, (const T*)dact,
                        (const T*)dpool, N, H, W, CS, mean, invstd, scale, shift, (const float*)nullptr, partial,
                        (T*)nullptr);
@@ -752,12 +779,12 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
                        CS, mean, invstd, scale, shift, partial);
   }
   float* zrow = ab + 2 * CS + (size_t)IMG_WGRAD_WG * 9 * CS;  // [W] zeros (image-wgrad pass only, see below)
-  SPCL_LAUNCH(bnrelu_bwd_fin_kernel, dim3(CS), dim3(256), 0, st, (const float*)partial, nwg, C, CS,
+  SPCL_LAUNCH(bnrelu_bwd_fin_kernel, dim3(CS), dim3(256), 0, st, fin_src, nwg, C, CS,
                      M, training, mean, invstd, scale, dgamma, dbeta, ab, img != nullptr ? zrow : (float*)nullptr,
-                     img != nullptr ? W : 0);
+                     img != nullptr ? W : 0, rows != nullptr ? 1 : 0);
   prof_cost(2.0 * tb + gb, 0.0);
   if (pool) {
-    SPCL_LAUNCH((bnrelu_bwd_pool_kernel<T, true>), dim3(rows < STREAM_MAX_WG ? rows : STREAM_MAX_WG), dim3(256), 0, st, (const T*)y,
+    SPCL_LAUNCH((bnrelu_bwd_pool_kernel<T, true>), dim3(prows < STREAM_MAX_WG ? prows : STREAM_MAX_WG), dim3(256), 0, st, (const T*)y,
                        (const T*)dact, (const T*)dpool, N, H, W, CS, mean, invstd, scale, shift, (const float*)ab,
                        (float*)nullptr, (T*)dy);
   } else if (img != nullptr) {  // first conv of a one-channel image block: dy is consumed in registers by its dW
@@ -887,5 +914,33 @@ extern "C" int spcl_bnrelu_backward_image_wgrad(const void* y, const void* dact,
     return SPCL_EINVAL;
   }
   SPCL_LAUNCH_CHECK("bnrelu_backward_image_wgrad");
+  return SPCL_OK;
+}
+
+
+extern "C" int spcl_bnrelu_backward_rows(const void* y, const void* dact, const float* image, const float* rows, int nrows,
+                                         int dtype, int N, int H, int W, int C, int CS, const float* mean,
+                                         const float* invstd, const float* scale, const float* shift, int training,
+                                         float* ws, float* dgamma, float* dbeta, void* dy, float* dw, void* stream) {
+  SPCL_CHECK_ARG(y && dact && rows && mean && invstd && scale && shift && ws && dgamma && dbeta,
+                 "bnrelu_backward_rows: null pointer");
+  SPCL_CHECK_ARG((image != nullptr) == (dw != nullptr) && (image != nullptr) != (dy != nullptr),
+                 "bnrelu_backward_rows: either (image, dw) for the fused first-layer weight gradient or dy");
+  SPCL_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && CS >= C && CS % 16 == 0 && CS <= 1024 && nrows > 0,
+                 "bnrelu_backward_rows: bad shape");
+  SPCL_CHECK_ARG(image == nullptr || (CS <= 256 && (CS & (CS - 1)) == 0), "bnrelu_backward_rows: image path needs CS "
+                 "a power of two in 16..256");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SPCL_F32)
+    bnrelu_bwd_launch<float>(y, dact, nullptr, N, H, W, C, CS, mean, invstd, scale, shift, training, ws, dgamma, dbeta, dy,
+                             st, image, dw, rows, nrows);
+  else if (dtype == SPCL_BF16)
+    bnrelu_bwd_launch<bf16_t>(y, dact, nullptr, N, H, W, C, CS, mean, invstd, scale, shift, training, ws, dgamma, dbeta,
+                              dy, st, image, dw, rows, nrows);
+  else {
+    set_error("bnrelu_backward_rows: dtype %d", dtype);
+    return SPCL_EINVAL;
+  }
+  SPCL_LAUNCH_CHECK("bnrelu_backward_rows");
   return SPCL_OK;
 }

@@ -492,3 +492,52 @@ extern "C" int spcl_conv3x3_forward(const void* x, int dtype, int N, int H, int 
   SPCL_LAUNCH_CHECK("conv3x3_forward");
   return SPCL_OK;
 }
+
+// dgrad of the SECOND conv of a block fused with the per-tile partial sums of the FIRST conv's BatchNorm backward (the
+// dgrad's output g is the gradient of relu(bn(y2))): saves the separate reduction pass over (y2, g).  Only where a
+// specialised kernel exists (bf16, tiles of 14 columns): ask spcl_conv_dgrad_bnstats_supported first.
+static bool dgrad_bnstats_args(ConvArgs& a, int dtype, int N, int H, int W, int CinK, int CoutS) {
+  if (dtype != SPCL_BF16 || N <= 0 || H <= 0 || W <= 0 || CinK % 16 != 0 || CoutS % 16 != 0) return false;
+  if (!(CinK <= 64 || CinK % 64 == 0)) return false;
+  a.in_scale = a.in_shift = nullptr;
+  a.stats = nullptr;
+  a.N = N; a.H = H; a.W = W; a.CinS = CinK; a.CinK = CinK; a.CoutS = CoutS; a.in_mode = 0;
+  a.tilesX = a.tilesY = 0;
+  a.tpw = 1;
+  a.dbg = 0;
+  return true;
+}
+
+extern "C" int spcl_conv_dgrad_bnstats_supported(int dtype, int N, int H, int W, int CinK, int CoutS) {
+  static const bool off = getenv("SPCL_NO_DGRAD_BNSTATS") != nullptr;  // A/B switch
+  ConvArgs a;
+  if (off || !dgrad_bnstats_args(a, dtype, N, H, W, CinK, CoutS)) return 0;
+  a.x = nullptr; a.y = nullptr; a.wp = nullptr;
+  float dummy;
+  a.rows2 = &dummy;
+  TileCfg t = pick_tile(H, W);
+  return (t.tw == 14 && launch_conv_fast(a, t.th, nullptr, true)) ? 1 : 0;
+}
+
+extern "C" int spcl_conv3x3_dgrad_bnstats(const void* dy, int dtype, int N, int H, int W, int CinK, int CoutS,
+                                          const void* w_packed, void* g, const void* y2, const float* scale2,
+                                          const float* shift2, const float* mean2, float* rows2, void* stream) {
+  SPCL_CHECK_ARG(dy && w_packed && g && y2 && scale2 && shift2 && mean2 && rows2, "conv3x3_dgrad_bnstats: null pointer");
+  ConvArgs a;
+  if (!dgrad_bnstats_args(a, dtype, N, H, W, CinK, CoutS)) {
+    set_error("conv3x3_dgrad_bnstats: unsupported configuration");
+    return SPCL_EUNSUPPORTED;
+  }
+  a.x = dy; a.y = g; a.wp = w_packed;
+  a.y2 = y2; a.scale2 = scale2; a.shift2 = shift2; a.mean2 = mean2; a.rows2 = rows2;
+  hipStream_t st = (hipStream_t)stream;
+  const double px = (double)N * H * W;
+  prof_cost(px * (CinK + 2.0 * CoutS) * 2.0 + 9.0 * CinK * CoutS * 2.0, 2.0 * px * 9.0 * CinK * CoutS);
+  TileCfg t = pick_tile(H, W);
+  if (!(t.tw == 14 && launch_conv_fast(a, t.th, st))) {
+    set_error("conv3x3_dgrad_bnstats: no specialised kernel for H=%d W=%d CinK=%d CoutS=%d", H, W, CinK, CoutS);
+    return SPCL_EUNSUPPORTED;
+  }
+  SPCL_LAUNCH_CHECK("conv3x3_dgrad_bnstats");
+  return SPCL_OK;
+}

@@ -37,6 +37,12 @@ struct ConvArgs {
   int tpw;  // tiles per workgroup (processed sequentially)
   int dbg;  // ablation bits (experiments only, 0 in production): 1 no BN transform, 2 no k-loop, 4 no stats,
             // 8 no output stores, 16 no staging loads
+  // dgrad + BatchNorm-backward partial sums of the layer whose activation gradient this conv produces (fast path only)
+  const void* y2 = nullptr;
+  const float* scale2 = nullptr;
+  const float* shift2 = nullptr;
+  const float* mean2 = nullptr;
+  float* rows2 = nullptr;
 };
 
 template <typename T> __device__ __forceinline__ f32x4 mfma_chunk(u32x4 w, u32x4 x, f32x4 acc);
@@ -117,6 +123,6 @@ __device__ __forceinline__ void write_tile_stats(float* stats, int tile, int Cou
 }
 
 // conv_fast.hip: returns true when a specialised kernel exists for this configuration and was launched
-bool launch_conv_fast(const ConvArgs& a, int th, hipStream_t st);
+bool launch_conv_fast(const ConvArgs& a, int th, hipStream_t st, bool dry = false);
 
 }  // namespace spcl

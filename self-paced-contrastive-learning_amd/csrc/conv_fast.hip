@@ -21,6 +21,12 @@ struct FastArgs {
   const float* in_scale;
   const float* in_shift;
   int N, H, W, CinK, CoutS, tilesX, tilesY, gy;
+  // MODE 2 (dgrad whose output g is the gradient of relu(bn(y2))): per-tile partial sums of that BatchNorm's backward
+  const unsigned char* y2;  // [N][H][W][CoutS] raw conv output of the layer being differentiated
+  const float* scale2;      // its BN scale / shift / mean, [CoutS]
+  const float* shift2;
+  const float* mean2;
+  float* rows2;             // [tile][2][CoutS]: sum dz, sum dz (y2 - mean)
 };
 
 // waves per SIMD the register allocator must leave room for: what the tile's LDS footprint allows anyway, at most 4
@@ -183,11 +189,20 @@ conv3x3_fast_kernel(FastArgs a) {
   int ob = (py * a.W + px) * rowb;
   const int dob = (DPY * a.W + DPX) * rowb, wrapo = (a.W - TW) * rowb;
   f32x4 ssum[NT], ssq[NT];
+  f32x4 sc2[NT], sh2[NT], mu2[NT];  // MODE 2: BN coefficients of this lane's 4 channels per n-tile
+  const unsigned char* y2b = nullptr;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     ssum[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     ssq[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (MODE == 2) {
+      const int cb = (nt0 + j) * 16 + 4 * g;
+      sc2[j] = *(const f32x4*)(a.scale2 + cb);
+      sh2[j] = *(const f32x4*)(a.shift2 + cb);
+      mu2[j] = *(const f32x4*)(a.mean2 + cb);
+    }
   }
+  if (MODE == 2) y2b = a.y2 + (yb - a.y);
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const bool ok = (16 * i + 15 < NPIX) || (16 * i + r16 < NPIX);  // compile-time true except in the last m-tile
@@ -195,8 +210,26 @@ conv3x3_fast_kernel(FastArgs a) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         store4_fast<bf16_t>(yb + ob + j * 32, acc[i][j]);
-        ssum[j] += acc[i][j];
-        ssq[j] += acc[i][j] * acc[i][j];
+        if (MODE == 2) {
+          // dz = g [relu(bn(y2)) > 0] with g as STORED (bf16): sum dz and sum dz (y2 - mean) of the lane's 4 channels
+          const uint2 yr = *(const uint2*)(y2b + ob + j * 32);
+          const f32x2 glo = {acc[i][j][0], acc[i][j][1]}, ghi = {acc[i][j][2], acc[i][j][3]};
+          const uint32_t g0 = __builtin_bit_cast(uint32_t, __builtin_convertvector(glo, bf16x2v));
+          const uint32_t g1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(ghi, bf16x2v));
+          const float yv[4] = {__uint_as_float(yr.x << 16), __uint_as_float(yr.x & 0xffff0000u),
+                               __uint_as_float(yr.y << 16), __uint_as_float(yr.y & 0xffff0000u)};
+          const float gv[4] = {__uint_as_float(g0 << 16), __uint_as_float(g0 & 0xffff0000u),
+                               __uint_as_float(g1 << 16), __uint_as_float(g1 & 0xffff0000u)};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float dz = fmaf(sc2[j][r], yv[r], sh2[j][r]) > 0.f ? gv[r] : 0.f;
+            ssum[j][r] += dz;
+            ssq[j][r] = fmaf(dz, yv[r] - mu2[j][r], ssq[j][r]);
+          }
+        } else {
+          ssum[j] += acc[i][j];
+          ssq[j] += acc[i][j] * acc[i][j];
+        }
       }
     }
     px += DPX;
@@ -206,7 +239,18 @@ conv3x3_fast_kernel(FastArgs a) {
       ob += wrapo;
     }
   }
-  if (a.stats != nullptr) {
+  if (MODE == 2) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      f32x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float s1 = row16_sum(ssum[j][r]), s2 = row16_sum(ssq[j][r]);
+        o[r] = r16 == 0 ? s1 : s2;
+      }
+      if (r16 < 2) *(f32x4*)(a.rows2 + ((size_t)tile * 2 + r16) * a.CoutS + (nt0 + j) * 16 + 4 * g) = o;
+    }
+  } else if (a.stats != nullptr) {
 #pragma unroll
     for (int j = 0; j < NT; ++j)
       write_tile_stats(a.stats, tile, a.CoutS, (nt0 + j) * 16 + 4 * g, r16, (float)NPIX, ssum[j], ssq[j]);
@@ -303,19 +347,21 @@ static void launch_fast(const FastArgs& a, int mode, hipStream_t st) {
   const size_t lds = fast_lds_bytes(KC, TH);
   dim3 grid(a.tilesX, a.tilesY, a.N * a.gy), block(64 * NW);
   if (mode == 1) SPCL_LAUNCH((conv3x3_fast_kernel<KC, TH, NT, 1, NW>), grid, block, lds, st, a);
+  else if (a.rows2 != nullptr) SPCL_LAUNCH((conv3x3_fast_kernel<KC, TH, NT, 2, NW>), grid, block, lds, st, a);
   else SPCL_LAUNCH((conv3x3_fast_kernel<KC, TH, NT, 0, NW>), grid, block, lds, st, a);
 }
 
-bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st) {
+bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
   if (c.H % th != 0 || c.W % 14 != 0) return false;
   if (c.in_mode == 2) {
     if (c.CinS != 1 || c.CoutS != 16 || th != 14) return false;
     FastArgs a;
     a.x = (const unsigned char*)c.x; a.y = (unsigned char*)c.y; a.wp = (const u32x4*)c.wp; a.stats = c.stats;
     a.in_scale = a.in_shift = nullptr;
+    a.y2 = nullptr; a.scale2 = a.shift2 = a.mean2 = nullptr; a.rows2 = nullptr;
     a.N = c.N; a.H = c.H; a.W = c.W; a.CinK = 16; a.CoutS = 16;
     a.tilesX = c.W / 14; a.tilesY = c.H / 14; a.gy = 1;
-    SPCL_LAUNCH((conv3x3_image_kernel<14>), dim3(a.tilesX, a.tilesY, a.N), dim3(64), 0, st, a);
+    if (!dry) SPCL_LAUNCH((conv3x3_image_kernel<14>), dim3(a.tilesX, a.tilesY, a.N), dim3(64), 0, st, a);
     return true;
   }
   if (c.CinS != c.CinK) return false;
@@ -332,11 +378,13 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st) {
   FastArgs a;
   a.x = (const unsigned char*)c.x; a.y = (unsigned char*)c.y; a.wp = (const u32x4*)c.wp; a.stats = c.stats;
   a.in_scale = c.in_scale; a.in_shift = c.in_shift;
+  a.y2 = (const unsigned char*)c.y2; a.scale2 = c.scale2; a.shift2 = c.shift2; a.mean2 = c.mean2; a.rows2 = c.rows2;
+  if (c.rows2 != nullptr && c.in_mode != 0) return false;
   a.N = c.N; a.H = c.H; a.W = c.W; a.CinK = c.CinK; a.CoutS = c.CoutS;
   a.tilesX = c.W / 14; a.tilesY = c.H / th; a.gy = ntn / (NT * nw);
 #define SPCL_FAST_CASE(KC_, TH_, NT_, NW_)                               \
   if (KC == KC_ && th == TH_ && NT == NT_ && nw == NW_) {                \
-    launch_fast<KC_, TH_, NT_, NW_>(a, c.in_mode, st);                   \
+    if (!dry) launch_fast<KC_, TH_, NT_, NW_>(a, c.in_mode, st);         \
     return true;                                                         \
   }
   SPCL_FAST_CASE(16, 14, 1, 1)  // Conv1.b forward / dgrad (16 -> 16 @ 224^2)

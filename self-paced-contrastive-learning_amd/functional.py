@@ -339,6 +339,41 @@ def _image_wgrad_fusable(cfg, cin, cout_s):
     return cfg.image_input and cin == 1 and cout_s <= 256 and cout_s & (cout_s - 1) == 0
 
 
+def _dgrad_bnstats(dy, wp_t, y2, st2, dt_code, dtype, N, H, W, cin_k, cout_s):
+    """input gradient of a block's second conv + the per-tile partial sums of the first conv's BN backward (one kernel)
+    -> (g, rows) or None where no specialised kernel exists (the caller then runs the separate reduction pass)."""
+    if not _n.call("spcl_conv_dgrad_bnstats_supported", dt_code, N, H, W, cin_k, cout_s):
+        return None
+    dev = dy.device
+    nt = _n.call("spcl_conv_num_tiles", N, H, W)
+    g = torch.empty(N, H, W, cout_s, dtype=dtype, device=dev)
+    rows = torch.empty(nt * 2 * cout_s, dtype=torch.float32, device=dev)
+    _n.call("spcl_conv3x3_dgrad_bnstats", _n.ptr(dy), dt_code, N, H, W, cin_k, cout_s, _n.ptr(wp_t), _n.ptr(g),
+            _n.ptr(y2), _n.ptr(st2[2]), _n.ptr(st2[3]), _n.ptr(st2[0]), _n.ptr(rows), _n.stream())
+    rows.ntiles = nt
+    return g, rows
+
+
+def _bnrelu_bwd_rows(y, dact, image, rows, dt_code, dtype, N, H, W, C, cs, st, training, sinks):
+    """BN+ReLU backward finished from the dgrad's per-tile rows -> (dy or dW, dgamma, dbeta)."""
+    dev = y.device
+    nbytes = _n.call("spcl_bnrelu_image_wgrad_workspace_bytes" if image is not None else
+                     "spcl_bnrelu_bwd_workspace_bytes", N, H, W, cs)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    if image is not None:
+        first = _grad_buffer(sinks[0], (C, 1, 3, 3), dev)
+        dgamma, dbeta = _grad_buffer(sinks[1], (C,), dev), _grad_buffer(sinks[2], (C,), dev)
+        dy, dw = None, first
+    else:
+        first = torch.empty(N, H, W, cs, dtype=dtype, device=dev)
+        dgamma, dbeta = _grad_buffer(sinks[0], (C,), dev), _grad_buffer(sinks[1], (C,), dev)
+        dy, dw = first, None
+    _n.call("spcl_bnrelu_backward_rows", _n.ptr(y), _n.ptr(dact), _n.ptr(image), _n.ptr(rows), rows.ntiles, dt_code, N,
+            H, W, C, cs, _n.ptr(st[0]), _n.ptr(st[1]), _n.ptr(st[2]), _n.ptr(st[3]), int(training), _n.ptr(ws),
+            _n.ptr(dgamma), _n.ptr(dbeta), _n.ptr(dy), _n.ptr(dw), _n.stream())
+    return first, dgamma, dbeta
+
+
 class _ConvBlockFn(torch.autograd.Function):
     """[conv3x3 -> BN -> ReLU] x2 (+ 2x2 max-pool), semi_seg/arch/unet.py:67-82 + :118-121, as HIP kernels.
 
@@ -405,14 +440,31 @@ class _ConvBlockFn(torch.autograd.Function):
         wpa_t, wpb_t = ctx.packed_t
         if wpb_t is None:
             wpb_t = _pack(wb, 1, dtc, dtype)
-        daa, _ = _conv(dyb, dtc, dtype, N, H, W, cout_s, cout_s, cout_s, wpb_t, 0, None, None, False)
-        # ---- first conv
-        if ctx.needs_input_grad[1] and not ctx.needs_input_grad[0] and _image_wgrad_fusable(cfg, cin, cout_s):
-            dya = None  # dy of this layer feeds only dW: one fused pass, nothing written
-            dwa, dga, dba = _bnrelu_bwd_image_wgrad(ya, daa, xs, dtc, N, H, W, cout, cout_s, sta, cfg.training,
-                                                    sk[0:3])
+        # the dgrad's output is d loss / d relu(bn_a(ya)): where a specialised kernel exists its epilogue also leaves the
+        # per-tile partial sums of bn_a's backward (no separate reduction pass over ya and the gradient)
+        fused = _dgrad_bnstats(dyb, wpb_t, ya, sta, dtc, dtype, N, H, W, cout_s, cout_s) if dtype == torch.bfloat16 \
+            else None
+        if fused is not None:
+            daa, rows = fused
         else:
-            dya, dga, dba = _bnrelu_bwd(ya, daa, None, dtc, dtype, N, H, W, cout, cout_s, sta, cfg.training, sk[1:3])
+            daa, _ = _conv(dyb, dtc, dtype, N, H, W, cout_s, cout_s, cout_s, wpb_t, 0, None, None, False)
+        # ---- first conv
+        image_fused = ctx.needs_input_grad[1] and not ctx.needs_input_grad[0] and _image_wgrad_fusable(cfg, cin, cout_s)
+        if image_fused:
+            dya = None  # dy of this layer feeds only dW: one fused pass, nothing written
+            if fused is not None:
+                dwa, dga, dba = _bnrelu_bwd_rows(ya, daa, xs, rows, dtc, dtype, N, H, W, cout, cout_s, sta, cfg.training,
+                                                 sk[0:3])
+            else:
+                dwa, dga, dba = _bnrelu_bwd_image_wgrad(ya, daa, xs, dtc, N, H, W, cout, cout_s, sta, cfg.training,
+                                                        sk[0:3])
+        else:
+            if fused is not None:
+                dya, dga, dba = _bnrelu_bwd_rows(ya, daa, None, rows, dtc, dtype, N, H, W, cout, cout_s, sta,
+                                                 cfg.training, sk[1:3])
+            else:
+                dya, dga, dba = _bnrelu_bwd(ya, daa, None, dtc, dtype, N, H, W, cout, cout_s, sta, cfg.training,
+                                            sk[1:3])
             dwa = _wgrad(xs, dya, dtc, N, H, W, cin, cin_s, cin_k, cout, cout_s, mode_a, None, None, sk[0]) \
                 if ctx.needs_input_grad[1] else None
         dx = None

@@ -51,6 +51,10 @@ _SIGNATURES = {
     "spcl_bnrelu_backward_image_wgrad": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P,
                                                  c_int, _P, _P, _P, _P, _P]),
     "spcl_accumulate_scalars": (c_int, [c_int, _P, _P, _P, _P]),
+    "spcl_conv_dgrad_bnstats_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "spcl_conv3x3_dgrad_bnstats": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "spcl_bnrelu_backward_rows": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P,
+                                          c_int, _P, _P, _P, _P, _P, _P]),
     "spcl_conv1x1_forward": (c_int, [_P, c_int, c_size_t, c_int, c_int, c_int, _P, _P, _P, _P]),
     "spcl_conv1x1_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
     "spcl_conv1x1_backward": (c_int, [_P, _P, c_int, c_size_t, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
@@ -102,7 +106,7 @@ def call(name: str, *args):
     if fn is None:
         raise NativeLibraryError(f"libspcl_hip.so does not export {name}")
     rc = fn(*args)
-    if fn.restype is c_int and name not in ("spcl_abi_version", "spcl_conv_num_tiles", "spcl_profile_count") and rc != 0:
+    if fn.restype is c_int and name not in ("spcl_abi_version", "spcl_conv_num_tiles", "spcl_profile_count", "spcl_conv_dgrad_bnstats_supported") and rc != 0:
         raise RuntimeError(f"{name} failed ({rc}): {L.spcl_last_error().decode()}")
     return rc
 

@@ -337,6 +337,54 @@ def test_bn_finalize_many_tiles_all_launch_shapes(ntiles, C):
     assert float(st[:, C:].abs().max()) == 0.0 if cs > C else True
 
 
+@pytest.mark.parametrize("N,C,H,W", [(2, 16, 28, 28), (1, 32, 56, 28), (2, 64, 14, 14), (1, 128, 28, 14), (3, 16, 224, 42),
+                                     (9, 16, 224, 224)])
+def test_dgrad_with_fused_bn_backward_sums(N, C, H, W):
+    """spcl_conv3x3_dgrad_bnstats + spcl_bnrelu_backward_rows against the three-kernel path they replace (plain dgrad,
+    BN-backward reduction pass, apply): g bit-identical, dgamma / dbeta / dy equal up to summation order."""
+    n = _n()
+    dtype, dtc, cs = torch.bfloat16, 1, ru16(C)
+    if not n.call("spcl_conv_dgrad_bnstats_supported", dtc, N, H, W, cs, cs):
+        pytest.skip("no specialised kernel for this shape")
+    g_ = torch.Generator().manual_seed(C + H)
+    dy_in = nhwc(rnd(torch.randn(N, C, H, W, generator=g_), dtype), dtype)
+    y2 = nhwc(rnd(torch.randn(N, C, H, W, generator=g_) * 1.3 + 0.2, dtype), dtype)
+    w = torch.randn(C, C, 3, 3, generator=g_) / (3.0 * C ** 0.5)
+    wp_t = pack(n, w, 1, dtype)
+    st = torch.zeros(4, cs)
+    st[0, :C] = torch.randn(C, generator=g_) * 0.1 + 0.2          # mean
+    st[1, :C] = torch.rand(C, generator=g_) + 0.5                 # invstd
+    st[2, :C] = st[1, :C] * (torch.rand(C, generator=g_) + 0.5)   # scale = gamma * invstd
+    st[3, :C] = torch.randn(C, generator=g_) * 0.2 - st[0, :C] * st[2, :C]
+    st = st.cuda()
+    # reference path: plain dgrad, then the BN backward with its own reduction pass
+    g_ref, _ = conv(n, dy_in, dtype, N, H, W, cs, cs, cs, wp_t, 0)
+    ws = torch.empty(n.call("spcl_bnrelu_bwd_workspace_bytes", N, H, W, cs) // 4, device="cuda")
+    dg0, db0 = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    dy0 = torch.empty(N, H, W, cs, dtype=dtype, device="cuda")
+    n.call("spcl_bnrelu_pool_backward", n.ptr(y2), n.ptr(g_ref), None, dtc, N, H, W, C, cs, n.ptr(st[0]), n.ptr(st[1]),
+           n.ptr(st[2]), n.ptr(st[3]), 1, n.ptr(ws), n.ptr(dg0), n.ptr(db0), n.ptr(dy0), n.stream())
+    # fused path
+    nt = n.call("spcl_conv_num_tiles", N, H, W)
+    g1 = torch.empty(N, H, W, cs, dtype=dtype, device="cuda")
+    rows = torch.full((nt * 2 * cs,), float("nan"), device="cuda")
+    n.call("spcl_conv3x3_dgrad_bnstats", n.ptr(dy_in), dtc, N, H, W, cs, cs, n.ptr(wp_t), n.ptr(g1), n.ptr(y2),
+           n.ptr(st[2]), n.ptr(st[3]), n.ptr(st[0]), n.ptr(rows), n.stream())
+    assert torch.equal(g1, g_ref)
+    assert not torch.isnan(rows).any()
+    dg1, db1 = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    dy1 = torch.empty(N, H, W, cs, dtype=dtype, device="cuda")
+    n.call("spcl_bnrelu_backward_rows", n.ptr(y2), n.ptr(g1), None, n.ptr(rows), nt, dtc, N, H, W, C, cs, n.ptr(st[0]),
+           n.ptr(st[1]), n.ptr(st[2]), n.ptr(st[3]), 1, n.ptr(ws), n.ptr(dg1), n.ptr(db1), n.ptr(dy1), None, n.stream())
+    assert relerr(dg1, dg0) < 2e-5 and relerr(db1, db0) < 2e-5
+    assert relerr(dy1.float(), dy0.float()) < 8e-3
+    # deterministic
+    rows2 = torch.empty_like(rows)
+    n.call("spcl_conv3x3_dgrad_bnstats", n.ptr(dy_in), dtc, N, H, W, cs, cs, n.ptr(wp_t), n.ptr(g1), n.ptr(y2),
+           n.ptr(st[2]), n.ptr(st[3]), n.ptr(st[0]), n.ptr(rows2), n.stream())
+    assert torch.equal(rows, rows2)
+
+
 def test_fused_radam_matches_torch_radam():
     """spcl_radam_step == torch.optim.RAdam (CPU, single tensor) over the un-rectified (rho_t <= 5) and rectified
     steps, with weight decay and a learning-rate change in between."""
