@@ -327,6 +327,10 @@ static TileCfg pick_tile(int H, int W) {
   if (H % 14 == 0 && W % 14 == 0 && H <= t77_max_h) return {7, 7};
   if (H % 14 == 0 && W % 14 == 0 && H <= th7_max_h) return {7, 14};
   if (H % 14 == 0 && W % 14 == 0) return {14, 14};
+  // other sizes (256^2 Prostate slices, ...): still the 14-column tiles of the specialised kernels -- their last tile per
+  // row / column is shifted back inside the image -- as long as the recomputed overlap stays below a quarter
+  const int th = H <= th7_max_h ? 7 : 14;
+  if (H >= th && W >= 14 && (long)cdiv(H, th) * th * cdiv(W, 14) * 14 * 4 <= (long)H * W * 5) return {th, 14};
   return {16, 16};
 }
 

@@ -64,7 +64,11 @@ conv3x3_fast_kernel(FastArgs a) {
     by = n % a.gy;
     n /= a.gy;
   }
-  const int y0 = ty * TH, x0 = tx * TW;
+  // image sizes that are not a multiple of the tile: the last tile of a row / column is shifted back inside the image
+  // (it recomputes oy rows / ox columns of its neighbour -- identical values, written twice -- and leaves them out of
+  // its statistics)
+  const int y0 = min(ty * TH, a.H - TH), x0 = min(tx * TW, a.W - TW);
+  const int oy = ty * TH - y0, ox = tx * TW - x0;
   const int tile = (n * a.tilesY + ty) * a.tilesX + tx;
   const int ntn = a.CoutS >> 4;
   const int nt0 = (by * NW + wave) * NT;
@@ -203,10 +207,13 @@ conv3x3_fast_kernel(FastArgs a) {
     }
   }
   if (MODE == 2) y2b = a.y2 + (yb - a.y);
+  const bool shifted = (oy | ox) != 0;  // wave-uniform
+  int pyc = py;                         // the pixel's row inside the tile, walked with px
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const bool ok = (16 * i + 15 < NPIX) || (16 * i + r16 < NPIX);  // compile-time true except in the last m-tile
     if (ok) {
+      const float keep = (!shifted || (pyc >= oy && px >= ox)) ? 1.f : 0.f;  // 0: the neighbour tile counts this pixel
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         store4_fast<bf16_t>(yb + ob + j * 32, acc[i][j]);
@@ -222,20 +229,23 @@ conv3x3_fast_kernel(FastArgs a) {
                                __uint_as_float(g1 << 16), __uint_as_float(g1 & 0xffff0000u)};
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float dz = fmaf(sc2[j][r], yv[r], sh2[j][r]) > 0.f ? gv[r] : 0.f;
+            const float dz = fmaf(sc2[j][r], yv[r], sh2[j][r]) > 0.f ? gv[r] * keep : 0.f;
             ssum[j][r] += dz;
             ssq[j][r] = fmaf(dz, yv[r] - mu2[j][r], ssq[j][r]);
           }
         } else {
-          ssum[j] += acc[i][j];
-          ssq[j] += acc[i][j] * acc[i][j];
+          const f32x4 av = acc[i][j] * keep;
+          ssum[j] += av;
+          ssq[j] += av * acc[i][j];
         }
       }
     }
     px += DPX;
+    pyc += DPY;
     ob += dob;
     if (px >= TW) {
       px -= TW;
+      pyc += 1;
       ob += wrapo;
     }
   }
@@ -253,7 +263,8 @@ conv3x3_fast_kernel(FastArgs a) {
   } else if (a.stats != nullptr) {
 #pragma unroll
     for (int j = 0; j < NT; ++j)
-      write_tile_stats(a.stats, tile, a.CoutS, (nt0 + j) * 16 + 4 * g, r16, (float)NPIX, ssum[j], ssq[j]);
+      write_tile_stats(a.stats, tile, a.CoutS, (nt0 + j) * 16 + 4 * g, r16, (float)((TH - oy) * (TW - ox)), ssum[j],
+                       ssq[j]);
   }
 }
 
@@ -270,7 +281,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void co
   __shared__ uint32_t pairs[(TH + 2) * LW];
   const int lane = threadIdx.x, r16 = lane & 15, g = lane >> 4;
   const int tx = blockIdx.x, ty = blockIdx.y, n = blockIdx.z;
-  const int y0 = ty * TH, x0 = tx * TW;
+  const int y0 = min(ty * TH, a.H - TH), x0 = min(tx * TW, a.W - TW);  // shifted last tiles, as in the kernel above
+  const int oy = ty * TH - y0, ox = tx * TW - x0;
   const int tile = (n * a.tilesY + ty) * a.tilesX + tx;
 
   // A fragment: row = cout r16, k-group g = ky: W[cout][0][ky][0..2], 0.  Packed index of (cout, ci = 0, tap):
@@ -324,22 +336,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void co
   int ob = (py * a.W + px) * rowb;
   const int dob = (DPY * a.W + DPX) * rowb, wrapo = (a.W - TW) * rowb;
   f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
+  const bool shifted = (oy | ox) != 0;
+  int pyc = py;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const bool ok = (16 * i + 15 < NPIX) || (16 * i + r16 < NPIX);
     if (ok) {
+      const float keep = (!shifted || (pyc >= oy && px >= ox)) ? 1.f : 0.f;
       store4_fast<bf16_t>(yb + ob, acc[i]);
-      ssum += acc[i];
-      ssq += acc[i] * acc[i];
+      const f32x4 av = acc[i] * keep;
+      ssum += av;
+      ssq += av * acc[i];
     }
     px += DPX;
+    pyc += DPY;
     ob += dob;
     if (px >= TW) {
       px -= TW;
+      pyc += 1;
       ob += wrapo;
     }
   }
-  if (a.stats != nullptr) write_tile_stats(a.stats, tile, a.CoutS, 4 * g, r16, (float)NPIX, ssum, ssq);
+  if (a.stats != nullptr)
+    write_tile_stats(a.stats, tile, a.CoutS, 4 * g, r16, (float)((TH - oy) * (TW - ox)), ssum, ssq);
 }
 
 template <int KC, int TH, int NT, int NW>
@@ -352,7 +371,7 @@ static void launch_fast(const FastArgs& a, int mode, hipStream_t st) {
 }
 
 bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
-  if (c.H % th != 0 || c.W % 14 != 0) return false;
+  if (c.H < th || c.W < 14) return false;
   if (c.in_mode == 2) {
     if (c.CinS != 1 || c.CoutS != 16 || th != 14) return false;
     FastArgs a;
@@ -360,7 +379,7 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
     a.in_scale = a.in_shift = nullptr;
     a.y2 = nullptr; a.scale2 = a.shift2 = a.mean2 = nullptr; a.rows2 = nullptr;
     a.N = c.N; a.H = c.H; a.W = c.W; a.CinK = 16; a.CoutS = 16;
-    a.tilesX = c.W / 14; a.tilesY = c.H / 14; a.gy = 1;
+    a.tilesX = cdiv(c.W, 14); a.tilesY = cdiv(c.H, 14); a.gy = 1;
     if (!dry) SPCL_LAUNCH((conv3x3_image_kernel<14>), dim3(a.tilesX, a.tilesY, a.N), dim3(64), 0, st, a);
     return true;
   }
@@ -381,7 +400,7 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
   a.y2 = (const unsigned char*)c.y2; a.scale2 = c.scale2; a.shift2 = c.shift2; a.mean2 = c.mean2; a.rows2 = c.rows2;
   if (c.rows2 != nullptr && c.in_mode != 0) return false;
   a.N = c.N; a.H = c.H; a.W = c.W; a.CinK = c.CinK; a.CoutS = c.CoutS;
-  a.tilesX = c.W / 14; a.tilesY = c.H / th; a.gy = ntn / (NT * nw);
+  a.tilesX = cdiv(c.W, 14); a.tilesY = cdiv(c.H, th); a.gy = ntn / (NT * nw);
 #define SPCL_FAST_CASE(KC_, TH_, NT_, NW_)                               \
   if (KC == KC_ && th == TH_ && NT == NT_ && nw == NW_) {                \
     if (!dry) launch_fast<KC_, TH_, NT_, NW_>(a, c.in_mode, st);         \

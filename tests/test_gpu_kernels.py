@@ -64,7 +64,9 @@ def conv(n, xs, dtype, N, H, W, cin_s, cin_k, cout_s, wp, mode, scale=None, shif
 
 
 SHAPES = [(2, 16, 16, 28, 28), (1, 32, 64, 20, 18), (2, 128, 64, 14, 14), (1, 64, 256, 7, 9), (3, 8, 24, 33, 16),
-          (1, 256, 256, 14, 14), (2, 32, 32, 21, 42), (1, 64, 128, 35, 14), (1, 16, 32, 126, 28), (1, 32, 16, 238, 14)]
+          (1, 256, 256, 14, 14), (2, 32, 32, 21, 42), (1, 64, 128, 35, 14), (1, 16, 32, 126, 28), (1, 32, 16, 238, 14),
+          # sizes that are not a multiple of the 14-column tiles: shifted last tiles of the specialised kernels
+          (1, 16, 16, 60, 44), (2, 32, 64, 50, 30), (1, 16, 16, 256, 64), (1, 64, 64, 64, 64), (1, 128, 128, 32, 128)]
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
