@@ -330,7 +330,9 @@ static TileCfg pick_tile(int H, int W) {
   // other sizes (256^2 Prostate slices, ...): still the 14-column tiles of the specialised kernels -- their last tile per
   // row / column is shifted back inside the image -- as long as the recomputed overlap stays below a quarter
   const int th = H <= th7_max_h ? 7 : 14;
-  if (H >= th && W >= 14 && (long)cdiv(H, th) * th * cdiv(W, 14) * 14 * 4 <= (long)H * W * 5) return {th, 14};
+  static const int max_overlap = getenv("SPCL_CONV_OVERLAP_PCT") ? atoi(getenv("SPCL_CONV_OVERLAP_PCT")) : 25;
+  if (H >= th && W >= 14 && (long)cdiv(H, th) * th * cdiv(W, 14) * 14 * 100 <= (long)H * W * (100 + max_overlap))
+    return {th, 14};
   return {16, 16};
 }
 
