@@ -329,7 +329,7 @@ static TileCfg pick_tile(int H, int W) {
   if (H % 14 == 0 && W % 14 == 0) return {14, 14};
   // other sizes (256^2 Prostate slices, ...): still the 14-column tiles of the specialised kernels -- their last tile per
   // row / column is shifted back inside the image -- as long as the recomputed overlap stays below a quarter
-  const int th = H <= th7_max_h ? 7 : 14;
+  const int th = H <= (th7_max_h > 128 ? th7_max_h : 128) ? 7 : 14;  // 128^2 (the 256^2 family's second level) like 112^2
   static const int max_overlap = getenv("SPCL_CONV_OVERLAP_PCT") ? atoi(getenv("SPCL_CONV_OVERLAP_PCT")) : 25;
   if (H >= th && W >= 14 && (long)cdiv(H, th) * th * cdiv(W, 14) * 14 * 100 <= (long)H * W * (100 + max_overlap))
     return {th, 14};
