@@ -189,3 +189,27 @@ def test_meter_batching_is_one_launch_with_the_same_sums():
     assert many[10].summary()["mean"] == float(vals[10 % 4])
     M.flush_batch()
     assert many[0].summary()["mean"] == 1.5
+
+
+@pytest.mark.parametrize("n,d", [(1, 8), (2, 1), (3, 2), (2, 255), (5, 256), (64, 3), (65, 7), (511, 16), (512, 16)])
+@pytest.mark.parametrize("mname", ["supcon1", "soft_12_cg"])
+def test_loss_edge_sizes_vs_oracle(n, d, mname):
+    """smallest batches (one slice: the only positive is the other view), 1- and 2-dimensional projections, the largest
+    supported width, and the sizes right at the schedule switches (2n = 64 / 66 -> one-launch vs sweeps, 2n = 1022 / 1024 ->
+    sweeps vs materialised logits)."""
+    mode, gamma, cg = MODES[mname]
+    g = torch.Generator().manual_seed(n * 31 + d)
+    z1 = torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=1)
+    z2 = torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=1)
+    labels = [i % 4 for i in range(n)]
+    a, b = z1.clone().requires_grad_(True), z2.clone().requires_grad_(True)
+    ref = O.supcon_loss(a, b, labels, gamma=gamma, mode=mode or "hard", correct_grad=cg)
+    ref["loss"].backward()
+    x, y = z1.cuda().requires_grad_(True), z2.cuda().requires_grad_(True)
+    crit = _crit(mode, gamma, cg)
+    loss = crit(x, y, target=labels)
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), ref["loss"].item(), rtol=1e-4, atol=1e-5)
+    scale = float(a.grad.abs().max()) + 1e-12
+    np.testing.assert_allclose(x.grad.cpu().numpy(), a.grad.numpy(), rtol=2e-3, atol=2e-4 * scale)
+    np.testing.assert_allclose(y.grad.cpu().numpy(), b.grad.numpy(), rtol=2e-3, atol=2e-4 * scale)
