@@ -275,8 +275,16 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # SPCL_BENCH_ONE_DEVICE=1 (self-test on a one-GPU box): every rank on cuda:0 over gloo, to exercise the N>1 control
+        # flow (broadcast, flat bucket all-reduce, capture fallbacks, rank-0 reporting) -- not a measurement
+        one_device = os.environ.get("SPCL_BENCH_ONE_DEVICE") == "1"
+        if one_device:
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
         torch.cuda.set_device(0)
     device = torch.device("cuda", local if world > 1 else 0)
@@ -296,13 +304,19 @@ def main():
     run = step
     used_graph = False
     if not args.no_graph:
+        # N > 1: the collective stays OUTSIDE the graphs by default (compute graph, eager all-reduce of the flat bucket,
+        # update graph).  A whole-step capture that the communication library refuses leaves the capture stream
+        # invalidated on this stack and no later capture (or eager launch on it) recovers -- found with the one-device
+        # gloo self-test (SPCL_BENCH_ONE_DEVICE=1); SPCL_BENCH_WHOLE_GRAPH=1 opts in to capturing the collective too.
+        if world > 1 and os.environ.get("SPCL_BENCH_WHOLE_GRAPH") != "1":
+            args.split_graph = True
         try:
             if args.split_graph:
                 raise RuntimeError("--split-graph")
             run = graph_capture(step, device)
             used_graph = True
         except Exception as e:  # noqa: BLE001  -- report; keep the collective outside the graphs, else eager
-            if rank == 0:
+            if rank == 0 and str(e) != "--split-graph":
                 print(f"[bench] whole-step hipGraph capture failed ({type(e).__name__}: {e})", file=sys.stderr)
             try:
                 torch.cuda.synchronize()

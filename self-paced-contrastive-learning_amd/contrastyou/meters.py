@@ -14,9 +14,10 @@ _BATCH = None
 
 
 def begin_batch():
+    """start remembering device adds.  Anything still pending from an earlier, unfinished batch (a step that raised, an
+    aborted hipGraph capture whose tensors no longer exist) is dropped, not replayed."""
     global _BATCH
-    if _BATCH is None:
-        _BATCH = []
+    _BATCH = []
 
 
 def flush_batch():
