@@ -369,15 +369,18 @@ def main():
         loss = epocher.meters.statistics()
         line["final_meters"] = {k: round(v["mean"], 5) for g in loss.values() for k, v in g.items()
                                 if k in ("loss", "sp_weight", "reg_loss")}
-    if rank == 0 and not args.no_roofline:
+    if not args.no_roofline:
+        # EVERY rank runs the instrumented steps (they contain the step's collective: rank 0 alone would wait for the
+        # others forever); rank 0 reports
         try:
             roof, breakdown, tot = measure_roofline(step, args)
-            line["roofline"] = roof
-            line["kernel_breakdown"] = breakdown
-            line["instrumented_step_ms"] = round(tot * 1e3, 3)
+            if rank == 0:
+                line["roofline"] = roof
+                line["kernel_breakdown"] = breakdown
+                line["instrumented_step_ms"] = round(tot * 1e3, 3)
         except Exception as e:  # noqa: BLE001
             line["roofline"] = None
-            print(f"[bench] roofline pass failed: {type(e).__name__}: {e}", file=sys.stderr)
+            print(f"[bench] roofline pass failed on rank {rank}: {type(e).__name__}: {e}", file=sys.stderr)
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -27,7 +27,7 @@ def test_bench_two_ranks_on_one_device():
     env = dict(os.environ, SPCL_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2",
-           "--warmup", "1", "--bs", "4", "--no-cpu-baseline", "--no-roofline"]
+           "--warmup", "1", "--bs", "4"]  # default flags otherwise: the roofline pass runs on every rank
     out = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=540)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -36,3 +36,4 @@ def test_bench_two_ranks_on_one_device():
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak"
     assert line["config"]["hipgraph"] == "split" and line["config"]["global_batch"] == 8
     assert line["value"] > 0 and line["final_meters"]["loss"] == line["final_meters"]["loss"]  # finite loss
+    assert line["roofline"] is not None and line["roofline"]["frac"] > 0 and "cpu_baseline" not in line
