@@ -99,7 +99,11 @@ class CombineEpochHook(EpocherHook):
         self._broadcast("set_epocher", epocher)
 
     def __call__(self, **kwargs):
-        return sum(self._broadcast("__call__", **kwargs))
+        losses = self._broadcast("__call__", **kwargs)
+        total = losses[0] if losses else 0  # sum() would start from 0 + loss: one more launch for the same value
+        for extra in losses[1:]:
+            total = total + extra
+        return total
 
     def close(self):
         self._broadcast("close")
