@@ -32,6 +32,44 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA
 MFMA_F32_PEAK_TFLOPS = 157.3
 
 
+class Watchdog:
+    """N > 1 only: a rank whose peers stopped answering must EXIT non-zero instead of sitting in a collective.  A daemon
+    thread watches a heartbeat the main thread touches between phases / steps; after ``limit`` seconds of silence it
+    dumps every thread's stack and leaves with ``os._exit(3)`` (never a re-exec of a process that holds the GPU)."""
+
+    def __init__(self, limit):
+        import threading
+        self.limit, self.t, self.phase, self.on = float(limit), time.monotonic(), "start", True
+        threading.Thread(target=self._run, daemon=True).start()
+
+    def beat(self, phase=None):
+        self.t = time.monotonic()
+        if phase is not None:
+            self.phase = phase
+
+    def stop(self):
+        self.on = False
+
+    def _run(self):
+        import faulthandler
+        while self.on:
+            time.sleep(1.0)
+            if self.on and time.monotonic() - self.t > self.limit:
+                print(f"[bench] rank {os.environ.get('RANK', '0')}: no progress for {self.limit:.0f} s in phase "
+                      f"'{self.phase}' -- a peer or a collective stalled; exiting 3", file=sys.stderr, flush=True)
+                faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+                sys.stderr.flush()
+                os._exit(3)
+
+
+class _NoWatchdog:
+    def beat(self, phase=None):
+        pass
+
+    def stop(self):
+        pass
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -44,6 +82,8 @@ def parse():
     ap.add_argument("--split-graph", action="store_true", help="force the compute / collective / update split capture")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra keys (per-replay distribution, contrastive 4096x128 microbench)")
     ap.add_argument("--cpu-bs", type=int, default=8, help="batch of the CPU-oracle sample (bounded work)")
     ap.add_argument("--workload", default="pretrain", choices=["pretrain", "contrastive", "finetune", "prostate"],
                     help="pretrain = BASELINE configs[1] (the metric); prostate = configs[3] shape: 256x256, bs=64/GPU, "
@@ -198,8 +238,9 @@ def measure_roofline(step, args):
             continue  # kernels without a declared cost (latency-bound glue) cannot carry a roofline
         avg = g["t"] / g["n"]
         peak_tf = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
-        traffic = None
-        try:  # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, KiB -> bytes)
+        traffic, latest = None, None
+        try:  # HBM bytes per launch: NOT measured in this run -- read from the committed PMC passes of profiles/
+            # (tools/pmc_traffic.py: separate rocprofv3 --pmc runs, 2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes)
             import glob
             latest = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_hbm_traffic.json")))[-1]  # newest round
             traffic = json.load(open(latest))[sym]["hbm_bytes_per_launch_corrected"]
@@ -213,7 +254,9 @@ def measure_roofline(step, args):
             ach = g["flops"] / g["t"] / 1e12
             out = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak_tf, "unit": "TFLOP/s",
                    "frac": round(ach / peak_tf, 4), "traffic": traffic}
-        out.update({"kernel": sym, "avg_us": round(avg * 1e6, 2), "launches_per_step": g["n"] / reps,
+        out.update({"kernel": sym, "traffic_source": (os.path.relpath(latest, REPO) + " (committed PMC profile, not this run)"
+                                                      if traffic is not None else None),
+                    "avg_us": round(avg * 1e6, 2), "launches_per_step": g["n"] / reps,
                     "algorithmic_bytes_per_launch": int(g["bytes"] / g["n"]),
                     "algorithmic_flops_per_launch": float(g["flops"] / g["n"]),
                     "mfma_tflops": round(g["flops"] / g["t"] / 1e12, 1),
@@ -231,39 +274,56 @@ def measure_roofline(step, args):
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
 def cpu_baseline(args):
-    """The oracle's restatement of the same step on the host cores: bounded sample (a few steps at --cpu-bs)."""
+    """The oracle's restatement of the same step on the host cores: bounded samples at bs=8 (BASELINE configs[0]'s CPU
+    shape) and at the GPU leg's bs, same gamma / labels / optimizer settings as the GPU leg."""
     from oracle import spcl_oracle as O
-    threads = min(os.cpu_count() or 1, 32)  # torch's CPU conv stops scaling (and collapses) far below 256 threads
+    cores = os.cpu_count() or 1
+    threads = min(cores, 32)  # torch's CPU conv stops scaling (and collapses) far below 256 threads
     torch.set_num_threads(threads)
-    bs = args.cpu_bs
-    g = torch.Generator().manual_seed(1234)
-    sd = O.init_unet_state(1, 4, 256, seed=10, encoder_only=True)
-    sd = {k: (v.requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in sd.items()}
-    psd = {k: v.requires_grad_(True) for k, v in O.init_projector_state(256, 256, 256, seed=11).items()}
-    leaves = [v for v in list(sd.values()) + list(psd.values()) if v.is_floating_point() and v.requires_grad]
-    opt = torch.optim.RAdam(leaves, lr=2e-4, weight_decay=1e-5)
-    img = torch.rand(bs, 1, args.size, args.size, generator=g)
-    img_tf = torch.rand(bs, 1, args.size, args.size, generator=g)
-    labels = [i % 3 for i in range(bs)]
+    gamma = 3.0 + 67.0 * (40 / 80) ** 0.5  # the GPU leg's mid-schedule age parameter (build_step)
 
-    def one():
-        r = O.pretrain_step(img, img_tf, sd, psd, labels, gamma=3.0, mode="soft", correct_grad=True)
-        for k, p in list(sd.items()) + list(psd.items()):
-            if k in r["grads"] and r["grads"][k] is not None:
-                p.grad = r["grads"][k]
-        opt.step()
-        opt.zero_grad()
+    def sample(bs, budget_s):
+        g = torch.Generator().manual_seed(1234)
+        sd = O.init_unet_state(1, 4, 256, seed=10, encoder_only=True)
+        sd = {k: (v.requires_grad_(True) if v.is_floating_point() and "running" not in k else v)
+              for k, v in sd.items()}
+        psd = {k: v.requires_grad_(True) for k, v in O.init_projector_state(256, 256, 256, seed=11).items()}
+        leaves = [v for v in list(sd.values()) + list(psd.values()) if v.is_floating_point() and v.requires_grad]
+        opt = torch.optim.RAdam(leaves, lr=5e-7 * 400, weight_decay=1e-5)
+        img = torch.rand(bs, 1, args.size, args.size, generator=g)
+        img_tf = torch.rand(bs, 1, args.size, args.size, generator=g)
+        labels = [i % 3 for i in range(bs)]
 
-    one()  # warm-up
-    t0 = time.perf_counter()
-    n = 0
-    while n < 2 or (time.perf_counter() - t0 < 10.0 and n < 40):
-        one()
-        n += 1
-    dt = time.perf_counter() - t0
-    return {"value": round(bs * n / dt, 2), "unit": "slices/s", "cores": threads, "kind": "port",
-            "sample": f"{n} steps of the oracle's pre-train step (fwd+bwd+RAdam) at bs={bs} ({2 * bs} images "
-                      f"{args.size}x{args.size}), fp32, torch CPU {threads} threads, {dt:.1f}s"}
+        def one():
+            r = O.pretrain_step(img, img_tf, sd, psd, labels, gamma=gamma, mode="soft", correct_grad=True)
+            for k, p in list(sd.items()) + list(psd.items()):
+                if k in r["grads"] and r["grads"][k] is not None:
+                    p.grad = r["grads"][k]
+            opt.step()
+            opt.zero_grad()
+
+        one()  # warm-up
+        t0 = time.perf_counter()
+        n = 0
+        while n < 2 or (time.perf_counter() - t0 < budget_s and n < 40):
+            one()
+            n += 1
+        dt = time.perf_counter() - t0
+        return bs * n / dt, n, dt
+
+    small = sample(args.cpu_bs, 8.0)
+    out = {"value": round(small[0], 2), "unit": "slices/s", "cores": threads, "kind": "port",
+           "host_cpu_count": cores,
+           "sample": f"{small[1]} steps of the oracle's pre-train step (fwd+bwd+RAdam) at bs={args.cpu_bs} "
+                     f"({2 * args.cpu_bs} images {args.size}x{args.size}), fp32, gamma={gamma:.1f} soft, torch CPU "
+                     f"{threads} threads of {cores} host CPUs, {small[2]:.1f}s",
+           "parallel_info": " | ".join(ln.strip() for ln in torch.__config__.parallel_info().splitlines()
+                                       if "threads" in ln or "OpenMP" in ln or "MKL" in ln)[:400]}
+    if args.bs != args.cpu_bs:
+        big = sample(args.bs, 8.0)
+        out["at_gpu_batch"] = {"value": round(big[0], 2), "bs": args.bs,
+                               "sample": f"{big[1]} steps at bs={args.bs}, {big[2]:.1f}s"}
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ main
@@ -272,9 +332,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    wd = _NoWatchdog()
     if world > 1:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # a stalled peer must end the run, not hang it: bounded process-group timeout + the heartbeat watchdog
+        limit = float(os.environ.get("SPCL_BENCH_WATCHDOG_S", "60"))
+        pg_timeout = datetime.timedelta(seconds=max(2 * limit, 120.0))
         # SPCL_BENCH_ONE_DEVICE=1 (self-test on a one-GPU box): every rank on cuda:0 over gloo, to exercise the N>1 control
         # flow (broadcast, flat bucket all-reduce, capture fallbacks, rank-0 reporting) -- not a measurement
         one_device = os.environ.get("SPCL_BENCH_ONE_DEVICE") == "1"
@@ -282,9 +347,10 @@ def main():
             local = 0
         torch.cuda.set_device(local)
         if one_device:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=pg_timeout)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=pg_timeout)
+        wd = Watchdog(limit)
     else:
         torch.cuda.set_device(0)
     device = torch.device("cuda", local if world > 1 else 0)
@@ -300,8 +366,10 @@ def main():
             args.bs = 64
         if "--size" not in sys.argv:
             args.size = 256
+    wd.beat("build")
     step, epocher, nparams = build_step(args, device, rank, world)
     run = step
+    wd.beat("capture")
     used_graph = False
     if not args.no_graph:
         # N > 1: the collective stays OUTSIDE the graphs by default (compute graph, eager all-reduce of the flat bucket,
@@ -327,9 +395,12 @@ def main():
                     print(f"[bench] split capture failed too ({type(e2).__name__}: {e2}); running eagerly",
                           file=sys.stderr)
                 run = step
+    wd.beat("warmup")
     for _ in range(args.warmup):
         run()
+        wd.beat()
     torch.cuda.synchronize()
+    wd.beat("timed")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -341,11 +412,17 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    wd.beat("reduce")
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-
+    # per-replay distribution AFTER the timed region (HIP events on the launch stream around every single replay):
+    # median / p10 / p90 of one step's GPU time -- an extra key, `value` stays the wall-clock aggregate above
+    replay = None
+    if not args.no_extras:
+        wd.beat("replay distribution")
+        replay = replay_distribution(run, max(args.steps, 50) if world == 1 else args.steps, wd)
     ms = elapsed / args.steps * 1e3
     value = args.bs * world * args.steps / elapsed
     prostate = args.workload == "prostate"
@@ -369,26 +446,63 @@ def main():
         loss = epocher.meters.statistics()
         line["final_meters"] = {k: round(v["mean"], 5) for g in loss.values() for k, v in g.items()
                                 if k in ("loss", "sp_weight", "reg_loss")}
-    if not args.no_roofline:
-        # EVERY rank runs the instrumented steps (they contain the step's collective: rank 0 alone would wait for the
-        # others forever); rank 0 reports
+    if replay is not None:
+        line["replay_us"] = replay
+    if not args.no_roofline and rank == 0:
+        # rank 0 alone runs the instrumented steps, WITHOUT the collective (it is not a kernel of this library): compute
+        # + update phases only, so no peer is needed and a failure here cannot leave another rank inside a collective
+        wd.beat("roofline")
         try:
-            roof, breakdown, tot = measure_roofline(step, args)
-            if rank == 0:
-                line["roofline"] = roof
-                line["kernel_breakdown"] = breakdown
-                line["instrumented_step_ms"] = round(tot * 1e3, 3)
+            roof, breakdown, tot = measure_roofline(local_step(step), args)
+            line["roofline"] = roof
+            line["kernel_breakdown"] = breakdown
+            line["instrumented_step_ms"] = round(tot * 1e3, 3)
         except Exception as e:  # noqa: BLE001
             line["roofline"] = None
             print(f"[bench] roofline pass failed on rank {rank}: {type(e).__name__}: {e}", file=sys.stderr)
+    wd.beat("final barrier")
     if world > 1:
         dist.barrier()
+    wd.stop()
+    if rank == 0 and world == 1 and not args.no_extras:
+        try:
+            line["extra"] = {"contrastive_4096x128": contrastive_numbers(device, steps=50, warmup=10)}
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] contrastive extra failed: {type(e).__name__}: {e}", file=sys.stderr)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def local_step(step):
+    """the step without its collective (compute + update phases of the epocher): what one GPU's kernels do"""
+    epocher, batch = step.epocher, step.batch
+
+    def run():
+        with epocher.meters.focus_on(epocher.meter_focus):
+            epocher.step_update(epocher.step_compute(batch, seed=7))
+    return run
+
+
+def replay_distribution(run, k, wd=None):
+    """GPU time of single steps: HIP events (torch's current stream == the launch stream of every kernel and of the
+    graph replay) around each of ``k`` further steps."""
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(k)]
+    torch.cuda.synchronize()
+    for a, b in ev:
+        a.record()
+        run()
+        b.record()
+        if wd is not None:
+            wd.beat()
+    torch.cuda.synchronize()
+    us = sorted(a.elapsed_time(b) * 1e3 for a, b in ev)
+    pick = lambda q: round(us[min(len(us) - 1, int(q * len(us)))], 1)  # noqa: E731
+    return {"n": k, "median": pick(0.5), "p10": pick(0.1), "p90": pick(0.9), "min": round(us[0], 1),
+            "note": "HIP-event time of single steps, measured after the timed region"}
 
 
 def bench_finetune(args, device):
@@ -447,8 +561,9 @@ def bench_finetune(args, device):
     print(json.dumps(line))
 
 
-def bench_contrastive(args, device):
-    """BASELINE.json configs[4] microbench: loss only, 2n=4096 samples, proj_dim=128 (fp32 exact-MFMA path)."""
+def contrastive_numbers(device, steps=50, warmup=10):
+    """BASELINE.json configs[4]: SelfPacedSupConLoss (soft, gamma 12, correct_grad) at 2n=4096 samples, proj_dim=128,
+    forward and forward+backward, eager and replayed from a hipGraph (HIP events on the launch stream)."""
     import spcl_amd  # noqa
     from spcl_amd.contrastyou.losses.contrast_loss3 import SelfPacedSupConLoss
     n, d = 2048, 128
@@ -467,16 +582,17 @@ def bench_contrastive(args, device):
         loss.backward()
 
     def timed(fn):
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             fn()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
         torch.cuda.synchronize()
-        e0.record()
-        for _ in range(args.steps):
+        for a, b in ev:
+            a.record()
             fn()
-        e1.record()
+            b.record()
         torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / args.steps * 1e3  # us
+        us = sorted(a.elapsed_time(b) * 1e3 for a, b in ev)
+        return us[len(us) // 2]  # median, us
 
     res, eager = {}, {}
     for name, fn in (("fwd", fwd), ("fwd_bwd", fwdbwd)):
@@ -496,20 +612,27 @@ def bench_contrastive(args, device):
         res[name] = timed(graph.replay)
     mat_bytes = 3 * 4096 * 4096 * 4 + 2 * 4096 * 128 * 4
     ach = mat_bytes / (res["fwd"] * 1e-6) / 1e9
-    line = {"metric": "contrastive similarity+softmax 4096x128 (microbench)", "value": round(1e6 / res["fwd_bwd"], 1),
+    return {"fwd_us": round(res["fwd"], 1), "fwd_bwd_us": round(res["fwd_bwd"], 1),
+            "eager_fwd_us": round(eager["fwd"], 1), "eager_fwd_bwd_us": round(eager["fwd_bwd"], 1),
+            "frac": round(ach / HBM_PEAK_GBS, 4), "achieved_GBps": round(ach, 1), "algorithmic_bytes": mat_bytes,
+            "note": "median of single hipGraph replays (HIP events); frac = SURVEY 8(d)'s materialised-fp32 schedule "
+                    "bytes (205.5 MB) / forward time / 8 TB/s"}
+
+
+def bench_contrastive(args, device):
+    """BASELINE.json configs[4] microbench: loss only, 2n=4096 samples, proj_dim=128."""
+    r = contrastive_numbers(device, steps=args.steps, warmup=args.warmup)
+    line = {"metric": "contrastive similarity+softmax 4096x128 (microbench)", "value": round(1e6 / r["fwd_bwd_us"], 1),
             "unit": "loss fwd+bwd /s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(res["fwd_bwd"] * 1e-3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(r["fwd_bwd_us"] * 1e-3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[4]: SelfPacedSupConLoss 2n=4096 d=128", "hipgraph": True,
-                       "fwd_us": round(res["fwd"], 1), "fwd_bwd_us": round(res["fwd_bwd"], 1),
-                       "eager_fwd_us": round(eager["fwd"], 1), "eager_fwd_bwd_us": round(eager["fwd_bwd"], 1)},
-            "roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                       "fwd_us": r["fwd_us"], "fwd_bwd_us": r["fwd_bwd_us"],
+                       "eager_fwd_us": r["eager_fwd_us"], "eager_fwd_bwd_us": r["eager_fwd_bwd_us"]},
+            "roofline": {"bound": "hbm", "achieved": r["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": r["frac"], "traffic": None,
                          "note": "SURVEY 8(d) accounting: the materialised-fp32 schedule's bytes (205.5 MB: S written "
-                                 "once, read for the row sums, read for the weighted NLL) / forward time.  The kernels "
-                                 "move 134 MB (logits written once with the row sums fused in, read once by the "
-                                 "self-paced pass); logits from 3 x 4.295 GFLOP of split-bf16 MFMA",
-                         "moved_GBps": round((2 * 4096 * 4096 * 4) / (res["fwd"] * 1e-6) / 1e9, 1)}}
+                                 "once, read for the row sums, read for the weighted NLL) / forward time"}}
     print(json.dumps(line))
 
 
