@@ -130,6 +130,25 @@ int spcl_conv3x3_wgrad(const void* x, const void* dy, int dtype, int N, int H, i
                        int Cout, int CoutS, int in_mode, const float* in_scale, const float* in_shift, float* partial,
                        float* dw_oihw, void* stream);
 
+/* The same weight gradients for SEVERAL layers in ONE launch (bf16, channel counts multiples of 64: _Conv3.b.._Conv5.b
+ * and the decoder's wide layers).  The workgroups split the union of the layers' pixel ranges, so the launch writes
+ * one split-K partial per CU in total instead of one per CU and layer (csrc/wgrad_gemm.hip).  x / dy / in_mode (0 or
+ * 1) / in_scale / in_shift as above with CinK == Cin; dw_oihw [Cout][Cin][3][3] f32 is overwritten, or added to when
+ * accumulate != 0 (a gradient bucket that was zeroed before backward and may already hold another use's gradient).
+ * partial: spcl_conv_wgrad_batched_workspace_bytes(items, n) bytes.  items is host memory, read during the call. */
+#define SPCL_WGRAD_BATCH_MAX 8
+typedef struct spcl_wgrad_item {
+  const void* x;
+  const void* dy;
+  const float* in_scale;
+  const float* in_shift;
+  float* dw_oihw;
+  int N, H, W, Cin, CinS, Cout, CoutS, in_mode;
+} spcl_wgrad_item;
+int spcl_conv_wgrad_batched_supported(int dtype, int Cin, int CinS, int Cout, int CoutS, int in_mode);
+size_t spcl_conv_wgrad_batched_workspace_bytes(const spcl_wgrad_item* items, int n);
+int spcl_conv3x3_wgrad_batched(const spcl_wgrad_item* items, int n, int accumulate, float* partial, void* stream);
+
 /* train-mode BatchNorm statistics (unet.py:73,76; torch.nn.BatchNorm2d semantics): combines the conv epilogue
  * partials stats[ntiles][3][CS] (Chan, fixed order, in double; the tail of the buffer is scratch) -> mean, invstd = 1/sqrt(var_biased+eps), scale = gamma*invstd,
  * shift = beta-mean*scale (all [CS] f32, zero in the channel padding) and updates running_mean / running_var

@@ -387,10 +387,7 @@ static WgradPlan wgrad_plan(int N, int H, int W, int CinK, int CoutS, int esize)
   WgradPlan p;
   p.NJ = CoutS >= 32 ? 2 : 1;
   p.MI = CinK >= 32 ? 2 : 1;
-  // 64x64-channel blocks (8 waves) where both channel counts allow: a 32-channel slice of a wider pixel is a 64-byte
-  // half of every 128-byte line and every tile is re-read by more block pairs (profiles/r01_conv_pmc_notes.md)
-  static const int env_big = getenv("SPCL_WGRAD_BIG") ? atoi(getenv("SPCL_WGRAD_BIG")) : 1;
-  if (env_big && esize == 2 && CinK % 64 == 0 && CoutS % 64 == 0) p.MI = p.NJ = 4;
+  // (bf16 layers whose channel counts are both multiples of 64 never get here: wgrad_gemm.hip)
   p.nblk_ci = CinK / (16 * p.MI);
   p.nblk_co = CoutS / (16 * p.NJ);
   // 14-row tiles when the height divides by 14 but not by 16 (56 / 28 / 14: 12.5 % padded pixels instead of 23 %)
@@ -427,9 +424,7 @@ static void launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t st)
 
 template <typename T, int TH>
 static void launch_wgrad_th(const WgradArgs& a, const WgradPlan& p, hipStream_t st) {
-  if (p.MI == 4 && p.NJ == 4) {
-    if (sizeof(T) == 2) launch_wgrad<bf16_t, 4, 4, TH, 8>(a, p, st);  // bf16 only (wgrad_plan)
-  } else if (p.MI == 1 && p.NJ == 1) launch_wgrad<T, 1, 1, TH, 4>(a, p, st);
+  if (p.MI == 1 && p.NJ == 1) launch_wgrad<T, 1, 1, TH, 4>(a, p, st);
   else if (p.MI == 1 && p.NJ == 2) launch_wgrad<T, 1, 2, TH, 4>(a, p, st);
   else if (p.MI == 2 && p.NJ == 1) launch_wgrad<T, 2, 1, TH, 4>(a, p, st);
   else launch_wgrad<T, 2, 2, TH, 4>(a, p, st);
@@ -445,11 +440,29 @@ static void launch_wgrad_t(const WgradArgs& a, const WgradPlan& p, hipStream_t s
 
 using namespace spcl;
 
+// the one-layer form of the batched kernel (wgrad_gemm.hip) for bf16 layers with 64-multiple channel counts
+static bool wide_item(spcl_wgrad_item& it, const void* x, const void* dy, int N, int H, int W, int Cin, int CinS, int CinK,
+                      int Cout, int CoutS, int in_mode, const float* in_scale, const float* in_shift, float* dw) {
+  if (Cin != CinK || CinS != CinK || Cout != CoutS ||
+      !spcl_conv_wgrad_batched_supported(SPCL_BF16, Cin, CinS, Cout, CoutS, in_mode))
+    return false;
+  it.x = x; it.dy = dy; it.in_scale = in_scale; it.in_shift = in_shift; it.dw_oihw = dw;
+  it.N = N; it.H = H; it.W = W; it.Cin = Cin; it.CinS = CinS; it.Cout = Cout; it.CoutS = CoutS; it.in_mode = in_mode;
+  return true;
+}
+
 extern "C" size_t spcl_conv_wgrad_workspace_bytes(int N, int H, int W, int CinK, int CoutS) {
   if (N <= 0 || H <= 0 || W <= 0 || CinK <= 0 || CoutS <= 0 || CinK % 16 || CoutS % 16) return 0;
-  // sized for the f32 plan (its split count is >= the bf16 one)
+  // sized for the f32 plan (its split count is >= the bf16 one) and for the wide-layer kernel
   const size_t a = wgrad_plan(N, H, W, CinK, CoutS, 4).partial_floats, b = wgrad_plan(N, H, W, CinK, CoutS, 2).partial_floats;
-  return (a > b ? a : b) * sizeof(float);
+  size_t bytes = (a > b ? a : b) * sizeof(float);
+  spcl_wgrad_item it;
+  static float dummy;
+  if (wide_item(it, &dummy, &dummy, N, H, W, CinK, CinK, CinK, CoutS, CoutS, 0, nullptr, nullptr, &dummy)) {
+    const size_t w = spcl_conv_wgrad_batched_workspace_bytes(&it, 1);
+    if (w > bytes) bytes = w;
+  }
+  return bytes;
 }
 
 extern "C" int spcl_conv3x3_wgrad(const void* x, const void* dy, int dtype, int N, int H, int W, int Cin, int CinS,
@@ -463,6 +476,11 @@ extern "C" int spcl_conv3x3_wgrad(const void* x, const void* dy, int dtype, int 
   if (in_mode == 2) SPCL_CHECK_ARG(CinK == 16 && CinS >= 1 && CinS <= 16, "conv3x3_wgrad: image mode needs Cin<=16");
   else SPCL_CHECK_ARG(CinS == CinK, "conv3x3_wgrad: CinS must equal CinK");
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == SPCL_BF16) {
+    spcl_wgrad_item it;
+    if (wide_item(it, x, dy, N, H, W, Cin, CinS, CinK, Cout, CoutS, in_mode, in_scale, in_shift, dw_oihw))
+      return spcl_conv3x3_wgrad_batched(&it, 1, 0, partial, stream);
+  }
   WgradPlan p = wgrad_plan(N, H, W, CinK, CoutS, dtype == SPCL_F32 ? 4 : 2);
   WgradArgs a;
   a.x = x; a.dy = dy; a.in_scale = in_scale; a.in_shift = in_shift; a.partial = partial;

@@ -43,15 +43,28 @@ class GradBucket:
 
     def arm_sinks(self):
         """Offer every parameter its slice of the bucket as the place its next gradient is written to
-        (functional.take_grad_sink): the HIP backward kernels then fill the bucket directly and ``gather`` has nothing
-        left to copy.  Call after the gradients were cleared (``p.grad = None``), once per step."""
+        (functional.take_grad_sink, claimed in backward): the HIP backward kernels then fill the bucket directly and
+        ``gather`` has nothing left to copy.  Call after the gradients were cleared (``p.grad = None``), once per step,
+        before backward.  Also opens the deferred weight-gradient queue (functional.DeferredWgrads): the wide layers'
+        weight gradients are ADDED into their (zeroed) slices by one batched launch when ``gather`` flushes it."""
+        from . import functional as _F
         for p, v in zip(self.params, self.views):
             p._grad_sink = v
             p._grad_sink_armed = True
+        if self.flat.is_cuda:
+            self.flat.zero_()
+            _F.open_deferred_wgrads()
+
+    def disarm_sinks(self):
+        for p in self.params:
+            p._grad_sink_armed = False
 
     def gather(self):
         """grads -> bucket (one fused foreach copy of those not already written in place); params without a grad
-        contribute zeros."""
+        contribute zeros.  Flushes the deferred weight gradients first and disarms the sinks nobody claimed."""
+        from . import functional as _F
+        _F.flush_deferred_wgrads()
+        self.disarm_sinks()
         srcs, dsts = [], []
         for p, v in zip(self.params, self.views):
             if p.grad is None:

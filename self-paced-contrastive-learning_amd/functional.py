@@ -14,10 +14,11 @@ SP_NONE, SP_HARD, SP_SOFT = 0, 1, 2
 # --------------------------------------------------------------------------------------------- gradient sinks
 def take_grad_sink(param, needed: bool = True):
     """Where a parameter's gradient should be written: its ARMED sink (a contiguous fp32 view of a flat gradient bucket,
-    installed by ddp.FlatParams.zero_grad) or None (allocate).  A sink serves one backward per arming: the backward
-    kernels write the gradient straight into the bucket and return a fresh view of it, which autograd adopts as
-    ``param.grad`` without a copy; a second use of the same parameter in that step allocates normally and autograd adds
-    it into the bucket in place."""
+    installed by ddp.FlatParams.zero_grad) or None (allocate).  Claimed IN BACKWARD, at the point the kernel writes
+    (a forward that never runs backward leaves the arming untouched).  A sink serves one backward per arming: the
+    backward kernels write the gradient straight into the bucket and return a fresh view of it, which autograd adopts
+    as ``param.grad`` without a copy; a second use of the same parameter in that step allocates normally and autograd
+    adds it into the bucket in place.  ``ddp.GradBucket.gather`` disarms whatever was not claimed."""
     if not needed or param is None:
         return None
     sink = getattr(param, "_grad_sink", None)
@@ -165,8 +166,7 @@ class _ProjectorFn(torch.autograd.Function):
                 _n.ptr(z), _n.stream())
         ctx.save_for_backward(w1c, w2c, pooled, pre, o)
         ctx.meta = (N, H, W, C, cs, hid, out_dim, bool(normalize), x.dtype, feat.dtype)
-        ng = ctx.needs_input_grad
-        ctx.sinks = tuple(take_grad_sink(p, ng[i + 1]) for i, p in enumerate((w1, b1, w2, b2)))
+        ctx.params = (w1, b1, w2, b2)  # their gradient sinks are claimed in backward, where the kernels write
         return z
 
     @staticmethod
@@ -176,7 +176,8 @@ class _ProjectorFn(torch.autograd.Function):
         dev = dz.device
         mlp = hid > 0
         dzc = dz.detach().contiguous().float()
-        sk = ctx.sinks
+        ng = ctx.needs_input_grad
+        sk = tuple(take_grad_sink(p, ng[i + 1]) for i, p in enumerate(ctx.params))
         dw1 = _grad_buffer(sk[0], w1c.shape, dev)
         db1 = _grad_buffer(sk[1], (w1c.shape[0],), dev)
         dw2 = _grad_buffer(sk[2], w2c.shape, dev) if mlp else None
@@ -299,8 +300,71 @@ def _bn_stats(stats, cfg: BlockCfg, C, cs, gamma, beta, which, dev):
     return st
 
 
+class DeferredWgrads:
+    """Weight gradients of the wide (channel counts multiples of 64) bf16 layers, queued during backward and computed by
+    ONE batched launch (csrc/wgrad_gemm.hip: the split-K partials are then written once per CU for all layers together
+    instead of once per CU and layer).
+
+    Only gradients that go STRAIGHT INTO A FLAT GRADIENT BUCKET are deferred (the parameter's armed sink, see
+    ``take_grad_sink``): the buffer autograd adopts as ``param.grad`` is the bucket slice, which is filled at ``flush``.
+    ``ddp.GradBucket.arm_sinks`` opens the queue (and zeroes the bucket: the batched kernel ADDS into it, so a second
+    use of a parameter that autograd accumulated into the slice before the flush is kept) and ``gather`` flushes it
+    before anything reads the bucket."""
+
+    def __init__(self):
+        self.items, self.keep = [], []
+
+    def add(self, x_store, dy, scale, shift, sink, N, H, W, cin, cin_s, cout, cout_s, in_mode):
+        it = _n.WgradItem(x_store.data_ptr(), dy.data_ptr(), scale.data_ptr() if scale is not None else None,
+                          shift.data_ptr() if shift is not None else None, sink.data_ptr(), N, H, W, cin, cin_s, cout,
+                          cout_s, in_mode)
+        self.items.append(it)
+        self.keep.append((x_store, dy, scale, shift))  # operands stay alive until the launch (NOT the returned view)
+        if len(self.items) == _n.WGRAD_BATCH_MAX:
+            self.flush()
+
+    def flush(self):
+        if not self.items:
+            return
+        wgrad_batched(self.items, accumulate=True, device=self.keep[0][1].device)
+        self.items, self.keep = [], []
+
+
+_deferred: "DeferredWgrads | None" = None
+
+
+def open_deferred_wgrads():
+    """start queueing (idempotent); returns the queue"""
+    global _deferred
+    if _deferred is None:
+        _deferred = DeferredWgrads()
+    return _deferred
+
+
+def flush_deferred_wgrads(close: bool = True):
+    global _deferred
+    if _deferred is not None:
+        _deferred.flush()
+        if close:
+            _deferred = None
+
+
+def wgrad_batched(items, accumulate, device):
+    """one launch for ``items`` (list of native.WgradItem, at most native.WGRAD_BATCH_MAX)"""
+    arr = (_n.WgradItem * len(items))(*items)
+    nbytes = _n.call("spcl_conv_wgrad_batched_workspace_bytes", arr, len(items))
+    if nbytes == 0:
+        raise RuntimeError("wgrad_batched: unsupported item (bf16 NHWC, channel counts multiples of 64, in_mode 0/1)")
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+    _n.call("spcl_conv3x3_wgrad_batched", arr, len(items), int(bool(accumulate)), _n.ptr(ws), _n.stream())
+
+
 def _wgrad(x_store, dy, dt_code, N, H, W, cin, cin_s, cin_k, cout, cout_s, in_mode, scale, shift, sink=None):
     dev = dy.device
+    if (_deferred is not None and sink is not None and cin_s == cin_k
+            and _n.call("spcl_conv_wgrad_batched_supported", dt_code, cin, cin_s, cout, cout_s, in_mode)):
+        _deferred.add(x_store, dy, scale, shift, sink, N, H, W, cin, cin_s, cout, cout_s, in_mode)
+        return sink.view((cout, cin, 3, 3))  # filled when the queue is flushed (before the bucket is read)
     nbytes = _n.call("spcl_conv_wgrad_workspace_bytes", N, H, W, cin_k, cout_s)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
     dw = _grad_buffer(sink, (cout, cin, 3, 3), dev)
@@ -411,8 +475,7 @@ class _ConvBlockFn(torch.autograd.Function):
         _n.call("spcl_bnrelu_pool_forward", _n.ptr(yb), dtc, N, H, W, cout_s, _n.ptr(stb[2]), _n.ptr(stb[3]),
                 _n.ptr(act), _n.ptr(pool), _n.stream())
         ctx.save_for_backward(xs, ya, yb, sta, stb, wa, wb)
-        ng = ctx.needs_input_grad
-        ctx.sinks = tuple(take_grad_sink(p, ng[i + 1]) for i, p in enumerate((wa, ga, ba, wb, gb, bb)))
+        ctx.params = (wa, ga, ba, wb, gb, bb)
         ctx.packed_t = (wpa_t, wpb_t)
         ctx.cfg = cfg
         ctx.meta = (N, cin, H, W, cout, cout_s, cin_s, cin_k, mode_a, x.dtype)
@@ -433,7 +496,8 @@ class _ConvBlockFn(torch.autograd.Function):
         if da_s is None and dp_s is None:
             return (None,) * 8
         # ---- second conv
-        sk = ctx.sinks  # (wa, ga, ba, wb, gb, bb)
+        ng = ctx.needs_input_grad
+        sk = tuple(take_grad_sink(p, ng[i + 1]) for i, p in enumerate(ctx.params))  # (wa, ga, ba, wb, gb, bb)
         dyb, dgb, dbb = _bnrelu_bwd(yb, da_s, dp_s, dtc, dtype, N, H, W, cout, cout_s, stb, cfg.training, sk[4:6])
         dwb = _wgrad(ya, dyb, dtc, N, H, W, cout, cout_s, cout_s, cout, cout_s, 1, sta[2], sta[3], sk[3]) \
             if ctx.needs_input_grad[4] else None
@@ -514,8 +578,7 @@ class _ConvBNReLUFn(torch.autograd.Function):
         _n.call("spcl_bnrelu_pool_forward", _n.ptr(y), dtc, N, H, W, cout_s, _n.ptr(st[2]), _n.ptr(st[3]), _n.ptr(act),
                 None, _n.stream())
         ctx.save_for_backward(xs, y, st, w)
-        ng = ctx.needs_input_grad
-        ctx.sinks = tuple(take_grad_sink(p, ng[i + 1]) for i, p in enumerate((w, gamma, beta)))
+        ctx.params = (w, gamma, beta)
         ctx.packed_t = wp_t
         ctx.cfg = cfg
         ctx.meta = (N, cin, H, W, cout, cout_s, cin_s, x.dtype)
@@ -529,7 +592,8 @@ class _ConvBNReLUFn(torch.autograd.Function):
         dtype = cfg.dtype
         dtc = _n.dtype_code(dtype)
         da_s = to_nhwc_padded(d_act, dtype)
-        sk = ctx.sinks
+        ng = ctx.needs_input_grad
+        sk = tuple(take_grad_sink(p, ng[i + 1]) for i, p in enumerate(ctx.params))
         dy, dg, db = _bnrelu_bwd(y, da_s, None, dtc, dtype, N, H, W, cout, cout_s, st, cfg.training, sk[1:3])
         dw = _wgrad(xs, dy, dtc, N, H, W, cin, cin_s, cin_s, cout, cout_s, 0, None, None, sk[0]) \
             if ctx.needs_input_grad[1] else None
@@ -574,7 +638,7 @@ class _Conv1x1Fn(torch.autograd.Function):
         _n.call("spcl_conv1x1_forward", _n.ptr(xs), _n.dtype_code(dtype), N * H * W, C, cs, K, _n.ptr(wc), _n.ptr(bc),
                 _n.ptr(out), _n.stream())
         ctx.save_for_backward(xs, wc)
-        ctx.sinks = (take_grad_sink(w, ctx.needs_input_grad[1]), take_grad_sink(b, ctx.needs_input_grad[2]))
+        ctx.params = (w, b)
         ctx.meta = (N, C, H, W, K, cs, dtype, x.dtype, tuple(w.shape))
         return out.permute(0, 3, 1, 2)
 
@@ -585,8 +649,10 @@ class _Conv1x1Fn(torch.autograd.Function):
         do = _class_map_storage(dout)
         dev = do.device
         dxs = torch.empty(N, H, W, cs, dtype=dtype, device=dev)
-        dw = _grad_buffer(ctx.sinks[0], (K, C), dev)
-        db = _grad_buffer(ctx.sinks[1], (K,), dev)
+        sinks = (take_grad_sink(ctx.params[0], ctx.needs_input_grad[1]),
+                 take_grad_sink(ctx.params[1], ctx.needs_input_grad[2]))
+        dw = _grad_buffer(sinks[0], (K, C), dev)
+        db = _grad_buffer(sinks[1], (K,), dev)
         ws = torch.empty(_n.call("spcl_conv1x1_bwd_workspace_bytes", C, K) // 4, dtype=torch.float32, device=dev)
         _n.call("spcl_conv1x1_backward", _n.ptr(xs), _n.ptr(do), _n.dtype_code(dtype), N * H * W, C, cs, K, _n.ptr(wc),
                 _n.ptr(dxs), _n.ptr(dw), _n.ptr(db), _n.ptr(ws), _n.stream())

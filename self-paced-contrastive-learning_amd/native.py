@@ -41,6 +41,9 @@ _SIGNATURES = {
     "spcl_conv_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "spcl_conv3x3_wgrad": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P,
                                    _P, _P, _P, _P]),
+    "spcl_conv_wgrad_batched_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "spcl_conv_wgrad_batched_workspace_bytes": (c_size_t, [_P, c_int]),
+    "spcl_conv3x3_wgrad_batched": (c_int, [_P, c_int, c_int, _P, _P]),
     "spcl_bn_finalize": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
     "spcl_bn_eval_affine": (c_int, [c_int, c_int, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P]),
     "spcl_bnrelu_pool_forward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
@@ -78,6 +81,18 @@ _SIGNATURES = {
 }
 
 
+class WgradItem(ctypes.Structure):
+    """``spcl_wgrad_item`` of include/spcl_hip.h (one layer of a batched weight-gradient launch)"""
+    _fields_ = [("x", c_void_p), ("dy", c_void_p), ("in_scale", c_void_p), ("in_shift", c_void_p),
+                ("dw_oihw", c_void_p), ("N", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int), ("CinS", c_int),
+                ("Cout", c_int), ("CoutS", c_int), ("in_mode", c_int)]
+
+
+WGRAD_BATCH_MAX = 8
+_NO_STATUS = ("spcl_abi_version", "spcl_conv_num_tiles", "spcl_profile_count", "spcl_conv_dgrad_bnstats_supported",
+              "spcl_conv_wgrad_batched_supported")
+
+
 class NativeLibraryError(RuntimeError):
     pass
 
@@ -106,7 +121,7 @@ def call(name: str, *args):
     if fn is None:
         raise NativeLibraryError(f"libspcl_hip.so does not export {name}")
     rc = fn(*args)
-    if fn.restype is c_int and name not in ("spcl_abi_version", "spcl_conv_num_tiles", "spcl_profile_count", "spcl_conv_dgrad_bnstats_supported") and rc != 0:
+    if fn.restype is c_int and name not in _NO_STATUS and rc != 0:
         raise RuntimeError(f"{name} failed ({rc}): {L.spcl_last_error().decode()}")
     return rc
 

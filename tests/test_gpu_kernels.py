@@ -167,6 +167,75 @@ def test_conv_wgrad(dt, N, ci, co, H, W, mode):
     assert relerr(dw.cpu(), ref) < (2e-5 if dt == "f32" else 2e-3)
 
 
+def _wgrad_item(n, N, ci, co, H, W, mode, seed, keep):
+    """one layer of a batched weight-gradient launch + its fp64 reference on the same bf16-rounded operands"""
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(seed)
+    x = rnd(torch.randn(N, ci, H, W, generator=g), dtype)
+    dy = rnd(torch.randn(N, co, H, W, generator=g), dtype)
+    sc, sh = torch.randn(ci, generator=g), torch.randn(ci, generator=g) * 0.3
+    xin = rnd(torch.relu(x * sc[None, :, None, None] + sh[None, :, None, None]), dtype) if mode == 1 else x
+    ref = torch.nn.grad.conv2d_weight(xin.double(), (co, ci, 3, 3), dy.double(), 1, 1).float()
+    xs, dys, scd, shd = nhwc(x, dtype), nhwc(dy, dtype), sc.cuda(), sh.cuda()
+    dw = torch.full((co, ci, 3, 3), 0.25, device="cuda")
+    keep += [xs, dys, scd, shd, dw]
+    it = n.WgradItem(xs.data_ptr(), dys.data_ptr(), scd.data_ptr() if mode else None, shd.data_ptr() if mode else None,
+                     dw.data_ptr(), N, H, W, ci, ci, co, co, mode)
+    return it, dw, ref
+
+
+@pytest.mark.parametrize("accumulate", [0, 1])
+@pytest.mark.parametrize("layers", [
+    # the five >=64-channel encoder layers of a 224x224 step at reduced batch (56 / 28 / 14 squares, both input modes)
+    [(4, 64, 64, 56, 56, 1), (4, 64, 128, 28, 28, 0), (4, 128, 128, 28, 28, 1), (4, 128, 256, 14, 14, 0),
+     (4, 256, 256, 14, 14, 1)],
+    # 256x256 inputs (64 / 32 / 16 squares: 16-row tiles), a ragged one, a single tiny one
+    [(2, 64, 64, 64, 64, 1), (2, 64, 128, 32, 32, 0), (2, 256, 256, 16, 16, 1)],
+    [(3, 64, 192, 23, 37, 1), (1, 128, 64, 5, 70, 0)],
+    [(1, 64, 64, 3, 3, 1)],
+    # eight layers (the batch limit), decoder-like widths
+    [(1, 64 * (1 + i % 3), 64 * (1 + (i + 1) % 2), 14 + 7 * (i % 3), 14 + i, i % 2) for i in range(8)],
+])
+def test_conv_wgrad_batched(layers, accumulate):
+    """several layers' weight gradients in ONE launch (csrc/wgrad_gemm.hip) vs fp64 on identical bf16 operands; with
+    accumulate the result is added to what the gradient buffer held (0.25 here)."""
+    n = _n()
+    keep, items, outs = [], [], []
+    for k, (N, ci, co, H, W, mode) in enumerate(layers):
+        it, dw, ref = _wgrad_item(n, N, ci, co, H, W, mode, 100 + k, keep)
+        items.append(it)
+        outs.append((dw, ref))
+    arr = (n.WgradItem * len(items))(*items)
+    nbytes = n.call("spcl_conv_wgrad_batched_workspace_bytes", arr, len(items))
+    assert nbytes > 0
+    ws = torch.empty(nbytes // 4, device="cuda")
+    n.call("spcl_conv3x3_wgrad_batched", arr, len(items), accumulate, n.ptr(ws), n.stream())
+    for k, (dw, ref) in enumerate(outs):
+        got = dw.cpu() - (0.25 if accumulate else 0.0)
+        assert relerr(got, ref) < 2e-3, (k, layers[k], relerr(got, ref))
+    # bit-for-bit repeatable (fixed-order reduction, no atomics)
+    first = [dw.clone() for dw, _ in outs]
+    for dw, _ in outs:
+        dw.fill_(0.25)
+    n.call("spcl_conv3x3_wgrad_batched", arr, len(items), accumulate, n.ptr(ws), n.stream())
+    for a, (dw, _) in zip(first, outs):
+        assert torch.equal(a, dw)
+
+
+def test_conv_wgrad_batched_rejects_what_it_cannot_do():
+    n = _n()
+    keep = []
+    it, _, _ = _wgrad_item(n, 1, 64, 64, 8, 8, 0, 1, keep)
+    bad = n.WgradItem(it.x, it.dy, None, None, it.dw_oihw, 1, 8, 8, 48, 48, 64, 64, 0)  # 48 input channels
+    arr = (n.WgradItem * 1)(bad)
+    assert n.call("spcl_conv_wgrad_batched_workspace_bytes", arr, 1) == 0
+    assert not n.call("spcl_conv_wgrad_batched_supported", n.SPCL_F32, 64, 64, 64, 64, 0)
+    assert not n.call("spcl_conv_wgrad_batched_supported", n.SPCL_BF16, 64, 64, 64, 64, 2)
+    ws = torch.empty(1024, device="cuda")
+    with pytest.raises(RuntimeError):
+        n.call("spcl_conv3x3_wgrad_batched", arr, 1, 0, n.ptr(ws), n.stream())
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 def test_conv_wgrad_image_mode(dt):
     n = _n()
