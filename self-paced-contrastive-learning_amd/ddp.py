@@ -46,13 +46,12 @@ class GradBucket:
         (functional.take_grad_sink, claimed in backward): the HIP backward kernels then fill the bucket directly and
         ``gather`` has nothing left to copy.  Call after the gradients were cleared (``p.grad = None``), once per step,
         before backward.  Also opens the deferred weight-gradient queue (functional.DeferredWgrads): the wide layers'
-        weight gradients are ADDED into their (zeroed) slices by one batched launch when ``gather`` flushes it."""
+        weight gradients are written into their slices by one batched launch when ``gather`` flushes it."""
         from . import functional as _F
         for p, v in zip(self.params, self.views):
             p._grad_sink = v
             p._grad_sink_armed = True
         if self.flat.is_cuda:
-            self.flat.zero_()
             _F.open_deferred_wgrads()
 
     def disarm_sinks(self):
@@ -63,11 +62,16 @@ class GradBucket:
         """grads -> bucket (one fused foreach copy of those not already written in place); params without a grad
         contribute zeros.  Flushes the deferred weight gradients first and disarms the sinks nobody claimed."""
         from . import functional as _F
-        _F.flush_deferred_wgrads()
+        deferred = _F.flush_deferred_wgrads()
         self.disarm_sinks()
         srcs, dsts = [], []
         for p, v in zip(self.params, self.views):
-            if p.grad is None:
+            if v.data_ptr() in deferred:
+                # the slice holds the batched launch's result; autograd holds what OTHER uses of the parameter gave
+                if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
+                    v.add_(p.grad)
+                p.grad = v
+            elif p.grad is None:
                 v.zero_()
             elif p.grad.data_ptr() != v.data_ptr():
                 srcs.append(p.grad)

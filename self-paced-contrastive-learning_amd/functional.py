@@ -306,27 +306,28 @@ class DeferredWgrads:
     instead of once per CU and layer).
 
     Only gradients that go STRAIGHT INTO A FLAT GRADIENT BUCKET are deferred (the parameter's armed sink, see
-    ``take_grad_sink``): the buffer autograd adopts as ``param.grad`` is the bucket slice, which is filled at ``flush``.
-    ``ddp.GradBucket.arm_sinks`` opens the queue (and zeroes the bucket: the batched kernel ADDS into it, so a second
-    use of a parameter that autograd accumulated into the slice before the flush is kept) and ``gather`` flushes it
-    before anything reads the bucket."""
+    ``take_grad_sink``), and autograd never sees them: the backward returns ``None`` for that parameter and the batched
+    launch writes the bucket slice when the queue is flushed.  ``ddp.GradBucket.arm_sinks`` opens the queue, ``gather``
+    flushes it before anything reads the bucket, adds what autograd accumulated from OTHER uses of the same parameter in
+    that step (they do not get the sink) and points ``param.grad`` at the slice."""
 
     def __init__(self):
-        self.items, self.keep = [], []
+        self.items, self.keep, self.targets = [], [], set()
 
     def add(self, x_store, dy, scale, shift, sink, N, H, W, cin, cin_s, cout, cout_s, in_mode):
         it = _n.WgradItem(x_store.data_ptr(), dy.data_ptr(), scale.data_ptr() if scale is not None else None,
                           shift.data_ptr() if shift is not None else None, sink.data_ptr(), N, H, W, cin, cin_s, cout,
                           cout_s, in_mode)
         self.items.append(it)
-        self.keep.append((x_store, dy, scale, shift))  # operands stay alive until the launch (NOT the returned view)
+        self.keep.append((x_store, dy, scale, shift))  # operands stay alive until the launch
+        self.targets.add(sink.data_ptr())
         if len(self.items) == _n.WGRAD_BATCH_MAX:
             self.flush()
 
     def flush(self):
         if not self.items:
             return
-        wgrad_batched(self.items, accumulate=True, device=self.keep[0][1].device)
+        wgrad_batched(self.items, accumulate=False, device=self.keep[0][1].device)
         self.items, self.keep = [], []
 
 
@@ -342,11 +343,16 @@ def open_deferred_wgrads():
 
 
 def flush_deferred_wgrads(close: bool = True):
+    """launch what is queued; returns the data pointers of the bucket slices that were written by the queue since it
+    was opened"""
     global _deferred
+    targets = set()
     if _deferred is not None:
         _deferred.flush()
+        targets = _deferred.targets
         if close:
             _deferred = None
+    return targets
 
 
 def wgrad_batched(items, accumulate, device):
@@ -364,7 +370,7 @@ def _wgrad(x_store, dy, dt_code, N, H, W, cin, cin_s, cin_k, cout, cout_s, in_mo
     if (_deferred is not None and sink is not None and cin_s == cin_k
             and _n.call("spcl_conv_wgrad_batched_supported", dt_code, cin, cin_s, cout, cout_s, in_mode)):
         _deferred.add(x_store, dy, scale, shift, sink, N, H, W, cin, cin_s, cout, cout_s, in_mode)
-        return sink.view((cout, cin, 3, 3))  # filled when the queue is flushed (before the bucket is read)
+        return None  # written into the bucket slice when the queue is flushed; autograd gets no gradient from this use
     nbytes = _n.call("spcl_conv_wgrad_workspace_bytes", N, H, W, cin_k, cout_s)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
     dw = _grad_buffer(sink, (cout, cin, 3, 3), dev)

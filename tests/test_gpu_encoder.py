@@ -241,6 +241,50 @@ def test_gradient_sinks_fill_the_flat_bucket_in_place():
     assert _relerr(f3.cpu().numpy(), f2.cpu().numpy()) < 1e-6
 
 
+def test_deferred_wide_weight_gradients_bf16():
+    """bf16: the weight gradients of the >=64-channel layers are queued during backward and computed by ONE batched launch
+    when the flat bucket is gathered (functional.DeferredWgrads).  Same values as the immediate per-layer path (other
+    pixel splits -> fp32 summation order only), also when a parameter is used twice in the step (the second use does not
+    get the sink; autograd adds it into the bucket slice BEFORE the flush, which therefore adds instead of overwriting),
+    and a forward without backward leaves no armed sink behind."""
+    import spcl_amd  # noqa
+    from spcl_amd import ddp, functional as F_
+    from spcl_amd.contrastyou.projectors.heads import ProjectionHead
+
+    def run(sinks, twice):
+        net, _ = _unet(256, 3, torch.bfloat16)
+        head = ProjectionHead(input_dim=256, hidden_dim=32, output_dim=16, head_type="mlp", normalize=True)
+        head.load_state_dict(O.init_projector_state(256, 32, 16, seed=5))
+        head.cuda()
+        for name in net.decoder_names:
+            getattr(net, "_" + name).requires_grad_(False)
+        params = [p for p in list(net.parameters()) + list(head.parameters()) if p.requires_grad]
+        flat = ddp.FlatParams(params)
+        x = torch.rand(4, 1, 64, 64, generator=torch.Generator().manual_seed(1)).cuda()
+        with torch.no_grad():
+            net(x, until="Conv5")  # a forward that never runs backward
+        z = head(net(x, until="Conv5"))
+        loss = (z * torch.arange(16, device="cuda")).sum()
+        if twice:
+            loss = loss + 0.5 * head(net(x.flip(3), until="Conv5")).sum()
+        if sinks:
+            flat.zero_grad()
+            assert F_._deferred is not None
+        loss.backward()
+        queued = len(F_._deferred.items) if F_._deferred is not None else 0
+        flat.gather_grads()
+        assert F_._deferred is None and not any(getattr(p, "_grad_sink_armed", False) for p in params)
+        return flat.flat.clone(), queued, {k: p.grad for k, p in net.named_parameters() if p.grad is not None}
+
+    for twice in (False, True):
+        f0, q0, _ = run(False, twice)
+        f1, q1, g1 = run(True, twice)
+        assert q0 == 0 and q1 == 5  # _Conv3.b, _Conv4.a/b, _Conv5.a/b (64..256 channels)
+        assert _relerr(f1.cpu().numpy(), f0.cpu().numpy()) < 2e-3, twice
+        w = g1["_Conv5.conv.3.weight"]
+        assert w.abs().max() > 0 and torch.isfinite(w).all()
+
+
 def test_three_combined_hooks_share_one_encoder_pass_fp32():
     """SURVEY row N4 / BASELINE configs[3] shape: three self-paced hooks on Conv5 (partition, patient, self meta-labels,
     weights 1 / 0.5 / 0.25, each with its own projector) through the pre-train epocher's step_compute, against the oracle:
