@@ -264,6 +264,17 @@ int spcl_radam_step(float* param, const float* grad, float* exp_avg, float* exp_
 int spcl_accumulate_scalars(int k, const void* const* src, void* const* dst, const float* count, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * Pre-train augmentation on device (replaces the PIL recipe of semi_seg/augment.py:6-22
+ * `ACDCStrongTransforms.pretrain`: RandomRotation -> RandomVerticalFlip -> RandomHorizontalFlip -> RandomCrop ->
+ * ColorJitter(brightness, contrast) -> ToTensor): one OH x OW view per parameter row, gathered from the device-resident
+ * slice store src [S][HS][WS] f32 in [0,1].  params: device int32 [nviews][8] = {slice, cos * 65536, sin * 65536 (rounded;
+ * rotation counter-clockwise about the image centre, nearest sampling, 0 outside), flags (1 horizontal flip, 2 vertical
+ * flip, 4 contrast before brightness), crop top, crop left, brightness factor (f32 bits), contrast factor (f32 bits)}.
+ * out [nviews][OH][OW] f32.  Geometry is integer arithmetic: bit-exact against oracle.augment_view. */
+int spcl_augment_views(const float* src, int S, int HS, int WS, const int* params, int nviews, float* out, int OH,
+                       int OW, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * Per-sample random flips of an NCHW batch (TensorRandomFlip(axis=[1,2], threshold=0.8), new_epocher.py:112, applied
  * per sample in new_pretrain.py:57-58): out[n] = x[n] flipped along H when flags[n] & 1 and along W when flags[n] & 2.
  * flags: device uint8[N] (the host draws the decisions from python `random`, as the reference does).  x != out. */

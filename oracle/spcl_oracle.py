@@ -438,3 +438,78 @@ def pretrain_step(images: Tensor, images_tf: Tensor, sd: Dict[str, Tensor], proj
     grads = torch.autograd.grad(r["loss"], list(leaves.values()), allow_unused=True)
     return {"loss": r["loss"].detach(), "rho": r["rho"], "feature": feat.detach(),
             "grads": {k: g for k, g in zip(leaves.keys(), grads)}}
+
+
+# --------------------------------------------------------------------------------------
+# data path: batch composition, partition meta-labels, the augmentation arithmetic
+# --------------------------------------------------------------------------------------
+def contrast_batch_indices(scan_of: Sequence[str], partition_of: Sequence[str], scan_sample_num: int,
+                           partition_sample_num: int = 1, shuffle: bool = False) -> List[int]:
+    """ONE batch of ``ContrastBatchSampler`` (semi_seg/data/rearr.py:47-74), restated literally: draw the scans, then per
+    scan and per partition (first-seen order) ``random.sample`` of the sorted intersection; ``ValueError`` -> skip.
+    Consumes python's global ``random`` like the reference."""
+    import random
+    scan2index: Dict[str, List[int]] = {}
+    partition2index: Dict[str, List[int]] = {}
+    for i, (s, p) in enumerate(zip(scan_of, partition_of)):
+        scan2index.setdefault(s, []).append(i)
+        partition2index.setdefault(p, []).append(i)
+    batch: List[int] = []
+    for scan in random.sample(list(scan2index.keys()), scan_sample_num):
+        for part in partition2index.values():
+            try:
+                batch.extend(random.sample(sorted(set(scan2index[scan]) & set(part)), partition_sample_num))
+            except ValueError:
+                continue
+    if shuffle:
+        random.shuffle(batch)
+    return batch
+
+
+def acdc_partition(filename: str, scan_len: int, partition_num: int = 3) -> str:
+    """semi_seg/data/dataset.py:34-43"""
+    import re
+    cut = scan_len // partition_num
+    cur = int(re.findall(r"\d+", filename)[-1])
+    return "0" if cur <= cut - 1 else ("1" if cur <= 2 * cut else "2")
+
+
+def prostate_partition(filename: str, scan_len: int, partition_num: int = 8) -> str:
+    """semi_seg/data/dataset.py:66-71"""
+    import re
+    return str(int(re.findall(r"\d+", filename)[-1]) // (scan_len // partition_num + 1))
+
+
+def augment_view(img, row, out_hw):
+    """One augmented view as ``spcl_augment_views`` defines it (include/spcl_hip.h; the build's on-device form of
+    semi_seg/augment.py:6-22): ``img`` [H,W] float32 numpy, ``row`` = [slice, cos_q16, sin_q16, flags, top, left,
+    brightness bits, contrast bits].  Geometry in exact integer arithmetic (half-pixel coordinates, 16.16 rotation,
+    nearest by arithmetic shift, 0 outside); colour in float32 with the mean accumulated in float64 (the kernel's
+    float32 block reduction agrees to ~1e-7)."""
+    import struct
+    import numpy as np
+    hs, ws = img.shape
+    oh, ow = out_hw
+    _, cq, sq, flags, top, left, bb, cb = [int(v) for v in row]
+    b = np.float32(struct.unpack("<f", struct.pack("<i", bb))[0])
+    c = np.float32(struct.unpack("<f", struct.pack("<i", cb))[0])
+    ii, jj = np.meshgrid(np.arange(oh, dtype=np.int64), np.arange(ow, dtype=np.int64), indexing="ij")
+    y, x = ii + top, jj + left
+    if flags & 1:
+        x = ws - 1 - x
+    if flags & 2:
+        y = hs - 1 - y
+    dx2, dy2 = 2 * x + 1 - ws, 2 * y + 1 - hs
+    sx = (cq * dx2 + sq * dy2 + 65536 * ws) >> 17
+    sy = (-sq * dx2 + cq * dy2 + 65536 * hs) >> 17
+    ok = (sx >= 0) & (sx < ws) & (sy >= 0) & (sy < hs)
+    u = np.where(ok, img[np.clip(sy, 0, hs - 1), np.clip(sx, 0, ws - 1)], np.float32(0)).astype(np.float32)
+    one, zero = np.float32(1), np.float32(0)
+    contrast_first = bool(flags & 4)
+    if not contrast_first:
+        u = np.clip(b * u, zero, one)
+    mean = np.float32(u.astype(np.float64).mean())
+    u = np.clip(c * u + (one - c) * mean, zero, one).astype(np.float32)
+    if contrast_first:
+        u = np.clip(b * u, zero, one)
+    return u.astype(np.float32)

@@ -48,9 +48,76 @@ static void launch_flip(const void* x, void* out, int N, int C, int H, int W, co
                           H, W, flags);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The pre-train augmentation recipe on device (semi_seg/augment.py:6-22 `ACDCStrongTransforms.pretrain`, which the
+// reference runs with PIL in DataLoader workers): RandomRotation -> RandomVerticalFlip -> RandomHorizontalFlip ->
+// RandomCrop -> ColorJitter(brightness, contrast) -> ToTensor, one view per workgroup, gathered straight from the
+// device-resident slice store.  Geometry is INTEGER arithmetic (bit-exact against the oracle): the rotation is a 16.16
+// fixed-point matrix applied to half-pixel coordinates, sampling is nearest (torchvision's default), outside = 0.
+//   params[v] = {slice, cos_q16, sin_q16, flags (1 hflip, 2 vflip, 4 contrast before brightness), top, left,
+//                brightness (f32 bits), contrast (f32 bits)}
+// Colour (float-tensor semantics): brightness u = clamp(b u); contrast u = clamp(c u + (1 - c) mean(u)), the mean taken
+// over the view right before the contrast step -> two passes over the view's pixels inside the workgroup with a fixed-order
+// block reduction between them.
+__global__ __launch_bounds__(1024) void augment_views_kernel(const float* __restrict__ src, int S, int HS, int WS,
+                                                             const int* __restrict__ params, float* __restrict__ out,
+                                                             int OH, int OW) {
+  __shared__ float red[16];
+  const int v = blockIdx.x;
+  const int* pr = params + v * 8;
+  const int slice = pr[0], cq = pr[1], sq = pr[2], flags = pr[3], top = pr[4], left = pr[5];
+  const float b = __int_as_float(pr[6]), c = __int_as_float(pr[7]);
+  const float* img = src + (size_t)slice * HS * WS;
+  const bool contrast_first = flags & 4;
+  auto sample = [&](int p) -> float {
+    const int i = p / OW, j = p - i * OW;
+    int y = i + top, x = j + left;           // position in the rotated + flipped image (same size as the slice)
+    if (flags & 1) x = WS - 1 - x;           // undo the horizontal flip
+    if (flags & 2) y = HS - 1 - y;           // undo the vertical flip
+    const int dx2 = 2 * x + 1 - WS, dy2 = 2 * y + 1 - HS;  // half-pixel units from the centre
+    // inverse rotation (output -> source): [ c s ; -s c ] in 16.16; + centre; floor of (source + 0.5) by arithmetic shift
+    const int sx = (cq * dx2 + sq * dy2 + 65536 * WS) >> 17;
+    const int sy = (-sq * dx2 + cq * dy2 + 65536 * HS) >> 17;
+    return (sx >= 0 && sx < WS && sy >= 0 && sy < HS) ? img[(size_t)sy * WS + sx] : 0.f;
+  };
+  const int np = OH * OW;
+  float part = 0.f;
+  for (int p = threadIdx.x; p < np; p += 1024) {
+    float u = sample(p);
+    if (!contrast_first) u = fminf(fmaxf(b * u, 0.f), 1.f);
+    part += u;
+  }
+  part = wave_sum(part);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+  __syncthreads();
+  float total = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) total += red[w];  // fixed order
+  const float mean = total / (float)np;
+  float* o = out + (size_t)v * np;
+  for (int p = threadIdx.x; p < np; p += 1024) {
+    float u = sample(p);
+    if (!contrast_first) u = fminf(fmaxf(b * u, 0.f), 1.f);
+    u = fminf(fmaxf(c * u + (1.f - c) * mean, 0.f), 1.f);
+    if (contrast_first) u = fminf(fmaxf(b * u, 0.f), 1.f);
+    o[p] = u;
+  }
+}
+
 }  // namespace spcl
 
 using namespace spcl;
+
+extern "C" int spcl_augment_views(const float* src, int S, int HS, int WS, const int* params, int nviews, float* out,
+                                  int OH, int OW, void* stream) {
+  SPCL_CHECK_ARG(src && params && out, "augment_views: null pointer");
+  SPCL_CHECK_ARG(S > 0 && HS > 0 && WS > 0 && nviews > 0 && OH > 0 && OW > 0 && OH <= HS && OW <= WS && HS <= 4096 &&
+                     WS <= 4096,
+                 "augment_views: bad shape (crop %dx%d of %dx%d)", OH, OW, HS, WS);
+  SPCL_LAUNCH(augment_views_kernel, dim3(nviews), dim3(1024), 0, (hipStream_t)stream, src, S, HS, WS, params, out, OH, OW);
+  SPCL_LAUNCH_CHECK("augment_views");
+  return SPCL_OK;
+}
 
 extern "C" int spcl_flip_batch(const void* x, void* out, int elem_size, int N, int C, int H, int W,
                                const uint8_t* flags, void* stream) {

@@ -1,0 +1,8 @@
+"""On-device data path of the pre-train loop: slice store resident in HBM, the reference's
+contrastive batch composition (``ContrastBatchSampler``), partition meta-labels, and the pre-train augmentation recipe
+as one HIP launch per batch instead of PIL in DataLoader workers."""
+from .rearr import ContrastBatchSampler, ContrastDataset  # noqa: F401
+from .dataset import (ACDCSliceStore, DeviceSliceStore, ProstateSliceStore, acdc_partition, prostate_partition,  # noqa: F401
+                      synthetic_slice_store)
+from .augment import PretrainViews, draw_view_params  # noqa: F401
+from .loader import ContrastiveDeviceLoader, InfiniteRandomSampler, get_contrastive_dataloader  # noqa: F401

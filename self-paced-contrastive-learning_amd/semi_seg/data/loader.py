@@ -1,0 +1,74 @@
+"""Loaders of the contrastive pre-train loop (``semi_seg/trainers/_helper.py:31-74``): ACDC batches are composed by
+``ContrastBatchSampler``, the other data sets by an infinite random permutation with batch size ``scan_sample_num x
+partition_num``; every batch is gathered + augmented on the device and handed over in the reference's tuple format
+``((image, image_tf, target, target_tf), filenames, (partitions, scans))``."""
+import random
+from typing import Iterator
+
+import torch
+
+from .augment import PretrainViews
+from .rearr import ContrastBatchSampler
+
+
+class InfiniteRandomSampler:
+    """``contrastyou/data/sampler.py:203-228``: endless stream of random permutations of the data set"""
+
+    def __init__(self, data_source, shuffle=True):
+        self._n, self._shuffle = len(data_source), shuffle
+
+    def __iter__(self) -> Iterator[int]:
+        while True:
+            order = list(range(self._n))
+            if self._shuffle:
+                random.shuffle(order)
+            yield from order
+
+
+class ContrastiveDeviceLoader:
+    """infinite iterator of device batches"""
+
+    def __init__(self, store, *, batch_sampler=None, sampler=None, batch_size=None, out_hw=(224, 224), **recipe):
+        assert (batch_sampler is None) != (sampler is None)
+        self.dataset, self._views = store, PretrainViews(store.images, out_hw, **recipe)
+        self._batch_sampler, self._sampler, self._batch_size = batch_sampler, sampler, batch_size
+        self._it = None
+
+    def _index_batches(self):
+        if self._batch_sampler is not None:
+            yield from iter(self._batch_sampler)
+        else:
+            it = iter(self._sampler)
+            while True:
+                yield [next(it) for _ in range(self._batch_size)]
+
+    def __iter__(self):
+        self._it = self._index_batches()
+        return self
+
+    def __next__(self):
+        if self._it is None:
+            self._it = self._index_batches()
+        idx = next(self._it)
+        img, img_tf = self._views(idx)
+        metas = [self.dataset.meta(i) for i in idx]
+        tgt = torch.zeros(len(idx), 1, 1, 1, dtype=torch.long, device=img.device)  # pre-training never reads the labels
+        return (img, img_tf, tgt, tgt), [m[0] for m in metas], ([m[1] for m in metas], [m[2] for m in metas])
+
+
+def get_contrastive_dataloader(partial_loader, contrastive_params, device="cuda", out_hw=(224, 224)):
+    """``_get_contrastive_dataloader`` (semi_seg/trainers/_helper.py:31-74): a loader over ALL training scans of the data
+    set behind ``partial_loader`` (its ``.dataset``, or the store itself) -> (contrastive loader, monitor loader).
+    ``num_workers`` is accepted and ignored: there are no worker processes on this path."""
+    params = dict(contrastive_params)
+    params.pop("num_workers", None)
+    store = getattr(partial_loader, "dataset", partial_loader)
+    if not hasattr(store, "images") or not hasattr(store, "meta"):
+        raise TypeError("get_contrastive_dataloader: expected a semi_seg.data.DeviceSliceStore (or a loader whose "
+                        f"`.dataset` is one), got {type(store).__name__}")
+    if getattr(store, "data_name", "acdc") == "acdc":  # "only group the acdc dataset" (_helper.py:58-63)
+        loader = ContrastiveDeviceLoader(store, batch_sampler=ContrastBatchSampler(store, **params), out_hw=out_hw)
+    else:
+        loader = ContrastiveDeviceLoader(store, sampler=InfiniteRandomSampler(store, shuffle=True),
+                                         batch_size=params["scan_sample_num"] * store.partition_num, out_hw=out_hw)
+    return loader, None

@@ -121,6 +121,12 @@ class PretrainEncoderEpocher:
         self.close_hooks()
         return self.meters.statistics()
 
+    def _run_pretrain(self):
+        """the batch loop of ``_PretrainEpocherMixin._run_pretrain`` (new_pretrain.py:52-89): ``num_batches`` iterations
+        over the (infinite) contrastive loader; the per-batch seed is drawn in ``step_compute`` (:54)."""
+        for self.cur_batch_num, data in zip(range(self._num_batches), self._chain_dataloader):
+            self.step(data)
+
     def step(self, data, seed=None):
         """One iteration of new_pretrain.py:53-89; returns the (device) regularisation loss."""
         reg_loss = self.step_compute(data, seed)

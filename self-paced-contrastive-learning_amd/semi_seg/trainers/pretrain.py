@@ -51,57 +51,154 @@ class WarmupCosine:
 
 
 class PretrainEncoderTrainer:
-    def __init__(self, *, model: nn.Module, chain_dataloader: Iterable, save_dir: Optional[str] = None,
-                 max_epoch: int = 80, num_batches: int = 200, device="cuda", lr=5e-7, weight_decay=1e-5,
-                 warmup_max=10, multiplier=400, **kwargs):
+    """``PretrainEncoderTrainer`` as ``main_pretrain_encoder.py:54-72`` drives it.
+
+    Accepts the reference's constructor call unchanged --
+    ``PretrainEncoderTrainer(model=, labeled_loader=, unlabeled_loader=, val_loader=, test_loader=, criterion=,
+    config=, save_dir=, **config["Trainer"])`` (``SemiTrainer.__init__`` ``semi_seg/trainers/new_trainer.py:20-35`` +
+    ``_PretrainTrainerMixin.__init__`` ``new_pretrain.py:36-45``): optimiser and schedule are read from
+    ``config["Optim"]`` / ``config["Scheduler"]`` in ``init()`` (``contrastyou/trainer/base.py:60-83``), the contrastive
+    loader is built from ``unlabeled_loader`` and ``config["ContrastiveLoaderParams"]`` (a missing section raises
+    ``RuntimeError`` as the reference does) -- or the mirror's own short form ``chain_dataloader=`` with keyword
+    hyper-parameters.  Epoch bookkeeping follows ``new_pretrain.py:69-85``: ``range(max(_cur_epoch + 1, _start_epoch),
+    max_epoch)``, i.e. a fresh trainer runs epochs 1 .. max_epoch - 1 and a resumed one continues after the saved epoch."""
+    RUN_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))),
+                            "runs2")
+
+    def __init__(self, *, model: nn.Module, chain_dataloader: Optional[Iterable] = None, labeled_loader=None,
+                 unlabeled_loader=None, val_loader=None, test_loader=None, criterion=None, config: Optional[dict] = None,
+                 save_dir: Optional[str] = None, max_epoch: int = 80, num_batches: int = 200, device="cuda",
+                 lr=None, weight_decay=None, warmup_max=None, multiplier=None, two_stage: bool = False,
+                 disable_bn: bool = False, **kwargs):
         self._model = model
-        self._chain_dataloader = chain_dataloader
+        self._labeled_loader, self._unlabeled_loader = labeled_loader, unlabeled_loader
+        self._val_loader, self._test_loader = val_loader, test_loader
+        self._criterion = self._sup_criterion = criterion
+        self._two_stage, self._disable_bn = two_stage, disable_bn
+        self._config = config
         self._save_dir = save_dir
         self._max_epoch, self._num_batches, self._device = max_epoch, num_batches, device
-        self._optim_cfg = dict(lr=lr, weight_decay=weight_decay)
-        self._sched_cfg = dict(warmup_max=warmup_max, multiplier=multiplier)
+        optim_cfg = dict((config or {}).get("Optim", {}))
+        self._optim_name = optim_cfg.pop("name", "RAdam")
+        for k in ("pre_lr", "ft_lr"):  # trainer/base.py:64: these two keys never reach the optimiser
+            optim_cfg.pop(k, None)
+        if lr is not None:
+            optim_cfg["lr"] = lr
+        if weight_decay is not None:
+            optim_cfg["weight_decay"] = weight_decay
+        optim_cfg.setdefault("lr", 5e-7)
+        optim_cfg.setdefault("weight_decay", 1e-5)
+        self._optim_cfg = optim_cfg
+        sched = (config or {}).get("Scheduler", None)
+        if config is None or sched is not None or warmup_max is not None or multiplier is not None:
+            sched = dict(sched or {})
+            if warmup_max is not None:
+                sched["warmup_max"] = warmup_max
+            if multiplier is not None:
+                sched["multiplier"] = multiplier
+            sched.setdefault("warmup_max", 10)
+            sched.setdefault("multiplier", 400)
+        self._sched_cfg = sched  # None: no scheduler (trainer/base.py:72-73)
+        if chain_dataloader is None:
+            if config is None or "ContrastiveLoaderParams" not in config:  # new_pretrain.py:38-40
+                raise RuntimeError("`ContrastiveLoaderParams` should be found in config, given \n`" +
+                                   ", ".join((config or {}).keys()) + "`")
+            from ..data import get_contrastive_dataloader  # row N2
+            chain_dataloader, self._monitor_loader = get_contrastive_dataloader(
+                unlabeled_loader, config["ContrastiveLoaderParams"], device=device)
+        self._chain_dataloader = self._contrastive_loader = chain_dataloader
         self.__hooks__ = nn.ModuleList()
-        self.forward_until = None
-        self._cur_epoch, self._start_epoch = 0, 0
+        self._inference_until = None
+        self._cur_epoch, self._start_epoch, self._best_score = 0, 0, 0
         self._optimizer = self._scheduler = self._flat = None
+        self.__initialized__ = False
         self.history = []
+        if save_dir and config is not None and _ddp.on_master():  # trainer/base.py:40-41 (dump_config)
+            os.makedirs(save_dir, exist_ok=True)
+            import yaml
+            with open(os.path.join(save_dir, "config.yaml"), "w") as f:
+                yaml.safe_dump(config, f)
+
+    @property
+    def save_dir(self):
+        return str(self._save_dir)
+
+    @staticmethod
+    def on_master():
+        return _ddp.on_master()
+
+    # new_pretrain.py:47-62
+    @property
+    def forward_until(self):
+        if self._inference_until is None:
+            return list(type(self._model).decoder_names)[-1]
+        return self._inference_until
+
+    @forward_until.setter
+    def forward_until(self, forward_until):
+        if isinstance(forward_until, str):
+            if forward_until == "all":
+                self._inference_until = None
+                return
+            assert forward_until in type(self._model).arch_elements, forward_until
+        self._inference_until = forward_until
 
     # trainer/base.py:49-58
+    def register_hook(self, hook):
+        from ...contrastyou.hooks.base import TrainerHook
+        assert isinstance(hook, TrainerHook), hook
+        self.__hooks__.append(hook)
+
     def register_hooks(self, *hooks):
-        assert self._optimizer is None, "`register_hook` must be called before `init()`"
+        if self.__initialized__:
+            raise RuntimeError("`register_hook must be called before `init()``")
         for h in hooks:
-            self.__hooks__.append(h)
-        self.forward_until = feature_until_from_hooks(*hooks)
+            self.register_hook(h)
 
     # trainer/base.py:44-47,60-83
     def init(self):
         self._model.to(self._device)
         self.__hooks__.to(self._device)
         _ddp.broadcast_state(self._model, self.__hooks__)
+        # call inside ``model.set_grad(False, start=until, include_start=False)`` (main_pretrain_encoder.py:69): only
+        # parameters that require grad join the flat parameter, exactly the reference's optimiser membership
         params = [p for p in self._model.parameters() if p.requires_grad]
         hook_params = [p for h in self.__hooks__ for p in h.parameters()]
-        # the reference gives model and hook parameters two groups with identical lr / weight decay
+        # the reference gives model and hook parameters two groups with identical hyper-parameters
         # (trainer/base.py:62-68): one flat parameter is the same optimisation problem
         self._flat = _ddp.FlatParams(params + hook_params)
-        self._optimizer = FusedRAdam([self._flat.param], **self._optim_cfg)  # torch.optim.RAdam semantics, one launch
-        self._scheduler = WarmupCosine(self._optimizer, max_epoch=self._max_epoch, **self._sched_cfg)
+        if self._optim_name == "RAdam":
+            self._optimizer = FusedRAdam([self._flat.param], **self._optim_cfg)  # torch.optim.RAdam semantics, HIP kernel
+        elif hasattr(torch.optim, self._optim_name):
+            self._optimizer = getattr(torch.optim, self._optim_name)([self._flat.param], **self._optim_cfg)
+        else:
+            raise KeyError(self._optim_name)
+        self._scheduler = None
+        if self._sched_cfg is not None:
+            self._scheduler = WarmupCosine(self._optimizer, max_epoch=self._max_epoch, **self._sched_cfg)
+        self.__initialized__ = True
 
     def _create_tra_epoch(self):
         epocher = PretrainEncoderEpocher(model=self._model, optimizer=self._optimizer,
                                          chain_dataloader=self._chain_dataloader, num_batches=self._num_batches,
                                          cur_epoch=self._cur_epoch, device=self._device,
-                                         inference_until=self.forward_until or "Conv5", flat_params=self._flat)
+                                         inference_until=self._inference_until or "Conv5", flat_params=self._flat)
         epocher.add_hooks([h() for h in self.__hooks__])
         epocher.init()
         return epocher
 
-    # trainers/new_pretrain.py:69-85
+    def run_tra_epoch(self):
+        return self._create_tra_epoch().run()
+
+    # trainer/base.py:85-92, trainers/new_pretrain.py:69-85
     def start_training(self):
-        for self._cur_epoch in range(max(self._cur_epoch + 1, self._start_epoch) if self._cur_epoch else 0,
-                                     self._max_epoch):
-            stats = self._create_tra_epoch().run()
+        if not self.__initialized__:
+            raise RuntimeError(f"{self.__class__.__name__} should call `init()` first")
+        for self._cur_epoch in range(max(self._cur_epoch + 1, self._start_epoch), self._max_epoch):
+            stats = self.run_tra_epoch()
             self.history.append(stats)
-            self._scheduler.step()
+            if self._scheduler is not None:
+                self._scheduler.step()
             if self._save_dir and _ddp.on_master():
                 self.save_to("last.pth")
         return self.history
@@ -109,15 +206,18 @@ class PretrainEncoderTrainer:
     # trainer/_io.py:49-71,120-134
     def state_dict(self):
         return {"_model": self._model.state_dict(), "_optimizer": self._optimizer.state_dict(),
-                "_scheduler": self._scheduler.state_dict(), "__hooks__": self.__hooks__.state_dict(),
+                "_scheduler": self._scheduler.state_dict() if self._scheduler is not None else None,
+                "__hooks__": self.__hooks__.state_dict(),
                 "_hook_schedulers": [getattr(s, "_scheduler").state_dict() if hasattr(s, "_scheduler") else None
                                      for h in self.__hooks__ for s in getattr(h, "_hooks", [h])],
-                "_buffers": {"_cur_epoch": self._cur_epoch, "_start_epoch": self._start_epoch}}
+                "_buffers": {"_cur_epoch": self._cur_epoch, "_start_epoch": self._start_epoch,
+                             "_best_score": self._best_score}}
 
     def load_state_dict(self, sd):
         self._model.load_state_dict(sd["_model"])
         self._optimizer.load_state_dict(sd["_optimizer"])
-        self._scheduler.load_state_dict(sd["_scheduler"])
+        if self._scheduler is not None and sd.get("_scheduler") is not None:
+            self._scheduler.load_state_dict(sd["_scheduler"])
         self.__hooks__.load_state_dict(sd["__hooks__"])
         subs = [s for h in self.__hooks__ for s in getattr(h, "_hooks", [h])]
         for s, ssd in zip(subs, sd.get("_hook_schedulers", [])):
@@ -125,8 +225,10 @@ class PretrainEncoderTrainer:
                 s._scheduler.load_state_dict(ssd)
         self._cur_epoch = sd["_buffers"]["_cur_epoch"]
         self._start_epoch = sd["_buffers"]["_start_epoch"]
+        self._best_score = sd["_buffers"].get("_best_score", 0)
 
-    def save_to(self, name):
+    def save_to(self, save_name=None, name=None):
+        name = save_name or name
         os.makedirs(self._save_dir, exist_ok=True)
         tmp = os.path.join(self._save_dir, name + ".tmp")
         torch.save(self.state_dict(), tmp)

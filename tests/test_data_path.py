@@ -1,0 +1,81 @@
+"""SURVEY row N2 (on-device data path), host side: the contrastive batch composition, the partition meta-labels and the
+augmentation parameter draws against the oracle's literal restatement of the reference (semi_seg/data/rearr.py:37-98,
+semi_seg/data/dataset.py:34-43,66-71, semi_seg/augment.py:6-22)."""
+import random
+
+import pytest
+import torch
+
+from oracle import spcl_oracle as O
+
+import spcl_amd  # noqa: F401
+from spcl_amd.semi_seg.data import (ContrastBatchSampler, InfiniteRandomSampler, acdc_partition, draw_view_params,
+                                    prostate_partition, synthetic_slice_store)
+
+
+@pytest.mark.parametrize("scan_num,part_num,shuffle", [(3, 1, False), (5, 1, True), (2, 2, False), (6, 3, True)])
+def test_contrast_batch_sampler_draws_the_reference_batches(scan_num, part_num, shuffle):
+    store = synthetic_slice_store(scans=7, slices_per_scan=(4, 11), size=16, device="cpu", seed=3)
+    scans, parts = store.show_scan_names(), store.show_partitions()
+    random.seed(11)
+    it = iter(ContrastBatchSampler(store, scan_sample_num=scan_num, partition_sample_num=part_num, shuffle=shuffle))
+    got = [next(it) for _ in range(25)]
+    random.seed(11)
+    want = [O.contrast_batch_indices(scans, parts, scan_num, part_num, shuffle) for _ in range(25)]
+    assert got == want
+    for b in got:  # every drawn (scan, partition) pair contributes exactly partition_sample_num slices
+        pairs = {}
+        for i in b:
+            pairs.setdefault((scans[i], parts[i]), []).append(i)
+        assert all(len(v) == part_num for v in pairs.values()) and len({s for s, _ in pairs}) <= scan_num
+
+
+def test_short_scans_skip_partitions_they_cannot_fill():
+    store = synthetic_slice_store(scans=4, slices_per_scan=(2, 3), size=8, device="cpu", seed=1)  # 2-3 slices: empty thirds
+    it = iter(ContrastBatchSampler(store, scan_sample_num=4, partition_sample_num=1))
+    random.seed(5)
+    got = next(it)
+    random.seed(5)
+    assert got == O.contrast_batch_indices(store.show_scan_names(), store.show_partitions(), 4, 1)
+    assert len(got) < 4 * 3  # some (scan, partition) pairs are empty
+    with pytest.raises(AssertionError):
+        iter(ContrastBatchSampler(store, scan_sample_num=5))
+
+
+def test_partition_meta_labels():
+    # ACDC: scan of 10 slices -> cutting point 3: indices 0-2 | 3-6 | 7-9 (dataset.py:34-43)
+    assert [acdc_partition(f"patient004_00_{k:02d}", 10) for k in range(10)] == list("0001111222")
+    assert [acdc_partition(f"patient100_01_{k}", 7) for k in range(7)] == list("0011122")
+    # Prostate: 20 slices, 8 partitions -> cutting point 2 -> index // 3 (dataset.py:66-71)
+    assert [prostate_partition(f"Case07_{k:02d}", 20) for k in range(20)] == [str(k // 3) for k in range(20)]
+    for k in range(12):
+        assert acdc_partition(f"patient001_00_{k:02d}", 12) == O.acdc_partition(f"patient001_00_{k:02d}", 12)
+        assert prostate_partition(f"Case01_{k:02d}", 12) == O.prostate_partition(f"Case01_{k:02d}", 12)
+    store = synthetic_slice_store(scans=3, slices_per_scan=(9, 9), size=8, device="cpu")
+    assert store.meta(4) == ("patient001_00_04", "1", "patient001_00")
+    assert store.get_scan_list() == ["patient001_00", "patient002_00", "patient003_00"]
+    with pytest.raises(AttributeError):
+        store._get_scan_name("scan_without_pattern")
+
+
+def test_view_parameter_draws_follow_the_recipe():
+    rng = random.Random(0)
+    rows = [draw_view_params(7, (256, 256), (224, 224), rng=rng) for _ in range(4000)]
+    import struct
+    f = lambda bits: struct.unpack("<f", struct.pack("<i", bits))[0]  # noqa: E731
+    for r in rows:
+        assert r[0] == 7 and 0 <= r[4] <= 32 and 0 <= r[5] <= 32 and 0 <= r[3] < 8
+        assert abs(r[1] ** 2 + r[2] ** 2 - 65536 ** 2) < 2 * 65536 * 2  # a rotation, quantised to 16.16
+        assert r[1] >= int(0.7071 * 65536) - 1  # |angle| <= 45 degrees
+        assert 0.5 <= f(r[6]) <= 1.5 and 0.5 <= f(r[7]) <= 1.5
+    for bit in (1, 2, 4):  # flips and the jitter order are fair coins
+        assert 0.45 < sum(1 for r in rows if r[3] & bit) / len(rows) < 0.55
+    same = draw_view_params(0, (224, 224), (224, 224), degrees=0, brightness=None, contrast=None, flips=False, rng=rng)
+    assert same[1:3] == [65536, 0] and same[4:6] == [0, 0] and f(same[6]) == 1.0 and f(same[7]) == 1.0
+
+
+def test_infinite_random_sampler_is_a_stream_of_permutations():
+    random.seed(2)
+    it = iter(InfiniteRandomSampler(range(5)))
+    a, b = [next(it) for _ in range(5)], [next(it) for _ in range(5)]
+    assert sorted(a) == sorted(b) == list(range(5))
