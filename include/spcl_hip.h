@@ -70,6 +70,16 @@ int spcl_supcon_materialize(const float* labels, const float* mask, int n, int d
                             float gamma, const float* ws_fwd, float* sim_logits, float* sim_exp, float* pos_mask,
                             float* neg_mask, float* sp_mask, void* stream);
 
+/* SupConLoss1(exclude_other_pos=True) (contrast_loss3.py:97-100: every positive pair is scored against the row's
+ * negatives only, their sum divided by the row's negative ratio + 1e-4) and its gradient; not used by the hooks, plain
+ * fp32 row kernels.  labels / mask as above (both NULL = SimCLR); ws of spcl_supcon_xpos_workspace_bytes(n, d) (0 when
+ * n > 4096) keeps d loss / d logits for the backward; out[0] = loss, out[3] = max | |row| - 1 |. */
+size_t spcl_supcon_xpos_workspace_bytes(int n, int d);
+int spcl_supcon_xpos_forward(const float* z1, const float* z2, const float* labels, const float* mask, int n, int d,
+                             float temperature, float* ws, float* out, void* stream);
+int spcl_supcon_xpos_backward(const float* z1, const float* z2, int n, int d, float temperature, const float* ws,
+                              const float* grad_out, float* dz1, float* dz2, void* stream);
+
 /* ---------------------------------------------------------------- projector ------------------------------
  * Replaces contrastyou/projectors/heads.py:9-25,78-92 + nn.py:8-15,29-36,56-58:
  * AdaptiveAvgPool2d((1,1)) -> Flatten -> Linear -> LeakyReLU(0.01) -> Linear -> F.normalize(p=2,dim=1).
@@ -129,6 +139,20 @@ size_t spcl_conv_wgrad_workspace_bytes(int N, int H, int W, int CinK, int CoutS)
 int spcl_conv3x3_wgrad(const void* x, const void* dy, int dtype, int N, int H, int W, int Cin, int CinS, int CinK,
                        int Cout, int CoutS, int in_mode, const float* in_scale, const float* in_shift, float* partial,
                        float* dw_oihw, void* stream);
+
+/* nn.AdaptiveAvgPool2d / nn.AdaptiveMaxPool2d((OH, OW)) on an NHWC tensor x [N,H,W,Cs] of dtype (C real channels) ->
+ * out [N,OH,OW,C] f32 (contrastyou/projectors/nn.py:56-64: the pooling of ProjectionHead(pool_name="adaptive_max") and of
+ * DenseProjectionHead, heads.py:96-120).  mode 0 average, 1 maximum (argmax [N,OH,OW,C] int32 receives the flat y * W + x of
+ * the first maximum).  Backward: dx [N,H,W,Cs] of dtype, deterministic (one thread per input element, no atomics). */
+int spcl_adaptive_pool2d_forward(const void* x, int dtype, int N, int H, int W, int C, int Cs, int OH, int OW, int mode,
+                                 float* out, int* argmax, void* stream);
+int spcl_adaptive_pool2d_backward(const float* dout, const int* argmax, int dtype, int N, int H, int W, int C, int Cs,
+                                  int OH, int OW, int mode, void* dx, void* stream);
+
+/* F.normalize(p=2, dim=-1, eps=1e-12) of `rows` rows of O floats (projectors/nn.py:29-36 on a pixel-major map) and its
+ * backward. */
+int spcl_l2norm_rows_forward(const float* x, size_t rows, int O, float* z, void* stream);
+int spcl_l2norm_rows_backward(const float* x, const float* dz, size_t rows, int O, float* dx, void* stream);
 
 /* The same weight gradients for SEVERAL layers in ONE launch (bf16, channel counts multiples of 64: _Conv3.b.._Conv5.b
  * and the decoder's wide layers).  The workgroups split the union of the layers' pixel ranges, so the launch writes

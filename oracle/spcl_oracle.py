@@ -126,12 +126,13 @@ def supcon_grad(z1: Tensor, z2: Tensor, labels=None, mask=None, *, t=0.07, gamma
 # --------------------------------------------------------------------------------------
 # projector
 # --------------------------------------------------------------------------------------
-def projector_forward(feat: Tensor, params: Dict[str, Tensor], *, head_type="mlp", normalize=True) -> Tensor:
-    """AdaptiveAvgPool2d((1,1)) -> Flatten -> Linear -> LeakyReLU(0.01) -> Linear -> L2 normalise.
+def projector_forward(feat: Tensor, params: Dict[str, Tensor], *, head_type="mlp", normalize=True,
+                      pool_name="adaptive_avg") -> Tensor:
+    """AdaptiveAvgPool2d((1,1)) (or AdaptiveMaxPool2d) -> Flatten -> Linear -> LeakyReLU(0.01) -> Linear -> L2 normalise.
 
     ``params`` uses the reference's state_dict keys: ``_header.2.{weight,bias}``, ``_header.4.{weight,bias}``.
     """
-    x = feat.mean(dim=(2, 3))
+    x = feat.mean(dim=(2, 3)) if pool_name == "adaptive_avg" else F.adaptive_max_pool2d(feat, 1).flatten(1)
     if head_type == "mlp":
         x = F.linear(x, params["_header.2.weight"], params["_header.2.bias"])
         x = F.leaky_relu(x, 0.01)
@@ -141,6 +142,58 @@ def projector_forward(feat: Tensor, params: Dict[str, Tensor], *, head_type="mlp
     if normalize:
         x = x / x.norm(dim=1, keepdim=True).clamp_min(1e-12)
     return x
+
+
+def adaptive_pool2d(x: Tensor, out_hw, mode="avg") -> Tensor:
+    """nn.AdaptiveAvgPool2d / nn.AdaptiveMaxPool2d(out_hw) (contrastyou/projectors/nn.py:56-64): window (oy, ox) = rows
+    floor(oy H / OH) .. ceil((oy + 1) H / OH) - 1, same for the columns; the maximum's gradient goes to the FIRST
+    maximum of the window in scan order (the ATen ops themselves, as everywhere in this file)."""
+    return F.adaptive_avg_pool2d(x, out_hw) if mode == "avg" else F.adaptive_max_pool2d(x, out_hw)
+
+
+def dense_projector_forward(feat: Tensor, params: Dict[str, Tensor], *, head_type="mlp", normalize=True,
+                            pool_name="adaptive_avg", spatial_size=(16, 16)) -> Tensor:
+    """``DenseProjectionHead.forward`` (contrastyou/projectors/heads.py:96-120): 1x1-conv MLP (``_projector.0`` ->
+    LeakyReLU(0.01) -> ``_projector.2``; linear head: ``_projector.0`` only) -> adaptive pool -> L2 normalise over the
+    channels."""
+    x = F.conv2d(feat, params["_projector.0.weight"], params["_projector.0.bias"])
+    if head_type == "mlp":
+        x = F.conv2d(F.leaky_relu(x, 0.01), params["_projector.2.weight"], params["_projector.2.bias"])
+    if pool_name in ("adaptive_avg", "adaptive_max"):
+        x = adaptive_pool2d(x, spatial_size, "avg" if pool_name == "adaptive_avg" else "max")
+    if normalize:
+        x = x / x.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    return x
+
+
+def supcon_loss_exclude_other_pos(z1: Tensor, z2: Tensor, labels=None, mask: Optional[Tensor] = None, *,
+                                  t: float = 0.07) -> Tensor:
+    """``SupConLoss1(exclude_other_pos=True)`` (contrast_loss3.py:59-110 with the branch at :97-100): each positive pair
+    is scored against the row's negatives only, their sum divided by the row's negative ratio + 1e-4."""
+    n, dt = z1.shape[0], z1.dtype
+    pos, neg = build_masks(n, labels, mask, dtype=dt)
+    P = torch.cat([z1, z2], 0)
+    S = (P @ P.t()) / t
+    L = S - S.max().detach()
+    E = torch.exp(L)
+    c, q = pos.sum(1), neg.sum(1)
+    nsum = (E * neg).sum(1, keepdim=True)
+    ratio = q / (c + q)
+    ll = L - torch.log(E + nsum / (ratio + 1e-4)[:, None] + 1e-16)
+    return -((ll * pos).sum(1) / c).mean()
+
+
+def dense_region_points(seed: int, batch: int, h: int, w: int, point_nums: int = 5):
+    """the pixels ``_INFONCEDenseHook.region_extractor`` visits (semi_seg/hooks/infonce.py:228-237 under
+    ``FixRandomSeed(seed)``): per slice ``np.random.choice`` of distinct rows and of distinct columns"""
+    import numpy as np
+    state = np.random.get_state()
+    np.random.seed(seed % (2 ** 32))
+    pts = [[(int(x), int(y)) for x, y in zip(np.random.choice(range(h), point_nums, replace=False),
+                                             np.random.choice(range(w), point_nums, replace=False))]
+           for _ in range(batch)]
+    np.random.set_state(state)
+    return pts
 
 
 # --------------------------------------------------------------------------------------

@@ -110,14 +110,25 @@ class SupConLoss1(_SupConBase):
 
     def __init__(self, temperature=0.07, exclude_other_pos=False, sync_checks=True):
         super().__init__(temperature, sync_checks)
-        if exclude_other_pos:
-            raise NotImplementedError("exclude_other_pos=True (contrast_loss3.py:97-100) is not on the pre-train hot "
-                                      "path (INFONCEHook.init_criterion uses the default) and is not built")
         self._exclude_pos = exclude_other_pos
 
     def forward(self, proj_feat1, proj_feat2, target=None, mask: Tensor = None, **kwargs):
         labels_t, mask_t = self._prepare_targets(proj_feat1, proj_feat2, target, mask)
-        return self._run(proj_feat1, proj_feat2, labels_t, mask_t, F_hip.SP_NONE, 1e6, False)
+        if not self._exclude_pos:
+            return self._run(proj_feat1, proj_feat2, labels_t, mask_t, F_hip.SP_NONE, 1e6, False)
+        # :97-100 -- each positive against the row's negatives only (csrc/supcon_xpos.hip); the taps are those of the
+        # plain loss on the same inputs (same masks / logits), evaluated without a graph
+        assert proj_feat1.shape == proj_feat2.shape, (proj_feat1.shape, proj_feat2.shape)
+        self._state = F_hip.SupConState()
+        self._taps_cache = self._host_out = None
+        with torch.no_grad():
+            F_hip.supcon_loss(proj_feat1, proj_feat2, labels_t, mask_t, t=self._t, state=self._state)
+        out = torch.empty(8, dtype=torch.float32, device=proj_feat1.device)
+        loss = F_hip.supcon_loss_exclude_other_pos(proj_feat1, proj_feat2, labels_t, mask_t, t=self._t, out=out)
+        self._state.out = out
+        if self.sync_checks:
+            self.check()
+        return loss
 
 
 class SelfPacedSupConLoss(_SupConBase):

@@ -173,9 +173,143 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restric
   Elem<T>::store(dfeat + idx, v);
 }
 
+// ---- nn.AdaptiveAvgPool2d / nn.AdaptiveMaxPool2d((OH, OW)) on an NHWC tensor (projectors/nn.py:56-64; the pooling of
+// ProjectionHead(pool_name="adaptive_max") and of DenseProjectionHead, projectors/heads.py:96-120).  Window of output
+// (oy, ox) = rows floor(oy H / OH) .. ceil((oy + 1) H / OH) - 1, same for columns (torch's rule).  One thread per output
+// element; max keeps the FIRST maximum's flat input index for the backward (torch's tie rule in scan order).
+template <typename T, bool MAX>
+__global__ __launch_bounds__(256) void adaptive_pool_fwd_kernel(const T* __restrict__ x, int H, int W, int C, int Cs,
+                                                                int OH, int OW, float* __restrict__ out,
+                                                                int* __restrict__ arg, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % C);
+  size_t r = idx / C;
+  const int ox = (int)(r % OW);
+  r /= OW;
+  const int oy = (int)(r % OH);
+  const size_t n = r / OH;
+  const int y0 = (oy * H) / OH, y1 = ((oy + 1) * H + OH - 1) / OH;
+  const int x0 = (ox * W) / OW, x1 = ((ox + 1) * W + OW - 1) / OW;
+  float acc = MAX ? -INFINITY : 0.f;
+  int best = 0;
+  for (int y = y0; y < y1; ++y)
+    for (int xx = x0; xx < x1; ++xx) {
+      const float v = Elem<T>::load(x + ((n * H + y) * W + xx) * (size_t)Cs + c);
+      if (MAX) {
+        if (v > acc || (y == y0 && xx == x0)) {
+          acc = v;
+          best = y * W + xx;
+        }
+      } else {
+        acc += v;
+      }
+    }
+  out[idx] = MAX ? acc : acc / (float)((y1 - y0) * (x1 - x0));
+  if (MAX) arg[idx] = best;
+}
+
+// dx[n][y][x][c] = sum over the windows (oy, ox) that contain (y, x) of dout / window size (avg) or of dout where the
+// window's arg-max is (y, x) (max).  One thread per INPUT element walks the (at most 2 x 2 ... few) covering windows:
+// no atomics, deterministic.
+template <typename T, bool MAX>
+__global__ __launch_bounds__(256) void adaptive_pool_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ arg,
+                                                                int H, int W, int C, int Cs, int OH, int OW,
+                                                                T* __restrict__ dx, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int c = (int)(idx % Cs);
+  size_t r = idx / Cs;
+  const int xx = (int)(r % W);
+  r /= W;
+  const int y = (int)(r % H);
+  const size_t n = r / H;
+  float g = 0.f;
+  if (c < C) {
+    // windows containing row y: oy with floor(oy H / OH) <= y < ceil((oy + 1) H / OH)
+    int oy_lo = (int)(((long)y * OH) / H), ox_lo = (int)(((long)xx * OW) / W);
+    while (oy_lo > 0 && ((oy_lo) * H + OH - 1) / OH > y) --oy_lo;   // previous window still reaches y
+    while (ox_lo > 0 && ((ox_lo) * W + OW - 1) / OW > xx) --ox_lo;
+    for (int oy = oy_lo; oy < OH && (oy * H) / OH <= y; ++oy) {
+      const int y0 = (oy * H) / OH, y1 = ((oy + 1) * H + OH - 1) / OH;
+      if (y < y0 || y >= y1) continue;
+      for (int ox = ox_lo; ox < OW && (ox * W) / OW <= xx; ++ox) {
+        const int x0 = (ox * W) / OW, x1 = ((ox + 1) * W + OW - 1) / OW;
+        if (xx < x0 || xx >= x1) continue;
+        const size_t o = ((n * OH + oy) * OW + ox) * (size_t)C + c;
+        if (MAX) g += arg[o] == y * W + xx ? dout[o] : 0.f;
+        else g += dout[o] / (float)((y1 - y0) * (x1 - x0));
+      }
+    }
+  }
+  Elem<T>::store(dx + idx, g);
+}
+
 }  // namespace spcl
 
 using namespace spcl;
+
+extern "C" int spcl_adaptive_pool2d_forward(const void* x, int dtype, int N, int H, int W, int C, int Cs, int OH, int OW,
+                                            int mode, float* out, int* argmax, void* stream) {
+  SPCL_CHECK_ARG(x && out, "adaptive_pool2d_forward: null pointer");
+  SPCL_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && Cs >= C && OH > 0 && OW > 0, "adaptive_pool2d_forward: bad shape");
+  SPCL_CHECK_ARG(mode == 0 || (mode == 1 && argmax), "adaptive_pool2d_forward: mode %d (0 avg, 1 max + argmax)", mode);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t total = (size_t)N * OH * OW * C;
+  dim3 g((unsigned)((total + 255) / 256));
+  if (dtype == SPCL_F32 && mode == 0)
+    SPCL_LAUNCH((adaptive_pool_fwd_kernel<float, false>), g, dim3(256), 0, st, (const float*)x, H, W, C, Cs, OH, OW, out, argmax, total);
+  else if (dtype == SPCL_F32)
+    SPCL_LAUNCH((adaptive_pool_fwd_kernel<float, true>), g, dim3(256), 0, st, (const float*)x, H, W, C, Cs, OH, OW, out, argmax, total);
+  else if (dtype == SPCL_BF16 && mode == 0)
+    SPCL_LAUNCH((adaptive_pool_fwd_kernel<bf16_t, false>), g, dim3(256), 0, st, (const bf16_t*)x, H, W, C, Cs, OH, OW, out, argmax, total);
+  else if (dtype == SPCL_BF16)
+    SPCL_LAUNCH((adaptive_pool_fwd_kernel<bf16_t, true>), g, dim3(256), 0, st, (const bf16_t*)x, H, W, C, Cs, OH, OW, out, argmax, total);
+  else {
+    set_error("adaptive_pool2d_forward: dtype %d", dtype);
+    return SPCL_EINVAL;
+  }
+  SPCL_LAUNCH_CHECK("adaptive_pool2d_forward");
+  return SPCL_OK;
+}
+
+extern "C" int spcl_adaptive_pool2d_backward(const float* dout, const int* argmax, int dtype, int N, int H, int W, int C,
+                                             int Cs, int OH, int OW, int mode, void* dx, void* stream) {
+  SPCL_CHECK_ARG(dout && dx, "adaptive_pool2d_backward: null pointer");
+  SPCL_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && Cs >= C && OH > 0 && OW > 0, "adaptive_pool2d_backward: bad shape");
+  SPCL_CHECK_ARG(mode == 0 || (mode == 1 && argmax), "adaptive_pool2d_backward: mode %d", mode);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t total = (size_t)N * H * W * Cs;
+  dim3 g((unsigned)((total + 255) / 256));
+  if (dtype == SPCL_F32 && mode == 0)
+    SPCL_LAUNCH((adaptive_pool_bwd_kernel<float, false>), g, dim3(256), 0, st, dout, argmax, H, W, C, Cs, OH, OW, (float*)dx, total);
+  else if (dtype == SPCL_F32)
+    SPCL_LAUNCH((adaptive_pool_bwd_kernel<float, true>), g, dim3(256), 0, st, dout, argmax, H, W, C, Cs, OH, OW, (float*)dx, total);
+  else if (dtype == SPCL_BF16 && mode == 0)
+    SPCL_LAUNCH((adaptive_pool_bwd_kernel<bf16_t, false>), g, dim3(256), 0, st, dout, argmax, H, W, C, Cs, OH, OW, (bf16_t*)dx, total);
+  else if (dtype == SPCL_BF16)
+    SPCL_LAUNCH((adaptive_pool_bwd_kernel<bf16_t, true>), g, dim3(256), 0, st, dout, argmax, H, W, C, Cs, OH, OW, (bf16_t*)dx, total);
+  else {
+    set_error("adaptive_pool2d_backward: dtype %d", dtype);
+    return SPCL_EINVAL;
+  }
+  SPCL_LAUNCH_CHECK("adaptive_pool2d_backward");
+  return SPCL_OK;
+}
+
+extern "C" int spcl_l2norm_rows_forward(const float* x, size_t rows, int O, float* z, void* stream) {
+  SPCL_CHECK_ARG(x && z && rows > 0 && O > 0, "l2norm_rows_forward: bad argument");
+  SPCL_LAUNCH(l2norm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, (int)rows, O, z);
+  SPCL_LAUNCH_CHECK("l2norm_rows_forward");
+  return SPCL_OK;
+}
+
+extern "C" int spcl_l2norm_rows_backward(const float* x, const float* dz, size_t rows, int O, float* dx, void* stream) {
+  SPCL_CHECK_ARG(x && dz && dx && rows > 0 && O > 0, "l2norm_rows_backward: bad argument");
+  SPCL_LAUNCH(l2norm_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, dz, (int)rows, O, dx);
+  SPCL_LAUNCH_CHECK("l2norm_rows_backward");
+  return SPCL_OK;
+}
 
 extern "C" int spcl_proj_forward(const void* feat, int dtype, int N, int HW, int C, int Cs, const float* w1,
                                  const float* b1, const float* w2, const float* b2, int hid, int out_dim,

@@ -94,6 +94,42 @@ def supcon_loss(z1, z2, labels=None, mask=None, *, t=0.07, sp_mode=SP_NONE, gamm
     return _SupConFn.apply(z1, z2, labels, mask, float(t), int(sp_mode), float(gamma), bool(correct_grad), state)
 
 
+class _SupConXposFn(torch.autograd.Function):
+    """SupConLoss1(exclude_other_pos=True), contrast_loss3.py:97-100 (csrc/supcon_xpos.hip)"""
+
+    @staticmethod
+    def forward(ctx, z1, z2, labels, mask, t, out):
+        _n.require_gpu(z1, z2, labels, mask)
+        z1c, z2c = z1.detach().contiguous().float(), z2.detach().contiguous().float()
+        n, d = z1c.shape
+        nbytes = _n.call("spcl_supcon_xpos_workspace_bytes", n, d)
+        if nbytes == 0:
+            raise RuntimeError(f"supcon (exclude_other_pos): unsupported shape n={n} d={d} (n <= 4096)")
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=z1.device)
+        _n.call("spcl_supcon_xpos_forward", _n.ptr(z1c), _n.ptr(z2c), _n.ptr(labels), _n.ptr(mask), n, d, c_float(t),
+                _n.ptr(ws), _n.ptr(out), _n.stream())
+        ctx.save_for_backward(z1c, z2c, ws)
+        ctx.meta = (n, d, t, z1.dtype, z2.dtype)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        z1c, z2c, ws = ctx.saved_tensors
+        n, d, t, dt1, dt2 = ctx.meta
+        dz1, dz2 = torch.empty_like(z1c), torch.empty_like(z2c)
+        go = grad_out.detach().reshape(1).float().contiguous()
+        _n.call("spcl_supcon_xpos_backward", _n.ptr(z1c), _n.ptr(z2c), n, d, c_float(t), _n.ptr(ws), _n.ptr(go),
+                _n.ptr(dz1), _n.ptr(dz2), _n.stream())
+        return dz1.to(dt1), dz2.to(dt2), None, None, None, None
+
+
+def supcon_loss_exclude_other_pos(z1, z2, labels=None, mask=None, *, t=0.07, out=None):
+    """-> loss (0-dim tensor with grad_fn); ``out`` (8 floats on the device) receives loss / norm defect"""
+    if out is None:
+        out = torch.empty(8, dtype=torch.float32, device=z1.device)
+    return _SupConXposFn.apply(z1, z2, labels, mask, float(t), out)
+
+
 def stacked_halves(a: torch.Tensor, b: torch.Tensor):
     """the tensor whose first / second half of rows a and b are (``torch.chunk(z, 2)`` outputs), else None"""
     base = a._base
@@ -198,6 +234,105 @@ class _ProjectorFn(torch.autograd.Function):
 
 def projector(feat, w1, b1, w2=None, b2=None, normalize=True):
     return _ProjectorFn.apply(feat, w1, b1, w2, b2, normalize)
+
+
+class _FlipBatchFn(torch.autograd.Function):
+    """per-sample H / W flips of an [N,C,H,W] batch (spcl_flip_batch); a flip is its own inverse, so is its gradient"""
+
+    @staticmethod
+    def forward(ctx, x, flags):
+        xc = x.detach().contiguous()
+        out = torch.empty_like(xc)
+        N, C, H, W = xc.shape
+        _n.call("spcl_flip_batch", _n.ptr(xc), _n.ptr(out), xc.element_size(), N, C, H, W, _n.ptr(flags), _n.stream())
+        ctx.flags = flags
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        gc = g.contiguous()
+        out = torch.empty_like(gc)
+        N, C, H, W = gc.shape
+        _n.call("spcl_flip_batch", _n.ptr(gc), _n.ptr(out), gc.element_size(), N, C, H, W, _n.ptr(ctx.flags), _n.stream())
+        return out, None
+
+
+def flip_batch(x, flags):
+    """differentiable form of TensorRandomFlip.apply_batch: ``flags`` uint8 [N] (bit 0 flip H, bit 1 flip W)"""
+    return _FlipBatchFn.apply(x, flags)
+
+
+class _AdaptivePoolFn(torch.autograd.Function):
+    """nn.AdaptiveAvgPool2d / nn.AdaptiveMaxPool2d((oh, ow)) on NHWC storage -> f32 logical [N,C,oh,ow]"""
+
+    @staticmethod
+    def forward(ctx, x, out_hw, mode):
+        _n.require_gpu(x)
+        xs, cs = as_nhwc(x.detach())
+        N, H, W, _ = xs.shape
+        C = x.shape[1]
+        oh, ow = out_hw
+        out = torch.empty(N, oh, ow, C, dtype=torch.float32, device=x.device)
+        arg = torch.empty(N, oh, ow, C, dtype=torch.int32, device=x.device) if mode == 1 else None
+        _n.call("spcl_adaptive_pool2d_forward", _n.ptr(xs), _n.dtype_code(xs.dtype), N, H, W, C, cs, oh, ow, mode,
+                _n.ptr(out), _n.ptr(arg), _n.stream())
+        ctx.arg = arg
+        ctx.meta = (N, H, W, C, cs, oh, ow, mode, xs.dtype, x.dtype)
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dout):
+        N, H, W, C, cs, oh, ow, mode, sdt, xdt = ctx.meta
+        do = _class_map_storage(dout)
+        dx = torch.empty(N, H, W, cs, dtype=sdt, device=dout.device)
+        _n.call("spcl_adaptive_pool2d_backward", _n.ptr(do), _n.ptr(ctx.arg), _n.dtype_code(sdt), N, H, W, C, cs, oh, ow,
+                mode, _n.ptr(dx), _n.stream())
+        g = nhwc_to_logical(dx, C)
+        return (g if g.dtype == xdt else g.to(xdt)), None, None
+
+
+def adaptive_pool2d(x, out_hw, mode="avg"):
+    return _AdaptivePoolFn.apply(x, (int(out_hw[0]), int(out_hw[1])), 1 if mode == "max" else 0)
+
+
+class _L2NormChannelsFn(torch.autograd.Function):
+    """F.normalize(x, p=2, dim=1) of a logical [N,C,H,W] f32 map with NHWC storage (rows = pixels)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        _n.require_gpu(x)
+        xs = _class_map_storage(x.detach())
+        N, H, W, C = xs.shape
+        z = torch.empty_like(xs)
+        _n.call("spcl_l2norm_rows_forward", _n.ptr(xs), N * H * W, C, _n.ptr(z), _n.stream())
+        ctx.save_for_backward(xs)
+        return z.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dz):
+        (xs,) = ctx.saved_tensors
+        N, H, W, C = xs.shape
+        dzs = _class_map_storage(dz)
+        dx = torch.empty_like(xs)
+        _n.call("spcl_l2norm_rows_backward", _n.ptr(xs), _n.ptr(dzs), N * H * W, C, _n.ptr(dx), _n.stream())
+        return dx.permute(0, 3, 1, 2)
+
+
+def l2norm_channels(x):
+    return _L2NormChannelsFn.apply(x)
+
+
+def pixelwise_mlp(feat, w1, b1, w2=None, b2=None):
+    """1x1-conv MLP of ``get_contrastive_dense_projector`` (projectors/heads.py:28-39) on a logical [N,C,H,W] map:
+    every pixel is a row of the projector kernels (no pooling, no normalisation) -> f32 logical [N,O,H,W].
+    ``w1`` [hid,C,1,1] (or [O,C,1,1] for the linear head), ``w2`` [O,hid,1,1]."""
+    xs, cs = as_nhwc(feat)  # differentiable view ops only
+    N, H, W, _ = xs.shape
+    C = feat.shape[1]
+    rows = torch.as_strided(xs, (N * H * W, C, 1, 1), (cs, 1, cs, cs), xs.storage_offset())
+    o = projector(rows, w1.reshape(w1.shape[0], -1), b1, None if w2 is None else w2.reshape(w2.shape[0], -1), b2,
+                  normalize=False)
+    return o.view(N, H, W, o.shape[1]).permute(0, 3, 1, 2)
 
 
 # --------------------------------------------------------------------------------------------- encoder blocks

@@ -26,10 +26,18 @@ _SIGNATURES = {
     "spcl_supcon_backward": (c_int, [_P, _P, c_int, c_int, c_float, c_int, c_float, _P, _P, _P, _P, _P, _P, _P]),
     "spcl_supcon_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
     "spcl_supcon_materialize": (c_int, [_P, _P, c_int, c_int, c_float, c_int, c_float, _P, _P, _P, _P, _P, _P, _P]),
+    "spcl_supcon_xpos_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "spcl_supcon_xpos_forward": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, _P, _P, _P]),
+    "spcl_supcon_xpos_backward": (c_int, [_P, _P, c_int, c_int, c_float, _P, _P, _P, _P, _P]),
     "spcl_proj_forward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int,
                                   _P, _P, _P, _P, _P]),
     "spcl_proj_backward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, _P, _P, _P,
                                    _P, _P, _P, _P, _P, _P, _P]),
+    "spcl_adaptive_pool2d_forward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "spcl_adaptive_pool2d_backward": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P,
+                                              _P]),
+    "spcl_l2norm_rows_forward": (c_int, [_P, c_size_t, c_int, _P, _P]),
+    "spcl_l2norm_rows_backward": (c_int, [_P, _P, c_size_t, c_int, _P, _P]),
     "spcl_conv_packed_elems": (c_size_t, [c_int, c_int, c_int, c_int]),
     "spcl_conv_pack_weights": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
     "spcl_conv_pack_weights_both": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),

@@ -1,2 +1,2 @@
-from .pretrain import PretrainEncoderEpocher, unzip_twice_transformed  # noqa: F401
+from .pretrain import PretrainDecoderEpocher, PretrainEncoderEpocher, unzip_twice_transformed  # noqa: F401
 from .finetune import EvalEpocher, FineTuneEpocher  # noqa: F401

@@ -33,19 +33,24 @@ class SIMCLRGenerator:
 
 
 class FixRandomSeed:
-    """Context manager: seed python's RNG, restore its state on exit (contract of deepclustering2.FixRandomSeed as
-    used at semi_seg/epochers/new_pretrain.py:57,64 and semi_seg/hooks/infonce.py:177)."""
+    """Context manager: seed python's and numpy's RNGs, restore their states on exit (contract of
+    deepclustering2.FixRandomSeed as used at semi_seg/epochers/new_pretrain.py:57,64 and semi_seg/hooks/infonce.py:177,
+    211-214 -- the dense hook draws its points with ``np.random.choice``)."""
 
     def __init__(self, seed):
         self._seed = seed
 
     def __enter__(self):
-        self._state = random.getstate()
+        import numpy as np
+        self._state, self._np_state = random.getstate(), np.random.get_state()
         random.seed(self._seed)
+        np.random.seed(self._seed % (2 ** 32))
         return self
 
     def __exit__(self, *a):
+        import numpy as np
         random.setstate(self._state)
+        np.random.set_state(self._np_state)
 
 
 class TensorRandomFlip:
@@ -81,6 +86,9 @@ class TensorRandomFlip:
                 flags = torch.tensor([int(d[0]) | (int(d[1]) << 1) for d in dec], dtype=torch.uint8, device=x.device)
                 if len(self._plans) < 256:
                     self._plans[key] = flags
+            if x.requires_grad and out is None:  # features on the autograd graph (the dense hook): differentiable form
+                from ... import functional as _F
+                return _F.flip_batch(x, flags)
             xc = x.contiguous()
             if out is None:
                 out = torch.empty_like(xc)

@@ -196,3 +196,8 @@ class PretrainEncoderEpocher:
         if self.on_master():
             self.meters["reg_loss"].add(reg_loss.detach())
         _meters.flush_batch()
+
+
+class PretrainDecoderEpocher(PretrainEncoderEpocher):
+    """``PretrainDecoderEpocher`` (new_pretrain.py:117-126): the same loop run up to a decoder feature (SURVEY row N3;
+    the only difference in the reference is the assertion on the loaders' transform freedom)."""

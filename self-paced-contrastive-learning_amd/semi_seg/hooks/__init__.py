@@ -1,4 +1,4 @@
-from .infonce import INFONCEHook, SelfPacedINFONCEHook, PScheduler  # noqa: F401
+from .infonce import INFONCEHook, SelfPacedINFONCEHook, PScheduler, get_n_point_coordinate  # noqa: F401
 from .creator import create_infonce_hooks, create_sp_infonce_hooks, feature_until_from_hooks  # noqa: F401
 
 

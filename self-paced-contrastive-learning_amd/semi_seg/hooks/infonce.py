@@ -57,22 +57,23 @@ class INFONCEHook(TrainerHook):
                  data_name: str, contrast_on: str, sync_checks: bool = True, tap_callback=None) -> None:
         super().__init__(hook_name=name)
         assert feature_name in encoder_names + decoder_names, feature_name
-        if feature_name not in encoder_names:
-            raise NotImplementedError("dense (decoder) contrastive hooks are SURVEY row N3: not built")
         self._feature_name, self._weight = feature_name, weight
         self._sync_checks, self._tap_callback = sync_checks, tap_callback
         self._contrast_on, self._data_name = contrast_on, data_name
         self._extractor = SingleFeatureExtractor(model, feature_name=feature_name)
-        self._projector = self.init_projector(input_dim=model.get_channel_dim(feature_name),
-                                              spatial_size=spatial_size or (1, 1))
+        if feature_name in encoder_names:  # :73-76
+            spatial_size = spatial_size or (1, 1)
+        else:
+            spatial_size = spatial_size or (10, 10)
+        self._projector = self.init_projector(input_dim=model.get_channel_dim(feature_name), spatial_size=spatial_size)
         self._criterion = self.init_criterion()
         self._learnable_models = (self._projector,)
 
     # -- pieces a subclass may swap
     @property
-    def projector_class(self):
-        from ...contrastyou.projectors.heads import ProjectionHead
-        return ProjectionHead
+    def projector_class(self):  # :101-106
+        from ...contrastyou.projectors.heads import DenseProjectionHead, ProjectionHead
+        return ProjectionHead if self.is_encoder else DenseProjectionHead
 
     def init_projector(self, *, input_dim, spatial_size):
         return self.projector_class(input_dim=input_dim, hidden_dim=256, output_dim=256, head_type="mlp",
@@ -95,7 +96,8 @@ class INFONCEHook(TrainerHook):
         return get_label(self._contrast_on, self._data_name, partition_group, label_group)
 
     def _new_epoch_hook(self):
-        return self._epoch_hook_class(name=self._hook_name, weight=self._weight, extractor=self._extractor,
+        cls = self._epoch_hook_class if self.is_encoder else self._dense_hook_class  # :83-91
+        return cls(name=self._hook_name, weight=self._weight, extractor=self._extractor,
                                       projector=self._projector, criterion=self._criterion,
                                       label_generator=self._label_generator, tap_callback=self._tap_callback)
 
@@ -109,6 +111,11 @@ class SelfPacedINFONCEHook(INFONCEHook):
     def __init__(self, *, name, model: nn.Module, feature_name: str, weight: float = 1.0, spatial_size=(1, 1),
                  data_name: str, contrast_on: str, mode="soft", p=0.5, begin_value=1e6, end_value=1e6,
                  correct_grad: bool = False, max_epoch: int, sync_checks: bool = True, tap_callback=None) -> None:
+        if feature_name not in encoder_names:
+            # the reference constructs this combination and then fails in the first batch: its __call__ (:133-141) always
+            # hands out the encoder-style epoch hook, which feeds the dense head's [2B, C, h, w] map to the criterion
+            raise NotImplementedError("SelfPacedINFONCEHook on a decoder feature: the reference has no dense self-paced "
+                                      "hook (semi_seg/hooks/infonce.py:133-141); use INFONCEHook")
         # needed by init_criterion, which the base constructor calls
         self._mode, self._correct_grad = mode, correct_grad
         self._p, self._max_epoch = float(p), int(max_epoch)
@@ -224,5 +231,50 @@ class _SPINFONCEEpochHook(_INFONCEEpochHook):
         return loss
 
 
+def get_n_point_coordinate(h, w, n):
+    """:20-22: n distinct rows x n distinct columns, drawn from numpy's global RNG"""
+    import numpy as np
+    return [(x, y) for x, y in zip(np.random.choice(range(h), n, replace=False),
+                                   np.random.choice(range(w), n, replace=False))]
+
+
+class _INFONCEDenseHook(_INFONCEEpochHook):
+    """:201-241: contrast ``point_nums`` pixels per slice of the dense (decoder) projection between the
+    two views -- every sampled point is its own class, its positive is the same point of the other view."""
+    point_nums = 5
+
+    @meter_focus
+    def __call__(self, *, affine_transformer, seed, unlabeled_tf_logits, unlabeled_logits_tf, partition_group,
+                 label_group, **kwargs):
+        n_unl = len(unlabeled_logits_tf)
+        feature = self._extractor.feature()[-n_unl * 2:]
+        first, second = torch.chunk(feature, 2, dim=0)
+        with FixRandomSeed(seed):  # view 1's features get the sample-wise flips view 2's images got (:206-207)
+            first = affine_transformer.apply_batch(first) if hasattr(affine_transformer, "apply_batch") else \
+                torch.stack([affine_transformer(x) for x in first], dim=0)
+        z_first, z_second = torch.chunk(self._projector(torch.cat([first, second.contiguous()], dim=0)), 2)
+        with FixRandomSeed(seed):
+            a = self.region_extractor(z_first, point_nums=self.point_nums)
+        with FixRandomSeed(seed):
+            b = self.region_extractor(z_second, point_nums=self.point_nums)
+        labels = torch.arange(a.shape[0], dtype=torch.float32, device=a.device)
+        loss = self._criterion(a, b, target=labels)
+        self._record(loss)
+        return loss if self._weight == 1 else loss * self._weight
+
+    @staticmethod
+    def region_extractor(normalize_features, point_nums=5):
+        """:228-237: per slice ``point_nums`` pixels (distinct rows, distinct columns) -> [B * point_nums, C]; the draws
+        happen slice by slice in the reference's order, the pixels are fetched by one gather"""
+        h, w = normalize_features.shape[2:]
+        bi, xi, yi = [], [], []
+        for b in range(normalize_features.shape[0]):
+            for x, y in get_n_point_coordinate(n=point_nums, h=h, w=w):
+                bi.append(b), xi.append(int(x)), yi.append(int(y))
+        dev = normalize_features.device
+        return normalize_features[torch.tensor(bi, device=dev), :, torch.tensor(xi, device=dev), torch.tensor(yi, device=dev)]
+
+
 INFONCEHook._epoch_hook_class = _INFONCEEpochHook
+INFONCEHook._dense_hook_class = _INFONCEDenseHook
 SelfPacedINFONCEHook._epoch_hook_class = _SPINFONCEEpochHook

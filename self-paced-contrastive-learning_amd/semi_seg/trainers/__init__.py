@@ -1,2 +1,2 @@
-from .pretrain import PretrainEncoderTrainer, WarmupCosine  # noqa: F401
+from .pretrain import PretrainDecoderTrainer, PretrainEncoderTrainer, WarmupCosine  # noqa: F401
 from .finetune import FineTuneTrainer  # noqa: F401

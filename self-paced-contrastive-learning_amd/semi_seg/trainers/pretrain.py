@@ -15,7 +15,7 @@ from torch import nn
 
 from ... import ddp as _ddp
 from ...optim import FusedRAdam
-from ..epochers.pretrain import PretrainEncoderEpocher
+from ..epochers.pretrain import PretrainDecoderEpocher, PretrainEncoderEpocher
 from ..hooks.creator import feature_until_from_hooks
 
 
@@ -178,8 +178,10 @@ class PretrainEncoderTrainer:
             self._scheduler = WarmupCosine(self._optimizer, max_epoch=self._max_epoch, **self._sched_cfg)
         self.__initialized__ = True
 
+    train_epocher = PretrainEncoderEpocher
+
     def _create_tra_epoch(self):
-        epocher = PretrainEncoderEpocher(model=self._model, optimizer=self._optimizer,
+        epocher = self.train_epocher(model=self._model, optimizer=self._optimizer,
                                          chain_dataloader=self._chain_dataloader, num_batches=self._num_batches,
                                          cur_epoch=self._cur_epoch, device=self._device,
                                          inference_until=self._inference_until or "Conv5", flat_params=self._flat)
@@ -236,3 +238,10 @@ class PretrainEncoderTrainer:
 
     def resume_from_path(self, path):
         self.load_state_dict(torch.load(path, map_location="cpu"))
+
+
+class PretrainDecoderTrainer(PretrainEncoderTrainer):
+    """``PretrainDecoderTrainer`` (new_pretrain.py:107-110), driven by ``main_pretrain_decoder.py:53-71`` with
+    ``forward_until`` = a decoder feature and ``model.set_grad(True, start="Conv5", end=until, include_start=False)``
+    inside ``model.set_grad(False)`` (row N3)."""
+    train_epocher = PretrainDecoderEpocher

@@ -1,0 +1,178 @@
+"""Round-2 additions on the GPU against the reference's golden vectors (tests/golden/g6_round2.npz) and the oracle:
+SupConLoss1(exclude_other_pos=True) (contrast_loss3.py:97-100), ProjectionHead(pool_name="adaptive_max"),
+DenseProjectionHead (projectors/heads.py:96-120), the adaptive pooling kernels, and the dense InfoNCE hook
+(semi_seg/hooks/infonce.py:201-241)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import spcl_oracle as O
+from tests.test_oracle_golden import labels_of
+
+
+def test_exclude_other_pos_golden_and_oracle(golden):
+    import spcl_amd  # noqa
+    from spcl_amd.contrastyou.losses.contrast_loss3 import SupConLoss1
+    g = golden("g6_round2.npz")
+    for key in g["xpos/cases"]:
+        key = str(key)
+        n, d, lname = int(key.split("/")[1].split("_")[0][1:]), int(key.split("_")[1][1:]), key.split("_", 2)[2]
+        z1 = torch.tensor(g[f"xpos/n{n}_d{d}/z1"], device="cuda", requires_grad=True)
+        z2 = torch.tensor(g[f"xpos/n{n}_d{d}/z2"], device="cuda", requires_grad=True)
+        crit = SupConLoss1(temperature=0.07, exclude_other_pos=True)
+        loss = crit(z1, z2, target=labels_of(lname, n))
+        loss.backward()
+        np.testing.assert_allclose(loss.item(), g[f"{key}/loss"], rtol=1e-4, err_msg=key)
+        np.testing.assert_allclose(z1.grad.cpu().numpy(), g[f"{key}/dz1"], rtol=2e-3, atol=1e-5, err_msg=key)
+        np.testing.assert_allclose(z2.grad.cpu().numpy(), g[f"{key}/dz2"], rtol=2e-3, atol=1e-5, err_msg=key)
+        assert crit.pos_mask.shape == (2 * n, 2 * n)  # the taps are still there
+    # larger, against the oracle; SimCLR (no target) and an explicit mask too
+    gen = torch.Generator().manual_seed(5)
+    z1 = torch.nn.functional.normalize(torch.randn(300, 128, generator=gen), dim=1)
+    z2 = torch.nn.functional.normalize(torch.randn(300, 128, generator=gen), dim=1)
+    mask = (torch.arange(300)[:, None] % 7 == torch.arange(300)[None, :] % 7).float()
+    for kw in (dict(target=[i % 5 for i in range(300)]), dict(), dict(mask=mask)):
+        a, b = z1.clone().requires_grad_(True), z2.clone().requires_grad_(True)
+        ref = O.supcon_loss_exclude_other_pos(a, b, kw.get("target"), kw.get("mask"))
+        ref.backward()
+        x, y = z1.cuda().requires_grad_(True), z2.cuda().requires_grad_(True)
+        kwg = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in kw.items()}
+        loss = SupConLoss1(exclude_other_pos=True)(x, y, **kwg)
+        loss.backward()
+        np.testing.assert_allclose(loss.item(), ref.item(), rtol=1e-4)
+        scale = float(a.grad.abs().max())
+        np.testing.assert_allclose(x.grad.cpu().numpy(), a.grad.numpy(), rtol=2e-3, atol=2e-4 * scale)
+    with pytest.raises(AssertionError):  # not unit-norm (contrast_loss3.py:62)
+        SupConLoss1(exclude_other_pos=True)(2 * z1.cuda(), z2.cuda(), target=[i % 5 for i in range(300)])
+
+
+def _load_head(head, g, tag):
+    sd = {k[len(tag) + 7:]: torch.tensor(g[k]) for k in g.files if k.startswith(f"{tag}/param/")}
+    head.load_state_dict(sd, strict=True)
+    return head.cuda()
+
+
+def test_adaptive_max_projection_head_golden(golden):
+    import spcl_amd  # noqa
+    from spcl_amd.contrastyou.projectors.heads import ProjectionHead
+    g = golden("g6_round2.npz")
+    head = _load_head(ProjectionHead(input_dim=32, hidden_dim=24, output_dim=16, head_type="mlp", normalize=True,
+                                     pool_name="adaptive_max"), g, "maxhead")
+    x = torch.tensor(g["maxhead/x"], device="cuda", requires_grad=True)
+    z = head(x)
+    (z * torch.tensor(g["maxhead/r"], device="cuda")).sum().backward()
+    np.testing.assert_allclose(z.detach().cpu().numpy(), g["maxhead/z"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g["maxhead/dx"], rtol=1e-3, atol=1e-6)
+    for k, p in head.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), g[f"maxhead/grad/{k}"], rtol=1e-3, atol=1e-6, err_msg=k)
+    # a spatial size other than (1, 1) constructs, and fails in forward as the reference's Flatten -> Linear does
+    bad = ProjectionHead(input_dim=32, output_dim=16, head_type="mlp", normalize=True, spatial_size=(2, 2)).cuda()
+    with pytest.raises(RuntimeError):
+        bad(x)
+
+
+@pytest.mark.parametrize("tag,kw", [("dense_mlp", dict(head_type="mlp", pool_name="adaptive_avg", spatial_size=(5, 4))),
+                                    ("dense_lin", dict(head_type="linear", pool_name="adaptive_max", spatial_size=(3, 3)))])
+def test_dense_projection_head_golden(golden, tag, kw):
+    import spcl_amd  # noqa
+    from spcl_amd.contrastyou.projectors.heads import DenseProjectionHead
+    g = golden("g6_round2.npz")
+    head = _load_head(DenseProjectionHead(input_dim=16, hidden_dim=24, output_dim=12, normalize=True, **kw), g, tag)
+    assert sorted(head.state_dict()) == sorted(k[len(tag) + 7:] for k in g.files if k.startswith(f"{tag}/param/"))
+    x = torch.tensor(g[f"{tag}/x"], device="cuda", requires_grad=True)
+    z = head(x)
+    assert tuple(z.shape) == g[f"{tag}/z"].shape
+    (z * torch.tensor(g[f"{tag}/r"], device="cuda")).sum().backward()
+    np.testing.assert_allclose(z.detach().cpu().numpy(), g[f"{tag}/z"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g[f"{tag}/dx"], rtol=1e-3, atol=2e-6)
+    for k, p in head.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), g[f"{tag}/grad/{k}"], rtol=1e-3, atol=2e-6, err_msg=k)
+
+
+@pytest.mark.parametrize("mode", ["avg", "max"])
+@pytest.mark.parametrize("shape,out", [((2, 16, 14, 11), (5, 4)), ((1, 48, 7, 7), (10, 10)), ((3, 32, 28, 28), (1, 1)),
+                                       ((2, 64, 9, 13), (9, 13))])
+def test_adaptive_pool_vs_oracle_bf16_and_f32(mode, shape, out):
+    import spcl_amd  # noqa
+    from spcl_amd import functional as F_
+    gen = torch.Generator().manual_seed(sum(shape))
+    for dt in (torch.float32, torch.bfloat16):
+        x = torch.randn(*shape, generator=gen).to(dt).float()
+        xr = x.clone().requires_grad_(True)
+        ref = O.adaptive_pool2d(xr, out, mode)
+        r = torch.randn(ref.shape, generator=gen)
+        (ref * r).sum().backward()
+        xg = x.to(dt).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        got = F_.adaptive_pool2d(xg, out, mode)
+        (got * r.cuda()).sum().backward()
+        np.testing.assert_allclose(got.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-6)
+        tol = 1e-6 if dt == torch.float32 else 8e-3
+        np.testing.assert_allclose(xg.grad.float().cpu().numpy(), xr.grad.numpy(), rtol=tol, atol=tol)
+
+
+def test_dense_infonce_hook_step_vs_oracle_fp32():
+    """INFONCEHook on a decoder feature (Up_conv3): encoder + decoder forward, dense head, 5 points per slice drawn under
+    FixRandomSeed, SupConLoss1 with every point its own class -- loss and the decoder / head gradients against the oracle
+    (the encoder is frozen, as main_pretrain_decoder.py:66-69 arranges)."""
+    import spcl_amd  # noqa
+    from spcl_amd import ddp
+    from spcl_amd.semi_seg.arch import UNet
+    from spcl_amd.semi_seg.epochers import PretrainDecoderEpocher
+    from spcl_amd.semi_seg.hooks import create_infonce_hooks, feature_until_from_hooks
+    from spcl_amd.synthetic import acdc_like_meta
+    mc, bs, size, seed = 128, 4, 32, 13
+    net = UNet(input_dim=1, num_classes=4, max_channel=mc)
+    sd = O.init_unet_state(1, 4, mc, seed=23)
+    net.load_state_dict(sd, strict=True)
+    net.cuda().train()
+    hook = create_infonce_hooks(model=net, feature_names="Up_conv3", weights=0.5, contrast_ons="partition",
+                                data_name="acdc").cuda()
+    assert feature_until_from_hooks(hook) == "Up_conv3"
+    head = hook._hooks[0]._projector
+    assert type(head).__name__ == "DenseProjectionHead" and tuple(head._spatial_size) == (10, 10)
+    psd = {k: v.detach().cpu().clone() for k, v in head.state_dict().items()}
+    with net.set_grad(False):
+        with net.set_grad(True, start="Conv5", end="Up_conv3", include_start=False):
+            params = [p for p in net.parameters() if p.requires_grad] + list(hook.parameters())
+            flat = ddp.FlatParams(params)
+            g = torch.Generator().manual_seed(3)
+            img, img_tf = torch.rand(bs, 1, size, size, generator=g), torch.rand(bs, 1, size, size, generator=g)
+            filenames, partitions, groups = acdc_like_meta(bs)
+            tgt = torch.zeros(bs, 1, 1, 1, dtype=torch.long).cuda()
+            batch = ((img.cuda(), img_tf.cuda(), tgt, tgt), filenames, (partitions, groups))
+            ep = PretrainDecoderEpocher(model=net, optimizer=torch.optim.SGD([flat.param], lr=0.0),
+                                        chain_dataloader=iter([]), num_batches=1, device="cuda",
+                                        inference_until="Up_conv3", flat_params=flat)
+            ep.add_hooks([hook()])
+            with ep.meters.focus_on(ep.meter_focus):
+                loss = ep.step_compute(batch, seed=seed)
+    # ---- oracle
+    flips = O.random_flip_decisions(seed, bs)
+    x2 = O.apply_flips(img_tf, flips)
+    osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+           for k, v in sd.items()}
+    feat = O.unet_forward(torch.cat([img, x2], 0), osd, "Up_conv3", train=True, momentum=0.1)
+    opsd = {k: v.clone().requires_grad_(True) for k, v in psd.items()}
+    f1 = O.apply_flips(feat[:bs], flips)
+    z = O.dense_projector_forward(torch.cat([f1, feat[bs:]], 0), opsd, head_type="mlp", normalize=True,
+                                  pool_name="adaptive_avg", spatial_size=(10, 10))
+    pts = O.dense_region_points(seed, bs, 10, 10, 5)
+    sel = lambda zz: torch.cat([torch.stack([zz[b][:, x, y] for x, y in pts[b]]) for b in range(bs)])  # noqa: E731
+    a, b = sel(z[:bs]), sel(z[bs:])
+    ref = 0.5 * O.supcon_loss(a, b, list(range(a.shape[0])))["loss"]
+    ref.backward()
+    np.testing.assert_allclose(float(loss.detach()), float(ref.detach()), rtol=2e-4)
+    rel = lambda u, v: float(np.abs(u - v).max() / max(1e-30, np.abs(v).max()))  # noqa: E731
+    checked = 0
+    for k, p in net.named_parameters():
+        if k.startswith(("_Up5", "_Up_conv5", "_Up4", "_Up_conv4", "_Up3", "_Up_conv3")):
+            assert p.grad is not None and osd[k].grad is not None, k
+            assert rel(p.grad.cpu().numpy(), osd[k].grad.numpy()) < 5e-3, (k, rel(p.grad.cpu().numpy(), osd[k].grad.numpy()))
+            checked += 1
+        elif k.startswith("_Conv"):
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k  # frozen encoder
+    assert checked >= 18
+    for k, p in head.named_parameters():
+        assert rel(p.grad.cpu().numpy(), opsd[k].grad.numpy()) < 5e-3, k

@@ -284,3 +284,38 @@ def test_dice_counts_and_universal_dice_known_answers():
                                rtol=1e-6)
     mean2, _ = O.universal_dice(i, u, ["a", "b"])  # slice-wise groups: an empty class scores 1 (1e-6 / 1e-6)
     np.testing.assert_allclose(float(mean2[1]), 0.5 * ((2 + 1e-6) / (3 + 1e-6) + 1.0), rtol=1e-6)
+
+
+def test_round2_golden_heads_and_exclude_other_pos(golden):
+    """g6 (written from the reference by tools/gen_golden.py round2): SupConLoss1(exclude_other_pos=True), the
+    adaptive-max pooled ProjectionHead and DenseProjectionHead -- the oracle's restatements reproduce them."""
+    g = golden("g6_round2.npz")
+    for key in g["xpos/cases"]:
+        key = str(key)
+        n, d, lname = key.split("/")[1].split("_")[0][1:], key.split("_")[1][1:], key.split("_", 2)[2]
+        n, d = int(n), int(d)
+        z1 = torch.tensor(g[f"xpos/n{n}_d{d}/z1"], requires_grad=True)
+        z2 = torch.tensor(g[f"xpos/n{n}_d{d}/z2"], requires_grad=True)
+        loss = O.supcon_loss_exclude_other_pos(z1, z2, labels_of(lname, n))
+        loss.backward()
+        np.testing.assert_allclose(loss.item(), g[f"{key}/loss"], rtol=2e-5, err_msg=key)
+        np.testing.assert_allclose(z1.grad.numpy(), g[f"{key}/dz1"], rtol=2e-3, atol=2e-6, err_msg=key)
+        np.testing.assert_allclose(z2.grad.numpy(), g[f"{key}/dz2"], rtol=2e-3, atol=2e-6, err_msg=key)
+    x = torch.tensor(g["maxhead/x"], requires_grad=True)
+    params = {k[len("maxhead/param/"):]: torch.tensor(g[k], requires_grad=True) for k in g.files
+              if k.startswith("maxhead/param/")}
+    z = O.projector_forward(x, params, pool_name="adaptive_max")
+    (z * torch.tensor(g["maxhead/r"])).sum().backward()
+    np.testing.assert_allclose(z.detach().numpy(), g["maxhead/z"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(x.grad.numpy(), g["maxhead/dx"], rtol=1e-4, atol=1e-6)
+    for tag, kw in {"dense_mlp": dict(head_type="mlp", pool_name="adaptive_avg", spatial_size=(5, 4)),
+                    "dense_lin": dict(head_type="linear", pool_name="adaptive_max", spatial_size=(3, 3))}.items():
+        x = torch.tensor(g[f"{tag}/x"], requires_grad=True)
+        params = {k[len(tag) + 7:]: torch.tensor(g[k], requires_grad=True) for k in g.files
+                  if k.startswith(f"{tag}/param/")}
+        z = O.dense_projector_forward(x, params, **kw)
+        (z * torch.tensor(g[f"{tag}/r"])).sum().backward()
+        np.testing.assert_allclose(z.detach().numpy(), g[f"{tag}/z"], rtol=1e-5, atol=1e-6, err_msg=tag)
+        np.testing.assert_allclose(x.grad.numpy(), g[f"{tag}/dx"], rtol=1e-4, atol=1e-6, err_msg=tag)
+        for k, p in params.items():
+            np.testing.assert_allclose(p.grad.numpy(), g[f"{tag}/grad/{k}"], rtol=1e-4, atol=1e-6, err_msg=(tag, k))

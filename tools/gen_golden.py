@@ -291,15 +291,62 @@ def gen_decoder(UNet):
     print("g5_decoder done")
 
 
+def gen_round2(SupConLoss1):
+    """round 2 additions: SupConLoss1(exclude_other_pos=True), ProjectionHead(pool_name="adaptive_max"),
+    DenseProjectionHead (contrastyou/projectors/heads.py:96-120)"""
+    from contrastyou.projectors.heads import ProjectionHead, DenseProjectionHead
+    out = {}
+    cases = []
+    for (n, d) in [(4, 16), (8, 256), (30, 256)]:
+        z1, z2 = unit_rows(n, d, 100 + n), unit_rows(n, d, 200 + n)
+        for lname, labels in label_sets(n).items():
+            key = f"xpos/n{n}_d{d}_{lname}"
+            a, b = z1.clone().requires_grad_(True), z2.clone().requires_grad_(True)
+            crit = SupConLoss1(temperature=0.07, exclude_other_pos=True)
+            loss = crit(a, b, target=labels)
+            loss.backward()
+            out[f"{key}/loss"], out[f"{key}/dz1"], out[f"{key}/dz2"] = loss.detach().numpy(), a.grad.numpy(), b.grad.numpy()
+            cases.append(key)
+        out[f"xpos/n{n}_d{d}/z1"], out[f"xpos/n{n}_d{d}/z2"] = z1.numpy(), z2.numpy()
+    out["xpos/cases"] = np.array(cases)
+    g = torch.Generator().manual_seed(77)
+    # adaptive-max pooled head
+    head = ProjectionHead(input_dim=32, hidden_dim=24, output_dim=16, head_type="mlp", normalize=True,
+                          pool_name="adaptive_max")
+    x = torch.randn(5, 32, 7, 9, generator=g, requires_grad=True)
+    r = torch.randn(5, 16, generator=g)
+    z = head(x)
+    (z * r).sum().backward()
+    out["maxhead/x"], out["maxhead/r"], out["maxhead/z"], out["maxhead/dx"] = x.detach().numpy(), r.numpy(), z.detach().numpy(), x.grad.numpy()
+    for k, p in head.named_parameters():
+        out[f"maxhead/param/{k}"], out[f"maxhead/grad/{k}"] = p.detach().numpy(), p.grad.numpy()
+    # dense heads: mlp with avg pooling to (5, 4) from 14 x 11 (overlapping, uneven windows), linear with max pooling
+    for tag, kw in {"dense_mlp": dict(head_type="mlp", pool_name="adaptive_avg", spatial_size=(5, 4), hidden_dim=24),
+                    "dense_lin": dict(head_type="linear", pool_name="adaptive_max", spatial_size=(3, 3), hidden_dim=24)}.items():
+        head = DenseProjectionHead(input_dim=16, output_dim=12, normalize=True, **kw)
+        x = torch.randn(3, 16, 14, 11, generator=g, requires_grad=True)
+        z = head(x)
+        r = torch.randn(z.shape, generator=g)
+        (z * r).sum().backward()
+        out[f"{tag}/x"], out[f"{tag}/r"], out[f"{tag}/z"], out[f"{tag}/dx"] = x.detach().numpy(), r.numpy(), z.detach().numpy(), x.grad.numpy()
+        for k, p in head.named_parameters():
+            out[f"{tag}/param/{k}"], out[f"{tag}/grad/{k}"] = p.detach().numpy(), p.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "g6_round2.npz"), **out)
+    print("g6_round2:", len(cases), "xpos cases + 3 heads")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     SupConLoss1, SelfPacedSupConLoss, ProjectionHead, UNet, SFE = _import_reference()
+    if sys.argv[1:] == ["round2"]:  # only the round-2 additions (the others are unchanged)
+        return gen_round2(SupConLoss1)
     gen_loss(SupConLoss1, SelfPacedSupConLoss)
     gen_projector(ProjectionHead)
     gen_encoder(UNet)
     gen_step(UNet, ProjectionHead, SelfPacedSupConLoss, SFE)
     gen_decoder(UNet)
+    gen_round2(SupConLoss1)
 
 
 if __name__ == "__main__":
