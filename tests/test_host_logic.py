@@ -116,8 +116,17 @@ def test_hook_factories_and_feature_until():
     h2 = create_infonce_hooks(model=model, feature_names="Conv4", weights=1.0, contrast_ons="self")
     assert feature_until_from_hooks(h2) == "Conv4"
     assert h2._hooks[0]._projector._header[2].in_features == 128
+    # decoder feature: the dense head with its default (10, 10) pooling (hooks/infonce.py:73-76,101-106) ...
+    h3 = create_infonce_hooks(model=model, feature_names="Up_conv3", weights=1.0, contrast_ons="self")
+    assert feature_until_from_hooks(h3) == "Up_conv3"
+    assert type(h3._hooks[0]._projector).__name__ == "DenseProjectionHead"
+    assert tuple(h3._hooks[0]._projector._spatial_size) == (10, 10)
+    assert "_hooks.0._projector._projector.0.weight" in h3.state_dict() and type(h3()).__name__ == "_INFONCEDenseHook"
+    assert feature_until_from_hooks(h2, h3) == "Up_conv3"
+    # ... which has no self-paced form in the reference (its SP hook always hands out the encoder-style epoch hook)
     with pytest.raises(NotImplementedError):
-        create_infonce_hooks(model=model, feature_names="Up_conv3", weights=1.0, contrast_ons="self")
+        create_sp_infonce_hooks(model=model, feature_names="Up_conv3", weights=1.0, contrast_ons="self", begin_values=3,
+                                end_values=70, mode="soft", max_epoch=80)
 
 
 def test_unet_state_dict_keys_are_the_reference_keys():
