@@ -121,7 +121,7 @@ def test_hook_factories_and_feature_until():
     assert feature_until_from_hooks(h3) == "Up_conv3"
     assert type(h3._hooks[0]._projector).__name__ == "DenseProjectionHead"
     assert tuple(h3._hooks[0]._projector._spatial_size) == (10, 10)
-    assert "_hooks.0._projector._projector.0.weight" in h3.state_dict() and type(h3()).__name__ == "_INFONCEDenseHook"
+    assert "_hooks.0._projector._projector.0.weight" in h3.state_dict() and type(h3._hooks[0]()).__name__ == "_INFONCEDenseHook"
     assert feature_until_from_hooks(h2, h3) == "Up_conv3"
     # ... which has no self-paced form in the reference (its SP hook always hands out the encoder-style epoch hook)
     with pytest.raises(NotImplementedError):
