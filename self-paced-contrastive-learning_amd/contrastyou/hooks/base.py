@@ -91,6 +91,17 @@ def _silent_phase(self, **kwargs):
 class CombineEpochHook(EpocherHook):
     def __init__(self, *epocher_hook: EpocherHook) -> None:
         self._epocher_hook = tuple(epocher_hook)
+        # hooks that pool the SAME tapped feature to (1, 1) share one pooling pass (and one feature gradient): see
+        # semi_seg/hooks/infonce.py `_two_views` (several meta-labels on one encoder pass)
+        groups = {}
+        for h in self._epocher_hook:
+            key = getattr(h, "shared_pool_key", None)
+            if key is not None:
+                groups.setdefault(key, []).append(h)
+        for members in groups.values():
+            if len(members) > 1:
+                for h in members:
+                    h._share_pool = True
 
     def _broadcast(self, method, *args, **kwargs):
         return [getattr(hook, method)(*args, **kwargs) for hook in self._epocher_hook]

@@ -12,6 +12,7 @@ from typing import List
 import torch
 from torch import nn
 
+from ... import functional as F_hip
 from ...contrastyou.hooks.base import EpocherHook, TrainerHook
 from ...contrastyou.losses.contrast_loss3 import SelfPacedSupConLoss, SupConLoss1
 from ...contrastyou.meters import AverageValueMeter
@@ -150,6 +151,16 @@ class _INFONCEEpochHook(EpocherHook):
         self._extractor.bind()
         self._n = 0             # batches seen this epoch
         self._label_cache = {}  # batch composition -> device label tensor
+        self._share_pool = False  # set by CombineEpochHook when several hooks pool the same feature
+
+    @property
+    def shared_pool_key(self):
+        """hooks with equal keys average-pool the same tensor to (1, 1): they can share the pooled rows"""
+        p = self._projector
+        if type(p).__name__ != "ProjectionHead" or tuple(getattr(p, "_spatial_size", ())) != (1, 1) \
+                or getattr(p, "_pool_name", None) != "adaptive_avg":
+            return None
+        return (id(self._extractor._model), self._extractor._feature_name)
 
     @meter_focus
     def configure_meters(self, meters):
@@ -184,6 +195,18 @@ class _INFONCEEpochHook(EpocherHook):
         if feature.shape[0] != 2 * n_unl:  # a slice costs a zero-fill + strided copy in backward: only when needed
             feature = feature[-2 * n_unl:]
         if tuple(getattr(self._projector, "_spatial_size", (1, 1))) == (1, 1):
+            if self._share_pool:
+                # K hooks on one feature (run_self_paced_acdc:61-70 / hooks/creator.py:102-124): pool ONCE -- the K
+                # projectors then read [2n, C] rows and autograd adds K [2n, C] gradients before ONE pooling backward,
+                # instead of K passes over the feature map forward and K full-size gradients + K - 1 adds backward
+                pooled = getattr(feature, "_spcl_pooled", None)
+                if pooled is None:
+                    pooled = F_hip.adaptive_pool2d(feature, (1, 1), "avg")
+                    try:
+                        feature._spcl_pooled = pooled  # lives as long as the tapped tensor (this step)
+                    except AttributeError:
+                        pass
+                return pooled
             return feature
         first, second = torch.chunk(feature, 2, dim=0)
         with FixRandomSeed(seed):

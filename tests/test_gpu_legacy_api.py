@@ -1,0 +1,121 @@
+"""SURVEY row N4, second half: the OLD ``init()``-driven pre-train API (semi_seg/epochers/comparable.py:250-450,
+semi_seg/epochers/_mixins.py:181-274, semi_seg/utils.py:55-117) on the HIP kernels, and the shared pooling pass of
+several hooks on one feature."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import spcl_oracle as O
+
+
+def _relmax(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(1e-30, np.abs(b).max())
+
+
+def test_old_api_epocher_init_run_vs_oracle_fp32():
+    import spcl_amd  # noqa
+    from spcl_amd import ddp
+    from spcl_amd.contrastyou.losses.contrast_loss3 import SelfPacedSupConLoss, SupConLoss1
+    from spcl_amd.semi_seg.arch import UNet
+    from spcl_amd.semi_seg.epochers import ContrastiveProjectorWrapper, InfoNCEPretrainEpocher
+    from spcl_amd.synthetic import acdc_like_meta
+    mc, bs = 128, 12
+    net = UNet(input_dim=1, num_classes=4, max_channel=mc)
+    sd = O.init_unet_state(1, 4, mc, seed=9)
+    net.load_state_dict(sd, strict=True)
+    net.cuda().train()
+    # trainers/trainer.py:150-165: ProjectorParams.GlobalParams -> wrapper, LossParams -> one criterion per global feature
+    wrapper = ContrastiveProjectorWrapper(max_channel=mc)
+    wrapper.register_global_projector(feature_names=["Conv5", "Conv5", "Conv4"], head_type=["mlp", "linear", "mlp"],
+                                      output_dim=[64, 32, 64], normalize=True, pool_name="adaptive_avg")
+    wrapper.cuda()
+    assert list(wrapper._projectors.keys()) == ["0|Conv5", "1|Conv5", "2|Conv4"] and wrapper.feature_names[2] == "Conv4"
+    crits = [SelfPacedSupConLoss(weight_update="soft", correct_grad=True), SupConLoss1(), SupConLoss1()]
+    crits[0].set_gamma(9.0)
+    heads = [{k: v.detach().cpu().clone() for k, v in p.state_dict().items()} for p in wrapper]
+    for name in net.decoder_names:
+        getattr(net, "_" + name).requires_grad_(False)
+    flat = ddp.FlatParams([p for p in net.parameters() if p.requires_grad] + list(wrapper.parameters()))
+    g = torch.Generator().manual_seed(4)
+    img, img_tf = torch.rand(bs, 1, 32, 32, generator=g), torch.rand(bs, 1, 32, 32, generator=g)
+    filenames, partitions, groups = acdc_like_meta(bs)
+    tgt = torch.zeros(bs, 1, 1, 1, dtype=torch.long).cuda()
+    batch = ((img.cuda(), img_tf.cuda(), tgt, tgt), filenames, (partitions, groups))
+    ep = InfoNCEPretrainEpocher(model=net, optimizer=torch.optim.SGD([flat.param], lr=0.0), chain_dataloader=[batch],
+                                num_batches=1, device="cuda", flat_params=flat,
+                                feature_names=["Conv5", "Conv5", "Conv4"], feature_importance=[1.0, 0.5, 0.25],
+                                data_name="acdc")
+    with pytest.raises(RuntimeError):  # comparable.py:287-290
+        ep.run()
+    with pytest.raises(AssertionError):  # comparable.py:259
+        ep.init(reg_weight=1.0)
+    ep.init(reg_weight=2.0, projectors_wrapper=wrapper, infoNCE_criterion=crits)
+    ep.set_global_contrast_method(contrast_on_list=["partition", "patient", "self"])
+    stats = ep.run()
+    # ---- oracle: NO image flip on this path (_mixins.py:225-260); Conv4 is tapped on the way to Conv5
+    osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+           for k, v in sd.items()}
+    x = torch.cat([img, img_tf], 0)
+    f4 = O.encoder_forward(x, osd, "Conv4", train=True, momentum=0.1)
+    osd2 = {k: (v if not k.endswith(("running_mean", "running_var", "num_batches_tracked")) else sd[k].clone())
+            for k, v in osd.items()}
+    f5 = O.encoder_forward(x, osd2, "Conv5", train=True, momentum=0.1)
+    feats = [f5, f5, f4]
+    kinds = [("mlp", "partition", dict(gamma=9.0, mode="soft", correct_grad=True)), ("linear", "patient", {}),
+             ("mlp", "self", {})]
+    losses, leaves = [], []
+    for f, psd, (ht, on, kw) in zip(feats, heads, kinds):
+        psd = {k: v.clone().requires_grad_(True) for k, v in psd.items()}
+        z = O.projector_forward(f, psd, head_type=ht)
+        labels = O.get_label(on, "acdc", partitions, groups)
+        # old path: criterion(proj_feature_tf, proj_tf_feature): the FIRST view's rows come first (comparable.py:449-450)
+        losses.append(O.supcon_loss(z[:bs], z[bs:], labels, **kw)["loss"])
+        leaves.append(psd)
+    w = [1.0, 0.5, 0.25]
+    reg = sum(l * wi for l, wi in zip(losses, w)) / (sum(w) + 1e-16)
+    (2.0 * reg).backward()
+    np.testing.assert_allclose(stats["semi"]["reg_loss"]["mean"], float(reg.detach()), rtol=2e-4)
+    np.testing.assert_allclose(stats["semi"]["mi"]["mean"], -float(reg.detach()), rtol=2e-4)
+    np.testing.assert_allclose(stats["semi"]["mi_Conv4|2"]["mean"], -float(losses[2].detach()), rtol=2e-4)
+    for k, p in net.named_parameters():
+        if p.requires_grad and osd[k].grad is not None:
+            assert _relmax(p.grad.cpu().numpy(), osd[k].grad.numpy()) < 5e-3, k
+    for hi, proj in enumerate(wrapper):
+        for k, p in proj.named_parameters():
+            assert _relmax(p.grad.cpu().numpy(), leaves[hi][k].grad.numpy()) < 5e-3, (hi, k)
+
+
+def test_combined_hooks_share_the_pooling_pass():
+    """three hooks on Conv5 inside one CombineTrainerHook pool the tapped feature ONCE (the projectors read [2n, C] rows);
+    loss and gradients equal those of the per-hook pooling (fp32 summation order of the pooled gradient aside)."""
+    import spcl_amd  # noqa
+    from spcl_amd.semi_seg.hooks import create_sp_infonce_hooks
+    from tests.test_gpu_configs import _step
+
+    def run(share):
+        import spcl_amd.contrastyou.hooks.base as B
+        orig = B.CombineEpochHook.__init__
+        if not share:
+            def no_share(self, *hooks):
+                self._epocher_hook = tuple(hooks)
+            B.CombineEpochHook.__init__ = no_share
+        try:
+            torch.manual_seed(0)  # same projector initialisation in both runs
+            r = _step(64, 6, torch.float32, ["partition", "patient", "self"], [1.0, 0.5, 0.25], 8.0, "prostate",
+                      mc=128, partition_num=3)
+        finally:
+            B.CombineEpochHook.__init__ = orig
+        grads = {k: p.grad.clone() for k, p in r["net"].named_parameters() if p.grad is not None}
+        for hi, h in enumerate(r["hook"]._hooks):
+            grads.update({f"h{hi}.{k}": p.grad.clone() for k, p in h._projector.named_parameters()})
+        return r["loss"], grads
+
+    l1, g1 = run(True)
+    l0, g0 = run(False)
+    np.testing.assert_allclose(l1, l0, rtol=1e-6)
+    assert g1.keys() == g0.keys() and len(g1) >= 30 + 12
+    for k in g0:
+        assert _relmax(g1[k].cpu().numpy(), g0[k].cpu().numpy()) < 1e-4, k
