@@ -83,6 +83,7 @@ struct SupconArgs {
   int sp_mode;
   unsigned long long* stamps;  // debug (SPCL_SUPCON_STAMPS=1): s_memtime ticks of wave 0 per phase, else null
   int ns;  // n-tile sub-splits of a 64-column tile (1, 2 or 4): blockIdx.y = column split * ns + sub-split
+  int dbg = 0;  // experiments only (SPCL_SUPCON_DBG): 1 no logit stores, 2 no exponentials, 4 no MFMAs
 };
 
 // ------------------------------------------------------------------------------------------------ prep
@@ -613,20 +614,181 @@ __global__ __launch_bounds__(256) void supcon_logits_kernel(SupconArgs a, const 
       const int J0 = jt * 64 + nt * 32, j = J0 + n32;
       // wave-uniform: does this 32 x 32 tile touch the diagonal or the column padding?
       const bool edge = (I0 < J0 + 32 && J0 < I0 + 32) || J0 + 32 > a.N2;
-      float* dst = Lmat + (size_t)I0 * a.N2p + j;
+      // The logits are SYMMETRIC, so the tile is stored TRANSPOSED: lane (column j, rows i = I0 + 8q + 4kh .. +3) writes
+      // its four consecutive rows as ONE 16-byte store into row j of the matrix -- 4 store instructions of 1 KiB per
+      // tile instead of 16 of 256 B (dword stores are store-issue-bound: 6x the time per byte of dwordx4 stores).  The four q
+      // of a lane pair fill whole 128-byte lines of row j in L2.
+      float* dst = Lmat + (size_t)j * a.N2p + I0 + 4 * kh;
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int ri = 8 * (v >> 2) + 4 * kh + (v & 3);  // row slot of c[v]
-        const float lg = fmaf(c[v], inv_t, -m);          // logit = c/t - m
-        float e = __builtin_amdgcn_exp2f(fmaf(c[v], k2, -m2));  // exp(logit)
-        if (edge) e = (j == I0 + ri || j >= a.N2) ? 0.f : e;
-        D[v] += e;
-        dst[(size_t)ri * a.N2p] = lg;
+      for (int q = 0; q < 4; ++q) {
+        f32x4 lg4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int v = 4 * q + r;
+          const int ri = 8 * q + 4 * kh + r;                 // row slot of c[v]
+          lg4[r] = fmaf(c[v], inv_t, -m);                    // logit = c/t - m
+          float e = __builtin_amdgcn_exp2f(fmaf(c[v], k2, -m2));  // exp(logit)
+          if (edge) e = (j == I0 + ri || j >= a.N2) ? 0.f : e;
+          D[v] += e;
+        }
+        *(f32x4*)(dst + 8 * q) = lg4;
       }
     }
     SUPCON_STAMP(3)  // MFMA + epilogue issue of both n-tiles
   }
   // D[v] of lane l = partial sum of row I0 + 8 (v / 4) + 4 kh + v % 4 over this lane's columns: fold the 32 lanes
+#pragma unroll
+  for (int v = 0; v < 16; ++v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) D[v] += __shfl_xor(D[v], o, 64);
+  }
+  if (n32 == 0) {
+#pragma unroll
+    for (int v = 0; v < 16; ++v)
+      a.partA[(size_t)blockIdx.y * a.N2p + I0 + 8 * (v >> 2) + 4 * kh + (v & 3)] = D[v];
+  }
+  SUPCON_STAMP(4)  // row-sum fold
+  if (stamp) {
+    unsigned long long* o = a.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 6;
+    for (int k = 0; k < 6; ++k) o[k] = tk[k];
+  }
+#undef SUPCON_STAMP
+}
+
+// ---- second generation of the logits kernel (round 2).  Same arithmetic and outputs as supcon_logits_kernel; what
+// changed is the data movement: a workgroup is 8 waves = 256 rows (A operands in registers), the 64-row J tiles (both bf16
+// splits, 32 KB at d = 128) arrive by LDS-DMA into a ring of three images two tiles ahead of the MFMAs -- no register
+// staging, no LDS commit pass, ONE barrier per tile -- and the source addresses carry the chunk swizzle (the DMA writes
+// lane-linear).  In-kernel stamps of the first version showed 30 % of a workgroup's life in its preamble and 20 % in
+// barrier + commit; the MFMAs themselves are 6 us of the chip's time at this size.
+__device__ __forceinline__ void supcon_dma16(const void* src, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(src), "s"(lds_dst)
+               : "memory");
+}
+
+template <int DP>
+__global__ __launch_bounds__(512) void supcon_logits2_kernel(SupconArgs a, const bf16_t* __restrict__ Ph,
+                                                            const bf16_t* __restrict__ Pm, float* __restrict__ Lmat) {
+  constexpr int CPR = DP / 8, KS = DP / 16;
+  constexpr int TILE_BYTES = 2 * 64 * DP * 2;      // both splits of a 64-row J tile
+  constexpr int GROUPS = TILE_BYTES / 1024;        // 1 KiB DMA pieces per tile
+  constexpr int GPW = GROUPS / 8;                  // per wave
+  constexpr int RPG = 1024 / (DP * 2);             // rows per piece
+  static_assert(GROUPS % 8 == 0, "tile pieces must divide over the 8 waves");
+  extern __shared__ __attribute__((aligned(1024))) float lds_raw[];
+  const unsigned lds_base = (unsigned)(uintptr_t)(float __attribute__((address_space(3)))*)lds_raw;
+  __shared__ float red[8];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n32 = lane & 31, kh = lane >> 5;
+  const int I0 = blockIdx.x * 256 + wave * 32;
+  const float inv_t = 1.f / a.t;
+  const int ntiles = a.N2p / 64;
+  const int nmine = (ntiles - (int)blockIdx.y + (int)gridDim.y - 1) / (int)gridDim.y;  // tiles blockIdx.y, + gridDim.y ..
+
+  // one DMA piece = RPG rows x (DP * 2) bytes of one split; lane -> (row in piece, chunk position), source chunk swizzled
+  const int prow = lane / CPR, pcp = lane % CPR;
+  auto issue = [&](int k) {  // k-th tile of this workgroup -> ring slot k % 3
+    const int jt = blockIdx.y + k * gridDim.y;
+    const unsigned slot = lds_base + (unsigned)((k % 3) * TILE_BYTES);
+#pragma unroll
+    for (int u = 0; u < GPW; ++u) {
+      const int gidx = wave * GPW + u;                 // piece of the tile
+      const int sp = gidx / (GROUPS / 2), gr = gidx % (GROUPS / 2);
+      const int row = gr * RPG + prow;
+      const bf16_t* src = (sp ? Pm : Ph) + (size_t)(jt * 64 + row) * DP + ((pcp ^ big_swz<DP>(row)) * 8);
+      supcon_dma16(src, __builtin_amdgcn_readfirstlane(slot + gidx * 1024));
+    }
+  };
+  const bool stamp = a.stamps != nullptr && threadIdx.x == 0;
+  unsigned long long tk[6] = {0, 0, 0, 0, 0, 0}, t0 = stamp ? __builtin_amdgcn_s_memtime() : 0, t1;
+#define SUPCON_STAMP(k)                                   \
+  if (stamp) {                                            \
+    t1 = __builtin_amdgcn_s_memtime();                    \
+    tk[k] += t1 - t0;                                     \
+    t0 = t1;                                              \
+  }
+  if (nmine > 0) issue(0);
+  if (nmine > 1) issue(1);
+  bf16x8v ah[KS], am[KS];  // this wave's rows: lane -> row I0 + n32, k = 16 ks + 8 kh ..
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    ah[ks] = *(const bf16x8v*)(Ph + (size_t)(I0 + n32) * DP + 16 * ks + 8 * kh);
+    am[ks] = *(const bf16x8v*)(Pm + (size_t)(I0 + n32) * DP + 16 * ks + 8 * kh);
+  }
+  // max logit (its loads overlap the transfers above)
+  float mv = 0.f;
+  {
+    const int n4 = a.N2 & ~3;
+    for (int i = threadIdx.x * 4; i < n4; i += 512 * 4) {
+      const f32x4 r = *(const f32x4*)(a.rn2 + i);
+      mv = fmaxf(mv, fmaxf(fmaxf(r[0], r[1]), fmaxf(r[2], r[3])));
+    }
+    if ((int)threadIdx.x < a.N2 - n4) mv = fmaxf(mv, a.rn2[n4 + threadIdx.x]);
+    mv = wave_max(mv / a.t);
+    if (lane == 0) red[wave] = mv;
+  }
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(ah[ks]), "v"(am[ks]));
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GPW) : "memory");  // tile 0 has landed (tile 1 may still be on its way)
+  __syncthreads();
+  float m = red[0];
+#pragma unroll
+  for (int w = 1; w < 8; ++w) m = fmaxf(m, red[w]);
+  const float k2 = inv_t * 1.44269504088896340736f, m2 = m * 1.44269504088896340736f;
+  float D[16];
+#pragma unroll
+  for (int v = 0; v < 16; ++v) D[v] = 0.f;
+  SUPCON_STAMP(0)  // preamble: operands, max logit, first tile
+  for (int k = 0; k < nmine; ++k) {
+    const int jt = blockIdx.y + k * gridDim.y;
+    if (k + 2 < nmine) issue(k + 2);
+    SUPCON_STAMP(1)  // DMA issue  // slot (k + 2) % 3 was read during tile k - 1: every wave passed the barrier since
+    const u32x4* tile = (const u32x4*)((const unsigned char*)lds_raw + (k % 3) * TILE_BYTES);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      f32x16 c;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) c[v] = 0.f;
+      const int row = nt * 32 + n32;
+      const u32x4* rh = tile + row * CPR;
+      const u32x4* rm = tile + (64 + row) * CPR;
+      const int key = big_swz<DP>(row);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8v bh = __builtin_bit_cast(bf16x8v, rh[(2 * ks + kh) ^ key]);
+        const bf16x8v bm = __builtin_bit_cast(bf16x8v, rm[(2 * ks + kh) ^ key]);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bm, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[ks], bh, c, 0, 0, 0);
+      }
+      const int J0 = jt * 64 + nt * 32, j = J0 + n32;
+      const bool edge = (I0 < J0 + 32 && J0 < I0 + 32) || J0 + 32 > a.N2;  // wave-uniform: diagonal / column padding
+      float* dst = Lmat + (size_t)j * a.N2p + I0 + 4 * kh;  // symmetric matrix, stored transposed: 16 bytes per lane
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f32x4 lg4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int v = 4 * q + r;
+          const int ri = 8 * q + 4 * kh + r;
+          lg4[r] = fmaf(c[v], inv_t, -m);
+          float e = __builtin_amdgcn_exp2f(fmaf(c[v], k2, -m2));
+          if (edge) e = (j == I0 + ri || j >= a.N2) ? 0.f : e;
+          D[v] += e;
+        }
+        *(f32x4*)(dst + 8 * q) = lg4;
+      }
+    }
+    // tile k + 1 must have landed before anyone reads it: everything older than the youngest 12 operations of this
+    // wave (tile k + 2's pieces and this tile's 8 stores) -- the counter completes in order, stores included
+    SUPCON_STAMP(3)  // MFMA + epilogue of both n-tiles
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GPW + 8) : "memory");
+    __syncthreads();
+    SUPCON_STAMP(2)  // wait for the next tile + barrier
+  }
 #pragma unroll
   for (int v = 0; v < 16; ++v) {
 #pragma unroll
@@ -1062,6 +1224,8 @@ static SupconArgs make_args(const SupconLayout& L, const float* ws, const float*
   a.gamma = gamma;
   a.inv_gamma = (float)(1.0 / (double)gamma);
   a.sp_mode = sp_mode;
+  static const int env_dbg = getenv("SPCL_SUPCON_DBG") ? atoi(getenv("SPCL_SUPCON_DBG")) : 0;
+  a.dbg = env_dbg;
   return a;
 }
 
@@ -1099,10 +1263,30 @@ static int launch_forward_big(const SupconLayout& L, SupconArgs a, float* ws, in
   const double n2 = (double)L.N2p;
   prof_cost(n2 * n2 * 4 + 2 * n2 * DP * 4, 2.0 * n2 * n2 * DP);  // logits written once; f32-equivalent FLOPs
   static const bool env_stamps = getenv("SPCL_SUPCON_STAMPS") != nullptr;
-  const size_t nwg = (size_t)(L.N2p / 128) * L.CSB;
-  if (env_stamps) (void)hipMalloc(&a.stamps, nwg * 6 * sizeof(unsigned long long));  // debug only (synchronises)
-  SPCL_LAUNCH((supcon_logits_kernel<DP>), dim3(L.N2p / 128, L.CSB), dim3(256), (size_t)2 * 64 * DP * 2, st, a, Ph, Pm,
-                     Lmat);
+  const size_t nwg = (size_t)(L.N2p / 128) * L.CSB;  // (>= the number of workgroups of either kernel)
+  if (env_stamps) {  // debug only (synchronises)
+    (void)hipMalloc(&a.stamps, nwg * 6 * sizeof(unsigned long long));
+    (void)hipMemset(a.stamps, 0, nwg * 6 * sizeof(unsigned long long));
+  }
+  static const bool env_v1 = getenv("SPCL_SUPCON_LOGITS_V1") != nullptr;  // A/B switch
+  bool v2 = false;
+  if constexpr (DP <= 128) {  // three tile images of 2 x 64 x DP bf16 fit the LDS
+    if (L.N2p % 256 == 0 && !env_v1) {
+      constexpr int ring = 3 * 2 * 64 * DP * 2;
+      static bool attr = false;
+      if (!attr) {
+        (void)hipFuncSetAttribute((const void*)supcon_logits2_kernel<DP>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  ring);
+        attr = true;
+      }
+      SPCL_LAUNCH((supcon_logits2_kernel<DP>), dim3(L.N2p / 256, L.CSB), dim3(512), (size_t)ring, st, a, Ph, Pm, Lmat);
+      v2 = true;
+    }
+  }
+  if (!v2) {
+    SPCL_LAUNCH((supcon_logits_kernel<DP>), dim3(L.N2p / 128, L.CSB), dim3(256), (size_t)2 * 64 * DP * 2, st, a, Ph, Pm,
+                Lmat);
+  }
   if (a.stamps != nullptr) {
     std::vector<unsigned long long> h(nwg * 6);
     (void)hipStreamSynchronize(st);
@@ -1111,9 +1295,9 @@ static int launch_forward_big(const SupconLayout& L, SupconArgs a, float* ws, in
     a.stamps = nullptr;
     double s6[6] = {0, 0, 0, 0, 0, 0};
     for (size_t w = 0; w < nwg; ++w)
-      for (int k = 0; k < 6; ++k) s6[k] += (double)h[w * 6 + k] / nwg;
+      for (int k = 0; k < 6; ++k) s6[k] += (double)h[w * 6 + k] / (v2 ? nwg / 2 : nwg);
     fprintf(stderr, "[supcon stamps] N2p=%d DP=%d wgs=%zu tiles/wg=%d | memtime ticks per wg (100 MHz): preamble %.0f, "
-                    "wait-wg %.0f, commit %.0f, compute %.0f, fold %.0f\n", L.N2p, DP, nwg, L.N2p / 64 / L.CSB, s6[0],
+                    "wait-wg / DMA issue %.0f, commit / tile wait %.0f, compute %.0f, fold %.0f\n", L.N2p, DP, nwg, L.N2p / 64 / L.CSB, s6[0],
             s6[1], s6[2], s6[3], s6[4]);
   }
   prof_cost(n2 * n2 * 4, 0.0);
