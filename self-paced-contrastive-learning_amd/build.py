@@ -14,6 +14,9 @@ LIB = os.path.join(HERE, "lib", "libspcl_hip.so")
 OBJ = os.path.join(HERE, "build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# per-file extras.  supcon.hip: the first kernel-argument dwords arrive in SGPRs at wave launch (gfx950 kernarg preload)
+# instead of through a scalar load -- the large-batch sweeps start their transfers one memory round trip earlier.
+EXTRA = {"supcon.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=14"]}
 
 
 def _sources():
@@ -37,8 +40,8 @@ def build(force=False, verbose=True):
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.rsplit(".", 1)[0] + ".o")
         objs.append(o)
-        if force or _stale(o, [s] + headers):
-            cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", s, "-o", o]
+        if force or _stale(o, [s, os.path.abspath(__file__)] + headers):
+            cmd = [HIPCC] + FLAGS + EXTRA.get(src, []) + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", s, "-o", o]
             jobs.append((src, cmd))
 
     def run(job):

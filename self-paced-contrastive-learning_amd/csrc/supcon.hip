@@ -12,6 +12,7 @@
 // reference's fp32 torch.mm to rounding.  One wave owns 16 rows of S; a workgroup of 4 waves shares the
 // 64-row P_J tile staged in LDS (16-byte chunks XOR-swizzled by row -> conflict-free ds_read_b128).
 #include "common.hpp"
+#include <type_traits>
 #include <vector>
 
 namespace spcl {
@@ -19,9 +20,10 @@ namespace spcl {
 struct SupconLayout {
   int n, d, N2, N2p, DP, CS, NS;
   int big, CSB;  // large batches: logits materialised once by split-bf16 MFMA (CSB column splits), see below
-  size_t off_P, off_rn2, off_logD, off_c, off_W, off_rowloss, off_partA, off_partB, off_Ph, off_Pm, off_L, off_dz, total;
+  size_t off_P, off_rn2, off_logD, off_c, off_W, off_rowloss, off_cls, off_partA, off_partB, off_partC, off_partD, off_fin, off_Ph, off_Pm, off_L, off_dz, total;
 };
-constexpr int SUPCON_BIG_N2 = 1024;  // from this many rows on the forward materialises the logits
+constexpr int SUPCON_BIG_N2 = 1024;
+constexpr int SUPCON_TILES_MAXT = 16;  // J tiles per workgroup of the fused large-batch sweeps  // from this many rows on the forward materialises the logits
 
 static int supcon_big_wgs() {
   static const int v = getenv("SPCL_SUPCON_WGS") ? atoi(getenv("SPCL_SUPCON_WGS")) : 512;
@@ -50,12 +52,21 @@ static SupconLayout supcon_layout(int n, int d) {
   L.off_c = o;        o += L.N2p;
   L.off_W = o;        o += L.N2p;
   L.off_rowloss = o;  o += L.N2p;
+  L.off_cls = o;      o += L.N2p;  // class id per row (labels[i mod n], or i mod n): large batches
   L.CSB = 1;
   if (L.big)  // 128-row blocks x CSB column splits ~ two workgroups per CU
     while ((L.N2p / 128) * L.CSB < supcon_big_wgs() && L.CSB * 2 * 64 <= L.N2p) L.CSB *= 2;
-  const int prow = L.CS > L.CSB ? L.CS : L.CSB;
+  int prow = L.CS > L.CSB ? L.CS : L.CSB;
+  if (L.big && L.N2p / 256 > prow) prow = L.N2p / 256;  // the fused sweeps: one partial row per 256-row block
   L.off_partA = o;    o += (size_t)prow * L.N2p;
   L.off_partB = o;    o += (size_t)prow * L.N2p;
+  L.off_partC = L.off_partD = L.off_fin = o;
+  if (L.big) {  // the fused sweeps keep four kinds of partial rows alive at once, and their finish a few doubles
+    L.off_partC = o;  o += (size_t)prow * L.N2p;
+    L.off_partD = o;  o += (size_t)prow * L.N2p;
+    o = round_up(o, 2);
+    L.off_fin = o;    o += (size_t)(L.N2p / 256) * 8 + 2;
+  }
   L.off_Ph = L.off_Pm = L.off_L = o;
   if (L.big) {  // bf16 splits of P (N2p x DP halves each) and the logits [N2p][N2p]
     L.off_Ph = o;     o += (size_t)L.N2p * L.DP / 2;
@@ -90,7 +101,8 @@ struct SupconArgs {
 __global__ __launch_bounds__(256) void supcon_prep_kernel(const float* __restrict__ z1, const float* __restrict__ z2,
                                                           int n, int d, int N2p, int DP, float* __restrict__ P,
                                                           float* __restrict__ rn2, bf16_t* __restrict__ Ph,
-                                                          bf16_t* __restrict__ Pm) {
+                                                          bf16_t* __restrict__ Pm, const float* __restrict__ labels,
+                                                          float* __restrict__ cls) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= N2p) return;
@@ -107,7 +119,60 @@ __global__ __launch_bounds__(256) void supcon_prep_kernel(const float* __restric
     s += v * v;
   }
   s = wave_sum(s);
-  if (lane == 0) rn2[row] = s;
+  if (lane == 0) {
+    rn2[row] = s;
+    if (cls != nullptr) {  // positives are the pairs of equal class id (SimCLR: the two views of an image)
+      const int in = row >= n ? row - n : row;
+      cls[row] = row >= 2 * n ? -1.f : (labels != nullptr ? labels[in] : (float)in);
+    }
+  }
+}
+
+// Large batches (d <= 128): the same outputs, eight consecutive features per thread -- 16-byte loads and stores for
+// P and both bf16 splits (the one-element-per-lane kernel above writes 2 bytes per store instruction).
+template <int DP>
+__global__ __launch_bounds__(256) void supcon_prep_big_kernel(const float* __restrict__ z1, const float* __restrict__ z2,
+                                                              int n, int d, float* __restrict__ P,
+                                                              float* __restrict__ rn2, bf16_t* __restrict__ Ph,
+                                                              bf16_t* __restrict__ Pm, const float* __restrict__ labels,
+                                                              float* __restrict__ cls) {
+  constexpr int TPR = DP / 8;                      // threads per row
+  const int row = blockIdx.x * (256 / TPR) + (int)threadIdx.x / TPR;
+  const int k0 = ((int)threadIdx.x % TPR) * 8;
+  const float* src = row < n ? z1 + (size_t)row * d : (row < 2 * n ? z2 + (size_t)(row - n) * d : nullptr);
+  float v[8];
+  if (src != nullptr && (d & 3) == 0 && k0 + 8 <= d) {  // rows are 16-byte aligned when d % 4 == 0
+    const f32x4 a = *(const f32x4*)(src + k0), b = *(const f32x4*)(src + k0 + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] = a[e];
+      v[4 + e] = b[e];
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (src != nullptr && k0 + e < d) ? src[k0 + e] : 0.f;
+  }
+  float s = 0.f;
+  typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+  u16x8 h, m;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {  // v = hi + mid + O(2^-16 v): two bf16 terms carry 16 mantissa bits
+    s += v[e] * v[e];
+    h[e] = f32_to_bf16(v[e]);
+    m[e] = f32_to_bf16(v[e] - bf16_to_f32(h[e]));
+  }
+  float* pd = P + (size_t)row * DP + k0;
+  *(f32x4*)pd = (f32x4){v[0], v[1], v[2], v[3]};
+  *(f32x4*)(pd + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+  *(u16x8*)(Ph + (size_t)row * DP + k0) = h;
+  *(u16x8*)(Pm + (size_t)row * DP + k0) = m;
+#pragma unroll
+  for (int o = TPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (k0 == 0) {
+    rn2[row] = s;
+    const int in = row >= n ? row - n : row;
+    cls[row] = row >= 2 * n ? -1.f : (labels != nullptr ? labels[in] : (float)in);
+  }
 }
 
 // [N2p][DP] -> [DP][N2p] of one bf16 split (blockIdx.y) through an LDS tile of 64 rows: coalesced on both sides
@@ -738,9 +803,7 @@ __global__ __launch_bounds__(512) void supcon_logits2_kernel(SupconArgs a, const
 #pragma unroll
   for (int w = 1; w < 8; ++w) m = fmaxf(m, red[w]);
   const float k2 = inv_t * 1.44269504088896340736f, m2 = m * 1.44269504088896340736f;
-  float D[16];
-#pragma unroll
-  for (int v = 0; v < 16; ++v) D[v] = 0.f;
+  float D = 0.f;  // this lane's own row I0 + n32 (its column of every product), summed over the streamed rows
   SUPCON_STAMP(0)  // preamble: operands, max logit, first tile
   for (int k = 0; k < nmine; ++k) {
     const int jt = blockIdx.y + k * gridDim.y;
@@ -756,28 +819,31 @@ __global__ __launch_bounds__(512) void supcon_logits2_kernel(SupconArgs a, const
       const u32x4* rh = tile + row * CPR;
       const u32x4* rm = tile + (64 + row) * CPR;
       const int key = big_swz<DP>(row);
+      // streamed rows = A operand, own rows = B operand: c[4q + r] of lane l is the pair (own row I0 + l % 32, streamed
+      // row J0 + 8q + 4 (l / 32) + r) -- the same operand roles, term order and therefore the same bits as the fused
+      // forward sweeps (supcon_tiles_kernel), whose statistics the backward pairs with these logits
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const bf16x8v bh = __builtin_bit_cast(bf16x8v, rh[(2 * ks + kh) ^ key]);
         const bf16x8v bm = __builtin_bit_cast(bf16x8v, rm[(2 * ks + kh) ^ key]);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bh, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks], bm, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[ks], bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, ah[ks], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bm, ah[ks], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh, am[ks], c, 0, 0, 0);
       }
-      const int J0 = jt * 64 + nt * 32, j = J0 + n32;
+      const int J0 = jt * 64 + nt * 32, i = I0 + n32;
       const bool edge = (I0 < J0 + 32 && J0 < I0 + 32) || J0 + 32 > a.N2;  // wave-uniform: diagonal / column padding
-      float* dst = Lmat + (size_t)j * a.N2p + I0 + 4 * kh;  // symmetric matrix, stored transposed: 16 bytes per lane
+      float* dst = Lmat + (size_t)i * a.N2p + J0 + 4 * kh;  // 16 bytes per lane and q; a row's 32 columns fill one line
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         f32x4 lg4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int v = 4 * q + r;
-          const int ri = 8 * q + 4 * kh + r;
+          const int j = J0 + 8 * q + 4 * kh + r;
           lg4[r] = fmaf(c[v], inv_t, -m);
           float e = __builtin_amdgcn_exp2f(fmaf(c[v], k2, -m2));
-          if (edge) e = (j == I0 + ri || j >= a.N2) ? 0.f : e;
-          D[v] += e;
+          if (edge) e = (j == i || j >= a.N2) ? 0.f : e;
+          D += e;
         }
         *(f32x4*)(dst + 8 * q) = lg4;
       }
@@ -789,22 +855,399 @@ __global__ __launch_bounds__(512) void supcon_logits2_kernel(SupconArgs a, const
     __syncthreads();
     SUPCON_STAMP(2)  // wait for the next tile + barrier
   }
-#pragma unroll
-  for (int v = 0; v < 16; ++v) {
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) D[v] += __shfl_xor(D[v], o, 64);
-  }
-  if (n32 == 0) {
-#pragma unroll
-    for (int v = 0; v < 16; ++v)
-      a.partA[(size_t)blockIdx.y * a.N2p + I0 + 8 * (v >> 2) + 4 * kh + (v & 3)] = D[v];
-  }
+  D += __shfl_xor(D, 32, 64);
+  if (kh == 0) a.partA[(size_t)blockIdx.y * a.N2p + I0 + n32] = D;
   SUPCON_STAMP(4)  // row-sum fold
   if (stamp) {
     unsigned long long* o = a.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 6;
     for (int k = 0; k < 6; ++k) o[k] = tk[k];
   }
 #undef SUPCON_STAMP
+}
+
+// ---- fused large-batch forward (round 2): NO logits matrix.  The self-paced loss needs two sweeps over the similarity
+// tiles (row sums D_i first, then the weights that depend on log D_i); at 16x the f32 matrix rate the split-bf16 product
+// of a whole sweep is ~3 us of the chip's time at 4096 x 128, cheaper than writing and re-reading 67 MB.  Both sweeps run
+// this kernel (PASS 0: D_i and the positive count c_i; PASS 1: sum_j pos w l and W_i).  Tiling and tile ring are those
+// of supcon_logits2_kernel, with the operand roles swapped and the data movement reworked:
+//  * a wave's OWN 32 rows are the B operand (registers), the streamed 64-row tiles the A operand (LDS): lane l then
+//    holds own row I0 + l % 32 as its COLUMN of every 32 x 32 product and 16 streamed rows in its accumulators, so a
+//    row's statistics are plain in-register sums over the whole sweep -- two scalars per lane, ONE cross-half add at
+//    the end -- instead of 16 per-row partials and an 80-shuffle butterfly;
+//  * the own rows arrive by coalesced LDS-DMA into a per-wave staging image and are read back as fragments (direct
+//    fragment loads touch 32 bytes of every 128-byte line: 4x over-fetch, 30 % of the old kernel's life);
+//  * class ids of own and streamed rows (written by the prep kernel: positives = equal class id) and, in PASS 1, the
+//    CSB row-sum partials of the own rows come the same way: log D_i is formed in the prologue, there is no finishing
+//    launch between the sweeps.
+// All global->LDS traffic is inline-asm DMA, so the only compiler-visible vector loads are the row norms of the
+// max-logit scan, issued FIRST and consumed after the last explicit wait: hipcc's own waits never drain the ring.
+// Instruction order of one "products | stats" block: per 16 features two fragment reads (one step ahead of their
+// MFMAs), three MFMAs, and NV vector instructions of the statistics behind each MFMA; whatever is left follows.
+template <int KS, int NV, int XR>
+__device__ __forceinline__ void supcon_pace() {
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if (NV > 0) __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+    }
+  }
+}
+
+// Argument order: the first 14 dwords are preloaded into SGPRs at wave launch (-amdgpu-kernarg-preload-count, see
+// build.py) -- everything the first transfers need, so the prologue does not start with a scalar-load round trip.
+struct SupconTilesTail {
+  float* out0;
+  float* out1;
+  float* logD_out;
+  float gamma, inv_gamma;
+  unsigned long long* stamps;
+};
+template <int DP, int PASS, int SP>
+__global__ __launch_bounds__(512) void supcon_tiles_kernel(const bf16_t* __restrict__ Ph, const bf16_t* __restrict__ Pm,
+                                                          const float* __restrict__ cls, const float* __restrict__ rn2,
+                                                          int N2, int N2p, int CSB, float t,
+                                                          const float* __restrict__ Dpart /* [CSB][N2p], PASS 1 */,
+                                                          SupconTilesTail q) {
+  constexpr int CPR = DP / 8, KS = DP / 16;
+  constexpr int TILE_BYTES = 2 * 64 * DP * 2;      // both splits of a 64-row tile
+  constexpr int GROUPS = TILE_BYTES / 1024;        // 1 KiB DMA pieces per tile
+  constexpr int GPW = GROUPS / 8;                  // per wave
+  constexpr int RPG = 1024 / (DP * 2);             // rows per piece
+  constexpr int APW = 32 * DP * 2 / 1024;          // pieces of one split of a wave's 32 rows
+  constexpr int MAXT = SUPCON_TILES_MAXT;          // tiles per workgroup (class ids staged in LDS), also CSB <= MAXT
+  static_assert(GROUPS % 8 == 0 && 8 * APW * 1024 == 2 * TILE_BYTES, "staging = ring image 2 + one more image");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds_b[];
+  const unsigned lds_base = (unsigned)(uintptr_t)(unsigned char __attribute__((address_space(3)))*)lds_b;
+  // [3 ring images][1 more image: with image 2 the staging of the own rows, 32 rows x DP bf16 per wave]
+  const float* owncls = (const float*)(lds_b + 4 * TILE_BYTES);  // [256] class ids of this block's own rows
+  const float* tilecls = owncls + 256;                           // [MAXT * 64] class ids of the streamed rows
+  const float* dpart = tilecls + MAXT * 64;                      // [CSB][256] row-sum partials of the own rows
+  __shared__ float red[8];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n32 = lane & 31, kh = lane >> 5;
+  const int I0 = blockIdx.x * 256 + wave * 32;
+  const float inv_t = 1.f / t;
+  const int ntiles = N2p / 64;
+  const int t_begin = (int)(((long)blockIdx.y * ntiles) / CSB), t_end = (int)(((long)(blockIdx.y + 1) * ntiles) / CSB);
+  const int nmine = t_end - t_begin;               // >= 2 (the launcher bounds CSB), <= MAXT
+  const bool stamp = q.stamps != nullptr && threadIdx.x == 0;
+  const unsigned long long rt0 = stamp ? __builtin_amdgcn_s_memrealtime() : 0;
+  unsigned long long tk[6] = {0, 0, 0, 0, 0, 0}, t0 = stamp ? __builtin_amdgcn_s_memtime() : 0, t1;
+// slots: 0 transfers issued, 1 own hi rows landed, 2 own lo rows landed, 3 barrier + row constants, 4 tile loop, 5 tail
+#define SUPCON_STAMP(k)                                    \
+  if (stamp) {                                            \
+    t1 = __builtin_amdgcn_s_memtime();                    \
+    tk[k] += t1 - t0;                                     \
+    t0 = t1;                                              \
+  }
+
+  // ---- the only compiler-managed vector loads: squared row norms for the max logit (zeros beyond N2)
+  f32x4 rn[8];
+  {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)rn2, 0, N2 * 4, 0x00020000);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      rn[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (threadIdx.x + 512 * u) * 16, 0, 0));
+  }
+  const int prow = lane / CPR, pcp = lane % CPR;   // lane -> (row in a piece, chunk position); source chunk swizzled
+  auto issue = [&](int k) {                        // k-th tile of this workgroup -> ring image k % 3
+    const int jt = t_begin + k;
+    const unsigned slot = lds_base + (unsigned)((k % 3) * TILE_BYTES);
+#pragma unroll
+    for (int u = 0; u < GPW; ++u) {
+      const int gidx = wave * GPW + u;
+      const int sp = gidx / (GROUPS / 2), gr = gidx % (GROUPS / 2);
+      const int row = gr * RPG + prow;
+      const bf16_t* src = (sp ? Pm : Ph) + (size_t)(jt * 64 + row) * DP + ((pcp ^ big_swz<DP>(row)) * 8);
+      supcon_dma16(src, __builtin_amdgcn_readfirstlane(slot + gidx * 1024));
+    }
+  };
+  const unsigned stage = lds_base + 2 * TILE_BYTES + (unsigned)wave * (APW * 1024);
+  auto issue_own = [&](const bf16_t* split) {      // this wave's 32 rows of one split -> its staging image
+#pragma unroll
+    for (int u = 0; u < APW; ++u) {
+      const int row = u * RPG + prow;
+      const bf16_t* src = split + (size_t)(I0 + row) * DP + ((pcp ^ big_swz<DP>(row)) * 8);
+      supcon_dma16(src, __builtin_amdgcn_readfirstlane(stage + u * 1024));
+    }
+  };
+  auto read_own = [&](bf16x8v* dst) {
+    const u32x4* r = (const u32x4*)(lds_b + 2 * TILE_BYTES + wave * (APW * 1024)) + n32 * CPR;
+    const int key = big_swz<DP>(n32);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) dst[ks] = __builtin_bit_cast(bf16x8v, r[(2 * ks + kh) ^ key]);
+  };
+  // oldest transfers: class ids of the rows this workgroup meets and (PASS 1) the row-sum partials of its own rows,
+  // 256 floats per piece
+  const unsigned stat_base = lds_base + 4 * TILE_BYTES;
+  if (wave == 0) supcon_dma16(cls + blockIdx.x * 256 + lane * 4, __builtin_amdgcn_readfirstlane(stat_base));
+  if (wave == 1)
+    for (int p = 0; p * 4 < nmine; ++p)
+      supcon_dma16(cls + t_begin * 64 + p * 256 + lane * 4, __builtin_amdgcn_readfirstlane(stat_base + 1024 + p * 1024));
+  if (PASS == 1)
+    for (int c = wave; c < CSB; c += 8)
+      supcon_dma16(Dpart + (size_t)c * N2p + blockIdx.x * 256 + lane * 4,
+                   __builtin_amdgcn_readfirstlane(stat_base + 1024 + MAXT * 256 + c * 1024));
+  bf16x8v oh[KS], om[KS];
+  issue_own(Ph);
+  issue(0);
+  issue(1);
+  SUPCON_STAMP(0)
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GPW) : "memory");  // the hi rows have landed
+  SUPCON_STAMP(1)
+  read_own(oh);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(oh[ks]));
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // ... and have been read: the image is free again
+  issue_own(Pm);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // everything so far (tiles 0 and 1 included)
+  SUPCON_STAMP(2)
+  read_own(om);
+  float mv = 0.f;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    asm volatile("" : "+v"(rn[u]));  // the scan stays behind the explicit wait above
+    mv = fmaxf(mv, fmaxf(fmaxf(rn[u][0], rn[u][1]), fmaxf(rn[u][2], rn[u][3])));
+  }
+  mv = wave_max(mv / t);
+  if (lane == 0) red[wave] = mv;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(om[ks]));
+  __syncthreads();
+  float m = red[0];
+#pragma unroll
+  for (int w = 1; w < 8; ++w) m = fmaxf(m, red[w]);
+  const float k2 = inv_t * 1.44269504088896340736f, m2 = m * 1.44269504088896340736f;
+  const int own = I0 + n32;                        // this lane's own row (its column of every product)
+  const float cown = owncls[wave * 32 + n32];
+  const float gamma = q.gamma, inv_gamma = q.inv_gamma;
+  float* const o0 = q.out0 + (size_t)blockIdx.y * N2p + own;   // (kernel arguments fetched here, not in the tail)
+  float* const o1 = q.out1 + (size_t)blockIdx.y * N2p + own;
+  asm volatile("" ::"v"(o0), "v"(o1));
+  float ld = 0.f;                                  // PASS 1: log D of the own row, from the CSB partials of sweep 0
+  if (PASS == 1) {
+    float D = 0.f;
+    for (int c = 0; c < CSB; ++c) D += dpart[c * 256 + wave * 32 + n32];
+    ld = logf(D + 1e-16f);
+    if (blockIdx.y == 0 && kh == 0) q.logD_out[own] = ld;
+  }
+  float s0 = 0.f, s1 = 0.f;
+  // The 24 MFMAs of a 32-row half tile (768 matrix-pipe cycles) and the ~100 vector instructions that turn the PREVIOUS
+  // half tile's accumulators into statistics are independent: they are written as one basic block so that the vector
+  // work issues in the shadow of the MFMAs (two accumulator sets).  The diagonal / padding masks exist only in the
+  // `EDGE` copy of the block (wave-uniform branch).
+  // FIX = false: every element counted as a valid pair (no masks: the fast path).  FIX = true: takes back what the
+  // fast path added for the pairs that are not (the diagonal, padding rows) -- run after it on the rare edge blocks.
+  auto stats = [&](auto fix_c, const f32x16& c, int kE, int ntE) {
+    constexpr bool FIX = decltype(fix_c)::value;
+    const int S0 = (t_begin + kE) * 64 + ntE * 32;  // streamed rows S0 + 8q + 4kh + r live in c[4q + r]
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 cs4 = *(const f32x4*)(tilecls + kE * 64 + ntE * 32 + 8 * q + 4 * kh);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int v = 4 * q + r;
+        const bool pos = cs4[r] == cown;
+        float sgn = 1.f;
+        if (FIX) {
+          const int sr = S0 + 8 * q + 4 * kh + r;
+          const bool ok = sr != own && sr < N2 && own < N2;
+          sgn = ok ? 0.f : -1.f;
+        }
+        if (PASS == 0) {
+          const float e = __builtin_amdgcn_exp2f(fmaf(c[v], k2, -m2));  // exp(c / t - m)
+          s0 += FIX ? sgn * e : e;
+          s1 += pos ? sgn : 0.f;
+        } else {
+          const float ell = fmaf(c[v], inv_t, -m) - ld;
+          float w;
+          if (SP == 0) w = pos ? sgn : 0.f;
+          else if (SP == 1) w = (pos && -ell <= gamma) ? sgn : 0.f;
+          else w = pos ? sgn * fmaxf(fmaf(inv_gamma, ell, 1.f), 0.f) : 0.f;
+          s0 = fmaf(w, ell, s0);
+          s1 += w;
+        }
+      }
+    }
+  };
+  auto stat1 = [&](float cv, float clsv) {  // one element of the fast path
+    const bool pos = clsv == cown;
+    if (PASS == 0) {
+      s0 += __builtin_amdgcn_exp2f(fmaf(cv, k2, -m2));  // exp(c / t - m)
+      s1 += pos ? 1.f : 0.f;
+    } else {
+      const float ell = fmaf(cv, inv_t, -m) - ld;  // rounded exactly as the backward rounds it (hard threshold)
+      float w;
+      if (SP == 0) w = pos ? 1.f : 0.f;
+      else if (SP == 1) w = (pos && -ell <= gamma) ? 1.f : 0.f;
+      else w = pos ? fmaxf(fmaf(inv_gamma, ell, 1.f), 0.f) : 0.f;
+      s0 = fmaf(w, ell, s0);
+      s1 += w;
+    }
+  };
+  // products of half tile (k, nt) into cn; with STATS the fast-path statistics of ce = half tile (kE, ntE), two
+  // elements behind every three MFMAs (source order = the order the matrix and vector pipes should see)
+  auto products = [&](auto stats_c, int k, int nt, f32x16& cn, const f32x16& ce, int kE, int ntE) {
+    constexpr bool STATS = decltype(stats_c)::value;
+    const u32x4* tile = (const u32x4*)(lds_b + (k % 3) * TILE_BYTES);
+    f32x4 cs4[4];
+    if (STATS) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) cs4[q] = *(const f32x4*)(tilecls + kE * 64 + ntE * 32 + 8 * q + 4 * kh);
+    }
+#pragma unroll
+    for (int v = 0; v < 16; ++v) cn[v] = 0.f;
+    const int row = nt * 32 + n32;
+    const u32x4* rh = tile + row * CPR;
+    const u32x4* rm = tile + (64 + row) * CPR;
+    const int key = big_swz<DP>(row);
+    constexpr int EPK = 16 / KS;  // elements per 16-feature step (KS = 4 or 8)
+    // fragments one step ahead of their MFMAs (the LDS latency is off the matrix pipe's dependency chain)
+    bf16x8v sh = __builtin_bit_cast(bf16x8v, rh[kh ^ key]), sm = __builtin_bit_cast(bf16x8v, rm[kh ^ key]);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8v nh = sh, nm = sm;
+      if (ks + 1 < KS) {
+        nh = __builtin_bit_cast(bf16x8v, rh[(2 * ks + 2 + kh) ^ key]);
+        nm = __builtin_bit_cast(bf16x8v, rm[(2 * ks + 2 + kh) ^ key]);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // (the scheduler would sink the reads back next to their MFMAs)
+      cn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sh, oh[ks], cn, 0, 0, 0);
+      cn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sm, oh[ks], cn, 0, 0, 0);
+      cn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sh, om[ks], cn, 0, 0, 0);
+      if (STATS) {
+#pragma unroll
+        for (int u = 0; u < EPK; ++u) {
+          const int v = ks * EPK + u;
+          stat1(ce[v], cs4[v >> 2][v & 3]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      sh = nh;
+      sm = nm;
+    }
+  };
+  auto is_edge = [&](int kE, int ntE) {  // wave-uniform: does this 32 x 32 product touch the diagonal or the padding?
+    const int S0 = (t_begin + kE) * 64 + ntE * 32;
+    return (I0 < S0 + 32 && S0 < I0 + 32) || S0 + 32 > N2 || I0 + 32 > N2;
+  };
+  const std::true_type yes;
+  const std::false_type no;
+  SUPCON_STAMP(3)
+  if (nmine > 2) issue(2);  // image 2 doubles as the staging of waves 0..3: free since the barrier above
+  f32x16 c0, c1;
+  products(no, 0, 0, c0, c0, 0, 0);
+  for (int k = 0; k < nmine; ++k) {
+    products(yes, k, 1, c1, c0, k, 0);
+    if (is_edge(k, 0)) stats(yes, c0, k, 0);
+    // tile k + 1 must have landed before anyone reads it: all but the pieces of tile k + 2, if that is on its way
+    if (k + 2 < nmine) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (k + 3 < nmine) issue(k + 3);  // into the image of tile k, which every wave has finished reading
+    if (k + 1 < nmine) products(yes, k + 1, 0, c0, c1, k, 1);
+    else stats(no, c1, k, 1);
+    if (is_edge(k, 1)) stats(yes, c1, k, 1);
+  }
+  SUPCON_STAMP(4)
+  s0 += __shfl_xor(s0, 32, 64);
+  s1 += __shfl_xor(s1, 32, 64);
+  if (kh == 0) {
+    *o0 = s0;
+    *o1 = s1;
+  }
+  SUPCON_STAMP(5)
+  if (stamp) {
+    unsigned long long* o = q.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+    for (int k = 0; k < 6; ++k) o[k] = tk[k];
+    o[6] = rt0;
+    o[7] = __builtin_amdgcn_s_memrealtime();
+  }
+#undef SUPCON_STAMP
+}
+
+// Finish of the fused forward, two small launches (device-scope fences for a "last workgroup finishes" scheme cost
+// more than a launch on this chip: every release writes the L2 back).  supcon_fin2_kernel: per row the CSB partials of
+// the second sweep -> row loss numerator, W_i, c_i (kept for the backward), and one partial of the scalars per 256-row
+// workgroup.  supcon_fin3_kernel: those partials in index order -> loss / rho / kappa.
+__global__ __launch_bounds__(256) void supcon_fin2_kernel(const float* __restrict__ pL, const float* __restrict__ pW,
+                                                         const float* __restrict__ pC, int CSB, int N2, int N2p,
+                                                         float* __restrict__ rowloss, float* __restrict__ W,
+                                                         float* __restrict__ cnt, const float* __restrict__ rn2,
+                                                         double* __restrict__ blk /* [gridDim.x][4] */) {
+  __shared__ double red[4][4];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float l = 0.f, w = 0.f, c = 0.f;
+  float vl[SUPCON_TILES_MAXT], vw[SUPCON_TILES_MAXT], vc[SUPCON_TILES_MAXT];
+#pragma unroll
+  for (int s = 0; s < SUPCON_TILES_MAXT; ++s) {  // CSB <= MAXT: every load in flight at once (one memory round trip)
+    const size_t o = (size_t)(s < CSB ? s : CSB - 1) * N2p + i;
+    vl[s] = pL[o];
+    vw[s] = pW[o];
+    vc[s] = pC[o];
+  }
+  const float r2 = rn2[i];
+#pragma unroll
+  for (int s = 0; s < SUPCON_TILES_MAXT; ++s) {
+    l += s < CSB ? vl[s] : 0.f;
+    w += s < CSB ? vw[s] : 0.f;
+    c += s < CSB ? vc[s] : 0.f;
+  }
+  rowloss[i] = l;
+  W[i] = w;
+  cnt[i] = c;
+  double v[4] = {0.0, 0.0, 0.0, 0.0};
+  if (i < N2) {
+    v[0] = (double)(l / c);
+    v[1] = (double)w;
+    v[2] = (double)c;
+    v[3] = (double)fabsf(sqrtf(r2) - 1.f);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int o = 32; o > 0; o >>= 1) {
+    v[0] += __shfl_xor(v[0], o, 64);
+    v[1] += __shfl_xor(v[1], o, 64);
+    v[2] += __shfl_xor(v[2], o, 64);
+    v[3] = fmax(v[3], __shfl_xor(v[3], o, 64));
+  }
+  if (lane == 0)
+    for (int k = 0; k < 4; ++k) red[k][wave] = v[k];
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const int k = threadIdx.x;
+    blk[(size_t)blockIdx.x * 4 + k] = k < 3 ? red[k][0] + red[k][1] + red[k][2] + red[k][3]
+                                            : fmax(fmax(red[3][0], red[3][1]), fmax(red[3][2], red[3][3]));
+  }
+}
+
+__global__ __launch_bounds__(64) void supcon_fin3_kernel(const double* __restrict__ blk, int nblk, int N2,
+                                                        int correct_grad, float* __restrict__ out) {
+  const int lane = threadIdx.x;
+  double v[4] = {0.0, 0.0, 0.0, 0.0};
+  if (lane < nblk)  // nblk = N2p / 256 <= 64
+    for (int k = 0; k < 4; ++k) v[k] = blk[(size_t)lane * 4 + k];
+  // fixed butterfly over the lanes: the same association whatever the number of workgroups that ran
+  for (int o = 32; o > 0; o >>= 1) {
+    v[0] += __shfl_xor(v[0], o, 64);
+    v[1] += __shfl_xor(v[1], o, 64);
+    v[2] += __shfl_xor(v[2], o, 64);
+    v[3] = fmax(v[3], __shfl_xor(v[3], o, 64));
+  }
+  if (lane == 0) {
+    float loss = (float)(-(v[0] / (double)N2));
+    float rho = (float)(v[1] / v[2]);
+    float kappa = 1.f / (float)N2;
+    if (correct_grad && rho > 0.f) {
+      loss = loss / rho;
+      kappa = kappa / rho;
+    }
+    out[0] = loss;
+    out[1] = rho;
+    out[2] = kappa;
+    out[3] = (float)v[3];
+  }
 }
 
 // One wave per row of the materialised logits: D_i from the column-split partials, then the self-paced weights, the
@@ -1254,12 +1697,111 @@ static bool supcon_use_big(const SupconLayout& L, const float* mask) {
   return L.big && mask == nullptr && !exact;
 }
 
+// Large batches, d <= 128: the forward keeps no logits matrix (two fused sweeps, supcon_tiles_kernel); the backward
+// materialises it on demand.  SPCL_SUPCON_MATERIALIZE=1 restores the round-1 schedule (logits written by the forward).
+static bool supcon_use_fused(const SupconLayout& L) {
+  static const bool mat = getenv("SPCL_SUPCON_MATERIALIZE") != nullptr;
+  return !mat && L.DP <= 128 && L.N2p % 256 == 0 && L.N2p <= 16384;
+}
+static int supcon_fused_csb(const SupconLayout& L) {  // column splits: 2 .. SUPCON_TILES_MAXT tiles per workgroup
+  const int ntiles = L.N2p / 64;
+  int csb = L.CSB < SUPCON_TILES_MAXT ? L.CSB : SUPCON_TILES_MAXT;
+  while (csb * 2 > ntiles) csb /= 2;
+  while (ntiles > csb * SUPCON_TILES_MAXT) csb *= 2;  // (N2p <= 16384: at most 256 tiles, csb <= 16)
+  return csb;
+}
+template <int DP>
+static size_t supcon_tiles_lds() {
+  return (size_t)4 * 2 * 64 * DP * 2 + 1024 + SUPCON_TILES_MAXT * 256 + SUPCON_TILES_MAXT * 1024;
+}
+
+template <int DP>
+static void launch_logits2(const SupconLayout& L, SupconArgs a, const bf16_t* Ph, const bf16_t* Pm, float* Lmat,
+                           hipStream_t st) {
+  constexpr int ring = 3 * 2 * 64 * DP * 2;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)supcon_logits2_kernel<DP>, hipFuncAttributeMaxDynamicSharedMemorySize, ring);
+    attr = true;
+  }
+  SPCL_LAUNCH((supcon_logits2_kernel<DP>), dim3(L.N2p / 256, L.CSB), dim3(512), (size_t)ring, st, a, Ph, Pm, Lmat);
+}
+
 template <int DP>
 static int launch_forward_big(const SupconLayout& L, SupconArgs a, float* ws, int correct_grad, float* out,
                               hipStream_t st) {
   const bf16_t* Ph = (const bf16_t*)(ws + L.off_Ph);
   const bf16_t* Pm = (const bf16_t*)(ws + L.off_Pm);
   float* Lmat = ws + L.off_L;
+  if constexpr (DP <= 128) {
+    if (supcon_use_fused(L)) {
+      const int csb = supcon_fused_csb(L), nrb = L.N2p / 256;
+      const size_t lds = supcon_tiles_lds<DP>();
+      static bool attr = false;
+      if (!attr) {
+        const void* fns[4] = {(const void*)supcon_tiles_kernel<DP, 0, 0>, (const void*)supcon_tiles_kernel<DP, 1, 0>,
+                              (const void*)supcon_tiles_kernel<DP, 1, 1>, (const void*)supcon_tiles_kernel<DP, 1, 2>};
+        for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+      }
+      const double n2f = (double)L.N2p;
+      const float* cls = ws + L.off_cls;
+      float *pD = ws + L.off_partA, *pW = ws + L.off_partB, *pC = ws + L.off_partC, *pL = ws + L.off_partD;
+      static const bool env_stamps = getenv("SPCL_SUPCON_STAMPS") != nullptr;
+      const size_t nwg = (size_t)nrb * csb;
+      for (int pass = 0; pass < 2; ++pass) {
+        if (env_stamps) {  // debug only (synchronises)
+          (void)hipMalloc(&a.stamps, nwg * 8 * sizeof(unsigned long long));
+          (void)hipMemset(a.stamps, 0, nwg * 8 * sizeof(unsigned long long));
+        }
+        prof_cost(2 * n2f * DP * 4, 2.0 * n2f * n2f * DP);
+        SupconTilesTail q;
+        q.gamma = a.gamma;
+        q.inv_gamma = a.inv_gamma;
+        q.stamps = a.stamps;
+        q.out0 = pass == 0 ? pD : pL;
+        q.out1 = pass == 0 ? pC : pW;
+        q.logD_out = ws + L.off_logD;
+#define SPCL_TILES1(SP_)                                                                                          \
+  SPCL_LAUNCH((supcon_tiles_kernel<DP, 1, SP_>), dim3(nrb, csb), dim3(512), lds, st, Ph, Pm, cls, a.rn2, L.N2, \
+              L.N2p, csb, a.t, (const float*)pD, q)
+        if (pass == 0)
+          SPCL_LAUNCH((supcon_tiles_kernel<DP, 0, 0>), dim3(nrb, csb), dim3(512), lds, st, Ph, Pm, cls, a.rn2, L.N2,
+                      L.N2p, csb, a.t, (const float*)nullptr, q);
+        else if (a.sp_mode == 0) SPCL_TILES1(0);
+        else if (a.sp_mode == 1) SPCL_TILES1(1);
+        else SPCL_TILES1(2);
+#undef SPCL_TILES1
+        if (a.stamps != nullptr) {
+          std::vector<unsigned long long> h(nwg * 8);
+          (void)hipStreamSynchronize(st);
+          (void)hipMemcpy(h.data(), a.stamps, h.size() * 8, hipMemcpyDeviceToHost);
+          (void)hipFree(a.stamps);
+          a.stamps = nullptr;
+          double s6[6] = {0, 0, 0, 0, 0, 0}, life = 0;
+          unsigned long long first = ~0ull, last = 0, last_start = 0;
+          for (size_t w = 0; w < nwg; ++w) {
+            for (int k = 0; k < 6; ++k) s6[k] += (double)h[w * 8 + k] / nwg;
+            life += (double)(h[w * 8 + 7] - h[w * 8 + 6]) / nwg;
+            if (h[w * 8 + 6] < first) first = h[w * 8 + 6];
+            if (h[w * 8 + 6] > last_start) last_start = h[w * 8 + 6];
+            if (h[w * 8 + 7] > last) last = h[w * 8 + 7];
+          }
+          fprintf(stderr, "[supcon tiles pass %d] N2p=%d DP=%d wgs=%zu tiles/wg=%d | ticks per wg: transfers issued %.0f, "
+                          "own hi landed %.0f, own lo landed %.0f, barrier + row constants %.0f, tile loop %.0f, tail %.0f | 100 MHz clock: wg life "
+                          "%.2f us, first start -> last start %.2f us, first start -> last end %.2f us\n", pass, L.N2p, DP,
+                  nwg, L.N2p / 64 / csb, s6[0], s6[1], s6[2], s6[3], s6[4], s6[5], life / 100.0,
+                  (double)(last_start - first) / 100.0, (double)(last - first) / 100.0);
+        }
+      }
+      SPCL_LAUNCH(supcon_fin2_kernel, dim3(nrb), dim3(256), 0, st, (const float*)pL, (const float*)pW, (const float*)pC,
+                  csb, L.N2, L.N2p, ws + L.off_rowloss, ws + L.off_W, ws + L.off_c, (const float*)(ws + L.off_rn2),
+                  (double*)(ws + L.off_fin));
+      SPCL_LAUNCH(supcon_fin3_kernel, dim3(1), dim3(64), 0, st, (const double*)(ws + L.off_fin), nrb, L.N2,
+                  correct_grad, out);
+      return 0;
+    }
+  }
   const double n2 = (double)L.N2p;
   prof_cost(n2 * n2 * 4 + 2 * n2 * DP * 4, 2.0 * n2 * n2 * DP);  // logits written once; f32-equivalent FLOPs
   static const bool env_stamps = getenv("SPCL_SUPCON_STAMPS") != nullptr;
@@ -1272,14 +1814,7 @@ static int launch_forward_big(const SupconLayout& L, SupconArgs a, float* ws, in
   bool v2 = false;
   if constexpr (DP <= 128) {  // three tile images of 2 x 64 x DP bf16 fit the LDS
     if (L.N2p % 256 == 0 && !env_v1) {
-      constexpr int ring = 3 * 2 * 64 * DP * 2;
-      static bool attr = false;
-      if (!attr) {
-        (void)hipFuncSetAttribute((const void*)supcon_logits2_kernel<DP>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  ring);
-        attr = true;
-      }
-      SPCL_LAUNCH((supcon_logits2_kernel<DP>), dim3(L.N2p / 256, L.CSB), dim3(512), (size_t)ring, st, a, Ph, Pm, Lmat);
+      launch_logits2<DP>(L, a, Ph, Pm, Lmat, st);
       v2 = true;
     }
   }
@@ -1357,9 +1892,18 @@ extern "C" int spcl_supcon_forward(const float* z1, const float* z2, const float
     return SPCL_OK;
   }
   const bool big = supcon_use_big(L, mask);
+  if (big && L.DP <= 128) {
+    const int rows = 256 / (L.DP / 8);
+    if (L.DP == 64)
+      SPCL_LAUNCH((supcon_prep_big_kernel<64>), dim3(L.N2p / rows), dim3(256), 0, st, z1, z2, n, d, ws + L.off_P,
+                  ws + L.off_rn2, (bf16_t*)(ws + L.off_Ph), (bf16_t*)(ws + L.off_Pm), labels, ws + L.off_cls);
+    else
+      SPCL_LAUNCH((supcon_prep_big_kernel<128>), dim3(L.N2p / rows), dim3(256), 0, st, z1, z2, n, d, ws + L.off_P,
+                  ws + L.off_rn2, (bf16_t*)(ws + L.off_Ph), (bf16_t*)(ws + L.off_Pm), labels, ws + L.off_cls);
+  } else
   SPCL_LAUNCH(supcon_prep_kernel, dim3(L.N2p / 4), dim3(256), 0, st, z1, z2, n, d, L.N2p, L.DP,
                      ws + L.off_P, ws + L.off_rn2, big ? (bf16_t*)(ws + L.off_Ph) : (bf16_t*)nullptr,
-                     big ? (bf16_t*)(ws + L.off_Pm) : (bf16_t*)nullptr);
+                     big ? (bf16_t*)(ws + L.off_Pm) : (bf16_t*)nullptr, labels, big ? ws + L.off_cls : (float*)nullptr);
   if (big) {
     if (L.DP == 64) launch_forward_big<64>(L, a, ws, correct_grad, out, st);
     else if (L.DP == 128) launch_forward_big<128>(L, a, ws, correct_grad, out, st);
@@ -1392,6 +1936,12 @@ extern "C" int spcl_supcon_backward(const float* labels, const float* mask, int 
     bf16_t* PhT = (bf16_t*)(ws_bwd + (size_t)(L.CS > L.CSB ? L.CS : L.CSB) * L.N2p * L.DP);
     bf16_t* PmT = PhT + (size_t)L.N2p * L.DP;
     const float* Lmat = ws_fwd + L.off_L;
+    if (supcon_use_fused(L)) {  // the fused forward kept no logits: write them now (its row-sum partials go to the
+                                // forward's partial rows, which nobody reads any more)
+      float* wsm = const_cast<float*>(ws_fwd);
+      if (L.DP == 64) launch_logits2<64>(L, a, (const bf16_t*)(ws_fwd + L.off_Ph), (const bf16_t*)(ws_fwd + L.off_Pm), wsm + L.off_L, st);
+      else launch_logits2<128>(L, a, (const bf16_t*)(ws_fwd + L.off_Ph), (const bf16_t*)(ws_fwd + L.off_Pm), wsm + L.off_L, st);
+    }
     SPCL_LAUNCH(supcon_transpose_kernel, dim3(L.N2p / 64, 2), dim3(256), 0, st,
                        (const bf16_t*)(ws_fwd + L.off_Ph), (const bf16_t*)(ws_fwd + L.off_Pm), L.N2p, L.DP, PhT, PmT);
     dim3 grid(L.N2p / 128, L.CSB);
