@@ -127,6 +127,13 @@ int spcl_conv_pack_weights_block(const float* wa_oihw, int CinA, int CoutA, void
  * BatchNorm that follows; the buffer holds spcl_bn_stats_elems(ntiles, CoutS) floats (tile rows + the finalize
  * kernel's partial rows). */
 int spcl_conv_num_tiles(int N, int H, int W);
+/* Statistics rows the convolution of this configuration writes (stats [rows][3][CoutS], rows2 [rows][2][CoutS]): the
+ * pixel tiles above, except for the bf16 layers with >= 64 input and output channels (multiples of 64), whose
+ * workgroup-level GEMM kernel (csrc/conv_gemm.hip) writes one row per (image band, pixel half). */
+int spcl_conv_stat_rows(int dtype, int N, int H, int W, int CinK, int CoutS);
+/* Experimental workgroup-level GEMM kernel for those layers (csrc/conv_gemm.hip), off by default (also SPCL_CONV_GEMM=1).
+ * Switch it BEFORE packing weights: the packed layout of the layers it takes follows the switch. */
+void spcl_conv_set_gemm(int on);
 size_t spcl_bn_stats_elems(int ntiles, int CS);
 int spcl_conv3x3_forward(const void* x, int dtype, int N, int H, int W, int CinS, int CinK, int CoutS,
                          const void* w_packed, int in_mode, const float* in_scale, const float* in_shift, void* y,

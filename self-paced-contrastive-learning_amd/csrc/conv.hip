@@ -245,8 +245,22 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
 // kind 1 (dgrad):    A[cout=ci][k=(tap,co)]     = W[co][ci][8-tap]        (roles of Cin/Cout swapped by the caller)
 template <typename T>
 __device__ __forceinline__ float pack_value(const float* __restrict__ w, int Cin, int Cout, int kind, int KinK, int NoutS,
-                                            size_t idx) {
+                                            size_t idx, bool gemm) {
   constexpr int EPC = Chunk<T>::EPC;
+  if (gemm) {
+    // conv_gemm.hip: packed[slab][tap][32-channel output tile][ks][lane][8]: lane (n32 = output channel in the tile,
+    // kh = lane / 32) holds input channels 64 slab + 16 ks + 8 kh .. +7 of tap `tap` -- one 1 KiB piece per A fragment
+    size_t r = idx;
+    const int e = (int)(r % 8); r /= 8;
+    const int lane = (int)(r % 64); r /= 64;
+    const int ks = (int)(r % 4); r /= 4;
+    const int cot = (int)(r % (NoutS >> 5)); r /= (NoutS >> 5);
+    const int tap = (int)(r % 9); r /= 9;
+    const int slab = (int)r;
+    const int kch = slab * 64 + ks * 16 + (lane >> 5) * 8 + e, nch = cot * 32 + (lane & 31);
+    if (kind == 0) return (kch < Cin && nch < Cout) ? w[((size_t)nch * Cin + kch) * 9 + tap] : 0.f;
+    return (kch < Cout && nch < Cin) ? w[((size_t)kch * Cin + nch) * 9 + (8 - tap)] : 0.f;
+  }
   const int KC = conv_kc(KinK);
   const int CP = KC / EPC;
   const int nsteps = conv_nsteps<T>(KC);
@@ -275,20 +289,21 @@ __device__ __forceinline__ float pack_value(const float* __restrict__ w, int Cin
 
 template <typename T>
 __global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict__ w, int Cin, int Cout, int kind,
-                                                        int KinK, int NoutS, T* __restrict__ packed, size_t total) {
+                                                        int KinK, int NoutS, T* __restrict__ packed, size_t total,
+                                                        bool gemm) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
-  Elem<T>::store(packed + idx, pack_value<T>(w, Cin, Cout, kind, KinK, NoutS, idx));
+  Elem<T>::store(packed + idx, pack_value<T>(w, Cin, Cout, kind, KinK, NoutS, idx, gemm));
 }
 
 // forward (kind 0) and dgrad (kind 1) layouts of one layer in one launch
 template <typename T>
 __global__ __launch_bounds__(256) void conv_pack_both_kernel(const float* __restrict__ w, int Cin, int Cout, int CinK,
                                                              int CoutS, T* __restrict__ p0, size_t t0,
-                                                             T* __restrict__ p1, size_t t1) {
+                                                             T* __restrict__ p1, size_t t1, bool gemm) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < t0) Elem<T>::store(p0 + idx, pack_value<T>(w, Cin, Cout, 0, CinK, CoutS, idx));
-  else if (idx < t0 + t1) Elem<T>::store(p1 + idx - t0, pack_value<T>(w, Cin, Cout, 1, CoutS, CinK, idx - t0));
+  if (idx < t0) Elem<T>::store(p0 + idx, pack_value<T>(w, Cin, Cout, 0, CinK, CoutS, idx, gemm));
+  else if (idx < t0 + t1) Elem<T>::store(p1 + idx - t0, pack_value<T>(w, Cin, Cout, 1, CoutS, CinK, idx - t0, gemm));
 }
 
 // the two convolutions of a block (forward + dgrad layouts each) in one launch
@@ -297,17 +312,18 @@ __global__ __launch_bounds__(256) void conv_pack_block_kernel(const float* __res
                                                               T* __restrict__ a0, size_t ta0, T* __restrict__ a1,
                                                               size_t ta1, const float* __restrict__ wb, int CinB,
                                                               int CoutB, T* __restrict__ b0, size_t tb0,
-                                                              T* __restrict__ b1, size_t tb1) {
+                                                              T* __restrict__ b1, size_t tb1, bool gemm_a,
+                                                              bool gemm_b) {
   size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int CinKA = (CinA + 15) / 16 * 16, CoutSA = (CoutA + 15) / 16 * 16;
   const int CinKB = (CinB + 15) / 16 * 16, CoutSB = (CoutB + 15) / 16 * 16;
-  if (idx < ta0) { Elem<T>::store(a0 + idx, pack_value<T>(wa, CinA, CoutA, 0, CinKA, CoutSA, idx)); return; }
+  if (idx < ta0) { Elem<T>::store(a0 + idx, pack_value<T>(wa, CinA, CoutA, 0, CinKA, CoutSA, idx, gemm_a)); return; }
   idx -= ta0;
-  if (idx < ta1) { Elem<T>::store(a1 + idx, pack_value<T>(wa, CinA, CoutA, 1, CoutSA, CinKA, idx)); return; }
+  if (idx < ta1) { Elem<T>::store(a1 + idx, pack_value<T>(wa, CinA, CoutA, 1, CoutSA, CinKA, idx, gemm_a)); return; }
   idx -= ta1;
-  if (idx < tb0) { Elem<T>::store(b0 + idx, pack_value<T>(wb, CinB, CoutB, 0, CinKB, CoutSB, idx)); return; }
+  if (idx < tb0) { Elem<T>::store(b0 + idx, pack_value<T>(wb, CinB, CoutB, 0, CinKB, CoutSB, idx, gemm_b)); return; }
   idx -= tb0;
-  if (idx < tb1) Elem<T>::store(b1 + idx, pack_value<T>(wb, CinB, CoutB, 1, CoutSB, CinKB, idx));
+  if (idx < tb1) Elem<T>::store(b1 + idx, pack_value<T>(wb, CinB, CoutB, 1, CoutSB, CinKB, idx, gemm_b));
 }
 
 template <typename T> static size_t packed_elems(int KinK, int NoutS) {
@@ -370,6 +386,7 @@ static int launch_conv(const ConvArgs& a0, hipStream_t st) {
 
 template <typename T>
 static int launch_conv_t(const ConvArgs& a, hipStream_t st) {
+  if (sizeof(T) == 2 && conv_use_gemm(a.CinK, a.CoutS)) return launch_conv_gemm(a, st) ? 0 : 1;
   TileCfg t = pick_tile(a.H, a.W);
   static const int no_fast = getenv("SPCL_CONV_NO_FAST") ? atoi(getenv("SPCL_CONV_NO_FAST")) : 0;
   if (sizeof(T) == 2 && t.tw == 14 && !no_fast && launch_conv_fast(a, t.th, st)) return 0;
@@ -388,6 +405,13 @@ extern "C" int spcl_conv_num_tiles(int N, int H, int W) {
   return N * cdiv(H, t.th) * cdiv(W, t.tw);
 }
 
+extern "C" void spcl_conv_set_gemm(int on) { conv_set_gemm(on); }
+
+extern "C" int spcl_conv_stat_rows(int dtype, int N, int H, int W, int CinK, int CoutS) {
+  if (dtype == SPCL_BF16 && conv_use_gemm(CinK, CoutS)) return conv_gemm_stat_rows(N, H, W, CinK, CoutS);
+  return spcl_conv_num_tiles(N, H, W);
+}
+
 extern "C" size_t spcl_conv_packed_elems(int Cin, int Cout, int kind, int dtype) {
   const int KinK = round_up(kind == 0 ? Cin : Cout, 16), NoutS = round_up(kind == 0 ? Cout : Cin, 16);
   return dtype == SPCL_F32 ? packed_elems<float>(KinK, NoutS) : packed_elems<bf16_t>(KinK, NoutS);
@@ -402,11 +426,11 @@ extern "C" int spcl_conv_pack_weights(const float* w_oihw, int Cin, int Cout, in
   if (dtype == SPCL_F32) {
     size_t total = packed_elems<float>(KinK, NoutS);
     SPCL_LAUNCH(conv_pack_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w_oihw, Cin,
-                       Cout, kind, KinK, NoutS, (float*)packed, total);
+                       Cout, kind, KinK, NoutS, (float*)packed, total, false);
   } else if (dtype == SPCL_BF16) {
     size_t total = packed_elems<bf16_t>(KinK, NoutS);
     SPCL_LAUNCH(conv_pack_kernel<bf16_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w_oihw, Cin,
-                       Cout, kind, KinK, NoutS, (bf16_t*)packed, total);
+                       Cout, kind, KinK, NoutS, (bf16_t*)packed, total, conv_use_gemm(KinK, NoutS));
   } else {
     set_error("conv_pack_weights: dtype %d", dtype);
     return SPCL_EINVAL;
@@ -424,11 +448,12 @@ extern "C" int spcl_conv_pack_weights_both(const float* w_oihw, int Cin, int Cou
   if (dtype == SPCL_F32) {
     const size_t t0 = packed_elems<float>(CinK, CoutS), t1 = packed_elems<float>(CoutS, CinK);
     SPCL_LAUNCH(conv_pack_both_kernel<float>, dim3((unsigned)((t0 + t1 + 255) / 256)), dim3(256), 0, st, w_oihw,
-                       Cin, Cout, CinK, CoutS, (float*)packed_fwd, t0, (float*)packed_dgrad, t1);
+                       Cin, Cout, CinK, CoutS, (float*)packed_fwd, t0, (float*)packed_dgrad, t1, false);
   } else if (dtype == SPCL_BF16) {
     const size_t t0 = packed_elems<bf16_t>(CinK, CoutS), t1 = packed_elems<bf16_t>(CoutS, CinK);
     SPCL_LAUNCH(conv_pack_both_kernel<bf16_t>, dim3((unsigned)((t0 + t1 + 255) / 256)), dim3(256), 0, st,
-                       w_oihw, Cin, Cout, CinK, CoutS, (bf16_t*)packed_fwd, t0, (bf16_t*)packed_dgrad, t1);
+                       w_oihw, Cin, Cout, CinK, CoutS, (bf16_t*)packed_fwd, t0, (bf16_t*)packed_dgrad, t1,
+                       conv_use_gemm(CinK, CoutS));
   } else {
     set_error("conv_pack_weights_both: dtype %d", dtype);
     return SPCL_EINVAL;
@@ -449,13 +474,13 @@ extern "C" int spcl_conv_pack_weights_block(const float* wa_oihw, int CinA, int 
     const size_t tb0 = packed_elems<float>(kb, sb), tb1 = packed_elems<float>(sb, kb);
     SPCL_LAUNCH(conv_pack_block_kernel<float>, dim3((unsigned)((ta0 + ta1 + tb0 + tb1 + 255) / 256)), dim3(256), 0, st,
                 wa_oihw, CinA, CoutA, (float*)a_fwd, ta0, (float*)a_dgrad, ta1, wb_oihw, CinB, CoutB, (float*)b_fwd, tb0,
-                (float*)b_dgrad, tb1);
+                (float*)b_dgrad, tb1, false, false);
   } else if (dtype == SPCL_BF16) {
     const size_t ta0 = packed_elems<bf16_t>(ka, sa), ta1 = packed_elems<bf16_t>(sa, ka);
     const size_t tb0 = packed_elems<bf16_t>(kb, sb), tb1 = packed_elems<bf16_t>(sb, kb);
     SPCL_LAUNCH(conv_pack_block_kernel<bf16_t>, dim3((unsigned)((ta0 + ta1 + tb0 + tb1 + 255) / 256)), dim3(256), 0, st,
                 wa_oihw, CinA, CoutA, (bf16_t*)a_fwd, ta0, (bf16_t*)a_dgrad, ta1, wb_oihw, CinB, CoutB, (bf16_t*)b_fwd,
-                tb0, (bf16_t*)b_dgrad, tb1);
+                tb0, (bf16_t*)b_dgrad, tb1, conv_use_gemm(ka, sa), conv_use_gemm(kb, sb));
   } else {
     set_error("conv_pack_weights_block: dtype %d", dtype);
     return SPCL_EINVAL;
@@ -489,11 +514,16 @@ extern "C" int spcl_conv3x3_forward(const void* x, int dtype, int N, int H, int 
     prof_cost(px * ((in_mode == 2 ? CinS * 4.0 : CinK * es) + CoutS * es) + 9.0 * CinK * CoutS * es,
               2.0 * px * 9.0 * cin * CoutS);
   }
-  if (dtype == SPCL_F32) launch_conv_t<float>(a, st);
-  else if (dtype == SPCL_BF16) launch_conv_t<bf16_t>(a, st);
+  int rc = 0;
+  if (dtype == SPCL_F32) rc = launch_conv_t<float>(a, st);
+  else if (dtype == SPCL_BF16) rc = launch_conv_t<bf16_t>(a, st);
   else {
     set_error("conv3x3_forward: dtype %d", dtype);
     return SPCL_EINVAL;
+  }
+  if (rc != 0) {
+    set_error("conv3x3_forward: no kernel for N=%d H=%d W=%d CinK=%d CoutS=%d in_mode=%d", N, H, W, CinK, CoutS, in_mode);
+    return SPCL_EUNSUPPORTED;
   }
   SPCL_LAUNCH_CHECK("conv3x3_forward");
   return SPCL_OK;
@@ -518,6 +548,7 @@ extern "C" int spcl_conv_dgrad_bnstats_supported(int dtype, int N, int H, int W,
   static const bool off = getenv("SPCL_NO_DGRAD_BNSTATS") != nullptr;  // A/B switch
   ConvArgs a;
   if (off || !dgrad_bnstats_args(a, dtype, N, H, W, CinK, CoutS)) return 0;
+  if (conv_use_gemm(CinK, CoutS)) return 1;
   a.x = nullptr; a.y = nullptr; a.wp = nullptr;
   float dummy;
   a.rows2 = &dummy;
@@ -540,7 +571,12 @@ extern "C" int spcl_conv3x3_dgrad_bnstats(const void* dy, int dtype, int N, int 
   const double px = (double)N * H * W;
   prof_cost(px * (CinK + 2.0 * CoutS) * 2.0 + 9.0 * CinK * CoutS * 2.0, 2.0 * px * 9.0 * CinK * CoutS);
   TileCfg t = pick_tile(H, W);
-  if (!(t.tw == 14 && launch_conv_fast(a, t.th, st))) {
+  if (conv_use_gemm(CinK, CoutS)) {
+    if (!launch_conv_gemm(a, st)) {
+      set_error("conv3x3_dgrad_bnstats: H=%d W=%d CinK=%d CoutS=%d outside the gemm kernel's range", H, W, CinK, CoutS);
+      return SPCL_EUNSUPPORTED;
+    }
+  } else if (!(t.tw == 14 && launch_conv_fast(a, t.th, st))) {
     set_error("conv3x3_dgrad_bnstats: no specialised kernel for H=%d W=%d CinK=%d CoutS=%d", H, W, CinK, CoutS);
     return SPCL_EUNSUPPORTED;
   }

@@ -125,4 +125,11 @@ __device__ __forceinline__ void write_tile_stats(float* stats, int tile, int Cou
 // conv_fast.hip: returns true when a specialised kernel exists for this configuration and was launched
 bool launch_conv_fast(const ConvArgs& a, int th, hipStream_t st, bool dry = false);
 
+// conv_gemm.hip: the bf16 layers with >= 64 input and output channels (multiples of 64).  conv_use_gemm decides the
+// packed weight layout too (conv.hip pack_value), so a layer it accepts has no other kernel.
+bool conv_use_gemm(int CinK, int CoutS);
+void conv_set_gemm(int on);
+bool launch_conv_gemm(const ConvArgs& a, hipStream_t st);
+int conv_gemm_stat_rows(int N, int H, int W, int CinK, int CoutS);
+
 }  // namespace spcl

@@ -411,7 +411,7 @@ def _conv(x_store, dt_code, dtype, N, H, W, cin_s, cin_k, cout_s, wp, in_mode, s
     stats = None
     if want_stats:
         # rows [tile][3][cout_s] of Chan partials (+ the finalize kernel's scratch rows), see include/spcl_hip.h
-        nt = _n.call("spcl_conv_num_tiles", N, H, W)
+        nt = _n.call("spcl_conv_stat_rows", dt_code, N, H, W, cin_k, cout_s)
         stats = torch.empty(_n.call("spcl_bn_stats_elems", nt, cout_s), dtype=torch.float32, device=dev)
         stats.ntiles = nt
     _n.call("spcl_conv3x3_forward", _n.ptr(x_store), dt_code, N, H, W, cin_s, cin_k, cout_s, _n.ptr(wp), in_mode,
@@ -550,7 +550,7 @@ def _dgrad_bnstats(dy, wp_t, y2, st2, dt_code, dtype, N, H, W, cin_k, cout_s):
     if not _n.call("spcl_conv_dgrad_bnstats_supported", dt_code, N, H, W, cin_k, cout_s):
         return None
     dev = dy.device
-    nt = _n.call("spcl_conv_num_tiles", N, H, W)
+    nt = _n.call("spcl_conv_stat_rows", dt_code, N, H, W, cin_k, cout_s)
     g = torch.empty(N, H, W, cout_s, dtype=dtype, device=dev)
     rows = torch.empty(nt * 2 * cout_s, dtype=torch.float32, device=dev)
     _n.call("spcl_conv3x3_dgrad_bnstats", _n.ptr(dy), dt_code, N, H, W, cin_k, cout_s, _n.ptr(wp_t), _n.ptr(g),

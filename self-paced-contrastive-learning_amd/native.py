@@ -43,6 +43,8 @@ _SIGNATURES = {
     "spcl_conv_pack_weights_both": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
     "spcl_conv_pack_weights_block": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, c_int, _P, _P, c_int, _P]),
     "spcl_conv_num_tiles": (c_int, [c_int, c_int, c_int]),
+    "spcl_conv_stat_rows": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "spcl_conv_set_gemm": (None, [c_int]),
     "spcl_bn_stats_elems": (c_size_t, [c_int, c_int]),
     "spcl_conv3x3_forward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P,
                                      _P]),
@@ -98,7 +100,7 @@ class WgradItem(ctypes.Structure):
 
 
 WGRAD_BATCH_MAX = 8
-_NO_STATUS = ("spcl_abi_version", "spcl_conv_num_tiles", "spcl_profile_count", "spcl_conv_dgrad_bnstats_supported",
+_NO_STATUS = ("spcl_abi_version", "spcl_conv_num_tiles", "spcl_conv_stat_rows", "spcl_conv_set_gemm", "spcl_profile_count", "spcl_conv_dgrad_bnstats_supported",
               "spcl_conv_wgrad_batched_supported")
 
 

@@ -55,7 +55,7 @@ def conv(n, xs, dtype, N, H, W, cin_s, cin_k, cout_s, wp, mode, scale=None, shif
     y = torch.empty(N, H, W, cout_s, dtype=dtype, device="cuda")
     st = None
     if stats:
-        nt = n.call("spcl_conv_num_tiles", N, H, W)
+        nt = n.call("spcl_conv_stat_rows", n.dtype_code(dtype), N, H, W, cin_k, cout_s)
         st = torch.empty(n.call("spcl_bn_stats_elems", nt, cout_s), dtype=torch.float32, device="cuda")
         st.ntiles = nt
     n.call("spcl_conv3x3_forward", n.ptr(xs), n.dtype_code(dtype), N, H, W, cin_s, cin_k, cout_s, n.ptr(wp), mode,
@@ -66,12 +66,48 @@ def conv(n, xs, dtype, N, H, W, cin_s, cin_k, cout_s, wp, mode, scale=None, shif
 SHAPES = [(2, 16, 16, 28, 28), (1, 32, 64, 20, 18), (2, 128, 64, 14, 14), (1, 64, 256, 7, 9), (3, 8, 24, 33, 16),
           (1, 256, 256, 14, 14), (2, 32, 32, 21, 42), (1, 64, 128, 35, 14), (1, 16, 32, 126, 28), (1, 32, 16, 238, 14),
           # sizes that are not a multiple of the 14-column tiles: shifted last tiles of the specialised kernels
-          (1, 16, 16, 60, 44), (2, 32, 64, 50, 30), (1, 16, 16, 256, 64), (1, 64, 64, 64, 64), (1, 128, 128, 32, 128)]
+          (1, 16, 16, 60, 44), (2, 32, 64, 50, 30), (1, 16, 16, 256, 64), (1, 64, 64, 64, 64), (1, 128, 128, 32, 128),
+          # the >= 64-channel bf16 layers (workgroup-level GEMM kernel): the encoder's sizes, the 256^2 family's, odd ones
+          (2, 64, 64, 56, 56), (2, 64, 128, 28, 28), (3, 128, 128, 28, 28), (2, 128, 256, 14, 14), (2, 256, 256, 16, 16),
+          (1, 64, 64, 9, 5), (1, 192, 64, 3, 70), (1, 64, 192, 1, 1), (1, 128, 64, 130, 66)]
+
+
+GEMM_SHAPES = [s_ for s_ in SHAPES if s_[1] % 64 == 0 and s_[2] % 64 == 0 and max(s_[1], s_[2]) >= 128]
+
+
+@pytest.fixture
+def gemm_conv():
+    """the experimental workgroup-level GEMM kernel of the >= 64-channel bf16 layers (off by default); the switch also
+    selects the packed weight layout, so it is flipped before anything is packed and restored afterwards"""
+    n = _n()
+    n.call("spcl_conv_set_gemm", 1)
+    yield n
+    n.call("spcl_conv_set_gemm", 0)
+
+
+@pytest.mark.parametrize("N,ci,co,H,W", GEMM_SHAPES)
+def test_conv_gemm_forward_dgrad(gemm_conv, N, ci, co, H, W):
+    _fwd_body("bf16", N, ci, co, H, W)
+    _dgrad_body("bf16", N, ci, co, H, W)
+
+
+@pytest.mark.parametrize("N,ci,co,H,W", [(2, 128, 128, 28, 28), (1, 256, 64, 14, 14), (1, 64, 128, 30, 17)])
+def test_conv_gemm_fused_bnrelu_input(gemm_conv, N, ci, co, H, W):
+    _fused_in_body("bf16", N, ci, co, H, W)
+
+
+@pytest.mark.parametrize("N,C,H,W", [(1, 128, 28, 14), (2, 256, 14, 14), (1, 128, 33, 20)])
+def test_conv_gemm_dgrad_with_fused_bn_backward_sums(gemm_conv, N, C, H, W):
+    _dgrad_bn_body(N, C, H, W)
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("N,ci,co,H,W", SHAPES)
 def test_conv_forward_raw_and_stats(dt, N, ci, co, H, W):
+    _fwd_body(dt, N, ci, co, H, W)
+
+
+def _fwd_body(dt, N, ci, co, H, W):
     n = _n()
     dtype = DT[dt]
     g = torch.Generator().manual_seed(ci * 1000 + co + H)
@@ -97,10 +133,15 @@ def test_conv_forward_raw_and_stats(dt, N, ci, co, H, W):
 
 
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
-def test_conv_forward_fused_bnrelu_input(dt):
+@pytest.mark.parametrize("N,ci,co,H,W", [(2, 32, 48, 28, 28), (2, 128, 128, 28, 28), (1, 256, 64, 14, 14),
+                                         (1, 64, 64, 30, 17)])
+def test_conv_forward_fused_bnrelu_input(dt, N, ci, co, H, W):
+    _fused_in_body(dt, N, ci, co, H, W)
+
+
+def _fused_in_body(dt, N, ci, co, H, W):
     n = _n()
     dtype = DT[dt]
-    N, ci, co, H, W = 2, 32, 48, 28, 28
     g = torch.Generator().manual_seed(3)
     x = rnd(torch.randn(N, ci, H, W, generator=g), dtype)
     w = rnd(torch.randn(co, ci, 3, 3, generator=g) / 17, dtype)
@@ -108,7 +149,7 @@ def test_conv_forward_fused_bnrelu_input(dt):
     act = rnd(torch.relu(x * sc[None, :, None, None] + sh[None, :, None, None]), dtype)  # staged value is rounded
     ref = F.conv2d(act.double(), w.double(), None, 1, 1).float()
     xs, wp, scd, shd = nhwc(x, dtype), pack(n, w, 0, dtype), sc.cuda(), sh.cuda()
-    y, _ = conv(n, xs, dtype, N, H, W, 32, 32, 48, wp, 1, scd, shd)
+    y, _ = conv(n, xs, dtype, N, H, W, ci, ci, co, wp, 1, scd, shd)
     assert relerr(y.permute(0, 3, 1, 2).float().cpu(), ref) < TOL[dt]
 
 
@@ -131,6 +172,10 @@ def test_conv_forward_image_mode(dt, ci):
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("N,ci,co,H,W", SHAPES)
 def test_conv_dgrad(dt, N, ci, co, H, W):
+    _dgrad_body(dt, N, ci, co, H, W)
+
+
+def _dgrad_body(dt, N, ci, co, H, W):
     n = _n()
     dtype = DT[dt]
     g = torch.Generator().manual_seed(ci + co + W)
@@ -409,8 +454,12 @@ def test_bn_finalize_many_tiles_all_launch_shapes(ntiles, C):
 
 
 @pytest.mark.parametrize("N,C,H,W", [(2, 16, 28, 28), (1, 32, 56, 28), (2, 64, 14, 14), (1, 128, 28, 14), (3, 16, 224, 42),
-                                     (9, 16, 224, 224)])
+                                     (9, 16, 224, 224), (2, 256, 14, 14), (1, 64, 56, 56), (1, 128, 33, 20)])
 def test_dgrad_with_fused_bn_backward_sums(N, C, H, W):
+    _dgrad_bn_body(N, C, H, W)
+
+
+def _dgrad_bn_body(N, C, H, W):
     """spcl_conv3x3_dgrad_bnstats + spcl_bnrelu_backward_rows against the three-kernel path they replace (plain dgrad,
     BN-backward reduction pass, apply): g bit-identical, dgamma / dbeta / dy equal up to summation order."""
     n = _n()
@@ -436,7 +485,7 @@ def test_dgrad_with_fused_bn_backward_sums(N, C, H, W):
     n.call("spcl_bnrelu_pool_backward", n.ptr(y2), n.ptr(g_ref), None, dtc, N, H, W, C, cs, n.ptr(st[0]), n.ptr(st[1]),
            n.ptr(st[2]), n.ptr(st[3]), 1, n.ptr(ws), n.ptr(dg0), n.ptr(db0), n.ptr(dy0), n.stream())
     # fused path
-    nt = n.call("spcl_conv_num_tiles", N, H, W)
+    nt = n.call("spcl_conv_stat_rows", dtc, N, H, W, cs, cs)
     g1 = torch.empty(N, H, W, cs, dtype=dtype, device="cuda")
     rows = torch.full((nt * 2 * cs,), float("nan"), device="cuda")
     n.call("spcl_conv3x3_dgrad_bnstats", n.ptr(dy_in), dtc, N, H, W, cs, cs, n.ptr(wp_t), n.ptr(g1), n.ptr(y2),

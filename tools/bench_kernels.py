@@ -48,7 +48,7 @@ def main():
             wp = torch.empty(n.call("spcl_conv_packed_elems", ci, co, 0, dtc), dtype=dtype, device="cuda")
             n.call("spcl_conv_pack_weights", n.ptr(w), ci, co, 0, dtc, n.ptr(wp), n.stream())
             y = torch.empty(N, H, W, cs_o, dtype=dtype, device="cuda")
-            nt_ = n.call("spcl_conv_num_tiles", N, H, W)
+            nt_ = n.call("spcl_conv_stat_rows", dtc, N, H, W, 16 if img else cs_i, cs_o)
             st = torch.empty(n.call("spcl_bn_stats_elems", nt_, cs_o), device="cuda")
             mode = 2 if img else 1
             t = timeit(lambda: n.call("spcl_conv3x3_forward", n.ptr(x), dtc, N, H, W, ci if img else cs_i, 16 if img else cs_i,
