@@ -128,12 +128,13 @@ int spcl_conv_pack_weights_block(const float* wa_oihw, int CinA, int CoutA, void
  * kernel's partial rows). */
 int spcl_conv_num_tiles(int N, int H, int W);
 /* Statistics rows the convolution of this configuration writes (stats [rows][3][CoutS], rows2 [rows][2][CoutS]): the
- * pixel tiles above, except for the bf16 layers with >= 64 input and output channels (multiples of 64), whose
- * workgroup-level GEMM kernel (csrc/conv_gemm.hip) writes one row per (image band, pixel half). */
+ * pixel tiles above, except where the workgroup-level GEMM kernel runs (csrc/conv_gemm.hip: bf16, channel counts
+ * multiples of 64 with one side >= 128, see spcl_conv_set_gemm), which writes one row per (image band, pixel part). */
 int spcl_conv_stat_rows(int dtype, int N, int H, int W, int CinK, int CoutS);
-/* Experimental workgroup-level GEMM kernel for those layers (csrc/conv_gemm.hip), off by default (also SPCL_CONV_GEMM=1).
- * Switch it BEFORE packing weights: the packed layout of the layers it takes follows the switch. */
-void spcl_conv_set_gemm(int on);
+/* Which kernel takes those layers: -1 (default, also SPCL_CONV_GEMM unset) the GEMM kernel only at image sizes the
+ * per-wave kernels have no specialisation for (widths that do not tile by 14 columns: the 32^2 / 16^2 levels of 256^2
+ * inputs), 1 (SPCL_CONV_GEMM=1) wherever it fits, 0 never.  Packed weights are valid under every setting. */
+void spcl_conv_set_gemm(int mode);
 size_t spcl_bn_stats_elems(int ntiles, int CS);
 int spcl_conv3x3_forward(const void* x, int dtype, int N, int H, int W, int CinS, int CinK, int CoutS,
                          const void* w_packed, int in_mode, const float* in_scale, const float* in_shift, void* y,

@@ -247,10 +247,11 @@ template <typename T>
 __device__ __forceinline__ float pack_value(const float* __restrict__ w, int Cin, int Cout, int kind, int KinK, int NoutS,
                                             size_t idx, bool gemm) {
   constexpr int EPC = Chunk<T>::EPC;
-  if (gemm) {
-    // conv_gemm.hip: packed[slab][tap][32-channel output tile][ks][lane][8]: lane (n32 = output channel in the tile,
-    // kh = lane / 32) holds input channels 64 slab + 16 ks + 8 kh .. +7 of tap `tap` -- one 1 KiB piece per A fragment
-    size_t r = idx;
+  if (gemm && idx >= (size_t)9 * KinK * NoutS) {
+    // second half of a dual-layout buffer, for conv_gemm.hip: packed[slab][tap][32-channel output tile][ks][lane][8]:
+    // lane (n32 = output channel in the tile, kh = lane / 32) holds input channels 64 slab + 16 ks + 8 kh .. +7 of tap
+    // `tap` -- one 1 KiB piece per A fragment
+    size_t r = idx - (size_t)9 * KinK * NoutS;
     const int e = (int)(r % 8); r /= 8;
     const int lane = (int)(r % 64); r /= 64;
     const int ks = (int)(r % 4); r /= 4;
@@ -326,9 +327,12 @@ __global__ __launch_bounds__(256) void conv_pack_block_kernel(const float* __res
   if (idx < tb1) Elem<T>::store(b1 + idx, pack_value<T>(wb, CinB, CoutB, 1, CoutSB, CinKB, idx, gemm_b));
 }
 
+// bf16 layers the workgroup-level GEMM kernel can take (conv_gemm.hip) carry BOTH layouts, the per-wave kernels' first:
+// which kernel runs is decided per launch from the image size (conv_use_gemm), the weights do not know it
 template <typename T> static size_t packed_elems(int KinK, int NoutS) {
   const int KC = conv_kc(KinK);
-  return (size_t)(KinK / KC) * conv_nsteps<T>(KC) * (NoutS / 16) * 64 * Chunk<T>::EPC;
+  const size_t one = (size_t)(KinK / KC) * conv_nsteps<T>(KC) * (NoutS / 16) * 64 * Chunk<T>::EPC;
+  return (sizeof(T) == 2 && conv_gemm_channels(KinK, NoutS)) ? 2 * one : one;
 }
 
 struct TileCfg { int th, tw; };
@@ -350,6 +354,21 @@ static TileCfg pick_tile(int H, int W) {
   if (H >= th && W >= 14 && (long)cdiv(H, th) * th * cdiv(W, 14) * 14 * 100 <= (long)H * W * (100 + max_overlap))
     return {th, 14};
   return {16, 16};
+}
+
+// Which kernel takes a bf16 layer with GEMM-eligible channels: the workgroup-level GEMM kernel where the per-wave
+// kernels have no specialisation for the image size (widths that are not 14-column tileable: 32^2, 16^2 of the 256^2
+// family, where the generic kernel is 2-3x slower), or everywhere when forced (spcl_conv_set_gemm(1) / SPCL_CONV_GEMM=1:
+// at the 14-column sizes it is at parity or slower, profiles/r02_conv_gemm_notes.md); never with 0.
+static int g_gemm_mode = -2;  // -2: read the environment on first use; -1 auto; 0 never; 1 always
+void conv_set_gemm(int mode) { g_gemm_mode = mode < 0 ? -1 : (mode > 0 ? 1 : 0); }
+bool conv_use_gemm(int CinK, int CoutS, int H, int W) {
+  if (g_gemm_mode == -2) {
+    const char* e = getenv("SPCL_CONV_GEMM");
+    g_gemm_mode = e == nullptr ? -1 : (atoi(e) > 0 ? 1 : 0);
+  }
+  if (g_gemm_mode == 0 || !conv_gemm_channels(CinK, CoutS) || !conv_gemm_fits(H, W, CinK, CoutS)) return false;
+  return g_gemm_mode == 1 || pick_tile(H, W).tw != 14;
 }
 
 template <typename T, int TH, int TW>
@@ -386,7 +405,7 @@ static int launch_conv(const ConvArgs& a0, hipStream_t st) {
 
 template <typename T>
 static int launch_conv_t(const ConvArgs& a, hipStream_t st) {
-  if (sizeof(T) == 2 && conv_use_gemm(a.CinK, a.CoutS)) return launch_conv_gemm(a, st) ? 0 : 1;
+  if (sizeof(T) == 2 && conv_use_gemm(a.CinK, a.CoutS, a.H, a.W)) return launch_conv_gemm(a, st) ? 0 : 1;
   TileCfg t = pick_tile(a.H, a.W);
   static const int no_fast = getenv("SPCL_CONV_NO_FAST") ? atoi(getenv("SPCL_CONV_NO_FAST")) : 0;
   if (sizeof(T) == 2 && t.tw == 14 && !no_fast && launch_conv_fast(a, t.th, st)) return 0;
@@ -408,7 +427,7 @@ extern "C" int spcl_conv_num_tiles(int N, int H, int W) {
 extern "C" void spcl_conv_set_gemm(int on) { conv_set_gemm(on); }
 
 extern "C" int spcl_conv_stat_rows(int dtype, int N, int H, int W, int CinK, int CoutS) {
-  if (dtype == SPCL_BF16 && conv_use_gemm(CinK, CoutS)) return conv_gemm_stat_rows(N, H, W, CinK, CoutS);
+  if (dtype == SPCL_BF16 && conv_use_gemm(CinK, CoutS, H, W)) return conv_gemm_stat_rows(N, H, W, CinK, CoutS);
   return spcl_conv_num_tiles(N, H, W);
 }
 
@@ -430,7 +449,7 @@ extern "C" int spcl_conv_pack_weights(const float* w_oihw, int Cin, int Cout, in
   } else if (dtype == SPCL_BF16) {
     size_t total = packed_elems<bf16_t>(KinK, NoutS);
     SPCL_LAUNCH(conv_pack_kernel<bf16_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w_oihw, Cin,
-                       Cout, kind, KinK, NoutS, (bf16_t*)packed, total, conv_use_gemm(KinK, NoutS));
+                       Cout, kind, KinK, NoutS, (bf16_t*)packed, total, conv_gemm_channels(KinK, NoutS));
   } else {
     set_error("conv_pack_weights: dtype %d", dtype);
     return SPCL_EINVAL;
@@ -453,7 +472,7 @@ extern "C" int spcl_conv_pack_weights_both(const float* w_oihw, int Cin, int Cou
     const size_t t0 = packed_elems<bf16_t>(CinK, CoutS), t1 = packed_elems<bf16_t>(CoutS, CinK);
     SPCL_LAUNCH(conv_pack_both_kernel<bf16_t>, dim3((unsigned)((t0 + t1 + 255) / 256)), dim3(256), 0, st,
                        w_oihw, Cin, Cout, CinK, CoutS, (bf16_t*)packed_fwd, t0, (bf16_t*)packed_dgrad, t1,
-                       conv_use_gemm(CinK, CoutS));
+                       conv_gemm_channels(CinK, CoutS));
   } else {
     set_error("conv_pack_weights_both: dtype %d", dtype);
     return SPCL_EINVAL;
@@ -480,7 +499,7 @@ extern "C" int spcl_conv_pack_weights_block(const float* wa_oihw, int CinA, int 
     const size_t tb0 = packed_elems<bf16_t>(kb, sb), tb1 = packed_elems<bf16_t>(sb, kb);
     SPCL_LAUNCH(conv_pack_block_kernel<bf16_t>, dim3((unsigned)((ta0 + ta1 + tb0 + tb1 + 255) / 256)), dim3(256), 0, st,
                 wa_oihw, CinA, CoutA, (bf16_t*)a_fwd, ta0, (bf16_t*)a_dgrad, ta1, wb_oihw, CinB, CoutB, (bf16_t*)b_fwd,
-                tb0, (bf16_t*)b_dgrad, tb1, conv_use_gemm(ka, sa), conv_use_gemm(kb, sb));
+                tb0, (bf16_t*)b_dgrad, tb1, conv_gemm_channels(ka, sa), conv_gemm_channels(kb, sb));
   } else {
     set_error("conv_pack_weights_block: dtype %d", dtype);
     return SPCL_EINVAL;
@@ -548,7 +567,7 @@ extern "C" int spcl_conv_dgrad_bnstats_supported(int dtype, int N, int H, int W,
   static const bool off = getenv("SPCL_NO_DGRAD_BNSTATS") != nullptr;  // A/B switch
   ConvArgs a;
   if (off || !dgrad_bnstats_args(a, dtype, N, H, W, CinK, CoutS)) return 0;
-  if (conv_use_gemm(CinK, CoutS)) return 1;
+  if (conv_use_gemm(CinK, CoutS, H, W)) return 1;
   a.x = nullptr; a.y = nullptr; a.wp = nullptr;
   float dummy;
   a.rows2 = &dummy;
@@ -571,7 +590,7 @@ extern "C" int spcl_conv3x3_dgrad_bnstats(const void* dy, int dtype, int N, int 
   const double px = (double)N * H * W;
   prof_cost(px * (CinK + 2.0 * CoutS) * 2.0 + 9.0 * CinK * CoutS * 2.0, 2.0 * px * 9.0 * CinK * CoutS);
   TileCfg t = pick_tile(H, W);
-  if (conv_use_gemm(CinK, CoutS)) {
+  if (conv_use_gemm(CinK, CoutS, H, W)) {
     if (!launch_conv_gemm(a, st)) {
       set_error("conv3x3_dgrad_bnstats: H=%d W=%d CinK=%d CoutS=%d outside the gemm kernel's range", H, W, CinK, CoutS);
       return SPCL_EUNSUPPORTED;

@@ -125,10 +125,15 @@ __device__ __forceinline__ void write_tile_stats(float* stats, int tile, int Cou
 // conv_fast.hip: returns true when a specialised kernel exists for this configuration and was launched
 bool launch_conv_fast(const ConvArgs& a, int th, hipStream_t st, bool dry = false);
 
-// conv_gemm.hip: the bf16 layers with >= 64 input and output channels (multiples of 64).  conv_use_gemm decides the
-// packed weight layout too (conv.hip pack_value), so a layer it accepts has no other kernel.
-bool conv_use_gemm(int CinK, int CoutS);
-void conv_set_gemm(int on);
+// conv_gemm.hip: workgroup-level GEMM kernel for bf16 layers whose channel counts are multiples of 64 with at least one
+// side >= 128 (64 -> 64, Conv3.b: 896 short single-slab workgroups, stays with the per-wave kernel).  Their packed weight
+// buffers carry both layouts (conv.hip packed_elems / pack_value); conv_use_gemm (conv.hip) picks the kernel per launch.
+__host__ __device__ inline bool conv_gemm_channels(int CinK, int CoutS) {
+  return CinK % 64 == 0 && CoutS % 64 == 0 && CinK >= 64 && CoutS >= 64 && (CinK >= 128 || CoutS >= 128);
+}
+bool conv_gemm_fits(int H, int W, int CinK, int CoutS);
+bool conv_use_gemm(int CinK, int CoutS, int H, int W);
+void conv_set_gemm(int mode);
 bool launch_conv_gemm(const ConvArgs& a, hipStream_t st);
 int conv_gemm_stat_rows(int N, int H, int W, int CinK, int CoutS);
 

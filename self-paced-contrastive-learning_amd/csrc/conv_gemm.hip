@@ -375,15 +375,9 @@ __global__ __launch_bounds__(512) void conv3x3_gemm_kernel(GemmArgs a) {
   }
 }
 
-// OFF by default: at N = 64 the kernel is at parity with the per-wave kernels on the 14^2 layers and slower on the 28^2
-// ones (profiles/r02_conv_gemm_notes.md).  spcl_conv_set_gemm(1) / SPCL_CONV_GEMM=1 turn it on -- BEFORE the weights
-// are packed: the packed layout follows this switch (conv.hip pack_value).
-static int g_use_gemm = -1;
-void conv_set_gemm(int on) { g_use_gemm = on ? 1 : 0; }
-bool conv_use_gemm(int CinK, int CoutS) {
-  if (g_use_gemm < 0) g_use_gemm = getenv("SPCL_CONV_GEMM") != nullptr ? 1 : 0;
-  // 64 -> 64 (Conv3.b at 56^2: 896 short workgroups of a single slab) stays with the per-wave kernel
-  return g_use_gemm == 1 && CinK % 64 == 0 && CoutS % 64 == 0 && CinK >= 64 && CoutS >= 64 && (CinK >= 128 || CoutS >= 128);
+bool conv_gemm_fits(int H, int W, int CinK, int CoutS) {
+  const GemmGeom gg = gemm_geom(1, H, W, CinK, CoutS);
+  return (gg.R + 2) * gg.HWc <= 400 && gg.gh <= 2 && gg.lds_bytes() <= 160 * 1024;
 }
 
 int conv_gemm_stat_rows(int N, int H, int W, int CinK, int CoutS) { return N * gemm_geom(N, H, W, CinK, CoutS).rows(); }
@@ -409,12 +403,13 @@ static void launch_gemm_mode(const GemmArgs& g, int mode, dim3 grid, size_t lds,
 // returns false when the configuration is outside the kernel's range (the caller reports the error: the packed
 // weights of a gemm-eligible layer are in this kernel's layout, so there is no other kernel to fall back to)
 bool launch_conv_gemm(const ConvArgs& c, hipStream_t st) {
-  if (!conv_use_gemm(c.CinK, c.CoutS) || c.CinS != c.CinK || c.in_mode > 1) return false;
+  if (!conv_gemm_channels(c.CinK, c.CoutS) || c.CinS != c.CinK || c.in_mode > 1) return false;
   if (c.rows2 != nullptr && c.in_mode != 0) return false;
   const GemmGeom gg = gemm_geom(c.N, c.H, c.W, c.CinK, c.CoutS);
   if ((gg.R + 2) * gg.HWc > 400 || gg.gh > 2 || gg.lds_bytes() > 160 * 1024) return false;
   GemmArgs g;
-  g.x = (const unsigned char*)c.x; g.y = (unsigned char*)c.y; g.wp = (const unsigned char*)c.wp; g.stats = c.stats;
+  g.x = (const unsigned char*)c.x; g.y = (unsigned char*)c.y; g.wp = (const unsigned char*)c.wp + (size_t)9 * c.CinK * c.CoutS * 2;  // second layout of the dual buffer
+  g.stats = c.stats;
   g.in_scale = c.in_scale; g.in_shift = c.in_shift;
   g.y2 = (const unsigned char*)c.y2; g.scale2 = c.scale2; g.shift2 = c.shift2; g.mean2 = c.mean2; g.rows2 = c.rows2;
   g.N = c.N; g.H = c.H; g.W = c.W; g.CinK = c.CinK; g.CoutS = c.CoutS;

@@ -58,14 +58,20 @@ def test_host_only_entry_points(lib):
     assert lib.spcl_conv_packed_elems(1, 16, 0, 1) == 5 * 64 * 8   # image layer padded to 16 input channels
     assert lib.spcl_conv_num_tiles(64, 224, 224) == 64 * 16 * 16  # 14x14 tiles
     assert lib.spcl_conv_num_tiles(64, 112, 112) == 64 * 16 * 8   # 7x14 tiles below 224^2
-    # statistics rows = pixel tiles, except under the experimental GEMM kernel of the wide bf16 layers (one row per
-    # image band and pixel part: 14x14 is one band of four parts)
+    # statistics rows = pixel tiles, except where the workgroup-level GEMM kernel of the wide bf16 layers runs (one row per
+    # image band and pixel part): by default only at sizes without a 14-column specialisation
     assert lib.spcl_conv_stat_rows(1, 64, 14, 14, 256, 256) == lib.spcl_conv_num_tiles(64, 14, 14)
+    assert lib.spcl_conv_stat_rows(1, 64, 16, 16, 256, 256) == 64 * 4      # 16x16: one band of four pixel parts
+    assert lib.spcl_conv_stat_rows(0, 64, 16, 16, 256, 256) == lib.spcl_conv_num_tiles(64, 16, 16)  # f32: never
+    assert lib.spcl_conv_stat_rows(1, 64, 16, 16, 64, 64) == lib.spcl_conv_num_tiles(64, 16, 16)    # 64 -> 64: never
     lib.spcl_conv_set_gemm(1)
     assert lib.spcl_conv_stat_rows(1, 64, 14, 14, 256, 256) == 64 * 4
-    assert lib.spcl_conv_stat_rows(0, 64, 14, 14, 256, 256) == lib.spcl_conv_num_tiles(64, 14, 14)  # f32: never
-    assert lib.spcl_conv_stat_rows(1, 64, 56, 56, 64, 64) == lib.spcl_conv_num_tiles(64, 56, 56)    # 64 -> 64: never
     lib.spcl_conv_set_gemm(0)
+    assert lib.spcl_conv_stat_rows(1, 64, 16, 16, 256, 256) == lib.spcl_conv_num_tiles(64, 16, 16)
+    lib.spcl_conv_set_gemm(-1)
+    # the wide bf16 layers carry both weight layouts
+    assert lib.spcl_conv_packed_elems(256, 256, 0, 1) == 2 * 9 * 256 * 256
+    assert lib.spcl_conv_packed_elems(64, 64, 0, 1) == 9 * 64 * 64
     assert lib.spcl_conv_num_tiles(64, 14, 14) == 64 * 2 * 1      # 7x14 tiles at 14^2 too
     assert lib.spcl_conv_num_tiles(2, 30, 30) == 2 * 2 * 2        # 16x16 tiles
     assert lib.spcl_conv_wgrad_workspace_bytes(64, 224, 224, 16, 16) > 0

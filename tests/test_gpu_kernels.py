@@ -77,12 +77,12 @@ GEMM_SHAPES = [s_ for s_ in SHAPES if s_[1] % 64 == 0 and s_[2] % 64 == 0 and ma
 
 @pytest.fixture
 def gemm_conv():
-    """the experimental workgroup-level GEMM kernel of the >= 64-channel bf16 layers (off by default); the switch also
-    selects the packed weight layout, so it is flipped before anything is packed and restored afterwards"""
+    """the workgroup-level GEMM kernel of the wide bf16 layers forced on at EVERY image size (by default it only takes the
+    sizes the per-wave kernels have no specialisation for)"""
     n = _n()
     n.call("spcl_conv_set_gemm", 1)
     yield n
-    n.call("spcl_conv_set_gemm", 0)
+    n.call("spcl_conv_set_gemm", -1)
 
 
 @pytest.mark.parametrize("N,ci,co,H,W", GEMM_SHAPES)

@@ -64,7 +64,13 @@ def test_projector_variants_vs_oracle(head_type, normalize):
 def test_projector_scope_errors():
     import spcl_amd  # noqa
     from spcl_amd.contrastyou.projectors.heads import ProjectionHead
-    with pytest.raises(NotImplementedError):
-        ProjectionHead(input_dim=8, output_dim=8, head_type="mlp", normalize=True, pool_name="adaptive_max")
+    # adaptive_max exists since round 2 (heads.py:26-45); pooling to anything but (1, 1) cannot feed the flat MLP head:
+    # the reference fails in its first Linear, here the forward says why
+    head = ProjectionHead(input_dim=8, output_dim=8, head_type="mlp", normalize=True, pool_name="adaptive_max").cuda()
+    assert head(torch.rand(2, 8, 4, 4).cuda()).shape == (2, 8)
+    bad = ProjectionHead(input_dim=8, output_dim=8, head_type="mlp", normalize=True, pool_name="adaptive_avg",
+                         spatial_size=(2, 2)).cuda()
+    with pytest.raises(RuntimeError):
+        bad(torch.rand(2, 8, 4, 4).cuda())
     with pytest.raises(AssertionError):
         ProjectionHead(input_dim=8, output_dim=8, head_type="conv", normalize=True)
