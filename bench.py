@@ -80,6 +80,10 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
     ap.add_argument("--split-graph", action="store_true", help="force the compute / collective / update split capture")
+    ap.add_argument("--ddp-overlap", action="store_true",
+                    help="N>1: all-reduce the early gradient bucket (projector + Conv5..Conv3) from a backward hook while "
+                         "Conv2..Conv1 are differentiated (ddp.enable_unet_overlap); runs the step eagerly -- a "
+                         "collective on a second stream inside the step's hipGraph costs more than it hides on this stack")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -130,6 +134,8 @@ def build_step(args, device, rank, world):
     epocher = PretrainEncoderEpocher(model=model, optimizer=opt, chain_dataloader=loader, num_batches=10 ** 9,
                                      device=device, inference_until="Conv5", flat_params=flat)
     epocher.add_hooks([hook()])
+    if getattr(args, "ddp_overlap", False):
+        ddp.enable_unet_overlap(flat, model)
     model.train()
     batch = next(loader)
     nparams = sum(p.numel() for p in params + hparams)
@@ -366,6 +372,8 @@ def main():
             args.bs = 64
         if "--size" not in sys.argv:
             args.size = 256
+    if args.ddp_overlap:
+        args.no_graph = True  # the early bucket's collective is launched from inside backward
     wd.beat("build")
     step, epocher, nparams = build_step(args, device, rank, world)
     run = step

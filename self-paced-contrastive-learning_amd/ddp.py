@@ -24,9 +24,15 @@ class GradBucket:
     """Flat fp32 bucket over the gradients of ``params`` (fixed order).  ``allreduce()`` averages them across ranks
     and leaves ``p.grad`` pointing at views of the bucket (no copy back)."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None):
+    def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None, allow_missing_grads: bool = False):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         assert len(self.params) > 0
+        # A member that received NO gradient would still be stepped by an optimizer over the flat parameter (zeros in
+        # its slice: weight decay and stale momentum move it), where torch.optim -- and the reference's optimiser over
+        # model.parameters() -- skips it.  So the bucket must hold exactly the parameters the step reaches: build it
+        # inside ``model.set_grad(False, start=until, include_start=False)`` (as the trainers do).  ``gather`` raises
+        # otherwise, unless the caller asks for the zeros explicitly.
+        self.allow_missing_grads = allow_missing_grads
         dev = self.params[0].device
         self.numel = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
@@ -58,20 +64,33 @@ class GradBucket:
         for p in self.params:
             p._grad_sink_armed = False
 
-    def gather(self):
-        """grads -> bucket (one fused foreach copy of those not already written in place); params without a grad
-        contribute zeros.  Flushes the deferred weight gradients first and disarms the sinks nobody claimed."""
+    def gather(self, first: int = 0, last: int = None, final: bool = True):
+        """grads -> bucket (one fused foreach copy of those not already written in place) for members
+        ``first .. last - 1`` (default: all).  Flushes the deferred weight gradients first; ``final`` (the step's last
+        gather) also closes their queue and disarms the sinks nobody claimed.  A member without a gradient raises (see
+        the constructor) or, with ``allow_missing_grads``, contributes zeros."""
         from . import functional as _F
-        deferred = _F.flush_deferred_wgrads()
-        self.disarm_sinks()
+        deferred = _F.flush_deferred_wgrads(close=final)
+        if final:
+            self.disarm_sinks()
+            deferred = deferred | getattr(self, "_early_deferred", set())
+            self._early_deferred = set()
+        else:
+            self._early_deferred = getattr(self, "_early_deferred", set()) | deferred
+        last = len(self.params) if last is None else last
         srcs, dsts = [], []
-        for p, v in zip(self.params, self.views):
+        for p, v in zip(self.params[first:last], self.views[first:last]):
             if v.data_ptr() in deferred:
                 # the slice holds the batched launch's result; autograd holds what OTHER uses of the parameter gave
                 if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
                     v.add_(p.grad)
                 p.grad = v
             elif p.grad is None:
+                if not self.allow_missing_grads:
+                    raise RuntimeError(
+                        f"GradBucket.gather: member {tuple(p.shape)} received no gradient in this step; an optimizer "
+                        "over the flat parameter would still move it (torch.optim would skip it).  Build the bucket "
+                        "from the parameters the step reaches, or pass allow_missing_grads=True to get zeros.")
                 v.zero_()
             elif p.grad.data_ptr() != v.data_ptr():
                 srcs.append(p.grad)
@@ -96,8 +115,8 @@ class FlatParams(GradBucket):
     ~10 per parameter tensor, and the flat gradient bucket it consumes is exactly the buffer the RCCL all-reduce
     works on.  Module ``state_dict``s are unaffected (the parameters keep their identity, only their storage moves)."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None):
-        super().__init__(params, process_group)
+    def __init__(self, params: Iterable[torch.nn.Parameter], process_group=None, allow_missing_grads: bool = False):
+        super().__init__(params, process_group, allow_missing_grads)
         self.data = torch.empty(self.numel, dtype=torch.float32, device=self.flat.device)
         off = 0
         with torch.no_grad():
@@ -107,6 +126,7 @@ class FlatParams(GradBucket):
                 p.data = v
                 off += p.numel()
         self.param = torch.nn.Parameter(self.data)
+        self._early_idx, self._early_off, self._early = None, 0, None
 
     def zero_grad(self):
         for p in self.params:
@@ -115,22 +135,78 @@ class FlatParams(GradBucket):
         self.arm_sinks()
 
     def gather_grads(self):
-        """module grads -> flat bucket, which becomes ``self.param.grad`` (no communication)."""
-        self.gather()
+        """module grads -> flat bucket, which becomes ``self.param.grad`` (no communication).  With the early bucket
+        already on its way (``reduce_early``) only the remaining head is gathered."""
+        if self._early is not None:
+            self.gather(first=0, last=self._early_idx, final=True)
+        else:
+            self.gather()
         self.param.grad = self.flat
         return self.flat
 
     def allreduce_(self):
-        """mean of the flat bucket across ranks, in place (the step's ONE collective; no-op for a single process)."""
+        """mean of the flat bucket across ranks, in place (the step's ONE collective, or -- with the early bucket on its
+        way -- the head's plus the wait for the tail's; no-op for a single process)."""
         if is_distributed():
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            if self._early is not None:
+                dist.all_reduce(self.flat[:self._early_off], op=dist.ReduceOp.SUM, group=self.group)
+                if self._early is not True:
+                    self._early.wait()
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
             self.flat.div_(dist.get_world_size(self.group))
+        self._early = None
         return self.flat
 
     def reduce(self):
         """module grads -> flat bucket -> (all-reduce mean across ranks) -> ``self.param.grad``."""
         self.gather_grads()
         return self.allreduce_()
+
+    # ---- two-bucket overlap (SURVEY 8e; off unless ``overlap_from`` is called).  Members are in module order, so the
+    # gradients that backward finishes FIRST (projector, Conv5 .. Conv3) are the TAIL of the flat bucket:
+    # ``reduce_early()`` -- called from a backward hook at the Conv3 | Conv2 boundary -- gathers that tail and starts its
+    # all-reduce asynchronously while Conv2 .. Conv1 are still being differentiated; ``reduce()`` then handles the head
+    # and waits.  Sums are elementwise, so the result equals the one-bucket reduce (tests/test_ddp_gloo.py).
+    def overlap_from(self, first_early_param):
+        """members from ``first_early_param`` (a member, or its index) to the end form the early bucket"""
+        idx = first_early_param if isinstance(first_early_param, int) else \
+            next(i for i, p in enumerate(self.params) if p is first_early_param)
+        assert 0 < idx < len(self.params)
+        self._early_idx = idx
+        self._early_off = sum(p.numel() for p in self.params[:idx])
+        return self
+
+    def reduce_early(self):
+        """gather the early bucket and start its all-reduce (no-op when overlap is off or it already ran this step)"""
+        if self._early_idx is None or self._early is not None:
+            return
+        self.gather(first=self._early_idx, final=False)
+        self._early = True
+        if is_distributed():
+            self._early = dist.all_reduce(self.flat[self._early_off:], op=dist.ReduceOp.SUM, group=self.group,
+                                          async_op=True)
+
+    def early_hook(self):
+        """a callback for a backward hook (``tensor.register_hook``) that starts the early bucket"""
+        def hook(*args):
+            self.reduce_early()
+        return hook
+
+
+def enable_unet_overlap(flat: "FlatParams", net, early_block: str = "Conv3", hook_block: str = "Conv2"):
+    """Two-bucket overlap for a UNet encoder step: everything from ``early_block`` on (Conv3 .. Conv5 and
+    whatever follows the encoder in the bucket: projector heads) is all-reduced from a backward hook at the output of
+    ``hook_block`` -- it fires when the gradient of that block's pooled output exists, i.e. when every later block has
+    been differentiated.  ``disable_unet_overlap`` undoes it."""
+    first = next(getattr(net, "_" + early_block).parameters())
+    flat.overlap_from(first)
+    net._boundary_hooks[hook_block] = flat.early_hook()
+
+
+def disable_unet_overlap(flat: "FlatParams", net):
+    net._boundary_hooks.clear()
+    flat._early_idx, flat._early_off, flat._early = None, 0, None
 
 
 @torch.no_grad()

@@ -168,6 +168,7 @@ class UNet(nn.Module):
             setattr(self, f"_Up_conv{lvl}", _ConvBlock(prev, co, momentum=momentum))
             prev = co
         self._Deconv_1x1 = _Conv1x1(prev, num_classes, kernel_size=(1, 1), stride=(1, 1), padding=(0, 0))
+        self._boundary_hooks = {}  # encoder block name -> callable run in backward at that block's output (see forward)
 
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, x, until: str = None):
@@ -187,6 +188,11 @@ class UNet(nn.Module):
                 return out
             skips[name] = out
             e = blk.take_pooled()
+            cb = self._boundary_hooks.get(name)
+            if cb is not None and e is not None and e.requires_grad:
+                # fires when backward has produced the gradient of this block's pooled output, i.e. once every later
+                # block has been differentiated (ddp.enable_unet_overlap starts the early gradient bucket there)
+                e.register_hook(lambda g, cb=cb: cb() and None)
         # decoding + concat path (unet.py:193-230)
         d = skips["Conv5"]
         for lvl, skip in ((5, "Conv4"), (4, "Conv3"), (3, "Conv2"), (2, "Conv1")):

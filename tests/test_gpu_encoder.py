@@ -440,3 +440,48 @@ def test_unet_api_surface():
             pass
     with pytest.raises(RuntimeError):  # CPU tensor: no fallback
         m.cpu()(torch.zeros(1, 1, 16, 16), until="Conv1")
+
+
+def test_two_bucket_overlap_step_equals_the_plain_step():
+    """ddp.enable_unet_overlap on one process: the early bucket (Conv3 .. Conv5 + projector) is gathered from the backward
+    hook on Conv2 -- the batched wide weight gradients are flushed there, the narrow layers' sinks are still being
+    written -- and the rest after backward: the flat gradient is bit-identical to the one-gather step's."""
+    import spcl_amd  # noqa
+    from spcl_amd import ddp
+    from spcl_amd.semi_seg.epochers import PretrainEncoderEpocher
+    from spcl_amd.semi_seg.hooks import create_sp_infonce_hooks
+    from spcl_amd.synthetic import acdc_like_meta
+    grads = []
+    for overlap in (False, True):
+        torch.manual_seed(9)  # the projector head draws its initial weights from the global generator
+        net, _ = _unet(256, 21)
+        net.set_compute_dtype(torch.bfloat16)
+        hook = create_sp_infonce_hooks(model=net, feature_names="Conv5", weights=1.0, contrast_ons="partition",
+                                       begin_values=8.0, end_values=8.0, mode="soft", max_epoch=10, p=0.5,
+                                       correct_grad=True, data_name="acdc", sync_checks=False).cuda()
+        for name in net.decoder_names:
+            getattr(net, "_" + name).requires_grad_(False)
+        flat = ddp.FlatParams([p for p in net.parameters() if p.requires_grad] + list(hook.parameters()))
+        fired = []
+        if overlap:
+            ddp.enable_unet_overlap(flat, net)
+            start = net._boundary_hooks["Conv2"]
+            net._boundary_hooks["Conv2"] = lambda: (start(), fired.append(flat._early))[0]
+        bs = 6
+        g = torch.Generator().manual_seed(17)
+        a, b = torch.rand(bs, 1, 112, 112, generator=g), torch.rand(bs, 1, 112, 112, generator=g)
+        filenames, partitions, groups = acdc_like_meta(bs)
+        tgt = torch.zeros(bs, 1, 1, 1, dtype=torch.long).cuda()
+        ep = PretrainEncoderEpocher(model=net, optimizer=torch.optim.SGD([flat.param], lr=0.0), chain_dataloader=iter([]),
+                                    num_batches=1, device="cuda", inference_until="Conv5", flat_params=flat)
+        ep.add_hooks([hook()])
+        net.train()
+        with ep.meters.focus_on(ep.meter_focus):
+            ep.step_compute(((a.cuda(), b.cuda(), tgt, tgt), filenames, (partitions, groups)), seed=3)
+        if overlap:
+            assert fired == [True]  # the hook at Conv2's output ran once, during backward, and gathered the early bucket
+        grads.append(flat.flat.clone())
+        flat.allreduce_()
+        assert flat._early is None
+    assert torch.equal(grads[0], grads[1])
+    assert float(grads[0].abs().max()) > 0

@@ -204,8 +204,16 @@ def test_gradient_sinks_are_armed_once_per_step_on_cpu():
     flat.zero_grad()
     WriteIntoSink.apply(lin.weight).backward()
     assert lin.weight.grad.data_ptr() == flat.views[0].data_ptr()
-    g = flat.gather_grads()
-    assert torch.equal(g[:12], torch.full((12,), 3.0)) and torch.equal(g[12:], torch.zeros(3))  # bias had no gradient
+    # the bias received no gradient: an optimizer over the flat parameter would move it anyway (torch.optim skips such
+    # parameters), so gather refuses unless the zeros are asked for
+    with pytest.raises(RuntimeError, match="received no gradient"):
+        flat.gather_grads()
+    lin2 = torch.nn.Linear(4, 3)
+    flat2 = ddp.FlatParams(lin2.parameters(), allow_missing_grads=True)
+    flat2.zero_grad()
+    WriteIntoSink.apply(lin2.weight).backward()
+    g = flat2.gather_grads()
+    assert torch.equal(g[:12], torch.full((12,), 3.0)) and torch.equal(g[12:], torch.zeros(3))
 
 
 def test_meter_batching_falls_back_to_immediate_adds_off_gpu():
