@@ -493,6 +493,9 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_fin_kernel(const float* __rest
   if (c == 0)  // scratch the next launch wants zeroed (the image-wgrad pass's zero row): saves a memset launch
     for (int z = threadIdx.x; z < nzero; z += 256) zero_fill[z] = 0.f;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the channel's coefficients are requested WITH the partials (one memory round trip instead of a second, dependent
+  // one after the reduction: this kernel is pure latency, ten launches per step)
+  const float c_invstd = invstd[c], c_scale = scale[c], c_mean = mean[c];
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll 4
   for (int w = threadIdx.x; w < nwg; w += 256) {
@@ -506,15 +509,15 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_fin_kernel(const float* __rest
   if (threadIdx.x == 0) {
     s1 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
     s2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-    if (s2_centered) s2 *= invstd[c];  // rows held sum dz (y - mean): dgamma = invstd * that
+    if (s2_centered) s2 *= c_invstd;  // rows held sum dz (y - mean): dgamma = invstd * that
     if (c < C) {
       dbeta[c] = s1;
       dgamma[c] = s2;
     }
     float A = 0.f, B = 0.f;
     if (training) {
-      A = -scale[c] * invstd[c] * (s2 / M);
-      B = -scale[c] * (s1 / M) - A * mean[c];
+      A = -c_scale * c_invstd * (s2 / M);
+      B = -c_scale * (s1 / M) - A * c_mean;
     }
     ab[c] = A;
     ab[CS + c] = B;
