@@ -234,6 +234,21 @@ int spcl_conv_dgrad_bnstats_supported(int dtype, int N, int H, int W, int CinK, 
 int spcl_conv3x3_dgrad_bnstats(const void* dy, int dtype, int N, int H, int W, int CinK, int CoutS, const void* w_packed,
                                void* g, const void* y2, const float* scale2, const float* shift2, const float* mean2,
                                float* rows2, void* stream);
+
+/* The same across a POOLED block boundary: dy = gradient of the next block's first conv output (H x W), g = its input
+ * gradient = d loss / d maxpool2x2(relu(bn(y2))), y2 [N][H2][W2][CoutS] the raw second-conv output of the block before
+ * (H == H2 / 2, W == W2 / 2; semi_seg/arch/unet.py:118-121,159-166).  rows2 [spcl_conv_stat_rows(...)][2][CoutS]: per conv
+ * tile, sum dz and sum dz (y2 - mean) with dz = g routed to the window's first positive maximum -- what
+ * spcl_bnrelu_pool_backward's reduction pass computes, without that pass.  bf16, per-wave kernels only: ask
+ * spcl_conv_dgrad_poolstats_supported first; finish with spcl_bnrelu_pool_backward_rows. */
+int spcl_conv_dgrad_poolstats_supported(int dtype, int N, int H, int W, int CinK, int CoutS, int H2, int W2);
+int spcl_conv3x3_dgrad_poolstats(const void* dy, int dtype, int N, int H, int W, int CinK, int CoutS, const void* w_packed,
+                                 void* g, const void* y2, int H2, int W2, const float* scale2, const float* shift2,
+                                 const float* mean2, float* rows2, void* stream);
+int spcl_bnrelu_pool_backward_rows(const void* y, const void* dpool, const float* rows, int nrows, int dtype, int N, int H,
+                                   int W, int C, int CS, const float* mean, const float* invstd, const float* scale,
+                                   const float* shift, int training, float* ws, float* dgamma, float* dbeta, void* dy,
+                                   void* stream);
 int spcl_bnrelu_backward_rows(const void* y, const void* dact, const float* image, const float* rows, int nrows, int dtype,
                               int N, int H, int W, int C, int CS, const float* mean, const float* invstd,
                               const float* scale, const float* shift, int training, float* ws, float* dgamma,

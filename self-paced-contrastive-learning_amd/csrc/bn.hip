@@ -947,3 +947,27 @@ extern "C" int spcl_bnrelu_backward_rows(const void* y, const void* dact, const 
   SPCL_LAUNCH_CHECK("bnrelu_backward_rows");
   return SPCL_OK;
 }
+
+// BN + ReLU + 2x2 max-pool backward finished from per-tile rows that came with the dgrad producing dpool
+// (spcl_conv3x3_dgrad_poolstats): final reduction of the rows -> coefficients -> the apply pass.  No `dact` here: a block
+// whose activation is also consumed directly (skip connection, hook tap) keeps the two-pass path.
+extern "C" int spcl_bnrelu_pool_backward_rows(const void* y, const void* dpool, const float* rows, int nrows, int dtype,
+                                              int N, int H, int W, int C, int CS, const float* mean, const float* invstd,
+                                              const float* scale, const float* shift, int training, float* ws,
+                                              float* dgamma, float* dbeta, void* dy, void* stream) {
+  SPCL_CHECK_ARG(y && dpool && rows && mean && invstd && scale && shift && ws && dgamma && dbeta && dy,
+                 "bnrelu_pool_backward_rows: null pointer");
+  SPCL_CHECK_ARG(N > 0 && H >= 2 && W >= 2 && C > 0 && CS >= C && CS % 16 == 0 && CS <= 1024 && nrows > 0,
+                 "bnrelu_pool_backward_rows: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SPCL_BF16)
+    bnrelu_bwd_launch<bf16_t>(y, nullptr, dpool, N, H, W, C, CS, mean, invstd, scale, shift, training, ws, dgamma, dbeta,
+                              dy, st, nullptr, nullptr, rows, nrows);
+  else {
+    set_error("bnrelu_pool_backward_rows: dtype %d (bf16 only: the rows come from the specialised dgrad kernels)", dtype);
+    return SPCL_EINVAL;
+  }
+  SPCL_LAUNCH_CHECK("bnrelu_pool_backward_rows");
+  return SPCL_OK;
+}
+

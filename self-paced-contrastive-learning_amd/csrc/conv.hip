@@ -602,3 +602,47 @@ extern "C" int spcl_conv3x3_dgrad_bnstats(const void* dy, int dtype, int N, int 
   SPCL_LAUNCH_CHECK("conv3x3_dgrad_bnstats");
   return SPCL_OK;
 }
+
+// The same for a POOLED boundary: dy is the gradient of the next block's first conv output, g = its input gradient =
+// d loss / d maxpool2x2(relu(bn(y2))) at H x W, y2 the raw conv output of the block before at H2 x W2 (H = H2 / 2).  The
+// epilogue routes g to the window's first positive maximum and leaves the per-tile partial sums of that BatchNorm's
+// backward: the separate reduction pass over y2 (bnrelu_bwd_pool_kernel<T, false>) disappears.  Per-wave kernels only.
+extern "C" int spcl_conv_dgrad_poolstats_supported(int dtype, int N, int H, int W, int CinK, int CoutS, int H2, int W2) {
+  static const bool off = getenv("SPCL_NO_DGRAD_POOLSTATS") != nullptr;  // A/B switch
+  ConvArgs a;
+  if (off || H != H2 / 2 || W != W2 / 2 || !dgrad_bnstats_args(a, dtype, N, H, W, CinK, CoutS)) return 0;
+  if (conv_use_gemm(CinK, CoutS, H, W)) return 0;
+  a.x = nullptr; a.y = nullptr; a.wp = nullptr;
+  float dummy;
+  a.rows2 = &dummy;
+  a.H2 = H2; a.W2 = W2;
+  TileCfg t = pick_tile(H, W);
+  return (t.tw == 14 && launch_conv_fast(a, t.th, nullptr, true)) ? 1 : 0;
+}
+
+extern "C" int spcl_conv3x3_dgrad_poolstats(const void* dy, int dtype, int N, int H, int W, int CinK, int CoutS,
+                                            const void* w_packed, void* g, const void* y2, int H2, int W2,
+                                            const float* scale2, const float* shift2, const float* mean2, float* rows2,
+                                            void* stream) {
+  SPCL_CHECK_ARG(dy && w_packed && g && y2 && scale2 && shift2 && mean2 && rows2, "conv3x3_dgrad_poolstats: null pointer");
+  ConvArgs a;
+  if (H != H2 / 2 || W != W2 / 2 || !dgrad_bnstats_args(a, dtype, N, H, W, CinK, CoutS) ||
+      conv_use_gemm(CinK, CoutS, H, W)) {
+    set_error("conv3x3_dgrad_poolstats: unsupported configuration");
+    return SPCL_EUNSUPPORTED;
+  }
+  a.x = dy; a.y = g; a.wp = w_packed;
+  a.y2 = y2; a.scale2 = scale2; a.shift2 = shift2; a.mean2 = mean2; a.rows2 = rows2;
+  a.H2 = H2; a.W2 = W2;
+  hipStream_t st = (hipStream_t)stream;
+  const double px = (double)N * H * W;
+  prof_cost(px * (CinK + CoutS) * 2.0 + (double)N * H2 * W2 * CoutS * 2.0 + 9.0 * CinK * CoutS * 2.0, 2.0 * px * 9.0 * CinK * CoutS);
+  TileCfg t = pick_tile(H, W);
+  if (!(t.tw == 14 && launch_conv_fast(a, t.th, st))) {
+    set_error("conv3x3_dgrad_poolstats: no specialised kernel for H=%d W=%d CinK=%d CoutS=%d", H, W, CinK, CoutS);
+    return SPCL_EUNSUPPORTED;
+  }
+  SPCL_LAUNCH_CHECK("conv3x3_dgrad_poolstats");
+  return SPCL_OK;
+}
+

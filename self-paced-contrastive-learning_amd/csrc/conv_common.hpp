@@ -43,6 +43,9 @@ struct ConvArgs {
   const float* shift2 = nullptr;
   const float* mean2 = nullptr;
   float* rows2 = nullptr;
+  // ... or, with H2 > 0, of the POOLED layer: y2 is [N][H2][W2][CoutS] at twice the resolution (H == H2 / 2), the dgrad's
+  // output is the gradient of maxpool2x2(relu(bn(y2)))
+  int H2 = 0, W2 = 0;
 };
 
 template <typename T> __device__ __forceinline__ f32x4 mfma_chunk(u32x4 w, u32x4 x, f32x4 acc);

@@ -27,6 +27,8 @@ struct FastArgs {
   const float* shift2;
   const float* mean2;
   float* rows2;             // [tile][2][CoutS]: sum dz, sum dz (y2 - mean)
+  // MODE 3 (dgrad whose output g is the gradient of maxpool2x2(relu(bn(y2)))): y2 is [N][H2][W2][CoutS], H = H2 / 2
+  int H2, W2;
 };
 
 // waves per SIMD the register allocator must leave room for: what the tile's LDS footprint allows anyway, at most 4
@@ -199,7 +201,7 @@ conv3x3_fast_kernel(FastArgs a) {
   for (int j = 0; j < NT; ++j) {
     ssum[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     ssq[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (MODE == 2) {
+    if (MODE == 2 || MODE == 3) {
       const int cb = (nt0 + j) * 16 + 4 * g;
       sc2[j] = *(const f32x4*)(a.scale2 + cb);
       sh2[j] = *(const f32x4*)(a.shift2 + cb);
@@ -233,6 +235,36 @@ conv3x3_fast_kernel(FastArgs a) {
             ssum[j][r] += dz;
             ssq[j][r] = fmaf(dz, yv[r] - mu2[j][r], ssq[j][r]);
           }
+        } else if (MODE == 3) {
+          // the 2x2 window of y2 under this pooled pixel: the gradient goes to the first maximum of relu(bn(y2)) in scan
+          // order if that maximum is positive (bn.hip bnrelu_bwd_pool_kernel<T, false>, the pass this epilogue replaces)
+          const f32x2 glo = {acc[i][j][0], acc[i][j][1]}, ghi = {acc[i][j][2], acc[i][j][3]};
+          const uint32_t g0 = __builtin_bit_cast(uint32_t, __builtin_convertvector(glo, bf16x2v));
+          const uint32_t g1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(ghi, bf16x2v));
+          const float gv[4] = {__uint_as_float(g0 << 16), __uint_as_float(g0 & 0xffff0000u),
+                               __uint_as_float(g1 << 16), __uint_as_float(g1 & 0xffff0000u)};
+          const unsigned char* wb = a.y2 + ((((size_t)n * a.H2 + 2 * (y0 + pyc)) * a.W2 + 2 * (x0 + px)) * rowb) +
+                                    ((nt0 + j) * 16 + 4 * g) * 2;
+          uint2 yr[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) yr[k] = *(const uint2*)(wb + ((size_t)(k >> 1) * a.W2 + (k & 1)) * rowb);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float zb = -1.f, yb = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const uint32_t wd = r < 2 ? yr[k].x : yr[k].y;
+              const float yv = (r & 1) ? __uint_as_float(wd & 0xffff0000u) : __uint_as_float(wd << 16);
+              const float z = fmaf(sc2[j][r], yv, sh2[j][r]);
+              if (k == 0 || z > zb) {
+                zb = z;
+                yb = yv;
+              }
+            }
+            const float dz = zb > 0.f ? gv[r] * keep : 0.f;
+            ssum[j][r] += dz;
+            ssq[j][r] = fmaf(dz, yb - mu2[j][r], ssq[j][r]);
+          }
         } else {
           const f32x4 av = acc[i][j] * keep;
           ssum[j] += av;
@@ -249,7 +281,7 @@ conv3x3_fast_kernel(FastArgs a) {
       ob += wrapo;
     }
   }
-  if (MODE == 2) {
+  if (MODE == 2 || MODE == 3) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       f32x4 o;
@@ -366,6 +398,7 @@ static void launch_fast(const FastArgs& a, int mode, hipStream_t st) {
   const size_t lds = fast_lds_bytes(KC, TH);
   dim3 grid(a.tilesX, a.tilesY, a.N * a.gy), block(64 * NW);
   if (mode == 1) SPCL_LAUNCH((conv3x3_fast_kernel<KC, TH, NT, 1, NW>), grid, block, lds, st, a);
+  else if (a.rows2 != nullptr && a.H2 > 0) SPCL_LAUNCH((conv3x3_fast_kernel<KC, TH, NT, 3, NW>), grid, block, lds, st, a);
   else if (a.rows2 != nullptr) SPCL_LAUNCH((conv3x3_fast_kernel<KC, TH, NT, 2, NW>), grid, block, lds, st, a);
   else SPCL_LAUNCH((conv3x3_fast_kernel<KC, TH, NT, 0, NW>), grid, block, lds, st, a);
 }
@@ -377,7 +410,7 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
     FastArgs a;
     a.x = (const unsigned char*)c.x; a.y = (unsigned char*)c.y; a.wp = (const u32x4*)c.wp; a.stats = c.stats;
     a.in_scale = a.in_shift = nullptr;
-    a.y2 = nullptr; a.scale2 = a.shift2 = a.mean2 = nullptr; a.rows2 = nullptr;
+    a.y2 = nullptr; a.scale2 = a.shift2 = a.mean2 = nullptr; a.rows2 = nullptr; a.H2 = a.W2 = 0;
     a.N = c.N; a.H = c.H; a.W = c.W; a.CinK = 16; a.CoutS = 16;
     a.tilesX = cdiv(c.W, 14); a.tilesY = cdiv(c.H, 14); a.gy = 1;
     if (!dry) SPCL_LAUNCH((conv3x3_image_kernel<14>), dim3(a.tilesX, a.tilesY, a.N), dim3(64), 0, st, a);
@@ -398,9 +431,14 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
   a.x = (const unsigned char*)c.x; a.y = (unsigned char*)c.y; a.wp = (const u32x4*)c.wp; a.stats = c.stats;
   a.in_scale = c.in_scale; a.in_shift = c.in_shift;
   a.y2 = (const unsigned char*)c.y2; a.scale2 = c.scale2; a.shift2 = c.shift2; a.mean2 = c.mean2; a.rows2 = c.rows2;
+  a.H2 = c.H2; a.W2 = c.W2;
   if (c.rows2 != nullptr && c.in_mode != 0) return false;
   a.N = c.N; a.H = c.H; a.W = c.W; a.CinK = c.CinK; a.CoutS = c.CoutS;
   a.tilesX = cdiv(c.W, 14); a.tilesY = cdiv(c.H, th); a.gy = ntn / (NT * nw);
+  // pooled BatchNorm-backward sums in the epilogue (MODE 3): measured per block against dgrad + separate reduction pass
+  // (N = 64): 32 -> 16 @112^2 43 vs 49 us, 128 -> 64 @28^2 21 vs 25.5, 256 -> 128 @14^2 30.5 vs 30.6, but the one-wave
+  // 64 -> 32 @56^2 kernel 53.5 vs 43 (56 scattered 8-byte loads per lane behind one wave's MFMAs): not offered there
+  if (c.rows2 != nullptr && c.H2 > 0 && KC == 64 && nw == 1) return false;
 #define SPCL_FAST_CASE(KC_, TH_, NT_, NW_)                               \
   if (KC == KC_ && th == TH_ && NT == NT_ && nw == NW_) {                \
     if (!dry) launch_fast<KC_, TH_, NT_, NW_>(a, c.in_mode, st);         \

@@ -358,13 +358,28 @@ def to_nhwc_padded(x: torch.Tensor, dtype: torch.dtype):
     return out
 
 
+class PoolLink:
+    """What the NEXT block's backward needs to leave the BatchNorm-backward partial sums of THIS block's second conv in the
+    epilogue of its own input-gradient kernel (spcl_conv3x3_dgrad_poolstats): this block's raw second-conv output and BN
+    coefficients.  The next block fills ``rows`` / ``dx_ptr``; this block's backward uses them if the pooled gradient it
+    receives IS that kernel's output (same storage: nothing else contributed to it), else runs its own reduction pass."""
+    __slots__ = ("yb", "stb", "N", "H", "W", "cout_s", "rows", "dx_ptr")
+
+    def __init__(self, yb, stb, N, H, W, cout_s):
+        self.yb, self.stb, self.N, self.H, self.W, self.cout_s = yb, stb, N, H, W, cout_s
+        self.rows, self.dx_ptr = None, 0
+
+
 class BlockCfg:
     """Static configuration of one fused Conv-BN-ReLU(-Conv-BN-ReLU)(-MaxPool) block call."""
-    __slots__ = ("dtype", "training", "momentum", "eps", "track", "need_act", "need_pool", "image_input", "buffers")
+    __slots__ = ("dtype", "training", "momentum", "eps", "track", "need_act", "need_pool", "image_input", "buffers",
+                 "link_in", "link_out")
 
     def __init__(self, dtype, training, momentum, eps, track, need_act, need_pool, image_input, buffers):
         self.dtype, self.training, self.momentum, self.eps, self.track = dtype, training, momentum, eps, track
         self.need_act, self.need_pool, self.image_input, self.buffers = need_act, need_pool, image_input, buffers
+        self.link_in = None   # PoolLink of the block whose pooled output is this block's input (set by the caller)
+        self.link_out = None  # PoolLink this call offers to the next block (set by the forward)
 
 
 def _pack(w, kind, dt_code, dtype):
@@ -579,6 +594,19 @@ def _bnrelu_bwd_rows(y, dact, image, rows, dt_code, dtype, N, H, W, C, cs, st, t
     return first, dgamma, dbeta
 
 
+def _bnrelu_pool_bwd_rows(y, dpool, rows, dt_code, dtype, N, H, W, C, cs, st, training, sinks):
+    """BN + ReLU + max-pool backward finished from the rows the next block's dgrad left -> (dy, dgamma, dbeta)."""
+    dev = y.device
+    ws = torch.empty(_n.call("spcl_bnrelu_bwd_workspace_bytes", N, H, W, cs) // 4, dtype=torch.float32, device=dev)
+    dgamma = _grad_buffer(sinks[0], (C,), dev)
+    dbeta = _grad_buffer(sinks[1], (C,), dev)
+    dy = torch.empty(N, H, W, cs, dtype=dtype, device=dev)
+    _n.call("spcl_bnrelu_pool_backward_rows", _n.ptr(y), _n.ptr(dpool), _n.ptr(rows), rows.ntiles, dt_code, N, H, W, C, cs,
+            _n.ptr(st[0]), _n.ptr(st[1]), _n.ptr(st[2]), _n.ptr(st[3]), int(training), _n.ptr(ws), _n.ptr(dgamma),
+            _n.ptr(dbeta), _n.ptr(dy), _n.stream())
+    return dy, dgamma, dbeta
+
+
 class _ConvBlockFn(torch.autograd.Function):
     """[conv3x3 -> BN -> ReLU] x2 (+ 2x2 max-pool), semi_seg/arch/unet.py:67-82 + :118-121, as HIP kernels.
 
@@ -619,6 +647,8 @@ class _ConvBlockFn(torch.autograd.Function):
         ctx.params = (wa, ga, ba, wb, gb, bb)
         ctx.packed_t = (wpa_t, wpb_t)
         ctx.cfg = cfg
+        if need_bwd and pool is not None and act is None and cfg.training and dtype == torch.bfloat16:
+            cfg.link_out = PoolLink(yb, stb, N, H, W, cout_s)  # the pooled output is this block's only product
         ctx.meta = (N, cin, H, W, cout, cout_s, cin_s, cin_k, mode_a, x.dtype)
         outs = []
         outs.append(nhwc_to_logical(act, cout) if act is not None else None)
@@ -639,7 +669,16 @@ class _ConvBlockFn(torch.autograd.Function):
         # ---- second conv
         ng = ctx.needs_input_grad
         sk = tuple(take_grad_sink(p, ng[i + 1]) for i, p in enumerate(ctx.params))  # (wa, ga, ba, wb, gb, bb)
-        dyb, dgb, dbb = _bnrelu_bwd(yb, da_s, dp_s, dtc, dtype, N, H, W, cout, cout_s, stb, cfg.training, sk[4:6])
+        lk = cfg.link_out
+        if (lk is not None and lk.rows is not None and da_s is None and dp_s is not None
+                and dp_s.data_ptr() == lk.dx_ptr):
+            # the next block's input-gradient kernel left this BatchNorm's partial sums next to the gradient itself
+            dyb, dgb, dbb = _bnrelu_pool_bwd_rows(yb, dp_s, lk.rows, dtc, dtype, N, H, W, cout, cout_s, stb, cfg.training,
+                                                  sk[4:6])
+        else:
+            dyb, dgb, dbb = _bnrelu_bwd(yb, da_s, dp_s, dtc, dtype, N, H, W, cout, cout_s, stb, cfg.training, sk[4:6])
+        if lk is not None:
+            lk.rows, lk.dx_ptr = None, 0
         dwb = _wgrad(ya, dyb, dtc, N, H, W, cout, cout_s, cout_s, cout, cout_s, 1, sta[2], sta[3], sk[3]) \
             if ctx.needs_input_grad[4] else None
         wpa_t, wpb_t = ctx.packed_t
@@ -678,7 +717,20 @@ class _ConvBlockFn(torch.autograd.Function):
                 raise NotImplementedError("gradient w.r.t. the input image is not on the hot path")
             if wpa_t is None:
                 wpa_t = _pack(wa, 1, dtc, dtype)
-            dxs, _ = _conv(dya, dtc, dtype, N, H, W, cout_s, cout_s, cin_s, wpa_t, 0, None, None, False)
+            li = cfg.link_in
+            dxs = None
+            if (li is not None and dtype == torch.bfloat16 and li.cout_s == cin_s and li.N == N
+                    and _n.call("spcl_conv_dgrad_poolstats_supported", dtc, N, H, W, cout_s, cin_s, li.H, li.W)):
+                nt = _n.call("spcl_conv_stat_rows", dtc, N, H, W, cout_s, cin_s)
+                dxs = torch.empty(N, H, W, cin_s, dtype=dtype, device=dya.device)
+                rows = torch.empty(nt * 2 * cin_s, dtype=torch.float32, device=dya.device)
+                _n.call("spcl_conv3x3_dgrad_poolstats", _n.ptr(dya), dtc, N, H, W, cout_s, cin_s, _n.ptr(wpa_t),
+                        _n.ptr(dxs), _n.ptr(li.yb), li.H, li.W, _n.ptr(li.stb[2]), _n.ptr(li.stb[3]), _n.ptr(li.stb[0]),
+                        _n.ptr(rows), _n.stream())
+                rows.ntiles = nt
+                li.rows, li.dx_ptr = rows, dxs.data_ptr()
+            if dxs is None:
+                dxs, _ = _conv(dya, dtc, dtype, N, H, W, cout_s, cout_s, cin_s, wpa_t, 0, None, None, False)
             dx = nhwc_to_logical(dxs, cin)
             if dx.dtype != xdt:
                 dx = dx.to(xdt)

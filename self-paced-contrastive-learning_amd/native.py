@@ -66,6 +66,11 @@ _SIGNATURES = {
     "spcl_accumulate_scalars": (c_int, [c_int, _P, _P, _P, _P]),
     "spcl_conv_dgrad_bnstats_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "spcl_conv3x3_dgrad_bnstats": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "spcl_conv_dgrad_poolstats_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "spcl_conv3x3_dgrad_poolstats": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, _P, _P,
+                                             _P, _P, _P]),
+    "spcl_bnrelu_pool_backward_rows": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P,
+                                               c_int, _P, _P, _P, _P, _P]),
     "spcl_bnrelu_backward_rows": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P,
                                           c_int, _P, _P, _P, _P, _P, _P]),
     "spcl_conv1x1_forward": (c_int, [_P, c_int, c_size_t, c_int, c_int, c_int, _P, _P, _P, _P]),
@@ -100,7 +105,7 @@ class WgradItem(ctypes.Structure):
 
 
 WGRAD_BATCH_MAX = 8
-_NO_STATUS = ("spcl_abi_version", "spcl_conv_num_tiles", "spcl_conv_stat_rows", "spcl_conv_set_gemm", "spcl_profile_count", "spcl_conv_dgrad_bnstats_supported",
+_NO_STATUS = ("spcl_abi_version", "spcl_conv_num_tiles", "spcl_conv_stat_rows", "spcl_conv_set_gemm", "spcl_profile_count", "spcl_conv_dgrad_bnstats_supported", "spcl_conv_dgrad_poolstats_supported",
               "spcl_conv_wgrad_batched_supported")
 
 

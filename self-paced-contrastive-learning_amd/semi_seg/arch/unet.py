@@ -73,6 +73,7 @@ class _ConvBlock(nn.Module):
         self._compute_dtype = None  # None -> config default at call time
         self._plan = None           # (need_act, need_pool) set by UNet.forward for one call
         self._pooled = None
+        self._link_in = self._link_out = None  # functional.PoolLink hand-over between consecutive encoder blocks
 
     def _cfg(self, need_act, need_pool):
         bn_a, bn_b = self.conv[1], self.conv[4]
@@ -95,9 +96,11 @@ class _ConvBlock(nn.Module):
         if len(self._forward_hooks) > 0:
             need_act = True  # a forward hook (arch/hook.py feature tap) wants the block output
         c = self.conv
-        act, pooled = F_hip.conv_block(x, c[0].weight, c[1].weight, c[1].bias, c[3].weight, c[4].weight, c[4].bias,
-                                       self._cfg(need_act, need_pool))
+        cfg = self._cfg(need_act, need_pool)
+        cfg.link_in, self._link_in = self._link_in, None
+        act, pooled = F_hip.conv_block(x, c[0].weight, c[1].weight, c[1].bias, c[3].weight, c[4].weight, c[4].bias, cfg)
         self._pooled = pooled
+        self._link_out = cfg.link_out  # for the block that consumes the pooled output (UNet.forward hands it over)
         return act
 
     def take_pooled(self):
@@ -183,6 +186,9 @@ class UNet(nn.Module):
             blk = getattr(self, "_" + name)
             is_last = (until == name) or k == len(_ENCODER) - 1
             blk._plan = (is_last or not encoder_only, not is_last)  # the decoder needs every block output (skips)
+            if k > 0:
+                prev = getattr(self, "_" + _ENCODER[k - 1])
+                blk._link_in, prev._link_out = prev._link_out, None
             out = blk(e)
             if until == name:
                 return out

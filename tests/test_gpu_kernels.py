@@ -578,3 +578,48 @@ def test_builtin_kernel_timer_reports_symbols_and_costs():
     finally:
         n.call("spcl_profile_enable", 0)
     assert n.call("spcl_profile_count") == 0
+
+
+@pytest.mark.parametrize("N,ci,co,H2,W2", [(2, 16, 32, 56, 56), (1, 32, 64, 28, 56), (2, 64, 128, 28, 28), (1, 128, 256, 28, 28),
+                                           (3, 16, 32, 224, 42), (1, 16, 32, 57, 31)])
+def test_dgrad_with_fused_pooled_bn_backward_sums(N, ci, co, H2, W2):
+    """spcl_conv3x3_dgrad_poolstats + spcl_bnrelu_pool_backward_rows against the path they replace (plain dgrad of the next
+    block's first conv, then spcl_bnrelu_pool_backward with its own reduction pass over y2): the input gradient g is
+    bit-identical, dgamma / dbeta / dy equal up to summation order.  ci = channels of the pooled layer, co = of the conv."""
+    n = _n()
+    dtype, dtc = torch.bfloat16, 1
+    H, W = H2 // 2, W2 // 2
+    if not n.call("spcl_conv_dgrad_poolstats_supported", dtc, N, H, W, co, ci, H2, W2):
+        pytest.skip("no specialised kernel for this shape")
+    g_ = torch.Generator().manual_seed(ci + H2)
+    dy_in = nhwc(rnd(torch.randn(N, co, H, W, generator=g_), dtype), dtype)            # grad of the conv's output
+    y2 = nhwc(rnd(torch.randn(N, ci, H2, W2, generator=g_) * 1.3 + 0.2, dtype), dtype)  # pooled layer's raw output
+    w = torch.randn(co, ci, 3, 3, generator=g_) / (3.0 * co ** 0.5)
+    wp_t = pack(n, w, 1, dtype)
+    st = torch.zeros(4, ci)
+    st[0] = torch.randn(ci, generator=g_) * 0.1 + 0.2          # mean
+    st[1] = torch.rand(ci, generator=g_) + 0.5                 # invstd
+    st[2] = st[1] * (torch.rand(ci, generator=g_) + 0.5)       # scale = gamma * invstd
+    st[3] = torch.randn(ci, generator=g_) * 0.2 - st[0] * st[2]
+    st = st.cuda()
+    ws = torch.empty(n.call("spcl_bnrelu_bwd_workspace_bytes", N, H2, W2, ci) // 4, device="cuda")
+    # reference path
+    g_ref, _ = conv(n, dy_in, dtype, N, H, W, co, co, ci, wp_t, 0)
+    dg0, db0 = torch.empty(ci, device="cuda"), torch.empty(ci, device="cuda")
+    dy0 = torch.empty(N, H2, W2, ci, dtype=dtype, device="cuda")
+    n.call("spcl_bnrelu_pool_backward", n.ptr(y2), None, n.ptr(g_ref), dtc, N, H2, W2, ci, ci, n.ptr(st[0]), n.ptr(st[1]),
+           n.ptr(st[2]), n.ptr(st[3]), 1, n.ptr(ws), n.ptr(dg0), n.ptr(db0), n.ptr(dy0), n.stream())
+    # fused path
+    nt = n.call("spcl_conv_stat_rows", dtc, N, H, W, co, ci)
+    g1 = torch.empty(N, H, W, ci, dtype=dtype, device="cuda")
+    rows = torch.full((nt * 2 * ci,), float("nan"), device="cuda")
+    n.call("spcl_conv3x3_dgrad_poolstats", n.ptr(dy_in), dtc, N, H, W, co, ci, n.ptr(wp_t), n.ptr(g1), n.ptr(y2), H2, W2,
+           n.ptr(st[2]), n.ptr(st[3]), n.ptr(st[0]), n.ptr(rows), n.stream())
+    assert torch.equal(g1, g_ref)
+    assert not torch.isnan(rows).any()
+    dg1, db1 = torch.empty(ci, device="cuda"), torch.empty(ci, device="cuda")
+    dy1 = torch.empty(N, H2, W2, ci, dtype=dtype, device="cuda")
+    n.call("spcl_bnrelu_pool_backward_rows", n.ptr(y2), n.ptr(g1), n.ptr(rows), nt, dtc, N, H2, W2, ci, ci, n.ptr(st[0]),
+           n.ptr(st[1]), n.ptr(st[2]), n.ptr(st[3]), 1, n.ptr(ws), n.ptr(dg1), n.ptr(db1), n.ptr(dy1), n.stream())
+    assert relerr(dg1, dg0) < 2e-5 and relerr(db1, db0) < 2e-5
+    assert relerr(dy1.float(), dy0.float()) < 8e-3
