@@ -96,6 +96,22 @@ int spcl_proj_backward(const float* dz, int dtype, int N, int HW, int C, int Cs,
                        float* dw1, float* db1, float* dw2, float* db2, float* scratch /* [N,hid]+[N,out]+[N,C] f32 */,
                        void* dfeat, void* stream);
 
+/* K <= 4 heads of IDENTICAL shape on the SAME feature -- several meta-label hooks on one encoder tap (hooks/creator.py:
+ * 102-124 builds one INFONCEHook per contrast_on, each with its own ProjectionHead; semi_seg/hooks/infonce.py:224-231
+ * projects the same tensor in each): the feature is average-pooled once and every layer of all K heads is ONE launch
+ * (blockIdx.z = head); the backward sums the K input gradients in head order and broadcasts once.  The pointer
+ * arguments marked [] are HOST arrays of K device pointers; the rest as spcl_proj_forward / spcl_proj_backward.
+ * scratch: K * N * (out_dim + hid) + N * C floats. */
+int spcl_proj_heads_forward(int K, const void* feat, int dtype, int N, int HW, int C, int Cs, const float* const* w1 /*[]*/,
+                            const float* const* b1 /*[]*/, const float* const* w2 /*[]*/, const float* const* b2 /*[]*/,
+                            int hid, int out_dim, int normalize, float* pooled, float* const* pre /*[]*/,
+                            float* const* o /*[]*/, float* const* z /*[]*/, void* stream);
+int spcl_proj_heads_backward(int K, const float* const* dz /*[]*/, int dtype, int N, int HW, int C, int Cs,
+                             const float* const* w1 /*[]*/, const float* const* w2 /*[]*/, int hid, int out_dim,
+                             int normalize, const float* pooled, const float* const* pre /*[]*/,
+                             const float* const* o /*[]*/, float* const* dw1 /*[]*/, float* const* db1 /*[]*/,
+                             float* const* dw2 /*[]*/, float* const* db2 /*[]*/, float* scratch, void* dfeat, void* stream);
+
 /* ---------------------------------------------------------------- encoder --------------------------------
  * Replaces semi_seg/arch/unet.py:67-82 (_ConvBlock: Conv2d 3x3 no bias -> BatchNorm2d -> ReLU, x2),
  * :118-121 (MaxPool2d 2x2), :156-190 (forward until Conv5) and their autograd backward (K1-K4, K17).

@@ -102,6 +102,12 @@ class CombineEpochHook(EpocherHook):
             if len(members) > 1:
                 for h in members:
                     h._share_pool = True
+                # ... and, when their projector heads have one shape, run as ONE batched projection (one launch per
+                # layer for all heads; `batchable_heads` decides)
+                fn = getattr(members[0], "batchable_heads", None)
+                if fn is not None and fn(members):
+                    for h in members:
+                        h._batch_group = members
 
     def _broadcast(self, method, *args, **kwargs):
         return [getattr(hook, method)(*args, **kwargs) for hook in self._epocher_hook]

@@ -33,11 +33,19 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const T* __restrict__ feat
 // the rows n are processed RB at a time with all their loads issued together (a row-at-a-time loop was a chain of
 // eight ~1 us global-load latencies: 12.5 us for a 64x256x256 product).  act = leaky (x is a saved pre-activation)
 // when LEAKY_IN.
+// Up to PROJ_MAX_HEADS projector heads of identical shape run as ONE launch per layer: blockIdx.z picks the head, the
+// pointer tables (passed by value) its tensors.  A single head is the table of length one.
+constexpr int PROJ_MAX_HEADS = 4;
+struct CPtrs { const float* p[PROJ_MAX_HEADS]; };
+struct MPtrs { float* p[PROJ_MAX_HEADS]; };
+
 template <bool LEAKY_IN>
-__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
-                                                         const float* __restrict__ b, int N, int K, int O,
-                                                         float* __restrict__ y) {
+__global__ __launch_bounds__(256) void linear_fwd_kernel(CPtrs xs, CPtrs Ws, CPtrs bs, int N, int K, int O, MPtrs ys) {
   constexpr int RB = 8, KMAX = 8;  // K <= 512
+  const float* __restrict__ x = xs.p[blockIdx.z];
+  const float* __restrict__ W = Ws.p[blockIdx.z];
+  const float* __restrict__ b = bs.p[blockIdx.z];
+  float* __restrict__ y = ys.p[blockIdx.z];
   const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (o >= O) return;
@@ -74,8 +82,9 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
 }
 
 // z = o / max(||o||, 1e-12)   (F.normalize p=2 dim=1)
-__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ o, int N, int O,
-                                                         float* __restrict__ z) {
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(CPtrs os, int N, int O, MPtrs zs) {
+  const float* __restrict__ o = os.p[blockIdx.z];
+  float* __restrict__ z = zs.p[blockIdx.z];
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (n >= N) return;
@@ -90,8 +99,10 @@ __global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict
 }
 
 // do = (dz - z (z.dz)) / max(||o||,eps)
-__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ o, const float* __restrict__ dz,
-                                                         int N, int O, float* __restrict__ d_o) {
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(CPtrs os, CPtrs dzs, int N, int O, MPtrs d_os) {
+  const float* __restrict__ o = os.p[blockIdx.z];
+  const float* __restrict__ dz = dzs.p[blockIdx.z];
+  float* __restrict__ d_o = d_os.p[blockIdx.z];
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (n >= N) return;
@@ -118,9 +129,11 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
 
 // dW[o][k] = sum_n g[n][o] * act(x[n][k]);  db[o] = sum_n g[n][o]      (thread per (o,k), n sequential)
 template <bool LEAKY_IN>
-__global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ x,
-                                                           int N, int K, int O, float* __restrict__ dW,
-                                                           float* __restrict__ db) {
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(CPtrs gs, CPtrs xs, int N, int K, int O, MPtrs dWs, MPtrs dbs) {
+  const float* __restrict__ g = gs.p[blockIdx.z];
+  const float* __restrict__ x = xs.p[blockIdx.z];
+  float* __restrict__ dW = dWs.p[blockIdx.z];
+  float* __restrict__ db = dbs.p[blockIdx.z];
   const int o = blockIdx.y;
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= K) return;
@@ -139,25 +152,30 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
 
 // dx[n][k] = (sum_o g[n][o] W[o][k]) * (LEAKY_OUT ? leaky'(pre[n][k]) : 1).  Workgroup = (row n, 64 columns k): the
 // 4 waves take interleaved o and are combined through LDS in fixed order.
+// NSUM > 0: the heads share the input (the pooled feature): ONE output, the sum over the NSUM heads in index order.
 template <bool LEAKY_OUT>
-__global__ __launch_bounds__(256) void linear_dgrad_kernel(const float* __restrict__ g, const float* __restrict__ W,
-                                                           const float* __restrict__ pre, int N, int K, int O,
-                                                           float* __restrict__ dx) {
+__global__ __launch_bounds__(256) void linear_dgrad_kernel(CPtrs gs, CPtrs Ws, CPtrs pres, int N, int K, int O, MPtrs dxs,
+                                                           int nsum) {
   __shared__ float red[4][64];
   const int n = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int k = blockIdx.x * 64 + lane;
+  const int h0 = nsum > 0 ? 0 : blockIdx.z, h1 = nsum > 0 ? nsum : blockIdx.z + 1;
   float s = 0.f;
   if (k < K) {
+    for (int h = h0; h < h1; ++h) {
+      const float* __restrict__ g = gs.p[h];
+      const float* __restrict__ W = Ws.p[h];
 #pragma unroll 8
-    for (int o = wave; o < O; o += 4) s = fmaf(g[(size_t)n * O + o], W[(size_t)o * K + k], s);
+      for (int o = wave; o < O; o += 4) s = fmaf(g[(size_t)n * O + o], W[(size_t)o * K + k], s);
+    }
   }
   red[wave][lane] = s;
   __syncthreads();
   if (wave == 0 && k < K) {
     float v = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
-    if (LEAKY_OUT) v *= pre[(size_t)n * K + k] > 0.f ? 1.f : kLeaky;
-    dx[(size_t)n * K + k] = v;
+    if (LEAKY_OUT) v *= pres.p[h0][(size_t)n * K + k] > 0.f ? 1.f : kLeaky;
+    dxs.p[h0][(size_t)n * K + k] = v;
   }
 }
 
@@ -257,6 +275,16 @@ extern "C" int spcl_adaptive_pool2d_forward(const void* x, int dtype, int N, int
   hipStream_t st = (hipStream_t)stream;
   const size_t total = (size_t)N * OH * OW * C;
   dim3 g((unsigned)((total + 255) / 256));
+  if (mode == 0 && OH == 1 && OW == 1 && (dtype == SPCL_F32 || dtype == SPCL_BF16)) {
+    // global average (every ProjectionHead, and the pooling several hooks share): the coalesced kernel of the projector
+    // path (4 waves x 64 channels per image: 5 us at 128 x 16 x 16 x 256; the one-thread-per-output kernel below walks
+    // H x W strided 2-byte loads per thread: 72 us)
+    dim3 pg(cdiv(C, 64), N);
+    if (dtype == SPCL_F32) SPCL_LAUNCH(avgpool_kernel<float>, pg, dim3(256), 0, st, (const float*)x, H * W, C, Cs, out);
+    else SPCL_LAUNCH(avgpool_kernel<bf16_t>, pg, dim3(256), 0, st, (const bf16_t*)x, H * W, C, Cs, out);
+    SPCL_LAUNCH_CHECK("adaptive_pool2d_forward");
+    return SPCL_OK;
+  }
   if (dtype == SPCL_F32 && mode == 0)
     SPCL_LAUNCH((adaptive_pool_fwd_kernel<float, false>), g, dim3(256), 0, st, (const float*)x, H, W, C, Cs, OH, OW, out, argmax, total);
   else if (dtype == SPCL_F32)
@@ -281,6 +309,12 @@ extern "C" int spcl_adaptive_pool2d_backward(const float* dout, const int* argma
   hipStream_t st = (hipStream_t)stream;
   const size_t total = (size_t)N * H * W * Cs;
   dim3 g((unsigned)((total + 255) / 256));
+  if (mode == 0 && OH == 1 && OW == 1 && (dtype == SPCL_F32 || dtype == SPCL_BF16)) {  // global average: one broadcast
+    if (dtype == SPCL_F32) SPCL_LAUNCH(avgpool_bwd_kernel<float>, g, dim3(256), 0, st, dout, H * W, C, Cs, (float*)dx, total);
+    else SPCL_LAUNCH(avgpool_bwd_kernel<bf16_t>, g, dim3(256), 0, st, dout, H * W, C, Cs, (bf16_t*)dx, total);
+    SPCL_LAUNCH_CHECK("adaptive_pool2d_backward");
+    return SPCL_OK;
+  }
   if (dtype == SPCL_F32 && mode == 0)
     SPCL_LAUNCH((adaptive_pool_bwd_kernel<float, false>), g, dim3(256), 0, st, dout, argmax, H, W, C, Cs, OH, OW, (float*)dx, total);
   else if (dtype == SPCL_F32)
@@ -297,17 +331,105 @@ extern "C" int spcl_adaptive_pool2d_backward(const float* dout, const int* argma
   return SPCL_OK;
 }
 
+static CPtrs c1(const float* p) { CPtrs t{}; t.p[0] = p; return t; }
+static MPtrs m1(float* p) { MPtrs t{}; t.p[0] = p; return t; }
+
 extern "C" int spcl_l2norm_rows_forward(const float* x, size_t rows, int O, float* z, void* stream) {
   SPCL_CHECK_ARG(x && z && rows > 0 && O > 0, "l2norm_rows_forward: bad argument");
-  SPCL_LAUNCH(l2norm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, (int)rows, O, z);
+  SPCL_LAUNCH(l2norm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, c1(x), (int)rows, O, m1(z));
   SPCL_LAUNCH_CHECK("l2norm_rows_forward");
   return SPCL_OK;
 }
 
 extern "C" int spcl_l2norm_rows_backward(const float* x, const float* dz, size_t rows, int O, float* dx, void* stream) {
   SPCL_CHECK_ARG(x && dz && dx && rows > 0 && O > 0, "l2norm_rows_backward: bad argument");
-  SPCL_LAUNCH(l2norm_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, dz, (int)rows, O, dx);
+  SPCL_LAUNCH(l2norm_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, c1(x), c1(dz), (int)rows, O, m1(dx));
   SPCL_LAUNCH_CHECK("l2norm_rows_backward");
+  return SPCL_OK;
+}
+
+// K heads of one shape on the same feature: average pool once, then one launch per layer for all heads
+static int proj_heads_forward(int K, const void* feat, int dtype, int N, int HW, int C, int Cs, const float* const* w1,
+                              const float* const* b1, const float* const* w2, const float* const* b2, int hid, int out_dim,
+                              int normalize, float* pooled, float* const* pre, float* const* o, float* const* z,
+                              hipStream_t st, const char* who) {
+  dim3 pg(cdiv(C, 64), N);
+  if (dtype == SPCL_F32)
+    SPCL_LAUNCH(avgpool_kernel<float>, pg, dim3(256), 0, st, (const float*)feat, HW, C, Cs, pooled);
+  else if (dtype == SPCL_BF16)
+    SPCL_LAUNCH(avgpool_kernel<bf16_t>, pg, dim3(256), 0, st, (const bf16_t*)feat, HW, C, Cs, pooled);
+  else {
+    set_error("%s: dtype %d", who, dtype);
+    return SPCL_EINVAL;
+  }
+  CPtrs P{}, W1{}, B1{}, W2{}, B2{}, PRE{}, O{};
+  MPtrs PREm{}, Om{}, Zm{};
+  for (int k = 0; k < K; ++k) {
+    P.p[k] = pooled; W1.p[k] = w1[k]; B1.p[k] = b1[k];
+    if (hid > 0) { W2.p[k] = w2[k]; B2.p[k] = b2[k]; PRE.p[k] = pre[k]; PREm.p[k] = pre[k]; }
+    O.p[k] = o[k]; Om.p[k] = o[k]; Zm.p[k] = z[k];
+  }
+  const int ny = (N + 7) / 8 < 8 ? (N + 7) / 8 : 8;  // 8 rows per block iteration
+  if (hid > 0) {
+    SPCL_LAUNCH(linear_fwd_kernel<false>, dim3(cdiv(hid, 4), ny, K), dim3(256), 0, st, P, W1, B1, N, C, hid, PREm);
+    SPCL_LAUNCH(linear_fwd_kernel<true>, dim3(cdiv(out_dim, 4), ny, K), dim3(256), 0, st, PRE, W2, B2, N, hid, out_dim, Om);
+  } else {
+    SPCL_LAUNCH(linear_fwd_kernel<false>, dim3(cdiv(out_dim, 4), ny, K), dim3(256), 0, st, P, W1, B1, N, C, out_dim, Om);
+  }
+  if (normalize)
+    SPCL_LAUNCH(l2norm_fwd_kernel, dim3(cdiv(N, 4), 1, K), dim3(256), 0, st, O, N, out_dim, Zm);
+  else
+    for (int k = 0; k < K; ++k)
+      (void)hipMemcpyAsync(z[k], o[k], (size_t)N * out_dim * sizeof(float), hipMemcpyDeviceToDevice, st);
+  return SPCL_OK;
+}
+
+static int proj_heads_backward(int K, const float* const* dz, int dtype, int N, int HW, int C, int Cs,
+                               const float* const* w1, const float* const* w2, int hid, int out_dim, int normalize,
+                               const float* pooled, const float* const* pre, const float* const* o, float* const* dw1,
+                               float* const* db1, float* const* dw2, float* const* db2, float* scratch, void* dfeat,
+                               hipStream_t st, const char* who) {
+  // scratch: [K][N,out] d_o | [K][N,hid] dpre | [N,C] dpool
+  float* d_o = scratch;
+  float* dpre = d_o + (size_t)K * N * out_dim;
+  float* dpool = dpre + (size_t)K * N * (hid > 0 ? hid : 0);
+  CPtrs DZ{}, O{}, GO{}, PRE{}, W1{}, W2{}, DPRE{}, P{};
+  MPtrs DOm{}, DPREm{}, DW1{}, DB1{}, DW2{}, DB2{}, DPOOL{};
+  for (int k = 0; k < K; ++k) {
+    DZ.p[k] = dz[k]; O.p[k] = o[k]; W1.p[k] = w1[k]; P.p[k] = pooled;
+    DOm.p[k] = d_o + (size_t)k * N * out_dim;
+    GO.p[k] = normalize ? DOm.p[k] : dz[k];
+    DW1.p[k] = dw1[k]; DB1.p[k] = db1[k];
+    if (hid > 0) {
+      PRE.p[k] = pre[k]; W2.p[k] = w2[k]; DW2.p[k] = dw2[k]; DB2.p[k] = db2[k];
+      DPREm.p[k] = dpre + (size_t)k * N * hid; DPRE.p[k] = DPREm.p[k];
+    }
+  }
+  DPOOL.p[0] = dpool;
+  if (normalize) SPCL_LAUNCH(l2norm_bwd_kernel, dim3(cdiv(N, 4), 1, K), dim3(256), 0, st, O, DZ, N, out_dim, DOm);
+  if (hid > 0) {
+    SPCL_LAUNCH(linear_wgrad_kernel<true>, dim3(cdiv(hid, 256), out_dim, K), dim3(256), 0, st, GO, PRE, N, hid, out_dim, DW2, DB2);
+    SPCL_LAUNCH(linear_dgrad_kernel<true>, dim3(cdiv(hid, 64), N, K), dim3(256), 0, st, GO, W2, PRE, N, hid, out_dim, DPREm, 0);
+    SPCL_LAUNCH(linear_wgrad_kernel<false>, dim3(cdiv(C, 256), hid, K), dim3(256), 0, st, DPRE, P, N, C, hid, DW1, DB1);
+    if (dfeat)
+      SPCL_LAUNCH(linear_dgrad_kernel<false>, dim3(cdiv(C, 64), N, 1), dim3(256), 0, st, DPRE, W1, CPtrs{}, N, C, hid, DPOOL, K);
+  } else {
+    SPCL_LAUNCH(linear_wgrad_kernel<false>, dim3(cdiv(C, 256), out_dim, K), dim3(256), 0, st, GO, P, N, C, out_dim, DW1, DB1);
+    if (dfeat)
+      SPCL_LAUNCH(linear_dgrad_kernel<false>, dim3(cdiv(C, 64), N, 1), dim3(256), 0, st, GO, W1, CPtrs{}, N, C, out_dim, DPOOL, K);
+  }
+  if (dfeat) {
+    const size_t total = (size_t)N * HW * Cs;
+    dim3 g((unsigned)((total + 255) / 256));
+    if (dtype == SPCL_F32)
+      SPCL_LAUNCH(avgpool_bwd_kernel<float>, g, dim3(256), 0, st, (const float*)dpool, HW, C, Cs, (float*)dfeat, total);
+    else if (dtype == SPCL_BF16)
+      SPCL_LAUNCH(avgpool_bwd_kernel<bf16_t>, g, dim3(256), 0, st, (const float*)dpool, HW, C, Cs, (bf16_t*)dfeat, total);
+    else {
+      set_error("%s: dtype %d", who, dtype);
+      return SPCL_EINVAL;
+    }
+  }
   return SPCL_OK;
 }
 
@@ -318,30 +440,9 @@ extern "C" int spcl_proj_forward(const void* feat, int dtype, int N, int HW, int
   SPCL_CHECK_ARG(N > 0 && HW > 0 && C > 0 && Cs >= C && out_dim > 0 && hid >= 0, "proj_forward: bad shape");
   SPCL_CHECK_ARG(hid == 0 || (w2 && b2 && pre), "proj_forward: mlp head needs w2/b2/pre");
   SPCL_CHECK_ARG(C <= 512 && hid <= 512, "proj_forward: at most 512 input / hidden features (C=%d, hid=%d)", C, hid);
-  hipStream_t st = (hipStream_t)stream;
-  dim3 pg(cdiv(C, 64), N);
-  if (dtype == SPCL_F32)
-    SPCL_LAUNCH(avgpool_kernel<float>, pg, dim3(256), 0, st, (const float*)feat, HW, C, Cs, pooled);
-  else if (dtype == SPCL_BF16)
-    SPCL_LAUNCH(avgpool_kernel<bf16_t>, pg, dim3(256), 0, st, (const bf16_t*)feat, HW, C, Cs, pooled);
-  else {
-    set_error("proj_forward: dtype %d", dtype);
-    return SPCL_EINVAL;
-  }
-  const int ny = (N + 7) / 8 < 8 ? (N + 7) / 8 : 8;  // 8 rows per block iteration
-  if (hid > 0) {
-    SPCL_LAUNCH(linear_fwd_kernel<false>, dim3(cdiv(hid, 4), ny), dim3(256), 0, st, (const float*)pooled, w1,
-                       b1, N, C, hid, pre);
-    SPCL_LAUNCH(linear_fwd_kernel<true>, dim3(cdiv(out_dim, 4), ny), dim3(256), 0, st, (const float*)pre, w2,
-                       b2, N, hid, out_dim, o);
-  } else {
-    SPCL_LAUNCH(linear_fwd_kernel<false>, dim3(cdiv(out_dim, 4), ny), dim3(256), 0, st, (const float*)pooled,
-                       w1, b1, N, C, out_dim, o);
-  }
-  if (normalize)
-    SPCL_LAUNCH(l2norm_fwd_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, (const float*)o, N, out_dim, z);
-  else
-    (void)hipMemcpyAsync(z, o, (size_t)N * out_dim * sizeof(float), hipMemcpyDeviceToDevice, st);
+  const int rc = proj_heads_forward(1, feat, dtype, N, HW, C, Cs, &w1, &b1, &w2, &b2, hid, out_dim, normalize, pooled, &pre,
+                                    &o, &z, (hipStream_t)stream, "proj_forward");
+  if (rc != SPCL_OK) return rc;
   SPCL_LAUNCH_CHECK("proj_forward");
   return SPCL_OK;
 }
@@ -353,46 +454,49 @@ extern "C" int spcl_proj_backward(const float* dz, int dtype, int N, int HW, int
   SPCL_CHECK_ARG(dz && w1 && pooled && o && dw1 && db1 && scratch, "proj_backward: null pointer");
   SPCL_CHECK_ARG(N > 0 && HW > 0 && C > 0 && Cs >= C && out_dim > 0 && hid >= 0, "proj_backward: bad shape");
   SPCL_CHECK_ARG(hid == 0 || (w2 && pre && dw2 && db2), "proj_backward: mlp head needs w2/pre/dw2/db2");
-  hipStream_t st = (hipStream_t)stream;
-  float* d_o = scratch;                                 // [N,out]
-  float* dpre = scratch + (size_t)N * out_dim;          // [N,hid]
-  float* dpool = dpre + (size_t)N * (hid > 0 ? hid : 0);  // [N,C]
-  const float* go = dz;
-  if (normalize) {
-    SPCL_LAUNCH(l2norm_bwd_kernel, dim3(cdiv(N, 4)), dim3(256), 0, st, o, dz, N, out_dim, d_o);
-    go = d_o;
-  }
-  if (hid > 0) {
-    SPCL_LAUNCH(linear_wgrad_kernel<true>, dim3(cdiv(hid, 256), out_dim), dim3(256), 0, st, go, pre, N, hid,
-                       out_dim, dw2, db2);
-    SPCL_LAUNCH(linear_dgrad_kernel<true>, dim3(cdiv(hid, 64), N), dim3(256), 0, st, go, w2, pre, N, hid,
-                       out_dim, dpre);
-    SPCL_LAUNCH(linear_wgrad_kernel<false>, dim3(cdiv(C, 256), hid), dim3(256), 0, st, (const float*)dpre,
-                       pooled, N, C, hid, dw1, db1);
-    if (dfeat)
-      SPCL_LAUNCH(linear_dgrad_kernel<false>, dim3(cdiv(C, 64), N), dim3(256), 0, st, (const float*)dpre, w1,
-                         (const float*)nullptr, N, C, hid, dpool);
-  } else {
-    SPCL_LAUNCH(linear_wgrad_kernel<false>, dim3(cdiv(C, 256), out_dim), dim3(256), 0, st, go, pooled, N, C,
-                       out_dim, dw1, db1);
-    if (dfeat)
-      SPCL_LAUNCH(linear_dgrad_kernel<false>, dim3(cdiv(C, 64), N), dim3(256), 0, st, go, w1,
-                         (const float*)nullptr, N, C, out_dim, dpool);
-  }
-  if (dfeat) {
-    const size_t total = (size_t)N * HW * Cs;
-    dim3 g((unsigned)((total + 255) / 256));
-    if (dtype == SPCL_F32)
-      SPCL_LAUNCH(avgpool_bwd_kernel<float>, g, dim3(256), 0, st, (const float*)dpool, HW, C, Cs,
-                         (float*)dfeat, total);
-    else if (dtype == SPCL_BF16)
-      SPCL_LAUNCH(avgpool_bwd_kernel<bf16_t>, g, dim3(256), 0, st, (const float*)dpool, HW, C, Cs,
-                         (bf16_t*)dfeat, total);
-    else {
-      set_error("proj_backward: dtype %d", dtype);
-      return SPCL_EINVAL;
-    }
-  }
+  const int rc = proj_heads_backward(1, &dz, dtype, N, HW, C, Cs, &w1, &w2, hid, out_dim, normalize, pooled, &pre, &o, &dw1,
+                                     &db1, &dw2, &db2, scratch, dfeat, (hipStream_t)stream, "proj_backward");
+  if (rc != SPCL_OK) return rc;
   SPCL_LAUNCH_CHECK("proj_backward");
+  return SPCL_OK;
+}
+
+// K <= 4 heads of identical shape on the SAME feature (several meta-label hooks on one encoder tap, SURVEY row N4;
+// hooks/creator.py:102-124): pointer arrays of length K (host memory), everything else as the single-head calls.
+// scratch: K * N * (out_dim + hid) + N * C floats.
+extern "C" int spcl_proj_heads_forward(int K, const void* feat, int dtype, int N, int HW, int C, int Cs,
+                                       const float* const* w1, const float* const* b1, const float* const* w2,
+                                       const float* const* b2, int hid, int out_dim, int normalize, float* pooled,
+                                       float* const* pre, float* const* o, float* const* z, void* stream) {
+  SPCL_CHECK_ARG(K >= 1 && K <= PROJ_MAX_HEADS, "proj_heads_forward: %d heads (1..%d)", K, PROJ_MAX_HEADS);
+  SPCL_CHECK_ARG(feat && w1 && b1 && pooled && o && z && (hid == 0 || (w2 && b2 && pre)), "proj_heads_forward: null pointer");
+  SPCL_CHECK_ARG(N > 0 && HW > 0 && C > 0 && Cs >= C && out_dim > 0 && hid >= 0 && C <= 512 && hid <= 512,
+                 "proj_heads_forward: bad shape");
+  for (int k = 0; k < K; ++k)
+    SPCL_CHECK_ARG(w1[k] && b1[k] && o[k] && z[k] && (hid == 0 || (w2[k] && b2[k] && pre[k])),
+                   "proj_heads_forward: null pointer in head %d", k);
+  const int rc = proj_heads_forward(K, feat, dtype, N, HW, C, Cs, w1, b1, w2, b2, hid, out_dim, normalize, pooled, pre, o, z,
+                                    (hipStream_t)stream, "proj_heads_forward");
+  if (rc != SPCL_OK) return rc;
+  SPCL_LAUNCH_CHECK("proj_heads_forward");
+  return SPCL_OK;
+}
+
+extern "C" int spcl_proj_heads_backward(int K, const float* const* dz, int dtype, int N, int HW, int C, int Cs,
+                                        const float* const* w1, const float* const* w2, int hid, int out_dim,
+                                        int normalize, const float* pooled, const float* const* pre,
+                                        const float* const* o, float* const* dw1, float* const* db1, float* const* dw2,
+                                        float* const* db2, float* scratch, void* dfeat, void* stream) {
+  SPCL_CHECK_ARG(K >= 1 && K <= PROJ_MAX_HEADS, "proj_heads_backward: %d heads (1..%d)", K, PROJ_MAX_HEADS);
+  SPCL_CHECK_ARG(dz && w1 && pooled && o && dw1 && db1 && scratch && (hid == 0 || (w2 && pre && dw2 && db2)),
+                 "proj_heads_backward: null pointer");
+  SPCL_CHECK_ARG(N > 0 && HW > 0 && C > 0 && Cs >= C && out_dim > 0 && hid >= 0, "proj_heads_backward: bad shape");
+  for (int k = 0; k < K; ++k)
+    SPCL_CHECK_ARG(dz[k] && w1[k] && o[k] && dw1[k] && db1[k] && (hid == 0 || (w2[k] && pre[k] && dw2[k] && db2[k])),
+                   "proj_heads_backward: null pointer in head %d", k);
+  const int rc = proj_heads_backward(K, dz, dtype, N, HW, C, Cs, w1, w2, hid, out_dim, normalize, pooled, pre, o, dw1, db1,
+                                     dw2, db2, scratch, dfeat, (hipStream_t)stream, "proj_heads_backward");
+  if (rc != SPCL_OK) return rc;
+  SPCL_LAUNCH_CHECK("proj_heads_backward");
   return SPCL_OK;
 }

@@ -236,6 +236,69 @@ def projector(feat, w1, b1, w2=None, b2=None, normalize=True):
     return _ProjectorFn.apply(feat, w1, b1, w2, b2, normalize)
 
 
+class _ProjectorHeadsFn(torch.autograd.Function):
+    """K <= 4 MLP heads of identical shape on the SAME feature (several meta-label hooks on one encoder tap): the feature is
+    pooled once and every layer of all heads is one launch (spcl_proj_heads_forward / _backward).  Inputs: feat, normalize,
+    then (w1, b1, w2, b2) per head; outputs: one z [N, out] per head."""
+
+    @staticmethod
+    def forward(ctx, feat, normalize, *params):
+        K = len(params) // 4
+        heads = [params[4 * k:4 * k + 4] for k in range(K)]
+        _n.require_gpu(feat, *params)
+        x, cs = as_nhwc(feat.detach())
+        N, H, W, _ = x.shape
+        C = feat.shape[1]
+        dev = feat.device
+        hid, out_dim = heads[0][0].shape[0], heads[0][2].shape[0]
+        cont = [[t.detach().contiguous().float() for t in h] for h in heads]
+        pooled = torch.empty(N, C, dtype=torch.float32, device=dev)
+        pre = torch.empty(K, N, hid, dtype=torch.float32, device=dev)
+        o = torch.empty(K, N, out_dim, dtype=torch.float32, device=dev)
+        z = [torch.empty(N, out_dim, dtype=torch.float32, device=dev) for _ in range(K)]  # separate: handed to autograd
+        col = lambda i: _n.ptr_array([c[i] for c in cont])  # noqa: E731
+        _n.call("spcl_proj_heads_forward", K, _n.ptr(x), _n.dtype_code(x.dtype), N, H * W, C, cs, col(0), col(1), col(2),
+                col(3), hid, out_dim, int(bool(normalize)), _n.ptr(pooled), _n.ptr_array(list(pre)), _n.ptr_array(list(o)),
+                _n.ptr_array(z), _n.stream())
+        ctx.save_for_backward(pooled, pre, o, *[c[0] for c in cont], *[c[2] for c in cont])
+        ctx.meta = (K, N, H, W, C, cs, hid, out_dim, bool(normalize), x.dtype, feat.dtype)
+        ctx.params = params
+        return tuple(z)
+
+    @staticmethod
+    def backward(ctx, *dzs):
+        K, N, H, W, C, cs, hid, out_dim, normalize, xdt, fdt = ctx.meta
+        saved = ctx.saved_tensors
+        pooled, pre, o = saved[:3]
+        w1s, w2s = saved[3:3 + K], saved[3 + K:3 + 2 * K]
+        dev = pooled.device
+        dzc = [torch.zeros(N, out_dim, dtype=torch.float32, device=dev) if g is None else g.detach().contiguous().float()
+               for g in dzs]
+        ng = ctx.needs_input_grad
+        sk = [take_grad_sink(p, ng[i + 2]) for i, p in enumerate(ctx.params)]
+        shapes = ((hid, C), (hid,), (out_dim, hid), (out_dim,))
+        grads = [_grad_buffer(sk[i], shapes[i % 4], dev) for i in range(4 * K)]
+        scratch = torch.empty(K * N * (out_dim + hid) + N * C, dtype=torch.float32, device=dev)
+        need_dfeat = ng[0]
+        dfeat = torch.empty(N, H, W, cs, dtype=xdt, device=dev) if need_dfeat else None
+        col = lambda i: _n.ptr_array([grads[4 * k + i] for k in range(K)])  # noqa: E731
+        _n.call("spcl_proj_heads_backward", K, _n.ptr_array(dzc), _n.dtype_code(xdt), N, H * W, C, cs, _n.ptr_array(list(w1s)),
+                _n.ptr_array(list(w2s)), hid, out_dim, int(normalize), _n.ptr(pooled), _n.ptr_array(list(pre)),
+                _n.ptr_array(list(o)), col(0), col(1), col(2), col(3), _n.ptr(scratch), _n.ptr(dfeat), _n.stream())
+        gfeat = None
+        if need_dfeat:
+            gfeat = nhwc_to_logical(dfeat, C)
+            if gfeat.dtype != fdt:
+                gfeat = gfeat.to(fdt)
+        return (gfeat, None) + tuple(grads)
+
+
+def projector_heads(feat, heads, normalize=True):
+    """``heads``: list of (w1, b1, w2, b2) of identical shapes (at most 4) -> list of z [N, out], one per head"""
+    flat = [t for h in heads for t in h]
+    return list(_ProjectorHeadsFn.apply(feat, normalize, *flat))
+
+
 class _FlipBatchFn(torch.autograd.Function):
     """per-sample H / W flips of an [N,C,H,W] batch (spcl_flip_batch); a flip is its own inverse, so is its gradient"""
 

@@ -33,6 +33,10 @@ _SIGNATURES = {
                                   _P, _P, _P, _P, _P]),
     "spcl_proj_backward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, _P, _P, _P,
                                    _P, _P, _P, _P, _P, _P, _P]),
+    "spcl_proj_heads_forward": (c_int, [c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, c_int, c_int,
+                                        _P, _P, _P, _P, _P]),
+    "spcl_proj_heads_backward": (c_int, [c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, _P, _P,
+                                         _P, _P, _P, _P, _P, _P, _P, _P]),
     "spcl_adaptive_pool2d_forward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "spcl_adaptive_pool2d_backward": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P,
                                               _P]),
@@ -157,6 +161,11 @@ def ptr(t):
 
 def stream():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr_array(tensors):
+    """host array of device pointers (None -> NULL), for the entry points that take K tensors of one kind"""
+    return (c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
 
 
 def dtype_code(dt: torch.dtype) -> int:

@@ -152,6 +152,7 @@ class _INFONCEEpochHook(EpocherHook):
         self._n = 0             # batches seen this epoch
         self._label_cache = {}  # batch composition -> device label tensor
         self._share_pool = False  # set by CombineEpochHook when several hooks pool the same feature
+        self._batch_group = None  # ... and the hooks whose heads then run as one batched projection
 
     @property
     def shared_pool_key(self):
@@ -161,6 +162,33 @@ class _INFONCEEpochHook(EpocherHook):
                 or getattr(p, "_pool_name", None) != "adaptive_avg":
             return None
         return (id(self._extractor._model), self._extractor._feature_name)
+
+    @staticmethod
+    def batchable_heads(members):
+        """2..4 hooks whose ProjectionHeads are MLP heads of one shape (the K meta-label hooks of
+        hooks/creator.py:102-124 all are): functional.projector_heads runs them together"""
+        ps = [m._projector for m in members]
+        if not 2 <= len(ps) <= 4 or any(getattr(p, "_head_type", None) != "mlp" for p in ps):
+            return False
+        shape = lambda p: (tuple(p._header[2].weight.shape), tuple(p._header[4].weight.shape), bool(p._normalize))  # noqa: E731
+        return all(shape(p) == shape(ps[0]) for p in ps)
+
+    def _project(self, feature, base):
+        """z of this hook's head; with a batch group the first hook of the step projects for all of them (cached on the
+        tapped tensor, which lives exactly one step)"""
+        if self._batch_group is None:
+            return self._projector(feature)
+        cache = getattr(base, "_spcl_zs", None)
+        if cache is None or cache[0] != feature.shape[0]:
+            heads = [(p._header[2].weight, p._header[2].bias, p._header[4].weight, p._header[4].bias)
+                     for p in (m._projector for m in self._batch_group)]
+            zs = F_hip.projector_heads(feature, heads, self._projector._normalize)
+            cache = (feature.shape[0], {id(m._projector): z for m, z in zip(self._batch_group, zs)})
+            try:
+                base._spcl_zs = cache
+            except AttributeError:
+                pass
+        return cache[1][id(self._projector)]
 
     @meter_focus
     def configure_meters(self, meters):
@@ -195,6 +223,8 @@ class _INFONCEEpochHook(EpocherHook):
         if feature.shape[0] != 2 * n_unl:  # a slice costs a zero-fill + strided copy in backward: only when needed
             feature = feature[-2 * n_unl:]
         if tuple(getattr(self._projector, "_spatial_size", (1, 1))) == (1, 1):
+            if self._batch_group is not None:
+                return feature  # the batched projection pools it (once for all heads)
             if self._share_pool:
                 # K hooks on one feature (run_self_paced_acdc:61-70 / hooks/creator.py:102-124): pool ONCE -- the K
                 # projectors then read [2n, C] rows and autograd adds K [2n, C] gradients before ONE pooling backward,
@@ -224,7 +254,7 @@ class _INFONCEEpochHook(EpocherHook):
     def __call__(self, *, affine_transformer, seed, unlabeled_tf_logits, unlabeled_logits_tf, partition_group,
                  label_group, **kwargs):
         feature = self._two_views(len(unlabeled_logits_tf), affine_transformer, seed)
-        z_first, z_second = torch.chunk(self._projector(feature), 2)
+        z_first, z_second = torch.chunk(self._project(feature, self._extractor.feature()), 2)
         loss = self._criterion(z_first, z_second, target=self._labels(partition_group, label_group, feature.device))
         self._record(loss)
         return loss if self._weight == 1 else loss * self._weight

@@ -74,3 +74,35 @@ def test_projector_scope_errors():
         bad(torch.rand(2, 8, 4, 4).cuda())
     with pytest.raises(AssertionError):
         ProjectionHead(input_dim=8, output_dim=8, head_type="conv", normalize=True)
+
+
+@pytest.mark.parametrize("K,dtype", [(2, torch.float32), (3, torch.bfloat16), (4, torch.float32)])
+def test_batched_heads_equal_the_single_head_calls(K, dtype):
+    """functional.projector_heads (one launch per layer for K heads on one feature) against K functional.projector calls:
+    identical z per head, identical parameter gradients, the feature gradient = the sum of the K single-head ones."""
+    import spcl_amd  # noqa
+    from spcl_amd import functional as F_hip
+    g = torch.Generator().manual_seed(K)
+    N, C, H, W, hid, out = 10, 64, 6, 5, 48, 24
+    feat = torch.randn(N, C, H, W, generator=g).cuda().to(dtype)
+    heads = [[(torch.randn(hid, C, generator=g) / 8).cuda(), (torch.randn(hid, generator=g) / 8).cuda(),
+              (torch.randn(out, hid, generator=g) / 7).cuda(), (torch.randn(out, generator=g) / 7).cuda()]
+             for _ in range(K)]
+    up = [torch.randn(N, out, generator=g).cuda() for _ in range(K)]
+
+    def run(batched):
+        f = feat.clone().requires_grad_(True)
+        hs = [[t.clone().requires_grad_(True) for t in h] for h in heads]
+        zs = F_hip.projector_heads(f, hs) if batched else [F_hip.projector(f, *h) for h in hs]
+        sum((z * u).sum() for z, u in zip(zs, up)).backward()
+        return [z.detach() for z in zs], f.grad, [[t.grad for t in h] for h in hs]
+
+    z0, gf0, gp0 = run(False)
+    z1, gf1, gp1 = run(True)
+    for a, b in zip(z0, z1):
+        assert torch.equal(a, b)
+    for ha, hb in zip(gp0, gp1):
+        for a, b in zip(ha, hb):
+            assert torch.equal(a, b)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2  # the K gradients are added in f32 before the one bf16 rounding
+    assert float((gf0.float() - gf1.float()).abs().max()) <= tol * float(gf0.float().abs().max())
