@@ -343,6 +343,10 @@ int spcl_augment_views(const float* src, int S, int HS, int WS, const int* param
  * flags: device uint8[N] (the host draws the decisions from python `random`, as the reference does).  x != out. */
 int spcl_flip_batch(const void* x, void* out, int elem_size, int N, int C, int H, int W, const uint8_t* flags,
                     void* stream);
+/* The pre-train step's input pair in one launch: out [2N][C][H][W] = [ first | flip(second, flags) ] -- the per-sample
+ * flip of view 2 and the torch.cat of semi_seg/epochers/new_pretrain.py:57-58,93. */
+int spcl_flip_pair(const void* first, const void* second, void* out, int elem_size, int N, int C, int H, int W,
+                   const uint8_t* flags, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Built-in kernel timer (bench.py's live roofline measurement): spcl_profile_enable(1) clears the log and makes every

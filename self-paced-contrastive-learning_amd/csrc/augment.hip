@@ -8,19 +8,23 @@ namespace spcl {
 
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void flip_batch_kernel(const T* __restrict__ x, T* __restrict__ out, int N, int C,
-                                                         int H, int W, const uint8_t* __restrict__ flags) {
+                                                         int H, int W, const uint8_t* __restrict__ flags,
+                                                         const T* __restrict__ head, int NH) {
+  // head != null: `out` has NH + N samples, the first NH are a plain copy of `head` (the unflipped view of the pair)
   const int WV = W / VEC;
-  const size_t total = (size_t)N * C * H * WV;
+  const size_t total = (size_t)(N + NH) * C * H * WV;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int wv = (int)(idx % WV);
     size_t r = idx / WV;
     const int h = (int)(r % H);
     r /= H;  // r = n*C + c
     const int n = (int)(r / C);
-    const uint8_t f = flags[n];
+    const bool copy = n < NH;
+    const uint8_t f = copy ? (uint8_t)0 : flags[n - NH];
     const int sh = (f & 1) ? H - 1 - h : h;
     const int swv = (f & 2) ? WV - 1 - wv : wv;
-    const T* src = x + (r * H + sh) * (size_t)W + (size_t)swv * VEC;
+    const size_t rs = copy ? r : r - (size_t)NH * C;  // sample-channel row inside its source
+    const T* src = (copy ? head : x) + (rs * H + sh) * (size_t)W + (size_t)swv * VEC;
     T v[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) v[e] = src[e];  // contiguous: one vector load
@@ -36,16 +40,17 @@ __global__ __launch_bounds__(256) void flip_batch_kernel(const T* __restrict__ x
 }
 
 template <typename T>
-static void launch_flip(const void* x, void* out, int N, int C, int H, int W, const uint8_t* flags, hipStream_t st) {
+static void launch_flip(const void* x, void* out, int N, int C, int H, int W, const uint8_t* flags, hipStream_t st,
+                        const void* head = nullptr, int NH = 0) {
   constexpr int V = 16 / (int)sizeof(T);
-  const bool vec = W % V == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0);
-  const size_t total = (size_t)N * C * H * (vec ? W / V : W);
+  const bool vec = W % V == 0 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)head % 16 == 0);
+  const size_t total = (size_t)(N + NH) * C * H * (vec ? W / V : W);
   size_t blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   if (vec) SPCL_LAUNCH((flip_batch_kernel<T, V>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)x, (T*)out, N,
-                              C, H, W, flags);
+                              C, H, W, flags, (const T*)head, NH);
   else SPCL_LAUNCH((flip_batch_kernel<T, 1>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)x, (T*)out, N, C,
-                          H, W, flags);
+                          H, W, flags, (const T*)head, NH);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -132,5 +137,23 @@ extern "C" int spcl_flip_batch(const void* x, void* out, int elem_size, int N, i
     return SPCL_EINVAL;
   }
   SPCL_LAUNCH_CHECK("flip_batch");
+  return SPCL_OK;
+}
+
+// The pre-train step's input pair in ONE launch (new_pretrain.py:57-58,93: flip view 2 per sample, then
+// torch.cat([view 1, flipped view 2])): out [2N][C][H][W] = [ first | flip(second, flags) ].
+extern "C" int spcl_flip_pair(const void* first, const void* second, void* out, int elem_size, int N, int C, int H, int W,
+                              const uint8_t* flags, void* stream) {
+  SPCL_CHECK_ARG(first && second && out && flags, "flip_pair: null pointer");
+  SPCL_CHECK_ARG(N > 0 && C > 0 && H > 0 && W > 0, "flip_pair: bad shape");
+  SPCL_CHECK_ARG(first != out && second != out, "flip_pair: in-place is not supported");
+  hipStream_t st = (hipStream_t)stream;
+  if (elem_size == 4) launch_flip<uint32_t>(second, out, N, C, H, W, flags, st, first, N);
+  else if (elem_size == 2) launch_flip<uint16_t>(second, out, N, C, H, W, flags, st, first, N);
+  else {
+    set_error("flip_pair: elem_size %d", elem_size);
+    return SPCL_EINVAL;
+  }
+  SPCL_LAUNCH_CHECK("flip_pair");
   return SPCL_OK;
 }

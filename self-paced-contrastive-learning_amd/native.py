@@ -94,6 +94,7 @@ _SIGNATURES = {
     "spcl_split2_channels": (c_int, [_P, _P, _P, c_int, c_size_t, c_int, c_int, _P]),
     "spcl_augment_views": (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int, _P]),
     "spcl_flip_batch": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "spcl_flip_pair": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "spcl_profile_enable": (c_int, [c_int]),
     "spcl_profile_count": (c_int, []),
     "spcl_profile_get": (c_int, [c_int, c_char_p, c_int, _P, _P, _P]),

@@ -68,6 +68,29 @@ class TensorRandomFlip:
         dims = [a for a in self._axis if random.random() < self._threshold]
         return x.flip(dims) if dims else x
 
+    def apply_pair(self, first: torch.Tensor, second: torch.Tensor) -> torch.Tensor:
+        """``torch.cat([first, stack([self(s) for s in second])])`` (new_pretrain.py:57-58,93) as ONE HIP launch
+        (``spcl_flip_pair``) for contiguous [N,C,H,W] GPU tensors of one shape and dtype; draws the same random stream as
+        ``apply_batch(second)``."""
+        if not (first.is_cuda and second.is_cuda and first.dim() == 4 and first.shape == second.shape
+                and first.dtype == second.dtype and tuple(self._axis) == (1, 2)
+                and not first.requires_grad and not second.requires_grad):
+            return torch.cat([first, self.apply_batch(second)], dim=0)
+        from ... import native as _n
+        dec = tuple(tuple(d) for d in self.decisions(second.shape[0]))
+        key = (dec, second.device, "flags")
+        flags = self._plans.get(key)
+        if flags is None:
+            flags = torch.tensor([int(d[0]) | (int(d[1]) << 1) for d in dec], dtype=torch.uint8, device=second.device)
+            if len(self._plans) < 256:
+                self._plans[key] = flags
+        a, b = first.contiguous(), second.contiguous()
+        N, C, H, W = a.shape
+        out = torch.empty((2 * N, C, H, W), dtype=a.dtype, device=a.device)
+        _n.call("spcl_flip_pair", _n.ptr(a), _n.ptr(b), _n.ptr(out), a.element_size(), N, C, H, W, _n.ptr(flags),
+                _n.stream())
+        return out
+
     def apply_batch(self, x: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
         """Batched equivalent of ``stack([self(s) for s in x])`` drawing the same random stream.
 

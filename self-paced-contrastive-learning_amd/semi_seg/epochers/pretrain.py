@@ -143,14 +143,12 @@ class PretrainEncoderEpocher:
         (unlabeled_image, unlabeled_image_tf), _, unlabeled_filename, unl_partition, unl_group = \
             unzip_twice_transformed(data, self._device)
         if unlabeled_image.is_cuda and unlabeled_image.shape == unlabeled_image_tf.shape:
-            # both views land in ONE [2n,C,H,W] buffer (view 1 copied, view 2 flipped straight into its half), so the
+            # both views land in ONE [2n,C,H,W] buffer in one launch (view 1 copied, view 2 flipped into its half), so the
             # torch.cat of new_pretrain.py:93 is a zero-copy view in `_forward_pass`
-            pair = torch.empty((2 * len(unlabeled_image),) + tuple(unlabeled_image.shape[1:]),
-                               dtype=unlabeled_image.dtype, device=unlabeled_image.device)
             n_unl = len(unlabeled_image)
-            pair[:n_unl].copy_(unlabeled_image)
             with FixRandomSeed(seed):
-                self._affine_transformer.apply_batch(unlabeled_image_tf.to(pair.dtype), out=pair[n_unl:])
+                pair = self._affine_transformer.apply_pair(unlabeled_image,
+                                                           unlabeled_image_tf.to(unlabeled_image.dtype))
             unlabeled_image, unlabeled_image_tf = pair[:n_unl], pair[n_unl:]
         else:
             with FixRandomSeed(seed):

@@ -82,3 +82,23 @@ def test_contrastive_device_loader_batches():
     assert pimg.shape == (16, 1, 224, 224) and all(s.startswith("Case") for s in ps)
     with pytest.raises(TypeError):
         get_contrastive_dataloader([1, 2, 3], {"scan_sample_num": 2})
+
+
+def test_flip_pair_equals_cat_of_view1_and_flipped_view2():
+    """TensorRandomFlip.apply_pair (spcl_flip_pair: the pre-train step's input pair in one launch) == torch.cat([first,
+    apply_batch(second)]) with the same random stream, for f32 and bf16, vector and scalar widths."""
+    import random
+
+    import spcl_amd  # noqa
+    from spcl_amd.semi_seg.epochers.helper import TensorRandomFlip
+    for dtype, W in ((torch.float32, 224), (torch.bfloat16, 64), (torch.float32, 30)):
+        g = torch.Generator().manual_seed(W)
+        a = torch.rand(6, 1, 20, W, generator=g).cuda().to(dtype)
+        b = torch.rand(6, 1, 20, W, generator=g).cuda().to(dtype)
+        tf = TensorRandomFlip(axis=[1, 2], threshold=0.5)
+        random.seed(5)
+        pair = tf.apply_pair(a, b)
+        random.seed(5)
+        ref = torch.cat([a, tf.apply_batch(b)], dim=0)
+        assert pair.shape == ref.shape and torch.equal(pair, ref)
+        assert not torch.equal(pair[6:], b)  # some sample really was flipped
