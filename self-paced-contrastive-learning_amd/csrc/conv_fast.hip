@@ -21,6 +21,7 @@ struct FastArgs {
   const float* in_scale;
   const float* in_shift;
   int N, H, W, CinK, CoutS, tilesX, tilesY, gy;
+  int xcd_remap;  // 1: tiles of an image are dealt to the XCDs in contiguous row-major blocks (see the kernel)
   // MODE 2 (dgrad whose output g is the gradient of relu(bn(y2))): per-tile partial sums of that BatchNorm's backward
   const unsigned char* y2;  // [N][H][W][CoutS] raw conv output of the layer being differentiated
   const float* scale2;      // its BN scale / shift / mean, [CoutS]
@@ -60,7 +61,19 @@ conv3x3_fast_kernel(FastArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r16 = lane & 15, g = lane >> 4;
-  const int tx = blockIdx.x, ty = blockIdx.y;
+  // Workgroups go to the 8 XCDs round-robin in launch order (x fastest): horizontally adjacent tiles would sit on
+  // different XCDs and fetch their shared halo columns from HBM twice.  When an image's tile count divides by 8 each XCD
+  // gets a block of consecutive tiles in row-major order instead (whole tile rows at 224^2: both halo directions hit L2).
+  int tx = blockIdx.x, ty = blockIdx.y;
+  {
+    const int T = a.tilesX * a.tilesY;
+    if (a.xcd_remap && (T & 7) == 0) {
+      const int L = ty * a.tilesX + tx;
+      const int L2 = (L & 7) * (T >> 3) + (L >> 3);
+      ty = L2 / a.tilesX;
+      tx = L2 - ty * a.tilesX;
+    }
+  }
   int n = blockIdx.z, by = 0;
   if (a.gy > 1) {
     by = n % a.gy;
@@ -412,7 +425,7 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
     a.in_scale = a.in_shift = nullptr;
     a.y2 = nullptr; a.scale2 = a.shift2 = a.mean2 = nullptr; a.rows2 = nullptr; a.H2 = a.W2 = 0;
     a.N = c.N; a.H = c.H; a.W = c.W; a.CinK = 16; a.CoutS = 16;
-    a.tilesX = cdiv(c.W, 14); a.tilesY = cdiv(c.H, 14); a.gy = 1;
+    a.tilesX = cdiv(c.W, 14); a.tilesY = cdiv(c.H, 14); a.gy = 1; a.xcd_remap = 0;
     if (!dry) SPCL_LAUNCH((conv3x3_image_kernel<14>), dim3(a.tilesX, a.tilesY, a.N), dim3(64), 0, st, a);
     return true;
   }
@@ -435,6 +448,8 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
   if (c.rows2 != nullptr && c.in_mode != 0) return false;
   a.N = c.N; a.H = c.H; a.W = c.W; a.CinK = c.CinK; a.CoutS = c.CoutS;
   a.tilesX = cdiv(c.W, 14); a.tilesY = cdiv(c.H, th); a.gy = ntn / (NT * nw);
+  static const int env_remap = getenv("SPCL_CONV_XCD_REMAP") ? atoi(getenv("SPCL_CONV_XCD_REMAP")) : 1;
+  a.xcd_remap = (env_remap && a.gy == 1) ? 1 : 0;  // (with gy > 1 the z index interleaves channel blocks: left alone)
   // pooled BatchNorm-backward sums in the epilogue (MODE 3): measured per block against dgrad + separate reduction pass
   // (N = 64): 32 -> 16 @112^2 43 vs 49 us, 128 -> 64 @28^2 21 vs 25.5, 256 -> 128 @14^2 30.5 vs 30.6, but the one-wave
   // 64 -> 32 @56^2 kernel 53.5 vs 43 (56 scattered 8-byte loads per lane behind one wave's MFMAs): not offered there
