@@ -29,6 +29,7 @@ struct WgradArgs {
   int N, H, W, CinS, CinK, CoutS, in_mode;
   int tilesX, tilesY, ntiles, nblk_ci, nblk_co;
   int dbuf;  // 1: LDS tile image double buffered (one barrier per tile); 0: single buffer, twice the residency
+  int xcd_remap;  // 1: a round's tiles are dealt to the XCDs in contiguous eighths (see the tile loop)
   unsigned long long* stamps;  // debug (SPCL_WGRAD_STAMPS=1): per-workgroup cycle counts of the loop phases, else null
 };
 
@@ -275,7 +276,13 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_wgrad_kernel(WgradArgs a)
   unsigned long long t_store = 0, t_bar = 0, t_issue = 0, t_comp = 0, t_first = 0, t_all = 0, ntl = 0;
   const bool stamp = a.stamps != nullptr;
   const unsigned long long c_begin = stamp ? __builtin_amdgcn_s_memtime() : 0;
-  int tile = blockIdx.x;
+  // Round k of the grid covers tiles k G .. k G + G - 1.  Workgroups go to the 8 XCDs round-robin, so with tile = k G + b
+  // neighbouring tiles (which share halo columns / rows of x) sit on different XCDs.  Optional (xcd_remap, OFF: it
+  // measured slower here, unlike in the forward conv kernels): XCD x takes the x-th eighth of the round's tiles,
+  // tile = k G + (b % 8) (G / 8) + b / 8 (a bijection within the round).
+  const int G = (int)gridDim.x;
+  const int pos = (a.xcd_remap && (G & 7) == 0) ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  int tile = pos;
   int buf = 0;
   if (tile < a.ntiles) load_tile(tile);
   if (stamp) t_first = __builtin_amdgcn_s_memtime() - c_begin;
@@ -488,6 +495,8 @@ extern "C" int spcl_conv3x3_wgrad(const void* x, const void* dy, int dtype, int 
   a.tilesX = p.tilesX; a.tilesY = p.tilesY; a.ntiles = p.ntiles; a.nblk_ci = p.nblk_ci; a.nblk_co = p.nblk_co;
   static const int env_dbuf = getenv("SPCL_WGRAD_DBUF") ? atoi(getenv("SPCL_WGRAD_DBUF")) : 1;
   a.dbuf = env_dbuf;
+  static const int env_remap = getenv("SPCL_WGRAD_XCD_REMAP") ? atoi(getenv("SPCL_WGRAD_XCD_REMAP")) : 0;  // measured: +3..12 us per step, off
+  a.xcd_remap = env_remap;
   static const int env_stamps = getenv("SPCL_WGRAD_STAMPS") ? atoi(getenv("SPCL_WGRAD_STAMPS")) : 0;
   static unsigned long long* stamp_buf = nullptr;
   a.stamps = nullptr;
