@@ -1613,6 +1613,251 @@ __global__ __launch_bounds__(256) void supcon_bwd_fin_kernel(const float* __rest
   else dz2[(size_t)(row - n) * d + k] = v;
 }
 
+// ---- fused large-batch backward (round 2): NO logits matrix either.  d loss / d P_i = sum_j H_ij P_j / t with
+// H = G + G^T, G_ij = kc_i (pos w_ij - W_i exp(l_ij)) (see supcon_bwd_big_kernel).  One kernel:
+//   1. the similarity tile is RECOMPUTED exactly as in the forward sweeps (same operand roles, same bits: own rows = B
+//      operand in registers, streamed 64-row tiles = A operand from LDS), so lane l holds column `own row I0 + l % 32`
+//      and 16 streamed rows of every 32 x 32 product;
+//   2. H is formed element-wise in the accumulator registers (row statistics of the own row per lane, of the streamed
+//      rows from a small LDS table written by supcon_bwd_prep_kernel);
+//   3. that register tile is the A operand of the second product WITHOUT any lane movement: an accumulator tile X
+//      (rows = streamed s, columns = own o) used as A computes X^T B = sum_s H(o, s) P_s -- rows of dP for the own
+//      rows.  The k index an A lane pairs with element e of k-step s' is streamed row 16 s' + 8 (e >> 2) + 4 kh + (e & 3);
+//      the B operand (P_s[d] for 8 such rows and one feature d) comes from a TRANSPOSED copy of P whose rows are
+//      permuted inside each group of 16 (bits 2 and 3 swapped) so that those 8 rows are one 16-byte chunk
+//      (supcon_bwd_prep_kernel writes it; the tile image is XOR-swizzled by (d >> 1) & 7: conflict-free ds_read_b128).
+// Per streamed tile a workgroup holds two LDS images (rows x features for step 1, features x rows for step 3), both
+// brought by LDS-DMA one tile ahead into a ring of two.
+__global__ __launch_bounds__(256) void supcon_bwd_prep_kernel(const bf16_t* __restrict__ Ph, const bf16_t* __restrict__ Pm,
+                                                             int N2, int N2p, int DP, bf16_t* __restrict__ PhT,
+                                                             bf16_t* __restrict__ PmT, const float* __restrict__ logD,
+                                                             const float* __restrict__ W, const float* __restrict__ cnt,
+                                                             const float* __restrict__ cls,
+                                                             const float* __restrict__ out_fwd,
+                                                             float* __restrict__ st /* [4][N2p] */) {
+  __shared__ bf16_t tl[64][256 + 2];
+  const bf16_t* src = blockIdx.y ? Pm : Ph;
+  bf16_t* dst = blockIdx.y ? PmT : PhT;
+  const int R0 = blockIdx.x * 64;
+  for (int c = threadIdx.x; c < 64 * DP; c += 256) {
+    const int r = c / DP, k = c - r * DP;
+    tl[r][k] = src[(size_t)(R0 + r) * DP + k];
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  // position `lane` of the transposed row holds the source row with bits 2 and 3 swapped
+  const int srow = (lane & ~12) | ((lane & 4) << 1) | ((lane & 8) >> 1);
+  for (int k = threadIdx.x >> 6; k < DP; k += 4) dst[(size_t)k * N2p + R0 + lane] = tl[srow][k];
+  if (blockIdx.y == 0 && threadIdx.x < 64) {  // row statistics in the form the element-wise step wants
+    const int j = R0 + threadIdx.x;
+    const bool ok = j < N2;
+    const float ld = logD[j];
+    const float kc = ok ? -out_fwd[2] / cnt[j] : 0.f;
+    st[j] = ld;
+    st[N2p + j] = kc * W[j] * __expf(-ld);  // A_j = kc_j W_j / D_j
+    st[2 * (size_t)N2p + j] = kc;
+    st[3 * (size_t)N2p + j] = cls[j];
+  }
+}
+
+template <int DP, int SP>
+__global__ __launch_bounds__(512) void supcon_bwd_tiles_kernel(const bf16_t* __restrict__ Ph, const bf16_t* __restrict__ Pm,
+                                                              const bf16_t* __restrict__ PhT,
+                                                              const bf16_t* __restrict__ PmT,
+                                                              const float* __restrict__ rn2, int N2, int N2p, int CSB,
+                                                              float t, const float* __restrict__ st /* [4][N2p] */,
+                                                              float gamma, float inv_gamma,
+                                                              float* __restrict__ dPpart /* [CSB][N2p][DP] */) {
+  constexpr int CPR = DP / 8, KS = DP / 16, NT = DP / 32;
+  constexpr int IMG = 2 * 64 * DP * 2;             // one image (both splits) of a 64-row tile: 32 KB at d = 128
+  constexpr int STAGE = 2 * IMG;                   // rows x features, then features x rows
+  constexpr int GROUPS = IMG / 1024, GPW = GROUPS / 8;  // 1 KiB DMA pieces per image, per wave
+  constexpr int RPG = 1024 / (DP * 2);             // rows per piece (row image)
+  constexpr int APW = 32 * DP * 2 / 1024;          // pieces of one split of a wave's 32 own rows
+  constexpr int MAXT = SUPCON_TILES_MAXT;
+  static_assert(DP == 128 || DP == 64, "feature width");
+  static_assert(8 * APW * 1024 == STAGE, "own-row staging = the second ring stage");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds_b[];
+  const unsigned lds_base = (unsigned)(uintptr_t)(unsigned char __attribute__((address_space(3)))*)lds_b;
+  const float* tst = (const float*)(lds_b + 2 * STAGE);  // [4][MAXT * 64] statistics of the streamed rows
+  __shared__ float red[8];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n32 = lane & 31, kh = lane >> 5;
+  const int I0 = blockIdx.x * 256 + wave * 32;
+  const float inv_t = 1.f / t;
+  const int ntiles = N2p / 64;
+  const int t_begin = (int)(((long)blockIdx.y * ntiles) / CSB), t_end = (int)(((long)(blockIdx.y + 1) * ntiles) / CSB);
+  const int nmine = t_end - t_begin;
+
+  // compiler-managed vector loads, issued first and consumed after the last explicit wait: row norms (max logit) and
+  // the own row's statistics
+  f32x4 rn[8];
+  {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)rn2, 0, N2 * 4, 0x00020000);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      rn[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (threadIdx.x + 512 * u) * 16, 0, 0));
+  }
+  const int own = I0 + n32;
+  float o_ld = st[own], o_A = st[N2p + own], o_kc = st[2 * (size_t)N2p + own], o_cls = st[3 * (size_t)N2p + own];
+
+  const int prow = lane / CPR, pcp = lane % CPR;
+  const int tdl = lane >> 3, tcp = lane & 7;       // transposed image: 8 feature rows of 128 bytes per piece
+  auto issue = [&](int k) {                        // k-th tile of this workgroup -> ring stage k & 1
+    const int jt = t_begin + k;
+    const unsigned stage = lds_base + (unsigned)((k & 1) * STAGE);
+#pragma unroll
+    for (int u = 0; u < GPW; ++u) {                // rows x features (as the forward sweeps)
+      const int gidx = wave * GPW + u;
+      const int sp = gidx / (GROUPS / 2), gr = gidx % (GROUPS / 2);
+      const int row = gr * RPG + prow;
+      const bf16_t* src = (sp ? Pm : Ph) + (size_t)(jt * 64 + row) * DP + ((pcp ^ big_swz<DP>(row)) * 8);
+      supcon_dma16(src, __builtin_amdgcn_readfirstlane(stage + gidx * 1024));
+    }
+#pragma unroll
+    for (int u = 0; u < GPW; ++u) {                // features x rows
+      const int gidx = wave * GPW + u;
+      const int sp = gidx / (GROUPS / 2), gr = gidx % (GROUPS / 2);
+      const int d = gr * 8 + tdl;
+      const bf16_t* src = (sp ? PmT : PhT) + (size_t)d * N2p + jt * 64 + ((tcp ^ ((d >> 1) & 7)) * 8);
+      supcon_dma16(src, __builtin_amdgcn_readfirstlane(stage + IMG + gidx * 1024));
+    }
+  };
+  const unsigned stage_own = lds_base + STAGE + (unsigned)wave * (APW * 1024);
+  auto issue_own = [&](const bf16_t* split) {
+#pragma unroll
+    for (int u = 0; u < APW; ++u) {
+      const int row = u * RPG + prow;
+      const bf16_t* src = split + (size_t)(I0 + row) * DP + ((pcp ^ big_swz<DP>(row)) * 8);
+      supcon_dma16(src, __builtin_amdgcn_readfirstlane(stage_own + u * 1024));
+    }
+  };
+  auto read_own = [&](bf16x8v* dst) {
+    const u32x4* r = (const u32x4*)(lds_b + STAGE + wave * (APW * 1024)) + n32 * CPR;
+    const int key = big_swz<DP>(n32);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) dst[ks] = __builtin_bit_cast(bf16x8v, r[(2 * ks + kh) ^ key]);
+  };
+  // statistics of the streamed rows of this workgroup's tiles: 4 arrays x (nmine * 64 floats), 256 floats per piece
+  {
+    const unsigned sb = lds_base + 2 * STAGE;
+    const int ppa = (nmine + 3) / 4;                 // pieces per array
+    for (int p = wave; p < 4 * ppa; p += 8) {
+      const int arr = p / ppa, q = p - arr * ppa;
+      supcon_dma16(st + (size_t)arr * N2p + t_begin * 64 + q * 256 + lane * 4,
+                   __builtin_amdgcn_readfirstlane(sb + (unsigned)(arr * MAXT * 256 + q * 1024)));
+    }
+  }
+  bf16x8v oh[KS], om[KS];
+  issue_own(Ph);
+  issue(0);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GPW) : "memory");  // the hi rows have landed
+  read_own(oh);
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(oh[ks]));
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  issue_own(Pm);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  read_own(om);
+  float mv = 0.f;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    asm volatile("" : "+v"(rn[u]));
+    mv = fmaxf(mv, fmaxf(fmaxf(rn[u][0], rn[u][1]), fmaxf(rn[u][2], rn[u][3])));
+  }
+  asm volatile("" : "+v"(o_ld), "+v"(o_A), "+v"(o_kc), "+v"(o_cls));
+  mv = wave_max(mv / t);
+  if (lane == 0) red[wave] = mv;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(om[ks]));
+  __syncthreads();
+  float m = red[0];
+#pragma unroll
+  for (int w = 1; w < 8; ++w) m = fmaxf(m, red[w]);
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[nt][v] = 0.f;
+
+  for (int k = 0; k < nmine; ++k) {
+    const int jt = t_begin + k;
+    if (k + 1 < nmine) issue(k + 1);  // into the other stage: read during tile k - 1, every wave passed the barrier since
+    const u32x4* simg = (const u32x4*)(lds_b + (k & 1) * STAGE);
+    const u32x4* timg = (const u32x4*)(lds_b + (k & 1) * STAGE + IMG);
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      // ---- 1. similarities of the 32 streamed rows x this wave's 32 own rows
+      f32x16 c;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) c[v] = 0.f;
+      const int row = sub * 32 + n32;
+      const u32x4* rh = simg + row * CPR;
+      const u32x4* rm = simg + (64 + row) * CPR;
+      const int key = big_swz<DP>(row);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8v sh = __builtin_bit_cast(bf16x8v, rh[(2 * ks + kh) ^ key]);
+        const bf16x8v sm = __builtin_bit_cast(bf16x8v, rm[(2 * ks + kh) ^ key]);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sh, oh[ks], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sm, oh[ks], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sh, om[ks], c, 0, 0, 0);
+      }
+      // ---- 2. H(own, streamed) in place; c[4q + r] is streamed row S0 + 8q + 4kh + r
+      const int S0 = jt * 64 + sub * 32;
+      const bool edge = (I0 < S0 + 32 && S0 < I0 + 32) || S0 + 32 > N2 || I0 + 32 > N2;
+      bf16x8v hh[2], hl[2];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int so = k * 64 + sub * 32 + 8 * q + 4 * kh;  // offset of these four streamed rows in the statistics table
+        const f32x4 s_ld = *(const f32x4*)(tst + so), s_A = *(const f32x4*)(tst + MAXT * 64 + so);
+        const f32x4 s_kc = *(const f32x4*)(tst + 2 * MAXT * 64 + so), s_cls = *(const f32x4*)(tst + 3 * MAXT * 64 + so);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int v = 4 * q + r;
+          const float lg = fmaf(c[v], inv_t, -m);
+          const bool pos = s_cls[r] == o_cls;
+          const float w_os = pos ? sp_weight(SP, lg - o_ld, gamma, inv_gamma) : 0.f;
+          const float w_so = pos ? sp_weight(SP, lg - s_ld[r], gamma, inv_gamma) : 0.f;
+          float h = fmaf(o_kc, w_os, fmaf(s_kc[r], w_so, -__expf(lg) * (o_A + s_A[r])));
+          if (edge) {
+            const int sr = S0 + 8 * q + 4 * kh + r;
+            if (sr == own || sr >= N2 || own >= N2) h = 0.f;
+          }
+          const __bf16 b = (__bf16)h;
+          hh[q >> 1][(q & 1) * 4 + r] = b;
+          hl[q >> 1][(q & 1) * 4 + r] = (__bf16)(h - (float)b);
+        }
+      }
+      // ---- 3. dP(own) += H^T-as-A x P(streamed): element e of k-step s' is streamed row 16 s' + 8 (e >> 2) + 4 kh + (e & 3),
+      // i.e. positions 16 s' + 8 kh .. + 7 of the permuted transposed image
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int d = 32 * nt + n32;
+        const int tkey = (d >> 1) & 7;
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+          const int chunk = 4 * sub + 2 * sp + kh;
+          const bf16x8v bh = __builtin_bit_cast(bf16x8v, timg[d * 8 + (chunk ^ tkey)]);
+          const bf16x8v bm = __builtin_bit_cast(bf16x8v, timg[(DP + d) * 8 + (chunk ^ tkey)]);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hh[sp], bh, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hh[sp], bm, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hl[sp], bh, acc[nt], 0, 0, 0);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile has landed (requested a whole tile ago)
+    __syncthreads();
+  }
+  // acc[nt][v] = dP[I0 + 8 (v / 4) + 4 kh + v % 4][32 nt + n32]
+  float* dst = dPpart + ((size_t)blockIdx.y * N2p + I0) * DP + n32;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) dst[(size_t)(8 * (v >> 2) + 4 * kh + (v & 3)) * DP + 32 * nt] = acc[nt][v];
+}
+
 // ------------------------------------------------------------------------------------------------ taps
 // Lazily materialised hook taps; same k order as the MFMA chain (k = 16s + 4g + u) -> bitwise the same logits.
 __global__ __launch_bounds__(256) void supcon_materialize_kernel(SupconArgs a, int DP, float* sim_logits, float* sim_exp,
@@ -1702,6 +1947,13 @@ static bool supcon_use_big(const SupconLayout& L, const float* mask) {
 static bool supcon_use_fused(const SupconLayout& L) {
   static const bool mat = getenv("SPCL_SUPCON_MATERIALIZE") != nullptr;
   return !mat && L.DP <= 128 && L.N2p % 256 == 0 && L.N2p <= 16384;
+}
+static int supcon_fused_csb(const SupconLayout& L);
+// partial rows of dP in the backward workspace: column splits of whichever backward kernel runs
+static size_t supcon_bwd_rows(const SupconLayout& L) {
+  int r = L.CS > L.CSB ? L.CS : L.CSB;
+  if (L.big && L.DP <= 128 && L.N2p % 256 == 0 && L.N2p <= 16384 && supcon_fused_csb(L) > r) r = supcon_fused_csb(L);
+  return (size_t)r;
 }
 static int supcon_fused_csb(const SupconLayout& L) {  // column splits: 2 .. SUPCON_TILES_MAXT tiles per workgroup
   const int ntiles = L.N2p / 64;
@@ -1861,8 +2113,8 @@ extern "C" size_t spcl_supcon_bwd_workspace_bytes(int n, int d) {
   if (n <= 0 || d <= 0 || d > 256) return 0;
   SupconLayout L = supcon_layout(n, d);
   // column-split partials of dP, then (large batches) the transposed bf16 splits of P [2][DP][N2p]
-  return (size_t)(L.CS > L.CSB ? L.CS : L.CSB) * L.N2p * L.DP * sizeof(float) +
-         (L.big ? (size_t)2 * L.N2p * L.DP * sizeof(bf16_t) : 0);
+  return supcon_bwd_rows(L) * L.N2p * L.DP * sizeof(float) +
+         (L.big ? (size_t)4 * L.N2p * sizeof(float) + (size_t)2 * L.N2p * L.DP * sizeof(bf16_t) : 0);
 }
 
 extern "C" int spcl_supcon_forward(const float* z1, const float* z2, const float* labels, const float* mask, int n,
@@ -1932,8 +2184,41 @@ extern "C" int spcl_supcon_backward(const float* labels, const float* mask, int 
     return SPCL_OK;
   }
   int nsplit = L.CS;
-  if (supcon_use_big(L, mask)) {  // the forward of this call materialised the logits (same decision, same workspace)
-    bf16_t* PhT = (bf16_t*)(ws_bwd + (size_t)(L.CS > L.CSB ? L.CS : L.CSB) * L.N2p * L.DP);
+  static const bool env_bwd_mat = getenv("SPCL_SUPCON_BWD_MATERIALIZE") != nullptr;  // A/B: logits written, then read
+  if (supcon_use_big(L, mask) && supcon_use_fused(L) && !env_bwd_mat) {
+    // fused backward: similarities recomputed tile by tile, H applied from the accumulator registers (no logits matrix)
+    float* stt = ws_bwd + supcon_bwd_rows(L) * L.N2p * L.DP;
+    bf16_t* PhT = (bf16_t*)(stt + (size_t)4 * L.N2p);
+    bf16_t* PmT = PhT + (size_t)L.N2p * L.DP;
+    const bf16_t* Ph = (const bf16_t*)(ws_fwd + L.off_Ph);
+    const bf16_t* Pm = (const bf16_t*)(ws_fwd + L.off_Pm);
+    SPCL_LAUNCH(supcon_bwd_prep_kernel, dim3(L.N2p / 64, 2), dim3(256), 0, st, Ph, Pm, L.N2, L.N2p, L.DP, PhT, PmT,
+                a.logD, a.W, a.cnt, ws_fwd + L.off_cls, out_fwd, stt);
+    const int csb = supcon_fused_csb(L);
+    const double n2 = (double)L.N2p;
+    prof_cost(4 * n2 * L.DP * 4, 4.0 * n2 * n2 * L.DP);
+#define SPCL_BWD_TILES(DP_, SP_)                                                                                       \
+  do {                                                                                                                 \
+    constexpr size_t lds_ = (size_t)2 * 2 * (2 * 64 * DP_ * 2) + 4 * SUPCON_TILES_MAXT * 256;                          \
+    static bool attr_ = false;                                                                                         \
+    if (!attr_) {                                                                                                      \
+      (void)hipFuncSetAttribute((const void*)supcon_bwd_tiles_kernel<DP_, SP_>,                                        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);                                \
+      attr_ = true;                                                                                                    \
+    }                                                                                                                  \
+    SPCL_LAUNCH((supcon_bwd_tiles_kernel<DP_, SP_>), dim3(L.N2p / 256, csb), dim3(512), lds_, st, Ph, Pm,              \
+                (const bf16_t*)PhT, (const bf16_t*)PmT, a.rn2, L.N2, L.N2p, csb, a.t, (const float*)stt, a.gamma,      \
+                a.inv_gamma, ws_bwd);                                                                                  \
+  } while (0)
+    if (L.DP == 64) {
+      if (sp_mode == 0) SPCL_BWD_TILES(64, 0); else if (sp_mode == 1) SPCL_BWD_TILES(64, 1); else SPCL_BWD_TILES(64, 2);
+    } else {
+      if (sp_mode == 0) SPCL_BWD_TILES(128, 0); else if (sp_mode == 1) SPCL_BWD_TILES(128, 1); else SPCL_BWD_TILES(128, 2);
+    }
+#undef SPCL_BWD_TILES
+    nsplit = csb;
+  } else if (supcon_use_big(L, mask)) {  // logits materialised (by the forward, or just below), then read once
+    bf16_t* PhT = (bf16_t*)(ws_bwd + supcon_bwd_rows(L) * L.N2p * L.DP + (size_t)4 * L.N2p);
     bf16_t* PmT = PhT + (size_t)L.N2p * L.DP;
     const float* Lmat = ws_fwd + L.off_L;
     if (supcon_use_fused(L)) {  // the fused forward kept no logits: write them now (its row-sum partials go to the
