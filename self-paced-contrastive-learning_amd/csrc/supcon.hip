@@ -65,7 +65,7 @@ static SupconLayout supcon_layout(int n, int d) {
     L.off_partC = o;  o += (size_t)prow * L.N2p;
     L.off_partD = o;  o += (size_t)prow * L.N2p;
     o = round_up(o, 2);
-    L.off_fin = o;    o += (size_t)(L.N2p / 256) * 8 + 2;
+    L.off_fin = o;    o += (size_t)(L.N2p / 256) * SUPCON_TILES_MAXT * 8 + 2;  // one partial of 4 doubles per workgroup of sweep 1
   }
   L.off_Ph = L.off_Pm = L.off_L = o;
   if (L.big) {  // bf16 splits of P (N2p x DP halves each) and the logits [N2p][N2p]
@@ -903,6 +903,10 @@ struct SupconTilesTail {
   float* logD_out;
   float gamma, inv_gamma;
   unsigned long long* stamps;
+  // PASS 1: the count partials of sweep 0 ([CSB][N2p]), c_i out, one partial of the loss scalars per workgroup
+  const float* Cpart;
+  float* cnt_out;
+  double* blk;  // [gridDim.y * gridDim.x][4]: sum l_i / c_i, sum W_i, sum c_i, max | |p_i| - 1 |
 };
 template <int DP, int PASS, int SP>
 __global__ __launch_bounds__(512) void supcon_tiles_kernel(const bf16_t* __restrict__ Ph, const bf16_t* __restrict__ Pm,
@@ -1010,6 +1014,14 @@ __global__ __launch_bounds__(512) void supcon_tiles_kernel(const bf16_t* __restr
   for (int u = 0; u < 8; ++u) {
     asm volatile("" : "+v"(rn[u]));  // the scan stays behind the explicit wait above
     mv = fmaxf(mv, fmaxf(fmaxf(rn[u][0], rn[u][1]), fmaxf(rn[u][2], rn[u][3])));
+  }
+  float dv = 0.f;  // max | |p_i| - 1 |: every workgroup holds all row norms right now; one of them will report it
+  if (PASS == 1 && blockIdx.x == 0 && blockIdx.y == 0) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if ((int)(threadIdx.x + 512 * u) * 4 + e < N2) dv = fmaxf(dv, fabsf(sqrtf(rn[u][e]) - 1.f));
   }
   mv = wave_max(mv / t);
   if (lane == 0) red[wave] = mv;
@@ -1136,6 +1148,10 @@ __global__ __launch_bounds__(512) void supcon_tiles_kernel(const bf16_t* __restr
   const std::true_type yes;
   const std::false_type no;
   SUPCON_STAMP(3)
+  if (PASS == 1)  // the count partials of the own rows, needed only after the loop: into the staging image of waves 4..7
+    for (int c = wave; c < CSB; c += 8)
+      supcon_dma16(q.Cpart + (size_t)c * N2p + blockIdx.x * 256 + lane * 4,
+                   __builtin_amdgcn_readfirstlane(lds_base + 3 * TILE_BYTES + c * 1024));
   if (nmine > 2) issue(2);  // image 2 doubles as the staging of waves 0..3: free since the barrier above
   f32x16 c0, c1;
   products(no, 0, 0, c0, c0, 0, 0);
@@ -1157,6 +1173,34 @@ __global__ __launch_bounds__(512) void supcon_tiles_kernel(const bf16_t* __restr
   if (kh == 0) {
     *o0 = s0;
     *o1 = s1;
+  }
+  if (PASS == 1) {
+    // this workgroup's share of the scalars: sum_i l_i^(split) / c_i over its 256 own rows (c_i from the CSB partials
+    // that arrived during the loop), sum W_i^(split); the first column split also carries sum c_i and writes c_i
+    const float* cp = (const float*)(lds_b + 3 * TILE_BYTES);
+    float ci = 0.f;
+    for (int c = 0; c < CSB; ++c) ci += cp[c * 256 + wave * 32 + n32];
+    const bool mine = kh == 0 && own < N2;
+    double v0 = mine ? (double)(s0 / ci) : 0.0, v1 = mine ? (double)s1 : 0.0;
+    double v2 = (mine && blockIdx.y == 0) ? (double)ci : 0.0;
+    if (blockIdx.y == 0 && kh == 0) q.cnt_out[own] = ci;
+    for (int o = 32; o > 0; o >>= 1) {
+      v0 += __shfl_xor(v0, o, 64);
+      v1 += __shfl_xor(v1, o, 64);
+      v2 += __shfl_xor(v2, o, 64);
+      dv = fmaxf(dv, __shfl_xor(dv, o, 64));
+    }
+    __shared__ double redd[4][8];
+    if (lane == 0) {
+      redd[0][wave] = v0; redd[1][wave] = v1; redd[2][wave] = v2; redd[3][wave] = (double)dv;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+      const int kk = threadIdx.x;
+      double r = redd[kk][0];
+      for (int w = 1; w < 8; ++w) r = kk < 3 ? r + redd[kk][w] : fmax(r, redd[kk][w]);
+      q.blk[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + kk] = r;
+    }
   }
   SUPCON_STAMP(5)
   if (stamp) {
@@ -1226,8 +1270,12 @@ __global__ __launch_bounds__(64) void supcon_fin3_kernel(const double* __restric
                                                         int correct_grad, float* __restrict__ out) {
   const int lane = threadIdx.x;
   double v[4] = {0.0, 0.0, 0.0, 0.0};
-  if (lane < nblk)  // nblk = N2p / 256 <= 64
-    for (int k = 0; k < 4; ++k) v[k] = blk[(size_t)lane * 4 + k];
+  for (int b = lane; b < nblk; b += 64) {  // lane-strided, then the fixed butterfly: one association for a given nblk
+    v[0] += blk[(size_t)b * 4];
+    v[1] += blk[(size_t)b * 4 + 1];
+    v[2] += blk[(size_t)b * 4 + 2];
+    v[3] = fmax(v[3], blk[(size_t)b * 4 + 3]);
+  }
   // fixed butterfly over the lanes: the same association whatever the number of workgroups that ran
   for (int o = 32; o > 0; o >>= 1) {
     v[0] += __shfl_xor(v[0], o, 64);
@@ -1631,7 +1679,8 @@ __global__ __launch_bounds__(256) void supcon_bwd_fin_kernel(const float* __rest
 __global__ __launch_bounds__(256) void supcon_bwd_prep_kernel(const bf16_t* __restrict__ Ph, const bf16_t* __restrict__ Pm,
                                                              int N2, int N2p, int DP, bf16_t* __restrict__ PhT,
                                                              bf16_t* __restrict__ PmT, const float* __restrict__ logD,
-                                                             const float* __restrict__ W, const float* __restrict__ cnt,
+                                                             const float* __restrict__ Wpart, int csb,
+                                                             const float* __restrict__ cnt,
                                                              const float* __restrict__ cls,
                                                              const float* __restrict__ out_fwd,
                                                              float* __restrict__ st /* [4][N2p] */) {
@@ -1653,8 +1702,10 @@ __global__ __launch_bounds__(256) void supcon_bwd_prep_kernel(const bf16_t* __re
     const bool ok = j < N2;
     const float ld = logD[j];
     const float kc = ok ? -out_fwd[2] / cnt[j] : 0.f;
+    float Wj = 0.f;  // W_j = the CSB column-split partials of the forward's second sweep
+    for (int c = 0; c < csb; ++c) Wj += Wpart[(size_t)c * N2p + j];
     st[j] = ld;
-    st[N2p + j] = kc * W[j] * __expf(-ld);  // A_j = kc_j W_j / D_j
+    st[N2p + j] = kc * Wj * __expf(-ld);  // A_j = kc_j W_j / D_j
     st[2 * (size_t)N2p + j] = kc;
     st[3 * (size_t)N2p + j] = cls[j];
   }
@@ -2014,6 +2065,9 @@ static int launch_forward_big(const SupconLayout& L, SupconArgs a, float* ws, in
         q.out0 = pass == 0 ? pD : pL;
         q.out1 = pass == 0 ? pC : pW;
         q.logD_out = ws + L.off_logD;
+        q.Cpart = pC;
+        q.cnt_out = ws + L.off_c;
+        q.blk = (double*)(ws + L.off_fin);
 #define SPCL_TILES1(SP_)                                                                                          \
   SPCL_LAUNCH((supcon_tiles_kernel<DP, 1, SP_>), dim3(nrb, csb), dim3(512), lds, st, Ph, Pm, cls, a.rn2, L.N2, \
               L.N2p, csb, a.t, (const float*)pD, q)
@@ -2046,10 +2100,9 @@ static int launch_forward_big(const SupconLayout& L, SupconArgs a, float* ws, in
                   (double)(last_start - first) / 100.0, (double)(last - first) / 100.0);
         }
       }
-      SPCL_LAUNCH(supcon_fin2_kernel, dim3(nrb), dim3(256), 0, st, (const float*)pL, (const float*)pW, (const float*)pC,
-                  csb, L.N2, L.N2p, ws + L.off_rowloss, ws + L.off_W, ws + L.off_c, (const float*)(ws + L.off_rn2),
-                  (double*)(ws + L.off_fin));
-      SPCL_LAUNCH(supcon_fin3_kernel, dim3(1), dim3(64), 0, st, (const double*)(ws + L.off_fin), nrb, L.N2,
+      // the per-row W_i the backward wants stay as the CSB partials (its prep kernel adds them up); c_i and log D_i were
+      // written by sweep 1; the scalars are one more tiny launch over the workgroups' partials
+      SPCL_LAUNCH(supcon_fin3_kernel, dim3(1), dim3(64), 0, st, (const double*)(ws + L.off_fin), nrb * csb, L.N2,
                   correct_grad, out);
       return 0;
     }
@@ -2193,7 +2246,7 @@ extern "C" int spcl_supcon_backward(const float* labels, const float* mask, int 
     const bf16_t* Ph = (const bf16_t*)(ws_fwd + L.off_Ph);
     const bf16_t* Pm = (const bf16_t*)(ws_fwd + L.off_Pm);
     SPCL_LAUNCH(supcon_bwd_prep_kernel, dim3(L.N2p / 64, 2), dim3(256), 0, st, Ph, Pm, L.N2, L.N2p, L.DP, PhT, PmT,
-                a.logD, a.W, a.cnt, ws_fwd + L.off_cls, out_fwd, stt);
+                a.logD, ws_fwd + L.off_partB, supcon_fused_csb(L), a.cnt, ws_fwd + L.off_cls, out_fwd, stt);
     const int csb = supcon_fused_csb(L);
     const double n2 = (double)L.N2p;
     prof_cost(4 * n2 * L.DP * 4, 4.0 * n2 * n2 * L.DP);
@@ -2221,6 +2274,13 @@ extern "C" int spcl_supcon_backward(const float* labels, const float* mask, int 
     bf16_t* PhT = (bf16_t*)(ws_bwd + supcon_bwd_rows(L) * L.N2p * L.DP + (size_t)4 * L.N2p);
     bf16_t* PmT = PhT + (size_t)L.N2p * L.DP;
     const float* Lmat = ws_fwd + L.off_L;
+    if (supcon_use_fused(L)) {  // the fused forward left W_i as column-split partials: add them up (fin2 also rewrites c_i)
+      float* wsm0 = const_cast<float*>(ws_fwd);
+      SPCL_LAUNCH(supcon_fin2_kernel, dim3(L.N2p / 256), dim3(256), 0, st, (const float*)(ws_fwd + L.off_partD),
+                  (const float*)(ws_fwd + L.off_partB), (const float*)(ws_fwd + L.off_partC), supcon_fused_csb(L), L.N2,
+                  L.N2p, wsm0 + L.off_rowloss, wsm0 + L.off_W, wsm0 + L.off_c, (const float*)(ws_fwd + L.off_rn2),
+                  (double*)(ws_bwd));  // (its scalar partials land in the not-yet-used head of the backward workspace)
+    }
     if (supcon_use_fused(L)) {  // the fused forward kept no logits: write them now (its row-sum partials go to the
                                 // forward's partial rows, which nobody reads any more)
       float* wsm = const_cast<float*>(ws_fwd);
