@@ -1181,8 +1181,9 @@ __global__ __launch_bounds__(512) void supcon_tiles_kernel(const bf16_t* __restr
     float ci = 0.f;
     for (int c = 0; c < CSB; ++c) ci += cp[c * 256 + wave * 32 + n32];
     const bool mine = kh == 0 && own < N2;
-    double v0 = mine ? (double)(s0 / ci) : 0.0, v1 = mine ? (double)s1 : 0.0;
-    double v2 = (mine && blockIdx.y == 0) ? (double)ci : 0.0;
+    // (32 rows per wave in f32, the eight waves and everything after in f64)
+    float v0 = mine ? s0 / ci : 0.f, v1 = mine ? s1 : 0.f;
+    float v2 = (mine && blockIdx.y == 0) ? ci : 0.f;
     if (blockIdx.y == 0 && kh == 0) q.cnt_out[own] = ci;
     for (int o = 32; o > 0; o >>= 1) {
       v0 += __shfl_xor(v0, o, 64);
@@ -1192,7 +1193,7 @@ __global__ __launch_bounds__(512) void supcon_tiles_kernel(const bf16_t* __restr
     }
     __shared__ double redd[4][8];
     if (lane == 0) {
-      redd[0][wave] = v0; redd[1][wave] = v1; redd[2][wave] = v2; redd[3][wave] = (double)dv;
+      redd[0][wave] = (double)v0; redd[1][wave] = (double)v1; redd[2][wave] = (double)v2; redd[3][wave] = (double)dv;
     }
     __syncthreads();
     if (threadIdx.x < 4) {
@@ -1702,8 +1703,12 @@ __global__ __launch_bounds__(256) void supcon_bwd_prep_kernel(const bf16_t* __re
     const bool ok = j < N2;
     const float ld = logD[j];
     const float kc = ok ? -out_fwd[2] / cnt[j] : 0.f;
-    float Wj = 0.f;  // W_j = the CSB column-split partials of the forward's second sweep
-    for (int c = 0; c < csb; ++c) Wj += Wpart[(size_t)c * N2p + j];
+    float wv[SUPCON_TILES_MAXT];  // W_j = the CSB <= MAXT column-split partials of the forward's second sweep: all loads
+#pragma unroll                      // in flight together (one memory round trip)
+    for (int c = 0; c < SUPCON_TILES_MAXT; ++c) wv[c] = Wpart[(size_t)(c < csb ? c : csb - 1) * N2p + j];
+    float Wj = 0.f;
+#pragma unroll
+    for (int c = 0; c < SUPCON_TILES_MAXT; ++c) Wj += c < csb ? wv[c] : 0.f;
     st[j] = ld;
     st[N2p + j] = kc * Wj * __expf(-ld);  // A_j = kc_j W_j / D_j
     st[2 * (size_t)N2p + j] = kc;
