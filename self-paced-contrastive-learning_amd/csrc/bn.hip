@@ -763,7 +763,8 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
   prof_cost(tb + gb, 0.0);
   const float* fin_src = partial;
   if (rows != nullptr) {  // the partial sums came with the dgrad that produced dact (per conv tile, centred s2)
-    if (nrows <= BWD_MAX_WG) {
+    static const int fin_rows = getenv("SPCL_BWD_FIN_MAX_ROWS") ? atoi(getenv("SPCL_BWD_FIN_MAX_ROWS")) : BWD_MAX_WG;
+    if (nrows <= fin_rows) {
       fin_src = rows;
       nwg = nrows;
     } else {
