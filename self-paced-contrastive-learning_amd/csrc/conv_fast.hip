@@ -21,6 +21,7 @@ struct FastArgs {
   const float* in_scale;
   const float* in_shift;
   int N, H, W, CinK, CoutS, tilesX, tilesY, gy;
+  int lds_flip;   // bytes between the two halo images of the cross-slab pipeline (0: one image)
   int xcd_remap;  // 1: tiles of an image are dealt to the XCDs in contiguous row-major blocks (see the kernel)
   // MODE 2 (dgrad whose output g is the gradient of relu(bn(y2))): per-tile partial sums of that BatchNorm's backward
   const unsigned char* y2;  // [N][H][W][CoutS] raw conv output of the layer being differentiated
@@ -122,10 +123,21 @@ conv3x3_fast_kernel(FastArgs a) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll 1
-  for (int slab = 0; slab < nslab; ++slab) {
-    if (slab > 0) __syncthreads();  // every wave is done reading the previous slab
-    float ssc[8], ssh[8];
+  // Slabs of KC input channels, software-pipelined across slabs when the launcher provides two halo images (flip != 0;
+  // one wave per SIMD on the 14^2 layers, so nothing else hides a slab's load phase): the NEXT slab's halo is requested
+  // before this slab's k-loop and lands in registers while the MFMAs run, and the weight fragments stream through a ring
+  // of WR k-steps: a ring slot is refilled with the fragment WR steps ahead (same slab or the next one) right after its
+  // use.  The last slab is peeled (no refill across its end), so that every path into the loop head has the same order
+  // of outstanding loads -- halo first, then WR x NT fragments -- and the counted waits stay exact (vmcnt is in-order).
+  const int flip = a.lds_flip;
+  const unsigned wvo = (unsigned)(nt0 * 64 + lane) * 16u;  // the lane's byte offset inside a k-step's fragment row
+  const size_t wstep = (size_t)ntn * 1024;                  // bytes per k-step
+  u32x4 v[ITER];
+  float ssc[8], ssh[8];
+  constexpr bool STREAM_W = PRELOAD_SLAB && KC == 64;  // (the only shape with more than one slab)
+  constexpr int WR = STREAM_W ? 9 : (PRELOAD_SLAB ? NSTEPS : 1);
+  u32x4 wsl[WR][NT];
+  auto issue_halo = [&](int slab) {
     if (MODE == 1) {
 #pragma unroll
       for (int e = 0; e < 8; e += 4) {
@@ -133,16 +145,7 @@ conv3x3_fast_kernel(FastArgs a) {
         *(f32x4*)&ssh[e] = *(const f32x4*)(a.in_shift + slab * KC + ch * 8 + e);
       }
     }
-    const u32x4* wslab = a.wp + ((size_t)slab * NSTEPS * ntn + nt0) * 64 + lane;
-    u32x4 wsl[PRELOAD_SLAB ? NSTEPS : 1][NT];
-    if (PRELOAD_SLAB) {
-#pragma unroll
-      for (int s = 0; s < NSTEPS; ++s)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) wsl[s][j] = wslab[(size_t)(s * ntn + j) * 64];
-    }
     const unsigned char* xs = xb + slab * (KC * 2);
-    u32x4 v[ITER];
 #pragma unroll
     for (int k = 0; k < ITER; ++k) {
       const int dky = QS >= HW_ ? k * (QS / HW_) : k / (HW_ / QS);
@@ -156,6 +159,9 @@ conv3x3_fast_kernel(FastArgs a) {
       v[k] = (u32x4){0u, 0u, 0u, 0u};
       if (inb) v[k] = *(const u32x4*)(xs + soff + voff);
     }
+  };
+  unsigned char* lpw = lp;  // staging destination / fragment bases of the current halo image
+  auto slab_body = [&](const int slab, const bool refill) {
 #pragma unroll
     for (int k = 0; k < ITER; ++k) {
       const int dky = QS >= HW_ ? k * (QS / HW_) : k / (HW_ / QS);
@@ -170,35 +176,86 @@ conv3x3_fast_kernel(FastArgs a) {
         }
         if (inb) tv = bnrelu_regs<bf16_t>(tv, ssc, ssh);
       }
-      if (in_range) *(u32x4*)(lp + (dky * HW_ + dkx) * PS) = tv;
+      if (in_range) *(u32x4*)(lpw + (dky * HW_ + dkx) * PS) = tv;
     }
+    if (refill) issue_halo(slab + 1);
     __syncthreads();
 
     // ------------ k-loop: NSTEPS x (one 16-byte x fragment per m-tile, NT MFMAs on it)
-#pragma unroll
-    for (int s = 0; s < NSTEPS; ++s) {
-      u32x4 wf[NT];
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-        wf[j] = PRELOAD_W ? wall[s][j] : (PRELOAD_SLAB ? wsl[s][j] : wslab[(size_t)(s * ntn + j) * 64]);
-      int off;
+    const u32x4* wslab = a.wp + ((size_t)slab * NSTEPS * ntn + nt0) * 64 + lane;
+    auto frag_off = [&](const int s) {
       if (CP >= 4) {
         const int fc0 = 4 * s, tap = fc0 / CP, c0 = fc0 % CP, ky = tap / 3, kx = tap % 3;
-        off = (ky * HW_ + kx) * PS + c0 * 16;  // compile-time: the ds_read offset field
-      } else {
-        int fc = 4 * s + g;
-        if (fc >= 9 * CP) fc = 0;  // K padding: the weights there are zero, any finite x will do
-        const int tap = fc / CP, c = fc % CP, ky = (tap * 11) >> 5, kx = tap - 3 * ky;
-        off = (ky * HW_ + kx) * PS + c * 16;
+        return (ky * HW_ + kx) * PS + c0 * 16;  // compile-time: the ds_read offset field
       }
+      int fc = 4 * s + g;
+      if (fc >= 9 * CP) fc = 0;  // K padding: the weights there are zero, any finite x will do
+      const int tap = fc / CP, c = fc % CP, ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+      return (ky * HW_ + kx) * PS + c * 16;
+    };
+    if (STREAM_W) {
+      const unsigned char* wrun = (const unsigned char*)a.wp + ((size_t)slab * NSTEPS + WR) * wstep;
+      // weight ring + fragments one step ahead, every step fenced (sched_barrier(0)): left to itself the scheduler bunches
+      // the refills next to their uses or keeps them all live, and either spills or waits on every load
+      u32x4 xf[2][MT];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const u32x4 xf = *(const u32x4*)(lds + abase[i] + off);
+      for (int i = 0; i < MT; ++i) xf[0][i] = *(const u32x4*)(lds + abase[i] + frag_off(0));
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = mfma_chunk<bf16_t>(wf[j], xf, acc[i][j]);
+      for (int s = 0; s < NSTEPS; ++s) {
+        u32x4 wf[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          wf[j] = wsl[s % WR][j];
+          if (s + WR < NSTEPS || refill) wsl[s % WR][j] = *(const u32x4*)(wrun + wvo + j * 1024);
+        }
+        wrun += wstep;  // uniform running pointer: one scalar add per step instead of NSTEPS hoisted offsets
+        if (s + 1 < NSTEPS) {
+#pragma unroll
+          for (int i = 0; i < MT; ++i) xf[(s + 1) & 1][i] = *(const u32x4*)(lds + abase[i] + frag_off(s + 1));
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = mfma_chunk<bf16_t>(wf[j], xf[s & 1][i], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < NSTEPS; ++s) {
+        u32x4 wf[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          wf[j] = PRELOAD_W ? wall[s][j] : (PRELOAD_SLAB ? wsl[s][j] : wslab[(size_t)(s * ntn + j) * 64]);
+        const int off = frag_off(s);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const u32x4 xf = *(const u32x4*)(lds + abase[i] + off);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = mfma_chunk<bf16_t>(wf[j], xf, acc[i][j]);
+        }
       }
     }
+  };
+  issue_halo(0);
+  if (PRELOAD_SLAB) {
+#pragma unroll
+    for (int s = 0; s < WR; ++s)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) wsl[s][j] = a.wp[((size_t)s * ntn + nt0 + j) * 64 + lane];
   }
+  int img = 0;
+#pragma unroll 1
+  for (int slab = 0; slab + 1 < nslab; ++slab) {
+    if (slab > 0 && flip == 0) __syncthreads();  // one halo image: every wave is done reading the previous slab
+    slab_body(slab, true);
+    const int d = img ? -flip : flip;
+    img ^= 1;
+    lpw += d;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) abase[i] += d;
+  }
+  if (nslab > 1 && flip == 0) __syncthreads();
+  slab_body(nslab - 1, false);
 
   // ------------ epilogue: lane holds couts 16 (nt0 + j) + 4 g .. +3 of pixel p = 16 i + r16 (tiles are always full)
   constexpr int DPY = 16 / TW, DPX = 16 % TW;
@@ -408,12 +465,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void co
 
 template <int KC, int TH, int NT, int NW>
 static void launch_fast(const FastArgs& a, int mode, hipStream_t st) {
-  const size_t lds = fast_lds_bytes(KC, TH);
+  static const int env_pipe = getenv("SPCL_CONV_FAST_PIPE") ? atoi(getenv("SPCL_CONV_FAST_PIPE")) : 1;
+  const bool pipe = env_pipe && KC == 64 && a.CinK > KC;  // more than one slab: two halo images
+  FastArgs b = a;
+  b.lds_flip = pipe ? fast_lds_bytes(KC, TH) : 0;
+  const size_t lds = fast_lds_bytes(KC, TH) * (pipe ? 2 : 1);
   dim3 grid(a.tilesX, a.tilesY, a.N * a.gy), block(64 * NW);
-  if (mode == 1) SPCL_LAUNCH((conv3x3_fast_kernel<KC, TH, NT, 1, NW>), grid, block, lds, st, a);
-  else if (a.rows2 != nullptr && a.H2 > 0) SPCL_LAUNCH((conv3x3_fast_kernel<KC, TH, NT, 3, NW>), grid, block, lds, st, a);
-  else if (a.rows2 != nullptr) SPCL_LAUNCH((conv3x3_fast_kernel<KC, TH, NT, 2, NW>), grid, block, lds, st, a);
-  else SPCL_LAUNCH((conv3x3_fast_kernel<KC, TH, NT, 0, NW>), grid, block, lds, st, a);
+  if (mode == 1) SPCL_LAUNCH((conv3x3_fast_kernel<KC, TH, NT, 1, NW>), grid, block, lds, st, b);
+  else if (a.rows2 != nullptr && a.H2 > 0) SPCL_LAUNCH((conv3x3_fast_kernel<KC, TH, NT, 3, NW>), grid, block, lds, st, b);
+  else if (a.rows2 != nullptr) SPCL_LAUNCH((conv3x3_fast_kernel<KC, TH, NT, 2, NW>), grid, block, lds, st, b);
+  else SPCL_LAUNCH((conv3x3_fast_kernel<KC, TH, NT, 0, NW>), grid, block, lds, st, b);
 }
 
 bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
@@ -425,7 +486,7 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
     a.in_scale = a.in_shift = nullptr;
     a.y2 = nullptr; a.scale2 = a.shift2 = a.mean2 = nullptr; a.rows2 = nullptr; a.H2 = a.W2 = 0;
     a.N = c.N; a.H = c.H; a.W = c.W; a.CinK = 16; a.CoutS = 16;
-    a.tilesX = cdiv(c.W, 14); a.tilesY = cdiv(c.H, 14); a.gy = 1; a.xcd_remap = 0;
+    a.tilesX = cdiv(c.W, 14); a.tilesY = cdiv(c.H, 14); a.gy = 1; a.xcd_remap = 0; a.lds_flip = 0;
     if (!dry) SPCL_LAUNCH((conv3x3_image_kernel<14>), dim3(a.tilesX, a.tilesY, a.N), dim3(64), 0, st, a);
     return true;
   }
