@@ -197,6 +197,29 @@ int spcl_conv_wgrad_batched_supported(int dtype, int Cin, int CinS, int Cout, in
 size_t spcl_conv_wgrad_batched_workspace_bytes(const spcl_wgrad_item* items, int n);
 int spcl_conv3x3_wgrad_batched(const spcl_wgrad_item* items, int n, int accumulate, float* partial, void* stream);
 
+/* Deferred final sums ("tails") of the weight gradients that do NOT go through the batched GEMM kernel: the narrow
+ * layers' split partials of spcl_conv3x3_wgrad and the first layer's per-workgroup rows of the fused BN-backward +
+ * weight-gradient pass (spcl_bnrelu_backward_image_wgrad / spcl_bnrelu_backward_rows with an image).  Each of those
+ * ends in its own few-microsecond reduction launch; with a capture armed the producer skips it and describes the
+ * pending sum instead, and spcl_conv3x3_wgrad_batched_tails finishes up to SPCL_WGRAD_TAILS_MAX of them in extra
+ * workgroups of the batched launch's reduction kernel (fixed summation order; dw written, or added to when
+ * accumulate != 0).  The producer's `partial` / `ws` buffer must stay alive until that launch has run.
+ *   spcl_wgrad_tail_capture(slot): one-shot, per calling thread -- the NEXT call of one of the producers above fills
+ *   *slot and leaves dw untouched (slot == NULL disarms).  A producer that takes the batched path itself (bf16, channel
+ *   counts multiples of 64) ignores the capture and clears it; slot->kind stays -1 then.
+ * unet.py:72,75 weight gradients; replaces nothing new in the reference, only removes launches. */
+#define SPCL_WGRAD_TAILS_MAX 8
+typedef struct spcl_wgrad_tail {
+  const float* partial; /* kind 0: [nsplit][nblk_ci*nblk_co][9*CIB*COB]; kind 1: [nsplit][9][COB] */
+  float* dw;            /* OIHW destination */
+  int kind;             /* -1 empty, 0 conv split partials, 1 first-layer rows */
+  int nsplit, nblk_ci, nblk_co, CIB, COB, Cin, Cout;
+} spcl_wgrad_tail;
+int spcl_wgrad_tail_capture(spcl_wgrad_tail* slot);
+/* n may be 0 (tails only; partial may then be NULL), ntails may be 0 (== spcl_conv3x3_wgrad_batched) */
+int spcl_conv3x3_wgrad_batched_tails(const spcl_wgrad_item* items, int n, const spcl_wgrad_tail* tails, int ntails,
+                                     int accumulate, float* partial, void* stream);
+
 /* train-mode BatchNorm statistics (unet.py:73,76; torch.nn.BatchNorm2d semantics): combines the conv epilogue
  * partials stats[ntiles][3][CS] (Chan, fixed order, in double; the tail of the buffer is scratch) -> mean, invstd = 1/sqrt(var_biased+eps), scale = gamma*invstd,
  * shift = beta-mean*scale (all [CS] f32, zero in the channel padding) and updates running_mean / running_var

@@ -751,6 +751,7 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
                              int nrows = 0) {
   constexpr int EPC = Chunk<T>::EPC;
   const bool pool = dpool != nullptr;
+  spcl_wgrad_tail* tail = img != nullptr ? take_tail_capture() : nullptr;
   const int PL = 256 / (CS / EPC);
   const size_t npix = (size_t)N * H * W;
   const int prows = N * ((H + 1) / 2);
@@ -799,7 +800,12 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
     prof_cost(2.0 * tb + (double)npix * 4, 2.0 * 9 * npix * C);
     SPCL_LAUNCH((bnrelu_bwd_image_wgrad_kernel<T>), dim3(g), dim3(256), 4 * 9 * CS * sizeof(float), st, (const T*)y,
                        (const T*)dact, img, N, H, W, CS, scale, shift, (const float*)ab, (const float*)zrow, wpart);
-    SPCL_LAUNCH(image_wgrad_final_kernel, dim3(9), dim3(256), 0, st, (const float*)wpart, g, C, CS, dw);
+    if (tail != nullptr) {  // the nine taps' final sums ride in the batched weight-gradient reduction
+      tail->partial = wpart; tail->dw = dw; tail->kind = 1; tail->nsplit = g; tail->nblk_ci = tail->nblk_co = 1;
+      tail->CIB = 1; tail->COB = CS; tail->Cin = 1; tail->Cout = C;
+    } else {
+      SPCL_LAUNCH(image_wgrad_final_kernel, dim3(9), dim3(256), 0, st, (const float*)wpart, g, C, CS, dw);
+    }
   } else {
     SPCL_LAUNCH((bnrelu_bwd_apply_lin_kernel<T>), dim3(stream_grid(npix, PL, STREAM_UNROLL, STREAM_MAX_WG)), dim3(256), 0,
                        st, (const T*)y, (const T*)dact, npix, CS, scale, shift, (const float*)ab, (T*)dy);

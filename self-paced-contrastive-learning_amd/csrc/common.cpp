@@ -18,6 +18,15 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// ---- one-shot weight-gradient tail capture (see spcl_wgrad_tail_capture in the header)
+static thread_local spcl_wgrad_tail* g_tail_slot = nullptr;
+spcl_wgrad_tail* take_tail_capture() {
+  spcl_wgrad_tail* s = g_tail_slot;
+  g_tail_slot = nullptr;
+  return s;
+}
+void arm_tail_capture(spcl_wgrad_tail* slot) { g_tail_slot = slot; }
+
 // ---- kernel timer
 struct ProfRecord {
   const void* fn;
@@ -96,5 +105,14 @@ extern "C" int spcl_profile_get(int i, char* name, int name_cap, float* usec, do
     free(dem);
   }
   snprintf(name, (size_t)name_cap, "%s", nm.c_str());
+  return SPCL_OK;
+}
+
+extern "C" int spcl_wgrad_tail_capture(spcl_wgrad_tail* slot) {
+  if (slot) {
+    memset(slot, 0, sizeof(*slot));
+    slot->kind = -1;
+  }
+  spcl::arm_tail_capture(slot);
   return SPCL_OK;
 }

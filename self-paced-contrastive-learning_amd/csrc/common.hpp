@@ -83,6 +83,10 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// one-shot capture of a weight gradient's pending final sum (spcl_wgrad_tail_capture): the producer that finds a slot
+// fills it, skips its own reduction launch and clears the capture
+spcl_wgrad_tail* take_tail_capture();
+
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline int round_up(int a, int b) { return cdiv(a, b) * b; }
 

@@ -392,8 +392,8 @@ struct WgradPlan {
 };
 static WgradPlan wgrad_plan(int N, int H, int W, int CinK, int CoutS, int esize) {
   WgradPlan p;
-  p.NJ = CoutS >= 32 ? 2 : 1;
-  p.MI = CinK >= 32 ? 2 : 1;
+  p.NJ = CoutS % 32 == 0 ? 2 : 1;  // (48 padded channels: three 16-blocks, not one and a half 32-blocks)
+  p.MI = CinK % 32 == 0 ? 2 : 1;
   // (bf16 layers whose channel counts are both multiples of 64 never get here: wgrad_gemm.hip)
   p.nblk_ci = CinK / (16 * p.MI);
   p.nblk_co = CoutS / (16 * p.NJ);
@@ -483,6 +483,7 @@ extern "C" int spcl_conv3x3_wgrad(const void* x, const void* dy, int dtype, int 
   if (in_mode == 2) SPCL_CHECK_ARG(CinK == 16 && CinS >= 1 && CinS <= 16, "conv3x3_wgrad: image mode needs Cin<=16");
   else SPCL_CHECK_ARG(CinS == CinK, "conv3x3_wgrad: CinS must equal CinK");
   hipStream_t st = (hipStream_t)stream;
+  spcl_wgrad_tail* tail = take_tail_capture();  // non-null: leave the final sum to spcl_conv3x3_wgrad_batched_tails
   if (dtype == SPCL_BF16) {
     spcl_wgrad_item it;
     if (wide_item(it, x, dy, N, H, W, Cin, CinS, CinK, Cout, CoutS, in_mode, in_scale, in_shift, dw_oihw))
@@ -517,7 +518,10 @@ extern "C" int spcl_conv3x3_wgrad(const void* x, const void* dy, int dtype, int 
     return SPCL_EINVAL;
   }
   const int slab = 9 * 16 * p.MI * 16 * p.NJ;
-  if (slab >= 16384)
+  if (tail != nullptr) {
+    tail->partial = partial; tail->dw = dw_oihw; tail->kind = 0; tail->nsplit = p.nsplit; tail->nblk_ci = p.nblk_ci;
+    tail->nblk_co = p.nblk_co; tail->CIB = 16 * p.MI; tail->COB = 16 * p.NJ; tail->Cin = Cin; tail->Cout = Cout;
+  } else if (slab >= 16384)
     SPCL_LAUNCH(wgrad_reduce_kernel<4>, dim3(cdiv(slab, 256), p.nblk_ci * p.nblk_co), dim3(p.nsplit >= 64 ? 1024 : 256), 0,
                 st, (const float*)partial, p.nsplit, p.nblk_ci, p.nblk_co, 16 * p.MI, 16 * p.NJ, Cin, Cout, dw_oihw);
   else

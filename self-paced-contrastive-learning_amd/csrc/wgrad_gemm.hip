@@ -25,6 +25,7 @@
 // each block in fixed order (deterministic, no float atomics) into the OIHW f32 gradients.
 #include <stdlib.h>
 #include <type_traits>
+#include <string.h>
 #include "conv_common.hpp"
 
 namespace spcl {
@@ -51,6 +52,19 @@ struct WbArgs {
   float* partial;
   unsigned long long* stamps;  // debug (SPCL_WGRAD_GEMM_STAMPS=1): per-workgroup cycle sums of the loop phases, else null
   int dbg;  // experiments only (SPCL_WGRAD_GEMM_DBG, 0 in production): 1 no staging, 2 no MFMA loop, 4 no x transform, 8 no slab write
+};
+
+// pending final sums of the narrow layers (spcl_wgrad_tail), finished by extra workgroups of the reduce kernel
+struct WbTail {
+  const float* partial;
+  float* dw;
+  int kind, nsplit, nblk_ci, nblk_co, CIB, COB, Cin, Cout;
+  int u0;  // first tail unit of this entry
+};
+struct WbTails {
+  WbTail t[SPCL_WGRAD_TAILS_MAX];
+  int n;
+  int first;  // blockIdx.x of the first tail unit
 };
 
 // 32-byte slot permutation of a pixel column (see the header): distinct for columns c, c+2, c+8, c+10 of equal parity
@@ -403,8 +417,67 @@ __global__ __launch_bounds__(768) void wgrad_gemm_kernel(WbArgs a) {
 // waves, wave = tap, lane = fragment lane; a thread sums its float4 (4 consecutive ci of one co, one tap) over the splits
 // with coalesced 16-byte loads (1 KiB per wave and split).  The 16 ci x 16 co x 9 taps go through LDS into OIHW order,
 // where the 16 ci x 9 taps of one co are 144 consecutive floats: the gradient leaves in 576-byte runs.
-__global__ __launch_bounds__(576) void wgrad_gemm_reduce_kernel(WbArgs a) {
+// Tail units (blockIdx.x >= tl.first): kind 0 = 64 consecutive outputs of one (ci, co) block of a narrow layer's split
+// partials -- the 9 waves take the splits p = w, w + 9, ... (8 loads in flight each) and are combined through LDS in wave
+// order; kind 1 = one tap of the first layer's per-workgroup rows.  Fixed order -> deterministic.
+__device__ __forceinline__ void wb_tail_unit(const WbTails& tl, int unit, int accumulate, float* red) {
+  int idx = 0;
+#pragma unroll 1
+  for (int i = 1; i < tl.n; ++i)
+    if (unit >= tl.t[i].u0) idx = i;
+  const WbTail& t = tl.t[idx];
+  const int u = unit - t.u0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (t.kind == 0) {
+    const int slab = 9 * t.CIB * t.COB;
+    const int chunks = (slab + 63) >> 6;
+    const int blk = u / chunks, inner = (u - blk * chunks) * 64 + lane;
+    float s = 0.f;
+    if (inner < slab) {
+      const size_t stride = (size_t)t.nblk_ci * t.nblk_co * slab;
+      const float* src = t.partial + (size_t)blk * slab + inner;
+#pragma unroll 8
+      for (int p = wave; p < t.nsplit; p += 9) s += src[(size_t)p * stride];
+    }
+    red[wave * 64 + lane] = s;
+    __syncthreads();
+    if (wave == 0 && inner < slab) {
+      float v = red[lane];
+#pragma unroll
+      for (int w = 1; w < 9; ++w) v += red[w * 64 + lane];
+      const int bci = blk / t.nblk_co, bco = blk - bci * t.nblk_co;
+      const int co_l = inner % t.COB, ci_l = (inner / t.COB) % t.CIB, tap = inner / (t.COB * t.CIB);
+      const int ci = bci * t.CIB + ci_l, co = bco * t.COB + co_l;
+      if (ci < t.Cin && co < t.Cout) {
+        float* dst = t.dw + ((size_t)co * t.Cin + ci) * 9 + tap;
+        *dst = accumulate ? *dst + v : v;
+      }
+    }
+  } else {
+    const int CS = t.COB, RL = 576 / CS;  // CS <= 256: at least two row lanes
+    const int c = threadIdx.x % CS, rl = threadIdx.x / CS;
+    float s = 0.f;
+    if (rl < RL) {
+#pragma unroll 8
+      for (int w = rl; w < t.nsplit; w += RL) s += t.partial[((size_t)w * 9 + u) * CS + c];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < CS && threadIdx.x < t.Cout) {
+      float tot = 0.f;
+      for (int k = 0; k < RL; ++k) tot += red[k * CS + threadIdx.x];
+      float* dst = t.dw + threadIdx.x * 9 + u;
+      *dst = accumulate ? *dst + tot : tot;
+    }
+  }
+}
+
+__global__ __launch_bounds__(576) void wgrad_gemm_reduce_kernel(WbArgs a, WbTails tl) {
   __shared__ float tile[16 * 16 * 9 + 16];
+  if ((int)blockIdx.x >= tl.first) {
+    wb_tail_unit(tl, blockIdx.x - tl.first, a.accumulate, tile);
+    return;
+  }
   int idx = 0;
   const int wgu = blockIdx.x;  // unit index over all items: e0 counts (block, m, co-tile) units here
 #pragma unroll 1
@@ -554,14 +627,53 @@ extern "C" size_t spcl_conv_wgrad_batched_workspace_bytes(const spcl_wgrad_item*
   return (size_t)pl.nwg * WB_SLAB * sizeof(float);
 }
 
+static bool wb_tail_ok(const spcl_wgrad_tail& t) {
+  if (!t.partial || !t.dw || t.nsplit < 1) return false;
+  if (t.kind == 0)
+    return t.nblk_ci > 0 && t.nblk_co > 0 && t.CIB > 0 && t.COB > 0 && t.Cin > 0 && t.Cout > 0 &&
+           t.Cin <= t.nblk_ci * t.CIB && t.Cout <= t.nblk_co * t.COB;
+  return t.kind == 1 && t.COB >= 16 && t.COB <= 256 && t.Cout > 0 && t.Cout <= t.COB;
+}
+
 extern "C" int spcl_conv3x3_wgrad_batched(const spcl_wgrad_item* items, int n, int accumulate, float* partial,
                                           void* stream) {
-  SPCL_CHECK_ARG(items && partial, "conv3x3_wgrad_batched: null pointer");
-  SPCL_CHECK_ARG(n >= 1 && n <= WB_MAX, "conv3x3_wgrad_batched: %d items (1..%d)", n, WB_MAX);
+  SPCL_CHECK_ARG(n >= 1, "conv3x3_wgrad_batched: %d items (1..%d)", n, WB_MAX);
+  return spcl_conv3x3_wgrad_batched_tails(items, n, nullptr, 0, accumulate, partial, stream);
+}
+
+extern "C" int spcl_conv3x3_wgrad_batched_tails(const spcl_wgrad_item* items, int n, const spcl_wgrad_tail* tails,
+                                                int ntails, int accumulate, float* partial, void* stream) {
+  SPCL_CHECK_ARG(n >= 0 && n <= WB_MAX, "conv3x3_wgrad_batched: %d items (0..%d)", n, WB_MAX);
+  SPCL_CHECK_ARG(ntails >= 0 && ntails <= SPCL_WGRAD_TAILS_MAX, "conv3x3_wgrad_batched: %d tails (0..%d)", ntails,
+                 SPCL_WGRAD_TAILS_MAX);
+  SPCL_CHECK_ARG(n + ntails > 0, "conv3x3_wgrad_batched: nothing to do");
+  SPCL_CHECK_ARG((n == 0 || (items && partial)) && (ntails == 0 || tails), "conv3x3_wgrad_batched: null pointer");
   for (int i = 0; i < n; ++i)
     SPCL_CHECK_ARG(wb_item_ok(items[i]), "conv3x3_wgrad_batched: item %d: bf16 NHWC, channel counts multiples of 64, "
                                          "in_mode 0/1 (with scale/shift)", i);
+  WbTails tl;
+  memset(&tl, 0, sizeof(tl));
+  int tail_units = 0;
+  for (int i = 0; i < ntails; ++i) {
+    SPCL_CHECK_ARG(wb_tail_ok(tails[i]), "conv3x3_wgrad_batched: tail %d is not a captured weight-gradient tail", i);
+    WbTail& t = tl.t[i];
+    t.partial = tails[i].partial; t.dw = tails[i].dw; t.kind = tails[i].kind; t.nsplit = tails[i].nsplit;
+    t.nblk_ci = tails[i].nblk_ci; t.nblk_co = tails[i].nblk_co; t.CIB = tails[i].CIB; t.COB = tails[i].COB;
+    t.Cin = tails[i].Cin; t.Cout = tails[i].Cout;
+    t.u0 = tail_units;
+    tail_units += t.kind == 0 ? t.nblk_ci * t.nblk_co * cdiv(9 * t.CIB * t.COB, 64) : 9;
+  }
+  tl.n = ntails;
   hipStream_t st = (hipStream_t)stream;
+  if (n == 0) {  // tails only
+    WbArgs a;
+    memset(&a, 0, sizeof(a));
+    a.accumulate = accumulate ? 1 : 0;
+    tl.first = 0;
+    SPCL_LAUNCH(wgrad_gemm_reduce_kernel, dim3(tail_units), dim3(576), 0, st, a, tl);
+    SPCL_LAUNCH_CHECK("conv3x3_wgrad_batched_tails");
+    return SPCL_OK;
+  }
   WbPlan pl;
   wb_plan(items, n, pl);
   pl.args.partial = partial;
@@ -591,7 +703,8 @@ extern "C" int spcl_conv3x3_wgrad_batched(const spcl_wgrad_item* items, int n, i
   else if (env_ring == 3) wb_launch<14, 3>(pl, st);
   else if (env_ring == 4) wb_launch<14, 4>(pl, st);
   else wb_launch<14, 2>(pl, st);
-  SPCL_LAUNCH(wgrad_gemm_reduce_kernel, dim3(pl.total_e), dim3(576), 0, st, pl.args);
+  tl.first = pl.total_e;
+  SPCL_LAUNCH(wgrad_gemm_reduce_kernel, dim3(pl.total_e + tail_units), dim3(576), 0, st, pl.args, tl);
   if (pl.args.stamps) {
     static unsigned long long h[4096 * 8];
     (void)hipStreamSynchronize(st);

@@ -2,6 +2,8 @@
 no host synchronisation anywhere in this file."""
 from __future__ import annotations
 
+import ctypes
+import os
 from ctypes import c_float, c_int
 
 import torch
@@ -526,6 +528,7 @@ class DeferredWgrads:
 
     def __init__(self):
         self.items, self.keep, self.targets = [], [], set()
+        self.tails = []
 
     def add(self, x_store, dy, scale, shift, sink, N, H, W, cin, cin_s, cout, cout_s, in_mode):
         it = _n.WgradItem(x_store.data_ptr(), dy.data_ptr(), scale.data_ptr() if scale is not None else None,
@@ -537,14 +540,35 @@ class DeferredWgrads:
         if len(self.items) == _n.WGRAD_BATCH_MAX:
             self.flush()
 
+    def capture_tail(self, sink, keep, launch):
+        """Run ``launch()`` -- one of the narrow layers' weight-gradient producers writing to ``sink`` -- with a tail
+        capture armed (``spcl_wgrad_tail_capture``): its few-microsecond final reduction launch is skipped and rides in
+        the batched launch's reduction kernel at the next flush.  ``keep``: the buffers the pending sum reads.  Returns
+        True when the producer left a tail (the gradient then reaches ``sink`` at the flush, like a deferred item)."""
+        tail = _n.WgradTail()
+        _n.call("spcl_wgrad_tail_capture", ctypes.byref(tail))
+        try:
+            launch()
+        finally:
+            _n.call("spcl_wgrad_tail_capture", None)
+        if tail.kind < 0:
+            return False
+        self.tails.append(tail)
+        self.keep.append(keep)
+        self.targets.add(sink.data_ptr())
+        if len(self.tails) == _n.WGRAD_TAILS_MAX:
+            self.flush()
+        return True
+
     def flush(self):
-        if not self.items:
+        if not self.items and not self.tails:
             return
-        wgrad_batched(self.items, accumulate=False, device=self.keep[0][1].device)
-        self.items, self.keep = [], []
+        wgrad_batched(self.items, accumulate=False, device=self.keep[0][1].device, tails=self.tails)
+        self.items, self.keep, self.tails = [], [], []
 
 
 _deferred: "DeferredWgrads | None" = None
+_TAILS = os.environ.get("SPCL_WGRAD_TAILS", "1") != "0"  # A/B switch: 0 keeps every layer's own final reduction launch
 
 
 def open_deferred_wgrads():
@@ -568,14 +592,19 @@ def flush_deferred_wgrads(close: bool = True):
     return targets
 
 
-def wgrad_batched(items, accumulate, device):
-    """one launch for ``items`` (list of native.WgradItem, at most native.WGRAD_BATCH_MAX)"""
-    arr = (_n.WgradItem * len(items))(*items)
-    nbytes = _n.call("spcl_conv_wgrad_batched_workspace_bytes", arr, len(items))
-    if nbytes == 0:
-        raise RuntimeError("wgrad_batched: unsupported item (bf16 NHWC, channel counts multiples of 64, in_mode 0/1)")
-    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
-    _n.call("spcl_conv3x3_wgrad_batched", arr, len(items), int(bool(accumulate)), _n.ptr(ws), _n.stream())
+def wgrad_batched(items, accumulate, device, tails=()):
+    """one launch for ``items`` (list of native.WgradItem, at most native.WGRAD_BATCH_MAX) and the captured ``tails``
+    (native.WgradTail, at most native.WGRAD_TAILS_MAX)"""
+    arr, ws = None, None
+    if items:
+        arr = (_n.WgradItem * len(items))(*items)
+        nbytes = _n.call("spcl_conv_wgrad_batched_workspace_bytes", arr, len(items))
+        if nbytes == 0:
+            raise RuntimeError("wgrad_batched: unsupported item (bf16 NHWC, channel counts multiples of 64, in_mode 0/1)")
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=device)
+    tarr = (_n.WgradTail * len(tails))(*tails) if tails else None
+    _n.call("spcl_conv3x3_wgrad_batched_tails", arr, len(items), tarr, len(tails), int(bool(accumulate)), _n.ptr(ws),
+            _n.stream())
 
 
 def _wgrad(x_store, dy, dt_code, N, H, W, cin, cin_s, cin_k, cout, cout_s, in_mode, scale, shift, sink=None):
@@ -587,8 +616,17 @@ def _wgrad(x_store, dy, dt_code, N, H, W, cin, cin_s, cin_k, cout, cout_s, in_mo
     nbytes = _n.call("spcl_conv_wgrad_workspace_bytes", N, H, W, cin_k, cout_s)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
     dw = _grad_buffer(sink, (cout, cin, 3, 3), dev)
-    _n.call("spcl_conv3x3_wgrad", _n.ptr(x_store), _n.ptr(dy), dt_code, N, H, W, cin, cin_s, cin_k, cout, cout_s,
-            in_mode, _n.ptr(scale), _n.ptr(shift), _n.ptr(ws), _n.ptr(dw), _n.stream())
+
+    def launch():
+        _n.call("spcl_conv3x3_wgrad", _n.ptr(x_store), _n.ptr(dy), dt_code, N, H, W, cin, cin_s, cin_k, cout, cout_s,
+                in_mode, _n.ptr(scale), _n.ptr(shift), _n.ptr(ws), _n.ptr(dw), _n.stream())
+
+    if _deferred is not None and sink is not None and _TAILS:
+        # narrow layer straight into a bucket slice: its final sum joins the batched launch (no separate reduce launch)
+        if _deferred.capture_tail(sink, (ws, dy, x_store, scale, shift), launch):
+            return None
+        return dw
+    launch()
     return dw
 
 
@@ -612,9 +650,17 @@ def _bnrelu_bwd_image_wgrad(y, dact, image, dt_code, N, H, W, C, cs, st, trainin
     dw = _grad_buffer(sinks[0], (C, 1, 3, 3), dev)
     dgamma = _grad_buffer(sinks[1], (C,), dev)
     dbeta = _grad_buffer(sinks[2], (C,), dev)
-    _n.call("spcl_bnrelu_backward_image_wgrad", _n.ptr(y), _n.ptr(dact), _n.ptr(image), dt_code, N, H, W, C, cs,
-            _n.ptr(st[0]), _n.ptr(st[1]), _n.ptr(st[2]), _n.ptr(st[3]), int(training), _n.ptr(ws), _n.ptr(dgamma),
-            _n.ptr(dbeta), _n.ptr(dw), _n.stream())
+
+    def launch():
+        _n.call("spcl_bnrelu_backward_image_wgrad", _n.ptr(y), _n.ptr(dact), _n.ptr(image), dt_code, N, H, W, C, cs,
+                _n.ptr(st[0]), _n.ptr(st[1]), _n.ptr(st[2]), _n.ptr(st[3]), int(training), _n.ptr(ws), _n.ptr(dgamma),
+                _n.ptr(dbeta), _n.ptr(dw), _n.stream())
+
+    if _deferred is not None and sinks[0] is not None and _TAILS:
+        if _deferred.capture_tail(sinks[0], (ws, dact), launch):
+            dw = None  # reaches the bucket slice when the queue is flushed
+    else:
+        launch()
     return dw, dgamma, dbeta
 
 
@@ -651,9 +697,16 @@ def _bnrelu_bwd_rows(y, dact, image, rows, dt_code, dtype, N, H, W, C, cs, st, t
         first = torch.empty(N, H, W, cs, dtype=dtype, device=dev)
         dgamma, dbeta = _grad_buffer(sinks[0], (C,), dev), _grad_buffer(sinks[1], (C,), dev)
         dy, dw = first, None
-    _n.call("spcl_bnrelu_backward_rows", _n.ptr(y), _n.ptr(dact), _n.ptr(image), _n.ptr(rows), rows.ntiles, dt_code, N,
-            H, W, C, cs, _n.ptr(st[0]), _n.ptr(st[1]), _n.ptr(st[2]), _n.ptr(st[3]), int(training), _n.ptr(ws),
-            _n.ptr(dgamma), _n.ptr(dbeta), _n.ptr(dy), _n.ptr(dw), _n.stream())
+    def launch():
+        _n.call("spcl_bnrelu_backward_rows", _n.ptr(y), _n.ptr(dact), _n.ptr(image), _n.ptr(rows), rows.ntiles, dt_code,
+                N, H, W, C, cs, _n.ptr(st[0]), _n.ptr(st[1]), _n.ptr(st[2]), _n.ptr(st[3]), int(training), _n.ptr(ws),
+                _n.ptr(dgamma), _n.ptr(dbeta), _n.ptr(dy), _n.ptr(dw), _n.stream())
+
+    if image is not None and _deferred is not None and sinks[0] is not None and _TAILS:
+        if _deferred.capture_tail(sinks[0], (ws, dact), launch):
+            first = None  # the weight gradient reaches the bucket slice when the queue is flushed
+    else:
+        launch()
     return first, dgamma, dbeta
 
 

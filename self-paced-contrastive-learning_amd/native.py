@@ -58,6 +58,8 @@ _SIGNATURES = {
     "spcl_conv_wgrad_batched_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "spcl_conv_wgrad_batched_workspace_bytes": (c_size_t, [_P, c_int]),
     "spcl_conv3x3_wgrad_batched": (c_int, [_P, c_int, c_int, _P, _P]),
+    "spcl_wgrad_tail_capture": (c_int, [_P]),
+    "spcl_conv3x3_wgrad_batched_tails": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P]),
     "spcl_bn_finalize": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
     "spcl_bn_eval_affine": (c_int, [c_int, c_int, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P]),
     "spcl_bnrelu_pool_forward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
@@ -109,7 +111,14 @@ class WgradItem(ctypes.Structure):
                 ("Cout", c_int), ("CoutS", c_int), ("in_mode", c_int)]
 
 
+class WgradTail(ctypes.Structure):
+    """``spcl_wgrad_tail`` of include/spcl_hip.h (a weight gradient's pending final sum)"""
+    _fields_ = [("partial", c_void_p), ("dw", c_void_p), ("kind", c_int), ("nsplit", c_int), ("nblk_ci", c_int),
+                ("nblk_co", c_int), ("CIB", c_int), ("COB", c_int), ("Cin", c_int), ("Cout", c_int)]
+
+
 WGRAD_BATCH_MAX = 8
+WGRAD_TAILS_MAX = 8
 _NO_STATUS = ("spcl_abi_version", "spcl_conv_num_tiles", "spcl_conv_stat_rows", "spcl_conv_set_gemm", "spcl_profile_count", "spcl_conv_dgrad_bnstats_supported", "spcl_conv_dgrad_poolstats_supported",
               "spcl_conv_wgrad_batched_supported")
 

@@ -267,6 +267,90 @@ def test_conv_wgrad_batched(layers, accumulate):
         assert torch.equal(a, dw)
 
 
+@pytest.mark.parametrize("with_wide", [False, True])
+@pytest.mark.parametrize("accumulate", [0, 1])
+def test_conv_wgrad_tails_ride_in_the_batched_reduction(with_wide, accumulate):
+    """The narrow layers' final sums (and the first layer's rows of the fused BN-backward + weight-gradient pass) captured
+    as tails and finished by the batched launch's reduction kernel equal what their own reduction launches give (only
+    the summation tree differs), with and without >= 64-channel items in the same launch."""
+    import ctypes
+    n = _n()
+    keep, tails, expect = [], [], []
+    g = torch.Generator().manual_seed(77)
+    for (dt, N, ci, co, H, W, mode) in [("bf16", 3, 16, 16, 56, 56, 1), ("bf16", 2, 16, 32, 28, 42, 0),
+                                        ("bf16", 2, 32, 32, 28, 28, 1), ("bf16", 2, 32, 64, 14, 14, 0),
+                                        ("f32", 2, 24, 40, 14, 21, 0), ("bf16", 2, 1, 16, 30, 44, 2)]:
+        dtype = DT[dt]
+        x = rnd(torch.randn(N, ci, H, W, generator=g), dtype) if mode != 2 else torch.rand(N, 1, H, W, generator=g)
+        dy = rnd(torch.randn(N, co, H, W, generator=g), dtype)
+        cs_i, cs_o = ru16(ci), ru16(co)
+        sc, sh = torch.zeros(cs_i), torch.zeros(cs_i)
+        sc[:ci], sh[:ci] = torch.randn(ci, generator=g), torch.randn(ci, generator=g) * 0.3
+        xs = nhwc(x, dtype) if mode != 2 else x.permute(0, 2, 3, 1).contiguous().cuda()
+        dys, scd, shd = nhwc(dy, dtype), sc.cuda(), sh.cuda()
+        nb = n.call("spcl_conv_wgrad_workspace_bytes", N, H, W, cs_i, cs_o)
+        ws, ws2 = torch.empty(nb // 4, device="cuda"), torch.empty(nb // 4, device="cuda")
+        dw_own = torch.empty(co, ci, 3, 3, device="cuda")
+        dw_tail = torch.full((co, ci, 3, 3), 0.25, device="cuda")
+        args = lambda w_, d_: (n.ptr(xs), n.ptr(dys), n.dtype_code(dtype), N, H, W, ci, ci if mode == 2 else cs_i, cs_i,
+                               co, cs_o, mode, n.ptr(scd) if mode == 1 else None, n.ptr(shd) if mode == 1 else None,
+                               n.ptr(w_), n.ptr(d_), n.stream())
+        n.call("spcl_conv3x3_wgrad", *args(ws, dw_own))
+        t = n.WgradTail()
+        n.call("spcl_wgrad_tail_capture", ctypes.byref(t))
+        n.call("spcl_conv3x3_wgrad", *args(ws2, dw_tail))
+        assert t.kind == 0 and t.dw == dw_tail.data_ptr()
+        assert torch.all(dw_tail == 0.25)  # untouched until the batched launch
+        keep += [xs, dys, scd, shd, ws, ws2]
+        tails.append(t)
+        expect.append((dw_own, dw_tail))
+    # a capture is one-shot: the next producer runs its own reduction again
+    n.call("spcl_conv3x3_wgrad", *args(ws, dw_own))
+    # kind 1: the first layer's rows
+    N, C, H, W = 2, 16, 30, 44
+    dtype, dtc, cs = torch.bfloat16, n.dtype_code(torch.bfloat16), 16
+    x = torch.rand(N, 1, H, W, generator=g)
+    y = rnd(F.conv2d(x, torch.randn(C, 1, 3, 3, generator=g) * 0.5, padding=1), dtype)
+    dact = rnd(torch.randn(N, C, H, W, generator=g), dtype)
+    st = torch.zeros(4, cs)
+    st[0, :C], st[1, :C] = y.mean(dim=(0, 2, 3)), 1.0 / torch.sqrt(y.var(dim=(0, 2, 3), unbiased=False) + 1e-5)
+    st[2, :C], st[3, :C] = st[1, :C], -st[0, :C] * st[1, :C]
+    st = st.cuda()
+    ys, das, xs = nhwc(y, dtype), nhwc(dact, dtype), x.permute(0, 2, 3, 1).contiguous().cuda()
+    nb = n.call("spcl_bnrelu_image_wgrad_workspace_bytes", N, H, W, cs)
+    wsa, wsb = torch.empty(nb // 4, device="cuda"), torch.empty(nb // 4, device="cuda")
+    dgm, dbt = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    dw_own, dw_tail = torch.empty(C, 1, 3, 3, device="cuda"), torch.full((C, 1, 3, 3), 0.25, device="cuda")
+    iargs = lambda w_, d_: (n.ptr(ys), n.ptr(das), n.ptr(xs), dtc, N, H, W, C, cs, n.ptr(st[0]), n.ptr(st[1]),
+                            n.ptr(st[2]), n.ptr(st[3]), 1, n.ptr(w_), n.ptr(dgm), n.ptr(dbt), n.ptr(d_), n.stream())
+    n.call("spcl_bnrelu_backward_image_wgrad", *iargs(wsa, dw_own))
+    t = n.WgradTail()
+    n.call("spcl_wgrad_tail_capture", ctypes.byref(t))
+    n.call("spcl_bnrelu_backward_image_wgrad", *iargs(wsb, dw_tail))
+    assert t.kind == 1
+    tails.append(t)
+    expect.append((dw_own, dw_tail))
+    items, outs = [], []
+    if with_wide:
+        for k, (N_, ci, co, H_, W_, mode) in enumerate([(2, 64, 64, 28, 28, 1), (2, 128, 64, 14, 14, 0)]):
+            it, dw, ref = _wgrad_item(n, N_, ci, co, H_, W_, mode, 300 + k, keep)
+            items.append(it)
+            outs.append((dw, ref))
+    arr = (n.WgradItem * len(items))(*items) if items else None
+    wsw = torch.empty(n.call("spcl_conv_wgrad_batched_workspace_bytes", arr, len(items)) // 4, device="cuda") \
+        if items else None
+    tarr = (n.WgradTail * len(tails))(*tails)
+    n.call("spcl_conv3x3_wgrad_batched_tails", arr, len(items), tarr, len(tails), accumulate, n.ptr(wsw), n.stream())
+    for k, (own, tl) in enumerate(expect):
+        got = tl - (0.25 if accumulate else 0.0)
+        assert relerr(got.cpu(), own.cpu()) < 2e-6, (k, relerr(got.cpu(), own.cpu()))
+    for k, (dw, ref) in enumerate(outs):
+        assert relerr(dw.cpu() - (0.25 if accumulate else 0.0), ref) < 2e-3
+    with pytest.raises(RuntimeError):  # an empty / foreign descriptor is refused
+        bad = (n.WgradTail * 1)(n.WgradTail())
+        n.call("spcl_conv3x3_wgrad_batched_tails", None, 0, bad, 1, 0, None, n.stream())
+
+
 def test_conv_wgrad_batched_rejects_what_it_cannot_do():
     n = _n()
     keep = []
