@@ -9,6 +9,7 @@
 //   * BatchNorm partials leave as three 16-byte stores per 16-lane row.
 // On the 16->16 layer at 224^2 this is 47 us against 80 us for the generic kernel (pure copy of the same tiles: 42).
 #include <stdlib.h>
+#include <vector>
 #include "conv_common.hpp"
 
 namespace spcl {
@@ -21,6 +22,7 @@ struct FastArgs {
   const float* in_scale;
   const float* in_shift;
   int N, H, W, CinK, CoutS, tilesX, tilesY, gy;
+  unsigned long long* stamps;  // debug (SPCL_FAST_STAMPS=1): s_memtime ticks of wave 0 per phase, else null
   int lds_flip;   // bytes between the two halo images of the cross-slab pipeline (0: one image)
   int xcd_remap;  // 1: tiles of an image are dealt to the XCDs in contiguous row-major blocks (see the kernel)
   // MODE 2 (dgrad whose output g is the gradient of relu(bn(y2))): per-tile partial sums of that BatchNorm's backward
@@ -62,6 +64,14 @@ conv3x3_fast_kernel(FastArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r16 = lane & 15, g = lane >> 4;
+  // phase timing of wave 0 (debug builds only, -DSPCL_FAST_STAMPS_BUILD=1 + SPCL_FAST_STAMPS=1: the eight counter registers
+  // alone push the 128-register kernels into spilling)
+#ifndef SPCL_FAST_STAMPS_BUILD
+#define SPCL_FAST_STAMPS_BUILD 0
+#endif
+  const bool stamp = SPCL_FAST_STAMPS_BUILD && a.stamps != nullptr && t == 0;
+  unsigned long long t_begin = 0, t_k0 = 0, t_k1 = 0, t_store = 0;
+  if (stamp) t_begin = __builtin_amdgcn_s_memtime();
   // Workgroups go to the 8 XCDs round-robin in launch order (x fastest): horizontally adjacent tiles would sit on
   // different XCDs and fetch their shared halo columns from HBM twice.  When an image's tile count divides by 8 each XCD
   // gets a block of consecutive tiles in row-major order instead (whole tile rows at 224^2: both halo directions hit L2).
@@ -179,7 +189,9 @@ conv3x3_fast_kernel(FastArgs a) {
       if (in_range) *(u32x4*)(lpw + (dky * HW_ + dkx) * PS) = tv;
     }
     if (refill) issue_halo(slab + 1);
+    if (stamp && slab == 0) t_store = __builtin_amdgcn_s_memtime();
     __syncthreads();
+    if (stamp && slab == 0) t_k0 = __builtin_amdgcn_s_memtime();
 
     // ------------ k-loop: NSTEPS x (one 16-byte x fragment per m-tile, NT MFMAs on it)
     const u32x4* wslab = a.wp + ((size_t)slab * NSTEPS * ntn + nt0) * 64 + lane;
@@ -256,6 +268,7 @@ conv3x3_fast_kernel(FastArgs a) {
   }
   if (nslab > 1 && flip == 0) __syncthreads();
   slab_body(nslab - 1, false);
+  if (stamp) t_k1 = __builtin_amdgcn_s_memtime();
 
   // ------------ epilogue: lane holds couts 16 (nt0 + j) + 4 g .. +3 of pixel p = 16 i + r16 (tiles are always full)
   constexpr int DPY = 16 / TW, DPX = 16 % TW;
@@ -281,9 +294,61 @@ conv3x3_fast_kernel(FastArgs a) {
   if (MODE == 2) y2b = a.y2 + (yb - a.y);
   const bool shifted = (oy | ox) != 0;  // wave-uniform
   int pyc = py;                         // the pixel's row inside the tile, walked with px
+  // MODE 2 / 3: every y2 value the statistics need is requested BEFORE the first output store (the k-loop's fragment
+  // registers are free now).  Loads and stores retire in order: a load issued after a store is only usable once that
+  // store is acknowledged, and one request - wait - compute round per (m-tile, n-tile) is a memory latency each (the
+  // MODE 3 epilogue of the 128-workgroup Conv5.a dgrad took 24k cycles of its 54k that way).
+  constexpr int NWIN = MODE == 3 ? 4 : 1;
+  // ... in chunks of GM m-tiles, the next chunk's requests ahead of this chunk's stores, two chunks in flight within a
+  // register budget that the kernel's occupancy target leaves
+  constexpr bool YPRE = (MODE == 2 || MODE == 3) && KC == 64;  // (the narrow layers have the occupancy to hide it instead)
+  constexpr int YBUD = MODE == 3 ? 64 : 56, YR1 = NT * NWIN * 2;
+  constexpr int GM = YBUD / (2 * YR1) > 0 ? YBUD / (2 * YR1) : 1;
+  uint2 ypre[YPRE ? MT : 1][NT][NWIN];
+  int lpx = px, lpyc = pyc, lob = ob;  // walker of the requests
+  auto request_chunk = [&](const int c) {
+#pragma unroll
+    for (int ii = 0; ii < GM; ++ii) {
+      const int i = c * GM + ii;
+      if (i < MT) {
+        const bool ok = (16 * i + 15 < NPIX) || (16 * i + r16 < NPIX);
+        if (ok) {
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            if (MODE == 2) {
+              ypre[i][j][0] = *(const uint2*)(y2b + lob + j * 32);
+            } else {
+              const unsigned char* wb = a.y2 +
+                                        ((((size_t)n * a.H2 + 2 * (y0 + lpyc)) * a.W2 + 2 * (x0 + lpx)) * rowb) +
+                                        ((nt0 + j) * 16 + 4 * g) * 2;
+#pragma unroll
+              for (int k = 0; k < 4; ++k)
+                ypre[i][j][k] = *(const uint2*)(wb + ((size_t)(k >> 1) * a.W2 + (k & 1)) * rowb);
+            }
+          }
+        }
+        lpx += DPX;
+        lpyc += DPY;
+        lob += dob;
+        if (lpx >= TW) {
+          lpx -= TW;
+          lpyc += 1;
+          lob += wrapo;
+        }
+      }
+    }
+  };
+  if (YPRE) {
+    request_chunk(0);
+    __builtin_amdgcn_sched_barrier(0);  // (the scheduler would hoist every later request up here too)
+  }
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const bool ok = (16 * i + 15 < NPIX) || (16 * i + r16 < NPIX);  // compile-time true except in the last m-tile
+    if (YPRE && i % GM == 0 && (i / GM + 1) * GM < MT) {
+      request_chunk(i / GM + 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     if (ok) {
       const float keep = (!shifted || (pyc >= oy && px >= ox)) ? 1.f : 0.f;  // 0: the neighbour tile counts this pixel
 #pragma unroll
@@ -291,7 +356,7 @@ conv3x3_fast_kernel(FastArgs a) {
         store4_fast<bf16_t>(yb + ob + j * 32, acc[i][j]);
         if (MODE == 2) {
           // dz = g [relu(bn(y2)) > 0] with g as STORED (bf16): sum dz and sum dz (y2 - mean) of the lane's 4 channels
-          const uint2 yr = *(const uint2*)(y2b + ob + j * 32);
+          const uint2 yr = YPRE ? ypre[i][j][0] : *(const uint2*)(y2b + ob + j * 32);
           const f32x2 glo = {acc[i][j][0], acc[i][j][1]}, ghi = {acc[i][j][2], acc[i][j][3]};
           const uint32_t g0 = __builtin_bit_cast(uint32_t, __builtin_convertvector(glo, bf16x2v));
           const uint32_t g1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(ghi, bf16x2v));
@@ -313,11 +378,16 @@ conv3x3_fast_kernel(FastArgs a) {
           const uint32_t g1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(ghi, bf16x2v));
           const float gv[4] = {__uint_as_float(g0 << 16), __uint_as_float(g0 & 0xffff0000u),
                                __uint_as_float(g1 << 16), __uint_as_float(g1 & 0xffff0000u)};
-          const unsigned char* wb = a.y2 + ((((size_t)n * a.H2 + 2 * (y0 + pyc)) * a.W2 + 2 * (x0 + px)) * rowb) +
-                                    ((nt0 + j) * 16 + 4 * g) * 2;
           uint2 yr[4];
+          if (YPRE) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) yr[k] = *(const uint2*)(wb + ((size_t)(k >> 1) * a.W2 + (k & 1)) * rowb);
+            for (int k = 0; k < 4; ++k) yr[k] = ypre[i][j][k];
+          } else {
+            const unsigned char* wb = a.y2 + ((((size_t)n * a.H2 + 2 * (y0 + pyc)) * a.W2 + 2 * (x0 + px)) * rowb) +
+                                      ((nt0 + j) * 16 + 4 * g) * 2;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) yr[k] = *(const uint2*)(wb + ((size_t)(k >> 1) * a.W2 + (k & 1)) * rowb);
+          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float zb = -1.f, yb = 0.f;
@@ -367,6 +437,12 @@ conv3x3_fast_kernel(FastArgs a) {
     for (int j = 0; j < NT; ++j)
       write_tile_stats(a.stats, tile, a.CoutS, (nt0 + j) * 16 + 4 * g, r16, (float)((TH - oy) * (TW - ox)), ssum[j],
                        ssq[j]);
+  }
+  if (stamp) {
+    __builtin_amdgcn_s_waitcnt(0);  // (the epilogue's stores issued; their acknowledgements are not awaited by the kernel)
+    const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+    unsigned long long* o = a.stamps + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4;
+    o[0] = t_store - t_begin; o[1] = t_k0 - t_store; o[2] = t_k1 - t_k0; o[3] = t_end - t_k1;
   }
 }
 
@@ -471,10 +547,30 @@ static void launch_fast(const FastArgs& a, int mode, hipStream_t st) {
   b.lds_flip = pipe ? fast_lds_bytes(KC, TH) : 0;
   const size_t lds = fast_lds_bytes(KC, TH) * (pipe ? 2 : 1);
   dim3 grid(a.tilesX, a.tilesY, a.N * a.gy), block(64 * NW);
+  static const bool env_stamps = SPCL_FAST_STAMPS_BUILD && getenv("SPCL_FAST_STAMPS") != nullptr;
+  const size_t nwg = (size_t)grid.x * grid.y * grid.z;
+  b.stamps = nullptr;
+  if (env_stamps) {  // debug only (synchronises)
+    (void)hipMalloc(&b.stamps, nwg * 4 * sizeof(unsigned long long));
+    (void)hipMemset(b.stamps, 0, nwg * 4 * sizeof(unsigned long long));
+  }
   if (mode == 1) SPCL_LAUNCH((conv3x3_fast_kernel<KC, TH, NT, 1, NW>), grid, block, lds, st, b);
   else if (a.rows2 != nullptr && a.H2 > 0) SPCL_LAUNCH((conv3x3_fast_kernel<KC, TH, NT, 3, NW>), grid, block, lds, st, b);
   else if (a.rows2 != nullptr) SPCL_LAUNCH((conv3x3_fast_kernel<KC, TH, NT, 2, NW>), grid, block, lds, st, b);
   else SPCL_LAUNCH((conv3x3_fast_kernel<KC, TH, NT, 0, NW>), grid, block, lds, st, b);
+  if (b.stamps != nullptr) {
+    std::vector<unsigned long long> h(nwg * 4);
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(h.data(), b.stamps, h.size() * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(b.stamps);
+    double s4[4] = {0, 0, 0, 0};
+    for (size_t i = 0; i < nwg; ++i)
+      for (int k = 0; k < 4; ++k) s4[k] += (double)h[i * 4 + k];
+    fprintf(stderr, "[conv_fast stamps] <%d,%d,%d,m%d,%d> %dx%d CinK %d CoutS %d wgs %zu | s_memtime ticks per wg: setup + first "
+            "halo + LDS store %.0f, barrier %.0f, k-loops (all slabs) %.0f, epilogue %.0f\n", KC, TH, NT,
+            mode == 1 ? 1 : (a.rows2 ? (a.H2 > 0 ? 3 : 2) : 0), NW, a.H, a.W, a.CinK, a.CoutS, nwg, s4[0] / nwg, s4[1] / nwg,
+            s4[2] / nwg, s4[3] / nwg);
+  }
 }
 
 bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
@@ -486,7 +582,7 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
     a.in_scale = a.in_shift = nullptr;
     a.y2 = nullptr; a.scale2 = a.shift2 = a.mean2 = nullptr; a.rows2 = nullptr; a.H2 = a.W2 = 0;
     a.N = c.N; a.H = c.H; a.W = c.W; a.CinK = 16; a.CoutS = 16;
-    a.tilesX = cdiv(c.W, 14); a.tilesY = cdiv(c.H, 14); a.gy = 1; a.xcd_remap = 0; a.lds_flip = 0;
+    a.tilesX = cdiv(c.W, 14); a.tilesY = cdiv(c.H, 14); a.gy = 1; a.xcd_remap = 0; a.lds_flip = 0; a.stamps = nullptr;
     if (!dry) SPCL_LAUNCH((conv3x3_image_kernel<14>), dim3(a.tilesX, a.tilesY, a.N), dim3(64), 0, st, a);
     return true;
   }
@@ -498,6 +594,12 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
   // 64 -> 64 channels: four one-n-tile waves when the loader also applies BN+ReLU (more lanes for the transform:
   // Conv3.b forward 38 -> 30 us) and on the small images; two two-n-tile waves for the plain 56^2 dgrad
   if (KC == 64 && ntn == 4 && env_nt1 != 3 && (c.in_mode == 1 || c.H <= 28)) NT = 1;
+  // few tiles (14^2 images): with two n-tiles per wave a 128-channel output is ONE workgroup per tile -- 128 workgroups for
+  // Conv5.a's dgrad at N = 64, half the CUs idle; one n-tile per wave doubles the workgroups
+  static const int env_fill = getenv("SPCL_CONV_FAST_FILL") ? atoi(getenv("SPCL_CONV_FAST_FILL")) : 1;
+  if (env_fill && KC == 64 && NT == 2 && ntn >= 8 && ntn % 4 == 0 &&
+      (long)c.N * cdiv(c.W, 14) * cdiv(c.H, th) * cdiv(ntn, 8) < 256)
+    NT = 1;
   int nw = ntn / NT;
   if (nw > 4) nw = 4;
   if (ntn % (NT * nw) != 0) return false;
