@@ -43,6 +43,12 @@ struct FastArgs {
 // one k-group with {4-11} of the next (MI355X_MICROARCH, LDS) -- so a read is conflict-free when the pixel index q of
 // fragment pixel p is congruent to p mod 8.  With 16-pixel rows the 14-wide tile makes q = p + 2 py and every row wrap
 // inside a lane group collides (PMC, round 2: 44 % of all LDS cycles were bank conflicts); RP = 22 gives q = p + 8 py.
+#ifndef SPCL_FAST_WPE_NT1
+#define SPCL_FAST_WPE_NT1 2  // (3 waves per SIMD measured 6-14 us per step slower: spills + a 6-step ring)
+#endif
+#ifndef SPCL_FAST_WR_NT1
+#define SPCL_FAST_WR_NT1 9
+#endif
 #ifndef SPCL_FAST_RP
 #define SPCL_FAST_RP 22
 #endif
@@ -62,6 +68,7 @@ constexpr int fast_wpe(int KC, int TH, int NW, int NT) {
   w = w > 4 ? 4 : (w < 1 ? 1 : w);
   const int acc = (TH * 14 + 15) / 16 * NT * 4;  // accumulator registers of a wave
   if (acc > 80 && w > 2) return 2;               // 13 m-tiles x 2 n-tiles: give the allocator 256 registers
+  if (KC == 64 && NT == 1 && NW >= 2 && w > 2) return SPCL_FAST_WPE_NT1;  // 9-step ring of one n-tile: 36 registers
   if (fast_preload_slab(KC, NW, NT) && w > 2) return 2;  // a slab's weight fragments live in registers (PRELOAD_SLAB)
   return w;
 }
@@ -160,7 +167,7 @@ conv3x3_fast_kernel(FastArgs a) {
   u32x4 v[ITER];
   float ssc[8], ssh[8];
   constexpr bool STREAM_W = PRELOAD_SLAB && KC == 64;  // (the only shape with more than one slab)
-  constexpr int WR = STREAM_W ? 9 : (PRELOAD_SLAB ? NSTEPS : 1);
+  constexpr int WR = STREAM_W ? (NT == 1 ? SPCL_FAST_WR_NT1 : 9) : (PRELOAD_SLAB ? NSTEPS : 1);
   u32x4 wsl[WR][NT];
   auto issue_halo = [&](int slab) {
     if (MODE == 1) {
