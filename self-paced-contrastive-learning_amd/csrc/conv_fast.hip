@@ -49,6 +49,9 @@ struct FastArgs {
 #ifndef SPCL_FAST_WR_NT1
 #define SPCL_FAST_WR_NT1 9
 #endif
+#ifndef SPCL_FAST_YPRE_MINKC
+#define SPCL_FAST_YPRE_MINKC 16
+#endif
 #ifndef SPCL_FAST_RP
 #define SPCL_FAST_RP 22
 #endif
@@ -62,11 +65,12 @@ constexpr int fast_lds_bytes(int KC, int TH) { return (TH + 2) * fast_row_pitch(
 // only a handful in flight otherwise, hides under the activation loads): 9 x NT (KC = 32) or 18 x NT (KC = 64)
 // fragments of 4 registers; a one-wave KC = 64 workgroup also holds 18 staging chunks and would spill
 constexpr bool fast_preload_slab(int KC, int NW, int NT) { return KC == 32 || (KC == 64 && NW >= 2 && NT >= 1); }
-constexpr int fast_wpe(int KC, int TH, int NW, int NT) {
+constexpr int fast_wpe(int KC, int TH, int NW, int NT, int MODE = 0) {
   const int wgs = 160 * 1024 / fast_lds_bytes(KC, TH);
   int w = (wgs * NW + 3) / 4;
   w = w > 4 ? 4 : (w < 1 ? 1 : w);
   const int acc = (TH * 14 + 15) / 16 * NT * 4;  // accumulator registers of a wave
+  if (KC == 16 && MODE >= 2 && SPCL_FAST_YPRE_MINKC <= 16 && w > 3 && acc <= 80) return 3;  // room for the y2 requests
   if (acc > 80 && w > 2) return 2;               // 13 m-tiles x 2 n-tiles: give the allocator 256 registers
   if (KC == 64 && NT == 1 && NW >= 2 && w > 2) return SPCL_FAST_WPE_NT1;  // 9-step ring of one n-tile: 36 registers
   if (fast_preload_slab(KC, NW, NT) && w > 2) return 2;  // a slab's weight fragments live in registers (PRELOAD_SLAB)
@@ -74,7 +78,7 @@ constexpr int fast_wpe(int KC, int TH, int NW, int NT) {
 }
 
 template <int KC, int TH, int NT, int MODE, int NW>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(fast_wpe(KC, TH, NW, NT)))) void
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(fast_wpe(KC, TH, NW, NT, MODE)))) void
 conv3x3_fast_kernel(FastArgs a) {
   constexpr int TW = 14, HW_ = 16, CP = KC / 8, NHALO = (TH + 2) * HW_, PS = fast_pixel_stride(KC);
   constexpr int RP = fast_row_pitch(KC);  // LDS row pitch in pixels (HW_ of them are halo pixels)
@@ -323,7 +327,7 @@ conv3x3_fast_kernel(FastArgs a) {
   constexpr int NWIN = MODE == 3 ? 4 : 1;
   // ... in chunks of GM m-tiles, the next chunk's requests ahead of this chunk's stores, two chunks in flight within a
   // register budget that the kernel's occupancy target leaves
-  constexpr bool YPRE = (MODE == 2 || MODE == 3) && KC == 64;  // (the narrow layers have the occupancy to hide it instead)
+  constexpr bool YPRE = (MODE == 2 || MODE == 3) && KC >= SPCL_FAST_YPRE_MINKC;  // (128-register kernels: no room)
   constexpr int YBUD = MODE == 3 ? 64 : 56, YR1 = NT * NWIN * 2;
   constexpr int GM = YBUD / (2 * YR1) > 0 ? YBUD / (2 * YR1) : 1;
   uint2 ypre[YPRE ? MT : 1][NT][NWIN];
