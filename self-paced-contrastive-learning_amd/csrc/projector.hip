@@ -129,13 +129,13 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(CPtrs os, CPtrs dzs, in
 
 // dW[o][k] = sum_n g[n][o] * act(x[n][k]);  db[o] = sum_n g[n][o]      (thread per (o,k), n sequential)
 template <bool LEAKY_IN>
-__global__ __launch_bounds__(256) void linear_wgrad_kernel(CPtrs gs, CPtrs xs, int N, int K, int O, MPtrs dWs, MPtrs dbs) {
-  const float* __restrict__ g = gs.p[blockIdx.z];
-  const float* __restrict__ x = xs.p[blockIdx.z];
-  float* __restrict__ dW = dWs.p[blockIdx.z];
-  float* __restrict__ db = dbs.p[blockIdx.z];
-  const int o = blockIdx.y;
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void linear_wgrad_body(const CPtrs& gs, const CPtrs& xs, int N, int K, int O, const MPtrs& dWs,
+                                                  const MPtrs& dbs, int bx, int o, int z) {
+  const float* __restrict__ g = gs.p[z];
+  const float* __restrict__ x = xs.p[z];
+  float* __restrict__ dW = dWs.p[z];
+  float* __restrict__ db = dbs.p[z];
+  const int k = bx * 256 + threadIdx.x;
   if (k >= K) return;
   float s = 0.f, sb = 0.f;
 #pragma unroll 8
@@ -149,18 +149,20 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(CPtrs gs, CPtrs xs, i
   dW[(size_t)o * K + k] = s;
   if (k == 0) db[o] = sb;
 }
+template <bool LEAKY_IN>
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(CPtrs gs, CPtrs xs, int N, int K, int O, MPtrs dWs, MPtrs dbs) {
+  linear_wgrad_body<LEAKY_IN>(gs, xs, N, K, O, dWs, dbs, blockIdx.x, blockIdx.y, blockIdx.z);
+}
 
 // dx[n][k] = (sum_o g[n][o] W[o][k]) * (LEAKY_OUT ? leaky'(pre[n][k]) : 1).  Workgroup = (row n, 64 columns k): the
 // 4 waves take interleaved o and are combined through LDS in fixed order.
 // NSUM > 0: the heads share the input (the pooled feature): ONE output, the sum over the NSUM heads in index order.
 template <bool LEAKY_OUT>
-__global__ __launch_bounds__(256) void linear_dgrad_kernel(CPtrs gs, CPtrs Ws, CPtrs pres, int N, int K, int O, MPtrs dxs,
-                                                           int nsum) {
-  __shared__ float red[4][64];
-  const int n = blockIdx.y;
+__device__ __forceinline__ void linear_dgrad_body(const CPtrs& gs, const CPtrs& Ws, const CPtrs& pres, int N, int K, int O,
+                                                  const MPtrs& dxs, int nsum, int bx, int n, int z, float (*red)[64]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int k = blockIdx.x * 64 + lane;
-  const int h0 = nsum > 0 ? 0 : blockIdx.z, h1 = nsum > 0 ? nsum : blockIdx.z + 1;
+  const int k = bx * 64 + lane;
+  const int h0 = nsum > 0 ? 0 : z, h1 = nsum > 0 ? nsum : z + 1;
   float s = 0.f;
   if (k < K) {
     for (int h = h0; h < h1; ++h) {
@@ -176,6 +178,24 @@ __global__ __launch_bounds__(256) void linear_dgrad_kernel(CPtrs gs, CPtrs Ws, C
     float v = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
     if (LEAKY_OUT) v *= pres.p[h0][(size_t)n * K + k] > 0.f ? 1.f : kLeaky;
     dxs.p[h0][(size_t)n * K + k] = v;
+  }
+}
+// One layer's weight gradient AND input gradient in one launch (they read the same g and are independent; each is a
+// few-microsecond launch of its own otherwise): blocks [0, nwb) are the weight-gradient grid (bx fastest, then o), the rest
+// the input-gradient grid (bx fastest, then n); blockIdx.z = head.  With nsum > 0 the input-gradient part runs for z = 0 only.
+template <bool LEAKY>
+__global__ __launch_bounds__(256) void linear_bwd_pair_kernel(CPtrs gs, CPtrs xs, CPtrs Ws, CPtrs pres, int N, int K, int O,
+                                                              MPtrs dWs, MPtrs dbs, MPtrs dxs, int nsum, int gxw, int nwb,
+                                                              int gxd) {
+  __shared__ float red[4][64];
+  const int b = blockIdx.x;
+  if (b < nwb) {
+    const int o = b / gxw;
+    linear_wgrad_body<LEAKY>(gs, xs, N, K, O, dWs, dbs, b - o * gxw, o, blockIdx.z);
+  } else {
+    if (nsum > 0 && blockIdx.z > 0) return;
+    const int r = b - nwb, n = r / gxd;
+    linear_dgrad_body<LEAKY>(gs, Ws, pres, N, K, O, dxs, nsum, r - n * gxd, n, blockIdx.z, red);
   }
 }
 
@@ -408,15 +428,26 @@ static int proj_heads_backward(int K, const float* const* dz, int dtype, int N, 
   DPOOL.p[0] = dpool;
   if (normalize) SPCL_LAUNCH(l2norm_bwd_kernel, dim3(cdiv(N, 4), 1, K), dim3(256), 0, st, O, DZ, N, out_dim, DOm);
   if (hid > 0) {
-    SPCL_LAUNCH(linear_wgrad_kernel<true>, dim3(cdiv(hid, 256), out_dim, K), dim3(256), 0, st, GO, PRE, N, hid, out_dim, DW2, DB2);
-    SPCL_LAUNCH(linear_dgrad_kernel<true>, dim3(cdiv(hid, 64), N, K), dim3(256), 0, st, GO, W2, PRE, N, hid, out_dim, DPREm, 0);
-    SPCL_LAUNCH(linear_wgrad_kernel<false>, dim3(cdiv(C, 256), hid, K), dim3(256), 0, st, DPRE, P, N, C, hid, DW1, DB1);
-    if (dfeat)
-      SPCL_LAUNCH(linear_dgrad_kernel<false>, dim3(cdiv(C, 64), N, 1), dim3(256), 0, st, DPRE, W1, CPtrs{}, N, C, hid, DPOOL, K);
+    {  // layer 2: dW2 / db2 and the hidden gradient (through the leaky ReLU) in one launch
+      const int gxw = cdiv(hid, 256), nwb = gxw * out_dim, gxd = cdiv(hid, 64);
+      SPCL_LAUNCH(linear_bwd_pair_kernel<true>, dim3(nwb + gxd * N, 1, K), dim3(256), 0, st, GO, PRE, W2, PRE, N, hid, out_dim,
+                  DW2, DB2, DPREm, 0, gxw, nwb, gxd);
+    }
+    if (dfeat) {  // layer 1: dW1 / db1 and the pooled feature's gradient (summed over the heads) in one launch
+      const int gxw = cdiv(C, 256), nwb = gxw * hid, gxd = cdiv(C, 64);
+      SPCL_LAUNCH(linear_bwd_pair_kernel<false>, dim3(nwb + gxd * N, 1, K), dim3(256), 0, st, DPRE, P, W1, CPtrs{}, N, C, hid,
+                  DW1, DB1, DPOOL, K, gxw, nwb, gxd);
+    } else {
+      SPCL_LAUNCH(linear_wgrad_kernel<false>, dim3(cdiv(C, 256), hid, K), dim3(256), 0, st, DPRE, P, N, C, hid, DW1, DB1);
+    }
   } else {
-    SPCL_LAUNCH(linear_wgrad_kernel<false>, dim3(cdiv(C, 256), out_dim, K), dim3(256), 0, st, GO, P, N, C, out_dim, DW1, DB1);
-    if (dfeat)
-      SPCL_LAUNCH(linear_dgrad_kernel<false>, dim3(cdiv(C, 64), N, 1), dim3(256), 0, st, GO, W1, CPtrs{}, N, C, out_dim, DPOOL, K);
+    if (dfeat) {
+      const int gxw = cdiv(C, 256), nwb = gxw * out_dim, gxd = cdiv(C, 64);
+      SPCL_LAUNCH(linear_bwd_pair_kernel<false>, dim3(nwb + gxd * N, 1, K), dim3(256), 0, st, GO, P, W1, CPtrs{}, N, C, out_dim,
+                  DW1, DB1, DPOOL, K, gxw, nwb, gxd);
+    } else {
+      SPCL_LAUNCH(linear_wgrad_kernel<false>, dim3(cdiv(C, 256), out_dim, K), dim3(256), 0, st, GO, P, N, C, out_dim, DW1, DB1);
+    }
   }
   if (dfeat) {
     const size_t total = (size_t)N * HW * Cs;

@@ -406,7 +406,8 @@ static WgradPlan wgrad_plan(int N, int H, int W, int CinK, int CoutS, int esize)
   const int nblk = p.nblk_ci * p.nblk_co;
   // exactly one resident "wave" of workgroups (LDS-limited residency x 256 CUs): measured optimum -- more workgroups
   // only add partial slabs and a tail, fewer leave CUs idle (tools/bench_kernels.py wgrad sweeps)
-  const size_t lds = 2 * wgrad_lds_bytes(p.MI, p.NJ, p.TH, esize);
+  static const int plan_dbuf = getenv("SPCL_WGRAD_DBUF") ? atoi(getenv("SPCL_WGRAD_DBUF")) : 1;
+  const size_t lds = (plan_dbuf ? 2 : 1) * wgrad_lds_bytes(p.MI, p.NJ, p.TH, esize);
   int per_cu = (int)((160 * 1024) / lds);
   if (per_cu > 4) per_cu = 4;
   if (per_cu < 1) per_cu = 1;
