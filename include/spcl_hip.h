@@ -65,6 +65,20 @@ int spcl_supcon_backward(const float* labels, const float* mask, int n, int d, f
                          float gamma, const float* ws_fwd, float* ws_bwd, const float* out_fwd,
                          const float* grad_out, float* dz1, float* dz2, void* stream);
 size_t spcl_supcon_bwd_workspace_bytes(int n, int d);
+/* K (1..4) losses of ONE shape in the launches of one -- the K meta-label hooks that semi_seg/hooks/creator.py:102-124
+ * puts on one feature, each with its own label vector and its own self-paced age parameter (hooks/infonce.py:133-141).
+ * Head h reads z1 + h z_stride and z2 + h z_stride ([n,d] f32 each), labels + h n (NULL: SimCLR for every head), uses
+ * gammas[h] (host array, read during the call), owns ws + h ws_stride floats (>= spcl_supcon_workspace_bytes(n,d) / 4)
+ * and writes out + 8 h.  Same arithmetic, per head, as spcl_supcon_forward / _backward (bit-identical results).  Only the
+ * training-size schedules (2n below the large-batch threshold; SPCL_EUNSUPPORTED otherwise) and no explicit mask.
+ * backward: grad_out[K] (device), dz1 / dz2 + h z_stride, ws_bwd + h wsb_stride floats. */
+int spcl_supcon_forward_heads(int K, const float* z1, const float* z2, size_t z_stride, const float* labels, int n,
+                              int d, float temperature, int sp_mode, const float* gammas, int correct_grad, float* ws,
+                              size_t ws_stride, float* out, void* stream);
+int spcl_supcon_backward_heads(int K, const float* labels, int n, int d, float temperature, int sp_mode,
+                               const float* gammas, const float* ws_fwd, size_t ws_stride, float* ws_bwd,
+                               size_t wsb_stride, const float* out_fwd, const float* grad_out, float* dz1, float* dz2,
+                               size_t z_stride, void* stream);
 /* lazily materialise the [2n,2n] hook taps (contrast_loss3.py:175-178,188): any pointer may be NULL */
 int spcl_supcon_materialize(const float* labels, const float* mask, int n, int d, float temperature, int sp_mode,
                             float gamma, const float* ws_fwd, float* sim_logits, float* sim_exp, float* pos_mask,

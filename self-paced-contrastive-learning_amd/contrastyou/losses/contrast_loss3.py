@@ -19,7 +19,7 @@ from torch import Tensor, nn
 
 from ... import functional as F_hip
 
-__all__ = ["SupConLoss1", "SelfPacedSupConLoss", "is_normalized", "exp_sim_temperature"]
+__all__ = ["SupConLoss1", "SelfPacedSupConLoss", "is_normalized", "exp_sim_temperature", "supcon_heads"]
 
 
 def is_normalized(feature: Tensor, dim=1) -> bool:
@@ -166,3 +166,55 @@ class SelfPacedSupConLoss(_SupConBase):
     @property
     def age_param(self):  # :220-222
         return self.__gamma
+
+
+_HEADS_MAX_ROWS = 1024  # 2n from which csrc/supcon.hip switches to the large-batch schedule (one head per call there)
+
+
+def supcon_heads(criteria, projections, targets):
+    """The K losses ``criteria[k](*torch.chunk(projections[k], 2), target=targets[k])`` in the launches of ONE
+    (``spcl_supcon_forward_heads``): the K meta-label hooks of ``semi_seg/hooks/creator.py:102-124`` on one feature, each
+    with its own label vector and its own age parameter.  Every criterion ends up in exactly the state a call of its own
+    would leave (result block, workspace for the taps, ``downgrade_ratio``).  Returns the list of K 0-dim losses, or
+    ``None`` when the group is not batchable: mixed classes / temperatures / weight rules, ``exclude_other_pos``,
+    fewer than 2 or more than 4 heads, different shapes, or the large-batch size -- the caller then calls one by one."""
+    K = len(criteria)
+    if not 2 <= K <= 4 or len(projections) != K or len(targets) != K:
+        return None
+    c0 = criteria[0]
+    if any(type(c) is not type(c0) or c._t != c0._t for c in criteria):
+        return None
+    if isinstance(c0, SelfPacedSupConLoss):
+        if any(c._weight_update != c0._weight_update or c._correct_grad != c0._correct_grad for c in criteria):
+            return None
+        mode = F_hip.SP_HARD if c0._weight_update == "hard" else F_hip.SP_SOFT
+        gammas, correct = [c.age_param for c in criteria], c0._correct_grad
+    elif type(c0) is SupConLoss1:
+        if any(c._exclude_pos for c in criteria):
+            return None
+        mode, gammas, correct = F_hip.SP_NONE, [1e6] * K, False
+    else:
+        return None
+    z0 = projections[0]
+    if (z0.dim() != 2 or z0.shape[0] % 2 or z0.shape[0] >= _HEADS_MAX_ROWS or z0.shape[1] > 256
+            or any(z.shape != z0.shape for z in projections)):
+        return None
+    n = z0.shape[0] // 2
+    labels = []
+    for tgt in targets:
+        if tgt is None:
+            return None
+        lt = tgt if isinstance(tgt, Tensor) else torch.tensor(list(tgt), dtype=torch.float32, device=z0.device)
+        lt = lt.to(device=z0.device, dtype=torch.float32)
+        assert lt.numel() == n, (lt.shape, n)  # contrast_loss3.py:48-54 / :133-139
+        labels.append(lt.reshape(n))
+    labels_t = torch.stack(labels)
+    states = [F_hip.SupConState() for _ in range(K)]
+    losses = F_hip.supcon_loss_heads(list(projections), labels_t, t=c0._t, sp_mode=mode, gammas=gammas,
+                                     correct_grad=correct, states=states)
+    for c, st in zip(criteria, states):
+        c._state, c._taps_cache, c._host_out = st, None, None
+    for c in criteria:
+        if c.sync_checks:
+            c.check()
+    return list(losses.unbind(0))

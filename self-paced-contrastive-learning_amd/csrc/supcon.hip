@@ -95,17 +95,35 @@ struct SupconArgs {
   unsigned long long* stamps;  // debug (SPCL_SUPCON_STAMPS=1): s_memtime ticks of wave 0 per phase, else null
   int ns;  // n-tile sub-splits of a 64-column tile (1, 2 or 4): blockIdx.y = column split * ns + sub-split
   int dbg = 0;  // experiments only (SPCL_SUPCON_DBG): 1 no logit stores, 2 no exponentials, 4 no MFMAs
+  // K losses of one shape in the launches of one (spcl_supcon_forward_heads; small / mid schedules): head h reads
+  // z + h hs_z, labels + h hs_lab, uses gk[h] and owns workspace + h hs_ws, out + 8 h.  Single-head launches: strides 0.
+  long hs_ws = 0, hs_z = 0;
+  int hs_lab = 0;
+  float gk[4] = {0.f, 0.f, 0.f, 0.f}, igk[4] = {0.f, 0.f, 0.f, 0.f};
 };
+__device__ __forceinline__ SupconArgs supcon_head(SupconArgs a, int h) {
+  const size_t o = (size_t)h * a.hs_ws;
+  a.P += o; a.rn2 += o; a.logD += o; a.cnt += o; a.W += o; a.partA += o; a.partB += o;
+  if (a.labels != nullptr) a.labels += (size_t)h * a.hs_lab;
+  a.gamma = a.gk[h];
+  a.inv_gamma = a.igk[h];
+  return a;
+}
 
 // ------------------------------------------------------------------------------------------------ prep
 __global__ __launch_bounds__(256) void supcon_prep_kernel(const float* __restrict__ z1, const float* __restrict__ z2,
                                                           int n, int d, int N2p, int DP, float* __restrict__ P,
                                                           float* __restrict__ rn2, bf16_t* __restrict__ Ph,
                                                           bf16_t* __restrict__ Pm, const float* __restrict__ labels,
-                                                          float* __restrict__ cls) {
+                                                          float* __restrict__ cls, long hs_z, long hs_ws, int hs_lab) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= N2p) return;
+  {  // head blockIdx.z of a batched launch (strides 0 otherwise; the bf16 splits belong to the large-batch path: one head)
+    const size_t h = blockIdx.z;
+    z1 += h * hs_z; z2 += h * hs_z; P += h * hs_ws; rn2 += h * hs_ws;
+    if (labels != nullptr) labels += h * hs_lab;
+  }
   const float* src = row < n ? z1 + (size_t)row * d : (row < 2 * n ? z2 + (size_t)(row - n) * d : nullptr);
   float s = 0.f;
   for (int k = lane; k < DP; k += 64) {
@@ -277,7 +295,8 @@ __device__ __forceinline__ float sp_weight(int sp_mode, float ell, float gamma, 
 
 // ------------------------------------------------------------------------------------------------ sweeps
 template <int DP, int MODE>
-__global__ __launch_bounds__(256) void supcon_sweep_kernel(SupconArgs a) {
+__global__ __launch_bounds__(256) void supcon_sweep_kernel(SupconArgs a_) {
+  const SupconArgs a = supcon_head(a_, blockIdx.z);
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ float red[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -342,6 +361,14 @@ __global__ __launch_bounds__(1024) void supcon_small_kernel(const float* __restr
                                                            float* __restrict__ cnt_out, float* __restrict__ W_out,
                                                            float* __restrict__ rowloss_out, int correct_grad,
                                                            float* __restrict__ out, float* __restrict__ dz_unit) {
+  {  // head blockIdx.x of a batched launch (strides 0 otherwise)
+    const size_t h = blockIdx.x, o = h * a.hs_ws;
+    z1 += h * a.hs_z; z2 += h * a.hs_z;
+    P_out += o; rn2_out += o; logD_out += o; cnt_out += o; W_out += o; rowloss_out += o;
+    out += 8 * h;
+    if (dz_unit != nullptr) dz_unit += o;
+    a = supcon_head(a, (int)h);
+  }
   // 16 waves on one CU (four per SIMD, so that the dependent exact-f32 MFMA chains of one wave hide behind the others):
   // wave = (row block rb of 16 rows, column quarter cq).  Forward: the wave owns the 16 x 16 tile S[rb][cq]; row sums
   // are exchanged through LDS in fixed order.  Backward: the wave owns dP[rb][64-feature slice cq] and needs the
@@ -561,9 +588,10 @@ __global__ __launch_bounds__(1024) void supcon_small_kernel(const float* __restr
 // dz = grad_out * (dLoss/dP for a unit gradient) of the training-size path
 __global__ __launch_bounds__(256) void supcon_scale_kernel(const float* __restrict__ dz_unit, int n, int d, int DP,
                                                           const float* __restrict__ grad_out, float* __restrict__ dz1,
-                                                          float* __restrict__ dz2) {
+                                                          float* __restrict__ dz2, long hs_ws, long hs_z) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= 2 * n * d) return;
+  dz_unit += (size_t)blockIdx.y * hs_ws; grad_out += blockIdx.y; dz1 += (size_t)blockIdx.y * hs_z; dz2 += (size_t)blockIdx.y * hs_z;
   const int row = idx / d, k = idx - row * d;
   const float v = dz_unit[(size_t)row * DP + k] * grad_out[0];
   if (row < n) dz1[(size_t)row * d + k] = v;
@@ -1369,7 +1397,14 @@ __global__ __launch_bounds__(1024) void supcon_fin_kernel(const float* __restric
                                                           const float* __restrict__ partB, int CS, int N2, int N2p,
                                                           float* __restrict__ outA, float* __restrict__ outB,
                                                           const float* __restrict__ cnt, const float* __restrict__ rn2,
-                                                          int correct_grad, float* __restrict__ out) {
+                                                          int correct_grad, float* __restrict__ out, long hs_ws) {
+  {  // head blockIdx.x of a batched launch (stride 0 otherwise)
+    const size_t o = (size_t)blockIdx.x * hs_ws;
+    partA += o; partB += o; outA += o; outB += o;
+    if (cnt != nullptr) cnt += o;
+    if (rn2 != nullptr) rn2 += o;
+    out += 8 * blockIdx.x;
+  }
   __shared__ double red[3][16];
   __shared__ float redm[16];
   double s_loss = 0.0, s_w = 0.0, s_c = 0.0;
@@ -1435,8 +1470,11 @@ __global__ __launch_bounds__(1024) void supcon_fin_kernel(const float* __restric
 
 // ------------------------------------------------------------------------------------------------ backward
 template <int DP>
-__global__ __launch_bounds__(256) void supcon_bwd_kernel(SupconArgs a, const float* __restrict__ out_fwd,
-                                                         float* __restrict__ dPpart /* [CS][N2p][DP] */) {
+__global__ __launch_bounds__(256) void supcon_bwd_kernel(SupconArgs a_, const float* __restrict__ out_fwd,
+                                                         float* __restrict__ dPpart /* [CS][N2p][DP] */, long hs_wsb) {
+  const SupconArgs a = supcon_head(a_, blockIdx.z);
+  out_fwd += 8 * blockIdx.z;
+  dPpart += (size_t)blockIdx.z * hs_wsb;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ float red[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1650,10 +1688,12 @@ __global__ __launch_bounds__(256) void supcon_bwd_big_kernel(SupconArgs a, const
 __global__ __launch_bounds__(256) void supcon_bwd_fin_kernel(const float* __restrict__ dPpart, int CS, int n, int d,
                                                              int N2p, int DP, float t,
                                                              const float* __restrict__ grad_out,
-                                                             float* __restrict__ dz1, float* __restrict__ dz2) {
+                                                             float* __restrict__ dz1, float* __restrict__ dz2,
+                                                             long hs_wsb, long hs_z) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)2 * n * d;
   if (idx >= total) return;
+  dPpart += (size_t)blockIdx.y * hs_wsb; grad_out += blockIdx.y; dz1 += (size_t)blockIdx.y * hs_z; dz2 += (size_t)blockIdx.y * hs_z;
   const int row = (int)(idx / d), k = (int)(idx % d);
   float s = 0.f;
   for (int c = 0; c < CS; ++c) s += dPpart[((size_t)c * N2p + row) * DP + k];
@@ -1967,6 +2007,8 @@ static SupconArgs make_args(const SupconLayout& L, const float* ws, const float*
   a.t = t;
   a.gamma = gamma;
   a.inv_gamma = (float)(1.0 / (double)gamma);
+  a.gk[0] = a.gamma;
+  a.igk[0] = a.inv_gamma;
   a.sp_mode = sp_mode;
   static const int env_dbg = getenv("SPCL_SUPCON_DBG") ? atoi(getenv("SPCL_SUPCON_DBG")) : 0;
   a.dbg = env_dbg;
@@ -1975,16 +2017,16 @@ static SupconArgs make_args(const SupconLayout& L, const float* ws, const float*
 
 template <int DP>
 static int launch_forward(const SupconLayout& L, SupconArgs a, float* ws, int correct_grad, float* out,
-                          hipStream_t st) {
-  dim3 grid(L.N2p / 64, L.CS);
+                          hipStream_t st, int K = 1) {
+  dim3 grid(L.N2p / 64, L.CS, K);
   size_t lds = (size_t)64 * DP * sizeof(float);
   SPCL_LAUNCH((supcon_sweep_kernel<DP, 0>), grid, dim3(256), lds, st, a);
-  SPCL_LAUNCH((supcon_fin_kernel<0>), dim3(1), dim3(1024), 0, st, a.partA, a.partB, L.CS, L.N2, L.N2p,
-                     ws + L.off_logD, ws + L.off_c, (const float*)nullptr, (const float*)nullptr, 0, out);
+  SPCL_LAUNCH((supcon_fin_kernel<0>), dim3(K), dim3(1024), 0, st, a.partA, a.partB, L.CS, L.N2, L.N2p,
+                     ws + L.off_logD, ws + L.off_c, (const float*)nullptr, (const float*)nullptr, 0, out, a.hs_ws);
   SPCL_LAUNCH((supcon_sweep_kernel<DP, 1>), grid, dim3(256), lds, st, a);
-  SPCL_LAUNCH((supcon_fin_kernel<1>), dim3(1), dim3(1024), 0, st, a.partA, a.partB, L.CS, L.N2, L.N2p,
+  SPCL_LAUNCH((supcon_fin_kernel<1>), dim3(K), dim3(1024), 0, st, a.partA, a.partB, L.CS, L.N2, L.N2p,
                      ws + L.off_rowloss, ws + L.off_W, (const float*)(ws + L.off_c), (const float*)(ws + L.off_rn2),
-                     correct_grad, out);
+                     correct_grad, out, a.hs_ws);
   return 0;
 }
 
@@ -2154,7 +2196,7 @@ static int launch_forward_big(const SupconLayout& L, SupconArgs a, float* ws, in
                        ws + L.off_logD, ws + L.off_c, a.partA, a.partB);
   SPCL_LAUNCH((supcon_fin_kernel<1>), dim3(1), dim3(1024), 0, st, a.partA, a.partB, 1, L.N2, L.N2p,
                      ws + L.off_rowloss, ws + L.off_W, (const float*)(ws + L.off_c), (const float*)(ws + L.off_rn2),
-                     correct_grad, out);
+                     correct_grad, out, 0L);
   return 0;
 }
 
@@ -2175,6 +2217,60 @@ extern "C" size_t spcl_supcon_bwd_workspace_bytes(int n, int d) {
          (L.big ? (size_t)4 * L.N2p * sizeof(float) + (size_t)2 * L.N2p * L.DP * sizeof(bf16_t) : 0);
 }
 
+// K = 1: the single-head entry (strides 0).  K > 1: heads of one shape (small / mid schedules only).
+static int supcon_forward_impl(int K, const float* z1, const float* z2, long z_stride, const float* labels,
+                               const float* mask, int n, int d, float temperature, int sp_mode, const float* gammas,
+                               int correct_grad, float* ws, long ws_stride, float* out, hipStream_t st, const char* who) {
+  SupconLayout L = supcon_layout(n, d);
+  SupconArgs a = make_args(L, ws, labels, mask, temperature, sp_mode, gammas[0]);
+  if (K > 1) {
+    a.hs_ws = ws_stride; a.hs_z = z_stride; a.hs_lab = n;
+    for (int h = 0; h < K; ++h) {
+      a.gk[h] = gammas[h];
+      a.igk[h] = (float)(1.0 / (double)gammas[h]);
+    }
+  }
+  if (supcon_use_small(L)) {
+    const size_t lds = ((size_t)64 * L.DP + 4 * 64 + 2 * 4 * 64 + 4 * 4 * 4 * 64) * sizeof(float) + 16 * sizeof(double);
+#define SPCL_SMALL(DP_)                                                                                            \
+  SPCL_LAUNCH((supcon_small_kernel<DP_>), dim3(K), dim3(1024), lds, st, z1, z2, d, a, ws + L.off_P, ws + L.off_rn2,  \
+              ws + L.off_logD, ws + L.off_c, ws + L.off_W, ws + L.off_rowloss, correct_grad, out, ws + L.off_dz)
+    if (L.DP == 64) SPCL_SMALL(64);
+    else if (L.DP == 128) SPCL_SMALL(128);
+    else SPCL_SMALL(256);
+#undef SPCL_SMALL
+    SPCL_LAUNCH_CHECK(who);
+    return SPCL_OK;
+  }
+  const bool big = supcon_use_big(L, mask);
+  if (K > 1 && L.big) {
+    set_error("%s: 2n = %d is a large-batch shape: one head per call", who, L.N2);
+    return SPCL_EUNSUPPORTED;
+  }
+  if (big && L.DP <= 128) {
+    const int rows = 256 / (L.DP / 8);
+    if (L.DP == 64)
+      SPCL_LAUNCH((supcon_prep_big_kernel<64>), dim3(L.N2p / rows), dim3(256), 0, st, z1, z2, n, d, ws + L.off_P,
+                  ws + L.off_rn2, (bf16_t*)(ws + L.off_Ph), (bf16_t*)(ws + L.off_Pm), labels, ws + L.off_cls);
+    else
+      SPCL_LAUNCH((supcon_prep_big_kernel<128>), dim3(L.N2p / rows), dim3(256), 0, st, z1, z2, n, d, ws + L.off_P,
+                  ws + L.off_rn2, (bf16_t*)(ws + L.off_Ph), (bf16_t*)(ws + L.off_Pm), labels, ws + L.off_cls);
+  } else
+  SPCL_LAUNCH(supcon_prep_kernel, dim3(L.N2p / 4, 1, K), dim3(256), 0, st, z1, z2, n, d, L.N2p, L.DP,
+                     ws + L.off_P, ws + L.off_rn2, big ? (bf16_t*)(ws + L.off_Ph) : (bf16_t*)nullptr,
+                     big ? (bf16_t*)(ws + L.off_Pm) : (bf16_t*)nullptr, labels, big ? ws + L.off_cls : (float*)nullptr,
+                     a.hs_z, a.hs_ws, a.hs_lab);
+  if (big) {
+    if (L.DP == 64) launch_forward_big<64>(L, a, ws, correct_grad, out, st);
+    else if (L.DP == 128) launch_forward_big<128>(L, a, ws, correct_grad, out, st);
+    else launch_forward_big<256>(L, a, ws, correct_grad, out, st);
+  } else if (L.DP == 64) launch_forward<64>(L, a, ws, correct_grad, out, st, K);
+  else if (L.DP == 128) launch_forward<128>(L, a, ws, correct_grad, out, st, K);
+  else launch_forward<256>(L, a, ws, correct_grad, out, st, K);
+  SPCL_LAUNCH_CHECK(who);
+  return SPCL_OK;
+}
+
 extern "C" int spcl_supcon_forward(const float* z1, const float* z2, const float* labels, const float* mask, int n,
                                    int d, float temperature, int sp_mode, float gamma, int correct_grad, float* ws,
                                    float* out, void* stream) {
@@ -2186,44 +2282,32 @@ extern "C" int spcl_supcon_forward(const float* z1, const float* z2, const float
   }
   SPCL_CHECK_ARG(sp_mode >= 0 && sp_mode <= 2, "supcon_forward: sp_mode %d", sp_mode);
   SPCL_CHECK_ARG(temperature > 0.f, "supcon_forward: temperature must be > 0");
-  hipStream_t st = (hipStream_t)stream;
-  SupconLayout L = supcon_layout(n, d);
-  SupconArgs a = make_args(L, ws, labels, mask, temperature, sp_mode, gamma);
-  if (supcon_use_small(L)) {
-    const size_t lds = ((size_t)64 * L.DP + 4 * 64 + 2 * 4 * 64 + 4 * 4 * 4 * 64) * sizeof(float) + 16 * sizeof(double);
-#define SPCL_SMALL(DP_)                                                                                            \
-  SPCL_LAUNCH((supcon_small_kernel<DP_>), dim3(1), dim3(1024), lds, st, z1, z2, d, a, ws + L.off_P, ws + L.off_rn2,  \
-              ws + L.off_logD, ws + L.off_c, ws + L.off_W, ws + L.off_rowloss, correct_grad, out, ws + L.off_dz)
-    if (L.DP == 64) SPCL_SMALL(64);
-    else if (L.DP == 128) SPCL_SMALL(128);
-    else SPCL_SMALL(256);
-#undef SPCL_SMALL
-    SPCL_LAUNCH_CHECK("supcon_forward");
-    return SPCL_OK;
-  }
-  const bool big = supcon_use_big(L, mask);
-  if (big && L.DP <= 128) {
-    const int rows = 256 / (L.DP / 8);
-    if (L.DP == 64)
-      SPCL_LAUNCH((supcon_prep_big_kernel<64>), dim3(L.N2p / rows), dim3(256), 0, st, z1, z2, n, d, ws + L.off_P,
-                  ws + L.off_rn2, (bf16_t*)(ws + L.off_Ph), (bf16_t*)(ws + L.off_Pm), labels, ws + L.off_cls);
-    else
-      SPCL_LAUNCH((supcon_prep_big_kernel<128>), dim3(L.N2p / rows), dim3(256), 0, st, z1, z2, n, d, ws + L.off_P,
-                  ws + L.off_rn2, (bf16_t*)(ws + L.off_Ph), (bf16_t*)(ws + L.off_Pm), labels, ws + L.off_cls);
-  } else
-  SPCL_LAUNCH(supcon_prep_kernel, dim3(L.N2p / 4), dim3(256), 0, st, z1, z2, n, d, L.N2p, L.DP,
-                     ws + L.off_P, ws + L.off_rn2, big ? (bf16_t*)(ws + L.off_Ph) : (bf16_t*)nullptr,
-                     big ? (bf16_t*)(ws + L.off_Pm) : (bf16_t*)nullptr, labels, big ? ws + L.off_cls : (float*)nullptr);
-  if (big) {
-    if (L.DP == 64) launch_forward_big<64>(L, a, ws, correct_grad, out, st);
-    else if (L.DP == 128) launch_forward_big<128>(L, a, ws, correct_grad, out, st);
-    else launch_forward_big<256>(L, a, ws, correct_grad, out, st);
-  } else if (L.DP == 64) launch_forward<64>(L, a, ws, correct_grad, out, st);
-  else if (L.DP == 128) launch_forward<128>(L, a, ws, correct_grad, out, st);
-  else launch_forward<256>(L, a, ws, correct_grad, out, st);
-  SPCL_LAUNCH_CHECK("supcon_forward");
-  return SPCL_OK;
+  return supcon_forward_impl(1, z1, z2, 0, labels, mask, n, d, temperature, sp_mode, &gamma, correct_grad, ws, 0, out,
+                             (hipStream_t)stream, "supcon_forward");
 }
+
+extern "C" int spcl_supcon_forward_heads(int K, const float* z1, const float* z2, size_t z_stride, const float* labels,
+                                         int n, int d, float temperature, int sp_mode, const float* gammas,
+                                         int correct_grad, float* ws, size_t ws_stride, float* out, void* stream) {
+  SPCL_CHECK_ARG(z1 && z2 && ws && out && gammas, "supcon_forward_heads: null pointer");
+  SPCL_CHECK_ARG(K >= 1 && K <= 4, "supcon_forward_heads: %d heads (1..4)", K);
+  SPCL_CHECK_ARG(n > 0 && d > 0, "supcon_forward_heads: bad shape n=%d d=%d", n, d);
+  if (d > 256) {
+    set_error("supcon_forward_heads: proj dim %d > 256 unsupported", d);
+    return SPCL_EUNSUPPORTED;
+  }
+  SPCL_CHECK_ARG(sp_mode >= 0 && sp_mode <= 2, "supcon_forward_heads: sp_mode %d", sp_mode);
+  SPCL_CHECK_ARG(temperature > 0.f, "supcon_forward_heads: temperature must be > 0");
+  SPCL_CHECK_ARG(K == 1 || (z_stride >= (size_t)n * d && ws_stride * sizeof(float) >= spcl_supcon_workspace_bytes(n, d)),
+                 "supcon_forward_heads: head strides smaller than a head");
+  return supcon_forward_impl(K, z1, z2, (long)z_stride, labels, nullptr, n, d, temperature, sp_mode, gammas, correct_grad,
+                             ws, (long)ws_stride, out, (hipStream_t)stream, "supcon_forward_heads");
+}
+
+static int supcon_backward_impl(int K, const float* labels, const float* mask, int n, int d, float temperature,
+                                int sp_mode, const float* gammas, const float* ws_fwd, long ws_stride, float* ws_bwd,
+                                long wsb_stride, const float* out_fwd, const float* grad_out, float* dz1, float* dz2,
+                                long z_stride, hipStream_t st, const char* who);
 
 extern "C" int spcl_supcon_backward(const float* labels, const float* mask, int n, int d, float temperature,
                                     int sp_mode, float gamma, const float* ws_fwd, float* ws_bwd,
@@ -2231,14 +2315,48 @@ extern "C" int spcl_supcon_backward(const float* labels, const float* mask, int 
                                     void* stream) {
   SPCL_CHECK_ARG(ws_fwd && ws_bwd && out_fwd && grad_out && dz1 && dz2, "supcon_backward: null pointer");
   SPCL_CHECK_ARG(n > 0 && d > 0 && d <= 256, "supcon_backward: bad shape n=%d d=%d", n, d);
-  hipStream_t st = (hipStream_t)stream;
+  return supcon_backward_impl(1, labels, mask, n, d, temperature, sp_mode, &gamma, ws_fwd, 0, ws_bwd, 0, out_fwd, grad_out,
+                              dz1, dz2, 0, (hipStream_t)stream, "supcon_backward");
+}
+
+extern "C" int spcl_supcon_backward_heads(int K, const float* labels, int n, int d, float temperature, int sp_mode,
+                                          const float* gammas, const float* ws_fwd, size_t ws_stride, float* ws_bwd,
+                                          size_t wsb_stride, const float* out_fwd, const float* grad_out, float* dz1,
+                                          float* dz2, size_t z_stride, void* stream) {
+  SPCL_CHECK_ARG(ws_fwd && ws_bwd && out_fwd && grad_out && dz1 && dz2 && gammas, "supcon_backward_heads: null pointer");
+  SPCL_CHECK_ARG(K >= 1 && K <= 4, "supcon_backward_heads: %d heads (1..4)", K);
+  SPCL_CHECK_ARG(n > 0 && d > 0 && d <= 256, "supcon_backward_heads: bad shape n=%d d=%d", n, d);
+  SPCL_CHECK_ARG(K == 1 || (z_stride >= (size_t)n * d && ws_stride * sizeof(float) >= spcl_supcon_workspace_bytes(n, d) &&
+                            wsb_stride * sizeof(float) >= spcl_supcon_bwd_workspace_bytes(n, d)),
+                 "supcon_backward_heads: head strides smaller than a head");
+  return supcon_backward_impl(K, labels, nullptr, n, d, temperature, sp_mode, gammas, ws_fwd, (long)ws_stride, ws_bwd,
+                              (long)wsb_stride, out_fwd, grad_out, dz1, dz2, (long)z_stride, (hipStream_t)stream,
+                              "supcon_backward_heads");
+}
+
+static int supcon_backward_impl(int K, const float* labels, const float* mask, int n, int d, float temperature,
+                                int sp_mode, const float* gammas, const float* ws_fwd, long ws_stride, float* ws_bwd,
+                                long wsb_stride, const float* out_fwd, const float* grad_out, float* dz1, float* dz2,
+                                long z_stride, hipStream_t st, const char* who) {
+  const float gamma = gammas[0];
   SupconLayout L = supcon_layout(n, d);
   SupconArgs a = make_args(L, ws_fwd, labels, mask, temperature, sp_mode, gamma);
+  if (K > 1) {
+    if (L.big) {
+      set_error("%s: 2n = %d is a large-batch shape: one head per call", who, L.N2);
+      return SPCL_EUNSUPPORTED;
+    }
+    a.hs_ws = ws_stride; a.hs_z = z_stride; a.hs_lab = n;
+    for (int h = 0; h < K; ++h) {
+      a.gk[h] = gammas[h];
+      a.igk[h] = (float)(1.0 / (double)gammas[h]);
+    }
+  }
   if (supcon_use_small(L)) {  // the forward left dLoss/dP for a unit gradient in its workspace
     const int total = 2 * n * d;
-    SPCL_LAUNCH(supcon_scale_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, ws_fwd + L.off_dz, n, d, L.DP, grad_out,
-                       dz1, dz2);
-    SPCL_LAUNCH_CHECK("supcon_backward");
+    SPCL_LAUNCH(supcon_scale_kernel, dim3(cdiv(total, 256), K), dim3(256), 0, st, ws_fwd + L.off_dz, n, d, L.DP, grad_out,
+                       dz1, dz2, a.hs_ws, a.hs_z);
+    SPCL_LAUNCH_CHECK(who);
     return SPCL_OK;
   }
   int nsplit = L.CS;
@@ -2305,16 +2423,17 @@ extern "C" int spcl_supcon_backward(const float* labels, const float* mask, int 
     else SPCL_LAUNCH((supcon_bwd_big_kernel<256>), grid, dim3(256), lds, st, a, (const bf16_t*)PhT, (const bf16_t*)PmT, Lmat, out_fwd, ws_bwd);
     nsplit = L.CSB;
   } else {
-    dim3 grid(L.N2p / 64, L.CS);
+    dim3 grid(L.N2p / 64, L.CS, K);
     size_t lds = (size_t)64 * L.DP * sizeof(float);
-    if (L.DP == 64) SPCL_LAUNCH((supcon_bwd_kernel<64>), grid, dim3(256), lds, st, a, out_fwd, ws_bwd);
-    else if (L.DP == 128) SPCL_LAUNCH((supcon_bwd_kernel<128>), grid, dim3(256), lds, st, a, out_fwd, ws_bwd);
-    else SPCL_LAUNCH((supcon_bwd_kernel<256>), grid, dim3(256), lds, st, a, out_fwd, ws_bwd);
+    if (L.DP == 64) SPCL_LAUNCH((supcon_bwd_kernel<64>), grid, dim3(256), lds, st, a, out_fwd, ws_bwd, wsb_stride);
+    else if (L.DP == 128) SPCL_LAUNCH((supcon_bwd_kernel<128>), grid, dim3(256), lds, st, a, out_fwd, ws_bwd, wsb_stride);
+    else SPCL_LAUNCH((supcon_bwd_kernel<256>), grid, dim3(256), lds, st, a, out_fwd, ws_bwd, wsb_stride);
   }
   size_t total = (size_t)2 * n * d;
-  SPCL_LAUNCH(supcon_bwd_fin_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                     (const float*)ws_bwd, nsplit, n, d, L.N2p, L.DP, temperature, grad_out, dz1, dz2);
-  SPCL_LAUNCH_CHECK("supcon_backward");
+  SPCL_LAUNCH(supcon_bwd_fin_kernel, dim3((unsigned)((total + 255) / 256), K), dim3(256), 0, st,
+                     (const float*)ws_bwd, nsplit, n, d, L.N2p, L.DP, temperature, grad_out, dz1, dz2, wsb_stride,
+                     a.hs_z);
+  SPCL_LAUNCH_CHECK(who);
   return SPCL_OK;
 }
 

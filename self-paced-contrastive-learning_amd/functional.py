@@ -96,6 +96,71 @@ def supcon_loss(z1, z2, labels=None, mask=None, *, t=0.07, sp_mode=SP_NONE, gamm
     return _SupConFn.apply(z1, z2, labels, mask, float(t), int(sp_mode), float(gamma), bool(correct_grad), state)
 
 
+class _SupConHeadsFn(torch.autograd.Function):
+    """K (2..4) losses of one shape in the launches of one (spcl_supcon_forward_heads / _backward_heads): the K meta-label
+    hooks on one feature, each with its own labels and age parameter.  Inputs after the fixed ones: the K stacked
+    [2n, d] projections; output: a [K] tensor of losses.  Per head the arithmetic (and the workspace / result block the
+    ``states`` receive) is exactly that of ``_SupConFn``."""
+
+    @staticmethod
+    def forward(ctx, labels, t, sp_mode, gammas, correct_grad, states, *zs):
+        K = len(zs)
+        _n.require_gpu(*zs)
+        n2, d = zs[0].shape
+        assert n2 % 2 == 0 and all(z.shape == zs[0].shape for z in zs), [tuple(z.shape) for z in zs]
+        n = n2 // 2
+        dev = zs[0].device
+        step = n2 * d * 4
+        if all(z.dtype == torch.float32 and z.is_contiguous() and z.data_ptr() == zs[0].data_ptr() + k * step
+               for k, z in enumerate(zs)):
+            zall = zs[0].detach()  # the batched projection wrote its heads back to back: no copy
+        else:
+            zall = torch.stack([z.detach().float() for z in zs])
+        nbytes = _n.call("spcl_supcon_workspace_bytes", n, d)
+        if nbytes == 0:
+            raise RuntimeError(f"supcon: unsupported shape n={n} d={d} (d must be <= 256)")
+        ws_stride = (nbytes // 4 + 63) // 64 * 64
+        ws = torch.empty(K * ws_stride, dtype=torch.float32, device=dev)
+        out = torch.empty(K, 8, dtype=torch.float32, device=dev)
+        gam = (c_float * K)(*[float(g) for g in gammas])
+        base = zall.data_ptr()
+        _n.call("spcl_supcon_forward_heads", K, base, base + n * d * 4, n2 * d, _n.ptr(labels), n, d, c_float(t), sp_mode, gam,
+                int(bool(correct_grad)), _n.ptr(ws), ws_stride, _n.ptr(out), _n.stream())
+        for k, st in enumerate(states):
+            st.n, st.d, st.t, st.sp_mode, st.gamma = n, d, t, sp_mode, float(gammas[k])
+            st.labels, st.mask = (labels[k] if labels is not None else None), None
+            st.ws, st.out = ws[k * ws_stride:(k + 1) * ws_stride], out[k]
+        ctx.keep = (labels, ws, out, zall)
+        ctx.meta = (K, n, d, t, sp_mode, tuple(float(g) for g in gammas), ws_stride, [z.dtype for z in zs])
+        return out[:, 0].clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        K, n, d, t, sp_mode, gammas, ws_stride, dtypes = ctx.meta
+        labels, ws, out, _ = ctx.keep
+        dev = ws.device
+        dz = torch.empty(K, 2 * n, d, dtype=torch.float32, device=dev)
+        wsb_stride = (_n.call("spcl_supcon_bwd_workspace_bytes", n, d) // 4 + 63) // 64 * 64
+        wsb = torch.empty(K * wsb_stride, dtype=torch.float32, device=dev)
+        go = grad_out.detach().reshape(K).float().contiguous()
+        gam = (c_float * K)(*gammas)
+        base = dz.data_ptr()
+        _n.call("spcl_supcon_backward_heads", K, _n.ptr(labels), n, d, c_float(t), sp_mode, gam, _n.ptr(ws), ws_stride,
+                _n.ptr(wsb), wsb_stride, _n.ptr(out), _n.ptr(go), base, base + n * d * 4, 2 * n * d, _n.stream())
+        return (None, None, None, None, None, None) + tuple(dz[k].to(dtypes[k]) for k in range(K))
+
+
+def supcon_loss_heads(zs, labels=None, *, t=0.07, sp_mode=SP_NONE, gammas=None, correct_grad=False, states=None):
+    """[K] losses of the K stacked [2n, d] projections ``zs`` (2 <= K <= 4); ``labels``: [K, n] float tensor or None;
+    ``gammas``: K floats; ``states``: K SupConState objects that receive each head's device-side statistics."""
+    K = len(zs)
+    if states is None:
+        states = [SupConState() for _ in range(K)]
+    if gammas is None:
+        gammas = [1e6] * K
+    return _SupConHeadsFn.apply(labels, float(t), int(sp_mode), tuple(gammas), bool(correct_grad), states, *zs)
+
+
 class _SupConXposFn(torch.autograd.Function):
     """SupConLoss1(exclude_other_pos=True), contrast_loss3.py:97-100 (csrc/supcon_xpos.hip)"""
 
@@ -257,7 +322,7 @@ class _ProjectorHeadsFn(torch.autograd.Function):
         pooled = torch.empty(N, C, dtype=torch.float32, device=dev)
         pre = torch.empty(K, N, hid, dtype=torch.float32, device=dev)
         o = torch.empty(K, N, out_dim, dtype=torch.float32, device=dev)
-        z = [torch.empty(N, out_dim, dtype=torch.float32, device=dev) for _ in range(K)]  # separate: handed to autograd
+        z = list(torch.empty(K, N, out_dim, dtype=torch.float32, device=dev).unbind(0))  # back to back: the batched loss reads them in place
         col = lambda i: _n.ptr_array([c[i] for c in cont])  # noqa: E731
         _n.call("spcl_proj_heads_forward", K, _n.ptr(x), _n.dtype_code(x.dtype), N, H * W, C, cs, col(0), col(1), col(2),
                 col(3), hid, out_dim, int(bool(normalize)), _n.ptr(pooled), _n.ptr_array(list(pre)), _n.ptr_array(list(o)),

@@ -52,6 +52,10 @@ _SIGNATURES = {
     "spcl_bn_stats_elems": (c_size_t, [c_int, c_int]),
     "spcl_conv3x3_forward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P,
                                      _P]),
+    "spcl_supcon_forward_heads": (c_int, [c_int, _P, _P, c_size_t, _P, c_int, c_int, c_float, c_int, _P, c_int, _P,
+                                          c_size_t, _P, _P]),
+    "spcl_supcon_backward_heads": (c_int, [c_int, _P, c_int, c_int, c_float, c_int, _P, _P, c_size_t, _P, c_size_t, _P,
+                                           _P, _P, _P, c_size_t, _P]),
     "spcl_conv_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "spcl_conv3x3_wgrad": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P,
                                    _P, _P, _P, _P]),

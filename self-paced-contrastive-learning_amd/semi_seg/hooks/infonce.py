@@ -14,7 +14,7 @@ from torch import nn
 
 from ... import functional as F_hip
 from ...contrastyou.hooks.base import EpocherHook, TrainerHook
-from ...contrastyou.losses.contrast_loss3 import SelfPacedSupConLoss, SupConLoss1
+from ...contrastyou.losses.contrast_loss3 import SelfPacedSupConLoss, SupConLoss1, supcon_heads
 from ...contrastyou.meters import AverageValueMeter
 from ..arch.hook import SingleFeatureExtractor
 from ..arch.unet import UNet
@@ -190,6 +190,25 @@ class _INFONCEEpochHook(EpocherHook):
                 pass
         return cache[1][id(self._projector)]
 
+    def _group_loss(self, feature, base, partition_group, label_group):
+        """This hook's loss out of the group's batched evaluation -- the first hook of the step projects for all heads AND
+        evaluates all K criteria in the launches of one (contrast_loss3.supcon_heads; row N4), cached on the tapped tensor
+        like the projections -- or None when there is no group or its criteria cannot be batched."""
+        if self._batch_group is None:
+            return None
+        cache = getattr(base, "_spcl_losses", None)
+        if cache is None or cache[0] != feature.shape[0]:
+            members = self._batch_group
+            zs = [m._project(feature, base) for m in members]
+            targets = [m._labels(partition_group, label_group, feature.device) for m in members]
+            losses = supcon_heads([m._criterion for m in members], zs, targets)
+            cache = (feature.shape[0], None if losses is None else {id(m): l for m, l in zip(members, losses)})
+            try:
+                base._spcl_losses = cache
+            except AttributeError:
+                return None  # (nowhere to keep the other heads' losses: evaluate one by one)
+        return None if cache[1] is None else cache[1][id(self)]
+
     @meter_focus
     def configure_meters(self, meters):
         meters = super().configure_meters(meters)
@@ -254,8 +273,11 @@ class _INFONCEEpochHook(EpocherHook):
     def __call__(self, *, affine_transformer, seed, unlabeled_tf_logits, unlabeled_logits_tf, partition_group,
                  label_group, **kwargs):
         feature = self._two_views(len(unlabeled_logits_tf), affine_transformer, seed)
-        z_first, z_second = torch.chunk(self._project(feature, self._extractor.feature()), 2)
-        loss = self._criterion(z_first, z_second, target=self._labels(partition_group, label_group, feature.device))
+        base = self._extractor.feature()
+        loss = self._group_loss(feature, base, partition_group, label_group)
+        if loss is None:
+            z_first, z_second = torch.chunk(self._project(feature, base), 2)
+            loss = self._criterion(z_first, z_second, target=self._labels(partition_group, label_group, feature.device))
         self._record(loss)
         return loss if self._weight == 1 else loss * self._weight
 

@@ -213,3 +213,58 @@ def test_loss_edge_sizes_vs_oracle(n, d, mname):
     scale = float(a.grad.abs().max()) + 1e-12
     np.testing.assert_allclose(x.grad.cpu().numpy(), a.grad.numpy(), rtol=2e-3, atol=2e-4 * scale)
     np.testing.assert_allclose(y.grad.cpu().numpy(), b.grad.numpy(), rtol=2e-3, atol=2e-4 * scale)
+
+
+@pytest.mark.parametrize("n,d", [(32, 128), (20, 64), (64, 128), (100, 256), (256, 96)])
+@pytest.mark.parametrize("K", [2, 3, 4])
+@pytest.mark.parametrize("mode", [None, "hard", "soft"])
+def test_losses_of_k_heads_in_one_launch_equal_the_single_calls(n, d, K, mode):
+    """K criteria of one kind (own labels, own age parameter) evaluated by spcl_supcon_forward_heads /
+    _backward_heads -- losses, gradients, rho and the taps are bit-identical to K calls of spcl_supcon_forward / _backward
+    (small one-launch schedule at 2n <= 64, the sweeps above)."""
+    import spcl_amd  # noqa: F401
+    from spcl_amd.contrastyou.losses.contrast_loss3 import supcon_heads
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(n * 7 + d + K)
+    zs = [torch.nn.functional.normalize(torch.randn(2 * n, d, generator=g), dim=1).to(dev) for _ in range(K)]
+    labels = [torch.randint(0, 3 + k, (n,), generator=g).float().to(dev) for k in range(K)]
+    gammas = [3.0 + 2.5 * k for k in range(K)]
+    weights = [1.0 + 0.5 * k for k in range(K)]  # different upstream gradients per head
+
+    def crits():
+        return [_crit(mode, gammas[k], mode == "soft") for k in range(K)]
+
+    # one by one
+    a_z = [z.clone().requires_grad_(True) for z in zs]
+    a_c = crits()
+    a_l = [c(*torch.chunk(z, 2), target=t) for c, z, t in zip(a_c, a_z, labels)]
+    sum(w * l for w, l in zip(weights, a_l)).backward()
+    # batched
+    b_z = [z.clone().requires_grad_(True) for z in zs]
+    b_c = crits()
+    b_l = supcon_heads(b_c, b_z, labels)
+    assert b_l is not None and len(b_l) == K
+    sum(w * l for w, l in zip(weights, b_l)).backward()
+    for k in range(K):
+        assert torch.equal(a_l[k], b_l[k]), (k, a_l[k].item(), b_l[k].item())
+        assert torch.equal(a_z[k].grad, b_z[k].grad), k
+        assert torch.equal(a_c[k]._state.out[:4], b_c[k]._state.out[:4]), k  # loss, rho, kappa, norm defect
+        if mode is not None:
+            assert a_c[k].downgrade_ratio == b_c[k].downgrade_ratio
+            assert torch.equal(a_c[k].sp_mask, b_c[k].sp_mask)
+        assert torch.equal(a_c[k].sim_logits, b_c[k].sim_logits)
+        assert torch.equal(a_c[k].pos_mask, b_c[k].pos_mask)
+
+
+def test_loss_heads_refuses_what_it_cannot_batch():
+    import spcl_amd  # noqa: F401
+    from spcl_amd.contrastyou.losses.contrast_loss3 import SupConLoss1, supcon_heads
+    dev = "cuda:0"
+    z = [torch.nn.functional.normalize(torch.randn(64, 32), dim=1).to(dev) for _ in range(2)]
+    lab = [torch.zeros(32, device=dev)] * 2
+    assert supcon_heads([_crit(None, 1, False), _crit("soft", 3.0, False)], z, lab) is None        # mixed kinds
+    assert supcon_heads([_crit("soft", 3.0, False), _crit("hard", 3.0, False)], z, lab) is None    # mixed weight rules
+    assert supcon_heads([SupConLoss1(exclude_other_pos=True), SupConLoss1(exclude_other_pos=True)], z, lab) is None
+    assert supcon_heads([_crit(None, 1, False)], z[:1], lab[:1]) is None                           # one head
+    big = [torch.nn.functional.normalize(torch.randn(1024, 32), dim=1).to(dev) for _ in range(2)]
+    assert supcon_heads([_crit(None, 1, False)] * 2, big, [torch.zeros(512, device=dev)] * 2) is None  # large-batch size
