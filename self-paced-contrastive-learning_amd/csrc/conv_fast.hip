@@ -52,6 +52,9 @@ struct FastArgs {
 #ifndef SPCL_FAST_YPRE_MINKC
 #define SPCL_FAST_YPRE_MINKC 16
 #endif
+#ifndef SPCL_FAST_DBG
+#define SPCL_FAST_DBG 0  /* timing experiments only (wrong results): 1 no ring refills, 2 no fragment reads in the k-loop */
+#endif
 #ifndef SPCL_FAST_RP
 #define SPCL_FAST_RP 22
 #endif
@@ -232,7 +235,10 @@ conv3x3_fast_kernel(FastArgs a) {
       return (ky * RP + kx) * PS + c * 16;
     };
     if (STREAM_W) {
-      const unsigned char* wrun = (const unsigned char*)a.wp + ((size_t)slab * NSTEPS + WR) * wstep;
+      // refills by buffer loads: one resource descriptor, the lane's 32-bit offset, a wave-uniform running offset (a
+      // 1 KiB-per-wave vector-memory request is the expensive instruction of the step: no 64-bit address arithmetic on top)
+      const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, 0x7fffffff, 0x00020000);
+      unsigned wrun = (unsigned)(((size_t)slab * NSTEPS + WR) * wstep);
       // weight ring + fragments one step ahead, every step fenced (sched_barrier(0)): left to itself the scheduler bunches
       // the refills next to their uses or keeps them all live, and either spills or waits on every load
       u32x4 xf[2][MT];
@@ -240,22 +246,26 @@ conv3x3_fast_kernel(FastArgs a) {
       for (int i = 0; i < MT; ++i) xf[0][i] = *(const u32x4*)(lds + abase[i] + frag_off(0));
 #pragma unroll
       for (int s = 0; s < NSTEPS; ++s) {
+        // per m-tile: its NT MFMAs, then the NEXT step's fragment of that m-tile (and, after the first m-tile, the ring
+        // refill): the reads issue in the shadow of the MFMAs.  With one fence per STEP all reads of step s + 1 were
+        // issued between the last MFMA of step s and the first of s + 1 -- a ~100-cycle bubble per step with one wave
+        // per SIMD (k-loop of Conv5.b: 350 cycles per step for 224 of MFMA)
         u32x4 wf[NT];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          wf[j] = wsl[s % WR][j];
-          if (s + WR < NSTEPS || refill) wsl[s % WR][j] = *(const u32x4*)(wrun + wvo + j * 1024);
-        }
-        wrun += wstep;  // uniform running pointer: one scalar add per step instead of NSTEPS hoisted offsets
-        if (s + 1 < NSTEPS) {
+        for (int j = 0; j < NT; ++j) wf[j] = wsl[s % WR][j];
 #pragma unroll
-          for (int i = 0; i < MT; ++i) xf[(s + 1) & 1][i] = *(const u32x4*)(lds + abase[i] + frag_off(s + 1));
-        }
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i) {
 #pragma unroll
           for (int j = 0; j < NT; ++j) acc[i][j] = mfma_chunk<bf16_t>(wf[j], xf[s & 1][i], acc[i][j]);
-        __builtin_amdgcn_sched_barrier(0);
+          if (s + 1 < NSTEPS && !(SPCL_FAST_DBG & 2)) xf[(s + 1) & 1][i] = *(const u32x4*)(lds + abase[i] + frag_off(s + 1));
+          if (i == MT - 1 && (s + WR < NSTEPS || refill) && !(SPCL_FAST_DBG & 1)) {  // (after the step's last MFMA: wf is dead, no copies)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              wsl[s % WR][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvo + j * 1024, wrun, 0));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        wrun += (unsigned)wstep;  // uniform running offset: one scalar add per step instead of NSTEPS hoisted offsets
       }
     } else {
 #pragma unroll
