@@ -146,6 +146,11 @@ int spcl_conv_pack_weights_both(const float* w_oihw, int Cin, int Cout, int dtyp
 int spcl_conv_pack_weights_block(const float* wa_oihw, int CinA, int CoutA, void* a_fwd, void* a_dgrad,
                                  const float* wb_oihw, int CinB, int CoutB, void* b_fwd, void* b_dgrad, int dtype,
                                  void* stream);
+/* the same for weights that will be used at image size H x W: the band-GEMM layout of a dual-layout buffer is written only
+ * where spcl_conv3x3_forward picks that kernel at this size (H = W = 0: both layouts, == spcl_conv_pack_weights_block) */
+int spcl_conv_pack_weights_block_at(const float* wa_oihw, int CinA, int CoutA, void* a_fwd, void* a_dgrad,
+                                    const float* wb_oihw, int CinB, int CoutB, void* b_fwd, void* b_dgrad, int dtype,
+                                    int H, int W, void* stream);
 
 /* y = conv3x3(act(x)), NHWC, implicit GEMM on MFMA.                    (unet.py:72,75; dgrad: with kind-1 weights)
  * x [N,H,W,CinS] of dtype; CinK = GEMM-K channels (multiple of 16, == CinS for in_mode 0/1).

@@ -313,18 +313,18 @@ __global__ __launch_bounds__(256) void conv_pack_block_kernel(const float* __res
                                                               T* __restrict__ a0, size_t ta0, T* __restrict__ a1,
                                                               size_t ta1, const float* __restrict__ wb, int CinB,
                                                               int CoutB, T* __restrict__ b0, size_t tb0,
-                                                              T* __restrict__ b1, size_t tb1, bool gemm_a,
-                                                              bool gemm_b) {
+                                                              T* __restrict__ b1, size_t tb1, bool gemm_a0,
+                                                              bool gemm_a1, bool gemm_b0, bool gemm_b1) {
   size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int CinKA = (CinA + 15) / 16 * 16, CoutSA = (CoutA + 15) / 16 * 16;
   const int CinKB = (CinB + 15) / 16 * 16, CoutSB = (CoutB + 15) / 16 * 16;
-  if (idx < ta0) { Elem<T>::store(a0 + idx, pack_value<T>(wa, CinA, CoutA, 0, CinKA, CoutSA, idx, gemm_a)); return; }
+  if (idx < ta0) { Elem<T>::store(a0 + idx, pack_value<T>(wa, CinA, CoutA, 0, CinKA, CoutSA, idx, gemm_a0)); return; }
   idx -= ta0;
-  if (idx < ta1) { Elem<T>::store(a1 + idx, pack_value<T>(wa, CinA, CoutA, 1, CoutSA, CinKA, idx, gemm_a)); return; }
+  if (idx < ta1) { Elem<T>::store(a1 + idx, pack_value<T>(wa, CinA, CoutA, 1, CoutSA, CinKA, idx, gemm_a1)); return; }
   idx -= ta1;
-  if (idx < tb0) { Elem<T>::store(b0 + idx, pack_value<T>(wb, CinB, CoutB, 0, CinKB, CoutSB, idx, gemm_b)); return; }
+  if (idx < tb0) { Elem<T>::store(b0 + idx, pack_value<T>(wb, CinB, CoutB, 0, CinKB, CoutSB, idx, gemm_b0)); return; }
   idx -= tb0;
-  if (idx < tb1) Elem<T>::store(b1 + idx, pack_value<T>(wb, CinB, CoutB, 1, CoutSB, CinKB, idx, gemm_b));
+  if (idx < tb1) Elem<T>::store(b1 + idx, pack_value<T>(wb, CinB, CoutB, 1, CoutSB, CinKB, idx, gemm_b1));
 }
 
 // bf16 layers the workgroup-level GEMM kernel can take (conv_gemm.hip) carry BOTH layouts, the per-wave kernels' first:
@@ -484,8 +484,17 @@ extern "C" int spcl_conv_pack_weights_both(const float* w_oihw, int Cin, int Cou
 extern "C" int spcl_conv_pack_weights_block(const float* wa_oihw, int CinA, int CoutA, void* a_fwd, void* a_dgrad,
                                            const float* wb_oihw, int CinB, int CoutB, void* b_fwd, void* b_dgrad,
                                            int dtype, void* stream) {
+  return spcl_conv_pack_weights_block_at(wa_oihw, CinA, CoutA, a_fwd, a_dgrad, wb_oihw, CinB, CoutB, b_fwd, b_dgrad, dtype,
+                                         0, 0, stream);
+}
+
+// H, W > 0: the image size the packed weights will be used at -- the second (band-GEMM) layout of a dual-layout buffer is
+// written only where spcl_conv3x3_forward would pick that kernel at this size (it reads nothing else of it); 0, 0: both.
+extern "C" int spcl_conv_pack_weights_block_at(const float* wa_oihw, int CinA, int CoutA, void* a_fwd, void* a_dgrad,
+                                              const float* wb_oihw, int CinB, int CoutB, void* b_fwd, void* b_dgrad,
+                                              int dtype, int H, int W, void* stream) {
   SPCL_CHECK_ARG(wa_oihw && wb_oihw && a_fwd && a_dgrad && b_fwd && b_dgrad, "conv_pack_weights_block: null pointer");
-  SPCL_CHECK_ARG(CinA > 0 && CoutA > 0 && CinB > 0 && CoutB > 0, "conv_pack_weights_block: bad args");
+  SPCL_CHECK_ARG(CinA > 0 && CoutA > 0 && CinB > 0 && CoutB > 0 && H >= 0 && W >= 0, "conv_pack_weights_block: bad args");
   hipStream_t st = (hipStream_t)stream;
   const int ka = round_up(CinA, 16), sa = round_up(CoutA, 16), kb = round_up(CinB, 16), sb = round_up(CoutB, 16);
   if (dtype == SPCL_F32) {
@@ -493,13 +502,19 @@ extern "C" int spcl_conv_pack_weights_block(const float* wa_oihw, int CinA, int 
     const size_t tb0 = packed_elems<float>(kb, sb), tb1 = packed_elems<float>(sb, kb);
     SPCL_LAUNCH(conv_pack_block_kernel<float>, dim3((unsigned)((ta0 + ta1 + tb0 + tb1 + 255) / 256)), dim3(256), 0, st,
                 wa_oihw, CinA, CoutA, (float*)a_fwd, ta0, (float*)a_dgrad, ta1, wb_oihw, CinB, CoutB, (float*)b_fwd, tb0,
-                (float*)b_dgrad, tb1, false, false);
+                (float*)b_dgrad, tb1, false, false, false, false);
   } else if (dtype == SPCL_BF16) {
-    const size_t ta0 = packed_elems<bf16_t>(ka, sa), ta1 = packed_elems<bf16_t>(sa, ka);
-    const size_t tb0 = packed_elems<bf16_t>(kb, sb), tb1 = packed_elems<bf16_t>(sb, kb);
+    // elements to write of each buffer: both layouts, or only the per-wave kernels' (the first half)
+    auto want = [&](int K, int S) { return conv_gemm_channels(K, S) && (H == 0 || W == 0 || conv_use_gemm(K, S, H, W)); };
+    auto elems = [&](int K, int S, bool g) {
+      const size_t all = packed_elems<bf16_t>(K, S);
+      return (conv_gemm_channels(K, S) && !g) ? all / 2 : all;
+    };
+    const bool ga0 = want(ka, sa), ga1 = want(sa, ka), gb0 = want(kb, sb), gb1 = want(sb, kb);
+    const size_t ta0 = elems(ka, sa, ga0), ta1 = elems(sa, ka, ga1), tb0 = elems(kb, sb, gb0), tb1 = elems(sb, kb, gb1);
     SPCL_LAUNCH(conv_pack_block_kernel<bf16_t>, dim3((unsigned)((ta0 + ta1 + tb0 + tb1 + 255) / 256)), dim3(256), 0, st,
                 wa_oihw, CinA, CoutA, (bf16_t*)a_fwd, ta0, (bf16_t*)a_dgrad, ta1, wb_oihw, CinB, CoutB, (bf16_t*)b_fwd,
-                tb0, (bf16_t*)b_dgrad, tb1, conv_gemm_channels(ka, sa), conv_gemm_channels(kb, sb));
+                tb0, (bf16_t*)b_dgrad, tb1, ga0, ga1, gb0, gb1);
   } else {
     set_error("conv_pack_weights_block: dtype %d", dtype);
     return SPCL_EINVAL;

@@ -533,8 +533,9 @@ def _pack_both(w, dt_code, dtype):
     return p0, p1
 
 
-def _pack_block(wa, wb, dt_code, dtype):
-    """both convolutions of a block, forward and dgrad layouts, one launch -> ((a_fwd, a_dgrad), (b_fwd, b_dgrad))."""
+def _pack_block(wa, wb, dt_code, dtype, H=0, W=0):
+    """both convolutions of a block, forward and dgrad layouts, one launch -> ((a_fwd, a_dgrad), (b_fwd, b_dgrad)).
+    ``H, W``: the image size they are used at (the band-GEMM layout is only written where that kernel runs)."""
     sizes = []
     for w in (wa, wb):
         co, ci = w.shape[0], w.shape[1]
@@ -545,8 +546,8 @@ def _pack_block(wa, wb, dt_code, dtype):
         parts.append(buf[off:off + n_])
         off += n_
     wac, wbc = wa.detach().contiguous().float(), wb.detach().contiguous().float()
-    _n.call("spcl_conv_pack_weights_block", _n.ptr(wac), wa.shape[1], wa.shape[0], _n.ptr(parts[0]), _n.ptr(parts[1]),
-            _n.ptr(wbc), wb.shape[1], wb.shape[0], _n.ptr(parts[2]), _n.ptr(parts[3]), dt_code, _n.stream())
+    _n.call("spcl_conv_pack_weights_block_at", _n.ptr(wac), wa.shape[1], wa.shape[0], _n.ptr(parts[0]), _n.ptr(parts[1]),
+            _n.ptr(wbc), wb.shape[1], wb.shape[0], _n.ptr(parts[2]), _n.ptr(parts[3]), dt_code, int(H), int(W), _n.stream())
     return (parts[0], parts[1]), (parts[2], parts[3])
 
 
@@ -633,6 +634,7 @@ class DeferredWgrads:
 
 
 _deferred: "DeferredWgrads | None" = None
+_PACK_AT = os.environ.get("SPCL_PACK_AT", "1") != "0"  # A/B switch: 0 packs the band-GEMM layout whether or not it is used
 _TAILS = os.environ.get("SPCL_WGRAD_TAILS", "1") != "0"  # A/B switch: 0 keeps every layer's own final reduction launch
 
 
@@ -813,7 +815,7 @@ class _ConvBlockFn(torch.autograd.Function):
             mode_a = 0
         need_bwd = any(ctx.needs_input_grad)
         if need_bwd:  # the dgrad layouts are packed alongside (same launch) and kept for backward
-            (wpa, wpa_t), (wpb, wpb_t) = _pack_block(wa, wb, dtc, dtype)
+            (wpa, wpa_t), (wpb, wpb_t) = _pack_block(wa, wb, dtc, dtype, *((H, W) if _PACK_AT else (0, 0)))
         else:
             wpa, wpb, wpa_t, wpb_t = _pack(wa, 0, dtc, dtype), _pack(wb, 0, dtc, dtype), None, None
         ya, sa = _conv(xs, dtc, dtype, N, H, W, cin_s, cin_k, cout_s, wpa, mode_a, None, None, cfg.training)
