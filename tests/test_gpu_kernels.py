@@ -707,3 +707,32 @@ def test_dgrad_with_fused_pooled_bn_backward_sums(N, ci, co, H2, W2):
            n.ptr(st[1]), n.ptr(st[2]), n.ptr(st[3]), 1, n.ptr(ws), n.ptr(dg1), n.ptr(db1), n.ptr(dy1), n.stream())
     assert relerr(dg1, dg0) < 2e-5 and relerr(db1, db0) < 2e-5
     assert relerr(dy1.float(), dy0.float()) < 8e-3
+
+
+def test_block_pack_writes_the_band_gemm_layout_only_where_that_kernel_runs():
+    """spcl_conv_pack_weights_block_at: at an image size where the per-wave kernels run (28^2) the second half of a
+    dual-layout buffer stays untouched and the first half equals the size-agnostic pack; at 32^2 (band GEMM kernel) and
+    with H = W = 0 both halves are written, identical to spcl_conv_pack_weights_block."""
+    n = _n()
+    dtype, dtc = torch.bfloat16, n.dtype_code(torch.bfloat16)
+    g = torch.Generator().manual_seed(3)
+    wa, wb = torch.randn(128, 64, 3, 3, generator=g).cuda(), torch.randn(128, 128, 3, 3, generator=g).cuda()
+    sizes = [n.call("spcl_conv_packed_elems", ci, co, kind, dtc) for (ci, co) in ((64, 128), (128, 128)) for kind in (0, 1)]
+
+    def run(fn, *hw):
+        bufs = [torch.full((s,), 7.0, dtype=dtype, device="cuda") for s in sizes]
+        n.call(fn, n.ptr(wa), 64, 128, n.ptr(bufs[0]), n.ptr(bufs[1]), n.ptr(wb), 128, 128, n.ptr(bufs[2]), n.ptr(bufs[3]),
+               dtc, *hw, n.stream())
+        return bufs
+
+    ref = run("spcl_conv_pack_weights_block")
+    for b in ref:
+        assert not torch.any(b == 7.0)  # every element written
+    both = run("spcl_conv_pack_weights_block_at", 0, 0)
+    big = run("spcl_conv_pack_weights_block_at", 32, 32)
+    small = run("spcl_conv_pack_weights_block_at", 28, 28)
+    for r, a, b, c in zip(ref, both, big, small):
+        assert torch.equal(r, a) and torch.equal(r, b)
+        half = r.numel() // 2
+        assert torch.equal(c[:half], r[:half])
+        assert torch.all(c[half:] == 7.0)
