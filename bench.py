@@ -78,8 +78,13 @@ def parse():
     ap.add_argument("--bs", type=int, default=32, help="slices per GPU (two views each)")
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--no-graph", action="store_true", help="do not capture the step in a hipGraph")
-    ap.add_argument("--split-graph", action="store_true", help="force the compute / collective / update split capture")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="launch every kernel eagerly (default: the epocher replays its step from a hipGraph, stepgraph.py)")
+    ap.add_argument("--pool", type=int, default=8,
+                    help="distinct resident synthetic batches the loader cycles through (fresh images, slice order and "
+                         "label vector every step; all in HBM before the timed region)")
+    ap.add_argument("--fresh-rand", action="store_true",
+                    help="draw every batch on the device inside the step (two torch.rand launches) instead of the pool")
     ap.add_argument("--ddp-overlap", action="store_true",
                     help="N>1: all-reduce the early gradient bucket (projector + Conv5..Conv3) from a backward hook while "
                          "Conv2..Conv1 are differentiated (ddp.enable_unet_overlap); runs the step eagerly -- a "
@@ -129,22 +134,28 @@ def build_step(args, device, rank, world):
     flat = ddp.FlatParams(params + hparams)  # one flat parameter + one flat gradient bucket (all-reduced when N>1)
     from spcl_amd.optim import FusedRAdam
     opt = FusedRAdam([flat.param], lr=5e-7 * 400, weight_decay=1e-5)  # torch.optim.RAdam semantics, HIP kernel
-    loader = SyntheticPretrainLoader(bs=args.bs, size=args.size, device=device, seed=1234 + rank, resident=True,
-                                     meta="prostate" if prostate else "acdc")
+    loader = SyntheticPretrainLoader(bs=args.bs, size=args.size, device=device, seed=1234 + rank,
+                                     resident=not getattr(args, "fresh_rand", False),
+                                     meta="prostate" if prostate else "acdc", pool=getattr(args, "pool", 1))
+    # the product loop's own step: PretrainEncoderEpocher.step captures itself in a hipGraph after two eager steps and
+    # replays it from then on (labels / flip flags of every new batch through its stage, stepgraph.py)
     epocher = PretrainEncoderEpocher(model=model, optimizer=opt, chain_dataloader=loader, num_batches=10 ** 9,
-                                     device=device, inference_until="Conv5", flat_params=flat)
+                                     device=device, inference_until="Conv5", flat_params=flat,
+                                     graph=not getattr(args, "no_graph", False))
     epocher.add_hooks([hook()])
     if getattr(args, "ddp_overlap", False):
         ddp.enable_unet_overlap(flat, model)
     model.train()
-    batch = next(loader)
     nparams = sum(p.numel() for p in params + hparams)
+    import random
+    random.seed(4321 + rank)  # the per-step flip seeds (new_pretrain.py:54) are drawn from python's RNG
 
     def step():
+        """one iteration of the epocher's loop on the loader's NEXT batch, with a freshly drawn flip seed"""
         with epocher.meters.focus_on(epocher.meter_focus):
-            return epocher.step(batch, seed=7)
+            return epocher.step(next(loader))
 
-    step.epocher, step.batch = epocher, batch
+    step.epocher, step.batch, step.flat, step.model = epocher, next(loader), flat, model
     return step, epocher, nparams
 
 
@@ -163,46 +174,8 @@ def graph_capture(step, device):
     return g.replay
 
 
-def graph_capture_split(step, device):
-    """Fallback when the whole-step capture is refused (e.g. the RCCL collective cannot be captured on a given
-    stack): graph A = forward + loss + backward + gradient gather, the flat all-reduce launched eagerly, graph B =
-    optimizer step + meters.  Two replays and one collective per step instead of ~150 launches."""
-    epocher, batch = step.epocher, step.batch
-    state = {}
-
-    def compute():
-        with epocher.meters.focus_on(epocher.meter_focus):
-            state["loss"] = epocher.step_compute(batch, seed=7)
-
-    def update():
-        with epocher.meters.focus_on(epocher.meter_focus):
-            epocher.step_update(state["loss"])
-
-    s = torch.cuda.Stream(device=device)
-    s.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(s):
-        for _ in range(3):
-            compute()
-            epocher.step_exchange()
-            update()
-    torch.cuda.current_stream().wait_stream(s)
-    torch.cuda.synchronize()
-    ga = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(ga):
-        compute()
-    gb = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(gb, pool=ga.pool()):
-        update()
-
-    def run():
-        ga.replay()
-        epocher.step_exchange()
-        gb.replay()
-    return run
-
-
 # ------------------------------------------------------------------------------------------------ roofline (live)
-def measure_roofline(step, args):
+def measure_roofline(step, args, phases=False):
     """Instrumented pass with the library's built-in kernel timer: every kernel launch of libspcl_hip.so is bracketed
     by HIP events ON ITS LAUNCH STREAM (spcl_profile_* of the C ABI; eager launches, not the graph) and reported with
     its kernel symbol -- the names rocprofv3 prints -- and the algorithmic bytes / FLOPs its entry point declares
@@ -213,6 +186,16 @@ def measure_roofline(step, args):
     step()
     torch.cuda.synchronize()
     native.call("spcl_profile_enable", 1)
+    marks, epocher, orig_fwd = [], getattr(step, "epocher", None), None
+    if phases and epocher is not None:  # launch-log index where the encoder forward of each instrumented step ends
+        orig_fwd = epocher._forward_pass
+
+        def marked_forward(**kw):
+            start = native.call("spcl_profile_count")
+            out = orig_fwd(**kw)
+            marks.append((start, native.call("spcl_profile_count")))
+            return out
+        epocher._forward_pass = marked_forward
     try:
         for _ in range(reps):
             step()
@@ -221,8 +204,10 @@ def measure_roofline(step, args):
         name = ctypes.create_string_buffer(256)
         us, by, fl = ctypes.c_float(), ctypes.c_double(), ctypes.c_double()
         groups = {}
+        launches = []
         for i in range(n):
             native.call("spcl_profile_get", i, name, 256, ctypes.byref(us), ctypes.byref(by), ctypes.byref(fl))
+            launches.append((name.value.decode(), us.value * 1e-6, by.value, fl.value))
             g = groups.setdefault(name.value.decode(), {"t": 0.0, "n": 0, "bytes": 0.0, "flops": 0.0, "roof": 0.0,
                                                         "hbm_t": 0.0, "mfma_t": 0.0})
             g["t"] += us.value * 1e-6
@@ -236,6 +221,8 @@ def measure_roofline(step, args):
             g["mfma_t"] += mfma_t
     finally:
         native.call("spcl_profile_enable", 0)
+        if orig_fwd is not None:
+            del epocher._forward_pass  # (the instance attribute shadowing the method)
     total = sum(g["t"] for g in groups.values()) / reps
     ranked = sorted(groups.items(), key=lambda kv: -kv[1]["t"])
     out = None
@@ -275,7 +262,51 @@ def measure_roofline(step, args):
     breakdown = [{"kernel": k, "us_per_step": round(g["t"] / reps * 1e6, 1), "launches": g["n"] / reps,
                   "GBps": round(g["bytes"] / g["t"] / 1e9, 0) if g["bytes"] > 0 else None,
                   "TFLOPs": round(g["flops"] / g["t"] / 1e12, 1) if g["flops"] > 0 else None} for k, g in ranked[:16]]
-    return out, breakdown, total
+    if not phases:
+        return out, breakdown, total
+    return out, breakdown, total, phase_fractions(launches, marks, reps, args)
+
+
+def phase_fractions(launches, marks, reps, args):
+    """SURVEY 8(d)'s fractions from the same instrumented pass: the encoder forward (launches between the marks) against
+    its mixed roofline (sum over launches of max(bytes / 8 TB/s, FLOPs / peak): 90.8 us at N = 64, 224^2, bf16) and
+    against the matrix peak, the four matrix-bound layers one by one, and the whole step's mixed bound (the caller
+    divides it by the timed step)."""
+    peak = (MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS) * 1e12
+    bw = HBM_PEAK_GBS * 1e9
+    roof = lambda by, fl: max(by / bw, fl / peak)  # noqa: E731
+    step_roof = sum(roof(by, fl) for _, _, by, fl in launches) / reps
+    if not marks:
+        return {"_step_roof_s": step_roof}
+    t_fwd = sum(sum(l[1] for l in launches[a:b]) for a, b in marks) / len(marks)
+    fl_fwd = sum(sum(l[3] for l in launches[a:b]) for a, b in marks) / len(marks)
+    roof_fwd = sum(sum(roof(l[2], l[3]) for l in launches[a:b]) for a, b in marks) / len(marks)
+    n_fwd = sum(b - a for a, b in marks) / len(marks)
+    per_layer = {}
+    names = ["C1a", "C1b", "C2a", "C2b", "C3a", "C3b", "C4a", "C4b", "C5a", "C5b"]
+    for a, b in marks:
+        convs = [l for l in launches[a:b] if l[3] > 0]
+        if len(convs) != len(names):
+            per_layer = None
+            break
+        for nm, l in zip(names, convs):
+            d = per_layer.setdefault(nm, {"t": 0.0, "fl": 0.0, "by": 0.0})
+            d["t"] += l[1]
+            d["fl"] += l[3]
+            d["by"] += l[2]
+    layers = None
+    if per_layer:
+        layers = {nm: {"us": round(d["t"] / len(marks) * 1e6, 2), "TFLOPs": round(d["fl"] / d["t"] / 1e12, 1),
+                       "frac_of_mfma_peak": round(d["fl"] / d["t"] / peak, 4),
+                       "GBps": round(d["by"] / d["t"] / 1e9, 0)} for nm, d in per_layer.items()}
+    return {"_step_roof_s": step_roof,
+            "encoder_fwd": {"t_us": round(t_fwd * 1e6, 1), "launches": n_fwd,
+                            "mixed_roofline_us": round(roof_fwd * 1e6, 1), "mixed_frac": round(roof_fwd / t_fwd, 4),
+                            "mfma_util": round(fl_fwd / t_fwd / peak, 4), "gflop": round(fl_fwd / 1e9, 1),
+                            "per_layer": layers,
+                            "note": "sum of the kernel durations between the start of UNet.forward and its return (eager "
+                                    "instrumented pass, HIP events per launch); mixed_frac = sum of max(bytes / 8 TB/s, "
+                                    "FLOPs / peak) over those launches / that time (SURVEY 8d: 90.8 us at N=64 224^2 bf16)"}}
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
@@ -378,31 +409,21 @@ def main():
     step, epocher, nparams = build_step(args, device, rank, world)
     run = step
     wd.beat("capture")
-    used_graph = False
+    # the step captures ITSELF (epocher.step: two eager steps, then capture + replay).  Those steps run here, ahead of
+    # the W warm-up steps, so that the timed region holds replays only whatever W is.
+    capture_steps = 0
     if not args.no_graph:
-        # N > 1: the collective stays OUTSIDE the graphs by default (compute graph, eager all-reduce of the flat bucket,
-        # update graph).  A whole-step capture that the communication library refuses leaves the capture stream
-        # invalidated on this stack and no later capture (or eager launch on it) recovers -- found with the one-device
-        # gloo self-test (SPCL_BENCH_ONE_DEVICE=1); SPCL_BENCH_WHOLE_GRAPH=1 opts in to capturing the collective too.
-        if world > 1 and os.environ.get("SPCL_BENCH_WHOLE_GRAPH") != "1":
-            args.split_graph = True
-        try:
-            if args.split_graph:
-                raise RuntimeError("--split-graph")
-            run = graph_capture(step, device)
-            used_graph = True
-        except Exception as e:  # noqa: BLE001  -- report; keep the collective outside the graphs, else eager
-            if rank == 0 and str(e) != "--split-graph":
-                print(f"[bench] whole-step hipGraph capture failed ({type(e).__name__}: {e})", file=sys.stderr)
-            try:
-                torch.cuda.synchronize()
-                run = graph_capture_split(step, device)
-                used_graph = "split"
-            except Exception as e2:  # noqa: BLE001
-                if rank == 0:
-                    print(f"[bench] split capture failed too ({type(e2).__name__}: {e2}); running eagerly",
-                          file=sys.stderr)
-                run = step
+        while capture_steps < 4 and not (epocher._step_graph is not None and epocher._step_graph.captured):
+            run()
+            capture_steps += 1
+            wd.beat()
+        sg = epocher._step_graph
+        if sg is None or not sg.captured:
+            if rank == 0:
+                print("[bench] the epocher did not capture its step (see the warning above); running eagerly",
+                      file=sys.stderr)
+    sg = epocher._step_graph
+    used_graph = False if (sg is None or not sg.captured) else ("epocher-split" if world > 1 else "epocher")
     wd.beat("warmup")
     for _ in range(args.warmup):
         run()
@@ -448,7 +469,10 @@ def main():
                                 "correct_grad) fwd+bwd + RAdam") + (" + flat RCCL grad all-reduce" if world > 1 else ""),
                    "slices_per_gpu": args.bs, "images_per_gpu_step": 2 * args.bs, "image": f"1x{args.size}x{args.size}",
                    "global_batch": args.bs * world, "parallelism": f"dp{world}", "params": nparams,
-                   "hipgraph": used_graph},
+                   "hipgraph": used_graph, "capture_steps": capture_steps,
+                   "batches": ("drawn on device every step (torch.rand)" if args.fresh_rand else
+                               f"{args.pool} distinct resident batches cycled") + ", fresh flip seed and label vector "
+                              "every step (PretrainEncoderEpocher.step on next(loader))"},
     }
     if rank == 0:
         loss = epocher.meters.statistics()
@@ -461,10 +485,16 @@ def main():
         # + update phases only, so no peer is needed and a failure here cannot leave another rank inside a collective
         wd.beat("roofline")
         try:
-            roof, breakdown, tot = measure_roofline(local_step(step), args)
+            if args.ddp_overlap:  # the instrumented steps run on this rank alone: no early collective from backward
+                from spcl_amd import ddp as _ddp
+                _ddp.disable_unet_overlap(step.flat, step.model)
+            roof, breakdown, tot, fractions = measure_roofline(local_step(step), args, phases=True)
             line["roofline"] = roof
             line["kernel_breakdown"] = breakdown
             line["instrumented_step_ms"] = round(tot * 1e3, 3)
+            if fractions:
+                fractions["step_mixed_frac"] = round(fractions.pop("_step_roof_s") / (ms * 1e-3), 4)
+                line.setdefault("extra", {}).update(fractions)
         except Exception as e:  # noqa: BLE001
             line["roofline"] = None
             print(f"[bench] roofline pass failed on rank {rank}: {type(e).__name__}: {e}", file=sys.stderr)
@@ -474,7 +504,7 @@ def main():
     wd.stop()
     if rank == 0 and world == 1 and not args.no_extras:
         try:
-            line["extra"] = {"contrastive_4096x128": contrastive_numbers(device, steps=50, warmup=10)}
+            line.setdefault("extra", {})["contrastive_4096x128"] = contrastive_numbers(device, steps=50, warmup=10)
         except Exception as e:  # noqa: BLE001
             print(f"[bench] contrastive extra failed: {type(e).__name__}: {e}", file=sys.stderr)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -492,6 +522,7 @@ def local_step(step):
     def run():
         with epocher.meters.focus_on(epocher.meter_focus):
             epocher.step_update(epocher.step_compute(batch, seed=7))
+    run.epocher = epocher
     return run
 
 

@@ -368,6 +368,12 @@ int spcl_radam_step(float* param, const float* grad, float* exp_avg, float* exp_
  * (of device pointers / floats) read at call time: ONE launch for all of a step's meter updates. */
 int spcl_accumulate_scalars(int k, const void* const* src, void* const* dst, const float* count, void* stream);
 
+/* Per-step HOST inputs of a hipGraph-captured step (the label vector `torch.Tensor(target)` of
+ * contrastyou/losses/contrast_loss3.py:133-139, the per-sample flip decisions of semi_seg/epochers/new_pretrain.py:57-58):
+ * nbytes (multiple of 4) bytes of host memory are copied to the persistent device block dst, in stream order.  The bytes
+ * travel as kernel arguments (read at call time: host_src may be reused as soon as the call returns), 3 584 per launch. */
+int spcl_stage_bytes(void* dst, const void* host_src, size_t nbytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * Pre-train augmentation on device (replaces the PIL recipe of semi_seg/augment.py:6-22
  * `ACDCStrongTransforms.pretrain`: RandomRotation -> RandomVerticalFlip -> RandomHorizontalFlip -> RandomCrop ->

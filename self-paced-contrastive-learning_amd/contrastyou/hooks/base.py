@@ -83,6 +83,18 @@ class EpocherHook:
     def close(self):
         return None
 
+    # ---- hipGraph replay of the epocher's step (stepgraph.py; no counterpart in the reference)
+    def graph_key(self):
+        """A hashable description of every HOST value this hook's ``__call__`` bakes into its kernel launches (weights,
+        age parameter, shapes of its own), or None when a captured step cannot stand in for a call -- the default: a hook
+        that does not say so is never replayed.  Per-step host data must reach the kernels through
+        ``epocher.stage.bind`` (label vectors do)."""
+        return None
+
+    def after_replay(self):
+        """called after each replayed step (the hook's ``__call__`` did not run): deferred host-side checks"""
+        return None
+
 
 def _silent_phase(self, **kwargs):
     return None
@@ -124,6 +136,15 @@ class CombineEpochHook(EpocherHook):
 
     def close(self):
         self._broadcast("close")
+
+    def graph_key(self):
+        keys = tuple(h.graph_key() if hasattr(h, "graph_key") else None for h in self._epocher_hook)
+        return None if any(k is None for k in keys) else ("combine",) + keys
+
+    def after_replay(self):
+        for h in self._epocher_hook:
+            if hasattr(h, "after_replay"):
+                h.after_replay()
 
 
 def _fan_out(phase):

@@ -22,6 +22,10 @@ from ... import functional as F_hip
 __all__ = ["SupConLoss1", "SelfPacedSupConLoss", "is_normalized", "exp_sim_temperature", "supcon_heads"]
 
 
+def _capturing() -> bool:
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
 def is_normalized(feature: Tensor, dim=1) -> bool:
     """contrast_loss3.py:20-22 (host-side helper; the fused kernel evaluates the same test on device)."""
     norms = feature.norm(dim=dim)
@@ -74,8 +78,8 @@ class _SupConBase(nn.Module):
             proj_feat1, proj_feat2 = stacked, None
         loss = F_hip.supcon_loss(proj_feat1, proj_feat2, labels_t, mask_t, t=self._t, sp_mode=sp_mode, gamma=gamma,
                                  correct_grad=correct_grad, state=self._state)
-        if self.sync_checks:
-            self.check()
+        if self.sync_checks and not _capturing():
+            self.check()  # (a captured step is checked after its replay: _INFONCEEpochHook.after_replay)
         return loss
 
     # ---- deferred contract checks -------------------------------------------------------------------------
@@ -126,7 +130,7 @@ class SupConLoss1(_SupConBase):
         out = torch.empty(8, dtype=torch.float32, device=proj_feat1.device)
         loss = F_hip.supcon_loss_exclude_other_pos(proj_feat1, proj_feat2, labels_t, mask_t, t=self._t, out=out)
         self._state.out = out
-        if self.sync_checks:
+        if self.sync_checks and not _capturing():
             self.check()
         return loss
 
@@ -215,6 +219,6 @@ def supcon_heads(criteria, projections, targets):
     for c, st in zip(criteria, states):
         c._state, c._taps_cache, c._host_out = st, None, None
     for c in criteria:
-        if c.sync_checks:
+        if c.sync_checks and not _capturing():
             c.check()
     return list(losses.unbind(0))

@@ -37,6 +37,23 @@ def flush_batch():
         _n.call("spcl_accumulate_scalars", k, src, dst, cnt, _n.stream())
 
 
+# ---- host-side adds of a captured step: a hipGraph replay repeats the step's device work but not the python floats its
+# hooks hand to the meters (``age_param``); between begin_host_log() and end_host_log() they are remembered so that
+# stepgraph.StepGraph can re-apply them after every replay.
+_HOST_LOG = None
+
+
+def begin_host_log():
+    global _HOST_LOG
+    _HOST_LOG = []
+
+
+def end_host_log():
+    global _HOST_LOG
+    log, _HOST_LOG = _HOST_LOG, None
+    return log or []
+
+
 class AverageValueMeter:
     """Running mean.  Tensor values are accumulated IN PLACE into persistent device scalars (sum and count), so the
     accumulation is a pair of tiny device ops that also replay correctly from a captured hipGraph."""
@@ -63,6 +80,8 @@ class AverageValueMeter:
             for x in value:
                 self.add(x, n)
         else:
+            if _HOST_LOG is not None:
+                _HOST_LOG.append((self, float(value), n))
             self._sum += float(value) * n
             self._n += n
 

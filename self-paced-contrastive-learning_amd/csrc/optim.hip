@@ -3,6 +3,7 @@
 // torch's foreach implementation is ~40 elementwise launches over the 1.3 M-element flat parameter (~270 us per
 // step); this is one 1-thread "tick" (step counter + the scalar coefficients, in double) and one streaming kernel
 // (p, g, m, v read once, p, m, v written once: 28 bytes per element).
+#include <string.h>
 #include "common.hpp"
 
 namespace spcl {
@@ -90,6 +91,34 @@ extern "C" int spcl_accumulate_scalars(int k, const void* const* src, void* cons
   }
   SPCL_LAUNCH(accumulate_scalars_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
   SPCL_LAUNCH_CHECK("accumulate_scalars");
+  return SPCL_OK;
+}
+
+// Per-step host inputs of a captured step (label vectors, flip flags, scalars): the bytes travel AS KERNEL ARGUMENTS
+// (copied at launch time: no pinned host buffer whose lifetime the caller would have to guard, no DMA engine) and one
+// tiny launch writes them to their persistent device block, in stream order ahead of the replay that reads them.
+constexpr int STAGE_WORDS = 896;  // 3 584 bytes per launch (kernel arguments are limited to 4 KB)
+struct StageWords {
+  uint32_t w[STAGE_WORDS];
+};
+__global__ __launch_bounds__(256) void stage_bytes_kernel(uint32_t* __restrict__ dst, int nwords, StageWords s) {
+  for (int i = threadIdx.x; i < nwords; i += 256) dst[i] = s.w[i];
+}
+
+extern "C" int spcl_stage_bytes(void* dst, const void* host_src, size_t nbytes, void* stream) {
+  SPCL_CHECK_ARG(dst && host_src, "stage_bytes: null pointer");
+  SPCL_CHECK_ARG(nbytes % 4 == 0 && (uintptr_t)dst % 4 == 0, "stage_bytes: size and destination must be multiples of 4");
+  const uint32_t* src = (const uint32_t*)host_src;
+  uint32_t* d = (uint32_t*)dst;
+  size_t left = nbytes / 4;
+  while (left > 0) {
+    const int n = left > (size_t)STAGE_WORDS ? STAGE_WORDS : (int)left;
+    StageWords s;
+    memcpy(s.w, src, (size_t)n * 4);
+    SPCL_LAUNCH(stage_bytes_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, d, n, s);
+    src += n; d += n; left -= n;
+  }
+  SPCL_LAUNCH_CHECK("stage_bytes");
   return SPCL_OK;
 }
 

@@ -75,6 +75,7 @@ _SIGNATURES = {
     "spcl_bnrelu_backward_image_wgrad": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P,
                                                  c_int, _P, _P, _P, _P, _P]),
     "spcl_accumulate_scalars": (c_int, [c_int, _P, _P, _P, _P]),
+    "spcl_stage_bytes": (c_int, [_P, _P, c_size_t, _P]),
     "spcl_conv_dgrad_bnstats_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "spcl_conv3x3_dgrad_bnstats": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "spcl_conv_dgrad_poolstats_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),

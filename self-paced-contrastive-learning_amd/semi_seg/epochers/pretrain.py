@@ -15,6 +15,8 @@ from torch import nn
 from ...contrastyou import meters as _meters
 from ...contrastyou.meters import AverageValueMeter, MeterInterface
 from ... import ddp as _ddp
+from ... import native as _n
+from ... import stepgraph as _sg
 from .helper import FixRandomSeed, TensorRandomFlip
 
 
@@ -41,7 +43,7 @@ class PretrainEncoderEpocher:
 
     def __init__(self, *, model: nn.Module, optimizer, chain_dataloader: Iterable, num_batches: int, cur_epoch=0,
                  device="cuda", inference_until: str = "Conv5", grad_bucket: Optional[_ddp.GradBucket] = None,
-                 flat_params: Optional[_ddp.FlatParams] = None, **kwargs) -> None:
+                 flat_params: Optional[_ddp.FlatParams] = None, graph: Optional[bool] = None, **kwargs) -> None:
         self._model = model
         self._optimizer = optimizer
         self._chain_dataloader = chain_dataloader
@@ -59,6 +61,13 @@ class PretrainEncoderEpocher:
             self.meters.register_meter("reg_loss", AverageValueMeter())
         self.cur_batch_num = 0
         self._ones = {}
+        # the step as a hipGraph (stepgraph.py): on by default where it can work -- a CUDA device, the flat parameter with
+        # the fused optimizer, hooks that declare what they bake into their launches (``graph_key``)
+        self._graph_on = _sg.graph_default() if graph is None else bool(graph)
+        self.stage = None       # stepgraph.StepStage: the step's host-written inputs (hooks bind their label slots)
+        self._step_graph = None
+        self._pair = None       # persistent [2n, C, H, W] input pair of the captured step
+        self._staged = None
 
     # ---- contrastyou/epochers/base.py:47-60
     def add_hook(self, hook):
@@ -128,11 +137,85 @@ class PretrainEncoderEpocher:
             self.step(data)
 
     def step(self, data, seed=None):
-        """One iteration of new_pretrain.py:53-89; returns the (device) regularisation loss."""
+        """One iteration of new_pretrain.py:53-89; returns the (device) regularisation loss.  Replayed from a hipGraph
+        once the step's shape has been seen (``graph=`` / SPCL_STEP_GRAPH, stepgraph.py); the replay returns the captured
+        step's loss tensor, which then holds the new step's value."""
+        key = self._graph_key(data) if self._graph_on else None
+        if key is not None:
+            return self._step_staged(data, seed, key)
         reg_loss = self.step_compute(data, seed)
         self.step_exchange()
         self.step_update(reg_loss)
         return reg_loss
+
+    # ---- the captured step
+    def _graph_key(self, data):
+        """everything a capture of this step bakes into its launches, or None when the step cannot be captured: images'
+        shape and dtype, the batch size, and what every hook declares (``EpocherHook.graph_key``: class, weight, age
+        parameter ...)."""
+        from ...optim import FusedRAdam
+        flat = self._flat_params
+        if (self._device.type != "cuda" or flat is None or not isinstance(self._optimizer, FusedRAdam)
+                or getattr(flat, "_early_idx", None) is not None or not self._hooks
+                or tuple(self._affine_transformer._axis) != (1, 2)):
+            return None
+        (image, image_tf, *_), _, (partition_list, group_list) = data
+        if not (torch.is_tensor(image) and torch.is_tensor(image_tf) and image.dim() == 4
+                and image.shape == image_tf.shape and image.dtype == image_tf.dtype and image.is_floating_point()
+                and len(partition_list) == len(image) == len(group_list)):
+            return None
+        if self._pair is not None and (self._pair.shape[1:] != image.shape[1:] or self._pair.shape[0] != 2 * len(image)
+                                       or self._pair.dtype != image.dtype):
+            return None  # a ragged last batch: that step runs eagerly, the graph of the full shape stays valid
+        keys = []
+        for h in self._hooks:
+            k = h.graph_key() if hasattr(h, "graph_key") else None
+            if k is None:
+                return None
+            keys.append(k)
+        return (tuple(image.shape), image.dtype, self._inference_until, _ddp.is_distributed(), tuple(keys))
+
+    def _flip_flags(self, batch):
+        """the flag bytes ``TensorRandomFlip`` would act on under ``FixRandomSeed(seed)`` (new_pretrain.py:57-58)"""
+        with FixRandomSeed(batch["seed"]):
+            dec = self._affine_transformer.decisions(batch["n"])
+        flags = [int(d[0]) | (int(d[1]) << 1) for d in dec]
+        return flags + [0] * (-len(flags) % 4)
+
+    def _step_staged(self, data, seed, key):
+        seed = random.randint(0, int(1e7)) if seed is None else seed
+        (image, image_tf), _, filename, unl_partition, unl_group = unzip_twice_transformed(data, self._device)
+        n = len(image)
+        if self.stage is None:
+            self.stage = _sg.StepStage(self._device)
+            self._pair = torch.empty((2 * n,) + tuple(image.shape[1:]), dtype=image.dtype, device=self._device)
+            self._step_graph = _sg.StepGraph(self._compute_staged, self.step_exchange, self.step_update,
+                                             split=_ddp.is_distributed())
+        batch = {"seed": seed, "n": n, "partition_group": list(unl_partition), "label_group": list(unl_group),
+                 "filename": filename}
+        self.stage.begin(batch)  # every bound slot (labels, flags) refilled from this batch, one upload
+        try:
+            flags = self.stage.bind("flip_flags", (n + 3) // 4 * 4, "u8", self._flip_flags)
+            a, b = image.contiguous(), image_tf.contiguous()
+            N, C, H, W = a.shape
+            _n.call("spcl_flip_pair", _n.ptr(a), _n.ptr(b), _n.ptr(self._pair), a.element_size(), N, C, H, W,
+                    _n.ptr(flags), _n.stream())  # the loader's tensors -> the persistent pair (eager, in front of the replay)
+            self._staged = batch
+            if hasattr(self._optimizer, "sync_lr"):
+                self._optimizer.sync_lr()
+            loss = self._step_graph.run(key)
+            if self._step_graph.captured:
+                for h in self._hooks:
+                    h.after_replay()
+        finally:
+            self.stage.end()
+        return loss
+
+    def _compute_staged(self):
+        batch, n = self._staged, self._staged["n"]
+        _meters.begin_batch()
+        return self._compute_views(self._pair[:n], self._pair[n:], batch["seed"], batch["partition_group"],
+                                   batch["label_group"], batch["filename"])
 
     # the three phases of a step, separately callable so that a driver can capture the compute and the update in
     # hipGraphs and keep the collective outside when a whole-step capture is not possible
@@ -153,6 +236,11 @@ class PretrainEncoderEpocher:
         else:
             with FixRandomSeed(seed):
                 unlabeled_image_tf = self._affine_transformer.apply_batch(unlabeled_image_tf)
+        return self._compute_views(unlabeled_image, unlabeled_image_tf, seed, unl_partition, unl_group,
+                                   unlabeled_filename)
+
+    def _compute_views(self, unlabeled_image, unlabeled_image_tf, seed, unl_partition, unl_group, unlabeled_filename):
+        """new_pretrain.py:60-83 from the two (flipped) views on: forward, hooks, backward, gradient gather"""
         unlabeled_logits, unlabeled_tf_logits = self.forward_pass(unlabeled_image=unlabeled_image,
                                                                   unlabeled_image_tf=unlabeled_image_tf)
         # new_pretrain.py:64-65 flips the Conv5 "logits" as well; the InfoNCE hook only takes len() of them

@@ -224,7 +224,14 @@ class _INFONCEEpochHook(EpocherHook):
 
     def _labels(self, partition_group, label_group, device):
         """labels as a device tensor; cached per distinct (partition, group) content so that a repeated batch
-        composition (the synthetic benchmark) costs no host->device copy."""
+        composition (the synthetic benchmark) costs no host->device copy.  In a staged step (the epocher replays its
+        step from a hipGraph, stepgraph.py) the vector lives in this hook's slot of the epocher's stage, which the
+        epocher refills from every new batch."""
+        stage = getattr(getattr(self, "_epocher", None), "stage", None)
+        if stage is not None and stage.active:
+            return stage.bind(("labels", id(self)), len(partition_group), "f32",
+                              lambda b: self._label_generator(partition_group=b["partition_group"],
+                                                              label_group=b["label_group"]))
         key = (tuple(partition_group), tuple(label_group))
         t = self._label_cache.get(key)
         if t is None:
@@ -284,6 +291,24 @@ class _INFONCEEpochHook(EpocherHook):
     def close(self):
         self._extractor.remove()
 
+    def graph_key(self):
+        """replayable when the projector pools to (1, 1) (no seeded feature flip, `_two_views`) and no TensorBoard tap is
+        still due; bakes the loss weight and the criterion's scalars (age parameter: changes per epoch)"""
+        if tuple(getattr(self._projector, "_spatial_size", (1, 1))) != (1, 1):
+            return None
+        if self._tap_callback is not None and self._n < 2:
+            return None
+        c = self._criterion
+        return (type(self).__name__, self._name, float(self._weight), type(c).__name__, float(c._t),
+                getattr(c, "age_param", None), getattr(c, "_weight_update", None), getattr(c, "_correct_grad", None),
+                getattr(c, "_exclude_pos", None))
+
+    def after_replay(self):
+        c = self._criterion
+        c._taps_cache = c._host_out = None  # the captured result block now holds the new step's values
+        if c.sync_checks:
+            c.check()  # the reference's unit-norm assertion / NaN guard, one readback (as in an eager step)
+
 
 class _SPINFONCEEpochHook(_INFONCEEpochHook):
     @meter_focus
@@ -317,6 +342,9 @@ class _INFONCEDenseHook(_INFONCEEpochHook):
     """:201-241: contrast ``point_nums`` pixels per slice of the dense (decoder) projection between the
     two views -- every sampled point is its own class, its positive is the same point of the other view."""
     point_nums = 5
+
+    def graph_key(self):
+        return None  # seeded feature flips and freshly drawn point indices every step: runs eagerly
 
     @meter_focus
     def __call__(self, *, affine_transformer, seed, unlabeled_tf_logits, unlabeled_logits_tf, partition_group,

@@ -1,0 +1,196 @@
+"""A training step replayed from a hipGraph INSIDE the epocher loop (``semi_seg/epochers/new_pretrain.py:52-89`` is the
+loop being mirrored): the ~90 kernel launches of a pre-train step cost ~4 ms of host time when issued one by one and
+1.2 ms of GPU time, so the product loop -- not only the benchmark -- captures the step once and replays it.
+
+What changes from step to step is HOST data: the label vectors the hooks build from the batch's strings, the per-sample
+flip decisions drawn from the step's seed, and the loader's fresh image tensors.  They reach the replayed kernels
+through persistent device memory:
+
+* ``StepStage``: ONE persistent device block of slots.  A slot is bound to a *fill function* ``fill(batch) -> values`` by
+  whoever consumes it (a hook binds its label vector, the epocher its flip flags); before every step all slots are
+  refilled from the new batch on the host and uploaded by ``spcl_stage_bytes`` (the bytes travel as kernel arguments:
+  one tiny launch, nothing to keep alive).  The captured kernels read the slots by pointer.
+* the images are copied (view 1) / flipped (view 2) into a persistent ``[2n, C, H, W]`` buffer by ONE eager launch
+  (``spcl_flip_pair``) in front of the replay: the loader's tensors may live anywhere.
+
+``StepGraph`` is the small state machine around it: the first steps of a shape run eagerly (they are real steps, and
+they warm the allocator), the next one is captured and replayed, every later one is refill + upload + replay.  With
+``torch.distributed`` initialised the collective stays outside: compute graph, eager all-reduce, update graph.  Host-side
+effects of a step that a replay would lose (meter adds of python floats) are logged at capture and re-applied.
+Values that are baked into the capture (the age parameter gamma, changed once per epoch by
+``SelfPacedINFONCEHook.__call__``) are part of the graph's key: a new epocher captures anew."""
+from __future__ import annotations
+
+import ctypes
+import os
+import warnings
+
+import numpy as np
+import torch
+
+from . import native as _n
+
+_DTYPES = {"f32": np.float32, "u8": np.uint8, "i32": np.int32}
+
+
+class StepStage:
+    """persistent device block + host mirror of a step's host-written inputs (see the module docstring)"""
+
+    def __init__(self, device, capacity: int = 64 * 1024):
+        self.device = torch.device(device)
+        self.capacity = capacity
+        self._dev = torch.zeros(capacity, dtype=torch.uint8, device=self.device)
+        self._host = np.zeros(capacity, dtype=np.uint8)
+        self._slots = {}   # key -> (offset, count, numpy dtype, fill, device view)
+        self._used = 0
+        self.active = False  # True while a staged step runs: consumers bind / read their slots
+        self.batch = None    # the current step's host-side description (what the fill functions receive)
+
+    # ---- consumers
+    def bind(self, key, count: int, kind: str, fill):
+        """device view (``count`` elements of ``kind`` in f32 / u8 / i32) of slot ``key``, created on first use and filled
+        from the current batch; ``fill(batch)`` returns ``count`` values.  Later steps refill it in ``begin``."""
+        dt = _DTYPES[kind]
+        slot = self._slots.get(key)
+        if slot is not None and (slot[1] != count or slot[2] is not dt):
+            raise RuntimeError(f"StepStage: slot {key!r} was bound with {slot[1]} x {slot[2].__name__}, now {count} x "
+                               f"{dt.__name__} (a different batch shape needs its own stage)")
+        if slot is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError(f"StepStage: slot {key!r} first bound during graph capture (the eager steps before the "
+                                   "capture must take the same path)")
+            nbytes = (count * np.dtype(dt).itemsize + 15) // 16 * 16
+            if self._used + nbytes > self.capacity:
+                raise RuntimeError("StepStage: capacity exceeded")
+            off = self._used
+            self._used += nbytes
+            tdt = {np.float32: torch.float32, np.uint8: torch.uint8, np.int32: torch.int32}[dt]
+            view = self._dev[off:off + count * np.dtype(dt).itemsize].view(tdt)
+            slot = self._slots[key] = (off, count, dt, fill, view)
+            self._write(slot)
+            self._upload(off, nbytes)  # first use: this slot alone, in stream order ahead of its consumer
+        return slot[4]
+
+    # ---- the epocher
+    def begin(self, batch):
+        """a staged step starts: refill every slot from ``batch`` and upload the block (one launch per 3.5 KB)"""
+        self.batch = batch
+        self.active = True
+        if self._slots:
+            for slot in self._slots.values():
+                self._write(slot)
+            self._upload(0, self._used)
+
+    def end(self):
+        self.active = False
+
+    def _write(self, slot):
+        off, count, dt, fill, _ = slot
+        vals = np.asarray(fill(self.batch), dtype=dt).reshape(-1)
+        if vals.size != count:
+            raise RuntimeError(f"StepStage: fill returned {vals.size} values for a slot of {count}")
+        self._host[off:off + count * vals.itemsize] = vals.view(np.uint8)
+
+    def _upload(self, off, nbytes):
+        src = self._host[off:off + nbytes]
+        _n.call("spcl_stage_bytes", ctypes.c_void_p(self._dev.data_ptr() + off), src.ctypes.data_as(ctypes.c_void_p),
+                nbytes, _n.stream())
+
+
+def graph_default() -> bool:
+    """the epochers capture their step unless SPCL_STEP_GRAPH=0"""
+    return os.environ.get("SPCL_STEP_GRAPH", "1") != "0"
+
+
+class StepGraph:
+    """Capture-and-replay state machine of one epocher's step.
+
+    ``compute()`` = forward + loss + backward + gradient gather, ``exchange()`` = the collective (eager, never
+    captured), ``update()`` = optimizer + meters; ``split`` keeps ``exchange`` between two graphs (N > 1), otherwise the
+    whole step is one graph.  ``run(key)`` executes one step: eagerly while ``warm`` steps of this ``key`` (batch shape +
+    everything baked into the kernels' arguments) have not run yet, then capture + replay, then replay."""
+
+    def __init__(self, compute, exchange, update, split: bool, warm: int = 2):
+        self._compute, self._exchange, self._update = compute, exchange, update
+        self._split, self._warm = bool(split), int(warm)
+        self.key = None
+        self._seen = 0
+        self._graphs = None
+        self._result = None
+        self._host_log = []
+        self.failed = False
+        self.replays = 0
+
+    @property
+    def captured(self):
+        return self._graphs is not None
+
+    def _eager(self):
+        loss = self._compute()
+        self._exchange()
+        self._update(loss)
+        return loss
+
+    def run(self, key):
+        from .contrastyou import meters as _meters
+        if self.failed:
+            return self._eager()
+        if key != self.key:  # a new shape / configuration: drop the graphs, start over
+            self.key, self._seen, self._graphs, self._result = key, 0, None, None
+        if self._graphs is None:
+            if self._seen < self._warm:
+                self._seen += 1
+                return self._eager()
+            try:
+                self._capture()
+            except Exception as e:  # noqa: BLE001 -- a capture that fails must not end the training run
+                self.failed = True
+                self._graphs = None
+                _meters.end_host_log()
+                try:
+                    torch.cuda.synchronize()
+                except Exception:  # noqa: BLE001
+                    pass
+                warnings.warn(f"hipGraph capture of the training step failed ({type(e).__name__}: {e}); "
+                              "continuing with eager launches")
+                return self._eager()
+            self._replay(first=True)
+            return self._result
+        self._replay(first=False)
+        return self._result
+
+    def _capture(self):
+        from .contrastyou import meters as _meters
+        torch.cuda.synchronize()
+        state = {}
+        _meters.begin_host_log()
+        try:
+            if self._split:
+                ga = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga):
+                    state["loss"] = self._compute()
+                gb = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gb, pool=ga.pool()):
+                    self._update(state["loss"])
+                self._graphs = (ga, gb)
+            else:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    state["loss"] = self._compute()
+                    self._update(state["loss"])
+                self._graphs = (g,)
+        finally:
+            self._host_log = _meters.end_host_log()
+        self._result = state["loss"]
+
+    def _replay(self, first):
+        if self._split:
+            self._graphs[0].replay()
+            self._exchange()
+            self._graphs[1].replay()
+        else:
+            self._graphs[0].replay()
+        if not first:  # the capture pass already performed the host-side adds once
+            for meter, value, n in self._host_log:
+                meter.add(value, n)
+        self.replays += 1

@@ -4,45 +4,57 @@ tuple format ((image, image_tf, target, target_tf), filenames, (partitions, grou
 import torch
 
 
-def acdc_like_meta(bs: int):
-    partitions = [str(i % 3) for i in range(bs)]
-    groups = [f"patient{i // 3:03d}_00" for i in range(bs)]
-    filenames = [f"patient{i // 3:03d}_00_{i % 3:02d}" for i in range(bs)]
+def acdc_like_meta(bs: int, shift: int = 0):
+    """``shift`` rotates the batch composition (a different slice order per batch, as a sampler would give)"""
+    idx = [(i + shift) % bs for i in range(bs)]
+    partitions = [str(i % 3) for i in idx]
+    groups = [f"patient{i // 3:03d}_00" for i in idx]
+    filenames = [f"patient{i // 3:03d}_00_{i % 3:02d}" for i in idx]
     return filenames, partitions, groups
 
 
-def prostate_like_meta(bs: int, partition_num: int = 8):
+def prostate_like_meta(bs: int, partition_num: int = 8, shift: int = 0):
     """Prostate-like batch composition (BASELINE.json configs[3]): scans "CaseNN" cut into ``partition_num`` slice
     partitions; group strings "CaseNN_k" (patient id before the underscore, semi_seg/hooks/utils.py:53-56)."""
-    partitions = [str(i % partition_num) for i in range(bs)]
-    groups = [f"Case{i // partition_num:02d}_{i % partition_num}" for i in range(bs)]
-    filenames = [f"Case{i // partition_num:02d}_{i % partition_num:03d}" for i in range(bs)]
+    idx = [(i + shift) % bs for i in range(bs)]
+    partitions = [str(i % partition_num) for i in idx]
+    groups = [f"Case{i // partition_num:02d}_{i % partition_num}" for i in idx]
+    filenames = [f"Case{i // partition_num:02d}_{i % partition_num:03d}" for i in idx]
     return filenames, partitions, groups
 
 
 class SyntheticPretrainLoader:
-    """Infinite iterator; ``resident=True`` re-yields ONE pre-generated device batch (inputs already in HBM when the
-    timed region starts), otherwise draws a fresh batch on device every step."""
+    """Infinite iterator.  ``resident=True`` cycles through ``pool`` DISTINCT pre-generated device batches (inputs already
+    in HBM when the timed region starts; every batch has its own images and its own slice order, hence its own label
+    vector); otherwise it draws a fresh batch on device every step (two ``torch.rand`` launches per step)."""
 
-    def __init__(self, bs=32, size=224, channels=1, device="cuda", seed=1234, resident=True, meta="acdc"):
+    def __init__(self, bs=32, size=224, channels=1, device="cuda", seed=1234, resident=True, meta="acdc", pool=1):
         self.bs, self.size, self.channels, self.device, self.resident = bs, size, channels, device, resident
         self.gen = torch.Generator(device=device).manual_seed(seed)
-        self.meta = prostate_like_meta(bs) if meta == "prostate" else acdc_like_meta(bs)
-        self._batch = self._draw() if resident else None
+        self._meta_fn = prostate_like_meta if meta == "prostate" else acdc_like_meta
+        self.meta = self._meta_fn(bs)
+        self._drawn = 0
+        self._pool = [self._draw() for _ in range(max(1, pool))] if resident else None
+        self._next = 0
 
     def _draw(self):
         shape = (self.bs, self.channels, self.size, self.size)
         img = torch.rand(shape, device=self.device, generator=self.gen)
         img_tf = torch.rand(shape, device=self.device, generator=self.gen)
         tgt = torch.zeros((self.bs, 1, 1, 1), dtype=torch.long, device=self.device)
-        filenames, partitions, groups = self.meta
+        filenames, partitions, groups = self.meta if self._drawn == 0 else self._meta_fn(self.bs, shift=5 * self._drawn)
+        self._drawn += 1
         return (img, img_tf, tgt, tgt), filenames, (partitions, groups)
 
     def __iter__(self):
         return self
 
     def __next__(self):
-        return self._batch if self.resident else self._draw()
+        if not self.resident:
+            return self._draw()
+        batch = self._pool[self._next]
+        self._next = (self._next + 1) % len(self._pool)
+        return batch
 
 
 class SyntheticLabeledLoader:

@@ -1,0 +1,200 @@
+"""The epocher's step replayed from a hipGraph (stepgraph.py) against the same steps launched eagerly: identical bits.
+
+The product loop ``PretrainEncoderEpocher._run_pretrain`` (mirror of semi_seg/epochers/new_pretrain.py:52-89) captures its
+step after two eager iterations; every later iteration refills the stage (label vectors, flip flags) from the new batch
+and replays.  Fresh images, a fresh slice order (hence label vector) and a fresh flip seed every step."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(graph, dtype=torch.float32, sync_checks=False, cmax=128, size=32, three_hooks=False, seed=3):
+    import spcl_amd  # noqa
+    from spcl_amd import ddp
+    from spcl_amd.optim import FusedRAdam
+    from spcl_amd.semi_seg.arch import UNet
+    from spcl_amd.semi_seg.epochers import PretrainEncoderEpocher
+    from spcl_amd.semi_seg.hooks import create_sp_infonce_hooks
+    torch.manual_seed(seed)
+    net = UNet(input_dim=1, num_classes=4, max_channel=cmax).cuda()
+    net.set_compute_dtype(dtype)
+    if three_hooks:
+        hook = create_sp_infonce_hooks(model=net, feature_names=["Conv5"] * 3, weights=[1.0, 0.5, 0.25],
+                                       contrast_ons=["partition", "patient", "self"], begin_values=8.0, end_values=8.0,
+                                       mode="soft", max_epoch=10, p=0.5, correct_grad=True, data_name="prostate",
+                                       sync_checks=sync_checks).cuda()
+    else:
+        hook = create_sp_infonce_hooks(model=net, feature_names="Conv5", weights=1.0, contrast_ons="partition",
+                                       begin_values=9.0, end_values=9.0, mode="soft", max_epoch=10, p=0.5,
+                                       correct_grad=True, data_name="acdc", sync_checks=sync_checks).cuda()
+    for name in net.decoder_names:
+        getattr(net, "_" + name).requires_grad_(False)
+    flat = ddp.FlatParams([p for p in net.parameters() if p.requires_grad] + list(hook.parameters()))
+    opt = FusedRAdam([flat.param], lr=2e-3, weight_decay=1e-5)
+    ep = PretrainEncoderEpocher(model=net, optimizer=opt, chain_dataloader=iter([]), num_batches=100, device="cuda",
+                                inference_until="Conv5", flat_params=flat, graph=graph)
+    ep.add_hooks([hook()])
+    net.train()
+    return net, hook, flat, opt, ep
+
+
+def _batches(steps, bs, size, meta="acdc", seed=17):
+    from spcl_amd.synthetic import acdc_like_meta, prostate_like_meta
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    tgt = torch.zeros(bs, 1, 1, 1, dtype=torch.long).cuda()
+    for k in range(steps):
+        a, b = torch.rand(bs, 1, size, size, generator=g).cuda(), torch.rand(bs, 1, size, size, generator=g).cuda()
+        fn, part, grp = (prostate_like_meta(bs, 4, shift=3 * k) if meta == "prostate" else acdc_like_meta(bs, shift=5 * k))
+        out.append(((a, b, tgt, tgt), fn, (part, grp)))
+    return out
+
+
+def _run(ep, batches, seeds=None):
+    curve = []
+    random.seed(99)
+    with ep.meters.focus_on(ep.meter_focus):
+        for k, batch in enumerate(batches):
+            loss = ep.step(batch, seed=None if seeds is None else seeds[k])
+            curve.append(loss.detach().clone())
+    torch.cuda.synchronize()
+    return [float(c) for c in curve]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_graphed_steps_equal_eager_steps_bit_for_bit(dtype):
+    steps, bs = 7, 12
+    res = {}
+    for graph in (False, True):
+        net, hook, flat, opt, ep = _setup(graph, dtype)
+        curve = _run(ep, _batches(steps, bs, 32))
+        sg = ep._step_graph
+        if graph:
+            assert sg is not None and sg.captured and not sg.failed and sg.replays == steps - 2, (sg.replays,)
+        else:
+            assert sg is None
+        stats = ep.meters.statistics()["semi"]
+        res[graph] = (curve, flat.data.clone(), {k: v.clone() for k, v in net.state_dict().items()},
+                      {k: v["mean"] for k, v in stats.items()},
+                      [float(s) for s in opt.state[flat.param]["step"].reshape(1)])
+    ce, cg = res[False][0], res[True][0]
+    assert ce == cg, (ce, cg)
+    assert len(set(ce)) == steps  # the batches (and so the losses) really differ from step to step
+    assert torch.equal(res[False][1], res[True][1])
+    for k, v in res[False][2].items():
+        assert torch.equal(v, res[True][2][k]), k
+    assert res[False][4] == res[True][4] == [float(steps)]
+    for k, v in res[False][3].items():  # meters: loss, sp_weight, age_param (a python float re-applied per replay), reg_loss
+        np.testing.assert_allclose(v, res[True][3][k], rtol=1e-6, err_msg=k)
+    assert set(res[True][3]) >= {"loss", "sp_weight", "age_param", "reg_loss"}
+
+
+def test_graphed_three_hooks_and_sync_checks():
+    """three meta-label hooks on one feature (batched projection + batched losses, row N4) through the graph, with the
+    reference's per-step assertions on (``sync_checks=True``: checked after each replay)"""
+    steps, bs = 6, 8
+    res = {}
+    for graph in (False, True):
+        net, hook, flat, opt, ep = _setup(graph, torch.float32, sync_checks=True, three_hooks=True)
+        curve = _run(ep, _batches(steps, bs, 32, meta="prostate"))
+        if graph:
+            assert ep._step_graph.captured and ep._step_graph.replays == steps - 2
+            crit = hook._hooks[1]._criterion
+            assert 0.0 < crit.downgrade_ratio <= 1.0  # reads the captured result block after the last replay
+        res[graph] = (curve, flat.data.clone())
+    assert res[False][0] == res[True][0]
+    assert torch.equal(res[False][1], res[True][1])
+
+
+def test_replay_reports_nan_like_the_eager_step():
+    """``RuntimeError(loss)`` on NaN (contrast_loss3.py:203-204) survives the graph: checked after the replay"""
+    net, hook, flat, opt, ep = _setup(True, torch.float32, sync_checks=True)
+    batches = _batches(5, 8, 32)
+    _run(ep, batches[:4])
+    assert ep._step_graph.captured
+    with torch.no_grad():
+        flat.data[:1000] = float("nan")
+    with pytest.raises((RuntimeError, AssertionError)):
+        with ep.meters.focus_on(ep.meter_focus):
+            ep.step(batches[4])
+
+
+def test_ragged_batch_runs_eagerly_and_graph_survives():
+    net, hook, flat, opt, ep = _setup(True, torch.float32)
+    full = _batches(5, 12, 32)
+    small = _batches(1, 6, 32, seed=5)
+    _run(ep, full[:4])
+    sg = ep._step_graph
+    n = sg.replays
+    _run(ep, small)          # other shape: the old eager path
+    assert sg.replays == n and sg.captured
+    _run(ep, full[4:])
+    assert sg.replays == n + 1
+
+
+def test_new_epoch_recaptures_with_the_new_age_parameter():
+    """gamma is baked into the capture; the next epoch's hook (new gamma) belongs to a new epocher and a new graph"""
+    import spcl_amd  # noqa
+    from spcl_amd.semi_seg.epochers import PretrainEncoderEpocher
+    res = {}
+    for graph in (False, True):
+        net, hook, flat, opt, ep = _setup(graph, torch.float32)
+        hook._hooks[0]._scheduler.begin_value, hook._hooks[0]._scheduler.end_value = 4.0, 40.0
+        curves = []
+        for epoch in range(2):
+            ep = PretrainEncoderEpocher(model=net, optimizer=opt, chain_dataloader=iter([]), num_batches=100,
+                                        device="cuda", inference_until="Conv5", flat_params=flat, graph=graph)
+            ep.add_hooks([hook()])
+            curves += _run(ep, _batches(4, 12, 32, seed=30 + epoch))
+            ep.close_hooks()
+        res[graph] = (curves, flat.data.clone())
+    assert res[False][0] == res[True][0]
+    assert torch.equal(res[False][1], res[True][1])
+
+
+def test_stage_bytes_roundtrip():
+    """spcl_stage_bytes: host bytes -> device block, also beyond one launch's 3 584 bytes"""
+    import ctypes
+    from spcl_amd import native as _n
+    for nbytes in (4, 64, 3584, 3588, 9000):
+        src = np.random.RandomState(nbytes).randint(0, 256, size=nbytes, dtype=np.uint8)
+        dst = torch.zeros(nbytes + 16, dtype=torch.uint8, device="cuda")
+        _n.call("spcl_stage_bytes", _n.ptr(dst), src.ctypes.data_as(ctypes.c_void_p), nbytes, _n.stream())
+        got = dst.cpu().numpy()
+        assert np.array_equal(got[:nbytes], src) and not got[nbytes:].any()
+
+
+def test_trainer_loop_uses_the_graph():
+    """PretrainEncoderTrainer.start_training -> epocher.run -> _run_pretrain: the loop a user gets through the seam"""
+    import spcl_amd  # noqa
+    from spcl_amd.semi_seg.arch import UNet
+    from spcl_amd.semi_seg.hooks import create_sp_infonce_hooks
+    from spcl_amd.semi_seg.trainers import PretrainEncoderTrainer
+    from spcl_amd.synthetic import SyntheticPretrainLoader
+    torch.manual_seed(5)
+    net = UNet(input_dim=1, num_classes=4, max_channel=128).cuda()
+    loader = SyntheticPretrainLoader(bs=9, size=32, device="cuda", seed=3, resident=True, pool=3)
+    seen = []
+
+    class Spy(PretrainEncoderTrainer):
+        def _create_tra_epoch(self):
+            ep = super()._create_tra_epoch()
+            seen.append(ep)
+            return ep
+
+    with net.set_grad(False, start="Conv5", include_start=False):
+        tr = Spy(model=net, chain_dataloader=loader, max_epoch=3, num_batches=6, device="cuda", lr=1e-3)
+        tr.register_hooks(create_sp_infonce_hooks(model=net, feature_names="Conv5", weights=1.0, contrast_ons="partition",
+                                                  begin_values=5.0, end_values=50.0, mode="soft", max_epoch=3, p=0.5,
+                                                  correct_grad=True, data_name="acdc", sync_checks=False))
+        tr.init()
+        hist = tr.start_training()
+    assert len(hist) == 2 and len(seen) == 2
+    for ep in seen:
+        assert ep._step_graph is not None and ep._step_graph.captured and ep._step_graph.replays == 4
+    for h in hist:
+        assert np.isfinite(h["semi"]["loss"]["mean"])
