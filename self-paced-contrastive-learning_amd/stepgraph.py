@@ -120,6 +120,10 @@ class StepGraph:
         self._host_log = []
         self.failed = False
         self.replays = 0
+        # warm steps AND the capture run on one private stream: autograd's AccumulateGrad nodes remember the stream they
+        # were created on, and a node kept alive from an eager step on the default stream would make the capture wait on
+        # (i.e. fork into) the default stream
+        self._stream = None
 
     @property
     def captured(self):
@@ -131,6 +135,16 @@ class StepGraph:
         self._update(loss)
         return loss
 
+    def _warm_step(self):
+        if self._stream is None:
+            self._stream = torch.cuda.Stream()
+        cur = torch.cuda.current_stream()
+        self._stream.wait_stream(cur)
+        with torch.cuda.stream(self._stream):
+            loss = self._eager()
+        cur.wait_stream(self._stream)
+        return loss
+
     def run(self, key):
         from .contrastyou import meters as _meters
         if self.failed:
@@ -140,7 +154,7 @@ class StepGraph:
         if self._graphs is None:
             if self._seen < self._warm:
                 self._seen += 1
-                return self._eager()
+                return self._warm_step()
             try:
                 self._capture()
             except Exception as e:  # noqa: BLE001 -- a capture that fails must not end the training run
@@ -167,15 +181,15 @@ class StepGraph:
         try:
             if self._split:
                 ga = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga):
+                with torch.cuda.graph(ga, stream=self._stream):
                     state["loss"] = self._compute()
                 gb = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gb, pool=ga.pool()):
+                with torch.cuda.graph(gb, pool=ga.pool(), stream=self._stream):
                     self._update(state["loss"])
                 self._graphs = (ga, gb)
             else:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, stream=self._stream):
                     state["loss"] = self._compute()
                     self._update(state["loss"])
                 self._graphs = (g,)

@@ -77,9 +77,9 @@ def test_graphed_steps_equal_eager_steps_bit_for_bit(dtype):
             assert sg is not None and sg.captured and not sg.failed and sg.replays == steps - 2, (sg.replays,)
         else:
             assert sg is None
-        stats = ep.meters.statistics()["semi"]
+        stats = ep.meters.statistics()
         res[graph] = (curve, flat.data.clone(), {k: v.clone() for k, v in net.state_dict().items()},
-                      {k: v["mean"] for k, v in stats.items()},
+                      {f"{g}/{k}": v["mean"] for g, ms in stats.items() for k, v in ms.items()},
                       [float(s) for s in opt.state[flat.param]["step"].reshape(1)])
     ce, cg = res[False][0], res[True][0]
     assert ce == cg, (ce, cg)
@@ -90,7 +90,7 @@ def test_graphed_steps_equal_eager_steps_bit_for_bit(dtype):
     assert res[False][4] == res[True][4] == [float(steps)]
     for k, v in res[False][3].items():  # meters: loss, sp_weight, age_param (a python float re-applied per replay), reg_loss
         np.testing.assert_allclose(v, res[True][3][k], rtol=1e-6, err_msg=k)
-    assert set(res[True][3]) >= {"loss", "sp_weight", "age_param", "reg_loss"}
+    assert {k.split("/")[-1] for k in res[True][3]} >= {"loss", "sp_weight", "age_param", "reg_loss"}
 
 
 def test_graphed_three_hooks_and_sync_checks():
@@ -117,7 +117,7 @@ def test_replay_reports_nan_like_the_eager_step():
     _run(ep, batches[:4])
     assert ep._step_graph.captured
     with torch.no_grad():
-        flat.data[:1000] = float("nan")
+        flat.data[-300:] = float("nan")  # the projector's last bias (a NaN in a conv weight dies in the next ReLU's fmax)
     with pytest.raises((RuntimeError, AssertionError)):
         with ep.meters.focus_on(ep.meter_focus):
             ep.step(batches[4])
@@ -197,4 +197,4 @@ def test_trainer_loop_uses_the_graph():
     for ep in seen:
         assert ep._step_graph is not None and ep._step_graph.captured and ep._step_graph.replays == 4
     for h in hist:
-        assert np.isfinite(h["semi"]["loss"]["mean"])
+        assert np.isfinite(h["semi"]["reg_loss"]["mean"])

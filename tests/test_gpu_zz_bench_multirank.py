@@ -52,6 +52,6 @@ def test_bench_two_ranks_on_one_device(tmp_path):
     assert len(lines) == 1, out[-2000:]  # rank 0 only
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak"
-    assert line["config"]["hipgraph"] == "split" and line["config"]["global_batch"] == 8
+    assert line["config"]["hipgraph"] == "epocher-split" and line["config"]["global_batch"] == 8
     assert line["value"] > 0 and line["final_meters"]["loss"] == line["final_meters"]["loss"]  # finite loss
     assert line["roofline"] is not None and line["roofline"]["frac"] > 0 and "cpu_baseline" not in line
