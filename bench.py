@@ -159,21 +159,6 @@ def build_step(args, device, rank, world):
     return step, epocher, nparams
 
 
-def graph_capture(step, device):
-    """Capture one whole step (fwd + bwd + all-reduce + optimizer) in a hipGraph: removes ~200 launches of host time."""
-    s = torch.cuda.Stream(device=device)
-    s.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(s):
-        for _ in range(3):
-            step()
-    torch.cuda.current_stream().wait_stream(s)
-    torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
-        step()
-    return g.replay
-
-
 # ------------------------------------------------------------------------------------------------ roofline (live)
 def measure_roofline(step, args, phases=False):
     """Instrumented pass with the library's built-in kernel timer: every kernel launch of libspcl_hip.so is bracketed
@@ -562,7 +547,7 @@ def bench_finetune(args, device):
     opt = FusedRAdam([flat.param], lr=1e-4, weight_decay=1e-5)
     loader = SyntheticLabeledLoader(bs=args.bs, size=args.size, device=device, seed=77)
     ep = FineTuneEpocher(model=model, optimizer=opt, labeled_loader=loader, sup_criterion=KL_div(), num_batches=10 ** 9,
-                         device=device, flat_params=flat)
+                         device=device, flat_params=flat, graph=not args.no_graph)
     model.train()
     batch = next(loader)
 
@@ -570,7 +555,9 @@ def bench_finetune(args, device):
         with ep.meters.focus_on(ep.meter_focus):
             return ep.step(batch)
 
-    run = step if args.no_graph else graph_capture(step, device)
+    run = step  # FineTuneEpocher.step captures itself after two eager steps (stepgraph.py)
+    for _ in range(0 if args.no_graph else 3):
+        run()
     for _ in range(args.warmup):
         run()
     torch.cuda.synchronize()
@@ -586,11 +573,13 @@ def bench_finetune(args, device):
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "SURVEY N1 / BASELINE.json configs[2] fine-tune half: UNet base (max_channel=256) full "
                                    "forward+backward, softmax + KL_div on one-hot labels, RAdam",
-                       "slices_per_gpu": args.bs, "image": f"1x{args.size}x{args.size}", "hipgraph": not args.no_graph},
+                       "slices_per_gpu": args.bs, "image": f"1x{args.size}x{args.size}",
+                       "hipgraph": "epocher" if (ep._step_graph is not None and ep._step_graph.captured) else False},
             "final_meters": {"sup_loss": round(stats["sup_loss"]["mean"], 5),
                              "sup_dice": {k: round(v, 4) for k, v in stats["sup_dice"].items()}}}
     if not args.no_roofline:
         try:
+            ep._graph_on = False  # the instrumented pass launches every kernel eagerly
             roof, breakdown, tot = measure_roofline(step, args)
             line["roofline"], line["kernel_breakdown"] = roof, breakdown
             line["instrumented_step_ms"] = round(tot * 1e3, 3)

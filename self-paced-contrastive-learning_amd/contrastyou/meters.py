@@ -173,6 +173,17 @@ class UniversalDice:
         if group_name is not None:
             names = [group_name] * B if isinstance(group_name, str) else list(group_name)
         inter, union = F_hip.dice_counts(pred, target, self._C)
+        self.add_counts(inter, union, names)
+
+    def group_names_for(self, B, group_name=None):
+        """the per-sample group names ``add`` would record for a batch of ``B`` samples"""
+        if group_name is None:
+            return [str(self._n) + f"_{i:03d}" for i in range(B)]
+        return [group_name] * B if isinstance(group_name, str) else list(group_name)
+
+    def add_counts(self, inter, union, names):
+        """record one batch's per-sample intersection / union counts ([B, C] device tensors the caller hands over)"""
+        assert inter.shape == union.shape and inter.shape[0] == len(names) and inter.shape[1] == self._C
         self._intersections.append(inter)
         self._unions.append(union)
         self._group_names.extend(names)

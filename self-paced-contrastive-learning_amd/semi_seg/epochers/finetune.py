@@ -9,6 +9,7 @@ from torch import nn
 
 from ... import ddp as _ddp
 from ... import functional as F_hip
+from ... import stepgraph as _sg
 from ...contrastyou.losses.kl import class2one_hot
 from ...contrastyou import meters as _meters
 from ...contrastyou.meters import AverageValueMeter, MeterInterface, UniversalDice
@@ -97,12 +98,19 @@ class FineTuneEpocher(_EpocherBase):
     meter_focus = "semi"
 
     def __init__(self, *, model: nn.Module, optimizer, labeled_loader: Iterable, sup_criterion, num_batches: int,
-                 cur_epoch=0, device="cuda", flat_params: Optional[_ddp.FlatParams] = None, **kwargs):
+                 cur_epoch=0, device="cuda", flat_params: Optional[_ddp.FlatParams] = None,
+                 graph: Optional[bool] = None, **kwargs):
         self._optimizer = optimizer
         self._labeled_loader = labeled_loader
         self._sup_criterion = sup_criterion
         self._flat_params = flat_params
         self._unit = None
+        # the step as a hipGraph (stepgraph.py): image and label map are copied into persistent buffers in front of the
+        # replay; the Dice counts come back in persistent [B, C] tensors and are handed to the meter after it
+        self._graph_on = _sg.graph_default() if graph is None else bool(graph)
+        self._step_graph = None
+        self._static = None  # (image, target) buffers of the captured step
+        self._counts = None
         super().__init__(model=model, num_batches=num_batches, cur_epoch=cur_epoch, device=device)
 
     def configure_meters(self, meters):
@@ -121,9 +129,46 @@ class FineTuneEpocher(_EpocherBase):
         return self._model(labeled_image)
 
     def step(self, labeled_data):
-        """one iteration of ``_run_only_label`` (new_epocher.py:260-283); returns the (device) supervised loss."""
+        """one iteration of ``_run_only_label`` (new_epocher.py:260-283); returns the (device) supervised loss.  Replayed
+        from a hipGraph once the batch shape has been seen (``graph=`` / SPCL_STEP_GRAPH)."""
         (labeled_image, _), labeled_target, labeled_filename, _, label_group = \
             unzip_twice_transformed_labeled(labeled_data, self._device)
+        key = self._graph_key(labeled_image, labeled_target) if self._graph_on else None
+        if key is None:
+            sup_loss = self.step_compute(labeled_image, labeled_target)
+            self.step_exchange()
+            self.step_update(sup_loss)
+            inter, union = self._counts
+        else:
+            if self._static is None:
+                self._static = (torch.empty_like(labeled_image), torch.empty_like(labeled_target))
+                self._step_graph = _sg.StepGraph(lambda: self.step_compute(*self._static), self.step_exchange,
+                                                 self.step_update, split=_ddp.is_distributed())
+            self._static[0].copy_(labeled_image, non_blocking=True)
+            self._static[1].copy_(labeled_target, non_blocking=True)
+            if hasattr(self._optimizer, "sync_lr"):
+                self._optimizer.sync_lr()
+            sup_loss = self._step_graph.run(key)
+            inter, union = (t.clone() for t in self._counts)  # the captured step's result tensors are rewritten by the next replay
+        if self.on_master():
+            dice = self.meters["sup_dice"]
+            dice.add_counts(inter, union, dice.group_names_for(inter.shape[0], list(label_group)))
+        return sup_loss
+
+    def _graph_key(self, image, target):
+        from ...optim import FusedRAdam
+        if (self._device.type != "cuda" or self._flat_params is None or not isinstance(self._optimizer, FusedRAdam)
+                or getattr(self._flat_params, "_early_idx", None) is not None):
+            return None
+        if self._static is not None and (self._static[0].shape != image.shape or self._static[0].dtype != image.dtype
+                                         or self._static[1].shape != target.shape
+                                         or self._static[1].dtype != target.dtype):
+            return None  # ragged last batch: eager
+        return (tuple(image.shape), image.dtype, tuple(target.shape), target.dtype, _ddp.is_distributed(),
+                type(self._sup_criterion).__name__)
+
+    # the three phases of a step (compute / collective / update), as in the pre-train epocher
+    def step_compute(self, labeled_image, labeled_target):
         label_logits = self._forward_pass(labeled_image)
         onehot_target = class2one_hot(labeled_target.squeeze(1), self.num_classes)
         sup_loss = self._sup_criterion(F_hip.softmax_classes(label_logits), onehot_target, disable_assert=True)
@@ -132,19 +177,26 @@ class FineTuneEpocher(_EpocherBase):
         if self._flat_params is not None:
             self._flat_params.zero_grad()  # arms the gradient sinks: backward fills the flat bucket in place
             sup_loss.backward(gradient=self._unit)
-            self._flat_params.reduce()
+            self._flat_params.gather_grads()
         else:
             self._optimizer.zero_grad(set_to_none=True)
             sup_loss.backward(gradient=self._unit)
+        with torch.no_grad():  # Dice counts of the training batch (new_epocher.py:279-282): [B, C] intersections / unions
+            self._counts = F_hip.dice_counts(F_hip.argmax_classes(label_logits.detach()), labeled_target.squeeze(1),
+                                             self.num_classes)
+        return sup_loss
+
+    def step_exchange(self):
+        if self._flat_params is not None:
+            self._flat_params.allreduce_()
+
+    def step_update(self, sup_loss):
         self._optimizer.step()
         if self.on_master():
             with torch.no_grad():
                 _meters.begin_batch()
                 self.meters["sup_loss"].add(sup_loss.detach())
                 _meters.flush_batch()
-                self.meters["sup_dice"].add(F_hip.argmax_classes(label_logits.detach()), labeled_target.squeeze(1),
-                                            group_name=list(label_group))
-        return sup_loss
 
     def _run_only_label(self):
         for self.cur_batch_num, labeled_data in zip(range(self._num_batches), self._labeled_loader):

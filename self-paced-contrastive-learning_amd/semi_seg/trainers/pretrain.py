@@ -187,6 +187,7 @@ class PretrainEncoderTrainer:
                                          inference_until=self._inference_until or "Conv5", flat_params=self._flat)
         epocher.add_hooks([h() for h in self.__hooks__])
         epocher.init()
+        self._last_epocher = epocher
         return epocher
 
     def run_tra_epoch(self):

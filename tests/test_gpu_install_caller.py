@@ -20,7 +20,7 @@ CONFIG = {  # config/base.yaml + config/pretrain.yaml + config/hooks/spinfonce.y
     "Data": {"name": "acdc", "labeled_scan_num": 1},
     "LabeledLoader": {"shuffle": True, "batch_size": 5, "num_workers": 5},
     "UnlabeledLoader": {"shuffle": True, "batch_size": 5, "num_workers": 5},
-    "Trainer": {"save_dir": "tmp", "device": "cuda", "num_batches": 2, "max_epoch": 3, "two_stage": False,
+    "Trainer": {"save_dir": "tmp", "device": "cuda", "num_batches": 6, "max_epoch": 3, "two_stage": False,
                 "disable_bn": False, "name": None},
     "ContrastiveLoaderParams": {"scan_sample_num": 4, "partition_sample_num": 1, "num_workers": 8},
     "SPInfonceParams": {"feature_names": "Conv5", "weights": 1, "contrast_ons": "partition", "begin_values": 10000,
@@ -83,6 +83,9 @@ def test_worker_body_runs_on_the_installed_mirror(tmp_path):
         trainer.init()
         trainer.start_training()
     success(save_dir=trainer.save_dir)
+    # the loop the seam hands out replays its step from a hipGraph (stepgraph.py): 2 eager steps, capture, 4 replays
+    sg = trainer._last_epocher._step_graph
+    assert sg is not None and sg.captured and not sg.failed and sg.replays == 4
     # ---- what the run must have left behind
     assert os.path.exists(os.path.join(trainer.save_dir, ".success"))
     assert os.path.exists(os.path.join(trainer.save_dir, "last.pth"))

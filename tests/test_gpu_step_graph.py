@@ -198,3 +198,44 @@ def test_trainer_loop_uses_the_graph():
         assert ep._step_graph is not None and ep._step_graph.captured and ep._step_graph.replays == 4
     for h in hist:
         assert np.isfinite(h["semi"]["reg_loss"]["mean"])
+
+
+def test_finetune_graphed_steps_equal_eager_steps():
+    """FineTuneEpocher (new_epocher.py:260-283: full UNet, softmax + KL_div, Dice of the training batch): replayed steps
+    equal eager steps bit for bit, and the Dice meter receives every step's counts"""
+    import spcl_amd  # noqa
+    from spcl_amd import ddp
+    from spcl_amd.contrastyou.losses.kl import KL_div
+    from spcl_amd.optim import FusedRAdam
+    from spcl_amd.semi_seg.arch import UNet
+    from spcl_amd.semi_seg.epochers import FineTuneEpocher
+    steps, bs, size = 6, 6, 32
+    g = torch.Generator().manual_seed(8)
+    batches = []
+    for k in range(steps):
+        img = torch.rand(bs, 1, size, size, generator=g).cuda()
+        tgt = torch.randint(0, 4, (bs, 1, size, size), generator=g).cuda()
+        groups = [f"patient{(i + k) % 3:03d}_00" for i in range(bs)]
+        batches.append(((img, img, tgt, tgt), [f"f{i}" for i in range(bs)], (["0"] * bs, groups)))
+    res = {}
+    for graph in (False, True):
+        torch.manual_seed(4)
+        net = UNet(input_dim=1, num_classes=4, max_channel=128).cuda()
+        flat = ddp.FlatParams([p for p in net.parameters() if p.requires_grad])
+        opt = FusedRAdam([flat.param], lr=1e-3, weight_decay=1e-5)
+        ep = FineTuneEpocher(model=net, optimizer=opt, labeled_loader=iter([]), sup_criterion=KL_div(), num_batches=steps,
+                             device="cuda", flat_params=flat, graph=graph)
+        net.train()
+        curve = []
+        with ep.meters.focus_on(ep.meter_focus):
+            for b in batches:
+                curve.append(float(ep.step(b).detach()))
+        if graph:
+            assert ep._step_graph.captured and ep._step_graph.replays == steps - 2
+        stats = ep.meters.statistics()["semi"]
+        res[graph] = (curve, flat.data.clone(), stats)
+    assert res[False][0] == res[True][0]
+    assert len(set(res[False][0])) == steps
+    assert torch.equal(res[False][1], res[True][1])
+    assert res[False][2]["sup_dice"] == res[True][2]["sup_dice"]
+    np.testing.assert_allclose(res[False][2]["sup_loss"]["mean"], res[True][2]["sup_loss"]["mean"], rtol=1e-6)
