@@ -79,3 +79,36 @@ def test_infinite_random_sampler_is_a_stream_of_permutations():
     it = iter(InfiniteRandomSampler(range(5)))
     a, b = [next(it) for _ in range(5)], [next(it) for _ in range(5)]
     assert sorted(a) == sorted(b) == list(range(5))
+
+
+@pytest.mark.parametrize("kind", ["acdc", "prostate"])
+def test_sampler_and_partitions_against_the_reference_fixture(golden, kind):
+    """g7_data.npz (tools/gen_golden.py gen_data): index streams drawn by the REFERENCE's ``ContrastBatchSampler``
+    (semi_seg/data/rearr.py:37-98, imported by file path) and the partition tables of the reference's
+    ``_get_partition`` (semi_seg/data/dataset.py:34-43,66-71) on the synthetic stores' file stems -- the mirror and the
+    oracle's restatement both reproduce them exactly."""
+    g = golden("g7_data.npz")
+    store = synthetic_slice_store(scans=7, slices_per_scan=(4, 11) if kind == "acdc" else (9, 26), size=8, device="cpu",
+                                  seed=3, kind=kind)
+    stems = [str(s) for s in g[f"{kind}/stems"]]
+    assert list(store.get_memory_dictionary()["img"]) == stems
+    want_parts, want_scans = [str(p) for p in g[f"{kind}/partitions"]], [str(s) for s in g[f"{kind}/scans"]]
+    assert store.show_partitions() == want_parts
+    assert store.show_scan_names() == want_scans
+    lens = dict(zip((str(s) for s in g[f"{kind}/scan_len_names"]), (int(v) for v in g[f"{kind}/scan_len"])))
+    part = O.acdc_partition if kind == "acdc" else O.prostate_partition
+    assert [part(f, lens[s]) for f, s in zip(stems, want_scans)] == want_parts  # the oracle's restatement
+    assert len(set(want_parts)) == (3 if kind == "acdc" else 8)
+    for si, (scan_num, part_num, shuffle) in enumerate(g[f"{kind}/settings"].tolist()):
+        flat, ls = g[f"{kind}/stream{si}/flat"].tolist(), g[f"{kind}/stream{si}/lens"].tolist()
+        want, off = [], 0
+        for n in ls:
+            want.append(flat[off:off + n])
+            off += n
+        random.seed(11)
+        it = iter(ContrastBatchSampler(store, scan_sample_num=scan_num, partition_sample_num=part_num,
+                                       shuffle=bool(shuffle)))
+        assert [next(it) for _ in range(25)] == want, (kind, si)
+        random.seed(11)
+        assert [O.contrast_batch_indices(want_scans, want_parts, scan_num, part_num, bool(shuffle))
+                for _ in range(25)] == want, (kind, si)

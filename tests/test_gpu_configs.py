@@ -24,6 +24,11 @@ def _relmax(a, b):
     return np.abs(a - b).max() / max(1e-30, np.abs(b).max())
 
 
+def _cos(a, b):
+    a, b = np.asarray(a, dtype=np.float64).ravel(), np.asarray(b, dtype=np.float64).ravel()
+    return float(a @ b / max(1e-300, np.linalg.norm(a) * np.linalg.norm(b)))
+
+
 def _rell2(a, b):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     return np.linalg.norm(a - b) / max(1e-30, np.linalg.norm(b))
@@ -121,12 +126,23 @@ def _check_grads_bf16(run, emu, f32, floor=0.05, slack=2.5):
     for hi, h in enumerate(run["hook"]._hooks):
         pairs += [(f"h{hi}.{k}", p.grad, leaves_e[hi][k].grad, leaves_f[hi][k].grad)
                   for k, p in h._projector.named_parameters()]
+    table = []
     for k, g, ge, gf in pairs:
         g = g.float().cpu().numpy()
         noise = _rell2(ge.numpy(), gf.numpy())
         d_emu, d_f32 = _rell2(g, ge.numpy()), _rell2(g, gf.numpy())
         assert d_emu < max(floor, slack * noise), (k, d_emu, noise)
         assert d_f32 < max(floor, slack * noise), (k, d_f32, noise)
+        # ... and a criterion no zero, scaled or sign-flipped gradient can pass, however noisy the tensor: direction and
+        # length.  Two samples f + n1, f + n2 of the same noise (|n| = noise |f|) have cosine 1 / (1 + noise^2) in
+        # expectation (0.78 at the noisiest tensor, noise 0.53) and equal expected length.
+        cos_e, cos_f = _cos(g, ge.numpy()), _cos(g, gf.numpy())
+        ratio = float(np.linalg.norm(g) / max(1e-30, np.linalg.norm(ge.numpy())))
+        table.append((k, round(noise, 3), round(d_emu, 3), round(cos_e, 3), round(cos_f, 3), round(ratio, 3)))
+        lim = min(0.9, 1.0 / (1.0 + noise * noise) - 0.1)
+        assert cos_e > lim and cos_f > lim, (k, cos_e, cos_f, lim, noise)
+        assert 0.7 < ratio < 1.4, (k, ratio)
+    return table
 
 
 def _check_grads_fp32(run, o64, o32):
@@ -177,6 +193,36 @@ def test_config1_full_step_bf16_vs_emulating_oracle(size, bs):
     loss32, osd32, leaves32, _ = _oracle(run, "partition", 1.0, 10.0, "acdc")
     assert abs(run["loss"] - loss32) <= 3e-2 * abs(loss32)  # and not further from fp32 than bf16 storage explains
     _check_grads_bf16(run, (osd, leaves), (osd32, leaves32))
+
+
+def test_config1_full_size_bs32_bf16():
+    """BASELINE configs[1] at the metric's EXACT size -- bs = 32 -> N = 64 images of 224x224, bf16: the benchmarked launch
+    geometry (16 384 conv tiles, two-level BN finalize, one split-K slab per CU in the batched weight gradient) forward
+    AND backward, against the oracle with the same storage roundings and against the fp32 oracle."""
+    run = _step(224, 32, torch.bfloat16, "partition", 1.0, 10.0, "acdc")
+    loss, osd, leaves, rhos = _oracle(run, "partition", 1.0, 10.0, "acdc", q=O.BF16Emulation)
+    np.testing.assert_allclose(run["loss"], loss, rtol=2e-2)
+    np.testing.assert_allclose(run["hook"]._hooks[0]._criterion.downgrade_ratio, rhos[0], rtol=2e-2)
+    loss32, osd32, leaves32, _ = _oracle(run, "partition", 1.0, 10.0, "acdc")
+    assert abs(run["loss"] - loss32) <= 3e-2 * abs(loss32)
+    table = _check_grads_bf16(run, (osd, leaves), (osd32, leaves32))
+    print("tensor, noise(emu vs f32), d(hip, emu), cos(hip, emu), cos(hip, f32), |hip| / |emu|")
+    for row in table:
+        print(row)
+
+
+def test_config1_full_size_bs32_fp32():
+    """the same size in fp32 parity mode against the fp32 and fp64 oracles (`_check_grads_fp32`)"""
+    run = _step(224, 32, torch.float32, "partition", 1.0, 10.0, "acdc")
+    loss, osd, leaves, rhos = _oracle(run, "partition", 1.0, 10.0, "acdc")
+    loss64, osd64, leaves64, _ = _oracle(run, "partition", 1.0, 10.0, "acdc", dtype=torch.float64)
+    np.testing.assert_allclose(run["loss"], loss, rtol=1e-4)
+    np.testing.assert_allclose(run["loss"], loss64, rtol=1e-4)
+    np.testing.assert_allclose(run["hook"]._hooks[0]._criterion.downgrade_ratio, rhos[0], rtol=1e-4)
+    _check_grads_fp32(run, (osd64, leaves64), (osd, leaves))
+    for k, b in run["net"].named_buffers():
+        if k.startswith("_Conv") and "num_batches" not in k:
+            np.testing.assert_allclose(b.cpu().numpy(), osd[k].numpy(), rtol=1e-4, atol=1e-6, err_msg=k)
 
 
 def test_config3_three_hooks_256_fp32():

@@ -413,6 +413,69 @@ def test_pretrain_loss_curve_matches_oracle_over_steps_fp32():
         assert err < 0.1 * delta + 3e-5, (k, err, delta)
 
 
+def test_pretrain_loss_curve_bf16_tracks_the_fp32_oracle_over_24_steps():
+    """The benchmarked dtype over a multi-step run (the north star's "contrastive loss curve"): 24 consecutive pre-train
+    steps with bf16 activation storage (fresh batch, slice order and flip seed every step, FusedRAdam on the flat
+    parameter, the step replayed from the epocher's hipGraph from the third step on) next to the fp32 CPU oracle driven by
+    torch.optim.RAdam: every step's loss within 2 %, and the curve really moves."""
+    import spcl_amd  # noqa
+    from spcl_amd import ddp
+    from spcl_amd.optim import FusedRAdam
+    from spcl_amd.semi_seg.epochers import PretrainEncoderEpocher
+    from spcl_amd.semi_seg.hooks import create_sp_infonce_hooks
+    from spcl_amd.synthetic import acdc_like_meta
+    net, sd = _unet(128, 23)
+    net.set_compute_dtype(torch.bfloat16)
+    bs, steps, lr, wd, gamma, size = 12, 24, 2e-3, 1e-5, 10.0, 64
+    hook = create_sp_infonce_hooks(model=net, feature_names="Conv5", weights=1.0, contrast_ons="partition",
+                                   begin_values=gamma, end_values=gamma, mode="soft", max_epoch=10, p=0.5,
+                                   correct_grad=True, data_name="acdc", sync_checks=False).cuda()
+    for name in net.decoder_names:
+        getattr(net, "_" + name).requires_grad_(False)
+    enc_names = [k for k, p in net.named_parameters() if p.requires_grad]
+    head = hook._hooks[0]._projector
+    psd0 = {k: v.detach().cpu().clone() for k, v in head.state_dict().items()}
+    flat = ddp.FlatParams([p for p in net.parameters() if p.requires_grad] + list(hook.parameters()))
+    opt = FusedRAdam([flat.param], lr=lr, weight_decay=wd)
+    g = torch.Generator().manual_seed(19)
+    batches = [(torch.rand(bs, 1, size, size, generator=g), torch.rand(bs, 1, size, size, generator=g))
+               for _ in range(steps)]
+    metas = [acdc_like_meta(bs, shift=5 * k) for k in range(steps)]
+    tgt = torch.zeros(bs, 1, 1, 1, dtype=torch.long).cuda()
+    ep = PretrainEncoderEpocher(model=net, optimizer=opt, chain_dataloader=iter([]), num_batches=steps, device="cuda",
+                                inference_until="Conv5", flat_params=flat)
+    ep.add_hooks([hook()])
+    net.train()
+    curve = []
+    with ep.meters.focus_on(ep.meter_focus):
+        for k, (a, b) in enumerate(batches):
+            fn, part, grp = metas[k]
+            curve.append(ep.step(((a.cuda(), b.cuda(), tgt, tgt), fn, (part, grp)), seed=300 + k).detach().clone())
+    curve = [float(c) for c in curve]
+    assert ep._step_graph is not None and ep._step_graph.captured and ep._step_graph.replays == steps - 2
+    osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+           for k, v in sd.items()}
+    opsd = {k: v.clone().requires_grad_(True) for k, v in psd0.items()}
+    leaves = [osd[k] for k in enc_names] + [opsd[k] for k, _ in head.named_parameters()]
+    oopt = torch.optim.RAdam(leaves, lr=lr, weight_decay=wd)
+    ocurve = []
+    for k, (a, b) in enumerate(batches):
+        fn, part, grp = metas[k]
+        labels = O.get_label("partition", "acdc", part, grp)
+        x2 = O.apply_flips(b, O.random_flip_decisions(300 + k, bs))
+        feat = O.encoder_forward(torch.cat([a, x2], 0), osd, "Conv5", train=True, momentum=0.1)
+        z = O.projector_forward(feat, opsd)
+        r = O.supcon_loss(z[:bs], z[bs:], labels, gamma=gamma, mode="soft", correct_grad=True)
+        oopt.zero_grad()
+        r["loss"].backward()
+        oopt.step()
+        ocurve.append(float(r["loss"].detach()))
+    print("bf16 HIP :", [round(c, 4) for c in curve])
+    print("fp32 orac:", [round(c, 4) for c in ocurve])
+    np.testing.assert_allclose(curve, ocurve, rtol=2e-2)
+    assert max(ocurve) - min(ocurve) > 0.02  # the parameters really moved
+
+
 def test_bn_kat5_statistics():
     """KAT-5: after the first block the fused BN has mean 0 / biased var 1 before the affine; running_var uses the
     unbiased variance with momentum 0.1."""

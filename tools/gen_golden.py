@@ -310,6 +310,7 @@ def gen_round2(SupConLoss1):
         out[f"xpos/n{n}_d{d}/z1"], out[f"xpos/n{n}_d{d}/z2"] = z1.numpy(), z2.numpy()
     out["xpos/cases"] = np.array(cases)
     g = torch.Generator().manual_seed(77)
+    torch.manual_seed(606)  # the heads below draw their initial weights from the global generator: reproducible fixture
     # adaptive-max pooled head
     head = ProjectionHead(input_dim=32, hidden_dim=24, output_dim=16, head_type="mlp", normalize=True,
                           pool_name="adaptive_max")
@@ -335,18 +336,108 @@ def gen_round2(SupConLoss1):
     print("g6_round2:", len(cases), "xpos cases + 3 heads")
 
 
+def gen_data():
+    """round 3, SURVEY row N2: index streams of the reference's ``ContrastBatchSampler`` (semi_seg/data/rearr.py:37-98,
+    imported BY FILE PATH: it needs only the standard library and torch.utils.data.Sampler) and the partition tables of
+    the reference's ``ACDCDataset._get_partition`` / ``ProstateDataset._get_partition`` (semi_seg/data/dataset.py:34-43,
+    66-71; the module is executed with its ``contrastyou.*`` imports stubbed -- the base classes are PNG-folder readers --
+    and the two methods are called on bare instances that carry only the scan-length table and the ``group_re`` search
+    of contrastyou/data/dataset/{acdc.py:16,prostate.py} ).  Inputs: the file stems of the mirror's synthetic stores."""
+    import importlib.util
+    import random
+    import re
+    import warnings
+    spec = importlib.util.spec_from_file_location("ref_rearr", os.path.join(REF_SRC, "semi_seg", "data", "rearr.py"))
+    rearr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rearr)
+
+    # ---- semi_seg/data/dataset.py with stubbed imports
+    class _Base:
+        group_re = None
+
+        def _get_scan_name(self, filename=None, stem=None):  # contrastyou/data/dataset/base.py:179-186
+            return re.compile(self.group_re).search(stem if stem is not None else filename).group(0)
+
+    saved = {k: sys.modules.get(k) for k in ("contrastyou.augment", "contrastyou.data", "contrastyou.data.dataset",
+                                             "contrastyou.data.dataset.base", "refdata", "refdata.rearr")}
+    def _module(name, **a):
+        m = types.ModuleType(name)
+        m.__dict__.update(a)
+        return m
+
+    def mk(name, **a):
+        sys.modules[name] = _module(name, **a)
+
+    names = ("ACDCDataset", "ProstateDataset", "mmWHSCTDataset", "mmWHSMRDataset", "ProstateMDDataset")
+    if "contrastyou" not in sys.modules:
+        sys.modules["contrastyou"] = _module("contrastyou")
+    mk("contrastyou.augment", SequentialWrapper=object)
+    mk("contrastyou.data", **{n: type(n, (_Base,), {}) for n in names})
+    mk("contrastyou.data.dataset")
+    mk("contrastyou.data.dataset.base", get_stem=lambda p: os.path.splitext(os.path.basename(str(p)))[0])
+    pkg = _module("refdata")
+    pkg.__path__ = []
+    sys.modules["refdata"], sys.modules["refdata.rearr"] = pkg, rearr
+    spec = importlib.util.spec_from_file_location("refdata.dataset", os.path.join(REF_SRC, "semi_seg", "data", "dataset.py"))
+    refds = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(refds)
+    for k, v in saved.items():
+        if v is None:
+            sys.modules.pop(k, None)
+        else:
+            sys.modules[k] = v
+
+    import spcl_amd  # noqa: F401  (the mirror only supplies the synthetic file stems)
+    from spcl_amd.semi_seg.data import synthetic_slice_store
+    out = {}
+    for kind, cls, regex, info_attr in (("acdc", refds.ACDCDataset, r"patient\d+_\d+", "_acdc_info"),
+                                        ("prostate", refds.ProstateDataset, r"Case\d+", "_prostate_info")):
+        store = synthetic_slice_store(scans=7, slices_per_scan=(4, 11) if kind == "acdc" else (9, 26), size=8,
+                                      device="cpu", seed=3, kind=kind)
+        stems = list(store.get_memory_dictionary()["img"])
+        ds = cls.__new__(cls)  # a bare instance: no PNG folder
+        ds.group_re = regex
+        info = {}
+        for f in stems:
+            sname = ds._get_scan_name(f)
+            info[sname] = max(info.get(sname, 0), int(re.findall(r"\d+", f)[-1]) + 1)
+        setattr(ds, info_attr, info)
+        ds.get_memory_dictionary = lambda stems=stems: {"img": list(stems)}
+        out[f"{kind}/stems"] = np.array(stems)
+        out[f"{kind}/partitions"] = np.array([ds._get_partition(f) for f in stems])
+        out[f"{kind}/scans"] = np.array([ds._get_scan_name(f) for f in stems])
+        out[f"{kind}/scan_len_names"] = np.array(list(info.keys()))
+        out[f"{kind}/scan_len"] = np.array(list(info.values()), dtype=np.int64)
+        settings = [(3, 1, False), (5, 1, True), (2, 2, False), (6, 3, True)]
+        out[f"{kind}/settings"] = np.array([[a, b, int(c)] for a, b, c in settings], dtype=np.int64)
+        for si, (scan_num, part_num, shuffle) in enumerate(settings):
+            random.seed(11)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", DeprecationWarning)  # random.sample over dict keys (python < 3.11)
+                it = iter(rearr.ContrastBatchSampler(ds, scan_sample_num=scan_num, partition_sample_num=part_num,
+                                                     shuffle=shuffle))
+                batches = [next(it) for _ in range(25)]
+            out[f"{kind}/stream{si}/flat"] = np.array([i for b in batches for i in b], dtype=np.int64)
+            out[f"{kind}/stream{si}/lens"] = np.array([len(b) for b in batches], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "g7_data.npz"), **out)
+    print("g7_data:", {k: v.shape for k, v in out.items() if k.endswith("lens") or k.endswith("stems")})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     SupConLoss1, SelfPacedSupConLoss, ProjectionHead, UNet, SFE = _import_reference()
     if sys.argv[1:] == ["round2"]:  # only the round-2 additions (the others are unchanged)
         return gen_round2(SupConLoss1)
+    if sys.argv[1:] == ["data"]:  # only the round-3 data-path fixture
+        return gen_data()
     gen_loss(SupConLoss1, SelfPacedSupConLoss)
     gen_projector(ProjectionHead)
     gen_encoder(UNet)
     gen_step(UNet, ProjectionHead, SelfPacedSupConLoss, SFE)
     gen_decoder(UNet)
     gen_round2(SupConLoss1)
+    gen_data()
 
 
 if __name__ == "__main__":
