@@ -54,23 +54,29 @@ class GradBucket:
         before backward.  Also opens the deferred weight-gradient queue (functional.DeferredWgrads): the wide layers'
         weight gradients are written into their slices by one batched launch when ``gather`` flushes it."""
         from . import functional as _F
+        # a FRESH queue per arming: whatever an aborted step left queued (and the tensors it kept alive) is dropped
+        self._queue = _F.DeferredWgrads() if self.flat.is_cuda else None
         for p, v in zip(self.params, self.views):
             p._grad_sink = v
             p._grad_sink_armed = True
-        if self.flat.is_cuda:
-            _F.open_deferred_wgrads()
+            v._spcl_queue = self._queue
 
     def disarm_sinks(self):
-        for p in self.params:
+        for p, v in zip(self.params, self.views):
             p._grad_sink_armed = False
+            v._spcl_queue = None
+        self._queue = None
 
     def gather(self, first: int = 0, last: int = None, final: bool = True):
         """grads -> bucket (one fused foreach copy of those not already written in place) for members
         ``first .. last - 1`` (default: all).  Flushes the deferred weight gradients first; ``final`` (the step's last
         gather) also closes their queue and disarms the sinks nobody claimed.  A member without a gradient raises (see
         the constructor) or, with ``allow_missing_grads``, contributes zeros."""
-        from . import functional as _F
-        deferred = _F.flush_deferred_wgrads(close=final)
+        queue = getattr(self, "_queue", None)
+        deferred = set()
+        if queue is not None:  # this bucket's own queue: its targets are slices of THIS bucket only
+            queue.flush()
+            deferred = set(queue.targets)
         if final:
             self.disarm_sinks()
             deferred = deferred | getattr(self, "_early_deferred", set())
@@ -132,6 +138,7 @@ class FlatParams(GradBucket):
         for p in self.params:
             p.grad = None
         self.param.grad = None
+        self._early = None  # a step that never reached allreduce_() must not leave the early bucket marked as sent
         self.arm_sinks()
 
     def gather_grads(self):

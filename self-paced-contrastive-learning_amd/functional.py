@@ -633,30 +633,15 @@ class DeferredWgrads:
         self.items, self.keep, self.tails = [], [], []
 
 
-_deferred: "DeferredWgrads | None" = None
 _PACK_AT = os.environ.get("SPCL_PACK_AT", "1") != "0"  # A/B switch: 0 packs the band-GEMM layout whether or not it is used
 _TAILS = os.environ.get("SPCL_WGRAD_TAILS", "1") != "0"  # A/B switch: 0 keeps every layer's own final reduction launch
 
 
-def open_deferred_wgrads():
-    """start queueing (idempotent); returns the queue"""
-    global _deferred
-    if _deferred is None:
-        _deferred = DeferredWgrads()
-    return _deferred
-
-
-def flush_deferred_wgrads(close: bool = True):
-    """launch what is queued; returns the data pointers of the bucket slices that were written by the queue since it
-    was opened"""
-    global _deferred
-    targets = set()
-    if _deferred is not None:
-        _deferred.flush()
-        targets = _deferred.targets
-        if close:
-            _deferred = None
-    return targets
+def sink_queue(sink):
+    """the deferred weight-gradient queue of the bucket that armed ``sink`` (``ddp.GradBucket.arm_sinks`` hangs it on the
+    bucket's views), or None: every bucket owns its queue, so two buckets armed in one step never see each other's items
+    and a step that was aborted between arming and gathering leaves nothing behind for the next one"""
+    return getattr(sink, "_spcl_queue", None) if sink is not None else None
 
 
 def wgrad_batched(items, accumulate, device, tails=()):
@@ -676,9 +661,10 @@ def wgrad_batched(items, accumulate, device, tails=()):
 
 def _wgrad(x_store, dy, dt_code, N, H, W, cin, cin_s, cin_k, cout, cout_s, in_mode, scale, shift, sink=None):
     dev = dy.device
-    if (_deferred is not None and sink is not None and cin_s == cin_k
+    queue = sink_queue(sink)
+    if (queue is not None and cin_s == cin_k
             and _n.call("spcl_conv_wgrad_batched_supported", dt_code, cin, cin_s, cout, cout_s, in_mode)):
-        _deferred.add(x_store, dy, scale, shift, sink, N, H, W, cin, cin_s, cout, cout_s, in_mode)
+        queue.add(x_store, dy, scale, shift, sink, N, H, W, cin, cin_s, cout, cout_s, in_mode)
         return None  # written into the bucket slice when the queue is flushed; autograd gets no gradient from this use
     nbytes = _n.call("spcl_conv_wgrad_workspace_bytes", N, H, W, cin_k, cout_s)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
@@ -688,9 +674,9 @@ def _wgrad(x_store, dy, dt_code, N, H, W, cin, cin_s, cin_k, cout, cout_s, in_mo
         _n.call("spcl_conv3x3_wgrad", _n.ptr(x_store), _n.ptr(dy), dt_code, N, H, W, cin, cin_s, cin_k, cout, cout_s,
                 in_mode, _n.ptr(scale), _n.ptr(shift), _n.ptr(ws), _n.ptr(dw), _n.stream())
 
-    if _deferred is not None and sink is not None and _TAILS:
+    if queue is not None and _TAILS:
         # narrow layer straight into a bucket slice: its final sum joins the batched launch (no separate reduce launch)
-        if _deferred.capture_tail(sink, (ws, dy, x_store, scale, shift), launch):
+        if queue.capture_tail(sink, (ws, dy, x_store, scale, shift), launch):
             return None
         return dw
     launch()
@@ -723,8 +709,9 @@ def _bnrelu_bwd_image_wgrad(y, dact, image, dt_code, N, H, W, C, cs, st, trainin
                 _n.ptr(st[0]), _n.ptr(st[1]), _n.ptr(st[2]), _n.ptr(st[3]), int(training), _n.ptr(ws), _n.ptr(dgamma),
                 _n.ptr(dbeta), _n.ptr(dw), _n.stream())
 
-    if _deferred is not None and sinks[0] is not None and _TAILS:
-        if _deferred.capture_tail(sinks[0], (ws, dact), launch):
+    queue = sink_queue(sinks[0])
+    if queue is not None and _TAILS:
+        if queue.capture_tail(sinks[0], (ws, dact), launch):
             dw = None  # reaches the bucket slice when the queue is flushed
     else:
         launch()
@@ -769,8 +756,9 @@ def _bnrelu_bwd_rows(y, dact, image, rows, dt_code, dtype, N, H, W, C, cs, st, t
                 N, H, W, C, cs, _n.ptr(st[0]), _n.ptr(st[1]), _n.ptr(st[2]), _n.ptr(st[3]), int(training), _n.ptr(ws),
                 _n.ptr(dgamma), _n.ptr(dbeta), _n.ptr(dy), _n.ptr(dw), _n.stream())
 
-    if image is not None and _deferred is not None and sinks[0] is not None and _TAILS:
-        if _deferred.capture_tail(sinks[0], (ws, dact), launch):
+    queue = sink_queue(sinks[0]) if image is not None else None
+    if queue is not None and _TAILS:
+        if queue.capture_tail(sinks[0], (ws, dact), launch):
             first = None  # the weight gradient reaches the bucket slice when the queue is flushed
     else:
         launch()

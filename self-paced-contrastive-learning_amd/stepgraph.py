@@ -97,6 +97,9 @@ class StepStage:
                 nbytes, _n.stream())
 
 
+_SIDE_STREAMS = {}
+
+
 def graph_default() -> bool:
     """the epochers capture their step unless SPCL_STEP_GRAPH=0"""
     return os.environ.get("SPCL_STEP_GRAPH", "1") != "0"
@@ -136,8 +139,11 @@ class StepGraph:
         return loss
 
     def _warm_step(self):
-        if self._stream is None:
-            self._stream = torch.cuda.Stream()
+        if self._stream is None:  # ONE private stream per device for every StepGraph of the process (epoch after epoch)
+            dev = torch.cuda.current_device()
+            if dev not in _SIDE_STREAMS:
+                _SIDE_STREAMS[dev] = torch.cuda.Stream()
+            self._stream = _SIDE_STREAMS[dev]
         cur = torch.cuda.current_stream()
         self._stream.wait_stream(cur)
         with torch.cuda.stream(self._stream):

@@ -140,7 +140,8 @@ def _check_grads_bf16(run, emu, f32, floor=0.05, slack=2.5):
         ratio = float(np.linalg.norm(g) / max(1e-30, np.linalg.norm(ge.numpy())))
         table.append((k, round(noise, 3), round(d_emu, 3), round(cos_e, 3), round(cos_f, 3), round(ratio, 3)))
         lim = min(0.9, 1.0 / (1.0 + noise * noise) - 0.1)
-        assert cos_e > lim and cos_f > lim, (k, cos_e, cos_f, lim, noise)
+        # (measured: cos_e >= 0.936 at N = 64 x 224^2; 0.868 on a projector tensor of the 256^2 three-hook step, noise 0.52)
+        assert cos_e > min(0.9, 1.0 / (1.0 + noise * noise)) and cos_f > lim, (k, cos_e, cos_f, lim, noise)
         assert 0.7 < ratio < 1.4, (k, ratio)
     return table
 

@@ -277,11 +277,12 @@ def test_deferred_wide_weight_gradients_bf16():
             loss = loss + 0.5 * head(net(x.flip(3), until="Conv5")).sum()
         if sinks:
             flat.zero_grad()
-            assert F_._deferred is not None
+            assert flat._queue is not None and all(F_.sink_queue(v) is flat._queue for v in flat.views)
         loss.backward()
-        queued = len(F_._deferred.items) if F_._deferred is not None else 0
+        queued = len(flat._queue.items) if getattr(flat, "_queue", None) is not None else 0
         flat.gather_grads()
-        assert F_._deferred is None and not any(getattr(p, "_grad_sink_armed", False) for p in params)
+        assert flat._queue is None and not any(getattr(p, "_grad_sink_armed", False) for p in params)
+        assert all(F_.sink_queue(v) is None for v in flat.views)
         return flat.flat.clone(), queued, {k: p.grad for k, p in net.named_parameters() if p.grad is not None}
 
     for twice in (False, True):
@@ -291,6 +292,50 @@ def test_deferred_wide_weight_gradients_bf16():
         assert _relerr(f1.cpu().numpy(), f0.cpu().numpy()) < 2e-3, twice
         w = g1["_Conv5.conv.3.weight"]
         assert w.abs().max() > 0 and torch.isfinite(w).all()
+
+
+def test_two_buckets_armed_in_one_step_keep_their_own_deferred_gradients():
+    """the deferred weight-gradient queue belongs to the bucket that armed the sink.  Two buckets armed in one
+    step (Conv1..Conv4 | Conv5 + head) both receive their wide layers' gradients whatever the gather order, and a step
+    aborted after arming leaves nothing queued for the next one."""
+    import spcl_amd  # noqa
+    from spcl_amd import ddp
+    from spcl_amd.contrastyou.projectors.heads import ProjectionHead
+
+    def run(two_buckets, order=(0, 1), abort_first=False):
+        net, _ = _unet(256, 3, torch.bfloat16)
+        head = ProjectionHead(input_dim=256, hidden_dim=32, output_dim=16, head_type="mlp", normalize=True)
+        head.load_state_dict(O.init_projector_state(256, 32, 16, seed=5))
+        head.cuda()
+        for name in net.decoder_names:
+            getattr(net, "_" + name).requires_grad_(False)
+        pa = [p for k, p in net.named_parameters() if p.requires_grad and not k.startswith("_Conv5")]
+        pb = [p for k, p in net.named_parameters() if p.requires_grad and k.startswith("_Conv5")] + list(head.parameters())
+        buckets = [ddp.GradBucket(pa), ddp.GradBucket(pb)] if two_buckets else [ddp.GradBucket(pa + pb)]
+        x = torch.rand(4, 1, 64, 64, generator=torch.Generator().manual_seed(1)).cuda()
+
+        def fwd():
+            z = head(net(x, until="Conv5"))
+            return (z * torch.arange(16, device="cuda")).sum()
+        if abort_first:  # arm, run half a step, never gather
+            for b in buckets:
+                b.arm_sinks()
+            fwd().backward()
+            for p in pa + pb:
+                p.grad = None
+        for b in buckets:
+            b.arm_sinks()
+        fwd().backward()
+        for i in (order if two_buckets else (0,)):
+            buckets[i].gather()
+        return torch.cat([b.flat for b in buckets]).clone()
+
+    ref = run(False)
+    for order in ((0, 1), (1, 0)):
+        got = run(True, order)
+        assert torch.equal(got, ref), order
+    assert torch.equal(run(True, (0, 1), abort_first=True), ref)
+    assert ref.abs().max() > 0
 
 
 def test_three_combined_hooks_share_one_encoder_pass_fp32():
