@@ -57,13 +57,18 @@ def build(force=False, verbose=True):
                 raise RuntimeError(f"hipcc failed on {src}:\n{out}")
             if verbose:
                 print(f"[spcl build] compiled {src}")
+    linked = False
     if jobs or force or _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
+        linked = True
         if verbose:
             print(f"[spcl build] linked {LIB}")
+    if verbose:  # a reader of the log can tell a rebuild from a reuse of objects that travelled with the tree
+        print(f"[spcl build] compiled {len(jobs)} / reused {len(objs) - len(jobs)} of {len(objs)} objects; "
+              f"{'linked' if linked else 'reused'} {os.path.basename(LIB)} (--force rebuilds everything)")
     return LIB
 
 

@@ -18,6 +18,26 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// ---- hipFuncSetAttribute with its result kept: a kernel that needs more dynamic LDS than the default 64 KB asks for it once;
+// if the runtime refuses, the launch behind it fails with an unspecific "invalid value".  The refusal is remembered here
+// and SPCL_LAUNCH_CHECK reports IT (results were discarded).
+static thread_local char g_attr_err[256] = "";
+void func_lds_limit(const void* fn, int bytes, const char* what) {
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    snprintf(g_attr_err, sizeof(g_attr_err), "hipFuncSetAttribute(%s, max dynamic LDS = %d bytes): %s", what, bytes,
+             hipGetErrorString(e));
+    (void)hipGetLastError();
+  }
+}
+const char* take_attr_error() {
+  if (!g_attr_err[0]) return nullptr;
+  static thread_local char out[256];
+  memcpy(out, g_attr_err, sizeof(out));
+  g_attr_err[0] = 0;
+  return out;
+}
+
 // ---- one-shot weight-gradient tail capture (see spcl_wgrad_tail_capture in the header)
 static thread_local spcl_wgrad_tail* g_tail_slot = nullptr;
 spcl_wgrad_tail* take_tail_capture() {

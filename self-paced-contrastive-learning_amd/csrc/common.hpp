@@ -22,8 +22,16 @@ void set_error(const char* fmt, ...);
     }                                    \
   } while (0)
 
+void func_lds_limit(const void* fn, int bytes, const char* what);  // hipFuncSetAttribute, result remembered
+const char* take_attr_error();
+
 #define SPCL_LAUNCH_CHECK(name)                                                 \
   do {                                                                          \
+    if (const char* a_ = spcl::take_attr_error()) {                             \
+      (void)hipGetLastError();                                                  \
+      spcl::set_error("%s: %s", name, a_);                                      \
+      return SPCL_ELAUNCH;                                                      \
+    }                                                                           \
     hipError_t e_ = hipGetLastError();                                          \
     if (e_ != hipSuccess) {                                                     \
       spcl::set_error("%s: launch failed: %s", name, hipGetErrorString(e_));    \

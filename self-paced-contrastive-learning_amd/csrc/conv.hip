@@ -392,12 +392,10 @@ static int launch_conv(const ConvArgs& a0, hipStream_t st) {
   const int gy = cdiv(ntn, NT * wn);
   dim3 grid(cdiv(tiles, a.tpw), gy), block(64 * wn);
   if (NT == 1) {
-    if (lds > 65536) (void)hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<T, TH, TW, 1>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 65536) spcl::func_lds_limit((const void*)conv3x3_mfma_kernel<T, TH, TW, 1>, (int)lds, "conv3x3_mfma_kernel<T, TH, TW, 1>");
     SPCL_LAUNCH((conv3x3_mfma_kernel<T, TH, TW, 1>), grid, block, lds, st, a);
   } else {
-    if (lds > 65536) (void)hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<T, TH, TW, 2>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 65536) spcl::func_lds_limit((const void*)conv3x3_mfma_kernel<T, TH, TW, 2>, (int)lds, "conv3x3_mfma_kernel<T, TH, TW, 2>");
     SPCL_LAUNCH((conv3x3_mfma_kernel<T, TH, TW, 2>), grid, block, lds, st, a);
   }
   return 0;

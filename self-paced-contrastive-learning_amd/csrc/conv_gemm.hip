@@ -388,8 +388,7 @@ static void launch_gemm_mode(const GemmArgs& g, int mode, dim3 grid, size_t lds,
   do {                                                                                                       \
     static bool attr = false;                                                                                \
     if (!attr) {                                                                                             \
-      (void)hipFuncSetAttribute((const void*)conv3x3_gemm_kernel<GH, MODE_>,                                 \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                     \
+      spcl::func_lds_limit((const void*)conv3x3_gemm_kernel<GH, MODE_>, (int)(160 * 1024), "conv3x3_gemm_kernel");                     \
       attr = true;                                                                                           \
     }                                                                                                        \
     SPCL_LAUNCH((conv3x3_gemm_kernel<GH, MODE_>), grid, dim3(512), lds, st, g);                              \

@@ -2071,7 +2071,7 @@ static void launch_logits2(const SupconLayout& L, SupconArgs a, const bf16_t* Ph
   constexpr int ring = 3 * 2 * 64 * DP * 2;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)supcon_logits2_kernel<DP>, hipFuncAttributeMaxDynamicSharedMemorySize, ring);
+    spcl::func_lds_limit((const void*)supcon_logits2_kernel<DP>, (int)(ring), "supcon_logits2_kernel<DP>");
     attr = true;
   }
   SPCL_LAUNCH((supcon_logits2_kernel<DP>), dim3(L.N2p / 256, L.CSB), dim3(512), (size_t)ring, st, a, Ph, Pm, Lmat);
@@ -2091,7 +2091,7 @@ static int launch_forward_big(const SupconLayout& L, SupconArgs a, float* ws, in
       if (!attr) {
         const void* fns[4] = {(const void*)supcon_tiles_kernel<DP, 0, 0>, (const void*)supcon_tiles_kernel<DP, 1, 0>,
                               (const void*)supcon_tiles_kernel<DP, 1, 1>, (const void*)supcon_tiles_kernel<DP, 1, 2>};
-        for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        for (const void* f : fns) spcl::func_lds_limit(f, (int)lds, "supcon_tiles_kernel");
         attr = true;
       }
       const double n2f = (double)L.N2p;
@@ -2378,8 +2378,7 @@ static int supcon_backward_impl(int K, const float* labels, const float* mask, i
     constexpr size_t lds_ = (size_t)2 * 2 * (2 * 64 * DP_ * 2) + 4 * SUPCON_TILES_MAXT * 256;                          \
     static bool attr_ = false;                                                                                         \
     if (!attr_) {                                                                                                      \
-      (void)hipFuncSetAttribute((const void*)supcon_bwd_tiles_kernel<DP_, SP_>,                                        \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);                                \
+      spcl::func_lds_limit((const void*)supcon_bwd_tiles_kernel<DP_, SP_>, (int)lds_, "supcon_bwd_tiles_kernel");                                \
       attr_ = true;                                                                                                    \
     }                                                                                                                  \
     SPCL_LAUNCH((supcon_bwd_tiles_kernel<DP_, SP_>), dim3(L.N2p / 256, csb), dim3(512), lds_, st, Ph, Pm,              \

@@ -424,8 +424,7 @@ template <typename T, int MI, int NJ, int TH, int NWV>
 static void launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t st) {
   const size_t lds = (a.dbuf ? 2 : 1) * wgrad_lds_bytes(MI, NJ, TH, (int)sizeof(T));
   if (lds > 65536)
-    (void)hipFuncSetAttribute((const void*)conv3x3_wgrad_kernel<T, MI, NJ, TH, NWV>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    spcl::func_lds_limit((const void*)conv3x3_wgrad_kernel<T, MI, NJ, TH, NWV>, (int)lds, "conv3x3_wgrad_kernel<T, MI, NJ, TH, NWV>");
   SPCL_LAUNCH((conv3x3_wgrad_kernel<T, MI, NJ, TH, NWV>), dim3(p.nsplit, p.nblk_ci * p.nblk_co), dim3(64 * NWV), lds, st,
               a);
 }

@@ -602,8 +602,7 @@ template <int TH, int RING> static void wb_launch(const WbPlan& pl, hipStream_t 
   const size_t ldsb = (size_t)(2 * XGRP + NDB * DGRP) * 1024;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)wgrad_gemm_kernel<TH, RING>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)ldsb);
+    spcl::func_lds_limit((const void*)wgrad_gemm_kernel<TH, RING>, (int)ldsb, "wgrad_gemm_kernel<TH, RING>");
     attr = true;
   }
   SPCL_LAUNCH((wgrad_gemm_kernel<TH, RING>), dim3(pl.nwg), dim3(768), ldsb, st, pl.args);

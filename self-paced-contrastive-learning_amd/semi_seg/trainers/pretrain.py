@@ -184,7 +184,7 @@ class PretrainEncoderTrainer:
         epocher = self.train_epocher(model=self._model, optimizer=self._optimizer,
                                          chain_dataloader=self._chain_dataloader, num_batches=self._num_batches,
                                          cur_epoch=self._cur_epoch, device=self._device,
-                                         inference_until=self._inference_until or "Conv5", flat_params=self._flat)
+                                         inference_until=self._inference_until, flat_params=self._flat)
         epocher.add_hooks([h() for h in self.__hooks__])
         epocher.init()
         self._last_epocher = epocher
