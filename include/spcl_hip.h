@@ -152,6 +152,20 @@ int spcl_conv_pack_weights_block_at(const float* wa_oihw, int CinA, int CoutA, v
                                     const float* wb_oihw, int CinB, int CoutB, void* b_fwd, void* b_dgrad, int dtype,
                                     int H, int W, void* stream);
 
+/* forward + dgrad layouts of up to SPCL_PACK_MULTI_MAX layers in ONE launch (every conv weight of the UNet encoder at the
+ * start of its forward pass: unet.py:123-131 are ten nn.Conv2d; one launch instead of one per block).  Per layer: the
+ * OIHW master, both destination buffers (sizes as spcl_conv_packed_elems) and the image size it will be used at (as
+ * spcl_conv_pack_weights_block_at: 0, 0 = both layouts of a dual-layout buffer).  items is host memory, read during the
+ * call. */
+#define SPCL_PACK_MULTI_MAX 20
+typedef struct spcl_pack_item {
+  const float* w_oihw;
+  void* fwd;
+  void* dgrad;
+  int Cin, Cout, H, W;
+} spcl_pack_item;
+int spcl_conv_pack_weights_multi(const spcl_pack_item* items, int n, int dtype, void* stream);
+
 /* y = conv3x3(act(x)), NHWC, implicit GEMM on MFMA.                    (unet.py:72,75; dgrad: with kind-1 weights)
  * x [N,H,W,CinS] of dtype; CinK = GEMM-K channels (multiple of 16, == CinS for in_mode 0/1).
  * in_mode 0: act = identity;  1: act = relu(in_scale[c]*x+in_shift[c])  (the producer's BatchNorm-apply + ReLU,

@@ -327,6 +327,32 @@ __global__ __launch_bounds__(256) void conv_pack_block_kernel(const float* __res
   if (idx < tb1) Elem<T>::store(b1 + idx, pack_value<T>(wb, CinB, CoutB, 1, CoutSB, CinKB, idx, gemm_b1));
 }
 
+// forward + dgrad layouts of many layers in one launch (spcl_conv_pack_weights_multi): 2 segments per layer
+struct PackSeg {
+  const float* w;
+  void* out;
+  unsigned long long end;  // exclusive prefix sum of the segments' element counts
+  int Cin, Cout, kind, KinK, NoutS, gemm;
+};
+struct PackSegs {
+  PackSeg s[2 * SPCL_PACK_MULTI_MAX];
+  int n;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void conv_pack_multi_kernel(PackSegs p) {
+  const unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long begin = 0;
+  for (int k = 0; k < p.n; ++k) {
+    const PackSeg& g = p.s[k];
+    if (idx < g.end) {
+      const size_t i = (size_t)(idx - begin);
+      Elem<T>::store((T*)g.out + i, pack_value<T>(g.w, g.Cin, g.Cout, g.kind, g.KinK, g.NoutS, i, g.gemm != 0));
+      return;
+    }
+    begin = g.end;
+  }
+}
+
 // bf16 layers the workgroup-level GEMM kernel can take (conv_gemm.hip) carry BOTH layouts, the per-wave kernels' first:
 // which kernel runs is decided per launch from the image size (conv_use_gemm), the weights do not know it
 template <typename T> static size_t packed_elems(int KinK, int NoutS) {
@@ -518,6 +544,50 @@ extern "C" int spcl_conv_pack_weights_block_at(const float* wa_oihw, int CinA, i
     return SPCL_EINVAL;
   }
   SPCL_LAUNCH_CHECK("conv_pack_weights_block");
+  return SPCL_OK;
+}
+
+template <typename T>
+static int pack_multi_t(const spcl_pack_item* items, int n, hipStream_t st) {
+  PackSegs p;
+  p.n = 0;
+  unsigned long long total = 0;
+  for (int i = 0; i < n; ++i) {
+    const spcl_pack_item& it = items[i];
+    const int k = round_up(it.Cin, 16), s = round_up(it.Cout, 16);
+    for (int kind = 0; kind < 2; ++kind) {
+      const int K = kind == 0 ? k : s, S = kind == 0 ? s : k;  // GEMM-K / output channels of this layout
+      bool gemm = false;
+      size_t elems = packed_elems<T>(K, S);
+      if (sizeof(T) == 2 && conv_gemm_channels(K, S)) {  // dual-layout buffer: the band-GEMM half only where it is used
+        gemm = it.H == 0 || it.W == 0 || conv_use_gemm(K, S, it.H, it.W);
+        if (!gemm) elems /= 2;
+      }
+      PackSeg& g = p.s[p.n++];
+      total += elems;
+      g.w = it.w_oihw; g.out = kind == 0 ? it.fwd : it.dgrad; g.end = total;
+      g.Cin = it.Cin; g.Cout = it.Cout; g.kind = kind; g.KinK = K; g.NoutS = S; g.gemm = gemm ? 1 : 0;
+    }
+  }
+  SPCL_LAUNCH(conv_pack_multi_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+  return 0;
+}
+
+extern "C" int spcl_conv_pack_weights_multi(const spcl_pack_item* items, int n, int dtype, void* stream) {
+  SPCL_CHECK_ARG(items && n >= 1 && n <= SPCL_PACK_MULTI_MAX, "conv_pack_weights_multi: 1 <= n <= %d layers",
+                 SPCL_PACK_MULTI_MAX);
+  for (int i = 0; i < n; ++i) {
+    SPCL_CHECK_ARG(items[i].w_oihw && items[i].fwd && items[i].dgrad, "conv_pack_weights_multi: null pointer (layer %d)", i);
+    SPCL_CHECK_ARG(items[i].Cin > 0 && items[i].Cout > 0 && items[i].H >= 0 && items[i].W >= 0,
+                   "conv_pack_weights_multi: bad shape (layer %d)", i);
+  }
+  if (dtype == SPCL_F32) pack_multi_t<float>(items, n, (hipStream_t)stream);
+  else if (dtype == SPCL_BF16) pack_multi_t<bf16_t>(items, n, (hipStream_t)stream);
+  else {
+    set_error("conv_pack_weights_multi: dtype %d", dtype);
+    return SPCL_EINVAL;
+  }
+  SPCL_LAUNCH_CHECK("conv_pack_weights_multi");
   return SPCL_OK;
 }
 

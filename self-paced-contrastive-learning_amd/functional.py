@@ -551,6 +551,45 @@ def _pack_block(wa, wb, dt_code, dtype, H=0, W=0):
     return (parts[0], parts[1]), (parts[2], parts[3])
 
 
+# ---- weights of several layers packed ahead of their use, in ONE launch (UNet.forward announces the layers it is about to
+# run: one pack launch per forward pass instead of one per block).  Entries are consumed by the block that uses them.
+_PREPACKED = {}
+_PREPACK = os.environ.get("SPCL_PREPACK", "1") != "0"  # A/B switch: 0 = every block packs right before its convolutions
+
+
+def prepack_weights(layers, dtype):
+    """``layers``: list of (weight [Cout, Cin, 3, 3], H, W) about to be used at image size H x W with storage ``dtype``:
+    forward and dgrad layouts of all of them in one launch (spcl_conv_pack_weights_multi), handed to the blocks through
+    ``take_prepacked``.  Anything left over from an earlier, unfinished forward is dropped."""
+    _PREPACKED.clear()
+    if not _PREPACK or not layers:
+        return
+    dtc = _n.dtype_code(dtype)
+    dev = layers[0][0].device
+    sizes = []
+    for w, H, W in layers:
+        co, ci = w.shape[0], w.shape[1]
+        sizes.append((_n.call("spcl_conv_packed_elems", ci, co, 0, dtc), _n.call("spcl_conv_packed_elems", ci, co, 1, dtc)))
+    for i in range(0, len(layers), _n.PACK_MULTI_MAX):
+        part, psz = layers[i:i + _n.PACK_MULTI_MAX], sizes[i:i + _n.PACK_MULTI_MAX]
+        buf = torch.empty(sum(a + b for a, b in psz), dtype=dtype, device=dev)
+        items, keep, off = [], [], 0
+        for (w, H, W), (n0, n1) in zip(part, psz):
+            wc = w.detach().contiguous().float()
+            p0, p1 = buf[off:off + n0], buf[off + n0:off + n0 + n1]
+            off += n0 + n1
+            items.append(_n.PackItem(wc.data_ptr(), p0.data_ptr(), p1.data_ptr(), w.shape[1], w.shape[0],
+                                     int(H) if _PACK_AT else 0, int(W) if _PACK_AT else 0))
+            keep.append(wc)
+            _PREPACKED[(w.data_ptr(), dtc, int(H), int(W))] = (p0, p1)
+        arr = (_n.PackItem * len(items))(*items)
+        _n.call("spcl_conv_pack_weights_multi", arr, len(items), dtc, _n.stream())
+
+
+def take_prepacked(w, dtc, H, W):
+    return _PREPACKED.pop((w.data_ptr(), dtc, int(H), int(W)), None)
+
+
 def _conv(x_store, dt_code, dtype, N, H, W, cin_s, cin_k, cout_s, wp, in_mode, scale, shift, want_stats):
     dev = x_store.device
     y = torch.empty(N, H, W, cout_s, dtype=dtype, device=dev)
@@ -802,7 +841,10 @@ class _ConvBlockFn(torch.autograd.Function):
             cin_s = cin_k = xs.shape[3]
             mode_a = 0
         need_bwd = any(ctx.needs_input_grad)
-        if need_bwd:  # the dgrad layouts are packed alongside (same launch) and kept for backward
+        pre_a, pre_b = take_prepacked(wa, dtc, H, W), take_prepacked(wb, dtc, H, W)
+        if pre_a is not None and pre_b is not None:  # packed with the other layers at the start of the forward pass
+            (wpa, wpa_t), (wpb, wpb_t) = pre_a, pre_b
+        elif need_bwd:  # the dgrad layouts are packed alongside (same launch) and kept for backward
             (wpa, wpa_t), (wpb, wpb_t) = _pack_block(wa, wb, dtc, dtype, *((H, W) if _PACK_AT else (0, 0)))
         else:
             wpa, wpb, wpa_t, wpb_t = _pack(wa, 0, dtc, dtype), _pack(wb, 0, dtc, dtype), None, None
@@ -932,7 +974,10 @@ class _ConvBNReLUFn(torch.autograd.Function):
         xs = to_nhwc_padded(x.detach(), dtype)
         cin_s = xs.shape[3]
         need_bwd = any(ctx.needs_input_grad)
-        if need_bwd:
+        pre = take_prepacked(w, dtc, H, W)
+        if pre is not None:
+            wp, wp_t = pre
+        elif need_bwd:
             wp, wp_t = _pack_both(w, dtc, dtype)
         else:
             wp, wp_t = _pack(w, 0, dtc, dtype), None

@@ -47,6 +47,7 @@ _SIGNATURES = {
     "spcl_conv_pack_weights_both": (c_int, [_P, c_int, c_int, c_int, _P, _P, _P]),
     "spcl_conv_pack_weights_block": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, c_int, _P, _P, c_int, _P]),
     "spcl_conv_pack_weights_block_at": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, c_int, _P, _P, c_int, c_int, c_int, _P]),
+    "spcl_conv_pack_weights_multi": (c_int, [_P, c_int, c_int, _P]),
     "spcl_conv_num_tiles": (c_int, [c_int, c_int, c_int]),
     "spcl_conv_stat_rows": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "spcl_conv_set_gemm": (None, [c_int]),
@@ -115,6 +116,15 @@ class WgradItem(ctypes.Structure):
     _fields_ = [("x", c_void_p), ("dy", c_void_p), ("in_scale", c_void_p), ("in_shift", c_void_p),
                 ("dw_oihw", c_void_p), ("N", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int), ("CinS", c_int),
                 ("Cout", c_int), ("CoutS", c_int), ("in_mode", c_int)]
+
+
+class PackItem(ctypes.Structure):
+    """``spcl_pack_item`` of include/spcl_hip.h (one layer of a multi-layer weight pack)"""
+    _fields_ = [("w_oihw", c_void_p), ("fwd", c_void_p), ("dgrad", c_void_p), ("Cin", c_int), ("Cout", c_int),
+                ("H", c_int), ("W", c_int)]
+
+
+PACK_MULTI_MAX = 20
 
 
 class WgradTail(ctypes.Structure):

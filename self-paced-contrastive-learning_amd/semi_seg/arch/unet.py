@@ -180,6 +180,7 @@ class UNet(nn.Module):
                 raise KeyError(f"`return_until` should be in {', '.join(self.layer_dimension.keys())},"
                                f" given {until}  ")
         encoder_only = until in _ENCODER
+        self._prepack(x, until)
         e = x
         skips = {}
         for k, name in enumerate(_ENCODER):
@@ -209,6 +210,37 @@ class UNet(nn.Module):
             if until == f"Up_conv{lvl}":
                 return d
         return self._Deconv_1x1(d)
+
+    def _prepack(self, x, until):
+        """announce the 3x3 convolutions this forward pass runs (and the image size each runs at): their weights are packed
+        into MFMA fragment order by ONE launch up front (functional.prepack_weights) instead of one launch per block"""
+        if not x.is_cuda or x.dim() != 4:
+            return
+        H, W = int(x.shape[2]), int(x.shape[3])
+        layers, dtypes = [], set()
+
+        def block(m, h, w):
+            dtypes.add(m._compute_dtype or _config.get_compute_dtype())
+            layers.extend([(m.conv[0].weight, h, w), (m.conv[3].weight, h, w)])
+
+        done = False
+        for k, name in enumerate(_ENCODER):
+            block(getattr(self, "_" + name), H >> k, W >> k)
+            if until == name:
+                done = True
+                break
+        if not done:
+            h, w = H >> (len(_ENCODER) - 1), W >> (len(_ENCODER) - 1)
+            for lvl in (5, 4, 3, 2):
+                h, w = 2 * h, 2 * w
+                up = getattr(self, f"_Up{lvl}")
+                dtypes.add(up._compute_dtype or _config.get_compute_dtype())
+                layers.append((up.up[1].weight, h, w))
+                block(getattr(self, f"_Up_conv{lvl}"), h, w)
+                if until == f"Up_conv{lvl}":
+                    break
+        if len(dtypes) == 1:
+            F_hip.prepack_weights(layers, dtypes.pop())
 
     def set_compute_dtype(self, dtype):
         """torch.float32 (parity mode) or torch.bfloat16 for all fused blocks of this network."""

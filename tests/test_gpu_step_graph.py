@@ -191,6 +191,7 @@ def test_trainer_loop_uses_the_graph():
         tr.register_hooks(create_sp_infonce_hooks(model=net, feature_names="Conv5", weights=1.0, contrast_ons="partition",
                                                   begin_values=5.0, end_values=50.0, mode="soft", max_epoch=3, p=0.5,
                                                   correct_grad=True, data_name="acdc", sync_checks=False))
+        tr.forward_until = "Conv5"
         tr.init()
         hist = tr.start_training()
     assert len(hist) == 2 and len(seen) == 2
