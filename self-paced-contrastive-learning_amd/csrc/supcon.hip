@@ -286,6 +286,30 @@ __device__ __forceinline__ PairMask pair_mask(const SupconArgs& a, int i, int j,
   return p;
 }
 
+// the same decision with the label of every row (view 1 rows, then view 2 rows) already staged in LDS: no global load on
+// the dependent path (the one-workgroup kernel evaluates 32 of these per lane in its backward half)
+__device__ __forceinline__ PairMask pair_mask_staged(const SupconArgs& a, int i, int j, const float* __restrict__ row_lab) {
+  PairMask p;
+  if (i >= a.N2 || j >= a.N2 || i == j) {
+    p.pos = false;
+    p.valid = false;
+    return p;
+  }
+  const int in = i >= a.n ? i - a.n : i, jn = j >= a.n ? j - a.n : j;
+  if (a.mask != nullptr) {
+    float mv = a.mask[(size_t)in * a.n + jn];
+    p.pos = (mv == 1.f);
+    p.valid = p.pos || (mv == 0.f);
+  } else if (a.labels != nullptr) {
+    p.pos = (row_lab[j] == row_lab[i]);
+    p.valid = true;
+  } else {
+    p.pos = (in == jn);
+    p.valid = true;
+  }
+  return p;
+}
+
 __device__ __forceinline__ float sp_weight(int sp_mode, float ell, float gamma, float inv_gamma) {
   if (sp_mode == 0) return 1.f;
   float l = -ell;
@@ -379,15 +403,21 @@ __global__ __launch_bounds__(1024) void supcon_small_kernel(const float* __restr
   float* st_logD = st_rn2 + 64;       // [64]
   float* st_W = st_logD + 64;         // [64]
   float* st_kc = st_W + 64;           // [64]
-  float* part = st_kc + 64;           // [2][4 cq][64 rows]: partial row sums of a column quarter
-  float* sx = part + 2 * 4 * 64;      // [4 rb][4 cq][4 r][64 lanes]: the logits, for the backward
+  float* st_lab = st_kc + 64;         // [64] label of every row (0 beyond 2n / without labels)
+  float* part = st_lab + 64;          // [2][4 cq][64 rows]: partial row sums of a column quarter
+  float* sx = part + 2 * 4 * 64;      // [4 rb][4 cq][4 r][64 lanes]: the H = G + G^T tiles, for the backward
   double* red = (double*)(sx + 4 * 4 * 4 * 64);  // [4][4]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, g = lane >> 4;
   const int rb = wave & 3, cq = wave >> 2;
   const int I0 = rb * 16, i = I0 + r16;
+  if (a.dbg & 128) return;  // (experiments: the launch floor of this workgroup shape)
 
   // ---- padded P into LDS (and to the workspace for the lazily materialised taps), squared row norms: 4 rows per wave
+  if (wave == 15) {  // ... and every row's label (requested with the first loads, read from LDS from here on)
+    const int row = lane, rn = row >= a.n ? row - a.n : row;
+    st_lab[row] = (a.labels != nullptr && row < a.N2) ? a.labels[rn] : 0.f;
+  }
   {
     constexpr int KPL = DP / 64;
     float v[4][KPL];
@@ -400,6 +430,10 @@ __global__ __launch_bounds__(1024) void supcon_small_kernel(const float* __restr
         const int k = lane + 64 * q;
         v[rr][q] = (src != nullptr && k < d) ? src[k] : 0.f;
       }
+    }
+    if (a.dbg & 256) {  // (experiments: after the global loads have landed)
+      if (v[0][0] + v[1][0] + v[2][0] + v[3][0] == 12345.f) out[7] = 1.f;
+      return;
     }
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
@@ -420,6 +454,7 @@ __global__ __launch_bounds__(1024) void supcon_small_kernel(const float* __restr
     }
   }
   __syncthreads();
+  if (a.dbg & 16) return;  // (experiments: SPCL_SUPCON_DBG=16 stops after the load phase, 32 after the S tiles, 64 after the forward)
   const float m = wave_max(st_rn2[lane]) / a.t;
 
   // ---- the 16 x 16 tile S[rb][cq] (same k order as sim_tile: the logits are bitwise those of the sweep kernels)
@@ -435,17 +470,15 @@ __global__ __launch_bounds__(1024) void supcon_small_kernel(const float* __restr
       for (int u = 0; u < 4; ++u) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[u], b4[u], c, 0, 0, 0);
     }
   }
-  const int in = i >= a.n ? i - a.n : i;
-  const float lab_i = (a.labels != nullptr && i < a.N2) ? a.labels[in] : 0.f;
+  if (a.dbg & 32) { if (c[0] == 12345.f) out[7] = c[1]; return; }
   PairMask pm[4];
   float accD = 0.f, accC = 0.f;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    pm[r] = pair_mask(a, i, 16 * cq + 4 * g + r, lab_i);
+    pm[r] = pair_mask_staged(a, i, 16 * cq + 4 * g + r, st_lab);
     c[r] = c[r] / a.t - m;  // from here on c holds the logits
     accD += pm[r].valid ? expf(c[r]) : 0.f;
     accC += pm[r].pos ? 1.f : 0.f;
-    sx[((rb * 4 + cq) * 4 + r) * 64 + lane] = c[r];
   }
   accD += __shfl_xor(accD, 16, 64);
   accD += __shfl_xor(accD, 32, 64);
@@ -535,12 +568,31 @@ __global__ __launch_bounds__(1024) void supcon_small_kernel(const float* __restr
     out[2] = kappa;
     out[3] = dm;
   }
-  if (dz_unit == nullptr) return;
+  if (dz_unit == nullptr || (a.dbg & 64)) return;
 
   // ---- dLoss/dP for a unit upstream gradient: H = G + G^T for this wave's 16 rows x all 64 columns, then
   // dP[rows][64 cq .. 64 cq + 63] += H P_J on the same MFMA
   const float kc_i = i < a.N2 ? -kappa / cnt_i : 0.f;
   if (cq == 0 && g == 0) st_kc[i] = kc_i;
+  __syncthreads();
+  // H tile (rb, cq) from this wave's own logits (c[]) -- every pair's two exponentials are evaluated ONCE, by the wave that
+  // owns the tile (all sixteen waves did all four tiles of their row block before: the backward half was vector-ALU
+  // bound, 13.6 of the kernel's 36 us at d = 256) -- and handed to the four waves of the row block through LDS
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int j = 16 * cq + 4 * g + r;
+    float hv = 0.f;
+    if (i < a.N2 && j < a.N2 && i != j) {
+      const PairMask pji = pair_mask_staged(a, j, i, st_lab);
+      const float ell_ij = c[r] - logD_i, ell_ji = c[r] - st_logD[j];
+      const float w_ij = sp_weight(a.sp_mode, ell_ij, a.gamma, a.inv_gamma);
+      const float w_ji = sp_weight(a.sp_mode, ell_ji, a.gamma, a.inv_gamma);
+      const float g_ij = kc_i * ((pm[r].pos ? w_ij : 0.f) - (pm[r].valid ? W_i * expf(ell_ij) : 0.f));
+      const float g_ji = st_kc[j] * ((pji.pos ? w_ji : 0.f) - (pji.valid ? st_W[j] * expf(ell_ji) : 0.f));
+      hv = g_ij + g_ji;
+    }
+    sx[((rb * 4 + cq) * 4 + r) * 64 + lane] = hv;
+  }
   __syncthreads();
   if (64 * cq >= DP) return;  // feature slices beyond the padded width (DP = 64 or 128)
   f32x4 acc2[4];
@@ -550,24 +602,7 @@ __global__ __launch_bounds__(1024) void supcon_small_kernel(const float* __restr
   for (int nt = 0; nt < 4; ++nt) {
     float h[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int j = 16 * nt + 4 * g + r;
-      float hv = 0.f;
-      if (i < a.N2 && j < a.N2 && i != j) {
-        const int jn = j >= a.n ? j - a.n : j;
-        const float lab_j = a.labels != nullptr ? a.labels[jn] : 0.f;
-        const PairMask pij = pair_mask(a, i, j, lab_i);
-        const PairMask pji = pair_mask(a, j, i, lab_j);
-        const float logit = sx[((rb * 4 + nt) * 4 + r) * 64 + lane];
-        const float ell_ij = logit - logD_i, ell_ji = logit - st_logD[j];
-        const float w_ij = sp_weight(a.sp_mode, ell_ij, a.gamma, a.inv_gamma);
-        const float w_ji = sp_weight(a.sp_mode, ell_ji, a.gamma, a.inv_gamma);
-        const float g_ij = kc_i * ((pij.pos ? w_ij : 0.f) - (pij.valid ? W_i * expf(ell_ij) : 0.f));
-        const float g_ji = st_kc[j] * ((pji.pos ? w_ji : 0.f) - (pji.valid ? st_W[j] * expf(ell_ji) : 0.f));
-        hv = g_ij + g_ji;
-      }
-      h[r] = hv;
-    }
+    for (int r = 0; r < 4; ++r) h[r] = sx[((rb * 4 + nt) * 4 + r) * 64 + lane];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = nt * 16 + 4 * g + r;
@@ -2231,7 +2266,7 @@ static int supcon_forward_impl(int K, const float* z1, const float* z2, long z_s
     }
   }
   if (supcon_use_small(L)) {
-    const size_t lds = ((size_t)64 * L.DP + 4 * 64 + 2 * 4 * 64 + 4 * 4 * 4 * 64) * sizeof(float) + 16 * sizeof(double);
+    const size_t lds = ((size_t)64 * L.DP + 5 * 64 + 2 * 4 * 64 + 4 * 4 * 4 * 64) * sizeof(float) + 16 * sizeof(double);
 #define SPCL_SMALL(DP_)                                                                                            \
   SPCL_LAUNCH((supcon_small_kernel<DP_>), dim3(K), dim3(1024), lds, st, z1, z2, d, a, ws + L.off_P, ws + L.off_rn2,  \
               ws + L.off_logD, ws + L.off_c, ws + L.off_W, ws + L.off_rowloss, correct_grad, out, ws + L.off_dz)
