@@ -279,7 +279,11 @@ def phase_fractions(launches, marks, reps, args):
             d["t"] += l[1]
             d["fl"] += l[3]
             d["by"] += l[2]
-    layers = None
+    layers, survey_us = None, None
+    if per_layer:
+        # SURVEY 8(d)'s bound counts the ten convolutions only (each reads its input once and writes its output once, the
+        # BatchNorm / ReLU / pooling work fused away): 90.8 us at N = 64, 224^2, bf16
+        survey_us = sum(roof(d["by"], d["fl"]) for d in per_layer.values()) / len(marks) * 1e6
     if per_layer:
         layers = {nm: {"us": round(d["t"] / len(marks) * 1e6, 2), "TFLOPs": round(d["fl"] / d["t"] / 1e12, 1),
                        "frac_of_mfma_peak": round(d["fl"] / d["t"] / peak, 4),
@@ -287,11 +291,16 @@ def phase_fractions(launches, marks, reps, args):
     return {"_step_roof_s": step_roof,
             "encoder_fwd": {"t_us": round(t_fwd * 1e6, 1), "launches": n_fwd,
                             "mixed_roofline_us": round(roof_fwd * 1e6, 1), "mixed_frac": round(roof_fwd / t_fwd, 4),
+                            "survey_bound_us": None if survey_us is None else round(survey_us, 1),
+                            "survey_mixed_frac": None if survey_us is None else round(survey_us * 1e-6 / t_fwd, 4),
                             "mfma_util": round(fl_fwd / t_fwd / peak, 4), "gflop": round(fl_fwd / 1e9, 1),
                             "per_layer": layers,
                             "note": "sum of the kernel durations between the start of UNet.forward and its return (eager "
                                     "instrumented pass, HIP events per launch); mixed_frac = sum of max(bytes / 8 TB/s, "
-                                    "FLOPs / peak) over those launches / that time (SURVEY 8d: 90.8 us at N=64 224^2 bf16)"}}
+                                    "FLOPs / peak) over ALL those launches (BatchNorm passes included) / that time; "
+                                    "survey_mixed_frac = the same bound over the ten convolutions only (SURVEY 8d: 90.8 us "
+                                    "at N=64 224^2 bf16) / that time.  Eager kernel durations run ~10 % above the same "
+                                    "kernels inside the replayed graph (profiles/r03_step_timeline.txt)"}}
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
@@ -409,6 +418,10 @@ def main():
                       file=sys.stderr)
     sg = epocher._step_graph
     used_graph = False if (sg is None or not sg.captured) else ("epocher-split" if world > 1 else "epocher")
+    ddp_check = None
+    if world > 1 and os.environ.get("SPCL_BENCH_DDP_CHECK") == "1":
+        wd.beat("ddp check")
+        ddp_check = check_ddp_mean(step, world, device)
     wd.beat("warmup")
     for _ in range(args.warmup):
         run()
@@ -465,6 +478,8 @@ def main():
                                 if k in ("loss", "sp_weight", "reg_loss")}
     if replay is not None:
         line["replay_us"] = replay
+    if ddp_check is not None:
+        line["ddp_check"] = ddp_check
     if not args.no_roofline and rank == 0:
         # rank 0 alone runs the instrumented steps, WITHOUT the collective (it is not a kernel of this library): compute
         # + update phases only, so no peer is needed and a failure here cannot leave another rank inside a collective
@@ -498,6 +513,29 @@ def main():
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def check_ddp_mean(step, world, device):
+    """N > 1 self-test (SPCL_BENCH_DDP_CHECK=1): every rank differentiates ITS batch, the flat gradients of all ranks are
+    gathered, and the step's one collective must leave exactly their mean in every rank's bucket (a sum of `world`
+    terms in rank order, divided by `world`; bit for bit at two ranks).  No optimizer step."""
+    epocher, flat = step.epocher, step.flat
+    with epocher.meters.focus_on(epocher.meter_focus):
+        epocher.step_compute(step.batch, seed=7)
+    local = flat.flat.clone()
+    parts = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(parts, local)
+    epocher.step_exchange()
+    mean = parts[0].clone()
+    for p in parts[1:]:
+        mean += p
+    mean /= world
+    diff = float((flat.flat - mean).abs().max())
+    differ = float((parts[0] - parts[-1]).abs().max())  # the ranks really saw different batches
+    from spcl_amd.contrastyou import meters as _meters
+    _meters.flush_batch()
+    return {"max_abs_diff_vs_mean_of_rank_gradients": diff, "max_abs_diff_between_ranks": differ,
+            "grad_abs_max": float(mean.abs().max())}
 
 
 def local_step(step):

@@ -49,6 +49,9 @@ struct FastArgs {
 #ifndef SPCL_FAST_WR_NT1
 #define SPCL_FAST_WR_NT1 9
 #endif
+#ifndef SPCL_FAST_WPE_KC32
+#define SPCL_FAST_WPE_KC32 2  // waves per SIMD the 32-channel-slab kernels (a slab's 9 x NT weight fragments in registers) must fit
+#endif
 #ifndef SPCL_FAST_YPRE_MINKC
 #define SPCL_FAST_YPRE_MINKC 16
 #endif
@@ -76,6 +79,7 @@ constexpr int fast_wpe(int KC, int TH, int NW, int NT, int MODE = 0) {
   if (KC == 16 && MODE >= 2 && SPCL_FAST_YPRE_MINKC <= 16 && w > 3 && acc <= 80) return 3;  // room for the y2 requests
   if (acc > 80 && w > 2) return 2;               // 13 m-tiles x 2 n-tiles: give the allocator 256 registers
   if (KC == 64 && NT == 1 && NW >= 2 && w > 2) return SPCL_FAST_WPE_NT1;  // 9-step ring of one n-tile: 36 registers
+  if (KC == 32 && fast_preload_slab(KC, NW, NT) && w > SPCL_FAST_WPE_KC32) return SPCL_FAST_WPE_KC32;
   if (fast_preload_slab(KC, NW, NT) && w > 2) return 2;  // a slab's weight fragments live in registers (PRELOAD_SLAB)
   return w;
 }

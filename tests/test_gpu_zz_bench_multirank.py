@@ -27,7 +27,8 @@ def _free_port():
 
 
 def test_bench_two_ranks_on_one_device(tmp_path):
-    env = dict(os.environ, SPCL_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", SPCL_BENCH_WATCHDOG_S="60")
+    env = dict(os.environ, SPCL_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", SPCL_BENCH_WATCHDOG_S="60",
+               SPCL_BENCH_DDP_CHECK="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2",
            "--warmup", "1", "--bs", "4", "--size", "64", "--no-extras"]
@@ -54,4 +55,7 @@ def test_bench_two_ranks_on_one_device(tmp_path):
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak"
     assert line["config"]["hipgraph"] == "epocher-split" and line["config"]["global_batch"] == 8
     assert line["value"] > 0 and line["final_meters"]["loss"] == line["final_meters"]["loss"]  # finite loss
+    chk = line["ddp_check"]  # the collective left the mean of the two ranks' (different) gradients in the bucket
+    assert chk["max_abs_diff_vs_mean_of_rank_gradients"] == 0.0 and chk["max_abs_diff_between_ranks"] > 0.0
+    assert chk["grad_abs_max"] > 0.0
     assert line["roofline"] is not None and line["roofline"]["frac"] > 0 and "cpu_baseline" not in line
