@@ -376,6 +376,11 @@ int spcl_split2_channels(const void* in, void* a, void* b, int elem_size, size_t
 int spcl_radam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, int64_t* step,
                     const float* lr, double beta1, double beta2, double eps, double weight_decay, float* coef,
                     void* stream);
+/* the same, and the step's meter updates (spcl_accumulate_scalars' k <= 8 pairs) ride in its coefficient launch: one
+ * launch less per training step.  k == 0: exactly spcl_radam_step. */
+int spcl_radam_step_scalars(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, int64_t* step,
+                            const float* lr, double beta1, double beta2, double eps, double weight_decay, float* coef,
+                            int k, const void* const* src, void* const* dst, const float* count, void* stream);
 
 /* Running means of the host-side meters (contrastyou/meters/averagemeter.py via MeterInterface) kept on the device:
  * for i < k (k <= 8):  dst[i][0] += count[i] * src[i][0];  dst[i][1] += count[i].  src / dst / count are HOST arrays

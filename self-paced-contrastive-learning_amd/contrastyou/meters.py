@@ -20,6 +20,24 @@ def begin_batch():
     _BATCH = []
 
 
+def take_batch(limit=8):
+    """hand the first ``limit`` remembered adds to a caller that performs them inside a launch of its own (the fused
+    optimizer's coefficient kernel, optim.FusedRAdam.step(scalar_adds=...)); the rest stays queued for flush_batch().
+    Returns (src, dst, count) ctypes arrays and their length, or None when nothing is pending."""
+    global _BATCH
+    if not _BATCH:
+        return None
+    from ctypes import c_float, c_void_p
+    part, _BATCH = _BATCH[:limit], _BATCH[limit:]
+    dsts = [d.data_ptr() for _, d, _ in part]
+    if len(set(dsts)) != len(dsts):  # a meter added to twice in one step: keep the plain path's chunking
+        _BATCH = part + _BATCH
+        return None
+    k = len(part)
+    return ((c_void_p * k)(*[v.data_ptr() for v, _, _ in part]), (c_void_p * k)(*dsts),
+            (c_float * k)(*[float(n) for _, _, n in part]), k, part)
+
+
 def flush_batch():
     """perform the remembered adds (same arithmetic: sum += n * value, count += n) and leave batching mode"""
     global _BATCH

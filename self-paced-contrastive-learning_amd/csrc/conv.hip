@@ -327,29 +327,36 @@ __global__ __launch_bounds__(256) void conv_pack_block_kernel(const float* __res
   if (idx < tb1) Elem<T>::store(b1 + idx, pack_value<T>(wb, CinB, CoutB, 1, CoutSB, CinKB, idx, gemm_b1));
 }
 
-// forward + dgrad layouts of many layers in one launch (spcl_conv_pack_weights_multi): 2 segments per layer
+// forward + dgrad layouts of many layers in one launch (spcl_conv_pack_weights_multi): 2 segments per layer, every
+// workgroup inside ONE segment (segments are rounded up to whole workgroups of PACK_EPB elements).  The workgroup finds its
+// segment from the table of last-block indices with statically indexed compares (the table arrives with the kernel
+// arguments in a few wide scalar loads; a per-thread walk over dynamically indexed argument structs was a chain of 2 x 20
+// dependent scalar loads: 20 us for what five separate launches did in 27).
+constexpr int PACK_EPB = 1024, PACK_SEGS = 2 * SPCL_PACK_MULTI_MAX;
 struct PackSeg {
   const float* w;
   void* out;
-  unsigned long long end;  // exclusive prefix sum of the segments' element counts
+  unsigned count;  // elements of this segment
+  int blk_begin;   // its first workgroup
   int Cin, Cout, kind, KinK, NoutS, gemm;
 };
 struct PackSegs {
-  PackSeg s[2 * SPCL_PACK_MULTI_MAX];
-  int n;
+  int blk_end[PACK_SEGS];  // exclusive; INT_MAX beyond the last segment
+  PackSeg s[PACK_SEGS];
 };
 template <typename T>
 __global__ __launch_bounds__(256) void conv_pack_multi_kernel(PackSegs p) {
-  const unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned long long begin = 0;
-  for (int k = 0; k < p.n; ++k) {
-    const PackSeg& g = p.s[k];
-    if (idx < g.end) {
-      const size_t i = (size_t)(idx - begin);
-      Elem<T>::store((T*)g.out + i, pack_value<T>(g.w, g.Cin, g.Cout, g.kind, g.KinK, g.NoutS, i, g.gemm != 0));
-      return;
-    }
-    begin = g.end;
+  const int b = blockIdx.x;
+  int seg = 0;
+#pragma unroll
+  for (int k = 0; k < PACK_SEGS; ++k) seg += b >= p.blk_end[k] ? 1 : 0;
+  const PackSeg g = p.s[seg];
+  const unsigned base = (unsigned)(b - g.blk_begin) * PACK_EPB + threadIdx.x;
+#pragma unroll
+  for (int e = 0; e < PACK_EPB / 256; ++e) {
+    const unsigned i = base + e * 256;
+    if (i < g.count)
+      Elem<T>::store((T*)g.out + i, pack_value<T>(g.w, g.Cin, g.Cout, g.kind, g.KinK, g.NoutS, (size_t)i, g.gemm != 0));
   }
 }
 
@@ -550,8 +557,7 @@ extern "C" int spcl_conv_pack_weights_block_at(const float* wa_oihw, int CinA, i
 template <typename T>
 static int pack_multi_t(const spcl_pack_item* items, int n, hipStream_t st) {
   PackSegs p;
-  p.n = 0;
-  unsigned long long total = 0;
+  int nseg = 0, blocks = 0;
   for (int i = 0; i < n; ++i) {
     const spcl_pack_item& it = items[i];
     const int k = round_up(it.Cin, 16), s = round_up(it.Cout, 16);
@@ -563,13 +569,18 @@ static int pack_multi_t(const spcl_pack_item* items, int n, hipStream_t st) {
         gemm = it.H == 0 || it.W == 0 || conv_use_gemm(K, S, it.H, it.W);
         if (!gemm) elems /= 2;
       }
-      PackSeg& g = p.s[p.n++];
-      total += elems;
-      g.w = it.w_oihw; g.out = kind == 0 ? it.fwd : it.dgrad; g.end = total;
+      PackSeg& g = p.s[nseg];
+      g.w = it.w_oihw; g.out = kind == 0 ? it.fwd : it.dgrad; g.count = (unsigned)elems; g.blk_begin = blocks;
       g.Cin = it.Cin; g.Cout = it.Cout; g.kind = kind; g.KinK = K; g.NoutS = S; g.gemm = gemm ? 1 : 0;
+      blocks += (int)((elems + PACK_EPB - 1) / PACK_EPB);
+      p.blk_end[nseg++] = blocks;
     }
   }
-  SPCL_LAUNCH(conv_pack_multi_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+  for (int k = nseg; k < PACK_SEGS; ++k) {
+    p.blk_end[k] = 0x7fffffff;
+    p.s[k] = p.s[0];
+  }
+  SPCL_LAUNCH(conv_pack_multi_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, p);
   return 0;
 }
 

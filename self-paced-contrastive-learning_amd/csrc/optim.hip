@@ -8,8 +8,26 @@
 
 namespace spcl {
 
+struct ScalarAdds {
+  const float* src[8];
+  float* dst[8];
+  float count[8];
+  int k;
+};
+
 // coef[0] = lr / (1 - beta1^t);  coef[1] = rect * sqrt(1 - beta2^t) when rho_t > 5 else 0;  coef[2] = rho_t > 5
-__global__ void radam_tick_kernel(int64_t* step, const float* lr, double beta1, double beta2, float* coef) {
+// Threads 1 .. k of the same (one-wave) launch perform the step's meter updates (spcl_radam_step_scalars): the running
+// means of the host-side meters are one more few-microsecond launch per step otherwise.
+__global__ __launch_bounds__(64) void radam_tick_kernel(int64_t* step, const float* lr, double beta1, double beta2,
+                                                        float* coef, ScalarAdds a) {
+  if (threadIdx.x > 0) {
+    const int i = threadIdx.x - 1;
+    if (i < a.k) {
+      a.dst[i][0] = fmaf(a.count[i], a.src[i][0], a.dst[i][0]);
+      a.dst[i][1] += a.count[i];
+    }
+    return;
+  }
   const int64_t t = step[0] + 1;
   step[0] = t;
   const double b1t = pow(beta1, (double)t), b2t = pow(beta2, (double)t);
@@ -62,12 +80,6 @@ __global__ __launch_bounds__(256) void radam_apply_kernel(float* __restrict__ p,
 
 using namespace spcl;
 
-struct ScalarAdds {
-  const float* src[8];
-  float* dst[8];
-  float count[8];
-  int k;
-};
 // running means of the host-side meters: dst = [sum, count];  sum += count_i * src,  count += count_i
 __global__ void accumulate_scalars_kernel(ScalarAdds a) {
   const int i = threadIdx.x;
@@ -77,18 +89,24 @@ __global__ void accumulate_scalars_kernel(ScalarAdds a) {
   }
 }
 
-extern "C" int spcl_accumulate_scalars(int k, const void* const* src, void* const* dst, const float* count,
-                                       void* stream) {
-  SPCL_CHECK_ARG(k >= 1 && k <= 8 && src && dst && count, "accumulate_scalars: 1 <= k <= 8 pairs per call");
-  ScalarAdds a;
+static int fill_scalar_adds(ScalarAdds& a, int k, const void* const* src, void* const* dst, const float* count,
+                            const char* who) {
   a.k = k;
   for (int i = 0; i < k; ++i) {
-    SPCL_CHECK_ARG(src[i] && dst[i], "accumulate_scalars: null pointer");
-    for (int j = 0; j < i; ++j) SPCL_CHECK_ARG(dst[j] != dst[i], "accumulate_scalars: a destination appears twice");
+    SPCL_CHECK_ARG(src[i] && dst[i], "%s: null pointer", who);
+    for (int j = 0; j < i; ++j) SPCL_CHECK_ARG(dst[j] != dst[i], "%s: a destination appears twice", who);
     a.src[i] = (const float*)src[i];
     a.dst[i] = (float*)dst[i];
     a.count[i] = count[i];
   }
+  return SPCL_OK;
+}
+
+extern "C" int spcl_accumulate_scalars(int k, const void* const* src, void* const* dst, const float* count,
+                                       void* stream) {
+  SPCL_CHECK_ARG(k >= 1 && k <= 8 && src && dst && count, "accumulate_scalars: 1 <= k <= 8 pairs per call");
+  ScalarAdds a;
+  if (int rc = fill_scalar_adds(a, k, src, dst, count, "accumulate_scalars")) return rc;
   SPCL_LAUNCH(accumulate_scalars_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
   SPCL_LAUNCH_CHECK("accumulate_scalars");
   return SPCL_OK;
@@ -125,13 +143,26 @@ extern "C" int spcl_stage_bytes(void* dst, const void* host_src, size_t nbytes, 
 extern "C" int spcl_radam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
                                int64_t* step, const float* lr, double beta1, double beta2, double eps,
                                double weight_decay, float* coef, void* stream) {
+  return spcl_radam_step_scalars(param, grad, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, weight_decay, coef, 0,
+                                 nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int spcl_radam_step_scalars(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                                       int64_t* step, const float* lr, double beta1, double beta2, double eps,
+                                       double weight_decay, float* coef, int k, const void* const* src,
+                                       void* const* dst, const float* count, void* stream) {
   SPCL_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && step && lr && coef, "radam_step: null pointer");
+  SPCL_CHECK_ARG(k >= 0 && k <= 8 && (k == 0 || (src && dst && count)), "radam_step: 0 <= k <= 8 scalar adds");
+  ScalarAdds adds;
+  adds.k = 0;
+  if (k > 0)
+    if (int rc = fill_scalar_adds(adds, k, src, dst, count, "radam_step")) return rc;
   SPCL_CHECK_ARG(n > 0, "radam_step: empty parameter");
   SPCL_CHECK_ARG(((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16 == 0,
                  "radam_step: buffers must be 16-byte aligned");
   SPCL_CHECK_ARG(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0, "radam_step: betas");
   hipStream_t st = (hipStream_t)stream;
-  SPCL_LAUNCH(radam_tick_kernel, dim3(1), dim3(1), 0, st, step, lr, beta1, beta2, coef);
+  SPCL_LAUNCH(radam_tick_kernel, dim3(1), dim3(k > 0 ? 64 : 1), 0, st, step, lr, beta1, beta2, coef, adds);
   const size_t n4 = n / 4;
   size_t blocks = (n4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;

@@ -108,6 +108,8 @@ _SIGNATURES = {
     "spcl_profile_count": (c_int, []),
     "spcl_profile_get": (c_int, [c_int, c_char_p, c_int, _P, _P, _P]),
     "spcl_radam_step": (c_int, [_P, _P, _P, _P, c_size_t, _P, _P, c_double, c_double, c_double, c_double, _P, _P]),
+    "spcl_radam_step_scalars": (c_int, [_P, _P, _P, _P, c_size_t, _P, _P, c_double, c_double, c_double, c_double, _P,
+                                        c_int, _P, _P, _P, _P]),
 }
 
 

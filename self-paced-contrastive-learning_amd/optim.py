@@ -46,7 +46,9 @@ class FusedRAdam(torch.optim.Optimizer):
                     st["lr_host"] = float(group["lr"])
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, scalar_adds=None):
+        """``scalar_adds``: what ``contrastyou.meters.take_batch()`` returned -- the step's meter updates, performed by
+        the first parameter's coefficient launch (one launch less per step)."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -64,9 +66,15 @@ class FusedRAdam(torch.optim.Optimizer):
                 if not capturing and st["lr_host"] != float(group["lr"]):  # None after load_state_dict
                     st["lr_dev"].fill_(float(group["lr"]))
                     st["lr_host"] = float(group["lr"])
-                _n.call("spcl_radam_step", _n.ptr(p), _n.ptr(g), _n.ptr(st["exp_avg"]), _n.ptr(st["exp_avg_sq"]),
+                k, src, dst, cnt = 0, None, None, None
+                if scalar_adds is not None:
+                    src, dst, cnt, k = scalar_adds[:4]
+                    scalar_adds = None
+                _n.call("spcl_radam_step_scalars", _n.ptr(p), _n.ptr(g), _n.ptr(st["exp_avg"]), _n.ptr(st["exp_avg_sq"]),
                         p.numel(), _n.ptr(st["step"]), _n.ptr(st["lr_dev"]), float(b1), float(b2), float(group["eps"]),
-                        float(group["weight_decay"]), _n.ptr(st["coef"]), _n.stream())
+                        float(group["weight_decay"]), _n.ptr(st["coef"]), k, src, dst, cnt, _n.stream())
+        if scalar_adds is not None:  # no parameter was stepped: the adds still have to happen
+            _n.call("spcl_accumulate_scalars", scalar_adds[3], scalar_adds[0], scalar_adds[1], scalar_adds[2], _n.stream())
         return loss
 
     def load_state_dict(self, state_dict):

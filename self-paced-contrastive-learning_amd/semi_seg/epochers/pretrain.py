@@ -278,9 +278,13 @@ class PretrainEncoderEpocher:
             self._grad_bucket.allreduce()
 
     def step_update(self, reg_loss):
-        self._optimizer.step()
         if self.on_master():
             self.meters["reg_loss"].add(reg_loss.detach())
+        from ...optim import FusedRAdam
+        if isinstance(self._optimizer, FusedRAdam):  # the meters' device adds ride in the optimizer's coefficient launch
+            self._optimizer.step(scalar_adds=_meters.take_batch())
+        else:
+            self._optimizer.step()
         _meters.flush_batch()
 
 
