@@ -307,6 +307,30 @@ int spcl_conv3x3_dgrad_bnstats(const void* dy, int dtype, int N, int H, int W, i
                                void* g, const void* y2, const float* scale2, const float* shift2, const float* mean2,
                                float* rows2, void* stream);
 
+/* ---- image3: the first conv of a block whose input is a ONE-CHANNEL f32 image (unet.py:123 with input_dim == 1, the
+ * configuration every driver of the reference uses).  Its BatchNorm backward and weight gradient need no pass over the
+ * activations: with dy = scale dz + A y + B (the folded BN backward), dW[c][t] = scale[c] sum_p dz[p][c] img[p + t] +
+ * A[c] (W R)[c][t] + B[c] sum_p img[p + t], R = the 9 x 9 autocorrelation of the zero-padded image batch (y is linear in
+ * the image).  Replaces spcl_bnrelu_backward_rows(image != NULL) + the dgrad before it where supported (bf16, 16 -> 16
+ * channels, sizes tiled 14 x 14):
+ *   spcl_image_autocorr          image [N][H][W] f32 -> out [spcl_image_autocorr_rows(N, H, W)][64] partial rows
+ *   spcl_conv3x3_dgrad_bnstats_image   spcl_conv3x3_dgrad_bnstats + rows 2 .. 10 of rows11 [tiles][11][CoutS] = the nine
+ *                                sums sum_p dz[p][co] image[p + tap] (tiles = spcl_conv_stat_rows)
+ *   spcl_bnrelu_backward_rows_image3   rows11 + autocorrelation + the f32 master weights [C][1][3][3] -> dgamma, dbeta, dW
+ *                                (ws: spcl_bnrelu_image3_workspace_bytes(CS) bytes) */
+int spcl_image_autocorr_rows(int N, int H, int W);
+int spcl_image_autocorr(const float* image, int N, int H, int W, float* out, void* stream);
+int spcl_conv_dgrad_bnstats_image_supported(int dtype, int N, int H, int W, int CinK, int CoutS);
+int spcl_conv3x3_dgrad_bnstats_image(const void* dy, int dtype, int N, int H, int W, int CinK, int CoutS,
+                                     const void* w_packed, void* g, const void* y2, const float* scale2,
+                                     const float* shift2, const float* mean2, const float* image, float* rows11,
+                                     void* stream);
+size_t spcl_bnrelu_image3_workspace_bytes(int CS);
+int spcl_bnrelu_backward_rows_image3(const float* rows11, int nrows, const float* acorr, int nacorr, const float* w_oihw,
+                                     int N, int H, int W, int C, int CS, const float* mean, const float* invstd,
+                                     const float* scale, int training, float* ws, float* dgamma, float* dbeta, float* dw,
+                                     void* stream);
+
 /* The same across a POOLED block boundary: dy = gradient of the next block's first conv output (H x W), g = its input
  * gradient = d loss / d maxpool2x2(relu(bn(y2))), y2 [N][H2][W2][CoutS] the raw second-conv output of the block before
  * (H == H2 / 2, W == W2 / 2; semi_seg/arch/unet.py:118-121,159-166).  rows2 [spcl_conv_stat_rows(...)][2][CoutS]: per conv

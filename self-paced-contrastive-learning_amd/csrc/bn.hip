@@ -481,14 +481,34 @@ __global__ __launch_bounds__(256, 3) void bnrelu_bwd_pool_kernel(const T* __rest
 // dbeta = sum dz, dgamma = sum dz*yhat.  One workgroup per channel: threads stride over the workgroup partials, then
 // a fixed-order butterfly and a fixed-order sum of the 4 waves -> deterministic.  Folded coefficients for pass 2:
 //   training: A = -scale*invstd*dgamma/M,  B = -scale*dbeta/M - A*mean;   eval: A = B = 0
+// `rs`: sub-rows per partial row (2; 11 with the image sums below).
+// image3 (the first conv of a one-channel-image block; replaces the fused BN-backward + weight-gradient pass over y and g):
+// with dy = scale dz + A y + B the weight gradient is
+//   dW[c][t] = scale[c] S1[c][t] + A[c] sum_p y[p][c] img[p + t] + B[c] sum_p img[p + t]
+// S1 = sum_p dz img are sub-rows 2 .. 10 (left by the dgrad that produced dz, conv_fast.hip MODE 4); y is LINEAR in the
+// image, y[p][c] = sum_t' W[c][t'] img[p + t'], so the second sum is (W R)[c][t] with R[t'][t] = sum_p img[p + t'] img[p + t],
+// the 9 x 9 autocorrelation of the zero-padded image batch (image_autocorr_kernel: 45 + 9 sums, 13 MB read) -- no pass
+// over the activations at all.  W and img as the forward convolution saw them (bf16-rounded); the sums in double.
+struct Image3Args {
+  const float* acorr;   // [nacorr][64]: 45 upper-triangle R sums, then 9 image sums per partial row; null = off
+  int nacorr;
+  const float* w_oihw;  // [C][1][3][3] f32 master weights
+  float* dw;            // [C][9]
+};
+__device__ __forceinline__ int acorr_index(int a, int b) {  // upper triangle of the symmetric 9 x 9 matrix, a <= b
+  return a * 9 - a * (a - 1) / 2 + (b - a);
+}
 __global__ __launch_bounds__(256) void bnrelu_bwd_fin_kernel(const float* __restrict__ partial, int nwg, int C, int CS,
                                                              float M, int training, const float* __restrict__ mean,
                                                              const float* __restrict__ invstd,
                                                              const float* __restrict__ scale,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                              float* __restrict__ ab, float* __restrict__ zero_fill,
-                                                             int nzero, int s2_centered) {
-  __shared__ float red[2][4];
+                                                             int nzero, int s2_centered, int rs, Image3Args im) {
+  __shared__ float red[11][4];
+  __shared__ double racc4[4][64];
+  __shared__ double racc[54];
+  __shared__ float coef[2];
   const int c = blockIdx.x;
   if (c == 0)  // scratch the next launch wants zeroed (the image-wgrad pass's zero row): saves a memset launch
     for (int z = threadIdx.x; z < nzero; z += 256) zero_fill[z] = 0.f;
@@ -497,15 +517,39 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_fin_kernel(const float* __rest
   // one after the reduction: this kernel is pure latency, ten launches per step)
   const float c_invstd = invstd[c], c_scale = scale[c], c_mean = mean[c];
   float s1 = 0.f, s2 = 0.f;
+  float st[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) st[t] = 0.f;
+  const bool img3 = im.acorr != nullptr;
 #pragma unroll 4
   for (int w = threadIdx.x; w < nwg; w += 256) {
-    s1 += partial[((size_t)w * 2 + 0) * CS + c];
-    s2 += partial[((size_t)w * 2 + 1) * CS + c];
+    s1 += partial[((size_t)w * rs + 0) * CS + c];
+    s2 += partial[((size_t)w * rs + 1) * CS + c];
+    if (img3) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) st[t] += partial[((size_t)w * rs + 2 + t) * CS + c];
+    }
   }
   s1 = wave_sum(s1);
   s2 = wave_sum(s2);
   if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
+  if (img3) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      st[t] = wave_sum(st[t]);
+      if (lane == 0) red[2 + t][wave] = st[t];
+    }
+    {  // the autocorrelation / image sums over the partial rows of image_autocorr_kernel, in double: wave p takes rows
+       // p, p + 4, ... (eight loads in flight per lane), the four waves are added in fixed order below
+      double a = 0.0;
+#pragma unroll 8
+      for (int w = wave; w < im.nacorr; w += 4) a += (double)im.acorr[(size_t)w * 64 + lane];
+      racc4[wave][lane] = a;
+    }
+  }
   __syncthreads();
+  if (img3 && threadIdx.x < 54)
+    racc[threadIdx.x] = (racc4[0][threadIdx.x] + racc4[1][threadIdx.x]) + (racc4[2][threadIdx.x] + racc4[3][threadIdx.x]);
   if (threadIdx.x == 0) {
     s1 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
     s2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
@@ -521,21 +565,88 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_fin_kernel(const float* __rest
     }
     ab[c] = A;
     ab[CS + c] = B;
+    coef[0] = A;
+    coef[1] = B;
+  }
+  if (!img3) return;
+  __syncthreads();
+  if (threadIdx.x < 9 && c < C) {
+    const int t = threadIdx.x;
+    const double S1 = (double)((red[2 + t][0] + red[2 + t][1]) + (red[2 + t][2] + red[2 + t][3]));
+    double wr = 0.0;
+    for (int u = 0; u < 9; ++u) {
+      const float wb = bf16_to_f32(f32_to_bf16(im.w_oihw[c * 9 + u]));  // the weight the forward MFMA multiplied with
+      wr += (double)wb * racc[u <= t ? acorr_index(u, t) : acorr_index(t, u)];
+    }
+    im.dw[c * 9 + t] = (float)((double)c_scale * S1 + (double)coef[0] * wr + (double)coef[1] * racc[45 + t]);
+  }
+}
+
+// R[t'][t] = sum over all pixels p of all images of img0[p + t' - 1] img0[p + t - 1] (img0: the image as the forward
+// convolution saw it, bf16-rounded, zero outside) for the 45 tap pairs t' <= t, and sum_p img[p + t - 1] for the 9 taps:
+// one partial row [64] per workgroup (a band of rows of one image; 54 used).  Threads walk the band's pixels, nine loads
+// per pixel (L1-resident neighbours), 45 + 9 FMAs; fixed-order reduction (butterfly, then the four waves).
+constexpr int ACORR_BAND = 56;
+__global__ __launch_bounds__(256) void image_autocorr_kernel(const float* __restrict__ img, int H, int W,
+                                                             float* __restrict__ out) {
+  __shared__ float red[4][54];
+  const int bands = (H + ACORR_BAND - 1) / ACORR_BAND;
+  const int n = blockIdx.x / bands, b = blockIdx.x - n * bands;
+  const int r0 = b * ACORR_BAND, r1 = min(H, r0 + ACORR_BAND);
+  const float* base = img + (size_t)n * H * W;
+  float acc[54];
+#pragma unroll
+  for (int k = 0; k < 54; ++k) acc[k] = 0.f;
+  const int npx = (r1 - r0) * W;
+  for (int p = threadIdx.x; p < npx; p += 256) {
+    const int yy = r0 + p / W, xx = p % W;
+    float f[9], v[9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int gy = yy + ky - 1, gx = xx + kx - 1;
+        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const float x = in ? base[(size_t)(in ? gy : 0) * W + (in ? gx : 0)] : 0.f;
+        f[ky * 3 + kx] = x;
+        v[ky * 3 + kx] = bf16_to_f32(f32_to_bf16(x));
+      }
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < 9; ++a)
+#pragma unroll
+      for (int bb = a; bb < 9; ++bb) {
+        acc[k] = fmaf(v[a], v[bb], acc[k]);
+        ++k;
+      }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[45 + t] += f[t];
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 54; ++k) {
+    const float sv = wave_sum(acc[k]);
+    if (lane == 0) red[wave][k] = sv;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int k = threadIdx.x;
+    out[(size_t)blockIdx.x * 64 + k] = k < 54 ? (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]) : 0.f;
   }
 }
 
 // rows [nrows][2][CS] of per-tile partial sums (the dgrad epilogue of conv_fast.hip, MODE 2) folded G at a time, so that
 // the per-channel final sum never walks more than BWD_MAX_WG rows
 __global__ __launch_bounds__(256) void bwd_rows_group_kernel(const float* __restrict__ rows, int nrows, int G, int CS,
-                                                             float* __restrict__ out) {
+                                                             float* __restrict__ out, int rs /* sub-rows: 2 or 11 */) {
   const int w = blockIdx.x;
-  for (int o = threadIdx.x; o < 2 * CS; o += 256) {
+  for (int o = threadIdx.x; o < rs * CS; o += 256) {
     float s = 0.f;
     for (int k = 0; k < G; ++k) {
       const int r = w * G + k;
-      if (r < nrows) s += rows[(size_t)r * 2 * CS + o];
+      if (r < nrows) s += rows[(size_t)r * rs * CS + o];
     }
-    out[(size_t)w * 2 * CS + o] = s;
+    out[(size_t)w * rs * CS + o] = s;
   }
 }
 
@@ -751,6 +862,8 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
                              int nrows = 0) {
   constexpr int EPC = Chunk<T>::EPC;
   const bool pool = dpool != nullptr;
+  constexpr int rs = 2;  // sub-rows of a partial row (the image3 path has eleven: spcl_bnrelu_backward_rows_image3)
+  const Image3Args im3{nullptr, 0, nullptr, nullptr};
   spcl_wgrad_tail* tail = img != nullptr ? take_tail_capture() : nullptr;
   const int PL = 256 / (CS / EPC);
   const size_t npix = (size_t)N * H * W;
@@ -771,7 +884,7 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
     } else {
       const int G = (nrows + BWD_MAX_WG - 1) / BWD_MAX_WG;
       nwg = (nrows + G - 1) / G;
-      SPCL_LAUNCH(bwd_rows_group_kernel, dim3(nwg), dim3(256), 0, st, rows, nrows, G, CS, partial);
+      SPCL_LAUNCH(bwd_rows_group_kernel, dim3(nwg), dim3(256), 0, st, rows, nrows, G, CS, partial, rs);
     }
   } else if (pool) {
     nwg = prows < BWD_MAX_WG ? prows : BWD_MAX_WG;
@@ -786,7 +899,7 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
   float* zrow = ab + 2 * CS + (size_t)IMG_WGRAD_WG * 9 * CS;  // [W] zeros (image-wgrad pass only, see below)
   SPCL_LAUNCH(bnrelu_bwd_fin_kernel, dim3(CS), dim3(256), 0, st, fin_src, nwg, C, CS,
                      M, training, mean, invstd, scale, dgamma, dbeta, ab, img != nullptr ? zrow : (float*)nullptr,
-                     img != nullptr ? W : 0, rows != nullptr ? 1 : 0);
+                     img != nullptr ? W : 0, rows != nullptr ? 1 : 0, rs, im3);
   prof_cost(2.0 * tb + gb, 0.0);
   if (pool) {
     SPCL_LAUNCH((bnrelu_bwd_pool_kernel<T, true>), dim3(prows < STREAM_MAX_WG ? prows : STREAM_MAX_WG), dim3(256), 0, st, (const T*)y,
@@ -952,6 +1065,55 @@ extern "C" int spcl_bnrelu_backward_rows(const void* y, const void* dact, const 
     return SPCL_EINVAL;
   }
   SPCL_LAUNCH_CHECK("bnrelu_backward_rows");
+  return SPCL_OK;
+}
+
+// ---- image3: BN + ReLU backward of the FIRST conv of a one-channel-image block and that conv's weight gradient, finished
+// from the eleven-row tiles of spcl_conv3x3_dgrad_bnstats_image and the image autocorrelation: no pass over y / g at all
+// (see bnrelu_bwd_fin_kernel).  Replaces spcl_bnrelu_backward_rows(image != NULL) where that dgrad kernel exists.
+extern "C" int spcl_image_autocorr_rows(int N, int H, int W) {
+  (void)W;
+  return N * ((H + ACORR_BAND - 1) / ACORR_BAND);
+}
+
+extern "C" int spcl_image_autocorr(const float* image, int N, int H, int W, float* out, void* stream) {
+  SPCL_CHECK_ARG(image && out && N > 0 && H > 0 && W > 0, "image_autocorr: bad arguments");
+  prof_cost((double)N * H * W * 4.0, 2.0 * 54.0 * N * H * W);
+  SPCL_LAUNCH(image_autocorr_kernel, dim3(spcl_image_autocorr_rows(N, H, W)), dim3(256), 0, (hipStream_t)stream, image, H,
+              W, out);
+  SPCL_LAUNCH_CHECK("image_autocorr");
+  return SPCL_OK;
+}
+
+extern "C" size_t spcl_bnrelu_image3_workspace_bytes(int CS) {
+  return ((size_t)BWD_MAX_WG * 11 * CS + 2 * (size_t)CS) * sizeof(float);
+}
+
+extern "C" int spcl_bnrelu_backward_rows_image3(const float* rows11, int nrows, const float* acorr, int nacorr,
+                                                const float* w_oihw, int N, int H, int W, int C, int CS,
+                                                const float* mean, const float* invstd, const float* scale,
+                                                int training, float* ws, float* dgamma, float* dbeta, float* dw,
+                                                void* stream) {
+  SPCL_CHECK_ARG(rows11 && acorr && w_oihw && mean && invstd && scale && ws && dgamma && dbeta && dw,
+                 "bnrelu_backward_rows_image3: null pointer");
+  SPCL_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && CS >= C && CS % 16 == 0 && CS <= 256 && nrows > 0 && nacorr > 0,
+                 "bnrelu_backward_rows_image3: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  float* partial = ws;                             // [nwg][11][CS]
+  float* ab = ws + (size_t)BWD_MAX_WG * 11 * CS;   // [2][CS]: the folded coefficients (kept for symmetry with the other paths)
+  const float* fin_src = rows11;
+  int nwg = nrows;
+  if (nrows > BWD_MAX_WG) {
+    const int G = (nrows + BWD_MAX_WG - 1) / BWD_MAX_WG;
+    nwg = (nrows + G - 1) / G;
+    prof_cost((double)nrows * 11 * CS * 4.0, 0.0);
+    SPCL_LAUNCH(bwd_rows_group_kernel, dim3(nwg), dim3(256), 0, st, rows11, nrows, G, CS, partial, 11);
+    fin_src = partial;
+  }
+  const Image3Args im{acorr, nacorr, w_oihw, dw};
+  SPCL_LAUNCH(bnrelu_bwd_fin_kernel, dim3(CS), dim3(256), 0, st, fin_src, nwg, C, CS, (float)((size_t)N * H * W), training,
+              mean, invstd, scale, dgamma, dbeta, ab, (float*)nullptr, 0, 1, 11, im);
+  SPCL_LAUNCH_CHECK("bnrelu_backward_rows_image3");
   return SPCL_OK;
 }
 

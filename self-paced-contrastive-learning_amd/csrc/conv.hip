@@ -697,6 +697,49 @@ extern "C" int spcl_conv3x3_dgrad_bnstats(const void* dy, int dtype, int N, int 
   return SPCL_OK;
 }
 
+// The same for the block behind a ONE-CHANNEL f32 image (unet.py:123, input_dim == 1): rows2 is [tile][11][CoutS] and rows
+// 2 .. 10 hold sum_p dz[p][co] image[p + tap] -- the data-dependent part of the first conv's weight gradient (bn.hip,
+// spcl_bnrelu_backward_rows_image3 finishes it without another pass over y2 / g).  16 -> 16 channels on 14 x 14 tiles only.
+extern "C" int spcl_conv_dgrad_bnstats_image_supported(int dtype, int N, int H, int W, int CinK, int CoutS) {
+  static const bool off = getenv("SPCL_NO_IMAGE3") != nullptr;  // A/B switch
+  ConvArgs a;
+  if (off || CinK != 16 || CoutS != 16 || !dgrad_bnstats_args(a, dtype, N, H, W, CinK, CoutS)) return 0;
+  if (!spcl_conv_dgrad_bnstats_supported(dtype, N, H, W, CinK, CoutS) || conv_use_gemm(CinK, CoutS, H, W)) return 0;
+  a.x = nullptr; a.y = nullptr; a.wp = nullptr;
+  float dummy;
+  a.rows2 = &dummy;
+  a.img2 = &dummy;
+  TileCfg t = pick_tile(H, W);
+  return (t.tw == 14 && t.th == 14 && launch_conv_fast(a, t.th, nullptr, true)) ? 1 : 0;
+}
+
+extern "C" int spcl_conv3x3_dgrad_bnstats_image(const void* dy, int dtype, int N, int H, int W, int CinK, int CoutS,
+                                                const void* w_packed, void* g, const void* y2, const float* scale2,
+                                                const float* shift2, const float* mean2, const float* image,
+                                                float* rows11, void* stream) {
+  SPCL_CHECK_ARG(dy && w_packed && g && y2 && scale2 && shift2 && mean2 && image && rows11,
+                 "conv3x3_dgrad_bnstats_image: null pointer");
+  ConvArgs a;
+  if (!spcl_conv_dgrad_bnstats_image_supported(dtype, N, H, W, CinK, CoutS) ||
+      !dgrad_bnstats_args(a, dtype, N, H, W, CinK, CoutS)) {
+    set_error("conv3x3_dgrad_bnstats_image: unsupported configuration (bf16, 16 -> 16 channels, 14 x 14 tiles)");
+    return SPCL_EUNSUPPORTED;
+  }
+  a.x = dy; a.y = g; a.wp = w_packed;
+  a.y2 = y2; a.scale2 = scale2; a.shift2 = shift2; a.mean2 = mean2; a.rows2 = rows11; a.img2 = image;
+  hipStream_t st = (hipStream_t)stream;
+  const double px = (double)N * H * W;
+  prof_cost(px * (CinK + 2.0 * CoutS) * 2.0 + px * 4.0 + 9.0 * CinK * CoutS * 2.0,
+            2.0 * px * 9.0 * CinK * CoutS + 2.0 * px * 9.0 * CoutS);
+  TileCfg t = pick_tile(H, W);
+  if (!(t.tw == 14 && launch_conv_fast(a, t.th, st))) {
+    set_error("conv3x3_dgrad_bnstats_image: no specialised kernel for H=%d W=%d", H, W);
+    return SPCL_EUNSUPPORTED;
+  }
+  SPCL_LAUNCH_CHECK("conv3x3_dgrad_bnstats_image");
+  return SPCL_OK;
+}
+
 // The same for a POOLED boundary: dy is the gradient of the next block's first conv output, g = its input gradient =
 // d loss / d maxpool2x2(relu(bn(y2))) at H x W, y2 the raw conv output of the block before at H2 x W2 (H = H2 / 2).  The
 // epilogue routes g to the window's first positive maximum and leaves the per-tile partial sums of that BatchNorm's

@@ -46,6 +46,9 @@ struct ConvArgs {
   // ... or, with H2 > 0, of the POOLED layer: y2 is [N][H2][W2][CoutS] at twice the resolution (H == H2 / 2), the dgrad's
   // output is the gradient of maxpool2x2(relu(bn(y2)))
   int H2 = 0, W2 = 0;
+  // ... and, for the block whose first conv reads a ONE-CHANNEL f32 image (unet.py:123), the nine sums
+  // sum_p dz[p][co] img[p + tap] of that conv's weight gradient as rows 2 .. 10 of rows2 ([tile][11][CoutS], MODE 4)
+  const float* img2 = nullptr;
 };
 
 template <typename T> __device__ __forceinline__ f32x4 mfma_chunk(u32x4 w, u32x4 x, f32x4 acc);

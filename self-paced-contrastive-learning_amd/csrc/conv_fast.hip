@@ -33,6 +33,10 @@ struct FastArgs {
   float* rows2;             // [tile][2][CoutS]: sum dz, sum dz (y2 - mean)
   // MODE 3 (dgrad whose output g is the gradient of maxpool2x2(relu(bn(y2)))): y2 is [N][H2][W2][CoutS], H = H2 / 2
   int H2, W2;
+  // MODE 4 (= MODE 2 for the layer behind a one-channel f32 image): rows2 is [tile][11][CoutS]; rows 2 .. 10 hold
+  // sum_p dz[p][co] img[p + tap], the data-dependent part of that layer's weight gradient (dy = scale dz + A y + B: the
+  // A and B terms need no pass over the activations, bn.hip image3)
+  const float* img2;
 };
 
 // waves per SIMD the register allocator must leave room for: what the tile's LDS footprint allows anyway, at most 4
@@ -134,6 +138,22 @@ conv3x3_fast_kernel(FastArgs a) {
   const bool interior = y0 > 0 && x0 > 0 && y0 + TH < a.H && x0 + TW < a.W;  // whole halo inside the image
   const int nslab = KC < 64 ? 1 : a.CinK / KC;
   const int gps = (KC < 64 ? KC : a.CinK) * 2;  // bytes per pixel of x
+
+  constexpr bool M2 = MODE == 2 || MODE == 4;  // BN-backward sums of the layer whose activation gradient this is
+  // MODE 4: the lane's four pixels of the 16 x 16 image halo (row lane / 4, columns 4 (lane % 4) ..), zero outside the
+  // image; parked in registers across the k-loop, written to LDS when the activation halo is no longer needed
+  float imgv[MODE == 4 ? 4 : 1];
+  if (MODE == 4) {
+    const int hr = lane >> 2, hc = (lane & 3) * 4;
+    const int gy = y0 - 1 + hr;
+    const float* ir = a.img2 + ((size_t)n * a.H + (gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy))) * a.W;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int gx = x0 - 1 + hc + e;
+      const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      imgv[e] = in ? ir[gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx)] : 0.f;
+    }
+  }
 
   u32x4 wall[PRELOAD_W ? NSTEPS : 1][NT];
   if (PRELOAD_W) {
@@ -324,14 +344,20 @@ conv3x3_fast_kernel(FastArgs a) {
   for (int j = 0; j < NT; ++j) {
     ssum[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     ssq[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (MODE == 2 || MODE == 3) {
+    if (M2 || MODE == 3) {
       const int cb = (nt0 + j) * 16 + 4 * g;
       sc2[j] = *(const f32x4*)(a.scale2 + cb);
       sh2[j] = *(const f32x4*)(a.shift2 + cb);
       mu2[j] = *(const f32x4*)(a.mean2 + cb);
     }
   }
-  if (MODE == 2) y2b = a.y2 + (yb - a.y);
+  if (M2) y2b = a.y2 + (yb - a.y);
+  if (MODE == 4) {  // (one wave per workgroup: its own LDS reads of the k-loop are behind it)
+    float* limg = (float*)lds;
+    *(f32x4*)(limg + (lane >> 2) * 16 + (lane & 3) * 4) = (f32x4){imgv[0], imgv[1], imgv[2], imgv[3]};
+    __syncthreads();  // (one wave: an ordering point for the compiler -- without it the f32 tap reads below were scheduled
+                      //  ahead of this vector store and picked up whatever the LDS held: found by the determinism test)
+  }
   const bool shifted = (oy | ox) != 0;  // wave-uniform
   int pyc = py;                         // the pixel's row inside the tile, walked with px
   // MODE 2 / 3: every y2 value the statistics need is requested BEFORE the first output store (the k-loop's fragment
@@ -341,7 +367,7 @@ conv3x3_fast_kernel(FastArgs a) {
   constexpr int NWIN = MODE == 3 ? 4 : 1;
   // ... in chunks of GM m-tiles, the next chunk's requests ahead of this chunk's stores, two chunks in flight within a
   // register budget that the kernel's occupancy target leaves
-  constexpr bool YPRE = (MODE == 2 || MODE == 3) && KC >= SPCL_FAST_YPRE_MINKC;  // (128-register kernels: no room)
+  constexpr bool YPRE = (M2 || MODE == 3) && KC >= SPCL_FAST_YPRE_MINKC;  // (128-register kernels: no room)
   constexpr int YBUD = MODE == 3 ? 64 : 56, YR1 = NT * NWIN * 2;
   constexpr int GM = YBUD / (2 * YR1) > 0 ? YBUD / (2 * YR1) : 1;
   uint2 ypre[YPRE ? MT : 1][NT][NWIN];
@@ -355,7 +381,7 @@ conv3x3_fast_kernel(FastArgs a) {
         if (ok) {
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
-            if (MODE == 2) {
+            if (M2) {
               ypre[i][j][0] = *(const uint2*)(y2b + lob + j * 32);
             } else {
               const unsigned char* wb = a.y2 +
@@ -394,7 +420,7 @@ conv3x3_fast_kernel(FastArgs a) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         store4_fast<bf16_t>(yb + ob + j * 32, acc[i][j]);
-        if (MODE == 2) {
+        if (M2) {
           // dz = g [relu(bn(y2)) > 0] with g as STORED (bf16): sum dz and sum dz (y2 - mean) of the lane's 4 channels
           const uint2 yr = YPRE ? ypre[i][j][0] : *(const uint2*)(y2b + ob + j * 32);
           const f32x2 glo = {acc[i][j][0], acc[i][j][1]}, ghi = {acc[i][j][2], acc[i][j][3]};
@@ -409,6 +435,7 @@ conv3x3_fast_kernel(FastArgs a) {
             const float dz = fmaf(sc2[j][r], yv[r], sh2[j][r]) > 0.f ? gv[r] * keep : 0.f;
             ssum[j][r] += dz;
             ssq[j][r] = fmaf(dz, yv[r] - mu2[j][r], ssq[j][r]);
+            if (MODE == 4) acc[i][j][r] = dz;  // (g is stored: the accumulator now carries dz for the tap sums below)
           }
         } else if (MODE == 3) {
           // the 2x2 window of y2 under this pooled pixel: the gradient goes to the first maximum of relu(bn(y2)) in scan
@@ -461,7 +488,8 @@ conv3x3_fast_kernel(FastArgs a) {
       ob += wrapo;
     }
   }
-  if (MODE == 2 || MODE == 3) {
+  constexpr int RS = MODE == 4 ? 11 : 2;  // rows per tile of rows2
+  if (M2 || MODE == 3) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       f32x4 o;
@@ -470,7 +498,48 @@ conv3x3_fast_kernel(FastArgs a) {
         const float s1 = row16_sum(ssum[j][r]), s2 = row16_sum(ssq[j][r]);
         o[r] = r16 == 0 ? s1 : s2;
       }
-      if (r16 < 2) *(f32x4*)(a.rows2 + ((size_t)tile * 2 + r16) * a.CoutS + (nt0 + j) * 16 + 4 * g) = o;
+      if (r16 < 2) *(f32x4*)(a.rows2 + ((size_t)tile * RS + r16) * a.CoutS + (nt0 + j) * 16 + 4 * g) = o;
+    }
+    if (MODE == 4) {
+      // S[tap][co] = sum over the tile's pixels of dz[p][co] img[p + tap]: 9 x 4 accumulators per lane over its MT
+      // pixels (36 packed FMAs per pixel in the shadow of the other waves' memory waits), one 16-lane row sum per value
+      static_assert(MODE != 4 || NT == 1, "image tap sums: one n-tile");
+      // single-dword LDS reads (volatile, LDS address space): the tap values of a pixel sit at 4-byte-aligned addresses
+      // and the compiler's pairing of neighbours into ds_read2_b32 ... offset1:offset0+1 returned a wrong SECOND dword in
+      // ~10 % of the tiles, differently from run to run (the three centre-column taps; found by the determinism test,
+      // tools/diag/img3_determinism.py) -- adjacent pairs appear to want 8-byte alignment on this part
+      typedef const volatile float __attribute__((address_space(3))) lds_cvf;
+      lds_cvf* limg = (lds_cvf*)(uintptr_t)((unsigned)(uintptr_t)(unsigned char __attribute__((address_space(3)))*)lds);
+      f32x4 S[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) S[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      int qy = r16 / TW, qx = r16 - qy * TW;  // the lane's pixel of m-tile 0 (tile coordinates)
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const bool ok = (16 * i + 15 < NPIX) || (16 * i + r16 < NPIX);
+        if (ok) {
+          lds_cvf* c0 = limg + qy * 16 + qx;  // halo (qy + ky, qx + kx) is image pixel (qy + ky - 1, qx + kx - 1)
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) S[ky * 3 + kx] += acc[i][0] * c0[ky * 16 + kx];
+        }
+        qx += DPX;
+        qy += DPY;
+        if (qx >= TW) {
+          qx -= TW;
+          qy += 1;
+        }
+      }
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float sv = row16_sum(S[t][r]);
+          o[r] = r16 == t ? sv : o[r];
+        }
+      if (r16 < 9) *(f32x4*)(a.rows2 + ((size_t)tile * RS + 2 + r16) * a.CoutS + nt0 * 16 + 4 * g) = o;
     }
   } else if (a.stats != nullptr) {
 #pragma unroll
@@ -594,7 +663,10 @@ static void launch_fast(const FastArgs& a, int mode, hipStream_t st) {
     (void)hipMalloc(&b.stamps, nwg * 4 * sizeof(unsigned long long));
     (void)hipMemset(b.stamps, 0, nwg * 4 * sizeof(unsigned long long));
   }
-  if (mode == 1) SPCL_LAUNCH((conv3x3_fast_kernel<KC, TH, NT, 1, NW>), grid, block, lds, st, b);
+  if (a.img2 != nullptr) {
+    if constexpr (KC == 16 && TH == 14 && NT == 1 && NW == 1)
+      SPCL_LAUNCH((conv3x3_fast_kernel<KC, TH, NT, 4, NW>), grid, block, lds, st, b);
+  } else if (mode == 1) SPCL_LAUNCH((conv3x3_fast_kernel<KC, TH, NT, 1, NW>), grid, block, lds, st, b);
   else if (a.rows2 != nullptr && a.H2 > 0) SPCL_LAUNCH((conv3x3_fast_kernel<KC, TH, NT, 3, NW>), grid, block, lds, st, b);
   else if (a.rows2 != nullptr) SPCL_LAUNCH((conv3x3_fast_kernel<KC, TH, NT, 2, NW>), grid, block, lds, st, b);
   else SPCL_LAUNCH((conv3x3_fast_kernel<KC, TH, NT, 0, NW>), grid, block, lds, st, b);
@@ -620,7 +692,7 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
     FastArgs a;
     a.x = (const unsigned char*)c.x; a.y = (unsigned char*)c.y; a.wp = (const u32x4*)c.wp; a.stats = c.stats;
     a.in_scale = a.in_shift = nullptr;
-    a.y2 = nullptr; a.scale2 = a.shift2 = a.mean2 = nullptr; a.rows2 = nullptr; a.H2 = a.W2 = 0;
+    a.y2 = nullptr; a.scale2 = a.shift2 = a.mean2 = nullptr; a.rows2 = nullptr; a.H2 = a.W2 = 0; a.img2 = nullptr;
     a.N = c.N; a.H = c.H; a.W = c.W; a.CinK = 16; a.CoutS = 16;
     a.tilesX = cdiv(c.W, 14); a.tilesY = cdiv(c.H, 14); a.gy = 1; a.xcd_remap = 0; a.lds_flip = 0; a.stamps = nullptr;
     if (!dry) SPCL_LAUNCH((conv3x3_image_kernel<14>), dim3(a.tilesX, a.tilesY, a.N), dim3(64), 0, st, a);
@@ -648,7 +720,9 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
   a.in_scale = c.in_scale; a.in_shift = c.in_shift;
   a.y2 = (const unsigned char*)c.y2; a.scale2 = c.scale2; a.shift2 = c.shift2; a.mean2 = c.mean2; a.rows2 = c.rows2;
   a.H2 = c.H2; a.W2 = c.W2;
+  a.img2 = c.img2;
   if (c.rows2 != nullptr && c.in_mode != 0) return false;
+  if (c.img2 != nullptr && !(c.rows2 != nullptr && c.H2 == 0 && KC == 16 && th == 14 && ntn == 1)) return false;
   a.N = c.N; a.H = c.H; a.W = c.W; a.CinK = c.CinK; a.CoutS = c.CoutS;
   a.tilesX = cdiv(c.W, 14); a.tilesY = cdiv(c.H, th); a.gy = ntn / (NT * nw);
   static const int env_remap = getenv("SPCL_CONV_XCD_REMAP") ? atoi(getenv("SPCL_CONV_XCD_REMAP")) : 1;

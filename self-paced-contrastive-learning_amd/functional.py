@@ -804,6 +804,52 @@ def _bnrelu_bwd_rows(y, dact, image, rows, dt_code, dtype, N, H, W, C, cs, st, t
     return first, dgamma, dbeta
 
 
+# opt-in (SPCL_IMAGE3=1): parity-green but SLOWER than the fused BN-backward + weight-gradient pass it replaces as it stands
+# (the dgrad epilogue's 36 FMAs per pixel and lane do not hide behind its memory waits)
+_IMAGE3 = os.environ.get("SPCL_IMAGE3", "0") == "1"
+
+
+def _image3_supported(cfg, cin, dt_code, N, H, W, cout_s):
+    """the first conv of a one-channel-image block can get its BN backward and weight gradient WITHOUT a pass over its
+    output (csrc/bn.hip image3: dgrad epilogue sums + image autocorrelation)"""
+    return bool(_IMAGE3 and cfg.image_input and cin == 1 and cfg.dtype == torch.bfloat16 and
+                _n.call("spcl_conv_dgrad_bnstats_image_supported", dt_code, N, H, W, cout_s, cout_s))
+
+
+def _image_autocorr(image, N, H, W):
+    """partial rows of the 9 x 9 autocorrelation (45 sums) and the 9 shifted sums of the zero-padded f32 image batch"""
+    rows = _n.call("spcl_image_autocorr_rows", N, H, W)
+    out = torch.empty(rows, 64, dtype=torch.float32, device=image.device)
+    _n.call("spcl_image_autocorr", _n.ptr(image), N, H, W, _n.ptr(out), _n.stream())
+    return out
+
+
+def _dgrad_bnstats_image(dy, wp_t, y2, st2, image, dt_code, dtype, N, H, W, cs):
+    """_dgrad_bnstats for the image block: the per-tile rows carry nine more sub-rows, sum dz * image[p + tap]"""
+    dev = dy.device
+    nt = _n.call("spcl_conv_stat_rows", dt_code, N, H, W, cs, cs)
+    g = torch.empty(N, H, W, cs, dtype=dtype, device=dev)
+    rows = torch.empty(nt * 11 * cs, dtype=torch.float32, device=dev)
+    _n.call("spcl_conv3x3_dgrad_bnstats_image", _n.ptr(dy), dt_code, N, H, W, cs, cs, _n.ptr(wp_t), _n.ptr(g), _n.ptr(y2),
+            _n.ptr(st2[2]), _n.ptr(st2[3]), _n.ptr(st2[0]), _n.ptr(image), _n.ptr(rows), _n.stream())
+    rows.ntiles = nt
+    return g, rows
+
+
+def _bnrelu_bwd_rows_image3(rows, acorr, w, N, H, W, C, cs, st, training, sinks):
+    """BN + ReLU backward of the image block's first conv and its weight gradient from the rows and the autocorrelation
+    -> (dW, dgamma, dbeta); dW goes straight into its sink (no tail: the final kernel writes it)"""
+    dev = rows.device
+    ws = torch.empty(_n.call("spcl_bnrelu_image3_workspace_bytes", cs) // 4, dtype=torch.float32, device=dev)
+    dw = _grad_buffer(sinks[0], (C, 1, 3, 3), dev)
+    dgamma, dbeta = _grad_buffer(sinks[1], (C,), dev), _grad_buffer(sinks[2], (C,), dev)
+    wc = w.detach().contiguous().float()
+    _n.call("spcl_bnrelu_backward_rows_image3", _n.ptr(rows), rows.ntiles, _n.ptr(acorr), acorr.shape[0], _n.ptr(wc), N, H,
+            W, C, cs, _n.ptr(st[0]), _n.ptr(st[1]), _n.ptr(st[2]), int(training), _n.ptr(ws), _n.ptr(dgamma), _n.ptr(dbeta),
+            _n.ptr(dw), _n.stream())
+    return dw, dgamma, dbeta
+
+
 def _bnrelu_pool_bwd_rows(y, dpool, rows, dt_code, dtype, N, H, W, C, cs, st, training, sinks):
     """BN + ReLU + max-pool backward finished from the rows the next block's dgrad left -> (dy, dgamma, dbeta)."""
     dev = y.device
@@ -856,6 +902,10 @@ class _ConvBlockFn(torch.autograd.Function):
         pool = torch.empty(N, H // 2, W // 2, cout_s, dtype=dtype, device=dev) if cfg.need_pool else None
         _n.call("spcl_bnrelu_pool_forward", _n.ptr(yb), dtc, N, H, W, cout_s, _n.ptr(stb[2]), _n.ptr(stb[3]),
                 _n.ptr(act), _n.ptr(pool), _n.stream())
+        ctx.acorr = None
+        if (need_bwd and ctx.needs_input_grad[1] and not ctx.needs_input_grad[0]
+                and _image3_supported(cfg, cin, dtc, N, H, W, cout_s)):
+            ctx.acorr = _image_autocorr(xs, N, H, W)  # (of the input image only: ready long before backward needs it)
         ctx.save_for_backward(xs, ya, yb, sta, stb, wa, wb)
         ctx.params = (wa, ga, ba, wb, gb, bb)
         ctx.packed_t = (wpa_t, wpb_t)
@@ -899,15 +949,22 @@ class _ConvBlockFn(torch.autograd.Function):
             wpb_t = _pack(wb, 1, dtc, dtype)
         # the dgrad's output is d loss / d relu(bn_a(ya)): where a specialised kernel exists its epilogue also leaves the
         # per-tile partial sums of bn_a's backward (no separate reduction pass over ya and the gradient)
-        fused = _dgrad_bnstats(dyb, wpb_t, ya, sta, dtc, dtype, N, H, W, cout_s, cout_s) if dtype == torch.bfloat16 \
-            else None
+        image3 = ctx.acorr is not None
+        if image3:
+            fused = _dgrad_bnstats_image(dyb, wpb_t, ya, sta, xs, dtc, dtype, N, H, W, cout_s)
+        else:
+            fused = _dgrad_bnstats(dyb, wpb_t, ya, sta, dtc, dtype, N, H, W, cout_s, cout_s) \
+                if dtype == torch.bfloat16 else None
         if fused is not None:
             daa, rows = fused
         else:
             daa, _ = _conv(dyb, dtc, dtype, N, H, W, cout_s, cout_s, cout_s, wpb_t, 0, None, None, False)
         # ---- first conv
         image_fused = ctx.needs_input_grad[1] and not ctx.needs_input_grad[0] and _image_wgrad_fusable(cfg, cin, cout_s)
-        if image_fused:
+        if image3:
+            dya = None  # no pass over ya / the gradient at all: rows + image autocorrelation -> dW, dgamma, dbeta
+            dwa, dga, dba = _bnrelu_bwd_rows_image3(rows, ctx.acorr, wa, N, H, W, cout, cout_s, sta, cfg.training, sk[0:3])
+        elif image_fused:
             dya = None  # dy of this layer feeds only dW: one fused pass, nothing written
             if fused is not None:
                 dwa, dga, dba = _bnrelu_bwd_rows(ya, daa, xs, rows, dtc, dtype, N, H, W, cout, cout_s, sta, cfg.training,

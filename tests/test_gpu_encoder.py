@@ -294,6 +294,54 @@ def test_deferred_wide_weight_gradients_bf16():
         assert w.abs().max() > 0 and torch.isfinite(w).all()
 
 
+def test_image3_first_layer_gradient_without_a_pass_over_its_output():
+    """bf16, one-channel image, 224 x 224 (14 x 14 tiles): the first conv's weight gradient and BN backward come from the
+    Conv1.b dgrad epilogue's tap sums + the image autocorrelation (csrc/bn.hip image3: dW = scale S1 + A (W R) + B S3) instead
+    of the fused pass over y and g.  Same values as that pass (which tests/test_gpu_kernels.py holds against fp64 math):
+    dgamma / dbeta bit for bit (same per-tile rows), dW within bf16 storage noise; and the standalone kernels against numpy."""
+    import spcl_amd  # noqa
+    from spcl_amd import functional as F_, native as _n
+    g = torch.Generator().manual_seed(2)
+    img = torch.rand(3, 1, 224, 224, generator=g).cuda()
+    # ---- the autocorrelation kernel alone
+    acorr = F_._image_autocorr(img.permute(0, 2, 3, 1).contiguous(), 3, 224, 224).double().sum(0).cpu().numpy()
+    a = torch.nn.functional.pad(img.bfloat16().double().cpu(), (2, 2, 2, 2))[:, 0]
+    f = torch.nn.functional.pad(img.double().cpu(), (2, 2, 2, 2))[:, 0]
+    shift = lambda t, k: t[:, 1 + k // 3:1 + k // 3 + 224, 1 + k % 3:1 + k % 3 + 224]  # noqa: E731  img0[p + tap - 1]
+    k = 0
+    for u in range(9):
+        for v in range(u, 9):
+            want = float((shift(a, u) * shift(a, v)).sum())
+            assert abs(acorr[k] - want) < 2e-6 * abs(want), (u, v, acorr[k], want)
+            k += 1
+    for t in range(9):
+        want = float(shift(f, t).sum())
+        assert abs(acorr[45 + t] - want) < 2e-6 * abs(want), (t, acorr[45 + t], want)
+    # ---- the whole block, new path against the old one
+    res, default = {}, F_._IMAGE3
+    for on in (False, True, True):
+        F_._IMAGE3 = on
+        try:
+            net, _ = _unet(256, 7, torch.bfloat16)
+            for name in net.decoder_names:
+                getattr(net, "_" + name).requires_grad_(False)
+            out = net(img, until="Conv2")
+            w = torch.rand(out.shape, generator=torch.Generator().manual_seed(3)).cuda().to(out.dtype)
+            (out.float() * w.float()).sum().backward()
+            c1 = net._Conv1.conv
+            grads = [p.grad.detach().float().cpu().clone() for p in (c1[0].weight, c1[1].weight, c1[1].bias, c1[3].weight)]
+            if on in res:  # the second run of the new path: bit-identical (fixed-order sums, no racing reads)
+                assert all(torch.equal(a, b) for a, b in zip(res[on], grads))
+            res[on] = grads
+        finally:
+            F_._IMAGE3 = default
+    dw0, dg0, db0, dwb0 = res[False]
+    dw1, dg1, db1, dwb1 = res[True]
+    assert torch.equal(dg0, dg1) and torch.equal(db0, db1) and torch.equal(dwb0, dwb1)
+    assert dw0.abs().max() > 0
+    assert _relerr(dw1.numpy(), dw0.numpy()) < 3e-3, _relerr(dw1.numpy(), dw0.numpy())
+
+
 def test_two_buckets_armed_in_one_step_keep_their_own_deferred_gradients():
     """the deferred weight-gradient queue belongs to the bucket that armed the sink.  Two buckets armed in one
     step (Conv1..Conv4 | Conv5 + head) both receive their wide layers' gradients whatever the gather order, and a step

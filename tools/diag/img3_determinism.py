@@ -1,0 +1,44 @@
+import sys, torch
+sys.path.insert(0, "/root/repo")
+import spcl_amd
+from spcl_amd import functional as F_, native as _n
+torch.manual_seed(0)
+N,H,W,cs=16,224,224,16
+dtc=_n.dtype_code(torch.bfloat16)
+g=torch.Generator().manual_seed(1)
+img=torch.rand(N,H,W,1,generator=g).cuda()
+dy=(torch.randn(N,H,W,cs,generator=g)*0.01).cuda().bfloat16()
+y2=torch.randn(N,H,W,cs,generator=g).cuda().bfloat16()
+w=torch.randn(16,16,3,3,generator=g).cuda()*0.1
+st=torch.stack([torch.zeros(cs),torch.ones(cs),torch.ones(cs),torch.zeros(cs)]).cuda().contiguous()
+wp=F_._pack(w,1,dtc,torch.bfloat16)
+outs=[]
+for rep in range(3):
+    gg,rows=F_._dgrad_bnstats_image(dy,wp,y2,st,img,dtc,torch.bfloat16,N,H,W,cs)
+    ac=F_._image_autocorr(img,N,H,W)
+    torch.cuda.synchronize()
+    outs.append((gg.clone(),rows.clone(),ac.clone()))
+for k,name in enumerate(("g","rows","acorr")):
+    a,b,c=outs[0][k],outs[1][k],outs[2][k]
+    print(name, torch.equal(a,b), torch.equal(a,c), float((a.float()-b.float()).abs().max()))
+r0,r1=outs[0][1].view(-1,11,cs),outs[1][1].view(-1,11,cs)
+d=(r0-r1).abs()
+print("rows diff per subrow:", d.amax(dim=(0,2)))
+bad=(d.amax(dim=(1,2))>0).nonzero().flatten()
+print("bad tiles:", bad[:20].tolist(), len(bad))
+# compare with reference for S1
+# ---- reference for the tap sums: S1[tile][tap][co] = sum over the tile's pixels of dz[p][co] * img[p + tap - 1]
+gg = outs[0][0].float()
+dz = gg * (y2.float() > 0).float()                       # scale 1, shift 0
+imgp = torch.nn.functional.pad(img[..., 0], (1, 1, 1, 1))  # [N, H+2, W+2]
+ref = torch.zeros(N, 16, 16, 9, cs, dtype=torch.float64, device="cuda")
+for t in range(9):
+    ky, kx = t // 3, t % 3
+    sh = imgp[:, ky:ky + H, kx:kx + W]                   # img[p + tap - 1]
+    prod = (dz.double() * sh.double().unsqueeze(-1))       # [N,H,W,cs]
+    ref[:, :, :, t] = prod.view(N, 16, 14, 16, 14, cs).sum(dim=(2, 4))
+ref = ref.view(-1, 9, cs)
+for rep in range(3):
+    got = outs[rep][1].view(-1, 11, cs)[:, 2:].double()
+    err = (got - ref).abs()
+    print("run", rep, "max err per tap:", [round(float(e), 4) for e in err.amax(dim=(0, 2))], "ref max", float(ref.abs().max()))
