@@ -200,7 +200,7 @@ def supcon_heads(criteria, projections, targets):
     else:
         return None
     z0 = projections[0]
-    if (z0.dim() != 2 or z0.shape[0] % 2 or z0.shape[0] >= _HEADS_MAX_ROWS or z0.shape[1] > 256
+    if (z0.dim() != 2 or z0.shape[0] % 2 or z0.shape[0] >= _HEADS_MAX_ROWS or z0.shape[1] > 4096
             or any(z.shape != z0.shape for z in projections)):
         return None
     n = z0.shape[0] // 2

@@ -23,6 +23,7 @@ struct SupconLayout {
   size_t off_P, off_rn2, off_logD, off_c, off_W, off_rowloss, off_cls, off_partA, off_partB, off_partC, off_partD, off_fin, off_Ph, off_Pm, off_L, off_dz, total;
 };
 constexpr int SUPCON_BIG_N2 = 1024;
+constexpr int SPCL_SUPCON_MAX_D = 4096;  // widest projection (d > 256 takes the chunked exact-f32 sweeps)
 constexpr int SUPCON_TILES_MAXT = 16;  // J tiles per workgroup of the fused large-batch sweeps  // from this many rows on the forward materialises the logits
 
 static int supcon_big_wgs() {
@@ -35,9 +36,13 @@ static SupconLayout supcon_layout(int n, int d) {
   L.n = n;
   L.d = d;
   L.N2 = 2 * n;
-  L.big = L.N2 >= SUPCON_BIG_N2;
+  // d > 256 ("wide": ProjectionHead(output_dim=...) takes any width, contrastyou/projectors/heads.py:78-92): the padded
+  // width is a multiple of 256 and the exact-f32 sweeps walk it in 256-feature chunks (supcon_sweep_wide_kernel); the
+  // one-workgroup and large-batch schedules are for d <= 256
+  const bool wide = d > 256;
+  L.big = L.N2 >= SUPCON_BIG_N2 && !wide;
   L.N2p = round_up(L.N2, L.big ? 128 : 64);
-  L.DP = d <= 64 ? 64 : (d <= 128 ? 128 : 256);
+  L.DP = d <= 64 ? 64 : (d <= 128 ? 128 : (d <= 256 ? 256 : round_up(d, 256)));
   int rb = L.N2p / 64;
   int cs = 1;
   while (rb * cs < 512 && cs * 2 <= rb) cs *= 2;
@@ -371,6 +376,187 @@ __global__ __launch_bounds__(256) void supcon_sweep_kernel(SupconArgs a_) {
     a.partA[(size_t)blockIdx.y * a.N2p + i] = acc0;
     a.partB[(size_t)blockIdx.y * a.N2p + i] = acc1;
   }
+}
+
+// ------------------------------------------------------------------------------------------------ wide features
+// d > 256: the same sweeps with the feature dimension walked in chunks of 256 (P rows are LD = 256 * nch floats apart):
+// per streamed 64-row tile the similarity tile is ACCUMULATED over the chunks -- each chunk staged in LDS in turn, the
+// own rows' fragments re-read from global memory per chunk -- before anything nonlinear touches it.  The generic path
+// for rare widths: correctness and the reference's "any output_dim" contract, not speed.
+constexpr int WIDE_C = 256;
+__device__ __forceinline__ void stage_tile_ld(const float* __restrict__ P, int LD, int J0, float* lds, int sub, int ns) {
+  constexpr int CPR = WIDE_C / 4;
+  for (int c = threadIdx.x; c < 64 * CPR; c += 256) {
+    int row = c / CPR, ch = c % CPR;
+    if (((row >> 4) % ns) != sub) continue;
+    f32x4 v = *(const f32x4*)(P + (size_t)(J0 + row) * LD + ch * 4);
+    *(f32x4*)(lds + row * WIDE_C + ((ch ^ (row & 15)) << 2)) = v;
+  }
+}
+__device__ __forceinline__ f32x4 sim_tile_acc(const float* lds, int nt, const f32x4* bi, int r16, int g, f32x4 acc) {
+  const int row = nt * 16 + r16;
+  const float* base = lds + row * WIDE_C;
+#pragma unroll
+  for (int s = 0; s < WIDE_C / 16; ++s) {
+    f32x4 a4 = *(const f32x4*)(base + (((4 * s + g) ^ r16) << 2));
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[0], bi[s][0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[1], bi[s][1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[2], bi[s][2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[3], bi[s][3], acc, 0, 0, 0);
+  }
+  return acc;
+}
+// the similarity tiles S[nt] (nt = ysub, ysub + ns, ... < 4) of this wave's 16 rows against streamed tile jt
+__device__ __forceinline__ void wide_sim_tiles(const SupconArgs& a, int LD, int nch, int jt, int i, float* lds, int ysub,
+                                               int r16, int g, f32x4* c /* [4] */) {
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) c[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int ch = 0; ch < nch; ++ch) {
+    __syncthreads();
+    stage_tile_ld(a.P + ch * WIDE_C, LD, jt * 64, lds, ysub, a.ns);
+    __syncthreads();
+    f32x4 bi[WIDE_C / 16];
+#pragma unroll
+    for (int s = 0; s < WIDE_C / 16; ++s) bi[s] = *(const f32x4*)(a.P + (size_t)i * LD + ch * WIDE_C + 16 * s + 4 * g);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+      if (nt >= ysub && (nt - ysub) % a.ns == 0) c[nt] = sim_tile_acc(lds, nt, bi, r16, g, c[nt]);
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void supcon_sweep_wide_kernel(SupconArgs a_, int LD, int nch) {
+  const SupconArgs a = supcon_head(a_, blockIdx.z);
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ float red[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int i = blockIdx.x * 64 + wave * 16 + r16;
+  const float m = block_max_logit(a.rn2, a.N2, a.t, red);
+  const int in = i >= a.n ? i - a.n : i;
+  const float lab_i = (a.labels != nullptr && i < a.N2) ? a.labels[in] : 0.f;
+  float logD_i = 0.f;
+  if (MODE == 1) logD_i = a.logD[i];
+  float acc0 = 0.f, acc1 = 0.f;
+  const int ntiles = a.N2p / 64;
+  const int ysub = blockIdx.y % a.ns, ycs = blockIdx.y / a.ns, ncs = gridDim.y / a.ns;
+  for (int jt = ycs; jt < ntiles; jt += ncs) {
+    f32x4 cs[4];
+    wide_sim_tiles(a, LD, nch, jt, i, lds, ysub, r16, g, cs);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      if (!(nt >= ysub && (nt - ysub) % a.ns == 0)) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = jt * 64 + nt * 16 + 4 * g + r;
+        PairMask pm = pair_mask(a, i, j, lab_i);
+        const float logit = cs[nt][r] / a.t - m;
+        if (MODE == 0) {
+          acc0 += pm.valid ? expf(logit) : 0.f;
+          acc1 += pm.pos ? 1.f : 0.f;
+        } else {
+          const float ell = logit - logD_i;
+          const float w = sp_weight(a.sp_mode, ell, a.gamma, a.inv_gamma);
+          acc0 += pm.pos ? w * ell : 0.f;
+          acc1 += pm.pos ? w : 0.f;
+        }
+      }
+    }
+  }
+  acc0 += __shfl_xor(acc0, 16, 64);
+  acc0 += __shfl_xor(acc0, 32, 64);
+  acc1 += __shfl_xor(acc1, 16, 64);
+  acc1 += __shfl_xor(acc1, 32, 64);
+  if (g == 0) {
+    a.partA[(size_t)blockIdx.y * a.N2p + i] = acc0;
+    a.partB[(size_t)blockIdx.y * a.N2p + i] = acc1;
+  }
+}
+
+// backward: dP[:, output chunk oc = blockIdx.z % nch] (head = blockIdx.z / nch).  The similarity tile is recomputed over
+// ALL chunks for every output chunk (nch times the forward's matrix work: the price of constant registers), then
+// H = G + G^T multiplies the staged chunk oc of the streamed rows.
+__global__ __launch_bounds__(256) void supcon_bwd_wide_kernel(SupconArgs a_, int LD, int nch,
+                                                              const float* __restrict__ out_fwd,
+                                                              float* __restrict__ dPpart /* [CS][N2p][LD] */,
+                                                              long hs_wsb) {
+  const int head = blockIdx.z / nch, oc = blockIdx.z - head * nch;
+  const SupconArgs a = supcon_head(a_, head);
+  out_fwd += 8 * head;
+  dPpart += (size_t)head * hs_wsb;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ float red[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r16 = lane & 15, g = lane >> 4;
+  const int I0 = blockIdx.x * 64 + wave * 16;
+  const int i = I0 + r16;
+  const float m = block_max_logit(a.rn2, a.N2, a.t, red);
+  const float kappa = out_fwd[2];
+  const int in = i >= a.n ? i - a.n : i;
+  const float lab_i = (a.labels != nullptr && i < a.N2) ? a.labels[in] : 0.f;
+  const float logD_i = a.logD[i], W_i = a.W[i];
+  const float kc_i = -kappa / a.cnt[i];
+  f32x4 acc2[WIDE_C / 64][4];
+#pragma unroll
+  for (int kt = 0; kt < WIDE_C / 64; ++kt)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc2[kt][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int ntiles = a.N2p / 64;
+  const int ysub = blockIdx.y % a.ns, ycs = blockIdx.y / a.ns, ncs = gridDim.y / a.ns;
+  for (int jt = ycs; jt < ntiles; jt += ncs) {
+    f32x4 cs[4];
+    wide_sim_tiles(a, LD, nch, jt, i, lds, ysub, r16, g, cs);
+    if (nch > 1 && oc != nch - 1) {  // (the last chunk is the one still staged)
+      __syncthreads();
+      stage_tile_ld(a.P + oc * WIDE_C, LD, jt * 64, lds, ysub, a.ns);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      if (!(nt >= ysub && (nt - ysub) % a.ns == 0)) continue;
+      float h[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = jt * 64 + nt * 16 + 4 * g + r;
+        float hv = 0.f;
+        if (i < a.N2 && j < a.N2 && i != j) {
+          const int jn = j >= a.n ? j - a.n : j;
+          const float lab_j = a.labels != nullptr ? a.labels[jn] : 0.f;
+          PairMask pij = pair_mask(a, i, j, lab_i);
+          PairMask pji = pair_mask(a, j, i, lab_j);
+          const float logit = cs[nt][r] / a.t - m;
+          const float ell_ij = logit - logD_i;
+          const float ell_ji = logit - a.logD[j];
+          const float w_ij = sp_weight(a.sp_mode, ell_ij, a.gamma, a.inv_gamma);
+          const float w_ji = sp_weight(a.sp_mode, ell_ji, a.gamma, a.inv_gamma);
+          const float g_ij = kc_i * ((pij.pos ? w_ij : 0.f) - (pij.valid ? W_i * expf(ell_ij) : 0.f));
+          const float g_ji = (-kappa / a.cnt[j]) * ((pji.pos ? w_ji : 0.f) - (pji.valid ? a.W[j] * expf(ell_ji) : 0.f));
+          hv = g_ij + g_ji;
+        }
+        h[r] = hv;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = nt * 16 + 4 * g + r;
+        const float* base = lds + row * WIDE_C;
+#pragma unroll
+        for (int kt = 0; kt < WIDE_C / 64; ++kt) {
+          f32x4 b4 = *(const f32x4*)(base + (((16 * kt + r16) ^ (row & 15)) << 2));
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            acc2[kt][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(h[r], b4[u], acc2[kt][u], 0, 0, 0);
+        }
+      }
+    }
+  }
+  float* dst = dPpart + (size_t)blockIdx.y * a.N2p * LD + oc * WIDE_C;
+#pragma unroll
+  for (int kt = 0; kt < WIDE_C / 64; ++kt)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      f32x4 v = {acc2[kt][0][rr], acc2[kt][1][rr], acc2[kt][2][rr], acc2[kt][3][rr]};
+      *(f32x4*)(dst + (size_t)(I0 + 4 * g + rr) * LD + 64 * kt + 4 * r16) = v;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ training sizes
@@ -2065,9 +2251,24 @@ static int launch_forward(const SupconLayout& L, SupconArgs a, float* ws, int co
   return 0;
 }
 
+static int launch_forward_wide(const SupconLayout& L, SupconArgs a, float* ws, int correct_grad, float* out,
+                               hipStream_t st, int K) {
+  dim3 grid(L.N2p / 64, L.CS, K);
+  const size_t lds = (size_t)64 * WIDE_C * sizeof(float);
+  const int nch = L.DP / WIDE_C;
+  SPCL_LAUNCH((supcon_sweep_wide_kernel<0>), grid, dim3(256), lds, st, a, L.DP, nch);
+  SPCL_LAUNCH((supcon_fin_kernel<0>), dim3(K), dim3(1024), 0, st, a.partA, a.partB, L.CS, L.N2, L.N2p,
+                     ws + L.off_logD, ws + L.off_c, (const float*)nullptr, (const float*)nullptr, 0, out, a.hs_ws);
+  SPCL_LAUNCH((supcon_sweep_wide_kernel<1>), grid, dim3(256), lds, st, a, L.DP, nch);
+  SPCL_LAUNCH((supcon_fin_kernel<1>), dim3(K), dim3(1024), 0, st, a.partA, a.partB, L.CS, L.N2, L.N2p,
+                     ws + L.off_rowloss, ws + L.off_W, (const float*)(ws + L.off_c), (const float*)(ws + L.off_rn2),
+                     correct_grad, out, a.hs_ws);
+  return 0;
+}
+
 static bool supcon_use_small(const SupconLayout& L) {
   static const bool sweeps = getenv("SPCL_SUPCON_SWEEPS") != nullptr;  // A/B switch: the multi-launch sweeps at any size
-  return !L.big && L.N2p == 64 && !sweeps;
+  return !L.big && L.N2p == 64 && !sweeps && L.DP <= 256;
 }
 
 static bool supcon_use_big(const SupconLayout& L, const float* mask) {
@@ -2240,12 +2441,12 @@ static int launch_forward_big(const SupconLayout& L, SupconArgs a, float* ws, in
 using namespace spcl;
 
 extern "C" size_t spcl_supcon_workspace_bytes(int n, int d) {
-  if (n <= 0 || d <= 0 || d > 256) return 0;
+  if (n <= 0 || d <= 0 || d > SPCL_SUPCON_MAX_D) return 0;
   return supcon_layout(n, d).total * sizeof(float);
 }
 
 extern "C" size_t spcl_supcon_bwd_workspace_bytes(int n, int d) {
-  if (n <= 0 || d <= 0 || d > 256) return 0;
+  if (n <= 0 || d <= 0 || d > SPCL_SUPCON_MAX_D) return 0;
   SupconLayout L = supcon_layout(n, d);
   // column-split partials of dP, then (large batches) the transposed bf16 splits of P [2][DP][N2p]
   return supcon_bwd_rows(L) * L.N2p * L.DP * sizeof(float) +
@@ -2301,7 +2502,8 @@ static int supcon_forward_impl(int K, const float* z1, const float* z2, long z_s
     else launch_forward_big<256>(L, a, ws, correct_grad, out, st);
   } else if (L.DP == 64) launch_forward<64>(L, a, ws, correct_grad, out, st, K);
   else if (L.DP == 128) launch_forward<128>(L, a, ws, correct_grad, out, st, K);
-  else launch_forward<256>(L, a, ws, correct_grad, out, st, K);
+  else if (L.DP == 256) launch_forward<256>(L, a, ws, correct_grad, out, st, K);
+  else launch_forward_wide(L, a, ws, correct_grad, out, st, K);
   SPCL_LAUNCH_CHECK(who);
   return SPCL_OK;
 }
@@ -2311,8 +2513,8 @@ extern "C" int spcl_supcon_forward(const float* z1, const float* z2, const float
                                    float* out, void* stream) {
   SPCL_CHECK_ARG(z1 && z2 && ws && out, "supcon_forward: null pointer");
   SPCL_CHECK_ARG(n > 0 && d > 0, "supcon_forward: bad shape n=%d d=%d", n, d);
-  if (d > 256) {
-    set_error("supcon_forward: proj dim %d > 256 unsupported", d);
+  if (d > SPCL_SUPCON_MAX_D) {
+    set_error("supcon_forward: proj dim %d > 4096 unsupported", d);
     return SPCL_EUNSUPPORTED;
   }
   SPCL_CHECK_ARG(sp_mode >= 0 && sp_mode <= 2, "supcon_forward: sp_mode %d", sp_mode);
@@ -2327,8 +2529,8 @@ extern "C" int spcl_supcon_forward_heads(int K, const float* z1, const float* z2
   SPCL_CHECK_ARG(z1 && z2 && ws && out && gammas, "supcon_forward_heads: null pointer");
   SPCL_CHECK_ARG(K >= 1 && K <= 4, "supcon_forward_heads: %d heads (1..4)", K);
   SPCL_CHECK_ARG(n > 0 && d > 0, "supcon_forward_heads: bad shape n=%d d=%d", n, d);
-  if (d > 256) {
-    set_error("supcon_forward_heads: proj dim %d > 256 unsupported", d);
+  if (d > SPCL_SUPCON_MAX_D) {
+    set_error("supcon_forward_heads: proj dim %d > 4096 unsupported", d);
     return SPCL_EUNSUPPORTED;
   }
   SPCL_CHECK_ARG(sp_mode >= 0 && sp_mode <= 2, "supcon_forward_heads: sp_mode %d", sp_mode);
@@ -2349,7 +2551,7 @@ extern "C" int spcl_supcon_backward(const float* labels, const float* mask, int 
                                     const float* out_fwd, const float* grad_out, float* dz1, float* dz2,
                                     void* stream) {
   SPCL_CHECK_ARG(ws_fwd && ws_bwd && out_fwd && grad_out && dz1 && dz2, "supcon_backward: null pointer");
-  SPCL_CHECK_ARG(n > 0 && d > 0 && d <= 256, "supcon_backward: bad shape n=%d d=%d", n, d);
+  SPCL_CHECK_ARG(n > 0 && d > 0 && d <= SPCL_SUPCON_MAX_D, "supcon_backward: bad shape n=%d d=%d", n, d);
   return supcon_backward_impl(1, labels, mask, n, d, temperature, sp_mode, &gamma, ws_fwd, 0, ws_bwd, 0, out_fwd, grad_out,
                               dz1, dz2, 0, (hipStream_t)stream, "supcon_backward");
 }
@@ -2360,7 +2562,7 @@ extern "C" int spcl_supcon_backward_heads(int K, const float* labels, int n, int
                                           float* dz2, size_t z_stride, void* stream) {
   SPCL_CHECK_ARG(ws_fwd && ws_bwd && out_fwd && grad_out && dz1 && dz2 && gammas, "supcon_backward_heads: null pointer");
   SPCL_CHECK_ARG(K >= 1 && K <= 4, "supcon_backward_heads: %d heads (1..4)", K);
-  SPCL_CHECK_ARG(n > 0 && d > 0 && d <= 256, "supcon_backward_heads: bad shape n=%d d=%d", n, d);
+  SPCL_CHECK_ARG(n > 0 && d > 0 && d <= SPCL_SUPCON_MAX_D, "supcon_backward_heads: bad shape n=%d d=%d", n, d);
   SPCL_CHECK_ARG(K == 1 || (z_stride >= (size_t)n * d && ws_stride * sizeof(float) >= spcl_supcon_workspace_bytes(n, d) &&
                             wsb_stride * sizeof(float) >= spcl_supcon_bwd_workspace_bytes(n, d)),
                  "supcon_backward_heads: head strides smaller than a head");
@@ -2461,7 +2663,12 @@ static int supcon_backward_impl(int K, const float* labels, const float* mask, i
     size_t lds = (size_t)64 * L.DP * sizeof(float);
     if (L.DP == 64) SPCL_LAUNCH((supcon_bwd_kernel<64>), grid, dim3(256), lds, st, a, out_fwd, ws_bwd, wsb_stride);
     else if (L.DP == 128) SPCL_LAUNCH((supcon_bwd_kernel<128>), grid, dim3(256), lds, st, a, out_fwd, ws_bwd, wsb_stride);
-    else SPCL_LAUNCH((supcon_bwd_kernel<256>), grid, dim3(256), lds, st, a, out_fwd, ws_bwd, wsb_stride);
+    else if (L.DP == 256) SPCL_LAUNCH((supcon_bwd_kernel<256>), grid, dim3(256), lds, st, a, out_fwd, ws_bwd, wsb_stride);
+    else {
+      const int nch = L.DP / WIDE_C;
+      SPCL_LAUNCH(supcon_bwd_wide_kernel, dim3(L.N2p / 64, L.CS, K * nch), dim3(256), (size_t)64 * WIDE_C * sizeof(float), st,
+                  a, L.DP, nch, out_fwd, ws_bwd, wsb_stride);
+    }
   }
   size_t total = (size_t)2 * n * d;
   SPCL_LAUNCH(supcon_bwd_fin_kernel, dim3((unsigned)((total + 255) / 256), K), dim3(256), 0, st,
@@ -2476,7 +2683,7 @@ extern "C" int spcl_supcon_materialize(const float* labels, const float* mask, i
                                        float* sim_exp, float* pos_mask, float* neg_mask, float* sp_mask,
                                        void* stream) {
   SPCL_CHECK_ARG(ws_fwd, "supcon_materialize: null workspace");
-  SPCL_CHECK_ARG(n > 0 && d > 0 && d <= 256, "supcon_materialize: bad shape");
+  SPCL_CHECK_ARG(n > 0 && d > 0 && d <= SPCL_SUPCON_MAX_D, "supcon_materialize: bad shape");
   hipStream_t st = (hipStream_t)stream;
   SupconLayout L = supcon_layout(n, d);
   SupconArgs a = make_args(L, ws_fwd, labels, mask, temperature, sp_mode, gamma);

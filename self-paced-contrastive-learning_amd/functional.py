@@ -60,7 +60,7 @@ class _SupConFn(torch.autograd.Function):
             n, d = z1c.shape
         nbytes = _n.call("spcl_supcon_workspace_bytes", n, d)
         if nbytes == 0:
-            raise RuntimeError(f"supcon: unsupported shape n={n} d={d} (d must be <= 256)")
+            raise RuntimeError(f"supcon: unsupported shape n={n} d={d} (d must be <= 4096)")
         ws = torch.empty(nbytes // 4, dtype=torch.float32, device=z1.device)
         out = torch.empty(8, dtype=torch.float32, device=z1.device)  # the kernel writes loss, rho, kappa, norm defect
         _n.call("spcl_supcon_forward", _n.ptr(z1c), _n.ptr(z2c), _n.ptr(labels), _n.ptr(mask), n, d, c_float(t),
@@ -118,7 +118,7 @@ class _SupConHeadsFn(torch.autograd.Function):
             zall = torch.stack([z.detach().float() for z in zs])
         nbytes = _n.call("spcl_supcon_workspace_bytes", n, d)
         if nbytes == 0:
-            raise RuntimeError(f"supcon: unsupported shape n={n} d={d} (d must be <= 256)")
+            raise RuntimeError(f"supcon: unsupported shape n={n} d={d} (d must be <= 4096)")
         ws_stride = (nbytes // 4 + 63) // 64 * 64
         ws = torch.empty(K * ws_stride, dtype=torch.float32, device=dev)
         out = torch.empty(K, 8, dtype=torch.float32, device=dev)

@@ -52,7 +52,8 @@ def test_host_only_entry_points(lib):
     lib.spcl_conv_packed_elems.restype = ctypes.c_size_t
     lib.spcl_conv_wgrad_workspace_bytes.restype = ctypes.c_size_t
     assert lib.spcl_supcon_workspace_bytes(32, 256) > 64 * 256 * 4
-    assert lib.spcl_supcon_workspace_bytes(32, 1000) == 0  # proj dim > 256 unsupported
+    assert lib.spcl_supcon_workspace_bytes(32, 1000) > lib.spcl_supcon_workspace_bytes(32, 256)  # d > 256: chunked sweeps
+    assert lib.spcl_supcon_workspace_bytes(32, 5000) == 0  # proj dim > 4096 unsupported
     # 16->16 bf16 forward pack: 1 slab x 5 k-steps x 1 n-tile x 64 lanes x 8 elements
     assert lib.spcl_conv_packed_elems(16, 16, 0, 1) == 5 * 64 * 8
     assert lib.spcl_conv_packed_elems(1, 16, 0, 1) == 5 * 64 * 8   # image layer padded to 16 input channels

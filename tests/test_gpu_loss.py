@@ -55,6 +55,60 @@ def test_loss_golden_all_cases(golden):
                 np.testing.assert_allclose(crit.sp_mask.cpu().numpy(), g[f"{key}/sp_mask"], atol=1e-5)
 
 
+def test_loss_golden_wide_projections(golden):
+    """proj dim > 256 (the reference's ProjectionHead(output_dim=...) / contrast_loss3.py:25-31 take any width): d = 512 and
+    d = 600 against fixtures written from the reference (g8_wide.npz) -- the chunked exact-f32 sweeps of csrc/supcon.hip"""
+    g = golden("g8_wide.npz")
+    dev = "cuda:0"
+    for key in g["wide/cases"]:
+        key = str(key)
+        n, d, lname, mname = parse_case(key.split("/", 1)[1])
+        mode, gamma, cg = MODES[mname]
+        z1 = torch.tensor(g[f"wide/n{n}_d{d}/z1"], device=dev, requires_grad=True)
+        z2 = torch.tensor(g[f"wide/n{n}_d{d}/z2"], device=dev, requires_grad=True)
+        crit = _crit(mode, gamma, cg)
+        loss = crit(z1, z2, target=labels_of(lname, n))
+        loss.backward()
+        np.testing.assert_allclose(loss.item(), g[f"{key}/loss"], rtol=1e-4, atol=1e-5, err_msg=key)
+        if mname == "hard_7":
+            np.testing.assert_allclose(z1.grad.norm().item(), np.linalg.norm(g[f"{key}/dz1"]), rtol=5e-2)
+        else:
+            np.testing.assert_allclose(z1.grad.cpu().numpy(), g[f"{key}/dz1"], rtol=1e-3, atol=1e-5, err_msg=key)
+            np.testing.assert_allclose(z2.grad.cpu().numpy(), g[f"{key}/dz2"], rtol=1e-3, atol=1e-5, err_msg=key)
+        if mode is not None:
+            np.testing.assert_allclose(crit.downgrade_ratio, g[f"{key}/rho"], rtol=1e-4, err_msg=key)
+        if n <= 8:  # the lazily materialised taps at a wide d
+            assert crit.sim_logits.shape == (2 * n, 2 * n) and torch.isfinite(crit.sim_exp).all()
+
+
+def test_wide_projection_head_and_loss_end_to_end(golden):
+    """ProjectionHead(output_dim=512) against the reference's (g8_wide.npz), then the self-paced loss on its 512-wide
+    output against the oracle, gradients down to the head's input"""
+    from spcl_amd.contrastyou.projectors.heads import ProjectionHead
+    g = golden("g8_wide.npz")
+    head = ProjectionHead(input_dim=32, hidden_dim=24, output_dim=512, head_type="mlp", normalize=True)
+    head.load_state_dict({k.split("/", 2)[2]: torch.tensor(g[k]) for k in g.files if k.startswith("widehead/param/")})
+    head.cuda()
+    x = torch.tensor(g["widehead/x"], device="cuda", requires_grad=True)
+    z = head(x)
+    np.testing.assert_allclose(z.detach().cpu().numpy(), g["widehead/z"], rtol=1e-4, atol=1e-6)
+    (z * torch.tensor(g["widehead/r"], device="cuda")).sum().backward()
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g["widehead/dx"], rtol=2e-3, atol=1e-6)
+    for k, p in head.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), g[f"widehead/grad/{k}"], rtol=2e-3, atol=2e-6, err_msg=k)
+    # loss on the wide projection (3 slices x 2 views), vs the oracle
+    zz = head(x.detach()).detach()
+    a, b = zz[:3].cpu().clone().requires_grad_(True), zz[3:].cpu().clone().requires_grad_(True)
+    ref = O.supcon_loss(a, b, [0, 1, 0], gamma=9.0, mode="soft", correct_grad=True)
+    ref["loss"].backward()
+    u, v = zz[:3].clone().requires_grad_(True), zz[3:].clone().requires_grad_(True)
+    crit = _crit("soft", 9.0, True)
+    loss = crit(u, v, target=[0, 1, 0])
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), float(ref["loss"]), rtol=1e-4)
+    np.testing.assert_allclose(u.grad.cpu().numpy(), a.grad.numpy(), rtol=1e-3, atol=1e-5)
+
+
 def test_loss_mask_input(golden):
     g = golden("g1_loss.npz")
     dev = "cuda:0"
@@ -70,7 +124,8 @@ def test_loss_mask_input(golden):
 
 
 @pytest.mark.parametrize("n,d,nlab", [(32, 256, 3), (30, 256, 10), (100, 128, 7), (512, 128, 3), (2048, 128, 512),
-                                      (33, 100, 4), (700, 64, 5), (601, 200, 9), (2048, 128, 3)])
+                                      (33, 100, 4), (700, 64, 5), (601, 200, 9), (2048, 128, 3),
+                                      (32, 512, 3), (80, 1000, 5), (300, 384, 7), (600, 512, 4)])  # last four: d > 256
 @pytest.mark.parametrize("mname", ["supcon1", "soft_12_cg", "hard_1e6"])
 def test_loss_vs_oracle_seeded(n, d, nlab, mname):
     """Sizes up to BASELINE config E (2n=4096, d=128) against the fp32 oracle on the same seeded inputs."""

@@ -54,6 +54,24 @@ def test_g1_loss_matches_reference(golden):
             np.testing.assert_allclose(a.numpy(), g[f"{key}/dz1"], rtol=2e-3, atol=5e-6, err_msg=key)
 
 
+def test_g8_wide_projection_loss_matches_reference(golden):
+    """the oracle at projection widths beyond 256 (fixture written from the reference, tools/gen_golden.py wide)"""
+    g = golden("g8_wide.npz")
+    for key in g["wide/cases"]:
+        key = str(key)
+        n, d, lname, mname = parse_case(key.split("/", 1)[1])
+        mode, gamma, cg = MODES[mname]
+        z1 = torch.tensor(g[f"wide/n{n}_d{d}/z1"], requires_grad=True)
+        z2 = torch.tensor(g[f"wide/n{n}_d{d}/z2"], requires_grad=True)
+        r = O.supcon_loss(z1, z2, labels_of(lname, n), gamma=gamma, mode=mode or "hard", correct_grad=cg)
+        r["loss"].backward()
+        np.testing.assert_allclose(r["loss"].item(), g[f"{key}/loss"], rtol=2e-6, atol=1e-7, err_msg=key)
+        np.testing.assert_allclose(z1.grad.numpy(), g[f"{key}/dz1"], rtol=1e-4, atol=2e-6, err_msg=key)
+        np.testing.assert_allclose(z2.grad.numpy(), g[f"{key}/dz2"], rtol=1e-4, atol=2e-6, err_msg=key)
+        if mode is not None:
+            np.testing.assert_allclose(float(r["rho"]), g[f"{key}/rho"], rtol=1e-6, err_msg=key)
+
+
 def test_g1_mask_input(golden):
     g = golden("g1_loss.npz")
     z1 = torch.tensor(g["mask_n6_d32/z1"], requires_grad=True)

@@ -336,6 +336,50 @@ def gen_round2(SupConLoss1):
     print("g6_round2:", len(cases), "xpos cases + 3 heads")
 
 
+def gen_wide(SupConLoss1, SelfPacedSupConLoss):
+    """round 3: projection widths beyond 256 (the reference's ``ProjectionHead(output_dim=...)`` and
+    ``contrast_loss3.py:25-31`` take any width): both losses at d = 512 and d = 600 (not a multiple of the 256-feature
+    chunks), and a ProjectionHead with a 512-wide output."""
+    from contrastyou.projectors.heads import ProjectionHead
+    out, cases = {}, []
+    for (n, d) in [(8, 512), (30, 600)]:
+        z1, z2 = unit_rows(n, d, 300 + n), unit_rows(n, d, 400 + n)
+        out[f"wide/n{n}_d{d}/z1"], out[f"wide/n{n}_d{d}/z2"] = z1.numpy(), z2.numpy()
+        for lname, labels in label_sets(n).items():
+            for mname, mode, gamma, cg in LOSS_MODES:
+                # (the full grid lives in g1; here a sample that touches every mode and label set -- the fixture stays small)
+                if n == 8 and lname in ("distinct", "acdc") and mname not in ("supcon1", "soft_12_cg"):
+                    continue
+                if n == 30 and (lname, mname) not in (("mod3", "soft_12_cg"), ("none", "supcon1"), ("acdc", "hard_7"),
+                                                      ("mod3", "soft_3_cg")):
+                    continue
+                key = f"wide/n{n}_d{d}_{lname}_{mname}"
+                a, b = z1.clone().requires_grad_(True), z2.clone().requires_grad_(True)
+                if mode is None:
+                    crit = SupConLoss1(temperature=0.07)
+                else:
+                    crit = SelfPacedSupConLoss(temperature=0.07, weight_update=mode, correct_grad=cg)
+                    crit.set_gamma(gamma)
+                loss = crit(a, b, target=labels)
+                loss.backward()
+                out[f"{key}/loss"], out[f"{key}/dz1"], out[f"{key}/dz2"] = loss.detach().numpy(), a.grad.numpy(), b.grad.numpy()
+                out[f"{key}/rho"] = np.float32(getattr(crit, "downgrade_ratio", 1.0))
+                cases.append(key)
+    out["wide/cases"] = np.array(cases)
+    torch.manual_seed(707)
+    g = torch.Generator().manual_seed(78)
+    head = ProjectionHead(input_dim=32, hidden_dim=24, output_dim=512, head_type="mlp", normalize=True)
+    x = torch.randn(6, 32, 5, 7, generator=g, requires_grad=True)
+    r = torch.randn(6, 512, generator=g)
+    z = head(x)
+    (z * r).sum().backward()
+    out["widehead/x"], out["widehead/r"], out["widehead/z"], out["widehead/dx"] = x.detach().numpy(), r.numpy(), z.detach().numpy(), x.grad.numpy()
+    for k, p in head.named_parameters():
+        out[f"widehead/param/{k}"], out[f"widehead/grad/{k}"] = p.detach().numpy(), p.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "g8_wide.npz"), **out)
+    print("g8_wide:", len(cases), "loss cases + 1 head")
+
+
 def gen_data():
     """round 3, SURVEY row N2: index streams of the reference's ``ContrastBatchSampler`` (semi_seg/data/rearr.py:37-98,
     imported BY FILE PATH: it needs only the standard library and torch.utils.data.Sampler) and the partition tables of
@@ -431,6 +475,8 @@ def main():
         return gen_round2(SupConLoss1)
     if sys.argv[1:] == ["data"]:  # only the round-3 data-path fixture
         return gen_data()
+    if sys.argv[1:] == ["wide"]:  # only the round-3 wide-projection fixture
+        return gen_wide(SupConLoss1, SelfPacedSupConLoss)
     gen_loss(SupConLoss1, SelfPacedSupConLoss)
     gen_projector(ProjectionHead)
     gen_encoder(UNet)
@@ -438,6 +484,7 @@ def main():
     gen_decoder(UNet)
     gen_round2(SupConLoss1)
     gen_data()
+    gen_wide(SupConLoss1, SelfPacedSupConLoss)
 
 
 if __name__ == "__main__":
