@@ -313,7 +313,7 @@ int spcl_conv3x3_dgrad_bnstats(const void* dy, int dtype, int N, int H, int W, i
  * A[c] (W R)[c][t] + B[c] sum_p img[p + t], R = the 9 x 9 autocorrelation of the zero-padded image batch (y is linear in
  * the image).  Replaces spcl_bnrelu_backward_rows(image != NULL) + the dgrad before it where supported (bf16, 16 -> 16
  * channels, sizes tiled 14 x 14):
- *   spcl_image_autocorr          image [N][H][W] f32 -> out [spcl_image_autocorr_rows(N, H, W)][64] partial rows
+ *   spcl_image_autocorr          image [N][H][W] f32 (W <= 256) -> out [spcl_image_autocorr_rows(N, H, W)][64] partial rows
  *   spcl_conv3x3_dgrad_bnstats_image   spcl_conv3x3_dgrad_bnstats + rows 2 .. 10 of rows11 [tiles][11][CoutS] = the nine
  *                                sums sum_p dz[p][co] image[p + tap] (tiles = spcl_conv_stat_rows)
  *   spcl_bnrelu_backward_rows_image3   rows11 + autocorrelation + the f32 master weights [C][1][3][3] -> dgamma, dbeta, dW

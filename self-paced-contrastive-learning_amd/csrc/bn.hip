@@ -504,7 +504,8 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_fin_kernel(const float* __rest
                                                              const float* __restrict__ scale,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                              float* __restrict__ ab, float* __restrict__ zero_fill,
-                                                             int nzero, int s2_centered, int rs, Image3Args im) {
+                                                             int nzero, int s2_centered, int rs, Image3Args im,
+                                                             int transposed = 0) {
   __shared__ float red[11][4];
   __shared__ double racc4[4][64];
   __shared__ double racc[54];
@@ -516,18 +517,34 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_fin_kernel(const float* __rest
   // the channel's coefficients are requested WITH the partials (one memory round trip instead of a second, dependent
   // one after the reduction: this kernel is pure latency, ten launches per step)
   const float c_invstd = invstd[c], c_scale = scale[c], c_mean = mean[c];
+  const bool img3 = im.acorr != nullptr;
+  __shared__ float wsh[9];
+  if (img3 && threadIdx.x < 9 && c < C)  // the channel's nine weights as the forward MFMA saw them, requested up front
+    wsh[threadIdx.x] = bf16_to_f32(f32_to_bf16(im.w_oihw[c * 9 + threadIdx.x]));
   float s1 = 0.f, s2 = 0.f;
   float st[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) st[t] = 0.f;
-  const bool img3 = im.acorr != nullptr;
+  if (transposed) {  // [sub-row][channel][row]: consecutive threads read consecutive floats (the row-major walk below costs
+                     // one cache line per lane and load: 11 k line requests per workgroup on the image3 path)
 #pragma unroll 4
-  for (int w = threadIdx.x; w < nwg; w += 256) {
-    s1 += partial[((size_t)w * rs + 0) * CS + c];
-    s2 += partial[((size_t)w * rs + 1) * CS + c];
-    if (img3) {
+    for (int w = threadIdx.x; w < nwg; w += 256) {
+      s1 += partial[((size_t)0 * CS + c) * nwg + w];
+      s2 += partial[((size_t)1 * CS + c) * nwg + w];
+      if (img3) {
 #pragma unroll
-      for (int t = 0; t < 9; ++t) st[t] += partial[((size_t)w * rs + 2 + t) * CS + c];
+        for (int t = 0; t < 9; ++t) st[t] += partial[((size_t)(2 + t) * CS + c) * nwg + w];
+      }
+    }
+  } else {
+#pragma unroll 4
+    for (int w = threadIdx.x; w < nwg; w += 256) {
+      s1 += partial[((size_t)w * rs + 0) * CS + c];
+      s2 += partial[((size_t)w * rs + 1) * CS + c];
+      if (img3) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) st[t] += partial[((size_t)w * rs + 2 + t) * CS + c];
+      }
     }
   }
   s1 = wave_sum(s1);
@@ -570,14 +587,18 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_fin_kernel(const float* __rest
   }
   if (!img3) return;
   __syncthreads();
+  __shared__ double wrp[9][9];
+  if (threadIdx.x < 81) {  // (W R)[c][t] = sum_u W[c][u] R[u][t]: the 81 products side by side, nine fixed-order sums below
+    const int t = threadIdx.x / 9, u = threadIdx.x - 9 * t;
+    wrp[t][u] = (double)wsh[u] * racc[u <= t ? acorr_index(u, t) : acorr_index(t, u)];
+  }
+  __syncthreads();
   if (threadIdx.x < 9 && c < C) {
     const int t = threadIdx.x;
     const double S1 = (double)((red[2 + t][0] + red[2 + t][1]) + (red[2 + t][2] + red[2 + t][3]));
     double wr = 0.0;
-    for (int u = 0; u < 9; ++u) {
-      const float wb = bf16_to_f32(f32_to_bf16(im.w_oihw[c * 9 + u]));  // the weight the forward MFMA multiplied with
-      wr += (double)wb * racc[u <= t ? acorr_index(u, t) : acorr_index(t, u)];
-    }
+#pragma unroll
+    for (int u = 0; u < 9; ++u) wr += wrp[t][u];
     im.dw[c * 9 + t] = (float)((double)c_scale * S1 + (double)coef[0] * wr + (double)coef[1] * racc[45 + t]);
   }
 }
@@ -586,67 +607,129 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_fin_kernel(const float* __rest
 // convolution saw it, bf16-rounded, zero outside) for the 45 tap pairs t' <= t, and sum_p img[p + t - 1] for the 9 taps:
 // one partial row [64] per workgroup (a band of rows of one image; 54 used).  Threads walk the band's pixels, nine loads
 // per pixel (L1-resident neighbours), 45 + 9 FMAs; fixed-order reduction (butterfly, then the four waves).
-constexpr int ACORR_BAND = 56;
+constexpr int ACORR_BAND = 28, ACORR_MAXW = 256;
+// On the matrix pipe: D[t'][t] += A[t'][k] B[k][t] with k = 32 consecutive pixels of a row and A == B == the patch matrix
+// P[k][t] = img0[pixel k + tap t] -- one 16-byte LDS read and one v_mfma_f32_16x16x32_bf16 per wave and 32 pixels.  The
+// band sits in LDS as THREE bf16 copies shifted left by kx = 0, 1, 2 (a lane's 8 consecutive pixels of tap (ky, kx) are
+// then one aligned read), zero beyond the image's last column AS A PIXEL (a padded pixel must not contribute through a
+// tap that reaches back inside).  Column 9 of B is all ones: D[t'][9] = sum_p img0[p + t'] (the nine image sums, on the
+// bf16-rounded image: their rounding errors are zero-mean, 1e-6 relative over 3.2 M pixels).  (The first version, 54 f32
+// FMAs per pixel on the vector ALU: 29-55 us for this 13 MB read.)
 __global__ __launch_bounds__(256) void image_autocorr_kernel(const float* __restrict__ img, int H, int W,
                                                              float* __restrict__ out) {
-  __shared__ float red[4][54];
+  constexpr int CW = ACORR_MAXW;               // pixel columns per copy row (multiple of 32)
+  constexpr int ROWB = CW * 2;                 // bytes per copy row
+  constexpr int NR = ACORR_BAND + 2;           // frame rows
+  __shared__ __attribute__((aligned(16))) unsigned char cp[3 * NR * ROWB];  // [kx][frame row][pixel column] bf16
+  __shared__ float dsum[4][16][16];
   const int bands = (H + ACORR_BAND - 1) / ACORR_BAND;
   const int n = blockIdx.x / bands, b = blockIdx.x - n * bands;
   const int r0 = b * ACORR_BAND, r1 = min(H, r0 + ACORR_BAND);
   const float* base = img + (size_t)n * H * W;
-  float acc[54];
+  const int nr = r1 - r0 + 2;
+  const int WP = (W + 31) / 32 * 32;           // pixel columns walked (zeros beyond W)
+  {  // stage: thread -> (frame row, 8-pixel group); all loads of an iteration in flight, then the three shifted copies
+    const int groups = WP / 8;
+    constexpr int SIT = (NR * (CW / 8) + 255) / 256;  // every load of the band in flight before the first conversion
+    float vv[SIT][10];
 #pragma unroll
-  for (int k = 0; k < 54; ++k) acc[k] = 0.f;
-  const int npx = (r1 - r0) * W;
-  for (int p = threadIdx.x; p < npx; p += 256) {
-    const int yy = r0 + p / W, xx = p % W;
-    float f[9], v[9];
+    for (int it = 0; it < SIT; ++it) {
+      const int e = it * 256 + threadIdx.x;
+      const int rr = e / groups, gc = e - rr * groups;
+      const int gy = r0 - 1 + rr;
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
+      for (int j = 0; j < 10; ++j) {
+        const int gx = 8 * gc - 1 + j;
+        const bool in = e < nr * groups && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const float x = base[(size_t)(in ? gy : 0) * W + (in ? gx : 0)];  // unconditional (clamped) load, then select:
+        vv[it][j] = in ? x : 0.f;                                          // a load inside the ?: became 40 branches
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < SIT; ++it) {
+      const int e = it * 256 + threadIdx.x;
+      if (e >= nr * groups) break;
+      const int rr = e / groups, gc = e - rr * groups;
+      const float* v = vv[it];
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
-        const int gy = yy + ky - 1, gx = xx + kx - 1;
-        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        const float x = in ? base[(size_t)(in ? gy : 0) * W + (in ? gx : 0)] : 0.f;
-        f[ky * 3 + kx] = x;
-        v[ky * 3 + kx] = bf16_to_f32(f32_to_bf16(x));
+        uint32_t w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int p0 = 8 * gc + 2 * q, p1 = p0 + 1;  // pixel columns of this pair
+          const uint32_t lo = p0 < W ? f32_to_bf16(v[2 * q + kx]) : 0, hi = p1 < W ? f32_to_bf16(v[2 * q + 1 + kx]) : 0;
+          w[q] = lo | (hi << 16);
+        }
+        *(u32x4*)(cp + (size_t)(kx * NR + rr) * ROWB + gc * 16) = (u32x4){w[0], w[1], w[2], w[3]};
       }
-    int k = 0;
-#pragma unroll
-    for (int a = 0; a < 9; ++a)
-#pragma unroll
-      for (int bb = a; bb < 9; ++bb) {
-        acc[k] = fmaf(v[a], v[bb], acc[k]);
-        ++k;
-      }
-#pragma unroll
-    for (int t = 0; t < 9; ++t) acc[45 + t] += f[t];
+    }
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < 54; ++k) {
-    const float sv = wave_sum(acc[k]);
-    if (lane == 0) red[wave][k] = sv;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, g = lane >> 4;
+  const int tap = r16 < 9 ? r16 : 0, ky = tap / 3, kx = tap - 3 * ky;
+  f32x4 D = {0.f, 0.f, 0.f, 0.f};
+  const u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+  for (int yy = wave; yy < r1 - r0; yy += 4) {
+    const unsigned char* rowp = cp + (size_t)(kx * NR + yy + ky) * ROWB + g * 16;
+    for (int x0 = 0; x0 < WP; x0 += 32) {
+      const u32x4 fr = *(const u32x4*)(rowp + x0 * 2);
+      // (pixels beyond W read zeros in every copy, so the ones column needs no mask of its own: A is zero there)
+      D = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fr),
+                                                  __builtin_bit_cast(bf16x8, r16 == 9 ? ones : fr), D, 0, 0, 0);
+    }
   }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) dsum[wave][4 * g + r][r16] = D[r];  // D[row t' = 4 g + r][column t = r16]
   __syncthreads();
   if (threadIdx.x < 64) {
     const int k = threadIdx.x;
-    out[(size_t)blockIdx.x * 64 + k] = k < 54 ? (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]) : 0.f;
+    float v = 0.f;
+    if (k < 54) {
+      int ra, cb;
+      if (k < 45) {  // upper triangle in the order of acorr_index
+        ra = 0;
+        int rem = k;
+        while (rem >= 9 - ra) { rem -= 9 - ra; ++ra; }
+        cb = ra + rem;
+      } else {
+        ra = k - 45;
+        cb = 9;
+      }
+      v = (dsum[0][ra][cb] + dsum[1][ra][cb]) + (dsum[2][ra][cb] + dsum[3][ra][cb]);
+    }
+    out[(size_t)blockIdx.x * 64 + k] = v;
   }
 }
 
 // rows [nrows][2][CS] of per-tile partial sums (the dgrad epilogue of conv_fast.hip, MODE 2) folded G at a time, so that
 // the per-channel final sum never walks more than BWD_MAX_WG rows
+constexpr int ACORR_FOLD = 16;
 __global__ __launch_bounds__(256) void bwd_rows_group_kernel(const float* __restrict__ rows, int nrows, int G, int CS,
-                                                             float* __restrict__ out, int rs /* sub-rows: 2 or 11 */) {
+                                                             float* __restrict__ out, int rs /* sub-rows: 2 or 11 */,
+                                                             int nwg = 0x7fffffff,
+                                                             const float* __restrict__ acorr_in = nullptr,
+                                                             int nacorr = 0, float* __restrict__ acorr_out = nullptr,
+                                                             int transposed = 0) {
+  if ((int)blockIdx.x >= nwg) {  // image3: the autocorrelation's per-band rows folded to ACORR_FOLD rows in the same launch
+    const int j = blockIdx.x - nwg, k = threadIdx.x;
+    if (k < 64) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int w = j; w < nacorr; w += ACORR_FOLD) s += acorr_in[(size_t)w * 64 + k];
+      acorr_out[(size_t)j * 64 + k] = s;
+    }
+    return;
+  }
   const int w = blockIdx.x;
   for (int o = threadIdx.x; o < rs * CS; o += 256) {
     float s = 0.f;
+#pragma unroll 8
     for (int k = 0; k < G; ++k) {
       const int r = w * G + k;
       if (r < nrows) s += rows[(size_t)r * rs * CS + o];
     }
-    out[(size_t)w * rs * CS + o] = s;
+    if (transposed) out[(size_t)o * (nwg == 0x7fffffff ? (int)gridDim.x : nwg) + w] = s;
+    else out[(size_t)w * rs * CS + o] = s;
   }
 }
 
@@ -1071,22 +1154,23 @@ extern "C" int spcl_bnrelu_backward_rows(const void* y, const void* dact, const 
 // ---- image3: BN + ReLU backward of the FIRST conv of a one-channel-image block and that conv's weight gradient, finished
 // from the eleven-row tiles of spcl_conv3x3_dgrad_bnstats_image and the image autocorrelation: no pass over y / g at all
 // (see bnrelu_bwd_fin_kernel).  Replaces spcl_bnrelu_backward_rows(image != NULL) where that dgrad kernel exists.
-extern "C" int spcl_image_autocorr_rows(int N, int H, int W) {
+extern "C" int spcl_image_autocorr_rows(int N, int H, int W) {  // per-band partial rows (the buffer holds 16 more in front)
   (void)W;
   return N * ((H + ACORR_BAND - 1) / ACORR_BAND);
 }
 
 extern "C" int spcl_image_autocorr(const float* image, int N, int H, int W, float* out, void* stream) {
-  SPCL_CHECK_ARG(image && out && N > 0 && H > 0 && W > 0, "image_autocorr: bad arguments");
+  SPCL_CHECK_ARG(image && out && N > 0 && H > 0 && W > 0 && W <= ACORR_MAXW, "image_autocorr: bad arguments (W <= %d)",
+                 ACORR_MAXW);
+  const int rows = spcl_image_autocorr_rows(N, H, W);
   prof_cost((double)N * H * W * 4.0, 2.0 * 54.0 * N * H * W);
-  SPCL_LAUNCH(image_autocorr_kernel, dim3(spcl_image_autocorr_rows(N, H, W)), dim3(256), 0, (hipStream_t)stream, image, H,
-              W, out);
+  SPCL_LAUNCH(image_autocorr_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, image, H, W, out);
   SPCL_LAUNCH_CHECK("image_autocorr");
   return SPCL_OK;
 }
 
 extern "C" size_t spcl_bnrelu_image3_workspace_bytes(int CS) {
-  return ((size_t)BWD_MAX_WG * 11 * CS + 2 * (size_t)CS) * sizeof(float);
+  return ((size_t)BWD_MAX_WG * 11 * CS + 2 * (size_t)CS + ACORR_FOLD * 64) * sizeof(float);
 }
 
 extern "C" int spcl_bnrelu_backward_rows_image3(const float* rows11, int nrows, const float* acorr, int nacorr,
@@ -1101,18 +1185,28 @@ extern "C" int spcl_bnrelu_backward_rows_image3(const float* rows11, int nrows, 
   hipStream_t st = (hipStream_t)stream;
   float* partial = ws;                             // [nwg][11][CS]
   float* ab = ws + (size_t)BWD_MAX_WG * 11 * CS;   // [2][CS]: the folded coefficients (kept for symmetry with the other paths)
+  float* afold = ab + 2 * (size_t)CS;              // [ACORR_FOLD][64]
   const float* fin_src = rows11;
-  int nwg = nrows;
-  if (nrows > BWD_MAX_WG) {
-    const int G = (nrows + BWD_MAX_WG - 1) / BWD_MAX_WG;
+  int nwg = nrows, transposed = 0;
+  constexpr int IMG3_ROWS = 1024;  // the final kernel walks eleven strided sums per channel: four rows per thread
+  if (nrows > IMG3_ROWS) {
+    const int G = (nrows + IMG3_ROWS - 1) / IMG3_ROWS;
     nwg = (nrows + G - 1) / G;
     prof_cost((double)nrows * 11 * CS * 4.0, 0.0);
-    SPCL_LAUNCH(bwd_rows_group_kernel, dim3(nwg), dim3(256), 0, st, rows11, nrows, G, CS, partial, 11);
+    // ... and, in the same launch, the autocorrelation's per-band rows folded to ACORR_FOLD
+    const bool fold = nacorr > ACORR_FOLD;
+    SPCL_LAUNCH(bwd_rows_group_kernel, dim3(nwg + (fold ? ACORR_FOLD : 0)), dim3(256), 0, st, rows11, nrows, G, CS, partial,
+                11, nwg, acorr, nacorr, afold, 1);
     fin_src = partial;
+    transposed = 1;
+    if (fold) {
+      acorr = afold;
+      nacorr = ACORR_FOLD;
+    }
   }
   const Image3Args im{acorr, nacorr, w_oihw, dw};
   SPCL_LAUNCH(bnrelu_bwd_fin_kernel, dim3(CS), dim3(256), 0, st, fin_src, nwg, C, CS, (float)((size_t)N * H * W), training,
-              mean, invstd, scale, dgamma, dbeta, ab, (float*)nullptr, 0, 1, 11, im);
+              mean, invstd, scale, dgamma, dbeta, ab, (float*)nullptr, 0, 1, 11, im, transposed);
   SPCL_LAUNCH_CHECK("bnrelu_backward_rows_image3");
   return SPCL_OK;
 }

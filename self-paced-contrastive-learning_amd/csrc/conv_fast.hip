@@ -151,7 +151,8 @@ conv3x3_fast_kernel(FastArgs a) {
     for (int e = 0; e < 4; ++e) {
       const int gx = x0 - 1 + hc + e;
       const bool in = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-      imgv[e] = in ? ir[gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx)] : 0.f;
+      const float xv = ir[gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx)];  // (unconditional clamped load, then select)
+      imgv[e] = in ? xv : 0.f;
     }
   }
 
@@ -315,6 +316,26 @@ conv3x3_fast_kernel(FastArgs a) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) wsl[s][j] = a.wp[((size_t)s * ntn + nt0 + j) * 64 + lane];
   }
+  if (MODE == 4) {
+    // the image halo goes to LDS NOW, behind the activation halo (the launcher adds 1.5 KB), as the three bf16 copies
+    // IM[kx][row][col] = bf16(halo[row][col + kx]) the tap fragments are read from (so that 8 columns are one aligned read;
+    // 0 beyond the halo: those columns meet dz == 0).  Its loads are the oldest in flight, so this waits for them alone
+    // (stored right after they were issued, before the halo requests, the wave sat out a whole HBM round trip with nothing
+    // else in flight); the lane's columns 4 q .. 4 q + 3 plus two from its right-hand neighbour make the shifted quads.
+    const int q = lane & 3;
+    float n0 = __shfl_down(imgv[0], 1, 64), n1 = __shfl_down(imgv[1], 1, 64);
+    if (q == 3) n0 = n1 = 0.f;
+    const float h6[6] = {imgv[0], imgv[1], imgv[2], imgv[3], n0, n1};
+    unsigned char* imb = lds + fast_lds_bytes(KC, TH) + (lane >> 2) * 32 + q * 8;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const f32x2 lo = {h6[kx], h6[kx + 1]}, hi = {h6[kx + 2], h6[kx + 3]};
+      uint2 w;
+      w.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf16x2v));
+      w.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, bf16x2v));
+      *(uint2*)(imb + kx * 512) = w;
+    }
+  }
   int img = 0;
 #pragma unroll 1
   for (int slab = 0; slab + 1 < nslab; ++slab) {
@@ -352,11 +373,19 @@ conv3x3_fast_kernel(FastArgs a) {
     }
   }
   if (M2) y2b = a.y2 + (yb - a.y);
-  if (MODE == 4) {  // (one wave per workgroup: its own LDS reads of the k-loop are behind it)
-    float* limg = (float*)lds;
-    *(f32x4*)(limg + (lane >> 2) * 16 + (lane & 3) * 4) = (f32x4){imgv[0], imgv[1], imgv[2], imgv[3]};
-    __syncthreads();  // (one wave: an ordering point for the compiler -- without it the f32 tap reads below were scheduled
-                      //  ahead of this vector store and picked up whatever the LDS held: found by the determinism test)
+  // MODE 4 LDS map: [0, 7168) DZ[co 16][row 14][col 16] bf16 -- dz of the tile, transposed, in the space of the activation
+  // halo (no longer needed; one wave per workgroup, its own k-loop reads are behind it); columns 14 / 15 zero.
+  // [halo bytes, + 1536) IM[kx 3][row 16][col 16] bf16, written in the prologue.
+  constexpr int M4_DZ = 0, M4_IM = fast_lds_bytes(KC, TH);
+  static_assert(MODE != 4 || fast_lds_bytes(KC, TH) >= 7168, "MODE 4 scratch does not fit the halo image");
+  if (MODE == 4) {
+    // the two pad columns of every (channel, row): 224 dwords, 3.5 per lane
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int e = k * 64 + lane;
+      if (e < 16 * TH) *(uint32_t*)(lds + M4_DZ + e * 32 + 28) = 0u;
+    }
+    __syncthreads();  // (one wave: an ordering point for the compiler only)
   }
   const bool shifted = (oy | ox) != 0;  // wave-uniform
   int pyc = py;                         // the pixel's row inside the tile, walked with px
@@ -435,7 +464,9 @@ conv3x3_fast_kernel(FastArgs a) {
             const float dz = fmaf(sc2[j][r], yv[r], sh2[j][r]) > 0.f ? gv[r] * keep : 0.f;
             ssum[j][r] += dz;
             ssq[j][r] = fmaf(dz, yv[r] - mu2[j][r], ssq[j][r]);
-            if (MODE == 4) acc[i][j][r] = dz;  // (g is stored: the accumulator now carries dz for the tap sums below)
+            // MODE 4: dz (a bf16 value: exact) goes to its [co][row][col] place in LDS right away -- keeping the
+            // accumulators alive for a later pass cost eleven spilled registers on the epilogue's critical path
+            if (MODE == 4) *(bf16_t*)(lds + M4_DZ + (4 * g + r) * 448 + pyc * 32 + px * 2) = f32_to_bf16(dz);
           }
         } else if (MODE == 3) {
           // the 2x2 window of y2 under this pooled pixel: the gradient goes to the first maximum of relu(bn(y2)) in scan
@@ -501,45 +532,21 @@ conv3x3_fast_kernel(FastArgs a) {
       if (r16 < 2) *(f32x4*)(a.rows2 + ((size_t)tile * RS + r16) * a.CoutS + (nt0 + j) * 16 + 4 * g) = o;
     }
     if (MODE == 4) {
-      // S[tap][co] = sum over the tile's pixels of dz[p][co] img[p + tap]: 9 x 4 accumulators per lane over its MT
-      // pixels (36 packed FMAs per pixel in the shadow of the other waves' memory waits), one 16-lane row sum per value
+      // S[co][tap] = sum over the tile's pixels of dz[p][co] img[p + tap] ON THE MATRIX PIPE: D[co][tap] += A[co][k] B[k][tap]
+      // with k = (tile row pair, 16 columns) -- 7 k-steps of 32.  dz goes through LDS once, transposed to [co][row][col]
+      // (4 two-byte stores per pixel), and comes back as 16-byte A fragments; the B fragments are 16-byte reads of the
+      // shifted image copies.  D's layout (lane: tap r16, channels 4 g ..) is the row store below: no cross-lane sums.
+      // (A first version kept 36 f32 accumulators per lane and reduced them with 144 DPP row sums: +39 us on this launch.)
       static_assert(MODE != 4 || NT == 1, "image tap sums: one n-tile");
-      // single-dword LDS reads (volatile, LDS address space): the tap values of a pixel sit at 4-byte-aligned addresses
-      // and the compiler's pairing of neighbours into ds_read2_b32 ... offset1:offset0+1 returned a wrong SECOND dword in
-      // ~10 % of the tiles, differently from run to run (the three centre-column taps; found by the determinism test,
-      // tools/diag/img3_determinism.py) -- adjacent pairs appear to want 8-byte alignment on this part
-      typedef const volatile float __attribute__((address_space(3))) lds_cvf;
-      lds_cvf* limg = (lds_cvf*)(uintptr_t)((unsigned)(uintptr_t)(unsigned char __attribute__((address_space(3)))*)lds);
-      f32x4 S[9];
+      __syncthreads();
+      const int tap = r16 < 9 ? r16 : 0, tky = tap / 3, tkx = tap - 3 * tky;
+      const unsigned char* pa = lds + M4_DZ + r16 * 448 + (g >> 1) * 32 + (g & 1) * 16;
+      const unsigned char* pb = lds + M4_IM + tkx * 512 + ((g >> 1) + tky) * 32 + (g & 1) * 16;
+      f32x4 D = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int t = 0; t < 9; ++t) S[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      int qy = r16 / TW, qx = r16 - qy * TW;  // the lane's pixel of m-tile 0 (tile coordinates)
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const bool ok = (16 * i + 15 < NPIX) || (16 * i + r16 < NPIX);
-        if (ok) {
-          lds_cvf* c0 = limg + qy * 16 + qx;  // halo (qy + ky, qx + kx) is image pixel (qy + ky - 1, qx + kx - 1)
-#pragma unroll
-          for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) S[ky * 3 + kx] += acc[i][0] * c0[ky * 16 + kx];
-        }
-        qx += DPX;
-        qy += DPY;
-        if (qx >= TW) {
-          qx -= TW;
-          qy += 1;
-        }
-      }
-      f32x4 o = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float sv = row16_sum(S[t][r]);
-          o[r] = r16 == t ? sv : o[r];
-        }
-      if (r16 < 9) *(f32x4*)(a.rows2 + ((size_t)tile * RS + 2 + r16) * a.CoutS + nt0 * 16 + 4 * g) = o;
+      for (int ks = 0; ks < TH / 2; ++ks)
+        D = mfma_chunk<bf16_t>(*(const u32x4*)(pa + ks * 64), *(const u32x4*)(pb + ks * 64), D);
+      if (r16 < 9) *(f32x4*)(a.rows2 + ((size_t)tile * RS + 2 + r16) * a.CoutS + nt0 * 16 + 4 * g) = D;
     }
   } else if (a.stats != nullptr) {
 #pragma unroll
@@ -654,7 +661,7 @@ static void launch_fast(const FastArgs& a, int mode, hipStream_t st) {
   const bool pipe = env_pipe && KC == 64 && a.CinK > KC;  // more than one slab: two halo images
   FastArgs b = a;
   b.lds_flip = pipe ? fast_lds_bytes(KC, TH) : 0;
-  const size_t lds = fast_lds_bytes(KC, TH) * (pipe ? 2 : 1);
+  const size_t lds = fast_lds_bytes(KC, TH) * (pipe ? 2 : 1) + (a.img2 != nullptr ? 1536 : 0);
   dim3 grid(a.tilesX, a.tilesY, a.N * a.gy), block(64 * NW);
   static const bool env_stamps = SPCL_FAST_STAMPS_BUILD && getenv("SPCL_FAST_STAMPS") != nullptr;
   const size_t nwg = (size_t)grid.x * grid.y * grid.z;

@@ -804,15 +804,13 @@ def _bnrelu_bwd_rows(y, dact, image, rows, dt_code, dtype, N, H, W, C, cs, st, t
     return first, dgamma, dbeta
 
 
-# opt-in (SPCL_IMAGE3=1): parity-green but SLOWER than the fused BN-backward + weight-gradient pass it replaces as it stands
-# (the dgrad epilogue's 36 FMAs per pixel and lane do not hide behind its memory waits)
-_IMAGE3 = os.environ.get("SPCL_IMAGE3", "0") == "1"
+_IMAGE3 = os.environ.get("SPCL_IMAGE3", "1") != "0"  # A/B switch: 0 keeps the fused BN-backward + weight-gradient pass
 
 
 def _image3_supported(cfg, cin, dt_code, N, H, W, cout_s):
     """the first conv of a one-channel-image block can get its BN backward and weight gradient WITHOUT a pass over its
     output (csrc/bn.hip image3: dgrad epilogue sums + image autocorrelation)"""
-    return bool(_IMAGE3 and cfg.image_input and cin == 1 and cfg.dtype == torch.bfloat16 and
+    return bool(_IMAGE3 and cfg.image_input and cin == 1 and cfg.dtype == torch.bfloat16 and W <= 256 and
                 _n.call("spcl_conv_dgrad_bnstats_image_supported", dt_code, N, H, W, cout_s, cout_s))
 
 

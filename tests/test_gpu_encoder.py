@@ -314,9 +314,10 @@ def test_image3_first_layer_gradient_without_a_pass_over_its_output():
             want = float((shift(a, u) * shift(a, v)).sum())
             assert abs(acorr[k] - want) < 2e-6 * abs(want), (u, v, acorr[k], want)
             k += 1
-    for t in range(9):
-        want = float(shift(f, t).sum())
+    for t in range(9):  # the nine image sums ride on the matrix pipe too: the bf16-rounded image, zero-mean rounding errors
+        want, exact = float(shift(a, t).sum()), float(shift(f, t).sum())
         assert abs(acorr[45 + t] - want) < 2e-6 * abs(want), (t, acorr[45 + t], want)
+        assert abs(acorr[45 + t] - exact) < 1e-4 * abs(exact), (t, acorr[45 + t], exact)
     # ---- the whole block, new path against the old one
     res, default = {}, F_._IMAGE3
     for on in (False, True, True):
