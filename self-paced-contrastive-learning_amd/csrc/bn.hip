@@ -607,7 +607,7 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_fin_kernel(const float* __rest
 // convolution saw it, bf16-rounded, zero outside) for the 45 tap pairs t' <= t, and sum_p img[p + t - 1] for the 9 taps:
 // one partial row [64] per workgroup (a band of rows of one image; 54 used).  Threads walk the band's pixels, nine loads
 // per pixel (L1-resident neighbours), 45 + 9 FMAs; fixed-order reduction (butterfly, then the four waves).
-constexpr int ACORR_BAND = 28, ACORR_MAXW = 256;
+constexpr int ACORR_BAND = 20, ACORR_MAXW = 256;
 // On the matrix pipe: D[t'][t] += A[t'][k] B[k][t] with k = 32 consecutive pixels of a row and A == B == the patch matrix
 // P[k][t] = img0[pixel k + tap t] -- one 16-byte LDS read and one v_mfma_f32_16x16x32_bf16 per wave and 32 pixels.  The
 // band sits in LDS as THREE bf16 copies shifted left by kx = 0, 1, 2 (a lane's 8 consecutive pixels of tap (ky, kx) are
@@ -618,9 +618,13 @@ constexpr int ACORR_BAND = 28, ACORR_MAXW = 256;
 __global__ __launch_bounds__(256) void image_autocorr_kernel(const float* __restrict__ img, int H, int W,
                                                              float* __restrict__ out) {
   constexpr int CW = ACORR_MAXW;               // pixel columns per copy row (multiple of 32)
-  constexpr int ROWB = CW * 2;                 // bytes per copy row
   constexpr int NR = ACORR_BAND + 2;           // frame rows
-  __shared__ __attribute__((aligned(16))) unsigned char cp[3 * NR * ROWB];  // [kx][frame row][pixel column] bf16
+  // A fragment read is 16 lanes (the taps) x 4 k-groups of 16 bytes from nine different (ky, kx) rows: with power-of-two
+  // pitches all nine start in the same banks (the k-loop was LDS-bandwidth bound: 15 us for a 13 MB read).  Row pitch
+  // = 12 sixteen-byte slots mod 16, copy pitch = 4 slots mod 16: tap (ky, kx), k-group g starts at slot 12 ky + 4 kx + g.
+  constexpr int ROWB = CW * 2 + 192;
+  constexpr int COPYB = (NR * ROWB + 255) / 256 * 256 + 64;
+  __shared__ __attribute__((aligned(16))) unsigned char cp[3 * COPYB];  // [kx][frame row][pixel column] bf16
   __shared__ float dsum[4][16][16];
   const int bands = (H + ACORR_BAND - 1) / ACORR_BAND;
   const int n = blockIdx.x / bands, b = blockIdx.x - n * bands;
@@ -660,7 +664,7 @@ __global__ __launch_bounds__(256) void image_autocorr_kernel(const float* __rest
           const uint32_t lo = p0 < W ? f32_to_bf16(v[2 * q + kx]) : 0, hi = p1 < W ? f32_to_bf16(v[2 * q + 1 + kx]) : 0;
           w[q] = lo | (hi << 16);
         }
-        *(u32x4*)(cp + (size_t)(kx * NR + rr) * ROWB + gc * 16) = (u32x4){w[0], w[1], w[2], w[3]};
+        *(u32x4*)(cp + (size_t)kx * COPYB + (size_t)rr * ROWB + gc * 16) = (u32x4){w[0], w[1], w[2], w[3]};
       }
     }
   }
@@ -670,7 +674,7 @@ __global__ __launch_bounds__(256) void image_autocorr_kernel(const float* __rest
   f32x4 D = {0.f, 0.f, 0.f, 0.f};
   const u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
   for (int yy = wave; yy < r1 - r0; yy += 4) {
-    const unsigned char* rowp = cp + (size_t)(kx * NR + yy + ky) * ROWB + g * 16;
+    const unsigned char* rowp = cp + (size_t)kx * COPYB + (size_t)(yy + ky) * ROWB + g * 16;
     for (int x0 = 0; x0 < WP; x0 += 32) {
       const u32x4 fr = *(const u32x4*)(rowp + x0 * 2);
       // (pixels beyond W read zeros in every copy, so the ones column needs no mask of its own: A is zero there)

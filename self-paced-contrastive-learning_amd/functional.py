@@ -885,6 +885,11 @@ class _ConvBlockFn(torch.autograd.Function):
             cin_s = cin_k = xs.shape[3]
             mode_a = 0
         need_bwd = any(ctx.needs_input_grad)
+        ctx.acorr = None
+        if (need_bwd and ctx.needs_input_grad[1] and not ctx.needs_input_grad[0]
+                and _image3_supported(cfg, cin, dtc, N, H, W, cout_s)):
+            # of the input image only, and FIRST: the views have just been written (cache-warm), backward needs it much later
+            ctx.acorr = _image_autocorr(xs, N, H, W)
         pre_a, pre_b = take_prepacked(wa, dtc, H, W), take_prepacked(wb, dtc, H, W)
         if pre_a is not None and pre_b is not None:  # packed with the other layers at the start of the forward pass
             (wpa, wpa_t), (wpb, wpb_t) = pre_a, pre_b
@@ -900,10 +905,6 @@ class _ConvBlockFn(torch.autograd.Function):
         pool = torch.empty(N, H // 2, W // 2, cout_s, dtype=dtype, device=dev) if cfg.need_pool else None
         _n.call("spcl_bnrelu_pool_forward", _n.ptr(yb), dtc, N, H, W, cout_s, _n.ptr(stb[2]), _n.ptr(stb[3]),
                 _n.ptr(act), _n.ptr(pool), _n.stream())
-        ctx.acorr = None
-        if (need_bwd and ctx.needs_input_grad[1] and not ctx.needs_input_grad[0]
-                and _image3_supported(cfg, cin, dtc, N, H, W, cout_s)):
-            ctx.acorr = _image_autocorr(xs, N, H, W)  # (of the input image only: ready long before backward needs it)
         ctx.save_for_backward(xs, ya, yb, sta, stb, wa, wb)
         ctx.params = (wa, ga, ba, wb, gb, bb)
         ctx.packed_t = (wpa_t, wpb_t)
