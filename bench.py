@@ -432,8 +432,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    host = []
     for _ in range(args.steps):
+        h0 = time.perf_counter()
         run()
+        host.append(time.perf_counter() - h0)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -476,6 +479,10 @@ def main():
         loss = epocher.meters.statistics()
         line["final_meters"] = {k: round(v["mean"], 5) for g in loss.values() for k, v in g.items()
                                 if k in ("loss", "sp_weight", "reg_loss")}
+    hs = sorted(host)
+    line["host_us_per_step"] = {"median": round(hs[len(hs) // 2] * 1e6, 1), "max": round(hs[-1] * 1e6, 1),
+                                "note": "host time to enqueue one step (stage refill + upload, flip launch, graph replay); "
+                                        "it must stay below the GPU's step time for the queue to run ahead"}
     if replay is not None:
         line["replay_us"] = replay
     if ddp_check is not None:

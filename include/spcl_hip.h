@@ -125,6 +125,14 @@ int spcl_proj_heads_backward(int K, const float* const* dz /*[]*/, int dtype, in
                              int normalize, const float* pooled, const float* const* pre /*[]*/,
                              const float* const* o /*[]*/, float* const* dw1 /*[]*/, float* const* db1 /*[]*/,
                              float* const* dw2 /*[]*/, float* const* db2 /*[]*/, float* scratch, void* dfeat, void* stream);
+/* the same with the feature gradient as ONE value per (image, channel): dfeat_nc [N][Cs] of dtype (Cs == C), = dpooled / HW,
+ * what every pixel of that image and channel receives from the global average pool (heads.py:9-18).  The N x HW x Cs
+ * broadcast is never written; spcl_bnrelu_backward_bcast consumes the [N][Cs] form. */
+int spcl_proj_heads_backward_pooled(int K, const float* const* dz, int dtype, int N, int HW, int C, int Cs,
+                                    const float* const* w1, const float* const* w2, int hid, int out_dim, int normalize,
+                                    const float* pooled, const float* const* pre, const float* const* o, float* const* dw1,
+                                    float* const* db1, float* const* dw2, float* const* db2, float* scratch, void* dfeat_nc,
+                                    void* stream);
 
 /* ---------------------------------------------------------------- encoder --------------------------------
  * Replaces semi_seg/arch/unet.py:67-82 (_ConvBlock: Conv2d 3x3 no bias -> BatchNorm2d -> ReLU, x2),
@@ -280,6 +288,11 @@ int spcl_bnrelu_pool_backward(const void* y, const void* dact, const void* dpool
                               int C, int CS, const float* mean, const float* invstd, const float* scale,
                               const float* shift, int training, float* ws, float* dgamma, float* dbeta, void* dy,
                               void* stream);
+/* BN + ReLU backward (no pooling) for a gradient that is the same for every pixel of an image: dact_nc [N][CS] of dtype.
+ * Same arithmetic as spcl_bnrelu_pool_backward(dact = the expanded tensor, dpool = NULL). */
+int spcl_bnrelu_backward_bcast(const void* y, const void* dact_nc, int dtype, int N, int H, int W, int C, int CS,
+                               const float* mean, const float* invstd, const float* scale, const float* shift, int training,
+                               float* ws, float* dgamma, float* dbeta, void* dy, void* stream);
 
 /* BatchNorm+ReLU backward of the FIRST conv of a one-channel image block, fused with that conv's weight gradient
  * (`_Conv1.conv.0`/`.1`/`.2` backward, semi_seg/arch/unet.py:70-72 with input_dim = 1, + autograd).  The input image

@@ -360,6 +360,90 @@ __global__ __launch_bounds__(256, 5) void bnrelu_bwd_reduce_lin_kernel(const T* 
   wg_reduce_partials<T, EPC>(s1, s2, CS, CPC, PL, partial, red);
 }
 
+// ---- the same two passes for a BROADCAST gradient: g[n][p][c] = gb[n][c] for every pixel p of image n -- the gradient of a
+// global average pool (projectors/heads.py:9-18: AdaptiveAvgPool2d((1, 1))), which the projector's backward then hands
+// over as [N][CS] values instead of writing N x HW x CS of them.  Workgroup = (image, pixel split): the thread's gradient
+// chunk is loaded once.
+template <typename T>
+__global__ __launch_bounds__(256, 5) void bnrelu_bwd_reduce_bcast_kernel(const T* __restrict__ y, const T* __restrict__ gb,
+                                                                      int HW, int CS, int SPLIT,
+                                                                      const float* __restrict__ mean,
+                                                                      const float* __restrict__ invstd,
+                                                                      const float* __restrict__ scale,
+                                                                      const float* __restrict__ shift,
+                                                                      float* __restrict__ partial /* [grid][2][CS] */) {
+  constexpr int EPC = Chunk<T>::EPC, EPW = Word<T>::EPW;
+  __shared__ float red[256][2 * EPC + 1];
+  const int CPC = CS / EPC, PL = 256 / CPC;
+  const int cc = threadIdx.x % CPC, pl = threadIdx.x / CPC;
+  const int n = blockIdx.x / SPLIT, sp = blockIdx.x - n * SPLIT;
+  float s1[EPC], s2[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = 0.f;
+  if (pl < PL) {
+    float sc[EPC], sh[EPC], mu[EPC], is[EPC];
+    load_coef<EPC>(sc, scale, cc);
+    load_coef<EPC>(sh, shift, cc);
+    load_coef<EPC>(mu, mean, cc);
+    load_coef<EPC>(is, invstd, cc);
+    const u32x4 rg = *(const u32x4*)(gb + (size_t)n * CS + cc * EPC);
+    const T* yn = y + (size_t)n * HW * CS + cc * EPC;
+    for (int p = sp * PL + pl; p < HW; p += SPLIT * PL) {
+      const u32x4 ry = *(const u32x4*)(yn + (size_t)p * CS);
+#pragma unroll
+      for (int wi = 0; wi < 4; ++wi)
+#pragma unroll
+        for (int h = 0; h < EPW; ++h) {
+          const int e = wi * EPW + h;
+          const float yv = Word<T>::get(ry[wi], h);
+          const float dz = fmaf(sc[e], yv, sh[e]) > 0.f ? Word<T>::get(rg[wi], h) : 0.f;
+          s1[e] += dz;
+          s2[e] = fmaf(dz, yv - mu[e], s2[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) s2[e] *= is[e];
+  }
+  wg_reduce_partials<T, EPC>(s1, s2, CS, CPC, PL, partial, red);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 6) void bnrelu_bwd_apply_bcast_kernel(const T* __restrict__ y, const T* __restrict__ gb,
+                                                                     int HW, int CS, int SPLIT,
+                                                                     const float* __restrict__ scale,
+                                                                     const float* __restrict__ shift,
+                                                                     const float* __restrict__ ab, T* __restrict__ dy) {
+  constexpr int EPC = Chunk<T>::EPC, EPW = Word<T>::EPW;
+  const int CPC = CS / EPC, PL = 256 / CPC;
+  const int cc = threadIdx.x % CPC, pl = threadIdx.x / CPC;
+  if (pl >= PL) return;
+  const int n = blockIdx.x / SPLIT, sp = blockIdx.x - n * SPLIT;
+  float sc[EPC], sh[EPC], A[EPC], B[EPC];
+  load_coef<EPC>(sc, scale, cc);
+  load_coef<EPC>(sh, shift, cc);
+  load_coef<EPC>(A, ab, cc);
+  load_coef<EPC>(B, ab + CS, cc);
+  const u32x4 rg = *(const u32x4*)(gb + (size_t)n * CS + cc * EPC);
+  const size_t base = (size_t)n * HW * CS + cc * EPC;
+  for (int p = sp * PL + pl; p < HW; p += SPLIT * PL) {
+    const u32x4 ry = *(const u32x4*)(y + base + (size_t)p * CS);
+    u32x4 out;
+#pragma unroll
+    for (int wi = 0; wi < 4; ++wi) {
+      float o[EPW];
+#pragma unroll
+      for (int h = 0; h < EPW; ++h) {
+        const int e = wi * EPW + h;
+        const float yv = Word<T>::get(ry[wi], h);
+        const float dz = fmaf(sc[e], yv, sh[e]) > 0.f ? Word<T>::get(rg[wi], h) : 0.f;
+        o[h] = fmaf(sc[e], dz, fmaf(A[e], yv, B[e]));
+      }
+      out[wi] = Word<T>::make(o);
+    }
+    *(u32x4*)(dy + base + (size_t)p * CS) = out;
+  }
+}
+
 // the window's dz for channel element (wi, h): pooled gradient routed to the first maximum, ReLU gate
 template <typename T>
 __device__ __forceinline__ void window_dz(const Window<T>& w, const u32x4* rg, bool has_g, u32x4 rdp, bool complete,
@@ -946,7 +1030,7 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
                              const float* mean, const float* invstd, const float* scale, const float* shift,
                              int training, float* ws, float* dgamma, float* dbeta, void* dy, hipStream_t st,
                              const float* img = nullptr, float* dw = nullptr, const float* rows = nullptr,
-                             int nrows = 0) {
+                             int nrows = 0, bool bcast = false /* dact is [N][CS], one value per image and channel */) {
   constexpr int EPC = Chunk<T>::EPC;
   const bool pool = dpool != nullptr;
   constexpr int rs = 2;  // sub-rows of a partial row (the image3 path has eleven: spcl_bnrelu_backward_rows_image3)
@@ -958,7 +1042,7 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
   float* partial = ws;                           // [nwg][2][CS]
   float* ab = ws + (size_t)BWD_MAX_WG * 2 * CS;  // [2][CS]: folded BN-backward coefficients
   const float M = (float)npix;
-  int nwg;
+  int nwg, bsplit = 1;
   const double tb = (double)npix * CS * sizeof(T);  // bytes of one full-resolution tensor
   const double gb = (dact != nullptr ? tb : 0.0) + (pool ? 0.25 * tb : 0.0);
   prof_cost(tb + gb, 0.0);
@@ -978,6 +1062,13 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
     SPCL_LAUNCH((bnrelu_bwd_pool_kernel<T, false>), dim3(nwg), dim3(256), 0, st, (const T*)y, (const T*)dact,
                        (const T*)dpool, N, H, W, CS, mean, invstd, scale, shift, (const float*)nullptr, partial,
                        (T*)nullptr);
+  } else if (bcast) {
+    bsplit = (H * W + PL - 1) / PL;
+    while (bsplit > 1 && N * bsplit > BWD_MAX_WG) bsplit = (bsplit + 1) / 2;
+    nwg = N * bsplit;
+    prof_cost(tb, 0.0);
+    SPCL_LAUNCH((bnrelu_bwd_reduce_bcast_kernel<T>), dim3(nwg), dim3(256), 0, st, (const T*)y, (const T*)dact, H * W, CS,
+                bsplit, mean, invstd, scale, shift, partial);
   } else {
     nwg = stream_grid(npix, PL, STREAM_UNROLL, BWD_MAX_WG);
     SPCL_LAUNCH((bnrelu_bwd_reduce_lin_kernel<T>), dim3(nwg), dim3(256), 0, st, (const T*)y, (const T*)dact, npix,
@@ -1006,6 +1097,10 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
     } else {
       SPCL_LAUNCH(image_wgrad_final_kernel, dim3(9), dim3(256), 0, st, (const float*)wpart, g, C, CS, dw);
     }
+  } else if (bcast) {
+    prof_cost(2.0 * tb, 0.0);
+    SPCL_LAUNCH((bnrelu_bwd_apply_bcast_kernel<T>), dim3(N * bsplit), dim3(256), 0, st, (const T*)y, (const T*)dact, H * W,
+                CS, bsplit, scale, shift, (const float*)ab, (T*)dy);
   } else {
     SPCL_LAUNCH((bnrelu_bwd_apply_lin_kernel<T>), dim3(stream_grid(npix, PL, STREAM_UNROLL, STREAM_MAX_WG)), dim3(256), 0,
                        st, (const T*)y, (const T*)dact, npix, CS, scale, shift, (const float*)ab, (T*)dy);
@@ -1097,6 +1192,30 @@ extern "C" int spcl_bnrelu_pool_backward(const void* y, const void* dact, const 
     return SPCL_EINVAL;
   }
   SPCL_LAUNCH_CHECK("bnrelu_pool_backward");
+  return SPCL_OK;
+}
+
+// BN + ReLU backward for a gradient that is the same for every pixel of an image: dact_nc [N][CS] of dtype (what
+// spcl_proj_heads_backward_pooled leaves: the gradient of the global average pool in front of the projector,
+// contrastyou/projectors/heads.py:9-18).  Same arithmetic as spcl_bnrelu_pool_backward on the expanded tensor.
+extern "C" int spcl_bnrelu_backward_bcast(const void* y, const void* dact_nc, int dtype, int N, int H, int W, int C, int CS,
+                                          const float* mean, const float* invstd, const float* scale, const float* shift,
+                                          int training, float* ws, float* dgamma, float* dbeta, void* dy, void* stream) {
+  SPCL_CHECK_ARG(y && dact_nc && mean && invstd && scale && shift && ws && dgamma && dbeta && dy,
+                 "bnrelu_backward_bcast: null pointer");
+  SPCL_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && CS >= C && CS % 16 == 0 && CS <= 1024, "bnrelu_backward_bcast: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SPCL_F32)
+    bnrelu_bwd_launch<float>(y, dact_nc, nullptr, N, H, W, C, CS, mean, invstd, scale, shift, training, ws, dgamma, dbeta,
+                             dy, st, nullptr, nullptr, nullptr, 0, true);
+  else if (dtype == SPCL_BF16)
+    bnrelu_bwd_launch<bf16_t>(y, dact_nc, nullptr, N, H, W, C, CS, mean, invstd, scale, shift, training, ws, dgamma, dbeta,
+                              dy, st, nullptr, nullptr, nullptr, 0, true);
+  else {
+    set_error("bnrelu_backward_bcast: dtype %d", dtype);
+    return SPCL_EINVAL;
+  }
+  SPCL_LAUNCH_CHECK("bnrelu_backward_bcast");
   return SPCL_OK;
 }
 

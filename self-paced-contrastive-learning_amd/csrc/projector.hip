@@ -157,9 +157,17 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(CPtrs gs, CPtrs xs, i
 // dx[n][k] = (sum_o g[n][o] W[o][k]) * (LEAKY_OUT ? leaky'(pre[n][k]) : 1).  Workgroup = (row n, 64 columns k): the
 // 4 waves take interleaved o and are combined through LDS in fixed order.
 // NSUM > 0: the heads share the input (the pooled feature): ONE output, the sum over the NSUM heads in index order.
+// `nc` != null: ALSO the pooled feature's gradient divided by HW in the feature's storage type, [N][K] -- the gradient of
+// the global average pool as the ONE value per (image, channel) it is; the consumer (bn.hip, spcl_bnrelu_backward_bcast)
+// reads it as such and the N x HW x K broadcast tensor is never written.
+struct PooledOut {
+  void* nc;
+  int dtype, HW;
+};
 template <bool LEAKY_OUT>
 __device__ __forceinline__ void linear_dgrad_body(const CPtrs& gs, const CPtrs& Ws, const CPtrs& pres, int N, int K, int O,
-                                                  const MPtrs& dxs, int nsum, int bx, int n, int z, float (*red)[64]) {
+                                                  const MPtrs& dxs, int nsum, int bx, int n, int z, float (*red)[64],
+                                                  PooledOut po = PooledOut{nullptr, 0, 1}) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int k = bx * 64 + lane;
   const int h0 = nsum > 0 ? 0 : z, h1 = nsum > 0 ? nsum : z + 1;
@@ -178,6 +186,11 @@ __device__ __forceinline__ void linear_dgrad_body(const CPtrs& gs, const CPtrs& 
     float v = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
     if (LEAKY_OUT) v *= pres.p[h0][(size_t)n * K + k] > 0.f ? 1.f : kLeaky;
     dxs.p[h0][(size_t)n * K + k] = v;
+    if (po.nc != nullptr) {  // == avgpool_bwd_kernel's value, once per (image, channel)
+      const float pv = v / (float)po.HW;
+      if (po.dtype == SPCL_BF16) ((bf16_t*)po.nc)[(size_t)n * K + k] = f32_to_bf16(pv);
+      else ((float*)po.nc)[(size_t)n * K + k] = pv;
+    }
   }
 }
 // One layer's weight gradient AND input gradient in one launch (they read the same g and are independent; each is a
@@ -186,7 +199,7 @@ __device__ __forceinline__ void linear_dgrad_body(const CPtrs& gs, const CPtrs& 
 template <bool LEAKY>
 __global__ __launch_bounds__(256) void linear_bwd_pair_kernel(CPtrs gs, CPtrs xs, CPtrs Ws, CPtrs pres, int N, int K, int O,
                                                               MPtrs dWs, MPtrs dbs, MPtrs dxs, int nsum, int gxw, int nwb,
-                                                              int gxd) {
+                                                              int gxd, PooledOut po = PooledOut{nullptr, 0, 1}) {
   __shared__ float red[4][64];
   const int b = blockIdx.x;
   if (b < nwb) {
@@ -195,7 +208,7 @@ __global__ __launch_bounds__(256) void linear_bwd_pair_kernel(CPtrs gs, CPtrs xs
   } else {
     if (nsum > 0 && blockIdx.z > 0) return;
     const int r = b - nwb, n = r / gxd;
-    linear_dgrad_body<LEAKY>(gs, Ws, pres, N, K, O, dxs, nsum, r - n * gxd, n, blockIdx.z, red);
+    linear_dgrad_body<LEAKY>(gs, Ws, pres, N, K, O, dxs, nsum, r - n * gxd, n, blockIdx.z, red, po);
   }
 }
 
@@ -408,7 +421,8 @@ static int proj_heads_backward(int K, const float* const* dz, int dtype, int N, 
                                const float* const* w1, const float* const* w2, int hid, int out_dim, int normalize,
                                const float* pooled, const float* const* pre, const float* const* o, float* const* dw1,
                                float* const* db1, float* const* dw2, float* const* db2, float* scratch, void* dfeat,
-                               hipStream_t st, const char* who) {
+                               hipStream_t st, const char* who, bool nc_only = false /* dfeat is [N][Cs] (Cs == C) */) {
+  const PooledOut po{nc_only ? dfeat : nullptr, dtype, HW};
   // scratch: [K][N,out] d_o | [K][N,hid] dpre | [N,C] dpool
   float* d_o = scratch;
   float* dpre = d_o + (size_t)K * N * out_dim;
@@ -436,7 +450,7 @@ static int proj_heads_backward(int K, const float* const* dz, int dtype, int N, 
     if (dfeat) {  // layer 1: dW1 / db1 and the pooled feature's gradient (summed over the heads) in one launch
       const int gxw = cdiv(C, 256), nwb = gxw * hid, gxd = cdiv(C, 64);
       SPCL_LAUNCH(linear_bwd_pair_kernel<false>, dim3(nwb + gxd * N, 1, K), dim3(256), 0, st, DPRE, P, W1, CPtrs{}, N, C, hid,
-                  DW1, DB1, DPOOL, K, gxw, nwb, gxd);
+                  DW1, DB1, DPOOL, K, gxw, nwb, gxd, po);
     } else {
       SPCL_LAUNCH(linear_wgrad_kernel<false>, dim3(cdiv(C, 256), hid, K), dim3(256), 0, st, DPRE, P, N, C, hid, DW1, DB1);
     }
@@ -444,12 +458,12 @@ static int proj_heads_backward(int K, const float* const* dz, int dtype, int N, 
     if (dfeat) {
       const int gxw = cdiv(C, 256), nwb = gxw * out_dim, gxd = cdiv(C, 64);
       SPCL_LAUNCH(linear_bwd_pair_kernel<false>, dim3(nwb + gxd * N, 1, K), dim3(256), 0, st, GO, P, W1, CPtrs{}, N, C, out_dim,
-                  DW1, DB1, DPOOL, K, gxw, nwb, gxd);
+                  DW1, DB1, DPOOL, K, gxw, nwb, gxd, po);
     } else {
       SPCL_LAUNCH(linear_wgrad_kernel<false>, dim3(cdiv(C, 256), out_dim, K), dim3(256), 0, st, GO, P, N, C, out_dim, DW1, DB1);
     }
   }
-  if (dfeat) {
+  if (dfeat && !nc_only) {
     const size_t total = (size_t)N * HW * Cs;
     dim3 g((unsigned)((total + 255) / 256));
     if (dtype == SPCL_F32)
@@ -510,6 +524,29 @@ extern "C" int spcl_proj_heads_forward(int K, const void* feat, int dtype, int N
                                     (hipStream_t)stream, "proj_heads_forward");
   if (rc != SPCL_OK) return rc;
   SPCL_LAUNCH_CHECK("proj_heads_forward");
+  return SPCL_OK;
+}
+
+// spcl_proj_heads_backward with the feature gradient as ONE value per (image, channel): dfeat_nc [N][Cs] of dtype, Cs == C
+// (= dpooled / HW, what every pixel of that image and channel would receive).  K = 1: the single head.
+extern "C" int spcl_proj_heads_backward_pooled(int K, const float* const* dz, int dtype, int N, int HW, int C, int Cs,
+                                               const float* const* w1, const float* const* w2, int hid, int out_dim,
+                                               int normalize, const float* pooled, const float* const* pre,
+                                               const float* const* o, float* const* dw1, float* const* db1,
+                                               float* const* dw2, float* const* db2, float* scratch, void* dfeat_nc,
+                                               void* stream) {
+  SPCL_CHECK_ARG(K >= 1 && K <= PROJ_MAX_HEADS, "proj_heads_backward_pooled: %d heads (1..%d)", K, PROJ_MAX_HEADS);
+  SPCL_CHECK_ARG(dz && w1 && pooled && o && dw1 && db1 && scratch && dfeat_nc && (hid == 0 || (w2 && pre && dw2 && db2)),
+                 "proj_heads_backward_pooled: null pointer");
+  SPCL_CHECK_ARG(N > 0 && HW > 0 && C > 0 && Cs == C && out_dim > 0 && hid >= 0 && (dtype == SPCL_F32 || dtype == SPCL_BF16),
+                 "proj_heads_backward_pooled: bad shape (Cs must equal C)");
+  for (int k = 0; k < K; ++k)
+    SPCL_CHECK_ARG(dz[k] && w1[k] && o[k] && dw1[k] && db1[k] && (hid == 0 || (w2[k] && pre[k] && dw2[k] && db2[k])),
+                   "proj_heads_backward_pooled: null pointer in head %d", k);
+  const int rc = proj_heads_backward(K, dz, dtype, N, HW, C, Cs, w1, w2, hid, out_dim, normalize, pooled, pre, o, dw1, db1,
+                                     dw2, db2, scratch, dfeat_nc, (hipStream_t)stream, "proj_heads_backward_pooled", true);
+  if (rc != SPCL_OK) return rc;
+  SPCL_LAUNCH_CHECK("proj_heads_backward_pooled");
   return SPCL_OK;
 }
 

@@ -287,6 +287,15 @@ class _ProjectorFn(torch.autograd.Function):
         db2 = _grad_buffer(sk[3], (out_dim,), dev) if mlp else None
         scratch = torch.empty(N * (out_dim + hid + C), dtype=torch.float32, device=dev)
         need_dfeat = ctx.needs_input_grad[0]
+        if need_dfeat and _BCAST and cs == C and H * W > 1 and xdt == fdt:
+            # the gradient of the global average pool as what it is -- one value per (image, channel) -- behind a stride-0
+            # view: the block it came from reads the [N, C] form (broadcast_rows), anything else sees an ordinary tensor
+            dnc = torch.empty(N, C, dtype=xdt, device=dev)
+            one = lambda t: _n.ptr_array([t])  # noqa: E731
+            _n.call("spcl_proj_heads_backward_pooled", 1, one(dzc), _n.dtype_code(xdt), N, H * W, C, cs, one(w1c), one(w2c),
+                    hid, out_dim, int(normalize), _n.ptr(pooled), one(pre), one(o), one(dw1), one(db1), one(dw2), one(db2),
+                    _n.ptr(scratch), _n.ptr(dnc), _n.stream())
+            return dnc.view(N, C, 1, 1).expand(N, C, H, W), dw1, db1, dw2, db2, None
         dfeat = torch.empty(N, H, W, cs, dtype=xdt, device=dev) if need_dfeat else None
         _n.call("spcl_proj_backward", _n.ptr(dzc), _n.dtype_code(xdt), N, H * W, C, cs, _n.ptr(w1c), _n.ptr(w2c), hid,
                 out_dim, int(normalize), _n.ptr(pooled), _n.ptr(pre), _n.ptr(o), _n.ptr(dw1), _n.ptr(db1),
@@ -347,8 +356,15 @@ class _ProjectorHeadsFn(torch.autograd.Function):
         grads = [_grad_buffer(sk[i], shapes[i % 4], dev) for i in range(4 * K)]
         scratch = torch.empty(K * N * (out_dim + hid) + N * C, dtype=torch.float32, device=dev)
         need_dfeat = ng[0]
-        dfeat = torch.empty(N, H, W, cs, dtype=xdt, device=dev) if need_dfeat else None
         col = lambda i: _n.ptr_array([grads[4 * k + i] for k in range(K)])  # noqa: E731
+        if need_dfeat and _BCAST and cs == C and H * W > 1 and xdt == fdt:  # (see _ProjectorFn.backward)
+            dnc = torch.empty(N, C, dtype=xdt, device=dev)
+            _n.call("spcl_proj_heads_backward_pooled", K, _n.ptr_array(dzc), _n.dtype_code(xdt), N, H * W, C, cs,
+                    _n.ptr_array(list(w1s)), _n.ptr_array(list(w2s)), hid, out_dim, int(normalize), _n.ptr(pooled),
+                    _n.ptr_array(list(pre)), _n.ptr_array(list(o)), col(0), col(1), col(2), col(3), _n.ptr(scratch),
+                    _n.ptr(dnc), _n.stream())
+            return (dnc.view(N, C, 1, 1).expand(N, C, H, W), None) + tuple(grads)
+        dfeat = torch.empty(N, H, W, cs, dtype=xdt, device=dev) if need_dfeat else None
         _n.call("spcl_proj_heads_backward", K, _n.ptr_array(dzc), _n.dtype_code(xdt), N, H * W, C, cs, _n.ptr_array(list(w1s)),
                 _n.ptr_array(list(w2s)), hid, out_dim, int(normalize), _n.ptr(pooled), _n.ptr_array(list(pre)),
                 _n.ptr_array(list(o)), col(0), col(1), col(2), col(3), _n.ptr(scratch), _n.ptr(dfeat), _n.stream())
@@ -722,6 +738,31 @@ def _wgrad(x_store, dy, dt_code, N, H, W, cin, cin_s, cin_k, cout, cout_s, in_mo
     return dw
 
 
+_BCAST = os.environ.get("SPCL_POOL_BCAST", "1") != "0"  # A/B switch: 0 materialises the average pool's gradient
+
+
+def broadcast_rows(g, dtype):
+    """``g`` [N, C, H, W] whose every pixel of an (image, channel) holds the same value through stride-0 dimensions (what
+    the projector's backward hands over for a global average pool: ``[N, C] .view(N, C, 1, 1).expand(N, C, H, W)``) ->
+    the contiguous [N, C] tensor behind it, else None"""
+    if (g is None or g.dim() != 4 or g.dtype != dtype or g.shape[1] % 16 or g.shape[2] * g.shape[3] <= 1
+            or g.stride(2) != 0 or g.stride(3) != 0 or g.stride(1) != 1 or g.stride(0) != g.shape[1]):
+        return None
+    return torch.as_strided(g, (g.shape[0], g.shape[1]), (g.shape[1], 1), g.storage_offset())
+
+
+def _bnrelu_bwd_bcast(y, g_nc, dt_code, dtype, N, H, W, C, cs, st, training, sinks=(None, None)):
+    """_bnrelu_bwd for a gradient that is one value per (image, channel) (spcl_bnrelu_backward_bcast)"""
+    dev = y.device
+    ws = torch.empty(_n.call("spcl_bnrelu_bwd_workspace_bytes", N, H, W, cs) // 4, dtype=torch.float32, device=dev)
+    dgamma = _grad_buffer(sinks[0], (C,), dev)
+    dbeta = _grad_buffer(sinks[1], (C,), dev)
+    dy = torch.empty(N, H, W, cs, dtype=dtype, device=dev)
+    _n.call("spcl_bnrelu_backward_bcast", _n.ptr(y), _n.ptr(g_nc), dt_code, N, H, W, C, cs, _n.ptr(st[0]), _n.ptr(st[1]),
+            _n.ptr(st[2]), _n.ptr(st[3]), int(training), _n.ptr(ws), _n.ptr(dgamma), _n.ptr(dbeta), _n.ptr(dy), _n.stream())
+    return dy, dgamma, dbeta
+
+
 def _bnrelu_bwd(y, dact, dpool, dt_code, dtype, N, H, W, C, cs, st, training, sinks=(None, None)):
     dev = y.device
     ws = torch.empty(_n.call("spcl_bnrelu_bwd_workspace_bytes", N, H, W, cs) // 4, dtype=torch.float32, device=dev)
@@ -924,15 +965,20 @@ class _ConvBlockFn(torch.autograd.Function):
         N, cin, H, W, cout, cout_s, cin_s, cin_k, mode_a, xdt = ctx.meta
         dtype = cfg.dtype
         dtc = _n.dtype_code(dtype)
-        da_s = to_nhwc_padded(d_act, dtype) if d_act is not None else None
+        g_nc = broadcast_rows(d_act, dtype) if (_BCAST and d_pool is None and d_act is not None
+                                                  and d_act.shape[1] == cout_s) else None
+        da_s = to_nhwc_padded(d_act, dtype) if (d_act is not None and g_nc is None) else None
         dp_s = to_nhwc_padded(d_pool, dtype) if d_pool is not None else None
-        if da_s is None and dp_s is None:
+        if da_s is None and dp_s is None and g_nc is None:
             return (None,) * 8
         # ---- second conv
         ng = ctx.needs_input_grad
         sk = tuple(take_grad_sink(p, ng[i + 1]) for i, p in enumerate(ctx.params))  # (wa, ga, ba, wb, gb, bb)
         lk = cfg.link_out
-        if (lk is not None and lk.rows is not None and da_s is None and dp_s is not None
+        if g_nc is not None:
+            # the block's output fed a global average pool only: its gradient is one value per (image, channel)
+            dyb, dgb, dbb = _bnrelu_bwd_bcast(yb, g_nc, dtc, dtype, N, H, W, cout, cout_s, stb, cfg.training, sk[4:6])
+        elif (lk is not None and lk.rows is not None and da_s is None and dp_s is not None
                 and dp_s.data_ptr() == lk.dx_ptr):
             # the next block's input-gradient kernel left this BatchNorm's partial sums next to the gradient itself
             dyb, dgb, dbb = _bnrelu_pool_bwd_rows(yb, dp_s, lk.rows, dtc, dtype, N, H, W, cout, cout_s, stb, cfg.training,

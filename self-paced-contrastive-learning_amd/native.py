@@ -37,6 +37,8 @@ _SIGNATURES = {
                                         _P, _P, _P, _P, _P]),
     "spcl_proj_heads_backward": (c_int, [c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, _P, _P,
                                          _P, _P, _P, _P, _P, _P, _P, _P]),
+    "spcl_proj_heads_backward_pooled": (c_int, [c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, _P,
+                                                _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "spcl_adaptive_pool2d_forward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "spcl_adaptive_pool2d_backward": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P,
                                               _P]),
@@ -72,6 +74,8 @@ _SIGNATURES = {
     "spcl_bnrelu_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "spcl_bnrelu_pool_backward": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P,
                                           c_int, _P, _P, _P, _P, _P]),
+    "spcl_bnrelu_backward_bcast": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P,
+                                           _P, _P, _P]),
     "spcl_bnrelu_image_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "spcl_bnrelu_backward_image_wgrad": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P,
                                                  c_int, _P, _P, _P, _P, _P]),

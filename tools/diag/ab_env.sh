@@ -1,0 +1,8 @@
+#!/bin/bash
+# same-box A/B of an environment switch: ab_env.sh VAR v1 v2 [rounds]  -> per run: mean ms per step and the MEDIAN of 100
+# single-replay HIP-event times (robust against the occasional slow run on a shared box)
+VAR=$1; A=$2; B=$3; R=${4:-3}
+for i in $(seq $R); do for v in $A $B; do
+  echo -n "$VAR=$v "
+  env $VAR=$v python bench.py --no-cpu-baseline --no-roofline --steps 100 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], 'median', d['replay_us']['median'], 'p10', d['replay_us']['p10'])"
+done; done
