@@ -270,7 +270,7 @@ def phase_fractions(launches, marks, reps, args):
     per_layer = {}
     names = ["C1a", "C1b", "C2a", "C2b", "C3a", "C3b", "C4a", "C4b", "C5a", "C5b"]
     for a, b in marks:
-        convs = [l for l in launches[a:b] if l[3] > 0]
+        convs = [l for l in launches[a:b] if l[3] > 0 and "conv3x3" in l[0]]  # (the image autocorrelation declares FLOPs too)
         if len(convs) != len(names):
             per_layer = None
             break
