@@ -1,5 +1,6 @@
 import sys, torch
-sys.path.insert(0, "/root/repo")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import spcl_amd
 from spcl_amd import functional as F_, native as _n
 torch.manual_seed(0)
