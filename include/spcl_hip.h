@@ -173,6 +173,10 @@ typedef struct spcl_pack_item {
   int Cin, Cout, H, W;
 } spcl_pack_item;
 int spcl_conv_pack_weights_multi(const spcl_pack_item* items, int n, int dtype, void* stream);
+/* the same launch also runs spcl_image_autocorr(image, N, H, W, acorr) (see "image3" below) in workgroups of its own: two
+ * short, independent jobs at the start of a forward pass overlap and pay one launch.  image == NULL: the plain pack. */
+int spcl_conv_pack_weights_multi_acorr(const spcl_pack_item* items, int n, int dtype, const float* image, int N, int H,
+                                       int W, float* acorr, void* stream);
 
 /* y = conv3x3(act(x)), NHWC, implicit GEMM on MFMA.                    (unet.py:72,75; dgrad: with kind-1 weights)
  * x [N,H,W,CinS] of dtype; CinK = GEMM-K channels (multiple of 16, == CinS for in_mode 0/1).

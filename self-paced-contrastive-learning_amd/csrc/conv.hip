@@ -15,6 +15,7 @@
 //     (exact-f32, the parity path).
 #include <stdlib.h>
 #include "conv_common.hpp"
+#include "image_acorr.hpp"
 
 namespace spcl {
 
@@ -345,8 +346,26 @@ struct PackSegs {
   PackSeg s[PACK_SEGS];
 };
 template <typename T>
+__device__ __forceinline__ void conv_pack_multi_body(const PackSegs& p, const int b);
+
+// ... and, in the SAME launch, the image autocorrelation of the "image3" path (bn.hip): both are a dozen microseconds of
+// work that fills a fraction of the chip, neither depends on the other, and as one launch they overlap and pay one launch
+// floor (26 us back to back).  The pack workgroups come first: they are short, and every workgroup of the launch reserves
+// the autocorrelation's LDS, so whichever job is dispatched first holds the CUs' slots until it retires.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_pack_multi_acorr_kernel(PackSegs p, const float* __restrict__ img, int H, int W,
+                                                                   float* __restrict__ acorr, int npack) {
+  if ((int)blockIdx.x < npack) conv_pack_multi_body<T>(p, blockIdx.x);
+  else image_autocorr_body(img, H, W, acorr, blockIdx.x - npack);
+}
+
+template <typename T>
 __global__ __launch_bounds__(256) void conv_pack_multi_kernel(PackSegs p) {
-  const int b = blockIdx.x;
+  conv_pack_multi_body<T>(p, blockIdx.x);
+}
+
+template <typename T>
+__device__ __forceinline__ void conv_pack_multi_body(const PackSegs& p, const int b) {
   int seg = 0;
 #pragma unroll
   for (int k = 0; k < PACK_SEGS; ++k) seg += b >= p.blk_end[k] ? 1 : 0;
@@ -555,7 +574,8 @@ extern "C" int spcl_conv_pack_weights_block_at(const float* wa_oihw, int CinA, i
 }
 
 template <typename T>
-static int pack_multi_t(const spcl_pack_item* items, int n, hipStream_t st) {
+static int pack_multi_t(const spcl_pack_item* items, int n, hipStream_t st, const float* img = nullptr, int N = 0, int H = 0,
+                        int W = 0, float* acorr = nullptr) {
   PackSegs p;
   int nseg = 0, blocks = 0;
   for (int i = 0; i < n; ++i) {
@@ -580,20 +600,34 @@ static int pack_multi_t(const spcl_pack_item* items, int n, hipStream_t st) {
     p.blk_end[k] = 0x7fffffff;
     p.s[k] = p.s[0];
   }
-  SPCL_LAUNCH(conv_pack_multi_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, p);
+  if (img != nullptr) {
+    const int nacorr = N * image_autocorr_bands(H);
+    prof_cost((double)N * H * W * 4.0, 2.0 * 54.0 * N * H * W);
+    SPCL_LAUNCH(conv_pack_multi_acorr_kernel<T>, dim3((unsigned)(nacorr + blocks)), dim3(256), 0, st, p, img, H, W, acorr,
+                blocks);
+  } else {
+    SPCL_LAUNCH(conv_pack_multi_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, p);
+  }
   return 0;
 }
 
 extern "C" int spcl_conv_pack_weights_multi(const spcl_pack_item* items, int n, int dtype, void* stream) {
+  return spcl_conv_pack_weights_multi_acorr(items, n, dtype, nullptr, 0, 0, 0, nullptr, stream);
+}
+
+extern "C" int spcl_conv_pack_weights_multi_acorr(const spcl_pack_item* items, int n, int dtype, const float* image, int N,
+                                                  int H, int W, float* acorr, void* stream) {
   SPCL_CHECK_ARG(items && n >= 1 && n <= SPCL_PACK_MULTI_MAX, "conv_pack_weights_multi: 1 <= n <= %d layers",
                  SPCL_PACK_MULTI_MAX);
+  SPCL_CHECK_ARG(image == nullptr || (acorr && N > 0 && H > 0 && W > 0 && W <= ACORR_MAXW),
+                 "conv_pack_weights_multi_acorr: bad image arguments (W <= %d)", ACORR_MAXW);
   for (int i = 0; i < n; ++i) {
     SPCL_CHECK_ARG(items[i].w_oihw && items[i].fwd && items[i].dgrad, "conv_pack_weights_multi: null pointer (layer %d)", i);
     SPCL_CHECK_ARG(items[i].Cin > 0 && items[i].Cout > 0 && items[i].H >= 0 && items[i].W >= 0,
                    "conv_pack_weights_multi: bad shape (layer %d)", i);
   }
-  if (dtype == SPCL_F32) pack_multi_t<float>(items, n, (hipStream_t)stream);
-  else if (dtype == SPCL_BF16) pack_multi_t<bf16_t>(items, n, (hipStream_t)stream);
+  if (dtype == SPCL_F32) pack_multi_t<float>(items, n, (hipStream_t)stream, image, N, H, W, acorr);
+  else if (dtype == SPCL_BF16) pack_multi_t<bf16_t>(items, n, (hipStream_t)stream, image, N, H, W, acorr);
   else {
     set_error("conv_pack_weights_multi: dtype %d", dtype);
     return SPCL_EINVAL;

@@ -573,11 +573,21 @@ _PREPACKED = {}
 _PREPACK = os.environ.get("SPCL_PREPACK", "1") != "0"  # A/B switch: 0 = every block packs right before its convolutions
 
 
-def prepack_weights(layers, dtype):
+_PREPACKED_ACORR = {}
+
+
+def take_prepacked_acorr(image):
+    return _PREPACKED_ACORR.pop(image.data_ptr(), None)
+
+
+def prepack_weights(layers, dtype, image=None):
     """``layers``: list of (weight [Cout, Cin, 3, 3], H, W) about to be used at image size H x W with storage ``dtype``:
     forward and dgrad layouts of all of them in one launch (spcl_conv_pack_weights_multi), handed to the blocks through
-    ``take_prepacked``.  Anything left over from an earlier, unfinished forward is dropped."""
+    ``take_prepacked``.  Anything left over from an earlier, unfinished forward is dropped.
+    ``image`` [N, H, W] (or [N, H, W, 1]) f32: the same launch also computes its autocorrelation rows (``_image_autocorr``,
+    the image3 path of the first block), handed over through ``take_prepacked_acorr``."""
     _PREPACKED.clear()
+    _PREPACKED_ACORR.clear()
     if not _PREPACK or not layers:
         return
     dtc = _n.dtype_code(dtype)
@@ -599,7 +609,14 @@ def prepack_weights(layers, dtype):
             keep.append(wc)
             _PREPACKED[(w.data_ptr(), dtc, int(H), int(W))] = (p0, p1)
         arr = (_n.PackItem * len(items))(*items)
-        _n.call("spcl_conv_pack_weights_multi", arr, len(items), dtc, _n.stream())
+        if image is not None and i == 0:
+            N, H, W = int(image.shape[0]), int(image.shape[1]), int(image.shape[2])
+            acorr = torch.empty(_n.call("spcl_image_autocorr_rows", N, H, W), 64, dtype=torch.float32, device=dev)
+            _n.call("spcl_conv_pack_weights_multi_acorr", arr, len(items), dtc, _n.ptr(image), N, H, W, _n.ptr(acorr),
+                    _n.stream())
+            _PREPACKED_ACORR[image.data_ptr()] = acorr
+        else:
+            _n.call("spcl_conv_pack_weights_multi", arr, len(items), dtc, _n.stream())
 
 
 def take_prepacked(w, dtc, H, W):
@@ -929,8 +946,10 @@ class _ConvBlockFn(torch.autograd.Function):
         ctx.acorr = None
         if (need_bwd and ctx.needs_input_grad[1] and not ctx.needs_input_grad[0]
                 and _image3_supported(cfg, cin, dtc, N, H, W, cout_s)):
-            # of the input image only, and FIRST: the views have just been written (cache-warm), backward needs it much later
-            ctx.acorr = _image_autocorr(xs, N, H, W)
+            # of the input image only: usually it came with the forward pass's weight-pack launch (UNet._prepack), else now
+            ctx.acorr = take_prepacked_acorr(xs)
+            if ctx.acorr is None:
+                ctx.acorr = _image_autocorr(xs, N, H, W)
         pre_a, pre_b = take_prepacked(wa, dtc, H, W), take_prepacked(wb, dtc, H, W)
         if pre_a is not None and pre_b is not None:  # packed with the other layers at the start of the forward pass
             (wpa, wpa_t), (wpb, wpb_t) = pre_a, pre_b

@@ -50,6 +50,7 @@ _SIGNATURES = {
     "spcl_conv_pack_weights_block": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, c_int, _P, _P, c_int, _P]),
     "spcl_conv_pack_weights_block_at": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, c_int, _P, _P, c_int, c_int, c_int, _P]),
     "spcl_conv_pack_weights_multi": (c_int, [_P, c_int, c_int, _P]),
+    "spcl_conv_pack_weights_multi_acorr": (c_int, [_P, c_int, c_int, _P, c_int, c_int, c_int, _P, _P]),
     "spcl_conv_num_tiles": (c_int, [c_int, c_int, c_int]),
     "spcl_conv_stat_rows": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "spcl_conv_set_gemm": (None, [c_int]),

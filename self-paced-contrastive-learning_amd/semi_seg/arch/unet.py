@@ -240,7 +240,16 @@ class UNet(nn.Module):
                 if until == f"Up_conv{lvl}":
                     break
         if len(dtypes) == 1:
-            F_hip.prepack_weights(layers, dtypes.pop())
+            dtype = dtypes.pop()
+            # the first block's "image3" backward wants the autocorrelation of the one-channel input: same launch
+            c1 = self._Conv1.conv
+            image = None
+            if (x.shape[1] == 1 and x.dtype == torch.float32 and x.is_contiguous() and torch.is_grad_enabled()
+                    and c1[0].weight.requires_grad and not x.requires_grad and self._Conv1.training
+                    and F_hip._image3_supported(self._Conv1._cfg(True, False), 1, F_hip._n.dtype_code(dtype), int(x.shape[0]),
+                                                H, W, F_hip._ru16(c1[0].weight.shape[0]))):
+                image = x.detach().view(x.shape[0], H, W)
+            F_hip.prepack_weights(layers, dtype, image)
 
     def set_compute_dtype(self, dtype):
         """torch.float32 (parity mode) or torch.bfloat16 for all fused blocks of this network."""
