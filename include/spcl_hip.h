@@ -455,6 +455,10 @@ int spcl_flip_batch(const void* x, void* out, int elem_size, int N, int C, int H
  * flip of view 2 and the torch.cat of semi_seg/epochers/new_pretrain.py:57-58,93. */
 int spcl_flip_pair(const void* first, const void* second, void* out, int elem_size, int N, int C, int H, int W,
                    const uint8_t* flags, void* stream);
+/* the same launch also performs spcl_stage_bytes(stage_dst, host_src, nbytes) and takes the N flag bytes from
+ * host_src + flag_off (kernel arguments: nbytes <= 3 584): the two eager launches in front of a replayed step are one. */
+int spcl_flip_pair_stage(const void* first, const void* second, void* out, int elem_size, int N, int C, int H, int W,
+                         void* stage_dst, const void* host_src, size_t nbytes, size_t flag_off, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Built-in kernel timer (bench.py's live roofline measurement): spcl_profile_enable(1) clears the log and makes every

@@ -2,14 +2,21 @@
 // sample by sample in new_pretrain.py:57-58,64-65) as ONE streaming launch: out[n] = flip(x[n], dims(flags[n])).
 // The reference loops over the samples on the host (one flip kernel each); the batched torch formulation is still
 // ~10 launches (index_select / flip / index_copy per pattern).  16-byte vectors, reversed in registers for W flips.
+#include <string.h>
 #include "common.hpp"
 
 namespace spcl {
 
-template <typename T, int VEC>
-__global__ __launch_bounds__(256) void flip_batch_kernel(const T* __restrict__ x, T* __restrict__ out, int N, int C,
-                                                         int H, int W, const uint8_t* __restrict__ flags,
-                                                         const T* __restrict__ head, int NH) {
+// STAGED: the launch also carries the step's host-written inputs (stepgraph.StepStage: label vectors, these flip flags) as
+// kernel arguments -- workgroup 0 writes them to their persistent device block (what spcl_stage_bytes does in a launch
+// of its own), and every workgroup reads ITS flags from the arguments (the device block is being written meanwhile).
+constexpr int FLIP_STAGE_WORDS = 896;  // 3 584 bytes
+struct FlipStage {
+  uint32_t w[FLIP_STAGE_WORDS];
+};
+template <typename T, int VEC, bool STAGED>
+__device__ __forceinline__ void flip_batch_body(const T* __restrict__ x, T* __restrict__ out, int N, int C, int H, int W,
+                                                const uint8_t* __restrict__ flags, const T* __restrict__ head, int NH) {
   // head != null: `out` has NH + N samples, the first NH are a plain copy of `head` (the unflipped view of the pair)
   const int WV = W / VEC;
   const size_t total = (size_t)(N + NH) * C * H * WV;
@@ -37,6 +44,23 @@ __global__ __launch_bounds__(256) void flip_batch_kernel(const T* __restrict__ x
       for (int e = 0; e < VEC; ++e) dst[e] = v[e];
     }
   }
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void flip_batch_kernel(const T* __restrict__ x, T* __restrict__ out, int N, int C,
+                                                         int H, int W, const uint8_t* __restrict__ flags,
+                                                         const T* __restrict__ head, int NH) {
+  flip_batch_body<T, VEC, false>(x, out, N, C, H, W, flags, head, NH);
+}
+
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void flip_pair_stage_kernel(const T* __restrict__ x, T* __restrict__ out, int N, int C,
+                                                              int H, int W, const T* __restrict__ head, int NH,
+                                                              uint32_t* __restrict__ stage_dst, int nwords, int flag_off,
+                                                              FlipStage s) {
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < nwords; i += 256) stage_dst[i] = s.w[i];
+  flip_batch_body<T, VEC, true>(x, out, N, C, H, W, (const uint8_t*)s.w + flag_off, head, NH);
 }
 
 template <typename T>
@@ -137,6 +161,42 @@ extern "C" int spcl_flip_batch(const void* x, void* out, int elem_size, int N, i
     return SPCL_EINVAL;
   }
   SPCL_LAUNCH_CHECK("flip_batch");
+  return SPCL_OK;
+}
+
+// spcl_flip_pair with the flags taken from a block of host bytes that the same launch also writes to `stage_dst` (see
+// spcl_stage_bytes): host_src[0 .. nbytes) (nbytes <= 3 584, multiple of 4), the N flag bytes at host_src + flag_off.
+extern "C" int spcl_flip_pair_stage(const void* first, const void* second, void* out, int elem_size, int N, int C, int H,
+                                    int W, void* stage_dst, const void* host_src, size_t nbytes, size_t flag_off,
+                                    void* stream) {
+  SPCL_CHECK_ARG(first && second && out && stage_dst && host_src, "flip_pair_stage: null pointer");
+  SPCL_CHECK_ARG(N > 0 && C > 0 && H > 0 && W > 0, "flip_pair_stage: bad shape");
+  SPCL_CHECK_ARG(first != out && second != out, "flip_pair_stage: in-place is not supported");
+  SPCL_CHECK_ARG(nbytes % 4 == 0 && nbytes <= (size_t)FLIP_STAGE_WORDS * 4 && flag_off + (size_t)N <= nbytes &&
+                     (uintptr_t)stage_dst % 4 == 0,
+                 "flip_pair_stage: at most %d staged bytes, the flags inside them", FLIP_STAGE_WORDS * 4);
+  FlipStage s;
+  memcpy(s.w, host_src, nbytes);
+  hipStream_t st = (hipStream_t)stream;
+  auto go = [&](auto tag) {
+    typedef decltype(tag) T;
+    constexpr int V = 16 / (int)sizeof(T);
+    const bool vec = W % V == 0 && ((uintptr_t)second % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)first % 16 == 0);
+    const size_t total = (size_t)2 * N * C * H * (vec ? W / V : W);
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (vec) SPCL_LAUNCH((flip_pair_stage_kernel<T, V>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)second, (T*)out,
+                         N, C, H, W, (const T*)first, N, (uint32_t*)stage_dst, (int)(nbytes / 4), (int)flag_off, s);
+    else SPCL_LAUNCH((flip_pair_stage_kernel<T, 1>), dim3((unsigned)blocks), dim3(256), 0, st, (const T*)second, (T*)out, N,
+                     C, H, W, (const T*)first, N, (uint32_t*)stage_dst, (int)(nbytes / 4), (int)flag_off, s);
+  };
+  if (elem_size == 4) go(uint32_t{});
+  else if (elem_size == 2) go(uint16_t{});
+  else {
+    set_error("flip_pair_stage: elem_size %d", elem_size);
+    return SPCL_EINVAL;
+  }
+  SPCL_LAUNCH_CHECK("flip_pair_stage");
   return SPCL_OK;
 }
 

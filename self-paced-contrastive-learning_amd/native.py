@@ -117,6 +117,7 @@ _SIGNATURES = {
     "spcl_augment_views": (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int, _P]),
     "spcl_flip_batch": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "spcl_flip_pair": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "spcl_flip_pair_stage": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, c_size_t, c_size_t, _P]),
     "spcl_profile_enable": (c_int, [c_int]),
     "spcl_profile_count": (c_int, []),
     "spcl_profile_get": (c_int, [c_int, c_char_p, c_int, _P, _P, _P]),

@@ -193,13 +193,23 @@ class PretrainEncoderEpocher:
                                              split=_ddp.is_distributed())
         batch = {"seed": seed, "n": n, "partition_group": list(unl_partition), "label_group": list(unl_group),
                  "filename": filename}
-        self.stage.begin(batch)  # every bound slot (labels, flags) refilled from this batch, one upload
+        # every bound slot (labels, flags) refilled from this batch; the block travels in the flip launch below when it fits
+        # its kernel arguments (one eager launch in front of the replay instead of two), else by spcl_stage_bytes
+        flag_off = self.stage.offset_of("flip_flags")
+        fused = flag_off is not None and 0 < self.stage._used <= 3584
+        self.stage.begin(batch, upload=not fused)
         try:
             flags = self.stage.bind("flip_flags", (n + 3) // 4 * 4, "u8", self._flip_flags)
             a, b = image.contiguous(), image_tf.contiguous()
             N, C, H, W = a.shape
-            _n.call("spcl_flip_pair", _n.ptr(a), _n.ptr(b), _n.ptr(self._pair), a.element_size(), N, C, H, W,
-                    _n.ptr(flags), _n.stream())  # the loader's tensors -> the persistent pair (eager, in front of the replay)
+            if fused:
+                import ctypes
+                dst, host, used = self.stage.host_block()
+                _n.call("spcl_flip_pair_stage", _n.ptr(a), _n.ptr(b), _n.ptr(self._pair), a.element_size(), N, C, H, W,
+                        ctypes.c_void_p(dst), host.ctypes.data_as(ctypes.c_void_p), used, flag_off, _n.stream())
+            else:
+                _n.call("spcl_flip_pair", _n.ptr(a), _n.ptr(b), _n.ptr(self._pair), a.element_size(), N, C, H, W,
+                        _n.ptr(flags), _n.stream())  # the loader's tensors -> the persistent pair (eager, before the replay)
             self._staged = batch
             if hasattr(self._optimizer, "sync_lr"):
                 self._optimizer.sync_lr()

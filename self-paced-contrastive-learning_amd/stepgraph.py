@@ -72,14 +72,24 @@ class StepStage:
         return slot[4]
 
     # ---- the epocher
-    def begin(self, batch):
-        """a staged step starts: refill every slot from ``batch`` and upload the block (one launch per 3.5 KB)"""
+    def begin(self, batch, upload: bool = True):
+        """a staged step starts: refill every slot from ``batch`` and upload the block (one launch per 3.5 KB).
+        ``upload=False``: the caller uploads ``host_block()`` itself (spcl_flip_pair_stage carries it in its own launch)."""
         self.batch = batch
         self.active = True
         if self._slots:
             for slot in self._slots.values():
                 self._write(slot)
-            self._upload(0, self._used)
+            if upload:
+                self._upload(0, self._used)
+
+    def host_block(self):
+        """(device pointer, host bytes, length) of the used part of the block -- for a launch that carries it along"""
+        return self._dev.data_ptr(), self._host[:self._used], self._used
+
+    def offset_of(self, key):
+        slot = self._slots.get(key)
+        return None if slot is None else slot[0]
 
     def end(self):
         self.active = False

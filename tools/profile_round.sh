@@ -13,7 +13,7 @@ python bench.py > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 rm -rf $OUT/prof_kt $OUT/prof_f $OUT/prof_w
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_kt -- python bench.py --no-cpu-baseline --no-extras --no-roofline --steps 40 > $OUT/${TAG}_kt_bench.json 2> $OUT/${TAG}_kt.err
 python tools/prof_summary.py $OUT/prof_kt $OUT/${TAG}_kernel_stats_bench_graph.csv 60 > $OUT/${TAG}_kernel_stats_bench_graph.txt 2>&1
-python tools/step_timeline.py $OUT/prof_kt stage_bytes > $OUT/${TAG}_step_timeline.txt 2>&1
+python tools/step_timeline.py $OUT/prof_kt flip_pair_stage > $OUT/${TAG}_step_timeline.txt 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/prof_f -- python bench.py --no-cpu-baseline --no-extras --no-roofline --no-graph --steps 3 --warmup 1 > /dev/null 2> $OUT/${TAG}_pmc_f.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/prof_w -- python bench.py --no-cpu-baseline --no-extras --no-roofline --no-graph --steps 3 --warmup 1 > /dev/null 2> $OUT/${TAG}_pmc_w.err
 python tools/pmc_traffic.py $OUT/prof_f $OUT/prof_w $OUT/${TAG}_pmc_hbm_traffic.json > $OUT/${TAG}_pmc_hbm_traffic.txt 2>&1
