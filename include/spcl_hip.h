@@ -332,7 +332,8 @@ int spcl_conv3x3_dgrad_bnstats(const void* dy, int dtype, int N, int H, int W, i
  * channels, sizes tiled 14 x 14):
  *   spcl_image_autocorr          image [N][H][W] f32 (W <= 256) -> out [spcl_image_autocorr_rows(N, H, W)][64] partial rows
  *   spcl_conv3x3_dgrad_bnstats_image   spcl_conv3x3_dgrad_bnstats + rows 2 .. 10 of rows11 [tiles][11][CoutS] = the nine
- *                                sums sum_p dz[p][co] image[p + tap] (tiles = spcl_conv_stat_rows)
+ *                                sums sum_p dz[p][co] image[p + tap] (tiles = spcl_conv_stat_rows); g == NULL: the
+ *                                gradient tensor is not written (image3 needs only the rows)
  *   spcl_bnrelu_backward_rows_image3   rows11 + autocorrelation + the f32 master weights [C][1][3][3] -> dgamma, dbeta, dW
  *                                (ws: spcl_bnrelu_image3_workspace_bytes(CS) bytes) */
 int spcl_image_autocorr_rows(int N, int H, int W);

@@ -751,8 +751,8 @@ extern "C" int spcl_conv3x3_dgrad_bnstats_image(const void* dy, int dtype, int N
                                                 const void* w_packed, void* g, const void* y2, const float* scale2,
                                                 const float* shift2, const float* mean2, const float* image,
                                                 float* rows11, void* stream) {
-  SPCL_CHECK_ARG(dy && w_packed && g && y2 && scale2 && shift2 && mean2 && image && rows11,
-                 "conv3x3_dgrad_bnstats_image: null pointer");
+  SPCL_CHECK_ARG(dy && w_packed && y2 && scale2 && shift2 && mean2 && image && rows11,
+                 "conv3x3_dgrad_bnstats_image: null pointer");  // g may be null: the gradient itself is not written
   ConvArgs a;
   if (!spcl_conv_dgrad_bnstats_image_supported(dtype, N, H, W, CinK, CoutS) ||
       !dgrad_bnstats_args(a, dtype, N, H, W, CinK, CoutS)) {
@@ -763,7 +763,7 @@ extern "C" int spcl_conv3x3_dgrad_bnstats_image(const void* dy, int dtype, int N
   a.y2 = y2; a.scale2 = scale2; a.shift2 = shift2; a.mean2 = mean2; a.rows2 = rows11; a.img2 = image;
   hipStream_t st = (hipStream_t)stream;
   const double px = (double)N * H * W;
-  prof_cost(px * (CinK + 2.0 * CoutS) * 2.0 + px * 4.0 + 9.0 * CinK * CoutS * 2.0,
+  prof_cost(px * (CinK + (g ? 2.0 : 1.0) * CoutS) * 2.0 + px * 4.0 + 9.0 * CinK * CoutS * 2.0,
             2.0 * px * 9.0 * CinK * CoutS + 2.0 * px * 9.0 * CoutS);
   TileCfg t = pick_tile(H, W);
   if (!(t.tw == 14 && launch_conv_fast(a, t.th, st))) {

@@ -372,7 +372,7 @@ conv3x3_fast_kernel(FastArgs a) {
       mu2[j] = *(const f32x4*)(a.mean2 + cb);
     }
   }
-  if (M2) y2b = a.y2 + (yb - a.y);
+  if (M2) y2b = a.y2 + (((size_t)n * a.H + y0) * a.W + x0) * rowb + (nt0 * 16 + 4 * g) * 2;
   // MODE 4 LDS map: [0, 7168) DZ[co 16][row 14][col 16] bf16 -- dz of the tile, transposed, in the space of the activation
   // halo (no longer needed; one wave per workgroup, its own k-loop reads are behind it); columns 14 / 15 zero.
   // [halo bytes, + 1536) IM[kx 3][row 16][col 16] bf16, written in the prologue.
@@ -448,7 +448,8 @@ conv3x3_fast_kernel(FastArgs a) {
       const float keep = (!shifted || (pyc >= oy && px >= ox)) ? 1.f : 0.f;  // 0: the neighbour tile counts this pixel
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        store4_fast<bf16_t>(yb + ob + j * 32, acc[i][j]);
+        // (MODE 4: nobody downstream may want g itself -- the image block's first conv needs only the sums below)
+        if (MODE != 4 || a.y != nullptr) store4_fast<bf16_t>(yb + ob + j * 32, acc[i][j]);
         if (M2) {
           // dz = g [relu(bn(y2)) > 0] with g as STORED (bf16): sum dz and sum dz (y2 - mean) of the lane's 4 channels
           const uint2 yr = YPRE ? ypre[i][j][0] : *(const uint2*)(y2b + ob + j * 32);

@@ -880,11 +880,12 @@ def _image_autocorr(image, N, H, W):
     return out
 
 
-def _dgrad_bnstats_image(dy, wp_t, y2, st2, image, dt_code, dtype, N, H, W, cs):
-    """_dgrad_bnstats for the image block: the per-tile rows carry nine more sub-rows, sum dz * image[p + tap]"""
+def _dgrad_bnstats_image(dy, wp_t, y2, st2, image, dt_code, dtype, N, H, W, cs, want_g=False):
+    """_dgrad_bnstats for the image block: the per-tile rows carry nine more sub-rows, sum dz * image[p + tap].  The
+    gradient g itself is only written on request: with image3 nothing downstream reads it (103 MB at 64 x 224^2)."""
     dev = dy.device
     nt = _n.call("spcl_conv_stat_rows", dt_code, N, H, W, cs, cs)
-    g = torch.empty(N, H, W, cs, dtype=dtype, device=dev)
+    g = torch.empty(N, H, W, cs, dtype=dtype, device=dev) if want_g else None
     rows = torch.empty(nt * 11 * cs, dtype=torch.float32, device=dev)
     _n.call("spcl_conv3x3_dgrad_bnstats_image", _n.ptr(dy), dt_code, N, H, W, cs, cs, _n.ptr(wp_t), _n.ptr(g), _n.ptr(y2),
             _n.ptr(st2[2]), _n.ptr(st2[3]), _n.ptr(st2[0]), _n.ptr(image), _n.ptr(rows), _n.stream())

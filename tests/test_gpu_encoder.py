@@ -318,6 +318,22 @@ def test_image3_first_layer_gradient_without_a_pass_over_its_output():
         want, exact = float(shift(a, t).sum()), float(shift(f, t).sum())
         assert abs(acorr[45 + t] - want) < 2e-6 * abs(want), (t, acorr[45 + t], want)
         assert abs(acorr[45 + t] - exact) < 1e-4 * abs(exact), (t, acorr[45 + t], exact)
+    # ---- the dgrad entry with and without the gradient tensor: same rows, and g is the plain dgrad
+    gq = torch.Generator().manual_seed(4)
+    dyq = torch.randn(2, 140, 140, 16, generator=gq).cuda().bfloat16()
+    y2q = torch.randn(2, 140, 140, 16, generator=gq).cuda().bfloat16()
+    wq = torch.randn(16, 16, 3, 3, generator=gq).cuda() * 0.1
+    stq = [torch.randn(16, generator=gq).cuda() * 0.1, torch.rand(16, generator=gq).cuda() + 0.5,
+           torch.rand(16, generator=gq).cuda() + 0.5, torch.randn(16, generator=gq).cuda() * 0.1]
+    imq = torch.rand(2, 140, 140, generator=gq).cuda()
+    wpt = F_._pack(wq, 1, _n.dtype_code(torch.bfloat16), torch.bfloat16)
+    g_a, rows_a = F_._dgrad_bnstats_image(dyq, wpt, y2q, stq, imq, _n.dtype_code(torch.bfloat16), torch.bfloat16, 2, 140, 140,
+                                          16, want_g=True)
+    g_b, rows_b = F_._dgrad_bnstats_image(dyq, wpt, y2q, stq, imq, _n.dtype_code(torch.bfloat16), torch.bfloat16, 2, 140, 140,
+                                          16)
+    assert g_b is None and torch.equal(rows_a, rows_b) and rows_a.abs().max() > 0
+    want_g = torch.nn.functional.conv_transpose2d(dyq.float().permute(0, 3, 1, 2), wq.bfloat16().float(), padding=1)
+    assert _relerr(g_a.float().permute(0, 3, 1, 2).cpu().numpy(), want_g.cpu().numpy()) < 6e-3
     # ---- the whole block, new path against the old one
     res, default = {}, F_._IMAGE3
     for on in (False, True, True):
