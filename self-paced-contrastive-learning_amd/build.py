@@ -17,6 +17,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # per-file extras.  supcon.hip: the first kernel-argument dwords arrive in SGPRs at wave launch (gfx950 kernarg preload)
 # instead of through a scalar load -- the large-batch sweeps start their transfers one memory round trip earlier.
 EXTRA = {"supcon.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=14"]}
+if os.environ.get("SPCL_BUILD_NOSLP"):  # experiment: no SLP packing of adjacent f32 operations (v_pk_*_f32) in the named files
+    for _f in os.environ["SPCL_BUILD_NOSLP"].split(","):
+        EXTRA.setdefault(_f, []).append("-fno-slp-vectorize")
 
 
 def _sources():

@@ -95,6 +95,10 @@ __device__ __forceinline__ float wave_max(float v) {
 // fills it, skips its own reduction launch and clears the capture
 spcl_wgrad_tail* take_tail_capture();
 
+// wgrad.hip: final sum of a weight gradient's split partial slabs
+void launch_wgrad_reduce(const float* partial, int nsplit, int nblk_ci, int nblk_co, int CIB, int COB, int Cin, int Cout,
+                         float* dw_oihw, hipStream_t st);
+
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline int round_up(int a, int b) { return cdiv(a, b) * b; }
 

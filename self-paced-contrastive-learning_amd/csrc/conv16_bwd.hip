@@ -1,0 +1,534 @@
+// Backward of the image block's SECOND convolution (semi_seg/arch/unet.py:75 behind unet.py:72-74 with input_dim == 1:
+// 16 -> 16 channels at the image resolution) in ONE pass over its two inputs.  The layer's gradient dy and the first
+// conv's raw output y2 used to be read twice -- once by the weight-gradient kernel (wgrad.hip: x = relu(bn(y2)) and dy),
+// once by the input-gradient kernel (conv_fast.hip MODE 4: dy through the flipped filters, y2 for the BatchNorm-backward
+// sums of the layer below) -- 2 x 206 MB at 64 x 224^2.  Here a workgroup of NW waves (2; 1 and 4 are built for comparison)
+// per 14 x 14 tile
+//   1. stages the dy halo (16 x 16 pixels, zero outside the image) in LDS and forms g = dgrad(dy) on the matrix pipe
+//      (the conv_fast.hip mapping: 13 m-tiles of 16 pixels -- dealt to the waves -- x 5 k-steps of (tap, 8 channels) chunks);
+//   2. loads y2 at the tile's pixels ONCE: x = relu(scale2 y2 + shift2) goes to LDS pixel-major, and
+//        dW[tap][ci][co] += sum_q x[q][ci] dy[q - tap][co]                 (q over the tile, dy from the halo image)
+//      runs as 7 k-steps of 32 pixels with BOTH operands read transposed (ds_read_b64_tr_b16), the taps dealt to the waves
+//      -- accumulated in registers over the workgroup's tiles, one partial slab per workgroup at the end (summed by
+//      wgrad_reduce_kernel or by the batched launch's tail, as the stand-alone kernel's slabs are);
+//   3. dz = g [x > 0], the BatchNorm-backward sums of the layer below and the nine image tap sums of its weight gradient
+//      (image3, bn.hip) as MODE 4 leaves them: rows11 [tile][11][16] (dz takes x's place in LDS, read transposed as well).
+// Nothing is written per pixel.  LDS per workgroup: dy halo 11 264 B + image copies 1 536 B + x tile (later dz) 7 168 B +
+// 512 B = 20 480 B.  A workgroup walks its tiles with the next tile's global requests in flight.
+//
+// What the measurements said (tools/diag/conv16_phases.py, in-kernel stamps): the two kernels this
+// replaces are NOT bound by HBM but by instruction issue -- per tile ~1 300 vector-ALU instructions (4 cycles each on a
+// SIMD), 170 KB of LDS traffic and 135 MFMAs that hardly overlap -- so reading dy and y2 once saves the duplicated staging
+// work (~10 us of 104), not the 206 MB.  Traps on the way, each worth a third of the kernel's time: image loads behind
+// `if (wave == 0)` went through one register with s_waitcnt vmcnt(0) after each; the first in-loop use of the BatchNorm
+// coefficients carried the compiler's vmcnt(0) for their pre-loop load, i.e. a wait for the freshly issued prefetch on every
+// trip; lane-invariant addresses hoisted out of the tile loop and spilled; prefetched values spilled right behind their loads.
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include "conv_common.hpp"
+
+namespace spcl {
+
+struct Bwd16Args {
+  const unsigned char* dy;  // [N][H][W][16] bf16
+  const u32x4* wp;          // packed dgrad fragments of the 16 -> 16 filters (conv.hip kind 1): 5 k-steps x 64 lanes
+  const unsigned char* y2;  // [N][H][W][16] bf16, raw output of the first conv
+  const float* scale2;      // its BatchNorm scale / shift / batch mean [16]
+  const float* shift2;
+  const float* mean2;
+  const float* img;         // [N][H][W] f32, the block's input
+  float* rows11;            // [tile][11][16]
+  float* partial;           // [workgroup][9][16 ci][16 co]
+  int N, H, W, tilesX, tilesY, ipw, xcd_remap;
+  int dbg;  // ablation bits (timing experiments only, wrong results; 0 in production): 1 no dgrad MFMAs, 2 no pixel pass,
+            // 4 no weight-gradient phase, 8 no dz / tap sums, 16 no global requests after the first tile
+  unsigned long long* stamps;  // debug (SPCL_CONV16_STAMPS=1): s_memtime ticks of wave 0 per phase, summed over its tiles
+};
+
+constexpr int B16_TH = 14, B16_TW = 14, B16_HW = 16, B16_RP = 22, B16_PS = 32;
+constexpr int B16_DY = 0, B16_DY_BYTES = (B16_TH + 2) * B16_RP * B16_PS;  // 11 264
+constexpr int B16_IM = B16_DY_BYTES, B16_IM_BYTES = 1536;
+constexpr int B16_XT = B16_IM + B16_IM_BYTES, B16_XT_ROW = 16 * 32, B16_XT_BYTES = B16_TH * B16_XT_ROW;
+constexpr int B16_RED = B16_XT + B16_XT_BYTES;  // [wave <= 4][2][16] f32: the waves' shares of the BatchNorm sums
+constexpr int B16_LDS = B16_RED + 512;           // 20 480
+
+__device__ __forceinline__ bf16x8 b16_tr_frag(unsigned addr) {
+  // 8 pixels (k) of the lane's channel: two hardware-transposed reads of 4 pixels x 16 channels, 8 pixels apart
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(uintptr_t)addr);
+  const s16x4 hi =
+      __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(uintptr_t)(addr + 8 * B16_PS));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// SHIFTED: the image size is not a multiple of the tile (last tiles shifted back inside: pixels two tiles cover count once)
+// NW: waves per tile (1, 2 or 4): m-tile i of 13 goes to wave i % NW, tap t of 9 to wave t % NW
+constexpr int b16_wpe(int NW) { return NW == 1 ? 2 : 3; }
+template <bool SHIFTED, int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(b16_wpe(NW)))) void conv16_bwd_kernel(Bwd16Args a) {
+  constexpr int TH = B16_TH, TW = B16_TW, HW_ = B16_HW, RP = B16_RP, PS = B16_PS;
+  constexpr int NPIX = TH * TW, NSTEPS = 5, NTHR = 64 * NW, ITER = 512 / NTHR, RPI = NTHR / 32;  // halo rows per staging step
+  constexpr int MW = (13 + NW - 1) / NW, TPW = (9 + NW - 1) / NW;  // m-tiles / taps per wave: i = wave + NW j
+  constexpr int SPX = (16 * NW) % TW, SPY = (16 * NW) / TW;         // 16 NW pixels on = SPY rows + SPX columns
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const unsigned lds_base = (unsigned)(uintptr_t)(unsigned char __attribute__((address_space(3)))*)lds;
+  const int t0 = threadIdx.x;
+  const int wave = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane(t0 >> 6);
+
+  int tx = blockIdx.x, ty = blockIdx.y;
+  {
+    const int T = a.tilesX * a.tilesY;  // (conv_fast.hip: an XCD's workgroups take neighbouring tiles)
+    if (a.xcd_remap && (T & 7) == 0) {
+      const int L = ty * a.tilesX + tx;
+      const int L2 = (L & 7) * (T >> 3) + (L >> 3);
+      ty = L2 / a.tilesX;
+      tx = L2 - ty * a.tilesX;
+    }
+  }
+  const int y0 = min(ty * TH, a.H - TH), x0 = min(tx * TW, a.W - TW);
+  const int oy = ty * TH - y0, ox = tx * TW - x0;
+  const bool interior = y0 > 0 && x0 > 0 && y0 + TH < a.H && x0 + TW < a.W;
+  const bool shifted = SHIFTED && (oy | ox) != 0;
+  const int rowb = 32;
+
+  u32x4 wall[NSTEPS];
+#pragma unroll
+  for (int s = 0; s < NSTEPS; ++s) wall[s] = a.wp[s * 64 + (t0 & 63)];
+  const f32x4 sc2 = *(const f32x4*)(a.scale2 + 4 * ((t0 & 63) >> 4)), sh2 = *(const f32x4*)(a.shift2 + 4 * ((t0 & 63) >> 4)),
+              mu2 = *(const f32x4*)(a.mean2 + 4 * ((t0 & 63) >> 4));
+  // zero for the whole launch: the two pad columns of the x / dz tile, pad pixels 16, 17 of every dy halo row (the shifted
+  // weight-gradient fragments read them next to x == 0; LDS starts out undefined)
+  if (t0 < 4 * TH) *(u32x4*)(lds + B16_XT + (t0 >> 2) * B16_XT_ROW + TW * PS + (t0 & 3) * 16) = (u32x4){0u, 0u, 0u, 0u};
+  if (t0 >= NTHR - 64)
+    *(u32x4*)(lds + B16_DY + (((t0 & 63) >> 2) * RP + HW_) * PS + (t0 & 3) * 16) = (u32x4){0u, 0u, 0u, 0u};
+
+  if (t0 < 48) {  // copy kx = 1: column 15, kx = 2: columns 14, 15 of the 16 rows
+    const int r = t0 & 15, k = t0 >> 4;
+    ((bf16_t*)(lds + B16_IM))[(k == 0 ? 256 + 15 : (k == 1 ? 512 + 14 : 512 + 15)) + r * 16] = 0;
+  }
+  // wave w owns the taps w, w + 4, (w + 8): no cross-wave reduction of the weight gradient
+  f32x4 wacc[TPW];
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) wacc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- global requests of one tile.  issue_halo: the image halo (wave 0: 4 pixels per lane, clamped addresses -- the zero
+  // padding is applied when they are used) and the dy halo (2 chunks per thread, masked lanes keep zero); issue_y2: y2 at the
+  // wave's pixels (4 x 8 bytes).  Issued for tile t + 1 before / after the weight-gradient phase of tile t.  Everything
+  // derived from the thread index is recomputed behind an opaque copy where it is used: left loop-invariant, the addresses
+  // and flags are hoisted out of the tile loop and spilled around it.
+  float imgv[256 / (64 * NW)];
+  u32x4 v[ITER];
+  uint2 ypre[MW];
+  // image halo: the workgroup's threads share the 16 x 16 pixels (PPT consecutive columns each: one register per thread with
+  // four waves -- as four registers of wave 0 alone they were the first to be spilled, right behind their loads)
+  constexpr int PPT = 256 / NTHR;
+  auto issue_img = [&](const int n) {
+    int t = t0;
+    asm volatile("" : "+v"(t));
+    const int hr = (t * PPT) >> 4, hc = (t * PPT) & 15;
+    const int gy = y0 - 1 + hr;
+    const float* ir = a.img + ((size_t)n * a.H + (gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy))) * a.W;
+#pragma unroll
+    for (int e = 0; e < PPT; ++e) {
+      const int gx = x0 - 1 + hc + e;
+      imgv[e] = ir[gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx)];
+    }
+  };
+  auto issue_halo = [&](const int n) {
+    int t = t0;
+    asm volatile("" : "+v"(t));
+    const int ch = t & 1, q0 = t >> 1, hy0 = q0 / HW_, hx0 = q0 % HW_;
+    const unsigned voff = (unsigned)((hy0 * a.W + hx0) * 32 + ch * 16);
+    const unsigned char* xb = a.dy + (((long)n * a.H + (y0 - 1)) * a.W + (x0 - 1)) * 32;
+#pragma unroll
+    for (int k = 0; k < ITER; ++k) {
+      const long soff = (long)(RPI * k) * a.W * 32;
+      bool inb = true;
+      if (!interior) {
+        const int gy = y0 - 1 + hy0 + RPI * k, gx = x0 - 1 + hx0;
+        inb = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      }
+      v[k] = (u32x4){0u, 0u, 0u, 0u};
+      if (inb) v[k] = *(const u32x4*)(xb + soff + voff);
+    }
+  };
+  auto issue_y2 = [&](const int n) {
+    int t = t0;
+    asm volatile("" : "+v"(t));
+    const int r16 = t & 15, g = (t & 63) >> 4;
+    const int p0 = 16 * wave + r16, py0 = p0 / TW, px0 = p0 - py0 * TW;
+    const unsigned char* y2b = a.y2 + (((size_t)n * a.H + y0) * a.W + x0) * rowb + 4 * g * 2;
+    int py = py0, px = px0;
+#pragma unroll
+    for (int j = 0; j < MW; ++j) {
+      const bool ok = 16 * (wave + NW * j) + r16 < NPIX;
+      ypre[j] = *(const uint2*)(y2b + (ok ? (py * a.W + px) * rowb : 0));  // (a lane beyond the last pixel: unused)
+      px += SPX;
+      py += SPY;
+      if (px >= TW) {
+        px -= TW;
+        py += 1;
+      }
+    }
+  };
+
+#ifndef SPCL_CONV16_STAMPS_BUILD
+#define SPCL_CONV16_STAMPS_BUILD 0  /* -DSPCL_CONV16_STAMPS_BUILD=1 + SPCL_CONV16_STAMPS=1: the counters cost sixteen registers */
+#endif
+  const bool stamp = SPCL_CONV16_STAMPS_BUILD && a.stamps != nullptr && t0 == 0;
+  unsigned long long tph[7] = {0, 0, 0, 0, 0, 0, 0}, tc = 0;
+// (every phase boundary also fences the instruction scheduler: left free it hoists the next phase's LDS reads and address
+// arithmetic across, runs out of registers and spills the image halo right behind its loads -- an s_waitcnt vmcnt(0) per tile)
+#define B16_STAMP(k)                                      \
+  __builtin_amdgcn_sched_barrier(0);                      \
+  if (stamp) {                                            \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+    tph[k] += now_ - tc;                                  \
+    tc = now_;                                            \
+  }
+  const int n_first = blockIdx.z * a.ipw;
+  if (stamp) tc = __builtin_amdgcn_s_memtime();
+  if (n_first < a.N) {
+    issue_img(n_first);
+    issue_halo(n_first);
+    issue_y2(n_first);
+  }
+  // the filter fragments and BatchNorm coefficients have arrived BEFORE the tile loop: their first use inside it would carry
+  // the compiler's wait, and on every later trip that s_waitcnt vmcnt(0) waits for the next tile's requests just issued
+  // (a throw-away LDS store of a combination of them: ordinary code the compiler must wait for, on every path into the loop)
+  {
+    const u32x4 wx = wall[0] ^ wall[1] ^ wall[2] ^ wall[3] ^ wall[4];
+    const f32x4 cx = sc2 + sh2 + mu2;
+    *(u32x4*)(lds + B16_RED) = wx;
+    *(f32x4*)(lds + B16_RED + 16) = cx;
+  }
+#pragma unroll 1
+  for (int it = 0; it < a.ipw; ++it) {
+    const int n = n_first + it;
+    if (n >= a.N) break;
+    int t = t0;
+    asm volatile("" : "+v"(t));
+    const int lane = t & 63, r16 = t & 15, g = lane >> 4;
+    const int p0 = 16 * wave + r16, py0 = p0 / TW, px0 = p0 - py0 * TW;
+    const int tile = (n * a.tilesY + ty) * a.tilesX + tx;
+    // ---- image copies IM[kx][row][col] = bf16(halo[row][col + kx]) (conv_fast.hip MODE 4), zero outside the image: a thread
+    // puts each of its pixels where the three copies want it (columns 16 - kx .. 15 of copy kx stay zero, written once)
+    {
+      const int hr = (t * PPT) >> 4, hc = (t * PPT) & 15;
+      const int gy = y0 - 1 + hr;
+#pragma unroll
+      for (int e = 0; e < PPT; ++e) {
+        const int gx = x0 - 1 + hc + e;
+        const float hv = (interior || (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)) ? imgv[e] : 0.f;
+        const bf16_t hb = f32_to_bf16(hv);
+        bf16_t* imb = (bf16_t*)(lds + B16_IM) + hr * 16 + hc + e;
+        imb[0] = hb;
+        if (hc + e >= 1) imb[256 - 1] = hb;
+        if (hc + e >= 2) imb[512 - 2] = hb;
+      }
+    }
+    // ---- dy halo -> LDS
+    {
+      const int ch = t & 1, q0 = t >> 1, hy0 = q0 / HW_, hx0 = q0 % HW_;
+      unsigned char* const lp = lds + B16_DY + (hy0 * RP + hx0) * PS + ch * 16;
+#pragma unroll
+      for (int k = 0; k < ITER; ++k) *(u32x4*)(lp + (RPI * k * RP) * PS) = v[k];
+    }
+    // ---- the next tile's image and dy requests, as soon as their registers are free: in flight for a whole tile period
+    // (issued one phase before their use they were outstanding a third of the time -- 15 KB per workgroup, not enough bytes
+    // in flight to stream from HBM)
+    // (with one or two waves per tile the registers run out: there the requests follow the pixel pass)
+    constexpr bool EARLY = NW >= 4;
+    const bool more = it + 1 < a.ipw && n + 1 < a.N && !(a.dbg & 16);
+    if (EARLY && more) issue_halo(n + 1);
+    B16_STAMP(0)  // staging: image copies, wait for the dy halo, LDS stores, next requests
+    __syncthreads();
+    B16_STAMP(1)  // barrier 1
+
+    // ---- input gradient g at the wave's m-tiles (pixels 16 (wave + 4 j) + r16): 5 k-steps
+    f32x4 acc[MW];
+    {
+      int abase[MW];
+      int py = py0, px = px0;
+#pragma unroll
+      for (int j = 0; j < MW; ++j) {
+        const bool ok = 16 * (wave + NW * j) + r16 < NPIX;
+        abase[j] = B16_DY + (ok ? (py * RP + px) * PS : 0);
+        acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        px += SPX;
+        py += SPY;
+        if (px >= TW) {
+          px -= TW;
+          py += 1;
+        }
+      }
+      if (!(a.dbg & 1))
+#pragma unroll
+      for (int s = 0; s < NSTEPS; ++s) {
+        int fc = 4 * s + g;
+        if (fc >= 18) fc = 0;  // K padding: zero weights
+        const int tap = fc >> 1, c = fc & 1, ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+        const int off = (ky * RP + kx) * PS + c * 16;
+#pragma unroll
+        for (int j = 0; j < MW; ++j) {
+          if (wave + NW * j < 13) {  // (wave-uniform: the last round is not full)
+            const u32x4 xf = *(const u32x4*)(lds + abase[j] + off);
+            acc[j] = mfma_chunk<bf16_t>(wall[s], xf, acc[j]);
+          }
+        }
+      }
+    }
+
+    B16_STAMP(2)  // dgrad
+    // ---- one pass over the wave's pixels: x = relu(bn(y2)) -> LDS, pixel-major (a pixel another tile counts: 0);
+    // dz = g [x > 0] with g as a bf16 value, parked as packed bf16; the BatchNorm-backward sums of the layer below
+    uint2 dzp[MW];
+    f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
+    {
+      int px = px0, py = py0;
+#pragma unroll
+      for (int j = 0; j < MW; ++j) {
+        const bool ok = 16 * (wave + NW * j) + r16 < NPIX;
+        dzp[j] = (uint2){0u, 0u};
+        if (ok && !(a.dbg & 2)) {
+          const bool keep = !shifted || (py >= oy && px >= ox);
+          const float yv[4] = {__uint_as_float(ypre[j].x << 16), __uint_as_float(ypre[j].x & 0xffff0000u),
+                               __uint_as_float(ypre[j].y << 16), __uint_as_float(ypre[j].y & 0xffff0000u)};
+          const f32x2 glo = {acc[j][0], acc[j][1]}, ghi = {acc[j][2], acc[j][3]};
+          const uint32_t g0 = __builtin_bit_cast(uint32_t, __builtin_convertvector(glo, bf16x2v));
+          const uint32_t g1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(ghi, bf16x2v));
+          const float gv[4] = {__uint_as_float(g0 << 16), __uint_as_float(g0 & 0xffff0000u),
+                               __uint_as_float(g1 << 16), __uint_as_float(g1 & 0xffff0000u)};
+          float xv[4], dz[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float z = fmaf(sc2[r], yv[r], sh2[r]);
+            xv[r] = keep ? fmaxf(z, 0.f) : 0.f;
+            dz[r] = (z > 0.f && keep) ? gv[r] : 0.f;
+            ssum[r] += dz[r];
+            ssq[r] = fmaf(dz[r], yv[r] - mu2[r], ssq[r]);
+          }
+          const f32x2 lo = {xv[0], xv[1]}, hi = {xv[2], xv[3]};
+          uint2 w;
+          w.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf16x2v));
+          w.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, bf16x2v));
+          *(uint2*)(lds + B16_XT + py * B16_XT_ROW + px * PS + g * 8) = w;
+          // (dz is a bf16 value or zero: its upper halves are the exact packing)
+          dzp[j].x = (__float_as_uint(dz[0]) >> 16) | (__float_as_uint(dz[1]) & 0xffff0000u);
+          dzp[j].y = (__float_as_uint(dz[2]) >> 16) | (__float_as_uint(dz[3]) & 0xffff0000u);
+        }
+        px += SPX;
+        py += SPY;
+        if (px >= TW) {
+          px -= TW;
+          py += 1;
+        }
+      }
+    }
+    {
+      // the wave's share of the two sums -> LDS; wave 0 adds the four shares in wave order after the barrier
+      f32x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float s1 = row16_sum(ssum[r]), s2 = row16_sum(ssq[r]);
+        o[r] = r16 == 0 ? s1 : s2;
+      }
+      if (r16 < 2) *(f32x4*)(lds + B16_RED + ((wave * 2 + r16) * 16 + 4 * g) * 4) = o;
+    }
+    if (more) {  // (likewise: the y2 registers were consumed by the pass above; the image halo rides along)
+      if (!EARLY) issue_halo(n + 1);
+      issue_y2(n + 1);
+      issue_img(n + 1);
+    }
+    B16_STAMP(3)  // pixel pass
+    __syncthreads();
+    B16_STAMP(1)
+    if (t < 32) {
+      const float* red = (const float*)(lds + B16_RED) + t;
+      float tot = red[0];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) tot += red[32 * w];
+      a.rows11[(size_t)tile * 11 * 16 + t] = tot;
+    }
+
+    // ---- weight gradient of the tile: dW[tap][ci][co] += sum_q x[q][ci] dy[q + (2 - ky, 2 - kx)][co] in halo coordinates.
+    // k-step ks = tile rows 2 ks, 2 ks + 1; lane group g -> row g >> 1, columns 4 (g & 1) .. + 3 and + 8 ..: the 32 lanes one
+    // transposed read serves sit in ONE row, 256 contiguous bytes (no bank conflicts)
+    const unsigned tr_col = (unsigned)((4 * (g & 1) + (r16 >> 2)) * PS + (r16 & 3) * 8);
+    const unsigned tr_x = lds_base + B16_XT + (g >> 1) * B16_XT_ROW + tr_col;
+    if (!(a.dbg & 4)) {
+      unsigned ax = tr_x, ad[TPW];
+#pragma unroll
+      for (int j = 0; j < TPW; ++j) {
+        const int tap = min(wave + NW * j, 8), ky = tap / 3, kx = tap - 3 * ky;
+        ad[j] = lds_base + B16_DY + (g >> 1) * RP * PS + tr_col + (2 - ky) * RP * PS + (2 - kx) * PS;
+      }
+      // (one wave per tile: rolled, or the scheduler hoists all 140 fragment reads of the nine taps and spills)
+#pragma unroll NW == 1 ? 1 : TH / 2
+      for (int ks = 0; ks < TH / 2; ++ks) {
+        const bf16x8 af = b16_tr_frag(ax + ks * 2 * B16_XT_ROW);
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+          if (wave + NW * j < 9) {
+            const bf16x8 bf = b16_tr_frag(ad[j] + ks * 2 * RP * PS);
+            wacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, wacc[j], 0, 0, 0);
+          }
+        }
+      }
+    }
+    B16_STAMP(4)  // weight gradient (+ the two row sums)
+    __syncthreads();
+    B16_STAMP(1)
+
+    // ---- dz takes x's place in LDS; S[co][tap] = sum_p dz[p][co] img[p + tap] on the matrix pipe (wave 0: 7 k-steps of 32
+    // pixels, same pixel order as above): A = dz read transposed, B = the lane's tap: 2 x 4 columns of the shifted image copy
+    {
+      int px = px0, py = py0;
+#pragma unroll
+      for (int j = 0; j < MW; ++j) {
+        const bool ok = 16 * (wave + NW * j) + r16 < NPIX;
+        if (ok) *(uint2*)(lds + B16_XT + py * B16_XT_ROW + px * PS + g * 8) = dzp[j];
+        px += SPX;
+        py += SPY;
+        if (px >= TW) {
+          px -= TW;
+          py += 1;
+        }
+      }
+    }
+    B16_STAMP(5)  // dz stores
+    __syncthreads();
+    B16_STAMP(1)
+    if (wave == 0 && !(a.dbg & 8)) {
+      const int tap = r16 < 9 ? r16 : 0, tky = tap / 3, tkx = tap - 3 * tky;
+      const unsigned char* pb = lds + B16_IM + tkx * 512 + ((g >> 1) + tky) * 32 + (g & 1) * 8;
+      f32x4 D = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < TH / 2; ++ks) {
+        const bf16x8 af = b16_tr_frag(tr_x + ks * 2 * B16_XT_ROW);
+        const uint2 b0 = *(const uint2*)(pb + ks * 64), b1 = *(const uint2*)(pb + ks * 64 + 16);
+        const u32x4 bq = {b0.x, b0.y, b1.x, b1.y};
+        D = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, bq), D, 0, 0, 0);
+      }
+      if (r16 < 9) *(f32x4*)(a.rows11 + ((size_t)tile * 11 + 2 + r16) * 16 + 4 * g) = D;
+    }
+    B16_STAMP(6)  // tap sums
+    if (NW > 1) __syncthreads();  // every wave restages the image copies: behind wave 0's reads
+    // (the dy halo is free since the barrier after the weight gradient; x / dz is rewritten only after the next staging
+    // barrier, which wave 0 reaches after its reads)
+  }
+
+  if (stamp) {
+    unsigned long long* o = a.stamps + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) o[k] = tph[k];
+  }
+  // ---- the workgroup's partial slab [tap][ci][co]: lane holds co = r16, ci = 4 g + r of the wave's taps
+  float* out = a.partial + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (9 * 256);
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) {
+    const int tap = wave + NW * j;
+    if (tap < 9) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[(tap * 16 + 4 * ((t0 & 63) >> 4) + r) * 16 + (t0 & 15)] = wacc[j][r];
+    }
+  }
+}
+
+int conv16_bwd_nw() {
+  // measured inside the step (64 x 224^2, same box, median of single replays; separate launches 1204.7 us): one wave per
+  // tile 1208, two 1194, four 1242
+  static const int env = getenv("SPCL_CONV16_NW") ? atoi(getenv("SPCL_CONV16_NW")) : 2;
+  return env == 1 || env == 4 ? env : 2;
+}
+
+int conv16_bwd_ipw(int N, int H, int W) {
+  // one resident generation of workgroups where the batch allows it: LDS (20 KB) and registers allow 8 / 6 / 3 per CU
+  const int nw = conv16_bwd_nw(), resident = 256 * (nw == 1 ? 8 : (nw == 2 ? 6 : 3));
+  const long tiles = (long)cdiv(H, B16_TH) * cdiv(W, B16_TW);
+  static const int env_ipw = getenv("SPCL_CONV16_IPW") ? atoi(getenv("SPCL_CONV16_IPW")) : 0;
+  int ipw = env_ipw > 0 ? env_ipw : (int)((tiles * N + resident - 1) / resident);
+  if (ipw < 1) ipw = 1;
+  if (ipw > N) ipw = N;
+  return ipw;
+}
+
+}  // namespace spcl
+
+using namespace spcl;
+
+extern "C" int spcl_conv16_bwd_fused_supported(int dtype, int N, int H, int W, int CinK, int CoutS) {
+  static const bool off = getenv("SPCL_NO_CONV16_FUSED") != nullptr;  // A/B switch
+  if (off || CinK != 16 || CoutS != 16) return 0;
+  return spcl_conv_dgrad_bnstats_image_supported(dtype, N, H, W, CinK, CoutS);
+}
+
+extern "C" int spcl_conv16_bwd_fused_splits(int N, int H, int W) {
+  if (N <= 0 || H < B16_TH || W < B16_TW) return 0;
+  const int ipw = conv16_bwd_ipw(N, H, W);
+  return cdiv(H, B16_TH) * cdiv(W, B16_TW) * cdiv(N, ipw);
+}
+
+extern "C" int spcl_conv16_bwd_fused(const void* dy, int dtype, int N, int H, int W, const void* w_packed_dgrad,
+                                     const void* y2, const float* scale2, const float* shift2, const float* mean2,
+                                     const float* image, float* rows11, float* partial, float* dw_oihw, int Cin, int Cout,
+                                     void* stream) {
+  SPCL_CHECK_ARG(dy && w_packed_dgrad && y2 && scale2 && shift2 && mean2 && image && rows11 && partial && dw_oihw,
+                 "conv16_bwd_fused: null pointer");
+  SPCL_CHECK_ARG(Cin > 0 && Cin <= 16 && Cout > 0 && Cout <= 16, "conv16_bwd_fused: channel counts");
+  if (!spcl_conv16_bwd_fused_supported(dtype, N, H, W, 16, 16)) {
+    set_error("conv16_bwd_fused: unsupported configuration (bf16, 16 -> 16 channels, 14 x 14 tiles)");
+    return SPCL_EUNSUPPORTED;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  spcl_wgrad_tail* tail = take_tail_capture();
+  Bwd16Args a;
+  a.dy = (const unsigned char*)dy; a.wp = (const u32x4*)w_packed_dgrad; a.y2 = (const unsigned char*)y2;
+  a.scale2 = scale2; a.shift2 = shift2; a.mean2 = mean2; a.img = image; a.rows11 = rows11; a.partial = partial;
+  a.N = N; a.H = H; a.W = W; a.tilesX = cdiv(W, B16_TW); a.tilesY = cdiv(H, B16_TH);
+  a.ipw = conv16_bwd_ipw(N, H, W);
+  static const int env_remap = getenv("SPCL_CONV_XCD_REMAP") ? atoi(getenv("SPCL_CONV_XCD_REMAP")) : 1;
+  a.xcd_remap = env_remap;
+  a.dbg = getenv("SPCL_CONV16_DBG") ? atoi(getenv("SPCL_CONV16_DBG")) : 0;  // (read per call: experiments flip it)
+  const int nz = cdiv(N, a.ipw), nsplit = a.tilesX * a.tilesY * nz;
+  const double px = (double)N * H * W;
+  prof_cost(px * 32.0 * 2.0 + px * 4.0 + (double)nsplit * 9 * 256 * 4.0, 2.0 * px * 9.0 * 256 * 2.0 + 2.0 * px * 9.0 * 16);
+  a.stamps = nullptr;
+  const bool want_stamps = SPCL_CONV16_STAMPS_BUILD && getenv("SPCL_CONV16_STAMPS") != nullptr;  // debug only (synchronises)
+  const size_t nwg = (size_t)a.tilesX * a.tilesY * nz;
+  if (want_stamps) {
+    (void)hipMalloc(&a.stamps, nwg * 8 * sizeof(unsigned long long));
+    (void)hipMemset(a.stamps, 0, nwg * 8 * sizeof(unsigned long long));
+  }
+  const int nw = conv16_bwd_nw();
+  const bool even = H % B16_TH == 0 && W % B16_TW == 0;
+  const dim3 grid(a.tilesX, a.tilesY, nz);
+#define B16_CASE(NW_)                                                                                       \
+  if (nw == NW_) {                                                                                          \
+    if (even) SPCL_LAUNCH((conv16_bwd_kernel<false, NW_>), grid, dim3(64 * NW_), B16_LDS, st, a);            \
+    else SPCL_LAUNCH((conv16_bwd_kernel<true, NW_>), grid, dim3(64 * NW_), B16_LDS, st, a);                  \
+  }
+  B16_CASE(1) B16_CASE(2) B16_CASE(4)
+#undef B16_CASE
+  if (a.stamps != nullptr) {
+    std::vector<unsigned long long> h(nwg * 8);
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(h.data(), a.stamps, h.size() * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(a.stamps);
+    double ph[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (size_t i = 0; i < nwg; ++i)
+      for (int k = 0; k < 7; ++k) ph[k] += (double)h[i * 8 + k];
+    fprintf(stderr, "[conv16_bwd stamps] %zu workgroups x %d tiles | s_memtime ticks of wave 0 per TILE: staging %.0f, barriers %.0f, "
+            "dgrad %.0f, pixel pass %.0f, wgrad %.0f, dz stores %.0f, tap sums %.0f\n", nwg, a.ipw, ph[0] / nwg / a.ipw,
+            ph[1] / nwg / a.ipw, ph[2] / nwg / a.ipw, ph[3] / nwg / a.ipw, ph[4] / nwg / a.ipw, ph[5] / nwg / a.ipw,
+            ph[6] / nwg / a.ipw);
+  }
+  if (tail != nullptr) {
+    tail->partial = partial; tail->dw = dw_oihw; tail->kind = 0; tail->nsplit = nsplit; tail->nblk_ci = 1;
+    tail->nblk_co = 1; tail->CIB = 16; tail->COB = 16; tail->Cin = Cin; tail->Cout = Cout;
+  } else {
+    launch_wgrad_reduce(partial, nsplit, 1, 1, 16, 16, Cin, Cout, dw_oihw, st);
+  }
+  SPCL_LAUNCH_CHECK("conv16_bwd_fused");
+  return SPCL_OK;
+}

@@ -443,6 +443,18 @@ static void launch_wgrad_t(const WgradArgs& a, const WgradPlan& p, hipStream_t s
   else launch_wgrad_th<T, 16>(a, p, st);
 }
 
+// the final sum of [nsplit][nblk_ci * nblk_co][9][CIB][COB] partial slabs into the OIHW gradient (also conv16_bwd.hip)
+void launch_wgrad_reduce(const float* partial, int nsplit, int nblk_ci, int nblk_co, int CIB, int COB, int Cin, int Cout,
+                         float* dw_oihw, hipStream_t st) {
+  const int slab = 9 * CIB * COB;
+  if (slab >= 16384)
+    SPCL_LAUNCH(wgrad_reduce_kernel<4>, dim3(cdiv(slab, 256), nblk_ci * nblk_co), dim3(nsplit >= 64 ? 1024 : 256), 0, st,
+                partial, nsplit, nblk_ci, nblk_co, CIB, COB, Cin, Cout, dw_oihw);
+  else
+    SPCL_LAUNCH(wgrad_reduce_kernel<1>, dim3(cdiv(slab, 64), nblk_ci * nblk_co), dim3(nsplit >= 64 ? 1024 : 256), 0, st,
+                partial, nsplit, nblk_ci, nblk_co, CIB, COB, Cin, Cout, dw_oihw);
+}
+
 }  // namespace spcl
 
 using namespace spcl;
@@ -517,16 +529,12 @@ extern "C" int spcl_conv3x3_wgrad(const void* x, const void* dy, int dtype, int 
     set_error("conv3x3_wgrad: dtype %d", dtype);
     return SPCL_EINVAL;
   }
-  const int slab = 9 * 16 * p.MI * 16 * p.NJ;
   if (tail != nullptr) {
     tail->partial = partial; tail->dw = dw_oihw; tail->kind = 0; tail->nsplit = p.nsplit; tail->nblk_ci = p.nblk_ci;
     tail->nblk_co = p.nblk_co; tail->CIB = 16 * p.MI; tail->COB = 16 * p.NJ; tail->Cin = Cin; tail->Cout = Cout;
-  } else if (slab >= 16384)
-    SPCL_LAUNCH(wgrad_reduce_kernel<4>, dim3(cdiv(slab, 256), p.nblk_ci * p.nblk_co), dim3(p.nsplit >= 64 ? 1024 : 256), 0,
-                st, (const float*)partial, p.nsplit, p.nblk_ci, p.nblk_co, 16 * p.MI, 16 * p.NJ, Cin, Cout, dw_oihw);
-  else
-    SPCL_LAUNCH(wgrad_reduce_kernel<1>, dim3(cdiv(slab, 64), p.nblk_ci * p.nblk_co), dim3(p.nsplit >= 64 ? 1024 : 256), 0,
-                st, (const float*)partial, p.nsplit, p.nblk_ci, p.nblk_co, 16 * p.MI, 16 * p.NJ, Cin, Cout, dw_oihw);
+  } else {
+    launch_wgrad_reduce(partial, p.nsplit, p.nblk_ci, p.nblk_co, 16 * p.MI, 16 * p.NJ, Cin, Cout, dw_oihw, st);
+  }
   if (a.stamps) {
     std::vector<unsigned long long> h(nwg * 8);
     (void)hipStreamSynchronize(st);

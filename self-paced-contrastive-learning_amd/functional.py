@@ -893,6 +893,32 @@ def _dgrad_bnstats_image(dy, wp_t, y2, st2, image, dt_code, dtype, N, H, W, cs, 
     return g, rows
 
 
+_CONV16_FUSED = os.environ.get("SPCL_CONV16_FUSED", "1") != "0"  # A/B switch: 0 = separate wgrad and dgrad launches
+
+
+def _conv16_bwd_fused(dy, wp_t, y2, st2, image, dt_code, N, H, W, cin, cout, cs, sink):
+    """the image block's second conv, whole backward in one launch (csrc/conv16_bwd.hip): -> (dW or None when it went into
+    a bucket slice, rows11 of the first conv's BatchNorm backward / weight gradient)"""
+    dev = dy.device
+    nt = _n.call("spcl_conv_stat_rows", dt_code, N, H, W, cs, cs)
+    rows = torch.empty(nt * 11 * cs, dtype=torch.float32, device=dev)
+    rows.ntiles = nt
+    ws = torch.empty(_n.call("spcl_conv16_bwd_fused_splits", N, H, W) * 9 * 256, dtype=torch.float32, device=dev)
+    dw = _grad_buffer(sink, (cout, cin, 3, 3), dev)
+
+    def launch():
+        _n.call("spcl_conv16_bwd_fused", _n.ptr(dy), dt_code, N, H, W, _n.ptr(wp_t), _n.ptr(y2), _n.ptr(st2[2]),
+                _n.ptr(st2[3]), _n.ptr(st2[0]), _n.ptr(image), _n.ptr(rows), _n.ptr(ws), _n.ptr(dw), cin, cout, _n.stream())
+
+    queue = sink_queue(sink)
+    if queue is not None and _TAILS:
+        if queue.capture_tail(sink, (ws, dy, y2, image, rows), launch):
+            return None, rows
+        return dw, rows
+    launch()
+    return dw, rows
+
+
 def _bnrelu_bwd_rows_image3(rows, acorr, w, N, H, W, C, cs, st, training, sinks):
     """BN + ReLU backward of the image block's first conv and its weight gradient from the rows and the autocorrelation
     -> (dW, dgamma, dbeta); dW goes straight into its sink (no tail: the final kernel writes it)"""
@@ -1007,15 +1033,23 @@ class _ConvBlockFn(torch.autograd.Function):
             dyb, dgb, dbb = _bnrelu_bwd(yb, da_s, dp_s, dtc, dtype, N, H, W, cout, cout_s, stb, cfg.training, sk[4:6])
         if lk is not None:
             lk.rows, lk.dx_ptr = None, 0
-        dwb = _wgrad(ya, dyb, dtc, N, H, W, cout, cout_s, cout_s, cout, cout_s, 1, sta[2], sta[3], sk[3]) \
-            if ctx.needs_input_grad[4] else None
         wpa_t, wpb_t = ctx.packed_t
         if wpb_t is None:
             wpb_t = _pack(wb, 1, dtc, dtype)
+        image3 = ctx.acorr is not None
+        # image block: this conv's weight gradient AND the sums the first conv's backward needs in one pass over dyb / ya
+        one_pass = (image3 and _CONV16_FUSED and ctx.needs_input_grad[4] and cout == cout_s
+                    and _n.call("spcl_conv16_bwd_fused_supported", dtc, N, H, W, cout_s, cout_s))
+        if one_pass:
+            dwb, rows16 = _conv16_bwd_fused(dyb, wpb_t, ya, sta, xs, dtc, N, H, W, cout, cout, cout_s, sk[3])
+        else:
+            dwb = _wgrad(ya, dyb, dtc, N, H, W, cout, cout_s, cout_s, cout, cout_s, 1, sta[2], sta[3], sk[3]) \
+                if ctx.needs_input_grad[4] else None
         # the dgrad's output is d loss / d relu(bn_a(ya)): where a specialised kernel exists its epilogue also leaves the
         # per-tile partial sums of bn_a's backward (no separate reduction pass over ya and the gradient)
-        image3 = ctx.acorr is not None
-        if image3:
+        if one_pass:
+            fused = (None, rows16)
+        elif image3:
             fused = _dgrad_bnstats_image(dyb, wpb_t, ya, sta, xs, dtc, dtype, N, H, W, cout_s)
         else:
             fused = _dgrad_bnstats(dyb, wpb_t, ya, sta, dtc, dtype, N, H, W, cout_s, cout_s) \

@@ -354,9 +354,43 @@ def test_image3_first_layer_gradient_without_a_pass_over_its_output():
             F_._IMAGE3 = default
     dw0, dg0, db0, dwb0 = res[False]
     dw1, dg1, db1, dwb1 = res[True]
-    assert torch.equal(dg0, dg1) and torch.equal(db0, db1) and torch.equal(dwb0, dwb1)
+    assert torch.equal(dg0, dg1) and torch.equal(db0, db1)
+    assert _relerr(dwb1.numpy(), dwb0.numpy()) < 2e-5  # (the one-pass kernel sums the same products in another order)
     assert dw0.abs().max() > 0
     assert _relerr(dw1.numpy(), dw0.numpy()) < 3e-3, _relerr(dw1.numpy(), dw0.numpy())
+
+
+@pytest.mark.parametrize("N,H,W", [(2, 140, 154), (9, 224, 224), (1, 256, 256)])
+def test_conv16_backward_in_one_pass(N, H, W):
+    """csrc/conv16_bwd.hip: the image block's second conv (unet.py:75, 16 -> 16 channels) -- weight gradient and the rows the
+    first conv's backward is finished from, in one launch.  Rows: the dgrad kernel's up to the order of the f32 sums;
+    dW: against fp64 math on the same bf16 operands, and next to the stand-alone weight-gradient kernel.  256 x 256 has
+    shifted last tiles (pixels two tiles cover count once); N = 9 at 224 x 224 makes workgroups walk two images (the last one)."""
+    import spcl_amd  # noqa
+    from spcl_amd import functional as F_, native as _n
+    dtc = _n.dtype_code(torch.bfloat16)
+    gq = torch.Generator().manual_seed(11 + N)
+    dy = torch.randn(N, H, W, 16, generator=gq).cuda().bfloat16()
+    y2 = torch.randn(N, H, W, 16, generator=gq).cuda().bfloat16()
+    w = torch.randn(16, 16, 3, 3, generator=gq).cuda() * 0.1
+    st = [torch.randn(16, generator=gq).cuda() * 0.1, torch.rand(16, generator=gq).cuda() + 0.5,
+          torch.rand(16, generator=gq).cuda() + 0.5, torch.randn(16, generator=gq).cuda() * 0.3]  # mean, -, scale, shift
+    img = torch.rand(N, H, W, generator=gq).cuda()
+    assert _n.call("spcl_conv16_bwd_fused_supported", dtc, N, H, W, 16, 16)
+    wpt = F_._pack(w, 1, dtc, torch.bfloat16)
+    _, rows_ref = F_._dgrad_bnstats_image(dy, wpt, y2, st, img, dtc, torch.bfloat16, N, H, W, 16)
+    dw_old = F_._wgrad(y2, dy, dtc, N, H, W, 16, 16, 16, 16, 16, 1, st[2], st[3], None)
+    for _ in range(2):
+        dw, rows = F_._conv16_bwd_fused(dy, wpt, y2, st, img, dtc, N, H, W, 16, 16, 16, None)
+        # (the two BatchNorm sums are combined from four waves' shares, the tap sums walk the pixels in another order)
+        assert _relerr(rows.cpu().numpy(), rows_ref.cpu().numpy()) < 2e-6
+        x = torch.relu(torch.addcmul(st[3], y2.float(), st[2])).bfloat16().double().permute(0, 3, 1, 2)
+        want = torch.nn.grad.conv2d_weight(x, (16, 16, 3, 3), dy.double().permute(0, 3, 1, 2), padding=1)
+        assert _relerr(dw.cpu().numpy(), want.cpu().numpy()) < 2e-5, _relerr(dw.cpu().numpy(), want.cpu().numpy())
+        assert _relerr(dw.cpu().numpy(), dw_old.cpu().numpy()) < 2e-5
+        if _ == 0:
+            first = (dw.clone(), rows.clone())
+    assert torch.equal(first[0], dw) and torch.equal(first[1], rows)  # fixed-order sums
 
 
 def test_two_buckets_armed_in_one_step_keep_their_own_deferred_gradients():
