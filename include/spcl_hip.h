@@ -347,12 +347,21 @@ int spcl_conv3x3_dgrad_bnstats_image(const void* dy, int dtype, int N, int H, in
  * weight gradient (what spcl_conv3x3_wgrad(x = y2, in_mode 1, scale2, shift2) computes; partial = the split slabs,
  * spcl_conv16_bwd_fused_splits(N, H, W) x 9 x 256 floats; the final sum goes to dw_oihw [Cout][Cin][3][3] or to a captured
  * tail, as there) AND the rows11 of spcl_conv3x3_dgrad_bnstats_image(g == NULL).  Nothing is written per pixel.
- * Same gate as spcl_conv_dgrad_bnstats_image_supported. */
+ * Same gate as spcl_conv_dgrad_bnstats_image_supported.
+ * Exactly one of rows11 ([tiles][11][CoutS], as above) / wg_rows: ONE row set per workgroup (its tiles summed in
+ * registers), [11][16][spcl_conv16_bwd_fused_splits] -- the layout spcl_bnrelu_backward_wgrows_image3 finishes from without
+ * a folding launch; with wg_rows the same launch folds the autocorrelation's partial rows acorr [nacorr][64] to
+ * acorr16 [16][64]. */
 int spcl_conv16_bwd_fused_supported(int dtype, int N, int H, int W, int CinK, int CoutS);
 int spcl_conv16_bwd_fused_splits(int N, int H, int W);
 int spcl_conv16_bwd_fused(const void* dy, int dtype, int N, int H, int W, const void* w_packed_dgrad, const void* y2,
                           const float* scale2, const float* shift2, const float* mean2, const float* image,
-                          float* rows11, float* partial, float* dw_oihw, int Cin, int Cout, void* stream);
+                          float* rows11, float* partial, float* dw_oihw, int Cin, int Cout, float* wg_rows,
+                          const float* acorr, int nacorr, float* acorr16, void* stream);
+int spcl_bnrelu_backward_wgrows_image3(const float* wg_rows, int nwg, const float* acorr, int nacorr, const float* w_oihw,
+                                       int N, int H, int W, int C, int CS, const float* mean, const float* invstd,
+                                       const float* scale, int training, float* ws, float* dgamma, float* dbeta,
+                                       float* dw, void* stream);
 size_t spcl_bnrelu_image3_workspace_bytes(int CS);
 int spcl_bnrelu_backward_rows_image3(const float* rows11, int nrows, const float* acorr, int nacorr, const float* w_oihw,
                                      int N, int H, int W, int C, int CS, const float* mean, const float* invstd,

@@ -1238,6 +1238,28 @@ extern "C" int spcl_bnrelu_backward_rows_image3(const float* rows11, int nrows, 
   return SPCL_OK;
 }
 
+// ... from ONE row set per workgroup of spcl_conv16_bwd_fused, already in the final kernel's layout
+// ([sub-row 11][channel CS][workgroup]) and with the autocorrelation rows already folded: the final kernel alone
+extern "C" int spcl_bnrelu_backward_wgrows_image3(const float* wg_rows, int nwg, const float* acorr, int nacorr,
+                                                  const float* w_oihw, int N, int H, int W, int C, int CS,
+                                                  const float* mean, const float* invstd, const float* scale,
+                                                  int training, float* ws, float* dgamma, float* dbeta, float* dw,
+                                                  void* stream) {
+  SPCL_CHECK_ARG(wg_rows && acorr && w_oihw && mean && invstd && scale && ws && dgamma && dbeta && dw,
+                 "bnrelu_backward_wgrows_image3: null pointer");
+  SPCL_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && CS >= C && CS % 16 == 0 && CS <= 256 && nwg > 0 && nacorr > 0 &&
+                     nacorr <= 64,
+                 "bnrelu_backward_wgrows_image3: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  float* ab = ws + (size_t)BWD_MAX_WG * 11 * CS;
+  const Image3Args im{acorr, nacorr, w_oihw, dw};
+  prof_cost((double)nwg * 11 * CS * 4.0, 0.0);
+  SPCL_LAUNCH(bnrelu_bwd_fin_kernel, dim3(CS), dim3(256), 0, st, wg_rows, nwg, C, CS, (float)((size_t)N * H * W), training,
+              mean, invstd, scale, dgamma, dbeta, ab, (float*)nullptr, 0, 1, 11, im, 1);
+  SPCL_LAUNCH_CHECK("bnrelu_backward_wgrows_image3");
+  return SPCL_OK;
+}
+
 // BN + ReLU + 2x2 max-pool backward finished from per-tile rows that came with the dgrad producing dpool
 // (spcl_conv3x3_dgrad_poolstats): final reduction of the rows -> coefficients -> the apply pass.  No `dact` here: a block
 // whose activation is also consumed directly (skip connection, hook tap) keeps the two-pass path.

@@ -38,7 +38,14 @@ struct Bwd16Args {
   const float* shift2;
   const float* mean2;
   const float* img;         // [N][H][W] f32, the block's input
-  float* rows11;            // [tile][11][16]
+  float* rows11;            // [tile][11][16], or null with wg_rows
+  // ... or ONE row set per WORKGROUP (its tiles summed in registers), written as the final kernel wants it,
+  // [sub-row 11][channel 16][workgroup] (bn.hip bnrelu_bwd_fin_kernel, transposed): no per-tile rows, no folding launch
+  float* wg_rows;
+  int nwg;                  // workgroups that walk tiles (the grid's extra z-slice folds the autocorrelation rows, below)
+  const float* acorr_in;    // [nacorr][64] partial rows of image_autocorr_kernel -> acorr_out [16][64] (row j: rows j, j + 16, ..)
+  int nacorr;
+  float* acorr_out;
   float* partial;           // [workgroup][9][16 ci][16 co]
   int N, H, W, tilesX, tilesY, ipw, xcd_remap;
   int dbg;  // ablation bits (timing experiments only, wrong results; 0 in production): 1 no dgrad MFMAs, 2 no pixel pass,
@@ -64,7 +71,8 @@ __device__ __forceinline__ bf16x8 b16_tr_frag(unsigned addr) {
 // SHIFTED: the image size is not a multiple of the tile (last tiles shifted back inside: pixels two tiles cover count once)
 // NW: waves per tile (1, 2 or 4): m-tile i of 13 goes to wave i % NW, tap t of 9 to wave t % NW
 constexpr int b16_wpe(int NW) { return NW == 1 ? 2 : 3; }
-template <bool SHIFTED, int NW>
+// WGROWS: row sets per workgroup (wg_rows) instead of per tile (rows11)
+template <bool SHIFTED, int NW, bool WGROWS>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(b16_wpe(NW)))) void conv16_bwd_kernel(Bwd16Args a) {
   constexpr int TH = B16_TH, TW = B16_TW, HW_ = B16_HW, RP = B16_RP, PS = B16_PS;
   constexpr int NPIX = TH * TW, NSTEPS = 5, NTHR = 64 * NW, ITER = 512 / NTHR, RPI = NTHR / 32;  // halo rows per staging step
@@ -74,6 +82,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(b16_wpe
   const unsigned lds_base = (unsigned)(uintptr_t)(unsigned char __attribute__((address_space(3)))*)lds;
   const int t0 = threadIdx.x;
   const int wave = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane(t0 >> 6);
+  if (WGROWS && (int)blockIdx.z * (int)(gridDim.x * gridDim.y) >= a.nwg) {  // the extra z-slice (bn.hip bwd_rows_group_kernel's job)
+    const int j = blockIdx.y * gridDim.x + blockIdx.x;
+    if (j < 16 && t0 < 64) {
+      float sacc = 0.f;
+#pragma unroll 8
+      for (int w = j; w < a.nacorr; w += 16) sacc += a.acorr_in[(size_t)w * 64 + t0];
+      a.acorr_out[(size_t)j * 64 + t0] = sacc;
+    }
+    return;
+  }
 
   int tx = blockIdx.x, ty = blockIdx.y;
   {
@@ -107,6 +125,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(b16_wpe
     ((bf16_t*)(lds + B16_IM))[(k == 0 ? 256 + 15 : (k == 1 ? 512 + 14 : 512 + 15)) + r * 16] = 0;
   }
   // wave w owns the taps w, w + 4, (w + 8): no cross-wave reduction of the weight gradient
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f}, csq = {0.f, 0.f, 0.f, 0.f}, Dacc = {0.f, 0.f, 0.f, 0.f};  // WGROWS: summed over the tiles
   f32x4 wacc[TPW];
 #pragma unroll
   for (int j = 0; j < TPW; ++j) wacc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -325,7 +344,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(b16_wpe
         }
       }
     }
-    {
+    if (WGROWS) {
+      csum += ssum;
+      csq += ssq;
+    } else {
       // the wave's share of the two sums -> LDS; wave 0 adds the four shares in wave order after the barrier
       f32x4 o;
 #pragma unroll
@@ -343,7 +365,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(b16_wpe
     B16_STAMP(3)  // pixel pass
     __syncthreads();
     B16_STAMP(1)
-    if (t < 32) {
+    if (!WGROWS && t < 32) {
       const float* red = (const float*)(lds + B16_RED) + t;
       float tot = red[0];
 #pragma unroll
@@ -402,7 +424,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(b16_wpe
     if (wave == 0 && !(a.dbg & 8)) {
       const int tap = r16 < 9 ? r16 : 0, tky = tap / 3, tkx = tap - 3 * tky;
       const unsigned char* pb = lds + B16_IM + tkx * 512 + ((g >> 1) + tky) * 32 + (g & 1) * 8;
-      f32x4 D = {0.f, 0.f, 0.f, 0.f};
+      f32x4 D = WGROWS ? Dacc : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < TH / 2; ++ks) {
         const bf16x8 af = b16_tr_frag(tr_x + ks * 2 * B16_XT_ROW);
@@ -410,7 +432,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(b16_wpe
         const u32x4 bq = {b0.x, b0.y, b1.x, b1.y};
         D = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, bq), D, 0, 0, 0);
       }
-      if (r16 < 9) *(f32x4*)(a.rows11 + ((size_t)tile * 11 + 2 + r16) * 16 + 4 * g) = D;
+      if (WGROWS) Dacc = D;
+      else if (r16 < 9) *(f32x4*)(a.rows11 + ((size_t)tile * 11 + 2 + r16) * 16 + 4 * g) = D;
     }
     B16_STAMP(6)  // tap sums
     if (NW > 1) __syncthreads();  // every wave restages the image copies: behind wave 0's reads
@@ -423,8 +446,36 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(b16_wpe
 #pragma unroll
     for (int k = 0; k < 7; ++k) o[k] = tph[k];
   }
+  const size_t wg = (size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  if (WGROWS) {
+    // the workgroup's row set [11][16] -> wg_rows [sub-row][channel][workgroup]: the two BatchNorm sums from the waves' shares
+    // (through LDS, wave order), the tap sums from wave 0's accumulator (lane: tap r16, channels 4 g ..)
+    const int r16 = t0 & 15, g = (t0 & 63) >> 4;
+    __syncthreads();
+    {
+      f32x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float s1 = row16_sum(csum[r]), s2 = row16_sum(csq[r]);
+        o[r] = r16 == 0 ? s1 : s2;
+      }
+      if (r16 < 2) *(f32x4*)(lds + B16_RED + ((wave * 2 + r16) * 16 + 4 * g) * 4) = o;
+    }
+    __syncthreads();
+    if (t0 < 32) {
+      const float* red = (const float*)(lds + B16_RED) + t0;
+      float tot = red[0];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) tot += red[32 * w];
+      a.wg_rows[(size_t)t0 * a.nwg + wg] = tot;  // t0 = sub-row * 16 + channel
+    }
+    if (wave == 0 && r16 < 9) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a.wg_rows[((size_t)(2 + r16) * 16 + 4 * g + r) * a.nwg + wg] = Dacc[r];
+    }
+  }
   // ---- the workgroup's partial slab [tap][ci][co]: lane holds co = r16, ci = 4 g + r of the wave's taps
-  float* out = a.partial + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (9 * 256);
+  float* out = a.partial + wg * (9 * 256);
 #pragma unroll
   for (int j = 0; j < TPW; ++j) {
     const int tap = wave + NW * j;
@@ -472,9 +523,11 @@ extern "C" int spcl_conv16_bwd_fused_splits(int N, int H, int W) {
 extern "C" int spcl_conv16_bwd_fused(const void* dy, int dtype, int N, int H, int W, const void* w_packed_dgrad,
                                      const void* y2, const float* scale2, const float* shift2, const float* mean2,
                                      const float* image, float* rows11, float* partial, float* dw_oihw, int Cin, int Cout,
-                                     void* stream) {
-  SPCL_CHECK_ARG(dy && w_packed_dgrad && y2 && scale2 && shift2 && mean2 && image && rows11 && partial && dw_oihw,
+                                     float* wg_rows, const float* acorr, int nacorr, float* acorr16, void* stream) {
+  SPCL_CHECK_ARG(dy && w_packed_dgrad && y2 && scale2 && shift2 && mean2 && image && partial && dw_oihw,
                  "conv16_bwd_fused: null pointer");
+  SPCL_CHECK_ARG((rows11 != nullptr) != (wg_rows != nullptr), "conv16_bwd_fused: exactly one of rows11 / wg_rows");
+  SPCL_CHECK_ARG(wg_rows == nullptr || (acorr && acorr16 && nacorr > 0), "conv16_bwd_fused: wg_rows comes with the autocorrelation rows");
   SPCL_CHECK_ARG(Cin > 0 && Cin <= 16 && Cout > 0 && Cout <= 16, "conv16_bwd_fused: channel counts");
   if (!spcl_conv16_bwd_fused_supported(dtype, N, H, W, 16, 16)) {
     set_error("conv16_bwd_fused: unsupported configuration (bf16, 16 -> 16 channels, 14 x 14 tiles)");
@@ -485,31 +538,37 @@ extern "C" int spcl_conv16_bwd_fused(const void* dy, int dtype, int N, int H, in
   Bwd16Args a;
   a.dy = (const unsigned char*)dy; a.wp = (const u32x4*)w_packed_dgrad; a.y2 = (const unsigned char*)y2;
   a.scale2 = scale2; a.shift2 = shift2; a.mean2 = mean2; a.img = image; a.rows11 = rows11; a.partial = partial;
+  a.wg_rows = wg_rows; a.acorr_in = acorr; a.nacorr = nacorr; a.acorr_out = acorr16;
   a.N = N; a.H = H; a.W = W; a.tilesX = cdiv(W, B16_TW); a.tilesY = cdiv(H, B16_TH);
   a.ipw = conv16_bwd_ipw(N, H, W);
   static const int env_remap = getenv("SPCL_CONV_XCD_REMAP") ? atoi(getenv("SPCL_CONV_XCD_REMAP")) : 1;
   a.xcd_remap = env_remap;
   a.dbg = getenv("SPCL_CONV16_DBG") ? atoi(getenv("SPCL_CONV16_DBG")) : 0;  // (read per call: experiments flip it)
   const int nz = cdiv(N, a.ipw), nsplit = a.tilesX * a.tilesY * nz;
+  a.nwg = nsplit;
   const double px = (double)N * H * W;
   prof_cost(px * 32.0 * 2.0 + px * 4.0 + (double)nsplit * 9 * 256 * 4.0, 2.0 * px * 9.0 * 256 * 2.0 + 2.0 * px * 9.0 * 16);
   a.stamps = nullptr;
   const bool want_stamps = SPCL_CONV16_STAMPS_BUILD && getenv("SPCL_CONV16_STAMPS") != nullptr;  // debug only (synchronises)
-  const size_t nwg = (size_t)a.tilesX * a.tilesY * nz;
+  const size_t nwg = (size_t)nsplit;
   if (want_stamps) {
     (void)hipMalloc(&a.stamps, nwg * 8 * sizeof(unsigned long long));
     (void)hipMemset(a.stamps, 0, nwg * 8 * sizeof(unsigned long long));
   }
   const int nw = conv16_bwd_nw();
-  const bool even = H % B16_TH == 0 && W % B16_TW == 0;
-  const dim3 grid(a.tilesX, a.tilesY, nz);
-#define B16_CASE(NW_)                                                                                       \
-  if (nw == NW_) {                                                                                          \
-    if (even) SPCL_LAUNCH((conv16_bwd_kernel<false, NW_>), grid, dim3(64 * NW_), B16_LDS, st, a);            \
-    else SPCL_LAUNCH((conv16_bwd_kernel<true, NW_>), grid, dim3(64 * NW_), B16_LDS, st, a);                  \
+  const bool even = H % B16_TH == 0 && W % B16_TW == 0, wgr = wg_rows != nullptr;
+  const dim3 grid(a.tilesX, a.tilesY, nz + (wgr ? 1 : 0));
+#define B16_LAUNCH(SH_, NW_, WG_) SPCL_LAUNCH((conv16_bwd_kernel<SH_, NW_, WG_>), grid, dim3(64 * NW_), B16_LDS, st, a)
+#define B16_CASE(NW_)                                       \
+  if (nw == NW_) {                                          \
+    if (even && wgr) B16_LAUNCH(false, NW_, true);          \
+    else if (even) B16_LAUNCH(false, NW_, false);           \
+    else if (wgr) B16_LAUNCH(true, NW_, true);              \
+    else B16_LAUNCH(true, NW_, false);                      \
   }
   B16_CASE(1) B16_CASE(2) B16_CASE(4)
 #undef B16_CASE
+#undef B16_LAUNCH
   if (a.stamps != nullptr) {
     std::vector<unsigned long long> h(nwg * 8);
     (void)hipStreamSynchronize(st);

@@ -894,21 +894,31 @@ def _dgrad_bnstats_image(dy, wp_t, y2, st2, image, dt_code, dtype, N, H, W, cs, 
 
 
 _CONV16_FUSED = os.environ.get("SPCL_CONV16_FUSED", "1") != "0"  # A/B switch: 0 = separate wgrad and dgrad launches
+_CONV16_WGROWS = os.environ.get("SPCL_CONV16_WGROWS", "1") != "0"  # A/B switch: 0 = per-tile rows + the folding launch
 
 
-def _conv16_bwd_fused(dy, wp_t, y2, st2, image, dt_code, N, H, W, cin, cout, cs, sink):
+def _conv16_bwd_fused(dy, wp_t, y2, st2, image, dt_code, N, H, W, cin, cout, cs, sink, acorr=None):
     """the image block's second conv, whole backward in one launch (csrc/conv16_bwd.hip): -> (dW or None when it went into
-    a bucket slice, rows11 of the first conv's BatchNorm backward / weight gradient)"""
+    a bucket slice, rows of the first conv's BatchNorm backward / weight gradient).  With ``acorr`` (the autocorrelation's
+    partial rows) the rows come as ONE set per workgroup in the final kernel's layout (``rows.wg``) and the same launch
+    folds ``acorr`` to 16 rows (``rows.acorr16``): no per-tile rows, no folding launch; else per tile ([tiles][11][cs])."""
     dev = dy.device
-    nt = _n.call("spcl_conv_stat_rows", dt_code, N, H, W, cs, cs)
-    rows = torch.empty(nt * 11 * cs, dtype=torch.float32, device=dev)
-    rows.ntiles = nt
-    ws = torch.empty(_n.call("spcl_conv16_bwd_fused_splits", N, H, W) * 9 * 256, dtype=torch.float32, device=dev)
+    nsplit = _n.call("spcl_conv16_bwd_fused_splits", N, H, W)
+    if acorr is not None:
+        rows = torch.empty(11 * cs * nsplit, dtype=torch.float32, device=dev)
+        rows.wg, rows.acorr16 = nsplit, torch.empty(16, 64, dtype=torch.float32, device=dev)
+    else:
+        nt = _n.call("spcl_conv_stat_rows", dt_code, N, H, W, cs, cs)
+        rows = torch.empty(nt * 11 * cs, dtype=torch.float32, device=dev)
+        rows.ntiles, rows.wg = nt, 0
+    ws = torch.empty(nsplit * 9 * 256, dtype=torch.float32, device=dev)
     dw = _grad_buffer(sink, (cout, cin, 3, 3), dev)
 
     def launch():
         _n.call("spcl_conv16_bwd_fused", _n.ptr(dy), dt_code, N, H, W, _n.ptr(wp_t), _n.ptr(y2), _n.ptr(st2[2]),
-                _n.ptr(st2[3]), _n.ptr(st2[0]), _n.ptr(image), _n.ptr(rows), _n.ptr(ws), _n.ptr(dw), cin, cout, _n.stream())
+                _n.ptr(st2[3]), _n.ptr(st2[0]), _n.ptr(image), _n.ptr(rows) if not rows.wg else None, _n.ptr(ws), _n.ptr(dw),
+                cin, cout, _n.ptr(rows) if rows.wg else None, _n.ptr(acorr), 0 if acorr is None else acorr.shape[0],
+                _n.ptr(rows.acorr16) if rows.wg else None, _n.stream())
 
     queue = sink_queue(sink)
     if queue is not None and _TAILS:
@@ -927,6 +937,11 @@ def _bnrelu_bwd_rows_image3(rows, acorr, w, N, H, W, C, cs, st, training, sinks)
     dw = _grad_buffer(sinks[0], (C, 1, 3, 3), dev)
     dgamma, dbeta = _grad_buffer(sinks[1], (C,), dev), _grad_buffer(sinks[2], (C,), dev)
     wc = w.detach().contiguous().float()
+    if getattr(rows, "wg", 0):  # one row set per workgroup of the one-pass kernel, autocorrelation already folded
+        _n.call("spcl_bnrelu_backward_wgrows_image3", _n.ptr(rows), rows.wg, _n.ptr(rows.acorr16), 16, _n.ptr(wc), N, H, W, C,
+                cs, _n.ptr(st[0]), _n.ptr(st[1]), _n.ptr(st[2]), int(training), _n.ptr(ws), _n.ptr(dgamma), _n.ptr(dbeta),
+                _n.ptr(dw), _n.stream())
+        return dw, dgamma, dbeta
     _n.call("spcl_bnrelu_backward_rows_image3", _n.ptr(rows), rows.ntiles, _n.ptr(acorr), acorr.shape[0], _n.ptr(wc), N, H,
             W, C, cs, _n.ptr(st[0]), _n.ptr(st[1]), _n.ptr(st[2]), int(training), _n.ptr(ws), _n.ptr(dgamma), _n.ptr(dbeta),
             _n.ptr(dw), _n.stream())
@@ -1041,7 +1056,8 @@ class _ConvBlockFn(torch.autograd.Function):
         one_pass = (image3 and _CONV16_FUSED and ctx.needs_input_grad[4] and cout == cout_s
                     and _n.call("spcl_conv16_bwd_fused_supported", dtc, N, H, W, cout_s, cout_s))
         if one_pass:
-            dwb, rows16 = _conv16_bwd_fused(dyb, wpb_t, ya, sta, xs, dtc, N, H, W, cout, cout, cout_s, sk[3])
+            dwb, rows16 = _conv16_bwd_fused(dyb, wpb_t, ya, sta, xs, dtc, N, H, W, cout, cout, cout_s, sk[3],
+                                            acorr=ctx.acorr if _CONV16_WGROWS else None)
         else:
             dwb = _wgrad(ya, dyb, dtc, N, H, W, cout, cout_s, cout_s, cout, cout_s, 1, sta[2], sta[3], sk[3]) \
                 if ctx.needs_input_grad[4] else None

@@ -97,7 +97,9 @@ _SIGNATURES = {
     "spcl_conv16_bwd_fused_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "spcl_conv16_bwd_fused_splits": (c_int, [c_int, c_int, c_int]),
     "spcl_conv16_bwd_fused": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int,
-                                      _P]),
+                                      _P, _P, c_int, _P, _P]),
+    "spcl_bnrelu_backward_wgrows_image3": (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P,
+                                                   c_int, _P, _P, _P, _P, _P]),
     "spcl_conv3x3_dgrad_bnstats_image": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P,
                                                  _P, _P]),
     "spcl_bnrelu_image3_workspace_bytes": (c_size_t, [c_int]),
