@@ -58,7 +58,9 @@ constexpr int B16_DY = 0, B16_DY_BYTES = (B16_TH + 2) * B16_RP * B16_PS;  // 11 
 constexpr int B16_IM = B16_DY_BYTES, B16_IM_BYTES = 1536;
 constexpr int B16_XT = B16_IM + B16_IM_BYTES, B16_XT_ROW = 16 * 32, B16_XT_BYTES = B16_TH * B16_XT_ROW;
 constexpr int B16_RED = B16_XT + B16_XT_BYTES;  // [wave <= 4][2][16] f32: the waves' shares of the BatchNorm sums
-constexpr int B16_LDS = B16_RED + 512;           // 20 480
+constexpr int B16_ACC = B16_RED + 512;           // [9 taps][16] f32: the workgroup's tap sums over its tiles (WGROWS)
+constexpr int B16_TRASH = B16_ACC + 576;         // 32 bytes nobody reads (see the throw-away store before the tile loop)
+constexpr int B16_LDS = B16_TRASH + 32;          // 21 088
 
 __device__ __forceinline__ bf16x8 b16_tr_frag(unsigned addr) {
   // 8 pixels (k) of the lane's channel: two hardware-transposed reads of 4 pixels x 16 channels, 8 pixels apart
@@ -124,8 +126,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(b16_wpe
     const int r = t0 & 15, k = t0 >> 4;
     ((bf16_t*)(lds + B16_IM))[(k == 0 ? 256 + 15 : (k == 1 ? 512 + 14 : 512 + 15)) + r * 16] = 0;
   }
+  if (WGROWS)  // the per-wave BatchNorm sums and wave 0's tap sums of the workgroup's tiles live in LDS (carried in registers
+               // they pushed the kernel over its budget: 204 bytes of scratch per lane)
+    for (int i = t0; i < (512 + 576) / 4; i += NTHR) ((float*)(lds + B16_RED))[i] = 0.f;
   // wave w owns the taps w, w + 4, (w + 8): no cross-wave reduction of the weight gradient
-  f32x4 csum = {0.f, 0.f, 0.f, 0.f}, csq = {0.f, 0.f, 0.f, 0.f}, Dacc = {0.f, 0.f, 0.f, 0.f};  // WGROWS: summed over the tiles
   f32x4 wacc[TPW];
 #pragma unroll
   for (int j = 0; j < TPW; ++j) wacc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -218,8 +222,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(b16_wpe
   {
     const u32x4 wx = wall[0] ^ wall[1] ^ wall[2] ^ wall[3] ^ wall[4];
     const f32x4 cx = sc2 + sh2 + mu2;
-    *(u32x4*)(lds + B16_RED) = wx;
-    *(f32x4*)(lds + B16_RED + 16) = cx;
+    *(u32x4*)(lds + B16_TRASH) = wx;
+    *(f32x4*)(lds + B16_TRASH + 16) = cx;
   }
 #pragma unroll 1
   for (int it = 0; it < a.ipw; ++it) {
@@ -344,18 +348,19 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(b16_wpe
         }
       }
     }
-    if (WGROWS) {
-      csum += ssum;
-      csq += ssq;
-    } else {
-      // the wave's share of the two sums -> LDS; wave 0 adds the four shares in wave order after the barrier
+    {
+      // the wave's share of the two sums -> LDS (per tile: wave 0 adds the shares in wave order after the barrier; WGROWS:
+      // added to the wave's own running sums, combined once at the end)
       f32x4 o;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float s1 = row16_sum(ssum[r]), s2 = row16_sum(ssq[r]);
         o[r] = r16 == 0 ? s1 : s2;
       }
-      if (r16 < 2) *(f32x4*)(lds + B16_RED + ((wave * 2 + r16) * 16 + 4 * g) * 4) = o;
+      if (r16 < 2) {
+        f32x4* rp = (f32x4*)(lds + B16_RED + ((wave * 2 + r16) * 16 + 4 * g) * 4);
+        *rp = WGROWS ? *rp + o : o;
+      }
     }
     if (more) {  // (likewise: the y2 registers were consumed by the pass above; the image halo rides along)
       if (!EARLY) issue_halo(n + 1);
@@ -424,7 +429,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(b16_wpe
     if (wave == 0 && !(a.dbg & 8)) {
       const int tap = r16 < 9 ? r16 : 0, tky = tap / 3, tkx = tap - 3 * tky;
       const unsigned char* pb = lds + B16_IM + tkx * 512 + ((g >> 1) + tky) * 32 + (g & 1) * 8;
-      f32x4 D = WGROWS ? Dacc : (f32x4){0.f, 0.f, 0.f, 0.f};
+      f32x4* dp = (f32x4*)(lds + B16_ACC + (r16 * 16 + 4 * g) * 4);
+      f32x4 D = (WGROWS && r16 < 9) ? *dp : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < TH / 2; ++ks) {
         const bf16x8 af = b16_tr_frag(tr_x + ks * 2 * B16_XT_ROW);
@@ -432,8 +438,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(b16_wpe
         const u32x4 bq = {b0.x, b0.y, b1.x, b1.y};
         D = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, bq), D, 0, 0, 0);
       }
-      if (WGROWS) Dacc = D;
-      else if (r16 < 9) *(f32x4*)(a.rows11 + ((size_t)tile * 11 + 2 + r16) * 16 + 4 * g) = D;
+      if (WGROWS) {
+        if (r16 < 9) *dp = D;
+      } else if (r16 < 9) *(f32x4*)(a.rows11 + ((size_t)tile * 11 + 2 + r16) * 16 + 4 * g) = D;
     }
     B16_STAMP(6)  // tap sums
     if (NW > 1) __syncthreads();  // every wave restages the image copies: behind wave 0's reads
@@ -448,30 +455,20 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(b16_wpe
   }
   const size_t wg = (size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
   if (WGROWS) {
-    // the workgroup's row set [11][16] -> wg_rows [sub-row][channel][workgroup]: the two BatchNorm sums from the waves' shares
-    // (through LDS, wave order), the tap sums from wave 0's accumulator (lane: tap r16, channels 4 g ..)
-    const int r16 = t0 & 15, g = (t0 & 63) >> 4;
+    // the workgroup's row set [11][16] -> wg_rows [sub-row][channel][workgroup]: the two BatchNorm sums from the waves' running
+    // shares (wave order), the tap sums from wave 0's
     __syncthreads();
-    {
-      f32x4 o;
+    for (int i = t0; i < 11 * 16; i += NTHR) {
+      float tot;
+      if (i < 32) {
+        const float* red = (const float*)(lds + B16_RED) + i;
+        tot = red[0];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float s1 = row16_sum(csum[r]), s2 = row16_sum(csq[r]);
-        o[r] = r16 == 0 ? s1 : s2;
+        for (int w = 1; w < NW; ++w) tot += red[32 * w];
+      } else {
+        tot = ((const float*)(lds + B16_ACC))[i - 32];
       }
-      if (r16 < 2) *(f32x4*)(lds + B16_RED + ((wave * 2 + r16) * 16 + 4 * g) * 4) = o;
-    }
-    __syncthreads();
-    if (t0 < 32) {
-      const float* red = (const float*)(lds + B16_RED) + t0;
-      float tot = red[0];
-#pragma unroll
-      for (int w = 1; w < NW; ++w) tot += red[32 * w];
-      a.wg_rows[(size_t)t0 * a.nwg + wg] = tot;  // t0 = sub-row * 16 + channel
-    }
-    if (wave == 0 && r16 < 9) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) a.wg_rows[((size_t)(2 + r16) * 16 + 4 * g + r) * a.nwg + wg] = Dacc[r];
+      a.wg_rows[(size_t)i * a.nwg + wg] = tot;  // i = sub-row * 16 + channel
     }
   }
   // ---- the workgroup's partial slab [tap][ci][co]: lane holds co = r16, ci = 4 g + r of the wave's taps
