@@ -418,8 +418,7 @@ __global__ __launch_bounds__(768) void wgrad_gemm_kernel(WbArgs a) {
 // with coalesced 16-byte loads (1 KiB per wave and split).  The 16 ci x 16 co x 9 taps go through LDS into OIHW order,
 // where the 16 ci x 9 taps of one co are 144 consecutive floats: the gradient leaves in 576-byte runs.
 // Tail units (blockIdx.x >= tl.first): kind 0 = 64 consecutive outputs of one (ci, co) block of a narrow layer's split
-// partials -- the 9 waves take the splits p = w, w + 9, ... (8 loads in flight each) and are combined through LDS in wave
-// order; kind 1 = one tap of the first layer's per-workgroup rows.  Fixed order -> deterministic.
+// partials -- 9 waves x 4 quarter-waves of 16-byte loads, combined by two shuffles and through LDS in wave order; kind 1 = one tap of the first layer's per-workgroup rows.  Fixed order -> deterministic.
 __device__ __forceinline__ void wb_tail_unit(const WbTails& tl, int unit, int accumulate, float* red) {
   int idx = 0;
 #pragma unroll 1
@@ -429,19 +428,30 @@ __device__ __forceinline__ void wb_tail_unit(const WbTails& tl, int unit, int ac
   const int u = unit - t.u0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (t.kind == 0) {
-    const int slab = 9 * t.CIB * t.COB;
-    const int chunks = (slab + 63) >> 6;
-    const int blk = u / chunks, inner = (u - blk * chunks) * 64 + lane;
-    float s = 0.f;
-    if (inner < slab) {
+    // unit = 64 consecutive outputs of one block: a quarter-wave loads them as 16 x 16 bytes (two whole lines), the four
+    // quarters of the nine waves take the splits p = 4 w + q, + 36, ... (8 loads in flight each).  (One output per lane and
+    // one split per wave: a thread walked nsplit / 9 splits, 21 round trips for the 1 536 slabs of conv16_bwd.hip -- the
+    // launch's critical path; 16 outputs per quarter-wave instead: half-used lines, slower still.)
+    const int slab = 9 * t.CIB * t.COB;  // a multiple of 64 (CIB, COB multiples of 16)
+    const int chunks = slab >> 6;
+    const int blk = u / chunks, o16 = lane & 15, q = lane >> 4;
+    const int inner0 = (u - blk * chunks) * 64;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    {
       const size_t stride = (size_t)t.nblk_ci * t.nblk_co * slab;
-      const float* src = t.partial + (size_t)blk * slab + inner;
+      const float* src = t.partial + (size_t)blk * slab + inner0 + 4 * o16;
 #pragma unroll 8
-      for (int p = wave; p < t.nsplit; p += 9) s += src[(size_t)p * stride];
+      for (int p = 4 * wave + q; p < t.nsplit; p += 36) s += *(const f32x4*)(src + (size_t)p * stride);
     }
-    red[wave * 64 + lane] = s;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {  // quarters (0 + 2), (1 + 3), then their sum: fixed order
+      s[e] += __shfl_down(s[e], 32, 64);
+      s[e] += __shfl_down(s[e], 16, 64);
+    }
+    if (lane < 16) *(f32x4*)(red + wave * 64 + 4 * lane) = s;
     __syncthreads();
-    if (wave == 0 && inner < slab) {
+    if (wave == 0) {
+      const int inner = inner0 + lane;
       float v = red[lane];
 #pragma unroll
       for (int w = 1; w < 9; ++w) v += red[w * 64 + lane];
@@ -473,7 +483,7 @@ __device__ __forceinline__ void wb_tail_unit(const WbTails& tl, int unit, int ac
 }
 
 __global__ __launch_bounds__(576) void wgrad_gemm_reduce_kernel(WbArgs a, WbTails tl) {
-  __shared__ float tile[16 * 16 * 9 + 16];
+  __shared__ __attribute__((aligned(16))) float tile[16 * 16 * 9 + 16];
   if ((int)blockIdx.x >= tl.first) {
     wb_tail_unit(tl, blockIdx.x - tl.first, a.accumulate, tile);
     return;
@@ -630,7 +640,8 @@ static bool wb_tail_ok(const spcl_wgrad_tail& t) {
   if (!t.partial || !t.dw || t.nsplit < 1) return false;
   if (t.kind == 0)
     return t.nblk_ci > 0 && t.nblk_co > 0 && t.CIB > 0 && t.COB > 0 && t.Cin > 0 && t.Cout > 0 &&
-           t.Cin <= t.nblk_ci * t.CIB && t.Cout <= t.nblk_co * t.COB;
+           t.Cin <= t.nblk_ci * t.CIB && t.Cout <= t.nblk_co * t.COB && (9 * t.CIB * t.COB) % 64 == 0 &&
+           (uintptr_t)t.partial % 16 == 0;
   return t.kind == 1 && t.COB >= 16 && t.COB <= 256 && t.Cout > 0 && t.Cout <= t.COB;
 }
 
@@ -660,7 +671,7 @@ extern "C" int spcl_conv3x3_wgrad_batched_tails(const spcl_wgrad_item* items, in
     t.nblk_ci = tails[i].nblk_ci; t.nblk_co = tails[i].nblk_co; t.CIB = tails[i].CIB; t.COB = tails[i].COB;
     t.Cin = tails[i].Cin; t.Cout = tails[i].Cout;
     t.u0 = tail_units;
-    tail_units += t.kind == 0 ? t.nblk_ci * t.nblk_co * cdiv(9 * t.CIB * t.COB, 64) : 9;
+    tail_units += t.kind == 0 ? t.nblk_ci * t.nblk_co * (9 * t.CIB * t.COB / 64) : 9;
   }
   tl.n = ntails;
   hipStream_t st = (hipStream_t)stream;
