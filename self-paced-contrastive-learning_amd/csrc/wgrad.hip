@@ -431,9 +431,15 @@ static void launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t st)
 
 template <typename T, int TH>
 static void launch_wgrad_th(const WgradArgs& a, const WgradPlan& p, hipStream_t st) {
+  // 8 waves on the 32 x 32 block (18 (tap, ci-tile) units: 3 or 2 per wave instead of 5 or 4, the staging spread over twice
+  // the threads): Conv2.b + Conv3.a -8 us per step, same box.  Bit 1 of SPCL_WGRAD_W8: the same for the 16 x 32 block.
+  static const int env_w8 = getenv("SPCL_WGRAD_W8") ? atoi(getenv("SPCL_WGRAD_W8")) : 1;
   if (p.MI == 1 && p.NJ == 1) launch_wgrad<T, 1, 1, TH, 4>(a, p, st);
-  else if (p.MI == 1 && p.NJ == 2) launch_wgrad<T, 1, 2, TH, 4>(a, p, st);
-  else if (p.MI == 2 && p.NJ == 1) launch_wgrad<T, 2, 1, TH, 4>(a, p, st);
+  else if (p.MI == 1 && p.NJ == 2) {
+    if (env_w8 & 2) launch_wgrad<T, 1, 2, TH, 8>(a, p, st);
+    else launch_wgrad<T, 1, 2, TH, 4>(a, p, st);
+  } else if (p.MI == 2 && p.NJ == 1) launch_wgrad<T, 2, 1, TH, 4>(a, p, st);
+  else if (env_w8 & 1) launch_wgrad<T, 2, 2, TH, 8>(a, p, st);
   else launch_wgrad<T, 2, 2, TH, 4>(a, p, st);
 }
 
