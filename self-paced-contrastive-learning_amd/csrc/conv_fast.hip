@@ -720,6 +720,9 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
   if (env_fill && KC == 64 && NT == 2 && ntn >= 8 && ntn % 4 == 0 &&
       (long)c.N * cdiv(c.W, 14) * cdiv(c.H, th) * cdiv(ntn, 8) < 256)
     NT = 1;
+  // experiment: the two n-tiles of a 16 / 32-channel-slab layer as two one-n-tile waves sharing the halo image
+  static const int env_narrow = getenv("SPCL_CONV_FAST_NARROW_NT1") ? atoi(getenv("SPCL_CONV_FAST_NARROW_NT1")) : 0;
+  if (env_narrow && KC < 64 && ntn == 2 && th == 7) NT = 1;
   int nw = ntn / NT;
   if (nw > 4) nw = 4;
   if (ntn % (NT * nw) != 0) return false;
@@ -748,6 +751,8 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
   SPCL_FAST_CASE(16, 14, 2, 1)  // Up_conv2.a dgrad (16 -> 32 @ 224^2)
   SPCL_FAST_CASE(32, 14, 1, 1)  // Up_conv2.a forward (cat(16, 16) -> 16 @ 224^2)
   SPCL_FAST_CASE(16, 7, 2, 1)   // Conv2.a forward (16 -> 32 @ 112^2)
+  SPCL_FAST_CASE(16, 7, 1, 2)   //   "   as two one-n-tile waves (SPCL_CONV_FAST_NARROW_NT1)
+  SPCL_FAST_CASE(32, 7, 1, 2)   // Conv2.b   "
   SPCL_FAST_CASE(32, 7, 1, 1)   // Conv2.a dgrad (32 -> 16)
   SPCL_FAST_CASE(32, 7, 2, 1)   // Conv2.b forward / dgrad
   SPCL_FAST_CASE(32, 7, 2, 2)   // Conv3.a forward (32 -> 64 @ 56^2)
