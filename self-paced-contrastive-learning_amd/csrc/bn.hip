@@ -63,14 +63,25 @@ struct BnFinalArgs {
   float* shift;
 };
 
+__device__ __forceinline__ void bn_final_channel(int c, int C, double n, double s1, double s2, const BnFinalArgs& f);
+__device__ __forceinline__ void store_agent(double* p, double v) {
+  __hip_atomic_store((unsigned long long*)p, __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double load_agent(const double* p) {
+  return __builtin_bit_cast(double, __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
 // SRC = float: tile rows (count, mean, M2);  double: partial rows (n, sum x, sum x^2).
 // FINAL: write the BatchNorm coefficients, else one partial row per blockIdx.y.
 // CW channels per workgroup (16: 64-byte row segments; 4 workgroups of 4 channels were tried for the 64-channel /
 // 2048-tile layers and were no faster: the single launch is a latency chain, which is why 1024 tiles already go two-level)
 template <typename SRC, bool FINAL, int CW>
 __global__ __launch_bounds__(1024) void bn_reduce_kernel(const SRC* __restrict__ rows, int nrows, int rows_per_group,
-                                                         int C, int CS, double* __restrict__ partial, BnFinalArgs f) {
+                                                         int C, int CS, double* __restrict__ partial, BnFinalArgs f,
+                                                         unsigned* tickets = nullptr) {
   __shared__ double red[3][1024 / CW][CW];
+  __shared__ unsigned s_ticket;
   const int TL = blockDim.x / CW;
   const int c16 = threadIdx.x % CW, tl = threadIdx.x / CW;
   const int c = blockIdx.x * CW + c16;
@@ -100,12 +111,50 @@ __global__ __launch_bounds__(1024) void bn_reduce_kernel(const SRC* __restrict__
     }
     __syncthreads();
   }
+  if (!FINAL && tickets != nullptr) {
+    // Both levels in ONE launch: the group's row leaves with agent-scope stores (written through: no L2 write-back fence),
+    // the workgroup takes a ticket once they are acknowledged, and the LAST group of this channel block folds all the rows
+    // (agent-scope loads: another XCD's L2 never held them) and finishes.  Fixed order -> deterministic; the ticket resets
+    // itself for the next launch.
+    if (tl == 0) {
+      double* q = partial + (size_t)blockIdx.y * 3 * CS + c;
+      store_agent(q, n); store_agent(q + CS, s1); store_agent(q + 2 * CS, s2);
+      __builtin_amdgcn_s_waitcnt(0);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+      s_ticket = __hip_atomic_fetch_add(tickets + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_ticket != gridDim.y - 1) return;
+    if (threadIdx.x == 0) __hip_atomic_store(tickets + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    n = 0.0; s1 = 0.0; s2 = 0.0;
+    for (int r = tl; r < (int)gridDim.y; r += TL) {
+      const double* p = partial + (size_t)r * 3 * CS + c;
+      n += load_agent(p); s1 += load_agent(p + CS); s2 += load_agent(p + 2 * CS);
+    }
+    __syncthreads();
+    red[0][tl][c16] = n; red[1][tl][c16] = s1; red[2][tl][c16] = s2;
+    __syncthreads();
+    for (int o = TL >> 1; o > 0; o >>= 1) {
+      if (tl < o) {
+        n += red[0][tl + o][c16]; s1 += red[1][tl + o][c16]; s2 += red[2][tl + o][c16];
+        red[0][tl][c16] = n; red[1][tl][c16] = s1; red[2][tl][c16] = s2;
+      }
+      __syncthreads();
+    }
+    if (tl == 0) bn_final_channel(c, C, n, s1, s2, f);
+    return;
+  }
   if (tl != 0) return;
   if (!FINAL) {
     double* q = partial + (size_t)blockIdx.y * 3 * CS + c;
     q[0] = n; q[CS] = s1; q[2 * CS] = s2;
     return;
   }
+  bn_final_channel(c, C, n, s1, s2, f);
+}
+
+__device__ __forceinline__ void bn_final_channel(int c, int C, double n, double s1, double s2, const BnFinalArgs& f) {
   if (c >= C) {  // channel padding
     f.mean[c] = 0.f; f.invstd[c] = 0.f; f.scale[c] = 0.f; f.shift[c] = 0.f;
     return;
@@ -1016,6 +1065,30 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
 
 using namespace spcl;
 
+// Self-resetting tickets of the one-launch two-level reduction (one per 16-channel block), one zeroed buffer per device,
+// created at the first call OUTSIDE a stream capture (an allocation is not capturable; the eager warm-up steps come first).
+// SPCL_BN_ONE_LAUNCH=0 keeps the two launches.
+constexpr int BN_TICKETS = 64;
+static unsigned* bn_tickets(hipStream_t st) {
+  static const bool on = !(getenv("SPCL_BN_ONE_LAUNCH") && atoi(getenv("SPCL_BN_ONE_LAUNCH")) == 0);
+  if (!on) return nullptr;
+  static unsigned* buf[16] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (buf[dev] == nullptr) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+    unsigned* p = nullptr;
+    if (hipMalloc(&p, BN_TICKETS * sizeof(unsigned)) != hipSuccess) return nullptr;
+    if (hipMemsetAsync(p, 0, BN_TICKETS * sizeof(unsigned), st) != hipSuccess) {  // (in stream order ahead of its first user)
+      (void)hipFree(p);
+      return nullptr;
+    }
+    buf[dev] = p;
+  }
+  return buf[dev];
+}
+
 extern "C" size_t spcl_bn_stats_elems(int ntiles, int CS) {
   return ((size_t)ntiles + 2 * (size_t)bn_groups(ntiles)) * 3 * CS;  // tile rows + double-precision partial rows
 }
@@ -1031,13 +1104,19 @@ extern "C" int spcl_bn_finalize(float* stats, int ntiles, int C, int CS, const f
   const int groups = bn_groups(ntiles);
   if (groups == 0) {
     SPCL_LAUNCH((bn_reduce_kernel<float, true, 16>), dim3(CS / 16, 1), dim3(ntiles > 256 ? 1024 : 256), 0, st, stats,
-                       ntiles, ntiles, C, CS, (double*)nullptr, f);
+                       ntiles, ntiles, C, CS, (double*)nullptr, f, (unsigned*)nullptr);
   } else {
     double* partial = (double*)(stats + (size_t)ntiles * 3 * CS);  // spcl_bn_stats_elems reserves it
-    SPCL_LAUNCH((bn_reduce_kernel<float, false, 16>), dim3(CS / 16, groups), dim3(256), 0, st, stats, ntiles,
-                       BN_GROUP_TILES, C, CS, partial, f);
-    SPCL_LAUNCH((bn_reduce_kernel<double, true, 16>), dim3(CS / 16, 1), dim3(groups > 64 ? 1024 : 256), 0, st,
-                       (const double*)partial, groups, groups, C, CS, (double*)nullptr, f);
+    unsigned* tickets = bn_tickets(st);
+    if (tickets != nullptr && CS / 16 <= BN_TICKETS) {
+      SPCL_LAUNCH((bn_reduce_kernel<float, false, 16>), dim3(CS / 16, groups), dim3(256), 0, st, stats, ntiles,
+                  BN_GROUP_TILES, C, CS, partial, f, tickets);
+    } else {
+      SPCL_LAUNCH((bn_reduce_kernel<float, false, 16>), dim3(CS / 16, groups), dim3(256), 0, st, stats, ntiles,
+                  BN_GROUP_TILES, C, CS, partial, f, (unsigned*)nullptr);
+      SPCL_LAUNCH((bn_reduce_kernel<double, true, 16>), dim3(CS / 16, 1), dim3(groups > 64 ? 1024 : 256), 0, st,
+                  (const double*)partial, groups, groups, C, CS, (double*)nullptr, f, (unsigned*)nullptr);
+    }
   }
   SPCL_LAUNCH_CHECK("bn_finalize");
   return SPCL_OK;
