@@ -431,6 +431,17 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    gc_log = []
+    if os.environ.get("SPCL_BENCH_HOSTDIAG") == "1":  # which host stalls sit in the timed region: garbage collections?
+        import gc
+        _gc_t = [0.0]
+
+        def _gc_cb(phase, info):
+            if phase == "start":
+                _gc_t[0] = time.perf_counter()
+            else:
+                gc_log.append((len(host), info.get("generation"), round((time.perf_counter() - _gc_t[0]) * 1e3, 2)))
+        gc.callbacks.append(_gc_cb)
     t0 = time.perf_counter()
     host = []
     for _ in range(args.steps):
@@ -438,6 +449,9 @@ def main():
         run()
         host.append(time.perf_counter() - h0)
     torch.cuda.synchronize()
+    if os.environ.get("SPCL_BENCH_HOSTDIAG") == "1" and rank == 0:
+        slow = sorted(((round(h * 1e3, 2), i) for i, h in enumerate(host)), reverse=True)[:8]
+        print(f"[bench hostdiag] slowest host steps (ms, index): {slow}; gc (step, generation, ms): {gc_log}", file=sys.stderr)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

@@ -57,7 +57,10 @@ class _EpocherBase:
 
     def run(self):
         with self.meters.focus_on(self.meter_focus):
-            self._run()
+            try:
+                self._run()
+            finally:
+                _sg.gc_release()  # (a step-graph capture froze the garbage collector's view of the heap)
         return self.meters.statistics()
 
 

@@ -126,7 +126,10 @@ class PretrainEncoderEpocher:
         with self.meters.focus_on(self.meter_focus):
             self.meters["lr"].add([g["lr"] for g in self._optimizer.param_groups])
             self._model.train()
-            self._run_pretrain()
+            try:
+                self._run_pretrain()
+            finally:
+                _sg.gc_release()  # (the capture froze the garbage collector's view of the heap, stepgraph._gc_settle)
         self.close_hooks()
         return self.meters.statistics()
 
