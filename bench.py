@@ -564,8 +564,15 @@ def local_step(step):
     epocher, batch = step.epocher, step.batch
 
     def run():
-        with epocher.meters.focus_on(epocher.meter_focus):
-            epocher.step_update(epocher.step_compute(batch, seed=7))
+        from spcl_amd import stepgraph as _sg
+
+        def body():
+            with epocher.meters.focus_on(epocher.meter_focus):
+                epocher.step_update(epocher.step_compute(batch, seed=7))
+        if next(epocher._model.parameters()).is_cuda:  # (on the stream every other backward pass of this model ran on)
+            _sg.run_on_side_stream(body)
+        else:
+            body()
     run.epocher = epocher
     return run
 

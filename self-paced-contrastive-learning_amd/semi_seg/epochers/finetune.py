@@ -138,9 +138,15 @@ class FineTuneEpocher(_EpocherBase):
             unzip_twice_transformed_labeled(labeled_data, self._device)
         key = self._graph_key(labeled_image, labeled_target) if self._graph_on else None
         if key is None:
-            sup_loss = self.step_compute(labeled_image, labeled_target)
-            self.step_exchange()
-            self.step_update(sup_loss)
+            def eager():
+                loss = self.step_compute(labeled_image, labeled_target)
+                self.step_exchange()
+                self.step_update(loss)
+                return loss
+            if self._graph_on and self._device.type == "cuda":  # (keep every backward pass on the graphs' stream)
+                sup_loss = _sg.run_on_side_stream(eager, self._device)
+            else:
+                sup_loss = eager()
             inter, union = self._counts
         else:
             if self._static is None:

@@ -146,10 +146,16 @@ class PretrainEncoderEpocher:
         key = self._graph_key(data) if self._graph_on else None
         if key is not None:
             return self._step_staged(data, seed, key)
-        reg_loss = self.step_compute(data, seed)
-        self.step_exchange()
-        self.step_update(reg_loss)
-        return reg_loss
+
+        def eager():
+            reg_loss = self.step_compute(data, seed)
+            self.step_exchange()
+            self.step_update(reg_loss)
+            return reg_loss
+        if self._graph_on and self._device.type == "cuda":
+            # (an epocher that graphs its steps keeps every backward pass on the graphs' stream: stepgraph.side_stream)
+            return _sg.run_on_side_stream(eager, self._device)
+        return eager()
 
     # ---- the captured step
     def _graph_key(self, data):

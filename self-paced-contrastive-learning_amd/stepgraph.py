@@ -135,6 +135,32 @@ def gc_release():
     gc.unfreeze()
 
 
+def side_stream(device=None):
+    """the ONE private stream per device on which everything a step graph may later capture runs: warm steps, captures,
+    and the eager steps of an epocher that graphs its steps (a ragged batch, a hook without a key).  autograd's
+    AccumulateGrad nodes remember the stream they were created on; a node born on the default stream makes a later
+    capture fork into it (hipStreamEndCapture segfaults on this stack)."""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    if dev is None:
+        dev = torch.cuda.current_device()
+    if dev not in _SIDE_STREAMS:
+        _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+    return _SIDE_STREAMS[dev]
+
+
+def run_on_side_stream(fn, device=None):
+    """``fn()`` on ``side_stream`` between two stream waits (the caller's stream sees its results)"""
+    side = side_stream(device)
+    cur = torch.cuda.current_stream()
+    if cur == side:
+        return fn()
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        out = fn()
+    cur.wait_stream(side)
+    return out
+
+
 def graph_default() -> bool:
     """the epochers capture their step unless SPCL_STEP_GRAPH=0"""
     return os.environ.get("SPCL_STEP_GRAPH", "1") != "0"
@@ -175,10 +201,7 @@ class StepGraph:
 
     def _warm_step(self):
         if self._stream is None:  # ONE private stream per device for every StepGraph of the process (epoch after epoch)
-            dev = torch.cuda.current_device()
-            if dev not in _SIDE_STREAMS:
-                _SIDE_STREAMS[dev] = torch.cuda.Stream()
-            self._stream = _SIDE_STREAMS[dev]
+            self._stream = side_stream()
         cur = torch.cuda.current_stream()
         self._stream.wait_stream(cur)
         with torch.cuda.stream(self._stream):
