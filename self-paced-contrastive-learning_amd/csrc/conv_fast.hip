@@ -717,8 +717,9 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
   // few tiles (14^2 images): with two n-tiles per wave a 128-channel output is ONE workgroup per tile -- 128 workgroups for
   // Conv5.a's dgrad at N = 64, half the CUs idle; one n-tile per wave doubles the workgroups
   static const int env_fill = getenv("SPCL_CONV_FAST_FILL") ? atoi(getenv("SPCL_CONV_FAST_FILL")) : 1;
+  static const int env_fill_max = getenv("SPCL_CONV_FAST_FILL_MAX") ? atoi(getenv("SPCL_CONV_FAST_FILL_MAX")) : 256;
   if (env_fill && KC == 64 && NT == 2 && ntn >= 8 && ntn % 4 == 0 &&
-      (long)c.N * cdiv(c.W, 14) * cdiv(c.H, th) * cdiv(ntn, 8) < 256)
+      (long)c.N * cdiv(c.W, 14) * cdiv(c.H, th) * cdiv(ntn, 8) < env_fill_max)
     NT = 1;
   // experiment: the two n-tiles of a 16 / 32-channel-slab layer as two one-n-tile waves sharing the halo image
   static const int env_narrow = getenv("SPCL_CONV_FAST_NARROW_NT1") ? atoi(getenv("SPCL_CONV_FAST_NARROW_NT1")) : 0;
