@@ -62,6 +62,13 @@ constexpr int B16_ACC = B16_RED + 512;           // [9 taps][16] f32: the workgr
 constexpr int B16_TRASH = B16_ACC + 576;         // 32 bytes nobody reads (see the throw-away store before the tile loop)
 constexpr int B16_LDS = B16_TRASH + 32;          // 21 088
 
+// the ablation bits of Bwd16Args.dbg exist only in -DSPCL_CONV16_DBG_BUILD=1 builds (tools/diag/conv16_phases.py): as run-time
+// conditions they were scalar branches inside the unrolled loops -- the first build had ~200 branches per tile and wave
+#ifndef SPCL_CONV16_DBG_BUILD
+#define SPCL_CONV16_DBG_BUILD 0
+#endif
+#define B16_DBG(a) (SPCL_CONV16_DBG_BUILD ? (a).dbg : 0)
+
 __device__ __forceinline__ bf16x8 b16_tr_frag(unsigned addr) {
   // 8 pixels (k) of the lane's channel: two hardware-transposed reads of 4 pixels x 16 channels, 8 pixels apart
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(uintptr_t)addr);
@@ -184,7 +191,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(b16_wpe
     int py = py0, px = px0;
 #pragma unroll
     for (int j = 0; j < MW; ++j) {
-      const bool ok = 16 * (wave + NW * j) + r16 < NPIX;
+      const bool ok = j < MW - 1 || 16 * (wave + NW * j) + r16 < NPIX;  // (only the last round can run past pixel 195)
       ypre[j] = *(const uint2*)(y2b + (ok ? (py * a.W + px) * rowb : 0));  // (a lane beyond the last pixel: unused)
       px += SPX;
       py += SPY;
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(b16_wpe
     // in flight to stream from HBM)
     // (with one or two waves per tile the registers run out: there the requests follow the pixel pass)
     constexpr bool EARLY = NW >= 4;
-    const bool more = it + 1 < a.ipw && n + 1 < a.N && !(a.dbg & 16);
+    const bool more = it + 1 < a.ipw && n + 1 < a.N && !(B16_DBG(a) & 16);
     if (EARLY && more) issue_halo(n + 1);
     B16_STAMP(0)  // staging: image copies, wait for the dy halo, LDS stores, next requests
     __syncthreads();
@@ -275,7 +282,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(b16_wpe
       int py = py0, px = px0;
 #pragma unroll
       for (int j = 0; j < MW; ++j) {
-        const bool ok = 16 * (wave + NW * j) + r16 < NPIX;
+        const bool ok = j < MW - 1 || 16 * (wave + NW * j) + r16 < NPIX;  // (only the last round can run past pixel 195)
         abase[j] = B16_DY + (ok ? (py * RP + px) * PS : 0);
         acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         px += SPX;
@@ -285,7 +292,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(b16_wpe
           py += 1;
         }
       }
-      if (!(a.dbg & 1))
+      if (!(B16_DBG(a) & 1))
 #pragma unroll
       for (int s = 0; s < NSTEPS; ++s) {
         int fc = 4 * s + g;
@@ -294,10 +301,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(b16_wpe
         const int off = (ky * RP + kx) * PS + c * 16;
 #pragma unroll
         for (int j = 0; j < MW; ++j) {
-          if (wave + NW * j < 13) {  // (wave-uniform: the last round is not full)
-            const u32x4 xf = *(const u32x4*)(lds + abase[j] + off);
-            acc[j] = mfma_chunk<bf16_t>(wall[s], xf, acc[j]);
-          }
+          // (a wave whose last round holds no m-tile computes on the halo's first pixels and never uses the result: five
+          // MFMAs cheaper than a scalar branch per (k-step, m-tile))
+          const u32x4 xf = *(const u32x4*)(lds + abase[j] + off);
+          acc[j] = mfma_chunk<bf16_t>(wall[s], xf, acc[j]);
         }
       }
     }
@@ -311,9 +318,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(b16_wpe
       int px = px0, py = py0;
 #pragma unroll
       for (int j = 0; j < MW; ++j) {
-        const bool ok = 16 * (wave + NW * j) + r16 < NPIX;
+        const bool ok = j < MW - 1 || 16 * (wave + NW * j) + r16 < NPIX;  // (only the last round can run past pixel 195)
         dzp[j] = (uint2){0u, 0u};
-        if (ok && !(a.dbg & 2)) {
+        if (ok && !(B16_DBG(a) & 2)) {
           const bool keep = !shifted || (py >= oy && px >= ox);
           const float yv[4] = {__uint_as_float(ypre[j].x << 16), __uint_as_float(ypre[j].x & 0xffff0000u),
                                __uint_as_float(ypre[j].y << 16), __uint_as_float(ypre[j].y & 0xffff0000u)};
@@ -383,7 +390,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(b16_wpe
     // transposed read serves sit in ONE row, 256 contiguous bytes (no bank conflicts)
     const unsigned tr_col = (unsigned)((4 * (g & 1) + (r16 >> 2)) * PS + (r16 & 3) * 8);
     const unsigned tr_x = lds_base + B16_XT + (g >> 1) * B16_XT_ROW + tr_col;
-    if (!(a.dbg & 4)) {
+    if (!(B16_DBG(a) & 4)) {
       unsigned ax = tr_x, ad[TPW];
 #pragma unroll
       for (int j = 0; j < TPW; ++j) {
@@ -396,10 +403,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(b16_wpe
         const bf16x8 af = b16_tr_frag(ax + ks * 2 * B16_XT_ROW);
 #pragma unroll
         for (int j = 0; j < TPW; ++j) {
-          if (wave + NW * j < 9) {
-            const bf16x8 bf = b16_tr_frag(ad[j] + ks * 2 * RP * PS);
-            wacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, wacc[j], 0, 0, 0);
-          }
+          // (likewise: a wave without a tap in the last round repeats tap 8 into an accumulator nobody stores)
+          const bf16x8 bf = b16_tr_frag(ad[j] + ks * 2 * RP * PS);
+          wacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, wacc[j], 0, 0, 0);
         }
       }
     }
@@ -413,7 +419,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(b16_wpe
       int px = px0, py = py0;
 #pragma unroll
       for (int j = 0; j < MW; ++j) {
-        const bool ok = 16 * (wave + NW * j) + r16 < NPIX;
+        const bool ok = j < MW - 1 || 16 * (wave + NW * j) + r16 < NPIX;  // (only the last round can run past pixel 195)
         if (ok) *(uint2*)(lds + B16_XT + py * B16_XT_ROW + px * PS + g * 8) = dzp[j];
         px += SPX;
         py += SPY;
@@ -426,7 +432,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(b16_wpe
     B16_STAMP(5)  // dz stores
     __syncthreads();
     B16_STAMP(1)
-    if (wave == 0 && !(a.dbg & 8)) {
+    if (wave == 0 && !(B16_DBG(a) & 8)) {
       const int tap = r16 < 9 ? r16 : 0, tky = tap / 3, tkx = tap - 3 * tky;
       const unsigned char* pb = lds + B16_IM + tkx * 512 + ((g >> 1) + tky) * 32 + (g & 1) * 8;
       f32x4* dp = (f32x4*)(lds + B16_ACC + (r16 * 16 + 4 * g) * 4);

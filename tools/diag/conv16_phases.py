@@ -1,5 +1,6 @@
 """Ablation timing of csrc/conv16_bwd.hip at the benchmark's size (64 x 224 x 224): which phase costs what.
-    python tools/diag/conv16_phases.py        (needs an MI355X; SPCL_CONV16_DBG bits, see Bwd16Args.dbg)"""
+    python tools/diag/conv16_phases.py        (needs an MI355X; the SPCL_CONV16_DBG bits of Bwd16Args.dbg and the stamps act
+    only in a library built with -DSPCL_CONV16_DBG_BUILD=1 / -DSPCL_CONV16_STAMPS_BUILD=1; QUICK=1: the full kernel only)"""
 import os
 import sys
 import torch
@@ -45,7 +46,7 @@ stream = _n.stream()
 
 def fused():
     _n.call("spcl_conv16_bwd_fused", _n.ptr(dy), dtc, N, H, W, _n.ptr(wpt), _n.ptr(y2), _n.ptr(st[2]), _n.ptr(st[3]),
-            _n.ptr(st[0]), _n.ptr(img), _n.ptr(rows), _n.ptr(ws), _n.ptr(dw), 16, 16, stream)
+            _n.ptr(st[0]), _n.ptr(img), _n.ptr(rows), _n.ptr(ws), _n.ptr(dw), 16, 16, None, None, 0, None, stream)
 
 
 for dbg in ([0] if os.environ.get("QUICK") else [0, 1, 2, 4, 8, 16, 1 | 2, 4 | 8, 1 | 2 | 4 | 8, 1 | 2 | 4 | 8 | 16]):
