@@ -98,7 +98,12 @@ template <> struct Frag<float> {
 
 // NWV waves per workgroup: 4 for the 16/32-channel blocks; 8 for the 64x64 block (MI = NJ = 4), whose 36 (tap, ci-tile)
 // units and 23 staging chunks per thread would not fit two waves per SIMD in a 4-wave workgroup
-template <typename T, int MI, int NJ, int TH, int NWV>
+// IM: the input mode (0 raw, 1 BN + ReLU in the staging, 2 f32 image) and the debug stamps are compile-time: as run-time
+// conditions inside the unrolled staging loops they were ~100 scalar branches per tile
+#ifndef SPCL_WGRAD_STAMPS_BUILD
+#define SPCL_WGRAD_STAMPS_BUILD 0
+#endif
+template <typename T, int MI, int NJ, int TH, int NWV, int IM>
 __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
   constexpr int NTHR = 64 * NWV;
   constexpr int EPC = Chunk<T>::EPC, ESZ = (int)sizeof(T);
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_wgrad_kernel(WgradArgs a)
   const int dch = threadIdx.x % DCP, dpl = threadIdx.x / DCP;
   const int dry0 = dpl / WG_TW, dcol = dpl - dry0 * WG_TW;
   float sc[EPC], sh[EPC];
-  if (a.in_mode == 1) {
+  if (IM == 1) {
 #pragma unroll
     for (int e = 0; e < EPC; e += 4) {
       *(f32x4*)&sc[e] = *(const f32x4*)(a.in_scale + ci0 + xch * EPC + e);
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_wgrad_kernel(WgradArgs a)
 
   // ---- global -> registers (issued one tile ahead of the MFMAs).  Addresses = one wave-uniform 64-bit tile base + a
   // 32-bit per-thread offset fixed for the whole launch + a wave-uniform row step per iteration.
-  const int xvoff = (xhy0 * a.W + xhx) * a.CinS + (a.in_mode == 2 ? 0 : ci0 + xch * EPC);
+  const int xvoff = (xhy0 * a.W + xhx) * a.CinS + (IM == 2 ? 0 : ci0 + xch * EPC);
   const int dvoff = (dry0 * a.W + dcol) * a.CoutS + co0 + dch * EPC;
   auto load_tile = [&](int tile) {
     const int n = tile / tpi;
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_wgrad_kernel(WgradArgs a)
       const bool ok = xact && hy < NHROWS && colok && (interior || (gy >= 0 && gy < a.H));
       xmask |= (ok ? 1u : 0u) << i;
       const long rowoff = xorigin + (long)(i * XRPI) * a.W * a.CinS;  // wave-uniform
-      if (a.in_mode == 2) {
+      if (IM == 2) {
         u32x4 v = {0u, 0u, 0u, 0u};
         if (ok) {
           const float* src = (const float*)a.x + rowoff + xvoff;
@@ -232,7 +237,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_wgrad_kernel(WgradArgs a)
       if (xact && hy < NHROWS) {
         u32x4 v = rx[i];
         if (!(xmask & (1u << i))) v = (u32x4){0u, 0u, 0u, 0u};  // zero padding stays zero (also after BN + ReLU)
-        else if (a.in_mode == 1) v = wg_bnrelu_chunk<T>(v, sc, sh);
+        else if (IM == 1) v = wg_bnrelu_chunk<T>(v, sc, sh);
         *(u32x4*)(bx + hy * XRP + xhx * XS + xch * 16) = v;
       }
     }
@@ -274,7 +279,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_wgrad_kernel(WgradArgs a)
 
   // debug stamps (SPCL_WGRAD_STAMPS=1): s_memtime ticks of wave 0 per loop phase, summed over the workgroup's tiles
   unsigned long long t_store = 0, t_bar = 0, t_issue = 0, t_comp = 0, t_first = 0, t_all = 0, ntl = 0;
-  const bool stamp = a.stamps != nullptr;
+  const bool stamp = SPCL_WGRAD_STAMPS_BUILD && a.stamps != nullptr;
   const unsigned long long c_begin = stamp ? __builtin_amdgcn_s_memtime() : 0;
   // Round k of the grid covers tiles k G .. k G + G - 1.  Workgroups go to the 8 XCDs round-robin, so with tile = k G + b
   // neighbouring tiles (which share halo columns / rows of x) sit on different XCDs.  Optional (xcd_remap, OFF: it
@@ -420,13 +425,21 @@ static WgradPlan wgrad_plan(int N, int H, int W, int CinK, int CoutS, int esize)
   return p;
 }
 
-template <typename T, int MI, int NJ, int TH, int NWV>
-static void launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t st) {
+template <typename T, int MI, int NJ, int TH, int NWV, int IM>
+static void launch_wgrad_im(const WgradArgs& a, const WgradPlan& p, hipStream_t st) {
   const size_t lds = (a.dbuf ? 2 : 1) * wgrad_lds_bytes(MI, NJ, TH, (int)sizeof(T));
   if (lds > 65536)
-    spcl::func_lds_limit((const void*)conv3x3_wgrad_kernel<T, MI, NJ, TH, NWV>, (int)lds, "conv3x3_wgrad_kernel<T, MI, NJ, TH, NWV>");
-  SPCL_LAUNCH((conv3x3_wgrad_kernel<T, MI, NJ, TH, NWV>), dim3(p.nsplit, p.nblk_ci * p.nblk_co), dim3(64 * NWV), lds, st,
+    spcl::func_lds_limit((const void*)conv3x3_wgrad_kernel<T, MI, NJ, TH, NWV, IM>, (int)lds,
+                         "conv3x3_wgrad_kernel<T, MI, NJ, TH, NWV, IM>");
+  SPCL_LAUNCH((conv3x3_wgrad_kernel<T, MI, NJ, TH, NWV, IM>), dim3(p.nsplit, p.nblk_ci * p.nblk_co), dim3(64 * NWV), lds, st,
               a);
+}
+
+template <typename T, int MI, int NJ, int TH, int NWV>
+static void launch_wgrad(const WgradArgs& a, const WgradPlan& p, hipStream_t st) {
+  if (a.in_mode == 1) launch_wgrad_im<T, MI, NJ, TH, NWV, 1>(a, p, st);
+  else if (a.in_mode == 0) launch_wgrad_im<T, MI, NJ, TH, NWV, 0>(a, p, st);
+  else if constexpr (MI == 1 && NWV == 4) launch_wgrad_im<T, MI, NJ, TH, NWV, 2>(a, p, st);  // (image mode: CinK == 16)
 }
 
 template <typename T, int TH>
@@ -436,7 +449,7 @@ static void launch_wgrad_th(const WgradArgs& a, const WgradPlan& p, hipStream_t 
   static const int env_w8 = getenv("SPCL_WGRAD_W8") ? atoi(getenv("SPCL_WGRAD_W8")) : 1;
   if (p.MI == 1 && p.NJ == 1) launch_wgrad<T, 1, 1, TH, 4>(a, p, st);
   else if (p.MI == 1 && p.NJ == 2) {
-    if (env_w8 & 2) launch_wgrad<T, 1, 2, TH, 8>(a, p, st);
+    if ((env_w8 & 2) && a.in_mode != 2) launch_wgrad<T, 1, 2, TH, 8>(a, p, st);  // (the image mode exists for 4 waves only)
     else launch_wgrad<T, 1, 2, TH, 4>(a, p, st);
   } else if (p.MI == 2 && p.NJ == 1) launch_wgrad<T, 2, 1, TH, 4>(a, p, st);
   else if (env_w8 & 1) launch_wgrad<T, 2, 2, TH, 8>(a, p, st);
@@ -516,7 +529,7 @@ extern "C" int spcl_conv3x3_wgrad(const void* x, const void* dy, int dtype, int 
   a.dbuf = env_dbuf;
   static const int env_remap = getenv("SPCL_WGRAD_XCD_REMAP") ? atoi(getenv("SPCL_WGRAD_XCD_REMAP")) : 0;  // measured: +3..12 us per step, off
   a.xcd_remap = env_remap;
-  static const int env_stamps = getenv("SPCL_WGRAD_STAMPS") ? atoi(getenv("SPCL_WGRAD_STAMPS")) : 0;
+  static const int env_stamps = (SPCL_WGRAD_STAMPS_BUILD && getenv("SPCL_WGRAD_STAMPS")) ? atoi(getenv("SPCL_WGRAD_STAMPS")) : 0;
   static unsigned long long* stamp_buf = nullptr;
   a.stamps = nullptr;
   const size_t nwg = (size_t)p.nsplit * p.nblk_ci * p.nblk_co;
