@@ -261,9 +261,11 @@ struct Window {
   bool valid[4];
   size_t off[4];
   // (n, oy) wave-uniform; ox per thread
+  // FAST: H and W even -- every window is complete (the validity flags fold away: no per-load / per-store branches)
+  template <bool FAST = false>
   __device__ __forceinline__ void load(const T* y, size_t row0, int oy, int ox, int H, int W, int CS, int cc) {
     constexpr int EPC = Chunk<T>::EPC;
-    const bool y1 = 2 * oy + 1 < H, x1 = 2 * ox + 1 < W;
+    const bool y1 = FAST || 2 * oy + 1 < H, x1 = FAST || 2 * ox + 1 < W;
     const size_t o00 = (row0 * W + 2 * ox) * CS + cc * EPC;  // row0 = n*H + 2*oy
     off[0] = o00; off[1] = o00 + CS; off[2] = o00 + (size_t)W * CS; off[3] = off[2] + CS;
     valid[0] = true; valid[1] = x1; valid[2] = y1; valid[3] = x1 && y1;
@@ -276,7 +278,7 @@ struct Window {
 };
 
 // ---- forward with 2x2 max-pool (act optional)
-template <typename T>
+template <typename T, bool FAST>
 __global__ __launch_bounds__(256, 4) void bnrelu_fwd_pool_kernel(const T* __restrict__ y, int N, int H, int W, int CS,
                                                               const float* __restrict__ scale,
                                                               const float* __restrict__ shift, T* __restrict__ act,
@@ -296,8 +298,8 @@ __global__ __launch_bounds__(256, 4) void bnrelu_fwd_pool_kernel(const T* __rest
     for (int ox = pl; ox < PW; ox += 2 * PL) {
       Window<T> w[2];
       const bool second = ox + PL < PW;
-      w[0].load(y, row0, oy, ox, H, W, CS, cc);
-      if (second) w[1].load(y, row0, oy, ox + PL, H, W, CS, cc);
+      w[0].template load<FAST>(y, row0, oy, ox, H, W, CS, cc);
+      if (second) w[1].template load<FAST>(y, row0, oy, ox + PL, H, W, CS, cc);
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         if (u == 1 && !second) break;
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(256, 4) void bnrelu_fwd_pool_kernel(const T* __rest
           for (int k = 0; k < 4; ++k)
             if (w[u].valid[k]) *(u32x4*)(act + w[u].off[k]) = aw[k];
         }
-        if (pool != nullptr && oy < OH && oxu < OW)
+        if (pool != nullptr && (FAST || (oy < OH && oxu < OW)))
           *(u32x4*)(pool + (((size_t)n * OH + oy) * OW + oxu) * CS + cc * EPC) = mxw;
       }
     }
@@ -519,7 +521,9 @@ __device__ __forceinline__ void window_dz(const Window<T>& w, const u32x4* rg, b
 }
 
 // ---- pass 1 / pass 2 with pooling.  APPLY == false: partial sums;  true: dy
-template <typename T, bool APPLY>
+// FAST: H and W even, pooled gradient only (dact == null, dpool given) -- the training step's case: the run-time flags
+// of the general form are scalar / exec branches around every load and store of the loop
+template <typename T, bool APPLY, bool FAST>
 __global__ __launch_bounds__(256, 3) void bnrelu_bwd_pool_kernel(const T* __restrict__ y, const T* __restrict__ dact,
                                                               const T* __restrict__ dpool, int N, int H, int W, int CS,
                                                               const float* __restrict__ mean,
@@ -533,7 +537,7 @@ __global__ __launch_bounds__(256, 3) void bnrelu_bwd_pool_kernel(const T* __rest
   const int CPC = CS / EPC, PL = 256 / CPC;
   const int cc = threadIdx.x % CPC, pl = threadIdx.x / CPC;
   const int PH = (H + 1) / 2, PW = (W + 1) / 2, OH = H / 2, OW = W / 2;
-  const bool has_g = dact != nullptr;
+  const bool has_g = !FAST && dact != nullptr;
   float s1[EPC], s2[EPC];
 #pragma unroll
   for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = 0.f;
@@ -549,7 +553,7 @@ __global__ __launch_bounds__(256, 3) void bnrelu_bwd_pool_kernel(const T* __rest
       const size_t row0 = (size_t)n * H + 2 * oy;
       for (int ox = pl; ox < PW; ox += PL) {
         Window<T> w;
-        w.load(y, row0, oy, ox, H, W, CS, cc);
+        w.template load<FAST>(y, row0, oy, ox, H, W, CS, cc);
         u32x4 rg[4], rdp = {0u, 0u, 0u, 0u};
         if (has_g) {
 #pragma unroll
@@ -558,7 +562,7 @@ __global__ __launch_bounds__(256, 3) void bnrelu_bwd_pool_kernel(const T* __rest
             if (w.valid[k]) rg[k] = *(const u32x4*)(dact + w.off[k]);
           }
         }
-        const bool complete = dpool != nullptr && oy < OH && ox < OW;  // floor semantics of max_pool2d
+        const bool complete = FAST || (dpool != nullptr && oy < OH && ox < OW);  // floor semantics of max_pool2d
         if (complete) rdp = *(const u32x4*)(dpool + (((size_t)n * OH + oy) * OW + ox) * CS + cc * EPC);
         u32x4 out[4];
 #pragma unroll
@@ -968,8 +972,13 @@ static int bnrelu_fwd_launch(const void* y, int N, int H, int W, int CS, const f
   prof_cost(tb * (1.0 + (act != nullptr ? 1.0 : 0.0) + (pool != nullptr ? 0.25 : 0.0)), 0.0);
   if (pool != nullptr) {
     const int rows = N * ((H + 1) / 2);
-    SPCL_LAUNCH((bnrelu_fwd_pool_kernel<T>), dim3(rows < STREAM_MAX_WG ? rows : STREAM_MAX_WG), dim3(256), 0, st, (const T*)y, N, H,
+    if (H % 2 == 0 && W % 2 == 0) {
+      SPCL_LAUNCH((bnrelu_fwd_pool_kernel<T, true>), dim3(rows < STREAM_MAX_WG ? rows : STREAM_MAX_WG), dim3(256), 0, st, (const T*)y, N, H,
                        W, CS, scale, shift, (T*)act, (T*)pool);
+    } else {
+      SPCL_LAUNCH((bnrelu_fwd_pool_kernel<T, false>), dim3(rows < STREAM_MAX_WG ? rows : STREAM_MAX_WG), dim3(256), 0, st, (const T*)y, N, H,
+                       W, CS, scale, shift, (T*)act, (T*)pool);
+    }
   } else {
     const size_t npix = (size_t)N * H * W;
     SPCL_LAUNCH((bnrelu_fwd_lin_kernel<T>), dim3(stream_grid(npix, PL, STREAM_UNROLL, STREAM_MAX_WG)), dim3(256), 0, st,
@@ -1012,9 +1021,15 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
     }
   } else if (pool) {
     nwg = prows < BWD_MAX_WG ? prows : BWD_MAX_WG;
-    SPCL_LAUNCH((bnrelu_bwd_pool_kernel<T, false>), dim3(nwg), dim3(256), 0, st, (const T*)y, (const T*)dact,
+    if (H % 2 == 0 && W % 2 == 0 && dact == nullptr && dpool != nullptr) {
+      SPCL_LAUNCH((bnrelu_bwd_pool_kernel<T, false, true>), dim3(nwg), dim3(256), 0, st, (const T*)y, (const T*)dact,
                        (const T*)dpool, N, H, W, CS, mean, invstd, scale, shift, (const float*)nullptr, partial,
                        (T*)nullptr);
+    } else {
+      SPCL_LAUNCH((bnrelu_bwd_pool_kernel<T, false, false>), dim3(nwg), dim3(256), 0, st, (const T*)y, (const T*)dact,
+                       (const T*)dpool, N, H, W, CS, mean, invstd, scale, shift, (const float*)nullptr, partial,
+                       (T*)nullptr);
+    }
   } else if (bcast) {
     bsplit = (H * W + PL - 1) / PL;
     while (bsplit > 1 && N * bsplit > BWD_MAX_WG) bsplit = (bsplit + 1) / 2;
@@ -1033,9 +1048,15 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
                      img != nullptr ? W : 0, rows != nullptr ? 1 : 0, rs, im3);
   prof_cost(2.0 * tb + gb, 0.0);
   if (pool) {
-    SPCL_LAUNCH((bnrelu_bwd_pool_kernel<T, true>), dim3(prows < STREAM_MAX_WG ? prows : STREAM_MAX_WG), dim3(256), 0, st, (const T*)y,
+    if (H % 2 == 0 && W % 2 == 0 && dact == nullptr && dpool != nullptr) {
+      SPCL_LAUNCH((bnrelu_bwd_pool_kernel<T, true, true>), dim3(prows < STREAM_MAX_WG ? prows : STREAM_MAX_WG), dim3(256), 0, st, (const T*)y,
                        (const T*)dact, (const T*)dpool, N, H, W, CS, mean, invstd, scale, shift, (const float*)ab,
                        (float*)nullptr, (T*)dy);
+    } else {
+      SPCL_LAUNCH((bnrelu_bwd_pool_kernel<T, true, false>), dim3(prows < STREAM_MAX_WG ? prows : STREAM_MAX_WG), dim3(256), 0, st, (const T*)y,
+                       (const T*)dact, (const T*)dpool, N, H, W, CS, mean, invstd, scale, shift, (const float*)ab,
+                       (float*)nullptr, (T*)dy);
+    }
   } else if (img != nullptr) {  // first conv of a one-channel image block: dy is consumed in registers by its dW
     float* wpart = ab + 2 * CS;  // [IMG_WGRAD_WG][9][CS];  zrow = the image row above / below the image
     static const int want = getenv("SPCL_IMGWG_WG") ? atoi(getenv("SPCL_IMGWG_WG")) : 1280;  // 5 resident per CU

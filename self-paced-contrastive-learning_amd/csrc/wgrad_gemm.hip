@@ -30,6 +30,12 @@
 
 namespace spcl {
 
+// the ablation bits (WbArgs.dbg) and the in-kernel stamps act only in a -DSPCL_WGRAD_GEMM_DBG_BUILD=1 build: run-time
+// conditions in the tile loops are scalar branches on every trip
+#ifndef SPCL_WGRAD_GEMM_DBG_BUILD
+#define SPCL_WGRAD_GEMM_DBG_BUILD 0
+#endif
+#define WB_DBG(a) (SPCL_WGRAD_GEMM_DBG_BUILD ? (a).dbg : 0)
 constexpr int WB_MAX = SPCL_WGRAD_BATCH_MAX;
 constexpr int WB_SLAB = 9 * 64 * 64;  // floats per workgroup partial
 
@@ -261,10 +267,10 @@ __global__ __launch_bounds__(768) void wgrad_gemm_kernel(WbArgs a) {
     typedef std::true_type Yes;
     typedef std::false_type No;
     const int nt = t_end - t_begin;
-    const bool go = !(a.dbg & 1);
-    const bool fuse = fused && !(a.dbg & 4);
+    const bool go = !(WB_DBG(a) & 1);
+    const bool fuse = fused && !(WB_DBG(a) & 4);
     unsigned long long pt_write = 0, pt_issue = 0, pt_bar = 0;
-    const bool stamp = a.stamps != nullptr;
+    const bool stamp = SPCL_WGRAD_GEMM_DBG_BUILD && a.stamps != nullptr;
     __builtin_amdgcn_s_setprio(3);  // four short instruction streams beside eight MFMA streams: never wait for issue
     if (nt > 0 && go) {
       if (NDB == 3) dma_dy(0);
@@ -388,12 +394,12 @@ __global__ __launch_bounds__(768) void wgrad_gemm_kernel(WbArgs a) {
   };
 
   unsigned long long ct_bar = 0, ct_comp = 0;
-  const bool cstamp = a.stamps != nullptr;
+  const bool cstamp = SPCL_WGRAD_GEMM_DBG_BUILD && a.stamps != nullptr;
   for (int k = 0; k < t_end - t_begin; ++k) {
     const unsigned long long s0 = cstamp ? __builtin_amdgcn_s_memtime() : 0;
     __syncthreads();  // barrier k: the producers have staged tile k (and every consumer has left tile k - 1)
     const unsigned long long s1 = cstamp ? __builtin_amdgcn_s_memtime() : 0;
-    if (!(a.dbg & 2)) compute(k);
+    if (!(WB_DBG(a) & 2)) compute(k);
     if (cstamp) {
       ct_bar += s1 - s0; ct_comp += __builtin_amdgcn_s_memtime() - s1;
     }
@@ -405,7 +411,7 @@ __global__ __launch_bounds__(768) void wgrad_gemm_kernel(WbArgs a) {
 
   // ---- partial slab in fragment order: [tap][m][co-tile][lane][4 rows]  (1 KiB per wave-store)
   float* out = a.partial + ((size_t)it.wg0 + (size_t)blk * it.nsplit + split) * WB_SLAB;  // splits of a block adjacent
-  if (a.dbg & 8) return;
+  if (WB_DBG(a) & 8) return;
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
