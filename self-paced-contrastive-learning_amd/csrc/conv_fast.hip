@@ -569,7 +569,8 @@ conv3x3_fast_kernel(FastArgs a) {
 // (x[q], x[q+1], x[q+2], x[q+3]: three taps and a finite pad against a zero weight) is one ds_read2_b32.
 // Weights come from the ordinary packed forward layout (kind 0, CinK = 16): three 2-byte loads per lane.
 // The kernel is a pure output stream (32 bytes per pixel out, 4 in).
-template <int TH>
+// EVEN: the image size is a multiple of the tile (no shifted last tiles: the `keep` factor of the statistics folds away)
+template <int TH, bool EVEN>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void conv3x3_image_kernel(FastArgs a) {
   constexpr int TW = 14, HW_ = 16, LW = HW_ + 2;  // LDS row: 16 halo pixels + 2 so that pair q+2 of the last tap exists
   constexpr int NPIX = TH * TW, MT = (NPIX + 15) / 16, NHALO = (TH + 2) * HW_;
@@ -592,20 +593,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void co
     }
   }
 
-  // stage: lane -> halo pixels q = lane + 64 k; pair = (x[q], x[q+1]) with zero outside the image
+  // stage: lane -> halo pixels q = lane + 64 k (four halo rows of 16 per step: a lane keeps its column); pair =
+  // (x[q], x[q+1]) with zero outside the image -- ONE clamped load per pixel, the right-hand neighbour comes from the next
+  // lane (the second load and its bounds checks were a third of the staging's instructions; the kernel is issue-bound)
   const float* img = (const float*)a.x + (size_t)n * a.H * a.W;
+  {
+    const int hx = r16, gx = x0 - 1 + hx;
+    const bool colok = gx >= 0 && gx < a.W;
+    const int gxc = gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx);
 #pragma unroll
-  for (int k = 0; k < (NHALO + 63) / 64; ++k) {
-    const int q = lane + 64 * k;
-    const int hy = q / HW_, hx = q % HW_;
-    const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-    float v0 = 0.f, v1 = 0.f;
-    if (q < NHALO && gy >= 0 && gy < a.H) {
-      if (gx >= 0 && gx < a.W) v0 = img[(size_t)gy * a.W + gx];
-      if (gx + 1 >= 0 && gx + 1 < a.W && hx + 1 < HW_) v1 = img[(size_t)gy * a.W + gx + 1];
+    for (int k = 0; k < (NHALO + 63) / 64; ++k) {
+      const int hy = g + 4 * k;
+      const int gy = y0 - 1 + hy;
+      const int gyc = gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy);
+      const float raw = img[(size_t)gyc * a.W + gxc];
+      const float v0 = (colok && gy >= 0 && gy < a.H) ? raw : 0.f;
+      float v1 = __shfl_down(v0, 1, 64);
+      if (hx == HW_ - 1) v1 = 0.f;
+      const f32x2 pv = {v0, v1};
+      if (NHALO % 64 == 0 || hy < TH + 2) pairs[hy * LW + hx] = __builtin_bit_cast(uint32_t, __builtin_convertvector(pv, bf16x2v));
     }
-    const f32x2 pv = {v0, v1};
-    if (q < NHALO) pairs[hy * LW + hx] = __builtin_bit_cast(uint32_t, __builtin_convertvector(pv, bf16x2v));
   }
   if (lane < 2 * (TH + 2)) pairs[(lane >> 1) * LW + HW_ + (lane & 1)] = 0u;  // the two pad pairs of each row
   __syncthreads();
@@ -631,17 +638,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void co
   int ob = (py * a.W + px) * rowb;
   const int dob = (DPY * a.W + DPX) * rowb, wrapo = (a.W - TW) * rowb;
   f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
-  const bool shifted = (oy | ox) != 0;
+  const bool shifted = !EVEN && (oy | ox) != 0;
   int pyc = py;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const bool ok = (16 * i + 15 < NPIX) || (16 * i + r16 < NPIX);
     if (ok) {
-      const float keep = (!shifted || (pyc >= oy && px >= ox)) ? 1.f : 0.f;
       store4_fast<bf16_t>(yb + ob, acc[i]);
-      const f32x4 av = acc[i] * keep;
-      ssum += av;
-      ssq += av * acc[i];
+      if (EVEN) {
+        ssum += acc[i];
+        ssq += acc[i] * acc[i];
+      } else {
+        const float keep = (!shifted || (pyc >= oy && px >= ox)) ? 1.f : 0.f;
+        const f32x4 av = acc[i] * keep;
+        ssum += av;
+        ssq += av * acc[i];
+      }
     }
     px += DPX;
     pyc += DPY;
@@ -703,7 +715,10 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
     a.y2 = nullptr; a.scale2 = a.shift2 = a.mean2 = nullptr; a.rows2 = nullptr; a.H2 = a.W2 = 0; a.img2 = nullptr;
     a.N = c.N; a.H = c.H; a.W = c.W; a.CinK = 16; a.CoutS = 16;
     a.tilesX = cdiv(c.W, 14); a.tilesY = cdiv(c.H, 14); a.gy = 1; a.xcd_remap = 0; a.lds_flip = 0; a.stamps = nullptr;
-    if (!dry) SPCL_LAUNCH((conv3x3_image_kernel<14>), dim3(a.tilesX, a.tilesY, a.N), dim3(64), 0, st, a);
+    if (!dry) {
+      if (c.H % 14 == 0 && c.W % 14 == 0) SPCL_LAUNCH((conv3x3_image_kernel<14, true>), dim3(a.tilesX, a.tilesY, a.N), dim3(64), 0, st, a);
+      else SPCL_LAUNCH((conv3x3_image_kernel<14, false>), dim3(a.tilesX, a.tilesY, a.N), dim3(64), 0, st, a);
+    }
     return true;
   }
   if (c.CinS != c.CinK) return false;
