@@ -510,7 +510,7 @@ def test_bn_relu_backward_fused_image_wgrad(dt, N, C, H, W):
     assert torch.equal(dw, dw3)
 
 
-@pytest.mark.parametrize("ntiles,C", [(3000, 64), (1500, 32), (700, 64), (5000, 48), (2048, 128)])
+@pytest.mark.parametrize("ntiles,C", [(3000, 64), (1500, 32), (700, 64), (5000, 48), (2048, 128), (16384, 16)])
 def test_bn_finalize_many_tiles_all_launch_shapes(ntiles, C):
     """spcl_bn_finalize from many per-tile (count, mean, M2) rows: the one-launch (16- and 4-channel workgroups) and the
     two-level paths against float64 pooling of the same rows."""
@@ -535,6 +535,13 @@ def test_bn_finalize_many_tiles_all_launch_shapes(ntiles, C):
     np.testing.assert_allclose(st[0, :C].cpu().numpy(), mu[:C].float().numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(st[1, :C].cpu().numpy(), (1 / torch.sqrt(var[:C] + 1e-5)).float().numpy(), rtol=1e-5)
     assert float(st[:, C:].abs().max()) == 0.0 if cs > C else True
+    # the two-level path is ONE launch whose last group finishes (self-resetting tickets): again and again the same bits
+    for _ in range(3):
+        st2 = torch.empty(4, cs, device="cuda")
+        stats_d = stats.cuda()
+        n.call("spcl_bn_finalize", n.ptr(stats_d), ntiles, C, cs, n.ptr(gamma_d), n.ptr(beta_d), c_float(0.1),
+               c_float(1e-5), None, None, None, n.ptr(st2[0]), n.ptr(st2[1]), n.ptr(st2[2]), n.ptr(st2[3]), n.stream())
+        assert torch.equal(st, st2)
 
 
 @pytest.mark.parametrize("N,C,H,W", [(2, 16, 28, 28), (1, 32, 56, 28), (2, 64, 14, 14), (1, 128, 28, 14), (3, 16, 224, 42),
