@@ -14,6 +14,8 @@ LIB = os.path.join(HERE, "lib", "libspcl_hip.so")
 OBJ = os.path.join(HERE, "build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# experiments / debug builds: SPCL_BUILD_DEFS="-DSPCL_CONV16_STAMPS_BUILD=1 -DSPCL_FAST_WIDE_STORES=0" (use with --force)
+FLAGS += os.environ.get("SPCL_BUILD_DEFS", "").split()
 # per-file extras.  supcon.hip: the first kernel-argument dwords arrive in SGPRs at wave launch (gfx950 kernarg preload)
 # instead of through a scalar load -- the large-batch sweeps start their transfers one memory round trip earlier.
 EXTRA = {"supcon.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=14"]}

@@ -59,6 +59,9 @@ struct FastArgs {
 #ifndef SPCL_FAST_YPRE_MINKC
 #define SPCL_FAST_YPRE_MINKC 16
 #endif
+#ifndef SPCL_FAST_WIDE_STORES
+#define SPCL_FAST_WIDE_STORES 1
+#endif
 #ifndef SPCL_FAST_DBG
 #define SPCL_FAST_DBG 0  /* timing experiments only (wrong results): 1 no ring refills, 2 no fragment reads in the k-loop */
 #endif
@@ -437,6 +440,8 @@ conv3x3_fast_kernel(FastArgs a) {
     request_chunk(0);
     __builtin_amdgcn_sched_barrier(0);  // (the scheduler would hoist every later request up here too)
   }
+  uint2 pk_prev[NT];
+  int ob_prev = 0;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const bool ok = (16 * i + 15 < NPIX) || (16 * i + r16 < NPIX);  // compile-time true except in the last m-tile
@@ -449,7 +454,32 @@ conv3x3_fast_kernel(FastArgs a) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         // (MODE 4: nobody downstream may want g itself -- the image block's first conv needs only the sums below)
-        if (MODE != 4 || a.y != nullptr) store4_fast<bf16_t>(yb + ob + j * 32, acc[i][j]);
+        if (MODE != 4 || a.y != nullptr) {
+          // complete m-tiles leave in PAIRS: lanes g and g ^ 1 hold the two 8-byte halves of a pixel's 16-byte channel run,
+          // one v_permlane16_swap per dword gives the even lane group its pixel of m-tile i - 1 whole and the odd one its
+          // pixel of m-tile i -- half the store instructions for the same bytes (conv3x3_image_kernel below)
+          // (not in the one-wave KC = 64 kernels: at their 128-register budget the parked halves spill)
+          constexpr bool PAIRED = SPCL_FAST_WIDE_STORES && MODE != 4 && !(KC == 64 && NW == 1);
+          const bool first = PAIRED && i % 2 == 0 && i + 1 < MT && 16 * (i + 1) + 15 < NPIX;
+          const bool second = PAIRED && i % 2 == 1 && 16 * i + 15 < NPIX;
+          if (first || second) {
+            const f32x2 lo = {acc[i][j][0], acc[i][j][1]}, hi = {acc[i][j][2], acc[i][j][3]};
+            uint2 pkc;
+            pkc.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf16x2v));
+            pkc.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, bf16x2v));
+            if (first) {
+              pk_prev[j] = pkc;
+              ob_prev = ob;
+            } else {
+              const auto rx = __builtin_amdgcn_permlane16_swap(pk_prev[j].x, pkc.x, false, false);
+              const auto ry = __builtin_amdgcn_permlane16_swap(pk_prev[j].y, pkc.y, false, false);
+              const u32x4 v = {rx[0], ry[0], rx[1], ry[1]};
+              *(u32x4*)(yb + ((g & 1) ? ob - 8 : ob_prev) + j * 32) = v;
+            }
+          } else {
+            store4_fast<bf16_t>(yb + ob + j * 32, acc[i][j]);
+          }
+        }
         if (M2) {
           // dz = g [relu(bn(y2)) > 0] with g as STORED (bf16): sum dz and sum dz (y2 - mean) of the lane's 4 channels
           const uint2 yr = YPRE ? ypre[i][j][0] : *(const uint2*)(y2b + ob + j * 32);
@@ -640,11 +670,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void co
   f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
   const bool shifted = !EVEN && (oy | ox) != 0;
   int pyc = py;
+  // Two m-tiles per 16-byte store: lanes g and g ^ 1 hold the two 8-byte halves of a pixel's 16-byte channel run, so one
+  // v_permlane16_swap per dword gives the even lane group both halves of its pixel in m-tile i and the odd one both halves of
+  // its pixel in m-tile i + 1 -- half the store instructions for the same bytes (the kernel is a 103 MB output stream).
+  uint2 pk[MT];
+  int obs[MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const bool ok = (16 * i + 15 < NPIX) || (16 * i + r16 < NPIX);
+    obs[i] = ob;
+    {
+      const f32x2 lo = {acc[i][0], acc[i][1]}, hi = {acc[i][2], acc[i][3]};
+      pk[i].x = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf16x2v));
+      pk[i].y = __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, bf16x2v));
+    }
     if (ok) {
-      store4_fast<bf16_t>(yb + ob, acc[i]);
       if (EVEN) {
         ssum += acc[i];
         ssq += acc[i] * acc[i];
@@ -663,6 +703,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void co
       pyc += 1;
       ob += wrapo;
     }
+  }
+  constexpr int NPAIR = SPCL_FAST_WIDE_STORES ? (NPIX / 16) / 2 : 0;  // pairs of COMPLETE m-tiles
+#pragma unroll
+  for (int p = 0; p < NPAIR; ++p) {
+    const int i = 2 * p;
+    const auto rx = __builtin_amdgcn_permlane16_swap(pk[i].x, pk[i + 1].x, false, false);
+    const auto ry = __builtin_amdgcn_permlane16_swap(pk[i].y, pk[i + 1].y, false, false);
+    const u32x4 v = {rx[0], ry[0], rx[1], ry[1]};
+    *(u32x4*)(yb + ((g & 1) ? obs[i + 1] - 8 : obs[i])) = v;
+  }
+#pragma unroll
+  for (int i = 2 * NPAIR; i < MT; ++i) {
+    const bool ok = (16 * i + 15 < NPIX) || (16 * i + r16 < NPIX);
+    if (ok) *(uint2*)(yb + obs[i]) = pk[i];
   }
   if (a.stats != nullptr)
     write_tile_stats(a.stats, tile, a.CoutS, 4 * g, r16, (float)((TH - oy) * (TW - ox)), ssum, ssq);
