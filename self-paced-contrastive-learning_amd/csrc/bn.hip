@@ -1009,6 +1009,7 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
   const double gb = (dact != nullptr ? tb : 0.0) + (pool ? 0.25 * tb : 0.0);
   prof_cost(tb + gb, 0.0);
   const float* fin_src = partial;
+  int fin_transposed = 0;
   if (rows != nullptr) {  // the partial sums came with the dgrad that produced dact (per conv tile, centred s2)
     static const int fin_rows = getenv("SPCL_BWD_FIN_MAX_ROWS") ? atoi(getenv("SPCL_BWD_FIN_MAX_ROWS")) : BWD_MAX_WG;
     if (nrows <= fin_rows) {
@@ -1017,7 +1018,10 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
     } else {
       const int G = (nrows + BWD_MAX_WG - 1) / BWD_MAX_WG;
       nwg = (nrows + G - 1) / G;
-      SPCL_LAUNCH(bwd_rows_group_kernel, dim3(nwg), dim3(256), 0, st, rows, nrows, G, CS, partial, rs);
+      // (folded rows written transposed, [sub-row][channel][row]: the final kernel's loads are then coalesced)
+      SPCL_LAUNCH(bwd_rows_group_kernel, dim3(nwg), dim3(256), 0, st, rows, nrows, G, CS, partial, rs, nwg,
+                  (const float*)nullptr, 0, (float*)nullptr, 1);
+      fin_transposed = 1;
     }
   } else if (pool) {
     nwg = prows < BWD_MAX_WG ? prows : BWD_MAX_WG;
@@ -1045,7 +1049,7 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
   float* zrow = ab + 2 * CS + (size_t)IMG_WGRAD_WG * 9 * CS;  // [W] zeros (image-wgrad pass only, see below)
   SPCL_LAUNCH(bnrelu_bwd_fin_kernel, dim3(CS), dim3(256), 0, st, fin_src, nwg, C, CS,
                      M, training, mean, invstd, scale, dgamma, dbeta, ab, img != nullptr ? zrow : (float*)nullptr,
-                     img != nullptr ? W : 0, rows != nullptr ? 1 : 0, rs, im3);
+                     img != nullptr ? W : 0, rows != nullptr ? 1 : 0, rs, im3, fin_transposed);
   prof_cost(2.0 * tb + gb, 0.0);
   if (pool) {
     if (H % 2 == 0 && W % 2 == 0 && dact == nullptr && dpool != nullptr) {
