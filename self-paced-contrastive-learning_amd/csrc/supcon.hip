@@ -110,8 +110,10 @@ __device__ __forceinline__ SupconArgs supcon_head(SupconArgs a, int h) {
   const size_t o = (size_t)h * a.hs_ws;
   a.P += o; a.rn2 += o; a.logD += o; a.cnt += o; a.W += o; a.partA += o; a.partB += o;
   if (a.labels != nullptr) a.labels += (size_t)h * a.hs_lab;
-  a.gamma = a.gk[h];
-  a.inv_gamma = a.igk[h];
+  // (a select chain, not a.gk[h]: a run-time index into a by-value kernel argument makes the compiler copy the whole
+  // struct to scratch memory -- 184 bytes per lane, a memory round trip at the head of these latency-bound kernels)
+  a.gamma = h == 0 ? a.gk[0] : (h == 1 ? a.gk[1] : (h == 2 ? a.gk[2] : a.gk[3]));
+  a.inv_gamma = h == 0 ? a.igk[0] : (h == 1 ? a.igk[1] : (h == 2 ? a.igk[2] : a.igk[3]));
   return a;
 }
 
