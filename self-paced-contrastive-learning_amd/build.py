@@ -16,8 +16,10 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # experiments / debug builds: SPCL_BUILD_DEFS="-DSPCL_CONV16_STAMPS_BUILD=1 -DSPCL_FAST_WIDE_STORES=0" (use with --force)
 FLAGS += os.environ.get("SPCL_BUILD_DEFS", "").split()
-# per-file extras.  supcon.hip: the first kernel-argument dwords arrive in SGPRs at wave launch (gfx950 kernarg preload)
-# instead of through a scalar load -- the large-batch sweeps start their transfers one memory round trip earlier.
+# The first kernel-argument dwords arrive in SGPRs at wave launch (gfx950 kernarg preload) instead of through a scalar load:
+# the short one-tile workgroups of the convolutions start their first transfers a memory round trip earlier (whole step,
+# same box, build A/B: 1159.6 -> 1152.6 us); supcon.hip was tuned with 14 (the large-batch sweeps).
+PRELOAD = ["-mllvm", "-amdgpu-kernarg-preload-count=16"]
 EXTRA = {"supcon.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=14"]}
 if os.environ.get("SPCL_BUILD_NOSLP"):  # experiment: no SLP packing of adjacent f32 operations (v_pk_*_f32) in the named files
     for _f in os.environ["SPCL_BUILD_NOSLP"].split(","):
@@ -46,7 +48,8 @@ def build(force=False, verbose=True):
         o = os.path.join(OBJ, src.rsplit(".", 1)[0] + ".o")
         objs.append(o)
         if force or _stale(o, [s, os.path.abspath(__file__)] + headers):
-            cmd = [HIPCC] + FLAGS + EXTRA.get(src, []) + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", s, "-o", o]
+            extra = EXTRA.get(src, PRELOAD if src.endswith(".hip") and "kernarg-preload" not in " ".join(FLAGS) else [])
+            cmd = [HIPCC] + FLAGS + extra + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", s, "-o", o]
             jobs.append((src, cmd))
 
     def run(job):
