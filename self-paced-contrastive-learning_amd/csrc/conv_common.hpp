@@ -122,7 +122,11 @@ __device__ __forceinline__ void write_tile_stats(float* stats, int tile, int Cou
   for (int r = 0; r < 4; ++r) {
     const float s1 = row16_sum(ssum[r]), s2 = row16_sum(ssq[r]);
     const float mean = s1 * inv;
-    const float m2 = fmaxf(s2 - s1 * mean, 0.f);  // M2 = sum x^2 - n mean^2
+    // M2 = sum x^2 - n mean^2, the product rounded on its own (not contracted into an FMA): a tile whose values are all
+    // equal then gives exactly 0, as the rounded sum of squares minus the equally rounded product
+    float prod = s1 * mean;
+    asm volatile("" : "+v"(prod));  // (an opaque copy: no contraction across it)
+    const float m2 = fmaxf(s2 - prod, 0.f);
     o[r] = r16 == 0 ? cnt : (r16 == 1 ? mean : m2);
   }
   if (r16 < 3) *(f32x4*)(stats + ((size_t)tile * 3 + r16) * CoutS + cb) = o;

@@ -365,7 +365,9 @@ __global__ __launch_bounds__(512) void conv3x3_gemm_kernel(GemmArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           mean[r] = t1[r] * inv;
-          m2[r] = fmaxf(t2[r] - t1[r] * mean[r], 0.f);  // M2 = sum x^2 - n mean^2
+          float prod = t1[r] * mean[r];
+          asm volatile("" : "+v"(prod));  // M2 = sum x^2 - n mean^2, the product rounded on its own (conv_common.hpp)
+          m2[r] = fmaxf(t2[r] - prod, 0.f);
         }
         *(f32x4*)o = (f32x4){cnt, cnt, cnt, cnt};
         *(f32x4*)(o + a.CoutS) = mean;
