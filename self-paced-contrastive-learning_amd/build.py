@@ -16,7 +16,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -fno-slp-vectorize: left on, hipcc packs adjacent f32 adds / multiplies / FMAs of the epilogues into v_pk_*_f32, which
 # issue slower than the two scalar instructions they replace on gfx950 (MI355X_MICROARCH.md, price list); same arithmetic,
 # same bits.  Whole step, same box, build A/B: 1147.4 -> 1134.8 us.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize"]
+ARCH = os.environ.get("SPCL_BUILD_ARCH", "gfx950")  # (experiments: gfx950:xnack-)
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize"]
 # experiments / debug builds: SPCL_BUILD_DEFS="-DSPCL_CONV16_STAMPS_BUILD=1 -DSPCL_FAST_WIDE_STORES=0" (use with --force)
 FLAGS += os.environ.get("SPCL_BUILD_DEFS", "").split()
 # The first kernel-argument dwords arrive in SGPRs at wave launch (gfx950 kernarg preload) instead of through a scalar load:
@@ -70,7 +71,7 @@ def build(force=False, verbose=True):
                 print(f"[spcl build] compiled {src}")
     linked = False
     if jobs or force or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
