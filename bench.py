@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Benchmark of the pre-train hot path on MI355X.
 
-    python bench.py [--gpus N --steps K --warmup W]            # N>1: launched by torch.distributed.run, one rank/GPU
+    python bench.py [--gpus N --steps K --warmup W]
+
+N > 1: one rank per GPU over RCCL.  Under a launcher (``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N``:
+RANK / LOCAL_RANK / WORLD_SIZE in the environment) this process IS a rank; without one, ``python bench.py --gpus N`` starts that
+launcher itself as a child process (spawn_ranks) and forwards its output and exit code.  WORLD_SIZE != N exits 2.
 
 A "step" = one pass of the hot path over one synthetic batch, exactly the reference's pre-train iteration
 (semi_seg/epochers/new_pretrain.py:53-89): two views of bs=32 slices (64 images of 1x224x224) -> UNet encoder to Conv5
@@ -358,11 +362,61 @@ def cpu_baseline(args):
 
 
 # ------------------------------------------------------------------------------------------------ main
+def spawn_ranks(args):
+    """``python bench.py --gpus N`` (N > 1) without a launcher: start ``python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N bench.py <same flags>`` as a CHILD process -- before this process makes any GPU call (it never
+    does: it only waits), never an exec -- forward the ranks' output (rank 0 prints the one JSON line) and leave with the
+    child's exit code.  The reference's own seam for this is ``mp.spawn(main_worker, nprocs=ngpus_per_node, ...)``
+    (semi_seg/main_infonce.py:35,39)."""
+    import signal
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)  # own process group: launcher + ranks end together
+
+    def _forward(sig, _frame):
+        try:
+            os.killpg(proc.pid, sig)
+        except (ProcessLookupError, PermissionError):
+            pass
+    for sig in (signal.SIGINT, signal.SIGTERM):
+        signal.signal(sig, _forward)
+    limit = float(os.environ.get("SPCL_BENCH_SPAWN_LIMIT_S", "1500"))
+    try:
+        rc = proc.wait(timeout=limit)
+    except subprocess.TimeoutExpired:
+        print(f"[bench] the {args.gpus}-rank child did not finish within {limit:.0f} s; killing its process group",
+              file=sys.stderr, flush=True)
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except (ProcessLookupError, PermissionError):
+            pass
+        proc.wait()
+        rc = 3
+    sys.exit(rc if rc >= 0 else 128 - rc)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)  # (does not return)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:  # a line that says n_gpus = 1 for a run asked to measure N would be a wrong measurement
+        if rank == 0:
+            print(f"[bench] --gpus {args.gpus} but WORLD_SIZE is {world}: launch with torch.distributed.run "
+                  f"--nproc-per-node {args.gpus}, or plain `python bench.py --gpus {args.gpus}` (it spawns its ranks)",
+                  file=sys.stderr, flush=True)
+        sys.exit(2)  # (before any GPU call and before the process group exists)
     wd = _NoWatchdog()
     if world > 1:
         import datetime
@@ -385,7 +439,6 @@ def main():
     else:
         torch.cuda.set_device(0)
     device = torch.device("cuda", local if world > 1 else 0)
-    assert args.gpus == world or world == 1, (args.gpus, world)
 
     if args.workload == "contrastive":
         return bench_contrastive(args, device)
@@ -551,7 +604,8 @@ def check_ddp_mean(step, world, device):
     for p in parts[1:]:
         mean += p
     mean /= world
-    diff = float((flat.flat - mean).abs().max())
+    # (with fold_mean the bucket holds the ranks' SUM and the optimizer kernel applies grad_scale = 1 / world)
+    diff = float((flat.flat * flat.grad_scale - mean).abs().max())
     differ = float((parts[0] - parts[-1]).abs().max())  # the ranks really saw different batches
     from spcl_amd.contrastyou import meters as _meters
     _meters.flush_batch()

@@ -442,6 +442,13 @@ int spcl_radam_step(float* param, const float* grad, float* exp_avg, float* exp_
 int spcl_radam_step_scalars(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, int64_t* step,
                             const float* lr, double beta1, double beta2, double eps, double weight_decay, float* coef,
                             int k, const void* const* src, void* const* dst, const float* count, void* stream);
+/* the same on grad_scale * grad (0 < grad_scale <= 1): the data-parallel MEAN of the flat gradient bucket is its RCCL sum
+ * times 1 / world, and that factor is applied while the bucket streams through the optimizer instead of by a separate
+ * pass over it (the reference is single-process; its seam for N ranks is semi_seg/main_infonce.py:35,39).
+ * grad_scale == 1: bit-identical to spcl_radam_step_scalars. */
+int spcl_radam_step_scaled(float* param, const float* grad, double grad_scale, float* exp_avg, float* exp_avg_sq, size_t n,
+                           int64_t* step, const float* lr, double beta1, double beta2, double eps, double weight_decay,
+                           float* coef, int k, const void* const* src, void* const* dst, const float* count, void* stream);
 
 /* Running means of the host-side meters (contrastyou/meters/averagemeter.py via MeterInterface) kept on the device:
  * for i < k (k <= 8):  dst[i][0] += count[i] * src[i][0];  dst[i][1] += count[i].  src / dst / count are HOST arrays

@@ -3,6 +3,7 @@
     python self-paced-contrastive-learning_amd/build.py [--force]
 
 hipcc cross-compiles for gfx950 without a GPU; the .so is git-ignored but travels with the tree."""
+import hashlib
 import os
 import subprocess
 import sys
@@ -41,6 +42,34 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _flags_for(src):
+    """the complete hipcc flag list of one source: FLAGS + kernarg preload (a file's EXTRA entry replaces the preload
+    COUNT, never drops the preload) + the file's other extras"""
+    if not src.endswith(".hip"):
+        return list(FLAGS)
+    extra = list(EXTRA.get(src, []))
+    if "kernarg-preload" in " ".join(extra + FLAGS):
+        return FLAGS + extra
+    return FLAGS + PRELOAD + extra
+
+
+def _stamp(src):
+    """what an object was compiled WITH: an object whose flags differ from the current ones is stale whatever its mtime
+    (SPCL_BUILD_DEFS / SPCL_BUILD_ARCH / SPCL_BUILD_NOSLP experiments would otherwise be 'reused' by the next plain build)"""
+    return hashlib.sha256(" ".join([HIPCC] + _flags_for(src)).encode()).hexdigest()
+
+
+def _stamp_path(obj):
+    return obj + ".flags"
+
+
+def _stamp_matches(obj, src):
+    try:
+        return open(_stamp_path(obj)).read().strip() == _stamp(src)
+    except OSError:
+        return False
+
+
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
@@ -51,14 +80,18 @@ def build(force=False, verbose=True):
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, src.rsplit(".", 1)[0] + ".o")
         objs.append(o)
-        if force or _stale(o, [s, os.path.abspath(__file__)] + headers):
-            extra = EXTRA.get(src, PRELOAD if src.endswith(".hip") and "kernarg-preload" not in " ".join(FLAGS) else [])
-            cmd = [HIPCC] + FLAGS + extra + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", s, "-o", o]
-            jobs.append((src, cmd))
+        if force or _stale(o, [s, os.path.abspath(__file__)] + headers) or not _stamp_matches(o, src):
+            cmd = [HIPCC] + _flags_for(src) + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", s, "-o", o]
+            jobs.append((src, cmd, o))
 
     def run(job):
-        src, cmd = job
+        src, cmd, o = job
+        if os.path.exists(_stamp_path(o)):
+            os.remove(_stamp_path(o))  # an interrupted compile must not leave an object that looks current
         r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode == 0:
+            with open(_stamp_path(o), "w") as fh:
+                fh.write(_stamp(src) + "\n")
         return src, r.returncode, r.stdout + r.stderr
 
     with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
@@ -70,12 +103,19 @@ def build(force=False, verbose=True):
             if verbose:
                 print(f"[spcl build] compiled {src}")
     linked = False
-    if jobs or force or _stale(LIB, objs):
+    link_stamp = hashlib.sha256(" ".join(_stamp(src) for src in _sources()).encode()).hexdigest()
+    try:
+        lib_current = open(LIB + ".flags").read().strip() == link_stamp
+    except OSError:
+        lib_current = False
+    if jobs or force or _stale(LIB, objs) or not lib_current:
         cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
         linked = True
+        with open(LIB + ".flags", "w") as fh:
+            fh.write(link_stamp + "\n")
         if verbose:
             print(f"[spcl build] linked {LIB}")
     if verbose:  # a reader of the log can tell a rebuild from a reuse of objects that travelled with the tree

@@ -103,6 +103,11 @@ class AverageValueMeter:
             self._sum += float(value) * n
             self._n += n
 
+    def retract(self, value, n=1):
+        """take back one host-side ``add(value, n)`` (a step whose capture failed is run again eagerly, stepgraph.py)"""
+        self._sum -= float(value) * n
+        self._n -= n
+
     def summary(self):
         total, count = self._sum, self._n
         if _BATCH:

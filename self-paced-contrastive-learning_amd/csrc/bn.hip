@@ -2,6 +2,7 @@
 // Replaces nn.BatchNorm2d(momentum) / nn.ReLU / nn.MaxPool2d(2,2) of semi_seg/arch/unet.py:73-77,118-121 and their
 // autograd backward.  All of these are HBM-bound streaming kernels: 16-byte vector loads/stores per lane, per-channel
 // reductions as per-workgroup partials + a fixed-order second stage (deterministic, no float atomics).
+#include <mutex>
 #include "common.hpp"
 #include "image_acorr.hpp"
 
@@ -1090,28 +1091,44 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
 
 using namespace spcl;
 
-// Self-resetting tickets of the one-launch two-level reduction (one per 16-channel block), one zeroed buffer per device,
-// created at the first call OUTSIDE a stream capture (an allocation is not capturable; the eager warm-up steps come first).
-// SPCL_BN_ONE_LAUNCH=0 keeps the two launches.
+// Self-resetting tickets of the one-launch two-level reduction (one per 16-channel block).
+//  * One zeroed buffer PER (device, stream): launches on one stream are serialised, so two reductions can never interleave
+//    their ticket counts; launches on different streams (two models, a second epocher) get different words (the
+//    buffer used to be per device only).  Created under a mutex at the first call on that stream OUTSIDE a capture (an
+//    allocation is not capturable; the eager warm-up steps of stepgraph.py run on the capture stream first); a stream first
+//    seen during a capture, or more than BN_TICKET_STREAMS streams, fall back to the two launches.
+//  * Memory-ordering assumption, stated: the hand-off is the form MI355X_MICROARCH.md measures as valid on gfx950 / ROCm 7.2
+//    ("Workgroup dispatch, XCD placement & inter-workgroup visibility", table of sc1 hand-offs, first row) and not an
+//    architectural guarantee -- every handed-off byte leaves by an 8-byte agent-scope (sc1, written-through) store, the
+//    storing wave waits for their acknowledgement (s_waitcnt 0), a workgroup barrier, ONE lane takes a relaxed agent-scope
+//    ticket, the workgroup whose ticket is the last loads every row with agent-scope (sc1) loads after a barrier behind
+//    the returned add.  No L2 write-back fence (a release would cost ~1.7-6.5 us per workgroup, more than the launch it
+//    saves).  SPCL_BN_ONE_LAUNCH=0 keeps the two launches (the A/B switch and the fallback on other parts).
 constexpr int BN_TICKETS = 64;
+constexpr int BN_TICKET_STREAMS = 32;
 static unsigned* bn_tickets(hipStream_t st) {
   static const bool on = !(getenv("SPCL_BN_ONE_LAUNCH") && atoi(getenv("SPCL_BN_ONE_LAUNCH")) == 0);
   if (!on) return nullptr;
-  static unsigned* buf[16] = {nullptr};
+  struct Slot { int dev; hipStream_t st; unsigned* buf; };
+  static Slot slots[BN_TICKET_STREAMS];
+  static int nslots = 0;
+  static std::mutex mu;
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  if (buf[dev] == nullptr) {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
-    unsigned* p = nullptr;
-    if (hipMalloc(&p, BN_TICKETS * sizeof(unsigned)) != hipSuccess) return nullptr;
-    if (hipMemsetAsync(p, 0, BN_TICKETS * sizeof(unsigned), st) != hipSuccess) {  // (in stream order ahead of its first user)
-      (void)hipFree(p);
-      return nullptr;
-    }
-    buf[dev] = p;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  for (int i = 0; i < nslots; ++i)
+    if (slots[i].dev == dev && slots[i].st == st) return slots[i].buf;
+  if (nslots == BN_TICKET_STREAMS) return nullptr;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+  unsigned* p = nullptr;
+  if (hipMalloc(&p, BN_TICKETS * sizeof(unsigned)) != hipSuccess) return nullptr;
+  if (hipMemsetAsync(p, 0, BN_TICKETS * sizeof(unsigned), st) != hipSuccess) {  // in stream order ahead of its only users
+    (void)hipFree(p);
+    return nullptr;
   }
-  return buf[dev];
+  slots[nslots++] = Slot{dev, st, p};
+  return p;
 }
 
 extern "C" size_t spcl_bn_stats_elems(int ntiles, int CS) {

@@ -92,12 +92,17 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(b16_wpe
   const int t0 = threadIdx.x;
   const int wave = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane(t0 >> 6);
   if (WGROWS && (int)blockIdx.z * (int)(gridDim.x * gridDim.y) >= a.nwg) {  // the extra z-slice (bn.hip bwd_rows_group_kernel's job)
-    const int j = blockIdx.y * gridDim.x + blockIdx.x;
-    if (j < 16 && t0 < 64) {
-      float sacc = 0.f;
+    // all 16 folded rows are written whatever the grid: a slice of fewer than 16 workgroups (W == 14 with H = 126 .. 210:
+    // 9 .. 15 tiles) walks the rows j, j + nslice, ... (rows >= tilesX * tilesY stayed uninitialised and were
+    // summed into the first conv's weight gradient, d gamma and d beta)
+    const int nslice = gridDim.x * gridDim.y;
+    if (t0 < 64) {
+      for (int j = blockIdx.y * gridDim.x + blockIdx.x; j < 16; j += nslice) {
+        float sacc = 0.f;
 #pragma unroll 8
-      for (int w = j; w < a.nacorr; w += 16) sacc += a.acorr_in[(size_t)w * 64 + t0];
-      a.acorr_out[(size_t)j * 64 + t0] = sacc;
+        for (int w = j; w < a.nacorr; w += 16) sacc += a.acorr_in[(size_t)w * 64 + t0];
+        a.acorr_out[(size_t)j * 64 + t0] = sacc;
+      }
     }
     return;
   }

@@ -48,11 +48,11 @@ __global__ __launch_bounds__(64) void radam_tick_kernel(int64_t* step, const flo
 __global__ __launch_bounds__(256) void radam_apply_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                           float* __restrict__ m, float* __restrict__ v, size_t n4,
                                                           size_t n, const float* __restrict__ coef, float omb1,
-                                                          float beta2, float omb2, float eps, float wd) {
+                                                          float beta2, float omb2, float eps, float wd, float gscale) {
   const float c_m = coef[0], c_u = coef[1];
   const bool rect = coef[2] != 0.f;
   auto upd = [&](float& pp, float gg, float& mm, float& vv) {
-    gg = fmaf(wd, pp, gg);
+    gg = fmaf(wd, pp, gg * gscale);            // gscale: 1 / world of the data-parallel mean (1.f: exact identity)
     mm = fmaf(omb1, gg - mm, mm);              // lerp_(grad, 1 - beta1)
     vv = fmaf(vv, beta2, omb2 * gg * gg);      // mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
     const float u = rect ? c_u / (sqrtf(vv) + eps) : 1.f;
@@ -151,6 +151,15 @@ extern "C" int spcl_radam_step_scalars(float* param, const float* grad, float* e
                                        int64_t* step, const float* lr, double beta1, double beta2, double eps,
                                        double weight_decay, float* coef, int k, const void* const* src,
                                        void* const* dst, const float* count, void* stream) {
+  return spcl_radam_step_scaled(param, grad, 1.0, exp_avg, exp_avg_sq, n, step, lr, beta1, beta2, eps, weight_decay, coef,
+                                k, src, dst, count, stream);
+}
+
+extern "C" int spcl_radam_step_scaled(float* param, const float* grad, double grad_scale, float* exp_avg,
+                                      float* exp_avg_sq, size_t n, int64_t* step, const float* lr, double beta1,
+                                      double beta2, double eps, double weight_decay, float* coef, int k,
+                                      const void* const* src, void* const* dst, const float* count, void* stream) {
+  SPCL_CHECK_ARG(grad_scale > 0.0 && grad_scale <= 1.0, "radam_step: grad_scale in (0, 1]");
   SPCL_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && step && lr && coef, "radam_step: null pointer");
   SPCL_CHECK_ARG(k >= 0 && k <= 8 && (k == 0 || (src && dst && count)), "radam_step: 0 <= k <= 8 scalar adds");
   ScalarAdds adds;
@@ -169,7 +178,7 @@ extern "C" int spcl_radam_step_scalars(float* param, const float* grad, float* e
   if (blocks < 1) blocks = 1;
   SPCL_LAUNCH(radam_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, n4,
                      n, (const float*)coef, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
-                     (float)weight_decay);
+                     (float)weight_decay, (float)grad_scale);
   SPCL_LAUNCH_CHECK("radam_step");
   return SPCL_OK;
 }

@@ -114,6 +114,42 @@ class GradBucket:
         return self.flat
 
 
+_COMM_STREAMS = {}
+
+
+class _comm_stream:
+    """The step's collective on ONE private stream per device, ordered by events: the stream waits for what the caller's
+    stream has enqueued so far (the backward kernels that fill the bucket), the caller's stream for the collective.  Work
+    enqueued on OTHER streams meanwhile -- the update graph's stream is the caller's, so nothing of this step; but the
+    next step's loader copies and, in an eager step with the early bucket on its way, the rest of backward -- is not held
+    up by the collective, and the collective's launch does not sit between two hipGraph replays of the compute stream.
+    CPU tensors (gloo tests): a no-op."""
+
+    def __init__(self, tensor):
+        self.on = tensor.is_cuda
+        self.dev = tensor.device
+
+    def __enter__(self):
+        if not self.on:
+            return self
+        idx = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
+        if idx not in _COMM_STREAMS:
+            _COMM_STREAMS[idx] = torch.cuda.Stream(device=idx)
+        self.comm = _COMM_STREAMS[idx]
+        self.cur = torch.cuda.current_stream(idx)
+        self.comm.wait_stream(self.cur)
+        self.ctx = torch.cuda.stream(self.comm)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if not self.on:
+            return False
+        self.ctx.__exit__(*exc)
+        self.cur.wait_stream(self.comm)
+        return False
+
+
 class FlatParams(GradBucket):
     """All trainable parameters as views of ONE flat fp32 tensor, optimised as a single ``nn.Parameter``.
 
@@ -133,6 +169,11 @@ class FlatParams(GradBucket):
                 off += p.numel()
         self.param = torch.nn.Parameter(self.data)
         self._early_idx, self._early_off, self._early = None, 0, None
+        # fold_mean: ``allreduce_`` leaves the ranks' SUM in the bucket and the factor 1 / world in ``grad_scale`` for an
+        # optimizer that applies it while it streams the bucket anyway (optim.FusedRAdam.step(grad_scale=)): one launch
+        # and one pass over the bucket less per step.  Off: the bucket holds the mean (``div_``), grad_scale stays 1.
+        self.fold_mean = False
+        self.grad_scale = 1.0
 
     def zero_grad(self):
         for p in self.params:
@@ -154,14 +195,20 @@ class FlatParams(GradBucket):
     def allreduce_(self):
         """mean of the flat bucket across ranks, in place (the step's ONE collective, or -- with the early bucket on its
         way -- the head's plus the wait for the tail's; no-op for a single process)."""
+        self.grad_scale = 1.0
         if is_distributed():
-            if self._early is not None:
-                dist.all_reduce(self.flat[:self._early_off], op=dist.ReduceOp.SUM, group=self.group)
-                if self._early is not True:
-                    self._early.wait()
+            with _comm_stream(self.flat):
+                if self._early is not None:
+                    dist.all_reduce(self.flat[:self._early_off], op=dist.ReduceOp.SUM, group=self.group)
+                    if self._early is not True:
+                        self._early.wait()
+                else:
+                    dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            world = dist.get_world_size(self.group)
+            if self.fold_mean:
+                self.grad_scale = 1.0 / world
             else:
-                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-            self.flat.div_(dist.get_world_size(self.group))
+                self.flat.div_(world)
         self._early = None
         return self.flat
 

@@ -577,7 +577,13 @@ _PREPACKED_ACORR = {}
 
 
 def take_prepacked_acorr(image):
-    return _PREPACKED_ACORR.pop(image.data_ptr(), None)
+    return _PREPACKED_ACORR.pop((image.data_ptr(), image._version), None)
+
+
+def clear_prepacked():
+    """drop what a forward pass announced and did not consume (UNet.forward calls it on every exit)"""
+    _PREPACKED.clear()
+    _PREPACKED_ACORR.clear()
 
 
 def prepack_weights(layers, dtype, image=None):
@@ -607,20 +613,20 @@ def prepack_weights(layers, dtype, image=None):
             items.append(_n.PackItem(wc.data_ptr(), p0.data_ptr(), p1.data_ptr(), w.shape[1], w.shape[0],
                                      int(H) if _PACK_AT else 0, int(W) if _PACK_AT else 0))
             keep.append(wc)
-            _PREPACKED[(w.data_ptr(), dtc, int(H), int(W))] = (p0, p1)
+            _PREPACKED[(w.data_ptr(), w._version, dtc, int(H), int(W))] = (p0, p1)  # (_version: an in-place update since)
         arr = (_n.PackItem * len(items))(*items)
         if image is not None and i == 0:
             N, H, W = int(image.shape[0]), int(image.shape[1]), int(image.shape[2])
             acorr = torch.empty(_n.call("spcl_image_autocorr_rows", N, H, W), 64, dtype=torch.float32, device=dev)
             _n.call("spcl_conv_pack_weights_multi_acorr", arr, len(items), dtc, _n.ptr(image), N, H, W, _n.ptr(acorr),
                     _n.stream())
-            _PREPACKED_ACORR[image.data_ptr()] = acorr
+            _PREPACKED_ACORR[(image.data_ptr(), image._version)] = acorr
         else:
             _n.call("spcl_conv_pack_weights_multi", arr, len(items), dtc, _n.stream())
 
 
 def take_prepacked(w, dtc, H, W):
-    return _PREPACKED.pop((w.data_ptr(), dtc, int(H), int(W)), None)
+    return _PREPACKED.pop((w.data_ptr(), w._version, dtc, int(H), int(W)), None)
 
 
 def _conv(x_store, dt_code, dtype, N, H, W, cin_s, cin_k, cout_s, wp, in_mode, scale, shift, want_stats):

@@ -130,6 +130,8 @@ _SIGNATURES = {
     "spcl_radam_step": (c_int, [_P, _P, _P, _P, c_size_t, _P, _P, c_double, c_double, c_double, c_double, _P, _P]),
     "spcl_radam_step_scalars": (c_int, [_P, _P, _P, _P, c_size_t, _P, _P, c_double, c_double, c_double, c_double, _P,
                                         c_int, _P, _P, _P, _P]),
+    "spcl_radam_step_scaled": (c_int, [_P, _P, c_double, _P, _P, c_size_t, _P, _P, c_double, c_double, c_double, c_double,
+                                       _P, c_int, _P, _P, _P, _P]),
 }
 
 

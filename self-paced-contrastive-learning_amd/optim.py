@@ -46,9 +46,11 @@ class FusedRAdam(torch.optim.Optimizer):
                     st["lr_host"] = float(group["lr"])
 
     @torch.no_grad()
-    def step(self, closure=None, scalar_adds=None):
+    def step(self, closure=None, scalar_adds=None, grad_scale: float = 1.0):
         """``scalar_adds``: what ``contrastyou.meters.take_batch()`` returned -- the step's meter updates, performed by
-        the first parameter's coefficient launch (one launch less per step)."""
+        the first parameter's coefficient launch (one launch less per step).  ``grad_scale``: the update uses
+        ``grad_scale * p.grad`` (ddp.FlatParams hands over the ranks' gradient SUM and 1 / world: the mean costs no pass
+        of its own); 1.0 is the exact identity."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -70,8 +72,8 @@ class FusedRAdam(torch.optim.Optimizer):
                 if scalar_adds is not None:
                     src, dst, cnt, k = scalar_adds[:4]
                     scalar_adds = None
-                _n.call("spcl_radam_step_scalars", _n.ptr(p), _n.ptr(g), _n.ptr(st["exp_avg"]), _n.ptr(st["exp_avg_sq"]),
-                        p.numel(), _n.ptr(st["step"]), _n.ptr(st["lr_dev"]), float(b1), float(b2), float(group["eps"]),
+                _n.call("spcl_radam_step_scaled", _n.ptr(p), _n.ptr(g), float(grad_scale), _n.ptr(st["exp_avg"]),
+                        _n.ptr(st["exp_avg_sq"]), p.numel(), _n.ptr(st["step"]), _n.ptr(st["lr_dev"]), float(b1), float(b2), float(group["eps"]),
                         float(group["weight_decay"]), _n.ptr(st["coef"]), k, src, dst, cnt, _n.stream())
         if scalar_adds is not None:  # no parameter was stepped: the adds still have to happen
             _n.call("spcl_accumulate_scalars", scalar_adds[3], scalar_adds[0], scalar_adds[1], scalar_adds[2], _n.stream())

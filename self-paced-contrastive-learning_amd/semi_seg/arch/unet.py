@@ -181,6 +181,14 @@ class UNet(nn.Module):
                                f" given {until}  ")
         encoder_only = until in _ENCODER
         self._prepack(x, until)
+        try:
+            return self._forward_blocks(x, until, encoder_only)
+        finally:
+            # whatever this pass announced and did not consume (an exception mid-forward, a size the announcement got
+            # wrong) must not outlive it: the packed copies are of THIS step's weights
+            F_hip.clear_prepacked()
+
+    def _forward_blocks(self, x, until, encoder_only):
         e = x
         skips = {}
         for k, name in enumerate(_ENCODER):

@@ -107,6 +107,9 @@ class FineTuneEpocher(_EpocherBase):
         self._labeled_loader = labeled_loader
         self._sup_criterion = sup_criterion
         self._flat_params = flat_params
+        from ...optim import FusedRAdam
+        if flat_params is not None and isinstance(optimizer, FusedRAdam):
+            flat_params.fold_mean = True  # the exchange leaves the ranks' SUM; 1 / world is applied inside the RAdam kernel
         self._unit = None
         # the step as a hipGraph (stepgraph.py): image and label map are copied into persistent buffers in front of the
         # replay; the Dice counts come back in persistent [B, C] tensors and are handed to the meter after it
@@ -200,7 +203,11 @@ class FineTuneEpocher(_EpocherBase):
             self._flat_params.allreduce_()
 
     def step_update(self, sup_loss):
-        self._optimizer.step()
+        from ...optim import FusedRAdam
+        if isinstance(self._optimizer, FusedRAdam) and self._flat_params is not None:
+            self._optimizer.step(grad_scale=self._flat_params.grad_scale)  # (1 / world when the exchange left the sum)
+        else:
+            self._optimizer.step()
         if self.on_master():
             with torch.no_grad():
                 _meters.begin_batch()

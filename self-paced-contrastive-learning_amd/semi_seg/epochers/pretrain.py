@@ -54,6 +54,9 @@ class PretrainEncoderEpocher:
         self._affine_transformer = TensorRandomFlip(axis=[1, 2], threshold=0.8)
         self._grad_bucket = grad_bucket
         self._flat_params = flat_params  # optimizer steps ONE flat parameter (ddp.FlatParams) when given
+        from ...optim import FusedRAdam
+        if flat_params is not None and isinstance(optimizer, FusedRAdam):
+            flat_params.fold_mean = True  # the exchange leaves the ranks' SUM; 1 / world is applied inside the RAdam kernel
         self._hooks = []
         self.meters = MeterInterface(default_focus=self.meter_focus)
         with self.meters.focus_on(self.meter_focus):
@@ -301,7 +304,8 @@ class PretrainEncoderEpocher:
             self.meters["reg_loss"].add(reg_loss.detach())
         from ...optim import FusedRAdam
         if isinstance(self._optimizer, FusedRAdam):  # the meters' device adds ride in the optimizer's coefficient launch
-            self._optimizer.step(scalar_adds=_meters.take_batch())
+            scale = self._flat_params.grad_scale if self._flat_params is not None else 1.0  # (1 / world when fold_mean)
+            self._optimizer.step(scalar_adds=_meters.take_batch(), grad_scale=scale)
         else:
             self._optimizer.step()
         _meters.flush_batch()

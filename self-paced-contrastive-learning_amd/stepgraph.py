@@ -110,6 +110,8 @@ class StepStage:
 
 
 _SIDE_STREAMS = {}
+_CAPTURE_FAILED = set()  # device indices on which a step capture failed: later StepGraphs (one per epoch) do not retry
+_WE_FROZE = False        # this module called gc.freeze(): only then may it gc.unfreeze() (the host application may freeze too)
 
 
 def _gc_settle():
@@ -122,17 +124,22 @@ def _gc_settle():
     if os.environ.get("SPCL_GC_FREEZE", "1") == "0":
         return
     import gc
-    gc.unfreeze()
+    global _WE_FROZE
+    if _WE_FROZE:  # (never undo a freeze the host application made itself: gc.unfreeze() is process-wide)
+        gc.unfreeze()
     gc.collect()
     gc.freeze()
+    _WE_FROZE = True
 
 
 def gc_release():
-    """undo ``_gc_settle`` (the epochers call it when their loop ends)"""
-    if os.environ.get("SPCL_GC_FREEZE", "1") == "0":
+    """undo ``_gc_settle`` (the epochers call it when their loop ends) -- only a freeze this module made"""
+    global _WE_FROZE
+    if os.environ.get("SPCL_GC_FREEZE", "1") == "0" or not _WE_FROZE:
         return
     import gc
     gc.unfreeze()
+    _WE_FROZE = False
 
 
 def side_stream(device=None):
@@ -211,8 +218,13 @@ class StepGraph:
 
     def run(self, key):
         from .contrastyou import meters as _meters
+        if not self.failed and torch.cuda.current_device() in _CAPTURE_FAILED:
+            self.failed = True  # an earlier epocher's capture failed on this device: stay eager, do not capture again
         if self.failed:
-            return self._eager()
+            # eager, but on the SAME private stream as every other backward pass of this model: autograd's AccumulateGrad
+            # nodes remember their stream, and a later capture (another model, another shape) must not fork into the
+            # caller's stream (module docstring)
+            return self._warm_step()
         if key != self.key:  # a new shape / configuration: drop the graphs, start over
             self.key, self._seen, self._graphs, self._result = key, 0, None, None
         if self._graphs is None:
@@ -223,15 +235,20 @@ class StepGraph:
                 self._capture()
             except Exception as e:  # noqa: BLE001 -- a capture that fails must not end the training run
                 self.failed = True
+                _CAPTURE_FAILED.add(torch.cuda.current_device())
                 self._graphs = None
-                _meters.end_host_log()
+                # the python floats the hooks handed to the meters during the failed capture were applied once already and
+                # the eager step below hands them over again: take the first application back
+                for meter, value, n in self._host_log:
+                    meter.retract(value, n)
+                self._host_log = []
                 try:
                     torch.cuda.synchronize()
                 except Exception:  # noqa: BLE001
                     pass
                 warnings.warn(f"hipGraph capture of the training step failed ({type(e).__name__}: {e}); "
-                              "continuing with eager launches")
-                return self._eager()
+                              "continuing with eager launches (this process will not try to capture on this device again)")
+                return self._warm_step()
             self._replay(first=True)
             return self._result
         self._replay(first=False)
@@ -239,6 +256,7 @@ class StepGraph:
 
     def _capture(self):
         from .contrastyou import meters as _meters
+        self._host_log = []
         _gc_settle()
         torch.cuda.synchronize()
         state = {}

@@ -104,3 +104,34 @@ def test_product_path_has_no_cpu_fallback():
                 src = open(os.path.join(root, f)).read()
                 assert "oracle" not in src.replace("oracle.", "").replace("oracle", "oracle") or \
                     "import oracle" not in src and "from oracle" not in src, os.path.join(root, f)
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    """``bench.py --gpus N`` inside a launcher environment of another size exits 2 before any GPU call: a line that says
+    n_gpus = 1 for a run asked to measure N would be a wrong measurement (VERDICT r03 missing #1)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    assert "WORLD_SIZE is 1" in r.stderr and not r.stdout.strip()
+
+
+def test_bench_spawn_forwards_the_childs_exit_code(tmp_path):
+    """the N > 1 parent: starts ``python -m torch.distributed.run --nproc-per-node N bench.py <same flags>`` as a child and
+    leaves with its exit code.  Here (no GPU) the two ranks fail in ``torch.cuda.set_device``: the parent must come back
+    non-zero, promptly, with nothing on stdout."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("CPU-only check (on a GPU box tests/test_gpu_zz_bench_multirank.py runs the real thing)")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode not in (0, 2), (r.returncode, r.stderr[-800:])
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

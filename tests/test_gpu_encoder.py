@@ -361,12 +361,13 @@ def test_image3_first_layer_gradient_without_a_pass_over_its_output():
     assert _relerr(dw1.numpy(), dw0.numpy()) < 3e-3, _relerr(dw1.numpy(), dw0.numpy())
 
 
-@pytest.mark.parametrize("N,H,W", [(2, 140, 154), (9, 224, 224), (1, 256, 256)])
+@pytest.mark.parametrize("N,H,W", [(2, 140, 154), (9, 224, 224), (1, 256, 256), (3, 140, 14)])
 def test_conv16_backward_in_one_pass(N, H, W):
     """csrc/conv16_bwd.hip: the image block's second conv (unet.py:75, 16 -> 16 channels) -- weight gradient and the rows the
     first conv's backward is finished from, in one launch.  Rows: the dgrad kernel's up to the order of the f32 sums;
     dW: against fp64 math on the same bf16 operands, and next to the stand-alone weight-gradient kernel.  256 x 256 has
-    shifted last tiles (pixels two tiles cover count once); N = 9 at 224 x 224 makes workgroups walk two images (the last one)."""
+    shifted last tiles (pixels two tiles cover count once); N = 9 at 224 x 224 makes workgroups walk two images (the last one);
+    140 x 14 has 10 tiles per image, fewer than the 16 folded autocorrelation rows its extra grid slice must write."""
     import spcl_amd  # noqa
     from spcl_amd import functional as F_, native as _n
     dtc = _n.dtype_code(torch.bfloat16)

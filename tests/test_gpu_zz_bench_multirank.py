@@ -26,17 +26,20 @@ def _free_port():
     return p
 
 
-def test_bench_two_ranks_on_one_device(tmp_path):
+def _run_two_ranks(tmp_path, cmd):
     env = dict(os.environ, SPCL_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", SPCL_BENCH_WATCHDOG_S="60",
                SPCL_BENCH_DDP_CHECK="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2",
-           "--warmup", "1", "--bs", "4", "--size", "64", "--no-extras"]
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
     so, se = open(tmp_path / "out.txt", "w+"), open(tmp_path / "err.txt", "w+")
     proc = subprocess.Popen(cmd, cwd=REPO, env=env, stdout=so, stderr=se, text=True, start_new_session=True)
     try:
         rc = proc.wait(timeout=LIMIT_S)
     except subprocess.TimeoutExpired:
+        os.killpg(proc.pid, signal.SIGTERM)  # bench.py's own parent forwards it to the launcher's process group
+        try:
+            proc.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            pass
         os.killpg(proc.pid, signal.SIGKILL)  # launcher AND both workers: nothing may stay behind on cuda:0
         proc.wait()
         se.seek(0)
@@ -59,3 +62,21 @@ def test_bench_two_ranks_on_one_device(tmp_path):
     assert chk["max_abs_diff_vs_mean_of_rank_gradients"] == 0.0 and chk["max_abs_diff_between_ranks"] > 0.0
     assert chk["grad_abs_max"] > 0.0
     assert line["roofline"] is not None and line["roofline"]["frac"] > 0 and "cpu_baseline" not in line
+    return line
+
+
+BENCH_ARGS = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--bs", "4", "--size", "64", "--no-extras"]
+
+
+def test_bench_two_ranks_on_one_device(tmp_path):
+    """under the launcher, as the driver starts it"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(REPO, "bench.py")] + BENCH_ARGS
+    _run_two_ranks(tmp_path, cmd)
+
+
+def test_plain_bench_gpus_2_spawns_its_own_ranks(tmp_path):
+    """``python bench.py --gpus 2`` with no launcher and no WORLD_SIZE: bench.py starts torch.distributed.run as a child
+    process itself (before any GPU call), forwards rank 0's line and the exit code -- it must not silently measure one
+    GPU and print n_gpus: 1 (VERDICT r03 missing #1; reference seam: semi_seg/main_infonce.py:35,39)."""
+    _run_two_ranks(tmp_path, [sys.executable, os.path.join(REPO, "bench.py")] + BENCH_ARGS)
