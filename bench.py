@@ -164,18 +164,48 @@ def build_step(args, device, rank, world):
 
 
 # ------------------------------------------------------------------------------------------------ roofline (live)
-def measure_roofline(step, args, phases=False):
-    """Instrumented pass with the library's built-in kernel timer: every kernel launch of libspcl_hip.so is bracketed
-    by HIP events ON ITS LAUNCH STREAM (spcl_profile_* of the C ABI; eager launches, not the graph) and reported with
-    its kernel symbol -- the names rocprofv3 prints -- and the algorithmic bytes / FLOPs its entry point declares
-    (DESIGN.md section 3).  Returns the roofline of the kernel symbol with the largest total time and a breakdown."""
+def _read_profile_log(lo, hi):
+    """entries lo .. hi - 1 of the library's launch log as (kernel symbol, seconds, algorithmic bytes, FLOPs)"""
     import ctypes
     from spcl_amd import native
+    name = ctypes.create_string_buffer(256)
+    us, by, fl = ctypes.c_float(), ctypes.c_double(), ctypes.c_double()
+    out = []
+    for i in range(lo, hi):
+        native.call("spcl_profile_get", i, name, 256, ctypes.byref(us), ctypes.byref(by), ctypes.byref(fl))
+        out.append((name.value.decode(), us.value * 1e-6, by.value, fl.value))
+    return out
+
+
+def _pmc_table():
+    """HBM bytes per launch by kernel symbol: NOT measured in this run -- read from the newest committed PMC passes of
+    profiles/ (tools/pmc_traffic.py: separate rocprofv3 --pmc runs, 2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes)"""
+    try:
+        import glob
+        latest = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_hbm_traffic.json")))[-1]  # newest round
+        return json.load(open(latest)), os.path.relpath(latest, REPO)
+    except Exception:  # noqa: BLE001
+        return {}, None
+
+
+def measure_roofline(step, args, phases=False, graph=False):
+    """Instrumented pass with the library's built-in kernel timer: every kernel launch of libspcl_hip.so is bracketed
+    by HIP events ON ITS LAUNCH STREAM (spcl_profile_* of the C ABI) and reported with its kernel symbol -- the names
+    rocprofv3 prints -- and the algorithmic bytes / FLOPs its entry point declares.
+
+    ``graph=True`` (the timed configuration, N = 1): the epocher captures its step ANEW with the timer on, so the event
+    records become nodes of the hipGraph between the kernel nodes; the durations read are those of the launches INSIDE a
+    replayed step, the configuration `value` was measured in and `rocprofv3 --kernel-trace` of this command sees
+    (profiles/rNN_kernel_stats_bench_graph.csv).  ``graph=False`` (N > 1 on rank 0, --no-graph, or when the events of a
+    capture cannot be read on this stack): eager launches, ~5-10 % longer per kernel.
+    Returns the roofline of the kernel symbol with the largest total time per step, a breakdown, the step's kernel time."""
+    from spcl_amd import native
     reps = 5
+    epocher = getattr(step, "epocher", None)
     step()
     torch.cuda.synchronize()
     native.call("spcl_profile_enable", 1)
-    marks, epocher, orig_fwd = [], getattr(step, "epocher", None), None
+    marks, orig_fwd = [], None
     if phases and epocher is not None:  # launch-log index where the encoder forward of each instrumented step ends
         orig_fwd = epocher._forward_pass
 
@@ -185,75 +215,120 @@ def measure_roofline(step, args, phases=False):
             marks.append((start, native.call("spcl_profile_count")))
             return out
         epocher._forward_pass = marked_forward
+    source = "eager launches"
     try:
-        for _ in range(reps):
-            step()
-        torch.cuda.synchronize()
-        n = native.call("spcl_profile_count")
-        name = ctypes.create_string_buffer(256)
-        us, by, fl = ctypes.c_float(), ctypes.c_double(), ctypes.c_double()
-        groups = {}
-        launches = []
-        for i in range(n):
-            native.call("spcl_profile_get", i, name, 256, ctypes.byref(us), ctypes.byref(by), ctypes.byref(fl))
-            launches.append((name.value.decode(), us.value * 1e-6, by.value, fl.value))
-            g = groups.setdefault(name.value.decode(), {"t": 0.0, "n": 0, "bytes": 0.0, "flops": 0.0, "roof": 0.0,
-                                                        "hbm_t": 0.0, "mfma_t": 0.0})
-            g["t"] += us.value * 1e-6
-            g["n"] += 1
-            g["bytes"] += by.value
-            g["flops"] += fl.value
-            peak_tf = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
-            hbm_t, mfma_t = by.value / (HBM_PEAK_GBS * 1e9), fl.value / (peak_tf * 1e12)
-            g["roof"] += max(hbm_t, mfma_t)
-            g["hbm_t"] += hbm_t
-            g["mfma_t"] += mfma_t
+        launches = None
+        if graph and epocher is not None and epocher._step_graph is not None and epocher._step_graph.captured:
+            from spcl_amd import stepgraph as _sg
+            old = epocher._step_graph
+            try:
+                epocher._step_graph = _sg.StepGraph(old._compute, old._exchange, old._update, split=old._split)
+                lo = hi = 0
+                for _ in range(6):  # two warm steps, then the capture (its launches are log entries lo .. hi - 1)
+                    lo = native.call("spcl_profile_count")
+                    step()
+                    hi = native.call("spcl_profile_count")
+                    if epocher._step_graph.captured:
+                        break
+                if not epocher._step_graph.captured or hi <= lo:
+                    raise RuntimeError("the instrumented step was not captured")
+                for _ in range(reps):  # every replay re-records the capture's events; the last replay's times are read
+                    step()
+                torch.cuda.synchronize()
+                launches = _read_profile_log(lo, hi)
+                marks = [(a - lo, b - lo) for a, b in marks if lo <= a and b <= hi]
+                if not launches or min(l[1] for l in launches) <= 0.0:
+                    raise RuntimeError("events recorded inside the capture returned no time")
+                reps_read = 1
+                source = "hipGraph replay (event-record nodes between the kernel nodes of the captured step)"
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench] in-graph kernel timing unavailable ({type(e).__name__}: {e}); eager launches instead",
+                      file=sys.stderr)
+                launches, marks = None, []
+                native.call("spcl_profile_enable", 1)  # (clears the log)
+            finally:
+                # the product graph comes back; the instrumented one (its event nodes would stay in every replay) is dropped
+                epocher._step_graph = old
+        if launches is None:
+            if graph and epocher is not None:
+                epocher._graph_on = False  # every kernel launched eagerly for the rest of this process's roofline pass
+            for _ in range(reps):
+                step()
+            torch.cuda.synchronize()
+            launches = _read_profile_log(0, native.call("spcl_profile_count"))
+            reps_read = reps
     finally:
         native.call("spcl_profile_enable", 0)
         if orig_fwd is not None:
             del epocher._forward_pass  # (the instance attribute shadowing the method)
+    reps = reps_read
+    peak_tf = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+    groups = {}
+    for sym, t, by, fl in launches:
+        g = groups.setdefault(sym, {"t": 0.0, "n": 0, "bytes": 0.0, "flops": 0.0, "roof": 0.0, "hbm_t": 0.0, "mfma_t": 0.0})
+        hbm_t, mfma_t = by / (HBM_PEAK_GBS * 1e9), fl / (peak_tf * 1e12)
+        g["t"] += t
+        g["n"] += 1
+        g["bytes"] += by
+        g["flops"] += fl
+        g["roof"] += max(hbm_t, mfma_t)
+        g["hbm_t"] += hbm_t
+        g["mfma_t"] += mfma_t
     total = sum(g["t"] for g in groups.values()) / reps
     ranked = sorted(groups.items(), key=lambda kv: -kv[1]["t"])
-    out = None
+    pmc, pmc_src = _pmc_table()
+
+    def describe(sym, g):
+        avg = g["t"] / g["n"]
+        traffic = pmc.get(sym, {}).get("hbm_bytes_per_launch_corrected")
+        if g["hbm_t"] >= g["mfma_t"]:
+            ach = g["bytes"] / g["t"] / 1e9
+            d = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic}
+        else:
+            ach = g["flops"] / g["t"] / 1e12
+            d = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak_tf, "unit": "TFLOP/s",
+                 "frac": round(ach / peak_tf, 4), "traffic": traffic}
+        abytes = g["bytes"] / g["n"]
+        d.update({"kernel": sym, "avg_us": round(avg * 1e6, 2), "launches_per_step": g["n"] / reps,
+                  "us_per_step": round(g["t"] / reps * 1e6, 1),
+                  "algorithmic_bytes_per_launch": int(abytes),
+                  "algorithmic_flops_per_launch": float(g["flops"] / g["n"]),
+                  "GBps": round(g["bytes"] / g["t"] / 1e9, 0), "mfma_tflops": round(g["flops"] / g["t"] / 1e12, 1),
+                  "mixed_roofline_frac": round(g["roof"] / g["t"], 4),
+                  "pmc_traffic_over_algorithmic": (round(traffic / abytes, 3) if traffic and abytes > 0 else None),
+                  "share_of_instrumented_step": round(g["t"] / reps / total, 4)})
+        return d
+    out, top3 = None, []
     for sym, g in ranked:
         if g["bytes"] <= 0:
             continue  # kernels without a declared cost (latency-bound glue) cannot carry a roofline
-        avg = g["t"] / g["n"]
-        peak_tf = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
-        traffic, latest = None, None
-        try:  # HBM bytes per launch: NOT measured in this run -- read from the committed PMC passes of profiles/
-            # (tools/pmc_traffic.py: separate rocprofv3 --pmc runs, 2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes)
-            import glob
-            latest = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_hbm_traffic.json")))[-1]  # newest round
-            traffic = json.load(open(latest))[sym]["hbm_bytes_per_launch_corrected"]
-        except Exception:  # noqa: BLE001
-            pass
-        if g["hbm_t"] >= g["mfma_t"]:
-            ach = g["bytes"] / g["t"] / 1e9
-            out = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic}
-        else:
-            ach = g["flops"] / g["t"] / 1e12
-            out = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak_tf, "unit": "TFLOP/s",
-                   "frac": round(ach / peak_tf, 4), "traffic": traffic}
-        out.update({"kernel": sym, "traffic_source": (os.path.relpath(latest, REPO) + " (committed PMC profile, not this run)"
-                                                      if traffic is not None else None),
-                    "avg_us": round(avg * 1e6, 2), "launches_per_step": g["n"] / reps,
-                    "algorithmic_bytes_per_launch": int(g["bytes"] / g["n"]),
-                    "algorithmic_flops_per_launch": float(g["flops"] / g["n"]),
-                    "mfma_tflops": round(g["flops"] / g["t"] / 1e12, 1),
-                    "mixed_roofline_frac": round(g["roof"] / g["t"], 4),
-                    "share_of_instrumented_step": round(g["t"] / reps / total, 4),
-                    "note": "kernel symbol with the largest total time among the library's launches in one step "
-                            "(eager pass, HIP events on the launch stream via spcl_profile_*); bytes/FLOPs are the "
-                            "algorithmic figures of DESIGN.md section 3 summed over its launches"})
-        break
+        d = describe(sym, g)
+        if out is None:
+            out = dict(d)
+            out.update({"traffic_source": (pmc_src + " (committed PMC profile, not this run)"
+                                           if d["traffic"] is not None else None),
+                        "timing_source": source,
+                        "note": "kernel symbol with the largest total time among the library's launches in one step (the "
+                                "ranking rocprofv3 --stats makes), HIP events on the launch stream via spcl_profile_*; bytes "
+                                "/ FLOPs are the algorithmic figures of DESIGN.md section 3 summed over its launches; frac "
+                                "is against the roofline that bounds it (bound), mixed_roofline_frac against max(bytes / "
+                                "8 TB/s, FLOPs / peak) per launch"})
+        top3.append(d)
+        if len(top3) == 3:
+            break
     breakdown = [{"kernel": k, "us_per_step": round(g["t"] / reps * 1e6, 1), "launches": g["n"] / reps,
                   "GBps": round(g["bytes"] / g["t"] / 1e9, 0) if g["bytes"] > 0 else None,
                   "TFLOPs": round(g["flops"] / g["t"] / 1e12, 1) if g["flops"] > 0 else None} for k, g in ranked[:16]]
+    small = [l for l in launches if l[1] < 8e-6]
+    tax = {"launches_per_step": len(launches) / reps, "launches_under_8us": len(small) / reps,
+           "their_us_per_step": round(sum(l[1] for l in small) / reps * 1e6, 1), "timing_source": source}
     if not phases:
         return out, breakdown, total
-    return out, breakdown, total, phase_fractions(launches, marks, reps, args)
+    fr = phase_fractions(launches, marks, reps, args)
+    fr["top3"] = top3
+    fr["launch_tax"] = tax
+    return out, breakdown, total, fr
 
 
 def phase_fractions(launches, marks, reps, args):
@@ -299,12 +374,11 @@ def phase_fractions(launches, marks, reps, args):
                             "survey_mixed_frac": None if survey_us is None else round(survey_us * 1e-6 / t_fwd, 4),
                             "mfma_util": round(fl_fwd / t_fwd / peak, 4), "gflop": round(fl_fwd / 1e9, 1),
                             "per_layer": layers,
-                            "note": "sum of the kernel durations between the start of UNet.forward and its return (eager "
-                                    "instrumented pass, HIP events per launch); mixed_frac = sum of max(bytes / 8 TB/s, "
+                            "note": "sum of the kernel durations between the start of UNet.forward and its return (the "
+                                    "instrumented pass of `roofline`, HIP events per launch: see its timing_source); mixed_frac = sum of max(bytes / 8 TB/s, "
                                     "FLOPs / peak) over ALL those launches (BatchNorm passes included) / that time; "
                                     "survey_mixed_frac = the same bound over the ten convolutions only (SURVEY 8d: 90.8 us "
-                                    "at N=64 224^2 bf16) / that time.  Eager kernel durations run ~10 % above the same "
-                                    "kernels inside the replayed graph (profiles/r03_step_timeline.txt)"}}
+                                    "at N=64 224^2 bf16) / that time"}}
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
@@ -562,12 +636,22 @@ def main():
             if args.ddp_overlap:  # the instrumented steps run on this rank alone: no early collective from backward
                 from spcl_amd import ddp as _ddp
                 _ddp.disable_unet_overlap(step.flat, step.model)
-            roof, breakdown, tot, fractions = measure_roofline(local_step(step), args, phases=True)
+            in_graph = world == 1 and bool(used_graph) and os.environ.get("SPCL_BENCH_GRAPH_EVENTS", "1") != "0"
+            if in_graph:  # the timed configuration itself: kernel durations inside a replayed step (see measure_roofline)
+                roof, breakdown, tot, fractions = measure_roofline(step, args, phases=True, graph=True)
+            else:
+                roof, breakdown, tot, fractions = measure_roofline(local_step(step), args, phases=True)
             line["roofline"] = roof
             line["kernel_breakdown"] = breakdown
             line["instrumented_step_ms"] = round(tot * 1e3, 3)
             if fractions:
                 fractions["step_mixed_frac"] = round(fractions.pop("_step_roof_s") / (ms * 1e-3), 4)
+                enc = fractions.get("encoder_fwd") or {}
+                if enc.get("survey_bound_us"):
+                    # the ten convolutions' sum of max(bytes / 8 TB/s, FLOPs / peak) forward (90.8 us at N = 64,
+                    # 224^2, bf16), x 3 for forward + input gradient + weight gradient, against the TIMED step
+                    fractions["step_survey_frac"] = round(3.0 * enc["survey_bound_us"] * 1e-3 / ms, 4)
+                    fractions["step_survey_bound_us"] = round(3.0 * enc["survey_bound_us"], 1)
                 line.setdefault("extra", {}).update(fractions)
         except Exception as e:  # noqa: BLE001
             line["roofline"] = None
@@ -581,12 +665,47 @@ def main():
             line.setdefault("extra", {})["contrastive_4096x128"] = contrastive_numbers(device, steps=50, warmup=10)
         except Exception as e:  # noqa: BLE001
             print(f"[bench] contrastive extra failed: {type(e).__name__}: {e}", file=sys.stderr)
+    if rank == 0 and world == 1 and not args.no_extras and args.dtype == "bf16" and args.workload == "pretrain":
+        try:  # the reference's own arithmetic end to end (fp32 storage, exact-f32 MFMA): a short pass of the same step
+            line.setdefault("extra", {})["fp32_step"] = fp32_numbers(args, device)
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] fp32 extra failed: {type(e).__name__}: {e}", file=sys.stderr)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def fp32_numbers(args, device, steps=12, warmup=4):
+    """`--dtype fp32` in short: the same pre-train step with fp32 storage and the exact-f32 MFMA path (the parity mode, the
+    reference's own arithmetic), through the same epocher and its hipGraph, fresh batches per step."""
+    import copy
+    a = copy.copy(args)
+    a.dtype = "fp32"
+    step, epocher, _ = build_step(a, device, 0, 1)
+    for _ in range(4):
+        step()
+        if epocher._step_graph is not None and epocher._step_graph.captured:
+            break
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    sg = epocher._step_graph
+    out = {"ms_per_step": round(dt * 1e3, 4), "slices_s": round(a.bs / dt, 1), "steps": steps,
+           "hipgraph": bool(sg is not None and sg.captured), "dtype": "fp32",
+           "note": "same workload, fp32 storage + v_mfma_f32_16x16x4_f32 (exact f32, 1/16 of the bf16 matrix rate)"}
+    from spcl_amd import stepgraph as _sg
+    _sg.gc_release()
+    del step, epocher
+    torch.cuda.empty_cache()
+    return out
 
 
 def check_ddp_mean(step, world, device):

@@ -471,6 +471,15 @@ int spcl_stage_bytes(void* dst, const void* host_src, size_t nbytes, void* strea
  * out [nviews][OH][OW] f32.  Geometry is integer arithmetic: bit-exact against oracle.augment_view. */
 int spcl_augment_views(const float* src, int S, int HS, int WS, const int* params, int nviews, float* out, int OH,
                        int OW, void* stream);
+/* The same recipe in PIL's own arithmetic -- what semi_seg/augment.py:6-22 computes through torchvision on 8-bit slices:
+ * Image.rotate(angle, NEAREST) (Geometry.c affine_fixed: 16.16 coefficients a0..a5 rounded on the host as PIL rounds them),
+ * transposes, crop, ImageEnhance.Brightness / .Contrast (Image.blend on 8-bit values, truncating; Contrast against
+ * int(mean + 0.5)), ToTensor (/ 255).  src holds 8-bit grey levels as k / 255.  params: device int32 [nviews][12] =
+ * {slice, a0, a1, a2, a3, a4, a5, flags (1 hflip, 2 vflip, 4 contrast before brightness), crop top, crop left, brightness
+ * (f32 bits), contrast (f32 bits)}.  Bit-exact against PIL itself: tests/golden/g9_augment.npz (tools/gen_golden.py augment),
+ * oracle.augment_view_pil. */
+int spcl_augment_views_pil(const float* src, int S, int HS, int WS, const int* params, int nviews, float* out, int OH,
+                           int OW, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Per-sample random flips of an NCHW batch (TensorRandomFlip(axis=[1,2], threshold=0.8), new_epocher.py:112, applied

@@ -566,3 +566,66 @@ def augment_view(img, row, out_hw):
     if contrast_first:
         u = np.clip(b * u, zero, one)
     return u.astype(np.float32)
+
+
+def pil_affine_q16(angle: float, ws: int, hs: int):
+    """The six 16.16 coefficients PIL's ``Image.rotate(angle, NEAREST)`` hands its nearest-neighbour affine loop
+    (PIL/Image.py ``rotate``: matrix from ``-radians(angle)``, entries ``round(.., 15)``, centre (w/2, h/2); Geometry.c
+    ``affine_fixed``: ``FIX(v) = floor(v * 65536 + 0.5)``, the half-pixel offset folded into a2 / a5).  torchvision's
+    ``RandomRotation`` (semi_seg/augment.py:9) forwards to exactly this call."""
+    import math
+    a = -math.radians(angle % 360.0)
+    m = [round(math.cos(a), 15), round(math.sin(a), 15), 0.0, round(-math.sin(a), 15), round(math.cos(a), 15), 0.0]
+    cx, cy = ws / 2, hs / 2
+    m[2] = m[0] * (-cx) + m[1] * (-cy) + m[2]
+    m[5] = m[3] * (-cx) + m[4] * (-cy) + m[5]
+    m[2] += cx
+    m[5] += cy
+    fix = lambda v: int(math.floor(v * 65536.0 + 0.5))  # noqa: E731
+    return [fix(m[0]), fix(m[1]), fix(m[2] + m[0] * 0.5 + m[1] * 0.5), fix(m[3]), fix(m[4]),
+            fix(m[5] + m[3] * 0.5 + m[4] * 0.5)]
+
+
+def augment_view_pil(img_u8, row, out_hw):
+    """One augmented view in PIL's own arithmetic (semi_seg/augment.py:6-22 as torchvision executes it on an 8-bit 'L'
+    image): ``img_u8`` [H,W] uint8 numpy, ``row`` = [slice, a0, a1, a2, a3, a4, a5, flags, top, left, brightness bits,
+    contrast bits] (``pil_affine_q16``; flags 1 hflip, 2 vflip, 4 contrast before brightness).  Returns float32 [oh,ow] =
+    ToTensor of the 8-bit result.  Pinned to PIL itself by tests/golden/g9_augment.npz (tools/gen_golden.py augment).
+
+      rotate   Geometry.c affine_fixed: xin = (a2 + x a0 + y a1) >> 16, yin = (a5 + x a3 + y a4) >> 16, 0 outside
+      flips    Image.transpose; crop: Image.crop -- index arithmetic composed in front of the rotation
+      colour   ImageEnhance.Brightness / Contrast = Image.blend(degenerate, image, f): float32 in1 + f * (in2 - in1),
+               truncated to 8 bits (clipped when f is outside [0, 1]); degenerate = black / int(mean + 0.5)"""
+    import struct
+    import numpy as np
+    hs, ws = img_u8.shape
+    oh, ow = out_hw
+    _, a0, a1, a2, a3, a4, a5, flags, top, left, bb, cb = [int(v) for v in row]
+    b = np.float32(struct.unpack("<f", struct.pack("<i", bb))[0])
+    c = np.float32(struct.unpack("<f", struct.pack("<i", cb))[0])
+    ii, jj = np.meshgrid(np.arange(oh, dtype=np.int64), np.arange(ow, dtype=np.int64), indexing="ij")
+    y, x = ii + top, jj + left
+    if flags & 1:
+        x = ws - 1 - x
+    if flags & 2:
+        y = hs - 1 - y
+    xin, yin = (a2 + x * a0 + y * a1) >> 16, (a5 + x * a3 + y * a4) >> 16
+    ok = (xin >= 0) & (xin < ws) & (yin >= 0) & (yin < hs)
+    u = np.where(ok, img_u8[np.clip(yin, 0, hs - 1), np.clip(xin, 0, ws - 1)], 0).astype(np.int64)
+
+    def blend(in1, in2, alpha):
+        t = in1.astype(np.float32) + alpha * (in2 - in1).astype(np.float32)  # float32 product, float32 sum
+        if np.float32(0) <= alpha <= np.float32(1):
+            return t.astype(np.int64)
+        return np.where(t <= 0, 0, np.where(t >= 255, 255, t.astype(np.int64)))
+
+    def brightness(u):
+        return blend(np.zeros_like(u), u, b)
+
+    def contrast(u):
+        mean = (2 * int(u.sum()) + u.size) // (2 * u.size)  # int(mean + 0.5)
+        return blend(np.full_like(u, mean), u, c)
+
+    u = brightness(contrast(u)) if flags & 4 else contrast(brightness(u))
+    return (u.astype(np.float32) / np.float32(255)).astype(np.float32)
+

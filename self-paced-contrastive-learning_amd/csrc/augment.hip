@@ -133,9 +133,86 @@ __global__ __launch_bounds__(1024) void augment_views_kernel(const float* __rest
   }
 }
 
+// The same recipe in PIL's OWN arithmetic (what the reference's DataLoader workers compute on 8-bit slices,
+// semi_seg/augment.py:6-22 through torchvision -> PIL): bit-exact against tests/golden/g9_augment.npz, which PIL itself wrote.
+//   * RandomRotation = Image.rotate(angle, NEAREST) = ImagingTransformAffine's fixed-point nearest path (Geometry.c
+//     affine_fixed): xin = (a2 + x a0 + y a1) >> 16, yin = (a5 + x a3 + y a4) >> 16 with the six 16.16 coefficients rounded
+//     from the double-precision matrix on the host exactly as PIL rounds them (semi_seg/data/augment.py pil_affine_q16);
+//     0 outside.  Flips and the crop are index arithmetic in front of it (output -> cropped -> unflipped -> rotated).
+//   * ColorJitter on a one-channel image = ImageEnhance.Brightness / .Contrast = Image.blend(degenerate, image, factor) on
+//     8-bit values: float(in1) + factor * float(in2 - in1) in f32 (product and sum rounded separately), TRUNCATED to 8 bits
+//     (clipped to [0, 255] when the factor extrapolates); Brightness blends with black, Contrast with the image's mean grey
+//     level int(mean + 0.5) taken right before the contrast step.  Saturation and hue are the identity on one channel.
+//   * ToTensor: value / 255 in f32.
+//   params[v] = {slice, a0, a1, a2, a3, a4, a5, flags (1 hflip, 2 vflip, 4 contrast before brightness), top, left,
+//                brightness (f32 bits), contrast (f32 bits)};  the store holds 8-bit grey levels as k / 255 (k = round(255 v)).
+__device__ __forceinline__ int pil_blend(int in1, int in2, float alpha, bool interpolate) {
+  const float t = __fadd_rn((float)in1, __fmul_rn(alpha, (float)(in2 - in1)));  // no contraction: PIL's C rounds both
+  if (interpolate) return (int)t;  // 0 <= alpha <= 1: (UINT8) of a value already inside [0, 255]
+  return t <= 0.f ? 0 : (t >= 255.f ? 255 : (int)t);
+}
+
+__global__ __launch_bounds__(1024) void augment_views_pil_kernel(const float* __restrict__ src, int S, int HS, int WS,
+                                                                 const int* __restrict__ params, float* __restrict__ out,
+                                                                 int OH, int OW) {
+  __shared__ int red[16];
+  const int v = blockIdx.x;
+  const int* pr = params + v * 12;
+  const int slice = pr[0], a0 = pr[1], a1 = pr[2], a2 = pr[3], a3 = pr[4], a4 = pr[5], a5 = pr[6], flags = pr[7];
+  const int top = pr[8], left = pr[9];
+  const float b = __int_as_float(pr[10]), c = __int_as_float(pr[11]);
+  const bool b_in = b >= 0.f && b <= 1.f, c_in = c >= 0.f && c <= 1.f;
+  const float* img = src + (size_t)slice * HS * WS;
+  const bool contrast_first = flags & 4;
+  auto sample = [&](int p) -> int {
+    const int i = p / OW, j = p - i * OW;
+    int y = i + top, x = j + left;           // position in the rotated + flipped image (same size as the slice)
+    if (flags & 1) x = WS - 1 - x;           // undo the horizontal flip
+    if (flags & 2) y = HS - 1 - y;           // undo the vertical flip
+    const int xin = (a2 + x * a0 + y * a1) >> 16, yin = (a5 + x * a3 + y * a4) >> 16;
+    if (!(xin >= 0 && xin < WS && yin >= 0 && yin < HS)) return 0;
+    return (int)__fadd_rn(__fmul_rn(img[(size_t)yin * WS + xin], 255.f), 0.5f);  // the 8-bit grey level of the store
+  };
+  const int np = OH * OW;
+  int part = 0;
+  for (int p = threadIdx.x; p < np; p += 1024) {
+    int u = sample(p);
+    if (!contrast_first) u = pil_blend(0, u, b, b_in);
+    part += u;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+  __syncthreads();
+  long long total = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) total += red[w];
+  const int mean = (int)((2 * total + np) / (2LL * np));  // int(sum / count + 0.5), exactly
+  float* o = out + (size_t)v * np;
+  for (int p = threadIdx.x; p < np; p += 1024) {
+    int u = sample(p);
+    if (!contrast_first) u = pil_blend(0, u, b, b_in);
+    u = pil_blend(mean, u, c, c_in);
+    if (contrast_first) u = pil_blend(0, u, b, b_in);
+    o[p] = __fdiv_rn((float)u, 255.f);
+  }
+}
+
 }  // namespace spcl
 
 using namespace spcl;
+
+extern "C" int spcl_augment_views_pil(const float* src, int S, int HS, int WS, const int* params, int nviews, float* out,
+                                      int OH, int OW, void* stream) {
+  SPCL_CHECK_ARG(src && params && out, "augment_views_pil: null pointer");
+  SPCL_CHECK_ARG(S > 0 && HS > 0 && WS > 0 && nviews > 0 && OH > 0 && OW > 0 && OH <= HS && OW <= WS && HS <= 4096 &&
+                     WS <= 4096,
+                 "augment_views_pil: bad shape (crop %dx%d of %dx%d)", OH, OW, HS, WS);
+  SPCL_LAUNCH(augment_views_pil_kernel, dim3(nviews), dim3(1024), 0, (hipStream_t)stream, src, S, HS, WS, params, out, OH,
+              OW);
+  SPCL_LAUNCH_CHECK("augment_views_pil");
+  return SPCL_OK;
+}
 
 extern "C" int spcl_augment_views(const float* src, int S, int HS, int WS, const int* params, int nviews, float* out,
                                   int OH, int OW, void* stream) {

@@ -776,6 +776,7 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
     return true;
   }
   if (c.CinS != c.CinK) return false;
+  if (launch_conv_stream(c, th, st, dry)) return true;
   const int ntn = c.CoutS / 16, KC = conv_kc(c.CinK);
   static const int env_nt1 = getenv("SPCL_CONV_FAST_NT1") ? atoi(getenv("SPCL_CONV_FAST_NT1")) : 0;
   int NT = ntn >= 2 ? 2 : 1;

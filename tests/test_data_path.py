@@ -112,3 +112,46 @@ def test_sampler_and_partitions_against_the_reference_fixture(golden, kind):
         random.seed(11)
         assert [O.contrast_batch_indices(want_scans, want_parts, scan_num, part_num, bool(shuffle))
                 for _ in range(25)] == want, (kind, si)
+
+
+def test_oracle_augment_view_pil_is_pinned_to_pil():
+    """oracle.augment_view_pil -- the restatement the HIP kernel `spcl_augment_views_pil` is tested against -- reproduces, bit
+    for bit, the 60 views of tests/golden/g9_augment.npz that PIL itself produced (tools/gen_golden.py augment: the PIL calls
+    torchvision's RandomRotation / flips / RandomCrop / ColorJitter / ToTensor of semi_seg/augment.py:6-22 forward to)."""
+    import os
+    import struct
+    import numpy as np
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g9_augment.npz"))
+    bits = lambda x: struct.unpack("<i", struct.pack("<f", float(x)))[0]  # noqa: E731
+    rows, want = g["rows"], g["views"]
+    assert rows.shape == (60, 9) and want.shape == (60, 224, 224) and want.dtype == np.uint8
+    seen = set()
+    for r, w in zip(rows, want):
+        si, ang, vf, hf, top, left, b, c, cf = r
+        img = g[f"slice{int(si)}"]
+        flags = (1 if hf else 0) | (2 if vf else 0) | (4 if cf else 0)
+        row = [0] + O.pil_affine_q16(float(ang), img.shape[1], img.shape[0]) + [flags, int(top), int(left), bits(b), bits(c)]
+        got = O.augment_view_pil(img, row, (224, 224))
+        np.testing.assert_array_equal(got, w.astype(np.float32) / np.float32(255), err_msg=str(r))
+        seen.add((flags, b <= 1.0, c <= 1.0))
+    assert len(seen) >= 12  # flips, both jitter orders, interpolating (<= 1) and clipping (> 1) blends all occur
+
+
+def test_pil_exact_parameter_rows_follow_the_reference_ranges():
+    from spcl_amd.semi_seg.data.augment import draw_view_params_pil, pil_affine_q16
+    import struct
+    import numpy as np
+    rng = random.Random(5)
+    rows = [draw_view_params_pil(7, (256, 256), (224, 224), rng=rng) for _ in range(2000)]
+    f = lambda i: struct.unpack("<f", struct.pack("<i", i))[0]  # noqa: E731
+    assert all(r[0] == 7 and len(r) == 12 for r in rows)
+    assert all(0 <= r[8] <= 32 and 0 <= r[9] <= 32 for r in rows)                      # RandomCrop(224) of 256
+    assert all(0.5 <= f(r[10]) <= 1.5 and 0.5 <= f(r[11]) <= 1.5 for r in rows)        # ColorJitter ranges
+    cos45 = int(np.floor(np.cos(np.radians(45.0)) * 65536 + 0.5))
+    assert all(cos45 - 1 <= r[1] <= 65536 and abs(r[2]) <= cos45 + 1 and r[4] == -r[2] and r[5] == r[1] for r in rows)  # |angle| <= 45
+    for bit in (1, 2, 4):
+        share = sum(1 for r in rows if r[7] & bit) / len(rows)
+        assert 0.45 < share < 0.55
+    assert pil_affine_q16(0.0, 224, 224) == O.pil_affine_q16(0.0, 224, 224) == [65536, 0, 32768, 0, 65536, 32768]
+    assert pil_affine_q16(17.5, 272, 240) == O.pil_affine_q16(17.5, 272, 240)
+

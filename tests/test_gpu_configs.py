@@ -6,7 +6,8 @@ seeded inputs.
   configs[0]  bs=8, 224x224, UNet max_channel=256, fp32           loss rtol 1e-4; every gradient within max(5e-3 of its
                                                                   max, 8x the fp32 oracle's own) and 2.5x its relative L2 of the fp64 oracle
   configs[1]  bf16 storage through all five blocks (>=112x112)    loss rtol 2e-2 vs the bf16-emulating oracle
-  configs[3]  256x256, three combined hooks (reduced N)           fp32 as configs[0]; bf16 loss rtol 2e-2
+  configs[3]  256x256, three combined hooks (reduced N, and the   fp32 as configs[0]; bf16 loss rtol 2e-2
+              exact N = 128 in bf16)
   configs[4]  hard threshold gamma=7 at 2n >= 1024                loss / rho rtol 1e-4, gradients 5e-3 (relative L2; all but
                                                                   <= 24 rows touched by a flipped pair within 2e-3 of max)
 """
@@ -246,6 +247,26 @@ def test_config3_three_hooks_256_bf16():
     np.testing.assert_allclose(run["loss"], loss, rtol=2e-2)
     _, osd32, leaves32, _ = _oracle(run, ons, weights, 8.0, "prostate")
     _check_grads_bf16(run, (osd, leaves), (osd32, leaves32))
+
+
+def test_config3_full_size_bs64_256_bf16():
+    """BASELINE configs[3] at its EXACT size (VERDICT r03 #7a): bs = 64 -> N = 128 images of 256x256, three self-paced hooks
+    (partition, patient, self) on one encoder pass, bf16 -- the launch geometry `bench.py --workload prostate` times: shifted
+    last tiles of the 14-column kernels at 256 / 128 / 64 pixels (conv16_bwd_kernel<true, ...> over 128 images), the band-GEMM
+    layers at 32^2 / 16^2, the four-head projector / loss chains at 2n = 128 -- forward AND backward against the oracle with
+    the same storage roundings and against the fp32 oracle (CPU oracle: ~10-20 s per evaluation)."""
+    ons, weights = ["partition", "patient", "self"], [1.0, 1.0, 1.0]
+    run = _step(256, 64, torch.bfloat16, ons, weights, 8.0, "prostate", partition_num=4)
+    loss, osd, leaves, rhos = _oracle(run, ons, weights, 8.0, "prostate", q=O.BF16Emulation)
+    np.testing.assert_allclose(run["loss"], loss, rtol=2e-2)
+    for h, rho in zip(run["hook"]._hooks, rhos):
+        np.testing.assert_allclose(h._criterion.downgrade_ratio, rho, rtol=2e-2, atol=2e-3)
+    loss32, osd32, leaves32, _ = _oracle(run, ons, weights, 8.0, "prostate")
+    assert abs(run["loss"] - loss32) <= 3e-2 * abs(loss32)
+    table = _check_grads_bf16(run, (osd, leaves), (osd32, leaves32))
+    print("tensor, noise(emu vs f32), d(hip, emu), cos(hip, emu), cos(hip, f32), |hip| / |emu|")
+    for row in table:
+        print(row)
 
 
 @pytest.mark.parametrize("n,d,nlab", [(512, 128, 3), (2048, 128, 3), (1024, 64, 16)])

@@ -42,7 +42,7 @@ def test_augment_views_geometry_is_bit_exact(size, out):
 def test_augment_views_colour_and_two_independent_views():
     from spcl_amd.semi_seg.data import PretrainViews
     store = _store(scans=4, slices_per_scan=(6, 8), size=256, seed=4)
-    views = PretrainViews(store.images, (224, 224))
+    views = PretrainViews(store.images, (224, 224), pil_exact=False)  # the round-2 float recipe (8-int rows)
     rng = random.Random(9)
     idx = [3, 7, 11, 20, 5]
     rows = views.params(idx, rng)
@@ -55,6 +55,59 @@ def test_augment_views_colour_and_two_independent_views():
     assert got.min() >= 0.0 and got.max() <= 1.0
     a, b = views(idx, random.Random(1))
     assert a.shape == b.shape == (5, 1, 224, 224) and a.is_cuda and not torch.equal(a, b)
+
+
+def _g9():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g9_augment.npz"))
+
+
+def _g9_row(r, hw):
+    """a golden row [slice, angle, vflip, hflip, top, left, b, c, contrast_first] as spcl_augment_views_pil takes it"""
+    import struct
+    bits = lambda x: struct.unpack("<i", struct.pack("<f", float(x)))[0]  # noqa: E731
+    si, ang, vf, hf, top, left, b, c, cf = r
+    flags = (1 if hf else 0) | (2 if vf else 0) | (4 if cf else 0)
+    return [int(si)] + O.pil_affine_q16(float(ang), hw[1], hw[0]) + [flags, int(top), int(left), bits(b), bits(c)]
+
+
+def test_augment_views_pil_reproduces_what_pil_itself_wrote():
+    """`spcl_augment_views_pil` against tests/golden/g9_augment.npz -- 60 views PIL 12.2 produced with the calls torchvision's
+    transforms of ``ACDCStrongTransforms.pretrain`` (semi_seg/augment.py:6-22) forward to: rotation (nearest, PIL's fixed-point
+    affine), both flips, crop, brightness / contrast in both orders, ToTensor.  EVERY pixel of every view, bit for bit; and the
+    oracle's restatement gives the same bits (the CPU suite pins it to the fixture as well)."""
+    from spcl_amd.semi_seg.data import PretrainViews
+    g = _g9()
+    rows, want = g["rows"], g["views"]
+    for si in range(6):
+        img = g[f"slice{si}"]
+        store = torch.from_numpy(img.astype(np.float32) / np.float32(255)).cuda()[None]  # 8-bit grey levels as k / 255
+        views = PretrainViews(store, (224, 224))
+        sel = [k for k in range(len(rows)) if int(rows[k][0]) == si]
+        prm = [[0] + _g9_row(rows[k], img.shape)[1:] for k in sel]
+        got = views.apply(prm).cpu().numpy()[:, 0]
+        for j, k in enumerate(sel):
+            np.testing.assert_array_equal(got[j], want[k].astype(np.float32) / np.float32(255), err_msg=str(rows[k]))
+            np.testing.assert_array_equal(got[j], O.augment_view_pil(img, [0] + prm[j][1:], (224, 224)))
+
+
+def test_augment_views_pil_random_rows_match_the_oracle():
+    """the product's own parameter draws (``PretrainViews.params``: 12-int rows in torchvision's draw order) on a synthetic
+    store, odd sizes included: kernel == oracle.augment_view_pil on every pixel; two independent views per slice"""
+    from spcl_amd.semi_seg.data import PretrainViews
+    for size, out in ((256, 224), (97, 50), (64, 64)):
+        store = _store(scans=3, slices_per_scan=(4, 5), size=size, seed=2)
+        u8 = torch.round(store.images * 255).clamp(0, 255)
+        store_q = (u8 / 255).contiguous()  # an 8-bit store, as decoded PNG slices are
+        views = PretrainViews(store_q, (out, out))
+        rng = random.Random(size)
+        idx = [rng.randrange(store_q.shape[0]) for _ in range(6)]
+        rows = views.params(idx, rng)
+        assert len(rows) == 12 and all(len(r) == 12 for r in rows) and rows[0] != rows[6]
+        got = views.apply(rows).cpu().numpy()[:, 0]
+        imgs = u8.cpu().numpy().astype(np.uint8)
+        for k, r in enumerate(rows):
+            np.testing.assert_array_equal(got[k], O.augment_view_pil(imgs[r[0]], r, (out, out)), err_msg=str(r))
 
 
 def test_contrastive_device_loader_batches():

@@ -467,9 +467,68 @@ def gen_data():
     print("g7_data:", {k: v.shape for k, v in out.items() if k.endswith("lens") or k.endswith("stems")})
 
 
+def gen_augment():
+    """g9_augment.npz: views PIL ITSELF produces with the operations torchvision's transforms of
+    ``ACDCStrongTransforms.pretrain`` (semi_seg/augment.py:6-22) forward to on an 8-bit 'L' image -- torchvision is not
+    installed here, and each of these transforms is one PIL call (torchvision/transforms/_functional_pil.py):
+    RandomRotation -> ``Image.rotate(angle, NEAREST, expand=False, fillcolor=0)``, RandomVerticalFlip / HorizontalFlip ->
+    ``transpose(FLIP_TOP_BOTTOM / FLIP_LEFT_RIGHT)``, RandomCrop(224) -> ``crop((left, top, left + 224, top + 224))``,
+    ColorJitter -> ``ImageEnhance.Brightness(img).enhance(b)`` / ``ImageEnhance.Contrast(img).enhance(c)`` in the drawn
+    order (saturation / hue: identity on one channel), ToTensor -> / 255.  Inputs: six seeded uint8 slices (square,
+    non-square, crop == image); 60 views with seeded parameters over the recipe's ranges plus hand-picked edge cases
+    (angle 0 / 45 / -45, factors 1.0, 0.5, 1.5, a factor < 1: PIL's interpolating blend branch, > 1: the clipping one)."""
+    import random
+    from PIL import Image, ImageEnhance
+    rs = np.random.RandomState(90)
+    sizes = [(256, 256), (256, 256), (240, 272), (272, 240), (224, 224), (224, 224)]
+    slices = []
+    for k, (h, w) in enumerate(sizes):
+        # smooth structure + noise, full 8-bit range: blobs make a wrong rotation visible, noise makes every pixel count
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+        base = 0.5 + 0.25 * np.sin(xx / (7.0 + k)) * np.cos(yy / (11.0 - k)) + 0.25 * rs.rand(h, w)
+        slices.append(np.clip(base * 255.0, 0, 255).astype(np.uint8))
+    rng = random.Random(91)
+    rows = []  # [slice, angle, vflip, hflip, top, left, brightness, contrast, contrast_first]
+    for v in range(48):
+        si = v % 6
+        h, w = sizes[si]
+        rows.append([si, rng.uniform(-45.0, 45.0), float(rng.random() < 0.5), float(rng.random() < 0.5),
+                     float(rng.randint(0, h - 224)), float(rng.randint(0, w - 224)), rng.uniform(0.5, 1.5),
+                     rng.uniform(0.5, 1.5), float(rng.random() < 0.5)])
+    edge = [(0.0, 1.0, 1.0), (45.0, 0.5, 1.5), (-45.0, 1.5, 0.5), (10.0, 1.0, 0.75), (-30.0, 0.75, 1.0), (3.25, 1.25, 1.25)]
+    for e, (ang, b, c) in enumerate(edge):
+        for cf in (0.0, 1.0):
+            si = (2 * e + int(cf)) % 6
+            h, w = sizes[si]
+            rows.append([si, ang, float(e % 2), float((e // 2) % 2), float((h - 224) // 2), float((w - 224) // 3), b, c, cf])
+    outs = []
+    for si, ang, vf, hf, top, left, b, c, cf in rows:
+        im = Image.fromarray(slices[int(si)], "L").rotate(ang, Image.NEAREST, expand=False, fillcolor=0)
+        if vf:
+            im = im.transpose(Image.FLIP_TOP_BOTTOM)
+        if hf:
+            im = im.transpose(Image.FLIP_LEFT_RIGHT)
+        top, left = int(top), int(left)
+        im = im.crop((left, top, left + 224, top + 224))
+        if cf:
+            im = ImageEnhance.Brightness(ImageEnhance.Contrast(im).enhance(c)).enhance(b)
+        else:
+            im = ImageEnhance.Contrast(ImageEnhance.Brightness(im).enhance(b)).enhance(c)
+        outs.append(np.asarray(im).copy())
+    out = {f"slice{k}": s for k, s in enumerate(slices)}
+    out["rows"] = np.array(rows, dtype=np.float64)
+    out["views"] = np.stack(outs).astype(np.uint8)
+    import PIL
+    out["pil_version"] = np.array(PIL.__version__)
+    np.savez_compressed(os.path.join(OUT, "g9_augment.npz"), **out)
+    print("g9_augment:", out["rows"].shape, out["views"].shape, "PIL", PIL.__version__)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if sys.argv[1:] == ["augment"]:  # only the round-4 augmentation fixture (PIL alone, no reference import)
+        return gen_augment()
     SupConLoss1, SelfPacedSupConLoss, ProjectionHead, UNet, SFE = _import_reference()
     if sys.argv[1:] == ["round2"]:  # only the round-2 additions (the others are unchanged)
         return gen_round2(SupConLoss1)
@@ -485,6 +544,7 @@ def main():
     gen_round2(SupConLoss1)
     gen_data()
     gen_wide(SupConLoss1, SelfPacedSupConLoss)
+    gen_augment()
 
 
 if __name__ == "__main__":
