@@ -188,17 +188,78 @@ def _pmc_table():
         return {}, None
 
 
+def _short_kernel_name(n):
+    import re
+    n = n.split("(")[0].replace("void ", "")
+    return re.sub(r"\s+", "", n)
+
+
+def graph_kernel_times(args, first_kernel="flip_pair_stage"):
+    """Per-launch kernel durations INSIDE the replayed step, by `tools/step_timeline.py`'s method: a CHILD process runs this
+    same command (no extras / roofline / CPU baseline) under `rocprofv3 --kernel-trace`; its trace is cut into steps at every
+    launch of the step's first kernel and the median duration of every launch position over the last 20 steps is returned as
+    [(kernel name, seconds)].  HIP events recorded during a stream capture return no time on this stack (tried: the
+    event-record nodes replay, hipEventElapsedTime fails), and the profiler cannot attach to a running process -- hence the
+    child, which is a plain subprocess (the program after `--` is python itself: no exec of a process that holds the GPU).
+    None when rocprofv3 is missing or the trace cannot be read."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    out = tempfile.mkdtemp(prefix="spcl_bench_trace_", dir="/tmp")
+    cmd = [exe, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
+           "--no-cpu-baseline", "--no-extras", "--no-roofline", "--steps", "30", "--warmup", "5", "--bs", str(args.bs),
+           "--size", str(args.size), "--dtype", args.dtype, "--workload", args.workload, "--pool", str(args.pool)]
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+        files = glob.glob(out + "/**/*kernel_trace.csv", recursive=True)
+        if r.returncode != 0 or not files:
+            print(f"[bench] rocprofv3 child failed (rc {r.returncode}): {r.stderr[-400:]}", file=sys.stderr)
+            return None
+        rows = sorted(csv.DictReader(open(files[0])), key=lambda q: int(q["Start_Timestamp"]))
+        steps, cur = [], None
+        for q in rows:
+            n = _short_kernel_name(q["Kernel_Name"])
+            if first_kernel in n and (cur is None or len(cur) > 4):
+                cur = []
+                steps.append(cur)
+            if cur is not None:
+                cur.append((n, (int(q["End_Timestamp"]) - int(q["Start_Timestamp"])) * 1e-9))
+        if len(steps) < 8:
+            return None
+        lens = sorted(len(st) for st in steps)
+        L = lens[len(lens) // 2]
+        steps = [st for st in steps if len(st) == L][-20:]
+        res = []
+        for i in range(L):
+            d = sorted(st[i][1] for st in steps)
+            res.append((steps[-1][i][0], d[len(d) // 2]))
+        return res
+    except Exception as e:  # noqa: BLE001
+        print(f"[bench] rocprofv3 child: {type(e).__name__}: {e}", file=sys.stderr)
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
 def measure_roofline(step, args, phases=False, graph=False):
     """Instrumented pass with the library's built-in kernel timer: every kernel launch of libspcl_hip.so is bracketed
-    by HIP events ON ITS LAUNCH STREAM (spcl_profile_* of the C ABI) and reported with its kernel symbol -- the names
-    rocprofv3 prints -- and the algorithmic bytes / FLOPs its entry point declares.
+    by HIP events ON ITS LAUNCH STREAM (spcl_profile_* of the C ABI; eager launches) and reported with its kernel symbol --
+    the names rocprofv3 prints -- and the algorithmic bytes / FLOPs its entry point declares.
 
-    ``graph=True`` (the timed configuration, N = 1): the epocher captures its step ANEW with the timer on, so the event
-    records become nodes of the hipGraph between the kernel nodes; the durations read are those of the launches INSIDE a
-    replayed step, the configuration `value` was measured in and `rocprofv3 --kernel-trace` of this command sees
-    (profiles/rNN_kernel_stats_bench_graph.csv).  ``graph=False`` (N > 1 on rank 0, --no-graph, or when the events of a
-    capture cannot be read on this stack): eager launches, ~5-10 % longer per kernel.
-    Returns the roofline of the kernel symbol with the largest total time per step, a breakdown, the step's kernel time."""
+    ``graph=True`` (the timed configuration, N = 1): the DURATIONS are then replaced, launch by launch, by those of the same
+    launches inside the replayed hipGraph (``graph_kernel_times``: a child run of this command under rocprofv3
+    --kernel-trace, the method of tools/step_timeline.py) -- the configuration `value` was measured in and the committed
+    profiles/rNN_kernel_stats_bench_graph.csv shows.  Eager durations (N > 1 on rank 0, --no-graph, no profiler) run ~5-10 %
+    above them.  Returns the roofline of the kernel symbol with the largest total time per step, a breakdown, the step's
+    kernel time."""
     from spcl_amd import native
     reps = 5
     epocher = getattr(step, "epocher", None)
@@ -215,52 +276,45 @@ def measure_roofline(step, args, phases=False, graph=False):
             marks.append((start, native.call("spcl_profile_count")))
             return out
         epocher._forward_pass = marked_forward
-    source = "eager launches"
+    source = "eager launches (HIP events on the launch stream)"
     try:
-        launches = None
-        if graph and epocher is not None and epocher._step_graph is not None and epocher._step_graph.captured:
-            from spcl_amd import stepgraph as _sg
-            old = epocher._step_graph
-            try:
-                epocher._step_graph = _sg.StepGraph(old._compute, old._exchange, old._update, split=old._split)
-                lo = hi = 0
-                for _ in range(6):  # two warm steps, then the capture (its launches are log entries lo .. hi - 1)
-                    lo = native.call("spcl_profile_count")
-                    step()
-                    hi = native.call("spcl_profile_count")
-                    if epocher._step_graph.captured:
-                        break
-                if not epocher._step_graph.captured or hi <= lo:
-                    raise RuntimeError("the instrumented step was not captured")
-                for _ in range(reps):  # every replay re-records the capture's events; the last replay's times are read
-                    step()
-                torch.cuda.synchronize()
-                launches = _read_profile_log(lo, hi)
-                marks = [(a - lo, b - lo) for a, b in marks if lo <= a and b <= hi]
-                if not launches or min(l[1] for l in launches) <= 0.0:
-                    raise RuntimeError("events recorded inside the capture returned no time")
-                reps_read = 1
-                source = "hipGraph replay (event-record nodes between the kernel nodes of the captured step)"
-            except Exception as e:  # noqa: BLE001
-                print(f"[bench] in-graph kernel timing unavailable ({type(e).__name__}: {e}); eager launches instead",
-                      file=sys.stderr)
-                launches, marks = None, []
-                native.call("spcl_profile_enable", 1)  # (clears the log)
-            finally:
-                # the product graph comes back; the instrumented one (its event nodes would stay in every replay) is dropped
-                epocher._step_graph = old
-        if launches is None:
-            if graph and epocher is not None:
-                epocher._graph_on = False  # every kernel launched eagerly for the rest of this process's roofline pass
-            for _ in range(reps):
-                step()
-            torch.cuda.synchronize()
-            launches = _read_profile_log(0, native.call("spcl_profile_count"))
-            reps_read = reps
+        for _ in range(reps):
+            step()
+        torch.cuda.synchronize()
+        launches = _read_profile_log(0, native.call("spcl_profile_count"))
+        reps_read = reps
     finally:
         native.call("spcl_profile_enable", 0)
         if orig_fwd is not None:
             del epocher._forward_pass  # (the instance attribute shadowing the method)
+    if graph and len(launches) % reps == 0:
+        per = len(launches) // reps
+        one = launches[-per:]                       # the last instrumented step: names, bytes, FLOPs in launch order
+        gt = graph_kernel_times(args)
+        if gt is not None:
+            lib = [(n, t) for n, t in gt if n.startswith("spcl::")]
+            names_e = [_short_kernel_name(l[0]) for l in one]
+            # the eager entry points launch exactly the kernels the capture recorded, in the same order (a one-thread tick
+            # or a memset node of the graph that is not a library launch is skipped by the name walk)
+            j, matched, hit = 0, [], 0
+            for i, ne in enumerate(names_e):
+                k = j
+                while k < len(lib) and k < j + 4 and lib[k][0] != ne:
+                    k += 1
+                if k < len(lib) and k < j + 4:  # found within the next few graph launches: its in-graph duration
+                    matched.append((one[i][0], lib[k][1], one[i][2], one[i][3]))
+                    j, hit = k + 1, hit + 1
+                else:  # (the eager pass launches spcl_flip_pair where the product step launches spcl_flip_pair_stage)
+                    matched.append(one[i])
+            if hit >= 0.9 * per:
+                first = len(launches) - per
+                marks = [(a - first, b - first) for a, b in marks if a >= first]
+                launches, reps_read = matched, 1
+                source = (f"inside the replayed hipGraph for {hit} of {per} launches: rocprofv3 --kernel-trace of a child run "
+                          "of this command, median of 20 replays per launch (tools/step_timeline.py's method); the rest eager")
+            else:
+                print(f"[bench] graph trace did not line up with the eager launch log ({hit} of {per}); eager "
+                      "durations kept", file=sys.stderr)
     reps = reps_read
     peak_tf = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
     groups = {}
@@ -636,11 +690,9 @@ def main():
             if args.ddp_overlap:  # the instrumented steps run on this rank alone: no early collective from backward
                 from spcl_amd import ddp as _ddp
                 _ddp.disable_unet_overlap(step.flat, step.model)
-            in_graph = world == 1 and bool(used_graph) and os.environ.get("SPCL_BENCH_GRAPH_EVENTS", "1") != "0"
-            if in_graph:  # the timed configuration itself: kernel durations inside a replayed step (see measure_roofline)
-                roof, breakdown, tot, fractions = measure_roofline(step, args, phases=True, graph=True)
-            else:
-                roof, breakdown, tot, fractions = measure_roofline(local_step(step), args, phases=True)
+            in_graph = world == 1 and bool(used_graph) and os.environ.get("SPCL_BENCH_GRAPH_TRACE", "1") != "0"
+            # in_graph: the durations are those of the launches inside a replayed step (see measure_roofline)
+            roof, breakdown, tot, fractions = measure_roofline(local_step(step), args, phases=True, graph=in_graph)
             line["roofline"] = roof
             line["kernel_breakdown"] = breakdown
             line["instrumented_step_ms"] = round(tot * 1e3, 3)
