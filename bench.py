@@ -836,15 +836,15 @@ def bench_finetune(args, device):
     model.set_compute_dtype(dtype)
     flat = ddp.FlatParams([p for p in model.parameters() if p.requires_grad])
     opt = FusedRAdam([flat.param], lr=1e-4, weight_decay=1e-5)
-    loader = SyntheticLabeledLoader(bs=args.bs, size=args.size, device=device, seed=77)
+    loader = SyntheticLabeledLoader(bs=args.bs, size=args.size, device=device, seed=77, pool=args.pool)
     ep = FineTuneEpocher(model=model, optimizer=opt, labeled_loader=loader, sup_criterion=KL_div(), num_batches=10 ** 9,
                          device=device, flat_params=flat, graph=not args.no_graph)
     model.train()
-    batch = next(loader)
 
     def step():
+        """one iteration of the epocher's loop on the loader's NEXT batch (own images and label maps, all resident)"""
         with ep.meters.focus_on(ep.meter_focus):
-            return ep.step(batch)
+            return ep.step(next(loader))
 
     run = step  # FineTuneEpocher.step captures itself after two eager steps (stepgraph.py)
     for _ in range(0 if args.no_graph else 3):
@@ -865,6 +865,7 @@ def bench_finetune(args, device):
             "config": {"workload": "SURVEY N1 / BASELINE.json configs[2] fine-tune half: UNet base (max_channel=256) full "
                                    "forward+backward, softmax + KL_div on one-hot labels, RAdam",
                        "slices_per_gpu": args.bs, "image": f"1x{args.size}x{args.size}",
+                       "batches": f"{args.pool} distinct resident labelled batches cycled (FineTuneEpocher.step on next(loader))",
                        "hipgraph": "epocher" if (ep._step_graph is not None and ep._step_graph.captured) else False},
             "final_meters": {"sup_loss": round(stats["sup_loss"]["mean"], 5),
                              "sup_dice": {k: round(v, 4) for k, v in stats["sup_dice"].items()}}}

@@ -413,6 +413,14 @@ int spcl_kl_div_forward(const float* prob, const float* target, size_t npix, int
                         void* stream);
 int spcl_kl_div_backward(const float* prob, const float* target, size_t npix, int K, float eps, const float* grad_loss,
                          float* dprob, void* stream);
+/* The supervised criterion of the fine-tune loop in one pass (semi_seg/epochers/new_epocher.py:268-282:
+ * KL_div(logits.softmax(1), class2one_hot(target, C)) and the Dice counts of logits.max(1)[1] against target):
+ * logits [B * per_sample][K] f32, labels [B * per_sample] int64 -> loss (mean over positions), dlogits_unit (the gradient
+ * w.r.t. the logits for grad_loss == 1: the caller scales it), inter / union [B][K] int64 (ZEROED by the caller; K == the
+ * number of classes).  Per pixel the arithmetic of spcl_softmax_forward / spcl_kl_div_forward / _backward /
+ * spcl_softmax_backward in the same order: the same bits.  ws: spcl_kl_workspace_bytes(). */
+int spcl_sup_loss_forward(const float* logits, const int64_t* labels, int B, int per_sample, int K, float eps, float* ws,
+                          float* loss, float* dlogits_unit, int64_t* inter_zeroed, int64_t* union_zeroed, void* stream);
 int spcl_one_hot(const int64_t* labels, size_t npix, int K, float* out, void* stream);
 int spcl_argmax_classes(const float* logits, size_t npix, int K, int64_t* out, void* stream);
 int spcl_dice_counts(const int64_t* pred, const int64_t* target, int B, int per_sample, int C, int64_t* inter_zeroed,

@@ -335,6 +335,72 @@ __global__ __launch_bounds__(256) void dice_counts_kernel(const int64_t* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------------ fused supervised loss
+// The fine-tune criterion as the reference composes it (semi_seg/epochers/new_epocher.py:268-282):
+//   onehot = class2one_hot(target, C);  loss = KL_div(logits.softmax(1), onehot);  Dice counts of logits.max(1)[1] vs target
+// in ONE pass over the class map instead of seven (softmax, one-hot, KL forward, arg-max, Dice counts, and -- for a unit
+// upstream gradient -- KL backward and softmax backward): per pixel the same arithmetic in the same order as the separate
+// kernels (softmax_fwd_kernel, kl_fwd_kernel with t = one-hot: the terms with t == 0 add exact zeros; kl_bwd_kernel +
+// softmax_bwd_kernel with grad_loss == 1), so a pixel's probabilities, loss term and gradient are bit-identical to theirs.
+// Grid (gx, B): blockIdx.y = sample, as dice_counts_kernel.  partial[wg] = the workgroup's loss sum.
+__global__ __launch_bounds__(256) void sup_loss_fwd_kernel(const float* __restrict__ logits,
+                                                           const int64_t* __restrict__ labels, int per_sample, int K,
+                                                           float eps, float inv_m, float* __restrict__ partial,
+                                                           float* __restrict__ dlogits, int C,
+                                                           unsigned long long* __restrict__ inter,
+                                                           unsigned long long* __restrict__ uni) {
+  __shared__ float red[4];
+  __shared__ unsigned int si[64], su[64];
+  const int n = blockIdx.y;
+  if (threadIdx.x < 64) si[threadIdx.x] = su[threadIdx.x] = 0u;
+  __syncthreads();
+  float s = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < per_sample; i += gridDim.x * 256) {
+    const size_t p = (size_t)n * per_sample + i;
+    const int64_t l = labels[p];
+    float v[HEAD_MAX_K];
+    float m = -INFINITY;
+    int best = 0;
+#pragma unroll
+    for (int k = 0; k < HEAD_MAX_K; ++k)
+      if (k < K) {
+        v[k] = logits[p * K + k];
+        m = fmaxf(m, v[k]);
+        if (k > 0 && v[k] > v[best]) best = k;  // first maximum (torch.max(1)[1])
+      }
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < HEAD_MAX_K; ++k)
+      if (k < K) { v[k] = expf(v[k] - m); sum += v[k]; }
+    const float inv = 1.f / sum;
+    float pl = 0.f;
+#pragma unroll
+    for (int k = 0; k < HEAD_MAX_K; ++k)
+      if (k < K) { v[k] = v[k] * inv; pl = (l == k) ? v[k] : pl; }
+    const bool lab_ok = l >= 0 && l < K;
+    float dpl = 0.f, dot = 0.f;
+    if (lab_ok) {
+      s -= 1.f * logf((pl + eps) / (1.f + eps));
+      dpl = -(1.f * inv_m) * 1.f / (pl + eps);  // kl_bwd_kernel with gscale == 1: -gs * t / (p + eps)
+      dot = fmaf(pl, dpl, 0.f);                // softmax_bwd_kernel's dot: the one non-zero term
+    }
+#pragma unroll
+    for (int k = 0; k < HEAD_MAX_K; ++k)
+      if (k < K) dlogits[p * K + k] = v[k] * (((lab_ok && l == k) ? dpl : -0.f) - dot);
+    if (best < C) atomicAdd(&su[best], 1u);
+    if (l >= 0 && l < C) atomicAdd(&su[l], 1u);
+    if (l == best && best < C) atomicAdd(&si[best], 1u);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (threadIdx.x < C) {
+    if (si[threadIdx.x]) atomicAdd(&inter[(size_t)n * C + threadIdx.x], (unsigned long long)si[threadIdx.x]);
+    if (su[threadIdx.x]) atomicAdd(&uni[(size_t)n * C + threadIdx.x], (unsigned long long)su[threadIdx.x]);
+  }
+}
+
 static int head_grid(size_t n, int cap) {
   size_t g = (n + 255) / 256;
   if (g > (size_t)cap) g = cap;
@@ -440,6 +506,26 @@ extern "C" int spcl_argmax_classes(const float* logits, size_t npix, int K, int6
   SPCL_CHECK_ARG(logits && out && npix > 0 && K > 0, "argmax_classes: bad args");
   SPCL_LAUNCH(argmax_kernel, dim3(head_grid(npix, 4096)), dim3(256), 0, (hipStream_t)stream, logits, npix, K, out);
   SPCL_LAUNCH_CHECK("argmax_classes");
+  return SPCL_OK;
+}
+
+extern "C" int spcl_sup_loss_forward(const float* logits, const int64_t* labels, int B, int per_sample, int K, float eps,
+                                     float* ws, float* loss, float* dlogits_unit, int64_t* inter_zeroed,
+                                     int64_t* union_zeroed, void* stream) {
+  SPCL_CHECK_ARG(logits && labels && ws && loss && dlogits_unit && inter_zeroed && union_zeroed,
+                 "sup_loss_forward: null pointer");
+  SPCL_CHECK_ARG(B > 0 && per_sample > 0 && K > 0 && K <= HEAD_MAX_K, "sup_loss_forward: bad shape (K <= %d)", HEAD_MAX_K);
+  hipStream_t st = (hipStream_t)stream;
+  int gx = (per_sample + 255) / 256;
+  const int cap = HEAD_RED_WG / B > 1 ? HEAD_RED_WG / B : 1;  // (the workspace holds HEAD_RED_WG partial sums)
+  if (gx > cap) gx = cap;
+  if (gx > 64) gx = 64;
+  const size_t npix = (size_t)B * per_sample;
+  prof_cost((double)npix * (K * 8.0 + 8.0), 0.0);
+  SPCL_LAUNCH(sup_loss_fwd_kernel, dim3(gx, B), dim3(256), 0, st, logits, labels, per_sample, K, eps, 1.f / (float)npix, ws,
+              dlogits_unit, K, (unsigned long long*)inter_zeroed, (unsigned long long*)union_zeroed);
+  SPCL_LAUNCH(head_partial_sum_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, gx * B, 1, 1.f / (float)npix, loss);
+  SPCL_LAUNCH_CHECK("sup_loss_forward");
   return SPCL_OK;
 }
 

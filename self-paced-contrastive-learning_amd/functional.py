@@ -1313,6 +1313,44 @@ def kl_div(prob, target, eps=1e-16):
     return _KLDivFn.apply(prob, target, eps)
 
 
+class _SupLossFn(torch.autograd.Function):
+    """``KL_div(logits.softmax(1), class2one_hot(target, C))`` + the Dice counts of ``logits.max(1)[1]`` against ``target``
+    (semi_seg/epochers/new_epocher.py:268-282) in ONE launch over the class map; the gradient w.r.t. the logits for a unit
+    upstream gradient is written by the same launch and scaled in backward.  ``counts`` receives (inter, union) [B, C]."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, eps, counts):
+        _n.require_gpu(logits, labels)
+        ls = _class_map_storage(logits.detach())
+        N, H, W, K = ls.shape
+        lab = labels.detach().long().contiguous()
+        if tuple(lab.shape) != (N, H, W):
+            raise AssertionError(f"labels {tuple(lab.shape)} do not match the class map {(N, H, W)}")
+        dev = ls.device
+        ws = torch.empty(_n.call("spcl_kl_workspace_bytes") // 4, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        dl = torch.empty_like(ls)
+        inter = torch.zeros(N, K, dtype=torch.int64, device=dev)
+        union = torch.zeros(N, K, dtype=torch.int64, device=dev)
+        _n.call("spcl_sup_loss_forward", _n.ptr(ls), _n.ptr(lab), N, H * W, K, c_float(eps), _n.ptr(ws), _n.ptr(loss),
+                _n.ptr(dl), _n.ptr(inter), _n.ptr(union), _n.stream())
+        counts.append((inter, union))
+        ctx.save_for_backward(dl)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return (dl * g.detach().float()).permute(0, 3, 1, 2), None, None, None
+
+
+def sup_loss_kl_onehot(logits, labels, eps=1e-16):
+    """-> (loss, (inter, union)): the fine-tune criterion and the training batch's Dice counts, fused (``_SupLossFn``)"""
+    counts = []
+    loss = _SupLossFn.apply(logits, labels, eps, counts)
+    return loss, counts[0]
+
+
 def one_hot_classes(labels: torch.Tensor, K: int) -> torch.Tensor:
     """class2one_hot: [N,H,W] integer labels -> logical [N,K,H,W] f32 one-hot (NHWC storage)."""
     _n.require_gpu(labels)

@@ -113,6 +113,7 @@ _SIGNATURES = {
     "spcl_kl_workspace_bytes": (c_size_t, []),
     "spcl_kl_div_forward": (c_int, [_P, _P, c_size_t, c_int, c_float, _P, _P, _P]),
     "spcl_kl_div_backward": (c_int, [_P, _P, c_size_t, c_int, c_float, _P, _P, _P]),
+    "spcl_sup_loss_forward": (c_int, [_P, _P, c_int, c_int, c_int, c_float, _P, _P, _P, _P, _P, _P]),
     "spcl_one_hot": (c_int, [_P, c_size_t, c_int, _P, _P]),
     "spcl_argmax_classes": (c_int, [_P, c_size_t, c_int, _P, _P]),
     "spcl_dice_counts": (c_int, [_P, _P, c_int, c_int, c_int, _P, _P, _P]),

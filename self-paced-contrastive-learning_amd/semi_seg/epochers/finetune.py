@@ -2,6 +2,7 @@
 ``FineTuneEpocher`` (:241-289; the labelled-only branch of ``SemiSupervisedEpocher``).  Same control flow and meters
 (``sup_loss``, ``sup_dice`` / ``loss``, ``dice``); the network, softmax, KL_div, arg-max and Dice counts are HIP
 kernels and the meters take device values (no per-step ``.item()``)."""
+import os
 from typing import Iterable, Optional
 
 import torch
@@ -10,9 +11,11 @@ from torch import nn
 from ... import ddp as _ddp
 from ... import functional as F_hip
 from ... import stepgraph as _sg
-from ...contrastyou.losses.kl import class2one_hot
+from ...contrastyou.losses.kl import KL_div, class2one_hot
 from ...contrastyou import meters as _meters
 from ...contrastyou.meters import AverageValueMeter, MeterInterface, UniversalDice
+
+_FUSED_SUP_LOSS = os.environ.get("SPCL_FUSED_SUP_LOSS", "1") != "0"  # A/B switch: 0 = the seven separate launches
 
 
 def unzip_single_transformed(data, device):
@@ -182,8 +185,15 @@ class FineTuneEpocher(_EpocherBase):
     # the three phases of a step (compute / collective / update), as in the pre-train epocher
     def step_compute(self, labeled_image, labeled_target):
         label_logits = self._forward_pass(labeled_image)
-        onehot_target = class2one_hot(labeled_target.squeeze(1), self.num_classes)
-        sup_loss = self._sup_criterion(F_hip.softmax_classes(label_logits), onehot_target, disable_assert=True)
+        fused = (_FUSED_SUP_LOSS and isinstance(self._sup_criterion, KL_div) and label_logits.is_cuda
+                 and label_logits.shape[1] == self.num_classes <= 16)
+        if fused:
+            # new_epocher.py:268-282 in one launch: softmax, one-hot, KL_div, arg-max and the Dice counts (and, for the unit
+            # gradient the loop backpropagates, the gradient w.r.t. the logits): functional._SupLossFn
+            sup_loss, counts = F_hip.sup_loss_kl_onehot(label_logits, labeled_target.squeeze(1), self._sup_criterion._eps)
+        else:
+            onehot_target = class2one_hot(labeled_target.squeeze(1), self.num_classes)
+            sup_loss = self._sup_criterion(F_hip.softmax_classes(label_logits), onehot_target, disable_assert=True)
         if self._unit is None or self._unit.device != sup_loss.device or self._unit.dtype != sup_loss.dtype:
             self._unit = torch.ones((), dtype=sup_loss.dtype, device=sup_loss.device)
         if self._flat_params is not None:
@@ -193,9 +203,12 @@ class FineTuneEpocher(_EpocherBase):
         else:
             self._optimizer.zero_grad(set_to_none=True)
             sup_loss.backward(gradient=self._unit)
-        with torch.no_grad():  # Dice counts of the training batch (new_epocher.py:279-282): [B, C] intersections / unions
-            self._counts = F_hip.dice_counts(F_hip.argmax_classes(label_logits.detach()), labeled_target.squeeze(1),
-                                             self.num_classes)
+        if fused:
+            self._counts = counts
+        else:
+            with torch.no_grad():  # Dice counts of the training batch (new_epocher.py:279-282): [B, C] intersections / unions
+                self._counts = F_hip.dice_counts(F_hip.argmax_classes(label_logits.detach()), labeled_target.squeeze(1),
+                                                 self.num_classes)
         return sup_loss
 
     def step_exchange(self):

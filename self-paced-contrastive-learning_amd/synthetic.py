@@ -63,12 +63,15 @@ class SyntheticLabeledLoader:
     target_tf), filenames, (partitions, groups)), else the single-transform format ((image, target), ...) of the
     validation loaders.  ``length`` makes it a finite, re-iterable loader (``len()`` is what EvalEpocher reads)."""
 
-    def __init__(self, bs=8, size=224, channels=1, num_classes=4, device="cuda", seed=99, twice=True, length=None):
+    def __init__(self, bs=8, size=224, channels=1, num_classes=4, device="cuda", seed=99, twice=True, length=None, pool=1):
         self.bs, self.size, self.channels, self.K, self.device = bs, size, channels, num_classes, device
         self.twice, self.length = twice, length
         self.gen = torch.Generator(device=device).manual_seed(seed)
         self.meta = acdc_like_meta(bs)
-        self._batch = self._draw()
+        # ``pool`` distinct resident batches (own images and label maps), cycled by ``next()``: a benchmark step then sees
+        # fresh data every step, as the pre-train loader gives it
+        self._pool = [self._draw() for _ in range(max(1, pool))]
+        self._batch, self._next = self._pool[0], 0
 
     def _draw(self):
         img = torch.rand((self.bs, self.channels, self.size, self.size), device=self.device, generator=self.gen)
@@ -91,4 +94,6 @@ class SyntheticLabeledLoader:
         return iter([self._batch] * self.length)
 
     def __next__(self):
-        return self._batch
+        batch = self._pool[self._next]
+        self._next = (self._next + 1) % len(self._pool)
+        return batch

@@ -124,6 +124,40 @@ def test_softmax_kl_onehot_argmax_dice_vs_oracle(K):
     assert torch.equal(inter.cpu(), ri) and torch.equal(union.cpu(), ru)
 
 
+@pytest.mark.parametrize("K,shape", [(4, (3, 13, 10)), (2, (2, 31, 17)), (7, (1, 64, 64)), (4, (5, 224, 224))])
+def test_fused_sup_loss_is_the_separate_kernels_in_one_launch(K, shape):
+    """`spcl_sup_loss_forward` (new_epocher.py:268-282 in one pass) against the oracle and against the chain it replaces
+    (softmax -> one-hot -> KL_div -> backward, arg-max -> Dice counts): loss within float summation order, the gradient for a
+    unit upstream gradient BIT-identical per pixel, the Dice counts equal; a non-unit upstream gradient scales it."""
+    from spcl_amd import functional as F
+    g = torch.Generator().manual_seed(K * 31 + shape[1])
+    logits = torch.randn(shape[0], K, shape[1], shape[2], generator=g) * 3
+    labels = torch.randint(0, K, shape, generator=g)
+    lr = logits.clone().requires_grad_(True)
+    ref = O.finetune_loss(lr, labels)
+    ref.backward()
+    # the chain of separate launches
+    la = logits.cuda().requires_grad_(True)
+    loss_a = F.kl_div(F.softmax_classes(la), F.one_hot_classes(labels.cuda(), K))
+    loss_a.backward()
+    ia, ua = F.dice_counts(F.argmax_classes(la.detach()), labels.cuda(), K)
+    # fused
+    lb = logits.cuda().requires_grad_(True)
+    loss_b, (ib, ub) = F.sup_loss_kl_onehot(lb, labels.cuda())
+    loss_b.backward()
+    assert abs(float(loss_b) - float(ref.detach())) < 1e-5 * max(1.0, abs(float(ref.detach())))
+    assert abs(float(loss_b) - float(loss_a)) < 2e-6 * max(1.0, abs(float(loss_a)))
+    assert torch.equal(lb.grad, la.grad)  # the same per-pixel arithmetic in the same order
+    np.testing.assert_allclose(lb.grad.cpu().numpy(), lr.grad.numpy(), rtol=1e-4, atol=1e-8)
+    assert torch.equal(ib, ia) and torch.equal(ub, ua)
+    ri, ru = O.dice_counts(logits.max(1)[1], labels, K)
+    assert torch.equal(ib.cpu(), ri) and torch.equal(ub.cpu(), ru)
+    lc = logits.cuda().requires_grad_(True)
+    loss_c, _ = F.sup_loss_kl_onehot(lc, labels.cuda())
+    (loss_c * 1.7).backward()
+    np.testing.assert_allclose(lc.grad.cpu().numpy(), 1.7 * lr.grad.numpy(), rtol=1e-4, atol=1e-8)
+
+
 def test_universal_dice_meter_matches_oracle():
     from spcl_amd.contrastyou.meters import UniversalDice
     g = torch.Generator().manual_seed(3)
