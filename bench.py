@@ -869,6 +869,11 @@ def bench_finetune(args, device):
                        "hipgraph": "epocher" if (ep._step_graph is not None and ep._step_graph.captured) else False},
             "final_meters": {"sup_loss": round(stats["sup_loss"]["mean"], 5),
                              "sup_dice": {k: round(v, 4) for k, v in stats["sup_dice"].items()}}}
+    if not args.no_cpu_baseline:
+        try:
+            line["cpu_baseline"] = cpu_baseline_finetune(args)
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] fine-tune CPU baseline failed: {type(e).__name__}: {e}", file=sys.stderr)
     if not args.no_roofline:
         try:
             ep._graph_on = False  # the instrumented pass launches every kernel eagerly
@@ -879,6 +884,39 @@ def bench_finetune(args, device):
             line["roofline"] = None
             print(f"[bench] roofline pass failed: {type(e).__name__}: {e}", file=sys.stderr)
     print(json.dumps(line))
+
+
+def cpu_baseline_finetune(args, budget_s=8.0):
+    """The oracle's restatement of the fine-tune step (full UNet forward + softmax / KL_div + backward + RAdam,
+    new_epocher.py:260-283) on the host cores: a bounded sample at bs = --cpu-bs."""
+    from oracle import spcl_oracle as O
+    cores = os.cpu_count() or 1
+    threads = min(cores, 32)
+    torch.set_num_threads(threads)
+    bs = args.cpu_bs
+    g = torch.Generator().manual_seed(77)
+    sd = O.init_unet_state(1, 4, 256, seed=10)
+    sd = {k: (v.requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in sd.items()}
+    leaves = [v for v in sd.values() if v.is_floating_point() and v.requires_grad]
+    opt = torch.optim.RAdam(leaves, lr=1e-4, weight_decay=1e-5)
+    img = torch.rand(bs, 1, args.size, args.size, generator=g)
+    lab = torch.randint(0, 4, (bs, args.size, args.size), generator=g)
+
+    def one():
+        loss = O.finetune_loss(O.unet_forward(img, sd, train=True), lab)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+    one()
+    t0, n = time.perf_counter(), 0
+    while n < 2 or (time.perf_counter() - t0 < budget_s and n < 40):
+        one()
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(bs * n / dt, 2), "unit": "slices/s", "cores": threads, "kind": "port", "host_cpu_count": cores,
+            "sample": f"{n} steps of the oracle's fine-tune step (full UNet fwd+bwd + KL_div + RAdam) at bs={bs} "
+                      f"({args.size}x{args.size}), fp32, torch CPU {threads} threads of {cores} host CPUs, {dt:.1f}s"}
 
 
 def contrastive_numbers(device, steps=50, warmup=10):

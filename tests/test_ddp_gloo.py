@@ -41,6 +41,20 @@ def _worker(rank, world, port, q):
     loss.backward()
     red = flat.reduce().clone()
     opt.step()
+    # fold_mean (what the epochers switch on under FusedRAdam): the exchange leaves the ranks' SUM in the bucket and the
+    # factor 1 / world in grad_scale, for the optimizer kernel to apply (spcl_radam_step_scaled); sum * scale == the mean
+    flat.zero_grad()
+    ((model(xs) - ys) ** 2).mean().backward()
+    flat.fold_mean = True
+    summed = flat.reduce().clone()
+    assert flat.grad_scale == 1.0 / world
+    flat.zero_grad()
+    ((model(xs) - ys) ** 2).mean().backward()
+    flat.fold_mean = False
+    mean = flat.reduce().clone()
+    assert flat.grad_scale == 1.0 and torch.equal(summed * 0.5, mean)
+    for p_ in model.parameters():
+        p_.grad = None
     # plain GradBucket gives the same averaged gradients
     m2 = torch.nn.Linear(3, 2)
     ddp.broadcast_state(m2)
