@@ -292,6 +292,16 @@ int spcl_bnrelu_pool_backward(const void* y, const void* dact, const void* dpool
                               int C, int CS, const float* mean, const float* invstd, const float* scale,
                               const float* shift, int training, float* ws, float* dgamma, float* dbeta, void* dy,
                               void* stream);
+/* The same two calls with the activation written / its gradient read as a CHANNEL SLICE of a wider NHWC tensor
+ * (act_stride / dact_stride = elements between two pixels, >= CS, a multiple of 8): the decoder's
+ * `torch.cat((skip, up), dim=1)` (semi_seg/arch/unet.py:194-224) then needs no copy in either direction -- both producers
+ * write their half of the concatenated tensor, both consumers read their half of its gradient (round 4, row N1). */
+int spcl_bnrelu_pool_forward_strided(const void* y, int dtype, int N, int H, int W, int CS, const float* scale,
+                                     const float* shift, void* act_out, int act_stride, void* pool_out, void* stream);
+int spcl_bnrelu_pool_backward_strided(const void* y, const void* dact, int dact_stride, const void* dpool, int dtype, int N,
+                                      int H, int W, int C, int CS, const float* mean, const float* invstd,
+                                      const float* scale, const float* shift, int training, float* ws, float* dgamma,
+                                      float* dbeta, void* dy, void* stream);
 /* BN + ReLU backward (no pooling) for a gradient that is the same for every pixel of an image: dact_nc [N][CS] of dtype.
  * Same arithmetic as spcl_bnrelu_pool_backward(dact = the expanded tensor, dpool = NULL). */
 int spcl_bnrelu_backward_bcast(const void* y, const void* dact_nc, int dtype, int N, int H, int W, int C, int CS,

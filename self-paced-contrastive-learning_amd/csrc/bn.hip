@@ -229,7 +229,8 @@ constexpr int IMG_WGRAD_WG = 2048;  // upper bound of the workgroups of the fuse
 template <typename T>
 __global__ __launch_bounds__(256, 6) void bnrelu_fwd_lin_kernel(const T* __restrict__ y, size_t npix, int CS,
                                                              const float* __restrict__ scale,
-                                                             const float* __restrict__ shift, T* __restrict__ act) {
+                                                             const float* __restrict__ shift, T* __restrict__ act,
+                                                             int AS /* elements between two pixels of act (>= CS) */) {
   constexpr int EPC = Chunk<T>::EPC, U = STREAM_UNROLL;
   const int CPC = CS / EPC, PL = 256 / CPC;
   const int cc = threadIdx.x % CPC, pl = threadIdx.x / CPC;
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(256, 6) void bnrelu_fwd_lin_kernel(const T* __restr
       unpack<T>(r[u], v);
 #pragma unroll
       for (int e = 0; e < EPC; ++e) v[e] = fmaxf(fmaf(sc[e], v[e], sh[e]), 0.f);
-      *(u32x4*)(act + (p + u * stride) * CS + cc * EPC) = pack<T>(v);
+      *(u32x4*)(act + (p + u * stride) * AS + cc * EPC) = pack<T>(v);
     }
   }
 }
@@ -283,7 +284,7 @@ template <typename T, bool FAST>
 __global__ __launch_bounds__(256, 4) void bnrelu_fwd_pool_kernel(const T* __restrict__ y, int N, int H, int W, int CS,
                                                               const float* __restrict__ scale,
                                                               const float* __restrict__ shift, T* __restrict__ act,
-                                                              T* __restrict__ pool) {
+                                                              T* __restrict__ pool, int AS) {
   constexpr int EPC = Chunk<T>::EPC, EPW = Word<T>::EPW;
   const int CPC = CS / EPC, PL = 256 / CPC;
   const int cc = threadIdx.x % CPC, pl = threadIdx.x / CPC;
@@ -324,9 +325,12 @@ __global__ __launch_bounds__(256, 4) void bnrelu_fwd_pool_kernel(const T* __rest
         }
         const int oxu = ox + u * PL;
         if (act != nullptr) {
+          // (act may be a channel slice of a wider tensor -- the skip half of a decoder concatenation: AS elements per pixel)
+          const size_t a00 = (row0 * W + 2 * oxu) * AS + cc * EPC;
+          const size_t aoff[4] = {a00, a00 + AS, a00 + (size_t)W * AS, a00 + (size_t)W * AS + AS};
 #pragma unroll
           for (int k = 0; k < 4; ++k)
-            if (w[u].valid[k]) *(u32x4*)(act + w[u].off[k]) = aw[k];
+            if (w[u].valid[k]) *(u32x4*)(act + aoff[k]) = aw[k];
         }
         if (pool != nullptr && (FAST || (oy < OH && oxu < OW)))
           *(u32x4*)(pool + (((size_t)n * OH + oy) * OW + oxu) * CS + cc * EPC) = mxw;
@@ -369,7 +373,8 @@ __global__ __launch_bounds__(256, 5) void bnrelu_bwd_reduce_lin_kernel(const T* 
                                                                     const float* __restrict__ invstd,
                                                                     const float* __restrict__ scale,
                                                                     const float* __restrict__ shift,
-                                                                    float* __restrict__ partial /* [grid][2][CS] */) {
+                                                                    float* __restrict__ partial /* [grid][2][CS] */,
+                                                                    int GS /* elements between two pixels of g */) {
   constexpr int EPC = Chunk<T>::EPC, EPW = Word<T>::EPW, U = STREAM_UNROLL;
   __shared__ float red[256][2 * EPC + 1];
   const int CPC = CS / EPC, PL = 256 / CPC;
@@ -391,7 +396,7 @@ __global__ __launch_bounds__(256, 5) void bnrelu_bwd_reduce_lin_kernel(const T* 
         ry[u] = rg[u] = (u32x4){0u, 0u, 0u, 0u};  // a zero gradient contributes nothing
         if (p + u * stride < npix) {
           ry[u] = *(const u32x4*)(y + (p + u * stride) * CS + cc * EPC);
-          rg[u] = *(const u32x4*)(g + (p + u * stride) * CS + cc * EPC);
+          rg[u] = *(const u32x4*)(g + (p + u * stride) * GS + cc * EPC);
         }
       }
 #pragma unroll
@@ -532,7 +537,7 @@ __global__ __launch_bounds__(256, 3) void bnrelu_bwd_pool_kernel(const T* __rest
                                                               const float* __restrict__ scale,
                                                               const float* __restrict__ shift,
                                                               const float* __restrict__ ab, float* __restrict__ partial,
-                                                              T* __restrict__ dy) {
+                                                              T* __restrict__ dy, int GS = 0 /* dact pixel stride */) {
   constexpr int EPC = Chunk<T>::EPC, EPW = Word<T>::EPW;
   __shared__ float red[APPLY ? 1 : 256][2 * EPC + 1];
   const int CPC = CS / EPC, PL = 256 / CPC;
@@ -557,10 +562,12 @@ __global__ __launch_bounds__(256, 3) void bnrelu_bwd_pool_kernel(const T* __rest
         w.template load<FAST>(y, row0, oy, ox, H, W, CS, cc);
         u32x4 rg[4], rdp = {0u, 0u, 0u, 0u};
         if (has_g) {
+          const size_t g00 = (row0 * W + 2 * ox) * GS + cc * EPC;
+          const size_t goff[4] = {g00, g00 + GS, g00 + (size_t)W * GS, g00 + (size_t)W * GS + GS};
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             rg[k] = (u32x4){0u, 0u, 0u, 0u};
-            if (w.valid[k]) rg[k] = *(const u32x4*)(dact + w.off[k]);
+            if (w.valid[k]) rg[k] = *(const u32x4*)(dact + goff[k]);
           }
         }
         const bool complete = FAST || (dpool != nullptr && oy < OH && ox < OW);  // floor semantics of max_pool2d
@@ -785,7 +792,8 @@ __global__ __launch_bounds__(256, 6) void bnrelu_bwd_apply_lin_kernel(const T* _
                                                                    size_t npix, int CS,
                                                                    const float* __restrict__ scale,
                                                                    const float* __restrict__ shift,
-                                                                   const float* __restrict__ ab, T* __restrict__ dy) {
+                                                                   const float* __restrict__ ab, T* __restrict__ dy,
+                                                                   int GS) {
   constexpr int EPC = Chunk<T>::EPC, EPW = Word<T>::EPW, U = STREAM_UNROLL;
   const int CPC = CS / EPC, PL = 256 / CPC;
   const int cc = threadIdx.x % CPC, pl = threadIdx.x / CPC;
@@ -802,7 +810,7 @@ __global__ __launch_bounds__(256, 6) void bnrelu_bwd_apply_lin_kernel(const T* _
     for (int u = 0; u < U; ++u)
       if (p + u * stride < npix) {
         ry[u] = *(const u32x4*)(y + (p + u * stride) * CS + cc * EPC);
-        rg[u] = *(const u32x4*)(g + (p + u * stride) * CS + cc * EPC);
+        rg[u] = *(const u32x4*)(g + (p + u * stride) * GS + cc * EPC);
       }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -964,26 +972,31 @@ static int stream_grid(size_t positions, int PL, int unroll, int cap) {
   return (int)g;
 }
 
+// Pixel strides (in elements) of the activation written by the forward / of the activation gradient read by the backward when
+// they are channel slices of a wider tensor (the `_strided` entry points set them around their call; 0 = dense, CS).
+static thread_local int tl_act_stride = 0, tl_dact_stride = 0;
+
 template <typename T>
 static int bnrelu_fwd_launch(const void* y, int N, int H, int W, int CS, const float* scale, const float* shift,
                              void* act, void* pool, hipStream_t st) {
   constexpr int EPC = Chunk<T>::EPC;
   const int PL = 256 / (CS / EPC);
+  const int AS = tl_act_stride > 0 ? tl_act_stride : CS;
   const double tb = (double)N * H * W * CS * sizeof(T);  // bytes of one full-resolution tensor
   prof_cost(tb * (1.0 + (act != nullptr ? 1.0 : 0.0) + (pool != nullptr ? 0.25 : 0.0)), 0.0);
   if (pool != nullptr) {
     const int rows = N * ((H + 1) / 2);
     if (H % 2 == 0 && W % 2 == 0) {
       SPCL_LAUNCH((bnrelu_fwd_pool_kernel<T, true>), dim3(rows < STREAM_MAX_WG ? rows : STREAM_MAX_WG), dim3(256), 0, st, (const T*)y, N, H,
-                       W, CS, scale, shift, (T*)act, (T*)pool);
+                       W, CS, scale, shift, (T*)act, (T*)pool, AS);
     } else {
       SPCL_LAUNCH((bnrelu_fwd_pool_kernel<T, false>), dim3(rows < STREAM_MAX_WG ? rows : STREAM_MAX_WG), dim3(256), 0, st, (const T*)y, N, H,
-                       W, CS, scale, shift, (T*)act, (T*)pool);
+                       W, CS, scale, shift, (T*)act, (T*)pool, AS);
     }
   } else {
     const size_t npix = (size_t)N * H * W;
     SPCL_LAUNCH((bnrelu_fwd_lin_kernel<T>), dim3(stream_grid(npix, PL, STREAM_UNROLL, STREAM_MAX_WG)), dim3(256), 0, st,
-                       (const T*)y, npix, CS, scale, shift, (T*)act);
+                       (const T*)y, npix, CS, scale, shift, (T*)act, AS);
   }
   return 0;
 }
@@ -996,6 +1009,7 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
                              int nrows = 0, bool bcast = false /* dact is [N][CS], one value per image and channel */) {
   constexpr int EPC = Chunk<T>::EPC;
   const bool pool = dpool != nullptr;
+  const int GS = tl_dact_stride > 0 ? tl_dact_stride : CS;
   constexpr int rs = 2;  // sub-rows of a partial row (the image3 path has eleven: spcl_bnrelu_backward_rows_image3)
   const Image3Args im3{nullptr, 0, nullptr, nullptr};
   spcl_wgrad_tail* tail = img != nullptr ? take_tail_capture() : nullptr;
@@ -1033,7 +1047,7 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
     } else {
       SPCL_LAUNCH((bnrelu_bwd_pool_kernel<T, false, false>), dim3(nwg), dim3(256), 0, st, (const T*)y, (const T*)dact,
                        (const T*)dpool, N, H, W, CS, mean, invstd, scale, shift, (const float*)nullptr, partial,
-                       (T*)nullptr);
+                       (T*)nullptr, GS);
     }
   } else if (bcast) {
     bsplit = (H * W + PL - 1) / PL;
@@ -1045,7 +1059,7 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
   } else {
     nwg = stream_grid(npix, PL, STREAM_UNROLL, BWD_MAX_WG);
     SPCL_LAUNCH((bnrelu_bwd_reduce_lin_kernel<T>), dim3(nwg), dim3(256), 0, st, (const T*)y, (const T*)dact, npix,
-                       CS, mean, invstd, scale, shift, partial);
+                       CS, mean, invstd, scale, shift, partial, GS);
   }
   float* zrow = ab + 2 * CS + (size_t)IMG_WGRAD_WG * 9 * CS;  // [W] zeros (image-wgrad pass only, see below)
   SPCL_LAUNCH(bnrelu_bwd_fin_kernel, dim3(CS), dim3(256), 0, st, fin_src, nwg, C, CS,
@@ -1060,7 +1074,7 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
     } else {
       SPCL_LAUNCH((bnrelu_bwd_pool_kernel<T, true, false>), dim3(prows < STREAM_MAX_WG ? prows : STREAM_MAX_WG), dim3(256), 0, st, (const T*)y,
                        (const T*)dact, (const T*)dpool, N, H, W, CS, mean, invstd, scale, shift, (const float*)ab,
-                       (float*)nullptr, (T*)dy);
+                       (float*)nullptr, (T*)dy, GS);
     }
   } else if (img != nullptr) {  // first conv of a one-channel image block: dy is consumed in registers by its dW
     float* wpart = ab + 2 * CS;  // [IMG_WGRAD_WG][9][CS];  zrow = the image row above / below the image
@@ -1082,7 +1096,7 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
                 CS, bsplit, scale, shift, (const float*)ab, (T*)dy);
   } else {
     SPCL_LAUNCH((bnrelu_bwd_apply_lin_kernel<T>), dim3(stream_grid(npix, PL, STREAM_UNROLL, STREAM_MAX_WG)), dim3(256), 0,
-                       st, (const T*)y, (const T*)dact, npix, CS, scale, shift, (const float*)ab, (T*)dy);
+                       st, (const T*)y, (const T*)dact, npix, CS, scale, shift, (const float*)ab, (T*)dy, GS);
   }
   return 0;
 }
@@ -1191,6 +1205,17 @@ extern "C" int spcl_bnrelu_pool_forward(const void* y, int dtype, int N, int H, 
   return SPCL_OK;
 }
 
+extern "C" int spcl_bnrelu_pool_forward_strided(const void* y, int dtype, int N, int H, int W, int CS, const float* scale,
+                                                const float* shift, void* act_out, int act_stride, void* pool_out,
+                                                void* stream) {
+  SPCL_CHECK_ARG(act_out && act_stride >= CS && act_stride % 8 == 0,
+                 "bnrelu_pool_forward_strided: act_out with a pixel stride >= CS, a multiple of 8 elements");
+  tl_act_stride = act_stride;
+  const int rc = spcl_bnrelu_pool_forward(y, dtype, N, H, W, CS, scale, shift, act_out, pool_out, stream);
+  tl_act_stride = 0;
+  return rc;
+}
+
 extern "C" size_t spcl_bnrelu_bwd_workspace_bytes(int N, int H, int W, int CS) {
   (void)N; (void)H; (void)W;
   return ((size_t)BWD_MAX_WG * 2 * CS + 2 * (size_t)CS) * sizeof(float);
@@ -1218,6 +1243,20 @@ extern "C" int spcl_bnrelu_pool_backward(const void* y, const void* dact, const 
   }
   SPCL_LAUNCH_CHECK("bnrelu_pool_backward");
   return SPCL_OK;
+}
+
+extern "C" int spcl_bnrelu_pool_backward_strided(const void* y, const void* dact, int dact_stride, const void* dpool,
+                                                 int dtype, int N, int H, int W, int C, int CS, const float* mean,
+                                                 const float* invstd, const float* scale, const float* shift,
+                                                 int training, float* ws, float* dgamma, float* dbeta, void* dy,
+                                                 void* stream) {
+  SPCL_CHECK_ARG(dact && dact_stride >= CS && dact_stride % 8 == 0,
+                 "bnrelu_pool_backward_strided: dact with a pixel stride >= CS, a multiple of 8 elements");
+  tl_dact_stride = dact_stride;
+  const int rc = spcl_bnrelu_pool_backward(y, dact, dpool, dtype, N, H, W, C, CS, mean, invstd, scale, shift, training, ws,
+                                           dgamma, dbeta, dy, stream);
+  tl_dact_stride = 0;
+  return rc;
 }
 
 // BN + ReLU backward for a gradient that is the same for every pixel of an image: dact_nc [N][CS] of dtype (what

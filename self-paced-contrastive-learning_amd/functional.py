@@ -504,6 +504,42 @@ def to_nhwc_padded(x: torch.Tensor, dtype: torch.dtype):
     return out
 
 
+def nhwc_channel_slice(x, dtype):
+    """``(view [N,H,W,C], S)`` when the logical NCHW tensor ``x`` is a 16-byte-aligned CHANNEL SLICE of a dense NHWC tensor of
+    ``dtype`` with S > C channels per pixel (one half of a decoder concatenation's gradient, ``_VirtualCatFn``) -- what the
+    ``_strided`` BatchNorm entry points read in place; else None (the caller re-packs)."""
+    if x is None or x.dim() != 4 or x.dtype != dtype:
+        return None
+    N, C, H, W = x.shape
+    sN, sC, sH, sW = x.stride()
+    if sC != 1 or sW <= C or sW % 8 or C % 16 or sH != W * sW or sN != H * W * sW:
+        return None
+    if (x.storage_offset() * x.element_size()) % 16:
+        return None
+    return x.permute(0, 2, 3, 1), sW
+
+
+def _bnrelu_fwd(y, dt_code, N, H, W, cs, scale, shift, act, pool):
+    """BN-apply + ReLU (+ 2x2 max-pool) writer; ``act`` may be a channel slice of a wider NHWC tensor (pixel stride > cs)"""
+    if act is not None and act.stride(2) != cs:
+        _n.call("spcl_bnrelu_pool_forward_strided", _n.ptr(y), dt_code, N, H, W, cs, _n.ptr(scale), _n.ptr(shift),
+                _n.ptr(act), int(act.stride(2)), _n.ptr(pool), _n.stream())
+    else:
+        _n.call("spcl_bnrelu_pool_forward", _n.ptr(y), dt_code, N, H, W, cs, _n.ptr(scale), _n.ptr(shift), _n.ptr(act),
+                _n.ptr(pool), _n.stream())
+
+
+def _act_buffer(cfg, N, H, W, cs, dtype, dev):
+    """the block's activation output: the caller's destination (``cfg.act_dst``: its half of a concatenation buffer) when it
+    fits, else a fresh dense tensor"""
+    dst = getattr(cfg, "act_dst", None)
+    if (dst is not None and tuple(dst.shape) == (N, H, W, cs) and dst.dtype == dtype and dst.device == dev
+            and dst.stride(3) == 1 and dst.stride(2) % 8 == 0 and dst.stride(1) == W * dst.stride(2)
+            and dst.stride(0) == H * W * dst.stride(2) and (dst.storage_offset() * dst.element_size()) % 16 == 0):
+        return dst
+    return torch.empty(N, H, W, cs, dtype=dtype, device=dev)
+
+
 class PoolLink:
     """What the NEXT block's backward needs to leave the BatchNorm-backward partial sums of THIS block's second conv in the
     epilogue of its own input-gradient kernel (spcl_conv3x3_dgrad_poolstats): this block's raw second-conv output and BN
@@ -519,13 +555,15 @@ class PoolLink:
 class BlockCfg:
     """Static configuration of one fused Conv-BN-ReLU(-Conv-BN-ReLU)(-MaxPool) block call."""
     __slots__ = ("dtype", "training", "momentum", "eps", "track", "need_act", "need_pool", "image_input", "buffers",
-                 "link_in", "link_out")
+                 "link_in", "link_out", "act_dst")
 
     def __init__(self, dtype, training, momentum, eps, track, need_act, need_pool, image_input, buffers):
         self.dtype, self.training, self.momentum, self.eps, self.track = dtype, training, momentum, eps, track
         self.need_act, self.need_pool, self.image_input, self.buffers = need_act, need_pool, image_input, buffers
         self.link_in = None   # PoolLink of the block whose pooled output is this block's input (set by the caller)
         self.link_out = None  # PoolLink this call offers to the next block (set by the forward)
+        self.act_dst = None   # [N,H,W,cout_s] view (pixel stride >= cout_s) the activation is written to: one half of a
+                              # decoder concatenation buffer (UNet.forward), so that torch.cat needs no copy
 
 
 def _pack(w, kind, dt_code, dtype):
@@ -786,15 +824,21 @@ def _bnrelu_bwd_bcast(y, g_nc, dt_code, dtype, N, H, W, C, cs, st, training, sin
     return dy, dgamma, dbeta
 
 
-def _bnrelu_bwd(y, dact, dpool, dt_code, dtype, N, H, W, C, cs, st, training, sinks=(None, None)):
+def _bnrelu_bwd(y, dact, dpool, dt_code, dtype, N, H, W, C, cs, st, training, sinks=(None, None), dact_stride=0):
+    """``dact_stride`` > 0: ``dact`` is a channel slice of a wider NHWC tensor with that many elements per pixel"""
     dev = y.device
     ws = torch.empty(_n.call("spcl_bnrelu_bwd_workspace_bytes", N, H, W, cs) // 4, dtype=torch.float32, device=dev)
     dgamma = _grad_buffer(sinks[0], (C,), dev)
     dbeta = _grad_buffer(sinks[1], (C,), dev)
     dy = torch.empty(N, H, W, cs, dtype=dtype, device=dev)
-    _n.call("spcl_bnrelu_pool_backward", _n.ptr(y), _n.ptr(dact), _n.ptr(dpool), dt_code, N, H, W, C, cs,
-            _n.ptr(st[0]), _n.ptr(st[1]), _n.ptr(st[2]), _n.ptr(st[3]), int(training), _n.ptr(ws), _n.ptr(dgamma),
-            _n.ptr(dbeta), _n.ptr(dy), _n.stream())
+    if dact_stride and dact is not None:
+        _n.call("spcl_bnrelu_pool_backward_strided", _n.ptr(y), _n.ptr(dact), int(dact_stride), _n.ptr(dpool), dt_code, N, H,
+                W, C, cs, _n.ptr(st[0]), _n.ptr(st[1]), _n.ptr(st[2]), _n.ptr(st[3]), int(training), _n.ptr(ws),
+                _n.ptr(dgamma), _n.ptr(dbeta), _n.ptr(dy), _n.stream())
+    else:
+        _n.call("spcl_bnrelu_pool_backward", _n.ptr(y), _n.ptr(dact), _n.ptr(dpool), dt_code, N, H, W, C, cs,
+                _n.ptr(st[0]), _n.ptr(st[1]), _n.ptr(st[2]), _n.ptr(st[3]), int(training), _n.ptr(ws), _n.ptr(dgamma),
+                _n.ptr(dbeta), _n.ptr(dy), _n.stream())
     return dy, dgamma, dbeta
 
 
@@ -1009,10 +1053,9 @@ class _ConvBlockFn(torch.autograd.Function):
         sta = _bn_stats(sa, cfg, cout, cout_s, ga, ba, 0, dev)
         yb, sb = _conv(ya, dtc, dtype, N, H, W, cout_s, cout_s, cout_s, wpb, 1, sta[2], sta[3], cfg.training)
         stb = _bn_stats(sb, cfg, cout, cout_s, gb, bb, 1, dev)
-        act = torch.empty(N, H, W, cout_s, dtype=dtype, device=dev) if cfg.need_act else None
+        act = _act_buffer(cfg, N, H, W, cout_s, dtype, dev) if cfg.need_act else None
         pool = torch.empty(N, H // 2, W // 2, cout_s, dtype=dtype, device=dev) if cfg.need_pool else None
-        _n.call("spcl_bnrelu_pool_forward", _n.ptr(yb), dtc, N, H, W, cout_s, _n.ptr(stb[2]), _n.ptr(stb[3]),
-                _n.ptr(act), _n.ptr(pool), _n.stream())
+        _bnrelu_fwd(yb, dtc, N, H, W, cout_s, stb[2], stb[3], act, pool)
         ctx.save_for_backward(xs, ya, yb, sta, stb, wa, wb)
         ctx.params = (wa, ga, ba, wb, gb, bb)
         ctx.packed_t = (wpa_t, wpb_t)
@@ -1034,7 +1077,12 @@ class _ConvBlockFn(torch.autograd.Function):
         dtc = _n.dtype_code(dtype)
         g_nc = broadcast_rows(d_act, dtype) if (_BCAST and d_pool is None and d_act is not None
                                                   and d_act.shape[1] == cout_s) else None
-        da_s = to_nhwc_padded(d_act, dtype) if (d_act is not None and g_nc is None) else None
+        da_stride = 0
+        da_sl = nhwc_channel_slice(d_act, dtype) if (d_act is not None and g_nc is None) else None
+        if da_sl is not None:  # the skip half of a concatenation's gradient, read in place (spcl_bnrelu_pool_backward_strided)
+            da_s, da_stride = da_sl
+        else:
+            da_s = to_nhwc_padded(d_act, dtype) if (d_act is not None and g_nc is None) else None
         dp_s = to_nhwc_padded(d_pool, dtype) if d_pool is not None else None
         if da_s is None and dp_s is None and g_nc is None:
             return (None,) * 8
@@ -1051,7 +1099,8 @@ class _ConvBlockFn(torch.autograd.Function):
             dyb, dgb, dbb = _bnrelu_pool_bwd_rows(yb, dp_s, lk.rows, dtc, dtype, N, H, W, cout, cout_s, stb, cfg.training,
                                                   sk[4:6])
         else:
-            dyb, dgb, dbb = _bnrelu_bwd(yb, da_s, dp_s, dtc, dtype, N, H, W, cout, cout_s, stb, cfg.training, sk[4:6])
+            dyb, dgb, dbb = _bnrelu_bwd(yb, da_s, dp_s, dtc, dtype, N, H, W, cout, cout_s, stb, cfg.training, sk[4:6],
+                                        dact_stride=da_stride)
         if lk is not None:
             lk.rows, lk.dx_ptr = None, 0
         wpa_t, wpb_t = ctx.packed_t
@@ -1161,9 +1210,8 @@ class _ConvBNReLUFn(torch.autograd.Function):
             wp, wp_t = _pack(w, 0, dtc, dtype), None
         y, s = _conv(xs, dtc, dtype, N, H, W, cin_s, cin_s, cout_s, wp, 0, None, None, cfg.training)
         st = _bn_stats(s, cfg, cout, cout_s, gamma, beta, 0, dev)
-        act = torch.empty(N, H, W, cout_s, dtype=dtype, device=dev)
-        _n.call("spcl_bnrelu_pool_forward", _n.ptr(y), dtc, N, H, W, cout_s, _n.ptr(st[2]), _n.ptr(st[3]), _n.ptr(act),
-                None, _n.stream())
+        act = _act_buffer(cfg, N, H, W, cout_s, dtype, dev)
+        _bnrelu_fwd(y, dtc, N, H, W, cout_s, st[2], st[3], act, None)
         ctx.save_for_backward(xs, y, st, w)
         ctx.params = (w, gamma, beta)
         ctx.packed_t = wp_t
@@ -1178,10 +1226,12 @@ class _ConvBNReLUFn(torch.autograd.Function):
         N, cin, H, W, cout, cout_s, cin_s, xdt = ctx.meta
         dtype = cfg.dtype
         dtc = _n.dtype_code(dtype)
-        da_s = to_nhwc_padded(d_act, dtype)
+        da_sl = nhwc_channel_slice(d_act, dtype)
+        da_s, da_stride = da_sl if da_sl is not None else (to_nhwc_padded(d_act, dtype), 0)
         ng = ctx.needs_input_grad
         sk = tuple(take_grad_sink(p, ng[i + 1]) for i, p in enumerate(ctx.params))
-        dy, dg, db = _bnrelu_bwd(y, da_s, None, dtc, dtype, N, H, W, cout, cout_s, st, cfg.training, sk[1:3])
+        dy, dg, db = _bnrelu_bwd(y, da_s, None, dtc, dtype, N, H, W, cout, cout_s, st, cfg.training, sk[1:3],
+                                 dact_stride=da_stride)
         dw = _wgrad(xs, dy, dtc, N, H, W, cin, cin_s, cin_s, cout, cout_s, 0, None, None, sk[0]) \
             if ctx.needs_input_grad[1] else None
         dx = None
@@ -1438,6 +1488,41 @@ class _Concat2Fn(torch.autograd.Function):
                 _n.stream())
         ga, gb = ga.permute(0, 3, 1, 2), gb.permute(0, 3, 1, 2)
         return (ga if ga.dtype == adt else ga.to(adt)), (gb if gb.dtype == bdt else gb.to(bdt)), None
+
+
+class _VirtualCatFn(torch.autograd.Function):
+    """``torch.cat((a, b), dim=1)`` (semi_seg/arch/unet.py:194-224) when a and b ALREADY are the two channel halves of one
+    dense NHWC buffer -- their producers wrote them there (``BlockCfg.act_dst``): no launch forward, no launch backward (the
+    gradient's halves are handed on as channel-slice views, which the BatchNorm-backward kernels read in place)."""
+
+    @staticmethod
+    def forward(ctx, a, b, holder):
+        buf = holder[0]
+        ctx.ca = a.shape[1]
+        return buf.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:, :ctx.ca], g[:, ctx.ca:], None
+
+
+def cat_buffer(N, H, W, ca, cb, dtype, device):
+    """a dense [N,H,W,ca+cb] buffer and its two channel-slice views (destinations for the producers of a concatenation)"""
+    buf = torch.empty(N, H, W, ca + cb, dtype=dtype, device=device)
+    return buf, buf[..., :ca], buf[..., ca:]
+
+
+def virtual_cat(a, b, buf):
+    """cat((a, b), 1) without a copy when a and b are the two halves of ``buf`` (see ``cat_buffer``); else the copying kernel"""
+    ca, cb = a.shape[1], b.shape[1]
+    es = buf.element_size()
+    ok = (a.dtype == b.dtype == buf.dtype and a.stride(1) == 1 and b.stride(1) == 1
+          and a.data_ptr() == buf.data_ptr() and b.data_ptr() == buf.data_ptr() + ca * es
+          and a.stride(3) == ca + cb == b.stride(3) and tuple(a.shape[2:]) == tuple(buf.shape[1:3]) == tuple(b.shape[2:])
+          and a.shape[0] == buf.shape[0] == b.shape[0] and buf.shape[3] == ca + cb)
+    if not ok:
+        return concat_channels(a, b, buf.dtype)
+    return _VirtualCatFn.apply(a, b, [buf])
 
 
 def concat_channels(a, b, dtype):

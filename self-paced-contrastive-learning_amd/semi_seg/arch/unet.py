@@ -25,6 +25,11 @@ from ... import functional as F_hip
 
 __all__ = ["UNet", "arch_order", "get_channel_dim", "sort_arch"]
 
+_VIRTUAL_CAT = __import__("os").environ.get("SPCL_VIRTUAL_CAT", "1") != "0"  # A/B switch (see UNet._forward_blocks)
+# narrowest skip that takes part.  A 16-channel pixel is a 32-byte run inside a 64-byte stride: the two producers then each
+# write HALF of every line (bnrelu_fwd_lin 51 -> 88 us per step at 224^2) and the copy is cheaper; from 32 channels on the
+# in-place halves win (fine-tune step, same box, three rounds: off 2.481 ms, >= 16: 2.455, >= 32: 2.439, >= 64: 2.449)
+_VIRTUAL_CAT_MINC = int(__import__("os").environ.get("SPCL_VIRTUAL_CAT_MINC", "32"))
 _ENCODER = ("Conv1", "Conv2", "Conv3", "Conv4", "Conv5")
 _DECODER = ("Up5", "Up_conv5", "Up4", "Up_conv4", "Up3", "Up_conv3", "Up2", "Up_conv2", "Deconv_1x1")
 
@@ -74,6 +79,7 @@ class _ConvBlock(nn.Module):
         self._plan = None           # (need_act, need_pool) set by UNet.forward for one call
         self._pooled = None
         self._link_in = self._link_out = None  # functional.PoolLink hand-over between consecutive encoder blocks
+        self._act_dst = None        # where UNet.forward wants this call's activation written (half of a concat buffer)
 
     def _cfg(self, need_act, need_pool):
         bn_a, bn_b = self.conv[1], self.conv[4]
@@ -98,6 +104,7 @@ class _ConvBlock(nn.Module):
         c = self.conv
         cfg = self._cfg(need_act, need_pool)
         cfg.link_in, self._link_in = self._link_in, None
+        cfg.act_dst, self._act_dst = self._act_dst, None
         act, pooled = F_hip.conv_block(x, c[0].weight, c[1].weight, c[1].bias, c[3].weight, c[4].weight, c[4].bias, cfg)
         self._pooled = pooled
         self._link_out = cfg.link_out  # for the block that consumes the pooled output (UNet.forward hands it over)
@@ -121,6 +128,7 @@ class _UpConv(nn.Module):
         )
 
         self._compute_dtype = None
+        self._act_dst = None
 
     def forward(self, x):
         bn = self.up[2]
@@ -129,6 +137,7 @@ class _UpConv(nn.Module):
         cfg = F_hip.BlockCfg(dtype, training, float(bn.momentum), float(bn.eps),
                              (self.training and bn.track_running_stats,), True, False, False,
                              ((bn.running_mean, bn.running_var, bn.num_batches_tracked),))
+        cfg.act_dst, self._act_dst = self._act_dst, None
         x = F_hip.upsample2x(x, dtype)  # nn.Upsample(scale_factor=2), nearest
         return F_hip.conv_bn_relu(x, self.up[1].weight, bn.weight, bn.bias, cfg)
 
@@ -191,10 +200,27 @@ class UNet(nn.Module):
     def _forward_blocks(self, x, until, encoder_only):
         e = x
         skips = {}
+        # torch.cat((skip, up), dim=1) of the decoder (unet.py:194-224) without a copy: both producers -- the encoder block's
+        # BN+ReLU writer and the up-convolution's -- write their half of ONE [N, H, W, 2C] buffer, the concatenation is a
+        # view of it and its gradient is read back half by half in place (functional.virtual_cat; SPCL_VIRTUAL_CAT=0: the
+        # copying kernels).  Not for a block with a forward hook (a feature tap wants a dense tensor of its own).
+        cats = {}
+        if not encoder_only and x.is_cuda and _VIRTUAL_CAT and x.dim() == 4:
+            H0, W0 = int(x.shape[2]), int(x.shape[3])
+            for k, name in enumerate(_ENCODER[:-1]):
+                blk = getattr(self, "_" + name)
+                c = self.get_channel_dim(name)
+                h, w = H0 >> k, W0 >> k
+                if (c % 16 == 0 and c >= _VIRTUAL_CAT_MINC and len(blk._forward_hooks) == 0 and h >= 2 and w >= 2
+                        and h % 2 == 0 and w % 2 == 0):
+                    dt = blk._compute_dtype or _config.get_compute_dtype()
+                    cats[name] = F_hip.cat_buffer(int(x.shape[0]), h, w, c, c, dt, x.device)
         for k, name in enumerate(_ENCODER):
             blk = getattr(self, "_" + name)
             is_last = (until == name) or k == len(_ENCODER) - 1
             blk._plan = (is_last or not encoder_only, not is_last)  # the decoder needs every block output (skips)
+            if name in cats and until != name:
+                blk._act_dst = cats[name][1]
             if k > 0:
                 prev = getattr(self, "_" + _ENCODER[k - 1])
                 blk._link_in, prev._link_out = prev._link_out, None
@@ -211,9 +237,15 @@ class UNet(nn.Module):
         # decoding + concat path (unet.py:193-230)
         d = skips["Conv5"]
         for lvl, skip in ((5, "Conv4"), (4, "Conv3"), (3, "Conv2"), (2, "Conv1")):
-            d = getattr(self, f"_Up{lvl}")(d)
+            up = getattr(self, f"_Up{lvl}")
+            if skip in cats:
+                up._act_dst = cats[skip][2]
+            d = up(d)
             blk = getattr(self, f"_Up_conv{lvl}")
-            d = F_hip.concat_channels(skips[skip], d, blk._compute_dtype or _config.get_compute_dtype())
+            if skip in cats:
+                d = F_hip.virtual_cat(skips[skip], d, cats[skip][0])
+            else:
+                d = F_hip.concat_channels(skips[skip], d, blk._compute_dtype or _config.get_compute_dtype())
             d = blk(d)
             if until == f"Up_conv{lvl}":
                 return d
