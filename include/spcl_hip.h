@@ -296,6 +296,11 @@ int spcl_bnrelu_pool_backward(const void* y, const void* dact, const void* dpool
  * (act_stride / dact_stride = elements between two pixels, >= CS, a multiple of 8): the decoder's
  * `torch.cat((skip, up), dim=1)` (semi_seg/arch/unet.py:194-224) then needs no copy in either direction -- both producers
  * write their half of the concatenated tensor, both consumers read their half of its gradient (round 4, row N1). */
+/* BN-apply + ReLU written 2x2-REPLICATED: up_out [N][2H][2W][CS] = nearest-upsample(relu(scale y + shift)) -- the activation of
+ * a block whose only consumer is the decoder's nn.Upsample(scale_factor=2) (semi_seg/arch/unet.py:89): neither the
+ * low-resolution activation nor a separate upsampling pass is written (round 4, row N1). */
+int spcl_bnrelu_up2_forward(const void* y, int dtype, int N, int H, int W, int CS, const float* scale, const float* shift,
+                            void* up_out, void* stream);
 int spcl_bnrelu_pool_forward_strided(const void* y, int dtype, int N, int H, int W, int CS, const float* scale,
                                      const float* shift, void* act_out, int act_stride, void* pool_out, void* stream);
 int spcl_bnrelu_pool_backward_strided(const void* y, const void* dact, int dact_stride, const void* dpool, int dtype, int N,

@@ -256,6 +256,46 @@ __global__ __launch_bounds__(256, 6) void bnrelu_fwd_lin_kernel(const T* __restr
   }
 }
 
+// ---- forward, no pooling, output written 2x2-replicated: up[n, 2h + a, 2w + b, :] = relu(scale*y[n, h, w, :] + shift) -- the
+// activation of a block whose only consumer is the decoder's nn.Upsample(scale_factor=2) (semi_seg/arch/unet.py:89, nearest):
+// the upsampled tensor is written directly, the low-resolution activation and the separate upsampling launch are skipped
+template <typename T>
+__global__ __launch_bounds__(256, 6) void bnrelu_fwd_up2_kernel(const T* __restrict__ y, unsigned nrows /* N*H */, int W,
+                                                             int CS, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, T* __restrict__ up) {
+  constexpr int EPC = Chunk<T>::EPC;
+  const int CPC = CS / EPC, PL = 256 / CPC;
+  const int cc = threadIdx.x % CPC, pl = threadIdx.x / CPC;
+  if (pl >= PL) return;
+  float sc[EPC], sh[EPC];
+  load_coef<EPC>(sc, scale, cc);
+  load_coef<EPC>(sh, shift, cc);
+  for (unsigned r = blockIdx.x; r < nrows; r += gridDim.x) {  // r = n*H + h -> output rows 2r, 2r + 1 (wave-uniform)
+    const T* yr = y + (size_t)r * W * CS + cc * EPC;
+    T* o0 = up + (size_t)(2 * r) * (2 * W) * CS + cc * EPC;
+    for (int w = pl; w < W; w += 2 * PL) {
+      u32x4 rr[2];
+      const bool second = w + PL < W;
+      rr[0] = *(const u32x4*)(yr + (size_t)w * CS);
+      if (second) rr[1] = *(const u32x4*)(yr + (size_t)(w + PL) * CS);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (u == 1 && !second) break;
+        float v[EPC];
+        unpack<T>(rr[u], v);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v[e] = fmaxf(fmaf(sc[e], v[e], sh[e]), 0.f);
+        const u32x4 pv = pack<T>(v);
+        T* o = o0 + (size_t)(2 * (w + u * PL)) * CS;
+        *(u32x4*)o = pv;
+        *(u32x4*)(o + CS) = pv;
+        *(u32x4*)(o + (size_t)2 * W * CS) = pv;
+        *(u32x4*)(o + (size_t)2 * W * CS + CS) = pv;
+      }
+    }
+  }
+}
+
 // one 2x2 window of one channel chunk: raw loads (issued together), then the math
 template <typename T>
 struct Window {
@@ -1202,6 +1242,29 @@ extern "C" int spcl_bnrelu_pool_forward(const void* y, int dtype, int N, int H, 
   if (dtype == SPCL_F32) bnrelu_fwd_launch<float>(y, N, H, W, CS, scale, shift, act_out, pool_out, st);
   else bnrelu_fwd_launch<bf16_t>(y, N, H, W, CS, scale, shift, act_out, pool_out, st);
   SPCL_LAUNCH_CHECK("bnrelu_pool_forward");
+  return SPCL_OK;
+}
+
+extern "C" int spcl_bnrelu_up2_forward(const void* y, int dtype, int N, int H, int W, int CS, const float* scale,
+                                       const float* shift, void* up_out, void* stream) {
+  SPCL_CHECK_ARG(y && scale && shift && up_out, "bnrelu_up2_forward: null pointer");
+  SPCL_CHECK_ARG(N > 0 && H > 0 && W > 0 && CS > 0 && CS % 16 == 0 && CS <= 1024, "bnrelu_up2_forward: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned nrows = (unsigned)N * (unsigned)H;
+  const unsigned grid = nrows < (unsigned)STREAM_MAX_WG ? nrows : (unsigned)STREAM_MAX_WG;
+  const double tb = (double)N * H * W * CS * (dtype == SPCL_F32 ? 4.0 : 2.0);
+  prof_cost(5.0 * tb, 0.0);
+  if (dtype == SPCL_F32)
+    SPCL_LAUNCH((bnrelu_fwd_up2_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)y, nrows, W, CS, scale, shift,
+                (float*)up_out);
+  else if (dtype == SPCL_BF16)
+    SPCL_LAUNCH((bnrelu_fwd_up2_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)y, nrows, W, CS, scale, shift,
+                (bf16_t*)up_out);
+  else {
+    set_error("bnrelu_up2_forward: dtype %d", dtype);
+    return SPCL_EINVAL;
+  }
+  SPCL_LAUNCH_CHECK("bnrelu_up2_forward");
   return SPCL_OK;
 }
 

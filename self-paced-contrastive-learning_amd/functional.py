@@ -555,7 +555,7 @@ class PoolLink:
 class BlockCfg:
     """Static configuration of one fused Conv-BN-ReLU(-Conv-BN-ReLU)(-MaxPool) block call."""
     __slots__ = ("dtype", "training", "momentum", "eps", "track", "need_act", "need_pool", "image_input", "buffers",
-                 "link_in", "link_out", "act_dst")
+                 "link_in", "link_out", "act_dst", "up2")
 
     def __init__(self, dtype, training, momentum, eps, track, need_act, need_pool, image_input, buffers):
         self.dtype, self.training, self.momentum, self.eps, self.track = dtype, training, momentum, eps, track
@@ -564,6 +564,8 @@ class BlockCfg:
         self.link_out = None  # PoolLink this call offers to the next block (set by the forward)
         self.act_dst = None   # [N,H,W,cout_s] view (pixel stride >= cout_s) the activation is written to: one half of a
                               # decoder concatenation buffer (UNet.forward), so that torch.cat needs no copy
+        self.up2 = False      # the activation's only consumer is nn.Upsample(scale_factor=2): write it 2x2-replicated, return
+                              # the [N, C, 2H, 2W] tensor (spcl_bnrelu_up2_forward); backward sums the 2x2 gradients first
 
 
 def _pack(w, kind, dt_code, dtype):
@@ -1053,9 +1055,16 @@ class _ConvBlockFn(torch.autograd.Function):
         sta = _bn_stats(sa, cfg, cout, cout_s, ga, ba, 0, dev)
         yb, sb = _conv(ya, dtc, dtype, N, H, W, cout_s, cout_s, cout_s, wpb, 1, sta[2], sta[3], cfg.training)
         stb = _bn_stats(sb, cfg, cout, cout_s, gb, bb, 1, dev)
-        act = _act_buffer(cfg, N, H, W, cout_s, dtype, dev) if cfg.need_act else None
-        pool = torch.empty(N, H // 2, W // 2, cout_s, dtype=dtype, device=dev) if cfg.need_pool else None
-        _bnrelu_fwd(yb, dtc, N, H, W, cout_s, stb[2], stb[3], act, pool)
+        ctx.up2 = bool(getattr(cfg, "up2", False)) and cfg.need_act and not cfg.need_pool
+        if ctx.up2:
+            act = torch.empty(N, 2 * H, 2 * W, cout_s, dtype=dtype, device=dev)
+            pool = None
+            _n.call("spcl_bnrelu_up2_forward", _n.ptr(yb), dtc, N, H, W, cout_s, _n.ptr(stb[2]), _n.ptr(stb[3]), _n.ptr(act),
+                    _n.stream())
+        else:
+            act = _act_buffer(cfg, N, H, W, cout_s, dtype, dev) if cfg.need_act else None
+            pool = torch.empty(N, H // 2, W // 2, cout_s, dtype=dtype, device=dev) if cfg.need_pool else None
+            _bnrelu_fwd(yb, dtc, N, H, W, cout_s, stb[2], stb[3], act, pool)
         ctx.save_for_backward(xs, ya, yb, sta, stb, wa, wb)
         ctx.params = (wa, ga, ba, wb, gb, bb)
         ctx.packed_t = (wpa_t, wpb_t)
@@ -1075,8 +1084,14 @@ class _ConvBlockFn(torch.autograd.Function):
         N, cin, H, W, cout, cout_s, cin_s, cin_k, mode_a, xdt = ctx.meta
         dtype = cfg.dtype
         dtc = _n.dtype_code(dtype)
-        g_nc = broadcast_rows(d_act, dtype) if (_BCAST and d_pool is None and d_act is not None
+        g_nc = broadcast_rows(d_act, dtype) if (_BCAST and d_pool is None and d_act is not None and not ctx.up2
                                                   and d_act.shape[1] == cout_s) else None
+        if ctx.up2 and d_act is not None:
+            # the forward returned the x2-upsampled activation: its gradient is summed over the 2x2 replicas first
+            du = to_nhwc_padded(d_act, dtype)
+            dsum = torch.empty(N, H, W, cout_s, dtype=dtype, device=du.device)
+            _n.call("spcl_upsample2x_backward", _n.ptr(du), _n.ptr(dsum), dtc, N, H, W, cout_s, _n.stream())
+            d_act = nhwc_to_logical(dsum, cout)
         da_stride = 0
         da_sl = nhwc_channel_slice(d_act, dtype) if (d_act is not None and g_nc is None) else None
         if da_sl is not None:  # the skip half of a concatenation's gradient, read in place (spcl_bnrelu_pool_backward_strided)

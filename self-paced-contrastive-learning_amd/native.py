@@ -72,6 +72,7 @@ _SIGNATURES = {
     "spcl_bn_finalize": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
     "spcl_bn_eval_affine": (c_int, [c_int, c_int, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P]),
     "spcl_bnrelu_pool_forward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
+    "spcl_bnrelu_up2_forward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "spcl_bnrelu_pool_forward_strided": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P]),
     "spcl_bnrelu_pool_backward_strided": (c_int, [_P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P,
                                                   _P, c_int, _P, _P, _P, _P, _P]),

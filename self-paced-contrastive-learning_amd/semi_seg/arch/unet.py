@@ -30,6 +30,7 @@ _VIRTUAL_CAT = __import__("os").environ.get("SPCL_VIRTUAL_CAT", "1") != "0"  # A
 # write HALF of every line (bnrelu_fwd_lin 51 -> 88 us per step at 224^2) and the copy is cheaper; from 32 channels on the
 # in-place halves win (fine-tune step, same box, three rounds: off 2.481 ms, >= 16: 2.455, >= 32: 2.439, >= 64: 2.449)
 _VIRTUAL_CAT_MINC = int(__import__("os").environ.get("SPCL_VIRTUAL_CAT_MINC", "32"))
+_FUSED_UPSAMPLE = __import__("os").environ.get("SPCL_FUSED_UPSAMPLE", "1") != "0"  # A/B switch (BlockCfg.up2)
 _ENCODER = ("Conv1", "Conv2", "Conv3", "Conv4", "Conv5")
 _DECODER = ("Up5", "Up_conv5", "Up4", "Up_conv4", "Up3", "Up_conv3", "Up2", "Up_conv2", "Deconv_1x1")
 
@@ -80,6 +81,7 @@ class _ConvBlock(nn.Module):
         self._pooled = None
         self._link_in = self._link_out = None  # functional.PoolLink hand-over between consecutive encoder blocks
         self._act_dst = None        # where UNet.forward wants this call's activation written (half of a concat buffer)
+        self._up2 = False           # this call's activation only feeds nn.Upsample(x2): return it upsampled (one launch less)
 
     def _cfg(self, need_act, need_pool):
         bn_a, bn_b = self.conv[1], self.conv[4]
@@ -105,6 +107,7 @@ class _ConvBlock(nn.Module):
         cfg = self._cfg(need_act, need_pool)
         cfg.link_in, self._link_in = self._link_in, None
         cfg.act_dst, self._act_dst = self._act_dst, None
+        cfg.up2, self._up2 = (self._up2 and len(self._forward_hooks) == 0), False
         act, pooled = F_hip.conv_block(x, c[0].weight, c[1].weight, c[1].bias, c[3].weight, c[4].weight, c[4].bias, cfg)
         self._pooled = pooled
         self._link_out = cfg.link_out  # for the block that consumes the pooled output (UNet.forward hands it over)
@@ -130,7 +133,8 @@ class _UpConv(nn.Module):
         self._compute_dtype = None
         self._act_dst = None
 
-    def forward(self, x):
+    def forward(self, x, pre_upsampled: bool = False):
+        """``pre_upsampled``: ``x`` already is the x2-upsampled tensor (the producing block wrote it that way, BlockCfg.up2)"""
         bn = self.up[2]
         dtype = self._compute_dtype or _config.get_compute_dtype()
         training = self.training or not bn.track_running_stats
@@ -138,7 +142,8 @@ class _UpConv(nn.Module):
                              (self.training and bn.track_running_stats,), True, False, False,
                              ((bn.running_mean, bn.running_var, bn.num_batches_tracked),))
         cfg.act_dst, self._act_dst = self._act_dst, None
-        x = F_hip.upsample2x(x, dtype)  # nn.Upsample(scale_factor=2), nearest
+        if not pre_upsampled:
+            x = F_hip.upsample2x(x, dtype)  # nn.Upsample(scale_factor=2), nearest
         return F_hip.conv_bn_relu(x, self.up[1].weight, bn.weight, bn.bias, cfg)
 
 
@@ -221,6 +226,10 @@ class UNet(nn.Module):
             blk._plan = (is_last or not encoder_only, not is_last)  # the decoder needs every block output (skips)
             if name in cats and until != name:
                 blk._act_dst = cats[name][1]
+            up2_first = (not encoder_only and k == len(_ENCODER) - 1 and x.is_cuda and _FUSED_UPSAMPLE
+                         and len(blk._forward_hooks) == 0 and len(self._Up5._forward_hooks) == 0
+                         and len(self._Up5.up[0]._forward_hooks) == 0)
+            blk._up2 = up2_first  # Conv5's activation only feeds Up5's nn.Upsample: written x2-upsampled directly
             if k > 0:
                 prev = getattr(self, "_" + _ENCODER[k - 1])
                 blk._link_in, prev._link_out = prev._link_out, None
@@ -236,12 +245,19 @@ class UNet(nn.Module):
                 e.register_hook(lambda g, cb=cb: cb() and None)
         # decoding + concat path (unet.py:193-230)
         d = skips["Conv5"]
+        pre_up = up2_first
         for lvl, skip in ((5, "Conv4"), (4, "Conv3"), (3, "Conv2"), (2, "Conv1")):
             up = getattr(self, f"_Up{lvl}")
             if skip in cats:
                 up._act_dst = cats[skip][2]
-            d = up(d)
+            d = up(d, pre_upsampled=pre_up)
             blk = getattr(self, f"_Up_conv{lvl}")
+            # this decoder block's activation feeds the next level's nn.Upsample only (not the last block, not the `until` one)
+            nxt = getattr(self, f"_Up{lvl - 1}", None) if lvl > 2 else None
+            pre_up = (nxt is not None and until != f"Up_conv{lvl}" and _FUSED_UPSAMPLE and d.is_cuda
+                      and len(blk._forward_hooks) == 0 and len(nxt._forward_hooks) == 0
+                      and len(nxt.up[0]._forward_hooks) == 0)
+            blk._up2 = pre_up
             if skip in cats:
                 d = F_hip.virtual_cat(skips[skip], d, cats[skip][0])
             else:
