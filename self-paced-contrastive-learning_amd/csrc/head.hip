@@ -515,6 +515,8 @@ extern "C" int spcl_sup_loss_forward(const float* logits, const int64_t* labels,
   SPCL_CHECK_ARG(logits && labels && ws && loss && dlogits_unit && inter_zeroed && union_zeroed,
                  "sup_loss_forward: null pointer");
   SPCL_CHECK_ARG(B > 0 && per_sample > 0 && K > 0 && K <= HEAD_MAX_K, "sup_loss_forward: bad shape (K <= %d)", HEAD_MAX_K);
+  SPCL_CHECK_ARG(B <= HEAD_RED_WG, "sup_loss_forward: at most %d samples per call (one partial sum per workgroup in ws)",
+                 HEAD_RED_WG);
   hipStream_t st = (hipStream_t)stream;
   int gx = (per_sample + 255) / 256;
   const int cap = HEAD_RED_WG / B > 1 ? HEAD_RED_WG / B : 1;  // (the workspace holds HEAD_RED_WG partial sums)

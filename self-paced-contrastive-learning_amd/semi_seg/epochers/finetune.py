@@ -186,7 +186,7 @@ class FineTuneEpocher(_EpocherBase):
     def step_compute(self, labeled_image, labeled_target):
         label_logits = self._forward_pass(labeled_image)
         fused = (_FUSED_SUP_LOSS and isinstance(self._sup_criterion, KL_div) and label_logits.is_cuda
-                 and label_logits.shape[1] == self.num_classes <= 16)
+                 and label_logits.shape[1] == self.num_classes <= 16 and label_logits.shape[0] <= 1024)
         if fused:
             # new_epocher.py:268-282 in one launch: softmax, one-hot, KL_div, arg-max and the Dice counts (and, for the unit
             # gradient the loop backpropagates, the gradient w.r.t. the logits): functional._SupLossFn
