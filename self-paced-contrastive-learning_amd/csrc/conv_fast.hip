@@ -781,6 +781,10 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
   static const int env_nt1 = getenv("SPCL_CONV_FAST_NT1") ? atoi(getenv("SPCL_CONV_FAST_NT1")) : 0;
   int NT = ntn >= 2 ? 2 : 1;
   if (env_nt1 == 1 && KC == 64 && ntn == 2) NT = 1;
+  // 64 -> 32 channels with the pooled BatchNorm-backward sums in the epilogue (Conv3.a's dgrad): as two one-n-tile waves,
+  // each with half of the epilogue's scattered loads -- 29 us against 23 + 15 for the plain one-wave kernel and the
+  // separate reduction pass (whole step 1.134 -> 1.126 ms, same box; SPCL_CONV_FAST_NT1=2 switches it off)
+  if (env_nt1 != 2 && KC == 64 && ntn == 2 && c.rows2 != nullptr && c.H2 > 0) NT = 1;
   // 64 -> 64 channels: four one-n-tile waves when the loader also applies BN+ReLU (more lanes for the transform:
   // Conv3.b forward 38 -> 30 us) and on the small images; two two-n-tile waves for the plain 56^2 dgrad
   if (KC == 64 && ntn == 4 && env_nt1 != 3 && (c.in_mode == 1 || c.H <= 28)) NT = 1;
@@ -812,6 +816,7 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
   // pooled BatchNorm-backward sums in the epilogue (MODE 3): measured per block against dgrad + separate reduction pass
   // (N = 64): 32 -> 16 @112^2 43 vs 49 us, 128 -> 64 @28^2 21 vs 25.5, 256 -> 128 @14^2 30.5 vs 30.6, but the one-wave
   // 64 -> 32 @56^2 kernel 53.5 vs 43 (56 scattered 8-byte loads per lane behind one wave's MFMAs): not offered there
+  // (that layer takes the two-wave form above)
   if (c.rows2 != nullptr && c.H2 > 0 && KC == 64 && nw == 1) return false;
 #define SPCL_FAST_CASE(KC_, TH_, NT_, NW_)                               \
   if (KC == KC_ && th == TH_ && NT == NT_ && nw == NW_) {                \
