@@ -165,7 +165,7 @@ int spcl_conv_pack_weights_block_at(const float* wa_oihw, int CinA, int CoutA, v
  * OIHW master, both destination buffers (sizes as spcl_conv_packed_elems) and the image size it will be used at (as
  * spcl_conv_pack_weights_block_at: 0, 0 = both layouts of a dual-layout buffer).  items is host memory, read during the
  * call. */
-#define SPCL_PACK_MULTI_MAX 20
+#define SPCL_PACK_MULTI_MAX 24
 typedef struct spcl_pack_item {
   const float* w_oihw;
   void* fwd;
@@ -200,6 +200,19 @@ size_t spcl_bn_stats_elems(int ntiles, int CS);
 int spcl_conv3x3_forward(const void* x, int dtype, int N, int H, int W, int CinS, int CinK, int CoutS,
                          const void* w_packed, int in_mode, const float* in_scale, const float* in_shift, void* y,
                          float* stats, void* stream);
+/* The decoder's torch.cat((skip, up), dim=1) -> Conv2d(2 Chalf, Cout, 3, 1, 1) (unet.py:194-197, 201-204, ... the first
+ * convolution of every Up_conv block) WITHOUT the concatenated tensor: input channels [0, Chalf) are read from xa, [Chalf,
+ * 2 Chalf) from xb, both dense [N][H][W][Chalf] bf16; w_packed = spcl_conv_pack_weights(kind 0) of the [Cout][2 Chalf]
+ * weight, y / stats as spcl_conv3x3_forward.  Only where a specialised kernel exists (Chalf 16 or 32, 14-column tiles,
+ * not a layer whose weight gradient the batched GEMM takes): spcl_conv_cat_supported answers; spcl_conv3x3_wgrad_cat is
+ * the matching weight gradient (workspace: spcl_conv_wgrad_workspace_bytes with CinK = 2 Chalf).  The input gradient is the
+ * ordinary dgrad: one [N][H][W][2 Chalf] tensor whose channel halves the two producers' backward passes read in place
+ * (spcl_bnrelu_pool_backward_strided). */
+int spcl_conv_cat_supported(int dtype, int N, int H, int W, int Chalf, int CoutS);
+int spcl_conv3x3_forward_cat(const void* xa, const void* xb, int dtype, int N, int H, int W, int Chalf, int CoutS,
+                             const void* w_packed, void* y, float* stats, void* stream);
+int spcl_conv3x3_wgrad_cat(const void* xa, const void* xb, const void* dy, int dtype, int N, int H, int W, int Chalf,
+                           int Cout, int CoutS, float* partial, float* dw_oihw, void* stream);
 
 /* dW[co][ci][ky][kx] (OIHW f32, overwritten) = sum_pixels act(x)[p+tap][ci] * dy[p][co]   (weight gradient of
  * unet.py:72,75).  x / in_mode / CinK as in forward; Cin, Cout = real channel counts of dW.
@@ -229,7 +242,7 @@ int spcl_l2norm_rows_backward(const float* x, const float* dz, size_t rows, int 
  * 1) / in_scale / in_shift as above with CinK == Cin; dw_oihw [Cout][Cin][3][3] f32 is overwritten, or added to when
  * accumulate != 0 (a gradient bucket that was zeroed before backward and may already hold another use's gradient).
  * partial: spcl_conv_wgrad_batched_workspace_bytes(items, n) bytes.  items is host memory, read during the call. */
-#define SPCL_WGRAD_BATCH_MAX 8
+#define SPCL_WGRAD_BATCH_MAX 16
 typedef struct spcl_wgrad_item {
   const void* x;
   const void* dy;
@@ -253,7 +266,7 @@ int spcl_conv3x3_wgrad_batched(const spcl_wgrad_item* items, int n, int accumula
  *   *slot and leaves dw untouched (slot == NULL disarms).  A producer that takes the batched path itself (bf16, channel
  *   counts multiples of 64) ignores the capture and clears it; slot->kind stays -1 then.
  * unet.py:72,75 weight gradients; replaces nothing new in the reference, only removes launches. */
-#define SPCL_WGRAD_TAILS_MAX 8
+#define SPCL_WGRAD_TAILS_MAX 16
 typedef struct spcl_wgrad_tail {
   const float* partial; /* kind 0: [nsplit][nblk_ci*nblk_co][9*CIB*COB]; kind 1: [nsplit][9][COB] */
   float* dw;            /* OIHW destination */

@@ -676,6 +676,52 @@ extern "C" int spcl_conv3x3_forward(const void* x, int dtype, int N, int H, int 
   return SPCL_OK;
 }
 
+// The decoder's torch.cat((skip, up), dim=1) -> Conv2d (unet.py:194-224) without the concatenated tensor: the convolution
+// reads its input channels [0, Chalf) from xa and [Chalf, 2 Chalf) from xb (both dense [N][H][W][Chalf] bf16, no input
+// transform).  Only where a specialised kernel exists (14-column tiles, 2 Chalf = 32 or 64): ask _supported first.
+static bool conv_cat_args(ConvArgs& a, int dtype, int N, int H, int W, int Chalf, int CoutS) {
+  static const bool off = getenv("SPCL_CONV_CAT") && atoi(getenv("SPCL_CONV_CAT")) == 0;  // A/B switch
+  if (off || dtype != SPCL_BF16 || N <= 0 || H <= 0 || W <= 0 || (Chalf != 16 && Chalf != 32) || CoutS % 16 != 0 || CoutS <= 0)
+    return false;
+  if ((2 * Chalf) % 64 == 0 && CoutS % 64 == 0) return false;  // (its weight gradient would be a batched-GEMM layer: wgrad.hip)
+  a.in_scale = a.in_shift = nullptr;
+  a.stats = nullptr;
+  a.N = N; a.H = H; a.W = W; a.CinS = 2 * Chalf; a.CinK = 2 * Chalf; a.CoutS = CoutS; a.in_mode = 0;
+  a.tilesX = a.tilesY = 0;
+  a.tpw = 1;
+  a.dbg = 0;
+  return !conv_use_gemm(a.CinK, CoutS, H, W) && pick_tile(H, W).tw == 14;
+}
+
+extern "C" int spcl_conv_cat_supported(int dtype, int N, int H, int W, int Chalf, int CoutS) {
+  ConvArgs a;
+  if (!conv_cat_args(a, dtype, N, H, W, Chalf, CoutS)) return 0;
+  static const char dummy[16] = {0};
+  a.x = dummy; a.x2 = dummy; a.y = nullptr; a.wp = nullptr;
+  return launch_conv_fast(a, pick_tile(H, W).th, nullptr, true) ? 1 : 0;
+}
+
+extern "C" int spcl_conv3x3_forward_cat(const void* xa, const void* xb, int dtype, int N, int H, int W, int Chalf, int CoutS,
+                                        const void* w_packed, void* y, float* stats, void* stream) {
+  SPCL_CHECK_ARG(xa && xb && y && w_packed, "conv3x3_forward_cat: null pointer");
+  SPCL_CHECK_ARG((uintptr_t)xa % 16 == 0 && (uintptr_t)xb % 16 == 0, "conv3x3_forward_cat: inputs must be 16-byte aligned");
+  ConvArgs a;
+  if (!conv_cat_args(a, dtype, N, H, W, Chalf, CoutS)) {
+    set_error("conv3x3_forward_cat: unsupported configuration (bf16, Chalf 16 or 32, 14-column tiles)");
+    return SPCL_EUNSUPPORTED;
+  }
+  a.x = xa; a.x2 = xb; a.y = y; a.wp = w_packed; a.stats = stats;
+  hipStream_t st = (hipStream_t)stream;
+  const double px = (double)N * H * W;
+  prof_cost(px * (2.0 * Chalf + CoutS) * 2.0 + 9.0 * 2.0 * Chalf * CoutS * 2.0, 2.0 * px * 9.0 * 2.0 * Chalf * CoutS);
+  if (!launch_conv_fast(a, pick_tile(H, W).th, st)) {
+    set_error("conv3x3_forward_cat: no specialised kernel for H=%d W=%d Chalf=%d CoutS=%d", H, W, Chalf, CoutS);
+    return SPCL_EUNSUPPORTED;
+  }
+  SPCL_LAUNCH_CHECK("conv3x3_forward_cat");
+  return SPCL_OK;
+}
+
 // dgrad of the SECOND conv of a block fused with the per-tile partial sums of the FIRST conv's BatchNorm backward (the
 // dgrad's output g is the gradient of relu(bn(y2))): saves the separate reduction pass over (y2, g).  Only where a
 // specialised kernel exists (bf16, tiles of 14 columns): ask spcl_conv_dgrad_bnstats_supported first.

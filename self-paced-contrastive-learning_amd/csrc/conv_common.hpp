@@ -49,6 +49,9 @@ struct ConvArgs {
   // ... and, for the block whose first conv reads a ONE-CHANNEL f32 image (unet.py:123), the nine sums
   // sum_p dz[p][co] img[p + tap] of that conv's weight gradient as rows 2 .. 10 of rows2 ([tile][11][CoutS], MODE 4)
   const float* img2 = nullptr;
+  // the input as the channel concatenation of TWO dense tensors (x: channels [0, CinK / 2), x2: the rest; each
+  // [N][H][W][CinK / 2]) -- torch.cat((skip, up), 1) of the decoder read in place (fast path only, one slab: CinK <= 64)
+  const void* x2 = nullptr;
 };
 
 template <typename T> __device__ __forceinline__ f32x4 mfma_chunk(u32x4 w, u32x4 x, f32x4 acc);

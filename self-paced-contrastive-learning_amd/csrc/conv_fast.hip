@@ -16,6 +16,7 @@ namespace spcl {
 
 struct FastArgs {
   const unsigned char* x;
+  const unsigned char* x2;  // non-null: the second half of the input channels comes from this tensor (ConvArgs::x2)
   unsigned char* y;
   const u32x4* wp;
   float* stats;
@@ -171,8 +172,14 @@ conv3x3_fast_kernel(FastArgs a) {
   // so iteration k moves by a compile-time (dky, dkx)
   const int ch = t & (CP - 1), q0 = t / CP;
   const int hy0 = q0 / HW_, hx0 = q0 % HW_;
-  const unsigned char* xb = a.x + (((long)n * a.H + (y0 - 1)) * a.W + (x0 - 1)) * gps;  // halo origin (may be outside)
-  const unsigned voff = (unsigned)((hy0 * a.W + hx0) * gps + ch * 16);
+  // (two sources: a pixel's chunks [0, CP / 2) sit in x, the others in x2, each tensor with half the pixel stride -- a
+  // per-thread choice of base pointer, fixed for the launch)
+  const bool two = a.x2 != nullptr;
+  const int gps1 = two ? gps / 2 : gps;
+  const int ch1 = two ? (ch & (CP / 2 - 1)) : ch;
+  const unsigned char* xsrc = (two && ch >= CP / 2) ? a.x2 : a.x;
+  const unsigned char* xb = xsrc + (((long)n * a.H + (y0 - 1)) * a.W + (x0 - 1)) * gps1;  // halo origin (may be outside)
+  const unsigned voff = (unsigned)((hy0 * a.W + hx0) * gps1 + ch1 * 16);
   unsigned char* const lp = lds + (hy0 * RP + hx0) * PS + ch * 16;
 
   // per-lane LDS base of each m-tile's pixel p = 16 i + r16 (+ the lane's k-group when a step stays inside one tap)
@@ -217,7 +224,7 @@ conv3x3_fast_kernel(FastArgs a) {
     for (int k = 0; k < ITER; ++k) {
       const int dky = QS >= HW_ ? k * (QS / HW_) : k / (HW_ / QS);
       const int dkx = QS >= HW_ ? 0 : (k % (HW_ / QS)) * QS;
-      const long soff = ((long)dky * a.W + dkx) * gps;  // wave-uniform
+      const long soff = ((long)dky * a.W + dkx) * gps1;  // wave-uniform
       bool inb = (NCH % NTHR == 0) || (k * NTHR + t < NCH);
       if (!interior) {
         const int gy = y0 - 1 + hy0 + dky, gx = x0 - 1 + hx0 + dkx;
@@ -764,7 +771,8 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
   if (c.in_mode == 2) {
     if (c.CinS != 1 || c.CoutS != 16 || th != 14) return false;
     FastArgs a;
-    a.x = (const unsigned char*)c.x; a.y = (unsigned char*)c.y; a.wp = (const u32x4*)c.wp; a.stats = c.stats;
+    if (c.x2 != nullptr) return false;
+    a.x = (const unsigned char*)c.x; a.x2 = nullptr; a.y = (unsigned char*)c.y; a.wp = (const u32x4*)c.wp; a.stats = c.stats;
     a.in_scale = a.in_shift = nullptr;
     a.y2 = nullptr; a.scale2 = a.shift2 = a.mean2 = nullptr; a.rows2 = nullptr; a.H2 = a.W2 = 0; a.img2 = nullptr;
     a.N = c.N; a.H = c.H; a.W = c.W; a.CinK = 16; a.CoutS = 16;
@@ -803,6 +811,9 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
   if (ntn % (NT * nw) != 0) return false;
   FastArgs a;
   a.x = (const unsigned char*)c.x; a.y = (unsigned char*)c.y; a.wp = (const u32x4*)c.wp; a.stats = c.stats;
+  a.x2 = (const unsigned char*)c.x2;
+  // two input tensors: one slab whose 16-byte chunks split evenly between them (32 = 16 + 16, 64 = 32 + 32 channels)
+  if (c.x2 != nullptr && !(c.CinK == KC && KC >= 32 && c.rows2 == nullptr && c.img2 == nullptr)) return false;
   a.in_scale = c.in_scale; a.in_shift = c.in_shift;
   a.y2 = (const unsigned char*)c.y2; a.scale2 = c.scale2; a.shift2 = c.shift2; a.mean2 = c.mean2; a.rows2 = c.rows2;
   a.H2 = c.H2; a.W2 = c.W2;

@@ -22,6 +22,8 @@ constexpr int WG_TW = 16, WG_HW = WG_TW + 2;
 
 struct WgradArgs {
   const void* x;
+  const void* x2;  // non-null: input channels [xsplit, 2 xsplit) come from this tensor, [0, xsplit) from x; both dense
+  int xsplit;      // [N][H][W][xsplit] (the decoder's concatenation read in place, spcl_conv3x3_wgrad_cat)
   const void* dy;
   const float* in_scale;
   const float* in_shift;
@@ -167,7 +169,13 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_wgrad_kernel(WgradArgs a)
 
   // ---- global -> registers (issued one tile ahead of the MFMAs).  Addresses = one wave-uniform 64-bit tile base + a
   // 32-bit per-thread offset fixed for the whole launch + a wave-uniform row step per iteration.
-  const int xvoff = (xhy0 * a.W + xhx) * a.CinS + (IM == 2 ? 0 : ci0 + xch * EPC);
+  // (two input tensors: the thread's channel chunk picks its tensor once; pixel stride = that tensor's channel count)
+  const bool xtwo = IM != 2 && a.x2 != nullptr;
+  const int xc0 = ci0 + xch * EPC;                              // the thread's first channel of the logical input
+  const int xps = xtwo ? a.xsplit : a.CinS;                     // elements between two pixels of the tensor it reads
+  const int xc1 = xtwo && xc0 >= a.xsplit ? xc0 - a.xsplit : xc0;
+  const T* const xsrc = xtwo && xc0 >= a.xsplit ? (const T*)a.x2 : (const T*)a.x;
+  const int xvoff = (xhy0 * a.W + xhx) * xps + (IM == 2 ? 0 : xc1);
   const int dvoff = (dry0 * a.W + dcol) * a.CoutS + co0 + dch * EPC;
   auto load_tile = [&](int tile) {
     const int n = tile / tpi;
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_wgrad_kernel(WgradArgs a)
     xmask = 0;
     const int gx = x0 - 1 + xhx;
     const bool colok = interior || (gx >= 0 && gx < a.W);
-    const long xorigin = (((long)n * a.H + (y0 - 1)) * a.W + (x0 - 1)) * a.CinS;  // halo origin, may be outside
+    const long xorigin = (((long)n * a.H + (y0 - 1)) * a.W + (x0 - 1)) * xps;  // halo origin, may be outside
     // Loads are UNCONDITIONAL (out-of-image lanes read a valid dummy address and are zeroed when the tile is written
     // to LDS): a load inside a divergent branch made the compiler wait for it at the join -- ten serialised L2 round
     // trips (~2 200 cycles) per tile, measured with in-kernel stamps.
@@ -188,7 +196,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_wgrad_kernel(WgradArgs a)
       const int gy = y0 - 1 + hy;
       const bool ok = xact && hy < NHROWS && colok && (interior || (gy >= 0 && gy < a.H));
       xmask |= (ok ? 1u : 0u) << i;
-      const long rowoff = xorigin + (long)(i * XRPI) * a.W * a.CinS;  // wave-uniform
+      const long rowoff = xorigin + (long)(i * XRPI) * a.W * xps;  // wave-uniform
       if (IM == 2) {
         u32x4 v = {0u, 0u, 0u, 0u};
         if (ok) {
@@ -209,7 +217,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_wgrad_kernel(WgradArgs a)
         }
         rx[i] = v;
       } else {
-        const T* src = ok ? (const T*)a.x + rowoff + xvoff : (const T*)a.x + ci0 + xch * EPC;
+        const T* src = ok ? xsrc + rowoff + xvoff : xsrc + xc1;
         rx[i] = *(const u32x4*)src;
       }
     }
@@ -503,9 +511,34 @@ extern "C" size_t spcl_conv_wgrad_workspace_bytes(int N, int H, int W, int CinK,
   return bytes;
 }
 
+static int conv3x3_wgrad_impl(const void* x, const void* x2, const void* dy, int dtype, int N, int H, int W, int Cin, int CinS,
+                              int CinK, int Cout, int CoutS, int in_mode, const float* in_scale, const float* in_shift,
+                              float* partial, float* dw_oihw, void* stream);
+
 extern "C" int spcl_conv3x3_wgrad(const void* x, const void* dy, int dtype, int N, int H, int W, int Cin, int CinS,
                                   int CinK, int Cout, int CoutS, int in_mode, const float* in_scale,
                                   const float* in_shift, float* partial, float* dw_oihw, void* stream) {
+  return conv3x3_wgrad_impl(x, nullptr, dy, dtype, N, H, W, Cin, CinS, CinK, Cout, CoutS, in_mode, in_scale, in_shift, partial,
+                            dw_oihw, stream);
+}
+
+// ... of the convolution behind the decoder's torch.cat((skip, up), dim=1) (unet.py:194-224), its input read from the two
+// tensors in place: xa = channels [0, Chalf), xb = [Chalf, 2 Chalf), both dense [N][H][W][Chalf] bf16 (Chalf 16 or 32; not
+// the layers the batched GEMM kernel takes: 2 Chalf and CoutS both multiples of 64).  Workspace as spcl_conv3x3_wgrad with
+// CinK = 2 Chalf.
+extern "C" int spcl_conv3x3_wgrad_cat(const void* xa, const void* xb, const void* dy, int dtype, int N, int H, int W, int Chalf,
+                                      int Cout, int CoutS, float* partial, float* dw_oihw, void* stream) {
+  SPCL_CHECK_ARG(xa && xb, "conv3x3_wgrad_cat: null pointer");
+  SPCL_CHECK_ARG(dtype == SPCL_BF16 && (Chalf == 16 || Chalf == 32) && !((2 * Chalf) % 64 == 0 && CoutS % 64 == 0),
+                 "conv3x3_wgrad_cat: bf16, Chalf 16 or 32, not a batched-GEMM layer");
+  SPCL_CHECK_ARG((uintptr_t)xa % 16 == 0 && (uintptr_t)xb % 16 == 0, "conv3x3_wgrad_cat: inputs must be 16-byte aligned");
+  return conv3x3_wgrad_impl(xa, xb, dy, dtype, N, H, W, 2 * Chalf, 2 * Chalf, 2 * Chalf, Cout, CoutS, 0, nullptr, nullptr,
+                            partial, dw_oihw, stream);
+}
+
+static int conv3x3_wgrad_impl(const void* x, const void* x2, const void* dy, int dtype, int N, int H, int W, int Cin, int CinS,
+                              int CinK, int Cout, int CoutS, int in_mode, const float* in_scale, const float* in_shift,
+                              float* partial, float* dw_oihw, void* stream) {
   SPCL_CHECK_ARG(x && dy && partial && dw_oihw, "conv3x3_wgrad: null pointer");
   SPCL_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3_wgrad: bad shape");
   SPCL_CHECK_ARG(CinK % 16 == 0 && CoutS % 16 == 0 && Cin <= CinK && Cout <= CoutS, "conv3x3_wgrad: channel padding");
@@ -517,12 +550,12 @@ extern "C" int spcl_conv3x3_wgrad(const void* x, const void* dy, int dtype, int 
   spcl_wgrad_tail* tail = take_tail_capture();  // non-null: leave the final sum to spcl_conv3x3_wgrad_batched_tails
   if (dtype == SPCL_BF16) {
     spcl_wgrad_item it;
-    if (wide_item(it, x, dy, N, H, W, Cin, CinS, CinK, Cout, CoutS, in_mode, in_scale, in_shift, dw_oihw))
+    if (x2 == nullptr && wide_item(it, x, dy, N, H, W, Cin, CinS, CinK, Cout, CoutS, in_mode, in_scale, in_shift, dw_oihw))
       return spcl_conv3x3_wgrad_batched(&it, 1, 0, partial, stream);
   }
   WgradPlan p = wgrad_plan(N, H, W, CinK, CoutS, dtype == SPCL_F32 ? 4 : 2);
   WgradArgs a;
-  a.x = x; a.dy = dy; a.in_scale = in_scale; a.in_shift = in_shift; a.partial = partial;
+  a.x = x; a.x2 = x2; a.xsplit = x2 ? CinK / 2 : 0; a.dy = dy; a.in_scale = in_scale; a.in_shift = in_shift; a.partial = partial;
   a.N = N; a.H = H; a.W = W; a.CinS = CinS; a.CinK = CinK; a.CoutS = CoutS; a.in_mode = in_mode;
   a.tilesX = p.tilesX; a.tilesY = p.tilesY; a.ntiles = p.ntiles; a.nblk_ci = p.nblk_ci; a.nblk_co = p.nblk_co;
   static const int env_dbuf = getenv("SPCL_WGRAD_DBUF") ? atoi(getenv("SPCL_WGRAD_DBUF")) : 1;

@@ -683,6 +683,20 @@ def _conv(x_store, dt_code, dtype, N, H, W, cin_s, cin_k, cout_s, wp, in_mode, s
     return y, stats
 
 
+def _conv_cat(xa, xb, dt_code, dtype, N, H, W, chalf, cout_s, wp, want_stats):
+    """the convolution of ``torch.cat((xa, xb), channel)`` read from the two tensors (spcl_conv3x3_forward_cat)"""
+    dev = xa.device
+    y = torch.empty(N, H, W, cout_s, dtype=dtype, device=dev)
+    stats = None
+    if want_stats:
+        nt = _n.call("spcl_conv_stat_rows", dt_code, N, H, W, 2 * chalf, cout_s)
+        stats = torch.empty(_n.call("spcl_bn_stats_elems", nt, cout_s), dtype=torch.float32, device=dev)
+        stats.ntiles = nt
+    _n.call("spcl_conv3x3_forward_cat", _n.ptr(xa), _n.ptr(xb), dt_code, N, H, W, chalf, cout_s, _n.ptr(wp), _n.ptr(y),
+            _n.ptr(stats), _n.stream())
+    return y, stats
+
+
 def _bn_stats(stats, cfg: BlockCfg, C, cs, gamma, beta, which, dev):
     """-> tensor [4, cs]: mean, invstd, scale, shift."""
     st = torch.empty(4, cs, dtype=torch.float32, device=dev)
@@ -721,7 +735,7 @@ class DeferredWgrads:
         self.items.append(it)
         self.keep.append((x_store, dy, scale, shift))  # operands stay alive until the launch
         self.targets.add(sink.data_ptr())
-        if len(self.items) == _n.WGRAD_BATCH_MAX:
+        if len(self.items) == _QUEUE_MAX[0]:
             self.flush()
 
     def capture_tail(self, sink, keep, launch):
@@ -740,7 +754,7 @@ class DeferredWgrads:
         self.tails.append(tail)
         self.keep.append(keep)
         self.targets.add(sink.data_ptr())
-        if len(self.tails) == _n.WGRAD_TAILS_MAX:
+        if len(self.tails) == _QUEUE_MAX[1]:
             self.flush()
         return True
 
@@ -751,6 +765,11 @@ class DeferredWgrads:
         self.items, self.keep, self.tails = [], [], []
 
 
+# items / tails a queue holds before it flushes by itself (A/B switch SPCL_WGRAD_QUEUE_MAX; the library's limits by default:
+# the whole UNet's eleven wide layers and ten narrow ones then leave in ONE batched launch at the gather)
+_QUEUE_MAX = (min(_n.WGRAD_BATCH_MAX, int(os.environ.get("SPCL_WGRAD_QUEUE_MAX", _n.WGRAD_BATCH_MAX))),
+              min(_n.WGRAD_TAILS_MAX, int(os.environ.get("SPCL_WGRAD_QUEUE_MAX", _n.WGRAD_TAILS_MAX))))
+_CONV_CAT = os.environ.get("SPCL_CONV_CAT", "1") != "0"  # A/B switch: 0 materialises the 16-channel decoder concatenation
 _PACK_AT = os.environ.get("SPCL_PACK_AT", "1") != "0"  # A/B switch: 0 packs the band-GEMM layout whether or not it is used
 _TAILS = os.environ.get("SPCL_WGRAD_TAILS", "1") != "0"  # A/B switch: 0 keeps every layer's own final reduction launch
 
@@ -795,6 +814,27 @@ def _wgrad(x_store, dy, dt_code, N, H, W, cin, cin_s, cin_k, cout, cout_s, in_mo
     if queue is not None and _TAILS:
         # narrow layer straight into a bucket slice: its final sum joins the batched launch (no separate reduce launch)
         if queue.capture_tail(sink, (ws, dy, x_store, scale, shift), launch):
+            return None
+        return dw
+    launch()
+    return dw
+
+
+def _wgrad_cat(xa, xb, dy, dt_code, N, H, W, chalf, cout, cout_s, sink=None):
+    """weight gradient of the convolution of ``cat((xa, xb), channel)``, the input read from the two tensors
+    (spcl_conv3x3_wgrad_cat); the final sum rides in the batched launch when ``sink`` belongs to a bucket, as in ``_wgrad``"""
+    dev = dy.device
+    nbytes = _n.call("spcl_conv_wgrad_workspace_bytes", N, H, W, 2 * chalf, cout_s)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    dw = _grad_buffer(sink, (cout, 2 * chalf, 3, 3), dev)
+
+    def launch():
+        _n.call("spcl_conv3x3_wgrad_cat", _n.ptr(xa), _n.ptr(xb), _n.ptr(dy), dt_code, N, H, W, chalf, cout, cout_s,
+                _n.ptr(ws), _n.ptr(dw), _n.stream())
+
+    queue = sink_queue(sink)
+    if queue is not None and _TAILS:
+        if queue.capture_tail(sink, (ws, dy, xa, xb), launch):
             return None
         return dw
     launch()
@@ -1020,14 +1060,25 @@ class _ConvBlockFn(torch.autograd.Function):
     loader, the second's into the (optional) activation / pooled writers."""
 
     @staticmethod
-    def forward(ctx, x, wa, ga, ba, wb, gb, bb, cfg: BlockCfg):
+    def forward(ctx, x, wa, ga, ba, wb, gb, bb, cfg: BlockCfg, x2=None):
+        """``x2``: the block's input is ``torch.cat((x, x2), 1)`` (the decoder's skip concatenation, unet.py:194-224), read
+        from the two tensors in place (``cat_pair_supported`` must have said yes): no concatenated tensor in the forward,
+        ONE gradient tensor in the backward whose channel halves are returned as views."""
         _n.require_gpu(x, wa, wb)
         dtype, dev = cfg.dtype, x.device
         dtc = _n.dtype_code(dtype)
         N, cin, H, W = x.shape
         cout = wa.shape[0]
         cout_s = _ru16(cout)
-        if cfg.image_input:
+        x2s = None
+        if x2 is not None:
+            xs, x2s = to_nhwc_padded(x.detach(), dtype), to_nhwc_padded(x2.detach(), dtype)
+            assert not cfg.image_input and x2.shape == x.shape and xs.shape[3] == cin and x2s.shape[3] == cin \
+                and wa.shape[1] == 2 * cin, (tuple(x.shape), tuple(x2.shape), tuple(wa.shape))
+            chalf, cin = cin, 2 * cin
+            cin_s = cin_k = cin
+            mode_a = 0
+        elif cfg.image_input:
             if cin > 16:
                 raise NotImplementedError("image-input block supports input_dim <= 16")
             xs = x.detach().float().permute(0, 2, 3, 1).contiguous()  # [N,H,W,cin] f32 (a view when cin == 1)
@@ -1051,7 +1102,10 @@ class _ConvBlockFn(torch.autograd.Function):
             (wpa, wpa_t), (wpb, wpb_t) = _pack_block(wa, wb, dtc, dtype, *((H, W) if _PACK_AT else (0, 0)))
         else:
             wpa, wpb, wpa_t, wpb_t = _pack(wa, 0, dtc, dtype), _pack(wb, 0, dtc, dtype), None, None
-        ya, sa = _conv(xs, dtc, dtype, N, H, W, cin_s, cin_k, cout_s, wpa, mode_a, None, None, cfg.training)
+        if x2s is not None:
+            ya, sa = _conv_cat(xs, x2s, dtc, dtype, N, H, W, chalf, cout_s, wpa, cfg.training)
+        else:
+            ya, sa = _conv(xs, dtc, dtype, N, H, W, cin_s, cin_k, cout_s, wpa, mode_a, None, None, cfg.training)
         sta = _bn_stats(sa, cfg, cout, cout_s, ga, ba, 0, dev)
         yb, sb = _conv(ya, dtc, dtype, N, H, W, cout_s, cout_s, cout_s, wpb, 1, sta[2], sta[3], cfg.training)
         stb = _bn_stats(sb, cfg, cout, cout_s, gb, bb, 1, dev)
@@ -1066,6 +1120,7 @@ class _ConvBlockFn(torch.autograd.Function):
             pool = torch.empty(N, H // 2, W // 2, cout_s, dtype=dtype, device=dev) if cfg.need_pool else None
             _bnrelu_fwd(yb, dtc, N, H, W, cout_s, stb[2], stb[3], act, pool)
         ctx.save_for_backward(xs, ya, yb, sta, stb, wa, wb)
+        ctx.x2s = x2s  # (not an input of this Function as a tensor object: a detached re-layout, kept directly)
         ctx.params = (wa, ga, ba, wb, gb, bb)
         ctx.packed_t = (wpa_t, wpb_t)
         ctx.cfg = cfg
@@ -1100,7 +1155,8 @@ class _ConvBlockFn(torch.autograd.Function):
             da_s = to_nhwc_padded(d_act, dtype) if (d_act is not None and g_nc is None) else None
         dp_s = to_nhwc_padded(d_pool, dtype) if d_pool is not None else None
         if da_s is None and dp_s is None and g_nc is None:
-            return (None,) * 8
+            return (None,) * 9
+        x2s = ctx.x2s
         # ---- second conv
         ng = ctx.needs_input_grad
         sk = tuple(take_grad_sink(p, ng[i + 1]) for i, p in enumerate(ctx.params))  # (wa, ga, ba, wb, gb, bb)
@@ -1164,10 +1220,14 @@ class _ConvBlockFn(torch.autograd.Function):
             else:
                 dya, dga, dba = _bnrelu_bwd(ya, daa, None, dtc, dtype, N, H, W, cout, cout_s, sta, cfg.training,
                                             sk[1:3])
-            dwa = _wgrad(xs, dya, dtc, N, H, W, cin, cin_s, cin_k, cout, cout_s, mode_a, None, None, sk[0]) \
-                if ctx.needs_input_grad[1] else None
-        dx = None
-        if ctx.needs_input_grad[0]:
+            if not ctx.needs_input_grad[1]:
+                dwa = None
+            elif x2s is not None:
+                dwa = _wgrad_cat(xs, x2s, dya, dtc, N, H, W, cin // 2, cout, cout_s, sk[0])
+            else:
+                dwa = _wgrad(xs, dya, dtc, N, H, W, cin, cin_s, cin_k, cout, cout_s, mode_a, None, None, sk[0])
+        dx = dx2 = None
+        if ctx.needs_input_grad[0] or (x2s is not None and ctx.needs_input_grad[8]):
             if cfg.image_input:
                 raise NotImplementedError("gradient w.r.t. the input image is not on the hot path")
             if wpa_t is None:
@@ -1186,17 +1246,43 @@ class _ConvBlockFn(torch.autograd.Function):
                 li.rows, li.dx_ptr = rows, dxs.data_ptr()
             if dxs is None:
                 dxs, _ = _conv(dya, dtc, dtype, N, H, W, cout_s, cout_s, cin_s, wpa_t, 0, None, None, False)
-            dx = nhwc_to_logical(dxs, cin)
-            if dx.dtype != xdt:
-                dx = dx.to(xdt)
+            if x2s is not None:
+                # one gradient tensor for the concatenation; each producer's backward reads its channel half in place
+                # (nhwc_channel_slice -> the _strided BatchNorm entry points)
+                full = dxs.permute(0, 3, 1, 2)
+                dx, dx2 = full[:, :cin // 2], full[:, cin // 2:]
+                if dx.dtype != xdt:
+                    dx, dx2 = dx.to(xdt), dx2.to(xdt)
+                if not ctx.needs_input_grad[0]:
+                    dx = None
+                if not ctx.needs_input_grad[8]:
+                    dx2 = None
+            else:
+                dx = nhwc_to_logical(dxs, cin)
+                if dx.dtype != xdt:
+                    dx = dx.to(xdt)
         ng = ctx.needs_input_grad
         return (dx, dwa, dga if ng[2] else None, dba if ng[3] else None, dwb, dgb if ng[5] else None,
-                dbb if ng[6] else None, None)
+                dbb if ng[6] else None, None, dx2)
 
 
-def conv_block(x, wa, ga, ba, wb, gb, bb, cfg: BlockCfg):
-    """-> (act or None, pooled or None), logical NCHW views over NHWC storage."""
-    return _ConvBlockFn.apply(x, wa, ga, ba, wb, gb, bb, cfg)
+def conv_block(x, wa, ga, ba, wb, gb, bb, cfg: BlockCfg, x2=None):
+    """-> (act or None, pooled or None), logical NCHW views over NHWC storage.  ``x2``: see ``_ConvBlockFn.forward``."""
+    return _ConvBlockFn.apply(x, wa, ga, ba, wb, gb, bb, cfg, x2)
+
+
+def cat_pair_supported(a, b, cout, dtype):
+    """can ``conv_block(a, ..., x2=b)`` stand for ``conv_block(torch.cat((a, b), 1), ...)``?  (two dense bf16 NHWC tensors of
+    16 or 32 channels each at a size the specialised convolution kernels tile: spcl_conv_cat_supported)"""
+    if not (_CONV_CAT and a.is_cuda and b.is_cuda and a.shape == b.shape and a.dim() == 4 and dtype == torch.bfloat16
+            and a.dtype == dtype and b.dtype == dtype):
+        return False
+    N, C, H, W = a.shape
+    for t in (a, b):
+        st, cs = as_nhwc(t)
+        if cs != C or (st.data_ptr() % 16):
+            return False
+    return bool(_n.call("spcl_conv_cat_supported", _n.dtype_code(dtype), N, H, W, C, _ru16(cout)))
 
 
 # --------------------------------------------------------------------------------------------- decoder / head (N1)
@@ -1395,8 +1481,8 @@ class _SupLossFn(torch.autograd.Function):
         ws = torch.empty(_n.call("spcl_kl_workspace_bytes") // 4, dtype=torch.float32, device=dev)
         loss = torch.empty((), dtype=torch.float32, device=dev)
         dl = torch.empty_like(ls)
-        inter = torch.zeros(N, K, dtype=torch.int64, device=dev)
-        union = torch.zeros(N, K, dtype=torch.int64, device=dev)
+        both = torch.zeros(2, N, K, dtype=torch.int64, device=dev)  # (one fill; a caller that keeps them clones ``inter._base`` once)
+        inter, union = both[0], both[1]
         _n.call("spcl_sup_loss_forward", _n.ptr(ls), _n.ptr(lab), N, H * W, K, c_float(eps), _n.ptr(ws), _n.ptr(loss),
                 _n.ptr(dl), _n.ptr(inter), _n.ptr(union), _n.stream())
         counts.append((inter, union))
@@ -1406,7 +1492,32 @@ class _SupLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dl,) = ctx.saved_tensors
+        if is_unit_gradient(g):  # the epocher's own ``backward(gradient=ones)``: x * 1.0 is x, the pass over the class map is skipped
+            return dl.permute(0, 3, 1, 2), None, None, None
         return (dl * g.detach().float()).permute(0, 3, 1, 2), None, None, None
+
+
+_UNIT_GRADIENTS = {}  # data_ptr -> weakref of a 0-dim tensor its owner promises to keep at exactly 1.0
+
+
+def register_unit_gradient(t: torch.Tensor):
+    """``t`` (0-dim, value 1.0, never written again by its owner) is what ``loss.backward(gradient=t)`` will be called with:
+    a backward that recognises it by its storage skips the multiplication by it.  Held weakly."""
+    import weakref
+    assert t.numel() == 1
+    _UNIT_GRADIENTS[t.data_ptr()] = weakref.ref(t)
+    return t
+
+
+def is_unit_gradient(g: torch.Tensor) -> bool:
+    ref = _UNIT_GRADIENTS.get(g.data_ptr()) if g.numel() == 1 else None
+    if ref is None:
+        return False
+    t = ref()
+    if t is None or t.data_ptr() != g.data_ptr() or t.dtype != g.dtype:
+        _UNIT_GRADIENTS.pop(g.data_ptr(), None)  # (the registered tensor is gone: its address may belong to anything now)
+        return False
+    return True
 
 
 def sup_loss_kl_onehot(logits, labels, eps=1e-16):

@@ -54,6 +54,9 @@ _SIGNATURES = {
     "spcl_conv_num_tiles": (c_int, [c_int, c_int, c_int]),
     "spcl_conv_stat_rows": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "spcl_conv_set_gemm": (None, [c_int]),
+    "spcl_conv_cat_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "spcl_conv3x3_forward_cat": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "spcl_conv3x3_wgrad_cat": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "spcl_bn_stats_elems": (c_size_t, [c_int, c_int]),
     "spcl_conv3x3_forward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P,
                                      _P]),
@@ -154,7 +157,7 @@ class PackItem(ctypes.Structure):
                 ("H", c_int), ("W", c_int)]
 
 
-PACK_MULTI_MAX = 20
+PACK_MULTI_MAX = 24
 
 
 class WgradTail(ctypes.Structure):
@@ -163,9 +166,9 @@ class WgradTail(ctypes.Structure):
                 ("nblk_co", c_int), ("CIB", c_int), ("COB", c_int), ("Cin", c_int), ("Cout", c_int)]
 
 
-WGRAD_BATCH_MAX = 8
-WGRAD_TAILS_MAX = 8
-_NO_STATUS = ("spcl_abi_version", "spcl_image_autocorr_rows", "spcl_conv_dgrad_bnstats_image_supported", "spcl_conv16_bwd_fused_supported", "spcl_conv16_bwd_fused_splits", "spcl_conv_num_tiles", "spcl_conv_stat_rows", "spcl_conv_set_gemm", "spcl_profile_count", "spcl_conv_dgrad_bnstats_supported", "spcl_conv_dgrad_poolstats_supported",
+WGRAD_BATCH_MAX = 16
+WGRAD_TAILS_MAX = 16
+_NO_STATUS = ("spcl_abi_version", "spcl_image_autocorr_rows", "spcl_conv_dgrad_bnstats_image_supported", "spcl_conv16_bwd_fused_supported", "spcl_conv16_bwd_fused_splits", "spcl_conv_num_tiles", "spcl_conv_stat_rows", "spcl_conv_set_gemm", "spcl_conv_cat_supported", "spcl_profile_count", "spcl_conv_dgrad_bnstats_supported", "spcl_conv_dgrad_poolstats_supported",
               "spcl_conv_wgrad_batched_supported")
 
 

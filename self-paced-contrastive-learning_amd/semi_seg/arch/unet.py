@@ -98,7 +98,8 @@ class _ConvBlock(nn.Module):
         return F_hip.BlockCfg(dtype, use_batch_stats(bn_a), float(bn_a.momentum), float(bn_a.eps), track, need_act,
                               need_pool, self._image_input, bufs)
 
-    def forward(self, x):
+    def forward(self, x, x2=None):
+        """``x2``: the input is ``torch.cat((x, x2), 1)``, read from the two tensors in place (functional.cat_pair_supported)"""
         need_act, need_pool = self._plan if self._plan is not None else (True, False)
         self._plan = None
         if len(self._forward_hooks) > 0:
@@ -108,7 +109,7 @@ class _ConvBlock(nn.Module):
         cfg.link_in, self._link_in = self._link_in, None
         cfg.act_dst, self._act_dst = self._act_dst, None
         cfg.up2, self._up2 = (self._up2 and len(self._forward_hooks) == 0), False
-        act, pooled = F_hip.conv_block(x, c[0].weight, c[1].weight, c[1].bias, c[3].weight, c[4].weight, c[4].bias, cfg)
+        act, pooled = F_hip.conv_block(x, c[0].weight, c[1].weight, c[1].bias, c[3].weight, c[4].weight, c[4].bias, cfg, x2)
         self._pooled = pooled
         self._link_out = cfg.link_out  # for the block that consumes the pooled output (UNet.forward hands it over)
         return act
@@ -258,11 +259,17 @@ class UNet(nn.Module):
                       and len(blk._forward_hooks) == 0 and len(nxt._forward_hooks) == 0
                       and len(nxt.up[0]._forward_hooks) == 0)
             blk._up2 = pre_up
+            bdt = blk._compute_dtype or _config.get_compute_dtype()
             if skip in cats:
-                d = F_hip.virtual_cat(skips[skip], d, cats[skip][0])
+                d = blk(F_hip.virtual_cat(skips[skip], d, cats[skip][0]))
+            elif (len(blk._forward_pre_hooks) == 0 and torch.is_tensor(skips[skip])
+                  and F_hip.cat_pair_supported(skips[skip], d, blk.conv[0].weight.shape[0], bdt)):
+                # the narrow level (16 + 16 channels: too narrow for the producers to write halves of one buffer -- half a
+                # cache line per pixel): both tensors stay where they are, the block's first convolution and its weight
+                # gradient read them side by side, the gradient comes back as one tensor read half by half
+                d = blk(skips[skip], x2=d)
             else:
-                d = F_hip.concat_channels(skips[skip], d, blk._compute_dtype or _config.get_compute_dtype())
-            d = blk(d)
+                d = blk(F_hip.concat_channels(skips[skip], d, bdt))
             if until == f"Up_conv{lvl}":
                 return d
         return self._Deconv_1x1(d)

@@ -164,7 +164,11 @@ class FineTuneEpocher(_EpocherBase):
             if hasattr(self._optimizer, "sync_lr"):
                 self._optimizer.sync_lr()
             sup_loss = self._step_graph.run(key)
-            inter, union = (t.clone() for t in self._counts)  # the captured step's result tensors are rewritten by the next replay
+            inter, union = self._counts  # the captured step's result tensors are rewritten by the next replay: keep copies
+            if inter._base is not None and inter._base is union._base:
+                inter, union = inter._base.clone().unbind(0)  # (the fused criterion's two halves of one buffer: one launch)
+            else:
+                inter, union = inter.clone(), union.clone()
         if self.on_master():
             dice = self.meters["sup_dice"]
             dice.add_counts(inter, union, dice.group_names_for(inter.shape[0], list(label_group)))
@@ -195,7 +199,7 @@ class FineTuneEpocher(_EpocherBase):
             onehot_target = class2one_hot(labeled_target.squeeze(1), self.num_classes)
             sup_loss = self._sup_criterion(F_hip.softmax_classes(label_logits), onehot_target, disable_assert=True)
         if self._unit is None or self._unit.device != sup_loss.device or self._unit.dtype != sup_loss.dtype:
-            self._unit = torch.ones((), dtype=sup_loss.dtype, device=sup_loss.device)
+            self._unit = F_hip.register_unit_gradient(torch.ones((), dtype=sup_loss.dtype, device=sup_loss.device))
         if self._flat_params is not None:
             self._flat_params.zero_grad()  # arms the gradient sinks: backward fills the flat bucket in place
             sup_loss.backward(gradient=self._unit)

@@ -156,6 +156,20 @@ def test_fused_sup_loss_is_the_separate_kernels_in_one_launch(K, shape):
     loss_c, _ = F.sup_loss_kl_onehot(lc, labels.cuda())
     (loss_c * 1.7).backward()
     np.testing.assert_allclose(lc.grad.cpu().numpy(), 1.7 * lr.grad.numpy(), rtol=1e-4, atol=1e-8)
+    # the epocher's ``backward(gradient=ones)`` with the ones registered: no scaling pass, the same bits
+    unit = F.register_unit_gradient(torch.ones((), device="cuda"))
+    ld = logits.cuda().requires_grad_(True)
+    loss_d, _ = F.sup_loss_kl_onehot(ld, labels.cuda())
+    assert F.is_unit_gradient(unit) and not F.is_unit_gradient(torch.ones((), device="cuda"))
+    loss_d.backward(gradient=unit)
+    assert torch.equal(ld.grad, la.grad)
+    two = torch.full((), 2.0, device="cuda")  # an unregistered upstream gradient still scales
+    le = logits.cuda().requires_grad_(True)
+    loss_e, _ = F.sup_loss_kl_onehot(le, labels.cuda())
+    loss_e.backward(gradient=two)
+    assert torch.equal(le.grad, la.grad * 2.0)
+    del unit
+    assert not any(r() is not None and F.is_unit_gradient(r()) for r in list(F._UNIT_GRADIENTS.values()))
 
 
 def test_universal_dice_meter_matches_oracle():
@@ -264,3 +278,49 @@ def test_full_unet_base_width_vs_oracle_fp32():
         # tiny batch statistics in the deepest layers amplify fp32 summation-order differences: 3e-2 of max
         assert _relerr(params[k].grad.cpu().numpy(), sdo[k].grad.numpy()) < 3e-2, (k, _relerr(
             params[k].grad.cpu().numpy(), sdo[k].grad.numpy()))
+
+
+@pytest.mark.parametrize("N,S", [(2, 224), (3, 112)])
+def test_in_place_decoder_data_movement_is_the_copying_path_bit_for_bit(N, S, monkeypatch):
+    """The decoder's concatenations / upsamples folded into their producers and consumers -- halves of one buffer written in
+    place (>= 32 channels), the 16 + 16 channel level read from its two tensors by the convolution and its weight gradient
+    (spcl_conv3x3_forward_cat / spcl_conv3x3_wgrad_cat), activations written x2-upsampled -- against the same network with
+    the copying kernels (concat2, upsample2x): logits, loss and EVERY parameter gradient bit for bit (bf16)."""
+    import spcl_amd  # noqa
+    from spcl_amd import functional as F
+    from spcl_amd.semi_seg.arch import UNet, unet as unet_mod
+    sd = O.init_unet_state(1, 4, 256, seed=11)
+    g = torch.Generator().manual_seed(12)
+    x = torch.rand(N, 1, S, S, generator=g).cuda()
+    labels = torch.randint(0, 4, (N, S, S), generator=g).cuda()
+
+    def run(in_place):
+        monkeypatch.setattr(unet_mod, "_VIRTUAL_CAT", in_place)
+        monkeypatch.setattr(unet_mod, "_FUSED_UPSAMPLE", in_place)
+        monkeypatch.setattr(F, "_CONV_CAT", in_place)
+        m = UNet(input_dim=1, num_classes=4, max_channel=256)
+        m.load_state_dict(sd, strict=True)
+        m.cuda().train()
+        m.set_compute_dtype(torch.bfloat16)
+        copies = []
+        real_cat = F.concat_channels
+        monkeypatch.setattr(F, "concat_channels", lambda *a, **k: (copies.append(1), real_cat(*a, **k))[1])
+        logits = m(x)
+        monkeypatch.setattr(F, "concat_channels", real_cat)
+        assert len(copies) == (0 if in_place else 4)  # no level falls back to the copying concatenation
+        loss, _ = F.sup_loss_kl_onehot(logits, labels)
+        loss.backward()
+        torch.cuda.synchronize()
+        return logits.detach().clone(), loss.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()}
+
+    la, lossa, ga = run(True)
+    lb, lossb, gb = run(False)
+    assert torch.equal(la, lb) and torch.equal(lossa, lossb)
+    assert set(ga) == set(gb)
+    for k in ga:
+        assert torch.equal(ga[k], gb[k]), k
+        assert float(ga[k].abs().max()) > 0, k
+    # and the narrow level really took the two-tensor convolution
+    monkeypatch.setattr(F, "_CONV_CAT", True)
+    a = torch.zeros(N, 16, S, S, device="cuda", dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    assert F.cat_pair_supported(a, a.clone(memory_format=torch.channels_last), 16, torch.bfloat16)
