@@ -434,6 +434,18 @@ int spcl_conv1x1_forward(const void* x, int dtype, size_t npix, int C, int CS, i
 size_t spcl_conv1x1_bwd_workspace_bytes(int C, int K);
 int spcl_conv1x1_backward(const void* x, const float* dout, int dtype, size_t npix, int C, int CS, int K, const float* w,
                           void* dx, float* dw, float* db, float* ws, void* stream);
+/* The decoder's LAST BatchNorm + ReLU (unet.py:79-81 of Up_conv2) folded into the 1x1 convolution that is its only
+ * consumer (unet.py:229), on both sides: y is the raw output of the last 3x3 convolution ([npix][CS] of dtype), the class map
+ * is conv1x1(relu(scale y + shift)) with the activation rounded to dtype exactly as the writer would have stored it -- no
+ * activation tensor.  Backward: dact = the gradient w.r.t. that activation, dw / db as spcl_conv1x1_backward, and rows
+ * [spcl_conv1x1_bwd_rows(npix)][2][CS] = the partial sums of that BatchNorm's backward (sum dz, sum dz (y - mean)) in the
+ * form spcl_bnrelu_backward_rows finishes: its reduction pass over (y, dact) disappears too. */
+int spcl_conv1x1_forward_bn(const void* y, int dtype, size_t npix, int C, int CS, int K, const float* scale,
+                            const float* shift, const float* w, const float* b, float* out, void* stream);
+int spcl_conv1x1_bwd_rows(size_t npix);
+int spcl_conv1x1_backward_bn(const void* y, const float* dout, int dtype, size_t npix, int C, int CS, int K,
+                             const float* scale, const float* shift, const float* mean, const float* w, void* dact,
+                             float* dw, float* db, float* ws, float* rows, void* stream);
 int spcl_softmax_forward(const float* logits, size_t npix, int K, float* prob, void* stream);
 int spcl_softmax_backward(const float* prob, const float* dprob, size_t npix, int K, float* dlogits, void* stream);
 size_t spcl_kl_workspace_bytes(void);

@@ -49,17 +49,29 @@ template <> struct VecIO<float> {
 
 // KB = compile-time bound of the class count (4 / 8 / 16) so that the per-class accumulators live in registers.
 // The weights sit in LDS as [KB][CS] with zeros in the channel padding and the unused classes: no bounds tests inside.
-template <typename T, int KB>
+// IN_BN: x is the RAW output of the last 3x3 convolution and the input of the 1x1 convolution is relu(scale x + shift),
+// rounded to T as the activation writer would have stored it (bnrelu_fwd_lin_kernel: the same FMA, the same conversion) --
+// the decoder's last BatchNorm + ReLU without a tensor of its own (spcl_conv1x1_forward_bn).
+template <typename T> __device__ __forceinline__ float round_as(float v);
+template <> __device__ __forceinline__ float round_as<float>(float v) { return v; }
+template <> __device__ __forceinline__ float round_as<bf16_t>(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+
+template <typename T, int KB, bool IN_BN = false>
 __global__ __launch_bounds__(256) void conv1x1_fwd_kernel(const T* __restrict__ x, size_t npix, int C, int CS, int K,
                                                           const float* __restrict__ w, const float* __restrict__ b,
-                                                          float* __restrict__ out) {
+                                                          float* __restrict__ out,
+                                                          const float* __restrict__ in_scale = nullptr,
+                                                          const float* __restrict__ in_shift = nullptr) {
   constexpr int VN = VecIO<T>::N;
   __shared__ float ws[KB * HEAD_MAX_C + KB];
+  __shared__ float bnc[IN_BN ? 2 * HEAD_MAX_C : 1];
   for (int i = threadIdx.x; i < KB * CS; i += 256) {
     const int k = i / CS, c = i - k * CS;
     ws[i] = (k < K && c < C) ? w[k * C + c] : 0.f;
   }
   if (threadIdx.x < KB) ws[KB * CS + threadIdx.x] = threadIdx.x < K ? b[threadIdx.x] : 0.f;
+  if (IN_BN)
+    for (int c = threadIdx.x; c < CS; c += 256) { bnc[c] = in_scale[c]; bnc[HEAD_MAX_C + c] = in_shift[c]; }
   __syncthreads();
   for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (size_t)gridDim.x * 256) {
     float acc[KB];
@@ -69,6 +81,10 @@ __global__ __launch_bounds__(256) void conv1x1_fwd_kernel(const T* __restrict__ 
     for (int c0 = 0; c0 < CS; c0 += VN) {
       float xv[VN];
       VecIO<T>::load(px + c0, xv);
+      if (IN_BN) {
+#pragma unroll
+        for (int e = 0; e < VN; ++e) xv[e] = round_as<T>(fmaxf(fmaf(bnc[c0 + e], xv[e], bnc[HEAD_MAX_C + c0 + e]), 0.f));
+      }
 #pragma unroll
       for (int e = 0; e < VN; ++e)
 #pragma unroll
@@ -88,15 +104,24 @@ __global__ __launch_bounds__(256) void conv1x1_fwd_kernel(const T* __restrict__ 
 // dX[p][c] = sum_k dO[p][k] w[k][c]; per-workgroup partials of dW[k][c] = sum_p dO[p][k] x[p][c], db[k] = sum_p dO[p][k].
 // Channels are walked in groups of CG = 64 / KB so that the KB x CG accumulators stay in registers; a pixel's group is
 // read and written as 16-byte vectors.
-template <typename T, int KB>
+// IN_BN (spcl_conv1x1_backward_bn): x is the raw 3x3-convolution output y; the 1x1 convolution's input is recomputed as in
+// the forward, dx is the gradient w.r.t. that ACTIVATION, and the workgroup also leaves the partial sums of the BatchNorm's
+// backward -- rows[wg][0][c] = sum dz, rows[wg][1][c] = sum dz (y - mean), dz = dx (as stored) where scale y + shift > 0 --
+// in the form the convolution kernels' dgrad epilogues leave them (bnrelu_bwd_reduce_lin_kernel's arithmetic per pixel).
+template <typename T, int KB, bool IN_BN = false>
 __global__ __launch_bounds__(256) void conv1x1_bwd_kernel(const T* __restrict__ x, const float* __restrict__ dout,
                                                           size_t npix, int C, int CS, int K,
                                                           const float* __restrict__ w, T* __restrict__ dx,
-                                                          float* __restrict__ partial /* [grid][K][C+1] */) {
+                                                          float* __restrict__ partial /* [grid][K][C+1] */,
+                                                          const float* __restrict__ in_scale = nullptr,
+                                                          const float* __restrict__ in_shift = nullptr,
+                                                          const float* __restrict__ in_mean = nullptr,
+                                                          float* __restrict__ rows = nullptr /* [grid][2][CS] */) {
   constexpr int CG = 64 / KB, VN = VecIO<T>::N;
   static_assert(CG % 4 == 0, "channel group");
   __shared__ float ws[KB * HEAD_MAX_C];
   __shared__ float red[4][KB * (CG + 1)];
+  __shared__ float red2[IN_BN ? 4 : 1][2 * CG];
   for (int i = threadIdx.x; i < KB * CS; i += 256) {
     const int k = i / CS, c = i - k * CS;
     ws[i] = (k < K && c < C) ? w[k * C + c] : 0.f;
@@ -106,11 +131,16 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_kernel(const T* __restrict__ 
   float* mypart = partial + (size_t)blockIdx.x * K * (C + 1);
   for (int c0 = 0; c0 < CS; c0 += CG) {
     float aw[KB][CG], ab[KB];
+    float s1[IN_BN ? CG : 1], s2[IN_BN ? CG : 1];
 #pragma unroll
     for (int k = 0; k < KB; ++k) {
       ab[k] = 0.f;
 #pragma unroll
       for (int c = 0; c < CG; ++c) aw[k][c] = 0.f;
+    }
+    if (IN_BN) {
+#pragma unroll
+      for (int c = 0; c < CG; ++c) s1[c] = s2[c] = 0.f;
     }
     for (size_t p = (size_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (size_t)gridDim.x * 256) {
       float g[KB];
@@ -134,13 +164,25 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_kernel(const T* __restrict__ 
       }
 #pragma unroll
       for (int c = 0; c < CG; ++c) {
+        // (IN_BN: the coefficients are wave-uniform loads straight from global memory -- scalar registers; as LDS reads the
+        // compiler hoisted all 48 into vector registers and the kernel fell to one wave per SIMD, 49 -> 101 us)
+        float xin = xv[c], z = 0.f;
+        if (IN_BN) {
+          z = fmaf(in_scale[c0 + c], xv[c], in_shift[c0 + c]);
+          xin = round_as<T>(fmaxf(z, 0.f));
+        }
         float dd = 0.f;
 #pragma unroll
         for (int k = 0; k < KB; ++k) {
-          aw[k][c] = fmaf(g[k], xv[c], aw[k][c]);
+          aw[k][c] = fmaf(g[k], xin, aw[k][c]);
           dd = fmaf(g[k], ws[k * CS + c0 + c], dd);  // zero weights in the channel padding: exact zeros there
         }
         d[c] = dd;
+        if (IN_BN) {
+          const float dz = z > 0.f ? round_as<T>(dd) : 0.f;
+          s1[c] += dz;
+          s2[c] = fmaf(dz, xv[c] - in_mean[c0 + c], s2[c]);
+        }
       }
       if (CG >= VN) {
 #pragma unroll
@@ -165,7 +207,20 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_kernel(const T* __restrict__ 
       const float sb = wave_sum(ab[k]);
       if (lane == 0) red[wave][k * (CG + 1) + CG] = sb;
     }
+    if (IN_BN) {
+#pragma unroll
+      for (int c = 0; c < CG; ++c) {
+        const float t1 = wave_sum(s1[c]), t2 = wave_sum(s2[c]);
+        if (lane == 0) { red2[wave][c] = t1; red2[wave][CG + c] = t2; }
+      }
+    }
     __syncthreads();
+    if (IN_BN && threadIdx.x < 2 * CG) {
+      const int which = threadIdx.x / CG, c = threadIdx.x - which * CG;
+      if (c0 + c < CS)
+        rows[((size_t)blockIdx.x * 2 + which) * CS + c0 + c] =
+            (red2[0][threadIdx.x] + red2[1][threadIdx.x]) + (red2[2][threadIdx.x] + red2[3][threadIdx.x]);
+    }
     for (int i = threadIdx.x; i < KB * (CG + 1); i += 256) {
       const int k = i / (CG + 1), c = i - k * (CG + 1);
       const float s = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
@@ -181,6 +236,21 @@ __global__ __launch_bounds__(256) void conv1x1_bwd_kernel(const T* __restrict__ 
   }
 }
 
+template <typename T>
+static void launch_conv1x1_fwd_bn(int grid, hipStream_t st, const void* x, size_t npix, int C, int CS, int K, const float* w,
+                                  const float* b, float* out, const float* sc, const float* sh) {
+  if (K <= 4) SPCL_LAUNCH((conv1x1_fwd_kernel<T, 4, true>), dim3(grid), dim3(256), 0, st, (const T*)x, npix, C, CS, K, w, b, out, sc, sh);
+  else if (K <= 8) SPCL_LAUNCH((conv1x1_fwd_kernel<T, 8, true>), dim3(grid), dim3(256), 0, st, (const T*)x, npix, C, CS, K, w, b, out, sc, sh);
+  else SPCL_LAUNCH((conv1x1_fwd_kernel<T, 16, true>), dim3(grid), dim3(256), 0, st, (const T*)x, npix, C, CS, K, w, b, out, sc, sh);
+}
+template <typename T>
+static void launch_conv1x1_bwd_bn(int grid, hipStream_t st, const void* x, const float* dout, size_t npix, int C, int CS,
+                                  int K, const float* w, void* dx, float* ws, const float* sc, const float* sh,
+                                  const float* mu, float* rows) {
+  if (K <= 4) SPCL_LAUNCH((conv1x1_bwd_kernel<T, 4, true>), dim3(grid), dim3(256), 0, st, (const T*)x, dout, npix, C, CS, K, w, (T*)dx, ws, sc, sh, mu, rows);
+  else if (K <= 8) SPCL_LAUNCH((conv1x1_bwd_kernel<T, 8, true>), dim3(grid), dim3(256), 0, st, (const T*)x, dout, npix, C, CS, K, w, (T*)dx, ws, sc, sh, mu, rows);
+  else SPCL_LAUNCH((conv1x1_bwd_kernel<T, 16, true>), dim3(grid), dim3(256), 0, st, (const T*)x, dout, npix, C, CS, K, w, (T*)dx, ws, sc, sh, mu, rows);
+}
 template <typename T>
 static void launch_conv1x1_fwd(int grid, hipStream_t st, const void* x, size_t npix, int C, int CS, int K, const float* w,
                                const float* b, float* out) {
@@ -528,6 +598,51 @@ extern "C" int spcl_conv1x1_backward(const void* x, const float* dout, int dtype
   SPCL_LAUNCH(conv1x1_finish_kernel, dim3(cdiv(K * (C + 1), 4)), dim3(256), 0, st, (const float*)ws, grid, K, C, dw,
               db);
   SPCL_LAUNCH_CHECK("conv1x1_backward");
+  return SPCL_OK;
+}
+
+// The decoder's last BatchNorm + ReLU folded into the 1x1 convolution on both sides (unet.py:82 -> :229): y is the raw output
+// of the last 3x3 convolution, the class map is conv1x1(relu(scale y + shift)) -- the activation tensor is never written.
+extern "C" int spcl_conv1x1_forward_bn(const void* y, int dtype, size_t npix, int C, int CS, int K, const float* scale,
+                                       const float* shift, const float* w, const float* b, float* out, void* stream) {
+  SPCL_CHECK_ARG(y && scale && shift && w && b && out, "conv1x1_forward_bn: null pointer");
+  SPCL_CHECK_ARG(npix > 0 && C > 0 && C <= CS && CS <= HEAD_MAX_C && K > 0 && K <= HEAD_MAX_K, "conv1x1_forward_bn: shape");
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = head_grid(npix, 4096);
+  prof_cost((double)npix * (CS * (dtype == SPCL_F32 ? 4.0 : 2.0) + K * 4.0), 2.0 * npix * C * K);
+  if (dtype == SPCL_F32) launch_conv1x1_fwd_bn<float>(grid, st, y, npix, C, CS, K, w, b, out, scale, shift);
+  else if (dtype == SPCL_BF16) launch_conv1x1_fwd_bn<bf16_t>(grid, st, y, npix, C, CS, K, w, b, out, scale, shift);
+  else {
+    set_error("conv1x1_forward_bn: dtype %d", dtype);
+    return SPCL_EINVAL;
+  }
+  SPCL_LAUNCH_CHECK("conv1x1_forward_bn");
+  return SPCL_OK;
+}
+
+extern "C" int spcl_conv1x1_bwd_rows(size_t npix) { return head_grid(npix, HEAD_RED_WG); }
+
+// ... and its backward: dact = gradient w.r.t. relu(scale y + shift) (what spcl_bnrelu_backward_rows applies), dw / db as
+// spcl_conv1x1_backward, rows [spcl_conv1x1_bwd_rows(npix)][2][CS] = that BatchNorm's backward partial sums (sum dz,
+// sum dz (y - mean)): the separate reduction pass over (y, dact) disappears.
+extern "C" int spcl_conv1x1_backward_bn(const void* y, const float* dout, int dtype, size_t npix, int C, int CS, int K,
+                                        const float* scale, const float* shift, const float* mean, const float* w,
+                                        void* dact, float* dw, float* db, float* ws, float* rows, void* stream) {
+  SPCL_CHECK_ARG(y && dout && scale && shift && mean && w && dact && dw && db && ws && rows, "conv1x1_backward_bn: null pointer");
+  SPCL_CHECK_ARG(npix > 0 && C > 0 && C <= CS && CS <= HEAD_MAX_C && K > 0 && K <= HEAD_MAX_K && CS % 16 == 0,
+                 "conv1x1_backward_bn: shape");
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = head_grid(npix, HEAD_RED_WG);
+  prof_cost((double)npix * (2.0 * CS * (dtype == SPCL_F32 ? 4.0 : 2.0) + K * 4.0), 4.0 * npix * C * K);
+  if (dtype == SPCL_F32) launch_conv1x1_bwd_bn<float>(grid, st, y, dout, npix, C, CS, K, w, dact, ws, scale, shift, mean, rows);
+  else if (dtype == SPCL_BF16) launch_conv1x1_bwd_bn<bf16_t>(grid, st, y, dout, npix, C, CS, K, w, dact, ws, scale, shift, mean, rows);
+  else {
+    set_error("conv1x1_backward_bn: dtype %d", dtype);
+    return SPCL_EINVAL;
+  }
+  SPCL_LAUNCH(conv1x1_finish_kernel, dim3(cdiv(K * (C + 1), 4)), dim3(256), 0, st, (const float*)ws, grid, K, C, dw,
+              db);
+  SPCL_LAUNCH_CHECK("conv1x1_backward_bn");
   return SPCL_OK;
 }
 

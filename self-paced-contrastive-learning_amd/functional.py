@@ -552,10 +552,21 @@ class PoolLink:
         self.rows, self.dx_ptr = None, 0
 
 
+class ActLink:
+    """A block whose activation has ONE consumer that applies the block's last BatchNorm + ReLU itself (``BlockCfg.lazy_act``:
+    the 1x1 head, ``conv1x1_bn``): the raw second-conv output and the BN coefficients the consumer needs, and -- filled by
+    the consumer's backward -- the BatchNorm-backward partial sums it left next to the activation gradient."""
+    __slots__ = ("yb", "stb", "N", "H", "W", "C", "cs", "rows", "dx_ptr")
+
+    def __init__(self, yb, stb, N, H, W, C, cs):
+        self.yb, self.stb, self.N, self.H, self.W, self.C, self.cs = yb, stb, N, H, W, C, cs
+        self.rows, self.dx_ptr = None, 0
+
+
 class BlockCfg:
     """Static configuration of one fused Conv-BN-ReLU(-Conv-BN-ReLU)(-MaxPool) block call."""
     __slots__ = ("dtype", "training", "momentum", "eps", "track", "need_act", "need_pool", "image_input", "buffers",
-                 "link_in", "link_out", "act_dst", "up2")
+                 "link_in", "link_out", "act_dst", "up2", "lazy_act", "link_act")
 
     def __init__(self, dtype, training, momentum, eps, track, need_act, need_pool, image_input, buffers):
         self.dtype, self.training, self.momentum, self.eps, self.track = dtype, training, momentum, eps, track
@@ -564,6 +575,8 @@ class BlockCfg:
         self.link_out = None  # PoolLink this call offers to the next block (set by the forward)
         self.act_dst = None   # [N,H,W,cout_s] view (pixel stride >= cout_s) the activation is written to: one half of a
                               # decoder concatenation buffer (UNet.forward), so that torch.cat needs no copy
+        self.lazy_act = False  # the activation's only consumer applies BN + ReLU itself: return the RAW output, offer link_act
+        self.link_act = None
         self.up2 = False      # the activation's only consumer is nn.Upsample(scale_factor=2): write it 2x2-replicated, return
                               # the [N, C, 2H, 2W] tensor (spcl_bnrelu_up2_forward); backward sums the 2x2 gradients first
 
@@ -1110,7 +1123,13 @@ class _ConvBlockFn(torch.autograd.Function):
         yb, sb = _conv(ya, dtc, dtype, N, H, W, cout_s, cout_s, cout_s, wpb, 1, sta[2], sta[3], cfg.training)
         stb = _bn_stats(sb, cfg, cout, cout_s, gb, bb, 1, dev)
         ctx.up2 = bool(getattr(cfg, "up2", False)) and cfg.need_act and not cfg.need_pool
-        if ctx.up2:
+        lazy = (bool(getattr(cfg, "lazy_act", False)) and cfg.need_act and not cfg.need_pool and not ctx.up2
+                and getattr(cfg, "act_dst", None) is None)
+        if lazy:
+            # no activation tensor: the consumer (conv1x1_bn) reads yb and applies scale / shift / ReLU in its loader
+            act, pool = yb, None
+            cfg.link_act = ActLink(yb, stb, N, H, W, cout, cout_s)
+        elif ctx.up2:
             act = torch.empty(N, 2 * H, 2 * W, cout_s, dtype=dtype, device=dev)
             pool = None
             _n.call("spcl_bnrelu_up2_forward", _n.ptr(yb), dtc, N, H, W, cout_s, _n.ptr(stb[2]), _n.ptr(stb[3]), _n.ptr(act),
@@ -1161,7 +1180,13 @@ class _ConvBlockFn(torch.autograd.Function):
         ng = ctx.needs_input_grad
         sk = tuple(take_grad_sink(p, ng[i + 1]) for i, p in enumerate(ctx.params))  # (wa, ga, ba, wb, gb, bb)
         lk = cfg.link_out
-        if g_nc is not None:
+        la = getattr(cfg, "link_act", None)
+        if (la is not None and la.rows is not None and da_s is not None and dp_s is None and da_stride == 0
+                and da_s.data_ptr() == la.dx_ptr):
+            # the consumer's backward (the 1x1 head) left this BatchNorm's partial sums next to the activation gradient
+            dyb, dgb, dbb = _bnrelu_bwd_rows(yb, da_s, None, la.rows, dtc, dtype, N, H, W, cout, cout_s, stb, cfg.training,
+                                             sk[4:6])
+        elif g_nc is not None:
             # the block's output fed a global average pool only: its gradient is one value per (image, channel)
             dyb, dgb, dbb = _bnrelu_bwd_bcast(yb, g_nc, dtc, dtype, N, H, W, cout, cout_s, stb, cfg.training, sk[4:6])
         elif (lk is not None and lk.rows is not None and da_s is None and dp_s is not None
@@ -1174,6 +1199,8 @@ class _ConvBlockFn(torch.autograd.Function):
                                         dact_stride=da_stride)
         if lk is not None:
             lk.rows, lk.dx_ptr = None, 0
+        if la is not None:
+            la.rows, la.dx_ptr = None, 0
         wpa_t, wpb_t = ctx.packed_t
         if wpb_t is None:
             wpb_t = _pack(wb, 1, dtc, dtype)
@@ -1402,6 +1429,63 @@ class _Conv1x1Fn(torch.autograd.Function):
 
 def conv1x1(x, w, b, dtype):
     return _Conv1x1Fn.apply(x, w, b, dtype)
+
+
+class _Conv1x1BnFn(torch.autograd.Function):
+    """``_Deconv_1x1(relu(bn(y)))`` for the block that returned its RAW second-conv output ``y`` (``BlockCfg.lazy_act``,
+    ``link``: its ``ActLink``): BN + ReLU in the loader of the 1x1 convolution (spcl_conv1x1_forward_bn); the backward
+    returns the gradient w.r.t. the ACTIVATION -- what the block's backward expects -- and leaves the BatchNorm-backward
+    partial sums in the link (spcl_conv1x1_backward_bn)."""
+
+    @staticmethod
+    def forward(ctx, y, w, b, link: ActLink):
+        _n.require_gpu(y, w, b)
+        N, C, H, W = y.shape
+        K = w.shape[0]
+        if K > 16 or C > 256:
+            raise NotImplementedError("conv1x1 head: at most 16 classes / 256 input channels")
+        ys = link.yb
+        assert (N, H, W, C) == (link.N, link.H, link.W, link.C) and ys.data_ptr() == y.data_ptr(), "not the linked block's output"
+        cs, dtype = link.cs, ys.dtype
+        wc, bc = w.detach().reshape(K, C).contiguous().float(), b.detach().contiguous().float()
+        out = torch.empty(N, H, W, K, dtype=torch.float32, device=y.device)
+        _n.call("spcl_conv1x1_forward_bn", _n.ptr(ys), _n.dtype_code(dtype), N * H * W, C, cs, K, _n.ptr(link.stb[2]),
+                _n.ptr(link.stb[3]), _n.ptr(wc), _n.ptr(bc), _n.ptr(out), _n.stream())
+        ctx.save_for_backward(wc)
+        ctx.link = link
+        ctx.params = (w, b)
+        ctx.meta = (N, C, H, W, K, cs, dtype, y.dtype, tuple(w.shape))
+        return out.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (wc,) = ctx.saved_tensors
+        link = ctx.link
+        N, C, H, W, K, cs, dtype, ydt, wshape = ctx.meta
+        do = _class_map_storage(dout)
+        dev = do.device
+        dact = torch.empty(N, H, W, cs, dtype=dtype, device=dev)
+        sinks = (take_grad_sink(ctx.params[0], ctx.needs_input_grad[1]),
+                 take_grad_sink(ctx.params[1], ctx.needs_input_grad[2]))
+        dw = _grad_buffer(sinks[0], (K, C), dev)
+        db = _grad_buffer(sinks[1], (K,), dev)
+        ws = torch.empty(_n.call("spcl_conv1x1_bwd_workspace_bytes", C, K) // 4, dtype=torch.float32, device=dev)
+        nrows = _n.call("spcl_conv1x1_bwd_rows", N * H * W)
+        rows = torch.empty(nrows * 2 * cs, dtype=torch.float32, device=dev)
+        rows.ntiles = nrows
+        st = link.stb
+        _n.call("spcl_conv1x1_backward_bn", _n.ptr(link.yb), _n.ptr(do), _n.dtype_code(dtype), N * H * W, C, cs, K,
+                _n.ptr(st[2]), _n.ptr(st[3]), _n.ptr(st[0]), _n.ptr(wc), _n.ptr(dact), _n.ptr(dw), _n.ptr(db), _n.ptr(ws),
+                _n.ptr(rows), _n.stream())
+        link.rows, link.dx_ptr = rows, dact.data_ptr()
+        dx = nhwc_to_logical(dact, C)
+        if dx.dtype != ydt:
+            dx = dx.to(ydt)
+        return dx, dw.reshape(wshape), db, None
+
+
+def conv1x1_bn(y, w, b, link: ActLink):
+    return _Conv1x1BnFn.apply(y, w, b, link)
 
 
 class _SoftmaxFn(torch.autograd.Function):

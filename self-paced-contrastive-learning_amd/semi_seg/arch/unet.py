@@ -30,6 +30,7 @@ _VIRTUAL_CAT = __import__("os").environ.get("SPCL_VIRTUAL_CAT", "1") != "0"  # A
 # write HALF of every line (bnrelu_fwd_lin 51 -> 88 us per step at 224^2) and the copy is cheaper; from 32 channels on the
 # in-place halves win (fine-tune step, same box, three rounds: off 2.481 ms, >= 16: 2.455, >= 32: 2.439, >= 64: 2.449)
 _VIRTUAL_CAT_MINC = int(__import__("os").environ.get("SPCL_VIRTUAL_CAT_MINC", "32"))
+_LAZY_HEAD = __import__("os").environ.get("SPCL_LAZY_HEAD", "1") != "0"  # A/B switch: 0 writes the last activation and reads it back
 _FUSED_UPSAMPLE = __import__("os").environ.get("SPCL_FUSED_UPSAMPLE", "1") != "0"  # A/B switch (BlockCfg.up2)
 _ENCODER = ("Conv1", "Conv2", "Conv3", "Conv4", "Conv5")
 _DECODER = ("Up5", "Up_conv5", "Up4", "Up_conv4", "Up3", "Up_conv3", "Up2", "Up_conv2", "Deconv_1x1")
@@ -82,6 +83,8 @@ class _ConvBlock(nn.Module):
         self._link_in = self._link_out = None  # functional.PoolLink hand-over between consecutive encoder blocks
         self._act_dst = None        # where UNet.forward wants this call's activation written (half of a concat buffer)
         self._up2 = False           # this call's activation only feeds nn.Upsample(x2): return it upsampled (one launch less)
+        self._lazy = False          # this call's activation only feeds the 1x1 head, which applies BN + ReLU itself
+        self._link_act = None       # functional.ActLink of a lazy call (UNet.forward hands it to the head)
 
     def _cfg(self, need_act, need_pool):
         bn_a, bn_b = self.conv[1], self.conv[4]
@@ -109,9 +112,11 @@ class _ConvBlock(nn.Module):
         cfg.link_in, self._link_in = self._link_in, None
         cfg.act_dst, self._act_dst = self._act_dst, None
         cfg.up2, self._up2 = (self._up2 and len(self._forward_hooks) == 0), False
+        cfg.lazy_act, self._lazy = (self._lazy and len(self._forward_hooks) == 0), False
         act, pooled = F_hip.conv_block(x, c[0].weight, c[1].weight, c[1].bias, c[3].weight, c[4].weight, c[4].bias, cfg, x2)
         self._pooled = pooled
         self._link_out = cfg.link_out  # for the block that consumes the pooled output (UNet.forward hands it over)
+        self._link_act = cfg.link_act
         return act
 
     def take_pooled(self):
@@ -153,10 +158,15 @@ class _Conv1x1(nn.Conv2d):
     class map comes back as a logical [N,K,H,W] view over [N,H,W,K] storage."""
     _compute_dtype = None
 
+    _link = None  # set by UNet.forward for one call: the producing block returned its RAW output (functional.ActLink)
+
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError("self-paced-contrastive-learning_amd runs on MI355X only: got a CPU tensor "
                                "(the HIP path has no CPU fallback)")
+        link, self._link = self._link, None
+        if link is not None:
+            return F_hip.conv1x1_bn(x, self.weight, self.bias, link)
         return F_hip.conv1x1(x, self.weight, self.bias, self._compute_dtype or _config.get_compute_dtype())
 
 
@@ -259,6 +269,13 @@ class UNet(nn.Module):
                       and len(blk._forward_hooks) == 0 and len(nxt._forward_hooks) == 0
                       and len(nxt.up[0]._forward_hooks) == 0)
             blk._up2 = pre_up
+            # the last block's activation feeds the 1x1 head only: the head applies that BatchNorm + ReLU in its own loader
+            # (forward and backward) and leaves the BatchNorm-backward sums; no activation tensor, two passes less
+            blk._lazy = (lvl == 2 and until is None and _LAZY_HEAD and d.is_cuda and len(blk._forward_hooks) == 0
+                         and len(self._Deconv_1x1._forward_hooks) == 0 and len(self._Deconv_1x1._forward_pre_hooks) == 0
+                         and blk.conv[3].weight.shape[0] % 16 == 0
+                         and (blk._compute_dtype or _config.get_compute_dtype()) ==
+                             (self._Deconv_1x1._compute_dtype or _config.get_compute_dtype()))
             bdt = blk._compute_dtype or _config.get_compute_dtype()
             if skip in cats:
                 d = blk(F_hip.virtual_cat(skips[skip], d, cats[skip][0]))
@@ -272,6 +289,7 @@ class UNet(nn.Module):
                 d = blk(F_hip.concat_channels(skips[skip], d, bdt))
             if until == f"Up_conv{lvl}":
                 return d
+        self._Deconv_1x1._link, blk._link_act = blk._link_act, None
         return self._Deconv_1x1(d)
 
     def _prepack(self, x, until):

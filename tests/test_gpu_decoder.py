@@ -298,6 +298,7 @@ def test_in_place_decoder_data_movement_is_the_copying_path_bit_for_bit(N, S, mo
         monkeypatch.setattr(unet_mod, "_VIRTUAL_CAT", in_place)
         monkeypatch.setattr(unet_mod, "_FUSED_UPSAMPLE", in_place)
         monkeypatch.setattr(F, "_CONV_CAT", in_place)
+        monkeypatch.setattr(unet_mod, "_LAZY_HEAD", False)  # (its BatchNorm-backward sums have their own order: next test)
         m = UNet(input_dim=1, num_classes=4, max_channel=256)
         m.load_state_dict(sd, strict=True)
         m.cuda().train()
@@ -324,3 +325,50 @@ def test_in_place_decoder_data_movement_is_the_copying_path_bit_for_bit(N, S, mo
     monkeypatch.setattr(F, "_CONV_CAT", True)
     a = torch.zeros(N, 16, S, S, device="cuda", dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
     assert F.cat_pair_supported(a, a.clone(memory_format=torch.channels_last), 16, torch.bfloat16)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_last_activation_folded_into_the_head_matches_the_written_one(dt, monkeypatch):
+    """`spcl_conv1x1_forward_bn` / `_backward_bn`: the decoder's last BatchNorm + ReLU applied inside the 1x1 head (no
+    activation tensor, the BatchNorm-backward sums left by the head's backward) against the same network writing the
+    activation: logits and loss bit for bit (the activation is rounded exactly as the writer stores it), gradients to the
+    summation order of the partial sums; eval mode too."""
+    import spcl_amd  # noqa
+    from spcl_amd import functional as F
+    from spcl_amd.semi_seg.arch import UNet, unet as unet_mod
+    sd = O.init_unet_state(1, 4, 256, seed=21)
+    g = torch.Generator().manual_seed(22)
+    x = torch.rand(3, 1, 112, 112, generator=g).cuda()
+    labels = torch.randint(0, 4, (3, 112, 112), generator=g).cuda()
+
+    def run(lazy, train=True):
+        monkeypatch.setattr(unet_mod, "_LAZY_HEAD", lazy)
+        m = UNet(input_dim=1, num_classes=4, max_channel=256)
+        m.load_state_dict(sd, strict=True)
+        m.cuda().train(train)
+        m.set_compute_dtype(dt)
+        used = []
+        real = F.conv1x1_bn
+        monkeypatch.setattr(F, "conv1x1_bn", lambda *a, **k: (used.append(1), real(*a, **k))[1])
+        logits = m(x)
+        monkeypatch.setattr(F, "conv1x1_bn", real)
+        assert len(used) == (1 if lazy else 0)
+        loss, _ = F.sup_loss_kl_onehot(logits, labels)
+        loss.backward()
+        torch.cuda.synchronize()
+        return (logits.detach().clone(), loss.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()},
+                {k: v.clone() for k, v in m.state_dict().items() if "running" in k})
+
+    for train in (True, False):
+        la, lossa, ga, ra = run(True, train)
+        lb, lossb, gb, rb = run(False, train)
+        assert torch.equal(la, lb) and torch.equal(lossa, lossb)
+        for k in rb:
+            assert torch.equal(ra[k], rb[k]), k
+        # fp32: the sums' order only; bf16: that order's last-bit differences re-rounded by every layer below (the encoder's
+        # first layers see ~1 % of their largest entry -- the noise floor test_gpu_configs.py documents for bf16 gradients)
+        tol = 2e-5 if dt == torch.float32 else 3e-2
+        for k in gb:
+            ref = gb[k].float()
+            err = float((ga[k].float() - ref).norm()) / max(float(ref.norm()), 1e-20)
+            assert err < tol, (k, err)
