@@ -213,6 +213,13 @@ int spcl_conv3x3_forward_cat(const void* xa, const void* xb, int dtype, int N, i
                              const void* w_packed, void* y, float* stats, void* stream);
 int spcl_conv3x3_wgrad_cat(const void* xa, const void* xb, const void* dy, int dtype, int N, int H, int W, int Chalf,
                            int Cout, int CoutS, float* partial, float* dw_oihw, void* stream);
+/* ... and the input gradient of that convolution as the gradients of the two concatenated tensors: the plain 3x3 convolution
+ * (w_packed = the dgrad layout, kind 1) whose output channels [0, CoutS / 2) are written to y_lo and [CoutS / 2, CoutS) to
+ * y_hi, both dense [N][H][W][CoutS / 2] bf16 (torch.cat's backward, unet.py:194-224, without the interleaved tensor).
+ * Where spcl_conv_split_supported says so (a specialised kernel, CoutS a multiple of 32). */
+int spcl_conv_split_supported(int dtype, int N, int H, int W, int CinK, int CoutS);
+int spcl_conv3x3_forward_split(const void* x, int dtype, int N, int H, int W, int CinK, int CoutS, const void* w_packed,
+                               void* y_lo, void* y_hi, void* stream);
 
 /* dW[co][ci][ky][kx] (OIHW f32, overwritten) = sum_pixels act(x)[p+tap][ci] * dy[p][co]   (weight gradient of
  * unet.py:72,75).  x / in_mode / CinK as in forward; Cin, Cout = real channel counts of dW.

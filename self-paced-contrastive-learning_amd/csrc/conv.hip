@@ -722,6 +722,52 @@ extern "C" int spcl_conv3x3_forward_cat(const void* xa, const void* xb, int dtyp
   return SPCL_OK;
 }
 
+// ... and its input gradient as the two gradients of the concatenated tensors: the plain convolution (dgrad weights) whose
+// output channels [0, CoutS / 2) go to y_lo and [CoutS / 2, CoutS) to y_hi, both dense [N][H][W][CoutS / 2] -- each producer's
+// backward then reads whole pixels instead of half of every line of one interleaved tensor.
+static bool conv_split_args(ConvArgs& a, int dtype, int N, int H, int W, int CinK, int CoutS) {
+  static const bool off = getenv("SPCL_CONV_SPLIT") && atoi(getenv("SPCL_CONV_SPLIT")) == 0;  // A/B switch
+  if (off || dtype != SPCL_BF16 || N <= 0 || H <= 0 || W <= 0 || CinK % 16 != 0 || CinK <= 0 || CoutS % 32 != 0 || CoutS <= 0)
+    return false;
+  if (!(CinK <= 64 || CinK % 64 == 0)) return false;
+  a.in_scale = a.in_shift = nullptr;
+  a.stats = nullptr;
+  a.N = N; a.H = H; a.W = W; a.CinS = CinK; a.CinK = CinK; a.CoutS = CoutS; a.in_mode = 0;
+  a.tilesX = a.tilesY = 0;
+  a.tpw = 1;
+  a.dbg = 0;
+  return !conv_use_gemm(CinK, CoutS, H, W) && pick_tile(H, W).tw == 14;
+}
+
+extern "C" int spcl_conv_split_supported(int dtype, int N, int H, int W, int CinK, int CoutS) {
+  ConvArgs a;
+  if (!conv_split_args(a, dtype, N, H, W, CinK, CoutS)) return 0;
+  static char dummy[16] = {0};
+  a.x = dummy; a.y = dummy; a.y_hi = dummy; a.wp = nullptr;
+  return launch_conv_fast(a, pick_tile(H, W).th, nullptr, true) ? 1 : 0;
+}
+
+extern "C" int spcl_conv3x3_forward_split(const void* x, int dtype, int N, int H, int W, int CinK, int CoutS,
+                                          const void* w_packed, void* y_lo, void* y_hi, void* stream) {
+  SPCL_CHECK_ARG(x && y_lo && y_hi && w_packed, "conv3x3_forward_split: null pointer");
+  SPCL_CHECK_ARG((uintptr_t)y_lo % 16 == 0 && (uintptr_t)y_hi % 16 == 0, "conv3x3_forward_split: outputs must be 16-byte aligned");
+  ConvArgs a;
+  if (!conv_split_args(a, dtype, N, H, W, CinK, CoutS)) {
+    set_error("conv3x3_forward_split: unsupported configuration (bf16, CoutS a multiple of 32, 14-column tiles)");
+    return SPCL_EUNSUPPORTED;
+  }
+  a.x = x; a.y = y_lo; a.y_hi = y_hi; a.wp = w_packed;
+  hipStream_t st = (hipStream_t)stream;
+  const double px = (double)N * H * W;
+  prof_cost(px * (CinK + CoutS) * 2.0 + 9.0 * CinK * CoutS * 2.0, 2.0 * px * 9.0 * CinK * CoutS);
+  if (!launch_conv_fast(a, pick_tile(H, W).th, st)) {
+    set_error("conv3x3_forward_split: no specialised kernel for H=%d W=%d CinK=%d CoutS=%d", H, W, CinK, CoutS);
+    return SPCL_EUNSUPPORTED;
+  }
+  SPCL_LAUNCH_CHECK("conv3x3_forward_split");
+  return SPCL_OK;
+}
+
 // dgrad of the SECOND conv of a block fused with the per-tile partial sums of the FIRST conv's BatchNorm backward (the
 // dgrad's output g is the gradient of relu(bn(y2))): saves the separate reduction pass over (y2, g).  Only where a
 // specialised kernel exists (bf16, tiles of 14 columns): ask spcl_conv_dgrad_bnstats_supported first.

@@ -52,6 +52,9 @@ struct ConvArgs {
   // the input as the channel concatenation of TWO dense tensors (x: channels [0, CinK / 2), x2: the rest; each
   // [N][H][W][CinK / 2]) -- torch.cat((skip, up), 1) of the decoder read in place (fast path only, one slab: CinK <= 64)
   const void* x2 = nullptr;
+  // the output as TWO dense tensors (y: channels [0, CoutS / 2), y_hi: the rest; each [N][H][W][CoutS / 2]) -- the gradient
+  // of such a concatenation written as the gradients of its parts (fast path only, plain dgrad: no statistics)
+  void* y_hi = nullptr;
 };
 
 template <typename T> __device__ __forceinline__ f32x4 mfma_chunk(u32x4 w, u32x4 x, f32x4 acc);

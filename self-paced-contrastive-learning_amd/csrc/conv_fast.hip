@@ -18,6 +18,7 @@ struct FastArgs {
   const unsigned char* x;
   const unsigned char* x2;  // non-null: the second half of the input channels comes from this tensor (ConvArgs::x2)
   unsigned char* y;
+  unsigned char* y_hi;      // non-null (MODE 0): output channels [CoutS / 2, CoutS) go to this tensor (ConvArgs::y_hi)
   const u32x4* wp;
   float* stats;
   const float* in_scale;
@@ -364,10 +365,20 @@ conv3x3_fast_kernel(FastArgs a) {
   // ------------ epilogue: lane holds couts 16 (nt0 + j) + 4 g .. +3 of pixel p = 16 i + r16 (tiles are always full)
   constexpr int DPY = 16 / TW, DPX = 16 % TW;
   const int rowb = a.CoutS * 2;
-  unsigned char* yb = a.y + (((size_t)n * a.H + y0) * a.W + x0) * rowb + (nt0 * 16 + 4 * g) * 2;
+  // (MODE 0 with y_hi: the output channels' upper half goes to a second dense tensor -- the gradient of a channel
+  // concatenation leaves as the two gradients of its parts; an n-tile belongs to one of them whole)
+  const bool twoy = MODE == 0 && a.y_hi != nullptr;
+  const int rowo = twoy ? rowb / 2 : rowb;  // bytes between two pixels of an output tensor
+  unsigned char* yj[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int gnt = nt0 + j, half = ntn / 2;
+    unsigned char* dst = (twoy && gnt >= half) ? a.y_hi : a.y;
+    yj[j] = dst + (((size_t)n * a.H + y0) * a.W + x0) * rowo + ((twoy && gnt >= half ? gnt - half : gnt) * 16 + 4 * g) * 2;
+  }
   int py = r16 / TW, px = r16 - py * TW;
-  int ob = (py * a.W + px) * rowb;
-  const int dob = (DPY * a.W + DPX) * rowb, wrapo = (a.W - TW) * rowb;
+  int ob = (py * a.W + px) * rowo;
+  const int dob = (DPY * a.W + DPX) * rowo, wrapo = (a.W - TW) * rowo;
   f32x4 ssum[NT], ssq[NT];
   f32x4 sc2[NT], sh2[NT], mu2[NT];  // MODE 2: BN coefficients of this lane's 4 channels per n-tile
   const unsigned char* y2b = nullptr;
@@ -481,10 +492,10 @@ conv3x3_fast_kernel(FastArgs a) {
               const auto rx = __builtin_amdgcn_permlane16_swap(pk_prev[j].x, pkc.x, false, false);
               const auto ry = __builtin_amdgcn_permlane16_swap(pk_prev[j].y, pkc.y, false, false);
               const u32x4 v = {rx[0], ry[0], rx[1], ry[1]};
-              *(u32x4*)(yb + ((g & 1) ? ob - 8 : ob_prev) + j * 32) = v;
+              *(u32x4*)(yj[j] + ((g & 1) ? ob - 8 : ob_prev)) = v;
             }
           } else {
-            store4_fast<bf16_t>(yb + ob + j * 32, acc[i][j]);
+            store4_fast<bf16_t>(yj[j] + ob, acc[i][j]);
           }
         }
         if (M2) {
@@ -772,7 +783,8 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
     if (c.CinS != 1 || c.CoutS != 16 || th != 14) return false;
     FastArgs a;
     if (c.x2 != nullptr) return false;
-    a.x = (const unsigned char*)c.x; a.x2 = nullptr; a.y = (unsigned char*)c.y; a.wp = (const u32x4*)c.wp; a.stats = c.stats;
+    if (c.y_hi != nullptr) return false;
+    a.x = (const unsigned char*)c.x; a.x2 = nullptr; a.y = (unsigned char*)c.y; a.y_hi = nullptr; a.wp = (const u32x4*)c.wp; a.stats = c.stats;
     a.in_scale = a.in_shift = nullptr;
     a.y2 = nullptr; a.scale2 = a.shift2 = a.mean2 = nullptr; a.rows2 = nullptr; a.H2 = a.W2 = 0; a.img2 = nullptr;
     a.N = c.N; a.H = c.H; a.W = c.W; a.CinK = 16; a.CoutS = 16;
@@ -812,6 +824,9 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
   FastArgs a;
   a.x = (const unsigned char*)c.x; a.y = (unsigned char*)c.y; a.wp = (const u32x4*)c.wp; a.stats = c.stats;
   a.x2 = (const unsigned char*)c.x2;
+  a.y_hi = (unsigned char*)c.y_hi;
+  if (c.y_hi != nullptr && !(c.in_mode == 0 && c.rows2 == nullptr && c.img2 == nullptr && c.stats == nullptr && ntn % 2 == 0))
+    return false;
   // two input tensors: one slab whose 16-byte chunks split evenly between them (32 = 16 + 16, 64 = 32 + 32 channels)
   if (c.x2 != nullptr && !(c.CinK == KC && KC >= 32 && c.rows2 == nullptr && c.img2 == nullptr)) return false;
   a.in_scale = c.in_scale; a.in_shift = c.in_shift;

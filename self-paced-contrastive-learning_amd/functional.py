@@ -782,6 +782,7 @@ class DeferredWgrads:
 # the whole UNet's eleven wide layers and ten narrow ones then leave in ONE batched launch at the gather)
 _QUEUE_MAX = (min(_n.WGRAD_BATCH_MAX, int(os.environ.get("SPCL_WGRAD_QUEUE_MAX", _n.WGRAD_BATCH_MAX))),
               min(_n.WGRAD_TAILS_MAX, int(os.environ.get("SPCL_WGRAD_QUEUE_MAX", _n.WGRAD_TAILS_MAX))))
+_CONV_SPLIT = os.environ.get("SPCL_CONV_SPLIT", "1") != "0"  # A/B switch: 0 leaves that level's gradient as one interleaved tensor
 _CONV_CAT = os.environ.get("SPCL_CONV_CAT", "1") != "0"  # A/B switch: 0 materialises the 16-channel decoder concatenation
 _PACK_AT = os.environ.get("SPCL_PACK_AT", "1") != "0"  # A/B switch: 0 packs the band-GEMM layout whether or not it is used
 _TAILS = os.environ.get("SPCL_WGRAD_TAILS", "1") != "0"  # A/B switch: 0 keeps every layer's own final reduction launch
@@ -1271,13 +1272,24 @@ class _ConvBlockFn(torch.autograd.Function):
                         _n.ptr(rows), _n.stream())
                 rows.ntiles = nt
                 li.rows, li.dx_ptr = rows, dxs.data_ptr()
-            if dxs is None:
+            split = None
+            if (dxs is None and x2s is not None and _CONV_SPLIT
+                    and _n.call("spcl_conv_split_supported", dtc, N, H, W, cout_s, cin_s)):
+                # the concatenation's gradient as the two dense gradients of its parts (one launch, no interleaved tensor)
+                split = (torch.empty(N, H, W, cin_s // 2, dtype=dtype, device=dya.device),
+                         torch.empty(N, H, W, cin_s // 2, dtype=dtype, device=dya.device))
+                _n.call("spcl_conv3x3_forward_split", _n.ptr(dya), dtc, N, H, W, cout_s, cin_s, _n.ptr(wpa_t),
+                        _n.ptr(split[0]), _n.ptr(split[1]), _n.stream())
+            elif dxs is None:
                 dxs, _ = _conv(dya, dtc, dtype, N, H, W, cout_s, cout_s, cin_s, wpa_t, 0, None, None, False)
             if x2s is not None:
-                # one gradient tensor for the concatenation; each producer's backward reads its channel half in place
-                # (nhwc_channel_slice -> the _strided BatchNorm entry points)
-                full = dxs.permute(0, 3, 1, 2)
-                dx, dx2 = full[:, :cin // 2], full[:, cin // 2:]
+                if split is not None:
+                    dx, dx2 = nhwc_to_logical(split[0], cin // 2), nhwc_to_logical(split[1], cin // 2)
+                else:
+                    # one gradient tensor for the concatenation; each producer's backward reads its channel half in place
+                    # (nhwc_channel_slice -> the _strided BatchNorm entry points)
+                    full = dxs.permute(0, 3, 1, 2)
+                    dx, dx2 = full[:, :cin // 2], full[:, cin // 2:]
                 if dx.dtype != xdt:
                     dx, dx2 = dx.to(xdt), dx2.to(xdt)
                 if not ctx.needs_input_grad[0]:
