@@ -257,6 +257,8 @@ typedef struct spcl_wgrad_item {
   const float* in_shift;
   float* dw_oihw;
   int N, H, W, Cin, CinS, Cout, CoutS, in_mode;
+  const void* x2; /* NULL, or: input channels [Cin / 2, Cin) come from this tensor and [0, Cin / 2) from x, both dense
+                     [N][H][W][Cin / 2] (the decoder's concatenation read in place; Cin a multiple of 128, in_mode 0) */
 } spcl_wgrad_item;
 int spcl_conv_wgrad_batched_supported(int dtype, int Cin, int CinS, int Cout, int CoutS, int in_mode);
 size_t spcl_conv_wgrad_batched_workspace_bytes(const spcl_wgrad_item* items, int n);

@@ -681,9 +681,11 @@ extern "C" int spcl_conv3x3_forward(const void* x, int dtype, int N, int H, int 
 // transform).  Only where a specialised kernel exists (14-column tiles, 2 Chalf = 32 or 64): ask _supported first.
 static bool conv_cat_args(ConvArgs& a, int dtype, int N, int H, int W, int Chalf, int CoutS) {
   static const bool off = getenv("SPCL_CONV_CAT") && atoi(getenv("SPCL_CONV_CAT")) == 0;  // A/B switch
-  if (off || dtype != SPCL_BF16 || N <= 0 || H <= 0 || W <= 0 || (Chalf != 16 && Chalf != 32) || CoutS % 16 != 0 || CoutS <= 0)
+  if (off || dtype != SPCL_BF16 || N <= 0 || H <= 0 || W <= 0 || CoutS % 16 != 0 || CoutS <= 0 ||
+      (Chalf != 16 && Chalf != 32 && Chalf != 64 && Chalf != 128))
     return false;
-  if ((2 * Chalf) % 64 == 0 && CoutS % 64 == 0) return false;  // (its weight gradient would be a batched-GEMM layer: wgrad.hip)
+  // (a layer whose weight gradient the batched GEMM kernel takes reads 64-channel blocks: the halves must be whole blocks)
+  if ((2 * Chalf) % 64 == 0 && CoutS % 64 == 0 && Chalf % 64 != 0) return false;
   a.in_scale = a.in_shift = nullptr;
   a.stats = nullptr;
   a.N = N; a.H = H; a.W = W; a.CinS = 2 * Chalf; a.CinK = 2 * Chalf; a.CoutS = CoutS; a.in_mode = 0;
@@ -707,7 +709,7 @@ extern "C" int spcl_conv3x3_forward_cat(const void* xa, const void* xb, int dtyp
   SPCL_CHECK_ARG((uintptr_t)xa % 16 == 0 && (uintptr_t)xb % 16 == 0, "conv3x3_forward_cat: inputs must be 16-byte aligned");
   ConvArgs a;
   if (!conv_cat_args(a, dtype, N, H, W, Chalf, CoutS)) {
-    set_error("conv3x3_forward_cat: unsupported configuration (bf16, Chalf 16 or 32, 14-column tiles)");
+    set_error("conv3x3_forward_cat: unsupported configuration (bf16, Chalf 16 / 32 / 64 / 128, 14-column tiles)");
     return SPCL_EUNSUPPORTED;
   }
   a.x = xa; a.x2 = xb; a.y = y; a.wp = w_packed; a.stats = stats;

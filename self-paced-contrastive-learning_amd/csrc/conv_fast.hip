@@ -175,11 +175,14 @@ conv3x3_fast_kernel(FastArgs a) {
   const int hy0 = q0 / HW_, hx0 = q0 % HW_;
   // (two sources: a pixel's chunks [0, CP / 2) sit in x, the others in x2, each tensor with half the pixel stride -- a
   // per-thread choice of base pointer, fixed for the launch)
+  // With more than one slab (CinK = 128 / 256) a whole slab lies in one tensor: a wave-uniform choice per slab instead.
   const bool two = a.x2 != nullptr;
+  const bool two_chunks = two && a.CinK == KC;
   const int gps1 = two ? gps / 2 : gps;
-  const int ch1 = two ? (ch & (CP / 2 - 1)) : ch;
-  const unsigned char* xsrc = (two && ch >= CP / 2) ? a.x2 : a.x;
-  const unsigned char* xb = xsrc + (((long)n * a.H + (y0 - 1)) * a.W + (x0 - 1)) * gps1;  // halo origin (may be outside)
+  const int ch1 = two_chunks ? (ch & (CP / 2 - 1)) : ch;
+  const long xorg = (((long)n * a.H + (y0 - 1)) * a.W + (x0 - 1)) * gps1;
+  const unsigned char* xb = ((two_chunks && ch >= CP / 2) ? a.x2 : a.x) + xorg;  // halo origin (may be outside)
+  const unsigned char* xb2 = two ? a.x2 + xorg : nullptr;
   const unsigned voff = (unsigned)((hy0 * a.W + hx0) * gps1 + ch1 * 16);
   unsigned char* const lp = lds + (hy0 * RP + hx0) * PS + ch * 16;
 
@@ -220,7 +223,9 @@ conv3x3_fast_kernel(FastArgs a) {
         *(f32x4*)&ssh[e] = *(const f32x4*)(a.in_shift + slab * KC + ch * 8 + e);
       }
     }
-    const unsigned char* xs = xb + slab * (KC * 2);
+    const int hslab = (a.CinK / KC) >> 1;  // slabs per tensor when the input is two tensors of whole slabs
+    const unsigned char* xs = (two && !two_chunks) ? (slab >= hslab ? xb2 + (slab - hslab) * (KC * 2) : xb + slab * (KC * 2))
+                                                   : xb + slab * (KC * 2);
 #pragma unroll
     for (int k = 0; k < ITER; ++k) {
       const int dky = QS >= HW_ ? k * (QS / HW_) : k / (HW_ / QS);
@@ -828,7 +833,10 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
   if (c.y_hi != nullptr && !(c.in_mode == 0 && c.rows2 == nullptr && c.img2 == nullptr && c.stats == nullptr && ntn % 2 == 0))
     return false;
   // two input tensors: one slab whose 16-byte chunks split evenly between them (32 = 16 + 16, 64 = 32 + 32 channels)
-  if (c.x2 != nullptr && !(c.CinK == KC && KC >= 32 && c.rows2 == nullptr && c.img2 == nullptr)) return false;
+  // ... or several slabs, half of them in each tensor (128 = 64 + 64, 256 = 128 + 128)
+  if (c.x2 != nullptr && !(((c.CinK == KC && KC >= 32) || (KC == 64 && (c.CinK / 64) % 2 == 0)) && c.rows2 == nullptr &&
+                           c.img2 == nullptr))
+    return false;
   a.in_scale = c.in_scale; a.in_shift = c.in_shift;
   a.y2 = (const unsigned char*)c.y2; a.scale2 = c.scale2; a.shift2 = c.shift2; a.mean2 = c.mean2; a.rows2 = c.rows2;
   a.H2 = c.H2; a.W2 = c.W2;

@@ -492,7 +492,7 @@ static bool wide_item(spcl_wgrad_item& it, const void* x, const void* dy, int N,
   if (Cin != CinK || CinS != CinK || Cout != CoutS ||
       !spcl_conv_wgrad_batched_supported(SPCL_BF16, Cin, CinS, Cout, CoutS, in_mode))
     return false;
-  it.x = x; it.dy = dy; it.in_scale = in_scale; it.in_shift = in_shift; it.dw_oihw = dw;
+  it.x = x; it.x2 = nullptr; it.dy = dy; it.in_scale = in_scale; it.in_shift = in_shift; it.dw_oihw = dw;
   it.N = N; it.H = H; it.W = W; it.Cin = Cin; it.CinS = CinS; it.Cout = Cout; it.CoutS = CoutS; it.in_mode = in_mode;
   return true;
 }
@@ -523,14 +523,16 @@ extern "C" int spcl_conv3x3_wgrad(const void* x, const void* dy, int dtype, int 
 }
 
 // ... of the convolution behind the decoder's torch.cat((skip, up), dim=1) (unet.py:194-224), its input read from the two
-// tensors in place: xa = channels [0, Chalf), xb = [Chalf, 2 Chalf), both dense [N][H][W][Chalf] bf16 (Chalf 16 or 32; not
-// the layers the batched GEMM kernel takes: 2 Chalf and CoutS both multiples of 64).  Workspace as spcl_conv3x3_wgrad with
-// CinK = 2 Chalf.
+// tensors in place: xa = channels [0, Chalf), xb = [Chalf, 2 Chalf), both dense [N][H][W][Chalf] bf16 (Chalf 16 / 32: the
+// narrow kernel above; 64 / 128 with CoutS a multiple of 64: the batched GEMM kernel, spcl_wgrad_item::x2).  Workspace as
+// spcl_conv3x3_wgrad with CinK = 2 Chalf.
 extern "C" int spcl_conv3x3_wgrad_cat(const void* xa, const void* xb, const void* dy, int dtype, int N, int H, int W, int Chalf,
                                       int Cout, int CoutS, float* partial, float* dw_oihw, void* stream) {
   SPCL_CHECK_ARG(xa && xb, "conv3x3_wgrad_cat: null pointer");
-  SPCL_CHECK_ARG(dtype == SPCL_BF16 && (Chalf == 16 || Chalf == 32) && !((2 * Chalf) % 64 == 0 && CoutS % 64 == 0),
-                 "conv3x3_wgrad_cat: bf16, Chalf 16 or 32, not a batched-GEMM layer");
+  SPCL_CHECK_ARG(dtype == SPCL_BF16 && (Chalf == 16 || Chalf == 32 || Chalf == 64 || Chalf == 128),
+                 "conv3x3_wgrad_cat: bf16, Chalf 16 / 32 / 64 / 128");
+  SPCL_CHECK_ARG(!((2 * Chalf) % 64 == 0 && CoutS % 64 == 0) || Chalf % 64 == 0,
+                 "conv3x3_wgrad_cat: a batched-GEMM layer needs halves of whole 64-channel blocks");
   SPCL_CHECK_ARG((uintptr_t)xa % 16 == 0 && (uintptr_t)xb % 16 == 0, "conv3x3_wgrad_cat: inputs must be 16-byte aligned");
   return conv3x3_wgrad_impl(xa, xb, dy, dtype, N, H, W, 2 * Chalf, 2 * Chalf, 2 * Chalf, Cout, CoutS, 0, nullptr, nullptr,
                             partial, dw_oihw, stream);
@@ -550,8 +552,10 @@ static int conv3x3_wgrad_impl(const void* x, const void* x2, const void* dy, int
   spcl_wgrad_tail* tail = take_tail_capture();  // non-null: leave the final sum to spcl_conv3x3_wgrad_batched_tails
   if (dtype == SPCL_BF16) {
     spcl_wgrad_item it;
-    if (x2 == nullptr && wide_item(it, x, dy, N, H, W, Cin, CinS, CinK, Cout, CoutS, in_mode, in_scale, in_shift, dw_oihw))
+    if (wide_item(it, x, dy, N, H, W, Cin, CinS, CinK, Cout, CoutS, in_mode, in_scale, in_shift, dw_oihw)) {
+      it.x2 = x2;  // (the batched kernel reads a 64-channel block from the tensor that holds it)
       return spcl_conv3x3_wgrad_batched(&it, 1, 0, partial, stream);
+    }
   }
   WgradPlan p = wgrad_plan(N, H, W, CinK, CoutS, dtype == SPCL_F32 ? 4 : 2);
   WgradArgs a;

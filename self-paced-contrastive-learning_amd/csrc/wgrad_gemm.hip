@@ -42,6 +42,7 @@ constexpr int WB_SLAB = 9 * 64 * 64;  // floats per workgroup partial
 
 struct WbItem {
   const bf16_t* x;
+  const bf16_t* x2;  // non-null: channels [Cin / 2, Cin) of the input live here, [0, Cin / 2) in x (pixel stride Cin / 2 each)
   const bf16_t* dy;
   const float* in_scale;
   const float* in_shift;
@@ -150,9 +151,12 @@ __global__ __launch_bounds__(768) void wgrad_gemm_kernel(WbArgs a) {
 
   if (wave >= 8) {
     // =============================================================================================== producers
-    const int H = it.H, W = it.W, CinS = it.CinS, CoutS = it.CoutS;
+    const int H = it.H, W = it.W, CoutS = it.CoutS;
     const bool fused = it.in_mode == 1;
-    const bf16_t* xg = it.x + bci * 64;
+    // (two input tensors: a 64-channel block lies in one of them whole -- a workgroup-uniform choice)
+    const bool xtwo = it.x2 != nullptr;
+    const int CinS = xtwo ? it.Cin / 2 : it.CinS;
+    const bf16_t* xg = xtwo ? (bci * 64 >= CinS ? it.x2 + (bci * 64 - CinS) : it.x + bci * 64) : it.x + bci * 64;
     const bf16_t* dyg = it.dy + bco * 64;
     const int pw = wave - 8;
     const int c = tid & 7, pb = (tid - 512) >> 3;  // 16-byte chunk of a pixel, pixel within a 32-pixel staging iteration
@@ -557,7 +561,7 @@ static int wb_plan(const spcl_wgrad_item* items, int n, WbPlan& pl) {
   for (int i = 0; i < n; ++i) {
     WbItem& w = pl.args.it[i];
     const spcl_wgrad_item& s = items[i];
-    w.x = (const bf16_t*)s.x; w.dy = (const bf16_t*)s.dy; w.in_scale = s.in_scale; w.in_shift = s.in_shift; w.dw = s.dw_oihw;
+    w.x = (const bf16_t*)s.x; w.x2 = (const bf16_t*)s.x2; w.dy = (const bf16_t*)s.dy; w.in_scale = s.in_scale; w.in_shift = s.in_shift; w.dw = s.dw_oihw;
     w.N = s.N; w.H = s.H; w.W = s.W; w.Cin = s.Cin; w.Cout = s.Cout; w.CinS = s.CinS; w.CoutS = s.CoutS;
     w.in_mode = s.in_mode;
     w.tilesX = cdiv(s.W, 16);
@@ -609,6 +613,7 @@ static bool wb_item_ok(const spcl_wgrad_item& s) {
   return s.x && s.dy && s.dw_oihw && s.N > 0 && s.H > 0 && s.W > 0 && s.Cin > 0 && s.Cout > 0 && s.Cin % 64 == 0 &&
          s.Cout % 64 == 0 && s.CinS >= s.Cin && s.CoutS >= s.Cout && s.CinS % 8 == 0 && s.CoutS % 8 == 0 &&
          (s.in_mode == 0 || (s.in_mode == 1 && s.in_scale && s.in_shift)) &&
+         (s.x2 == nullptr || (s.in_mode == 0 && s.Cin % 128 == 0 && s.CinS == s.Cin)) &&
          (long)s.N * s.H * s.W * (s.CinS > s.CoutS ? s.CinS : s.CoutS) < (1L << 31);
 }
 

@@ -741,12 +741,12 @@ class DeferredWgrads:
         self.items, self.keep, self.targets = [], [], set()
         self.tails = []
 
-    def add(self, x_store, dy, scale, shift, sink, N, H, W, cin, cin_s, cout, cout_s, in_mode):
+    def add(self, x_store, dy, scale, shift, sink, N, H, W, cin, cin_s, cout, cout_s, in_mode, x2=None):
         it = _n.WgradItem(x_store.data_ptr(), dy.data_ptr(), scale.data_ptr() if scale is not None else None,
                           shift.data_ptr() if shift is not None else None, sink.data_ptr(), N, H, W, cin, cin_s, cout,
-                          cout_s, in_mode)
+                          cout_s, in_mode, x2.data_ptr() if x2 is not None else None)
         self.items.append(it)
-        self.keep.append((x_store, dy, scale, shift))  # operands stay alive until the launch
+        self.keep.append((x_store, dy, scale, shift, x2))  # operands stay alive until the launch
         self.targets.add(sink.data_ptr())
         if len(self.items) == _QUEUE_MAX[0]:
             self.flush()
@@ -838,6 +838,11 @@ def _wgrad_cat(xa, xb, dy, dt_code, N, H, W, chalf, cout, cout_s, sink=None):
     """weight gradient of the convolution of ``cat((xa, xb), channel)``, the input read from the two tensors
     (spcl_conv3x3_wgrad_cat); the final sum rides in the batched launch when ``sink`` belongs to a bucket, as in ``_wgrad``"""
     dev = dy.device
+    queue = sink_queue(sink)
+    if queue is not None and _n.call("spcl_conv_wgrad_batched_supported", dt_code, 2 * chalf, 2 * chalf, cout, cout_s, 0):
+        # a wide layer: one item of the batched launch, its 64-channel input blocks read from the tensor that holds them
+        queue.add(xa, dy, None, None, sink, N, H, W, 2 * chalf, 2 * chalf, cout, cout_s, 0, x2=xb)
+        return None
     nbytes = _n.call("spcl_conv_wgrad_workspace_bytes", N, H, W, 2 * chalf, cout_s)
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
     dw = _grad_buffer(sink, (cout, 2 * chalf, 3, 3), dev)
@@ -846,7 +851,6 @@ def _wgrad_cat(xa, xb, dy, dt_code, N, H, W, chalf, cout, cout_s, sink=None):
         _n.call("spcl_conv3x3_wgrad_cat", _n.ptr(xa), _n.ptr(xb), _n.ptr(dy), dt_code, N, H, W, chalf, cout, cout_s,
                 _n.ptr(ws), _n.ptr(dw), _n.stream())
 
-    queue = sink_queue(sink)
     if queue is not None and _TAILS:
         if queue.capture_tail(sink, (ws, dy, xa, xb), launch):
             return None
@@ -1308,6 +1312,12 @@ class _ConvBlockFn(torch.autograd.Function):
 def conv_block(x, wa, ga, ba, wb, gb, bb, cfg: BlockCfg, x2=None):
     """-> (act or None, pooled or None), logical NCHW views over NHWC storage.  ``x2``: see ``_ConvBlockFn.forward``."""
     return _ConvBlockFn.apply(x, wa, ga, ba, wb, gb, bb, cfg, x2)
+
+
+def cat_pair_shape_ok(N, C, H, W, cout, dtype):
+    """``cat_pair_supported`` for two dense NHWC tensors of this shape that do not exist yet (UNet.forward plans with it)"""
+    return bool(_CONV_CAT and dtype == torch.bfloat16
+                and _n.call("spcl_conv_cat_supported", _n.dtype_code(dtype), N, H, W, C, _ru16(cout)))
 
 
 def cat_pair_supported(a, b, cout, dtype):

@@ -153,7 +153,7 @@ class WgradItem(ctypes.Structure):
     """``spcl_wgrad_item`` of include/spcl_hip.h (one layer of a batched weight-gradient launch)"""
     _fields_ = [("x", c_void_p), ("dy", c_void_p), ("in_scale", c_void_p), ("in_shift", c_void_p),
                 ("dw_oihw", c_void_p), ("N", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int), ("CinS", c_int),
-                ("Cout", c_int), ("CoutS", c_int), ("in_mode", c_int)]
+                ("Cout", c_int), ("CoutS", c_int), ("in_mode", c_int), ("x2", c_void_p)]
 
 
 class PackItem(ctypes.Structure):

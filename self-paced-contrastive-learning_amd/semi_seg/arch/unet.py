@@ -29,7 +29,15 @@ _VIRTUAL_CAT = __import__("os").environ.get("SPCL_VIRTUAL_CAT", "1") != "0"  # A
 # narrowest skip that takes part.  A 16-channel pixel is a 32-byte run inside a 64-byte stride: the two producers then each
 # write HALF of every line (bnrelu_fwd_lin 51 -> 88 us per step at 224^2) and the copy is cheaper; from 32 channels on the
 # in-place halves win (fine-tune step, same box, three rounds: off 2.481 ms, >= 16: 2.455, >= 32: 2.439, >= 64: 2.449)
+# Later (round 4): where the block's first convolution and its weight gradient can read the two tensors side by side and the
+# gradient leaves as two dense tensors (functional.cat_pair_shape_ok: sizes the specialised kernels tile) that beats the halves
+# of one buffer too -- 2.299 -> 2.261 ms with the 32-channel level moved over -- and is tried first (_CAT_PAIR_FIRST); the
+# buffer remains for the other sizes.
 _VIRTUAL_CAT_MINC = int(__import__("os").environ.get("SPCL_VIRTUAL_CAT_MINC", "32"))
+_CAT_PAIR_FIRST = __import__("os").environ.get("SPCL_CAT_PAIR_FIRST", "1") != "0"  # A/B switch: 0 = the buffer wherever >= MINC
+# widest level read as two tensors: the 64- and 128-channel levels work too (conv_fast slab by slab, the batched weight-gradient
+# kernel block by block; tested) but measure the same as the halves of one buffer, +1..4 us: they keep the buffer
+_CAT_PAIR_MAXC = int(__import__("os").environ.get("SPCL_CAT_PAIR_MAXC", "32"))
 _LAZY_HEAD = __import__("os").environ.get("SPCL_LAZY_HEAD", "1") != "0"  # A/B switch: 0 writes the last activation and reads it back
 _FUSED_UPSAMPLE = __import__("os").environ.get("SPCL_FUSED_UPSAMPLE", "1") != "0"  # A/B switch (BlockCfg.up2)
 _ENCODER = ("Conv1", "Conv2", "Conv3", "Conv4", "Conv5")
@@ -230,6 +238,10 @@ class UNet(nn.Module):
                 if (c % 16 == 0 and c >= _VIRTUAL_CAT_MINC and len(blk._forward_hooks) == 0 and h >= 2 and w >= 2
                         and h % 2 == 0 and w % 2 == 0):
                     dt = blk._compute_dtype or _config.get_compute_dtype()
+                    ub = getattr(self, f"_Up_conv{k + 2}")
+                    if (_CAT_PAIR_FIRST and c <= _CAT_PAIR_MAXC and len(ub._forward_pre_hooks) == 0
+                            and F_hip.cat_pair_shape_ok(int(x.shape[0]), c, h, w, c, ub._compute_dtype or dt)):
+                        continue  # this level's block reads the two tensors side by side (below): no buffer
                     cats[name] = F_hip.cat_buffer(int(x.shape[0]), h, w, c, c, dt, x.device)
         for k, name in enumerate(_ENCODER):
             blk = getattr(self, "_" + name)

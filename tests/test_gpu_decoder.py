@@ -294,33 +294,40 @@ def test_in_place_decoder_data_movement_is_the_copying_path_bit_for_bit(N, S, mo
     x = torch.rand(N, 1, S, S, generator=g).cuda()
     labels = torch.randint(0, 4, (N, S, S), generator=g).cuda()
 
-    def run(in_place):
+    def run(in_place, pair_first=True):
         monkeypatch.setattr(unet_mod, "_VIRTUAL_CAT", in_place)
         monkeypatch.setattr(unet_mod, "_FUSED_UPSAMPLE", in_place)
         monkeypatch.setattr(F, "_CONV_CAT", in_place)
+        monkeypatch.setattr(unet_mod, "_CAT_PAIR_FIRST", pair_first)
+        monkeypatch.setattr(unet_mod, "_CAT_PAIR_MAXC", 1024)  # (the wide levels too: slab-wise / block-wise two-tensor reads)
         monkeypatch.setattr(unet_mod, "_LAZY_HEAD", False)  # (its BatchNorm-backward sums have their own order: next test)
         m = UNet(input_dim=1, num_classes=4, max_channel=256)
         m.load_state_dict(sd, strict=True)
         m.cuda().train()
         m.set_compute_dtype(torch.bfloat16)
-        copies = []
+        copies, bufs = [], []
+        real_buf = F.cat_buffer
+        monkeypatch.setattr(F, "cat_buffer", lambda *a, **k: (bufs.append(1), real_buf(*a, **k))[1])
         real_cat = F.concat_channels
         monkeypatch.setattr(F, "concat_channels", lambda *a, **k: (copies.append(1), real_cat(*a, **k))[1])
         logits = m(x)
         monkeypatch.setattr(F, "concat_channels", real_cat)
+        monkeypatch.setattr(F, "cat_buffer", real_buf)
         assert len(copies) == (0 if in_place else 4)  # no level falls back to the copying concatenation
+        assert len(bufs) == (0 if (pair_first or not in_place) else 3)  # the buffer only where the two-tensor read is not asked for
         loss, _ = F.sup_loss_kl_onehot(logits, labels)
         loss.backward()
         torch.cuda.synchronize()
         return logits.detach().clone(), loss.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()}
 
-    la, lossa, ga = run(True)
     lb, lossb, gb = run(False)
-    assert torch.equal(la, lb) and torch.equal(lossa, lossb)
-    assert set(ga) == set(gb)
-    for k in ga:
-        assert torch.equal(ga[k], gb[k]), k
-        assert float(ga[k].abs().max()) > 0, k
+    for pair_first in (True, False):  # every level read from its two tensors / the >= 32-channel levels as halves of one buffer
+        la, lossa, ga = run(True, pair_first)
+        assert torch.equal(la, lb) and torch.equal(lossa, lossb)
+        assert set(ga) == set(gb)
+        for k in ga:
+            assert torch.equal(ga[k], gb[k]), (pair_first, k)
+            assert float(ga[k].abs().max()) > 0, k
     # and the narrow level really took the two-tensor convolution
     monkeypatch.setattr(F, "_CONV_CAT", True)
     a = torch.zeros(N, 16, S, S, device="cuda", dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
