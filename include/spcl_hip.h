@@ -210,9 +210,14 @@ int spcl_conv3x3_forward(const void* x, int dtype, int N, int H, int W, int CinS
  * (spcl_bnrelu_pool_backward_strided). */
 int spcl_conv_cat_supported(int dtype, int N, int H, int W, int Chalf, int CoutS);
 int spcl_conv3x3_forward_cat(const void* xa, const void* xb, int dtype, int N, int H, int W, int Chalf, int CoutS,
-                             const void* w_packed, void* y, float* stats, void* stream);
+                             const void* w_packed, const float* xb_scale, const float* xb_shift, void* y, float* stats,
+                             void* stream);
+/* xb_scale / xb_shift [Chalf] (both, or both NULL; Chalf 16 / 32): xb is the RAW output of the up-convolution (unet.py:90) and
+ * the concatenation holds relu(xb_scale xb + xb_shift) -- that BatchNorm + ReLU (unet.py:91-92) applied while the halo is
+ * staged, so the up-convolution's activation is never written either. */
 int spcl_conv3x3_wgrad_cat(const void* xa, const void* xb, const void* dy, int dtype, int N, int H, int W, int Chalf,
-                           int Cout, int CoutS, float* partial, float* dw_oihw, void* stream);
+                           int Cout, int CoutS, const float* xb_scale, const float* xb_shift, float* partial,
+                           float* dw_oihw, void* stream);
 /* ... and the input gradient of that convolution as the gradients of the two concatenated tensors: the plain 3x3 convolution
  * (w_packed = the dgrad layout, kind 1) whose output channels [0, CoutS / 2) are written to y_lo and [CoutS / 2, CoutS) to
  * y_hi, both dense [N][H][W][CoutS / 2] bf16 (torch.cat's backward, unet.py:194-224, without the interleaved tensor).

@@ -704,8 +704,11 @@ extern "C" int spcl_conv_cat_supported(int dtype, int N, int H, int W, int Chalf
 }
 
 extern "C" int spcl_conv3x3_forward_cat(const void* xa, const void* xb, int dtype, int N, int H, int W, int Chalf, int CoutS,
-                                        const void* w_packed, void* y, float* stats, void* stream) {
+                                        const void* w_packed, const float* xb_scale, const float* xb_shift, void* y,
+                                        float* stats, void* stream) {
   SPCL_CHECK_ARG(xa && xb && y && w_packed, "conv3x3_forward_cat: null pointer");
+  SPCL_CHECK_ARG((xb_scale == nullptr) == (xb_shift == nullptr), "conv3x3_forward_cat: xb_scale and xb_shift come together");
+  SPCL_CHECK_ARG(xb_scale == nullptr || Chalf <= 32, "conv3x3_forward_cat: the raw second tensor exists for Chalf 16 / 32 only");
   SPCL_CHECK_ARG((uintptr_t)xa % 16 == 0 && (uintptr_t)xb % 16 == 0, "conv3x3_forward_cat: inputs must be 16-byte aligned");
   ConvArgs a;
   if (!conv_cat_args(a, dtype, N, H, W, Chalf, CoutS)) {
@@ -713,6 +716,7 @@ extern "C" int spcl_conv3x3_forward_cat(const void* xa, const void* xb, int dtyp
     return SPCL_EUNSUPPORTED;
   }
   a.x = xa; a.x2 = xb; a.y = y; a.wp = w_packed; a.stats = stats;
+  if (xb_scale != nullptr) { a.in_mode = 1; a.in_scale = xb_scale; a.in_shift = xb_shift; }
   hipStream_t st = (hipStream_t)stream;
   const double px = (double)N * H * W;
   prof_cost(px * (2.0 * Chalf + CoutS) * 2.0 + 9.0 * 2.0 * Chalf * CoutS * 2.0, 2.0 * px * 9.0 * 2.0 * Chalf * CoutS);

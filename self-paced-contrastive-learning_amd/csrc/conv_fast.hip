@@ -219,8 +219,11 @@ conv3x3_fast_kernel(FastArgs a) {
     if (MODE == 1) {
 #pragma unroll
       for (int e = 0; e < 8; e += 4) {
-        *(f32x4*)&ssc[e] = *(const f32x4*)(a.in_scale + slab * KC + ch * 8 + e);
-        *(f32x4*)&ssh[e] = *(const f32x4*)(a.in_shift + slab * KC + ch * 8 + e);
+        // (two tensors, one slab: the coefficients belong to the SECOND tensor's channels -- x is an activation already, x2
+        // the raw output of the convolution whose BatchNorm + ReLU this loader applies; chunks of x keep ch1's entry unused)
+        const int cc = two_chunks ? ch1 : ch;
+        *(f32x4*)&ssc[e] = *(const f32x4*)(a.in_scale + slab * KC + cc * 8 + e);
+        *(f32x4*)&ssh[e] = *(const f32x4*)(a.in_shift + slab * KC + cc * 8 + e);
       }
     }
     const int hslab = (a.CinK / KC) >> 1;  // slabs per tensor when the input is two tensors of whole slabs
@@ -254,7 +257,7 @@ conv3x3_fast_kernel(FastArgs a) {
           const int gy = y0 - 1 + hy0 + dky, gx = x0 - 1 + hx0 + dkx;
           inb = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
         }
-        if (inb) tv = bnrelu_regs<bf16_t>(tv, ssc, ssh);
+        if (inb && (!two_chunks || ch >= CP / 2)) tv = bnrelu_regs<bf16_t>(tv, ssc, ssh);
       }
       if (in_range) *(u32x4*)(lpw + (dky * RP + dkx) * PS) = tv;
     }
@@ -837,6 +840,7 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
   if (c.x2 != nullptr && !(((c.CinK == KC && KC >= 32) || (KC == 64 && (c.CinK / 64) % 2 == 0)) && c.rows2 == nullptr &&
                            c.img2 == nullptr))
     return false;
+  if (c.x2 != nullptr && c.in_mode == 1 && c.CinK != KC) return false;  // (the half-transform exists for one slab only)
   a.in_scale = c.in_scale; a.in_shift = c.in_shift;
   a.y2 = (const unsigned char*)c.y2; a.scale2 = c.scale2; a.shift2 = c.shift2; a.mean2 = c.mean2; a.rows2 = c.rows2;
   a.H2 = c.H2; a.W2 = c.W2;

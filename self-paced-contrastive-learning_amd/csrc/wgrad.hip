@@ -134,11 +134,16 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_wgrad_kernel(WgradArgs a)
   const int dch = threadIdx.x % DCP, dpl = threadIdx.x / DCP;
   const int dry0 = dpl / WG_TW, dcol = dpl - dry0 * WG_TW;
   float sc[EPC], sh[EPC];
+  // (two input tensors with IM == 1: the coefficients are the SECOND tensor's -- x is an activation already, x2 the raw
+  // output of the convolution whose BatchNorm + ReLU is applied here; the first tensor's chunks are staged as they are)
+  const bool bn_x2 = IM == 1 && a.x2 != nullptr;
+  const bool bn_this = IM == 1 && (!bn_x2 || ci0 + xch * EPC >= a.xsplit);
   if (IM == 1) {
+    const int cc = bn_x2 ? (bn_this ? ci0 + xch * EPC - a.xsplit : 0) : ci0 + xch * EPC;
 #pragma unroll
     for (int e = 0; e < EPC; e += 4) {
-      *(f32x4*)&sc[e] = *(const f32x4*)(a.in_scale + ci0 + xch * EPC + e);
-      *(f32x4*)&sh[e] = *(const f32x4*)(a.in_shift + ci0 + xch * EPC + e);
+      *(f32x4*)&sc[e] = *(const f32x4*)(a.in_scale + cc + e);
+      *(f32x4*)&sh[e] = *(const f32x4*)(a.in_shift + cc + e);
     }
   }
 
@@ -245,7 +250,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_wgrad_kernel(WgradArgs a)
       if (xact && hy < NHROWS) {
         u32x4 v = rx[i];
         if (!(xmask & (1u << i))) v = (u32x4){0u, 0u, 0u, 0u};  // zero padding stays zero (also after BN + ReLU)
-        else if (IM == 1) v = wg_bnrelu_chunk<T>(v, sc, sh);
+        else if (IM == 1 && bn_this) v = wg_bnrelu_chunk<T>(v, sc, sh);
         *(u32x4*)(bx + hy * XRP + xhx * XS + xch * 16) = v;
       }
     }
@@ -524,18 +529,23 @@ extern "C" int spcl_conv3x3_wgrad(const void* x, const void* dy, int dtype, int 
 
 // ... of the convolution behind the decoder's torch.cat((skip, up), dim=1) (unet.py:194-224), its input read from the two
 // tensors in place: xa = channels [0, Chalf), xb = [Chalf, 2 Chalf), both dense [N][H][W][Chalf] bf16 (Chalf 16 / 32: the
-// narrow kernel above; 64 / 128 with CoutS a multiple of 64: the batched GEMM kernel, spcl_wgrad_item::x2).  Workspace as
-// spcl_conv3x3_wgrad with CinK = 2 Chalf.
+// narrow kernel above; 64 / 128 with CoutS a multiple of 64: the batched GEMM kernel, spcl_wgrad_item::x2).  xb_scale /
+// xb_shift [Chalf] (Chalf 16 / 32, or NULL): xb is the RAW output of a convolution and relu(xb_scale xb + xb_shift) is what
+// the concatenation holds (the up-convolution's BatchNorm + ReLU applied while staging).  Workspace as spcl_conv3x3_wgrad
+// with CinK = 2 Chalf.
 extern "C" int spcl_conv3x3_wgrad_cat(const void* xa, const void* xb, const void* dy, int dtype, int N, int H, int W, int Chalf,
-                                      int Cout, int CoutS, float* partial, float* dw_oihw, void* stream) {
+                                      int Cout, int CoutS, const float* xb_scale, const float* xb_shift, float* partial,
+                                      float* dw_oihw, void* stream) {
   SPCL_CHECK_ARG(xa && xb, "conv3x3_wgrad_cat: null pointer");
   SPCL_CHECK_ARG(dtype == SPCL_BF16 && (Chalf == 16 || Chalf == 32 || Chalf == 64 || Chalf == 128),
                  "conv3x3_wgrad_cat: bf16, Chalf 16 / 32 / 64 / 128");
   SPCL_CHECK_ARG(!((2 * Chalf) % 64 == 0 && CoutS % 64 == 0) || Chalf % 64 == 0,
                  "conv3x3_wgrad_cat: a batched-GEMM layer needs halves of whole 64-channel blocks");
   SPCL_CHECK_ARG((uintptr_t)xa % 16 == 0 && (uintptr_t)xb % 16 == 0, "conv3x3_wgrad_cat: inputs must be 16-byte aligned");
-  return conv3x3_wgrad_impl(xa, xb, dy, dtype, N, H, W, 2 * Chalf, 2 * Chalf, 2 * Chalf, Cout, CoutS, 0, nullptr, nullptr,
-                            partial, dw_oihw, stream);
+  SPCL_CHECK_ARG((xb_scale == nullptr) == (xb_shift == nullptr), "conv3x3_wgrad_cat: xb_scale and xb_shift come together");
+  SPCL_CHECK_ARG(xb_scale == nullptr || Chalf <= 32, "conv3x3_wgrad_cat: the raw second tensor exists for Chalf 16 / 32 only");
+  return conv3x3_wgrad_impl(xa, xb, dy, dtype, N, H, W, 2 * Chalf, 2 * Chalf, 2 * Chalf, Cout, CoutS, xb_scale ? 1 : 0,
+                            xb_scale, xb_shift, partial, dw_oihw, stream);
 }
 
 static int conv3x3_wgrad_impl(const void* x, const void* x2, const void* dy, int dtype, int N, int H, int W, int Cin, int CinS,

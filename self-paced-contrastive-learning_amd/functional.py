@@ -566,7 +566,7 @@ class ActLink:
 class BlockCfg:
     """Static configuration of one fused Conv-BN-ReLU(-Conv-BN-ReLU)(-MaxPool) block call."""
     __slots__ = ("dtype", "training", "momentum", "eps", "track", "need_act", "need_pool", "image_input", "buffers",
-                 "link_in", "link_out", "act_dst", "up2", "lazy_act", "link_act")
+                 "link_in", "link_out", "act_dst", "up2", "lazy_act", "link_act", "x2_link")
 
     def __init__(self, dtype, training, momentum, eps, track, need_act, need_pool, image_input, buffers):
         self.dtype, self.training, self.momentum, self.eps, self.track = dtype, training, momentum, eps, track
@@ -577,6 +577,7 @@ class BlockCfg:
                               # decoder concatenation buffer (UNet.forward), so that torch.cat needs no copy
         self.lazy_act = False  # the activation's only consumer applies BN + ReLU itself: return the RAW output, offer link_act
         self.link_act = None
+        self.x2_link = None    # ActLink of the producer of ``x2`` when that tensor is its RAW output (conv_block(..., x2=...))
         self.up2 = False      # the activation's only consumer is nn.Upsample(scale_factor=2): write it 2x2-replicated, return
                               # the [N, C, 2H, 2W] tensor (spcl_bnrelu_up2_forward); backward sums the 2x2 gradients first
 
@@ -696,8 +697,9 @@ def _conv(x_store, dt_code, dtype, N, H, W, cin_s, cin_k, cout_s, wp, in_mode, s
     return y, stats
 
 
-def _conv_cat(xa, xb, dt_code, dtype, N, H, W, chalf, cout_s, wp, want_stats):
-    """the convolution of ``torch.cat((xa, xb), channel)`` read from the two tensors (spcl_conv3x3_forward_cat)"""
+def _conv_cat(xa, xb, dt_code, dtype, N, H, W, chalf, cout_s, wp, want_stats, xb_scale=None, xb_shift=None):
+    """the convolution of ``torch.cat((xa, xb), channel)`` read from the two tensors (spcl_conv3x3_forward_cat);
+    ``xb_scale`` / ``xb_shift``: ``xb`` is a raw convolution output, the concatenation holds relu(scale xb + shift)"""
     dev = xa.device
     y = torch.empty(N, H, W, cout_s, dtype=dtype, device=dev)
     stats = None
@@ -705,8 +707,8 @@ def _conv_cat(xa, xb, dt_code, dtype, N, H, W, chalf, cout_s, wp, want_stats):
         nt = _n.call("spcl_conv_stat_rows", dt_code, N, H, W, 2 * chalf, cout_s)
         stats = torch.empty(_n.call("spcl_bn_stats_elems", nt, cout_s), dtype=torch.float32, device=dev)
         stats.ntiles = nt
-    _n.call("spcl_conv3x3_forward_cat", _n.ptr(xa), _n.ptr(xb), dt_code, N, H, W, chalf, cout_s, _n.ptr(wp), _n.ptr(y),
-            _n.ptr(stats), _n.stream())
+    _n.call("spcl_conv3x3_forward_cat", _n.ptr(xa), _n.ptr(xb), dt_code, N, H, W, chalf, cout_s, _n.ptr(wp),
+            _n.ptr(xb_scale), _n.ptr(xb_shift), _n.ptr(y), _n.ptr(stats), _n.stream())
     return y, stats
 
 
@@ -834,12 +836,13 @@ def _wgrad(x_store, dy, dt_code, N, H, W, cin, cin_s, cin_k, cout, cout_s, in_mo
     return dw
 
 
-def _wgrad_cat(xa, xb, dy, dt_code, N, H, W, chalf, cout, cout_s, sink=None):
+def _wgrad_cat(xa, xb, dy, dt_code, N, H, W, chalf, cout, cout_s, sink=None, xb_scale=None, xb_shift=None):
     """weight gradient of the convolution of ``cat((xa, xb), channel)``, the input read from the two tensors
     (spcl_conv3x3_wgrad_cat); the final sum rides in the batched launch when ``sink`` belongs to a bucket, as in ``_wgrad``"""
     dev = dy.device
     queue = sink_queue(sink)
-    if queue is not None and _n.call("spcl_conv_wgrad_batched_supported", dt_code, 2 * chalf, 2 * chalf, cout, cout_s, 0):
+    if (queue is not None and xb_scale is None
+            and _n.call("spcl_conv_wgrad_batched_supported", dt_code, 2 * chalf, 2 * chalf, cout, cout_s, 0)):
         # a wide layer: one item of the batched launch, its 64-channel input blocks read from the tensor that holds them
         queue.add(xa, dy, None, None, sink, N, H, W, 2 * chalf, 2 * chalf, cout, cout_s, 0, x2=xb)
         return None
@@ -849,10 +852,10 @@ def _wgrad_cat(xa, xb, dy, dt_code, N, H, W, chalf, cout, cout_s, sink=None):
 
     def launch():
         _n.call("spcl_conv3x3_wgrad_cat", _n.ptr(xa), _n.ptr(xb), _n.ptr(dy), dt_code, N, H, W, chalf, cout, cout_s,
-                _n.ptr(ws), _n.ptr(dw), _n.stream())
+                _n.ptr(xb_scale), _n.ptr(xb_shift), _n.ptr(ws), _n.ptr(dw), _n.stream())
 
     if queue is not None and _TAILS:
-        if queue.capture_tail(sink, (ws, dy, xa, xb), launch):
+        if queue.capture_tail(sink, (ws, dy, xa, xb, xb_scale, xb_shift), launch):
             return None
         return dw
     launch()
@@ -1096,6 +1099,10 @@ class _ConvBlockFn(torch.autograd.Function):
             chalf, cin = cin, 2 * cin
             cin_s = cin_k = cin
             mode_a = 0
+            xl = getattr(cfg, "x2_link", None)
+            if xl is not None:  # x2 is the up-convolution's raw output: its BatchNorm + ReLU happens in the loaders
+                assert xl.yb.data_ptr() == x2s.data_ptr() and xl.cs == chalf, "x2 is not the linked producer's output"
+            ctx.x2_coef = (xl.stb[2], xl.stb[3]) if xl is not None else (None, None)
         elif cfg.image_input:
             if cin > 16:
                 raise NotImplementedError("image-input block supports input_dim <= 16")
@@ -1121,7 +1128,7 @@ class _ConvBlockFn(torch.autograd.Function):
         else:
             wpa, wpb, wpa_t, wpb_t = _pack(wa, 0, dtc, dtype), _pack(wb, 0, dtc, dtype), None, None
         if x2s is not None:
-            ya, sa = _conv_cat(xs, x2s, dtc, dtype, N, H, W, chalf, cout_s, wpa, cfg.training)
+            ya, sa = _conv_cat(xs, x2s, dtc, dtype, N, H, W, chalf, cout_s, wpa, cfg.training, *ctx.x2_coef)
         else:
             ya, sa = _conv(xs, dtc, dtype, N, H, W, cin_s, cin_k, cout_s, wpa, mode_a, None, None, cfg.training)
         sta = _bn_stats(sa, cfg, cout, cout_s, ga, ba, 0, dev)
@@ -1255,7 +1262,7 @@ class _ConvBlockFn(torch.autograd.Function):
             if not ctx.needs_input_grad[1]:
                 dwa = None
             elif x2s is not None:
-                dwa = _wgrad_cat(xs, x2s, dya, dtc, N, H, W, cin // 2, cout, cout_s, sk[0])
+                dwa = _wgrad_cat(xs, x2s, dya, dtc, N, H, W, cin // 2, cout, cout_s, sk[0], *ctx.x2_coef)
             else:
                 dwa = _wgrad(xs, dya, dtc, N, H, W, cin, cin_s, cin_k, cout, cout_s, mode_a, None, None, sk[0])
         dx = dx2 = None
@@ -1360,8 +1367,13 @@ class _ConvBNReLUFn(torch.autograd.Function):
             wp, wp_t = _pack(w, 0, dtc, dtype), None
         y, s = _conv(xs, dtc, dtype, N, H, W, cin_s, cin_s, cout_s, wp, 0, None, None, cfg.training)
         st = _bn_stats(s, cfg, cout, cout_s, gamma, beta, 0, dev)
-        act = _act_buffer(cfg, N, H, W, cout_s, dtype, dev)
-        _bnrelu_fwd(y, dtc, N, H, W, cout_s, st[2], st[3], act, None)
+        if bool(getattr(cfg, "lazy_act", False)) and getattr(cfg, "act_dst", None) is None and cout == cout_s:
+            # the only consumer (the next block's two-tensor convolution) applies this BatchNorm + ReLU in its loaders
+            act = y
+            cfg.link_act = ActLink(y, st, N, H, W, cout, cout_s)
+        else:
+            act = _act_buffer(cfg, N, H, W, cout_s, dtype, dev)
+            _bnrelu_fwd(y, dtc, N, H, W, cout_s, st[2], st[3], act, None)
         ctx.save_for_backward(xs, y, st, w)
         ctx.params = (w, gamma, beta)
         ctx.packed_t = wp_t

@@ -55,10 +55,10 @@ _SIGNATURES = {
     "spcl_conv_stat_rows": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "spcl_conv_set_gemm": (None, [c_int]),
     "spcl_conv_cat_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
-    "spcl_conv3x3_forward_cat": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "spcl_conv3x3_forward_cat": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "spcl_conv_split_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "spcl_conv3x3_forward_split": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
-    "spcl_conv3x3_wgrad_cat": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "spcl_conv3x3_wgrad_cat": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "spcl_bn_stats_elems": (c_size_t, [c_int, c_int]),
     "spcl_conv3x3_forward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P,
                                      _P]),

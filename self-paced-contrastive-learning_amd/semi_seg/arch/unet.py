@@ -38,6 +38,10 @@ _CAT_PAIR_FIRST = __import__("os").environ.get("SPCL_CAT_PAIR_FIRST", "1") != "0
 # widest level read as two tensors: the 64- and 128-channel levels work too (conv_fast slab by slab, the batched weight-gradient
 # kernel block by block; tested) but measure the same as the halves of one buffer, +1..4 us: they keep the buffer
 _CAT_PAIR_MAXC = int(__import__("os").environ.get("SPCL_CAT_PAIR_MAXC", "32"))
+# the up-convolutions' BatchNorm + ReLU applied by the two-tensor convolution's and its weight gradient's loaders instead of
+# a writer pass: built, bit-identical (tests/test_gpu_decoder.py) and 13 us SLOWER per step (2.336 -> 2.349 ms: the transform in
+# two loaders costs more than the 27 us of writer passes it removes) -- off
+_LAZY_UP = __import__("os").environ.get("SPCL_LAZY_UP", "0") != "0"
 _LAZY_HEAD = __import__("os").environ.get("SPCL_LAZY_HEAD", "1") != "0"  # A/B switch: 0 writes the last activation and reads it back
 _FUSED_UPSAMPLE = __import__("os").environ.get("SPCL_FUSED_UPSAMPLE", "1") != "0"  # A/B switch (BlockCfg.up2)
 _ENCODER = ("Conv1", "Conv2", "Conv3", "Conv4", "Conv5")
@@ -91,6 +95,7 @@ class _ConvBlock(nn.Module):
         self._link_in = self._link_out = None  # functional.PoolLink hand-over between consecutive encoder blocks
         self._act_dst = None        # where UNet.forward wants this call's activation written (half of a concat buffer)
         self._up2 = False           # this call's activation only feeds nn.Upsample(x2): return it upsampled (one launch less)
+        self._x2_link = None        # functional.ActLink of the up-convolution whose RAW output this call's x2 is
         self._lazy = False          # this call's activation only feeds the 1x1 head, which applies BN + ReLU itself
         self._link_act = None       # functional.ActLink of a lazy call (UNet.forward hands it to the head)
 
@@ -121,6 +126,7 @@ class _ConvBlock(nn.Module):
         cfg.act_dst, self._act_dst = self._act_dst, None
         cfg.up2, self._up2 = (self._up2 and len(self._forward_hooks) == 0), False
         cfg.lazy_act, self._lazy = (self._lazy and len(self._forward_hooks) == 0), False
+        cfg.x2_link, self._x2_link = (self._x2_link if x2 is not None else None), None
         act, pooled = F_hip.conv_block(x, c[0].weight, c[1].weight, c[1].bias, c[3].weight, c[4].weight, c[4].bias, cfg, x2)
         self._pooled = pooled
         self._link_out = cfg.link_out  # for the block that consumes the pooled output (UNet.forward hands it over)
@@ -146,9 +152,12 @@ class _UpConv(nn.Module):
 
         self._compute_dtype = None
         self._act_dst = None
+        self._link_act = None
 
-    def forward(self, x, pre_upsampled: bool = False):
-        """``pre_upsampled``: ``x`` already is the x2-upsampled tensor (the producing block wrote it that way, BlockCfg.up2)"""
+    def forward(self, x, pre_upsampled: bool = False, lazy: bool = False):
+        """``pre_upsampled``: ``x`` already is the x2-upsampled tensor (the producing block wrote it that way, BlockCfg.up2);
+        ``lazy``: return the RAW convolution output -- the only consumer applies this BatchNorm + ReLU itself and takes the
+        coefficients from ``self._link_act`` (UNet.forward hands it to the next block: functional.ActLink)"""
         bn = self.up[2]
         dtype = self._compute_dtype or _config.get_compute_dtype()
         training = self.training or not bn.track_running_stats
@@ -156,9 +165,12 @@ class _UpConv(nn.Module):
                              (self.training and bn.track_running_stats,), True, False, False,
                              ((bn.running_mean, bn.running_var, bn.num_batches_tracked),))
         cfg.act_dst, self._act_dst = self._act_dst, None
+        cfg.lazy_act = bool(lazy) and cfg.act_dst is None
         if not pre_upsampled:
             x = F_hip.upsample2x(x, dtype)  # nn.Upsample(scale_factor=2), nearest
-        return F_hip.conv_bn_relu(x, self.up[1].weight, bn.weight, bn.bias, cfg)
+        out = F_hip.conv_bn_relu(x, self.up[1].weight, bn.weight, bn.bias, cfg)
+        self._link_act = cfg.link_act
+        return out
 
 
 class _Conv1x1(nn.Conv2d):
@@ -229,19 +241,21 @@ class UNet(nn.Module):
         # view of it and its gradient is read back half by half in place (functional.virtual_cat; SPCL_VIRTUAL_CAT=0: the
         # copying kernels).  Not for a block with a forward hook (a feature tap wants a dense tensor of its own).
         cats = {}
-        if not encoder_only and x.is_cuda and _VIRTUAL_CAT and x.dim() == 4:
+        pairs = set()  # skips whose level reads the two tensors side by side (decided here: the up-convolution may then be lazy)
+        if not encoder_only and x.is_cuda and x.dim() == 4:
             H0, W0 = int(x.shape[2]), int(x.shape[3])
             for k, name in enumerate(_ENCODER[:-1]):
                 blk = getattr(self, "_" + name)
                 c = self.get_channel_dim(name)
                 h, w = H0 >> k, W0 >> k
-                if (c % 16 == 0 and c >= _VIRTUAL_CAT_MINC and len(blk._forward_hooks) == 0 and h >= 2 and w >= 2
-                        and h % 2 == 0 and w % 2 == 0):
-                    dt = blk._compute_dtype or _config.get_compute_dtype()
-                    ub = getattr(self, f"_Up_conv{k + 2}")
-                    if (_CAT_PAIR_FIRST and c <= _CAT_PAIR_MAXC and len(ub._forward_pre_hooks) == 0
-                            and F_hip.cat_pair_shape_ok(int(x.shape[0]), c, h, w, c, ub._compute_dtype or dt)):
-                        continue  # this level's block reads the two tensors side by side (below): no buffer
+                if not (c % 16 == 0 and len(blk._forward_hooks) == 0 and h >= 2 and w >= 2 and h % 2 == 0 and w % 2 == 0):
+                    continue
+                dt = blk._compute_dtype or _config.get_compute_dtype()
+                ub = getattr(self, f"_Up_conv{k + 2}")
+                if (_CAT_PAIR_FIRST and c <= _CAT_PAIR_MAXC and len(ub._forward_pre_hooks) == 0
+                        and F_hip.cat_pair_shape_ok(int(x.shape[0]), c, h, w, c, ub._compute_dtype or dt)):
+                    pairs.add(name)  # this level's block reads the two tensors side by side (below): no buffer
+                elif _VIRTUAL_CAT and c >= _VIRTUAL_CAT_MINC:
                     cats[name] = F_hip.cat_buffer(int(x.shape[0]), h, w, c, c, dt, x.device)
         for k, name in enumerate(_ENCODER):
             blk = getattr(self, "_" + name)
@@ -273,8 +287,16 @@ class UNet(nn.Module):
             up = getattr(self, f"_Up{lvl}")
             if skip in cats:
                 up._act_dst = cats[skip][2]
-            d = up(d, pre_upsampled=pre_up)
             blk = getattr(self, f"_Up_conv{lvl}")
+            # the up-convolution's activation goes nowhere but into this level's two-tensor convolution: never written, its
+            # BatchNorm + ReLU applied by that convolution's (and its weight gradient's) loader
+            lazy_up = (_LAZY_UP and skip in pairs and until != f"Up{lvl}" and len(up._forward_hooks) == 0
+                       and all(len(m._forward_hooks) == 0 for m in up.up) and len(blk._forward_pre_hooks) == 0
+                       and self.get_channel_dim(skip) <= 32
+                       and (up._compute_dtype or _config.get_compute_dtype()) ==
+                           (blk._compute_dtype or _config.get_compute_dtype()))
+            d = up(d, pre_upsampled=pre_up, lazy=lazy_up)
+            lazy_up = lazy_up and up._link_act is not None
             # this decoder block's activation feeds the next level's nn.Upsample only (not the last block, not the `until` one)
             nxt = getattr(self, f"_Up{lvl - 1}", None) if lvl > 2 else None
             pre_up = (nxt is not None and until != f"Up_conv{lvl}" and _FUSED_UPSAMPLE and d.is_cuda
@@ -291,6 +313,10 @@ class UNet(nn.Module):
             bdt = blk._compute_dtype or _config.get_compute_dtype()
             if skip in cats:
                 d = blk(F_hip.virtual_cat(skips[skip], d, cats[skip][0]))
+            elif lazy_up:
+                assert F_hip.cat_pair_supported(skips[skip], d, blk.conv[0].weight.shape[0], bdt), "planned two-tensor level"
+                blk._x2_link, up._link_act = up._link_act, None
+                d = blk(skips[skip], x2=d)
             elif (len(blk._forward_pre_hooks) == 0 and torch.is_tensor(skips[skip])
                   and F_hip.cat_pair_supported(skips[skip], d, blk.conv[0].weight.shape[0], bdt)):
                 # the narrow level (16 + 16 channels: too narrow for the producers to write halves of one buffer -- half a

@@ -301,6 +301,7 @@ def test_in_place_decoder_data_movement_is_the_copying_path_bit_for_bit(N, S, mo
         monkeypatch.setattr(unet_mod, "_CAT_PAIR_FIRST", pair_first)
         monkeypatch.setattr(unet_mod, "_CAT_PAIR_MAXC", 1024)  # (the wide levels too: slab-wise / block-wise two-tensor reads)
         monkeypatch.setattr(unet_mod, "_LAZY_HEAD", False)  # (its BatchNorm-backward sums have their own order: next test)
+        monkeypatch.setattr(unet_mod, "_LAZY_UP", in_place and pair_first)  # (the up-convolutions' BN + ReLU in the consumers' loaders)
         m = UNet(input_dim=1, num_classes=4, max_channel=256)
         m.load_state_dict(sd, strict=True)
         m.cuda().train()
