@@ -408,6 +408,17 @@ static TileCfg pick_tile(int H, int W) {
   return {16, 16};
 }
 
+// ... per layer: a bf16 layer with 32 input channels above 112^2 (the decoder's 224^2 level: cat(16, 16) -> 16 and the
+// up-convolution 32 -> 16) takes the half-height tile too: its 14-row halo image is 24.5 KB -- six one-wave workgroups per
+// CU -- and those launches are latency chains (fine-tune step 2.357 -> 2.338 ms, same box, four rounds;
+// SPCL_CONV_TH7_KC32=0 switches back).  The 16-channel layers' image is 8 KB: they keep the 14 x 14 tile.
+static TileCfg pick_tile_k(int H, int W, int CinK) {
+  TileCfg t = pick_tile(H, W);
+  static const int kc32 = getenv("SPCL_CONV_TH7_KC32") ? atoi(getenv("SPCL_CONV_TH7_KC32")) : 1;
+  if (kc32 && CinK == 32 && t.th == 14 && t.tw == 14 && H % 7 == 0) t.th = 7;
+  return t;
+}
+
 // Which kernel takes a bf16 layer with GEMM-eligible channels: the workgroup-level GEMM kernel where the per-wave
 // kernels have no specialisation for the image size (widths that are not 14-column tileable: 32^2, 16^2 of the 256^2
 // family, where the generic kernel is 2-3x slower), or everywhere when forced (spcl_conv_set_gemm(1) / SPCL_CONV_GEMM=1:
@@ -456,7 +467,7 @@ static int launch_conv(const ConvArgs& a0, hipStream_t st) {
 template <typename T>
 static int launch_conv_t(const ConvArgs& a, hipStream_t st) {
   if (sizeof(T) == 2 && conv_use_gemm(a.CinK, a.CoutS, a.H, a.W)) return launch_conv_gemm(a, st) ? 0 : 1;
-  TileCfg t = pick_tile(a.H, a.W);
+  TileCfg t = sizeof(T) == 2 ? pick_tile_k(a.H, a.W, a.CinK) : pick_tile(a.H, a.W);
   static const int no_fast = getenv("SPCL_CONV_NO_FAST") ? atoi(getenv("SPCL_CONV_NO_FAST")) : 0;
   if (sizeof(T) == 2 && t.tw == 14 && !no_fast && launch_conv_fast(a, t.th, st)) return 0;
   if (t.th == 7 && t.tw == 7) return launch_conv<T, 7, 7>(a, st);
@@ -478,6 +489,10 @@ extern "C" void spcl_conv_set_gemm(int on) { conv_set_gemm(on); }
 
 extern "C" int spcl_conv_stat_rows(int dtype, int N, int H, int W, int CinK, int CoutS) {
   if (dtype == SPCL_BF16 && conv_use_gemm(CinK, CoutS, H, W)) return conv_gemm_stat_rows(N, H, W, CinK, CoutS);
+  if (dtype == SPCL_BF16) {
+    const TileCfg t = pick_tile_k(H, W, CinK);
+    return N * cdiv(H, t.th) * cdiv(W, t.tw);
+  }
   return spcl_conv_num_tiles(N, H, W);
 }
 
@@ -700,7 +715,7 @@ extern "C" int spcl_conv_cat_supported(int dtype, int N, int H, int W, int Chalf
   if (!conv_cat_args(a, dtype, N, H, W, Chalf, CoutS)) return 0;
   static const char dummy[16] = {0};
   a.x = dummy; a.x2 = dummy; a.y = nullptr; a.wp = nullptr;
-  return launch_conv_fast(a, pick_tile(H, W).th, nullptr, true) ? 1 : 0;
+  return launch_conv_fast(a, pick_tile_k(H, W, a.CinK).th, nullptr, true) ? 1 : 0;
 }
 
 extern "C" int spcl_conv3x3_forward_cat(const void* xa, const void* xb, int dtype, int N, int H, int W, int Chalf, int CoutS,
@@ -720,7 +735,7 @@ extern "C" int spcl_conv3x3_forward_cat(const void* xa, const void* xb, int dtyp
   hipStream_t st = (hipStream_t)stream;
   const double px = (double)N * H * W;
   prof_cost(px * (2.0 * Chalf + CoutS) * 2.0 + 9.0 * 2.0 * Chalf * CoutS * 2.0, 2.0 * px * 9.0 * 2.0 * Chalf * CoutS);
-  if (!launch_conv_fast(a, pick_tile(H, W).th, st)) {
+  if (!launch_conv_fast(a, pick_tile_k(H, W, a.CinK).th, st)) {
     set_error("conv3x3_forward_cat: no specialised kernel for H=%d W=%d Chalf=%d CoutS=%d", H, W, Chalf, CoutS);
     return SPCL_EUNSUPPORTED;
   }
