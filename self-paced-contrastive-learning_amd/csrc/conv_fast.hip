@@ -813,6 +813,10 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
   // each with half of the epilogue's scattered loads -- 29 us against 23 + 15 for the plain one-wave kernel and the
   // separate reduction pass (whole step 1.134 -> 1.126 ms, same box; SPCL_CONV_FAST_NT1=2 switches it off)
   if (env_nt1 != 2 && KC == 64 && ntn == 2 && c.rows2 != nullptr && c.H2 > 0) NT = 1;
+  // ... and every other 64 -> 32 layer too (the decoder's 112^2 level: up-convolution and cat(32, 32) -> 32): the one-wave
+  // workgroup's halo image is 23 KB, six WAVES per CU; two waves per image double that (fine-tune step 2.337 -> 2.305 ms,
+  // same box, three rounds)
+  if (env_nt1 != 2 && KC == 64 && ntn == 2) NT = 1;
   // 64 -> 64 channels: four one-n-tile waves when the loader also applies BN+ReLU (more lanes for the transform:
   // Conv3.b forward 38 -> 30 us) and on the small images; two two-n-tile waves for the plain 56^2 dgrad
   if (KC == 64 && ntn == 4 && env_nt1 != 3 && (c.in_mode == 1 || c.H <= 28)) NT = 1;
