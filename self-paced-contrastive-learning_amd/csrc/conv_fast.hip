@@ -820,6 +820,14 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
   // 64 -> 64 channels: four one-n-tile waves when the loader also applies BN+ReLU (more lanes for the transform:
   // Conv3.b forward 38 -> 30 us) and on the small images; two two-n-tile waves for the plain 56^2 dgrad
   if (KC == 64 && ntn == 4 && env_nt1 != 3 && (c.in_mode == 1 || c.H <= 28)) NT = 1;
+  // ... and with more than one slab of input channels (128 -> 64: the decoder's 56^2 level), where the cross-slab pipeline
+  // keeps TWO halo images (46 KB): three two-wave workgroups per CU otherwise
+  static const int env_wide = getenv("SPCL_CONV_FAST_NT1_WIDE") ? atoi(getenv("SPCL_CONV_FAST_NT1_WIDE")) : 1;
+  if (env_wide && KC == 64 && ntn == 4 && c.CinK > 64) NT = 1;
+  // ... and, re-measured in round 4, the 56^2 dgrad as well (Conv3.b's, with the BatchNorm-backward sums in its epilogue:
+  // pre-train step 1.160 -> 1.155 ms, same box, three rounds; fine-tune unchanged): four one-n-tile waves for every 64 -> 64
+  static const int env_all4 = getenv("SPCL_CONV_FAST_NT1_64") ? atoi(getenv("SPCL_CONV_FAST_NT1_64")) : 1;
+  if (env_all4 && KC == 64 && ntn == 4) NT = 1;
   // few tiles (14^2 images): with two n-tiles per wave a 128-channel output is ONE workgroup per tile -- 128 workgroups for
   // Conv5.a's dgrad at N = 64, half the CUs idle; one n-tile per wave doubles the workgroups
   static const int env_fill = getenv("SPCL_CONV_FAST_FILL") ? atoi(getenv("SPCL_CONV_FAST_FILL")) : 1;
