@@ -412,10 +412,12 @@ static TileCfg pick_tile(int H, int W) {
 // up-convolution 32 -> 16) takes the half-height tile too: its 14-row halo image is 24.5 KB -- six one-wave workgroups per
 // CU -- and those launches are latency chains (fine-tune step 2.357 -> 2.338 ms, same box, four rounds;
 // SPCL_CONV_TH7_KC32=0 switches back).  The 16-channel layers' image is 8 KB: they keep the 14 x 14 tile.
-static TileCfg pick_tile_k(int H, int W, int CinK) {
+static TileCfg pick_tile_k(int H, int W, int CinK, int CoutS = 0) {
   TileCfg t = pick_tile(H, W);
   static const int kc32 = getenv("SPCL_CONV_TH7_KC32") ? atoi(getenv("SPCL_CONV_TH7_KC32")) : 1;
   if (kc32 && CinK == 32 && t.th == 14 && t.tw == 14 && H % 7 == 0) t.th = 7;
+  // (16 -> 32 at 224^2 -- 104 accumulator registers on the 14-row tile -- measured on 7-row tiles too: no difference)
+  (void)CoutS;
   return t;
 }
 
@@ -467,7 +469,7 @@ static int launch_conv(const ConvArgs& a0, hipStream_t st) {
 template <typename T>
 static int launch_conv_t(const ConvArgs& a, hipStream_t st) {
   if (sizeof(T) == 2 && conv_use_gemm(a.CinK, a.CoutS, a.H, a.W)) return launch_conv_gemm(a, st) ? 0 : 1;
-  TileCfg t = sizeof(T) == 2 ? pick_tile_k(a.H, a.W, a.CinK) : pick_tile(a.H, a.W);
+  TileCfg t = sizeof(T) == 2 ? pick_tile_k(a.H, a.W, a.CinK, a.CoutS) : pick_tile(a.H, a.W);
   static const int no_fast = getenv("SPCL_CONV_NO_FAST") ? atoi(getenv("SPCL_CONV_NO_FAST")) : 0;
   if (sizeof(T) == 2 && t.tw == 14 && !no_fast && launch_conv_fast(a, t.th, st)) return 0;
   if (t.th == 7 && t.tw == 7) return launch_conv<T, 7, 7>(a, st);
@@ -490,7 +492,7 @@ extern "C" void spcl_conv_set_gemm(int on) { conv_set_gemm(on); }
 extern "C" int spcl_conv_stat_rows(int dtype, int N, int H, int W, int CinK, int CoutS) {
   if (dtype == SPCL_BF16 && conv_use_gemm(CinK, CoutS, H, W)) return conv_gemm_stat_rows(N, H, W, CinK, CoutS);
   if (dtype == SPCL_BF16) {
-    const TileCfg t = pick_tile_k(H, W, CinK);
+    const TileCfg t = pick_tile_k(H, W, CinK, CoutS);
     return N * cdiv(H, t.th) * cdiv(W, t.tw);
   }
   return spcl_conv_num_tiles(N, H, W);
@@ -765,7 +767,7 @@ extern "C" int spcl_conv_split_supported(int dtype, int N, int H, int W, int Cin
   if (!conv_split_args(a, dtype, N, H, W, CinK, CoutS)) return 0;
   static char dummy[16] = {0};
   a.x = dummy; a.y = dummy; a.y_hi = dummy; a.wp = nullptr;
-  return launch_conv_fast(a, pick_tile(H, W).th, nullptr, true) ? 1 : 0;
+  return launch_conv_fast(a, pick_tile_k(H, W, CinK, CoutS).th, nullptr, true) ? 1 : 0;
 }
 
 extern "C" int spcl_conv3x3_forward_split(const void* x, int dtype, int N, int H, int W, int CinK, int CoutS,
@@ -781,7 +783,7 @@ extern "C" int spcl_conv3x3_forward_split(const void* x, int dtype, int N, int H
   hipStream_t st = (hipStream_t)stream;
   const double px = (double)N * H * W;
   prof_cost(px * (CinK + CoutS) * 2.0 + 9.0 * CinK * CoutS * 2.0, 2.0 * px * 9.0 * CinK * CoutS);
-  if (!launch_conv_fast(a, pick_tile(H, W).th, st)) {
+  if (!launch_conv_fast(a, pick_tile_k(H, W, CinK, CoutS).th, st)) {
     set_error("conv3x3_forward_split: no specialised kernel for H=%d W=%d CinK=%d CoutS=%d", H, W, CinK, CoutS);
     return SPCL_EUNSUPPORTED;
   }
