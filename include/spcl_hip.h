@@ -334,6 +334,14 @@ int spcl_bnrelu_pool_backward_strided(const void* y, const void* dact, int dact_
                                       int H, int W, int C, int CS, const float* mean, const float* invstd,
                                       const float* scale, const float* shift, int training, float* ws, float* dgamma,
                                       float* dbeta, void* dy, void* stream);
+/* BN + ReLU backward of a block whose activation went through nn.Upsample(scale_factor=2) (unet.py:89) before its consumer:
+ * d_up = the gradient w.r.t. the UPSAMPLED activation [N][2H][2W][CS]; the 2 x 2 sums (spcl_upsample2x_backward) are formed
+ * inside the BatchNorm-backward reduction pass and left in dact [N][H][W][CS] (scratch, written) for the apply pass.  Results as
+ * spcl_upsample2x_backward followed by spcl_bnrelu_pool_backward(y, dact, NULL, ...), bit for bit; one pass over the fine
+ * gradient and one launch less. */
+int spcl_bnrelu_backward_up2(const void* y, const void* d_up, void* dact, int dtype, int N, int H, int W, int C, int CS,
+                             const float* mean, const float* invstd, const float* scale, const float* shift, int training,
+                             float* ws, float* dgamma, float* dbeta, void* dy, void* stream);
 /* BN + ReLU backward (no pooling) for a gradient that is the same for every pixel of an image: dact_nc [N][CS] of dtype.
  * Same arithmetic as spcl_bnrelu_pool_backward(dact = the expanded tensor, dpool = NULL). */
 int spcl_bnrelu_backward_bcast(const void* y, const void* dact_nc, int dtype, int N, int H, int W, int C, int CS,

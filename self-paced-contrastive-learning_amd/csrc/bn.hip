@@ -458,6 +458,83 @@ __global__ __launch_bounds__(256, 5) void bnrelu_bwd_reduce_lin_kernel(const T* 
   wg_reduce_partials<T, EPC>(s1, s2, CS, CPC, PL, partial, red);
 }
 
+// ---- pass 1 when the gradient arrives at TWICE the resolution (the activation went through nn.Upsample(scale_factor=2),
+// unet.py:89): g[p] = the sum of the 2 x 2 gradients (spcl_upsample2x_backward's arithmetic: (a + b) + (c + d) in f32, rounded
+// to T) is formed here, written for the apply pass, and folded into the BatchNorm sums in the same sweep -- the separate
+// upsample2x_bwd pass and one read of its output disappear.  Thread geometry and summation order of
+// bnrelu_bwd_reduce_lin_kernel (bit-identical sums).
+template <typename T>
+__global__ __launch_bounds__(256, 3) void bnrelu_bwd_reduce_up2_kernel(const T* __restrict__ y, const T* __restrict__ du,
+                                                                    T* __restrict__ g, size_t npix, int W, int CS,
+                                                                    const float* __restrict__ mean,
+                                                                    const float* __restrict__ invstd,
+                                                                    const float* __restrict__ scale,
+                                                                    const float* __restrict__ shift,
+                                                                    float* __restrict__ partial /* [grid][2][CS] */) {
+  constexpr int EPC = Chunk<T>::EPC, EPW = Word<T>::EPW, U = 2;  // (five 16-byte loads per position in flight: 2 x 5 of them)
+  __shared__ float red[256][2 * EPC + 1];
+  const int CPC = CS / EPC, PL = 256 / CPC;
+  const int cc = threadIdx.x % CPC, pl = threadIdx.x / CPC;
+  float s1[EPC], s2[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = 0.f;
+  if (pl < PL) {
+    float sc[EPC], sh[EPC], mu[EPC], is[EPC];
+    load_coef<EPC>(sc, scale, cc);
+    load_coef<EPC>(sh, shift, cc);
+    load_coef<EPC>(mu, mean, cc);
+    load_coef<EPC>(is, invstd, cc);
+    const size_t stride = (size_t)gridDim.x * PL;
+    const size_t rowstep = (size_t)2 * W * CS;  // elements between two rows of the fine gradient
+    for (size_t p = (size_t)blockIdx.x * PL + pl; p < npix; p += U * stride) {
+      u32x4 ry[U], ra[U][4];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const size_t q = p + u * stride;
+        ry[u] = (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ra[u][k] = (u32x4){0u, 0u, 0u, 0u};
+        if (q < npix) {
+          const unsigned r = (unsigned)q / (unsigned)W, w = (unsigned)q - r * (unsigned)W;  // r = n H + h: fine rows 2 r, 2 r + 1 (32-bit: the host checks)
+          const T* s = du + ((size_t)(2 * r) * (size_t)(2 * W) + 2 * w) * CS + cc * EPC;
+          ry[u] = *(const u32x4*)(y + q * CS + cc * EPC);
+          ra[u][0] = *(const u32x4*)s;
+          ra[u][1] = *(const u32x4*)(s + CS);
+          ra[u][2] = *(const u32x4*)(s + rowstep);
+          ra[u][3] = *(const u32x4*)(s + rowstep + CS);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        u32x4 go;
+#pragma unroll
+        for (int wi = 0; wi < 4; ++wi) {
+          float gv[EPW];
+#pragma unroll
+          for (int h = 0; h < EPW; ++h) {
+            const float acc = (Word<T>::get(ra[u][0][wi], h) + Word<T>::get(ra[u][1][wi], h)) +
+                              (Word<T>::get(ra[u][2][wi], h) + Word<T>::get(ra[u][3][wi], h));
+            gv[h] = acc;
+          }
+          go[wi] = Word<T>::make(gv);
+#pragma unroll
+          for (int h = 0; h < EPW; ++h) {
+            const int e = wi * EPW + h;
+            const float yv = Word<T>::get(ry[u][wi], h);
+            const float dz = fmaf(sc[e], yv, sh[e]) > 0.f ? Word<T>::get(go[wi], h) : 0.f;  // g as STORED
+            s1[e] += dz;
+            s2[e] = fmaf(dz, yv - mu[e], s2[e]);
+          }
+        }
+        if (p + u * stride < npix) *(u32x4*)(g + (p + u * stride) * CS + cc * EPC) = go;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) s2[e] *= is[e];
+  }
+  wg_reduce_partials<T, EPC>(s1, s2, CS, CPC, PL, partial, red);
+}
+
 // ---- the same two passes for a BROADCAST gradient: g[n][p][c] = gb[n][c] for every pixel p of image n -- the gradient of a
 // global average pool (projectors/heads.py:9-18: AdaptiveAvgPool2d((1, 1))), which the projector's backward then hands
 // over as [N][CS] values instead of writing N x HW x CS of them.  Workgroup = (image, pixel split): the thread's gradient
@@ -1015,6 +1092,7 @@ static int stream_grid(size_t positions, int PL, int unroll, int cap) {
 // Pixel strides (in elements) of the activation written by the forward / of the activation gradient read by the backward when
 // they are channel slices of a wider tensor (the `_strided` entry points set them around their call; 0 = dense, CS).
 static thread_local int tl_act_stride = 0, tl_dact_stride = 0;
+static thread_local const void* tl_up2_src = nullptr;  // spcl_bnrelu_backward_up2: the fine gradient; `dact` is then WRITTEN
 
 template <typename T>
 static int bnrelu_fwd_launch(const void* y, int N, int H, int W, int CS, const float* scale, const float* shift,
@@ -1096,6 +1174,11 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
     prof_cost(tb, 0.0);
     SPCL_LAUNCH((bnrelu_bwd_reduce_bcast_kernel<T>), dim3(nwg), dim3(256), 0, st, (const T*)y, (const T*)dact, H * W, CS,
                 bsplit, mean, invstd, scale, shift, partial);
+  } else if (tl_up2_src != nullptr) {
+    nwg = stream_grid(npix, PL, STREAM_UNROLL, BWD_MAX_WG);
+    prof_cost(tb * 6.0, 0.0);
+    SPCL_LAUNCH((bnrelu_bwd_reduce_up2_kernel<T>), dim3(nwg), dim3(256), 0, st, (const T*)y, (const T*)tl_up2_src, (T*)dact,
+                npix, W, CS, mean, invstd, scale, shift, partial);
   } else {
     nwg = stream_grid(npix, PL, STREAM_UNROLL, BWD_MAX_WG);
     SPCL_LAUNCH((bnrelu_bwd_reduce_lin_kernel<T>), dim3(nwg), dim3(256), 0, st, (const T*)y, (const T*)dact, npix,
@@ -1319,6 +1402,22 @@ extern "C" int spcl_bnrelu_pool_backward_strided(const void* y, const void* dact
   const int rc = spcl_bnrelu_pool_backward(y, dact, dpool, dtype, N, H, W, C, CS, mean, invstd, scale, shift, training, ws,
                                            dgamma, dbeta, dy, stream);
   tl_dact_stride = 0;
+  return rc;
+}
+
+// BN + ReLU backward of a block whose activation went through nn.Upsample(scale_factor=2) (unet.py:89): d_up is the gradient
+// w.r.t. the UPSAMPLED activation, [N][2H][2W][CS]; dact [N][H][W][CS] is scratch the call fills with the 2 x 2 sums
+// (= spcl_upsample2x_backward's output) on its way to the BatchNorm sums.  Results as spcl_bnrelu_pool_backward(y, dact, NULL).
+extern "C" int spcl_bnrelu_backward_up2(const void* y, const void* d_up, void* dact, int dtype, int N, int H, int W, int C,
+                                        int CS, const float* mean, const float* invstd, const float* scale,
+                                        const float* shift, int training, float* ws, float* dgamma, float* dbeta, void* dy,
+                                        void* stream) {
+  SPCL_CHECK_ARG(d_up && dact, "bnrelu_backward_up2: null pointer");
+  SPCL_CHECK_ARG((size_t)N * H * W * 4 < 0xffffffffull, "bnrelu_backward_up2: too many pixels");
+  tl_up2_src = d_up;
+  const int rc = spcl_bnrelu_pool_backward(y, dact, nullptr, dtype, N, H, W, C, CS, mean, invstd, scale, shift, training, ws,
+                                           dgamma, dbeta, dy, stream);
+  tl_up2_src = nullptr;
   return rc;
 }
 

@@ -784,6 +784,7 @@ class DeferredWgrads:
 # the whole UNet's eleven wide layers and ten narrow ones then leave in ONE batched launch at the gather)
 _QUEUE_MAX = (min(_n.WGRAD_BATCH_MAX, int(os.environ.get("SPCL_WGRAD_QUEUE_MAX", _n.WGRAD_BATCH_MAX))),
               min(_n.WGRAD_TAILS_MAX, int(os.environ.get("SPCL_WGRAD_QUEUE_MAX", _n.WGRAD_TAILS_MAX))))
+_UP2_BWD_FUSED = os.environ.get("SPCL_UP2_BWD_FUSED", "1") != "0"  # A/B switch: 0 sums the 2x2 gradients in a launch of its own
 _CONV_SPLIT = os.environ.get("SPCL_CONV_SPLIT", "1") != "0"  # A/B switch: 0 leaves that level's gradient as one interleaved tensor
 _CONV_CAT = os.environ.get("SPCL_CONV_CAT", "1") != "0"  # A/B switch: 0 materialises the 16-channel decoder concatenation
 _PACK_AT = os.environ.get("SPCL_PACK_AT", "1") != "0"  # A/B switch: 0 packs the band-GEMM layout whether or not it is used
@@ -887,14 +888,22 @@ def _bnrelu_bwd_bcast(y, g_nc, dt_code, dtype, N, H, W, C, cs, st, training, sin
     return dy, dgamma, dbeta
 
 
-def _bnrelu_bwd(y, dact, dpool, dt_code, dtype, N, H, W, C, cs, st, training, sinks=(None, None), dact_stride=0):
-    """``dact_stride`` > 0: ``dact`` is a channel slice of a wider NHWC tensor with that many elements per pixel"""
+def _bnrelu_bwd(y, dact, dpool, dt_code, dtype, N, H, W, C, cs, st, training, sinks=(None, None), dact_stride=0, d_up=None):
+    """``dact_stride`` > 0: ``dact`` is a channel slice of a wider NHWC tensor with that many elements per pixel.
+    ``d_up``: the gradient arrives at twice the resolution ([N, 2H, 2W, cs]: the activation went through nn.Upsample(x2));
+    its 2 x 2 sums are formed inside the reduction pass (spcl_bnrelu_backward_up2), ``dact`` is not given"""
     dev = y.device
     ws = torch.empty(_n.call("spcl_bnrelu_bwd_workspace_bytes", N, H, W, cs) // 4, dtype=torch.float32, device=dev)
     dgamma = _grad_buffer(sinks[0], (C,), dev)
     dbeta = _grad_buffer(sinks[1], (C,), dev)
     dy = torch.empty(N, H, W, cs, dtype=dtype, device=dev)
-    if dact_stride and dact is not None:
+    if d_up is not None:
+        assert dact is None and dpool is None
+        gsum = torch.empty(N, H, W, cs, dtype=dtype, device=dev)  # (the summed gradient, for the apply pass)
+        _n.call("spcl_bnrelu_backward_up2", _n.ptr(y), _n.ptr(d_up), _n.ptr(gsum), dt_code, N, H, W, C, cs, _n.ptr(st[0]),
+                _n.ptr(st[1]), _n.ptr(st[2]), _n.ptr(st[3]), int(training), _n.ptr(ws), _n.ptr(dgamma), _n.ptr(dbeta),
+                _n.ptr(dy), _n.stream())
+    elif dact_stride and dact is not None:
         _n.call("spcl_bnrelu_pool_backward_strided", _n.ptr(y), _n.ptr(dact), int(dact_stride), _n.ptr(dpool), dt_code, N, H,
                 W, C, cs, _n.ptr(st[0]), _n.ptr(st[1]), _n.ptr(st[2]), _n.ptr(st[3]), int(training), _n.ptr(ws),
                 _n.ptr(dgamma), _n.ptr(dbeta), _n.ptr(dy), _n.stream())
@@ -1172,12 +1181,17 @@ class _ConvBlockFn(torch.autograd.Function):
         dtc = _n.dtype_code(dtype)
         g_nc = broadcast_rows(d_act, dtype) if (_BCAST and d_pool is None and d_act is not None and not ctx.up2
                                                   and d_act.shape[1] == cout_s) else None
+        d_up = None
         if ctx.up2 and d_act is not None:
-            # the forward returned the x2-upsampled activation: its gradient is summed over the 2x2 replicas first
+            # the forward returned the x2-upsampled activation: its gradient is summed over the 2x2 replicas first -- inside
+            # the BatchNorm-backward reduction pass (spcl_bnrelu_backward_up2), or by its own launch
             du = to_nhwc_padded(d_act, dtype)
-            dsum = torch.empty(N, H, W, cout_s, dtype=dtype, device=du.device)
-            _n.call("spcl_upsample2x_backward", _n.ptr(du), _n.ptr(dsum), dtc, N, H, W, cout_s, _n.stream())
-            d_act = nhwc_to_logical(dsum, cout)
+            if _UP2_BWD_FUSED and d_pool is None:
+                d_up, d_act = du, None
+            else:
+                dsum = torch.empty(N, H, W, cout_s, dtype=dtype, device=du.device)
+                _n.call("spcl_upsample2x_backward", _n.ptr(du), _n.ptr(dsum), dtc, N, H, W, cout_s, _n.stream())
+                d_act = nhwc_to_logical(dsum, cout)
         da_stride = 0
         da_sl = nhwc_channel_slice(d_act, dtype) if (d_act is not None and g_nc is None) else None
         if da_sl is not None:  # the skip half of a concatenation's gradient, read in place (spcl_bnrelu_pool_backward_strided)
@@ -1185,7 +1199,7 @@ class _ConvBlockFn(torch.autograd.Function):
         else:
             da_s = to_nhwc_padded(d_act, dtype) if (d_act is not None and g_nc is None) else None
         dp_s = to_nhwc_padded(d_pool, dtype) if d_pool is not None else None
-        if da_s is None and dp_s is None and g_nc is None:
+        if da_s is None and dp_s is None and g_nc is None and d_up is None:
             return (None,) * 9
         x2s = ctx.x2s
         # ---- second conv
@@ -1208,7 +1222,7 @@ class _ConvBlockFn(torch.autograd.Function):
                                                   sk[4:6])
         else:
             dyb, dgb, dbb = _bnrelu_bwd(yb, da_s, dp_s, dtc, dtype, N, H, W, cout, cout_s, stb, cfg.training, sk[4:6],
-                                        dact_stride=da_stride)
+                                        dact_stride=da_stride, d_up=d_up)
         if lk is not None:
             lk.rows, lk.dx_ptr = None, 0
         if la is not None:

@@ -84,6 +84,8 @@ _SIGNATURES = {
     "spcl_bnrelu_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "spcl_bnrelu_pool_backward": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P,
                                           c_int, _P, _P, _P, _P, _P]),
+    "spcl_bnrelu_backward_up2": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P,
+                                         _P]),
     "spcl_bnrelu_backward_bcast": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_int, _P, _P,
                                            _P, _P, _P]),
     "spcl_bnrelu_image_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
