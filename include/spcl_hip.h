@@ -225,6 +225,14 @@ int spcl_conv3x3_wgrad_cat(const void* xa, const void* xb, const void* dy, int d
 int spcl_conv_split_supported(int dtype, int N, int H, int W, int CinK, int CoutS);
 int spcl_conv3x3_forward_split(const void* x, int dtype, int N, int H, int W, int CinK, int CoutS, const void* w_packed,
                                void* y_lo, void* y_hi, void* stream);
+/* ... the same with the BatchNorm-backward partial sums of the layer behind the UPPER half -- the up-convolution (unet.py:90-92):
+ * y2_hi [N][H][W][CoutS / 2] its raw output, scale2 / shift2 / mean2 [CoutS / 2] its coefficients; rows2
+ * [spcl_conv_stat_rows(dtype, N, H, W, CinK, CoutS)][2][CoutS / 2] (sum dz, sum dz (y2 - mean)) as spcl_conv3x3_dgrad_bnstats
+ * leaves them, for spcl_bnrelu_backward_rows: that layer's reduction pass over (y2, g_hi) disappears. */
+int spcl_conv_split_bnstats_supported(int dtype, int N, int H, int W, int CinK, int CoutS);
+int spcl_conv3x3_dgrad_split_bnstats(const void* dy, int dtype, int N, int H, int W, int CinK, int CoutS,
+                                     const void* w_packed, void* g_lo, void* g_hi, const void* y2_hi, const float* scale2,
+                                     const float* shift2, const float* mean2, float* rows2, void* stream);
 
 /* dW[co][ci][ky][kx] (OIHW f32, overwritten) = sum_pixels act(x)[p+tap][ci] * dy[p][co]   (weight gradient of
  * unet.py:72,75).  x / in_mode / CinK as in forward; Cin, Cout = real channel counts of dW.

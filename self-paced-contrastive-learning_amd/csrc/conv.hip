@@ -791,6 +791,45 @@ extern "C" int spcl_conv3x3_forward_split(const void* x, int dtype, int N, int H
   return SPCL_OK;
 }
 
+// ... and with the BatchNorm-backward partial sums of the layer behind the UPPER half (the up-convolution, unet.py:90-92: y2_hi
+// [N][H][W][CoutS / 2] its raw output, scale2 / shift2 / mean2 its coefficients): rows2 [spcl_conv_stat_rows(...)][2][CoutS / 2]
+// as spcl_conv3x3_dgrad_bnstats leaves them -- that layer's reduction pass over (y2, g_hi) disappears.
+extern "C" int spcl_conv_split_bnstats_supported(int dtype, int N, int H, int W, int CinK, int CoutS) {
+  static const bool off = getenv("SPCL_CONV_SPLIT_BNSTATS") && atoi(getenv("SPCL_CONV_SPLIT_BNSTATS")) == 0;  // A/B switch
+  ConvArgs a;
+  if (off || !conv_split_args(a, dtype, N, H, W, CinK, CoutS)) return 0;
+  static char dummy[16] = {0};
+  static float fdummy;
+  a.x = dummy; a.y = dummy; a.y_hi = dummy; a.wp = nullptr; a.rows2 = &fdummy;
+  return launch_conv_fast(a, pick_tile_k(H, W, CinK, CoutS).th, nullptr, true) ? 1 : 0;
+}
+
+extern "C" int spcl_conv3x3_dgrad_split_bnstats(const void* dy, int dtype, int N, int H, int W, int CinK, int CoutS,
+                                                const void* w_packed, void* g_lo, void* g_hi, const void* y2_hi,
+                                                const float* scale2, const float* shift2, const float* mean2, float* rows2,
+                                                void* stream) {
+  SPCL_CHECK_ARG(dy && g_lo && g_hi && w_packed && y2_hi && scale2 && shift2 && mean2 && rows2,
+                 "conv3x3_dgrad_split_bnstats: null pointer");
+  SPCL_CHECK_ARG((uintptr_t)g_lo % 16 == 0 && (uintptr_t)g_hi % 16 == 0 && (uintptr_t)y2_hi % 16 == 0,
+                 "conv3x3_dgrad_split_bnstats: tensors must be 16-byte aligned");
+  ConvArgs a;
+  if (!conv_split_args(a, dtype, N, H, W, CinK, CoutS)) {
+    set_error("conv3x3_dgrad_split_bnstats: unsupported configuration");
+    return SPCL_EUNSUPPORTED;
+  }
+  a.x = dy; a.y = g_lo; a.y_hi = g_hi; a.wp = w_packed;
+  a.y2 = y2_hi; a.scale2 = scale2; a.shift2 = shift2; a.mean2 = mean2; a.rows2 = rows2;
+  hipStream_t st = (hipStream_t)stream;
+  const double px = (double)N * H * W;
+  prof_cost(px * (CinK + 1.5 * CoutS) * 2.0 + 9.0 * CinK * CoutS * 2.0, 2.0 * px * 9.0 * CinK * CoutS);
+  if (!launch_conv_fast(a, pick_tile_k(H, W, CinK, CoutS).th, st)) {
+    set_error("conv3x3_dgrad_split_bnstats: no specialised kernel for H=%d W=%d CinK=%d CoutS=%d", H, W, CinK, CoutS);
+    return SPCL_EUNSUPPORTED;
+  }
+  SPCL_LAUNCH_CHECK("conv3x3_dgrad_split_bnstats");
+  return SPCL_OK;
+}
+
 // dgrad of the SECOND conv of a block fused with the per-tile partial sums of the FIRST conv's BatchNorm backward (the
 // dgrad's output g is the gradient of relu(bn(y2))): saves the separate reduction pass over (y2, g).  Only where a
 // specialised kernel exists (bf16, tiles of 14 columns): ask spcl_conv_dgrad_bnstats_supported first.

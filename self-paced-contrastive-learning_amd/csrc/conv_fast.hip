@@ -375,7 +375,11 @@ conv3x3_fast_kernel(FastArgs a) {
   const int rowb = a.CoutS * 2;
   // (MODE 0 with y_hi: the output channels' upper half goes to a second dense tensor -- the gradient of a channel
   // concatenation leaves as the two gradients of its parts; an n-tile belongs to one of them whole)
-  const bool twoy = MODE == 0 && a.y_hi != nullptr;
+  // MODE 2 with y_hi: the BatchNorm-backward sums are those of the UPPER half's layer only (y2 / scale2 / shift2 / mean2 / rows2
+  // all Chalf wide: the up-convolution whose activation is the second tensor of the concatenation); the lower half is the
+  // skip activation, whose block sees other gradients too and reduces for itself
+  const bool twoy = (MODE == 0 || MODE == 2) && a.y_hi != nullptr;
+  const bool up_only = MODE == 2 && twoy;
   const int rowo = twoy ? rowb / 2 : rowb;  // bytes between two pixels of an output tensor
   unsigned char* yj[NT];
 #pragma unroll
@@ -395,13 +399,24 @@ conv3x3_fast_kernel(FastArgs a) {
     ssum[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     ssq[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (M2 || MODE == 3) {
-      const int cb = (nt0 + j) * 16 + 4 * g;
+      const int gnt2 = nt0 + j, half2 = ntn / 2;
+      const int cb = (up_only ? (gnt2 >= half2 ? gnt2 - half2 : 0) : gnt2) * 16 + 4 * g;
       sc2[j] = *(const f32x4*)(a.scale2 + cb);
       sh2[j] = *(const f32x4*)(a.shift2 + cb);
       mu2[j] = *(const f32x4*)(a.mean2 + cb);
     }
   }
   if (M2) y2b = a.y2 + (((size_t)n * a.H + y0) * a.W + x0) * rowb + (nt0 * 16 + 4 * g) * 2;
+  const unsigned char* y2j[NT];  // per n-tile base of y2 (up_only: the half-width tensor, upper n-tiles only)
+  bool st2[NT];                  // does this n-tile take part in the statistics?
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int gnt2 = nt0 + j, half2 = ntn / 2;
+    st2[j] = !up_only || gnt2 >= half2;
+    y2j[j] = !M2 ? nullptr
+                 : (up_only ? a.y2 + (((size_t)n * a.H + y0) * a.W + x0) * rowo + ((st2[j] ? gnt2 - half2 : 0) * 16 + 4 * g) * 2
+                            : y2b + j * 32);
+  }
   // MODE 4 LDS map: [0, 7168) DZ[co 16][row 14][col 16] bf16 -- dz of the tile, transposed, in the space of the activation
   // halo (no longer needed; one wave per workgroup, its own k-loop reads are behind it); columns 14 / 15 zero.
   // [halo bytes, + 1536) IM[kx 3][row 16][col 16] bf16, written in the prologue.
@@ -440,7 +455,7 @@ conv3x3_fast_kernel(FastArgs a) {
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
             if (M2) {
-              ypre[i][j][0] = *(const uint2*)(y2b + lob + j * 32);
+              ypre[i][j][0] = *(const uint2*)(y2j[j] + lob);  // (a lower n-tile of the up-only form reads a valid dummy)
             } else {
               const unsigned char* wb = a.y2 +
                                         ((((size_t)n * a.H2 + 2 * (y0 + lpyc)) * a.W2 + 2 * (x0 + lpx)) * rowb) +
@@ -508,7 +523,7 @@ conv3x3_fast_kernel(FastArgs a) {
         }
         if (M2) {
           // dz = g [relu(bn(y2)) > 0] with g as STORED (bf16): sum dz and sum dz (y2 - mean) of the lane's 4 channels
-          const uint2 yr = YPRE ? ypre[i][j][0] : *(const uint2*)(y2b + ob + j * 32);
+          const uint2 yr = YPRE ? ypre[i][j][0] : *(const uint2*)(y2j[j] + ob);
           const f32x2 glo = {acc[i][j][0], acc[i][j][1]}, ghi = {acc[i][j][2], acc[i][j][3]};
           const uint32_t g0 = __builtin_bit_cast(uint32_t, __builtin_convertvector(glo, bf16x2v));
           const uint32_t g1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(ghi, bf16x2v));
@@ -518,7 +533,7 @@ conv3x3_fast_kernel(FastArgs a) {
                                __uint_as_float(g1 << 16), __uint_as_float(g1 & 0xffff0000u)};
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float dz = fmaf(sc2[j][r], yv[r], sh2[j][r]) > 0.f ? gv[r] * keep : 0.f;
+            const float dz = (st2[j] && fmaf(sc2[j][r], yv[r], sh2[j][r]) > 0.f) ? gv[r] * keep : 0.f;
             ssum[j][r] += dz;
             ssq[j][r] = fmaf(dz, yv[r] - mu2[j][r], ssq[j][r]);
             // MODE 4: dz (a bf16 value: exact) goes to its [co][row][col] place in LDS right away -- keeping the
@@ -586,7 +601,10 @@ conv3x3_fast_kernel(FastArgs a) {
         const float s1 = row16_sum(ssum[j][r]), s2 = row16_sum(ssq[j][r]);
         o[r] = r16 == 0 ? s1 : s2;
       }
-      if (r16 < 2) *(f32x4*)(a.rows2 + ((size_t)tile * RS + r16) * a.CoutS + (nt0 + j) * 16 + 4 * g) = o;
+      if (up_only) {
+        if (r16 < 2 && st2[j])
+          *(f32x4*)(a.rows2 + ((size_t)tile * RS + r16) * (a.CoutS / 2) + (nt0 + j - ntn / 2) * 16 + 4 * g) = o;
+      } else if (r16 < 2) *(f32x4*)(a.rows2 + ((size_t)tile * RS + r16) * a.CoutS + (nt0 + j) * 16 + 4 * g) = o;
     }
     if (MODE == 4) {
       // S[co][tap] = sum over the tile's pixels of dz[p][co] img[p + tap] ON THE MATRIX PIPE: D[co][tap] += A[co][k] B[k][tap]
@@ -845,7 +863,9 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
   a.x = (const unsigned char*)c.x; a.y = (unsigned char*)c.y; a.wp = (const u32x4*)c.wp; a.stats = c.stats;
   a.x2 = (const unsigned char*)c.x2;
   a.y_hi = (unsigned char*)c.y_hi;
-  if (c.y_hi != nullptr && !(c.in_mode == 0 && c.rows2 == nullptr && c.img2 == nullptr && c.stats == nullptr && ntn % 2 == 0))
+  // (two output tensors: the plain dgrad, or the one with the UPPER half's BatchNorm-backward sums -- MODE 2, same-resolution y2)
+  if (c.y_hi != nullptr && !(c.in_mode == 0 && (c.rows2 == nullptr || c.H2 == 0) && c.img2 == nullptr && c.stats == nullptr &&
+                             ntn % 2 == 0))
     return false;
   // two input tensors: one slab whose 16-byte chunks split evenly between them (32 = 16 + 16, 64 = 32 + 32 channels)
   // ... or several slabs, half of them in each tensor (128 = 64 + 64, 256 = 128 + 128)

@@ -566,7 +566,7 @@ class ActLink:
 class BlockCfg:
     """Static configuration of one fused Conv-BN-ReLU(-Conv-BN-ReLU)(-MaxPool) block call."""
     __slots__ = ("dtype", "training", "momentum", "eps", "track", "need_act", "need_pool", "image_input", "buffers",
-                 "link_in", "link_out", "act_dst", "up2", "lazy_act", "link_act", "x2_link")
+                 "link_in", "link_out", "act_dst", "up2", "lazy_act", "link_act", "x2_link", "bn_link", "x2_bn")
 
     def __init__(self, dtype, training, momentum, eps, track, need_act, need_pool, image_input, buffers):
         self.dtype, self.training, self.momentum, self.eps, self.track = dtype, training, momentum, eps, track
@@ -578,6 +578,8 @@ class BlockCfg:
         self.lazy_act = False  # the activation's only consumer applies BN + ReLU itself: return the RAW output, offer link_act
         self.link_act = None
         self.x2_link = None    # ActLink of the producer of ``x2`` when that tensor is its RAW output (conv_block(..., x2=...))
+        self.bn_link = None    # conv_bn_relu: its (raw output, BN coefficients) offered to the consumer of its activation ...
+        self.x2_bn = None      # ... conv_block(..., x2=that activation): its dgrad leaves that BatchNorm's backward sums there
         self.up2 = False      # the activation's only consumer is nn.Upsample(scale_factor=2): write it 2x2-replicated, return
                               # the [N, C, 2H, 2W] tensor (spcl_bnrelu_up2_forward); backward sums the 2x2 gradients first
 
@@ -1303,8 +1305,20 @@ class _ConvBlockFn(torch.autograd.Function):
                 # the concatenation's gradient as the two dense gradients of its parts (one launch, no interleaved tensor)
                 split = (torch.empty(N, H, W, cin_s // 2, dtype=dtype, device=dya.device),
                          torch.empty(N, H, W, cin_s // 2, dtype=dtype, device=dya.device))
-                _n.call("spcl_conv3x3_forward_split", _n.ptr(dya), dtc, N, H, W, cout_s, cin_s, _n.ptr(wpa_t),
-                        _n.ptr(split[0]), _n.ptr(split[1]), _n.stream())
+                xb = getattr(cfg, "x2_bn", None)
+                if (xb is not None and xb.cs == cin_s // 2 and (xb.N, xb.H, xb.W) == (N, H, W) and cfg.training
+                        and _n.call("spcl_conv_split_bnstats_supported", dtc, N, H, W, cout_s, cin_s)):
+                    # ... and the up-convolution's BatchNorm-backward sums in the same epilogue (its reduction pass disappears)
+                    nt = _n.call("spcl_conv_stat_rows", dtc, N, H, W, cout_s, cin_s)
+                    rows = torch.empty(nt * 2 * (cin_s // 2), dtype=torch.float32, device=dya.device)
+                    rows.ntiles = nt
+                    _n.call("spcl_conv3x3_dgrad_split_bnstats", _n.ptr(dya), dtc, N, H, W, cout_s, cin_s, _n.ptr(wpa_t),
+                            _n.ptr(split[0]), _n.ptr(split[1]), _n.ptr(xb.yb), _n.ptr(xb.stb[2]), _n.ptr(xb.stb[3]),
+                            _n.ptr(xb.stb[0]), _n.ptr(rows), _n.stream())
+                    xb.rows, xb.dx_ptr = rows, split[1].data_ptr()
+                else:
+                    _n.call("spcl_conv3x3_forward_split", _n.ptr(dya), dtc, N, H, W, cout_s, cin_s, _n.ptr(wpa_t),
+                            _n.ptr(split[0]), _n.ptr(split[1]), _n.stream())
             elif dxs is None:
                 dxs, _ = _conv(dya, dtc, dtype, N, H, W, cout_s, cout_s, cin_s, wpa_t, 0, None, None, False)
             if x2s is not None:
@@ -1392,6 +1406,7 @@ class _ConvBNReLUFn(torch.autograd.Function):
         ctx.params = (w, gamma, beta)
         ctx.packed_t = wp_t
         ctx.cfg = cfg
+        cfg.bn_link = ActLink(y, st, N, H, W, cout, cout_s) if (need_bwd and cout == cout_s) else None
         ctx.meta = (N, cin, H, W, cout, cout_s, cin_s, x.dtype)
         return nhwc_to_logical(act, cout)
 
@@ -1406,8 +1421,15 @@ class _ConvBNReLUFn(torch.autograd.Function):
         da_s, da_stride = da_sl if da_sl is not None else (to_nhwc_padded(d_act, dtype), 0)
         ng = ctx.needs_input_grad
         sk = tuple(take_grad_sink(p, ng[i + 1]) for i, p in enumerate(ctx.params))
-        dy, dg, db = _bnrelu_bwd(y, da_s, None, dtc, dtype, N, H, W, cout, cout_s, st, cfg.training, sk[1:3],
-                                 dact_stride=da_stride)
+        bl = getattr(cfg, "bn_link", None)
+        if bl is not None and bl.rows is not None and da_stride == 0 and da_s.data_ptr() == bl.dx_ptr:
+            # the consumer's input-gradient kernel left this BatchNorm's backward sums next to the gradient itself
+            dy, dg, db = _bnrelu_bwd_rows(y, da_s, None, bl.rows, dtc, dtype, N, H, W, cout, cout_s, st, cfg.training, sk[1:3])
+        else:
+            dy, dg, db = _bnrelu_bwd(y, da_s, None, dtc, dtype, N, H, W, cout, cout_s, st, cfg.training, sk[1:3],
+                                     dact_stride=da_stride)
+        if bl is not None:
+            bl.rows, bl.dx_ptr = None, 0
         dw = _wgrad(xs, dy, dtc, N, H, W, cin, cin_s, cin_s, cout, cout_s, 0, None, None, sk[0]) \
             if ctx.needs_input_grad[1] else None
         dx = None

@@ -58,6 +58,9 @@ _SIGNATURES = {
     "spcl_conv3x3_forward_cat": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "spcl_conv_split_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "spcl_conv3x3_forward_split": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "spcl_conv_split_bnstats_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "spcl_conv3x3_dgrad_split_bnstats": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P,
+                                                 _P]),
     "spcl_conv3x3_wgrad_cat": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "spcl_bn_stats_elems": (c_size_t, [c_int, c_int]),
     "spcl_conv3x3_forward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P,
@@ -175,7 +178,7 @@ class WgradTail(ctypes.Structure):
 
 WGRAD_BATCH_MAX = 16
 WGRAD_TAILS_MAX = 16
-_NO_STATUS = ("spcl_abi_version", "spcl_image_autocorr_rows", "spcl_conv_dgrad_bnstats_image_supported", "spcl_conv16_bwd_fused_supported", "spcl_conv16_bwd_fused_splits", "spcl_conv_num_tiles", "spcl_conv_stat_rows", "spcl_conv_set_gemm", "spcl_conv_cat_supported", "spcl_conv_split_supported", "spcl_conv1x1_bwd_rows", "spcl_profile_count", "spcl_conv_dgrad_bnstats_supported", "spcl_conv_dgrad_poolstats_supported",
+_NO_STATUS = ("spcl_abi_version", "spcl_image_autocorr_rows", "spcl_conv_dgrad_bnstats_image_supported", "spcl_conv16_bwd_fused_supported", "spcl_conv16_bwd_fused_splits", "spcl_conv_num_tiles", "spcl_conv_stat_rows", "spcl_conv_set_gemm", "spcl_conv_cat_supported", "spcl_conv_split_supported", "spcl_conv_split_bnstats_supported", "spcl_conv1x1_bwd_rows", "spcl_profile_count", "spcl_conv_dgrad_bnstats_supported", "spcl_conv_dgrad_poolstats_supported",
               "spcl_conv_wgrad_batched_supported")
 
 

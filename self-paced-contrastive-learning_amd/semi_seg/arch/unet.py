@@ -42,6 +42,10 @@ _CAT_PAIR_MAXC = int(__import__("os").environ.get("SPCL_CAT_PAIR_MAXC", "32"))
 # a writer pass: built, bit-identical (tests/test_gpu_decoder.py) and 13 us SLOWER per step (2.336 -> 2.349 ms: the transform in
 # two loaders costs more than the 27 us of writer passes it removes) -- off
 _LAZY_UP = __import__("os").environ.get("SPCL_LAZY_UP", "0") != "0"
+# the two-tensor level's dgrad also leaving the up-convolution's BatchNorm-backward sums (spcl_conv3x3_dgrad_split_bnstats):
+# built, tested, and measured +4 us per step (2.3015 -> 2.3068 ms, three rounds): the epilogue costs what the reduction pass
+# (20.8 + 11.9 us) cost -- off
+_SPLIT_BNSTATS = __import__("os").environ.get("SPCL_SPLIT_BNSTATS", "0") != "0"
 _LAZY_HEAD = __import__("os").environ.get("SPCL_LAZY_HEAD", "1") != "0"  # A/B switch: 0 writes the last activation and reads it back
 _FUSED_UPSAMPLE = __import__("os").environ.get("SPCL_FUSED_UPSAMPLE", "1") != "0"  # A/B switch (BlockCfg.up2)
 _ENCODER = ("Conv1", "Conv2", "Conv3", "Conv4", "Conv5")
@@ -96,6 +100,7 @@ class _ConvBlock(nn.Module):
         self._act_dst = None        # where UNet.forward wants this call's activation written (half of a concat buffer)
         self._up2 = False           # this call's activation only feeds nn.Upsample(x2): return it upsampled (one launch less)
         self._x2_link = None        # functional.ActLink of the up-convolution whose RAW output this call's x2 is
+        self._x2_bn = None          # functional.ActLink of the up-convolution whose ACTIVATION this call's x2 is
         self._lazy = False          # this call's activation only feeds the 1x1 head, which applies BN + ReLU itself
         self._link_act = None       # functional.ActLink of a lazy call (UNet.forward hands it to the head)
 
@@ -127,6 +132,7 @@ class _ConvBlock(nn.Module):
         cfg.up2, self._up2 = (self._up2 and len(self._forward_hooks) == 0), False
         cfg.lazy_act, self._lazy = (self._lazy and len(self._forward_hooks) == 0), False
         cfg.x2_link, self._x2_link = (self._x2_link if x2 is not None else None), None
+        cfg.x2_bn, self._x2_bn = (self._x2_bn if x2 is not None else None), None
         act, pooled = F_hip.conv_block(x, c[0].weight, c[1].weight, c[1].bias, c[3].weight, c[4].weight, c[4].bias, cfg, x2)
         self._pooled = pooled
         self._link_out = cfg.link_out  # for the block that consumes the pooled output (UNet.forward hands it over)
@@ -153,6 +159,7 @@ class _UpConv(nn.Module):
         self._compute_dtype = None
         self._act_dst = None
         self._link_act = None
+        self._bn_link = None  # functional.ActLink of the last call: (raw output, coefficients), for the consumer's dgrad
 
     def forward(self, x, pre_upsampled: bool = False, lazy: bool = False):
         """``pre_upsampled``: ``x`` already is the x2-upsampled tensor (the producing block wrote it that way, BlockCfg.up2);
@@ -170,6 +177,7 @@ class _UpConv(nn.Module):
             x = F_hip.upsample2x(x, dtype)  # nn.Upsample(scale_factor=2), nearest
         out = F_hip.conv_bn_relu(x, self.up[1].weight, bn.weight, bn.bias, cfg)
         self._link_act = cfg.link_act
+        self._bn_link = cfg.bn_link
         return out
 
 
@@ -322,6 +330,8 @@ class UNet(nn.Module):
                 # the narrow level (16 + 16 channels: too narrow for the producers to write halves of one buffer -- half a
                 # cache line per pixel): both tensors stay where they are, the block's first convolution and its weight
                 # gradient read them side by side, the gradient comes back as one tensor read half by half
+                if _SPLIT_BNSTATS and not any(len(m._forward_hooks) for m in (up, *up.up)):
+                    blk._x2_bn = up._bn_link  # (its dgrad then leaves the up-convolution's BatchNorm-backward sums too)
                 d = blk(skips[skip], x2=d)
             else:
                 d = blk(F_hip.concat_channels(skips[skip], d, bdt))

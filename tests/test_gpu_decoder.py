@@ -301,6 +301,7 @@ def test_in_place_decoder_data_movement_is_the_copying_path_bit_for_bit(N, S, mo
         monkeypatch.setattr(unet_mod, "_CAT_PAIR_FIRST", pair_first)
         monkeypatch.setattr(unet_mod, "_CAT_PAIR_MAXC", 1024)  # (the wide levels too: slab-wise / block-wise two-tensor reads)
         monkeypatch.setattr(unet_mod, "_LAZY_HEAD", False)  # (its BatchNorm-backward sums have their own order: next test)
+        monkeypatch.setattr(unet_mod, "_SPLIT_BNSTATS", False)  # (sums in another order: test_split_dgrad_... below)
         monkeypatch.setattr(unet_mod, "_LAZY_UP", in_place and pair_first)  # (the up-convolutions' BN + ReLU in the consumers' loaders)
         m = UNet(input_dim=1, num_classes=4, max_channel=256)
         m.load_state_dict(sd, strict=True)
@@ -380,3 +381,50 @@ def test_last_activation_folded_into_the_head_matches_the_written_one(dt, monkey
             ref = gb[k].float()
             err = float((ga[k].float() - ref).norm()) / max(float(ref.norm()), 1e-20)
             assert err < tol, (k, err)
+
+
+def test_split_dgrad_leaves_the_up_convolutions_bn_sums(monkeypatch):
+    """`spcl_conv3x3_dgrad_split_bnstats`: the two-tensor level's input-gradient kernel also leaves the BatchNorm-backward sums
+    of the up-convolution (whose activation is its second input): same network with and without -- logits identical, every
+    gradient to the summation order of those sums (fp32: 2e-5 of its norm)."""
+    import spcl_amd  # noqa
+    from spcl_amd import functional as F
+    from spcl_amd.semi_seg.arch import UNet, unet as unet_mod
+    sd = O.init_unet_state(1, 4, 256, seed=31)
+    g = torch.Generator().manual_seed(32)
+    x = torch.rand(2, 1, 224, 224, generator=g).cuda()
+    labels = torch.randint(0, 4, (2, 224, 224), generator=g).cuda()
+
+    def run(on):
+        monkeypatch.setattr(unet_mod, "_SPLIT_BNSTATS", on)
+        monkeypatch.setattr(unet_mod, "_LAZY_HEAD", False)
+        m = UNet(input_dim=1, num_classes=4, max_channel=256)
+        m.load_state_dict(sd, strict=True)
+        m.cuda().train()
+        m.set_compute_dtype(torch.bfloat16)
+        used = []
+        real = F._n.call
+
+        def spy(name, *a):
+            if name == "spcl_conv3x3_dgrad_split_bnstats":
+                used.append(1)
+            return real(name, *a)
+        monkeypatch.setattr(F._n, "call", spy)
+        logits = m(x)
+        loss, _ = F.sup_loss_kl_onehot(logits, labels)
+        loss.backward()
+        torch.cuda.synchronize()
+        monkeypatch.setattr(F._n, "call", real)
+        assert len(used) == (2 if on else 0)  # the 16- and the 32-channel level
+        return logits.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()}
+
+    la, ga = run(True)
+    lb, gb = run(False)
+    assert torch.equal(la, lb)
+    for k in gb:
+        ref = gb[k].float()
+        err = float((ga[k].float() - ref).norm()) / max(float(ref.norm()), 1e-20)
+        assert err < 3e-2, (k, err)  # bf16 storage: the sums' last bits re-rounded by every layer below (see the test above)
+    # the layers ABOVE the first affected BatchNorm see identical gradients
+    for k in ("_Deconv_1x1.weight", "_Up_conv2.conv.3.weight", "_Up_conv2.conv.0.weight"):
+        assert torch.equal(ga[k], gb[k]), k
