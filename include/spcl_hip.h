@@ -65,6 +65,10 @@ int spcl_supcon_backward(const float* labels, const float* mask, int n, int d, f
                          float gamma, const float* ws_fwd, float* ws_bwd, const float* out_fwd,
                          const float* grad_out, float* dz1, float* dz2, void* stream);
 size_t spcl_supcon_bwd_workspace_bytes(int n, int d);
+/* 1 (and the block's offset in the FORWARD workspace, in floats, and its row pitch) when spcl_supcon_forward leaves dLoss/dP
+ * for a unit upstream gradient there (the training sizes, 2n <= 64): rows [0, 2n) x [0, d) of it ARE the gradient when the
+ * upstream gradient is exactly 1 -- spcl_supcon_backward would only multiply them by it.  0: this shape recomputes. */
+int spcl_supcon_unit_gradient_block(int n, int d, size_t* offset_floats, int* row_pitch);
 /* K (1..4) losses of ONE shape in the launches of one -- the K meta-label hooks that semi_seg/hooks/creator.py:102-124
  * puts on one feature, each with its own label vector and its own self-paced age parameter (hooks/infonce.py:133-141).
  * Head h reads z1 + h z_stride and z2 + h z_stride ([n,d] f32 each), labels + h n (NULL: SimCLR for every head), uses

@@ -510,6 +510,7 @@ bool launch_conv_stream(const ConvArgs& c, int th, hipStream_t st, bool dry) {
   static const int env_on = getenv("SPCL_CONV_STREAM") ? atoi(getenv("SPCL_CONV_STREAM")) : 0;
   if (!env_on) return false;
   if (env_on == 2 && !(c.CinK == 32 && c.in_mode == 0 && c.rows2 == nullptr)) return false;
+  if (env_on == 3 && !(c.in_mode == 0 && c.rows2 == nullptr)) return false;  // 3: every plain convolution it has a kernel for
   if (c.H < th || c.W < 14 || c.in_mode == 2 || c.CinS != c.CinK || c.img2 != nullptr) return false;
   const int KC = c.CinK, ntn = c.CoutS / 16;
   if (KC != 16 && KC != 32) return false;

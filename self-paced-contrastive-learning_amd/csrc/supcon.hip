@@ -2558,6 +2558,18 @@ extern "C" int spcl_supcon_backward(const float* labels, const float* mask, int 
                               dz1, dz2, 0, (hipStream_t)stream, "supcon_backward");
 }
 
+// Where the forward left dLoss/dP for a UNIT upstream gradient (the training sizes: one 64-row block): its offset in the
+// forward workspace in floats and its row pitch; 0 when this shape's backward recomputes.  A caller whose upstream gradient is
+// exactly 1 takes rows [0, 2n) x [0, d) of that block as the gradient -- spcl_supcon_backward would only multiply it by 1.
+extern "C" int spcl_supcon_unit_gradient_block(int n, int d, size_t* offset_floats, int* row_pitch) {
+  if (n <= 0 || d <= 0 || d > SPCL_SUPCON_MAX_D || !offset_floats || !row_pitch) return 0;
+  SupconLayout L = supcon_layout(n, d);
+  if (!supcon_use_small(L)) return 0;
+  *offset_floats = L.off_dz;
+  *row_pitch = L.DP;
+  return 1;
+}
+
 extern "C" int spcl_supcon_backward_heads(int K, const float* labels, int n, int d, float temperature, int sp_mode,
                                           const float* gammas, const float* ws_fwd, size_t ws_stride, float* ws_bwd,
                                           size_t wsb_stride, const float* out_fwd, const float* grad_out, float* dz1,

@@ -76,6 +76,14 @@ class _SupConFn(torch.autograd.Function):
     def backward(ctx, grad_out):
         s = ctx.state
         dev = s.ws.device
+        if ctx.stacked and ctx.in_dtypes[0] == torch.float32 and is_unit_gradient(grad_out):
+            # the epocher's own ``backward(gradient=ones)``: the forward already left dLoss/dP for a unit gradient in its
+            # workspace (training sizes) -- that block IS the gradient, no scaling launch
+            off, pitch = ctypes.c_size_t(0), ctypes.c_int(0)
+            if (_n.call("spcl_supcon_unit_gradient_block", s.n, s.d, ctypes.byref(off), ctypes.byref(pitch))
+                    and pitch.value == s.d):
+                dz = s.ws[off.value:off.value + 2 * s.n * s.d].view(2 * s.n, s.d)
+                return dz, None, None, None, None, None, None, None, None
         dz = torch.empty(2 * s.n, s.d, dtype=torch.float32, device=dev)
         dz1, dz2 = dz[:s.n], dz[s.n:]
         wsb = torch.empty(_n.call("spcl_supcon_bwd_workspace_bytes", s.n, s.d) // 4, dtype=torch.float32, device=dev)

@@ -25,6 +25,7 @@ _SIGNATURES = {
     "spcl_supcon_forward": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, c_int, c_float, c_int, _P, _P, _P]),
     "spcl_supcon_backward": (c_int, [_P, _P, c_int, c_int, c_float, c_int, c_float, _P, _P, _P, _P, _P, _P, _P]),
     "spcl_supcon_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "spcl_supcon_unit_gradient_block": (c_int, [c_int, c_int, _P, _P]),
     "spcl_supcon_materialize": (c_int, [_P, _P, c_int, c_int, c_float, c_int, c_float, _P, _P, _P, _P, _P, _P, _P]),
     "spcl_supcon_xpos_workspace_bytes": (c_size_t, [c_int, c_int]),
     "spcl_supcon_xpos_forward": (c_int, [_P, _P, _P, _P, c_int, c_int, c_float, _P, _P, _P]),
@@ -178,7 +179,7 @@ class WgradTail(ctypes.Structure):
 
 WGRAD_BATCH_MAX = 16
 WGRAD_TAILS_MAX = 16
-_NO_STATUS = ("spcl_abi_version", "spcl_image_autocorr_rows", "spcl_conv_dgrad_bnstats_image_supported", "spcl_conv16_bwd_fused_supported", "spcl_conv16_bwd_fused_splits", "spcl_conv_num_tiles", "spcl_conv_stat_rows", "spcl_conv_set_gemm", "spcl_conv_cat_supported", "spcl_conv_split_supported", "spcl_conv_split_bnstats_supported", "spcl_conv1x1_bwd_rows", "spcl_profile_count", "spcl_conv_dgrad_bnstats_supported", "spcl_conv_dgrad_poolstats_supported",
+_NO_STATUS = ("spcl_abi_version", "spcl_image_autocorr_rows", "spcl_conv_dgrad_bnstats_image_supported", "spcl_conv16_bwd_fused_supported", "spcl_conv16_bwd_fused_splits", "spcl_conv_num_tiles", "spcl_conv_stat_rows", "spcl_conv_set_gemm", "spcl_supcon_unit_gradient_block", "spcl_conv_cat_supported", "spcl_conv_split_supported", "spcl_conv_split_bnstats_supported", "spcl_conv1x1_bwd_rows", "spcl_profile_count", "spcl_conv_dgrad_bnstats_supported", "spcl_conv_dgrad_poolstats_supported",
               "spcl_conv_wgrad_batched_supported")
 
 

@@ -16,6 +16,7 @@ from ...contrastyou import meters as _meters
 from ...contrastyou.meters import AverageValueMeter, MeterInterface
 from ... import ddp as _ddp
 from ... import native as _n
+from ... import functional as F_hip
 from ... import stepgraph as _sg
 from .helper import FixRandomSeed, TensorRandomFlip
 
@@ -289,7 +290,7 @@ class PretrainEncoderEpocher:
         key = (loss.device, loss.dtype)
         one = self._ones.get(key)
         if one is None:
-            one = self._ones[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
+            one = self._ones[key] = F_hip.register_unit_gradient(torch.ones((), dtype=loss.dtype, device=loss.device))
         return one
 
     def step_exchange(self):

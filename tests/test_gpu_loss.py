@@ -222,6 +222,38 @@ def test_loss_on_chunk_halves_takes_the_stacked_path_with_identical_results():
     assert torch.equal(res[0][2], res[1][2])
 
 
+def test_unit_upstream_gradient_is_the_forwards_block():
+    """``loss.backward(gradient=registered ones)`` (what the pre-train epocher does): the gradient is the block the forward
+    left in its workspace for a unit gradient -- no scaling launch -- and equals the ordinary backward bit for bit; an
+    unregistered gradient of the same value, a non-unit one and a shape whose backward recomputes take the ordinary path."""
+    import spcl_amd  # noqa
+    from spcl_amd import functional as F_hip
+    g = torch.Generator().manual_seed(5)
+    for n2, d in ((64, 128), (24, 64), (256, 128)):
+        z = torch.nn.functional.normalize(torch.randn(n2, d, generator=g), dim=1).cuda()
+        labels = [i % 3 for i in range(n2 // 2)]
+        unit = F_hip.register_unit_gradient(torch.ones((), device="cuda"))
+        grads = []
+        for grad in (None, unit, torch.ones((), device="cuda"), torch.full((), 0.5, device="cuda")):
+            zz = z.clone().requires_grad_(True)
+            h = zz * 1.0
+            crit = _crit("soft", 5.0, True)
+            loss = crit(*torch.chunk(h, 2), target=labels)
+            calls = []
+            real = F_hip._n.call
+            F_hip._n.call = lambda name, *a: (calls.append(name), real(name, *a))[1]
+            try:
+                loss.backward() if grad is None else loss.backward(gradient=grad)
+            finally:
+                F_hip._n.call = real
+            grads.append((zz.grad.clone(), "spcl_supcon_backward" in calls))
+        assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][0], grads[2][0])
+        assert torch.equal(grads[3][0], grads[0][0] * 0.5)
+        assert grads[0][1] and grads[2][1] and grads[3][1]      # ordinary backward launches
+        assert grads[1][1] == (n2 > 64)                         # the registered unit gradient skips it at the training sizes
+        del unit
+
+
 def test_meter_batching_is_one_launch_with_the_same_sums():
     import spcl_amd  # noqa
     from spcl_amd.contrastyou import meters as M
