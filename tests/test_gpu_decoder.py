@@ -280,7 +280,7 @@ def test_full_unet_base_width_vs_oracle_fp32():
             params[k].grad.cpu().numpy(), sdo[k].grad.numpy()))
 
 
-@pytest.mark.parametrize("N,S", [(2, 224), (3, 112)])
+@pytest.mark.parametrize("N,S", [(2, 224), (3, 112), (2, 128), (1, 256)])
 def test_in_place_decoder_data_movement_is_the_copying_path_bit_for_bit(N, S, monkeypatch):
     """The decoder's concatenations / upsamples folded into their producers and consumers -- halves of one buffer written in
     place (>= 32 channels), the 16 + 16 channel level read from its two tensors by the convolution and its weight gradient
@@ -315,8 +315,11 @@ def test_in_place_decoder_data_movement_is_the_copying_path_bit_for_bit(N, S, mo
         logits = m(x)
         monkeypatch.setattr(F, "concat_channels", real_cat)
         monkeypatch.setattr(F, "cat_buffer", real_buf)
-        assert len(copies) == (0 if in_place else 4)  # no level falls back to the copying concatenation
-        assert len(bufs) == (0 if (pair_first or not in_place) else 3)  # the buffer only where the two-tensor read is not asked for
+        if S in (224, 112):  # (14-column-tileable sizes: every level has its in-place form)
+            assert len(copies) == (0 if in_place else 4)  # no level falls back to the copying concatenation
+            assert len(bufs) == (0 if (pair_first or not in_place) else 3)  # the buffer only where the two-tensor read is not asked for
+        else:  # 128 / 256: shifted tiles at the top, the band-GEMM kernels below -- whatever mix results must agree
+            assert len(copies) == 4 if not in_place else len(copies) <= 4
         loss, _ = F.sup_loss_kl_onehot(logits, labels)
         loss.backward()
         torch.cuda.synchronize()
@@ -332,8 +335,9 @@ def test_in_place_decoder_data_movement_is_the_copying_path_bit_for_bit(N, S, mo
             assert float(ga[k].abs().max()) > 0, k
     # and the narrow level really took the two-tensor convolution
     monkeypatch.setattr(F, "_CONV_CAT", True)
-    a = torch.zeros(N, 16, S, S, device="cuda", dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
-    assert F.cat_pair_supported(a, a.clone(memory_format=torch.channels_last), 16, torch.bfloat16)
+    if S in (224, 112):
+        a = torch.zeros(N, 16, S, S, device="cuda", dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        assert F.cat_pair_supported(a, a.clone(memory_format=torch.channels_last), 16, torch.bfloat16)
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
