@@ -222,6 +222,17 @@ int spcl_conv3x3_forward_cat(const void* xa, const void* xb, int dtype, int N, i
 int spcl_conv3x3_wgrad_cat(const void* xa, const void* xb, const void* dy, int dtype, int N, int H, int W, int Chalf,
                            int Cout, int CoutS, const float* xb_scale, const float* xb_shift, float* partial,
                            float* dw_oihw, void* stream);
+/* nn.Upsample(scale_factor=2) -> Conv2d of the up-convolution (unet.py:89-90) without the upsampled tensor: x_half is the
+ * half-resolution activation [N][H / 2][W / 2][CinK], H x W the convolution's size; the loaders turn a fine halo pixel
+ * (gy, gx) into pixel (gy >> 1, gx >> 1) of x_half.  Forward (y / stats as spcl_conv3x3_forward; where
+ * spcl_conv_up2_supported says so) and weight gradient (workspace: spcl_conv_wgrad_workspace_bytes; the batched kernel
+ * takes it through spcl_wgrad_item::x_up2).  The input gradient is the ordinary dgrad followed by the 2 x 2 sum
+ * (spcl_upsample2x_backward / spcl_bnrelu_backward_up2). */
+int spcl_conv_up2_supported(int dtype, int N, int H, int W, int CinK, int CoutS);
+int spcl_conv3x3_forward_up2(const void* x_half, int dtype, int N, int H, int W, int CinK, int CoutS, const void* w_packed,
+                             void* y, float* stats, void* stream);
+int spcl_conv3x3_wgrad_up2(const void* x_half, const void* dy, int dtype, int N, int H, int W, int Cin, int Cout, int CoutS,
+                           float* partial, float* dw_oihw, void* stream);
 /* ... and the input gradient of that convolution as the gradients of the two concatenated tensors: the plain 3x3 convolution
  * (w_packed = the dgrad layout, kind 1) whose output channels [0, CoutS / 2) are written to y_lo and [CoutS / 2, CoutS) to
  * y_hi, both dense [N][H][W][CoutS / 2] bf16 (torch.cat's backward, unet.py:194-224, without the interleaved tensor).
@@ -276,6 +287,7 @@ typedef struct spcl_wgrad_item {
   int N, H, W, Cin, CinS, Cout, CoutS, in_mode;
   const void* x2; /* NULL, or: input channels [Cin / 2, Cin) come from this tensor and [0, Cin / 2) from x, both dense
                      [N][H][W][Cin / 2] (the decoder's concatenation read in place; Cin a multiple of 128, in_mode 0) */
+  int x_up2;      /* 1: x is [N][H / 2][W / 2][CinS] and the layer's input its nearest x2 upsample (unet.py:89), in_mode 0 */
 } spcl_wgrad_item;
 int spcl_conv_wgrad_batched_supported(int dtype, int Cin, int CinS, int Cout, int CoutS, int in_mode);
 size_t spcl_conv_wgrad_batched_workspace_bytes(const spcl_wgrad_item* items, int n);

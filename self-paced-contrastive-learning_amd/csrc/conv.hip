@@ -745,6 +745,52 @@ extern "C" int spcl_conv3x3_forward_cat(const void* xa, const void* xb, int dtyp
   return SPCL_OK;
 }
 
+// nn.Upsample(scale_factor=2) -> Conv2d (the up-convolution, unet.py:89-90) without the upsampled tensor: x is the
+// half-resolution activation [N][H / 2][W / 2][CinK], H x W the convolution's (fine) size; y / stats as spcl_conv3x3_forward.
+static bool conv_up2_args(ConvArgs& a, int dtype, int N, int H, int W, int CinK, int CoutS) {
+  static const bool off = getenv("SPCL_CONV_UP2") && atoi(getenv("SPCL_CONV_UP2")) == 0;  // A/B switch
+  if (off || dtype != SPCL_BF16 || N <= 0 || H <= 0 || W <= 0 || H % 2 || W % 2 || CinK % 16 != 0 || CinK <= 0 ||
+      CoutS % 16 != 0 || CoutS <= 0)
+    return false;
+  if (!(CinK <= 64 || CinK % 64 == 0)) return false;
+  a.in_scale = a.in_shift = nullptr;
+  a.stats = nullptr;
+  a.N = N; a.H = H; a.W = W; a.CinS = CinK; a.CinK = CinK; a.CoutS = CoutS; a.in_mode = 0;
+  a.tilesX = a.tilesY = 0;
+  a.tpw = 1;
+  a.dbg = 0;
+  a.x_up2 = true;
+  return !conv_use_gemm(CinK, CoutS, H, W) && pick_tile(H, W).tw == 14;
+}
+
+extern "C" int spcl_conv_up2_supported(int dtype, int N, int H, int W, int CinK, int CoutS) {
+  ConvArgs a;
+  if (!conv_up2_args(a, dtype, N, H, W, CinK, CoutS)) return 0;
+  static const char dummy[16] = {0};
+  a.x = dummy; a.y = nullptr; a.wp = nullptr;
+  return launch_conv_fast(a, pick_tile_k(H, W, CinK, CoutS).th, nullptr, true) ? 1 : 0;
+}
+
+extern "C" int spcl_conv3x3_forward_up2(const void* x_half, int dtype, int N, int H, int W, int CinK, int CoutS,
+                                        const void* w_packed, void* y, float* stats, void* stream) {
+  SPCL_CHECK_ARG(x_half && y && w_packed, "conv3x3_forward_up2: null pointer");
+  ConvArgs a;
+  if (!conv_up2_args(a, dtype, N, H, W, CinK, CoutS)) {
+    set_error("conv3x3_forward_up2: unsupported configuration (bf16, even sizes, 14-column tiles)");
+    return SPCL_EUNSUPPORTED;
+  }
+  a.x = x_half; a.y = y; a.wp = w_packed; a.stats = stats;
+  hipStream_t st = (hipStream_t)stream;
+  const double px = (double)N * H * W;
+  prof_cost(px * (0.25 * CinK + CoutS) * 2.0 + 9.0 * CinK * CoutS * 2.0, 2.0 * px * 9.0 * CinK * CoutS);
+  if (!launch_conv_fast(a, pick_tile_k(H, W, CinK, CoutS).th, st)) {
+    set_error("conv3x3_forward_up2: no specialised kernel for H=%d W=%d CinK=%d CoutS=%d", H, W, CinK, CoutS);
+    return SPCL_EUNSUPPORTED;
+  }
+  SPCL_LAUNCH_CHECK("conv3x3_forward_up2");
+  return SPCL_OK;
+}
+
 // ... and its input gradient as the two gradients of the concatenated tensors: the plain convolution (dgrad weights) whose
 // output channels [0, CoutS / 2) go to y_lo and [CoutS / 2, CoutS) to y_hi, both dense [N][H][W][CoutS / 2] -- each producer's
 // backward then reads whole pixels instead of half of every line of one interleaved tensor.

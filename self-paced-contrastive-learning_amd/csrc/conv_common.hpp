@@ -55,6 +55,9 @@ struct ConvArgs {
   // the output as TWO dense tensors (y: channels [0, CoutS / 2), y_hi: the rest; each [N][H][W][CoutS / 2]) -- the gradient
   // of such a concatenation written as the gradients of its parts (fast path only, plain dgrad: no statistics)
   void* y_hi = nullptr;
+  // x is [N][H / 2][W / 2][CinK] and the input of the convolution is its nearest-neighbour x2 upsample (unet.py:89
+  // nn.Upsample(scale_factor=2) in front of the up-convolution), never materialised (fast path only, in_mode 0)
+  bool x_up2 = false;
 };
 
 template <typename T> __device__ __forceinline__ f32x4 mfma_chunk(u32x4 w, u32x4 x, f32x4 acc);

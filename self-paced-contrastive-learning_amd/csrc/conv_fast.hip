@@ -19,6 +19,7 @@ struct FastArgs {
   const unsigned char* x2;  // non-null: the second half of the input channels comes from this tensor (ConvArgs::x2)
   unsigned char* y;
   unsigned char* y_hi;      // non-null (MODE 0): output channels [CoutS / 2, CoutS) go to this tensor (ConvArgs::y_hi)
+  int up2;                  // 1: x is [N][H / 2][W / 2][CinK] and the convolution's input its nearest x2 upsample (ConvArgs::x_up2)
   const u32x4* wp;
   float* stats;
   const float* in_scale;
@@ -240,7 +241,14 @@ conv3x3_fast_kernel(FastArgs a) {
         inb = inb && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
       }
       v[k] = (u32x4){0u, 0u, 0u, 0u};
-      if (inb) v[k] = *(const u32x4*)(xs + soff + voff);
+      if (a.up2) {
+        // the input is nn.Upsample(scale_factor=2)(x): halo pixel (gy, gx) of the fine image is pixel (gy >> 1, gx >> 1) of
+        // the [N][H / 2][W / 2] tensor x -- the upsampled tensor is never written (a per-load address instead of a stride)
+        const int gy = y0 - 1 + hy0 + dky, gx = x0 - 1 + hx0 + dkx;
+        if (inb)
+          v[k] = *(const u32x4*)(a.x + (((long)n * (a.H >> 1) + (gy >> 1)) * (a.W >> 1) + (gx >> 1)) * gps + slab * (KC * 2) +
+                                 ch * 16);
+      } else if (inb) v[k] = *(const u32x4*)(xs + soff + voff);
     }
   };
   unsigned char* lpw = lp;  // staging destination / fragment bases of the current halo image
@@ -810,7 +818,9 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
     FastArgs a;
     if (c.x2 != nullptr) return false;
     if (c.y_hi != nullptr) return false;
+    if (c.x_up2) return false;
     a.x = (const unsigned char*)c.x; a.x2 = nullptr; a.y = (unsigned char*)c.y; a.y_hi = nullptr; a.wp = (const u32x4*)c.wp; a.stats = c.stats;
+    a.up2 = 0;
     a.in_scale = a.in_shift = nullptr;
     a.y2 = nullptr; a.scale2 = a.shift2 = a.mean2 = nullptr; a.rows2 = nullptr; a.H2 = a.W2 = 0; a.img2 = nullptr;
     a.N = c.N; a.H = c.H; a.W = c.W; a.CinK = 16; a.CoutS = 16;
@@ -863,6 +873,11 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
   a.x = (const unsigned char*)c.x; a.y = (unsigned char*)c.y; a.wp = (const u32x4*)c.wp; a.stats = c.stats;
   a.x2 = (const unsigned char*)c.x2;
   a.y_hi = (unsigned char*)c.y_hi;
+  a.up2 = c.x_up2 ? 1 : 0;
+  // (the upsampled input: plain convolutions of one tensor, even image sizes, 32-bit byte offsets)
+  if (c.x_up2 && !(c.in_mode == 0 && c.x2 == nullptr && c.rows2 == nullptr && c.img2 == nullptr && c.H % 2 == 0 &&
+                   c.W % 2 == 0 && (double)c.N * c.H * c.W / 4.0 * c.CinK * 2.0 < 2147483648.0))
+    return false;
   // (two output tensors: the plain dgrad, or the one with the UPPER half's BatchNorm-backward sums -- MODE 2, same-resolution y2)
   if (c.y_hi != nullptr && !(c.in_mode == 0 && (c.rows2 == nullptr || c.H2 == 0) && c.img2 == nullptr && c.stats == nullptr &&
                              ntn % 2 == 0))

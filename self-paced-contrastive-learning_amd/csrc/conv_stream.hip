@@ -502,7 +502,7 @@ static void launch_stream(const StreamArgs& a0, int mode, hipStream_t st) {
 
 // conv_fast.hip's launcher asks here first: true when the streaming kernel took the launch
 bool launch_conv_stream(const ConvArgs& c, int th, hipStream_t st, bool dry) {
-  if (c.x2 != nullptr || c.y_hi != nullptr) return false;  // (two-tensor inputs / outputs exist in conv_fast.hip only)
+  if (c.x2 != nullptr || c.y_hi != nullptr || c.x_up2) return false;  // (two-tensor inputs / outputs exist in conv_fast.hip only)
   // 0 (default) off; 1 every supported shape; 2 only plain 32-input-channel convolutions (no fused input BatchNorm, no
   // BatchNorm-backward sums in the epilogue).  Isolated launches of those run 20-30 % faster than conv_fast, but neither the
   // pre-train step (1.123 -> 1.138 ms with 1) nor the fine-tune step (2.451 -> 2.469 ms with 2) gains: the tile is bound by

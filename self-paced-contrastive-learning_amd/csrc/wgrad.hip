@@ -24,6 +24,7 @@ struct WgradArgs {
   const void* x;
   const void* x2;  // non-null: input channels [xsplit, 2 xsplit) come from this tensor, [0, xsplit) from x; both dense
   int xsplit;      // [N][H][W][xsplit] (the decoder's concatenation read in place, spcl_conv3x3_wgrad_cat)
+  int x_up2;       // 1: x is [N][H / 2][W / 2][CinS] and the layer's input its nearest x2 upsample (spcl_conv3x3_wgrad_up2)
   const void* dy;
   const float* in_scale;
   const float* in_shift;
@@ -223,6 +224,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_wgrad_kernel(WgradArgs a)
         rx[i] = v;
       } else {
         const T* src = ok ? xsrc + rowoff + xvoff : xsrc + xc1;
+        if (a.x_up2 && ok)  // fine halo pixel (gy, gx) = pixel (gy >> 1, gx >> 1) of the half-resolution tensor
+          src = xsrc + (((long)n * (a.H >> 1) + (gy >> 1)) * (a.W >> 1) + (gx >> 1)) * a.CinS + xc1;
         rx[i] = *(const u32x4*)src;
       }
     }
@@ -497,7 +500,7 @@ static bool wide_item(spcl_wgrad_item& it, const void* x, const void* dy, int N,
   if (Cin != CinK || CinS != CinK || Cout != CoutS ||
       !spcl_conv_wgrad_batched_supported(SPCL_BF16, Cin, CinS, Cout, CoutS, in_mode))
     return false;
-  it.x = x; it.x2 = nullptr; it.dy = dy; it.in_scale = in_scale; it.in_shift = in_shift; it.dw_oihw = dw;
+  it.x = x; it.x2 = nullptr; it.x_up2 = 0; it.dy = dy; it.in_scale = in_scale; it.in_shift = in_shift; it.dw_oihw = dw;
   it.N = N; it.H = H; it.W = W; it.Cin = Cin; it.CinS = CinS; it.Cout = Cout; it.CoutS = CoutS; it.in_mode = in_mode;
   return true;
 }
@@ -518,7 +521,7 @@ extern "C" size_t spcl_conv_wgrad_workspace_bytes(int N, int H, int W, int CinK,
 
 static int conv3x3_wgrad_impl(const void* x, const void* x2, const void* dy, int dtype, int N, int H, int W, int Cin, int CinS,
                               int CinK, int Cout, int CoutS, int in_mode, const float* in_scale, const float* in_shift,
-                              float* partial, float* dw_oihw, void* stream);
+                              float* partial, float* dw_oihw, void* stream, bool x_up2 = false);
 
 extern "C" int spcl_conv3x3_wgrad(const void* x, const void* dy, int dtype, int N, int H, int W, int Cin, int CinS,
                                   int CinK, int Cout, int CoutS, int in_mode, const float* in_scale,
@@ -548,9 +551,20 @@ extern "C" int spcl_conv3x3_wgrad_cat(const void* xa, const void* xb, const void
                             xb_scale, xb_shift, partial, dw_oihw, stream);
 }
 
+// ... of the up-convolution (unet.py:89-90): its input is nn.Upsample(scale_factor=2)(x_half), read from the half-resolution
+// tensor [N][H / 2][W / 2][Cin] (H x W = the convolution's size; bf16, Cin == CinS == CinK, no input transform).
+extern "C" int spcl_conv3x3_wgrad_up2(const void* x_half, const void* dy, int dtype, int N, int H, int W, int Cin, int Cout,
+                                      int CoutS, float* partial, float* dw_oihw, void* stream) {
+  SPCL_CHECK_ARG(dtype == SPCL_BF16 && H % 2 == 0 && W % 2 == 0 && Cin % 16 == 0,
+                 "conv3x3_wgrad_up2: bf16, even sizes, Cin a multiple of 16");
+  SPCL_CHECK_ARG((double)N * H * W / 4.0 * Cin * 2.0 < 2147483648.0, "conv3x3_wgrad_up2: tensor too large for 32-bit offsets");
+  return conv3x3_wgrad_impl(x_half, nullptr, dy, dtype, N, H, W, Cin, Cin, Cin, Cout, CoutS, 0, nullptr, nullptr, partial,
+                            dw_oihw, stream, true);
+}
+
 static int conv3x3_wgrad_impl(const void* x, const void* x2, const void* dy, int dtype, int N, int H, int W, int Cin, int CinS,
                               int CinK, int Cout, int CoutS, int in_mode, const float* in_scale, const float* in_shift,
-                              float* partial, float* dw_oihw, void* stream) {
+                              float* partial, float* dw_oihw, void* stream, bool x_up2) {
   SPCL_CHECK_ARG(x && dy && partial && dw_oihw, "conv3x3_wgrad: null pointer");
   SPCL_CHECK_ARG(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3_wgrad: bad shape");
   SPCL_CHECK_ARG(CinK % 16 == 0 && CoutS % 16 == 0 && Cin <= CinK && Cout <= CoutS, "conv3x3_wgrad: channel padding");
@@ -564,12 +578,13 @@ static int conv3x3_wgrad_impl(const void* x, const void* x2, const void* dy, int
     spcl_wgrad_item it;
     if (wide_item(it, x, dy, N, H, W, Cin, CinS, CinK, Cout, CoutS, in_mode, in_scale, in_shift, dw_oihw)) {
       it.x2 = x2;  // (the batched kernel reads a 64-channel block from the tensor that holds it)
+      it.x_up2 = x_up2 ? 1 : 0;
       return spcl_conv3x3_wgrad_batched(&it, 1, 0, partial, stream);
     }
   }
   WgradPlan p = wgrad_plan(N, H, W, CinK, CoutS, dtype == SPCL_F32 ? 4 : 2);
   WgradArgs a;
-  a.x = x; a.x2 = x2; a.xsplit = x2 ? CinK / 2 : 0; a.dy = dy; a.in_scale = in_scale; a.in_shift = in_shift; a.partial = partial;
+  a.x = x; a.x2 = x2; a.xsplit = x2 ? CinK / 2 : 0; a.x_up2 = x_up2 ? 1 : 0; a.dy = dy; a.in_scale = in_scale; a.in_shift = in_shift; a.partial = partial;
   a.N = N; a.H = H; a.W = W; a.CinS = CinS; a.CinK = CinK; a.CoutS = CoutS; a.in_mode = in_mode;
   a.tilesX = p.tilesX; a.tilesY = p.tilesY; a.ntiles = p.ntiles; a.nblk_ci = p.nblk_ci; a.nblk_co = p.nblk_co;
   static const int env_dbuf = getenv("SPCL_WGRAD_DBUF") ? atoi(getenv("SPCL_WGRAD_DBUF")) : 1;

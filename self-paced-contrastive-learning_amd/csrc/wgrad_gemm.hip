@@ -43,6 +43,7 @@ constexpr int WB_SLAB = 9 * 64 * 64;  // floats per workgroup partial
 struct WbItem {
   const bf16_t* x;
   const bf16_t* x2;  // non-null: channels [Cin / 2, Cin) of the input live here, [0, Cin / 2) in x (pixel stride Cin / 2 each)
+  int x_up2;         // 1: x is [N][H / 2][W / 2][CinS], the layer's input its nearest x2 upsample
   const bf16_t* dy;
   const float* in_scale;
   const float* in_shift;
@@ -227,8 +228,10 @@ __global__ __launch_bounds__(768) void wgrad_gemm_kernel(WbArgs a) {
     unsigned xmask = 0;
     auto load_x = [&]() {
       const int y0 = cx.ty * TH - 1, x0 = cx.tx * 16 - 1;
+      const bool up2 = it.x_up2 != 0;  // (fine pixel (gy, gx) = pixel (gy >> 1, gx >> 1) of the image's half-resolution plane)
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(xg + (((long)cx.n * H + y0) * W + x0) * CinS), 0, 0x7fffffff, 0x00020000);
+          (void*)(up2 ? xg + (long)cx.n * (H >> 1) * (W >> 1) * CinS : xg + (((long)cx.n * H + y0) * W + x0) * CinS), 0,
+          0x7fffffff, 0x00020000);
       xmask = 0;
 #pragma unroll
       for (int i = 0; i < NXI; ++i) {
@@ -236,7 +239,8 @@ __global__ __launch_bounds__(768) void wgrad_gemm_kernel(WbArgs a) {
           const int gy = y0 + (xyx[i] >> 8), gx = x0 + (xyx[i] & 255);
           const bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
           xmask |= (ok ? 1u : 0u) << i;
-          const unsigned off = (unsigned)((xyx[i] >> 8) * xrow2 + (xyx[i] & 255) * xcol2 + xc2);
+          const unsigned off = up2 ? (unsigned)((((gy >> 1) * (W >> 1)) + (gx >> 1)) * xcol2 + xc2)
+                                   : (unsigned)((xyx[i] >> 8) * xrow2 + (xyx[i] & 255) * xcol2 + xc2);
           rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(ok ? off : WB_OOB), 0, 0);
         }
       }
@@ -561,7 +565,7 @@ static int wb_plan(const spcl_wgrad_item* items, int n, WbPlan& pl) {
   for (int i = 0; i < n; ++i) {
     WbItem& w = pl.args.it[i];
     const spcl_wgrad_item& s = items[i];
-    w.x = (const bf16_t*)s.x; w.x2 = (const bf16_t*)s.x2; w.dy = (const bf16_t*)s.dy; w.in_scale = s.in_scale; w.in_shift = s.in_shift; w.dw = s.dw_oihw;
+    w.x = (const bf16_t*)s.x; w.x2 = (const bf16_t*)s.x2; w.x_up2 = s.x_up2; w.dy = (const bf16_t*)s.dy; w.in_scale = s.in_scale; w.in_shift = s.in_shift; w.dw = s.dw_oihw;
     w.N = s.N; w.H = s.H; w.W = s.W; w.Cin = s.Cin; w.Cout = s.Cout; w.CinS = s.CinS; w.CoutS = s.CoutS;
     w.in_mode = s.in_mode;
     w.tilesX = cdiv(s.W, 16);
@@ -614,6 +618,7 @@ static bool wb_item_ok(const spcl_wgrad_item& s) {
          s.Cout % 64 == 0 && s.CinS >= s.Cin && s.CoutS >= s.Cout && s.CinS % 8 == 0 && s.CoutS % 8 == 0 &&
          (s.in_mode == 0 || (s.in_mode == 1 && s.in_scale && s.in_shift)) &&
          (s.x2 == nullptr || (s.in_mode == 0 && s.Cin % 128 == 0 && s.CinS == s.Cin)) &&
+         (s.x_up2 == 0 || (s.in_mode == 0 && s.x2 == nullptr && s.H % 2 == 0 && s.W % 2 == 0)) &&
          (long)s.N * s.H * s.W * (s.CinS > s.CoutS ? s.CinS : s.CoutS) < (1L << 31);
 }
 

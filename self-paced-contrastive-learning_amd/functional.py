@@ -571,10 +571,22 @@ class ActLink:
         self.rows, self.dx_ptr = None, 0
 
 
+class UpLink:
+    """Between a block whose activation has ONE consumer -- an up-convolution reading it at half resolution
+    (``BlockCfg.up_in``) -- and that consumer: the consumer's backward leaves the FINE input gradient here instead of summing
+    its 2 x 2 windows, and returns an unwritten half-resolution tensor whose address the block recognises; the block's
+    BatchNorm-backward reduction pass forms the sums on its way (spcl_bnrelu_backward_up2).  A gradient that arrives at the
+    block with any other address means somebody else contributed to it: the block raises instead of using garbage."""
+    __slots__ = ("d_up", "dx_ptr")
+
+    def __init__(self):
+        self.d_up, self.dx_ptr = None, 0
+
+
 class BlockCfg:
     """Static configuration of one fused Conv-BN-ReLU(-Conv-BN-ReLU)(-MaxPool) block call."""
     __slots__ = ("dtype", "training", "momentum", "eps", "track", "need_act", "need_pool", "image_input", "buffers",
-                 "link_in", "link_out", "act_dst", "up2", "lazy_act", "link_act", "x2_link", "bn_link", "x2_bn")
+                 "link_in", "link_out", "act_dst", "up2", "lazy_act", "link_act", "x2_link", "bn_link", "x2_bn", "up_in", "up_link")
 
     def __init__(self, dtype, training, momentum, eps, track, need_act, need_pool, image_input, buffers):
         self.dtype, self.training, self.momentum, self.eps, self.track = dtype, training, momentum, eps, track
@@ -586,6 +598,8 @@ class BlockCfg:
         self.lazy_act = False  # the activation's only consumer applies BN + ReLU itself: return the RAW output, offer link_act
         self.link_act = None
         self.x2_link = None    # ActLink of the producer of ``x2`` when that tensor is its RAW output (conv_block(..., x2=...))
+        self.up_in = False     # conv_bn_relu: the input is nn.Upsample(x2) of the HALF-resolution tensor passed in (read in place)
+        self.up_link = None    # UpLink shared by that conv_bn_relu call and the block that produced its input
         self.bn_link = None    # conv_bn_relu: its (raw output, BN coefficients) offered to the consumer of its activation ...
         self.x2_bn = None      # ... conv_block(..., x2=that activation): its dgrad leaves that BatchNorm's backward sums there
         self.up2 = False      # the activation's only consumer is nn.Upsample(scale_factor=2): write it 2x2-replicated, return
@@ -753,10 +767,10 @@ class DeferredWgrads:
         self.items, self.keep, self.targets = [], [], set()
         self.tails = []
 
-    def add(self, x_store, dy, scale, shift, sink, N, H, W, cin, cin_s, cout, cout_s, in_mode, x2=None):
+    def add(self, x_store, dy, scale, shift, sink, N, H, W, cin, cin_s, cout, cout_s, in_mode, x2=None, x_up2=False):
         it = _n.WgradItem(x_store.data_ptr(), dy.data_ptr(), scale.data_ptr() if scale is not None else None,
                           shift.data_ptr() if shift is not None else None, sink.data_ptr(), N, H, W, cin, cin_s, cout,
-                          cout_s, in_mode, x2.data_ptr() if x2 is not None else None)
+                          cout_s, in_mode, x2.data_ptr() if x2 is not None else None, 1 if x_up2 else 0)
         self.items.append(it)
         self.keep.append((x_store, dy, scale, shift, x2))  # operands stay alive until the launch
         self.targets.add(sink.data_ptr())
@@ -794,6 +808,7 @@ class DeferredWgrads:
 # the whole UNet's eleven wide layers and ten narrow ones then leave in ONE batched launch at the gather)
 _QUEUE_MAX = (min(_n.WGRAD_BATCH_MAX, int(os.environ.get("SPCL_WGRAD_QUEUE_MAX", _n.WGRAD_BATCH_MAX))),
               min(_n.WGRAD_TAILS_MAX, int(os.environ.get("SPCL_WGRAD_QUEUE_MAX", _n.WGRAD_TAILS_MAX))))
+_CONV_UP2 = os.environ.get("SPCL_CONV_UP2", "1") != "0"  # A/B switch: 0 writes the x2-upsampled activations (BlockCfg.up2)
 _UP2_BWD_FUSED = os.environ.get("SPCL_UP2_BWD_FUSED", "1") != "0"  # A/B switch: 0 sums the 2x2 gradients in a launch of its own
 _CONV_SPLIT = os.environ.get("SPCL_CONV_SPLIT", "1") != "0"  # A/B switch: 0 leaves that level's gradient as one interleaved tensor
 _CONV_CAT = os.environ.get("SPCL_CONV_CAT", "1") != "0"  # A/B switch: 0 materialises the 16-channel decoder concatenation
@@ -845,6 +860,37 @@ def _wgrad(x_store, dy, dt_code, N, H, W, cin, cin_s, cin_k, cout, cout_s, in_mo
         return dw
     launch()
     return dw
+
+
+def _wgrad_up2(x_half, dy, dt_code, N, H, W, cin, cout, cout_s, sink=None):
+    """weight gradient of the up-convolution, its input ``nn.Upsample(x2)(x_half)`` read from the half-resolution tensor
+    (spcl_conv3x3_wgrad_up2 / spcl_wgrad_item::x_up2); H x W = the convolution's size"""
+    dev = dy.device
+    queue = sink_queue(sink)
+    if queue is not None and _n.call("spcl_conv_wgrad_batched_supported", dt_code, cin, cin, cout, cout_s, 0):
+        queue.add(x_half, dy, None, None, sink, N, H, W, cin, cin, cout, cout_s, 0, x_up2=True)
+        return None
+    nbytes = _n.call("spcl_conv_wgrad_workspace_bytes", N, H, W, cin, cout_s)
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    dw = _grad_buffer(sink, (cout, cin, 3, 3), dev)
+
+    def launch():
+        _n.call("spcl_conv3x3_wgrad_up2", _n.ptr(x_half), _n.ptr(dy), dt_code, N, H, W, cin, cout, cout_s, _n.ptr(ws),
+                _n.ptr(dw), _n.stream())
+
+    if queue is not None and _TAILS:
+        if queue.capture_tail(sink, (ws, dy, x_half), launch):
+            return None
+        return dw
+    launch()
+    return dw
+
+
+def up_in_shape_ok(N, cin, H, W, cout, dtype):
+    """can ``conv_bn_relu`` read ``nn.Upsample(x2)`` of a dense [N, cin, H/2, W/2] tensor in its loaders (H x W the
+    convolution's size)?  (spcl_conv_up2_supported: bf16, sizes the specialised kernels tile)"""
+    return bool(_CONV_UP2 and dtype == torch.bfloat16 and cin % 16 == 0
+                and _n.call("spcl_conv_up2_supported", _n.dtype_code(dtype), N, H, W, cin, _ru16(cout)))
 
 
 def _wgrad_cat(xa, xb, dy, dt_code, N, H, W, chalf, cout, cout_s, sink=None, xb_scale=None, xb_shift=None):
@@ -1192,7 +1238,18 @@ class _ConvBlockFn(torch.autograd.Function):
         g_nc = broadcast_rows(d_act, dtype) if (_BCAST and d_pool is None and d_act is not None and not ctx.up2
                                                   and d_act.shape[1] == cout_s) else None
         d_up = None
-        if ctx.up2 and d_act is not None:
+        ul = getattr(cfg, "up_link", None)
+        if ul is not None and ul.d_up is not None:
+            # the consuming up-convolution left its FINE input gradient in the link (UpLink) and sent an unwritten tensor
+            du, ptr = ul.d_up, ul.dx_ptr
+            ul.d_up, ul.dx_ptr = None, 0
+            got = to_nhwc_padded(d_act, dtype).data_ptr() if d_act is not None else 0
+            if got != ptr or d_pool is not None:
+                raise RuntimeError("conv_block: the activation read at half resolution by an up-convolution received a gradient "
+                                   "from somewhere else as well (its 2 x 2 sums were left to this block): run with "
+                                   "SPCL_UP2_BWD_FUSED=0")
+            d_up, d_act = du, None
+        elif ctx.up2 and d_act is not None:
             # the forward returned the x2-upsampled activation: its gradient is summed over the 2x2 replicas first -- inside
             # the BatchNorm-backward reduction pass (spcl_bnrelu_backward_up2), or by its own launch
             du = to_nhwc_padded(d_act, dtype)
@@ -1389,6 +1446,9 @@ class _ConvBNReLUFn(torch.autograd.Function):
         dtype, dev = cfg.dtype, x.device
         dtc = _n.dtype_code(dtype)
         N, cin, H, W = x.shape
+        up_in = bool(getattr(cfg, "up_in", False))
+        if up_in:
+            H, W = 2 * H, 2 * W  # the convolution's size: x is the half-resolution tensor, upsampled by the loaders
         cout = w.shape[0]
         cout_s = _ru16(cout)
         xs = to_nhwc_padded(x.detach(), dtype)
@@ -1401,7 +1461,18 @@ class _ConvBNReLUFn(torch.autograd.Function):
             wp, wp_t = _pack_both(w, dtc, dtype)
         else:
             wp, wp_t = _pack(w, 0, dtc, dtype), None
-        y, s = _conv(xs, dtc, dtype, N, H, W, cin_s, cin_s, cout_s, wp, 0, None, None, cfg.training)
+        if up_in:
+            assert cin_s == cin, "the in-place upsample needs an unpadded channel count"
+            y = torch.empty(N, H, W, cout_s, dtype=dtype, device=dev)
+            s = None
+            if cfg.training:
+                nt = _n.call("spcl_conv_stat_rows", dtc, N, H, W, cin_s, cout_s)
+                s = torch.empty(_n.call("spcl_bn_stats_elems", nt, cout_s), dtype=torch.float32, device=dev)
+                s.ntiles = nt
+            _n.call("spcl_conv3x3_forward_up2", _n.ptr(xs), dtc, N, H, W, cin_s, cout_s, _n.ptr(wp), _n.ptr(y), _n.ptr(s),
+                    _n.stream())
+        else:
+            y, s = _conv(xs, dtc, dtype, N, H, W, cin_s, cin_s, cout_s, wp, 0, None, None, cfg.training)
         st = _bn_stats(s, cfg, cout, cout_s, gamma, beta, 0, dev)
         if bool(getattr(cfg, "lazy_act", False)) and getattr(cfg, "act_dst", None) is None and cout == cout_s:
             # the only consumer (the next block's two-tensor convolution) applies this BatchNorm + ReLU in its loaders
@@ -1416,6 +1487,7 @@ class _ConvBNReLUFn(torch.autograd.Function):
         ctx.cfg = cfg
         cfg.bn_link = ActLink(y, st, N, H, W, cout, cout_s) if (need_bwd and cout == cout_s) else None
         ctx.meta = (N, cin, H, W, cout, cout_s, cin_s, x.dtype)
+        ctx.up_in = up_in
         return nhwc_to_logical(act, cout)
 
     @staticmethod
@@ -1423,6 +1495,7 @@ class _ConvBNReLUFn(torch.autograd.Function):
         xs, y, st, w = ctx.saved_tensors
         cfg = ctx.cfg
         N, cin, H, W, cout, cout_s, cin_s, xdt = ctx.meta
+        up_in = ctx.up_in
         dtype = cfg.dtype
         dtc = _n.dtype_code(dtype)
         da_sl = nhwc_channel_slice(d_act, dtype)
@@ -1438,12 +1511,24 @@ class _ConvBNReLUFn(torch.autograd.Function):
                                      dact_stride=da_stride)
         if bl is not None:
             bl.rows, bl.dx_ptr = None, 0
-        dw = _wgrad(xs, dy, dtc, N, H, W, cin, cin_s, cin_s, cout, cout_s, 0, None, None, sk[0]) \
-            if ctx.needs_input_grad[1] else None
+        if not ctx.needs_input_grad[1]:
+            dw = None
+        elif up_in:
+            dw = _wgrad_up2(xs, dy, dtc, N, H, W, cin, cout, cout_s, sk[0])
+        else:
+            dw = _wgrad(xs, dy, dtc, N, H, W, cin, cin_s, cin_s, cout, cout_s, 0, None, None, sk[0])
         dx = None
         if ctx.needs_input_grad[0]:
             wp_t = ctx.packed_t if ctx.packed_t is not None else _pack(w, 1, dtc, dtype)
             dxs, _ = _conv(dy, dtc, dtype, N, H, W, cout_s, cout_s, cin_s, wp_t, 0, None, None, False)
+            if up_in:  # the gradient w.r.t. the half-resolution input: the 2 x 2 sums of the fine gradient
+                dsum = torch.empty(N, H // 2, W // 2, cin_s, dtype=dtype, device=dxs.device)
+                ul = getattr(cfg, "up_link", None)
+                if ul is not None and _UP2_BWD_FUSED and cfg.training:
+                    ul.d_up, ul.dx_ptr = dxs, dsum.data_ptr()  # (dsum stays unwritten: the producing block sums, see UpLink)
+                else:
+                    _n.call("spcl_upsample2x_backward", _n.ptr(dxs), _n.ptr(dsum), dtc, N, H // 2, W // 2, cin_s, _n.stream())
+                dxs = dsum
             dx = nhwc_to_logical(dxs, cin)
             if dx.dtype != xdt:
                 dx = dx.to(xdt)

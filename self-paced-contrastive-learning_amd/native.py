@@ -62,6 +62,9 @@ _SIGNATURES = {
     "spcl_conv_split_bnstats_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "spcl_conv3x3_dgrad_split_bnstats": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P,
                                                  _P]),
+    "spcl_conv_up2_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "spcl_conv3x3_forward_up2": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "spcl_conv3x3_wgrad_up2": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "spcl_conv3x3_wgrad_cat": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "spcl_bn_stats_elems": (c_size_t, [c_int, c_int]),
     "spcl_conv3x3_forward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P,
@@ -159,7 +162,7 @@ class WgradItem(ctypes.Structure):
     """``spcl_wgrad_item`` of include/spcl_hip.h (one layer of a batched weight-gradient launch)"""
     _fields_ = [("x", c_void_p), ("dy", c_void_p), ("in_scale", c_void_p), ("in_shift", c_void_p),
                 ("dw_oihw", c_void_p), ("N", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int), ("CinS", c_int),
-                ("Cout", c_int), ("CoutS", c_int), ("in_mode", c_int), ("x2", c_void_p)]
+                ("Cout", c_int), ("CoutS", c_int), ("in_mode", c_int), ("x2", c_void_p), ("x_up2", c_int)]
 
 
 class PackItem(ctypes.Structure):
@@ -179,7 +182,7 @@ class WgradTail(ctypes.Structure):
 
 WGRAD_BATCH_MAX = 16
 WGRAD_TAILS_MAX = 16
-_NO_STATUS = ("spcl_abi_version", "spcl_image_autocorr_rows", "spcl_conv_dgrad_bnstats_image_supported", "spcl_conv16_bwd_fused_supported", "spcl_conv16_bwd_fused_splits", "spcl_conv_num_tiles", "spcl_conv_stat_rows", "spcl_conv_set_gemm", "spcl_supcon_unit_gradient_block", "spcl_conv_cat_supported", "spcl_conv_split_supported", "spcl_conv_split_bnstats_supported", "spcl_conv1x1_bwd_rows", "spcl_profile_count", "spcl_conv_dgrad_bnstats_supported", "spcl_conv_dgrad_poolstats_supported",
+_NO_STATUS = ("spcl_abi_version", "spcl_image_autocorr_rows", "spcl_conv_dgrad_bnstats_image_supported", "spcl_conv16_bwd_fused_supported", "spcl_conv16_bwd_fused_splits", "spcl_conv_num_tiles", "spcl_conv_stat_rows", "spcl_conv_set_gemm", "spcl_supcon_unit_gradient_block", "spcl_conv_cat_supported", "spcl_conv_up2_supported", "spcl_conv_split_supported", "spcl_conv_split_bnstats_supported", "spcl_conv1x1_bwd_rows", "spcl_profile_count", "spcl_conv_dgrad_bnstats_supported", "spcl_conv_dgrad_poolstats_supported",
               "spcl_conv_wgrad_batched_supported")
 
 

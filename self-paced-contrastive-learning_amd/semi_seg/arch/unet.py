@@ -101,6 +101,7 @@ class _ConvBlock(nn.Module):
         self._up2 = False           # this call's activation only feeds nn.Upsample(x2): return it upsampled (one launch less)
         self._x2_link = None        # functional.ActLink of the up-convolution whose RAW output this call's x2 is
         self._x2_bn = None          # functional.ActLink of the up-convolution whose ACTIVATION this call's x2 is
+        self._up_link = None        # functional.UpLink shared with the up-convolution that reads this call's activation
         self._lazy = False          # this call's activation only feeds the 1x1 head, which applies BN + ReLU itself
         self._link_act = None       # functional.ActLink of a lazy call (UNet.forward hands it to the head)
 
@@ -131,6 +132,7 @@ class _ConvBlock(nn.Module):
         cfg.act_dst, self._act_dst = self._act_dst, None
         cfg.up2, self._up2 = (self._up2 and len(self._forward_hooks) == 0), False
         cfg.lazy_act, self._lazy = (self._lazy and len(self._forward_hooks) == 0), False
+        cfg.up_link, self._up_link = self._up_link, None
         cfg.x2_link, self._x2_link = (self._x2_link if x2 is not None else None), None
         cfg.x2_bn, self._x2_bn = (self._x2_bn if x2 is not None else None), None
         act, pooled = F_hip.conv_block(x, c[0].weight, c[1].weight, c[1].bias, c[3].weight, c[4].weight, c[4].bias, cfg, x2)
@@ -161,7 +163,7 @@ class _UpConv(nn.Module):
         self._link_act = None
         self._bn_link = None  # functional.ActLink of the last call: (raw output, coefficients), for the consumer's dgrad
 
-    def forward(self, x, pre_upsampled: bool = False, lazy: bool = False):
+    def forward(self, x, pre_upsampled: bool = False, lazy: bool = False, virtual_up: bool = False, up_link=None):
         """``pre_upsampled``: ``x`` already is the x2-upsampled tensor (the producing block wrote it that way, BlockCfg.up2);
         ``lazy``: return the RAW convolution output -- the only consumer applies this BatchNorm + ReLU itself and takes the
         coefficients from ``self._link_act`` (UNet.forward hands it to the next block: functional.ActLink)"""
@@ -173,7 +175,9 @@ class _UpConv(nn.Module):
                              ((bn.running_mean, bn.running_var, bn.num_batches_tracked),))
         cfg.act_dst, self._act_dst = self._act_dst, None
         cfg.lazy_act = bool(lazy) and cfg.act_dst is None
-        if not pre_upsampled:
+        cfg.up_in = bool(virtual_up)  # the convolution and its weight gradient read nn.Upsample(x2)(x) from x itself
+        cfg.up_link = up_link if virtual_up else None
+        if not pre_upsampled and not virtual_up:
             x = F_hip.upsample2x(x, dtype)  # nn.Upsample(scale_factor=2), nearest
         out = F_hip.conv_bn_relu(x, self.up[1].weight, bn.weight, bn.bias, cfg)
         self._link_act = cfg.link_act
@@ -274,7 +278,15 @@ class UNet(nn.Module):
             up2_first = (not encoder_only and k == len(_ENCODER) - 1 and x.is_cuda and _FUSED_UPSAMPLE
                          and len(blk._forward_hooks) == 0 and len(self._Up5._forward_hooks) == 0
                          and len(self._Up5.up[0]._forward_hooks) == 0)
-            blk._up2 = up2_first  # Conv5's activation only feeds Up5's nn.Upsample: written x2-upsampled directly
+            virt_first = False
+            if up2_first:  # ... or not written upsampled at all: Up5's loaders read it at half resolution (functional.up_in_shape_ok)
+                hh, ww = int(x.shape[2]) >> k, int(x.shape[3]) >> k
+                virt_first = F_hip.up_in_shape_ok(int(x.shape[0]), self.get_channel_dim(name), 2 * hh, 2 * ww,
+                                                  self.get_channel_dim("Up_conv5"),
+                                                  self._Up5._compute_dtype or _config.get_compute_dtype())
+            blk._up2 = up2_first and not virt_first  # Conv5's activation only feeds Up5's nn.Upsample: written x2-upsampled directly
+            up_link = F_hip.UpLink() if (up2_first and virt_first) else None
+            blk._up_link = up_link
             if k > 0:
                 prev = getattr(self, "_" + _ENCODER[k - 1])
                 blk._link_in, prev._link_out = prev._link_out, None
@@ -290,7 +302,7 @@ class UNet(nn.Module):
                 e.register_hook(lambda g, cb=cb: cb() and None)
         # decoding + concat path (unet.py:193-230)
         d = skips["Conv5"]
-        pre_up = up2_first
+        pre_up, virt_up = up2_first and not virt_first, up2_first and virt_first
         for lvl, skip in ((5, "Conv4"), (4, "Conv3"), (3, "Conv2"), (2, "Conv1")):
             up = getattr(self, f"_Up{lvl}")
             if skip in cats:
@@ -303,14 +315,22 @@ class UNet(nn.Module):
                        and self.get_channel_dim(skip) <= 32
                        and (up._compute_dtype or _config.get_compute_dtype()) ==
                            (blk._compute_dtype or _config.get_compute_dtype()))
-            d = up(d, pre_upsampled=pre_up, lazy=lazy_up)
+            d = up(d, pre_upsampled=pre_up, lazy=lazy_up, virtual_up=virt_up, up_link=up_link)
             lazy_up = lazy_up and up._link_act is not None
             # this decoder block's activation feeds the next level's nn.Upsample only (not the last block, not the `until` one)
             nxt = getattr(self, f"_Up{lvl - 1}", None) if lvl > 2 else None
             pre_up = (nxt is not None and until != f"Up_conv{lvl}" and _FUSED_UPSAMPLE and d.is_cuda
                       and len(blk._forward_hooks) == 0 and len(nxt._forward_hooks) == 0
                       and len(nxt.up[0]._forward_hooks) == 0)
+            virt_up = False
+            if pre_up:  # ... read at half resolution by the next up-convolution's loaders instead, where they can
+                virt_up = F_hip.up_in_shape_ok(int(d.shape[0]), self.get_channel_dim(f"Up_conv{lvl}"), 2 * int(d.shape[2]),
+                                               2 * int(d.shape[3]), self.get_channel_dim(f"Up_conv{lvl - 1}"),
+                                               nxt._compute_dtype or _config.get_compute_dtype())
+                pre_up = not virt_up
             blk._up2 = pre_up
+            up_link = F_hip.UpLink() if virt_up else None
+            blk._up_link = up_link
             # the last block's activation feeds the 1x1 head only: the head applies that BatchNorm + ReLU in its own loader
             # (forward and backward) and leaves the BatchNorm-backward sums; no activation tensor, two passes less
             blk._lazy = (lvl == 2 and until is None and _LAZY_HEAD and d.is_cuda and len(blk._forward_hooks) == 0

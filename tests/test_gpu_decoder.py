@@ -432,3 +432,38 @@ def test_split_dgrad_leaves_the_up_convolutions_bn_sums(monkeypatch):
     # the layers ABOVE the first affected BatchNorm see identical gradients
     for k in ("_Deconv_1x1.weight", "_Up_conv2.conv.3.weight", "_Up_conv2.conv.0.weight"):
         assert torch.equal(ga[k], gb[k]), k
+
+
+def test_up_link_refuses_a_second_contribution():
+    """UpLink: the up-convolution that reads a block's activation at half resolution leaves the 2 x 2 gradient sums to that
+    block and sends an unwritten tensor -- if anything else contributed to the activation's gradient the block must say so
+    (it cannot tell garbage from a gradient), and with the single consumer the result equals the upsampled-tensor path."""
+    import spcl_amd  # noqa
+    from spcl_amd import functional as F
+    from spcl_amd.semi_seg.arch.unet import _ConvBlock, _UpConv
+    torch.manual_seed(3)
+    blk = _ConvBlock(32, 64).cuda().train()
+    up = _UpConv(64, 32).cuda().train()
+    for m in (blk, up):
+        m._compute_dtype = torch.bfloat16
+    x = torch.rand(2, 32, 28, 28, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+    assert F.up_in_shape_ok(2, 64, 56, 56, 32, torch.bfloat16)
+
+    def run(extra, virtual):
+        for m in (blk, up):
+            m.zero_grad(set_to_none=True)
+        link = F.UpLink() if virtual else None
+        blk._plan, blk._up_link = (True, False), link
+        a = blk(x)
+        o = up(a, virtual_up=virtual, up_link=link)
+        loss = o.float().square().mean() + (a.float().mean() if extra else 0.0)
+        loss.backward()
+        torch.cuda.synchronize()
+        return [p.grad.clone() for p in list(blk.parameters()) + list(up.parameters())]
+
+    ga, gb = run(False, True), run(False, False)
+    for a, b in zip(ga, gb):
+        assert torch.equal(a, b)
+    with pytest.raises(RuntimeError, match="half resolution"):
+        run(True, True)
+    run(True, False)  # (the ordinary path takes a second consumer)
