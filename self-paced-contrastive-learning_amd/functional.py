@@ -553,22 +553,24 @@ class PoolLink:
     epilogue of its own input-gradient kernel (spcl_conv3x3_dgrad_poolstats): this block's raw second-conv output and BN
     coefficients.  The next block fills ``rows`` / ``dx_ptr``; this block's backward uses them if the pooled gradient it
     receives IS that kernel's output (same storage: nothing else contributed to it), else runs its own reduction pass."""
-    __slots__ = ("yb", "stb", "N", "H", "W", "cout_s", "rows", "dx_ptr")
+    __slots__ = ("yb", "stb", "N", "H", "W", "cout_s", "rows", "dx_ptr", "holder")
 
     def __init__(self, yb, stb, N, H, W, cout_s):
         self.yb, self.stb, self.N, self.H, self.W, self.cout_s = yb, stb, N, H, W, cout_s
-        self.rows, self.dx_ptr = None, 0
+        # ``holder``: the gradient tensor ``dx_ptr`` is the address of, kept alive until the consumer has compared -- a freed
+        # tensor's address is the first thing the allocator hands out again (to the re-layout copy of a foreign gradient, say)
+        self.rows, self.dx_ptr, self.holder = None, 0, None
 
 
 class ActLink:
     """A block whose activation has ONE consumer that applies the block's last BatchNorm + ReLU itself (``BlockCfg.lazy_act``:
     the 1x1 head, ``conv1x1_bn``): the raw second-conv output and the BN coefficients the consumer needs, and -- filled by
     the consumer's backward -- the BatchNorm-backward partial sums it left next to the activation gradient."""
-    __slots__ = ("yb", "stb", "N", "H", "W", "C", "cs", "rows", "dx_ptr")
+    __slots__ = ("yb", "stb", "N", "H", "W", "C", "cs", "rows", "dx_ptr", "holder")
 
     def __init__(self, yb, stb, N, H, W, C, cs):
         self.yb, self.stb, self.N, self.H, self.W, self.C, self.cs = yb, stb, N, H, W, C, cs
-        self.rows, self.dx_ptr = None, 0
+        self.rows, self.dx_ptr, self.holder = None, 0, None  # (holder: see PoolLink)
 
 
 class UpLink:
@@ -577,10 +579,10 @@ class UpLink:
     its 2 x 2 windows, and returns an unwritten half-resolution tensor whose address the block recognises; the block's
     BatchNorm-backward reduction pass forms the sums on its way (spcl_bnrelu_backward_up2).  A gradient that arrives at the
     block with any other address means somebody else contributed to it: the block raises instead of using garbage."""
-    __slots__ = ("d_up", "dx_ptr")
+    __slots__ = ("d_up", "dx_ptr", "holder", "version")
 
     def __init__(self):
-        self.d_up, self.dx_ptr = None, 0
+        self.d_up, self.dx_ptr, self.holder, self.version = None, 0, None, 0
 
 
 class BlockCfg:
@@ -1241,10 +1243,14 @@ class _ConvBlockFn(torch.autograd.Function):
         ul = getattr(cfg, "up_link", None)
         if ul is not None and ul.d_up is not None:
             # the consuming up-convolution left its FINE input gradient in the link (UpLink) and sent an unwritten tensor
-            du, ptr = ul.d_up, ul.dx_ptr
-            ul.d_up, ul.dx_ptr = None, 0
-            got = to_nhwc_padded(d_act, dtype).data_ptr() if d_act is not None else 0
-            if got != ptr or d_pool is not None:
+            # (compared while the link still holds the unwritten tensor: released first, its address is the first thing the
+            # allocator hands out again -- to the very re-layout copy a foreign gradient would need)
+            du, holder = ul.d_up, ul.holder
+            same = (d_act is not None and d_pool is None and d_act.data_ptr() == ul.dx_ptr and d_act.dtype == holder.dtype
+                    and holder._version == ul.version and nhwc_channel_slice(d_act, dtype) is None
+                    and to_nhwc_padded(d_act, dtype).data_ptr() == ul.dx_ptr)
+            ul.d_up, ul.dx_ptr, ul.holder = None, 0, None
+            if not same:
                 raise RuntimeError("conv_block: the activation read at half resolution by an up-convolution received a gradient "
                                    "from somewhere else as well (its 2 x 2 sums were left to this block): run with "
                                    "SPCL_UP2_BWD_FUSED=0")
@@ -1291,9 +1297,9 @@ class _ConvBlockFn(torch.autograd.Function):
             dyb, dgb, dbb = _bnrelu_bwd(yb, da_s, dp_s, dtc, dtype, N, H, W, cout, cout_s, stb, cfg.training, sk[4:6],
                                         dact_stride=da_stride, d_up=d_up)
         if lk is not None:
-            lk.rows, lk.dx_ptr = None, 0
+            lk.rows, lk.dx_ptr, lk.holder = None, 0, None
         if la is not None:
-            la.rows, la.dx_ptr = None, 0
+            la.rows, la.dx_ptr, la.holder = None, 0, None
         wpa_t, wpb_t = ctx.packed_t
         if wpb_t is None:
             wpb_t = _pack(wb, 1, dtc, dtype)
@@ -1363,7 +1369,7 @@ class _ConvBlockFn(torch.autograd.Function):
                         _n.ptr(dxs), _n.ptr(li.yb), li.H, li.W, _n.ptr(li.stb[2]), _n.ptr(li.stb[3]), _n.ptr(li.stb[0]),
                         _n.ptr(rows), _n.stream())
                 rows.ntiles = nt
-                li.rows, li.dx_ptr = rows, dxs.data_ptr()
+                li.rows, li.dx_ptr, li.holder = rows, dxs.data_ptr(), dxs
             split = None
             if (dxs is None and x2s is not None and _CONV_SPLIT
                     and _n.call("spcl_conv_split_supported", dtc, N, H, W, cout_s, cin_s)):
@@ -1380,7 +1386,7 @@ class _ConvBlockFn(torch.autograd.Function):
                     _n.call("spcl_conv3x3_dgrad_split_bnstats", _n.ptr(dya), dtc, N, H, W, cout_s, cin_s, _n.ptr(wpa_t),
                             _n.ptr(split[0]), _n.ptr(split[1]), _n.ptr(xb.yb), _n.ptr(xb.stb[2]), _n.ptr(xb.stb[3]),
                             _n.ptr(xb.stb[0]), _n.ptr(rows), _n.stream())
-                    xb.rows, xb.dx_ptr = rows, split[1].data_ptr()
+                    xb.rows, xb.dx_ptr, xb.holder = rows, split[1].data_ptr(), split[1]
                 else:
                     _n.call("spcl_conv3x3_forward_split", _n.ptr(dya), dtc, N, H, W, cout_s, cin_s, _n.ptr(wpa_t),
                             _n.ptr(split[0]), _n.ptr(split[1]), _n.stream())
@@ -1510,7 +1516,7 @@ class _ConvBNReLUFn(torch.autograd.Function):
             dy, dg, db = _bnrelu_bwd(y, da_s, None, dtc, dtype, N, H, W, cout, cout_s, st, cfg.training, sk[1:3],
                                      dact_stride=da_stride)
         if bl is not None:
-            bl.rows, bl.dx_ptr = None, 0
+            bl.rows, bl.dx_ptr, bl.holder = None, 0, None
         if not ctx.needs_input_grad[1]:
             dw = None
         elif up_in:
@@ -1525,7 +1531,9 @@ class _ConvBNReLUFn(torch.autograd.Function):
                 dsum = torch.empty(N, H // 2, W // 2, cin_s, dtype=dtype, device=dxs.device)
                 ul = getattr(cfg, "up_link", None)
                 if ul is not None and _UP2_BWD_FUSED and cfg.training:
-                    ul.d_up, ul.dx_ptr = dxs, dsum.data_ptr()  # (dsum stays unwritten: the producing block sums, see UpLink)
+                    # (dsum stays unwritten: the producing block sums, see UpLink; its version counter tells an in-place
+                    # accumulation into it -- autograd adds a second contribution that way when it owns the buffer)
+                    ul.d_up, ul.dx_ptr, ul.holder, ul.version = dxs, dsum.data_ptr(), dsum, dsum._version
                 else:
                     _n.call("spcl_upsample2x_backward", _n.ptr(dxs), _n.ptr(dsum), dtc, N, H // 2, W // 2, cin_s, _n.stream())
                 dxs = dsum
@@ -1640,7 +1648,7 @@ class _Conv1x1BnFn(torch.autograd.Function):
         _n.call("spcl_conv1x1_backward_bn", _n.ptr(link.yb), _n.ptr(do), _n.dtype_code(dtype), N * H * W, C, cs, K,
                 _n.ptr(st[2]), _n.ptr(st[3]), _n.ptr(st[0]), _n.ptr(wc), _n.ptr(dact), _n.ptr(dw), _n.ptr(db), _n.ptr(ws),
                 _n.ptr(rows), _n.stream())
-        link.rows, link.dx_ptr = rows, dact.data_ptr()
+        link.rows, link.dx_ptr, link.holder = rows, dact.data_ptr(), dact
         dx = nhwc_to_logical(dact, C)
         if dx.dtype != ydt:
             dx = dx.to(ydt)
