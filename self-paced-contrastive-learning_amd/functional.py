@@ -553,24 +553,30 @@ class PoolLink:
     epilogue of its own input-gradient kernel (spcl_conv3x3_dgrad_poolstats): this block's raw second-conv output and BN
     coefficients.  The next block fills ``rows`` / ``dx_ptr``; this block's backward uses them if the pooled gradient it
     receives IS that kernel's output (same storage: nothing else contributed to it), else runs its own reduction pass."""
-    __slots__ = ("yb", "stb", "N", "H", "W", "cout_s", "rows", "dx_ptr", "holder")
+    __slots__ = ("yb", "stb", "N", "H", "W", "cout_s", "rows", "dx_ptr", "holder", "version")
 
     def __init__(self, yb, stb, N, H, W, cout_s):
         self.yb, self.stb, self.N, self.H, self.W, self.cout_s = yb, stb, N, H, W, cout_s
         # ``holder``: the gradient tensor ``dx_ptr`` is the address of, kept alive until the consumer has compared -- a freed
         # tensor's address is the first thing the allocator hands out again (to the re-layout copy of a foreign gradient, say)
-        self.rows, self.dx_ptr, self.holder = None, 0, None
+        self.rows, self.dx_ptr, self.holder, self.version = None, 0, None, 0
+
+    def fresh(self, ptr):
+        """is the gradient at ``ptr`` exactly the tensor the producer left (same storage, never accumulated into in place)?"""
+        return self.rows is not None and ptr == self.dx_ptr and self.holder is not None and self.holder._version == self.version
 
 
 class ActLink:
     """A block whose activation has ONE consumer that applies the block's last BatchNorm + ReLU itself (``BlockCfg.lazy_act``:
     the 1x1 head, ``conv1x1_bn``): the raw second-conv output and the BN coefficients the consumer needs, and -- filled by
     the consumer's backward -- the BatchNorm-backward partial sums it left next to the activation gradient."""
-    __slots__ = ("yb", "stb", "N", "H", "W", "C", "cs", "rows", "dx_ptr", "holder")
+    __slots__ = ("yb", "stb", "N", "H", "W", "C", "cs", "rows", "dx_ptr", "holder", "version")
 
     def __init__(self, yb, stb, N, H, W, C, cs):
         self.yb, self.stb, self.N, self.H, self.W, self.C, self.cs = yb, stb, N, H, W, C, cs
-        self.rows, self.dx_ptr, self.holder = None, 0, None  # (holder: see PoolLink)
+        self.rows, self.dx_ptr, self.holder, self.version = None, 0, None, 0  # (holder / version: see PoolLink)
+
+    fresh = PoolLink.fresh
 
 
 class UpLink:
@@ -1280,16 +1286,14 @@ class _ConvBlockFn(torch.autograd.Function):
         sk = tuple(take_grad_sink(p, ng[i + 1]) for i, p in enumerate(ctx.params))  # (wa, ga, ba, wb, gb, bb)
         lk = cfg.link_out
         la = getattr(cfg, "link_act", None)
-        if (la is not None and la.rows is not None and da_s is not None and dp_s is None and da_stride == 0
-                and da_s.data_ptr() == la.dx_ptr):
+        if la is not None and da_s is not None and dp_s is None and da_stride == 0 and la.fresh(da_s.data_ptr()):
             # the consumer's backward (the 1x1 head) left this BatchNorm's partial sums next to the activation gradient
             dyb, dgb, dbb = _bnrelu_bwd_rows(yb, da_s, None, la.rows, dtc, dtype, N, H, W, cout, cout_s, stb, cfg.training,
                                              sk[4:6])
         elif g_nc is not None:
             # the block's output fed a global average pool only: its gradient is one value per (image, channel)
             dyb, dgb, dbb = _bnrelu_bwd_bcast(yb, g_nc, dtc, dtype, N, H, W, cout, cout_s, stb, cfg.training, sk[4:6])
-        elif (lk is not None and lk.rows is not None and da_s is None and dp_s is not None
-                and dp_s.data_ptr() == lk.dx_ptr):
+        elif lk is not None and da_s is None and dp_s is not None and lk.fresh(dp_s.data_ptr()):
             # the next block's input-gradient kernel left this BatchNorm's partial sums next to the gradient itself
             dyb, dgb, dbb = _bnrelu_pool_bwd_rows(yb, dp_s, lk.rows, dtc, dtype, N, H, W, cout, cout_s, stb, cfg.training,
                                                   sk[4:6])
@@ -1369,7 +1373,7 @@ class _ConvBlockFn(torch.autograd.Function):
                         _n.ptr(dxs), _n.ptr(li.yb), li.H, li.W, _n.ptr(li.stb[2]), _n.ptr(li.stb[3]), _n.ptr(li.stb[0]),
                         _n.ptr(rows), _n.stream())
                 rows.ntiles = nt
-                li.rows, li.dx_ptr, li.holder = rows, dxs.data_ptr(), dxs
+                li.rows, li.dx_ptr, li.holder, li.version = rows, dxs.data_ptr(), dxs, dxs._version
             split = None
             if (dxs is None and x2s is not None and _CONV_SPLIT
                     and _n.call("spcl_conv_split_supported", dtc, N, H, W, cout_s, cin_s)):
@@ -1386,7 +1390,7 @@ class _ConvBlockFn(torch.autograd.Function):
                     _n.call("spcl_conv3x3_dgrad_split_bnstats", _n.ptr(dya), dtc, N, H, W, cout_s, cin_s, _n.ptr(wpa_t),
                             _n.ptr(split[0]), _n.ptr(split[1]), _n.ptr(xb.yb), _n.ptr(xb.stb[2]), _n.ptr(xb.stb[3]),
                             _n.ptr(xb.stb[0]), _n.ptr(rows), _n.stream())
-                    xb.rows, xb.dx_ptr, xb.holder = rows, split[1].data_ptr(), split[1]
+                    xb.rows, xb.dx_ptr, xb.holder, xb.version = rows, split[1].data_ptr(), split[1], split[1]._version
                 else:
                     _n.call("spcl_conv3x3_forward_split", _n.ptr(dya), dtc, N, H, W, cout_s, cin_s, _n.ptr(wpa_t),
                             _n.ptr(split[0]), _n.ptr(split[1]), _n.stream())
@@ -1509,7 +1513,7 @@ class _ConvBNReLUFn(torch.autograd.Function):
         ng = ctx.needs_input_grad
         sk = tuple(take_grad_sink(p, ng[i + 1]) for i, p in enumerate(ctx.params))
         bl = getattr(cfg, "bn_link", None)
-        if bl is not None and bl.rows is not None and da_stride == 0 and da_s.data_ptr() == bl.dx_ptr:
+        if bl is not None and da_stride == 0 and bl.fresh(da_s.data_ptr()):
             # the consumer's input-gradient kernel left this BatchNorm's backward sums next to the gradient itself
             dy, dg, db = _bnrelu_bwd_rows(y, da_s, None, bl.rows, dtc, dtype, N, H, W, cout, cout_s, st, cfg.training, sk[1:3])
         else:
@@ -1648,7 +1652,7 @@ class _Conv1x1BnFn(torch.autograd.Function):
         _n.call("spcl_conv1x1_backward_bn", _n.ptr(link.yb), _n.ptr(do), _n.dtype_code(dtype), N * H * W, C, cs, K,
                 _n.ptr(st[2]), _n.ptr(st[3]), _n.ptr(st[0]), _n.ptr(wc), _n.ptr(dact), _n.ptr(dw), _n.ptr(db), _n.ptr(ws),
                 _n.ptr(rows), _n.stream())
-        link.rows, link.dx_ptr, link.holder = rows, dact.data_ptr(), dact
+        link.rows, link.dx_ptr, link.holder, link.version = rows, dact.data_ptr(), dact, dact._version
         dx = nhwc_to_logical(dact, C)
         if dx.dtype != ydt:
             dx = dx.to(ydt)
