@@ -717,3 +717,51 @@ def test_two_bucket_overlap_step_equals_the_plain_step():
         assert flat._early is None
     assert torch.equal(grads[0], grads[1])
     assert float(grads[0].abs().max()) > 0
+
+
+def test_pool_link_ignores_a_gradient_it_did_not_produce():
+    """PoolLink: the next block's input-gradient kernel leaves the previous block's BatchNorm-backward sums next to the
+    pooled gradient it returns; if the pooled tensor had a second consumer, autograd hands the previous block the SUM of two
+    gradients -- a different tensor, or the same one accumulated in place -- and the sums no longer belong to it: the block
+    must notice (storage + version counter, the link keeping the tensor alive) and reduce for itself."""
+    import spcl_amd  # noqa
+    from spcl_amd import functional as F
+    from spcl_amd.semi_seg.arch.unet import _ConvBlock
+    torch.manual_seed(7)
+    a = _ConvBlock(16, 32).cuda().train()
+    b = _ConvBlock(32, 64).cuda().train()
+    for m in (a, b):
+        m._compute_dtype = torch.bfloat16
+    x = torch.rand(4, 16, 56, 56, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+
+    def run(extra, link):
+        for m in (a, b):
+            m.zero_grad(set_to_none=True)
+        a._plan = (False, True)
+        a(x)
+        p = a.take_pooled()
+        b._plan = (True, False)
+        if link:
+            b._link_in, a._link_out = a._link_out, None
+        else:
+            a._link_out = None
+        o = b(p)
+        loss = o.float().square().mean() + (p.float().square().mean() * 3.0 if extra else 0.0)
+        used = []
+        real = F._n.call
+        F._n.call = lambda name, *args: (used.append(name), real(name, *args))[1]
+        try:
+            loss.backward()
+        finally:
+            F._n.call = real
+        torch.cuda.synchronize()
+        return [q.grad.clone() for q in a.parameters()], "spcl_bnrelu_pool_backward_rows" in used
+
+    (g1, rows1), (g0, rows0) = run(False, True), run(False, False)
+    assert rows1 and not rows0  # the link is taken when the gradient is the producer's own ...
+    (h1, hrows1), (h0, hrows0) = run(True, True), run(True, False)
+    assert not hrows1 and not hrows0  # ... and not when something else contributed
+    for u, v in zip(h1, h0):
+        assert torch.equal(u, v)  # (both reduce for themselves: identical)
+    for u, v in zip(g1, g0):  # the linked sums are taken in another order: close, not equal
+        assert float((u.float() - v.float()).norm()) <= 2e-2 * float(v.float().norm()) + 1e-12
