@@ -175,6 +175,22 @@ class SelfPacedSupConLoss(_SupConBase):
 _HEADS_MAX_ROWS = 1024  # 2n from which csrc/supcon.hip switches to the large-batch schedule (one head per call there)
 
 
+def _adjacent_rows(rows, n):
+    """the [K, n] float32 tensor whose rows ARE the K given vectors when they lie back to back in one allocation, else None"""
+    b = rows[0]._base
+    if b is None or any(r._base is not b or not r.is_contiguous() or r.dtype != torch.float32 for r in rows):
+        return None
+    if any(r.data_ptr() != rows[0].data_ptr() + k * n * 4 for k, r in enumerate(rows)):
+        return None
+    if b.dtype not in (torch.float32, torch.uint8) or not b.is_contiguous() or b.dim() != 1:
+        return None
+    byte_off = rows[0].data_ptr() - b.data_ptr()
+    if byte_off % 4 or (b.data_ptr() % 4) or (b.numel() * b.element_size()) % 4:
+        return None
+    fb = b if b.dtype == torch.float32 else b.view(torch.float32)
+    return torch.as_strided(fb, (len(rows), n), (n, 1), byte_off // 4)
+
+
 def supcon_heads(criteria, projections, targets):
     """The K losses ``criteria[k](*torch.chunk(projections[k], 2), target=targets[k])`` in the launches of ONE
     (``spcl_supcon_forward_heads``): the K meta-label hooks of ``semi_seg/hooks/creator.py:102-124`` on one feature, each
@@ -212,7 +228,9 @@ def supcon_heads(criteria, projections, targets):
         lt = lt.to(device=z0.device, dtype=torch.float32)
         assert lt.numel() == n, (lt.shape, n)  # contrast_loss3.py:48-54 / :133-139
         labels.append(lt.reshape(n))
-    labels_t = torch.stack(labels)
+    labels_t = _adjacent_rows(labels, n)  # (the K hooks' slots of the epocher's stage sit back to back: no stacking launch)
+    if labels_t is None:
+        labels_t = torch.stack(labels)
     states = [F_hip.SupConState() for _ in range(K)]
     losses = F_hip.supcon_loss_heads(list(projections), labels_t, t=c0._t, sp_mode=mode, gammas=gammas,
                                      correct_grad=correct, states=states)
@@ -221,4 +239,4 @@ def supcon_heads(criteria, projections, targets):
     for c in criteria:
         if c.sync_checks and not _capturing():
             c.check()
-    return list(losses.unbind(0))
+    return list(losses)

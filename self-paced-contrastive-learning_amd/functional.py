@@ -140,17 +140,23 @@ class _SupConHeadsFn(torch.autograd.Function):
             st.ws, st.out = ws[k * ws_stride:(k + 1) * ws_stride], out[k]
         ctx.keep = (labels, ws, out, zall)
         ctx.meta = (K, n, d, t, sp_mode, tuple(float(g) for g in gammas), ws_stride, [z.dtype for z in zs])
-        return out[:, 0].clone()
+        # K separate 0-dim losses (views of the result block: no copy; a [K] tensor that the hooks then unbind costs a
+        # stacking launch in its backward)
+        return tuple(out[k, 0] for k in range(K))
 
     @staticmethod
-    def backward(ctx, grad_out):
+    def backward(ctx, *grads_out):
         K, n, d, t, sp_mode, gammas, ws_stride, dtypes = ctx.meta
         labels, ws, out, _ = ctx.keep
         dev = ws.device
         dz = torch.empty(K, 2 * n, d, dtype=torch.float32, device=dev)
         wsb_stride = (_n.call("spcl_supcon_bwd_workspace_bytes", n, d) // 4 + 63) // 64 * 64
         wsb = torch.empty(K * wsb_stride, dtype=torch.float32, device=dev)
-        go = grad_out.detach().reshape(K).float().contiguous()
+        if all(g is not None and is_unit_gradient(g) for g in grads_out):
+            go = _ones_k(K, dev)  # every head's upstream gradient is the epocher's registered 1: a cached vector of ones
+        else:
+            go = torch.stack([torch.zeros((), dtype=torch.float32, device=dev) if g is None else g.detach().float().reshape(())
+                              for g in grads_out])
         gam = (c_float * K)(*gammas)
         base = dz.data_ptr()
         _n.call("spcl_supcon_backward_heads", K, _n.ptr(labels), n, d, c_float(t), sp_mode, gam, _n.ptr(ws), ws_stride,
@@ -158,9 +164,20 @@ class _SupConHeadsFn(torch.autograd.Function):
         return (None, None, None, None, None, None) + tuple(dz[k].to(dtypes[k]) for k in range(K))
 
 
+_ONES_K = {}
+
+
+def _ones_k(K, dev):
+    key = (K, str(dev))
+    t = _ONES_K.get(key)
+    if t is None:
+        t = _ONES_K[key] = torch.ones(K, dtype=torch.float32, device=dev)
+    return t
+
+
 def supcon_loss_heads(zs, labels=None, *, t=0.07, sp_mode=SP_NONE, gammas=None, correct_grad=False, states=None):
-    """[K] losses of the K stacked [2n, d] projections ``zs`` (2 <= K <= 4); ``labels``: [K, n] float tensor or None;
-    ``gammas``: K floats; ``states``: K SupConState objects that receive each head's device-side statistics."""
+    """K 0-dim losses (a tuple) of the K stacked [2n, d] projections ``zs`` (2 <= K <= 4); ``labels``: [K, n] float tensor or
+    None; ``gammas``: K floats; ``states``: K SupConState objects that receive each head's device-side statistics."""
     K = len(zs)
     if states is None:
         states = [SupConState() for _ in range(K)]
