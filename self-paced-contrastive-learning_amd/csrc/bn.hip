@@ -64,7 +64,6 @@ struct BnFinalArgs {
   float* shift;
 };
 
-__device__ __forceinline__ void bn_final_channel(int c, int C, double n, double s1, double s2, const BnFinalArgs& f);
 __device__ __forceinline__ void store_agent(double* p, double v) {
   __hip_atomic_store((unsigned long long*)p, __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED,
                      __HIP_MEMORY_SCOPE_AGENT);
@@ -77,15 +76,64 @@ __device__ __forceinline__ double load_agent(const double* p) {
 // FINAL: write the BatchNorm coefficients, else one partial row per blockIdx.y.
 // CW channels per workgroup (16: 64-byte row segments; 4 workgroups of 4 channels were tried for the 64-channel /
 // 2048-tile layers and were no faster: the single launch is a latency chain, which is why 1024 tiles already go two-level)
+// Latency, not work, is what these launches cost (a trivial dependent launch replays in 1.5 us; this kernel took 5-9): the row
+// lanes are folded by two wave shuffles and ONE barrier (it was a log2(64)-round LDS tree: -0.5 .. -1.4 us per launch, ten
+// launches per pre-train step), and the channel's gamma / beta / running statistics are four plain loads issued together
+// behind the reduction.  Requesting them FIRST (-DSPCL_BN_PREFETCH=1) looked like one round trip less and measured +4 us per
+// launch: vector-memory results return in order, and those four lines (parameters the optimizer wrote, buffers last touched
+// a step ago) are slower to arrive than the rows the producing convolution has just left -- everything queues behind them.
+struct BnChan { float gamma, beta, rm, rv; };
+// (four PLAIN loads at clamped / substituted addresses, issued together: inside `if`s -- a null running-statistics pointer, the
+// channel padding -- every one of them was waited for at its join: four dependent ~1.7 us round trips per launch)
+__device__ __forceinline__ BnChan bn_prefetch_channel(int c, int C, const BnFinalArgs& f) {
+  const int cc = c < C ? c : C - 1;
+  const float* rm = f.running_mean != nullptr ? f.running_mean : f.gamma;
+  const float* rv = f.running_var != nullptr ? f.running_var : f.gamma;
+  BnChan ch;
+  ch.gamma = f.gamma[cc];
+  ch.beta = f.beta[cc];
+  ch.rm = rm[cc];
+  ch.rv = rv[cc];
+  return ch;
+}
+__device__ __forceinline__ void bn_final_channel(int c, int C, double n, double s1, double s2, const BnFinalArgs& f,
+                                                 const BnChan& ch);
+__device__ __forceinline__ double shfl_xor_f64(double v, int m) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)u, m, 64), hi = (unsigned)__shfl_xor((int)(unsigned)(u >> 32), m, 64);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// sum over the row lanes tl of one channel (threads tid = tl * CW + c16, CW = 16: a wave holds four row lanes of each channel):
+// two shuffles inside the wave, the waves' values through LDS, thread (tl 0, c16) adds them in wave order.  Fixed order.
+template <int CW>
+__device__ __forceinline__ void bn_fold_lanes(double& n, double& s1, double& s2, double (*red)[1024 / 64][CW]) {
+  static_assert(CW == 16, "four row lanes per wave");
+  const int c16 = threadIdx.x % CW, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  n += shfl_xor_f64(n, 16); s1 += shfl_xor_f64(s1, 16); s2 += shfl_xor_f64(s2, 16);
+  n += shfl_xor_f64(n, 32); s1 += shfl_xor_f64(s1, 32); s2 += shfl_xor_f64(s2, 32);
+  if ((threadIdx.x & 63) < CW) { red[0][wave][c16] = n; red[1][wave][c16] = s1; red[2][wave][c16] = s2; }
+  __syncthreads();
+  if (threadIdx.x < CW) {
+    n = red[0][0][c16]; s1 = red[1][0][c16]; s2 = red[2][0][c16];
+    for (int w = 1; w < nw; ++w) { n += red[0][w][c16]; s1 += red[1][w][c16]; s2 += red[2][w][c16]; }
+  }
+}
+
 template <typename SRC, bool FINAL, int CW>
 __global__ __launch_bounds__(1024) void bn_reduce_kernel(const SRC* __restrict__ rows, int nrows, int rows_per_group,
                                                          int C, int CS, double* __restrict__ partial, BnFinalArgs f,
                                                          unsigned* tickets = nullptr) {
-  __shared__ double red[3][1024 / CW][CW];
+  __shared__ double red[3][1024 / 64][CW];
   __shared__ unsigned s_ticket;
   const int TL = blockDim.x / CW;
   const int c16 = threadIdx.x % CW, tl = threadIdx.x / CW;
   const int c = blockIdx.x * CW + c16;
+  const bool finishes = FINAL || tickets != nullptr;  // this launch writes the coefficients (some workgroup of it)
+  BnChan ch = {0.f, 0.f, 0.f, 0.f};
+#ifndef SPCL_BN_PREFETCH
+#define SPCL_BN_PREFETCH 0
+#endif
+  if (SPCL_BN_PREFETCH && finishes) ch = bn_prefetch_channel(c, C, f);  // (every thread: no divergent region around the loads)
   const int r0 = blockIdx.y * rows_per_group, r1 = min(nrows, r0 + rows_per_group);
   double n = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll 8
@@ -103,15 +151,7 @@ __global__ __launch_bounds__(1024) void bn_reduce_kernel(const SRC* __restrict__
       s2 += q;
     }
   }
-  red[0][tl][c16] = n; red[1][tl][c16] = s1; red[2][tl][c16] = s2;
-  __syncthreads();
-  for (int o = TL >> 1; o > 0; o >>= 1) {
-    if (tl < o) {
-      n += red[0][tl + o][c16]; s1 += red[1][tl + o][c16]; s2 += red[2][tl + o][c16];
-      red[0][tl][c16] = n; red[1][tl][c16] = s1; red[2][tl][c16] = s2;
-    }
-    __syncthreads();
-  }
+  bn_fold_lanes<CW>(n, s1, s2, red);
   if (!FINAL && tickets != nullptr) {
     // Both levels in ONE launch: the group's row leaves with agent-scope stores (written through: no L2 write-back fence),
     // the workgroup takes a ticket once they are acknowledged, and the LAST group of this channel block folds all the rows
@@ -134,16 +174,8 @@ __global__ __launch_bounds__(1024) void bn_reduce_kernel(const SRC* __restrict__
       n += load_agent(p); s1 += load_agent(p + CS); s2 += load_agent(p + 2 * CS);
     }
     __syncthreads();
-    red[0][tl][c16] = n; red[1][tl][c16] = s1; red[2][tl][c16] = s2;
-    __syncthreads();
-    for (int o = TL >> 1; o > 0; o >>= 1) {
-      if (tl < o) {
-        n += red[0][tl + o][c16]; s1 += red[1][tl + o][c16]; s2 += red[2][tl + o][c16];
-        red[0][tl][c16] = n; red[1][tl][c16] = s1; red[2][tl][c16] = s2;
-      }
-      __syncthreads();
-    }
-    if (tl == 0) bn_final_channel(c, C, n, s1, s2, f);
+    bn_fold_lanes<CW>(n, s1, s2, red);
+    if (tl == 0) bn_final_channel(c, C, n, s1, s2, f, SPCL_BN_PREFETCH ? ch : bn_prefetch_channel(c, C, f));
     return;
   }
   if (tl != 0) return;
@@ -152,10 +184,11 @@ __global__ __launch_bounds__(1024) void bn_reduce_kernel(const SRC* __restrict__
     q[0] = n; q[CS] = s1; q[2 * CS] = s2;
     return;
   }
-  bn_final_channel(c, C, n, s1, s2, f);
+  bn_final_channel(c, C, n, s1, s2, f, SPCL_BN_PREFETCH ? ch : bn_prefetch_channel(c, C, f));
 }
 
-__device__ __forceinline__ void bn_final_channel(int c, int C, double n, double s1, double s2, const BnFinalArgs& f) {
+__device__ __forceinline__ void bn_final_channel(int c, int C, double n, double s1, double s2, const BnFinalArgs& f,
+                                                 const BnChan& ch) {
   if (c >= C) {  // channel padding
     f.mean[c] = 0.f; f.invstd[c] = 0.f; f.scale[c] = 0.f; f.shift[c] = 0.f;
     return;
@@ -164,15 +197,15 @@ __device__ __forceinline__ void bn_final_channel(int c, int C, double n, double 
   const double m2 = fmax(s2 - s1 * mu, 0.0);
   const double var = m2 / n;
   const float is = 1.0f / sqrtf((float)var + f.eps);
-  const float sc = f.gamma[c] * is;
+  const float sc = ch.gamma * is;
   f.mean[c] = (float)mu;
   f.invstd[c] = is;
   f.scale[c] = sc;
-  f.shift[c] = f.beta[c] - (float)mu * sc;
-  if (f.running_mean != nullptr) f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * (float)mu;
+  f.shift[c] = ch.beta - (float)mu * sc;
+  if (f.running_mean != nullptr) f.running_mean[c] = (1.f - f.momentum) * ch.rm + f.momentum * (float)mu;
   if (f.running_var != nullptr) {
     const double unbiased = n > 1.0 ? m2 / (n - 1.0) : var;
-    f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unbiased;
+    f.running_var[c] = (1.f - f.momentum) * ch.rv + f.momentum * (float)unbiased;
   }
   if (f.nbt != nullptr && c == 0) f.nbt[0] += 1;
 }
