@@ -494,6 +494,356 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(b16_wpe
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same pass with the m-tiles laid along the TILE ROWS (round 4): m-tile = one row of the 14 x 14 tile as 16 pixel columns
+// (14 real + 2 that read the zeroed pad pixels 16, 17 of the halo rows and are never used), wave w takes the rows w, w + 2,
+// ... (7 each: the MFMA count per wave is the old one's -- 13 linear m-tiles dealt to two waves were 7 rounds as well).  A
+// lane's pixel column is then r16 for every round and its row is wave-uniform, so everything the linear pixel order computed
+// per round and per phase (row / column of pixel 16 (wave + 2 j) + r16, a carry, a validity flag -- four loops of seven
+// rounds, ~150 of the ~670 vector instructions per tile and wave) becomes an immediate offset of the LDS instruction or a
+// scalar addition: dgrad fragment address = lane base + (tap, chunk) offset of the lane's k-group (five dwords per k-group,
+// read from a 4 x 5 table in LDS once per tile) + round * 2 rows; x / dz store address = lane base + round * 2 rows; y2
+// address = scalar row base + lane offset.  The two unused pixel columns are switched off ONCE per tile for the whole pixel
+// pass (they are the same lanes in every round), their y2 request is lane 13's (no read beyond the tensor's end).
+// Same MFMA operands per output pixel and weight element as the linear kernel: g, x, dz and dW bit for bit; the
+// BatchNorm sums add the same terms in another lane order.
+constexpr int B16_TAB = B16_LDS;              // [4 k-groups][8] dwords: (tap, chunk) byte offsets of the five k-steps
+constexpr int B16_LDS_ROWS = B16_TAB + 128;   // 21 216
+
+template <bool SHIFTED, bool WGROWS>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3))) void conv16_bwd_rows_kernel(Bwd16Args a) {
+  constexpr int NW = 2;
+  constexpr int TH = B16_TH, TW = B16_TW, HW_ = B16_HW, RP = B16_RP, PS = B16_PS;
+  constexpr int NSTEPS = 5, NTHR = 64 * NW, ITER = 512 / NTHR, RPI = NTHR / 32;
+  constexpr int MW = TH / NW, TPW = (9 + NW - 1) / NW;
+  static_assert(TH % NW == 0, "rows are dealt to the waves evenly");
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const unsigned lds_base = (unsigned)(uintptr_t)(unsigned char __attribute__((address_space(3)))*)lds;
+  const int t0 = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(t0 >> 6);
+  if (WGROWS && (int)blockIdx.z * (int)(gridDim.x * gridDim.y) >= a.nwg) {  // the extra z-slice: the autocorrelation rows
+    const int nslice = gridDim.x * gridDim.y;
+    if (t0 < 64) {
+      for (int j = blockIdx.y * gridDim.x + blockIdx.x; j < 16; j += nslice) {
+        float sacc = 0.f;
+#pragma unroll 8
+        for (int w = j; w < a.nacorr; w += 16) sacc += a.acorr_in[(size_t)w * 64 + t0];
+        a.acorr_out[(size_t)j * 64 + t0] = sacc;
+      }
+    }
+    return;
+  }
+
+  int tx = blockIdx.x, ty = blockIdx.y;
+  {
+    const int T = a.tilesX * a.tilesY;
+    if (a.xcd_remap && (T & 7) == 0) {
+      const int L = ty * a.tilesX + tx;
+      const int L2 = (L & 7) * (T >> 3) + (L >> 3);
+      ty = L2 / a.tilesX;
+      tx = L2 - ty * a.tilesX;
+    }
+  }
+  const int y0 = min(ty * TH, a.H - TH), x0 = min(tx * TW, a.W - TW);
+  const int oy = ty * TH - y0, ox = tx * TW - x0;
+  const bool interior = y0 > 0 && x0 > 0 && y0 + TH < a.H && x0 + TW < a.W;
+  const bool shifted = SHIFTED && (oy | ox) != 0;
+
+  u32x4 wall[NSTEPS];
+#pragma unroll
+  for (int s = 0; s < NSTEPS; ++s) wall[s] = a.wp[s * 64 + (t0 & 63)];
+  const f32x4 sc2 = *(const f32x4*)(a.scale2 + 4 * ((t0 & 63) >> 4)), sh2 = *(const f32x4*)(a.shift2 + 4 * ((t0 & 63) >> 4)),
+              mu2 = *(const f32x4*)(a.mean2 + 4 * ((t0 & 63) >> 4));
+  if (t0 < 4 * TH) *(u32x4*)(lds + B16_XT + (t0 >> 2) * B16_XT_ROW + TW * PS + (t0 & 3) * 16) = (u32x4){0u, 0u, 0u, 0u};
+  if (t0 >= NTHR - 64)
+    *(u32x4*)(lds + B16_DY + (((t0 & 63) >> 2) * RP + HW_) * PS + (t0 & 3) * 16) = (u32x4){0u, 0u, 0u, 0u};
+  if (t0 < 48) {
+    const int r = t0 & 15, k = t0 >> 4;
+    ((bf16_t*)(lds + B16_IM))[(k == 0 ? 256 + 15 : (k == 1 ? 512 + 14 : 512 + 15)) + r * 16] = 0;
+  }
+  if (t0 >= 64 && t0 < 64 + 20) {  // the k-step table: lane group g, k-step s -> chunk 4 s + g = (tap, 8-channel half)
+    const int e = t0 - 64, gq = e / NSTEPS, s = e - gq * NSTEPS;
+    int fc = 4 * s + gq;
+    if (fc >= 18) fc = 0;  // K padding: zero weights
+    const int tap = fc >> 1, c = fc & 1, ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+    ((unsigned*)(lds + B16_TAB))[gq * 8 + s] = (unsigned)((ky * RP + kx) * PS + c * 16);
+  }
+  if (WGROWS)
+    for (int i = t0; i < (512 + 576) / 4; i += NTHR) ((float*)(lds + B16_RED))[i] = 0.f;
+  f32x4 wacc[TPW];
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) wacc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float imgv[256 / NTHR];
+  u32x4 v[ITER];
+  uint2 ypre[MW];
+  constexpr int PPT = 256 / NTHR;
+  auto issue_img = [&](const int n) {
+    int t = t0;
+    asm volatile("" : "+v"(t));
+    const int hr = (t * PPT) >> 4, hc = (t * PPT) & 15;
+    const int gy = y0 - 1 + hr;
+    const float* ir = a.img + ((size_t)n * a.H + (gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy))) * a.W;
+#pragma unroll
+    for (int e = 0; e < PPT; ++e) {
+      const int gx = x0 - 1 + hc + e;
+      imgv[e] = ir[gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx)];
+    }
+  };
+  auto issue_halo = [&](const int n) {
+    int t = t0;
+    asm volatile("" : "+v"(t));
+    const int ch = t & 1, q0 = t >> 1, hy0 = q0 / HW_, hx0 = q0 % HW_;
+    const unsigned voff = (unsigned)((hy0 * a.W + hx0) * 32 + ch * 16);
+    const unsigned char* xb = a.dy + (((long)n * a.H + (y0 - 1)) * a.W + (x0 - 1)) * 32;
+#pragma unroll
+    for (int k = 0; k < ITER; ++k) {
+      const long soff = (long)(RPI * k) * a.W * 32;
+      bool inb = true;
+      if (!interior) {
+        const int gy = y0 - 1 + hy0 + RPI * k, gx = x0 - 1 + hx0;
+        inb = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      }
+      v[k] = (u32x4){0u, 0u, 0u, 0u};
+      if (inb) v[k] = *(const u32x4*)(xb + soff + voff);
+    }
+  };
+  // y2 at the wave's rows: ONE lane offset (pixel column r16 -- 13 for the two unused columns -- and channel quarter g),
+  // the row base is wave-uniform (scalar additions per round)
+  auto issue_y2 = [&](const int n) {
+    int t = t0;
+    asm volatile("" : "+v"(t));
+    const int r16 = t & 15, g = (t & 63) >> 4;
+    const unsigned voff = (unsigned)(min(r16, TW - 1) * 32 + g * 8);
+    const unsigned char* y2b = a.y2 + (((size_t)n * a.H + y0 + wave) * a.W + x0) * 32;
+#pragma unroll
+    for (int j = 0; j < MW; ++j) ypre[j] = *(const uint2*)(y2b + (size_t)(NW * j) * a.W * 32 + voff);
+  };
+
+  const bool stamp = SPCL_CONV16_STAMPS_BUILD && a.stamps != nullptr && t0 == 0;
+  unsigned long long tph[7] = {0, 0, 0, 0, 0, 0, 0}, tc = 0;
+  const int n_first = blockIdx.z * a.ipw;
+  if (stamp) tc = __builtin_amdgcn_s_memtime();
+  if (n_first < a.N) {
+    issue_img(n_first);
+    issue_halo(n_first);
+    issue_y2(n_first);
+  }
+  {  // (filter fragments and BatchNorm coefficients have arrived before the tile loop: see the linear kernel)
+    const u32x4 wx = wall[0] ^ wall[1] ^ wall[2] ^ wall[3] ^ wall[4];
+    const f32x4 cx = sc2 + sh2 + mu2;
+    *(u32x4*)(lds + B16_TRASH) = wx;
+    *(f32x4*)(lds + B16_TRASH + 16) = cx;
+  }
+  __syncthreads();  // the k-step table is read before the first staging barrier
+#pragma unroll 1
+  for (int it = 0; it < a.ipw; ++it) {
+    const int n = n_first + it;
+    if (n >= a.N) break;
+    int t = t0;
+    asm volatile("" : "+v"(t));
+    const int lane = t & 63, r16 = t & 15, g = lane >> 4;
+    const int tile = (n * a.tilesY + ty) * a.tilesX + tx;
+    const u32x4 tabA = *(const u32x4*)(lds + B16_TAB + g * 32);
+    const unsigned tabB = *(const unsigned*)(lds + B16_TAB + g * 32 + 16);
+    {
+      const int hr = (t * PPT) >> 4, hc = (t * PPT) & 15;
+      const int gy = y0 - 1 + hr;
+#pragma unroll
+      for (int e = 0; e < PPT; ++e) {
+        const int gx = x0 - 1 + hc + e;
+        const float hv = (interior || (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)) ? imgv[e] : 0.f;
+        const bf16_t hb = f32_to_bf16(hv);
+        bf16_t* imb = (bf16_t*)(lds + B16_IM) + hr * 16 + hc + e;
+        imb[0] = hb;
+        if (hc + e >= 1) imb[256 - 1] = hb;
+        if (hc + e >= 2) imb[512 - 2] = hb;
+      }
+    }
+    {
+      const int ch = t & 1, q0 = t >> 1, hy0 = q0 / HW_, hx0 = q0 % HW_;
+      unsigned char* const lp = lds + B16_DY + (hy0 * RP + hx0) * PS + ch * 16;
+#pragma unroll
+      for (int k = 0; k < ITER; ++k) *(u32x4*)(lp + (RPI * k * RP) * PS) = v[k];
+    }
+    const bool more = it + 1 < a.ipw && n + 1 < a.N;
+    B16_STAMP(0)
+    __syncthreads();
+    B16_STAMP(1)
+
+    // ---- input gradient g at the wave's rows wave + 2 j, pixel column r16: 5 k-steps
+    f32x4 acc[MW];
+    {
+      const unsigned lb = (unsigned)(B16_DY + (wave * RP + r16) * PS);
+      const unsigned offs[NSTEPS] = {tabA[0] + lb, tabA[1] + lb, tabA[2] + lb, tabA[3] + lb, tabB + lb};
+#pragma unroll
+      for (int j = 0; j < MW; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < NSTEPS; ++s) {
+#pragma unroll
+        for (int j = 0; j < MW; ++j) {
+          const u32x4 xf = *(const u32x4*)(lds + offs[s] + j * (NW * RP * PS));
+          acc[j] = mfma_chunk<bf16_t>(wall[s], xf, acc[j]);
+        }
+      }
+    }
+
+    B16_STAMP(2)
+    // ---- the pixel pass of the wave's seven pixels per lane (columns 14, 15 switched off for the whole of it)
+    uint2 dzp[MW];
+#pragma unroll
+    for (int j = 0; j < MW; ++j) dzp[j] = (uint2){0u, 0u};
+    f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
+    const unsigned xaddr = (unsigned)(B16_XT + wave * B16_XT_ROW + r16 * PS + g * 8);
+    if (r16 < TW) {
+      const bool keep_x = !SHIFTED || r16 >= ox;
+#pragma unroll
+      for (int j = 0; j < MW; ++j) {
+        const bool keep = !shifted || (keep_x && wave + NW * j >= oy);
+        const float yv[4] = {__uint_as_float(ypre[j].x << 16), __uint_as_float(ypre[j].x & 0xffff0000u),
+                             __uint_as_float(ypre[j].y << 16), __uint_as_float(ypre[j].y & 0xffff0000u)};
+        const f32x2 glo = {acc[j][0], acc[j][1]}, ghi = {acc[j][2], acc[j][3]};
+        const uint32_t g0 = __builtin_bit_cast(uint32_t, __builtin_convertvector(glo, bf16x2v));
+        const uint32_t g1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(ghi, bf16x2v));
+        const float gv[4] = {__uint_as_float(g0 << 16), __uint_as_float(g0 & 0xffff0000u),
+                             __uint_as_float(g1 << 16), __uint_as_float(g1 & 0xffff0000u)};
+        float xv[4], dz[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float z = fmaf(sc2[r], yv[r], sh2[r]);
+          xv[r] = keep ? fmaxf(z, 0.f) : 0.f;
+          dz[r] = (z > 0.f && keep) ? gv[r] : 0.f;
+          ssum[r] += dz[r];
+          ssq[r] = fmaf(dz[r], yv[r] - mu2[r], ssq[r]);
+        }
+        const f32x2 lo = {xv[0], xv[1]}, hi = {xv[2], xv[3]};
+        uint2 w;
+        w.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf16x2v));
+        w.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, bf16x2v));
+        *(uint2*)(lds + xaddr + j * (NW * B16_XT_ROW)) = w;
+        dzp[j].x = (__float_as_uint(dz[0]) >> 16) | (__float_as_uint(dz[1]) & 0xffff0000u);
+        dzp[j].y = (__float_as_uint(dz[2]) >> 16) | (__float_as_uint(dz[3]) & 0xffff0000u);
+      }
+    }
+    {
+      f32x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float s1 = row16_sum(ssum[r]), s2 = row16_sum(ssq[r]);
+        o[r] = r16 == 0 ? s1 : s2;
+      }
+      if (r16 < 2) {
+        f32x4* rp = (f32x4*)(lds + B16_RED + ((wave * 2 + r16) * 16 + 4 * g) * 4);
+        *rp = WGROWS ? *rp + o : o;
+      }
+    }
+    if (more) {
+      issue_halo(n + 1);
+      issue_y2(n + 1);
+      issue_img(n + 1);
+    }
+    B16_STAMP(3)
+    __syncthreads();
+    B16_STAMP(1)
+    if (!WGROWS && t < 32) {
+      const float* red = (const float*)(lds + B16_RED) + t;
+      float tot = red[0];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) tot += red[32 * w];
+      a.rows11[(size_t)tile * 11 * 16 + t] = tot;
+    }
+
+    // ---- weight gradient of the tile (as in the linear kernel: both operands read transposed, the taps dealt to the waves)
+    const unsigned tr_col = (unsigned)((4 * (g & 1) + (r16 >> 2)) * PS + (r16 & 3) * 8);
+    const unsigned tr_x = lds_base + B16_XT + (g >> 1) * B16_XT_ROW + tr_col;
+    {
+      unsigned ax = tr_x, ad[TPW];
+#pragma unroll
+      for (int j = 0; j < TPW; ++j) {
+        const int tap = min(wave + NW * j, 8), ky = tap / 3, kx = tap - 3 * ky;
+        ad[j] = lds_base + B16_DY + (g >> 1) * RP * PS + tr_col + (2 - ky) * RP * PS + (2 - kx) * PS;
+      }
+#pragma unroll
+      for (int ks = 0; ks < TH / 2; ++ks) {
+        const bf16x8 af = b16_tr_frag(ax + ks * 2 * B16_XT_ROW);
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+          const bf16x8 bf = b16_tr_frag(ad[j] + ks * 2 * RP * PS);
+          wacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, wacc[j], 0, 0, 0);
+        }
+      }
+    }
+    B16_STAMP(4)
+    __syncthreads();
+    B16_STAMP(1)
+
+    // ---- dz takes x's place in LDS; the nine image tap sums on the matrix pipe (wave 0)
+    if (r16 < TW) {
+#pragma unroll
+      for (int j = 0; j < MW; ++j) *(uint2*)(lds + xaddr + j * (NW * B16_XT_ROW)) = dzp[j];
+    }
+    B16_STAMP(5)
+    __syncthreads();
+    B16_STAMP(1)
+    if (wave == 0) {
+      const int tap = r16 < 9 ? r16 : 0, tky = tap / 3, tkx = tap - 3 * tky;
+      const unsigned char* pb = lds + B16_IM + tkx * 512 + ((g >> 1) + tky) * 32 + (g & 1) * 8;
+      f32x4* dp = (f32x4*)(lds + B16_ACC + (r16 * 16 + 4 * g) * 4);
+      f32x4 D = (WGROWS && r16 < 9) ? *dp : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < TH / 2; ++ks) {
+        const bf16x8 af = b16_tr_frag(tr_x + ks * 2 * B16_XT_ROW);
+        const uint2 b0 = *(const uint2*)(pb + ks * 64), b1 = *(const uint2*)(pb + ks * 64 + 16);
+        const u32x4 bq = {b0.x, b0.y, b1.x, b1.y};
+        D = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, bq), D, 0, 0, 0);
+      }
+      if (WGROWS) {
+        if (r16 < 9) *dp = D;
+      } else if (r16 < 9) *(f32x4*)(a.rows11 + ((size_t)tile * 11 + 2 + r16) * 16 + 4 * g) = D;
+    }
+    B16_STAMP(6)
+    __syncthreads();  // every wave restages the image copies: behind wave 0's reads
+  }
+
+  if (stamp) {
+    unsigned long long* o = a.stamps + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) o[k] = tph[k];
+  }
+  const size_t wg = (size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  if (WGROWS) {
+    __syncthreads();
+    for (int i = t0; i < 11 * 16; i += NTHR) {
+      float tot;
+      if (i < 32) {
+        const float* red = (const float*)(lds + B16_RED) + i;
+        tot = red[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) tot += red[32 * w];
+      } else {
+        tot = ((const float*)(lds + B16_ACC))[i - 32];
+      }
+      a.wg_rows[(size_t)i * a.nwg + wg] = tot;
+    }
+  }
+  float* out = a.partial + wg * (9 * 256);
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) {
+    const int tap = wave + NW * j;
+    if (tap < 9) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[(tap * 16 + 4 * ((t0 & 63) >> 4) + r) * 16 + (t0 & 15)] = wacc[j][r];
+    }
+  }
+}
+
+int conv16_bwd_rowmap() {
+  // the row-mapped kernel (two waves per tile): SPCL_CONV16_ROWMAP=0 switches back to the linear pixel order
+  static const int env = getenv("SPCL_CONV16_ROWMAP") ? atoi(getenv("SPCL_CONV16_ROWMAP")) : 1;
+  return env;
+}
+
 int conv16_bwd_nw() {
   // measured inside the step (64 x 224^2, same box, median of single replays; separate launches 1204.7 us): one wave per
   // tile 1208, two 1194, four 1242
@@ -574,7 +924,16 @@ extern "C" int spcl_conv16_bwd_fused(const void* dy, int dtype, int N, int H, in
     else if (wgr) B16_LAUNCH(true, NW_, true);              \
     else B16_LAUNCH(true, NW_, false);                      \
   }
-  B16_CASE(1) B16_CASE(2) B16_CASE(4)
+  if (nw == 2 && conv16_bwd_rowmap()) {
+#define B16_ROWS(SH_, WG_) SPCL_LAUNCH((conv16_bwd_rows_kernel<SH_, WG_>), grid, dim3(128), B16_LDS_ROWS, st, a)
+    if (even && wgr) B16_ROWS(false, true);
+    else if (even) B16_ROWS(false, false);
+    else if (wgr) B16_ROWS(true, true);
+    else B16_ROWS(true, false);
+#undef B16_ROWS
+  } else {
+    B16_CASE(1) B16_CASE(2) B16_CASE(4)
+  }
 #undef B16_CASE
 #undef B16_LAUNCH
   if (a.stamps != nullptr) {
