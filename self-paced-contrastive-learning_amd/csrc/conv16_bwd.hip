@@ -77,6 +77,12 @@ __device__ __forceinline__ bf16x8 b16_tr_frag(unsigned addr) {
   return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+__device__ __forceinline__ bf16x8 b16_tr_frag2(unsigned addr_lo, unsigned addr_hi) {  // the two halves at their own addresses
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(uintptr_t)addr_lo);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(uintptr_t)addr_hi);
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
 // SHIFTED: the image size is not a multiple of the tile (last tiles shifted back inside: pixels two tiles cover count once)
 // NW: waves per tile (1, 2 or 4): m-tile i of 13 goes to wave i % NW, tap t of 9 to wave t % NW
 constexpr int b16_wpe(int NW) { return NW == 1 ? 2 : 3; }
@@ -550,11 +556,14 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3))) void c
   const bool interior = y0 > 0 && x0 > 0 && y0 + TH < a.H && x0 + TW < a.W;
   const bool shifted = SHIFTED && (oy | ox) != 0;
 
-  u32x4 wall[NSTEPS];
-#pragma unroll
-  for (int s = 0; s < NSTEPS; ++s) wall[s] = a.wp[s * 64 + (t0 & 63)];
-  const f32x4 sc2 = *(const f32x4*)(a.scale2 + 4 * ((t0 & 63) >> 4)), sh2 = *(const f32x4*)(a.shift2 + 4 * ((t0 & 63) >> 4)),
-              mu2 = *(const f32x4*)(a.mean2 + 4 * ((t0 & 63) >> 4));
+  // the two unused pixel columns (and, in a shifted tile, the columns another tile counts) carry scale 0, shift -1: their
+  // x = relu(-1) = 0 and their dz = 0 fall out of the same arithmetic -- no mask, no switched-off lanes in the pixel pass
+  f32x4 sc2 = *(const f32x4*)(a.scale2 + 4 * ((t0 & 63) >> 4)), sh2 = *(const f32x4*)(a.shift2 + 4 * ((t0 & 63) >> 4));
+  const f32x4 mu2 = *(const f32x4*)(a.mean2 + 4 * ((t0 & 63) >> 4));
+  if ((t0 & 15) >= TW || (SHIFTED && (t0 & 15) < ox)) {
+    sc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    sh2 = (f32x4){-1.f, -1.f, -1.f, -1.f};
+  }
   if (t0 < 4 * TH) *(u32x4*)(lds + B16_XT + (t0 >> 2) * B16_XT_ROW + TW * PS + (t0 & 3) * 16) = (u32x4){0u, 0u, 0u, 0u};
   if (t0 >= NTHR - 64)
     *(u32x4*)(lds + B16_DY + (((t0 & 63) >> 2) * RP + HW_) * PS + (t0 & 3) * 16) = (u32x4){0u, 0u, 0u, 0u};
@@ -630,21 +639,98 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3))) void c
     issue_halo(n_first);
     issue_y2(n_first);
   }
-  {  // (filter fragments and BatchNorm coefficients have arrived before the tile loop: see the linear kernel)
-    const u32x4 wx = wall[0] ^ wall[1] ^ wall[2] ^ wall[3] ^ wall[4];
+  {  // (the BatchNorm coefficients have arrived before the tile loop: see the linear kernel)
     const f32x4 cx = sc2 + sh2 + mu2;
-    *(u32x4*)(lds + B16_TRASH) = wx;
     *(f32x4*)(lds + B16_TRASH + 16) = cx;
   }
   __syncthreads();  // the k-step table is read before the first staging barrier
-#pragma unroll 1
-  for (int it = 0; it < a.ipw; ++it) {
-    const int n = n_first + it;
-    if (n >= a.N) break;
+  uint2 dzp[MW];
+  // ---- second half of a tile: weight gradient, dz in x's place, the image tap sums
+  auto second_half = [&](const int n) {
     int t = t0;
     asm volatile("" : "+v"(t));
     const int lane = t & 63, r16 = t & 15, g = lane >> 4;
     const int tile = (n * a.tilesY + ty) * a.tilesX + tx;
+    const unsigned xaddr = (unsigned)(B16_XT + wave * B16_XT_ROW + r16 * PS + (((g + (r16 >> 2)) & 3) << 3));
+    B16_STAMP(3)
+    __syncthreads();
+    B16_STAMP(1)
+    if (!WGROWS && t < 32) {
+      const float* red = (const float*)(lds + B16_RED) + t;
+      float tot = red[0];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) tot += red[32 * w];
+      a.rows11[(size_t)tile * 11 * 16 + t] = tot;
+    }
+
+    // ---- weight gradient of the tile (as in the linear kernel: both operands read transposed, the taps dealt to the waves)
+    const unsigned tr_col = (unsigned)((4 * (g & 1) + (r16 >> 2)) * PS + (r16 & 3) * 8);
+    // (the x / dz tile's swizzle: quad r16 & 3 of pixel column 4 (g & 1) + (r16 >> 2) -- and of the column 8 further on)
+    const unsigned tr_x = lds_base + B16_XT + (g >> 1) * B16_XT_ROW + (4 * (g & 1) + (r16 >> 2)) * PS + ((((r16 & 3) + (g & 1)) & 3) << 3);
+    const unsigned tr_xh = (tr_x + 8 * PS) ^ 16u;  // (quad index + 2 mod 4: bit 4 of a 32-byte-aligned pixel's offset)
+    {
+      unsigned ad[TPW];
+#pragma unroll
+      for (int j = 0; j < TPW; ++j) {
+        const int tap = min(wave + NW * j, 8), ky = tap / 3, kx = tap - 3 * ky;
+        ad[j] = lds_base + B16_DY + (g >> 1) * RP * PS + tr_col + (2 - ky) * RP * PS + (2 - kx) * PS;
+      }
+#pragma unroll
+      for (int ks = 0; ks < TH / 2; ++ks) {
+        const bf16x8 af = b16_tr_frag2(tr_x + ks * 2 * B16_XT_ROW, tr_xh + ks * 2 * B16_XT_ROW);
+#pragma unroll
+        for (int j = 0; j < TPW; ++j) {
+          const bf16x8 bf = b16_tr_frag(ad[j] + ks * 2 * RP * PS);
+          wacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, wacc[j], 0, 0, 0);
+        }
+      }
+    }
+    B16_STAMP(4)
+    __syncthreads();
+    B16_STAMP(1)
+
+    // ---- dz takes x's place in LDS; the nine image tap sums on the matrix pipe (wave 0)
+#pragma unroll
+    for (int j = 0; j < MW; ++j) *(uint2*)(lds + xaddr + j * (NW * B16_XT_ROW)) = dzp[j];
+    B16_STAMP(5)
+    __syncthreads();
+    B16_STAMP(1)
+    if (wave == 0) {
+      const int tap = r16 < 9 ? r16 : 0, tky = tap / 3, tkx = tap - 3 * tky;
+      const unsigned char* pb = lds + B16_IM + tkx * 512 + ((g >> 1) + tky) * 32 + (g & 1) * 8;
+      f32x4* dp = (f32x4*)(lds + B16_ACC + (r16 * 16 + 4 * g) * 4);
+      f32x4 D = (WGROWS && r16 < 9) ? *dp : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < TH / 2; ++ks) {
+        const bf16x8 af = b16_tr_frag2(tr_x + ks * 2 * B16_XT_ROW, tr_xh + ks * 2 * B16_XT_ROW);
+        const uint2 b0 = *(const uint2*)(pb + ks * 64), b1 = *(const uint2*)(pb + ks * 64 + 16);
+        const u32x4 bq = {b0.x, b0.y, b1.x, b1.y};
+        D = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, bq), D, 0, 0, 0);
+      }
+      if (WGROWS) {
+        if (r16 < 9) *dp = D;
+      } else if (r16 < 9) *(f32x4*)(a.rows11 + ((size_t)tile * 11 + 2 + r16) * 16 + 4 * g) = D;
+    }
+    B16_STAMP(6)
+    __syncthreads();  // every wave restages the image copies: behind wave 0's reads
+  };
+  // The tile loop leaves from its MIDDLE (behind the pixel pass, where the next tile's requests are issued) and the last
+  // tile's second half runs behind it: with `if (more) issue` inside one body the prefetched registers met their old values
+  // in a phi at the loop's end, and the copies there waited for the requests just issued (s_waitcnt vmcnt(0) + 37 v_mov per
+  // tile in one build of this kernel).
+  int n = n_first;
+  if (n_first < a.N)
+#pragma unroll 1
+  for (int it = 0;; ++it, ++n) {
+    int t = t0;
+    asm volatile("" : "+v"(t));
+    const int lane = t & 63, r16 = t & 15, g = lane >> 4;
+    const int tile = (n * a.tilesY + ty) * a.tilesX + tx;
+    // the filter fragments (5 KB, L1-resident) are requested again for every tile -- behind the tile's own requests issued a
+    // tile period ago, used after everything older: twenty registers that are free outside the dgrad rows
+    u32x4 wall[NSTEPS];
+#pragma unroll
+    for (int s = 0; s < NSTEPS; ++s) wall[s] = a.wp[s * 64 + lane];
     const u32x4 tabA = *(const u32x4*)(lds + B16_TAB + g * 32);
     const unsigned tabB = *(const unsigned*)(lds + B16_TAB + g * 32 + 16);
     {
@@ -667,43 +753,32 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3))) void c
 #pragma unroll
       for (int k = 0; k < ITER; ++k) *(u32x4*)(lp + (RPI * k * RP) * PS) = v[k];
     }
-    const bool more = it + 1 < a.ipw && n + 1 < a.N;
     B16_STAMP(0)
     __syncthreads();
     B16_STAMP(1)
 
-    // ---- input gradient g at the wave's rows wave + 2 j, pixel column r16: 5 k-steps
-    f32x4 acc[MW];
+    // ---- row by row: the input gradient g of the wave's row wave + 2 j (pixel column r16, 5 k-steps) and its pixel pass
+    // (x = relu(bn(y2)) -> LDS, dz = g [x > 0] parked as packed bf16, the BatchNorm-backward sums): one accumulator alive.
+    // The x / dz tile is swizzled -- channel quad q of pixel column p sits at p * 32 + ((q + (p >> 2)) & 3) * 8 -- so that
+    // the 16 lanes one ds_write_b64 cycle serves (one quad, 16 columns) hit 16 different bank pairs (dense: four-way
+    // conflicts, a third of the kernel's LDS cycles by SQ_LDS_BANK_CONFLICT)
+    f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
+    const unsigned xaddr = (unsigned)(B16_XT + wave * B16_XT_ROW + r16 * PS + (((g + (r16 >> 2)) & 3) << 3));
     {
       const unsigned lb = (unsigned)(B16_DY + (wave * RP + r16) * PS);
       const unsigned offs[NSTEPS] = {tabA[0] + lb, tabA[1] + lb, tabA[2] + lb, tabA[3] + lb, tabB + lb};
 #pragma unroll
-      for (int j = 0; j < MW; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < NSTEPS; ++s) {
-#pragma unroll
-        for (int j = 0; j < MW; ++j) {
-          const u32x4 xf = *(const u32x4*)(lds + offs[s] + j * (NW * RP * PS));
-          acc[j] = mfma_chunk<bf16_t>(wall[s], xf, acc[j]);
-        }
-      }
-    }
-
-    B16_STAMP(2)
-    // ---- the pixel pass of the wave's seven pixels per lane (columns 14, 15 switched off for the whole of it)
-    uint2 dzp[MW];
-#pragma unroll
-    for (int j = 0; j < MW; ++j) dzp[j] = (uint2){0u, 0u};
-    f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
-    const unsigned xaddr = (unsigned)(B16_XT + wave * B16_XT_ROW + r16 * PS + g * 8);
-    if (r16 < TW) {
-      const bool keep_x = !SHIFTED || r16 >= ox;
-#pragma unroll
       for (int j = 0; j < MW; ++j) {
-        const bool keep = !shifted || (keep_x && wave + NW * j >= oy);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NSTEPS; ++s) {
+          const u32x4 xf = *(const u32x4*)(lds + offs[s] + j * (NW * RP * PS));
+          acc = mfma_chunk<bf16_t>(wall[s], xf, acc);
+        }
+        const bool keep_y = !shifted || wave + NW * j >= oy;  // (wave-uniform; shifted tiles only)
         const float yv[4] = {__uint_as_float(ypre[j].x << 16), __uint_as_float(ypre[j].x & 0xffff0000u),
                              __uint_as_float(ypre[j].y << 16), __uint_as_float(ypre[j].y & 0xffff0000u)};
-        const f32x2 glo = {acc[j][0], acc[j][1]}, ghi = {acc[j][2], acc[j][3]};
+        const f32x2 glo = {acc[0], acc[1]}, ghi = {acc[2], acc[3]};
         const uint32_t g0 = __builtin_bit_cast(uint32_t, __builtin_convertvector(glo, bf16x2v));
         const uint32_t g1 = __builtin_bit_cast(uint32_t, __builtin_convertvector(ghi, bf16x2v));
         const float gv[4] = {__uint_as_float(g0 << 16), __uint_as_float(g0 & 0xffff0000u),
@@ -711,9 +786,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3))) void c
         float xv[4], dz[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float z = fmaf(sc2[r], yv[r], sh2[r]);
-          xv[r] = keep ? fmaxf(z, 0.f) : 0.f;
-          dz[r] = (z > 0.f && keep) ? gv[r] : 0.f;
+          float z = fmaf(sc2[r], yv[r], sh2[r]);
+          if (SHIFTED) z = keep_y ? z : -1.f;
+          xv[r] = fmaxf(z, 0.f);
+          dz[r] = z > 0.f ? gv[r] : 0.f;
           ssum[r] += dz[r];
           ssq[r] = fmaf(dz[r], yv[r] - mu2[r], ssq[r]);
         }
@@ -724,8 +800,13 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3))) void c
         *(uint2*)(lds + xaddr + j * (NW * B16_XT_ROW)) = w;
         dzp[j].x = (__float_as_uint(dz[0]) >> 16) | (__float_as_uint(dz[1]) & 0xffff0000u);
         dzp[j].y = (__float_as_uint(dz[2]) >> 16) | (__float_as_uint(dz[3]) & 0xffff0000u);
+        // (packed HERE: the compiler sinks the packing to the stores behind the weight-gradient phase and keeps the four
+        // f32 values of every row alive until then -- 28 registers instead of 14)
+        asm volatile("" : "+v"(dzp[j].x), "+v"(dzp[j].y));
+        __builtin_amdgcn_sched_barrier(0);  // (left free, the scheduler hoists every row's fragment reads and spills)
       }
     }
+    B16_STAMP(2)
     {
       f32x4 o;
 #pragma unroll
@@ -738,73 +819,13 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3))) void c
         *rp = WGROWS ? *rp + o : o;
       }
     }
-    if (more) {
-      issue_halo(n + 1);
-      issue_y2(n + 1);
-      issue_img(n + 1);
-    }
-    B16_STAMP(3)
-    __syncthreads();
-    B16_STAMP(1)
-    if (!WGROWS && t < 32) {
-      const float* red = (const float*)(lds + B16_RED) + t;
-      float tot = red[0];
-#pragma unroll
-      for (int w = 1; w < NW; ++w) tot += red[32 * w];
-      a.rows11[(size_t)tile * 11 * 16 + t] = tot;
-    }
-
-    // ---- weight gradient of the tile (as in the linear kernel: both operands read transposed, the taps dealt to the waves)
-    const unsigned tr_col = (unsigned)((4 * (g & 1) + (r16 >> 2)) * PS + (r16 & 3) * 8);
-    const unsigned tr_x = lds_base + B16_XT + (g >> 1) * B16_XT_ROW + tr_col;
-    {
-      unsigned ax = tr_x, ad[TPW];
-#pragma unroll
-      for (int j = 0; j < TPW; ++j) {
-        const int tap = min(wave + NW * j, 8), ky = tap / 3, kx = tap - 3 * ky;
-        ad[j] = lds_base + B16_DY + (g >> 1) * RP * PS + tr_col + (2 - ky) * RP * PS + (2 - kx) * PS;
-      }
-#pragma unroll
-      for (int ks = 0; ks < TH / 2; ++ks) {
-        const bf16x8 af = b16_tr_frag(ax + ks * 2 * B16_XT_ROW);
-#pragma unroll
-        for (int j = 0; j < TPW; ++j) {
-          const bf16x8 bf = b16_tr_frag(ad[j] + ks * 2 * RP * PS);
-          wacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, wacc[j], 0, 0, 0);
-        }
-      }
-    }
-    B16_STAMP(4)
-    __syncthreads();
-    B16_STAMP(1)
-
-    // ---- dz takes x's place in LDS; the nine image tap sums on the matrix pipe (wave 0)
-    if (r16 < TW) {
-#pragma unroll
-      for (int j = 0; j < MW; ++j) *(uint2*)(lds + xaddr + j * (NW * B16_XT_ROW)) = dzp[j];
-    }
-    B16_STAMP(5)
-    __syncthreads();
-    B16_STAMP(1)
-    if (wave == 0) {
-      const int tap = r16 < 9 ? r16 : 0, tky = tap / 3, tkx = tap - 3 * tky;
-      const unsigned char* pb = lds + B16_IM + tkx * 512 + ((g >> 1) + tky) * 32 + (g & 1) * 8;
-      f32x4* dp = (f32x4*)(lds + B16_ACC + (r16 * 16 + 4 * g) * 4);
-      f32x4 D = (WGROWS && r16 < 9) ? *dp : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < TH / 2; ++ks) {
-        const bf16x8 af = b16_tr_frag(tr_x + ks * 2 * B16_XT_ROW);
-        const uint2 b0 = *(const uint2*)(pb + ks * 64), b1 = *(const uint2*)(pb + ks * 64 + 16);
-        const u32x4 bq = {b0.x, b0.y, b1.x, b1.y};
-        D = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, bq), D, 0, 0, 0);
-      }
-      if (WGROWS) {
-        if (r16 < 9) *dp = D;
-      } else if (r16 < 9) *(f32x4*)(a.rows11 + ((size_t)tile * 11 + 2 + r16) * 16 + 4 * g) = D;
-    }
-    B16_STAMP(6)
-    __syncthreads();  // every wave restages the image copies: behind wave 0's reads
+    if (!(it + 1 < a.ipw && n + 1 < a.N)) break;
+    issue_halo(n + 1);
+    issue_y2(n + 1);
+    issue_img(n + 1);
+    second_half(n);
   }
+  if (n_first < a.N) second_half(n);
 
   if (stamp) {
     unsigned long long* o = a.stamps + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8;
