@@ -514,13 +514,26 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(b16_wpe
 // pass (they are the same lanes in every round), their y2 request is lane 13's (no read beyond the tensor's end).
 // Same MFMA operands per output pixel and weight element as the linear kernel: g, x, dz and dW bit for bit; the
 // BatchNorm sums add the same terms in another lane order.
-constexpr int B16_TAB = B16_LDS;              // [4 k-groups][8] dwords: (tap, chunk) byte offsets of the five k-steps
-constexpr int B16_LDS_ROWS = B16_TAB + 128;   // 21 216
+// LDS of the row-mapped kernel: the dy halo with 18-pixel rows (16 + the two zeroed pad pixels; the 22-pixel pitch of the linear
+// kernel kept ITS m-tiles, which cross tile rows, off each other's banks -- here every lane group of an access sits in one
+// row): 19 168 B, eight workgroups = four waves per SIMD where the registers allow it
+#ifndef SPCL_CONV16_ROWS_WPE
+#define SPCL_CONV16_ROWS_WPE 4
+#endif
+constexpr int R16_RP = 18;
+constexpr int R16_DY = 0, R16_DY_BYTES = (B16_TH + 2) * R16_RP * B16_PS;  // 9 216
+constexpr int R16_IM = R16_DY_BYTES;
+constexpr int R16_XT = R16_IM + B16_IM_BYTES;
+constexpr int R16_RED = R16_XT + B16_XT_BYTES;
+constexpr int R16_ACC = R16_RED + 512;
+constexpr int R16_TRASH = R16_ACC + 576;
+constexpr int R16_TAB = R16_TRASH + 32;        // [4 k-groups][8] dwords: (tap, chunk) byte offsets of the five k-steps
+constexpr int B16_LDS_ROWS = R16_TAB + 128;    // 19 168
 
 template <bool SHIFTED, bool WGROWS>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3))) void conv16_bwd_rows_kernel(Bwd16Args a) {
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SPCL_CONV16_ROWS_WPE))) void conv16_bwd_rows_kernel(Bwd16Args a) {
   constexpr int NW = 2;
-  constexpr int TH = B16_TH, TW = B16_TW, HW_ = B16_HW, RP = B16_RP, PS = B16_PS;
+  constexpr int TH = B16_TH, TW = B16_TW, HW_ = B16_HW, RP = R16_RP, PS = B16_PS;
   constexpr int NSTEPS = 5, NTHR = 64 * NW, ITER = 512 / NTHR, RPI = NTHR / 32;
   constexpr int MW = TH / NW, TPW = (9 + NW - 1) / NW;
   static_assert(TH % NW == 0, "rows are dealt to the waves evenly");
@@ -556,30 +569,22 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3))) void c
   const bool interior = y0 > 0 && x0 > 0 && y0 + TH < a.H && x0 + TW < a.W;
   const bool shifted = SHIFTED && (oy | ox) != 0;
 
-  // the two unused pixel columns (and, in a shifted tile, the columns another tile counts) carry scale 0, shift -1: their
-  // x = relu(-1) = 0 and their dz = 0 fall out of the same arithmetic -- no mask, no switched-off lanes in the pixel pass
-  f32x4 sc2 = *(const f32x4*)(a.scale2 + 4 * ((t0 & 63) >> 4)), sh2 = *(const f32x4*)(a.shift2 + 4 * ((t0 & 63) >> 4));
-  const f32x4 mu2 = *(const f32x4*)(a.mean2 + 4 * ((t0 & 63) >> 4));
-  if ((t0 & 15) >= TW || (SHIFTED && (t0 & 15) < ox)) {
-    sc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
-    sh2 = (f32x4){-1.f, -1.f, -1.f, -1.f};
-  }
-  if (t0 < 4 * TH) *(u32x4*)(lds + B16_XT + (t0 >> 2) * B16_XT_ROW + TW * PS + (t0 & 3) * 16) = (u32x4){0u, 0u, 0u, 0u};
+  if (t0 < 4 * TH) *(u32x4*)(lds + R16_XT + (t0 >> 2) * B16_XT_ROW + TW * PS + (t0 & 3) * 16) = (u32x4){0u, 0u, 0u, 0u};
   if (t0 >= NTHR - 64)
-    *(u32x4*)(lds + B16_DY + (((t0 & 63) >> 2) * RP + HW_) * PS + (t0 & 3) * 16) = (u32x4){0u, 0u, 0u, 0u};
+    *(u32x4*)(lds + R16_DY + (((t0 & 63) >> 2) * RP + HW_) * PS + (t0 & 3) * 16) = (u32x4){0u, 0u, 0u, 0u};
   if (t0 < 48) {
     const int r = t0 & 15, k = t0 >> 4;
-    ((bf16_t*)(lds + B16_IM))[(k == 0 ? 256 + 15 : (k == 1 ? 512 + 14 : 512 + 15)) + r * 16] = 0;
+    ((bf16_t*)(lds + R16_IM))[(k == 0 ? 256 + 15 : (k == 1 ? 512 + 14 : 512 + 15)) + r * 16] = 0;
   }
   if (t0 >= 64 && t0 < 64 + 20) {  // the k-step table: lane group g, k-step s -> chunk 4 s + g = (tap, 8-channel half)
     const int e = t0 - 64, gq = e / NSTEPS, s = e - gq * NSTEPS;
     int fc = 4 * s + gq;
     if (fc >= 18) fc = 0;  // K padding: zero weights
     const int tap = fc >> 1, c = fc & 1, ky = (tap * 11) >> 5, kx = tap - 3 * ky;
-    ((unsigned*)(lds + B16_TAB))[gq * 8 + s] = (unsigned)((ky * RP + kx) * PS + c * 16);
+    ((unsigned*)(lds + R16_TAB))[gq * 8 + s] = (unsigned)((ky * RP + kx) * PS + c * 16);
   }
   if (WGROWS)
-    for (int i = t0; i < (512 + 576) / 4; i += NTHR) ((float*)(lds + B16_RED))[i] = 0.f;
+    for (int i = t0; i < (512 + 576) / 4; i += NTHR) ((float*)(lds + R16_RED))[i] = 0.f;
   f32x4 wacc[TPW];
 #pragma unroll
   for (int j = 0; j < TPW; ++j) wacc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -588,47 +593,53 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3))) void c
   u32x4 v[ITER];
   uint2 ypre[MW];
   constexpr int PPT = 256 / NTHR;
+  // Every global request is a buffer load: a scalar descriptor per tensor and tile (base = the tile's first halo / tile /
+  // image pixel: scalar arithmetic), ONE 32-bit lane offset per request kind and a scalar row offset per request -- as
+  // global loads with 64-bit lane addresses each request cost two address registers and their additions
+  auto rsrc = [](const void* p) { return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 0x7fffffff, 0x00020000); };
+  constexpr int OOB = (int)0x80000000u;  // (>= num_records: the load returns zeros and touches no memory; 0x7ffffff0 is INSIDE 2 GiB - 1)
   auto issue_img = [&](const int n) {
     int t = t0;
     asm volatile("" : "+v"(t));
     const int hr = (t * PPT) >> 4, hc = (t * PPT) & 15;
     const int gy = y0 - 1 + hr;
-    const float* ir = a.img + ((size_t)n * a.H + (gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy))) * a.W;
+    const __amdgpu_buffer_rsrc_t rs = rsrc(a.img + (size_t)n * a.H * a.W);
+    const int rowo = (gy < 0 ? 0 : (gy >= a.H ? a.H - 1 : gy)) * a.W;
 #pragma unroll
     for (int e = 0; e < PPT; ++e) {
       const int gx = x0 - 1 + hc + e;
-      imgv[e] = ir[gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx)];
+      imgv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (rowo + (gx < 0 ? 0 : (gx >= a.W ? a.W - 1 : gx))) * 4, 0, 0));
     }
   };
   auto issue_halo = [&](const int n) {
     int t = t0;
     asm volatile("" : "+v"(t));
     const int ch = t & 1, q0 = t >> 1, hy0 = q0 / HW_, hx0 = q0 % HW_;
-    const unsigned voff = (unsigned)((hy0 * a.W + hx0) * 32 + ch * 16);
-    const unsigned char* xb = a.dy + (((long)n * a.H + (y0 - 1)) * a.W + (x0 - 1)) * 32;
+    const int voff = (hy0 * a.W + hx0) * 32 + ch * 16;
+    const __amdgpu_buffer_rsrc_t rs = rsrc(a.dy + (((long)n * a.H + (y0 - 1)) * a.W + (x0 - 1)) * 32);
 #pragma unroll
     for (int k = 0; k < ITER; ++k) {
-      const long soff = (long)(RPI * k) * a.W * 32;
       bool inb = true;
       if (!interior) {
         const int gy = y0 - 1 + hy0 + RPI * k, gx = x0 - 1 + hx0;
         inb = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
       }
-      v[k] = (u32x4){0u, 0u, 0u, 0u};
-      if (inb) v[k] = *(const u32x4*)(xb + soff + voff);
+      v[k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, inb ? voff : OOB, RPI * k * a.W * 32, 0));
     }
   };
   // y2 at the wave's rows: ONE lane offset (pixel column r16 -- 13 for the two unused columns -- and channel quarter g),
-  // the row base is wave-uniform (scalar additions per round)
+  // the row is a scalar offset
   auto issue_y2 = [&](const int n) {
     int t = t0;
     asm volatile("" : "+v"(t));
     const int r16 = t & 15, g = (t & 63) >> 4;
-    const unsigned voff = (unsigned)(min(r16, TW - 1) * 32 + g * 8);
-    const unsigned char* y2b = a.y2 + (((size_t)n * a.H + y0 + wave) * a.W + x0) * 32;
+    const int voff = min(r16, TW - 1) * 32 + g * 8;
+    const __amdgpu_buffer_rsrc_t rs = rsrc(a.y2 + (((size_t)n * a.H + y0 + wave) * a.W + x0) * 32);
 #pragma unroll
-    for (int j = 0; j < MW; ++j) ypre[j] = *(const uint2*)(y2b + (size_t)(NW * j) * a.W * 32 + voff);
+    for (int j = 0; j < MW; ++j)
+      ypre[j] = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, NW * j * a.W * 32, 0));
   };
+  const __amdgpu_buffer_rsrc_t rs_wp = rsrc(a.wp), rs_sc = rsrc(a.scale2), rs_sh = rsrc(a.shift2), rs_mu = rsrc(a.mean2);
 
   const bool stamp = SPCL_CONV16_STAMPS_BUILD && a.stamps != nullptr && t0 == 0;
   unsigned long long tph[7] = {0, 0, 0, 0, 0, 0, 0}, tc = 0;
@@ -639,10 +650,6 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3))) void c
     issue_halo(n_first);
     issue_y2(n_first);
   }
-  {  // (the BatchNorm coefficients have arrived before the tile loop: see the linear kernel)
-    const f32x4 cx = sc2 + sh2 + mu2;
-    *(f32x4*)(lds + B16_TRASH + 16) = cx;
-  }
   __syncthreads();  // the k-step table is read before the first staging barrier
   uint2 dzp[MW];
   // ---- second half of a tile: weight gradient, dz in x's place, the image tap sums
@@ -651,12 +658,12 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3))) void c
     asm volatile("" : "+v"(t));
     const int lane = t & 63, r16 = t & 15, g = lane >> 4;
     const int tile = (n * a.tilesY + ty) * a.tilesX + tx;
-    const unsigned xaddr = (unsigned)(B16_XT + wave * B16_XT_ROW + r16 * PS + (((g + (r16 >> 2)) & 3) << 3));
+    const unsigned xaddr = (unsigned)(R16_XT + wave * B16_XT_ROW + r16 * PS + (((g + (r16 >> 2)) & 3) << 3));
     B16_STAMP(3)
     __syncthreads();
     B16_STAMP(1)
     if (!WGROWS && t < 32) {
-      const float* red = (const float*)(lds + B16_RED) + t;
+      const float* red = (const float*)(lds + R16_RED) + t;
       float tot = red[0];
 #pragma unroll
       for (int w = 1; w < NW; ++w) tot += red[32 * w];
@@ -666,14 +673,14 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3))) void c
     // ---- weight gradient of the tile (as in the linear kernel: both operands read transposed, the taps dealt to the waves)
     const unsigned tr_col = (unsigned)((4 * (g & 1) + (r16 >> 2)) * PS + (r16 & 3) * 8);
     // (the x / dz tile's swizzle: quad r16 & 3 of pixel column 4 (g & 1) + (r16 >> 2) -- and of the column 8 further on)
-    const unsigned tr_x = lds_base + B16_XT + (g >> 1) * B16_XT_ROW + (4 * (g & 1) + (r16 >> 2)) * PS + ((((r16 & 3) + (g & 1)) & 3) << 3);
+    const unsigned tr_x = lds_base + R16_XT + (g >> 1) * B16_XT_ROW + (4 * (g & 1) + (r16 >> 2)) * PS + ((((r16 & 3) + (g & 1)) & 3) << 3);
     const unsigned tr_xh = (tr_x + 8 * PS) ^ 16u;  // (quad index + 2 mod 4: bit 4 of a 32-byte-aligned pixel's offset)
     {
       unsigned ad[TPW];
 #pragma unroll
       for (int j = 0; j < TPW; ++j) {
         const int tap = min(wave + NW * j, 8), ky = tap / 3, kx = tap - 3 * ky;
-        ad[j] = lds_base + B16_DY + (g >> 1) * RP * PS + tr_col + (2 - ky) * RP * PS + (2 - kx) * PS;
+        ad[j] = lds_base + R16_DY + (g >> 1) * RP * PS + tr_col + (2 - ky) * RP * PS + (2 - kx) * PS;
       }
 #pragma unroll
       for (int ks = 0; ks < TH / 2; ++ks) {
@@ -683,6 +690,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3))) void c
           const bf16x8 bf = b16_tr_frag(ad[j] + ks * 2 * RP * PS);
           wacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, wacc[j], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);  // (one k-step's twelve fragment reads in flight, not seven: registers)
       }
     }
     B16_STAMP(4)
@@ -697,8 +705,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3))) void c
     B16_STAMP(1)
     if (wave == 0) {
       const int tap = r16 < 9 ? r16 : 0, tky = tap / 3, tkx = tap - 3 * tky;
-      const unsigned char* pb = lds + B16_IM + tkx * 512 + ((g >> 1) + tky) * 32 + (g & 1) * 8;
-      f32x4* dp = (f32x4*)(lds + B16_ACC + (r16 * 16 + 4 * g) * 4);
+      const unsigned char* pb = lds + R16_IM + tkx * 512 + ((g >> 1) + tky) * 32 + (g & 1) * 8;
+      f32x4* dp = (f32x4*)(lds + R16_ACC + (r16 * 16 + 4 * g) * 4);
       f32x4 D = (WGROWS && r16 < 9) ? *dp : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < TH / 2; ++ks) {
@@ -730,9 +738,20 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3))) void c
     // tile period ago, used after everything older: twenty registers that are free outside the dgrad rows
     u32x4 wall[NSTEPS];
 #pragma unroll
-    for (int s = 0; s < NSTEPS; ++s) wall[s] = a.wp[s * 64 + lane];
-    const u32x4 tabA = *(const u32x4*)(lds + B16_TAB + g * 32);
-    const unsigned tabB = *(const unsigned*)(lds + B16_TAB + g * 32 + 16);
+    for (int s = 0; s < NSTEPS; ++s)
+      wall[s] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_wp, lane * 16, s * 1024, 0));
+    // ... and so are the BatchNorm coefficients of the lane's channel quad.  The two unused pixel columns (and, in a shifted
+    // tile, the columns another tile counts) carry scale 0, shift -1: their x = relu(-1) = 0 and their dz = 0 fall out of the
+    // same arithmetic -- no mask, no switched-off lanes in the pixel pass
+    f32x4 sc2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_sc, g * 16, 0, 0));
+    f32x4 sh2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_sh, g * 16, 0, 0));
+    const f32x4 mu2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_mu, g * 16, 0, 0));
+    if (r16 >= TW || (SHIFTED && r16 < ox)) {
+      sc2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+      sh2 = (f32x4){-1.f, -1.f, -1.f, -1.f};
+    }
+    const u32x4 tabA = *(const u32x4*)(lds + R16_TAB + g * 32);
+    const unsigned tabB = *(const unsigned*)(lds + R16_TAB + g * 32 + 16);
     {
       const int hr = (t * PPT) >> 4, hc = (t * PPT) & 15;
       const int gy = y0 - 1 + hr;
@@ -741,7 +760,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3))) void c
         const int gx = x0 - 1 + hc + e;
         const float hv = (interior || (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)) ? imgv[e] : 0.f;
         const bf16_t hb = f32_to_bf16(hv);
-        bf16_t* imb = (bf16_t*)(lds + B16_IM) + hr * 16 + hc + e;
+        bf16_t* imb = (bf16_t*)(lds + R16_IM) + hr * 16 + hc + e;
         imb[0] = hb;
         if (hc + e >= 1) imb[256 - 1] = hb;
         if (hc + e >= 2) imb[512 - 2] = hb;
@@ -749,7 +768,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3))) void c
     }
     {
       const int ch = t & 1, q0 = t >> 1, hy0 = q0 / HW_, hx0 = q0 % HW_;
-      unsigned char* const lp = lds + B16_DY + (hy0 * RP + hx0) * PS + ch * 16;
+      unsigned char* const lp = lds + R16_DY + (hy0 * RP + hx0) * PS + ch * 16;
 #pragma unroll
       for (int k = 0; k < ITER; ++k) *(u32x4*)(lp + (RPI * k * RP) * PS) = v[k];
     }
@@ -763,9 +782,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3))) void c
     // the 16 lanes one ds_write_b64 cycle serves (one quad, 16 columns) hit 16 different bank pairs (dense: four-way
     // conflicts, a third of the kernel's LDS cycles by SQ_LDS_BANK_CONFLICT)
     f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
-    const unsigned xaddr = (unsigned)(B16_XT + wave * B16_XT_ROW + r16 * PS + (((g + (r16 >> 2)) & 3) << 3));
+    const unsigned xaddr = (unsigned)(R16_XT + wave * B16_XT_ROW + r16 * PS + (((g + (r16 >> 2)) & 3) << 3));
     {
-      const unsigned lb = (unsigned)(B16_DY + (wave * RP + r16) * PS);
+      const unsigned lb = (unsigned)(R16_DY + (wave * RP + r16) * PS);
       const unsigned offs[NSTEPS] = {tabA[0] + lb, tabA[1] + lb, tabA[2] + lb, tabA[3] + lb, tabB + lb};
 #pragma unroll
       for (int j = 0; j < MW; ++j) {
@@ -815,7 +834,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3))) void c
         o[r] = r16 == 0 ? s1 : s2;
       }
       if (r16 < 2) {
-        f32x4* rp = (f32x4*)(lds + B16_RED + ((wave * 2 + r16) * 16 + 4 * g) * 4);
+        f32x4* rp = (f32x4*)(lds + R16_RED + ((wave * 2 + r16) * 16 + 4 * g) * 4);
         *rp = WGROWS ? *rp + o : o;
       }
     }
@@ -838,12 +857,12 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(3))) void c
     for (int i = t0; i < 11 * 16; i += NTHR) {
       float tot;
       if (i < 32) {
-        const float* red = (const float*)(lds + B16_RED) + i;
+        const float* red = (const float*)(lds + R16_RED) + i;
         tot = red[0];
 #pragma unroll
         for (int w = 1; w < NW; ++w) tot += red[32 * w];
       } else {
-        tot = ((const float*)(lds + B16_ACC))[i - 32];
+        tot = ((const float*)(lds + R16_ACC))[i - 32];
       }
       a.wg_rows[(size_t)i * a.nwg + wg] = tot;
     }
@@ -874,7 +893,8 @@ int conv16_bwd_nw() {
 
 int conv16_bwd_ipw(int N, int H, int W) {
   // one resident generation of workgroups where the batch allows it: LDS (20 KB) and registers allow 8 / 6 / 3 per CU
-  const int nw = conv16_bwd_nw(), resident = 256 * (nw == 1 ? 8 : (nw == 2 ? 6 : 3));
+  const int nw = conv16_bwd_nw();
+  const int resident = 256 * (nw == 1 ? 8 : (nw == 2 ? (conv16_bwd_rowmap() ? 2 * SPCL_CONV16_ROWS_WPE : 6) : 3));
   const long tiles = (long)cdiv(H, B16_TH) * cdiv(W, B16_TW);
   static const int env_ipw = getenv("SPCL_CONV16_IPW") ? atoi(getenv("SPCL_CONV16_IPW")) : 0;
   int ipw = env_ipw > 0 ? env_ipw : (int)((tiles * N + resident - 1) / resident);
