@@ -68,11 +68,24 @@ struct FastArgs {
 #ifndef SPCL_FAST_DBG
 #define SPCL_FAST_DBG 0  /* timing experiments only (wrong results): 1 no ring refills, 2 no fragment reads in the k-loop */
 #endif
+// SPCL_FAST_ROWMAP (round 4): the m-tiles lie along the TILE ROWS -- m-tile i = row i of the tile as 16 pixel columns, of
+// which the last two read halo columns 16, 17 (never staged: whatever they hold only reaches D's columns 14, 15, which nobody
+// uses) -- instead of 16 consecutive pixels of the 14-wide tile in linear order.  A lane's pixel column is r16 in every
+// m-tile and its row is the m-tile's index: fragment bases, output offsets and the statistics' positions are ONE per-lane
+// value plus compile-time / wave-uniform steps (the linear order cost a division per m-tile base, a carry walk per m-tile in
+// the epilogue, validity predicates in the last m-tile), the 16 lanes of every ds_read_b128 group sit in one halo row (no
+// bank conflicts whatever the row pitch: the 22-pixel pitch -- 27-40 % padding -- goes back to 18, i.e. more workgroups per
+// CU where the halo image decides the occupancy).  7-row tiles keep 7 m-tiles, 14-row tiles take 14 for 13 (+ 8 % MFMAs on
+// the two 224^2 layers, which are bound by vector instructions).  Same k order per output: outputs bit for bit; the
+// statistics add the same terms in another lane order.
+#ifndef SPCL_FAST_ROWMAP
+#define SPCL_FAST_ROWMAP 1
+#endif
 #ifndef SPCL_FAST_RP
-#define SPCL_FAST_RP 22
+#define SPCL_FAST_RP (SPCL_FAST_ROWMAP ? 18 : 22)
 #endif
 #ifndef SPCL_FAST_RP_NARROW
-#define SPCL_FAST_RP_NARROW 22
+#define SPCL_FAST_RP_NARROW (SPCL_FAST_ROWMAP ? 18 : 22)
 #endif
 constexpr int fast_pixel_stride(int KC) { return KC == 16 ? 32 : KC * 2 + 32; }
 constexpr int fast_row_pitch(int KC) { return KC == 64 ? SPCL_FAST_RP : SPCL_FAST_RP_NARROW; }
@@ -85,7 +98,7 @@ constexpr int fast_wpe(int KC, int TH, int NW, int NT, int MODE = 0) {
   const int wgs = 160 * 1024 / fast_lds_bytes(KC, TH);
   int w = (wgs * NW + 3) / 4;
   w = w > 4 ? 4 : (w < 1 ? 1 : w);
-  const int acc = (TH * 14 + 15) / 16 * NT * 4;  // accumulator registers of a wave
+  const int acc = (SPCL_FAST_ROWMAP ? TH : (TH * 14 + 15) / 16) * NT * 4;  // accumulator registers of a wave
   if (KC == 16 && MODE >= 2 && SPCL_FAST_YPRE_MINKC <= 16 && w > 3 && acc <= 80) return 3;  // room for the y2 requests
   if (acc > 80 && w > 2) return 2;               // 13 m-tiles x 2 n-tiles: give the allocator 256 registers
   if (KC == 64 && NT == 1 && NW >= 2 && w > 2) return SPCL_FAST_WPE_NT1;  // 9-step ring of one n-tile: 36 registers
@@ -100,7 +113,8 @@ conv3x3_fast_kernel(FastArgs a) {
   constexpr int TW = 14, HW_ = 16, CP = KC / 8, NHALO = (TH + 2) * HW_, PS = fast_pixel_stride(KC);
   constexpr int RP = fast_row_pitch(KC);  // LDS row pitch in pixels (HW_ of them are halo pixels)
   constexpr int NTHR = 64 * NW, NCH = NHALO * CP, ITER = (NCH + NTHR - 1) / NTHR, QS = NTHR / CP;
-  constexpr int NPIX = TH * TW, MT = (NPIX + 15) / 16, NSTEPS = (9 * CP + 3) / 4;
+  constexpr bool RM = SPCL_FAST_ROWMAP != 0;
+  constexpr int NPIX = TH * TW, MT = RM ? TH : (NPIX + 15) / 16, NSTEPS = (9 * CP + 3) / 4;
   constexpr bool PRELOAD_W = KC == 16;  // 5 k-steps: every weight fragment of the wave lives in registers
   constexpr bool PRELOAD_SLAB = fast_preload_slab(KC, NW, NT);
   static_assert(QS >= HW_ ? QS % HW_ == 0 : HW_ % QS == 0, "staging walk needs whole/even halo rows per iteration");
@@ -191,10 +205,14 @@ conv3x3_fast_kernel(FastArgs a) {
   int abase[MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    int p = 16 * i + r16;
-    if (p >= NPIX) p = 0;
-    const int py = p / TW, px = p - py * TW;
-    abase[i] = (py * RP + px) * PS + (CP >= 4 ? g * 16 : 0);
+    if (RM) {
+      abase[i] = (i * RP + r16) * PS + (CP >= 4 ? g * 16 : 0);
+    } else {
+      int p = 16 * i + r16;
+      if (p >= NPIX) p = 0;
+      const int py = p / TW, px = p - py * TW;
+      abase[i] = (py * RP + px) * PS + (CP >= 4 ? g * 16 : 0);
+    }
   }
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -332,6 +350,10 @@ conv3x3_fast_kernel(FastArgs a) {
           const u32x4 xf = *(const u32x4*)(lds + abase[i] + off);
 #pragma unroll
           for (int j = 0; j < NT; ++j) acc[i][j] = mfma_chunk<bf16_t>(wf[j], xf, acc[i][j]);
+          // (row order, 14-row tiles: the fragment addresses are immediates now, and the scheduler -- no address register to
+          // hold it back -- requests all 14 fragments of several steps at once: 126 registers + the weight fragments spilled
+          // right behind their loads, three serialised round trips at the head of every workgroup, + 14 us on Conv1.b)
+          if (RM && !PRELOAD_SLAB && i % 7 == 6) __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
@@ -379,7 +401,7 @@ conv3x3_fast_kernel(FastArgs a) {
   if (stamp) t_k1 = __builtin_amdgcn_s_memtime();
 
   // ------------ epilogue: lane holds couts 16 (nt0 + j) + 4 g .. +3 of pixel p = 16 i + r16 (tiles are always full)
-  constexpr int DPY = 16 / TW, DPX = 16 % TW;
+  constexpr int DPY = RM ? 1 : 16 / TW, DPX = RM ? 0 : 16 % TW;  // from m-tile to m-tile: one row on / 16 pixels on
   const int rowb = a.CoutS * 2;
   // (MODE 0 with y_hi: the output channels' upper half goes to a second dense tensor -- the gradient of a channel
   // concatenation leaves as the two gradients of its parts; an n-tile belongs to one of them whole)
@@ -396,7 +418,7 @@ conv3x3_fast_kernel(FastArgs a) {
     unsigned char* dst = (twoy && gnt >= half) ? a.y_hi : a.y;
     yj[j] = dst + (((size_t)n * a.H + y0) * a.W + x0) * rowo + ((twoy && gnt >= half ? gnt - half : gnt) * 16 + 4 * g) * 2;
   }
-  int py = r16 / TW, px = r16 - py * TW;
+  int py = RM ? 0 : r16 / TW, px = r16 - py * TW;
   int ob = (py * a.W + px) * rowo;
   const int dob = (DPY * a.W + DPX) * rowo, wrapo = (a.W - TW) * rowo;
   f32x4 ssum[NT], ssq[NT];
@@ -458,7 +480,7 @@ conv3x3_fast_kernel(FastArgs a) {
     for (int ii = 0; ii < GM; ++ii) {
       const int i = c * GM + ii;
       if (i < MT) {
-        const bool ok = (16 * i + 15 < NPIX) || (16 * i + r16 < NPIX);
+        const bool ok = RM || (16 * i + 15 < NPIX) || (16 * i + r16 < NPIX);  // (row order: the unused columns are off already)
         if (ok) {
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
@@ -477,7 +499,7 @@ conv3x3_fast_kernel(FastArgs a) {
         lpx += DPX;
         lpyc += DPY;
         lob += dob;
-        if (lpx >= TW) {
+        if (!RM && lpx >= TW) {
           lpx -= TW;
           lpyc += 1;
           lob += wrapo;
@@ -485,6 +507,9 @@ conv3x3_fast_kernel(FastArgs a) {
       }
     }
   };
+  // (row order: pixel columns 14, 15 of every m-tile are nobody's -- the same lanes throughout, switched off once for the whole
+  // epilogue: their requests, stores and statistics never happen)
+  if (!RM || r16 < TW) {
   if (YPRE) {
     request_chunk(0);
     __builtin_amdgcn_sched_barrier(0);  // (the scheduler would hoist every later request up here too)
@@ -493,7 +518,7 @@ conv3x3_fast_kernel(FastArgs a) {
   int ob_prev = 0;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    const bool ok = (16 * i + 15 < NPIX) || (16 * i + r16 < NPIX);  // compile-time true except in the last m-tile
+    const bool ok = RM || (16 * i + 15 < NPIX) || (16 * i + r16 < NPIX);  // compile-time true except in the last linear m-tile
     if (YPRE && i % GM == 0 && (i / GM + 1) * GM < MT) {
       request_chunk(i / GM + 1);
       __builtin_amdgcn_sched_barrier(0);
@@ -509,8 +534,8 @@ conv3x3_fast_kernel(FastArgs a) {
           // pixel of m-tile i -- half the store instructions for the same bytes (conv3x3_image_kernel below)
           // (not in the one-wave KC = 64 kernels: at their 128-register budget the parked halves spill)
           constexpr bool PAIRED = SPCL_FAST_WIDE_STORES && MODE != 4 && !(KC == 64 && NW == 1);
-          const bool first = PAIRED && i % 2 == 0 && i + 1 < MT && 16 * (i + 1) + 15 < NPIX;
-          const bool second = PAIRED && i % 2 == 1 && 16 * i + 15 < NPIX;
+          const bool first = PAIRED && i % 2 == 0 && i + 1 < MT && (RM || 16 * (i + 1) + 15 < NPIX);
+          const bool second = PAIRED && i % 2 == 1 && (RM || 16 * i + 15 < NPIX);
           if (first || second) {
             const f32x2 lo = {acc[i][j][0], acc[i][j][1]}, hi = {acc[i][j][2], acc[i][j][3]};
             uint2 pkc;
@@ -593,11 +618,12 @@ conv3x3_fast_kernel(FastArgs a) {
     px += DPX;
     pyc += DPY;
     ob += dob;
-    if (px >= TW) {
+    if (!RM && px >= TW) {
       px -= TW;
       pyc += 1;
       ob += wrapo;
     }
+  }
   }
   constexpr int RS = MODE == 4 ? 11 : 2;  // rows per tile of rows2
   if (M2 || MODE == 3) {
