@@ -807,15 +807,15 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SPCL_CONV16
         for (int r = 0; r < 4; ++r) {
           float z = fmaf(sc2[r], yv[r], sh2[r]);
           if (SHIFTED) z = keep_y ? z : -1.f;
-          xv[r] = fmaxf(z, 0.f);
+          xv[r] = z;  // (ReLU on the rounded pairs below)
           dz[r] = z > 0.f ? gv[r] : 0.f;
           ssum[r] += dz[r];
           ssq[r] = fmaf(dz[r], yv[r] - mu2[r], ssq[r]);
         }
         const f32x2 lo = {xv[0], xv[1]}, hi = {xv[2], xv[3]};
         uint2 w;
-        w.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf16x2v));
-        w.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(hi, bf16x2v));
+        w.x = relu_bf16x2(__builtin_bit_cast(uint32_t, __builtin_convertvector(lo, bf16x2v)));
+        w.y = relu_bf16x2(__builtin_bit_cast(uint32_t, __builtin_convertvector(hi, bf16x2v)));
         *(uint2*)(lds + xaddr + j * (NW * B16_XT_ROW)) = w;
         dzp[j].x = (__float_as_uint(dz[0]) >> 16) | (__float_as_uint(dz[1]) & 0xffff0000u);
         dzp[j].y = (__float_as_uint(dz[2]) >> 16) | (__float_as_uint(dz[3]) & 0xffff0000u);

@@ -86,6 +86,13 @@ __device__ __forceinline__ float row16_sum(float v) {
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2v;
+typedef __attribute__((ext_vector_type(2))) short s16x2v;
+
+// relu of a packed bf16 pair: the maximum with 0 of its halves read as signed 16-bit integers (v_pk_max_i16)
+__device__ __forceinline__ uint32_t relu_bf16x2(uint32_t packed) {
+  const s16x2v z = {0, 0};
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2v, packed), z));
+}
 
 // relu(scale*v+shift) on one 16-byte chunk with the coefficients already in registers (packed-f32 FMA and one
 // v_cvt_pk_bf16_f32 per channel pair on the bf16 path)
@@ -101,10 +108,13 @@ template <> __device__ __forceinline__ u32x4 bnrelu_regs<bf16_t>(u32x4 raw, cons
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     float lo = __uint_as_float(raw[e] << 16), hi = __uint_as_float(raw[e] & 0xffff0000u);
-    lo = fmaxf(fmaf(s[2 * e], lo, b[2 * e]), 0.f);  // same arithmetic as wgrad's staging: identical activations
-    hi = fmaxf(fmaf(s[2 * e + 1], hi, b[2 * e + 1]), 0.f);
+    lo = fmaf(s[2 * e], lo, b[2 * e]);  // same arithmetic as wgrad's staging: identical activations
+    hi = fmaf(s[2 * e + 1], hi, b[2 * e + 1]);
     const f32x2 v = {lo, hi};
-    out[e] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2v));
+    // ReLU on the ROUNDED pair, as a signed 16-bit maximum with 0 (one v_pk_max_i16 for two v_max_f32): rounding to bf16 keeps
+    // the sign, so relu-then-round and round-then-relu are the same bits (-0 and every negative value have the sign bit set
+    // and become +0; a NaN stays a NaN instead of becoming 0)
+    out[e] = relu_bf16x2(__builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2v)));
   }
   return out;
 }

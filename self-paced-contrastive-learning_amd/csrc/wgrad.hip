@@ -9,15 +9,11 @@
 // them in fixed order (deterministic, no float atomics) into the OIHW f32 gradient.
 #include <stdlib.h>
 #include <vector>
-#include "common.hpp"
+#include "conv_common.hpp"
 
 namespace spcl {
 
-typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
-template <typename T> struct Chunk;
-template <> struct Chunk<float> { static constexpr int EPC = 4; };
-template <> struct Chunk<bf16_t> { static constexpr int EPC = 8; };
-
+// (u32x4, Chunk<T>, relu_bf16x2: conv_common.hpp)
 constexpr int WG_TW = 16, WG_HW = WG_TW + 2;
 
 struct WgradArgs {
@@ -49,9 +45,10 @@ template <> __device__ __forceinline__ u32x4 wg_bnrelu_chunk<bf16_t>(u32x4 raw, 
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     float lo = __uint_as_float(raw[e] << 16), hi = __uint_as_float(raw[e] & 0xffff0000u);
-    lo = fmaxf(fmaf(s[2 * e], lo, b[2 * e]), 0.f);
-    hi = fmaxf(fmaf(s[2 * e + 1], hi, b[2 * e + 1]), 0.f);
-    out[e] = (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    lo = fmaf(s[2 * e], lo, b[2 * e]);
+    hi = fmaf(s[2 * e + 1], hi, b[2 * e + 1]);
+    const f32x2 v = {lo, hi};  // (ReLU on the rounded pair: conv_common.hpp relu_bf16x2 -- the same bits)
+    out[e] = relu_bf16x2(__builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2v)));
   }
   return out;
 }
