@@ -681,10 +681,21 @@ conv3x3_fast_kernel(FastArgs a) {
 template <int TH, bool EVEN>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void conv3x3_image_kernel(FastArgs a) {
   constexpr int TW = 14, HW_ = 16, LW = HW_ + 2;  // LDS row: 16 halo pixels + 2 so that pair q+2 of the last tap exists
-  constexpr int NPIX = TH * TW, MT = (NPIX + 15) / 16, NHALO = (TH + 2) * HW_;
+  constexpr bool RM = SPCL_FAST_ROWMAP != 0;  // m-tile i = tile row i, pixel column r16 (see conv3x3_fast_kernel)
+  constexpr int NPIX = TH * TW, MT = RM ? TH : (NPIX + 15) / 16, NHALO = (TH + 2) * HW_;
   __shared__ uint32_t pairs[(TH + 2) * LW];
   const int lane = threadIdx.x, r16 = lane & 15, g = lane >> 4;
-  const int tx = blockIdx.x, ty = blockIdx.y, n = blockIdx.z;
+  int tx = blockIdx.x, ty = blockIdx.y;
+  const int n = blockIdx.z;
+  {  // (an XCD's workgroups take neighbouring tiles: the 128-byte lines two tiles of a row share are completed in ONE L2)
+    const int T = a.tilesX * a.tilesY;
+    if (a.xcd_remap && (T & 7) == 0) {
+      const int L = ty * a.tilesX + tx;
+      const int L2 = (L & 7) * (T >> 3) + (L >> 3);
+      ty = L2 / a.tilesX;
+      tx = L2 - ty * a.tilesX;
+    }
+  }
   const int y0 = min(ty * TH, a.H - TH), x0 = min(tx * TW, a.W - TW);  // shifted last tiles, as in the kernel above
   const int oy = ty * TH - y0, ox = tx * TW - x0;
   const int tile = (n * a.tilesY + ty) * a.tilesX + tx;
@@ -730,7 +741,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void co
   for (int i = 0; i < MT; ++i) {
     int p = 16 * i + r16;
     if (p >= NPIX) p = 0;
-    const int py = p / TW, px = p - py * TW;
+    const int py = RM ? i : p / TW, px = RM ? r16 : p - py * TW;  // (row order: columns 14, 15 read the pad pairs; unused)
     const int gg = g < 3 ? g : 0;  // k-group 3 is all padding (zero weights): read something valid
     const uint32_t* src = pairs + (py + gg) * LW + px;
     const uint32_t lo = src[0], hi = src[2];
@@ -739,10 +750,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void co
                                                        (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
   }
 
-  constexpr int DPY = 16 / TW, DPX = 16 % TW;
+  constexpr int DPY = RM ? 1 : 16 / TW, DPX = RM ? 0 : 16 % TW;
   const int rowb = a.CoutS * 2;
   unsigned char* yb = a.y + (((size_t)n * a.H + y0) * a.W + x0) * rowb + 4 * g * 2;
-  int py = r16 / TW, px = r16 - py * TW;
+  int py = RM ? 0 : r16 / TW, px = r16 - py * TW;
   int ob = (py * a.W + px) * rowb;
   const int dob = (DPY * a.W + DPX) * rowb, wrapo = (a.W - TW) * rowb;
   f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = {0.f, 0.f, 0.f, 0.f};
@@ -753,9 +764,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void co
   // its pixel in m-tile i + 1 -- half the store instructions for the same bytes (the kernel is a 103 MB output stream).
   uint2 pk[MT];
   int obs[MT];
+  if (!RM || r16 < TW) {  // (row order: the two unused pixel columns are off for the whole epilogue)
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    const bool ok = (16 * i + 15 < NPIX) || (16 * i + r16 < NPIX);
+    const bool ok = RM || (16 * i + 15 < NPIX) || (16 * i + r16 < NPIX);
     obs[i] = ob;
     {
       const f32x2 lo = {acc[i][0], acc[i][1]}, hi = {acc[i][2], acc[i][3]};
@@ -776,13 +788,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void co
     px += DPX;
     pyc += DPY;
     ob += dob;
-    if (px >= TW) {
+    if (!RM && px >= TW) {
       px -= TW;
       pyc += 1;
       ob += wrapo;
     }
   }
-  constexpr int NPAIR = SPCL_FAST_WIDE_STORES ? (NPIX / 16) / 2 : 0;  // pairs of COMPLETE m-tiles
+  constexpr int NPAIR = SPCL_FAST_WIDE_STORES ? (RM ? MT / 2 : (NPIX / 16) / 2) : 0;  // pairs of COMPLETE m-tiles
 #pragma unroll
   for (int p = 0; p < NPAIR; ++p) {
     const int i = 2 * p;
@@ -793,8 +805,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void co
   }
 #pragma unroll
   for (int i = 2 * NPAIR; i < MT; ++i) {
-    const bool ok = (16 * i + 15 < NPIX) || (16 * i + r16 < NPIX);
+    const bool ok = RM || (16 * i + 15 < NPIX) || (16 * i + r16 < NPIX);
     if (ok) *(uint2*)(yb + obs[i]) = pk[i];
+  }
   }
   if (a.stats != nullptr)
     write_tile_stats(a.stats, tile, a.CoutS, 4 * g, r16, (float)((TH - oy) * (TW - ox)), ssum, ssq);
@@ -850,7 +863,8 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
     a.in_scale = a.in_shift = nullptr;
     a.y2 = nullptr; a.scale2 = a.shift2 = a.mean2 = nullptr; a.rows2 = nullptr; a.H2 = a.W2 = 0; a.img2 = nullptr;
     a.N = c.N; a.H = c.H; a.W = c.W; a.CinK = 16; a.CoutS = 16;
-    a.tilesX = cdiv(c.W, 14); a.tilesY = cdiv(c.H, 14); a.gy = 1; a.xcd_remap = 0; a.lds_flip = 0; a.stamps = nullptr;
+    static const int env_img_remap = getenv("SPCL_IMAGE_XCD_REMAP") ? atoi(getenv("SPCL_IMAGE_XCD_REMAP")) : 1;
+    a.tilesX = cdiv(c.W, 14); a.tilesY = cdiv(c.H, 14); a.gy = 1; a.xcd_remap = env_img_remap; a.lds_flip = 0; a.stamps = nullptr;
     if (!dry) {
       if (c.H % 14 == 0 && c.W % 14 == 0) SPCL_LAUNCH((conv3x3_image_kernel<14, true>), dim3(a.tilesX, a.tilesY, a.N), dim3(64), 0, st, a);
       else SPCL_LAUNCH((conv3x3_image_kernel<14, false>), dim3(a.tilesX, a.tilesY, a.N), dim3(64), 0, st, a);
