@@ -4,5 +4,5 @@
 VAR=$1; A=$2; B=$3; R=${4:-3}
 for i in $(seq $R); do for v in $A $B; do
   echo -n "$VAR=$v "
-  env $VAR=$v python bench.py --no-cpu-baseline --no-roofline --steps 100 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], 'median', d['replay_us']['median'], 'p10', d['replay_us']['p10'])"
+  env $VAR=$v python bench.py --no-cpu-baseline --no-roofline --steps 100 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); r=d.get('replay_us') or {}; print(d['ms_per_step'], 'median', r.get('median'), 'p10', r.get('p10'))"
 done; done

@@ -8,5 +8,5 @@ trap 'cp /tmp/libspcl_prod.so '$LIB EXIT INT TERM
 for i in $(seq $R); do for v in $A $B; do
   cp $v $LIB
   echo -n "$(basename $v) "
-  timeout 200 python bench.py --no-cpu-baseline --no-roofline --steps 100 "$@" 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], 'median', d['replay_us']['median'], 'p10', d['replay_us']['p10'])"
+  timeout 200 python bench.py --no-cpu-baseline --no-roofline --steps 100 "$@" 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); r=d.get('replay_us') or {}; print(d['ms_per_step'], 'median', r.get('median'), 'p10', r.get('p10'))"
 done; done

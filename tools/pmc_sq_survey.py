@@ -17,11 +17,15 @@ for d in sys.argv[1:]:
             if "spcl::" not in r["Kernel_Name"]:
                 continue
             k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("spcl::", "")
-            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
-            cnt[k][r["Counter_Name"]] += 1
+            agg[k][(d, r["Counter_Name"])] += float(r["Counter_Value"])
+            cnt[k][(d, r["Counter_Name"])] += 1
 rows = []
-for k, c in agg.items():
+for k, c2 in agg.items():
     n = max(cnt[k].values())
+    c = {}
+    for (d, name), v in c2.items():  # a counter collected in several passes (SQ_BUSY_CYCLES): the mean of the passes
+        c.setdefault(name, []).append(v)
+    c = {name: sum(v) / len(v) for name, v in c.items()}
     busy = c.get("SQ_BUSY_CYCLES", 0.0) / 32.0
     if busy <= 0:
         continue
