@@ -733,7 +733,6 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SPCL_CONV16
     int t = t0;
     asm volatile("" : "+v"(t));
     const int lane = t & 63, r16 = t & 15, g = lane >> 4;
-    const int tile = (n * a.tilesY + ty) * a.tilesX + tx;
     // the filter fragments (5 KB, L1-resident) are requested again for every tile -- behind the tile's own requests issued a
     // tile period ago, used after everything older: twenty registers that are free outside the dgrad rows
     u32x4 wall[NSTEPS];
@@ -822,7 +821,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SPCL_CONV16
         // (packed HERE: the compiler sinks the packing to the stores behind the weight-gradient phase and keeps the four
         // f32 values of every row alive until then -- 28 registers instead of 14)
         asm volatile("" : "+v"(dzp[j].x), "+v"(dzp[j].y));
-        __builtin_amdgcn_sched_barrier(0);  // (left free, the scheduler hoists every row's fragment reads and spills)
+        // (left free, the scheduler hoists every row's fragment reads and spills.  Requesting row j + 1's fragments right
+        // behind row j's MFMAs -- into the registers those just read, so that they land under the row's vector instructions --
+        // measured no different: with four waves per SIMD the LDS latency is covered already.  Neither did a start-up stagger
+        // of the workgroups by thirds of a tile period: the phases are not in lock-step)
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     B16_STAMP(2)
