@@ -72,7 +72,7 @@ struct WbTail {
 struct WbTails {
   WbTail t[SPCL_WGRAD_TAILS_MAX];
   int n;
-  int first;  // blockIdx.x of the first tail unit
+  int first;  // number of tail units = blockIdx.x of the first unit of the wide layers (the tails are dispatched first)
 };
 
 // 32-byte slot permutation of a pixel column (see the header): distinct for columns c, c+2, c+8, c+10 of equal parity
@@ -498,12 +498,15 @@ __device__ __forceinline__ void wb_tail_unit(const WbTails& tl, int unit, int ac
 
 __global__ __launch_bounds__(576) void wgrad_gemm_reduce_kernel(WbArgs a, WbTails tl) {
   __shared__ __attribute__((aligned(16))) float tile[16 * 16 * 9 + 16];
-  if ((int)blockIdx.x >= tl.first) {
-    wb_tail_unit(tl, blockIdx.x - tl.first, a.accumulate, tile);
+  // The tail units come FIRST in dispatch order: theirs are the long chains (a unit of the first block's one-pass backward
+  // walks its 2 048 slabs as 36 streams of 57 sixteen-byte loads), and dispatched behind the ~2 000 short units of the wide
+  // layers they were the launch's critical path
+  if ((int)blockIdx.x < tl.first) {
+    wb_tail_unit(tl, blockIdx.x, a.accumulate, tile);
     return;
   }
   int idx = 0;
-  const int wgu = blockIdx.x;  // unit index over all items: e0 counts (block, m, co-tile) units here
+  const int wgu = blockIdx.x - tl.first;  // unit index over all items: e0 counts (block, m, co-tile) units here
 #pragma unroll 1
   for (int i = 1; i < a.n; ++i)
     if (wgu >= a.it[i].e0) idx = i;
@@ -695,7 +698,7 @@ extern "C" int spcl_conv3x3_wgrad_batched_tails(const spcl_wgrad_item* items, in
     WbArgs a;
     memset(&a, 0, sizeof(a));
     a.accumulate = accumulate ? 1 : 0;
-    tl.first = 0;
+    tl.first = tail_units;
     SPCL_LAUNCH(wgrad_gemm_reduce_kernel, dim3(tail_units), dim3(576), 0, st, a, tl);
     SPCL_LAUNCH_CHECK("conv3x3_wgrad_batched_tails");
     return SPCL_OK;
@@ -729,7 +732,7 @@ extern "C" int spcl_conv3x3_wgrad_batched_tails(const spcl_wgrad_item* items, in
   else if (env_ring == 3) wb_launch<14, 3>(pl, st);
   else if (env_ring == 4) wb_launch<14, 4>(pl, st);
   else wb_launch<14, 2>(pl, st);
-  tl.first = pl.total_e;
+  tl.first = tail_units;
   SPCL_LAUNCH(wgrad_gemm_reduce_kernel, dim3(pl.total_e + tail_units), dim3(576), 0, st, pl.args, tl);
   if (pl.args.stamps) {
     static unsigned long long h[4096 * 8];
