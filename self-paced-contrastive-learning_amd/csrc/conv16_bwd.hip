@@ -520,6 +520,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(b16_wpe
 #ifndef SPCL_CONV16_ROWS_WPE
 #define SPCL_CONV16_ROWS_WPE 4
 #endif
+// (the shifted-tile form -- image sizes that are not a multiple of 14 -- needs a few registers more for its keep masks: asked
+// for four waves per SIMD it takes 128 registers and spills a prefetched halo register right behind its load; asked for three
+// it comes out at 121 without a spill)
+constexpr int r16_wpe(bool shifted) { return shifted && SPCL_CONV16_ROWS_WPE > 3 ? 3 : SPCL_CONV16_ROWS_WPE; }
 constexpr int R16_RP = 18;
 constexpr int R16_DY = 0, R16_DY_BYTES = (B16_TH + 2) * R16_RP * B16_PS;  // 9 216
 constexpr int R16_IM = R16_DY_BYTES;
@@ -531,7 +535,7 @@ constexpr int R16_TAB = R16_TRASH + 32;        // [4 k-groups][8] dwords: (tap, 
 constexpr int B16_LDS_ROWS = R16_TAB + 128;    // 19 168
 
 template <bool SHIFTED, bool WGROWS>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SPCL_CONV16_ROWS_WPE))) void conv16_bwd_rows_kernel(Bwd16Args a) {
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(r16_wpe(SHIFTED)))) void conv16_bwd_rows_kernel(Bwd16Args a) {
   constexpr int NW = 2;
   constexpr int TH = B16_TH, TW = B16_TW, HW_ = B16_HW, RP = R16_RP, PS = B16_PS;
   constexpr int NSTEPS = 5, NTHR = 64 * NW, ITER = 512 / NTHR, RPI = NTHR / 32;
@@ -897,6 +901,7 @@ int conv16_bwd_nw() {
 int conv16_bwd_ipw(int N, int H, int W) {
   // one resident generation of workgroups where the batch allows it: LDS (20 KB) and registers allow 8 / 6 / 3 per CU
   const int nw = conv16_bwd_nw();
+  // (the shifted-tile form is built for three waves per SIMD and comes out at 121 registers: four are resident all the same)
   const int resident = 256 * (nw == 1 ? 8 : (nw == 2 ? (conv16_bwd_rowmap() ? 2 * SPCL_CONV16_ROWS_WPE : 6) : 3));
   const long tiles = (long)cdiv(H, B16_TH) * cdiv(W, B16_TW);
   static const int env_ipw = getenv("SPCL_CONV16_IPW") ? atoi(getenv("SPCL_CONV16_IPW")) : 0;
