@@ -53,6 +53,9 @@ struct FastArgs {
 #ifndef SPCL_FAST_WPE_NT1
 #define SPCL_FAST_WPE_NT1 2  // (3 waves per SIMD measured 6-14 us per step slower: spills + a 6-step ring)
 #endif
+#ifndef SPCL_FAST_WPE_NT1_NW4
+#define SPCL_FAST_WPE_NT1_NW4 3
+#endif
 #ifndef SPCL_FAST_WR_NT1
 #define SPCL_FAST_WR_NT1 9
 #endif
@@ -101,7 +104,10 @@ constexpr int fast_wpe(int KC, int TH, int NW, int NT, int MODE = 0) {
   const int acc = (SPCL_FAST_ROWMAP ? TH : (TH * 14 + 15) / 16) * NT * 4;  // accumulator registers of a wave
   if (KC == 16 && MODE >= 2 && SPCL_FAST_YPRE_MINKC <= 16 && w > 3 && acc <= 80) return 3;  // room for the y2 requests
   if (acc > 80 && w > 2) return 2;               // 13 m-tiles x 2 n-tiles: give the allocator 256 registers
-  if (KC == 64 && NT == 1 && NW >= 2 && w > 2) return SPCL_FAST_WPE_NT1;  // 9-step ring of one n-tile: 36 registers
+  // 9-step ring of one n-tile: 36 registers.  Four-wave workgroups (every 64 -> 64 layer): three waves per SIMD = three
+  // workgroups per CU since the row order freed the m-tile bases (168 registers, one harmless address spill)
+  if (KC == 64 && NT == 1 && NW == 4 && w > 2) return SPCL_FAST_WPE_NT1_NW4;
+  if (KC == 64 && NT == 1 && NW >= 2 && w > 2) return SPCL_FAST_WPE_NT1;
   if (KC == 32 && fast_preload_slab(KC, NW, NT) && w > SPCL_FAST_WPE_KC32) return SPCL_FAST_WPE_KC32;
   if (fast_preload_slab(KC, NW, NT) && w > 2) return 2;  // a slab's weight fragments live in registers (PRELOAD_SLAB)
   return w;
