@@ -1201,7 +1201,12 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
                        (T*)nullptr, GS);
     }
   } else if (bcast) {
+    // pixel splits per image: every workgroup leaves a row of 2 CS partial sums that bnrelu_bwd_fin_kernel walks one cache
+    // line per lane -- one pass of 8 pixels per workgroup (25 splits of a 14 x 14 map: 1 600 rows) made that kernel 9.5 us
+    // of the step; SPCL_BCAST_SPLIT_MAX splits -> N x that many rows
+    static const int env_split = getenv("SPCL_BCAST_SPLIT_MAX") ? atoi(getenv("SPCL_BCAST_SPLIT_MAX")) : 4;
     bsplit = (H * W + PL - 1) / PL;
+    if (env_split > 0 && bsplit > env_split) bsplit = env_split;
     while (bsplit > 1 && N * bsplit > BWD_MAX_WG) bsplit = (bsplit + 1) / 2;
     nwg = N * bsplit;
     prof_cost(tb, 0.0);
