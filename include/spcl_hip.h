@@ -204,6 +204,16 @@ size_t spcl_bn_stats_elems(int ntiles, int CS);
 int spcl_conv3x3_forward(const void* x, int dtype, int N, int H, int W, int CinS, int CinK, int CoutS,
                          const void* w_packed, int in_mode, const float* in_scale, const float* in_shift, void* y,
                          float* stats, void* stream);
+/* The first convolution of the image block (semi_seg/arch/unet.py:123 behind :67-71, nn.Conv2d(1, 16, 3, 1, 1, bias=False)
+ * on the f32 slice, in_mode 2 of spcl_conv3x3_forward) that ALSO leaves the image's autocorrelation partial rows -- what
+ * spcl_image_autocorr / spcl_conv_pack_weights_multi_acorr compute in a pass of their own for the "image3" backward of that
+ * convolution (spcl_bnrelu_backward_rows_image3): acorr_rows [rows][64] f32, one row per 14 x 14 tile, same layout and
+ * meaning per row (45 upper-triangle sums R[t'][t] + 9 image sums over the tile's pixels), so spcl_conv16_bwd_fused's
+ * fold and the image3 final kernels take them unchanged.  _rows: the number of rows, 0 where the specialised kernel does
+ * not take the shape (bf16, CinS == 1, CoutS == 16, H and W multiples of 14 above 112). */
+int spcl_conv3x3_forward_image_acorr_rows(int dtype, int N, int H, int W, int CinS, int CoutS);
+int spcl_conv3x3_forward_image_acorr(const void* x, int dtype, int N, int H, int W, int CinS, int CoutS,
+                                     const void* w_packed, void* y, float* stats, float* acorr_rows, void* stream);
 /* The decoder's torch.cat((skip, up), dim=1) -> Conv2d(2 Chalf, Cout, 3, 1, 1) (unet.py:194-197, 201-204, ... the first
  * convolution of every Up_conv block) WITHOUT the concatenated tensor: input channels [0, Chalf) are read from xa, [Chalf,
  * 2 Chalf) from xb, both dense [N][H][W][Chalf] bf16; w_packed = spcl_conv_pack_weights(kind 0) of the [Cout][2 Chalf]

@@ -693,6 +693,55 @@ extern "C" int spcl_conv3x3_forward(const void* x, int dtype, int N, int H, int 
   return SPCL_OK;
 }
 
+// The image convolution (semi_seg/arch/unet.py:123, 1 -> 16 channels, in_mode 2) with the image's autocorrelation partial
+// rows as a by-product (ConvArgs::acorr_rows; csrc/conv_fast.hip conv3x3_image_kernel<.., ACORR>): one row [64] per tile in
+// the layout of spcl_image_autocorr's band rows, so everything downstream (spcl_conv16_bwd_fused's fold,
+// spcl_bnrelu_backward_*_image3) takes them unchanged.  _rows: the number of rows (tiles), 0 where the specialised kernel
+// does not take the shape (bf16, one input channel, 16 output channels, whole 14 x 14 tiles).
+static bool image_acorr_args(ConvArgs& a, int dtype, int N, int H, int W, int CinS, int CoutS) {
+  static const bool off = getenv("SPCL_ACORR_IN_CONV") && atoi(getenv("SPCL_ACORR_IN_CONV")) == 0;  // A/B switch
+  if (off || dtype != SPCL_BF16 || N <= 0 || H <= 0 || W <= 0 || CinS != 1 || CoutS != 16) return false;
+  a.N = N; a.H = H; a.W = W; a.CinS = CinS; a.CinK = 16; a.CoutS = CoutS; a.in_mode = 2;
+  a.tilesX = a.tilesY = 0; a.tpw = 1; a.dbg = 0;
+  const TileCfg t = pick_tile_k(H, W, 16, CoutS);
+  static const int no_fast = getenv("SPCL_CONV_NO_FAST") ? atoi(getenv("SPCL_CONV_NO_FAST")) : 0;
+  return !no_fast && t.tw == 14 && t.th == 14 && H % 14 == 0 && W % 14 == 0;
+}
+
+extern "C" int spcl_conv3x3_forward_image_acorr_rows(int dtype, int N, int H, int W, int CinS, int CoutS) {
+  ConvArgs a;
+  float dummy = 0.f;
+  a.x = nullptr; a.y = nullptr; a.wp = nullptr; a.stats = nullptr; a.in_scale = a.in_shift = nullptr;
+  if (!image_acorr_args(a, dtype, N, H, W, CinS, CoutS)) return 0;
+  a.acorr_rows = &dummy;
+  if (!launch_conv_fast(a, 14, nullptr, true)) return 0;
+  return N * cdiv(H, 14) * cdiv(W, 14);
+}
+
+extern "C" int spcl_conv3x3_forward_image_acorr(const void* x, int dtype, int N, int H, int W, int CinS, int CoutS,
+                                                const void* w_packed, void* y, float* stats, float* acorr_rows,
+                                                void* stream) {
+  SPCL_CHECK_ARG(x && y && w_packed && acorr_rows, "conv3x3_forward_image_acorr: null pointer");
+  ConvArgs a;
+  a.x = x; a.y = y; a.wp = w_packed; a.stats = stats; a.in_scale = a.in_shift = nullptr;
+  if (!image_acorr_args(a, dtype, N, H, W, CinS, CoutS)) {
+    set_error("conv3x3_forward_image_acorr: unsupported configuration (ask spcl_conv3x3_forward_image_acorr_rows)");
+    return SPCL_EUNSUPPORTED;
+  }
+  a.acorr_rows = acorr_rows;
+  {
+    const double px = (double)N * H * W;
+    prof_cost(px * (4.0 + CoutS * 2.0) + 9.0 * 16 * CoutS * 2.0 + (double)N * cdiv(H, 14) * cdiv(W, 14) * 256.0,
+              2.0 * px * 9.0 * CinS * CoutS + 2.0 * px * 2.0 * 256.0);
+  }
+  if (!launch_conv_fast(a, 14, (hipStream_t)stream)) {
+    set_error("conv3x3_forward_image_acorr: no kernel for N=%d H=%d W=%d", N, H, W);
+    return SPCL_EUNSUPPORTED;
+  }
+  SPCL_LAUNCH_CHECK("conv3x3_forward_image_acorr");
+  return SPCL_OK;
+}
+
 // The decoder's torch.cat((skip, up), dim=1) -> Conv2d (unet.py:194-224) without the concatenated tensor: the convolution
 // reads its input channels [0, Chalf) from xa and [Chalf, 2 Chalf) from xb (both dense [N][H][W][Chalf] bf16, no input
 // transform).  Only where a specialised kernel exists (14-column tiles, 2 Chalf = 32 or 64): ask _supported first.

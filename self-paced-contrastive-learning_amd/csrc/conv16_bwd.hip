@@ -546,13 +546,25 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(r16_wpe(SHI
   const int t0 = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(t0 >> 6);
   if (WGROWS && (int)blockIdx.z * (int)(gridDim.x * gridDim.y) >= a.nwg) {  // the extra z-slice: the autocorrelation rows
+    // (16 384 per-tile rows when the image convolution leaves them (spcl_conv3x3_forward_image_acorr): one column per thread
+    // and one row per load was a chain of 1 024 dependent round trips -- 120 us, longer than the launch it hides in.  The
+    // workgroup's 128 threads take 16 column quads x 8 row lanes with 16-byte loads, 16 in flight each; the row lanes are
+    // added through LDS in lane order: fixed order, deterministic)
     const int nslice = gridDim.x * gridDim.y;
-    if (t0 < 64) {
-      for (int j = blockIdx.y * gridDim.x + blockIdx.x; j < 16; j += nslice) {
-        float sacc = 0.f;
-#pragma unroll 8
-        for (int w = j; w < a.nacorr; w += 16) sacc += a.acorr_in[(size_t)w * 64 + t0];
-        a.acorr_out[(size_t)j * 64 + t0] = sacc;
+    float* fold = (float*)lds;  // [8 row lanes][64]
+    const int cq = t0 & 15, rl = t0 >> 4;
+    for (int j = blockIdx.y * gridDim.x + blockIdx.x; j < 16; j += nslice) {
+      f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 16
+      for (int w = j + 16 * rl; w < a.nacorr; w += 128) sacc += *(const f32x4*)(a.acorr_in + (size_t)w * 64 + 4 * cq);
+      __syncthreads();
+      *(f32x4*)(fold + rl * 64 + 4 * cq) = sacc;
+      __syncthreads();
+      if (t0 < 64) {
+        float tot = fold[t0];
+#pragma unroll
+        for (int r = 1; r < 8; ++r) tot += fold[r * 64 + t0];
+        a.acorr_out[(size_t)j * 64 + t0] = tot;
       }
     }
     return;

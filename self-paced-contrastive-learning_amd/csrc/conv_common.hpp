@@ -58,6 +58,10 @@ struct ConvArgs {
   // x is [N][H / 2][W / 2][CinK] and the input of the convolution is its nearest-neighbour x2 upsample (unet.py:89
   // nn.Upsample(scale_factor=2) in front of the up-convolution), never materialised (fast path only, in_mode 0)
   bool x_up2 = false;
+  // in_mode 2 (the one-channel image convolution) with the image's autocorrelation rows as a by-product: one row [64] per
+  // tile ([N * tiles][64]: 45 + 9 sums over the tile's pixels, the layout of image_autocorr_kernel's band rows) -- fast
+  // path only, image sizes that are multiples of the 14 x 14 tile
+  float* acorr_rows = nullptr;
 };
 
 template <typename T> __device__ __forceinline__ f32x4 mfma_chunk(u32x4 w, u32x4 x, f32x4 acc);

@@ -40,6 +40,7 @@ struct FastArgs {
   // sum_p dz[p][co] img[p + tap], the data-dependent part of that layer's weight gradient (dy = scale dz + A y + B: the
   // A and B terms need no pass over the activations, bn.hip image3)
   const float* img2;
+  float* acorr_rows;  // conv3x3_image_kernel<.., ACORR = true>: [tile][64] autocorrelation partial rows of the image (ConvArgs::acorr_rows)
 };
 
 // waves per SIMD the register allocator must leave room for: what the tile's LDS footprint allows anyway, at most 4
@@ -684,7 +685,12 @@ conv3x3_fast_kernel(FastArgs a) {
 // Weights come from the ordinary packed forward layout (kind 0, CinK = 16): three 2-byte loads per lane.
 // The kernel is a pure output stream (32 bytes per pixel out, 4 in).
 // EVEN: the image size is a multiple of the tile (no shifted last tiles: the `keep` factor of the statistics folds away)
-template <int TH, bool EVEN>
+// ACORR: the tile's share of the image's 9 x 9 autocorrelation (image_acorr.hpp: R[t'][t] = sum_p img0[p + t'] img0[p + t],
+// and the nine sums of img0[p + t]) from the bf16 halo pairs that sit in LDS anyway -- 7 k-steps of 32 pixels (two tile rows
+// of 16 columns, the last two masked), A = B = the patch matrix (one ds_read2_b32 pair per operand), a second accumulator
+// against a ones operand for the image sums: 14 MFMAs and ~60 instructions per tile instead of a 13 MB pass of its own
+// (image_autocorr_body in the weight-pack launch: ~15 us of the step's first launch).  EVEN sizes only.
+template <int TH, bool EVEN, bool ACORR = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void conv3x3_image_kernel(FastArgs a) {
   constexpr int TW = 14, HW_ = 16, LW = HW_ + 2;  // LDS row: 16 halo pixels + 2 so that pair q+2 of the last tap exists
   constexpr bool RM = SPCL_FAST_ROWMAP != 0;  // m-tile i = tile row i, pixel column r16 (see conv3x3_fast_kernel)
@@ -817,6 +823,45 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void co
   }
   if (a.stats != nullptr)
     write_tile_stats(a.stats, tile, a.CoutS, 4 * g, r16, (float)((TH - oy) * (TW - ox)), ssum, ssq);
+  if (ACORR) {
+    static_assert(!ACORR || (EVEN && TH % 2 == 0), "autocorrelation rows: whole 14 x 14 tiles");
+    __shared__ float dsum[2][16][16];
+    const int tap = r16 < 9 ? r16 : 0, ky = tap / 3, kx = tap - 3 * ky;
+    // lane (tap r16, k-group g): pixels 8 (g & 1) .. + 7 of tile row 2 ks + (g >> 1), shifted by the tap = halo pairs
+    // s, s + 2, s + 4, s + 6 with s = (row + ky) LW + 8 (g & 1) + kx; pixel columns 14, 15 (the last pair of the upper
+    // k-groups) are not the tile's: zero in A, so their products vanish whatever B holds
+    const uint32_t* src = pairs + ((g >> 1) + ky) * LW + 8 * (g & 1) + kx;
+    const bool upper = (g & 1) != 0;
+    const u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    f32x4 D = {0.f, 0.f, 0.f, 0.f}, S = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < TH / 2; ++ks) {
+      const uint32_t* q = src + ks * 2 * LW;
+      const u32x4 fb = {q[0], q[2], q[4], q[6]};
+      u32x4 fa = fb;
+      fa[3] = upper ? 0u : fb[3];
+      D = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb), D, 0, 0, 0);
+      S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, ones), S, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {  // D[row t' = 4 g + r][column t = r16]; every column of S holds the row's image sum
+      dsum[0][4 * g + r][r16] = D[r];
+      dsum[1][4 * g + r][r16] = S[r];
+    }
+    __syncthreads();  // (one wave: an ordering point)
+    const int k = lane;
+    float v = 0.f;
+    if (k < 45) {  // upper triangle in the order of bn.hip acorr_index: row ra = number of row starts <= k
+      int ra = 0;
+#pragma unroll
+      for (int i = 1; i < 9; ++i) ra += k >= i * 9 - i * (i - 1) / 2 ? 1 : 0;
+      const int cb = ra + (k - (ra * 9 - ra * (ra - 1) / 2));
+      v = dsum[0][ra][cb];
+    } else if (k < 54) {
+      v = dsum[1][k - 45][0];
+    }
+    a.acorr_rows[(size_t)tile * 64 + k] = v;
+  }
 }
 
 template <int KC, int TH, int NT, int NW>
@@ -871,8 +916,11 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
     a.N = c.N; a.H = c.H; a.W = c.W; a.CinK = 16; a.CoutS = 16;
     static const int env_img_remap = getenv("SPCL_IMAGE_XCD_REMAP") ? atoi(getenv("SPCL_IMAGE_XCD_REMAP")) : 1;
     a.tilesX = cdiv(c.W, 14); a.tilesY = cdiv(c.H, 14); a.gy = 1; a.xcd_remap = env_img_remap; a.lds_flip = 0; a.stamps = nullptr;
+    a.acorr_rows = c.acorr_rows;
+    if (c.acorr_rows != nullptr && !(c.H % 14 == 0 && c.W % 14 == 0)) return false;  // (whole tiles only)
     if (!dry) {
-      if (c.H % 14 == 0 && c.W % 14 == 0) SPCL_LAUNCH((conv3x3_image_kernel<14, true>), dim3(a.tilesX, a.tilesY, a.N), dim3(64), 0, st, a);
+      if (c.acorr_rows != nullptr) SPCL_LAUNCH((conv3x3_image_kernel<14, true, true>), dim3(a.tilesX, a.tilesY, a.N), dim3(64), 0, st, a);
+      else if (c.H % 14 == 0 && c.W % 14 == 0) SPCL_LAUNCH((conv3x3_image_kernel<14, true>), dim3(a.tilesX, a.tilesY, a.N), dim3(64), 0, st, a);
       else SPCL_LAUNCH((conv3x3_image_kernel<14, false>), dim3(a.tilesX, a.tilesY, a.N), dim3(64), 0, st, a);
     }
     return true;
@@ -938,6 +986,7 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
   a.y2 = (const unsigned char*)c.y2; a.scale2 = c.scale2; a.shift2 = c.shift2; a.mean2 = c.mean2; a.rows2 = c.rows2;
   a.H2 = c.H2; a.W2 = c.W2;
   a.img2 = c.img2;
+  a.acorr_rows = nullptr;
   if (c.rows2 != nullptr && c.in_mode != 0) return false;
   if (c.img2 != nullptr && !(c.rows2 != nullptr && c.H2 == 0 && KC == 16 && th == 14 && ntn == 1)) return false;
   a.N = c.N; a.H = c.H; a.W = c.W; a.CinK = c.CinK; a.CoutS = c.CoutS;

@@ -718,6 +718,8 @@ def prepack_weights(layers, dtype, image=None):
             keep.append(wc)
             _PREPACKED[(w.data_ptr(), w._version, dtc, int(H), int(W))] = (p0, p1)  # (_version: an in-place update since)
         arr = (_n.PackItem * len(items))(*items)
+        if image is not None and i == 0 and _acorr_in_conv_rows(dtc, *[int(v) for v in image.shape[:3]]) > 0:
+            image = None  # (the image convolution leaves the autocorrelation rows itself: _conv_image_acorr)
         if image is not None and i == 0:
             N, H, W = int(image.shape[0]), int(image.shape[1]), int(image.shape[2])
             acorr = torch.empty(_n.call("spcl_image_autocorr_rows", N, H, W), 64, dtype=torch.float32, device=dev)
@@ -726,6 +728,28 @@ def prepack_weights(layers, dtype, image=None):
             _PREPACKED_ACORR[(image.data_ptr(), image._version)] = acorr
         else:
             _n.call("spcl_conv_pack_weights_multi", arr, len(items), dtc, _n.stream())
+
+
+def _acorr_in_conv_rows(dt_code, N, H, W, cin=1, cout_s=16):
+    """rows ([rows][64] f32) the image block's first convolution leaves as the image's autocorrelation partials when it
+    runs as spcl_conv3x3_forward_image_acorr; 0: that form does not take the shape (the rows come from their own pass)"""
+    return _n.call("spcl_conv3x3_forward_image_acorr_rows", dt_code, N, H, W, cin, cout_s)
+
+
+def _conv_image_acorr(x_store, dt_code, dtype, N, H, W, cin_s, cout_s, wp, want_stats, rows):
+    """the one-channel image convolution + the image's autocorrelation rows in ONE launch
+    (spcl_conv3x3_forward_image_acorr) -> (y, stats, acorr [rows][64])"""
+    dev = x_store.device
+    y = torch.empty(N, H, W, cout_s, dtype=dtype, device=dev)
+    stats = None
+    if want_stats:
+        nt = _n.call("spcl_conv_stat_rows", dt_code, N, H, W, 16, cout_s)
+        stats = torch.empty(_n.call("spcl_bn_stats_elems", nt, cout_s), dtype=torch.float32, device=dev)
+        stats.ntiles = nt
+    acorr = torch.empty(rows, 64, dtype=torch.float32, device=dev)
+    _n.call("spcl_conv3x3_forward_image_acorr", _n.ptr(x_store), dt_code, N, H, W, cin_s, cout_s, _n.ptr(wp), _n.ptr(y),
+            _n.ptr(stats), _n.ptr(acorr), _n.stream())
+    return y, stats, acorr
 
 
 def take_prepacked(w, dtc, H, W):
@@ -1204,11 +1228,13 @@ class _ConvBlockFn(torch.autograd.Function):
             mode_a = 0
         need_bwd = any(ctx.needs_input_grad)
         ctx.acorr = None
+        acorr_rows = 0
         if (need_bwd and ctx.needs_input_grad[1] and not ctx.needs_input_grad[0]
                 and _image3_supported(cfg, cin, dtc, N, H, W, cout_s)):
             # of the input image only: usually it came with the forward pass's weight-pack launch (UNet._prepack), else now
             ctx.acorr = take_prepacked_acorr(xs)
-            if ctx.acorr is None:
+            acorr_rows = _acorr_in_conv_rows(dtc, N, H, W, cin, cout_s) if (ctx.acorr is None and x2s is None) else 0
+            if ctx.acorr is None and acorr_rows == 0:
                 ctx.acorr = _image_autocorr(xs, N, H, W)
         pre_a, pre_b = take_prepacked(wa, dtc, H, W), take_prepacked(wb, dtc, H, W)
         if pre_a is not None and pre_b is not None:  # packed with the other layers at the start of the forward pass
@@ -1219,6 +1245,8 @@ class _ConvBlockFn(torch.autograd.Function):
             wpa, wpb, wpa_t, wpb_t = _pack(wa, 0, dtc, dtype), _pack(wb, 0, dtc, dtype), None, None
         if x2s is not None:
             ya, sa = _conv_cat(xs, x2s, dtc, dtype, N, H, W, chalf, cout_s, wpa, cfg.training, *ctx.x2_coef)
+        elif acorr_rows > 0:  # the image convolution leaves the autocorrelation rows of the image3 backward itself
+            ya, sa, ctx.acorr = _conv_image_acorr(xs, dtc, dtype, N, H, W, cin_s, cout_s, wpa, cfg.training, acorr_rows)
         else:
             ya, sa = _conv(xs, dtc, dtype, N, H, W, cin_s, cin_k, cout_s, wpa, mode_a, None, None, cfg.training)
         sta = _bn_stats(sa, cfg, cout, cout_s, ga, ba, 0, dev)

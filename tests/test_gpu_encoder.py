@@ -294,6 +294,44 @@ def test_deferred_wide_weight_gradients_bf16():
         assert w.abs().max() > 0 and torch.isfinite(w).all()
 
 
+@pytest.mark.parametrize("N,H,W", [(3, 224, 224), (2, 140, 154), (5, 448, 224)])
+def test_image_conv_leaves_the_autocorrelation_rows(N, H, W):
+    """spcl_conv3x3_forward_image_acorr (csrc/conv_fast.hip conv3x3_image_kernel<.., ACORR>): the first convolution of the
+    image block (unet.py:123, 1 -> 16 channels) that also leaves the image's autocorrelation partial rows, one per 14 x 14
+    tile -- y and the BatchNorm partials bit for bit those of spcl_conv3x3_forward (in_mode 2), the rows' totals those of the
+    stand-alone pass (spcl_image_autocorr: other partial sums, f32 order) and of numpy on the bf16-rounded, zero-padded
+    image; twice (fixed-order sums).  Sizes the tile does not divide are refused (the rows come from their own pass)."""
+    import spcl_amd  # noqa
+    from spcl_amd import functional as F_, native as _n
+    dtc = _n.dtype_code(torch.bfloat16)
+    g = torch.Generator().manual_seed(7 + N)
+    img = torch.rand(N, H, W, generator=g).cuda()
+    w = torch.randn(16, 1, 3, 3, generator=g).cuda() * 0.3
+    wp = F_._pack(w, 0, dtc, torch.bfloat16)
+    rows = F_._acorr_in_conv_rows(dtc, N, H, W)
+    assert rows == N * (H // 14) * (W // 14)
+    assert F_._acorr_in_conv_rows(dtc, 1, 256, 256) == 0 and F_._acorr_in_conv_rows(dtc, 1, 112, 112) == 0
+    y0, s0 = F_._conv(img.view(N, H, W, 1), dtc, torch.bfloat16, N, H, W, 1, 16, 16, wp, 2, None, None, True)
+    y1, s1, ac = F_._conv_image_acorr(img.view(N, H, W, 1), dtc, torch.bfloat16, N, H, W, 1, 16, wp, True, rows)
+    y2, s2, ac2 = F_._conv_image_acorr(img.view(N, H, W, 1), dtc, torch.bfloat16, N, H, W, 1, 16, wp, True, rows)
+    assert torch.equal(y0, y1) and torch.equal(s0[:s0.ntiles * 48], s1[:s1.ntiles * 48])
+    assert torch.equal(ac, ac2) and torch.equal(y1, y2)
+    tot = ac.double().sum(0).cpu().numpy()
+    ref = F_._image_autocorr(img.contiguous(), N, H, W).double().sum(0).cpu().numpy()
+    assert _relerr(tot[:54], ref[:54]) < 1e-6 and np.abs(tot[54:]).max() == 0.0
+    a = torch.nn.functional.pad(img.bfloat16().double().cpu(), (2, 2, 2, 2))
+    shift = lambda k: a[:, 1 + k // 3:1 + k // 3 + H, 1 + k % 3:1 + k % 3 + W]  # noqa: E731  img0[p + tap - 1]
+    k = 0
+    for u in range(9):
+        for v in range(u, 9):
+            want = float((shift(u) * shift(v)).sum())
+            assert abs(tot[k] - want) < 2e-6 * abs(want) + 1e-6, (u, v, tot[k], want)
+            k += 1
+    for t in range(9):
+        want = float(shift(t).sum())
+        assert abs(tot[45 + t] - want) < 2e-6 * abs(want) + 1e-6
+
+
 def test_image3_first_layer_gradient_without_a_pass_over_its_output():
     """bf16, one-channel image, 224 x 224 (14 x 14 tiles): the first conv's weight gradient and BN backward come from the
     Conv1.b dgrad epilogue's tap sums + the image autocorrelation (csrc/bn.hip image3: dW = scale S1 + A (W R) + B S3) instead
