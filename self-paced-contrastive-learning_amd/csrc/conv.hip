@@ -252,7 +252,8 @@ __device__ __forceinline__ float pack_value(const float* __restrict__ w, int Cin
     // second half of a dual-layout buffer, for conv_gemm.hip: packed[slab][tap][32-channel output tile][ks][lane][8]:
     // lane (n32 = output channel in the tile, kh = lane / 32) holds input channels 64 slab + 16 ks + 8 kh .. +7 of tap
     // `tap` -- one 1 KiB piece per A fragment
-    size_t r = idx - (size_t)9 * KinK * NoutS;
+    unsigned r = (unsigned)(idx - (size_t)9 * KinK * NoutS);  // (32-bit: a 64-bit division by a run-time value is ~150 instructions,
+                                                            // and this function did five per element -- the pack launch was 12.9 us)
     const int e = (int)(r % 8); r /= 8;
     const int lane = (int)(r % 64); r /= 64;
     const int ks = (int)(r % 4); r /= 4;
@@ -267,7 +268,7 @@ __device__ __forceinline__ float pack_value(const float* __restrict__ w, int Cin
   const int CP = KC / EPC;
   const int nsteps = conv_nsteps<T>(KC);
   const int ntn = NoutS >> 4;
-  size_t r = idx;
+  unsigned r = (unsigned)idx;  // (packed buffers hold a few million elements)
   const int e = (int)(r % EPC); r /= EPC;
   const int lane = (int)(r % 64); r /= 64;
   const int nt = (int)(r % ntn); r /= ntn;
@@ -333,7 +334,10 @@ __global__ __launch_bounds__(256) void conv_pack_block_kernel(const float* __res
 // segment from the table of last-block indices with statically indexed compares (the table arrives with the kernel
 // arguments in a few wide scalar loads; a per-thread walk over dynamically indexed argument structs was a chain of 2 x 20
 // dependent scalar loads: 20 us for what five separate launches did in 27).
-constexpr int PACK_EPB = 1024, PACK_SEGS = 2 * SPCL_PACK_MULTI_MAX;
+#ifndef SPCL_PACK_EPB
+#define SPCL_PACK_EPB 1024
+#endif
+constexpr int PACK_EPB = SPCL_PACK_EPB, PACK_SEGS = 2 * SPCL_PACK_MULTI_MAX;
 struct PackSeg {
   const float* w;
   void* out;
