@@ -958,8 +958,12 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
       (long)c.N * cdiv(c.W, 14) * cdiv(c.H, th) * cdiv(ntn, 8) < env_fill_max)
     NT = 1;
   // experiment: the two n-tiles of a 16 / 32-channel-slab layer as two one-n-tile waves sharing the halo image
-  static const int env_narrow = getenv("SPCL_CONV_FAST_NARROW_NT1") ? atoi(getenv("SPCL_CONV_FAST_NARROW_NT1")) : 0;
-  if (env_narrow && KC < 64 && ntn == 2 && th == 7) NT = 1;
+  // (1 = all of them: + 4 us per step when measured, and again after the row order.  Per launch then: Conv2.a / Conv2.b forward
+  // +- 0.7 us, but Conv2.b's dgrad -- 32 -> 32 with the BatchNorm-backward sums in its epilogue, 202 registers as one wave --
+  // 42.9 -> 38.6 us as two waves of 140: 2 = that form only, the default)
+  static const int env_narrow = getenv("SPCL_CONV_FAST_NARROW_NT1") ? atoi(getenv("SPCL_CONV_FAST_NARROW_NT1")) : 2;
+  if (env_narrow == 1 && KC < 64 && ntn == 2 && th == 7) NT = 1;
+  if (env_narrow == 2 && KC == 32 && ntn == 2 && th == 7 && c.rows2 != nullptr && c.H2 == 0 && c.img2 == nullptr) NT = 1;
   int nw = ntn / NT;
   if (nw > 4) nw = 4;
   if (ntn % (NT * nw) != 0) return false;
