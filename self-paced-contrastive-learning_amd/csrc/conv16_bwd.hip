@@ -23,6 +23,10 @@
 // `if (wave == 0)` went through one register with s_waitcnt vmcnt(0) after each; the first in-loop use of the BatchNorm
 // coefficients carried the compiler's vmcnt(0) for their pre-loop load, i.e. a wait for the freshly issued prefetch on every
 // trip; lane-invariant addresses hoisted out of the tile loop and spilled; prefetched values spilled right behind their loads.
+//
+// Round 4: the production kernel is conv16_bwd_rows_kernel further down (m-tiles along the tile rows, two waves, four waves per
+// SIMD: 84.6 -> 72.8 us); conv16_bwd_kernel below -- linear m-tiles, 1 / 2 / 4 waves per tile -- stays as the reference the
+// row-ordered form is compared with bit for bit (tools/diag/conv16_check.py) and behind SPCL_CONV16_ROWMAP=0.
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
