@@ -676,11 +676,19 @@ __device__ __forceinline__ void window_dz(const Window<T>& w, const u32x4* rg, b
   }
 }
 
+#ifndef SPCL_BWD_POOL_MAXW
+#define SPCL_BWD_POOL_MAXW 0
+#endif
+#if SPCL_BWD_POOL_MAXW
+#define BWD_POOL_WPE __attribute__((amdgpu_waves_per_eu(3, SPCL_BWD_POOL_MAXW)))
+#else
+#define BWD_POOL_WPE
+#endif
 // ---- pass 1 / pass 2 with pooling.  APPLY == false: partial sums;  true: dy
 // FAST: H and W even, pooled gradient only (dact == null, dpool given) -- the training step's case: the run-time flags
 // of the general form are scalar / exec branches around every load and store of the loop
 template <typename T, bool APPLY, bool FAST>
-__global__ __launch_bounds__(256, 3) void bnrelu_bwd_pool_kernel(const T* __restrict__ y, const T* __restrict__ dact,
+__global__ __launch_bounds__(256, 3) BWD_POOL_WPE void bnrelu_bwd_pool_kernel(const T* __restrict__ y, const T* __restrict__ dact,
                                                               const T* __restrict__ dpool, int N, int H, int W, int CS,
                                                               const float* __restrict__ mean,
                                                               const float* __restrict__ invstd,
@@ -722,6 +730,10 @@ __global__ __launch_bounds__(256, 3) void bnrelu_bwd_pool_kernel(const T* __rest
         }
         const bool complete = FAST || (dpool != nullptr && oy < OH && ox < OW);  // floor semantics of max_pool2d
         if (complete) rdp = *(const u32x4*)(dpool + (((size_t)n * OH + oy) * OW + ox) * CS + cc * EPC);
+        // (all five requests of the window before any arithmetic: with the shorter FAST body the scheduler sank the pooled
+        // gradient's load to its use behind the waits for the window -- a second, dependent round trip per iteration, + 2.5 us
+        // on the 224^2 launch)
+        if (APPLY && FAST) __builtin_amdgcn_sched_barrier(0);
         u32x4 out[4];
 #pragma unroll
         for (int wi = 0; wi < 4; ++wi) {
@@ -741,6 +753,30 @@ __global__ __launch_bounds__(256, 3) void bnrelu_bwd_pool_kernel(const T* __rest
               const float dzb = (complete && zb > 0.f) ? Word<T>::get(rdp[wi], h) : 0.f;
               s1[e] += dzb;
               s2[e] = fmaf(dzb, yb - c0[e], s2[e]);
+              continue;
+            }
+            if (APPLY && FAST) {
+              // the training step's case, written for the instruction count (this kernel is the step's largest symbol: 4
+              // launches, 79 us, its vector port 63 % busy beside 0.69 of the HBM peak): whole windows, pooled gradient only.
+              // The first maximum of relu(z) in scan order as LANE MASKS -- z_k > (running maximum, >= 0) for k = 1 .. 3,
+              // combined by scalar and-nots -- instead of a tracked index and four index compares: 30 vector instructions
+              // per (window, channel) for 44.  Same values: dz_k = dp at that pixel if its z > 0, else 0; o = fma(sc, dz, X).
+              float yk[4], z[4];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                yk[k] = Word<T>::get(w.ry[k][wi], h);
+                z[k] = fmaf(sc[e], yk[k], sh[e]);
+              }
+              float m = fmaxf(z[0], 0.f);
+              const bool s1 = z[1] > m;
+              m = fmaxf(m, z[1]);
+              const bool s2 = z[2] > m;
+              m = fmaxf(m, z[2]);
+              const bool s3 = z[3] > m;
+              const bool b[4] = {z[0] > 0.f && !s1 && !s2 && !s3, s1 && !s2 && !s3, s2 && !s3, s3};
+              const float dp = Word<T>::get(rdp[wi], h);
+#pragma unroll
+              for (int k = 0; k < 4; ++k) o[k][h] = fmaf(sc[e], b[k] ? dp : 0.f, fmaf(c0[e], yk[k], c1[e]));
               continue;
             }
             float yk[4], dz[4];
