@@ -671,9 +671,10 @@ def test_builtin_kernel_timer_reports_symbols_and_costs():
     assert n.call("spcl_profile_count") == 0
 
 
+@pytest.mark.parametrize("neg_scales", [False, True])
 @pytest.mark.parametrize("N,ci,co,H2,W2", [(2, 16, 32, 56, 56), (1, 32, 64, 28, 56), (2, 64, 128, 28, 28), (1, 128, 256, 28, 28),
                                            (3, 16, 32, 224, 42), (1, 16, 32, 57, 31)])
-def test_dgrad_with_fused_pooled_bn_backward_sums(N, ci, co, H2, W2):
+def test_dgrad_with_fused_pooled_bn_backward_sums(N, ci, co, H2, W2, neg_scales):
     """spcl_conv3x3_dgrad_poolstats + spcl_bnrelu_pool_backward_rows against the path they replace (plain dgrad of the next
     block's first conv, then spcl_bnrelu_pool_backward with its own reduction pass over y2): the input gradient g is
     bit-identical, dgamma / dbeta / dy equal up to summation order.  ci = channels of the pooled layer, co = of the conv."""
@@ -691,6 +692,9 @@ def test_dgrad_with_fused_pooled_bn_backward_sums(N, ci, co, H2, W2):
     st[0] = torch.randn(ci, generator=g_) * 0.1 + 0.2          # mean
     st[1] = torch.rand(ci, generator=g_) + 0.5                 # invstd
     st[2] = st[1] * (torch.rand(ci, generator=g_) + 0.5)       # scale = gamma * invstd
+    if neg_scales:  # (all-positive scales take the epilogue's monotone form of the window scan; a negative or zero gamma the scan)
+        st[2][::5] *= -1.0
+        st[2][3] = 0.0
     st[3] = torch.randn(ci, generator=g_) * 0.2 - st[0] * st[2]
     st = st.cuda()
     ws = torch.empty(n.call("spcl_bnrelu_bwd_workspace_bytes", N, H2, W2, ci) // 4, device="cuda")
