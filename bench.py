@@ -194,6 +194,23 @@ def _short_kernel_name(n):
     return re.sub(r"\s+", "", n)
 
 
+_PROFILER_ENV = ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_LIBRARY_PATH")
+_PROFILER_ENV_PREFIXES = ("ROCPROFILER_", "ROCPROF_", "ROCP_")
+
+
+def _under_profiler(env=None):
+    """is a profiler's tool library loaded into THIS process (rocprofv3 -- python bench.py ...)?"""
+    env = os.environ if env is None else env
+    for k, v in env.items():
+        if not v:
+            continue
+        if k == "LD_PRELOAD" and ("rocprof" in v or "roctx" in v or "rocprofiler" in v):
+            return True
+        if k in ("ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB") or k.startswith(("ROCPROFILER_", "ROCPROF_")):
+            return True
+    return False
+
+
 def graph_kernel_times(args, first_kernel="flip_pair_stage"):
     """Per-launch kernel durations INSIDE the replayed step, by `tools/step_timeline.py`'s method: a CHILD process runs this
     same command (no extras / roofline / CPU baseline) under `rocprofv3 --kernel-trace`; its trace is cut into steps at every
@@ -210,6 +227,11 @@ def graph_kernel_times(args, first_kernel="flip_pair_stage"):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None
+    if _under_profiler():
+        # this process is itself being profiled: the child would inherit the preloaded tool library, which initialises the
+        # GPU in the env -> python3 -> target chain of the rocprofv3 script -- the exec-after-GPU-init hop this pool refuses
+        print("[bench] running under a profiler: no rocprofv3 child (pass --no-roofline there)", file=sys.stderr)
+        return None
     out = tempfile.mkdtemp(prefix="spcl_bench_trace_", dir="/tmp")
     cmd = [exe, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
            "--no-cpu-baseline", "--no-extras", "--no-roofline", "--steps", "30", "--warmup", "5", "--bs", str(args.bs),
@@ -217,6 +239,8 @@ def graph_kernel_times(args, first_kernel="flip_pair_stage"):
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
+    for k in [k for k in env if k in _PROFILER_ENV or k.startswith(_PROFILER_ENV_PREFIXES)]:
+        env.pop(k, None)  # (never hand a tool library to the child's launcher chain)
     try:
         r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
         files = glob.glob(out + "/**/*kernel_trace.csv", recursive=True)
@@ -722,6 +746,14 @@ def main():
             line.setdefault("extra", {})["fp32_step"] = fp32_numbers(args, device)
         except Exception as e:  # noqa: BLE001
             print(f"[bench] fp32 extra failed: {type(e).__name__}: {e}", file=sys.stderr)
+    if rank == 0 and world == 1 and not args.no_extras and args.workload == "pretrain":
+        # the two other workloads the framework is benchmarked on (tools/profile_round_all.sh writes their full lines), as short
+        # graphed passes so that the driver's line carries them too
+        for key, fn in (("finetune_step", finetune_numbers), ("prostate_step", prostate_numbers)):
+            try:
+                line.setdefault("extra", {})[key] = fn(args, device)
+            except Exception as e:  # noqa: BLE001
+                print(f"[bench] {key} extra failed: {type(e).__name__}: {e}", file=sys.stderr)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:
@@ -756,6 +788,59 @@ def fp32_numbers(args, device, steps=12, warmup=4):
     from spcl_amd import stepgraph as _sg
     _sg.gc_release()
     del step, epocher
+    torch.cuda.empty_cache()
+    return out
+
+
+def _short_pass(step, graph_of, steps, warmup):
+    """``steps`` timed calls of ``step`` after the epocher has captured itself and ``warmup`` replays -> seconds per step"""
+    for _ in range(4):
+        step()
+        sg = graph_of()
+        if sg is not None and sg.captured:
+            break
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def prostate_numbers(args, device, steps=20, warmup=5):
+    """`--workload prostate` in short (BASELINE.json configs[3] shape: 256^2, bs 64, three combined self-paced hooks)."""
+    import copy
+    a = copy.copy(args)
+    a.workload, a.bs, a.size = "prostate", 64, 256
+    step, epocher, _ = build_step(a, device, 0, 1)
+    dt = _short_pass(step, lambda: epocher._step_graph, steps, warmup)
+    sg = epocher._step_graph
+    out = {"ms_per_step": round(dt * 1e3, 4), "slices_s": round(a.bs / dt, 1), "steps": steps, "dtype": a.dtype,
+           "hipgraph": bool(sg is not None and sg.captured),
+           "workload": "BASELINE.json configs[3] shape: 64 x 2 images of 256^2, three self-paced hooks on one encoder pass"}
+    from spcl_amd import stepgraph as _sg
+    _sg.gc_release()
+    del step, epocher
+    torch.cuda.empty_cache()
+    return out
+
+
+def finetune_numbers(args, device, steps=20, warmup=5):
+    """`--workload finetune` in short (SURVEY N1 / BASELINE.json configs[2]'s fine-tune half: full UNet, 32 x 224^2)."""
+    import copy
+    a = copy.copy(args)
+    a.workload, a.bs, a.size, a.no_graph = "finetune", 32, 224, False
+    step, ep = build_finetune_step(a, device)
+    dt = _short_pass(step, lambda: ep._step_graph, steps, warmup)
+    sg = ep._step_graph
+    out = {"ms_per_step": round(dt * 1e3, 4), "slices_s": round(a.bs / dt, 1), "steps": steps, "dtype": a.dtype,
+           "hipgraph": bool(sg is not None and sg.captured),
+           "workload": "fine-tune step: full UNet fwd+bwd, softmax + KL_div on one-hot labels, Dice counts, RAdam; 32 x 224^2"}
+    from spcl_amd import stepgraph as _sg
+    _sg.gc_release()
+    del step, ep
     torch.cuda.empty_cache()
     return out
 
@@ -820,9 +905,8 @@ def replay_distribution(run, k, wd=None):
             "note": "HIP-event time of single steps, measured after the timed region"}
 
 
-def bench_finetune(args, device):
-    """SURVEY row N1 (BASELINE.json configs[2], the fine-tune half): full UNet fwd+bwd + softmax/KL_div + RAdam on
-    synthetic labelled 224^2 slices, single GPU, hipGraph.  One slice = one image here (no second view)."""
+def build_finetune_step(args, device):
+    """-> (step, epocher): one iteration of FineTuneEpocher's loop on the synthetic labelled loader's next batch"""
     import spcl_amd  # noqa
     from spcl_amd import ddp
     from spcl_amd.contrastyou.losses.kl import KL_div
@@ -846,6 +930,13 @@ def bench_finetune(args, device):
         with ep.meters.focus_on(ep.meter_focus):
             return ep.step(next(loader))
 
+    return step, ep
+
+
+def bench_finetune(args, device):
+    """SURVEY row N1 (BASELINE.json configs[2], the fine-tune half): full UNet fwd+bwd + softmax/KL_div + RAdam on
+    synthetic labelled 224^2 slices, single GPU, hipGraph.  One slice = one image here (no second view)."""
+    step, ep = build_finetune_step(args, device)
     run = step  # FineTuneEpocher.step captures itself after two eager steps (stepgraph.py)
     for _ in range(0 if args.no_graph else 3):
         run()

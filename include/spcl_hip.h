@@ -31,6 +31,10 @@ extern "C" {
 #define SPCL_ELAUNCH (-2)
 #define SPCL_EUNSUPPORTED (-3)
 
+/* Bumped whenever a struct layout, a limit (SPCL_*_MAX) or an entry point's meaning changes.  The library is git-ignored and
+ * travels next to the sources: the Python binding (native.py) refuses a library whose version is not the header's, so that a
+ * stale build fails at load time instead of running kernels on structs of another stride. */
+#define SPCL_ABI_VERSION 3
 int spcl_abi_version(void);
 const char* spcl_last_error(void);
 

@@ -251,21 +251,27 @@ def _conv_block(x, sd, prefix, train, momentum, eps=1e-5, q=None):
     return x
 
 
-def _up_conv(x, sd, prefix, train, momentum, eps=1e-5):
-    """nearest x2 upsample -> conv3x3 -> BN -> ReLU (unet.py:85-97)."""
+def _up_conv(x, sd, prefix, train, momentum, eps=1e-5, q=None):
+    """nearest x2 upsample -> conv3x3 -> BN -> ReLU (unet.py:85-97).  ``q``: the bf16 mode's storage points (the raw conv
+    output and the activation, as in ``_conv_block``)."""
     x = F.interpolate(x, scale_factor=2, mode="nearest")
-    x = F.conv2d(x, sd[f"{prefix}.up.1.weight"], None, 1, 1)
+    w = sd[f"{prefix}.up.1.weight"]
+    x = F.conv2d(x, q.weight(w) if q else w, None, 1, 1)
+    if q:
+        x = q.act(x)
     x = F.batch_norm(x, sd[f"{prefix}.up.2.running_mean"], sd[f"{prefix}.up.2.running_var"],
                      sd[f"{prefix}.up.2.weight"], sd[f"{prefix}.up.2.bias"], train, momentum, eps)
     if train:
         sd[f"{prefix}.up.2.num_batches_tracked"] += 1
-    return F.relu(x)
+    x = F.relu(x)
+    return q.act(x) if q else x
 
 
 def unet_forward(x: Tensor, sd: Dict[str, Tensor], until: Optional[str] = None, *, train=True, momentum=0.1,
                  q=None):
     """Full UNet forward with early exit (unet.py:156-230).  ``sd`` = state_dict-style dict (mutated: BN stats).
-    ``q`` = BF16Emulation to mimic the bf16 mode's storage roundings in the encoder (None = reference fp32)."""
+    ``q`` = BF16Emulation to mimic the bf16 mode's storage roundings -- encoder and decoder blocks, up-convolutions; the
+    1x1 head reads the rounded activation and computes in fp32 -- (None = reference fp32)."""
     if until is not None and until not in LAYER_DIMENSION and until != "Deconv_1x1":
         raise KeyError(until)
     feats = {}
@@ -279,9 +285,9 @@ def unet_forward(x: Tensor, sd: Dict[str, Tensor], until: Optional[str] = None, 
             return e
     d = e
     for lvl, skip in ((5, "Conv4"), (4, "Conv3"), (3, "Conv2"), (2, "Conv1")):
-        d = _up_conv(d, sd, f"_Up{lvl}", train, momentum)
+        d = _up_conv(d, sd, f"_Up{lvl}", train, momentum, q=q)
         d = torch.cat((feats[skip], d), 1)
-        d = _conv_block(d, sd, f"_Up_conv{lvl}", train, momentum)
+        d = _conv_block(d, sd, f"_Up_conv{lvl}", train, momentum, q=q)
         if until == f"Up_conv{lvl}":
             return d
     return F.conv2d(d, sd["_Deconv_1x1.weight"], sd["_Deconv_1x1.bias"])

@@ -87,7 +87,7 @@ static void prof_clear() {
 }
 }  // namespace spcl
 
-extern "C" int spcl_abi_version(void) { return 2; }
+extern "C" int spcl_abi_version(void) { return SPCL_ABI_VERSION; }
 extern "C" const char* spcl_last_error(void) { return spcl::g_err; }
 
 extern "C" int spcl_profile_enable(int on) {

@@ -173,7 +173,16 @@ class FlatParams(GradBucket):
         # optimizer that applies it while it streams the bucket anyway (optim.FusedRAdam.step(grad_scale=)): one launch
         # and one pass over the bucket less per step.  Off: the bucket holds the mean (``div_``), grad_scale stays 1.
         self.fold_mean = False
-        self.grad_scale = 1.0
+
+    @property
+    def grad_scale(self) -> float:
+        """the factor a consumer of the bucket must apply to obtain the ranks' MEAN: 1 / world while ``fold_mean`` is on
+        in a distributed job, else exactly 1.0.  A pure function of (fold_mean, world size): valid BEFORE the first
+        collective, so a captured update graph that bakes it in (stepgraph.py never runs the exchange inside the capture)
+        holds the right value whatever ran before the capture."""
+        if self.fold_mean and is_distributed():
+            return 1.0 / dist.get_world_size(self.group)
+        return 1.0
 
     def zero_grad(self):
         for p in self.params:
@@ -195,7 +204,6 @@ class FlatParams(GradBucket):
     def allreduce_(self):
         """mean of the flat bucket across ranks, in place (the step's ONE collective, or -- with the early bucket on its
         way -- the head's plus the wait for the tail's; no-op for a single process)."""
-        self.grad_scale = 1.0
         if is_distributed():
             with _comm_stream(self.flat):
                 if self._early is not None:
@@ -204,11 +212,8 @@ class FlatParams(GradBucket):
                         self._early.wait()
                 else:
                     dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-            world = dist.get_world_size(self.group)
-            if self.fold_mean:
-                self.grad_scale = 1.0 / world
-            else:
-                self.flat.div_(world)
+            if not self.fold_mean:  # (fold_mean: the bucket keeps the SUM, ``grad_scale`` is 1 / world)
+                self.flat.div_(dist.get_world_size(self.group))
         self._early = None
         return self.flat
 

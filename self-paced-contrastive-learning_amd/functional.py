@@ -1809,17 +1809,23 @@ def register_unit_gradient(t: torch.Tensor):
     a backward that recognises it by its storage skips the multiplication by it.  Held weakly."""
     import weakref
     assert t.numel() == 1
-    _UNIT_GRADIENTS[t.data_ptr()] = weakref.ref(t)
+    _UNIT_GRADIENTS[t.data_ptr()] = (weakref.ref(t), t._version)
     return t
 
 
 def is_unit_gradient(g: torch.Tensor) -> bool:
-    ref = _UNIT_GRADIENTS.get(g.data_ptr()) if g.numel() == 1 else None
-    if ref is None:
+    ent = _UNIT_GRADIENTS.get(g.data_ptr()) if g.numel() == 1 else None
+    if ent is None:
         return False
+    ref, version = ent
     t = ref()
     if t is None or t.data_ptr() != g.data_ptr() or t.dtype != g.dtype:
         _UNIT_GRADIENTS.pop(g.data_ptr(), None)  # (the registered tensor is gone: its address may belong to anything now)
+        return False
+    if t._version != version:
+        # written in place since it was registered (a caller scaling the loss through it): no longer known to hold 1.0 -- the
+        # promise is broken for good, the backward multiplies by whatever it holds now
+        _UNIT_GRADIENTS.pop(g.data_ptr(), None)
         return False
     return True
 

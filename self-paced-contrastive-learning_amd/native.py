@@ -182,6 +182,7 @@ class WgradTail(ctypes.Structure):
                 ("nblk_co", c_int), ("CIB", c_int), ("COB", c_int), ("Cin", c_int), ("Cout", c_int)]
 
 
+ABI_VERSION = 3  # == SPCL_ABI_VERSION of include/spcl_hip.h (tests/test_abi.py compares them); lib() refuses any other library
 WGRAD_BATCH_MAX = 16
 WGRAD_TAILS_MAX = 16
 _NO_STATUS = ("spcl_abi_version", "spcl_conv3x3_forward_image_acorr_rows", "spcl_image_autocorr_rows", "spcl_conv_dgrad_bnstats_image_supported", "spcl_conv16_bwd_fused_supported", "spcl_conv16_bwd_fused_splits", "spcl_conv_num_tiles", "spcl_conv_stat_rows", "spcl_conv_set_gemm", "spcl_supcon_unit_gradient_block", "spcl_conv_cat_supported", "spcl_conv_up2_supported", "spcl_conv_split_supported", "spcl_conv_split_bnstats_supported", "spcl_conv1x1_bwd_rows", "spcl_profile_count", "spcl_conv_dgrad_bnstats_supported", "spcl_conv_dgrad_poolstats_supported",
@@ -201,6 +202,12 @@ def lib():
                 f"{LIB_PATH} is missing: build it with `python self-paced-contrastive-learning_amd/build.py` "
                 "(there is no CPU / eager fallback for the hot path)")
         L = ctypes.CDLL(LIB_PATH)
+        L.spcl_abi_version.restype, L.spcl_abi_version.argtypes = c_int, []
+        have = L.spcl_abi_version()
+        if have != ABI_VERSION:
+            raise NativeLibraryError(
+                f"{LIB_PATH} has C-ABI version {have}, this binding was written for {ABI_VERSION} (include/spcl_hip.h "
+                "SPCL_ABI_VERSION): a stale build -- rebuild with `python self-paced-contrastive-learning_amd/build.py`")
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name, None)
             if fn is None:

@@ -111,8 +111,11 @@ class FineTuneEpocher(_EpocherBase):
         self._sup_criterion = sup_criterion
         self._flat_params = flat_params
         from ...optim import FusedRAdam
-        if flat_params is not None and isinstance(optimizer, FusedRAdam):
-            flat_params.fold_mean = True  # the exchange leaves the ranks' SUM; 1 / world is applied inside the RAdam kernel
+        if flat_params is not None:
+            # FusedRAdam: the exchange leaves the ranks' SUM, 1 / world is applied inside the RAdam kernel; any other
+            # optimizer reads the bucket as it is and must find the MEAN there (the flag is state of the shared FlatParams:
+            # an earlier epocher may have set it)
+            flat_params.fold_mean = isinstance(optimizer, FusedRAdam)
         self._unit = None
         # the step as a hipGraph (stepgraph.py): image and label map are copied into persistent buffers in front of the
         # replay; the Dice counts come back in persistent [B, C] tensors and are handed to the meter after it

@@ -56,8 +56,11 @@ class PretrainEncoderEpocher:
         self._grad_bucket = grad_bucket
         self._flat_params = flat_params  # optimizer steps ONE flat parameter (ddp.FlatParams) when given
         from ...optim import FusedRAdam
-        if flat_params is not None and isinstance(optimizer, FusedRAdam):
-            flat_params.fold_mean = True  # the exchange leaves the ranks' SUM; 1 / world is applied inside the RAdam kernel
+        if flat_params is not None:
+            # FusedRAdam: the exchange leaves the ranks' SUM, 1 / world is applied inside the RAdam kernel; any other
+            # optimizer reads the bucket as it is and must find the MEAN there (the flag is state of the shared FlatParams:
+            # an earlier epocher may have set it)
+            flat_params.fold_mean = isinstance(optimizer, FusedRAdam)
         self._hooks = []
         self.meters = MeterInterface(default_focus=self.meter_focus)
         with self.meters.focus_on(self.meter_focus):

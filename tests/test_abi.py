@@ -43,7 +43,9 @@ def test_native_signature_table_matches_header():
     from spcl_amd import native
     assert sorted(native._SIGNATURES) == declared_symbols()
     L = native.lib()
-    assert native.call("spcl_abi_version") >= 1
+    hdr = open(HEADER).read()
+    declared = int(re.search(r"#define\s+SPCL_ABI_VERSION\s+(\d+)", hdr).group(1))
+    assert native.call("spcl_abi_version") == declared == native.ABI_VERSION  # (lib() refuses a library of another version)
     assert L.spcl_last_error() is not None
 
 

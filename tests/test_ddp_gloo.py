@@ -46,6 +46,8 @@ def _worker(rank, world, port, q):
     flat.zero_grad()
     ((model(xs) - ys) ** 2).mean().backward()
     flat.fold_mean = True
+    # (valid BEFORE the collective: a captured update graph bakes the factor in without ever running the exchange)
+    assert flat.grad_scale == 1.0 / world
     summed = flat.reduce().clone()
     assert flat.grad_scale == 1.0 / world
     flat.zero_grad()

@@ -168,8 +168,16 @@ def test_fused_sup_loss_is_the_separate_kernels_in_one_launch(K, shape):
     loss_e, _ = F.sup_loss_kl_onehot(le, labels.cuda())
     loss_e.backward(gradient=two)
     assert torch.equal(le.grad, la.grad * 2.0)
+    # a caller that scales the registered tensor IN PLACE (loss scaling) breaks the promise: recognised by its version
+    # counter, the backward multiplies by what the tensor holds now
+    unit.mul_(3.0)
+    assert not F.is_unit_gradient(unit)
+    lf = logits.cuda().requires_grad_(True)
+    loss_f, _ = F.sup_loss_kl_onehot(lf, labels.cuda())
+    loss_f.backward(gradient=unit)
+    assert torch.equal(lf.grad, la.grad * 3.0)
     del unit
-    assert not any(r() is not None and F.is_unit_gradient(r()) for r in list(F._UNIT_GRADIENTS.values()))
+    assert not any(r() is not None and F.is_unit_gradient(r()) for r, _ in list(F._UNIT_GRADIENTS.values()))
 
 
 def test_universal_dice_meter_matches_oracle():
