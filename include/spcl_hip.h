@@ -34,7 +34,7 @@ extern "C" {
 /* Bumped whenever a struct layout, a limit (SPCL_*_MAX) or an entry point's meaning changes.  The library is git-ignored and
  * travels next to the sources: the Python binding (native.py) refuses a library whose version is not the header's, so that a
  * stale build fails at load time instead of running kernels on structs of another stride. */
-#define SPCL_ABI_VERSION 3
+#define SPCL_ABI_VERSION 4
 int spcl_abi_version(void);
 const char* spcl_last_error(void);
 
@@ -185,6 +185,10 @@ int spcl_conv_pack_weights_multi(const spcl_pack_item* items, int n, int dtype, 
  * short, independent jobs at the start of a forward pass overlap and pay one launch.  image == NULL: the plain pack. */
 int spcl_conv_pack_weights_multi_acorr(const spcl_pack_item* items, int n, int dtype, const float* image, int N, int H,
                                        int W, float* acorr, void* stream);
+/* ... and zeroes zero_bytes bytes at `zero` in the same launch (the step's BatchNorm accumulator blocks, see spcl_bn_acc below:
+ * they must be zero before the first convolution of the pass, and this is the pass's first launch).  zero == NULL: none. */
+int spcl_conv_pack_weights_multi_zero(const spcl_pack_item* items, int n, int dtype, const float* image, int N, int H, int W,
+                                      float* acorr, void* zero, size_t zero_bytes, void* stream);
 
 /* y = conv3x3(act(x)), NHWC, implicit GEMM on MFMA.                    (unet.py:72,75; dgrad: with kind-1 weights)
  * x [N,H,W,CinS] of dtype; CinK = GEMM-K channels (multiple of 16, == CinS for in_mode 0/1).
@@ -612,6 +616,56 @@ int spcl_flip_pair_stage(const void* first, const void* second, void* out, int e
 int spcl_profile_enable(int on);
 int spcl_profile_count(void);
 int spcl_profile_get(int i, char* name, int name_cap, float* usec, double* bytes, double* flops);
+
+/* ---------------------------------------------------------------- BatchNorm sums as fixed-point accumulator blocks --------
+ * Replaces the finalize launches between a train-mode nn.BatchNorm2d's producer and consumer (semi_seg/arch/unet.py:73,76 and
+ * its autograd backward): the producing kernel's epilogue ADDS its tile's sums to a block of 64-bit fixed-point words
+ * (integer atomics: exact, order-free, bit-for-bit deterministic), the next launch derives the coefficients in its prologue.
+ * A block is spcl_bn_acc_elems(CS) int64 words, ZEROED by the caller before the producer launch (one memset per step for all
+ * blocks of a step).  Forward blocks hold sum x / sum x^2, backward blocks sum dz / sum dz (y - mean).  csrc/bn_acc.hpp has
+ * the format.  Offered for bf16 layers the specialised 14-column convolution kernels take, with at most 4096 tiles, CS <= 256. */
+typedef struct spcl_bn_acc {
+  long long* acc;                 /* the forward block of this BatchNorm */
+  const float* gamma;             /* [C] */
+  const float* beta;              /* [C] */
+  float* running_mean;            /* [C] or NULL (no update) */
+  float* running_var;             /* [C] or NULL */
+  long long* num_batches_tracked; /* or NULL */
+  float* st;                      /* [4][CS] mean, invstd, scale, shift: WRITTEN by the consuming launch's first workgroup */
+  float momentum, eps;
+  float count;                    /* values per channel: N * H * W */
+  int C, CS;
+} spcl_bn_acc;
+size_t spcl_bn_acc_elems(int CS);
+/* can spcl_conv3x3_forward_acc run this layer with its input read as it is (in_kind 0), through a BatchNorm + ReLU whose
+ * coefficients are derived from a block (1) or come as arrays (2), and (with_stats_acc) its output statistics added to a block? */
+int spcl_conv_bn_acc_supported(int dtype, int N, int H, int W, int CinK, int CoutS, int in_kind, int with_stats_acc);
+/* spcl_conv3x3_forward with blocks on either side: in_bn != NULL -> the input is the previous convolution's RAW output and
+ * relu(scale x + shift) of its BatchNorm is applied by the loader, scale / shift derived from in_bn->acc (no spcl_bn_finalize);
+ * in_bn == NULL: scale / shift from in_scale / in_shift when given, else the input is read as it is;
+ * stats_acc != NULL -> the output's statistics are added to that block; else stats_rows (per-tile rows, or NULL). */
+int spcl_conv3x3_forward_acc(const void* x, int dtype, int N, int H, int W, int CinK, int CoutS, const void* w_packed,
+                             const spcl_bn_acc* in_bn, const float* in_scale, const float* in_shift, void* y,
+                             long long* stats_acc, float* stats_rows, void* stream);
+/* spcl_bn_finalize + spcl_bnrelu_pool_forward in one launch (coefficients derived in the prologue) */
+int spcl_bnrelu_pool_forward_acc(const void* y, int dtype, int N, int H, int W, int CS, const spcl_bn_acc* bn, void* act_out,
+                                 void* pool_out, void* stream);
+/* spcl_conv3x3_dgrad_bnstats / _poolstats with the BatchNorm-backward sums added to a block instead of written as rows */
+int spcl_conv_dgrad_bnstats_acc_supported(int dtype, int N, int H, int W, int CinK, int CoutS);
+int spcl_conv3x3_dgrad_bnstats_acc(const void* dy, int dtype, int N, int H, int W, int CinK, int CoutS, const void* w_packed,
+                                   void* g, const void* y2, const float* scale2, const float* shift2, const float* mean2,
+                                   long long* acc, void* stream);
+int spcl_conv_dgrad_poolstats_acc_supported(int dtype, int N, int H, int W, int CinK, int CoutS, int H2, int W2);
+int spcl_conv3x3_dgrad_poolstats_acc(const void* dy, int dtype, int N, int H, int W, int CinK, int CoutS, const void* w_packed,
+                                     void* g, const void* y2, int H2, int W2, const float* scale2, const float* shift2,
+                                     const float* mean2, long long* acc, void* stream);
+/* the BatchNorm + ReLU (+ max-pool) backward's apply pass with A, B derived from a backward block in its prologue (no reduction
+ * pass where a dgrad filled the block, no finalize launch): exactly one of dact [N][H][W][CS], dpool [N][H/2][W/2][CS]
+ * (block already filled) or dact_nc [N][CS] (one value per image and channel: this call's reduction pass fills the block).
+ * st4 = the forward's [4][CS].  dgamma / dbeta [C] are written by the apply launch. */
+int spcl_bnrelu_backward_acc(const void* y, const void* dact, const void* dpool, const void* dact_nc, int dtype, int N, int H,
+                             int W, int C, int CS, const float* st4, int training, long long* acc, float* dgamma, float* dbeta,
+                             void* dy, void* stream);
 
 #ifdef __cplusplus
 }

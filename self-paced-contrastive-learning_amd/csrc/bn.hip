@@ -3,6 +3,7 @@
 // autograd backward.  All of these are HBM-bound streaming kernels: 16-byte vector loads/stores per lane, per-channel
 // reductions as per-workgroup partials + a fixed-order second stage (deterministic, no float atomics).
 #include <mutex>
+#include "bn_acc.hpp"
 #include "common.hpp"
 #include "image_acorr.hpp"
 
@@ -255,6 +256,49 @@ template <int EPC> __device__ __forceinline__ void load_coef(float* dst, const f
   for (int e = 0; e < EPC; e += 4) *(f32x4*)&dst[e] = *(const f32x4*)(src + cc * EPC + e);
 }
 
+// Coefficients from a fixed-point accumulator block (bn_acc.hpp) in the prologue of a 256-thread streaming kernel, CS <= 256:
+// thread c derives channel c's pair, LDS hands every thread the eight of its chunk; the launch's first workgroup also leaves
+// what the finalize launch used to leave (forward: mean / invstd / scale / shift + running statistics; backward: dgamma,
+// dbeta).  Must be called by ALL threads of the workgroup (a barrier inside).
+template <int EPC>
+__device__ __forceinline__ void acc_coef_fwd(const BnAccFwd& bn, int cc, float* sc, float* sh) {
+  __shared__ float cl[2][256];
+  const int c = threadIdx.x;
+  if (c < bn.CS) {
+    BnAccFwdRaw raw;
+    raw.load(bn, c);
+    float a, b;
+    bn_acc_fwd_channel(bn, raw, c, a, b, blockIdx.x == 0);
+    cl[0][c] = a;
+    cl[1][c] = b;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    sc[e] = cl[0][cc * EPC + e];
+    sh[e] = cl[1][cc * EPC + e];
+  }
+}
+template <int EPC>
+__device__ __forceinline__ void acc_coef_bwd(const BnAccBwd& bw, int cc, float* A, float* B) {
+  __shared__ float cl[2][256];
+  const int c = threadIdx.x;
+  if (c < bw.CS) {
+    BnAccBwdRaw raw;
+    raw.load(bw, c);
+    float a, b;
+    bn_acc_bwd_channel(bw, raw, c, a, b, blockIdx.x == 0);
+    cl[0][c] = a;
+    cl[1][c] = b;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    A[e] = cl[0][cc * EPC + e];
+    B[e] = cl[1][cc * EPC + e];
+  }
+}
+
 constexpr int STREAM_UNROLL = 2;
 constexpr int IMG_WGRAD_WG = 2048;  // upper bound of the workgroups of the fused image-wgrad pass
 
@@ -263,14 +307,18 @@ template <typename T>
 __global__ __launch_bounds__(256, 6) void bnrelu_fwd_lin_kernel(const T* __restrict__ y, size_t npix, int CS,
                                                              const float* __restrict__ scale,
                                                              const float* __restrict__ shift, T* __restrict__ act,
-                                                             int AS /* elements between two pixels of act (>= CS) */) {
+                                                             int AS /* elements between two pixels of act (>= CS) */,
+                                                             BnAccFwd bn = BnAccFwd{}) {
   constexpr int EPC = Chunk<T>::EPC, U = STREAM_UNROLL;
   const int CPC = CS / EPC, PL = 256 / CPC;
   const int cc = threadIdx.x % CPC, pl = threadIdx.x / CPC;
-  if (pl >= PL) return;
   float sc[EPC], sh[EPC];
-  load_coef<EPC>(sc, scale, cc);
-  load_coef<EPC>(sh, shift, cc);
+  if (bn.acc != nullptr) acc_coef_fwd<EPC>(bn, cc, sc, sh);  // (wave-uniform; before any thread leaves: a barrier inside)
+  if (pl >= PL) return;
+  if (bn.acc == nullptr) {
+    load_coef<EPC>(sc, scale, cc);
+    load_coef<EPC>(sh, shift, cc);
+  }
   const size_t stride = (size_t)gridDim.x * PL;
   for (size_t p = (size_t)blockIdx.x * PL + pl; p < npix; p += U * stride) {
     u32x4 r[U];
@@ -357,15 +405,18 @@ template <typename T, bool FAST>
 __global__ __launch_bounds__(256, 4) void bnrelu_fwd_pool_kernel(const T* __restrict__ y, int N, int H, int W, int CS,
                                                               const float* __restrict__ scale,
                                                               const float* __restrict__ shift, T* __restrict__ act,
-                                                              T* __restrict__ pool, int AS) {
+                                                              T* __restrict__ pool, int AS, BnAccFwd bn = BnAccFwd{}) {
   constexpr int EPC = Chunk<T>::EPC, EPW = Word<T>::EPW;
   const int CPC = CS / EPC, PL = 256 / CPC;
   const int cc = threadIdx.x % CPC, pl = threadIdx.x / CPC;
+  float sc[EPC], sh[EPC];
+  if (bn.acc != nullptr) acc_coef_fwd<EPC>(bn, cc, sc, sh);  // (wave-uniform; before any thread leaves: a barrier inside)
   if (pl >= PL) return;
   const int PH = (H + 1) / 2, PW = (W + 1) / 2, OH = H / 2, OW = W / 2;
-  float sc[EPC], sh[EPC];
-  load_coef<EPC>(sc, scale, cc);
-  load_coef<EPC>(sh, shift, cc);
+  if (bn.acc == nullptr) {
+    load_coef<EPC>(sc, scale, cc);
+    load_coef<EPC>(sh, shift, cc);
+  }
   const int rows = N * PH;
   for (int r = blockIdx.x; r < rows; r += gridDim.x) {
     const int n = r / PH, oy = r - n * PH;  // wave-uniform
@@ -422,13 +473,26 @@ constexpr int STREAM_MAX_WG = 2048;  // long-lived workgroups: launching a wave 
 
 template <typename T, int EPC>
 __device__ __forceinline__ void wg_reduce_partials(const float* s1, const float* s2, int CS, int CPC, int PL,
-                                                   float* __restrict__ partial, float (*red)[2 * EPC + 1]) {
+                                                   float* __restrict__ partial, float (*red)[2 * EPC + 1],
+                                                   long long* __restrict__ acc = nullptr) {
 #pragma unroll
   for (int e = 0; e < EPC; ++e) {
     red[threadIdx.x][e] = s1[e];
     red[threadIdx.x][EPC + e] = s2[e];
   }
   __syncthreads();
+  if (acc != nullptr) {
+    // thread o -> word o of the block's row: channel o / 4, sum (o / 2) % 2, limb o % 2 (the two limb threads of a sum both
+    // form it -- the same fixed-order LDS walk -- and each adds its limb: consecutive lanes, consecutive words)
+    for (int o = threadIdx.x; o < 4 * CS; o += 256) {
+      const int c = o >> 2, which = (o >> 1) & 1, limb = o & 1;
+      const int ccc = c / EPC, e = c - ccc * EPC;
+      float s = 0.f;
+      for (int p = 0; p < PL; ++p) s += red[p * CPC + ccc][which * EPC + e];
+      bn_acc_add_word(acc, CS, (int)(blockIdx.x & (BN_ACC_REPLICAS - 1)), c, which, limb, s);
+    }
+    return;
+  }
   for (int o = threadIdx.x; o < 2 * CS; o += 256) {
     const int which = o / CS, c = o - which * CS;
     const int ccc = c / EPC, e = c - ccc * EPC;
@@ -579,7 +643,10 @@ __global__ __launch_bounds__(256, 5) void bnrelu_bwd_reduce_bcast_kernel(const T
                                                                       const float* __restrict__ invstd,
                                                                       const float* __restrict__ scale,
                                                                       const float* __restrict__ shift,
-                                                                      float* __restrict__ partial /* [grid][2][CS] */) {
+                                                                      float* __restrict__ partial /* [grid][2][CS] */,
+                                                                      long long* __restrict__ acc = nullptr) {
+  // acc != null: the workgroup's sums are ADDED to that fixed-point block (bn_acc.hpp; sum dz (y - mean) NOT yet scaled by
+  // invstd: the consumer does) instead of leaving a partial row for the finalize launch
   constexpr int EPC = Chunk<T>::EPC, EPW = Word<T>::EPW;
   __shared__ float red[256][2 * EPC + 1];
   const int CPC = CS / EPC, PL = 256 / CPC;
@@ -609,10 +676,12 @@ __global__ __launch_bounds__(256, 5) void bnrelu_bwd_reduce_bcast_kernel(const T
           s2[e] = fmaf(dz, yv - mu[e], s2[e]);
         }
     }
+    if (acc == nullptr) {
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) s2[e] *= is[e];
+      for (int e = 0; e < EPC; ++e) s2[e] *= is[e];
+    }
   }
-  wg_reduce_partials<T, EPC>(s1, s2, CS, CPC, PL, partial, red);
+  wg_reduce_partials<T, EPC>(s1, s2, CS, CPC, PL, partial, red, acc);
 }
 
 template <typename T>
@@ -620,17 +689,21 @@ __global__ __launch_bounds__(256, 6) void bnrelu_bwd_apply_bcast_kernel(const T*
                                                                      int HW, int CS, int SPLIT,
                                                                      const float* __restrict__ scale,
                                                                      const float* __restrict__ shift,
-                                                                     const float* __restrict__ ab, T* __restrict__ dy) {
+                                                                     const float* __restrict__ ab, T* __restrict__ dy,
+                                                                     BnAccBwd bw = BnAccBwd{}) {
   constexpr int EPC = Chunk<T>::EPC, EPW = Word<T>::EPW;
   const int CPC = CS / EPC, PL = 256 / CPC;
   const int cc = threadIdx.x % CPC, pl = threadIdx.x / CPC;
+  float sc[EPC], sh[EPC], A[EPC], B[EPC];
+  if (bw.acc != nullptr) acc_coef_bwd<EPC>(bw, cc, A, B);  // (before any thread leaves: a barrier inside)
   if (pl >= PL) return;
   const int n = blockIdx.x / SPLIT, sp = blockIdx.x - n * SPLIT;
-  float sc[EPC], sh[EPC], A[EPC], B[EPC];
   load_coef<EPC>(sc, scale, cc);
   load_coef<EPC>(sh, shift, cc);
-  load_coef<EPC>(A, ab, cc);
-  load_coef<EPC>(B, ab + CS, cc);
+  if (bw.acc == nullptr) {
+    load_coef<EPC>(A, ab, cc);
+    load_coef<EPC>(B, ab + CS, cc);
+  }
   const u32x4 rg = *(const u32x4*)(gb + (size_t)n * CS + cc * EPC);
   const size_t base = (size_t)n * HW * CS + cc * EPC;
   for (int p = sp * PL + pl; p < HW; p += SPLIT * PL) {
@@ -687,7 +760,9 @@ __device__ __forceinline__ void window_dz(const Window<T>& w, const u32x4* rg, b
 // ---- pass 1 / pass 2 with pooling.  APPLY == false: partial sums;  true: dy
 // FAST: H and W even, pooled gradient only (dact == null, dpool given) -- the training step's case: the run-time flags
 // of the general form are scalar / exec branches around every load and store of the loop
-template <typename T, bool APPLY, bool FAST>
+// ACC: the apply pass derives A, B from a fixed-point accumulator block in its prologue (bn_acc.hpp) -- its own instantiation:
+// the prologue's registers would take the plain form from five to four waves per SIMD (97 registers for 93)
+template <typename T, bool APPLY, bool FAST, bool ACC = false>
 __global__ __launch_bounds__(256, 3) BWD_POOL_WPE void bnrelu_bwd_pool_kernel(const T* __restrict__ y, const T* __restrict__ dact,
                                                               const T* __restrict__ dpool, int N, int H, int W, int CS,
                                                               const float* __restrict__ mean,
@@ -695,7 +770,8 @@ __global__ __launch_bounds__(256, 3) BWD_POOL_WPE void bnrelu_bwd_pool_kernel(co
                                                               const float* __restrict__ scale,
                                                               const float* __restrict__ shift,
                                                               const float* __restrict__ ab, float* __restrict__ partial,
-                                                              T* __restrict__ dy, int GS = 0 /* dact pixel stride */) {
+                                                              T* __restrict__ dy, int GS = 0 /* dact pixel stride */,
+                                                              BnAccBwd bw = BnAccBwd{}) {
   constexpr int EPC = Chunk<T>::EPC, EPW = Word<T>::EPW;
   __shared__ float red[APPLY ? 1 : 256][2 * EPC + 1];
   const int CPC = CS / EPC, PL = 256 / CPC;
@@ -705,12 +781,17 @@ __global__ __launch_bounds__(256, 3) BWD_POOL_WPE void bnrelu_bwd_pool_kernel(co
   float s1[EPC], s2[EPC];
 #pragma unroll
   for (int e = 0; e < EPC; ++e) s1[e] = s2[e] = 0.f;
+  float c0[EPC], c1[EPC];  // reduce: c0 = mean, c1 = invstd;  apply: c0 = A, c1 = B
+  constexpr bool from_acc = APPLY && ACC;  // (apply pass: A, B derived from a fixed-point block, bn_acc.hpp)
+  if (from_acc) acc_coef_bwd<EPC>(bw, cc, c0, c1);
   if (pl < PL) {
-    float sc[EPC], sh[EPC], c0[EPC], c1[EPC];  // reduce: c0 = mean, c1 = invstd;  apply: c0 = A, c1 = B
+    float sc[EPC], sh[EPC];
     load_coef<EPC>(sc, scale, cc);
     load_coef<EPC>(sh, shift, cc);
-    load_coef<EPC>(c0, APPLY ? ab : mean, cc);
-    load_coef<EPC>(c1, APPLY ? ab + CS : invstd, cc);
+    if (!from_acc) {
+      load_coef<EPC>(c0, APPLY ? ab : mean, cc);
+      load_coef<EPC>(c1, APPLY ? ab + CS : invstd, cc);
+    }
     const int rows = N * PH;
     for (int r = blockIdx.x; r < rows; r += gridDim.x) {
       const int n = r / PH, oy = r - n * PH;  // wave-uniform
@@ -979,16 +1060,19 @@ __global__ __launch_bounds__(256, 6) void bnrelu_bwd_apply_lin_kernel(const T* _
                                                                    const float* __restrict__ scale,
                                                                    const float* __restrict__ shift,
                                                                    const float* __restrict__ ab, T* __restrict__ dy,
-                                                                   int GS) {
+                                                                   int GS, BnAccBwd bw = BnAccBwd{}) {
   constexpr int EPC = Chunk<T>::EPC, EPW = Word<T>::EPW, U = STREAM_UNROLL;
   const int CPC = CS / EPC, PL = 256 / CPC;
   const int cc = threadIdx.x % CPC, pl = threadIdx.x / CPC;
-  if (pl >= PL) return;
   float sc[EPC], sh[EPC], A[EPC], B[EPC];
+  if (bw.acc != nullptr) acc_coef_bwd<EPC>(bw, cc, A, B);  // (before any thread leaves: a barrier inside)
+  if (pl >= PL) return;
   load_coef<EPC>(sc, scale, cc);
   load_coef<EPC>(sh, shift, cc);
-  load_coef<EPC>(A, ab, cc);
-  load_coef<EPC>(B, ab + CS, cc);
+  if (bw.acc == nullptr) {
+    load_coef<EPC>(A, ab, cc);
+    load_coef<EPC>(B, ab + CS, cc);
+  }
   const size_t stride = (size_t)gridDim.x * PL;
   for (size_t p = (size_t)blockIdx.x * PL + pl; p < npix; p += U * stride) {
     u32x4 ry[U], rg[U];
@@ -1165,8 +1249,12 @@ static thread_local const void* tl_up2_src = nullptr;  // spcl_bnrelu_backward_u
 
 template <typename T>
 static int bnrelu_fwd_launch(const void* y, int N, int H, int W, int CS, const float* scale, const float* shift,
-                             void* act, void* pool, hipStream_t st) {
+                             void* act, void* pool, hipStream_t st, const BnAccFwd* bnp = nullptr) {
   constexpr int EPC = Chunk<T>::EPC;
+  const BnAccFwd bn = bnp != nullptr ? *bnp : BnAccFwd{};
+  // (coefficients derived in every workgroup's prologue: fewer, longer-lived workgroups amortise it)
+  static const int acc_wg = lab_env("SPCL_ACC_STREAM_WG", 768);
+  const int STREAM_MAX_WG = bnp != nullptr ? acc_wg : spcl::STREAM_MAX_WG;
   const int PL = 256 / (CS / EPC);
   const int AS = tl_act_stride > 0 ? tl_act_stride : CS;
   const double tb = (double)N * H * W * CS * sizeof(T);  // bytes of one full-resolution tensor
@@ -1175,15 +1263,15 @@ static int bnrelu_fwd_launch(const void* y, int N, int H, int W, int CS, const f
     const int rows = N * ((H + 1) / 2);
     if (H % 2 == 0 && W % 2 == 0) {
       SPCL_LAUNCH((bnrelu_fwd_pool_kernel<T, true>), dim3(rows < STREAM_MAX_WG ? rows : STREAM_MAX_WG), dim3(256), 0, st, (const T*)y, N, H,
-                       W, CS, scale, shift, (T*)act, (T*)pool, AS);
+                       W, CS, scale, shift, (T*)act, (T*)pool, AS, bn);
     } else {
       SPCL_LAUNCH((bnrelu_fwd_pool_kernel<T, false>), dim3(rows < STREAM_MAX_WG ? rows : STREAM_MAX_WG), dim3(256), 0, st, (const T*)y, N, H,
-                       W, CS, scale, shift, (T*)act, (T*)pool, AS);
+                       W, CS, scale, shift, (T*)act, (T*)pool, AS, bn);
     }
   } else {
     const size_t npix = (size_t)N * H * W;
     SPCL_LAUNCH((bnrelu_fwd_lin_kernel<T>), dim3(stream_grid(npix, PL, STREAM_UNROLL, STREAM_MAX_WG)), dim3(256), 0, st,
-                       (const T*)y, npix, CS, scale, shift, (T*)act, AS);
+                       (const T*)y, npix, CS, scale, shift, (T*)act, AS, bn);
   }
   return 0;
 }
@@ -1193,8 +1281,16 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
                              const float* mean, const float* invstd, const float* scale, const float* shift,
                              int training, float* ws, float* dgamma, float* dbeta, void* dy, hipStream_t st,
                              const float* img = nullptr, float* dw = nullptr, const float* rows = nullptr,
-                             int nrows = 0, bool bcast = false /* dact is [N][CS], one value per image and channel */) {
+                             int nrows = 0, bool bcast = false /* dact is [N][CS], one value per image and channel */,
+                             long long* acc = nullptr /* the sums as a fixed-point block (bn_acc.hpp): no finalize launch */) {
   constexpr int EPC = Chunk<T>::EPC;
+  // acc: either FILLED already by the dgrad that produced dact / dpool (lin / pool apply), or -- bcast -- filled by this
+  // call's reduction pass; the apply kernel derives A, B in its prologue, its first workgroup writes dgamma / dbeta
+  const BnAccBwd bw = acc != nullptr ? BnAccBwd{acc, mean /* = st[0]: mean, invstd, scale, shift are [4][CS] */, dgamma, dbeta,
+                                                (float)((size_t)N * H * W), training, C, CS}
+                                     : BnAccBwd{};
+  static const int acc_wg = lab_env("SPCL_ACC_STREAM_WG", 768);
+  const int STREAM_MAX_WG = acc != nullptr ? acc_wg : spcl::STREAM_MAX_WG;  // (see bnrelu_fwd_launch)
   const bool pool = dpool != nullptr;
   const int GS = tl_dact_stride > 0 ? tl_dact_stride : CS;
   constexpr int rs = 2;  // sub-rows of a partial row (the image3 path has eleven: spcl_bnrelu_backward_rows_image3)
@@ -1203,8 +1299,8 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
   const int PL = 256 / (CS / EPC);
   const size_t npix = (size_t)N * H * W;
   const int prows = N * ((H + 1) / 2);
-  float* partial = ws;                           // [nwg][2][CS]
-  float* ab = ws + (size_t)BWD_MAX_WG * 2 * CS;  // [2][CS]: folded BN-backward coefficients
+  float* partial = ws;                           // [nwg][2][CS]  (ws may be null with `acc`: neither is touched then)
+  float* ab = ws != nullptr ? ws + (size_t)BWD_MAX_WG * 2 * CS : nullptr;  // [2][CS]: folded BN-backward coefficients
   const float M = (float)npix;
   int nwg, bsplit = 1;
   const double tb = (double)npix * CS * sizeof(T);  // bytes of one full-resolution tensor
@@ -1212,7 +1308,9 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
   prof_cost(tb + gb, 0.0);
   const float* fin_src = partial;
   int fin_transposed = 0;
-  if (rows != nullptr) {  // the partial sums came with the dgrad that produced dact (per conv tile, centred s2)
+  if (acc != nullptr && !bcast) {
+    nwg = 0;  // (the block is complete: nothing to reduce, nothing to finalize)
+  } else if (rows != nullptr) {  // the partial sums came with the dgrad that produced dact (per conv tile, centred s2)
     static const int fin_rows = getenv("SPCL_BWD_FIN_MAX_ROWS") ? atoi(getenv("SPCL_BWD_FIN_MAX_ROWS")) : BWD_MAX_WG;
     if (nrows <= fin_rows) {
       fin_src = rows;
@@ -1247,7 +1345,7 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
     nwg = N * bsplit;
     prof_cost(tb, 0.0);
     SPCL_LAUNCH((bnrelu_bwd_reduce_bcast_kernel<T>), dim3(nwg), dim3(256), 0, st, (const T*)y, (const T*)dact, H * W, CS,
-                bsplit, mean, invstd, scale, shift, partial);
+                bsplit, mean, invstd, scale, shift, partial, acc);
   } else if (tl_up2_src != nullptr) {
     nwg = stream_grid(npix, PL, STREAM_UNROLL, BWD_MAX_WG);
     prof_cost(tb * 6.0, 0.0);
@@ -1258,18 +1356,29 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
     SPCL_LAUNCH((bnrelu_bwd_reduce_lin_kernel<T>), dim3(nwg), dim3(256), 0, st, (const T*)y, (const T*)dact, npix,
                        CS, mean, invstd, scale, shift, partial, GS);
   }
-  float* zrow = ab + 2 * CS + (size_t)IMG_WGRAD_WG * 9 * CS;  // [W] zeros (image-wgrad pass only, see below)
-  SPCL_LAUNCH(bnrelu_bwd_fin_kernel, dim3(CS), dim3(256), 0, st, fin_src, nwg, C, CS,
-                     M, training, mean, invstd, scale, dgamma, dbeta, ab, img != nullptr ? zrow : (float*)nullptr,
-                     img != nullptr ? W : 0, rows != nullptr ? 1 : 0, rs, im3, fin_transposed);
+  float* zrow = ab != nullptr ? ab + 2 * CS + (size_t)IMG_WGRAD_WG * 9 * CS : nullptr;  // [W] zeros (image-wgrad pass only, see below)
+  if (acc == nullptr)
+    SPCL_LAUNCH(bnrelu_bwd_fin_kernel, dim3(CS), dim3(256), 0, st, fin_src, nwg, C, CS,
+                       M, training, mean, invstd, scale, dgamma, dbeta, ab, img != nullptr ? zrow : (float*)nullptr,
+                       img != nullptr ? W : 0, rows != nullptr ? 1 : 0, rs, im3, fin_transposed);
   prof_cost(2.0 * tb + gb, 0.0);
   if (pool) {
     if (H % 2 == 0 && W % 2 == 0 && dact == nullptr && dpool != nullptr) {
-      SPCL_LAUNCH((bnrelu_bwd_pool_kernel<T, true, true>), dim3(prows < STREAM_MAX_WG ? prows : STREAM_MAX_WG), dim3(256), 0, st, (const T*)y,
+      if (acc != nullptr)
+        SPCL_LAUNCH((bnrelu_bwd_pool_kernel<T, true, true, true>), dim3(prows < STREAM_MAX_WG ? prows : STREAM_MAX_WG), dim3(256), 0, st,
+                    (const T*)y, (const T*)dact, (const T*)dpool, N, H, W, CS, mean, invstd, scale, shift, (const float*)ab,
+                    (float*)nullptr, (T*)dy, 0, bw);
+      else
+        SPCL_LAUNCH((bnrelu_bwd_pool_kernel<T, true, true>), dim3(prows < STREAM_MAX_WG ? prows : STREAM_MAX_WG), dim3(256), 0, st, (const T*)y,
                        (const T*)dact, (const T*)dpool, N, H, W, CS, mean, invstd, scale, shift, (const float*)ab,
                        (float*)nullptr, (T*)dy);
     } else {
-      SPCL_LAUNCH((bnrelu_bwd_pool_kernel<T, true, false>), dim3(prows < STREAM_MAX_WG ? prows : STREAM_MAX_WG), dim3(256), 0, st, (const T*)y,
+      if (acc != nullptr)
+        SPCL_LAUNCH((bnrelu_bwd_pool_kernel<T, true, false, true>), dim3(prows < STREAM_MAX_WG ? prows : STREAM_MAX_WG), dim3(256), 0, st,
+                    (const T*)y, (const T*)dact, (const T*)dpool, N, H, W, CS, mean, invstd, scale, shift, (const float*)ab,
+                    (float*)nullptr, (T*)dy, GS, bw);
+      else
+        SPCL_LAUNCH((bnrelu_bwd_pool_kernel<T, true, false>), dim3(prows < STREAM_MAX_WG ? prows : STREAM_MAX_WG), dim3(256), 0, st, (const T*)y,
                        (const T*)dact, (const T*)dpool, N, H, W, CS, mean, invstd, scale, shift, (const float*)ab,
                        (float*)nullptr, (T*)dy, GS);
     }
@@ -1290,10 +1399,10 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
   } else if (bcast) {
     prof_cost(2.0 * tb, 0.0);
     SPCL_LAUNCH((bnrelu_bwd_apply_bcast_kernel<T>), dim3(N * bsplit), dim3(256), 0, st, (const T*)y, (const T*)dact, H * W,
-                CS, bsplit, scale, shift, (const float*)ab, (T*)dy);
+                CS, bsplit, scale, shift, (const float*)ab, (T*)dy, bw);
   } else {
     SPCL_LAUNCH((bnrelu_bwd_apply_lin_kernel<T>), dim3(stream_grid(npix, PL, STREAM_UNROLL, STREAM_MAX_WG)), dim3(256), 0,
-                       st, (const T*)y, (const T*)dact, npix, CS, scale, shift, (const float*)ab, (T*)dy, GS);
+                       st, (const T*)y, (const T*)dact, npix, CS, scale, shift, (const float*)ab, (T*)dy, GS, bw);
   }
   return 0;
 }
@@ -1399,6 +1508,58 @@ extern "C" int spcl_bnrelu_pool_forward(const void* y, int dtype, int N, int H, 
   if (dtype == SPCL_F32) bnrelu_fwd_launch<float>(y, N, H, W, CS, scale, shift, act_out, pool_out, st);
   else bnrelu_fwd_launch<bf16_t>(y, N, H, W, CS, scale, shift, act_out, pool_out, st);
   SPCL_LAUNCH_CHECK("bnrelu_pool_forward");
+  return SPCL_OK;
+}
+
+// BN-apply + ReLU (+ 2x2 max-pool) with scale / shift DERIVED from a fixed-point accumulator block (bn_acc.hpp) in the kernel's
+// prologue: what spcl_bn_finalize + spcl_bnrelu_pool_forward do in two launches, in one.  The launch's first workgroup writes
+// bn->st (mean, invstd, scale, shift: what backward / a later eval needs) and updates the running statistics.  CS <= 256.
+extern "C" int spcl_bnrelu_pool_forward_acc(const void* y, int dtype, int N, int H, int W, int CS, const spcl_bn_acc* bn,
+                                            void* act_out, void* pool_out, void* stream) {
+  SPCL_CHECK_ARG(y && bn && (act_out || pool_out), "bnrelu_pool_forward_acc: null pointer");
+  SPCL_CHECK_ARG(N > 0 && H > 0 && W > 0 && CS > 0 && CS % 16 == 0 && CS <= 256, "bnrelu_pool_forward_acc: bad shape (CS <= 256)");
+  SPCL_CHECK_ARG(!pool_out || (H >= 2 && W >= 2), "bnrelu_pool_forward_acc: 2x2 pooling needs H,W >= 2");
+  SPCL_CHECK_ARG(bn->acc && bn->gamma && bn->beta && bn->st && bn->CS == CS && bn->C > 0 && bn->C <= CS && bn->count >= 1.f,
+                 "bnrelu_pool_forward_acc: bad accumulator description");
+  hipStream_t st = (hipStream_t)stream;
+  const BnAccFwd f{bn->acc, bn->gamma, bn->beta, bn->running_mean, bn->running_var, bn->num_batches_tracked, bn->st,
+                   bn->momentum, bn->eps, bn->count, bn->C, bn->CS, 1.0 / (double)bn->count};
+  if (dtype == SPCL_F32) bnrelu_fwd_launch<float>(y, N, H, W, CS, nullptr, nullptr, act_out, pool_out, st, &f);
+  else if (dtype == SPCL_BF16) bnrelu_fwd_launch<bf16_t>(y, N, H, W, CS, nullptr, nullptr, act_out, pool_out, st, &f);
+  else {
+    set_error("bnrelu_pool_forward_acc: dtype %d", dtype);
+    return SPCL_EINVAL;
+  }
+  SPCL_LAUNCH_CHECK("bnrelu_pool_forward_acc");
+  return SPCL_OK;
+}
+
+// BN + ReLU (+ max-pool) BACKWARD apply pass with its coefficients derived from a fixed-point accumulator block: no reduction
+// pass over the tensors where the dgrad that produced the incoming gradient filled the block (spcl_conv3x3_dgrad_bnstats_acc /
+// _poolstats_acc), and no finalize launch in any case.  Exactly one of
+//   dact    [N][H][W][CS]      gradient w.r.t. the activation; the block is already filled
+//   dpool   [N][H/2][W/2][CS]  gradient w.r.t. the pooled activation (H, W even); the block is already filled
+//   dact_nc [N][CS]            one value per (image, channel) (global average pool); THIS call's reduction pass fills the block
+// st = the forward's [4][CS] (mean, invstd, scale, shift).  The first workgroup of the apply launch writes dgamma / dbeta.
+extern "C" int spcl_bnrelu_backward_acc(const void* y, const void* dact, const void* dpool, const void* dact_nc, int dtype,
+                                        int N, int H, int W, int C, int CS, const float* st4, int training, long long* acc,
+                                        float* dgamma, float* dbeta, void* dy, void* stream) {
+  SPCL_CHECK_ARG(y && st4 && acc && dgamma && dbeta && dy, "bnrelu_backward_acc: null pointer");
+  SPCL_CHECK_ARG((dact != nullptr) + (dpool != nullptr) + (dact_nc != nullptr) == 1,
+                 "bnrelu_backward_acc: exactly one of dact, dpool, dact_nc");
+  SPCL_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && CS >= C && CS % 16 == 0 && CS <= 256, "bnrelu_backward_acc: bad shape (CS <= 256)");
+  SPCL_CHECK_ARG(!dpool || (H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0), "bnrelu_backward_acc: pooled form needs even H, W");
+  SPCL_CHECK_ARG(dtype == SPCL_BF16 || dtype == SPCL_F32, "bnrelu_backward_acc: dtype %d", dtype);
+  hipStream_t st = (hipStream_t)stream;
+  const float *mean = st4, *invstd = st4 + CS, *scale = st4 + 2 * CS, *shift = st4 + 3 * CS;
+  const void* g = dact_nc != nullptr ? dact_nc : dact;
+  if (dtype == SPCL_F32)
+    bnrelu_bwd_launch<float>(y, g, dpool, N, H, W, C, CS, mean, invstd, scale, shift, training, nullptr, dgamma, dbeta, dy, st,
+                             nullptr, nullptr, nullptr, 0, dact_nc != nullptr, acc);
+  else
+    bnrelu_bwd_launch<bf16_t>(y, g, dpool, N, H, W, C, CS, mean, invstd, scale, shift, training, nullptr, dgamma, dbeta, dy, st,
+                              nullptr, nullptr, nullptr, 0, dact_nc != nullptr, acc);
+  SPCL_LAUNCH_CHECK("bnrelu_backward_acc");
   return SPCL_OK;
 }
 

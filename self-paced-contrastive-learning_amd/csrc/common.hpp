@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include "../../include/spcl_hip.h"
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -98,6 +99,22 @@ spcl_wgrad_tail* take_tail_capture();
 // wgrad.hip: final sum of a weight gradient's split partial slabs
 void launch_wgrad_reduce(const float* partial, int nsplit, int nblk_ci, int nblk_co, int CIB, int COB, int Cin, int Cout,
                          float* dw_oihw, hipStream_t st);
+
+// Tuning / ablation knobs read from the environment exist in LAB builds only (-DSPCL_LAB=1: tools/diag/mk_variant.sh,
+// SPCL_BUILD_DEFS): the shipped library compiles every one of them to its default -- nothing in the process environment can
+// change what a production kernel computes.
+#ifndef SPCL_LAB
+#define SPCL_LAB 0
+#endif
+inline int lab_env(const char* name, int dflt) {
+#if SPCL_LAB
+  const char* e = getenv(name);
+  return e != nullptr ? atoi(e) : dflt;
+#else
+  (void)name;
+  return dflt;
+#endif
+}
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline int round_up(int a, int b) { return cdiv(a, b) * b; }

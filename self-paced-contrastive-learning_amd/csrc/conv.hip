@@ -14,6 +14,7 @@
 //   * bf16: v_mfma_f32_16x16x32_bf16 (8 bf16 / lane / operand);  f32: 4x v_mfma_f32_16x16x4_f32 per 16-byte chunk
 //     (exact-f32, the parity path).
 #include <stdlib.h>
+#include "bn_acc.hpp"
 #include "conv_common.hpp"
 #include "image_acorr.hpp"
 
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(256) void conv_pack_block_kernel(const float* __res
 #ifndef SPCL_PACK_EPB
 #define SPCL_PACK_EPB 1024
 #endif
-constexpr int PACK_EPB = SPCL_PACK_EPB, PACK_SEGS = 2 * SPCL_PACK_MULTI_MAX;
+constexpr int PACK_EPB = SPCL_PACK_EPB, PACK_SEGS = 2 * SPCL_PACK_MULTI_MAX + 1;  // (+ 1: the zero-fill segment, kind 2)
 struct PackSeg {
   const float* w;
   void* out;
@@ -378,8 +379,12 @@ __device__ __forceinline__ void conv_pack_multi_body(const PackSegs& p, const in
 #pragma unroll
   for (int e = 0; e < PACK_EPB / 256; ++e) {
     const unsigned i = base + e * 256;
-    if (i < g.count)
-      Elem<T>::store((T*)g.out + i, pack_value<T>(g.w, g.Cin, g.Cout, g.kind, g.KinK, g.NoutS, (size_t)i, g.gemm != 0));
+    if (i < g.count) {
+      // kind 2: not a weight layout at all -- a region to ZERO (the step's BatchNorm accumulator blocks, bn_acc.hpp: they must
+      // be zero before the first convolution runs, and this launch is the first of every forward pass: no fill launch)
+      if (g.kind == 2) Elem<T>::store((T*)g.out + i, 0.f);
+      else Elem<T>::store((T*)g.out + i, pack_value<T>(g.w, g.Cin, g.Cout, g.kind, g.KinK, g.NoutS, (size_t)i, g.gemm != 0));
+    }
   }
 }
 
@@ -596,7 +601,7 @@ extern "C" int spcl_conv_pack_weights_block_at(const float* wa_oihw, int CinA, i
 
 template <typename T>
 static int pack_multi_t(const spcl_pack_item* items, int n, hipStream_t st, const float* img = nullptr, int N = 0, int H = 0,
-                        int W = 0, float* acorr = nullptr) {
+                        int W = 0, float* acorr = nullptr, void* zero = nullptr, size_t zero_bytes = 0) {
   PackSegs p;
   int nseg = 0, blocks = 0;
   for (int i = 0; i < n; ++i) {
@@ -616,6 +621,13 @@ static int pack_multi_t(const spcl_pack_item* items, int n, hipStream_t st, cons
       blocks += (int)((elems + PACK_EPB - 1) / PACK_EPB);
       p.blk_end[nseg++] = blocks;
     }
+  }
+  if (zero != nullptr && zero_bytes > 0) {  // the zero-fill segment (kind 2), as elements of T
+    PackSeg& g = p.s[nseg];
+    g.w = nullptr; g.out = zero; g.count = (unsigned)(zero_bytes / sizeof(T)); g.blk_begin = blocks;
+    g.Cin = g.Cout = g.KinK = g.NoutS = 16; g.kind = 2; g.gemm = 0;
+    blocks += (int)((g.count + PACK_EPB - 1) / PACK_EPB);
+    p.blk_end[nseg++] = blocks;
   }
   for (int k = nseg; k < PACK_SEGS; ++k) {
     p.blk_end[k] = 0x7fffffff;
@@ -638,6 +650,15 @@ extern "C" int spcl_conv_pack_weights_multi(const spcl_pack_item* items, int n, 
 
 extern "C" int spcl_conv_pack_weights_multi_acorr(const spcl_pack_item* items, int n, int dtype, const float* image, int N,
                                                   int H, int W, float* acorr, void* stream) {
+  return spcl_conv_pack_weights_multi_zero(items, n, dtype, image, N, H, W, acorr, nullptr, 0, stream);
+}
+
+// ... and the same launch ZEROES `zero_bytes` bytes at `zero` (a multiple of 4; the step's BatchNorm accumulator blocks,
+// spcl_bn_acc_elems): the pack is the first launch of a forward pass, the blocks must be zero before the first convolution
+extern "C" int spcl_conv_pack_weights_multi_zero(const spcl_pack_item* items, int n, int dtype, const float* image, int N,
+                                                 int H, int W, float* acorr, void* zero, size_t zero_bytes, void* stream) {
+  SPCL_CHECK_ARG((zero == nullptr) == (zero_bytes == 0) && zero_bytes % 4 == 0 && zero_bytes < (1ull << 31),
+                 "conv_pack_weights_multi_zero: bad zero region");
   SPCL_CHECK_ARG(items && n >= 1 && n <= SPCL_PACK_MULTI_MAX, "conv_pack_weights_multi: 1 <= n <= %d layers",
                  SPCL_PACK_MULTI_MAX);
   SPCL_CHECK_ARG(image == nullptr || (acorr && N > 0 && H > 0 && W > 0 && W <= ACORR_MAXW),
@@ -647,8 +668,8 @@ extern "C" int spcl_conv_pack_weights_multi_acorr(const spcl_pack_item* items, i
     SPCL_CHECK_ARG(items[i].Cin > 0 && items[i].Cout > 0 && items[i].H >= 0 && items[i].W >= 0,
                    "conv_pack_weights_multi: bad shape (layer %d)", i);
   }
-  if (dtype == SPCL_F32) pack_multi_t<float>(items, n, (hipStream_t)stream, image, N, H, W, acorr);
-  else if (dtype == SPCL_BF16) pack_multi_t<bf16_t>(items, n, (hipStream_t)stream, image, N, H, W, acorr);
+  if (dtype == SPCL_F32) pack_multi_t<float>(items, n, (hipStream_t)stream, image, N, H, W, acorr, zero, zero_bytes);
+  else if (dtype == SPCL_BF16) pack_multi_t<bf16_t>(items, n, (hipStream_t)stream, image, N, H, W, acorr, zero, zero_bytes);
   else {
     set_error("conv_pack_weights_multi: dtype %d", dtype);
     return SPCL_EINVAL;
@@ -657,15 +678,77 @@ extern "C" int spcl_conv_pack_weights_multi_acorr(const spcl_pack_item* items, i
   return SPCL_OK;
 }
 
+static BnAccFwd bn_acc_fwd_of(const spcl_bn_acc& b) {
+  return BnAccFwd{b.acc, b.gamma, b.beta, b.running_mean, b.running_var, b.num_batches_tracked, b.st, b.momentum, b.eps,
+                  b.count, b.C, b.CS, 1.0 / (double)b.count};
+}
+
+static int conv3x3_forward_impl(const void* x, int dtype, int N, int H, int W, int CinS, int CinK, int CoutS,
+                                const void* w_packed, int in_mode, const float* in_scale, const float* in_shift,
+                                void* y, float* stats, void* stream, const BnAccFwd* in_bn, long long* stats_acc);
+
 extern "C" int spcl_conv3x3_forward(const void* x, int dtype, int N, int H, int W, int CinS, int CinK, int CoutS,
                                     const void* w_packed, int in_mode, const float* in_scale, const float* in_shift,
                                     void* y, float* stats, void* stream) {
+  return conv3x3_forward_impl(x, dtype, N, H, W, CinS, CinK, CoutS, w_packed, in_mode, in_scale, in_shift, y, stats, stream,
+                              nullptr, nullptr);
+}
+
+// The forward convolution with its BatchNorm sums going through fixed-point accumulator blocks (bn_acc.hpp) on either side:
+//   in_bn != NULL:     the input is the RAW output of the previous convolution; relu(scale x + shift) of ITS BatchNorm is applied
+//                      by the loader with scale / shift derived from in_bn->acc in the prologue (no finalize launch); the first
+//                      workgroup writes in_bn->st and the running statistics.  in_bn == NULL: scale / shift from the arrays
+//                      in_scale / in_shift when given (spcl_conv3x3_forward's in_mode 1), else the input is read as it is.
+//   stats_acc != NULL: the output's sum x / sum x^2 are added to that block (zeroed by the caller) instead of per-tile rows.
+// bf16 layers the specialised 14-column kernels take, at most BN_ACC_MAX_TILES tiles: spcl_conv_bn_acc_supported says which.
+extern "C" int spcl_conv_bn_acc_supported(int dtype, int N, int H, int W, int CinK, int CoutS, int in_kind,
+                                          int with_stats_acc) {
+  // in_kind: 0 the input is read as it is, 1 its BatchNorm + ReLU from a block (in_bn), 2 from scale / shift arrays
+  if (dtype != SPCL_BF16 || N <= 0 || H <= 0 || W <= 0 || CinK <= 0 || CoutS <= 0 || CinK % 16 || CoutS % 16) return 0;
+  if (!(CinK <= 64 || CinK % 64 == 0) || (in_kind != 1 && !with_stats_acc) || in_kind < 0 || in_kind > 2) return 0;
+  if (conv_use_gemm(CinK, CoutS, H, W)) return 0;
+  ConvArgs a;
+  a.x = nullptr; a.y = nullptr; a.wp = nullptr; a.stats = nullptr; a.in_scale = a.in_shift = nullptr;
+  a.N = N; a.H = H; a.W = W; a.CinS = CinK; a.CinK = CinK; a.CoutS = CoutS; a.in_mode = in_kind != 0 ? 1 : 0;
+  a.tilesX = a.tilesY = 0; a.tpw = 1; a.dbg = 0;
+  BnAccFwd b{};
+  long long dummy;
+  b.acc = &dummy; b.CS = CinK; b.C = CinK;
+  if (in_kind == 1) a.in_bn = &b;
+  if (with_stats_acc) a.stats_acc = &dummy;
+  const TileCfg t = pick_tile_k(H, W, CinK, CoutS);
+  return (t.tw == 14 && launch_conv_fast(a, t.th, nullptr, true)) ? 1 : 0;
+}
+
+extern "C" size_t spcl_bn_acc_elems(int CS) { return CS > 0 ? bn_acc_words(CS) : 0; }
+
+extern "C" int spcl_conv3x3_forward_acc(const void* x, int dtype, int N, int H, int W, int CinK, int CoutS,
+                                        const void* w_packed, const spcl_bn_acc* in_bn, const float* in_scale,
+                                        const float* in_shift, void* y, long long* stats_acc, float* stats_rows,
+                                        void* stream) {
+  SPCL_CHECK_ARG(in_bn != nullptr || stats_acc != nullptr, "conv3x3_forward_acc: neither side uses an accumulator block");
+  SPCL_CHECK_ARG(!(stats_acc != nullptr && stats_rows != nullptr), "conv3x3_forward_acc: statistics either as a block or as rows");
+  SPCL_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr) && !(in_bn != nullptr && in_scale != nullptr),
+                 "conv3x3_forward_acc: the input's coefficients either from a block or from scale / shift arrays");
+  BnAccFwd b{};
+  if (in_bn != nullptr) {
+    SPCL_CHECK_ARG(in_bn->acc && in_bn->gamma && in_bn->beta && in_bn->st && in_bn->count >= 1.f && in_bn->C > 0 &&
+                   in_bn->C <= in_bn->CS && in_bn->CS == CinK, "conv3x3_forward_acc: bad in_bn (CS must equal CinK)");
+    b = bn_acc_fwd_of(*in_bn);
+  }
+  return conv3x3_forward_impl(x, dtype, N, H, W, CinK, CinK, CoutS, w_packed, (in_bn != nullptr || in_scale != nullptr) ? 1 : 0,
+                              in_scale, in_shift, y, stats_rows, stream, in_bn != nullptr ? &b : nullptr, stats_acc);
+}
+
+static int conv3x3_forward_impl(const void* x, int dtype, int N, int H, int W, int CinS, int CinK, int CoutS,
+                                const void* w_packed, int in_mode, const float* in_scale, const float* in_shift,
+                                void* y, float* stats, void* stream, const BnAccFwd* in_bn, long long* stats_acc) {
   SPCL_CHECK_ARG(x && y && w_packed, "conv3x3_forward: null pointer");
   SPCL_CHECK_ARG(N > 0 && H > 0 && W > 0, "conv3x3_forward: bad shape");
   SPCL_CHECK_ARG(CinK % 16 == 0 && CoutS % 16 == 0 && CinK > 0 && CoutS > 0, "conv3x3_forward: CinK=%d CoutS=%d must "
                  "be multiples of 16", CinK, CoutS);
   SPCL_CHECK_ARG(in_mode >= 0 && in_mode <= 2, "conv3x3_forward: in_mode %d", in_mode);
-  SPCL_CHECK_ARG(in_mode != 1 || (in_scale && in_shift), "conv3x3_forward: in_mode 1 needs scale/shift");
+  SPCL_CHECK_ARG(in_mode != 1 || (in_scale && in_shift) || in_bn != nullptr, "conv3x3_forward: in_mode 1 needs scale/shift");
   if (in_mode == 2) SPCL_CHECK_ARG(CinK == 16 && CinS >= 1 && CinS <= 16, "conv3x3_forward: image mode needs Cin<=16");
   else SPCL_CHECK_ARG(CinS == CinK, "conv3x3_forward: CinS (%d) must equal CinK (%d)", CinS, CinK);
   SPCL_CHECK_ARG(CinK <= 64 || CinK % 64 == 0, "conv3x3_forward: CinK=%d must be <=64 or a multiple of 64", CinK);
@@ -675,7 +758,17 @@ extern "C" int spcl_conv3x3_forward(const void* x, int dtype, int N, int H, int 
   a.tilesX = a.tilesY = 0;
   a.tpw = 1;
   a.dbg = 0;
+  a.in_bn = in_bn;
+  a.stats_acc = stats_acc;
   hipStream_t st = (hipStream_t)stream;
+  if (in_bn != nullptr || stats_acc != nullptr) {  // only the specialised kernels know the blocks: never a silent fallback
+    const TileCfg t = pick_tile_k(H, W, CinK, CoutS);
+    if (dtype != SPCL_BF16 || conv_use_gemm(CinK, CoutS, H, W) || t.tw != 14 || !launch_conv_fast(a, t.th, st, true)) {
+      set_error("conv3x3_forward_acc: no kernel with accumulator blocks for N=%d H=%d W=%d CinK=%d CoutS=%d (ask "
+                "spcl_conv_bn_acc_supported)", N, H, W, CinK, CoutS);
+      return SPCL_EUNSUPPORTED;
+    }
+  }
   {  // algorithmic cost of the launch: x once, y once, the packed weights once
     const double px = (double)N * H * W, es = dtype == SPCL_F32 ? 4.0 : 2.0;
     const double cin = in_mode == 2 ? CinS : CinK;
@@ -956,17 +1049,53 @@ extern "C" int spcl_conv_dgrad_bnstats_supported(int dtype, int N, int H, int W,
   return (t.tw == 14 && launch_conv_fast(a, t.th, nullptr, true)) ? 1 : 0;
 }
 
+static int dgrad_bnstats_impl(const void* dy, int dtype, int N, int H, int W, int CinK, int CoutS, const void* w_packed, void* g,
+                              const void* y2, const float* scale2, const float* shift2, const float* mean2, float* rows2,
+                              long long* acc, void* stream);
+
 extern "C" int spcl_conv3x3_dgrad_bnstats(const void* dy, int dtype, int N, int H, int W, int CinK, int CoutS,
                                           const void* w_packed, void* g, const void* y2, const float* scale2,
                                           const float* shift2, const float* mean2, float* rows2, void* stream) {
-  SPCL_CHECK_ARG(dy && w_packed && g && y2 && scale2 && shift2 && mean2 && rows2, "conv3x3_dgrad_bnstats: null pointer");
+  SPCL_CHECK_ARG(rows2, "conv3x3_dgrad_bnstats: null pointer");
+  return dgrad_bnstats_impl(dy, dtype, N, H, W, CinK, CoutS, w_packed, g, y2, scale2, shift2, mean2, rows2, nullptr, stream);
+}
+
+// ... with the sums ADDED to a fixed-point accumulator block (bn_acc.hpp; spcl_bn_acc_elems(CoutS) words, zeroed by the caller)
+// instead of written as per-tile rows: the BatchNorm-backward apply pass derives its coefficients from the block in its
+// prologue (spcl_bnrelu_backward_acc), no reduction / finalize launch in between.  Specialised per-wave kernels only.
+extern "C" int spcl_conv_dgrad_bnstats_acc_supported(int dtype, int N, int H, int W, int CinK, int CoutS) {
   ConvArgs a;
-  if (!dgrad_bnstats_args(a, dtype, N, H, W, CinK, CoutS)) {
+  if (!spcl_conv_dgrad_bnstats_supported(dtype, N, H, W, CinK, CoutS) || conv_use_gemm(CinK, CoutS, H, W)) return 0;
+  if (!dgrad_bnstats_args(a, dtype, N, H, W, CinK, CoutS)) return 0;
+  a.x = nullptr; a.y = nullptr; a.wp = nullptr;
+  float dummy;
+  long long dummy2;
+  a.rows2 = &dummy;
+  a.rows2_acc = &dummy2;
+  TileCfg t = pick_tile(H, W);
+  return (t.tw == 14 && launch_conv_fast(a, t.th, nullptr, true)) ? 1 : 0;
+}
+
+extern "C" int spcl_conv3x3_dgrad_bnstats_acc(const void* dy, int dtype, int N, int H, int W, int CinK, int CoutS,
+                                              const void* w_packed, void* g, const void* y2, const float* scale2,
+                                              const float* shift2, const float* mean2, long long* acc, void* stream) {
+  SPCL_CHECK_ARG(acc, "conv3x3_dgrad_bnstats_acc: null pointer");
+  return dgrad_bnstats_impl(dy, dtype, N, H, W, CinK, CoutS, w_packed, g, y2, scale2, shift2, mean2, nullptr, acc, stream);
+}
+
+static int dgrad_bnstats_impl(const void* dy, int dtype, int N, int H, int W, int CinK, int CoutS, const void* w_packed, void* g,
+                              const void* y2, const float* scale2, const float* shift2, const float* mean2, float* rows2,
+                              long long* acc, void* stream) {
+  SPCL_CHECK_ARG(dy && w_packed && g && y2 && scale2 && shift2 && mean2, "conv3x3_dgrad_bnstats: null pointer");
+  ConvArgs a;
+  if (!dgrad_bnstats_args(a, dtype, N, H, W, CinK, CoutS) || (acc != nullptr && conv_use_gemm(CinK, CoutS, H, W))) {
     set_error("conv3x3_dgrad_bnstats: unsupported configuration");
     return SPCL_EUNSUPPORTED;
   }
   a.x = dy; a.y = g; a.wp = w_packed;
-  a.y2 = y2; a.scale2 = scale2; a.shift2 = shift2; a.mean2 = mean2; a.rows2 = rows2;
+  a.y2 = y2; a.scale2 = scale2; a.shift2 = shift2; a.mean2 = mean2;
+  a.rows2 = acc != nullptr ? (float*)acc : rows2;  // (with a block: only the mode marker, never written)
+  a.rows2_acc = acc;
   hipStream_t st = (hipStream_t)stream;
   const double px = (double)N * H * W;
   prof_cost(px * (CinK + 2.0 * CoutS) * 2.0 + 9.0 * CinK * CoutS * 2.0, 2.0 * px * 9.0 * CinK * CoutS);
@@ -1044,11 +1173,47 @@ extern "C" int spcl_conv_dgrad_poolstats_supported(int dtype, int N, int H, int 
   return (t.tw == 14 && launch_conv_fast(a, t.th, nullptr, true)) ? 1 : 0;
 }
 
+static int dgrad_poolstats_impl(const void* dy, int dtype, int N, int H, int W, int CinK, int CoutS, const void* w_packed,
+                                void* g, const void* y2, int H2, int W2, const float* scale2, const float* shift2,
+                                const float* mean2, float* rows2, long long* acc, void* stream);
+
 extern "C" int spcl_conv3x3_dgrad_poolstats(const void* dy, int dtype, int N, int H, int W, int CinK, int CoutS,
                                             const void* w_packed, void* g, const void* y2, int H2, int W2,
                                             const float* scale2, const float* shift2, const float* mean2, float* rows2,
                                             void* stream) {
-  SPCL_CHECK_ARG(dy && w_packed && g && y2 && scale2 && shift2 && mean2 && rows2, "conv3x3_dgrad_poolstats: null pointer");
+  SPCL_CHECK_ARG(rows2, "conv3x3_dgrad_poolstats: null pointer");
+  return dgrad_poolstats_impl(dy, dtype, N, H, W, CinK, CoutS, w_packed, g, y2, H2, W2, scale2, shift2, mean2, rows2, nullptr,
+                              stream);
+}
+
+// ... with the sums added to a fixed-point accumulator block (see spcl_conv3x3_dgrad_bnstats_acc)
+extern "C" int spcl_conv_dgrad_poolstats_acc_supported(int dtype, int N, int H, int W, int CinK, int CoutS, int H2, int W2) {
+  ConvArgs a;
+  if (!spcl_conv_dgrad_poolstats_supported(dtype, N, H, W, CinK, CoutS, H2, W2)) return 0;
+  if (!dgrad_bnstats_args(a, dtype, N, H, W, CinK, CoutS)) return 0;
+  a.x = nullptr; a.y = nullptr; a.wp = nullptr;
+  float dummy;
+  long long dummy2;
+  a.rows2 = &dummy;
+  a.rows2_acc = &dummy2;
+  a.H2 = H2; a.W2 = W2;
+  TileCfg t = pick_tile(H, W);
+  return (t.tw == 14 && launch_conv_fast(a, t.th, nullptr, true)) ? 1 : 0;
+}
+
+extern "C" int spcl_conv3x3_dgrad_poolstats_acc(const void* dy, int dtype, int N, int H, int W, int CinK, int CoutS,
+                                                const void* w_packed, void* g, const void* y2, int H2, int W2,
+                                                const float* scale2, const float* shift2, const float* mean2,
+                                                long long* acc, void* stream) {
+  SPCL_CHECK_ARG(acc, "conv3x3_dgrad_poolstats_acc: null pointer");
+  return dgrad_poolstats_impl(dy, dtype, N, H, W, CinK, CoutS, w_packed, g, y2, H2, W2, scale2, shift2, mean2, nullptr, acc,
+                              stream);
+}
+
+static int dgrad_poolstats_impl(const void* dy, int dtype, int N, int H, int W, int CinK, int CoutS, const void* w_packed,
+                                void* g, const void* y2, int H2, int W2, const float* scale2, const float* shift2,
+                                const float* mean2, float* rows2, long long* acc, void* stream) {
+  SPCL_CHECK_ARG(dy && w_packed && g && y2 && scale2 && shift2 && mean2, "conv3x3_dgrad_poolstats: null pointer");
   ConvArgs a;
   if (H != H2 / 2 || W != W2 / 2 || !dgrad_bnstats_args(a, dtype, N, H, W, CinK, CoutS) ||
       conv_use_gemm(CinK, CoutS, H, W)) {
@@ -1056,7 +1221,9 @@ extern "C" int spcl_conv3x3_dgrad_poolstats(const void* dy, int dtype, int N, in
     return SPCL_EUNSUPPORTED;
   }
   a.x = dy; a.y = g; a.wp = w_packed;
-  a.y2 = y2; a.scale2 = scale2; a.shift2 = shift2; a.mean2 = mean2; a.rows2 = rows2;
+  a.y2 = y2; a.scale2 = scale2; a.shift2 = shift2; a.mean2 = mean2;
+  a.rows2 = acc != nullptr ? (float*)acc : rows2;  // (with a block: only the mode marker, never written)
+  a.rows2_acc = acc;
   a.H2 = H2; a.W2 = W2;
   hipStream_t st = (hipStream_t)stream;
   const double px = (double)N * H * W;

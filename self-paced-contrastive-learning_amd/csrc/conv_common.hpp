@@ -4,6 +4,7 @@
 
 namespace spcl {
 
+struct BnAccFwd;
 template <typename T> struct Chunk;
 template <> struct Chunk<float> { static constexpr int EPC = 4; };
 template <> struct Chunk<bf16_t> { static constexpr int EPC = 8; };
@@ -62,6 +63,11 @@ struct ConvArgs {
   // tile ([N * tiles][64]: 45 + 9 sums over the tile's pixels, the layout of image_autocorr_kernel's band rows) -- fast
   // path only, image sizes that are multiples of the 14 x 14 tile
   float* acorr_rows = nullptr;
+  // BatchNorm sums through fixed-point accumulator blocks (bn_acc.hpp; fast path only -- a launch that carries one of these
+  // and finds no specialised kernel FAILS, it never falls back to a kernel that would ignore them):
+  long long* stats_acc = nullptr;        // the output's statistics are added here instead of written as per-tile `stats` rows
+  long long* rows2_acc = nullptr;        // the dgrad's BatchNorm-backward sums are added here instead of written as `rows2`
+  const struct BnAccFwd* in_bn = nullptr;  // in_mode 1: scale / shift derived from this block in the prologue (HOST pointer)
 };
 
 template <typename T> __device__ __forceinline__ f32x4 mfma_chunk(u32x4 w, u32x4 x, f32x4 acc);

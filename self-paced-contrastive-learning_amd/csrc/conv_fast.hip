@@ -10,6 +10,7 @@
 // On the 16->16 layer at 224^2 this is 47 us against 80 us for the generic kernel (pure copy of the same tiles: 42).
 #include <stdlib.h>
 #include <vector>
+#include "bn_acc.hpp"
 #include "conv_common.hpp"
 
 namespace spcl {
@@ -41,6 +42,11 @@ struct FastArgs {
   // A and B terms need no pass over the activations, bn.hip image3)
   const float* img2;
   float* acorr_rows;  // conv3x3_image_kernel<.., ACORR = true>: [tile][64] autocorrelation partial rows of the image (ConvArgs::acorr_rows)
+  // BatchNorm sums as fixed-point accumulator blocks (bn_acc.hpp) instead of per-tile rows + a reduction launch:
+  long long* stats_acc;  // non-null: the output's sum x, sum x^2 are ADDED here (`stats` is then ignored)
+  long long* rows2_acc;  // non-null (MODE 2 / 3): sum dz, sum dz (y2 - mean) are ADDED here (`rows2` is then only a mode marker)
+  BnAccFwd in_bn;        // in_bn.acc non-null (MODE 5 .. 7): scale / shift of the input's BatchNorm are DERIVED from that block in
+                         // the prologue (in_scale / in_shift unused); the launch's first workgroup writes in_bn.st and the running statistics
 };
 
 // waves per SIMD the register allocator must leave room for: what the tile's LDS footprint allows anyway, at most 4
@@ -167,6 +173,12 @@ conv3x3_fast_kernel(FastArgs a) {
   const int gps = (KC < 64 ? KC : a.CinK) * 2;  // bytes per pixel of x
 
   constexpr bool M2 = MODE == 2 || MODE == 4;  // BN-backward sums of the layer whose activation gradient this is
+  // MODE 5 / 6 / 7 = MODE 1 (relu(scale x + shift) of the input's BatchNorm in the loader) with scale / shift DERIVED in the
+  // prologue from a fixed-point accumulator block (bn_acc.hpp), the block's eight replicas of a channel split over 4 / 2 / 1
+  // threads (= workgroup threads / input channels).  Instantiations of their own: the prologue's registers (2 / 4 / 8 replicas
+  // x 32 bytes in flight per thread) are allocated for the form present, and must not weigh on the block 1 / 2 kernels at all
+  constexpr bool M1 = MODE == 1 || MODE >= 5;
+  constexpr int ACC_TPC = MODE == 5 ? 4 : (MODE == 6 ? 2 : 1);
   // MODE 4: the lane's four pixels of the 16 x 16 image halo (row lane / 4, columns 4 (lane % 4) ..), zero outside the
   // image; parked in registers across the k-loop, written to LDS when the activation halo is no longer needed
   float imgv[MODE == 4 ? 4 : 1];
@@ -241,8 +253,25 @@ conv3x3_fast_kernel(FastArgs a) {
   constexpr bool STREAM_W = PRELOAD_SLAB && KC == 64;  // (the only shape with more than one slab)
   constexpr int WR = STREAM_W ? (NT == 1 ? SPCL_FAST_WR_NT1 : 9) : (PRELOAD_SLAB ? NSTEPS : 1);
   u32x4 wsl[WR][NT];
-  auto issue_halo = [&](int slab) {
-    if (MODE == 1) {
+  // MODE 5 .. 7: thread (part, c) turns its share of channel c's replicas into partial integer sums -- its loads are the FIRST
+  // of the workgroup, so they return first and the arithmetic runs under the halo's flight -- the parts meet in LDS, thread c
+  // derives scale / shift and parks them in LDS behind the halo image(s); every thread then takes its chunk's eight from there
+  // (slab 0: after the barrier below; later slabs: plain LDS reads).  The first workgroup of the launch also writes mean /
+  // invstd / scale / shift and the running statistics (what the finalize launch used to leave for backward / eval).
+  constexpr bool acc_in = MODE >= 5;
+  float* const coef_l = (float*)(lds + fast_lds_bytes(KC, TH) * (a.lds_flip != 0 ? 2 : 1));  // [2][CinK]
+  auto load_coef_lds = [&](int slab) {
+    const int cc = two_chunks ? ch1 : ch;
+#pragma unroll
+    for (int e = 0; e < 8; e += 4) {
+      *(f32x4*)&ssc[e] = *(const f32x4*)(coef_l + slab * KC + cc * 8 + e);
+      *(f32x4*)&ssh[e] = *(const f32x4*)(coef_l + a.CinK + slab * KC + cc * 8 + e);
+    }
+  };
+  auto issue_halo = [&](int slab, const bool first = false) {
+    if (acc_in) {
+      if (!first) load_coef_lds(slab);
+    } else if (M1) {
 #pragma unroll
       for (int e = 0; e < 8; e += 4) {
         // (two tensors, one slab: the coefficients belong to the SECOND tensor's channels -- x is an activation already, x2
@@ -284,7 +313,7 @@ conv3x3_fast_kernel(FastArgs a) {
       const int dkx = QS >= HW_ ? 0 : (k % (HW_ / QS)) * QS;
       const bool in_range = (NCH % NTHR == 0) || (k * NTHR + t < NCH);
       u32x4 tv = v[k];
-      if (MODE == 1) {
+      if (M1) {
         bool inb = true;  // zero padding applies to the ACTIVATION: outside pixels stay 0, not relu(shift)
         if (!interior) {
           const int gy = y0 - 1 + hy0 + dky, gx = x0 - 1 + hx0 + dkx;
@@ -365,12 +394,56 @@ conv3x3_fast_kernel(FastArgs a) {
       }
     }
   };
-  issue_halo(0);
+#ifndef SPCL_ACC_DBG
+#define SPCL_ACC_DBG 0  /* timing experiments only (wrong results): 1 no coefficient arithmetic, 2 no block loads either */
+#endif
+  const int acc_part = acc_in ? t / a.CinK : 0, acc_c = t - acc_part * a.CinK;  // (the launcher: CinK * ACC_TPC == threads)
+  constexpr int ACC_RPT = BN_ACC_REPLICAS / ACC_TPC > 0 ? BN_ACC_REPLICAS / ACC_TPC : 1;  // replicas per thread
+  const bool acc_has = acc_part * ACC_RPT < BN_ACC_REPLICAS;  // (fewer replicas than threads per channel: the others idle)
+  BnAccPart<ACC_RPT> accp;
+  BnAccFwdParams accprm;
+  if (acc_in && SPCL_ACC_DBG < 2) {
+    accp.load(a.in_bn.acc, a.CinK, acc_c, acc_has ? ACC_RPT * acc_part : 0);
+    accprm.load(a.in_bn, acc_c);
+  }
+  issue_halo(0, true);
   if (PRELOAD_SLAB) {
 #pragma unroll
     for (int s = 0; s < WR; ++s)
 #pragma unroll
       for (int j = 0; j < NT; ++j) wsl[s][j] = a.wp[((size_t)s * ntn + nt0 + j) * 64 + lane];
+  }
+  if (acc_in) {
+    const bool writer = (blockIdx.x | blockIdx.y | blockIdx.z) == 0;
+    BnAccSums sums{0, 0, 0, 0, 0};
+    if (SPCL_ACC_DBG < 2 && acc_has) sums = accp.sums();
+    if (SPCL_ACC_DBG < 2) sums.flag = accp.flag;
+    if (ACC_TPC > 1) {  // partial sums of the other threads of a channel, through LDS: [part - 1][channel][4]
+      long long* const part_l = (long long*)(coef_l + 2 * a.CinK);
+      if (acc_part > 0) {
+        long long* q = part_l + ((size_t)(acc_part - 1) * a.CinK + acc_c) * 4;
+        *(i64x2*)q = (i64x2){sums.h1, sums.l1};
+        *(i64x2*)(q + 2) = (i64x2){sums.h2, sums.l2};
+      }
+      __syncthreads();
+      if (acc_part == 0) {
+#pragma unroll
+        for (int k = 1; k < ACC_TPC; ++k) {
+          const long long* q = part_l + ((size_t)(k - 1) * a.CinK + acc_c) * 4;
+          const i64x2 u = *(const i64x2*)q, w = *(const i64x2*)(q + 2);
+          sums.h1 += u[0]; sums.l1 += u[1]; sums.h2 += w[0]; sums.l2 += w[1];
+        }
+      }
+    }
+    if (t < a.CinK) {
+      float sc_, sh_;
+      if (SPCL_ACC_DBG == 0) bn_acc_fwd_channel(a.in_bn, sums, accprm, t, sc_, sh_, writer);
+      else { sc_ = a.in_bn.gamma[t]; sh_ = a.in_bn.beta[t]; }
+      coef_l[t] = sc_;
+      coef_l[a.CinK + t] = sh_;
+    }
+    __syncthreads();
+    load_coef_lds(0);
   }
   if (MODE == 4) {
     // the image halo goes to LDS NOW, behind the activation halo (the launcher adds 1.5 KB), as the three bf16 copies
@@ -633,7 +706,20 @@ conv3x3_fast_kernel(FastArgs a) {
   }
   }
   constexpr int RS = MODE == 4 ? 11 : 2;  // rows per tile of rows2
-  if (M2 || MODE == 3) {
+  // (the replica of a fixed-point accumulator block this workgroup adds to: its index in dispatch order mod 8 = its XCD)
+  const int replica = (int)((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & (BN_ACC_REPLICAS - 1));
+  if ((MODE == 2 || MODE == 3) && a.rows2_acc != nullptr) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      f32x4 s1, s2;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s1[r] = row16_sum(ssum[j][r]);
+        s2[r] = row16_sum(ssq[j][r]);
+      }
+      bn_acc_add_row16(a.rows2_acc, a.CoutS, replica, (nt0 + j) * 16 + 4 * g, r16, s1, s2);
+    }
+  } else if (M2 || MODE == 3) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       f32x4 o;
@@ -663,6 +749,19 @@ conv3x3_fast_kernel(FastArgs a) {
       for (int ks = 0; ks < TH / 2; ++ks)
         D = mfma_chunk<bf16_t>(*(const u32x4*)(pa + ks * 64), *(const u32x4*)(pb + ks * 64), D);
       if (r16 < 9) *(f32x4*)(a.rows2 + ((size_t)tile * RS + 2 + r16) * a.CoutS + nt0 * 16 + 4 * g) = D;
+    }
+  } else if ((MODE == 0 || M1) && a.stats_acc != nullptr) {
+    // (forming the sums and issuing the adds BEFORE the output stores was measured too: no gain -- what the adds cost is their
+    // serialisation at the memory side, ~18 ns per add on one address, not their place in the epilogue)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      f32x4 s1, s2;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s1[r] = row16_sum(ssum[j][r]);
+        s2[r] = row16_sum(ssq[j][r]);
+      }
+      bn_acc_add_row16(a.stats_acc, a.CoutS, replica, (nt0 + j) * 16 + 4 * g, r16, s1, s2);
     }
   } else if (a.stats != nullptr) {
 #pragma unroll
@@ -870,7 +969,9 @@ static void launch_fast(const FastArgs& a, int mode, hipStream_t st) {
   const bool pipe = env_pipe && KC == 64 && a.CinK > KC;  // more than one slab: two halo images
   FastArgs b = a;
   b.lds_flip = pipe ? fast_lds_bytes(KC, TH) : 0;
-  const size_t lds = fast_lds_bytes(KC, TH) * (pipe ? 2 : 1) + (a.img2 != nullptr ? 1536 : 0);
+  const size_t lds = fast_lds_bytes(KC, TH) * (pipe ? 2 : 1) + (a.img2 != nullptr ? 1536 : 0) +
+                     (a.in_bn.acc != nullptr ? (size_t)a.CinK * 8 + (size_t)64 * NW * 32 : 0);  // (+ MODE 5 .. 7: the derived
+                                                                                          // scale / shift and the partial sums)
   dim3 grid(a.tilesX, a.tilesY, a.N * a.gy), block(64 * NW);
   static const bool env_stamps = SPCL_FAST_STAMPS_BUILD && getenv("SPCL_FAST_STAMPS") != nullptr;
   const size_t nwg = (size_t)grid.x * grid.y * grid.z;
@@ -882,6 +983,13 @@ static void launch_fast(const FastArgs& a, int mode, hipStream_t st) {
   if (a.img2 != nullptr) {
     if constexpr (KC == 16 && TH == 14 && NT == 1 && NW == 1)
       SPCL_LAUNCH((conv3x3_fast_kernel<KC, TH, NT, 4, NW>), grid, block, lds, st, b);
+  } else if (mode == 1 && a.in_bn.acc != nullptr) {
+    if constexpr (KC == 64) {  // (threads per input channel; launch_conv_fast has checked that it is 4, 2 or 1)
+      const int tpc = 64 * NW / a.CinK;
+      if (tpc == 4) SPCL_LAUNCH((conv3x3_fast_kernel<KC, TH, NT, 5, NW>), grid, block, lds, st, b);
+      else if (tpc == 2) SPCL_LAUNCH((conv3x3_fast_kernel<KC, TH, NT, 6, NW>), grid, block, lds, st, b);
+      else SPCL_LAUNCH((conv3x3_fast_kernel<KC, TH, NT, 7, NW>), grid, block, lds, st, b);
+    }
   } else if (mode == 1) SPCL_LAUNCH((conv3x3_fast_kernel<KC, TH, NT, 1, NW>), grid, block, lds, st, b);
   else if (a.rows2 != nullptr && a.H2 > 0) SPCL_LAUNCH((conv3x3_fast_kernel<KC, TH, NT, 3, NW>), grid, block, lds, st, b);
   else if (a.rows2 != nullptr) SPCL_LAUNCH((conv3x3_fast_kernel<KC, TH, NT, 2, NW>), grid, block, lds, st, b);
@@ -917,6 +1025,9 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
     static const int env_img_remap = getenv("SPCL_IMAGE_XCD_REMAP") ? atoi(getenv("SPCL_IMAGE_XCD_REMAP")) : 1;
     a.tilesX = cdiv(c.W, 14); a.tilesY = cdiv(c.H, 14); a.gy = 1; a.xcd_remap = env_img_remap; a.lds_flip = 0; a.stamps = nullptr;
     a.acorr_rows = c.acorr_rows;
+    a.stats_acc = a.rows2_acc = nullptr;
+    a.in_bn = BnAccFwd{};
+    if (c.stats_acc != nullptr || c.rows2_acc != nullptr || c.in_bn != nullptr) return false;  // (16 384 tiles: rows + reduction)
     if (c.acorr_rows != nullptr && !(c.H % 14 == 0 && c.W % 14 == 0)) return false;  // (whole tiles only)
     if (!dry) {
       if (c.acorr_rows != nullptr) SPCL_LAUNCH((conv3x3_image_kernel<14, true, true>), dim3(a.tilesX, a.tilesY, a.N), dim3(64), 0, st, a);
@@ -926,7 +1037,8 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
     return true;
   }
   if (c.CinS != c.CinK) return false;
-  if (launch_conv_stream(c, th, st, dry)) return true;
+  const bool wants_acc = c.stats_acc != nullptr || c.rows2_acc != nullptr || c.in_bn != nullptr;
+  if (!wants_acc && launch_conv_stream(c, th, st, dry)) return true;
   const int ntn = c.CoutS / 16, KC = conv_kc(c.CinK);
   static const int env_nt1 = getenv("SPCL_CONV_FAST_NT1") ? atoi(getenv("SPCL_CONV_FAST_NT1")) : 0;
   int NT = ntn >= 2 ? 2 : 1;
@@ -991,6 +1103,21 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
   a.H2 = c.H2; a.W2 = c.W2;
   a.img2 = c.img2;
   a.acorr_rows = nullptr;
+  // fixed-point accumulator blocks (bn_acc.hpp): plain one-tensor-output launches with few enough tiles (same-address adds
+  // serialise at the memory side: ~18 ns each, tiles / 8 of them per address); the prologue form needs 4, 2 or 1 threads per
+  // input channel
+  a.stats_acc = c.stats_acc;
+  a.rows2_acc = c.rows2_acc;
+  a.in_bn = c.in_bn != nullptr ? *c.in_bn : BnAccFwd{};
+  if (wants_acc) {
+    const long tiles = (long)c.N * cdiv(c.W, 14) * cdiv(c.H, th);
+    if (c.y_hi != nullptr || c.img2 != nullptr) return false;
+    if (c.stats_acc != nullptr && (c.rows2 != nullptr || tiles > BN_ACC_MAX_TILES_FWD)) return false;
+    if (c.rows2_acc != nullptr && (c.rows2 == nullptr || tiles > BN_ACC_MAX_TILES_BWD)) return false;  // (rows2: the mode marker)
+    if (c.in_bn != nullptr && !(c.in_mode == 1 && KC == 64 && c.x2 == nullptr && c.in_bn->CS == c.CinK &&
+                                (c.CinK * 4 == 64 * nw || c.CinK * 2 == 64 * nw || c.CinK == 64 * nw)))
+      return false;  // (MODE 5 / 6 / 7 exist for the 64-channel-slab kernels: 4, 2 or 1 threads per input channel)
+  }
   if (c.rows2 != nullptr && c.in_mode != 0) return false;
   if (c.img2 != nullptr && !(c.rows2 != nullptr && c.H2 == 0 && KC == 16 && th == 14 && ntn == 1)) return false;
   a.N = c.N; a.H = c.H; a.W = c.W; a.CinK = c.CinK; a.CoutS = c.CoutS;

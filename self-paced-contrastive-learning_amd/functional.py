@@ -570,10 +570,13 @@ class PoolLink:
     epilogue of its own input-gradient kernel (spcl_conv3x3_dgrad_poolstats): this block's raw second-conv output and BN
     coefficients.  The next block fills ``rows`` / ``dx_ptr``; this block's backward uses them if the pooled gradient it
     receives IS that kernel's output (same storage: nothing else contributed to it), else runs its own reduction pass."""
-    __slots__ = ("yb", "stb", "N", "H", "W", "cout_s", "rows", "dx_ptr", "holder", "version")
+    __slots__ = ("yb", "stb", "N", "H", "W", "cout_s", "rows", "dx_ptr", "holder", "version", "acc")
 
-    def __init__(self, yb, stb, N, H, W, cout_s):
+    def __init__(self, yb, stb, N, H, W, cout_s, acc=None):
         self.yb, self.stb, self.N, self.H, self.W, self.cout_s = yb, stb, N, H, W, cout_s
+        # ``acc``: a zeroed fixed-point accumulator block (bn_acc_block) the next block's dgrad may ADD the sums to instead of
+        # writing per-tile rows; ``rows`` is then ``ACC_ROWS`` and the apply pass derives its coefficients from the block
+        self.acc = acc
         # ``holder``: the gradient tensor ``dx_ptr`` is the address of, kept alive until the consumer has compared -- a freed
         # tensor's address is the first thing the allocator hands out again (to the re-layout copy of a foreign gradient, say)
         self.rows, self.dx_ptr, self.holder, self.version = None, 0, None, 0
@@ -720,14 +723,18 @@ def prepack_weights(layers, dtype, image=None):
         arr = (_n.PackItem * len(items))(*items)
         if image is not None and i == 0 and _acorr_in_conv_rows(dtc, *[int(v) for v in image.shape[:3]]) > 0:
             image = None  # (the image convolution leaves the autocorrelation rows itself: _conv_image_acorr)
+        # (the pass's BatchNorm accumulator arena is zeroed by this launch -- the first of the pass -- instead of a fill launch)
+        zero = _acc_arena_take_dirty(dev) if i == 0 else None
+        zbytes = ctypes.c_size_t(zero.numel() * 8 if zero is not None else 0)
         if image is not None and i == 0:
             N, H, W = int(image.shape[0]), int(image.shape[1]), int(image.shape[2])
             acorr = torch.empty(_n.call("spcl_image_autocorr_rows", N, H, W), 64, dtype=torch.float32, device=dev)
-            _n.call("spcl_conv_pack_weights_multi_acorr", arr, len(items), dtc, _n.ptr(image), N, H, W, _n.ptr(acorr),
-                    _n.stream())
+            _n.call("spcl_conv_pack_weights_multi_zero", arr, len(items), dtc, _n.ptr(image), N, H, W, _n.ptr(acorr),
+                    _n.ptr(zero), zbytes, _n.stream())
             _PREPACKED_ACORR[(image.data_ptr(), image._version)] = acorr
         else:
-            _n.call("spcl_conv_pack_weights_multi", arr, len(items), dtc, _n.stream())
+            _n.call("spcl_conv_pack_weights_multi_zero", arr, len(items), dtc, None, 0, 0, 0, None, _n.ptr(zero), zbytes,
+                    _n.stream())
 
 
 def _acorr_in_conv_rows(dt_code, N, H, W, cin=1, cout_s=16):
@@ -783,6 +790,77 @@ def _conv_cat(xa, xb, dt_code, dtype, N, H, W, chalf, cout_s, wp, want_stats, xb
     _n.call("spcl_conv3x3_forward_cat", _n.ptr(xa), _n.ptr(xb), dt_code, N, H, W, chalf, cout_s, _n.ptr(wp),
             _n.ptr(xb_scale), _n.ptr(xb_shift), _n.ptr(y), _n.ptr(stats), _n.stream())
     return y, stats
+
+
+# ---- BatchNorm sums as fixed-point accumulator blocks (csrc/bn_acc.hpp): the producing kernel's epilogue ADDS its tile's sums
+# (exact integer atomics: order-free, bit-for-bit deterministic), the next launch derives the coefficients in its prologue -- no
+# finalize launch between them.  A block must be ZERO before its producer runs: all blocks of a forward pass (and of the
+# backward that follows it) are slices of ONE zero-filled arena, i.e. one fill launch per step.
+_BN_ACC = os.environ.get("SPCL_BN_ACC", "1") != "0"  # A/B switch: 0 keeps the per-tile rows + finalize launches everywhere
+_ACC_ARENA = {"buf": None, "off": 0, "used": 0, "need": 0, "dirty": False}
+
+
+def bn_acc_arena_begin(device):
+    """a new forward pass starts (UNet.forward): an arena of what the previous pass used, zeroed by the pass's weight-pack
+    launch (``prepack_weights``) or, failing that, by a fill of its own at the first block taken; blocks beyond it (the first
+    pass, a changed shape) come from on-demand zero-filled chunks"""
+    a = _ACC_ARENA
+    a["need"], a["used"], a["off"] = a["used"], 0, 0
+    a["buf"] = torch.empty(a["need"], dtype=torch.int64, device=device) if (a["need"] > 0 and _BN_ACC) else None
+    a["dirty"] = a["buf"] is not None
+
+
+def _acc_arena_take_dirty(device):
+    """the arena still to be zeroed, for a launch that can do it on its way (-> tensor or None); the caller MUST zero it"""
+    a = _ACC_ARENA
+    if a["dirty"] and a["buf"] is not None and a["buf"].device == device:
+        a["dirty"] = False
+        return a["buf"]
+    return None
+
+
+def bn_acc_block(cs, device):
+    """a zeroed accumulator block for a BatchNorm of ``cs`` (padded) channels -> int64 tensor [spcl_bn_acc_elems(cs)]"""
+    words = _n.call("spcl_bn_acc_elems", int(cs))
+    a = _ACC_ARENA
+    buf = a["buf"]
+    if buf is not None and a["dirty"]:  # nobody zeroed it on the way (no weight-pack launch in this pass)
+        buf.zero_()
+        a["dirty"] = False
+    if buf is None or buf.device != device or a["off"] + words > buf.numel():
+        buf = a["buf"] = torch.zeros(max(words, 1 << 15), dtype=torch.int64, device=device)
+        a["off"] = 0
+    blk = buf[a["off"]:a["off"] + words]
+    a["off"] += words
+    a["used"] += words
+    return blk
+
+
+def _bn_acc_desc(acc, cfg: "BlockCfg", C, cs, gamma, beta, which, count, st, keep):
+    """the ``spcl_bn_acc`` of one BatchNorm (native.BnAcc); ``keep`` collects the tensors its pointers borrow"""
+    g, b = gamma.detach().contiguous().float(), beta.detach().contiguous().float()
+    rm, rv, nbt = cfg.buffers[which]
+    upd = cfg.track[which]
+    keep.extend([g, b])
+    return _n.BnAcc(acc.data_ptr(), g.data_ptr(), b.data_ptr(), rm.data_ptr() if upd else None,
+                    rv.data_ptr() if upd else None, nbt.data_ptr() if (upd and nbt is not None) else None, st.data_ptr(),
+                    float(cfg.momentum), float(cfg.eps), float(count), int(C), int(cs))
+
+
+def _conv_acc(x_store, dt_code, dtype, N, H, W, cin_k, cout_s, wp, in_bn, in_scale, in_shift, stats_acc, want_rows):
+    """spcl_conv3x3_forward_acc: the input's BatchNorm + ReLU from a block (``in_bn``: native.BnAcc) or from scale / shift
+    arrays or none; the output's statistics into ``stats_acc`` or, ``want_rows``, per-tile rows -> (y, rows or None)"""
+    dev = x_store.device
+    y = torch.empty(N, H, W, cout_s, dtype=dtype, device=dev)
+    rows = None
+    if want_rows and stats_acc is None:
+        nt = _n.call("spcl_conv_stat_rows", dt_code, N, H, W, cin_k, cout_s)
+        rows = torch.empty(_n.call("spcl_bn_stats_elems", nt, cout_s), dtype=torch.float32, device=dev)
+        rows.ntiles = nt
+    _n.call("spcl_conv3x3_forward_acc", _n.ptr(x_store), dt_code, N, H, W, cin_k, cout_s, _n.ptr(wp),
+            ctypes.byref(in_bn) if in_bn is not None else None, _n.ptr(in_scale), _n.ptr(in_shift), _n.ptr(y),
+            _n.ptr(stats_acc), _n.ptr(rows), _n.stream())
+    return y, rows
 
 
 def _bn_stats(stats, cfg: BlockCfg, C, cs, gamma, beta, which, dev):
@@ -1188,6 +1266,39 @@ def _bnrelu_pool_bwd_rows(y, dpool, rows, dt_code, dtype, N, H, W, C, cs, st, tr
     return dy, dgamma, dbeta
 
 
+ACC_ROWS = object()  # ``PoolLink.rows`` / a dgrad's ``rows`` when the sums went into a fixed-point accumulator block instead
+
+
+def _take_acc(ctx, name):
+    """the backward accumulator block ``ctx.<name>`` -- ONCE: a block is zero only for the first backward after its forward
+    (a second backward through the same graph finds None and takes the rows + finalize path)"""
+    acc = getattr(ctx, name, None)
+    setattr(ctx, name, None)
+    return acc
+
+
+def _dgrad_bnstats_acc(dy, wp_t, y2, st2, dt_code, dtype, N, H, W, cin_k, cout_s, acc):
+    """``_dgrad_bnstats`` with the sums ADDED to the block ``acc`` (spcl_conv3x3_dgrad_bnstats_acc) -> g"""
+    g = torch.empty(N, H, W, cout_s, dtype=dtype, device=dy.device)
+    _n.call("spcl_conv3x3_dgrad_bnstats_acc", _n.ptr(dy), dt_code, N, H, W, cin_k, cout_s, _n.ptr(wp_t), _n.ptr(g), _n.ptr(y2),
+            _n.ptr(st2[2]), _n.ptr(st2[3]), _n.ptr(st2[0]), _n.ptr(acc), _n.stream())
+    return g
+
+
+def _bnrelu_bwd_acc(y, dact, dpool, dact_nc, dt_code, dtype, N, H, W, C, cs, st, training, sinks, acc):
+    """BN + ReLU (+ max-pool) backward's apply pass with its coefficients derived from the block ``acc``
+    (spcl_bnrelu_backward_acc): exactly one of dact / dpool (block already filled by the dgrad that produced the gradient) or
+    dact_nc [N, cs] (this call's reduction pass fills it) -> (dy, dgamma, dbeta)"""
+    dev = y.device
+    dgamma = _grad_buffer(sinks[0], (C,), dev)
+    dbeta = _grad_buffer(sinks[1], (C,), dev)
+    dy = torch.empty(N, H, W, cs, dtype=dtype, device=dev)
+    assert st.is_contiguous() and tuple(st.shape) == (4, cs)
+    _n.call("spcl_bnrelu_backward_acc", _n.ptr(y), _n.ptr(dact), _n.ptr(dpool), _n.ptr(dact_nc), dt_code, N, H, W, C, cs,
+            _n.ptr(st), int(training), _n.ptr(acc), _n.ptr(dgamma), _n.ptr(dbeta), _n.ptr(dy), _n.stream())
+    return dy, dgamma, dbeta
+
+
 class _ConvBlockFn(torch.autograd.Function):
     """[conv3x3 -> BN -> ReLU] x2 (+ 2x2 max-pool), semi_seg/arch/unet.py:67-82 + :118-121, as HIP kernels.
 
@@ -1243,19 +1354,56 @@ class _ConvBlockFn(torch.autograd.Function):
             (wpa, wpa_t), (wpb, wpb_t) = _pack_block(wa, wb, dtc, dtype, *((H, W) if _PACK_AT else (0, 0)))
         else:
             wpa, wpb, wpa_t, wpb_t = _pack(wa, 0, dtc, dtype), _pack(wb, 0, dtc, dtype), None, None
-        if x2s is not None:
-            ya, sa = _conv_cat(xs, x2s, dtc, dtype, N, H, W, chalf, cout_s, wpa, cfg.training, *ctx.x2_coef)
-        elif acorr_rows > 0:  # the image convolution leaves the autocorrelation rows of the image3 backward itself
-            ya, sa, ctx.acorr = _conv_image_acorr(xs, dtc, dtype, N, H, W, cin_s, cout_s, wpa, cfg.training, acorr_rows)
-        else:
-            ya, sa = _conv(xs, dtc, dtype, N, H, W, cin_s, cin_k, cout_s, wpa, mode_a, None, None, cfg.training)
-        sta = _bn_stats(sa, cfg, cout, cout_s, ga, ba, 0, dev)
-        yb, sb = _conv(ya, dtc, dtype, N, H, W, cout_s, cout_s, cout_s, wpb, 1, sta[2], sta[3], cfg.training)
-        stb = _bn_stats(sb, cfg, cout, cout_s, gb, bb, 1, dev)
         ctx.up2 = bool(getattr(cfg, "up2", False)) and cfg.need_act and not cfg.need_pool
         lazy = (bool(getattr(cfg, "lazy_act", False)) and cfg.need_act and not cfg.need_pool and not ctx.up2
                 and getattr(cfg, "act_dst", None) is None)
-        if lazy:
+        # BatchNorm sums through fixed-point accumulator blocks where the layer's kernels offer it (bf16, the specialised
+        # convolution kernels, few enough tiles: Conv3 .. Conv5 of the 224^2 step): no finalize launch on either BatchNorm
+        count = float(N) * H * W
+        acc_ok = _BN_ACC and cfg.training and dtype == torch.bfloat16 and cout_s <= 256 and cout == cout_s
+        sup = lambda ci, co, kind, out: bool(_n.call("spcl_conv_bn_acc_supported", dtc, N, H, W, ci, co, kind, out))  # noqa: E731
+        use_a = (acc_ok and x2s is None and acorr_rows == 0 and mode_a == 0 and sup(cin_k, cout_s, 0, 1)
+                 and sup(cout_s, cout_s, 1, 0))
+        use_b = (acc_ok and not lazy and not ctx.up2 and getattr(cfg, "act_dst", None) is None
+                 and sup(cout_s, cout_s, 1 if use_a else 2, 1))
+        keep = []
+        ctx.acc_bwd_a = ctx.acc_bwd_b = None
+        if use_a:
+            acc_a = bn_acc_block(cout_s, dev)
+            ya, _ = _conv_acc(xs, dtc, dtype, N, H, W, cin_k, cout_s, wpa, None, None, None, acc_a, False)
+            sta = torch.empty(4, cout_s, dtype=torch.float32, device=dev)  # written by the second convolution's first workgroup
+            bn_a = _bn_acc_desc(acc_a, cfg, cout, cout_s, ga, ba, 0, count, sta, keep)
+        else:
+            if x2s is not None:
+                ya, sa = _conv_cat(xs, x2s, dtc, dtype, N, H, W, chalf, cout_s, wpa, cfg.training, *ctx.x2_coef)
+            elif acorr_rows > 0:  # the image convolution leaves the autocorrelation rows of the image3 backward itself
+                ya, sa, ctx.acorr = _conv_image_acorr(xs, dtc, dtype, N, H, W, cin_s, cout_s, wpa, cfg.training, acorr_rows)
+            else:
+                ya, sa = _conv(xs, dtc, dtype, N, H, W, cin_s, cin_k, cout_s, wpa, mode_a, None, None, cfg.training)
+            sta = _bn_stats(sa, cfg, cout, cout_s, ga, ba, 0, dev)
+        if use_a or use_b:
+            acc_b = bn_acc_block(cout_s, dev) if use_b else None
+            yb, sb = _conv_acc(ya, dtc, dtype, N, H, W, cout_s, cout_s, wpb, bn_a if use_a else None,
+                               None if use_a else sta[2], None if use_a else sta[3], acc_b, cfg.training)
+        else:
+            yb, sb = _conv(ya, dtc, dtype, N, H, W, cout_s, cout_s, cout_s, wpb, 1, sta[2], sta[3], cfg.training)
+        if use_b:
+            stb = torch.empty(4, cout_s, dtype=torch.float32, device=dev)  # written by the activation writer's first workgroup
+            bn_b = _bn_acc_desc(acc_b, cfg, cout, cout_s, gb, bb, 1, count, stb, keep)
+        else:
+            stb = _bn_stats(sb, cfg, cout, cout_s, gb, bb, 1, dev)
+        if acc_ok and any(ctx.needs_input_grad):
+            # the backward's blocks are zeroed with the forward's (one fill per step): sum dz / sum dz (y - mean) of both
+            # BatchNorms, added by whichever kernel produces the incoming gradient
+            if not cfg.image_input and _n.call("spcl_conv_dgrad_bnstats_acc_supported", dtc, N, H, W, cout_s, cout_s):
+                ctx.acc_bwd_a = bn_acc_block(cout_s, dev)
+            ctx.acc_bwd_b = bn_acc_block(cout_s, dev)
+        if use_b:
+            act = torch.empty(N, H, W, cout_s, dtype=dtype, device=dev) if cfg.need_act else None
+            pool = torch.empty(N, H // 2, W // 2, cout_s, dtype=dtype, device=dev) if cfg.need_pool else None
+            _n.call("spcl_bnrelu_pool_forward_acc", _n.ptr(yb), dtc, N, H, W, cout_s, ctypes.byref(bn_b), _n.ptr(act),
+                    _n.ptr(pool), _n.stream())
+        elif lazy:
             # no activation tensor: the consumer (conv1x1_bn) reads yb and applies scale / shift / ReLU in its loader
             act, pool = yb, None
             cfg.link_act = ActLink(yb, stb, N, H, W, cout, cout_s)
@@ -1274,7 +1422,7 @@ class _ConvBlockFn(torch.autograd.Function):
         ctx.packed_t = (wpa_t, wpb_t)
         ctx.cfg = cfg
         if need_bwd and pool is not None and act is None and cfg.training and dtype == torch.bfloat16:
-            cfg.link_out = PoolLink(yb, stb, N, H, W, cout_s)  # the pooled output is this block's only product
+            cfg.link_out = PoolLink(yb, stb, N, H, W, cout_s, ctx.acc_bwd_b)  # the pooled output is this block's only product
         ctx.meta = (N, cin, H, W, cout, cout_s, cin_s, cin_k, mode_a, x.dtype)
         outs = []
         outs.append(nhwc_to_logical(act, cout) if act is not None else None)
@@ -1337,11 +1485,20 @@ class _ConvBlockFn(torch.autograd.Function):
                                              sk[4:6])
         elif g_nc is not None:
             # the block's output fed a global average pool only: its gradient is one value per (image, channel)
-            dyb, dgb, dbb = _bnrelu_bwd_bcast(yb, g_nc, dtc, dtype, N, H, W, cout, cout_s, stb, cfg.training, sk[4:6])
+            acc = _take_acc(ctx, "acc_bwd_b")
+            if acc is not None:  # (reduction pass adds into the block, the apply pass derives its coefficients: no finalize)
+                dyb, dgb, dbb = _bnrelu_bwd_acc(yb, None, None, g_nc, dtc, dtype, N, H, W, cout, cout_s, stb, cfg.training,
+                                                sk[4:6], acc)
+            else:
+                dyb, dgb, dbb = _bnrelu_bwd_bcast(yb, g_nc, dtc, dtype, N, H, W, cout, cout_s, stb, cfg.training, sk[4:6])
         elif lk is not None and da_s is None and dp_s is not None and lk.fresh(dp_s.data_ptr()):
             # the next block's input-gradient kernel left this BatchNorm's partial sums next to the gradient itself
-            dyb, dgb, dbb = _bnrelu_pool_bwd_rows(yb, dp_s, lk.rows, dtc, dtype, N, H, W, cout, cout_s, stb, cfg.training,
-                                                  sk[4:6])
+            if lk.rows is ACC_ROWS:  # ... in this block's accumulator block
+                dyb, dgb, dbb = _bnrelu_bwd_acc(yb, None, dp_s, None, dtc, dtype, N, H, W, cout, cout_s, stb, cfg.training,
+                                                sk[4:6], _take_acc(ctx, "acc_bwd_b"))
+            else:
+                dyb, dgb, dbb = _bnrelu_pool_bwd_rows(yb, dp_s, lk.rows, dtc, dtype, N, H, W, cout, cout_s, stb, cfg.training,
+                                                      sk[4:6])
         else:
             dyb, dgb, dbb = _bnrelu_bwd(yb, da_s, dp_s, dtc, dtype, N, H, W, cout, cout_s, stb, cfg.training, sk[4:6],
                                         dact_stride=da_stride, d_up=d_up)
@@ -1369,8 +1526,12 @@ class _ConvBlockFn(torch.autograd.Function):
         elif image3:
             fused = _dgrad_bnstats_image(dyb, wpb_t, ya, sta, xs, dtc, dtype, N, H, W, cout_s)
         else:
-            fused = _dgrad_bnstats(dyb, wpb_t, ya, sta, dtc, dtype, N, H, W, cout_s, cout_s) \
-                if dtype == torch.bfloat16 else None
+            acc = _take_acc(ctx, "acc_bwd_a")
+            if acc is not None:  # the sums go into the block, the apply pass below derives its coefficients from it
+                fused = (_dgrad_bnstats_acc(dyb, wpb_t, ya, sta, dtc, dtype, N, H, W, cout_s, cout_s, acc), (ACC_ROWS, acc))
+            else:
+                fused = _dgrad_bnstats(dyb, wpb_t, ya, sta, dtc, dtype, N, H, W, cout_s, cout_s) \
+                    if dtype == torch.bfloat16 else None
         if fused is not None:
             daa, rows = fused
         else:
@@ -1389,7 +1550,10 @@ class _ConvBlockFn(torch.autograd.Function):
                 dwa, dga, dba = _bnrelu_bwd_image_wgrad(ya, daa, xs, dtc, N, H, W, cout, cout_s, sta, cfg.training,
                                                         sk[0:3])
         else:
-            if fused is not None:
+            if fused is not None and isinstance(rows, tuple) and rows[0] is ACC_ROWS:
+                dya, dga, dba = _bnrelu_bwd_acc(ya, daa, None, None, dtc, dtype, N, H, W, cout, cout_s, sta, cfg.training,
+                                                sk[1:3], rows[1])
+            elif fused is not None:
                 dya, dga, dba = _bnrelu_bwd_rows(ya, daa, None, rows, dtc, dtype, N, H, W, cout, cout_s, sta,
                                                  cfg.training, sk[1:3])
             else:
@@ -1411,13 +1575,21 @@ class _ConvBlockFn(torch.autograd.Function):
             dxs = None
             if (li is not None and dtype == torch.bfloat16 and li.cout_s == cin_s and li.N == N
                     and _n.call("spcl_conv_dgrad_poolstats_supported", dtc, N, H, W, cout_s, cin_s, li.H, li.W)):
-                nt = _n.call("spcl_conv_stat_rows", dtc, N, H, W, cout_s, cin_s)
                 dxs = torch.empty(N, H, W, cin_s, dtype=dtype, device=dya.device)
-                rows = torch.empty(nt * 2 * cin_s, dtype=torch.float32, device=dya.device)
-                _n.call("spcl_conv3x3_dgrad_poolstats", _n.ptr(dya), dtc, N, H, W, cout_s, cin_s, _n.ptr(wpa_t),
-                        _n.ptr(dxs), _n.ptr(li.yb), li.H, li.W, _n.ptr(li.stb[2]), _n.ptr(li.stb[3]), _n.ptr(li.stb[0]),
-                        _n.ptr(rows), _n.stream())
-                rows.ntiles = nt
+                if (li.acc is not None and _n.call("spcl_conv_dgrad_poolstats_acc_supported", dtc, N, H, W, cout_s, cin_s,
+                                                   li.H, li.W)):
+                    # ... added to the producing block's accumulator block (zeroed with its forward): no rows, no finalize
+                    _n.call("spcl_conv3x3_dgrad_poolstats_acc", _n.ptr(dya), dtc, N, H, W, cout_s, cin_s, _n.ptr(wpa_t),
+                            _n.ptr(dxs), _n.ptr(li.yb), li.H, li.W, _n.ptr(li.stb[2]), _n.ptr(li.stb[3]), _n.ptr(li.stb[0]),
+                            _n.ptr(li.acc), _n.stream())
+                    rows = ACC_ROWS
+                else:
+                    nt = _n.call("spcl_conv_stat_rows", dtc, N, H, W, cout_s, cin_s)
+                    rows = torch.empty(nt * 2 * cin_s, dtype=torch.float32, device=dya.device)
+                    _n.call("spcl_conv3x3_dgrad_poolstats", _n.ptr(dya), dtc, N, H, W, cout_s, cin_s, _n.ptr(wpa_t),
+                            _n.ptr(dxs), _n.ptr(li.yb), li.H, li.W, _n.ptr(li.stb[2]), _n.ptr(li.stb[3]), _n.ptr(li.stb[0]),
+                            _n.ptr(rows), _n.stream())
+                    rows.ntiles = nt
                 li.rows, li.dx_ptr, li.holder, li.version = rows, dxs.data_ptr(), dxs, dxs._version
             split = None
             if (dxs is None and x2s is not None and _CONV_SPLIT

@@ -52,6 +52,7 @@ _SIGNATURES = {
     "spcl_conv_pack_weights_block_at": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, c_int, _P, _P, c_int, c_int, c_int, _P]),
     "spcl_conv_pack_weights_multi": (c_int, [_P, c_int, c_int, _P]),
     "spcl_conv_pack_weights_multi_acorr": (c_int, [_P, c_int, c_int, _P, c_int, c_int, c_int, _P, _P]),
+    "spcl_conv_pack_weights_multi_zero": (c_int, [_P, c_int, c_int, _P, c_int, c_int, c_int, _P, _P, c_size_t, _P]),
     "spcl_conv_num_tiles": (c_int, [c_int, c_int, c_int]),
     "spcl_conv_stat_rows": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "spcl_conv_set_gemm": (None, [c_int]),
@@ -157,6 +158,18 @@ _SIGNATURES = {
                                         c_int, _P, _P, _P, _P]),
     "spcl_radam_step_scaled": (c_int, [_P, _P, c_double, _P, _P, c_size_t, _P, _P, c_double, c_double, c_double, c_double,
                                        _P, c_int, _P, _P, _P, _P]),
+    # BatchNorm sums as fixed-point accumulator blocks (csrc/bn_acc.hpp)
+    "spcl_bn_acc_elems": (c_size_t, [c_int]),
+    "spcl_conv_bn_acc_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "spcl_conv3x3_forward_acc": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "spcl_bnrelu_pool_forward_acc": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "spcl_conv_dgrad_bnstats_acc_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "spcl_conv3x3_dgrad_bnstats_acc": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "spcl_conv_dgrad_poolstats_acc_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    "spcl_conv3x3_dgrad_poolstats_acc": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, _P,
+                                                 _P, _P, _P, _P]),
+    "spcl_bnrelu_backward_acc": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, _P, _P,
+                                         _P]),
 }
 
 
@@ -173,6 +186,13 @@ class PackItem(ctypes.Structure):
                 ("H", c_int), ("W", c_int)]
 
 
+class BnAcc(ctypes.Structure):
+    """``spcl_bn_acc`` of include/spcl_hip.h (a BatchNorm whose statistics travel as a fixed-point accumulator block)"""
+    _fields_ = [("acc", c_void_p), ("gamma", c_void_p), ("beta", c_void_p), ("running_mean", c_void_p),
+                ("running_var", c_void_p), ("num_batches_tracked", c_void_p), ("st", c_void_p), ("momentum", c_float),
+                ("eps", c_float), ("count", c_float), ("C", c_int), ("CS", c_int)]
+
+
 PACK_MULTI_MAX = 24
 
 
@@ -182,11 +202,12 @@ class WgradTail(ctypes.Structure):
                 ("nblk_co", c_int), ("CIB", c_int), ("COB", c_int), ("Cin", c_int), ("Cout", c_int)]
 
 
-ABI_VERSION = 3  # == SPCL_ABI_VERSION of include/spcl_hip.h (tests/test_abi.py compares them); lib() refuses any other library
+ABI_VERSION = 4  # == SPCL_ABI_VERSION of include/spcl_hip.h (tests/test_abi.py compares them); lib() refuses any other library
 WGRAD_BATCH_MAX = 16
 WGRAD_TAILS_MAX = 16
 _NO_STATUS = ("spcl_abi_version", "spcl_conv3x3_forward_image_acorr_rows", "spcl_image_autocorr_rows", "spcl_conv_dgrad_bnstats_image_supported", "spcl_conv16_bwd_fused_supported", "spcl_conv16_bwd_fused_splits", "spcl_conv_num_tiles", "spcl_conv_stat_rows", "spcl_conv_set_gemm", "spcl_supcon_unit_gradient_block", "spcl_conv_cat_supported", "spcl_conv_up2_supported", "spcl_conv_split_supported", "spcl_conv_split_bnstats_supported", "spcl_conv1x1_bwd_rows", "spcl_profile_count", "spcl_conv_dgrad_bnstats_supported", "spcl_conv_dgrad_poolstats_supported",
-              "spcl_conv_wgrad_batched_supported")
+              "spcl_conv_wgrad_batched_supported", "spcl_conv_bn_acc_supported", "spcl_conv_dgrad_bnstats_acc_supported",
+              "spcl_conv_dgrad_poolstats_acc_supported")
 
 
 class NativeLibraryError(RuntimeError):

@@ -237,6 +237,8 @@ class UNet(nn.Module):
                 raise KeyError(f"`return_until` should be in {', '.join(self.layer_dimension.keys())},"
                                f" given {until}  ")
         encoder_only = until in _ENCODER
+        if x.is_cuda:
+            F_hip.bn_acc_arena_begin(x.device)  # one zero fill for every BatchNorm accumulator block of this pass (and its backward)
         self._prepack(x, until)
         try:
             return self._forward_blocks(x, until, encoder_only)

@@ -793,7 +793,11 @@ def test_pool_link_ignores_a_gradient_it_did_not_produce():
         finally:
             F._n.call = real
         torch.cuda.synchronize()
-        return [q.grad.clone() for q in a.parameters()], "spcl_bnrelu_pool_backward_rows" in used
+        # the link was taken <=> block a did NOT run its own reduction pass over (y, pooled gradient): its sums came with the
+        # gradient, as per-tile rows (spcl_bnrelu_pool_backward_rows) or in its accumulator block (spcl_bnrelu_backward_acc)
+        taken = "spcl_bnrelu_pool_backward" not in used
+        assert not taken or "spcl_bnrelu_pool_backward_rows" in used or "spcl_conv3x3_dgrad_poolstats_acc" in used
+        return [q.grad.clone() for q in a.parameters()], taken
 
     (g1, rows1), (g0, rows0) = run(False, True), run(False, False)
     assert rows1 and not rows0  # the link is taken when the gradient is the producer's own ...

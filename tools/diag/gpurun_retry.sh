@@ -1,0 +1,10 @@
+#!/bin/bash
+# gpurun with retries while no box / slot is free (exit code 3, nothing charged): gpurun_retry.sh <timeout-seconds> '<command>'
+T=$1; shift
+for i in $(seq 30); do
+  /usr/local/graft/bin/gpurun --timeout $T -- "$@"
+  rc=$?
+  [ $rc -ne 3 ] && exit $rc
+  sleep 90
+done
+exit 3
