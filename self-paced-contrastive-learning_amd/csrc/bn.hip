@@ -1311,7 +1311,7 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
   if (acc != nullptr && !bcast) {
     nwg = 0;  // (the block is complete: nothing to reduce, nothing to finalize)
   } else if (rows != nullptr) {  // the partial sums came with the dgrad that produced dact (per conv tile, centred s2)
-    static const int fin_rows = getenv("SPCL_BWD_FIN_MAX_ROWS") ? atoi(getenv("SPCL_BWD_FIN_MAX_ROWS")) : BWD_MAX_WG;
+    static const int fin_rows = lab_env("SPCL_BWD_FIN_MAX_ROWS", BWD_MAX_WG);
     if (nrows <= fin_rows) {
       fin_src = rows;
       nwg = nrows;
@@ -1338,7 +1338,7 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
     // pixel splits per image: every workgroup leaves a row of 2 CS partial sums that bnrelu_bwd_fin_kernel walks one cache
     // line per lane -- one pass of 8 pixels per workgroup (25 splits of a 14 x 14 map: 1 600 rows) made that kernel 9.5 us
     // of the step; SPCL_BCAST_SPLIT_MAX splits -> N x that many rows
-    static const int env_split = getenv("SPCL_BCAST_SPLIT_MAX") ? atoi(getenv("SPCL_BCAST_SPLIT_MAX")) : 4;
+    static const int env_split = lab_env("SPCL_BCAST_SPLIT_MAX", 4);
     bsplit = (H * W + PL - 1) / PL;
     if (env_split > 0 && bsplit > env_split) bsplit = env_split;
     while (bsplit > 1 && N * bsplit > BWD_MAX_WG) bsplit = (bsplit + 1) / 2;
@@ -1384,7 +1384,7 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
     }
   } else if (img != nullptr) {  // first conv of a one-channel image block: dy is consumed in registers by its dW
     float* wpart = ab + 2 * CS;  // [IMG_WGRAD_WG][9][CS];  zrow = the image row above / below the image
-    static const int want = getenv("SPCL_IMGWG_WG") ? atoi(getenv("SPCL_IMGWG_WG")) : 1280;  // 5 resident per CU
+    static const int want = lab_env("SPCL_IMGWG_WG", 1280);  // 5 resident per CU
     const int cap = want < IMG_WGRAD_WG ? (want > 0 ? want : 1) : IMG_WGRAD_WG;
     const int g = N * H < cap ? N * H : cap;
     prof_cost(2.0 * tb + (double)npix * 4, 2.0 * 9 * npix * C);
@@ -1427,7 +1427,7 @@ using namespace spcl;
 constexpr int BN_TICKETS = 64;
 constexpr int BN_TICKET_STREAMS = 32;
 static unsigned* bn_tickets(hipStream_t st) {
-  static const bool on = !(getenv("SPCL_BN_ONE_LAUNCH") && atoi(getenv("SPCL_BN_ONE_LAUNCH")) == 0);
+  static const bool on = !(lab_env("SPCL_BN_ONE_LAUNCH", 1) == 0);
   if (!on) return nullptr;
   struct Slot { int dev; hipStream_t st; unsigned* buf; };
   static Slot slots[BN_TICKET_STREAMS];

@@ -33,11 +33,16 @@ constexpr double BN_ACC_HI = 1024.0, BN_ACC_HI_INV = 1.0 / 1024.0;
 constexpr double BN_ACC_LO = 1152921504606846976.0 /* 2^60 */, BN_ACC_LO_INV = 1.0 / 1152921504606846976.0;
 constexpr float BN_ACC_MAX = 1099511627776.0f;  // 2^40
 // Layers with more producer tiles than this keep the per-tile rows + reduction launch.  Same-address adds serialise at the
-// memory side: measured ~18 ns each (one replica for the 2 048 tiles of Conv3.a: 17 -> 53 us), i.e. tiles / 8 x 18 ns per
-// address spread over the launch.  Forward statistics of a 2 048-tile layer (Conv3 at N = 64, 224^2) cost their producers
-// + 2.8 / + 3 us and the consumer prologues + 4 / + 1 us: as much as the two reduction launches they replace -- not offered.
-// The dgrads' backward sums cost their producers + 0 .. 1.4 us at the same tile count (longer, more staggered epilogues).
-constexpr int BN_ACC_MAX_TILES_FWD = 1024;
+// memory side: measured ~18 ns each (ONE replica for the 2 048 tiles of Conv3.a: 17 -> 53 us; two: 33; four: 22.6; eight: 19),
+// i.e. tiles / 8 x 18 ns per address, spread over the launch.  At 2 048 tiles (Conv3 at N = 64, 224^2) the forward
+// statistics cost their producers + 2.8 / + 3 us and the consumer prologues + 4 / + 1 us -- what the two reduction launches
+// they replace cost (same-box A/B of the whole step with the limit at 1 024 and at 4 096: 1 045 vs 1 050 us, bench medians
+// 1 053 vs 1 055: equal) -- so the limit only decides the launch count there; the dgrads' backward sums cost their producers
+// + 0 .. 1.4 us at the same tile count (longer, more staggered epilogues).  Blocks 1 / 2 (8 192 / 16 384 tiles) stay on rows.
+#ifndef SPCL_ACC_FWD_TILES
+#define SPCL_ACC_FWD_TILES 4096
+#endif
+constexpr int BN_ACC_MAX_TILES_FWD = SPCL_ACC_FWD_TILES;
 constexpr int BN_ACC_MAX_TILES_BWD = 4096;
 
 __host__ __device__ inline size_t bn_acc_words(int CS) { return (size_t)BN_ACC_REPLICAS * CS * 4 + BN_ACC_FLAG_WORDS; }

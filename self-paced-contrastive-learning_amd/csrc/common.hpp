@@ -116,6 +116,15 @@ inline int lab_env(const char* name, int dflt) {
 #endif
 }
 
+inline bool lab_flag(const char* name) {  // "is the variable set at all" (the switches that are on by their mere presence)
+#if SPCL_LAB
+  return getenv(name) != nullptr;
+#else
+  (void)name;
+  return false;
+#endif
+}
+
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline int round_up(int a, int b) { return cdiv(a, b) * b; }
 

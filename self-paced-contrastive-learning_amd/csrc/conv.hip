@@ -403,15 +403,15 @@ static TileCfg pick_tile(int H, int W) {
   // (SPCL_CONV_T77_MAXH=14) beat 7x14 at 14^2 only in the generic kernel; the specialised one is 10-15 % faster on 7x14.
   // (Packing all layers' weights in one launch at the start of forward was measured too: 40 us per step SLOWER than
   // the per-layer pack right before each conv, which leaves the fragments hot in L2 for the waves that fetch them.)
-  static const int th7_max_h = getenv("SPCL_CONV_TH7_MAXH") ? atoi(getenv("SPCL_CONV_TH7_MAXH")) : 112;
-  static const int t77_max_h = getenv("SPCL_CONV_T77_MAXH") ? atoi(getenv("SPCL_CONV_T77_MAXH")) : 0;
+  static const int th7_max_h = lab_env("SPCL_CONV_TH7_MAXH", 112);
+  static const int t77_max_h = lab_env("SPCL_CONV_T77_MAXH", 0);
   if (H % 14 == 0 && W % 14 == 0 && H <= t77_max_h) return {7, 7};
   if (H % 14 == 0 && W % 14 == 0 && H <= th7_max_h) return {7, 14};
   if (H % 14 == 0 && W % 14 == 0) return {14, 14};
   // other sizes (256^2 Prostate slices, ...): still the 14-column tiles of the specialised kernels -- their last tile per
   // row / column is shifted back inside the image -- as long as the recomputed overlap stays below a quarter
   const int th = H <= (th7_max_h > 128 ? th7_max_h : 128) ? 7 : 14;  // 128^2 (the 256^2 family's second level) like 112^2
-  static const int max_overlap = getenv("SPCL_CONV_OVERLAP_PCT") ? atoi(getenv("SPCL_CONV_OVERLAP_PCT")) : 25;
+  static const int max_overlap = lab_env("SPCL_CONV_OVERLAP_PCT", 25);
   if (H >= th && W >= 14 && (long)cdiv(H, th) * th * cdiv(W, 14) * 14 * 100 <= (long)H * W * (100 + max_overlap))
     return {th, 14};
   return {16, 16};
@@ -423,7 +423,7 @@ static TileCfg pick_tile(int H, int W) {
 // SPCL_CONV_TH7_KC32=0 switches back).  The 16-channel layers' image is 8 KB: they keep the 14 x 14 tile.
 static TileCfg pick_tile_k(int H, int W, int CinK, int CoutS = 0) {
   TileCfg t = pick_tile(H, W);
-  static const int kc32 = getenv("SPCL_CONV_TH7_KC32") ? atoi(getenv("SPCL_CONV_TH7_KC32")) : 1;
+  static const int kc32 = lab_env("SPCL_CONV_TH7_KC32", 1);
   if (kc32 && CinK == 32 && t.th == 14 && t.tw == 14 && H % 7 == 0) t.th = 7;
   // (16 -> 32 at 224^2 -- 104 accumulator registers on the 14-row tile -- measured on 7-row tiles too: no difference)
   (void)CoutS;
@@ -438,8 +438,7 @@ static int g_gemm_mode = -2;  // -2: read the environment on first use; -1 auto;
 void conv_set_gemm(int mode) { g_gemm_mode = mode < 0 ? -1 : (mode > 0 ? 1 : 0); }
 bool conv_use_gemm(int CinK, int CoutS, int H, int W) {
   if (g_gemm_mode == -2) {
-    const char* e = getenv("SPCL_CONV_GEMM");
-    g_gemm_mode = e == nullptr ? -1 : (atoi(e) > 0 ? 1 : 0);
+    g_gemm_mode = !lab_flag("SPCL_CONV_GEMM") ? -1 : (lab_env("SPCL_CONV_GEMM", 0) > 0 ? 1 : 0);
   }
   if (g_gemm_mode == 0 || !conv_gemm_channels(CinK, CoutS) || !conv_gemm_fits(H, W, CinK, CoutS)) return false;
   return g_gemm_mode == 1 || pick_tile(H, W).tw != 14;
@@ -452,12 +451,12 @@ static int launch_conv(const ConvArgs& a0, hipStream_t st) {
   a.tilesY = cdiv(a.H, TH);
   const int ntn = a.CoutS / 16;
   const int KC = conv_kc(a.CinK);
-  static const int env_lds_extra = getenv("SPCL_CONV_LDS_EXTRA") ? atoi(getenv("SPCL_CONV_LDS_EXTRA")) : 0;
+  static const int env_lds_extra = lab_env("SPCL_CONV_LDS_EXTRA", 0);
   const size_t lds = (size_t)(TH + 2) * (TW + 2) * conv_pstride<T>(KC) + env_lds_extra;
   const int tiles = a.N * a.tilesX * a.tilesY;
-  static const int env_tpw = getenv("SPCL_CONV_TPW") ? atoi(getenv("SPCL_CONV_TPW")) : 0;
+  static const int env_tpw = lab_env("SPCL_CONV_TPW", 0);
   a.tpw = env_tpw > 0 ? env_tpw : 1;
-  static const int env_dbg = getenv("SPCL_CONV_DBG") ? atoi(getenv("SPCL_CONV_DBG")) : 0;
+  static const int env_dbg = lab_env("SPCL_CONV_DBG", 0);
   a.dbg = env_dbg;
   // waves per workgroup x n-tiles per wave
   int NT = ntn >= 2 ? 2 : 1;
@@ -479,7 +478,7 @@ template <typename T>
 static int launch_conv_t(const ConvArgs& a, hipStream_t st) {
   if (sizeof(T) == 2 && conv_use_gemm(a.CinK, a.CoutS, a.H, a.W)) return launch_conv_gemm(a, st) ? 0 : 1;
   TileCfg t = sizeof(T) == 2 ? pick_tile_k(a.H, a.W, a.CinK, a.CoutS) : pick_tile(a.H, a.W);
-  static const int no_fast = getenv("SPCL_CONV_NO_FAST") ? atoi(getenv("SPCL_CONV_NO_FAST")) : 0;
+  static const int no_fast = lab_env("SPCL_CONV_NO_FAST", 0);
   if (sizeof(T) == 2 && t.tw == 14 && !no_fast && launch_conv_fast(a, t.th, st)) return 0;
   if (t.th == 7 && t.tw == 7) return launch_conv<T, 7, 7>(a, st);
   if (t.th == 7) return launch_conv<T, 7, 14>(a, st);
@@ -796,12 +795,12 @@ static int conv3x3_forward_impl(const void* x, int dtype, int N, int H, int W, i
 // spcl_bnrelu_backward_*_image3) takes them unchanged.  _rows: the number of rows (tiles), 0 where the specialised kernel
 // does not take the shape (bf16, one input channel, 16 output channels, whole 14 x 14 tiles).
 static bool image_acorr_args(ConvArgs& a, int dtype, int N, int H, int W, int CinS, int CoutS) {
-  static const bool off = getenv("SPCL_ACORR_IN_CONV") && atoi(getenv("SPCL_ACORR_IN_CONV")) == 0;  // A/B switch
+  static const bool off = lab_env("SPCL_ACORR_IN_CONV", 1) == 0;  // A/B switch
   if (off || dtype != SPCL_BF16 || N <= 0 || H <= 0 || W <= 0 || CinS != 1 || CoutS != 16) return false;
   a.N = N; a.H = H; a.W = W; a.CinS = CinS; a.CinK = 16; a.CoutS = CoutS; a.in_mode = 2;
   a.tilesX = a.tilesY = 0; a.tpw = 1; a.dbg = 0;
   const TileCfg t = pick_tile_k(H, W, 16, CoutS);
-  static const int no_fast = getenv("SPCL_CONV_NO_FAST") ? atoi(getenv("SPCL_CONV_NO_FAST")) : 0;
+  static const int no_fast = lab_env("SPCL_CONV_NO_FAST", 0);
   return !no_fast && t.tw == 14 && t.th == 14 && H % 14 == 0 && W % 14 == 0;
 }
 
@@ -843,7 +842,7 @@ extern "C" int spcl_conv3x3_forward_image_acorr(const void* x, int dtype, int N,
 // reads its input channels [0, Chalf) from xa and [Chalf, 2 Chalf) from xb (both dense [N][H][W][Chalf] bf16, no input
 // transform).  Only where a specialised kernel exists (14-column tiles, 2 Chalf = 32 or 64): ask _supported first.
 static bool conv_cat_args(ConvArgs& a, int dtype, int N, int H, int W, int Chalf, int CoutS) {
-  static const bool off = getenv("SPCL_CONV_CAT") && atoi(getenv("SPCL_CONV_CAT")) == 0;  // A/B switch
+  static const bool off = lab_env("SPCL_CONV_CAT", 1) == 0;  // A/B switch
   if (off || dtype != SPCL_BF16 || N <= 0 || H <= 0 || W <= 0 || CoutS % 16 != 0 || CoutS <= 0 ||
       (Chalf != 16 && Chalf != 32 && Chalf != 64 && Chalf != 128))
     return false;
@@ -894,7 +893,7 @@ extern "C" int spcl_conv3x3_forward_cat(const void* xa, const void* xb, int dtyp
 // nn.Upsample(scale_factor=2) -> Conv2d (the up-convolution, unet.py:89-90) without the upsampled tensor: x is the
 // half-resolution activation [N][H / 2][W / 2][CinK], H x W the convolution's (fine) size; y / stats as spcl_conv3x3_forward.
 static bool conv_up2_args(ConvArgs& a, int dtype, int N, int H, int W, int CinK, int CoutS) {
-  static const bool off = getenv("SPCL_CONV_UP2") && atoi(getenv("SPCL_CONV_UP2")) == 0;  // A/B switch
+  static const bool off = lab_env("SPCL_CONV_UP2", 1) == 0;  // A/B switch
   if (off || dtype != SPCL_BF16 || N <= 0 || H <= 0 || W <= 0 || H % 2 || W % 2 || CinK % 16 != 0 || CinK <= 0 ||
       CoutS % 16 != 0 || CoutS <= 0)
     return false;
@@ -941,7 +940,7 @@ extern "C" int spcl_conv3x3_forward_up2(const void* x_half, int dtype, int N, in
 // output channels [0, CoutS / 2) go to y_lo and [CoutS / 2, CoutS) to y_hi, both dense [N][H][W][CoutS / 2] -- each producer's
 // backward then reads whole pixels instead of half of every line of one interleaved tensor.
 static bool conv_split_args(ConvArgs& a, int dtype, int N, int H, int W, int CinK, int CoutS) {
-  static const bool off = getenv("SPCL_CONV_SPLIT") && atoi(getenv("SPCL_CONV_SPLIT")) == 0;  // A/B switch
+  static const bool off = lab_env("SPCL_CONV_SPLIT", 1) == 0;  // A/B switch
   if (off || dtype != SPCL_BF16 || N <= 0 || H <= 0 || W <= 0 || CinK % 16 != 0 || CinK <= 0 || CoutS % 32 != 0 || CoutS <= 0)
     return false;
   if (!(CinK <= 64 || CinK % 64 == 0)) return false;
@@ -987,7 +986,7 @@ extern "C" int spcl_conv3x3_forward_split(const void* x, int dtype, int N, int H
 // [N][H][W][CoutS / 2] its raw output, scale2 / shift2 / mean2 its coefficients): rows2 [spcl_conv_stat_rows(...)][2][CoutS / 2]
 // as spcl_conv3x3_dgrad_bnstats leaves them -- that layer's reduction pass over (y2, g_hi) disappears.
 extern "C" int spcl_conv_split_bnstats_supported(int dtype, int N, int H, int W, int CinK, int CoutS) {
-  static const bool off = getenv("SPCL_CONV_SPLIT_BNSTATS") && atoi(getenv("SPCL_CONV_SPLIT_BNSTATS")) == 0;  // A/B switch
+  static const bool off = lab_env("SPCL_CONV_SPLIT_BNSTATS", 1) == 0;  // A/B switch
   ConvArgs a;
   if (off || !conv_split_args(a, dtype, N, H, W, CinK, CoutS)) return 0;
   static char dummy[16] = {0};
@@ -1038,7 +1037,7 @@ static bool dgrad_bnstats_args(ConvArgs& a, int dtype, int N, int H, int W, int 
 }
 
 extern "C" int spcl_conv_dgrad_bnstats_supported(int dtype, int N, int H, int W, int CinK, int CoutS) {
-  static const bool off = getenv("SPCL_NO_DGRAD_BNSTATS") != nullptr;  // A/B switch
+  static const bool off = lab_flag("SPCL_NO_DGRAD_BNSTATS");  // A/B switch
   ConvArgs a;
   if (off || !dgrad_bnstats_args(a, dtype, N, H, W, CinK, CoutS)) return 0;
   if (conv_use_gemm(CinK, CoutS, H, W)) return 1;
@@ -1117,7 +1116,7 @@ static int dgrad_bnstats_impl(const void* dy, int dtype, int N, int H, int W, in
 // 2 .. 10 hold sum_p dz[p][co] image[p + tap] -- the data-dependent part of the first conv's weight gradient (bn.hip,
 // spcl_bnrelu_backward_rows_image3 finishes it without another pass over y2 / g).  16 -> 16 channels on 14 x 14 tiles only.
 extern "C" int spcl_conv_dgrad_bnstats_image_supported(int dtype, int N, int H, int W, int CinK, int CoutS) {
-  static const bool off = getenv("SPCL_NO_IMAGE3") != nullptr;  // A/B switch
+  static const bool off = lab_flag("SPCL_NO_IMAGE3");  // A/B switch
   ConvArgs a;
   if (off || CinK != 16 || CoutS != 16 || !dgrad_bnstats_args(a, dtype, N, H, W, CinK, CoutS)) return 0;
   if (!spcl_conv_dgrad_bnstats_supported(dtype, N, H, W, CinK, CoutS) || conv_use_gemm(CinK, CoutS, H, W)) return 0;
@@ -1161,7 +1160,7 @@ extern "C" int spcl_conv3x3_dgrad_bnstats_image(const void* dy, int dtype, int N
 // epilogue routes g to the window's first positive maximum and leaves the per-tile partial sums of that BatchNorm's
 // backward: the separate reduction pass over y2 (bnrelu_bwd_pool_kernel<T, false>) disappears.  Per-wave kernels only.
 extern "C" int spcl_conv_dgrad_poolstats_supported(int dtype, int N, int H, int W, int CinK, int CoutS, int H2, int W2) {
-  static const bool off = getenv("SPCL_NO_DGRAD_POOLSTATS") != nullptr;  // A/B switch
+  static const bool off = lab_flag("SPCL_NO_DGRAD_POOLSTATS");  // A/B switch
   ConvArgs a;
   if (off || H != H2 / 2 || W != W2 / 2 || !dgrad_bnstats_args(a, dtype, N, H, W, CinK, CoutS)) return 0;
   if (conv_use_gemm(CinK, CoutS, H, W)) return 0;

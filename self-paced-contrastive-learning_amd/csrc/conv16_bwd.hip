@@ -903,14 +903,14 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(r16_wpe(SHI
 
 int conv16_bwd_rowmap() {
   // the row-mapped kernel (two waves per tile): SPCL_CONV16_ROWMAP=0 switches back to the linear pixel order
-  static const int env = getenv("SPCL_CONV16_ROWMAP") ? atoi(getenv("SPCL_CONV16_ROWMAP")) : 1;
+  static const int env = lab_env("SPCL_CONV16_ROWMAP", 1);
   return env;
 }
 
 int conv16_bwd_nw() {
   // measured inside the step (64 x 224^2, same box, median of single replays; separate launches 1204.7 us): one wave per
   // tile 1208, two 1194, four 1242
-  static const int env = getenv("SPCL_CONV16_NW") ? atoi(getenv("SPCL_CONV16_NW")) : 2;
+  static const int env = lab_env("SPCL_CONV16_NW", 2);
   return env == 1 || env == 4 ? env : 2;
 }
 
@@ -920,7 +920,7 @@ int conv16_bwd_ipw(int N, int H, int W) {
   // (the shifted-tile form is built for three waves per SIMD and comes out at 121 registers: four are resident all the same)
   const int resident = 256 * (nw == 1 ? 8 : (nw == 2 ? (conv16_bwd_rowmap() ? 2 * SPCL_CONV16_ROWS_WPE : 6) : 3));
   const long tiles = (long)cdiv(H, B16_TH) * cdiv(W, B16_TW);
-  static const int env_ipw = getenv("SPCL_CONV16_IPW") ? atoi(getenv("SPCL_CONV16_IPW")) : 0;
+  static const int env_ipw = lab_env("SPCL_CONV16_IPW", 0);
   int ipw = env_ipw > 0 ? env_ipw : (int)((tiles * N + resident - 1) / resident);
   if (ipw < 1) ipw = 1;
   if (ipw > N) ipw = N;
@@ -932,7 +932,7 @@ int conv16_bwd_ipw(int N, int H, int W) {
 using namespace spcl;
 
 extern "C" int spcl_conv16_bwd_fused_supported(int dtype, int N, int H, int W, int CinK, int CoutS) {
-  static const bool off = getenv("SPCL_NO_CONV16_FUSED") != nullptr;  // A/B switch
+  static const bool off = lab_flag("SPCL_NO_CONV16_FUSED");  // A/B switch
   if (off || CinK != 16 || CoutS != 16) return 0;
   return spcl_conv_dgrad_bnstats_image_supported(dtype, N, H, W, CinK, CoutS);
 }
@@ -964,15 +964,15 @@ extern "C" int spcl_conv16_bwd_fused(const void* dy, int dtype, int N, int H, in
   a.wg_rows = wg_rows; a.acorr_in = acorr; a.nacorr = nacorr; a.acorr_out = acorr16;
   a.N = N; a.H = H; a.W = W; a.tilesX = cdiv(W, B16_TW); a.tilesY = cdiv(H, B16_TH);
   a.ipw = conv16_bwd_ipw(N, H, W);
-  static const int env_remap = getenv("SPCL_CONV_XCD_REMAP") ? atoi(getenv("SPCL_CONV_XCD_REMAP")) : 1;
+  static const int env_remap = lab_env("SPCL_CONV_XCD_REMAP", 1);
   a.xcd_remap = env_remap;
-  a.dbg = getenv("SPCL_CONV16_DBG") ? atoi(getenv("SPCL_CONV16_DBG")) : 0;  // (read per call: experiments flip it)
+  a.dbg = lab_env("SPCL_CONV16_DBG", 0);  // (read per call: experiments flip it)
   const int nz = cdiv(N, a.ipw), nsplit = a.tilesX * a.tilesY * nz;
   a.nwg = nsplit;
   const double px = (double)N * H * W;
   prof_cost(px * 32.0 * 2.0 + px * 4.0 + (double)nsplit * 9 * 256 * 4.0, 2.0 * px * 9.0 * 256 * 2.0 + 2.0 * px * 9.0 * 16);
   a.stamps = nullptr;
-  const bool want_stamps = SPCL_CONV16_STAMPS_BUILD && getenv("SPCL_CONV16_STAMPS") != nullptr;  // debug only (synchronises)
+  const bool want_stamps = SPCL_CONV16_STAMPS_BUILD && lab_flag("SPCL_CONV16_STAMPS");  // debug only (synchronises)
   const size_t nwg = (size_t)nsplit;
   if (want_stamps) {
     (void)hipMalloc(&a.stamps, nwg * 8 * sizeof(unsigned long long));

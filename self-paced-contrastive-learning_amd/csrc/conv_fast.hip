@@ -965,7 +965,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void co
 
 template <int KC, int TH, int NT, int NW>
 static void launch_fast(const FastArgs& a, int mode, hipStream_t st) {
-  static const int env_pipe = getenv("SPCL_CONV_FAST_PIPE") ? atoi(getenv("SPCL_CONV_FAST_PIPE")) : 1;
+  static const int env_pipe = lab_env("SPCL_CONV_FAST_PIPE", 1);
   const bool pipe = env_pipe && KC == 64 && a.CinK > KC;  // more than one slab: two halo images
   FastArgs b = a;
   b.lds_flip = pipe ? fast_lds_bytes(KC, TH) : 0;
@@ -973,7 +973,7 @@ static void launch_fast(const FastArgs& a, int mode, hipStream_t st) {
                      (a.in_bn.acc != nullptr ? (size_t)a.CinK * 8 + (size_t)64 * NW * 32 : 0);  // (+ MODE 5 .. 7: the derived
                                                                                           // scale / shift and the partial sums)
   dim3 grid(a.tilesX, a.tilesY, a.N * a.gy), block(64 * NW);
-  static const bool env_stamps = SPCL_FAST_STAMPS_BUILD && getenv("SPCL_FAST_STAMPS") != nullptr;
+  static const bool env_stamps = SPCL_FAST_STAMPS_BUILD && lab_flag("SPCL_FAST_STAMPS");
   const size_t nwg = (size_t)grid.x * grid.y * grid.z;
   b.stamps = nullptr;
   if (env_stamps) {  // debug only (synchronises)
@@ -1022,7 +1022,7 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
     a.in_scale = a.in_shift = nullptr;
     a.y2 = nullptr; a.scale2 = a.shift2 = a.mean2 = nullptr; a.rows2 = nullptr; a.H2 = a.W2 = 0; a.img2 = nullptr;
     a.N = c.N; a.H = c.H; a.W = c.W; a.CinK = 16; a.CoutS = 16;
-    static const int env_img_remap = getenv("SPCL_IMAGE_XCD_REMAP") ? atoi(getenv("SPCL_IMAGE_XCD_REMAP")) : 1;
+    static const int env_img_remap = lab_env("SPCL_IMAGE_XCD_REMAP", 1);
     a.tilesX = cdiv(c.W, 14); a.tilesY = cdiv(c.H, 14); a.gy = 1; a.xcd_remap = env_img_remap; a.lds_flip = 0; a.stamps = nullptr;
     a.acorr_rows = c.acorr_rows;
     a.stats_acc = a.rows2_acc = nullptr;
@@ -1040,7 +1040,7 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
   const bool wants_acc = c.stats_acc != nullptr || c.rows2_acc != nullptr || c.in_bn != nullptr;
   if (!wants_acc && launch_conv_stream(c, th, st, dry)) return true;
   const int ntn = c.CoutS / 16, KC = conv_kc(c.CinK);
-  static const int env_nt1 = getenv("SPCL_CONV_FAST_NT1") ? atoi(getenv("SPCL_CONV_FAST_NT1")) : 0;
+  static const int env_nt1 = lab_env("SPCL_CONV_FAST_NT1", 0);
   int NT = ntn >= 2 ? 2 : 1;
   if (env_nt1 == 1 && KC == 64 && ntn == 2) NT = 1;
   // 64 -> 32 channels with the pooled BatchNorm-backward sums in the epilogue (Conv3.a's dgrad): as two one-n-tile waves,
@@ -1056,16 +1056,16 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
   if (KC == 64 && ntn == 4 && env_nt1 != 3 && (c.in_mode == 1 || c.H <= 28)) NT = 1;
   // ... and with more than one slab of input channels (128 -> 64: the decoder's 56^2 level), where the cross-slab pipeline
   // keeps TWO halo images (46 KB): three two-wave workgroups per CU otherwise
-  static const int env_wide = getenv("SPCL_CONV_FAST_NT1_WIDE") ? atoi(getenv("SPCL_CONV_FAST_NT1_WIDE")) : 1;
+  static const int env_wide = lab_env("SPCL_CONV_FAST_NT1_WIDE", 1);
   if (env_wide && KC == 64 && ntn == 4 && c.CinK > 64) NT = 1;
   // ... and, re-measured in round 4, the 56^2 dgrad as well (Conv3.b's, with the BatchNorm-backward sums in its epilogue:
   // pre-train step 1.160 -> 1.155 ms, same box, three rounds; fine-tune unchanged): four one-n-tile waves for every 64 -> 64
-  static const int env_all4 = getenv("SPCL_CONV_FAST_NT1_64") ? atoi(getenv("SPCL_CONV_FAST_NT1_64")) : 1;
+  static const int env_all4 = lab_env("SPCL_CONV_FAST_NT1_64", 1);
   if (env_all4 && KC == 64 && ntn == 4) NT = 1;
   // few tiles (14^2 images): with two n-tiles per wave a 128-channel output is ONE workgroup per tile -- 128 workgroups for
   // Conv5.a's dgrad at N = 64, half the CUs idle; one n-tile per wave doubles the workgroups
-  static const int env_fill = getenv("SPCL_CONV_FAST_FILL") ? atoi(getenv("SPCL_CONV_FAST_FILL")) : 1;
-  static const int env_fill_max = getenv("SPCL_CONV_FAST_FILL_MAX") ? atoi(getenv("SPCL_CONV_FAST_FILL_MAX")) : 256;
+  static const int env_fill = lab_env("SPCL_CONV_FAST_FILL", 1);
+  static const int env_fill_max = lab_env("SPCL_CONV_FAST_FILL_MAX", 256);
   if (env_fill && KC == 64 && NT == 2 && ntn >= 8 && ntn % 4 == 0 &&
       (long)c.N * cdiv(c.W, 14) * cdiv(c.H, th) * cdiv(ntn, 8) < env_fill_max)
     NT = 1;
@@ -1073,7 +1073,7 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
   // (1 = all of them: + 4 us per step when measured, and again after the row order.  Per launch then: Conv2.a / Conv2.b forward
   // +- 0.7 us, but Conv2.b's dgrad -- 32 -> 32 with the BatchNorm-backward sums in its epilogue, 202 registers as one wave --
   // 42.9 -> 38.6 us as two waves of 140: 2 = that form only, the default)
-  static const int env_narrow = getenv("SPCL_CONV_FAST_NARROW_NT1") ? atoi(getenv("SPCL_CONV_FAST_NARROW_NT1")) : 2;
+  static const int env_narrow = lab_env("SPCL_CONV_FAST_NARROW_NT1", 2);
   if (env_narrow == 1 && KC < 64 && ntn == 2 && th == 7) NT = 1;
   if (env_narrow == 2 && KC == 32 && ntn == 2 && th == 7 && c.rows2 != nullptr && c.H2 == 0 && c.img2 == nullptr) NT = 1;
   int nw = ntn / NT;
@@ -1122,7 +1122,7 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
   if (c.img2 != nullptr && !(c.rows2 != nullptr && c.H2 == 0 && KC == 16 && th == 14 && ntn == 1)) return false;
   a.N = c.N; a.H = c.H; a.W = c.W; a.CinK = c.CinK; a.CoutS = c.CoutS;
   a.tilesX = cdiv(c.W, 14); a.tilesY = cdiv(c.H, th); a.gy = ntn / (NT * nw);
-  static const int env_remap = getenv("SPCL_CONV_XCD_REMAP") ? atoi(getenv("SPCL_CONV_XCD_REMAP")) : 1;
+  static const int env_remap = lab_env("SPCL_CONV_XCD_REMAP", 1);
   a.xcd_remap = (env_remap && a.gy == 1) ? 1 : 0;  // (with gy > 1 the z index interleaves channel blocks: left alone)
   // pooled BatchNorm-backward sums in the epilogue (MODE 3): measured per block against dgrad + separate reduction pass
   // (N = 64): 32 -> 16 @112^2 43 vs 49 us, 128 -> 64 @28^2 21 vs 25.5, 256 -> 128 @14^2 30.5 vs 30.6, but the one-wave

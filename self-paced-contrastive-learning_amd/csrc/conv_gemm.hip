@@ -420,7 +420,7 @@ bool launch_conv_gemm(const ConvArgs& c, hipStream_t st) {
   g.magic_tw = ((1u << 22) + gg.TWc - 1) / gg.TWc;
   const int mode = c.rows2 != nullptr ? 2 : c.in_mode;
   dim3 grid(gg.tilesX * gg.bandsY, c.CoutS / 64, c.N);
-  static const bool env_stamps = getenv("SPCL_GEMM_STAMPS") != nullptr;
+  static const bool env_stamps = lab_flag("SPCL_GEMM_STAMPS");
   const size_t nwg = (size_t)grid.x * grid.y * grid.z;
   g.stamps = nullptr;
   if (env_stamps) {  // debug only (synchronises)

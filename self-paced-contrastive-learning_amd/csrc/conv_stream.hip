@@ -458,7 +458,7 @@ template <int KC, int TH, int NT>
 static void launch_stream(const StreamArgs& a0, int mode, hipStream_t st) {
   StreamArgs a = a0;
   const int lds = 2 * st_img_bytes(KC, TH);
-  static const int env_wpc = getenv("SPCL_CONV_STREAM_WPC") ? atoi(getenv("SPCL_CONV_STREAM_WPC")) : 0;
+  static const int env_wpc = lab_env("SPCL_CONV_STREAM_WPC", 0);
   auto go = [&](auto kern, int wpe) {
     int wpc = 160 * 1024 / lds;             // resident workgroups (= waves) per CU: LDS ...
     if (wpc > 4 * wpe) wpc = 4 * wpe;       // ... and the register budget the kernel was compiled for
@@ -474,7 +474,7 @@ static void launch_stream(const StreamArgs& a0, int mode, hipStream_t st) {
     a.nwg = nwg;
     func_lds_limit((const void*)kern, lds, "conv3x3_stream_kernel");
     a.stamps = nullptr;
-    static const bool env_stamps = SPCL_STREAM_STAMPS_BUILD && getenv("SPCL_STREAM_STAMPS") != nullptr;
+    static const bool env_stamps = SPCL_STREAM_STAMPS_BUILD && lab_flag("SPCL_STREAM_STAMPS");
     if (env_stamps) {  // debug only (synchronises)
       (void)hipMalloc(&a.stamps, (size_t)nwg * 5 * 8);
       (void)hipMemset(a.stamps, 0, (size_t)nwg * 5 * 8);
@@ -507,7 +507,7 @@ bool launch_conv_stream(const ConvArgs& c, int th, hipStream_t st, bool dry) {
   // BatchNorm-backward sums in the epilogue).  Isolated launches of those run 20-30 % faster than conv_fast, but neither the
   // pre-train step (1.123 -> 1.138 ms with 1) nor the fine-tune step (2.451 -> 2.469 ms with 2) gains: the tile is bound by
   // the instructions it executes, not by the exposed halo latency (profiles/r04_experiments/NOTES.md)
-  static const int env_on = getenv("SPCL_CONV_STREAM") ? atoi(getenv("SPCL_CONV_STREAM")) : 0;
+  static const int env_on = lab_env("SPCL_CONV_STREAM", 0);
   if (!env_on) return false;
   if (env_on == 2 && !(c.CinK == 32 && c.in_mode == 0 && c.rows2 == nullptr)) return false;
   if (env_on == 3 && !(c.in_mode == 0 && c.rows2 == nullptr)) return false;  // 3: every plain convolution it has a kernel for

@@ -717,7 +717,7 @@ extern "C" int spcl_sup_loss_forward(const float* logits, const int64_t* labels,
   if (gx > 64) gx = 64;
   const size_t npix = (size_t)B * per_sample;
   prof_cost((double)npix * (K * 8.0 + 8.0), 0.0);
-  static const bool no_k4 = getenv("SPCL_SUP_LOSS_K4") && atoi(getenv("SPCL_SUP_LOSS_K4")) == 0;  // A/B switch
+  static const bool no_k4 = lab_env("SPCL_SUP_LOSS_K4", 1) == 0;  // A/B switch
   if (K == 4 && !no_k4 && (per_sample + gx * 256 - 1) / (gx * 256) < 32768 && (uintptr_t)logits % 16 == 0 &&
       (uintptr_t)dlogits_unit % 16 == 0)
     SPCL_LAUNCH(sup_loss_fwd4_kernel, dim3(gx, B), dim3(256), 0, st, logits, labels, per_sample, eps, 1.f / (float)npix, ws,

@@ -27,7 +27,7 @@ constexpr int SPCL_SUPCON_MAX_D = 4096;  // widest projection (d > 256 takes the
 constexpr int SUPCON_TILES_MAXT = 16;  // J tiles per workgroup of the fused large-batch sweeps  // from this many rows on the forward materialises the logits
 
 static int supcon_big_wgs() {
-  static const int v = getenv("SPCL_SUPCON_WGS") ? atoi(getenv("SPCL_SUPCON_WGS")) : 512;
+  static const int v = lab_env("SPCL_SUPCON_WGS", 512);
   return v;
 }
 
@@ -2233,7 +2233,7 @@ static SupconArgs make_args(const SupconLayout& L, const float* ws, const float*
   a.gk[0] = a.gamma;
   a.igk[0] = a.inv_gamma;
   a.sp_mode = sp_mode;
-  static const int env_dbg = getenv("SPCL_SUPCON_DBG") ? atoi(getenv("SPCL_SUPCON_DBG")) : 0;
+  static const int env_dbg = lab_env("SPCL_SUPCON_DBG", 0);
   a.dbg = env_dbg;
   return a;
 }
@@ -2269,19 +2269,19 @@ static int launch_forward_wide(const SupconLayout& L, SupconArgs a, float* ws, i
 }
 
 static bool supcon_use_small(const SupconLayout& L) {
-  static const bool sweeps = getenv("SPCL_SUPCON_SWEEPS") != nullptr;  // A/B switch: the multi-launch sweeps at any size
+  static const bool sweeps = lab_flag("SPCL_SUPCON_SWEEPS");  // A/B switch: the multi-launch sweeps at any size
   return !L.big && L.N2p == 64 && !sweeps && L.DP <= 256;
 }
 
 static bool supcon_use_big(const SupconLayout& L, const float* mask) {
-  static const bool exact = getenv("SPCL_SUPCON_EXACT") != nullptr;  // A/B switch: keep the exact-f32 sweeps
+  static const bool exact = lab_flag("SPCL_SUPCON_EXACT");  // A/B switch: keep the exact-f32 sweeps
   return L.big && mask == nullptr && !exact;
 }
 
 // Large batches, d <= 128: the forward keeps no logits matrix (two fused sweeps, supcon_tiles_kernel); the backward
 // materialises it on demand.  SPCL_SUPCON_MATERIALIZE=1 restores the round-1 schedule (logits written by the forward).
 static bool supcon_use_fused(const SupconLayout& L) {
-  static const bool mat = getenv("SPCL_SUPCON_MATERIALIZE") != nullptr;
+  static const bool mat = lab_flag("SPCL_SUPCON_MATERIALIZE");
   return !mat && L.DP <= 128 && L.N2p % 256 == 0 && L.N2p <= 16384;
 }
 static int supcon_fused_csb(const SupconLayout& L);
@@ -2335,7 +2335,7 @@ static int launch_forward_big(const SupconLayout& L, SupconArgs a, float* ws, in
       const double n2f = (double)L.N2p;
       const float* cls = ws + L.off_cls;
       float *pD = ws + L.off_partA, *pW = ws + L.off_partB, *pC = ws + L.off_partC, *pL = ws + L.off_partD;
-      static const bool env_stamps = getenv("SPCL_SUPCON_STAMPS") != nullptr;
+      static const bool env_stamps = lab_flag("SPCL_SUPCON_STAMPS");
       const size_t nwg = (size_t)nrb * csb;
       for (int pass = 0; pass < 2; ++pass) {
         if (env_stamps) {  // debug only (synchronises)
@@ -2394,13 +2394,13 @@ static int launch_forward_big(const SupconLayout& L, SupconArgs a, float* ws, in
   }
   const double n2 = (double)L.N2p;
   prof_cost(n2 * n2 * 4 + 2 * n2 * DP * 4, 2.0 * n2 * n2 * DP);  // logits written once; f32-equivalent FLOPs
-  static const bool env_stamps = getenv("SPCL_SUPCON_STAMPS") != nullptr;
+  static const bool env_stamps = lab_flag("SPCL_SUPCON_STAMPS");
   const size_t nwg = (size_t)(L.N2p / 128) * L.CSB;  // (>= the number of workgroups of either kernel)
   if (env_stamps) {  // debug only (synchronises)
     (void)hipMalloc(&a.stamps, nwg * 6 * sizeof(unsigned long long));
     (void)hipMemset(a.stamps, 0, nwg * 6 * sizeof(unsigned long long));
   }
-  static const bool env_v1 = getenv("SPCL_SUPCON_LOGITS_V1") != nullptr;  // A/B switch
+  static const bool env_v1 = lab_flag("SPCL_SUPCON_LOGITS_V1");  // A/B switch
   bool v2 = false;
   if constexpr (DP <= 128) {  // three tile images of 2 x 64 x DP bf16 fit the LDS
     if (L.N2p % 256 == 0 && !env_v1) {
@@ -2611,7 +2611,7 @@ static int supcon_backward_impl(int K, const float* labels, const float* mask, i
     return SPCL_OK;
   }
   int nsplit = L.CS;
-  static const bool env_bwd_mat = getenv("SPCL_SUPCON_BWD_MATERIALIZE") != nullptr;  // A/B: logits written, then read
+  static const bool env_bwd_mat = lab_flag("SPCL_SUPCON_BWD_MATERIALIZE");  // A/B: logits written, then read
   if (supcon_use_big(L, mask) && supcon_use_fused(L) && !env_bwd_mat) {
     // fused backward: similarities recomputed tile by tile, H applied from the accumulator registers (no logits matrix)
     float* stt = ws_bwd + supcon_bwd_rows(L) * L.N2p * L.DP;

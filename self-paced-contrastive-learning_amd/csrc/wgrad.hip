@@ -416,7 +416,7 @@ static WgradPlan wgrad_plan(int N, int H, int W, int CinK, int CoutS, int esize)
   p.nblk_ci = CinK / (16 * p.MI);
   p.nblk_co = CoutS / (16 * p.NJ);
   // 14-row tiles when the height divides by 14 but not by 16 (56 / 28 / 14: 12.5 % padded pixels instead of 23 %)
-  static const int env_th = getenv("SPCL_WGRAD_TH") ? atoi(getenv("SPCL_WGRAD_TH")) : 0;
+  static const int env_th = lab_env("SPCL_WGRAD_TH", 0);
   p.TH = env_th ? env_th : ((H % 16 != 0 && H % 14 == 0) ? 14 : 16);
   p.tilesX = cdiv(W, WG_TW);
   p.tilesY = cdiv(H, p.TH);
@@ -424,12 +424,12 @@ static WgradPlan wgrad_plan(int N, int H, int W, int CinK, int CoutS, int esize)
   const int nblk = p.nblk_ci * p.nblk_co;
   // exactly one resident "wave" of workgroups (LDS-limited residency x 256 CUs): measured optimum -- more workgroups
   // only add partial slabs and a tail, fewer leave CUs idle (tools/bench_kernels.py wgrad sweeps)
-  static const int plan_dbuf = getenv("SPCL_WGRAD_DBUF") ? atoi(getenv("SPCL_WGRAD_DBUF")) : 1;
+  static const int plan_dbuf = lab_env("SPCL_WGRAD_DBUF", 1);
   const size_t lds = (plan_dbuf ? 2 : 1) * wgrad_lds_bytes(p.MI, p.NJ, p.TH, esize);
   int per_cu = (int)((160 * 1024) / lds);
   if (per_cu > 4) per_cu = 4;
   if (per_cu < 1) per_cu = 1;
-  static const int env_wgs = getenv("SPCL_WGRAD_WGS") ? atoi(getenv("SPCL_WGRAD_WGS")) : 0;
+  static const int env_wgs = lab_env("SPCL_WGRAD_WGS", 0);
   int ns = cdiv(env_wgs > 0 ? env_wgs : 256 * per_cu, nblk);
   if (ns > p.ntiles) ns = p.ntiles;
   if (ns < 1) ns = 1;
@@ -459,7 +459,7 @@ template <typename T, int TH>
 static void launch_wgrad_th(const WgradArgs& a, const WgradPlan& p, hipStream_t st) {
   // 8 waves on the 32 x 32 block (18 (tap, ci-tile) units: 3 or 2 per wave instead of 5 or 4, the staging spread over twice
   // the threads): Conv2.b + Conv3.a -8 us per step, same box.  Bit 1 of SPCL_WGRAD_W8: the same for the 16 x 32 block.
-  static const int env_w8 = getenv("SPCL_WGRAD_W8") ? atoi(getenv("SPCL_WGRAD_W8")) : 1;
+  static const int env_w8 = lab_env("SPCL_WGRAD_W8", 1);
   if (p.MI == 1 && p.NJ == 1) launch_wgrad<T, 1, 1, TH, 4>(a, p, st);
   else if (p.MI == 1 && p.NJ == 2) {
     if ((env_w8 & 2) && a.in_mode != 2) launch_wgrad<T, 1, 2, TH, 8>(a, p, st);  // (the image mode exists for 4 waves only)
@@ -584,11 +584,11 @@ static int conv3x3_wgrad_impl(const void* x, const void* x2, const void* dy, int
   a.x = x; a.x2 = x2; a.xsplit = x2 ? CinK / 2 : 0; a.x_up2 = x_up2 ? 1 : 0; a.dy = dy; a.in_scale = in_scale; a.in_shift = in_shift; a.partial = partial;
   a.N = N; a.H = H; a.W = W; a.CinS = CinS; a.CinK = CinK; a.CoutS = CoutS; a.in_mode = in_mode;
   a.tilesX = p.tilesX; a.tilesY = p.tilesY; a.ntiles = p.ntiles; a.nblk_ci = p.nblk_ci; a.nblk_co = p.nblk_co;
-  static const int env_dbuf = getenv("SPCL_WGRAD_DBUF") ? atoi(getenv("SPCL_WGRAD_DBUF")) : 1;
+  static const int env_dbuf = lab_env("SPCL_WGRAD_DBUF", 1);
   a.dbuf = env_dbuf;
-  static const int env_remap = getenv("SPCL_WGRAD_XCD_REMAP") ? atoi(getenv("SPCL_WGRAD_XCD_REMAP")) : 0;  // measured: +3..12 us per step, off
+  static const int env_remap = lab_env("SPCL_WGRAD_XCD_REMAP", 0);  // measured: +3..12 us per step, off
   a.xcd_remap = env_remap;
-  static const int env_stamps = (SPCL_WGRAD_STAMPS_BUILD && getenv("SPCL_WGRAD_STAMPS")) ? atoi(getenv("SPCL_WGRAD_STAMPS")) : 0;
+  static const int env_stamps = SPCL_WGRAD_STAMPS_BUILD ? lab_env("SPCL_WGRAD_STAMPS", 0) : 0;
   static unsigned long long* stamp_buf = nullptr;
   a.stamps = nullptr;
   const size_t nwg = (size_t)p.nsplit * p.nblk_ci * p.nblk_co;

@@ -541,7 +541,7 @@ static int wb_cu_count() {
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    if (getenv("SPCL_WGRAD_GEMM_WGS")) n = atoi(getenv("SPCL_WGRAD_GEMM_WGS"));
+    if (lab_flag("SPCL_WGRAD_GEMM_WGS")) n = lab_env("SPCL_WGRAD_GEMM_WGS", n);
   }
   return n;
 }
@@ -563,7 +563,7 @@ static int wb_plan(const spcl_wgrad_item* items, int n, WbPlan& pl) {
                   (items[i].Cout / 64);
     }
   pl.th = waste[1] < waste[0] ? 16 : 14;
-  if (getenv("SPCL_WGRAD_GEMM_TH")) pl.th = atoi(getenv("SPCL_WGRAD_GEMM_TH")) == 16 ? 16 : 14;
+  if (lab_flag("SPCL_WGRAD_GEMM_TH")) pl.th = lab_env("SPCL_WGRAD_GEMM_TH", 14) == 16 ? 16 : 14;
   long units = 0;
   for (int i = 0; i < n; ++i) {
     WbItem& w = pl.args.it[i];
@@ -707,9 +707,9 @@ extern "C" int spcl_conv3x3_wgrad_batched_tails(const spcl_wgrad_item* items, in
   wb_plan(items, n, pl);
   pl.args.partial = partial;
   pl.args.accumulate = accumulate ? 1 : 0;
-  static const int env_dbg = getenv("SPCL_WGRAD_GEMM_DBG") ? atoi(getenv("SPCL_WGRAD_GEMM_DBG")) : 0;
+  static const int env_dbg = lab_env("SPCL_WGRAD_GEMM_DBG", 0);
   pl.args.dbg = env_dbg;
-  static const int env_stamps = getenv("SPCL_WGRAD_GEMM_STAMPS") ? atoi(getenv("SPCL_WGRAD_GEMM_STAMPS")) : 0;
+  static const int env_stamps = lab_env("SPCL_WGRAD_GEMM_STAMPS", 0);
   static unsigned long long* stamp_buf = nullptr;
   pl.args.stamps = nullptr;
   if (env_stamps) {  // debug only (synchronises)
@@ -726,7 +726,7 @@ extern "C" int spcl_conv3x3_wgrad_batched_tails(const spcl_wgrad_item* items, in
     flops += 2.0 * px * 9.0 * items[i].Cin * items[i].Cout;
   }
   prof_cost(bytes, flops);
-  static const int env_ring = getenv("SPCL_WGRAD_GEMM_RING") ? atoi(getenv("SPCL_WGRAD_GEMM_RING")) : 2;
+  static const int env_ring = lab_env("SPCL_WGRAD_GEMM_RING", 2);
   if (pl.th == 16) wb_launch<16, 2>(pl, st);
   else if (env_ring == 1) wb_launch<14, 1>(pl, st);
   else if (env_ring == 3) wb_launch<14, 3>(pl, st);

@@ -787,16 +787,18 @@ def test_pool_link_ignores_a_gradient_it_did_not_produce():
         loss = o.float().square().mean() + (p.float().square().mean() * 3.0 if extra else 0.0)
         used = []
         real = F._n.call
-        F._n.call = lambda name, *args: (used.append(name), real(name, *args))[1]
+        F._n.call = lambda name, *args: (used.append((name, args)), real(name, *args))[1]
         try:
             loss.backward()
         finally:
             F._n.call = real
         torch.cuda.synchronize()
-        # the link was taken <=> block a did NOT run its own reduction pass over (y, pooled gradient): its sums came with the
-        # gradient, as per-tile rows (spcl_bnrelu_pool_backward_rows) or in its accumulator block (spcl_bnrelu_backward_acc)
-        taken = "spcl_bnrelu_pool_backward" not in used
-        assert not taken or "spcl_bnrelu_pool_backward_rows" in used or "spcl_conv3x3_dgrad_poolstats_acc" in used
+        # the link was taken <=> block a did NOT run its own reduction pass over (y, POOLED gradient: the third argument): its
+        # sums came with the gradient, as per-tile rows (spcl_bnrelu_pool_backward_rows) or in its accumulator block
+        # (spcl_conv3x3_dgrad_poolstats_acc + spcl_bnrelu_backward_acc)
+        names = [u[0] for u in used]
+        taken = not any(nm == "spcl_bnrelu_pool_backward" and args[2] is not None for nm, args in used)
+        assert not taken or "spcl_bnrelu_pool_backward_rows" in names or "spcl_conv3x3_dgrad_poolstats_acc" in names
         return [q.grad.clone() for q in a.parameters()], taken
 
     (g1, rows1), (g0, rows0) = run(False, True), run(False, False)
