@@ -996,9 +996,12 @@ extern "C" int spcl_conv16_bwd_fused(const void* dy, int dtype, int N, int H, in
     else if (wgr) B16_ROWS(true, true);
     else B16_ROWS(true, false);
 #undef B16_ROWS
-  } else {
+  }
+#if SPCL_LAB  // (the linear-m-tile kernel lost its A/B in round 4: instantiated in lab builds only -- SPCL_CONV16_ROWMAP=0 / _NW)
+  else {
     B16_CASE(1) B16_CASE(2) B16_CASE(4)
   }
+#endif
 #undef B16_CASE
 #undef B16_LAUNCH
   if (a.stamps != nullptr) {

@@ -163,9 +163,9 @@ __device__ __forceinline__ void write_tile_stats(float* stats, int tile, int Cou
 
 // conv_fast.hip: returns true when a specialised kernel exists for this configuration and was launched
 bool launch_conv_fast(const ConvArgs& a, int th, hipStream_t st, bool dry = false);
-// conv_stream.hip: the persistent DMA-pipelined variant for the layers with <= 32 input channels (asked first by
-// launch_conv_fast; SPCL_CONV_STREAM=0 switches it off)
-bool launch_conv_stream(const ConvArgs& a, int th, hipStream_t st, bool dry = false);
+// (tools/experiments/conv_stream.hip: the persistent DMA-pipelined variant for the layers with <= 32 input channels of round
+// 4 -- isolated launches 20-30 % faster, no gain inside the step where every launch carries a fused BatchNorm mode -- is a lab
+// record now, not part of the library)
 
 // conv_gemm.hip: workgroup-level GEMM kernel for bf16 layers whose channel counts are multiples of 64 with at least one
 // side >= 128 (64 -> 64, Conv3.b: 896 short single-slab workgroups, stays with the per-wave kernel).  Their packed weight

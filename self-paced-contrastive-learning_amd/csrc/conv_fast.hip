@@ -1038,7 +1038,6 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
   }
   if (c.CinS != c.CinK) return false;
   const bool wants_acc = c.stats_acc != nullptr || c.rows2_acc != nullptr || c.in_bn != nullptr;
-  if (!wants_acc && launch_conv_stream(c, th, st, dry)) return true;
   const int ntn = c.CoutS / 16, KC = conv_kc(c.CinK);
   static const int env_nt1 = lab_env("SPCL_CONV_FAST_NT1", 0);
   int NT = ntn >= 2 ? 2 : 1;

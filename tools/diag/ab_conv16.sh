@@ -1,4 +1,7 @@
 #!/bin/bash
+# NOTE (round 5): switches read by the LIBRARY (csrc lab_env / lab_flag) exist in LAB builds only -- build one with
+#   bash tools/diag/mk_variant_all.sh lab ""   and run this script with it in place (tools/diag/ab_lib.sh swaps libraries);
+# the Python-side switches (functional.py, unet.py) work with the shipped library.
 # same-box comparison of the one-pass block-1 backward (csrc/conv16_bwd.hip) with 1 / 2 / 4 waves per tile against the two
 # separate launches: median of 100 single-replay HIP-event times per run
 for i in 1 2; do

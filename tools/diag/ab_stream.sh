@@ -1,4 +1,7 @@
 #!/bin/bash
+# NOTE (round 5): switches read by the LIBRARY (csrc lab_env / lab_flag) exist in LAB builds only -- build one with
+#   bash tools/diag/mk_variant_all.sh lab ""   and run this script with it in place (tools/diag/ab_lib.sh swaps libraries);
+# the Python-side switches (functional.py, unet.py) work with the shipped library.
 # same-box A/B of the persistent DMA-pipelined convolution (csrc/conv_stream.hip): kernel micro-bench + whole step
 OUT=gpurun_out
 for v in 0 1; do

@@ -8,7 +8,7 @@ pids=()
 for f in $P/csrc/*.hip $P/csrc/*.cpp; do
   b=$(basename ${f%.*}); PRE=16; [ "$b" = "supcon" ] && PRE=14
   X="-x hip"; EXTRA="-mllvm -amdgpu-kernarg-preload-count=$PRE"; [ "${f##*.}" = "cpp" ] && { X=""; EXTRA=""; }
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fno-slp-vectorize $EXTRA $DEFS $X -c $f -o $O/$b.o &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fno-slp-vectorize $EXTRA -DSPCL_LAB=1 $DEFS $X -c $f -o $O/$b.o &
   pids+=($!)
   [ ${#pids[@]} -ge 6 ] && { wait ${pids[0]}; pids=("${pids[@]:1}"); }
 done

@@ -1,3 +1,6 @@
+// LAB RECORD (round 4), not compiled into libspcl_hip.so: it lived in csrc/ and was asked first by launch_conv_fast behind
+// SPCL_CONV_STREAM (default off).  Measured: plain 16- / 32-channel convolutions 20-30 % faster in isolation, nothing inside the
+// step (profiles/r04_experiments/NOTES.md).  To revive: move back to csrc/, restore the launch_conv_stream declaration / call.
 // Persistent, software-pipelined variant of the one-wave-per-tile 3x3 convolution (conv_fast.hip) for the HBM-bound
 // layers of the encoder (semi_seg/arch/unet.py:67-82,123-131: Conv1.b, Conv2.a/b forward and input gradients; <= 32 input
 // channels, one channel slab).
