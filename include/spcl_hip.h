@@ -592,6 +592,20 @@ int spcl_augment_views(const float* src, int S, int HS, int WS, const int* param
  * oracle.augment_view_pil. */
 int spcl_augment_views_pil(const float* src, int S, int HS, int WS, const int* params, int nviews, float* out, int OH,
                            int OW, void* stream);
+/* The reference's other PIL recipes, and the interpolation its wrapper really selects (semi_seg/augment.py:23-37,54-75;
+ * contrastyou/augment/synchronize.py:95-103: BILINEAR on images, NEAREST on targets): params[v][28] =
+ *   [0] slice [1] flags (1 hflip, 2 vflip, 4 contrast first, 8 bilinear image rotation, 16 crop first = the rotation turns the
+ *   crop about its centre) [2] top [3] left [4] pad [5] brightness [6] contrast (f32 bits) [8..13] PIL's 16.16 nearest
+ *   coefficients [14..25] the six doubles of PIL's rotation matrix -- of the image the rotation acts on (slice or crop).
+ * labels / label_out (optional, together): the slice's u8 label map through the same geometry with NEAREST -> int64. */
+int spcl_augment_views_recipe(const float* src, const unsigned char* labels, int S, int HS, int WS, const int* params,
+                              int nviews, float* out, long long* label_out, int OH, int OW, int max_pad, void* stream);
+/* Image.resize((OW, OH), BILINEAR) of every slice of a store of 8-bit levels (k / 255) -- torchvision Resize,
+ * semi_seg/augment.py:56,71,79 -- with the coefficient rows of Resample.c precomputed by the caller per axis
+ * (bounds[out][2] = first tap, tap count; kk[out][ksize]: 22 fractional bits); tmp: [S][HS][OW] floats. */
+int spcl_resize_bilinear_pil(const float* src, int S, int HS, int WS, const int* bounds_x, const int* kk_x, int ksize_x,
+                             const int* bounds_y, const int* kk_y, int ksize_y, float* tmp, float* out, int OH, int OW,
+                             void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Per-sample random flips of an NCHW batch (TensorRandomFlip(axis=[1,2], threshold=0.8), new_epocher.py:112, applied

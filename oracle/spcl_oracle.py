@@ -635,3 +635,186 @@ def augment_view_pil(img_u8, row, out_hw):
     u = brightness(contrast(u)) if flags & 4 else contrast(brightness(u))
     return (u.astype(np.float32) / np.float32(255)).astype(np.float32)
 
+
+
+# --------------------------------------------------------------------------------------
+# round 5: the rest of the reference's PIL recipes (semi_seg/augment.py:23-37,54-75) in PIL's own arithmetic.
+# contrastyou/augment/synchronize.py:95-103 (``switch_interpolation``) runs the COMMON transform with BILINEAR
+# interpolation on images and NEAREST on targets: torchvision's RandomRotation / Resize carry an ``interpolation``
+# attribute, so an image is rotated by ``Image.rotate(angle, BILINEAR)``, its label map by ``Image.rotate(angle, NEAREST)``.
+# Pinned to PIL itself by tests/golden/g10_augment_recipes.npz (tools/gen_golden.py recipes).
+def pil_rotate_matrix(angle: float, ws: int, hs: int):
+    """the six doubles ``Image.rotate(angle)`` hands ImagingTransformAffine (PIL/Image.py ``rotate``: entries
+    ``round(.., 15)``, rotation about (w/2, h/2)); ``pil_affine_q16`` is FIX() of these with the half-pixel folded in"""
+    import math
+    a = -math.radians(angle % 360.0)
+    m = [round(math.cos(a), 15), round(math.sin(a), 15), 0.0, round(-math.sin(a), 15), round(math.cos(a), 15), 0.0]
+    cx, cy = ws / 2, hs / 2
+    m[2] = m[0] * (-cx) + m[1] * (-cy) + m[2]
+    m[5] = m[3] * (-cx) + m[4] * (-cy) + m[5]
+    m[2] += cx
+    m[5] += cy
+    return m
+
+
+def pil_rotate_bilinear(img_u8, angle: float):
+    """``Image.rotate(angle, BILINEAR, expand=False, fillcolor=0)`` of an 8-bit image (Geometry.c: ImagingGenericTransform
+    with ``affine_transform`` -- xin = a0 (x + .5) + a1 (y + .5) + a2 in doubles -- and ``bilinear_filter8``: 0 outside
+    [0, w) x [0, h), neighbours clipped to the image, value truncated to 8 bits).  angle % 360 == 0 is PIL's copy."""
+    import numpy as np
+    hs, ws = img_u8.shape
+    if angle % 360.0 == 0.0:
+        return img_u8.copy()
+    m = pil_rotate_matrix(angle, ws, hs)
+    yy, xx = np.meshgrid(np.arange(hs, dtype=np.float64) + 0.5, np.arange(ws, dtype=np.float64) + 0.5, indexing="ij")
+    xin = m[0] * xx + m[1] * yy + m[2]
+    yin = m[3] * xx + m[4] * yy + m[5]
+    return pil_bilinear_sample(img_u8, xin, yin)
+
+
+def pil_bilinear_sample(img_u8, xin, yin):
+    """``bilinear_filter8`` (Geometry.c) at double coordinates (arrays): -> uint8 array, 0 where the point is outside"""
+    import numpy as np
+    hs, ws = img_u8.shape
+    inside = (xin >= 0.0) & (xin < ws) & (yin >= 0.0) & (yin < hs)
+    xs, ys = xin - 0.5, yin - 0.5
+    x = np.where(xs < 0.0, np.floor(xs), np.trunc(xs)).astype(np.int64)  # FLOOR(v): floor below zero, (int) above
+    y = np.where(ys < 0.0, np.floor(ys), np.trunc(ys)).astype(np.int64)
+    dx, dy = xs - x, ys - y
+    img = img_u8.astype(np.float64)
+    x0, x1 = np.clip(x, 0, ws - 1), np.clip(x + 1, 0, ws - 1)
+    yc = np.clip(y, 0, hs - 1)
+    r0a, r0b = img[yc, x0], img[yc, x1]
+    v1 = r0a + (r0b - r0a) * dx
+    has2 = (y + 1 >= 0) & (y + 1 < hs)
+    y1 = np.clip(y + 1, 0, hs - 1)
+    r1a, r1b = img[y1, x0], img[y1, x1]
+    v2 = np.where(has2, r1a + (r1b - r1a) * dx, v1)
+    v = v1 + (v2 - v1) * dy
+    return np.where(inside, v.astype(np.int64), 0).astype(np.uint8)  # (UINT8) v1: truncation
+
+
+def pil_resize_bilinear(img_u8, out_hw):
+    """``Image.resize((ow, oh), BILINEAR)`` of an 8-bit image (Resample.c): per axis a triangle filter whose support grows
+    with the down-scaling factor, coefficients normalised in double and rounded to 22 fractional bits, horizontal pass then
+    vertical pass with an 8-bit intermediate; accumulators start at 2^21 and are shifted (clip8)."""
+    import numpy as np
+    PREC = 32 - 8 - 2
+
+    def coeffs(in_size, out_size):
+        scale = in_size / out_size
+        fscale = max(scale, 1.0)
+        support = 1.0 * fscale
+        ksize = int(math.ceil(support)) * 2 + 1
+        bounds, kk = [], np.zeros((out_size, ksize), dtype=np.int64)
+        for xx in range(out_size):
+            center = (xx + 0.5) * scale
+            ss = 1.0 / fscale
+            xmin = max(int(center - support + 0.5), 0)
+            xmax = min(int(center + support + 0.5), in_size) - xmin
+            w = []
+            for x in range(xmax):
+                t = (x + xmin - center + 0.5) * ss
+                t = -t if t < 0.0 else t
+                w.append(1.0 - t if t < 1.0 else 0.0)
+            ww = sum(w)  # (left to right, as the C loop)
+            for x in range(xmax):
+                v = w[x] / ww if ww != 0.0 else w[x]
+                kk[xx, x] = int(-0.5 + v * (1 << PREC)) if v < 0 else int(0.5 + v * (1 << PREC))
+            bounds.append((xmin, xmax))
+        return bounds, kk
+
+    def clip8(v):
+        return np.clip(v >> PREC, 0, 255)
+
+    hs, ws = img_u8.shape
+    oh, ow = out_hw
+    cur = img_u8.astype(np.int64)
+    if ow != ws:
+        b, kk = coeffs(ws, ow)
+        nxt = np.zeros((hs, ow), dtype=np.int64)
+        for xx, (xmin, xmax) in enumerate(b):
+            nxt[:, xx] = clip8((1 << (PREC - 1)) + (cur[:, xmin:xmin + xmax] * kk[xx, :xmax][None, :]).sum(1))
+        cur = nxt
+    if oh != hs:
+        b, kk = coeffs(hs, oh)
+        nxt = np.zeros((oh, cur.shape[1]), dtype=np.int64)
+        for yy, (ymin, ymax) in enumerate(b):
+            nxt[yy, :] = clip8((1 << (PREC - 1)) + (cur[ymin:ymin + ymax, :] * kk[yy, :ymax][:, None]).sum(0))
+        cur = nxt
+    return cur.astype(np.uint8)
+
+
+def resize_shorter_edge(hw, size: int):
+    """torchvision ``Resize(int)``: the shorter edge becomes ``size``, the other keeps the aspect ratio (int())"""
+    h, w = hw
+    if (w <= h and w == size) or (h <= w and h == size):
+        return h, w
+    if w < h:
+        return int(size * h / w), size
+    return size, int(size * w / h)
+
+
+def pil_rotate_nearest(img_u8, angle: float):
+    """``Image.rotate(angle, NEAREST, expand=False, fillcolor=0)`` (Geometry.c affine_fixed, as ``augment_view_pil``)"""
+    import numpy as np
+    hs, ws = img_u8.shape
+    a0, a1, a2, a3, a4, a5 = pil_affine_q16(angle, ws, hs)
+    yy, xx = np.meshgrid(np.arange(hs, dtype=np.int64), np.arange(ws, dtype=np.int64), indexing="ij")
+    xin, yin = (a2 + xx * a0 + yy * a1) >> 16, (a5 + xx * a3 + yy * a4) >> 16
+    ok = (xin >= 0) & (xin < ws) & (yin >= 0) & (yin < hs)
+    return np.where(ok, img_u8[np.clip(yin, 0, hs - 1), np.clip(xin, 0, ws - 1)], 0).astype(np.uint8)
+
+
+def pil_color_jitter(u8, b, c, contrast_first):
+    """ImageEnhance.Brightness / .Contrast on an 8-bit image in the drawn order (``augment_view_pil``'s blends)"""
+    import numpy as np
+    b, c = np.float32(b), np.float32(c)
+    u = u8.astype(np.int64)
+
+    def blend(in1, in2, alpha):
+        t = in1.astype(np.float32) + alpha * (in2 - in1).astype(np.float32)
+        if np.float32(0) <= alpha <= np.float32(1):
+            return t.astype(np.int64)
+        return np.where(t <= 0, 0, np.where(t >= 255, 255, t.astype(np.int64)))
+
+    def brightness(u):
+        return blend(np.zeros_like(u), u, b)
+
+    def contrast(u):
+        mean = (2 * int(u.sum()) + u.size) // (2 * u.size)
+        return blend(np.full_like(u, mean), u, c)
+
+    u = brightness(contrast(u)) if contrast_first else contrast(brightness(u))
+    return u.astype(np.uint8)
+
+
+def recipe_view(img_u8, label_u8, out_hw, *, angle=0.0, vflip=False, hflip=False, top=0, left=0, pad=0, crop_first=False,
+                brightness=1.0, contrast=1.0, contrast_first=False):
+    """One view of a reference recipe, operation by operation as torchvision / PIL execute it on 8-bit images (image:
+    BILINEAR rotation, label map: NEAREST -- contrastyou/augment/synchronize.py:95-103):
+      crop_first=False  rotate -> vflip -> hflip -> pad (zeros) -> crop -> jitter     (`pretrain`, semi_seg/augment.py:6-22,54-69)
+      crop_first=True   crop -> rotate the crop                                      (`label`, :23-34; CenterCrop `val` with angle 0)
+    -> (uint8 image view, uint8 label view or None)"""
+    import numpy as np
+    oh, ow = out_hw
+
+    def geometry(a, rotate):
+        if crop_first:
+            a = a[top:top + oh, left:left + ow]
+            return rotate(a, angle)
+        a = rotate(a, angle)
+        if vflip:
+            a = a[::-1, :]
+        if hflip:
+            a = a[:, ::-1]
+        if pad:
+            a = np.pad(a, pad, mode="constant")
+        return a[top:top + oh, left:left + ow]
+
+    img = geometry(np.ascontiguousarray(img_u8), lambda a, ang: pil_rotate_bilinear(np.ascontiguousarray(a), ang))
+    img = pil_color_jitter(np.ascontiguousarray(img), brightness, contrast, contrast_first)
+    lab = None
+    if label_u8 is not None:
+        lab = np.ascontiguousarray(geometry(np.ascontiguousarray(label_u8), lambda a, ang: pil_rotate_nearest(np.ascontiguousarray(a), ang)))
+    return img, lab

@@ -198,9 +198,173 @@ __global__ __launch_bounds__(1024) void augment_views_pil_kernel(const float* __
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The reference's OTHER recipes in PIL's arithmetic (semi_seg/augment.py:23-37 ACDC `label` / `val`, :54-75 Prostate
+// `pretrain` / `label` / `val`), and the interpolation its wrapper really selects: contrastyou/augment/synchronize.py:95-103
+// runs the common transform with BILINEAR on images and NEAREST on targets, so an image is rotated by
+// Image.rotate(angle, BILINEAR) -- Geometry.c ImagingGenericTransform: affine_transform in doubles, bilinear_filter8 -- and
+// its label map by the fixed-point nearest loop above.  One view per workgroup, params[v][28]:
+//   [0] slice  [1] flags (1 hflip, 2 vflip, 4 contrast before brightness, 8 bilinear image rotation, 16 crop FIRST: the
+//   rotation turns the OH x OW crop about its own centre -- the `label` recipes: RandomCrop, then RandomRotation)
+//   [2] top [3] left: the crop's offsets -- in the padded, rotated + flipped image, or (crop first) in the slice
+//   [4] pad (RandomCrop(padding=), zeros)  [5] brightness, [6] contrast (f32 bits; 1.0 = the identity, exactly)
+//   [8..13] the 16.16 nearest coefficients  [14..25] the six doubles of the rotation matrix (bilinear)
+// Both are computed on the host exactly as PIL computes them (semi_seg/data/augment.py), for the image the rotation acts
+// on: the whole slice, or the crop.  `labels` / `label_out` (optional): the slice's 8-bit label map through the same
+// geometry with NEAREST, written as int64 (pil_augment.ToLabel).
+constexpr int RECIPE_W = 28;
+__global__ __launch_bounds__(1024) void augment_views_recipe_kernel(const float* __restrict__ src,
+                                                                    const unsigned char* __restrict__ labels, int S, int HS,
+                                                                    int WS, const int* __restrict__ params,
+                                                                    float* __restrict__ out, long long* __restrict__ label_out,
+                                                                    int OH, int OW) {
+  __shared__ int red[16];
+  const int v = blockIdx.x;
+  const int* pr = params + v * RECIPE_W;
+  const int slice = pr[0], flags = pr[1], top = pr[2], left = pr[3], pad = pr[4];
+  const float b = __int_as_float(pr[5]), c = __int_as_float(pr[6]);
+  const int a0 = pr[8], a1 = pr[9], a2 = pr[10], a3 = pr[11], a4 = pr[12], a5 = pr[13];
+  double m[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+    m[k] = __hiloint2double(pr[14 + 2 * k + 1], pr[14 + 2 * k]);  // (little endian: low word first)
+  const bool b_in = b >= 0.f && b <= 1.f, c_in = c >= 0.f && c <= 1.f;
+  const bool contrast_first = flags & 4, bilinear = flags & 8, crop_first = flags & 16;
+  const float* img = src + (size_t)slice * HS * WS;
+  const unsigned char* lab = labels != nullptr ? labels + (size_t)slice * HS * WS : nullptr;
+  // the image the rotation acts on: the slice, or its crop (a window of it)
+  const int wx0 = crop_first ? left : 0, wy0 = crop_first ? top : 0, ww = crop_first ? OW : WS, wh = crop_first ? OH : HS;
+  auto level = [&](int xc, int yc) -> int {  // 8-bit grey level of window pixel (xc, yc)
+    return (int)__fadd_rn(__fmul_rn(img[(size_t)(wy0 + yc) * WS + wx0 + xc], 255.f), 0.5f);
+  };
+  // (x, y): the pixel of the ROTATED window this output pixel shows, or none
+  auto locate = [&](int p, int& x, int& y) -> bool {
+    const int i = p / OW, j = p - i * OW;
+    if (crop_first) { x = j; y = i; return true; }
+    y = i + top - pad;
+    x = j + left - pad;
+    if (x < 0 || x >= WS || y < 0 || y >= HS) return false;  // the zero padding of RandomCrop(padding=)
+    if (flags & 1) x = WS - 1 - x;
+    if (flags & 2) y = HS - 1 - y;
+    return true;
+  };
+  auto sample = [&](int p) -> int {
+    int x, y;
+    if (!locate(p, x, y)) return 0;
+    if (!bilinear) {
+      const int xin = (a2 + x * a0 + y * a1) >> 16, yin = (a5 + x * a3 + y * a4) >> 16;
+      return (xin >= 0 && xin < ww && yin >= 0 && yin < wh) ? level(xin, yin) : 0;
+    }
+    // affine_transform + bilinear_filter8 (Geometry.c), every product and sum rounded on its own as the C doubles are
+    const double xc = (double)x + 0.5, yc = (double)y + 0.5;
+    double xin = __dadd_rn(__dadd_rn(__dmul_rn(m[0], xc), __dmul_rn(m[1], yc)), m[2]);
+    double yin = __dadd_rn(__dadd_rn(__dmul_rn(m[3], xc), __dmul_rn(m[4], yc)), m[5]);
+    if (xin < 0.0 || xin >= (double)ww || yin < 0.0 || yin >= (double)wh) return 0;
+    xin -= 0.5;
+    yin -= 0.5;
+    const int xf = xin < 0.0 ? (int)floor(xin) : (int)xin, yf = yin < 0.0 ? (int)floor(yin) : (int)yin;
+    const double dx = xin - (double)xf, dy = yin - (double)yf;
+    const int x0 = min(max(xf, 0), ww - 1), x1 = min(max(xf + 1, 0), ww - 1), y0 = min(max(yf, 0), wh - 1);
+    const double p00 = (double)level(x0, y0), p01 = (double)level(x1, y0);
+    double v1 = __dadd_rn(p00, __dmul_rn(__dsub_rn(p01, p00), dx));
+    double v2 = v1;
+    if (yf + 1 >= 0 && yf + 1 < wh) {
+      const double p10 = (double)level(x0, yf + 1), p11 = (double)level(x1, yf + 1);
+      v2 = __dadd_rn(p10, __dmul_rn(__dsub_rn(p11, p10), dx));
+    }
+    v1 = __dadd_rn(v1, __dmul_rn(__dsub_rn(v2, v1), dy));
+    return (int)v1;  // (UINT8) of a value inside [0, 255]
+  };
+  const int np = OH * OW;
+  int part = 0;
+  for (int p = threadIdx.x; p < np; p += 1024) {
+    int u = sample(p);
+    if (!contrast_first) u = pil_blend(0, u, b, b_in);
+    part += u;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+  __syncthreads();
+  long long total = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) total += red[w];
+  const int mean = (int)((2 * total + np) / (2LL * np));  // int(sum / count + 0.5), exactly
+  float* o = out + (size_t)v * np;
+  for (int p = threadIdx.x; p < np; p += 1024) {
+    int u = sample(p);
+    if (!contrast_first) u = pil_blend(0, u, b, b_in);
+    u = pil_blend(mean, u, c, c_in);
+    if (contrast_first) u = pil_blend(0, u, b, b_in);
+    o[p] = __fdiv_rn((float)u, 255.f);
+    if (label_out != nullptr) {  // the label map through the same geometry, NEAREST
+      int x, y, lv = 0;
+      if (locate(p, x, y)) {
+        const int xin = (a2 + x * a0 + y * a1) >> 16, yin = (a5 + x * a3 + y * a4) >> 16;
+        if (xin >= 0 && xin < ww && yin >= 0 && yin < wh) lv = lab[(size_t)(wy0 + yin) * WS + wx0 + xin];
+      }
+      label_out[(size_t)v * np + p] = lv;
+    }
+  }
+}
+
+// Image.resize((OW, OH), BILINEAR) of 8-bit images (Resample.c; torchvision Resize, semi_seg/augment.py:56,71,79): one pass
+// along x, one along y, each with the per-output coefficient rows the host precomputed exactly as precompute_coeffs /
+// normalize_coeffs_8bpc do (kk: 22 fractional bits, bounds: first tap / tap count), an 8-bit intermediate between them.
+// Applied ONCE when a store is built (the transform is deterministic), not per view.
+__global__ __launch_bounds__(256) void resize_pass_kernel(const float* __restrict__ src, int n_lines, int in_len, int out_len,
+                                                         int line_stride_in, int elem_stride_in, int line_stride_out,
+                                                         int elem_stride_out, size_t img_stride_in, size_t img_stride_out,
+                                                         const int* __restrict__ bounds, const int* __restrict__ kk, int ksize,
+                                                         float* __restrict__ dst) {
+  const int img = blockIdx.y;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)n_lines * out_len) return;
+  const int line = (int)(idx / out_len), xx = (int)(idx - (size_t)line * out_len);
+  const int xmin = bounds[2 * xx], xmax = bounds[2 * xx + 1];
+  const float* in = src + img * img_stride_in + (size_t)line * line_stride_in;
+  long long ss = 1LL << 21;
+  for (int x = 0; x < xmax; ++x) {
+    const int lvl = (int)__fadd_rn(__fmul_rn(in[(size_t)(x + xmin) * elem_stride_in], 255.f), 0.5f);
+    ss += (long long)lvl * kk[(size_t)xx * ksize + x];
+  }
+  long long q = ss >> 22;
+  q = q < 0 ? 0 : (q > 255 ? 255 : q);
+  dst[img * img_stride_out + (size_t)line * line_stride_out + (size_t)xx * elem_stride_out] = __fdiv_rn((float)q, 255.f);
+}
+
 }  // namespace spcl
 
 using namespace spcl;
+
+extern "C" int spcl_augment_views_recipe(const float* src, const unsigned char* labels, int S, int HS, int WS,
+                                         const int* params, int nviews, float* out, long long* label_out, int OH, int OW,
+                                         int max_pad, void* stream) {
+  SPCL_CHECK_ARG(src && params && out, "augment_views_recipe: null pointer");
+  SPCL_CHECK_ARG((labels != nullptr) == (label_out != nullptr), "augment_views_recipe: labels come with label_out");
+  SPCL_CHECK_ARG(S > 0 && HS > 0 && WS > 0 && nviews > 0 && OH > 0 && OW > 0 && max_pad >= 0 && OH <= HS + 2 * max_pad &&
+                     OW <= WS + 2 * max_pad && HS <= 4096 && WS <= 4096,
+                 "augment_views_recipe: bad shape (crop %dx%d of %dx%d + %d)", OH, OW, HS, WS, max_pad);
+  SPCL_LAUNCH(augment_views_recipe_kernel, dim3(nviews), dim3(1024), 0, (hipStream_t)stream, src, labels, S, HS, WS, params, out,
+              label_out, OH, OW);
+  SPCL_LAUNCH_CHECK("augment_views_recipe");
+  return SPCL_OK;
+}
+
+extern "C" int spcl_resize_bilinear_pil(const float* src, int S, int HS, int WS, const int* bounds_x, const int* kk_x,
+                                        int ksize_x, const int* bounds_y, const int* kk_y, int ksize_y, float* tmp, float* out,
+                                        int OH, int OW, void* stream) {
+  SPCL_CHECK_ARG(src && bounds_x && kk_x && bounds_y && kk_y && tmp && out, "resize_bilinear_pil: null pointer");
+  SPCL_CHECK_ARG(S > 0 && HS > 0 && WS > 0 && OH > 0 && OW > 0 && ksize_x > 0 && ksize_y > 0, "resize_bilinear_pil: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  // horizontal: [S][HS][WS] -> tmp [S][HS][OW]; vertical: tmp -> out [S][OH][OW]
+  SPCL_LAUNCH(resize_pass_kernel, dim3((unsigned)(((size_t)HS * OW + 255) / 256), S), dim3(256), 0, st, src, HS, WS, OW, WS, 1, OW,
+              1, (size_t)HS * WS, (size_t)HS * OW, bounds_x, kk_x, ksize_x, tmp);
+  SPCL_LAUNCH(resize_pass_kernel, dim3((unsigned)(((size_t)OW * OH + 255) / 256), S), dim3(256), 0, st, (const float*)tmp, OW, HS,
+              OH, 1, OW, 1, OW, (size_t)HS * OW, (size_t)OH * OW, bounds_y, kk_y, ksize_y, out);
+  SPCL_LAUNCH_CHECK("resize_bilinear_pil");
+  return SPCL_OK;
+}
 
 extern "C" int spcl_augment_views_pil(const float* src, int S, int HS, int WS, const int* params, int nviews, float* out,
                                       int OH, int OW, void* stream) {

@@ -146,6 +146,8 @@ _SIGNATURES = {
     "spcl_concat2_channels": (c_int, [_P, _P, _P, c_int, c_size_t, c_int, c_int, _P]),
     "spcl_split2_channels": (c_int, [_P, _P, _P, c_int, c_size_t, c_int, c_int, _P]),
     "spcl_augment_views": (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int, _P]),
+    "spcl_augment_views_recipe": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, c_int, c_int, _P]),
+    "spcl_resize_bilinear_pil": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, _P, _P, c_int, _P, _P, c_int, c_int, _P]),
     "spcl_augment_views_pil": (c_int, [_P, c_int, c_int, c_int, _P, c_int, _P, c_int, c_int, _P]),
     "spcl_flip_batch": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "spcl_flip_pair": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),

@@ -4,5 +4,6 @@ as one HIP launch per batch instead of PIL in DataLoader workers."""
 from .rearr import ContrastBatchSampler, ContrastDataset  # noqa: F401
 from .dataset import (ACDCSliceStore, DeviceSliceStore, ProstateSliceStore, acdc_partition, prostate_partition,  # noqa: F401
                       synthetic_slice_store)
-from .augment import PretrainViews, draw_view_params  # noqa: F401
-from .loader import ContrastiveDeviceLoader, InfiniteRandomSampler, get_contrastive_dataloader  # noqa: F401
+from .augment import RECIPES, PretrainViews, RecipeViews, draw_view_params, resize_store  # noqa: F401
+from .loader import (ContrastiveDeviceLoader, InfiniteRandomSampler, LabeledDeviceLoader,  # noqa: F401
+                     get_contrastive_dataloader)

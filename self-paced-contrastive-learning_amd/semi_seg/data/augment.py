@@ -80,6 +80,192 @@ def draw_view_params_pil(slice_index: int, src_hw, out_hw, *, degrees=45.0, brig
     return [slice_index] + pil_affine_q16(angle, ws, hs) + [flags, top, left, _f32_bits(b), _f32_bits(c)]
 
 
+# ---- round 5: every recipe of semi_seg/augment.py, with the interpolation the reference's wrapper selects
+# (contrastyou/augment/synchronize.py:95-103: BILINEAR on images, NEAREST on targets) -- spcl_augment_views_recipe
+RECIPE_W = 28
+RECIPES = {
+    # ACDCStrongTransforms.pretrain (semi_seg/augment.py:6-22)
+    "acdc_pretrain": dict(degrees=45.0, flips=True, pad=0, crop_first=False, brightness=(0.5, 1.5), contrast=(0.5, 1.5), resize=None),
+    # ProstateStrongTransforms.pretrain (:54-69): Resize(224) happens once, when the store is built (``resize_store``)
+    "prostate_pretrain": dict(degrees=10.0, flips=True, pad=20, crop_first=False, brightness=(0.9, 1.1), contrast=(0.9, 1.1),
+                              resize=224),
+    # ACDCStrongTransforms.label (:23-34): RandomCrop(224), THEN RandomRotation(30) of the crop; no colour jitter
+    "acdc_label": dict(degrees=30.0, flips=False, pad=0, crop_first=True, brightness=None, contrast=None, resize=None),
+    # ProstateStrongTransforms.label (:70-80): Resize(224), RandomCrop(224)
+    "prostate_label": dict(degrees=0.0, flips=False, pad=0, crop_first=True, brightness=None, contrast=None, resize=224),
+}
+
+
+def pil_rotate_matrix(angle: float, ws: int, hs: int):
+    """the six doubles ``Image.rotate(angle)`` hands its transform (PIL/Image.py): what the bilinear rotation works with"""
+    a = -math.radians(angle % 360.0)
+    m = [round(math.cos(a), 15), round(math.sin(a), 15), 0.0, round(-math.sin(a), 15), round(math.cos(a), 15), 0.0]
+    cx, cy = ws / 2, hs / 2
+    m[2] = m[0] * (-cx) + m[1] * (-cy) + m[2]
+    m[5] = m[3] * (-cx) + m[4] * (-cy) + m[5]
+    m[2] += cx
+    m[5] += cy
+    return m
+
+
+def _f64_words(x: float):
+    lo, hi = struct.unpack("<ii", struct.pack("<d", x))
+    return [lo, hi]
+
+
+def recipe_row(slice_index, src_hw, out_hw, *, angle=0.0, vflip=False, hflip=False, top=0, left=0, pad=0, crop_first=False,
+               brightness=1.0, contrast=1.0, contrast_first=False, bilinear=True):
+    """one parameter row of ``spcl_augment_views_recipe`` (28 ints) from the drawn values"""
+    (hs, ws), (oh, ow) = src_hw, out_hw
+    rw, rh = (ow, oh) if crop_first else (ws, hs)  # the image the rotation acts on
+    flags = (1 if hflip else 0) | (2 if vflip else 0) | (4 if contrast_first else 0) | (8 if bilinear else 0) | (16 if crop_first else 0)
+    row = [slice_index, flags, int(top), int(left), int(pad), _f32_bits(float(brightness)), _f32_bits(float(contrast)), 0]
+    row += pil_affine_q16(angle, rw, rh)
+    for v in pil_rotate_matrix(angle, rw, rh):
+        row += _f64_words(v)
+    row += [0] * (RECIPE_W - len(row))
+    return row
+
+
+def draw_recipe_params(slice_index, src_hw, out_hw, recipe, rng=random):
+    """the random draws of one view in the order torchvision makes them for the recipe's common transform, then the jitter"""
+    (hs, ws), (oh, ow) = src_hw, out_hw
+    r = recipe
+    pad = int(r["pad"])
+
+    def crop():
+        return rng.randint(0, hs + 2 * pad - oh), rng.randint(0, ws + 2 * pad - ow)
+    if r["crop_first"]:
+        top, left = crop()
+        angle = rng.uniform(-r["degrees"], r["degrees"]) if r["degrees"] else 0.0
+        vflip = hflip = False
+    else:
+        angle = rng.uniform(-r["degrees"], r["degrees"]) if r["degrees"] else 0.0
+        vflip = bool(r["flips"] and rng.random() < 0.5)
+        hflip = bool(r["flips"] and rng.random() < 0.5)
+        top, left = crop()
+    b = rng.uniform(*r["brightness"]) if r["brightness"] else 1.0
+    c = rng.uniform(*r["contrast"]) if r["contrast"] else 1.0
+    cf = bool(r["brightness"] and rng.random() < 0.5)
+    return recipe_row(slice_index, src_hw, out_hw, angle=angle, vflip=vflip, hflip=hflip, top=top, left=left, pad=pad,
+                      crop_first=r["crop_first"], brightness=b, contrast=c, contrast_first=cf, bilinear=True)
+
+
+def center_crop_row(slice_index, src_hw, out_hw):
+    """``CenterCrop`` (the `val` transform, semi_seg/augment.py:35-37): torchvision's int(round((h - oh) / 2.0)) offsets"""
+    (hs, ws), (oh, ow) = src_hw, out_hw
+    return recipe_row(slice_index, src_hw, out_hw, top=int(round((hs - oh) / 2.0)), left=int(round((ws - ow) / 2.0)),
+                      crop_first=True, bilinear=False)
+
+
+def resize_coeffs(in_size: int, out_size: int):
+    """Resample.c ``precompute_coeffs`` + ``normalize_coeffs_8bpc`` for the bilinear filter -> (bounds [out][2], kk [out][ksize])"""
+    scale = in_size / out_size
+    fscale = max(scale, 1.0)
+    support = 1.0 * fscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds, kk = [], []
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        ss = 1.0 / fscale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = []
+        for x in range(xmax):
+            t = (x + xmin - center + 0.5) * ss
+            t = -t if t < 0.0 else t
+            w.append(1.0 - t if t < 1.0 else 0.0)
+        ww = 0.0
+        for v in w:
+            ww += v
+        row = [0] * ksize
+        for x in range(xmax):
+            v = w[x] / ww if ww != 0.0 else w[x]
+            row[x] = int(-0.5 + v * (1 << 22)) if v < 0 else int(0.5 + v * (1 << 22))
+        bounds.append([xmin, xmax])
+        kk.append(row)
+    return bounds, kk, ksize
+
+
+def resize_shorter_edge(hw, size: int):
+    """torchvision ``Resize(int)``: the shorter edge becomes ``size``, the other keeps the aspect ratio"""
+    h, w = hw
+    if (w <= h and w == size) or (h <= w and h == size):
+        return h, w
+    if w < h:
+        return int(size * h / w), size
+    return size, int(size * w / h)
+
+
+def resize_store(images: torch.Tensor, size: int) -> torch.Tensor:
+    """``transforms.Resize(size)`` (bilinear, PIL's arithmetic) of every slice of an 8-bit store [S, H, W] -> [S, oh, ow]"""
+    _n.require_gpu(images)
+    S, HS, WS = images.shape
+    oh, ow = resize_shorter_edge((HS, WS), size)
+    if (oh, ow) == (HS, WS):
+        return images
+    bx, kx, ksx = resize_coeffs(WS, ow)
+    by, ky, ksy = resize_coeffs(HS, oh)
+    dev = images.device
+    t = lambda a: torch.tensor(a, dtype=torch.int32).to(dev)  # noqa: E731
+    tbx, tkx, tby, tky = t(bx), t(kx), t(by), t(ky)
+    tmp = torch.empty(S, HS, ow, dtype=torch.float32, device=dev)
+    out = torch.empty(S, oh, ow, dtype=torch.float32, device=dev)
+    src = images.float().contiguous()
+    _n.call("spcl_resize_bilinear_pil", _n.ptr(src), S, HS, WS, _n.ptr(tbx), _n.ptr(tkx), ksx, _n.ptr(tby), _n.ptr(tky), ksy,
+            _n.ptr(tmp), _n.ptr(out), oh, ow, _n.stream())
+    return out
+
+
+class RecipeViews:
+    """views of a device store by one of ``RECIPES`` (or a dict of the same keys): ``pairs(indices)`` -> two INDEPENDENT
+    views per slice (SequentialWrapperTwice(total_freedom=True): the pre-train recipes); ``labelled(indices)`` -> ONE geometry
+    per slice applied to image (bilinear) and label map (nearest) -- the `label` recipes, whose two returned versions share
+    the common seed and have no image-only randomness: they are the same tensors twice."""
+
+    def __init__(self, images: torch.Tensor, recipe="acdc_pretrain", out_hw=(224, 224), labels: torch.Tensor = None):
+        _n.require_gpu(images)
+        self.recipe = dict(RECIPES[recipe]) if isinstance(recipe, str) else dict(recipe)
+        if self.recipe.get("resize"):
+            images = resize_store(images, int(self.recipe["resize"]))
+            if labels is not None:
+                raise NotImplementedError("label maps are resized with NEAREST by the reference: resize them before building the store")
+        self.images, self.out_hw = images.float().contiguous(), tuple(out_hw)
+        self.labels = labels.to(torch.uint8).contiguous() if labels is not None else None
+
+    def rows(self, indices: Sequence[int], rng=random):
+        hw = tuple(self.images.shape[1:])
+        return [draw_recipe_params(i, hw, self.out_hw, self.recipe, rng) for i in indices]
+
+    def apply(self, rows, with_labels=False):
+        S, HS, WS = self.images.shape
+        oh, ow = self.out_hw
+        dev = self.images.device
+        p = torch.tensor(rows, dtype=torch.int32).to(dev, non_blocking=True)
+        out = torch.empty(len(rows), 1, oh, ow, dtype=torch.float32, device=dev)
+        lab_out = torch.empty(len(rows), 1, oh, ow, dtype=torch.int64, device=dev) if with_labels else None
+        _n.call("spcl_augment_views_recipe", _n.ptr(self.images), _n.ptr(self.labels) if with_labels else None, S, HS, WS,
+                _n.ptr(p), len(rows), _n.ptr(out), _n.ptr(lab_out), oh, ow, int(self.recipe["pad"]), _n.stream())
+        return (out, lab_out) if with_labels else out
+
+    def pairs(self, indices: Sequence[int], rng=random):
+        both = self.apply(self.rows(indices, rng) + self.rows(indices, rng))
+        n = len(indices)
+        return both[:n], both[n:]
+
+    __call__ = pairs
+
+    def labelled(self, indices: Sequence[int], rng=random):
+        assert self.labels is not None, "RecipeViews.labelled needs the store's label maps"
+        return self.apply(self.rows(indices, rng), with_labels=True)
+
+    def val(self, indices: Sequence[int]):
+        """``CenterCrop(out_hw)`` of image (and label map when the store has one): the reference's `val` transform"""
+        hw = tuple(self.images.shape[1:])
+        rows = [center_crop_row(i, hw, self.out_hw) for i in indices]
+        return self.apply(rows, with_labels=self.labels is not None)
+
+
 class PretrainViews:
     """``images`` [S,H,W] device store -> two views [B,1,oh,ow] each for a list of slice indices"""
 

@@ -88,25 +88,41 @@ class DeviceSliceStore(ContrastDataset):
 
     @classmethod
     def from_folder(cls, root: str, device="cuda", size: Optional[int] = None):
-        """PNG folder ``root/img/*.png`` (the reference's layout) -> store; slices are centre-padded / cropped to one size"""
+        """PNG folder ``root/img/*.png`` (+ ``root/gt/*.png`` label maps of the same stems when present: the reference's layout,
+        contrastyou/data/dataset/base.py:76-140 ``sub_folders``) -> store.  Slices are centre-padded / cropped to ONE size (the
+        store is one tensor); grey levels are kept as k / 255, label maps as uint8 class codes.  ``<name>_info.npy`` (scan ->
+        number of slices) is read when it lies next to the folders (semi_seg/data/dataset.py:28-31)."""
         from PIL import Image
         import numpy as np
         files = sorted(f for f in os.listdir(os.path.join(root, "img")) if f.lower().endswith(".png"))
-        arrs = [np.asarray(Image.open(os.path.join(root, "img", f)).convert("L"), dtype=np.float32) / 255.0 for f in files]
+        arrs = [np.asarray(Image.open(os.path.join(root, "img", f)).convert("L"), dtype=np.uint8) for f in files]
+        gt_dir = os.path.join(root, "gt")
+        gts = None
+        if os.path.isdir(gt_dir):
+            missing = [f for f in files if not os.path.exists(os.path.join(gt_dir, f))]
+            if missing:
+                raise FileNotFoundError(f"label maps missing for {len(missing)} slices, e.g. {missing[0]}")
+            gts = [np.asarray(Image.open(os.path.join(gt_dir, f)).convert("L"), dtype=np.uint8) for f in files]
+            assert all(a.shape == g.shape for a, g in zip(arrs, gts)), "a slice and its label map differ in size"
         size = size or max(max(a.shape) for a in arrs)
-        out = torch.zeros(len(arrs), size, size)
-        for k, a in enumerate(arrs):
-            h, w = a.shape
-            t = torch.from_numpy(a)[max(0, (h - size) // 2):max(0, (h - size) // 2) + size,
-                                    max(0, (w - size) // 2):max(0, (w - size) // 2) + size]
-            oy, ox = (size - t.shape[0]) // 2, (size - t.shape[1]) // 2
-            out[k, oy:oy + t.shape[0], ox:ox + t.shape[1]] = t
+
+        def centred(list_of_arrays, dtype):
+            out = torch.zeros(len(list_of_arrays), size, size, dtype=dtype)
+            for k, a in enumerate(list_of_arrays):
+                h, w = a.shape
+                t = torch.from_numpy(np.ascontiguousarray(a))[max(0, (h - size) // 2):max(0, (h - size) // 2) + size,
+                                                              max(0, (w - size) // 2):max(0, (w - size) // 2) + size]
+                oy, ox = (size - t.shape[0]) // 2, (size - t.shape[1]) // 2
+                out[k, oy:oy + t.shape[0], ox:ox + t.shape[1]] = t.to(dtype)
+            return out
+        images = centred(arrs, torch.float32) / 255.0
+        targets = centred(gts, torch.uint8) if gts is not None else None
         info = None
         for name in ("acdc_info.npy", "prostate_info.npy"):
             p = os.path.join(root, name)
             if os.path.exists(p):
                 info = np.load(p, allow_pickle=True).item()
-        return cls(out.to(device), files, info)
+        return cls(images.to(device), files, info, targets=targets.to(device) if targets is not None else None)
 
 
 class ACDCSliceStore(DeviceSliceStore):

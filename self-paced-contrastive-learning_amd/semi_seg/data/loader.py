@@ -7,7 +7,7 @@ from typing import Iterator
 
 import torch
 
-from .augment import PretrainViews
+from .augment import RECIPES, PretrainViews, RecipeViews
 from .rearr import ContrastBatchSampler
 
 
@@ -28,9 +28,19 @@ class InfiniteRandomSampler:
 class ContrastiveDeviceLoader:
     """infinite iterator of device batches"""
 
-    def __init__(self, store, *, batch_sampler=None, sampler=None, batch_size=None, out_hw=(224, 224), **recipe):
+    def __init__(self, store, *, batch_sampler=None, sampler=None, batch_size=None, out_hw=(224, 224), recipe=None,
+                 **legacy_recipe):
+        """``recipe``: a key of ``augment.RECIPES`` (default: the store's own pre-train recipe -- ACDCStrongTransforms.pretrain /
+        ProstateStrongTransforms.pretrain, semi_seg/augment.py:6-22,54-69, images rotated with BILINEAR as the reference's
+        wrapper selects) or a dict of the same keys; ``legacy_recipe`` keywords (``pil_exact=``, ``degrees=`` ...) select the
+        round-4 ``PretrainViews`` (nearest image rotation) instead."""
         assert (batch_sampler is None) != (sampler is None)
-        self.dataset, self._views = store, PretrainViews(store.images, out_hw, **recipe)
+        self.dataset = store
+        if legacy_recipe:
+            self._views = PretrainViews(store.images, out_hw, **legacy_recipe)
+        else:
+            name = recipe or ("prostate_pretrain" if getattr(store, "data_name", "acdc") == "prostate" else "acdc_pretrain")
+            self._views = RecipeViews(store.images, name, out_hw)
         self._batch_sampler, self._sampler, self._batch_size = batch_sampler, sampler, batch_size
         self._it = None
 
@@ -54,6 +64,38 @@ class ContrastiveDeviceLoader:
         metas = [self.dataset.meta(i) for i in idx]
         tgt = torch.zeros(len(idx), 1, 1, 1, dtype=torch.long, device=img.device)  # pre-training never reads the labels
         return (img, img_tf, tgt, tgt), [m[0] for m in metas], ([m[1] for m in metas], [m[2] for m in metas])
+
+
+class LabeledDeviceLoader:
+    """the labelled loader of the fine-tune loop (``FineTuneEpocher._run_only_label``, semi_seg/epochers/new_epocher.py:260-283)
+    on device: batches ``((image, image_tf, target, target_tf), filenames, (partitions, scans))`` from a store WITH label maps
+    through the data set's `label` recipe (``ACDCStrongTransforms.label``, semi_seg/augment.py:23-34: RandomCrop, then
+    RandomRotation(30) -- one geometry for the image, BILINEAR, and its label map, NEAREST; SequentialWrapperTwice without
+    total freedom and without image-only randomness returns the same pair twice)."""
+
+    def __init__(self, store, *, batch_size, sampler=None, out_hw=(224, 224), recipe=None):
+        if getattr(store, "targets", None) is None:
+            raise ValueError("LabeledDeviceLoader: the store has no label maps (DeviceSliceStore(..., targets=))")
+        self.dataset, self._batch_size = store, int(batch_size)
+        name = recipe or ("prostate_label" if getattr(store, "data_name", "acdc") == "prostate" else "acdc_label")
+        rec = dict(RECIPES[name]) if isinstance(name, str) else dict(name)
+        if rec.get("resize"):
+            raise NotImplementedError("resize the store (images BILINEAR, label maps NEAREST) before building the loader")
+        self._views = RecipeViews(store.images, rec, out_hw, labels=store.targets)
+        self._sampler = sampler if sampler is not None else InfiniteRandomSampler(store, shuffle=True)
+        self._it = None
+
+    def __iter__(self):
+        self._it = iter(self._sampler)
+        return self
+
+    def __next__(self):
+        if self._it is None:
+            self._it = iter(self._sampler)
+        idx = [next(self._it) for _ in range(self._batch_size)]
+        img, tgt = self._views.labelled(idx)
+        metas = [self.dataset.meta(i) for i in idx]
+        return (img, img, tgt, tgt), [m[0] for m in metas], ([m[1] for m in metas], [m[2] for m in metas])
 
 
 def get_contrastive_dataloader(partial_loader, contrastive_params, device="cuda", out_hw=(224, 224)):

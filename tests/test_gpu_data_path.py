@@ -155,3 +155,119 @@ def test_flip_pair_equals_cat_of_view1_and_flipped_view2():
         ref = torch.cat([a, tf.apply_batch(b)], dim=0)
         assert pair.shape == ref.shape and torch.equal(pair, ref)
         assert not torch.equal(pair[6:], b)  # some sample really was flipped
+
+
+# ---- round 5: spcl_augment_views_recipe / spcl_resize_bilinear_pil against what PIL itself wrote (g10)
+def _g10():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g10_augment_recipes.npz"))
+
+
+def _dev_store(a_u8):
+    return torch.from_numpy(a_u8.astype(np.float32) / np.float32(255)).cuda()[None]
+
+
+def test_recipe_views_reproduce_what_pil_itself_wrote():
+    """ACDC pre-train views with the BILINEAR image rotation, Prostate pre-train views (device Resize(224) + rotation + flips +
+    RandomCrop(224, padding=20) + jitter), ACDC labelled pairs (crop, then rotation; image BILINEAR, label map NEAREST -> int64)
+    and CenterCrop(224): EVERY pixel of every view of tests/golden/g10_augment_recipes.npz, bit for bit."""
+    from spcl_amd.semi_seg.data import augment as A
+    g = _g10()
+    for k in range(4):  # the store-build Resize(224): bilinear in Resample.c's fixed point, two passes
+        got = A.resize_store(_dev_store(g[f"slice{k}"]), 224)
+        np.testing.assert_array_equal(torch.round(got[0] * 255).cpu().numpy().astype(np.uint8), g[f"resized{k}"])
+        np.testing.assert_array_equal(got[0].cpu().numpy(), g[f"resized{k}"].astype(np.float32) / np.float32(255))
+    for r, w in zip(g["rows_acdc"], g["views_acdc"]):
+        si, ang, vf, hf, top, left, b, c, cf = r
+        img = g[f"slice{int(si)}"]
+        views = A.RecipeViews(_dev_store(img), "acdc_pretrain", (224, 224))
+        row = A.recipe_row(0, img.shape, (224, 224), angle=float(ang), vflip=bool(vf), hflip=bool(hf), top=int(top), left=int(left),
+                           brightness=b, contrast=c, contrast_first=bool(cf))
+        got = views.apply([row]).cpu().numpy()[0, 0]
+        np.testing.assert_array_equal(got, w.astype(np.float32) / np.float32(255), err_msg=str(r))
+    for r, w in zip(g["rows_prostate"], g["views_prostate"]):
+        si, ang, vf, hf, top, left, b, c, cf = r
+        views = A.RecipeViews(_dev_store(g[f"slice{int(si)}"]), "prostate_pretrain", (224, 224))  # (resizes the store itself)
+        assert tuple(views.images.shape[1:]) == g[f"resized{int(si)}"].shape
+        row = A.recipe_row(0, tuple(views.images.shape[1:]), (224, 224), angle=float(ang), vflip=bool(vf), hflip=bool(hf),
+                           top=int(top), left=int(left), pad=20, brightness=b, contrast=c, contrast_first=bool(cf))
+        got = views.apply([row]).cpu().numpy()[0, 0]
+        np.testing.assert_array_equal(got, w.astype(np.float32) / np.float32(255), err_msg=str(r))
+    for r, w, lw in zip(g["rows_label"], g["views_label"], g["labels_label"]):
+        si, ang, top, left = r
+        img, lab = g[f"slice{int(si)}"], g[f"label{int(si)}"]
+        views = A.RecipeViews(_dev_store(img), "acdc_label", (224, 224), labels=torch.from_numpy(lab).cuda()[None])
+        row = A.recipe_row(0, img.shape, (224, 224), angle=float(ang), top=int(top), left=int(left), crop_first=True)
+        got, glab = views.apply([row], with_labels=True)
+        assert glab.dtype == torch.int64 and tuple(glab.shape) == (1, 1, 224, 224)
+        np.testing.assert_array_equal(got.cpu().numpy()[0, 0], w.astype(np.float32) / np.float32(255), err_msg=str(r))
+        np.testing.assert_array_equal(glab.cpu().numpy()[0, 0], lw.astype(np.int64), err_msg=str(r))
+    for si in range(4):
+        views = A.RecipeViews(_dev_store(g[f"slice{si}"]), "acdc_label", (224, 224),
+                              labels=torch.from_numpy(g[f"label{si}"]).cuda()[None])
+        got, glab = views.val([0])
+        np.testing.assert_array_equal(torch.round(got[0, 0] * 255).cpu().numpy().astype(np.uint8), g["views_val"][si])
+        np.testing.assert_array_equal(glab.cpu().numpy()[0, 0], g["labels_val"][si].astype(np.int64))
+
+
+def test_recipe_views_random_rows_match_the_oracle_and_pairs_are_independent():
+    """the product's own draws for every recipe on a synthetic 8-bit store (odd sizes too): kernel == oracle.recipe_view on
+    every pixel; ``pairs`` gives two different views per slice, ``labelled`` one geometry for image and label map"""
+    import struct
+    from spcl_amd.semi_seg.data import augment as A
+    f32 = lambda i: struct.unpack("<f", struct.pack("<i", i))[0]  # noqa: E731
+    f64 = lambda lo, hi: struct.unpack("<d", struct.pack("<ii", lo, hi))[0]  # noqa: E731
+    for name, size, out in (("acdc_pretrain", 256, 224), ("prostate_pretrain", 250, 224), ("acdc_label", 97, 50)):
+        store = _store(scans=3, slices_per_scan=(4, 5), size=size, seed=5)
+        u8 = torch.round(store.images * 255).clamp(0, 255)
+        lab = (u8 / 64).floor().clamp(0, 3).to(torch.uint8) if "label" in name else None
+        views = A.RecipeViews((u8 / 255).contiguous(), name, (out, out), labels=lab)
+        imgs = torch.round(views.images * 255).cpu().numpy().astype(np.uint8)
+        rng = random.Random(size)
+        idx = [rng.randrange(imgs.shape[0]) for _ in range(5)]
+        if lab is None:
+            a, b = views.pairs(idx, random.Random(3))
+            assert tuple(a.shape) == (5, 1, out, out) and not torch.equal(a, b)
+        rows = views.rows(idx, rng)
+        res = views.apply(rows, with_labels=lab is not None)
+        got = (res[0] if lab is not None else res).cpu().numpy()[:, 0]
+        for k, r in enumerate(rows):
+            fl = r[1]
+            # (the angle is not in the row: the oracle gets PIL's matrix back through atan2 of its doubles -- exact enough to
+            # reproduce round(cos, 15) / round(sin, 15) -- so compare through the oracle's own matrix entry points instead)
+            ang = -np.degrees(np.arctan2(f64(r[16], r[17]), f64(r[14], r[15])))
+            want, wlab = O.recipe_view(imgs[r[0]], lab[r[0]].cpu().numpy() if lab is not None else None, (out, out), angle=float(ang),
+                                       vflip=bool(fl & 2), hflip=bool(fl & 1), top=r[2], left=r[3], pad=r[4],
+                                       crop_first=bool(fl & 16), brightness=f32(r[5]), contrast=f32(r[6]), contrast_first=bool(fl & 4))
+            if O.pil_affine_q16(float(ang), *(((out, out)) if fl & 16 else (imgs.shape[2], imgs.shape[1]))) != r[8:14]:
+                continue  # (the recovered angle differs from the drawn one in its last bit: another matrix)
+            np.testing.assert_array_equal(got[k], want.astype(np.float32) / np.float32(255), err_msg=f"{name} {r[:8]}")
+            if lab is not None:
+                np.testing.assert_array_equal(res[1].cpu().numpy()[k, 0], wlab.astype(np.int64))
+
+
+def test_labelled_loader_and_default_pretrain_recipe():
+    """LabeledDeviceLoader: batches in the reference's tuple format from a store with label maps, image and label map through
+    ONE geometry (label pixels are the store's class codes or the rotation's zero fill); the contrastive loader's default views
+    are the data set's own pre-train recipe (bilinear image rotation; Prostate: resized to 224 when the store is built)"""
+    from spcl_amd.semi_seg.data import ContrastiveDeviceLoader, InfiniteRandomSampler, LabeledDeviceLoader, RecipeViews
+    store = _store(scans=4, slices_per_scan=(6, 8), size=256, seed=8)
+    u8 = torch.round(store.images * 255).clamp(0, 255)
+    store.images = (u8 / 255).contiguous()
+    store.targets = (u8 / 64).floor().clamp(0, 3).to(torch.uint8)
+    random.seed(5)
+    (img, img2, tgt, tgt2), names, (parts, scans) = next(iter(LabeledDeviceLoader(store, batch_size=6)))
+    assert tuple(img.shape) == (6, 1, 224, 224) and tgt.dtype == torch.int64 and tuple(tgt.shape) == (6, 1, 224, 224)
+    assert img2 is img and tgt2 is tgt and len(names) == 6 and all(n.startswith(s) for n, s in zip(names, scans))
+    assert int(tgt.min()) >= 0 and int(tgt.max()) <= 3
+    # label = floor(level / 64) in the store; both went through one geometry, the image bilinearly: away from class borders
+    # (where the four neighbours agree) the relation still holds
+    lv = torch.round(img * 255)
+    agree = ((lv / 64).floor().clamp(0, 3).long() == tgt).float().mean()
+    assert float(agree) > 0.9
+    with pytest.raises(ValueError):
+        LabeledDeviceLoader(_store(scans=2, slices_per_scan=(4, 5), size=64, seed=1), batch_size=2)
+    loader = ContrastiveDeviceLoader(store, sampler=InfiniteRandomSampler(store), batch_size=4)
+    assert isinstance(loader._views, RecipeViews) and loader._views.recipe["degrees"] == 45.0
+    (a, b, _, _), _, _ = next(iter(loader))
+    assert tuple(a.shape) == (4, 1, 224, 224) and not torch.equal(a, b)

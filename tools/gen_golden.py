@@ -524,9 +524,115 @@ def gen_augment():
     print("g9_augment:", out["rows"].shape, out["views"].shape, "PIL", PIL.__version__)
 
 
+def gen_recipes():
+    """g10_augment_recipes.npz: views PIL ITSELF produces for the reference's other recipes, and with the interpolation its
+    wrapper selects (contrastyou/augment/synchronize.py:95-103: the common transform runs with BILINEAR on images and NEAREST
+    on targets; torchvision's RandomRotation / Resize forward to ``Image.rotate(angle, interp)`` / ``Image.resize(size, interp)``):
+      acdc_pretrain      rotate(45, BILINEAR) -> flips -> crop(224) -> jitter [0.5, 1.5]      semi_seg/augment.py:6-22
+      prostate_pretrain  Resize(224) -> rotate(10, BILINEAR) -> flips -> crop(224, padding=20) -> jitter [0.9, 1.1]   :54-69
+      acdc_label         crop(224) -> rotate(30): image BILINEAR, label map NEAREST, no jitter   :23-34
+      val                CenterCrop(224)                                                        :35-37
+    Inputs: seeded uint8 slices (square and not) with blob label maps of four classes."""
+    import random
+    from PIL import Image, ImageEnhance, ImageOps
+    rs = np.random.RandomState(100)
+    sizes = [(256, 256), (240, 272), (288, 256), (320, 320)]
+    slices, labels = [], []
+    for k, (h, w) in enumerate(sizes):
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+        base = 0.5 + 0.25 * np.sin(xx / (6.0 + k)) * np.cos(yy / (10.0 - k)) + 0.25 * rs.rand(h, w)
+        slices.append(np.clip(base * 255.0, 0, 255).astype(np.uint8))
+        coarse = rs.randint(0, 4, size=(h // 16 + 1, w // 16 + 1)).astype(np.uint8)
+        labels.append(np.kron(coarse, np.ones((16, 16), dtype=np.uint8))[:h, :w].copy())
+    rng = random.Random(101)
+    out = {}
+    for k in range(len(sizes)):
+        out[f"slice{k}"], out[f"label{k}"] = slices[k], labels[k]
+
+    def jitter(im, b, c, cf):
+        if cf:
+            return ImageEnhance.Brightness(ImageEnhance.Contrast(im).enhance(c)).enhance(b)
+        return ImageEnhance.Contrast(ImageEnhance.Brightness(im).enhance(b)).enhance(c)
+
+    # ---- Resize(224) of every slice (torchvision: shorter edge -> 224, BILINEAR)
+    def resize224(a):
+        h, w = a.shape
+        if w <= h:
+            ow, oh = 224, int(224 * h / w)
+        else:
+            oh, ow = 224, int(224 * w / h)
+        return np.asarray(Image.fromarray(a, "L").resize((ow, oh), Image.BILINEAR)).copy()
+    resized = [resize224(a) for a in slices]
+    for k, a in enumerate(resized):
+        out[f"resized{k}"] = a
+    # ---- acdc_pretrain (bilinear rotation) and prostate_pretrain
+    rows_a, views_a, rows_p, views_p = [], [], [], []
+    for v in range(24):
+        si = v % 4
+        h, w = sizes[si]
+        ang = [0.0, 45.0, -45.0][v] if v < 3 else rng.uniform(-45.0, 45.0)
+        vf, hf = rng.random() < 0.5, rng.random() < 0.5
+        top, left = rng.randint(0, h - 224), rng.randint(0, w - 224)
+        b, c, cf = rng.uniform(0.5, 1.5), rng.uniform(0.5, 1.5), rng.random() < 0.5
+        im = Image.fromarray(slices[si], "L").rotate(ang, Image.BILINEAR, expand=False, fillcolor=0)
+        if vf:
+            im = im.transpose(Image.FLIP_TOP_BOTTOM)
+        if hf:
+            im = im.transpose(Image.FLIP_LEFT_RIGHT)
+        im = jitter(im.crop((left, top, left + 224, top + 224)), b, c, cf)
+        rows_a.append([si, ang, float(vf), float(hf), top, left, b, c, float(cf)])
+        views_a.append(np.asarray(im).copy())
+    for v in range(24):
+        si = v % 4
+        h, w = resized[si].shape
+        ang = [0.0, 10.0, -10.0][v] if v < 3 else rng.uniform(-10.0, 10.0)
+        vf, hf = rng.random() < 0.5, rng.random() < 0.5
+        top, left = rng.randint(0, h + 40 - 224), rng.randint(0, w + 40 - 224)
+        b, c, cf = rng.uniform(0.9, 1.1), rng.uniform(0.9, 1.1), rng.random() < 0.5
+        im = Image.fromarray(resized[si], "L").rotate(ang, Image.BILINEAR, expand=False, fillcolor=0)
+        if vf:
+            im = im.transpose(Image.FLIP_TOP_BOTTOM)
+        if hf:
+            im = im.transpose(Image.FLIP_LEFT_RIGHT)
+        im = ImageOps.expand(im, border=20, fill=0)  # torchvision F.pad(img, 20, fill=0, 'constant') on a PIL image
+        im = jitter(im.crop((left, top, left + 224, top + 224)), b, c, cf)
+        rows_p.append([si, ang, float(vf), float(hf), top, left, b, c, float(cf)])
+        views_p.append(np.asarray(im).copy())
+    # ---- acdc_label: crop, then rotate the crop; image BILINEAR, label NEAREST (the same drawn parameters)
+    rows_l, views_l, labs_l = [], [], []
+    for v in range(20):
+        si = v % 4
+        h, w = sizes[si]
+        top, left = rng.randint(0, h - 224), rng.randint(0, w - 224)
+        ang = [0.0, 30.0, -30.0][v] if v < 3 else rng.uniform(-30.0, 30.0)
+        box = (left, top, left + 224, top + 224)
+        im = Image.fromarray(slices[si], "L").crop(box).rotate(ang, Image.BILINEAR, expand=False, fillcolor=0)
+        lb = Image.fromarray(labels[si], "L").crop(box).rotate(ang, Image.NEAREST, expand=False, fillcolor=0)
+        rows_l.append([si, ang, top, left])
+        views_l.append(np.asarray(im).copy())
+        labs_l.append(np.asarray(lb).copy())
+    # ---- val: CenterCrop(224) (torchvision: int(round((h - 224) / 2.0)))
+    vals, vlabs = [], []
+    for si, (h, w) in enumerate(sizes):
+        top, left = int(round((h - 224) / 2.0)), int(round((w - 224) / 2.0))
+        vals.append(slices[si][top:top + 224, left:left + 224].copy())
+        vlabs.append(labels[si][top:top + 224, left:left + 224].copy())
+    out.update(rows_acdc=np.array(rows_a, dtype=np.float64), views_acdc=np.stack(views_a),
+               rows_prostate=np.array(rows_p, dtype=np.float64), views_prostate=np.stack(views_p),
+               rows_label=np.array(rows_l, dtype=np.float64), views_label=np.stack(views_l), labels_label=np.stack(labs_l),
+               views_val=np.stack(vals), labels_val=np.stack(vlabs))
+    import PIL
+    out["pil_version"] = np.array(PIL.__version__)
+    np.savez_compressed(os.path.join(OUT, "g10_augment_recipes.npz"), **out)
+    print("g10_augment_recipes:", {k: v.shape for k, v in out.items() if k.startswith(("views", "labels_"))}, "PIL", PIL.__version__)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if sys.argv[1:] == ["recipes"]:  # only the round-5 recipe fixture (PIL alone, no reference import)
+        gen_recipes()
+        return
     if sys.argv[1:] == ["augment"]:  # only the round-4 augmentation fixture (PIL alone, no reference import)
         return gen_augment()
     SupConLoss1, SelfPacedSupConLoss, ProjectionHead, UNet, SFE = _import_reference()
