@@ -1064,7 +1064,10 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
   // few tiles (14^2 images): with two n-tiles per wave a 128-channel output is ONE workgroup per tile -- 128 workgroups for
   // Conv5.a's dgrad at N = 64, half the CUs idle; one n-tile per wave doubles the workgroups
   static const int env_fill = lab_env("SPCL_CONV_FAST_FILL", 1);
-  static const int env_fill_max = lab_env("SPCL_CONV_FAST_FILL_MAX", 256);
+  // (round 5, same box: 512 takes Conv5 at N = 64 -- 128 tiles x 2 cout halves = 256 workgroups, one wave per SIMD -- to 512
+  // one-n-tile workgroups: Conv5.a / .b forward 14.2 / 23.7 -> 13.8 / 23.4 us, Conv5.b's dgrad 23.0 -> 21.8; 1 100, which
+  // takes Conv4 too, loses 4 us there)
+  static const int env_fill_max = lab_env("SPCL_CONV_FAST_FILL_MAX", 512);
   if (env_fill && KC == 64 && NT == 2 && ntn >= 8 && ntn % 4 == 0 &&
       (long)c.N * cdiv(c.W, 14) * cdiv(c.H, th) * cdiv(ntn, 8) < env_fill_max)
     NT = 1;
