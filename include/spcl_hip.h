@@ -545,11 +545,14 @@ int spcl_split2_channels(const void* in, void* a, void* b, int elem_size, size_t
  * flat fp32 parameter:  g' = g + wd p;  m = lerp(m, g', 1-b1);  v = b2 v + (1-b2) g'^2;  t = ++step;
  *   rho_t = rho_inf - 2 t b2^t/(1-b2^t);  p -= lr m/(1-b1^t) * (rho_t > 5 ? rect(rho_t) sqrt(1-b2^t)/(sqrt(v)+eps) : 1).
  * step (int64) and lr (float) live in device memory so that a captured hipGraph replays with an advancing step
- * count and a host-updated learning rate; coef: 4 floats of device scratch.  All buffers 16-byte aligned. */
+ * count and a host-updated learning rate; coef: 4 floats of device scratch, ZERO before the first call (coef[0..2] hold
+ * the step's scalar coefficients afterwards, coef[3] is a ticket word that is zero between launches).  One launch: every
+ * workgroup derives the coefficients from the (read-only) counter, the last one to finish writes the counter back.
+ * All buffers 16-byte aligned. */
 int spcl_radam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, int64_t* step,
                     const float* lr, double beta1, double beta2, double eps, double weight_decay, float* coef,
                     void* stream);
-/* the same, and the step's meter updates (spcl_accumulate_scalars' k <= 8 pairs) ride in its coefficient launch: one
+/* the same, and the step's meter updates (spcl_accumulate_scalars' k <= 8 pairs) ride in the same launch: one
  * launch less per training step.  k == 0: exactly spcl_radam_step. */
 int spcl_radam_step_scalars(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, int64_t* step,
                             const float* lr, double beta1, double beta2, double eps, double weight_decay, float* coef,
