@@ -83,6 +83,16 @@ int spcl_supcon_unit_gradient_block(int n, int d, size_t* offset_floats, int* ro
 int spcl_supcon_forward_heads(int K, const float* z1, const float* z2, size_t z_stride, const float* labels, int n,
                               int d, float temperature, int sp_mode, const float* gammas, int correct_grad, float* ws,
                               size_t ws_stride, float* out, void* stream);
+/* The projector's F.normalize (contrastyou/projectors/heads.py:15-17, nn.py:29-36) and its backward inside the loss launch:
+ * o1 / o2 are the K heads' rows BEFORE normalisation; the launch normalises them (z = o / max(||o||, 1e-12): the rows it
+ * leaves in the workspace for the taps are the normalised ones, bit for bit those of spcl_l2norm_rows_forward), evaluates
+ * the loss exactly as spcl_supcon_forward_heads does on them, and the unit-gradient block (spcl_supcon_unit_gradient_block;
+ * spcl_supcon_backward(_heads) scales it) holds d loss / d o.  Training sizes only: spcl_supcon_rows_supported(n, d) != 0
+ * (2n <= 64, d <= 256: the one-workgroup schedule); labels [K][n] or NULL, no explicit mask.  K = 1: strides unused. */
+int spcl_supcon_rows_supported(int n, int d);
+int spcl_supcon_forward_rows(int K, const float* o1, const float* o2, size_t o_stride, const float* labels, int n, int d,
+                             float temperature, int sp_mode, const float* gammas, int correct_grad, float* ws,
+                             size_t ws_stride, float* out, void* stream);
 int spcl_supcon_backward_heads(int K, const float* labels, int n, int d, float temperature, int sp_mode,
                                const float* gammas, const float* ws_fwd, size_t ws_stride, float* ws_bwd,
                                size_t wsb_stride, const float* out_fwd, const float* grad_out, float* dz1, float* dz2,
@@ -333,7 +343,6 @@ int spcl_wgrad_tail_capture(spcl_wgrad_tail* slot);
 /* n may be 0 (tails only; partial may then be NULL), ntails may be 0 (== spcl_conv3x3_wgrad_batched) */
 int spcl_conv3x3_wgrad_batched_tails(const spcl_wgrad_item* items, int n, const spcl_wgrad_tail* tails, int ntails,
                                      int accumulate, float* partial, void* stream);
-
 /* train-mode BatchNorm statistics (unet.py:73,76; torch.nn.BatchNorm2d semantics): combines the conv epilogue
  * partials stats[ntiles][3][CS] (Chan, fixed order, in double; the tail of the buffer is scratch) -> mean, invstd = 1/sqrt(var_biased+eps), scale = gamma*invstd,
  * shift = beta-mean*scale (all [CS] f32, zero in the channel padding) and updates running_mean / running_var

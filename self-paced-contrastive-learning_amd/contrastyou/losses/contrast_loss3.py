@@ -68,7 +68,7 @@ class _SupConBase(nn.Module):
             assert labels_t.numel() == batch_size, (labels_t.shape, batch_size)
         return labels_t, mask_t
 
-    def _run(self, proj_feat1, proj_feat2, labels_t, mask_t, sp_mode, gamma, correct_grad):
+    def _run(self, proj_feat1, proj_feat2, labels_t, mask_t, sp_mode, gamma, correct_grad, normalize_inputs=False):
         assert proj_feat1.shape == proj_feat2.shape, (proj_feat1.shape, proj_feat2.shape)  # :63 / :155
         self._state = F_hip.SupConState()
         self._taps_cache = None
@@ -77,7 +77,7 @@ class _SupConBase(nn.Module):
         if stacked is not None:  # the two views are torch.chunk halves of one projection: skip the chunk / cat copies
             proj_feat1, proj_feat2 = stacked, None
         loss = F_hip.supcon_loss(proj_feat1, proj_feat2, labels_t, mask_t, t=self._t, sp_mode=sp_mode, gamma=gamma,
-                                 correct_grad=correct_grad, state=self._state)
+                                 correct_grad=correct_grad, state=self._state, normalize_inputs=normalize_inputs)
         if self.sync_checks and not _capturing():
             self.check()  # (a captured step is checked after its replay: _INFONCEEpochHook.after_replay)
         return loss
@@ -116,10 +116,15 @@ class SupConLoss1(_SupConBase):
         super().__init__(temperature, sync_checks)
         self._exclude_pos = exclude_other_pos
 
-    def forward(self, proj_feat1, proj_feat2, target=None, mask: Tensor = None, **kwargs):
+    def forward(self, proj_feat1, proj_feat2, target=None, mask: Tensor = None, normalize_inputs=False, **kwargs):
+        """``normalize_inputs=True`` (not in the reference): the inputs are the projector's rows BEFORE its
+        ``F.normalize`` (``ProjectionHead(...)(x, normalize=False)``); the loss is that of the normalised rows, the
+        normalisation and its backward run inside the loss launch (training sizes) instead of in two launches of their own."""
         labels_t, mask_t = self._prepare_targets(proj_feat1, proj_feat2, target, mask)
         if not self._exclude_pos:
-            return self._run(proj_feat1, proj_feat2, labels_t, mask_t, F_hip.SP_NONE, 1e6, False)
+            return self._run(proj_feat1, proj_feat2, labels_t, mask_t, F_hip.SP_NONE, 1e6, False, normalize_inputs)
+        if normalize_inputs:
+            proj_feat1, proj_feat2 = F_hip.l2norm_rows(proj_feat1), F_hip.l2norm_rows(proj_feat2)
         # :97-100 -- each positive against the row's negatives only (csrc/supcon_xpos.hip); the taps are those of the
         # plain loss on the same inputs (same masks / logits), evaluated without a graph
         assert proj_feat1.shape == proj_feat2.shape, (proj_feat1.shape, proj_feat2.shape)
@@ -147,10 +152,11 @@ class SelfPacedSupConLoss(_SupConBase):
         self.__gamma = 1e6
         self._correct_grad = correct_grad
 
-    def forward(self, proj_feat1, proj_feat2, target=None, mask: Tensor = None, **kwargs):
+    def forward(self, proj_feat1, proj_feat2, target=None, mask: Tensor = None, normalize_inputs=False, **kwargs):
+        """``normalize_inputs``: see ``SupConLoss1.forward``"""
         labels_t, mask_t = self._prepare_targets(proj_feat1, proj_feat2, target, mask)
         mode = F_hip.SP_HARD if self._weight_update == "hard" else F_hip.SP_SOFT  # :209-213
-        return self._run(proj_feat1, proj_feat2, labels_t, mask_t, mode, self.__gamma, self._correct_grad)
+        return self._run(proj_feat1, proj_feat2, labels_t, mask_t, mode, self.__gamma, self._correct_grad, normalize_inputs)
 
     sp_mask = property(lambda self: self._tap("sp_mask"))
 
@@ -191,7 +197,7 @@ def _adjacent_rows(rows, n):
     return torch.as_strided(fb, (len(rows), n), (n, 1), byte_off // 4)
 
 
-def supcon_heads(criteria, projections, targets):
+def supcon_heads(criteria, projections, targets, normalize_inputs=False):
     """The K losses ``criteria[k](*torch.chunk(projections[k], 2), target=targets[k])`` in the launches of ONE
     (``spcl_supcon_forward_heads``): the K meta-label hooks of ``semi_seg/hooks/creator.py:102-124`` on one feature, each
     with its own label vector and its own age parameter.  Every criterion ends up in exactly the state a call of its own
@@ -233,7 +239,7 @@ def supcon_heads(criteria, projections, targets):
         labels_t = torch.stack(labels)
     states = [F_hip.SupConState() for _ in range(K)]
     losses = F_hip.supcon_loss_heads(list(projections), labels_t, t=c0._t, sp_mode=mode, gammas=gammas,
-                                     correct_grad=correct, states=states)
+                                     correct_grad=correct, states=states, normalize_inputs=normalize_inputs)
     for c, st in zip(criteria, states):
         c._state, c._taps_cache, c._host_out = st, None, None
     for c in criteria:

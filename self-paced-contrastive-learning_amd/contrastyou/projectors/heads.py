@@ -41,7 +41,10 @@ class ProjectionHead(_ProjectorHeadBase):
                                                  input_dim=self._input_dim, hidden_dim=hidden_dim,
                                                  output_dim=output_dim, normalize=normalize)
 
-    def forward(self, features):
+    def forward(self, features, normalize=None):
+        """``normalize`` (not in the reference): overrides the constructor's setting for this call -- ``False`` returns the
+        rows before ``F.normalize`` for a criterion that normalises in its own launch (``normalize_inputs=True``)"""
+        norm = self._normalize if normalize is None else bool(normalize)
         h = self._header
         if tuple(self._spatial_size) != (1, 1):
             k = self._spatial_size[0] * self._spatial_size[1]
@@ -50,8 +53,8 @@ class ProjectionHead(_ProjectorHeadBase):
         if self._pool_name == "adaptive_max":
             features = F_hip.adaptive_pool2d(features, (1, 1), "max")
         if self._head_type == "mlp":
-            return F_hip.projector(features, h[2].weight, h[2].bias, h[4].weight, h[4].bias, self._normalize)
-        return F_hip.projector(features, h[2].weight, h[2].bias, None, None, self._normalize)
+            return F_hip.projector(features, h[2].weight, h[2].bias, h[4].weight, h[4].bias, norm)
+        return F_hip.projector(features, h[2].weight, h[2].bias, None, None, norm)
 
 
 class DenseProjectionHead(_ProjectorHeadBase):

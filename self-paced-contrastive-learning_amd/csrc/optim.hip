@@ -23,7 +23,7 @@ struct ScalarAdds {
 // waits for anybody: the ticket orders one word, not work.  coef[3] is the ticket (zero between launches).
 // Threads 1 .. k of workgroup 0 perform the step's meter updates (spcl_radam_step_scalars): the running means of the
 // host-side meters are one more few-microsecond launch per step otherwise.
-__global__ __launch_bounds__(256) void radam_apply_kernel(float* __restrict__ p, const float* __restrict__ g,
+__global__ __launch_bounds__(1024) void radam_apply_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                           float* __restrict__ m, float* __restrict__ v, size_t n4,
                                                           size_t n, int64_t* step, const float* __restrict__ lr,
                                                           double beta1, double beta2, float* coef, float eps, float wd,
@@ -193,10 +193,12 @@ extern "C" int spcl_radam_step_scaled(float* param, const float* grad, double gr
   SPCL_CHECK_ARG(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0, "radam_step: betas");
   hipStream_t st = (hipStream_t)stream;
   const size_t n4 = n / 4;
-  size_t blocks = (n4 + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
+  // (few, wide workgroups: the tickets are same-address atomics, which the memory side serialises at ~8 ns each -- 2 048
+  // of them, from workgroups that all finish together, were 16 us at the end of a 7 us kernel)
+  size_t blocks = (n4 + 1023) / 1024;
+  if (blocks > 256) blocks = 256;
   if (blocks < 1) blocks = 1;
-  SPCL_LAUNCH(radam_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, n4, n, step,
+  SPCL_LAUNCH(radam_apply_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, param, grad, exp_avg, exp_avg_sq, n4, n, step,
               lr, beta1, beta2, coef, (float)eps, (float)weight_decay, (float)grad_scale, adds);
   SPCL_LAUNCH_CHECK("radam_step");
   return SPCL_OK;

@@ -413,7 +413,8 @@ static int proj_heads_forward(int K, const void* feat, int dtype, int N, int HW,
     SPCL_LAUNCH(l2norm_fwd_kernel, dim3(cdiv(N, 4), 1, K), dim3(256), 0, st, O, N, out_dim, Zm);
   else
     for (int k = 0; k < K; ++k)
-      (void)hipMemcpyAsync(z[k], o[k], (size_t)N * out_dim * sizeof(float), hipMemcpyDeviceToDevice, st);
+      if (z[k] != o[k])  // (the caller may pass z == o: the rows before normalisation ARE the output then, no copy)
+        (void)hipMemcpyAsync(z[k], o[k], (size_t)N * out_dim * sizeof(float), hipMemcpyDeviceToDevice, st);
   return SPCL_OK;
 }
 
@@ -496,7 +497,7 @@ extern "C" int spcl_proj_backward(const float* dz, int dtype, int N, int HW, int
                                   const float* w2, int hid, int out_dim, int normalize, const float* pooled,
                                   const float* pre, const float* o, float* dw1, float* db1, float* dw2, float* db2,
                                   float* scratch, void* dfeat, void* stream) {
-  SPCL_CHECK_ARG(dz && w1 && pooled && o && dw1 && db1 && scratch, "proj_backward: null pointer");
+  SPCL_CHECK_ARG(dz && w1 && pooled && (o || !normalize) && dw1 && db1 && scratch, "proj_backward: null pointer");
   SPCL_CHECK_ARG(N > 0 && HW > 0 && C > 0 && Cs >= C && out_dim > 0 && hid >= 0, "proj_backward: bad shape");
   SPCL_CHECK_ARG(hid == 0 || (w2 && pre && dw2 && db2), "proj_backward: mlp head needs w2/pre/dw2/db2");
   const int rc = proj_heads_backward(1, &dz, dtype, N, HW, C, Cs, &w1, &w2, hid, out_dim, normalize, pooled, &pre, &o, &dw1,
@@ -541,7 +542,8 @@ extern "C" int spcl_proj_heads_backward_pooled(int K, const float* const* dz, in
   SPCL_CHECK_ARG(N > 0 && HW > 0 && C > 0 && Cs == C && out_dim > 0 && hid >= 0 && (dtype == SPCL_F32 || dtype == SPCL_BF16),
                  "proj_heads_backward_pooled: bad shape (Cs must equal C)");
   for (int k = 0; k < K; ++k)
-    SPCL_CHECK_ARG(dz[k] && w1[k] && o[k] && dw1[k] && db1[k] && (hid == 0 || (w2[k] && pre[k] && dw2[k] && db2[k])),
+    SPCL_CHECK_ARG(dz[k] && w1[k] && (o[k] || !normalize) && dw1[k] && db1[k] &&
+                       (hid == 0 || (w2[k] && pre[k] && dw2[k] && db2[k])),
                    "proj_heads_backward_pooled: null pointer in head %d", k);
   const int rc = proj_heads_backward(K, dz, dtype, N, HW, C, Cs, w1, w2, hid, out_dim, normalize, pooled, pre, o, dw1, db1,
                                      dw2, db2, scratch, dfeat_nc, (hipStream_t)stream, "proj_heads_backward_pooled", true);
@@ -560,7 +562,8 @@ extern "C" int spcl_proj_heads_backward(int K, const float* const* dz, int dtype
                  "proj_heads_backward: null pointer");
   SPCL_CHECK_ARG(N > 0 && HW > 0 && C > 0 && Cs >= C && out_dim > 0 && hid >= 0, "proj_heads_backward: bad shape");
   for (int k = 0; k < K; ++k)
-    SPCL_CHECK_ARG(dz[k] && w1[k] && o[k] && dw1[k] && db1[k] && (hid == 0 || (w2[k] && pre[k] && dw2[k] && db2[k])),
+    SPCL_CHECK_ARG(dz[k] && w1[k] && (o[k] || !normalize) && dw1[k] && db1[k] &&
+                       (hid == 0 || (w2[k] && pre[k] && dw2[k] && db2[k])),
                    "proj_heads_backward: null pointer in head %d", k);
   const int rc = proj_heads_backward(K, dz, dtype, N, HW, C, Cs, w1, w2, hid, out_dim, normalize, pooled, pre, o, dw1, db1,
                                      dw2, db2, scratch, dfeat, (hipStream_t)stream, "proj_heads_backward");

@@ -566,7 +566,11 @@ __global__ __launch_bounds__(256) void supcon_bwd_wide_kernel(SupconArgs a_, int
 // exact-f32 MFMA (kept in registers: 16 rows x 64 columns per wave), row sums, self-paced weights, the final scalars,
 // and dLoss/dP for a unit upstream gradient (backward then is one scaling launch).  Same arithmetic per element as the
 // sweep kernels; the seven launches they take at this size are latency, not work.
-template <int DP>
+// RAW: z1 / z2 are the projector's rows BEFORE F.normalize (projectors/heads.py:15-17, nn.py:29-36): the kernel normalises
+// them itself (same arithmetic as l2norm_fwd_kernel: the normalised rows land in P_out bit for bit) and the unit-gradient
+// block it leaves is d loss / d raw rows (F.normalize's backward folded into the last phase) -- the head chain's two
+// normalisation launches do not exist (spcl_supcon_forward_rows).
+template <int DP, bool RAW = false>
 __global__ __launch_bounds__(1024) void supcon_small_kernel(const float* __restrict__ z1, const float* __restrict__ z2,
                                                            int d, SupconArgs a, float* __restrict__ P_out,
                                                            float* __restrict__ rn2_out, float* __restrict__ logD_out,
@@ -595,6 +599,7 @@ __global__ __launch_bounds__(1024) void supcon_small_kernel(const float* __restr
   float* part = st_lab + 64;          // [2][4 cq][64 rows]: partial row sums of a column quarter
   float* sx = part + 2 * 4 * 64;      // [4 rb][4 cq][4 r][64 lanes]: the H = G + G^T tiles, for the backward
   double* red = (double*)(sx + 4 * 4 * 4 * 64);  // [4][4]
+  float* st_inv = (float*)(red + 16);  // [64] RAW: 1 / max(||raw row||, 1e-12)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, g = lane >> 4;
   const int rb = wave & 3, cq = wave >> 2;
@@ -622,6 +627,19 @@ __global__ __launch_bounds__(1024) void supcon_small_kernel(const float* __restr
     if (a.dbg & 256) {  // (experiments: after the global loads have landed)
       if (v[0][0] + v[1][0] + v[2][0] + v[3][0] == 12345.f) out[7] = 1.f;
       return;
+    }
+    if (RAW) {  // z = o / max(||o||, 1e-12), the sum in l2norm_fwd_kernel's order
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < KPL; ++q) s = fmaf(v[rr][q], v[rr][q], s);
+        s = wave_sum(s);
+        const float inv = 1.f / fmaxf(sqrtf(s), 1e-12f);
+#pragma unroll
+        for (int q = 0; q < KPL; ++q) v[rr][q] *= inv;
+        if (lane == 0) st_inv[4 * wave + rr] = sqrtf(s) > 1e-12f ? inv : -1e12f;  // (negative: F.normalize's clamp branch)
+      }
     }
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
@@ -782,10 +800,12 @@ __global__ __launch_bounds__(1024) void supcon_small_kernel(const float* __restr
     sx[((rb * 4 + cq) * 4 + r) * 64 + lane] = hv;
   }
   __syncthreads();
-  if (64 * cq >= DP) return;  // feature slices beyond the padded width (DP = 64 or 128)
+  const bool live = 64 * cq < DP;  // (feature slices beyond the padded width, DP = 64 or 128, have nothing to do)
+  if (!RAW && !live) return;
   f32x4 acc2[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) acc2[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (live) {
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
     float h[4];
@@ -799,12 +819,42 @@ __global__ __launch_bounds__(1024) void supcon_small_kernel(const float* __restr
       for (int u = 0; u < 4; ++u) acc2[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(h[r], b4[u], acc2[u], 0, 0, 0);
     }
   }
+  }
   // acc2[u][rr] = dP[I0 + 4g + rr][64 cq + 4*r16 + u]  (times 1/t here, times grad_out in the backward call)
   const float inv_t = 1.f / a.t;
+  if (!RAW) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const f32x4 v = {acc2[0][rr] * inv_t, acc2[1][rr] * inv_t, acc2[2][rr] * inv_t, acc2[3][rr] * inv_t};
+      *(f32x4*)(dz_unit + (size_t)(I0 + 4 * g + rr) * DP + 64 * cq + 4 * r16) = v;
+    }
+    return;
+  }
+  // RAW: d raw = (dz - z (z . dz)) / ||raw||  (l2norm_bwd_kernel): the row's dot product from the four feature slices
+  // through LDS in fixed order (`part` is free by now), z from the swizzled image
+  f32x4 dzv[4], zv[4];
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) {
-    const f32x4 v = {acc2[0][rr] * inv_t, acc2[1][rr] * inv_t, acc2[2][rr] * inv_t, acc2[3][rr] * inv_t};
-    *(f32x4*)(dz_unit + (size_t)(I0 + 4 * g + rr) * DP + 64 * cq + 4 * r16) = v;
+    const int row = I0 + 4 * g + rr;
+    dzv[rr] = (f32x4){acc2[0][rr] * inv_t, acc2[1][rr] * inv_t, acc2[2][rr] * inv_t, acc2[3][rr] * inv_t};
+    zv[rr] = live ? *(const f32x4*)(lds + row * DP + (((16 * cq + r16) ^ (row & 15)) << 2)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    float pd = (dzv[rr][0] * zv[rr][0] + dzv[rr][1] * zv[rr][1]) + (dzv[rr][2] * zv[rr][2] + dzv[rr][3] * zv[rr][3]);
+    pd += __shfl_xor(pd, 1, 64);
+    pd += __shfl_xor(pd, 2, 64);
+    pd += __shfl_xor(pd, 4, 64);
+    pd += __shfl_xor(pd, 8, 64);
+    if (r16 == 0) part[cq * 64 + row] = pd;
+  }
+  __syncthreads();
+  if (!live) return;
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int row = I0 + 4 * g + rr;
+    const float inv = st_inv[row];
+    const float dot = inv < 0.f ? 0.f : (part[row] + part[64 + row]) + (part[128 + row] + part[192 + row]);
+    const float sc = fabsf(inv);  // (clamp branch: the denominator is the constant eps -- d raw = dz * 1e12)
+    const f32x4 v = (dzv[rr] - zv[rr] * dot) * sc;
+    *(f32x4*)(dz_unit + (size_t)row * DP + 64 * cq + 4 * r16) = v;
   }
 }
 
@@ -2458,7 +2508,8 @@ extern "C" size_t spcl_supcon_bwd_workspace_bytes(int n, int d) {
 // K = 1: the single-head entry (strides 0).  K > 1: heads of one shape (small / mid schedules only).
 static int supcon_forward_impl(int K, const float* z1, const float* z2, long z_stride, const float* labels,
                                const float* mask, int n, int d, float temperature, int sp_mode, const float* gammas,
-                               int correct_grad, float* ws, long ws_stride, float* out, hipStream_t st, const char* who) {
+                               int correct_grad, float* ws, long ws_stride, float* out, hipStream_t st, const char* who,
+                               bool raw = false) {
   SupconLayout L = supcon_layout(n, d);
   SupconArgs a = make_args(L, ws, labels, mask, temperature, sp_mode, gammas[0]);
   if (K > 1) {
@@ -2469,16 +2520,25 @@ static int supcon_forward_impl(int K, const float* z1, const float* z2, long z_s
     }
   }
   if (supcon_use_small(L)) {
-    const size_t lds = ((size_t)64 * L.DP + 5 * 64 + 2 * 4 * 64 + 4 * 4 * 4 * 64) * sizeof(float) + 16 * sizeof(double);
-#define SPCL_SMALL(DP_)                                                                                            \
-  SPCL_LAUNCH((supcon_small_kernel<DP_>), dim3(K), dim3(1024), lds, st, z1, z2, d, a, ws + L.off_P, ws + L.off_rn2,  \
-              ws + L.off_logD, ws + L.off_c, ws + L.off_W, ws + L.off_rowloss, correct_grad, out, ws + L.off_dz)
-    if (L.DP == 64) SPCL_SMALL(64);
-    else if (L.DP == 128) SPCL_SMALL(128);
-    else SPCL_SMALL(256);
+    const size_t lds = ((size_t)64 * L.DP + 6 * 64 + 2 * 4 * 64 + 4 * 4 * 4 * 64) * sizeof(float) + 16 * sizeof(double);
+#define SPCL_SMALL(DP_, RAW_)                                                                                      \
+  SPCL_LAUNCH((supcon_small_kernel<DP_, RAW_>), dim3(K), dim3(1024), lds, st, z1, z2, d, a, ws + L.off_P,           \
+              ws + L.off_rn2, ws + L.off_logD, ws + L.off_c, ws + L.off_W, ws + L.off_rowloss, correct_grad, out,   \
+              ws + L.off_dz)
+    if (raw) {
+      if (L.DP == 64) SPCL_SMALL(64, true);
+      else if (L.DP == 128) SPCL_SMALL(128, true);
+      else SPCL_SMALL(256, true);
+    } else if (L.DP == 64) SPCL_SMALL(64, false);
+    else if (L.DP == 128) SPCL_SMALL(128, false);
+    else SPCL_SMALL(256, false);
 #undef SPCL_SMALL
     SPCL_LAUNCH_CHECK(who);
     return SPCL_OK;
+  }
+  if (raw) {
+    set_error("%s: rows before normalisation are taken by the one-workgroup schedule only (2n <= 64)", who);
+    return SPCL_EUNSUPPORTED;
   }
   const bool big = supcon_use_big(L, mask);
   if (K > 1 && L.big) {
@@ -2541,6 +2601,25 @@ extern "C" int spcl_supcon_forward_heads(int K, const float* z1, const float* z2
                  "supcon_forward_heads: head strides smaller than a head");
   return supcon_forward_impl(K, z1, z2, (long)z_stride, labels, nullptr, n, d, temperature, sp_mode, gammas, correct_grad,
                              ws, (long)ws_stride, out, (hipStream_t)stream, "supcon_forward_heads");
+}
+
+extern "C" int spcl_supcon_rows_supported(int n, int d) {
+  if (n <= 0 || d <= 0 || d > SPCL_SUPCON_MAX_D) return 0;
+  return supcon_use_small(supcon_layout(n, d)) ? 1 : 0;
+}
+
+extern "C" int spcl_supcon_forward_rows(int K, const float* o1, const float* o2, size_t o_stride, const float* labels,
+                                        int n, int d, float temperature, int sp_mode, const float* gammas,
+                                        int correct_grad, float* ws, size_t ws_stride, float* out, void* stream) {
+  SPCL_CHECK_ARG(o1 && o2 && ws && out && gammas, "supcon_forward_rows: null pointer");
+  SPCL_CHECK_ARG(K >= 1 && K <= 4, "supcon_forward_rows: %d heads (1..4)", K);
+  SPCL_CHECK_ARG(n > 0 && d > 0 && d <= SPCL_SUPCON_MAX_D, "supcon_forward_rows: bad shape n=%d d=%d", n, d);
+  SPCL_CHECK_ARG(sp_mode >= 0 && sp_mode <= 2, "supcon_forward_rows: sp_mode %d", sp_mode);
+  SPCL_CHECK_ARG(temperature > 0.f, "supcon_forward_rows: temperature must be > 0");
+  SPCL_CHECK_ARG(K == 1 || (o_stride >= (size_t)n * d && ws_stride * sizeof(float) >= spcl_supcon_workspace_bytes(n, d)),
+                 "supcon_forward_rows: head strides smaller than a head");
+  return supcon_forward_impl(K, o1, o2, (long)o_stride, labels, nullptr, n, d, temperature, sp_mode, gammas, correct_grad,
+                             ws, (long)ws_stride, out, (hipStream_t)stream, "supcon_forward_rows", true);
 }
 
 static int supcon_backward_impl(int K, const float* labels, const float* mask, int n, int d, float temperature,

@@ -47,7 +47,7 @@ class _SupConFn(torch.autograd.Function):
     comes back as one [2n, d] tensor (no chunk / cat copies around the loss)."""
 
     @staticmethod
-    def forward(ctx, z1, z2, labels, mask, t, sp_mode, gamma, correct_grad, state: SupConState):
+    def forward(ctx, z1, z2, labels, mask, t, sp_mode, gamma, correct_grad, state: SupConState, raw=False):
         stacked = z2 is None
         _n.require_gpu(z1, labels, mask) if stacked else _n.require_gpu(z1, z2, labels, mask)
         z1c = z1.detach().contiguous().float()
@@ -63,8 +63,15 @@ class _SupConFn(torch.autograd.Function):
             raise RuntimeError(f"supcon: unsupported shape n={n} d={d} (d must be <= 4096)")
         ws = torch.empty(nbytes // 4, dtype=torch.float32, device=z1.device)
         out = torch.empty(8, dtype=torch.float32, device=z1.device)  # the kernel writes loss, rho, kappa, norm defect
-        _n.call("spcl_supcon_forward", _n.ptr(z1c), _n.ptr(z2c), _n.ptr(labels), _n.ptr(mask), n, d, c_float(t),
-                sp_mode, c_float(gamma), int(bool(correct_grad)), _n.ptr(ws), _n.ptr(out), _n.stream())
+        if raw:
+            # the rows BEFORE F.normalize: the launch normalises them itself and its unit-gradient block is d loss / d raw
+            # rows (spcl_supcon_forward_rows; supcon_loss has checked that the shape is supported and there is no mask)
+            gam = (c_float * 1)(float(gamma))
+            _n.call("spcl_supcon_forward_rows", 1, _n.ptr(z1c), _n.ptr(z2c), 0, _n.ptr(labels), n, d, c_float(t), sp_mode,
+                    gam, int(bool(correct_grad)), _n.ptr(ws), 0, _n.ptr(out), _n.stream())
+        else:
+            _n.call("spcl_supcon_forward", _n.ptr(z1c), _n.ptr(z2c), _n.ptr(labels), _n.ptr(mask), n, d, c_float(t),
+                    sp_mode, c_float(gamma), int(bool(correct_grad)), _n.ptr(ws), _n.ptr(out), _n.stream())
         state.n, state.d, state.t, state.sp_mode, state.gamma = n, d, t, sp_mode, gamma
         state.labels, state.mask, state.ws, state.out = labels, mask, ws, out
         ctx.state = state
@@ -83,7 +90,7 @@ class _SupConFn(torch.autograd.Function):
             if (_n.call("spcl_supcon_unit_gradient_block", s.n, s.d, ctypes.byref(off), ctypes.byref(pitch))
                     and pitch.value == s.d):
                 dz = s.ws[off.value:off.value + 2 * s.n * s.d].view(2 * s.n, s.d)
-                return dz, None, None, None, None, None, None, None, None
+                return dz, None, None, None, None, None, None, None, None, None
         dz = torch.empty(2 * s.n, s.d, dtype=torch.float32, device=dev)
         dz1, dz2 = dz[:s.n], dz[s.n:]
         wsb = torch.empty(_n.call("spcl_supcon_bwd_workspace_bytes", s.n, s.d) // 4, dtype=torch.float32, device=dev)
@@ -92,16 +99,32 @@ class _SupConFn(torch.autograd.Function):
                 c_float(s.gamma), _n.ptr(s.ws), _n.ptr(wsb), _n.ptr(s.out), _n.ptr(go), _n.ptr(dz1), _n.ptr(dz2),
                 _n.stream())
         if ctx.stacked:
-            return dz.to(ctx.in_dtypes[0]), None, None, None, None, None, None, None, None
-        return dz1.to(ctx.in_dtypes[0]), dz2.to(ctx.in_dtypes[1]), None, None, None, None, None, None, None
+            return dz.to(ctx.in_dtypes[0]), None, None, None, None, None, None, None, None, None
+        return dz1.to(ctx.in_dtypes[0]), dz2.to(ctx.in_dtypes[1]), None, None, None, None, None, None, None, None
+
+
+def supcon_rows_supported(n, d, mask=None):
+    """can the loss launch take the rows BEFORE F.normalize (``normalize_inputs``)?  training sizes, no explicit mask"""
+    return mask is None and bool(_n.call("spcl_supcon_rows_supported", int(n), int(d)))
 
 
 def supcon_loss(z1, z2, labels=None, mask=None, *, t=0.07, sp_mode=SP_NONE, gamma=1e6, correct_grad=False,
-                state: SupConState = None):
-    """loss (0-dim tensor with grad_fn).  ``state`` receives the device-side statistics (rho = state.out[1])."""
+                state: SupConState = None, normalize_inputs=False):
+    """loss (0-dim tensor with grad_fn).  ``state`` receives the device-side statistics (rho = state.out[1]).
+    ``normalize_inputs``: z1 / z2 are rows BEFORE ``F.normalize(dim=1)``; the loss is that of the normalised rows and
+    the gradient the one w.r.t. the given rows -- inside the loss launch where its schedule allows
+    (``supcon_rows_supported``), by the row-normalisation kernels in front of it otherwise."""
     if state is None:
         state = SupConState()
-    return _SupConFn.apply(z1, z2, labels, mask, float(t), int(sp_mode), float(gamma), bool(correct_grad), state)
+    raw = False
+    if normalize_inputs:
+        n = z1.shape[0] // 2 if z2 is None else z1.shape[0]
+        if z1.dtype == torch.float32 and supcon_rows_supported(n, z1.shape[1], mask):
+            raw = True
+        else:
+            z1 = l2norm_rows(z1)
+            z2 = l2norm_rows(z2) if z2 is not None else None
+    return _SupConFn.apply(z1, z2, labels, mask, float(t), int(sp_mode), float(gamma), bool(correct_grad), state, raw)
 
 
 class _SupConHeadsFn(torch.autograd.Function):
@@ -111,7 +134,7 @@ class _SupConHeadsFn(torch.autograd.Function):
     ``states`` receive) is exactly that of ``_SupConFn``."""
 
     @staticmethod
-    def forward(ctx, labels, t, sp_mode, gammas, correct_grad, states, *zs):
+    def forward(ctx, labels, t, sp_mode, gammas, correct_grad, states, raw, *zs):
         K = len(zs)
         _n.require_gpu(*zs)
         n2, d = zs[0].shape
@@ -132,8 +155,9 @@ class _SupConHeadsFn(torch.autograd.Function):
         out = torch.empty(K, 8, dtype=torch.float32, device=dev)
         gam = (c_float * K)(*[float(g) for g in gammas])
         base = zall.data_ptr()
-        _n.call("spcl_supcon_forward_heads", K, base, base + n * d * 4, n2 * d, _n.ptr(labels), n, d, c_float(t), sp_mode, gam,
-                int(bool(correct_grad)), _n.ptr(ws), ws_stride, _n.ptr(out), _n.stream())
+        _n.call("spcl_supcon_forward_rows" if raw else "spcl_supcon_forward_heads", K, base, base + n * d * 4, n2 * d,
+                _n.ptr(labels), n, d, c_float(t), sp_mode, gam, int(bool(correct_grad)), _n.ptr(ws), ws_stride, _n.ptr(out),
+                _n.stream())
         for k, st in enumerate(states):
             st.n, st.d, st.t, st.sp_mode, st.gamma = n, d, t, sp_mode, float(gammas[k])
             st.labels, st.mask = (labels[k] if labels is not None else None), None
@@ -161,7 +185,7 @@ class _SupConHeadsFn(torch.autograd.Function):
         base = dz.data_ptr()
         _n.call("spcl_supcon_backward_heads", K, _n.ptr(labels), n, d, c_float(t), sp_mode, gam, _n.ptr(ws), ws_stride,
                 _n.ptr(wsb), wsb_stride, _n.ptr(out), _n.ptr(go), base, base + n * d * 4, 2 * n * d, _n.stream())
-        return (None, None, None, None, None, None) + tuple(dz[k].to(dtypes[k]) for k in range(K))
+        return (None, None, None, None, None, None, None) + tuple(dz[k].to(dtypes[k]) for k in range(K))
 
 
 _ONES_K = {}
@@ -175,15 +199,23 @@ def _ones_k(K, dev):
     return t
 
 
-def supcon_loss_heads(zs, labels=None, *, t=0.07, sp_mode=SP_NONE, gammas=None, correct_grad=False, states=None):
+def supcon_loss_heads(zs, labels=None, *, t=0.07, sp_mode=SP_NONE, gammas=None, correct_grad=False, states=None,
+                      normalize_inputs=False):
     """K 0-dim losses (a tuple) of the K stacked [2n, d] projections ``zs`` (2 <= K <= 4); ``labels``: [K, n] float tensor or
-    None; ``gammas``: K floats; ``states``: K SupConState objects that receive each head's device-side statistics."""
+    None; ``gammas``: K floats; ``states``: K SupConState objects that receive each head's device-side statistics.
+    ``normalize_inputs``: as in ``supcon_loss``."""
     K = len(zs)
     if states is None:
         states = [SupConState() for _ in range(K)]
     if gammas is None:
         gammas = [1e6] * K
-    return _SupConHeadsFn.apply(labels, float(t), int(sp_mode), tuple(gammas), bool(correct_grad), states, *zs)
+    raw = False
+    if normalize_inputs:
+        if all(z.dtype == torch.float32 for z in zs) and supcon_rows_supported(zs[0].shape[0] // 2, zs[0].shape[1]):
+            raw = True
+        else:
+            zs = [l2norm_rows(z) for z in zs]
+    return _SupConHeadsFn.apply(labels, float(t), int(sp_mode), tuple(gammas), bool(correct_grad), states, raw, *zs)
 
 
 class _SupConXposFn(torch.autograd.Function):
@@ -288,11 +320,12 @@ class _ProjectorFn(torch.autograd.Function):
         pooled = torch.empty(N, C, dtype=torch.float32, device=dev)
         pre = torch.empty(N, hid, dtype=torch.float32, device=dev) if mlp else None
         o = torch.empty(N, out_dim, dtype=torch.float32, device=dev)
-        z = torch.empty(N, out_dim, dtype=torch.float32, device=dev)
+        z = torch.empty(N, out_dim, dtype=torch.float32, device=dev) if normalize else o  # (no copy without normalisation)
         _n.call("spcl_proj_forward", _n.ptr(x), _n.dtype_code(x.dtype), N, H * W, C, cs, _n.ptr(w1c), _n.ptr(b1c),
                 _n.ptr(w2c), _n.ptr(b2c), hid, out_dim, int(bool(normalize)), _n.ptr(pooled), _n.ptr(pre), _n.ptr(o),
                 _n.ptr(z), _n.stream())
-        ctx.save_for_backward(w1c, w2c, pooled, pre, o)
+        # (without normalisation the output IS o: the backward does not read it then, and an output must not be saved raw)
+        ctx.save_for_backward(w1c, w2c, pooled, pre, o if normalize else None)
         ctx.meta = (N, H, W, C, cs, hid, out_dim, bool(normalize), x.dtype, feat.dtype)
         ctx.params = (w1, b1, w2, b2)  # their gradient sinks are claimed in backward, where the kernels write
         return z
@@ -356,12 +389,13 @@ class _ProjectorHeadsFn(torch.autograd.Function):
         pooled = torch.empty(N, C, dtype=torch.float32, device=dev)
         pre = torch.empty(K, N, hid, dtype=torch.float32, device=dev)
         o = torch.empty(K, N, out_dim, dtype=torch.float32, device=dev)
-        z = list(torch.empty(K, N, out_dim, dtype=torch.float32, device=dev).unbind(0))  # back to back: the batched loss reads them in place
+        # back to back: the batched loss reads them in place (without normalisation the heads' rows are the output: no copy)
+        z = list((torch.empty(K, N, out_dim, dtype=torch.float32, device=dev) if normalize else o).unbind(0))
         col = lambda i: _n.ptr_array([c[i] for c in cont])  # noqa: E731
         _n.call("spcl_proj_heads_forward", K, _n.ptr(x), _n.dtype_code(x.dtype), N, H * W, C, cs, col(0), col(1), col(2),
                 col(3), hid, out_dim, int(bool(normalize)), _n.ptr(pooled), _n.ptr_array(list(pre)), _n.ptr_array(list(o)),
                 _n.ptr_array(z), _n.stream())
-        ctx.save_for_backward(pooled, pre, o, *[c[0] for c in cont], *[c[2] for c in cont])
+        ctx.save_for_backward(pooled, pre, o if normalize else None, *[c[0] for c in cont], *[c[2] for c in cont])
         ctx.meta = (K, N, H, W, C, cs, hid, out_dim, bool(normalize), x.dtype, feat.dtype)
         ctx.params = params
         return tuple(z)
@@ -371,6 +405,7 @@ class _ProjectorHeadsFn(torch.autograd.Function):
         K, N, H, W, C, cs, hid, out_dim, normalize, xdt, fdt = ctx.meta
         saved = ctx.saved_tensors
         pooled, pre, o = saved[:3]
+        o = [None] * K if o is None else list(o)  # (without normalisation the backward does not read the rows)
         w1s, w2s = saved[3:3 + K], saved[3 + K:3 + 2 * K]
         dev = pooled.device
         dzc = [torch.zeros(N, out_dim, dtype=torch.float32, device=dev) if g is None else g.detach().contiguous().float()
@@ -386,13 +421,13 @@ class _ProjectorHeadsFn(torch.autograd.Function):
             dnc = torch.empty(N, C, dtype=xdt, device=dev)
             _n.call("spcl_proj_heads_backward_pooled", K, _n.ptr_array(dzc), _n.dtype_code(xdt), N, H * W, C, cs,
                     _n.ptr_array(list(w1s)), _n.ptr_array(list(w2s)), hid, out_dim, int(normalize), _n.ptr(pooled),
-                    _n.ptr_array(list(pre)), _n.ptr_array(list(o)), col(0), col(1), col(2), col(3), _n.ptr(scratch),
+                    _n.ptr_array(list(pre)), _n.ptr_array(o), col(0), col(1), col(2), col(3), _n.ptr(scratch),
                     _n.ptr(dnc), _n.stream())
             return (dnc.view(N, C, 1, 1).expand(N, C, H, W), None) + tuple(grads)
         dfeat = torch.empty(N, H, W, cs, dtype=xdt, device=dev) if need_dfeat else None
         _n.call("spcl_proj_heads_backward", K, _n.ptr_array(dzc), _n.dtype_code(xdt), N, H * W, C, cs, _n.ptr_array(list(w1s)),
                 _n.ptr_array(list(w2s)), hid, out_dim, int(normalize), _n.ptr(pooled), _n.ptr_array(list(pre)),
-                _n.ptr_array(list(o)), col(0), col(1), col(2), col(3), _n.ptr(scratch), _n.ptr(dfeat), _n.stream())
+                _n.ptr_array(o), col(0), col(1), col(2), col(3), _n.ptr(scratch), _n.ptr(dfeat), _n.stream())
         gfeat = None
         if need_dfeat:
             gfeat = nhwc_to_logical(dfeat, C)
@@ -491,6 +526,33 @@ class _L2NormChannelsFn(torch.autograd.Function):
 
 def l2norm_channels(x):
     return _L2NormChannelsFn.apply(x)
+
+
+class _L2NormRowsFn(torch.autograd.Function):
+    """F.normalize(x, p=2, dim=1) of [rows, d] f32 rows (projectors/nn.py:29-36)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        _n.require_gpu(x)
+        xc = x.detach().contiguous().float()
+        z = torch.empty_like(xc)
+        _n.call("spcl_l2norm_rows_forward", _n.ptr(xc), xc.shape[0], xc.shape[1], _n.ptr(z), _n.stream())
+        ctx.save_for_backward(xc)
+        ctx.in_dtype = x.dtype
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        (xc,) = ctx.saved_tensors
+        dx = torch.empty_like(xc)
+        _n.call("spcl_l2norm_rows_backward", _n.ptr(xc), _n.ptr(dz.detach().contiguous().float()), xc.shape[0], xc.shape[1],
+                _n.ptr(dx), _n.stream())
+        return dx.to(ctx.in_dtype)
+
+
+def l2norm_rows(x):
+    assert x.dim() == 2, x.shape
+    return _L2NormRowsFn.apply(x)
 
 
 def pixelwise_mlp(feat, w1, b1, w2=None, b2=None):

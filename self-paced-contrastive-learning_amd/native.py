@@ -72,6 +72,9 @@ _SIGNATURES = {
                                      _P]),
     "spcl_supcon_forward_heads": (c_int, [c_int, _P, _P, c_size_t, _P, c_int, c_int, c_float, c_int, _P, c_int, _P,
                                           c_size_t, _P, _P]),
+    "spcl_supcon_rows_supported": (c_int, [c_int, c_int]),
+    "spcl_supcon_forward_rows": (c_int, [c_int, _P, _P, c_size_t, _P, c_int, c_int, c_float, c_int, _P, c_int, _P,
+                                         c_size_t, _P, _P]),
     "spcl_supcon_backward_heads": (c_int, [c_int, _P, c_int, c_int, c_float, c_int, _P, _P, c_size_t, _P, c_size_t, _P,
                                            _P, _P, _P, c_size_t, _P]),
     "spcl_conv_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
@@ -209,7 +212,7 @@ WGRAD_BATCH_MAX = 16
 WGRAD_TAILS_MAX = 16
 _NO_STATUS = ("spcl_abi_version", "spcl_conv3x3_forward_image_acorr_rows", "spcl_image_autocorr_rows", "spcl_conv_dgrad_bnstats_image_supported", "spcl_conv16_bwd_fused_supported", "spcl_conv16_bwd_fused_splits", "spcl_conv_num_tiles", "spcl_conv_stat_rows", "spcl_conv_set_gemm", "spcl_supcon_unit_gradient_block", "spcl_conv_cat_supported", "spcl_conv_up2_supported", "spcl_conv_split_supported", "spcl_conv_split_bnstats_supported", "spcl_conv1x1_bwd_rows", "spcl_profile_count", "spcl_conv_dgrad_bnstats_supported", "spcl_conv_dgrad_poolstats_supported",
               "spcl_conv_wgrad_batched_supported", "spcl_conv_bn_acc_supported", "spcl_conv_dgrad_bnstats_acc_supported",
-              "spcl_conv_dgrad_poolstats_acc_supported")
+              "spcl_conv_dgrad_poolstats_acc_supported", "spcl_supcon_rows_supported")
 
 
 class NativeLibraryError(RuntimeError):

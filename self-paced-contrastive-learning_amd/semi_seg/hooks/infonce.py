@@ -7,6 +7,7 @@ Differences that do not change results: the TensorBoard figure taps of the first
 delivered to an optional ``tap_callback(name, tensor, epocher)`` instead of a global writer; the feature flip before the
 projector (:177-178) is skipped when the projector pools to (1,1) -- a global average is flip-invariant."""
 import math
+import os
 from typing import List
 
 import torch
@@ -20,6 +21,8 @@ from ..arch.hook import SingleFeatureExtractor
 from ..arch.unet import UNet
 from ..epochers.helper import FixRandomSeed
 from .utils import get_label, meter_focus
+
+_FUSE_NORM = os.environ.get("SPCL_FUSE_NORM", "1") != "0"  # A/B switch: 0 keeps the projector's normalisation launches
 
 encoder_names = list(UNet.encoder_names)
 decoder_names = list(UNet.decoder_names)
@@ -173,24 +176,34 @@ class _INFONCEEpochHook(EpocherHook):
         shape = lambda p: (tuple(p._header[2].weight.shape), tuple(p._header[4].weight.shape), bool(p._normalize))  # noqa: E731
         return all(shape(p) == shape(ps[0]) for p in ps)
 
-    def _project(self, feature, base):
-        """z of this hook's head; with a batch group the first hook of the step projects for all of them (cached on the
-        tapped tensor, which lives exactly one step)"""
+    def _fuse_norm(self):
+        """may the projector's F.normalize run inside the criterion's launch?  (ProjectionHead(normalize=True) in front of
+        one of the two supervised-contrastive criteria: ``projector(x, normalize=False)`` + ``criterion(...,
+        normalize_inputs=True)`` is the same function of the feature, two launches shorter)"""
+        if not _FUSE_NORM:
+            return False
+        members = self._batch_group if self._batch_group is not None else (self,)
+        return all(type(m._projector).__name__ == "ProjectionHead" and bool(getattr(m._projector, "_normalize", False))
+                   and isinstance(m._criterion, (SupConLoss1, SelfPacedSupConLoss)) for m in members)
+
+    def _project(self, feature, base, raw=False):
+        """z of this hook's head (``raw``: its rows before F.normalize); with a batch group the first hook of the step
+        projects for all of them (cached on the tapped tensor, which lives exactly one step)"""
         if self._batch_group is None:
-            return self._projector(feature)
+            return self._projector(feature, normalize=False) if raw else self._projector(feature)
         cache = getattr(base, "_spcl_zs", None)
-        if cache is None or cache[0] != feature.shape[0]:
+        if cache is None or cache[0] != (feature.shape[0], raw):
             heads = [(p._header[2].weight, p._header[2].bias, p._header[4].weight, p._header[4].bias)
                      for p in (m._projector for m in self._batch_group)]
-            zs = F_hip.projector_heads(feature, heads, self._projector._normalize)
-            cache = (feature.shape[0], {id(m._projector): z for m, z in zip(self._batch_group, zs)})
+            zs = F_hip.projector_heads(feature, heads, self._projector._normalize and not raw)
+            cache = ((feature.shape[0], raw), {id(m._projector): z for m, z in zip(self._batch_group, zs)})
             try:
                 base._spcl_zs = cache
             except AttributeError:
                 pass
         return cache[1][id(self._projector)]
 
-    def _group_loss(self, feature, base, partition_group, label_group):
+    def _group_loss(self, feature, base, partition_group, label_group, raw=False):
         """This hook's loss out of the group's batched evaluation -- the first hook of the step projects for all heads AND
         evaluates all K criteria in the launches of one (contrast_loss3.supcon_heads; row N4), cached on the tapped tensor
         like the projections -- or None when there is no group or its criteria cannot be batched."""
@@ -199,9 +212,9 @@ class _INFONCEEpochHook(EpocherHook):
         cache = getattr(base, "_spcl_losses", None)
         if cache is None or cache[0] != feature.shape[0]:
             members = self._batch_group
-            zs = [m._project(feature, base) for m in members]
+            zs = [m._project(feature, base, raw) for m in members]
             targets = [m._labels(partition_group, label_group, feature.device) for m in members]
-            losses = supcon_heads([m._criterion for m in members], zs, targets)
+            losses = supcon_heads([m._criterion for m in members], zs, targets, normalize_inputs=raw)
             cache = (feature.shape[0], None if losses is None else {id(m): l for m, l in zip(members, losses)})
             try:
                 base._spcl_losses = cache
@@ -281,10 +294,12 @@ class _INFONCEEpochHook(EpocherHook):
                  label_group, **kwargs):
         feature = self._two_views(len(unlabeled_logits_tf), affine_transformer, seed)
         base = self._extractor.feature()
-        loss = self._group_loss(feature, base, partition_group, label_group)
+        raw = self._fuse_norm()
+        loss = self._group_loss(feature, base, partition_group, label_group, raw)
         if loss is None:
-            z_first, z_second = torch.chunk(self._project(feature, base), 2)
-            loss = self._criterion(z_first, z_second, target=self._labels(partition_group, label_group, feature.device))
+            z_first, z_second = torch.chunk(self._project(feature, base, raw), 2)
+            loss = self._criterion(z_first, z_second, target=self._labels(partition_group, label_group, feature.device),
+                                   **({"normalize_inputs": True} if raw else {}))
         self._record(loss)
         return loss if self._weight == 1 else loss * self._weight
 

@@ -396,3 +396,27 @@ def test_config4_hard_gamma7_large_batch(n, d, nlab):
     scale = float(np.abs(want).max())
     bad_rows = int((np.abs(got - want).max(axis=1) > 2e-3 * scale).sum())
     assert bad_rows <= 24 and np.abs(got - want).max() < 0.1 * scale, (bad_rows, np.abs(got - want).max() / scale)
+
+
+@pytest.mark.parametrize("ons,weights,data_name", [("partition", 1.0, "acdc"),
+                                                   (["partition", "patient", "self"], [1.0, 0.5, 0.25], "prostate")])
+def test_normalisation_inside_the_loss_launch_is_the_same_step(ons, weights, data_name, monkeypatch):
+    """the hook's default (``projector(x, normalize=False)`` + ``criterion(..., normalize_inputs=True)``: F.normalize and
+    its backward inside the loss launch) against the projector's own normalisation launches (SPCL_FUSE_NORM=0), one hook and
+    the three batched ones: same loss bits; gradients equal to 1e-3 in relative L2 per tensor (the row dot product of
+    F.normalize's backward is summed in another order: 1e-7 at the head, amplified by the cancellations of five BatchNorm
+    backwards on the way down)"""
+    import spcl_amd.semi_seg.hooks.infonce as H
+    got = {}
+    for fuse in (True, False):
+        monkeypatch.setattr(H, "_FUSE_NORM", fuse)
+        run = _step(64, 8, torch.float32, ons, weights, 6.0, data_name, partition_num=4)
+        grads = {k: p.grad.clone() for k, p in run["net"].named_parameters() if p.grad is not None}
+        for hi, h in enumerate(run["hook"]._hooks):
+            grads.update({f"head{hi}.{k}": p.grad.clone() for k, p in h._projector.named_parameters()})
+        got[fuse] = (run["loss"], grads)
+    assert got[True][0] == got[False][0], (got[True][0], got[False][0])
+    assert got[True][1].keys() == got[False][1].keys() and len(got[True][1]) > 10
+    for k, a in got[True][1].items():
+        b = got[False][1][k]
+        assert _rell2(a.cpu().numpy(), b.cpu().numpy()) < 1e-3, (k, _rell2(a.cpu().numpy(), b.cpu().numpy()))

@@ -355,3 +355,77 @@ def test_loss_heads_refuses_what_it_cannot_batch():
     assert supcon_heads([_crit(None, 1, False)], z[:1], lab[:1]) is None                           # one head
     big = [torch.nn.functional.normalize(torch.randn(1024, 32), dim=1).to(dev) for _ in range(2)]
     assert supcon_heads([_crit(None, 1, False)] * 2, big, [torch.zeros(512, device=dev)] * 2) is None  # large-batch size
+
+
+@pytest.mark.parametrize("n,d,nlab", [(32, 256, 3), (8, 128, 2), (5, 100, 2), (30, 64, 7), (64, 128, 5)])
+@pytest.mark.parametrize("mname", ["supcon1", "soft_12_cg", "hard_1e6"])
+def test_normalize_inputs_is_normalize_then_loss(n, d, nlab, mname):
+    """``criterion(o1, o2, normalize_inputs=True)`` (spcl_supcon_forward_rows: F.normalize of projectors/nn.py:29-36 and its
+    backward inside the loss launch at training sizes; row-normalisation kernels in front of the sweeps at (64, 128)) against
+    the oracle on F.normalize(o) and against the two-step HIP path: same loss bits (the normalised rows are the same bits),
+    gradient w.r.t. the raw rows to 1e-5 of its scale (another summation order in the row dot product)."""
+    import spcl_amd  # noqa: F401
+    import spcl_amd.functional as F_hip
+    mode, gamma, cg = MODES[mname]
+    g = torch.Generator().manual_seed(n * 11 + d)
+    o = torch.randn(2 * n, d, generator=g) * (0.2 + 3.0 * torch.rand(2 * n, 1, generator=g))  # rows of very different norms
+    labels = [i % nlab for i in range(n)]
+    a = o.clone().requires_grad_(True)
+    z = torch.nn.functional.normalize(a, dim=1)
+    ref = O.supcon_loss(z[:n], z[n:], labels, gamma=gamma, mode=mode or "hard", correct_grad=cg)
+    (2.5 * ref["loss"]).backward()
+    # fused
+    x = o.cuda().requires_grad_(True)
+    crit = _crit(mode, gamma, cg)
+    loss = crit(*torch.chunk(x, 2), target=labels, normalize_inputs=True)
+    (2.5 * loss).backward()
+    # two steps on the device
+    y = o.cuda().requires_grad_(True)
+    crit2 = _crit(mode, gamma, cg)
+    loss2 = crit2(*torch.chunk(F_hip.l2norm_rows(y), 2), target=labels)
+    (2.5 * loss2).backward()
+    assert torch.equal(loss, loss2), (loss.item(), loss2.item())
+    np.testing.assert_allclose(loss.item(), ref["loss"].item(), rtol=1e-4, atol=1e-5)
+    scale = float(a.grad.abs().max())
+    np.testing.assert_allclose(x.grad.cpu().numpy(), y.grad.cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), a.grad.numpy(), rtol=2e-3, atol=2e-4 * scale)
+    if mode is not None:
+        np.testing.assert_allclose(crit.downgrade_ratio, float(ref["rho"]), rtol=1e-4)
+        assert torch.equal(crit.sp_mask, crit2.sp_mask)
+    assert torch.equal(crit.sim_logits, crit2.sim_logits)  # the taps see the normalised rows
+    crit.check()  # unit-norm assertion of the reference: on the rows the launch normalised
+
+
+def test_normalize_inputs_unit_gradient_block_and_heads():
+    """the epocher's registered unit gradient takes the forward's block (now d loss / d raw rows) as the gradient, and K
+    heads in one launch (spcl_supcon_forward_rows, K > 1) equal K single calls bit for bit"""
+    import spcl_amd  # noqa: F401
+    import spcl_amd.functional as F_hip
+    from spcl_amd.contrastyou.losses.contrast_loss3 import supcon_heads
+    dev = "cuda:0"
+    n, d, K = 32, 256, 3
+    g = torch.Generator().manual_seed(5)
+    os_ = [(torch.randn(2 * n, d, generator=g) * 1.7).to(dev) for _ in range(K)]
+    labels = [torch.randint(0, 3 + k, (n,), generator=g).float().to(dev) for k in range(K)]
+    ones = torch.ones((), device=dev)
+    F_hip.register_unit_gradient(ones)
+    a = os_[0].clone().requires_grad_(True)
+    c = _crit("soft", 4.0, True)
+    c(*torch.chunk(a, 2), target=labels[0], normalize_inputs=True).backward(gradient=ones)
+    b = os_[0].clone().requires_grad_(True)
+    c2 = _crit("soft", 4.0, True)
+    (c2(*torch.chunk(b, 2), target=labels[0], normalize_inputs=True) * 1.0).backward()  # ordinary upstream gradient
+    assert torch.equal(a.grad, b.grad)
+    # K heads
+    a_z = [o.clone().requires_grad_(True) for o in os_]
+    a_c = [_crit("hard", 3.0 + k, False) for k in range(K)]
+    a_l = [cr(*torch.chunk(z, 2), target=t, normalize_inputs=True) for cr, z, t in zip(a_c, a_z, labels)]
+    sum(a_l).backward()
+    b_z = [o.clone().requires_grad_(True) for o in os_]
+    b_c = [_crit("hard", 3.0 + k, False) for k in range(K)]
+    b_l = supcon_heads(b_c, b_z, labels, normalize_inputs=True)
+    sum(b_l).backward()
+    for k in range(K):
+        assert torch.equal(a_l[k], b_l[k])
+        assert torch.equal(a_z[k].grad, b_z[k].grad)
+        assert torch.equal(a_c[k].sim_logits, b_c[k].sim_logits)

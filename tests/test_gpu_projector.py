@@ -106,3 +106,27 @@ def test_batched_heads_equal_the_single_head_calls(K, dtype):
             assert torch.equal(a, b)
     tol = 1e-5 if dtype == torch.float32 else 2e-2  # the K gradients are added in f32 before the one bf16 rounding
     assert float((gf0.float() - gf1.float()).abs().max()) <= tol * float(gf0.float().abs().max())
+
+
+def test_projector_call_time_normalize_false_returns_the_rows_before_normalisation():
+    """``head(x, normalize=False)`` (the hook's form in front of ``criterion(..., normalize_inputs=True)``): the rows whose
+    F.normalize the ordinary call returns, bit for bit, and the same parameter / input gradients through
+    ``l2norm_rows`` as through the head's own normalisation"""
+    import spcl_amd.functional as F_hip
+    head, _ = _head(64, 48, 32, 3)
+    x = torch.randn(6, 64, 5, 5, generator=torch.Generator().manual_seed(1)).relu().cuda()
+    r = torch.randn(6, 32, generator=torch.Generator().manual_seed(2)).cuda()
+    xa = x.clone().requires_grad_(True)
+    za = head(xa)
+    (za * r).sum().backward()
+    ga = {k: p.grad.clone() for k, p in head.named_parameters()}
+    head.zero_grad(set_to_none=True)
+    xb = x.clone().requires_grad_(True)
+    ob = head(xb, normalize=False)
+    zb = F_hip.l2norm_rows(ob)
+    (zb * r).sum().backward()
+    assert torch.equal(za, zb)
+    assert not torch.equal(ob, zb)
+    assert torch.equal(xa.grad, xb.grad)
+    for k, p in head.named_parameters():
+        assert torch.equal(p.grad, ga[k]), k
