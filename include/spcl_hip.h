@@ -34,7 +34,7 @@ extern "C" {
 /* Bumped whenever a struct layout, a limit (SPCL_*_MAX) or an entry point's meaning changes.  The library is git-ignored and
  * travels next to the sources: the Python binding (native.py) refuses a library whose version is not the header's, so that a
  * stale build fails at load time instead of running kernels on structs of another stride. */
-#define SPCL_ABI_VERSION 4
+#define SPCL_ABI_VERSION 5
 int spcl_abi_version(void);
 const char* spcl_last_error(void);
 
@@ -554,14 +554,11 @@ int spcl_split2_channels(const void* in, void* a, void* b, int elem_size, size_t
  * flat fp32 parameter:  g' = g + wd p;  m = lerp(m, g', 1-b1);  v = b2 v + (1-b2) g'^2;  t = ++step;
  *   rho_t = rho_inf - 2 t b2^t/(1-b2^t);  p -= lr m/(1-b1^t) * (rho_t > 5 ? rect(rho_t) sqrt(1-b2^t)/(sqrt(v)+eps) : 1).
  * step (int64) and lr (float) live in device memory so that a captured hipGraph replays with an advancing step
- * count and a host-updated learning rate; coef: 4 floats of device scratch, ZERO before the first call (coef[0..2] hold
- * the step's scalar coefficients afterwards, coef[3] is a ticket word that is zero between launches).  One launch: every
- * workgroup derives the coefficients from the (read-only) counter, the last one to finish writes the counter back.
- * All buffers 16-byte aligned. */
+ * count and a host-updated learning rate; coef: 4 floats of device scratch.  All buffers 16-byte aligned. */
 int spcl_radam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, int64_t* step,
                     const float* lr, double beta1, double beta2, double eps, double weight_decay, float* coef,
                     void* stream);
-/* the same, and the step's meter updates (spcl_accumulate_scalars' k <= 8 pairs) ride in the same launch: one
+/* the same, and the step's meter updates (spcl_accumulate_scalars' k <= 8 pairs) ride in its coefficient launch: one
  * launch less per training step.  k == 0: exactly spcl_radam_step. */
 int spcl_radam_step_scalars(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, int64_t* step,
                             const float* lr, double beta1, double beta2, double eps, double weight_decay, float* coef,
@@ -573,6 +570,14 @@ int spcl_radam_step_scalars(float* param, const float* grad, float* exp_avg, flo
 int spcl_radam_step_scaled(float* param, const float* grad, double grad_scale, float* exp_avg, float* exp_avg_sq, size_t n,
                            int64_t* step, const float* lr, double beta1, double beta2, double eps, double weight_decay,
                            float* coef, int k, const void* const* src, void* const* dst, const float* count, void* stream);
+/* the same WITHOUT the coefficient launch: coef[0..2] = { lr / (1 - b1^t), rho_t > 5 ? rect(rho_t) sqrt(1 - b2^t) : 0,
+ * rho_t > 5 } and coef[3] = t were computed by the caller on the host (the formulas above, in double) and are already in
+ * device memory -- a step replayed from a hipGraph uploads a few host-written bytes per replay anyway (labels, flip flags:
+ * spcl_stage_bytes / spcl_flip_pair_stage), the four floats travel with them.  The launch records t in *step (so that the
+ * counter, which spcl_radam_step reads, stays the state_dict's truth) and performs the k meter updates. */
+int spcl_radam_apply_staged(float* param, const float* grad, double grad_scale, float* exp_avg, float* exp_avg_sq, size_t n,
+                            int64_t* step, const float* coef, double beta1, double beta2, double eps, double weight_decay,
+                            int k, const void* const* src, void* const* dst, const float* count, void* stream);
 
 /* Running means of the host-side meters (contrastyou/meters/averagemeter.py via MeterInterface) kept on the device:
  * for i < k (k <= 8):  dst[i][0] += count[i] * src[i][0];  dst[i][1] += count[i].  src / dst / count are HOST arrays

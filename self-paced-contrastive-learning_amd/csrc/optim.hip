@@ -1,8 +1,8 @@
 // Fused RAdam step on ONE flat fp32 parameter (the optimizer step of the pre-train iteration,
 // contrastyou/trainer/base.py:62 -> RAdam; the build follows torch.optim.RAdam).
 // torch's foreach implementation is ~40 elementwise launches over the 1.3 M-element flat parameter (~270 us per
-// step); this is ONE streaming kernel (p, g, m, v read once, p, m, v written once: 28 bytes per element) that also keeps
-// the step counter and derives the scalar coefficients (in double) itself.
+// step); this is one 1-thread "tick" (step counter + the scalar coefficients, in double) and one streaming kernel
+// (p, g, m, v read once, p, m, v written once: 28 bytes per element).
 #include <string.h>
 #include "common.hpp"
 
@@ -15,59 +15,78 @@ struct ScalarAdds {
   int k;
 };
 
+// beta^t by repeated squaring: IEEE multiplications only, so that the host (optim.py radam_coefficients, the staged steps)
+// and this kernel produce the same bits -- a replayed step and an eager one then update with identical coefficients
+__device__ __forceinline__ double ipow(double b, int64_t e) {
+#pragma clang fp contract(off)
+  double r = 1.0;
+  while (e > 0) {
+    if (e & 1) r *= b;
+    b *= b;
+    e >>= 1;
+  }
+  return r;
+}
+
 // coef[0] = lr / (1 - beta1^t);  coef[1] = rect * sqrt(1 - beta2^t) when rho_t > 5 else 0;  coef[2] = rho_t > 5
-// Round 5: no launch of its own for these.  Thread 0 of EVERY workgroup derives them (in double, ~1 us under the flight of
-// the workgroup's first loads) from the step counter, which stays read-only while the launch runs: each workgroup takes
-// a ticket when it is done (its read of the counter is behind it by then), and the workgroup that takes the LAST ticket
-// writes the incremented counter and the coefficients (kept in `coef` for inspection) and resets the ticket.  Nobody
-// waits for anybody: the ticket orders one word, not work.  coef[3] is the ticket (zero between launches).
-// Threads 1 .. k of workgroup 0 perform the step's meter updates (spcl_radam_step_scalars): the running means of the
-// host-side meters are one more few-microsecond launch per step otherwise.
-__global__ __launch_bounds__(1024) void radam_apply_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                          float* __restrict__ m, float* __restrict__ v, size_t n4,
-                                                          size_t n, int64_t* step, const float* __restrict__ lr,
-                                                          double beta1, double beta2, float* coef, float eps, float wd,
-                                                          float gscale, ScalarAdds a) {
-  __shared__ float sc[3];
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  f32x4 pp = {0.f, 0.f, 0.f, 0.f}, gg = pp, mm = pp, vv = pp;
-  if (i < n4) {  // the first round's requests go out ahead of the coefficient arithmetic
-    pp = ((f32x4*)p)[i]; gg = ((const f32x4*)g)[i]; mm = ((f32x4*)m)[i]; vv = ((f32x4*)v)[i];
-  }
-  int64_t t = 0;
-  if (threadIdx.x == 0) {
-    t = step[0] + 1;
-    const double b1t = pow(beta1, (double)t), b2t = pow(beta2, (double)t);
-    const double bc1 = 1.0 - b1t, bc2 = 1.0 - b2t;
-    const double rho_inf = 2.0 / (1.0 - beta2) - 1.0;
-    const double rho_t = rho_inf - 2.0 * (double)t * b2t / bc2;
-    sc[0] = (float)((double)lr[0] / bc1);
-    if (rho_t > 5.0) {
-      const double rect = sqrt((rho_t - 4.0) * (rho_t - 2.0) * rho_inf / ((rho_inf - 4.0) * (rho_inf - 2.0) * rho_t));
-      sc[1] = (float)(rect * sqrt(bc2));
-      sc[2] = 1.f;
-    } else {
-      sc[1] = 0.f;
-      sc[2] = 0.f;
+// Threads 1 .. k of the same (one-wave) launch perform the step's meter updates (spcl_radam_step_scalars): the running
+// means of the host-side meters are one more few-microsecond launch per step otherwise.
+__global__ __launch_bounds__(64) void radam_tick_kernel(int64_t* step, const float* lr, double beta1, double beta2,
+                                                        float* coef, ScalarAdds a) {
+  if (threadIdx.x > 0) {
+    const int i = threadIdx.x - 1;
+    if (i < a.k) {
+      a.dst[i][0] = fmaf(a.count[i], a.src[i][0], a.dst[i][0]);
+      a.dst[i][1] += a.count[i];
     }
-  } else if (blockIdx.x == 0 && (int)threadIdx.x <= a.k) {
-    const int j = threadIdx.x - 1;
-    a.dst[j][0] = fmaf(a.count[j], a.src[j][0], a.dst[j][0]);
-    a.dst[j][1] += a.count[j];
+    return;
   }
-  __syncthreads();
-  const float c_m = sc[0], c_u = sc[1];
-  const bool rect = sc[2] != 0.f;
-  const float omb1 = (float)(1.0 - beta1), b2f = (float)beta2, omb2 = (float)(1.0 - beta2);
-  auto upd = [&](float& pe, float ge, float& me, float& ve) {
-    ge = fmaf(wd, pe, ge * gscale);            // gscale: 1 / world of the data-parallel mean (1.f: exact identity)
-    me = fmaf(omb1, ge - me, me);              // lerp_(grad, 1 - beta1)
-    ve = fmaf(ve, b2f, omb2 * ge * ge);        // mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
-    const float u = rect ? c_u / (sqrtf(ve) + eps) : 1.f;
-    pe = fmaf(-c_m * me, u, pe);
+#pragma clang fp contract(off)
+  const int64_t t = step[0] + 1;
+  step[0] = t;
+  const double b1t = ipow(beta1, t), b2t = ipow(beta2, t);
+  const double bc1 = 1.0 - b1t, bc2 = 1.0 - b2t;
+  const double rho_inf = 2.0 / (1.0 - beta2) - 1.0;
+  const double rho_t = rho_inf - 2.0 * (double)t * b2t / bc2;
+  coef[0] = (float)((double)lr[0] / bc1);
+  if (rho_t > 5.0) {
+    const double rect = sqrt((rho_t - 4.0) * (rho_t - 2.0) * rho_inf / ((rho_inf - 4.0) * (rho_inf - 2.0) * rho_t));
+    coef[1] = (float)(rect * sqrt(bc2));
+    coef[2] = 1.f;
+  } else {
+    coef[1] = 0.f;
+    coef[2] = 0.f;
+  }
+}
+
+// STAGED (spcl_radam_apply_staged): the coefficients were computed on the host and travel with the step's staged bytes
+// (coef[3] = the step count t they belong to): no coefficient launch; workgroup 0 records t in the device counter and its
+// threads 1 .. k perform the meter updates.
+template <bool STAGED>
+__global__ __launch_bounds__(256) void radam_apply_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                          float* __restrict__ m, float* __restrict__ v, size_t n4,
+                                                          size_t n, const float* __restrict__ coef, float omb1,
+                                                          float beta2, float omb2, float eps, float wd, float gscale,
+                                                          int64_t* step, ScalarAdds a) {
+  const float c_m = coef[0], c_u = coef[1];
+  const bool rect = coef[2] != 0.f;
+  if (STAGED && blockIdx.x == 0) {
+    if (threadIdx.x == 0) step[0] = (int64_t)coef[3];
+    else if ((int)threadIdx.x <= a.k) {
+      const int j = threadIdx.x - 1;
+      a.dst[j][0] = fmaf(a.count[j], a.src[j][0], a.dst[j][0]);
+      a.dst[j][1] += a.count[j];
+    }
+  }
+  auto upd = [&](float& pp, float gg, float& mm, float& vv) {
+    gg = fmaf(wd, pp, gg * gscale);            // gscale: 1 / world of the data-parallel mean (1.f: exact identity)
+    mm = fmaf(omb1, gg - mm, mm);              // lerp_(grad, 1 - beta1)
+    vv = fmaf(vv, beta2, omb2 * gg * gg);      // mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+    const float u = rect ? c_u / (sqrtf(vv) + eps) : 1.f;
+    pp = fmaf(-c_m * mm, u, pp);
   };
-  while (i < n4) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    f32x4 pp = ((f32x4*)p)[i], gg = ((const f32x4*)g)[i], mm = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float pe = pp[e], me = mm[e], ve = vv[e];
@@ -77,23 +96,10 @@ __global__ __launch_bounds__(1024) void radam_apply_kernel(float* __restrict__ p
     ((f32x4*)p)[i] = pp;
     ((f32x4*)m)[i] = mm;
     ((f32x4*)v)[i] = vv;
-    i += stride;
-    if (i < n4) {
-      pp = ((f32x4*)p)[i]; gg = ((const f32x4*)g)[i]; mm = ((f32x4*)m)[i]; vv = ((f32x4*)v)[i];
-    }
   }
   if (blockIdx.x == 0 && threadIdx.x < (int)(n - 4 * n4)) {  // tail of n % 4 elements
-    const size_t q = 4 * n4 + threadIdx.x;
-    upd(p[q], g[q], m[q], v[q]);
-  }
-  if (threadIdx.x == 0) {
-    unsigned* ticket = (unsigned*)(coef + 3);
-    const unsigned mine = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (mine == gridDim.x - 1) {  // every workgroup has read step[0] by now (each before its own ticket)
-      step[0] = t;
-      coef[0] = sc[0]; coef[1] = sc[1]; coef[2] = sc[2];
-      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    const size_t i = 4 * n4 + threadIdx.x;
+    upd(p[i], g[i], m[i], v[i]);
   }
 }
 
@@ -192,14 +198,40 @@ extern "C" int spcl_radam_step_scaled(float* param, const float* grad, double gr
                  "radam_step: buffers must be 16-byte aligned");
   SPCL_CHECK_ARG(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0, "radam_step: betas");
   hipStream_t st = (hipStream_t)stream;
+  SPCL_LAUNCH(radam_tick_kernel, dim3(1), dim3(k > 0 ? 64 : 1), 0, st, step, lr, beta1, beta2, coef, adds);
   const size_t n4 = n / 4;
-  // (few, wide workgroups: the tickets are same-address atomics, which the memory side serialises at ~8 ns each -- 2 048
-  // of them, from workgroups that all finish together, were 16 us at the end of a 7 us kernel)
-  size_t blocks = (n4 + 1023) / 1024;
-  if (blocks > 256) blocks = 256;
+  size_t blocks = (n4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
-  SPCL_LAUNCH(radam_apply_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, param, grad, exp_avg, exp_avg_sq, n4, n, step,
-              lr, beta1, beta2, coef, (float)eps, (float)weight_decay, (float)grad_scale, adds);
+  SPCL_LAUNCH(radam_apply_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq, n4,
+                     n, (const float*)coef, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
+                     (float)weight_decay, (float)grad_scale, (int64_t*)nullptr, adds);
   SPCL_LAUNCH_CHECK("radam_step");
+  return SPCL_OK;
+}
+
+extern "C" int spcl_radam_apply_staged(float* param, const float* grad, double grad_scale, float* exp_avg,
+                                       float* exp_avg_sq, size_t n, int64_t* step, const float* coef, double beta1,
+                                       double beta2, double eps, double weight_decay, int k, const void* const* src,
+                                       void* const* dst, const float* count, void* stream) {
+  SPCL_CHECK_ARG(grad_scale > 0.0 && grad_scale <= 1.0, "radam_apply_staged: grad_scale in (0, 1]");
+  SPCL_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && step && coef, "radam_apply_staged: null pointer");
+  SPCL_CHECK_ARG(k >= 0 && k <= 8 && (k == 0 || (src && dst && count)), "radam_apply_staged: 0 <= k <= 8 scalar adds");
+  ScalarAdds adds;
+  adds.k = 0;
+  if (k > 0)
+    if (int rc = fill_scalar_adds(adds, k, src, dst, count, "radam_apply_staged")) return rc;
+  SPCL_CHECK_ARG(n > 0, "radam_apply_staged: empty parameter");
+  SPCL_CHECK_ARG(((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | (uintptr_t)coef) % 16 == 0,
+                 "radam_apply_staged: buffers must be 16-byte aligned");
+  SPCL_CHECK_ARG(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0, "radam_apply_staged: betas");
+  const size_t n4 = n / 4;
+  size_t blocks = (n4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  SPCL_LAUNCH(radam_apply_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+              exp_avg_sq, n4, n, coef, (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
+              (float)weight_decay, (float)grad_scale, step, adds);
+  SPCL_LAUNCH_CHECK("radam_apply_staged");
   return SPCL_OK;
 }

@@ -309,7 +309,7 @@ class PretrainEncoderEpocher:
         from ...optim import FusedRAdam
         if isinstance(self._optimizer, FusedRAdam):  # the meters' device adds ride in the optimizer's coefficient launch
             scale = self._flat_params.grad_scale if self._flat_params is not None else 1.0  # (1 / world when fold_mean)
-            self._optimizer.step(scalar_adds=_meters.take_batch(), grad_scale=scale)
+            self._optimizer.step(scalar_adds=_meters.take_batch(), grad_scale=scale, stage=self.stage)
         else:
             self._optimizer.step()
         _meters.flush_batch()

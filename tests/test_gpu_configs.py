@@ -410,6 +410,7 @@ def test_normalisation_inside_the_loss_launch_is_the_same_step(ons, weights, dat
     got = {}
     for fuse in (True, False):
         monkeypatch.setattr(H, "_FUSE_NORM", fuse)
+        torch.manual_seed(123)  # (the hooks' projectors are initialised from the global generator)
         run = _step(64, 8, torch.float32, ons, weights, 6.0, data_name, partition_num=4)
         grads = {k: p.grad.clone() for k, p in run["net"].named_parameters() if p.grad is not None}
         for hi, h in enumerate(run["hook"]._hooks):
