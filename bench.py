@@ -662,10 +662,33 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     wd.beat("reduce")
+    multi = None
     if world > 1:
+        # every rank's own clock (a slow rank or a slow link shows here) ...
+        per_rank = torch.zeros(world, device=device, dtype=torch.float64)
+        per_rank[rank] = elapsed / args.steps * 1e3
+        dist.all_reduce(per_rank)
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # ... and the step's one collective alone: HIP events around the epocher's exchange (flat bucket, communication
+        # stream, both stream waits included), median of 20 after 5 warm calls, MAX over the ranks
+        xs = []
+        for k in range(25):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            epocher.step_exchange()
+            e1.record()
+            e1.synchronize()
+            if k >= 5:
+                xs.append(e0.elapsed_time(e1) * 1e3)
+        xs.sort()
+        ar = torch.tensor([xs[len(xs) // 2]], device=device, dtype=torch.float64)
+        dist.all_reduce(ar, op=dist.ReduceOp.MAX)
+        multi = {"per_rank_ms_per_step": [round(float(v), 4) for v in per_rank.tolist()],
+                 "allreduce_us": round(float(ar.item()), 1),
+                 "allreduce_note": "the flat gradient bucket's all-reduce on the communication stream, between its two "
+                                   "stream waits, alone on an idle GPU (median of 20, max over ranks)"}
     # per-replay distribution AFTER the timed region (HIP events on the launch stream around every single replay):
     # median / p10 / p90 of one step's GPU time -- an extra key, `value` stays the wall-clock aggregate above
     replay = None
@@ -706,6 +729,8 @@ def main():
         line["replay_us"] = replay
     if ddp_check is not None:
         line["ddp_check"] = ddp_check
+    if multi is not None:
+        line["multi_gpu"] = multi
     if not args.no_roofline and rank == 0:
         # rank 0 alone runs the instrumented steps, WITHOUT the collective (it is not a kernel of this library): compute
         # + update phases only, so no peer is needed and a failure here cannot leave another rank inside a collective

@@ -77,6 +77,8 @@ class _SupConFn(torch.autograd.Function):
         ctx.state = state
         ctx.stacked = stacked
         ctx.in_dtypes = (z1.dtype, z1.dtype if stacked else z2.dtype)
+        # a LEAF input keeps the gradient it is handed as its .grad (AccumulateGrad steals the buffer): it must then own it
+        ctx.leaf_input = bool(z1.is_leaf)
         return out[0]
 
     @staticmethod
@@ -90,6 +92,8 @@ class _SupConFn(torch.autograd.Function):
             if (_n.call("spcl_supcon_unit_gradient_block", s.n, s.d, ctypes.byref(off), ctypes.byref(pitch))
                     and pitch.value == s.d):
                 dz = s.ws[off.value:off.value + 2 * s.n * s.d].view(2 * s.n, s.d)
+                if ctx.leaf_input:  # (in-place operations on that .grad would write into the workspace the taps read)
+                    dz = dz.clone()
                 return dz, None, None, None, None, None, None, None, None, None
         dz = torch.empty(2 * s.n, s.d, dtype=torch.float32, device=dev)
         dz1, dz2 = dz[:s.n], dz[s.n:]

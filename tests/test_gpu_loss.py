@@ -429,3 +429,22 @@ def test_normalize_inputs_unit_gradient_block_and_heads():
         assert torch.equal(a_l[k], b_l[k])
         assert torch.equal(a_z[k].grad, b_z[k].grad)
         assert torch.equal(a_c[k].sim_logits, b_c[k].sim_logits)
+
+
+def test_unit_gradient_of_a_leaf_input_owns_its_buffer():
+    """a LEAF projection that receives the forward's unit-gradient block as its ``.grad`` must own it -- an
+    in-place operation on that gradient (clipping, loss scaling) must not write into the workspace the taps read"""
+    import spcl_amd  # noqa
+    from spcl_amd import functional as F_hip
+    z = torch.nn.functional.normalize(torch.randn(64, 128, generator=torch.Generator().manual_seed(2)), dim=1).cuda()
+    z.requires_grad_(True)  # a leaf, stacked halves
+    unit = F_hip.register_unit_gradient(torch.ones((), device="cuda"))
+    crit = _crit("soft", 5.0, True)
+    loss = crit(*torch.chunk(z, 2), target=[i % 3 for i in range(32)])
+    loss.backward(gradient=unit)
+    ws_before = crit._state.ws.clone()
+    z.grad.mul_(7.0)
+    assert torch.equal(crit._state.ws, ws_before)
+    ws = crit._state.ws
+    lo, hi = ws.data_ptr(), ws.data_ptr() + ws.numel() * 4
+    assert not (lo <= z.grad.data_ptr() < hi)

@@ -62,6 +62,9 @@ def _run_two_ranks(tmp_path, cmd):
     assert chk["max_abs_diff_vs_mean_of_rank_gradients"] == 0.0 and chk["max_abs_diff_between_ranks"] > 0.0
     assert chk["grad_abs_max"] > 0.0
     assert line["roofline"] is not None and line["roofline"]["frac"] > 0 and "cpu_baseline" not in line
+    mg = line["multi_gpu"]  # every rank's own step time and the collective alone (diagnosable on first contact)
+    assert len(mg["per_rank_ms_per_step"]) == 2 and all(v > 0 for v in mg["per_rank_ms_per_step"])
+    assert max(mg["per_rank_ms_per_step"]) <= line["ms_per_step"] * 1.001 and mg["allreduce_us"] > 0
     return line
 
 
