@@ -118,6 +118,8 @@ int spcl_supcon_xpos_backward(const float* z1, const float* z2, int n, int d, fl
  * feat [N,H,W,Cs] NHWC (dtype), first C of Cs channels used; w1 [hid,C] b1 [hid] w2 [out,hid] b2 [out] f32
  * (hid == 0 -> "linear" head: w1 is [out,C], w2/b2 ignored).  Saved for backward: pooled [N,C], pre [N,hid],
  * o [N,out] (un-normalised), all f32.  z [N,out] f32.
+ * feat == NULL (spcl_proj_forward, spcl_proj_heads_forward): `pooled` is an INPUT -- the rows the producer of the feature
+ * map left beside it (spcl_bnrelu_gap_forward) -- and no pooling launch runs; normalize == 0 with z == o: no copy.
  */
 int spcl_proj_forward(const void* feat, int dtype, int N, int HW, int C, int Cs, const float* w1, const float* b1,
                       const float* w2, const float* b2, int hid, int out_dim, int normalize, float* pooled,
@@ -681,6 +683,14 @@ int spcl_conv3x3_forward_acc(const void* x, int dtype, int N, int H, int W, int 
 /* spcl_bn_finalize + spcl_bnrelu_pool_forward in one launch (coefficients derived in the prologue) */
 int spcl_bnrelu_pool_forward_acc(const void* y, int dtype, int N, int H, int W, int CS, const spcl_bn_acc* bn, void* act_out,
                                  void* pool_out, void* stream);
+/* BN-apply + ReLU of a block's last convolution (unet.py:76-77) with the activation's global average per (image, channel) as
+ * a side output: gap_out[n][c] = mean over the pixels of act_out as stored -- the AdaptiveAvgPool2d((1, 1)) at the head of
+ * the projector (contrastyou/projectors/heads.py:78-92, nn.py:56-58) then has nothing to read back (spcl_proj_forward with
+ * feat == NULL takes the rows).  bn == NULL: coefficients from scale / shift; else derived from the accumulator block as in
+ * spcl_bnrelu_pool_forward_acc (scale / shift unused).  spcl_bnrelu_gap_supported: small maps (H W <= 4096), CS <= 256. */
+int spcl_bnrelu_gap_supported(int dtype, int H, int W, int C, int CS);
+int spcl_bnrelu_gap_forward(const void* y, int dtype, int N, int H, int W, int C, int CS, const float* scale,
+                            const float* shift, const spcl_bn_acc* bn, void* act_out, float* gap_out, void* stream);
 /* spcl_conv3x3_dgrad_bnstats / _poolstats with the BatchNorm-backward sums added to a block instead of written as rows */
 int spcl_conv_dgrad_bnstats_acc_supported(int dtype, int N, int H, int W, int CinK, int CoutS);
 int spcl_conv3x3_dgrad_bnstats_acc(const void* dy, int dtype, int N, int H, int W, int CinK, int CoutS, const void* w_packed,

@@ -337,6 +337,84 @@ __global__ __launch_bounds__(256, 6) void bnrelu_fwd_lin_kernel(const T* __restr
   }
 }
 
+// ---- forward, no pooling, with the GLOBAL AVERAGE of the activation as a side output: gap[n][c] = mean over the image's pixels
+// of act as stored (rounded to T) -- what the projector's AdaptiveAvgPool2d((1, 1)) (contrastyou/projectors/heads.py:78-92,
+// nn.py:56-58) would compute from the tensor this launch writes, without a launch of its own reading it back.  One workgroup
+// per image (the small maps at the encoder's end: 14 x 14 x 256 is 100 KB); the pixel lanes of a channel chunk meet in LDS in
+// fixed order.
+template <typename T>
+__global__ __launch_bounds__(256) void bnrelu_fwd_gap_kernel(const T* __restrict__ y, int HW, int C, int CS, int CW,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, T* __restrict__ act,
+                                                            float* __restrict__ gap, BnAccFwd bn) {
+  // workgroup = (image blockIdx.x, channels [c0, c0 + CW) with c0 = blockIdx.y * CW): 256 / (CW / EPC) pixel lanes
+  constexpr int EPC = Chunk<T>::EPC, U = 4;
+  __shared__ float part[256 * EPC];  // [pixel lane][CW] (PL * CW <= 256 * EPC)
+  __shared__ float cl[2][256];
+  const int c0 = blockIdx.y * CW;
+  const int CPC = CW / EPC, PL = 256 / CPC;
+  const int cc = threadIdx.x % CPC, pl = threadIdx.x / CPC;
+  const bool live = pl < PL;
+  float sc[EPC], sh[EPC];
+  if (bn.acc != nullptr) {
+    // the window's coefficients from the accumulator block; the window's workgroup of image 0 writes them (and the running
+    // statistics) where the finalize launch used to
+    const int c = threadIdx.x;
+    if (c < CW) {
+      BnAccFwdRaw raw;
+      raw.load(bn, c0 + c);
+      float a_, b_;
+      bn_acc_fwd_channel(bn, raw, c0 + c, a_, b_, blockIdx.x == 0);
+      cl[0][c] = a_;
+      cl[1][c] = b_;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      sc[e] = cl[0][cc * EPC + e];
+      sh[e] = cl[1][cc * EPC + e];
+    }
+  } else if (live) {
+    load_coef<EPC>(sc, scale + c0, cc);
+    load_coef<EPC>(sh, shift + c0, cc);
+  }
+  float s[EPC];
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) s[e] = 0.f;
+  if (live) {
+    const T* yb = y + (size_t)blockIdx.x * HW * CS + c0 + cc * EPC;
+    T* ab = act + (size_t)blockIdx.x * HW * CS + c0 + cc * EPC;
+    for (int p = pl; p < HW; p += U * PL) {
+      u32x4 r[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (p + u * PL < HW) r[u] = *(const u32x4*)(yb + (size_t)(p + u * PL) * CS);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (p + u * PL >= HW) break;
+        float v[EPC];
+        unpack<T>(r[u], v);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) v[e] = fmaxf(fmaf(sc[e], v[e], sh[e]), 0.f);
+        const u32x4 pk = pack<T>(v);
+        *(u32x4*)(ab + (size_t)(p + u * PL) * CS) = pk;
+        unpack<T>(pk, v);  // the mean is that of the STORED values
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) s[e] += v[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) part[pl * CW + cc * EPC + e] = s[e];
+  }
+  __syncthreads();
+  const int c = threadIdx.x;
+  if (c < CW && c0 + c < C) {
+    float t = 0.f;
+    for (int q = 0; q < PL; ++q) t += part[q * CW + c];
+    gap[(size_t)blockIdx.x * C + c0 + c] = t / (float)HW;
+  }
+}
+
 // ---- forward, no pooling, output written 2x2-replicated: up[n, 2h + a, 2w + b, :] = relu(scale*y[n, h, w, :] + shift) -- the
 // activation of a block whose only consumer is the decoder's nn.Upsample(scale_factor=2) (semi_seg/arch/unet.py:89, nearest):
 // the upsampled tensor is written directly, the low-resolution activation and the separate upsampling launch are skipped
@@ -1508,6 +1586,38 @@ extern "C" int spcl_bnrelu_pool_forward(const void* y, int dtype, int N, int H, 
   if (dtype == SPCL_F32) bnrelu_fwd_launch<float>(y, N, H, W, CS, scale, shift, act_out, pool_out, st);
   else bnrelu_fwd_launch<bf16_t>(y, N, H, W, CS, scale, shift, act_out, pool_out, st);
   SPCL_LAUNCH_CHECK("bnrelu_pool_forward");
+  return SPCL_OK;
+}
+
+// BN-apply + ReLU with the activation's global average per (image, channel) as a side output (bnrelu_fwd_gap_kernel): the
+// coefficients from scale / shift, or -- bn != NULL -- derived from an accumulator block as in spcl_bnrelu_pool_forward_acc.
+// gap_out [N][C] f32.  Small maps (H W <= 4096) of CS <= 256 channels (C <= 256 threads finish the means).
+extern "C" int spcl_bnrelu_gap_supported(int dtype, int H, int W, int C, int CS) {
+  return (dtype == SPCL_F32 || dtype == SPCL_BF16) && H > 0 && W > 0 && (long)H * W <= 4096 && C > 0 && C <= CS && CS <= 256 &&
+         CS % 16 == 0;
+}
+
+extern "C" int spcl_bnrelu_gap_forward(const void* y, int dtype, int N, int H, int W, int C, int CS, const float* scale,
+                                       const float* shift, const spcl_bn_acc* bn, void* act_out, float* gap_out,
+                                       void* stream) {
+  SPCL_CHECK_ARG(y && act_out && gap_out && (bn || (scale && shift)), "bnrelu_gap_forward: null pointer");
+  SPCL_CHECK_ARG(N > 0 && spcl_bnrelu_gap_supported(dtype, H, W, C, CS), "bnrelu_gap_forward: unsupported shape / dtype");
+  BnAccFwd f{};
+  if (bn != nullptr) {
+    SPCL_CHECK_ARG(bn->acc && bn->gamma && bn->beta && bn->st && bn->CS == CS && bn->C > 0 && bn->C <= CS && bn->count >= 1.f,
+                   "bnrelu_gap_forward: bad accumulator description");
+    f = BnAccFwd{bn->acc, bn->gamma, bn->beta, bn->running_mean, bn->running_var, bn->num_batches_tracked, bn->st,
+                 bn->momentum, bn->eps, bn->count, bn->C, bn->CS, 1.0 / (double)bn->count};
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int CW = CS % 64 == 0 ? 64 : CS;  // channels per workgroup: 64-channel windows (128 bytes of a bf16 pixel) where they tile
+  if (dtype == SPCL_F32)
+    SPCL_LAUNCH((bnrelu_fwd_gap_kernel<float>), dim3(N, CS / CW), dim3(256), 0, st, (const float*)y, H * W, C, CS, CW, scale,
+                shift, (float*)act_out, gap_out, f);
+  else
+    SPCL_LAUNCH((bnrelu_fwd_gap_kernel<bf16_t>), dim3(N, CS / CW), dim3(256), 0, st, (const bf16_t*)y, H * W, C, CS, CW, scale,
+                shift, (bf16_t*)act_out, gap_out, f);
+  SPCL_LAUNCH_CHECK("bnrelu_gap_forward");
   return SPCL_OK;
 }
 

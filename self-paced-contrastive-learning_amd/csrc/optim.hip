@@ -33,6 +33,7 @@ __device__ __forceinline__ double ipow(double b, int64_t e) {
 // means of the host-side meters are one more few-microsecond launch per step otherwise.
 __global__ __launch_bounds__(64) void radam_tick_kernel(int64_t* step, const float* lr, double beta1, double beta2,
                                                         float* coef, ScalarAdds a) {
+#pragma clang fp contract(off)  // (IEEE operations one by one, as the host computes them: optim.py radam_coefficients)
   if (threadIdx.x > 0) {
     const int i = threadIdx.x - 1;
     if (i < a.k) {
@@ -41,7 +42,6 @@ __global__ __launch_bounds__(64) void radam_tick_kernel(int64_t* step, const flo
     }
     return;
   }
-#pragma clang fp contract(off)
   const int64_t t = step[0] + 1;
   step[0] = t;
   const double b1t = ipow(beta1, t), b2t = ipow(beta2, t);

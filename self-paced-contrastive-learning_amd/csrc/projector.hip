@@ -387,7 +387,9 @@ static int proj_heads_forward(int K, const void* feat, int dtype, int N, int HW,
                               int normalize, float* pooled, float* const* pre, float* const* o, float* const* z,
                               hipStream_t st, const char* who) {
   dim3 pg(cdiv(C, 64), N);
-  if (dtype == SPCL_F32)
+  if (feat == nullptr) {
+    // `pooled` was filled by the producer of the feature map (spcl_bnrelu_gap_forward): nothing to read back
+  } else if (dtype == SPCL_F32)
     SPCL_LAUNCH(avgpool_kernel<float>, pg, dim3(256), 0, st, (const float*)feat, HW, C, Cs, pooled);
   else if (dtype == SPCL_BF16)
     SPCL_LAUNCH(avgpool_kernel<bf16_t>, pg, dim3(256), 0, st, (const bf16_t*)feat, HW, C, Cs, pooled);
@@ -482,7 +484,7 @@ static int proj_heads_backward(int K, const float* const* dz, int dtype, int N, 
 extern "C" int spcl_proj_forward(const void* feat, int dtype, int N, int HW, int C, int Cs, const float* w1,
                                  const float* b1, const float* w2, const float* b2, int hid, int out_dim,
                                  int normalize, float* pooled, float* pre, float* o, float* z, void* stream) {
-  SPCL_CHECK_ARG(feat && w1 && b1 && pooled && o && z, "proj_forward: null pointer");
+  SPCL_CHECK_ARG(w1 && b1 && pooled && o && z, "proj_forward: null pointer");
   SPCL_CHECK_ARG(N > 0 && HW > 0 && C > 0 && Cs >= C && out_dim > 0 && hid >= 0, "proj_forward: bad shape");
   SPCL_CHECK_ARG(hid == 0 || (w2 && b2 && pre), "proj_forward: mlp head needs w2/b2/pre");
   SPCL_CHECK_ARG(C <= 512 && hid <= 512, "proj_forward: at most 512 input / hidden features (C=%d, hid=%d)", C, hid);
@@ -515,7 +517,7 @@ extern "C" int spcl_proj_heads_forward(int K, const void* feat, int dtype, int N
                                        const float* const* b2, int hid, int out_dim, int normalize, float* pooled,
                                        float* const* pre, float* const* o, float* const* z, void* stream) {
   SPCL_CHECK_ARG(K >= 1 && K <= PROJ_MAX_HEADS, "proj_heads_forward: %d heads (1..%d)", K, PROJ_MAX_HEADS);
-  SPCL_CHECK_ARG(feat && w1 && b1 && pooled && o && z && (hid == 0 || (w2 && b2 && pre)), "proj_heads_forward: null pointer");
+  SPCL_CHECK_ARG(w1 && b1 && pooled && o && z && (hid == 0 || (w2 && b2 && pre)), "proj_heads_forward: null pointer");
   SPCL_CHECK_ARG(N > 0 && HW > 0 && C > 0 && Cs >= C && out_dim > 0 && hid >= 0 && C <= 512 && hid <= 512,
                  "proj_heads_forward: bad shape");
   for (int k = 0; k < K; ++k)

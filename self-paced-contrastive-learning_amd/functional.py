@@ -321,11 +321,12 @@ class _ProjectorFn(torch.autograd.Function):
         w1c, b1c = w1.detach().contiguous().float(), b1.detach().contiguous().float()
         w2c = w2.detach().contiguous().float() if mlp else None
         b2c = b2.detach().contiguous().float() if mlp else None
-        pooled = torch.empty(N, C, dtype=torch.float32, device=dev)
+        gap = _gap_of(feat, N, C) if H * W > 1 else None  # (the rows the feature map's producer left: no pooling launch)
+        pooled = gap if gap is not None else torch.empty(N, C, dtype=torch.float32, device=dev)
         pre = torch.empty(N, hid, dtype=torch.float32, device=dev) if mlp else None
         o = torch.empty(N, out_dim, dtype=torch.float32, device=dev)
         z = torch.empty(N, out_dim, dtype=torch.float32, device=dev) if normalize else o  # (no copy without normalisation)
-        _n.call("spcl_proj_forward", _n.ptr(x), _n.dtype_code(x.dtype), N, H * W, C, cs, _n.ptr(w1c), _n.ptr(b1c),
+        _n.call("spcl_proj_forward", None if gap is not None else _n.ptr(x), _n.dtype_code(x.dtype), N, H * W, C, cs, _n.ptr(w1c), _n.ptr(b1c),
                 _n.ptr(w2c), _n.ptr(b2c), hid, out_dim, int(bool(normalize)), _n.ptr(pooled), _n.ptr(pre), _n.ptr(o),
                 _n.ptr(z), _n.stream())
         # (without normalisation the output IS o: the backward does not read it then, and an output must not be saved raw)
@@ -390,13 +391,14 @@ class _ProjectorHeadsFn(torch.autograd.Function):
         dev = feat.device
         hid, out_dim = heads[0][0].shape[0], heads[0][2].shape[0]
         cont = [[t.detach().contiguous().float() for t in h] for h in heads]
-        pooled = torch.empty(N, C, dtype=torch.float32, device=dev)
+        gap = _gap_of(feat, N, C) if H * W > 1 else None
+        pooled = gap if gap is not None else torch.empty(N, C, dtype=torch.float32, device=dev)
         pre = torch.empty(K, N, hid, dtype=torch.float32, device=dev)
         o = torch.empty(K, N, out_dim, dtype=torch.float32, device=dev)
         # back to back: the batched loss reads them in place (without normalisation the heads' rows are the output: no copy)
         z = list((torch.empty(K, N, out_dim, dtype=torch.float32, device=dev) if normalize else o).unbind(0))
         col = lambda i: _n.ptr_array([c[i] for c in cont])  # noqa: E731
-        _n.call("spcl_proj_heads_forward", K, _n.ptr(x), _n.dtype_code(x.dtype), N, H * W, C, cs, col(0), col(1), col(2),
+        _n.call("spcl_proj_heads_forward", K, None if gap is not None else _n.ptr(x), _n.dtype_code(x.dtype), N, H * W, C, cs, col(0), col(1), col(2),
                 col(3), hid, out_dim, int(bool(normalize)), _n.ptr(pooled), _n.ptr_array(list(pre)), _n.ptr_array(list(o)),
                 _n.ptr_array(z), _n.stream())
         ctx.save_for_backward(pooled, pre, o if normalize else None, *[c[0] for c in cont], *[c[2] for c in cont])
@@ -680,7 +682,8 @@ class UpLink:
 class BlockCfg:
     """Static configuration of one fused Conv-BN-ReLU(-Conv-BN-ReLU)(-MaxPool) block call."""
     __slots__ = ("dtype", "training", "momentum", "eps", "track", "need_act", "need_pool", "image_input", "buffers",
-                 "link_in", "link_out", "act_dst", "up2", "lazy_act", "link_act", "x2_link", "bn_link", "x2_bn", "up_in", "up_link")
+                 "link_in", "link_out", "act_dst", "up2", "lazy_act", "link_act", "x2_link", "bn_link", "x2_bn", "up_in", "up_link",
+                 "gap")
 
     def __init__(self, dtype, training, momentum, eps, track, need_act, need_pool, image_input, buffers):
         self.dtype, self.training, self.momentum, self.eps, self.track = dtype, training, momentum, eps, track
@@ -696,6 +699,7 @@ class BlockCfg:
         self.up_link = None    # UpLink shared by that conv_bn_relu call and the block that produced its input
         self.bn_link = None    # conv_bn_relu: its (raw output, BN coefficients) offered to the consumer of its activation ...
         self.x2_bn = None      # ... conv_block(..., x2=that activation): its dgrad leaves that BatchNorm's backward sums there
+        self.gap = None       # set by the forward: [N, C] f32 global average of the activation it wrote (small maps), see conv_block
         self.up2 = False      # the activation's only consumer is nn.Upsample(scale_factor=2): write it 2x2-replicated, return
                               # the [N, C, 2H, 2W] tensor (spcl_bnrelu_up2_forward); backward sums the 2x2 gradients first
 
@@ -1006,6 +1010,7 @@ _UP2_BWD_FUSED = os.environ.get("SPCL_UP2_BWD_FUSED", "1") != "0"  # A/B switch:
 _CONV_SPLIT = os.environ.get("SPCL_CONV_SPLIT", "1") != "0"  # A/B switch: 0 leaves that level's gradient as one interleaved tensor
 _CONV_CAT = os.environ.get("SPCL_CONV_CAT", "1") != "0"  # A/B switch: 0 materialises the 16-channel decoder concatenation
 _PACK_AT = os.environ.get("SPCL_PACK_AT", "1") != "0"  # A/B switch: 0 packs the band-GEMM layout whether or not it is used
+_GAP = os.environ.get("SPCL_GAP", "1") != "0"  # A/B switch: 0 leaves the global average to the projector's own pooling launch
 _TAILS = os.environ.get("SPCL_WGRAD_TAILS", "1") != "0"  # A/B switch: 0 keeps every layer's own final reduction launch
 
 
@@ -1464,7 +1469,19 @@ class _ConvBlockFn(torch.autograd.Function):
             if not cfg.image_input and _n.call("spcl_conv_dgrad_bnstats_acc_supported", dtc, N, H, W, cout_s, cout_s):
                 ctx.acc_bwd_a = bn_acc_block(cout_s, dev)
             ctx.acc_bwd_b = bn_acc_block(cout_s, dev)
-        if use_b:
+        # small maps whose activation is the block's only product (the encoder's last block under a feature tap): the writer
+        # also leaves the activation's global average per (image, channel) -- the projector's AdaptiveAvgPool2d((1, 1)) then
+        # has nothing to read back (conv_block hangs it on the returned tensor, _ProjectorFn looks for it)
+        cfg.gap = None
+        want_gap = (_GAP and cfg.need_act and not cfg.need_pool and not lazy and not ctx.up2 and cfg.act_dst is None
+                    and H * W <= 1024 and _n.call("spcl_bnrelu_gap_supported", dtc, H, W, cout, cout_s))
+        if want_gap:
+            act, pool = torch.empty(N, H, W, cout_s, dtype=dtype, device=dev), None
+            cfg.gap = torch.empty(N, cout, dtype=torch.float32, device=dev)
+            _n.call("spcl_bnrelu_gap_forward", _n.ptr(yb), dtc, N, H, W, cout, cout_s, None if use_b else _n.ptr(stb[2]),
+                    None if use_b else _n.ptr(stb[3]), ctypes.byref(bn_b) if use_b else None, _n.ptr(act), _n.ptr(cfg.gap),
+                    _n.stream())
+        elif use_b:
             act = torch.empty(N, H, W, cout_s, dtype=dtype, device=dev) if cfg.need_act else None
             pool = torch.empty(N, H // 2, W // 2, cout_s, dtype=dtype, device=dev) if cfg.need_pool else None
             _n.call("spcl_bnrelu_pool_forward_acc", _n.ptr(yb), dtc, N, H, W, cout_s, ctypes.byref(bn_b), _n.ptr(act),
@@ -1704,7 +1721,23 @@ class _ConvBlockFn(torch.autograd.Function):
 
 def conv_block(x, wa, ga, ba, wb, gb, bb, cfg: BlockCfg, x2=None):
     """-> (act or None, pooled or None), logical NCHW views over NHWC storage.  ``x2``: see ``_ConvBlockFn.forward``."""
-    return _ConvBlockFn.apply(x, wa, ga, ba, wb, gb, bb, cfg, x2)
+    act, pool = _ConvBlockFn.apply(x, wa, ga, ba, wb, gb, bb, cfg, x2)
+    gap = getattr(cfg, "gap", None)
+    if gap is not None and act is not None:
+        # the activation's global average, left by its writer: valid while the tensor is not written in place (its version
+        # counter says so); a slice / copy of the tensor simply does not carry it and is pooled the ordinary way
+        act._spcl_gap = (gap, act._version)
+        cfg.gap = None
+    return act, pool
+
+
+def _gap_of(feat, N, C):
+    """the [N, C] global average the producer of ``feat`` left on it (``conv_block``), if still valid, else None"""
+    gap = getattr(feat, "_spcl_gap", None)
+    if (gap is None or gap[1] != feat._version or tuple(gap[0].shape) != (N, C) or gap[0].device != feat.device
+            or tuple(feat.shape[:2]) != (N, C)):
+        return None
+    return gap[0]
 
 
 def cat_pair_shape_ok(N, C, H, W, cout, dtype):

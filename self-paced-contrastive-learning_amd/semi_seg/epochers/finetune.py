@@ -225,14 +225,20 @@ class FineTuneEpocher(_EpocherBase):
     def step_update(self, sup_loss):
         from ...optim import FusedRAdam
         if isinstance(self._optimizer, FusedRAdam) and self._flat_params is not None:
-            self._optimizer.step(grad_scale=self._flat_params.grad_scale)  # (1 / world when the exchange left the sum)
-        else:
-            self._optimizer.step()
-        if self.on_master():
-            with torch.no_grad():
+            adds = None
+            if self.on_master():  # the meter's device add rides in the optimizer's coefficient launch (as in pre-training)
                 _meters.begin_batch()
                 self.meters["sup_loss"].add(sup_loss.detach())
-                _meters.flush_batch()
+                adds = _meters.take_batch()
+            self._optimizer.step(scalar_adds=adds, grad_scale=self._flat_params.grad_scale)  # (1 / world: the exchange left the sum)
+            _meters.flush_batch()
+        else:
+            self._optimizer.step()
+            if self.on_master():
+                with torch.no_grad():
+                    _meters.begin_batch()
+                    self.meters["sup_loss"].add(sup_loss.detach())
+                    _meters.flush_batch()
 
     def _run_only_label(self):
         for self.cur_batch_num, labeled_data in zip(range(self._num_batches), self._labeled_loader):

@@ -337,3 +337,104 @@ def test_conv_block_with_and_without_blocks_and_bit_for_bit_determinism(monkeypa
             assert relerr(p, q) < 2e-2, (cin, cout)
         for p, q in zip(a["bufs"], b["bufs"]):
             np.testing.assert_allclose(p.float().cpu().numpy(), q.float().cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("N,C,cs,H,W,dtype", [(4, 256, 256, 14, 14, torch.bfloat16), (3, 128, 128, 16, 16, torch.bfloat16),
+                                             (2, 40, 48, 9, 11, torch.bfloat16), (2, 64, 64, 14, 14, torch.float32),
+                                             (1, 16, 16, 64, 64, torch.bfloat16)])
+@pytest.mark.parametrize("from_block", [False, True])
+def test_activation_writer_with_the_global_average_as_a_side_output(N, C, cs, H, W, dtype, from_block):
+    """spcl_bnrelu_gap_forward: the activation is spcl_bnrelu_pool_forward's (resp. ..._acc's) bit for bit, gap[n][c] the mean
+    over the image of the STORED activation (what the projector's AdaptiveAvgPool2d((1, 1)) of projectors/heads.py:78-92
+    reads back), coefficients from arrays or derived from an accumulator block"""
+    n = _n()
+    dtc = 1 if dtype == torch.bfloat16 else 0
+    assert n.call("spcl_bnrelu_gap_supported", dtc, H, W, C, cs)
+    g = torch.Generator().manual_seed(C + H)
+    y = torch.zeros(N, H, W, cs)
+    y[..., :C] = torch.randn(N, H, W, C, generator=g) * 1.5 + 0.2
+    y = y.to(dtype).cuda()
+    gam, bet = torch.zeros(cs), torch.zeros(cs)
+    gam[:C], bet[:C] = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    gam, bet = gam.cuda(), bet.cuda()
+    count = N * H * W
+    act0 = torch.empty_like(y)
+    act1 = torch.empty_like(y)
+    gap = torch.full((N, C), float("nan"), device="cuda")
+    if from_block:
+        if dtype != torch.bfloat16 or not n.call("spcl_conv_bn_acc_supported", dtc, N, H, W, cs, cs, 0, 1) or C != cs:
+            pytest.skip("no accumulator producer for this shape")
+        # a real producer: the statistics of a convolution's output, added to a block by its epilogue
+        x = nhwc(rnd(torch.randn(N, cs, H, W, generator=g), dtype), dtype)
+        wp = pack(n, rnd(torch.randn(cs, cs, 3, 3, generator=g) / (3 * cs ** 0.5), dtype), 0, dtype)
+        accs = [_block(n, cs), _block(n, cs)]
+        ys = [torch.empty(N, H, W, cs, dtype=dtype, device="cuda") for _ in range(2)]
+        sts = [torch.empty(4, cs, device="cuda") for _ in range(2)]
+        rms = [torch.zeros(cs, device="cuda") for _ in range(2)]
+        rvs = [torch.ones(cs, device="cuda") for _ in range(2)]
+        nbts = [torch.zeros((), dtype=torch.int64, device="cuda") for _ in range(2)]
+        for k in range(2):
+            n.call("spcl_conv3x3_forward_acc", n.ptr(x), dtc, N, H, W, cs, cs, n.ptr(wp), None, None, None, n.ptr(ys[k]),
+                   n.ptr(accs[k]), None, n.stream())
+        d0 = _bn_desc(n, accs[0], gam, bet, rms[0], rvs[0], nbts[0], sts[0], count, C, cs)
+        d1 = _bn_desc(n, accs[1], gam, bet, rms[1], rvs[1], nbts[1], sts[1], count, C, cs)
+        n.call("spcl_bnrelu_pool_forward_acc", n.ptr(ys[0]), dtc, N, H, W, cs, ctypes.byref(d0), n.ptr(act0), None, n.stream())
+        n.call("spcl_bnrelu_gap_forward", n.ptr(ys[1]), dtc, N, H, W, C, cs, None, None, ctypes.byref(d1), n.ptr(act1), n.ptr(gap),
+               n.stream())
+        assert torch.equal(sts[0], sts[1]) and torch.equal(rms[0], rms[1]) and torch.equal(rvs[0], rvs[1]) and int(nbts[1]) == 1
+    else:
+        sc, sh = gam * 0.9, bet
+        n.call("spcl_bnrelu_pool_forward", n.ptr(y), dtc, N, H, W, cs, n.ptr(sc), n.ptr(sh), n.ptr(act0), None, n.stream())
+        n.call("spcl_bnrelu_gap_forward", n.ptr(y), dtc, N, H, W, C, cs, n.ptr(sc), n.ptr(sh), None, n.ptr(act1), n.ptr(gap),
+               n.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(act0, act1)
+    ref = act1.double().mean(dim=(1, 2))[:, :C]
+    np.testing.assert_allclose(gap.cpu().numpy(), ref.cpu().numpy(), rtol=2e-6, atol=1e-7)
+
+
+def test_projector_takes_the_block_s_global_average_and_falls_back_when_it_is_stale(monkeypatch):
+    """conv_block hangs the activation's global average on the tensor it returns; the projector then runs no pooling launch
+    (spcl_proj_forward with feat == NULL) and gives the result of the ordinary path (another summation order: 1e-6); a tensor
+    whose version counter moved since (an in-place write), or a slice of it, is pooled the ordinary way"""
+    import spcl_amd.functional as F_hip
+    from spcl_amd.semi_seg.arch.unet import _ConvBlock
+    g = torch.Generator().manual_seed(3)
+    blk = _ConvBlock(64, 128).cuda().train()
+    blk._compute_dtype = torch.bfloat16
+    x = torch.randn(4, 64, 14, 14, generator=g).cuda()
+    w1, b1 = (torch.randn(32, 128, generator=g) * 0.1).cuda().requires_grad_(True), torch.zeros(32).cuda().requires_grad_(True)
+    w2, b2 = (torch.randn(16, 32, generator=g) * 0.1).cuda().requires_grad_(True), torch.zeros(16).cuda().requires_grad_(True)
+
+    def run(gap_on, spoil=None):
+        monkeypatch.setattr(F_hip, "_GAP", gap_on)
+        blk.zero_grad(set_to_none=True)
+        for p in (w1, b1, w2, b2):
+            p.grad = None
+        torch.manual_seed(0)
+        act = blk(x)
+        has = getattr(act, "_spcl_gap", None) is not None
+        if spoil == "stale":  # (what an in-place write to the tensor does to its version counter)
+            act._spcl_gap = (act._spcl_gap[0], act._version - 1)
+        feat = act[:, :, :, :] if spoil == "slice" else act
+        calls = []
+        real = F_hip._n.call
+        F_hip._n.call = lambda name, *a: (calls.append((name, a[0] if a else None)), real(name, *a))[1]
+        try:
+            z = F_hip.projector(feat, w1, b1, w2, b2, True)
+        finally:
+            F_hip._n.call = real
+        z.square().sum().backward()
+        pooled_given = [a0 for nm, a0 in calls if nm == "spcl_proj_forward"][0] is None
+        return has, pooled_given, z.detach().clone(), w1.grad.clone(), blk.conv[0].weight.grad.clone()
+
+    has1, given1, z1, g1, c1 = run(True)
+    has0, given0, z0, g0, c0 = run(False)
+    assert has1 and given1 and not has0 and not given0
+    np.testing.assert_allclose(z1.cpu().numpy(), z0.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(g1.cpu().numpy(), g0.cpu().numpy(), rtol=1e-4, atol=1e-6)
+    assert relerr(c1.float(), c0.float()) < 1e-3
+    for spoil in ("stale", "slice"):
+        has, given, z, _, _ = run(True, spoil)
+        assert has and not given, spoil
+        assert torch.equal(z, z0), spoil
