@@ -707,6 +707,15 @@ int spcl_conv3x3_dgrad_poolstats_acc(const void* dy, int dtype, int N, int H, in
 int spcl_bnrelu_backward_acc(const void* y, const void* dact, const void* dpool, const void* dact_nc, int dtype, int N, int H,
                              int W, int C, int CS, const float* st4, int training, long long* acc, float* dgamma, float* dbeta,
                              void* dy, void* stream);
+/* ... and for a gradient that did NOT come with its sums -- an activation with several consumers (the decoder's skip
+ * connections, unet.py:193-230), the up-convolutions (:85-97), a gradient that arrives as a channel slice of a wider tensor
+ * (dact_stride > 0 elements per pixel) or at twice the resolution (d_up [N][2H][2W][CS] non-NULL: dact is then scratch the call
+ * fills with the 2 x 2 sums) --: the reduction pass ADDS its sums to the zeroed block `acc`, the apply pass derives the
+ * coefficients from it; two launches, no finalize launch between them.  Exactly spcl_bnrelu_pool_backward(_strided) /
+ * spcl_bnrelu_backward_up2's results (the sums in another, fixed-point order).  CS <= 256. */
+int spcl_bnrelu_backward_fill_acc(const void* y, void* dact, int dact_stride, const void* dpool, const void* d_up, int dtype,
+                                  int N, int H, int W, int C, int CS, const float* st4, int training, long long* acc,
+                                  float* dgamma, float* dbeta, void* dy, void* stream);
 
 #ifdef __cplusplus
 }

@@ -589,7 +589,10 @@ __global__ __launch_bounds__(256, 5) void bnrelu_bwd_reduce_lin_kernel(const T* 
                                                                     const float* __restrict__ scale,
                                                                     const float* __restrict__ shift,
                                                                     float* __restrict__ partial /* [grid][2][CS] */,
-                                                                    int GS /* elements between two pixels of g */) {
+                                                                    int GS /* elements between two pixels of g */,
+                                                                    long long* __restrict__ acc = nullptr) {
+  // acc != null (here and in the other reduction passes): the workgroup's sums are ADDED to that fixed-point block (bn_acc.hpp;
+  // sum dz (y - mean) NOT scaled by invstd: the consumer does) instead of leaving a partial row for the finalize launch
   constexpr int EPC = Chunk<T>::EPC, EPW = Word<T>::EPW, U = STREAM_UNROLL;
   __shared__ float red[256][2 * EPC + 1];
   const int CPC = CS / EPC, PL = 256 / CPC;
@@ -628,9 +631,9 @@ __global__ __launch_bounds__(256, 5) void bnrelu_bwd_reduce_lin_kernel(const T* 
           }
     }
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) s2[e] *= is[e];  // sum dz*yhat = invstd * sum dz*(y - mean)
+    for (int e = 0; e < EPC; ++e) s2[e] *= acc != nullptr ? 1.f : is[e];  // sum dz*yhat = invstd * sum dz*(y - mean)
   }
-  wg_reduce_partials<T, EPC>(s1, s2, CS, CPC, PL, partial, red);
+  wg_reduce_partials<T, EPC>(s1, s2, CS, CPC, PL, partial, red, acc);
 }
 
 // ---- pass 1 when the gradient arrives at TWICE the resolution (the activation went through nn.Upsample(scale_factor=2),
@@ -645,7 +648,8 @@ __global__ __launch_bounds__(256, 3) void bnrelu_bwd_reduce_up2_kernel(const T* 
                                                                     const float* __restrict__ invstd,
                                                                     const float* __restrict__ scale,
                                                                     const float* __restrict__ shift,
-                                                                    float* __restrict__ partial /* [grid][2][CS] */) {
+                                                                    float* __restrict__ partial /* [grid][2][CS] */,
+                                                                    long long* __restrict__ acc = nullptr) {
   constexpr int EPC = Chunk<T>::EPC, EPW = Word<T>::EPW, U = 2;  // (five 16-byte loads per position in flight: 2 x 5 of them)
   __shared__ float red[256][2 * EPC + 1];
   const int CPC = CS / EPC, PL = 256 / CPC;
@@ -705,9 +709,9 @@ __global__ __launch_bounds__(256, 3) void bnrelu_bwd_reduce_up2_kernel(const T* 
       }
     }
 #pragma unroll
-    for (int e = 0; e < EPC; ++e) s2[e] *= is[e];
+    for (int e = 0; e < EPC; ++e) s2[e] *= acc != nullptr ? 1.f : is[e];
   }
-  wg_reduce_partials<T, EPC>(s1, s2, CS, CPC, PL, partial, red);
+  wg_reduce_partials<T, EPC>(s1, s2, CS, CPC, PL, partial, red, acc);
 }
 
 // ---- the same two passes for a BROADCAST gradient: g[n][p][c] = gb[n][c] for every pixel p of image n -- the gradient of a
@@ -963,10 +967,10 @@ __global__ __launch_bounds__(256, 3) BWD_POOL_WPE void bnrelu_bwd_pool_kernel(co
     }
     if (!APPLY) {
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) s2[e] *= c1[e];
+      for (int e = 0; e < EPC; ++e) s2[e] *= bw.acc != nullptr ? 1.f : c1[e];
     }
   }
-  if (!APPLY) wg_reduce_partials<T, EPC>(s1, s2, CS, CPC, PL, partial, red);
+  if (!APPLY) wg_reduce_partials<T, EPC>(s1, s2, CS, CPC, PL, partial, red, const_cast<long long*>(bw.acc));  // (reduction pass: bw.acc = the block to fill)
 }
 
 // dbeta = sum dz, dgamma = sum dz*yhat.  One workgroup per channel: threads stride over the workgroup partials, then
@@ -1324,6 +1328,7 @@ static int stream_grid(size_t positions, int PL, int unroll, int cap) {
 // they are channel slices of a wider tensor (the `_strided` entry points set them around their call; 0 = dense, CS).
 static thread_local int tl_act_stride = 0, tl_dact_stride = 0;
 static thread_local const void* tl_up2_src = nullptr;  // spcl_bnrelu_backward_up2: the fine gradient; `dact` is then WRITTEN
+static thread_local bool tl_acc_fill = false;  // spcl_bnrelu_backward_fill_acc: this call's reduction pass fills the block
 
 template <typename T>
 static int bnrelu_fwd_launch(const void* y, int N, int H, int W, int CS, const float* scale, const float* shift,
@@ -1370,6 +1375,8 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
   static const int acc_wg = lab_env("SPCL_ACC_STREAM_WG", 768);
   const int STREAM_MAX_WG = acc != nullptr ? acc_wg : spcl::STREAM_MAX_WG;  // (see bnrelu_fwd_launch)
   const bool pool = dpool != nullptr;
+  const bool fill = acc != nullptr && tl_acc_fill;  // the reduction pass below ADDS to the block (<= 768 workgroups: ~100 adds per address)
+  const int RED_MAX_WG = fill ? STREAM_MAX_WG : BWD_MAX_WG;
   const int GS = tl_dact_stride > 0 ? tl_dact_stride : CS;
   constexpr int rs = 2;  // sub-rows of a partial row (the image3 path has eleven: spcl_bnrelu_backward_rows_image3)
   const Image3Args im3{nullptr, 0, nullptr, nullptr};
@@ -1386,7 +1393,7 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
   prof_cost(tb + gb, 0.0);
   const float* fin_src = partial;
   int fin_transposed = 0;
-  if (acc != nullptr && !bcast) {
+  if (acc != nullptr && !bcast && !fill) {
     nwg = 0;  // (the block is complete: nothing to reduce, nothing to finalize)
   } else if (rows != nullptr) {  // the partial sums came with the dgrad that produced dact (per conv tile, centred s2)
     static const int fin_rows = lab_env("SPCL_BWD_FIN_MAX_ROWS", BWD_MAX_WG);
@@ -1402,15 +1409,16 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
       fin_transposed = 1;
     }
   } else if (pool) {
-    nwg = prows < BWD_MAX_WG ? prows : BWD_MAX_WG;
+    nwg = prows < RED_MAX_WG ? prows : RED_MAX_WG;
+    const BnAccBwd rbw = fill ? bw : BnAccBwd{};
     if (H % 2 == 0 && W % 2 == 0 && dact == nullptr && dpool != nullptr) {
       SPCL_LAUNCH((bnrelu_bwd_pool_kernel<T, false, true>), dim3(nwg), dim3(256), 0, st, (const T*)y, (const T*)dact,
                        (const T*)dpool, N, H, W, CS, mean, invstd, scale, shift, (const float*)nullptr, partial,
-                       (T*)nullptr);
+                       (T*)nullptr, 0, rbw);
     } else {
       SPCL_LAUNCH((bnrelu_bwd_pool_kernel<T, false, false>), dim3(nwg), dim3(256), 0, st, (const T*)y, (const T*)dact,
                        (const T*)dpool, N, H, W, CS, mean, invstd, scale, shift, (const float*)nullptr, partial,
-                       (T*)nullptr, GS);
+                       (T*)nullptr, GS, rbw);
     }
   } else if (bcast) {
     // pixel splits per image: every workgroup leaves a row of 2 CS partial sums that bnrelu_bwd_fin_kernel walks one cache
@@ -1425,14 +1433,14 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
     SPCL_LAUNCH((bnrelu_bwd_reduce_bcast_kernel<T>), dim3(nwg), dim3(256), 0, st, (const T*)y, (const T*)dact, H * W, CS,
                 bsplit, mean, invstd, scale, shift, partial, acc);
   } else if (tl_up2_src != nullptr) {
-    nwg = stream_grid(npix, PL, STREAM_UNROLL, BWD_MAX_WG);
+    nwg = stream_grid(npix, PL, STREAM_UNROLL, RED_MAX_WG);
     prof_cost(tb * 6.0, 0.0);
     SPCL_LAUNCH((bnrelu_bwd_reduce_up2_kernel<T>), dim3(nwg), dim3(256), 0, st, (const T*)y, (const T*)tl_up2_src, (T*)dact,
-                npix, W, CS, mean, invstd, scale, shift, partial);
+                npix, W, CS, mean, invstd, scale, shift, partial, fill ? acc : (long long*)nullptr);
   } else {
-    nwg = stream_grid(npix, PL, STREAM_UNROLL, BWD_MAX_WG);
+    nwg = stream_grid(npix, PL, STREAM_UNROLL, RED_MAX_WG);
     SPCL_LAUNCH((bnrelu_bwd_reduce_lin_kernel<T>), dim3(nwg), dim3(256), 0, st, (const T*)y, (const T*)dact, npix,
-                       CS, mean, invstd, scale, shift, partial, GS);
+                       CS, mean, invstd, scale, shift, partial, GS, fill ? acc : (long long*)nullptr);
   }
   float* zrow = ab != nullptr ? ab + 2 * CS + (size_t)IMG_WGRAD_WG * 9 * CS : nullptr;  // [W] zeros (image-wgrad pass only, see below)
   if (acc == nullptr)
@@ -1764,6 +1772,39 @@ extern "C" int spcl_bnrelu_backward_up2(const void* y, const void* d_up, void* d
                                            dgamma, dbeta, dy, stream);
   tl_up2_src = nullptr;
   return rc;
+}
+
+// BN + ReLU (+ max-pool) backward whose reduction pass ADDS its sums to a (zeroed) fixed-point accumulator block and whose
+// apply pass derives the coefficients from it: two launches, no finalize launch in between -- for gradients that did not
+// come with their sums (spcl_bnrelu_backward_acc covers those that did): an activation with several consumers (the decoder's
+// skip connections), the up-convolutions, a gradient that arrives as a channel slice (dact_stride > 0) or at twice the
+// resolution (d_up non-NULL: dact is then scratch the call fills with the 2 x 2 sums).  st4 = the forward's [4][CS].
+extern "C" int spcl_bnrelu_backward_fill_acc(const void* y, void* dact, int dact_stride, const void* dpool, const void* d_up,
+                                             int dtype, int N, int H, int W, int C, int CS, const float* st4, int training,
+                                             long long* acc, float* dgamma, float* dbeta, void* dy, void* stream) {
+  SPCL_CHECK_ARG(y && st4 && acc && dgamma && dbeta && dy && (dact || dpool), "bnrelu_backward_fill_acc: null pointer");
+  SPCL_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && CS >= C && CS % 16 == 0 && CS <= 256, "bnrelu_backward_fill_acc: bad shape (CS <= 256)");
+  SPCL_CHECK_ARG(dtype == SPCL_BF16 || dtype == SPCL_F32, "bnrelu_backward_fill_acc: dtype %d", dtype);
+  SPCL_CHECK_ARG(!dpool || (H >= 2 && W >= 2), "bnrelu_backward_fill_acc: 2x2 pooling needs H,W >= 2");
+  SPCL_CHECK_ARG(dact_stride == 0 || (dact && dact_stride >= CS && dact_stride % 8 == 0 && !d_up),
+                 "bnrelu_backward_fill_acc: dact with a pixel stride >= CS, a multiple of 8 elements");
+  SPCL_CHECK_ARG(!d_up || (dact && !dpool && (size_t)N * H * W * 4 < 0xffffffffull), "bnrelu_backward_fill_acc: the x2 form takes d_up + scratch dact");
+  hipStream_t st = (hipStream_t)stream;
+  const float *mean = st4, *invstd = st4 + CS, *scale = st4 + 2 * CS, *shift = st4 + 3 * CS;
+  tl_acc_fill = true;
+  tl_dact_stride = dact_stride;
+  tl_up2_src = d_up;
+  if (dtype == SPCL_F32)
+    bnrelu_bwd_launch<float>(y, dact, dpool, N, H, W, C, CS, mean, invstd, scale, shift, training, nullptr, dgamma, dbeta, dy, st,
+                             nullptr, nullptr, nullptr, 0, false, acc);
+  else
+    bnrelu_bwd_launch<bf16_t>(y, dact, dpool, N, H, W, C, CS, mean, invstd, scale, shift, training, nullptr, dgamma, dbeta, dy, st,
+                              nullptr, nullptr, nullptr, 0, false, acc);
+  tl_acc_fill = false;
+  tl_dact_stride = 0;
+  tl_up2_src = nullptr;
+  SPCL_LAUNCH_CHECK("bnrelu_backward_fill_acc");
+  return SPCL_OK;
 }
 
 // BN + ReLU backward for a gradient that is the same for every pixel of an image: dact_nc [N][CS] of dtype (what

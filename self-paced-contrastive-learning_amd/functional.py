@@ -1010,6 +1010,7 @@ _UP2_BWD_FUSED = os.environ.get("SPCL_UP2_BWD_FUSED", "1") != "0"  # A/B switch:
 _CONV_SPLIT = os.environ.get("SPCL_CONV_SPLIT", "1") != "0"  # A/B switch: 0 leaves that level's gradient as one interleaved tensor
 _CONV_CAT = os.environ.get("SPCL_CONV_CAT", "1") != "0"  # A/B switch: 0 materialises the 16-channel decoder concatenation
 _PACK_AT = os.environ.get("SPCL_PACK_AT", "1") != "0"  # A/B switch: 0 packs the band-GEMM layout whether or not it is used
+_ACC_FILL = os.environ.get("SPCL_ACC_FILL", "1") != "0"  # A/B switch: 0 keeps the finalize launch of the generic BatchNorm backward
 _GAP = os.environ.get("SPCL_GAP", "1") != "0"  # A/B switch: 0 leaves the global average to the projector's own pooling launch
 _TAILS = os.environ.get("SPCL_WGRAD_TAILS", "1") != "0"  # A/B switch: 0 keeps every layer's own final reduction launch
 
@@ -1340,6 +1341,21 @@ def _bnrelu_pool_bwd_rows(y, dpool, rows, dt_code, dtype, N, H, W, C, cs, st, tr
 ACC_ROWS = object()  # ``PoolLink.rows`` / a dgrad's ``rows`` when the sums went into a fixed-point accumulator block instead
 
 
+def _bnrelu_bwd_fill(y, dact, dpool, dt_code, dtype, N, H, W, C, cs, st, training, sinks, acc, dact_stride=0, d_up=None):
+    """``_bnrelu_bwd`` whose reduction pass ADDS its sums to the zeroed block ``acc`` and whose apply pass derives the
+    coefficients from it (spcl_bnrelu_backward_fill_acc): two launches, no finalize launch -> (dy, dgamma, dbeta)"""
+    dev = y.device
+    dgamma = _grad_buffer(sinks[0], (C,), dev)
+    dbeta = _grad_buffer(sinks[1], (C,), dev)
+    dy = torch.empty(N, H, W, cs, dtype=dtype, device=dev)
+    if d_up is not None:
+        assert dact is None and dpool is None
+        dact = torch.empty(N, H, W, cs, dtype=dtype, device=dev)  # (the summed gradient, for the apply pass)
+    _n.call("spcl_bnrelu_backward_fill_acc", _n.ptr(y), _n.ptr(dact), int(dact_stride), _n.ptr(dpool), _n.ptr(d_up), dt_code,
+            N, H, W, C, cs, _n.ptr(st), int(training), _n.ptr(acc), _n.ptr(dgamma), _n.ptr(dbeta), _n.ptr(dy), _n.stream())
+    return dy, dgamma, dbeta
+
+
 def _take_acc(ctx, name):
     """the backward accumulator block ``ctx.<name>`` -- ONCE: a block is zero only for the first backward after its forward
     (a second backward through the same graph finds None and takes the rows + finalize path)"""
@@ -1583,8 +1599,15 @@ class _ConvBlockFn(torch.autograd.Function):
                 dyb, dgb, dbb = _bnrelu_pool_bwd_rows(yb, dp_s, lk.rows, dtc, dtype, N, H, W, cout, cout_s, stb, cfg.training,
                                                       sk[4:6])
         else:
-            dyb, dgb, dbb = _bnrelu_bwd(yb, da_s, dp_s, dtc, dtype, N, H, W, cout, cout_s, stb, cfg.training, sk[4:6],
-                                        dact_stride=da_stride, d_up=d_up)
+            acc = _take_acc(ctx, "acc_bwd_b") if _ACC_FILL else None
+            if acc is not None:
+                # a gradient that did not come with its sums (several consumers: the decoder's skip connections): the reduction
+                # pass adds them to the block, the apply pass derives its coefficients -- no finalize launch
+                dyb, dgb, dbb = _bnrelu_bwd_fill(yb, da_s, dp_s, dtc, dtype, N, H, W, cout, cout_s, stb, cfg.training, sk[4:6],
+                                                 acc, dact_stride=da_stride, d_up=d_up)
+            else:
+                dyb, dgb, dbb = _bnrelu_bwd(yb, da_s, dp_s, dtc, dtype, N, H, W, cout, cout_s, stb, cfg.training, sk[4:6],
+                                            dact_stride=da_stride, d_up=d_up)
         if lk is not None:
             lk.rows, lk.dx_ptr, lk.holder = None, 0, None
         if la is not None:
@@ -1811,6 +1834,9 @@ class _ConvBNReLUFn(torch.autograd.Function):
         ctx.params = (w, gamma, beta)
         ctx.packed_t = wp_t
         ctx.cfg = cfg
+        # a block of the step's (zeroed) accumulator arena for the backward's sums: reduction pass adds, apply pass derives
+        ctx.acc_bwd = (bn_acc_block(cout_s, dev) if (_BN_ACC and _ACC_FILL and need_bwd and cfg.training and cout_s <= 256
+                                                     and dtype == torch.bfloat16) else None)
         cfg.bn_link = ActLink(y, st, N, H, W, cout, cout_s) if (need_bwd and cout == cout_s) else None
         ctx.meta = (N, cin, H, W, cout, cout_s, cin_s, x.dtype)
         ctx.up_in = up_in
@@ -1833,8 +1859,13 @@ class _ConvBNReLUFn(torch.autograd.Function):
             # the consumer's input-gradient kernel left this BatchNorm's backward sums next to the gradient itself
             dy, dg, db = _bnrelu_bwd_rows(y, da_s, None, bl.rows, dtc, dtype, N, H, W, cout, cout_s, st, cfg.training, sk[1:3])
         else:
-            dy, dg, db = _bnrelu_bwd(y, da_s, None, dtc, dtype, N, H, W, cout, cout_s, st, cfg.training, sk[1:3],
-                                     dact_stride=da_stride)
+            acc = _take_acc(ctx, "acc_bwd")
+            if acc is not None:
+                dy, dg, db = _bnrelu_bwd_fill(y, da_s, None, dtc, dtype, N, H, W, cout, cout_s, st, cfg.training, sk[1:3], acc,
+                                              dact_stride=da_stride)
+            else:
+                dy, dg, db = _bnrelu_bwd(y, da_s, None, dtc, dtype, N, H, W, cout, cout_s, st, cfg.training, sk[1:3],
+                                         dact_stride=da_stride)
         if bl is not None:
             bl.rows, bl.dx_ptr, bl.holder = None, 0, None
         if not ctx.needs_input_grad[1]:

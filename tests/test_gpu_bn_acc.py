@@ -438,3 +438,63 @@ def test_projector_takes_the_block_s_global_average_and_falls_back_when_it_is_st
         has, given, z, _, _ = run(True, spoil)
         assert has and not given, spoil
         assert torch.equal(z, z0), spoil
+
+
+@pytest.mark.parametrize("form", ["lin", "strided", "pool", "pool+act", "up2"])
+@pytest.mark.parametrize("N,C,H,W", [(2, 64, 56, 56), (3, 128, 28, 28), (2, 32, 112, 112), (1, 16, 30, 22)])
+def test_backward_whose_reduction_pass_fills_the_block_equals_the_three_launch_form(form, N, C, H, W):
+    """spcl_bnrelu_backward_fill_acc (reduction pass adds to the block, apply pass derives: no finalize launch) against
+    spcl_bnrelu_pool_backward / _strided / spcl_bnrelu_backward_up2 (reduction pass, finalize, apply) for every form of
+    incoming gradient the decoder produces (unet.py:85-97,193-230 backward): dy within bf16 rounding, dgamma / dbeta to 1e-5,
+    two runs bit-identical"""
+    n = _n()
+    dtype, dtc, cs = torch.bfloat16, 1, C
+    if form in ("pool", "pool+act") and (H % 2 or W % 2):
+        pytest.skip("whole windows only in this test")
+    g = torch.Generator().manual_seed(C + H + len(form))
+    y = (torch.randn(N, H, W, cs, generator=g) * 1.2 + 0.1).to(dtype).cuda()
+    gam, bet = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.3).cuda()
+    yf = y.double()
+    mean, var = yf.mean(dim=(0, 1, 2)), yf.var(dim=(0, 1, 2), unbiased=False)
+    st = torch.stack([mean, 1 / torch.sqrt(var + 1e-5), gam.double() / torch.sqrt(var + 1e-5),
+                      bet.double() - mean * gam.double() / torch.sqrt(var + 1e-5)]).float().contiguous()
+    dact = dpool = d_up = None
+    stride = 0
+    if form in ("lin", "pool+act"):
+        dact = (torch.randn(N, H, W, cs, generator=g) * 1e-2).to(dtype).cuda()
+    if form == "strided":
+        wide = (torch.randn(N, H, W, 2 * cs, generator=g) * 1e-2).to(dtype).cuda()
+        dact, stride = wide[..., cs:], 2 * cs  # the upper half of a concatenation's gradient, read in place
+    if form in ("pool", "pool+act"):
+        dpool = (torch.randn(N, H // 2, W // 2, cs, generator=g) * 1e-2).to(dtype).cuda()
+    if form == "up2":
+        d_up = (torch.randn(N, 2 * H, 2 * W, cs, generator=g) * 1e-2).to(dtype).cuda()
+    ws = torch.empty(n.call("spcl_bnrelu_bwd_workspace_bytes", N, H, W, cs) // 4, device="cuda")
+    dg0, db0, dy0 = torch.empty(C, device="cuda"), torch.empty(C, device="cuda"), torch.empty_like(y)
+    gs0 = torch.empty_like(y)
+    if form == "up2":
+        n.call("spcl_bnrelu_backward_up2", n.ptr(y), n.ptr(d_up), n.ptr(gs0), dtc, N, H, W, C, cs, n.ptr(st[0]), n.ptr(st[1]),
+               n.ptr(st[2]), n.ptr(st[3]), 1, n.ptr(ws), n.ptr(dg0), n.ptr(db0), n.ptr(dy0), n.stream())
+    elif form == "strided":
+        n.call("spcl_bnrelu_pool_backward_strided", n.ptr(y), dact.data_ptr(), stride, None, dtc, N, H, W, C, cs, n.ptr(st[0]),
+               n.ptr(st[1]), n.ptr(st[2]), n.ptr(st[3]), 1, n.ptr(ws), n.ptr(dg0), n.ptr(db0), n.ptr(dy0), n.stream())
+    else:
+        n.call("spcl_bnrelu_pool_backward", n.ptr(y), n.ptr(dact), n.ptr(dpool), dtc, N, H, W, C, cs, n.ptr(st[0]), n.ptr(st[1]),
+               n.ptr(st[2]), n.ptr(st[3]), 1, n.ptr(ws), n.ptr(dg0), n.ptr(db0), n.ptr(dy0), n.stream())
+    runs = []
+    for _ in range(2):
+        acc = _block(n, cs)
+        dg1, db1, dy1 = torch.empty(C, device="cuda"), torch.empty(C, device="cuda"), torch.empty_like(y)
+        gs1 = torch.empty_like(y) if form == "up2" else None
+        n.call("spcl_bnrelu_backward_fill_acc", n.ptr(y), gs1.data_ptr() if form == "up2" else (dact.data_ptr() if dact is not None else None),
+               stride, n.ptr(dpool), n.ptr(d_up), dtc, N, H, W, C, cs, n.ptr(st), 1, n.ptr(acc), n.ptr(dg1), n.ptr(db1),
+               n.ptr(dy1), n.stream())
+        runs.append((dg1, db1, dy1, gs1))
+    torch.cuda.synchronize()
+    dg1, db1, dy1, gs1 = runs[0]
+    assert all(torch.equal(a, b) for a, b in zip(runs[0][:3], runs[1][:3]))
+    np.testing.assert_allclose(db1.cpu().numpy(), db0.cpu().numpy(), rtol=2e-5, atol=1e-6 * float(db0.abs().max()) + 1e-9)
+    np.testing.assert_allclose(dg1.cpu().numpy(), dg0.cpu().numpy(), rtol=2e-5, atol=1e-6 * float(dg0.abs().max()) + 1e-9)
+    assert relerr(dy1.float(), dy0.float()) < 4e-3
+    if form == "up2":
+        assert torch.equal(gs1, gs0)

@@ -797,7 +797,9 @@ def test_pool_link_ignores_a_gradient_it_did_not_produce():
         # sums came with the gradient, as per-tile rows (spcl_bnrelu_pool_backward_rows) or in its accumulator block
         # (spcl_conv3x3_dgrad_poolstats_acc + spcl_bnrelu_backward_acc)
         names = [u[0] for u in used]
-        taken = not any(nm == "spcl_bnrelu_pool_backward" and args[2] is not None for nm, args in used)
+        own = (any(nm == "spcl_bnrelu_pool_backward" and args[2] is not None for nm, args in used)
+               or any(nm == "spcl_bnrelu_backward_fill_acc" and args[3] is not None for nm, args in used))  # (dpool given)
+        taken = not own
         assert not taken or "spcl_bnrelu_pool_backward_rows" in names or "spcl_conv3x3_dgrad_poolstats_acc" in names
         return [q.grad.clone() for q in a.parameters()], taken
 
