@@ -1600,6 +1600,11 @@ class _ConvBlockFn(torch.autograd.Function):
                                                       sk[4:6])
         else:
             acc = _take_acc(ctx, "acc_bwd_b") if _ACC_FILL else None
+            if acc is not None and lk is not None and lk.rows is ACC_ROWS:
+                # the next block's input-gradient kernel ADDED its sums to this block already -- of a gradient that then got
+                # company (a second consumer of the pooled tensor): the block is not zero any more, and its content is not
+                # this gradient's
+                acc = None
             if acc is not None:
                 # a gradient that did not come with its sums (several consumers: the decoder's skip connections): the reduction
                 # pass adds them to the block, the apply pass derives its coefficients -- no finalize launch

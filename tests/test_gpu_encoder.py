@@ -808,6 +808,8 @@ def test_pool_link_ignores_a_gradient_it_did_not_produce():
     (h1, hrows1), (h0, hrows0) = run(True, True), run(True, False)
     assert not hrows1 and not hrows0  # ... and not when something else contributed
     for u, v in zip(h1, h0):
-        assert torch.equal(u, v)  # (both reduce for themselves: identical)
+        # both reduce for themselves -- the unlinked block through its (clean) accumulator block, the linked one, whose block
+        # the consumer's kernel had already added to, through partial rows + the finalize launch: same sums, another order
+        assert float((u.float() - v.float()).norm()) <= 2e-3 * float(v.float().norm()) + 1e-12
     for u, v in zip(g1, g0):  # the linked sums are taken in another order: close, not equal
         assert float((u.float() - v.float()).norm()) <= 2e-2 * float(v.float().norm()) + 1e-12
