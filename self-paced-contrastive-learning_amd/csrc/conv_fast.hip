@@ -76,7 +76,7 @@ struct FastArgs {
 #define SPCL_FAST_WIDE_STORES 1
 #endif
 #ifndef SPCL_FAST_DBG
-#define SPCL_FAST_DBG 0  /* timing experiments only (wrong results): 1 no ring refills, 2 no fragment reads in the k-loop */
+#define SPCL_FAST_DBG 0  /* timing experiments only (wrong results): 1 no ring refills, 2 no fragment reads in the k-loop, 4 the 14^2 layers as two workgroups per (tile, cout block) with half of the slabs each (what a K-split pair of wave groups would run like) */
 #endif
 // SPCL_FAST_ROWMAP (round 4): the m-tiles lie along the TILE ROWS -- m-tile i = row i of the tile as 16 pixel columns, of
 // which the last two read halo columns 16, 17 (never staged: whatever they hold only reaches D's columns 14, 15, which nobody
@@ -156,6 +156,9 @@ conv3x3_fast_kernel(FastArgs a) {
     }
   }
   int n = blockIdx.z, by = 0;
+#if SPCL_FAST_DBG & 4  /* timing experiment (wrong results): two workgroups per (tile, cout block), each half of the slabs */
+  if (KC == 64 && a.CinK >= 128 && gridDim.z == 2u * a.N * a.gy) n >>= 1;
+#endif
   if (a.gy > 1) {
     by = n % a.gy;
     n /= a.gy;
@@ -169,7 +172,11 @@ conv3x3_fast_kernel(FastArgs a) {
   const int ntn = a.CoutS >> 4;
   const int nt0 = (by * NW + wave) * NT;
   const bool interior = y0 > 0 && x0 > 0 && y0 + TH < a.H && x0 + TW < a.W;  // whole halo inside the image
+#if SPCL_FAST_DBG & 4
+  const int nslab = KC < 64 ? 1 : ((a.CinK >= 128 && gridDim.z == 2u * a.N * a.gy) ? a.CinK / KC / 2 : a.CinK / KC);
+#else
   const int nslab = KC < 64 ? 1 : a.CinK / KC;
+#endif
   const int gps = (KC < 64 ? KC : a.CinK) * 2;  // bytes per pixel of x
 
   constexpr bool M2 = MODE == 2 || MODE == 4;  // BN-backward sums of the layer whose activation gradient this is
@@ -973,6 +980,9 @@ static void launch_fast(const FastArgs& a, int mode, hipStream_t st) {
                      (a.in_bn.acc != nullptr ? (size_t)a.CinK * 8 + (size_t)64 * NW * 32 : 0);  // (+ MODE 5 .. 7: the derived
                                                                                           // scale / shift and the partial sums)
   dim3 grid(a.tilesX, a.tilesY, a.N * a.gy), block(64 * NW);
+#if SPCL_FAST_DBG & 4
+  if (KC == 64 && a.CinK >= 128 && (long)a.tilesX * a.tilesY * a.N * a.gy <= 256) grid.z *= 2;
+#endif
   static const bool env_stamps = SPCL_FAST_STAMPS_BUILD && lab_flag("SPCL_FAST_STAMPS");
   const size_t nwg = (size_t)grid.x * grid.y * grid.z;
   b.stamps = nullptr;
