@@ -612,11 +612,14 @@ def test_pretrain_loss_curve_matches_oracle_over_steps_fp32():
         assert err < 0.1 * delta + 3e-5, (k, err, delta)
 
 
-def test_pretrain_loss_curve_bf16_tracks_the_fp32_oracle_over_24_steps():
-    """The benchmarked dtype over a multi-step run (the north star's "contrastive loss curve"): 24 consecutive pre-train
-    steps with bf16 activation storage (fresh batch, slice order and flip seed every step, FusedRAdam on the flat
-    parameter, the step replayed from the epocher's hipGraph from the third step on) next to the fp32 CPU oracle driven by
-    torch.optim.RAdam: every step's loss within 2 %, and the curve really moves."""
+@pytest.mark.parametrize("steps,rtol", [(24, 5e-3), (96, 5e-3)])
+def test_pretrain_loss_curve_bf16_tracks_the_fp32_oracle_over_many_steps(steps, rtol):
+    """The benchmarked dtype over a multi-step run (the north star's "contrastive loss curve"): 24 and 96 consecutive
+    pre-train steps with bf16 activation storage (fresh batch, slice order and flip seed every step, FusedRAdam on the flat
+    parameter -- its coefficients staged from the host --, the step replayed from the epocher's hipGraph from the third step
+    on) next to the fp32 CPU oracle driven by torch.optim.RAdam: every step's loss within 0.5 % (measured: 0.2 % at worst over
+    96 steps -- on random slices the loss stays near log(2n - 1), so this is a per-step agreement of two trajectories in different
+    arithmetic, not a learning curve), and the curve really moves."""
     import spcl_amd  # noqa
     from spcl_amd import ddp
     from spcl_amd.optim import FusedRAdam
@@ -625,7 +628,7 @@ def test_pretrain_loss_curve_bf16_tracks_the_fp32_oracle_over_24_steps():
     from spcl_amd.synthetic import acdc_like_meta
     net, sd = _unet(128, 23)
     net.set_compute_dtype(torch.bfloat16)
-    bs, steps, lr, wd, gamma, size = 12, 24, 2e-3, 1e-5, 10.0, 64
+    bs, lr, wd, gamma, size = 12, 2e-3, 1e-5, 10.0, 64
     hook = create_sp_infonce_hooks(model=net, feature_names="Conv5", weights=1.0, contrast_ons="partition",
                                    begin_values=gamma, end_values=gamma, mode="soft", max_epoch=10, p=0.5,
                                    correct_grad=True, data_name="acdc", sync_checks=False).cuda()
@@ -671,7 +674,7 @@ def test_pretrain_loss_curve_bf16_tracks_the_fp32_oracle_over_24_steps():
         ocurve.append(float(r["loss"].detach()))
     print("bf16 HIP :", [round(c, 4) for c in curve])
     print("fp32 orac:", [round(c, 4) for c in ocurve])
-    np.testing.assert_allclose(curve, ocurve, rtol=2e-2)
+    np.testing.assert_allclose(curve, ocurve, rtol=rtol)
     assert max(ocurve) - min(ocurve) > 0.02  # the parameters really moved
 
 
