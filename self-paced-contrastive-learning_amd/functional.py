@@ -683,7 +683,7 @@ class BlockCfg:
     """Static configuration of one fused Conv-BN-ReLU(-Conv-BN-ReLU)(-MaxPool) block call."""
     __slots__ = ("dtype", "training", "momentum", "eps", "track", "need_act", "need_pool", "image_input", "buffers",
                  "link_in", "link_out", "act_dst", "up2", "lazy_act", "link_act", "x2_link", "bn_link", "x2_bn", "up_in", "up_link",
-                 "gap")
+                 "gap", "want_gap")
 
     def __init__(self, dtype, training, momentum, eps, track, need_act, need_pool, image_input, buffers):
         self.dtype, self.training, self.momentum, self.eps, self.track = dtype, training, momentum, eps, track
@@ -700,6 +700,7 @@ class BlockCfg:
         self.bn_link = None    # conv_bn_relu: its (raw output, BN coefficients) offered to the consumer of its activation ...
         self.x2_bn = None      # ... conv_block(..., x2=that activation): its dgrad leaves that BatchNorm's backward sums there
         self.gap = None       # set by the forward: [N, C] f32 global average of the activation it wrote (small maps), see conv_block
+        self.want_gap = False  # the caller has a consumer for it (the block's output is tapped by a forward hook: semi_seg/arch/hook.py)
         self.up2 = False      # the activation's only consumer is nn.Upsample(scale_factor=2): write it 2x2-replicated, return
                               # the [N, C, 2H, 2W] tensor (spcl_bnrelu_up2_forward); backward sums the 2x2 gradients first
 
@@ -1489,7 +1490,8 @@ class _ConvBlockFn(torch.autograd.Function):
         # also leaves the activation's global average per (image, channel) -- the projector's AdaptiveAvgPool2d((1, 1)) then
         # has nothing to read back (conv_block hangs it on the returned tensor, _ProjectorFn looks for it)
         cfg.gap = None
-        want_gap = (_GAP and cfg.need_act and not cfg.need_pool and not lazy and not ctx.up2 and cfg.act_dst is None
+        want_gap = (_GAP and getattr(cfg, "want_gap", False) and cfg.need_act and not cfg.need_pool and not lazy
+                    and not ctx.up2 and cfg.act_dst is None
                     and H * W <= 1024 and _n.call("spcl_bnrelu_gap_supported", dtc, H, W, cout, cout_s))
         if want_gap:
             act, pool = torch.empty(N, H, W, cout_s, dtype=dtype, device=dev), None

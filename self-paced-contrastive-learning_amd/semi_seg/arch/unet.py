@@ -135,6 +135,7 @@ class _ConvBlock(nn.Module):
         cfg.up_link, self._up_link = self._up_link, None
         cfg.x2_link, self._x2_link = (self._x2_link if x2 is not None else None), None
         cfg.x2_bn, self._x2_bn = (self._x2_bn if x2 is not None else None), None
+        cfg.want_gap = len(self._forward_hooks) > 0  # a feature tap: its projector pools globally (functional.conv_block)
         act, pooled = F_hip.conv_block(x, c[0].weight, c[1].weight, c[1].bias, c[3].weight, c[4].weight, c[4].bias, cfg, x2)
         self._pooled = pooled
         self._link_out = cfg.link_out  # for the block that consumes the pooled output (UNet.forward hands it over)

@@ -402,6 +402,7 @@ def test_projector_takes_the_block_s_global_average_and_falls_back_when_it_is_st
     g = torch.Generator().manual_seed(3)
     blk = _ConvBlock(64, 128).cuda().train()
     blk._compute_dtype = torch.bfloat16
+    blk.register_forward_hook(lambda m, i, o: None)  # (a feature tap, as semi_seg/arch/hook.py registers one: the block then leaves the average)
     x = torch.randn(4, 64, 14, 14, generator=g).cuda()
     w1, b1 = (torch.randn(32, 128, generator=g) * 0.1).cuda().requires_grad_(True), torch.zeros(32).cuda().requires_grad_(True)
     w2, b2 = (torch.randn(16, 32, generator=g) * 0.1).cuda().requires_grad_(True), torch.zeros(16).cuda().requires_grad_(True)
