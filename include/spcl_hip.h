@@ -531,7 +531,8 @@ int spcl_kl_div_backward(const float* prob, const float* target, size_t npix, in
 /* The supervised criterion of the fine-tune loop in one pass (semi_seg/epochers/new_epocher.py:268-282:
  * KL_div(logits.softmax(1), class2one_hot(target, C)) and the Dice counts of logits.max(1)[1] against target):
  * logits [B * per_sample][K] f32, labels [B * per_sample] int64 -> loss (mean over positions), dlogits_unit (the gradient
- * w.r.t. the logits for grad_loss == 1: the caller scales it), inter / union [B][K] int64 (ZEROED by the caller; K == the
+ * w.r.t. the logits for grad_loss == 1: the caller scales it), inter / union [B][K] int64 (written, not added to: they
+ * need no zero fill -- the workgroups leave count rows in ws and the finishing launch adds them up in fixed order; K == the
  * number of classes).  Per pixel the arithmetic of spcl_softmax_forward / spcl_kl_div_forward / _backward /
  * spcl_softmax_backward in the same order: the same bits.  ws: spcl_kl_workspace_bytes(). */
 int spcl_sup_loss_forward(const float* logits, const int64_t* labels, int B, int per_sample, int K, float eps, float* ws,
@@ -591,6 +592,11 @@ int spcl_accumulate_scalars(int k, const void* const* src, void* const* dst, con
  * nbytes (multiple of 4) bytes of host memory are copied to the persistent device block dst, in stream order.  The bytes
  * travel as kernel arguments (read at call time: host_src may be reused as soon as the call returns), 3 584 per launch. */
 int spcl_stage_bytes(void* dst, const void* host_src, size_t nbytes, void* stream);
+/* two device-to-device copies in one launch (the labelled batch into the captured fine-tune step's persistent input buffers,
+ * semi_seg/epochers/new_epocher.py:260-266 hands the step a fresh image / target pair every iteration): sizes and addresses
+ * multiples of 16 bytes */
+int spcl_copy_pair(void* dst_a, const void* src_a, size_t bytes_a, void* dst_b, const void* src_b, size_t bytes_b,
+                   void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Pre-train augmentation on device (replaces the PIL recipe of semi_seg/augment.py:6-22

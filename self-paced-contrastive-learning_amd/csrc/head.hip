@@ -417,8 +417,7 @@ __global__ __launch_bounds__(256) void sup_loss_fwd_kernel(const float* __restri
                                                            const int64_t* __restrict__ labels, int per_sample, int K,
                                                            float eps, float inv_m, float* __restrict__ partial,
                                                            float* __restrict__ dlogits, int C,
-                                                           unsigned long long* __restrict__ inter,
-                                                           unsigned long long* __restrict__ uni) {
+                                                           unsigned* __restrict__ cnt /* [workgroup][2][HEAD_MAX_K] */) {
   __shared__ float red[4];
   __shared__ unsigned int si[64], su[64];
   const int n = blockIdx.y;
@@ -465,9 +464,12 @@ __global__ __launch_bounds__(256) void sup_loss_fwd_kernel(const float* __restri
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
   if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  // the workgroup's Dice counts as a row of the workspace (sup_loss_finish_kernel adds the rows of an image up in fixed
+  // order: no atomics on the result, which therefore needs no zero fill in front of the launch)
   if (threadIdx.x < C) {
-    if (si[threadIdx.x]) atomicAdd(&inter[(size_t)n * C + threadIdx.x], (unsigned long long)si[threadIdx.x]);
-    if (su[threadIdx.x]) atomicAdd(&uni[(size_t)n * C + threadIdx.x], (unsigned long long)su[threadIdx.x]);
+    unsigned* row = cnt + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 * HEAD_MAX_K;
+    row[threadIdx.x] = si[threadIdx.x];
+    row[HEAD_MAX_K + threadIdx.x] = su[threadIdx.x];
   }
 }
 
@@ -484,8 +486,7 @@ __global__ __launch_bounds__(256) void sup_loss_fwd4_kernel(const float* __restr
                                                             const int64_t* __restrict__ labels, int per_sample, float eps,
                                                             float inv_m, float* __restrict__ partial,
                                                             float* __restrict__ dlogits,
-                                                            unsigned long long* __restrict__ inter,
-                                                            unsigned long long* __restrict__ uni) {
+                                                            unsigned* __restrict__ cnt /* [workgroup][2][HEAD_MAX_K] */) {
   constexpr int K = 4;
   __shared__ float red[4];
   __shared__ unsigned int si[4][4], su[4][4];
@@ -544,9 +545,34 @@ __global__ __launch_bounds__(256) void sup_loss_fwd4_kernel(const float* __restr
   if (threadIdx.x < K) {
     const unsigned ti = si[0][threadIdx.x] + si[1][threadIdx.x] + si[2][threadIdx.x] + si[3][threadIdx.x];
     const unsigned tu = su[0][threadIdx.x] + su[1][threadIdx.x] + su[2][threadIdx.x] + su[3][threadIdx.x];
-    if (ti) atomicAdd(&inter[(size_t)n * K + threadIdx.x], (unsigned long long)ti);
-    if (tu) atomicAdd(&uni[(size_t)n * K + threadIdx.x], (unsigned long long)tu);
+    unsigned* row = cnt + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 2 * HEAD_MAX_K;
+    row[threadIdx.x] = ti;
+    row[HEAD_MAX_K + threadIdx.x] = tu;
   }
+}
+
+// the finish of spcl_sup_loss_forward: workgroup 0 = the loss (head_partial_sum_kernel's wave 0: same order, same bits), the
+// others one thread per (image, which, class): the image's gx count rows added in index order -> inter / union (plain stores)
+__global__ __launch_bounds__(256) void sup_loss_finish_kernel(const float* __restrict__ partial, int nwg, float scale,
+                                                              float* __restrict__ loss, const unsigned* __restrict__ cnt,
+                                                              int gx, int B, int C, unsigned long long* __restrict__ inter,
+                                                              unsigned long long* __restrict__ uni) {
+  if (blockIdx.x == 0) {
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x;
+    float s = 0.f;
+#pragma unroll 4
+    for (int w = lane; w < nwg; w += 64) s += partial[w];
+    s = wave_sum(s);
+    if (lane == 0) loss[0] = s * scale;
+    return;
+  }
+  const int o = (blockIdx.x - 1) * 256 + threadIdx.x;
+  if (o >= B * 2 * C) return;
+  const int n = o / (2 * C), r = o - n * 2 * C, which = r / C, c = r - which * C;
+  unsigned long long t = 0ull;
+  for (int bx = 0; bx < gx; ++bx) t += cnt[(size_t)(n * gx + bx) * 2 * HEAD_MAX_K + which * HEAD_MAX_K + c];
+  (which ? uni : inter)[(size_t)n * C + c] = t;
 }
 
 static int head_grid(size_t n, int cap) {
@@ -664,7 +690,8 @@ extern "C" int spcl_softmax_backward(const float* prob, const float* dprob, size
   return SPCL_OK;
 }
 
-extern "C" size_t spcl_kl_workspace_bytes(void) { return (size_t)HEAD_RED_WG * sizeof(float); }
+// (HEAD_RED_WG partial sums; behind them spcl_sup_loss_forward's per-workgroup Dice count rows [HEAD_RED_WG][2][HEAD_MAX_K] u32)
+extern "C" size_t spcl_kl_workspace_bytes(void) { return (size_t)HEAD_RED_WG * (1 + 2 * HEAD_MAX_K) * sizeof(float); }
 
 extern "C" int spcl_kl_div_forward(const float* prob, const float* target, size_t npix, int K, float eps, float* ws,
                                    float* loss, void* stream) {
@@ -716,16 +743,19 @@ extern "C" int spcl_sup_loss_forward(const float* logits, const int64_t* labels,
   if (gx > cap) gx = cap;
   if (gx > 64) gx = 64;
   const size_t npix = (size_t)B * per_sample;
+  unsigned* cnt = (unsigned*)(ws + HEAD_RED_WG);  // count rows of the gx * B <= HEAD_RED_WG workgroups
   prof_cost((double)npix * (K * 8.0 + 8.0), 0.0);
   static const bool no_k4 = lab_env("SPCL_SUP_LOSS_K4", 1) == 0;  // A/B switch
   if (K == 4 && !no_k4 && (per_sample + gx * 256 - 1) / (gx * 256) < 32768 && (uintptr_t)logits % 16 == 0 &&
       (uintptr_t)dlogits_unit % 16 == 0)
     SPCL_LAUNCH(sup_loss_fwd4_kernel, dim3(gx, B), dim3(256), 0, st, logits, labels, per_sample, eps, 1.f / (float)npix, ws,
-                dlogits_unit, (unsigned long long*)inter_zeroed, (unsigned long long*)union_zeroed);
+                dlogits_unit, cnt);
   else
     SPCL_LAUNCH(sup_loss_fwd_kernel, dim3(gx, B), dim3(256), 0, st, logits, labels, per_sample, K, eps, 1.f / (float)npix, ws,
-                dlogits_unit, K, (unsigned long long*)inter_zeroed, (unsigned long long*)union_zeroed);
-  SPCL_LAUNCH(head_partial_sum_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, gx * B, 1, 1.f / (float)npix, loss);
+                dlogits_unit, K, cnt);
+  SPCL_LAUNCH(sup_loss_finish_kernel, dim3(1 + (B * 2 * K + 255) / 256), dim3(256), 0, st, (const float*)ws, gx * B,
+              1.f / (float)npix, loss, (const unsigned*)cnt, gx, B, K, (unsigned long long*)inter_zeroed,
+              (unsigned long long*)union_zeroed);
   SPCL_LAUNCH_CHECK("sup_loss_forward");
   return SPCL_OK;
 }

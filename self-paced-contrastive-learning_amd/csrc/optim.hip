@@ -167,6 +167,34 @@ extern "C" int spcl_stage_bytes(void* dst, const void* host_src, size_t nbytes, 
   return SPCL_OK;
 }
 
+// Two device-to-device copies in ONE launch (the fine-tune step's image and label map into the captured step's persistent
+// input buffers: two copy launches of ~5 us each otherwise, whatever their size).  16-byte granules, grid-stride.
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+__global__ __launch_bounds__(256) void copy_pair_kernel(u32x4* __restrict__ da, const u32x4* __restrict__ sa, size_t na,
+                                                        u32x4* __restrict__ db, const u32x4* __restrict__ sb, size_t nb) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < na + nb; i += stride) {
+    if (i < na) da[i] = sa[i];
+    else db[i - na] = sb[i - na];
+  }
+}
+
+extern "C" int spcl_copy_pair(void* dst_a, const void* src_a, size_t bytes_a, void* dst_b, const void* src_b, size_t bytes_b,
+                              void* stream) {
+  SPCL_CHECK_ARG(dst_a && src_a && dst_b && src_b, "copy_pair: null pointer");
+  SPCL_CHECK_ARG(bytes_a % 16 == 0 && bytes_b % 16 == 0 &&
+                     ((uintptr_t)dst_a | (uintptr_t)src_a | (uintptr_t)dst_b | (uintptr_t)src_b) % 16 == 0,
+                 "copy_pair: sizes and addresses must be multiples of 16 bytes");
+  const size_t n = (bytes_a + bytes_b) / 16;
+  if (n == 0) return SPCL_OK;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  SPCL_LAUNCH(copy_pair_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (u32x4*)dst_a, (const u32x4*)src_a,
+              bytes_a / 16, (u32x4*)dst_b, (const u32x4*)src_b, bytes_b / 16);
+  SPCL_LAUNCH_CHECK("copy_pair");
+  return SPCL_OK;
+}
+
 extern "C" int spcl_radam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
                                int64_t* step, const float* lr, double beta1, double beta2, double eps,
                                double weight_decay, float* coef, void* stream) {

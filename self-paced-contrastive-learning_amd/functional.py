@@ -2094,7 +2094,7 @@ class _SupLossFn(torch.autograd.Function):
         ws = torch.empty(_n.call("spcl_kl_workspace_bytes") // 4, dtype=torch.float32, device=dev)
         loss = torch.empty((), dtype=torch.float32, device=dev)
         dl = torch.empty_like(ls)
-        both = torch.zeros(2, N, K, dtype=torch.int64, device=dev)  # (one fill; a caller that keeps them clones ``inter._base`` once)
+        both = torch.empty(2, N, K, dtype=torch.int64, device=dev)  # (written by the launch; a caller that keeps them clones ``inter._base`` once)
         inter, union = both[0], both[1]
         _n.call("spcl_sup_loss_forward", _n.ptr(ls), _n.ptr(lab), N, H * W, K, c_float(eps), _n.ptr(ws), _n.ptr(loss),
                 _n.ptr(dl), _n.ptr(inter), _n.ptr(union), _n.stream())

@@ -10,6 +10,7 @@ from torch import nn
 
 from ... import ddp as _ddp
 from ... import functional as F_hip
+from ... import native as _n
 from ... import stepgraph as _sg
 from ...contrastyou.losses.kl import KL_div, class2one_hot
 from ...contrastyou import meters as _meters
@@ -162,8 +163,17 @@ class FineTuneEpocher(_EpocherBase):
                 self._static = (torch.empty_like(labeled_image), torch.empty_like(labeled_target))
                 self._step_graph = _sg.StepGraph(lambda: self.step_compute(*self._static), self.step_exchange,
                                                  self.step_update, split=_ddp.is_distributed())
-            self._static[0].copy_(labeled_image, non_blocking=True)
-            self._static[1].copy_(labeled_target, non_blocking=True)
+            si, stg = self._static
+            a, b = labeled_image, labeled_target
+            if (a.is_contiguous() and b.is_contiguous() and a.dtype == si.dtype and b.dtype == stg.dtype
+                    and a.device == si.device and b.device == stg.device
+                    and (a.numel() * a.element_size()) % 16 == 0 and (b.numel() * b.element_size()) % 16 == 0
+                    and not ((a.data_ptr() | b.data_ptr() | si.data_ptr() | stg.data_ptr()) % 16)):
+                _n.call("spcl_copy_pair", _n.ptr(si), _n.ptr(a), a.numel() * a.element_size(), _n.ptr(stg), _n.ptr(b),
+                        b.numel() * b.element_size(), _n.stream())  # (both copies in one launch)
+            else:
+                si.copy_(a, non_blocking=True)
+                stg.copy_(b, non_blocking=True)
             if hasattr(self._optimizer, "sync_lr"):
                 self._optimizer.sync_lr()
             sup_loss = self._step_graph.run(key)

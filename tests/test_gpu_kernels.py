@@ -747,3 +747,19 @@ def test_block_pack_writes_the_band_gemm_layout_only_where_that_kernel_runs():
         half = r.numel() // 2
         assert torch.equal(c[:half], r[:half])
         assert torch.all(c[half:] == 7.0)
+
+
+def test_copy_pair_is_two_copies():
+    """spcl_copy_pair: both ranges copied by one launch, nothing beyond them touched"""
+    n = _n()
+    g = torch.Generator().manual_seed(1)
+    a = torch.randn(3 * 224 * 224 + 4, generator=g).cuda()
+    b = torch.randint(0, 4, (5 * 1000 + 2,), generator=g).cuda()  # int64
+    da = torch.full((a.numel() + 8,), -7.0, device="cuda")
+    db = torch.full((b.numel() + 4,), -7, dtype=torch.int64, device="cuda")
+    n.call("spcl_copy_pair", da.data_ptr(), a.data_ptr(), a.numel() * 4, db.data_ptr(), b.data_ptr(), b.numel() * 8, n.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(da[:a.numel()], a) and bool((da[a.numel():] == -7.0).all())
+    assert torch.equal(db[:b.numel()], b) and bool((db[b.numel():] == -7).all())
+    with pytest.raises(RuntimeError):
+        n.call("spcl_copy_pair", da.data_ptr() + 4, a.data_ptr(), 16, db.data_ptr(), b.data_ptr(), 16, n.stream())
