@@ -224,3 +224,45 @@ def test_meter_batching_falls_back_to_immediate_adds_off_gpu():
     m.add(4.0)
     M.flush_batch()
     assert m.summary()["mean"] == 3.0
+
+
+def test_radam_host_coefficients_are_torch_s_formulas():
+    """optim.radam_coefficients (the scalars a staged step uploads instead of launching the coefficient kernel): torch.optim.RAdam's
+    bias corrections and rectification (torch/optim/radam.py _single_tensor_radam) for the step counts where the rectified branch
+    switches on, beta^t by repeated squaring against ``**``, the learning rate taken as the float32 the device holds"""
+    import math
+
+    import numpy as np
+    from spcl_amd.optim import _ipow, radam_coefficients
+    b1, b2, lr = 0.9, 0.999, 2e-3
+    for t in (1, 2, 3, 5, 6, 7, 64, 1000, 12345, 10 ** 6):
+        # (the rounding of each squaring is squared with it: up to ~t / 2 ulp -- 1e-10 relative at a million steps, far below
+        # the float32 the coefficients are rounded to)
+        assert abs(_ipow(b2, t) - b2 ** t) <= max(4, t) * np.finfo(np.float64).eps * b2 ** t
+        c_m, c_u, flag, tt = radam_coefficients(t, lr, b1, b2)
+        bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t
+        rho_inf = 2 / (1 - b2) - 1
+        rho_t = rho_inf - 2 * t * b2 ** t / bc2
+        assert tt == float(t) and flag == (1.0 if rho_t > 5 else 0.0)
+        np.testing.assert_allclose(c_m, float(np.float32(lr)) / bc1, rtol=1e-12)
+        if rho_t > 5:
+            rect = math.sqrt((rho_t - 4) * (rho_t - 2) * rho_inf / ((rho_inf - 4) * (rho_inf - 2) * rho_t))
+            np.testing.assert_allclose(c_u, rect * math.sqrt(bc2), rtol=1e-10)
+        else:
+            assert c_u == 0.0
+    assert radam_coefficients(5, lr, b1, b2)[2] == 0.0 and radam_coefficients(6, lr, b1, b2)[2] == 1.0  # rho_t crosses 5 at t = 6
+
+
+def test_global_average_side_output_is_used_only_while_the_tensor_is_unchanged():
+    """functional._gap_of: the [N, C] rows a block left on its activation are handed to the projector only for that very tensor
+    object, with its version counter unmoved and matching shapes"""
+    from spcl_amd.functional import _gap_of
+    feat = torch.zeros(4, 8, 3, 3)
+    gap = torch.zeros(4, 8)
+    assert _gap_of(feat, 4, 8) is None
+    feat._spcl_gap = (gap, feat._version)
+    assert _gap_of(feat, 4, 8) is gap
+    assert _gap_of(feat[:, :, :, :], 4, 8) is None     # a view is another object: it does not carry the attribute
+    assert _gap_of(feat, 4, 16) is None and _gap_of(feat, 2, 8) is None
+    feat.add_(1.0)                                       # written in place: the average is stale
+    assert _gap_of(feat, 4, 8) is None
