@@ -670,9 +670,10 @@ class ActLink:
 class UpLink:
     """Between a block whose activation has ONE consumer -- an up-convolution reading it at half resolution
     (``BlockCfg.up_in``) -- and that consumer: the consumer's backward leaves the FINE input gradient here instead of summing
-    its 2 x 2 windows, and returns an unwritten half-resolution tensor whose address the block recognises; the block's
+    its 2 x 2 windows, and returns a shared half-resolution tensor of ZEROS whose address the block recognises; the block's
     BatchNorm-backward reduction pass forms the sums on its way (spcl_bnrelu_backward_up2).  A gradient that arrives at the
-    block with any other address means somebody else contributed to it: the block raises instead of using garbage."""
+    block with any other address means somebody else contributed to it (zeros + their gradient): the block then adds the
+    2 x 2 sums itself with the ordinary kernels."""
     __slots__ = ("d_up", "dx_ptr", "holder", "version")
 
     def __init__(self):
@@ -1549,12 +1550,19 @@ class _ConvBlockFn(torch.autograd.Function):
             same = (d_act is not None and d_pool is None and d_act.data_ptr() == ul.dx_ptr and d_act.dtype == holder.dtype
                     and holder._version == ul.version and nhwc_channel_slice(d_act, dtype) is None
                     and to_nhwc_padded(d_act, dtype).data_ptr() == ul.dx_ptr)
+            dirty = holder._version != ul.version  # (somebody wrote INTO the shared zeros: what they hold now is that gradient)
             ul.d_up, ul.dx_ptr, ul.holder = None, 0, None
-            if not same:
-                raise RuntimeError("conv_block: the activation read at half resolution by an up-convolution received a gradient "
-                                   "from somewhere else as well (its 2 x 2 sums were left to this block): run with "
-                                   "SPCL_UP2_BWD_FUSED=0")
-            d_up, d_act = du, None
+            if same:
+                d_up, d_act = du, None
+            else:
+                # somebody else contributed to this activation's gradient: what arrived is THEIR part (the link's tensor
+                # holds zeros), the 2 x 2 sums of the up-convolution's fine gradient are added here -- the ordinary kernels
+                gs = torch.empty(N, H, W, cout_s, dtype=dtype, device=du.device)
+                _n.call("spcl_upsample2x_backward", _n.ptr(du), _n.ptr(gs), dtc, N, H, W, cout_s, _n.stream())
+                gl = nhwc_to_logical(gs, cout)
+                d_act = gl if d_act is None else d_act.to(gl.dtype) + gl
+                if dirty:
+                    holder.zero_()  # (restore the shared tensor for its next use)
         elif ctx.up2 and d_act is not None:
             # the forward returned the x2-upsampled activation: its gradient is summed over the 2x2 replicas first -- inside
             # the BatchNorm-backward reduction pass (spcl_bnrelu_backward_up2), or by its own launch
@@ -1886,13 +1894,17 @@ class _ConvBNReLUFn(torch.autograd.Function):
             wp_t = ctx.packed_t if ctx.packed_t is not None else _pack(w, 1, dtc, dtype)
             dxs, _ = _conv(dy, dtc, dtype, N, H, W, cout_s, cout_s, cin_s, wp_t, 0, None, None, False)
             if up_in:  # the gradient w.r.t. the half-resolution input: the 2 x 2 sums of the fine gradient
-                dsum = torch.empty(N, H // 2, W // 2, cin_s, dtype=dtype, device=dxs.device)
                 ul = getattr(cfg, "up_link", None)
                 if ul is not None and _UP2_BWD_FUSED and cfg.training:
-                    # (dsum stays unwritten: the producing block sums, see UpLink; its version counter tells an in-place
-                    # accumulation into it -- autograd adds a second contribution that way when it owns the buffer)
+                    # the producing block forms the sums (UpLink); what travels through autograd in their place is a shared
+                    # tensor of ZEROS (one per shape, never written: the cache's reference keeps autograd from accumulating
+                    # into it in place) -- a second consumer of the activation then adds its gradient to zeros, and the block,
+                    # which sees a tensor that is not this one, adds the sums to that (it used to be unwritten
+                    # memory, and the block could only refuse)
+                    dsum = _up_zeros(N, H // 2, W // 2, cin_s, dtype, dxs.device)
                     ul.d_up, ul.dx_ptr, ul.holder, ul.version = dxs, dsum.data_ptr(), dsum, dsum._version
                 else:
+                    dsum = torch.empty(N, H // 2, W // 2, cin_s, dtype=dtype, device=dxs.device)
                     _n.call("spcl_upsample2x_backward", _n.ptr(dxs), _n.ptr(dsum), dtc, N, H // 2, W // 2, cin_s, _n.stream())
                 dxs = dsum
             dx = nhwc_to_logical(dxs, cin)
@@ -1900,6 +1912,18 @@ class _ConvBNReLUFn(torch.autograd.Function):
                 dx = dx.to(xdt)
         ng = ctx.needs_input_grad
         return dx, dw, dg if ng[2] else None, db if ng[3] else None, None
+
+
+_UP_ZEROS = {}
+
+
+def _up_zeros(N, H, W, cs, dtype, device):
+    """the shared all-zero [N, H, W, cs] tensor an UpLink sends through autograd in place of the gradient sums it hands over"""
+    key = (N, H, W, cs, dtype, device.type, device.index)
+    t = _UP_ZEROS.get(key)
+    if t is None:
+        t = _UP_ZEROS[key] = torch.zeros(N, H, W, cs, dtype=dtype, device=device)
+    return t
 
 
 def conv_bn_relu(x, w, gamma, beta, cfg: BlockCfg):
