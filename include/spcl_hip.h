@@ -722,6 +722,13 @@ int spcl_bnrelu_backward_acc(const void* y, const void* dact, const void* dpool,
 int spcl_bnrelu_backward_fill_acc(const void* y, void* dact, int dact_stride, const void* dpool, const void* d_up, int dtype,
                                   int N, int H, int W, int C, int CS, const float* st4, int training, long long* acc,
                                   float* dgamma, float* dbeta, void* dy, void* stream);
+/* ... and for a gradient whose sums came as per-tile rows [nrows][2][CS] (sum dz, sum dz (y - mean): what the dgrad epilogues
+ * leave where a layer has more tiles than the blocks take adds from): one small launch adds the rows to the zeroed block, the
+ * apply pass (exactly one of dact / dpool) derives its coefficients: spcl_bnrelu_backward_rows / spcl_bnrelu_pool_backward_rows
+ * without their finalize launch. */
+int spcl_bnrelu_backward_rows_acc(const void* y, const void* dact, const void* dpool, const float* rows, int nrows, int dtype,
+                                  int N, int H, int W, int C, int CS, const float* st4, int training, long long* acc,
+                                  float* dgamma, float* dbeta, void* dy, void* stream);
 
 #ifdef __cplusplus
 }

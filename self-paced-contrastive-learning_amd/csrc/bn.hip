@@ -1135,6 +1135,38 @@ __global__ __launch_bounds__(256) void bwd_rows_group_kernel(const float* __rest
   }
 }
 
+// the same rows ADDED to a fixed-point accumulator block (bn_acc.hpp) instead: G rows per workgroup (few workgroups: the adds
+// to one address serialise), then the apply pass derives its coefficients from the block -- no finalize launch.  Thread o ->
+// word o of the block's row (channel o / 4, sum (o / 2) % 2, limb o % 2; the two limb threads of a sum both form it).
+__global__ __launch_bounds__(256) void bwd_rows_acc_kernel(const float* __restrict__ rows, int nrows, int G, int CS,
+                                                           long long* __restrict__ acc) {
+  // the 256 / (4 CS) thread groups of a word split the workgroup's G rows among them and meet in LDS (fixed order)
+  __shared__ float part[256];
+  const int w = blockIdx.x, NW4 = 4 * CS;
+  const int NP = NW4 >= 256 ? 1 : 256 / NW4;
+  for (int o0 = 0; o0 < NW4; o0 += 256) {
+    const int o = o0 + (int)(threadIdx.x % (NW4 < 256 ? NW4 : 256)), p = NW4 < 256 ? (int)threadIdx.x / NW4 : 0;
+    const int c = o >> 2, which = (o >> 1) & 1, limb = o & 1;
+    float s = 0.f;
+    if (o < NW4 && p < NP) {
+#pragma unroll 8
+      for (int k = p; k < G; k += NP) {
+        const int r = w * G + k;
+        if (r < nrows) s += rows[((size_t)r * 2 + which) * CS + c];
+      }
+    }
+    if (NP > 1) {
+      part[threadIdx.x] = s;
+      __syncthreads();
+      if (p == 0 && o < NW4) {
+        for (int q = 1; q < NP; ++q) s += part[q * NW4 + o];
+      }
+      __syncthreads();
+    }
+    if (p == 0 && o < NW4) bn_acc_add_word(acc, CS, w & (BN_ACC_REPLICAS - 1), c, which, limb, s);
+  }
+}
+
 // ---- pass 2, no pooling (linear): dy = scale*dz + A*y + B
 template <typename T>
 __global__ __launch_bounds__(256, 6) void bnrelu_bwd_apply_lin_kernel(const T* __restrict__ y, const T* __restrict__ g,
@@ -1395,6 +1427,10 @@ static int bnrelu_bwd_launch(const void* y, const void* dact, const void* dpool,
   int fin_transposed = 0;
   if (acc != nullptr && !bcast && !fill) {
     nwg = 0;  // (the block is complete: nothing to reduce, nothing to finalize)
+  } else if (rows != nullptr && fill) {  // ... and go into the block: <= 512 workgroups add, the apply pass derives
+    const int G = (nrows + 511) / 512;
+    nwg = (nrows + G - 1) / G;
+    SPCL_LAUNCH(bwd_rows_acc_kernel, dim3(nwg), dim3(256), 0, st, rows, nrows, G, CS, acc);
   } else if (rows != nullptr) {  // the partial sums came with the dgrad that produced dact (per conv tile, centred s2)
     static const int fin_rows = lab_env("SPCL_BWD_FIN_MAX_ROWS", BWD_MAX_WG);
     if (nrows <= fin_rows) {
@@ -1804,6 +1840,33 @@ extern "C" int spcl_bnrelu_backward_fill_acc(const void* y, void* dact, int dact
   tl_dact_stride = 0;
   tl_up2_src = nullptr;
   SPCL_LAUNCH_CHECK("bnrelu_backward_fill_acc");
+  return SPCL_OK;
+}
+
+// ... and for a gradient whose sums came as per-tile ROWS [nrows][2][CS] (sum dz, sum dz (y - mean): the dgrad epilogues of
+// conv_fast.hip at tile counts beyond the blocks' own limit): one small launch adds the rows to the zeroed block, the apply
+// pass (dact: linear; dpool: 2 x 2 max-pool, even H, W) derives -- spcl_bnrelu_backward_rows / spcl_bnrelu_pool_backward_rows
+// without their finalize launch.  bf16 / f32, CS <= 256.
+extern "C" int spcl_bnrelu_backward_rows_acc(const void* y, const void* dact, const void* dpool, const float* rows, int nrows,
+                                             int dtype, int N, int H, int W, int C, int CS, const float* st4, int training,
+                                             long long* acc, float* dgamma, float* dbeta, void* dy, void* stream) {
+  SPCL_CHECK_ARG(y && rows && st4 && acc && dgamma && dbeta && dy && ((dact != nullptr) != (dpool != nullptr)),
+                 "bnrelu_backward_rows_acc: null pointer / exactly one of dact, dpool");
+  SPCL_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && CS >= C && CS % 16 == 0 && CS <= 256 && nrows > 0,
+                 "bnrelu_backward_rows_acc: bad shape (CS <= 256)");
+  SPCL_CHECK_ARG(!dpool || (H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0), "bnrelu_backward_rows_acc: pooled form needs even H, W");
+  SPCL_CHECK_ARG(dtype == SPCL_BF16 || dtype == SPCL_F32, "bnrelu_backward_rows_acc: dtype %d", dtype);
+  hipStream_t st = (hipStream_t)stream;
+  const float *mean = st4, *invstd = st4 + CS, *scale = st4 + 2 * CS, *shift = st4 + 3 * CS;
+  tl_acc_fill = true;
+  if (dtype == SPCL_F32)
+    bnrelu_bwd_launch<float>(y, dact, dpool, N, H, W, C, CS, mean, invstd, scale, shift, training, nullptr, dgamma, dbeta, dy, st,
+                             nullptr, nullptr, rows, nrows, false, acc);
+  else
+    bnrelu_bwd_launch<bf16_t>(y, dact, dpool, N, H, W, C, CS, mean, invstd, scale, shift, training, nullptr, dgamma, dbeta, dy, st,
+                              nullptr, nullptr, rows, nrows, false, acc);
+  tl_acc_fill = false;
+  SPCL_LAUNCH_CHECK("bnrelu_backward_rows_acc");
   return SPCL_OK;
 }
 

@@ -1358,6 +1358,18 @@ def _bnrelu_bwd_fill(y, dact, dpool, dt_code, dtype, N, H, W, C, cs, st, trainin
     return dy, dgamma, dbeta
 
 
+def _bnrelu_bwd_rows_acc(y, dact, dpool, rows, dt_code, dtype, N, H, W, C, cs, st, training, sinks, acc):
+    """``_bnrelu_bwd_rows`` / ``_bnrelu_pool_bwd_rows`` with the rows added to the zeroed block ``acc`` by one small launch and
+    the apply pass deriving its coefficients from it (spcl_bnrelu_backward_rows_acc): no finalize launch -> (dy, dgamma, dbeta)"""
+    dev = y.device
+    dgamma = _grad_buffer(sinks[0], (C,), dev)
+    dbeta = _grad_buffer(sinks[1], (C,), dev)
+    dy = torch.empty(N, H, W, cs, dtype=dtype, device=dev)
+    _n.call("spcl_bnrelu_backward_rows_acc", _n.ptr(y), _n.ptr(dact), _n.ptr(dpool), _n.ptr(rows), rows.ntiles, dt_code, N, H, W,
+            C, cs, _n.ptr(st), int(training), _n.ptr(acc), _n.ptr(dgamma), _n.ptr(dbeta), _n.ptr(dy), _n.stream())
+    return dy, dgamma, dbeta
+
+
 def _take_acc(ctx, name):
     """the backward accumulator block ``ctx.<name>`` -- ONCE: a block is zero only for the first backward after its forward
     (a second backward through the same graph finds None and takes the rows + finalize path)"""
@@ -1456,7 +1468,7 @@ class _ConvBlockFn(torch.autograd.Function):
         use_b = (acc_ok and not lazy and not ctx.up2 and getattr(cfg, "act_dst", None) is None
                  and sup(cout_s, cout_s, 1 if use_a else 2, 1))
         keep = []
-        ctx.acc_bwd_a = ctx.acc_bwd_b = None
+        ctx.acc_bwd_a = ctx.acc_bwd_b = ctx.acc_rows_a = None
         if use_a:
             acc_a = bn_acc_block(cout_s, dev)
             ya, _ = _conv_acc(xs, dtc, dtype, N, H, W, cin_k, cout_s, wpa, None, None, None, acc_a, False)
@@ -1486,6 +1498,8 @@ class _ConvBlockFn(torch.autograd.Function):
             # BatchNorms, added by whichever kernel produces the incoming gradient
             if not cfg.image_input and _n.call("spcl_conv_dgrad_bnstats_acc_supported", dtc, N, H, W, cout_s, cout_s):
                 ctx.acc_bwd_a = bn_acc_block(cout_s, dev)
+            elif not cfg.image_input and _ACC_FILL:
+                ctx.acc_rows_a = bn_acc_block(cout_s, dev)  # (more tiles than a block takes adds from: the dgrad's ROWS go in)
             ctx.acc_bwd_b = bn_acc_block(cout_s, dev)
         # small maps whose activation is the block's only product (the encoder's last block under a feature tap): the writer
         # also leaves the activation's global average per (image, channel) -- the projector's AdaptiveAvgPool2d((1, 1)) then
@@ -1606,8 +1620,13 @@ class _ConvBlockFn(torch.autograd.Function):
                 dyb, dgb, dbb = _bnrelu_bwd_acc(yb, None, dp_s, None, dtc, dtype, N, H, W, cout, cout_s, stb, cfg.training,
                                                 sk[4:6], _take_acc(ctx, "acc_bwd_b"))
             else:
-                dyb, dgb, dbb = _bnrelu_pool_bwd_rows(yb, dp_s, lk.rows, dtc, dtype, N, H, W, cout, cout_s, stb, cfg.training,
-                                                      sk[4:6])
+                acc = _take_acc(ctx, "acc_bwd_b") if (_ACC_FILL and H % 2 == 0 and W % 2 == 0 and cout_s <= 256) else None
+                if acc is not None:  # (the rows go into this block's own, untouched, accumulator block: no finalize launch)
+                    dyb, dgb, dbb = _bnrelu_bwd_rows_acc(yb, None, dp_s, lk.rows, dtc, dtype, N, H, W, cout, cout_s, stb,
+                                                         cfg.training, sk[4:6], acc)
+                else:
+                    dyb, dgb, dbb = _bnrelu_pool_bwd_rows(yb, dp_s, lk.rows, dtc, dtype, N, H, W, cout, cout_s, stb,
+                                                          cfg.training, sk[4:6])
         else:
             acc = _take_acc(ctx, "acc_bwd_b") if _ACC_FILL else None
             if acc is not None and lk is not None and lk.rows is ACC_ROWS:
@@ -1675,8 +1694,13 @@ class _ConvBlockFn(torch.autograd.Function):
                 dya, dga, dba = _bnrelu_bwd_acc(ya, daa, None, None, dtc, dtype, N, H, W, cout, cout_s, sta, cfg.training,
                                                 sk[1:3], rows[1])
             elif fused is not None:
-                dya, dga, dba = _bnrelu_bwd_rows(ya, daa, None, rows, dtc, dtype, N, H, W, cout, cout_s, sta,
-                                                 cfg.training, sk[1:3])
+                acc = _take_acc(ctx, "acc_rows_a")
+                if acc is not None:
+                    dya, dga, dba = _bnrelu_bwd_rows_acc(ya, daa, None, rows, dtc, dtype, N, H, W, cout, cout_s, sta,
+                                                         cfg.training, sk[1:3], acc)
+                else:
+                    dya, dga, dba = _bnrelu_bwd_rows(ya, daa, None, rows, dtc, dtype, N, H, W, cout, cout_s, sta,
+                                                     cfg.training, sk[1:3])
             else:
                 dya, dga, dba = _bnrelu_bwd(ya, daa, None, dtc, dtype, N, H, W, cout, cout_s, sta, cfg.training,
                                             sk[1:3])

@@ -168,6 +168,8 @@ _SIGNATURES = {
     "spcl_bnrelu_backward_fill_acc": (c_int, [_P, _P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P,
                                               _P, _P, _P]),
     "spcl_copy_pair": (c_int, [_P, _P, c_size_t, _P, _P, c_size_t, _P]),
+    "spcl_bnrelu_backward_rows_acc": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P, _P,
+                                              _P, _P, _P]),
     "spcl_radam_apply_staged": (c_int, [_P, _P, c_double, _P, _P, c_size_t, _P, _P, c_double, c_double, c_double, c_double,
                                         c_int, _P, _P, _P, _P]),
     # BatchNorm sums as fixed-point accumulator blocks (csrc/bn_acc.hpp)

@@ -499,3 +499,43 @@ def test_backward_whose_reduction_pass_fills_the_block_equals_the_three_launch_f
     assert relerr(dy1.float(), dy0.float()) < 4e-3
     if form == "up2":
         assert torch.equal(gs1, gs0)
+
+
+@pytest.mark.parametrize("pool", [False, True])
+@pytest.mark.parametrize("N,C,H,W,nrows", [(2, 32, 112, 112, 5000), (3, 16, 56, 56, 700), (1, 64, 28, 28, 9)])
+def test_rows_into_a_block_equal_rows_plus_finalize(pool, N, C, H, W, nrows):
+    """spcl_bnrelu_backward_rows_acc: per-tile rows (sum dz, sum dz (y - mean)) added to a block by one launch, the apply pass
+    derives -- against spcl_bnrelu_backward_rows / spcl_bnrelu_pool_backward_rows (group + finalize + apply) on the same rows"""
+    n = _n()
+    dtype, dtc, cs = torch.bfloat16, 1, C
+    g = torch.Generator().manual_seed(C + H + nrows)
+    y = (torch.randn(N, H, W, cs, generator=g) * 1.2 + 0.1).to(dtype).cuda()
+    gam, bet = (torch.rand(C, generator=g) + 0.5).cuda(), (torch.randn(C, generator=g) * 0.3).cuda()
+    yf = y.double()
+    mean, var = yf.mean(dim=(0, 1, 2)), yf.var(dim=(0, 1, 2), unbiased=False)
+    st = torch.stack([mean, 1 / torch.sqrt(var + 1e-5), gam.double() / torch.sqrt(var + 1e-5),
+                      bet.double() - mean * gam.double() / torch.sqrt(var + 1e-5)]).float().contiguous()
+    rows = (torch.randn(nrows, 2, cs, generator=g) * 0.05).cuda()  # (any rows: the two forms must agree on them)
+    dact = None if pool else (torch.randn(N, H, W, cs, generator=g) * 1e-2).to(dtype).cuda()
+    dpool = (torch.randn(N, H // 2, W // 2, cs, generator=g) * 1e-2).to(dtype).cuda() if pool else None
+    ws = torch.empty(n.call("spcl_bnrelu_bwd_workspace_bytes", N, H, W, cs) // 4, device="cuda")
+    dg0, db0, dy0 = torch.empty(C, device="cuda"), torch.empty(C, device="cuda"), torch.empty_like(y)
+    if pool:
+        n.call("spcl_bnrelu_pool_backward_rows", n.ptr(y), n.ptr(dpool), n.ptr(rows), nrows, dtc, N, H, W, C, cs, n.ptr(st[0]),
+               n.ptr(st[1]), n.ptr(st[2]), n.ptr(st[3]), 1, n.ptr(ws), n.ptr(dg0), n.ptr(db0), n.ptr(dy0), n.stream())
+    else:
+        n.call("spcl_bnrelu_backward_rows", n.ptr(y), n.ptr(dact), None, n.ptr(rows), nrows, dtc, N, H, W, C, cs, n.ptr(st[0]),
+               n.ptr(st[1]), n.ptr(st[2]), n.ptr(st[3]), 1, n.ptr(ws), n.ptr(dg0), n.ptr(db0), n.ptr(dy0), None, n.stream())
+    acc = _block(n, cs)
+    dg1, db1, dy1 = torch.empty(C, device="cuda"), torch.empty(C, device="cuda"), torch.empty_like(y)
+    n.call("spcl_bnrelu_backward_rows_acc", n.ptr(y), n.ptr(dact), n.ptr(dpool), n.ptr(rows), nrows, dtc, N, H, W, C, cs, n.ptr(st),
+           1, n.ptr(acc), n.ptr(dg1), n.ptr(db1), n.ptr(dy1), n.stream())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(db1.cpu().numpy(), db0.cpu().numpy(), rtol=2e-5, atol=1e-6 * float(db0.abs().max()) + 1e-9)
+    np.testing.assert_allclose(dg1.cpu().numpy(), dg0.cpu().numpy(), rtol=2e-5, atol=1e-6 * float(dg0.abs().max()) + 1e-9)
+    assert relerr(dy1.float(), dy0.float()) < 4e-3
+    s1, s2, flag = _totals(acc, cs)
+    assert flag == 0
+    # (a workgroup folds its rows in float before it adds: the block's totals are the rows' sums to float rounding)
+    ref = rows[:, 0].double().sum(0).cpu().numpy()
+    np.testing.assert_allclose(s1, ref, rtol=2e-5, atol=2e-6 * float(np.abs(ref).max()))

@@ -803,7 +803,8 @@ def test_pool_link_ignores_a_gradient_it_did_not_produce():
         own = (any(nm == "spcl_bnrelu_pool_backward" and args[2] is not None for nm, args in used)
                or any(nm == "spcl_bnrelu_backward_fill_acc" and args[3] is not None for nm, args in used))  # (dpool given)
         taken = not own
-        assert not taken or "spcl_bnrelu_pool_backward_rows" in names or "spcl_conv3x3_dgrad_poolstats_acc" in names
+        assert (not taken or "spcl_bnrelu_pool_backward_rows" in names or "spcl_bnrelu_backward_rows_acc" in names
+                or "spcl_conv3x3_dgrad_poolstats_acc" in names)
         return [q.grad.clone() for q in a.parameters()], taken
 
     (g1, rows1), (g0, rows0) = run(False, True), run(False, False)
