@@ -1005,10 +1005,8 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_fin_kernel(const float* __rest
   __shared__ double racc4[4][64];
   __shared__ double racc[54];
   __shared__ float coef[2];
-  // image3 launches run THREE workgroups per channel (grid 3 CS), each with three of the nine tap sums (and, all of them,
-  // the two BatchNorm sums the coefficients come from): 5 of the 11 sub-row walks per workgroup instead of 11 on 16 CUs
-  const int c = blockIdx.x % CS, grp = blockIdx.x / CS;
-  if (blockIdx.x == 0)  // scratch the next launch wants zeroed (the image-wgrad pass's zero row): saves a memset launch
+  const int c = blockIdx.x;
+  if (c == 0)  // scratch the next launch wants zeroed (the image-wgrad pass's zero row): saves a memset launch
     for (int z = threadIdx.x; z < nzero; z += 256) zero_fill[z] = 0.f;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // the channel's coefficients are requested WITH the partials (one memory round trip instead of a second, dependent
@@ -1030,8 +1028,7 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_fin_kernel(const float* __rest
       s2 += partial[((size_t)1 * CS + c) * nwg + w];
       if (img3) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
-          if (t / 3 == grp || gridDim.x == (unsigned)CS) st[t] += partial[((size_t)(2 + t) * CS + c) * nwg + w];
+        for (int t = 0; t < 9; ++t) st[t] += partial[((size_t)(2 + t) * CS + c) * nwg + w];
       }
     }
   } else {
@@ -1041,8 +1038,7 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_fin_kernel(const float* __rest
       s2 += partial[((size_t)w * rs + 1) * CS + c];
       if (img3) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
-          if (t / 3 == grp || gridDim.x == (unsigned)CS) st[t] += partial[((size_t)w * rs + 2 + t) * CS + c];
+        for (int t = 0; t < 9; ++t) st[t] += partial[((size_t)w * rs + 2 + t) * CS + c];
       }
     }
   }
@@ -1070,7 +1066,7 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_fin_kernel(const float* __rest
     s1 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
     s2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     if (s2_centered) s2 *= c_invstd;  // rows held sum dz (y - mean): dgamma = invstd * that
-    if (c < C && grp == 0) {
+    if (c < C) {
       dbeta[c] = s1;
       dgamma[c] = s2;
     }
@@ -1079,10 +1075,8 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_fin_kernel(const float* __rest
       A = -c_scale * c_invstd * (s2 / M);
       B = -c_scale * (s1 / M) - A * c_mean;
     }
-    if (grp == 0) {
-      ab[c] = A;
-      ab[CS + c] = B;
-    }
+    ab[c] = A;
+    ab[CS + c] = B;
     coef[0] = A;
     coef[1] = B;
   }
@@ -1094,7 +1088,7 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_fin_kernel(const float* __rest
     wrp[t][u] = (double)wsh[u] * racc[u <= t ? acorr_index(u, t) : acorr_index(t, u)];
   }
   __syncthreads();
-  if (threadIdx.x < 9 && c < C && ((int)threadIdx.x / 3 == grp || gridDim.x == (unsigned)CS)) {
+  if (threadIdx.x < 9 && c < C) {
     const int t = threadIdx.x;
     const double S1 = (double)((red[2 + t][0] + red[2 + t][1]) + (red[2 + t][2] + red[2 + t][3]));
     double wr = 0.0;
@@ -2009,7 +2003,7 @@ extern "C" int spcl_bnrelu_backward_rows_image3(const float* rows11, int nrows, 
     }
   }
   const Image3Args im{acorr, nacorr, w_oihw, dw};
-  SPCL_LAUNCH(bnrelu_bwd_fin_kernel, dim3(3 * CS), dim3(256), 0, st, fin_src, nwg, C, CS, (float)((size_t)N * H * W), training,
+  SPCL_LAUNCH(bnrelu_bwd_fin_kernel, dim3(CS), dim3(256), 0, st, fin_src, nwg, C, CS, (float)((size_t)N * H * W), training,
               mean, invstd, scale, dgamma, dbeta, ab, (float*)nullptr, 0, 1, 11, im, transposed);
   SPCL_LAUNCH_CHECK("bnrelu_backward_rows_image3");
   return SPCL_OK;
@@ -2031,7 +2025,7 @@ extern "C" int spcl_bnrelu_backward_wgrows_image3(const float* wg_rows, int nwg,
   float* ab = ws + (size_t)BWD_MAX_WG * 11 * CS;
   const Image3Args im{acorr, nacorr, w_oihw, dw};
   prof_cost((double)nwg * 11 * CS * 4.0, 0.0);
-  SPCL_LAUNCH(bnrelu_bwd_fin_kernel, dim3(3 * CS), dim3(256), 0, st, wg_rows, nwg, C, CS, (float)((size_t)N * H * W), training,
+  SPCL_LAUNCH(bnrelu_bwd_fin_kernel, dim3(CS), dim3(256), 0, st, wg_rows, nwg, C, CS, (float)((size_t)N * H * W), training,
               mean, invstd, scale, dgamma, dbeta, ab, (float*)nullptr, 0, 1, 11, im, 1);
   SPCL_LAUNCH_CHECK("bnrelu_backward_wgrows_image3");
   return SPCL_OK;
