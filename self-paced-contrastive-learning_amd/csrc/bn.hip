@@ -3,6 +3,7 @@
 // autograd backward.  All of these are HBM-bound streaming kernels: 16-byte vector loads/stores per lane, per-channel
 // reductions as per-workgroup partials + a fixed-order second stage (deterministic, no float atomics).
 #include <mutex>
+#include <type_traits>
 #include "bn_acc.hpp"
 #include "common.hpp"
 #include "image_acorr.hpp"
@@ -1005,8 +1006,13 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_fin_kernel(const float* __rest
   __shared__ double racc4[4][64];
   __shared__ double racc[54];
   __shared__ float coef[2];
-  const int c = blockIdx.x;
-  if (c == 0)  // scratch the next launch wants zeroed (the image-wgrad pass's zero row): saves a memset launch
+  // image3 launches may run THREE workgroups per channel (grid 3 CS), each with three of the nine tap sums (and, all of them,
+  // the two BatchNorm sums the coefficients come from): 5 of the 11 sub-row walks per workgroup instead of 11 on 16 CUs.  The
+  // walk is instantiated for 9 and for 3 taps with a wave-uniform first tap (no load sits behind a branch of its own).
+  const int c = blockIdx.x % CS, grp = blockIdx.x / CS;
+  const bool split = gridDim.x == 3u * (unsigned)CS;
+  const int t0 = split ? 3 * grp : 0, ntap = split ? 3 : 9;
+  if (blockIdx.x == 0)  // scratch the next launch wants zeroed (the image-wgrad pass's zero row): saves a memset launch
     for (int z = threadIdx.x; z < nzero; z += 256) zero_fill[z] = 0.f;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // the channel's coefficients are requested WITH the partials (one memory round trip instead of a second, dependent
@@ -1020,36 +1026,38 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_fin_kernel(const float* __rest
   float st[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) st[t] = 0.f;
-  if (transposed) {  // [sub-row][channel][row]: consecutive threads read consecutive floats (the row-major walk below costs
-                     // one cache line per lane and load: 11 k line requests per workgroup on the image3 path)
+  auto walk = [&](auto ntap_c) {
+    constexpr int NTAP = decltype(ntap_c)::value;  // 0: no tap sums (not the image3 path)
+    if (transposed) {  // [sub-row][channel][row]: consecutive threads read consecutive floats (the row-major walk below costs
+                       // one cache line per lane and load: 11 k line requests per workgroup on the image3 path)
 #pragma unroll 4
-    for (int w = threadIdx.x; w < nwg; w += 256) {
-      s1 += partial[((size_t)0 * CS + c) * nwg + w];
-      s2 += partial[((size_t)1 * CS + c) * nwg + w];
-      if (img3) {
+      for (int w = threadIdx.x; w < nwg; w += 256) {
+        s1 += partial[((size_t)0 * CS + c) * nwg + w];
+        s2 += partial[((size_t)1 * CS + c) * nwg + w];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) st[t] += partial[((size_t)(2 + t) * CS + c) * nwg + w];
+        for (int t = 0; t < NTAP; ++t) st[t] += partial[((size_t)(2 + t0 + t) * CS + c) * nwg + w];
+      }
+    } else {
+#pragma unroll 4
+      for (int w = threadIdx.x; w < nwg; w += 256) {
+        s1 += partial[((size_t)w * rs + 0) * CS + c];
+        s2 += partial[((size_t)w * rs + 1) * CS + c];
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) st[t] += partial[((size_t)w * rs + 2 + t0 + t) * CS + c];
       }
     }
-  } else {
-#pragma unroll 4
-    for (int w = threadIdx.x; w < nwg; w += 256) {
-      s1 += partial[((size_t)w * rs + 0) * CS + c];
-      s2 += partial[((size_t)w * rs + 1) * CS + c];
-      if (img3) {
-#pragma unroll
-        for (int t = 0; t < 9; ++t) st[t] += partial[((size_t)w * rs + 2 + t) * CS + c];
-      }
-    }
-  }
+  };
+  if (!img3) walk(std::integral_constant<int, 0>{});
+  else if (split) walk(std::integral_constant<int, 3>{});
+  else walk(std::integral_constant<int, 9>{});
   s1 = wave_sum(s1);
   s2 = wave_sum(s2);
   if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
   if (img3) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
+    for (int t = 0; t < 9; ++t) {  // (st[t] holds tap t0 + t; the entries beyond ntap are zero and land on unused rows)
       st[t] = wave_sum(st[t]);
-      if (lane == 0) red[2 + t][wave] = st[t];
+      if (lane == 0 && t < ntap) red[2 + t0 + t][wave] = st[t];
     }
     {  // the autocorrelation / image sums over the partial rows of image_autocorr_kernel, in double: wave p takes rows
        // p, p + 4, ... (eight loads in flight per lane), the four waves are added in fixed order below
@@ -1066,7 +1074,7 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_fin_kernel(const float* __rest
     s1 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
     s2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     if (s2_centered) s2 *= c_invstd;  // rows held sum dz (y - mean): dgamma = invstd * that
-    if (c < C) {
+    if (c < C && grp == 0) {
       dbeta[c] = s1;
       dgamma[c] = s2;
     }
@@ -1075,8 +1083,10 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_fin_kernel(const float* __rest
       A = -c_scale * c_invstd * (s2 / M);
       B = -c_scale * (s1 / M) - A * c_mean;
     }
-    ab[c] = A;
-    ab[CS + c] = B;
+    if (grp == 0) {
+      ab[c] = A;
+      ab[CS + c] = B;
+    }
     coef[0] = A;
     coef[1] = B;
   }
@@ -1088,7 +1098,7 @@ __global__ __launch_bounds__(256) void bnrelu_bwd_fin_kernel(const float* __rest
     wrp[t][u] = (double)wsh[u] * racc[u <= t ? acorr_index(u, t) : acorr_index(t, u)];
   }
   __syncthreads();
-  if (threadIdx.x < 9 && c < C) {
+  if ((int)threadIdx.x >= t0 && (int)threadIdx.x < t0 + ntap && c < C) {
     const int t = threadIdx.x;
     const double S1 = (double)((red[2 + t][0] + red[2 + t][1]) + (red[2 + t][2] + red[2 + t][3]));
     double wr = 0.0;
@@ -2003,7 +2013,7 @@ extern "C" int spcl_bnrelu_backward_rows_image3(const float* rows11, int nrows, 
     }
   }
   const Image3Args im{acorr, nacorr, w_oihw, dw};
-  SPCL_LAUNCH(bnrelu_bwd_fin_kernel, dim3(CS), dim3(256), 0, st, fin_src, nwg, C, CS, (float)((size_t)N * H * W), training,
+  SPCL_LAUNCH(bnrelu_bwd_fin_kernel, dim3(3 * CS), dim3(256), 0, st, fin_src, nwg, C, CS, (float)((size_t)N * H * W), training,
               mean, invstd, scale, dgamma, dbeta, ab, (float*)nullptr, 0, 1, 11, im, transposed);
   SPCL_LAUNCH_CHECK("bnrelu_backward_rows_image3");
   return SPCL_OK;
@@ -2025,7 +2035,7 @@ extern "C" int spcl_bnrelu_backward_wgrows_image3(const float* wg_rows, int nwg,
   float* ab = ws + (size_t)BWD_MAX_WG * 11 * CS;
   const Image3Args im{acorr, nacorr, w_oihw, dw};
   prof_cost((double)nwg * 11 * CS * 4.0, 0.0);
-  SPCL_LAUNCH(bnrelu_bwd_fin_kernel, dim3(CS), dim3(256), 0, st, wg_rows, nwg, C, CS, (float)((size_t)N * H * W), training,
+  SPCL_LAUNCH(bnrelu_bwd_fin_kernel, dim3(3 * CS), dim3(256), 0, st, wg_rows, nwg, C, CS, (float)((size_t)N * H * W), training,
               mean, invstd, scale, dgamma, dbeta, ab, (float*)nullptr, 0, 1, 11, im, 1);
   SPCL_LAUNCH_CHECK("bnrelu_backward_wgrows_image3");
   return SPCL_OK;
