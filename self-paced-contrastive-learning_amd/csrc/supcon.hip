@@ -839,10 +839,11 @@ __global__ __launch_bounds__(1024) void supcon_small_kernel(const float* __restr
     dzv[rr] = (f32x4){acc2[0][rr] * inv_t, acc2[1][rr] * inv_t, acc2[2][rr] * inv_t, acc2[3][rr] * inv_t};
     zv[rr] = live ? *(const f32x4*)(lds + row * DP + (((16 * cq + r16) ^ (row & 15)) << 2)) : (f32x4){0.f, 0.f, 0.f, 0.f};
     float pd = (dzv[rr][0] * zv[rr][0] + dzv[rr][1] * zv[rr][1]) + (dzv[rr][2] * zv[rr][2] + dzv[rr][3] * zv[rr][3]);
-    pd += __shfl_xor(pd, 1, 64);
-    pd += __shfl_xor(pd, 2, 64);
-    pd += __shfl_xor(pd, 4, 64);
-    pd += __shfl_xor(pd, 8, 64);
+    // (the sum over the 16 lanes of a row by DPP moves: no trips through the LDS crossbar)
+    pd += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, pd), 0xB1, 0xF, 0xF, true));
+    pd += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, pd), 0x4E, 0xF, 0xF, true));
+    pd += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, pd), 0x141, 0xF, 0xF, true));
+    pd += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, pd), 0x140, 0xF, 0xF, true));
     if (r16 == 0) part[cq * 64 + row] = pd;
   }
   __syncthreads();

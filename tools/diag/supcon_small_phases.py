@@ -14,13 +14,15 @@ import spcl_amd  # noqa
 from spcl_amd import native
 from spcl_amd import functional as F
 d = int(sys.argv[1])
+RAW = os.environ.get("PHASES_RAW", "0") == "1"  # the rows before F.normalize (spcl_supcon_forward_rows)
 n = 32
 g = torch.Generator().manual_seed(1)
 z = torch.nn.functional.normalize(torch.randn(2 * n, d, generator=g), dim=1).cuda()
 labels = (torch.arange(n) % 3).float().cuda()
 def run():
     st = F.SupConState()
-    F.supcon_loss(z, None, labels, None, t=0.07, sp_mode=F.SP_SOFT, gamma=12.0, correct_grad=True, state=st)
+    F.supcon_loss(z, None, labels, None, t=0.07, sp_mode=F.SP_SOFT, gamma=12.0, correct_grad=True, state=st,
+                  normalize_inputs=RAW)
 for _ in range(5):
     run()
 torch.cuda.synchronize()
@@ -38,4 +40,4 @@ for i in range(cnt):
         ts.append(us.value)
 native.call("spcl_profile_enable", 0)
 ts.sort()
-print(f"dbg={os.environ.get('SPCL_SUPCON_DBG')} d={d}: supcon_small median {ts[len(ts)//2]:.1f} us (min {ts[0]:.1f})")
+print(f"raw={int(RAW)} dbg={os.environ.get('SPCL_SUPCON_DBG')} d={d}: supcon_small median {ts[len(ts)//2]:.1f} us (min {ts[0]:.1f})")
