@@ -406,6 +406,7 @@ def test_projector_takes_the_block_s_global_average_and_falls_back_when_it_is_st
     x = torch.randn(4, 64, 14, 14, generator=g).cuda()
     w1, b1 = (torch.randn(32, 128, generator=g) * 0.1).cuda().requires_grad_(True), torch.zeros(32).cuda().requires_grad_(True)
     w2, b2 = (torch.randn(16, 32, generator=g) * 0.1).cuda().requires_grad_(True), torch.zeros(16).cuda().requires_grad_(True)
+    rr = torch.randn(4, 16, generator=g).cuda()
 
     def run(gap_on, spoil=None):
         monkeypatch.setattr(F_hip, "_GAP", gap_on)
@@ -425,7 +426,7 @@ def test_projector_takes_the_block_s_global_average_and_falls_back_when_it_is_st
             z = F_hip.projector(feat, w1, b1, w2, b2, True)
         finally:
             F_hip._n.call = real
-        z.square().sum().backward()
+        (z * rr).sum().backward()  # (not z.square().sum(): that is N for normalised rows -- a zero gradient, pure rounding noise)
         pooled_given = [a0 for nm, a0 in calls if nm == "spcl_proj_forward"][0] is None
         return has, pooled_given, z.detach().clone(), w1.grad.clone(), blk.conv[0].weight.grad.clone()
 
@@ -434,7 +435,7 @@ def test_projector_takes_the_block_s_global_average_and_falls_back_when_it_is_st
     assert has1 and given1 and not has0 and not given0
     np.testing.assert_allclose(z1.cpu().numpy(), z0.cpu().numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(g1.cpu().numpy(), g0.cpu().numpy(), rtol=1e-4, atol=1e-6)
-    assert relerr(c1.float(), c0.float()) < 1e-3
+    assert relerr(c1.float(), c0.float()) < 2e-2  # (bf16 block: the pooled rows differ in their last bits, the gradients in bf16 roundings)
     for spoil in ("stale", "slice"):
         has, given, z, _, _ = run(True, spoil)
         assert has and not given, spoil
