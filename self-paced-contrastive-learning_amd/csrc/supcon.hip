@@ -729,13 +729,10 @@ __global__ __launch_bounds__(1024) void supcon_small_kernel(const float* __restr
       s_c = (double)cnt_i;
       dev = fabsf(sqrtf(st_rn2[i]) - 1.f);
     }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
-      s_loss += __shfl_xor(s_loss, o, 64);
-      s_w += __shfl_xor(s_w, o, 64);
-      s_c += __shfl_xor(s_c, o, 64);
-      dev = fmaxf(dev, __shfl_xor(dev, o, 64));
-    }
+    s_loss = row16_sum_f64(s_loss);  // (the 16 rows of the block sit in the lanes of row g == 0: DPP moves, no shuffles)
+    s_w = row16_sum_f64(s_w);
+    s_c = row16_sum_f64(s_c);
+    dev = row16_max(dev);
     if (lane == 0) {
       red[rb * 4 + 0] = s_loss;
       red[rb * 4 + 1] = s_w;
