@@ -34,7 +34,7 @@ extern "C" {
 /* Bumped whenever a struct layout, a limit (SPCL_*_MAX) or an entry point's meaning changes.  The library is git-ignored and
  * travels next to the sources: the Python binding (native.py) refuses a library whose version is not the header's, so that a
  * stale build fails at load time instead of running kernels on structs of another stride. */
-#define SPCL_ABI_VERSION 5
+#define SPCL_ABI_VERSION 6
 int spcl_abi_version(void);
 const char* spcl_last_error(void);
 
@@ -220,6 +220,13 @@ int spcl_conv_stat_rows(int dtype, int N, int H, int W, int CinK, int CoutS);
  * per-wave kernels have no specialisation for (widths that do not tile by 14 columns: the 32^2 / 16^2 levels of 256^2
  * inputs), 1 (SPCL_CONV_GEMM=1) wherever it fits, 0 never.  Packed weights are valid under every setting. */
 void spcl_conv_set_gemm(int mode);
+/* How the f32-storage convolutions (forward, data gradient, weight gradient: nn.Conv2d of unet.py:72,75 run in torch's default
+ * float32, the north_star's "within fp32 tolerance" path) multiply: 1 (default) every f32 operand as the exact sum of three
+ * bf16 pieces, six v_mfma_f32_16x16x32_bf16 products per pair accumulated in f32 (the dropped terms are below 2^-24 of a
+ * product: f32-grade results at 3/8 of the exact path's matrix time); 0 v_mfma_f32_16x16x4_f32 (exact f32 products, 1/16 of
+ * the bf16 matrix rate).  Packed f32 weights carry both layouts: the switch may change between any two launches. */
+void spcl_conv_set_f32_split(int on);
+int spcl_conv_get_f32_split(void);
 size_t spcl_bn_stats_elems(int ntiles, int CS);
 int spcl_conv3x3_forward(const void* x, int dtype, int N, int H, int W, int CinS, int CinK, int CoutS,
                          const void* w_packed, int in_mode, const float* in_scale, const float* in_shift, void* y,

@@ -20,13 +20,30 @@
 
 namespace spcl {
 
+// ---- f32 storage on the bf16 matrix rate (SPLIT): every f32 operand is the exact sum of three bf16 pieces
+// (hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi - mid): 3 x 8 mantissa bits), the product of two operands is six
+// bf16 products (hi hi, hi mid, mid hi, mid mid, hi lo, lo hi; the three dropped ones are below 2^-24 of the product) summed
+// in the MFMA's f32 accumulator: 6 v_mfma_f32_16x16x32_bf16 per 32 k-values instead of 8 v_mfma_f32_16x16x4_f32 at 1/16
+// of the rate -- 3/8 of the matrix time, f32-grade results (tests/test_gpu_kernels.py: the f32 tolerances unchanged).  The
+// input is split ONCE per halo element in the staging (three bf16 planes per LDS pixel; each element is then read by nine
+// taps), the weights once per step by the pack kernel (pack_value<float>: second half of the packed buffer).
+__host__ __device__ inline int split_pstride(int KC) {  // LDS bytes per halo pixel: three bf16 planes, an ODD multiple of 32
+  const int b = 3 * KC * 2;
+  return (b / 32) % 2 == 1 ? b : b + 32;
+}
+__device__ __forceinline__ f32x4 mfma_bf16(u32x4 w, u32x4 x, f32x4 acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
+}
+
 // One workgroup = one TH x TW pixel tile (x a block of output channels); see the file header.  Instruction budget
 // (ISA audit): staging walks the halo with incremental coordinates (no divisions in the loop, no bounds
 // tests on interior tiles, BN coefficients of the thread's fixed channel chunk in registers); the epilogue walks the
 // pixels incrementally and accumulates the BatchNorm sums in one pass, reduced across lanes with DPP.
-template <typename T, int TH, int TW, int NT>
+// SPLIT (T = float only): the k-loop of the bf16 kernel on three planes, see above; a.wp points at the split half of the weights
+template <typename T, int TH, int TW, int NT, bool SPLIT = false>
 __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
-  constexpr int EPC = Chunk<T>::EPC;
+  static_assert(!SPLIT || sizeof(T) == 4, "the split k-loop is the f32 storage path");
+  constexpr int EPC = SPLIT ? 8 : Chunk<T>::EPC;  // channels per k-chunk (SPLIT: two 16-byte loads, one 16-byte chunk per plane)
   constexpr int NPIX = TH * TW;
   constexpr int MT = (NPIX + 15) / 16;
   constexpr int HW_ = TW + 2;
@@ -39,8 +56,9 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
   const int KC = conv_kc(a.CinK);
   const int CP = KC / EPC;
   const int log2cp = __builtin_ctz(CP);
-  const int PSTRIDE = conv_pstride<T>(KC);
-  const int nsteps = conv_nsteps<T>(KC);
+  const int PSTRIDE = SPLIT ? split_pstride(KC) : conv_pstride<T>(KC);
+  const int nsteps = SPLIT ? conv_nsteps<bf16_t>(KC) : conv_nsteps<T>(KC);
+  const int PLANE = KC * 2;  // SPLIT: bytes between the planes of a pixel
   const int nslab = a.CinK / KC;
   const int ntiles_n = a.CoutS >> 4;
 
@@ -108,12 +126,30 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
           const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
           inb = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
         }
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (inb && !(a.dbg & 16)) {
-          v = *(const u32x4*)(xb + goff);
-          if (a.in_mode == 1 && !(a.dbg & 1)) v = bnrelu_regs<T>(v, ssc, ssh);
+        if constexpr (SPLIT) {
+          u32x4 ph = {0u, 0u, 0u, 0u}, pm = ph, pl = ph;
+          if (inb) {
+            u32x4 v0 = *(const u32x4*)(xb + goff), v1 = *(const u32x4*)(xb + goff + 4);
+            if (a.in_mode == 1) {
+              v0 = bnrelu_regs<float>(v0, ssc, ssh);
+              v1 = bnrelu_regs<float>(v1, ssc + 4, ssh + 4);
+            }
+            float e[8];
+            *(f32x4*)&e[0] = __builtin_bit_cast(f32x4, v0);
+            *(f32x4*)&e[4] = __builtin_bit_cast(f32x4, v1);
+            split3_chunk(e, ph, pm, pl);
+          }
+          *(u32x4*)lp = ph;
+          *(u32x4*)(lp + PLANE) = pm;
+          *(u32x4*)(lp + 2 * PLANE) = pl;
+        } else {
+          u32x4 v = {0u, 0u, 0u, 0u};
+          if (inb && !(a.dbg & 16)) {
+            v = *(const u32x4*)(xb + goff);
+            if (a.in_mode == 1 && !(a.dbg & 1)) v = bnrelu_regs<T>(v, ssc, ssh);
+          }
+          *(u32x4*)lp = v;
         }
-        *(u32x4*)lp = v;
         lp += dlp;
         hx += dhx;
         hy += dhy;
@@ -129,7 +165,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
         const int q = idx >> log2cp, ch = idx & (CP - 1);
         const int hy = q / HW_, hx = q - hy * HW_;
         const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-        u32x4 v = {0u, 0u, 0u, 0u};
+        u32x4 v = {0u, 0u, 0u, 0u}, pm = v, pl = v;  // (pm, pl: the SPLIT planes)
         if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
           const float* src = (const float*)a.x + (((size_t)n * a.H + gy) * a.W + gx) * a.CinS;
           float e[EPC];
@@ -138,7 +174,9 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
             const int c = ch * EPC + k;
             e[k] = c < a.CinS ? src[c] : 0.f;
           }
-          if (sizeof(T) == 4) {
+          if constexpr (SPLIT) {
+            split3_chunk(e, v, pm, pl);
+          } else if (sizeof(T) == 4) {
             v = (u32x4){__float_as_uint(e[0]), __float_as_uint(e[1]), __float_as_uint(e[2]), __float_as_uint(e[3])};
           } else {
 #pragma unroll
@@ -147,6 +185,10 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
           }
         }
         *(u32x4*)(lds + q * PSTRIDE + ch * 16) = v;
+        if constexpr (SPLIT) {
+          *(u32x4*)(lds + q * PSTRIDE + ch * 16 + PLANE) = pm;
+          *(u32x4*)(lds + q * PSTRIDE + ch * 16 + 2 * PLANE) = pl;
+        }
       }
     }
     __syncthreads();
@@ -154,6 +196,77 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
 
     // ---------------- K loop over (tap, channel-chunk) steps; 4 chunks (k-groups g) per step
     const u32x4* wslab = wp + ((size_t)slab * nsteps * ntiles_n + nt0) * 64 + lane;
+    if constexpr (SPLIT) {
+      // three weight planes (hi, mid, lo: `wplane` fragments apart), three input planes per LDS pixel; products from the
+      // smallest to the largest
+      const size_t wplane = (size_t)nslab * nsteps * ntiles_n * 64;
+      u32x4 wf[3][NT], wnext[3][NT];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) wf[pl][j] = wslab[pl * wplane + (size_t)(j < nvalid ? j : 0) * 64];
+      // the input fragments run ONE m-tile ahead of the products (across the step boundary too): with one wave per SIMD --
+      // the wide layers' grids -- nothing else hides the LDS latency
+      auto xoff = [&](int s) {
+        if (CP >= 4) {
+          const int fc0 = 4 * s;
+          const int tap = fc0 >> log2cp, ch0 = fc0 & (CP - 1);
+          const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+          return (ky * HW_ + kx) * PSTRIDE + (ch0 + g) * 16;
+        }
+        int fc = 4 * s + g;
+        if (fc >= 9 * CP) fc = 0;  // K padding: weights there are zero
+        const int tap = fc >> log2cp, ch = fc & (CP - 1);
+        const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+        return (ky * HW_ + kx) * PSTRIDE + ch * 16;
+      };
+      int off = xoff(0);
+      u32x4 xh = *(const u32x4*)(lds + abase[0] + off);
+      u32x4 xm = *(const u32x4*)(lds + abase[0] + off + PLANE);
+      u32x4 xl = *(const u32x4*)(lds + abase[0] + off + 2 * PLANE);
+#pragma unroll 1
+      for (int s = 0; s < nsteps; ++s) {
+        // (unconditional -- the last step re-reads its own fragments -- and fenced: behind a branch the requests sat at the END
+        // of the previous trip and every step began with a wait for the L2)
+        const int sn = s + 1 < nsteps ? s + 1 : s;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            wnext[pl][j] = wslab[pl * wplane + ((size_t)sn * ntiles_n + (j < nvalid ? j : 0)) * 64];
+        const int offn = xoff(sn);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int an = i + 1 < MT ? abase[i + 1 < MT ? i + 1 : 0] + off : abase[0] + offn;
+          const u32x4 nh = *(const u32x4*)(lds + an);
+          const u32x4 nm = *(const u32x4*)(lds + an + PLANE);
+          const u32x4 nl = *(const u32x4*)(lds + an + 2 * PLANE);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = mfma_bf16(wf[2][j], xh, acc[i][j]);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = mfma_bf16(wf[0][j], xl, acc[i][j]);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = mfma_bf16(wf[1][j], xm, acc[i][j]);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = mfma_bf16(wf[1][j], xh, acc[i][j]);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = mfma_bf16(wf[0][j], xm, acc[i][j]);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = mfma_bf16(wf[0][j], xh, acc[i][j]);
+          xh = nh;
+          xm = nm;
+          xl = nl;
+        }
+        off = offn;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) wf[pl][j] = wnext[pl][j];
+      }
+      continue;
+    }
     u32x4 wf[NT], wnext[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) wf[j] = wslab[(size_t)(j < nvalid ? j : 0) * 64];
@@ -245,10 +358,37 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
 // flattened chunk fc = 4*step + g  (tap = fc / CP, channel chunk = fc % CP) of slab `slab`.
 // kind 0 (forward):  A[cout=o][k=(tap,ci)]      = W[o][ci][tap]
 // kind 1 (dgrad):    A[cout=ci][k=(tap,co)]     = W[co][ci][8-tap]        (roles of Cin/Cout swapped by the caller)
+// f32 buffers hold TWO layouts: the exact-f32 kernel's fragments first (f32_exact_elems floats), then the split kernel's --
+// packedS[plane 3][slab][step][ntile][lane][8] bf16 pieces in the bf16 kernel's fragment order, two pieces per float slot
+__host__ __device__ inline size_t f32_exact_elems(int KinK, int NoutS) {
+  const int KC = conv_kc(KinK);
+  return (size_t)(KinK / KC) * conv_nsteps<float>(KC) * (NoutS / 16) * 64 * 4;
+}
+__host__ __device__ inline size_t f32_split_plane_elems(int KinK, int NoutS) {  // bf16 pieces per plane
+  const int KC = conv_kc(KinK);
+  return (size_t)(KinK / KC) * conv_nsteps<bf16_t>(KC) * (NoutS / 16) * 64 * 8;
+}
+template <int EPC>
+__device__ __forceinline__ float pack_value_epc(const float* __restrict__ w, int Cin, int Cout, int kind, int KinK, int NoutS,
+                                                unsigned r);
+__device__ __forceinline__ uint32_t split_piece(float v, int plane) {  // bf16 bits of piece `plane` of v (split3_pair's pieces)
+  const Split3 o = split3_pair(v, 0.f);
+  return (plane == 0 ? o.hi : (plane == 1 ? o.mid : o.lo)) & 0xffffu;
+}
+
 template <typename T>
 __device__ __forceinline__ float pack_value(const float* __restrict__ w, int Cin, int Cout, int kind, int KinK, int NoutS,
                                             size_t idx, bool gemm) {
   constexpr int EPC = Chunk<T>::EPC;
+  if (sizeof(T) == 4 && idx >= f32_exact_elems(KinK, NoutS)) {
+    const unsigned per = (unsigned)f32_split_plane_elems(KinK, NoutS);
+    const unsigned b = 2u * (unsigned)(idx - f32_exact_elems(KinK, NoutS));  // first of the slot's two pieces
+    const int plane = (int)(b / per);
+    const unsigned r = b - (unsigned)plane * per;
+    const uint32_t p0 = split_piece(pack_value_epc<8>(w, Cin, Cout, kind, KinK, NoutS, r), plane);
+    const uint32_t p1 = split_piece(pack_value_epc<8>(w, Cin, Cout, kind, KinK, NoutS, r + 1), plane);
+    return __uint_as_float(p0 | (p1 << 16));
+  }
   if (gemm && idx >= (size_t)9 * KinK * NoutS) {
     // second half of a dual-layout buffer, for conv_gemm.hip: packed[slab][tap][32-channel output tile][ks][lane][8]:
     // lane (n32 = output channel in the tile, kh = lane / 32) holds input channels 64 slab + 16 ks + 8 kh .. +7 of tap
@@ -265,11 +405,16 @@ __device__ __forceinline__ float pack_value(const float* __restrict__ w, int Cin
     if (kind == 0) return (kch < Cin && nch < Cout) ? w[((size_t)nch * Cin + kch) * 9 + tap] : 0.f;
     return (kch < Cout && nch < Cin) ? w[((size_t)kch * Cin + nch) * 9 + (8 - tap)] : 0.f;
   }
+  return pack_value_epc<EPC>(w, Cin, Cout, kind, KinK, NoutS, (unsigned)idx);  // (packed buffers hold a few million elements)
+}
+
+template <int EPC>
+__device__ __forceinline__ float pack_value_epc(const float* __restrict__ w, int Cin, int Cout, int kind, int KinK, int NoutS,
+                                                unsigned r) {
   const int KC = conv_kc(KinK);
   const int CP = KC / EPC;
-  const int nsteps = conv_nsteps<T>(KC);
+  const int nsteps = (9 * CP + 3) / 4;  // conv_nsteps
   const int ntn = NoutS >> 4;
-  unsigned r = (unsigned)idx;  // (packed buffers hold a few million elements)
   const int e = (int)(r % EPC); r /= EPC;
   const int lane = (int)(r % 64); r /= 64;
   const int nt = (int)(r % ntn); r /= ntn;
@@ -393,6 +538,7 @@ __device__ __forceinline__ void conv_pack_multi_body(const PackSegs& p, const in
 template <typename T> static size_t packed_elems(int KinK, int NoutS) {
   const int KC = conv_kc(KinK);
   const size_t one = (size_t)(KinK / KC) * conv_nsteps<T>(KC) * (NoutS / 16) * 64 * Chunk<T>::EPC;
+  if (sizeof(T) == 4) return f32_exact_elems(KinK, NoutS) + 3 * f32_split_plane_elems(KinK, NoutS) / 2;  // both f32 layouts
   return (sizeof(T) == 2 && conv_gemm_channels(KinK, NoutS)) ? 2 * one : one;
 }
 
@@ -444,6 +590,11 @@ bool conv_use_gemm(int CinK, int CoutS, int H, int W) {
   return g_gemm_mode == 1 || pick_tile(H, W).tw != 14;
 }
 
+// f32 storage: 1 (default) the split-bf16 k-loop, 0 the exact-f32 MFMA (v_mfma_f32_16x16x4_f32, 1/16 of the bf16 matrix rate);
+// the packed buffers carry both layouts, so the switch may change between any two launches (spcl_conv_set_f32_split)
+static int g_f32_split = 1;
+bool conv_f32_split() { return g_f32_split != 0; }
+
 template <typename T, int TH, int TW>
 static int launch_conv(const ConvArgs& a0, hipStream_t st) {
   ConvArgs a = a0;
@@ -452,7 +603,8 @@ static int launch_conv(const ConvArgs& a0, hipStream_t st) {
   const int ntn = a.CoutS / 16;
   const int KC = conv_kc(a.CinK);
   static const int env_lds_extra = lab_env("SPCL_CONV_LDS_EXTRA", 0);
-  const size_t lds = (size_t)(TH + 2) * (TW + 2) * conv_pstride<T>(KC) + env_lds_extra;
+  const bool split = sizeof(T) == 4 && g_f32_split != 0;
+  const size_t lds = (size_t)(TH + 2) * (TW + 2) * (split ? split_pstride(KC) : conv_pstride<T>(KC)) + env_lds_extra;
   const int tiles = a.N * a.tilesX * a.tilesY;
   static const int env_tpw = lab_env("SPCL_CONV_TPW", 0);
   a.tpw = env_tpw > 0 ? env_tpw : 1;
@@ -460,10 +612,26 @@ static int launch_conv(const ConvArgs& a0, hipStream_t st) {
   a.dbg = env_dbg;
   // waves per workgroup x n-tiles per wave
   int NT = ntn >= 2 ? 2 : 1;
+  // split k-loop: matrix-bound, and ONE wave per SIMD issues a 16x16x32 MFMA every ~23 cycles where two reach the pipe's 16
+  // (tools/experiments/mfmalab): two n-tiles per wave only where that still leaves four-wave workgroups, two per CU
+  if (split && !(ntn >= 8 && (long)tiles * cdiv(ntn, 8) >= 512)) NT = 1;
   int wn = cdiv(ntn, NT);
   if (wn > 4) wn = 4;
   const int gy = cdiv(ntn, NT * wn);
   dim3 grid(cdiv(tiles, a.tpw), gy), block(64 * wn);
+  if constexpr (sizeof(T) == 4) {
+    if (split) {
+      a.wp = (const float*)a.wp + f32_exact_elems(a.CinK, a.CoutS);
+      if (NT == 1) {
+        if (lds > 65536) spcl::func_lds_limit((const void*)conv3x3_mfma_kernel<T, TH, TW, 1, true>, (int)lds, "conv3x3_mfma_kernel<float, TH, TW, 1, split>");
+        SPCL_LAUNCH((conv3x3_mfma_kernel<T, TH, TW, 1, true>), grid, block, lds, st, a);
+      } else {
+        if (lds > 65536) spcl::func_lds_limit((const void*)conv3x3_mfma_kernel<T, TH, TW, 2, true>, (int)lds, "conv3x3_mfma_kernel<float, TH, TW, 2, split>");
+        SPCL_LAUNCH((conv3x3_mfma_kernel<T, TH, TW, 2, true>), grid, block, lds, st, a);
+      }
+      return 0;
+    }
+  }
   if (NT == 1) {
     if (lds > 65536) spcl::func_lds_limit((const void*)conv3x3_mfma_kernel<T, TH, TW, 1>, (int)lds, "conv3x3_mfma_kernel<T, TH, TW, 1>");
     SPCL_LAUNCH((conv3x3_mfma_kernel<T, TH, TW, 1>), grid, block, lds, st, a);
@@ -496,6 +664,9 @@ extern "C" int spcl_conv_num_tiles(int N, int H, int W) {
 }
 
 extern "C" void spcl_conv_set_gemm(int on) { conv_set_gemm(on); }
+
+extern "C" void spcl_conv_set_f32_split(int on) { g_f32_split = on != 0 ? 1 : 0; }
+extern "C" int spcl_conv_get_f32_split(void) { return g_f32_split; }
 
 extern "C" int spcl_conv_stat_rows(int dtype, int N, int H, int W, int CinK, int CoutS) {
   if (dtype == SPCL_BF16 && conv_use_gemm(CinK, CoutS, H, W)) return conv_gemm_stat_rows(N, H, W, CinK, CoutS);

@@ -70,6 +70,37 @@ struct ConvArgs {
   const struct BnAccFwd* in_bn = nullptr;  // in_mode 1: scale / shift derived from this block in the prologue (HOST pointer)
 };
 
+// f32 storage computed on the bf16 matrix rate (conv.hip "SPLIT", wgrad.hip Frag<split_f32>): the element type of tensors
+// whose values are multiplied as three bf16 pieces
+struct split_f32 { float v; };
+template <> struct Chunk<split_f32> { static constexpr int EPC = 4; };
+bool conv_f32_split();  // conv.hip: spcl_conv_set_f32_split
+
+typedef __attribute__((ext_vector_type(2))) float f32x2_;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2v_;
+struct Split3 { uint32_t hi, mid, lo; };  // packed bf16 pairs
+__device__ __forceinline__ Split3 split3_pair(float v0, float v1) {
+  Split3 o;
+  f32x2_ v = {v0, v1};
+  o.hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2v_));
+  v[0] -= __uint_as_float(o.hi << 16);
+  v[1] -= __uint_as_float(o.hi & 0xffff0000u);
+  o.mid = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2v_));
+  v[0] -= __uint_as_float(o.mid << 16);
+  v[1] -= __uint_as_float(o.mid & 0xffff0000u);
+  o.lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2v_));
+  return o;
+}
+// ... of the eight f32 values of two 16-byte chunks: one 16-byte chunk per plane
+__device__ __forceinline__ void split3_chunk(const float* e, u32x4& ph, u32x4& pm, u32x4& pl) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const Split3 o = split3_pair(e[2 * k], e[2 * k + 1]);
+    ph[k] = o.hi;
+    pm[k] = o.mid;
+    pl[k] = o.lo;
+  }
+}
 template <typename T> __device__ __forceinline__ f32x4 mfma_chunk(u32x4 w, u32x4 x, f32x4 acc);
 template <> __device__ __forceinline__ f32x4 mfma_chunk<bf16_t>(u32x4 w, u32x4 x, f32x4 acc) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0,

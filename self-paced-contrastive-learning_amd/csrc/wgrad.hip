@@ -53,6 +53,10 @@ template <> __device__ __forceinline__ u32x4 wg_bnrelu_chunk<bf16_t>(u32x4 raw, 
   return out;
 }
 
+template <> __device__ __forceinline__ u32x4 wg_bnrelu_chunk<split_f32>(u32x4 raw, const float* s, const float* b) {
+  return wg_bnrelu_chunk<float>(raw, s, b);
+}
+
 // Operand fragment of one k-step for a 16-channel tile, read transposed from a [row][pixel][channel] LDS image.
 //   bf16: k-step = 32 pixels = 2 tile rows x 16; lane group g = lane>>4 holds 8 of them (two hardware-transposed
 //         4-pixel reads): row 2ks + (g&1), columns 8(g>>1) .. +7.  The 32 lanes a ds_read_b64_tr_b16 services together
@@ -66,7 +70,8 @@ template <> struct Frag<bf16_t> {
   static __device__ __forceinline__ int lane_row(int lane) { return (lane >> 4) & 1; }  // + 2 ks
   static __device__ __forceinline__ int lane_col(int lane) { return 8 * (lane >> 5) + ((lane & 15) >> 2); }
   static __device__ __forceinline__ int lane_chan_bytes(int lane) { return (lane & 3) * 8; }
-  static __device__ __forceinline__ type load(unsigned a0, int off, int pix_bytes) {
+  static constexpr int LSZ = 2, PLANES = 1;  // bytes per element in LDS, images per operand
+  static __device__ __forceinline__ type load(unsigned a0, int off, int pix_bytes, int = 0) {
     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(uintptr_t)(a0 + off));
     s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
         (s16x4 __attribute__((address_space(3)))*)(uintptr_t)(a0 + off + 4 * pix_bytes));
@@ -87,13 +92,43 @@ template <> struct Frag<float> {
   static __device__ __forceinline__ int lane_row(int) { return 0; }
   static __device__ __forceinline__ int lane_col(int lane) { return lane >> 4; }  // + 4 (ks % 4)
   static __device__ __forceinline__ int lane_chan_bytes(int lane) { return (lane & 15) * 4; }
-  static __device__ __forceinline__ type load(unsigned a0, int off, int) {
+  static constexpr int LSZ = 4, PLANES = 1;
+  static __device__ __forceinline__ type load(unsigned a0, int off, int, int = 0) {
     return *(const float __attribute__((address_space(3)))*)(uintptr_t)(a0 + off);
   }
   static __device__ __forceinline__ f32x4 mfma(type a, type b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
   }
   static constexpr int row_pad(int, int) { return 0; }
+};
+
+// f32 tensors multiplied as three bf16 pieces (conv_common.hpp split3_pair; spcl_conv_set_f32_split): THREE bf16 images per
+// operand in LDS (hi / mid / lo, each laid out exactly as the bf16 path's one -- same transposed reads, same bank analysis),
+// filled by the staging from the f32 chunks; six bf16 MFMAs per fragment pair, the smallest products first.
+struct Frag3 { bf16x8 h, m, l; };
+template <> struct Frag<split_f32> {
+  typedef Frag3 type;
+  static constexpr int KPIX = 32, LSZ = 2, PLANES = 3;
+  static __device__ __forceinline__ int lane_row(int lane) { return Frag<bf16_t>::lane_row(lane); }
+  static __device__ __forceinline__ int lane_col(int lane) { return Frag<bf16_t>::lane_col(lane); }
+  static __device__ __forceinline__ int lane_chan_bytes(int lane) { return Frag<bf16_t>::lane_chan_bytes(lane); }
+  static __device__ __forceinline__ type load(unsigned a0, int off, int pix_bytes, int plane_bytes) {
+    type f;
+    f.h = Frag<bf16_t>::load(a0, off, pix_bytes);
+    f.m = Frag<bf16_t>::load(a0 + plane_bytes, off, pix_bytes);
+    f.l = Frag<bf16_t>::load(a0 + 2 * plane_bytes, off, pix_bytes);
+    return f;
+  }
+  static __device__ __forceinline__ f32x4 mfma(const type& a, const type& b, f32x4 c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.l, b.h, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.l, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b.m, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.m, b.h, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.m, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.h, b.h, c, 0, 0, 0);
+    return c;
+  }
+  static constexpr int row_pad(int pix_bytes, int row_bytes) { return Frag<bf16_t>::row_pad(pix_bytes, row_bytes); }
 };
 
 // NWV waves per workgroup: 4 for the 16/32-channel blocks; 8 for the 64x64 block (MI = NJ = 4), whose 36 (tap, ci-tile)
@@ -103,17 +138,28 @@ template <> struct Frag<float> {
 #ifndef SPCL_WGRAD_STAMPS_BUILD
 #define SPCL_WGRAD_STAMPS_BUILD 0
 #endif
+// four f32 values (one 16-byte chunk) -> 8 bytes in each of the three bf16 images
+__device__ __forceinline__ void store_split(unsigned char* p, int plane_bytes, u32x4 v) {
+  const Split3 a = split3_pair(__uint_as_float(v[0]), __uint_as_float(v[1]));
+  const Split3 b = split3_pair(__uint_as_float(v[2]), __uint_as_float(v[3]));
+  *(uint2*)p = make_uint2(a.hi, b.hi);
+  *(uint2*)(p + plane_bytes) = make_uint2(a.mid, b.mid);
+  *(uint2*)(p + 2 * plane_bytes) = make_uint2(a.lo, b.lo);
+}
+
 template <typename T, int MI, int NJ, int TH, int NWV, int IM>
 __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_wgrad_kernel(WgradArgs a) {
   constexpr int NTHR = 64 * NWV;
-  constexpr int EPC = Chunk<T>::EPC, ESZ = (int)sizeof(T);
+  constexpr int EPC = Chunk<T>::EPC;
+  constexpr int LSZ = Frag<T>::LSZ, NPL = Frag<T>::PLANES, LCH = EPC * LSZ;  // LDS: bytes per element, images, bytes per chunk
   constexpr int CIB = 16 * MI, COB = 16 * NJ;
-  constexpr int XS = CIB * ESZ, DS = COB * ESZ;          // LDS bytes per pixel
-  constexpr int XCP = CIB / EPC, DCP = COB / EPC;        // 16-byte chunks per pixel
+  constexpr int XS = CIB * LSZ, DS = COB * LSZ;          // LDS bytes per pixel
+  constexpr int XCP = CIB / EPC, DCP = COB / EPC;        // 16-byte (global) chunks per pixel
   constexpr int XRP = WG_HW * XS + Frag<T>::row_pad(XS, WG_HW * XS);  // LDS bytes per halo row / dy row
   constexpr int DRP = WG_TW * DS + Frag<T>::row_pad(DS, WG_TW * DS);
   constexpr int NHROWS = TH + 2;
-  constexpr int X_BYTES = NHROWS * XRP, D_BYTES = TH * DRP, BUF_BYTES = X_BYTES + D_BYTES;
+  constexpr int XPLB = NHROWS * XRP, DPLB = TH * DRP;    // bytes of one x / dy image
+  constexpr int X_BYTES = NPL * XPLB, D_BYTES = NPL * DPLB, BUF_BYTES = X_BYTES + D_BYTES;
   constexpr int KSTEPS = TH * WG_TW / Frag<T>::KPIX;
   // staging maps: a thread owns one 16-byte channel chunk and one column; it walks the rows in compile-time steps
   constexpr int XPL = NTHR / XCP, XRPI = XPL / WG_HW, NX = (NHROWS + XRPI - 1) / XRPI;   // rows per iteration
@@ -156,7 +202,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_wgrad_kernel(WgradArgs a)
     if (u >= NUNITS) u = NUNITS - 1;  // clamped duplicate: computed, never written
     const int tap = u / MI, m = u - tap * MI;
     const int ky = tap / 3, kx = tap - 3 * ky;
-    uoff[uu] = ky * XRP + kx * XS + m * 16 * ESZ;
+    uoff[uu] = ky * XRP + kx * XS + m * 16 * LSZ;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[uu][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
@@ -251,13 +297,18 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_wgrad_kernel(WgradArgs a)
         u32x4 v = rx[i];
         if (!(xmask & (1u << i))) v = (u32x4){0u, 0u, 0u, 0u};  // zero padding stays zero (also after BN + ReLU)
         else if (IM == 1 && bn_this) v = wg_bnrelu_chunk<T>(v, sc, sh);
-        *(u32x4*)(bx + hy * XRP + xhx * XS + xch * 16) = v;
+        if constexpr (NPL == 3) store_split(bx + hy * XRP + xhx * XS + xch * LCH, XPLB, v);
+        else *(u32x4*)(bx + hy * XRP + xhx * XS + xch * LCH) = v;
       }
     }
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
       const int r = dry0 + i * DRPI;
-      if (r < TH) *(u32x4*)(bd + r * DRP + dcol * DS + dch * 16) = (dmask & (1u << i)) ? rd[i] : (u32x4){0u, 0u, 0u, 0u};
+      if (r < TH) {
+        const u32x4 v = (dmask & (1u << i)) ? rd[i] : (u32x4){0u, 0u, 0u, 0u};
+        if constexpr (NPL == 3) store_split(bd + r * DRP + dcol * DS + dch * LCH, DPLB, v);
+        else *(u32x4*)(bd + r * DRP + dcol * DS + dch * LCH) = v;
+      }
     }
   };
 
@@ -265,21 +316,22 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_wgrad_kernel(WgradArgs a)
     const unsigned xa0 = lds_base + buf * BUF_BYTES + xlane, da0 = lds_base + buf * BUF_BYTES + X_BYTES + dlane;
     // operand fragments are fetched one (k-step, unit) ahead of the MFMAs that consume them, so an LDS read's
     // latency hides under the previous unit's matrix work instead of stalling every pair of MFMAs
-    auto kpos_x = [&](int ks) { return (sizeof(T) == 2 ? 2 * ks : ks / 4) * XRP + (sizeof(T) == 2 ? 0 : 4 * (ks % 4)) * XS; };
-    auto kpos_d = [&](int ks) { return (sizeof(T) == 2 ? 2 * ks : ks / 4) * DRP + (sizeof(T) == 2 ? 0 : 4 * (ks % 4)) * DS; };
+    constexpr bool K32 = Frag<T>::KPIX == 32;  // k-step = two rows of 16 pixels (else 4 pixels of one row)
+    auto kpos_x = [&](int ks) { return (K32 ? 2 * ks : ks / 4) * XRP + (K32 ? 0 : 4 * (ks % 4)) * XS; };
+    auto kpos_d = [&](int ks) { return (K32 ? 2 * ks : ks / 4) * DRP + (K32 ? 0 : 4 * (ks % 4)) * DS; };
     typename Frag<T>::type bf[NJ], bf_next[NJ], af, af_next;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) bf[j] = Frag<T>::load(da0, kpos_d(0) + j * 16 * ESZ, DS);
-    af = Frag<T>::load(xa0 + uoff[0], kpos_x(0), XS);
+    for (int j = 0; j < NJ; ++j) bf[j] = Frag<T>::load(da0, kpos_d(0) + j * 16 * LSZ, DS, DPLB);
+    af = Frag<T>::load(xa0 + uoff[0], kpos_x(0), XS, XPLB);
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
 #pragma unroll
       for (int uu = 0; uu < UPW; ++uu) {
-        if (uu + 1 < UPW) af_next = Frag<T>::load(xa0 + uoff[uu + 1], kpos_x(ks), XS);
+        if (uu + 1 < UPW) af_next = Frag<T>::load(xa0 + uoff[uu + 1], kpos_x(ks), XS, XPLB);
         else if (ks + 1 < KSTEPS) {
-          af_next = Frag<T>::load(xa0 + uoff[0], kpos_x(ks + 1), XS);
+          af_next = Frag<T>::load(xa0 + uoff[0], kpos_x(ks + 1), XS, XPLB);
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) bf_next[j] = Frag<T>::load(da0, kpos_d(ks + 1) + j * 16 * ESZ, DS);
+          for (int j = 0; j < NJ; ++j) bf_next[j] = Frag<T>::load(da0, kpos_d(ks + 1) + j * 16 * LSZ, DS, DPLB);
         }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[uu][j] = Frag<T>::mfma(af, bf[j], acc[uu][j]);
@@ -396,16 +448,21 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
   }
 }
 
-// LDS bytes of ONE tile image (x halo + dy), row pitches padded as in the kernel
+// LDS bytes of ONE tile image (x halo + dy), row pitches padded as in the kernel.  esize: 4 f32, 2 bf16, 6 f32 held as three
+// bf16 images (Frag<split_f32>)
 static size_t wgrad_lds_bytes(int MI, int NJ, int TH, int esize) {
+  const int planes = esize == 6 ? 3 : 1;
+  if (esize == 6) esize = 2;
   const int XS = 16 * MI * esize, DS = 16 * NJ * esize;
   const int xrp = WG_HW * XS + (esize == 2 ? Frag<bf16_t>::row_pad(XS, WG_HW * XS) : 0);
   const int drp = WG_TW * DS + (esize == 2 ? Frag<bf16_t>::row_pad(DS, WG_TW * DS) : 0);
-  return (size_t)(TH + 2) * xrp + (size_t)TH * drp;
+  return planes * ((size_t)(TH + 2) * xrp + (size_t)TH * drp);
 }
+template <typename T> constexpr int wgrad_esize() { return Frag<T>::PLANES == 3 ? 6 : (int)sizeof(T); }
 
 struct WgradPlan {
   int TH, MI, NJ, nblk_ci, nblk_co, nsplit, ntiles, tilesX, tilesY;
+  int dbuf;  // the tile image double buffered (where two fit the CU's LDS)
   size_t partial_floats;
 };
 static WgradPlan wgrad_plan(int N, int H, int W, int CinK, int CoutS, int esize) {
@@ -425,7 +482,8 @@ static WgradPlan wgrad_plan(int N, int H, int W, int CinK, int CoutS, int esize)
   // exactly one resident "wave" of workgroups (LDS-limited residency x 256 CUs): measured optimum -- more workgroups
   // only add partial slabs and a tail, fewer leave CUs idle (tools/bench_kernels.py wgrad sweeps)
   static const int plan_dbuf = lab_env("SPCL_WGRAD_DBUF", 1);
-  const size_t lds = (plan_dbuf ? 2 : 1) * wgrad_lds_bytes(p.MI, p.NJ, p.TH, esize);
+  p.dbuf = plan_dbuf && 2 * wgrad_lds_bytes(p.MI, p.NJ, p.TH, esize) <= 160 * 1024 ? 1 : 0;
+  const size_t lds = (p.dbuf ? 2 : 1) * wgrad_lds_bytes(p.MI, p.NJ, p.TH, esize);
   int per_cu = (int)((160 * 1024) / lds);
   if (per_cu > 4) per_cu = 4;
   if (per_cu < 1) per_cu = 1;
@@ -440,7 +498,7 @@ static WgradPlan wgrad_plan(int N, int H, int W, int CinK, int CoutS, int esize)
 
 template <typename T, int MI, int NJ, int TH, int NWV, int IM>
 static void launch_wgrad_im(const WgradArgs& a, const WgradPlan& p, hipStream_t st) {
-  const size_t lds = (a.dbuf ? 2 : 1) * wgrad_lds_bytes(MI, NJ, TH, (int)sizeof(T));
+  const size_t lds = (a.dbuf ? 2 : 1) * wgrad_lds_bytes(MI, NJ, TH, wgrad_esize<T>());
   if (lds > 65536)
     spcl::func_lds_limit((const void*)conv3x3_wgrad_kernel<T, MI, NJ, TH, NWV, IM>, (int)lds,
                          "conv3x3_wgrad_kernel<T, MI, NJ, TH, NWV, IM>");
@@ -504,9 +562,12 @@ static bool wide_item(spcl_wgrad_item& it, const void* x, const void* dy, int N,
 
 extern "C" size_t spcl_conv_wgrad_workspace_bytes(int N, int H, int W, int CinK, int CoutS) {
   if (N <= 0 || H <= 0 || W <= 0 || CinK <= 0 || CoutS <= 0 || CinK % 16 || CoutS % 16) return 0;
-  // sized for the f32 plan (its split count is >= the bf16 one) and for the wide-layer kernel
-  const size_t a = wgrad_plan(N, H, W, CinK, CoutS, 4).partial_floats, b = wgrad_plan(N, H, W, CinK, CoutS, 2).partial_floats;
-  size_t bytes = (a > b ? a : b) * sizeof(float);
+  // sized for the largest of the three plans (exact f32, bf16, split f32) and for the wide-layer kernel
+  size_t bytes = 0;
+  for (int esize : {4, 2, 6}) {
+    const size_t b = wgrad_plan(N, H, W, CinK, CoutS, esize).partial_floats * sizeof(float);
+    if (b > bytes) bytes = b;
+  }
   spcl_wgrad_item it;
   static float dummy;
   if (wide_item(it, &dummy, &dummy, N, H, W, CinK, CinK, CinK, CoutS, CoutS, 0, nullptr, nullptr, &dummy)) {
@@ -579,13 +640,14 @@ static int conv3x3_wgrad_impl(const void* x, const void* x2, const void* dy, int
       return spcl_conv3x3_wgrad_batched(&it, 1, 0, partial, stream);
     }
   }
-  WgradPlan p = wgrad_plan(N, H, W, CinK, CoutS, dtype == SPCL_F32 ? 4 : 2);
+  const bool split = dtype == SPCL_F32 && conv_f32_split();
+  WgradPlan p = wgrad_plan(N, H, W, CinK, CoutS, dtype == SPCL_F32 ? (split ? 6 : 4) : 2);
   WgradArgs a;
   a.x = x; a.x2 = x2; a.xsplit = x2 ? CinK / 2 : 0; a.x_up2 = x_up2 ? 1 : 0; a.dy = dy; a.in_scale = in_scale; a.in_shift = in_shift; a.partial = partial;
   a.N = N; a.H = H; a.W = W; a.CinS = CinS; a.CinK = CinK; a.CoutS = CoutS; a.in_mode = in_mode;
   a.tilesX = p.tilesX; a.tilesY = p.tilesY; a.ntiles = p.ntiles; a.nblk_ci = p.nblk_ci; a.nblk_co = p.nblk_co;
   static const int env_dbuf = lab_env("SPCL_WGRAD_DBUF", 1);
-  a.dbuf = env_dbuf;
+  a.dbuf = env_dbuf && p.dbuf;
   static const int env_remap = lab_env("SPCL_WGRAD_XCD_REMAP", 0);  // measured: +3..12 us per step, off
   a.xcd_remap = env_remap;
   static const int env_stamps = SPCL_WGRAD_STAMPS_BUILD ? lab_env("SPCL_WGRAD_STAMPS", 0) : 0;
@@ -601,7 +663,8 @@ static int conv3x3_wgrad_impl(const void* x, const void* x2, const void* dy, int
     prof_cost(px * ((in_mode == 2 ? CinS * 4.0 : CinK * es) + CoutS * es) + 9.0 * Cin * Cout * 4.0,
               2.0 * px * 9.0 * Cin * Cout);
   }
-  if (dtype == SPCL_F32) launch_wgrad_t<float>(a, p, st);
+  if (dtype == SPCL_F32 && split) launch_wgrad_t<split_f32>(a, p, st);
+  else if (dtype == SPCL_F32) launch_wgrad_t<float>(a, p, st);
   else if (dtype == SPCL_BF16) launch_wgrad_t<bf16_t>(a, p, st);
   else {
     set_error("conv3x3_wgrad: dtype %d", dtype);

@@ -101,6 +101,56 @@ def test_conv_gemm_dgrad_with_fused_bn_backward_sums(gemm_conv, N, C, H, W):
     _dgrad_bn_body(N, C, H, W)
 
 
+@pytest.fixture
+def exact_f32():
+    """f32 storage on v_mfma_f32_16x16x4_f32 (exact f32 products) instead of the default split-bf16 k-loop
+    (spcl_conv_set_f32_split: three bf16 pieces per operand, six bf16 MFMAs per product) -- both hold the f32 tolerance"""
+    n = _n()
+    assert n.call("spcl_conv_get_f32_split") == 1  # the default
+    n.call("spcl_conv_set_f32_split", 0)
+    yield n
+    n.call("spcl_conv_set_f32_split", 1)
+
+
+F32_SHAPES = [(2, 16, 16, 28, 28), (1, 32, 64, 20, 18), (2, 128, 64, 14, 14), (3, 8, 24, 33, 16), (1, 256, 256, 14, 14),
+              (1, 16, 16, 60, 44), (1, 64, 64, 64, 64), (1, 64, 192, 1, 1)]
+
+
+@pytest.mark.parametrize("N,ci,co,H,W", F32_SHAPES)
+def test_conv_f32_exact_path_forward_dgrad_wgrad(exact_f32, N, ci, co, H, W):
+    _fwd_body("f32", N, ci, co, H, W)
+    _dgrad_body("f32", N, ci, co, H, W)
+    _wgrad_body("f32", N, ci, co, H, W, 0)
+    _wgrad_body("f32", N, ci, co, H, W, 1)
+
+
+def test_conv_f32_exact_path_fused_input_and_image(exact_f32):
+    _fused_in_body("f32", 2, 32, 48, 28, 28)
+    _fused_in_body("f32", 1, 64, 64, 30, 17)
+    for ci in (1, 3):
+        _image_mode_body("f32", ci)
+
+
+@pytest.mark.parametrize("N,ci,co,H,W", [(2, 64, 64, 28, 28), (1, 16, 32, 42, 56)])
+def test_conv_f32_split_agrees_with_exact_far_inside_the_tolerance(N, ci, co, H, W):
+    """same inputs through both f32 k-loops: the split products drop terms below 2^-24 of a product, the two results differ
+    by a few f32 roundings of the accumulated sum -- an order of magnitude inside the 2e-5 both are held to"""
+    n = _n()
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, ci, H, W, generator=g)
+    w = torch.randn(co, ci, 3, 3, generator=g) / (3 * ci ** 0.5)
+    xs, wp = nhwc(x, torch.float32), pack(n, w, 0, torch.float32)
+    ys, _ = conv(n, xs, torch.float32, N, H, W, ci, ci, co, wp, 0)
+    n.call("spcl_conv_set_f32_split", 0)
+    try:
+        ye, _ = conv(n, xs, torch.float32, N, H, W, ci, ci, co, wp, 0)  # (the SAME packed buffer: it carries both layouts)
+    finally:
+        n.call("spcl_conv_set_f32_split", 1)
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1).permute(0, 2, 3, 1).cuda()
+    assert relerr(ys, ye) < 2e-6
+    assert relerr(ys, ref) < 2e-6 and relerr(ye, ref) < 2e-6
+
+
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("N,ci,co,H,W", SHAPES)
 def test_conv_forward_raw_and_stats(dt, N, ci, co, H, W):
@@ -156,6 +206,10 @@ def _fused_in_body(dt, N, ci, co, H, W):
 @pytest.mark.parametrize("dt", ["f32", "bf16"])
 @pytest.mark.parametrize("ci", [1, 2, 3])
 def test_conv_forward_image_mode(dt, ci):
+    _image_mode_body(dt, ci)
+
+
+def _image_mode_body(dt, ci):
     n = _n()
     dtype = DT[dt]
     N, co, H, W = 2, 16, 28, 42
@@ -192,6 +246,10 @@ def _dgrad_body(dt, N, ci, co, H, W):
 @pytest.mark.parametrize("N,ci,co,H,W", SHAPES + [(4, 16, 16, 56, 56)])
 @pytest.mark.parametrize("mode", [0, 1])
 def test_conv_wgrad(dt, N, ci, co, H, W, mode):
+    _wgrad_body(dt, N, ci, co, H, W, mode)
+
+
+def _wgrad_body(dt, N, ci, co, H, W, mode):
     n = _n()
     dtype = DT[dt]
     g = torch.Generator().manual_seed(ci * 7 + co + H)
