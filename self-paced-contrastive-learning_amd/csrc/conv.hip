@@ -120,29 +120,58 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
       const int dgoff = (dhy * a.W + dhx) * a.CinS, wrapg = (a.W - HW_) * a.CinS;
       unsigned char* lp = lds + sq0 * PSTRIDE + sch * 16;
       const int dlp = QS * PSTRIDE;
+      if constexpr (SPLIT) {
+        // four halo elements per trip, their loads UNCONDITIONAL (a pixel outside the image reads the clamped one and is
+        // zeroed afterwards) and issued before the first is used: one element per trip behind `if (inb)` was one exposed
+        // round trip to memory per element -- the narrow layers' workgroups are ONE wave, nothing else covers it
+        constexpr int U = 4;
+        const float* xin = (const float*)a.x + (long)n * a.H * a.W * a.CinS + slab * KC + sch * EPC;
+        for (int q = sq0; q < NHALO; q += U * QS) {
+          u32x4 v0[U], v1[U];
+          bool ok[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+            ok[u] = q + u * QS < NHALO && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            const int cy = min(max(gy, 0), a.H - 1), cx = min(max(gx, 0), a.W - 1);
+            const float* src = xin + (cy * a.W + cx) * a.CinS;
+            v0[u] = *(const u32x4*)src;
+            v1[u] = *(const u32x4*)(src + 4);
+            hx += dhx;
+            hy += dhy;
+            if (hx >= HW_) {
+              hx -= HW_;
+              hy += 1;
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            if (a.in_mode == 1) {
+              v0[u] = bnrelu_regs<float>(v0[u], ssc, ssh);
+              v1[u] = bnrelu_regs<float>(v1[u], ssc + 4, ssh + 4);
+            }
+            float e[8];
+            *(f32x4*)&e[0] = __builtin_bit_cast(f32x4, v0[u]);
+            *(f32x4*)&e[4] = __builtin_bit_cast(f32x4, v1[u]);
+            u32x4 ph, pm, pl;
+            split3_chunk(e, ph, pm, pl);
+            if (!ok[u]) ph = pm = pl = (u32x4){0u, 0u, 0u, 0u};
+            if (q + u * QS < NHALO) {
+              *(u32x4*)lp = ph;
+              *(u32x4*)(lp + PLANE) = pm;
+              *(u32x4*)(lp + 2 * PLANE) = pl;
+            }
+            lp += dlp;
+          }
+        }
+      } else
       for (int q = sq0; q < NHALO; q += QS) {
         bool inb = true;
         if (!interior) {
           const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
           inb = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
         }
-        if constexpr (SPLIT) {
-          u32x4 ph = {0u, 0u, 0u, 0u}, pm = ph, pl = ph;
-          if (inb) {
-            u32x4 v0 = *(const u32x4*)(xb + goff), v1 = *(const u32x4*)(xb + goff + 4);
-            if (a.in_mode == 1) {
-              v0 = bnrelu_regs<float>(v0, ssc, ssh);
-              v1 = bnrelu_regs<float>(v1, ssc + 4, ssh + 4);
-            }
-            float e[8];
-            *(f32x4*)&e[0] = __builtin_bit_cast(f32x4, v0);
-            *(f32x4*)&e[4] = __builtin_bit_cast(f32x4, v1);
-            split3_chunk(e, ph, pm, pl);
-          }
-          *(u32x4*)lp = ph;
-          *(u32x4*)(lp + PLANE) = pm;
-          *(u32x4*)(lp + 2 * PLANE) = pl;
-        } else {
+        {
           u32x4 v = {0u, 0u, 0u, 0u};
           if (inb && !(a.dbg & 16)) {
             v = *(const u32x4*)(xb + goff);
@@ -160,12 +189,51 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
           goff += wrapg;
         }
       }
+    } else if constexpr (SPLIT) {
+      // the image convolution (CinS <= 16 real channels): four elements per trip, unconditional clamped loads as above
+      constexpr int U = 4;
+      const float* xin = (const float*)a.x + (size_t)n * a.H * a.W * a.CinS;
+      for (int idx0 = threadIdx.x; idx0 < NHALO * CP; idx0 += U * (int)blockDim.x) {
+        float e[U][EPC];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int idx = idx0 + u * (int)blockDim.x;
+          const int q = idx >> log2cp, ch = idx & (CP - 1);
+          const int hy = q / HW_, hx = q - hy * HW_;
+          const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+          ok[u] = idx < NHALO * CP && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+          const float* src = xin + (min(max(gy, 0), a.H - 1) * a.W + min(max(gx, 0), a.W - 1)) * a.CinS;
+#pragma unroll
+          for (int k = 0; k < EPC; ++k) {
+            e[u][k] = 0.f;
+            if (k < a.CinS) {  // (uniform)
+              const int c = ch * EPC + k;
+              const float v = src[min(c, a.CinS - 1)];
+              e[u][k] = c < a.CinS ? v : 0.f;
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int idx = idx0 + u * (int)blockDim.x;
+          const int q = idx >> log2cp, ch = idx & (CP - 1);
+          u32x4 ph, pm, pl;
+          split3_chunk(e[u], ph, pm, pl);
+          if (!ok[u]) ph = pm = pl = (u32x4){0u, 0u, 0u, 0u};
+          if (idx < NHALO * CP) {
+            *(u32x4*)(lds + q * PSTRIDE + ch * 16) = ph;
+            *(u32x4*)(lds + q * PSTRIDE + ch * 16 + PLANE) = pm;
+            *(u32x4*)(lds + q * PSTRIDE + ch * 16 + 2 * PLANE) = pl;
+          }
+        }
+      }
     } else {
       for (int idx = threadIdx.x; idx < NHALO * CP; idx += blockDim.x) {
         const int q = idx >> log2cp, ch = idx & (CP - 1);
         const int hy = q / HW_, hx = q - hy * HW_;
         const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-        u32x4 v = {0u, 0u, 0u, 0u}, pm = v, pl = v;  // (pm, pl: the SPLIT planes)
+        u32x4 v = {0u, 0u, 0u, 0u};
         if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
           const float* src = (const float*)a.x + (((size_t)n * a.H + gy) * a.W + gx) * a.CinS;
           float e[EPC];
@@ -174,9 +242,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
             const int c = ch * EPC + k;
             e[k] = c < a.CinS ? src[c] : 0.f;
           }
-          if constexpr (SPLIT) {
-            split3_chunk(e, v, pm, pl);
-          } else if (sizeof(T) == 4) {
+          if (sizeof(T) == 4) {
             v = (u32x4){__float_as_uint(e[0]), __float_as_uint(e[1]), __float_as_uint(e[2]), __float_as_uint(e[3])};
           } else {
 #pragma unroll
@@ -185,10 +251,6 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
           }
         }
         *(u32x4*)(lds + q * PSTRIDE + ch * 16) = v;
-        if constexpr (SPLIT) {
-          *(u32x4*)(lds + q * PSTRIDE + ch * 16 + PLANE) = pm;
-          *(u32x4*)(lds + q * PSTRIDE + ch * 16 + 2 * PLANE) = pl;
-        }
       }
     }
     __syncthreads();
@@ -351,6 +413,104 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
     }
   }
   }  // tiles of this workgroup
+}
+
+// The image convolution in f32 storage (unet.py:123, input_dim <= 4 -> 16 channels) as a DIRECT convolution on the vector
+// ALU: K = 9 CinS, so the matrix kernels above spent 16 x 9 k-values (and, split, six products each) on at most 36 real ones
+// and a one-wave workgroup's staging + k-loop + epilogue chain was 135 us at 64 x 224^2 for a 13 MB read and a 206 MB write.
+// Exact f32 FMAs.  One wave per pixel tile, the accumulator layout of the matrix kernels (lane = (pixel 16 i + r16, output
+// channels 4 g .. 4 g + 3)): same stores, same statistics rows.  Weights from the exact-f32 half of the packed buffer
+// (pack_value: W[co][ci][tap] of ci < 4 sits at packed[(tap * 64 + co) * 4 + ci] when CinK == CoutS == 16).
+template <int TH, int TW>
+__global__ __launch_bounds__(64) void conv3x3_image_f32_kernel(ConvArgs a) {
+  constexpr int NPIX = TH * TW, MT = (NPIX + 15) / 16, HW_ = TW + 2, NHALO = (TH + 2) * HW_;
+  __shared__ float halo[4][NHALO];
+  const int lane = threadIdx.x, r16 = lane & 15, g = lane >> 4;
+  const int tpi = a.tilesX * a.tilesY;
+  const int tile = blockIdx.x;
+  const int n = tile / tpi;
+  const int trem = tile - n * tpi;
+  const int ty = trem / a.tilesX, tx = trem - ty * a.tilesX;
+  const int y0 = ty * TH, x0 = tx * TW;
+  // ---- halo: unconditional clamped loads, all in flight before the first is used
+  {
+    const float* xin = (const float*)a.x + (size_t)n * a.H * a.W * a.CinS;
+    constexpr int NQ = (NHALO + 63) / 64;
+    for (int c = 0; c < a.CinS; ++c) {
+      float v[NQ];
+#pragma unroll
+      for (int k = 0; k < NQ; ++k) {
+        const int q = lane + 64 * k;
+        const int hy = q / HW_, hx = q - hy * HW_;
+        const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+        const float t = xin[(min(max(gy, 0), a.H - 1) * a.W + min(max(gx, 0), a.W - 1)) * a.CinS + c];
+        v[k] = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? t : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < NQ; ++k)
+        if (lane + 64 * k < NHALO) halo[c][lane + 64 * k] = v[k];
+    }
+  }
+  __syncthreads();
+  f32x4 acc[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int hb[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    int p = 16 * i + r16;
+    if (p >= NPIX) p = 0;
+    const int py = p / TW, px = p - py * TW;
+    hb[i] = py * HW_ + px;
+  }
+  const float* wp = (const float*)a.wp;
+  for (int c = 0; c < a.CinS; ++c) {
+    float w[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w[t][r] = wp[(t * 64 + 4 * g + r) * 4 + c];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float xv = halo[c][hb[i] + (t / 3) * HW_ + (t % 3)];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][r] = fmaf(w[t][r], xv, acc[i][r]);
+      }
+    }
+  }
+  // ---- epilogue: the matrix kernels' (stores + Chan partials of the tile)
+  constexpr int DPY = 16 / TW, DPX = 16 % TW;
+  const bool full_tile = y0 + TH <= a.H && x0 + TW <= a.W;
+  int py = r16 / TW, px = r16 - py * TW;
+  const int rowb = a.CoutS * 4;
+  int ob = (py * a.W + px) * rowb + 4 * g * 4;
+  const int dob = (DPY * a.W + DPX) * rowb, wrapo = (a.W - TW) * rowb;
+  unsigned char* yb = (unsigned char*)a.y + (((size_t)n * a.H + y0) * a.W + x0) * rowb;
+  f32x4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = ssum;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    bool ok = (16 * i + 15 < NPIX) || (16 * i + r16 < NPIX);
+    if (!full_tile) ok = ok && (y0 + py) < a.H && (x0 + px) < a.W;
+    if (ok) {
+      *(f32x4*)(yb + ob) = acc[i];
+      ssum += acc[i];
+      ssq += acc[i] * acc[i];
+    }
+    px += DPX;
+    py += DPY;
+    ob += dob;
+    if (px >= TW) {
+      px -= TW;
+      py += 1;
+      ob += wrapo;
+    }
+  }
+  if (a.stats != nullptr) {
+    const int vh = min(TH, a.H - y0), vw = min(TW, a.W - x0);
+    write_tile_stats(a.stats, tile, a.CoutS, 4 * g, r16, (float)(vh * vw), ssum, ssq);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------- weight packing
@@ -620,6 +780,10 @@ static int launch_conv(const ConvArgs& a0, hipStream_t st) {
   const int gy = cdiv(ntn, NT * wn);
   dim3 grid(cdiv(tiles, a.tpw), gy), block(64 * wn);
   if constexpr (sizeof(T) == 4) {
+    if (a.in_mode == 2 && a.CinS <= 4 && a.CinK == 16 && a.CoutS == 16) {  // (either f32 mode: exact FMAs)
+      SPCL_LAUNCH((conv3x3_image_f32_kernel<TH, TW>), dim3(tiles), dim3(64), 0, st, a);
+      return 0;
+    }
     if (split) {
       a.wp = (const float*)a.wp + f32_exact_elems(a.CinK, a.CoutS);
       if (NT == 1) {

@@ -317,6 +317,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_wgrad_kernel(WgradArgs a)
     // operand fragments are fetched one (k-step, unit) ahead of the MFMAs that consume them, so an LDS read's
     // latency hides under the previous unit's matrix work instead of stalling every pair of MFMAs
     constexpr bool K32 = Frag<T>::KPIX == 32;  // k-step = two rows of 16 pixels (else 4 pixels of one row)
+    constexpr bool SKIP_DUP = Frag<T>::PLANES == 3 && NUNITS % NWV != 0;
+    const bool last_real = wave + NWV * (UPW - 1) < NUNITS;  // wave-uniform: the wave's last unit exists
     auto kpos_x = [&](int ks) { return (K32 ? 2 * ks : ks / 4) * XRP + (K32 ? 0 : 4 * (ks % 4)) * XS; };
     auto kpos_d = [&](int ks) { return (K32 ? 2 * ks : ks / 4) * DRP + (K32 ? 0 : 4 * (ks % 4)) * DS; };
     typename Frag<T>::type bf[NJ], bf_next[NJ], af, af_next;
@@ -333,8 +335,12 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_wgrad_kernel(WgradArgs a)
 #pragma unroll
           for (int j = 0; j < NJ; ++j) bf_next[j] = Frag<T>::load(da0, kpos_d(ks + 1) + j * 16 * LSZ, DS, DPLB);
         }
+        // (the clamped duplicate unit of the waves that own one unit less: six MFMAs per fragment pair are worth a scalar
+        // branch -- 8 waves on 18 units computed 24)
+        if (!(SKIP_DUP && uu == UPW - 1 && !last_real)) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[uu][j] = Frag<T>::mfma(af, bf[j], acc[uu][j]);
+          for (int j = 0; j < NJ; ++j) acc[uu][j] = Frag<T>::mfma(af, bf[j], acc[uu][j]);
+        }
         af = af_next;
       }
 #pragma unroll
@@ -475,6 +481,11 @@ static WgradPlan wgrad_plan(int N, int H, int W, int CinK, int CoutS, int esize)
   // 14-row tiles when the height divides by 14 but not by 16 (56 / 28 / 14: 12.5 % padded pixels instead of 23 %)
   static const int env_th = lab_env("SPCL_WGRAD_TH", 0);
   p.TH = env_th ? env_th : ((H % 16 != 0 && H % 14 == 0) ? 14 : 16);
+  // three-image tiles (esize 6) of the 16-channel-sided blocks: 8 rows, single buffered -- three or four workgroups per CU
+  // instead of one (same box: 16 -> 16 at 224^2 186 -> 118 us, 16 -> 32 at 112^2 75 -> 53; the 32 x 32 blocks measured
+  // no better on 8 rows, buffered either way)
+  const bool narrow3 = esize == 6 && p.MI * p.NJ < 4 && H >= 8 && !env_th;
+  if (narrow3) p.TH = 8;
   p.tilesX = cdiv(W, WG_TW);
   p.tilesY = cdiv(H, p.TH);
   p.ntiles = N * p.tilesX * p.tilesY;
@@ -482,7 +493,7 @@ static WgradPlan wgrad_plan(int N, int H, int W, int CinK, int CoutS, int esize)
   // exactly one resident "wave" of workgroups (LDS-limited residency x 256 CUs): measured optimum -- more workgroups
   // only add partial slabs and a tail, fewer leave CUs idle (tools/bench_kernels.py wgrad sweeps)
   static const int plan_dbuf = lab_env("SPCL_WGRAD_DBUF", 1);
-  p.dbuf = plan_dbuf && 2 * wgrad_lds_bytes(p.MI, p.NJ, p.TH, esize) <= 160 * 1024 ? 1 : 0;
+  p.dbuf = plan_dbuf && !narrow3 && 2 * wgrad_lds_bytes(p.MI, p.NJ, p.TH, esize) <= 160 * 1024 ? 1 : 0;
   const size_t lds = (p.dbuf ? 2 : 1) * wgrad_lds_bytes(p.MI, p.NJ, p.TH, esize);
   int per_cu = (int)((160 * 1024) / lds);
   if (per_cu > 4) per_cu = 4;
@@ -529,6 +540,9 @@ static void launch_wgrad_th(const WgradArgs& a, const WgradPlan& p, hipStream_t 
 
 template <typename T>
 static void launch_wgrad_t(const WgradArgs& a, const WgradPlan& p, hipStream_t st) {
+  if constexpr (Frag<T>::PLANES == 3) {  // (the three-image tiles: 8 rows, so that two workgroups or two buffers fit a CU)
+    if (p.TH == 8) return launch_wgrad_th<T, 8>(a, p, st);
+  }
   if (p.TH == 14) launch_wgrad_th<T, 14>(a, p, st);
   else launch_wgrad_th<T, 16>(a, p, st);
 }
