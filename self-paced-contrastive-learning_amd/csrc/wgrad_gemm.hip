@@ -477,6 +477,26 @@ __device__ __forceinline__ void wb_tail_unit(const WbTails& tl, int unit, int ac
         *dst = accumulate ? *dst + v : v;
       }
     }
+  } else if (t.kind == 2) {
+    const int slab = 9 * t.CIB * t.COB, per = slab / 2304;
+    const int blk = u / per;
+    const int inner0 = (u - blk * per) * 2304 + 4 * (int)threadIdx.x;
+    const size_t stride = (size_t)t.nblk_ci * t.nblk_co * slab;
+    const float* src = t.partial + (size_t)blk * slab + inner0;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int p = 0; p < t.nsplit; ++p) s += *(const f32x4*)(src + (size_t)p * stride);
+    const int bci = blk / t.nblk_co, bco = blk - bci * t.nblk_co;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int inner = inner0 + e;
+      const int co_l = inner % t.COB, ci_l = (inner / t.COB) % t.CIB, tap = inner / (t.COB * t.CIB);
+      const int ci = bci * t.CIB + ci_l, co = bco * t.COB + co_l;
+      if (ci < t.Cin && co < t.Cout) {
+        float* dst = t.dw + ((size_t)co * t.Cin + ci) * 9 + tap;
+        *dst = accumulate ? *dst + s[e] : s[e];
+      }
+    }
   } else {
     const int CS = t.COB, RL = 576 / CS;  // CS <= 256: at least two row lanes
     const int c = threadIdx.x % CS, rl = threadIdx.x / CS;
@@ -689,8 +709,13 @@ extern "C" int spcl_conv3x3_wgrad_batched_tails(const spcl_wgrad_item* items, in
     t.partial = tails[i].partial; t.dw = tails[i].dw; t.kind = tails[i].kind; t.nsplit = tails[i].nsplit;
     t.nblk_ci = tails[i].nblk_ci; t.nblk_co = tails[i].nblk_co; t.CIB = tails[i].CIB; t.COB = tails[i].COB;
     t.Cin = tails[i].Cin; t.Cout = tails[i].Cout;
+    // few splits (the many-block layers: f32 storage sends every layer here): a unit of 64 outputs kept one quarter-wave of
+    // its nine waves busy and the launch was 18 000 workgroups of a few loads each (87 us for 70 MB); kind 2: 2 304 outputs
+    // per unit, one 16-byte column per thread, no LDS
+    if (t.kind == 0 && t.nsplit <= 16 && (9 * t.CIB * t.COB) % 2304 == 0) t.kind = 2;
     t.u0 = tail_units;
-    tail_units += t.kind == 0 ? t.nblk_ci * t.nblk_co * (9 * t.CIB * t.COB / 64) : 9;
+    tail_units += t.kind == 0 ? t.nblk_ci * t.nblk_co * (9 * t.CIB * t.COB / 64)
+                              : (t.kind == 2 ? t.nblk_ci * t.nblk_co * (9 * t.CIB * t.COB / 2304) : 9);
   }
   tl.n = ntails;
   hipStream_t st = (hipStream_t)stream;
