@@ -767,7 +767,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             print(f"[bench] contrastive extra failed: {type(e).__name__}: {e}", file=sys.stderr)
     if rank == 0 and world == 1 and not args.no_extras and args.dtype == "bf16" and args.workload == "pretrain":
-        try:  # the reference's own arithmetic end to end (fp32 storage, exact-f32 MFMA): a short pass of the same step
+        try:  # the reference's own storage type end to end (fp32 tensors, split-bf16 products): a short pass of the same step
             line.setdefault("extra", {})["fp32_step"] = fp32_numbers(args, device)
         except Exception as e:  # noqa: BLE001
             print(f"[bench] fp32 extra failed: {type(e).__name__}: {e}", file=sys.stderr)
@@ -787,9 +787,17 @@ def main():
         dist.destroy_process_group()
 
 
+def _f32_split():
+    import spcl_amd  # noqa: F401
+    from spcl_amd import native
+    return native.call("spcl_conv_get_f32_split")
+
+
 def fp32_numbers(args, device, steps=12, warmup=4):
-    """`--dtype fp32` in short: the same pre-train step with fp32 storage and the exact-f32 MFMA path (the parity mode, the
-    reference's own arithmetic), through the same epocher and its hipGraph, fresh batches per step."""
+    """`--dtype fp32` in short: the same pre-train step with fp32 storage (the parity mode: torch's default float32, as the
+    reference runs), through the same epocher and its hipGraph, fresh batches per step.  The convolutions multiply every f32
+    operand as three bf16 pieces (six bf16 MFMAs per product, f32-grade: spcl_conv_set_f32_split, include/spcl_hip.h); the
+    exact-f32 MFMA (1/16 of the bf16 matrix rate) stays one call away."""
     import copy
     a = copy.copy(args)
     a.dtype = "fp32"
@@ -809,7 +817,10 @@ def fp32_numbers(args, device, steps=12, warmup=4):
     sg = epocher._step_graph
     out = {"ms_per_step": round(dt * 1e3, 4), "slices_s": round(a.bs / dt, 1), "steps": steps,
            "hipgraph": bool(sg is not None and sg.captured), "dtype": "fp32",
-           "note": "same workload, fp32 storage + v_mfma_f32_16x16x4_f32 (exact f32, 1/16 of the bf16 matrix rate)"}
+           "f32_split": int(_f32_split()),
+           "note": "same workload, fp32 storage; convolutions multiply f32 operands as three bf16 pieces (six "
+                   "v_mfma_f32_16x16x32_bf16 per product, dropped terms < 2^-24: f32-grade, tests hold the f32 tolerances); "
+                   "f32_split 0 = v_mfma_f32_16x16x4_f32 (exact f32 products, 1/16 of the bf16 matrix rate)"}
     from spcl_amd import stepgraph as _sg
     _sg.gc_release()
     del step, epocher

@@ -146,17 +146,17 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
           }
 #pragma unroll
           for (int u = 0; u < U; ++u) {
-            if (a.in_mode == 1) {
-              v0[u] = bnrelu_regs<float>(v0[u], ssc, ssh);
-              v1[u] = bnrelu_regs<float>(v1[u], ssc + 4, ssh + 4);
-            }
-            float e[8];
-            *(f32x4*)&e[0] = __builtin_bit_cast(f32x4, v0[u]);
-            *(f32x4*)&e[4] = __builtin_bit_cast(f32x4, v1[u]);
-            u32x4 ph, pm, pl;
-            split3_chunk(e, ph, pm, pl);
-            if (!ok[u]) ph = pm = pl = (u32x4){0u, 0u, 0u, 0u};
-            if (q + u * QS < NHALO) {
+            if (q + u * QS < NHALO) {  // (the last trip is mostly past the end: whole waves skip the ~90 instructions)
+              if (a.in_mode == 1) {
+                v0[u] = bnrelu_regs<float>(v0[u], ssc, ssh);
+                v1[u] = bnrelu_regs<float>(v1[u], ssc + 4, ssh + 4);
+              }
+              float e[8];
+              *(f32x4*)&e[0] = __builtin_bit_cast(f32x4, v0[u]);
+              *(f32x4*)&e[4] = __builtin_bit_cast(f32x4, v1[u]);
+              u32x4 ph, pm, pl;
+              split3_chunk(e, ph, pm, pl);
+              if (!ok[u]) ph = pm = pl = (u32x4){0u, 0u, 0u, 0u};
               *(u32x4*)lp = ph;
               *(u32x4*)(lp + PLANE) = pm;
               *(u32x4*)(lp + 2 * PLANE) = pl;
