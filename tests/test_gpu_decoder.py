@@ -10,6 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import spcl_oracle as O
+from tests._stability import oracle_sensitivity
 
 
 def _unet(dtype=torch.float32):
@@ -256,9 +257,22 @@ def test_upsample2x_and_concat_match_torch(dt, N, C, H, W):
         assert torch.equal(a_d.grad.cpu(), r2[:, :C]) and torch.equal(b_d.grad.cpu(), r2[:, C:])
 
 
-def test_full_unet_base_width_vs_oracle_fp32():
+@pytest.mark.parametrize("f32_products", ["exact", "split"])
+def test_full_unet_base_width_vs_oracle_fp32(f32_products):
     """max_channel=256 (all channel counts multiples of 16: HIP concatenation / upsample path) on a small image: logits
-    and a sample of gradients against the CPU oracle's full UNet."""
+    and a sample of gradients against the CPU oracle's full UNet.  ``exact``: the f32 convolutions on the exact-f32 MFMA;
+    ``split`` (the default): gradients to the oracle's own sensitivity to fp32 rounding noise where that is larger than the
+    bar (tests/_stability.py)."""
+    import spcl_amd  # noqa
+    from spcl_amd import native as _nat
+    _nat.call("spcl_conv_set_f32_split", 1 if f32_products == "split" else 0)
+    try:
+        _full_unet_base_width_body(f32_products)
+    finally:
+        _nat.call("spcl_conv_set_f32_split", 1)
+
+
+def _full_unet_base_width_body(f32_products):
     import spcl_amd  # noqa
     from spcl_amd import functional as F
     from spcl_amd.semi_seg.arch import UNet
@@ -270,22 +284,31 @@ def test_full_unet_base_width_vs_oracle_fp32():
     g = torch.Generator().manual_seed(6)
     x = torch.rand(2, 1, 64, 64, generator=g)  # 4x4 at Conv5: batch statistics over 32 values per channel
     labels = torch.randint(0, 4, (2, 64, 64), generator=g)
-    sdo = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
-           for k, v in sd.items()}
-    ref_logits = O.unet_forward(x, sdo, None, train=True)
-    ref_loss = O.finetune_loss(ref_logits, labels)
-    ref_loss.backward()
+    keys = ("_Deconv_1x1.weight", "_Up_conv2.conv.0.weight", "_Up2.up.1.weight", "_Up_conv5.conv.3.weight",
+            "_Up5.up.2.weight", "_Conv5.conv.0.weight", "_Conv1.conv.0.weight", "_Conv3.conv.4.bias")
+
+    def oracle(x_):
+        sdo_ = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+                for k, v in sd.items()}
+        ref_logits_ = O.unet_forward(x_, sdo_, None, train=True)
+        ref_loss_ = O.finetune_loss(ref_logits_, labels)
+        ref_loss_.backward()
+        return ref_logits_, ref_loss_, sdo_
+
+    ref_logits, ref_loss, sdo = oracle(x)
+    slack = 0.0
+    if f32_products == "split":
+        slack = 3.0 * oracle_sensitivity((x,), lambda x_: {k: oracle(x_)[2][k].grad.numpy() for k in keys})
     logits = m(x.cuda())
     assert _relerr(logits.detach().cpu().numpy(), ref_logits.detach().numpy()) < 2e-3
     loss = F.kl_div(F.softmax_classes(logits), F.one_hot_classes(labels.cuda(), 4))
     assert abs(float(loss.detach()) - float(ref_loss.detach())) < 1e-3 * abs(float(ref_loss.detach()))
     loss.backward()
     params = dict(m.named_parameters())
-    for k in ("_Deconv_1x1.weight", "_Up_conv2.conv.0.weight", "_Up2.up.1.weight", "_Up_conv5.conv.3.weight",
-              "_Up5.up.2.weight", "_Conv5.conv.0.weight", "_Conv1.conv.0.weight", "_Conv3.conv.4.bias"):
+    for k in keys:
         # tiny batch statistics in the deepest layers amplify fp32 summation-order differences: 3e-2 of max
-        assert _relerr(params[k].grad.cpu().numpy(), sdo[k].grad.numpy()) < 3e-2, (k, _relerr(
-            params[k].grad.cpu().numpy(), sdo[k].grad.numpy()))
+        assert _relerr(params[k].grad.cpu().numpy(), sdo[k].grad.numpy()) < max(3e-2, slack), (k, _relerr(
+            params[k].grad.cpu().numpy(), sdo[k].grad.numpy()), slack)
 
 
 @pytest.mark.parametrize("N,S", [(2, 224), (3, 112), (2, 128), (1, 256)])

@@ -9,6 +9,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import spcl_oracle as O
+from tests._stability import oracle_sensitivity
 from tests.test_oracle_golden import labels_of
 
 
@@ -112,10 +113,23 @@ def test_adaptive_pool_vs_oracle_bf16_and_f32(mode, shape, out):
         np.testing.assert_allclose(xg.grad.float().cpu().numpy(), xr.grad.numpy(), rtol=tol, atol=tol)
 
 
-def test_dense_infonce_hook_step_vs_oracle_fp32():
+@pytest.mark.parametrize("f32_products", ["exact", "split"])
+def test_dense_infonce_hook_step_vs_oracle_fp32(f32_products):
     """INFONCEHook on a decoder feature (Up_conv3): encoder + decoder forward, dense head, 5 points per slice drawn under
     FixRandomSeed, SupConLoss1 with every point its own class -- loss and the decoder / head gradients against the oracle
-    (the encoder is frozen, as main_pretrain_decoder.py:66-69 arranges)."""
+    (the encoder is frozen, as main_pretrain_decoder.py:66-69 arranges).  ``exact``: the f32 convolutions on the exact-f32
+    MFMA, gradients to 5e-3; ``split`` (the default mode, three bf16 pieces per operand): to the oracle's own sensitivity to
+    fp32 rounding noise where that is larger (tests/_stability.py: ReLU / max-pool decisions at a tie)."""
+    import spcl_amd  # noqa
+    from spcl_amd import native as _nat
+    _nat.call("spcl_conv_set_f32_split", 1 if f32_products == "split" else 0)
+    try:
+        _dense_infonce_hook_step_body(f32_products)
+    finally:
+        _nat.call("spcl_conv_set_f32_split", 1)
+
+
+def _dense_infonce_hook_step_body(f32_products):
     import spcl_amd  # noqa
     from spcl_amd import ddp
     from spcl_amd.semi_seg.arch import UNet
@@ -149,27 +163,39 @@ def test_dense_infonce_hook_step_vs_oracle_fp32():
             with ep.meters.focus_on(ep.meter_focus):
                 loss = ep.step_compute(batch, seed=seed)
     # ---- oracle
-    flips = O.random_flip_decisions(seed, bs)
-    x2 = O.apply_flips(img_tf, flips)
-    osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
-           for k, v in sd.items()}
-    feat = O.unet_forward(torch.cat([img, x2], 0), osd, "Up_conv3", train=True, momentum=0.1)
-    opsd = {k: v.clone().requires_grad_(True) for k, v in psd.items()}
-    f1 = O.apply_flips(feat[:bs], flips)
-    z = O.dense_projector_forward(torch.cat([f1, feat[bs:]], 0), opsd, head_type="mlp", normalize=True,
-                                  pool_name="adaptive_avg", spatial_size=(10, 10))
-    pts = O.dense_region_points(seed, bs, 10, 10, 5)
-    sel = lambda zz: torch.cat([torch.stack([zz[b][:, x, y] for x, y in pts[b]]) for b in range(bs)])  # noqa: E731
-    a, b = sel(z[:bs]), sel(z[bs:])
-    ref = 0.5 * O.supcon_loss(a, b, list(range(a.shape[0])))["loss"]
-    ref.backward()
+    def oracle(img, img_tf):
+        flips = O.random_flip_decisions(seed, bs)
+        x2 = O.apply_flips(img_tf, flips)
+        osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+               for k, v in sd.items()}
+        feat = O.unet_forward(torch.cat([img, x2], 0), osd, "Up_conv3", train=True, momentum=0.1)
+        opsd = {k: v.clone().requires_grad_(True) for k, v in psd.items()}
+        f1 = O.apply_flips(feat[:bs], flips)
+        z = O.dense_projector_forward(torch.cat([f1, feat[bs:]], 0), opsd, head_type="mlp", normalize=True,
+                                      pool_name="adaptive_avg", spatial_size=(10, 10))
+        pts = O.dense_region_points(seed, bs, 10, 10, 5)
+        sel = lambda zz: torch.cat([torch.stack([zz[b][:, x, y] for x, y in pts[b]]) for b in range(bs)])  # noqa: E731
+        a, b = sel(z[:bs]), sel(z[bs:])
+        ref = 0.5 * O.supcon_loss(a, b, list(range(a.shape[0])))["loss"]
+        ref.backward()
+        return ref, osd, opsd
+
+    def oracle_grads(img, img_tf):
+        _, osd_, opsd_ = oracle(img, img_tf)
+        out = {k: v.grad.numpy() for k, v in osd_.items() if k.startswith("_Up") and torch.is_tensor(v) and v.grad is not None}
+        out.update({"head." + k: v.grad.numpy() for k, v in opsd_.items()})
+        return out
+
+    ref, osd, opsd = oracle(img, img_tf)
     np.testing.assert_allclose(float(loss.detach()), float(ref.detach()), rtol=2e-4)
+    # (split: what a 2e-6 perturbation of the images does to the oracle's own gradients bounds what can be asked)
+    slack = 3.0 * oracle_sensitivity((img, img_tf), oracle_grads) if f32_products == "split" else 0.0
     rel = lambda u, v: float(np.abs(u - v).max() / max(1e-30, np.abs(v).max()))  # noqa: E731
     checked = 0
     for k, p in net.named_parameters():
         if k.startswith(("_Up5", "_Up_conv5", "_Up4", "_Up_conv4", "_Up3", "_Up_conv3")):
             assert p.grad is not None and osd[k].grad is not None, k
-            assert rel(p.grad.cpu().numpy(), osd[k].grad.numpy()) < 5e-3, (k, rel(p.grad.cpu().numpy(), osd[k].grad.numpy()))
+            assert rel(p.grad.cpu().numpy(), osd[k].grad.numpy()) < max(5e-3, slack), (k, rel(p.grad.cpu().numpy(), osd[k].grad.numpy()), slack)
             checked += 1
         elif k.startswith("_Conv"):
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k  # frozen encoder
@@ -179,4 +205,4 @@ def test_dense_infonce_hook_step_vs_oracle_fp32():
     l2 = lambda u, v: float(np.linalg.norm(u - v) / max(1e-30, np.linalg.norm(v)))  # noqa: E731
     for k, p in head.named_parameters():
         got, want = p.grad.cpu().numpy(), opsd[k].grad.numpy()
-        assert l2(got, want) < 3e-3 and rel(got, want) < 2e-2, (k, l2(got, want), rel(got, want))
+        assert l2(got, want) < max(3e-3, slack) and rel(got, want) < max(2e-2, slack), (k, l2(got, want), rel(got, want), slack)

@@ -17,5 +17,6 @@ for wl in finetune prostate; do
   rm -rf $OUT/prof_tl
   tail -1 $OUT/${TAG}_step_timeline_$wl.txt
 done
-timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -6 > $OUT/${TAG}_gputest_full.log
+bash tools/diag/timeline_fp32.sh $TAG   # -> ${TAG}_step_timeline_fp32.txt (f32 storage, split-bf16 products)
+timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -6 > $OUT/${TAG}_gputest_full.log
 cat $OUT/${TAG}_gputest_full.log | tail -2
