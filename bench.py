@@ -97,6 +97,9 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra keys (per-replay distribution, contrastive 4096x128 microbench)")
+    ap.add_argument("--f32-exact", action="store_true",
+                    help="--dtype fp32 only: multiply on v_mfma_f32_16x16x4_f32 (exact f32 products, 1/16 of the bf16 matrix "
+                         "rate) instead of three bf16 pieces per operand (spcl_conv_set_f32_split(0))")
     ap.add_argument("--cpu-bs", type=int, default=8, help="batch of the CPU-oracle sample (bounded work)")
     ap.add_argument("--workload", default="pretrain", choices=["pretrain", "contrastive", "finetune", "prostate"],
                     help="pretrain = BASELINE configs[1] (the metric); prostate = configs[3] shape: 256x256, bs=64/GPU, "
@@ -106,6 +109,10 @@ def parse():
 
 # ------------------------------------------------------------------------------------------------ step construction
 def build_step(args, device, rank, world):
+    if getattr(args, "f32_exact", False):
+        import spcl_amd  # noqa: F401
+        from spcl_amd import native as _native
+        _native.call("spcl_conv_set_f32_split", 0)
     import spcl_amd
     from spcl_amd import ddp
     from spcl_amd.semi_seg.arch import UNet
@@ -236,6 +243,8 @@ def graph_kernel_times(args, first_kernel="flip_pair_stage"):
     cmd = [exe, "--kernel-trace", "--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
            "--no-cpu-baseline", "--no-extras", "--no-roofline", "--steps", "30", "--warmup", "5", "--bs", str(args.bs),
            "--size", str(args.size), "--dtype", args.dtype, "--workload", args.workload, "--pool", str(args.pool)]
+    if getattr(args, "f32_exact", False):
+        cmd.append("--f32-exact")
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
