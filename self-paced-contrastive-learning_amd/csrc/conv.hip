@@ -596,6 +596,88 @@ __device__ __forceinline__ float pack_value_epc(const float* __restrict__ w, int
   return v;
 }
 
+// ---- the same layouts 16 BYTES at a time (the step's pack launch, conv_pack_multi_body): the eight (bf16) or four (f32)
+// elements of a 16-byte chunk share everything but the GEMM-K channel, so one index decode -- five divisions by run-time
+// values -- and one 16-byte store serve them all (per element the launch was decode-bound: 13 us for 5 MB, 37 us in f32
+// storage where every float slot of the split layout decoded twice and split two weights into all three pieces to keep one)
+__device__ __forceinline__ void pack_gather(const float* __restrict__ w, int Cin, int Cout, int kind, int kch0, int nch, int tap,
+                                            int n, float* v) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    v[e] = 0.f;
+    if (e < n) {
+      const int kch = kch0 + e;
+      if (kind == 0) {
+        if (kch < Cin && nch < Cout) v[e] = w[((size_t)nch * Cin + kch) * 9 + tap];
+      } else {
+        if (kch < Cout && nch < Cin) v[e] = w[((size_t)kch * Cin + nch) * 9 + (8 - tap)];
+      }
+    }
+  }
+}
+// the standard layout's chunk that starts at element r (a multiple of EPC): its EPC values (zeros in the K padding)
+template <int EPC>
+__device__ __forceinline__ void pack_chunk_values(const float* __restrict__ w, int Cin, int Cout, int kind, int KinK, int NoutS,
+                                                  unsigned r, float* v) {
+  const int KC = conv_kc(KinK);
+  const int CP = KC / EPC;
+  const int nsteps = (9 * CP + 3) / 4;
+  const int ntn = NoutS >> 4;
+  r /= EPC;
+  const int lane = (int)(r % 64); r /= 64;
+  const int nt = (int)(r % ntn); r /= ntn;
+  const int step = (int)(r % nsteps); r /= nsteps;
+  const int slab = (int)r;
+  const int fc = 4 * step + (lane >> 4);
+  if (fc < 9 * CP) {
+    const int tap = fc / CP, ch = fc % CP;
+    pack_gather(w, Cin, Cout, kind, slab * KC + ch * EPC, nt * 16 + (lane & 15), tap, EPC, v);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+  }
+}
+__device__ __forceinline__ u32x4 pack_bf16x8(const float* v) {
+  u32x4 o;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = (uint32_t)f32_to_bf16(v[2 * k]) | ((uint32_t)f32_to_bf16(v[2 * k + 1]) << 16);
+  return o;
+}
+// bytes [16 c, 16 c + 16) of the packed buffer
+template <typename T>
+__device__ __forceinline__ u32x4 pack_chunk16(const float* __restrict__ w, int Cin, int Cout, int kind, int KinK, int NoutS,
+                                              unsigned c, bool gemm) {
+  float v[8];
+  if constexpr (sizeof(T) == 4) {
+    const unsigned r0 = 4u * c, exact = (unsigned)f32_exact_elems(KinK, NoutS);
+    if (r0 < exact) {
+      pack_chunk_values<4>(w, Cin, Cout, kind, KinK, NoutS, r0, v);
+      return (u32x4){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+    }
+    const unsigned per = (unsigned)f32_split_plane_elems(KinK, NoutS);
+    const unsigned b0 = 2u * (r0 - exact);  // the chunk's first bf16 piece: eight pieces of ONE plane
+    const int plane = (int)(b0 / per);
+    pack_chunk_values<8>(w, Cin, Cout, kind, KinK, NoutS, b0 - (unsigned)plane * per, v);
+    u32x4 ph, pm, pl;
+    split3_chunk(v, ph, pm, pl);
+    return plane == 0 ? ph : (plane == 1 ? pm : pl);
+  } else {
+    const unsigned r0 = 8u * c;
+    if (gemm && r0 >= 9u * (unsigned)KinK * (unsigned)NoutS) {  // conv_gemm.hip's layout (pack_value)
+      unsigned r = (r0 - 9u * (unsigned)KinK * (unsigned)NoutS) / 8;
+      const int lane = (int)(r % 64); r /= 64;
+      const int ks = (int)(r % 4); r /= 4;
+      const int cot = (int)(r % (NoutS >> 5)); r /= (NoutS >> 5);
+      const int tap = (int)(r % 9); r /= 9;
+      const int slab = (int)r;
+      pack_gather(w, Cin, Cout, kind, slab * 64 + ks * 16 + (lane >> 5) * 8, cot * 32 + (lane & 31), tap, 8, v);
+    } else {
+      pack_chunk_values<8>(w, Cin, Cout, kind, KinK, NoutS, r0, v);
+    }
+    return pack_bf16x8(v);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict__ w, int Cin, int Cout, int kind,
                                                         int KinK, int NoutS, T* __restrict__ packed, size_t total,
@@ -641,7 +723,7 @@ __global__ __launch_bounds__(256) void conv_pack_block_kernel(const float* __res
 // arguments in a few wide scalar loads; a per-thread walk over dynamically indexed argument structs was a chain of 2 x 20
 // dependent scalar loads: 20 us for what five separate launches did in 27).
 #ifndef SPCL_PACK_EPB
-#define SPCL_PACK_EPB 1024
+#define SPCL_PACK_EPB 2048
 #endif
 constexpr int PACK_EPB = SPCL_PACK_EPB, PACK_SEGS = 2 * SPCL_PACK_MULTI_MAX + 1;  // (+ 1: the zero-fill segment, kind 2)
 struct PackSeg {
@@ -680,15 +762,20 @@ __device__ __forceinline__ void conv_pack_multi_body(const PackSegs& p, const in
 #pragma unroll
   for (int k = 0; k < PACK_SEGS; ++k) seg += b >= p.blk_end[k] ? 1 : 0;
   const PackSeg g = p.s[seg];
-  const unsigned base = (unsigned)(b - g.blk_begin) * PACK_EPB + threadIdx.x;
+  constexpr int EPCH = 16 / (int)sizeof(T), CHUNKS = PACK_EPB / EPCH;  // elements per 16-byte chunk, chunks per workgroup
+  const unsigned c0 = (unsigned)(b - g.blk_begin) * CHUNKS;
 #pragma unroll
-  for (int e = 0; e < PACK_EPB / 256; ++e) {
-    const unsigned i = base + e * 256;
-    if (i < g.count) {
-      // kind 2: not a weight layout at all -- a region to ZERO (the step's BatchNorm accumulator blocks, bn_acc.hpp: they must
-      // be zero before the first convolution runs, and this launch is the first of every forward pass: no fill launch)
-      if (g.kind == 2) Elem<T>::store((T*)g.out + i, 0.f);
-      else Elem<T>::store((T*)g.out + i, pack_value<T>(g.w, g.Cin, g.Cout, g.kind, g.KinK, g.NoutS, (size_t)i, g.gemm != 0));
+  for (int k = 0; k < (CHUNKS + 255) / 256; ++k) {
+    const unsigned c = c0 + threadIdx.x + 256 * k;
+    const unsigned i = c * EPCH;  // the chunk's first element
+    if (CHUNKS % 256 != 0 && threadIdx.x + 256 * k >= CHUNKS) break;
+    if (i >= g.count) continue;
+    if (g.kind == 2) {
+      // not a weight layout at all -- a region to ZERO (the step's BatchNorm accumulator blocks, bn_acc.hpp: they must be zero
+      // before the first convolution runs, and this launch is the first of every forward pass: no fill launch)
+      for (int e = 0; e < EPCH && i + e < g.count; ++e) Elem<T>::store((T*)g.out + i + e, 0.f);
+    } else {  // (a layout's element count is a multiple of 256: whole chunks)
+      *(u32x4*)((T*)g.out + i) = pack_chunk16<T>(g.w, g.Cin, g.Cout, g.kind, g.KinK, g.NoutS, c, g.gemm != 0);
     }
   }
 }

@@ -821,3 +821,41 @@ def test_copy_pair_is_two_copies():
     assert torch.equal(db[:b.numel()], b) and bool((db[b.numel():] == -7).all())
     with pytest.raises(RuntimeError):
         n.call("spcl_copy_pair", da.data_ptr() + 4, a.data_ptr(), 16, db.data_ptr(), b.data_ptr(), 16, n.stream())
+
+
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_multi_layer_pack_writes_what_the_single_layer_pack_writes(dt):
+    """spcl_conv_pack_weights_multi (the step's one pack launch: 16 bytes per thread, one index decode per chunk) against
+    spcl_conv_pack_weights (one element per thread) on the same weights: every byte of both layouts of every layer -- narrow
+    layers, K padding (48 channels), the dual-layout bf16 layers (band-GEMM half included: H = W = 0), f32's exact + split
+    halves -- and the zero-fill region the same launch serves."""
+    n = _n()
+    dtype = DT[dt]
+    dtc = n.dtype_code(dtype)
+    g = torch.Generator().manual_seed(7)
+    layers = [(1, 16), (16, 16), (16, 32), (32, 48), (48, 64), (64, 64), (64, 128), (128, 256), (256, 128), (24, 40)]
+    items, keep, outs = [], [], []
+    for ci, co in layers:
+        w = torch.randn(co, ci, 3, 3, generator=g).cuda()
+        n0 = n.call("spcl_conv_packed_elems", ci, co, 0, dtc)
+        n1 = n.call("spcl_conv_packed_elems", ci, co, 1, dtc)
+        p0 = torch.full((n0,), 7.0, dtype=dtype, device="cuda")
+        p1 = torch.full((n1,), 7.0, dtype=dtype, device="cuda")
+        items.append(n.PackItem(w.data_ptr(), p0.data_ptr(), p1.data_ptr(), ci, co, 0, 0))
+        keep.append(w)
+        outs.append((w, p0, p1))
+    zero = torch.full((1000,), 3.0, dtype=torch.float32, device="cuda")
+    for i in range(0, len(items), n.PACK_MULTI_MAX):
+        part = items[i:i + n.PACK_MULTI_MAX]
+        arr = (n.PackItem * len(part))(*part)
+        if i == 0:
+            import ctypes
+            n.call("spcl_conv_pack_weights_multi_zero", arr, len(part), dtc, None, 0, 0, 0, None, n.ptr(zero),
+                   ctypes.c_size_t(zero.numel() * 4), n.stream())
+        else:
+            n.call("spcl_conv_pack_weights_multi", arr, len(part), dtc, n.stream())
+    assert float(zero.abs().max()) == 0.0
+    for w, p0, p1 in outs:
+        r0, r1 = pack(n, w.cpu(), 0, dtype), pack(n, w.cpu(), 1, dtype)
+        assert torch.equal(p0.view(torch.uint8), r0.view(torch.uint8)), tuple(w.shape)
+        assert torch.equal(p1.view(torch.uint8), r1.view(torch.uint8)), tuple(w.shape)
