@@ -224,7 +224,10 @@ void spcl_conv_set_gemm(int mode);
  * float32, the north_star's "within fp32 tolerance" path) multiply: 1 (default) every f32 operand as the exact sum of three
  * bf16 pieces, six v_mfma_f32_16x16x32_bf16 products per pair accumulated in f32 (the dropped terms are below 2^-24 of a
  * product: f32-grade results at 3/8 of the exact path's matrix time); 0 v_mfma_f32_16x16x4_f32 (exact f32 products, 1/16 of
- * the bf16 matrix rate).  Packed f32 weights carry both layouts: the switch may change between any two launches. */
+ * the bf16 matrix rate).  Packed f32 weights carry both layouts: the switch may change between any two launches.  One
+ * process-wide setting, read at launch time on the calling thread (not synchronised: set it before the threads that launch
+ * start, as the tests and bench.py --f32-exact do).  The one-channel image convolution (in_mode 2, CoutS == 16) is a direct
+ * exact-FMA kernel under both settings. */
 void spcl_conv_set_f32_split(int on);
 int spcl_conv_get_f32_split(void);
 size_t spcl_bn_stats_elems(int ntiles, int CS);
