@@ -27,6 +27,11 @@ namespace spcl {
 // of the rate -- 3/8 of the matrix time, f32-grade results (tests/test_gpu_kernels.py: the f32 tolerances unchanged).  The
 // input is split ONCE per halo element in the staging (three bf16 planes per LDS pixel; each element is then read by nine
 // taps), the weights once per step by the pack kernel (pack_value<float>: second half of the packed buffer).
+// channels per slab of the split layout (its own: the split half of a packed buffer is laid out for it)
+#ifndef SPCL_SPLIT_KC_MAX
+#define SPCL_SPLIT_KC_MAX 64
+#endif
+__host__ __device__ inline int split_kc(int CinK) { return CinK < SPCL_SPLIT_KC_MAX ? CinK : SPCL_SPLIT_KC_MAX; }
 __host__ __device__ inline int split_pstride(int KC) {  // LDS bytes per halo pixel: three bf16 planes, an ODD multiple of 32
   const int b = 3 * KC * 2;
   return (b / 32) % 2 == 1 ? b : b + 32;
@@ -53,7 +58,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int r16 = lane & 15, g = lane >> 4;
-  const int KC = conv_kc(a.CinK);
+  const int KC = SPLIT ? split_kc(a.CinK) : conv_kc(a.CinK);
   const int CP = KC / EPC;
   const int log2cp = __builtin_ctz(CP);
   const int PSTRIDE = SPLIT ? split_pstride(KC) : conv_pstride<T>(KC);
@@ -525,11 +530,11 @@ __host__ __device__ inline size_t f32_exact_elems(int KinK, int NoutS) {
   return (size_t)(KinK / KC) * conv_nsteps<float>(KC) * (NoutS / 16) * 64 * 4;
 }
 __host__ __device__ inline size_t f32_split_plane_elems(int KinK, int NoutS) {  // bf16 pieces per plane
-  const int KC = conv_kc(KinK);
+  const int KC = split_kc(KinK);
   return (size_t)(KinK / KC) * conv_nsteps<bf16_t>(KC) * (NoutS / 16) * 64 * 8;
 }
 template <int EPC>
-__device__ __forceinline__ float pack_value_epc(const float* __restrict__ w, int Cin, int Cout, int kind, int KinK, int NoutS,
+__device__ __forceinline__ float pack_value_epc(const float* __restrict__ w, int Cin, int Cout, int kind, int KC, int NoutS,
                                                 unsigned r);
 __device__ __forceinline__ uint32_t split_piece(float v, int plane) {  // bf16 bits of piece `plane` of v (split3_pair's pieces)
   const Split3 o = split3_pair(v, 0.f);
@@ -545,8 +550,8 @@ __device__ __forceinline__ float pack_value(const float* __restrict__ w, int Cin
     const unsigned b = 2u * (unsigned)(idx - f32_exact_elems(KinK, NoutS));  // first of the slot's two pieces
     const int plane = (int)(b / per);
     const unsigned r = b - (unsigned)plane * per;
-    const uint32_t p0 = split_piece(pack_value_epc<8>(w, Cin, Cout, kind, KinK, NoutS, r), plane);
-    const uint32_t p1 = split_piece(pack_value_epc<8>(w, Cin, Cout, kind, KinK, NoutS, r + 1), plane);
+    const uint32_t p0 = split_piece(pack_value_epc<8>(w, Cin, Cout, kind, split_kc(KinK), NoutS, r), plane);
+    const uint32_t p1 = split_piece(pack_value_epc<8>(w, Cin, Cout, kind, split_kc(KinK), NoutS, r + 1), plane);
     return __uint_as_float(p0 | (p1 << 16));
   }
   if (gemm && idx >= (size_t)9 * KinK * NoutS) {
@@ -565,13 +570,12 @@ __device__ __forceinline__ float pack_value(const float* __restrict__ w, int Cin
     if (kind == 0) return (kch < Cin && nch < Cout) ? w[((size_t)nch * Cin + kch) * 9 + tap] : 0.f;
     return (kch < Cout && nch < Cin) ? w[((size_t)kch * Cin + nch) * 9 + (8 - tap)] : 0.f;
   }
-  return pack_value_epc<EPC>(w, Cin, Cout, kind, KinK, NoutS, (unsigned)idx);  // (packed buffers hold a few million elements)
+  return pack_value_epc<EPC>(w, Cin, Cout, kind, conv_kc(KinK), NoutS, (unsigned)idx);  // (packed buffers hold a few million elements)
 }
 
 template <int EPC>
-__device__ __forceinline__ float pack_value_epc(const float* __restrict__ w, int Cin, int Cout, int kind, int KinK, int NoutS,
-                                                unsigned r) {
-  const int KC = conv_kc(KinK);
+__device__ __forceinline__ float pack_value_epc(const float* __restrict__ w, int Cin, int Cout, int kind, int KC, int NoutS,
+                                                unsigned r) {  // KC: channels per slab of the layout
   const int CP = KC / EPC;
   const int nsteps = (9 * CP + 3) / 4;  // conv_nsteps
   const int ntn = NoutS >> 4;
@@ -617,9 +621,8 @@ __device__ __forceinline__ void pack_gather(const float* __restrict__ w, int Cin
 }
 // the standard layout's chunk that starts at element r (a multiple of EPC): its EPC values (zeros in the K padding)
 template <int EPC>
-__device__ __forceinline__ void pack_chunk_values(const float* __restrict__ w, int Cin, int Cout, int kind, int KinK, int NoutS,
+__device__ __forceinline__ void pack_chunk_values(const float* __restrict__ w, int Cin, int Cout, int kind, int KC, int NoutS,
                                                   unsigned r, float* v) {
-  const int KC = conv_kc(KinK);
   const int CP = KC / EPC;
   const int nsteps = (9 * CP + 3) / 4;
   const int ntn = NoutS >> 4;
@@ -651,13 +654,13 @@ __device__ __forceinline__ u32x4 pack_chunk16(const float* __restrict__ w, int C
   if constexpr (sizeof(T) == 4) {
     const unsigned r0 = 4u * c, exact = (unsigned)f32_exact_elems(KinK, NoutS);
     if (r0 < exact) {
-      pack_chunk_values<4>(w, Cin, Cout, kind, KinK, NoutS, r0, v);
+      pack_chunk_values<4>(w, Cin, Cout, kind, conv_kc(KinK), NoutS, r0, v);
       return (u32x4){__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
     }
     const unsigned per = (unsigned)f32_split_plane_elems(KinK, NoutS);
     const unsigned b0 = 2u * (r0 - exact);  // the chunk's first bf16 piece: eight pieces of ONE plane
     const int plane = (int)(b0 / per);
-    pack_chunk_values<8>(w, Cin, Cout, kind, KinK, NoutS, b0 - (unsigned)plane * per, v);
+    pack_chunk_values<8>(w, Cin, Cout, kind, split_kc(KinK), NoutS, b0 - (unsigned)plane * per, v);
     u32x4 ph, pm, pl;
     split3_chunk(v, ph, pm, pl);
     return plane == 0 ? ph : (plane == 1 ? pm : pl);
@@ -672,7 +675,7 @@ __device__ __forceinline__ u32x4 pack_chunk16(const float* __restrict__ w, int C
       const int slab = (int)r;
       pack_gather(w, Cin, Cout, kind, slab * 64 + ks * 16 + (lane >> 5) * 8, cot * 32 + (lane & 31), tap, 8, v);
     } else {
-      pack_chunk_values<8>(w, Cin, Cout, kind, KinK, NoutS, r0, v);
+      pack_chunk_values<8>(w, Cin, Cout, kind, conv_kc(KinK), NoutS, r0, v);
     }
     return pack_bf16x8(v);
   }
@@ -851,7 +854,7 @@ static int launch_conv(const ConvArgs& a0, hipStream_t st) {
   const int KC = conv_kc(a.CinK);
   static const int env_lds_extra = lab_env("SPCL_CONV_LDS_EXTRA", 0);
   const bool split = sizeof(T) == 4 && g_f32_split != 0;
-  const size_t lds = (size_t)(TH + 2) * (TW + 2) * (split ? split_pstride(KC) : conv_pstride<T>(KC)) + env_lds_extra;
+  const size_t lds = (size_t)(TH + 2) * (TW + 2) * (split ? split_pstride(split_kc(a.CinK)) : conv_pstride<T>(KC)) + env_lds_extra;
   const int tiles = a.N * a.tilesX * a.tilesY;
   static const int env_tpw = lab_env("SPCL_CONV_TPW", 0);
   a.tpw = env_tpw > 0 ? env_tpw : 1;
