@@ -31,7 +31,14 @@ namespace spcl {
 #ifndef SPCL_SPLIT_KC_MAX
 #define SPCL_SPLIT_KC_MAX 64
 #endif
-__host__ __device__ inline int split_kc(int CinK) { return CinK < SPCL_SPLIT_KC_MAX ? CinK : SPCL_SPLIT_KC_MAX; }
+// ... fewer for the layers with one or two 16-channel output tiles: their workgroups are one or two waves, and with a
+// 64-channel image (60 KB) two of them fill a CU's LDS -- one wave per SIMD.  Same box, fp32 step: 32 -> 64 channels' dgrad
+// (K = 64, 32 outputs) 73.6 -> 58.1 us on 32-channel slabs; 16 -> 32's dgrad (K = 32, 16 outputs) 88.4 -> 70.1 on 16-channel
+// slabs; 32 outputs on 16-channel slabs lose (101 -> 115): twice the barriers for little residency.
+__host__ __device__ inline int split_kc(int CinK, int CoutS) {
+  const int cap = CoutS <= 16 ? 16 : (CoutS <= 32 ? 32 : SPCL_SPLIT_KC_MAX);
+  return CinK < cap ? CinK : cap;
+}
 __host__ __device__ inline int split_pstride(int KC) {  // LDS bytes per halo pixel: three bf16 planes, an ODD multiple of 32
   const int b = 3 * KC * 2;
   return (b / 32) % 2 == 1 ? b : b + 32;
@@ -58,7 +65,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
   const int r16 = lane & 15, g = lane >> 4;
-  const int KC = SPLIT ? split_kc(a.CinK) : conv_kc(a.CinK);
+  const int KC = SPLIT ? split_kc(a.CinK, a.CoutS) : conv_kc(a.CinK);
   const int CP = KC / EPC;
   const int log2cp = __builtin_ctz(CP);
   const int PSTRIDE = SPLIT ? split_pstride(KC) : conv_pstride<T>(KC);
@@ -530,7 +537,7 @@ __host__ __device__ inline size_t f32_exact_elems(int KinK, int NoutS) {
   return (size_t)(KinK / KC) * conv_nsteps<float>(KC) * (NoutS / 16) * 64 * 4;
 }
 __host__ __device__ inline size_t f32_split_plane_elems(int KinK, int NoutS) {  // bf16 pieces per plane
-  const int KC = split_kc(KinK);
+  const int KC = split_kc(KinK, NoutS);
   return (size_t)(KinK / KC) * conv_nsteps<bf16_t>(KC) * (NoutS / 16) * 64 * 8;
 }
 template <int EPC>
@@ -550,8 +557,8 @@ __device__ __forceinline__ float pack_value(const float* __restrict__ w, int Cin
     const unsigned b = 2u * (unsigned)(idx - f32_exact_elems(KinK, NoutS));  // first of the slot's two pieces
     const int plane = (int)(b / per);
     const unsigned r = b - (unsigned)plane * per;
-    const uint32_t p0 = split_piece(pack_value_epc<8>(w, Cin, Cout, kind, split_kc(KinK), NoutS, r), plane);
-    const uint32_t p1 = split_piece(pack_value_epc<8>(w, Cin, Cout, kind, split_kc(KinK), NoutS, r + 1), plane);
+    const uint32_t p0 = split_piece(pack_value_epc<8>(w, Cin, Cout, kind, split_kc(KinK, NoutS), NoutS, r), plane);
+    const uint32_t p1 = split_piece(pack_value_epc<8>(w, Cin, Cout, kind, split_kc(KinK, NoutS), NoutS, r + 1), plane);
     return __uint_as_float(p0 | (p1 << 16));
   }
   if (gemm && idx >= (size_t)9 * KinK * NoutS) {
@@ -660,7 +667,7 @@ __device__ __forceinline__ u32x4 pack_chunk16(const float* __restrict__ w, int C
     const unsigned per = (unsigned)f32_split_plane_elems(KinK, NoutS);
     const unsigned b0 = 2u * (r0 - exact);  // the chunk's first bf16 piece: eight pieces of ONE plane
     const int plane = (int)(b0 / per);
-    pack_chunk_values<8>(w, Cin, Cout, kind, split_kc(KinK), NoutS, b0 - (unsigned)plane * per, v);
+    pack_chunk_values<8>(w, Cin, Cout, kind, split_kc(KinK, NoutS), NoutS, b0 - (unsigned)plane * per, v);
     u32x4 ph, pm, pl;
     split3_chunk(v, ph, pm, pl);
     return plane == 0 ? ph : (plane == 1 ? pm : pl);
@@ -854,7 +861,7 @@ static int launch_conv(const ConvArgs& a0, hipStream_t st) {
   const int KC = conv_kc(a.CinK);
   static const int env_lds_extra = lab_env("SPCL_CONV_LDS_EXTRA", 0);
   const bool split = sizeof(T) == 4 && g_f32_split != 0;
-  const size_t lds = (size_t)(TH + 2) * (TW + 2) * (split ? split_pstride(split_kc(a.CinK)) : conv_pstride<T>(KC)) + env_lds_extra;
+  const size_t lds = (size_t)(TH + 2) * (TW + 2) * (split ? split_pstride(split_kc(a.CinK, a.CoutS)) : conv_pstride<T>(KC)) + env_lds_extra;
   const int tiles = a.N * a.tilesX * a.tilesY;
   static const int env_tpw = lab_env("SPCL_CONV_TPW", 0);
   a.tpw = env_tpw > 0 ? env_tpw : 1;
