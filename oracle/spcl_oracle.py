@@ -794,13 +794,15 @@ def recipe_view(img_u8, label_u8, out_hw, *, angle=0.0, vflip=False, hflip=False
     """One view of a reference recipe, operation by operation as torchvision / PIL execute it on 8-bit images (image:
     BILINEAR rotation, label map: NEAREST -- contrastyou/augment/synchronize.py:95-103):
       crop_first=False  rotate -> vflip -> hflip -> pad (zeros) -> crop -> jitter     (`pretrain`, semi_seg/augment.py:6-22,54-69)
-      crop_first=True   crop -> rotate the crop                                      (`label`, :23-34; CenterCrop `val` with angle 0)
+      crop_first=True   [pad ->] crop -> rotate the crop                              (`label`, :23-34; CenterCrop `val` with angle 0)
     -> (uint8 image view, uint8 label view or None)"""
     import numpy as np
     oh, ow = out_hw
 
     def geometry(a, rotate):
         if crop_first:
+            if pad:  # RandomCrop(size, padding=): zeros around the slice first (Spleen `label`, semi_seg/augment.py:107-110)
+                a = np.pad(a, pad, mode="constant")
             a = a[top:top + oh, left:left + ow]
             return rotate(a, angle)
         a = rotate(a, angle)

@@ -41,6 +41,8 @@ _MIRRORED = {
     "semi_seg.trainers.new_trainer": "semi_seg.trainers.finetune",
     "semi_seg.data": "semi_seg.data",
     "semi_seg.data.rearr": "semi_seg.data.rearr",
+    "semi_seg.data.creator": "semi_seg.data.creator",
+    "val": "val",
     "hook_creator": "hook_creator",
 }
 

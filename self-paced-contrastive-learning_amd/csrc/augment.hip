@@ -233,8 +233,17 @@ __global__ __launch_bounds__(1024) void augment_views_recipe_kernel(const float*
   const float* img = src + (size_t)slice * HS * WS;
   const unsigned char* lab = labels != nullptr ? labels + (size_t)slice * HS * WS : nullptr;
   // the image the rotation acts on: the slice, or its crop (a window of it)
-  const int wx0 = crop_first ? left : 0, wy0 = crop_first ? top : 0, ww = crop_first ? OW : WS, wh = crop_first ? OH : HS;
+  // (crop first: RandomCrop(padding=) pads with zeros BEFORE it crops -- the window's origin is (top - pad, left - pad) of the
+  // slice and window pixels outside the slice are the padding's zeros; a slice index outside the store reads as all padding)
+  const int wx0 = crop_first ? left - pad : 0, wy0 = crop_first ? top - pad : 0, ww = crop_first ? OW : WS,
+            wh = crop_first ? OH : HS;
+  const bool slice_ok = slice >= 0 && slice < S;
+  auto inside = [&](int xc, int yc) -> bool {
+    const int ys = wy0 + yc, xs = wx0 + xc;
+    return slice_ok && ys >= 0 && ys < HS && xs >= 0 && xs < WS;
+  };
   auto level = [&](int xc, int yc) -> int {  // 8-bit grey level of window pixel (xc, yc)
+    if (!inside(xc, yc)) return 0;
     return (int)__fadd_rn(__fmul_rn(img[(size_t)(wy0 + yc) * WS + wx0 + xc], 255.f), 0.5f);
   };
   // (x, y): the pixel of the ROTATED window this output pixel shows, or none
@@ -301,7 +310,7 @@ __global__ __launch_bounds__(1024) void augment_views_recipe_kernel(const float*
       int x, y, lv = 0;
       if (locate(p, x, y)) {
         const int xin = (a2 + x * a0 + y * a1) >> 16, yin = (a5 + x * a3 + y * a4) >> 16;
-        if (xin >= 0 && xin < ww && yin >= 0 && yin < wh) lv = lab[(size_t)(wy0 + yin) * WS + wx0 + xin];
+        if (xin >= 0 && xin < ww && yin >= 0 && yin < wh && inside(xin, yin)) lv = lab[(size_t)(wy0 + yin) * WS + wx0 + xin];
       }
       label_out[(size_t)v * np + p] = lv;
     }

@@ -7,3 +7,5 @@ from .dataset import (ACDCSliceStore, DeviceSliceStore, ProstateSliceStore, acdc
 from .augment import RECIPES, PretrainViews, RecipeViews, draw_view_params, resize_store  # noqa: F401
 from .loader import (ContrastiveDeviceLoader, InfiniteRandomSampler, LabeledDeviceLoader,  # noqa: F401
                      get_contrastive_dataloader)
+from .creator import (ScanBatchLoader, ScanBatchSampler, UnlabeledDeviceLoader, get_data, register_dataset,  # noqa: F401
+                      set_data_root, split_dataset)

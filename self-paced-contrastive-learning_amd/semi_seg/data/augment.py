@@ -151,6 +151,18 @@ def draw_recipe_params(slice_index, src_hw, out_hw, recipe, rng=random):
                       crop_first=r["crop_first"], brightness=b, contrast=c, contrast_first=cf, bilinear=True)
 
 
+def redraw_jitter(row, recipe, rng=random):
+    """a second version of a view under ``SequentialWrapperTwice(total_freedom=False)`` (contrastyou/augment/synchronize.py:
+    129-150): the common transform replays the same seed -- same geometry --, the image transform draws again"""
+    r = list(row)
+    b = rng.uniform(*recipe["brightness"]) if recipe["brightness"] else 1.0
+    c = rng.uniform(*recipe["contrast"]) if recipe["contrast"] else 1.0
+    cf = bool(recipe["brightness"] and rng.random() < 0.5)
+    r[1] = (r[1] & ~4) | (4 if cf else 0)
+    r[5], r[6] = _f32_bits(float(b)), _f32_bits(float(c))
+    return r
+
+
 def center_crop_row(slice_index, src_hw, out_hw):
     """``CenterCrop`` (the `val` transform, semi_seg/augment.py:35-37): torchvision's int(round((h - oh) / 2.0)) offsets"""
     (hs, ws), (oh, ow) = src_hw, out_hw

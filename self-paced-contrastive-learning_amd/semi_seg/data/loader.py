@@ -7,7 +7,7 @@ from typing import Iterator
 
 import torch
 
-from .augment import RECIPES, PretrainViews, RecipeViews
+from .augment import RECIPES, PretrainViews, RecipeViews, redraw_jitter
 from .rearr import ContrastBatchSampler
 
 
@@ -69,11 +69,15 @@ class ContrastiveDeviceLoader:
 class LabeledDeviceLoader:
     """the labelled loader of the fine-tune loop (``FineTuneEpocher._run_only_label``, semi_seg/epochers/new_epocher.py:260-283)
     on device: batches ``((image, image_tf, target, target_tf), filenames, (partitions, scans))`` from a store WITH label maps
-    through the data set's `label` recipe (``ACDCStrongTransforms.label``, semi_seg/augment.py:23-34: RandomCrop, then
-    RandomRotation(30) -- one geometry for the image, BILINEAR, and its label map, NEAREST; SequentialWrapperTwice without
-    total freedom and without image-only randomness returns the same pair twice)."""
+    through a recipe of ``augment.RECIPES`` -- by default the data set's `label` recipe (``ACDCStrongTransforms.label``,
+    semi_seg/augment.py:23-34: RandomCrop, then RandomRotation(30)); ``semi_seg.data.creator`` passes the `pretrain` recipe,
+    which is what the reference's ``get_data`` trains on (creator.py:30).  Image (BILINEAR) and label map (NEAREST) of a pair
+    share one geometry.  The second pair follows ``SequentialWrapperTwice`` (contrastyou/augment/synchronize.py:129-150):
+    ``total_freedom=True`` (its default, the `label` recipes keep it) -- an independent draw of the whole recipe;
+    ``False`` -- the first pair's geometry with a fresh draw of the image-only colour jitter (the same tensors when the
+    recipe has none)."""
 
-    def __init__(self, store, *, batch_size, sampler=None, out_hw=(224, 224), recipe=None):
+    def __init__(self, store, *, batch_size, sampler=None, out_hw=(224, 224), recipe=None, total_freedom=True):
         if getattr(store, "targets", None) is None:
             raise ValueError("LabeledDeviceLoader: the store has no label maps (DeviceSliceStore(..., targets=))")
         self.dataset, self._batch_size = store, int(batch_size)
@@ -83,6 +87,7 @@ class LabeledDeviceLoader:
             raise NotImplementedError("resize the store (images BILINEAR, label maps NEAREST) before building the loader")
         self._views = RecipeViews(store.images, rec, out_hw, labels=store.targets)
         self._sampler = sampler if sampler is not None else InfiniteRandomSampler(store, shuffle=True)
+        self._total_freedom = bool(total_freedom)
         self._it = None
 
     def __iter__(self):
@@ -93,9 +98,18 @@ class LabeledDeviceLoader:
         if self._it is None:
             self._it = iter(self._sampler)
         idx = [next(self._it) for _ in range(self._batch_size)]
-        img, tgt = self._views.labelled(idx)
+        rows = self._views.rows(idx)
+        if self._total_freedom:
+            rows2 = self._views.rows(idx)
+        elif self._views.recipe.get("brightness") or self._views.recipe.get("contrast"):
+            rows2 = [redraw_jitter(r, self._views.recipe) for r in rows]
+        else:
+            rows2 = None
+        n = len(idx)
+        img, tgt = self._views.apply(rows + (rows2 or []), with_labels=True)  # (both pairs in one launch)
+        img2, tgt2 = (img[n:], tgt[n:]) if rows2 is not None else (img, tgt)
         metas = [self.dataset.meta(i) for i in idx]
-        return (img, img, tgt, tgt), [m[0] for m in metas], ([m[1] for m in metas], [m[2] for m in metas])
+        return (img[:n], img2, tgt[:n], tgt2), [m[0] for m in metas], ([m[1] for m in metas], [m[2] for m in metas])
 
 
 def get_contrastive_dataloader(partial_loader, contrastive_params, device="cuda", out_hw=(224, 224)):

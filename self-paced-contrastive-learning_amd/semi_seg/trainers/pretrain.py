@@ -50,6 +50,42 @@ class WarmupCosine:
         self._apply()
 
 
+def read_optim_sched(config, *, lr=None, weight_decay=None, warmup_max=None, multiplier=None, default_lr=1e-7,
+                     default_multiplier=400):
+    """``Trainer._init_optimizer`` / ``_init_scheduler`` (contrastyou/trainer/base.py:60-83) as data: the optimizer's name
+    and keyword set from ``config["Optim"]`` (every key but ``name`` / ``pre_lr`` / ``ft_lr`` reaches the optimizer, :64),
+    the scheduler's from ``config["Scheduler"]`` (``None`` when the section is absent: no scheduler, :72-73).  The mirror's
+    own keywords (``lr=`` ...) only override when given; the defaults only fill a section-less (``config=None``) call."""
+    optim_cfg = dict((config or {}).get("Optim", {}))
+    name = optim_cfg.pop("name", "RAdam")
+    for k in ("pre_lr", "ft_lr"):
+        optim_cfg.pop(k, None)
+    if lr is not None:
+        optim_cfg["lr"] = lr
+    if weight_decay is not None:
+        optim_cfg["weight_decay"] = weight_decay
+    optim_cfg.setdefault("lr", default_lr)
+    optim_cfg.setdefault("weight_decay", 1e-5)
+    sched = (config or {}).get("Scheduler", None)
+    if config is None or sched is not None or warmup_max is not None or multiplier is not None:
+        sched = dict(sched or {})
+        if warmup_max is not None:
+            sched["warmup_max"] = warmup_max
+        if multiplier is not None:
+            sched["multiplier"] = multiplier
+        sched.setdefault("warmup_max", 10)
+        sched.setdefault("multiplier", default_multiplier)
+    return name, optim_cfg, sched
+
+
+def build_optimizer(name, flat_param, optim_cfg):
+    if name == "RAdam":
+        return FusedRAdam([flat_param], **optim_cfg)  # torch.optim.RAdam semantics, HIP kernel
+    if hasattr(torch.optim, name):
+        return getattr(torch.optim, name)([flat_param], **optim_cfg)
+    raise KeyError(name)
+
+
 class PretrainEncoderTrainer:
     """``PretrainEncoderTrainer`` as ``main_pretrain_encoder.py:54-72`` drives it.
 
@@ -78,27 +114,8 @@ class PretrainEncoderTrainer:
         self._config = config
         self._save_dir = save_dir
         self._max_epoch, self._num_batches, self._device = max_epoch, num_batches, device
-        optim_cfg = dict((config or {}).get("Optim", {}))
-        self._optim_name = optim_cfg.pop("name", "RAdam")
-        for k in ("pre_lr", "ft_lr"):  # trainer/base.py:64: these two keys never reach the optimiser
-            optim_cfg.pop(k, None)
-        if lr is not None:
-            optim_cfg["lr"] = lr
-        if weight_decay is not None:
-            optim_cfg["weight_decay"] = weight_decay
-        optim_cfg.setdefault("lr", 5e-7)
-        optim_cfg.setdefault("weight_decay", 1e-5)
-        self._optim_cfg = optim_cfg
-        sched = (config or {}).get("Scheduler", None)
-        if config is None or sched is not None or warmup_max is not None or multiplier is not None:
-            sched = dict(sched or {})
-            if warmup_max is not None:
-                sched["warmup_max"] = warmup_max
-            if multiplier is not None:
-                sched["multiplier"] = multiplier
-            sched.setdefault("warmup_max", 10)
-            sched.setdefault("multiplier", 400)
-        self._sched_cfg = sched  # None: no scheduler (trainer/base.py:72-73)
+        self._optim_name, self._optim_cfg, self._sched_cfg = read_optim_sched(
+            config, lr=lr, weight_decay=weight_decay, warmup_max=warmup_max, multiplier=multiplier, default_lr=5e-7)
         if chain_dataloader is None:
             if config is None or "ContrastiveLoaderParams" not in config:  # new_pretrain.py:38-40
                 raise RuntimeError("`ContrastiveLoaderParams` should be found in config, given \n`" +
@@ -167,12 +184,7 @@ class PretrainEncoderTrainer:
         # the reference gives model and hook parameters two groups with identical hyper-parameters
         # (trainer/base.py:62-68): one flat parameter is the same optimisation problem
         self._flat = _ddp.FlatParams(params + hook_params)
-        if self._optim_name == "RAdam":
-            self._optimizer = FusedRAdam([self._flat.param], **self._optim_cfg)  # torch.optim.RAdam semantics, HIP kernel
-        elif hasattr(torch.optim, self._optim_name):
-            self._optimizer = getattr(torch.optim, self._optim_name)([self._flat.param], **self._optim_cfg)
-        else:
-            raise KeyError(self._optim_name)
+        self._optimizer = build_optimizer(self._optim_name, self._flat.param, self._optim_cfg)
         self._scheduler = None
         if self._sched_cfg is not None:
             self._scheduler = WarmupCosine(self._optimizer, max_epoch=self._max_epoch, **self._sched_cfg)

@@ -199,6 +199,24 @@ def test_oracle_recipes_are_pinned_to_pil():
     assert (O.pil_rotate_nearest(np.ascontiguousarray(crop), float(r[1])) != g["views_label"][5]).mean() > 0.3
 
 
+def test_oracle_padded_crop_first_is_pinned_to_pil():
+    """RandomCrop(size, padding=20) followed by RandomRotation (Spleen `label`, semi_seg/augment.py:107-112): the oracle's
+    crop-first path pads with zeros before it crops, as torchvision does (F.pad on the PIL image, then F.crop, then
+    Image.rotate: BILINEAR for the image, NEAREST for the label map) -- checked against PIL itself, here"""
+    from PIL import Image, ImageOps
+    rng = np.random.RandomState(4)
+    img = (rng.rand(64, 72) * 255).astype(np.uint8)
+    lab = (img // 64).astype(np.uint8)
+    for top, left, ang in ((0, 0, 7.5), (40, 48, -9.0), (13, 29, 3.25), (40, 0, 0.0)):
+        want, wlab = [], []
+        for a, res in ((img, Image.BILINEAR), (lab, Image.NEAREST)):
+            im = ImageOps.expand(Image.fromarray(a), border=20, fill=0).crop((left, top, left + 64, top + 64))
+            (want if res == Image.BILINEAR else wlab).append(np.asarray(im.rotate(ang, res)))
+        got, glab = O.recipe_view(img, lab, (64, 64), angle=ang, top=top, left=left, pad=20, crop_first=True)
+        np.testing.assert_array_equal(got, want[0])
+        np.testing.assert_array_equal(glab, wlab[0])
+
+
 def test_recipe_parameter_rows_and_resize_coefficients():
     import struct
     from spcl_amd.semi_seg.data import augment as A
@@ -262,3 +280,61 @@ def test_store_from_a_png_folder_with_label_maps(tmp_path):
     (tmp_path / "gt" / f"{names[3]}.png").unlink()
     with pytest.raises(FileNotFoundError):
         ACDCSliceStore.from_folder(str(tmp_path), device="cpu")
+
+
+# ---- round 6: semi_seg/data/creator.py -- which scans train, validate and test
+def _cpu_store(scans, per_scan=5, labels=True):
+    from spcl_amd.semi_seg.data import ACDCSliceStore
+    names = [f"{s}_{k:02d}" for s in scans for k in range(per_scan)]
+    imgs = torch.arange(len(names), dtype=torch.float32)[:, None, None].expand(-1, 4, 4) / 1000.0
+    return ACDCSliceStore(imgs, names, targets=(imgs * 1000).to(torch.uint8) % 4 if labels else None)
+
+
+def test_creator_splits_follow_the_reference():
+    """``split_dataset`` (semi_seg/data/creator.py:58-84): ``np.random.permutation`` of the SORTED scan list under
+    ``fix_all_seed(seed)`` (surrounding generator states restored), cut at the running sums of the ratios;
+    ``split_dataset_with_predefined_filenames`` (:38-55) and its two errors; ``extract_sub_dataset_based_on_scan_names``
+    keeps the store's slice order, meta-labels and label maps; ``ScanBatchSampler`` = one batch per scan, first-seen order."""
+    from spcl_amd.semi_seg.data import creator as C
+    scans = ["patient100_00", "patient027_01", "patient038_01", "patient067_01", "patient003_00", "patient011_01",
+             "patient050_00", "patient051_01", "patient009_01", "patient070_00"]
+    store = _cpu_store(scans)
+    np.random.seed(77)
+    random.seed(77)
+    before = (np.random.get_state()[1].copy(), random.getstate())
+    for ratios, seed in (((0.5,), 1), ((0.35,), 1), ((0.2, 0.3), 5)):
+        subs = C.split_dataset(store, *ratios, seed=seed)
+        np.random.seed(seed)
+        perm = np.random.permutation(sorted(scans)).tolist()
+        np.random.seed(77)  # (what the context manager must have restored is checked below; re-arm for the next round)
+        cuts = [0] + [int(len(scans) * sum(ratios[:i + 1])) for i in range(len(ratios))] + [len(scans)]
+        assert [sorted(s.get_scan_list()) for s in subs] == [sorted(perm[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+        assert sum(len(s) for s in subs) == len(store)
+    sub = C.extract_sub_dataset_based_on_scan_names(store, [scans[3], scans[0]])
+    keep = [i for i, s in enumerate(store.show_scan_names()) if s in (scans[0], scans[3])]
+    assert torch.equal(sub.images, store.images[keep]) and torch.equal(sub.targets, store.targets[keep])
+    assert sub.show_partitions() == [store.show_partitions()[i] for i in keep] and type(sub) is type(store)
+    with C._seeded(3):
+        np.random.rand(4), random.random(), torch.rand(2)
+    assert np.array_equal(np.random.get_state()[1], before[0]) and random.getstate() == before[1]
+    # the published labelled scans: 10 training scans x (k / 10)
+    for k, want in ((1, ["patient100_00"]), (2, ["patient027_01", "patient100_00"]),
+                    (4, ["patient027_01", "patient038_01", "patient067_01", "patient100_00"])):
+        lab, unl = C.split_dataset_with_predefined_filenames(store, "acdc", labeled_ratio=float(float(k) / len(scans)))
+        assert lab.get_scan_list() == sorted(want) and sorted(unl.get_scan_list()) == sorted(set(scans) - set(want))
+    with pytest.raises(ValueError):
+        C.split_dataset_with_predefined_filenames(store, "acdc", labeled_ratio=0.3)
+    with pytest.raises(KeyError):
+        C.split_dataset_with_predefined_filenames(store, "spleen", labeled_ratio=0.1)
+    sampler = C.ScanBatchSampler(store)
+    batches = list(sampler)
+    assert len(sampler) == len(scans) == len(batches) and batches[0] == list(range(5)) and batches[-1] == list(range(45, 50))
+    # get_data_loaders' refusals (:104-110,124-125) come before any device work
+    C.register_dataset("acdc", lambda mode: _cpu_store(scans if mode == "train" else ["patient150_00", "patient151_01"]))
+    try:
+        with pytest.raises(RuntimeError):
+            C.get_data_loaders({"name": "acdc", "labeled_scan_num": 11}, {}, {})
+    finally:
+        C._FACTORIES.pop("acdc")
+    with pytest.raises(KeyError):
+        C.create_dataset("mmwhsct")

@@ -217,14 +217,20 @@ def test_recipe_views_random_rows_match_the_oracle_and_pairs_are_independent():
     from spcl_amd.semi_seg.data import augment as A
     f32 = lambda i: struct.unpack("<f", struct.pack("<i", i))[0]  # noqa: E731
     f64 = lambda lo, hi: struct.unpack("<d", struct.pack("<ii", lo, hi))[0]  # noqa: E731
-    for name, size, out in (("acdc_pretrain", 256, 224), ("prostate_pretrain", 250, 224), ("acdc_label", 97, 50)):
+    # (the last one: RandomCrop(size, padding=20) THEN RandomRotation -- Spleen `label`, semi_seg/augment.py:107-112 -- the
+    # crop window reaches into the zero padding around the slice, on the last slice of the store too: ADVICE r05)
+    padded_label = dict(degrees=10.0, flips=False, pad=20, crop_first=True, brightness=None, contrast=None, resize=None)
+    for name, size, out in (("acdc_pretrain", 256, 224), ("prostate_pretrain", 250, 224), ("acdc_label", 97, 50),
+                            (padded_label, 64, 64)):
         store = _store(scans=3, slices_per_scan=(4, 5), size=size, seed=5)
         u8 = torch.round(store.images * 255).clamp(0, 255)
-        lab = (u8 / 64).floor().clamp(0, 3).to(torch.uint8) if "label" in name else None
+        lab = (u8 / 64).floor().clamp(0, 3).to(torch.uint8) if (isinstance(name, dict) or "label" in name) else None
         views = A.RecipeViews((u8 / 255).contiguous(), name, (out, out), labels=lab)
         imgs = torch.round(views.images * 255).cpu().numpy().astype(np.uint8)
         rng = random.Random(size)
         idx = [rng.randrange(imgs.shape[0]) for _ in range(5)]
+        if isinstance(name, dict):
+            idx[-1] = imgs.shape[0] - 1  # the store's last slice: nothing behind it to read
         if lab is None:
             a, b = views.pairs(idx, random.Random(3))
             assert tuple(a.shape) == (5, 1, out, out) and not torch.equal(a, b)
@@ -258,8 +264,17 @@ def test_labelled_loader_and_default_pretrain_recipe():
     random.seed(5)
     (img, img2, tgt, tgt2), names, (parts, scans) = next(iter(LabeledDeviceLoader(store, batch_size=6)))
     assert tuple(img.shape) == (6, 1, 224, 224) and tgt.dtype == torch.int64 and tuple(tgt.shape) == (6, 1, 224, 224)
-    assert img2 is img and tgt2 is tgt and len(names) == 6 and all(n.startswith(s) for n, s in zip(names, scans))
+    # SequentialWrapperTwice keeps total_freedom=True for the `label` recipes (semi_seg/augment.py:23-34): the second pair is an
+    # independent crop / rotation of the same slices
+    assert not torch.equal(img2, img) and not torch.equal(tgt2, tgt) and tuple(img2.shape) == tuple(img.shape)
+    assert len(names) == 6 and all(n.startswith(s) for n, s in zip(names, scans))
     assert int(tgt.min()) >= 0 and int(tgt.max()) <= 3
+    # total_freedom=False: one geometry; a recipe without image-only randomness then returns the same tensors twice, the
+    # `pretrain` recipe (what creator.get_data trains on, creator.py:30) a fresh colour jitter of the same geometry
+    (i1, i2, t1, t2), _, _ = next(iter(LabeledDeviceLoader(store, batch_size=4, total_freedom=False)))
+    assert torch.equal(i1, i2) and torch.equal(t1, t2)
+    (i1, i2, t1, t2), _, _ = next(iter(LabeledDeviceLoader(store, batch_size=4, recipe="acdc_pretrain", total_freedom=False)))
+    assert torch.equal(t1, t2) and not torch.equal(i1, i2) and tuple(i1.shape) == (4, 1, 224, 224)
     # label = floor(level / 64) in the store; both went through one geometry, the image bilinearly: away from class borders
     # (where the four neighbours agree) the relation still holds
     lv = torch.round(img * 255)
