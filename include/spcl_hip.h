@@ -13,7 +13,9 @@
  *  - work is enqueued on the caller's stream (hipStream_t passed as void*); no host sync, no allocation,
  *    no internal threads -> every call is hipGraph-capturable
  *  - activations are NHWC ("channels last"), channel count padded to a multiple of 16 (pad lanes hold 0)
- *  - dtype: SPCL_F32 = 0 (parity mode, exact-f32 MFMA), SPCL_BF16 = 1 (bf16 storage, f32 accumulate)
+ *  - dtype: SPCL_F32 = 0 (f32 storage: the parity mode; convolution products are f32-grade split-bf16 by default, exact-f32
+ *    MFMA on request -- spcl_conv_set_f32_split below), SPCL_BF16 = 1 (bf16 storage, f32 accumulate)
+ *  - the library reads NOTHING from the environment: every switch is an argument or a setter declared here
  */
 #ifndef SPCL_HIP_H
 #define SPCL_HIP_H
@@ -47,16 +49,18 @@ const char* spcl_last_error(void);
  * sp_mode 0 = no self-pacing (SupConLoss1), 1 = hard, 2 = soft;  gamma = age parameter
  * ws      workspace of spcl_supcon_workspace_bytes(n,d) bytes (f32 aligned); holds the padded projections,
  *         the per-row statistics kept for backward and the column-split partials
- * Three schedules, chosen by size (same results within the parity tolerance, same workspace contract):
+ * Three schedules, chosen by size alone (same results within the parity tolerance, same workspace contract):
  *   2n <= 64 (the training sizes): one workgroup, one launch -- forward scalars, row statistics and dLoss/dP for a unit
  *     upstream gradient (kept in ws; spcl_supcon_backward then is one scaling launch); exact-f32 MFMA, same k order as the
- *     sweeps.  SPCL_SUPCON_SWEEPS=1 forces the sweeps at any size;
+ *     sweeps;
  *   64 < 2n < 1024, or an explicit `mask`: the [2n,2n] matrix is never materialised; every sweep recomputes its S tiles on the
  *     exact-f32 MFMA (bitwise an fmaf chain) -- the training sizes are launch-latency bound either way;
- *   2n >= 1024 (labels / SimCLR modes): the logits are formed ONCE on the bf16 matrix pipe from the two-term split
- *     P = Ph + Pm (S ~ Ph Ph^T + Ph Pm^T + Pm Ph^T, logit error ~1e-5), written to ws as f32 [2n,2n] (rounded up to 128)
- *     with the row sums fused in; the self-paced pass and the backward's H = G + G^T then stream that matrix
- *     (SURVEY 8(d)'s "materialised" schedule: 67 MB at 2n = 4096).  SPCL_SUPCON_EXACT=1 forces the first schedule.
+ *   2n >= 1024 (labels / SimCLR modes, d <= 128, 2n a multiple of 256): the forward is FUSED -- two sweeps over the
+ *     similarity tiles (row sums first, then the weights that depend on them), each recomputing S on the bf16 matrix pipe from
+ *     the two-term split P = Ph + Pm (S ~ Ph Ph^T + Ph Pm^T + Pm Ph^T, logit error ~1e-5); no logits matrix is written or
+ *     read (SURVEY 8(d) prices this size against the materialised schedule's 205.5 MB; the fused forward's own HBM traffic is
+ *     a few MB).  The backward forms H = G + G^T tile by tile the same way.  Other large shapes (d > 128, ragged 2n) keep
+ *     the round-1 schedule: logits written once to ws as f32 [2n,2n], streamed by the later passes.
  * out     [8] f32: out[0]=loss out[1]=rho(downgrade ratio) out[2]=kappa(effective -dloss/drow scale)
  *                  out[3]=max|‖z‖-1| (is_normalized contract, contrast_loss3.py:20-22,154)
  */
@@ -216,9 +220,9 @@ int spcl_conv_num_tiles(int N, int H, int W);
  * pixel tiles above, except where the workgroup-level GEMM kernel runs (csrc/conv_gemm.hip: bf16, channel counts
  * multiples of 64 with one side >= 128, see spcl_conv_set_gemm), which writes one row per (image band, pixel part). */
 int spcl_conv_stat_rows(int dtype, int N, int H, int W, int CinK, int CoutS);
-/* Which kernel takes those layers: -1 (default, also SPCL_CONV_GEMM unset) the GEMM kernel only at image sizes the
- * per-wave kernels have no specialisation for (widths that do not tile by 14 columns: the 32^2 / 16^2 levels of 256^2
- * inputs), 1 (SPCL_CONV_GEMM=1) wherever it fits, 0 never.  Packed weights are valid under every setting. */
+/* Which kernel takes those layers: -1 (default) the GEMM kernel only at image sizes the per-wave kernels have no
+ * specialisation for (widths that do not tile by 14 columns: the 32^2 / 16^2 levels of 256^2 inputs), 1 wherever it fits,
+ * 0 never.  Packed weights are valid under every setting. */
 void spcl_conv_set_gemm(int mode);
 /* How the f32-storage convolutions (forward, data gradient, weight gradient: nn.Conv2d of unet.py:72,75 run in torch's default
  * float32, the north_star's "within fp32 tolerance" path) multiply: 1 (default) every f32 operand as the exact sum of three

@@ -65,6 +65,16 @@ def run_oracle(data, hyper=HYPER):
     """-> dict(pre_curve, ft_curve, dice_mean[C], dsc (DSC1..3, DSC_mean), val_loss)"""
     from spcl_amd.synthetic import acdc_like_meta
     h = hyper
+    # (eight threads: the tensors are small, and on the GPU box's 2 x 128 hardware threads torch's default pool is 16 x slower)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(8, threads))
+    try:
+        return _run_oracle(data, h, acdc_like_meta)
+    finally:
+        torch.set_num_threads(threads)
+
+
+def _run_oracle(data, h, acdc_like_meta):
     sd = O.init_unet_state(1, 4, h["max_channel"], seed=h["unet_seed"])
     psd = O.init_projector_state(h["max_channel"], 256, 256, seed=h["unet_seed"] + 1)
     osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
