@@ -95,8 +95,15 @@ class InfoNCEPretrainEpocher(PretrainEncoderEpocher):
     """old-API pre-train epocher: the projectors and criteria arrive through ``init()``, one (projector, criterion,
     contrast_on) triple per feature position, the regularisation is their importance-weighted average."""
 
-    def __init__(self, *, feature_names: Union[str, Sequence[str]], feature_importance=None, data_name="acdc", **kwargs):
-        kwargs.setdefault("inference_until", "Conv5")  # _mixins.py:262: the old mixin runs the encoder only
+    def __init__(self, *, feature_names: Union[str, Sequence[str]], feature_importance=None, data_name="acdc",
+                 dense_pool_method="adaptive_avg", **kwargs):
+        names = [feature_names] if isinstance(feature_names, str) else list(feature_names)
+        # _mixins.py:262 runs the encoder only; a decoder feature position (test/test_infonce.py:21: "Up_conv2") needs the
+        # network run that far: until = the deepest requested position
+        from ..arch.unet import UNet
+        order = list(UNet.arch_elements)
+        kwargs.setdefault("inference_until", max(names + ["Conv5"], key=order.index))
+        self._dense_pool_method = dense_pool_method  # config["ProjectorParams"]["DenseParams"]["pool_method"] (:501)
         super().__init__(**kwargs)
         self._feature_position = [feature_names] if isinstance(feature_names, str) else list(feature_names)
         self._feature_importance = list(feature_importance) if feature_importance is not None else \
@@ -191,9 +198,9 @@ class InfoNCEPretrainEpocher(PretrainEncoderEpocher):
     # ---- comparable.py:366-387, 415-450
     def generate_infonce(self, *, feature_name, features, projector, seed, partition_group, label_group):
         proj_tf_feature, proj_feature_tf = self.unlabeled_projection(features, projector, seed)
-        if not isinstance(projector, ProjectionHead):
-            raise NotImplementedError("dense InfoNCE of the old API (comparable.py:452-561): use the hook path "
-                                      "(INFONCEHook on a decoder feature)")
+        if not isinstance(projector, ProjectionHead):  # "it goes to a **dense** representation on pixels" (:380-387)
+            return self._dense_based_infonce(feature_name=feature_name, proj_tf_feature=proj_tf_feature,
+                                             proj_feature_tf=proj_feature_tf, projector=projector)
         assert proj_tf_feature.dim() == 2, proj_tf_feature.shape
         contrast_on = next(self._encoder_contrastive_name_generator)
         criterion = next(self._encoder_criterion_generator)
@@ -206,3 +213,32 @@ class InfoNCEPretrainEpocher(PretrainEncoderEpocher):
         else:
             labels = gen(partition_list=partition_group, patient_list=label_group)
         return criterion(proj_feature_tf, proj_tf_feature, target=labels)
+
+    # ---- comparable.py:452-533: the dense branch.  Every pixel of the (pooled) dense projection is its own class, its
+    # positive the same pixel of the other view (``SupConLoss1`` without target: SimCLR identity positives).  The reference
+    # asks ``is_normalized`` (a device -> host readback) whether to normalise; here that is known from how the map was made:
+    # a head that normalises hands over unit pixels, a pooling that changes the size breaks them.
+    dense_output_size = (12, 12)  # comparable.py:500
+
+    def _dense_based_infonce(self, *, feature_name, proj_tf_feature, proj_feature_tf, projector):
+        from ... import functional as F_hip
+        unit = bool(getattr(projector, "_normalize", False))
+        if "Conv" in feature_name:  # _dense_infonce_for_encoder (:471-492): no spatial neighbourhood, pixels as they come
+            def rows(x):
+                x = x if unit else F_hip.l2norm_channels(x)  # Normalize(dim=2) of the [b, hw, c] view
+                return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1])  # _reshape_dense_feature + reshape(-1, c)
+            return self._normal_criterion(rows(proj_feature_tf), rows(proj_tf_feature))
+        assert "Up" in feature_name, feature_name  # _dense_infonce_for_decoder (:494-513)
+        if self._dense_pool_method not in ("adaptive_avg", "adaptive_max"):
+            raise NotImplementedError(f"dense pool_method {self._dense_pool_method!r}: adaptive_avg / adaptive_max are on the "
+                                      "HIP path (the reference's third choice, bilinear resizing, is not)")
+
+        def tailored(x):  # _dense_featuremap_tailoring (:515-532): resize to 12 x 12, unit pixels
+            if tuple(x.shape[2:]) != tuple(self.dense_output_size):
+                x = F_hip.adaptive_pool2d(x, self.dense_output_size, "max" if self._dense_pool_method == "adaptive_max" else "avg")
+                return F_hip.l2norm_channels(x)
+            return x if unit else F_hip.l2norm_channels(x)
+
+        def rows(x):
+            return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1])
+        return self._normal_criterion(rows(tailored(proj_tf_feature)), rows(tailored(proj_feature_tf)))

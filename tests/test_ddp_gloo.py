@@ -1,5 +1,6 @@
-"""CPU-only, world_size 2 over gloo: the N>1 exchange step (flat gradient bucket all-reduce, parameter/buffer
-broadcast, flat-parameter optimizer) behaves like single-process training on the concatenated batch."""
+"""CPU-only, world sizes 2 / 4 / 8 over gloo: the N>1 exchange step (flat gradient bucket all-reduce, parameter/buffer
+broadcast, flat-parameter optimizer, sum + ``grad_scale`` folding, the two-bucket overlap with even and uneven splits) behaves
+like single-process training on the concatenated batch."""
 import os
 import socket
 
@@ -33,7 +34,7 @@ def _worker(rank, world, port, q):
     assert flat.param.data_ptr() == next(model.parameters()).data_ptr()
     opt = torch.optim.SGD([flat.param], lr=0.1)
     g = torch.Generator().manual_seed(7)
-    X, Y = torch.randn(8, 6, generator=g), torch.randn(8, 2, generator=g)
+    X, Y = torch.randn(4 * world, 6, generator=g), torch.randn(4 * world, 2, generator=g)
     xs, ys = X[rank * 4:(rank + 1) * 4], Y[rank * 4:(rank + 1) * 4]
     model.eval()  # BN in eval so that per-rank statistics do not enter the comparison
     flat.zero_grad()
@@ -54,7 +55,7 @@ def _worker(rank, world, port, q):
     ((model(xs) - ys) ** 2).mean().backward()
     flat.fold_mean = False
     mean = flat.reduce().clone()
-    assert flat.grad_scale == 1.0 and torch.equal(summed * 0.5, mean)
+    assert flat.grad_scale == 1.0 and torch.equal(summed * (1.0 / world), mean)  # (world sizes are powers of two: exact)
     for p_ in model.parameters():
         p_.grad = None
     # plain GradBucket gives the same averaged gradients
@@ -69,30 +70,33 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(120)
-def test_flat_bucket_allreduce_matches_single_process():
-    world, port = 2, _free_port()
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_flat_bucket_allreduce_matches_single_process(world):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=90) for _ in range(world)], key=lambda t: t[0])
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
-        p.join(30)
+        p.join(60)
         assert p.exitcode == 0
     res = [(r, torch.tensor(a), torch.tensor(b), torch.tensor(c), torch.tensor(d), m) for r, a, b, c, d, m in res]
-    (r0, w0a, g0, p0, mg0, master0), (r1, w0b, g1, p1, mg1, master1) = res
-    assert torch.equal(w0a, w0b)            # broadcast equalised the initial weights
-    assert torch.allclose(g0, g1)           # every rank holds the same averaged gradient
-    assert torch.allclose(p0, p1)           # and the same updated parameters
-    assert master0 and not master1
-    assert torch.allclose(mg0, torch.full((2, 3), 1.5)) and torch.allclose(mg0, mg1)  # mean of 1 and 2
-    # single-process reference on the concatenated batch: mean over 8 samples == mean of the two rank means
+    r0, w0a, g0, p0, mg0, master0 = res[0]
+    assert master0
+    for r1, w0b, g1, p1, mg1, master1 in res[1:]:
+        assert torch.equal(w0a, w0b)            # broadcast equalised the initial weights
+        assert torch.allclose(g0, g1)           # every rank holds the same averaged gradient
+        assert torch.allclose(p0, p1)           # and the same updated parameters
+        assert not master1 and torch.allclose(mg0, mg1)
+    assert torch.allclose(mg0, torch.full((2, 3), (world + 1) / 2.0))  # mean of 1 .. world
+    # single-process reference on the concatenated batch: mean over 4 x world samples == mean of the rank means
     torch.manual_seed(100)
     model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.BatchNorm1d(5), torch.nn.Linear(5, 2)).eval()
     g = torch.Generator().manual_seed(7)
-    X, Y = torch.randn(8, 6, generator=g), torch.randn(8, 2, generator=g)
+    X, Y = torch.randn(4 * world, 6, generator=g), torch.randn(4 * world, 2, generator=g)
     ((model(X) - Y) ** 2).mean().backward()
     ref = torch.cat([p.grad.flatten() for p in model.parameters()])
     assert torch.allclose(g0, ref, atol=1e-6)
@@ -111,7 +115,7 @@ def test_single_process_paths_are_noops():
     assert flat.numel() == 15 and torch.equal(m.weight.grad, g) and m.weight.grad.data_ptr() == b.views[0].data_ptr()
 
 
-def _overlap_worker(rank, world, port, q):
+def _overlap_worker(rank, world, port, q, early_layer=2):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import copy
@@ -131,15 +135,17 @@ def _overlap_worker(rank, world, port, q):
         if overlap:
             # members are in module order: the early bucket is the TAIL (what backward finishes first); it starts when the
             # gradient w.r.t. the first layer's output exists, i.e. once everything after that layer is differentiated
-            flat.overlap_from(model[2].weight)
-            model[0].register_full_backward_pre_hook(
+            # (early_layer 4: an UNEVEN split -- only the last layer's 10 values go early, the other 59 wait for the end)
+            flat.overlap_from(model[early_layer].weight)
+            model[early_layer - 2].register_full_backward_pre_hook(
                 lambda m, go, flat=flat: (fired.append(flat._early is None), flat.reduce_early())[0] and None)
         for step in range(2):  # two steps: the per-step state is reset
             flat.zero_grad()
             ((model(xs * (step + 1)) - ys) ** 2).mean().backward()
             if overlap:
                 assert flat._early is not None  # the hook started the early bucket during backward
-                assert model[0].weight.grad is not None
+                assert model[0].weight.grad is not None and flat._early_off == sum(
+                    p.numel() for m in list(model)[:early_layer] for p in m.parameters())
             red = flat.reduce().clone()
             assert flat._early is None and flat.param.grad is flat.flat
             out.append(red.tolist())
@@ -148,24 +154,29 @@ def _overlap_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.timeout(120)
-def test_two_bucket_overlap_equals_the_flat_allreduce():
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,early_layer", [(2, 2), (2, 4), (4, 2), (8, 4)])
+def test_two_bucket_overlap_equals_the_flat_allreduce(world, early_layer):
     """ddp.FlatParams.overlap_from / reduce_early (projector + Conv5..Conv3 early, Conv2..Conv1 late): the
     tail of the bucket is all-reduced asynchronously from a backward hook, the head after backward; same averaged
     gradients as the one-bucket reduce, bit for bit at world size 2, on every rank and in every step."""
-    world, port = 2, _free_port()
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, q, early_layer)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=90) for _ in range(world)], key=lambda t: t[0])
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
-        p.join(30)
+        p.join(60)
         assert p.exitcode == 0
     for rank, out, fired in res:
         plain, bucketed = out[:2], out[2:]
-        assert plain == bucketed            # step by step, element by element
+        if world == 2:
+            assert plain == bucketed        # step by step, element by element (two addends: one order)
+        else:                               # (gloo's ring adds a slice's addends in an order that depends on its length)
+            assert torch.allclose(torch.tensor(plain), torch.tensor(bucketed), rtol=1e-6, atol=1e-7)
         assert fired == [True, True]        # the hook ran once per step and found the early bucket not yet started
-    assert res[0][1] == res[1][1]           # both ranks hold the same averaged gradients
+    for other in res[1:]:
+        assert res[0][1] == other[1]        # every rank holds the same averaged gradients
     assert any(v != 0.0 for v in res[0][1][0])

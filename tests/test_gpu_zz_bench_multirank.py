@@ -26,7 +26,7 @@ def _free_port():
     return p
 
 
-def _run_two_ranks(tmp_path, cmd):
+def _run_two_ranks(tmp_path, cmd, n=2):
     env = dict(os.environ, SPCL_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", SPCL_BENCH_WATCHDOG_S="60",
                SPCL_BENCH_DDP_CHECK="1")
     env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
@@ -55,15 +55,17 @@ def _run_two_ranks(tmp_path, cmd):
     lines = [ln for ln in out.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out[-2000:]  # rank 0 only
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak"
-    assert line["config"]["hipgraph"] == "epocher-split" and line["config"]["global_batch"] == 8
+    assert line["n_gpus"] == n and line["steps"] == 2 and line["scaling"] == "weak"
+    assert line["config"]["hipgraph"] == "epocher-split" and line["config"]["global_batch"] == 4 * n
     assert line["value"] > 0 and line["final_meters"]["loss"] == line["final_meters"]["loss"]  # finite loss
-    chk = line["ddp_check"]  # the collective left the mean of the two ranks' (different) gradients in the bucket
-    assert chk["max_abs_diff_vs_mean_of_rank_gradients"] == 0.0 and chk["max_abs_diff_between_ranks"] > 0.0
+    chk = line["ddp_check"]  # the collective left the mean of the ranks' (different) gradients in the bucket
+    # (two addends have one order: exact; from three on the collective's order is its own)
+    assert chk["max_abs_diff_vs_mean_of_rank_gradients"] <= (0.0 if n == 2 else 1e-6 * chk["grad_abs_max"])
+    assert chk["max_abs_diff_between_ranks"] > 0.0
     assert chk["grad_abs_max"] > 0.0
     assert line["roofline"] is not None and line["roofline"]["frac"] > 0 and "cpu_baseline" not in line
     mg = line["multi_gpu"]  # every rank's own step time and the collective alone (diagnosable on first contact)
-    assert len(mg["per_rank_ms_per_step"]) == 2 and all(v > 0 for v in mg["per_rank_ms_per_step"])
+    assert len(mg["per_rank_ms_per_step"]) == n and all(v > 0 for v in mg["per_rank_ms_per_step"])
     assert max(mg["per_rank_ms_per_step"]) <= line["ms_per_step"] * 1.001 and mg["allreduce_us"] > 0
     return line
 
@@ -83,3 +85,12 @@ def test_plain_bench_gpus_2_spawns_its_own_ranks(tmp_path):
     process itself (before any GPU call), forwards rank 0's line and the exit code -- it must not silently measure one
     GPU and print n_gpus: 1 (VERDICT r03 missing #1; reference seam: semi_seg/main_infonce.py:35,39)."""
     _run_two_ranks(tmp_path, [sys.executable, os.path.join(REPO, "bench.py")] + BENCH_ARGS)
+
+
+def test_bench_four_ranks_on_one_device(tmp_path):
+    """the same control flow at world size 4 (nothing beyond two ranks had ever run): four ranks share cuda:0"""
+    args = [a if a != "2" or i != 1 else "4" for i, a in enumerate(BENCH_ARGS)]
+    assert args[:2] == ["--gpus", "4"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(REPO, "bench.py")] + args
+    _run_two_ranks(tmp_path, cmd, n=4)
