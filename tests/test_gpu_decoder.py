@@ -259,6 +259,9 @@ def test_upsample2x_and_concat_match_torch(dt, N, C, H, W):
         assert torch.equal(a_d.grad.cpu(), r2[:, :C]) and torch.equal(b_d.grad.cpu(), r2[:, C:])
 
 
+SPLIT_SLACK_CAP = 5e-2
+
+
 @pytest.mark.parametrize("f32_products", ["exact", "split"])
 def test_full_unet_base_width_vs_oracle_fp32(f32_products):
     """max_channel=256 (all channel counts multiples of 16: HIP concatenation / upsample path) on a small image: logits
@@ -300,7 +303,10 @@ def _full_unet_base_width_body(f32_products):
     ref_logits, ref_loss, sdo = oracle(x)
     slack = 0.0
     if f32_products == "split":
-        slack = 3.0 * oracle_sensitivity((x,), lambda x_: {k: oracle(x_)[2][k].grad.numpy() for k in keys})
+        # capped (a bar derived from the failure it excuses pins nothing): what the cap cannot cover is
+        # covered without ties by test_f32_split_and_exact_products_agree_call_by_call and, against fp64 on a network whose
+        # statistics span > 1 000 values, by test_full_unet_wide_statistics_vs_fp64_oracle_fp32 below
+        slack = min(SPLIT_SLACK_CAP, 3.0 * oracle_sensitivity((x,), lambda x_: {k: oracle(x_)[2][k].grad.numpy() for k in keys}))
     logits = m(x.cuda())
     assert _relerr(logits.detach().cpu().numpy(), ref_logits.detach().numpy()) < 2e-3
     loss = F.kl_div(F.softmax_classes(logits), F.one_hot_classes(labels.cuda(), 4))
@@ -311,6 +317,114 @@ def _full_unet_base_width_body(f32_products):
         # tiny batch statistics in the deepest layers amplify fp32 summation-order differences: 3e-2 of max
         assert _relerr(params[k].grad.cpu().numpy(), sdo[k].grad.numpy()) < max(3e-2, slack), (k, _relerr(
             params[k].grad.cpu().numpy(), sdo[k].grad.numpy()), slack)
+
+
+def test_f32_split_and_exact_products_agree_call_by_call():
+    """Tie-independent half of the f32 product-mode parity: EVERY convolution, concatenating convolution and weight-gradient
+    call of one fine-tune step of the small full UNet (forward and backward), run under both modes ON THE SAME INPUTS -- no
+    ReLU / max-pool decision lies between the two results of a call, so they must agree to f32 rounding: outputs and
+    BatchNorm statistics rows within 2e-6 of the largest element (six bf16 products per element drop terms below 2^-24)."""
+    import spcl_amd  # noqa
+    from spcl_amd import functional as Fn
+    from spcl_amd import native as _nat
+    from spcl_amd.semi_seg.arch import UNet
+    sd = O.init_unet_state(1, 4, 256, seed=5)
+    m = UNet(input_dim=1, num_classes=4, max_channel=256)
+    m.load_state_dict(sd, strict=True)
+    m.cuda().train()
+    m.set_compute_dtype(torch.float32)
+    g = torch.Generator().manual_seed(6)
+    x = torch.rand(2, 1, 64, 64, generator=g)
+    labels = torch.randint(0, 4, (2, 64, 64), generator=g)
+    seen, worst = [], [("", 0.0)]
+
+    def rel(a, b):
+        return float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+
+    def both(fn, name):
+        def wrapped(*a, **k):
+            out = fn(*a, **k)
+            _nat.call("spcl_conv_set_f32_split", 0)
+            try:
+                ref = fn(*a, **k)
+            finally:
+                _nat.call("spcl_conv_set_f32_split", 1)
+            o, r = (out[0] if isinstance(out, tuple) else out), (ref[0] if isinstance(ref, tuple) else ref)
+            if torch.is_tensor(o) and o.dtype == torch.float32:
+                e = rel(o, r)
+                seen.append((name, tuple(o.shape), e))
+                worst[0] = max(worst[0], (f"{name}{tuple(o.shape)}", e), key=lambda t: t[1])
+            if isinstance(out, tuple) and len(out) > 1 and torch.is_tensor(out[1]) and hasattr(out[1], "ntiles"):
+                cs = out[0].shape[-1]
+                sa = out[1][:out[1].ntiles * 3 * cs].view(-1, 3, cs)
+                sb = ref[1][:ref[1].ntiles * 3 * cs].view(-1, 3, cs)
+                for comp, nm in ((1, "mean"), (2, "M2")):
+                    e = rel(sa[:, comp], sb[:, comp])
+                    seen.append((name + "." + nm, tuple(sa.shape), e))
+                    worst[0] = max(worst[0], (f"{name}.{nm}{tuple(o.shape)}", e), key=lambda t: t[1])
+            return out
+        return wrapped
+
+    names = [n for n in ("_conv", "_wgrad", "_conv_cat", "_wgrad_up2", "_wgrad_cat") if hasattr(Fn, n)]
+    saved = {n: getattr(Fn, n) for n in names}
+    _nat.call("spcl_conv_set_f32_split", 1)
+    try:
+        for n in names:
+            setattr(Fn, n, both(saved[n], n))
+        logits = m(x.cuda())
+        loss = Fn.kl_div(Fn.softmax_classes(logits), Fn.one_hot_classes(labels.cuda(), 4))
+        loss.backward()
+    finally:
+        for n in names:
+            setattr(Fn, n, saved[n])
+        _nat.call("spcl_conv_set_f32_split", 1)
+    kinds = {n for n, _, _ in seen}
+    assert len(seen) >= 60 and {"_conv", "_wgrad"} <= kinds, (len(seen), kinds)  # 23 convolutions x (forward, dgrad, wgrad)
+    assert worst[0][1] <= 2e-6, worst[0]
+    print(f"\n[f32 modes] {len(seen)} calls compared, worst {worst[0][0]}: {worst[0][1]:.2e}")
+
+
+def test_full_unet_wide_statistics_vs_fp64_oracle_fp32():
+    """The other tie-independent half: a fine-tune step of the full UNet whose SMALLEST batch statistic spans 16 x 8 x 8 =
+    1 024 values (16 slices of 128 x 128), default f32 product mode (split-bf16), against the oracle evaluated in fp64 --
+    logits, loss and a sample of gradients from every depth at the bars the exact-f32 path is held to on the small network
+    (gradients 5e-3 of the tensor's largest element).  With this many values per statistic no single ReLU / max-pool decision
+    moves a tensor."""
+    import spcl_amd  # noqa
+    from spcl_amd import functional as F
+    from spcl_amd import native as _nat
+    from spcl_amd.semi_seg.arch import UNet
+    assert _nat.call("spcl_conv_get_f32_split") == 1
+    sd = O.init_unet_state(1, 4, 256, seed=15)
+    m = UNet(input_dim=1, num_classes=4, max_channel=256)
+    m.load_state_dict(sd, strict=True)
+    m.cuda().train()
+    m.set_compute_dtype(torch.float32)
+    g = torch.Generator().manual_seed(16)
+    x = torch.rand(16, 1, 128, 128, generator=g)
+    labels = torch.randint(0, 4, (16, 128, 128), generator=g)
+    keys = ("_Deconv_1x1.weight", "_Up_conv2.conv.0.weight", "_Up2.up.1.weight", "_Up_conv5.conv.3.weight",
+            "_Up5.up.2.weight", "_Conv5.conv.0.weight", "_Conv1.conv.0.weight", "_Conv3.conv.4.bias", "_Conv4.conv.3.weight",
+            "_Up_conv3.conv.1.weight")
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(16, threads))
+    try:
+        sdo = {k: (v.double().requires_grad_(True) if v.is_floating_point() and "running" not in k else
+                   (v.double() if v.is_floating_point() else v.clone())) for k, v in sd.items()}
+        ref_logits = O.unet_forward(x.double(), sdo, None, train=True)
+        ref_loss = O.finetune_loss(ref_logits, labels)
+        ref_loss.backward()
+    finally:
+        torch.set_num_threads(threads)
+    logits = m(x.cuda())
+    assert _relerr(logits.detach().cpu().numpy(), ref_logits.detach().numpy()) < 1e-4
+    loss = F.kl_div(F.softmax_classes(logits), F.one_hot_classes(labels.cuda(), 4))
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) < 1e-5 * abs(float(ref_loss.detach()))
+    loss.backward()
+    params = dict(m.named_parameters())
+    errs = {k: _relerr(params[k].grad.cpu().numpy(), sdo[k].grad.numpy()) for k in keys}
+    assert max(errs.values()) < 5e-3, errs
+    print(f"\n[wide statistics, split-bf16 vs fp64] worst gradient {max(errs, key=errs.get)}: {max(errs.values()):.2e}")
 
 
 @pytest.mark.parametrize("N,S", [(2, 224), (3, 112), (2, 128), (1, 256)])

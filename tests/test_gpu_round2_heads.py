@@ -189,7 +189,9 @@ def _dense_infonce_hook_step_body(f32_products):
     ref, osd, opsd = oracle(img, img_tf)
     np.testing.assert_allclose(float(loss.detach()), float(ref.detach()), rtol=2e-4)
     # (split: what a 2e-6 perturbation of the images does to the oracle's own gradients bounds what can be asked)
-    slack = 3.0 * oracle_sensitivity((img, img_tf), oracle_grads) if f32_products == "split" else 0.0
+    # capped at 5e-2; the tie-independent checks of the two product modes are
+    # tests/test_gpu_decoder.py::test_f32_split_and_exact_products_agree_call_by_call / ..._wide_statistics_vs_fp64_oracle_fp32
+    slack = min(5e-2, 3.0 * oracle_sensitivity((img, img_tf), oracle_grads)) if f32_products == "split" else 0.0
     rel = lambda u, v: float(np.abs(u - v).max() / max(1e-30, np.abs(v).max()))  # noqa: E731
     checked = 0
     for k, p in net.named_parameters():
