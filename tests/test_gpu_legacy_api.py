@@ -112,7 +112,10 @@ def test_old_api_dense_branch_vs_oracle_fp32():
     wrapper.cuda()
     assert wrapper.feature_names == ["Conv5", "Conv5", "Up_conv2"]
     heads = [{k: v.detach().cpu().clone() for k, v in p.state_dict().items()} for p in wrapper]
-    flat = ddp.FlatParams(list(net.parameters()) + list(wrapper.parameters()))
+    with net.set_grad(False, start="Up_conv2", include_start=False):  # the bucket holds what the step reaches (ddp.GradBucket)
+        flat = ddp.FlatParams([p for p in net.parameters() if p.requires_grad] + list(wrapper.parameters()))
+    for name in ("Deconv_1x1",):
+        getattr(net, "_" + name).requires_grad_(False)
     g = torch.Generator().manual_seed(14)
     img, img_tf = torch.rand(bs, 1, 32, 32, generator=g), torch.rand(bs, 1, 32, 32, generator=g)
     filenames, partitions, groups = acdc_like_meta(bs)
