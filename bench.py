@@ -16,6 +16,9 @@ backward -> (flat RCCL gradient all-reduce when N>1) -> RAdam step.  bf16 storag
 Extra objects in the line:
   roofline      the dominant kernel call of the step, timed live with HIP events on its own stream in an instrumented
                 pass right after the timed region; algorithmic bytes/FLOPs per launch as defined in DESIGN.md
+  roofline_family  the same for the kernel FAMILY (all template instantiations of one __global__ together) with the largest
+                share of the step -- the 17 per-layer instantiations of conv3x3_fast_kernel, ~45 % of the step --: sum of the
+                launches' own bounds / their summed time
   cpu_baseline  the CPU oracle's restatement of the same step ("port"), timed on this box's host cores (rank 0, N=1)
 """
 import argparse
@@ -415,6 +418,29 @@ def measure_roofline(step, args, phases=False, graph=False):
     fr = phase_fractions(launches, marks, reps, args)
     fr["top3"] = top3
     fr["launch_tax"] = tax
+    # ---- by kernel FAMILY (all template instantiations of one __global__ together): the ranking by symbol splits
+    # conv3x3_fast_kernel<...> into its ~17 per-layer instantiations, none of which can be "dominant", although together they
+    # own ~45 % of the step.  frac = sum over the family's launches of max(bytes / 8 TB/s, FLOPs / peak)
+    # / their summed time: each launch against the roofline that bounds IT.
+    fams = {}
+    for sym, g in groups.items():
+        f = fams.setdefault(sym.split("<")[0], {"t": 0.0, "n": 0, "roof": 0.0, "hbm_t": 0.0, "mfma_t": 0.0, "bytes": 0.0,
+                                                 "flops": 0.0, "members": 0, "hbm_launch_t": 0.0})
+        for k in ("t", "n", "roof", "hbm_t", "mfma_t", "bytes", "flops"):
+            f[k] += g[k]
+        f["members"] += 1
+    fam_rank = sorted(((k, f) for k, f in fams.items() if f["roof"] > 0), key=lambda kv: -kv[1]["t"])
+
+    def fam_row(k, f):
+        return {"family": k, "instantiations": f["members"], "launches_per_step": f["n"] / reps,
+                "us_per_step": round(f["t"] / reps * 1e6, 1), "share_of_instrumented_step": round(f["t"] / reps / total, 4),
+                "bound_us_per_step": round(f["roof"] / reps * 1e6, 1), "frac": round(f["roof"] / f["t"], 4),
+                "GBps": round(f["bytes"] / f["t"] / 1e9, 0), "mfma_tflops": round(f["flops"] / f["t"] / 1e12, 1)}
+    if fam_rank:
+        top = fam_row(*fam_rank[0])
+        top.update({"bound": "mixed (per launch: max(algorithmic bytes / 8 TB/s, FLOPs / dense peak))",
+                    "others": [fam_row(k, f) for k, f in fam_rank[1:6]], "timing_source": source})
+        fr["roofline_family"] = top
     return out, breakdown, total, fr
 
 
@@ -762,6 +788,8 @@ def main():
                     # 224^2, bf16), x 3 for forward + input gradient + weight gradient, against the TIMED step
                     fractions["step_survey_frac"] = round(3.0 * enc["survey_bound_us"] * 1e-3 / ms, 4)
                     fractions["step_survey_bound_us"] = round(3.0 * enc["survey_bound_us"], 1)
+                if "roofline_family" in fractions:  # beside `roofline`, at the top level of the line
+                    line["roofline_family"] = fractions.pop("roofline_family")
                 line.setdefault("extra", {}).update(fractions)
         except Exception as e:  # noqa: BLE001
             line["roofline"] = None

@@ -7,3 +7,5 @@ for t in e["top3"]: print((t["kernel"][:50], t["us_per_step"], t["launches_per_s
 print(e["launch_tax"]); print(e.get("step_survey_frac"), e.get("step_survey_bound_us"), e.get("fp32_step"))
 print(e["encoder_fwd"]["t_us"], {k:(v["us"],v["TFLOPs"]) for k,v in e["encoder_fwd"]["per_layer"].items()})
 print(e.get("contrastive_4096x128"))
+f=d.get("roofline_family")
+if f: print({k:f[k] for k in ("family","instantiations","launches_per_step","us_per_step","share_of_instrumented_step","bound_us_per_step","frac")}); [print("   ", (o["family"], o["us_per_step"], o["frac"])) for o in f["others"]]
