@@ -1723,10 +1723,13 @@ class _ConvBlockFn(torch.autograd.Function):
                 dxs = torch.empty(N, H, W, cin_s, dtype=dtype, device=dya.device)
                 if (li.acc is not None and _n.call("spcl_conv_dgrad_poolstats_acc_supported", dtc, N, H, W, cout_s, cin_s,
                                                    li.H, li.W)):
-                    # ... added to the producing block's accumulator block (zeroed with its forward): no rows, no finalize
+                    # ... added to the producing block's accumulator block (zeroed with its forward): no rows, no finalize.
+                    # Taken ONCE, like ``_take_acc``: the block is zero only for the first backward after its forward; a second
+                    # backward through the same graph (retain_graph=True) finds None here and writes rows
+                    acc_in, li.acc = li.acc, None
                     _n.call("spcl_conv3x3_dgrad_poolstats_acc", _n.ptr(dya), dtc, N, H, W, cout_s, cin_s, _n.ptr(wpa_t),
                             _n.ptr(dxs), _n.ptr(li.yb), li.H, li.W, _n.ptr(li.stb[2]), _n.ptr(li.stb[3]), _n.ptr(li.stb[0]),
-                            _n.ptr(li.acc), _n.stream())
+                            _n.ptr(acc_in), _n.stream())
                     rows = ACC_ROWS
                 else:
                     nt = _n.call("spcl_conv_stat_rows", dtc, N, H, W, cout_s, cin_s)

@@ -78,6 +78,11 @@ class FusedRAdam(torch.optim.Optimizer):
         b1, b2 = group["betas"]
         return radam_coefficients(t, float(group["lr"]), float(b1), float(b2))
 
+    def forget_staged_steps(self):
+        """drop the host mirrors of the step counts: a staged step whose update launch did not happen left them one ahead of
+        the device counters (``_staged_coef`` advances at fill time); the next staged step reads the device's counts back"""
+        self._step_host.clear()
+
     @torch.no_grad()
     def sync_lr(self):
         """push the groups' current learning rates to the device (outside graph capture)."""

@@ -233,6 +233,13 @@ class PretrainEncoderEpocher:
             if self._step_graph.captured:
                 for h in self._hooks:
                     h.after_replay()
+        except BaseException:
+            # ``stage.begin`` advanced the optimizer's host mirror of the step count; if the update launch did not follow
+            # (a criterion's check raised, a hook aborted the step) the mirror is ahead of the device counter: drop it, the
+            # next staged step reads the device's count back
+            if hasattr(self._optimizer, "forget_staged_steps"):
+                self._optimizer.forget_staged_steps()
+            raise
         finally:
             self.stage.end()
         return loss

@@ -540,3 +540,30 @@ def test_rows_into_a_block_equal_rows_plus_finalize(pool, N, C, H, W, nrows):
     # (a workgroup folds its rows in float before it adds: the block's totals are the rows' sums to float rounding)
     ref = rows[:, 0].double().sum(0).cpu().numpy()
     np.testing.assert_allclose(s1, ref, rtol=2e-5, atol=2e-6 * float(np.abs(ref).max()))
+
+
+def test_second_backward_through_the_same_graph_falls_back_to_rows():
+    """``loss.backward(retain_graph=True)`` twice: an accumulator block is zero only for the first backward after
+    its forward -- both its producer (``_take_acc``) and the next block's input-gradient kernel (``PoolLink.acc``) take it once;
+    the second backward takes the rows + finalize path and must give the same gradients (two correct reductions of the same
+    sums: bf16 rounding of the intermediate gradients aside)."""
+    import spcl_amd  # noqa
+    from oracle import spcl_oracle as O
+    from spcl_amd.semi_seg.arch import UNet
+    net = UNet(input_dim=1, num_classes=4, max_channel=256)
+    net.load_state_dict(O.init_unet_state(1, 4, 256, seed=3), strict=True)
+    net.cuda().train()
+    net.set_compute_dtype(torch.bfloat16)
+    g = torch.Generator().manual_seed(8)
+    x = torch.rand(4, 1, 224, 224, generator=g).cuda()
+    r = torch.randn(4, 256, 14, 14, generator=g).cuda()
+    loss = (net(x, until="Conv5").float() * r).sum()
+    enc = [(k, p) for k, p in net.named_parameters() if k.startswith("_Conv")]
+    loss.backward(retain_graph=True)
+    first = {k: p.grad.detach().clone() for k, p in enc}
+    for _, p in enc:
+        p.grad = None
+    loss.backward()  # (raised 'null pointer' from spcl_bnrelu_backward_acc before the fix)
+    for k, p in enc:
+        a, b = p.grad.double(), first[k].double()
+        assert torch.isfinite(a).all() and float((a - b).norm() / b.norm().clamp_min(1e-30)) < 2e-2, k

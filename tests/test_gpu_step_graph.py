@@ -121,6 +121,9 @@ def test_replay_reports_nan_like_the_eager_step():
     with pytest.raises((RuntimeError, AssertionError)):
         with ep.meters.focus_on(ep.meter_focus):
             ep.step(batches[4])
+    # a staged step that raised drops the optimizer's host mirror of the step count (it advances at fill time, before it is
+    # known whether the update launch follows: ADVICE r05); the device counter is the authority -- here the replay did run
+    assert not opt._step_host and int(opt.state[flat.param]["step"].item()) == 5
 
 
 def test_ragged_batch_runs_eagerly_and_graph_survives():
