@@ -1178,8 +1178,18 @@ __global__ __launch_bounds__(512) void supcon_logits2_kernel(SupconArgs a, const
 //  * class ids of own and streamed rows (written by the prep kernel: positives = equal class id) and, in PASS 1, the
 //    CSB row-sum partials of the own rows come the same way: log D_i is formed in the prologue, there is no finishing
 //    launch between the sweeps.
+//  * round 6: the streamed tiles go through a ring of FOUR images (the two staging images of the own rows join it once
+//    those are in registers: at up to four tiles per workgroup -- 2n = 4096 on 256 CUs -- no image is ever reused) and
+//    are handed over by counting words in LDS (full[k] / done[k], see the kernel) instead of one workgroup barrier per
+//    tile.  Measured (profiles/r06_experiments/NOTES.md): with the barrier the loop ran at 1.52x its matrix time; with
+//    no synchronisation at all (wrong results) at 1.00x; with the words at 1.27x (sweep 0) / 1.34x (sweep 1) -- the two
+//    waves of a SIMD now run one behind the other, half a tile apart, instead of stalling together.  Also measured and
+//    NOT kept: the own rows' mid split by direct fragment loads (one memory round trip instead of two: the 32 lines a
+//    load touches cost the prologue 1.3 us more than the round trip saved), a fixed start-up delay of the second wave
+//    of each SIMD (+3 %), two alternating accumulators per half tile (+3 %: back-to-back accumulation is not a stall).
 // All global->LDS traffic is inline-asm DMA, so the only compiler-visible vector loads are the row norms of the
-// max-logit scan, issued FIRST and consumed after the last explicit wait: hipcc's own waits never drain the ring.
+// max-logit scan (and, PASS 1, the count partials of the own rows), issued FIRST and consumed after the last explicit
+// wait: hipcc's own waits never drain the ring.
 // Instruction order of one "products | stats" block: per 16 features two fragment reads (one step ahead of their
 // MFMAs), three MFMAs, and NV vector instructions of the statistics behind each MFMA; whatever is left follows.
 template <int KS, int NV, int XR>
@@ -1223,16 +1233,24 @@ __global__ __launch_bounds__(512) void supcon_tiles_kernel(const bf16_t* __restr
   static_assert(GROUPS % 8 == 0 && 8 * APW * 1024 == 2 * TILE_BYTES, "staging = ring image 2 + one more image");
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds_b[];
   const unsigned lds_base = (unsigned)(uintptr_t)(unsigned char __attribute__((address_space(3)))*)lds_b;
-  // [3 ring images][1 more image: with image 2 the staging of the own rows, 32 rows x DP bf16 per wave]
+  // [4 ring images; 2 and 3 are first the staging of the own rows' hi split, 32 rows x DP bf16 per wave]
   const float* owncls = (const float*)(lds_b + 4 * TILE_BYTES);  // [256] class ids of this block's own rows
   const float* tilecls = owncls + 256;                           // [MAXT * 64] class ids of the streamed rows
   const float* dpart = tilecls + MAXT * 64;                      // [CSB][256] row-sum partials of the own rows
   __shared__ float red[8];
+  // tile hand-off words (round 6): full[k] counts the waves whose pieces of this workgroup's k-th tile have landed, done[k]
+  // the waves that have read that tile for the last time.  They replace the workgroup barrier of every tile: with a barrier
+  // per tile the two waves of a SIMD restart in phase each time and stall TOGETHER on every fragment read, accumulator
+  // drain and barrier -- the loop ran at 1.52x its matrix time (18.7 k cycles for 12.3 k of MFMA per SIMD at 4 tiles per
+  // workgroup; without any synchronisation, wrong results: 12.2 k) -- while waves that only wait for what they really
+  // need drift apart and fill each other's stalls.
+  __shared__ unsigned tsync[2 * SUPCON_TILES_MAXT];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n32 = lane & 31, kh = lane >> 5;
   const int I0 = blockIdx.x * 256 + wave * 32;
   const float inv_t = 1.f / t;
   const int ntiles = N2p / 64;
+  if (threadIdx.x < 2 * SUPCON_TILES_MAXT) tsync[threadIdx.x] = 0u;  // (visible behind the prologue's barrier)
   const int t_begin = (int)(((long)blockIdx.y * ntiles) / CSB), t_end = (int)(((long)(blockIdx.y + 1) * ntiles) / CSB);
   const int nmine = t_end - t_begin;               // >= 2 (the launcher bounds CSB), <= MAXT
   const bool stamp = q.stamps != nullptr && threadIdx.x == 0;
@@ -1254,10 +1272,18 @@ __global__ __launch_bounds__(512) void supcon_tiles_kernel(const bf16_t* __restr
     for (int u = 0; u < 8; ++u)
       rn[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (threadIdx.x + 512 * u) * 16, 0, 0));
   }
+  // PASS 1: c_i of the lane's own row = the CSB count partials of sweep 0, needed only in the tail: requested here with the
+  // row norms (one value per lane and partial: same round trip), added up behind the explicit wait below
+  float cpart[PASS == 1 ? SUPCON_TILES_MAXT : 1];
+  if (PASS == 1) {
+#pragma unroll
+    for (int c = 0; c < SUPCON_TILES_MAXT; ++c)
+      cpart[c] = c < CSB ? q.Cpart[(size_t)c * N2p + blockIdx.x * 256 + wave * 32 + (lane & 31)] : 0.f;
+  }
   const int prow = lane / CPR, pcp = lane % CPR;   // lane -> (row in a piece, chunk position); source chunk swizzled
-  auto issue = [&](int k) {                        // k-th tile of this workgroup -> ring image k % 3
+  auto issue = [&](int k) {                        // k-th tile of this workgroup -> ring image k % 4
     const int jt = t_begin + k;
-    const unsigned slot = lds_base + (unsigned)((k % 3) * TILE_BYTES);
+    const unsigned slot = lds_base + (unsigned)((k % 4) * TILE_BYTES);
 #pragma unroll
     for (int u = 0; u < GPW; ++u) {
       const int gidx = wave * GPW + u;
@@ -1313,6 +1339,14 @@ __global__ __launch_bounds__(512) void supcon_tiles_kernel(const bf16_t* __restr
   for (int u = 0; u < 8; ++u) {
     asm volatile("" : "+v"(rn[u]));  // the scan stays behind the explicit wait above
     mv = fmaxf(mv, fmaxf(fmaxf(rn[u][0], rn[u][1]), fmaxf(rn[u][2], rn[u][3])));
+  }
+  float ci = 0.f;
+  if (PASS == 1) {
+#pragma unroll
+    for (int c = 0; c < SUPCON_TILES_MAXT; ++c) {
+      asm volatile("" : "+v"(cpart[c]));  // (stays behind the explicit wait, like the scan below)
+      ci += cpart[c];                     // same order as the tail's loop had: c = 0, 1, ...
+    }
   }
   float dv = 0.f;  // max | |p_i| - 1 |: every workgroup holds all row norms right now; one of them will report it
   if (PASS == 1 && blockIdx.x == 0 && blockIdx.y == 0) {
@@ -1402,7 +1436,7 @@ __global__ __launch_bounds__(512) void supcon_tiles_kernel(const bf16_t* __restr
   // elements behind every three MFMAs (source order = the order the matrix and vector pipes should see)
   auto products = [&](auto stats_c, int k, int nt, f32x16& cn, const f32x16& ce, int kE, int ntE) {
     constexpr bool STATS = decltype(stats_c)::value;
-    const u32x4* tile = (const u32x4*)(lds_b + (k % 3) * TILE_BYTES);
+    const u32x4* tile = (const u32x4*)(lds_b + (k % 4) * TILE_BYTES);
     f32x4 cs4[4];
     if (STATS) {
 #pragma unroll
@@ -1447,24 +1481,50 @@ __global__ __launch_bounds__(512) void supcon_tiles_kernel(const bf16_t* __restr
   const std::true_type yes;
   const std::false_type no;
   SUPCON_STAMP(3)
-  if (PASS == 1)  // the count partials of the own rows, needed only after the loop: into the staging image of waves 4..7
-    for (int c = wave; c < CSB; c += 8)
-      supcon_dma16(q.Cpart + (size_t)c * N2p + blockIdx.x * 256 + lane * 4,
-                   __builtin_amdgcn_readfirstlane(lds_base + 3 * TILE_BYTES + c * 1024));
-  if (nmine > 2) issue(2);  // image 2 doubles as the staging of waves 0..3: free since the barrier above
+  if (nmine > 2) issue(2);  // images 2 and 3 were the staging of the own rows: free since the barrier above
+  if (nmine > 3) issue(3);
+  // arrive: one lane adds 1 to a hand-off word; await: the wave spins (LDS reads only: neither touches vmcnt, the ring of
+  // transfers stays in flight) until all eight waves have arrived.  Plain LDS traffic is in order per wave and the data a
+  // word vouches for was in LDS before the word's add was issued (behind that wave's own vmcnt wait), so a wave that has
+  // seen the count may read the tile; the `memory` clobbers keep the compiler from moving tile reads across them.
+  auto arrive = [&](unsigned* w) {
+    asm volatile("" ::: "memory");
+    if (lane == 0) (void)__hip_atomic_fetch_add(w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+  };
+  auto await = [&](unsigned* w) {
+    asm volatile("" ::: "memory");
+    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < 8u)
+      __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+  };
+  unsigned* const full = tsync;
+  unsigned* const done = tsync + SUPCON_TILES_MAXT;
   f32x16 c0, c1;
   products(no, 0, 0, c0, c0, 0, 0);
   for (int k = 0; k < nmine; ++k) {
+    // this wave's pieces of tile k + 1 (requested two and a half tiles ago) have landed: all but the pieces of tiles k + 2
+    // and k + 3, if those are on their way -- said EARLY, so that nobody who gets to tile k + 1 first has to wait for this wave to get there
+    if (k + 1 < nmine) {
+      if (k + 3 < nmine) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * GPW) : "memory");
+      else if (k + 2 < nmine) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      arrive(full + k + 1);
+    }
     products(yes, k, 1, c1, c0, k, 0);
     if (is_edge(k, 0)) stats(yes, c0, k, 0);
-    // tile k + 1 must have landed before anyone reads it: all but the pieces of tile k + 2, if that is on its way
-    if (k + 2 < nmine) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(GPW) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (k + 3 < nmine) issue(k + 3);  // into the image of tile k, which every wave has finished reading
-    if (k + 1 < nmine) products(yes, k + 1, 0, c0, c1, k, 1);
-    else stats(no, c1, k, 1);
+    arrive(done + k);                        // this wave has read tile k for the last time
+    if (k + 1 < nmine) {
+      await(full + k + 1);                   // every wave's pieces of tile k + 1 are in LDS
+      products(yes, k + 1, 0, c0, c1, k, 1);
+    } else {
+      stats(no, c1, k, 1);
+    }
     if (is_edge(k, 1)) stats(yes, c1, k, 1);
+    if (k + 4 < nmine) {
+      await(done + k);                       // ... and only now, half a tile later, must everybody be through with tile k:
+      issue(k + 4);                          // its image takes tile k + 4 (up to four tiles per workgroup: never)
+    }
   }
   SUPCON_STAMP(4)
   s0 += __shfl_xor(s0, 32, 64);
@@ -1476,9 +1536,6 @@ __global__ __launch_bounds__(512) void supcon_tiles_kernel(const bf16_t* __restr
   if (PASS == 1) {
     // this workgroup's share of the scalars: sum_i l_i^(split) / c_i over its 256 own rows (c_i from the CSB partials
     // that arrived during the loop), sum W_i^(split); the first column split also carries sum c_i and writes c_i
-    const float* cp = (const float*)(lds_b + 3 * TILE_BYTES);
-    float ci = 0.f;
-    for (int c = 0; c < CSB; ++c) ci += cp[c * 256 + wave * 32 + n32];
     const bool mine = kh == 0 && own < N2;
     // (32 rows per wave in f32, the eight waves and everything after in f64)
     float v0 = mine ? s0 / ci : 0.f, v1 = mine ? s1 : 0.f;
@@ -2048,11 +2105,19 @@ __global__ __launch_bounds__(512) void supcon_bwd_tiles_kernel(const bf16_t* __r
   const unsigned lds_base = (unsigned)(uintptr_t)(unsigned char __attribute__((address_space(3)))*)lds_b;
   const float* tst = (const float*)(lds_b + 2 * STAGE);  // [4][MAXT * 64] statistics of the streamed rows
   __shared__ float red[8];
+  // tile hand-off words (round 6): full[k] counts the waves whose pieces of this workgroup's k-th tile have landed, done[k]
+  // the waves that have read that tile for the last time.  They replace the workgroup barrier of every tile: with a barrier
+  // per tile the two waves of a SIMD restart in phase each time and stall TOGETHER on every fragment read, accumulator
+  // drain and barrier -- the loop ran at 1.52x its matrix time (18.7 k cycles for 12.3 k of MFMA per SIMD at 4 tiles per
+  // workgroup; without any synchronisation, wrong results: 12.2 k) -- while waves that only wait for what they really
+  // need drift apart and fill each other's stalls.
+  __shared__ unsigned tsync[2 * SUPCON_TILES_MAXT];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n32 = lane & 31, kh = lane >> 5;
   const int I0 = blockIdx.x * 256 + wave * 32;
   const float inv_t = 1.f / t;
   const int ntiles = N2p / 64;
+  if (threadIdx.x < 2 * SUPCON_TILES_MAXT) tsync[threadIdx.x] = 0u;  // (visible behind the prologue's barrier)
   const int t_begin = (int)(((long)blockIdx.y * ntiles) / CSB), t_end = (int)(((long)(blockIdx.y + 1) * ntiles) / CSB);
   const int nmine = t_end - t_begin;
 
