@@ -1186,7 +1186,9 @@ __global__ __launch_bounds__(512) void supcon_logits2_kernel(SupconArgs a, const
 //    waves of a SIMD now run one behind the other, half a tile apart, instead of stalling together.  Also measured and
 //    NOT kept: the own rows' mid split by direct fragment loads (one memory round trip instead of two: the 32 lines a
 //    load touches cost the prologue 1.3 us more than the round trip saved), a fixed start-up delay of the second wave
-//    of each SIMD (+3 %), two alternating accumulators per half tile (+3 %: back-to-back accumulation is not a stall).
+//    of each SIMD (+3 %), two alternating accumulators per half tile (+3 %: back-to-back accumulation is not a stall),
+//    the closing scalar launch folded into sweep 1's last workgroup (agent-scope stores + ticket, no fence: sweep 1 grew by
+//    3.5 us for the 3.7 us of launch + boundary it removed -- the forward went from 39.8 to 41.8 us).
 // All global->LDS traffic is inline-asm DMA, so the only compiler-visible vector loads are the row norms of the
 // max-logit scan (and, PASS 1, the count partials of the own rows), issued FIRST and consumed after the last explicit
 // wait: hipcc's own waits never drain the ring.
@@ -2105,19 +2107,11 @@ __global__ __launch_bounds__(512) void supcon_bwd_tiles_kernel(const bf16_t* __r
   const unsigned lds_base = (unsigned)(uintptr_t)(unsigned char __attribute__((address_space(3)))*)lds_b;
   const float* tst = (const float*)(lds_b + 2 * STAGE);  // [4][MAXT * 64] statistics of the streamed rows
   __shared__ float red[8];
-  // tile hand-off words (round 6): full[k] counts the waves whose pieces of this workgroup's k-th tile have landed, done[k]
-  // the waves that have read that tile for the last time.  They replace the workgroup barrier of every tile: with a barrier
-  // per tile the two waves of a SIMD restart in phase each time and stall TOGETHER on every fragment read, accumulator
-  // drain and barrier -- the loop ran at 1.52x its matrix time (18.7 k cycles for 12.3 k of MFMA per SIMD at 4 tiles per
-  // workgroup; without any synchronisation, wrong results: 12.2 k) -- while waves that only wait for what they really
-  // need drift apart and fill each other's stalls.
-  __shared__ unsigned tsync[2 * SUPCON_TILES_MAXT];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n32 = lane & 31, kh = lane >> 5;
   const int I0 = blockIdx.x * 256 + wave * 32;
   const float inv_t = 1.f / t;
   const int ntiles = N2p / 64;
-  if (threadIdx.x < 2 * SUPCON_TILES_MAXT) tsync[threadIdx.x] = 0u;  // (visible behind the prologue's barrier)
   const int t_begin = (int)(((long)blockIdx.y * ntiles) / CSB), t_end = (int)(((long)(blockIdx.y + 1) * ntiles) / CSB);
   const int nmine = t_end - t_begin;
 

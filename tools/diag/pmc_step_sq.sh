@@ -8,4 +8,4 @@ for grp in "SQ_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST
   i=$((i+1))
   rocprofv3 --pmc $grp -d $OUT/g$i --output-format csv -- python3 bench.py --no-cpu-baseline --no-extras --no-roofline --no-graph --steps 3 --warmup 1 "$@" > $OUT/g$i.log 2>&1
 done
-python3 tools/pmc_sq_survey.py $OUT/g1 $OUT/g2
+python3 tools/pmc_sq_survey.py ${SQ_JSON:+--json $SQ_JSON} $OUT/g1 $OUT/g2
