@@ -1188,7 +1188,10 @@ __global__ __launch_bounds__(512) void supcon_logits2_kernel(SupconArgs a, const
 //    load touches cost the prologue 1.3 us more than the round trip saved), a fixed start-up delay of the second wave
 //    of each SIMD (+3 %), two alternating accumulators per half tile (+3 %: back-to-back accumulation is not a stall),
 //    the closing scalar launch folded into sweep 1's last workgroup (agent-scope stores + ticket, no fence: sweep 1 grew by
-//    3.5 us for the 3.7 us of launch + boundary it removed -- the forward went from 39.8 to 41.8 us).
+//    3.5 us for the 3.7 us of launch + boundary it removed -- the forward went from 39.8 to 41.8 us), and ONE wave per SIMD
+//    owning 64 rows (two row sets per fragment pair, six MFMAs per 16 features, statistics written between the MFMAs): a
+//    lone wave issues v_mfma_f32_32x32x16_bf16 at HALF the pipe's rate whatever the order of its accumulators and with
+//    no vector work at all (loop at 1.8 - 2.1x its matrix time: the matrix pipe of a SIMD needs two waves).
 // All global->LDS traffic is inline-asm DMA, so the only compiler-visible vector loads are the row norms of the
 // max-logit scan (and, PASS 1, the count partials of the own rows), issued FIRST and consumed after the last explicit
 // wait: hipcc's own waits never drain the ring.
