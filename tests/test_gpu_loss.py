@@ -125,7 +125,10 @@ def test_loss_mask_input(golden):
 
 @pytest.mark.parametrize("n,d,nlab", [(32, 256, 3), (30, 256, 10), (100, 128, 7), (512, 128, 3), (2048, 128, 512),
                                       (33, 100, 4), (700, 64, 5), (601, 200, 9), (2048, 128, 3),
-                                      (32, 512, 3), (80, 1000, 5), (300, 384, 7), (600, 512, 4)])  # last four: d > 256
+                                      (32, 512, 3), (80, 1000, 5), (300, 384, 7), (600, 512, 4),  # these four: d > 256
+                                      # more than four 64-row tiles per workgroup of the fused sweeps: the ring of four LDS
+                                      # images is REUSED behind the `done` hand-off words (5 resp. 16 tiles per workgroup)
+                                      (2560, 128, 5), (4096, 64, 7)])
 @pytest.mark.parametrize("mname", ["supcon1", "soft_12_cg", "hard_1e6"])
 def test_loss_vs_oracle_seeded(n, d, nlab, mname):
     """Sizes up to BASELINE config E (2n=4096, d=128) against the fp32 oracle on the same seeded inputs."""
