@@ -186,7 +186,13 @@ def test_main_tail_val_finetunes_from_the_config(tmp_path):
     orig_load = model.load_state_dict
     model.load_state_dict = lambda sd, *a, **kw: (restored.append({k: v.clone() for k, v in sd.items()}), orig_load(sd, *a, **kw))[1]
     base_config = dcopy(BASE_CONFIG)
-    trainers = val(model=model, save_dir=str(tmp_path), base_config=base_config, seed=10, labeled_ratios=ratio_zoo["acdc"][:2])
+    from semi_seg.data import creator as _creator
+    try:
+        trainers = val(model=model, save_dir=str(tmp_path), base_config=base_config, seed=10,
+                       labeled_ratios=ratio_zoo["acdc"][:2])
+    finally:  # (the registry is module state: leave it as it was found)
+        _creator._FACTORIES.pop("acdc", None)
+        _creator._OUT_HW["acdc"] = (224, 224)
     assert base_config == BASE_CONFIG  # _val works on deep copies (val.py:48)
     assert len(trainers) == 2 and len(restored) == 2
     for sd in restored:  # every ratio starts from the SAME pre-trained weights (val.py:34)
