@@ -104,3 +104,36 @@ def test_step_is_deterministic_bit_for_bit():
         outs.append((loss.detach().clone(), epocher._flat_params.flat.clone()))
     assert torch.equal(outs[0][0], outs[1][0])
     assert torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("n,d,mode", [(2048, 128, "soft"), (2560, 128, "hard"), (4096, 64, None)])
+def test_large_batch_loss_is_bit_stable_under_uneven_load(n, d, mode):
+    """The fused sweeps hand their LDS tiles over by counting words instead of a workgroup barrier (round 6): the same
+    inputs give the same bits every time -- loss and both gradients, forty repeats, with a streaming kernel on a second
+    stream every other repeat so that the waves' transfers do not always land in the same order.  2n = 4096: four tiles per
+    workgroup (every ring image used once); 5120 / 8192: the images are reused behind the `done` words.
+    (tools/diag/supcon_repeat.py: 300 repeats per shape.)"""
+    from spcl_amd.contrastyou.losses.contrast_loss3 import SelfPacedSupConLoss, SupConLoss1
+    g = torch.Generator().manual_seed(n + d)
+    z1 = torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=1).cuda().requires_grad_(True)
+    z2 = torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=1).cuda().requires_grad_(True)
+    labels = (torch.arange(n) % 7).float().cuda()
+    crit = SupConLoss1(sync_checks=False) if mode is None else SelfPacedSupConLoss(weight_update=mode, correct_grad=True,
+                                                                                     sync_checks=False)
+    if mode is not None:
+        crit.set_gamma(12.0)
+    side, junk, first = torch.cuda.Stream(), torch.empty(32 << 20, device="cuda"), None
+    for r in range(40):
+        if r % 2:
+            with torch.cuda.stream(side):
+                junk.add_(1.0)
+        z1.grad = z2.grad = None
+        loss = crit(z1, z2, target=labels)
+        loss.backward()
+        cur = (loss.detach().clone(), z1.grad.clone(), z2.grad.clone())
+        if first is None:
+            first = cur
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(first, cur)), r
+    torch.cuda.synchronize()
+    assert torch.isfinite(first[0]) and float(first[1].abs().max()) > 0
