@@ -14,11 +14,10 @@ backward -> (flat RCCL gradient all-reduce when N>1) -> RAdam step.  bf16 storag
 (BASELINE.json configs[1]).  Inputs are resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
 
 Extra objects in the line:
-  roofline      the dominant kernel call of the step, timed live with HIP events on its own stream in an instrumented
-                pass right after the timed region; algorithmic bytes/FLOPs per launch as defined in DESIGN.md
-  roofline_family  the same for the kernel FAMILY (all template instantiations of one __global__ together) with the largest
-                share of the step -- the 17 per-layer instantiations of conv3x3_fast_kernel, ~45 % of the step --: sum of the
-                launches' own bounds / their summed time
+  roofline      the dominant kernel of the step -- one __global__ template with ALL its instantiations' launches together
+                (conv3x3_fast_kernel: 17 launches, 42 % of the step) --, timed live with HIP events on its own stream in an
+                instrumented pass right after the timed region; algorithmic bytes/FLOPs as defined in DESIGN.md
+  roofline_symbol  the same for the single kernel SYMBOL with the largest total time (what rocprofv3 --stats ranks first)
   cpu_baseline  the CPU oracle's restatement of the same step ("port"), timed on this box's host cores (rank 0, N=1)
 """
 import argparse
@@ -425,21 +424,42 @@ def measure_roofline(step, args, phases=False, graph=False):
     fams = {}
     for sym, g in groups.items():
         f = fams.setdefault(sym.split("<")[0], {"t": 0.0, "n": 0, "roof": 0.0, "hbm_t": 0.0, "mfma_t": 0.0, "bytes": 0.0,
-                                                 "flops": 0.0, "members": 0, "hbm_launch_t": 0.0})
+                                                 "flops": 0.0, "members": 0, "traffic": 0.0, "traffic_known": True})
         for k in ("t", "n", "roof", "hbm_t", "mfma_t", "bytes", "flops"):
             f[k] += g[k]
         f["members"] += 1
+        tr = pmc.get(sym, {}).get("hbm_bytes_per_launch_corrected")
+        if tr is None:
+            f["traffic_known"] = False
+        else:
+            f["traffic"] += tr * g["n"]
     fam_rank = sorted(((k, f) for k, f in fams.items() if f["roof"] > 0), key=lambda kv: -kv[1]["t"])
 
     def fam_row(k, f):
-        return {"family": k, "instantiations": f["members"], "launches_per_step": f["n"] / reps,
+        hbm = f["hbm_t"] >= f["mfma_t"]  # the bound that owns more of the family's summed bound time
+        ach = f["bytes"] / f["t"] / 1e9 if hbm else f["flops"] / f["t"] / 1e12
+        peak = HBM_PEAK_GBS if hbm else peak_tf
+        return {"kernel": k + "<...>", "family": k, "instantiations": f["members"], "launches_per_step": f["n"] / reps,
+                "bound": "hbm" if hbm else "mfma", "achieved": round(ach, 1 if hbm else 2), "peak": peak,
+                "unit": "GB/s" if hbm else "TFLOP/s", "frac": round(ach / peak, 4),
+                "traffic": (int(f["traffic"] / f["n"]) if f["traffic_known"] and f["n"] else None),
+                "avg_us": round(f["t"] / f["n"] * 1e6, 2),
+                "algorithmic_bytes_per_launch": int(f["bytes"] / f["n"]),
+                "algorithmic_flops_per_launch": float(f["flops"] / f["n"]),
                 "us_per_step": round(f["t"] / reps * 1e6, 1), "share_of_instrumented_step": round(f["t"] / reps / total, 4),
-                "bound_us_per_step": round(f["roof"] / reps * 1e6, 1), "frac": round(f["roof"] / f["t"], 4),
-                "GBps": round(f["bytes"] / f["t"] / 1e9, 0), "mfma_tflops": round(f["flops"] / f["t"] / 1e12, 1)}
+                "bound_us_per_step": round(f["roof"] / reps * 1e6, 1), "mixed_roofline_frac": round(f["roof"] / f["t"], 4),
+                "GBps": round(f["bytes"] / f["t"] / 1e9, 0), "mfma_tflops": round(f["flops"] / f["t"] / 1e12, 1),
+                "pmc_traffic_over_algorithmic": (round(f["traffic"] / f["bytes"], 3)
+                                                 if f["traffic_known"] and f["bytes"] > 0 else None)}
     if fam_rank:
         top = fam_row(*fam_rank[0])
-        top.update({"bound": "mixed (per launch: max(algorithmic bytes / 8 TB/s, FLOPs / dense peak))",
-                    "others": [fam_row(k, f) for k, f in fam_rank[1:6]], "timing_source": source})
+        top.update({"others": [fam_row(k, f) for k, f in fam_rank[1:6]], "timing_source": source,
+                    "traffic_source": (pmc_src + " (committed PMC profile, not this run)" if top["traffic"] is not None else None),
+                    "note": "the kernel (one __global__ template, all its instantiations' launches together) with the largest "
+                            "share of the step; achieved = summed algorithmic bytes (or FLOPs) / summed launch time, per-launch "
+                            "figures are averages over its launches; bound = whichever of the two rooflines owns more of the "
+                            "launches' summed bound time; mixed_roofline_frac = sum over launches of max(bytes / 8 TB/s, "
+                            "FLOPs / peak) / summed time -- each launch against the roofline that bounds IT"})
         fr["roofline_family"] = top
     return out, breakdown, total, fr
 
@@ -788,8 +808,13 @@ def main():
                     # 224^2, bf16), x 3 for forward + input gradient + weight gradient, against the TIMED step
                     fractions["step_survey_frac"] = round(3.0 * enc["survey_bound_us"] * 1e-3 / ms, 4)
                     fractions["step_survey_bound_us"] = round(3.0 * enc["survey_bound_us"], 1)
-                if "roofline_family" in fractions:  # beside `roofline`, at the top level of the line
-                    line["roofline_family"] = fractions.pop("roofline_family")
+                if "roofline_family" in fractions:
+                    # the HEADLINE roofline is the kernel that owns the largest share of the step with all its template
+                    # instantiations together (conv3x3_fast_kernel: 17 launches, 42 %); ranked by symbol those 15
+                    # instantiations can never be "dominant" and the line would show a stream kernel that is 8 % of the step
+                    #  -- that one stays beside it as `roofline_symbol`
+                    line["roofline_symbol"] = roof
+                    line["roofline"] = fractions.pop("roofline_family")
                 line.setdefault("extra", {}).update(fractions)
         except Exception as e:  # noqa: BLE001
             line["roofline"] = None
