@@ -93,8 +93,9 @@ def parse():
                     help="draw every batch on the device inside the step (two torch.rand launches) instead of the pool")
     ap.add_argument("--ddp-overlap", action="store_true",
                     help="N>1: all-reduce the early gradient bucket (projector + Conv5..Conv3) from a backward hook while "
-                         "Conv2..Conv1 are differentiated (ddp.enable_unet_overlap); runs the step eagerly -- a "
-                         "collective on a second stream inside the step's hipGraph costs more than it hides on this stack")
+                         "Conv2..Conv1 are differentiated (ddp.enable_unet_overlap): the step is then THREE hipGraphs -- "
+                         "forward + backward down to the Conv3 | Conv2 boundary, the rest of backward, the update -- with the "
+                         "early collective started between the first two (stepgraph.StepGraph.cut)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -657,8 +658,6 @@ def main():
             args.bs = 64
         if "--size" not in sys.argv:
             args.size = 256
-    if args.ddp_overlap:
-        args.no_graph = True  # the early bucket's collective is launched from inside backward
     wd.beat("build")
     step, epocher, nparams = build_step(args, device, rank, world)
     run = step
@@ -677,7 +676,8 @@ def main():
                 print("[bench] the epocher did not capture its step (see the warning above); running eagerly",
                       file=sys.stderr)
     sg = epocher._step_graph
-    used_graph = False if (sg is None or not sg.captured) else ("epocher-split" if world > 1 else "epocher")
+    used_graph = False if (sg is None or not sg.captured) else \
+        (("epocher-split" if len(sg._graphs) == 2 else f"epocher-split{len(sg._graphs)}") if world > 1 else "epocher")
     ddp_check = None
     if world > 1 and os.environ.get("SPCL_BENCH_DDP_CHECK") == "1":
         wd.beat("ddp check")
@@ -742,8 +742,8 @@ def main():
         dist.all_reduce(ar, op=dist.ReduceOp.MAX)
         multi = {"per_rank_ms_per_step": [round(float(v), 4) for v in per_rank.tolist()],
                  "allreduce_us": round(float(ar.item()), 1),
-                 "allreduce_note": "the flat gradient bucket's all-reduce on the communication stream, between its two "
-                                   "stream waits, alone on an idle GPU (median of 20, max over ranks)"}
+                 "allreduce_note": "the flat gradient bucket's all-reduce alone on an idle GPU, HIP events on the caller's stream "
+                                   "(median of 20, max over ranks)"}
     # per-replay distribution AFTER the timed region (HIP events on the launch stream around every single replay):
     # median / p10 / p90 of one step's GPU time -- an extra key, `value` stays the wall-clock aggregate above
     replay = None
@@ -948,11 +948,17 @@ def check_ddp_mean(step, world, device):
     gathered, and the step's one collective must leave exactly their mean in every rank's bucket (a sum of `world`
     terms in rank order, divided by `world`; bit for bit at two ranks).  No optimizer step."""
     epocher, flat = step.epocher, step.flat
+    early_idx = flat._early_idx  # two-bucket overlap: the rank's OWN gradient is taken from a pass without the early collective
+    flat._early_idx = None
     with epocher.meters.focus_on(epocher.meter_focus):
         epocher.step_compute(step.batch, seed=7)
     local = flat.flat.clone()
     parts = [torch.empty_like(local) for _ in range(world)]
     dist.all_gather(parts, local)
+    if early_idx is not None:  # ... and the same batch again (the step is deterministic), the early bucket sent from backward
+        flat._early_idx = early_idx
+        with epocher.meters.focus_on(epocher.meter_focus):
+            epocher.step_compute(step.batch, seed=7)
     epocher.step_exchange()
     mean = parts[0].clone()
     for p in parts[1:]:

@@ -114,42 +114,6 @@ class GradBucket:
         return self.flat
 
 
-_COMM_STREAMS = {}
-
-
-class _comm_stream:
-    """The step's collective on ONE private stream per device, ordered by events: the stream waits for what the caller's
-    stream has enqueued so far (the backward kernels that fill the bucket), the caller's stream for the collective.  Work
-    enqueued on OTHER streams meanwhile -- the update graph's stream is the caller's, so nothing of this step; but the
-    next step's loader copies and, in an eager step with the early bucket on its way, the rest of backward -- is not held
-    up by the collective, and the collective's launch does not sit between two hipGraph replays of the compute stream.
-    CPU tensors (gloo tests): a no-op."""
-
-    def __init__(self, tensor):
-        self.on = tensor.is_cuda
-        self.dev = tensor.device
-
-    def __enter__(self):
-        if not self.on:
-            return self
-        idx = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
-        if idx not in _COMM_STREAMS:
-            _COMM_STREAMS[idx] = torch.cuda.Stream(device=idx)
-        self.comm = _COMM_STREAMS[idx]
-        self.cur = torch.cuda.current_stream(idx)
-        self.comm.wait_stream(self.cur)
-        self.ctx = torch.cuda.stream(self.comm)
-        self.ctx.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        if not self.on:
-            return False
-        self.ctx.__exit__(*exc)
-        self.cur.wait_stream(self.comm)
-        return False
-
-
 class FlatParams(GradBucket):
     """All trainable parameters as views of ONE flat fp32 tensor, optimised as a single ``nn.Parameter``.
 
@@ -169,6 +133,7 @@ class FlatParams(GradBucket):
                 off += p.numel()
         self.param = torch.nn.Parameter(self.data)
         self._early_idx, self._early_off, self._early = None, 0, None
+        self.cutter = None  # see ``reduce_early``
         # fold_mean: ``allreduce_`` leaves the ranks' SUM in the bucket and the factor 1 / world in ``grad_scale`` for an
         # optimizer that applies it while it streams the bucket anyway (optim.FusedRAdam.step(grad_scale=)): one launch
         # and one pass over the bucket less per step.  Off: the bucket holds the mean (``div_``), grad_scale stays 1.
@@ -205,13 +170,18 @@ class FlatParams(GradBucket):
         """mean of the flat bucket across ranks, in place (the step's ONE collective, or -- with the early bucket on its
         way -- the head's plus the wait for the tail's; no-op for a single process)."""
         if is_distributed():
-            with _comm_stream(self.flat):
-                if self._early is not None:
-                    dist.all_reduce(self.flat[:self._early_off], op=dist.ReduceOp.SUM, group=self.group)
-                    if self._early is not True:
-                        self._early.wait()
-                else:
-                    dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            # On the CALLER's stream (round 6; until then on a private communication stream between two stream waits).  A
+            # blocking collective of this torch is enqueued on the current stream itself; the private stream put two event
+            # hand-overs between the step's hipGraph replays, and a graph replay that starts behind another stream's event
+            # starts late: one-rank RCCL group on an MI355X, whole step, 0.989 ms as one graph -> 1.071 ms as compute graph |
+            # collective on the private stream | update graph -> 1.012 ms with the collective where the graphs are
+            # (tools/diag/split_graph_cost.py, profiles/r06_experiments/NOTES.md).
+            if self._early is not None:
+                dist.all_reduce(self.flat[:self._early_off], op=dist.ReduceOp.SUM, group=self.group)
+                if self._early is not True:
+                    self._early.wait()
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
             if not self.fold_mean:  # (fold_mean: the bucket keeps the SUM, ``grad_scale`` is 1 / world)
                 self.flat.div_(dist.get_world_size(self.group))
         self._early = None
@@ -237,10 +207,20 @@ class FlatParams(GradBucket):
         return self
 
     def reduce_early(self):
-        """gather the early bucket and start its all-reduce (no-op when overlap is off or it already ran this step)"""
+        """gather the early bucket and start its all-reduce (no-op when overlap is off or it already ran this step).  With
+        a ``cutter`` (stepgraph.StepGraph.cut of the step graph that replays this bucket's step) the collective's start is
+        handed to it: the gather is the last thing of one hipGraph, the start runs eagerly behind that graph's replay, the
+        rest of backward is the next graph."""
         if self._early_idx is None or self._early is not None:
             return
         self.gather(first=self._early_idx, final=False)
+        self._early = True  # (host state: ``gather_grads`` takes the head only -- also in a capture, where nothing is sent)
+        if self.cutter is not None:
+            self.cutter(self._start_early)
+        else:
+            self._start_early()
+
+    def _start_early(self):
         self._early = True
         if is_distributed():
             self._early = dist.all_reduce(self.flat[self._early_off:], op=dist.ReduceOp.SUM, group=self.group,

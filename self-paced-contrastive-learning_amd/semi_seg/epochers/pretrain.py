@@ -172,7 +172,7 @@ class PretrainEncoderEpocher:
         from ...optim import FusedRAdam
         flat = self._flat_params
         if (self._device.type != "cuda" or flat is None or not isinstance(self._optimizer, FusedRAdam)
-                or getattr(flat, "_early_idx", None) is not None or not self._hooks
+                or (getattr(flat, "_early_idx", None) is not None and not _ddp.is_distributed()) or not self._hooks
                 or tuple(self._affine_transformer._axis) != (1, 2)):
             return None
         (image, image_tf, *_), _, (partition_list, group_list) = data
@@ -189,7 +189,9 @@ class PretrainEncoderEpocher:
             if k is None:
                 return None
             keys.append(k)
-        return (tuple(image.shape), image.dtype, self._inference_until, _ddp.is_distributed(), tuple(keys))
+        # (two-bucket overlap in a distributed job: the early collective starts between two compute graphs, StepGraph.cut)
+        return (tuple(image.shape), image.dtype, self._inference_until, _ddp.is_distributed(),
+                getattr(flat, "_early_idx", None), tuple(keys))
 
     def _flip_flags(self, batch):
         """the flag bytes ``TensorRandomFlip`` would act on under ``FixRandomSeed(seed)`` (new_pretrain.py:57-58)"""
@@ -205,8 +207,10 @@ class PretrainEncoderEpocher:
         if self.stage is None:
             self.stage = _sg.StepStage(self._device)
             self._pair = torch.empty((2 * n,) + tuple(image.shape[1:]), dtype=image.dtype, device=self._device)
-            self._step_graph = _sg.StepGraph(self._compute_staged, self.step_exchange, self.step_update,
-                                             split=_ddp.is_distributed())
+            split = _ddp.is_distributed() and not _sg.collective_in_graph()
+            self._step_graph = _sg.StepGraph(self._compute_staged, self.step_exchange, self.step_update, split=split)
+            if split:
+                self._flat_params.cutter = self._step_graph.cut
         batch = {"seed": seed, "n": n, "partition_group": list(unl_partition), "label_group": list(unl_group),
                  "filename": filename}
         # every bound slot (labels, flags) refilled from this batch; the block travels in the flip launch below when it fits

@@ -15,7 +15,10 @@ through persistent device memory:
 
 ``StepGraph`` is the small state machine around it: the first steps of a shape run eagerly (they are real steps, and
 they warm the allocator), the next one is captured and replayed, every later one is refill + upload + replay.  With
-``torch.distributed`` initialised the collective stays outside: compute graph, eager all-reduce, update graph.  Host-side
+``torch.distributed`` initialised the collective stays outside: compute graph, eager all-reduce, update graph -- and when
+the compute phase calls ``StepGraph.cut(fn)`` on its way (ddp.FlatParams.reduce_early from the backward hook at the Conv3 |
+Conv2 boundary) the compute graph ENDS there, ``fn`` (the early bucket's asynchronous all-reduce) runs eagerly, and a
+second compute graph takes the rest of backward: three graphs, the early collective under blocks 2 .. 1.  Host-side
 effects of a step that a replay would lose (meter adds of python floats) are logged at capture and re-applied.
 Values that are baked into the capture (the age parameter gamma, changed once per epoch by
 ``SelfPacedINFONCEHook.__call__``) are part of the graph's key: a new epocher captures anew.  The capture also settles
@@ -168,6 +171,13 @@ def run_on_side_stream(fn, device=None):
     return out
 
 
+def collective_in_graph() -> bool:
+    """SPCL_GRAPH_COLLECTIVE=1: a distributed job captures its collective INSIDE the step's one hipGraph (RCCL's kernels are
+    capturable) instead of keeping it between a compute and an update graph.  Off by default: measured on ONE GPU only (a
+    one-rank RCCL group, tools/diag/split_graph_cost.py) -- no multi-GPU node was available to check a captured ring."""
+    return os.environ.get("SPCL_GRAPH_COLLECTIVE", "0") == "1"
+
+
 def graph_default() -> bool:
     """the epochers capture their step unless SPCL_STEP_GRAPH=0"""
     return os.environ.get("SPCL_STEP_GRAPH", "1") != "0"
@@ -195,6 +205,27 @@ class StepGraph:
         # were created on, and a node kept alive from an eager step on the default stream would make the capture wait on
         # (i.e. fork into) the default stream
         self._stream = None
+        self._cuts = []         # eager callables between the compute graphs, in order (recorded by ``cut`` at capture)
+        self._capturing = None  # the compute graphs of the capture in progress
+
+    def cut(self, fn):
+        """Called from INSIDE ``compute()``: everything launched so far belongs in front of ``fn()``, everything after it
+        behind.  In an eager step (or a one-process job, whose whole step is one graph) that is just ``fn()``.  While a
+        split capture is in progress the current graph ends here and a new graph of the same memory pool begins; ``fn`` is
+        recorded and runs at this point of every replay (the first of which follows the capture at once) -- NOT during the
+        capture itself: a capture executes no kernel, what ``fn`` would communicate does not exist yet.  The caller may be
+        autograd's device thread (a backward hook): the captures of a split step are therefore begun in hip's *relaxed*
+        mode, the only one in which a capture may be ended by another thread than the one that began it (measured on this
+        stack, tools/diag/graph_split_in_backward.py: `thread_local` and `global` fail with
+        hipErrorStreamCaptureWrongThread)."""
+        if self._capturing is None:
+            return fn()
+        self._capturing[-1].capture_end()
+        g = torch.cuda.CUDAGraph()
+        g.capture_begin(pool=self._capturing[0].pool(), capture_error_mode="relaxed")
+        self._capturing.append(g)
+        self._cuts.append(fn)
+        return None
 
     @property
     def captured(self):
@@ -263,17 +294,33 @@ class StepGraph:
         _meters.begin_host_log()
         try:
             if self._split:
-                ga = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga, stream=self._stream):
-                    state["loss"] = self._compute()
+                # (what ``torch.cuda.graph`` does around a capture, by hand: ``cut`` may end the first graph half way)
+                torch.cuda.empty_cache()
+                self._cuts = []
+                with torch.cuda.stream(self._stream):
+                    self._capturing = [torch.cuda.CUDAGraph()]
+                    self._capturing[0].capture_begin(capture_error_mode="relaxed")
+                    try:
+                        state["loss"] = self._compute()
+                    except BaseException:
+                        try:  # leave the stream out of capture mode whatever happened
+                            self._capturing[-1].capture_end()
+                        except Exception:  # noqa: BLE001
+                            pass
+                        raise
+                    else:
+                        self._capturing[-1].capture_end()
+                    finally:
+                        compute_graphs, self._capturing = self._capturing, None
                 gb = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gb, pool=ga.pool(), stream=self._stream):
+                with torch.cuda.graph(gb, pool=compute_graphs[0].pool(), stream=self._stream):
                     self._update(state["loss"])
-                self._graphs = (ga, gb)
+                self._graphs = (*compute_graphs, gb)
             else:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=self._stream):
                     state["loss"] = self._compute()
+                    self._exchange()  # (a no-op in a one-process job; see ``collective_in_graph``)
                     self._update(state["loss"])
                 self._graphs = (g,)
         finally:
@@ -282,9 +329,12 @@ class StepGraph:
 
     def _replay(self, first):
         if self._split:
-            self._graphs[0].replay()
+            for i, g in enumerate(self._graphs[:-1]):
+                g.replay()
+                if i < len(self._cuts):
+                    self._cuts[i]()
             self._exchange()
-            self._graphs[1].replay()
+            self._graphs[-1].replay()
         else:
             self._graphs[0].replay()
         if not first:  # the capture pass already performed the host-side adds once

@@ -26,7 +26,7 @@ def _free_port():
     return p
 
 
-def _run_two_ranks(tmp_path, cmd, n=2):
+def _run_two_ranks(tmp_path, cmd, n=2, graphs="epocher-split"):
     env = dict(os.environ, SPCL_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", SPCL_BENCH_WATCHDOG_S="60",
                SPCL_BENCH_DDP_CHECK="1")
     env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
@@ -56,7 +56,7 @@ def _run_two_ranks(tmp_path, cmd, n=2):
     assert len(lines) == 1, out[-2000:]  # rank 0 only
     line = json.loads(lines[0])
     assert line["n_gpus"] == n and line["steps"] == 2 and line["scaling"] == "weak"
-    assert line["config"]["hipgraph"] == "epocher-split" and line["config"]["global_batch"] == 4 * n
+    assert line["config"]["hipgraph"] == graphs and line["config"]["global_batch"] == 4 * n
     assert line["value"] > 0 and line["final_meters"]["loss"] == line["final_meters"]["loss"]  # finite loss
     chk = line["ddp_check"]  # the collective left the mean of the ranks' (different) gradients in the bucket
     # (two addends have one order: exact; from three on the collective's order is its own)
@@ -94,3 +94,20 @@ def test_bench_four_ranks_on_one_device(tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(REPO, "bench.py")] + args
     _run_two_ranks(tmp_path, cmd, n=4)
+
+
+def test_bench_two_ranks_overlapped_early_bucket_is_three_graphs(tmp_path):
+    """``--ddp-overlap`` in graph mode: the compute graph is cut at the Conv3 | Conv2 boundary from inside
+    backward (stepgraph.StepGraph.cut, called by ddp.FlatParams.reduce_early on autograd's thread), the early bucket's
+    asynchronous all-reduce starts between the two compute graphs of every replay, the head's follows the second, then the
+    update graph.  Same collective semantics: the bucket holds the mean of the ranks' gradients bit for bit, and the
+    run's loss meter equals the one-bucket run's."""
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                "127.0.0.1"]
+    (tmp_path / "a").mkdir(), (tmp_path / "b").mkdir()
+    over = _run_two_ranks(tmp_path / "a", launcher + ["--master-port", str(_free_port()), os.path.join(REPO, "bench.py")] +
+                          BENCH_ARGS + ["--ddp-overlap"], graphs="epocher-split3")
+    plain = _run_two_ranks(tmp_path / "b", launcher + ["--master-port", str(_free_port()),
+                                                       os.path.join(REPO, "bench.py")] + BENCH_ARGS)
+    a, b = over["final_meters"]["loss"], plain["final_meters"]["loss"]
+    assert abs(a - b) <= 1e-5 * abs(b), (a, b)
