@@ -129,9 +129,14 @@ def _overlap_worker(rank, world, port, q, early_layer=2):
     xs, ys = torch.randn(4, 6, generator=g), torch.randn(4, 2, generator=g)
     out = []
     fired = []
-    for overlap in (False, True):
+    for overlap in (False, True, "cut"):
         model = copy.deepcopy(base)
         flat = ddp.FlatParams(model.parameters())
+        deferred = []
+        if overlap == "cut":
+            # a step replayed from hipGraphs (stepgraph.StepGraph.cut): during the capture the hook only GATHERS, the start of
+            # the collective is handed to the cutter, which runs it between the two compute graphs of every replay
+            flat.cutter = deferred.append
         if overlap:
             # members are in module order: the early bucket is the TAIL (what backward finishes first); it starts when the
             # gradient w.r.t. the first layer's output exists, i.e. once everything after that layer is differentiated
@@ -142,6 +147,9 @@ def _overlap_worker(rank, world, port, q, early_layer=2):
         for step in range(2):  # two steps: the per-step state is reset
             flat.zero_grad()
             ((model(xs * (step + 1)) - ys) ** 2).mean().backward()
+            if overlap == "cut":
+                assert flat._early is True and len(deferred) == 1  # gathered, nothing sent yet
+                deferred.pop()()
             if overlap:
                 assert flat._early is not None  # the hook started the early bucket during backward
                 assert model[0].weight.grad is not None and flat._early_off == sum(
@@ -171,12 +179,13 @@ def test_two_bucket_overlap_equals_the_flat_allreduce(world, early_layer):
         p.join(60)
         assert p.exitcode == 0
     for rank, out, fired in res:
-        plain, bucketed = out[:2], out[2:]
+        plain, bucketed, cut = out[:2], out[2:4], out[4:]
+        assert bucketed == cut              # the collective started by the cutter instead of the hook: the same two all-reduces
         if world == 2:
             assert plain == bucketed        # step by step, element by element (two addends: one order)
         else:                               # (gloo's ring adds a slice's addends in an order that depends on its length)
             assert torch.allclose(torch.tensor(plain), torch.tensor(bucketed), rtol=1e-6, atol=1e-7)
-        assert fired == [True, True]        # the hook ran once per step and found the early bucket not yet started
+        assert fired == [True] * 4          # the hook ran once per step and found the early bucket not yet started
     for other in res[1:]:
         assert res[0][1] == other[1]        # every rank holds the same averaged gradients
     assert any(v != 0.0 for v in res[0][1][0])
