@@ -161,8 +161,13 @@ conv3x3_fast_kernel(FastArgs a) {
   if (KC == 64 && a.CinK >= 128 && gridDim.z == 2u * a.N * a.gy) n >>= 1;
 #endif
   if (a.gy > 1) {
-    by = n % a.gy;
-    n /= a.gy;
+    // z = by * N + n, the output-channel block SLOWEST: workgroups go to the XCDs round-robin in launch order, and the gy
+    // workgroups that stage the SAME halo (same image, same tile, another 64 output channels) must meet in one XCD's L2.
+    // With the channel block fastest (z = n * gy + by, rounds 2 - 5) they sat tilesX * tilesY apart in launch order, i.e.
+    // on gy different XCDs at 14^2 / 28^2: every halo came out of the Infinity Cache gy times.  Whole step, same box,
+    // nine rounds: -3 us (Conv4 / Conv5 and their dgrads; profiles/r06_experiments/NOTES.md).
+    by = n / a.N;
+    n -= by * a.N;
   }
   // image sizes that are not a multiple of the tile: the last tile of a row / column is shifted back inside the image
   // (it recomputes oy rows / ox columns of its neighbour -- identical values, written twice -- and leaves them out of
@@ -1150,7 +1155,7 @@ bool launch_conv_fast(const ConvArgs& c, int th, hipStream_t st, bool dry) {
   a.N = c.N; a.H = c.H; a.W = c.W; a.CinK = c.CinK; a.CoutS = c.CoutS;
   a.tilesX = cdiv(c.W, 14); a.tilesY = cdiv(c.H, th); a.gy = ntn / (NT * nw);
   static const int env_remap = lab_env("SPCL_CONV_XCD_REMAP", 1);
-  a.xcd_remap = (env_remap && a.gy == 1) ? 1 : 0;  // (with gy > 1 the z index interleaves channel blocks: left alone)
+  a.xcd_remap = (env_remap && a.gy == 1) ? 1 : 0;  // (with gy > 1 the z index carries the channel block: see the kernel)
   // pooled BatchNorm-backward sums in the epilogue (MODE 3): measured per block against dgrad + separate reduction pass
   // (N = 64): 32 -> 16 @112^2 43 vs 49 us, 128 -> 64 @28^2 21 vs 25.5, 256 -> 128 @14^2 30.5 vs 30.6, but the one-wave
   // 64 -> 32 @56^2 kernel 53.5 vs 43 (56 scattered 8-byte loads per lane behind one wave's MFMAs): not offered there
