@@ -64,17 +64,54 @@ class _EpocherBase:
             try:
                 self._run()
             finally:
-                _sg.gc_release()  # (a step-graph capture froze the garbage collector's view of the heap)
+                _sg.gc_release(final=False)  # (a capture froze the collector's view of the heap; the trainer undoes it)
         return self.meters.statistics()
+
+
+class _EvalGraphs:
+    """hipGraphs of one model's validation batch, one per batch shape (the reference's validation loaders hand over one SCAN
+    per batch, ``ScanBatchSampler``: a dozen distinct slice counts), kept ON THE MODEL across the EvalEpochers of a training
+    run (the trainer builds two per epoch, val + test).  A validation batch is ~70 launches of 3 - 10 us each; issued one by
+    one the pass is bound by the host (1.58 ms per batch at 8 and at 32 slices, tools/diag/eval_speed.py) -- and the
+    reference's fine-tune epoch is 200 training steps against ~200 validation batches.
+
+    An entry replays: forward in ``eval()`` mode, softmax, one-hot, criterion, arg-max, Dice counts -- the very launches of
+    the eager pass, so the values are the eager pass's bit for bit.  What a capture bakes in is the entry's key: shapes,
+    dtypes, criterion, and the storage of every parameter and buffer (``signature``: a FlatParams built later MOVES the
+    parameters; entries of another signature are dropped)."""
+
+    def __init__(self):
+        self.signature = None
+        self.entries = {}   # key -> dict(seen=, graph=, img=, tgt=, out=)
+        self.pool = None
+
+    @staticmethod
+    def of(model):
+        g = model.__dict__.get("_spcl_eval_graphs")
+        if g is None:
+            g = model.__dict__["_spcl_eval_graphs"] = _EvalGraphs()
+        return g
+
+    @staticmethod
+    def signature_of(model):
+        return hash(tuple(t.data_ptr() for t in model.parameters()) + tuple(t.data_ptr() for t in model.buffers())
+                    + (str(getattr(model, "_compute_dtype", None)),))
+
+    def sync(self, model):
+        sig = self.signature_of(model)
+        if sig != self.signature:
+            self.signature, self.entries, self.pool = sig, {}, None
 
 
 class EvalEpocher(_EpocherBase):
     meter_focus = "eval"
 
-    def __init__(self, *, model: nn.Module, loader: Iterable, sup_criterion, cur_epoch=0, device="cuda"):
+    def __init__(self, *, model: nn.Module, loader: Iterable, sup_criterion, cur_epoch=0, device="cuda",
+                 graph: Optional[bool] = None):
         self._loader = loader
         self._sup_criterion = sup_criterion
         super().__init__(model=model, num_batches=len(loader), cur_epoch=cur_epoch, device=device)
+        self._graph_on = (_sg.graph_default() if graph is None else bool(graph)) and self._device.type == "cuda"
 
     def configure_meters(self, meters):
         C = self.num_classes
@@ -90,15 +127,66 @@ class EvalEpocher(_EpocherBase):
         self._model.eval()
         return self._run_eval()
 
+    def _batch(self, eval_img, eval_target):
+        """one validation batch (new_epocher.py:84-90) -> (loss, per-sample intersections, unions)"""
+        eval_logits = self._model(eval_img)
+        onehot_target = class2one_hot(eval_target.squeeze(1), self.num_classes)
+        eval_loss = self._sup_criterion(F_hip.softmax_classes(eval_logits), onehot_target, disable_assert=True)
+        inter, union = F_hip.dice_counts(F_hip.argmax_classes(eval_logits), eval_target.squeeze(1), self.num_classes)
+        return eval_loss, inter, union
+
+    def _batch_replayed(self, graphs, eval_img, eval_target):
+        """``_batch`` from a hipGraph of this shape: first sight eager (lazily created workspaces are then outside any
+        graph's pool), second sight captured, from then on copy-in + replay + copy-out"""
+        key = (tuple(eval_img.shape), eval_img.dtype, tuple(eval_target.shape), eval_target.dtype,
+               type(self._sup_criterion).__name__, getattr(self._sup_criterion, "_eps", None), self.num_classes)
+        e = graphs.entries.get(key)
+        if e is None:
+            graphs.entries[key] = {"graph": None}
+            return _sg.run_on_side_stream(lambda: self._batch(eval_img, eval_target), self._device)
+        if e["graph"] is None:
+            if e.get("failed"):
+                return _sg.run_on_side_stream(lambda: self._batch(eval_img, eval_target), self._device)
+            e["img"], e["tgt"] = torch.empty_like(eval_img), torch.empty_like(eval_target)
+            g = torch.cuda.CUDAGraph()
+            try:
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g, pool=graphs.pool, stream=_sg.side_stream(self._device)):
+                    e["out"] = self._batch(e["img"], e["tgt"])
+            except Exception as exc:  # noqa: BLE001 -- a capture that fails must not end the validation pass
+                import warnings
+                e["failed"] = True
+                try:
+                    torch.cuda.synchronize()
+                except Exception:  # noqa: BLE001
+                    pass
+                warnings.warn(f"hipGraph capture of the validation batch failed ({type(exc).__name__}: {exc}); this shape "
+                              "continues with eager launches")
+                return _sg.run_on_side_stream(lambda: self._batch(eval_img, eval_target), self._device)
+            e["graph"] = g
+            if graphs.pool is None:
+                graphs.pool = g.pool()  # one pool for every shape: the batches replay one after the other
+        e["img"].copy_(eval_img, non_blocking=True)
+        e["tgt"].copy_(eval_target, non_blocking=True)
+        e["graph"].replay()
+        loss, inter, union = e["out"]  # (rewritten by the next replay of this shape: the meters get copies)
+        return loss.clone(), inter.clone(), union.clone()
+
     @torch.no_grad()
     def _run_eval(self):
+        graphs = None
+        if self._graph_on:
+            graphs = _EvalGraphs.of(self._model)
+            graphs.sync(self._model)
         for self.cur_batch_num, eval_data in zip(range(self._num_batches), self._loader):
             eval_img, eval_target, file_path, _, group = unzip_single_transformed(eval_data, self._device)
-            eval_logits = self._model(eval_img)
-            onehot_target = class2one_hot(eval_target.squeeze(1), self.num_classes)
-            eval_loss = self._sup_criterion(F_hip.softmax_classes(eval_logits), onehot_target, disable_assert=True)
+            if graphs is not None and eval_img.is_cuda and eval_img.is_contiguous() and eval_target.is_contiguous():
+                eval_loss, inter, union = self._batch_replayed(graphs, eval_img, eval_target)
+            else:
+                eval_loss, inter, union = self._batch(eval_img, eval_target)
             self.meters["loss"].add(eval_loss)
-            self.meters["dice"].add(F_hip.argmax_classes(eval_logits), eval_target.squeeze(1), group_name=list(group))
+            dice = self.meters["dice"]
+            dice.add_counts(inter, union, dice.group_names_for(inter.shape[0], list(group)))
 
 
 class FineTuneEpocher(_EpocherBase):

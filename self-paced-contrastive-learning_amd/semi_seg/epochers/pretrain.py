@@ -136,7 +136,7 @@ class PretrainEncoderEpocher:
             try:
                 self._run_pretrain()
             finally:
-                _sg.gc_release()  # (the capture froze the garbage collector's view of the heap, stepgraph._gc_settle)
+                _sg.gc_release(final=False)  # (the capture froze the collector's view of the heap; the trainer undoes it)
         self.close_hooks()
         return self.meters.statistics()
 

@@ -92,25 +92,29 @@ class FineTuneTrainer:
     def start_training(self):
         if not self.__initialized__:
             raise RuntimeError(f"{self.__class__.__name__} should call `init()` first")
-        for self._cur_epoch in range(max(self._cur_epoch + 1, self._start_epoch), self._max_epoch + 1):
-            train_metrics = self._create_tra_epoch().run()
-            eval_metrics = test_metrics = None
-            cur_score = float("nan")
-            if _ddp.on_master():
-                eval_metrics, cur_score = self.run_eval_epoch(model=self._model, loader=self._val_loader)
-                if self._test_loader is not None:
-                    test_metrics, _ = self.run_eval_epoch(model=self._model, loader=self._test_loader)
-            best = self._best_score < cur_score
-            if best:
-                self._best_score = cur_score
-            if _ddp.on_master() and self._save_dir:
+        from ... import stepgraph as _sg
+        try:
+            for self._cur_epoch in range(max(self._cur_epoch + 1, self._start_epoch), self._max_epoch + 1):
+                train_metrics = self._create_tra_epoch().run()
+                eval_metrics = test_metrics = None
+                cur_score = float("nan")
+                if _ddp.on_master():
+                    eval_metrics, cur_score = self.run_eval_epoch(model=self._model, loader=self._val_loader)
+                    if self._test_loader is not None:
+                        test_metrics, _ = self.run_eval_epoch(model=self._model, loader=self._test_loader)
+                best = self._best_score < cur_score
                 if best:
-                    self.save_to("best.pth")
-                self.save_to("last.pth")
-            self.history.append({"epoch": self._cur_epoch, "tra": train_metrics, "val": eval_metrics,
-                                 "test": test_metrics, "score": cur_score})
-            if self._scheduler is not None:
-                self._scheduler.step()
+                    self._best_score = cur_score
+                if _ddp.on_master() and self._save_dir:
+                    if best:
+                        self.save_to("best.pth")
+                    self.save_to("last.pth")
+                self.history.append({"epoch": self._cur_epoch, "tra": train_metrics, "val": eval_metrics,
+                                     "test": test_metrics, "score": cur_score})
+                if self._scheduler is not None:
+                    self._scheduler.step()
+        finally:
+            _sg.gc_release()  # (the epochers' captures keep the collector's heap frozen from one epoch to the next)
         return self.history
 
     def state_dict(self):

@@ -209,13 +209,17 @@ class PretrainEncoderTrainer:
     def start_training(self):
         if not self.__initialized__:
             raise RuntimeError(f"{self.__class__.__name__} should call `init()` first")
-        for self._cur_epoch in range(max(self._cur_epoch + 1, self._start_epoch), self._max_epoch):
-            stats = self.run_tra_epoch()
-            self.history.append(stats)
-            if self._scheduler is not None:
-                self._scheduler.step()
-            if self._save_dir and _ddp.on_master():
-                self.save_to("last.pth")
+        from ... import stepgraph as _sg
+        try:
+            for self._cur_epoch in range(max(self._cur_epoch + 1, self._start_epoch), self._max_epoch):
+                stats = self.run_tra_epoch()
+                self.history.append(stats)
+                if self._scheduler is not None:
+                    self._scheduler.step()
+                if self._save_dir and _ddp.on_master():
+                    self.save_to("last.pth")
+        finally:
+            _sg.gc_release()  # (the epochers' captures keep the collector's heap frozen from one epoch to the next)
         return self.history
 
     # trainer/_io.py:49-71,120-134

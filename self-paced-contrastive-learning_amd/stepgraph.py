@@ -117,28 +117,45 @@ _CAPTURE_FAILED = set()  # device indices on which a step capture failed: later 
 _WE_FROZE = False        # this module called gc.freeze(): only then may it gc.unfreeze() (the host application may freeze too)
 
 
+_SETTLED_AT = 0.0        # time.monotonic() of the last FULL settle
+_RESETTLE_AFTER_S = 120.0
+
+
 def _gc_settle():
     """A replayed step costs the host ~150 us; ONE generation-2 garbage collection of a process with torch, the model and
     the data set loaded takes ~80 ms (measured: it lands inside a 30-step timed region every few runs and triples its mean;
-    the GPU queue holds ~20 ms of work and runs dry).  At capture time -- a slow, once-per-epoch event anyway -- collect,
-    then move everything alive to the collector's permanent generation (``gc.freeze()``): later collections only look at
-    what the steps themselves allocate.  The previous capture's freeze is undone first, so dead cycles of an earlier epoch
-    are still found.  ``SPCL_GC_FREEZE=0`` leaves the collector alone; ``gc_release()`` undoes it."""
+    the GPU queue holds ~20 ms of work and runs dry).  At capture time collect, then move everything alive to the
+    collector's permanent generation (``gc.freeze()``): later collections only look at what the steps themselves allocate.
+
+    A capture happens once per EPOCH (the trainers build a new epocher every epoch) and the reference's epoch is 200 steps:
+    the full settle -- undo the previous freeze so that dead cycles of earlier epochs are found, collect the whole heap,
+    freeze again: 60 - 80 ms -- was a quarter of a 285 ms pre-train epoch (tools/diag/pretrain_epoch_time.py).  It now runs
+    at the first capture and then at most every two minutes; the captures in between collect what is NOT frozen (the
+    epochers, hooks and graphs of the epochs since: a few ms) and leave the permanent generation alone.  What died inside
+    it is found by the next full settle.  ``SPCL_GC_FREEZE=0`` leaves the collector alone; ``gc_release()`` undoes it."""
     if os.environ.get("SPCL_GC_FREEZE", "1") == "0":
         return
     import gc
-    global _WE_FROZE
+    import time
+    global _WE_FROZE, _SETTLED_AT
+    now = time.monotonic()
+    if _WE_FROZE and now - _SETTLED_AT < _RESETTLE_AFTER_S:
+        gc.collect()  # (the permanent generation is not traversed)
+        return
     if _WE_FROZE:  # (never undo a freeze the host application made itself: gc.unfreeze() is process-wide)
         gc.unfreeze()
     gc.collect()
     gc.freeze()
     _WE_FROZE = True
+    _SETTLED_AT = now
 
 
-def gc_release():
-    """undo ``_gc_settle`` (the epochers call it when their loop ends) -- only a freeze this module made"""
+def gc_release(final: bool = True):
+    """undo ``_gc_settle`` -- only a freeze this module made.  ``final=False`` is what an epocher says when its loop ends:
+    the freeze STAYS for the next epoch's capture (``_gc_settle`` re-settles when it is due); the trainers say
+    ``gc_release()`` when training ends, and so may anybody who drives epochers by hand."""
     global _WE_FROZE
-    if os.environ.get("SPCL_GC_FREEZE", "1") == "0" or not _WE_FROZE:
+    if os.environ.get("SPCL_GC_FREEZE", "1") == "0" or not _WE_FROZE or not final:
         return
     import gc
     gc.unfreeze()
