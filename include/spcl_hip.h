@@ -36,7 +36,7 @@ extern "C" {
 /* Bumped whenever a struct layout, a limit (SPCL_*_MAX) or an entry point's meaning changes.  The library is git-ignored and
  * travels next to the sources: the Python binding (native.py) refuses a library whose version is not the header's, so that a
  * stale build fails at load time instead of running kernels on structs of another stride. */
-#define SPCL_ABI_VERSION 6
+#define SPCL_ABI_VERSION 7
 int spcl_abi_version(void);
 const char* spcl_last_error(void);
 
@@ -639,6 +639,15 @@ int spcl_augment_views_pil(const float* src, int S, int HS, int WS, const int* p
  * labels / label_out (optional, together): the slice's u8 label map through the same geometry with NEAREST -> int64. */
 int spcl_augment_views_recipe(const float* src, const unsigned char* labels, int S, int HS, int WS, const int* params,
                               int nviews, float* out, long long* label_out, int OH, int OW, int max_pad, void* stream);
+/* The same views (bit for bit) from a grid that fills the chip: spcl_augment_views_recipe runs ONE workgroup per view, which
+ * samples its pixels twice (ImageEnhance.Contrast needs the view's mean first) -- 180 us for the 60 views of a pre-train batch
+ * on a quarter of the CUs.  Here up to 64 workgroups per view sample a chunk each once, park the 8-bit levels and their integer
+ * partial sum in `workspace` (spcl_augment_views_recipe_workspace_bytes, 8-byte aligned, contents irrelevant on entry), and
+ * a second launch finishes the pixels.  What semi_seg/data/augment.py RecipeViews calls (ABI 7). */
+size_t spcl_augment_views_recipe_workspace_bytes(int nviews, int OH, int OW);
+int spcl_augment_views_recipe_ws(const float* src, const unsigned char* labels, int S, int HS, int WS, const int* params,
+                                 int nviews, float* out, long long* label_out, int OH, int OW, int max_pad, void* workspace,
+                                 size_t workspace_bytes, void* stream);
 /* Image.resize((OW, OH), BILINEAR) of every slice of a store of 8-bit levels (k / 255) -- torchvision Resize,
  * semi_seg/augment.py:56,71,79 -- with the coefficient rows of Resample.c precomputed by the caller per axis
  * (bounds[out][2] = first tap, tap count; kk[out][ksize]: 22 fractional bits); tmp: [S][HS][OW] floats. */

@@ -213,41 +213,47 @@ __global__ __launch_bounds__(1024) void augment_views_pil_kernel(const float* __
 // on: the whole slice, or the crop.  `labels` / `label_out` (optional): the slice's 8-bit label map through the same
 // geometry with NEAREST, written as int64 (pil_augment.ToLabel).
 constexpr int RECIPE_W = 28;
-__global__ __launch_bounds__(1024) void augment_views_recipe_kernel(const float* __restrict__ src,
-                                                                    const unsigned char* __restrict__ labels, int S, int HS,
-                                                                    int WS, const int* __restrict__ params,
-                                                                    float* __restrict__ out, long long* __restrict__ label_out,
-                                                                    int OH, int OW) {
-  __shared__ int red[16];
-  const int v = blockIdx.x;
-  const int* pr = params + v * RECIPE_W;
-  const int slice = pr[0], flags = pr[1], top = pr[2], left = pr[3], pad = pr[4];
-  const float b = __int_as_float(pr[5]), c = __int_as_float(pr[6]);
-  const int a0 = pr[8], a1 = pr[9], a2 = pr[10], a3 = pr[11], a4 = pr[12], a5 = pr[13];
+// one view's geometry and samplers, built from its parameter row (shared by the one-workgroup kernel and the split pair)
+struct RecipeView {
+  const float* img;
+  const unsigned char* lab;
+  int flags, top, left, pad, HS, WS, OH, OW, wx0, wy0, ww, wh;
+  int a0, a1, a2, a3, a4, a5;
   double m[6];
+  float b, c;
+  bool b_in, c_in, contrast_first, bilinear, crop_first, slice_ok;
+
+  __device__ __forceinline__ RecipeView(const float* src, const unsigned char* labels, int S, int HS_, int WS_, const int* pr,
+                                        int OH_, int OW_) {
+    const int slice = pr[0];
+    flags = pr[1]; top = pr[2]; left = pr[3]; pad = pr[4];
+    b = __int_as_float(pr[5]); c = __int_as_float(pr[6]);
+    a0 = pr[8]; a1 = pr[9]; a2 = pr[10]; a3 = pr[11]; a4 = pr[12]; a5 = pr[13];
 #pragma unroll
-  for (int k = 0; k < 6; ++k)
-    m[k] = __hiloint2double(pr[14 + 2 * k + 1], pr[14 + 2 * k]);  // (little endian: low word first)
-  const bool b_in = b >= 0.f && b <= 1.f, c_in = c >= 0.f && c <= 1.f;
-  const bool contrast_first = flags & 4, bilinear = flags & 8, crop_first = flags & 16;
-  const float* img = src + (size_t)slice * HS * WS;
-  const unsigned char* lab = labels != nullptr ? labels + (size_t)slice * HS * WS : nullptr;
-  // the image the rotation acts on: the slice, or its crop (a window of it)
-  // (crop first: RandomCrop(padding=) pads with zeros BEFORE it crops -- the window's origin is (top - pad, left - pad) of the
-  // slice and window pixels outside the slice are the padding's zeros; a slice index outside the store reads as all padding)
-  const int wx0 = crop_first ? left - pad : 0, wy0 = crop_first ? top - pad : 0, ww = crop_first ? OW : WS,
-            wh = crop_first ? OH : HS;
-  const bool slice_ok = slice >= 0 && slice < S;
-  auto inside = [&](int xc, int yc) -> bool {
+    for (int k = 0; k < 6; ++k) m[k] = __hiloint2double(pr[14 + 2 * k + 1], pr[14 + 2 * k]);  // (little endian: low word first)
+    b_in = b >= 0.f && b <= 1.f; c_in = c >= 0.f && c <= 1.f;
+    contrast_first = flags & 4; bilinear = flags & 8; crop_first = flags & 16;
+    HS = HS_; WS = WS_; OH = OH_; OW = OW_;
+    img = src + (size_t)slice * HS * WS;
+    lab = labels != nullptr ? labels + (size_t)slice * HS * WS : nullptr;
+    // the image the rotation acts on: the slice, or its crop (a window of it)
+    // (crop first: RandomCrop(padding=) pads with zeros BEFORE it crops -- the window's origin is (top - pad, left - pad) of
+    // the slice and window pixels outside the slice are the padding's zeros; a slice index outside the store reads as all
+    // padding)
+    wx0 = crop_first ? left - pad : 0; wy0 = crop_first ? top - pad : 0;
+    ww = crop_first ? OW : WS; wh = crop_first ? OH : HS;
+    slice_ok = slice >= 0 && slice < S;
+  }
+  __device__ __forceinline__ bool inside(int xc, int yc) const {
     const int ys = wy0 + yc, xs = wx0 + xc;
     return slice_ok && ys >= 0 && ys < HS && xs >= 0 && xs < WS;
-  };
-  auto level = [&](int xc, int yc) -> int {  // 8-bit grey level of window pixel (xc, yc)
+  }
+  __device__ __forceinline__ int level(int xc, int yc) const {  // 8-bit grey level of window pixel (xc, yc)
     if (!inside(xc, yc)) return 0;
     return (int)__fadd_rn(__fmul_rn(img[(size_t)(wy0 + yc) * WS + wx0 + xc], 255.f), 0.5f);
-  };
+  }
   // (x, y): the pixel of the ROTATED window this output pixel shows, or none
-  auto locate = [&](int p, int& x, int& y) -> bool {
+  __device__ __forceinline__ bool locate(int p, int& x, int& y) const {
     const int i = p / OW, j = p - i * OW;
     if (crop_first) { x = j; y = i; return true; }
     y = i + top - pad;
@@ -256,8 +262,8 @@ __global__ __launch_bounds__(1024) void augment_views_recipe_kernel(const float*
     if (flags & 1) x = WS - 1 - x;
     if (flags & 2) y = HS - 1 - y;
     return true;
-  };
-  auto sample = [&](int p) -> int {
+  }
+  __device__ __forceinline__ int sample(int p) const {
     int x, y;
     if (!locate(p, x, y)) return 0;
     if (!bilinear) {
@@ -283,14 +289,38 @@ __global__ __launch_bounds__(1024) void augment_views_recipe_kernel(const float*
     }
     v1 = __dadd_rn(v1, __dmul_rn(__dsub_rn(v2, v1), dy));
     return (int)v1;  // (UINT8) of a value inside [0, 255]
-  };
+  }
+  // the level the contrast step sees (and averages): the sample, through the brightness step unless contrast comes first
+  __device__ __forceinline__ int before_contrast(int p) const {
+    const int u = sample(p);
+    return contrast_first ? u : pil_blend(0, u, b, b_in);
+  }
+  __device__ __forceinline__ float finish(int u, int mean) const {
+    u = pil_blend(mean, u, c, c_in);
+    if (contrast_first) u = pil_blend(0, u, b, b_in);
+    return __fdiv_rn((float)u, 255.f);
+  }
+  __device__ __forceinline__ long long label(int p) const {  // the label map through the same geometry, NEAREST
+    int x, y, lv = 0;
+    if (locate(p, x, y)) {
+      const int xin = (a2 + x * a0 + y * a1) >> 16, yin = (a5 + x * a3 + y * a4) >> 16;
+      if (xin >= 0 && xin < ww && yin >= 0 && yin < wh && inside(xin, yin)) lv = lab[(size_t)(wy0 + yin) * WS + wx0 + xin];
+    }
+    return lv;
+  }
+};
+
+__global__ __launch_bounds__(1024) void augment_views_recipe_kernel(const float* __restrict__ src,
+                                                                    const unsigned char* __restrict__ labels, int S, int HS,
+                                                                    int WS, const int* __restrict__ params,
+                                                                    float* __restrict__ out, long long* __restrict__ label_out,
+                                                                    int OH, int OW) {
+  __shared__ int red[16];
+  const int v = blockIdx.x;
+  const RecipeView rv(src, labels, S, HS, WS, params + v * RECIPE_W, OH, OW);
   const int np = OH * OW;
   int part = 0;
-  for (int p = threadIdx.x; p < np; p += 1024) {
-    int u = sample(p);
-    if (!contrast_first) u = pil_blend(0, u, b, b_in);
-    part += u;
-  }
+  for (int p = threadIdx.x; p < np; p += 1024) part += rv.before_contrast(p);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
@@ -301,19 +331,73 @@ __global__ __launch_bounds__(1024) void augment_views_recipe_kernel(const float*
   const int mean = (int)((2 * total + np) / (2LL * np));  // int(sum / count + 0.5), exactly
   float* o = out + (size_t)v * np;
   for (int p = threadIdx.x; p < np; p += 1024) {
-    int u = sample(p);
-    if (!contrast_first) u = pil_blend(0, u, b, b_in);
-    u = pil_blend(mean, u, c, c_in);
+    o[p] = rv.finish(rv.before_contrast(p), mean);
+    if (label_out != nullptr) label_out[(size_t)v * np + p] = rv.label(p);
+  }
+}
+
+// The same views from a grid that fills the chip (round 6).  One workgroup per view was 60 workgroups for a pre-train batch
+// -- a quarter of the CUs -- each sampling its 50 176 pixels TWICE (the contrast step needs the view's mean first): 180 us,
+// the longest launch of a training step on the product's own data path.  Split: G workgroups per view (four pixels per
+// thread: a pixel is a chain of dependent gathers, the launch is bound by how many are in flight) sample a chunk each ONCE,
+// park the levels as bytes and leave their integer partial sum; the second launch adds a view's partials in index order
+// (integers: the mean is the one-workgroup kernel's, bit for bit) and finishes the pixels.  60 views of 224^2: 33.6 + 7.4 us
+// with 16 workgroups per view, see profiles/r06_experiments/NOTES.md for the final split.
+constexpr int AUG_SPLIT_MAX = 64;
+static int aug_split(int np) {
+  const int g = (np + 1023) / 1024;
+  return g < 1 ? 1 : (g > AUG_SPLIT_MAX ? AUG_SPLIT_MAX : g);
+}
+__global__ __launch_bounds__(256) void augment_recipe_sample_kernel(const float* __restrict__ src,
+                                                                   const unsigned char* __restrict__ labels, int S, int HS,
+                                                                   int WS, const int* __restrict__ params,
+                                                                   unsigned char* __restrict__ levels,
+                                                                   long long* __restrict__ partials,
+                                                                   long long* __restrict__ label_out, int OH, int OW) {
+  __shared__ int red[4];
+  const int v = blockIdx.y, g = blockIdx.x, AUG_SPLIT = gridDim.x;
+  const RecipeView rv(src, labels, S, HS, WS, params + v * RECIPE_W, OH, OW);
+  const int np = OH * OW, chunk = (np + AUG_SPLIT - 1) / AUG_SPLIT;
+  const int p0 = g * chunk, p1 = min(np, p0 + chunk);
+  int part = 0;
+  for (int p = p0 + threadIdx.x; p < p1; p += 256) {
+    const int u = rv.before_contrast(p);
+    levels[(size_t)v * np + p] = (unsigned char)u;
+    part += u;
+    if (label_out != nullptr) label_out[(size_t)v * np + p] = rv.label(p);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[v * AUG_SPLIT + g] = (long long)red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void augment_recipe_finish_kernel(const int* __restrict__ params,
+                                                                   const unsigned char* __restrict__ levels,
+                                                                   const long long* __restrict__ partials,
+                                                                   float* __restrict__ out, int np, int AUG_SPLIT) {
+  const int v = blockIdx.y;
+  const int* pr = params + v * RECIPE_W;
+  const int flags = pr[1];
+  const float b = __int_as_float(pr[5]), c = __int_as_float(pr[6]);
+  const bool b_in = b >= 0.f && b <= 1.f, c_in = c >= 0.f && c <= 1.f, contrast_first = flags & 4;
+  // the view's sum: one partial per lane of the first wave (AUG_SPLIT <= 64), added by shuffles -- integers: any order is exact
+  __shared__ long long tot_s;
+  if (threadIdx.x < 64) {
+    long long x = (int)threadIdx.x < AUG_SPLIT ? partials[v * AUG_SPLIT + threadIdx.x] : 0LL;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    if (threadIdx.x == 0) tot_s = x;
+  }
+  __syncthreads();
+  const long long total = tot_s;
+  const int mean = (int)((2 * total + np) / (2LL * np));  // int(sum / count + 0.5), exactly
+  const size_t base = (size_t)v * np;
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < np; p += gridDim.x * 256) {
+    int u = pil_blend(mean, (int)levels[base + p], c, c_in);
     if (contrast_first) u = pil_blend(0, u, b, b_in);
-    o[p] = __fdiv_rn((float)u, 255.f);
-    if (label_out != nullptr) {  // the label map through the same geometry, NEAREST
-      int x, y, lv = 0;
-      if (locate(p, x, y)) {
-        const int xin = (a2 + x * a0 + y * a1) >> 16, yin = (a5 + x * a3 + y * a4) >> 16;
-        if (xin >= 0 && xin < ww && yin >= 0 && yin < wh && inside(xin, yin)) lv = lab[(size_t)(wy0 + yin) * WS + wx0 + xin];
-      }
-      label_out[(size_t)v * np + p] = lv;
-    }
+    out[base + p] = __fdiv_rn((float)u, 255.f);
   }
 }
 
@@ -357,6 +441,36 @@ extern "C" int spcl_augment_views_recipe(const float* src, const unsigned char* 
   SPCL_LAUNCH(augment_views_recipe_kernel, dim3(nviews), dim3(1024), 0, (hipStream_t)stream, src, labels, S, HS, WS, params, out,
               label_out, OH, OW);
   SPCL_LAUNCH_CHECK("augment_views_recipe");
+  return SPCL_OK;
+}
+
+extern "C" size_t spcl_augment_views_recipe_workspace_bytes(int nviews, int OH, int OW) {
+  if (nviews <= 0 || OH <= 0 || OW <= 0) return 0;
+  return (size_t)nviews * AUG_SPLIT_MAX * sizeof(long long) + (size_t)nviews * OH * OW;
+}
+
+extern "C" int spcl_augment_views_recipe_ws(const float* src, const unsigned char* labels, int S, int HS, int WS,
+                                            const int* params, int nviews, float* out, long long* label_out, int OH, int OW,
+                                            int max_pad, void* workspace, size_t workspace_bytes, void* stream) {
+  SPCL_CHECK_ARG(src && params && out && workspace, "augment_views_recipe_ws: null pointer");
+  SPCL_CHECK_ARG((labels != nullptr) == (label_out != nullptr), "augment_views_recipe_ws: labels come with label_out");
+  SPCL_CHECK_ARG(S > 0 && HS > 0 && WS > 0 && nviews > 0 && nviews <= 65535 && OH > 0 && OW > 0 && max_pad >= 0 &&
+                     OH <= HS + 2 * max_pad && OW <= WS + 2 * max_pad && HS <= 4096 && WS <= 4096,
+                 "augment_views_recipe_ws: bad shape (crop %dx%d of %dx%d + %d)", OH, OW, HS, WS, max_pad);
+  SPCL_CHECK_ARG(workspace_bytes >= spcl_augment_views_recipe_workspace_bytes(nviews, OH, OW) && (uintptr_t)workspace % 8 == 0,
+                 "augment_views_recipe_ws: workspace of %zu bytes, 8-byte aligned",
+                 spcl_augment_views_recipe_workspace_bytes(nviews, OH, OW));
+  long long* partials = (long long*)workspace;
+  unsigned char* levels = (unsigned char*)(partials + (size_t)nviews * AUG_SPLIT_MAX);
+  const int np = OH * OW, G = aug_split(np);
+  hipStream_t st = (hipStream_t)stream;
+  SPCL_LAUNCH(augment_recipe_sample_kernel, dim3(G, nviews), dim3(256), 0, st, src, labels, S, HS, WS, params, levels,
+              partials, label_out, OH, OW);
+  int fin = (np + 256 * 8 - 1) / (256 * 8);  // eight pixels per thread
+  if (fin < 1) fin = 1;
+  SPCL_LAUNCH(augment_recipe_finish_kernel, dim3(fin, nviews), dim3(256), 0, st, params, (const unsigned char*)levels,
+              (const long long*)partials, out, np, G);
+  SPCL_LAUNCH_CHECK("augment_views_recipe_ws");
   return SPCL_OK;
 }
 

@@ -18,6 +18,23 @@ import torch
 from ... import native as _n
 
 
+def _upload_i32(rows, device):
+    """parameter rows (nested lists of ints) -> int32 device tensor WITHOUT a host-device memcpy: the bytes travel as kernel
+    arguments (``spcl_stage_bytes``, 3.5 KB per launch).  ``torch.tensor(rows).to(device)`` copies from pageable memory,
+    which makes the host wait until the stream has drained -- once per batch: the loader could never run ahead of the step
+    (measured: 1.19 ms per pre-train step of 30 slices on the product's data path, 0.98 - 1.0 with this upload;
+    tools/diag/pretrain_epoch_time.py ... real)."""
+    import ctypes
+
+    import numpy as np
+    arr = np.ascontiguousarray(np.asarray(rows, dtype=np.int32))
+    out = torch.empty(arr.shape, dtype=torch.int32, device=device)
+    if arr.size:
+        _n.call("spcl_stage_bytes", ctypes.c_void_p(out.data_ptr()), arr.ctypes.data_as(ctypes.c_void_p), arr.nbytes,
+                _n.stream())
+    return out
+
+
 def _f32_bits(x: float) -> int:
     return struct.unpack("<i", struct.pack("<f", x))[0]
 
@@ -253,11 +270,15 @@ class RecipeViews:
         S, HS, WS = self.images.shape
         oh, ow = self.out_hw
         dev = self.images.device
-        p = torch.tensor(rows, dtype=torch.int32).to(dev, non_blocking=True)
+        p = _upload_i32(rows, dev)
         out = torch.empty(len(rows), 1, oh, ow, dtype=torch.float32, device=dev)
         lab_out = torch.empty(len(rows), 1, oh, ow, dtype=torch.int64, device=dev) if with_labels else None
-        _n.call("spcl_augment_views_recipe", _n.ptr(self.images), _n.ptr(self.labels) if with_labels else None, S, HS, WS,
-                _n.ptr(p), len(rows), _n.ptr(out), _n.ptr(lab_out), oh, ow, int(self.recipe["pad"]), _n.stream())
+        # (the split form: 16 workgroups per view instead of one, every pixel sampled once -- include/spcl_hip.h)
+        ws = torch.empty(_n.call("spcl_augment_views_recipe_workspace_bytes", len(rows), oh, ow) // 8 + 1, dtype=torch.int64,
+                         device=dev)
+        _n.call("spcl_augment_views_recipe_ws", _n.ptr(self.images), _n.ptr(self.labels) if with_labels else None, S, HS, WS,
+                _n.ptr(p), len(rows), _n.ptr(out), _n.ptr(lab_out), oh, ow, int(self.recipe["pad"]), _n.ptr(ws),
+                ws.numel() * 8, _n.stream())
         return (out, lab_out) if with_labels else out
 
     def pairs(self, indices: Sequence[int], rng=random):
@@ -296,11 +317,11 @@ class PretrainViews:
         """rows: parameter rows (lists of 12 ints, or 8 for the float recipe) -> [len(rows), 1, oh, ow] f32"""
         S, HS, WS = self.images.shape
         oh, ow = self.out_hw
-        p = torch.tensor(rows, dtype=torch.int32).to(self.images.device, non_blocking=True)
-        out = torch.empty(len(rows), 1, oh, ow, dtype=torch.float32, device=self.images.device)
         width = len(rows[0])
         if width not in (8, 12) or any(len(r) != width for r in rows):
             raise ValueError("PretrainViews.apply: parameter rows of 12 ints (PIL-exact) or 8 ints (float recipe)")
+        p = _upload_i32(rows, self.images.device)
+        out = torch.empty(len(rows), 1, oh, ow, dtype=torch.float32, device=self.images.device)
         entry = "spcl_augment_views_pil" if width == 12 else "spcl_augment_views"
         _n.call(entry, _n.ptr(self.images), S, HS, WS, _n.ptr(p), len(rows), _n.ptr(out), oh, ow, _n.stream())
         return out

@@ -286,3 +286,32 @@ def test_labelled_loader_and_default_pretrain_recipe():
     assert isinstance(loader._views, RecipeViews) and loader._views.recipe["degrees"] == 45.0
     (a, b, _, _), _, _ = next(iter(loader))
     assert tuple(a.shape) == (4, 1, 224, 224) and not torch.equal(a, b)
+
+
+def test_split_recipe_launches_equal_the_one_workgroup_launch():
+    """``spcl_augment_views_recipe_ws`` (16 workgroups per view + a finishing launch: what RecipeViews calls since round 6) against
+    ``spcl_augment_views_recipe`` (one workgroup per view) on drawn pre-train and labelled rows: every pixel of every view and
+    label map, bit for bit -- the partial sums are integers, the contrast step's mean is the same number."""
+    from spcl_amd import native as _n
+    from spcl_amd.semi_seg.data import augment as A
+    store = _store(scans=6, slices_per_scan=(5, 7), size=256, seed=12)
+    S, HS, WS = store.images.shape
+    labels = (torch.rand(S, HS, WS, device="cuda") * 4).to(torch.uint8)
+    rng = random.Random(7)
+    for recipe, with_labels, out_hw in (("acdc_pretrain", False, (224, 224)), ("prostate_pretrain", False, (224, 224)),
+                                        ("acdc_label", True, (224, 224)), ("acdc_pretrain", False, (97, 131))):
+        views = A.RecipeViews(store.images, recipe, out_hw, labels=labels if with_labels else None)
+        rows = views.rows([rng.randrange(S) for _ in range(23)], rng)
+        got = views.apply(rows, with_labels=with_labels)
+        p = A._upload_i32(rows, "cuda")
+        oh, ow = out_hw
+        ref = torch.empty(len(rows), 1, oh, ow, dtype=torch.float32, device="cuda")
+        ref_lab = torch.empty(len(rows), 1, oh, ow, dtype=torch.int64, device="cuda") if with_labels else None
+        si, hs, ws = views.images.shape
+        _n.call("spcl_augment_views_recipe", _n.ptr(views.images), _n.ptr(views.labels) if with_labels else None, si, hs, ws,
+                _n.ptr(p), len(rows), _n.ptr(ref), _n.ptr(ref_lab), oh, ow, int(views.recipe["pad"]), _n.stream())
+        if with_labels:
+            assert torch.equal(got[0], ref) and torch.equal(got[1], ref_lab), recipe
+        else:
+            assert torch.equal(got, ref), recipe
+        assert float(ref.max()) > 0.0

@@ -32,6 +32,12 @@ params = [p for p in model.parameters() if p.requires_grad] + list(hook.paramete
 flat = ddp.FlatParams(params)
 opt = FusedRAdam([flat.param], lr=5e-7 * 400, weight_decay=1e-5)
 loader = SyntheticPretrainLoader(bs=32, size=224, device=dev, seed=1234, resident=True, meta="acdc", pool=8)
+if len(sys.argv) > 2 and sys.argv[2] == "real":
+    # the product's own data path: a device-resident store of 8-bit slices, the reference's contrastive batch
+    # sampler (config/pretrain.yaml: 10 scans x 3 partitions = 30 slices), both views augmented on the device every step
+    from spcl_amd.semi_seg.data import get_contrastive_dataloader, synthetic_slice_store
+    store = synthetic_slice_store(device="cuda", scans=100, slices_per_scan=(9, 12), size=256, seed=6)
+    loader = iter(get_contrastive_dataloader(store, {"scan_sample_num": 10, "partition_sample_num": 1})[0])
 model.train()
 for epoch in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
     torch.cuda.synchronize()
@@ -39,11 +45,13 @@ for epoch in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
     ep = PretrainEncoderEpocher(model=model, optimizer=opt, chain_dataloader=loader, num_batches=200, device=dev,
                                 inference_until="Conv5", flat_params=flat, cur_epoch=epoch)
     ep.add_hooks([hook()])  # (the trainer-level hook hands out the epoch's hook: the age parameter follows its schedule)
-    ts = []
+    ts, tl = [], []
     with ep.meters.focus_on(ep.meter_focus):
         for i in range(200):
             a = time.perf_counter()
-            ep.step(next(loader))
+            batch = next(loader)
+            tl.append(time.perf_counter() - a)
+            ep.step(batch)
             if i < 4:
                 torch.cuda.synchronize()
             ts.append(time.perf_counter() - a)
@@ -51,4 +59,5 @@ for epoch in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
     ep.close_hooks()
     tot = time.perf_counter() - t0
     print(f"epoch {epoch}: total {tot * 1e3:.1f} ms; steps 0-3 (synchronised) {[round(t * 1e3, 2) for t in ts[:4]]} ms; "
-          f"(total - first four) / 196 = {(tot - sum(ts[:4])) / 196 * 1e3:.3f} ms", flush=True)
+          f"(total - first four) / 196 = {(tot - sum(ts[:4])) / 196 * 1e3:.3f} ms; host per step: loader "
+          f"{sorted(tl[4:])[98] * 1e6:.0f} us, loader + step {sorted(ts[4:])[98] * 1e6:.0f} us", flush=True)
