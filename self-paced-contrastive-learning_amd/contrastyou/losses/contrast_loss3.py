@@ -88,12 +88,51 @@ class _SupConBase(nn.Module):
             self._host_out = self._state.out.tolist()  # the single device->host readback
         return self._host_out
 
-    def check(self):
-        """Unit-norm assertion (contrast_loss3.py:62,154) and NaN guard (:107-108,203-204) of the last call."""
-        out = self._out()
+    @staticmethod
+    def _check_block(out):
         assert out[3] <= 1e-8 + 1e-5, "features need to be normalized first"
         if math.isnan(out[0]):
             raise RuntimeError(torch.tensor(out[0]))
+
+    def check(self):
+        """Unit-norm assertion (contrast_loss3.py:62,154) and NaN guard (:107-108,203-204) of the last call."""
+        self._check_block(self._out())
+
+    # A step replayed from a hipGraph is checked WITHOUT draining the queue: its result block is copied to pinned host memory
+    # behind the replay (asynchronously, with an event), and what is LOOKED AT is the previous step's copy, whose event fired
+    # a step ago.  The reference's errors are all raised (same types, same messages), one step after the step that earned
+    # them -- whose optimizer update, part of the same graph, had run by the time of a readback anyway -- or when the
+    # epoch's hooks close (``flush_check``).  With a readback per step the host cannot prepare step k + 1 while the GPU runs
+    # step k: 1.0 ms of kernels + 0.74 ms of host work per step instead of max(...) of them -- the reference's own
+    # configuration ran at 16 k slices/s instead of 27 k (tools/diag/pretrain_trainer_epochs.py).
+    def check_lagged(self):
+        lag = self.__dict__.get("_lag")
+        if lag is None:
+            lag = self.__dict__["_lag"] = {"slots": [], "pending": None, "next": 0}
+        if self._state is None or not self._state.out.is_cuda:
+            return self.check()
+        if not lag["slots"]:
+            lag["slots"] = [(torch.empty(self._state.out.numel(), dtype=self._state.out.dtype).pin_memory(),
+                             torch.cuda.Event()) for _ in range(2)]
+        host, ev = lag["slots"][lag["next"]]
+        host.copy_(self._state.out.reshape(-1), non_blocking=True)
+        ev.record()
+        prev, lag["pending"] = lag["pending"], lag["next"]
+        lag["next"] ^= 1
+        if prev is not None:
+            self._check_slot(prev)
+
+    def _check_slot(self, idx):
+        host, ev = self.__dict__["_lag"]["slots"][idx]
+        ev.synchronize()
+        self._check_block(host.tolist())
+
+    def flush_check(self):
+        """look at the copy ``check_lagged`` has pending (the hooks call it when they close: no error is lost)"""
+        lag = self.__dict__.get("_lag")
+        if lag and lag["pending"] is not None:
+            idx, lag["pending"] = lag["pending"], None
+            self._check_slot(idx)
 
     # ---- hook taps (contrast_loss3.py:83-88,175-178,188) --------------------------------------------------
     def _tap(self, name):

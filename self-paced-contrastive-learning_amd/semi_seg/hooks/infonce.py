@@ -305,6 +305,8 @@ class _INFONCEEpochHook(EpocherHook):
 
     def close(self):
         self._extractor.remove()
+        if hasattr(self._criterion, "flush_check"):
+            self._criterion.flush_check()  # (the last replayed step's check, see ``after_replay``)
 
     def graph_key(self):
         """replayable when the projector pools to (1, 1) (no seeded feature flip, `_two_views`) and no TensorBoard tap is
@@ -322,7 +324,7 @@ class _INFONCEEpochHook(EpocherHook):
         c = self._criterion
         c._taps_cache = c._host_out = None  # the captured result block now holds the new step's values
         if c.sync_checks:
-            c.check()  # the reference's unit-norm assertion / NaN guard, one readback (as in an eager step)
+            c.check_lagged()  # the reference's unit-norm assertion / NaN guard, without draining the queue (one step late)
 
 
 class _SPINFONCEEpochHook(_INFONCEEpochHook):

@@ -111,19 +111,30 @@ def test_graphed_three_hooks_and_sync_checks():
 
 
 def test_replay_reports_nan_like_the_eager_step():
-    """``RuntimeError(loss)`` on NaN (contrast_loss3.py:203-204) survives the graph: checked after the replay"""
-    net, hook, flat, opt, ep = _setup(True, torch.float32, sync_checks=True)
-    batches = _batches(5, 8, 32)
-    _run(ep, batches[:4])
-    assert ep._step_graph.captured
-    with torch.no_grad():
-        flat.data[-300:] = float("nan")  # the projector's last bias (a NaN in a conv weight dies in the next ReLU's fmax)
-    with pytest.raises((RuntimeError, AssertionError)):
+    """``RuntimeError(loss)`` on NaN (contrast_loss3.py:203-204) survives the graph.  A replayed step is checked without
+    draining the queue (its result block is copied to pinned memory behind the replay, the PREVIOUS step's copy is looked at):
+    the error of step k is raised by step k + 1 -- or, for the last step, when the epoch's hooks close."""
+    for how in ("next step", "close"):
+        net, hook, flat, opt, ep = _setup(True, torch.float32, sync_checks=True)
+        batches = _batches(6, 8, 32)
+        _run(ep, batches[:4])
+        assert ep._step_graph.captured
+        with torch.no_grad():
+            flat.data[-300:] = float("nan")  # the projector's last bias (a NaN in a conv weight dies in the next ReLU's fmax)
         with ep.meters.focus_on(ep.meter_focus):
-            ep.step(batches[4])
-    # a staged step that raised drops the optimizer's host mirror of the step count (it advances at fill time, before it is
-    # known whether the update launch follows: ADVICE r05); the device counter is the authority -- here the replay did run
-    assert not opt._step_host and int(opt.state[flat.param]["step"].item()) == 5
+            ep.step(batches[4])  # the step that earns the error: enqueued, not waited for
+        with pytest.raises((RuntimeError, AssertionError)):
+            if how == "close":
+                ep.close_hooks()
+            else:
+                with ep.meters.focus_on(ep.meter_focus):
+                    ep.step(batches[5])
+        if how == "next step":
+            # a staged step that raised drops the optimizer's host mirror of the step count (it advances at fill time, before
+            # it is known whether the update launch follows: ADVICE r05); the device counter is the authority -- both replays ran
+            assert not opt._step_host and int(opt.state[flat.param]["step"].item()) == 6
+        if how == "close":
+            ep._hooks = []  # (already closed)
 
 
 def test_ragged_batch_runs_eagerly_and_graph_survives():
