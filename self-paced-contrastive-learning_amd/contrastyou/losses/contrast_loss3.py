@@ -50,6 +50,12 @@ class _SupConBase(nn.Module):
         self._state: Optional[F_hip.SupConState] = None
         self._taps_cache = None
         self._host_out = None
+        self._lag = None  # ``check_lagged``: two pinned copies of the result block with their events, which one is pending
+
+    def __getstate__(self):  # (copy / pickle: the pinned buffers and events stay behind)
+        d = dict(self.__dict__)
+        d["_lag"] = None
+        return d
 
     # ---- inputs -------------------------------------------------------------------------------------------
     @staticmethod
@@ -106,11 +112,11 @@ class _SupConBase(nn.Module):
     # step k: 1.0 ms of kernels + 0.74 ms of host work per step instead of max(...) of them -- the reference's own
     # configuration ran at 16 k slices/s instead of 27 k (tools/diag/pretrain_trainer_epochs.py).
     def check_lagged(self):
-        lag = self.__dict__.get("_lag")
-        if lag is None:
-            lag = self.__dict__["_lag"] = {"slots": [], "pending": None, "next": 0}
         if self._state is None or not self._state.out.is_cuda:
             return self.check()
+        lag = self._lag
+        if lag is None:
+            lag = self._lag = {"slots": [], "pending": None, "next": 0}
         if not lag["slots"]:
             lag["slots"] = [(torch.empty(self._state.out.numel(), dtype=self._state.out.dtype).pin_memory(),
                              torch.cuda.Event()) for _ in range(2)]
@@ -123,13 +129,13 @@ class _SupConBase(nn.Module):
             self._check_slot(prev)
 
     def _check_slot(self, idx):
-        host, ev = self.__dict__["_lag"]["slots"][idx]
+        host, ev = self._lag["slots"][idx]
         ev.synchronize()
         self._check_block(host.tolist())
 
     def flush_check(self):
         """look at the copy ``check_lagged`` has pending (the hooks call it when they close: no error is lost)"""
-        lag = self.__dict__.get("_lag")
+        lag = self._lag
         if lag and lag["pending"] is not None:
             idx, lag["pending"] = lag["pending"], None
             self._check_slot(idx)
