@@ -53,7 +53,7 @@ trainer.register_hooks(*hooks)
 trainer.forward_until = feature_until_from_hooks(*hooks)
 stamps = [time.perf_counter()]
 orig_save = trainer.save_to
-save_s = []
+save_s, mem = [], []
 
 
 def timed_save(*a, **k):
@@ -62,6 +62,7 @@ def timed_save(*a, **k):
     out = orig_save(*a, **k)
     save_s.append(time.perf_counter() - t)
     stamps.append(time.perf_counter())
+    mem.append((torch.cuda.memory_reserved() / 2 ** 30, torch.cuda.memory_allocated() / 2 ** 30))
     return out
 
 
@@ -73,4 +74,5 @@ with model.set_grad(False, start=trainer.forward_until, include_start=False):
 torch.cuda.synchronize()
 for i in range(1, len(stamps)):
     print(f"epoch {i}: {1e3 * (stamps[i] - stamps[i - 1]):.1f} ms of which checkpoint write {1e3 * save_s[i - 1]:.1f} ms "
-          f"({6000 / (stamps[i] - stamps[i - 1]) / 1e3:.1f} k slices/s)", flush=True)
+          f"({6000 / (stamps[i] - stamps[i - 1]) / 1e3:.1f} k slices/s); device memory reserved {mem[i - 1][0]:.2f} GiB, "
+          f"allocated {mem[i - 1][1]:.2f} GiB", flush=True)
