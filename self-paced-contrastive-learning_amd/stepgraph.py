@@ -162,6 +162,30 @@ def gc_release(final: bool = True):
     _WE_FROZE = False
 
 
+_STEP_POOLS = {}
+
+
+def step_pool(device=None):
+    """the ONE graph memory pool per device that every step graph is captured into (``StepGraph._capture``).  A pool lives as
+    long as a graph holds it (the allocator asserts on a handle whose last graph is gone): a one-launch anchor graph, never
+    replayed, is captured into it once and kept."""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    if dev is None:
+        dev = torch.cuda.current_device()
+    if dev not in _STEP_POOLS:
+        handle = torch.cuda.graph_pool_handle()
+        anchor = torch.cuda.CUDAGraph()
+        side, cur = side_stream(dev), torch.cuda.current_stream(dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            anchor.capture_begin(pool=handle)
+            keep = torch.zeros(16, device=torch.device("cuda", dev))
+            anchor.capture_end()
+        cur.wait_stream(side)
+        _STEP_POOLS[dev] = (handle, anchor, keep)
+    return _STEP_POOLS[dev][0]
+
+
 def side_stream(device=None):
     """the ONE private stream per device on which everything a step graph may later capture runs: warm steps, captures,
     and the eager steps of an epocher that graphs its steps (a ragged batch, a hook without a key).  autograd's
@@ -239,7 +263,7 @@ class StepGraph:
             return fn()
         self._capturing[-1].capture_end()
         g = torch.cuda.CUDAGraph()
-        g.capture_begin(pool=self._capturing[0].pool(), capture_error_mode="relaxed")
+        g.capture_begin(pool=step_pool(), capture_error_mode="relaxed")
         self._capturing.append(g)
         self._cuts.append(fn)
         return None
@@ -309,37 +333,53 @@ class StepGraph:
         torch.cuda.synchronize()
         state = {}
         _meters.begin_host_log()
+        # Captures are begun and ended by hand, not by ``torch.cuda.graph``: (1) ``cut`` may end a graph half way through
+        # ``compute()``; (2) the context manager collects garbage (done above, cheaply) and EMPTIES THE ALLOCATOR'S CACHE --
+        # with a new epocher, i.e. a new capture, every 200 steps that was 6 - 7 ms per epoch of hipFree / hipMalloc for the
+        # same ~1.5 GB of activations (tools/diag/capture_cost.py: graph.__enter__ 9.5 ms of a 14 ms capture step).  All
+        # step graphs of a device share ONE memory pool instead: the blocks the previous epoch's graph gave back when it was
+        # collected are the blocks this capture takes.
+        mode = "relaxed" if self._split else "global"
+        pool = step_pool()
+
+        def begin():
+            g = torch.cuda.CUDAGraph()
+            g.capture_begin(pool=pool, capture_error_mode=mode)
+            return g
+
+        def capture(body, graphs):
+            """``body()`` captured into ``graphs`` (a list that ``cut`` may extend through ``self._capturing``)"""
+            try:
+                body()
+            except BaseException:
+                try:  # leave the stream out of capture mode whatever happened
+                    graphs[-1].capture_end()
+                except Exception:  # noqa: BLE001
+                    pass
+                raise
+            graphs[-1].capture_end()
+
         try:
-            if self._split:
-                # (what ``torch.cuda.graph`` does around a capture, by hand: ``cut`` may end the first graph half way)
-                torch.cuda.empty_cache()
-                self._cuts = []
-                with torch.cuda.stream(self._stream):
-                    self._capturing = [torch.cuda.CUDAGraph()]
-                    self._capturing[0].capture_begin(capture_error_mode="relaxed")
+            with torch.cuda.stream(self._stream):
+                if self._split:
+                    self._cuts = []
+                    self._capturing = [begin()]
                     try:
-                        state["loss"] = self._compute()
-                    except BaseException:
-                        try:  # leave the stream out of capture mode whatever happened
-                            self._capturing[-1].capture_end()
-                        except Exception:  # noqa: BLE001
-                            pass
-                        raise
-                    else:
-                        self._capturing[-1].capture_end()
+                        capture(lambda: state.__setitem__("loss", self._compute()), self._capturing)
                     finally:
                         compute_graphs, self._capturing = self._capturing, None
-                gb = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gb, pool=compute_graphs[0].pool(), stream=self._stream):
-                    self._update(state["loss"])
-                self._graphs = (*compute_graphs, gb)
-            else:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=self._stream):
-                    state["loss"] = self._compute()
-                    self._exchange()  # (a no-op in a one-process job; see ``collective_in_graph``)
-                    self._update(state["loss"])
-                self._graphs = (g,)
+                    gb = [begin()]
+                    capture(lambda: self._update(state["loss"]), gb)
+                    self._graphs = (*compute_graphs, gb[0])
+                else:
+                    g = [begin()]
+
+                    def whole():
+                        state["loss"] = self._compute()
+                        self._exchange()  # (a no-op in a one-process job; see ``collective_in_graph``)
+                        self._update(state["loss"])
+                    capture(whole, g)
+                    self._graphs = (g[0],)
         finally:
             self._host_log = _meters.end_host_log()
         self._result = state["loss"]
