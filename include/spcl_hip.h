@@ -36,7 +36,7 @@ extern "C" {
 /* Bumped whenever a struct layout, a limit (SPCL_*_MAX) or an entry point's meaning changes.  The library is git-ignored and
  * travels next to the sources: the Python binding (native.py) refuses a library whose version is not the header's, so that a
  * stale build fails at load time instead of running kernels on structs of another stride. */
-#define SPCL_ABI_VERSION 7
+#define SPCL_ABI_VERSION 8
 int spcl_abi_version(void);
 const char* spcl_last_error(void);
 
@@ -631,6 +631,23 @@ int spcl_augment_views(const float* src, int S, int HS, int WS, const int* param
  * oracle.augment_view_pil. */
 int spcl_augment_views_pil(const float* src, int S, int HS, int WS, const int* params, int nviews, float* out, int OH,
                            int OW, void* stream);
+/* The pixel-wise (1x1-convolution) MLP of the dense projector -- contrastyou/projectors/heads.py:28-39,96-120:
+ * Conv2d(C, hid, 1) -> LeakyReLU(0.01) -> Conv2d(hid, out, 1) on every pixel of a decoder feature map -- as tiled
+ * matrix products over the M = N*H*W pixel rows on the exact-f32 matrix instruction (ABI 8; until then the rows went through the
+ * global projector's 64-row kernels: 158 ms per training step at Up_conv3, 630 ms at Up_conv2).  Row-major operands:
+ *   forward          y[M][N]  = act(x)[M][K] W[N][K]^T + bias[N]      x: f32 or bf16 rows of pitch ldx (a channels-last map read
+ *                                                                      in place), act = LeakyReLU(0.01) when leaky_in (x is then a saved f32 pre-activation)
+ *   backward_input   dx[M][K] = (g[M][N] W[N][K]) * (pre ? LeakyReLU'(pre[M][K]) : 1)     dx: f32 or bf16 rows of pitch lddx
+ *   backward_weight  dW[N][K] = sum_m g[m][N] act(x)[m][K],  db[N] = sum_m g[m][N]  (db may be NULL): slabs of rows folded in
+ *                    index order (bit-deterministic); ws of spcl_rows_linear_backward_weight_workspace_bytes(M, N, K).
+ * K, N and the row pitches are multiples of 4. */
+int spcl_rows_linear_forward(const void* x, int x_dtype, long ldx, int leaky_in, const float* W, const float* bias, int M,
+                             int K, int N, float* y, void* stream);
+int spcl_rows_linear_backward_input(const float* g, const float* W, const float* pre, int M, int N, int K, void* dx,
+                                    int dx_dtype, long lddx, void* stream);
+size_t spcl_rows_linear_backward_weight_workspace_bytes(int M, int N, int K);
+int spcl_rows_linear_backward_weight(const float* g, const void* x, int x_dtype, long ldx, int leaky_in, int M, int N, int K,
+                                     float* ws, size_t ws_bytes, float* dW, float* db, void* stream);
 /* The reference's other PIL recipes, and the interpolation its wrapper really selects (semi_seg/augment.py:23-37,54-75;
  * contrastyou/augment/synchronize.py:95-103: BILINEAR on images, NEAREST on targets): params[v][28] =
  *   [0] slice [1] flags (1 hflip, 2 vflip, 4 contrast first, 8 bilinear image rotation, 16 crop first = the rotation turns the

@@ -1,0 +1,316 @@
+// The pixel-wise (1x1-convolution) MLP of the dense projector (contrastyou/projectors/heads.py:28-39,96-120:
+// Conv2d(C, hid, 1) -> LeakyReLU(0.01) -> Conv2d(hid, out, 1) on EVERY pixel of a decoder feature map) as
+// matrix products over the pixels: 188 000 rows at Up_conv3 and 753 000 at Up_conv2 for a 60-image batch.  Rounds 2 - 5
+// ran these rows through the global projector's kernels (projector.hip: one wave per output column walking all rows, built
+// for 64 rows), which re-read the whole input once per four output columns: 30 / 24 / 54 / 46 ms per launch, 158 ms per
+// training step at Up_conv3 and 630 ms at Up_conv2 (tools/diag/dense_step_time.py).  Here: three tiled products on the
+// exact-f32 matrix instruction (v_mfma_f32_16x16x4_f32: operands and accumulation in f32, as the reference's conv), one
+// tile-staging scheme for all of them:
+//   forward            Y[M][N]  = act(X)[M][K] W[N][K]^T + b[N]
+//   input gradient     D[M][K]  = (G[M][N] W[N][K]) . act'(P[M][K])
+//   weight gradient    dW[N][K] = sum_m G[m][N] act(X)[m][K],  db[N] = sum_m G[m][N]   (slabs of rows, fixed-order fold)
+// act = LeakyReLU(0.01) applied to the operand on load (X is then the saved pre-activation), act' its derivative.
+#include "common.hpp"
+
+namespace spcl {
+
+typedef __attribute__((ext_vector_type(4))) float rm_f32x4;
+constexpr float kRowsLeaky = 0.01f;
+constexpr int RM_KC = 32, RM_KP = RM_KC + 4;  // k per staged chunk; LDS row pitch (16-byte aligned rows)
+
+__device__ __forceinline__ float rm_act(float v, bool leaky) { return (!leaky || v > 0.f) ? v : kRowsLeaky * v; }
+
+// four consecutive elements of a row as floats (zeros beyond `valid`)
+template <typename T>
+__device__ __forceinline__ rm_f32x4 rm_load4(const T* p, int valid) {
+  rm_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (valid >= 4) {
+    if (sizeof(T) == 4) {
+      v = *(const rm_f32x4*)p;
+    } else {
+      const uint2 raw = *(const uint2*)p;
+      v[0] = __uint_as_float(raw.x << 16); v[1] = __uint_as_float(raw.x & 0xffff0000u);
+      v[2] = __uint_as_float(raw.y << 16); v[3] = __uint_as_float(raw.y & 0xffff0000u);
+    }
+  } else {
+    for (int e = 0; e < valid; ++e) v[e] = Elem<T>::load(p + e);
+  }
+  return v;
+}
+
+// One k-chunk of products: the wave's MT x NT tiles of 16 x 16 outputs from LDS tiles As[rows][RM_KP], Bs[cols][RM_KP] holding
+// RM_KC values of the reduction index per row.  Lane (r16, g) reads four consecutive k of "its" row of each tile (16 s + 4 g ..
+// + 3) and feeds element e of both to MFMA e: operand A and operand B walk the reduction index in the same order, which is
+// all the instruction needs.  D: row 4 g + r, column r16.
+template <int MT, int NT>
+__device__ __forceinline__ void rm_chunk(const float* As, const float* Bs, int arow0, rm_f32x4 (&acc)[MT][NT], int r16, int g) {
+#pragma unroll
+  for (int s = 0; s < RM_KC / 16; ++s) {
+    rm_f32x4 a[MT], b[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) a[i] = *(const rm_f32x4*)(As + (arow0 + 16 * i + r16) * RM_KP + 16 * s + 4 * g);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) b[j] = *(const rm_f32x4*)(Bs + (16 * j + r16) * RM_KP + 16 * s + 4 * g);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+  }
+}
+
+// ---- forward / input gradient: a 128 x 64 output tile per workgroup, four waves of 32 rows each
+// B_T = false: Bs[col][k] = W[n0 + col][k0 + k]  (W is [N][K]: the forward)
+// B_T = true:  Bs[col][k] = W[k0 + k][n0 + col]  (W is [Kred][N]: the input gradient, reduction over W's rows)
+template <typename TX, typename TY, bool LEAKY_IN, bool B_T, bool MASK>
+__global__ __launch_bounds__(256) void rows_gemm_kernel(const TX* __restrict__ X, long ldx, const float* __restrict__ W, long ldw,
+                                                        const float* __restrict__ bias, const float* __restrict__ P, long ldp,
+                                                        int M, int K, int N, TY* __restrict__ Y, long ldy) {
+  __shared__ __attribute__((aligned(16))) float As[128 * RM_KP];
+  __shared__ __attribute__((aligned(16))) float Bs[64 * RM_KP];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r16 = lane & 15, g = lane >> 4;
+  const long m0 = (long)blockIdx.x * 128;
+  const int n0 = blockIdx.y * 64;
+  rm_f32x4 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (rm_f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < K; k0 += RM_KC) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {  // A tile: 128 rows x 8 chunks of four
+      const int c = t + 256 * it, row = c >> 3, ch = c & 7;
+      const long m = m0 + row;
+      const int k = k0 + 4 * ch;
+      rm_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < M && k < K) v = rm_load4<TX>(X + m * ldx + k, K - k);
+      if (LEAKY_IN) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = rm_act(v[e], true);
+      }
+      *(rm_f32x4*)(As + row * RM_KP + 4 * ch) = v;
+    }
+    if (!B_T) {
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {  // B tile: 64 output columns x 8 chunks of four along k
+        const int c = t + 256 * it, col = c >> 3, ch = c & 7;
+        const int n = n0 + col, k = k0 + 4 * ch;
+        rm_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (n < N && k < K) v = rm_load4<float>(W + (long)n * ldw + k, K - k);
+        *(rm_f32x4*)(Bs + col * RM_KP + 4 * ch) = v;
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {  // W rows are the reduction index: read four columns of one row, store them transposed
+        const int c = t + 256 * it, kk = c >> 4, ch = c & 15;
+        const int k = k0 + kk, n = n0 + 4 * ch;
+        rm_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k < K && n < N) v = rm_load4<float>(W + (long)k * ldw + n, N - n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Bs[(4 * ch + e) * RM_KP + kk] = v[e];
+      }
+    }
+    __syncthreads();
+    rm_chunk<2, 4>(As, Bs, wave * 32, acc, r16, g);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + 16 * j + r16;
+      if (n >= N) continue;
+      const float bv = bias != nullptr ? bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long m = m0 + wave * 32 + 16 * i + 4 * g + r;
+        if (m >= M) continue;
+        float v = acc[i][j][r] + bv;
+        if (MASK) v *= P[m * ldp + n] > 0.f ? 1.f : kRowsLeaky;  // (torch: the slope at 0 is the negative one)
+        Elem<TY>::store(Y + m * ldy + n, v);
+      }
+    }
+}
+
+// ---- weight gradient: a 64 x 64 tile of dW per workgroup over one slab of rows; partial [slab][N][K] (+ [slab][N] for db)
+template <typename TX, bool LEAKY_IN>
+__global__ __launch_bounds__(256) void rows_wgrad_kernel(const float* __restrict__ G, long ldg, const TX* __restrict__ X, long ldx,
+                                                         int M, int N, int K, int slab_rows, int ktiles,
+                                                         float* __restrict__ part, float* __restrict__ part_b) {
+  __shared__ __attribute__((aligned(16))) float As[64 * RM_KP];  // G^T: [n][m]
+  __shared__ __attribute__((aligned(16))) float Bs[64 * RM_KP];  // act(X)^T: [k][m]
+  __shared__ float red[16][64];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r16 = lane & 15, g = lane >> 4;
+  const int nt_ = blockIdx.x / ktiles, kt_ = blockIdx.x - nt_ * ktiles;
+  const int n0 = nt_ * 64, k0 = kt_ * 64;
+  const long mb = (long)blockIdx.y * slab_rows;
+  const long me = mb + slab_rows < (long)M ? mb + slab_rows : (long)M;
+  rm_f32x4 acc[1][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[0][j] = (rm_f32x4){0.f, 0.f, 0.f, 0.f};
+  rm_f32x4 bsum = {0.f, 0.f, 0.f, 0.f};  // this thread's four columns n0 + 4 (t % 16) + e over its rows (db, k-tile 0 only)
+  for (long mc = mb; mc < me; mc += RM_KC) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {  // 32 rows x 16 chunks of four columns, stored transposed
+      const int c = t + 256 * it, mm = c >> 4, ch = c & 15;
+      const long m = mc + mm;
+      {
+        const int n = n0 + 4 * ch;
+        rm_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m < me && n < N) v = rm_load4<float>(G + m * ldg + n, N - n);
+        bsum += v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) As[(4 * ch + e) * RM_KP + mm] = v[e];
+      }
+      {
+        const int k = k0 + 4 * ch;
+        rm_f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (m < me && k < K) v = rm_load4<TX>(X + m * ldx + k, K - k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Bs[(4 * ch + e) * RM_KP + mm] = rm_act(v[e], LEAKY_IN);
+      }
+    }
+    __syncthreads();
+    rm_chunk<1, 4>(As, Bs, wave * 16, acc, r16, g);
+    __syncthreads();
+  }
+  float* o = part + (size_t)blockIdx.y * N * K;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int k = k0 + 16 * j + r16;
+    if (k >= K) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + wave * 16 + 4 * g + r;
+      if (n < N) o[(size_t)n * K + k] = acc[0][j][r];
+    }
+  }
+  if (kt_ == 0 && part_b != nullptr) {  // db: the 16 threads that staged the same four columns, added in index order
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[t >> 4][4 * (t & 15) + e] = bsum[e];
+    __syncthreads();
+    if (t < 64 && n0 + t < N) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) s += red[w][t];
+      part_b[(size_t)blockIdx.y * N + n0 + t] = s;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void rows_wgrad_fold_kernel(const float* __restrict__ part, const float* __restrict__ part_b,
+                                                              int nslab, int NK, int N, float* __restrict__ dW,
+                                                              float* __restrict__ db) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < NK) {
+    float s = 0.f;
+    for (int p = 0; p < nslab; ++p) s += part[(size_t)p * NK + i];
+    dW[i] = s;
+  } else if (i - NK < N && db != nullptr) {
+    const int n = i - NK;
+    float s = 0.f;
+    for (int p = 0; p < nslab; ++p) s += part_b[(size_t)p * N + n];
+    db[n] = s;
+  }
+}
+
+static int rows_slabs(int M) {
+  int s = (M + 2047) / 2048;
+  return s < 1 ? 1 : (s > 96 ? 96 : s);
+}
+static int rows_slab_rows(int M) {
+  const int s = rows_slabs(M);
+  const int r = (M + s - 1) / s;
+  return (r + RM_KC - 1) / RM_KC * RM_KC;
+}
+
+}  // namespace spcl
+
+using namespace spcl;
+
+extern "C" int spcl_rows_linear_forward(const void* x, int x_dtype, long ldx, int leaky_in, const float* W, const float* bias,
+                                        int M, int K, int N, float* y, void* stream) {
+  SPCL_CHECK_ARG(x && W && y, "rows_linear_forward: null pointer");
+  SPCL_CHECK_ARG(M > 0 && K > 0 && N > 0 && ldx >= K && K % 4 == 0 && ldx % 4 == 0,
+                 "rows_linear_forward: M, K, N > 0, K and the row pitch multiples of 4 (got %d, %d, %d, %ld)", M, K, N, ldx);
+  SPCL_CHECK_ARG(x_dtype == SPCL_F32 || x_dtype == SPCL_BF16, "rows_linear_forward: dtype %d", x_dtype);
+  SPCL_CHECK_ARG(!(leaky_in && x_dtype != SPCL_F32), "rows_linear_forward: a saved pre-activation is f32");
+  const dim3 grid((unsigned)((M + 127) / 128), (unsigned)((N + 63) / 64));
+  hipStream_t st = (hipStream_t)stream;
+  if (x_dtype == SPCL_BF16)
+    SPCL_LAUNCH((rows_gemm_kernel<bf16_t, float, false, false, false>), grid, dim3(256), 0, st, (const bf16_t*)x, ldx, W, (long)K,
+                bias, nullptr, 0L, M, K, N, y, (long)N);
+  else if (leaky_in)
+    SPCL_LAUNCH((rows_gemm_kernel<float, float, true, false, false>), grid, dim3(256), 0, st, (const float*)x, ldx, W, (long)K, bias,
+                nullptr, 0L, M, K, N, y, (long)N);
+  else
+    SPCL_LAUNCH((rows_gemm_kernel<float, float, false, false, false>), grid, dim3(256), 0, st, (const float*)x, ldx, W, (long)K, bias,
+                nullptr, 0L, M, K, N, y, (long)N);
+  SPCL_LAUNCH_CHECK("rows_linear_forward");
+  return SPCL_OK;
+}
+
+extern "C" int spcl_rows_linear_backward_input(const float* g, const float* W, const float* pre, int M, int N, int K, void* dx,
+                                               int dx_dtype, long lddx, void* stream) {
+  SPCL_CHECK_ARG(g && W && dx, "rows_linear_backward_input: null pointer");
+  SPCL_CHECK_ARG(M > 0 && K > 0 && N > 0 && lddx >= K && N % 4 == 0 && K % 4 == 0,
+                 "rows_linear_backward_input: M, K, N > 0, N and K multiples of 4 (got %d, %d, %d)", M, K, N);
+  SPCL_CHECK_ARG(dx_dtype == SPCL_F32 || dx_dtype == SPCL_BF16, "rows_linear_backward_input: dtype %d", dx_dtype);
+  // D[M][K] = G[M][N] W[N][K]: the reduction runs over W's ROWS (B_T); its "output columns" are the K inputs
+  const dim3 grid((unsigned)((M + 127) / 128), (unsigned)((K + 63) / 64));
+  hipStream_t st = (hipStream_t)stream;
+  if (dx_dtype == SPCL_BF16) {
+    if (pre != nullptr)
+      SPCL_LAUNCH((rows_gemm_kernel<float, bf16_t, false, true, true>), grid, dim3(256), 0, st, g, (long)N, W, (long)K, nullptr, pre,
+                  (long)K, M, N, K, (bf16_t*)dx, lddx);
+    else
+      SPCL_LAUNCH((rows_gemm_kernel<float, bf16_t, false, true, false>), grid, dim3(256), 0, st, g, (long)N, W, (long)K, nullptr,
+                  nullptr, 0L, M, N, K, (bf16_t*)dx, lddx);
+  } else {
+    if (pre != nullptr)
+      SPCL_LAUNCH((rows_gemm_kernel<float, float, false, true, true>), grid, dim3(256), 0, st, g, (long)N, W, (long)K, nullptr, pre,
+                  (long)K, M, N, K, (float*)dx, lddx);
+    else
+      SPCL_LAUNCH((rows_gemm_kernel<float, float, false, true, false>), grid, dim3(256), 0, st, g, (long)N, W, (long)K, nullptr,
+                  nullptr, 0L, M, N, K, (float*)dx, lddx);
+  }
+  SPCL_LAUNCH_CHECK("rows_linear_backward_input");
+  return SPCL_OK;
+}
+
+extern "C" size_t spcl_rows_linear_backward_weight_workspace_bytes(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  return (size_t)rows_slabs(M) * ((size_t)N * K + N) * sizeof(float);
+}
+
+extern "C" int spcl_rows_linear_backward_weight(const float* g, const void* x, int x_dtype, long ldx, int leaky_in, int M, int N,
+                                                int K, float* ws, size_t ws_bytes, float* dW, float* db, void* stream) {
+  SPCL_CHECK_ARG(g && x && ws && dW, "rows_linear_backward_weight: null pointer");
+  SPCL_CHECK_ARG(M > 0 && K > 0 && N > 0 && ldx >= K && N % 4 == 0 && K % 4 == 0 && ldx % 4 == 0,
+                 "rows_linear_backward_weight: M, K, N > 0, N, K and the row pitch multiples of 4 (got %d, %d, %d)", M, K, N);
+  SPCL_CHECK_ARG(x_dtype == SPCL_F32 || x_dtype == SPCL_BF16, "rows_linear_backward_weight: dtype %d", x_dtype);
+  SPCL_CHECK_ARG(!(leaky_in && x_dtype != SPCL_F32), "rows_linear_backward_weight: a saved pre-activation is f32");
+  SPCL_CHECK_ARG(ws_bytes >= spcl_rows_linear_backward_weight_workspace_bytes(M, N, K),
+                 "rows_linear_backward_weight: workspace of %zu bytes", spcl_rows_linear_backward_weight_workspace_bytes(M, N, K));
+  const int ns = rows_slabs(M), sr = rows_slab_rows(M), ktiles = (K + 63) / 64, ntiles = (N + 63) / 64;
+  const int nslab = (M + sr - 1) / sr;  // (slabs that hold rows: the rounded slab height may leave the last ones empty)
+  float* part = ws;
+  float* part_b = ws + (size_t)ns * N * K;
+  const dim3 grid((unsigned)(ntiles * ktiles), (unsigned)nslab);
+  hipStream_t st = (hipStream_t)stream;
+  if (x_dtype == SPCL_BF16)
+    SPCL_LAUNCH((rows_wgrad_kernel<bf16_t, false>), grid, dim3(256), 0, st, g, (long)N, (const bf16_t*)x, ldx, M, N, K, sr, ktiles, part,
+                part_b);
+  else if (leaky_in)
+    SPCL_LAUNCH((rows_wgrad_kernel<float, true>), grid, dim3(256), 0, st, g, (long)N, (const float*)x, ldx, M, N, K, sr, ktiles, part,
+                part_b);
+  else
+    SPCL_LAUNCH((rows_wgrad_kernel<float, false>), grid, dim3(256), 0, st, g, (long)N, (const float*)x, ldx, M, N, K, sr, ktiles, part,
+                part_b);
+  const int total = N * K + N;
+  SPCL_LAUNCH(rows_wgrad_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)part,
+              (const float*)part_b, nslab, N * K, N, dW, db);
+  SPCL_LAUNCH_CHECK("rows_linear_backward_weight");
+  return SPCL_OK;
+}

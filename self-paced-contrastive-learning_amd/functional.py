@@ -561,10 +561,85 @@ def l2norm_rows(x):
     return _L2NormRowsFn.apply(x)
 
 
+class _PixelMlpFn(torch.autograd.Function):
+    """The dense projector's 1x1-conv MLP on every pixel as matrix products over the N*H*W pixel rows (csrc/rows_mlp.hip:
+    exact-f32 MFMA; forward, input gradient, weight gradient with a fixed-order fold).  The feature map is read in place
+    (channels-last rows of pitch ``cs``), the hidden pre-activation is the only tensor kept for backward."""
+
+    @staticmethod
+    def forward(ctx, feat, w1, b1, w2, b2):
+        _n.require_gpu(feat, w1, b1, w2, b2)
+        x, cs = as_nhwc(feat.detach())
+        N, H, W, _ = x.shape
+        C, M, dev = feat.shape[1], N * H * W, feat.device
+        mlp = w2 is not None
+        w1c, b1c = w1.detach().reshape(w1.shape[0], -1).contiguous().float(), b1.detach().contiguous().float()
+        first = torch.empty(M, w1c.shape[0], dtype=torch.float32, device=dev)  # pre-activation (mlp) or the output (linear)
+        _n.call("spcl_rows_linear_forward", _n.ptr(x), _n.dtype_code(x.dtype), cs, 0, _n.ptr(w1c), _n.ptr(b1c), M, C,
+                w1c.shape[0], _n.ptr(first), _n.stream())
+        w2c = None
+        out = first
+        if mlp:
+            w2c, b2c = w2.detach().reshape(w2.shape[0], -1).contiguous().float(), b2.detach().contiguous().float()
+            out = torch.empty(M, w2c.shape[0], dtype=torch.float32, device=dev)
+            _n.call("spcl_rows_linear_forward", _n.ptr(first), _n.dtype_code(torch.float32), w1c.shape[0], 1, _n.ptr(w2c),
+                    _n.ptr(b2c), M, w1c.shape[0], w2c.shape[0], _n.ptr(out), _n.stream())
+        ctx.save_for_backward(x, w1c, w2c, first if mlp else None)
+        ctx.meta = (N, H, W, C, cs, x.dtype, feat.dtype)
+        ctx.params = (w1, b1, w2, b2)
+        return out.view(N, H, W, out.shape[1]).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, w1c, w2c, pre = ctx.saved_tensors
+        N, H, W, C, cs, xdt, fdt = ctx.meta
+        M, dev = N * H * W, dout.device
+        mlp = w2c is not None
+        g = _class_map_storage(dout.detach())  # [N, H, W, O] f32, contiguous
+        g = g.view(M, g.shape[3])
+        ng = ctx.needs_input_grad
+        sk = tuple(take_grad_sink(p, ng[i + 1]) for i, p in enumerate(ctx.params))
+        hid = w1c.shape[0]
+        dw1 = _grad_buffer(sk[0], (hid, C), dev)
+        db1 = _grad_buffer(sk[1], (hid,), dev)
+        dw2 = db2 = None
+
+        def wgrad(gm, xin, xdtype, ldx, leaky, n_out, k_in, dw, db):
+            ws = torch.empty(_n.call("spcl_rows_linear_backward_weight_workspace_bytes", M, n_out, k_in) // 4 + 1,
+                             dtype=torch.float32, device=dev)
+            _n.call("spcl_rows_linear_backward_weight", _n.ptr(gm), _n.ptr(xin), _n.dtype_code(xdtype), ldx, int(leaky), M, n_out,
+                    k_in, _n.ptr(ws), ws.numel() * 4, _n.ptr(dw), _n.ptr(db), _n.stream())
+
+        if mlp:
+            O = w2c.shape[0]
+            dw2 = _grad_buffer(sk[2], (O, hid), dev)
+            db2 = _grad_buffer(sk[3], (O,), dev)
+            wgrad(g, pre, torch.float32, hid, True, O, hid, dw2, db2)
+            dpre = torch.empty(M, hid, dtype=torch.float32, device=dev)
+            _n.call("spcl_rows_linear_backward_input", _n.ptr(g), _n.ptr(w2c), _n.ptr(pre), M, O, hid, _n.ptr(dpre),
+                    _n.dtype_code(torch.float32), hid, _n.stream())
+            g = dpre
+        wgrad(g, x, xdt, cs, False, hid, C, dw1, db1)
+        gfeat = None
+        if ng[0]:
+            dfeat = (torch.zeros if cs != C else torch.empty)(N, H, W, cs, dtype=xdt, device=dev)
+            _n.call("spcl_rows_linear_backward_input", _n.ptr(g), _n.ptr(w1c), None, M, hid, C, _n.ptr(dfeat), _n.dtype_code(xdt),
+                    cs, _n.stream())
+            gfeat = nhwc_to_logical(dfeat, C)
+            if gfeat.dtype != fdt:
+                gfeat = gfeat.to(fdt)
+        return gfeat, dw1.view(ctx.params[0].shape), db1, None if dw2 is None else dw2.view(ctx.params[2].shape), db2
+
+
 def pixelwise_mlp(feat, w1, b1, w2=None, b2=None):
     """1x1-conv MLP of ``get_contrastive_dense_projector`` (projectors/heads.py:28-39) on a logical [N,C,H,W] map:
-    every pixel is a row of the projector kernels (no pooling, no normalisation) -> f32 logical [N,O,H,W].
-    ``w1`` [hid,C,1,1] (or [O,C,1,1] for the linear head), ``w2`` [O,hid,1,1]."""
+    every pixel is a row (no pooling, no normalisation) -> f32 logical [N,O,H,W].
+    ``w1`` [hid,C,1,1] (or [O,C,1,1] for the linear head), ``w2`` [O,hid,1,1].  Matrix products over the pixel rows
+    (``_PixelMlpFn``) when the channel counts are multiples of 4 -- always, in the UNet --; else the rows go through the
+    global projector's kernels (correct, and slow beyond a few thousand rows)."""
+    dims = [feat.shape[1], w1.shape[0]] + ([w2.shape[0]] if w2 is not None else [])
+    if feat.is_cuda and all(d % 4 == 0 for d in dims):
+        return _PixelMlpFn.apply(feat, w1, b1, w2, b2)
     xs, cs = as_nhwc(feat)  # differentiable view ops only
     N, H, W, _ = xs.shape
     C = feat.shape[1]

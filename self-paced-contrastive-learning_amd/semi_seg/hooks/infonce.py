@@ -361,7 +361,38 @@ class _INFONCEDenseHook(_INFONCEEpochHook):
     point_nums = 5
 
     def graph_key(self):
-        return None  # seeded feature flips and freshly drawn point indices every step: runs eagerly
+        """replayable (round 6): what the step draws on the host -- the sample-wise feature flips and the points of every
+        slice -- reaches the captured launches through the epocher's stage (flag bytes, point indices), like the label vectors
+        of the global hooks"""
+        if self._tap_callback is not None and self._n < 2:
+            return None
+        c = self._criterion
+        return (type(self).__name__, self._name, float(self._weight), type(c).__name__, float(c._t), self.point_nums,
+                tuple(getattr(self._projector, "_spatial_size", ())))
+
+    def _staged_points(self, stage, B, h, w):
+        """[3][B * point_nums] int32 device view (slice, row, column of every sampled point), refilled from every new batch's
+        seed exactly as ``region_extractor`` draws them (slice by slice, numpy's RNG under FixRandomSeed(seed))"""
+        P = self.point_nums
+
+        def fill(batch):
+            bi, xi, yi = [], [], []
+            with FixRandomSeed(batch["seed"]):
+                for b in range(B):
+                    for x, y in get_n_point_coordinate(n=P, h=h, w=w):
+                        bi.append(b), xi.append(int(x)), yi.append(int(y))
+            return bi + xi + yi
+        return stage.bind(("dense_points", id(self), B, h, w), 3 * B * P, "i32", fill).view(3, B * P)
+
+    @staticmethod
+    def _gather_points(z, lin, B, P):
+        """z [B, C, h, w], lin [B * P] flat pixel indices (slice b's P points in order) -> [B * P, C]: what
+        ``z[bi, :, xi, yi]`` returns, as one gather along the flattened pixels (its backward is a scatter-add onto distinct
+        positions: capturable, and the same values)"""
+        C = z.shape[1]
+        zf = z.reshape(B, C, -1)
+        got = torch.gather(zf, 2, lin.view(B, 1, P).expand(B, C, P))
+        return got.permute(0, 2, 1).reshape(B * P, C)
 
     @meter_focus
     def __call__(self, *, affine_transformer, seed, unlabeled_tf_logits, unlabeled_logits_tf, partition_group,
@@ -369,14 +400,29 @@ class _INFONCEDenseHook(_INFONCEEpochHook):
         n_unl = len(unlabeled_logits_tf)
         feature = self._extractor.feature()[-n_unl * 2:]
         first, second = torch.chunk(feature, 2, dim=0)
-        with FixRandomSeed(seed):  # view 1's features get the sample-wise flips view 2's images got (:206-207)
-            first = affine_transformer.apply_batch(first) if hasattr(affine_transformer, "apply_batch") else \
-                torch.stack([affine_transformer(x) for x in first], dim=0)
+        stage = getattr(getattr(self, "_epocher", None), "stage", None)
+        staged = stage is not None and stage.active and first.is_cuda and hasattr(self._epocher, "_flip_flags")
+        if staged:
+            # a staged step (the epocher replays it from a hipGraph): the flags are the epocher's own slot -- view 1's features
+            # get the sample-wise flips view 2's images got, same seed, same draws (:206-207)
+            flags = stage.bind("flip_flags", (n_unl + 3) // 4 * 4, "u8", self._epocher._flip_flags)
+            first = F_hip.flip_batch(first, flags[:n_unl])
+        else:
+            with FixRandomSeed(seed):  # view 1's features get the sample-wise flips view 2's images got (:206-207)
+                first = affine_transformer.apply_batch(first) if hasattr(affine_transformer, "apply_batch") else \
+                    torch.stack([affine_transformer(x) for x in first], dim=0)
         z_first, z_second = torch.chunk(self._projector(torch.cat([first, second.contiguous()], dim=0)), 2)
-        with FixRandomSeed(seed):
-            a = self.region_extractor(z_first, point_nums=self.point_nums)
-        with FixRandomSeed(seed):
-            b = self.region_extractor(z_second, point_nums=self.point_nums)
+        if staged:
+            B, _, h, w = z_first.shape
+            pts = self._staged_points(stage, B, h, w).long()
+            lin = pts[1] * w + pts[2]
+            a = self._gather_points(z_first, lin, B, self.point_nums)
+            b = self._gather_points(z_second, lin, B, self.point_nums)
+        else:
+            with FixRandomSeed(seed):
+                a = self.region_extractor(z_first, point_nums=self.point_nums)
+            with FixRandomSeed(seed):
+                b = self.region_extractor(z_second, point_nums=self.point_nums)
         labels = torch.arange(a.shape[0], dtype=torch.float32, device=a.device)
         loss = self._criterion(a, b, target=labels)
         self._record(loss)

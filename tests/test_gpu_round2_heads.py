@@ -208,3 +208,50 @@ def _dense_infonce_hook_step_body(f32_products):
     for k, p in head.named_parameters():
         got, want = p.grad.cpu().numpy(), opsd[k].grad.numpy()
         assert l2(got, want) < max(3e-3, slack) and rel(got, want) < max(2e-2, slack), (k, l2(got, want), rel(got, want), slack)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape,hid,out", [((3, 64, 19, 23), 256, 256), ((2, 16, 40, 40), 128, 32), ((1, 32, 7, 5), 64, 0),
+                                           ((5, 128, 12, 12), 36, 20)])
+def test_pixelwise_mlp_rows_gemm_vs_torch(dt, shape, hid, out):
+    """``functional.pixelwise_mlp`` as matrix products over the pixel rows (csrc/rows_mlp.hip, round 6) against torch's own
+    conv2d -> leaky_relu -> conv2d in float64 on the same (storage-rounded) feature map: output, feature gradient, both
+    weight and bias gradients; row counts that are no multiple of the 128-row tile or of the weight gradient's slabs."""
+    import spcl_amd  # noqa
+    from spcl_amd import functional as F_
+    g = torch.Generator().manual_seed(sum(shape) + hid)
+    N, C, H, W = shape
+    x = torch.randn(N, C, H, W, generator=g).to(dt)
+    w1 = torch.randn(hid, C, 1, 1, generator=g) * 0.2
+    b1 = torch.randn(hid, generator=g) * 0.1
+    mlp = out > 0
+    w2 = torch.randn(out, hid, 1, 1, generator=g) * 0.2 if mlp else None
+    b2 = torch.randn(out, generator=g) * 0.1 if mlp else None
+    r = torch.randn(N, out if mlp else hid, H, W, generator=g)
+
+    def ref():
+        xs = x.double().clone().requires_grad_(True)
+        ps = [t.double().clone().requires_grad_(True) for t in (w1, b1) + ((w2, b2) if mlp else ())]
+        y = torch.nn.functional.conv2d(xs, ps[0], ps[1])
+        if mlp:
+            y = torch.nn.functional.conv2d(torch.nn.functional.leaky_relu(y, 0.01), ps[2], ps[3])
+        (y * r.double()).sum().backward()
+        return y.detach(), xs.grad, [p.grad for p in ps]
+
+    y_ref, dx_ref, dp_ref = ref()
+    xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    ps = [t.cuda().requires_grad_(True) for t in (w1, b1) + ((w2, b2) if mlp else ())]
+    y = F_.pixelwise_mlp(xg, *ps)
+    assert tuple(y.shape) == tuple(y_ref.shape) and y.dtype == torch.float32
+    (y * r.cuda()).sum().backward()
+    tol = 2e-5
+    np.testing.assert_allclose(y.detach().cpu().double().numpy(), y_ref.numpy(), rtol=tol, atol=tol * float(y_ref.abs().max()))
+    gtol = tol if dt == torch.float32 else 6e-3  # (the feature gradient is stored in the map's own dtype)
+    np.testing.assert_allclose(xg.grad.double().cpu().numpy(), dx_ref.numpy(), rtol=gtol, atol=gtol * float(dx_ref.abs().max()))
+    for p, want in zip(ps, dp_ref):
+        np.testing.assert_allclose(p.grad.double().cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-5 * float(want.abs().max()) + 1e-6)
+    # bit-deterministic: the weight gradient's slabs are folded in index order
+    xg2 = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    ps2 = [t.cuda().requires_grad_(True) for t in (w1, b1) + ((w2, b2) if mlp else ())]
+    (F_.pixelwise_mlp(xg2, *ps2) * r.cuda()).sum().backward()
+    assert torch.equal(xg2.grad, xg.grad) and all(torch.equal(a.grad, b.grad) for a, b in zip(ps, ps2))

@@ -254,3 +254,55 @@ def test_finetune_graphed_steps_equal_eager_steps():
     assert torch.equal(res[False][1], res[True][1])
     assert res[False][2]["sup_dice"] == res[True][2]["sup_dice"]
     np.testing.assert_allclose(res[False][2]["sup_loss"]["mean"], res[True][2]["sup_loss"]["mean"], rtol=1e-6)
+
+
+def _setup_dense(graph, dtype):
+    """decoder pre-training (main_pretrain_decoder.py:66-69: the encoder frozen, the decoder up to the tapped block trains)
+    with the DENSE InfoNCE hook on Up_conv3 (semi_seg/hooks/infonce.py:201-241)"""
+    import spcl_amd  # noqa
+    from spcl_amd import ddp
+    from spcl_amd.optim import FusedRAdam
+    from spcl_amd.semi_seg.arch import UNet
+    from spcl_amd.semi_seg.epochers import PretrainDecoderEpocher
+    from spcl_amd.semi_seg.hooks import create_infonce_hooks, feature_until_from_hooks
+    torch.manual_seed(5)
+    net = UNet(input_dim=1, num_classes=4, max_channel=128).cuda()
+    net.set_compute_dtype(dtype)
+    hook = create_infonce_hooks(model=net, feature_names="Up_conv3", weights=0.5, contrast_ons="partition",
+                                data_name="acdc").cuda()
+    assert feature_until_from_hooks(hook) == "Up_conv3"
+    assert type(hook._hooks[0]._projector).__name__ == "DenseProjectionHead"
+    for p in net.parameters():
+        p.requires_grad_(False)
+    for name in ("Up5", "Up_conv5", "Up4", "Up_conv4", "Up3", "Up_conv3"):
+        getattr(net, "_" + name).requires_grad_(True)
+    flat = ddp.FlatParams([p for p in net.parameters() if p.requires_grad] + list(hook.parameters()))
+    opt = FusedRAdam([flat.param], lr=2e-3, weight_decay=1e-5)
+    ep = PretrainDecoderEpocher(model=net, optimizer=opt, chain_dataloader=iter([]), num_batches=100, device="cuda",
+                                inference_until="Up_conv3", flat_params=flat, graph=graph)
+    ep.add_hooks([hook()])
+    net.train()
+    return net, hook, flat, opt, ep
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dense_hook_steps_replay_bit_for_bit(dtype):
+    """The dense decoder hook (round 6: replayable).  Its host-side draws -- the sample-wise feature flips and the five points
+    of every slice, numpy's RNG under the step's seed -- reach the captured launches through the stage; the replayed steps
+    equal the eager steps (``apply_batch`` + ``region_extractor``'s advanced indexing) bit for bit, seeds fresh every step."""
+    steps, bs = 7, 8
+    res = {}
+    for graph in (False, True):
+        net, hook, flat, opt, ep = _setup_dense(graph, dtype)
+        curve = _run(ep, _batches(steps, bs, 64))
+        sg = ep._step_graph
+        if graph:
+            assert sg is not None and sg.captured and not sg.failed and sg.replays == steps - 2, (sg and sg.replays,)
+        else:
+            assert sg is None
+        res[graph] = (curve, flat.data.clone(), {k: v.clone() for k, v in net.state_dict().items()})
+    assert res[False][0] == res[True][0], (res[False][0], res[True][0])
+    assert len(set(res[False][0])) == steps
+    assert torch.equal(res[False][1], res[True][1])
+    for k, v in res[False][2].items():
+        assert torch.equal(v, res[True][2][k]), k
