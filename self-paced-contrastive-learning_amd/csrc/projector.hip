@@ -296,6 +296,62 @@ __global__ __launch_bounds__(256) void adaptive_pool_bwd_kernel(const float* __r
   Elem<T>::store(dx + idx, g);
 }
 
+// The same gradient, one WAVE per input pixel (round 6): which windows cover (y, x) does not depend on the channel -- with
+// one thread per element every element paid the integer divisions of the window search (1.6 ms for the 188 000 x 256
+// gradient of a dense projection: the longest launch of a decoder pre-training step).  Here the search is wave-uniform and
+// a lane owns four consecutive channels (16-byte loads of dout, one 16- or 8-byte store).  Same windows in the same order,
+// same divisions: the old kernel's values bit for bit.  C and Cs multiples of 4.
+template <typename T, bool MAX>
+__global__ __launch_bounds__(256) void adaptive_pool_bwd_pix_kernel(const float* __restrict__ dout, const int* __restrict__ arg,
+                                                                    int H, int W, int C, int Cs, int OH, int OW,
+                                                                    T* __restrict__ dx, size_t npix) {
+  typedef __attribute__((ext_vector_type(4))) float v4f;
+  typedef __attribute__((ext_vector_type(4))) int v4i;
+  const int lane = threadIdx.x & 63;
+  const size_t pix = (size_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (pix >= npix) return;
+  const int xx = (int)(pix % W);
+  const size_t r = pix / W;
+  const int y = (int)(r % H);
+  const size_t n = r / H;
+  int oy_lo = (int)(((long)y * OH) / H), ox_lo = (int)(((long)xx * OW) / W);
+  while (oy_lo > 0 && ((oy_lo) * H + OH - 1) / OH > y) --oy_lo;   // previous window still reaches y
+  while (ox_lo > 0 && ((ox_lo) * W + OW - 1) / OW > xx) --ox_lo;
+  for (int c0 = 4 * lane; c0 < Cs; c0 += 256) {
+    v4f g = {0.f, 0.f, 0.f, 0.f};
+    if (c0 < C) {
+      for (int oy = oy_lo; oy < OH && (oy * H) / OH <= y; ++oy) {
+        const int y0 = (oy * H) / OH, y1 = ((oy + 1) * H + OH - 1) / OH;
+        if (y < y0 || y >= y1) continue;
+        for (int ox = ox_lo; ox < OW && (ox * W) / OW <= xx; ++ox) {
+          const int x0 = (ox * W) / OW, x1 = ((ox + 1) * W + OW - 1) / OW;
+          if (xx < x0 || xx >= x1) continue;
+          const size_t o = ((n * OH + oy) * OW + ox) * (size_t)C + c0;
+          const v4f d = *(const v4f*)(dout + o);
+          if (MAX) {
+            const v4i a = *(const v4i*)(arg + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] += a[e] == y * W + xx ? d[e] : 0.f;
+          } else {
+            const float size = (float)((y1 - y0) * (x1 - x0));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] += d[e] / size;
+          }
+        }
+      }
+    }
+    T* o = dx + pix * (size_t)Cs + c0;
+    if (sizeof(T) == 4) {
+      *(v4f*)o = g;
+    } else {
+      uint2 w;
+      w.x = (unsigned)f32_to_bf16(g[0]) | ((unsigned)f32_to_bf16(g[1]) << 16);
+      w.y = (unsigned)f32_to_bf16(g[2]) | ((unsigned)f32_to_bf16(g[3]) << 16);
+      *(uint2*)o = w;
+    }
+  }
+}
+
 }  // namespace spcl
 
 using namespace spcl;
@@ -345,6 +401,21 @@ extern "C" int spcl_adaptive_pool2d_backward(const float* dout, const int* argma
   if (mode == 0 && OH == 1 && OW == 1 && (dtype == SPCL_F32 || dtype == SPCL_BF16)) {  // global average: one broadcast
     if (dtype == SPCL_F32) SPCL_LAUNCH(avgpool_bwd_kernel<float>, g, dim3(256), 0, st, dout, H * W, C, Cs, (float*)dx, total);
     else SPCL_LAUNCH(avgpool_bwd_kernel<bf16_t>, g, dim3(256), 0, st, dout, H * W, C, Cs, (bf16_t*)dx, total);
+    SPCL_LAUNCH_CHECK("adaptive_pool2d_backward");
+    return SPCL_OK;
+  }
+  if (C % 4 == 0 && Cs % 4 == 0 && (dtype == SPCL_F32 || dtype == SPCL_BF16) && ((uintptr_t)dout % 16 == 0) &&
+      ((uintptr_t)dx % 16 == 0) && (argmax == nullptr || (uintptr_t)argmax % 16 == 0)) {
+    const size_t npix = (size_t)N * H * W;
+    dim3 pg((unsigned)((npix + 3) / 4));
+    if (dtype == SPCL_F32 && mode == 0)
+      SPCL_LAUNCH((adaptive_pool_bwd_pix_kernel<float, false>), pg, dim3(256), 0, st, dout, argmax, H, W, C, Cs, OH, OW, (float*)dx, npix);
+    else if (dtype == SPCL_F32)
+      SPCL_LAUNCH((adaptive_pool_bwd_pix_kernel<float, true>), pg, dim3(256), 0, st, dout, argmax, H, W, C, Cs, OH, OW, (float*)dx, npix);
+    else if (mode == 0)
+      SPCL_LAUNCH((adaptive_pool_bwd_pix_kernel<bf16_t, false>), pg, dim3(256), 0, st, dout, argmax, H, W, C, Cs, OH, OW, (bf16_t*)dx, npix);
+    else
+      SPCL_LAUNCH((adaptive_pool_bwd_pix_kernel<bf16_t, true>), pg, dim3(256), 0, st, dout, argmax, H, W, C, Cs, OH, OW, (bf16_t*)dx, npix);
     SPCL_LAUNCH_CHECK("adaptive_pool2d_backward");
     return SPCL_OK;
   }

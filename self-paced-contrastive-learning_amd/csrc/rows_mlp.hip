@@ -20,21 +20,23 @@ constexpr int RM_KC = 32, RM_KP = RM_KC + 4;  // k per staged chunk; LDS row pit
 
 __device__ __forceinline__ float rm_act(float v, bool leaky) { return (!leaky || v > 0.f) ? v : kRowsLeaky * v; }
 
-// four consecutive elements of a row as floats (zeros beyond `valid`)
+// four consecutive elements of a row as floats, or zeros when `ok` is false.  Branch-free: the load is issued from a valid
+// address either way (offset 0 of the tensor) and the result selected -- with a branch per load the compiler waited for every
+// load before it issued the next one (six memory round trips per k-chunk: the first version of these kernels ran at a
+// tenth of their present rate).  The extents are multiples of 4 (checked by the entry points): a chunk is whole or absent.
 template <typename T>
-__device__ __forceinline__ rm_f32x4 rm_load4(const T* p, int valid) {
-  rm_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if (valid >= 4) {
-    if (sizeof(T) == 4) {
-      v = *(const rm_f32x4*)p;
-    } else {
-      const uint2 raw = *(const uint2*)p;
-      v[0] = __uint_as_float(raw.x << 16); v[1] = __uint_as_float(raw.x & 0xffff0000u);
-      v[2] = __uint_as_float(raw.y << 16); v[3] = __uint_as_float(raw.y & 0xffff0000u);
-    }
+__device__ __forceinline__ rm_f32x4 rm_load4(const T* base, long off, bool ok) {
+  const T* p = base + (ok ? off : 0L);
+  rm_f32x4 v;
+  if (sizeof(T) == 4) {
+    v = *(const rm_f32x4*)p;
   } else {
-    for (int e = 0; e < valid; ++e) v[e] = Elem<T>::load(p + e);
+    const uint2 raw = *(const uint2*)p;
+    v[0] = __uint_as_float(raw.x << 16); v[1] = __uint_as_float(raw.x & 0xffff0000u);
+    v[2] = __uint_as_float(raw.y << 16); v[3] = __uint_as_float(raw.y & 0xffff0000u);
   }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
   return v;
 }
 
@@ -83,8 +85,7 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const TX* __restrict__ X
       const int c = t + 256 * it, row = c >> 3, ch = c & 7;
       const long m = m0 + row;
       const int k = k0 + 4 * ch;
-      rm_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m < M && k < K) v = rm_load4<TX>(X + m * ldx + k, K - k);
+      rm_f32x4 v = rm_load4<TX>(X, m * ldx + k, m < M && k < K);
       if (LEAKY_IN) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = rm_act(v[e], true);
@@ -96,8 +97,7 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const TX* __restrict__ X
       for (int it = 0; it < 2; ++it) {  // B tile: 64 output columns x 8 chunks of four along k
         const int c = t + 256 * it, col = c >> 3, ch = c & 7;
         const int n = n0 + col, k = k0 + 4 * ch;
-        rm_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (n < N && k < K) v = rm_load4<float>(W + (long)n * ldw + k, K - k);
+        const rm_f32x4 v = rm_load4<float>(W, (long)n * ldw + k, n < N && k < K);
         *(rm_f32x4*)(Bs + col * RM_KP + 4 * ch) = v;
       }
     } else {
@@ -105,8 +105,7 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const TX* __restrict__ X
       for (int it = 0; it < 2; ++it) {  // W rows are the reduction index: read four columns of one row, store them transposed
         const int c = t + 256 * it, kk = c >> 4, ch = c & 15;
         const int k = k0 + kk, n = n0 + 4 * ch;
-        rm_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (k < K && n < N) v = rm_load4<float>(W + (long)k * ldw + n, N - n);
+        const rm_f32x4 v = rm_load4<float>(W, (long)k * ldw + n, k < K && n < N);
 #pragma unroll
         for (int e = 0; e < 4; ++e) Bs[(4 * ch + e) * RM_KP + kk] = v[e];
       }
@@ -120,15 +119,19 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const TX* __restrict__ X
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = n0 + 16 * j + r16;
-      if (n >= N) continue;
-      const float bv = bias != nullptr ? bias[n] : 0.f;
+      const bool okn = n < N;
+      const float bv = bias != nullptr ? bias[okn ? n : 0] : 0.f;
+      const long mr = m0 + wave * 32 + 16 * i + 4 * g;
+      float pv[4] = {1.f, 1.f, 1.f, 1.f};
+      if (MASK) {  // (all four requested before the first is used)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pv[r] = P[(okn && mr + r < M) ? (mr + r) * ldp + n : 0L];
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const long m = m0 + wave * 32 + 16 * i + 4 * g + r;
-        if (m >= M) continue;
         float v = acc[i][j][r] + bv;
-        if (MASK) v *= P[m * ldp + n] > 0.f ? 1.f : kRowsLeaky;  // (torch: the slope at 0 is the negative one)
-        Elem<TY>::store(Y + m * ldy + n, v);
+        if (MASK) v *= pv[r] > 0.f ? 1.f : kRowsLeaky;  // (torch: the slope at 0 is the negative one)
+        if (okn && mr + r < M) Elem<TY>::store(Y + (mr + r) * ldy + n, v);
       }
     }
 }
@@ -157,16 +160,14 @@ __global__ __launch_bounds__(256) void rows_wgrad_kernel(const float* __restrict
       const long m = mc + mm;
       {
         const int n = n0 + 4 * ch;
-        rm_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (m < me && n < N) v = rm_load4<float>(G + m * ldg + n, N - n);
+        const rm_f32x4 v = rm_load4<float>(G, m * ldg + n, m < me && n < N);
         bsum += v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) As[(4 * ch + e) * RM_KP + mm] = v[e];
       }
       {
         const int k = k0 + 4 * ch;
-        rm_f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (m < me && k < K) v = rm_load4<TX>(X + m * ldx + k, K - k);
+        const rm_f32x4 v = rm_load4<TX>(X, m * ldx + k, m < me && k < K);
 #pragma unroll
         for (int e = 0; e < 4; ++e) Bs[(4 * ch + e) * RM_KP + mm] = rm_act(v[e], LEAKY_IN);
       }
