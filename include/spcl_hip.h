@@ -643,6 +643,14 @@ int spcl_augment_views_pil(const float* src, int S, int HS, int WS, const int* p
  * K, N and the row pitches are multiples of 4. */
 int spcl_rows_linear_forward(const void* x, int x_dtype, long ldx, int leaky_in, const float* W, const float* bias, int M,
                              int K, int N, float* y, void* stream);
+/* ... with the activation applied to the OUTPUT: h = LeakyReLU(x W^T + bias).  h has the pre-activation's sign: it may be passed
+ * as `pre` to spcl_rows_linear_backward_input, and to spcl_adaptive_avgpool2d_backward_act (the gradient of an adaptive average
+ * pooling of h [N][H][W][C], C % 4 == 0, multiplied by LeakyReLU' on its way out): the dense projector's pooled-hidden form --
+ * adaptive average pooling commutes with the linear second layer, which then runs on the pooled rows only. */
+int spcl_rows_linear_forward_act(const void* x, int x_dtype, long ldx, const float* W, const float* bias, int M, int K, int N,
+                                 float* h, void* stream);
+int spcl_adaptive_avgpool2d_backward_act(const float* dout, const float* act, int N, int H, int W, int C, int OH, int OW,
+                                         float* dx, void* stream);
 int spcl_rows_linear_backward_input(const float* g, const float* W, const float* pre, int M, int N, int K, void* dx,
                                     int dx_dtype, long lddx, void* stream);
 size_t spcl_rows_linear_backward_weight_workspace_bytes(int M, int N, int K);

@@ -69,6 +69,11 @@ class DenseProjectionHead(_ProjectorHeadBase):
 
     def forward(self, features):
         p = self._projector
+        if (self._head_type == "mlp" and self._pool_name == "adaptive_avg"
+                and F_hip.pixelwise_mlp_pooled_supported(features, p[0].weight, p[2].weight)):
+            # average pooling commutes with the (linear) second layer: pool the hidden activation, project the pooled rows
+            out = F_hip.pixelwise_mlp_pooled(features, p[0].weight, p[0].bias, p[2].weight, p[2].bias, self._spatial_size)
+            return F_hip.l2norm_channels(out) if self._normalize else out
         if self._head_type == "mlp":
             out = F_hip.pixelwise_mlp(features, p[0].weight, p[0].bias, p[2].weight, p[2].bias)
         else:

@@ -304,7 +304,10 @@ __global__ __launch_bounds__(256) void adaptive_pool_bwd_kernel(const float* __r
 template <typename T, bool MAX>
 __global__ __launch_bounds__(256) void adaptive_pool_bwd_pix_kernel(const float* __restrict__ dout, const int* __restrict__ arg,
                                                                     int H, int W, int C, int Cs, int OH, int OW,
-                                                                    T* __restrict__ dx, size_t npix) {
+                                                                    T* __restrict__ dx, size_t npix,
+                                                                    const float* __restrict__ act = nullptr) {
+  // act (optional, [npix][Cs] f32): the pooled tensor was LeakyReLU(pre) and `act` holds it -- the gradient leaves multiplied
+  // by LeakyReLU'(pre), whose sign `act` carries
   typedef __attribute__((ext_vector_type(4))) float v4f;
   typedef __attribute__((ext_vector_type(4))) int v4i;
   const int lane = threadIdx.x & 63;
@@ -339,6 +342,11 @@ __global__ __launch_bounds__(256) void adaptive_pool_bwd_pix_kernel(const float*
           }
         }
       }
+    }
+    if (act != nullptr) {
+      const v4f a = *(const v4f*)(act + pix * (size_t)Cs + c0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] *= a[e] > 0.f ? 1.f : kLeaky;
     }
     T* o = dx + pix * (size_t)Cs + c0;
     if (sizeof(T) == 4) {
@@ -644,3 +652,17 @@ extern "C" int spcl_proj_heads_backward(int K, const float* const* dz, int dtype
   SPCL_LAUNCH_CHECK("proj_heads_backward");
   return SPCL_OK;
 }
+
+// adaptive average pooling backward THROUGH a LeakyReLU: dx = unpool(dout) * LeakyReLU'(pre), with act = LeakyReLU(pre) [N][H][W][C]
+// f32 given instead of pre (same sign).  The dense projector's pooled-hidden form (functional._PixelMlpPooledFn).  C % 4 == 0.
+extern "C" int spcl_adaptive_avgpool2d_backward_act(const float* dout, const float* act, int N, int H, int W, int C, int OH, int OW,
+                                                    float* dx, void* stream) {
+  SPCL_CHECK_ARG(dout && act && dx, "adaptive_avgpool2d_backward_act: null pointer");
+  SPCL_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && OH > 0 && OW > 0, "adaptive_avgpool2d_backward_act: bad shape");
+  const size_t npix = (size_t)N * H * W;
+  SPCL_LAUNCH((adaptive_pool_bwd_pix_kernel<float, false>), dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dout,
+              (const int*)nullptr, H, W, C, C, OH, OW, dx, npix, act);
+  SPCL_LAUNCH_CHECK("adaptive_avgpool2d_backward_act");
+  return SPCL_OK;
+}
+

@@ -65,7 +65,7 @@ __device__ __forceinline__ void rm_chunk(const float* As, const float* Bs, int a
 // ---- forward / input gradient: a 128 x 64 output tile per workgroup, four waves of 32 rows each
 // B_T = false: Bs[col][k] = W[n0 + col][k0 + k]  (W is [N][K]: the forward)
 // B_T = true:  Bs[col][k] = W[k0 + k][n0 + col]  (W is [Kred][N]: the input gradient, reduction over W's rows)
-template <typename TX, typename TY, bool LEAKY_IN, bool B_T, bool MASK>
+template <typename TX, typename TY, bool LEAKY_IN, bool B_T, bool MASK, bool LEAKY_OUT = false>
 __global__ __launch_bounds__(256) void rows_gemm_kernel(const TX* __restrict__ X, long ldx, const float* __restrict__ W, long ldw,
                                                         const float* __restrict__ bias, const float* __restrict__ P, long ldp,
                                                         int M, int K, int N, TY* __restrict__ Y, long ldy) {
@@ -131,6 +131,7 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const TX* __restrict__ X
       for (int r = 0; r < 4; ++r) {
         float v = acc[i][j][r] + bv;
         if (MASK) v *= pv[r] > 0.f ? 1.f : kRowsLeaky;  // (torch: the slope at 0 is the negative one)
+        if (LEAKY_OUT) v = rm_act(v, true);
         if (okn && mr + r < M) Elem<TY>::store(Y + (mr + r) * ldy + n, v);
       }
     }
@@ -249,6 +250,26 @@ extern "C" int spcl_rows_linear_forward(const void* x, int x_dtype, long ldx, in
     SPCL_LAUNCH((rows_gemm_kernel<float, float, false, false, false>), grid, dim3(256), 0, st, (const float*)x, ldx, W, (long)K, bias,
                 nullptr, 0L, M, K, N, y, (long)N);
   SPCL_LAUNCH_CHECK("rows_linear_forward");
+  return SPCL_OK;
+}
+
+// forward with the activation applied to the OUTPUT: h = LeakyReLU(x W^T + b).  (The sign of h is the pre-activation's, so a
+// backward pass can take LeakyReLU' from h itself: spcl_rows_linear_backward_input's `pre` may be h.)
+extern "C" int spcl_rows_linear_forward_act(const void* x, int x_dtype, long ldx, const float* W, const float* bias, int M, int K,
+                                            int N, float* h, void* stream) {
+  SPCL_CHECK_ARG(x && W && h, "rows_linear_forward_act: null pointer");
+  SPCL_CHECK_ARG(M > 0 && K > 0 && N > 0 && ldx >= K && K % 4 == 0 && ldx % 4 == 0,
+                 "rows_linear_forward_act: M, K, N > 0, K and the row pitch multiples of 4 (got %d, %d, %d, %ld)", M, K, N, ldx);
+  SPCL_CHECK_ARG(x_dtype == SPCL_F32 || x_dtype == SPCL_BF16, "rows_linear_forward_act: dtype %d", x_dtype);
+  const dim3 grid((unsigned)((M + 127) / 128), (unsigned)((N + 63) / 64));
+  hipStream_t st = (hipStream_t)stream;
+  if (x_dtype == SPCL_BF16)
+    SPCL_LAUNCH((rows_gemm_kernel<bf16_t, float, false, false, false, true>), grid, dim3(256), 0, st, (const bf16_t*)x, ldx, W,
+                (long)K, bias, nullptr, 0L, M, K, N, h, (long)N);
+  else
+    SPCL_LAUNCH((rows_gemm_kernel<float, float, false, false, false, true>), grid, dim3(256), 0, st, (const float*)x, ldx, W, (long)K,
+                bias, nullptr, 0L, M, K, N, h, (long)N);
+  SPCL_LAUNCH_CHECK("rows_linear_forward_act");
   return SPCL_OK;
 }
 

@@ -631,6 +631,83 @@ class _PixelMlpFn(torch.autograd.Function):
         return gfeat, dw1.view(ctx.params[0].shape), db1, None if dw2 is None else dw2.view(ctx.params[2].shape), db2
 
 
+class _PixelMlpPooledFn(torch.autograd.Function):
+    """``adaptive_avg_pool(conv2(leaky(conv1(x))))`` of the dense projector computed as ``conv2(adaptive_avg_pool(leaky(conv1(x))))``:
+    the second 1x1 convolution is linear (bias included: an average of a constant is the constant), so it commutes with the
+    average pooling and runs on the N * oh * ow pooled rows instead of the N * H * W pixels -- 31x fewer rows for a 56^2 map
+    pooled to 10^2, 125x for 112^2; the products of the wide layer (hid x out) and its full-size output disappear.  Same
+    function; the sums are associated differently (differences at the 1e-7 level, tests/test_gpu_round2_heads.py)."""
+
+    @staticmethod
+    def forward(ctx, feat, w1, b1, w2, b2, out_hw):
+        _n.require_gpu(feat, w1, b1, w2, b2)
+        x, cs = as_nhwc(feat.detach())
+        N, H, W, _ = x.shape
+        C, M, dev = feat.shape[1], N * H * W, feat.device
+        oh, ow = out_hw
+        f32 = _n.dtype_code(torch.float32)
+        w1c, b1c = w1.detach().reshape(w1.shape[0], -1).contiguous().float(), b1.detach().contiguous().float()
+        w2c, b2c = w2.detach().reshape(w2.shape[0], -1).contiguous().float(), b2.detach().contiguous().float()
+        hid, O = w1c.shape[0], w2c.shape[0]
+        h = torch.empty(M, hid, dtype=torch.float32, device=dev)  # LeakyReLU(conv1(x)): the one full-size tensor kept
+        _n.call("spcl_rows_linear_forward_act", _n.ptr(x), _n.dtype_code(x.dtype), cs, _n.ptr(w1c), _n.ptr(b1c), M, C, hid,
+                _n.ptr(h), _n.stream())
+        hp = torch.empty(N * oh * ow, hid, dtype=torch.float32, device=dev)
+        _n.call("spcl_adaptive_pool2d_forward", _n.ptr(h), f32, N, H, W, hid, hid, oh, ow, 0, _n.ptr(hp), None, _n.stream())
+        out = torch.empty(N * oh * ow, O, dtype=torch.float32, device=dev)
+        _n.call("spcl_rows_linear_forward", _n.ptr(hp), f32, hid, 0, _n.ptr(w2c), _n.ptr(b2c), N * oh * ow, hid, O, _n.ptr(out),
+                _n.stream())
+        ctx.save_for_backward(x, h, hp, w1c, w2c)
+        ctx.meta = (N, H, W, C, cs, oh, ow, x.dtype, feat.dtype)
+        ctx.params = (w1, b1, w2, b2)
+        return out.view(N, oh, ow, O).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, h, hp, w1c, w2c = ctx.saved_tensors
+        N, H, W, C, cs, oh, ow, xdt, fdt = ctx.meta
+        M, Mp, dev = N * H * W, N * oh * ow, dout.device
+        hid, O = w1c.shape[0], w2c.shape[0]
+        f32 = _n.dtype_code(torch.float32)
+        g = _class_map_storage(dout.detach()).view(Mp, O)
+        ng = ctx.needs_input_grad
+        sk = tuple(take_grad_sink(p, ng[i + 1]) for i, p in enumerate(ctx.params))
+        dw1, db1 = _grad_buffer(sk[0], (hid, C), dev), _grad_buffer(sk[1], (hid,), dev)
+        dw2, db2 = _grad_buffer(sk[2], (O, hid), dev), _grad_buffer(sk[3], (O,), dev)
+
+        def wgrad(gm, rows, xin, xdtype, ldx, n_out, k_in, dw, db):
+            ws = torch.empty(_n.call("spcl_rows_linear_backward_weight_workspace_bytes", rows, n_out, k_in) // 4 + 1,
+                             dtype=torch.float32, device=dev)
+            _n.call("spcl_rows_linear_backward_weight", _n.ptr(gm), _n.ptr(xin), _n.dtype_code(xdtype), ldx, 0, rows, n_out, k_in,
+                    _n.ptr(ws), ws.numel() * 4, _n.ptr(dw), _n.ptr(db), _n.stream())
+
+        wgrad(g, Mp, hp, torch.float32, hid, O, hid, dw2, db2)
+        dhp = torch.empty(Mp, hid, dtype=torch.float32, device=dev)
+        _n.call("spcl_rows_linear_backward_input", _n.ptr(g), _n.ptr(w2c), None, Mp, O, hid, _n.ptr(dhp), f32, hid, _n.stream())
+        dpre = torch.empty(M, hid, dtype=torch.float32, device=dev)  # un-pooled, through the LeakyReLU (h carries its sign)
+        _n.call("spcl_adaptive_avgpool2d_backward_act", _n.ptr(dhp), _n.ptr(h), N, H, W, hid, oh, ow, _n.ptr(dpre), _n.stream())
+        wgrad(dpre, M, x, xdt, cs, hid, C, dw1, db1)
+        gfeat = None
+        if ng[0]:
+            dfeat = (torch.zeros if cs != C else torch.empty)(N, H, W, cs, dtype=xdt, device=dev)
+            _n.call("spcl_rows_linear_backward_input", _n.ptr(dpre), _n.ptr(w1c), None, M, hid, C, _n.ptr(dfeat), _n.dtype_code(xdt),
+                    cs, _n.stream())
+            gfeat = nhwc_to_logical(dfeat, C)
+            if gfeat.dtype != fdt:
+                gfeat = gfeat.to(fdt)
+        return gfeat, dw1.view(ctx.params[0].shape), db1, dw2.view(ctx.params[2].shape), db2, None
+
+
+def pixelwise_mlp_pooled_supported(feat, w1, w2) -> bool:
+    return bool(feat.is_cuda and w2 is not None and feat.shape[1] % 4 == 0 and w1.shape[0] % 4 == 0 and w2.shape[0] % 4 == 0)
+
+
+def pixelwise_mlp_pooled(feat, w1, b1, w2, b2, out_hw):
+    """``adaptive_avg_pool2d(pixelwise_mlp(feat, ...), out_hw)`` with the second layer applied AFTER the pooling (see
+    ``_PixelMlpPooledFn``) -> f32 logical [N, O, oh, ow]"""
+    return _PixelMlpPooledFn.apply(feat, w1, b1, w2, b2, tuple(int(v) for v in out_hw))
+
+
 def pixelwise_mlp(feat, w1, b1, w2=None, b2=None):
     """1x1-conv MLP of ``get_contrastive_dense_projector`` (projectors/heads.py:28-39) on a logical [N,C,H,W] map:
     every pixel is a row (no pooling, no normalisation) -> f32 logical [N,O,H,W].

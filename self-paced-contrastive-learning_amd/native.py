@@ -154,6 +154,8 @@ _SIGNATURES = {
     "spcl_augment_views_recipe": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, c_int, c_int, _P]),
     "spcl_augment_views_recipe_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "spcl_rows_linear_forward": (c_int, [_P, c_int, c_long, c_int, _P, _P, c_int, c_int, c_int, _P, _P]),
+    "spcl_rows_linear_forward_act": (c_int, [_P, c_int, c_long, _P, _P, c_int, c_int, c_int, _P, _P]),
+    "spcl_adaptive_avgpool2d_backward_act": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "spcl_rows_linear_backward_input": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, c_long, _P]),
     "spcl_rows_linear_backward_weight_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "spcl_rows_linear_backward_weight": (c_int, [_P, _P, c_int, c_long, c_int, c_int, c_int, c_int, _P, c_size_t, _P, _P, _P]),

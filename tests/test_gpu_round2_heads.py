@@ -255,3 +255,46 @@ def test_pixelwise_mlp_rows_gemm_vs_torch(dt, shape, hid, out):
     ps2 = [t.cuda().requires_grad_(True) for t in (w1, b1) + ((w2, b2) if mlp else ())]
     (F_.pixelwise_mlp(xg2, *ps2) * r.cuda()).sum().backward()
     assert torch.equal(xg2.grad, xg.grad) and all(torch.equal(a.grad, b.grad) for a, b in zip(ps, ps2))
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape,hid,out,hw", [((3, 64, 19, 23), 256, 256, (10, 10)), ((2, 16, 40, 40), 128, 32, (5, 4)),
+                                              ((4, 32, 9, 9), 64, 64, (1, 1)), ((2, 128, 14, 14), 36, 20, (14, 14))])
+def test_pooled_hidden_form_equals_pool_of_the_projection(dt, shape, hid, out, hw):
+    """``pixelwise_mlp_pooled`` (the second 1x1 convolution applied to the POOLED hidden activation: what DenseProjectionHead runs
+    for an mlp head with adaptive average pooling) against ``adaptive_pool2d(pixelwise_mlp(...))`` (the reference's order) and
+    against float64 torch: same function, sums associated differently."""
+    import spcl_amd  # noqa
+    from spcl_amd import functional as F_
+    g = torch.Generator().manual_seed(sum(shape) + hid + hw[0])
+    N, C, H, W = shape
+    x = torch.randn(N, C, H, W, generator=g).to(dt)
+    w1, b1 = torch.randn(hid, C, 1, 1, generator=g) * 0.2, torch.randn(hid, generator=g) * 0.1
+    w2, b2 = torch.randn(out, hid, 1, 1, generator=g) * 0.2, torch.randn(out, generator=g) * 0.1
+    r = torch.randn(N, out, *hw, generator=g)
+
+    xs = x.double().clone().requires_grad_(True)
+    ps64 = [t.double().clone().requires_grad_(True) for t in (w1, b1, w2, b2)]
+    y64 = torch.nn.functional.conv2d(torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(xs, ps64[0], ps64[1]), 0.01),
+                                     ps64[2], ps64[3])
+    y64 = torch.nn.functional.adaptive_avg_pool2d(y64, hw)
+    (y64 * r.double()).sum().backward()
+
+    res = {}
+    for form in ("pooled", "reference order"):
+        xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        ps = [t.cuda().requires_grad_(True) for t in (w1, b1, w2, b2)]
+        if form == "pooled":
+            y = F_.pixelwise_mlp_pooled(xg, *ps, hw)
+        else:
+            y = F_.adaptive_pool2d(F_.pixelwise_mlp(xg, *ps), hw, "avg")
+        (y * r.cuda()).sum().backward()
+        res[form] = (y.detach(), xg.grad, [p.grad for p in ps])
+    y, dx, dps = res["pooled"]
+    tol = 3e-5
+    np.testing.assert_allclose(y.cpu().double().numpy(), y64.detach().numpy(), rtol=tol, atol=tol * float(y64.detach().abs().max()))
+    np.testing.assert_allclose(y.cpu().numpy(), res["reference order"][0].cpu().numpy(), rtol=tol, atol=tol * float(y64.detach().abs().max()))
+    gtol = tol if dt == torch.float32 else 6e-3
+    np.testing.assert_allclose(dx.double().cpu().numpy(), xs.grad.numpy(), rtol=gtol, atol=gtol * float(xs.grad.abs().max()))
+    for got, want in zip(dps, [p.grad for p in ps64]):
+        np.testing.assert_allclose(got.double().cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-5 * float(want.abs().max()) + 1e-6)
