@@ -371,6 +371,19 @@ int spcl_bn_finalize(float* stats, int ntiles, int C, int CS, const float* gamma
 int spcl_bn_eval_affine(int C, int CS, const float* gamma, const float* beta, const float* running_mean,
                         const float* running_var, float eps, float* mean, float* invstd, float* scale, float* shift,
                         void* stream);
+/* ... of up to SPCL_BN_EVAL_MAX BatchNorms in one launch (the eval-mode forward of the full UNet: 22 layers); st: [4][CS] =
+ * mean, invstd, scale, shift of that layer, as spcl_bn_eval_affine writes them. */
+#define SPCL_BN_EVAL_MAX 32
+typedef struct {
+  const float* gamma;
+  const float* beta;
+  const float* running_mean;
+  const float* running_var;
+  float* st;
+  int C, CS;
+  float eps;
+} spcl_bn_eval_item;
+int spcl_bn_eval_affine_multi(const spcl_bn_eval_item* items, int n, void* stream);
 
 /* a = relu(scale*y+shift) [N,H,W,CS] (act_out, may be NULL) and/or its 2x2/2 max-pool p [N,H/2,W/2,CS]
  * (pool_out, may be NULL)                                                       -- unet.py:74,77 + :118-121 */

@@ -910,10 +910,39 @@ def take_prepacked_acorr(image):
     return _PREPACKED_ACORR.pop((image.data_ptr(), image._version), None)
 
 
+_EVAL_AFFINE = {}
+
+
 def clear_prepacked():
     """drop what a forward pass announced and did not consume (UNet.forward calls it on every exit)"""
     _PREPACKED.clear()
     _PREPACKED_ACORR.clear()
+    _EVAL_AFFINE.clear()
+
+
+def prepare_eval_affines(bns):
+    """``bns``: the BatchNorm2d modules an EVAL-mode forward pass is about to apply: mean / invstd / scale / shift of all of
+    them from their running statistics in ONE launch (spcl_bn_eval_affine_multi), handed to ``_bn_stats`` through
+    ``_EVAL_AFFINE`` (keyed by the running mean's storage).  One launch per layer was 22 launches of ~5 us in a validation
+    batch of the full UNet: a quarter of its GPU time."""
+    _EVAL_AFFINE.clear()
+    bns = [bn for bn in bns if bn.running_mean is not None and bn.running_mean.is_cuda and bn.weight is not None]
+    for i in range(0, len(bns), _n.BN_EVAL_MAX):
+        part = bns[i:i + _n.BN_EVAL_MAX]
+        dev = part[0].running_mean.device
+        sizes = [_ru16(bn.num_features) for bn in part]
+        buf = torch.empty(4 * sum(sizes), dtype=torch.float32, device=dev)
+        items, keep, off = [], [], 0
+        for bn, cs in zip(part, sizes):
+            g, b = bn.weight.detach().contiguous().float(), bn.bias.detach().contiguous().float()
+            st = buf[off:off + 4 * cs].view(4, cs)
+            off += 4 * cs
+            items.append(_n.BnEvalItem(g.data_ptr(), b.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                                       st.data_ptr(), bn.num_features, cs, float(bn.eps)))
+            keep.append((g, b))
+            _EVAL_AFFINE[(bn.running_mean.data_ptr(), cs)] = st
+        arr = (_n.BnEvalItem * len(items))(*items)
+        _n.call("spcl_bn_eval_affine_multi", arr, len(items), _n.stream())
 
 
 def prepack_weights(layers, dtype, image=None):
@@ -1098,6 +1127,9 @@ def _bn_stats(stats, cfg: BlockCfg, C, cs, gamma, beta, which, dev):
                 c_float(cfg.eps), _n.ptr(rm if upd else None), _n.ptr(rv if upd else None),
                 _n.ptr(nbt if upd else None), _n.ptr(st[0]), _n.ptr(st[1]), _n.ptr(st[2]), _n.ptr(st[3]), _n.stream())
     else:
+        pre = _EVAL_AFFINE.pop((rm.data_ptr(), cs), None) if rm.dtype == torch.float32 else None
+        if pre is not None:  # computed with the pass's other layers in one launch (prepare_eval_affines)
+            return pre
         _n.call("spcl_bn_eval_affine", C, cs, _n.ptr(g), _n.ptr(b), _n.ptr(rm), _n.ptr(rv), c_float(cfg.eps),
                 _n.ptr(st[0]), _n.ptr(st[1]), _n.ptr(st[2]), _n.ptr(st[3]), _n.stream())
     return st

@@ -89,6 +89,7 @@ _SIGNATURES = {
     "spcl_conv3x3_wgrad_batched_tails": (c_int, [_P, c_int, _P, c_int, c_int, _P, _P]),
     "spcl_bn_finalize": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_float, c_float, _P, _P, _P, _P, _P, _P, _P, _P]),
     "spcl_bn_eval_affine": (c_int, [c_int, c_int, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _P]),
+    "spcl_bn_eval_affine_multi": (c_int, [_P, c_int, _P]),
     "spcl_bnrelu_pool_forward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "spcl_bnrelu_up2_forward": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P]),
     "spcl_bnrelu_pool_forward_strided": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, c_int, _P, _P]),
@@ -209,6 +210,15 @@ class PackItem(ctypes.Structure):
     """``spcl_pack_item`` of include/spcl_hip.h (one layer of a multi-layer weight pack)"""
     _fields_ = [("w_oihw", c_void_p), ("fwd", c_void_p), ("dgrad", c_void_p), ("Cin", c_int), ("Cout", c_int),
                 ("H", c_int), ("W", c_int)]
+
+
+BN_EVAL_MAX = 32  # == SPCL_BN_EVAL_MAX
+
+
+class BnEvalItem(ctypes.Structure):
+    """``spcl_bn_eval_item`` of include/spcl_hip.h (one BatchNorm of a multi-layer eval-affine launch)"""
+    _fields_ = [("gamma", c_void_p), ("beta", c_void_p), ("running_mean", c_void_p), ("running_var", c_void_p),
+                ("st", c_void_p), ("C", c_int), ("CS", c_int), ("eps", c_float)]
 
 
 class BnAcc(ctypes.Structure):

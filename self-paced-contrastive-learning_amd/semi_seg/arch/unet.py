@@ -241,6 +241,7 @@ class UNet(nn.Module):
         if x.is_cuda:
             F_hip.bn_acc_arena_begin(x.device)  # one zero fill for every BatchNorm accumulator block of this pass (and its backward)
         self._prepack(x, until)
+        self._prepare_eval_bn(x, until)
         try:
             return self._forward_blocks(x, until, encoder_only)
         finally:
@@ -362,6 +363,33 @@ class UNet(nn.Module):
                 return d
         self._Deconv_1x1._link, blk._link_act = blk._link_act, None
         return self._Deconv_1x1(d)
+
+    def _prepare_eval_bn(self, x, until):
+        """an eval-mode pass (validation; a frozen block under ``disable_bn``): the coefficients of every BatchNorm it applies,
+        from the running statistics, in ONE launch up front (functional.prepare_eval_affines) instead of one per layer"""
+        if not x.is_cuda or x.dim() != 4:
+            return
+        bns = []
+        for name in _ENCODER:
+            m = getattr(self, "_" + name)
+            if not m.training:
+                bns.extend([m.conv[1], m.conv[4]])
+            if until == name:
+                break
+        else:
+            for lvl in (5, 4, 3, 2):
+                up, blk = getattr(self, f"_Up{lvl}"), getattr(self, f"_Up_conv{lvl}")
+                if not up.training:
+                    bns.append(up.up[2])
+                if until == f"Up{lvl}":
+                    break
+                if not blk.training:
+                    bns.extend([blk.conv[1], blk.conv[4]])
+                if until == f"Up_conv{lvl}":
+                    break
+        bns = [b for b in bns if isinstance(b, nn.BatchNorm2d)]
+        if len(bns) > 1:
+            F_hip.prepare_eval_affines(bns)
 
     def _prepack(self, x, until):
         """announce the 3x3 convolutions this forward pass runs (and the image size each runs at): their weights are packed
