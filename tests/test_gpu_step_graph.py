@@ -306,3 +306,28 @@ def test_dense_hook_steps_replay_bit_for_bit(dtype):
     assert torch.equal(res[False][1], res[True][1])
     for k, v in res[False][2].items():
         assert torch.equal(v, res[True][2][k]), k
+
+
+def test_replayed_steps_with_contract_checks_do_not_drain_the_queue():
+    """``sync_checks=True`` -- what hooks built from a config run with -- must not cost a device readback per step (round 6: it
+    did, and halved the real trainer's throughput): with torch's synchronisation debug mode set to ``error`` the replayed
+    steps run through (the check reads the PREVIOUS step's pinned copy behind an event), while the eager form of the same
+    check (``criterion.check()``: ``tolist()`` of a device tensor) is caught by that mode."""
+    net, hook, flat, opt, ep = _setup(True, torch.float32, sync_checks=True)
+    batches = _batches(8, 8, 32)
+    _run(ep, batches[:4])
+    assert ep._step_graph.captured
+    crit = hook._hooks[0]._criterion  # (the trainer-level hook's criterion: the epoch hook shares it)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        with ep.meters.focus_on(ep.meter_focus):
+            for b in batches[4:]:
+                ep.step(b)
+        crit._host_out = None
+        with pytest.raises(RuntimeError):
+            crit.check()  # the per-step readback this test guards against
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    ep.close_hooks()  # (the last step's pending check)
+    assert ep._step_graph.replays == 6
