@@ -85,3 +85,22 @@ def test_replayed_validation_equals_eager_validation(dtype):
     got3 = _eval(model, loader, graph=True)
     assert graphs.signature != sig
     assert torch.equal(ref3[1], got3[1]) and torch.equal(ref3[2], got3[2]) and ref3[4] == got3[4] and ref3[5] == got3[5]
+
+
+def test_replayed_validation_batches_do_not_synchronise():
+    """a validation pass whose batches are all replays issues no synchronising call before its statistics are read (torch's
+    sync-debug mode set to ``error`` around the batch loop)"""
+    from spcl_amd.contrastyou.losses.kl import KL_div
+    from spcl_amd.semi_seg.epochers.finetune import EvalEpocher
+    model = _model(torch.bfloat16)
+    loader = _Scans([6, 9, 6, 9, 6, 9])
+    _eval(model, loader, graph=True)  # eager, capture, replay of both shapes
+    ep = EvalEpocher(model=model, loader=loader, sup_criterion=KL_div(verbose=False), device="cuda", graph=True)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        with ep.meters.focus_on(ep.meter_focus):
+            ep._run()
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert 0.0 <= ep.get_score() <= 1.0
