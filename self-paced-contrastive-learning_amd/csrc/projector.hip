@@ -339,58 +339,67 @@ __global__ __launch_bounds__(256) void adaptive_avgpool_fwd_win_kernel(const flo
 template <typename T, bool MAX>
 __global__ __launch_bounds__(256) void adaptive_pool_bwd_pix_kernel(const float* __restrict__ dout, const int* __restrict__ arg,
                                                                     int H, int W, int C, int Cs, int OH, int OW,
-                                                                    T* __restrict__ dx, size_t npix,
+                                                                    T* __restrict__ dx, size_t nseg, int segs_per_row,
                                                                     const float* __restrict__ act = nullptr) {
   // act (optional, [npix][Cs] f32): the pooled tensor was LeakyReLU(pre) and `act` holds it -- the gradient leaves multiplied
   // by LeakyReLU'(pre), whose sign `act` carries
+  // A wave owns a SEGMENT of APB_SEG consecutive pixels of one image row: the row's windows (oy range) are found once per
+  // segment, the column windows per pixel (the search is a few integer divisions: per pixel and wave they were what a
+  // 753 000-pixel launch spent most of its time on)
   typedef __attribute__((ext_vector_type(4))) float v4f;
   typedef __attribute__((ext_vector_type(4))) int v4i;
+  constexpr int APB_SEG = 8;
   const int lane = threadIdx.x & 63;
-  const size_t pix = (size_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (pix >= npix) return;
-  const int xx = (int)(pix % W);
-  const size_t r = pix / W;
+  const size_t seg = (size_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (seg >= nseg) return;
+  const int sx = (int)(seg % segs_per_row);
+  const size_t r = seg / segs_per_row;
   const int y = (int)(r % H);
   const size_t n = r / H;
-  int oy_lo = (int)(((long)y * OH) / H), ox_lo = (int)(((long)xx * OW) / W);
+  int oy_lo = (int)(((long)y * OH) / H);
   while (oy_lo > 0 && ((oy_lo) * H + OH - 1) / OH > y) --oy_lo;   // previous window still reaches y
-  while (ox_lo > 0 && ((ox_lo) * W + OW - 1) / OW > xx) --ox_lo;
-  for (int c0 = 4 * lane; c0 < Cs; c0 += 256) {
-    v4f g = {0.f, 0.f, 0.f, 0.f};
-    if (c0 < C) {
-      for (int oy = oy_lo; oy < OH && (oy * H) / OH <= y; ++oy) {
-        const int y0 = (oy * H) / OH, y1 = ((oy + 1) * H + OH - 1) / OH;
-        if (y < y0 || y >= y1) continue;
-        for (int ox = ox_lo; ox < OW && (ox * W) / OW <= xx; ++ox) {
-          const int x0 = (ox * W) / OW, x1 = ((ox + 1) * W + OW - 1) / OW;
-          if (xx < x0 || xx >= x1) continue;
-          const size_t o = ((n * OH + oy) * OW + ox) * (size_t)C + c0;
-          const v4f d = *(const v4f*)(dout + o);
-          if (MAX) {
-            const v4i a = *(const v4i*)(arg + o);
+  const int xe = min(W, (sx + 1) * APB_SEG);
+  for (int xx = sx * APB_SEG; xx < xe; ++xx) {
+    const size_t pix = (n * H + y) * (size_t)W + xx;
+    int ox_lo = (int)(((long)xx * OW) / W);
+    while (ox_lo > 0 && ((ox_lo) * W + OW - 1) / OW > xx) --ox_lo;
+    for (int c0 = 4 * lane; c0 < Cs; c0 += 256) {
+      v4f g = {0.f, 0.f, 0.f, 0.f};
+      if (c0 < C) {
+        for (int oy = oy_lo; oy < OH && (oy * H) / OH <= y; ++oy) {
+          const int y0 = (oy * H) / OH, y1 = ((oy + 1) * H + OH - 1) / OH;
+          if (y < y0 || y >= y1) continue;
+          for (int ox = ox_lo; ox < OW && (ox * W) / OW <= xx; ++ox) {
+            const int x0 = (ox * W) / OW, x1 = ((ox + 1) * W + OW - 1) / OW;
+            if (xx < x0 || xx >= x1) continue;
+            const size_t o = ((n * OH + oy) * OW + ox) * (size_t)C + c0;
+            const v4f d = *(const v4f*)(dout + o);
+            if (MAX) {
+              const v4i a = *(const v4i*)(arg + o);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) g[e] += a[e] == y * W + xx ? d[e] : 0.f;
-          } else {
-            const float size = (float)((y1 - y0) * (x1 - x0));
+              for (int e = 0; e < 4; ++e) g[e] += a[e] == y * W + xx ? d[e] : 0.f;
+            } else {
+              const float size = (float)((y1 - y0) * (x1 - x0));
 #pragma unroll
-            for (int e = 0; e < 4; ++e) g[e] += d[e] / size;
+              for (int e = 0; e < 4; ++e) g[e] += d[e] / size;
+            }
           }
         }
       }
-    }
-    if (act != nullptr) {
-      const v4f a = *(const v4f*)(act + pix * (size_t)Cs + c0);
+      if (act != nullptr) {
+        const v4f a = *(const v4f*)(act + pix * (size_t)Cs + c0);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) g[e] *= a[e] > 0.f ? 1.f : kLeaky;
-    }
-    T* o = dx + pix * (size_t)Cs + c0;
-    if (sizeof(T) == 4) {
-      *(v4f*)o = g;
-    } else {
-      uint2 w;
-      w.x = (unsigned)f32_to_bf16(g[0]) | ((unsigned)f32_to_bf16(g[1]) << 16);
-      w.y = (unsigned)f32_to_bf16(g[2]) | ((unsigned)f32_to_bf16(g[3]) << 16);
-      *(uint2*)o = w;
+        for (int e = 0; e < 4; ++e) g[e] *= a[e] > 0.f ? 1.f : kLeaky;
+      }
+      T* o = dx + pix * (size_t)Cs + c0;
+      if (sizeof(T) == 4) {
+        *(v4f*)o = g;
+      } else {
+        uint2 w;
+        w.x = (unsigned)f32_to_bf16(g[0]) | ((unsigned)f32_to_bf16(g[1]) << 16);
+        w.y = (unsigned)f32_to_bf16(g[2]) | ((unsigned)f32_to_bf16(g[3]) << 16);
+        *(uint2*)o = w;
+      }
     }
   }
 }
@@ -456,16 +465,17 @@ extern "C" int spcl_adaptive_pool2d_backward(const float* dout, const int* argma
   }
   if (C % 4 == 0 && Cs % 4 == 0 && (dtype == SPCL_F32 || dtype == SPCL_BF16) && ((uintptr_t)dout % 16 == 0) &&
       ((uintptr_t)dx % 16 == 0) && (argmax == nullptr || (uintptr_t)argmax % 16 == 0)) {
-    const size_t npix = (size_t)N * H * W;
-    dim3 pg((unsigned)((npix + 3) / 4));
+    const int spr = (W + 7) / 8;  // segments of eight pixels per image row (APB_SEG)
+    const size_t nseg = (size_t)N * H * spr;
+    dim3 pg((unsigned)((nseg + 3) / 4));
     if (dtype == SPCL_F32 && mode == 0)
-      SPCL_LAUNCH((adaptive_pool_bwd_pix_kernel<float, false>), pg, dim3(256), 0, st, dout, argmax, H, W, C, Cs, OH, OW, (float*)dx, npix);
+      SPCL_LAUNCH((adaptive_pool_bwd_pix_kernel<float, false>), pg, dim3(256), 0, st, dout, argmax, H, W, C, Cs, OH, OW, (float*)dx, nseg, spr);
     else if (dtype == SPCL_F32)
-      SPCL_LAUNCH((adaptive_pool_bwd_pix_kernel<float, true>), pg, dim3(256), 0, st, dout, argmax, H, W, C, Cs, OH, OW, (float*)dx, npix);
+      SPCL_LAUNCH((adaptive_pool_bwd_pix_kernel<float, true>), pg, dim3(256), 0, st, dout, argmax, H, W, C, Cs, OH, OW, (float*)dx, nseg, spr);
     else if (mode == 0)
-      SPCL_LAUNCH((adaptive_pool_bwd_pix_kernel<bf16_t, false>), pg, dim3(256), 0, st, dout, argmax, H, W, C, Cs, OH, OW, (bf16_t*)dx, npix);
+      SPCL_LAUNCH((adaptive_pool_bwd_pix_kernel<bf16_t, false>), pg, dim3(256), 0, st, dout, argmax, H, W, C, Cs, OH, OW, (bf16_t*)dx, nseg, spr);
     else
-      SPCL_LAUNCH((adaptive_pool_bwd_pix_kernel<bf16_t, true>), pg, dim3(256), 0, st, dout, argmax, H, W, C, Cs, OH, OW, (bf16_t*)dx, npix);
+      SPCL_LAUNCH((adaptive_pool_bwd_pix_kernel<bf16_t, true>), pg, dim3(256), 0, st, dout, argmax, H, W, C, Cs, OH, OW, (bf16_t*)dx, nseg, spr);
     SPCL_LAUNCH_CHECK("adaptive_pool2d_backward");
     return SPCL_OK;
   }
@@ -701,9 +711,10 @@ extern "C" int spcl_adaptive_avgpool2d_backward_act(const float* dout, const flo
                                                     float* dx, void* stream) {
   SPCL_CHECK_ARG(dout && act && dx, "adaptive_avgpool2d_backward_act: null pointer");
   SPCL_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && OH > 0 && OW > 0, "adaptive_avgpool2d_backward_act: bad shape");
-  const size_t npix = (size_t)N * H * W;
-  SPCL_LAUNCH((adaptive_pool_bwd_pix_kernel<float, false>), dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dout,
-              (const int*)nullptr, H, W, C, C, OH, OW, dx, npix, act);
+  const int spr = (W + 7) / 8;
+  const size_t nseg = (size_t)N * H * spr;
+  SPCL_LAUNCH((adaptive_pool_bwd_pix_kernel<float, false>), dim3((unsigned)((nseg + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dout,
+              (const int*)nullptr, H, W, C, C, OH, OW, dx, nseg, spr, act);
   SPCL_LAUNCH_CHECK("adaptive_avgpool2d_backward_act");
   return SPCL_OK;
 }

@@ -69,11 +69,18 @@ template <typename TX, typename TY, bool LEAKY_IN, bool B_T, bool MASK, bool LEA
 __global__ __launch_bounds__(256) void rows_gemm_kernel(const TX* __restrict__ X, long ldx, const float* __restrict__ W, long ldw,
                                                         const float* __restrict__ bias, const float* __restrict__ P, long ldp,
                                                         int M, int K, int N, TY* __restrict__ Y, long ldy) {
-  __shared__ __attribute__((aligned(16))) float As[128 * RM_KP];
-  __shared__ __attribute__((aligned(16))) float Bs[64 * RM_KP];
+  // one buffer: the two operand tiles during the k-loop, then the 128 x 64 output tile on its way out (row pitch RM_CP)
+  constexpr int RM_CP = 68;
+  __shared__ __attribute__((aligned(16))) float smem[128 * RM_CP];
+  float* const As = smem;
+  float* const Bs = smem + 128 * RM_KP;
+  static_assert(128 * RM_KP + 64 * RM_KP <= 128 * RM_CP, "operand tiles fit the output tile's buffer");
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r16 = lane & 15, g = lane >> 4;
-  const long m0 = (long)blockIdx.x * 128;
-  const int n0 = blockIdx.y * 64;
+  // 1-D grid, the column block fastest: the workgroups that share a row block (the same A tile, the other 256-byte pieces of
+  // the same output rows) are dispatched together
+  const int ncb = (N + 63) / 64;
+  const long m0 = (long)(blockIdx.x / ncb) * 128;
+  const int n0 = (int)(blockIdx.x % ncb) * 64;
   rm_f32x4 acc[2][4];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -114,27 +121,47 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const TX* __restrict__ X
     rm_chunk<2, 4>(As, Bs, wave * 32, acc, r16, g);
     __syncthreads();
   }
+  // The accumulators leave through LDS: a lane holds four ROWS of one column (the instruction's D layout), stored as they
+  // are that is 32 scattered 4-byte stores per lane in 64-byte pieces -- the first version of this kernel wrote its 32 KB
+  // tile at a fifth of the rate the k-loop delivered it.  Transposed through the tile buffer a thread writes four
+  // consecutive columns (16 bytes, or 8 as bf16) and sixteen neighbouring threads one whole 256-byte row.
+  // (the k-loop's last barrier has passed: nobody reads the operand tiles any more)
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + 16 * j + r16;
-      const bool okn = n < N;
-      const float bv = bias != nullptr ? bias[okn ? n : 0] : 0.f;
-      const long mr = m0 + wave * 32 + 16 * i + 4 * g;
-      float pv[4] = {1.f, 1.f, 1.f, 1.f};
-      if (MASK) {  // (all four requested before the first is used)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) pv[r] = P[(okn && mr + r < M) ? (mr + r) * ldp + n : 0L];
-      }
+      for (int r = 0; r < 4; ++r) smem[(wave * 32 + 16 * i + 4 * g + r) * RM_CP + 16 * j + r16] = acc[i][j][r];
+  __syncthreads();
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = acc[i][j][r] + bv;
-        if (MASK) v *= pv[r] > 0.f ? 1.f : kRowsLeaky;  // (torch: the slope at 0 is the negative one)
-        if (LEAKY_OUT) v = rm_act(v, true);
-        if (okn && mr + r < M) Elem<TY>::store(Y + (mr + r) * ldy + n, v);
+  for (int it = 0; it < 8; ++it) {
+    const int c = t + 256 * it, row = c >> 4, ch = c & 15;
+    const long m = m0 + row;
+    const int n = n0 + 4 * ch;
+    const bool ok = m < M && n < N;  // (N is a multiple of 4: a chunk is whole or absent)
+    rm_f32x4 v = *(const rm_f32x4*)(smem + row * RM_CP + 4 * ch);
+    if (bias != nullptr) v += rm_load4<float>(bias, (long)n, n < N);
+    if (MASK) {
+      const rm_f32x4 pv = rm_load4<float>(P, m * ldp + n, ok);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= pv[e] > 0.f ? 1.f : kRowsLeaky;  // (torch: the slope at 0 is the negative one)
+    }
+    if (LEAKY_OUT) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = rm_act(v[e], true);
+    }
+    if (ok) {
+      TY* o = Y + m * ldy + n;
+      if (sizeof(TY) == 4) {
+        *(rm_f32x4*)o = v;
+      } else {
+        uint2 w;
+        w.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+        w.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+        *(uint2*)o = w;
       }
     }
+  }
 }
 
 // ---- weight gradient: a 64 x 64 tile of dW per workgroup over one slab of rows; partial [slab][N][K] (+ [slab][N] for db)
@@ -217,12 +244,20 @@ __global__ __launch_bounds__(256) void rows_wgrad_fold_kernel(const float* __res
   }
 }
 
-static int rows_slabs(int M) {
-  int s = (M + 2047) / 2048;
-  return s < 1 ? 1 : (s > 96 ? 96 : s);
+// slabs of rows of the weight gradient: enough workgroups to fill the chip several times over (a workgroup is a chain of
+// load -> barrier -> multiply -> barrier per 32 rows: with 1.5 workgroups per CU -- 96 slabs, the first version -- the launch
+// was latency bound at 0.4 TB/s), bounded by the bytes of partial tiles the fold then reads (at most 32 MB)
+static int rows_slabs(int M, int N, int K) {
+  const int tiles = ((N + 63) / 64) * ((K + 63) / 64);
+  long s = (M + 511) / 512;                                   // at least 512 rows per slab
+  const long want = (2048 + tiles - 1) / tiles;               // ~2 048 workgroups
+  if (s > want) s = want;
+  const long cap = (32L << 20) / ((long)N * K * 4 + N * 4);    // partial bytes
+  if (s > cap) s = cap;
+  return s < 1 ? 1 : (int)s;
 }
-static int rows_slab_rows(int M) {
-  const int s = rows_slabs(M);
+static int rows_slab_rows(int M, int N, int K) {
+  const int s = rows_slabs(M, N, K);
   const int r = (M + s - 1) / s;
   return (r + RM_KC - 1) / RM_KC * RM_KC;
 }
@@ -238,7 +273,7 @@ extern "C" int spcl_rows_linear_forward(const void* x, int x_dtype, long ldx, in
                  "rows_linear_forward: M, K, N > 0, K and the row pitch multiples of 4 (got %d, %d, %d, %ld)", M, K, N, ldx);
   SPCL_CHECK_ARG(x_dtype == SPCL_F32 || x_dtype == SPCL_BF16, "rows_linear_forward: dtype %d", x_dtype);
   SPCL_CHECK_ARG(!(leaky_in && x_dtype != SPCL_F32), "rows_linear_forward: a saved pre-activation is f32");
-  const dim3 grid((unsigned)((M + 127) / 128), (unsigned)((N + 63) / 64));
+  const dim3 grid((unsigned)((size_t)((M + 127) / 128) * ((N + 63) / 64)));
   hipStream_t st = (hipStream_t)stream;
   if (x_dtype == SPCL_BF16)
     SPCL_LAUNCH((rows_gemm_kernel<bf16_t, float, false, false, false>), grid, dim3(256), 0, st, (const bf16_t*)x, ldx, W, (long)K,
@@ -261,7 +296,7 @@ extern "C" int spcl_rows_linear_forward_act(const void* x, int x_dtype, long ldx
   SPCL_CHECK_ARG(M > 0 && K > 0 && N > 0 && ldx >= K && K % 4 == 0 && ldx % 4 == 0,
                  "rows_linear_forward_act: M, K, N > 0, K and the row pitch multiples of 4 (got %d, %d, %d, %ld)", M, K, N, ldx);
   SPCL_CHECK_ARG(x_dtype == SPCL_F32 || x_dtype == SPCL_BF16, "rows_linear_forward_act: dtype %d", x_dtype);
-  const dim3 grid((unsigned)((M + 127) / 128), (unsigned)((N + 63) / 64));
+  const dim3 grid((unsigned)((size_t)((M + 127) / 128) * ((N + 63) / 64)));
   hipStream_t st = (hipStream_t)stream;
   if (x_dtype == SPCL_BF16)
     SPCL_LAUNCH((rows_gemm_kernel<bf16_t, float, false, false, false, true>), grid, dim3(256), 0, st, (const bf16_t*)x, ldx, W,
@@ -280,7 +315,7 @@ extern "C" int spcl_rows_linear_backward_input(const float* g, const float* W, c
                  "rows_linear_backward_input: M, K, N > 0, N and K multiples of 4 (got %d, %d, %d)", M, K, N);
   SPCL_CHECK_ARG(dx_dtype == SPCL_F32 || dx_dtype == SPCL_BF16, "rows_linear_backward_input: dtype %d", dx_dtype);
   // D[M][K] = G[M][N] W[N][K]: the reduction runs over W's ROWS (B_T); its "output columns" are the K inputs
-  const dim3 grid((unsigned)((M + 127) / 128), (unsigned)((K + 63) / 64));
+  const dim3 grid((unsigned)((size_t)((M + 127) / 128) * ((K + 63) / 64)));
   hipStream_t st = (hipStream_t)stream;
   if (dx_dtype == SPCL_BF16) {
     if (pre != nullptr)
@@ -303,7 +338,7 @@ extern "C" int spcl_rows_linear_backward_input(const float* g, const float* W, c
 
 extern "C" size_t spcl_rows_linear_backward_weight_workspace_bytes(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  return (size_t)rows_slabs(M) * ((size_t)N * K + N) * sizeof(float);
+  return (size_t)rows_slabs(M, N, K) * ((size_t)N * K + N) * sizeof(float);
 }
 
 extern "C" int spcl_rows_linear_backward_weight(const float* g, const void* x, int x_dtype, long ldx, int leaky_in, int M, int N,
@@ -315,7 +350,7 @@ extern "C" int spcl_rows_linear_backward_weight(const float* g, const void* x, i
   SPCL_CHECK_ARG(!(leaky_in && x_dtype != SPCL_F32), "rows_linear_backward_weight: a saved pre-activation is f32");
   SPCL_CHECK_ARG(ws_bytes >= spcl_rows_linear_backward_weight_workspace_bytes(M, N, K),
                  "rows_linear_backward_weight: workspace of %zu bytes", spcl_rows_linear_backward_weight_workspace_bytes(M, N, K));
-  const int ns = rows_slabs(M), sr = rows_slab_rows(M), ktiles = (K + 63) / 64, ntiles = (N + 63) / 64;
+  const int ns = rows_slabs(M, N, K), sr = rows_slab_rows(M, N, K), ktiles = (K + 63) / 64, ntiles = (N + 63) / 64;
   const int nslab = (M + sr - 1) / sr;  // (slabs that hold rows: the rounded slab height may leave the last ones empty)
   float* part = ws;
   float* part_b = ws + (size_t)ns * N * K;
