@@ -298,3 +298,57 @@ def test_pooled_hidden_form_equals_pool_of_the_projection(dt, shape, hid, out, h
     np.testing.assert_allclose(dx.double().cpu().numpy(), xs.grad.numpy(), rtol=gtol, atol=gtol * float(xs.grad.abs().max()))
     for got, want in zip(dps, [p.grad for p in ps64]):
         np.testing.assert_allclose(got.double().cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-5 * float(want.abs().max()) + 1e-6)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_dense_head_at_full_size_vs_float64(dt):
+    """The dense projector at the size a training step runs it (30 x 2 maps of 64 channels at 56 x 56 = 188 160 pixel rows,
+    hidden and output 256, pooled to 10 x 10): the pooled-hidden form and the plain products + pooling, against torch in float64
+    ON THE DEVICE -- hundreds of weight-gradient slabs, every tile shape of the products (the unit tests above stop at 3 200
+    rows).  With 48 million hidden pre-activations a few lie within rounding of zero, where LeakyReLU' jumps by a factor 100
+    and f32 and f64 may disagree about the side: everything downstream of that derivative (feature gradient, first layer's
+    gradients) is compared with float64 on the pixels WITHOUT such a near-tie, and between the two device forms (which share the
+    pre-activations bit for bit, hence the decisions) everywhere."""
+    import spcl_amd  # noqa
+    from spcl_amd import functional as F_
+    g = torch.Generator().manual_seed(77)
+    N, C, H, W, hid, out, hw = 60, 64, 56, 56, 256, 256, (10, 10)
+    x = torch.randn(N, C, H, W, generator=g).to(dt)
+    w1, b1 = torch.randn(hid, C, 1, 1, generator=g) * 0.1, torch.randn(hid, generator=g) * 0.1
+    w2, b2 = torch.randn(out, hid, 1, 1, generator=g) * 0.1, torch.randn(out, generator=g) * 0.1
+    r = torch.randn(N, out, *hw, generator=g)
+
+    xs = x.cuda().double().requires_grad_(True)
+    ps64 = [t.cuda().double().requires_grad_(True) for t in (w1, b1, w2, b2)]
+    pre64 = torch.nn.functional.conv2d(xs, ps64[0], ps64[1])
+    y64 = torch.nn.functional.conv2d(torch.nn.functional.leaky_relu(pre64, 0.01), ps64[2], ps64[3])
+    y64 = torch.nn.functional.adaptive_avg_pool2d(y64, hw)
+    (y64 * r.cuda().double()).sum().backward()
+    clear = (pre64.detach().abs().amin(dim=1, keepdim=True) > 1e-4)  # [N, 1, H, W]: no hidden unit of the pixel near a tie
+    assert 0.5 < float(clear.double().mean()) < 1.0
+    want = {"y": y64.detach(), "dx": xs.grad, "dw1": ps64[0].grad, "db1": ps64[1].grad, "dw2": ps64[2].grad, "db2": ps64[3].grad}
+    del y64, pre64
+
+    def rel(a, b):
+        return float((a.double() - b.double()).abs().max() / b.double().abs().max())
+
+    forms = {}
+    for form in ("pooled", "reference order"):
+        xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        ps = [t.cuda().requires_grad_(True) for t in (w1, b1, w2, b2)]
+        if form == "pooled":
+            y = F_.pixelwise_mlp_pooled(xg, *ps, hw)
+        else:
+            y = F_.adaptive_pool2d(F_.pixelwise_mlp(xg, *ps), hw, "avg")
+        (y * r.cuda()).sum().backward()
+        got = {"y": y.detach(), "dx": xg.grad, "dw1": ps[0].grad, "db1": ps[1].grad, "dw2": ps[2].grad, "db2": ps[3].grad}
+        forms[form] = got
+        # against float64: what does not pass through LeakyReLU' everywhere; the feature gradient on the clear pixels
+        assert rel(got["y"], want["y"]) <= 3e-5 and rel(got["dw2"], want["dw2"]) <= 2e-4 and rel(got["db2"], want["db2"]) <= 2e-4, form
+        dx_tol = 3e-5 if dt == torch.float32 else 6e-3
+        assert rel(got["dx"] * clear, want["dx"] * clear) <= dx_tol, (form, rel(got["dx"] * clear, want["dx"] * clear))
+        # (a handful of one-sided decisions among 188 160 x 256 terms: the sums stay close)
+        assert rel(got["dw1"], want["dw1"]) <= 2e-2 and rel(got["db1"], want["db1"]) <= 2e-2, form
+    a, b = forms["pooled"], forms["reference order"]
+    for k in ("dx", "dw1", "db1", "dw2", "db2", "y"):
+        assert rel(a[k], b[k]) <= (2e-5 if k != "dx" or dt == torch.float32 else 8e-3), (k, rel(a[k], b[k]))
