@@ -297,8 +297,8 @@ __global__ __launch_bounds__(256) void adaptive_pool_bwd_kernel(const float* __r
 }
 
 // Adaptive AVERAGE pooling of an f32 map, one wave per output window, a lane = four consecutive channels (round 6: the dense
-// projector pools its 256-channel hidden activation -- 770 MB at Up_conv2 -- and the one-thread-per-output kernel above kept
-// one 4-byte load in flight per thread: 0.8 TB/s).  Pixels in the same order, one add per pixel: the old kernel's sums bit for
+// projector pools its 256-channel hidden activation -- 3.1 GB at Up_conv2 (60 maps of 224^2) -- and the one-thread-per-output
+// kernel above kept one 4-byte load in flight per thread: a fifth of the rate of this one).  Pixels in the same order, one add per pixel: the old kernel's sums bit for
 // bit; four pixels' loads are issued before the first add.  C % 4 == 0.
 __global__ __launch_bounds__(256) void adaptive_avgpool_fwd_win_kernel(const float* __restrict__ x, int H, int W, int C, int OH,
                                                                        int OW, float* __restrict__ out, size_t nwin) {
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(256) void adaptive_avgpool_fwd_win_kernel(const flo
 }
 
 // The same gradient, one WAVE per input pixel (round 6): which windows cover (y, x) does not depend on the channel -- with
-// one thread per element every element paid the integer divisions of the window search (1.6 ms for the 188 000 x 256
+// one thread per element every element paid the integer divisions of the window search (1.6 ms for the 753 000 x 256
 // gradient of a dense projection: the longest launch of a decoder pre-training step).  Here the search is wave-uniform and
 // a lane owns four consecutive channels (16-byte loads of dout, one 16- or 8-byte store).  Same windows in the same order,
 // same divisions: the old kernel's values bit for bit.  C and Cs multiples of 4.
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void adaptive_pool_bwd_pix_kernel(const float*
   // by LeakyReLU'(pre), whose sign `act` carries
   // A wave owns a SEGMENT of APB_SEG consecutive pixels of one image row: the row's windows (oy range) are found once per
   // segment, the column windows per pixel (the search is a few integer divisions: per pixel and wave they were what a
-  // 753 000-pixel launch spent most of its time on)
+  // 3-million-pixel launch spent most of its time on)
   typedef __attribute__((ext_vector_type(4))) float v4f;
   typedef __attribute__((ext_vector_type(4))) int v4i;
   constexpr int APB_SEG = 8;

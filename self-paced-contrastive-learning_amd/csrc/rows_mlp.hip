@@ -1,6 +1,6 @@
 // The pixel-wise (1x1-convolution) MLP of the dense projector (contrastyou/projectors/heads.py:28-39,96-120:
 // Conv2d(C, hid, 1) -> LeakyReLU(0.01) -> Conv2d(hid, out, 1) on EVERY pixel of a decoder feature map) as
-// matrix products over the pixels: 188 000 rows at Up_conv3 and 753 000 at Up_conv2 for a 60-image batch.  Rounds 2 - 5
+// matrix products over the pixels: 753 000 rows at Up_conv3 (112^2) and 3 million at Up_conv2 (224^2) for a 60-image batch.  Rounds 2 - 5
 // ran these rows through the global projector's kernels (projector.hip: one wave per output column walking all rows, built
 // for 64 rows), which re-read the whole input once per four output columns: 30 / 24 / 54 / 46 ms per launch, 158 ms per
 // training step at Up_conv3 and 630 ms at Up_conv2 (tools/diag/dense_step_time.py).  Here: three tiled products on the

@@ -302,7 +302,7 @@ def test_pooled_hidden_form_equals_pool_of_the_projection(dt, shape, hid, out, h
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_dense_head_at_full_size_vs_float64(dt):
-    """The dense projector at the size a training step runs it (30 x 2 maps of 64 channels at 56 x 56 = 188 160 pixel rows,
+    """The dense projector at a training step's size (30 x 2 maps of 64 channels at 56 x 56 -- Up_conv4's -- = 188 160 pixel rows,
     hidden and output 256, pooled to 10 x 10): the pooled-hidden form and the plain products + pooling, against torch in float64
     ON THE DEVICE -- hundreds of weight-gradient slabs, every tile shape of the products (the unit tests above stop at 3 200
     rows).  With 48 million hidden pre-activations a few lie within rounding of zero, where LeakyReLU' jumps by a factor 100
