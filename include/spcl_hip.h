@@ -36,7 +36,7 @@ extern "C" {
 /* Bumped whenever a struct layout, a limit (SPCL_*_MAX) or an entry point's meaning changes.  The library is git-ignored and
  * travels next to the sources: the Python binding (native.py) refuses a library whose version is not the header's, so that a
  * stale build fails at load time instead of running kernels on structs of another stride. */
-#define SPCL_ABI_VERSION 8
+#define SPCL_ABI_VERSION 9
 int spcl_abi_version(void);
 const char* spcl_last_error(void);
 
@@ -646,29 +646,32 @@ int spcl_augment_views_pil(const float* src, int S, int HS, int WS, const int* p
                            int OW, void* stream);
 /* The pixel-wise (1x1-convolution) MLP of the dense projector -- contrastyou/projectors/heads.py:28-39,96-120:
  * Conv2d(C, hid, 1) -> LeakyReLU(0.01) -> Conv2d(hid, out, 1) on every pixel of a decoder feature map -- as tiled
- * matrix products over the M = N*H*W pixel rows on the exact-f32 matrix instruction (ABI 8; until then the rows went through the
- * global projector's 64-row kernels: 158 ms per training step at Up_conv3, 630 ms at Up_conv2).  Row-major operands:
- *   forward          y[M][N]  = act(x)[M][K] W[N][K]^T + bias[N]      x: f32 or bf16 rows of pitch ldx (a channels-last map read
- *                                                                      in place), act = LeakyReLU(0.01) when leaky_in (x is then a saved f32 pre-activation)
- *   backward_input   dx[M][K] = (g[M][N] W[N][K]) * (pre ? LeakyReLU'(pre[M][K]) : 1)     dx: f32 or bf16 rows of pitch lddx
+ * matrix products over the M = N*H*W pixel rows on the exact-f32 matrix instruction (round 6; until then the rows went through the
+ * global projector's 64-row kernels: 158 ms per training step at Up_conv3, 630 ms at Up_conv2).  Row-major operands, f32
+ * accumulation; tensors with a dtype argument are f32 or bf16 rows (a channels-last map is read in place through its pitch):
+ *   forward          y[M][N]  = act(x)[M][K] W[N][K]^T + bias[N]      act = LeakyReLU(0.01) when leaky_in (x is then a saved f32
+ *                                                                      pre-activation); y f32
+ *   forward_act      h[M][N]  = LeakyReLU(x[M][K] W[N][K]^T + bias[N])   h of h_dtype.  h carries the pre-activation's sign: it
+ *                                                                      stands in for `pre` below
+ *   backward_input   dx[M][K] = (g[M][N] W[N][K]) * (pre ? LeakyReLU'(pre[M][K]) : 1)     (with pre: g is f32)
  *   backward_weight  dW[N][K] = sum_m g[m][N] act(x)[m][K],  db[N] = sum_m g[m][N]  (db may be NULL): slabs of rows folded in
  *                    index order (bit-deterministic); ws of spcl_rows_linear_backward_weight_workspace_bytes(M, N, K).
- * K, N and the row pitches are multiples of 4. */
+ *   spcl_adaptive_avgpool2d_backward_act: dx = unpool(dout [N][OH][OW][C] f32) * LeakyReLU'(.) with act = LeakyReLU(pre)
+ *                    [N][H][W][C] given instead of pre; act and dx of `dtype`; C % 4 == 0.
+ * The dense projector's pooled-hidden form (functional._PixelMlpPooledFn): adaptive average pooling commutes with the linear
+ * second layer, which then runs on the pooled rows only; the hidden activation and its gradient are stored in the feature
+ * map's dtype.  K, N and the row pitches are multiples of 4. */
 int spcl_rows_linear_forward(const void* x, int x_dtype, long ldx, int leaky_in, const float* W, const float* bias, int M,
                              int K, int N, float* y, void* stream);
-/* ... with the activation applied to the OUTPUT: h = LeakyReLU(x W^T + bias).  h has the pre-activation's sign: it may be passed
- * as `pre` to spcl_rows_linear_backward_input, and to spcl_adaptive_avgpool2d_backward_act (the gradient of an adaptive average
- * pooling of h [N][H][W][C], C % 4 == 0, multiplied by LeakyReLU' on its way out): the dense projector's pooled-hidden form --
- * adaptive average pooling commutes with the linear second layer, which then runs on the pooled rows only. */
 int spcl_rows_linear_forward_act(const void* x, int x_dtype, long ldx, const float* W, const float* bias, int M, int K, int N,
-                                 float* h, void* stream);
-int spcl_adaptive_avgpool2d_backward_act(const float* dout, const float* act, int N, int H, int W, int C, int OH, int OW,
-                                         float* dx, void* stream);
-int spcl_rows_linear_backward_input(const float* g, const float* W, const float* pre, int M, int N, int K, void* dx,
+                                 void* h, int h_dtype, void* stream);
+int spcl_adaptive_avgpool2d_backward_act(const float* dout, const void* act, int dtype, int N, int H, int W, int C, int OH,
+                                         int OW, void* dx, void* stream);
+int spcl_rows_linear_backward_input(const void* g, int g_dtype, const float* W, const float* pre, int M, int N, int K, void* dx,
                                     int dx_dtype, long lddx, void* stream);
 size_t spcl_rows_linear_backward_weight_workspace_bytes(int M, int N, int K);
-int spcl_rows_linear_backward_weight(const float* g, const void* x, int x_dtype, long ldx, int leaky_in, int M, int N, int K,
-                                     float* ws, size_t ws_bytes, float* dW, float* db, void* stream);
+int spcl_rows_linear_backward_weight(const void* g, int g_dtype, const void* x, int x_dtype, long ldx, int leaky_in, int M, int N,
+                                     int K, float* ws, size_t ws_bytes, float* dW, float* db, void* stream);
 /* The reference's other PIL recipes, and the interpolation its wrapper really selects (semi_seg/augment.py:23-37,54-75;
  * contrastyou/augment/synchronize.py:95-103: BILINEAR on images, NEAREST on targets): params[v][28] =
  *   [0] slice [1] flags (1 hflip, 2 vflip, 4 contrast first, 8 bilinear image rotation, 16 crop first = the rotation turns the

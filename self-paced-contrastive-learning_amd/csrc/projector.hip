@@ -300,7 +300,19 @@ __global__ __launch_bounds__(256) void adaptive_pool_bwd_kernel(const float* __r
 // projector pools its 256-channel hidden activation -- 3.1 GB at Up_conv2 (60 maps of 224^2) -- and the one-thread-per-output
 // kernel above kept one 4-byte load in flight per thread: a fifth of the rate of this one).  Pixels in the same order, one add per pixel: the old kernel's sums bit for
 // bit; four pixels' loads are issued before the first add.  C % 4 == 0.
-__global__ __launch_bounds__(256) void adaptive_avgpool_fwd_win_kernel(const float* __restrict__ x, int H, int W, int C, int OH,
+template <typename T>
+__device__ __forceinline__ __attribute__((ext_vector_type(4))) float ap_load4(const T* p) {
+  typedef __attribute__((ext_vector_type(4))) float v4f;
+  if (sizeof(T) == 4) return *(const v4f*)p;
+  const uint2 raw = *(const uint2*)p;
+  v4f v;
+  v[0] = __uint_as_float(raw.x << 16); v[1] = __uint_as_float(raw.x & 0xffff0000u);
+  v[2] = __uint_as_float(raw.y << 16); v[3] = __uint_as_float(raw.y & 0xffff0000u);
+  return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void adaptive_avgpool_fwd_win_kernel(const T* __restrict__ x, int H, int W, int C, int OH,
                                                                        int OW, float* __restrict__ out, size_t nwin) {
   typedef __attribute__((ext_vector_type(4))) float v4f;
   const int lane = threadIdx.x & 63;
@@ -316,14 +328,14 @@ __global__ __launch_bounds__(256) void adaptive_avgpool_fwd_win_kernel(const flo
   for (int c0 = 4 * lane; c0 < C; c0 += 256) {
     v4f acc = {0.f, 0.f, 0.f, 0.f};
     for (int y = y0; y < y1; ++y) {
-      const float* row = x + ((n * H + y) * W) * (size_t)C + c0;
+      const T* row = x + ((n * H + y) * W) * (size_t)C + c0;
       int xx = x0;
       for (; xx + 4 <= x1; xx += 4) {
-        const v4f a = *(const v4f*)(row + (size_t)xx * C), b = *(const v4f*)(row + (size_t)(xx + 1) * C);
-        const v4f c = *(const v4f*)(row + (size_t)(xx + 2) * C), d = *(const v4f*)(row + (size_t)(xx + 3) * C);
+        const v4f a = ap_load4<T>(row + (size_t)xx * C), b = ap_load4<T>(row + (size_t)(xx + 1) * C);
+        const v4f c = ap_load4<T>(row + (size_t)(xx + 2) * C), d = ap_load4<T>(row + (size_t)(xx + 3) * C);
         acc += a; acc += b; acc += c; acc += d;
       }
-      for (; xx < x1; ++xx) acc += *(const v4f*)(row + (size_t)xx * C);
+      for (; xx < x1; ++xx) acc += ap_load4<T>(row + (size_t)xx * C);
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[e] = acc[e] / size;
@@ -340,7 +352,7 @@ template <typename T, bool MAX>
 __global__ __launch_bounds__(256) void adaptive_pool_bwd_pix_kernel(const float* __restrict__ dout, const int* __restrict__ arg,
                                                                     int H, int W, int C, int Cs, int OH, int OW,
                                                                     T* __restrict__ dx, size_t nseg, int segs_per_row,
-                                                                    const float* __restrict__ act = nullptr) {
+                                                                    const T* __restrict__ act = nullptr) {
   // act (optional, [npix][Cs] f32): the pooled tensor was LeakyReLU(pre) and `act` holds it -- the gradient leaves multiplied
   // by LeakyReLU'(pre), whose sign `act` carries
   // A wave owns a SEGMENT of APB_SEG consecutive pixels of one image row: the row's windows (oy range) are found once per
@@ -387,7 +399,7 @@ __global__ __launch_bounds__(256) void adaptive_pool_bwd_pix_kernel(const float*
         }
       }
       if (act != nullptr) {
-        const v4f a = *(const v4f*)(act + pix * (size_t)Cs + c0);
+        const v4f a = ap_load4<T>(act + pix * (size_t)Cs + c0);
 #pragma unroll
         for (int e = 0; e < 4; ++e) g[e] *= a[e] > 0.f ? 1.f : kLeaky;
       }
@@ -426,10 +438,15 @@ extern "C" int spcl_adaptive_pool2d_forward(const void* x, int dtype, int N, int
     SPCL_LAUNCH_CHECK("adaptive_pool2d_forward");
     return SPCL_OK;
   }
-  if (dtype == SPCL_F32 && mode == 0 && C % 4 == 0 && Cs == C && (uintptr_t)x % 16 == 0 && (uintptr_t)out % 16 == 0) {
+  if ((dtype == SPCL_F32 || dtype == SPCL_BF16) && mode == 0 && C % 4 == 0 && Cs == C && (uintptr_t)x % 16 == 0 &&
+      (uintptr_t)out % 16 == 0) {
     const size_t nwin = (size_t)N * OH * OW;
-    SPCL_LAUNCH(adaptive_avgpool_fwd_win_kernel, dim3((unsigned)((nwin + 3) / 4)), dim3(256), 0, st, (const float*)x, H, W, C, OH, OW,
-                out, nwin);
+    if (dtype == SPCL_F32)
+      SPCL_LAUNCH(adaptive_avgpool_fwd_win_kernel<float>, dim3((unsigned)((nwin + 3) / 4)), dim3(256), 0, st, (const float*)x, H, W, C,
+                  OH, OW, out, nwin);
+    else
+      SPCL_LAUNCH(adaptive_avgpool_fwd_win_kernel<bf16_t>, dim3((unsigned)((nwin + 3) / 4)), dim3(256), 0, st, (const bf16_t*)x, H, W,
+                  C, OH, OW, out, nwin);
     SPCL_LAUNCH_CHECK("adaptive_pool2d_forward");
     return SPCL_OK;
   }
@@ -707,15 +724,20 @@ extern "C" int spcl_proj_heads_backward(int K, const float* const* dz, int dtype
 
 // adaptive average pooling backward THROUGH a LeakyReLU: dx = unpool(dout) * LeakyReLU'(pre), with act = LeakyReLU(pre) [N][H][W][C]
 // f32 given instead of pre (same sign).  The dense projector's pooled-hidden form (functional._PixelMlpPooledFn).  C % 4 == 0.
-extern "C" int spcl_adaptive_avgpool2d_backward_act(const float* dout, const float* act, int N, int H, int W, int C, int OH, int OW,
-                                                    float* dx, void* stream) {
+extern "C" int spcl_adaptive_avgpool2d_backward_act(const float* dout, const void* act, int dtype, int N, int H, int W, int C, int OH,
+                                                    int OW, void* dx, void* stream) {
   SPCL_CHECK_ARG(dout && act && dx, "adaptive_avgpool2d_backward_act: null pointer");
   SPCL_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && OH > 0 && OW > 0, "adaptive_avgpool2d_backward_act: bad shape");
+  SPCL_CHECK_ARG(dtype == SPCL_F32 || dtype == SPCL_BF16, "adaptive_avgpool2d_backward_act: dtype %d", dtype);
   const int spr = (W + 7) / 8;
   const size_t nseg = (size_t)N * H * spr;
-  SPCL_LAUNCH((adaptive_pool_bwd_pix_kernel<float, false>), dim3((unsigned)((nseg + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dout,
-              (const int*)nullptr, H, W, C, C, OH, OW, dx, nseg, spr, act);
+  const dim3 grid((unsigned)((nseg + 3) / 4));
+  if (dtype == SPCL_F32)
+    SPCL_LAUNCH((adaptive_pool_bwd_pix_kernel<float, false>), grid, dim3(256), 0, (hipStream_t)stream, dout, (const int*)nullptr, H, W,
+                C, C, OH, OW, (float*)dx, nseg, spr, (const float*)act);
+  else
+    SPCL_LAUNCH((adaptive_pool_bwd_pix_kernel<bf16_t, false>), grid, dim3(256), 0, (hipStream_t)stream, dout, (const int*)nullptr, H,
+                W, C, C, OH, OW, (bf16_t*)dx, nseg, spr, (const bf16_t*)act);
   SPCL_LAUNCH_CHECK("adaptive_avgpool2d_backward_act");
   return SPCL_OK;
 }
-

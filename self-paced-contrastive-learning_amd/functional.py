@@ -607,8 +607,8 @@ class _PixelMlpFn(torch.autograd.Function):
         def wgrad(gm, xin, xdtype, ldx, leaky, n_out, k_in, dw, db):
             ws = torch.empty(_n.call("spcl_rows_linear_backward_weight_workspace_bytes", M, n_out, k_in) // 4 + 1,
                              dtype=torch.float32, device=dev)
-            _n.call("spcl_rows_linear_backward_weight", _n.ptr(gm), _n.ptr(xin), _n.dtype_code(xdtype), ldx, int(leaky), M, n_out,
-                    k_in, _n.ptr(ws), ws.numel() * 4, _n.ptr(dw), _n.ptr(db), _n.stream())
+            _n.call("spcl_rows_linear_backward_weight", _n.ptr(gm), _n.dtype_code(gm.dtype), _n.ptr(xin), _n.dtype_code(xdtype), ldx,
+                    int(leaky), M, n_out, k_in, _n.ptr(ws), ws.numel() * 4, _n.ptr(dw), _n.ptr(db), _n.stream())
 
         if mlp:
             O = w2c.shape[0]
@@ -616,15 +616,15 @@ class _PixelMlpFn(torch.autograd.Function):
             db2 = _grad_buffer(sk[3], (O,), dev)
             wgrad(g, pre, torch.float32, hid, True, O, hid, dw2, db2)
             dpre = torch.empty(M, hid, dtype=torch.float32, device=dev)
-            _n.call("spcl_rows_linear_backward_input", _n.ptr(g), _n.ptr(w2c), _n.ptr(pre), M, O, hid, _n.ptr(dpre),
-                    _n.dtype_code(torch.float32), hid, _n.stream())
+            _n.call("spcl_rows_linear_backward_input", _n.ptr(g), _n.dtype_code(g.dtype), _n.ptr(w2c), _n.ptr(pre), M, O, hid,
+                    _n.ptr(dpre), _n.dtype_code(torch.float32), hid, _n.stream())
             g = dpre
         wgrad(g, x, xdt, cs, False, hid, C, dw1, db1)
         gfeat = None
         if ng[0]:
             dfeat = (torch.zeros if cs != C else torch.empty)(N, H, W, cs, dtype=xdt, device=dev)
-            _n.call("spcl_rows_linear_backward_input", _n.ptr(g), _n.ptr(w1c), None, M, hid, C, _n.ptr(dfeat), _n.dtype_code(xdt),
-                    cs, _n.stream())
+            _n.call("spcl_rows_linear_backward_input", _n.ptr(g), _n.dtype_code(g.dtype), _n.ptr(w1c), None, M, hid, C, _n.ptr(dfeat),
+                    _n.dtype_code(xdt), cs, _n.stream())
             gfeat = nhwc_to_logical(dfeat, C)
             if gfeat.dtype != fdt:
                 gfeat = gfeat.to(fdt)
@@ -649,11 +649,14 @@ class _PixelMlpPooledFn(torch.autograd.Function):
         w1c, b1c = w1.detach().reshape(w1.shape[0], -1).contiguous().float(), b1.detach().contiguous().float()
         w2c, b2c = w2.detach().reshape(w2.shape[0], -1).contiguous().float(), b2.detach().contiguous().float()
         hid, O = w1c.shape[0], w2c.shape[0]
-        h = torch.empty(M, hid, dtype=torch.float32, device=dev)  # LeakyReLU(conv1(x)): the one full-size tensor kept
+        # LeakyReLU(conv1(x)): the one full-size tensor kept -- in the feature map's own dtype (3.1 GB as f32 for 60 maps of
+        # 224^2: the head's launches are streams of this tensor)
+        h = torch.empty(M, hid, dtype=x.dtype, device=dev)
         _n.call("spcl_rows_linear_forward_act", _n.ptr(x), _n.dtype_code(x.dtype), cs, _n.ptr(w1c), _n.ptr(b1c), M, C, hid,
-                _n.ptr(h), _n.stream())
+                _n.ptr(h), _n.dtype_code(h.dtype), _n.stream())
         hp = torch.empty(N * oh * ow, hid, dtype=torch.float32, device=dev)
-        _n.call("spcl_adaptive_pool2d_forward", _n.ptr(h), f32, N, H, W, hid, hid, oh, ow, 0, _n.ptr(hp), None, _n.stream())
+        _n.call("spcl_adaptive_pool2d_forward", _n.ptr(h), _n.dtype_code(h.dtype), N, H, W, hid, hid, oh, ow, 0, _n.ptr(hp), None,
+                _n.stream())
         out = torch.empty(N * oh * ow, O, dtype=torch.float32, device=dev)
         _n.call("spcl_rows_linear_forward", _n.ptr(hp), f32, hid, 0, _n.ptr(w2c), _n.ptr(b2c), N * oh * ow, hid, O, _n.ptr(out),
                 _n.stream())
@@ -678,20 +681,21 @@ class _PixelMlpPooledFn(torch.autograd.Function):
         def wgrad(gm, rows, xin, xdtype, ldx, n_out, k_in, dw, db):
             ws = torch.empty(_n.call("spcl_rows_linear_backward_weight_workspace_bytes", rows, n_out, k_in) // 4 + 1,
                              dtype=torch.float32, device=dev)
-            _n.call("spcl_rows_linear_backward_weight", _n.ptr(gm), _n.ptr(xin), _n.dtype_code(xdtype), ldx, 0, rows, n_out, k_in,
-                    _n.ptr(ws), ws.numel() * 4, _n.ptr(dw), _n.ptr(db), _n.stream())
+            _n.call("spcl_rows_linear_backward_weight", _n.ptr(gm), _n.dtype_code(gm.dtype), _n.ptr(xin), _n.dtype_code(xdtype), ldx, 0,
+                    rows, n_out, k_in, _n.ptr(ws), ws.numel() * 4, _n.ptr(dw), _n.ptr(db), _n.stream())
 
         wgrad(g, Mp, hp, torch.float32, hid, O, hid, dw2, db2)
         dhp = torch.empty(Mp, hid, dtype=torch.float32, device=dev)
-        _n.call("spcl_rows_linear_backward_input", _n.ptr(g), _n.ptr(w2c), None, Mp, O, hid, _n.ptr(dhp), f32, hid, _n.stream())
-        dpre = torch.empty(M, hid, dtype=torch.float32, device=dev)  # un-pooled, through the LeakyReLU (h carries its sign)
-        _n.call("spcl_adaptive_avgpool2d_backward_act", _n.ptr(dhp), _n.ptr(h), N, H, W, hid, oh, ow, _n.ptr(dpre), _n.stream())
+        _n.call("spcl_rows_linear_backward_input", _n.ptr(g), f32, _n.ptr(w2c), None, Mp, O, hid, _n.ptr(dhp), f32, hid, _n.stream())
+        dpre = torch.empty(M, hid, dtype=h.dtype, device=dev)  # un-pooled, through the LeakyReLU (h carries its sign)
+        _n.call("spcl_adaptive_avgpool2d_backward_act", _n.ptr(dhp), _n.ptr(h), _n.dtype_code(h.dtype), N, H, W, hid, oh, ow,
+                _n.ptr(dpre), _n.stream())
         wgrad(dpre, M, x, xdt, cs, hid, C, dw1, db1)
         gfeat = None
         if ng[0]:
             dfeat = (torch.zeros if cs != C else torch.empty)(N, H, W, cs, dtype=xdt, device=dev)
-            _n.call("spcl_rows_linear_backward_input", _n.ptr(dpre), _n.ptr(w1c), None, M, hid, C, _n.ptr(dfeat), _n.dtype_code(xdt),
-                    cs, _n.stream())
+            _n.call("spcl_rows_linear_backward_input", _n.ptr(dpre), _n.dtype_code(dpre.dtype), _n.ptr(w1c), None, M, hid, C,
+                    _n.ptr(dfeat), _n.dtype_code(xdt), cs, _n.stream())
             gfeat = nhwc_to_logical(dfeat, C)
             if gfeat.dtype != fdt:
                 gfeat = gfeat.to(fdt)

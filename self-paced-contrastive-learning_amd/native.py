@@ -155,11 +155,11 @@ _SIGNATURES = {
     "spcl_augment_views_recipe": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, c_int, c_int, _P]),
     "spcl_augment_views_recipe_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "spcl_rows_linear_forward": (c_int, [_P, c_int, c_long, c_int, _P, _P, c_int, c_int, c_int, _P, _P]),
-    "spcl_rows_linear_forward_act": (c_int, [_P, c_int, c_long, _P, _P, c_int, c_int, c_int, _P, _P]),
-    "spcl_adaptive_avgpool2d_backward_act": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
-    "spcl_rows_linear_backward_input": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_int, c_long, _P]),
+    "spcl_rows_linear_forward_act": (c_int, [_P, c_int, c_long, _P, _P, c_int, c_int, c_int, _P, c_int, _P]),
+    "spcl_adaptive_avgpool2d_backward_act": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "spcl_rows_linear_backward_input": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, _P, c_int, c_long, _P]),
     "spcl_rows_linear_backward_weight_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "spcl_rows_linear_backward_weight": (c_int, [_P, _P, c_int, c_long, c_int, c_int, c_int, c_int, _P, c_size_t, _P, _P, _P]),
+    "spcl_rows_linear_backward_weight": (c_int, [_P, c_int, _P, c_int, c_long, c_int, c_int, c_int, c_int, _P, c_size_t, _P, _P, _P]),
     "spcl_augment_views_recipe_ws": (c_int, [_P, _P, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, c_int, c_int, _P, c_size_t,
                                              _P]),
     "spcl_resize_bilinear_pil": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, _P, _P, c_int, _P, _P, c_int, c_int, _P]),
@@ -237,7 +237,7 @@ class WgradTail(ctypes.Structure):
                 ("nblk_co", c_int), ("CIB", c_int), ("COB", c_int), ("Cin", c_int), ("Cout", c_int)]
 
 
-ABI_VERSION = 8  # == SPCL_ABI_VERSION of include/spcl_hip.h (tests/test_abi.py compares them); lib() refuses any other library
+ABI_VERSION = 9  # == SPCL_ABI_VERSION of include/spcl_hip.h (tests/test_abi.py compares them); lib() refuses any other library
 WGRAD_BATCH_MAX = 16
 WGRAD_TAILS_MAX = 16
 _NO_STATUS = ("spcl_abi_version", "spcl_conv3x3_forward_image_acorr_rows", "spcl_image_autocorr_rows", "spcl_conv_dgrad_bnstats_image_supported", "spcl_conv16_bwd_fused_supported", "spcl_conv16_bwd_fused_splits", "spcl_conv_num_tiles", "spcl_conv_stat_rows", "spcl_conv_set_gemm", "spcl_conv_set_f32_split", "spcl_conv_get_f32_split", "spcl_supcon_unit_gradient_block", "spcl_conv_cat_supported", "spcl_conv_up2_supported", "spcl_conv_split_supported", "spcl_conv_split_bnstats_supported", "spcl_conv1x1_bwd_rows", "spcl_profile_count", "spcl_conv_dgrad_bnstats_supported", "spcl_conv_dgrad_poolstats_supported",

@@ -291,13 +291,15 @@ def test_pooled_hidden_form_equals_pool_of_the_projection(dt, shape, hid, out, h
         (y * r.cuda()).sum().backward()
         res[form] = (y.detach(), xg.grad, [p.grad for p in ps])
     y, dx, dps = res["pooled"]
-    tol = 3e-5
+    # (bf16 maps: the pooled form keeps the hidden activation and its gradient in the map's dtype, 8 mantissa bits)
+    tol = 3e-5 if dt == torch.float32 else 6e-3
     np.testing.assert_allclose(y.cpu().double().numpy(), y64.detach().numpy(), rtol=tol, atol=tol * float(y64.detach().abs().max()))
     np.testing.assert_allclose(y.cpu().numpy(), res["reference order"][0].cpu().numpy(), rtol=tol, atol=tol * float(y64.detach().abs().max()))
-    gtol = tol if dt == torch.float32 else 6e-3
+    gtol = tol if dt == torch.float32 else 1e-2
     np.testing.assert_allclose(dx.double().cpu().numpy(), xs.grad.numpy(), rtol=gtol, atol=gtol * float(xs.grad.abs().max()))
+    ptol = (1e-4, 2e-5) if dt == torch.float32 else (2e-2, 1e-2)
     for got, want in zip(dps, [p.grad for p in ps64]):
-        np.testing.assert_allclose(got.double().cpu().numpy(), want.numpy(), rtol=1e-4, atol=2e-5 * float(want.abs().max()) + 1e-6)
+        np.testing.assert_allclose(got.double().cpu().numpy(), want.numpy(), rtol=ptol[0], atol=ptol[1] * float(want.abs().max()) + 1e-6)
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
@@ -344,11 +346,13 @@ def test_dense_head_at_full_size_vs_float64(dt):
         got = {"y": y.detach(), "dx": xg.grad, "dw1": ps[0].grad, "db1": ps[1].grad, "dw2": ps[2].grad, "db2": ps[3].grad}
         forms[form] = got
         # against float64: what does not pass through LeakyReLU' everywhere; the feature gradient on the clear pixels
-        assert rel(got["y"], want["y"]) <= 3e-5 and rel(got["dw2"], want["dw2"]) <= 2e-4 and rel(got["db2"], want["db2"]) <= 2e-4, form
-        dx_tol = 3e-5 if dt == torch.float32 else 6e-3
+        lo = form == "pooled" and dt == torch.bfloat16  # (hidden activation and its gradient kept in bf16)
+        assert rel(got["y"], want["y"]) <= (6e-3 if lo else 3e-5), (form, rel(got["y"], want["y"]))
+        assert rel(got["dw2"], want["dw2"]) <= (1e-2 if lo else 2e-4) and rel(got["db2"], want["db2"]) <= (1e-2 if lo else 2e-4), form
+        dx_tol = 3e-5 if dt == torch.float32 else 1e-2
         assert rel(got["dx"] * clear, want["dx"] * clear) <= dx_tol, (form, rel(got["dx"] * clear, want["dx"] * clear))
         # (a handful of one-sided decisions among 188 160 x 256 terms: the sums stay close)
         assert rel(got["dw1"], want["dw1"]) <= 2e-2 and rel(got["db1"], want["db1"]) <= 2e-2, form
     a, b = forms["pooled"], forms["reference order"]
     for k in ("dx", "dw1", "db1", "dw2", "db2", "y"):
-        assert rel(a[k], b[k]) <= (2e-5 if k != "dx" or dt == torch.float32 else 8e-3), (k, rel(a[k], b[k]))
+        assert rel(a[k], b[k]) <= (2e-5 if dt == torch.float32 else 2e-2), (k, rel(a[k], b[k]))

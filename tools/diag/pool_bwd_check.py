@@ -8,7 +8,7 @@ for (N, H, W, C, oh, ow) in [(60, 56, 56, 256, 10, 10), (8, 56, 56, 256, 10, 10)
     h = torch.randn(N, H, W, C, device="cuda")
     dhp = torch.randn(N, oh, ow, C, device="cuda")
     dpre = torch.empty(N, H, W, C, device="cuda")
-    _n.call("spcl_adaptive_avgpool2d_backward_act", _n.ptr(dhp), _n.ptr(h), N, H, W, C, oh, ow, _n.ptr(dpre), _n.stream())
+    _n.call("spcl_adaptive_avgpool2d_backward_act", _n.ptr(dhp), _n.ptr(h), _n.dtype_code(torch.float32), N, H, W, C, oh, ow, _n.ptr(dpre), _n.stream())
     x = torch.zeros(N, C, H, W, device="cuda", dtype=torch.float64, requires_grad=True)
     y = torch.nn.functional.adaptive_avg_pool2d(x, (oh, ow))
     y.backward(dhp.permute(0, 3, 1, 2).double())
